@@ -1,0 +1,116 @@
+/* orbm.h -- C ABI of the MI355X ORB matcher (drop-in for the hot part of ORB_SLAM2::ORBmatcher).
+ *
+ * Replaces:
+ *   static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)
+ *        reference include/ORBmatcher.h:44, src/ORBmatcher.cc:3994-4010                -> orbm_descriptor_distance
+ *   the exhaustive top-2 Hamming loops inside SearchByBoW / SearchForTriangulation
+ *        reference src/ORBmatcher.cc:287-321, :1069-1104, :1533-1594                  -> orbm_hamming_top2[_device]
+ *   (new, for cross-camera all-pairs work)                                            -> orbm_hamming_matrix[_device]
+ *   int ORBmatcher::SearchByProjection(Frame&, const Frame&, float th, bool bMono, cv::Mat Calib)
+ *        reference include/ORBmatcher.h:54-55, src/ORBmatcher.cc:3448-3641            -> orbm_search_by_projection
+ *   int ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, float th)
+ *        reference include/ORBmatcher.h:48, src/ORBmatcher.cc:62-149                  -> orbm_search_by_projection_points
+ *   Frame::AssignFeaturesToGrid / GetFeaturesInArea(cam, ...)
+ *        reference src/Frame.cc:348-395, :574-629                                     -> orbm_frame_create / orbm_features_in_area
+ *   ORBmatcher::ComputeThreeMaxima   reference src/ORBmatcher.cc:3948-3989             -> orbm_three_maxima
+ *
+ * No Frame* / MapPoint* crosses the ABI: the C++ wrapper (multi_orb_slam_amd/host/ORBmatcher.h) packs flat
+ * arrays.  The 3-D projection of map points stays on the host (it is cv::Mat float algebra in the reference,
+ * src/ORBmatcher.cc:3513-3528); queries arrive already projected.
+ *
+ * A matcher handle owns one HIP stream and scratch; use one handle per thread (the reference constructs an
+ * ORBmatcher on the stack per use and calls it from three threads).  No global mutable state.
+ */
+#ifndef ORBM_H
+#define ORBM_H
+#include "orb_types.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORBM_TH_HIGH = 100, ORBM_TH_LOW = 50, ORBM_HISTO_LENGTH = 30 }; /* reference src/ORBmatcher.cc:37-39 */
+enum { ORBM_GRID_COLS = 64, ORBM_GRID_ROWS = 48 };                     /* reference include/Frame.h:37-38   */
+
+typedef struct orbm_matcher orbm_matcher;
+typedef struct orbm_frame orbm_frame;
+
+int orbm_create(int device, orbm_matcher** out);
+void orbm_destroy(orbm_matcher* m);
+void* orbm_stream(const orbm_matcher* m);
+
+/* host helper, identical result to the reference's SWAR popcount; rows need 1-byte alignment only */
+int orbm_descriptor_distance(const uint8_t* a, const uint8_t* b);
+void orbm_three_maxima(const int* bin_sizes, int L, int* ind3);
+
+/* Exhaustive top-2 per query over all nr references, strict '<' updates in reference order:
+ * best_idx = lowest index attaining the minimum, second_dist = 2nd smallest WITH multiplicity,
+ * (-1, 256, 256) when nothing is closer than 256.  Host pointers. */
+int orbm_hamming_top2(orbm_matcher* m, const uint8_t* q, int nq, const uint8_t* r, int nr, int32_t* best_idx,
+                      int32_t* best_dist, int32_t* second_dist);
+/* Same on device pointers, asynchronous on `stream` (a hipStream_t; NULL = default stream).
+ * d_scratch: at least orbm_top2_scratch_bytes(nq, nr) bytes of HBM (may be NULL when that returns 0). */
+size_t orbm_top2_scratch_bytes(int nq, int nr);
+int orbm_hamming_top2_device(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, int32_t* d_best_idx,
+                             int32_t* d_best_dist, int32_t* d_second_dist, void* d_scratch, void* stream);
+
+/* Full nq x nr distance matrix, uint16 row-major (the HBM-write-bound mode). */
+int orbm_hamming_matrix(orbm_matcher* m, const uint8_t* q, int nq, const uint8_t* r, int nr, uint16_t* out);
+int orbm_hamming_matrix_device(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16_t* d_out,
+                               void* stream);
+
+/* -- projection-gated search ---------------------------------------------------------------------------- */
+typedef struct orbm_frame_desc { /* flat view of the Frame members the matcher reads (src/Frame.cc:191-288) */
+    int32_t n_total, n_cams;     /* N_total; global index g: cam-major concatenation (cam 2: g = N + i)      */
+    const float* un_x;           /* mvKeysUn_total[g].pt.x                                                   */
+    const float* un_y;
+    const int32_t* octave;       /* mvKeysUn_total[g].octave                                                 */
+    const float* angle;          /* mvKeysUn_total[g].angle                                                  */
+    const float* uright;         /* mvuRight_total[g]                                                        */
+    const int32_t* cam_of;       /* keypoint_to_cam[g]                                                       */
+    const int32_t* local_of;     /* cont_idx_to_local_cam_idx[g]                                             */
+    const uint8_t* const* desc;  /* mDescriptors_total[cam], N_cam x 32                                      */
+    float min_x, min_y, max_x, max_y; /* mnMinX, mnMinY, mnMaxX, mnMaxY                                      */
+} orbm_frame_desc;
+
+typedef struct orbm_query { /* one projected map point */
+    float u, v;             /* projection in the current frame                                               */
+    float radius;           /* th * mvScaleFactors[octave]                      (src/ORBmatcher.cc:3543)     */
+    float ur;               /* u - mbf*invzc  |  mTrackProjXR                   (:3573 | :113)               */
+    int32_t min_level, max_level; /* as handed to GetFeaturesInArea             (:3547-3552 | :89)           */
+    int32_t cam;
+    int32_t blocks;         /* 1 if the MapPoint has Observations()>0: its claim hides the feature (:3566)   */
+    float angle;            /* LastFrame.mvKeysUn_total[i].angle                (:3604)                      */
+    uint8_t desc[32];       /* pMP->GetDescriptor()                                                          */
+} orbm_query;
+
+/* Builds the 64x48 per-camera grid (round-to-cell insertion, ascending global indices) and uploads the frame. */
+int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** out);
+void orbm_frame_destroy(orbm_frame* f);
+/* grid as CSR: cell = (cam*64 + ix)*48 + iy; cell_start has n_cams*3072+1 entries */
+int orbm_frame_grid(const orbm_frame* f, int32_t* cell_start, int32_t* items);
+/* GetFeaturesInArea(cam, x, y, r, minLevel, maxLevel) on the GPU; returns count in *n (may exceed cap) */
+int orbm_features_in_area(orbm_matcher* m, const orbm_frame* f, int cam, float x, float y, float r,
+                          int min_level, int max_level, int32_t* out, int cap, int* n);
+
+/* Ordered candidate lists: for query i, cand_count[i] candidates in the reference's visiting order
+ * (ix, iy, ascending index) that pass the window/level/right-coordinate gates, with their distances.
+ * Lists are stored at [i*cap_per_query ...]; a count above cap_per_query => ORB_E_CAPACITY. */
+int orbm_project_candidates(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap_per_query,
+                            int32_t* cand_idx, uint16_t* cand_dist, int32_t* cand_count);
+
+/* SearchByProjection(CurrentFrame, LastFrame, th, bMono, Calib) from the projected queries on.
+ * match_of_feature[g] = index of the query whose MapPoint ends in CurrentFrame.mvpMapPoints[g], else -1.
+ * *nmatches = the reference's return value. */
+int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, int th_high,
+                              int check_orientation, int32_t* match_of_feature, int* nmatches);
+
+/* SearchByProjection(F, vpMapPoints, th): camera-1 grid only, top-2 with level bookkeeping and nnratio.
+ * occupied[g] != 0 where F.mvpMapPoints[g] already holds an observed point (may be NULL). */
+int orbm_search_by_projection_points(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,
+                                     const uint8_t* occupied, float nnratio, int th_high,
+                                     int32_t* match_of_feature, int* nmatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

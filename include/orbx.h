@@ -1,0 +1,86 @@
+/* orbx.h -- C ABI of the MI355X ORB extractor (drop-in for ORB_SLAM2::ORBextractor).
+ *
+ * Replaces, for N cameras per call:
+ *   ORBextractor::ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+ *        reference include/ORBextractor.h:51-52, src/ORBextractor.cc:411-471          -> orbx_create / orbx_tables
+ *   void ORBextractor::operator()(InputArray image, InputArray mask, vector<KeyPoint>&, OutputArray descriptors)
+ *        reference include/ORBextractor.h:60-62, src/ORBextractor.cc:1044-1107        -> orbx_extract
+ *   GetLevels/GetScaleFactor/GetScaleFactors/GetInverseScaleFactors/GetScaleSigmaSquares/
+ *   GetInverseScaleSigmaSquares   reference include/ORBextractor.h:64-84              -> orbx_tables
+ * Call sites being replaced: Frame::ExtractORB / ExtractORB_cam2, reference src/Frame.cc:397-419.
+ *
+ * All compute runs in hand-written HIP kernels on gfx950; there is no CPU fallback (ORB_E_NO_DEVICE).
+ * An extractor handle is single-caller (like the reference's non-re-entrant class) and owns one HIP stream
+ * and all device memory, sized at create time.  Plain pointers and sizes only.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+#include "orb_types.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orbx_params { /* ctor arguments, reference include/ORBextractor.h:51-52 */
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+} orbx_params;
+
+typedef struct orbx_extractor orbx_extractor;
+
+/* Host-only ctor arithmetic (reference src/ORBextractor.cc:416-470).  Arrays hold nlevels entries
+ * (umax16: 16).  Any output pointer may be NULL. */
+int orbx_tables(const orbx_params* p, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                int32_t* features_per_level, int32_t* umax16);
+
+/* params: n_cams entries (the reference builds one ORBextractor per camera, cam 2 with nFeatures/2:
+ * src/Tracking.cc:144-145).  max_width/max_height bound every image later passed in. */
+int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device,
+                orbx_extractor** out);
+void orbx_destroy(orbx_extractor* ex);
+
+/* == ORBextractor::operator() for n_cams images at once (host buffers in, host buffers out).
+ * gray[c]: 8-bit single channel, height[c] rows of stride[c] bytes.  An empty image (NULL / 0 size) yields
+ * n_out[c] = 0 and leaves that camera's outputs untouched (reference src/ORBextractor.cc:1047-1048).
+ * kps_out[c] / desc_out[c] have room for cap[c] keypoints / cap[c]*32 bytes; a camera can return up to
+ * nfeatures + 2*nlevels keypoints (quadtree overshoot, reference src/ORBextractor.cc:729-732). */
+int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, const int* width, const int* height,
+                 const int* stride, orb_keypoint* const* kps_out, uint8_t* const* desc_out, const int* cap,
+                 int* n_out);
+
+/* -- resident path (what bench.py times: images already in HBM) --------------------------------------- */
+/* copy one camera's image into the handle's HBM pyramid buffer (async on the handle's stream) */
+int orbx_upload(orbx_extractor* ex, int cam, const uint8_t* gray, int width, int height, int stride);
+/* same, from a DEVICE pointer (e.g. a frame grabber's or torch's buffer) */
+int orbx_upload_device(orbx_extractor* ex, int cam, const uint8_t* d_gray, int width, int height, int stride);
+/* run the whole extractor on the resident images of cameras [0, n_cams); results stay in HBM */
+int orbx_run(orbx_extractor* ex);
+/* number of keypoints camera `cam` produced in the last run */
+int orbx_count(const orbx_extractor* ex, int cam);
+/* copy the last run's results of one camera to host buffers */
+int orbx_download(orbx_extractor* ex, int cam, orb_keypoint* kps, uint8_t* desc, int cap);
+/* device pointers of the last run's results (valid until the next orbx_run) */
+const orb_keypoint* orbx_device_keypoints(const orbx_extractor* ex, int cam);
+const uint8_t* orbx_device_descriptors(const orbx_extractor* ex, int cam);
+/* the handle's hipStream_t */
+void* orbx_stream(const orbx_extractor* ex);
+/* redirect camera `cam`'s result buffers to caller-owned HBM (e.g. an RCCL all-gather send buffer);
+ * d_kps holds cap keypoints, d_desc cap*32 bytes.  NULL restores the internal buffers. */
+int orbx_bind_output(orbx_extractor* ex, int cam, orb_keypoint* d_kps, uint8_t* d_desc, int cap);
+
+/* -- stage inspection for level-by-level parity tests (not needed by a SLAM caller) -------------------- */
+/* pyramid level (dense w*h bytes) of the last run */
+int orbx_debug_level(orbx_extractor* ex, int cam, int level, uint8_t* out, int cap_bytes, int* w, int* h);
+/* candidates handed to the quadtree (x, y relative to (16,16); response = score), cell-major order */
+int orbx_debug_candidates(orbx_extractor* ex, int cam, int level, orb_keypoint* out, int cap, int* n);
+/* per-stage GPU time of the last run in microseconds: {pyramid, fast_cells, compact, d2h+octree(host wall),
+ * describe, total wall}; requires orbx_set_profiling(ex, 1) */
+int orbx_set_profiling(orbx_extractor* ex, int on);
+int orbx_stage_times_us(const orbx_extractor* ex, float* out6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

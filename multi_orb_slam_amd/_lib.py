@@ -1,0 +1,103 @@
+"""ctypes loader of lib/libmorb.so.  Fails loudly when the HIP library is missing: there is no fallback path."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_PKG, "csrc")
+LIB_PATH = os.path.join(_PKG, "lib", "libmorb.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("min_level", "<i4"),
+                        ("max_level", "<i4"), ("cam", "<i4"), ("blocks", "<i4"), ("angle", "<f4"),
+                        ("desc", "u1", (32,))])
+assert KP_DTYPE.itemsize == 28 and QUERY_DTYPE.itemsize == 68
+
+ORB_OK, ORB_E_ARG, ORB_E_HIP, ORB_E_CAPACITY, ORB_E_NO_DEVICE = 0, -1, -2, -3, -4
+
+
+class OrbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmorb error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):  # orbx_params
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class FrameDesc(C.Structure):  # orbm_frame_desc
+    _fields_ = [("n_total", C.c_int32), ("n_cams", C.c_int32), ("un_x", C.c_void_p), ("un_y", C.c_void_p),
+                ("octave", C.c_void_p), ("angle", C.c_void_p), ("uright", C.c_void_p), ("cam_of", C.c_void_p),
+                ("local_of", C.c_void_p), ("desc", C.c_void_p), ("min_x", C.c_float), ("min_y", C.c_float),
+                ("max_x", C.c_float), ("max_y", C.c_float)]
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into lib/libmorb.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbError(ORB_E_NO_DEVICE, "HIP library %s is not built (run `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` or `make -C multi_orb_slam_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    L.orb_last_error.restype = C.c_char_p
+    L.orbx_tables.argtypes = [vp] * 7
+    L.orbx_create.argtypes = [vp, i32, i32, i32, i32, vp]
+    L.orbx_destroy.argtypes = [vp]; L.orbx_destroy.restype = None
+    L.orbx_extract.argtypes = [vp, i32] + [vp] * 8
+    L.orbx_upload.argtypes = [vp, i32, vp, i32, i32, i32]
+    L.orbx_upload_device.argtypes = [vp, i32, vp, i32, i32, i32]
+    L.orbx_run.argtypes = [vp]
+    L.orbx_count.argtypes = [vp, i32]
+    L.orbx_download.argtypes = [vp, i32, vp, vp, i32]
+    L.orbx_device_keypoints.argtypes = [vp, i32]; L.orbx_device_keypoints.restype = vp
+    L.orbx_device_descriptors.argtypes = [vp, i32]; L.orbx_device_descriptors.restype = vp
+    L.orbx_stream.argtypes = [vp]; L.orbx_stream.restype = vp
+    L.orbx_bind_output.argtypes = [vp, i32, vp, vp, i32]
+    L.orbx_debug_level.argtypes = [vp, i32, i32, vp, i32, vp, vp]
+    L.orbx_debug_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.orbx_set_profiling.argtypes = [vp, i32]
+    L.orbx_stage_times_us.argtypes = [vp, vp]
+    L.orbm_create.argtypes = [i32, vp]
+    L.orbm_destroy.argtypes = [vp]; L.orbm_destroy.restype = None
+    L.orbm_stream.argtypes = [vp]; L.orbm_stream.restype = vp
+    L.orbm_descriptor_distance.argtypes = [vp, vp]
+    L.orbm_three_maxima.argtypes = [vp, i32, vp]; L.orbm_three_maxima.restype = None
+    L.orbm_hamming_top2.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+    L.orbm_top2_scratch_bytes.argtypes = [i32, i32]; L.orbm_top2_scratch_bytes.restype = C.c_size_t
+    L.orbm_hamming_top2_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp]
+    L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
+    L.orbm_hamming_matrix_device.argtypes = [vp, i32, vp, i32, vp, vp]
+    L.orbm_frame_create.argtypes = [vp, vp, vp]
+    L.orbm_frame_destroy.argtypes = [vp]; L.orbm_frame_destroy.restype = None
+    L.orbm_frame_grid.argtypes = [vp, vp, vp]
+    L.orbm_features_in_area.argtypes = [vp, vp, i32, f32, f32, f32, i32, i32, vp, i32, vp]
+    L.orbm_project_candidates.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    L.orbm_search_by_projection.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    L.orbm_search_by_projection_points.argtypes = [vp, vp, vp, i32, vp, f32, i32, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != ORB_OK:
+        raise OrbError(rc, lib().orb_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)

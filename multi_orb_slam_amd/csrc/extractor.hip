@@ -1,0 +1,956 @@
+// extractor.hip -- gfx950 kernels + C ABI of the ORB extractor (include/orbx.h).
+//
+// Per call (all cameras batched in every launch; integer / byte work, no MFMA by design):
+//   k_resize        K1     pyramid level l from the QUANTISED level l-1 (serial chain, reference
+//                          src/ORBextractor.cc:1109-1134): OpenCV's 11-bit fixed-point bilinear, coefficient tables
+//                          precomputed on the host so the kernel is pure integer.
+//   k_fast_cells    K2+K3  one workgroup per 30-px detection cell (reference src/ORBextractor.cc:790-830): image tile +
+//                          3-px halo staged in LDS, threshold-free FAST-9/16 score per pixel (App. A-2), cell-local
+//                          3x3 non-max suppression, per-cell threshold choice (iniTh, else minTh) and ordered
+//                          (row-major) compaction -- all in LDS.
+//   k_compact       K3b    per (camera, level): scan of the cell counts -> dense cell-major candidate list written
+//                          straight into pinned host memory (one stream sync, no second D2H).
+//   (host)          K4     quadtree distribution (octree.cpp) on the candidates.
+//   k_describe      K5-K7  one wave per keypoint: 45x45 patch (reflect-101 at the level edge) staged in LDS,
+//                          intensity-centroid moments + fastAtan2 on the raw patch, 7x7 sigma-2 fixed-point Gaussian
+//                          of the 39x39 neighbourhood actually sampled, 256 steered rBRIEF tests, keypoint record.
+// The reference's 19-px reflect-101 border of every level is never read by a later stage and is
+// not materialised.
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <vector>
+
+#include "../../include/orbx.h"
+#include "octree.h"
+#include "orb_common.h"
+
+namespace {
+
+using morb::DevBuf;
+
+constexpr int EDGE_THRESHOLD = 19;   // reference src/ORBextractor.cc:74
+constexpr int MIN_BORDER = 16;       // EDGE_THRESHOLD - 3, :772
+constexpr int PATCH_SIZE = 31;       // :72
+constexpr int HALF_PATCH = 15;       // :73
+constexpr int CELL_MAX = 64;         // largest wCell/hCell this build stages in LDS
+constexpr int TILE_PITCH = 72;       // LDS pitch of the image tile (CELL_MAX + 6 rounded up)
+constexpr int SCORE_PITCH = 68;      // LDS pitch of the score map (CELL_MAX + 2 rounded up)
+constexpr int MAX_LEVELS = 16;
+constexpr int COEF_BITS = 11;        // OpenCV INTER_RESIZE_COEF_BITS
+
+struct LevelInfo {
+    int w, h, stride;        // level size, row pitch in bytes (multiple of 64)
+    int pyr_off;             // byte offset inside the camera's pyramid buffer
+    int n_cols, n_rows, w_cell, h_cell;  // reference :782-788
+    int cell_base;           // first global cell id
+    int slot_base, slot_cap; // per-cell candidate slots: slot_base + local_cell*slot_cap (u32 units)
+    int cand_base;           // dense candidate list of this level (u32 units, in the pinned host buffer)
+    int xtab_off, ytab_off;  // resize coefficient tables (valid for level >= 1)
+    int ini_th, min_th;
+    float scale;             // mvScaleFactor[level]
+    float patch_size;        // (float)(int)(31 * scale)
+};
+
+struct SelKp {  // one keypoint chosen by the quadtree, input of k_describe
+    int x, y;        // level ROI coordinates
+    int camlevel;    // cam << 8 | level
+    int resp_out;    // response << 24 | output index within the camera
+};
+
+__device__ const signed char d_pattern[256][4] = {
+#include "../../include/orb_pattern_31.inc"
+};
+__device__ const int d_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // ctor :455-470
+
+// ------------------------------------------------------------------------------------------------ K1
+__global__ __launch_bounds__(256) void k_resize(const LevelInfo* __restrict__ L, int max_levels, int level,
+                                                uint8_t* __restrict__ pyr, size_t cam_pitch,
+                                                const int2* __restrict__ xtab, const int4* __restrict__ ytab) {
+    const int cam = blockIdx.z;
+    const LevelInfo D = L[cam * max_levels + level];
+    const LevelInfo S = L[cam * max_levels + level - 1];
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= D.h || x4 >= D.w) return;
+    const uint8_t* src = pyr + cam * cam_pitch + S.pyr_off;
+    uint8_t* dst = pyr + cam * cam_pitch + D.pyr_off;
+    const int4 yt = ytab[D.ytab_off + y];  // {row0, row1, beta0, beta1}, rows already clipped to [0, sh-1]
+    const uint8_t* s0 = src + (size_t)yt.x * S.stride;
+    const uint8_t* s1 = src + (size_t)yt.y * S.stride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x4 + k;
+        if (x < D.w) {
+            const int2 xt = xtab[D.xtab_off + x];  // {sx0 | sx1 << 16, alpha0 | alpha1 << 16}
+            const int sx0 = xt.x & 0xffff, sx1 = (unsigned)xt.x >> 16;
+            const int a0 = (short)(xt.y & 0xffff), a1 = xt.y >> 16;
+            const int h0 = s0[sx0] * a0 + s0[sx1] * a1;
+            const int h1 = s1[sx0] * a0 + s1[sx1] * a1;
+            const int v = ((((yt.z * (h0 >> 4)) >> 16) + ((yt.w * (h1 >> 4)) >> 16) + 2) >> 2);
+            out |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)y * D.stride + x4) = out;
+}
+
+// ------------------------------------------------------------------------------------------------ K2 + K3
+// FAST-9/16 corner score of the pixel at t: max over the 16 arcs of 9 contiguous ring pixels of the minimum
+// |centre - ring| with a common sign, minus 1 (== cornerScore<16>, threshold-independent for corners; App. A-2).
+__device__ __forceinline__ int fast_score_9_16(const uint8_t* t) {
+    const int v = t[0];
+    int d[16];
+    d[0] = v - t[3 * TILE_PITCH];          d[1] = v - t[3 * TILE_PITCH + 1];
+    d[2] = v - t[2 * TILE_PITCH + 2];      d[3] = v - t[1 * TILE_PITCH + 3];
+    d[4] = v - t[3];                       d[5] = v - t[-1 * TILE_PITCH + 3];
+    d[6] = v - t[-2 * TILE_PITCH + 2];     d[7] = v - t[-3 * TILE_PITCH + 1];
+    d[8] = v - t[-3 * TILE_PITCH];         d[9] = v - t[-3 * TILE_PITCH - 1];
+    d[10] = v - t[-2 * TILE_PITCH - 2];    d[11] = v - t[-1 * TILE_PITCH - 3];
+    d[12] = v - t[-3];                     d[13] = v - t[1 * TILE_PITCH - 3];
+    d[14] = v - t[2 * TILE_PITCH - 2];     d[15] = v - t[3 * TILE_PITCH - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int sp = -256, sm = 256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);  // min of d[k..k+8]
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);  // max of d[k..k+8]
+        sp = max(sp, lo9);
+        sm = min(sm, hi9);
+    }
+    return max(sp, -sm) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict__ L, const int2* __restrict__ cell_map,
+                                                    const uint8_t* __restrict__ pyr, size_t cam_pitch, int max_levels,
+                                                    int* __restrict__ cell_cnt, uint32_t* __restrict__ cell_items) {
+    __shared__ uint8_t tile[(CELL_MAX + 6) * TILE_PITCH];
+    __shared__ uint8_t score[(CELL_MAX + 2) * SCORE_PITCH];
+    __shared__ uint8_t keep[CELL_MAX * CELL_MAX];
+    __shared__ int s_any;
+
+    const int cell = blockIdx.x;
+    const int2 cm = cell_map[cell];  // {cam * max_levels + level, local cell index}
+    const LevelInfo Lv = L[cm.x];
+    const int cam = cm.x / max_levels;
+    const int ci = cm.y / Lv.n_cols, cj = cm.y - ci * Lv.n_cols;
+    // scored rectangle of this cell in level coordinates (App. A-3)
+    const int x0 = EDGE_THRESHOLD + cj * Lv.w_cell, y0 = EDGE_THRESHOLD + ci * Lv.h_cell;
+    const int cw = min(x0 + Lv.w_cell, Lv.w - EDGE_THRESHOLD) - x0;
+    const int ch = min(y0 + Lv.h_cell, Lv.h - EDGE_THRESHOLD) - y0;
+    const int tid = threadIdx.x;
+    if (cw <= 0 || ch <= 0) {
+        if (tid == 0) cell_cnt[cell] = 0;
+        return;
+    }
+    const uint8_t* img = pyr + cam * cam_pitch + Lv.pyr_off;
+    const int tw = cw + 6, th = ch + 6;
+
+    // stage the tile (origin x0-3, y0-3; always inside the level)
+    for (int i = tid; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        tile[ty * TILE_PITCH + tx] = img[(size_t)(y0 - 3 + ty) * Lv.stride + (x0 - 3 + tx)];
+    }
+    for (int i = tid; i < (ch + 2) * SCORE_PITCH; i += 256) score[i] = 0;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+
+    const int npx = cw * ch;
+    for (int p = tid; p < npx; p += 256) {
+        const int py = p / cw, px = p - py * cw;
+        int s = fast_score_9_16(&tile[(py + 3) * TILE_PITCH + px + 3]);
+        s = s >= Lv.min_th ? s : 0;  // "not a corner at minTh" stores 0, like FAST_t's zeroed score rows
+        score[(py + 1) * SCORE_PITCH + px + 1] = (uint8_t)s;
+    }
+    __syncthreads();
+
+    int any_ini = 0;
+    for (int p = tid; p < npx; p += 256) {
+        const int py = p / cw, px = p - py * cw;
+        const uint8_t* c = &score[(py + 1) * SCORE_PITCH + px + 1];
+        const int s = c[0];
+        const bool mx = s > 0 && s > c[-1] && s > c[1] && s > c[-SCORE_PITCH - 1] && s > c[-SCORE_PITCH] &&
+                        s > c[-SCORE_PITCH + 1] && s > c[SCORE_PITCH - 1] && s > c[SCORE_PITCH] && s > c[SCORE_PITCH + 1];
+        keep[p] = mx ? (uint8_t)s : 0;
+        any_ini |= (mx && s >= Lv.ini_th);
+    }
+    if (any_ini) s_any = 1;  // benign race: all writers store 1
+    __syncthreads();
+
+    // Ordered compaction by wave 0: candidates in row-major order, exactly FAST_t's emission order.
+    if (tid < 64) {
+        const int T = s_any ? Lv.ini_th : Lv.min_th;  // reference :809-817: retry with minTh only if the cell is empty
+        uint32_t* slot = cell_items + Lv.slot_base + (size_t)cm.y * Lv.slot_cap;
+        int total = 0;
+        for (int base = 0; base < npx; base += 64) {
+            const int p = base + tid;
+            const int s = p < npx ? keep[p] : 0;
+            const bool ok = s >= T && s > 0;
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int pos = total + __popcll(m & ((1ull << tid) - 1ull));
+                const int py = p / cw, px = p - py * cw;
+                const int xr = x0 + px - MIN_BORDER, yr = y0 + py - MIN_BORDER;  // relative to (16,16), :821-826
+                if (pos < Lv.slot_cap) slot[pos] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)s << 24);
+            }
+            total += __popcll(m);
+        }
+        if (tid == 0) cell_cnt[cell] = total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K3b
+__global__ __launch_bounds__(1024) void k_compact(const LevelInfo* __restrict__ L, const int* __restrict__ cell_cnt,
+                                                  const uint32_t* __restrict__ cell_items, int* __restrict__ cell_off,
+                                                  uint32_t* __restrict__ cand /*pinned host*/,
+                                                  int* __restrict__ level_cnt /*pinned host*/) {
+    __shared__ int wsum[16];
+    __shared__ int s_total;
+    const LevelInfo Lv = L[blockIdx.x];
+    const int ncell = Lv.n_cols * Lv.n_rows;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (Lv.w == 0 || ncell == 0) {
+        if (tid == 0) level_cnt[blockIdx.x] = 0;
+        return;
+    }
+    // exclusive scan of the cell counts, `per` consecutive cells per thread
+    const int per = (ncell + 1023) / 1024;
+    const int c0 = tid * per, c1 = min(ncell, c0 + per);
+    int mine = 0;
+    for (int c = c0; c < c1; ++c) mine += min(cell_cnt[Lv.cell_base + c], Lv.slot_cap);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < 16; ++w) { const int v = wsum[w]; wsum[w] = acc; acc += v; }
+        s_total = acc;
+    }
+    __syncthreads();
+    int run = wsum[wave] + incl - mine;
+    for (int c = c0; c < c1; ++c) {
+        cell_off[Lv.cell_base + c] = run;
+        run += min(cell_cnt[Lv.cell_base + c], Lv.slot_cap);
+    }
+    __syncthreads();
+    // copy: one wave per cell
+    for (int c = wave; c < ncell; c += 16) {
+        const int n = min(cell_cnt[Lv.cell_base + c], Lv.slot_cap);
+        const int off = cell_off[Lv.cell_base + c];
+        const uint32_t* src = cell_items + Lv.slot_base + (size_t)c * Lv.slot_cap;
+        for (int i = lane; i < n; i += 64) cand[Lv.cand_base + off + i] = src[i];
+    }
+    if (tid == 0) level_cnt[blockIdx.x] = s_total;
+}
+
+// ------------------------------------------------------------------------------------------------ K5-K7
+__device__ __forceinline__ int reflect101(int p, int n) {
+    // |offset| beyond the edge is at most 3 and n >= 39, so one reflection suffices
+    p = p < 0 ? -p : p;
+    return p >= n ? 2 * n - 2 - p : p;
+}
+
+// cv::fastAtan2 (OpenCV 2.4/3.x mathfuncs), float32, no contraction (App. A-5)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// Canonical sin/cos: fixed IEEE-double operation sequence, bit-identical on host and device.
+__device__ __forceinline__ void det_sincos(float angle_rad, float& cosv, float& sinv) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11;
+    const double x = (double)angle_rad;
+    const double kf = rint(x * TWO_OVER_PI);
+    const double r = (x - kf * PIO2_HI) - kf * PIO2_LO;
+    const double z = r * r;
+    double ps = 1.0 / 355687428096000.0;
+    ps = ps * z + (-1.0 / 1307674368000.0);
+    ps = ps * z + (1.0 / 6227020800.0);
+    ps = ps * z + (-1.0 / 39916800);
+    ps = ps * z + (1.0 / 362880);
+    ps = ps * z + (-1.0 / 5040);
+    ps = ps * z + (1.0 / 120);
+    ps = ps * z + (-1.0 / 6);
+    const double s = r + r * (z * ps);
+    double pc = 1.0 / 20922789888000.0;
+    pc = pc * z + (-1.0 / 87178291200.0);
+    pc = pc * z + (1.0 / 479001600);
+    pc = pc * z + (-1.0 / 3628800);
+    pc = pc * z + (1.0 / 40320);
+    pc = pc * z + (-1.0 / 720);
+    pc = pc * z + (1.0 / 24);
+    pc = pc * z + (-1.0 / 2);
+    const double c = 1.0 + z * pc;
+    const int q = ((int)kf) & 3;
+    const double cc = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+    const double ss = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    cosv = (float)cc;
+    sinv = (float)ss;
+}
+
+// Each wave owns a private LDS region; a wave's DS operations execute in issue order, so only the compiler has to be
+// kept from reordering the LDS stores of one phase past the loads of the next.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int PR = 22;                 // patch half-size: 19 (largest rotated tap + guard) + 3 (blur)
+constexpr int PW = 2 * PR + 1;         // 45
+constexpr int RAW_PITCH = 48;
+constexpr int BR_ = 19;                // blurred half-size
+constexpr int BW = 2 * BR_ + 1;        // 39
+constexpr int ROW_PITCH = 40;
+
+__global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ L, int max_levels,
+                                                  const uint8_t* __restrict__ pyr, size_t cam_pitch,
+                                                  const SelKp* __restrict__ sel, int nsel,
+                                                  orb_keypoint* const* __restrict__ kps_out,
+                                                  uint8_t* const* __restrict__ desc_out) {
+    __shared__ uint8_t s_raw[4][PW * RAW_PITCH];
+    __shared__ uint16_t s_row[4][PW * ROW_PITCH];
+    __shared__ uint8_t s_blur[4][BW * ROW_PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ki = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (ki >= nsel) return;
+    const SelKp K = sel[ki];
+    const int cam = K.camlevel >> 8, level = K.camlevel & 0xff;
+    const LevelInfo Lv = L[cam * max_levels + level];
+    const uint8_t* img = pyr + cam * cam_pitch + Lv.pyr_off;
+    uint8_t* raw = s_raw[wave];
+    uint16_t* rowp = s_row[wave];
+    uint8_t* blur = s_blur[wave];
+
+    // 45x45 raw patch, reflect-101 at the level edge (== GaussianBlur's border on the cloned level, :1086-1087)
+    for (int i = lane; i < PW * PW; i += 64) {
+        const int ry = i / PW, rx = i - ry * PW;
+        const int gy = reflect101(K.y - PR + ry, Lv.h), gx = reflect101(K.x - PR + rx, Lv.w);
+        raw[ry * RAW_PITCH + rx] = img[(size_t)gy * Lv.stride + gx];
+    }
+    wave_lds_sync();
+
+    // IC_Angle moments over the circular patch (reference :77-104), exact int32
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        const int vy = i / 31, ux = i - vy * 31;
+        const int v = vy - HALF_PATCH, u = ux - HALF_PATCH;
+        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        if (au <= d_umax[av]) {
+            const int I = raw[(PR + v) * RAW_PITCH + PR + u];
+            m10 += u * I;
+            m01 += v * I;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // 7x7 sigma-2 Gaussian, OpenCV 8-bit fixed point: taps [18,34,49,55,49,34,18] on both axes (App. A-4)
+    for (int i = lane; i < PW * BW; i += 64) {
+        const int ry = i / BW, bx = i - ry * BW;
+        const uint8_t* s = &raw[ry * RAW_PITCH + bx];  // window bx .. bx+6 is centred on raw column bx+3
+        const int r = 18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 49 * (s[2] + s[4]) + 55 * s[3];
+        rowp[ry * ROW_PITCH + bx] = (uint16_t)r;  // <= 257*255 = 65535
+    }
+    wave_lds_sync();
+    for (int i = lane; i < BW * BW; i += 64) {
+        const int by = i / BW, bx = i - by * BW;
+        const uint16_t* s = &rowp[by * ROW_PITCH + bx];
+        const int c = 18 * (s[0] + s[6 * ROW_PITCH]) + 34 * (s[ROW_PITCH] + s[5 * ROW_PITCH]) +
+                      49 * (s[2 * ROW_PITCH] + s[4 * ROW_PITCH]) + 55 * s[3 * ROW_PITCH];
+        const int v = (c + 32768) >> 16;
+        blur[by * ROW_PITCH + bx] = (uint8_t)min(v, 255);
+    }
+    wave_lds_sync();
+
+    // steered rBRIEF (reference :108-147): 4 tests per lane, lanes 2j / 2j+1 make byte j
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    det_sincos(angle * factorPI, a, b);
+    const uint8_t* centre = &blur[BR_ * ROW_PITCH + BR_];
+    int nib = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const signed char* q = d_pattern[4 * lane + j];
+        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
+        const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
+        const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
+        const int t0 = centre[r0 * ROW_PITCH + c0], t1 = centre[r1 * ROW_PITCH + c1];
+        nib |= (t0 < t1) << j;
+    }
+    const int other = __shfl_xor(nib, 1);
+    const int out_idx = K.resp_out & 0xffffff;
+    if ((lane & 1) == 0) desc_out[cam][(size_t)out_idx * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+    if (lane == 0) {
+        orb_keypoint kp;
+        const float fx = (float)K.x, fy = (float)K.y;
+        kp.x = level ? fx * Lv.scale : fx;  // pt *= scale only for level != 0 (:1096-1103)
+        kp.y = level ? fy * Lv.scale : fy;
+        kp.size = Lv.patch_size;
+        kp.angle = angle;
+        kp.response = (float)((unsigned)K.resp_out >> 24);
+        kp.octave = level;
+        kp.class_id = -1;
+        kps_out[cam][out_idx] = kp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host tables
+inline int cv_round(double v) { return (int)std::nearbyint(v); }
+inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct CamTables {
+    orbx_params p;
+    std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+    std::vector<int> quota;
+};
+
+void build_cam_tables(const orbx_params& p, CamTables& T) {
+    T.p = p;
+    const int n = p.nlevels;
+    const double sf = (double)p.scale_factor;  // the reference stores scaleFactor in a double member
+    T.scale.assign(n, 1.0f); T.sigma2.assign(n, 1.0f); T.inv_scale.assign(n, 1.0f); T.inv_sigma2.assign(n, 1.0f);
+    for (int i = 1; i < n; ++i) {
+        T.scale[i] = (float)((double)T.scale[i - 1] * sf);
+        T.sigma2[i] = T.scale[i] * T.scale[i];
+    }
+    for (int i = 0; i < n; ++i) { T.inv_scale[i] = 1.0f / T.scale[i]; T.inv_sigma2[i] = 1.0f / T.sigma2[i]; }
+    T.quota.assign(n, 0);
+    const float factor = (float)(1.0 / sf);
+    float desired = (float)p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)n));
+    int sum = 0;
+    for (int l = 0; l < n - 1; ++l) {
+        T.quota[l] = cv_round(desired);
+        sum += T.quota[l];
+        desired *= factor;
+    }
+    T.quota[n - 1] = std::max(p.nfeatures - sum, 0);
+}
+
+void compute_umax(int* umax) {
+    int v, v0, vmax = cv_floor(HALF_PATCH * std::sqrt(2.f) / 2 + 1);
+    int vmin = cv_ceil(HALF_PATCH * std::sqrt(2.f) / 2);
+    const double hp2 = HALF_PATCH * HALF_PATCH;
+    for (v = 0; v <= vmax; ++v) umax[v] = cv_round(std::sqrt(hp2 - v * v));
+    for (v = HALF_PATCH, v0 = 0; v >= vmin; --v) {
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
+}
+
+// OpenCV resize(INTER_LINEAR) coefficient tables for one axis pair (imgwarp.cpp, 8-bit fixed point path)
+void build_resize_tables(int sw, int sh, int dw, int dh, std::vector<int2>& xt, std::vector<int4>& yt) {
+    const int ONE = 1 << COEF_BITS;
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    auto sat_short = [](int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; };
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        const int a0 = sat_short(cv_round((1.f - fx) * ONE)), a1 = sat_short(cv_round(fx * ONE));
+        const int sx1 = std::min(sx + 1, sw - 1);
+        int2 e;
+        e.x = (sx & 0xffff) | (sx1 << 16);
+        e.y = (a0 & 0xffff) | (a1 << 16);
+        xt.push_back(e);
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        int4 e;
+        e.x = std::min(std::max(sy, 0), sh - 1);      // each tap's row is clipped, coefficients stay
+        e.y = std::min(std::max(sy + 1, 0), sh - 1);
+        e.z = sat_short(cv_round((1.f - fy) * ONE));
+        e.w = sat_short(cv_round(fy * ONE));
+        yt.push_back(e);
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+struct orbx_extractor {
+    int device = 0, n_cams = 0, max_w = 0, max_h = 0, max_levels = 0;
+    hipStream_t stream = nullptr;
+    std::vector<CamTables> cams;
+    std::vector<int> cur_w, cur_h;   // size of the resident image per camera (0 = none)
+    bool tables_dirty = true;
+
+    // geometry (host copies)
+    std::vector<LevelInfo> levels;   // [cam * max_levels + level]
+    std::vector<int2> cell_map;
+    int total_cells = 0;
+    size_t total_slots = 0;
+    size_t cam_pitch = 0;            // bytes of pyramid memory per camera
+    std::vector<int> out_cap;        // per camera keypoint capacity of the output buffers
+
+    // device memory
+    DevBuf<uint8_t> d_pyr;
+    DevBuf<LevelInfo> d_levels;
+    DevBuf<int2> d_cell_map, d_xtab;
+    DevBuf<int4> d_ytab;
+    DevBuf<int> d_cell_cnt, d_cell_off;
+    DevBuf<uint32_t> d_cell_items;
+    DevBuf<SelKp> d_sel;
+    std::vector<DevBuf<orb_keypoint>> d_kps;
+    std::vector<DevBuf<uint8_t>> d_desc;
+    std::vector<orb_keypoint*> out_kps;   // active output pointers (internal or bound)
+    std::vector<uint8_t*> out_desc;
+    std::vector<int> out_cap_active;
+    DevBuf<orb_keypoint*> d_out_kps;
+    DevBuf<uint8_t*> d_out_desc;
+    bool out_ptrs_dirty = true;
+
+    // pinned host (device-visible) buffers
+    uint32_t* h_cand = nullptr; size_t h_cand_cap = 0;
+    int* h_level_cnt = nullptr;
+    SelKp* h_sel = nullptr; size_t h_sel_cap = 0;
+
+    std::vector<int> n_out;          // keypoints per camera of the last run
+    std::vector<int> level_cnt_last; // candidates per (cam, level) of the last run
+    // scratch for the host quadtree
+    std::vector<int> cx, cy, cr, selected;
+
+    bool profiling = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float stage_us[6] = {0, 0, 0, 0, 0, 0};
+};
+
+static int rebuild_geometry(orbx_extractor* ex) {
+    const int ML = ex->max_levels;
+    ex->levels.assign((size_t)ex->n_cams * ML, LevelInfo{});
+    ex->cell_map.clear();
+    std::vector<int2> xt;
+    std::vector<int4> yt;
+    int cell_base = 0;
+    size_t slot_base = 0, cand_base = 0;
+    for (int c = 0; c < ex->n_cams; ++c) {
+        const CamTables& T = ex->cams[c];
+        const int W = ex->cur_w[c], H = ex->cur_h[c];
+        if (W == 0 || H == 0) continue;
+        int pyr_off = 0, pw = 0, ph = 0;
+        for (int l = 0; l < T.p.nlevels; ++l) {
+            LevelInfo& Lv = ex->levels[(size_t)c * ML + l];
+            const float s = T.inv_scale[l];
+            Lv.w = cv_round((double)((float)W * s));  // reference :1113-1114
+            Lv.h = cv_round((double)((float)H * s));
+            Lv.stride = align_up(Lv.w, 64);
+            Lv.pyr_off = pyr_off;
+            pyr_off += align_up(Lv.stride * Lv.h, 256);
+            Lv.ini_th = T.p.ini_th_fast; Lv.min_th = T.p.min_th_fast;
+            Lv.scale = T.scale[l];
+            Lv.patch_size = (float)(int)(PATCH_SIZE * T.scale[l]);  // :838
+            // cell grid, :774-788
+            const float width = (float)(Lv.w - 2 * MIN_BORDER), height = (float)(Lv.h - 2 * MIN_BORDER);
+            const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+            if (nCols < 1 || nRows < 1) {
+                morb::set_error("camera %d level %d is %dx%d: too small for the 30-px detection grid", c, l, Lv.w, Lv.h);
+                return ORB_E_ARG;
+            }
+            Lv.n_cols = nCols; Lv.n_rows = nRows;
+            Lv.w_cell = (int)std::ceil(width / nCols);
+            Lv.h_cell = (int)std::ceil(height / nRows);
+            if (Lv.w_cell > CELL_MAX || Lv.h_cell > CELL_MAX || Lv.w > 4096 + 2 * MIN_BORDER || Lv.h > 4096 + 2 * MIN_BORDER) {
+                morb::set_error("camera %d level %d (%dx%d): cell %dx%d or level size outside the supported range", c, l,
+                                Lv.w, Lv.h, Lv.w_cell, Lv.h_cell);
+                return ORB_E_ARG;
+            }
+            Lv.cell_base = cell_base;
+            Lv.slot_cap = ((Lv.w_cell + 1) / 2) * ((Lv.h_cell + 1) / 2);  // strict 8-neighbour maxima cannot be denser
+            Lv.slot_base = (int)slot_base;
+            Lv.cand_base = (int)cand_base;
+            const int ncell = nCols * nRows;
+            for (int k = 0; k < ncell; ++k) ex->cell_map.push_back(make_int2(c * ML + l, k));
+            cell_base += ncell;
+            slot_base += (size_t)ncell * Lv.slot_cap;
+            cand_base += (size_t)ncell * Lv.slot_cap;
+            if (l > 0) {
+                Lv.xtab_off = (int)xt.size(); Lv.ytab_off = (int)yt.size();
+                build_resize_tables(pw, ph, Lv.w, Lv.h, xt, yt);
+            }
+            pw = Lv.w; ph = Lv.h;
+        }
+        if ((size_t)pyr_off > ex->cam_pitch) { morb::set_error("image larger than the size given at create"); return ORB_E_ARG; }
+    }
+    if (slot_base > (size_t)INT32_MAX) { morb::set_error("candidate slot space exceeds 2^31 entries"); return ORB_E_ARG; }
+    ex->total_cells = cell_base;
+    ex->total_slots = slot_base;
+    int rc;
+    if ((rc = ex->d_levels.reserve(ex->levels.size())) || (rc = ex->d_cell_map.reserve(std::max<size_t>(ex->cell_map.size(), 1))) ||
+        (rc = ex->d_xtab.reserve(std::max<size_t>(xt.size(), 1))) || (rc = ex->d_ytab.reserve(std::max<size_t>(yt.size(), 1))) ||
+        (rc = ex->d_cell_cnt.reserve(std::max(cell_base, 1))) || (rc = ex->d_cell_off.reserve(std::max(cell_base, 1))) ||
+        (rc = ex->d_cell_items.reserve(std::max<size_t>(slot_base, 1))))
+        return rc;
+    if (slot_base > ex->h_cand_cap) {
+        if (ex->h_cand) (void)hipHostFree(ex->h_cand);
+        ex->h_cand = nullptr; ex->h_cand_cap = 0;
+        MORB_HIP(hipHostMalloc((void**)&ex->h_cand, slot_base * sizeof(uint32_t), hipHostMallocMapped));
+        ex->h_cand_cap = slot_base;
+    }
+    MORB_HIP(hipMemcpyAsync(ex->d_levels.p, ex->levels.data(), ex->levels.size() * sizeof(LevelInfo), hipMemcpyHostToDevice, ex->stream));
+    if (!ex->cell_map.empty())
+        MORB_HIP(hipMemcpyAsync(ex->d_cell_map.p, ex->cell_map.data(), ex->cell_map.size() * sizeof(int2), hipMemcpyHostToDevice, ex->stream));
+    if (!xt.empty()) MORB_HIP(hipMemcpyAsync(ex->d_xtab.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice, ex->stream));
+    if (!yt.empty()) MORB_HIP(hipMemcpyAsync(ex->d_ytab.p, yt.data(), yt.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
+    MORB_HIP(hipStreamSynchronize(ex->stream));  // xt / yt are locals
+    ex->tables_dirty = false;
+    return ORB_OK;
+}
+
+static size_t pyramid_bytes(const CamTables& T, int W, int H) {
+    size_t off = 0;
+    for (int l = 0; l < T.p.nlevels; ++l) {
+        const int w = cv_round((double)((float)W * T.inv_scale[l])), h = cv_round((double)((float)H * T.inv_scale[l]));
+        off += (size_t)align_up(align_up(w, 64) * h, 256);
+    }
+    return off;
+}
+
+extern "C" {
+
+int orbx_tables(const orbx_params* p, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                int32_t* features_per_level, int32_t* umax16) {
+    MORB_ARG(p && p->nlevels >= 1 && p->nlevels <= MAX_LEVELS && p->scale_factor > 1.0f && p->nfeatures >= 0);
+    CamTables T;
+    build_cam_tables(*p, T);
+    for (int i = 0; i < p->nlevels; ++i) {
+        if (scale) scale[i] = T.scale[i];
+        if (inv_scale) inv_scale[i] = T.inv_scale[i];
+        if (sigma2) sigma2[i] = T.sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = T.inv_sigma2[i];
+        if (features_per_level) features_per_level[i] = T.quota[i];
+    }
+    if (umax16) compute_umax(umax16);
+    return ORB_OK;
+}
+
+int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbx_extractor** out) {
+    MORB_ARG(params && out && n_cams >= 1 && n_cams <= 64 && max_width >= 64 && max_height >= 64);
+    for (int c = 0; c < n_cams; ++c)
+        MORB_ARG(params[c].nlevels >= 1 && params[c].nlevels <= MAX_LEVELS && params[c].scale_factor > 1.0f &&
+                 params[c].nfeatures >= 1 && params[c].min_th_fast >= 1 && params[c].ini_th_fast >= params[c].min_th_fast &&
+                 params[c].ini_th_fast <= 255);
+    {   // the kernels hard-code the ctor-derived constants; make sure the ctor arithmetic still yields them
+        int um[16];
+        compute_umax(um);
+        const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+        for (int i = 0; i < 16; ++i) MORB_ARG(um[i] == expect[i]);
+    }
+    int rc = morb::select_device(device);
+    if (rc != ORB_OK) return rc;
+    orbx_extractor* ex = new orbx_extractor();
+    ex->device = device; ex->n_cams = n_cams; ex->max_w = max_width; ex->max_h = max_height;
+    hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete ex; return ORB_E_HIP; }
+    ex->cams.resize(n_cams);
+    ex->cur_w.assign(n_cams, 0); ex->cur_h.assign(n_cams, 0);
+    ex->n_out.assign(n_cams, 0);
+    ex->d_kps.resize(n_cams); ex->d_desc.resize(n_cams);
+    ex->out_kps.assign(n_cams, nullptr); ex->out_desc.assign(n_cams, nullptr); ex->out_cap_active.assign(n_cams, 0);
+    ex->out_cap.assign(n_cams, 0);
+    size_t sel_cap = 0;
+    for (int c = 0; c < n_cams; ++c) {
+        build_cam_tables(params[c], ex->cams[c]);
+        ex->max_levels = std::max(ex->max_levels, params[c].nlevels);
+        ex->cam_pitch = std::max(ex->cam_pitch, pyramid_bytes(ex->cams[c], max_width, max_height));
+        ex->out_cap[c] = params[c].nfeatures + 4 * params[c].nlevels;  // quota + 2 overshoot per level, with margin
+        sel_cap += ex->out_cap[c];
+    }
+    ex->cam_pitch = (ex->cam_pitch + 4095) / 4096 * 4096 + 4096;
+#define ORBX_TRY(x) do { int rc_ = (x); if (rc_) { orbx_destroy(ex); return rc_; } } while (0)
+#define ORBX_TRY_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { morb::set_error("%s: %s", #x, hipGetErrorString(e_)); orbx_destroy(ex); return ORB_E_HIP; } } while (0)
+    ORBX_TRY(ex->d_pyr.reserve(ex->cam_pitch * n_cams));
+    for (int c = 0; c < n_cams; ++c) {
+        ORBX_TRY(ex->d_kps[c].reserve(ex->out_cap[c]));
+        ORBX_TRY(ex->d_desc[c].reserve((size_t)ex->out_cap[c] * 32));
+        ex->out_kps[c] = ex->d_kps[c].p; ex->out_desc[c] = ex->d_desc[c].p; ex->out_cap_active[c] = ex->out_cap[c];
+    }
+    ORBX_TRY(ex->d_out_kps.reserve(n_cams));
+    ORBX_TRY(ex->d_out_desc.reserve(n_cams));
+    ORBX_TRY(ex->d_sel.reserve(sel_cap));
+    ORBX_TRY_HIP(hipHostMalloc((void**)&ex->h_sel, sel_cap * sizeof(SelKp), hipHostMallocDefault));
+    ex->h_sel_cap = sel_cap;
+    ORBX_TRY_HIP(hipHostMalloc((void**)&ex->h_level_cnt, (size_t)n_cams * MAX_LEVELS * sizeof(int), hipHostMallocMapped));
+    for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
+    ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
+    *out = ex;
+    return ORB_OK;
+}
+
+void orbx_destroy(orbx_extractor* ex) {
+    if (!ex) return;
+    (void)hipSetDevice(ex->device);
+    if (ex->stream) (void)hipStreamSynchronize(ex->stream);
+    ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release();
+    ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release();
+    for (auto& b : ex->d_kps) b.release();
+    for (auto& b : ex->d_desc) b.release();
+    ex->d_out_kps.release(); ex->d_out_desc.release();
+    if (ex->h_cand) (void)hipHostFree(ex->h_cand);
+    if (ex->h_level_cnt) (void)hipHostFree(ex->h_level_cnt);
+    if (ex->h_sel) (void)hipHostFree(ex->h_sel);
+    for (int i = 0; i < 6; ++i) if (ex->ev[i]) (void)hipEventDestroy(ex->ev[i]);
+    if (ex->stream) (void)hipStreamDestroy(ex->stream);
+    delete ex;
+}
+
+void* orbx_stream(const orbx_extractor* ex) { return ex ? (void*)ex->stream : nullptr; }
+
+static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int width, int height, int stride, hipMemcpyKind kind) {
+    MORB_ARG(ex && cam >= 0 && cam < ex->n_cams);
+    MORB_HIP(hipSetDevice(ex->device));
+    if (!src || width <= 0 || height <= 0) {  // empty image: camera produces nothing (reference :1047-1048)
+        if (ex->cur_w[cam] != 0) { ex->cur_w[cam] = ex->cur_h[cam] = 0; ex->tables_dirty = true; }
+        return ORB_OK;
+    }
+    MORB_ARG(width <= ex->max_w && height <= ex->max_h && stride >= width);
+    if (ex->cur_w[cam] != width || ex->cur_h[cam] != height) {
+        ex->cur_w[cam] = width; ex->cur_h[cam] = height;
+        ex->tables_dirty = true;
+    }
+    // level 0 lives at offset 0 of the camera's pyramid buffer with pitch align64(width)
+    MORB_HIP(hipMemcpy2DAsync(ex->d_pyr.p + (size_t)cam * ex->cam_pitch, align_up(width, 64), src, stride, width, height, kind, ex->stream));
+    return ORB_OK;
+}
+
+int orbx_upload(orbx_extractor* ex, int cam, const uint8_t* gray, int width, int height, int stride) {
+    return upload_common(ex, cam, gray, width, height, stride, hipMemcpyHostToDevice);
+}
+
+int orbx_upload_device(orbx_extractor* ex, int cam, const uint8_t* d_gray, int width, int height, int stride) {
+    return upload_common(ex, cam, d_gray, width, height, stride, hipMemcpyDeviceToDevice);
+}
+
+int orbx_bind_output(orbx_extractor* ex, int cam, orb_keypoint* d_kps, uint8_t* d_desc, int cap) {
+    MORB_ARG(ex && cam >= 0 && cam < ex->n_cams);
+    if (!d_kps || !d_desc) {
+        ex->out_kps[cam] = ex->d_kps[cam].p; ex->out_desc[cam] = ex->d_desc[cam].p; ex->out_cap_active[cam] = ex->out_cap[cam];
+    } else {
+        MORB_ARG(cap >= 1);
+        ex->out_kps[cam] = d_kps; ex->out_desc[cam] = d_desc; ex->out_cap_active[cam] = cap;
+    }
+    ex->out_ptrs_dirty = true;
+    return ORB_OK;
+}
+
+int orbx_set_profiling(orbx_extractor* ex, int on) {
+    MORB_ARG(ex != nullptr);
+    ex->profiling = on != 0;
+    return ORB_OK;
+}
+
+int orbx_stage_times_us(const orbx_extractor* ex, float* out6) {
+    MORB_ARG(ex && out6);
+    for (int i = 0; i < 6; ++i) out6[i] = ex->stage_us[i];
+    return ORB_OK;
+}
+
+int orbx_run(orbx_extractor* ex) {
+    MORB_ARG(ex != nullptr);
+    MORB_HIP(hipSetDevice(ex->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    int rc;
+    if (ex->tables_dirty && (rc = rebuild_geometry(ex))) return rc;
+    if (ex->out_ptrs_dirty) {
+        MORB_HIP(hipMemcpyAsync(ex->d_out_kps.p, ex->out_kps.data(), ex->n_cams * sizeof(void*), hipMemcpyHostToDevice, ex->stream));
+        MORB_HIP(hipMemcpyAsync(ex->d_out_desc.p, ex->out_desc.data(), ex->n_cams * sizeof(void*), hipMemcpyHostToDevice, ex->stream));
+        MORB_HIP(hipStreamSynchronize(ex->stream));
+        ex->out_ptrs_dirty = false;
+    }
+    const int ML = ex->max_levels;
+    hipStream_t st = ex->stream;
+    std::fill(ex->n_out.begin(), ex->n_out.end(), 0);
+    if (ex->total_cells == 0) return ORB_OK;  // every camera empty
+    uint32_t* d_cand = nullptr; int* d_level_cnt = nullptr;
+    MORB_HIP(hipHostGetDevicePointer((void**)&d_cand, ex->h_cand, 0));
+    MORB_HIP(hipHostGetDevicePointer((void**)&d_level_cnt, ex->h_level_cnt, 0));
+
+    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[0], st));
+    // K1: pyramid chain
+    for (int l = 1; l < ML; ++l) {
+        int mw = 0, mh = 0;
+        for (int c = 0; c < ex->n_cams; ++c) {
+            const LevelInfo& Lv = ex->levels[(size_t)c * ML + l];
+            mw = std::max(mw, Lv.w); mh = std::max(mh, Lv.h);
+        }
+        if (mw == 0) continue;
+        dim3 grid((mw + 255) / 256, (mh + 3) / 4, ex->n_cams), block(64, 4, 1);
+        hipLaunchKernelGGL(k_resize, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
+                           (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
+    }
+    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[1], st));
+    // K2+K3: per-cell FAST / NMS / threshold / compaction
+    hipLaunchKernelGGL(k_fast_cells, dim3(ex->total_cells), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p,
+                       (const int2*)ex->d_cell_map.p, (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, ML, ex->d_cell_cnt.p,
+                       ex->d_cell_items.p);
+    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[2], st));
+    // K3b: dense cell-major lists into pinned host memory
+    hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ML), dim3(1024), 0, st, (const LevelInfo*)ex->d_levels.p,
+                       (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_cell_off.p, d_cand, d_level_cnt);
+    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[3], st));
+    MORB_HIP(hipGetLastError());
+    MORB_HIP(hipStreamSynchronize(st));
+    const auto t_host0 = std::chrono::steady_clock::now();
+
+    // K4 (host): quadtree per (camera, level); output order = level-major, list order inside a level
+    int nsel = 0;
+    for (int c = 0; c < ex->n_cams; ++c) {
+        const CamTables& T = ex->cams[c];
+        int out_idx = 0;
+        for (int l = 0; l < T.p.nlevels; ++l) {
+            const LevelInfo& Lv = ex->levels[(size_t)c * ML + l];
+            const int n = Lv.w ? ex->h_level_cnt[c * ML + l] : 0;
+            ex->level_cnt_last[(size_t)c * ML + l] = n;
+            if (n == 0) continue;
+            const uint32_t* cand = ex->h_cand + Lv.cand_base;
+            ex->cx.resize(n); ex->cy.resize(n); ex->cr.resize(n);
+            for (int i = 0; i < n; ++i) {
+                const uint32_t v = cand[i];
+                ex->cx[i] = v & 0xfff; ex->cy[i] = (v >> 12) & 0xfff; ex->cr[i] = v >> 24;
+            }
+            morb::distribute_octree(ex->cx.data(), ex->cy.data(), ex->cr.data(), n, Lv.w - 2 * MIN_BORDER, Lv.h - 2 * MIN_BORDER,
+                                    T.quota[l], ex->selected);
+            for (int s : ex->selected) {
+                if (out_idx >= ex->out_cap_active[c] || (size_t)nsel >= ex->h_sel_cap) {
+                    morb::set_error("camera %d produced more keypoints than its output capacity %d", c, ex->out_cap_active[c]);
+                    return ORB_E_CAPACITY;
+                }
+                SelKp& K = ex->h_sel[nsel++];
+                K.x = ex->cx[s] + MIN_BORDER; K.y = ex->cy[s] + MIN_BORDER;  // :843-844
+                K.camlevel = (c << 8) | l;
+                K.resp_out = (int)(((unsigned)ex->cr[s] << 24) | (unsigned)out_idx);
+                ++out_idx;
+            }
+        }
+        ex->n_out[c] = out_idx;
+    }
+    const auto t_host1 = std::chrono::steady_clock::now();
+    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[4], st));
+    if (nsel > 0) {
+        MORB_HIP(hipMemcpyAsync(ex->d_sel.p, ex->h_sel, (size_t)nsel * sizeof(SelKp), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_describe, dim3((nsel + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
+                           (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel.p, nsel,
+                           (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p);
+        MORB_HIP(hipGetLastError());
+    }
+    if (ex->profiling) {
+        MORB_HIP(hipEventRecord(ex->ev[5], st));
+        MORB_HIP(hipStreamSynchronize(st));
+        float ms;
+        MORB_HIP(hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1])); ex->stage_us[0] = ms * 1000.f;
+        MORB_HIP(hipEventElapsedTime(&ms, ex->ev[1], ex->ev[2])); ex->stage_us[1] = ms * 1000.f;
+        MORB_HIP(hipEventElapsedTime(&ms, ex->ev[2], ex->ev[3])); ex->stage_us[2] = ms * 1000.f;
+        ex->stage_us[3] = std::chrono::duration<float, std::micro>(t_host1 - t_host0).count();
+        MORB_HIP(hipEventElapsedTime(&ms, ex->ev[4], ex->ev[5])); ex->stage_us[4] = ms * 1000.f;
+        ex->stage_us[5] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    return ORB_OK;
+}
+
+int orbx_count(const orbx_extractor* ex, int cam) {
+    if (!ex || cam < 0 || cam >= ex->n_cams) return ORB_E_ARG;
+    return ex->n_out[cam];
+}
+
+const orb_keypoint* orbx_device_keypoints(const orbx_extractor* ex, int cam) {
+    return (ex && cam >= 0 && cam < ex->n_cams) ? ex->out_kps[cam] : nullptr;
+}
+const uint8_t* orbx_device_descriptors(const orbx_extractor* ex, int cam) {
+    return (ex && cam >= 0 && cam < ex->n_cams) ? ex->out_desc[cam] : nullptr;
+}
+
+int orbx_download(orbx_extractor* ex, int cam, orb_keypoint* kps, uint8_t* desc, int cap) {
+    MORB_ARG(ex && cam >= 0 && cam < ex->n_cams);
+    MORB_HIP(hipSetDevice(ex->device));
+    const int n = ex->n_out[cam];
+    if (n > cap) { morb::set_error("camera %d has %d keypoints, capacity %d", cam, n, cap); return ORB_E_CAPACITY; }
+    if (n > 0) {
+        MORB_ARG(kps && desc);
+        MORB_HIP(hipMemcpyAsync(kps, ex->out_kps[cam], (size_t)n * sizeof(orb_keypoint), hipMemcpyDeviceToHost, ex->stream));
+        MORB_HIP(hipMemcpyAsync(desc, ex->out_desc[cam], (size_t)n * 32, hipMemcpyDeviceToHost, ex->stream));
+    }
+    MORB_HIP(hipStreamSynchronize(ex->stream));
+    return ORB_OK;
+}
+
+int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, const int* width, const int* height,
+                 const int* stride, orb_keypoint* const* kps_out, uint8_t* const* desc_out, const int* cap, int* n_out) {
+    MORB_ARG(ex && n_cams == ex->n_cams && gray && width && height && stride && kps_out && desc_out && cap && n_out);
+    int rc;
+    for (int c = 0; c < n_cams; ++c)
+        if ((rc = orbx_upload(ex, c, gray[c], width[c], height[c], stride[c]))) return rc;
+    if ((rc = orbx_run(ex))) return rc;
+    for (int c = 0; c < n_cams; ++c) {
+        n_out[c] = ex->n_out[c];
+        if (n_out[c] == 0) continue;  // outputs untouched for an empty camera
+        if ((rc = orbx_download(ex, c, kps_out[c], desc_out[c], cap[c]))) return rc;
+    }
+    return ORB_OK;
+}
+
+int orbx_debug_level(orbx_extractor* ex, int cam, int level, uint8_t* out, int cap_bytes, int* w, int* h) {
+    MORB_ARG(ex && cam >= 0 && cam < ex->n_cams && level >= 0 && level < ex->cams[cam].p.nlevels && w && h);
+    MORB_ARG(!ex->tables_dirty);
+    MORB_HIP(hipSetDevice(ex->device));
+    const LevelInfo& Lv = ex->levels[(size_t)cam * ex->max_levels + level];
+    *w = Lv.w; *h = Lv.h;
+    if (Lv.w == 0) return ORB_OK;
+    if (Lv.w * Lv.h > cap_bytes) { morb::set_error("level needs %d bytes", Lv.w * Lv.h); return ORB_E_CAPACITY; }
+    MORB_HIP(hipMemcpy2DAsync(out, Lv.w, ex->d_pyr.p + (size_t)cam * ex->cam_pitch + Lv.pyr_off, Lv.stride, Lv.w, Lv.h,
+                              hipMemcpyDeviceToHost, ex->stream));
+    MORB_HIP(hipStreamSynchronize(ex->stream));
+    return ORB_OK;
+}
+
+int orbx_debug_candidates(orbx_extractor* ex, int cam, int level, orb_keypoint* out, int cap, int* n) {
+    MORB_ARG(ex && cam >= 0 && cam < ex->n_cams && level >= 0 && level < ex->cams[cam].p.nlevels && n);
+    MORB_ARG(!ex->tables_dirty);
+    const LevelInfo& Lv = ex->levels[(size_t)cam * ex->max_levels + level];
+    const int cnt = ex->level_cnt_last[(size_t)cam * ex->max_levels + level];
+    *n = cnt;
+    const uint32_t* cand = ex->h_cand + Lv.cand_base;
+    for (int i = 0; i < cnt && i < cap; ++i) {
+        const uint32_t v = cand[i];
+        out[i].x = (float)(v & 0xfff); out[i].y = (float)((v >> 12) & 0xfff);
+        out[i].size = 7.f; out[i].angle = -1.f; out[i].response = (float)(v >> 24); out[i].octave = 0; out[i].class_id = -1;
+    }
+    return ORB_OK;
+}
+
+}  // extern "C"

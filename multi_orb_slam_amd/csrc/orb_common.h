@@ -1,0 +1,63 @@
+// orb_common.h -- shared host-side helpers of the HIP library (error plumbing, small utilities).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/orb_types.h"
+
+namespace morb {
+
+void set_error(const char* fmt, ...);
+
+#define MORB_HIP(call)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            morb::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return ORB_E_HIP;                                                                       \
+        }                                                                                           \
+    } while (0)
+
+#define MORB_ARG(cond)                                                        \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            morb::set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+            return ORB_E_ARG;                                                 \
+        }                                                                     \
+    } while (0)
+
+// Selects `device` and verifies it is a gfx950 part.  The product has no CPU path: anything else is an error.
+int select_device(int device);
+
+template <typename T>
+struct DevBuf {  // grow-only device buffer
+    T* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return ORB_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        MORB_HIP(hipMalloc((void**)&p, n * sizeof(T)));
+        cap = n;
+        return ORB_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <typename T>
+struct PinnedBuf {  // grow-only pinned host buffer
+    T* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return ORB_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        MORB_HIP(hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault));
+        cap = n;
+        return ORB_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace morb

@@ -1,0 +1,139 @@
+"""Host-side mirror of the hot part of ORB_SLAM2::ORBmatcher over the C ABI (include/orbm.h)."""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import QUERY_DTYPE, FrameDesc, check, ptr
+
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # reference src/ORBmatcher.cc:37-39
+
+
+def descriptor_distance(a, b):
+    """static ORBmatcher::DescriptorDistance (reference src/ORBmatcher.cc:3994-4010)."""
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return _lib.lib().orbm_descriptor_distance(ptr(a), ptr(b))
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32); ind = np.zeros(3, np.int32)
+    _lib.lib().orbm_three_maxima(ptr(sizes), len(sizes), ptr(ind))
+    return tuple(int(i) for i in ind)
+
+
+class FrameData:
+    """Flat arrays of the Frame members the matcher reads (reference src/Frame.cc:191-288): cam-major global index."""
+
+    def __init__(self, un_x, un_y, octave, angle, uright, cam_of, local_of, descs, bounds):
+        self.un_x = np.ascontiguousarray(un_x, np.float32); self.un_y = np.ascontiguousarray(un_y, np.float32)
+        self.octave = np.ascontiguousarray(octave, np.int32); self.angle = np.ascontiguousarray(angle, np.float32)
+        self.uright = np.ascontiguousarray(uright, np.float32)
+        self.cam_of = np.ascontiguousarray(cam_of, np.int32); self.local_of = np.ascontiguousarray(local_of, np.int32)
+        self.descs = [np.ascontiguousarray(d, np.uint8) for d in descs]
+        self.bounds = tuple(float(b) for b in bounds)
+        self.n_total = len(self.un_x); self.n_cams = len(self.descs)
+        self._ptrs = (C.c_void_p * self.n_cams)(*[d.ctypes.data for d in self.descs])
+        self.c = FrameDesc(self.n_total, self.n_cams, self.un_x.ctypes.data, self.un_y.ctypes.data,
+                           self.octave.ctypes.data, self.angle.ctypes.data, self.uright.ctypes.data,
+                           self.cam_of.ctypes.data, self.local_of.ctypes.data, C.cast(self._ptrs, C.c_void_p),
+                           *self.bounds)
+
+    @staticmethod
+    def from_cameras(per_cam, width, height, uright=None):
+        """Frame merge (reference src/Frame.cc:191-239): per_cam = [(keypoints, descriptors), ...] -> `_total` arrays.
+        Undistortion is the identity (k1 == 0) and the image bounds are [0,W]x[0,H] (Frame.cc:743-779)."""
+        xs, ys, octs, angs, cams, locs, descs = [], [], [], [], [], [], []
+        for c, (k, d) in enumerate(per_cam):
+            xs.append(k["x"]); ys.append(k["y"]); octs.append(k["octave"]); angs.append(k["angle"])
+            cams.append(np.full(len(k), c, np.int32)); locs.append(np.arange(len(k), dtype=np.int32)); descs.append(d)
+        cat = np.concatenate
+        n = sum(len(x) for x in xs)
+        ur = np.full(n, -1.0, np.float32) if uright is None else uright
+        return FrameData(cat(xs), cat(ys), cat(octs), cat(angs), ur, cat(cams), cat(locs), descs, (0, 0, width, height))
+
+
+class Frame:
+    def __init__(self, matcher, data):
+        self.data = data
+        self._h = C.c_void_p()
+        self._m = matcher
+        check(_lib.lib().orbm_frame_create(matcher._h, C.byref(data.c), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().orbm_frame_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def grid(self):
+        cs = np.zeros(self.data.n_cams * 64 * 48 + 1, np.int32); items = np.zeros(max(self.data.n_total, 1), np.int32)
+        check(_lib.lib().orbm_frame_grid(self._h, ptr(cs), ptr(items)))
+        return cs, items[:cs[-1]]
+
+
+class Matcher:
+    """ORBmatcher(nnratio=0.6, checkOri=True) (reference include/ORBmatcher.h:41)."""
+
+    def __init__(self, nnratio=0.6, check_orientation=True, device=0):
+        self.nnratio = float(nnratio); self.check_orientation = bool(check_orientation)
+        self._h = C.c_void_p()
+        check(_lib.lib().orbm_create(device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().orbm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def stream(self):
+        return _lib.lib().orbm_stream(self._h)
+
+    DescriptorDistance = staticmethod(descriptor_distance)
+
+    def hamming_top2(self, q, r):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); r = np.ascontiguousarray(r, np.uint8).reshape(-1, 32)
+        bi = np.zeros(len(q), np.int32); bd = np.zeros(len(q), np.int32); sd = np.zeros(len(q), np.int32)
+        check(_lib.lib().orbm_hamming_top2(self._h, ptr(q), len(q), ptr(r), len(r), ptr(bi), ptr(bd), ptr(sd)))
+        return bi, bd, sd
+
+    def hamming_matrix(self, q, r):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); r = np.ascontiguousarray(r, np.uint8).reshape(-1, 32)
+        out = np.zeros((len(q), len(r)), np.uint16)
+        check(_lib.lib().orbm_hamming_matrix(self._h, ptr(q), len(q), ptr(r), len(r), ptr(out)))
+        return out
+
+    def frame(self, data):
+        return Frame(self, data)
+
+    def features_in_area(self, frame, cam, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(max(frame.data.n_total, 1), np.int32); n = C.c_int()
+        check(_lib.lib().orbm_features_in_area(self._h, frame._h, cam, x, y, r, min_level, max_level, ptr(out), len(out),
+                                               C.byref(n)))
+        return out[:n.value].copy()
+
+    def project_candidates(self, frame, queries, cap):
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE); nq = len(queries)
+        idx = np.zeros((max(nq, 1), cap), np.int32); dist = np.zeros((max(nq, 1), cap), np.uint16)
+        cnt = np.zeros(max(nq, 1), np.int32)
+        check(_lib.lib().orbm_project_candidates(self._h, frame._h, ptr(queries), nq, cap, ptr(idx), ptr(dist), ptr(cnt)))
+        return idx[:nq], dist[:nq], cnt[:nq]
+
+    def SearchByProjection(self, frame, queries, th_high=TH_HIGH):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono, Calib) from the projected queries on
+        (reference src/ORBmatcher.cc:3448-3641).  Returns (nmatches, match_of_feature)."""
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+        m = np.zeros(max(frame.data.n_total, 1), np.int32); n = C.c_int()
+        check(_lib.lib().orbm_search_by_projection(self._h, frame._h, ptr(queries), len(queries), th_high,
+                                                   int(self.check_orientation), ptr(m), C.byref(n)))
+        return n.value, m[:frame.data.n_total]
+
+    def SearchByProjectionPoints(self, frame, queries, occupied=None, th_high=TH_HIGH):
+        """SearchByProjection(F, vpMapPoints, th) (reference src/ORBmatcher.cc:62-149)."""
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+        m = np.zeros(max(frame.data.n_total, 1), np.int32); n = C.c_int()
+        occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        check(_lib.lib().orbm_search_by_projection_points(self._h, frame._h, ptr(queries), len(queries),
+                                                          None if occ is None else ptr(occ), self.nnratio, th_high,
+                                                          ptr(m), C.byref(n)))
+        return n.value, m[:frame.data.n_total]

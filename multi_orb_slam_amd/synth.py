@@ -1,0 +1,64 @@
+"""Deterministic synthetic camera streams and matcher inputs (no images ship with the reference).
+
+Counter-based integer hashing only, so the same bytes can be regenerated anywhere (numpy, C++) without an RNG
+library: scene = mid-grey canvas + axis-aligned rectangles of random size/grey level (FAST corners at many scales),
+frame t = the scene translated by (3t, t) px + fresh per-pixel noise in [-6, 6].
+"""
+import numpy as np
+
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def hash32(x):
+    """murmur3 finaliser on uint32 arrays."""
+    x = np.asarray(x, np.uint64) & _M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x85EBCA6B)) & _M32
+    x ^= x >> np.uint64(13); x = (x * np.uint64(0xC2B2AE35)) & _M32
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
+def _stream(seed, n):
+    return hash32(np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(seed & 0xFFFFFFFF))
+
+
+def scene_rects(cam, width, height):
+    n = max(8, int(400 * (width * height) / 307200.0))
+    r = _stream(0x51ED270B ^ (cam * 7919), 5 * n).astype(np.int64)
+    margin = 96
+    x0 = r[0::5] % (width + 2 * margin) - margin
+    y0 = r[1::5] % (height + 2 * margin) - margin
+    w = 4 + r[2::5] % 61
+    h = 4 + r[3::5] % 61
+    g = r[4::5] % 256
+    return np.stack([x0, y0, w, h, g], 1)
+
+
+def image(cam, t, width, height):
+    """uint8 HxW frame t of camera `cam`."""
+    img = np.full((height, width), 128, np.int32)
+    dx, dy = 3 * t, t
+    for x0, y0, w, h, g in scene_rects(cam, width, height):
+        xa, ya = max(0, x0 + dx), max(0, y0 + dy)
+        xb, yb = min(width, x0 + dx + w), min(height, y0 + dy + h)
+        if xa < xb and ya < yb:
+            img[ya:yb, xa:xb] = g
+    idx = np.arange(width * height, dtype=np.uint64) + np.uint64(((cam * 100003 + t) * 2654435761) & 0xFFFFFFFF)
+    noise = (hash32(idx) % np.uint32(13)).astype(np.int32).reshape(height, width) - 6
+    return np.clip(img + noise, 0, 255).astype(np.uint8)
+
+
+def descriptors(n, seed=42):
+    return hash32(np.arange(n * 8, dtype=np.uint64) + np.uint64((seed * 0x9E3779B1) & 0xFFFFFFFF)).view(np.uint8).reshape(n, 32).copy()
+
+
+def perturbed_queries(refs, seed=7, flip_p=0.08):
+    """Half of the rows = a reference row with each bit flipped with probability flip_p, the rest fresh random."""
+    n = len(refs)
+    bits = hash32(np.arange(n * 256, dtype=np.uint64) + np.uint64(seed * 77777)).astype(np.float64) / 2.0 ** 32 < flip_p
+    flips = np.packbits(bits.reshape(n, 256), axis=1, bitorder="little")
+    q = refs ^ flips
+    fresh = descriptors(n, seed + 1000)
+    half = (np.arange(n) % 2) == 1
+    q[half] = fresh[half]
+    return q

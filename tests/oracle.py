@@ -1,0 +1,272 @@
+"""ctypes binding of oracle/liborb_oracle.so (the CPU restatement).  TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_SO = os.path.join(ORACLE_DIR, "liborb_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class Query(C.Structure):
+    _fields_ = [("u", C.c_float), ("v", C.c_float), ("radius", C.c_float), ("ur", C.c_float),
+                ("min_level", C.c_int), ("max_level", C.c_int), ("cam", C.c_int), ("blocks", C.c_int),
+                ("angle", C.c_float), ("desc", C.c_uint8 * 32)]
+
+
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("min_level", "<i4"),
+                        ("max_level", "<i4"), ("cam", "<i4"), ("blocks", "<i4"), ("angle", "<f4"),
+                        ("desc", "u1", (32,))])
+assert QUERY_DTYPE.itemsize == C.sizeof(Query) == 68
+
+
+class Frame(C.Structure):
+    _fields_ = [("n_total", C.c_int), ("n_cams", C.c_int), ("un_x", C.c_void_p), ("un_y", C.c_void_p),
+                ("octave", C.c_void_p), ("angle", C.c_void_p), ("uright", C.c_void_p), ("cam_of", C.c_void_p),
+                ("local_of", C.c_void_p), ("desc", C.c_void_p), ("minX", C.c_float), ("minY", C.c_float),
+                ("maxX", C.c_float), ("maxY", C.c_float)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liborb_oracle.so"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_fast_atan2.restype = C.c_float
+        _lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.orc_ic_angle.restype = C.c_float
+        _lib.orc_det_sincos.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        _lib.orc_orb_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        _lib.orc_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.orc_tables.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+        _lib.orc_level_sizes.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.orc_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        _lib.orc_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_int]
+        _lib.orc_search_by_projection_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
+                                                         C.c_int, C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+# ---------------------------------------------------------------------------------------------- tables
+def tables(nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+    L = lib()
+    sc = np.zeros(nlevels, np.float32); inv = np.zeros_like(sc); s2 = np.zeros_like(sc); is2 = np.zeros_like(sc)
+    quota = np.zeros(nlevels, np.int32); umax = np.zeros(16, np.int32)
+    L.orc_tables(nfeatures, scale_factor, nlevels, ini_th, min_th, _p(sc), _p(inv), _p(s2), _p(is2), _p(quota), _p(umax))
+    return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, quota=quota, umax=umax)
+
+
+def level_sizes(W, H, scale_factor=1.2, nlevels=8):
+    w = np.zeros(nlevels, np.int32); h = np.zeros(nlevels, np.int32)
+    lib().orc_level_sizes(W, H, scale_factor, nlevels, _p(w), _p(h))
+    return [(int(a), int(b)) for a, b in zip(w, h)]
+
+
+def pattern():
+    out = np.zeros(1024, np.int8)
+    lib().orc_pattern(_p(out))
+    return out.reshape(256, 4)
+
+
+# ---------------------------------------------------------------------------------------------- image ops
+def resize_linear(src, dw, dh):
+    src = _u8(src); sh, sw = src.shape
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), sw, sh, sw, _p(dst), dw, dh, dw)
+    return dst
+
+
+def copy_make_border(src, border):
+    src = _u8(src); h, w = src.shape
+    dst = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+    lib().orc_copy_make_border_reflect101(_p(src), w, h, w, _p(dst), border, w + 2 * border)
+    return dst
+
+
+def pyramid(img, scale_factor=1.2, nlevels=8):
+    img = _u8(img); H, W = img.shape
+    sizes = level_sizes(W, H, scale_factor, nlevels)
+    out = np.zeros(sum(w * h for w, h in sizes), np.uint8)
+    lib().orc_pyramid(_p(img), W, H, W, scale_factor, nlevels, _p(out))
+    levels, off = [], 0
+    for w, h in sizes:
+        levels.append(out[off:off + w * h].reshape(h, w).copy()); off += w * h
+    return levels
+
+
+def corner_score(img, x, y, threshold):
+    img = _u8(img)
+    return lib().orc_corner_score(_p(img), img.shape[1], x, y, threshold)
+
+
+def is_corner(img, x, y, threshold):
+    img = _u8(img)
+    return bool(lib().orc_is_corner(_p(img), img.shape[1], x, y, threshold))
+
+
+def fast(view, threshold, cap=100000):
+    view = _u8(view); rows, cols = view.shape
+    out = np.zeros(cap, KP_DTYPE)
+    n = lib().orc_fast(_p(view), cols, rows, cols, threshold, _p(out), cap)
+    assert n <= cap
+    return out[:n]
+
+
+def cell_candidates(img, ini_th=20, min_th=7, cap=400000):
+    img = _u8(img); h, w = img.shape
+    out = np.zeros(cap, KP_DTYPE)
+    n = lib().orc_cell_candidates(_p(img), w, h, ini_th, min_th, _p(out), cap)
+    assert n <= cap
+    return out[:n]
+
+
+def distribute_octree(kps, minX, maxX, minY, maxY, N):
+    kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    out = np.zeros(max(len(kps), 1), KP_DTYPE)
+    n = lib().orc_distribute_octree(_p(kps), len(kps), minX, maxX, minY, maxY, N, _p(out), len(out))
+    return out[:n]
+
+
+def fast_atan2(y, x):
+    return np.float32(lib().orc_fast_atan2(float(y), float(x)))
+
+
+def ic_angle(img, x, y):
+    img = _u8(img); h, w = img.shape
+    m01 = C.c_int(); m10 = C.c_int()
+    a = lib().orc_ic_angle(_p(img), w, h, int(x), int(y), C.byref(m01), C.byref(m10))
+    return np.float32(a), m01.value, m10.value
+
+
+def gaussian_kernel():
+    k = np.zeros(7, np.int32); lib().orc_gaussian_kernel(_p(k)); return k
+
+
+def gaussian_blur7(img):
+    img = _u8(img); h, w = img.shape
+    dst = np.zeros_like(img)
+    lib().orc_gaussian_blur7(_p(img), w, h, _p(dst))
+    return dst
+
+
+def det_sincos(angle_rad):
+    c = C.c_float(); s = C.c_float()
+    lib().orc_det_sincos(float(angle_rad), C.byref(c), C.byref(s))
+    return np.float32(c.value), np.float32(s.value)
+
+
+def orb_descriptor(blurred, x, y, angle_deg):
+    blurred = _u8(blurred); h, w = blurred.shape
+    d = np.zeros(32, np.uint8)
+    lib().orc_orb_descriptor(_p(blurred), w, h, float(x), float(y), float(angle_deg), _p(d))
+    return d
+
+
+def extract(img, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+    img = _u8(img); H, W = img.shape
+    cap = nfeatures + 3 * nlevels + 64
+    kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+    n = lib().orc_extract(_p(img), W, H, W, nfeatures, scale_factor, nlevels, ini_th, min_th, _p(kps), _p(desc), cap)
+    assert n >= 0, "oracle capacity"
+    return kps[:n].copy(), desc[:n].copy()
+
+
+# ---------------------------------------------------------------------------------------------- matcher
+def descriptor_distance(a, b):
+    a = _u8(a); b = _u8(b)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def bf_top2(q, r):
+    q = _u8(q); r = _u8(r)
+    bi = np.zeros(len(q), np.int32); bd = np.zeros(len(q), np.int32); sd = np.zeros(len(q), np.int32)
+    lib().orc_bf_top2(_p(q), len(q), _p(r), len(r), _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def hamming_matrix(q, r):
+    q = _u8(q); r = _u8(r)
+    out = np.zeros((len(q), len(r)), np.uint16)
+    lib().orc_hamming_matrix(_p(q), len(q), _p(r), len(r), _p(out))
+    return out
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32); ind = np.zeros(3, np.int32)
+    lib().orc_three_maxima(_p(sizes), len(sizes), _p(ind))
+    return tuple(int(i) for i in ind)
+
+
+class FrameData:
+    """Flat arrays of the Frame members the matcher reads, cam-major global indexing."""
+
+    def __init__(self, un_x, un_y, octave, angle, uright, cam_of, local_of, descs, bounds):
+        self.un_x = np.ascontiguousarray(un_x, np.float32); self.un_y = np.ascontiguousarray(un_y, np.float32)
+        self.octave = np.ascontiguousarray(octave, np.int32); self.angle = np.ascontiguousarray(angle, np.float32)
+        self.uright = np.ascontiguousarray(uright, np.float32)
+        self.cam_of = np.ascontiguousarray(cam_of, np.int32); self.local_of = np.ascontiguousarray(local_of, np.int32)
+        self.descs = [_u8(d) for d in descs]
+        self.bounds = tuple(float(b) for b in bounds)  # minX, minY, maxX, maxY
+        self.n_total = len(self.un_x); self.n_cams = len(self.descs)
+        self._ptrs = (C.c_void_p * self.n_cams)(*[d.ctypes.data for d in self.descs])
+        self.c = Frame(self.n_total, self.n_cams, self.un_x.ctypes.data, self.un_y.ctypes.data, self.octave.ctypes.data,
+                       self.angle.ctypes.data, self.uright.ctypes.data, self.cam_of.ctypes.data,
+                       self.local_of.ctypes.data, C.cast(self._ptrs, C.c_void_p), *self.bounds)
+
+    def ptr(self):
+        return C.byref(self.c)
+
+
+def grid_csr(frame):
+    cs = np.zeros(frame.n_cams * 64 * 48 + 1, np.int32); items = np.zeros(max(frame.n_total, 1), np.int32)
+    lib().orc_grid_csr(frame.ptr(), _p(cs), _p(items))
+    return cs, items[:cs[-1]]
+
+
+def features_in_area(frame, cam, x, y, r, min_level=-1, max_level=-1):
+    out = np.zeros(max(frame.n_total, 1), np.int32)
+    n = lib().orc_features_in_area(frame.ptr(), cam, x, y, r, min_level, max_level, _p(out), len(out))
+    return out[:n].copy()
+
+
+def search_by_projection_frames(frame, queries, th_high=100, check_ori=True):
+    queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+    m = np.zeros(max(frame.n_total, 1), np.int32)
+    n = lib().orc_search_by_projection_frames(frame.ptr(), _p(queries), len(queries), th_high, int(check_ori), _p(m))
+    return n, m[:frame.n_total]
+
+
+def search_by_projection_points(frame, queries, occupied=None, nnratio=0.8, th_high=100):
+    queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+    m = np.zeros(max(frame.n_total, 1), np.int32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    n = lib().orc_search_by_projection_points(frame.ptr(), _p(queries), len(queries),
+                                              None if occ is None else _p(occ), nnratio, th_high, _p(m))
+    return n, m[:frame.n_total]

@@ -1,0 +1,122 @@
+"""GPU parity: HIP extractor (through the C ABI) vs the CPU oracle, stage by stage and end to end.  Bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from multi_orb_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(params, w, h):
+    import multi_orb_slam_amd as m
+    return m.Extractor(params, w, h)
+
+
+def _assert_same(kps, desc, okps, odesc):
+    assert len(kps) == len(okps), (len(kps), len(okps))
+    for f in kps.dtype.names:
+        a, b = kps[f], okps[f]
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                              b.view(np.uint32) if b.dtype == np.float32 else b), f
+    assert np.array_equal(desc, odesc)
+
+
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (320, 240, 300), (752, 480, 1200), (641, 479, 500)])
+def test_stages_and_end_to_end(w, h, nf):
+    import multi_orb_slam_amd as m
+    p = m.ExtractorParams(nfeatures=nf)
+    ex = _mk([p], w, h)
+    img = synth.image(0, 0, w, h)
+    kps, desc = ex(img)
+    # K1: every pyramid level
+    for l, ref in enumerate(oracle.pyramid(img)):
+        got = ex.debug_level(0, l)
+        assert got.shape == ref.shape and np.array_equal(got, ref), "level %d" % l
+        # K2/K3: candidates handed to the quadtree, cell-major order
+        cand = ex.debug_candidates(0, l)
+        ocand = oracle.cell_candidates(ref)
+        assert len(cand) == len(ocand), "level %d" % l
+        for f in ("x", "y", "response"):
+            assert np.array_equal(cand[f], ocand[f]), (l, f)
+    okps, odesc = oracle.extract(img, nfeatures=nf)
+    _assert_same(kps, desc, okps, odesc)
+    assert len(kps) > nf // 2
+    ex.close()
+
+
+def test_two_cameras_reference_config():
+    """configs[0]/[1]: 2 x 640x480, cam 1 with nFeatures, cam 2 with nFeatures/2 (reference src/Tracking.cc:144-145)."""
+    import multi_orb_slam_amd as m
+    ps = [m.ExtractorParams(nfeatures=1000), m.ExtractorParams(nfeatures=500)]
+    ex = _mk(ps, 640, 480)
+    for t in range(3):
+        imgs = [synth.image(c, t, 640, 480) for c in range(2)]
+        out = ex.extract(imgs)
+        for c in range(2):
+            okps, odesc = oracle.extract(imgs[c], nfeatures=ps[c].nfeatures)
+            _assert_same(out[c][0], out[c][1], okps, odesc)
+    ex.close()
+
+
+def test_mixed_sizes_empty_and_flat_images():
+    import multi_orb_slam_amd as m
+    ps = [m.ExtractorParams(nfeatures=400), m.ExtractorParams(nfeatures=400), m.ExtractorParams(nfeatures=200)]
+    ex = _mk(ps, 640, 480)
+    flat = np.full((300, 400), 77, np.uint8)           # no corners at all -> zero keypoints
+    imgs = [synth.image(3, 1, 640, 480), flat, None]   # None = empty image: untouched outputs, n = 0
+    out = ex.extract(imgs)
+    okps, odesc = oracle.extract(imgs[0], nfeatures=400)
+    _assert_same(out[0][0], out[0][1], okps, odesc)
+    assert len(out[1][0]) == 0 and len(out[2][0]) == 0
+    assert len(oracle.extract(flat, nfeatures=400)[0]) == 0
+    # a different size on the same handle re-derives the geometry
+    imgs = [synth.image(4, 0, 512, 384), synth.image(5, 0, 640, 480), synth.image(6, 0, 320, 240)]
+    out = ex.extract(imgs)
+    for c in range(3):
+        okps, odesc = oracle.extract(imgs[c], nfeatures=ps[c].nfeatures)
+        _assert_same(out[c][0], out[c][1], okps, odesc)
+    ex.close()
+
+
+def test_noise_and_low_contrast_images():
+    """Noise-only image (dense weak corners -> minTh fallback cells, many candidates) and a low-contrast scene."""
+    import multi_orb_slam_amd as m
+    rng = synth.hash32(np.arange(640 * 480, dtype=np.uint64) + np.uint64(99))
+    noise = (rng % 256).astype(np.uint8).reshape(480, 640)
+    low = (128 + (synth.image(2, 0, 640, 480).astype(np.int32) - 128) // 6).astype(np.uint8)
+    ex = _mk([m.ExtractorParams(nfeatures=1000)], 640, 480)
+    for img in (noise, low):
+        kps, desc = ex(img)
+        okps, odesc = oracle.extract(img, nfeatures=1000)
+        _assert_same(kps, desc, okps, odesc)
+    ex.close()
+
+
+def test_larger_configs():
+    """configs[2] (1280x720 @2000) end to end; 1920x1080 @4000 on one camera."""
+    import multi_orb_slam_amd as m
+    for (w, h, nf) in [(1280, 720, 2000), (1920, 1080, 4000)]:
+        ex = _mk([m.ExtractorParams(nfeatures=nf)], w, h)
+        img = synth.image(1, 0, w, h)
+        kps, desc = ex(img)
+        okps, odesc = oracle.extract(img, nfeatures=nf)
+        _assert_same(kps, desc, okps, odesc)
+        ex.close()
+
+
+def test_resident_path_and_determinism():
+    import multi_orb_slam_amd as m
+    ex = _mk([m.ExtractorParams(nfeatures=1000)] * 2, 640, 480)
+    imgs = [synth.image(c, 5, 640, 480) for c in range(2)]
+    for c in range(2):
+        ex.upload(c, imgs[c])
+    ex.run()
+    first = [ex.download(c) for c in range(2)]
+    ex.run()  # same resident images again: identical output
+    second = [ex.download(c) for c in range(2)]
+    for c in range(2):
+        assert np.array_equal(first[c][0], second[c][0]) and np.array_equal(first[c][1], second[c][1])
+        okps, odesc = oracle.extract(imgs[c], nfeatures=1000)
+        _assert_same(first[c][0], first[c][1], okps, odesc)
+    ex.close()

@@ -1,0 +1,137 @@
+"""GPU parity: HIP matcher (through the C ABI) vs the CPU oracle.  Bit-exact for every output."""
+import numpy as np
+import pytest
+
+import oracle
+import helpers
+from multi_orb_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    import multi_orb_slam_amd as m
+    mt = m.Matcher(0.8, True)
+    yield mt
+    mt.close()
+
+
+@pytest.mark.parametrize("nq,nr", [(1, 1), (1, 17), (63, 15), (64, 64), (65, 1000), (1000, 1000), (257, 4097),
+                                   (1500, 500), (5, 0), (0, 5)])
+def test_top2_bit_exact(matcher, nq, nr):
+    r = synth.descriptors(max(nr, 1), 42)[:nr]
+    q = synth.perturbed_queries(synth.descriptors(max(nq, 1), 42), 7)[:nq] if nq else np.zeros((0, 32), np.uint8)
+    bi, bd, sd = matcher.hamming_top2(q, r)
+    obi, obd, osd = oracle.bf_top2(q, r)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
+
+
+def test_top2_ties_and_duplicates(matcher):
+    # exact duplicates: the first index wins, the duplicate becomes the second best (App. A-9)
+    r = synth.descriptors(300, 3)
+    r[200] = r[10]; r[299] = r[10]; r[150] = r[149]
+    q = np.concatenate([r[[10, 149, 200]], ~r[[5]], np.zeros((1, 32), np.uint8)])
+    bi, bd, sd = matcher.hamming_top2(q, r)
+    obi, obd, osd = oracle.bf_top2(q, r)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
+    assert bi[0] == 10 and bd[0] == 0 and sd[0] == 0 and bi[2] == 10
+    # all-ones vs all-zero: distance 256 never registers (initial value 256, strict '<')
+    z = np.zeros((4, 32), np.uint8); o = np.full((3, 32), 255, np.uint8)
+    bi, bd, sd = matcher.hamming_top2(o, z)
+    assert (bi == -1).all() and (bd == 256).all() and (sd == 256).all()
+
+
+@pytest.mark.parametrize("nq,nr", [(1, 1), (3, 8), (70, 513), (129, 1024), (200, 1000), (64, 4099)])
+def test_matrix_bit_exact(matcher, nq, nr):
+    r = synth.descriptors(nr, 9); q = synth.descriptors(nq, 10)
+    q[0] = r[0]
+    out = matcher.hamming_matrix(q, r)
+    assert np.array_equal(out, oracle.hamming_matrix(q, r))
+
+
+def test_matrix_properties_full_size(matcher):
+    # size-independent properties at an all-pairs size: symmetry, zero diagonal, row checksum vs popcount identity
+    n = 4000
+    d = synth.descriptors(n, 123)
+    m = matcher.hamming_matrix(d, d)
+    assert (np.diag(m) == 0).all() and np.array_equal(m, m.T)
+    rows = np.array([0, 1, 1999, 3999])
+    assert np.array_equal(m[rows], oracle.hamming_matrix(d[rows], d))
+    bi, bd, sd = matcher.hamming_top2(d, d)
+    assert np.array_equal(bi, np.arange(n)) and (bd == 0).all()
+    mm = m.astype(np.int32); np.fill_diagonal(mm, 1000)
+    assert np.array_equal(sd, np.minimum(mm.min(1), 256))
+
+
+@pytest.mark.parametrize("n_per_cam,seed", [([400, 300], 1), ([1500, 700], 2), ([50], 3), ([0, 20], 4)])
+def test_grid_and_area_queries(matcher, n_per_cam, seed):
+    fr = helpers.make_frame_arrays(n_per_cam, 640, 480, seed)
+    import multi_orb_slam_amd as m
+    F = matcher.frame(m.FrameData(**fr)); OF = oracle.FrameData(**fr)
+    cs, items = F.grid(); ocs, oitems = oracle.grid_csr(OF)
+    assert np.array_equal(cs, ocs) and np.array_equal(items, oitems)
+    pts = [(320.0, 240.0, 40.0, -1, -1), (0.5, 0.5, 25.0, 0, 3), (639.0, 479.0, 60.0, 2, -1), (-30.0, 100.0, 20.0, -1, -1),
+           (700.0, 100.0, 70.0, 1, 2), (100.3, 200.7, 10.0, 0, 0), (333.0, 111.0, 300.0, -1, -1)]
+    for cam in range(len(n_per_cam)):
+        for (x, y, r, lo, hi) in pts:
+            got = matcher.features_in_area(F, cam, x, y, r, lo, hi)
+            exp = oracle.features_in_area(OF, cam, x, y, r, lo, hi)
+            assert np.array_equal(got, exp), (cam, x, y, r, lo, hi)
+    F.close()
+
+
+@pytest.mark.parametrize("n_per_cam,nq,th,blocks,seed", [([1000, 500], 1200, 15.0, 1, 1), ([1000, 1000], 2500, 30.0, 1, 2),
+                                                        ([300, 200], 900, 15.0, 2, 3), ([2000, 2000], 3000, 15.0, 0, 4),
+                                                        ([64], 10, 7.0, 1, 5)])
+def test_search_by_projection_frames(matcher, n_per_cam, nq, th, blocks, seed):
+    import multi_orb_slam_amd as m
+    fr = helpers.make_frame_arrays(n_per_cam, 640, 480, seed)
+    q = helpers.make_queries(fr, nq, seed + 40, th=th, blocks=blocks)
+    F = matcher.frame(m.FrameData(**fr)); OF = oracle.FrameData(**fr)
+    for check_ori in (True, False):
+        matcher.check_orientation = check_ori
+        n, mo = matcher.SearchByProjection(F, q)
+        on, omo = oracle.search_by_projection_frames(OF, q, 100, check_ori)
+        assert n == on and np.array_equal(mo, omo)
+        assert n > 0
+    matcher.check_orientation = True
+    # ordered candidate lists themselves
+    idx, dist, cnt = matcher.project_candidates(F, q[:200], 512)
+    for i in range(0, 200, 7):
+        # oracle candidate order + the right-coordinate gate
+        cand = oracle.features_in_area(OF, int(q["cam"][i]), float(q["u"][i]), float(q["v"][i]), float(q["radius"][i]),
+                                       int(q["min_level"][i]), int(q["max_level"][i]))
+        ur = fr["uright"][cand]
+        keep = ~((ur > 0) & (np.abs(np.float32(q["ur"][i]) - ur) > q["radius"][i]))
+        cand = cand[keep]
+        assert cnt[i] == len(cand) and np.array_equal(idx[i, :cnt[i]], cand)
+        alld = np.concatenate(fr["descs"])
+        exp = [oracle.descriptor_distance(q["desc"][i], alld[g]) for g in cand]
+        assert np.array_equal(dist[i, :cnt[i]], np.array(exp, np.uint16))
+    F.close()
+
+
+@pytest.mark.parametrize("n,nq,seed", [(1000, 800, 1), (1500, 2000, 2)])
+def test_search_by_projection_points(matcher, n, nq, seed):
+    import multi_orb_slam_amd as m
+    fr = helpers.make_frame_arrays([n, n // 2], 640, 480, seed)
+    q = helpers.make_queries(fr, nq, seed + 9, th=3 * 4.0)
+    q["cam"] = 0
+    q["max_level"] = np.maximum(q["max_level"], 0); q["min_level"] = q["max_level"] - 1
+    occ = (helpers.rand_unit(n + n // 2, seed + 77) < 0.2).astype(np.uint8)
+    F = matcher.frame(m.FrameData(**fr)); OF = oracle.FrameData(**fr)
+    for ratio in (0.8, 0.6):
+        matcher.nnratio = ratio
+        for o in (None, occ):
+            cnt, mo = matcher.SearchByProjectionPoints(F, q, o)
+            ocnt, omo = oracle.search_by_projection_points(OF, q, o, ratio, 100)
+            assert cnt == ocnt and np.array_equal(mo, omo)
+            assert cnt > 0
+    F.close()
+
+
+def test_no_device_fallback_is_an_error():
+    import multi_orb_slam_amd as m
+    with pytest.raises(m.OrbError):
+        m.Matcher(device=99)
