@@ -77,6 +77,10 @@ int orbx_debug_level(orbx_extractor* ex, int cam, int level, uint8_t* out, int c
 int orbx_debug_candidates(orbx_extractor* ex, int cam, int level, orb_keypoint* out, int cap, int* n);
 /* per-stage GPU time of the last run in microseconds: {pyramid, fast_cells, compact, d2h+octree(host wall),
  * describe, total wall}; requires orbx_set_profiling(ex, 1) */
+/* host-only: the library's quadtree (DistributeOctTree, reference src/ORBextractor.cc:540-764) on caller-supplied
+ * candidates (x, y relative to (16,16), integral; response); runs without a GPU.  *n_out may exceed cap. */
+int orbx_debug_distribute_octree(const orb_keypoint* in, int n, int min_x, int max_x, int min_y, int max_y,
+                                 int n_features, orb_keypoint* out, int cap, int* n_out);
 int orbx_set_profiling(orbx_extractor* ex, int on);
 int orbx_stage_times_us(const orbx_extractor* ex, float* out6);
 

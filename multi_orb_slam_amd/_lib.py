@@ -71,6 +71,7 @@ def lib():
     L.orbx_bind_output.argtypes = [vp, i32, vp, vp, i32]
     L.orbx_debug_level.argtypes = [vp, i32, i32, vp, i32, vp, vp]
     L.orbx_debug_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.orbx_debug_distribute_octree.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]
     L.orbx_set_profiling.argtypes = [vp, i32]
     L.orbx_stage_times_us.argtypes = [vp, vp]
     L.orbm_create.argtypes = [i32, vp]

@@ -953,4 +953,15 @@ int orbx_debug_candidates(orbx_extractor* ex, int cam, int level, orb_keypoint* 
     return ORB_OK;
 }
 
+int orbx_debug_distribute_octree(const orb_keypoint* in, int n, int min_x, int max_x, int min_y, int max_y,
+                                 int n_features, orb_keypoint* out, int cap, int* n_out) {
+    MORB_ARG(n >= 0 && n_out && (n == 0 || in) && (cap == 0 || out) && max_x > min_x && max_y > min_y);
+    std::vector<int> x(n), y(n), r(n), sel;
+    for (int i = 0; i < n; ++i) { x[i] = (int)in[i].x; y[i] = (int)in[i].y; r[i] = (int)in[i].response; }
+    morb::distribute_octree(x.data(), y.data(), r.data(), n, max_x - min_x, max_y - min_y, n_features, sel);
+    *n_out = (int)sel.size();
+    for (int i = 0; i < (int)sel.size() && i < cap; ++i) out[i] = in[sel[i]];
+    return ORB_OK;
+}
+
 }  // extern "C"

@@ -33,6 +33,15 @@ def tables(p: ExtractorParams):
     return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, quota=quota, umax=umax)
 
 
+def distribute_octree(kps, min_x, max_x, min_y, max_y, n_features):
+    """The library's host quadtree on caller-supplied candidates (no GPU needed)."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    out = np.zeros(max(len(kps), 1), KP_DTYPE); n = C.c_int()
+    check(_lib.lib().orbx_debug_distribute_octree(ptr(kps), len(kps), min_x, max_x, min_y, max_y, n_features, ptr(out),
+                                                  len(out), C.byref(n)))
+    return out[:n.value]
+
+
 class Extractor:
     """N-camera ORB extractor handle (one `orbx_extractor`)."""
 

@@ -97,8 +97,9 @@ def test_search_by_projection_frames(matcher, n_per_cam, nq, th, blocks, seed):
         assert n > 0
     matcher.check_orientation = True
     # ordered candidate lists themselves
-    idx, dist, cnt = matcher.project_candidates(F, q[:200], 512)
-    for i in range(0, 200, 7):
+    nchk = min(200, nq)
+    idx, dist, cnt = matcher.project_candidates(F, q[:nchk], 512)
+    for i in range(0, nchk, 7):
         # oracle candidate order + the right-coordinate gate
         cand = oracle.features_in_area(OF, int(q["cam"][i]), float(q["u"][i]), float(q["v"][i]), float(q["radius"][i]),
                                        int(q["min_level"][i]), int(q["max_level"][i]))

@@ -1,0 +1,139 @@
+"""Known-answer tests for the matcher half of the oracle and the host-only matcher code in libmorb.so.  CPU only."""
+import numpy as np
+import pytest
+import oracle
+import helpers
+import multi_orb_slam_amd as m
+from multi_orb_slam_amd import synth
+from multi_orb_slam_amd._lib import QUERY_DTYPE
+
+
+def test_descriptor_distance_kats():
+    a = synth.descriptors(50, 1)
+    for f in (oracle.descriptor_distance, m.descriptor_distance):
+        assert f(a[0], a[0]) == 0
+        assert f(a[0], ~a[0]) == 256
+        for bit in (0, 7, 8, 100, 255):
+            b = a[3].copy(); b[bit // 8] ^= 1 << (bit % 8)
+            assert f(a[3], b) == 1
+        for i in range(0, 48, 3):
+            assert f(a[i], a[i + 1]) == int(np.unpackbits(a[i] ^ a[i + 1]).sum())
+        # rows only need byte alignment
+        buf = np.zeros(70, np.uint8); buf[1:33] = a[5]; buf[34:66] = a[6]
+        assert f(buf[1:33], buf[34:66]) == int(np.unpackbits(a[5] ^ a[6]).sum())
+
+
+def test_bf_top2_semantics():
+    r = synth.descriptors(100, 2)
+    q = r[[7]].copy()
+    bi, bd, sd = oracle.bf_top2(q, r)
+    assert bi[0] == 7 and bd[0] == 0
+    r2 = r.copy(); r2[50] = r[7]                     # duplicate: first index wins, duplicate is the second best
+    bi, bd, sd = oracle.bf_top2(q, r2)
+    assert bi[0] == 7 and bd[0] == 0 and sd[0] == 0
+    bi, bd, sd = oracle.bf_top2(q, r[:0])            # empty reference set
+    assert bi[0] == -1 and bd[0] == 256 and sd[0] == 256
+    m_ = oracle.hamming_matrix(q, r)
+    srt = np.sort(m_[0])
+    bi, bd, sd = oracle.bf_top2(q, r)
+    assert bd[0] == srt[0] and sd[0] == srt[1]
+
+
+def test_three_maxima_edge_cases():
+    for f in (oracle.three_maxima, m.three_maxima):
+        h = [0] * 30
+        assert f(h) == (-1, -1, -1)
+        h[4] = 10
+        assert f(h) == (4, -1, -1)
+        h[9] = 10                                    # tie: the earlier bin stays first
+        assert f(h) == (4, 9, -1)
+        h[20] = 1                                    # exactly 0.1*max: NOT pruned (strict '<')
+        assert f(h) == (4, 9, 20)
+        h[4] = 11                                    # now 1 < 1.1 -> third pruned
+        assert f(h) == (4, 9, -1)
+        h = [0] * 30; h[2] = 100; h[3] = 9; h[5] = 50
+        assert f(h) == (2, 5, -1)
+        h[3] = 10
+        assert f(h) == (2, 5, 3)
+
+
+def test_grid_round_insertion_and_lookup_kats():
+    # Feature at x = 639.9 on a 640-wide image: round(639.9*0.1) = 64 -> outside the grid -> never found (App. A-8)
+    fr = dict(un_x=[5.0, 14.9, 15.0, 639.9, 320.0], un_y=[5.0, 5.0, 5.0, 5.0, 479.9], octave=[0, 1, 2, 0, 0],
+              angle=[0] * 5, uright=[-1] * 5, cam_of=[0] * 5, local_of=list(range(5)), descs=[synth.descriptors(5, 1)],
+              bounds=(0, 0, 640, 480))
+    F = oracle.FrameData(**fr)
+    cs, items = oracle.grid_csr(F)
+    assert len(items) == 3                           # 639.9 and y = 479.9 -> cell 64 / 48 -> dropped
+    assert oracle.features_in_area(F, 0, 320, 5, 1000).tolist() == [0, 1, 2]
+    # cell of x = 5 is round(0.5) = 1 (half away from zero), x = 14.9 -> 1, x = 15.0 -> round(1.5) = 2
+    assert cs[(0 * 64 + 1) * 48 + 1 + 1] - cs[(0 * 64 + 1) * 48 + 1] == 2
+    # strict window and level semantics
+    assert oracle.features_in_area(F, 0, 10.0, 5.0, 5.0).tolist() == [1]       # |dx| < r strict: 5.0 is excluded
+    assert oracle.features_in_area(F, 0, 10.0, 5.0, 5.01).tolist() == [0, 1, 2]
+    assert oracle.features_in_area(F, 0, 10.0, 5.0, 50, 1, -1).tolist() == [1, 2]   # ">= 1, no upper bound"
+    assert oracle.features_in_area(F, 0, 10.0, 5.0, 50, 0, 1).tolist() == [0, 1]    # "<= 1"
+    assert oracle.features_in_area(F, 0, 10.0, 5.0, 50, -1, -1).tolist() == [0, 1, 2]
+    assert oracle.features_in_area(F, 0, -500.0, 5.0, 10).tolist() == []
+
+
+def test_candidate_order_is_column_major_over_cells():
+    xs = [25.0, 25.0, 15.0, 15.0]; ys = [25.0, 15.0, 25.0, 15.0]
+    fr = dict(un_x=xs, un_y=ys, octave=[0] * 4, angle=[0] * 4, uright=[-1] * 4, cam_of=[0] * 4, local_of=list(range(4)),
+              descs=[synth.descriptors(4, 1)], bounds=(0, 0, 640, 480))
+    F = oracle.FrameData(**fr)
+    # ix outer, iy inner: (15,15)=3, (15,25)=2, (25,15)=1, (25,25)=0
+    assert oracle.features_in_area(F, 0, 20, 20, 12).tolist() == [3, 2, 1, 0]
+
+
+def _tiny_frame():
+    d = synth.descriptors(6, 9)
+    fr = dict(un_x=[100, 103, 106, 300, 303, 100], un_y=[100, 100, 100, 200, 200, 100], octave=[0, 0, 0, 1, 1, 0],
+              angle=[10, 10, 10, 10, 200, 10], uright=[-1, -1, -1, -1, -1, -1], cam_of=[0, 0, 0, 0, 0, 1],
+              local_of=[0, 1, 2, 3, 4, 0], descs=[d[:5], d[5:]], bounds=(0, 0, 640, 480))
+    return fr, d
+
+
+def test_search_by_projection_first_come_first_served():
+    fr, d = _tiny_frame()
+    F = oracle.FrameData(**fr)
+    q = np.zeros(3, QUERY_DTYPE)
+    q["u"] = 103; q["v"] = 100; q["radius"] = 15; q["ur"] = -1; q["min_level"] = -1; q["max_level"] = 1; q["cam"] = 0
+    q["blocks"] = 1; q["angle"] = 10
+    q["desc"][0] = d[1]; q["desc"][1] = d[1]; q["desc"][2] = d[1]
+    n, mo = oracle.search_by_projection_frames(F, q, 100, False)
+    # query 0 claims feature 1 (distance 0); queries 1 and 2 cannot see it any more and fall to their next best
+    assert mo[1] == 0 and n >= 1
+    dist = [oracle.descriptor_distance(d[1], d[k]) for k in (0, 2)]
+    if min(dist) <= 100:
+        nxt = (0, 2)[int(np.argmin(dist))] if dist[0] != dist[1] else 0
+        assert mo[nxt] == 1
+    # non-blocking claims can be overwritten by later queries (Observations() == 0 case, :3566-3568)
+    q["blocks"] = 0
+    n2, mo2 = oracle.search_by_projection_frames(F, q, 100, False)
+    assert mo2[1] == 2 and n2 == 3                    # three accepted matches counted, last writer wins
+    # camera gating: cam-1 query only sees feature 5
+    q["cam"] = 1
+    n3, mo3 = oracle.search_by_projection_frames(F, q[:1], 256, False)
+    assert (mo3[:5] == -1).all()
+
+
+def test_search_by_projection_rotation_histogram_rejects_outlier_bin():
+    fr = helpers.make_frame_arrays([400], 640, 480, 3)
+    q = helpers.make_queries(fr, 300, 11, dup_prob=1.0)
+    n_no, m_no = oracle.search_by_projection_frames(oracle.FrameData(**fr), q, 100, False)
+    n_yes, m_yes = oracle.search_by_projection_frames(oracle.FrameData(**fr), q, 100, True)
+    assert n_yes <= n_no and (m_yes >= 0).sum() == n_yes
+    # whatever survives the filter was also a match before it
+    keep = m_yes >= 0
+    assert np.array_equal(m_yes[keep], m_no[keep])
+
+
+def test_product_grid_host_code_matches_oracle_without_gpu():
+    """orbm_frame_* need a device; the pure-host pieces (distance, three maxima) are covered above.  Here: the
+    FrameData merge helper reproduces the reference's cam-major global indexing (src/Frame.cc:221-239)."""
+    k0 = np.zeros(3, m.KP_DTYPE); k1 = np.zeros(2, m.KP_DTYPE)
+    k0["x"] = [1, 2, 3]; k1["x"] = [7, 8]
+    fd = m.FrameData.from_cameras([(k0, synth.descriptors(3, 1)), (k1, synth.descriptors(2, 2))], 640, 480)
+    assert fd.n_total == 5 and fd.cam_of.tolist() == [0, 0, 0, 1, 1] and fd.local_of.tolist() == [0, 1, 2, 0, 1]
+    assert fd.un_x.tolist() == [1, 2, 3, 7, 8]
