@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/orbm.h"
@@ -60,6 +61,20 @@ using morb::PinnedBuf;
 // ------------------------------------------------------------------------------------------------ kernels
 constexpr int TOP2_WAVES = 16;
 
+// popcount(x) + acc in ONE instruction (v_bcnt_u32_b32's accumulate operand; hipcc otherwise emits bcnt + add3 trees)
+__device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc) {
+    unsigned r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+__device__ __forceinline__ unsigned ham256_chain(const uint4& q0, const uint4& q1, const uint4& a, const uint4& b) {
+    unsigned d = __popc(q0.x ^ a.x);
+    d = bcnt_acc(q0.y ^ a.y, d); d = bcnt_acc(q0.z ^ a.z, d); d = bcnt_acc(q0.w ^ a.w, d);
+    d = bcnt_acc(q1.x ^ b.x, d); d = bcnt_acc(q1.y ^ b.y, d); d = bcnt_acc(q1.z ^ b.z, d); d = bcnt_acc(q1.w ^ b.w, d);
+    return d;
+}
+
 __device__ __forceinline__ int ham256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
     return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
@@ -85,14 +100,22 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_hamming_top2(const uint4* _
     const int j0 = s0 + wave * chunk, j1 = min(s1, j0 + chunk);
 
     int b = 256, s = 256, bi = -1;
-#pragma unroll 4
-    for (int j = j0; j < j1; ++j) {
-        const uint4 r0 = r[2 * j], r1 = r[2 * j + 1];  // wave-uniform address -> scalar loads
-        const int d = ham256(q0, q1, r0, r1);
-        s = min(s, max(b, d));  // second = 2nd smallest with multiplicity (strict '<' chain, ORBmatcher.cc:311-320)
-        bi = d < b ? j : bi;
-        b = min(b, d);
+    // second = 2nd smallest with multiplicity, best index = first minimum (strict '<' chain, ORBmatcher.cc:311-320)
+#define TOP2_UPDATE(d, j) do { s = min(s, max(b, (d))); bi = (d) < b ? (j) : bi; b = min(b, (d)); } while (0)
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {  // 4 references (128 B through the scalar cache) per trip
+        const uint4 a0 = r[2 * j], a1 = r[2 * j + 1], b0 = r[2 * j + 2], b1 = r[2 * j + 3];
+        const uint4 c0 = r[2 * j + 4], c1 = r[2 * j + 5], e0 = r[2 * j + 6], e1 = r[2 * j + 7];
+        const int d0 = (int)ham256_chain(a0, a1, q0, q1), d1 = (int)ham256_chain(b0, b1, q0, q1);
+        const int d2 = (int)ham256_chain(c0, c1, q0, q1), d3 = (int)ham256_chain(e0, e1, q0, q1);
+        TOP2_UPDATE(d0, j); TOP2_UPDATE(d1, j + 1); TOP2_UPDATE(d2, j + 2); TOP2_UPDATE(d3, j + 3);
     }
+    for (; j < j1; ++j) {
+        const uint4 a0 = r[2 * j], a1 = r[2 * j + 1];  // wave-uniform address -> scalar loads
+        const int d = (int)ham256_chain(a0, a1, q0, q1);
+        TOP2_UPDATE(d, j);
+    }
+#undef TOP2_UPDATE
     sb[wave][lane] = b; ss[wave][lane] = s; si[wave][lane] = bi;
     __syncthreads();
     if (wave == 0 && qi < nq) {
@@ -124,19 +147,90 @@ __global__ void k_top2_merge(const int* __restrict__ p_idx, const int* __restric
     best_idx[qi] = I; best_dist[qi] = B; second_dist[qi] = Sd;
 }
 
-// One wave = 512 consecutive references (8 per lane), one block = 4 such tiles; grid.y walks the queries in chunks.
+// One wave = 512 consecutive references (8 per lane, 64 VGPRs), one block = 4 such tiles; grid.y walks the queries in
+// chunks.  Queries arrive through the scalar cache (wave-uniform address), two per iteration with the next pair
+// prefetched into SGPRs while the current pair is being processed, so the loop body is pure VALU + one 16-byte store
+// per lane per query row: 8 v_xor + 8 v_bcnt (accumulating form) per pair.
 constexpr int MAT_REFS_PER_LANE = 8;
 constexpr int MAT_REFS_PER_WAVE = 64 * MAT_REFS_PER_LANE;
 
-template <bool ALIGNED>
-__global__ __launch_bounds__(256) void k_hamming_matrix(const uint4* __restrict__ q, int nq,
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// Makes hipcc treat the eight dwords as used here (it inserts the s_waitcnt for their scalar loads at this point).
+__device__ __forceinline__ void touch_sgpr(const uint4& a, const uint4& b) {
+    asm volatile("" ::"s"(a.x), "s"(a.y), "s"(a.z), "s"(a.w), "s"(b.x), "s"(b.y), "s"(b.z), "s"(b.w));
+}
+
+// FULL: the wave's 512-reference tile lies completely inside [0, nr) and rows are 16-byte aligned: one unconditional
+// non-temporal dwordx4 store per lane (no exec-mask branch, so the loop stays one basic block and the scalar prefetch
+// below cannot be sunk past it).  Otherwise: guarded 2-byte stores (only the last partial tile / odd nr).
+template <bool FULL>
+__device__ __forceinline__ void mat_store_row(uint16_t* __restrict__ row, const unsigned (&d)[MAT_REFS_PER_LANE], int r0, int nr) {
+    if (FULL) {
+        v4u o;
+        o.x = d[0] | (d[1] << 16); o.y = d[2] | (d[3] << 16);
+        o.z = d[4] | (d[5] << 16); o.w = d[6] | (d[7] << 16);
+        *reinterpret_cast<v4u*>(row) = o;  // plain store: measured 3-8 % faster than `nt` for this pattern
+    } else {
+#pragma unroll
+        for (int k = 0; k < MAT_REFS_PER_LANE; ++k)
+            if (r0 + k < nr) row[k] = (uint16_t)d[k];
+    }
+}
+
+// Software pipeline over queries with two SGPR sets (x*, y*): while one query is processed the next one's 32 bytes are
+// in flight through the scalar cache.  SMEM returns out of order, so the only wait is lgkmcnt(0): `touch_sgpr` forces
+// that wait for the CURRENT set BEFORE the next load is issued; the sched_barriers keep hipcc from moving the load.
+template <bool FULL>
+__device__ __forceinline__ void mat_rows(const uint4* __restrict__ q, int qa, int qb, const uint4 (&ra)[MAT_REFS_PER_LANE],
+                                         const uint4 (&rb)[MAT_REFS_PER_LANE], uint16_t* __restrict__ out, int nr, int r0) {
+    uint4 x0 = q[2 * qa], x1 = q[2 * qa + 1], y0, y1;
+    unsigned d[MAT_REFS_PER_LANE];
+    const int npairs = (qb - qa) >> 1;
+    int qi = qa;
+    for (int p = 0; p < npairs; ++p, qi += 2) {
+        touch_sgpr(x0, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        y0 = q[2 * (qi + 1)]; y1 = q[2 * (qi + 1) + 1];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < MAT_REFS_PER_LANE; ++k) d[k] = ham256_chain(x0, x1, ra[k], rb[k]);
+        mat_store_row<FULL>(out + (size_t)qi * nr + r0, d, r0, nr);
+        touch_sgpr(y0, y1);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int qn = min(qi + 2, qb - 1);
+            x0 = q[2 * qn]; x1 = q[2 * qn + 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < MAT_REFS_PER_LANE; ++k) d[k] = ham256_chain(y0, y1, ra[k], rb[k]);
+        mat_store_row<FULL>(out + (size_t)(qi + 1) * nr + r0, d, r0, nr);
+    }
+    if ((qb - qa) & 1) {
+#pragma unroll
+        for (int k = 0; k < MAT_REFS_PER_LANE; ++k) d[k] = ham256_chain(x0, x1, ra[k], rb[k]);
+        mat_store_row<FULL>(out + (size_t)qi * nr + r0, d, r0, nr);
+    }
+}
+
+constexpr int MAT_WAVES = 8;  // 512 threads: a block writes 8 KB contiguous per query row
+
+// FULL (nr >= 512, nr % 8 == 0, 16-byte aligned rows) is decided on the host: two kernels, so the guarded path's
+// registers do not cost the streaming path its 6th wave per SIMD.
+template <bool FULL>
+__global__ __launch_bounds__(64 * MAT_WAVES, FULL ? 6 : 4) void k_hamming_matrix(const uint4* __restrict__ q, int nq,
                                                         const uint4* __restrict__ r, int nr,
                                                         uint16_t* __restrict__ out, int q_per_block) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x * MAT_WAVES + wave;
     if ((size_t)tile * MAT_REFS_PER_WAVE >= (size_t)nr) return;
-    const int r0 = tile * MAT_REFS_PER_WAVE + lane * MAT_REFS_PER_LANE;
+    // The last, partial tile is shifted back to end exactly at nr (it then recomputes a few columns of its neighbour
+    // and stores identical values): every wave keeps the branch-free full-tile path when nr >= 512 and nr % 8 == 0.
+    constexpr bool full = FULL;
+    const int tile_start = full ? min(tile * MAT_REFS_PER_WAVE, nr - MAT_REFS_PER_WAVE) : tile * MAT_REFS_PER_WAVE;
+    const int r0 = tile_start + lane * MAT_REFS_PER_LANE;
     uint4 ra[MAT_REFS_PER_LANE], rb[MAT_REFS_PER_LANE];
 #pragma unroll
     for (int k = 0; k < MAT_REFS_PER_LANE; ++k) {
@@ -144,26 +238,7 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint4* __restrict_
         ra[k] = r[2 * j]; rb[k] = r[2 * j + 1];
     }
     const int qa = blockIdx.y * q_per_block, qb = min(nq, qa + q_per_block);
-    for (int qi = qa; qi < qb; ++qi) {
-        const uint4 q0 = q[2 * qi], q1 = q[2 * qi + 1];  // wave-uniform -> scalar loads
-        unsigned d[MAT_REFS_PER_LANE];
-#pragma unroll
-        for (int k = 0; k < MAT_REFS_PER_LANE; ++k) d[k] = (unsigned)ham256(q0, q1, ra[k], rb[k]);
-        uint16_t* row = out + (size_t)qi * nr + r0;
-        if (ALIGNED) {
-            if (r0 + MAT_REFS_PER_LANE <= nr) {
-                typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                v4u o;
-                o.x = d[0] | (d[1] << 16); o.y = d[2] | (d[3] << 16);
-                o.z = d[4] | (d[5] << 16); o.w = d[6] | (d[7] << 16);
-                __builtin_nontemporal_store(o, reinterpret_cast<v4u*>(row));
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < MAT_REFS_PER_LANE; ++k)
-                if (r0 + k < nr) row[k] = (uint16_t)d[k];
-        }
-    }
+    mat_rows<FULL>(q, qa, qb, ra, rb, out, nr, r0);
 }
 
 struct FrameDev {
@@ -264,14 +339,19 @@ int top2_slices(int nq, int nr) {
 
 int launch_matrix(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16_t* d_out, hipStream_t st) {
     const int tiles = (nr + MAT_REFS_PER_WAVE - 1) / MAT_REFS_PER_WAVE;
-    const int q_per_block = 128;
-    dim3 grid((tiles + 3) / 4, (nq + q_per_block - 1) / q_per_block);
-    const bool aligned = (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0);
+    // queries per block: 256 at all-pairs sizes (long streaming rows); fewer when the grid would otherwise be too
+    // small to fill 256 CUs x 4 SIMDs (each wave walks its queries serially, ~0.35 us per query)
+    static const int q_per_block_env = [] { const char* e = getenv("MORB_MATRIX_QPB"); return e ? atoi(e) : 0; }();
+    int q_per_block = (int)std::min<long long>(256, std::max<long long>(8, ((long long)nq * tiles + 4095) / 4096));
+    q_per_block = (q_per_block + 1) & ~1;
+    if (q_per_block_env > 0) q_per_block = q_per_block_env;
+    dim3 grid((tiles + MAT_WAVES - 1) / MAT_WAVES, (nq + q_per_block - 1) / q_per_block);
+    const bool aligned = (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && nr >= MAT_REFS_PER_WAVE;
     if (aligned)
-        hipLaunchKernelGGL(k_hamming_matrix<true>, grid, dim3(256), 0, st, (const uint4*)d_q, nq, (const uint4*)d_r, nr,
+        hipLaunchKernelGGL(k_hamming_matrix<true>, grid, dim3(64 * MAT_WAVES), 0, st, (const uint4*)d_q, nq, (const uint4*)d_r, nr,
                            d_out, q_per_block);
     else
-        hipLaunchKernelGGL(k_hamming_matrix<false>, grid, dim3(256), 0, st, (const uint4*)d_q, nq, (const uint4*)d_r,
+        hipLaunchKernelGGL(k_hamming_matrix<false>, grid, dim3(64 * MAT_WAVES), 0, st, (const uint4*)d_q, nq, (const uint4*)d_r,
                            nr, d_out, q_per_block);
     MORB_HIP(hipGetLastError());
     return ORB_OK;

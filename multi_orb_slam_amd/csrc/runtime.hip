@@ -1,0 +1,54 @@
+// runtime.hip -- include/orb_rt.h: thin, checked wrappers over the HIP runtime for non-HIP hosts.
+#include "../../include/orb_rt.h"
+#include "orb_common.h"
+
+extern "C" {
+
+int orb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int orb_device_name(int device, char* out, int cap) {
+    MORB_ARG(out && cap > 0);
+    hipDeviceProp_t prop;
+    MORB_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(out, cap, "%s", prop.gcnArchName);
+    return ORB_OK;
+}
+
+int orb_set_device(int device) { MORB_HIP(hipSetDevice(device)); return ORB_OK; }
+int orb_malloc(void** d_ptr, size_t bytes) { MORB_ARG(d_ptr); MORB_HIP(hipMalloc(d_ptr, bytes)); return ORB_OK; }
+int orb_free(void* d_ptr) { MORB_HIP(hipFree(d_ptr)); return ORB_OK; }
+
+static int copy(void* dst, const void* src, size_t bytes, void* stream, hipMemcpyKind kind) {
+    if (bytes == 0) return ORB_OK;
+    MORB_ARG(dst && src);
+    if (stream) MORB_HIP(hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t)stream));
+    else MORB_HIP(hipMemcpy(dst, src, bytes, kind));
+    return ORB_OK;
+}
+int orb_memcpy_h2d(void* d, const void* h, size_t n, void* s) { return copy(d, h, n, s, hipMemcpyHostToDevice); }
+int orb_memcpy_d2h(void* h, const void* d, size_t n, void* s) { return copy(h, d, n, s, hipMemcpyDeviceToHost); }
+int orb_memcpy_d2d(void* d, const void* s_, size_t n, void* s) { return copy(d, s_, n, s, hipMemcpyDeviceToDevice); }
+int orb_memset(void* d, int v, size_t n, void* s) {
+    if (n == 0) return ORB_OK;
+    MORB_ARG(d != nullptr);
+    if (s) MORB_HIP(hipMemsetAsync(d, v, n, (hipStream_t)s));
+    else MORB_HIP(hipMemset(d, v, n));
+    return ORB_OK;
+}
+int orb_stream_sync(void* stream) { MORB_HIP(hipStreamSynchronize((hipStream_t)stream)); return ORB_OK; }
+int orb_device_sync(void) { MORB_HIP(hipDeviceSynchronize()); return ORB_OK; }
+int orb_event_create(void** ev) { MORB_ARG(ev); hipEvent_t e; MORB_HIP(hipEventCreate(&e)); *ev = (void*)e; return ORB_OK; }
+int orb_event_destroy(void* ev) { MORB_HIP(hipEventDestroy((hipEvent_t)ev)); return ORB_OK; }
+int orb_event_record(void* ev, void* stream) { MORB_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return ORB_OK; }
+int orb_event_elapsed_ms(void* a, void* b, float* ms) {
+    MORB_ARG(ms != nullptr);
+    MORB_HIP(hipEventSynchronize((hipEvent_t)b));
+    MORB_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return ORB_OK;
+}
+
+}  // extern "C"

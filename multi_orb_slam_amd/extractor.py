@@ -58,7 +58,10 @@ class Extractor:
 
     def close(self):
         if getattr(self, "_h", None):
-            _lib.lib().orbx_destroy(self._h)
+            try:
+                _lib.lib().orbx_destroy(self._h)
+            except Exception:
+                pass
             self._h = None
 
     __del__ = close

@@ -59,7 +59,10 @@ class Frame:
 
     def close(self):
         if getattr(self, "_h", None):
-            _lib.lib().orbm_frame_destroy(self._h)
+            try:
+                _lib.lib().orbm_frame_destroy(self._h)
+            except Exception:
+                pass
             self._h = None
 
     __del__ = close
@@ -80,7 +83,10 @@ class Matcher:
 
     def close(self):
         if getattr(self, "_h", None):
-            _lib.lib().orbm_destroy(self._h)
+            try:
+                _lib.lib().orbm_destroy(self._h)
+            except Exception:  # interpreter teardown
+                pass
             self._h = None
 
     __del__ = close
@@ -102,6 +108,22 @@ class Matcher:
         out = np.zeros((len(q), len(r)), np.uint16)
         check(_lib.lib().orbm_hamming_matrix(self._h, ptr(q), len(q), ptr(r), len(r), ptr(out)))
         return out
+
+    # -- device-pointer entry points (asynchronous on `stream`)
+    @staticmethod
+    def top2_scratch_bytes(nq, nr):
+        return int(_lib.lib().orbm_top2_scratch_bytes(nq, nr))
+
+    @staticmethod
+    def hamming_top2_device(d_q, nq, d_r, nr, d_best_idx, d_best_dist, d_second, d_scratch, stream):
+        check(_lib.lib().orbm_hamming_top2_device(C.c_void_p(d_q), nq, C.c_void_p(d_r), nr, C.c_void_p(d_best_idx),
+                                                  C.c_void_p(d_best_dist), C.c_void_p(d_second), C.c_void_p(d_scratch),
+                                                  C.c_void_p(stream)))
+
+    @staticmethod
+    def hamming_matrix_device(d_q, nq, d_r, nr, d_out, stream):
+        check(_lib.lib().orbm_hamming_matrix_device(C.c_void_p(d_q), nq, C.c_void_p(d_r), nr, C.c_void_p(d_out),
+                                                    C.c_void_p(stream)))
 
     def frame(self, data):
         return Frame(self, data)
