@@ -99,10 +99,14 @@ int orbm_project_candidates(orbm_matcher* m, const orbm_frame* f, const orbm_que
                             int32_t* cand_idx, uint16_t* cand_dist, int32_t* cand_count);
 
 /* SearchByProjection(CurrentFrame, LastFrame, th, bMono, Calib) from the projected queries on.
- * match_of_feature[g] = index of the query whose MapPoint ends in CurrentFrame.mvpMapPoints[g], else -1.
+ * occupied[g] != 0 where CurrentFrame.mvpMapPoints[g] already holds an observed point before the call (may be NULL:
+ * TrackWithMotionModel clears the vector first, reference src/Tracking.cc:1254).
+ * match_of_feature[g]: >= 0 = index of the query whose MapPoint ends in CurrentFrame.mvpMapPoints[g]; -1 = untouched;
+ * -2 = set to NULL by the rotation-histogram filter (reference src/ORBmatcher.cc:3631).
  * *nmatches = the reference's return value. */
-int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, int th_high,
-                              int check_orientation, int32_t* match_of_feature, int* nmatches);
+int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,
+                              const uint8_t* occupied, int th_high, int check_orientation,
+                              int32_t* match_of_feature, int* nmatches);
 
 /* SearchByProjection(F, vpMapPoints, th): camera-1 grid only, top-2 with level bookkeeping and nnratio.
  * occupied[g] != 0 where F.mvpMapPoints[g] already holds an observed point (may be NULL). */

@@ -89,7 +89,7 @@ def lib():
     L.orbm_frame_grid.argtypes = [vp, vp, vp]
     L.orbm_features_in_area.argtypes = [vp, vp, i32, f32, f32, f32, i32, i32, vp, i32, vp]
     L.orbm_project_candidates.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
-    L.orbm_search_by_projection.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    L.orbm_search_by_projection.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp]
     L.orbm_search_by_projection_points.argtypes = [vp, vp, vp, i32, vp, f32, i32, vp, vp]
     _lib = L
     return L

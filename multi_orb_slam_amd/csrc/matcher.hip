@@ -656,8 +656,9 @@ int orbm_project_candidates(orbm_matcher* m, const orbm_frame* f, const orbm_que
     return ORB_OK;
 }
 
-int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, int th_high,
-                              int check_orientation, int32_t* match_of_feature, int* nmatches) {
+int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,
+                              const uint8_t* occupied, int th_high, int check_orientation, int32_t* match_of_feature,
+                              int* nmatches) {
     MORB_ARG(m && cur && nq >= 0 && nmatches && (cur->n_total == 0 || match_of_feature));
     MORB_HIP(hipSetDevice(m->device));
     for (int g = 0; g < cur->n_total; g++) match_of_feature[g] = -1;
@@ -680,7 +681,7 @@ int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm
         for (int k = 0; k < cnt; k++) {
             const int g = ci[k];
             const int owner = match_of_feature[g];
-            if (owner >= 0 && q[owner].blocks) continue;
+            if (owner >= 0 ? q[owner].blocks != 0 : (occupied && occupied[g])) continue;
             if ((int)cd[k] < best) { best = cd[k]; bidx = g; }
         }
         if (best <= th_high && bidx >= 0) {
@@ -701,7 +702,7 @@ int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm
         orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, ind);
         for (int b = 0; b < ORBM_HISTO_LENGTH; b++)
             if (b != ind[0] && b != ind[1] && b != ind[2])
-                for (int g : rot[b]) { match_of_feature[g] = -1; nm--; }
+                for (int g : rot[b]) { match_of_feature[g] = -2; nm--; }
     }
     *nmatches = nm;
     return ORB_OK;

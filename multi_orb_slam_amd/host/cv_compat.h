@@ -1,0 +1,113 @@
+// cv_compat.h -- the handful of OpenCV types the ORB front end's public signatures mention, for builds without OpenCV
+// (this image has none).  Define HAVE_OPENCV to use the real headers instead; the wrappers only rely on members that
+// exist in both.  cv::KeyPoint is byte-compatible with orb_keypoint (28 bytes), which the wrappers static_assert.
+#pragma once
+#ifdef HAVE_OPENCV
+#include <opencv2/core/core.hpp>
+#else
+#include <cassert>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#define CV_8U 0
+#define CV_32F 5
+#define CV_8UC1 0
+#define CV_32FC1 5
+
+namespace cv {
+
+struct Point2f { float x = 0, y = 0; Point2f() {} Point2f(float x_, float y_) : x(x_), y(y_) {} };
+struct Point { int x = 0, y = 0; };
+
+struct KeyPoint {
+    Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1;
+};
+
+// Dense 2-D matrix of uchar or float with shared storage and row/column views (enough for descriptors, 3x3 / 4x4
+// pose algebra and 8-bit images).
+class Mat {
+public:
+    int rows = 0, cols = 0;
+    size_t step = 0;  // bytes per row
+    unsigned char* data = nullptr;
+
+    Mat() {}
+    Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(int r, int c, int type, void* ext, size_t step_ = 0) : rows(r), cols(c), type_(type) {
+        step = step_ ? step_ : (size_t)c * elemSize(); data = (unsigned char*)ext;
+    }
+    static Mat zeros(int r, int c, int type) { Mat m(r, c, type); std::memset(m.data, 0, m.step * r); return m; }
+    static Mat eye(int r, int c, int type) { Mat m = zeros(r, c, type); for (int i = 0; i < r && i < c; ++i) m.at<float>(i, i) = 1.f; return m; }
+    void create(int r, int c, int type) {
+        if (r == rows && c == cols && type == type_ && data && owner_) return;
+        rows = r; cols = c; type_ = type; step = (size_t)c * elemSize();
+        owner_.reset(new unsigned char[step * (size_t)(r > 0 ? r : 1)], std::default_delete<unsigned char[]>());
+        data = owner_.get();
+    }
+    void release() { owner_.reset(); data = nullptr; rows = cols = 0; step = 0; }
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    int type() const { return type_; }
+    size_t elemSize() const { return type_ == CV_32F ? 4 : 1; }
+    bool isContinuous() const { return step == (size_t)cols * elemSize(); }
+    template <typename T> T* ptr(int r = 0) { return reinterpret_cast<T*>(data + step * r); }
+    template <typename T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(data + step * r); }
+    unsigned char* ptr(int r = 0) { return data + step * r; }
+    const unsigned char* ptr(int r = 0) const { return data + step * r; }
+    template <typename T> T& at(int r, int c = 0) { return ptr<T>(r)[c]; }
+    template <typename T> const T& at(int r, int c = 0) const { return ptr<T>(r)[c]; }
+    // single-index access on column vectors, like cv::Mat::at<T>(i)
+    Mat row(int r) const { return view(r, r + 1, 0, cols); }
+    Mat col(int c) const { return view(0, rows, c, c + 1); }
+    Mat rowRange(int a, int b) const { return view(a, b, 0, cols); }
+    Mat colRange(int a, int b) const { return view(0, rows, a, b); }
+    Mat clone() const {
+        Mat m(rows, cols, type_);
+        for (int r = 0; r < rows; ++r) std::memcpy(m.ptr(r), ptr(r), (size_t)cols * elemSize());
+        return m;
+    }
+    Mat t() const {
+        assert(type_ == CV_32F);
+        Mat m(cols, rows, CV_32F);
+        for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) m.at<float>(c, r) = at<float>(r, c);
+        return m;
+    }
+private:
+    Mat view(int r0, int r1, int c0, int c1) const {
+        Mat m; m.rows = r1 - r0; m.cols = c1 - c0; m.type_ = type_; m.step = step; m.owner_ = owner_;
+        m.data = data + step * r0 + (size_t)c0 * elemSize();
+        return m;
+    }
+    int type_ = CV_8U;
+    std::shared_ptr<unsigned char> owner_;
+};
+
+// float matrix product / sum with double accumulation then rounding to float (what cv::gemm does for CV_32F)
+inline Mat operator*(const Mat& a, const Mat& b) {
+    assert(a.cols == b.rows);
+    Mat m(a.rows, b.cols, CV_32F);
+    for (int i = 0; i < a.rows; ++i)
+        for (int j = 0; j < b.cols; ++j) {
+            double s = 0;
+            for (int k = 0; k < a.cols; ++k) s += (double)a.at<float>(i, k) * (double)b.at<float>(k, j);
+            m.at<float>(i, j) = (float)s;
+        }
+    return m;
+}
+inline Mat operator+(const Mat& a, const Mat& b) {
+    Mat m(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) m.at<float>(i, j) = a.at<float>(i, j) + b.at<float>(i, j);
+    return m;
+}
+inline Mat operator-(const Mat& a) {
+    Mat m(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) m.at<float>(i, j) = -a.at<float>(i, j);
+    return m;
+}
+
+typedef const Mat& InputArray;
+typedef Mat& OutputArray;
+
+}  // namespace cv
+#endif

@@ -1,0 +1,56 @@
+// slam_types.h -- minimal stand-ins for the reference's Frame (include/Frame.h:155-261) and MapPoint
+// (include/MapPoint.h) carrying exactly the members ORBmatcher's two tracking searches read or write.  A real
+// integration compiles ORBmatcher.cc against the reference's own Frame.h / MapPoint.h instead: member names, types
+// and meanings are identical, so the wrapper source does not change (define MORB_USE_REFERENCE_TYPES and put the
+// reference's include/ on the include path).
+#pragma once
+#ifndef MORB_USE_REFERENCE_TYPES
+#include <map>
+#include <vector>
+#include "cv_compat.h"
+
+#define FRAME_GRID_ROWS 48
+#define FRAME_GRID_COLS 64
+
+namespace ORB_SLAM2 {
+
+class MapPoint {
+public:
+    cv::Mat GetWorldPos() { return mWorldPos; }
+    cv::Mat GetDescriptor() { return mDescriptor; }
+    int Observations() { return nObs; }
+    bool isBad() { return mbBad; }
+    // tracking scratch written by Frame::isInFrustum (src/Frame.cc:443-499)
+    float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
+    bool mbTrackInView = false;
+    int mnTrackScaleLevel = 0;
+    float mTrackViewCos = 1.f;
+
+    cv::Mat mWorldPos;    // 3x1 CV_32F
+    cv::Mat mDescriptor;  // 1x32 CV_8U
+    int nObs = 1;
+    bool mbBad = false;
+};
+
+class Frame {
+public:
+    // multi-camera "_total" view (src/Frame.cc:191-239): global index g, cam-major
+    int N = 0, N_cam2 = 0, N_total = 0;
+    std::vector<cv::KeyPoint> mvKeys_total, mvKeysUn_total, mvKeysUn;
+    std::vector<float> mvuRight_total, mvuRight, mvDepth_total;
+    std::vector<cv::Mat> mDescriptors_total;  // per camera, N_c x 32
+    cv::Mat mDescriptors;                     // camera 1
+    std::map<size_t, int> keypoint_to_cam, cont_idx_to_local_cam_idx;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    std::vector<float> mvScaleFactors;
+    cv::Mat mTcw;  // 4x4 CV_32F
+    float fx = 0, fy = 0, cx = 0, cy = 0, mb = 0, mbf = 0;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;  // static members in the reference
+};
+
+}  // namespace ORB_SLAM2
+#else
+#include "Frame.h"
+#include "MapPoint.h"
+#endif

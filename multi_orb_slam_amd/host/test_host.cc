@@ -1,0 +1,184 @@
+// test_host.cc -- C++ driver for the reference-signature host classes (ORB_SLAM2::ORBextractor / ORBmatcher).
+// tests/test_gpu_host_cpp.py writes the inputs, runs this program on the GPU box and compares its outputs with the
+// oracle.  Binary I/O only: little-endian int32 / float32 / uint8 arrays.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+
+using namespace ORB_SLAM2;
+
+static std::vector<unsigned char> slurp(const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { std::perror(path); std::exit(2); }
+    std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> b(n);
+    if (n && std::fread(b.data(), 1, n, f) != (size_t)n) { std::perror("read"); std::exit(2); }
+    std::fclose(f);
+    return b;
+}
+
+struct Reader {
+    const unsigned char* p;
+    template <typename T> T get() { T v; std::memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+    template <typename T> std::vector<T> arr(size_t n) { std::vector<T> v(n); std::memcpy(v.data(), p, n * sizeof(T)); p += n * sizeof(T); return v; }
+};
+
+static void put(FILE* f, const void* p, size_t n) { if (n && std::fwrite(p, 1, n, f) != n) { std::perror("write"); std::exit(2); } }
+
+// extract <image.bin> <w> <h> <nfeatures> <out.bin> [w2 h2 image2.bin nfeatures2]
+static int run_extract(int argc, char** argv) {
+    const int w = std::atoi(argv[3]), h = std::atoi(argv[4]), nf = std::atoi(argv[5]);
+    std::vector<unsigned char> img = slurp(argv[2]);
+    cv::Mat im(h, w, CV_8UC1, img.data());
+    ORBextractor ex(nf, 1.2f, 8, 20, 7);
+    std::vector<cv::KeyPoint> kps; cv::Mat desc;
+    ex(im, cv::Mat(), kps, desc);
+    // twice on the same object: the class is reusable and deterministic
+    std::vector<cv::KeyPoint> kps2; cv::Mat desc2;
+    ex(im, cv::Mat(), kps2, desc2);
+    if (kps.size() != kps2.size() || std::memcmp(kps.data(), kps2.data(), kps.size() * sizeof(cv::KeyPoint)) != 0) return 3;
+    // empty image: outputs untouched
+    std::vector<cv::KeyPoint> untouched(7); cv::Mat udesc(7, 32, CV_8U);
+    ex(cv::Mat(), cv::Mat(), untouched, udesc);
+    if (untouched.size() != 7 || udesc.rows != 7) return 4;
+    // getters (reference include/ORBextractor.h:64-84)
+    if (ex.GetLevels() != 8 || ex.GetScaleFactors().size() != 8 || ex.GetInverseScaleSigmaSquares().size() != 8) return 5;
+    FILE* f = std::fopen(argv[6], "wb");
+    int n = (int)kps.size();
+    put(f, &n, 4); put(f, kps.data(), (size_t)n * sizeof(cv::KeyPoint));
+    if (n) put(f, desc.ptr(0), (size_t)n * 32);
+    std::vector<float> sf = ex.GetScaleFactors();
+    put(f, sf.data(), 8 * 4);
+    std::fclose(f);
+    return 0;
+}
+
+// batch <out.bin> <w> <h> <image0.bin> <nf0> <image1.bin> <nf1>
+static int run_batch(int argc, char** argv) {
+    const int w = std::atoi(argv[3]), h = std::atoi(argv[4]);
+    std::vector<unsigned char> i0 = slurp(argv[5]), i1 = slurp(argv[7]);
+    ORBextractor e0(std::atoi(argv[6]), 1.2f, 8, 20, 7), e1(std::atoi(argv[8]), 1.2f, 8, 20, 7);
+    std::vector<cv::Mat> images = {cv::Mat(h, w, CV_8UC1, i0.data()), cv::Mat(h, w, CV_8UC1, i1.data())};
+    std::vector<std::vector<cv::KeyPoint> > kps; std::vector<cv::Mat> desc;
+    ORBextractor::ExtractBatch({&e0, &e1}, images, kps, desc);
+    FILE* f = std::fopen(argv[2], "wb");
+    for (int c = 0; c < 2; ++c) {
+        int n = (int)kps[c].size();
+        put(f, &n, 4); put(f, kps[c].data(), (size_t)n * sizeof(cv::KeyPoint));
+        if (n) put(f, desc[c].ptr(0), (size_t)n * 32);
+    }
+    std::fclose(f);
+    return 0;
+}
+
+static void read_frame(Reader& R, Frame& F) {
+    F.N = R.get<int>(); F.N_cam2 = R.get<int>(); F.N_total = F.N + F.N_cam2;
+    const int n = F.N_total;
+    std::vector<float> x = R.arr<float>(n), y = R.arr<float>(n), ang = R.arr<float>(n), ur = R.arr<float>(n);
+    std::vector<int> oct = R.arr<int>(n);
+    F.mvKeys_total.resize(n); F.mvKeysUn_total.resize(n); F.mvuRight_total = ur;
+    for (int g = 0; g < n; ++g) {
+        cv::KeyPoint k; k.pt.x = x[g]; k.pt.y = y[g]; k.angle = ang[g]; k.octave = oct[g];
+        F.mvKeys_total[g] = k; F.mvKeysUn_total[g] = k;
+        F.keypoint_to_cam[g] = g < F.N ? 0 : 1;
+        F.cont_idx_to_local_cam_idx[g] = g < F.N ? g : g - F.N;
+    }
+    F.mvKeysUn.assign(F.mvKeysUn_total.begin(), F.mvKeysUn_total.begin() + F.N);
+    F.mvuRight.assign(ur.begin(), ur.begin() + F.N);
+    F.mDescriptors_total.resize(2);
+    for (int c = 0; c < 2; ++c) {
+        const int nc = c == 0 ? F.N : F.N_cam2;
+        F.mDescriptors_total[c].create(nc > 0 ? nc : 1, 32, CV_8U);
+        std::vector<unsigned char> d = R.arr<unsigned char>((size_t)nc * 32);
+        if (nc) std::memcpy(F.mDescriptors_total[c].ptr(0), d.data(), d.size());
+    }
+    F.mDescriptors = F.mDescriptors_total[0];
+    F.mvpMapPoints.assign(n, nullptr);
+    F.mvbOutlier.assign(n, false);
+    F.mvScaleFactors = R.arr<float>(8);
+    F.mTcw = cv::Mat::eye(4, 4, CV_32F);
+    std::vector<float> T = R.arr<float>(16);
+    for (int i = 0; i < 16; ++i) F.mTcw.at<float>(i / 4, i % 4) = T[i];
+    F.fx = R.get<float>(); F.fy = R.get<float>(); F.cx = R.get<float>(); F.cy = R.get<float>();
+    F.mbf = R.get<float>(); F.mb = F.mbf / F.fx;
+    F.mnMinX = R.get<float>(); F.mnMinY = R.get<float>(); F.mnMaxX = R.get<float>(); F.mnMaxY = R.get<float>();
+}
+
+// match <case.bin> <out.bin>: [current frame][last frame][nmp x {world xyz, desc32, obs, has, outlier}][calib 4x3]
+//                             [local points: count x {projX, projY, projXR, level, viewCos, desc32, inview, bad}]
+static int run_match(int argc, char** argv) {
+    std::vector<unsigned char> buf = slurp(argv[2]);
+    Reader R{buf.data()};
+    Frame Cur, Last;
+    read_frame(R, Cur); read_frame(R, Last);
+    std::vector<MapPoint> pool(Last.N_total);
+    for (int i = 0; i < Last.N_total; ++i) {
+        MapPoint& mp = pool[i];
+        std::vector<float> xyz = R.arr<float>(3);
+        mp.mWorldPos = cv::Mat(3, 1, CV_32F);
+        for (int k = 0; k < 3; ++k) mp.mWorldPos.at<float>(k) = xyz[k];
+        mp.mDescriptor = cv::Mat(1, 32, CV_8U);
+        std::vector<unsigned char> d = R.arr<unsigned char>(32);
+        std::memcpy(mp.mDescriptor.ptr(0), d.data(), 32);
+        mp.nObs = R.get<int>();
+        const int has = R.get<int>(), outlier = R.get<int>();
+        Last.mvpMapPoints[i] = has ? &mp : nullptr;
+        Last.mvbOutlier[i] = outlier != 0;
+    }
+    cv::Mat calib(4, 3, CV_32F);
+    std::vector<float> cm = R.arr<float>(12);
+    for (int i = 0; i < 12; ++i) calib.at<float>(i / 3, i % 3) = cm[i];
+    const float th = R.get<float>();
+    const int check_ori = R.get<int>();
+
+    ORBmatcher matcher(0.9f, check_ori != 0);
+    const int n1 = matcher.SearchByProjection(Cur, Last, th, false, calib);
+    FILE* f = std::fopen(argv[3], "wb");
+    put(f, &n1, 4);
+    for (int g = 0; g < Cur.N_total; ++g) {
+        int idx = Cur.mvpMapPoints[g] ? (int)(Cur.mvpMapPoints[g] - pool.data()) : -1;
+        put(f, &idx, 4);
+    }
+    // second overload on a fresh current frame: SearchByProjection(F, vpMapPoints, th)
+    const int nlocal = R.get<int>();
+    std::vector<MapPoint> local(nlocal);
+    std::vector<MapPoint*> vp(nlocal);
+    for (int i = 0; i < nlocal; ++i) {
+        MapPoint& mp = local[i];
+        mp.mTrackProjX = R.get<float>(); mp.mTrackProjY = R.get<float>(); mp.mTrackProjXR = R.get<float>();
+        mp.mnTrackScaleLevel = R.get<int>(); mp.mTrackViewCos = R.get<float>();
+        mp.mDescriptor = cv::Mat(1, 32, CV_8U);
+        std::vector<unsigned char> d = R.arr<unsigned char>(32);
+        std::memcpy(mp.mDescriptor.ptr(0), d.data(), 32);
+        mp.mbTrackInView = R.get<int>() != 0; mp.mbBad = R.get<int>() != 0; mp.nObs = 2;
+        vp[i] = &mp;
+    }
+    const float th2 = R.get<float>();
+    Cur.mvpMapPoints.assign(Cur.N_total, nullptr);
+    ORBmatcher m2(0.8f);
+    const int n2 = m2.SearchByProjection(Cur, vp, th2);
+    put(f, &n2, 4);
+    for (int g = 0; g < Cur.N; ++g) {
+        int idx = Cur.mvpMapPoints[g] ? (int)(Cur.mvpMapPoints[g] - local.data()) : -1;
+        put(f, &idx, 4);
+    }
+    // static DescriptorDistance
+    const int dd = ORBmatcher::DescriptorDistance(Cur.mDescriptors.row(0), Cur.mDescriptors.row(1));
+    put(f, &dd, 4);
+    std::fclose(f);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: test_host extract|batch|match ...\n"); return 1; }
+    const std::string mode = argv[1];
+    if (mode == "extract" && argc >= 7) return run_extract(argc, argv);
+    if (mode == "batch" && argc >= 9) return run_batch(argc, argv);
+    if (mode == "match" && argc >= 4) return run_match(argc, argv);
+    std::fprintf(stderr, "bad arguments\n");
+    return 1;
+}

@@ -141,12 +141,15 @@ class Matcher:
         check(_lib.lib().orbm_project_candidates(self._h, frame._h, ptr(queries), nq, cap, ptr(idx), ptr(dist), ptr(cnt)))
         return idx[:nq], dist[:nq], cnt[:nq]
 
-    def SearchByProjection(self, frame, queries, th_high=TH_HIGH):
+    def SearchByProjection(self, frame, queries, th_high=TH_HIGH, occupied=None):
         """SearchByProjection(CurrentFrame, LastFrame, th, bMono, Calib) from the projected queries on
-        (reference src/ORBmatcher.cc:3448-3641).  Returns (nmatches, match_of_feature)."""
+        (reference src/ORBmatcher.cc:3448-3641).  Returns (nmatches, match_of_feature); match_of_feature[g] is the
+        query index, -1 (untouched) or -2 (cleared by the rotation-histogram filter)."""
         queries = np.ascontiguousarray(queries, QUERY_DTYPE)
         m = np.zeros(max(frame.data.n_total, 1), np.int32); n = C.c_int()
-        check(_lib.lib().orbm_search_by_projection(self._h, frame._h, ptr(queries), len(queries), th_high,
+        occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        check(_lib.lib().orbm_search_by_projection(self._h, frame._h, ptr(queries), len(queries),
+                                                   None if occ is None else ptr(occ), th_high,
                                                    int(self.check_orientation), ptr(m), C.byref(n)))
         return n.value, m[:frame.data.n_total]
 

@@ -883,8 +883,11 @@ int orc_features_in_area(const orc_frame* f, int cam, float x, float y, float r,
 // from the projected queries on (lines :3502-3552 happen on the host, App. A-10).
 //   match_of_feature[g]  : index of the query whose MapPoint ends up in CurrentFrame.mvpMapPoints[g], or -1
 //   returns nmatches exactly as the reference counts it (overwritten claims stay counted, :3597-3598).
-int orc_search_by_projection_frames(const orc_frame* cur, const orc_query* q, int nq, int th_high, int check_ori,
-                                    int* match_of_feature) {
+//   occupied[g] != 0 where CurrentFrame.mvpMapPoints[g] already holds an observed point before the call (may be NULL;
+//   TrackWithMotionModel clears the vector first, src/Tracking.cc:1254).
+//   match_of_feature[g]: >= 0 query index, -1 untouched, -2 set to NULL by the rotation-histogram filter (:3631).
+int orc_search_by_projection_frames(const orc_frame* cur, const orc_query* q, int nq, const uint8_t* occupied,
+                                    int th_high, int check_ori, int* match_of_feature) {
     FrameView F; make_view(cur, F);
     const int HISTO_LENGTH = 30;
     std::vector<int> rotHist[HISTO_LENGTH];
@@ -898,6 +901,7 @@ int orc_search_by_projection_frames(const orc_frame* cur, const orc_query* q, in
         if (cand.empty()) continue;
         int bestDist = 256, bestIdx2 = -1;
         for (int i2 : cand) {
+            if (occupied && occupied[i2] && match_of_feature[i2] < 0) continue;          // pre-existing observed point
             if (match_of_feature[i2] >= 0 && q[match_of_feature[i2]].blocks) continue;  // :3566-3568
             if (F.uright[i2] > 0) {                                                      // :3571-3577
                 const float er = std::fabs(Q.ur - F.uright[i2]);
@@ -925,7 +929,7 @@ int orc_search_by_projection_frames(const orc_frame* cur, const orc_query* q, in
         three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
         for (int i = 0; i < HISTO_LENGTH; i++)
             if (i != ind1 && i != ind2 && i != ind3)
-                for (int g : rotHist[i]) { match_of_feature[g] = -1; nmatches--; }
+                for (int g : rotHist[i]) { match_of_feature[g] = -2; nmatches--; }
     }
     return nmatches;
 }

@@ -60,6 +60,8 @@ def lib():
         _lib.orc_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         _lib.orc_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                               C.c_void_p, C.c_int]
+        _lib.orc_search_by_projection_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                         C.c_void_p]
         _lib.orc_search_by_projection_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
                                                          C.c_int, C.c_void_p]
     return _lib
@@ -256,10 +258,12 @@ def features_in_area(frame, cam, x, y, r, min_level=-1, max_level=-1):
     return out[:n].copy()
 
 
-def search_by_projection_frames(frame, queries, th_high=100, check_ori=True):
+def search_by_projection_frames(frame, queries, th_high=100, check_ori=True, occupied=None):
     queries = np.ascontiguousarray(queries, QUERY_DTYPE)
     m = np.zeros(max(frame.n_total, 1), np.int32)
-    n = lib().orc_search_by_projection_frames(frame.ptr(), _p(queries), len(queries), th_high, int(check_ori), _p(m))
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    n = lib().orc_search_by_projection_frames(frame.ptr(), _p(queries), len(queries), None if occ is None else _p(occ),
+                                              th_high, int(check_ori), _p(m))
     return n, m[:frame.n_total]
 
 
