@@ -82,11 +82,14 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MORB_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     import numpy as np
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import synth, pipeline, rt
@@ -94,16 +97,16 @@ def main():
 
     rt.set_device(local)
     params = [m.ExtractorParams(nfeatures=NFEAT)] * CAMS_PER_RANK
-    gather = None
-    fe = pipeline.FrontEnd(params, W, H, device=local, rank=rank, world_size=world)
-    if world > 1:
+    gcam = [rank * CAMS_PER_RANK + c for c in range(CAMS_PER_RANK)]
+    fe = pipeline.FrontEnd(params, W, H, device=local, rank=rank, world_size=world, global_cams=gcam)
+    if use_dist:
         import torch
         ex = DescriptorExchange(CAMS_PER_RANK, fe.cap, torch.device("cuda", local), dist)
         ex.bind(fe.ex)
         fe.gather = ex
+        fe.world = max(world, 2) if world == 1 else world   # world 1 + forced exchange still takes the block path
 
     # ---- synthetic stream of this rank's rig, resident in HBM before timing
-    gcam = [rank * CAMS_PER_RANK + c for c in range(CAMS_PER_RANK)]
     host_frames = [[synth.image(g, t, W, H) for g in gcam] for t in range(RING)]
     dev_frames = []
     for t in range(RING):
@@ -117,7 +120,7 @@ def main():
     parity = "skipped"
     if world == 1:
         from oracle_pipeline import OracleFrontEnd, assert_same_step
-        ofe = OracleFrontEnd(params, W, H)
+        ofe = OracleFrontEnd(params, W, H, gcam)
         for t in range(3):
             got = fe.step([(dev_frames[t][c].ptr, W) for c in range(CAMS_PER_RANK)], resident=True)
             assert_same_step(got, ofe.step(host_frames[t]))
@@ -170,7 +173,7 @@ def main():
         out["roofline"] = matcher_roofline(rt, m, fe.stream, a.matrix_n)
     if rank == 0 and world == 1 and not a.no_cpu:
         from oracle_pipeline import OracleFrontEnd
-        ofe = OracleFrontEnd(params, W, H)
+        ofe = OracleFrontEnd(params, W, H, gcam)
         ofe.step(host_frames[0])                      # warm caches, establish `prev`
         t0 = time.perf_counter()
         for i in range(a.cpu_frames):

@@ -37,6 +37,9 @@ typedef struct orbm_frame orbm_frame;
 int orbm_create(int device, orbm_matcher** out);
 void orbm_destroy(orbm_matcher* m);
 void* orbm_stream(const orbm_matcher* m);
+/* Make the matcher issue all its work on a caller-owned hipStream_t (e.g. orbx_stream(ex), so frame building and
+ * matching are ordered after the extractor's kernels without events); NULL restores the matcher's own stream. */
+int orbm_set_stream(orbm_matcher* m, void* stream);
 
 /* host helper, identical result to the reference's SWAR popcount; rows need 1-byte alignment only */
 int orbm_descriptor_distance(const uint8_t* a, const uint8_t* b);
@@ -85,6 +88,37 @@ typedef struct orbm_query { /* one projected map point */
 
 /* Builds the 64x48 per-camera grid (round-to-cell insertion, ascending global indices) and uploads the frame. */
 int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** out);
+
+/* Frame assembly ON THE DEVICE from HBM-resident extractor outputs -- the merge of reference src/Frame.cc:191-239,
+ * ComputeStereoFromRGBD (:959-986: depth lookup at (int)kp.pt.y,(int)kp.pt.x, uRight = x - mbf/d, -1 where d <= 0) and
+ * AssignFeaturesToGrid (:348-395) -- with no host round trip.  Undistortion is the identity (k1 == 0, :676-680).
+ * Everything is enqueued on the matcher's stream; the inputs must stay valid until that work has run. */
+typedef struct orbm_cam_features {
+    const orb_keypoint* d_kps; /* device, n keypoints (e.g. orbx_device_keypoints)                               */
+    const uint8_t* d_desc;     /* device, n x 32                                                                 */
+    int32_t n;
+    const float* d_depth;      /* device depth image in metres (imDepth after convertTo), or NULL: uRight = -1   */
+    int32_t depth_stride;      /* floats per row                                                                 */
+} orbm_cam_features;
+int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x,
+                           float min_y, float max_x, float max_y, orbm_frame** out);
+/* Host copies of a frame's merged arrays (any pointer may be NULL): keypoints and descriptors in global (cam-major)
+ * order, mvuRight_total, mvDepth_total.  Synchronises the matcher's stream. */
+int orbm_frame_download(orbm_matcher* m, const orbm_frame* f, orb_keypoint* kps, uint8_t* desc, float* uright,
+                        float* depth);
+int orbm_frame_count(const orbm_frame* f);
+
+/* Cross-camera exhaustive top-2 in one launch: every feature g of the frame against all features of the OTHER
+ * cameras (reference analogue: the unrestricted inner loop of src/ORBmatcher.cc:287-321).  best_idx indexes the
+ * concatenation of the other cameras' features in camera order; outputs have n_total entries (host pointers). */
+int orbm_cross_top2(orbm_matcher* m, const orbm_frame* f, int32_t* best_idx, int32_t* best_dist,
+                    int32_t* second_dist);
+/* Same over a list of HBM-resident descriptor blocks, one per camera of the whole rig in global camera order (e.g. the
+ * slices of an RCCL all-gather receive buffer): the cameras [first_query_block, +n_query_blocks) are the queries (the
+ * ones this process owns), every other block is a reference.  Outputs hold sum(counts[query blocks]) entries. */
+int orbm_cross_top2_blocks(orbm_matcher* m, const uint8_t* const* d_desc_blocks, const int* counts, int n_blocks,
+                           int first_query_block, int n_query_blocks, int32_t* best_idx, int32_t* best_dist,
+                           int32_t* second_dist);
 void orbm_frame_destroy(orbm_frame* f);
 /* grid as CSR: cell = (cam*64 + ix)*48 + iy; cell_start has n_cams*3072+1 entries */
 int orbm_frame_grid(const orbm_frame* f, int32_t* cell_start, int32_t* items);

@@ -29,6 +29,11 @@ class Params(C.Structure):  # orbx_params
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+class CamFeatures(C.Structure):  # orbm_cam_features
+    _fields_ = [("d_kps", C.c_void_p), ("d_desc", C.c_void_p), ("n", C.c_int32), ("d_depth", C.c_void_p),
+                ("depth_stride", C.c_int32)]
+
+
 class FrameDesc(C.Structure):  # orbm_frame_desc
     _fields_ = [("n_total", C.c_int32), ("n_cams", C.c_int32), ("un_x", C.c_void_p), ("un_y", C.c_void_p),
                 ("octave", C.c_void_p), ("angle", C.c_void_p), ("uright", C.c_void_p), ("cam_of", C.c_void_p),
@@ -86,6 +91,12 @@ def lib():
     L.orbm_hamming_matrix_device.argtypes = [vp, i32, vp, i32, vp, vp]
     L.orbm_frame_create.argtypes = [vp, vp, vp]
     L.orbm_frame_destroy.argtypes = [vp]; L.orbm_frame_destroy.restype = None
+    L.orbm_set_stream.argtypes = [vp, vp]
+    L.orbm_frame_from_device.argtypes = [vp, vp, i32, f32, f32, f32, f32, f32, vp]
+    L.orbm_frame_download.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.orbm_frame_count.argtypes = [vp]
+    L.orbm_cross_top2.argtypes = [vp, vp, vp, vp, vp]
+    L.orbm_cross_top2_blocks.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.orbm_frame_grid.argtypes = [vp, vp, vp]
     L.orbm_features_in_area.argtypes = [vp, vp, i32, f32, f32, f32, i32, i32, vp, i32, vp]
     L.orbm_project_candidates.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]

@@ -18,8 +18,15 @@
 // not materialised.
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <chrono>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbx.h"
@@ -504,6 +511,78 @@ void build_resize_tables(int sw, int sh, int dw, int dh, std::vector<int2>& xt, 
 
 }  // namespace
 
+// Small persistent worker pool for the host quadtree: the (camera, level) problems of one call are independent.
+// Workers spin for a short while after a job (the steady-state gap between frames is ~1 ms) before sleeping.
+class TaskPool {
+    struct Job {  // one per run(): stale workers can only ever touch their own (finished) job
+        std::function<void(int)> fn;
+        int n = 0;
+        std::atomic<int> next{0}, done{0};
+    };
+public:
+    explicit TaskPool(int n_workers) {
+        for (int i = 0; i < n_workers; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~TaskPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_.fetch_add(1); }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    template <typename F>
+    void run(int n_tasks, F&& fn) {
+        if (workers_.empty() || n_tasks <= 1) { for (int i = 0; i < n_tasks; ++i) fn(i); return; }
+        auto job = std::make_shared<Job>();
+        job->fn = [&fn](int i) { fn(i); };
+        job->n = n_tasks;
+        { std::lock_guard<std::mutex> lk(mu_); job_ = job; gen_.fetch_add(1); }
+        cv_.notify_all();
+        work(*job);
+        while (job->done.load(std::memory_order_acquire) < n_tasks) std::this_thread::yield();
+        // `fn` may go out of scope now: every task has finished, late workers see next >= n and never call job->fn
+    }
+private:
+    static void work(Job& j) {
+        for (;;) {
+            const int i = j.next.fetch_add(1);
+            if (i >= j.n) break;
+            j.fn(i);
+            j.done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void loop() {
+        unsigned seen = 0;
+        for (;;) {
+            const auto t0 = std::chrono::steady_clock::now();  // spin ~2 ms for the next job, then block
+            while (gen_.load(std::memory_order_acquire) == seen) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return gen_.load() != seen; });
+                    break;
+                }
+            }
+            std::shared_ptr<Job> job;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                seen = gen_.load();
+                if (stop_) return;
+                job = job_;
+            }
+            if (job) work(*job);
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<unsigned> gen_{0};
+    std::shared_ptr<Job> job_;
+    bool stop_ = false;
+};
+
+struct OctreeTask {
+    int cam, level, n;
+    std::vector<int> cx, cy, cr, selected;
+};
+
 // ================================================================================================ C ABI
 struct orbx_extractor {
     int device = 0, n_cams = 0, max_w = 0, max_h = 0, max_levels = 0;
@@ -544,8 +623,9 @@ struct orbx_extractor {
 
     std::vector<int> n_out;          // keypoints per camera of the last run
     std::vector<int> level_cnt_last; // candidates per (cam, level) of the last run
-    // scratch for the host quadtree
-    std::vector<int> cx, cy, cr, selected;
+    // host quadtree: one task per (camera, level), run on a small worker pool
+    std::vector<OctreeTask> tasks;
+    std::unique_ptr<TaskPool> pool;
 
     bool profiling = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -709,6 +789,13 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     ORBX_TRY_HIP(hipHostMalloc((void**)&ex->h_level_cnt, (size_t)n_cams * MAX_LEVELS * sizeof(int), hipHostMallocMapped));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
+    {
+        const char* e = getenv("MORB_OCTREE_THREADS");
+        int nt = e ? atoi(e) : 4;
+        const int hw = (int)std::thread::hardware_concurrency();
+        nt = std::max(1, std::min(nt, hw > 1 ? hw : 1));
+        ex->pool.reset(new TaskPool(nt - 1));  // the calling thread works too
+    }
     *out = ex;
     return ORB_OK;
 }
@@ -828,37 +915,62 @@ int orbx_run(orbx_extractor* ex) {
     MORB_HIP(hipStreamSynchronize(st));
     const auto t_host0 = std::chrono::steady_clock::now();
 
-    // K4 (host): quadtree per (camera, level); output order = level-major, list order inside a level
-    int nsel = 0;
+    // K4 (host): quadtree per (camera, level) on the worker pool; output order = level-major, list order inside a level
+    int n_tasks = 0;
     for (int c = 0; c < ex->n_cams; ++c) {
         const CamTables& T = ex->cams[c];
-        int out_idx = 0;
         for (int l = 0; l < T.p.nlevels; ++l) {
             const LevelInfo& Lv = ex->levels[(size_t)c * ML + l];
             const int n = Lv.w ? ex->h_level_cnt[c * ML + l] : 0;
             ex->level_cnt_last[(size_t)c * ML + l] = n;
             if (n == 0) continue;
-            const uint32_t* cand = ex->h_cand + Lv.cand_base;
-            ex->cx.resize(n); ex->cy.resize(n); ex->cr.resize(n);
-            for (int i = 0; i < n; ++i) {
-                const uint32_t v = cand[i];
-                ex->cx[i] = v & 0xfff; ex->cy[i] = (v >> 12) & 0xfff; ex->cr[i] = v >> 24;
-            }
-            morb::distribute_octree(ex->cx.data(), ex->cy.data(), ex->cr.data(), n, Lv.w - 2 * MIN_BORDER, Lv.h - 2 * MIN_BORDER,
-                                    T.quota[l], ex->selected);
-            for (int s : ex->selected) {
-                if (out_idx >= ex->out_cap_active[c] || (size_t)nsel >= ex->h_sel_cap) {
-                    morb::set_error("camera %d produced more keypoints than its output capacity %d", c, ex->out_cap_active[c]);
+            if ((int)ex->tasks.size() <= n_tasks) ex->tasks.emplace_back();
+            OctreeTask& t = ex->tasks[n_tasks++];
+            t.cam = c; t.level = l; t.n = n;
+        }
+    }
+    // biggest problems first (level 0 dominates): better balance across workers
+    std::sort(ex->tasks.begin(), ex->tasks.begin() + n_tasks, [](const OctreeTask& a, const OctreeTask& b) {
+        return a.n != b.n ? a.n > b.n : (a.cam != b.cam ? a.cam < b.cam : a.level < b.level);
+    });
+    ex->pool->run(n_tasks, [ex, ML](int i) {
+        OctreeTask& t = ex->tasks[i];
+        const LevelInfo& Lv = ex->levels[(size_t)t.cam * ML + t.level];
+        const uint32_t* cand = ex->h_cand + Lv.cand_base;
+        t.cx.resize(t.n); t.cy.resize(t.n); t.cr.resize(t.n);
+        for (int k = 0; k < t.n; ++k) {
+            const uint32_t v = cand[k];
+            t.cx[k] = v & 0xfff; t.cy[k] = (v >> 12) & 0xfff; t.cr[k] = v >> 24;
+        }
+        morb::distribute_octree(t.cx.data(), t.cy.data(), t.cr.data(), t.n, Lv.w - 2 * MIN_BORDER, Lv.h - 2 * MIN_BORDER,
+                                ex->cams[t.cam].quota[t.level], t.selected);
+    });
+    // assemble in (camera, level) order
+    std::vector<int> order(n_tasks);
+    for (int i = 0; i < n_tasks; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [ex](int a, int b) {
+        const OctreeTask &x = ex->tasks[a], &y = ex->tasks[b];
+        return x.cam != y.cam ? x.cam < y.cam : x.level < y.level;
+    });
+    int nsel = 0;
+    {
+        int cur_cam = -1, out_idx = 0;
+        for (int oi = 0; oi < n_tasks; ++oi) {
+            const OctreeTask& t = ex->tasks[order[oi]];
+            if (t.cam != cur_cam) { if (cur_cam >= 0) ex->n_out[cur_cam] = out_idx; cur_cam = t.cam; out_idx = 0; }
+            for (int s : t.selected) {
+                if (out_idx >= ex->out_cap_active[t.cam] || (size_t)nsel >= ex->h_sel_cap) {
+                    morb::set_error("camera %d produced more keypoints than its output capacity %d", t.cam, ex->out_cap_active[t.cam]);
                     return ORB_E_CAPACITY;
                 }
                 SelKp& K = ex->h_sel[nsel++];
-                K.x = ex->cx[s] + MIN_BORDER; K.y = ex->cy[s] + MIN_BORDER;  // :843-844
-                K.camlevel = (c << 8) | l;
-                K.resp_out = (int)(((unsigned)ex->cr[s] << 24) | (unsigned)out_idx);
+                K.x = t.cx[s] + MIN_BORDER; K.y = t.cy[s] + MIN_BORDER;  // :843-844
+                K.camlevel = (t.cam << 8) | t.level;
+                K.resp_out = (int)(((unsigned)t.cr[s] << 24) | (unsigned)out_idx);
                 ++out_idx;
             }
         }
-        ex->n_out[c] = out_idx;
+        if (cur_cam >= 0) ex->n_out[cur_cam] = out_idx;
     }
     const auto t_host1 = std::chrono::steady_clock::now();
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[4], st));

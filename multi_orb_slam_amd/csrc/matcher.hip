@@ -310,6 +310,268 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
     if (lane == 0) cand_count[qi] = total;
 }
 
+// ------------------------------------------------------------------------------------------------ device frame build
+struct CamFeat {
+    const orb_keypoint* kps; const uint4* desc; const float* depth;
+    int depth_stride, n, base;
+};
+
+// Frame merge + ComputeStereoFromRGBD + PosInGrid for every feature (reference src/Frame.cc:221-239, :959-986, :632-642)
+__global__ __launch_bounds__(256) void k_frame_fill(const CamFeat* __restrict__ cams, int n_cams, int n_total, float mbf,
+                                                    float minX, float minY, float invW, float invH,
+                                                    float* __restrict__ x, float* __restrict__ y, float* __restrict__ ur,
+                                                    float* __restrict__ depth_out, int* __restrict__ oct,
+                                                    float* __restrict__ ang, orb_keypoint* __restrict__ kps_g,
+                                                    uint4* __restrict__ desc_g, int* __restrict__ cell_of,
+                                                    int* __restrict__ cell_cnt) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_total) return;
+    int c = 0;
+    while (c + 1 < n_cams && g >= cams[c].base + cams[c].n) ++c;
+    const CamFeat C = cams[c];
+    const int l = g - C.base;
+    const orb_keypoint k = C.kps[l];
+    x[g] = k.x; y[g] = k.y; oct[g] = k.octave; ang[g] = k.angle; kps_g[g] = k;
+    desc_g[2 * g] = C.desc[2 * l]; desc_g[2 * g + 1] = C.desc[2 * l + 1];
+    float d = -1.f, u_r = -1.f;
+    if (C.depth) {
+        const float dv = C.depth[(size_t)(int)k.y * C.depth_stride + (int)k.x];  // imDepth.at<float>(v,u): float -> int truncation
+        if (dv > 0) { d = dv; u_r = k.x - mbf / dv; }
+    }
+    ur[g] = u_r; depth_out[g] = d;
+    const int px = (int)roundf((k.x - minX) * invW), py = (int)roundf((k.y - minY) * invH);
+    int cell = -1;
+    if (px >= 0 && px < ORBM_GRID_COLS && py >= 0 && py < ORBM_GRID_ROWS) {
+        cell = (c * ORBM_GRID_COLS + px) * ORBM_GRID_ROWS + py;
+        atomicAdd(&cell_cnt[cell], 1);
+    }
+    cell_of[g] = cell;
+}
+
+// exclusive scan of cnt[0..n) into start[0..n], single 1024-thread block; cursor = copy of start
+__global__ __launch_bounds__(1024) void k_scan_cells(const int* cnt, int n, int* __restrict__ start, int* cursor) {
+    // cnt and cursor may alias (the per-cell counters are turned into insert cursors in place)
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + 1023) / 1024;
+    const int c0 = min(n, tid * per), c1 = min(n, c0 + per);
+    int mine = 0;
+    for (int c = c0; c < c1; ++c) mine += cnt[c];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < 16; ++w) { const int v = wsum[w]; wsum[w] = acc; acc += v; }
+        start[n] = acc;
+    }
+    __syncthreads();
+    int run = wsum[wave] + incl - mine;
+    for (int c = c0; c < c1; ++c) { const int v = cnt[c]; start[c] = run; cursor[c] = run; run += v; }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_cells(const int* __restrict__ cell_of, int n_total, int* __restrict__ cursor,
+                                                       int* __restrict__ items) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_total) return;
+    const int cell = cell_of[g];
+    if (cell >= 0) items[atomicAdd(&cursor[cell], 1)] = g;
+}
+
+// ascending global index inside every cell (the atomics above scatter in arbitrary order; cells hold a handful of items)
+__global__ __launch_bounds__(256) void k_sort_cells(const int* __restrict__ start, int ncell, int* __restrict__ items) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncell) return;
+    const int s = start[c], e = start[c + 1];
+    for (int i = s + 1; i < e; ++i) {
+        const int v = items[i];
+        int j = i - 1;
+        while (j >= s && items[j] > v) { items[j + 1] = items[j]; --j; }
+        items[j + 1] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ device resolve
+// The reference resolves claims sequentially in query order (src/ORBmatcher.cc:3502-3614): a feature claimed by a query
+// whose MapPoint is observed ("blocks") is invisible to every LATER query.  Query q therefore depends only on queries
+// < q, and the sequential answer is the unique fixed point of:  choice[q] = first arg-min over q's ordered candidates
+// that are not occupied and not claimed by a blocking query q' < q.  One workgroup iterates that map (Jacobi) until
+// nothing changes -- after k sweeps the first k queries are final, in practice a handful of sweeps suffice.
+// status[0]: 0 ok, 1 not converged within max_it (host falls back), 2 a candidate list exceeded cap (host retries);
+// status[1] = nmatches, status[2] = sweeps, status[3] = longest candidate list.
+template <bool POINTS>
+__global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap,
+                                                  const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
+                                                  const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
+                                                  const float* __restrict__ f_angle, int th_high, float nnratio,
+                                                  int check_ori, int max_it, int* __restrict__ choice,
+                                                  int* claim_min, int* __restrict__ match_of_feature,
+                                                  int* __restrict__ status) {
+    __shared__ int s_hist[ORBM_HISTO_LENGTH];
+    __shared__ int s_keep[3];
+    __shared__ int s_red;
+    const int tid = threadIdx.x, T = blockDim.x;
+    // longest list
+    if (tid == 0) s_red = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int i = tid; i < nq; i += T) { mx = max(mx, cand_count[i]); choice[i] = -1; }
+    atomicMax(&s_red, mx);
+    __syncthreads();
+    const int maxcount = s_red;
+    if (maxcount > cap) {
+        if (tid == 0) { status[0] = 2; status[1] = 0; status[2] = 0; status[3] = maxcount; }
+        return;
+    }
+    int it = 0, changed = 1;
+    for (; it < max_it && changed; ++it) {
+        // claim_min is updated with L2 atomics: read and reset it with agent-scope accesses so no sweep can see a
+        // stale per-CU L1 copy of an earlier sweep's value
+        for (int g = tid; g < F.n_total; g += T) __hip_atomic_store(&claim_min[g], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        for (int i = tid; i < nq; i += T) {
+            const int c = choice[i];
+            if (c >= 0 && q[i].blocks) atomicMin(&claim_min[c], i);
+        }
+        __syncthreads();
+        int ch = 0;
+        for (int i = tid; i < nq; i += T) {
+            const int cnt = cand_count[i];
+            const int* ci = cand_idx + (size_t)i * cap;
+            const uint16_t* cd = cand_dist + (size_t)i * cap;
+            int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
+            for (int k = 0; k < cnt; ++k) {
+                const int g = ci[k];
+                if (occupied && occupied[g]) continue;
+                if (__hip_atomic_load(&claim_min[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) continue;
+                const int d = cd[k];
+                if (POINTS) {
+                    if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = F.octave[g]; bidx = g; }
+                    else if (d < best2) { lvl2 = F.octave[g]; best2 = d; }
+                } else {
+                    if (d < best) { best = d; bidx = g; }
+                }
+            }
+            int nc = -1;
+            if (best <= th_high && bidx >= 0) {
+                nc = bidx;
+                if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
+            }
+            if (nc != choice[i]) { ch = 1; choice[i] = nc; }
+        }
+        changed = __syncthreads_or(ch);
+    }
+    if (changed) {  // ran out of sweeps
+        if (tid == 0) { status[0] = 1; status[1] = 0; status[2] = it; status[3] = maxcount; }
+        return;
+    }
+    // owners: the last claimant in query order (claims after a blocking one are impossible, so max index == final owner)
+    for (int g = tid; g < F.n_total; g += T) match_of_feature[g] = -1;
+    if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
+    if (tid == 0) s_red = 0;
+    __syncthreads();
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    int acc = 0;
+    for (int i = tid; i < nq; i += T) {
+        const int c = choice[i];
+        if (c < 0) continue;
+        ++acc;
+        atomicMax(&match_of_feature[c], i);
+        if (!POINTS && check_ori) {
+            float rot = q[i].angle - f_angle[c];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < ORBM_HISTO_LENGTH) atomicAdd(&s_hist[bin], 1);
+        }
+    }
+    atomicAdd(&s_red, acc);
+    __syncthreads();
+    if (!POINTS && check_ori) {
+        if (tid == 0) {  // ComputeThreeMaxima (reference src/ORBmatcher.cc:3948-3989)
+            int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
+                const int sz = s_hist[b];
+                if (sz > m1) { m3 = m2; i3 = i2; m2 = m1; i2 = i1; m1 = sz; i1 = b; }
+                else if (sz > m2) { m3 = m2; i3 = i2; m2 = sz; i2 = b; }
+                else if (sz > m3) { m3 = sz; i3 = b; }
+            }
+            if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+            else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+            s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+        }
+        __syncthreads();
+        int rej = 0;
+        for (int i = tid; i < nq; i += T) {
+            const int c = choice[i];
+            if (c < 0) continue;
+            float rot = q[i].angle - f_angle[c];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < ORBM_HISTO_LENGTH && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
+                match_of_feature[c] = -2;  // every writer stores -2; owners were settled before the barrier
+                ++rej;
+            }
+        }
+        atomicSub(&s_red, rej);
+        __syncthreads();
+    }
+    if (tid == 0) { status[0] = 0; status[1] = s_red; status[2] = it; status[3] = maxcount; }
+}
+
+// Cross-camera top-2 in one launch: lane = query feature g, references = every feature outside g's camera segment.
+// Queries are features [q_off, q_off + nq) (the cameras this process owns); outputs are indexed from 0.
+__global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __restrict__ desc, int n_total,
+                                                                const int* __restrict__ cam_start, int n_cams, int q_off,
+                                                                int nq, int* __restrict__ best_idx,
+                                                                int* __restrict__ best_dist, int* __restrict__ second_dist) {
+    __shared__ int sb[TOP2_WAVES][64], ss[TOP2_WAVES][64], si[TOP2_WAVES][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.x * 64 + lane;
+    const int qc = q_off + (qi < nq ? qi : nq - 1);
+    const uint4 q0 = desc[2 * qc], q1 = desc[2 * qc + 1];
+    int c = 0;
+    while (c + 1 < n_cams && qc >= cam_start[c + 1]) ++c;
+    const int seg0 = cam_start[c], seg1 = cam_start[c + 1], seglen = seg1 - seg0;
+
+    const int S = gridDim.y;
+    const int slice = (n_total + S - 1) / S;
+    const int s0 = blockIdx.y * slice, s1 = min(n_total, s0 + slice);
+    const int chunk = (max(s1 - s0, 0) + TOP2_WAVES - 1) / TOP2_WAVES;
+    const int j0 = s0 + wave * chunk, j1 = min(s1, j0 + chunk);
+    int b = 256, s = 256, bi = -1;
+    for (int j = j0; j < j1; ++j) {
+        const uint4 a0 = desc[2 * j], a1 = desc[2 * j + 1];  // wave-uniform -> scalar loads
+        int d = (int)ham256_chain(a0, a1, q0, q1);
+        d = (j >= seg0 && j < seg1) ? 256 : d;               // own camera: distance 256 never registers
+        const int jj = j < seg0 ? j : j - seglen;            // index in the concatenation of the other cameras
+        s = min(s, max(b, d));
+        bi = d < b ? jj : bi;
+        b = min(b, d);
+    }
+    sb[wave][lane] = b; ss[wave][lane] = s; si[wave][lane] = bi;
+    __syncthreads();
+    if (wave == 0 && qi < nq) {
+        int B = 256, Sd = 256, I = -1;
+#pragma unroll
+        for (int w = 0; w < TOP2_WAVES; ++w) {
+            const int b2 = sb[w][lane], s2 = ss[w][lane], i2 = si[w][lane];
+            Sd = min(min(Sd, s2), max(B, b2));
+            I = b2 < B ? i2 : I;
+            B = min(B, b2);
+        }
+        const size_t o = (size_t)blockIdx.y * nq + qi;
+        best_idx[o] = I; best_dist[o] = B; second_dist[o] = Sd;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 int launch_top2(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd,
                 void* d_scratch, int S, hipStream_t st) {
@@ -360,36 +622,88 @@ int launch_matrix(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16
 }  // namespace
 
 // ================================================================================================ C ABI
+struct FrameBufs {  // device storage of one frame; recycled through the matcher's pool (no hipMalloc per frame)
+    DevBuf<float> d_x, d_y, d_ur, d_depth, d_ang;
+    DevBuf<int32_t> d_oct, d_cell_start, d_items, d_cell_of, d_cursor, d_cam_start;
+    DevBuf<uint8_t> d_desc;
+    DevBuf<orb_keypoint> d_kps;
+    DevBuf<CamFeat> d_cams;
+    void release() {
+        d_x.release(); d_y.release(); d_ur.release(); d_depth.release(); d_ang.release(); d_oct.release();
+        d_cell_start.release(); d_items.release(); d_cell_of.release(); d_cursor.release(); d_cam_start.release();
+        d_desc.release(); d_kps.release(); d_cams.release();
+    }
+};
+
 struct orbm_matcher {
     int device = 0;
-    hipStream_t stream = nullptr;
-    DevBuf<uint8_t> d_q, d_r, d_scratch, d_queries;
-    DevBuf<int32_t> d_i0, d_i1, d_i2;
+    hipStream_t own_stream = nullptr, stream = nullptr;  // `stream` = the one in use (own or caller's)
+    DevBuf<uint8_t> d_q, d_r, d_scratch, d_queries, d_occ;
+    DevBuf<int32_t> d_i0, d_i1, d_i2, d_choice, d_claim, d_match, d_status;
     DevBuf<uint16_t> d_u16;
-    PinnedBuf<int32_t> h_i0, h_i1;
+    PinnedBuf<int32_t> h_i0, h_i1, h_i2, h_match;
     PinnedBuf<uint16_t> h_u16;
+    PinnedBuf<uint8_t> h_ring;  // 4 slots of {CamFeat[64], int cam_start[65]} for asynchronous H2D
+    unsigned ring_pos = 0;
+    std::vector<FrameBufs*> pool;  // free list
+    bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
 };
 
 struct orbm_frame {
     orbm_matcher* owner = nullptr;
+    FrameBufs* b = nullptr;
     int n_total = 0, n_cams = 0;
     float minX = 0, minY = 0, maxX = 0, maxY = 0, invW = 0, invH = 0;
-    // host copies used by the sequential resolve
-    std::vector<int32_t> octave;
-    std::vector<float> angle;
-    std::vector<int32_t> cell_start, items;
-    // device
-    DevBuf<float> d_x, d_y, d_ur;
-    DevBuf<int32_t> d_oct, d_cell_start, d_items;
-    DevBuf<uint8_t> d_desc;
+    bool device_built = false;
+    // host copies used by the host resolve / orbm_frame_grid; filled at create for host-built frames, lazily otherwise
+    mutable std::vector<int32_t> octave, cell_start, items;
+    mutable std::vector<float> angle;
+    mutable bool host_valid = false;
+    std::vector<int32_t> cam_start;  // n_cams + 1
     FrameDev dev() const {
         FrameDev F;
-        F.n_total = n_total; F.n_cams = n_cams; F.un_x = d_x.p; F.un_y = d_y.p; F.uright = d_ur.p; F.octave = d_oct.p;
-        F.desc = (const uint4*)d_desc.p; F.cell_start = d_cell_start.p; F.items = d_items.p;
+        F.n_total = n_total; F.n_cams = n_cams; F.un_x = b->d_x.p; F.un_y = b->d_y.p; F.uright = b->d_ur.p;
+        F.octave = b->d_oct.p; F.desc = (const uint4*)b->d_desc.p; F.cell_start = b->d_cell_start.p; F.items = b->d_items.p;
         F.minX = minX; F.minY = minY; F.invW = invW; F.invH = invH;
         return F;
     }
 };
+
+static FrameBufs* take_bufs(orbm_matcher* m) {
+    if (!m->pool.empty()) { FrameBufs* b = m->pool.back(); m->pool.pop_back(); return b; }
+    return new FrameBufs();
+}
+
+static int reserve_frame(FrameBufs* b, int n, int n_cams) {
+    const size_t nn = (size_t)std::max(n, 1);
+    const int ncell = n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
+    int rc;
+    if ((rc = b->d_x.reserve(nn)) || (rc = b->d_y.reserve(nn)) || (rc = b->d_ur.reserve(nn)) || (rc = b->d_depth.reserve(nn)) ||
+        (rc = b->d_ang.reserve(nn)) || (rc = b->d_oct.reserve(nn)) || (rc = b->d_desc.reserve(nn * 32)) ||
+        (rc = b->d_kps.reserve(nn)) || (rc = b->d_cell_start.reserve(ncell + 1)) || (rc = b->d_items.reserve(nn)) ||
+        (rc = b->d_cell_of.reserve(nn)) || (rc = b->d_cursor.reserve(ncell + 1)) || (rc = b->d_cam_start.reserve(n_cams + 1)) ||
+        (rc = b->d_cams.reserve(n_cams)))
+        return rc;
+    return ORB_OK;
+}
+
+// host mirrors of a device-built frame (octave / angle / grid), fetched once on demand
+static int ensure_host_copies(const orbm_frame* f) {
+    if (f->host_valid) return ORB_OK;
+    orbm_matcher* m = f->owner;
+    const int n = f->n_total, ncell = f->n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
+    f->octave.assign(std::max(n, 1), 0); f->angle.assign(std::max(n, 1), 0.f);
+    f->cell_start.assign(ncell + 1, 0); f->items.assign(std::max(n, 1), 0);
+    if (n) {
+        MORB_HIP(hipMemcpyAsync(f->octave.data(), f->b->d_oct.p, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+        MORB_HIP(hipMemcpyAsync(f->angle.data(), f->b->d_ang.p, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+        MORB_HIP(hipMemcpyAsync(f->items.data(), f->b->d_items.p, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+    }
+    MORB_HIP(hipMemcpyAsync(f->cell_start.data(), f->b->d_cell_start.p, (size_t)(ncell + 1) * 4, hipMemcpyDeviceToHost, m->stream));
+    MORB_HIP(hipStreamSynchronize(m->stream));
+    f->host_valid = true;
+    return ORB_OK;
+}
 
 extern "C" {
 
@@ -399,8 +713,11 @@ int orbm_create(int device, orbm_matcher** out) {
     if (rc != ORB_OK) return rc;
     orbm_matcher* m = new orbm_matcher();
     m->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete m; return ORB_E_HIP; }
+    m->stream = m->own_stream;
+    const char* hr = getenv("MORB_HOST_RESOLVE");
+    m->host_resolve = hr && atoi(hr) != 0;
     *out = m;
     return ORB_OK;
 }
@@ -409,14 +726,24 @@ void orbm_destroy(orbm_matcher* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
-    m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release();
-    m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_u16.release();
-    m->h_i0.release(); m->h_i1.release(); m->h_u16.release();
-    (void)hipStreamDestroy(m->stream);
+    m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release(); m->d_occ.release();
+    m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release();
+    m->d_match.release(); m->d_status.release(); m->d_u16.release();
+    m->h_i0.release(); m->h_i1.release(); m->h_i2.release(); m->h_match.release(); m->h_u16.release(); m->h_ring.release();
+    for (FrameBufs* b : m->pool) { b->release(); delete b; }
+    (void)hipStreamDestroy(m->own_stream);
     delete m;
 }
 
 void* orbm_stream(const orbm_matcher* m) { return m ? (void*)m->stream : nullptr; }
+
+int orbm_set_stream(orbm_matcher* m, void* stream) {
+    MORB_ARG(m != nullptr);
+    MORB_HIP(hipSetDevice(m->device));
+    MORB_HIP(hipStreamSynchronize(m->stream));  // nothing of ours may still be in flight on the old stream
+    m->stream = stream ? (hipStream_t)stream : m->own_stream;
+    return ORB_OK;
+}
 
 int orbm_descriptor_distance(const uint8_t* a, const uint8_t* b) {
     int dist = 0;
@@ -528,10 +855,12 @@ int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** ou
     const int ncell = f->n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
     std::vector<int32_t> cell_of(n);
     F->cell_start.assign(ncell + 1, 0);
+    F->cam_start.assign(f->n_cams + 1, 0);
     for (int g = 0; g < n; g++) {
         const int px = (int)roundf((f->un_x[g] - F->minX) * F->invW);
         const int py = (int)roundf((f->un_y[g] - F->minY) * F->invH);
         const int cam = f->cam_of[g];
+        if (cam >= 0 && cam < f->n_cams) F->cam_start[cam + 1]++;
         if (px < 0 || px >= ORBM_GRID_COLS || py < 0 || py >= ORBM_GRID_ROWS || cam < 0 || cam >= f->n_cams) {
             cell_of[g] = -1;
             continue;
@@ -539,80 +868,174 @@ int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** ou
         cell_of[g] = (cam * ORBM_GRID_COLS + px) * ORBM_GRID_ROWS + py;
         F->cell_start[cell_of[g] + 1]++;
     }
+    for (int c = 0; c < f->n_cams; c++) F->cam_start[c + 1] += F->cam_start[c];
     for (int c = 0; c < ncell; c++) F->cell_start[c + 1] += F->cell_start[c];
-    F->items.assign(std::max(F->cell_start[ncell], 1), 0);
+    F->items.assign(std::max(n, 1), 0);
     {
         std::vector<int32_t> cursor(F->cell_start.begin(), F->cell_start.end() - 1);
         for (int g = 0; g < n; g++)
             if (cell_of[g] >= 0) F->items[cursor[cell_of[g]]++] = g;
     }
+    F->host_valid = true;
     // descriptors re-laid in global-index order so the kernel gathers with one index
     std::vector<uint8_t> desc((size_t)std::max(n, 1) * 32);
     for (int g = 0; g < n; g++) memcpy(&desc[(size_t)g * 32], f->desc[f->cam_of[g]] + (size_t)f->local_of[g] * 32, 32);
 
-    int rc;
-    const size_t nn = (size_t)std::max(n, 1);
-    if ((rc = F->d_x.reserve(nn)) || (rc = F->d_y.reserve(nn)) || (rc = F->d_ur.reserve(nn)) || (rc = F->d_oct.reserve(nn)) ||
-        (rc = F->d_desc.reserve(nn * 32)) || (rc = F->d_cell_start.reserve(ncell + 1)) ||
-        (rc = F->d_items.reserve(F->items.size()))) {
-        orbm_frame_destroy(F);
-        return rc;
-    }
+    F->b = take_bufs(m);
+    int rc = reserve_frame(F->b, n, f->n_cams);
+    if (rc) { orbm_frame_destroy(F); return rc; }
     hipStream_t st = m->stream;
+    const size_t nn = (size_t)n;
     if (n) {
-        MORB_HIP(hipMemcpyAsync(F->d_x.p, f->un_x, nn * 4, hipMemcpyHostToDevice, st));
-        MORB_HIP(hipMemcpyAsync(F->d_y.p, f->un_y, nn * 4, hipMemcpyHostToDevice, st));
-        MORB_HIP(hipMemcpyAsync(F->d_ur.p, f->uright, nn * 4, hipMemcpyHostToDevice, st));
-        MORB_HIP(hipMemcpyAsync(F->d_oct.p, f->octave, nn * 4, hipMemcpyHostToDevice, st));
-        MORB_HIP(hipMemcpyAsync(F->d_desc.p, desc.data(), nn * 32, hipMemcpyHostToDevice, st));
+        MORB_HIP(hipMemcpyAsync(F->b->d_x.p, f->un_x, nn * 4, hipMemcpyHostToDevice, st));
+        MORB_HIP(hipMemcpyAsync(F->b->d_y.p, f->un_y, nn * 4, hipMemcpyHostToDevice, st));
+        MORB_HIP(hipMemcpyAsync(F->b->d_ur.p, f->uright, nn * 4, hipMemcpyHostToDevice, st));
+        MORB_HIP(hipMemcpyAsync(F->b->d_ang.p, f->angle, nn * 4, hipMemcpyHostToDevice, st));
+        MORB_HIP(hipMemcpyAsync(F->b->d_oct.p, f->octave, nn * 4, hipMemcpyHostToDevice, st));
+        MORB_HIP(hipMemcpyAsync(F->b->d_desc.p, desc.data(), nn * 32, hipMemcpyHostToDevice, st));
+        MORB_HIP(hipMemcpyAsync(F->b->d_items.p, F->items.data(), nn * 4, hipMemcpyHostToDevice, st));
     }
-    MORB_HIP(hipMemcpyAsync(F->d_cell_start.p, F->cell_start.data(), (size_t)(ncell + 1) * 4, hipMemcpyHostToDevice, st));
-    MORB_HIP(hipMemcpyAsync(F->d_items.p, F->items.data(), F->items.size() * 4, hipMemcpyHostToDevice, st));
+    MORB_HIP(hipMemcpyAsync(F->b->d_cell_start.p, F->cell_start.data(), (size_t)(ncell + 1) * 4, hipMemcpyHostToDevice, st));
+    MORB_HIP(hipMemcpyAsync(F->b->d_cam_start.p, F->cam_start.data(), (size_t)(f->n_cams + 1) * 4, hipMemcpyHostToDevice, st));
     MORB_HIP(hipStreamSynchronize(st));  // `desc` and the caller's arrays may go away after return
     *out = F;
     return ORB_OK;
 }
 
+int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
+                           float max_x, float max_y, orbm_frame** out) {
+    MORB_ARG(m && cams && out && n_cams >= 1 && n_cams <= 64 && max_x > min_x && max_y > min_y);
+    MORB_HIP(hipSetDevice(m->device));
+    int n = 0;
+    for (int c = 0; c < n_cams; ++c) {
+        MORB_ARG(cams[c].n >= 0 && (cams[c].n == 0 || (cams[c].d_kps && cams[c].d_desc)));
+        MORB_ARG(((uintptr_t)cams[c].d_desc & 15) == 0 && ((uintptr_t)cams[c].d_kps & 3) == 0);
+        n += cams[c].n;
+    }
+    orbm_frame* F = new orbm_frame();
+    F->owner = m; F->n_total = n; F->n_cams = n_cams; F->device_built = true;
+    F->minX = min_x; F->minY = min_y; F->maxX = max_x; F->maxY = max_y;
+    F->invW = (float)ORBM_GRID_COLS / (max_x - min_x);
+    F->invH = (float)ORBM_GRID_ROWS / (max_y - min_y);
+    F->cam_start.assign(n_cams + 1, 0);
+    F->b = take_bufs(m);
+    int rc = reserve_frame(F->b, n, n_cams);
+    const size_t slot = 64 * sizeof(CamFeat) + 65 * sizeof(int);
+    if (!rc) rc = m->h_ring.reserve(slot * 4);  // ring of 4 parameter blocks: the H2D copies below are asynchronous
+    if (rc) { orbm_frame_destroy(F); return rc; }
+    uint8_t* hs = m->h_ring.p + (size_t)(m->ring_pos++ & 3) * slot;
+    CamFeat* hc = reinterpret_cast<CamFeat*>(hs);
+    int* hstart = reinterpret_cast<int*>(hs + 64 * sizeof(CamFeat));
+    int base = 0;
+    for (int c = 0; c < n_cams; ++c) {
+        hc[c].kps = cams[c].d_kps; hc[c].desc = (const uint4*)cams[c].d_desc; hc[c].depth = cams[c].d_depth;
+        hc[c].depth_stride = cams[c].depth_stride; hc[c].n = cams[c].n; hc[c].base = base;
+        F->cam_start[c] = base;
+        base += cams[c].n;
+    }
+    F->cam_start[n_cams] = base;
+    for (int c = 0; c <= n_cams; ++c) hstart[c] = F->cam_start[c];
+    const int ncell = n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
+    hipStream_t st = m->stream;
+    MORB_HIP(hipMemcpyAsync(F->b->d_cams.p, hc, (size_t)n_cams * sizeof(CamFeat), hipMemcpyHostToDevice, st));
+    MORB_HIP(hipMemcpyAsync(F->b->d_cam_start.p, hstart, (size_t)(n_cams + 1) * 4, hipMemcpyHostToDevice, st));
+    MORB_HIP(hipMemsetAsync(F->b->d_cursor.p, 0, (size_t)(ncell + 1) * 4, st));  // used as the per-cell counter first
+    if (n) {
+        hipLaunchKernelGGL(k_frame_fill, dim3((n + 255) / 256), dim3(256), 0, st, (const CamFeat*)F->b->d_cams.p, n_cams, n, mbf,
+                           F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
+                           F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_of.p,
+                           F->b->d_cursor.p);
+    }
+    // counts live in d_cursor; scan them into d_cell_start and leave d_cursor = running insert positions
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, (const int*)F->b->d_cursor.p, ncell, F->b->d_cell_start.p,
+                       F->b->d_cursor.p);
+    if (n) {
+        hipLaunchKernelGGL(k_scatter_cells, dim3((n + 255) / 256), dim3(256), 0, st, (const int*)F->b->d_cell_of.p, n,
+                           F->b->d_cursor.p, F->b->d_items.p);
+        hipLaunchKernelGGL(k_sort_cells, dim3((ncell + 255) / 256), dim3(256), 0, st, (const int*)F->b->d_cell_start.p, ncell,
+                           F->b->d_items.p);
+    }
+    MORB_HIP(hipGetLastError());
+    *out = F;
+    return ORB_OK;
+}
+
+int orbm_frame_count(const orbm_frame* f) { return f ? f->n_total : ORB_E_ARG; }
+
+int orbm_frame_download(orbm_matcher* m, const orbm_frame* f, orb_keypoint* kps, uint8_t* desc, float* uright, float* depth) {
+    MORB_ARG(m && f);
+    MORB_HIP(hipSetDevice(m->device));
+    const size_t n = (size_t)f->n_total;
+    if (n) {
+        if (kps) {
+            MORB_ARG(f->device_built);  // host-built frames were handed keypoint fields, not records
+            MORB_HIP(hipMemcpyAsync(kps, f->b->d_kps.p, n * sizeof(orb_keypoint), hipMemcpyDeviceToHost, m->stream));
+        }
+        if (desc) MORB_HIP(hipMemcpyAsync(desc, f->b->d_desc.p, n * 32, hipMemcpyDeviceToHost, m->stream));
+        if (uright) MORB_HIP(hipMemcpyAsync(uright, f->b->d_ur.p, n * 4, hipMemcpyDeviceToHost, m->stream));
+        if (depth) {
+            MORB_ARG(f->device_built);
+            MORB_HIP(hipMemcpyAsync(depth, f->b->d_depth.p, n * 4, hipMemcpyDeviceToHost, m->stream));
+        }
+    }
+    MORB_HIP(hipStreamSynchronize(m->stream));
+    return ORB_OK;
+}
+
 void orbm_frame_destroy(orbm_frame* f) {
     if (!f) return;
-    if (f->owner) (void)hipSetDevice(f->owner->device);
-    f->d_x.release(); f->d_y.release(); f->d_ur.release(); f->d_oct.release(); f->d_desc.release();
-    f->d_cell_start.release(); f->d_items.release();
+    if (f->b) {
+        if (f->owner) {
+            // kernels reading these buffers may still be queued: recycle only after the stream drained
+            (void)hipSetDevice(f->owner->device);
+            (void)hipStreamSynchronize(f->owner->stream);
+            f->owner->pool.push_back(f->b);
+        } else { f->b->release(); delete f->b; }
+    }
     delete f;
 }
 
 int orbm_frame_grid(const orbm_frame* f, int32_t* cell_start, int32_t* items) {
     MORB_ARG(f && cell_start);
+    int rc = ensure_host_copies(f);
+    if (rc) return rc;
     memcpy(cell_start, f->cell_start.data(), f->cell_start.size() * 4);
     if (items && f->cell_start.back() > 0) memcpy(items, f->items.data(), (size_t)f->cell_start.back() * 4);
     return ORB_OK;
 }
 
+// k_project into m->d_i0 (idx) / d_u16 (dist) / d_i1 (count); optionally copied to the pinned host mirrors
 static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap, int gate_right,
-                       int with_dist) {
+                       int with_dist, bool upload_queries, bool to_host) {
     int rc;
     if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_i0.reserve((size_t)nq * cap)) ||
-        (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)) || (rc = m->h_i0.reserve((size_t)nq * cap)) ||
-        (rc = m->h_u16.reserve((size_t)nq * cap)) || (rc = m->h_i1.reserve(nq)))
+        (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)))
         return rc;
-    MORB_HIP(hipMemcpyAsync(m->d_queries.p, q, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
+    if (upload_queries)
+        MORB_HIP(hipMemcpyAsync(m->d_queries.p, q, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_project, dim3((nq + 3) / 4), dim3(256), 0, m->stream, f->dev(),
                        (const orbm_query*)m->d_queries.p, nq, cap, gate_right, with_dist, m->d_i0.p, m->d_u16.p, m->d_i1.p);
     MORB_HIP(hipGetLastError());
-    MORB_HIP(hipMemcpyAsync(m->h_i1.p, m->d_i1.p, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
-    MORB_HIP(hipMemcpyAsync(m->h_i0.p, m->d_i0.p, (size_t)nq * cap * 4, hipMemcpyDeviceToHost, m->stream));
-    if (with_dist) MORB_HIP(hipMemcpyAsync(m->h_u16.p, m->d_u16.p, (size_t)nq * cap * 2, hipMemcpyDeviceToHost, m->stream));
-    MORB_HIP(hipStreamSynchronize(m->stream));
+    if (to_host) {
+        if ((rc = m->h_i0.reserve((size_t)nq * cap)) || (rc = m->h_u16.reserve((size_t)nq * cap)) || (rc = m->h_i1.reserve(nq)))
+            return rc;
+        MORB_HIP(hipMemcpyAsync(m->h_i1.p, m->d_i1.p, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+        MORB_HIP(hipMemcpyAsync(m->h_i0.p, m->d_i0.p, (size_t)nq * cap * 4, hipMemcpyDeviceToHost, m->stream));
+        if (with_dist) MORB_HIP(hipMemcpyAsync(m->h_u16.p, m->d_u16.p, (size_t)nq * cap * 2, hipMemcpyDeviceToHost, m->stream));
+        MORB_HIP(hipStreamSynchronize(m->stream));
+    }
     return ORB_OK;
 }
 
 // Runs k_project with a growing per-query capacity until every list fits; results in m->h_i0 / h_u16 / h_i1.
 static int project_all(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int gate_right, int with_dist,
-                       int* cap_out) {
-    int cap = 64;
+                       int* cap_out, int cap0 = 64) {
+    int cap = cap0;
+    bool first = true;
     for (;;) {
-        int rc = run_project(m, f, q, nq, cap, gate_right, with_dist);
+        int rc = run_project(m, f, q, nq, cap, gate_right, with_dist, first, true);
         if (rc) return rc;
+        first = false;
         int mx = 0;
         for (int i = 0; i < nq; i++) mx = std::max(mx, m->h_i1.p[i]);
         if (mx <= cap) break;
@@ -643,7 +1066,7 @@ int orbm_project_candidates(orbm_matcher* m, const orbm_frame* f, const orbm_que
     if (nq == 0) return ORB_OK;
     MORB_ARG(q && cand_idx && cand_dist && cand_count);
     MORB_HIP(hipSetDevice(m->device));
-    int rc = run_project(m, f, q, nq, cap_per_query, 1, 1);
+    int rc = run_project(m, f, q, nq, cap_per_query, 1, 1, true, true);
     if (rc) return rc;
     bool overflow = false;
     for (int i = 0; i < nq; i++) {
@@ -656,20 +1079,15 @@ int orbm_project_candidates(orbm_matcher* m, const orbm_frame* f, const orbm_que
     return ORB_OK;
 }
 
-int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,
-                              const uint8_t* occupied, int th_high, int check_orientation, int32_t* match_of_feature,
-                              int* nmatches) {
-    MORB_ARG(m && cur && nq >= 0 && nmatches && (cur->n_total == 0 || match_of_feature));
-    MORB_HIP(hipSetDevice(m->device));
-    for (int g = 0; g < cur->n_total; g++) match_of_feature[g] = -1;
-    *nmatches = 0;
-    if (nq == 0) return ORB_OK;
-    MORB_ARG(q != nullptr);
-    int cap = 0;
-    int rc = project_all(m, cur, q, nq, 1, 1, &cap);
+// Sequential resolve on the host from the ordered candidate lists (fallback of the device resolve; same semantics).
+static int host_resolve(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, const uint8_t* occupied,
+                        bool points, float nnratio, int th_high, int check_orientation, int cap0, int32_t* match_of_feature,
+                        int* nmatches) {
+    int rc = ensure_host_copies(cur);
     if (rc) return rc;
-    // Sequential first-come resolve in query order (reference src/ORBmatcher.cc:3502-3614): a feature claimed by a
-    // query whose MapPoint is observed is invisible to later queries; among the rest the first minimum wins.
+    int cap = 0;
+    if ((rc = project_all(m, cur, q, nq, 1, 1, &cap, cap0))) return rc;
+    for (int g = 0; g < cur->n_total; g++) match_of_feature[g] = -1;
     std::vector<int32_t> rot[ORBM_HISTO_LENGTH];
     const float factor = 1.0f / ORBM_HISTO_LENGTH;
     int nm = 0;
@@ -677,17 +1095,22 @@ int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm
         const int cnt = m->h_i1.p[i];
         const int32_t* ci = m->h_i0.p + (size_t)i * cap;
         const uint16_t* cd = m->h_u16.p + (size_t)i * cap;
-        int best = 256, bidx = -1;
+        int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
         for (int k = 0; k < cnt; k++) {
             const int g = ci[k];
             const int owner = match_of_feature[g];
             if (owner >= 0 ? q[owner].blocks != 0 : (occupied && occupied[g])) continue;
-            if ((int)cd[k] < best) { best = cd[k]; bidx = g; }
+            const int d = cd[k];
+            if (points) {
+                if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = cur->octave[g]; bidx = g; }
+                else if (d < best2) { lvl2 = cur->octave[g]; best2 = d; }
+            } else if (d < best) { best = d; bidx = g; }
         }
         if (best <= th_high && bidx >= 0) {
+            if (points && lvl == lvl2 && (float)best > nnratio * (float)best2) continue;
             match_of_feature[bidx] = i;
             nm++;
-            if (check_orientation) {
+            if (!points && check_orientation) {
                 float rotv = q[i].angle - cur->angle[bidx];
                 if (rotv < 0.0) rotv += 360.0f;
                 int bin = (int)roundf(rotv * factor);
@@ -696,7 +1119,7 @@ int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm
             }
         }
     }
-    if (check_orientation) {
+    if (!points && check_orientation) {
         int sizes[ORBM_HISTO_LENGTH], ind[3];
         for (int b = 0; b < ORBM_HISTO_LENGTH; b++) sizes[b] = (int)rot[b].size();
         orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, ind);
@@ -708,43 +1131,136 @@ int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm
     return ORB_OK;
 }
 
+// k_project + k_resolve on the device, one D2H of {status, matches}; falls back to host_resolve when the sweep limit is
+// hit, retries with a larger capacity when a candidate list overflowed.
+static int search_common(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, const uint8_t* occupied,
+                         bool points, float nnratio, int th_high, int check_orientation, int32_t* match_of_feature,
+                         int* nmatches) {
+    const int n = cur->n_total;
+    for (int g = 0; g < n; g++) match_of_feature[g] = -1;
+    *nmatches = 0;
+    if (nq == 0 || n == 0) return ORB_OK;
+    if (m->host_resolve)
+        return host_resolve(m, cur, q, nq, occupied, points, nnratio, th_high, check_orientation, 64, match_of_feature, nmatches);
+    int rc;
+    if ((rc = m->d_choice.reserve(nq)) || (rc = m->d_claim.reserve(n)) || (rc = m->d_match.reserve(n)) ||
+        (rc = m->d_status.reserve(4)) || (rc = m->h_match.reserve((size_t)n + 4)) || (rc = m->d_occ.reserve(std::max(n, 16))))
+        return rc;
+    if (occupied) MORB_HIP(hipMemcpyAsync(m->d_occ.p, occupied, (size_t)n, hipMemcpyHostToDevice, m->stream));
+    int cap = 64;
+    bool first = true;
+    for (;;) {
+        if ((rc = run_project(m, cur, q, nq, cap, 1, 1, first, false))) return rc;
+        first = false;
+        const uint8_t* d_occ = occupied ? m->d_occ.p : nullptr;
+        if (points)
+            hipLaunchKernelGGL(k_resolve<true>, dim3(1), dim3(1024), 0, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p,
+                               nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,
+                               (const float*)cur->b->d_ang.p, th_high, nnratio, 0, 256, m->d_choice.p, m->d_claim.p,
+                               m->d_match.p, m->d_status.p);
+        else
+            hipLaunchKernelGGL(k_resolve<false>, dim3(1), dim3(1024), 0, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p,
+                               nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,
+                               (const float*)cur->b->d_ang.p, th_high, nnratio, check_orientation, 256, m->d_choice.p,
+                               m->d_claim.p, m->d_match.p, m->d_status.p);
+        MORB_HIP(hipGetLastError());
+        MORB_HIP(hipMemcpyAsync(m->h_match.p, m->d_status.p, 16, hipMemcpyDeviceToHost, m->stream));
+        MORB_HIP(hipMemcpyAsync(m->h_match.p + 4, m->d_match.p, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+        MORB_HIP(hipStreamSynchronize(m->stream));
+        const int status = m->h_match.p[0];
+        if (status == 0) break;
+        if (status == 2) { cap = (m->h_match.p[3] + 63) & ~63; continue; }
+        // not converged within the sweep limit: exact host fallback
+        return host_resolve(m, cur, q, nq, occupied, points, nnratio, th_high, check_orientation, cap, match_of_feature, nmatches);
+    }
+    memcpy(match_of_feature, m->h_match.p + 4, (size_t)n * 4);
+    *nmatches = m->h_match.p[1];
+    return ORB_OK;
+}
+
+int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,
+                              const uint8_t* occupied, int th_high, int check_orientation, int32_t* match_of_feature,
+                              int* nmatches) {
+    MORB_ARG(m && cur && nq >= 0 && nmatches && (cur->n_total == 0 || match_of_feature) && (nq == 0 || q));
+    MORB_HIP(hipSetDevice(m->device));
+    return search_common(m, cur, q, nq, occupied, false, 0.f, th_high, check_orientation, match_of_feature, nmatches);
+}
+
 int orbm_search_by_projection_points(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,
                                      const uint8_t* occupied, float nnratio, int th_high, int32_t* match_of_feature,
                                      int* nmatches) {
-    MORB_ARG(m && cur && nq >= 0 && nmatches && (cur->n_total == 0 || match_of_feature));
+    MORB_ARG(m && cur && nq >= 0 && nmatches && (cur->n_total == 0 || match_of_feature) && (nq == 0 || q));
     MORB_HIP(hipSetDevice(m->device));
-    for (int g = 0; g < cur->n_total; g++) match_of_feature[g] = -1;
-    *nmatches = 0;
-    if (nq == 0) return ORB_OK;
-    MORB_ARG(q != nullptr);
     std::vector<orbm_query> q0(q, q + nq);
     for (auto& Q : q0) Q.cam = 0;  // camera-1 grid only (reference src/ORBmatcher.cc:88-89, src/Frame.cc:510-563)
-    int cap = 0;
-    int rc = project_all(m, cur, q0.data(), nq, 1, 1, &cap);
-    if (rc) return rc;
-    int nm = 0;
-    for (int i = 0; i < nq; i++) {
-        const int cnt = m->h_i1.p[i];
-        const int32_t* ci = m->h_i0.p + (size_t)i * cap;
-        const uint16_t* cd = m->h_u16.p + (size_t)i * cap;
-        int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
-        for (int k = 0; k < cnt; k++) {
-            const int g = ci[k];
-            if (occupied && occupied[g]) continue;
-            const int owner = match_of_feature[g];
-            if (owner >= 0 && q[owner].blocks) continue;
-            const int d = cd[k];
-            if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = cur->octave[g]; bidx = g; }
-            else if (d < best2) { lvl2 = cur->octave[g]; best2 = d; }
-        }
-        if (best <= th_high && bidx >= 0) {
-            if (lvl == lvl2 && (float)best > nnratio * (float)best2) continue;
-            match_of_feature[bidx] = i;
-            nm++;
-        }
+    return search_common(m, cur, q0.data(), nq, occupied, true, nnratio, th_high, 0, match_of_feature, nmatches);
+}
+
+// k_cross_top2 (+ merge) over `n` features in `d_desc` split into cameras by `d_cam_start`; queries [q_off, q_off+nq)
+static int cross_launch(orbm_matcher* m, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off, int nq,
+                        int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+    if (nq == 0) return ORB_OK;
+    const int qblocks = (nq + 63) / 64;
+    const int S = top2_slices(nq, n);
+    int rc;
+    if ((rc = m->d_i0.reserve(nq)) || (rc = m->d_i1.reserve(nq)) || (rc = m->d_i2.reserve(nq)) ||
+        (rc = m->d_scratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = m->h_i0.reserve(nq)) ||
+        (rc = m->h_i1.reserve(nq)) || (rc = m->h_i2.reserve(nq)))
+        return rc;
+    hipStream_t st = m->stream;
+    if (S <= 1) {
+        hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, 1), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
+                           n_cams, q_off, nq, m->d_i0.p, m->d_i1.p, m->d_i2.p);
+    } else {
+        int* p = (int*)m->d_scratch.p;
+        int *p_idx = p, *p_best = p + (size_t)S * nq, *p_second = p + 2 * (size_t)S * nq;
+        hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, S), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
+                           n_cams, q_off, nq, p_idx, p_best, p_second);
+        hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, m->d_i0.p,
+                           m->d_i1.p, m->d_i2.p);
     }
-    *nmatches = nm;
+    MORB_HIP(hipGetLastError());
+    MORB_HIP(hipMemcpyAsync(m->h_i0.p, m->d_i0.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    MORB_HIP(hipMemcpyAsync(m->h_i1.p, m->d_i1.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    MORB_HIP(hipMemcpyAsync(m->h_i2.p, m->d_i2.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    MORB_HIP(hipStreamSynchronize(st));
+    memcpy(best_idx, m->h_i0.p, (size_t)nq * 4); memcpy(best_dist, m->h_i1.p, (size_t)nq * 4);
+    memcpy(second_dist, m->h_i2.p, (size_t)nq * 4);
     return ORB_OK;
+}
+
+int orbm_cross_top2(orbm_matcher* m, const orbm_frame* f, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+    MORB_ARG(m && f);
+    MORB_HIP(hipSetDevice(m->device));
+    const int n = f->n_total;
+    if (n == 0) return ORB_OK;
+    MORB_ARG(best_idx && best_dist && second_dist);
+    return cross_launch(m, f->b->d_desc.p, n, f->b->d_cam_start.p, f->n_cams, 0, n, best_idx, best_dist, second_dist);
+}
+
+int orbm_cross_top2_blocks(orbm_matcher* m, const uint8_t* const* d_desc_blocks, const int* counts, int n_blocks,
+                           int first_query_block, int n_query_blocks, int32_t* best_idx, int32_t* best_dist,
+                           int32_t* second_dist) {
+    MORB_ARG(m && d_desc_blocks && counts && n_blocks >= 1 && n_blocks <= 512 && first_query_block >= 0 &&
+             n_query_blocks >= 0 && first_query_block + n_query_blocks <= n_blocks);
+    MORB_HIP(hipSetDevice(m->device));
+    std::vector<int> start(n_blocks + 1, 0);
+    for (int b = 0; b < n_blocks; ++b) { MORB_ARG(counts[b] >= 0); start[b + 1] = start[b] + counts[b]; }
+    const int n = start[n_blocks];
+    const int q_off = start[first_query_block], nq = start[first_query_block + n_query_blocks] - q_off;
+    if (nq == 0) return ORB_OK;
+    MORB_ARG(best_idx && best_dist && second_dist);
+    int rc;
+    if ((rc = m->d_r.reserve((size_t)n * 32)) || (rc = m->d_choice.reserve(n_blocks + 1))) return rc;
+    for (int b = 0; b < n_blocks; ++b)
+        if (counts[b]) {
+            MORB_ARG(d_desc_blocks[b] != nullptr);
+            MORB_HIP(hipMemcpyAsync(m->d_r.p + (size_t)start[b] * 32, d_desc_blocks[b], (size_t)counts[b] * 32,
+                                    hipMemcpyDeviceToDevice, m->stream));
+        }
+    MORB_HIP(hipMemcpyAsync(m->d_choice.p, start.data(), (size_t)(n_blocks + 1) * 4, hipMemcpyHostToDevice, m->stream));
+    MORB_HIP(hipStreamSynchronize(m->stream));  // `start` is a local
+    return cross_launch(m, m->d_r.p, n, m->d_choice.p, n_blocks, q_off, nq, best_idx, best_dist, second_dist);
 }
 
 }  // extern "C"

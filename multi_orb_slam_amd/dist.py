@@ -27,13 +27,12 @@ class DescriptorExchange:
         for c in range(self.n_cams):
             extractor.bind_output(c, self.send_kps[c].data_ptr(), self.send_desc[c].data_ptr(), self.cap)
 
-    def __call__(self, frontend, per_cam):
-        """-> (device pointers, counts, owning global camera) of every camera's descriptor block, global order."""
+    def __call__(self, frontend, counts):
+        """-> (device pointers, counts) of every camera's descriptor block of the whole rig, global camera order."""
         torch, dist = self.torch, self.dist
-        counts = [len(k) for k, _ in per_cam]
         self.send_cnt.copy_(torch.tensor(counts, dtype=torch.int32))
         if self.send_desc.is_cuda:
-            # descriptors were produced on the extractor's stream: make torch's stream wait for it
+            # descriptors were produced on the extractor's stream: make sure they have landed before RCCL reads them
             from . import rt
             rt.stream_sync(frontend.stream)
         dist.all_gather_into_tensor(self.recv_desc, self.send_desc)
@@ -42,7 +41,7 @@ class DescriptorExchange:
             torch.cuda.current_stream().synchronize()
         cnt = self.recv_cnt.cpu().numpy().tolist()
         ptrs = [self.recv_desc[g].data_ptr() for g in range(self.world * self.n_cams)]
-        return ptrs, cnt, list(range(self.world * self.n_cams))
+        return ptrs, cnt
 
 
 def shard_cameras(n_cameras, world_size, rank):

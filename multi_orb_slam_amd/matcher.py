@@ -2,7 +2,7 @@
 import ctypes as C
 import numpy as np
 from . import _lib
-from ._lib import QUERY_DTYPE, FrameDesc, check, ptr
+from ._lib import KP_DTYPE, QUERY_DTYPE, CamFeatures, FrameDesc, check, ptr
 
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # reference src/ORBmatcher.cc:37-39
 
@@ -50,12 +50,33 @@ class FrameData:
         return FrameData(cat(xs), cat(ys), cat(octs), cat(angs), ur, cat(cams), cat(locs), descs, (0, 0, width, height))
 
 
+class _Count:
+    def __init__(self, n_total, n_cams):
+        self.n_total, self.n_cams = n_total, n_cams
+
+
 class Frame:
-    def __init__(self, matcher, data):
-        self.data = data
-        self._h = C.c_void_p()
+    def __init__(self, matcher, data=None, handle=None, n_total=0, n_cams=0):
         self._m = matcher
-        check(_lib.lib().orbm_frame_create(matcher._h, C.byref(data.c), C.byref(self._h)))
+        if handle is not None:           # device-built frame (orbm_frame_from_device)
+            self._h = handle
+            self.data = _Count(n_total, n_cams)
+        else:
+            self.data = data
+            self._h = C.c_void_p()
+            check(_lib.lib().orbm_frame_create(matcher._h, C.byref(data.c), C.byref(self._h)))
+
+    def download(self, kps=True, desc=True, uright=True, depth=True):
+        """Host copies of the merged arrays of a device-built frame (global, cam-major order)."""
+        n = max(self.data.n_total, 1)
+        k = np.zeros(n, KP_DTYPE) if kps else None
+        d = np.zeros((n, 32), np.uint8) if desc else None
+        ur = np.zeros(n, np.float32) if uright else None
+        dp = np.zeros(n, np.float32) if depth else None
+        check(_lib.lib().orbm_frame_download(self._m._h, self._h, None if k is None else ptr(k), None if d is None else ptr(d),
+                                             None if ur is None else ptr(ur), None if dp is None else ptr(dp)))
+        nt = self.data.n_total
+        return tuple(None if a is None else a[:nt] for a in (k, d, ur, dp))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -127,6 +148,36 @@ class Matcher:
 
     def frame(self, data):
         return Frame(self, data)
+
+    def set_stream(self, stream):
+        check(_lib.lib().orbm_set_stream(self._h, C.c_void_p(stream) if stream else None))
+
+    def frame_from_device(self, cams, mbf, bounds):
+        """Frame assembly on the device (merge + depth -> uRight + grid) from HBM-resident per-camera outputs.
+        cams: [(d_kps, d_desc, n, d_depth or 0, depth_stride)]; bounds = (min_x, min_y, max_x, max_y)."""
+        arr = (CamFeatures * len(cams))(*[CamFeatures(c[0], c[1], c[2], c[3] or None, c[4]) for c in cams])
+        h = C.c_void_p()
+        check(_lib.lib().orbm_frame_from_device(self._h, arr, len(cams), mbf, bounds[0], bounds[1], bounds[2], bounds[3],
+                                                C.byref(h)))
+        return Frame(self, handle=h, n_total=sum(c[2] for c in cams), n_cams=len(cams))
+
+    def cross_top2_blocks(self, block_ptrs, counts, first_query_block, n_query_blocks):
+        """Cross-camera top-2 over HBM-resident descriptor blocks (one per camera of the whole rig)."""
+        nb = len(block_ptrs)
+        ptrs = (C.c_void_p * nb)(*block_ptrs)
+        cnt = (C.c_int * nb)(*counts)
+        nq = sum(counts[first_query_block:first_query_block + n_query_blocks])
+        bi = np.zeros(max(nq, 1), np.int32); bd = np.zeros(max(nq, 1), np.int32); sd = np.zeros(max(nq, 1), np.int32)
+        check(_lib.lib().orbm_cross_top2_blocks(self._h, ptrs, cnt, nb, first_query_block, n_query_blocks, ptr(bi), ptr(bd),
+                                                ptr(sd)))
+        return bi[:nq], bd[:nq], sd[:nq]
+
+    def cross_top2(self, frame):
+        n = max(frame.data.n_total, 1)
+        bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32); sd = np.zeros(n, np.int32)
+        check(_lib.lib().orbm_cross_top2(self._h, frame._h, ptr(bi), ptr(bd), ptr(sd)))
+        nt = frame.data.n_total
+        return bi[:nt], bd[:nt], sd[:nt]
 
     def features_in_area(self, frame, cam, x, y, r, min_level=-1, max_level=-1):
         out = np.zeros(max(frame.data.n_total, 1), np.int32); n = C.c_int()

@@ -826,6 +826,18 @@ int orc_extract(const uint8_t* img, int W, int H, int stride, int nfeatures, flo
 
 int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
 
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:959-986): depth lookup at (int)v,(int)u, virtual right coordinate.
+// Undistorted x == distorted x (k1 == 0, src/Frame.cc:676-680).
+void orc_stereo_from_depth(const KeyPoint* kps, int n, const float* depth, int stride, float mbf, float* uright,
+                           float* depth_out) {
+    for (int i = 0; i < n; i++) {
+        uright[i] = -1; depth_out[i] = -1;
+        const float v = kps[i].y, u = kps[i].x;
+        const float d = depth[(size_t)(int)v * stride + (int)u];
+        if (d > 0) { depth_out[i] = d; uright[i] = kps[i].x - mbf / d; }
+    }
+}
+
 // a12 brute-force top-2 (ORBmatcher.cc:287-321 inner loop over an unrestricted candidate set, App. A-9):
 // best_idx = -1 / best = second = 256 when nothing is closer than 256.
 void orc_bf_top2(const uint8_t* q, int nq, const uint8_t* r, int nr, int* best_idx, int* best_dist, int* second_dist) {

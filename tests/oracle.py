@@ -206,6 +206,15 @@ def descriptor_distance(a, b):
     return lib().orc_descriptor_distance(_p(a), _p(b))
 
 
+def stereo_from_depth(kps, depth, mbf):
+    kps = np.ascontiguousarray(kps, KP_DTYPE); depth = np.ascontiguousarray(depth, np.float32)
+    ur = np.zeros(len(kps), np.float32); dd = np.zeros(len(kps), np.float32)
+    L = lib()
+    L.orc_stereo_from_depth.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_stereo_from_depth(_p(kps), len(kps), _p(depth), depth.shape[1], mbf, _p(ur), _p(dd))
+    return ur, dd
+
+
 def bf_top2(q, r):
     q = _u8(q); r = _u8(r)
     bi = np.zeros(len(q), np.int32); bd = np.zeros(len(q), np.int32); sd = np.zeros(len(q), np.int32)

@@ -136,3 +136,98 @@ def test_no_device_fallback_is_an_error():
     import multi_orb_slam_amd as m
     with pytest.raises(m.OrbError):
         m.Matcher(device=99)
+
+
+# ------------------------------------------------------------------------------------------------ device-resident frame
+def _depth_image(w, h, seed):
+    d = 0.5 + (helpers.rand_unit(w * h, seed) * 8).astype(np.float32).reshape(h, w)
+    d[helpers.rand_unit(w * h, seed + 1).reshape(h, w) < 0.15] = 0.0      # holes: no depth -> uRight = -1
+    return d.astype(np.float32)
+
+
+@pytest.mark.parametrize("sizes", [[(640, 480, 1000), (640, 480, 500)], [(320, 240, 300)]])
+def test_frame_from_device_matches_host_assembly(matcher, sizes):
+    """Merge + ComputeStereoFromRGBD + AssignFeaturesToGrid on the device == oracle on the same keypoints."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import rt
+    W, H = sizes[0][0], sizes[0][1]
+    ex = m.Extractor([m.ExtractorParams(nfeatures=nf) for _, _, nf in sizes], W, H)
+    imgs = [synth.image(c, 0, W, H) for c in range(len(sizes))]
+    per_cam = ex.extract(imgs)
+    depths = [_depth_image(W, H, 50 + c) for c in range(len(sizes))]
+    dbufs = []
+    for d in depths:
+        b = rt.DeviceBuffer(d.nbytes); b.upload(d); dbufs.append(b)
+    matcher.set_stream(ex.stream)
+    cams = [(ex.device_keypoints(c), ex.device_descriptors(c), len(per_cam[c][0]), dbufs[c].ptr, W) for c in range(len(sizes))]
+    F = matcher.frame_from_device(cams, 40.0, (0, 0, W, H))
+    k, d, ur, dp = F.download()
+    ek = np.concatenate([p[0] for p in per_cam]); ed = np.concatenate([p[1] for p in per_cam])
+    assert k.tobytes() == ek.tobytes() and np.array_equal(d, ed)
+    eur = []; edp = []
+    for c in range(len(sizes)):
+        a, b = oracle.stereo_from_depth(per_cam[c][0], depths[c], 40.0)
+        eur.append(a); edp.append(b)
+    eur = np.concatenate(eur); edp = np.concatenate(edp)
+    assert np.array_equal(ur.view(np.uint32), eur.view(np.uint32)) and np.array_equal(dp.view(np.uint32), edp.view(np.uint32))
+    assert (ur > 0).sum() > len(ur) // 2 and (ur < 0).sum() > 10
+    # grid
+    cam_of = np.concatenate([np.full(len(p[0]), c, np.int32) for c, p in enumerate(per_cam)])
+    loc = np.concatenate([np.arange(len(p[0]), dtype=np.int32) for p in per_cam])
+    OF = oracle.FrameData(ek["x"], ek["y"], ek["octave"], ek["angle"], eur, cam_of, loc, [p[1] for p in per_cam], (0, 0, W, H))
+    cs, items = F.grid(); ocs, oitems = oracle.grid_csr(OF)
+    assert np.array_equal(cs, ocs) and np.array_equal(items, oitems)
+    # searches on the device-built frame
+    fr = dict(un_x=ek["x"], un_y=ek["y"], octave=ek["octave"], angle=ek["angle"], uright=eur, cam_of=cam_of, local_of=loc,
+              descs=[p[1] for p in per_cam], bounds=(0.0, 0.0, float(W), float(H)))
+    q = helpers.make_queries(fr, 1500, 3, th=15.0)
+    n, mo = matcher.SearchByProjection(F, q)
+    on, omo = oracle.search_by_projection_frames(OF, q, 100, True)
+    assert n == on and np.array_equal(mo, omo) and n > 100
+    # cross-camera top-2 in one launch
+    bi, bd, sd = matcher.cross_top2(F)
+    off = 0
+    for c, p in enumerate(per_cam):
+        others = [pp[1] for o, pp in enumerate(per_cam) if o != c]
+        refs = np.concatenate(others) if others else np.zeros((0, 32), np.uint8)
+        ebi, ebd, esd = oracle.bf_top2(p[1], refs)
+        nc = len(p[0])
+        assert np.array_equal(bi[off:off + nc], ebi) and np.array_equal(bd[off:off + nc], ebd) and np.array_equal(sd[off:off + nc], esd)
+        off += nc
+    F.close(); matcher.set_stream(None); ex.close()
+
+
+def test_device_resolve_long_dependency_chains_and_host_fallback_agree():
+    """Adversarial first-come chains: many identical queries fight over the same few features, so the Jacobi sweeps of
+    the device resolve have to propagate claims query by query.  Device resolve, host resolve (MORB_HOST_RESOLVE=1)
+    and the oracle must agree exactly."""
+    import os
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd._lib import QUERY_DTYPE
+    n = 400
+    fr = helpers.make_frame_arrays([n], 640, 480, 9, with_right=False)
+    fr["un_x"] = (100 + (np.arange(n) % 20) * 2).astype(np.float32); fr["un_y"] = (100 + (np.arange(n) // 20) * 2).astype(np.float32)
+    fr["octave"][:] = 0
+    fr["descs"][0][:] = synth.descriptors(1, 5)[0]            # all features identical: pure order decides
+    nq = 600
+    q = np.zeros(nq, QUERY_DTYPE)
+    q["u"] = 120; q["v"] = 120; q["radius"] = 60; q["ur"] = -1; q["min_level"] = -1; q["max_level"] = -1; q["cam"] = 0
+    q["blocks"] = 1; q["angle"] = fr["angle"][0]; q["desc"] = synth.descriptors(1, 5)[0]
+    q["blocks"][::7] = 0                                     # a few non-blocking claims that later queries overwrite
+    OF = oracle.FrameData(**fr)
+    results = []
+    for env in ("0", "1"):
+        os.environ["MORB_HOST_RESOLVE"] = env
+        mt = m.Matcher(0.8, False)
+        F = mt.frame(m.FrameData(**fr))
+        results.append(mt.SearchByProjection(F, q))
+        cntp, mop = mt.SearchByProjectionPoints(F, q)
+        results.append((cntp, mop))
+        F.close(); mt.close()
+    os.environ.pop("MORB_HOST_RESOLVE")
+    on, omo = oracle.search_by_projection_frames(OF, q, 100, False)
+    onp, omop = oracle.search_by_projection_points(OF, q, None, 0.8, 100)
+    for k, (cnt, mo) in enumerate(results):
+        e_n, e_m = (on, omo) if k % 2 == 0 else (onp, omop)
+        assert cnt == e_n and np.array_equal(mo, e_m), k
+    assert on >= n                                           # every feature ends up claimed
