@@ -40,6 +40,8 @@ void* orbm_stream(const orbm_matcher* m);
 /* Make the matcher issue all its work on a caller-owned hipStream_t (e.g. orbx_stream(ex), so frame building and
  * matching are ordered after the extractor's kernels without events); NULL restores the matcher's own stream. */
 int orbm_set_stream(orbm_matcher* m, void* stream);
+/* {status, nmatches, sweeps, longest candidate list} of the last device-side resolve (inspection only) */
+int orbm_debug_last_resolve(const orbm_matcher* m, int* out4);
 
 /* host helper, identical result to the reference's SWAR popcount; rows need 1-byte alignment only */
 int orbm_descriptor_distance(const uint8_t* a, const uint8_t* b);

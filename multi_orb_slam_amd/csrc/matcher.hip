@@ -250,11 +250,22 @@ struct FrameDev {
     float minX, minY, invW, invH;
 };
 
-// One wave per query.  Visits cells ix (outer) / iy (inner) and items in ascending order -- App. A-8 -- so the
-// compacted output order is exactly the reference's candidate order (it decides distance ties).
+// One wave per query.  The window's grid cells are enumerated ix (outer) / iy (inner) -- the reference's visiting
+// order, App. A-8 -- 64 cells at a time, one per lane: every lane fetches its cell's [start, end) in parallel, a wave
+// prefix sum turns the counts into ordered item positions, then the items are tested 64 at a time and the survivors
+// compacted with a ballot.  The output order is exactly the reference's candidate order (it decides distance ties);
+// the dependent-load chain is per 64 cells instead of per cell.
+// Output layout: element k of query i at [i*cap + k] (TRANSPOSED == 0) or [k*nq + i] (TRANSPOSED == 1, coalesced for
+// the thread-per-query resolve kernel).
+// With `topk` != NULL the wave also keeps the RESOLVE_K smallest (distance << 16 | position) keys of its non-occupied
+// survivors, sorted, and writes them (+ their feature indices) at topk[k*nq + i] / topk[(K + k)*nq + i]: the shortlist
+// the resolve kernel sweeps over.
+constexpr int RESOLVE_K = 6;
+
 __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap,
-                                                 int gate_right, int with_dist, int* __restrict__ cand_idx,
-                                                 uint16_t* __restrict__ cand_dist, int* __restrict__ cand_count) {
+                                                 int gate_right, int with_dist, int transposed, int* __restrict__ cand_idx,
+                                                 uint16_t* __restrict__ cand_dist, int* __restrict__ cand_count,
+                                                 const uint8_t* __restrict__ occupied, int* __restrict__ topk) {
     const int lane = threadIdx.x & 63;
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (qi >= nq) return;
@@ -265,49 +276,102 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
     const uint4 q0 = make_uint4(qd[0], qd[1], qd[2], qd[3]), q1 = make_uint4(qd[4], qd[5], qd[6], qd[7]);
 
     int total = 0;
+    int sk[RESOLVE_K], sg[RESOLVE_K];  // wave-uniform sorted shortlist
+#pragma unroll
+    for (int k = 0; k < RESOLVE_K; ++k) { sk[k] = 0x7fffffff; sg[k] = -1; }
     const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.invW));
     const int nMaxCellX = min(ORBM_GRID_COLS - 1, (int)ceilf((x - F.minX + r) * F.invW));
     const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.invH));
     const int nMaxCellY = min(ORBM_GRID_ROWS - 1, (int)ceilf((y - F.minY + r) * F.invH));
     const bool ok = nMinCellX < ORBM_GRID_COLS && nMaxCellX >= 0 && nMinCellY < ORBM_GRID_ROWS && nMaxCellY >= 0 &&
-                    cam >= 0 && cam < F.n_cams;
+                    nMinCellX <= nMaxCellX && nMinCellY <= nMaxCellY && cam >= 0 && cam < F.n_cams;
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
     if (ok) {
-        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
-            for (int iy = nMinCellY; iy <= nMaxCellY; ++iy) {
+        const int ny = nMaxCellY - nMinCellY + 1, ncells = (nMaxCellX - nMinCellX + 1) * ny;
+        for (int cbase = 0; cbase < ncells; cbase += 64) {
+            // this lane's cell of the chunk
+            const int ci = cbase + lane;
+            int cs = 0, cn = 0;
+            if (ci < ncells) {
+                const int ix = nMinCellX + ci / ny, iy = nMinCellY + ci % ny;
                 const int cell = (cam * ORBM_GRID_COLS + ix) * ORBM_GRID_ROWS + iy;
-                const int s = F.cell_start[cell], e = F.cell_start[cell + 1];
-                for (int base = s; base < e; base += 64) {
-                    const int k = base + lane;
-                    const bool valid = k < e;
-                    const int g = valid ? F.items[k] : 0;
-                    bool pass = valid;
-                    if (pass && bCheckLevels) {
-                        const int oct = F.octave[g];
-                        if (oct < minLevel) pass = false;
-                        if (maxLevel >= 0 && oct > maxLevel) pass = false;
-                    }
-                    if (pass) {
-                        const float distx = F.un_x[g] - x, disty = F.un_y[g] - y;
-                        pass = fabsf(distx) < r && fabsf(disty) < r;
-                    }
-                    if (pass && gate_right) {
-                        const float urg = F.uright[g];
-                        if (urg > 0 && fabsf(ur - urg) > r) pass = false;
-                    }
-                    const unsigned long long mask = __ballot(pass);
-                    const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (pass && pos < cap) {
-                        const size_t o = (size_t)qi * cap + pos;
-                        cand_idx[o] = g;
-                        if (with_dist) cand_dist[o] = (uint16_t)ham256(q0, q1, F.desc[2 * g], F.desc[2 * g + 1]);
-                    }
-                    total += __popcll(mask);
+                cs = F.cell_start[cell];
+                cn = F.cell_start[cell + 1] - cs;
+            }
+            int incl = cn;  // inclusive prefix of the item counts over the lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const int items_in_chunk = __shfl(incl, 63);
+            const int excl = incl - cn;
+            for (int tbase = 0; tbase < items_in_chunk; tbase += 64) {
+                const int t = tbase + lane;  // t-th item of the chunk in (cell, ascending index) order
+                const bool valid = t < items_in_chunk;
+                // owner lane = first lane whose inclusive prefix exceeds t (binary search over the wave)
+                int lo = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int probe = lo + step - 1;
+                    const int pv = __shfl(incl, probe);
+                    if (pv <= t) lo += step;
                 }
+                const int oexcl = __shfl(excl, lo), ostart = __shfl(cs, lo);
+                const int g = valid ? F.items[ostart + (t - oexcl)] : 0;
+                bool pass = valid;
+                if (pass && bCheckLevels) {
+                    const int oct = F.octave[g];
+                    if (oct < minLevel) pass = false;
+                    if (maxLevel >= 0 && oct > maxLevel) pass = false;
+                }
+                if (pass) {
+                    const float distx = F.un_x[g] - x, disty = F.un_y[g] - y;
+                    pass = fabsf(distx) < r && fabsf(disty) < r;
+                }
+                if (pass && gate_right) {
+                    const float urg = F.uright[g];
+                    if (urg > 0 && fabsf(ur - urg) > r) pass = false;
+                }
+                const unsigned long long mask = __ballot(pass);
+                const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
+                int dist = 0;
+                if (pass && with_dist) dist = ham256(q0, q1, F.desc[2 * g], F.desc[2 * g + 1]);
+                if (pass && pos < cap) {
+                    const size_t o = transposed ? (size_t)pos * nq + qi : (size_t)qi * cap + pos;
+                    cand_idx[o] = g;
+                    if (with_dist) cand_dist[o] = (uint16_t)dist;
+                }
+                if (topk) {  // merge this batch's survivors into the sorted shortlist (at most RESOLVE_K extractions)
+                    int key = (pass && !(occupied && occupied[g])) ? ((dist << 16) | pos) : 0x7fffffff;
+#pragma unroll
+                    for (int e = 0; e < RESOLVE_K; ++e) {
+                        int mn = key;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+                        if (mn >= sk[RESOLVE_K - 1]) break;  // wave-uniform: nothing left that beats the shortlist tail
+                        const int mg = __shfl(g, __ffsll((long long)__ballot(key == mn)) - 1);
+                        if (key == mn) key = 0x7fffffff;     // positions are unique, so exactly one lane matches
+                        int ck = mn, cg = mg;
+#pragma unroll
+                        for (int j = 0; j < RESOLVE_K; ++j)
+                            if (ck < sk[j]) { const int tk = sk[j], tg = sg[j]; sk[j] = ck; sg[j] = cg; ck = tk; cg = tg; }
+                    }
+                }
+                total += __popcll(mask);
             }
         }
     }
-    if (lane == 0) cand_count[qi] = total;
+    if (lane == 0) {
+        cand_count[qi] = total;
+        if (topk) {
+#pragma unroll
+            for (int k = 0; k < RESOLVE_K; ++k) {
+                topk[(size_t)k * nq + qi] = sk[k];
+                topk[(size_t)(RESOLVE_K + k) * nq + qi] = sg[k];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ device frame build
@@ -402,22 +466,31 @@ __global__ __launch_bounds__(256) void k_sort_cells(const int* __restrict__ star
 // < q, and the sequential answer is the unique fixed point of:  choice[q] = first arg-min over q's ordered candidates
 // that are not occupied and not claimed by a blocking query q' < q.  One workgroup iterates that map (Jacobi) until
 // nothing changes -- after k sweeps the first k queries are final, in practice a handful of sweeps suffice.
+// The claim table lives in LDS (one int per feature); entries carry the sweep number in the high 16 bits, decreasing,
+// so atomicMin both selects the newest sweep and the lowest query index and no reset pass is needed.
+// Candidates are read in the transposed layout [k*nq + i] (coalesced across the thread-per-query mapping).
 // status[0]: 0 ok, 1 not converged within max_it (host falls back), 2 a candidate list exceeded cap (host retries);
 // status[1] = nmatches, status[2] = sweeps, status[3] = longest candidate list.
+constexpr int RESOLVE_MAX_Q = 65535;
+// RESOLVE_K (above): sorted shortlist per query built by k_project; a full rescan happens only when all of it is taken
+
+// Evaluates query i against the current claim table.  `avail(g)` decides visibility.  Candidates are visited in the
+// order given; FRAMES: first minimum.  POINTS: best + second (with multiplicity) and their levels.
 template <bool POINTS>
 __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap,
                                                   const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
                                                   const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
                                                   const float* __restrict__ f_angle, int th_high, float nnratio,
                                                   int check_ori, int max_it, int* __restrict__ choice,
-                                                  int* claim_min, int* __restrict__ match_of_feature,
-                                                  int* __restrict__ status) {
+                                                  const int* __restrict__ topk /* 2*RESOLVE_K*nq ints */,
+                                                  int* __restrict__ match_of_feature, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) int s_claim[];  // F.n_total entries
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_keep[3];
     __shared__ int s_red;
     const int tid = threadIdx.x, T = blockDim.x;
-    // longest list
     if (tid == 0) s_red = 0;
+    for (int g = tid; g < F.n_total; g += T) s_claim[g] = 0x7fffffff;
     __syncthreads();
     int mx = 0;
     for (int i = tid; i < nq; i += T) { mx = max(mx, cand_count[i]); choice[i] = -1; }
@@ -428,33 +501,51 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         if (tid == 0) { status[0] = 2; status[1] = 0; status[2] = 0; status[3] = maxcount; }
         return;
     }
+    // shortlist written by k_project: keys (dist << 16 | visiting position) and feature indices, sorted, occupied excluded
+    const int* tk_key = topk;                             // [k*nq + i]
+    const int* tk_g = topk + (size_t)RESOLVE_K * nq;      // [k*nq + i]
     int it = 0, changed = 1;
     for (; it < max_it && changed; ++it) {
-        // claim_min is updated with L2 atomics: read and reset it with agent-scope accesses so no sweep can see a
-        // stale per-CU L1 copy of an earlier sweep's value
-        for (int g = tid; g < F.n_total; g += T) __hip_atomic_store(&claim_min[g], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
+        const int tag = (0x7ffe - it) << 16;  // newer sweep -> smaller tag -> wins atomicMin over stale entries
         for (int i = tid; i < nq; i += T) {
             const int c = choice[i];
-            if (c >= 0 && q[i].blocks) atomicMin(&claim_min[c], i);
+            const int bl = q[i].blocks;      // loaded unconditionally: both loads are in flight together
+            if (c >= 0 && bl) atomicMin(&s_claim[c], tag | i);
         }
         __syncthreads();
         int ch = 0;
         for (int i = tid; i < nq; i += T) {
+            // the whole shortlist is fetched up front (12 independent coalesced loads in flight), then walked
+            int sg[RESOLVE_K], sd[RESOLVE_K];
+#pragma unroll
+            for (int k = 0; k < RESOLVE_K; ++k) { sg[k] = tk_g[(size_t)k * nq + i]; sd[k] = tk_key[(size_t)k * nq + i] >> 16; }
             const int cnt = cand_count[i];
-            const int* ci = cand_idx + (size_t)i * cap;
-            const uint16_t* cd = cand_dist + (size_t)i * cap;
+            const int old = choice[i];
             int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
-            for (int k = 0; k < cnt; ++k) {
-                const int g = ci[k];
-                if (occupied && occupied[g]) continue;
-                if (__hip_atomic_load(&claim_min[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) continue;
-                const int d = cd[k];
-                if (POINTS) {
-                    if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = F.octave[g]; bidx = g; }
-                    else if (d < best2) { lvl2 = F.octave[g]; best2 = d; }
-                } else {
-                    if (d < best) { best = d; bidx = g; }
+            int found = 0, taken = 0;
+#pragma unroll
+            for (int k = 0; k < RESOLVE_K; ++k) {
+                const int g = sg[k];
+                if (g < 0 || found >= (POINTS ? 2 : 1)) continue;
+                const int cl = s_claim[g];
+                if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) { ++taken; continue; }
+                if (found == 0) { best = sd[k]; bidx = g; if (POINTS) lvl = F.octave[g]; }
+                else { best2 = sd[k]; lvl2 = F.octave[g]; }
+                ++found;
+            }
+            // the shortlist is exact unless it ran dry while longer lists exist: rescan everything (rare)
+            if (found < (POINTS ? 2 : 1) && cnt > RESOLVE_K && taken > 0) {
+                best = 256; best2 = 256; lvl = -1; lvl2 = -1; bidx = -1;
+                for (int k = 0; k < cnt; ++k) {
+                    const int g = cand_idx[(size_t)k * nq + i];
+                    if (occupied && occupied[g]) continue;
+                    const int cl = s_claim[g];
+                    if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) continue;
+                    const int d = cand_dist[(size_t)k * nq + i];
+                    if (POINTS) {
+                        if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = F.octave[g]; bidx = g; }
+                        else if (d < best2) { lvl2 = F.octave[g]; best2 = d; }
+                    } else if (d < best) { best = d; bidx = g; }
                 }
             }
             int nc = -1;
@@ -462,7 +553,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 nc = bidx;
                 if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
             }
-            if (nc != choice[i]) { ch = 1; choice[i] = nc; }
+            if (nc != old) { ch = 1; choice[i] = nc; }
         }
         changed = __syncthreads_or(ch);
     }
@@ -471,7 +562,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         return;
     }
     // owners: the last claimant in query order (claims after a blocking one are impossible, so max index == final owner)
-    for (int g = tid; g < F.n_total; g += T) match_of_feature[g] = -1;
+    for (int g = tid; g < F.n_total; g += T) s_claim[g] = -1;
     if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
     if (tid == 0) s_red = 0;
     __syncthreads();
@@ -481,7 +572,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         const int c = choice[i];
         if (c < 0) continue;
         ++acc;
-        atomicMax(&match_of_feature[c], i);
+        atomicMax(&s_claim[c], i);
         if (!POINTS && check_ori) {
             float rot = q[i].angle - f_angle[c];
             if (rot < 0.0) rot += 360.0f;
@@ -515,17 +606,17 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             int bin = (int)roundf(rot * factor);
             if (bin == ORBM_HISTO_LENGTH) bin = 0;
             if (bin >= 0 && bin < ORBM_HISTO_LENGTH && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
-                match_of_feature[c] = -2;  // every writer stores -2; owners were settled before the barrier
+                s_claim[c] = -2;  // every writer stores -2; owners were settled before the barrier
                 ++rej;
             }
         }
         atomicSub(&s_red, rej);
         __syncthreads();
     }
+    for (int g = tid; g < F.n_total; g += T) match_of_feature[g] = s_claim[g];
     if (tid == 0) { status[0] = 0; status[1] = s_red; status[2] = it; status[3] = maxcount; }
 }
 
-// Cross-camera top-2 in one launch: lane = query feature g, references = every feature outside g's camera segment.
 // Queries are features [q_off, q_off + nq) (the cameras this process owns); outputs are indexed from 0.
 __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __restrict__ desc, int n_total,
                                                                 const int* __restrict__ cam_start, int n_cams, int q_off,
@@ -646,6 +737,7 @@ struct orbm_matcher {
     PinnedBuf<uint8_t> h_ring;  // 4 slots of {CamFeat[64], int cam_start[65]} for asynchronous H2D
     unsigned ring_pos = 0;
     std::vector<FrameBufs*> pool;  // free list
+    int last_status[4] = {0, 0, 0, 0};  // {status, nmatches, sweeps, longest list} of the last device resolve
     bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
 };
 
@@ -736,6 +828,12 @@ void orbm_destroy(orbm_matcher* m) {
 }
 
 void* orbm_stream(const orbm_matcher* m) { return m ? (void*)m->stream : nullptr; }
+
+int orbm_debug_last_resolve(const orbm_matcher* m, int* out4) {
+    MORB_ARG(m && out4);
+    for (int k = 0; k < 4; ++k) out4[k] = m->last_status[k];
+    return ORB_OK;
+}
 
 int orbm_set_stream(orbm_matcher* m, void* stream) {
     MORB_ARG(m != nullptr);
@@ -1006,7 +1104,8 @@ int orbm_frame_grid(const orbm_frame* f, int32_t* cell_start, int32_t* items) {
 
 // k_project into m->d_i0 (idx) / d_u16 (dist) / d_i1 (count); optionally copied to the pinned host mirrors
 static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap, int gate_right,
-                       int with_dist, bool upload_queries, bool to_host) {
+                       int with_dist, bool upload_queries, bool to_host, int transposed = 0,
+                       const uint8_t* d_occupied = nullptr, int* d_topk = nullptr) {
     int rc;
     if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_i0.reserve((size_t)nq * cap)) ||
         (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)))
@@ -1014,7 +1113,8 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
     if (upload_queries)
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, q, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_project, dim3((nq + 3) / 4), dim3(256), 0, m->stream, f->dev(),
-                       (const orbm_query*)m->d_queries.p, nq, cap, gate_right, with_dist, m->d_i0.p, m->d_u16.p, m->d_i1.p);
+                       (const orbm_query*)m->d_queries.p, nq, cap, gate_right, with_dist, transposed, m->d_i0.p, m->d_u16.p,
+                       m->d_i1.p, d_occupied, d_topk);
     MORB_HIP(hipGetLastError());
     if (to_host) {
         if ((rc = m->h_i0.reserve((size_t)nq * cap)) || (rc = m->h_u16.reserve((size_t)nq * cap)) || (rc = m->h_i1.reserve(nq)))
@@ -1140,34 +1240,41 @@ static int search_common(orbm_matcher* m, const orbm_frame* cur, const orbm_quer
     for (int g = 0; g < n; g++) match_of_feature[g] = -1;
     *nmatches = 0;
     if (nq == 0 || n == 0) return ORB_OK;
-    if (m->host_resolve)
+    const size_t lds = (size_t)n * sizeof(int);
+    if (m->host_resolve || nq > RESOLVE_MAX_Q || lds > 150 * 1024)  // claim table must fit the 160 KB LDS of one CU
         return host_resolve(m, cur, q, nq, occupied, points, nnratio, th_high, check_orientation, 64, match_of_feature, nmatches);
+    if (lds > 48 * 1024) {  // large claim tables need the opt-in dynamic LDS limit (once per process)
+        static bool raised = false;
+        if (!raised) {
+            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            raised = true;
+        }
+    }
     int rc;
-    if ((rc = m->d_choice.reserve(nq)) || (rc = m->d_claim.reserve(n)) || (rc = m->d_match.reserve(n)) ||
+    if ((rc = m->d_choice.reserve(nq)) || (rc = m->d_claim.reserve((size_t)2 * RESOLVE_K * nq)) || (rc = m->d_match.reserve(n)) ||
         (rc = m->d_status.reserve(4)) || (rc = m->h_match.reserve((size_t)n + 4)) || (rc = m->d_occ.reserve(std::max(n, 16))))
         return rc;
     if (occupied) MORB_HIP(hipMemcpyAsync(m->d_occ.p, occupied, (size_t)n, hipMemcpyHostToDevice, m->stream));
     int cap = 64;
     bool first = true;
     for (;;) {
-        if ((rc = run_project(m, cur, q, nq, cap, 1, 1, first, false))) return rc;
-        first = false;
         const uint8_t* d_occ = occupied ? m->d_occ.p : nullptr;
-        if (points)
-            hipLaunchKernelGGL(k_resolve<true>, dim3(1), dim3(1024), 0, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p,
-                               nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,
-                               (const float*)cur->b->d_ang.p, th_high, nnratio, 0, 256, m->d_choice.p, m->d_claim.p,
-                               m->d_match.p, m->d_status.p);
-        else
-            hipLaunchKernelGGL(k_resolve<false>, dim3(1), dim3(1024), 0, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p,
-                               nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,
-                               (const float*)cur->b->d_ang.p, th_high, nnratio, check_orientation, 256, m->d_choice.p,
-                               m->d_claim.p, m->d_match.p, m->d_status.p);
+        if ((rc = run_project(m, cur, q, nq, cap, 1, 1, first, false, /*transposed=*/1, d_occ, m->d_claim.p))) return rc;
+        first = false;
+#define MORB_RESOLVE_LAUNCH(PT)                                                                                          \
+    hipLaunchKernelGGL((k_resolve<PT>), dim3(1), dim3(1024), lds, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, \
+                       nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
+                       (const float*)cur->b->d_ang.p, th_high, nnratio, points ? 0 : check_orientation, 256, m->d_choice.p,   \
+                       (const int*)m->d_claim.p, m->d_match.p, m->d_status.p)
+        if (points) MORB_RESOLVE_LAUNCH(true); else MORB_RESOLVE_LAUNCH(false);
+#undef MORB_RESOLVE_LAUNCH
         MORB_HIP(hipGetLastError());
         MORB_HIP(hipMemcpyAsync(m->h_match.p, m->d_status.p, 16, hipMemcpyDeviceToHost, m->stream));
         MORB_HIP(hipMemcpyAsync(m->h_match.p + 4, m->d_match.p, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
         MORB_HIP(hipStreamSynchronize(m->stream));
         const int status = m->h_match.p[0];
+        for (int k = 0; k < 4; ++k) m->last_status[k] = m->h_match.p[k];
         if (status == 0) break;
         if (status == 2) { cap = (m->h_match.p[3] + 63) & ~63; continue; }
         // not converged within the sweep limit: exact host fallback

@@ -83,7 +83,8 @@ def test_grid_and_area_queries(matcher, n_per_cam, seed):
 
 @pytest.mark.parametrize("n_per_cam,nq,th,blocks,seed", [([1000, 500], 1200, 15.0, 1, 1), ([1000, 1000], 2500, 30.0, 1, 2),
                                                         ([300, 200], 900, 15.0, 2, 3), ([2000, 2000], 3000, 15.0, 0, 4),
-                                                        ([64], 10, 7.0, 1, 5)])
+                                                        ([64], 10, 7.0, 1, 5), ([1000, 1000], 2000, 30.0, 1, 6),
+                                                        ([1000, 1000], 4000, 30.0, 1, 7)])
 def test_search_by_projection_frames(matcher, n_per_cam, nq, th, blocks, seed):
     import multi_orb_slam_amd as m
     fr = helpers.make_frame_arrays(n_per_cam, 640, 480, seed)
@@ -231,3 +232,15 @@ def test_device_resolve_long_dependency_chains_and_host_fallback_agree():
         e_n, e_m = (on, omo) if k % 2 == 0 else (onp, omop)
         assert cnt == e_n and np.array_equal(mo, e_m), k
     assert on >= n                                           # every feature ends up claimed
+
+
+def test_projection_search_large_frame_uses_big_lds_claim_table(matcher):
+    """8 cameras x 4000 features (configs[4] scale): 32000-entry claim table (128 KB of LDS), wide windows."""
+    import multi_orb_slam_amd as m
+    fr = helpers.make_frame_arrays([4000] * 8, 1920, 1080, 17)
+    q = helpers.make_queries(fr, 20000, 23, th=30.0)
+    F = matcher.frame(m.FrameData(**fr)); OF = oracle.FrameData(**fr)
+    n, mo = matcher.SearchByProjection(F, q)
+    on, omo = oracle.search_by_projection_frames(OF, q, 100, True)
+    assert n == on and np.array_equal(mo, omo) and n > 5000
+    F.close()
