@@ -1,0 +1,69 @@
+/* orbf.h -- one front-end timestep as ONE C call: N-camera extraction, frame assembly and the tracking-path matcher
+ * searches, enqueued back to back on one HIP stream with a single host synchronisation at the end.
+ *
+ * This is the batched form of what the reference does per frame on its tracking thread:
+ *   Frame::Frame (reference src/Frame.cc:148-288): ExtractORB + ExtractORB_cam2, the `_total` merge,
+ *     ComputeStereoFromRGBD, AssignFeaturesToGrid                                    -> extraction + device frame build
+ *   ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, ...) (src/ORBmatcher.cc:3448) -> projection search
+ *   exhaustive top-2 between the cameras (inner loop of src/ORBmatcher.cc:287-321)        -> cross-camera top-2
+ * It composes include/orbx.h and include/orbm.h (same results as calling them one by one); it exists because at
+ * 640x480 every kernel is a few microseconds and host round trips would otherwise dominate the frame.
+ */
+#ifndef ORBF_H
+#define ORBF_H
+#include "orbm.h"
+#include "orbx.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orbf_frontend orbf_frontend;
+
+typedef struct orbf_image {
+    const uint8_t* data; /* 8-bit grey; host pointer, or device pointer when on_device != 0; NULL = empty image */
+    int32_t width, height, stride;
+    int32_t on_device;
+} orbf_image;
+
+enum { ORBF_SKIP_CROSS = 1 }; /* flags of orbf_step */
+
+typedef struct orbf_result { /* all pointers: pinned host memory owned by the handle, valid until the next step */
+    int32_t n_cams, n_total;
+    const int32_t* counts;            /* [n_cams] keypoints per camera                                          */
+    const orb_keypoint* kps;          /* [n_total] mvKeys_total (global, cam-major index)                       */
+    const uint8_t* desc;              /* [n_total][32]                                                          */
+    const float* uright;              /* [n_total] mvuRight_total                                               */
+    const float* depth;               /* [n_total] mvDepth_total                                                */
+    int32_t nmatches;                 /* SearchByProjection return value (0 without queries)                    */
+    const int32_t* match_of_feature;  /* [n_total] as orbm_search_by_projection                                 */
+    const int32_t* cross_best_idx;    /* [n_total] as orbm_cross_top2 (NULL with ORBF_SKIP_CROSS)               */
+    const int32_t* cross_best_dist;
+    const int32_t* cross_second_dist;
+    float gpu_wait_us;                /* host time spent blocked in the final synchronisation                   */
+    int32_t n_queries;                /* queries searched this step                                             */
+    const orbm_query* queries;        /* [n_queries] (pinned copy)                                              */
+} orbf_result;
+
+int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbf_frontend** out);
+void orbf_destroy(orbf_frontend* f);
+/* HBM-resident depth image (metres, float32) of one camera for ComputeStereoFromRGBD; NULL: uRight = -1 */
+int orbf_set_depth(orbf_frontend* f, int cam, const float* d_depth, int stride_floats);
+/* mbf = Camera.bf; th_high / check_orientation as in ORBmatcher (defaults 40, 100, 1) */
+int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientation);
+/* queries: the projected last-frame map points (may be NULL / 0 on the first frame) */
+int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out);
+/* Synthetic-stream driver: like orbf_step, with the queries built natively from the PREVIOUS step's features moved by a
+ * constant image-plane motion (orbm_queries_from_motion on the handle's own pinned result buffers; no queries on the
+ * first step or after orbf_reset).  out->n_queries / out->queries expose what was searched. */
+typedef struct orbf_motion { float du, dv, th; } orbf_motion;
+int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out);
+int orbf_reset(orbf_frontend* f); /* forget the previous step (next orbf_step_motion searches nothing) */
+
+/* the composed handles, e.g. for orbx_bind_output / orbx_stage_times_us / orbm_cross_top2_blocks */
+orbx_extractor* orbf_extractor(orbf_frontend* f);
+orbm_matcher* orbf_matcher(orbf_frontend* f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -88,6 +88,13 @@ typedef struct orbm_query { /* one projected map point */
     uint8_t desc[32];       /* pMP->GetDescriptor()                                                          */
 } orbm_query;
 
+/* Host-only convenience for synthetic streams and tests: the last frame's features become projected map points under
+ * a constant image-plane motion (du, dv): u = x + du, v = y + dv, radius = th * scale_factors[octave],
+ * ur = u - mbf / depth (u where depth <= 0), levels octave-1 .. octave+1, blocks = 1, angle/desc copied.  A SLAM
+ * caller computes the same fields from its 3-D map points instead (reference src/ORBmatcher.cc:3502-3552). */
+int orbm_queries_from_motion(const orb_keypoint* kps, const uint8_t* desc, const float* depth, const int32_t* cam_of, int n,
+                             float du, float dv, float th, const float* scale_factors, float mbf, orbm_query* out);
+
 /* Builds the 64x48 per-camera grid (round-to-cell insertion, ascending global indices) and uploads the frame. */
 int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** out);
 

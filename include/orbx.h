@@ -70,6 +70,12 @@ void* orbx_stream(const orbx_extractor* ex);
  * d_kps holds cap keypoints, d_desc cap*32 bytes.  NULL restores the internal buffers. */
 int orbx_bind_output(orbx_extractor* ex, int cam, orb_keypoint* d_kps, uint8_t* d_desc, int cap);
 
+/* Additionally mirror every run's keypoints + descriptors, concatenated over the cameras in camera order, into
+ * pinned host memory: pass the DEVICE-visible aliases (hipHostGetDevicePointer) of buffers holding cap_total keypoints /
+ * cap_total*32 bytes.  The describe kernel writes them itself (no copy on the stream); they are complete once the
+ * handle's stream has been synchronised.  NULL disables. */
+int orbx_set_host_mirror(orbx_extractor* ex, orb_keypoint* kps_devptr, uint8_t* desc_devptr, int cap_total);
+
 /* -- stage inspection for level-by-level parity tests (not needed by a SLAM caller) -------------------- */
 /* pyramid level (dense w*h bytes) of the last run */
 int orbx_debug_level(orbx_extractor* ex, int cam, int level, uint8_t* out, int cap_bytes, int* w, int* h);

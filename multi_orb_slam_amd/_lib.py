@@ -34,6 +34,23 @@ class CamFeatures(C.Structure):  # orbm_cam_features
                 ("depth_stride", C.c_int32)]
 
 
+class FImage(C.Structure):  # orbf_image
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
+                ("on_device", C.c_int32)]
+
+
+class FResult(C.Structure):  # orbf_result
+    _fields_ = [("n_cams", C.c_int32), ("n_total", C.c_int32), ("counts", C.c_void_p), ("kps", C.c_void_p),
+                ("desc", C.c_void_p), ("uright", C.c_void_p), ("depth", C.c_void_p), ("nmatches", C.c_int32),
+                ("match_of_feature", C.c_void_p), ("cross_best_idx", C.c_void_p), ("cross_best_dist", C.c_void_p),
+                ("cross_second_dist", C.c_void_p), ("gpu_wait_us", C.c_float), ("n_queries", C.c_int32),
+                ("queries", C.c_void_p)]
+
+
+class FMotion(C.Structure):  # orbf_motion
+    _fields_ = [("du", C.c_float), ("dv", C.c_float), ("th", C.c_float)]
+
+
 class FrameDesc(C.Structure):  # orbm_frame_desc
     _fields_ = [("n_total", C.c_int32), ("n_cams", C.c_int32), ("un_x", C.c_void_p), ("un_y", C.c_void_p),
                 ("octave", C.c_void_p), ("angle", C.c_void_p), ("uright", C.c_void_p), ("cam_of", C.c_void_p),
@@ -95,6 +112,17 @@ def lib():
     L.orbm_frame_from_device.argtypes = [vp, vp, i32, f32, f32, f32, f32, f32, vp]
     L.orbm_frame_download.argtypes = [vp, vp, vp, vp, vp, vp]
     L.orbm_frame_count.argtypes = [vp]
+    L.orbf_create.argtypes = [vp, i32, i32, i32, i32, vp]
+    L.orbf_destroy.argtypes = [vp]; L.orbf_destroy.restype = None
+    L.orbf_set_depth.argtypes = [vp, i32, vp, i32]
+    L.orbf_configure.argtypes = [vp, f32, i32, i32]
+    L.orbf_step.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.orbf_step_motion.argtypes = [vp, vp, vp, i32, vp]
+    L.orbf_reset.argtypes = [vp]
+    L.orbf_extractor.argtypes = [vp]; L.orbf_extractor.restype = vp
+    L.orbf_matcher.argtypes = [vp]; L.orbf_matcher.restype = vp
+    L.orbm_debug_last_resolve.argtypes = [vp, vp]
+    L.orbm_queries_from_motion.argtypes = [vp, vp, vp, vp, i32, f32, f32, f32, vp, f32, vp]
     L.orbm_cross_top2.argtypes = [vp, vp, vp, vp, vp]
     L.orbm_cross_top2_blocks.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.orbm_frame_grid.argtypes = [vp, vp, vp]

@@ -60,6 +60,11 @@ struct LevelInfo {
     float patch_size;        // (float)(int)(31 * scale)
 };
 
+struct MirrorArgs {  // optional pinned-host (device-mapped) copy of the results in global, camera-major order
+    orb_keypoint* kps; uint8_t* desc;
+    int base[64];
+};
+
 struct SelKp {  // one keypoint chosen by the quadtree, input of k_describe
     int x, y;        // level ROI coordinates
     int camlevel;    // cam << 8 | level
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                                                   const uint8_t* __restrict__ pyr, size_t cam_pitch,
                                                   const SelKp* __restrict__ sel, int nsel,
                                                   orb_keypoint* const* __restrict__ kps_out,
-                                                  uint8_t* const* __restrict__ desc_out) {
+                                                  uint8_t* const* __restrict__ desc_out, MirrorArgs mir) {
     __shared__ uint8_t s_raw[4][PW * RAW_PITCH];
     __shared__ uint16_t s_row[4][PW * ROW_PITCH];
     __shared__ uint8_t s_blur[4][BW * ROW_PITCH];
@@ -417,7 +422,11 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     }
     const int other = __shfl_xor(nib, 1);
     const int out_idx = K.resp_out & 0xffffff;
-    if ((lane & 1) == 0) desc_out[cam][(size_t)out_idx * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+    if ((lane & 1) == 0) {
+        const uint8_t byte = (uint8_t)(nib | (other << 4));
+        desc_out[cam][(size_t)out_idx * 32 + (lane >> 1)] = byte;
+        if (mir.desc) mir.desc[(size_t)(mir.base[cam] + out_idx) * 32 + (lane >> 1)] = byte;
+    }
     if (lane == 0) {
         orb_keypoint kp;
         const float fx = (float)K.x, fy = (float)K.y;
@@ -429,6 +438,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         kp.octave = level;
         kp.class_id = -1;
         kps_out[cam][out_idx] = kp;
+        if (mir.kps) mir.kps[mir.base[cam] + out_idx] = kp;
     }
 }
 
@@ -615,6 +625,7 @@ struct orbx_extractor {
     DevBuf<orb_keypoint*> d_out_kps;
     DevBuf<uint8_t*> d_out_desc;
     bool out_ptrs_dirty = true;
+    orb_keypoint* mirror_kps = nullptr; uint8_t* mirror_desc = nullptr; int mirror_cap = 0;
 
     // pinned host (device-visible) buffers
     uint32_t* h_cand = nullptr; size_t h_cand_cap = 0;
@@ -856,6 +867,13 @@ int orbx_bind_output(orbx_extractor* ex, int cam, orb_keypoint* d_kps, uint8_t* 
     return ORB_OK;
 }
 
+int orbx_set_host_mirror(orbx_extractor* ex, orb_keypoint* kps_devptr, uint8_t* desc_devptr, int cap_total) {
+    MORB_ARG(ex != nullptr);
+    ex->mirror_kps = kps_devptr; ex->mirror_desc = desc_devptr; ex->mirror_cap = (kps_devptr && desc_devptr) ? cap_total : 0;
+    if (!ex->mirror_cap) { ex->mirror_kps = nullptr; ex->mirror_desc = nullptr; }
+    return ORB_OK;
+}
+
 int orbx_set_profiling(orbx_extractor* ex, int on) {
     MORB_ARG(ex != nullptr);
     ex->profiling = on != 0;
@@ -974,11 +992,18 @@ int orbx_run(orbx_extractor* ex) {
     }
     const auto t_host1 = std::chrono::steady_clock::now();
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[4], st));
+    MirrorArgs mir;
+    mir.kps = nullptr; mir.desc = nullptr;
+    if (ex->mirror_kps && nsel <= ex->mirror_cap) {
+        mir.kps = ex->mirror_kps; mir.desc = ex->mirror_desc;
+        int base = 0;
+        for (int c = 0; c < 64; ++c) { mir.base[c] = base; if (c < ex->n_cams) base += ex->n_out[c]; }
+    }
     if (nsel > 0) {
         MORB_HIP(hipMemcpyAsync(ex->d_sel.p, ex->h_sel, (size_t)nsel * sizeof(SelKp), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_describe, dim3((nsel + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
                            (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel.p, nsel,
-                           (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p);
+                           (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir);
         MORB_HIP(hipGetLastError());
     }
     if (ex->profiling) {

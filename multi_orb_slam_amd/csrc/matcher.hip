@@ -380,6 +380,38 @@ struct CamFeat {
     int depth_stride, n, base;
 };
 
+// Optional pinned-host (device-mapped) destinations: results the host needs are written there by the kernels
+// themselves, so no D2H copy kernels sit on the stream.
+struct HostMirror { orb_keypoint* kps; uint4* desc; float* ur; float* depth; };
+
+// One feature of the merged frame: the `_total` record, its stereo coordinate and its grid cell.
+__device__ __forceinline__ int frame_fill_one(const CamFeat* __restrict__ cams, int n_cams, int g, float mbf, float minX,
+                                              float minY, float invW, float invH, float* __restrict__ x,
+                                              float* __restrict__ y, float* __restrict__ ur, float* __restrict__ depth_out,
+                                              int* __restrict__ oct, float* __restrict__ ang,
+                                              orb_keypoint* __restrict__ kps_g, uint4* __restrict__ desc_g,
+                                              const HostMirror& hm) {
+    int c = 0;
+    while (c + 1 < n_cams && g >= cams[c].base + cams[c].n) ++c;
+    const CamFeat C = cams[c];
+    const int l = g - C.base;
+    const orb_keypoint k = C.kps[l];
+    const uint4 d0 = C.desc[2 * l], d1 = C.desc[2 * l + 1];
+    x[g] = k.x; y[g] = k.y; oct[g] = k.octave; ang[g] = k.angle; kps_g[g] = k;
+    desc_g[2 * g] = d0; desc_g[2 * g + 1] = d1;
+    float d = -1.f, u_r = -1.f;
+    if (C.depth) {
+        const float dv = C.depth[(size_t)(int)k.y * C.depth_stride + (int)k.x];  // imDepth.at<float>(v,u): float -> int truncation
+        if (dv > 0) { d = dv; u_r = k.x - mbf / dv; }
+    }
+    ur[g] = u_r; depth_out[g] = d;
+    if (hm.kps) { hm.kps[g] = k; hm.desc[2 * g] = d0; hm.desc[2 * g + 1] = d1; }
+    if (hm.ur) { hm.ur[g] = u_r; hm.depth[g] = d; }
+    const int px = (int)roundf((k.x - minX) * invW), py = (int)roundf((k.y - minY) * invH);
+    if (px >= 0 && px < ORBM_GRID_COLS && py >= 0 && py < ORBM_GRID_ROWS) return (c * ORBM_GRID_COLS + px) * ORBM_GRID_ROWS + py;
+    return -1;
+}
+
 // Frame merge + ComputeStereoFromRGBD + PosInGrid for every feature (reference src/Frame.cc:221-239, :959-986, :632-642)
 __global__ __launch_bounds__(256) void k_frame_fill(const CamFeat* __restrict__ cams, int n_cams, int n_total, float mbf,
                                                     float minX, float minY, float invW, float invH,
@@ -387,29 +419,78 @@ __global__ __launch_bounds__(256) void k_frame_fill(const CamFeat* __restrict__ 
                                                     float* __restrict__ depth_out, int* __restrict__ oct,
                                                     float* __restrict__ ang, orb_keypoint* __restrict__ kps_g,
                                                     uint4* __restrict__ desc_g, int* __restrict__ cell_of,
-                                                    int* __restrict__ cell_cnt) {
+                                                    int* __restrict__ cell_cnt, HostMirror hm) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= n_total) return;
-    int c = 0;
-    while (c + 1 < n_cams && g >= cams[c].base + cams[c].n) ++c;
-    const CamFeat C = cams[c];
-    const int l = g - C.base;
-    const orb_keypoint k = C.kps[l];
-    x[g] = k.x; y[g] = k.y; oct[g] = k.octave; ang[g] = k.angle; kps_g[g] = k;
-    desc_g[2 * g] = C.desc[2 * l]; desc_g[2 * g + 1] = C.desc[2 * l + 1];
-    float d = -1.f, u_r = -1.f;
-    if (C.depth) {
-        const float dv = C.depth[(size_t)(int)k.y * C.depth_stride + (int)k.x];  // imDepth.at<float>(v,u): float -> int truncation
-        if (dv > 0) { d = dv; u_r = k.x - mbf / dv; }
-    }
-    ur[g] = u_r; depth_out[g] = d;
-    const int px = (int)roundf((k.x - minX) * invW), py = (int)roundf((k.y - minY) * invH);
-    int cell = -1;
-    if (px >= 0 && px < ORBM_GRID_COLS && py >= 0 && py < ORBM_GRID_ROWS) {
-        cell = (c * ORBM_GRID_COLS + px) * ORBM_GRID_ROWS + py;
-        atomicAdd(&cell_cnt[cell], 1);
-    }
+    const int cell = frame_fill_one(cams, n_cams, g, mbf, minX, minY, invW, invH, x, y, ur, depth_out, oct, ang, kps_g, desc_g, hm);
+    if (cell >= 0) atomicAdd(&cell_cnt[cell], 1);
     cell_of[g] = cell;
+}
+
+// The whole frame assembly in ONE workgroup (n_total <= 8192, n_cams <= 4): fill, per-cell counts and cursors in LDS,
+// scan, scatter, per-cell sort.  Replaces memset + 4 launches on the small frames of a 2-4 camera rig.
+__global__ __launch_bounds__(1024) void k_frame_build_small(const CamFeat* __restrict__ cams, int n_cams, int n_total, float mbf,
+                                                            float minX, float minY, float invW, float invH,
+                                                            float* __restrict__ x, float* __restrict__ y,
+                                                            float* __restrict__ ur, float* __restrict__ depth_out,
+                                                            int* __restrict__ oct, float* __restrict__ ang,
+                                                            orb_keypoint* __restrict__ kps_g, uint4* __restrict__ desc_g,
+                                                            int* __restrict__ cell_start, int* __restrict__ items, HostMirror hm) {
+    extern __shared__ __attribute__((aligned(16))) int s_cells[];  // [ncell + 1] start | [ncell + 1] cursor
+    __shared__ int wsum[16];
+    const int ncell = n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
+    int* s_start = s_cells;
+    int* s_cur = s_cells + ncell + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c <= ncell; c += 1024) s_cur[c] = 0;
+    __syncthreads();
+    int mycell[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int g = tid + k * 1024;
+        mycell[k] = -1;
+        if (g < n_total) {
+            mycell[k] = frame_fill_one(cams, n_cams, g, mbf, minX, minY, invW, invH, x, y, ur, depth_out, oct, ang, kps_g, desc_g, hm);
+            if (mycell[k] >= 0) atomicAdd(&s_cur[mycell[k]], 1);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the counts (in s_cur) -> s_start; s_cur becomes the running insert position
+    const int per = (ncell + 1023) / 1024;
+    const int c0 = min(ncell, tid * per), c1 = min(ncell, c0 + per);
+    int mine = 0;
+    for (int c = c0; c < c1; ++c) mine += s_cur[c];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < 16; ++w) { const int v = wsum[w]; wsum[w] = acc; acc += v; }
+        s_start[ncell] = acc;
+    }
+    __syncthreads();
+    int run = wsum[wave] + incl - mine;
+    for (int c = c0; c < c1; ++c) { const int v = s_cur[c]; s_start[c] = run; s_cur[c] = run; run += v; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (mycell[k] >= 0) items[atomicAdd(&s_cur[mycell[k]], 1)] = tid + k * 1024;
+    __syncthreads();
+    for (int c = tid; c <= ncell; c += 1024) cell_start[c] = s_start[c];
+    for (int c = tid; c < ncell; c += 1024) {  // ascending global index inside every cell
+        const int sidx = s_start[c], e = s_start[c + 1];
+        for (int i = sidx + 1; i < e; ++i) {
+            const int v = items[i];
+            int j = i - 1;
+            while (j >= sidx && items[j] > v) { items[j + 1] = items[j]; --j; }
+            items[j + 1] = v;
+        }
+    }
 }
 
 // exclusive scan of cnt[0..n) into start[0..n], single 1024-thread block; cursor = copy of start
@@ -476,7 +557,9 @@ constexpr int RESOLVE_MAX_Q = 65535;
 
 // Evaluates query i against the current claim table.  `avail(g)` decides visibility.  Candidates are visited in the
 // order given; FRAMES: first minimum.  POINTS: best + second (with multiplicity) and their levels.
-template <bool POINTS>
+// LDSQ: the per-query sweep state (shortlist features + distances, blocks flag, current choice) also lives in LDS, so a
+// sweep touches no global memory at all; used whenever it fits next to the claim table.
+template <bool POINTS, bool LDSQ>
 __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap,
                                                   const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
                                                   const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
@@ -504,23 +587,43 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     // shortlist written by k_project: keys (dist << 16 | visiting position) and feature indices, sorted, occupied excluded
     const int* tk_key = topk;                             // [k*nq + i]
     const int* tk_g = topk + (size_t)RESOLVE_K * nq;      // [k*nq + i]
+    // LDS layout after the claim table: choice[nq] | shortlist g [K][nq] | shortlist d [K][nq] (u16) | cnt>K flag+blocks (u8)
+    int* l_choice = s_claim + F.n_total;
+    int* l_g = l_choice + nq;
+    unsigned short* l_d = reinterpret_cast<unsigned short*>(l_g + (size_t)RESOLVE_K * nq);
+    unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_d + (size_t)RESOLVE_K * nq);
+    if (LDSQ) {
+        for (int i = tid; i < nq; i += T) {
+            l_choice[i] = -1;
+            l_fl[i] = (unsigned char)((q[i].blocks ? 1 : 0) | (cand_count[i] > RESOLVE_K ? 2 : 0));
+#pragma unroll
+            for (int k = 0; k < RESOLVE_K; ++k) {
+                l_g[(size_t)k * nq + i] = tk_g[(size_t)k * nq + i];
+                l_d[(size_t)k * nq + i] = (unsigned short)(tk_key[(size_t)k * nq + i] >> 16);
+            }
+        }
+        __syncthreads();
+    }
     int it = 0, changed = 1;
     for (; it < max_it && changed; ++it) {
         const int tag = (0x7ffe - it) << 16;  // newer sweep -> smaller tag -> wins atomicMin over stale entries
         for (int i = tid; i < nq; i += T) {
-            const int c = choice[i];
-            const int bl = q[i].blocks;      // loaded unconditionally: both loads are in flight together
+            const int c = LDSQ ? l_choice[i] : choice[i];
+            const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;  // loaded unconditionally: both loads in flight together
             if (c >= 0 && bl) atomicMin(&s_claim[c], tag | i);
         }
         __syncthreads();
         int ch = 0;
         for (int i = tid; i < nq; i += T) {
-            // the whole shortlist is fetched up front (12 independent coalesced loads in flight), then walked
+            // the whole shortlist is fetched up front (independent loads in flight), then walked
             int sg[RESOLVE_K], sd[RESOLVE_K];
 #pragma unroll
-            for (int k = 0; k < RESOLVE_K; ++k) { sg[k] = tk_g[(size_t)k * nq + i]; sd[k] = tk_key[(size_t)k * nq + i] >> 16; }
-            const int cnt = cand_count[i];
-            const int old = choice[i];
+            for (int k = 0; k < RESOLVE_K; ++k) {
+                sg[k] = LDSQ ? l_g[(size_t)k * nq + i] : tk_g[(size_t)k * nq + i];
+                sd[k] = LDSQ ? (int)l_d[(size_t)k * nq + i] : (tk_key[(size_t)k * nq + i] >> 16);
+            }
+            const int cnt = LDSQ ? ((l_fl[i] & 2) ? RESOLVE_K + 1 : 0) : cand_count[i];  // only "longer than the shortlist" matters
+            const int old = LDSQ ? l_choice[i] : choice[i];
             int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
             int found = 0, taken = 0;
 #pragma unroll
@@ -536,7 +639,8 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             // the shortlist is exact unless it ran dry while longer lists exist: rescan everything (rare)
             if (found < (POINTS ? 2 : 1) && cnt > RESOLVE_K && taken > 0) {
                 best = 256; best2 = 256; lvl = -1; lvl2 = -1; bidx = -1;
-                for (int k = 0; k < cnt; ++k) {
+                const int full = cand_count[i];
+                for (int k = 0; k < full; ++k) {
                     const int g = cand_idx[(size_t)k * nq + i];
                     if (occupied && occupied[g]) continue;
                     const int cl = s_claim[g];
@@ -553,7 +657,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 nc = bidx;
                 if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
             }
-            if (nc != old) { ch = 1; choice[i] = nc; }
+            if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
         }
         changed = __syncthreads_or(ch);
     }
@@ -569,7 +673,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     const float factor = 1.0f / ORBM_HISTO_LENGTH;
     int acc = 0;
     for (int i = tid; i < nq; i += T) {
-        const int c = choice[i];
+        const int c = LDSQ ? l_choice[i] : choice[i];
         if (c < 0) continue;
         ++acc;
         atomicMax(&s_claim[c], i);
@@ -599,7 +703,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         __syncthreads();
         int rej = 0;
         for (int i = tid; i < nq; i += T) {
-            const int c = choice[i];
+            const int c = LDSQ ? l_choice[i] : choice[i];
             if (c < 0) continue;
             float rot = q[i].angle - f_angle[c];
             if (rot < 0.0) rot += 360.0f;
@@ -730,13 +834,15 @@ struct orbm_matcher {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;  // `stream` = the one in use (own or caller's)
     DevBuf<uint8_t> d_q, d_r, d_scratch, d_queries, d_occ;
-    DevBuf<int32_t> d_i0, d_i1, d_i2, d_choice, d_claim, d_match, d_status;
+    DevBuf<int32_t> d_i0, d_i1, d_i2, d_choice, d_claim, d_match, d_status, d_x0, d_x1, d_x2;
     DevBuf<uint16_t> d_u16;
     PinnedBuf<int32_t> h_i0, h_i1, h_i2, h_match;
     PinnedBuf<uint16_t> h_u16;
     PinnedBuf<uint8_t> h_ring;  // 4 slots of {CamFeat[64], int cam_start[65]} for asynchronous H2D
     unsigned ring_pos = 0;
     std::vector<FrameBufs*> pool;  // free list
+    // device-visible pinned destinations the next orbm_frame_from_device mirrors its merged arrays into (orbf_step)
+    orb_keypoint* mirror_kps = nullptr; uint8_t* mirror_desc = nullptr; float* mirror_ur = nullptr; float* mirror_depth = nullptr;
     int last_status[4] = {0, 0, 0, 0};  // {status, nmatches, sweeps, longest list} of the last device resolve
     bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
 };
@@ -820,7 +926,7 @@ void orbm_destroy(orbm_matcher* m) {
     (void)hipStreamSynchronize(m->stream);
     m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release(); m->d_occ.release();
     m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release();
-    m->d_match.release(); m->d_status.release(); m->d_u16.release();
+    m->d_match.release(); m->d_status.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
     m->h_i0.release(); m->h_i1.release(); m->h_i2.release(); m->h_match.release(); m->h_u16.release(); m->h_ring.release();
     for (FrameBufs* b : m->pool) { b->release(); delete b; }
     (void)hipStreamDestroy(m->own_stream);
@@ -851,6 +957,24 @@ int orbm_descriptor_distance(const uint8_t* a, const uint8_t* b) {
         dist += __builtin_popcountll(x ^ y);
     }
     return dist;
+}
+
+int orbm_queries_from_motion(const orb_keypoint* kps, const uint8_t* desc, const float* depth, const int32_t* cam_of, int n,
+                             float du, float dv, float th, const float* scale_factors, float mbf, orbm_query* out) {
+    MORB_ARG(n >= 0 && (n == 0 || (kps && desc && depth && cam_of && scale_factors && out)));
+    for (int i = 0; i < n; ++i) {
+        orbm_query& Q = out[i];
+        const orb_keypoint& k = kps[i];
+        const float u = k.x + du;
+        Q.u = u; Q.v = k.y + dv;
+        Q.radius = scale_factors[k.octave] * th;
+        const float inv = depth[i] > 0 ? 1.0f / depth[i] : 0.0f;
+        Q.ur = u - mbf * inv;
+        Q.min_level = k.octave - 1; Q.max_level = k.octave + 1;
+        Q.cam = cam_of[i]; Q.blocks = 1; Q.angle = k.angle;
+        memcpy(Q.desc, desc + (size_t)i * 32, 32);
+    }
+    return ORB_OK;
 }
 
 void orbm_three_maxima(const int* histo, int L, int* ind) {
@@ -1037,21 +1161,37 @@ int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n
     hipStream_t st = m->stream;
     MORB_HIP(hipMemcpyAsync(F->b->d_cams.p, hc, (size_t)n_cams * sizeof(CamFeat), hipMemcpyHostToDevice, st));
     MORB_HIP(hipMemcpyAsync(F->b->d_cam_start.p, hstart, (size_t)(n_cams + 1) * 4, hipMemcpyHostToDevice, st));
-    MORB_HIP(hipMemsetAsync(F->b->d_cursor.p, 0, (size_t)(ncell + 1) * 4, st));  // used as the per-cell counter first
-    if (n) {
-        hipLaunchKernelGGL(k_frame_fill, dim3((n + 255) / 256), dim3(256), 0, st, (const CamFeat*)F->b->d_cams.p, n_cams, n, mbf,
+    HostMirror hm{nullptr, nullptr, nullptr, nullptr};
+    if (m->mirror_kps) { hm.kps = m->mirror_kps; hm.desc = (uint4*)m->mirror_desc; }
+    if (m->mirror_ur) { hm.ur = m->mirror_ur; hm.depth = m->mirror_depth; }
+    const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int);
+    if (n > 0 && n <= 8192 && lds_small <= 150 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            MORB_HIP(hipFuncSetAttribute((const void*)k_frame_build_small, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            raised = true;
+        }
+        hipLaunchKernelGGL(k_frame_build_small, dim3(1), dim3(1024), lds_small, st, (const CamFeat*)F->b->d_cams.p, n_cams, n, mbf,
                            F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
-                           F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_of.p,
+                           F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_start.p,
+                           F->b->d_items.p, hm);
+    } else {
+        MORB_HIP(hipMemsetAsync(F->b->d_cursor.p, 0, (size_t)(ncell + 1) * 4, st));  // used as the per-cell counter first
+        if (n) {
+            hipLaunchKernelGGL(k_frame_fill, dim3((n + 255) / 256), dim3(256), 0, st, (const CamFeat*)F->b->d_cams.p, n_cams, n, mbf,
+                               F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
+                               F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_of.p,
+                               F->b->d_cursor.p, hm);
+        }
+        // counts live in d_cursor; scan them into d_cell_start and leave d_cursor = running insert positions
+        hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, (const int*)F->b->d_cursor.p, ncell, F->b->d_cell_start.p,
                            F->b->d_cursor.p);
-    }
-    // counts live in d_cursor; scan them into d_cell_start and leave d_cursor = running insert positions
-    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, (const int*)F->b->d_cursor.p, ncell, F->b->d_cell_start.p,
-                       F->b->d_cursor.p);
-    if (n) {
-        hipLaunchKernelGGL(k_scatter_cells, dim3((n + 255) / 256), dim3(256), 0, st, (const int*)F->b->d_cell_of.p, n,
-                           F->b->d_cursor.p, F->b->d_items.p);
-        hipLaunchKernelGGL(k_sort_cells, dim3((ncell + 255) / 256), dim3(256), 0, st, (const int*)F->b->d_cell_start.p, ncell,
-                           F->b->d_items.p);
+        if (n) {
+            hipLaunchKernelGGL(k_scatter_cells, dim3((n + 255) / 256), dim3(256), 0, st, (const int*)F->b->d_cell_of.p, n,
+                               F->b->d_cursor.p, F->b->d_items.p);
+            hipLaunchKernelGGL(k_sort_cells, dim3((ncell + 255) / 256), dim3(256), 0, st, (const int*)F->b->d_cell_start.p, ncell,
+                               F->b->d_items.p);
+        }
     }
     MORB_HIP(hipGetLastError());
     *out = F;
@@ -1232,57 +1372,98 @@ static int host_resolve(orbm_matcher* m, const orbm_frame* cur, const orbm_query
 }
 
 // k_project + k_resolve on the device, one D2H of {status, matches}; falls back to host_resolve when the sweep limit is
-// hit, retries with a larger capacity when a candidate list overflowed.
-static int search_common(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, const uint8_t* occupied,
-                         bool points, float nnratio, int th_high, int check_orientation, int32_t* match_of_feature,
-                         int* nmatches) {
-    const int n = cur->n_total;
-    for (int g = 0; g < n; g++) match_of_feature[g] = -1;
-    *nmatches = 0;
-    if (nq == 0 || n == 0) return ORB_OK;
+// hit, retries with a larger capacity when a candidate list overflowed.  Split in two so that a caller can enqueue
+// other work on the stream between the launch and the one synchronisation (orbf_step).
+struct SearchJob {
+    const orbm_frame* cur; const orbm_query* q; int nq; const uint8_t* occupied;
+    bool points; float nnratio; int th_high, check_ori;
+    int cap; bool device_path;
+};
+
+static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_device = false) {
+    const int n = J.cur->n_total;
+    J.device_path = false;
+    if (J.nq == 0 || n == 0) return ORB_OK;
     const size_t lds = (size_t)n * sizeof(int);
-    if (m->host_resolve || nq > RESOLVE_MAX_Q || lds > 150 * 1024)  // claim table must fit the 160 KB LDS of one CU
-        return host_resolve(m, cur, q, nq, occupied, points, nnratio, th_high, check_orientation, 64, match_of_feature, nmatches);
+    if (m->host_resolve || J.nq > RESOLVE_MAX_Q || lds > 150 * 1024) return ORB_OK;  // finish() takes the host path
     if (lds > 48 * 1024) {  // large claim tables need the opt-in dynamic LDS limit (once per process)
         static bool raised = false;
         if (!raised) {
-            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             raised = true;
         }
     }
     int rc;
-    if ((rc = m->d_choice.reserve(nq)) || (rc = m->d_claim.reserve((size_t)2 * RESOLVE_K * nq)) || (rc = m->d_match.reserve(n)) ||
+    if ((rc = m->d_choice.reserve(J.nq)) || (rc = m->d_claim.reserve((size_t)2 * RESOLVE_K * J.nq)) || (rc = m->d_match.reserve(n)) ||
         (rc = m->d_status.reserve(4)) || (rc = m->h_match.reserve((size_t)n + 4)) || (rc = m->d_occ.reserve(std::max(n, 16))))
         return rc;
-    if (occupied) MORB_HIP(hipMemcpyAsync(m->d_occ.p, occupied, (size_t)n, hipMemcpyHostToDevice, m->stream));
-    int cap = 64;
-    bool first = true;
-    for (;;) {
-        const uint8_t* d_occ = occupied ? m->d_occ.p : nullptr;
-        if ((rc = run_project(m, cur, q, nq, cap, 1, 1, first, false, /*transposed=*/1, d_occ, m->d_claim.p))) return rc;
-        first = false;
-#define MORB_RESOLVE_LAUNCH(PT)                                                                                          \
-    hipLaunchKernelGGL((k_resolve<PT>), dim3(1), dim3(1024), lds, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, \
+    if (J.occupied) MORB_HIP(hipMemcpyAsync(m->d_occ.p, J.occupied, (size_t)n, hipMemcpyHostToDevice, m->stream));
+    const uint8_t* d_occ = J.occupied ? m->d_occ.p : nullptr;
+    const orbm_frame* cur = J.cur;
+    const int nq = J.nq, cap = J.cap, th_high = J.th_high;
+    const float nnratio = J.nnratio;
+    if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device, false, /*transposed=*/1, d_occ, m->d_claim.p)))
+        return rc;
+    // claim table + (when it fits) the per-query sweep state
+    const size_t lds_q = lds + (size_t)nq * (sizeof(int) + RESOLVE_K * (sizeof(int) + sizeof(unsigned short)) + 1) + 16;
+    const bool ldsq = lds_q <= 150 * 1024;
+    const size_t lds_use = ldsq ? lds_q : lds;
+    if (lds_use > 48 * 1024) {
+        static bool raised2 = false;
+        if (!raised2) {
+            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            raised2 = true;
+        }
+    }
+#define MORB_RESOLVE_LAUNCH(PT, LQ)                                                                                      \
+    hipLaunchKernelGGL((k_resolve<PT, LQ>), dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, \
                        nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
-                       (const float*)cur->b->d_ang.p, th_high, nnratio, points ? 0 : check_orientation, 256, m->d_choice.p,   \
-                       (const int*)m->d_claim.p, m->d_match.p, m->d_status.p)
-        if (points) MORB_RESOLVE_LAUNCH(true); else MORB_RESOLVE_LAUNCH(false);
+                       (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
+                       (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp)
+    if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
+    else { if (J.points) MORB_RESOLVE_LAUNCH(true, false); else MORB_RESOLVE_LAUNCH(false, false); }
 #undef MORB_RESOLVE_LAUNCH
-        MORB_HIP(hipGetLastError());
-        MORB_HIP(hipMemcpyAsync(m->h_match.p, m->d_status.p, 16, hipMemcpyDeviceToHost, m->stream));
-        MORB_HIP(hipMemcpyAsync(m->h_match.p + 4, m->d_match.p, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
-        MORB_HIP(hipStreamSynchronize(m->stream));
+    MORB_HIP(hipGetLastError());  // status + matches are written by the kernel into the mapped pinned buffer
+    J.device_path = true;
+    return ORB_OK;
+}
+
+// After the stream has been synchronised.  match_of_feature may alias m->h_match.p + 4 (then nothing is copied).
+static int search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_feature, int* nmatches) {
+    const int n = J.cur->n_total;
+    *nmatches = 0;
+    if (J.nq == 0 || n == 0) { for (int g = 0; g < n; g++) match_of_feature[g] = -1; return ORB_OK; }
+    if (!J.device_path)
+        return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, 64, match_of_feature, nmatches);
+    for (;;) {
         const int status = m->h_match.p[0];
         for (int k = 0; k < 4; ++k) m->last_status[k] = m->h_match.p[k];
         if (status == 0) break;
-        if (status == 2) { cap = (m->h_match.p[3] + 63) & ~63; continue; }
+        if (status == 2) {  // a candidate list overflowed: retry with room for the longest one
+            J.cap = (m->h_match.p[3] + 63) & ~63;
+            int rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
+            if (rc) return rc;
+            MORB_HIP(hipStreamSynchronize(m->stream));
+            continue;
+        }
         // not converged within the sweep limit: exact host fallback
-        return host_resolve(m, cur, q, nq, occupied, points, nnratio, th_high, check_orientation, cap, match_of_feature, nmatches);
+        return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, J.cap, match_of_feature, nmatches);
     }
-    memcpy(match_of_feature, m->h_match.p + 4, (size_t)n * 4);
+    if (match_of_feature != m->h_match.p + 4) memcpy(match_of_feature, m->h_match.p + 4, (size_t)n * 4);
     *nmatches = m->h_match.p[1];
     return ORB_OK;
+}
+
+static int search_common(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, const uint8_t* occupied,
+                         bool points, float nnratio, int th_high, int check_orientation, int32_t* match_of_feature,
+                         int* nmatches) {
+    SearchJob J{cur, q, nq, occupied, points, nnratio, th_high, check_orientation, 64, false};
+    int rc = search_enqueue(m, J);
+    if (rc) return rc;
+    if (J.device_path) MORB_HIP(hipStreamSynchronize(m->stream));
+    return search_finish(m, J, match_of_feature, nmatches);
 }
 
 int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,
@@ -1303,34 +1484,38 @@ int orbm_search_by_projection_points(orbm_matcher* m, const orbm_frame* cur, con
     return search_common(m, cur, q0.data(), nq, occupied, true, nnratio, th_high, 0, match_of_feature, nmatches);
 }
 
-// k_cross_top2 (+ merge) over `n` features in `d_desc` split into cameras by `d_cam_start`; queries [q_off, q_off+nq)
-static int cross_launch(orbm_matcher* m, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off, int nq,
-                        int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+// k_cross_top2 (+ merge) over `n` features in `d_desc` split into cameras by `d_cam_start`; queries [q_off, q_off+nq).
+// Results land in the pinned mirrors m->h_i0/h_i1/h_i2 once the stream has been synchronised.
+static int cross_enqueue(orbm_matcher* m, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off, int nq) {
     if (nq == 0) return ORB_OK;
     const int qblocks = (nq + 63) / 64;
     const int S = top2_slices(nq, n);
     int rc;
-    if ((rc = m->d_i0.reserve(nq)) || (rc = m->d_i1.reserve(nq)) || (rc = m->d_i2.reserve(nq)) ||
-        (rc = m->d_scratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = m->h_i0.reserve(nq)) ||
+    if ((rc = m->d_scratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = m->h_i0.reserve(nq)) ||
         (rc = m->h_i1.reserve(nq)) || (rc = m->h_i2.reserve(nq)))
         return rc;
     hipStream_t st = m->stream;
-    if (S <= 1) {
+    if (S <= 1) {  // final results go straight to the mapped pinned mirrors
         hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, 1), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
-                           n_cams, q_off, nq, m->d_i0.p, m->d_i1.p, m->d_i2.p);
+                           n_cams, q_off, nq, m->h_i0.dp, m->h_i1.dp, m->h_i2.dp);
     } else {
         int* p = (int*)m->d_scratch.p;
         int *p_idx = p, *p_best = p + (size_t)S * nq, *p_second = p + 2 * (size_t)S * nq;
         hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, S), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
                            n_cams, q_off, nq, p_idx, p_best, p_second);
-        hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, m->d_i0.p,
-                           m->d_i1.p, m->d_i2.p);
+        hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, m->h_i0.dp,
+                           m->h_i1.dp, m->h_i2.dp);
     }
     MORB_HIP(hipGetLastError());
-    MORB_HIP(hipMemcpyAsync(m->h_i0.p, m->d_i0.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    MORB_HIP(hipMemcpyAsync(m->h_i1.p, m->d_i1.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    MORB_HIP(hipMemcpyAsync(m->h_i2.p, m->d_i2.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    MORB_HIP(hipStreamSynchronize(st));
+    return ORB_OK;
+}
+
+static int cross_launch(orbm_matcher* m, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off, int nq,
+                        int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+    if (nq == 0) return ORB_OK;
+    int rc = cross_enqueue(m, d_desc, n, d_cam_start, n_cams, q_off, nq);
+    if (rc) return rc;
+    MORB_HIP(hipStreamSynchronize(m->stream));
     memcpy(best_idx, m->h_i0.p, (size_t)nq * 4); memcpy(best_dist, m->h_i1.p, (size_t)nq * 4);
     memcpy(second_dist, m->h_i2.p, (size_t)nq * 4);
     return ORB_OK;
@@ -1368,6 +1553,171 @@ int orbm_cross_top2_blocks(orbm_matcher* m, const uint8_t* const* d_desc_blocks,
     MORB_HIP(hipMemcpyAsync(m->d_choice.p, start.data(), (size_t)(n_blocks + 1) * 4, hipMemcpyHostToDevice, m->stream));
     MORB_HIP(hipStreamSynchronize(m->stream));  // `start` is a local
     return cross_launch(m, m->d_r.p, n, m->d_choice.p, n_blocks, q_off, nq, best_idx, best_dist, second_dist);
+}
+
+
+// ================================================================================================ orbf (include/orbf.h)
+}  // extern "C"
+
+#include "../../include/orbf.h"
+#include <chrono>
+
+struct orbf_frontend {
+    int device = 0, n_cams = 0, max_w = 0, max_h = 0;
+    orbx_extractor* ex = nullptr;
+    orbm_matcher* mt = nullptr;
+    std::vector<const float*> d_depth;
+    std::vector<int> depth_stride;
+    std::vector<int32_t> counts;
+    float mbf = 40.f;
+    int th_high = ORBM_TH_HIGH, check_ori = 1;
+    int cap_total = 0;
+    // pinned host result buffers
+    PinnedBuf<orb_keypoint> h_kps;
+    PinnedBuf<uint8_t> h_desc, h_queries;
+    PinnedBuf<float> h_ur, h_depth;
+    PinnedBuf<int32_t> h_match;
+    // previous step (for orbf_step_motion)
+    int prev_n = 0;
+    std::vector<int32_t> prev_cam_of;
+    std::vector<float> scale_factors;
+};
+
+extern "C" {
+
+int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbf_frontend** out) {
+    MORB_ARG(params && out && n_cams >= 1 && n_cams <= 64);
+    orbf_frontend* f = new orbf_frontend();
+    f->device = device; f->n_cams = n_cams; f->max_w = max_width; f->max_h = max_height;
+    int rc = orbx_create(params, n_cams, max_width, max_height, device, &f->ex);
+    if (!rc) rc = orbm_create(device, &f->mt);
+    if (!rc) rc = orbm_set_stream(f->mt, orbx_stream(f->ex));  // one stream: frame build + matching follow extraction
+    if (rc) { orbf_destroy(f); return rc; }
+    f->d_depth.assign(n_cams, nullptr); f->depth_stride.assign(n_cams, 0); f->counts.assign(n_cams, 0);
+    f->scale_factors.assign(params[0].nlevels, 1.f);
+    if ((rc = orbx_tables(&params[0], f->scale_factors.data(), nullptr, nullptr, nullptr, nullptr, nullptr))) { orbf_destroy(f); return rc; }
+    for (int c = 0; c < n_cams; ++c) f->cap_total += params[c].nfeatures + 4 * params[c].nlevels;
+    const size_t cap = (size_t)f->cap_total;
+    if ((rc = f->h_kps.reserve(cap)) || (rc = f->h_desc.reserve(cap * 32)) || (rc = f->h_ur.reserve(cap)) ||
+        (rc = f->h_depth.reserve(cap)) || (rc = f->h_match.reserve(cap)) ||
+        (rc = orbx_set_host_mirror(f->ex, f->h_kps.dp, f->h_desc.dp, f->cap_total))) { orbf_destroy(f); return rc; }
+    *out = f;
+    return ORB_OK;
+}
+
+void orbf_destroy(orbf_frontend* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->mt) { (void)orbm_set_stream(f->mt, nullptr); orbm_destroy(f->mt); }
+    if (f->ex) orbx_destroy(f->ex);
+    f->h_kps.release(); f->h_desc.release(); f->h_queries.release(); f->h_ur.release(); f->h_depth.release(); f->h_match.release();
+    delete f;
+}
+
+orbx_extractor* orbf_extractor(orbf_frontend* f) { return f ? f->ex : nullptr; }
+orbm_matcher* orbf_matcher(orbf_frontend* f) { return f ? f->mt : nullptr; }
+
+int orbf_set_depth(orbf_frontend* f, int cam, const float* d_depth, int stride_floats) {
+    MORB_ARG(f && cam >= 0 && cam < f->n_cams);
+    f->d_depth[cam] = d_depth; f->depth_stride[cam] = stride_floats;
+    return ORB_OK;
+}
+
+int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientation) {
+    MORB_ARG(f && th_high >= 0 && th_high <= 256);
+    f->mbf = mbf; f->th_high = th_high; f->check_ori = check_orientation ? 1 : 0;
+    return ORB_OK;
+}
+
+static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
+                          orbf_result* out, bool queries_in_pinned);
+
+int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out) {
+    MORB_ARG(f && images && out && nq >= 0 && (nq == 0 || queries));
+    return orbf_step_impl(f, images, queries, nq, flags, out, false);
+}
+
+int orbf_reset(orbf_frontend* f) { MORB_ARG(f != nullptr); f->prev_n = 0; return ORB_OK; }
+
+int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out) {
+    MORB_ARG(f && images && motion && out);
+    const int nq = f->prev_n;
+    int rc;
+    if (nq) {
+        // the previous step's features are still in the pinned result buffers; turn them into queries BEFORE this step's
+        // kernels overwrite those buffers
+        if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
+        rc = orbm_queries_from_motion(f->h_kps.p, f->h_desc.p, f->h_depth.p, f->prev_cam_of.data(), nq, motion->du, motion->dv,
+                                      motion->th, f->scale_factors.data(), f->mbf, reinterpret_cast<orbm_query*>(f->h_queries.p));
+        if (rc) return rc;
+    }
+    return orbf_step_impl(f, images, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, flags, out, true);
+}
+
+static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
+                          orbf_result* out, bool queries_in_pinned) {
+    MORB_HIP(hipSetDevice(f->device));
+    orbm_matcher* m = f->mt;
+    int rc;
+    int W = 0, H = 0;
+    for (int c = 0; c < f->n_cams; ++c) {
+        const orbf_image& im = images[c];
+        rc = im.on_device ? orbx_upload_device(f->ex, c, im.data, im.width, im.height, im.stride)
+                          : orbx_upload(f->ex, c, im.data, im.width, im.height, im.stride);
+        if (rc) return rc;
+        W = std::max(W, im.width); H = std::max(H, im.height);
+    }
+    // queries go through pinned staging so their H2D overlaps the extractor's work
+    if (nq) {
+        if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))))
+            return rc;
+        if (!queries_in_pinned) memcpy(f->h_queries.p, queries, (size_t)nq * sizeof(orbm_query));
+        MORB_HIP(hipMemcpyAsync(m->d_queries.p, f->h_queries.p, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
+    }
+    if ((rc = orbx_run(f->ex))) return rc;  // one mid-pipeline sync inside (host quadtree)
+    std::vector<orbm_cam_features> cams(f->n_cams);
+    int n = 0;
+    for (int c = 0; c < f->n_cams; ++c) {
+        f->counts[c] = orbx_count(f->ex, c);
+        cams[c].d_kps = orbx_device_keypoints(f->ex, c); cams[c].d_desc = orbx_device_descriptors(f->ex, c);
+        cams[c].n = f->counts[c]; cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
+        n += f->counts[c];
+    }
+    if (W == 0 || H == 0) { W = f->max_w; H = f->max_h; }
+    orbm_frame* fr = nullptr;
+    // the frame-build kernel mirrors the merged arrays straight into this handle's pinned result buffers
+    m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = f->h_ur.dp; m->mirror_depth = f->h_depth.dp;
+    rc = orbm_frame_from_device(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, &fr);
+    m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = nullptr; m->mirror_depth = nullptr;
+    if (rc) return rc;
+    hipStream_t st = m->stream;
+    // (the fallback paths of the search read the queries on the host: always the pinned copy, which nothing overwrites)
+    SearchJob J{fr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
+    rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
+    const bool do_cross = !(flags & ORBF_SKIP_CROSS) && n > 0;
+    if (!rc && do_cross) rc = cross_enqueue(m, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n);
+    if (rc) { orbm_frame_destroy(fr); return rc; }
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipStreamSynchronize(st);
+    out->gpu_wait_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (e != hipSuccess) { morb::set_error("hipStreamSynchronize: %s", hipGetErrorString(e)); orbm_frame_destroy(fr); return ORB_E_HIP; }
+    int nmatches = 0;
+    if ((rc = f->h_match.reserve(std::max(n, 1)))) { orbm_frame_destroy(fr); return rc; }
+    rc = search_finish(m, J, f->h_match.p, &nmatches);
+    orbm_frame_destroy(fr);  // stream is idle: the buffers go straight back to the pool
+    if (rc) return rc;
+    f->prev_n = n;
+    f->prev_cam_of.resize(n);
+    for (int c = 0, g = 0; c < f->n_cams; ++c)
+        for (int k = 0; k < f->counts[c]; ++k) f->prev_cam_of[g++] = c;
+    out->n_queries = nq; out->queries = reinterpret_cast<const orbm_query*>(f->h_queries.p);
+    out->n_cams = f->n_cams; out->n_total = n; out->counts = f->counts.data();
+    out->kps = f->h_kps.p; out->desc = f->h_desc.p; out->uright = f->h_ur.p; out->depth = f->h_depth.p;
+    out->nmatches = nmatches; out->match_of_feature = f->h_match.p;
+    out->cross_best_idx = do_cross ? m->h_i0.p : nullptr;
+    out->cross_best_dist = do_cross ? m->h_i1.p : nullptr;
+    out->cross_second_dist = do_cross ? m->h_i2.p : nullptr;
+    return ORB_OK;
 }
 
 }  // extern "C"

@@ -46,18 +46,20 @@ struct DevBuf {  // grow-only device buffer
 };
 
 template <typename T>
-struct PinnedBuf {  // grow-only pinned host buffer
+struct PinnedBuf {  // grow-only pinned host buffer, mapped into the device address space (dp = device-visible alias)
     T* p = nullptr;
+    T* dp = nullptr;
     size_t cap = 0;
     int reserve(size_t n) {
         if (n <= cap) return ORB_OK;
         if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
-        MORB_HIP(hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault));
+        p = nullptr; dp = nullptr; cap = 0;
+        MORB_HIP(hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocMapped));
+        MORB_HIP(hipHostGetDevicePointer((void**)&dp, p, 0));
         cap = n;
         return ORB_OK;
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }
 };
 
 }  // namespace morb

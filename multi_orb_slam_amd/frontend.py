@@ -1,0 +1,88 @@
+"""ctypes mirror of include/orbf.h: one front-end timestep as one native call (single stream, single final sync)."""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import KP_DTYPE, QUERY_DTYPE, FImage, FMotion, FResult, Params, check, ptr
+
+SKIP_CROSS = 1
+
+
+def _view(addr, dtype, count, shape=None):
+    if not addr or count == 0:
+        return np.zeros(0 if shape is None else (0,) + tuple(shape[1:]), dtype)
+    nbytes = count * np.dtype(dtype).itemsize * (int(np.prod(shape[1:])) if shape is not None else 1)
+    buf = (C.c_char * nbytes).from_address(addr)
+    a = np.frombuffer(buf, dtype=dtype)
+    return a.reshape(shape) if shape is not None else a
+
+
+class NativeFrontEnd:
+    def __init__(self, params, max_width, max_height, device=0):
+        self.params = list(params); self.n_cams = len(self.params)
+        arr = (Params * self.n_cams)(*[p.c() for p in self.params])
+        self._h = C.c_void_p()
+        check(_lib.lib().orbf_create(arr, self.n_cams, max_width, max_height, device, C.byref(self._h)))
+        self._res = FResult()
+        self._imgs = (FImage * self.n_cams)()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                _lib.lib().orbf_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    __del__ = close
+
+    def set_depth(self, cam, d_ptr, stride_floats):
+        check(_lib.lib().orbf_set_depth(self._h, cam, C.c_void_p(d_ptr) if d_ptr else None, stride_floats))
+
+    def configure(self, mbf=40.0, th_high=100, check_orientation=True):
+        check(_lib.lib().orbf_configure(self._h, mbf, th_high, int(check_orientation)))
+
+    @property
+    def extractor_handle(self):
+        return _lib.lib().orbf_extractor(self._h)
+
+    @property
+    def matcher_handle(self):
+        return _lib.lib().orbf_matcher(self._h)
+
+    def reset(self):
+        check(_lib.lib().orbf_reset(self._h))
+
+    def step(self, images, queries=None, flags=0, copy=True, motion=None):
+        """images: [(ptr_or_array, width, height, stride, on_device)] or uint8 arrays.  `queries`: projected map points, or
+        `motion` = (du, dv, th): queries built natively from the previous step's features (synthetic-stream driver).
+        Returns a dict of numpy arrays (copies by default: the native buffers are reused by the next step)."""
+        keep = []
+        for c, im in enumerate(images):
+            if isinstance(im, np.ndarray):
+                im = np.ascontiguousarray(im, np.uint8); keep.append(im)
+                self._imgs[c] = FImage(im.ctypes.data, im.shape[1], im.shape[0], im.strides[0], 0)
+            elif im is None:
+                self._imgs[c] = FImage(None, 0, 0, 0, 0)
+            else:
+                self._imgs[c] = FImage(im[0], im[1], im[2], im[3], 1 if (len(im) < 5 or im[4]) else 0)
+        if motion is not None:
+            mo = FMotion(*motion)
+            check(_lib.lib().orbf_step_motion(self._h, self._imgs, C.byref(mo), flags, C.byref(self._res)))
+            nq = self._res.n_queries
+        else:
+            nq = 0 if queries is None else len(queries)
+            if nq:
+                queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+            check(_lib.lib().orbf_step(self._h, self._imgs, ptr(queries) if nq else None, nq, flags, C.byref(self._res)))
+        r = self._res
+        n = r.n_total
+        cp = (lambda a: a.copy()) if copy else (lambda a: a)
+        out = dict(counts=_view(r.counts, np.int32, r.n_cams).tolist(), kps=cp(_view(r.kps, KP_DTYPE, n)),
+                   desc=cp(_view(r.desc, np.uint8, n, (n, 32))), uright=cp(_view(r.uright, np.float32, n)),
+                   depth=cp(_view(r.depth, np.float32, n)), n_temporal=r.nmatches,
+                   match_of_feature=cp(_view(r.match_of_feature, np.int32, n)) if nq else np.zeros(0, np.int32),
+                   gpu_wait_us=r.gpu_wait_us, n_queries=nq)
+        if r.cross_best_idx:
+            out["cross"] = (cp(_view(r.cross_best_idx, np.int32, n)), cp(_view(r.cross_best_dist, np.int32, n)),
+                            cp(_view(r.cross_second_dist, np.int32, n)))
+        return out

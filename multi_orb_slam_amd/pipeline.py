@@ -10,6 +10,7 @@ The step mirrors the reference's per-frame front end: Frame::Frame (src/Frame.cc
 synthetic stream's known motion plays the motion model.  Keypoints, descriptors and depths come back to the host every
 step (the rest of a SLAM system needs them there); everything between extraction and the match lists stays in HBM.
 """
+import ctypes as C
 import numpy as np
 from ._lib import QUERY_DTYPE
 from .extractor import Extractor
@@ -31,17 +32,17 @@ def synth_depth_image(cam, width, height):
 
 
 def make_queries(prev, scale_factors):
-    """Last-frame map points projected into the current frame (what src/ORBmatcher.cc:3502-3552 computes on the host).
-    prev = (keypoints_total, descriptors_total, depth_total, cam_of)."""
+    """Last-frame map points projected into the current frame (what src/ORBmatcher.cc:3502-3552 computes on the host)
+    under the synthetic stream's known motion.  prev = (keypoints_total, descriptors_total, depth_total, cam_of).
+    Host-only C helper (orbm_queries_from_motion), shared by the GPU leg and the CPU-oracle leg of the benchmark."""
+    from . import _lib
+    from ._lib import ptr
     k, d, depth, cam_of = prev
-    q = np.zeros(len(k), QUERY_DTYPE)
-    u = k["x"] + np.float32(MOTION[0])
-    q["u"] = u; q["v"] = k["y"] + np.float32(MOTION[1])
-    q["radius"] = np.float32(TH_PROJ) * scale_factors[k["octave"]]
-    inv = np.where(depth > 0, np.float32(1.0) / np.maximum(depth, np.float32(1e-6)), np.float32(0)).astype(np.float32)
-    q["ur"] = u - np.float32(MBF) * inv
-    q["min_level"] = k["octave"] - 1; q["max_level"] = k["octave"] + 1
-    q["cam"] = cam_of; q["blocks"] = 1; q["angle"] = k["angle"]; q["desc"] = d
+    n = len(k)
+    q = np.empty(n, QUERY_DTYPE)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    _lib.check(_lib.lib().orbm_queries_from_motion(ptr(k), ptr(d), ptr(depth), ptr(cam_of), n, MOTION[0], MOTION[1], TH_PROJ,
+                                                   ptr(sf), MBF, ptr(q)))
     return q
 
 
@@ -51,61 +52,73 @@ def accept_cross(best_dist, second_dist):
 
 
 class FrontEnd:
-    """Extractor + matcher for the cameras owned by this process (one process per GPU)."""
+    """The front end of the cameras owned by this process (one process per GPU), on the native orbf_step entry."""
 
     def __init__(self, params_per_cam, width, height, device=0, rank=0, world_size=1, gather=None, global_cams=None):
+        from .frontend import NativeFrontEnd
+        from .extractor import tables
         self.params = list(params_per_cam); self.n_cams = len(self.params)
         self.width, self.height = width, height
         self.rank, self.world = rank, world_size
         self.gather = gather                      # DescriptorExchange (multi-GPU) or None
         self.global_cams = global_cams or list(range(rank * self.n_cams, (rank + 1) * self.n_cams))
         rt.set_device(device)
-        self.ex = Extractor(self.params, width, height, device)
-        self.mt = Matcher(BOW_RATIO, True, device)
-        self.mt.set_stream(self.ex.stream)        # one stream: frame build and matching are ordered after extraction
-        self.caps = self.ex.caps
+        self.fe = NativeFrontEnd(self.params, width, height, device)
+        self.fe.configure(MBF, 100, True)
+        self.caps = [p.nfeatures + 4 * p.nlevels for p in self.params]
         self.cap = max(self.caps)
-        self.scale = self.ex.GetScaleFactors(0)
+        self.scale = tables(self.params[0])["scale"]
         self.depth_host = [synth_depth_image(g, width, height) for g in self.global_cams]
         self.depth_dev = []
-        for d in self.depth_host:
+        for c, d in enumerate(self.depth_host):
             b = rt.DeviceBuffer(d.nbytes); b.upload(d); self.depth_dev.append(b)
+            self.fe.set_depth(c, b.ptr, width)
         rt.device_sync()
-        self.prev = None
+        self.copy_results = True   # False: results are views of the native pinned buffers (valid until the next step)
+        # thin views of the composed handles (stage timings, output binding, block-list cross matching)
+        self.ex = _Handle(Extractor, self.fe.extractor_handle, self.params)
+        self.mt = _Handle(Matcher, self.fe.matcher_handle)
         self.stream = self.ex.stream
 
     def close(self):
-        self.mt.close(); self.ex.close()
+        self.fe.close()
+
+    def reset(self):
+        self.fe.reset()
 
     # images: list of HxW uint8 arrays, or list of (device_ptr, stride) for HBM-resident frames
     def step(self, images, resident=False):
-        ex, mt = self.ex, self.mt
-        for c, im in enumerate(images):
-            if resident:
-                ex.upload_device(c, im[0], self.width, self.height, im[1])
-            else:
-                ex.upload(c, im)
-        ex.run()
-        counts = [ex.count(c) for c in range(self.n_cams)]
-        cams = [(ex.device_keypoints(c), ex.device_descriptors(c), counts[c], self.depth_dev[c].ptr, self.width)
-                for c in range(self.n_cams)]
-        frame = mt.frame_from_device(cams, MBF, (0.0, 0.0, float(self.width), float(self.height)))
-        kps, desc, uright, depth = frame.download()
-        cam_of = np.repeat(np.arange(self.n_cams, dtype=np.int32), counts)
-
-        n_temporal = 0; match_of = np.zeros(0, np.int32)
-        if self.prev is not None and frame.data.n_total > 0:
-            q = make_queries(self.prev, self.scale)
-            n_temporal, match_of = mt.SearchByProjection(frame, q)
-        self.prev = (kps, desc, depth, cam_of)
-
-        if self.world == 1 or self.gather is None:
-            bi, bd, sd = mt.cross_top2(frame)
-        else:
+        from .frontend import SKIP_CROSS
+        if resident:
+            images = [(im[0], self.width, self.height, im[1], 1) for im in images]
+        distributed = self.world > 1 and self.gather is not None
+        # queries = the previous step's features under the stream's known motion, built natively (orbf_step_motion;
+        # same arithmetic as make_queries, which the oracle leg uses)
+        r = self.fe.step(images, None, SKIP_CROSS if distributed else 0, copy=self.copy_results,
+                         motion=(MOTION[0], MOTION[1], TH_PROJ))
+        counts = r["counts"]
+        if distributed:
             ptrs, cnts = self.gather(self, counts)
-            bi, bd, sd = mt.cross_top2_blocks(ptrs, cnts, self.rank * self.n_cams, self.n_cams)
             assert cnts[self.rank * self.n_cams:(self.rank + 1) * self.n_cams] == counts
-        n_cross = int(accept_cross(bd, sd).sum())
-        frame.close()
-        return dict(kps=kps, desc=desc, uright=uright, depth=depth, counts=counts, n_temporal=n_temporal,
-                    match_of_feature=match_of, cross=(bi, bd, sd), n_cross=n_cross)
+            r["cross"] = self.mt.cross_top2_blocks(ptrs, cnts, self.rank * self.n_cams, self.n_cams)
+        bi, bd, sd = r["cross"]
+        r["n_cross"] = int(accept_cross(bd, sd).sum())
+        return r
+
+
+class _Handle:
+    """Borrowed view of a native handle owned by the front end: exposes the wrapper class' methods without owning it."""
+
+    def __init__(self, cls, handle, params=None):
+        self._cls = cls
+        self._h = C.c_void_p(handle)
+        if params is not None:
+            self.params = list(params); self.n_cams = len(self.params)
+
+    def __getattr__(self, name):
+        attr = getattr(self._cls, name)
+        if isinstance(attr, property):
+            return attr.fget(self)
+        if callable(attr):
+            return lambda *a, **k: attr(self, *a, **k)
+        return attr

@@ -1,0 +1,47 @@
+"""orbf_step (include/orbf.h): the whole timestep as one native call must equal the oracle pipeline bit for bit."""
+import numpy as np
+import pytest
+from multi_orb_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,h,nfs", [(320, 240, (300, 150)), (640, 480, (1000, 500)), (640, 480, (1000, 1000, 700))])
+def test_native_step_equals_oracle_pipeline(w, h, nfs):
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline, rt
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    params = [m.ExtractorParams(nfeatures=n) for n in nfs]
+    fe = pipeline.FrontEnd(params, w, h)
+    ofe = OracleFrontEnd(params, w, h)
+    bufs = []
+    for t in range(4):
+        imgs = [synth.image(c, t, w, h) for c in range(len(nfs))]
+        if t % 2 == 0:                                  # host images
+            got = fe.step(imgs)
+        else:                                           # HBM-resident images
+            row = []
+            for im in imgs:
+                b = rt.DeviceBuffer(im.nbytes); b.upload(im); row.append(b)
+            bufs.append(row)
+            got = fe.step([(b.ptr, w) for b in row], resident=True)
+        exp = ofe.step(imgs)
+        assert_same_step(got, exp)
+    assert got["n_temporal"] > 50 and sum(got["counts"]) > sum(nfs) // 2
+    fe.close()
+
+
+def test_native_step_with_an_empty_camera():
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd.frontend import NativeFrontEnd
+    import oracle
+    fe = NativeFrontEnd([m.ExtractorParams(nfeatures=300)] * 2, 320, 240)
+    img = synth.image(0, 0, 320, 240)
+    r = fe.step([img, None])
+    assert r["counts"][1] == 0 and r["counts"][0] > 100
+    ok, od = oracle.extract(img, nfeatures=300)
+    assert r["kps"].tobytes() == ok.tobytes() and np.array_equal(r["desc"], od)
+    assert (r["uright"] == -1).all()                    # no depth image set
+    bi, bd, sd = r["cross"]
+    assert (bi == -1).all() and (bd == 256).all()        # nothing to match against
+    fe.close()
