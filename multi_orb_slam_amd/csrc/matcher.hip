@@ -640,16 +640,27 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             if (found < (POINTS ? 2 : 1) && cnt > RESOLVE_K && taken > 0) {
                 best = 256; best2 = 256; lvl = -1; lvl2 = -1; bidx = -1;
                 const int full = cand_count[i];
-                for (int k = 0; k < full; ++k) {
-                    const int g = cand_idx[(size_t)k * nq + i];
-                    if (occupied && occupied[g]) continue;
-                    const int cl = s_claim[g];
-                    if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) continue;
-                    const int d = cand_dist[(size_t)k * nq + i];
-                    if (POINTS) {
-                        if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = F.octave[g]; bidx = g; }
-                        else if (d < best2) { lvl2 = F.octave[g]; best2 = d; }
-                    } else if (d < best) { best = d; bidx = g; }
+                for (int k0 = 0; k0 < full; k0 += 8) {  // 8 candidates per round: their loads are issued together
+                    int cg[8], cdist[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int k = min(k0 + u, full - 1);
+                        cg[u] = cand_idx[(size_t)k * nq + i];
+                        cdist[u] = cand_dist[(size_t)k * nq + i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (k0 + u >= full) continue;
+                        const int g = cg[u];
+                        if (occupied && occupied[g]) continue;
+                        const int cl = s_claim[g];
+                        if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) continue;
+                        const int d = cdist[u];
+                        if (POINTS) {
+                            if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = F.octave[g]; bidx = g; }
+                            else if (d < best2) { lvl2 = F.octave[g]; best2 = d; }
+                        } else if (d < best) { best = d; bidx = g; }
+                    }
                 }
             }
             int nc = -1;
