@@ -58,6 +58,8 @@ struct LevelInfo {
     int ini_th, min_th;
     float scale;             // mvScaleFactor[level]
     float patch_size;        // (float)(int)(31 * scale)
+    int quota;               // mnFeaturesPerLevel[level]
+    int sel_base;            // first slot of this (camera, level) in the device quadtree's output list (quota + 4 slots)
 };
 
 struct MirrorArgs {  // optional pinned-host (device-mapped) copy of the results in global, camera-major order
@@ -220,14 +222,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
 __global__ __launch_bounds__(1024) void k_compact(const LevelInfo* __restrict__ L, const int* __restrict__ cell_cnt,
                                                   const uint32_t* __restrict__ cell_items, int* __restrict__ cell_off,
                                                   uint32_t* __restrict__ cand /*pinned host*/,
-                                                  int* __restrict__ level_cnt /*pinned host*/) {
+                                                  int* __restrict__ level_cnt /*pinned host*/,
+                                                  uint32_t* __restrict__ cand_dev, int* __restrict__ level_cnt_dev) {
     __shared__ int wsum[16];
     __shared__ int s_total;
     const LevelInfo Lv = L[blockIdx.x];
     const int ncell = Lv.n_cols * Lv.n_rows;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (Lv.w == 0 || ncell == 0) {
-        if (tid == 0) level_cnt[blockIdx.x] = 0;
+        if (tid == 0) { level_cnt[blockIdx.x] = 0; level_cnt_dev[blockIdx.x] = 0; }
         return;
     }
     // exclusive scan of the cell counts, `per` consecutive cells per thread
@@ -260,9 +263,400 @@ __global__ __launch_bounds__(1024) void k_compact(const LevelInfo* __restrict__ 
         const int n = min(cell_cnt[Lv.cell_base + c], Lv.slot_cap);
         const int off = cell_off[Lv.cell_base + c];
         const uint32_t* src = cell_items + Lv.slot_base + (size_t)c * Lv.slot_cap;
-        for (int i = lane; i < n; i += 64) cand[Lv.cand_base + off + i] = src[i];
+        for (int i = lane; i < n; i += 64) { const uint32_t v = src[i]; cand[Lv.cand_base + off + i] = v; cand_dev[Lv.cand_base + off + i] = v; }
     }
-    if (tid == 0) level_cnt[blockIdx.x] = s_total;
+    if (tid == 0) { level_cnt[blockIdx.x] = s_total; level_cnt_dev[blockIdx.x] = s_total; }
+}
+
+
+// ------------------------------------------------------------------------------------------------ K4 on the device
+// DistributeOctTree (reference src/ORBextractor.cc:540-764) as ONE workgroup per (camera, level), all state in LDS.
+//
+// The reference keeps a std::list of nodes; a node owns the keypoints inside its box.  What has to be reproduced
+// exactly is (i) which nodes get split in which order and (ii) the final list order, because the output is "best
+// keypoint of every node, in list order".  Both follow from three facts about the reference's loops:
+//   * full pass: every node with > 1 keypoint is split, visiting the list front to back; the children (n1..n4, empty
+//     ones dropped) are pushed to the FRONT.  So after a pass the list is  reverse(creation order of all new children)
+//     followed by the surviving old nodes in their old order.
+//   * careful pass (entered when size + 3*expandable > N): the children created by the previous pass that hold > 1
+//     keypoint are sorted by (size, creation order) and split from the back (largest, newest first) until the list
+//     reaches N nodes.  Every split grows the list by (#non-empty children - 1), so the stopping point is a prefix sum.
+//   * a node's keypoints keep their relative order when they are dealt to its children (stable 4-way partition), which
+//     the final "first maximum response wins" depends on.
+// Here the list is an array in list order (node id == list position, rebuilt every pass), a node's keypoints are a
+// contiguous slice of the key arrays, and every pass is: classify keys -> one packed prefix sum (4 x 16-bit child
+// counters) -> new node array -> scatter keys.  Creation order inside a pass replaces the reference's heap-address
+// tie-break exactly as the host code and the oracle do.
+constexpr int OCT_NK = 4096;   // candidates per (camera, level) handled on the device
+constexpr int OCT_NL = 1024;   // live nodes (>= quota + 4)
+
+struct OctLds {
+    unsigned short kx[2][OCT_NK], ky[2][OCT_NK], ko[2][OCT_NK], kn[2][OCT_NK];
+    unsigned long long S[OCT_NK];          // inclusive packed prefix of child one-hots; reused as scratch
+    short ulx[2][OCT_NL], uly[2][OCT_NL], brx[2][OCT_NL], bry[2][OCT_NL];
+    unsigned short nb[2][OCT_NL], ne[2][OCT_NL], ncrt[2][OCT_NL];
+    unsigned char nfl[2][OCT_NL];          // bit0 = holds exactly one keypoint (bNoMore), bit1 = created by the last pass
+    unsigned short P[OCT_NL];              // parents of this pass in processing order
+    unsigned short procidx[OCT_NL];        // node -> index in P (0xffff: not split)
+    unsigned short newpos[OCT_NL];         // surviving node -> new list position
+    unsigned short cbase[OCT_NL];          // parent t -> creation index of its first child
+    unsigned long long pc[OCT_NL];         // parent t -> packed child counts
+    unsigned int sortkey[OCT_NL];
+    int wsum[16];
+    int v[8];                              // block-uniform scalars
+};
+
+__device__ __forceinline__ int oct_block_excl_scan(int val, int tid, int* wsum, int* total) {
+    // exclusive scan of one int per thread over the 1024-thread block
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = val;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int x = wsum[w]; if (w < wave) base += x; tot += x; }
+    if (total) *total = tot;
+    return base + incl - val;
+}
+
+// child of a key inside node box (ulx,uly)-(brx,bry): DivideNode's halfX/halfY and its '<' tests (:482-523)
+__device__ __forceinline__ int oct_child(int x, int y, int ulx, int uly, int brx, int bry, int& midx, int& midy) {
+    midx = ulx + (int)ceilf((float)(brx - ulx) / 2);
+    midy = uly + (int)ceilf((float)(bry - uly) / 2);
+    return (x < midx ? 0 : 1) + (y < midy ? 0 : 2);
+}
+
+// One split pass over the parents listed in L.P[0..np) (processing order).  `a` = current buffer, list size `sz`.
+// Returns the new size; *n_expand = number of new children holding > 1 keypoint.
+__device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, int* n_expand) {
+    const int b = a ^ 1;
+    for (int i = tid; i < sz; i += 1024) L.procidx[i] = 0xffff;
+    __syncthreads();
+    for (int t = tid; t < np; t += 1024) L.procidx[L.P[t]] = (unsigned short)t;
+    __syncthreads();
+    // classify + packed inclusive prefix over the key positions (4 keys per thread, blocked)
+    {
+        unsigned long long loc[4];
+        unsigned long long run = 0;
+        const int p0 = tid * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pos = p0 + k;
+            unsigned long long one = 0;
+            if (pos < n) {
+                const int node = L.kn[a][pos];
+                if (L.procidx[node] != 0xffff) {
+                    int mx, my;
+                    const int c = oct_child(L.kx[a][pos], L.ky[a][pos], L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
+                    one = 1ull << (16 * c);
+                }
+            }
+            run += one; loc[k] = run;
+        }
+        // exclusive scan of `run` across threads (64-bit: two 32-bit halves would lose carries between fields only if a
+        // field overflowed 16 bits, which n <= 4096 rules out)
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned long long incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        __syncthreads();
+        unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(L.pc);  // pc is free until step 4
+        if (lane == 63) wsum64[wave] = incl;
+        __syncthreads();
+        unsigned long long base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum64[w];
+        base += incl - run;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (p0 + k < n) L.S[p0 + k] = base + loc[k];
+    }
+    __syncthreads();
+    // per parent: child counts, number of non-empty children
+    int nch = 0;
+    unsigned long long tot = 0;
+    if (tid < np) {
+        const int node = L.P[tid];
+        const int kb = L.nb[a][node], ke = L.ne[a][node];
+        tot = L.S[ke - 1] - (kb ? L.S[kb - 1] : 0ull);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nch += ((tot >> (16 * c)) & 0xffff) ? 1 : 0;
+    }
+    int M = 0;
+    const int cb = oct_block_excl_scan(nch, tid, L.wsum, &M);
+    if (tid < np) { L.pc[tid] = tot; L.cbase[tid] = (unsigned short)cb; }
+    // survivors keep their relative order behind the new children
+    int surv = 0;
+    if (tid < sz) surv = L.procidx[tid] == 0xffff ? 1 : 0;
+    const int sr = oct_block_excl_scan(surv, tid, L.wsum, nullptr);
+    if (tid < sz && surv) {
+        const int np_ = M + sr;
+        L.newpos[tid] = (unsigned short)np_;
+        L.ulx[b][np_] = L.ulx[a][tid]; L.uly[b][np_] = L.uly[a][tid]; L.brx[b][np_] = L.brx[a][tid]; L.bry[b][np_] = L.bry[a][tid];
+        L.nb[b][np_] = L.nb[a][tid]; L.ne[b][np_] = L.ne[a][tid]; L.ncrt[b][np_] = 0xffff;
+        L.nfl[b][np_] = L.nfl[a][tid] & 1;  // no longer "fresh"
+    }
+    // children: creation index ci -> list position M-1-ci
+    int my_expand = 0;
+    if (tid < np) {
+        const int node = L.P[tid];
+        int mx, my;
+        (void)oct_child(0, 0, L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
+        const int x0[4] = {L.ulx[a][node], mx, L.ulx[a][node], mx}, y0[4] = {L.uly[a][node], L.uly[a][node], my, my};
+        const int x1[4] = {mx, L.brx[a][node], mx, L.brx[a][node]}, y1[4] = {my, my, L.bry[a][node], L.bry[a][node]};
+        int ci = cb, off = L.nb[a][node];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int cnt = (int)((tot >> (16 * c)) & 0xffff);
+            if (cnt == 0) continue;
+            const int pos = M - 1 - ci;
+            L.ulx[b][pos] = (short)x0[c]; L.uly[b][pos] = (short)y0[c]; L.brx[b][pos] = (short)x1[c]; L.bry[b][pos] = (short)y1[c];
+            L.nb[b][pos] = (unsigned short)off; L.ne[b][pos] = (unsigned short)(off + cnt);
+            L.ncrt[b][pos] = (unsigned short)ci;
+            L.nfl[b][pos] = (unsigned char)((cnt == 1 ? 1 : 0) | 2);
+            if (cnt > 1) ++my_expand;
+            off += cnt; ++ci;
+        }
+    }
+    int nexp = 0;
+    (void)oct_block_excl_scan(my_expand, tid, L.wsum, &nexp);
+    __syncthreads();
+    // keys: stable 4-way partition inside every split node, others stay where they are
+    for (int pos = tid; pos < n; pos += 1024) {
+        const int node = L.kn[a][pos];
+        const int t = L.procidx[node];
+        int npos = pos, nnode;
+        const int x = L.kx[a][pos], y = L.ky[a][pos];
+        if (t != 0xffff) {
+            int mx, my;
+            const int c = oct_child(x, y, L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
+            const unsigned long long cnts = L.pc[t];
+            const int kb = L.nb[a][node];
+            const unsigned long long before = kb ? L.S[kb - 1] : 0ull;
+            const int rank = (int)(((L.S[pos] - before) >> (16 * c)) & 0xffff) - 1;
+            int off = 0, ne_before = 0;
+            for (int c2 = 0; c2 < c; ++c2) { const int cc = (int)((cnts >> (16 * c2)) & 0xffff); off += cc; ne_before += cc ? 1 : 0; }
+            npos = kb + off + rank;
+            nnode = M - 1 - (L.cbase[t] + ne_before);
+        } else {
+            nnode = L.newpos[node];
+        }
+        L.kx[b][npos] = (unsigned short)x; L.ky[b][npos] = (unsigned short)y; L.ko[b][npos] = L.ko[a][pos];
+        L.kn[b][npos] = (unsigned short)nnode;
+    }
+    __syncthreads();
+    *n_expand = nexp;
+    return M + (sz - np);
+}
+
+// status: 0 ok, 1 = outside the device limits (host falls back)
+__global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ Lv_all, const uint32_t* __restrict__ cand,
+                                                 const int* __restrict__ level_cnt, SelKp* __restrict__ sel,
+                                                 int* __restrict__ sel_cnt, int* __restrict__ status, int max_levels) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char oct_raw[];
+    OctLds& L = *reinterpret_cast<OctLds*>(oct_raw);
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    const LevelInfo Lv = Lv_all[blk];
+    const int n = Lv.w ? level_cnt[blk] : 0;
+    const int N = Lv.quota;
+    if (n == 0) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 0; } return; }
+    const int width = Lv.w - 2 * MIN_BORDER, height = Lv.h - 2 * MIN_BORDER;
+    const int nIni = max(1, (int)roundf((float)width / (float)height));
+    if (n > OCT_NK || N + 4 > OCT_NL || nIni > 4 || width >= 32768 || height >= 32768) {
+        if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; }
+        return;
+    }
+    const uint32_t* cd = cand + Lv.cand_base;
+    const float hX = (float)width / (float)nIni;
+    // ---- roots (:544-585): vertical strips, keypoints dealt by (int)(x / hX), empty roots dropped, order = strip order
+    {
+        unsigned long long loc[4], run = 0;
+        int rx[4], ry[4], rr[4];
+        const int p0 = tid * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pos = p0 + k;
+            unsigned long long one = 0;
+            rx[k] = ry[k] = rr[k] = 0;
+            if (pos < n) {
+                const uint32_t v = cd[pos];
+                rx[k] = v & 0xfff; ry[k] = (v >> 12) & 0xfff;
+                int r = (int)((float)rx[k] / hX);
+                r = min(max(r, 0), nIni - 1);
+                rr[k] = r; one = 1ull << (16 * r);
+            }
+            run += one; loc[k] = run;
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned long long incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(L.pc);
+        if (lane == 63) wsum64[wave] = incl;
+        __syncthreads();
+        unsigned long long base = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) base += wsum64[w]; total += wsum64[w]; }
+        base += incl - run;
+        // root r -> list position (non-empty roots only) and key offset
+        int rpos[4], roff[4], np_ = 0, off = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = (int)((total >> (16 * r)) & 0xffff);
+            rpos[r] = np_; roff[r] = off;
+            if (c) ++np_;
+            off += c;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pos = p0 + k;
+            if (pos < n) {
+                const int r = rr[k];
+                const int rank = (int)(((base + loc[k]) >> (16 * r)) & 0xffff) - 1;
+                const int np2 = roff[r] + rank;
+                L.kx[0][np2] = (unsigned short)rx[k]; L.ky[0][np2] = (unsigned short)ry[k];
+                L.ko[0][np2] = (unsigned short)pos; L.kn[0][np2] = (unsigned short)rpos[r];
+            }
+        }
+        if (tid < nIni) {
+            const int c = (int)((total >> (16 * tid)) & 0xffff);
+            if (c) {
+                const int i = rpos[tid];
+                L.ulx[0][i] = (short)(int)(hX * (float)tid); L.uly[0][i] = 0;
+                L.brx[0][i] = (short)(int)(hX * (float)(tid + 1)); L.bry[0][i] = (short)height;
+                L.nb[0][i] = (unsigned short)roff[tid]; L.ne[0][i] = (unsigned short)(roff[tid] + c);
+                L.ncrt[0][i] = 0xffff; L.nfl[0][i] = (unsigned char)(c == 1 ? 1 : 0);
+            }
+        }
+        if (tid == 0) L.v[0] = np_;
+        __syncthreads();
+    }
+    int a = 0, sz = L.v[0];
+    // ---- main loop (:596-739)
+    bool finish = false;
+    while (!finish) {
+        const int prev_size = sz;
+        // parents = every node that still holds more than one keypoint, in list order
+        int flag = 0;
+        if (tid < sz) flag = (L.nfl[a][tid] & 1) ? 0 : 1;
+        int np = 0;
+        const int rk = oct_block_excl_scan(flag, tid, L.wsum, &np);
+        if (tid < sz && flag) L.P[rk] = (unsigned short)tid;
+        __syncthreads();
+        int n_expand = 0;
+        sz = oct_split_pass(L, a, n, sz, np, tid, &n_expand);
+        a ^= 1;
+        if (sz >= N || sz == prev_size) { finish = true; break; }
+        if (sz + n_expand * 3 > N) {
+            // careful passes: largest nodes first, stop the moment N is reached
+            while (!finish) {
+                const int ps = sz;
+                // candidates: children of the previous pass with > 1 keypoint
+                int isc = 0;
+                unsigned int key = 0;
+                if (tid < sz && (L.nfl[a][tid] & 2) && !(L.nfl[a][tid] & 1)) {
+                    isc = 1;
+                    key = ((unsigned)(L.ne[a][tid] - L.nb[a][tid]) << 16) | L.ncrt[a][tid];  // (size, creation order)
+                }
+                int nc = 0;
+                const int ci = oct_block_excl_scan(isc, tid, L.wsum, &nc);
+                if (isc) { L.sortkey[ci] = key; L.newpos[ci] = (unsigned short)tid; }  // newpos reused: candidate -> node
+                __syncthreads();
+                if (nc == 0) { finish = true; break; }
+                // descending rank (all keys distinct: creation order is unique)
+                int myrank = 0;
+                if (tid < nc) {
+                    const unsigned int mk = L.sortkey[tid];
+                    for (int j = 0; j < nc; ++j) myrank += L.sortkey[j] > mk ? 1 : 0;
+                    L.P[myrank] = L.newpos[tid];
+                }
+                __syncthreads();
+                // growth of every candidate if it were split: #non-empty children - 1  (needs the child counts: run the
+                // classification for ALL candidates, then keep only the prefix that is actually processed)
+                for (int i = tid; i < sz; i += 1024) L.procidx[i] = 0xffff;
+                __syncthreads();
+                if (tid < nc) L.procidx[L.P[tid]] = (unsigned short)tid;
+                __syncthreads();
+                // per-candidate child occupancy via atomics on 4 bits (cheap: only occupancy, not counts, is needed here)
+                unsigned int* occ = reinterpret_cast<unsigned int*>(L.S);  // scratch
+                for (int t = tid; t < nc; t += 1024) occ[t] = 0;
+                __syncthreads();
+                for (int pos = tid; pos < n; pos += 1024) {
+                    const int node = L.kn[a][pos];
+                    const int t = L.procidx[node];
+                    if (t != 0xffff) {
+                        int mx, my;
+                        const int c = oct_child(L.kx[a][pos], L.ky[a][pos], L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
+                        atomicOr(&occ[t], 1u << c);
+                    }
+                }
+                __syncthreads();
+                int growth = 0;
+                if (tid < nc) growth = __popc(occ[tid]) - 1;
+                int gtot = 0;
+                const int gex = oct_block_excl_scan(growth, tid, L.wsum, &gtot);
+                // first t (processing order) after which the list has reached N
+                if (tid == 0) L.v[1] = nc;  // default: process all
+                __syncthreads();
+                if (tid < nc && ps + gex + growth >= N && ps + gex < N) L.v[1] = tid + 1;
+                // (the condition holds for exactly one t when the running size crosses N; sizes never decrease)
+                __syncthreads();
+                const int np2 = L.v[1];
+                __syncthreads();
+                int ne2 = 0;
+                sz = oct_split_pass(L, a, n, sz, np2, tid, &ne2);
+                a ^= 1;
+                if (sz >= N || sz == ps) finish = true;
+            }
+        }
+    }
+    // ---- best keypoint per node, first maximum wins (:742-763); output in list order
+    if (tid < sz) {
+        const int kb = L.nb[a][tid], ke = L.ne[a][tid];
+        int best = L.ko[a][kb];
+        int bresp = (int)(cd[best] >> 24);
+        for (int k = kb + 1; k < ke; ++k) {
+            const int o = L.ko[a][k];
+            const int r = (int)(cd[o] >> 24);
+            if (r > bresp) { bresp = r; best = o; }
+        }
+        const uint32_t v = cd[best];
+        SelKp K;
+        K.x = (int)(v & 0xfff) + MIN_BORDER; K.y = (int)((v >> 12) & 0xfff) + MIN_BORDER;
+        K.camlevel = ((blk / max_levels) << 8) | (blk % max_levels);
+        K.resp_out = (int)((v & 0xff000000u) | (unsigned)tid);
+        sel[Lv.sel_base + tid] = K;
+    }
+    if (tid == 0) { sel_cnt[blk] = sz; status[blk] = 0; }
+}
+
+// out_base[blk] = first output index of (camera, level) inside its camera; n_out[cam]; cam_base[cam] (global order)
+__global__ void k_sel_offsets(const int* __restrict__ sel_cnt, int n_cams, int max_levels, int* __restrict__ out_base,
+                              int* __restrict__ n_out, int* __restrict__ cam_base, int* __restrict__ h_n_out,
+                              const int* __restrict__ status, int* __restrict__ h_status) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int gbase = 0, bad = 0;
+    for (int c = 0; c < n_cams; ++c) {
+        int run = 0;
+        for (int l = 0; l < max_levels; ++l) {
+            out_base[c * max_levels + l] = run;
+            run += sel_cnt[c * max_levels + l];
+            bad |= status[c * max_levels + l];
+        }
+        n_out[c] = run; cam_base[c] = gbase; h_n_out[c] = run;
+        gbase += run;
+    }
+    *h_status = bad;
 }
 
 // ------------------------------------------------------------------------------------------------ K5-K7
@@ -345,15 +739,29 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                                                   const uint8_t* __restrict__ pyr, size_t cam_pitch,
                                                   const SelKp* __restrict__ sel, int nsel,
                                                   orb_keypoint* const* __restrict__ kps_out,
-                                                  uint8_t* const* __restrict__ desc_out, MirrorArgs mir) {
+                                                  uint8_t* const* __restrict__ desc_out, MirrorArgs mir,
+                                                  const unsigned short* __restrict__ slot_blk,
+                                                  const int* __restrict__ sel_cnt, const int* __restrict__ out_base,
+                                                  const int* __restrict__ cam_base) {
     __shared__ uint8_t s_raw[4][PW * RAW_PITCH];
     __shared__ uint16_t s_row[4][PW * ROW_PITCH];
     __shared__ uint8_t s_blur[4][BW * ROW_PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ki = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
     if (ki >= nsel) return;
-    const SelKp K = sel[ki];
+    SelKp K = sel[ki];
+    int mirror_base = 0;
+    if (slot_blk) {
+        // device-quadtree mode: `sel` is the slotted list (quota + 4 slots per (camera, level)); the output position is
+        // the level's base inside its camera plus the list position the quadtree stored in the low 24 bits
+        const int blk = slot_blk[ki];
+        const int local = ki - L[blk].sel_base;
+        if (local >= sel_cnt[blk]) return;
+        K.resp_out = (int)(((unsigned)K.resp_out & 0xff000000u) | (unsigned)(out_base[blk] + local));
+        mirror_base = cam_base[K.camlevel >> 8];
+    }
     const int cam = K.camlevel >> 8, level = K.camlevel & 0xff;
+    if (!slot_blk) mirror_base = mir.base[cam];
     const LevelInfo Lv = L[cam * max_levels + level];
     const uint8_t* img = pyr + cam * cam_pitch + Lv.pyr_off;
     uint8_t* raw = s_raw[wave];
@@ -425,7 +833,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     if ((lane & 1) == 0) {
         const uint8_t byte = (uint8_t)(nib | (other << 4));
         desc_out[cam][(size_t)out_idx * 32 + (lane >> 1)] = byte;
-        if (mir.desc) mir.desc[(size_t)(mir.base[cam] + out_idx) * 32 + (lane >> 1)] = byte;
+        if (mir.desc) mir.desc[(size_t)(mirror_base + out_idx) * 32 + (lane >> 1)] = byte;
     }
     if (lane == 0) {
         orb_keypoint kp;
@@ -438,7 +846,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         kp.octave = level;
         kp.class_id = -1;
         kps_out[cam][out_idx] = kp;
-        if (mir.kps) mir.kps[mir.base[cam] + out_idx] = kp;
+        if (mir.kps) mir.kps[mirror_base + out_idx] = kp;
     }
 }
 
@@ -616,7 +1024,13 @@ struct orbx_extractor {
     DevBuf<int4> d_ytab;
     DevBuf<int> d_cell_cnt, d_cell_off;
     DevBuf<uint32_t> d_cell_items;
-    DevBuf<SelKp> d_sel;
+    DevBuf<SelKp> d_sel, d_sel_oct;
+    DevBuf<uint32_t> d_cand_dev;
+    DevBuf<int> d_level_cnt_dev, d_sel_cnt, d_oct_status, d_out_base, d_n_out, d_cam_base;
+    DevBuf<unsigned short> d_slot_blk;
+    int total_sel_slots = 0;
+    int* h_oct = nullptr;            // pinned, mapped: [0..n_cams) n_out, [n_cams] status
+    bool device_octree = true;
     std::vector<DevBuf<orb_keypoint>> d_kps;
     std::vector<DevBuf<uint8_t>> d_desc;
     std::vector<orb_keypoint*> out_kps;   // active output pointers (internal or bound)
@@ -682,6 +1096,7 @@ static int rebuild_geometry(orbx_extractor* ex) {
                                 Lv.w, Lv.h, Lv.w_cell, Lv.h_cell);
                 return ORB_E_ARG;
             }
+            Lv.quota = T.quota[l];
             Lv.cell_base = cell_base;
             Lv.slot_cap = ((Lv.w_cell + 1) / 2) * ((Lv.h_cell + 1) / 2);  // strict 8-neighbour maxima cannot be denser
             Lv.slot_base = (int)slot_base;
@@ -702,12 +1117,27 @@ static int rebuild_geometry(orbx_extractor* ex) {
     if (slot_base > (size_t)INT32_MAX) { morb::set_error("candidate slot space exceeds 2^31 entries"); return ORB_E_ARG; }
     ex->total_cells = cell_base;
     ex->total_slots = slot_base;
+    // slotted output list of the device quadtree: quota + 4 slots per (camera, level)
+    std::vector<unsigned short> slot_blk;
+    for (size_t b = 0; b < ex->levels.size(); ++b) {
+        LevelInfo& Lv = ex->levels[b];
+        Lv.sel_base = (int)slot_blk.size();
+        if (Lv.w == 0) continue;
+        for (int k = 0; k < Lv.quota + 4; ++k) slot_blk.push_back((unsigned short)b);
+    }
+    ex->total_sel_slots = (int)slot_blk.size();
     int rc;
     if ((rc = ex->d_levels.reserve(ex->levels.size())) || (rc = ex->d_cell_map.reserve(std::max<size_t>(ex->cell_map.size(), 1))) ||
         (rc = ex->d_xtab.reserve(std::max<size_t>(xt.size(), 1))) || (rc = ex->d_ytab.reserve(std::max<size_t>(yt.size(), 1))) ||
         (rc = ex->d_cell_cnt.reserve(std::max(cell_base, 1))) || (rc = ex->d_cell_off.reserve(std::max(cell_base, 1))) ||
-        (rc = ex->d_cell_items.reserve(std::max<size_t>(slot_base, 1))))
+        (rc = ex->d_cell_items.reserve(std::max<size_t>(slot_base, 1))) || (rc = ex->d_cand_dev.reserve(std::max<size_t>(slot_base, 1))) ||
+        (rc = ex->d_level_cnt_dev.reserve(ex->levels.size())) || (rc = ex->d_sel_cnt.reserve(ex->levels.size())) ||
+        (rc = ex->d_oct_status.reserve(ex->levels.size())) || (rc = ex->d_out_base.reserve(ex->levels.size())) ||
+        (rc = ex->d_n_out.reserve(ex->n_cams)) || (rc = ex->d_cam_base.reserve(ex->n_cams)) ||
+        (rc = ex->d_sel_oct.reserve(std::max<size_t>(slot_blk.size(), 1))) || (rc = ex->d_slot_blk.reserve(std::max<size_t>(slot_blk.size(), 1))))
         return rc;
+    if (!slot_blk.empty())
+        MORB_HIP(hipMemcpyAsync(ex->d_slot_blk.p, slot_blk.data(), slot_blk.size() * sizeof(unsigned short), hipMemcpyHostToDevice, ex->stream));
     if (slot_base > ex->h_cand_cap) {
         if (ex->h_cand) (void)hipHostFree(ex->h_cand);
         ex->h_cand = nullptr; ex->h_cand_cap = 0;
@@ -798,6 +1228,9 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     ORBX_TRY_HIP(hipHostMalloc((void**)&ex->h_sel, sel_cap * sizeof(SelKp), hipHostMallocDefault));
     ex->h_sel_cap = sel_cap;
     ORBX_TRY_HIP(hipHostMalloc((void**)&ex->h_level_cnt, (size_t)n_cams * MAX_LEVELS * sizeof(int), hipHostMallocMapped));
+    ORBX_TRY_HIP(hipHostMalloc((void**)&ex->h_oct, (size_t)(n_cams + 1) * sizeof(int), hipHostMallocMapped));
+    { const char* e = getenv("MORB_HOST_OCTREE"); ex->device_octree = !(e && atoi(e) != 0); }
+    ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
     {
@@ -816,13 +1249,16 @@ void orbx_destroy(orbx_extractor* ex) {
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release();
-    ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release();
+    ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release(); ex->d_sel_oct.release();
+    ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release(); ex->d_out_base.release();
+    ex->d_n_out.release(); ex->d_cam_base.release(); ex->d_slot_blk.release();
     for (auto& b : ex->d_kps) b.release();
     for (auto& b : ex->d_desc) b.release();
     ex->d_out_kps.release(); ex->d_out_desc.release();
     if (ex->h_cand) (void)hipHostFree(ex->h_cand);
     if (ex->h_level_cnt) (void)hipHostFree(ex->h_level_cnt);
     if (ex->h_sel) (void)hipHostFree(ex->h_sel);
+    if (ex->h_oct) (void)hipHostFree(ex->h_oct);
     for (int i = 0; i < 6; ++i) if (ex->ev[i]) (void)hipEventDestroy(ex->ev[i]);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
@@ -927,10 +1363,54 @@ int orbx_run(orbx_extractor* ex) {
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[2], st));
     // K3b: dense cell-major lists into pinned host memory
     hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ML), dim3(1024), 0, st, (const LevelInfo*)ex->d_levels.p,
-                       (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_cell_off.p, d_cand, d_level_cnt);
+                       (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_cell_off.p, d_cand, d_level_cnt,
+                       ex->d_cand_dev.p, ex->d_level_cnt_dev.p);
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[3], st));
     MORB_HIP(hipGetLastError());
-    MORB_HIP(hipStreamSynchronize(st));
+
+    // K4 on the device: quadtree -> output offsets -> K5-K7 straight from the slotted list; ONE sync afterwards, which
+    // overlaps the describe kernel.  Falls through to the host quadtree when a level is outside the device limits.
+    if (ex->device_octree && ex->total_sel_slots > 0) {
+        int* d_h_oct = nullptr;
+        MORB_HIP(hipHostGetDevicePointer((void**)&d_h_oct, ex->h_oct, 0));
+        MirrorArgs mir;
+        mir.kps = nullptr; mir.desc = nullptr;
+        if (ex->mirror_kps) { mir.kps = ex->mirror_kps; mir.desc = ex->mirror_desc; }  // cap_total covers every camera's capacity
+        for (int c = 0; c < 64; ++c) mir.base[c] = 0;
+        hipLaunchKernelGGL(k_octree, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
+                           (const uint32_t*)ex->d_cand_dev.p, (const int*)ex->d_level_cnt_dev.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
+                           ex->d_oct_status.p, ML);
+        hipLaunchKernelGGL(k_sel_offsets, dim3(1), dim3(64), 0, st, (const int*)ex->d_sel_cnt.p, ex->n_cams, ML, ex->d_out_base.p,
+                           ex->d_n_out.p, ex->d_cam_base.p, d_h_oct, (const int*)ex->d_oct_status.p, d_h_oct + ex->n_cams);
+        if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[4], st));
+        hipLaunchKernelGGL(k_describe, dim3((ex->total_sel_slots + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
+                           (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel_oct.p, ex->total_sel_slots,
+                           (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
+                           (const unsigned short*)ex->d_slot_blk.p, (const int*)ex->d_sel_cnt.p, (const int*)ex->d_out_base.p,
+                           (const int*)ex->d_cam_base.p);
+        if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[5], st));
+        MORB_HIP(hipGetLastError());
+        MORB_HIP(hipStreamSynchronize(st));
+        if (ex->h_oct[ex->n_cams] == 0) {
+            bool fits = true;
+            for (int c = 0; c < ex->n_cams; ++c) { ex->n_out[c] = ex->h_oct[c]; if (ex->n_out[c] > ex->out_cap_active[c]) fits = false; }
+            for (size_t b = 0; b < ex->levels.size(); ++b) ex->level_cnt_last[b] = ex->levels[b].w ? ex->h_level_cnt[b] : 0;
+            if (!fits) { morb::set_error("a camera produced more keypoints than its output capacity"); return ORB_E_CAPACITY; }
+            if (ex->profiling) {
+                float ms;
+                MORB_HIP(hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1])); ex->stage_us[0] = ms * 1000.f;
+                MORB_HIP(hipEventElapsedTime(&ms, ex->ev[1], ex->ev[2])); ex->stage_us[1] = ms * 1000.f;
+                MORB_HIP(hipEventElapsedTime(&ms, ex->ev[2], ex->ev[3])); ex->stage_us[2] = ms * 1000.f;
+                MORB_HIP(hipEventElapsedTime(&ms, ex->ev[3], ex->ev[4])); ex->stage_us[3] = ms * 1000.f;  // device quadtree
+                MORB_HIP(hipEventElapsedTime(&ms, ex->ev[4], ex->ev[5])); ex->stage_us[4] = ms * 1000.f;
+                ex->stage_us[5] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+            }
+            return ORB_OK;
+        }
+        std::fill(ex->n_out.begin(), ex->n_out.end(), 0);  // a level exceeded the device limits: redo the selection on the host
+    } else {
+        MORB_HIP(hipStreamSynchronize(st));
+    }
     const auto t_host0 = std::chrono::steady_clock::now();
 
     // K4 (host): quadtree per (camera, level) on the worker pool; output order = level-major, list order inside a level
@@ -1003,7 +1483,8 @@ int orbx_run(orbx_extractor* ex) {
         MORB_HIP(hipMemcpyAsync(ex->d_sel.p, ex->h_sel, (size_t)nsel * sizeof(SelKp), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_describe, dim3((nsel + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
                            (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel.p, nsel,
-                           (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir);
+                           (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
+                           (const unsigned short*)nullptr, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr);
         MORB_HIP(hipGetLastError());
     }
     if (ex->profiling) {

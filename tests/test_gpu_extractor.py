@@ -120,3 +120,34 @@ def test_resident_path_and_determinism():
         okps, odesc = oracle.extract(imgs[c], nfeatures=1000)
         _assert_same(first[c][0], first[c][1], okps, odesc)
     ex.close()
+
+
+def test_host_quadtree_path_equals_device_quadtree_path():
+    """MORB_HOST_OCTREE=1 forces the host quadtree (also the fallback when a level exceeds the device limits)."""
+    import os
+    import multi_orb_slam_amd as m
+    imgs = [synth.image(c, 2, 640, 480) for c in range(2)]
+    outs = []
+    for env in ("0", "1"):
+        os.environ["MORB_HOST_OCTREE"] = env
+        ex = _mk([m.ExtractorParams(nfeatures=1000), m.ExtractorParams(nfeatures=500)], 640, 480)
+        outs.append(ex.extract(imgs))
+        ex.close()
+    os.environ.pop("MORB_HOST_OCTREE")
+    for c in range(2):
+        assert outs[0][c][0].tobytes() == outs[1][c][0].tobytes() and np.array_equal(outs[0][c][1], outs[1][c][1])
+        okps, odesc = oracle.extract(imgs[c], nfeatures=(1000, 500)[c])
+        _assert_same(outs[0][c][0], outs[0][c][1], okps, odesc)
+
+
+@pytest.mark.parametrize("nf", [50, 217, 1500, 3000])
+def test_quota_sweep_device_quadtree(nf):
+    """Different quotas drive the quadtree through different full/careful pass patterns."""
+    import multi_orb_slam_amd as m
+    ex = _mk([m.ExtractorParams(nfeatures=nf)], 640, 480)
+    for t in range(2):
+        img = synth.image(7, t, 640, 480)
+        kps, desc = ex(img)
+        okps, odesc = oracle.extract(img, nfeatures=nf)
+        _assert_same(kps, desc, okps, odesc)
+    ex.close()

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_matcher.py tests/test_gpu_frontend.py -m gpu -q -x 2>&1 | tail -2
-for t in 2 4 8 12; do echo "threads=$t"; MORB_OCTREE_THREADS=$t python tools/step_breakdown.py 2>&1 | tail -1 | cut -c1-330; done
+timeout 300 python -X faulthandler -m pytest tests/test_gpu_extractor.py -m gpu -q -x > gpurun_out/dbg_ex.txt 2>&1; grep -E "passed|failed|Error|error|assert|Fatal|Memory" gpurun_out/dbg_ex.txt | head -8
