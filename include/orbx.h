@@ -57,6 +57,15 @@ int orbx_upload(orbx_extractor* ex, int cam, const uint8_t* gray, int width, int
 int orbx_upload_device(orbx_extractor* ex, int cam, const uint8_t* d_gray, int width, int height, int stride);
 /* run the whole extractor on the resident images of cameras [0, n_cams); results stay in HBM */
 int orbx_run(orbx_extractor* ex);
+/* Split form of orbx_run for callers that keep enqueueing dependent work on orbx_stream(ex): orbx_run_async returns
+ * without a host synchronisation (device-quadtree path; otherwise it behaves like orbx_run), the per-camera counts are in
+ * HBM (orbx_device_counts: int[n_cams]); orbx_finish synchronises the stream and makes orbx_count() valid.  It returns 1
+ * (not an error) when a pyramid level was outside the device quadtree's limits and the results were recomputed on the
+ * host path: work enqueued against the asynchronous counts must then be redone. */
+int orbx_run_async(orbx_extractor* ex);
+int orbx_finish(orbx_extractor* ex);
+const int* orbx_device_counts(const orbx_extractor* ex);
+int orbx_pending(const orbx_extractor* ex); /* 1 between an asynchronous orbx_run_async and orbx_finish */
 /* number of keypoints camera `cam` produced in the last run */
 int orbx_count(const orbx_extractor* ex, int cam);
 /* copy the last run's results of one camera to host buffers */

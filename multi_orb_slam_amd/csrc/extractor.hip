@@ -1031,6 +1031,8 @@ struct orbx_extractor {
     int total_sel_slots = 0;
     int* h_oct = nullptr;            // pinned, mapped: [0..n_cams) n_out, [n_cams] status
     bool device_octree = true;
+    bool pending = false;            // orbx_run_async enqueued, orbx_finish not yet called
+    std::chrono::steady_clock::time_point t_begin_async;
     std::vector<DevBuf<orb_keypoint>> d_kps;
     std::vector<DevBuf<uint8_t>> d_desc;
     std::vector<orb_keypoint*> out_kps;   // active output pointers (internal or bound)
@@ -1322,8 +1324,35 @@ int orbx_stage_times_us(const orbx_extractor* ex, float* out6) {
     return ORB_OK;
 }
 
+static int orbx_run_impl(orbx_extractor* ex, bool allow_async);
+
 int orbx_run(orbx_extractor* ex) {
     MORB_ARG(ex != nullptr);
+    int rc = orbx_run_impl(ex, false);
+    return rc;
+}
+
+// Enqueues the whole extractor without a host synchronisation when the device quadtree is in use (otherwise identical
+// to orbx_run).  Counts become known with orbx_finish(); until then they live in HBM (orbx_device_counts).
+int orbx_run_async(orbx_extractor* ex) {
+    MORB_ARG(ex != nullptr);
+    return orbx_run_impl(ex, true);
+}
+
+static int finish_device_path(orbx_extractor* ex);
+
+int orbx_finish(orbx_extractor* ex) {
+    MORB_ARG(ex != nullptr);
+    if (!ex->pending) return ORB_OK;
+    MORB_HIP(hipSetDevice(ex->device));
+    MORB_HIP(hipStreamSynchronize(ex->stream));
+    return finish_device_path(ex);
+}
+
+const int* orbx_device_counts(const orbx_extractor* ex) { return ex ? ex->d_n_out.p : nullptr; }
+int orbx_pending(const orbx_extractor* ex) { return ex && ex->pending ? 1 : 0; }
+
+static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
     MORB_HIP(hipSetDevice(ex->device));
     const auto t_begin = std::chrono::steady_clock::now();
     int rc;
@@ -1390,23 +1419,11 @@ int orbx_run(orbx_extractor* ex) {
                            (const int*)ex->d_cam_base.p);
         if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[5], st));
         MORB_HIP(hipGetLastError());
+        ex->pending = true; ex->t_begin_async = t_begin;
+        if (allow_async) return ORB_OK;
         MORB_HIP(hipStreamSynchronize(st));
-        if (ex->h_oct[ex->n_cams] == 0) {
-            bool fits = true;
-            for (int c = 0; c < ex->n_cams; ++c) { ex->n_out[c] = ex->h_oct[c]; if (ex->n_out[c] > ex->out_cap_active[c]) fits = false; }
-            for (size_t b = 0; b < ex->levels.size(); ++b) ex->level_cnt_last[b] = ex->levels[b].w ? ex->h_level_cnt[b] : 0;
-            if (!fits) { morb::set_error("a camera produced more keypoints than its output capacity"); return ORB_E_CAPACITY; }
-            if (ex->profiling) {
-                float ms;
-                MORB_HIP(hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1])); ex->stage_us[0] = ms * 1000.f;
-                MORB_HIP(hipEventElapsedTime(&ms, ex->ev[1], ex->ev[2])); ex->stage_us[1] = ms * 1000.f;
-                MORB_HIP(hipEventElapsedTime(&ms, ex->ev[2], ex->ev[3])); ex->stage_us[2] = ms * 1000.f;
-                MORB_HIP(hipEventElapsedTime(&ms, ex->ev[3], ex->ev[4])); ex->stage_us[3] = ms * 1000.f;  // device quadtree
-                MORB_HIP(hipEventElapsedTime(&ms, ex->ev[4], ex->ev[5])); ex->stage_us[4] = ms * 1000.f;
-                ex->stage_us[5] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
-            }
-            return ORB_OK;
-        }
+        ex->pending = false;
+        if (ex->h_oct[ex->n_cams] == 0) return finish_device_path(ex);
         std::fill(ex->n_out.begin(), ex->n_out.end(), 0);  // a level exceeded the device limits: redo the selection on the host
     } else {
         MORB_HIP(hipStreamSynchronize(st));
@@ -1499,6 +1516,35 @@ int orbx_run(orbx_extractor* ex) {
         ex->stage_us[5] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
     }
     return ORB_OK;
+}
+
+// After the stream has drained: adopt the device path's counts, or redo the selection on the host if a level was outside
+// the device limits (then the downstream work a caller enqueued on stale counts is invalid: it is told via the return).
+static int finish_device_path(orbx_extractor* ex) {
+    ex->pending = false;
+    if (ex->h_oct[ex->n_cams] == 0) {
+        for (int c = 0; c < ex->n_cams; ++c) {
+            ex->n_out[c] = ex->h_oct[c];
+            if (ex->n_out[c] > ex->out_cap_active[c]) { morb::set_error("a camera produced more keypoints than its output capacity"); return ORB_E_CAPACITY; }
+        }
+        for (size_t b = 0; b < ex->levels.size(); ++b) ex->level_cnt_last[b] = ex->levels[b].w ? ex->h_level_cnt[b] : 0;
+        if (ex->profiling) {
+            float ms;
+            MORB_HIP(hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1])); ex->stage_us[0] = ms * 1000.f;
+            MORB_HIP(hipEventElapsedTime(&ms, ex->ev[1], ex->ev[2])); ex->stage_us[1] = ms * 1000.f;
+            MORB_HIP(hipEventElapsedTime(&ms, ex->ev[2], ex->ev[3])); ex->stage_us[2] = ms * 1000.f;
+            MORB_HIP(hipEventElapsedTime(&ms, ex->ev[3], ex->ev[4])); ex->stage_us[3] = ms * 1000.f;  // device quadtree
+            MORB_HIP(hipEventElapsedTime(&ms, ex->ev[4], ex->ev[5])); ex->stage_us[4] = ms * 1000.f;
+            ex->stage_us[5] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - ex->t_begin_async).count();
+        }
+        return ORB_OK;
+    }
+    // a level exceeded the device limits: run the synchronous host-quadtree path on the same resident images
+    const bool saved = ex->device_octree;
+    ex->device_octree = false;
+    int rc = orbx_run_impl(ex, false);
+    ex->device_octree = saved;
+    return rc ? rc : 1;  // 1 = results valid, but they were produced by the fallback (anything enqueued on the async counts is stale)
 }
 
 int orbx_count(const orbx_extractor* ex, int cam) {

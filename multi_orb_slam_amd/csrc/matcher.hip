@@ -134,7 +134,8 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_hamming_top2(const uint4* _
 
 __global__ void k_top2_merge(const int* __restrict__ p_idx, const int* __restrict__ p_best,
                              const int* __restrict__ p_second, int S, int nq, int* __restrict__ best_idx,
-                             int* __restrict__ best_dist, int* __restrict__ second_dist) {
+                             int* __restrict__ best_dist, int* __restrict__ second_dist, const int* __restrict__ d_n = nullptr) {
+    if (d_n) nq = *d_n;  // partial arrays are laid out with stride nq: the producer used the same device count
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
     int B = 256, Sd = 256, I = -1;
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(64 * MAT_WAVES, FULL ? 6 : 4) void k_hamming_matrix
 
 struct FrameDev {
     int n_total, n_cams;
+    const int* n_total_dev;  // non-NULL: the feature count is only known on the device (n_total is then the capacity)
     const float* un_x; const float* un_y; const float* uright;
     const int* octave;
     const uint4* desc;  // global-index order, 2 x uint4 per feature
@@ -429,7 +431,10 @@ __global__ __launch_bounds__(256) void k_frame_fill(const CamFeat* __restrict__ 
 
 // The whole frame assembly in ONE workgroup (n_total <= 8192, n_cams <= 4): fill, per-cell counts and cursors in LDS,
 // scan, scatter, per-cell sort.  Replaces memset + 4 launches on the small frames of a 2-4 camera rig.
-__global__ __launch_bounds__(1024) void k_frame_build_small(const CamFeat* __restrict__ cams, int n_cams, int n_total, float mbf,
+struct CamFeat4 { CamFeat c[4]; };
+
+__global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int* __restrict__ cam_start_out, const int* __restrict__ d_counts,
+                                                            int* __restrict__ n_total_out, int n_cams, int n_total, float mbf,
                                                             float minX, float minY, float invW, float invH,
                                                             float* __restrict__ x, float* __restrict__ y,
                                                             float* __restrict__ ur, float* __restrict__ depth_out,
@@ -438,6 +443,26 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(const CamFeat* __res
                                                             int* __restrict__ cell_start, int* __restrict__ items, HostMirror hm) {
     extern __shared__ __attribute__((aligned(16))) int s_cells[];  // [ncell + 1] start | [ncell + 1] cursor
     __shared__ int wsum[16];
+    // kernel-argument copy of the per-camera descriptors (no H2D).  With d_counts the real counts come from the device
+    // (the extractor has not been synchronised yet): bases and the total are derived here.
+    __shared__ CamFeat s_cams[4];
+    __shared__ int s_ntotal;
+    if (threadIdx.x == 0) {
+        int base = 0;
+        for (int c = 0; c < n_cams; ++c) {
+            CamFeat cf = cams4.c[c];
+            if (d_counts) { cf.n = d_counts[c]; cf.base = base; }
+            s_cams[c] = cf;
+            cam_start_out[c] = cf.base;
+            base = cf.base + cf.n;
+        }
+        cam_start_out[n_cams] = base;
+        s_ntotal = d_counts ? base : n_total;
+        if (n_total_out) *n_total_out = s_ntotal;
+    }
+    __syncthreads();
+    const CamFeat* cams = s_cams;
+    n_total = s_ntotal;
     const int ncell = n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
     int* s_start = s_cells;
     int* s_cur = s_cells + ncell + 1;
@@ -567,13 +592,14 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                                                   int check_ori, int max_it, int* __restrict__ choice,
                                                   const int* __restrict__ topk /* 2*RESOLVE_K*nq ints */,
                                                   int* __restrict__ match_of_feature, int* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) int s_claim[];  // F.n_total entries
+    extern __shared__ __attribute__((aligned(16))) int s_claim[];  // one entry per feature (capacity F.n_total)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_keep[3];
     __shared__ int s_red;
     const int tid = threadIdx.x, T = blockDim.x;
+    const int NT = F.n_total_dev ? *F.n_total_dev : F.n_total;  // actual feature count
     if (tid == 0) s_red = 0;
-    for (int g = tid; g < F.n_total; g += T) s_claim[g] = 0x7fffffff;
+    for (int g = tid; g < NT; g += T) s_claim[g] = 0x7fffffff;
     __syncthreads();
     int mx = 0;
     for (int i = tid; i < nq; i += T) { mx = max(mx, cand_count[i]); choice[i] = -1; }
@@ -677,7 +703,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         return;
     }
     // owners: the last claimant in query order (claims after a blocking one are impossible, so max index == final owner)
-    for (int g = tid; g < F.n_total; g += T) s_claim[g] = -1;
+    for (int g = tid; g < NT; g += T) s_claim[g] = -1;
     if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
     if (tid == 0) s_red = 0;
     __syncthreads();
@@ -728,7 +754,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         atomicSub(&s_red, rej);
         __syncthreads();
     }
-    for (int g = tid; g < F.n_total; g += T) match_of_feature[g] = s_claim[g];
+    for (int g = tid; g < NT; g += T) match_of_feature[g] = s_claim[g];
     if (tid == 0) { status[0] = 0; status[1] = s_red; status[2] = it; status[3] = maxcount; }
 }
 
@@ -736,7 +762,10 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
 __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __restrict__ desc, int n_total,
                                                                 const int* __restrict__ cam_start, int n_cams, int q_off,
                                                                 int nq, int* __restrict__ best_idx,
-                                                                int* __restrict__ best_dist, int* __restrict__ second_dist) {
+                                                                int* __restrict__ best_dist, int* __restrict__ second_dist,
+                                                                const int* __restrict__ d_n) {
+    if (d_n) { n_total = *d_n; nq = n_total; }  // counts only known on the device: the launch was sized for the capacity
+    if (blockIdx.x * 64 >= nq) return;
     __shared__ int sb[TOP2_WAVES][64], ss[TOP2_WAVES][64], si[TOP2_WAVES][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -830,13 +859,13 @@ int launch_matrix(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16
 // ================================================================================================ C ABI
 struct FrameBufs {  // device storage of one frame; recycled through the matcher's pool (no hipMalloc per frame)
     DevBuf<float> d_x, d_y, d_ur, d_depth, d_ang;
-    DevBuf<int32_t> d_oct, d_cell_start, d_items, d_cell_of, d_cursor, d_cam_start;
+    DevBuf<int32_t> d_oct, d_cell_start, d_items, d_cell_of, d_cursor, d_cam_start, d_ntotal;
     DevBuf<uint8_t> d_desc;
     DevBuf<orb_keypoint> d_kps;
     DevBuf<CamFeat> d_cams;
     void release() {
         d_x.release(); d_y.release(); d_ur.release(); d_depth.release(); d_ang.release(); d_oct.release();
-        d_cell_start.release(); d_items.release(); d_cell_of.release(); d_cursor.release(); d_cam_start.release();
+        d_cell_start.release(); d_items.release(); d_cell_of.release(); d_cursor.release(); d_cam_start.release(); d_ntotal.release();
         d_desc.release(); d_kps.release(); d_cams.release();
     }
 };
@@ -864,6 +893,7 @@ struct orbm_frame {
     int n_total = 0, n_cams = 0;
     float minX = 0, minY = 0, maxX = 0, maxY = 0, invW = 0, invH = 0;
     bool device_built = false;
+    bool counts_on_device = false;  // n_total is a capacity until orbf_step has synchronised
     // host copies used by the host resolve / orbm_frame_grid; filled at create for host-built frames, lazily otherwise
     mutable std::vector<int32_t> octave, cell_start, items;
     mutable std::vector<float> angle;
@@ -871,7 +901,7 @@ struct orbm_frame {
     std::vector<int32_t> cam_start;  // n_cams + 1
     FrameDev dev() const {
         FrameDev F;
-        F.n_total = n_total; F.n_cams = n_cams; F.un_x = b->d_x.p; F.un_y = b->d_y.p; F.uright = b->d_ur.p;
+        F.n_total = n_total; F.n_cams = n_cams; F.n_total_dev = counts_on_device ? b->d_ntotal.p : nullptr; F.un_x = b->d_x.p; F.un_y = b->d_y.p; F.uright = b->d_ur.p;
         F.octave = b->d_oct.p; F.desc = (const uint4*)b->d_desc.p; F.cell_start = b->d_cell_start.p; F.items = b->d_items.p;
         F.minX = minX; F.minY = minY; F.invW = invW; F.invH = invH;
         return F;
@@ -891,6 +921,7 @@ static int reserve_frame(FrameBufs* b, int n, int n_cams) {
         (rc = b->d_ang.reserve(nn)) || (rc = b->d_oct.reserve(nn)) || (rc = b->d_desc.reserve(nn * 32)) ||
         (rc = b->d_kps.reserve(nn)) || (rc = b->d_cell_start.reserve(ncell + 1)) || (rc = b->d_items.reserve(nn)) ||
         (rc = b->d_cell_of.reserve(nn)) || (rc = b->d_cursor.reserve(ncell + 1)) || (rc = b->d_cam_start.reserve(n_cams + 1)) ||
+        (rc = b->d_ntotal.reserve(4)) ||
         (rc = b->d_cams.reserve(n_cams)))
         return rc;
     return ORB_OK;
@@ -1135,8 +1166,24 @@ int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** ou
     return ORB_OK;
 }
 
+}  // extern "C"
+
+// d_counts != NULL: cams[c].n are CAPACITIES, the real per-camera counts sit in HBM (orbx_device_counts) and are read by
+// the build kernel; the frame's n_total stays a capacity until the caller has synchronised and calls frame_set_counts.
+static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
+                                  float max_x, float max_y, const int* d_counts, orbm_frame** out);
+
+extern "C" {
+
 int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
                            float max_x, float max_y, orbm_frame** out) {
+    return frame_from_device_impl(m, cams, n_cams, mbf, min_x, min_y, max_x, max_y, nullptr, out);
+}
+
+}  // extern "C"
+
+static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
+                                  float max_x, float max_y, const int* d_counts, orbm_frame** out) {
     MORB_ARG(m && cams && out && n_cams >= 1 && n_cams <= 64 && max_x > min_x && max_y > min_y);
     MORB_HIP(hipSetDevice(m->device));
     int n = 0;
@@ -1146,7 +1193,7 @@ int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n
         n += cams[c].n;
     }
     orbm_frame* F = new orbm_frame();
-    F->owner = m; F->n_total = n; F->n_cams = n_cams; F->device_built = true;
+    F->owner = m; F->n_total = n; F->n_cams = n_cams; F->device_built = true; F->counts_on_device = d_counts != nullptr;
     F->minX = min_x; F->minY = min_y; F->maxX = max_x; F->maxY = max_y;
     F->invW = (float)ORBM_GRID_COLS / (max_x - min_x);
     F->invH = (float)ORBM_GRID_ROWS / (max_y - min_y);
@@ -1170,19 +1217,27 @@ int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n
     for (int c = 0; c <= n_cams; ++c) hstart[c] = F->cam_start[c];
     const int ncell = n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
     hipStream_t st = m->stream;
-    MORB_HIP(hipMemcpyAsync(F->b->d_cams.p, hc, (size_t)n_cams * sizeof(CamFeat), hipMemcpyHostToDevice, st));
-    MORB_HIP(hipMemcpyAsync(F->b->d_cam_start.p, hstart, (size_t)(n_cams + 1) * 4, hipMemcpyHostToDevice, st));
+    const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int);
+    const bool small = n > 0 && n <= 8192 && n_cams <= 4 && lds_small <= 150 * 1024;
+    MORB_ARG(d_counts == nullptr || small);  // device-side counts are only wired into the single-workgroup build
+    if (!small) {
+        MORB_HIP(hipMemcpyAsync(F->b->d_cams.p, hc, (size_t)n_cams * sizeof(CamFeat), hipMemcpyHostToDevice, st));
+        MORB_HIP(hipMemcpyAsync(F->b->d_cam_start.p, hstart, (size_t)(n_cams + 1) * 4, hipMemcpyHostToDevice, st));
+    }
     HostMirror hm{nullptr, nullptr, nullptr, nullptr};
     if (m->mirror_kps) { hm.kps = m->mirror_kps; hm.desc = (uint4*)m->mirror_desc; }
     if (m->mirror_ur) { hm.ur = m->mirror_ur; hm.depth = m->mirror_depth; }
-    const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int);
-    if (n > 0 && n <= 8192 && lds_small <= 150 * 1024) {
+    if (small) {
         static bool raised = false;
         if (!raised) {
             MORB_HIP(hipFuncSetAttribute((const void*)k_frame_build_small, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             raised = true;
         }
-        hipLaunchKernelGGL(k_frame_build_small, dim3(1), dim3(1024), lds_small, st, (const CamFeat*)F->b->d_cams.p, n_cams, n, mbf,
+        CamFeat4 c4;
+        memset(&c4, 0, sizeof(c4));
+        for (int c = 0; c < n_cams; ++c) c4.c[c] = hc[c];
+        hipLaunchKernelGGL(k_frame_build_small, dim3(1), dim3(1024), lds_small, st, c4, F->b->d_cam_start.p, d_counts, F->b->d_ntotal.p,
+                           n_cams, n, mbf,
                            F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
                            F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_start.p,
                            F->b->d_items.p, hm);
@@ -1208,6 +1263,17 @@ int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n
     *out = F;
     return ORB_OK;
 }
+
+// the caller has synchronised and learnt the real counts
+static void frame_set_counts(orbm_frame* F, const int* counts) {
+    int base = 0;
+    for (int c = 0; c < F->n_cams; ++c) { F->cam_start[c] = base; base += counts[c]; }
+    F->cam_start[F->n_cams] = base;
+    F->n_total = base;
+    F->counts_on_device = false;
+}
+
+extern "C" {
 
 int orbm_frame_count(const orbm_frame* f) { return f ? f->n_total : ORB_E_ARG; }
 
@@ -1497,7 +1563,8 @@ int orbm_search_by_projection_points(orbm_matcher* m, const orbm_frame* cur, con
 
 // k_cross_top2 (+ merge) over `n` features in `d_desc` split into cameras by `d_cam_start`; queries [q_off, q_off+nq).
 // Results land in the pinned mirrors m->h_i0/h_i1/h_i2 once the stream has been synchronised.
-static int cross_enqueue(orbm_matcher* m, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off, int nq) {
+static int cross_enqueue(orbm_matcher* m, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off, int nq,
+                         const int* d_n = nullptr) {
     if (nq == 0) return ORB_OK;
     const int qblocks = (nq + 63) / 64;
     const int S = top2_slices(nq, n);
@@ -1508,14 +1575,14 @@ static int cross_enqueue(orbm_matcher* m, const uint8_t* d_desc, int n, const in
     hipStream_t st = m->stream;
     if (S <= 1) {  // final results go straight to the mapped pinned mirrors
         hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, 1), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
-                           n_cams, q_off, nq, m->h_i0.dp, m->h_i1.dp, m->h_i2.dp);
+                           n_cams, q_off, nq, m->h_i0.dp, m->h_i1.dp, m->h_i2.dp, d_n);
     } else {
         int* p = (int*)m->d_scratch.p;
         int *p_idx = p, *p_best = p + (size_t)S * nq, *p_second = p + 2 * (size_t)S * nq;
         hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, S), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
-                           n_cams, q_off, nq, p_idx, p_best, p_second);
+                           n_cams, q_off, nq, p_idx, p_best, p_second, d_n);
         hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, m->h_i0.dp,
-                           m->h_i1.dp, m->h_i2.dp);
+                           m->h_i1.dp, m->h_i2.dp, d_n);
     }
     MORB_HIP(hipGetLastError());
     return ORB_OK;
@@ -1579,7 +1646,7 @@ struct orbf_frontend {
     orbm_matcher* mt = nullptr;
     std::vector<const float*> d_depth;
     std::vector<int> depth_stride;
-    std::vector<int32_t> counts;
+    std::vector<int32_t> counts, cam_cap;
     float mbf = 40.f;
     int th_high = ORBM_TH_HIGH, check_ori = 1;
     int cap_total = 0;
@@ -1607,7 +1674,7 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     f->d_depth.assign(n_cams, nullptr); f->depth_stride.assign(n_cams, 0); f->counts.assign(n_cams, 0);
     f->scale_factors.assign(params[0].nlevels, 1.f);
     if ((rc = orbx_tables(&params[0], f->scale_factors.data(), nullptr, nullptr, nullptr, nullptr, nullptr))) { orbf_destroy(f); return rc; }
-    for (int c = 0; c < n_cams; ++c) f->cap_total += params[c].nfeatures + 4 * params[c].nlevels;
+    for (int c = 0; c < n_cams; ++c) { f->cam_cap.push_back(params[c].nfeatures + 4 * params[c].nlevels); f->cap_total += f->cam_cap.back(); }
     const size_t cap = (size_t)f->cap_total;
     if ((rc = f->h_kps.reserve(cap)) || (rc = f->h_desc.reserve(cap * 32)) || (rc = f->h_ur.reserve(cap)) ||
         (rc = f->h_depth.reserve(cap)) || (rc = f->h_match.reserve(cap)) ||
@@ -1685,35 +1752,64 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         if (!queries_in_pinned) memcpy(f->h_queries.p, queries, (size_t)nq * sizeof(orbm_query));
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, f->h_queries.p, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
     }
-    if ((rc = orbx_run(f->ex))) return rc;  // one mid-pipeline sync inside (host quadtree)
+    // ---- extraction: enqueued without a host sync when the device quadtree is active
+    if ((rc = orbx_run_async(f->ex))) return rc;
     std::vector<orbm_cam_features> cams(f->n_cams);
-    int n = 0;
-    for (int c = 0; c < f->n_cams; ++c) {
-        f->counts[c] = orbx_count(f->ex, c);
-        cams[c].d_kps = orbx_device_keypoints(f->ex, c); cams[c].d_desc = orbx_device_descriptors(f->ex, c);
-        cams[c].n = f->counts[c]; cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
-        n += f->counts[c];
-    }
     if (W == 0 || H == 0) { W = f->max_w; H = f->max_h; }
-    orbm_frame* fr = nullptr;
-    // the frame-build kernel mirrors the merged arrays straight into this handle's pinned result buffers
-    m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = f->h_ur.dp; m->mirror_depth = f->h_depth.dp;
-    rc = orbm_frame_from_device(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, &fr);
-    m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = nullptr; m->mirror_depth = nullptr;
-    if (rc) return rc;
+    const int* d_counts = orbx_device_counts(f->ex);
+    int cap_sum = 0;
+    for (int c = 0; c < f->n_cams; ++c) cap_sum += f->cam_cap[c];
+    bool async_path = orbx_pending(f->ex) && f->n_cams <= 4 && cap_sum <= 8192 && !m->host_resolve;
     hipStream_t st = m->stream;
-    // (the fallback paths of the search read the queries on the host: always the pinned copy, which nothing overwrites)
-    SearchJob J{fr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
-    rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
-    const bool do_cross = !(flags & ORBF_SKIP_CROSS) && n > 0;
-    if (!rc && do_cross) rc = cross_enqueue(m, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n);
-    if (rc) { orbm_frame_destroy(fr); return rc; }
-    const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipStreamSynchronize(st);
-    out->gpu_wait_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    if (e != hipSuccess) { morb::set_error("hipStreamSynchronize: %s", hipGetErrorString(e)); orbm_frame_destroy(fr); return ORB_E_HIP; }
-    int nmatches = 0;
-    if ((rc = f->h_match.reserve(std::max(n, 1)))) { orbm_frame_destroy(fr); return rc; }
+    orbm_frame* fr = nullptr;
+    int n = 0, nmatches = 0;
+    bool do_cross = !(flags & ORBF_SKIP_CROSS);
+    SearchJob J{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
+    if ((rc = f->h_match.reserve(std::max(cap_sum, 1)))) return rc;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!async_path) {
+            rc = orbx_finish(f->ex);  // synchronises; counts are on the host from here on
+            if (rc < 0) return rc;
+        }
+        n = 0;
+        for (int c = 0; c < f->n_cams; ++c) {
+            cams[c].d_kps = orbx_device_keypoints(f->ex, c); cams[c].d_desc = orbx_device_descriptors(f->ex, c);
+            cams[c].n = async_path ? f->cam_cap[c] : orbx_count(f->ex, c);
+            cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
+            n += cams[c].n;
+        }
+        // the frame-build kernel mirrors the stereo arrays straight into this handle's pinned result buffers (keypoints
+        // and descriptors were mirrored by the extractor's describe kernel)
+        m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = f->h_ur.dp; m->mirror_depth = f->h_depth.dp;
+        rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, async_path ? d_counts : nullptr, &fr);
+        m->mirror_ur = nullptr; m->mirror_depth = nullptr;
+        if (rc) return rc;
+        J.cur = fr; J.cap = 64; J.device_path = false;
+        rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
+        if (!rc && do_cross && n > 0)
+            rc = cross_enqueue(m, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n, async_path ? fr->b->d_ntotal.p : nullptr);
+        if (rc) { orbm_frame_destroy(fr); return rc; }
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t e = hipStreamSynchronize(st);
+        out->gpu_wait_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (e != hipSuccess) { morb::set_error("hipStreamSynchronize: %s", hipGetErrorString(e)); orbm_frame_destroy(fr); return ORB_E_HIP; }
+        if (async_path) {
+            rc = orbx_finish(f->ex);  // stream already idle: adopts the counts (or reports the host-quadtree fallback)
+            if (rc < 0) { orbm_frame_destroy(fr); return rc; }
+            if (rc == 1) {  // counts used by the enqueued matcher work were stale: redo that part synchronously
+                orbm_frame_destroy(fr); fr = nullptr;
+                async_path = false;
+                continue;
+            }
+            for (int c = 0; c < f->n_cams; ++c) f->counts[c] = orbx_count(f->ex, c);
+            frame_set_counts(fr, f->counts.data());
+            n = fr->n_total;
+        } else {
+            for (int c = 0; c < f->n_cams; ++c) f->counts[c] = cams[c].n;
+        }
+        break;
+    }
+    do_cross = do_cross && n > 0;
     rc = search_finish(m, J, f->h_match.p, &nmatches);
     orbm_frame_destroy(fr);  // stream is idle: the buffers go straight back to the pool
     if (rc) return rc;

@@ -17,12 +17,25 @@ def _view(addr, dtype, count, shape=None):
 
 
 class NativeFrontEnd:
+    def _cached(self, name, addr, dtype, cap, row=None):
+        """numpy view over a native pinned buffer, created once per (address) and sliced per step."""
+        if not addr:
+            return None
+        ent = self._views.get(name)
+        if ent is None or ent[0] != addr:
+            shape = (cap,) if row is None else (cap, row)
+            ent = (addr, _view(addr, dtype, cap, shape if row is not None else None))
+            self._views[name] = ent
+        return ent[1]
+
     def __init__(self, params, max_width, max_height, device=0):
         self.params = list(params); self.n_cams = len(self.params)
         arr = (Params * self.n_cams)(*[p.c() for p in self.params])
         self._h = C.c_void_p()
         check(_lib.lib().orbf_create(arr, self.n_cams, max_width, max_height, device, C.byref(self._h)))
         self._res = FResult()
+        self._views = {}
+        self.cap_total = sum(p.nfeatures + 4 * p.nlevels for p in self.params)
         self._imgs = (FImage * self.n_cams)()
 
     def close(self):
@@ -76,13 +89,15 @@ class NativeFrontEnd:
             check(_lib.lib().orbf_step(self._h, self._imgs, ptr(queries) if nq else None, nq, flags, C.byref(self._res)))
         r = self._res
         n = r.n_total
+        cap = self.cap_total
         cp = (lambda a: a.copy()) if copy else (lambda a: a)
-        out = dict(counts=_view(r.counts, np.int32, r.n_cams).tolist(), kps=cp(_view(r.kps, KP_DTYPE, n)),
-                   desc=cp(_view(r.desc, np.uint8, n, (n, 32))), uright=cp(_view(r.uright, np.float32, n)),
-                   depth=cp(_view(r.depth, np.float32, n)), n_temporal=r.nmatches,
-                   match_of_feature=cp(_view(r.match_of_feature, np.int32, n)) if nq else np.zeros(0, np.int32),
+        V = self._cached
+        out = dict(counts=V("counts", r.counts, np.int32, self.n_cams).tolist(), kps=cp(V("kps", r.kps, KP_DTYPE, cap)[:n]),
+                   desc=cp(V("desc", r.desc, np.uint8, cap, 32)[:n]), uright=cp(V("ur", r.uright, np.float32, cap)[:n]),
+                   depth=cp(V("depth", r.depth, np.float32, cap)[:n]), n_temporal=r.nmatches,
+                   match_of_feature=cp(V("match", r.match_of_feature, np.int32, cap)[:n]) if nq else np.zeros(0, np.int32),
                    gpu_wait_us=r.gpu_wait_us, n_queries=nq)
         if r.cross_best_idx:
-            out["cross"] = (cp(_view(r.cross_best_idx, np.int32, n)), cp(_view(r.cross_best_dist, np.int32, n)),
-                            cp(_view(r.cross_second_dist, np.int32, n)))
+            out["cross"] = (cp(V("x0", r.cross_best_idx, np.int32, cap)[:n]), cp(V("x1", r.cross_best_dist, np.int32, cap)[:n]),
+                            cp(V("x2", r.cross_second_dist, np.int32, cap)[:n]))
         return out
