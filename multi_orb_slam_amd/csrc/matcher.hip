@@ -267,7 +267,7 @@ constexpr int RESOLVE_K = 6;
 __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap,
                                                  int gate_right, int with_dist, int transposed, int* __restrict__ cand_idx,
                                                  uint16_t* __restrict__ cand_dist, int* __restrict__ cand_count,
-                                                 const uint8_t* __restrict__ occupied, int* __restrict__ topk) {
+                                                 const uint8_t* __restrict__ occupied, int* __restrict__ topk, int short_th) {
     const int lane = threadIdx.x & 63;
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (qi >= nq) return;
@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
     const uint4 q0 = make_uint4(qd[0], qd[1], qd[2], qd[3]), q1 = make_uint4(qd[4], qd[5], qd[6], qd[7]);
 
     int total = 0;
+    int n_elig = 0;                    // survivors that could ever be accepted: not occupied and distance <= short_th
     int sk[RESOLVE_K], sg[RESOLVE_K];  // wave-uniform sorted shortlist
 #pragma unroll
     for (int k = 0; k < RESOLVE_K; ++k) { sk[k] = 0x7fffffff; sg[k] = -1; }
@@ -345,7 +346,12 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
                     if (with_dist) cand_dist[o] = (uint16_t)dist;
                 }
                 if (topk) {  // merge this batch's survivors into the sorted shortlist (at most RESOLVE_K extractions)
-                    int key = (pass && !(occupied && occupied[g])) ? ((dist << 16) | pos) : 0x7fffffff;
+                    // A frame search accepts only distance <= th_high, so farther candidates can neither win nor matter:
+                    // they stay out of the shortlist and out of the "list longer than the shortlist" count (short_th =
+                    // th_high there; 256 = keep everything for the top-2 / ratio-test search).
+                    const bool elig = pass && !(occupied && occupied[g]) && dist <= short_th;
+                    n_elig += __popcll(__ballot(elig));
+                    int key = elig ? ((dist << 16) | pos) : 0x7fffffff;
 #pragma unroll
                     for (int e = 0; e < RESOLVE_K; ++e) {
                         int mn = key;
@@ -372,6 +378,7 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
                 topk[(size_t)k * nq + qi] = sk[k];
                 topk[(size_t)(RESOLVE_K + k) * nq + qi] = sg[k];
             }
+            topk[(size_t)(2 * RESOLVE_K) * nq + qi] = n_elig;
         }
     }
 }
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                                                   const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
                                                   const float* __restrict__ f_angle, int th_high, float nnratio,
                                                   int check_ori, int max_it, int* __restrict__ choice,
-                                                  const int* __restrict__ topk /* 2*RESOLVE_K*nq ints */,
+                                                  const int* __restrict__ topk /* (2*RESOLVE_K+1)*nq ints */,
                                                   int* __restrict__ match_of_feature, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // one entry per feature (capacity F.n_total)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     if (LDSQ) {
         for (int i = tid; i < nq; i += T) {
             l_choice[i] = -1;
-            l_fl[i] = (unsigned char)((q[i].blocks ? 1 : 0) | (cand_count[i] > RESOLVE_K ? 2 : 0));
+            l_fl[i] = (unsigned char)((q[i].blocks ? 1 : 0) | (topk[(size_t)(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
 #pragma unroll
             for (int k = 0; k < RESOLVE_K; ++k) {
                 l_g[(size_t)k * nq + i] = tk_g[(size_t)k * nq + i];
@@ -648,7 +655,8 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 sg[k] = LDSQ ? l_g[(size_t)k * nq + i] : tk_g[(size_t)k * nq + i];
                 sd[k] = LDSQ ? (int)l_d[(size_t)k * nq + i] : (tk_key[(size_t)k * nq + i] >> 16);
             }
-            const int cnt = LDSQ ? ((l_fl[i] & 2) ? RESOLVE_K + 1 : 0) : cand_count[i];  // only "longer than the shortlist" matters
+            // only "more eligible candidates than the shortlist holds" matters
+            const int cnt = LDSQ ? ((l_fl[i] & 2) ? RESOLVE_K + 1 : 0) : topk[(size_t)(2 * RESOLVE_K) * nq + i];
             const int old = LDSQ ? l_choice[i] : choice[i];
             int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
             int found = 0, taken = 0;
@@ -1322,7 +1330,7 @@ int orbm_frame_grid(const orbm_frame* f, int32_t* cell_start, int32_t* items) {
 // k_project into m->d_i0 (idx) / d_u16 (dist) / d_i1 (count); optionally copied to the pinned host mirrors
 static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap, int gate_right,
                        int with_dist, bool upload_queries, bool to_host, int transposed = 0,
-                       const uint8_t* d_occupied = nullptr, int* d_topk = nullptr) {
+                       const uint8_t* d_occupied = nullptr, int* d_topk = nullptr, int short_th = 256) {
     int rc;
     if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_i0.reserve((size_t)nq * cap)) ||
         (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)))
@@ -1331,7 +1339,7 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, q, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_project, dim3((nq + 3) / 4), dim3(256), 0, m->stream, f->dev(),
                        (const orbm_query*)m->d_queries.p, nq, cap, gate_right, with_dist, transposed, m->d_i0.p, m->d_u16.p,
-                       m->d_i1.p, d_occupied, d_topk);
+                       m->d_i1.p, d_occupied, d_topk, short_th);
     MORB_HIP(hipGetLastError());
     if (to_host) {
         if ((rc = m->h_i0.reserve((size_t)nq * cap)) || (rc = m->h_u16.reserve((size_t)nq * cap)) || (rc = m->h_i1.reserve(nq)))
@@ -1472,7 +1480,7 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
         }
     }
     int rc;
-    if ((rc = m->d_choice.reserve(J.nq)) || (rc = m->d_claim.reserve((size_t)2 * RESOLVE_K * J.nq)) || (rc = m->d_match.reserve(n)) ||
+    if ((rc = m->d_choice.reserve(J.nq)) || (rc = m->d_claim.reserve((size_t)(2 * RESOLVE_K + 1) * J.nq)) || (rc = m->d_match.reserve(n)) ||
         (rc = m->d_status.reserve(4)) || (rc = m->h_match.reserve((size_t)n + 4)) || (rc = m->d_occ.reserve(std::max(n, 16))))
         return rc;
     if (J.occupied) MORB_HIP(hipMemcpyAsync(m->d_occ.p, J.occupied, (size_t)n, hipMemcpyHostToDevice, m->stream));
@@ -1480,7 +1488,8 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     const orbm_frame* cur = J.cur;
     const int nq = J.nq, cap = J.cap, th_high = J.th_high;
     const float nnratio = J.nnratio;
-    if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device, false, /*transposed=*/1, d_occ, m->d_claim.p)))
+    if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device, false, /*transposed=*/1, d_occ, m->d_claim.p,
+                          J.points ? 256 : th_high)))
         return rc;
     // claim table + (when it fits) the per-query sweep state
     const size_t lds_q = lds + (size_t)nq * (sizeof(int) + RESOLVE_K * (sizeof(int) + sizeof(unsigned short)) + 1) + 16;
