@@ -291,7 +291,8 @@ constexpr int OCT_NK = 4096;   // candidates per (camera, level) handled on the 
 constexpr int OCT_NL = 1024;   // live nodes (>= quota + 4)
 
 struct OctLds {
-    unsigned short kx[2][OCT_NK], ky[2][OCT_NK], ko[2][OCT_NK], kn[2][OCT_NK];
+    unsigned short kx[2][OCT_NK], ky[2][OCT_NK], kn[2][OCT_NK];
+    unsigned char kr[2][OCT_NK];           // FAST response of the key
     unsigned long long S[OCT_NK];          // inclusive packed prefix of child one-hots; reused as scratch
     short ulx[2][OCT_NL], uly[2][OCT_NL], brx[2][OCT_NL], bry[2][OCT_NL];
     unsigned short nb[2][OCT_NL], ne[2][OCT_NL], ncrt[2][OCT_NL];
@@ -449,7 +450,7 @@ __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, 
         } else {
             nnode = L.newpos[node];
         }
-        L.kx[b][npos] = (unsigned short)x; L.ky[b][npos] = (unsigned short)y; L.ko[b][npos] = L.ko[a][pos];
+        L.kx[b][npos] = (unsigned short)x; L.ky[b][npos] = (unsigned short)y; L.kr[b][npos] = L.kr[a][pos];
         L.kn[b][npos] = (unsigned short)nnode;
     }
     __syncthreads();
@@ -458,15 +459,31 @@ __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, 
 }
 
 // status: 0 ok, 1 = outside the device limits (host falls back)
-__global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ Lv_all, const uint32_t* __restrict__ cand,
-                                                 const int* __restrict__ level_cnt, SelKp* __restrict__ sel,
+// The candidates are read straight from the per-cell slots k_fast_cells filled (cell-major, row-major inside a cell: the
+// order the reference hands them to DistributeOctTree), so no separate compaction kernel sits between them.
+__global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ Lv_all, const int* __restrict__ cell_cnt,
+                                                 const uint32_t* __restrict__ cell_items, SelKp* __restrict__ sel,
                                                  int* __restrict__ sel_cnt, int* __restrict__ status, int max_levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char oct_raw[];
     OctLds& L = *reinterpret_cast<OctLds*>(oct_raw);
     const int blk = blockIdx.x, tid = threadIdx.x;
     const LevelInfo Lv = Lv_all[blk];
-    const int n = Lv.w ? level_cnt[blk] : 0;
     const int N = Lv.quota;
+    const int ncell = Lv.w ? Lv.n_cols * Lv.n_rows : 0;
+    if (ncell > 2 * OCT_NK) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; } return; }
+    // exclusive scan of the per-cell counts (cells in row-major order) -> dense position of every candidate
+    int* cell_off = reinterpret_cast<int*>(L.S);  // ncell + 1 ints of scratch
+    int n = 0;
+    {
+        const int per = (ncell + 1023) / 1024;
+        const int c0 = min(ncell, tid * per), c1 = min(ncell, c0 + per);
+        int mine = 0;
+        for (int c = c0; c < c1; ++c) mine += min(cell_cnt[Lv.cell_base + c], Lv.slot_cap);
+        const int ex = oct_block_excl_scan(mine, tid, L.wsum, &n);
+        int run = ex;
+        for (int c = c0; c < c1; ++c) { cell_off[c] = run; run += min(cell_cnt[Lv.cell_base + c], Lv.slot_cap); }
+        __syncthreads();
+    }
     if (n == 0) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 0; } return; }
     const int width = Lv.w - 2 * MIN_BORDER, height = Lv.h - 2 * MIN_BORDER;
     const int nIni = max(1, (int)roundf((float)width / (float)height));
@@ -474,8 +491,24 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
         if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; }
         return;
     }
-    const uint32_t* cd = cand + Lv.cand_base;
     const float hX = (float)width / (float)nIni;
+    // dense candidate list into buffer 1: thread per candidate, its cell found by bisection of the offsets (all the
+    // global loads of the block are independent and in flight together), then dealt to the roots into buffer 0
+    {
+        if (tid == 0) cell_off[ncell] = n;
+        __syncthreads();
+        for (int p = tid; p < n; p += 1024) {
+            int lo = 0, hi = ncell;  // last c with cell_off[c] <= p (empty cells share an offset: take the last one)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (cell_off[mid] <= p) lo = mid; else hi = mid;
+            }
+            const uint32_t v = cell_items[Lv.slot_base + (size_t)lo * Lv.slot_cap + (p - cell_off[lo])];
+            L.kx[1][p] = (unsigned short)(v & 0xfff); L.ky[1][p] = (unsigned short)((v >> 12) & 0xfff);
+            L.kr[1][p] = (unsigned char)(v >> 24);
+        }
+        __syncthreads();
+    }
     // ---- roots (:544-585): vertical strips, keypoints dealt by (int)(x / hX), empty roots dropped, order = strip order
     {
         unsigned long long loc[4], run = 0;
@@ -487,8 +520,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
             unsigned long long one = 0;
             rx[k] = ry[k] = rr[k] = 0;
             if (pos < n) {
-                const uint32_t v = cd[pos];
-                rx[k] = v & 0xfff; ry[k] = (v >> 12) & 0xfff;
+                rx[k] = L.kx[1][pos]; ry[k] = L.ky[1][pos];
                 int r = (int)((float)rx[k] / hX);
                 r = min(max(r, 0), nIni - 1);
                 rr[k] = r; one = 1ull << (16 * r);
@@ -525,7 +557,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                 const int rank = (int)(((base + loc[k]) >> (16 * r)) & 0xffff) - 1;
                 const int np2 = roff[r] + rank;
                 L.kx[0][np2] = (unsigned short)rx[k]; L.ky[0][np2] = (unsigned short)ry[k];
-                L.ko[0][np2] = (unsigned short)pos; L.kn[0][np2] = (unsigned short)rpos[r];
+                L.kr[0][np2] = L.kr[1][pos]; L.kn[0][np2] = (unsigned short)rpos[r];
             }
         }
         if (tid < nIni) {
@@ -623,18 +655,15 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
     // ---- best keypoint per node, first maximum wins (:742-763); output in list order
     if (tid < sz) {
         const int kb = L.nb[a][tid], ke = L.ne[a][tid];
-        int best = L.ko[a][kb];
-        int bresp = (int)(cd[best] >> 24);
+        int best = kb, bresp = L.kr[a][kb];
         for (int k = kb + 1; k < ke; ++k) {
-            const int o = L.ko[a][k];
-            const int r = (int)(cd[o] >> 24);
-            if (r > bresp) { bresp = r; best = o; }
+            const int r = L.kr[a][k];
+            if (r > bresp) { bresp = r; best = k; }
         }
-        const uint32_t v = cd[best];
         SelKp K;
-        K.x = (int)(v & 0xfff) + MIN_BORDER; K.y = (int)((v >> 12) & 0xfff) + MIN_BORDER;
+        K.x = (int)L.kx[a][best] + MIN_BORDER; K.y = (int)L.ky[a][best] + MIN_BORDER;
         K.camlevel = ((blk / max_levels) << 8) | (blk % max_levels);
-        K.resp_out = (int)((v & 0xff000000u) | (unsigned)tid);
+        K.resp_out = (int)(((unsigned)bresp << 24) | (unsigned)tid);
         sel[Lv.sel_base + tid] = K;
     }
     if (tid == 0) { sel_cnt[blk] = sz; status[blk] = 0; }
@@ -1031,6 +1060,7 @@ struct orbx_extractor {
     int total_sel_slots = 0;
     int* h_oct = nullptr;            // pinned, mapped: [0..n_cams) n_out, [n_cams] status
     bool device_octree = true;
+    bool cand_valid = false;         // h_cand / h_level_cnt hold the last run's candidates (k_compact ran)
     bool pending = false;            // orbx_run_async enqueued, orbx_finish not yet called
     std::chrono::steady_clock::time_point t_begin_async;
     std::vector<DevBuf<orb_keypoint>> d_kps;
@@ -1390,16 +1420,20 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
                        (const int2*)ex->d_cell_map.p, (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, ML, ex->d_cell_cnt.p,
                        ex->d_cell_items.p);
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[2], st));
-    // K3b: dense cell-major lists into pinned host memory
-    hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ML), dim3(1024), 0, st, (const LevelInfo*)ex->d_levels.p,
-                       (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_cell_off.p, d_cand, d_level_cnt,
-                       ex->d_cand_dev.p, ex->d_level_cnt_dev.p);
+    // K3b (only on the host-quadtree path and for the inspection hook): dense cell-major lists, also into pinned host memory
+    const bool dev_tree = ex->device_octree && ex->total_sel_slots > 0;
+    if (!dev_tree) {
+        hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ML), dim3(1024), 0, st, (const LevelInfo*)ex->d_levels.p,
+                           (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_cell_off.p, d_cand, d_level_cnt,
+                           ex->d_cand_dev.p, ex->d_level_cnt_dev.p);
+    }
+    ex->cand_valid = !dev_tree;
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[3], st));
     MORB_HIP(hipGetLastError());
 
     // K4 on the device: quadtree -> output offsets -> K5-K7 straight from the slotted list; ONE sync afterwards, which
     // overlaps the describe kernel.  Falls through to the host quadtree when a level is outside the device limits.
-    if (ex->device_octree && ex->total_sel_slots > 0) {
+    if (dev_tree) {
         int* d_h_oct = nullptr;
         MORB_HIP(hipHostGetDevicePointer((void**)&d_h_oct, ex->h_oct, 0));
         MirrorArgs mir;
@@ -1407,7 +1441,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         if (ex->mirror_kps) { mir.kps = ex->mirror_kps; mir.desc = ex->mirror_desc; }  // cap_total covers every camera's capacity
         for (int c = 0; c < 64; ++c) mir.base[c] = 0;
         hipLaunchKernelGGL(k_octree, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
-                           (const uint32_t*)ex->d_cand_dev.p, (const int*)ex->d_level_cnt_dev.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
+                           (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
                            ex->d_oct_status.p, ML);
         hipLaunchKernelGGL(k_sel_offsets, dim3(1), dim3(64), 0, st, (const int*)ex->d_sel_cnt.p, ex->n_cams, ML, ex->d_out_base.p,
                            ex->d_n_out.p, ex->d_cam_base.p, d_h_oct, (const int*)ex->d_oct_status.p, d_h_oct + ex->n_cams);
@@ -1425,6 +1459,12 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         ex->pending = false;
         if (ex->h_oct[ex->n_cams] == 0) return finish_device_path(ex);
         std::fill(ex->n_out.begin(), ex->n_out.end(), 0);  // a level exceeded the device limits: redo the selection on the host
+        hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ML), dim3(1024), 0, st, (const LevelInfo*)ex->d_levels.p,
+                           (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_cell_off.p, d_cand, d_level_cnt,
+                           ex->d_cand_dev.p, ex->d_level_cnt_dev.p);
+        MORB_HIP(hipGetLastError());
+        MORB_HIP(hipStreamSynchronize(st));
+        ex->cand_valid = true;
     } else {
         MORB_HIP(hipStreamSynchronize(st));
     }
@@ -1527,7 +1567,6 @@ static int finish_device_path(orbx_extractor* ex) {
             ex->n_out[c] = ex->h_oct[c];
             if (ex->n_out[c] > ex->out_cap_active[c]) { morb::set_error("a camera produced more keypoints than its output capacity"); return ORB_E_CAPACITY; }
         }
-        for (size_t b = 0; b < ex->levels.size(); ++b) ex->level_cnt_last[b] = ex->levels[b].w ? ex->h_level_cnt[b] : 0;
         if (ex->profiling) {
             float ms;
             MORB_HIP(hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1])); ex->stage_us[0] = ms * 1000.f;
@@ -1605,6 +1644,19 @@ int orbx_debug_level(orbx_extractor* ex, int cam, int level, uint8_t* out, int c
 int orbx_debug_candidates(orbx_extractor* ex, int cam, int level, orb_keypoint* out, int cap, int* n) {
     MORB_ARG(ex && cam >= 0 && cam < ex->n_cams && level >= 0 && level < ex->cams[cam].p.nlevels && n);
     MORB_ARG(!ex->tables_dirty);
+    if (!ex->cand_valid) {  // the device-quadtree path skips the dense lists: build them now from the per-cell slots
+        MORB_HIP(hipSetDevice(ex->device));
+        uint32_t* d_cand = nullptr; int* d_level_cnt = nullptr;
+        MORB_HIP(hipHostGetDevicePointer((void**)&d_cand, ex->h_cand, 0));
+        MORB_HIP(hipHostGetDevicePointer((void**)&d_level_cnt, ex->h_level_cnt, 0));
+        hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ex->max_levels), dim3(1024), 0, ex->stream, (const LevelInfo*)ex->d_levels.p,
+                           (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_cell_off.p, d_cand, d_level_cnt,
+                           ex->d_cand_dev.p, ex->d_level_cnt_dev.p);
+        MORB_HIP(hipGetLastError());
+        MORB_HIP(hipStreamSynchronize(ex->stream));
+        for (size_t b = 0; b < ex->levels.size(); ++b) ex->level_cnt_last[b] = ex->levels[b].w ? ex->h_level_cnt[b] : 0;
+        ex->cand_valid = true;
+    }
     const LevelInfo& Lv = ex->levels[(size_t)cam * ex->max_levels + level];
     const int cnt = ex->level_cnt_last[(size_t)cam * ex->max_levels + level];
     *n = cnt;

@@ -885,6 +885,10 @@ struct orbm_matcher {
     DevBuf<int32_t> d_i0, d_i1, d_i2, d_choice, d_claim, d_match, d_status, d_x0, d_x1, d_x2;
     DevBuf<uint16_t> d_u16;
     PinnedBuf<int32_t> h_i0, h_i1, h_i2, h_match;
+    PinnedBuf<int32_t> h_c0, h_c1, h_c2;  // cross top-2 results (own buffers: they coexist with a search's h_i0/h_i1)
+    DevBuf<uint8_t> d_cscratch;           // cross top-2 slice partials
+    hipStream_t side_stream = nullptr;    // orbf_step: cross top-2 runs here, next to project + resolve on `stream`
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     PinnedBuf<uint16_t> h_u16;
     PinnedBuf<uint8_t> h_ring;  // 4 slots of {CamFeat[64], int cam_start[65]} for asynchronous H2D
     unsigned ring_pos = 0;
@@ -964,6 +968,13 @@ int orbm_create(int device, orbm_matcher** out) {
     hipError_t e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete m; return ORB_E_HIP; }
     m->stream = m->own_stream;
+    if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
+        morb::set_error("side stream / events could not be created");
+        orbm_destroy(m);
+        return ORB_E_HIP;
+    }
     const char* hr = getenv("MORB_HOST_RESOLVE");
     m->host_resolve = hr && atoi(hr) != 0;
     *out = m;
@@ -974,12 +985,16 @@ void orbm_destroy(orbm_matcher* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
+    if (m->side_stream) { (void)hipStreamSynchronize(m->side_stream); (void)hipStreamDestroy(m->side_stream); }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    m->h_c0.release(); m->h_c1.release(); m->h_c2.release(); m->d_cscratch.release();
     m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release(); m->d_occ.release();
     m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release();
     m->d_match.release(); m->d_status.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
     m->h_i0.release(); m->h_i1.release(); m->h_i2.release(); m->h_match.release(); m->h_u16.release(); m->h_ring.release();
     for (FrameBufs* b : m->pool) { b->release(); delete b; }
-    (void)hipStreamDestroy(m->own_stream);
+    if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
 }
 
@@ -1571,27 +1586,26 @@ int orbm_search_by_projection_points(orbm_matcher* m, const orbm_frame* cur, con
 }
 
 // k_cross_top2 (+ merge) over `n` features in `d_desc` split into cameras by `d_cam_start`; queries [q_off, q_off+nq).
-// Results land in the pinned mirrors m->h_i0/h_i1/h_i2 once the stream has been synchronised.
-static int cross_enqueue(orbm_matcher* m, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off, int nq,
-                         const int* d_n = nullptr) {
+// Results land in the pinned mirrors m->h_c0/h_c1/h_c2 once stream `st` has been synchronised.
+static int cross_enqueue(orbm_matcher* m, hipStream_t st, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off,
+                         int nq, const int* d_n = nullptr) {
     if (nq == 0) return ORB_OK;
     const int qblocks = (nq + 63) / 64;
     const int S = top2_slices(nq, n);
     int rc;
-    if ((rc = m->d_scratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = m->h_i0.reserve(nq)) ||
-        (rc = m->h_i1.reserve(nq)) || (rc = m->h_i2.reserve(nq)))
+    if ((rc = m->d_cscratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = m->h_c0.reserve(nq)) ||
+        (rc = m->h_c1.reserve(nq)) || (rc = m->h_c2.reserve(nq)))
         return rc;
-    hipStream_t st = m->stream;
     if (S <= 1) {  // final results go straight to the mapped pinned mirrors
         hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, 1), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
-                           n_cams, q_off, nq, m->h_i0.dp, m->h_i1.dp, m->h_i2.dp, d_n);
+                           n_cams, q_off, nq, m->h_c0.dp, m->h_c1.dp, m->h_c2.dp, d_n);
     } else {
-        int* p = (int*)m->d_scratch.p;
+        int* p = (int*)m->d_cscratch.p;
         int *p_idx = p, *p_best = p + (size_t)S * nq, *p_second = p + 2 * (size_t)S * nq;
         hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, S), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
                            n_cams, q_off, nq, p_idx, p_best, p_second, d_n);
-        hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, m->h_i0.dp,
-                           m->h_i1.dp, m->h_i2.dp, d_n);
+        hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, m->h_c0.dp,
+                           m->h_c1.dp, m->h_c2.dp, d_n);
     }
     MORB_HIP(hipGetLastError());
     return ORB_OK;
@@ -1600,11 +1614,11 @@ static int cross_enqueue(orbm_matcher* m, const uint8_t* d_desc, int n, const in
 static int cross_launch(orbm_matcher* m, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off, int nq,
                         int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
     if (nq == 0) return ORB_OK;
-    int rc = cross_enqueue(m, d_desc, n, d_cam_start, n_cams, q_off, nq);
+    int rc = cross_enqueue(m, m->stream, d_desc, n, d_cam_start, n_cams, q_off, nq);
     if (rc) return rc;
     MORB_HIP(hipStreamSynchronize(m->stream));
-    memcpy(best_idx, m->h_i0.p, (size_t)nq * 4); memcpy(best_dist, m->h_i1.p, (size_t)nq * 4);
-    memcpy(second_dist, m->h_i2.p, (size_t)nq * 4);
+    memcpy(best_idx, m->h_c0.p, (size_t)nq * 4); memcpy(best_dist, m->h_c1.p, (size_t)nq * 4);
+    memcpy(second_dist, m->h_c2.p, (size_t)nq * 4);
     return ORB_OK;
 }
 
@@ -1794,10 +1808,24 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         m->mirror_ur = nullptr; m->mirror_depth = nullptr;
         if (rc) return rc;
         J.cur = fr; J.cap = 64; J.device_path = false;
-        rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
-        if (!rc && do_cross && n > 0)
-            rc = cross_enqueue(m, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n, async_path ? fr->b->d_ntotal.p : nullptr);
-        if (rc) { orbm_frame_destroy(fr); return rc; }
+        // fork: the camera-pair top-2 only needs the frame's descriptor block, so it runs on the side stream next to
+        // project + resolve (both are a handful of workgroups on a 256-CU part); join before the one host sync
+        const bool forked = do_cross && n > 0;
+        if (forked) {
+            hipError_t fe = hipEventRecord(m->ev_fork, st);
+            if (fe == hipSuccess) fe = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
+            if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); orbm_frame_destroy(fr); return ORB_E_HIP; }
+            rc = cross_enqueue(m, m->side_stream, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n,
+                               async_path ? fr->b->d_ntotal.p : nullptr);
+            hipError_t je = hipEventRecord(m->ev_join, m->side_stream);
+            if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
+        }
+        if (!rc) rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
+        if (forked) {  // join (also on the error path, so that the side stream never outlives the frame)
+            hipError_t je = hipStreamWaitEvent(st, m->ev_join, 0);
+            if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
+        }
+        if (rc) { (void)hipStreamSynchronize(st); orbm_frame_destroy(fr); return rc; }
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipStreamSynchronize(st);
         out->gpu_wait_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -1830,9 +1858,9 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     out->n_cams = f->n_cams; out->n_total = n; out->counts = f->counts.data();
     out->kps = f->h_kps.p; out->desc = f->h_desc.p; out->uright = f->h_ur.p; out->depth = f->h_depth.p;
     out->nmatches = nmatches; out->match_of_feature = f->h_match.p;
-    out->cross_best_idx = do_cross ? m->h_i0.p : nullptr;
-    out->cross_best_dist = do_cross ? m->h_i1.p : nullptr;
-    out->cross_second_dist = do_cross ? m->h_i2.p : nullptr;
+    out->cross_best_idx = do_cross ? m->h_c0.p : nullptr;
+    out->cross_best_dist = do_cross ? m->h_c1.p : nullptr;
+    out->cross_second_dist = do_cross ? m->h_c2.p : nullptr;
     return ORB_OK;
 }
 

@@ -31,6 +31,22 @@ def test_native_step_equals_oracle_pipeline(w, h, nfs):
     fe.close()
 
 
+def test_native_step_with_host_resolve_keeps_cross_results(monkeypatch):
+    """The exact host resolve (fallback of the device resolve) re-projects through the matcher's staging buffers; the
+    camera-pair top-2 of the same step must survive that."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    monkeypatch.setenv("MORB_HOST_RESOLVE", "1")
+    params = [m.ExtractorParams(nfeatures=300), m.ExtractorParams(nfeatures=150)]
+    fe = pipeline.FrontEnd(params, 320, 240)
+    ofe = OracleFrontEnd(params, 320, 240)
+    for t in range(3):
+        imgs = [synth.image(c, t, 320, 240) for c in range(2)]
+        assert_same_step(fe.step(imgs), ofe.step(imgs))
+    fe.close()
+
+
 def test_native_step_with_an_empty_camera():
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd.frontend import NativeFrontEnd

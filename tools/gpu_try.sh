@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python -X faulthandler -m pytest tests/test_gpu_extractor.py -m gpu -q -x > gpurun_out/dbg_ex.txt 2>&1; grep -E "passed|failed|Error|error|assert|Fatal|Memory" gpurun_out/dbg_ex.txt | head -8
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
+timeout 300 python tools/step_breakdown.py 2>&1 | tail -1 | cut -c1-400
+timeout 300 python bench.py 2>&1 | tail -1 | cut -c1-600
