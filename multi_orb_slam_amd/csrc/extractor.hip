@@ -67,6 +67,15 @@ struct MirrorArgs {  // optional pinned-host (device-mapped) copy of the results
     int base[64];
 };
 
+struct SelListArgs {  // device-quadtree mode of k_describe: the slotted selection and where its bookkeeping goes
+    const unsigned short* slot_blk;  // slot -> (camera, level) block; nullptr = host-list mode
+    const int* sel_cnt;              // keypoints the quadtree kept per block
+    const int* status;               // per-block quadtree status (non-zero: outside the device limits)
+    int* n_out;                      // per-camera totals in HBM (downstream kernels size themselves from these)
+    int* h_n_out;                    // the same + the OR of `status` behind them, in mapped pinned memory
+    int n_cams;
+};
+
 struct SelKp {  // one keypoint chosen by the quadtree, input of k_describe
     int x, y;        // level ROI coordinates
     int camlevel;    // cam << 8 | level
@@ -669,25 +678,6 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
     if (tid == 0) { sel_cnt[blk] = sz; status[blk] = 0; }
 }
 
-// out_base[blk] = first output index of (camera, level) inside its camera; n_out[cam]; cam_base[cam] (global order)
-__global__ void k_sel_offsets(const int* __restrict__ sel_cnt, int n_cams, int max_levels, int* __restrict__ out_base,
-                              int* __restrict__ n_out, int* __restrict__ cam_base, int* __restrict__ h_n_out,
-                              const int* __restrict__ status, int* __restrict__ h_status) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int gbase = 0, bad = 0;
-    for (int c = 0; c < n_cams; ++c) {
-        int run = 0;
-        for (int l = 0; l < max_levels; ++l) {
-            out_base[c * max_levels + l] = run;
-            run += sel_cnt[c * max_levels + l];
-            bad |= status[c * max_levels + l];
-        }
-        n_out[c] = run; cam_base[c] = gbase; h_n_out[c] = run;
-        gbase += run;
-    }
-    *h_status = bad;
-}
-
 // ------------------------------------------------------------------------------------------------ K5-K7
 __device__ __forceinline__ int reflect101(int p, int n) {
     // |offset| beyond the edge is at most 3 and n >= 39, so one reflection suffices
@@ -768,26 +758,45 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                                                   const uint8_t* __restrict__ pyr, size_t cam_pitch,
                                                   const SelKp* __restrict__ sel, int nsel,
                                                   orb_keypoint* const* __restrict__ kps_out,
-                                                  uint8_t* const* __restrict__ desc_out, MirrorArgs mir,
-                                                  const unsigned short* __restrict__ slot_blk,
-                                                  const int* __restrict__ sel_cnt, const int* __restrict__ out_base,
-                                                  const int* __restrict__ cam_base) {
+                                                  uint8_t* const* __restrict__ desc_out, MirrorArgs mir, SelListArgs sl) {
     __shared__ uint8_t s_raw[4][PW * RAW_PITCH];
     __shared__ uint16_t s_row[4][PW * ROW_PITCH];
     __shared__ uint8_t s_blur[4][BW * ROW_PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ki = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    const unsigned short* slot_blk = sl.slot_blk;
+    if (slot_blk && blockIdx.x == 0 && wave == 0) {
+        // bookkeeping of the device-quadtree mode, once per launch: per-camera totals and the fallback flag
+        int bad = 0;
+        for (int c = lane; c < sl.n_cams; c += 64) {
+            int run = 0;
+            for (int l = 0; l < max_levels; ++l) { run += sl.sel_cnt[c * max_levels + l]; bad |= sl.status[c * max_levels + l]; }
+            sl.n_out[c] = run; sl.h_n_out[c] = run;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
+        if (lane == 0) sl.h_n_out[sl.n_cams] = bad;
+    }
     if (ki >= nsel) return;
     SelKp K = sel[ki];
     int mirror_base = 0;
     if (slot_blk) {
         // device-quadtree mode: `sel` is the slotted list (quota + 4 slots per (camera, level)); the output position is
-        // the level's base inside its camera plus the list position the quadtree stored in the low 24 bits
+        // the level's base inside its camera plus the list position the quadtree stored in the low 24 bits.  Every wave
+        // sums the block counts in front of its own block itself (a handful of values): no offsets kernel in between.
         const int blk = slot_blk[ki];
         const int local = ki - L[blk].sel_base;
-        if (local >= sel_cnt[blk]) return;
-        K.resp_out = (int)(((unsigned)K.resp_out & 0xff000000u) | (unsigned)(out_base[blk] + local));
-        mirror_base = cam_base[K.camlevel >> 8];
+        if (local >= sl.sel_cnt[blk]) return;
+        const int first_of_cam = (blk / max_levels) * max_levels;
+        int before_cam = 0, before_blk = 0;
+        for (int i = lane; i < blk; i += 64) {
+            const int v = sl.sel_cnt[i];
+            if (i < first_of_cam) before_cam += v; else before_blk += v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { before_cam += __shfl_xor(before_cam, o); before_blk += __shfl_xor(before_blk, o); }
+        K.resp_out = (int)(((unsigned)K.resp_out & 0xff000000u) | (unsigned)(before_blk + local));
+        mirror_base = before_cam;
     }
     const int cam = K.camlevel >> 8, level = K.camlevel & 0xff;
     if (!slot_blk) mirror_base = mir.base[cam];
@@ -1055,7 +1064,7 @@ struct orbx_extractor {
     DevBuf<uint32_t> d_cell_items;
     DevBuf<SelKp> d_sel, d_sel_oct;
     DevBuf<uint32_t> d_cand_dev;
-    DevBuf<int> d_level_cnt_dev, d_sel_cnt, d_oct_status, d_out_base, d_n_out, d_cam_base;
+    DevBuf<int> d_level_cnt_dev, d_sel_cnt, d_oct_status, d_n_out;
     DevBuf<unsigned short> d_slot_blk;
     int total_sel_slots = 0;
     int* h_oct = nullptr;            // pinned, mapped: [0..n_cams) n_out, [n_cams] status
@@ -1164,8 +1173,8 @@ static int rebuild_geometry(orbx_extractor* ex) {
         (rc = ex->d_cell_cnt.reserve(std::max(cell_base, 1))) || (rc = ex->d_cell_off.reserve(std::max(cell_base, 1))) ||
         (rc = ex->d_cell_items.reserve(std::max<size_t>(slot_base, 1))) || (rc = ex->d_cand_dev.reserve(std::max<size_t>(slot_base, 1))) ||
         (rc = ex->d_level_cnt_dev.reserve(ex->levels.size())) || (rc = ex->d_sel_cnt.reserve(ex->levels.size())) ||
-        (rc = ex->d_oct_status.reserve(ex->levels.size())) || (rc = ex->d_out_base.reserve(ex->levels.size())) ||
-        (rc = ex->d_n_out.reserve(ex->n_cams)) || (rc = ex->d_cam_base.reserve(ex->n_cams)) ||
+        (rc = ex->d_oct_status.reserve(ex->levels.size())) ||
+        (rc = ex->d_n_out.reserve(ex->n_cams)) ||
         (rc = ex->d_sel_oct.reserve(std::max<size_t>(slot_blk.size(), 1))) || (rc = ex->d_slot_blk.reserve(std::max<size_t>(slot_blk.size(), 1))))
         return rc;
     if (!slot_blk.empty())
@@ -1282,8 +1291,8 @@ void orbx_destroy(orbx_extractor* ex) {
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release();
     ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release(); ex->d_sel_oct.release();
-    ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release(); ex->d_out_base.release();
-    ex->d_n_out.release(); ex->d_cam_base.release(); ex->d_slot_blk.release();
+    ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release();
+    ex->d_n_out.release(); ex->d_slot_blk.release();
     for (auto& b : ex->d_kps) b.release();
     for (auto& b : ex->d_desc) b.release();
     ex->d_out_kps.release(); ex->d_out_desc.release();
@@ -1443,14 +1452,12 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         hipLaunchKernelGGL(k_octree, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
                            (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
                            ex->d_oct_status.p, ML);
-        hipLaunchKernelGGL(k_sel_offsets, dim3(1), dim3(64), 0, st, (const int*)ex->d_sel_cnt.p, ex->n_cams, ML, ex->d_out_base.p,
-                           ex->d_n_out.p, ex->d_cam_base.p, d_h_oct, (const int*)ex->d_oct_status.p, d_h_oct + ex->n_cams);
         if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[4], st));
         hipLaunchKernelGGL(k_describe, dim3((ex->total_sel_slots + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
                            (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel_oct.p, ex->total_sel_slots,
                            (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
-                           (const unsigned short*)ex->d_slot_blk.p, (const int*)ex->d_sel_cnt.p, (const int*)ex->d_out_base.p,
-                           (const int*)ex->d_cam_base.p);
+                           SelListArgs{(const unsigned short*)ex->d_slot_blk.p, (const int*)ex->d_sel_cnt.p,
+                                       (const int*)ex->d_oct_status.p, ex->d_n_out.p, d_h_oct, ex->n_cams});
         if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[5], st));
         MORB_HIP(hipGetLastError());
         ex->pending = true; ex->t_begin_async = t_begin;
@@ -1541,7 +1548,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         hipLaunchKernelGGL(k_describe, dim3((nsel + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
                            (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel.p, nsel,
                            (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
-                           (const unsigned short*)nullptr, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr);
+                           SelListArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
         MORB_HIP(hipGetLastError());
     }
     if (ex->profiling) {

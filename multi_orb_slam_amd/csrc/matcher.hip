@@ -888,7 +888,7 @@ struct orbm_matcher {
     PinnedBuf<int32_t> h_c0, h_c1, h_c2;  // cross top-2 results (own buffers: they coexist with a search's h_i0/h_i1)
     DevBuf<uint8_t> d_cscratch;           // cross top-2 slice partials
     hipStream_t side_stream = nullptr;    // orbf_step: cross top-2 runs here, next to project + resolve on `stream`
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_q = nullptr;
     PinnedBuf<uint16_t> h_u16;
     PinnedBuf<uint8_t> h_ring;  // 4 slots of {CamFeat[64], int cam_start[65]} for asynchronous H2D
     unsigned ring_pos = 0;
@@ -970,6 +970,7 @@ int orbm_create(int device, orbm_matcher** out) {
     m->stream = m->own_stream;
     if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_q, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
         morb::set_error("side stream / events could not be created");
         orbm_destroy(m);
@@ -988,6 +989,7 @@ void orbm_destroy(orbm_matcher* m) {
     if (m->side_stream) { (void)hipStreamSynchronize(m->side_stream); (void)hipStreamDestroy(m->side_stream); }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->ev_q) (void)hipEventDestroy(m->ev_q);
     m->h_c0.release(); m->h_c1.release(); m->h_c2.release(); m->d_cscratch.release();
     m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release(); m->d_occ.release();
     m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release();
@@ -1773,7 +1775,9 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))))
             return rc;
         if (!queries_in_pinned) memcpy(f->h_queries.p, queries, (size_t)nq * sizeof(orbm_query));
-        MORB_HIP(hipMemcpyAsync(m->d_queries.p, f->h_queries.p, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
+        // on the side stream: the copy engine moves them while the extractor's kernels run; joined before the frame build
+        MORB_HIP(hipMemcpyAsync(m->d_queries.p, f->h_queries.p, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->side_stream));
+        MORB_HIP(hipEventRecord(m->ev_q, m->side_stream));
     }
     // ---- extraction: enqueued without a host sync when the device quadtree is active
     if ((rc = orbx_run_async(f->ex))) return rc;
@@ -1784,6 +1788,7 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     for (int c = 0; c < f->n_cams; ++c) cap_sum += f->cam_cap[c];
     bool async_path = orbx_pending(f->ex) && f->n_cams <= 4 && cap_sum <= 8192 && !m->host_resolve;
     hipStream_t st = m->stream;
+    if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
     orbm_frame* fr = nullptr;
     int n = 0, nmatches = 0;
     bool do_cross = !(flags & ORBF_SKIP_CROSS);
