@@ -149,13 +149,31 @@ __device__ __forceinline__ int fast_score_9_16(const uint8_t* t) {
     return max(sp, -sm) - 1;
 }
 
+// Necessary condition for fast_score_9_16(t) >= min_th, from 4 antipodal ring pairs: every 9-arc of the 16-ring contains
+// one pixel of each antipodal pair, so a bright arc (all d >= T, T = min_th + 1) needs d >= T on one side of EVERY pair,
+// and likewise a dark arc.  Pixels failing both keep the score 0 they would get anyway (the cv::FAST high-speed test).
+__device__ __forceinline__ bool fast_may_be_corner(const uint8_t* t, int T) {
+    const int v = t[0];
+    const int d0 = v - t[3 * TILE_PITCH], d8 = v - t[-3 * TILE_PITCH];
+    const int d4 = v - t[3], d12 = v - t[-3];
+    bool bright = (d0 >= T || d8 >= T) && (d4 >= T || d12 >= T);
+    bool dark = (d0 <= -T || d8 <= -T) && (d4 <= -T || d12 <= -T);
+    if (!(bright || dark)) return false;
+    const int d2 = v - t[2 * TILE_PITCH + 2], d10 = v - t[-2 * TILE_PITCH - 2];
+    const int d6 = v - t[-2 * TILE_PITCH + 2], d14 = v - t[2 * TILE_PITCH - 2];
+    bright = bright && (d2 >= T || d10 >= T) && (d6 >= T || d14 >= T);
+    dark = dark && (d2 <= -T || d10 <= -T) && (d6 <= -T || d14 <= -T);
+    return bright || dark;
+}
+
 __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict__ L, const int2* __restrict__ cell_map,
                                                     const uint8_t* __restrict__ pyr, size_t cam_pitch, int max_levels,
                                                     int* __restrict__ cell_cnt, uint32_t* __restrict__ cell_items) {
     __shared__ uint8_t tile[(CELL_MAX + 6) * TILE_PITCH];
     __shared__ uint8_t score[(CELL_MAX + 2) * SCORE_PITCH];
-    __shared__ uint8_t keep[CELL_MAX * CELL_MAX];
-    __shared__ int s_any;
+    __shared__ unsigned short s_surv[CELL_MAX * CELL_MAX];  // pixels that pass the quick test; reused as `keep` afterwards
+    __shared__ int s_any, s_nsurv;
+    uint8_t* keep = reinterpret_cast<uint8_t*>(s_surv);
 
     const int cell = blockIdx.x;
     const int2 cm = cell_map[cell];  // {cam * max_levels + level, local cell index}
@@ -173,19 +191,39 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
     }
     const uint8_t* img = pyr + cam * cam_pitch + Lv.pyr_off;
     const int tw = cw + 6, th = ch + 6;
+    // i / tw and p / cw for i < 70 * 70 by multiplication: exact because i * divisor < 2^20 (divisors <= 70)
+    const unsigned inv_tw = ((1u << 20) + tw - 1) / tw, inv_cw = ((1u << 20) + cw - 1) / cw;
 
     // stage the tile (origin x0-3, y0-3; always inside the level)
     for (int i = tid; i < tw * th; i += 256) {
-        const int ty = i / tw, tx = i - ty * tw;
+        const int ty = (int)(((unsigned)i * inv_tw) >> 20), tx = i - ty * tw;
         tile[ty * TILE_PITCH + tx] = img[(size_t)(y0 - 3 + ty) * Lv.stride + (x0 - 3 + tx)];
     }
     for (int i = tid; i < (ch + 2) * SCORE_PITCH; i += 256) score[i] = 0;
-    if (tid == 0) s_any = 0;
+    if (tid == 0) { s_any = 0; s_nsurv = 0; }
     __syncthreads();
 
+    // pass 1: quick test on every pixel, survivors compacted (any order) so that pass 2 runs the full score on dense lanes
     const int npx = cw * ch;
-    for (int p = tid; p < npx; p += 256) {
-        const int py = p / cw, px = p - py * cw;
+    const int lane = tid & 63;
+    for (int base = 0; base < npx; base += 256) {
+        const int p = base + tid;
+        bool ok = false;
+        if (p < npx) {
+            const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
+            ok = fast_may_be_corner(&tile[(py + 3) * TILE_PITCH + px + 3], Lv.min_th + 1);
+        }
+        const unsigned long long m = __ballot(ok);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&s_nsurv, __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (ok) s_surv[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+    }
+    __syncthreads();
+    const int nsurv = s_nsurv;
+    for (int i = tid; i < nsurv; i += 256) {
+        const int p = s_surv[i];
+        const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
         int s = fast_score_9_16(&tile[(py + 3) * TILE_PITCH + px + 3]);
         s = s >= Lv.min_th ? s : 0;  // "not a corner at minTh" stores 0, like FAST_t's zeroed score rows
         score[(py + 1) * SCORE_PITCH + px + 1] = (uint8_t)s;
@@ -194,7 +232,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
 
     int any_ini = 0;
     for (int p = tid; p < npx; p += 256) {
-        const int py = p / cw, px = p - py * cw;
+        const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
         const uint8_t* c = &score[(py + 1) * SCORE_PITCH + px + 1];
         const int s = c[0];
         const bool mx = s > 0 && s > c[-1] && s > c[1] && s > c[-SCORE_PITCH - 1] && s > c[-SCORE_PITCH] &&
@@ -217,7 +255,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
             const unsigned long long m = __ballot(ok);
             if (ok) {
                 const int pos = total + __popcll(m & ((1ull << tid) - 1ull));
-                const int py = p / cw, px = p - py * cw;
+                const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
                 const int xr = x0 + px - MIN_BORDER, yr = y0 + py - MIN_BORDER;  // relative to (16,16), :821-826
                 if (pos < Lv.slot_cap) slot[pos] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)s << 24);
             }
