@@ -53,7 +53,8 @@ int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, con
 /* -- resident path (what bench.py times: images already in HBM) --------------------------------------- */
 /* copy one camera's image into the handle's HBM pyramid buffer (async on the handle's stream) */
 int orbx_upload(orbx_extractor* ex, int cam, const uint8_t* gray, int width, int height, int stride);
-/* same, from a DEVICE pointer (e.g. a frame grabber's or torch's buffer) */
+/* same, from a DEVICE pointer (e.g. a frame grabber's or torch's buffer).  The image is read by the first kernel of the
+ * next orbx_run / orbx_run_async (all cameras in one launch): it must stay valid and unchanged until that run has finished. */
 int orbx_upload_device(orbx_extractor* ex, int cam, const uint8_t* d_gray, int width, int height, int stride);
 /* run the whole extractor on the resident images of cameras [0, n_cams); results stay in HBM */
 int orbx_run(orbx_extractor* ex);

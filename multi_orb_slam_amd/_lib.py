@@ -6,7 +6,8 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
-LIB_PATH = os.path.join(_PKG, "lib", "libmorb.so")
+# MORB_LIB_PATH: load an instrumented build of the same library (csrc/Makefile PHASES=1) instead; experiments only
+LIB_PATH = os.environ.get("MORB_LIB_PATH") or os.path.join(_PKG, "lib", "libmorb.so")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])

@@ -87,6 +87,28 @@ __device__ const signed char d_pattern[256][4] = {
 };
 __device__ const int d_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // ctor :455-470
 
+// ------------------------------------------------------------------------------------------------ K0
+// Level 0 of every camera whose image is already in HBM, in ONE launch (a 2-D copy per camera costs a launch each).
+struct IngestArgs { const uint8_t* src[64]; int stride[64]; };
+
+__global__ __launch_bounds__(256) void k_ingest(IngestArgs A, const LevelInfo* __restrict__ L, int max_levels,
+                                                uint8_t* __restrict__ pyr, size_t cam_pitch) {
+    const int cam = blockIdx.z;
+    const uint8_t* src = A.src[cam];
+    if (!src) return;
+    const LevelInfo D = L[cam * max_levels];
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int x16 = (blockIdx.x * 64 + threadIdx.x) * 16;
+    if (y >= D.h || x16 >= D.w) return;
+    const uint8_t* s = src + (size_t)y * A.stride[cam] + x16;
+    uint8_t* d = pyr + cam * cam_pitch + D.pyr_off + (size_t)y * D.stride + x16;  // 16-byte aligned: pitch is a multiple of 64
+    if (x16 + 16 <= D.w && (reinterpret_cast<uintptr_t>(s) & 15) == 0) {
+        *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+    } else {
+        for (int k = 0; k < 16 && x16 + k < D.w; ++k) d[k] = s[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K1
 __global__ __launch_bounds__(256) void k_resize(const LevelInfo* __restrict__ L, int max_levels, int level,
                                                 uint8_t* __restrict__ pyr, size_t cam_pitch,
@@ -337,6 +359,8 @@ __global__ __launch_bounds__(1024) void k_compact(const LevelInfo* __restrict__ 
 constexpr int OCT_NK = 4096;   // candidates per (camera, level) handled on the device
 constexpr int OCT_NL = 1024;   // live nodes (>= quota + 4)
 
+MORB_PHASE_DECL(g_ph_oct);
+
 struct OctLds {
     unsigned short kx[2][OCT_NK], ky[2][OCT_NK], kn[2][OCT_NK];
     unsigned char kr[2][OCT_NK];           // FAST response of the key
@@ -514,6 +538,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
     extern __shared__ __attribute__((aligned(16))) unsigned char oct_raw[];
     OctLds& L = *reinterpret_cast<OctLds*>(oct_raw);
     const int blk = blockIdx.x, tid = threadIdx.x;
+    MORB_PHASE(g_ph_oct, 0);
     const LevelInfo Lv = Lv_all[blk];
     const int N = Lv.quota;
     const int ncell = Lv.w ? Lv.n_cols * Lv.n_rows : 0;
@@ -538,6 +563,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
         if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; }
         return;
     }
+    MORB_PHASE(g_ph_oct, 1);
     const float hX = (float)width / (float)nIni;
     // dense candidate list into buffer 1: thread per candidate, its cell found by bisection of the offsets (all the
     // global loads of the block are independent and in flight together), then dealt to the roots into buffer 0
@@ -556,6 +582,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
         }
         __syncthreads();
     }
+    MORB_PHASE(g_ph_oct, 2);
     // ---- roots (:544-585): vertical strips, keypoints dealt by (int)(x / hX), empty roots dropped, order = strip order
     {
         unsigned long long loc[4], run = 0;
@@ -620,7 +647,9 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
         if (tid == 0) L.v[0] = np_;
         __syncthreads();
     }
+    MORB_PHASE(g_ph_oct, 3);
     int a = 0, sz = L.v[0];
+    int ph_i = 4;
     // ---- main loop (:596-739)
     bool finish = false;
     while (!finish) {
@@ -635,6 +664,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
         int n_expand = 0;
         sz = oct_split_pass(L, a, n, sz, np, tid, &n_expand);
         a ^= 1;
+        MORB_PHASE(g_ph_oct, ph_i); ph_i = min(ph_i + 1, 40);
         if (sz >= N || sz == prev_size) { finish = true; break; }
         if (sz + n_expand * 3 > N) {
             // careful passes: largest nodes first, stop the moment N is reached
@@ -695,6 +725,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                 int ne2 = 0;
                 sz = oct_split_pass(L, a, n, sz, np2, tid, &ne2);
                 a ^= 1;
+                MORB_PHASE(g_ph_oct, ph_i); ph_i = min(ph_i + 1, 40);
                 if (sz >= N || sz == ps) finish = true;
             }
         }
@@ -714,6 +745,10 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
         sel[Lv.sel_base + tid] = K;
     }
     if (tid == 0) { sel_cnt[blk] = sz; status[blk] = 0; }
+    MORB_PHASE(g_ph_oct, 62); MORB_PHASE(g_ph_oct, 63);
+#ifdef MORB_PHASE_CLOCKS
+    if (tid == 0 && blk == 0) g_ph_oct[61] = (unsigned long long)ph_i;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ K5-K7
@@ -1083,6 +1118,8 @@ struct orbx_extractor {
     hipStream_t stream = nullptr;
     std::vector<CamTables> cams;
     std::vector<int> cur_w, cur_h;   // size of the resident image per camera (0 = none)
+    IngestArgs ingest;               // device-resident sources to copy into level 0 at the start of the next run
+    bool ingest_pending = false;
     bool tables_dirty = true;
 
     // geometry (host copies)
@@ -1280,6 +1317,7 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete ex; return ORB_E_HIP; }
     ex->cams.resize(n_cams);
     ex->cur_w.assign(n_cams, 0); ex->cur_h.assign(n_cams, 0);
+    memset(&ex->ingest, 0, sizeof(ex->ingest));
     ex->n_out.assign(n_cams, 0);
     ex->d_kps.resize(n_cams); ex->d_desc.resize(n_cams);
     ex->out_kps.assign(n_cams, nullptr); ex->out_desc.assign(n_cams, nullptr); ex->out_cap_active.assign(n_cams, 0);
@@ -1350,6 +1388,7 @@ static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int wi
     MORB_HIP(hipSetDevice(ex->device));
     if (!src || width <= 0 || height <= 0) {  // empty image: camera produces nothing (reference :1047-1048)
         if (ex->cur_w[cam] != 0) { ex->cur_w[cam] = ex->cur_h[cam] = 0; ex->tables_dirty = true; }
+        ex->ingest.src[cam] = nullptr;
         return ORB_OK;
     }
     MORB_ARG(width <= ex->max_w && height <= ex->max_h && stride >= width);
@@ -1358,6 +1397,11 @@ static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int wi
         ex->tables_dirty = true;
     }
     // level 0 lives at offset 0 of the camera's pyramid buffer with pitch align64(width)
+    if (kind == hipMemcpyDeviceToDevice) {  // copied by k_ingest at the start of the run, all cameras in one launch
+        ex->ingest.src[cam] = src; ex->ingest.stride[cam] = stride; ex->ingest_pending = true;
+        return ORB_OK;
+    }
+    ex->ingest.src[cam] = nullptr;
     MORB_HIP(hipMemcpy2DAsync(ex->d_pyr.p + (size_t)cam * ex->cam_pitch, align_up(width, 64), src, stride, width, height, kind, ex->stream));
     return ORB_OK;
 }
@@ -1443,11 +1487,24 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
     const int ML = ex->max_levels;
     hipStream_t st = ex->stream;
     std::fill(ex->n_out.begin(), ex->n_out.end(), 0);
-    if (ex->total_cells == 0) return ORB_OK;  // every camera empty
+    if (ex->total_cells == 0) {  // every camera empty
+        memset(&ex->ingest, 0, sizeof(ex->ingest)); ex->ingest_pending = false;
+        return ORB_OK;
+    }
     uint32_t* d_cand = nullptr; int* d_level_cnt = nullptr;
     MORB_HIP(hipHostGetDevicePointer((void**)&d_cand, ex->h_cand, 0));
     MORB_HIP(hipHostGetDevicePointer((void**)&d_level_cnt, ex->h_level_cnt, 0));
 
+    if (ex->ingest_pending) {
+        int mw = 0, mh = 0;
+        for (int c = 0; c < ex->n_cams; ++c)
+            if (ex->ingest.src[c]) { mw = std::max(mw, ex->cur_w[c]); mh = std::max(mh, ex->cur_h[c]); }
+        if (mw > 0)
+            hipLaunchKernelGGL(k_ingest, dim3((mw + 1023) / 1024, (mh + 3) / 4, ex->n_cams), dim3(64, 4, 1), 0, st, ex->ingest,
+                               (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch);
+        for (int c = 0; c < ex->n_cams; ++c) ex->ingest.src[c] = nullptr;
+        ex->ingest_pending = false;
+    }
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[0], st));
     // K1: pyramid chain
     for (int l = 1; l < ML; ++l) {
@@ -1726,3 +1783,10 @@ int orbx_debug_distribute_octree(const orb_keypoint* in, int n, int min_x, int m
 }
 
 }  // extern "C"
+
+#ifdef MORB_PHASE_CLOCKS
+extern "C" int morb_debug_phases_extractor(int which, unsigned long long* out64) {
+    (void)which;
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_oct), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256) void k_frame_fill(const CamFeat* __restrict__ 
 // The whole frame assembly in ONE workgroup (n_total <= 8192, n_cams <= 4): fill, per-cell counts and cursors in LDS,
 // scan, scatter, per-cell sort.  Replaces memset + 4 launches on the small frames of a 2-4 camera rig.
 struct CamFeat4 { CamFeat c[4]; };
+MORB_PHASE_DECL(g_ph_fb);
 
 __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int* __restrict__ cam_start_out, const int* __restrict__ d_counts,
                                                             int* __restrict__ n_total_out, int n_cams, int n_total, float mbf,
@@ -448,12 +449,13 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
                                                             int* __restrict__ oct, float* __restrict__ ang,
                                                             orb_keypoint* __restrict__ kps_g, uint4* __restrict__ desc_g,
                                                             int* __restrict__ cell_start, int* __restrict__ items, HostMirror hm) {
-    extern __shared__ __attribute__((aligned(16))) int s_cells[];  // [ncell + 1] start | [ncell + 1] cursor
+    extern __shared__ __attribute__((aligned(16))) int s_cells[];  // [ncell + 1] start | [ncell + 1] cursor | u16 items[8192]
     __shared__ int wsum[16];
     // kernel-argument copy of the per-camera descriptors (no H2D).  With d_counts the real counts come from the device
     // (the extractor has not been synchronised yet): bases and the total are derived here.
     __shared__ CamFeat s_cams[4];
     __shared__ int s_ntotal;
+    MORB_PHASE(g_ph_fb, 0);
     if (threadIdx.x == 0) {
         int base = 0;
         for (int c = 0; c < n_cams; ++c) {
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c <= ncell; c += 1024) s_cur[c] = 0;
     __syncthreads();
+    MORB_PHASE(g_ph_fb, 1);
     int mycell[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -487,6 +490,7 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
         }
     }
     __syncthreads();
+    MORB_PHASE(g_ph_fb, 2);
     // exclusive scan of the counts (in s_cur) -> s_start; s_cur becomes the running insert position
     const int per = (ncell + 1023) / 1024;
     const int c0 = min(ncell, tid * per), c1 = min(ncell, c0 + per);
@@ -509,20 +513,29 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
     int run = wsum[wave] + incl - mine;
     for (int c = c0; c < c1; ++c) { const int v = s_cur[c]; s_start[c] = run; s_cur[c] = run; run += v; }
     __syncthreads();
+    MORB_PHASE(g_ph_fb, 3);
+    // scatter + per-cell sort in LDS (feature indices fit 16 bits here), one coalesced write of the finished item list
+    unsigned short* s_items = reinterpret_cast<unsigned short*>(s_cells + 2 * (ncell + 1));
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-        if (mycell[k] >= 0) items[atomicAdd(&s_cur[mycell[k]], 1)] = tid + k * 1024;
+        if (mycell[k] >= 0) s_items[atomicAdd(&s_cur[mycell[k]], 1)] = (unsigned short)(tid + k * 1024);
     __syncthreads();
+    MORB_PHASE(g_ph_fb, 4);
     for (int c = tid; c <= ncell; c += 1024) cell_start[c] = s_start[c];
     for (int c = tid; c < ncell; c += 1024) {  // ascending global index inside every cell
         const int sidx = s_start[c], e = s_start[c + 1];
         for (int i = sidx + 1; i < e; ++i) {
-            const int v = items[i];
+            const unsigned short v = s_items[i];
             int j = i - 1;
-            while (j >= sidx && items[j] > v) { items[j + 1] = items[j]; --j; }
-            items[j + 1] = v;
+            while (j >= sidx && s_items[j] > v) { s_items[j + 1] = s_items[j]; --j; }
+            s_items[j + 1] = v;
         }
     }
+    __syncthreads();
+    const int n_in_grid = s_start[ncell];
+    for (int i = tid; i < n_in_grid; i += 1024) items[i] = s_items[i];
+    __syncthreads();
+    MORB_PHASE(g_ph_fb, 5);
 }
 
 // exclusive scan of cnt[0..n) into start[0..n], single 1024-thread block; cursor = copy of start
@@ -585,6 +598,8 @@ __global__ __launch_bounds__(256) void k_sort_cells(const int* __restrict__ star
 // status[0]: 0 ok, 1 not converged within max_it (host falls back), 2 a candidate list exceeded cap (host retries);
 // status[1] = nmatches, status[2] = sweeps, status[3] = longest candidate list.
 constexpr int RESOLVE_MAX_Q = 65535;
+MORB_PHASE_DECL(g_ph_res);
+
 // RESOLVE_K (above): sorted shortlist per query built by k_project; a full rescan happens only when all of it is taken
 
 // Evaluates query i against the current claim table.  `avail(g)` decides visibility.  Candidates are visited in the
@@ -602,41 +617,56 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // one entry per feature (capacity F.n_total)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_keep[3];
-    __shared__ int s_red;
+    __shared__ int s_red, s_nres;
     const int tid = threadIdx.x, T = blockDim.x;
-    const int NT = F.n_total_dev ? *F.n_total_dev : F.n_total;  // actual feature count
+    const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    MORB_PHASE(g_ph_res, 0);
+    // the actual feature count is only needed by the last loops: nothing of the set-up waits for this load
+    const int NT = F.n_total_dev ? *F.n_total_dev : F.n_total;
+    // shortlist written by k_project: keys (dist << 16 | visiting position) and feature indices, sorted, occupied excluded
+    const int* tk_key = topk;                             // [k*nq + i]
+    const int* tk_g = topk + RESOLVE_K * nq;      // [k*nq + i]
+    // LDS after the claim table: rescan list u16[nq] (padded to 4 bytes); with LDSQ also
+    //   choice[nq] | shortlist g [K][nq] | query angle [nq] | feature angle [F.n_total] | shortlist d [K][nq] (u16) | flags [nq] (u8)
+    unsigned short* l_res = reinterpret_cast<unsigned short*>(s_claim + F.n_total);
+    int* l_choice = s_claim + F.n_total + (nq + 1) / 2;
+    int* l_g = l_choice + nq;
+    float* l_ang = reinterpret_cast<float*>(l_g + RESOLVE_K * nq);
+    float* l_fang = l_ang + nq;
+    unsigned short* l_d = reinterpret_cast<unsigned short*>(l_fang + F.n_total);
+    unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_d + RESOLVE_K * nq);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
     if (tid == 0) s_red = 0;
-    for (int g = tid; g < NT; g += T) s_claim[g] = 0x7fffffff;
-    __syncthreads();
+    for (int g = tid; g < F.n_total; g += T) {  // capacity-sized: rows past the real count are never referenced
+        s_claim[g] = 0x7fffffff;
+        if (LDSQ && !POINTS && check_ori) l_fang[g] = f_angle[g];
+    }
     int mx = 0;
-    for (int i = tid; i < nq; i += T) { mx = max(mx, cand_count[i]); choice[i] = -1; }
-    atomicMax(&s_red, mx);
+    for (int i = tid; i < nq; i += T) {  // every load of this pass is independent: one trip to HBM for the whole set-up
+        mx = max(mx, cand_count[i]);
+        if (LDSQ) {
+            l_choice[i] = -1;
+            l_fl[i] = (unsigned char)((q[i].blocks ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
+            l_ang[i] = q[i].angle;
+#pragma unroll
+            for (int k = 0; k < RESOLVE_K; ++k) {
+                l_g[k * nq + i] = tk_g[k * nq + i];
+                l_d[k * nq + i] = (unsigned short)(tk_key[k * nq + i] >> 16);
+            }
+        } else {
+            choice[i] = -1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if (lane == 0) atomicMax(&s_red, mx);  // one LDS atomic per wave: same-address atomics of a whole block serialise
     __syncthreads();
     const int maxcount = s_red;
     if (maxcount > cap) {
         if (tid == 0) { status[0] = 2; status[1] = 0; status[2] = 0; status[3] = maxcount; }
         return;
     }
-    // shortlist written by k_project: keys (dist << 16 | visiting position) and feature indices, sorted, occupied excluded
-    const int* tk_key = topk;                             // [k*nq + i]
-    const int* tk_g = topk + (size_t)RESOLVE_K * nq;      // [k*nq + i]
-    // LDS layout after the claim table: choice[nq] | shortlist g [K][nq] | shortlist d [K][nq] (u16) | cnt>K flag+blocks (u8)
-    int* l_choice = s_claim + F.n_total;
-    int* l_g = l_choice + nq;
-    unsigned short* l_d = reinterpret_cast<unsigned short*>(l_g + (size_t)RESOLVE_K * nq);
-    unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_d + (size_t)RESOLVE_K * nq);
-    if (LDSQ) {
-        for (int i = tid; i < nq; i += T) {
-            l_choice[i] = -1;
-            l_fl[i] = (unsigned char)((q[i].blocks ? 1 : 0) | (topk[(size_t)(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
-#pragma unroll
-            for (int k = 0; k < RESOLVE_K; ++k) {
-                l_g[(size_t)k * nq + i] = tk_g[(size_t)k * nq + i];
-                l_d[(size_t)k * nq + i] = (unsigned short)(tk_key[(size_t)k * nq + i] >> 16);
-            }
-        }
-        __syncthreads();
-    }
+    MORB_PHASE(g_ph_res, 2);
+    constexpr int NEED = POINTS ? 2 : 1;
     int it = 0, changed = 1;
     for (; it < max_it && changed; ++it) {
         const int tag = (0x7ffe - it) << 16;  // newer sweep -> smaller tag -> wins atomicMin over stale entries
@@ -645,57 +675,40 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;  // loaded unconditionally: both loads in flight together
             if (c >= 0 && bl) atomicMin(&s_claim[c], tag | i);
         }
+        if (tid == 0) s_nres = 0;
         __syncthreads();
         int ch = 0;
         for (int i = tid; i < nq; i += T) {
-            // the whole shortlist is fetched up front (independent loads in flight), then walked
             int sg[RESOLVE_K], sd[RESOLVE_K];
+            if (!LDSQ) {  // global shortlist: fetched up front (independent loads in flight), then walked
 #pragma unroll
-            for (int k = 0; k < RESOLVE_K; ++k) {
-                sg[k] = LDSQ ? l_g[(size_t)k * nq + i] : tk_g[(size_t)k * nq + i];
-                sd[k] = LDSQ ? (int)l_d[(size_t)k * nq + i] : (tk_key[(size_t)k * nq + i] >> 16);
+                for (int k = 0; k < RESOLVE_K; ++k) {
+                    sg[k] = tk_g[k * nq + i];
+                    sd[k] = tk_key[k * nq + i] >> 16;
+                }
             }
             // only "more eligible candidates than the shortlist holds" matters
-            const int cnt = LDSQ ? ((l_fl[i] & 2) ? RESOLVE_K + 1 : 0) : topk[(size_t)(2 * RESOLVE_K) * nq + i];
+            const bool longer = LDSQ ? (l_fl[i] & 2) != 0 : topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K;
             const int old = LDSQ ? l_choice[i] : choice[i];
             int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
             int found = 0, taken = 0;
 #pragma unroll
             for (int k = 0; k < RESOLVE_K; ++k) {
-                const int g = sg[k];
-                if (g < 0 || found >= (POINTS ? 2 : 1)) continue;
+                if (found >= NEED) break;
+                const int g = LDSQ ? l_g[k * nq + i] : sg[k];
+                if (g < 0) break;  // the shortlist is sorted: empty slots are at the end
                 const int cl = s_claim[g];
                 if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) { ++taken; continue; }
-                if (found == 0) { best = sd[k]; bidx = g; if (POINTS) lvl = F.octave[g]; }
-                else { best2 = sd[k]; lvl2 = F.octave[g]; }
+                const int d = LDSQ ? (int)l_d[k * nq + i] : sd[k];
+                if (found == 0) { best = d; bidx = g; if (POINTS) lvl = F.octave[g]; }
+                else { best2 = d; lvl2 = F.octave[g]; }
                 ++found;
             }
-            // the shortlist is exact unless it ran dry while longer lists exist: rescan everything (rare)
-            if (found < (POINTS ? 2 : 1) && cnt > RESOLVE_K && taken > 0) {
-                best = 256; best2 = 256; lvl = -1; lvl2 = -1; bidx = -1;
-                const int full = cand_count[i];
-                for (int k0 = 0; k0 < full; k0 += 8) {  // 8 candidates per round: their loads are issued together
-                    int cg[8], cdist[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int k = min(k0 + u, full - 1);
-                        cg[u] = cand_idx[(size_t)k * nq + i];
-                        cdist[u] = cand_dist[(size_t)k * nq + i];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (k0 + u >= full) continue;
-                        const int g = cg[u];
-                        if (occupied && occupied[g]) continue;
-                        const int cl = s_claim[g];
-                        if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) continue;
-                        const int d = cdist[u];
-                        if (POINTS) {
-                            if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = F.octave[g]; bidx = g; }
-                            else if (d < best2) { lvl2 = F.octave[g]; best2 = d; }
-                        } else if (d < best) { best = d; bidx = g; }
-                    }
-                }
+            // the shortlist is exact unless it ran dry while longer lists exist: those queries are rescanned below, one
+            // wave each (rare)
+            if (found < NEED && longer && taken > 0) {
+                l_res[atomicAdd(&s_nres, 1)] = (unsigned short)i;
+                continue;
             }
             int nc = -1;
             if (best <= th_high && bidx >= 0) {
@@ -704,7 +717,56 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             }
             if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
         }
+        __syncthreads();
+        const int nres = s_nres;
+        for (int r = wave; r < nres; r += nwaves) {
+            // full candidate list of query i, 64 candidates per round, keys (distance << 16 | visiting position): the
+            // smallest available key is the sequential scan's first minimum, the next one its runner-up
+            const int i = l_res[r];
+            const int full = cand_count[i];
+            int k1 = 0x7fffffff, k2 = 0x7fffffff;
+            for (int k0 = 0; k0 < full; k0 += 64) {
+                const int k = k0 + lane;
+                int key = 0x7fffffff;
+                if (k < full) {
+                    const int g = cand_idx[k * nq + i];
+                    const int d = cand_dist[k * nq + i];
+                    bool avail = !(occupied && occupied[g]);
+                    const int cl = s_claim[g];
+                    if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) avail = false;
+                    if (avail) key = (d << 16) | k;
+                }
+                int m1 = key;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m1 = min(m1, __shfl_xor(m1, o));
+                int m2 = 0x7fffffff;
+                if (POINTS) {
+                    m2 = key == m1 ? 0x7fffffff : key;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m2 = min(m2, __shfl_xor(m2, o));
+                }
+                // merge the round's (m1 <= m2) into the running (k1 <= k2)
+                if (m1 < k1) { k2 = min(k1, m2); k1 = m1; }
+                else k2 = min(k2, m1);
+            }
+            if (lane == 0) {
+                int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
+                if (k1 != 0x7fffffff) {
+                    best = k1 >> 16; bidx = cand_idx[(k1 & 0xffff) * nq + i];
+                    if (POINTS) lvl = F.octave[bidx];
+                }
+                if (POINTS && k2 != 0x7fffffff) { best2 = k2 >> 16; lvl2 = F.octave[cand_idx[(k2 & 0xffff) * nq + i]]; }
+                int nc = -1;
+                if (best <= th_high && bidx >= 0) {
+                    nc = bidx;
+                    if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
+                }
+                const int old = LDSQ ? l_choice[i] : choice[i];
+                if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
+            }
+        }
         changed = __syncthreads_or(ch);
+        MORB_PHASE(g_ph_res, min(3 + it, 50));
     }
     if (changed) {  // ran out of sweeps
         if (tid == 0) { status[0] = 1; status[1] = 0; status[2] = it; status[3] = maxcount; }
@@ -723,14 +785,25 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         ++acc;
         atomicMax(&s_claim[c], i);
         if (!POINTS && check_ori) {
-            float rot = q[i].angle - f_angle[c];
+            float rot = LDSQ ? l_ang[i] - l_fang[c] : q[i].angle - f_angle[c];
             if (rot < 0.0) rot += 360.0f;
             int bin = (int)roundf(rot * factor);
             if (bin == ORBM_HISTO_LENGTH) bin = 0;
-            if (bin >= 0 && bin < ORBM_HISTO_LENGTH) atomicAdd(&s_hist[bin], 1);
+            const bool inr = bin >= 0 && bin < ORBM_HISTO_LENGTH;
+            if (LDSQ) l_fl[i] = (unsigned char)((l_fl[i] & 3) | ((inr ? bin + 1 : 0) << 2));
+            // most matches of a frame share a rotation bin: count per wave, one atomic per distinct bin
+            unsigned long long todo = __ballot(inr);
+            while (todo) {
+                const int b0 = __shfl(bin, __ffsll((long long)todo) - 1);
+                const unsigned long long same = __ballot(inr && bin == b0);
+                if (inr && bin == b0 && lane == __ffsll((long long)same) - 1) atomicAdd(&s_hist[b0], __popcll(same));
+                todo &= ~same;
+            }
         }
     }
-    atomicAdd(&s_red, acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) atomicAdd(&s_red, acc);
     __syncthreads();
     if (!POINTS && check_ori) {
         if (tid == 0) {  // ComputeThreeMaxima (reference src/ORBmatcher.cc:3948-3989)
@@ -750,20 +823,32 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         for (int i = tid; i < nq; i += T) {
             const int c = LDSQ ? l_choice[i] : choice[i];
             if (c < 0) continue;
-            float rot = q[i].angle - f_angle[c];
-            if (rot < 0.0) rot += 360.0f;
-            int bin = (int)roundf(rot * factor);
-            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            int bin;
+            if (LDSQ) {
+                bin = (int)(l_fl[i] >> 2) - 1;  // -1: outside the histogram, never rejected
+            } else {
+                float rot = q[i].angle - f_angle[c];
+                if (rot < 0.0) rot += 360.0f;
+                bin = (int)roundf(rot * factor);
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            }
             if (bin >= 0 && bin < ORBM_HISTO_LENGTH && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
                 s_claim[c] = -2;  // every writer stores -2; owners were settled before the barrier
                 ++rej;
             }
         }
-        atomicSub(&s_red, rej);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rej += __shfl_xor(rej, o);
+        if (lane == 0) atomicSub(&s_red, rej);
         __syncthreads();
     }
+    MORB_PHASE(g_ph_res, 60);
     for (int g = tid; g < NT; g += T) match_of_feature[g] = s_claim[g];
     if (tid == 0) { status[0] = 0; status[1] = s_red; status[2] = it; status[3] = maxcount; }
+    MORB_PHASE(g_ph_res, 61);
+#ifdef MORB_PHASE_CLOCKS
+    if (tid == 0) g_ph_res[62] = (unsigned long long)it;
+#endif
 }
 
 // Queries are features [q_off, q_off + nq) (the cameras this process owns); outputs are indexed from 0.
@@ -1242,7 +1327,7 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
     for (int c = 0; c <= n_cams; ++c) hstart[c] = F->cam_start[c];
     const int ncell = n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
     hipStream_t st = m->stream;
-    const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int);
+    const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int) + (size_t)8192 * sizeof(unsigned short);
     const bool small = n > 0 && n <= 8192 && n_cams <= 4 && lds_small <= 150 * 1024;
     MORB_ARG(d_counts == nullptr || small);  // device-side counts are only wired into the single-workgroup build
     if (!small) {
@@ -1486,7 +1571,8 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     const int n = J.cur->n_total;
     J.device_path = false;
     if (J.nq == 0 || n == 0) return ORB_OK;
-    const size_t lds = (size_t)n * sizeof(int);
+    // claim table (one int per feature) + the rescan list (u16 per query, padded)
+    const size_t lds = (size_t)n * sizeof(int) + (size_t)((J.nq + 1) / 2) * sizeof(int);
     if (m->host_resolve || J.nq > RESOLVE_MAX_Q || lds > 150 * 1024) return ORB_OK;  // finish() takes the host path
     if (lds > 48 * 1024) {  // large claim tables need the opt-in dynamic LDS limit (once per process)
         static bool raised = false;
@@ -1509,7 +1595,7 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
                           J.points ? 256 : th_high)))
         return rc;
     // claim table + (when it fits) the per-query sweep state
-    const size_t lds_q = lds + (size_t)nq * (sizeof(int) + RESOLVE_K * (sizeof(int) + sizeof(unsigned short)) + 1) + 16;
+    const size_t lds_q = lds + (size_t)nq * (sizeof(int) + sizeof(float) + RESOLVE_K * (sizeof(int) + sizeof(unsigned short)) + 1) + (size_t)n * sizeof(float) + 16;
     const bool ldsq = lds_q <= 150 * 1024;
     const size_t lds_use = ldsq ? lds_q : lds;
     if (lds_use > 48 * 1024) {
@@ -1870,3 +1956,11 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
 }
 
 }  // extern "C"
+
+#ifdef MORB_PHASE_CLOCKS
+extern "C" int morb_debug_phases_matcher(int which, unsigned long long* out64) {
+    hipError_t e = which == 0 ? hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_res), 64 * sizeof(unsigned long long))
+                              : hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_fb), 64 * sizeof(unsigned long long));
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

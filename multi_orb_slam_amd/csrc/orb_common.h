@@ -6,6 +6,16 @@
 #include <string.h>
 #include "../../include/orb_types.h"
 
+// Phase clocks (experiments only, -DMORB_PHASE_CLOCKS): thread 0 of block 0 stamps wall_clock64() (100 MHz) at named
+// points of the single-workgroup kernels; read back with morb_debug_phases().  Compiled out of the product build.
+#ifdef MORB_PHASE_CLOCKS
+#define MORB_PHASE_DECL(name) __device__ unsigned long long name[64]
+#define MORB_PHASE(name, i) do { if (threadIdx.x == 0 && blockIdx.x == 0) name[i] = wall_clock64(); } while (0)
+#else
+#define MORB_PHASE_DECL(name)
+#define MORB_PHASE(name, i) do {} while (0)
+#endif
+
 namespace morb {
 
 void set_error(const char* fmt, ...);

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Phase clocks of the single-workgroup kernels (instrumented build: make -C multi_orb_slam_amd/csrc PHASES=1, run with
+MORB_LIB_PATH=multi_orb_slam_amd/lib/libmorb_phases.so).  Prints microseconds between consecutive stamps (100 MHz clock)."""
+import os, sys, ctypes as C, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import multi_orb_slam_amd as m
+from multi_orb_slam_amd import synth, pipeline, rt, _lib
+
+W, H = 640, 480
+fe = pipeline.FrontEnd([m.ExtractorParams(nfeatures=1000)] * 2, W, H)
+frames = [[synth.image(c, t, W, H) for c in range(2)] for t in range(6)]
+for t in range(6):
+    r = fe.step(frames[t])
+lib = _lib.lib()
+out = (C.c_uint64 * 64)()
+
+
+def deltas(v, idx):
+    return [round((v[b] - v[a]) / 100.0, 2) for a, b in zip(idx[:-1], idx[1:])]
+
+
+lib.morb_debug_phases_extractor(0, out); v = list(out)
+npass = int(v[61])
+idx = list(range(0, npass)) + [62]
+print("octree (cam0 level0): load-scan, limits, dense-load, roots, passes..., select:", deltas(v, idx), "total", (v[62] - v[0]) / 100.0)
+lib.morb_debug_phases_matcher(0, out); v = list(out)
+it = int(v[62])
+idx = [0, 1, 2] + list(range(3, 3 + it)) + [60, 61]
+print("resolve: init, ldsq-load, sweeps x%d, tail, write:" % it, deltas(v, idx), "total", (v[61] - v[0]) / 100.0)
+lib.morb_debug_phases_matcher(1, out); v = list(out)
+print("frame_build: counts, fill, scan, scatter, sort:", deltas(v, [0, 1, 2, 3, 4, 5]), "total", (v[5] - v[0]) / 100.0)
