@@ -42,6 +42,8 @@ typedef struct orbf_result { /* all pointers: pinned host memory owned by the ha
     float gpu_wait_us;                /* host time spent blocked in the final synchronisation                   */
     int32_t n_queries;                /* queries searched this step                                             */
     const orbm_query* queries;        /* [n_queries] (pinned copy)                                              */
+    float host_us[4];                 /* host timeline of the call: query preparation, enqueue of the whole step,
+                                         blocked in the final synchronisation, bookkeeping after it            */
 } orbf_result;
 
 int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbf_frontend** out);

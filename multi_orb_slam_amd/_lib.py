@@ -45,7 +45,7 @@ class FResult(C.Structure):  # orbf_result
                 ("desc", C.c_void_p), ("uright", C.c_void_p), ("depth", C.c_void_p), ("nmatches", C.c_int32),
                 ("match_of_feature", C.c_void_p), ("cross_best_idx", C.c_void_p), ("cross_best_dist", C.c_void_p),
                 ("cross_second_dist", C.c_void_p), ("gpu_wait_us", C.c_float), ("n_queries", C.c_int32),
-                ("queries", C.c_void_p)]
+                ("queries", C.c_void_p), ("host_us", C.c_float * 4)]
 
 
 class FMotion(C.Structure):  # orbf_motion

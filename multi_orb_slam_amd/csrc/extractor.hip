@@ -307,12 +307,7 @@ __global__ __launch_bounds__(1024) void k_compact(const LevelInfo* __restrict__ 
     const int c0 = tid * per, c1 = min(ncell, c0 + per);
     int mine = 0;
     for (int c = c0; c < c1; ++c) mine += min(cell_cnt[Lv.cell_base + c], Lv.slot_cap);
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
+    const int incl = wave_incl_scan(mine);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     if (tid == 0) {
@@ -381,12 +376,7 @@ struct OctLds {
 __device__ __forceinline__ int oct_block_excl_scan(int val, int tid, int* wsum, int* total) {
     // exclusive scan of one int per thread over the 1024-thread block
     const int lane = tid & 63, wave = tid >> 6;
-    int incl = val;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
+    const int incl = wave_incl_scan(val);
     __syncthreads();
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -404,14 +394,12 @@ __device__ __forceinline__ int oct_child(int x, int y, int ulx, int uly, int brx
     return (x < midx ? 0 : 1) + (y < midy ? 0 : 2);
 }
 
-// One split pass over the parents listed in L.P[0..np) (processing order).  `a` = current buffer, list size `sz`.
-// Returns the new size; *n_expand = number of new children holding > 1 keypoint.
+// One split pass over the parents listed in L.P[0..np) (processing order), used by the careful phase.  The caller has
+// set L.procidx[node] = t for exactly those parents (0xffff for every other node).  `a` = current buffer, list size
+// `sz`.  Returns the new size; *n_expand = number of new children holding > 1 keypoint.
 __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, int* n_expand) {
     const int b = a ^ 1;
-    for (int i = tid; i < sz; i += 1024) L.procidx[i] = 0xffff;
-    __syncthreads();
-    for (int t = tid; t < np; t += 1024) L.procidx[L.P[t]] = (unsigned short)t;
-    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
     // classify + packed inclusive prefix over the key positions (4 keys per thread, blocked)
     {
         unsigned long long loc[4];
@@ -431,54 +419,50 @@ __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, 
             }
             run += one; loc[k] = run;
         }
-        // exclusive scan of `run` across threads (64-bit: two 32-bit halves would lose carries between fields only if a
-        // field overflowed 16 bits, which n <= 4096 rules out)
-        const int lane = tid & 63, wave = tid >> 6;
-        unsigned long long incl = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
-        __syncthreads();
-        unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(L.pc);  // pc is free until step 4
+        // exclusive scan of `run` across threads (fields cannot carry into each other: n <= 4096 < 2^16)
+        const unsigned long long incl = wave_incl_scan(run);
+        unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(L.sortkey);  // the rank sort is over by now
         if (lane == 63) wsum64[wave] = incl;
         __syncthreads();
         unsigned long long base = 0;
         for (int w = 0; w < wave; ++w) base += wsum64[w];
         base += incl - run;
-        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (p0 + k < n) L.S[p0 + k] = base + loc[k];
     }
     __syncthreads();
-    // per parent: child counts, number of non-empty children
-    int nch = 0;
-    unsigned long long tot = 0;
+    // thread tid is parent t = tid (child counts) AND list node tid (survivor?): both ride in one packed scan
+    unsigned long long tot = 0, packed = 0;
     if (tid < np) {
         const int node = L.P[tid];
         const int kb = L.nb[a][node], ke = L.ne[a][node];
         tot = L.S[ke - 1] - (kb ? L.S[kb - 1] : 0ull);
+        int nch = 0, nex = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) nch += ((tot >> (16 * c)) & 0xffff) ? 1 : 0;
+        for (int c = 0; c < 4; ++c) { const int cnt = (int)((tot >> (16 * c)) & 0xffff); nch += cnt ? 1 : 0; nex += cnt > 1 ? 1 : 0; }
+        packed = (unsigned long long)nch | ((unsigned long long)nex << 32);
     }
-    int M = 0;
-    const int cb = oct_block_excl_scan(nch, tid, L.wsum, &M);
-    if (tid < np) { L.pc[tid] = tot; L.cbase[tid] = (unsigned short)cb; }
-    // survivors keep their relative order behind the new children
-    int surv = 0;
-    if (tid < sz) surv = L.procidx[tid] == 0xffff ? 1 : 0;
-    const int sr = oct_block_excl_scan(surv, tid, L.wsum, nullptr);
-    if (tid < sz && surv) {
+    const bool survivor = tid < sz && L.procidx[tid] == 0xffff;
+    if (survivor) packed |= 1ull << 16;
+    const unsigned long long incl = wave_incl_scan(packed);
+    unsigned long long* wsum64b = reinterpret_cast<unsigned long long*>(L.sortkey) + 16;
+    if (lane == 63) wsum64b[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const unsigned long long x = wsum64b[w]; if (w < wave) before += x; total += x; }
+    before += incl - packed;
+    const int M = (int)(total & 0xffff), nexp = (int)((total >> 32) & 0xffff);
+    const int cb = (int)(before & 0xffff), sr = (int)((before >> 16) & 0xffff);
+    if (survivor) {  // survivors keep their relative order behind the new children
         const int np_ = M + sr;
         L.newpos[tid] = (unsigned short)np_;
         L.ulx[b][np_] = L.ulx[a][tid]; L.uly[b][np_] = L.uly[a][tid]; L.brx[b][np_] = L.brx[a][tid]; L.bry[b][np_] = L.bry[a][tid];
         L.nb[b][np_] = L.nb[a][tid]; L.ne[b][np_] = L.ne[a][tid]; L.ncrt[b][np_] = 0xffff;
         L.nfl[b][np_] = L.nfl[a][tid] & 1;  // no longer "fresh"
     }
-    // children: creation index ci -> list position M-1-ci
-    int my_expand = 0;
-    if (tid < np) {
+    if (tid < np) {  // children: creation index ci -> list position M-1-ci
+        L.pc[tid] = tot; L.cbase[tid] = (unsigned short)cb;
         const int node = L.P[tid];
         int mx, my;
         (void)oct_child(0, 0, L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
@@ -494,12 +478,9 @@ __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, 
             L.nb[b][pos] = (unsigned short)off; L.ne[b][pos] = (unsigned short)(off + cnt);
             L.ncrt[b][pos] = (unsigned short)ci;
             L.nfl[b][pos] = (unsigned char)((cnt == 1 ? 1 : 0) | 2);
-            if (cnt > 1) ++my_expand;
             off += cnt; ++ci;
         }
     }
-    int nexp = 0;
-    (void)oct_block_excl_scan(my_expand, tid, L.wsum, &nexp);
     __syncthreads();
     // keys: stable 4-way partition inside every split node, others stay where they are
     for (int pos = tid; pos < n; pos += 1024) {
@@ -512,12 +493,130 @@ __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, 
             const int c = oct_child(x, y, L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
             const unsigned long long cnts = L.pc[t];
             const int kb = L.nb[a][node];
-            const unsigned long long before = kb ? L.S[kb - 1] : 0ull;
-            const int rank = (int)(((L.S[pos] - before) >> (16 * c)) & 0xffff) - 1;
+            const unsigned long long bef = kb ? L.S[kb - 1] : 0ull;
+            const int rank = (int)(((L.S[pos] - bef) >> (16 * c)) & 0xffff) - 1;
             int off = 0, ne_before = 0;
             for (int c2 = 0; c2 < c; ++c2) { const int cc = (int)((cnts >> (16 * c2)) & 0xffff); off += cc; ne_before += cc ? 1 : 0; }
             npos = kb + off + rank;
             nnode = M - 1 - (L.cbase[t] + ne_before);
+        } else {
+            nnode = L.newpos[node];
+        }
+        L.kx[b][npos] = (unsigned short)x; L.ky[b][npos] = (unsigned short)y; L.kr[b][npos] = L.kr[a][pos];
+        L.kn[b][npos] = (unsigned short)nnode;
+    }
+    __syncthreads();
+    *n_expand = nexp;
+    return M + (sz - np);
+}
+
+// A FULL pass (every node holding more than one keypoint is split, in list order): the specialisation of oct_split_pass
+// for processing order == list order.  A parent is addressed by its own list index, so no parent list and no
+// node -> parent map are built, and the three block scans (children, survivors, expandable children) ride in one packed
+// 64-bit scan: 6 barriers instead of 17, which is what a pass costs (every phase is an LDS dependency chain).
+__device__ int oct_split_full(OctLds& L, int a, int n, int sz, int tid, int* n_expand) {
+    const int b = a ^ 1;
+    const int lane = tid & 63, wave = tid >> 6;
+    // classify + packed inclusive prefix over the key positions (4 keys per thread, blocked)
+    {
+        unsigned long long loc[4];
+        unsigned long long run = 0;
+        const int p0 = tid * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pos = p0 + k;
+            unsigned long long one = 0;
+            if (pos < n) {
+                const int node = L.kn[a][pos];
+                if (!(L.nfl[a][node] & 1)) {
+                    int mx, my;
+                    const int c = oct_child(L.kx[a][pos], L.ky[a][pos], L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
+                    one = 1ull << (16 * c);
+                }
+            }
+            run += one; loc[k] = run;
+        }
+        const unsigned long long incl = wave_incl_scan(run);
+        unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(L.sortkey);  // free outside the careful pass
+        if (lane == 63) wsum64[wave] = incl;
+        __syncthreads();
+        unsigned long long base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum64[w];
+        base += incl - run;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (p0 + k < n) L.S[p0 + k] = base + loc[k];
+    }
+    __syncthreads();
+    // per node: child counts; {children, survivor, expandable children, parent} packed into one scan
+    unsigned long long tot = 0, packed = 0;
+    bool parent = false, survivor = false;
+    if (tid < sz) {
+        if (!(L.nfl[a][tid] & 1)) {
+            parent = true;
+            const int kb = L.nb[a][tid], ke = L.ne[a][tid];
+            tot = L.S[ke - 1] - (kb ? L.S[kb - 1] : 0ull);
+            int nch = 0, nex = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int cnt = (int)((tot >> (16 * c)) & 0xffff); nch += cnt ? 1 : 0; nex += cnt > 1 ? 1 : 0; }
+            packed = (unsigned long long)nch | ((unsigned long long)nex << 32) | (1ull << 48);
+        } else {
+            survivor = true;
+            packed = 1ull << 16;
+        }
+    }
+    const unsigned long long incl = wave_incl_scan(packed);
+    unsigned long long* wsum64b = reinterpret_cast<unsigned long long*>(L.sortkey) + 16;
+    if (lane == 63) wsum64b[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const unsigned long long x = wsum64b[w]; if (w < wave) before += x; total += x; }
+    before += incl - packed;
+    const int M = (int)(total & 0xffff), nexp = (int)((total >> 32) & 0xffff), np = (int)(total >> 48);
+    const int cb = (int)(before & 0xffff), sr = (int)((before >> 16) & 0xffff);
+    if (survivor) {  // survivors keep their relative order behind the new children
+        const int np_ = M + sr;
+        L.newpos[tid] = (unsigned short)np_;
+        L.ulx[b][np_] = L.ulx[a][tid]; L.uly[b][np_] = L.uly[a][tid]; L.brx[b][np_] = L.brx[a][tid]; L.bry[b][np_] = L.bry[a][tid];
+        L.nb[b][np_] = L.nb[a][tid]; L.ne[b][np_] = L.ne[a][tid]; L.ncrt[b][np_] = 0xffff;
+        L.nfl[b][np_] = 1;  // one keypoint, no longer "fresh"
+    }
+    if (parent) {  // children: creation index ci -> list position M-1-ci
+        L.pc[tid] = tot; L.cbase[tid] = (unsigned short)cb;
+        int mx, my;
+        (void)oct_child(0, 0, L.ulx[a][tid], L.uly[a][tid], L.brx[a][tid], L.bry[a][tid], mx, my);
+        const int x0[4] = {L.ulx[a][tid], mx, L.ulx[a][tid], mx}, y0[4] = {L.uly[a][tid], L.uly[a][tid], my, my};
+        const int x1[4] = {mx, L.brx[a][tid], mx, L.brx[a][tid]}, y1[4] = {my, my, L.bry[a][tid], L.bry[a][tid]};
+        int ci = cb, off = L.nb[a][tid];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int cnt = (int)((tot >> (16 * c)) & 0xffff);
+            if (cnt == 0) continue;
+            const int pos = M - 1 - ci;
+            L.ulx[b][pos] = (short)x0[c]; L.uly[b][pos] = (short)y0[c]; L.brx[b][pos] = (short)x1[c]; L.bry[b][pos] = (short)y1[c];
+            L.nb[b][pos] = (unsigned short)off; L.ne[b][pos] = (unsigned short)(off + cnt);
+            L.ncrt[b][pos] = (unsigned short)ci;
+            L.nfl[b][pos] = (unsigned char)((cnt == 1 ? 1 : 0) | 2);
+            off += cnt; ++ci;
+        }
+    }
+    __syncthreads();
+    // keys: stable 4-way partition inside every split node, others stay where they are
+    for (int pos = tid; pos < n; pos += 1024) {
+        const int node = L.kn[a][pos];
+        int npos = pos, nnode;
+        const int x = L.kx[a][pos], y = L.ky[a][pos];
+        if (!(L.nfl[a][node] & 1)) {
+            int mx, my;
+            const int c = oct_child(x, y, L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
+            const unsigned long long cnts = L.pc[node];
+            const int kb = L.nb[a][node];
+            const unsigned long long bef = kb ? L.S[kb - 1] : 0ull;
+            const int rank = (int)(((L.S[pos] - bef) >> (16 * c)) & 0xffff) - 1;
+            int off = 0, ne_before = 0;
+            for (int c2 = 0; c2 < c; ++c2) { const int cc = (int)((cnts >> (16 * c2)) & 0xffff); off += cc; ne_before += cc ? 1 : 0; }
+            npos = kb + off + rank;
+            nnode = M - 1 - (L.cbase[node] + ne_before);
         } else {
             nnode = L.newpos[node];
         }
@@ -602,12 +701,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
             run += one; loc[k] = run;
         }
         const int lane = tid & 63, wave = tid >> 6;
-        unsigned long long incl = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
+        const unsigned long long incl = wave_incl_scan(run);
         unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(L.pc);
         if (lane == 63) wsum64[wave] = incl;
         __syncthreads();
@@ -655,14 +749,8 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
     while (!finish) {
         const int prev_size = sz;
         // parents = every node that still holds more than one keypoint, in list order
-        int flag = 0;
-        if (tid < sz) flag = (L.nfl[a][tid] & 1) ? 0 : 1;
-        int np = 0;
-        const int rk = oct_block_excl_scan(flag, tid, L.wsum, &np);
-        if (tid < sz && flag) L.P[rk] = (unsigned short)tid;
-        __syncthreads();
         int n_expand = 0;
-        sz = oct_split_pass(L, a, n, sz, np, tid, &n_expand);
+        sz = oct_split_full(L, a, n, sz, tid, &n_expand);
         a ^= 1;
         MORB_PHASE(g_ph_oct, ph_i); ph_i = min(ph_i + 1, 40);
         if (sz >= N || sz == prev_size) { finish = true; break; }
@@ -680,26 +768,23 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                 int nc = 0;
                 const int ci = oct_block_excl_scan(isc, tid, L.wsum, &nc);
                 if (isc) { L.sortkey[ci] = key; L.newpos[ci] = (unsigned short)tid; }  // newpos reused: candidate -> node
+                unsigned int* occ = reinterpret_cast<unsigned int*>(L.S);  // scratch: child occupancy per candidate
+                L.procidx[tid] = 0xffff; occ[tid] = 0;
+                if (tid == 0) L.v[1] = nc;  // default: every candidate is processed
                 __syncthreads();
                 if (nc == 0) { finish = true; break; }
-                // descending rank (all keys distinct: creation order is unique)
-                int myrank = 0;
+                // descending rank (all keys distinct: creation order is unique) = processing order
                 if (tid < nc) {
                     const unsigned int mk = L.sortkey[tid];
+                    int myrank = 0;
                     for (int j = 0; j < nc; ++j) myrank += L.sortkey[j] > mk ? 1 : 0;
-                    L.P[myrank] = L.newpos[tid];
+                    const unsigned short node = L.newpos[tid];
+                    L.P[myrank] = node;
+                    L.procidx[node] = (unsigned short)myrank;
                 }
                 __syncthreads();
-                // growth of every candidate if it were split: #non-empty children - 1  (needs the child counts: run the
-                // classification for ALL candidates, then keep only the prefix that is actually processed)
-                for (int i = tid; i < sz; i += 1024) L.procidx[i] = 0xffff;
-                __syncthreads();
-                if (tid < nc) L.procidx[L.P[tid]] = (unsigned short)tid;
-                __syncthreads();
-                // per-candidate child occupancy via atomics on 4 bits (cheap: only occupancy, not counts, is needed here)
-                unsigned int* occ = reinterpret_cast<unsigned int*>(L.S);  // scratch
-                for (int t = tid; t < nc; t += 1024) occ[t] = 0;
-                __syncthreads();
+                // growth of every candidate if it were split: #non-empty children - 1  (needs the child occupancy: classify
+                // the keys of ALL candidates, then keep only the prefix that is actually processed)
                 for (int pos = tid; pos < n; pos += 1024) {
                     const int node = L.kn[a][pos];
                     const int t = L.procidx[node];
@@ -714,13 +799,12 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                 if (tid < nc) growth = __popc(occ[tid]) - 1;
                 int gtot = 0;
                 const int gex = oct_block_excl_scan(growth, tid, L.wsum, &gtot);
-                // first t (processing order) after which the list has reached N
-                if (tid == 0) L.v[1] = nc;  // default: process all
-                __syncthreads();
+                // first t (processing order) after which the list has reached N: the condition holds for exactly one t
+                // when the running size crosses N (sizes never decrease), for none otherwise
                 if (tid < nc && ps + gex + growth >= N && ps + gex < N) L.v[1] = tid + 1;
-                // (the condition holds for exactly one t when the running size crosses N; sizes never decrease)
                 __syncthreads();
                 const int np2 = L.v[1];
+                if (tid >= np2 && tid < nc) L.procidx[L.P[tid]] = 0xffff;  // candidates behind the stop are not split
                 __syncthreads();
                 int ne2 = 0;
                 sz = oct_split_pass(L, a, n, sz, np2, tid, &ne2);

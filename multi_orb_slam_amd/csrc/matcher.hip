@@ -1748,8 +1748,8 @@ int orbm_cross_top2_blocks(orbm_matcher* m, const uint8_t* const* d_desc_blocks,
 // ================================================================================================ orbf (include/orbf.h)
 }  // extern "C"
 
-#include "../../include/orbf.h"
 #include <chrono>
+#include "../../include/orbf.h"
 
 struct orbf_frontend {
     int device = 0, n_cams = 0, max_w = 0, max_h = 0;
@@ -1770,6 +1770,7 @@ struct orbf_frontend {
     int prev_n = 0;
     std::vector<int32_t> prev_cam_of;
     std::vector<float> scale_factors;
+    std::chrono::steady_clock::time_point t_entry;
 };
 
 extern "C" {
@@ -1823,6 +1824,7 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
 
 int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out) {
     MORB_ARG(f && images && out && nq >= 0 && (nq == 0 || queries));
+    f->t_entry = std::chrono::steady_clock::now();
     return orbf_step_impl(f, images, queries, nq, flags, out, false);
 }
 
@@ -1832,6 +1834,7 @@ int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_moti
     MORB_ARG(f && images && motion && out);
     const int nq = f->prev_n;
     int rc;
+    f->t_entry = std::chrono::steady_clock::now();
     if (nq) {
         // the previous step's features are still in the pinned result buffers; turn them into queries BEFORE this step's
         // kernels overwrite those buffers
@@ -1845,6 +1848,10 @@ int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_moti
 
 static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
                           orbf_result* out, bool queries_in_pinned) {
+    const auto t_impl = std::chrono::steady_clock::now();
+    auto us_between = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<float, std::micro>(b - a).count();
+    };
     MORB_HIP(hipSetDevice(f->device));
     orbm_matcher* m = f->mt;
     int rc;
@@ -1878,6 +1885,7 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     orbm_frame* fr = nullptr;
     int n = 0, nmatches = 0;
     bool do_cross = !(flags & ORBF_SKIP_CROSS);
+    auto t_synced = t_impl;
     SearchJob J{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
     if ((rc = f->h_match.reserve(std::max(cap_sum, 1)))) return rc;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1920,6 +1928,8 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipStreamSynchronize(st);
         out->gpu_wait_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        out->host_us[0] = us_between(f->t_entry, t_impl); out->host_us[1] = us_between(t_impl, t0); out->host_us[2] = out->gpu_wait_us;
+        t_synced = std::chrono::steady_clock::now();
         if (e != hipSuccess) { morb::set_error("hipStreamSynchronize: %s", hipGetErrorString(e)); orbm_frame_destroy(fr); return ORB_E_HIP; }
         if (async_path) {
             rc = orbx_finish(f->ex);  // stream already idle: adopts the counts (or reports the host-quadtree fallback)
@@ -1952,6 +1962,7 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     out->cross_best_idx = do_cross ? m->h_c0.p : nullptr;
     out->cross_best_dist = do_cross ? m->h_c1.p : nullptr;
     out->cross_second_dist = do_cross ? m->h_c2.p : nullptr;
+    out->host_us[3] = us_between(t_synced, std::chrono::steady_clock::now());
     return ORB_OK;
 }
 

@@ -16,6 +16,40 @@
 #define MORB_PHASE(name, i) do {} while (0)
 #endif
 
+#ifdef __HIPCC__
+// Wave64 inclusive prefix sums on the DPP lanes-shift path (row_shr 1/2/4/8, then row_bcast 15 and 31): six VALU-rate
+// steps instead of six ds_bpermute round trips per __shfl_up scan.  Every lane of the wave must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int morb_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true); }
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += morb_dpp0<0x111, 0xf>(v);
+    v += morb_dpp0<0x112, 0xf>(v);
+    v += morb_dpp0<0x114, 0xf>(v);
+    v += morb_dpp0<0x118, 0xf>(v);
+    v += morb_dpp0<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += morb_dpp0<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long morb_dpp0_u64(unsigned long long v) {
+    const unsigned int lo = (unsigned int)morb_dpp0<CTRL, ROW_MASK>((int)(unsigned int)v);
+    const unsigned int hi = (unsigned int)morb_dpp0<CTRL, ROW_MASK>((int)(unsigned int)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long wave_incl_scan(unsigned long long v) {
+    v += morb_dpp0_u64<0x111, 0xf>(v);
+    v += morb_dpp0_u64<0x112, 0xf>(v);
+    v += morb_dpp0_u64<0x114, 0xf>(v);
+    v += morb_dpp0_u64<0x118, 0xf>(v);
+    v += morb_dpp0_u64<0x142, 0xa>(v);
+    v += morb_dpp0_u64<0x143, 0xc>(v);
+    return v;
+}
+#endif
+
 namespace morb {
 
 void set_error(const char* fmt, ...);

@@ -96,7 +96,7 @@ class NativeFrontEnd:
                    desc=cp(V("desc", r.desc, np.uint8, cap, 32)[:n]), uright=cp(V("ur", r.uright, np.float32, cap)[:n]),
                    depth=cp(V("depth", r.depth, np.float32, cap)[:n]), n_temporal=r.nmatches,
                    match_of_feature=cp(V("match", r.match_of_feature, np.int32, cap)[:n]) if nq else np.zeros(0, np.int32),
-                   gpu_wait_us=r.gpu_wait_us, n_queries=nq)
+                   gpu_wait_us=r.gpu_wait_us, host_us=tuple(r.host_us), n_queries=nq)
         if r.cross_best_idx:
             out["cross"] = (cp(V("x0", r.cross_best_idx, np.int32, cap)[:n]), cp(V("x1", r.cross_best_dist, np.int32, cap)[:n]),
                             cp(V("x2", r.cross_second_dist, np.int32, cap)[:n]))

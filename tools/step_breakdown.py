@@ -17,12 +17,13 @@ for t in range(8):
 rt.device_sync()
 N = 300
 tot = wait = 0.0
+host = np.zeros(4)
 for it in range(N + 20):
     if it == 20:
-        tot = wait = 0.0
+        tot = wait = 0.0; host[:] = 0
     t = it % 8
     t0 = time.perf_counter()
     r = fe.step([(dev[t][c].ptr, W) for c in range(2)], resident=True)
-    tot += time.perf_counter() - t0; wait += r["gpu_wait_us"]
+    tot += time.perf_counter() - t0; wait += r["gpu_wait_us"]; host += np.array(r["host_us"])
 fe.ex.set_profiling(True); fe.step([(dev[1][c].ptr, W) for c in range(2)], resident=True)
-print(json.dumps({"step_us": round(tot / N * 1e6, 1), "final_sync_wait_us": round(wait / N, 1), "extractor": fe.ex.stage_times_us()}))
+print(json.dumps({"step_us": round(tot / N * 1e6, 1), "final_sync_wait_us": round(wait / N, 1), "host_us[query_prep,enqueue,wait,post]": [round(x / N, 1) for x in host], "extractor": fe.ex.stage_times_us()}))
