@@ -32,6 +32,7 @@
 #include "../../include/orbx.h"
 #include "octree.h"
 #include "orb_common.h"
+#include "frame_sink.h"
 
 namespace {
 
@@ -915,7 +916,8 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                                                   const uint8_t* __restrict__ pyr, size_t cam_pitch,
                                                   const SelKp* __restrict__ sel, int nsel,
                                                   orb_keypoint* const* __restrict__ kps_out,
-                                                  uint8_t* const* __restrict__ desc_out, MirrorArgs mir, SelListArgs sl) {
+                                                  uint8_t* const* __restrict__ desc_out, MirrorArgs mir, SelListArgs sl,
+                                                  FrameSink sink) {
     __shared__ uint8_t s_raw[4][PW * RAW_PITCH];
     __shared__ uint16_t s_row[4][PW * ROW_PITCH];
     __shared__ uint8_t s_blur[4][BW * ROW_PITCH];
@@ -1025,10 +1027,16 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     }
     const int other = __shfl_xor(nib, 1);
     const int out_idx = K.resp_out & 0xffffff;
-    if ((lane & 1) == 0) {
-        const uint8_t byte = (uint8_t)(nib | (other << 4));
-        desc_out[cam][(size_t)out_idx * 32 + (lane >> 1)] = byte;
-        if (mir.desc) mir.desc[(size_t)(mirror_base + out_idx) * 32 + (lane >> 1)] = byte;
+    // bytes sit in the even lanes (lane 2j = byte j): fold them into 8 dwords held by lanes 0, 8, .., 56
+    unsigned int word = (unsigned int)(nib | (other << 4));
+    word |= (unsigned int)__shfl_down((int)word, 2) << 8;
+    word |= (unsigned int)__shfl_down((int)word, 4) << 16;
+    const bool to_sink = slot_blk && sink.x;
+    const int g = mirror_base + out_idx;  // global index in camera-major order
+    if ((lane & 7) == 0) {
+        reinterpret_cast<uint32_t*>(desc_out[cam])[(size_t)out_idx * 8 + (lane >> 3)] = word;
+        if (mir.desc) reinterpret_cast<uint32_t*>(mir.desc)[(size_t)g * 8 + (lane >> 3)] = word;
+        if (to_sink) sink.desc[(size_t)g * 8 + (lane >> 3)] = word;
     }
     if (lane == 0) {
         orb_keypoint kp;
@@ -1041,7 +1049,21 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         kp.octave = level;
         kp.class_id = -1;
         kps_out[cam][out_idx] = kp;
-        if (mir.kps) mir.kps[mirror_base + out_idx] = kp;
+        if (mir.kps) mir.kps[g] = kp;
+        if (to_sink) {
+            // the per-feature half of the frame assembly: `_total` record, ComputeStereoFromRGBD, PosInGrid
+            sink.x[g] = kp.x; sink.y[g] = kp.y; sink.oct[g] = level; sink.ang[g] = angle; sink.kps[g] = kp;
+            float d = -1.f, u_r = -1.f;
+            const float* depth = sink.cam_depth[cam & 3];
+            if (depth) {
+                const float dv = depth[(size_t)(int)kp.y * sink.cam_depth_stride[cam & 3] + (int)kp.x];  // imDepth.at<float>(v,u)
+                if (dv > 0) { d = dv; u_r = kp.x - sink.mbf / dv; }
+            }
+            sink.ur[g] = u_r; sink.depth[g] = d;
+            if (sink.h_ur) { sink.h_ur[g] = u_r; sink.h_depth[g] = d; }
+            const int px = (int)roundf((kp.x - sink.minX) * sink.invW), py = (int)roundf((kp.y - sink.minY) * sink.invH);
+            sink.cell_of[g] = (px >= 0 && px < 64 && py >= 0 && py < 48) ? (cam * 64 + px) * 48 + py : -1;
+        }
     }
 }
 
@@ -1202,6 +1224,7 @@ struct orbx_extractor {
     hipStream_t stream = nullptr;
     std::vector<CamTables> cams;
     std::vector<int> cur_w, cur_h;   // size of the resident image per camera (0 = none)
+    FrameSink sink;                  // orbf_step: merged-frame destination of the describe kernel (x == nullptr: off)
     IngestArgs ingest;               // device-resident sources to copy into level 0 at the start of the next run
     bool ingest_pending = false;
     bool tables_dirty = true;
@@ -1402,6 +1425,7 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     ex->cams.resize(n_cams);
     ex->cur_w.assign(n_cams, 0); ex->cur_h.assign(n_cams, 0);
     memset(&ex->ingest, 0, sizeof(ex->ingest));
+    memset(&ex->sink, 0, sizeof(ex->sink));
     ex->n_out.assign(n_cams, 0);
     ex->d_kps.resize(n_cams); ex->d_desc.resize(n_cams);
     ex->out_kps.assign(n_cams, nullptr); ex->out_desc.assign(n_cams, nullptr); ex->out_cap_active.assign(n_cams, 0);
@@ -1554,6 +1578,12 @@ int orbx_finish(orbx_extractor* ex) {
     return finish_device_path(ex);
 }
 
+int orbx_set_frame_sink(orbx_extractor* ex, const FrameSink* sink) {
+    MORB_ARG(ex != nullptr && (sink == nullptr || ex->n_cams <= 4));
+    if (sink) ex->sink = *sink; else memset(&ex->sink, 0, sizeof(ex->sink));
+    return ORB_OK;
+}
+
 const int* orbx_device_counts(const orbx_extractor* ex) { return ex ? ex->d_n_out.p : nullptr; }
 int orbx_pending(const orbx_extractor* ex) { return ex && ex->pending ? 1 : 0; }
 
@@ -1636,7 +1666,8 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
                            (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel_oct.p, ex->total_sel_slots,
                            (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
                            SelListArgs{(const unsigned short*)ex->d_slot_blk.p, (const int*)ex->d_sel_cnt.p,
-                                       (const int*)ex->d_oct_status.p, ex->d_n_out.p, d_h_oct, ex->n_cams});
+                                       (const int*)ex->d_oct_status.p, ex->d_n_out.p, d_h_oct, ex->n_cams},
+                           allow_async ? ex->sink : FrameSink{});
         if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[5], st));
         MORB_HIP(hipGetLastError());
         ex->pending = true; ex->t_begin_async = t_begin;
@@ -1727,7 +1758,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         hipLaunchKernelGGL(k_describe, dim3((nsel + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
                            (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel.p, nsel,
                            (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
-                           SelListArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
+                           SelListArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, FrameSink{});
         MORB_HIP(hipGetLastError());
     }
     if (ex->profiling) {

@@ -1,0 +1,25 @@
+// frame_sink.h -- internal seam between the extractor's describe kernel and the matcher's frame (orbf_step only).
+// When a sink is set, the describe kernel of the device-quadtree path writes every keypoint straight into the merged
+// frame arrays (global index = keypoints of the earlier cameras + index inside its own camera), together with its stereo
+// coordinate and grid cell -- the per-feature half of the frame assembly (reference src/Frame.cc:221-239, :959-986,
+// :632-642), so that the frame kernel that follows only has to sort cell indices.
+#pragma once
+#include <stdint.h>
+#include "../../include/orb_types.h"
+
+struct orbx_extractor;
+
+struct FrameSink {
+    float *x, *y, *ur, *depth, *ang;   // [capacity] un-distorted position, uRight, depth, angle
+    int* oct;                          // [capacity] octave
+    orb_keypoint* kps;                 // [capacity] the `_total` records
+    uint32_t* desc;                    // [capacity][8] descriptors in global-index order
+    int* cell_of;                      // [capacity] grid cell (camera-major), -1 outside the grid
+    float *h_ur, *h_depth;             // mapped pinned mirrors of ur / depth (may be NULL)
+    const float* cam_depth[4];         // HBM depth image per camera (NULL: no stereo coordinate)
+    int cam_depth_stride[4];
+    float mbf, minX, minY, invW, invH;
+};
+
+// nullptr switches the sink off.  Used by the next orbx_run_async that takes the device-quadtree path (at most 4 cameras).
+extern "C" int orbx_set_frame_sink(orbx_extractor* ex, const FrameSink* sink);

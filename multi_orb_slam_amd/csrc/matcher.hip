@@ -19,6 +19,7 @@
 
 #include "../../include/orbm.h"
 #include "orb_common.h"
+#include "frame_sink.h"
 
 namespace morb {
 
@@ -448,7 +449,10 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
                                                             float* __restrict__ ur, float* __restrict__ depth_out,
                                                             int* __restrict__ oct, float* __restrict__ ang,
                                                             orb_keypoint* __restrict__ kps_g, uint4* __restrict__ desc_g,
-                                                            int* __restrict__ cell_start, int* __restrict__ items, HostMirror hm) {
+                                                            int* __restrict__ cell_start, int* __restrict__ items, HostMirror hm,
+                                                            const int* __restrict__ cell_of_in) {
+    // cell_of_in != NULL: the per-feature arrays and the cells were already written by the extractor's describe kernel
+    // (FrameSink); only the counts, the grid and its item lists are produced here.
     extern __shared__ __attribute__((aligned(16))) int s_cells[];  // [ncell + 1] start | [ncell + 1] cursor | u16 items[8192]
     __shared__ int wsum[16];
     // kernel-argument copy of the per-camera descriptors (no H2D).  With d_counts the real counts come from the device
@@ -485,7 +489,8 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
         const int g = tid + k * 1024;
         mycell[k] = -1;
         if (g < n_total) {
-            mycell[k] = frame_fill_one(cams, n_cams, g, mbf, minX, minY, invW, invH, x, y, ur, depth_out, oct, ang, kps_g, desc_g, hm);
+            mycell[k] = cell_of_in ? cell_of_in[g]
+                                   : frame_fill_one(cams, n_cams, g, mbf, minX, minY, invW, invH, x, y, ur, depth_out, oct, ang, kps_g, desc_g, hm);
             if (mycell[k] >= 0) atomicAdd(&s_cur[mycell[k]], 1);
         }
     }
@@ -522,18 +527,17 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
     __syncthreads();
     MORB_PHASE(g_ph_fb, 4);
     for (int c = tid; c <= ncell; c += 1024) cell_start[c] = s_start[c];
-    for (int c = tid; c < ncell; c += 1024) {  // ascending global index inside every cell
-        const int sidx = s_start[c], e = s_start[c + 1];
-        for (int i = sidx + 1; i < e; ++i) {
-            const unsigned short v = s_items[i];
-            int j = i - 1;
-            while (j >= sidx && s_items[j] > v) { s_items[j + 1] = s_items[j]; --j; }
-            s_items[j + 1] = v;
-        }
+    // ascending global index inside every cell: every feature ranks itself among the unsorted items of its cell
+    // (independent LDS reads; a per-cell insertion sort is a dependent chain, quadratic in the fullest cell)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (mycell[k] < 0) continue;
+        const int g = tid + k * 1024;
+        const int sidx = s_start[mycell[k]], e = s_start[mycell[k] + 1];
+        int rank = 0;
+        for (int i = sidx; i < e; ++i) rank += s_items[i] < g ? 1 : 0;
+        items[sidx + rank] = g;
     }
-    __syncthreads();
-    const int n_in_grid = s_start[ncell];
-    for (int i = tid; i < n_in_grid; i += 1024) items[i] = s_items[i];
     __syncthreads();
     MORB_PHASE(g_ph_fb, 5);
 }
@@ -1280,8 +1284,9 @@ int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** ou
 
 // d_counts != NULL: cams[c].n are CAPACITIES, the real per-camera counts sit in HBM (orbx_device_counts) and are read by
 // the build kernel; the frame's n_total stays a capacity until the caller has synchronised and calls frame_set_counts.
+// sink_filled: *out is a frame made by frame_prepare_sink whose per-feature arrays the describe kernel has filled.
 static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
-                                  float max_x, float max_y, const int* d_counts, orbm_frame** out);
+                                  float max_x, float max_y, const int* d_counts, orbm_frame** out, bool sink_filled = false);
 
 extern "C" {
 
@@ -1292,8 +1297,44 @@ int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n
 
 }  // extern "C"
 
+// Frame shell with storage for `n` features, no kernel launched yet.
+static int frame_shell(orbm_matcher* m, int n, int n_cams, float min_x, float min_y, float max_x, float max_y, bool counts_on_device,
+                       orbm_frame** out) {
+    orbm_frame* F = new orbm_frame();
+    F->owner = m; F->n_total = n; F->n_cams = n_cams; F->device_built = true; F->counts_on_device = counts_on_device;
+    F->minX = min_x; F->minY = min_y; F->maxX = max_x; F->maxY = max_y;
+    F->invW = (float)ORBM_GRID_COLS / (max_x - min_x);
+    F->invH = (float)ORBM_GRID_ROWS / (max_y - min_y);
+    F->cam_start.assign(n_cams + 1, 0);
+    F->b = take_bufs(m);
+    int rc = reserve_frame(F->b, n, n_cams);
+    if (rc) { orbm_frame_destroy(F); return rc; }
+    *out = F;
+    return ORB_OK;
+}
+
+// orbf_step: the frame the extractor's describe kernel is about to fill (capacity-sized) and the sink describing it
+static int frame_prepare_sink(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
+                              float max_x, float max_y, orbm_frame** out, FrameSink* sink) {
+    MORB_ARG(n_cams >= 1 && n_cams <= 4 && max_x > min_x && max_y > min_y);
+    int n = 0;
+    for (int c = 0; c < n_cams; ++c) n += cams[c].n;
+    orbm_frame* F = nullptr;
+    int rc = frame_shell(m, n, n_cams, min_x, min_y, max_x, max_y, true, &F);
+    if (rc) return rc;
+    memset(sink, 0, sizeof(*sink));
+    sink->x = F->b->d_x.p; sink->y = F->b->d_y.p; sink->ur = F->b->d_ur.p; sink->depth = F->b->d_depth.p; sink->ang = F->b->d_ang.p;
+    sink->oct = F->b->d_oct.p; sink->kps = F->b->d_kps.p; sink->desc = reinterpret_cast<uint32_t*>(F->b->d_desc.p);
+    sink->cell_of = F->b->d_cell_of.p;
+    sink->h_ur = m->mirror_ur; sink->h_depth = m->mirror_depth;
+    for (int c = 0; c < n_cams; ++c) { sink->cam_depth[c] = cams[c].d_depth; sink->cam_depth_stride[c] = cams[c].depth_stride; }
+    sink->mbf = mbf; sink->minX = F->minX; sink->minY = F->minY; sink->invW = F->invW; sink->invH = F->invH;
+    *out = F;
+    return ORB_OK;
+}
+
 static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
-                                  float max_x, float max_y, const int* d_counts, orbm_frame** out) {
+                                  float max_x, float max_y, const int* d_counts, orbm_frame** out, bool sink_filled) {
     MORB_ARG(m && cams && out && n_cams >= 1 && n_cams <= 64 && max_x > min_x && max_y > min_y);
     MORB_HIP(hipSetDevice(m->device));
     int n = 0;
@@ -1302,14 +1343,15 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
         MORB_ARG(((uintptr_t)cams[c].d_desc & 15) == 0 && ((uintptr_t)cams[c].d_kps & 3) == 0);
         n += cams[c].n;
     }
-    orbm_frame* F = new orbm_frame();
-    F->owner = m; F->n_total = n; F->n_cams = n_cams; F->device_built = true; F->counts_on_device = d_counts != nullptr;
-    F->minX = min_x; F->minY = min_y; F->maxX = max_x; F->maxY = max_y;
-    F->invW = (float)ORBM_GRID_COLS / (max_x - min_x);
-    F->invH = (float)ORBM_GRID_ROWS / (max_y - min_y);
-    F->cam_start.assign(n_cams + 1, 0);
-    F->b = take_bufs(m);
-    int rc = reserve_frame(F->b, n, n_cams);
+    orbm_frame* F = nullptr;
+    int rc;
+    if (sink_filled) {
+        F = *out;
+        MORB_ARG(F && F->n_total == n && F->n_cams == n_cams && d_counts);
+    } else if ((rc = frame_shell(m, n, n_cams, min_x, min_y, max_x, max_y, d_counts != nullptr, &F))) {
+        return rc;
+    }
+    rc = ORB_OK;
     const size_t slot = 64 * sizeof(CamFeat) + 65 * sizeof(int);
     if (!rc) rc = m->h_ring.reserve(slot * 4);  // ring of 4 parameter blocks: the H2D copies below are asynchronous
     if (rc) { orbm_frame_destroy(F); return rc; }
@@ -1330,6 +1372,7 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
     const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int) + (size_t)8192 * sizeof(unsigned short);
     const bool small = n > 0 && n <= 8192 && n_cams <= 4 && lds_small <= 150 * 1024;
     MORB_ARG(d_counts == nullptr || small);  // device-side counts are only wired into the single-workgroup build
+    MORB_ARG(!sink_filled || small);
     if (!small) {
         MORB_HIP(hipMemcpyAsync(F->b->d_cams.p, hc, (size_t)n_cams * sizeof(CamFeat), hipMemcpyHostToDevice, st));
         MORB_HIP(hipMemcpyAsync(F->b->d_cam_start.p, hstart, (size_t)(n_cams + 1) * 4, hipMemcpyHostToDevice, st));
@@ -1350,7 +1393,7 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
                            n_cams, n, mbf,
                            F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
                            F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_start.p,
-                           F->b->d_items.p, hm);
+                           F->b->d_items.p, hm, sink_filled ? (const int*)F->b->d_cell_of.p : nullptr);
     } else {
         MORB_HIP(hipMemsetAsync(F->b->d_cursor.p, 0, (size_t)(ncell + 1) * 4, st));  // used as the per-cell counter first
         if (n) {
@@ -1872,15 +1915,33 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, f->h_queries.p, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->side_stream));
         MORB_HIP(hipEventRecord(m->ev_q, m->side_stream));
     }
-    // ---- extraction: enqueued without a host sync when the device quadtree is active
-    if ((rc = orbx_run_async(f->ex))) return rc;
     std::vector<orbm_cam_features> cams(f->n_cams);
     if (W == 0 || H == 0) { W = f->max_w; H = f->max_h; }
-    const int* d_counts = orbx_device_counts(f->ex);
     int cap_sum = 0;
     for (int c = 0; c < f->n_cams; ++c) cap_sum += f->cam_cap[c];
-    bool async_path = orbx_pending(f->ex) && f->n_cams <= 4 && cap_sum <= 8192 && !m->host_resolve;
+    const bool small_rig = f->n_cams <= 4 && cap_sum <= 8192 && !m->host_resolve;
     hipStream_t st = m->stream;
+    // With a small rig the extractor's describe kernel fills the merged frame itself (FrameSink): prepare that frame now.
+    orbm_frame* fr_sink = nullptr;
+    if (small_rig) {
+        for (int c = 0; c < f->n_cams; ++c) {
+            cams[c].d_kps = orbx_device_keypoints(f->ex, c); cams[c].d_desc = orbx_device_descriptors(f->ex, c);
+            cams[c].n = f->cam_cap[c]; cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
+        }
+        FrameSink sink;
+        m->mirror_ur = f->h_ur.dp; m->mirror_depth = f->h_depth.dp;
+        rc = frame_prepare_sink(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, &fr_sink, &sink);
+        m->mirror_ur = nullptr; m->mirror_depth = nullptr;
+        if (rc) return rc;
+        if ((rc = orbx_set_frame_sink(f->ex, &sink))) { orbm_frame_destroy(fr_sink); return rc; }
+    }
+    // ---- extraction: enqueued without a host sync when the device quadtree is active
+    rc = orbx_run_async(f->ex);
+    (void)orbx_set_frame_sink(f->ex, nullptr);
+    if (rc) { if (fr_sink) orbm_frame_destroy(fr_sink); return rc; }
+    const int* d_counts = orbx_device_counts(f->ex);
+    bool async_path = orbx_pending(f->ex) && small_rig;
+    if (!async_path && fr_sink) { orbm_frame_destroy(fr_sink); fr_sink = nullptr; }  // the extractor took its synchronous path
     if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
     orbm_frame* fr = nullptr;
     int n = 0, nmatches = 0;
@@ -1903,9 +1964,12 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         // the frame-build kernel mirrors the stereo arrays straight into this handle's pinned result buffers (keypoints
         // and descriptors were mirrored by the extractor's describe kernel)
         m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = f->h_ur.dp; m->mirror_depth = f->h_depth.dp;
-        rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, async_path ? d_counts : nullptr, &fr);
+        const bool sink_filled = async_path && fr_sink != nullptr;
+        if (sink_filled) { fr = fr_sink; fr_sink = nullptr; }
+        rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, async_path ? d_counts : nullptr, &fr,
+                                    sink_filled);
         m->mirror_ur = nullptr; m->mirror_depth = nullptr;
-        if (rc) return rc;
+        if (rc) { if (sink_filled) orbm_frame_destroy(fr); return rc; }
         J.cur = fr; J.cap = 64; J.device_path = false;
         // fork: the camera-pair top-2 only needs the frame's descriptor block, so it runs on the side stream next to
         // project + resolve (both are a handful of workgroups on a 256-CU part); join before the one host sync
