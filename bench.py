@@ -31,8 +31,9 @@ MATRIX_N = 32000                 # all-pairs size of configs[4]: 8 cameras x 400
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-overlap", action="store_true", help="every step extracts its own images first (no orbf_prefetch)")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -116,15 +117,22 @@ def main():
         dev_frames.append(row)
     rt.device_sync()
 
-    # ---- parity gate: three steps bit-exact vs the CPU oracle (single-rank view; N > 1 checks its own cameras)
+    def frame_args(t):
+        return [(dev_frames[t % RING][c].ptr, W) for c in range(CAMS_PER_RANK)]
+
+    # Consecutive timesteps overlap: while step t is matched, the extraction of step t+1 already runs on the extractor's
+    # stream (the exchange buffers of the multi-GPU path are not double-buffered, so it is off there).
+    overlap = not use_dist and not a.no_overlap
+
+    # ---- parity gate: four steps bit-exact vs the CPU oracle (single-rank view; N > 1 checks its own cameras)
     parity = "skipped"
     if world == 1:
         from oracle_pipeline import OracleFrontEnd, assert_same_step
         ofe = OracleFrontEnd(params, W, H, gcam)
-        for t in range(3):
-            got = fe.step([(dev_frames[t][c].ptr, W) for c in range(CAMS_PER_RANK)], resident=True)
-            assert_same_step(got, ofe.step(host_frames[t]))
-        parity = "bit-exact vs oracle on 3 steps (keypoints, descriptors, temporal + cross-camera matches)"
+        for t in range(4):   # same call pattern as the timed loop: the next step's images are announced (orbf_prefetch)
+            got = fe.step(frame_args(t), resident=True, next_images=frame_args(t + 1) if overlap else None)
+            assert_same_step(got, ofe.step(host_frames[t % RING]))
+        parity = "bit-exact vs oracle on 4 steps (keypoints, descriptors, temporal + cross-camera matches)"
         fe.reset()
 
     def sync_all():
@@ -134,10 +142,11 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    def run(nsteps, t0):
+    def run(nsteps, t0, overlap=overlap):
+        # every step completes one timestep (extract + match); with `overlap` it also announces the next one's images, so K
+        # steps enqueue K extractions and complete K matchings either way
         for i in range(nsteps):
-            t = (t0 + i) % RING
-            fe.step([(dev_frames[t][c].ptr, W) for c in range(CAMS_PER_RANK)], resident=True)
+            fe.step(frame_args(t0 + i), resident=True, next_images=frame_args(t0 + i + 1) if overlap else None)
 
     fe.copy_results = False          # timed loop: consume the results in place (views of the pinned buffers)
     run(a.warmup, 0)
@@ -152,10 +161,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = world * a.steps / elapsed
+    # for reference: the same loop with every step extracting its own images first (latency of one isolated timestep)
+    serial_ms = None
+    if overlap:
+        fe.reset(); run(20, 0, False); sync_all()
+        t1 = time.perf_counter(); run(200, 20, False); sync_all()
+        serial_ms = 1e3 * (time.perf_counter() - t1) / 200
+        fe.reset()
 
     # per-stage GPU time of the extractor (HIP events) on one extra profiled step
     fe.ex.set_profiling(True)
-    fe.step([(dev_frames[1][c].ptr, W) for c in range(CAMS_PER_RANK)], resident=True)
+    fe.step(frame_args(0), resident=True); fe.step(frame_args(1), resident=True)
     stages = fe.ex.stage_times_us()
     fe.ex.set_profiling(False)
 
@@ -168,6 +184,8 @@ def main():
                    "cams_per_gpu": CAMS_PER_RANK, "width": W, "height": H, "nfeatures": NFEAT, "nlevels": 8,
                    "frame_unit": "one rig timestep (2 cameras)"},
         "parity": parity,
+        "overlap": ("extraction of timestep t+1 runs next to the matching of timestep t (orbf_prefetch); one isolated "
+                    "timestep takes %.4f ms" % serial_ms) if overlap else "off",
         "extractor_stage_us": {k: round(v, 1) for k, v in stages.items()},
     }
     if rank == 0 and not a.no_roofline:

@@ -52,6 +52,14 @@ void orbf_destroy(orbf_frontend* f);
 int orbf_set_depth(orbf_frontend* f, int cam, const float* d_depth, int stride_floats);
 /* mbf = Camera.bf; th_high / check_orientation as in ORBmatcher (defaults 40, 100, 1) */
 int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientation);
+/* Overlap of consecutive timesteps.  Declares the images of the step AFTER the next orbf_step / orbf_step_motion call:
+ * that call enqueues their extraction on the extractor's stream right after it has enqueued its own matching, so the two
+ * run next to each other on the GPU (matching occupies a handful of the 256 CUs), and the following step finds its
+ * features ready or in flight.  The following step must then be called with exactly these images (same pointers, sizes,
+ * strides), otherwise the prefetched work is dropped and the images are extracted again.  Host images are read while the
+ * intervening step runs; device images must stay unchanged until the step that consumes them has returned.  Results are
+ * bit-identical with and without prefetching; rigs of more than 4 cameras ignore the hint. */
+int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images);
 /* queries: the projected last-frame map points (may be NULL / 0 on the first frame) */
 int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out);
 /* Synthetic-stream driver: like orbf_step, with the queries built natively from the PREVIOUS step's features moved by a

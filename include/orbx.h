@@ -60,13 +60,18 @@ int orbx_upload_device(orbx_extractor* ex, int cam, const uint8_t* d_gray, int w
 int orbx_run(orbx_extractor* ex);
 /* Split form of orbx_run for callers that keep enqueueing dependent work on orbx_stream(ex): orbx_run_async returns
  * without a host synchronisation (device-quadtree path; otherwise it behaves like orbx_run), the per-camera counts are in
- * HBM (orbx_device_counts: int[n_cams]); orbx_finish synchronises the stream and makes orbx_count() valid.  It returns 1
- * (not an error) when a pyramid level was outside the device quadtree's limits and the results were recomputed on the
- * host path: work enqueued against the asynchronous counts must then be redone. */
+ * HBM (orbx_device_counts: int[n_cams] of the most recently enqueued run).  Up to TWO runs may be in flight: the second
+ * one (the next timestep's images, uploaded after the first run was enqueued) executes behind the first on the same
+ * stream while the caller consumes the first one's results.  orbx_finish waits for the OLDEST run in flight and makes
+ * orbx_count() valid for it.  It returns
+ *   1 (not an error) when a pyramid level was outside the device quadtree's limits and the results were recomputed on
+ *     the host path right away: work enqueued against the asynchronous counts must be redone;
+ *   2 in the same situation while a newer run is in flight: nothing was recomputed, because the resident images already
+ *     belong to the newer run -- upload this run's images again and call orbx_run (which abandons the newer run). */
 int orbx_run_async(orbx_extractor* ex);
 int orbx_finish(orbx_extractor* ex);
 const int* orbx_device_counts(const orbx_extractor* ex);
-int orbx_pending(const orbx_extractor* ex); /* 1 between an asynchronous orbx_run_async and orbx_finish */
+int orbx_pending(const orbx_extractor* ex); /* asynchronous runs in flight (0..2) */
 /* number of keypoints camera `cam` produced in the last run */
 int orbx_count(const orbx_extractor* ex, int cam);
 /* copy the last run's results of one camera to host buffers */

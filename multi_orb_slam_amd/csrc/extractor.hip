@@ -1252,8 +1252,25 @@ struct orbx_extractor {
     int* h_oct = nullptr;            // pinned, mapped: [0..n_cams) n_out, [n_cams] status
     bool device_octree = true;
     bool cand_valid = false;         // h_cand / h_level_cnt hold the last run's candidates (k_compact ran)
-    bool pending = false;            // orbx_run_async enqueued, orbx_finish not yet called
+    // (in-flight bookkeeping: see `inflight` below), orbx_finish not yet called
     std::chrono::steady_clock::time_point t_begin_async;
+    // up to two asynchronous runs may be in flight (the second one is the next timestep's, enqueued while the first one's
+    // results are being matched): run r uses slot r & 1 of the count mirrors and of the completion events
+    struct ChainGraph {  // captured kernel chain of one count slot (see orbx_run_impl)
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        int epoch = -1; orb_keypoint* mirror_kps = nullptr; uint8_t* mirror_desc = nullptr; FrameSink sink;
+        void destroy() {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+            exec = nullptr; graph = nullptr; epoch = -1;
+        }
+    } chain[2];
+    bool use_graph = true;           // MORB_CHAIN_GRAPH=0 keeps plain launches
+    int geom_epoch = 0;              // bumped by every rebuild_geometry
+    int inflight = 0; unsigned run_seq = 0;
+    bool prof_valid[2] = {false, false};  // the stage events were recorded for the run in this slot
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    int* d_h_oct = nullptr;          // device alias of h_oct
     std::vector<DevBuf<orb_keypoint>> d_kps;
     std::vector<DevBuf<uint8_t>> d_desc;
     std::vector<orb_keypoint*> out_kps;   // active output pointers (internal or bound)
@@ -1282,6 +1299,7 @@ struct orbx_extractor {
 
 static int rebuild_geometry(orbx_extractor* ex) {
     const int ML = ex->max_levels;
+    ++ex->geom_epoch;  // captured launch chains carry the old geometry
     ex->levels.assign((size_t)ex->n_cams * ML, LevelInfo{});
     ex->cell_map.clear();
     std::vector<int2> xt;
@@ -1356,7 +1374,7 @@ static int rebuild_geometry(orbx_extractor* ex) {
         (rc = ex->d_cell_items.reserve(std::max<size_t>(slot_base, 1))) || (rc = ex->d_cand_dev.reserve(std::max<size_t>(slot_base, 1))) ||
         (rc = ex->d_level_cnt_dev.reserve(ex->levels.size())) || (rc = ex->d_sel_cnt.reserve(ex->levels.size())) ||
         (rc = ex->d_oct_status.reserve(ex->levels.size())) ||
-        (rc = ex->d_n_out.reserve(ex->n_cams)) ||
+        (rc = ex->d_n_out.reserve(2 * ex->n_cams)) ||
         (rc = ex->d_sel_oct.reserve(std::max<size_t>(slot_blk.size(), 1))) || (rc = ex->d_slot_blk.reserve(std::max<size_t>(slot_blk.size(), 1))))
         return rc;
     if (!slot_blk.empty())
@@ -1453,8 +1471,11 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     ORBX_TRY_HIP(hipHostMalloc((void**)&ex->h_sel, sel_cap * sizeof(SelKp), hipHostMallocDefault));
     ex->h_sel_cap = sel_cap;
     ORBX_TRY_HIP(hipHostMalloc((void**)&ex->h_level_cnt, (size_t)n_cams * MAX_LEVELS * sizeof(int), hipHostMallocMapped));
-    ORBX_TRY_HIP(hipHostMalloc((void**)&ex->h_oct, (size_t)(n_cams + 1) * sizeof(int), hipHostMallocMapped));
+    ORBX_TRY_HIP(hipHostMalloc((void**)&ex->h_oct, (size_t)2 * (n_cams + 1) * sizeof(int), hipHostMallocMapped));
+    ORBX_TRY_HIP(hipHostGetDevicePointer((void**)&ex->d_h_oct, ex->h_oct, 0));
+    for (int i = 0; i < 2; ++i) ORBX_TRY_HIP(hipEventCreateWithFlags(&ex->ev_done[i], hipEventDisableTiming | hipEventReleaseToSystem));
     { const char* e = getenv("MORB_HOST_OCTREE"); ex->device_octree = !(e && atoi(e) != 0); }
+    { const char* e = getenv("MORB_CHAIN_GRAPH"); ex->use_graph = !(e && atoi(e) == 0); }
     ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
@@ -1473,6 +1494,7 @@ void orbx_destroy(orbx_extractor* ex) {
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
+    ex->chain[0].destroy(); ex->chain[1].destroy();
     ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release();
     ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release(); ex->d_sel_oct.release();
     ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release();
@@ -1484,6 +1506,7 @@ void orbx_destroy(orbx_extractor* ex) {
     if (ex->h_level_cnt) (void)hipHostFree(ex->h_level_cnt);
     if (ex->h_sel) (void)hipHostFree(ex->h_sel);
     if (ex->h_oct) (void)hipHostFree(ex->h_oct);
+    for (int i = 0; i < 2; ++i) if (ex->ev_done[i]) (void)hipEventDestroy(ex->ev_done[i]);
     for (int i = 0; i < 6; ++i) if (ex->ev[i]) (void)hipEventDestroy(ex->ev[i]);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
@@ -1572,9 +1595,9 @@ static int finish_device_path(orbx_extractor* ex);
 
 int orbx_finish(orbx_extractor* ex) {
     MORB_ARG(ex != nullptr);
-    if (!ex->pending) return ORB_OK;
+    if (ex->inflight == 0) return ORB_OK;
     MORB_HIP(hipSetDevice(ex->device));
-    MORB_HIP(hipStreamSynchronize(ex->stream));
+    MORB_HIP(hipEventSynchronize(ex->ev_done[(ex->run_seq - (unsigned)ex->inflight) & 1]));  // the OLDEST run in flight
     return finish_device_path(ex);
 }
 
@@ -1584,8 +1607,58 @@ int orbx_set_frame_sink(orbx_extractor* ex, const FrameSink* sink) {
     return ORB_OK;
 }
 
-const int* orbx_device_counts(const orbx_extractor* ex) { return ex ? ex->d_n_out.p : nullptr; }
-int orbx_pending(const orbx_extractor* ex) { return ex && ex->pending ? 1 : 0; }
+// counts of the most recently enqueued run
+const int* orbx_device_counts(const orbx_extractor* ex) { return ex ? ex->d_n_out.p + ((ex->run_seq - 1u) & 1u) * ex->n_cams : nullptr; }
+int orbx_pending(const orbx_extractor* ex) { return ex ? ex->inflight : 0; }
+void* orbx_done_event(const orbx_extractor* ex) { return ex ? (void*)ex->ev_done[(ex->run_seq - 1u) & 1u] : nullptr; }
+
+// K1 + K2/K3 of a run: the pyramid chain and the per-cell FAST kernel
+static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st) {
+    const int ML = ex->max_levels;
+    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[0], st));
+    for (int l = 1; l < ML; ++l) {
+        int mw = 0, mh = 0;
+        for (int c = 0; c < ex->n_cams; ++c) {
+            const LevelInfo& Lv = ex->levels[(size_t)c * ML + l];
+            mw = std::max(mw, Lv.w); mh = std::max(mh, Lv.h);
+        }
+        if (mw == 0) continue;
+        dim3 grid((mw + 255) / 256, (mh + 3) / 4, ex->n_cams), block(64, 4, 1);
+        hipLaunchKernelGGL(k_resize, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
+                           (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
+    }
+    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[1], st));
+    // per-cell FAST / NMS / threshold / compaction
+    hipLaunchKernelGGL(k_fast_cells, dim3(ex->total_cells), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p,
+                       (const int2*)ex->d_cell_map.p, (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, ML, ex->d_cell_cnt.p,
+                       ex->d_cell_items.p);
+    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[2], st));
+    MORB_HIP(hipGetLastError());
+    return ORB_OK;
+}
+
+// K4 on the device + K5-K7 from the slotted list, for the run that uses count slot `slot`
+static int launch_tree_describe(orbx_extractor* ex, hipStream_t st, unsigned slot, const FrameSink& sink) {
+    const int ML = ex->max_levels;
+    int* d_h_oct = ex->d_h_oct + slot * (ex->n_cams + 1);
+    MirrorArgs mir;
+    mir.kps = nullptr; mir.desc = nullptr;
+    if (ex->mirror_kps) { mir.kps = ex->mirror_kps; mir.desc = ex->mirror_desc; }  // cap_total covers every camera's capacity
+    for (int c = 0; c < 64; ++c) mir.base[c] = 0;
+    hipLaunchKernelGGL(k_octree, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
+                       (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
+                       ex->d_oct_status.p, ML);
+    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[4], st));
+    hipLaunchKernelGGL(k_describe, dim3((ex->total_sel_slots + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
+                       (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel_oct.p, ex->total_sel_slots,
+                       (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
+                       SelListArgs{(const unsigned short*)ex->d_slot_blk.p, (const int*)ex->d_sel_cnt.p,
+                                   (const int*)ex->d_oct_status.p, ex->d_n_out.p + slot * ex->n_cams, d_h_oct, ex->n_cams},
+                       sink);
+    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[5], st));
+    MORB_HIP(hipGetLastError());
+    return ORB_OK;
+}
 
 static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
     MORB_HIP(hipSetDevice(ex->device));
@@ -1600,7 +1673,12 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
     }
     const int ML = ex->max_levels;
     hipStream_t st = ex->stream;
-    std::fill(ex->n_out.begin(), ex->n_out.end(), 0);
+    if (allow_async && ex->inflight >= 2) { morb::set_error("two runs are already in flight: orbx_finish the older one first"); return ORB_E_ARG; }
+    if (!allow_async && ex->inflight > 0) {  // a synchronous run abandons whatever was still in flight
+        MORB_HIP(hipStreamSynchronize(st));
+        ex->inflight = 0;
+    }
+    if (ex->inflight == 0) std::fill(ex->n_out.begin(), ex->n_out.end(), 0);
     if (ex->total_cells == 0) {  // every camera empty
         memset(&ex->ingest, 0, sizeof(ex->ingest)); ex->ingest_pending = false;
         return ORB_OK;
@@ -1619,62 +1697,67 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         for (int c = 0; c < ex->n_cams; ++c) ex->ingest.src[c] = nullptr;
         ex->ingest_pending = false;
     }
-    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[0], st));
-    // K1: pyramid chain
-    for (int l = 1; l < ML; ++l) {
-        int mw = 0, mh = 0;
-        for (int c = 0; c < ex->n_cams; ++c) {
-            const LevelInfo& Lv = ex->levels[(size_t)c * ML + l];
-            mw = std::max(mw, Lv.w); mh = std::max(mh, Lv.h);
-        }
-        if (mw == 0) continue;
-        dim3 grid((mw + 255) / 256, (mh + 3) / 4, ex->n_cams), block(64, 4, 1);
-        hipLaunchKernelGGL(k_resize, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
-                           (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
-    }
-    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[1], st));
-    // K2+K3: per-cell FAST / NMS / threshold / compaction
-    hipLaunchKernelGGL(k_fast_cells, dim3(ex->total_cells), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p,
-                       (const int2*)ex->d_cell_map.p, (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, ML, ex->d_cell_cnt.p,
-                       ex->d_cell_items.p);
-    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[2], st));
-    // K3b (only on the host-quadtree path and for the inspection hook): dense cell-major lists, also into pinned host memory
     const bool dev_tree = ex->device_octree && ex->total_sel_slots > 0;
     if (!dev_tree) {
+        if ((rc = launch_pyramid_fast(ex, st))) return rc;
+        // K3b (only on the host-quadtree path and for the inspection hook): dense cell-major lists, also into pinned host memory
         hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ML), dim3(1024), 0, st, (const LevelInfo*)ex->d_levels.p,
                            (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_cell_off.p, d_cand, d_level_cnt,
                            ex->d_cand_dev.p, ex->d_level_cnt_dev.p);
+        if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[3], st));
+        MORB_HIP(hipGetLastError());
     }
     ex->cand_valid = !dev_tree;
-    if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[3], st));
-    MORB_HIP(hipGetLastError());
 
-    // K4 on the device: quadtree -> output offsets -> K5-K7 straight from the slotted list; ONE sync afterwards, which
-    // overlaps the describe kernel.  Falls through to the host quadtree when a level is outside the device limits.
+    // K4 on the device: quadtree -> K5-K7 straight from the slotted list; ONE sync afterwards.  Falls through to the host
+    // quadtree when a level is outside the device limits.
     if (dev_tree) {
-        int* d_h_oct = nullptr;
-        MORB_HIP(hipHostGetDevicePointer((void**)&d_h_oct, ex->h_oct, 0));
-        MirrorArgs mir;
-        mir.kps = nullptr; mir.desc = nullptr;
-        if (ex->mirror_kps) { mir.kps = ex->mirror_kps; mir.desc = ex->mirror_desc; }  // cap_total covers every camera's capacity
-        for (int c = 0; c < 64; ++c) mir.base[c] = 0;
-        hipLaunchKernelGGL(k_octree, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
-                           (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
-                           ex->d_oct_status.p, ML);
-        if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[4], st));
-        hipLaunchKernelGGL(k_describe, dim3((ex->total_sel_slots + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
-                           (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel_oct.p, ex->total_sel_slots,
-                           (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
-                           SelListArgs{(const unsigned short*)ex->d_slot_blk.p, (const int*)ex->d_sel_cnt.p,
-                                       (const int*)ex->d_oct_status.p, ex->d_n_out.p, d_h_oct, ex->n_cams},
-                           allow_async ? ex->sink : FrameSink{});
-        if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[5], st));
-        MORB_HIP(hipGetLastError());
-        ex->pending = true; ex->t_begin_async = t_begin;
+        const unsigned slot = ex->run_seq & 1u;
+        // The ten launches of the chain are captured once per slot into a kernel-only graph and replayed with one
+        // hipGraphLaunch (the host cost of enqueueing them is what bounds overlapped timesteps).  Everything the launches
+        // carry is in the key: geometry epoch, result mirrors, frame sink.
+        orbx_extractor::ChainGraph& G = ex->chain[slot];
+        const FrameSink sink = allow_async ? ex->sink : FrameSink{};
+        const bool graphable = ex->use_graph && allow_async && !ex->profiling;
+        bool done = false;
+        if (graphable) {
+            const bool hit = G.exec && G.epoch == ex->geom_epoch && G.mirror_kps == ex->mirror_kps && G.mirror_desc == ex->mirror_desc &&
+                             memcmp(&G.sink, &sink, sizeof(FrameSink)) == 0;
+            if (hit) {
+                MORB_HIP(hipGraphLaunch(G.exec, st));
+                done = true;
+            } else {
+                G.destroy();
+                hipGraph_t g = nullptr;
+                hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+                if (e == hipSuccess) {
+                    const int rc1 = launch_pyramid_fast(ex, st);
+                    const int rc2 = rc1 ? rc1 : launch_tree_describe(ex, st, slot, sink);
+                    e = hipStreamEndCapture(st, &g);
+                    if (!rc2 && e == hipSuccess && g && hipGraphInstantiate(&G.exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                        G.graph = g; G.epoch = ex->geom_epoch; G.mirror_kps = ex->mirror_kps; G.mirror_desc = ex->mirror_desc; G.sink = sink;
+                        MORB_HIP(hipGraphLaunch(G.exec, st));
+                        done = true;
+                    } else {
+                        if (g) (void)hipGraphDestroy(g);
+                        G.exec = nullptr;
+                    }
+                }
+                if (!done) { (void)hipGetLastError(); ex->use_graph = false; }  // plain launches from now on
+            }
+        }
+        if (!done) {
+            if ((rc = launch_pyramid_fast(ex, st))) return rc;
+            if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[3], st));
+            if ((rc = launch_tree_describe(ex, st, slot, sink))) return rc;
+        }
+        MORB_HIP(hipEventRecord(ex->ev_done[slot], st));
+        ex->prof_valid[slot] = ex->profiling && ex->inflight == 0;  // (one set of stage events: not for overlapped runs)
+        ++ex->run_seq; ++ex->inflight; ex->t_begin_async = t_begin;
         if (allow_async) return ORB_OK;
         MORB_HIP(hipStreamSynchronize(st));
-        ex->pending = false;
-        if (ex->h_oct[ex->n_cams] == 0) return finish_device_path(ex);
+        if (ex->h_oct[slot * (ex->n_cams + 1) + ex->n_cams] == 0) return finish_device_path(ex);
+        ex->inflight = 0;
         std::fill(ex->n_out.begin(), ex->n_out.end(), 0);  // a level exceeded the device limits: redo the selection on the host
         hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ML), dim3(1024), 0, st, (const LevelInfo*)ex->d_levels.p,
                            (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_cell_off.p, d_cand, d_level_cnt,
@@ -1778,13 +1861,15 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
 // After the stream has drained: adopt the device path's counts, or redo the selection on the host if a level was outside
 // the device limits (then the downstream work a caller enqueued on stale counts is invalid: it is told via the return).
 static int finish_device_path(orbx_extractor* ex) {
-    ex->pending = false;
-    if (ex->h_oct[ex->n_cams] == 0) {
+    const unsigned oldest = (ex->run_seq - (unsigned)ex->inflight) & 1u;
+    const int* h_oct = ex->h_oct + oldest * (ex->n_cams + 1);
+    --ex->inflight;
+    if (h_oct[ex->n_cams] == 0) {
         for (int c = 0; c < ex->n_cams; ++c) {
-            ex->n_out[c] = ex->h_oct[c];
+            ex->n_out[c] = h_oct[c];
             if (ex->n_out[c] > ex->out_cap_active[c]) { morb::set_error("a camera produced more keypoints than its output capacity"); return ORB_E_CAPACITY; }
         }
-        if (ex->profiling) {
+        if (ex->profiling && ex->prof_valid[oldest]) {
             float ms;
             MORB_HIP(hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1])); ex->stage_us[0] = ms * 1000.f;
             MORB_HIP(hipEventElapsedTime(&ms, ex->ev[1], ex->ev[2])); ex->stage_us[1] = ms * 1000.f;
@@ -1795,7 +1880,10 @@ static int finish_device_path(orbx_extractor* ex) {
         }
         return ORB_OK;
     }
-    // a level exceeded the device limits: run the synchronous host-quadtree path on the same resident images
+    // a level exceeded the device limits.  With a newer run in flight the resident images are already being replaced:
+    // the caller has to upload this run's images again and run synchronously (2).  Otherwise the synchronous
+    // host-quadtree path runs right here on the same resident images (1).
+    if (ex->inflight > 0) return 2;
     const bool saved = ex->device_octree;
     ex->device_octree = false;
     int rc = orbx_run_impl(ex, false);

@@ -23,3 +23,6 @@ struct FrameSink {
 
 // nullptr switches the sink off.  Used by the next orbx_run_async that takes the device-quadtree path (at most 4 cameras).
 extern "C" int orbx_set_frame_sink(orbx_extractor* ex, const FrameSink* sink);
+
+// completion event of the most recently enqueued asynchronous run (valid while it is in flight)
+extern "C" void* orbx_done_event(const orbx_extractor* ex);

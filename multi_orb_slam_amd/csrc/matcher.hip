@@ -1333,6 +1333,19 @@ static int frame_prepare_sink(orbm_matcher* m, const orbm_cam_features* cams, in
     return ORB_OK;
 }
 
+// the sink of an existing (persistent) frame
+static int frame_sink_of(orbm_matcher* m, orbm_frame* F, const orbm_cam_features* cams, int n_cams, float mbf, FrameSink* sink) {
+    MORB_ARG(F && n_cams >= 1 && n_cams <= 4);
+    memset(sink, 0, sizeof(*sink));
+    sink->x = F->b->d_x.p; sink->y = F->b->d_y.p; sink->ur = F->b->d_ur.p; sink->depth = F->b->d_depth.p; sink->ang = F->b->d_ang.p;
+    sink->oct = F->b->d_oct.p; sink->kps = F->b->d_kps.p; sink->desc = reinterpret_cast<uint32_t*>(F->b->d_desc.p);
+    sink->cell_of = F->b->d_cell_of.p;
+    sink->h_ur = m->mirror_ur; sink->h_depth = m->mirror_depth;
+    for (int c = 0; c < n_cams; ++c) { sink->cam_depth[c] = cams[c].d_depth; sink->cam_depth_stride[c] = cams[c].depth_stride; }
+    sink->mbf = mbf; sink->minX = F->minX; sink->minY = F->minY; sink->invW = F->invW; sink->invH = F->invH;
+    return ORB_OK;
+}
+
 static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
                                   float max_x, float max_y, const int* d_counts, orbm_frame** out, bool sink_filled) {
     MORB_ARG(m && cams && out && n_cams >= 1 && n_cams <= 64 && max_x > min_x && max_y > min_y);
@@ -1804,11 +1817,20 @@ struct orbf_frontend {
     float mbf = 40.f;
     int th_high = ORBM_TH_HIGH, check_ori = 1;
     int cap_total = 0;
-    // pinned host result buffers
-    PinnedBuf<orb_keypoint> h_kps;
-    PinnedBuf<uint8_t> h_desc, h_queries;
-    PinnedBuf<float> h_ur, h_depth;
+    // pinned host result buffers.  The per-feature results exist twice: the extraction of the NEXT timestep (orbf_prefetch)
+    // fills the other set while the caller still reads this step's.
+    struct ResultSet { PinnedBuf<orb_keypoint> kps; PinnedBuf<uint8_t> desc; PinnedBuf<float> ur, depth; } rs[2];
+    int cur = 0;  // set holding the results of the last completed step
+    PinnedBuf<uint8_t> h_queries;
     PinnedBuf<int32_t> h_match;
+    // Small rigs (<= 4 cameras): one persistent frame per result set, filled by the extractor's describe kernel (FrameSink)
+    orbm_frame* pframe[2] = {nullptr, nullptr};
+    int pframe_W[2] = {0, 0}, pframe_H[2] = {0, 0};
+    // extraction in flight for the NEXT step (enqueued by the previous orbf_step after orbf_prefetch)
+    struct InFlight { bool active = false; std::vector<orbf_image> images; int set = 0, W = 0, H = 0; } inflight;
+    std::vector<orbf_image> next_images;  // declared by orbf_prefetch, consumed by the next step
+    bool have_next = false;
+    bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path
     // previous step (for orbf_step_motion)
     int prev_n = 0;
     std::vector<int32_t> prev_cam_of;
@@ -1824,16 +1846,19 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     f->device = device; f->n_cams = n_cams; f->max_w = max_width; f->max_h = max_height;
     int rc = orbx_create(params, n_cams, max_width, max_height, device, &f->ex);
     if (!rc) rc = orbm_create(device, &f->mt);
-    if (!rc) rc = orbm_set_stream(f->mt, orbx_stream(f->ex));  // one stream: frame build + matching follow extraction
+    // two streams: the matcher's own one follows the extractor's through events, so that the next step's extraction can
+    // run next to this step's matching
     if (rc) { orbf_destroy(f); return rc; }
     f->d_depth.assign(n_cams, nullptr); f->depth_stride.assign(n_cams, 0); f->counts.assign(n_cams, 0);
     f->scale_factors.assign(params[0].nlevels, 1.f);
     if ((rc = orbx_tables(&params[0], f->scale_factors.data(), nullptr, nullptr, nullptr, nullptr, nullptr))) { orbf_destroy(f); return rc; }
     for (int c = 0; c < n_cams; ++c) { f->cam_cap.push_back(params[c].nfeatures + 4 * params[c].nlevels); f->cap_total += f->cam_cap.back(); }
     const size_t cap = (size_t)f->cap_total;
-    if ((rc = f->h_kps.reserve(cap)) || (rc = f->h_desc.reserve(cap * 32)) || (rc = f->h_ur.reserve(cap)) ||
-        (rc = f->h_depth.reserve(cap)) || (rc = f->h_match.reserve(cap)) ||
-        (rc = orbx_set_host_mirror(f->ex, f->h_kps.dp, f->h_desc.dp, f->cap_total))) { orbf_destroy(f); return rc; }
+    for (int k = 0; k < 2 && !rc; ++k)
+        if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
+            (rc = f->rs[k].depth.reserve(cap))) break;
+    if (!rc) rc = f->h_match.reserve(cap);
+    if (rc) { orbf_destroy(f); return rc; }
     *out = f;
     return ORB_OK;
 }
@@ -1841,9 +1866,13 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
 void orbf_destroy(orbf_frontend* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    if (f->mt) { (void)orbm_set_stream(f->mt, nullptr); orbm_destroy(f->mt); }
+    if (f->ex) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->ex));
+    if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
+    for (int k = 0; k < 2; ++k) if (f->pframe[k]) orbm_frame_destroy(f->pframe[k]);  // back to the matcher's pool first
+    if (f->mt) orbm_destroy(f->mt);
     if (f->ex) orbx_destroy(f->ex);
-    f->h_kps.release(); f->h_desc.release(); f->h_queries.release(); f->h_ur.release(); f->h_depth.release(); f->h_match.release();
+    for (int k = 0; k < 2; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); }
+    f->h_queries.release(); f->h_match.release();
     delete f;
 }
 
@@ -1871,7 +1900,20 @@ int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* quer
     return orbf_step_impl(f, images, queries, nq, flags, out, false);
 }
 
-int orbf_reset(orbf_frontend* f) { MORB_ARG(f != nullptr); f->prev_n = 0; return ORB_OK; }
+static int orbf_drain(orbf_frontend* f);
+
+int orbf_reset(orbf_frontend* f) {
+    MORB_ARG(f != nullptr);
+    f->prev_n = 0; f->have_next = false; f->overlap_ok = true;
+    return orbf_drain(f);
+}
+
+int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images) {
+    MORB_ARG(f && next_images);
+    f->next_images.assign(next_images, next_images + f->n_cams);
+    f->have_next = true;
+    return ORB_OK;
+}
 
 int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out) {
     MORB_ARG(f && images && motion && out);
@@ -1879,14 +1921,86 @@ int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_moti
     int rc;
     f->t_entry = std::chrono::steady_clock::now();
     if (nq) {
-        // the previous step's features are still in the pinned result buffers; turn them into queries BEFORE this step's
-        // kernels overwrite those buffers
+        // the previous step's features are still in their pinned result set
         if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
-        rc = orbm_queries_from_motion(f->h_kps.p, f->h_desc.p, f->h_depth.p, f->prev_cam_of.data(), nq, motion->du, motion->dv,
+        const orbf_frontend::ResultSet& R = f->rs[f->cur];
+        rc = orbm_queries_from_motion(R.kps.p, R.desc.p, R.depth.p, f->prev_cam_of.data(), nq, motion->du, motion->dv,
                                       motion->th, f->scale_factors.data(), f->mbf, reinterpret_cast<orbm_query*>(f->h_queries.p));
         if (rc) return rc;
     }
     return orbf_step_impl(f, images, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, flags, out, true);
+}
+
+static bool same_images(const std::vector<orbf_image>& a, const orbf_image* b, int n) {
+    if ((int)a.size() != n) return false;
+    for (int c = 0; c < n; ++c)
+        if (a[c].data != b[c].data || a[c].width != b[c].width || a[c].height != b[c].height || a[c].stride != b[c].stride ||
+            (a[c].on_device != 0) != (b[c].on_device != 0))
+            return false;
+    return true;
+}
+
+static bool small_rig(const orbf_frontend* f) { return f->n_cams <= 4 && f->cap_total <= 8192 && !f->mt->host_resolve; }
+
+static void fill_cam_capacities(orbf_frontend* f, orbm_cam_features* cams) {
+    for (int c = 0; c < f->n_cams; ++c) {
+        cams[c].d_kps = orbx_device_keypoints(f->ex, c); cams[c].d_desc = orbx_device_descriptors(f->ex, c);
+        cams[c].n = f->cam_cap[c]; cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
+    }
+}
+
+// Uploads + the whole extractor for one timestep into result set `set`, nothing synchronised.  Small rigs: the describe
+// kernel writes the merged frame pframe[set] through a FrameSink (*went_async = 1 unless the extractor took its
+// synchronous host-quadtree path; then the frame was not filled).
+static int enqueue_extract(orbf_frontend* f, const orbf_image* images, int set, int* W_out, int* H_out, int* went_async) {
+    orbm_matcher* m = f->mt;
+    int rc, W = 0, H = 0;
+    for (int c = 0; c < f->n_cams; ++c) {
+        const orbf_image& im = images[c];
+        rc = im.on_device ? orbx_upload_device(f->ex, c, im.data, im.width, im.height, im.stride)
+                          : orbx_upload(f->ex, c, im.data, im.width, im.height, im.stride);
+        if (rc) return rc;
+        W = std::max(W, im.width); H = std::max(H, im.height);
+    }
+    if (W == 0 || H == 0) { W = f->max_w; H = f->max_h; }
+    *W_out = W; *H_out = H;
+    orbf_frontend::ResultSet& R = f->rs[set];
+    if ((rc = orbx_set_host_mirror(f->ex, R.kps.dp, R.desc.dp, f->cap_total))) return rc;
+    *went_async = 0;
+    if (!small_rig(f)) return orbx_run_async(f->ex);  // (> 4 cameras: the frame is assembled by the matcher's own kernels)
+    std::vector<orbm_cam_features> cams(f->n_cams);
+    fill_cam_capacities(f, cams.data());
+    if (f->pframe[set] && (f->pframe_W[set] != W || f->pframe_H[set] != H)) { orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr; }
+    FrameSink sink;
+    m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp;
+    if (!f->pframe[set]) {
+        rc = frame_prepare_sink(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, &f->pframe[set], &sink);
+        f->pframe_W[set] = W; f->pframe_H[set] = H;
+    } else {
+        orbm_frame* F = f->pframe[set];
+        F->n_total = f->cap_total; F->counts_on_device = true; F->host_valid = false;
+        rc = frame_sink_of(m, F, cams.data(), f->n_cams, f->mbf, &sink);
+    }
+    m->mirror_ur = nullptr; m->mirror_depth = nullptr;
+    if (rc) return rc;
+    if ((rc = orbx_set_frame_sink(f->ex, &sink))) return rc;
+    const int before = orbx_pending(f->ex);
+    rc = orbx_run_async(f->ex);
+    (void)orbx_set_frame_sink(f->ex, nullptr);
+    if (rc) return rc;
+    *went_async = orbx_pending(f->ex) > before ? 1 : 0;
+    return ORB_OK;
+}
+
+// Everything in flight is waited for and dropped (results of a prefetched extraction included).
+static int orbf_drain(orbf_frontend* f) {
+    MORB_HIP(hipSetDevice(f->device));
+    MORB_HIP(hipStreamSynchronize((hipStream_t)orbx_stream(f->ex)));
+    MORB_HIP(hipStreamSynchronize(f->mt->stream));
+    MORB_HIP(hipStreamSynchronize(f->mt->side_stream));
+    while (orbx_pending(f->ex) > 0) { int rc = orbx_finish(f->ex); if (rc < 0) return rc; }
+    f->inflight.active = false;
+    return ORB_OK;
 }
 
 static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
@@ -1897,79 +2011,71 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     };
     MORB_HIP(hipSetDevice(f->device));
     orbm_matcher* m = f->mt;
-    int rc;
-    int W = 0, H = 0;
-    for (int c = 0; c < f->n_cams; ++c) {
-        const orbf_image& im = images[c];
-        rc = im.on_device ? orbx_upload_device(f->ex, c, im.data, im.width, im.height, im.stride)
-                          : orbx_upload(f->ex, c, im.data, im.width, im.height, im.stride);
-        if (rc) return rc;
-        W = std::max(W, im.width); H = std::max(H, im.height);
+    hipStream_t st = m->stream;                                   // matching
+    hipStream_t st_e = (hipStream_t)orbx_stream(f->ex);           // extraction
+    int rc, W = 0, H = 0, went_async = 0;
+    const bool small = small_rig(f);
+
+    // ---- this step's extraction: already in flight (orbf_prefetch during the previous step) or enqueued now
+    int set;
+    if (f->inflight.active && same_images(f->inflight.images, images, f->n_cams)) {
+        set = f->inflight.set; W = f->inflight.W; H = f->inflight.H; went_async = 1;
+        f->inflight.active = false;
+    } else {
+        if (f->inflight.active && (rc = orbf_drain(f))) return rc;  // prefetched for other images: dropped
+        set = f->cur ^ 1;
+        if ((rc = enqueue_extract(f, images, set, &W, &H, &went_async))) return rc;
     }
-    // queries go through pinned staging so their H2D overlaps the extractor's work
+    orbf_frontend::ResultSet& R = f->rs[set];
+
+    // queries go through pinned staging; their H2D runs on the side stream next to the extractor's work
     if (nq) {
         if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))))
             return rc;
         if (!queries_in_pinned) memcpy(f->h_queries.p, queries, (size_t)nq * sizeof(orbm_query));
-        // on the side stream: the copy engine moves them while the extractor's kernels run; joined before the frame build
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, f->h_queries.p, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->side_stream));
         MORB_HIP(hipEventRecord(m->ev_q, m->side_stream));
     }
     std::vector<orbm_cam_features> cams(f->n_cams);
-    if (W == 0 || H == 0) { W = f->max_w; H = f->max_h; }
-    int cap_sum = 0;
-    for (int c = 0; c < f->n_cams; ++c) cap_sum += f->cam_cap[c];
-    const bool small_rig = f->n_cams <= 4 && cap_sum <= 8192 && !m->host_resolve;
-    hipStream_t st = m->stream;
-    // With a small rig the extractor's describe kernel fills the merged frame itself (FrameSink): prepare that frame now.
-    orbm_frame* fr_sink = nullptr;
-    if (small_rig) {
-        for (int c = 0; c < f->n_cams; ++c) {
-            cams[c].d_kps = orbx_device_keypoints(f->ex, c); cams[c].d_desc = orbx_device_descriptors(f->ex, c);
-            cams[c].n = f->cam_cap[c]; cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
-        }
-        FrameSink sink;
-        m->mirror_ur = f->h_ur.dp; m->mirror_depth = f->h_depth.dp;
-        rc = frame_prepare_sink(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, &fr_sink, &sink);
-        m->mirror_ur = nullptr; m->mirror_depth = nullptr;
-        if (rc) return rc;
-        if ((rc = orbx_set_frame_sink(f->ex, &sink))) { orbm_frame_destroy(fr_sink); return rc; }
-    }
-    // ---- extraction: enqueued without a host sync when the device quadtree is active
-    rc = orbx_run_async(f->ex);
-    (void)orbx_set_frame_sink(f->ex, nullptr);
-    if (rc) { if (fr_sink) orbm_frame_destroy(fr_sink); return rc; }
-    const int* d_counts = orbx_device_counts(f->ex);
-    bool async_path = orbx_pending(f->ex) && small_rig;
-    if (!async_path && fr_sink) { orbm_frame_destroy(fr_sink); fr_sink = nullptr; }  // the extractor took its synchronous path
-    if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
     orbm_frame* fr = nullptr;
+    bool fr_persistent = false;
     int n = 0, nmatches = 0;
     bool do_cross = !(flags & ORBF_SKIP_CROSS);
     auto t_synced = t_impl;
     SearchJob J{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
-    if ((rc = f->h_match.reserve(std::max(cap_sum, 1)))) return rc;
+    if ((rc = f->h_match.reserve(std::max(f->cap_total, 1)))) return rc;
+    bool async_path = small && went_async;
+    bool next_enqueued = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (!async_path) {
+        if (async_path) {
+            // matching follows the extraction through its completion event; the counts are read from HBM
+            fr = f->pframe[set]; fr_persistent = true;
+            fill_cam_capacities(f, cams.data());
+            MORB_HIP(hipStreamWaitEvent(st, (hipEvent_t)orbx_done_event(f->ex), 0));
+            if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
+            orbm_frame* frp = fr;
+            rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, orbx_device_counts(f->ex), &frp, true);
+            if (rc) return rc;
+            n = fr->n_total;
+        } else {
             rc = orbx_finish(f->ex);  // synchronises; counts are on the host from here on
             if (rc < 0) return rc;
+            if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
+            n = 0;
+            for (int c = 0; c < f->n_cams; ++c) {
+                cams[c].d_kps = orbx_device_keypoints(f->ex, c); cams[c].d_desc = orbx_device_descriptors(f->ex, c);
+                cams[c].n = orbx_count(f->ex, c);
+                cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
+                n += cams[c].n;
+            }
+            // the frame-build kernel mirrors the stereo arrays straight into this step's pinned result set (keypoints and
+            // descriptors were mirrored by the extractor's describe kernel)
+            m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp;
+            rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, nullptr, &fr);
+            m->mirror_ur = nullptr; m->mirror_depth = nullptr;
+            if (rc) return rc;
+            fr_persistent = false;
         }
-        n = 0;
-        for (int c = 0; c < f->n_cams; ++c) {
-            cams[c].d_kps = orbx_device_keypoints(f->ex, c); cams[c].d_desc = orbx_device_descriptors(f->ex, c);
-            cams[c].n = async_path ? f->cam_cap[c] : orbx_count(f->ex, c);
-            cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
-            n += cams[c].n;
-        }
-        // the frame-build kernel mirrors the stereo arrays straight into this handle's pinned result buffers (keypoints
-        // and descriptors were mirrored by the extractor's describe kernel)
-        m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = f->h_ur.dp; m->mirror_depth = f->h_depth.dp;
-        const bool sink_filled = async_path && fr_sink != nullptr;
-        if (sink_filled) { fr = fr_sink; fr_sink = nullptr; }
-        rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, async_path ? d_counts : nullptr, &fr,
-                                    sink_filled);
-        m->mirror_ur = nullptr; m->mirror_depth = nullptr;
-        if (rc) { if (sink_filled) orbm_frame_destroy(fr); return rc; }
         J.cur = fr; J.cap = 64; J.device_path = false;
         // fork: the camera-pair top-2 only needs the frame's descriptor block, so it runs on the side stream next to
         // project + resolve (both are a handful of workgroups on a 256-CU part); join before the one host sync
@@ -1977,7 +2083,7 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         if (forked) {
             hipError_t fe = hipEventRecord(m->ev_fork, st);
             if (fe == hipSuccess) fe = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
-            if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); orbm_frame_destroy(fr); return ORB_E_HIP; }
+            if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); if (!fr_persistent) orbm_frame_destroy(fr); return ORB_E_HIP; }
             rc = cross_enqueue(m, m->side_stream, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n,
                                async_path ? fr->b->d_ntotal.p : nullptr);
             hipError_t je = hipEventRecord(m->ev_join, m->side_stream);
@@ -1988,18 +2094,44 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
             hipError_t je = hipStreamWaitEvent(st, m->ev_join, 0);
             if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
         }
-        if (rc) { (void)hipStreamSynchronize(st); orbm_frame_destroy(fr); return rc; }
+        if (rc) { (void)hipStreamSynchronize(st); if (!fr_persistent) orbm_frame_destroy(fr); return rc; }
+        // ---- the NEXT step's extraction goes onto the extractor's stream now: it runs while this step is being matched
+        if (async_path && attempt == 0 && f->have_next && f->overlap_ok && !next_enqueued) {
+            int w2 = 0, h2 = 0, async2 = 0;
+            rc = enqueue_extract(f, f->next_images.data(), set ^ 1, &w2, &h2, &async2);
+            if (rc) { (void)hipStreamSynchronize(st); return rc; }
+            if (async2) {
+                f->inflight.active = true; f->inflight.images = f->next_images; f->inflight.set = set ^ 1; f->inflight.W = w2; f->inflight.H = h2;
+            } else {
+                // the extractor ran synchronously (host quadtree): its outputs now belong to the next step, which cannot be
+                // kept apart from this one's -- give up overlapping; the next step extracts again
+                f->overlap_ok = false;
+            }
+            next_enqueued = true;
+        }
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipStreamSynchronize(st);
         out->gpu_wait_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
         out->host_us[0] = us_between(f->t_entry, t_impl); out->host_us[1] = us_between(t_impl, t0); out->host_us[2] = out->gpu_wait_us;
         t_synced = std::chrono::steady_clock::now();
-        if (e != hipSuccess) { morb::set_error("hipStreamSynchronize: %s", hipGetErrorString(e)); orbm_frame_destroy(fr); return ORB_E_HIP; }
+        if (e != hipSuccess) {
+            morb::set_error("hipStreamSynchronize: %s", hipGetErrorString(e));
+            if (!fr_persistent) orbm_frame_destroy(fr);
+            return ORB_E_HIP;
+        }
         if (async_path) {
-            rc = orbx_finish(f->ex);  // stream already idle: adopts the counts (or reports the host-quadtree fallback)
-            if (rc < 0) { orbm_frame_destroy(fr); return rc; }
-            if (rc == 1) {  // counts used by the enqueued matcher work were stale: redo that part synchronously
-                orbm_frame_destroy(fr); fr = nullptr;
+            rc = orbx_finish(f->ex);  // this step's run completed long ago: adopts its counts (or reports the fallback)
+            if (rc < 0) return rc;
+            if (rc == 1 || rc == 2) {
+                // a pyramid level was outside the device quadtree's limits: this step is redone on the synchronous path
+                if (rc == 2) {  // ... from its images, because the next step's extraction has replaced them in HBM
+                    if ((rc = orbf_drain(f))) return rc;
+                    f->overlap_ok = false;
+                    int w2, h2, a2;
+                    if ((rc = enqueue_extract(f, images, set, &w2, &h2, &a2))) return rc;
+                    if (a2) { rc = orbx_finish(f->ex); if (rc < 0) return rc; }
+                }
+                fr = nullptr; fr_persistent = false;
                 async_path = false;
                 continue;
             }
@@ -2011,17 +2143,19 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         }
         break;
     }
+    f->have_next = false;
     do_cross = do_cross && n > 0;
     rc = search_finish(m, J, f->h_match.p, &nmatches);
-    orbm_frame_destroy(fr);  // stream is idle: the buffers go straight back to the pool
+    if (!fr_persistent) orbm_frame_destroy(fr);  // stream is idle: the buffers go straight back to the pool
     if (rc) return rc;
+    f->cur = set;
     f->prev_n = n;
     f->prev_cam_of.resize(n);
     for (int c = 0, g = 0; c < f->n_cams; ++c)
         for (int k = 0; k < f->counts[c]; ++k) f->prev_cam_of[g++] = c;
     out->n_queries = nq; out->queries = reinterpret_cast<const orbm_query*>(f->h_queries.p);
     out->n_cams = f->n_cams; out->n_total = n; out->counts = f->counts.data();
-    out->kps = f->h_kps.p; out->desc = f->h_desc.p; out->uright = f->h_ur.p; out->depth = f->h_depth.p;
+    out->kps = R.kps.p; out->desc = R.desc.p; out->uright = R.ur.p; out->depth = R.depth.p;
     out->nmatches = nmatches; out->match_of_feature = f->h_match.p;
     out->cross_best_idx = do_cross ? m->h_c0.p : nullptr;
     out->cross_best_dist = do_cross ? m->h_c1.p : nullptr;

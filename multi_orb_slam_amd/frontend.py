@@ -21,12 +21,12 @@ class NativeFrontEnd:
         """numpy view over a native pinned buffer, created once per (address) and sliced per step."""
         if not addr:
             return None
-        ent = self._views.get(name)
-        if ent is None or ent[0] != addr:
+        ent = self._views.get((name, addr))  # (the per-feature results alternate between two native buffers)
+        if ent is None:
             shape = (cap,) if row is None else (cap, row)
-            ent = (addr, _view(addr, dtype, cap, shape if row is not None else None))
-            self._views[name] = ent
-        return ent[1]
+            ent = _view(addr, dtype, cap, shape if row is not None else None)
+            self._views[(name, addr)] = ent
+        return ent
 
     def __init__(self, params, max_width, max_height, device=0):
         self.params = list(params); self.n_cams = len(self.params)
@@ -65,19 +65,32 @@ class NativeFrontEnd:
     def reset(self):
         check(_lib.lib().orbf_reset(self._h))
 
-    def step(self, images, queries=None, flags=0, copy=True, motion=None):
-        """images: [(ptr_or_array, width, height, stride, on_device)] or uint8 arrays.  `queries`: projected map points, or
-        `motion` = (du, dv, th): queries built natively from the previous step's features (synthetic-stream driver).
-        Returns a dict of numpy arrays (copies by default: the native buffers are reused by the next step)."""
+    @staticmethod
+    def _fill(dst, images):
         keep = []
         for c, im in enumerate(images):
             if isinstance(im, np.ndarray):
                 im = np.ascontiguousarray(im, np.uint8); keep.append(im)
-                self._imgs[c] = FImage(im.ctypes.data, im.shape[1], im.shape[0], im.strides[0], 0)
+                dst[c] = FImage(im.ctypes.data, im.shape[1], im.shape[0], im.strides[0], 0)
             elif im is None:
-                self._imgs[c] = FImage(None, 0, 0, 0, 0)
+                dst[c] = FImage(None, 0, 0, 0, 0)
             else:
-                self._imgs[c] = FImage(im[0], im[1], im[2], im[3], 1 if (len(im) < 5 or im[4]) else 0)
+                dst[c] = FImage(im[0], im[1], im[2], im[3], 1 if (len(im) < 5 or im[4]) else 0)
+        return keep
+
+    def prefetch(self, next_images):
+        """Declare the images of the step after the next one (orbf_prefetch): their extraction overlaps the next step's
+        matching.  The arrays / device buffers must stay alive and unchanged until the step that consumes them returns."""
+        if not hasattr(self, "_next_imgs"):
+            self._next_imgs = (FImage * self.n_cams)()
+        self._next_keep = self._fill(self._next_imgs, next_images)   # keeps host arrays alive across the two steps
+        check(_lib.lib().orbf_prefetch(self._h, self._next_imgs))
+
+    def step(self, images, queries=None, flags=0, copy=True, motion=None):
+        """images: [(ptr_or_array, width, height, stride, on_device)] or uint8 arrays.  `queries`: projected map points, or
+        `motion` = (du, dv, th): queries built natively from the previous step's features (synthetic-stream driver).
+        Returns a dict of numpy arrays (copies by default: the native buffers are reused by the next step)."""
+        keep = self._fill(self._imgs, images)
         if motion is not None:
             mo = FMotion(*motion)
             check(_lib.lib().orbf_step_motion(self._h, self._imgs, C.byref(mo), flags, C.byref(self._res)))

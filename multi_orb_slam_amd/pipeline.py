@@ -87,11 +87,17 @@ class FrontEnd:
         self.fe.reset()
 
     # images: list of HxW uint8 arrays, or list of (device_ptr, stride) for HBM-resident frames
-    def step(self, images, resident=False):
+    def step(self, images, resident=False, next_images=None):
+        """next_images: the images of the FOLLOWING step (same form as `images`): their extraction is overlapped with this
+        step's matching (orbf_prefetch); the following call must then pass exactly them."""
         from .frontend import SKIP_CROSS
         if resident:
             images = [(im[0], self.width, self.height, im[1], 1) for im in images]
+            if next_images is not None:
+                next_images = [(im[0], self.width, self.height, im[1], 1) for im in next_images]
         distributed = self.world > 1 and self.gather is not None
+        if next_images is not None and not distributed:  # (the exchange buffers of a multi-GPU step are not double-buffered)
+            self.fe.prefetch(next_images)
         # queries = the previous step's features under the stream's known motion, built natively (orbf_step_motion;
         # same arithmetic as make_queries, which the oracle leg uses)
         r = self.fe.step(images, None, SKIP_CROSS if distributed else 0, copy=self.copy_results,

@@ -31,6 +31,51 @@ def test_native_step_equals_oracle_pipeline(w, h, nfs):
     fe.close()
 
 
+@pytest.mark.parametrize("w,h,nfs,resident", [(320, 240, (300, 150), False), (640, 480, (1000, 1000), True)])
+def test_overlapped_steps_equal_oracle_pipeline(w, h, nfs, resident):
+    """orbf_prefetch: the next step's extraction runs next to this step's matching; results must not change."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline, rt
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    params = [m.ExtractorParams(nfeatures=n) for n in nfs]
+    fe = pipeline.FrontEnd(params, w, h)
+    ofe = OracleFrontEnd(params, w, h)
+    T = 6
+    frames = [[synth.image(c, t, w, h) for c in range(len(nfs))] for t in range(T)]
+    dev = []
+    if resident:
+        for imgs in frames:
+            row = []
+            for im in imgs:
+                b = rt.DeviceBuffer(im.nbytes); b.upload(im); row.append(b)
+            dev.append(row)
+    arg = (lambda t: [(b.ptr, w) for b in dev[t]]) if resident else (lambda t: frames[t])
+    for t in range(T):
+        nxt = arg(t + 1) if t + 1 < T and t != 3 else None     # step 4 is NOT prefetched: plain path in between
+        got = fe.step(arg(t), resident=resident, next_images=nxt)
+        assert_same_step(got, ofe.step(frames[t]))
+    assert got["n_temporal"] > 50
+    fe.close()
+
+
+def test_prefetch_of_other_images_is_dropped():
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    params = [m.ExtractorParams(nfeatures=300), m.ExtractorParams(nfeatures=150)]
+    fe = pipeline.FrontEnd(params, 320, 240)
+    ofe = OracleFrontEnd(params, 320, 240)
+    frames = [[synth.image(c, t, 320, 240) for c in range(2)] for t in range(4)]
+    assert_same_step(fe.step(frames[0], next_images=frames[3]), ofe.step(frames[0]))   # announces frame 3 ...
+    assert_same_step(fe.step(frames[1], next_images=frames[2]), ofe.step(frames[1]))   # ... but frame 1 comes
+    assert_same_step(fe.step(frames[2]), ofe.step(frames[2]))
+    fe.reset(); ofe = OracleFrontEnd(params, 320, 240)                                   # reset drops what is in flight
+    assert_same_step(fe.step(frames[3], next_images=frames[0]), ofe.step(frames[3]))
+    fe.reset(); ofe = OracleFrontEnd(params, 320, 240)
+    assert_same_step(fe.step(frames[1]), ofe.step(frames[1]))
+    fe.close()
+
+
 def test_native_step_with_host_resolve_keeps_cross_results(monkeypatch):
     """The exact host resolve (fallback of the device resolve) re-projects through the matcher's staging buffers; the
     camera-pair top-2 of the same step must survive that."""

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python -X faulthandler tools/step_breakdown.py > gpurun_out/dbg.txt 2>&1; grep -v "^  File\|^$" gpurun_out/dbg.txt | head -30 | cut -c1-300
-MORB_GRAPH_FORK=1 timeout 300 python -X faulthandler tools/step_breakdown.py > gpurun_out/dbg.txt 2>&1; grep -v "^  File\|^$" gpurun_out/dbg.txt | head -30 | cut -c1-300
-MORB_STEP_GRAPH=0 timeout 300 python -X faulthandler tools/step_breakdown.py > gpurun_out/dbg.txt 2>&1; grep -v "^  File\|^$" gpurun_out/dbg.txt | head -30 | cut -c1-300
+timeout 900 python -X faulthandler -m pytest tests -m gpu -q -x 2>&1 | tail -5
+timeout 300 python tools/step_breakdown.py 2>&1 | tail -1 | cut -c1-400
+MORB_CHAIN_GRAPH=0 timeout 300 python tools/step_breakdown.py 2>&1 | tail -1 | cut -c1-400
+timeout 300 python bench.py 2>&1 | tail -1 | cut -c1-300
