@@ -1831,6 +1831,7 @@ struct orbf_frontend {
     std::vector<orbf_image> next_images;  // declared by orbf_prefetch, consumed by the next step
     bool have_next = false;
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path
+    hipEvent_t ev_extracted = nullptr;  // extractor stream -> matcher stream on the synchronous path
     // previous step (for orbf_step_motion)
     int prev_n = 0;
     std::vector<int32_t> prev_cam_of;
@@ -1854,6 +1855,7 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     if ((rc = orbx_tables(&params[0], f->scale_factors.data(), nullptr, nullptr, nullptr, nullptr, nullptr))) { orbf_destroy(f); return rc; }
     for (int c = 0; c < n_cams; ++c) { f->cam_cap.push_back(params[c].nfeatures + 4 * params[c].nlevels); f->cap_total += f->cam_cap.back(); }
     const size_t cap = (size_t)f->cap_total;
+    if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
     for (int k = 0; k < 2 && !rc; ++k)
         if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
             (rc = f->rs[k].depth.reserve(cap))) break;
@@ -1873,6 +1875,7 @@ void orbf_destroy(orbf_frontend* f) {
     if (f->ex) orbx_destroy(f->ex);
     for (int k = 0; k < 2; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); }
     f->h_queries.release(); f->h_match.release();
+    if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
     delete f;
 }
 
@@ -2060,6 +2063,9 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         } else {
             rc = orbx_finish(f->ex);  // synchronises; counts are on the host from here on
             if (rc < 0) return rc;
+            // the host-quadtree path returns with its describe kernel still running on the extractor's stream
+            MORB_HIP(hipEventRecord(f->ev_extracted, st_e));
+            MORB_HIP(hipStreamWaitEvent(st, f->ev_extracted, 0));
             if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
             n = 0;
             for (int c = 0; c < f->n_cams; ++c) {

@@ -58,6 +58,30 @@ def test_overlapped_steps_equal_oracle_pipeline(w, h, nfs, resident):
     fe.close()
 
 
+def test_overlap_survives_the_host_quadtree_fallback():
+    """Noise frames put more than 4096 candidates on level 0: the device quadtree reports 'outside my limits' and the step
+    is redone on the host path -- with the next step's extraction already in flight its images have to be uploaded again."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    w, h = 640, 480
+    params = [m.ExtractorParams(nfeatures=500)] * 2
+
+    def noise(c, t):
+        r = synth.hash32(np.arange(w * h, dtype=np.uint64) + np.uint64(1000 * t + 17 * c))
+        return (r % 256).astype(np.uint8).reshape(h, w)
+
+    frames = [[noise(c, t) for c in range(2)] for t in range(2)] + [[synth.image(c, t, w, h) for c in range(2)] for t in range(2, 5)]
+    fe = pipeline.FrontEnd(params, w, h)
+    ofe = OracleFrontEnd(params, w, h)
+    for t in range(5):
+        got = fe.step(frames[t], next_images=frames[t + 1] if t + 1 < 5 else None)
+        assert_same_step(got, ofe.step(frames[t]))
+        if t == 0:
+            assert len(fe.ex.debug_candidates(0, 0)) > 4096      # the case this test is about
+    fe.close()
+
+
 def test_prefetch_of_other_images_is_dropped():
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import pipeline
