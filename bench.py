@@ -90,7 +90,8 @@ def main():
         torch.cuda.set_device(local)
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # (no device_id=: eager communicator init made every hipStreamSynchronize of this process ~100 us slower here)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
     import numpy as np
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import synth, pipeline, rt
@@ -102,9 +103,7 @@ def main():
     fe = pipeline.FrontEnd(params, W, H, device=local, rank=rank, world_size=world, global_cams=gcam)
     if use_dist:
         import torch
-        ex = DescriptorExchange(CAMS_PER_RANK, fe.cap, torch.device("cuda", local), dist)
-        ex.bind(fe.ex)
-        fe.gather = ex
+        fe.gather = DescriptorExchange(torch.device("cuda", local), dist)
         fe.world = max(world, 2) if world == 1 else world   # world 1 + forced exchange still takes the block path
 
     # ---- synthetic stream of this rank's rig, resident in HBM before timing
@@ -120,9 +119,9 @@ def main():
     def frame_args(t):
         return [(dev_frames[t % RING][c].ptr, W) for c in range(CAMS_PER_RANK)]
 
-    # Consecutive timesteps overlap: while step t is matched, the extraction of step t+1 already runs on the extractor's
-    # stream (the exchange buffers of the multi-GPU path are not double-buffered, so it is off there).
-    overlap = not use_dist and not a.no_overlap
+    # Consecutive timesteps overlap: while step t is matched (and, with N > 1, exchanged), the extraction of step t+1 already
+    # runs on the extractor's stream.
+    overlap = not a.no_overlap
 
     # ---- parity gate: four steps bit-exact vs the CPU oracle (single-rank view; N > 1 checks its own cameras)
     parity = "skipped"
@@ -140,7 +139,7 @@ def main():
         if dist is not None:
             import torch
             torch.cuda.synchronize()
-            dist.barrier()
+            dist.barrier(device_ids=[local])
 
     def run(nsteps, t0, overlap=overlap):
         # every step completes one timestep (extract + match); with `overlap` it also announces the next one's images, so K
@@ -149,6 +148,10 @@ def main():
             fe.step(frame_args(t0 + i), resident=True, next_images=frame_args(t0 + i + 1) if overlap else None)
 
     fe.copy_results = False          # timed loop: consume the results in place (views of the pinned buffers)
+    # The interpreter's cyclic collector would otherwise run inside the loop (every torch.distributed call allocates
+    # containers; one young-generation pass costs ~120 us with torch imported): park it for the timed region.
+    import gc
+    gc.collect(); gc.freeze(); gc.disable()
     run(a.warmup, 0)
     sync_all()
     t_start = time.perf_counter()
@@ -169,6 +172,7 @@ def main():
         serial_ms = 1e3 * (time.perf_counter() - t1) / 200
         fe.reset()
 
+    gc.enable(); gc.unfreeze()
     # per-stage GPU time of the extractor (HIP events) on one extra profiled step
     fe.ex.set_profiling(True)
     fe.step(frame_args(0), resident=True); fe.step(frame_args(1), resident=True)

@@ -60,6 +60,11 @@ int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientati
  * intervening step runs; device images must stay unchanged until the step that consumes them has returned.  Results are
  * bit-identical with and without prefetching; rigs of more than 4 cameras ignore the hint. */
 int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images);
+/* Multi-GPU exchange: the HBM block holding the LAST step's merged descriptors -- cap_rows rows of 32 bytes in global
+ * (camera-major, packed) order followed by a 256-byte trailer of int32 per-camera counts -- ready to be the send buffer
+ * of one all-gather (every rank has the same capacity, hence the same block size).  Valid until the step after the next
+ * one starts; orbm_cross_top2_gathered consumes the gathered blocks. */
+int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_bytes, int* cap_rows);
 /* queries: the projected last-frame map points (may be NULL / 0 on the first frame) */
 int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out);
 /* Synthetic-stream driver: like orbf_step, with the queries built natively from the PREVIOUS step's features moved by a

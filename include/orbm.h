@@ -128,6 +128,16 @@ int orbm_cross_top2(orbm_matcher* m, const orbm_frame* f, int32_t* best_idx, int
 int orbm_cross_top2_blocks(orbm_matcher* m, const uint8_t* const* d_desc_blocks, const int* counts, int n_blocks,
                            int first_query_block, int n_query_blocks, int32_t* best_idx, int32_t* best_dist,
                            int32_t* second_dist);
+
+/* Multi-GPU form of orbm_cross_top2_blocks: `d_gathered` is the result of ONE all-gather of every rank's export block
+ * (orbf_export_block: cap_rows descriptor rows, the rank's cameras packed back to back, followed by a trailer of int32
+ * per-camera counts), `world` blocks of `block_bytes` in rank order.  Queries = the features of rank `rank`, candidates =
+ * every other camera of the rig; indices as in orbm_cross_top2 (position in the concatenation of the other cameras, global
+ * camera order).  Nothing about the counts has to be known on the host beforehand: counts_out[world * cams_per_rank]
+ * (may be NULL) and *nq_out are filled from the gathered trailers; the result arrays need room for cap_rows entries. */
+int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int world, size_t block_bytes, int cap_rows,
+                             int cams_per_rank, int rank, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                             int32_t* counts_out, int* nq_out);
 void orbm_frame_destroy(orbm_frame* f);
 /* grid as CSR: cell = (cam*64 + ix)*48 + iy; cell_start has n_cams*3072+1 entries */
 int orbm_frame_grid(const orbm_frame* f, int32_t* cell_start, int32_t* items);

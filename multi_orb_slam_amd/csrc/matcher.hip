@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/orbm.h"
+#include <chrono>
 #include "orb_common.h"
 #include "frame_sink.h"
 
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_hamming_top2(const uint4* _
 
 __global__ void k_top2_merge(const int* __restrict__ p_idx, const int* __restrict__ p_best,
                              const int* __restrict__ p_second, int S, int nq, int* __restrict__ best_idx,
-                             int* __restrict__ best_dist, int* __restrict__ second_dist, const int* __restrict__ d_n = nullptr) {
-    if (d_n) nq = *d_n;  // partial arrays are laid out with stride nq: the producer used the same device count
+                             int* __restrict__ best_dist, int* __restrict__ second_dist, const int* __restrict__ d_range = nullptr) {
+    if (d_range) nq = d_range[2];  // partial arrays are laid out with stride nq: the producer used the same device count
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
     int B = 256, Sd = 256, I = -1;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
                                                             int* __restrict__ oct, float* __restrict__ ang,
                                                             orb_keypoint* __restrict__ kps_g, uint4* __restrict__ desc_g,
                                                             int* __restrict__ cell_start, int* __restrict__ items, HostMirror hm,
-                                                            const int* __restrict__ cell_of_in) {
+                                                            const int* __restrict__ cell_of_in, int desc_rows) {
     // cell_of_in != NULL: the per-feature arrays and the cells were already written by the extractor's describe kernel
     // (FrameSink); only the counts, the grid and its item lists are produced here.
     extern __shared__ __attribute__((aligned(16))) int s_cells[];  // [ncell + 1] start | [ncell + 1] cursor | u16 items[8192]
@@ -471,7 +472,11 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
         }
         cam_start_out[n_cams] = base;
         s_ntotal = d_counts ? base : n_total;
-        if (n_total_out) *n_total_out = s_ntotal;
+        if (n_total_out) { n_total_out[0] = s_ntotal; n_total_out[1] = 0; n_total_out[2] = s_ntotal; }  // {features, first query, queries}
+        if (desc_g) {  // trailer of the descriptor block: the per-camera counts (what a multi-GPU exchange ships with it)
+            int* tail = reinterpret_cast<int*>(desc_g + 2 * (size_t)desc_rows);
+            for (int c = 0; c < n_cams; ++c) tail[c] = s_cams[c].n;
+        }
     }
     __syncthreads();
     const CamFeat* cams = s_cams;
@@ -855,13 +860,50 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
 #endif
 }
 
+// Multi-GPU exchange: `gathered` holds one block per rank (rank order), each = cap_rows descriptor rows (the rank's
+// cameras packed back to back) + the count trailer.  The rows in use are copied into one contiguous list in global camera
+// order; block (0, 0) also writes the camera starts, the {features, first query, queries} triple of rank `rank`, and a
+// copy of all counts into mapped pinned memory.  Every block recomputes the few prefix sums it needs from the trailers.
+__global__ __launch_bounds__(256) void k_repack_gathered(const uint8_t* __restrict__ gathered, int world, size_t block_bytes,
+                                                         int cap_rows, int cams_per_rank, int rank, uint4* __restrict__ dst,
+                                                         int* __restrict__ cam_start, int* __restrict__ range,
+                                                         int* __restrict__ h_counts) {
+    const int r = blockIdx.y;
+    int goff = 0, n_r = 0, own_off = 0, own_n = 0, total = 0;
+    for (int rr = 0; rr < world; ++rr) {
+        const int* tail = reinterpret_cast<const int*>(gathered + (size_t)rr * block_bytes + (size_t)cap_rows * 32);
+        int nr = 0;
+        for (int c = 0; c < cams_per_rank; ++c) nr += tail[c];
+        if (rr == r) { goff = total; n_r = nr; }
+        if (rr == rank) { own_off = total; own_n = nr; }
+        total += nr;
+    }
+    if (blockIdx.x == 0 && r == 0 && threadIdx.x == 0) {
+        int run = 0;
+        for (int rr = 0; rr < world; ++rr) {
+            const int* tail = reinterpret_cast<const int*>(gathered + (size_t)rr * block_bytes + (size_t)cap_rows * 32);
+            for (int c = 0; c < cams_per_rank; ++c) {
+                cam_start[rr * cams_per_rank + c] = run;
+                h_counts[rr * cams_per_rank + c] = tail[c];
+                run += tail[c];
+            }
+        }
+        cam_start[world * cams_per_rank] = run;
+        range[0] = total; range[1] = own_off; range[2] = own_n;
+        h_counts[world * cams_per_rank] = own_n;
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(gathered + (size_t)r * block_bytes);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * n_r; i += gridDim.x * 256) dst[2 * (size_t)goff + i] = src[i];
+}
+
 // Queries are features [q_off, q_off + nq) (the cameras this process owns); outputs are indexed from 0.
 __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __restrict__ desc, int n_total,
                                                                 const int* __restrict__ cam_start, int n_cams, int q_off,
                                                                 int nq, int* __restrict__ best_idx,
                                                                 int* __restrict__ best_dist, int* __restrict__ second_dist,
-                                                                const int* __restrict__ d_n) {
-    if (d_n) { n_total = *d_n; nq = n_total; }  // counts only known on the device: the launch was sized for the capacity
+                                                                const int* __restrict__ d_range) {
+    // counts only known on the device ({features, first query, queries}): the launch was sized for the capacity
+    if (d_range) { n_total = d_range[0]; q_off = d_range[1]; nq = d_range[2]; }
     if (blockIdx.x * 64 >= nq) return;
     __shared__ int sb[TOP2_WAVES][64], ss[TOP2_WAVES][64], si[TOP2_WAVES][64];
     const int lane = threadIdx.x & 63;
@@ -954,6 +996,8 @@ int launch_matrix(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16
 }  // namespace
 
 // ================================================================================================ C ABI
+constexpr size_t ORBM_BLOCK_TRAILER = 256;  // bytes behind the descriptor rows of a frame: int32 per-camera counts
+
 struct FrameBufs {  // device storage of one frame; recycled through the matcher's pool (no hipMalloc per frame)
     DevBuf<float> d_x, d_y, d_ur, d_depth, d_ang;
     DevBuf<int32_t> d_oct, d_cell_start, d_items, d_cell_of, d_cursor, d_cam_start, d_ntotal;
@@ -974,6 +1018,7 @@ struct orbm_matcher {
     DevBuf<int32_t> d_i0, d_i1, d_i2, d_choice, d_claim, d_match, d_status, d_x0, d_x1, d_x2;
     DevBuf<uint16_t> d_u16;
     PinnedBuf<int32_t> h_i0, h_i1, h_i2, h_match;
+    PinnedBuf<int32_t> h_gcnt;            // per-camera counts of a gathered multi-GPU exchange (+ own query count)
     PinnedBuf<int32_t> h_c0, h_c1, h_c2;  // cross top-2 results (own buffers: they coexist with a search's h_i0/h_i1)
     DevBuf<uint8_t> d_cscratch;           // cross top-2 slice partials
     hipStream_t side_stream = nullptr;    // orbf_step: cross top-2 runs here, next to project + resolve on `stream`
@@ -984,6 +1029,7 @@ struct orbm_matcher {
     std::vector<FrameBufs*> pool;  // free list
     // device-visible pinned destinations the next orbm_frame_from_device mirrors its merged arrays into (orbf_step)
     orb_keypoint* mirror_kps = nullptr; uint8_t* mirror_desc = nullptr; float* mirror_ur = nullptr; float* mirror_depth = nullptr;
+    int frame_min_rows = 0;  // the next device-built frame gets at least this many descriptor rows (fixed export block size)
     int last_status[4] = {0, 0, 0, 0};  // {status, nmatches, sweeps, longest list} of the last device resolve
     bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
 };
@@ -995,6 +1041,7 @@ struct orbm_frame {
     float minX = 0, minY = 0, maxX = 0, maxY = 0, invW = 0, invH = 0;
     bool device_built = false;
     bool counts_on_device = false;  // n_total is a capacity until orbf_step has synchronised
+    int desc_rows = 0;              // descriptor rows the frame was created for (the count trailer sits behind them)
     // host copies used by the host resolve / orbm_frame_grid; filled at create for host-built frames, lazily otherwise
     mutable std::vector<int32_t> octave, cell_start, items;
     mutable std::vector<float> angle;
@@ -1019,7 +1066,7 @@ static int reserve_frame(FrameBufs* b, int n, int n_cams) {
     const int ncell = n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
     int rc;
     if ((rc = b->d_x.reserve(nn)) || (rc = b->d_y.reserve(nn)) || (rc = b->d_ur.reserve(nn)) || (rc = b->d_depth.reserve(nn)) ||
-        (rc = b->d_ang.reserve(nn)) || (rc = b->d_oct.reserve(nn)) || (rc = b->d_desc.reserve(nn * 32)) ||
+        (rc = b->d_ang.reserve(nn)) || (rc = b->d_oct.reserve(nn)) || (rc = b->d_desc.reserve(nn * 32 + ORBM_BLOCK_TRAILER)) ||
         (rc = b->d_kps.reserve(nn)) || (rc = b->d_cell_start.reserve(ncell + 1)) || (rc = b->d_items.reserve(nn)) ||
         (rc = b->d_cell_of.reserve(nn)) || (rc = b->d_cursor.reserve(ncell + 1)) || (rc = b->d_cam_start.reserve(n_cams + 1)) ||
         (rc = b->d_ntotal.reserve(4)) ||
@@ -1079,7 +1126,7 @@ void orbm_destroy(orbm_matcher* m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->ev_q) (void)hipEventDestroy(m->ev_q);
-    m->h_c0.release(); m->h_c1.release(); m->h_c2.release(); m->d_cscratch.release();
+    m->h_c0.release(); m->h_c1.release(); m->h_c2.release(); m->d_cscratch.release(); m->h_gcnt.release();
     m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release(); m->d_occ.release();
     m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release();
     m->d_match.release(); m->d_status.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
@@ -1306,8 +1353,9 @@ static int frame_shell(orbm_matcher* m, int n, int n_cams, float min_x, float mi
     F->invW = (float)ORBM_GRID_COLS / (max_x - min_x);
     F->invH = (float)ORBM_GRID_ROWS / (max_y - min_y);
     F->cam_start.assign(n_cams + 1, 0);
+    F->desc_rows = std::max(std::max(n, 1), m->frame_min_rows);
     F->b = take_bufs(m);
-    int rc = reserve_frame(F->b, n, n_cams);
+    int rc = reserve_frame(F->b, F->desc_rows, n_cams);
     if (rc) { orbm_frame_destroy(F); return rc; }
     *out = F;
     return ORB_OK;
@@ -1365,7 +1413,7 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
         return rc;
     }
     rc = ORB_OK;
-    const size_t slot = 64 * sizeof(CamFeat) + 65 * sizeof(int);
+    const size_t slot = 64 * sizeof(CamFeat) + 65 * sizeof(int) + 64 * sizeof(int);
     if (!rc) rc = m->h_ring.reserve(slot * 4);  // ring of 4 parameter blocks: the H2D copies below are asynchronous
     if (rc) { orbm_frame_destroy(F); return rc; }
     uint8_t* hs = m->h_ring.p + (size_t)(m->ring_pos++ & 3) * slot;
@@ -1406,8 +1454,12 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
                            n_cams, n, mbf,
                            F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
                            F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_start.p,
-                           F->b->d_items.p, hm, sink_filled ? (const int*)F->b->d_cell_of.p : nullptr);
+                           F->b->d_items.p, hm, sink_filled ? (const int*)F->b->d_cell_of.p : nullptr, F->desc_rows);
     } else {
+        // count trailer of the descriptor block (the single-workgroup build writes it itself)
+        int* hcnt = reinterpret_cast<int*>(hs + 64 * sizeof(CamFeat) + 65 * sizeof(int));
+        for (int c = 0; c < n_cams; ++c) hcnt[c] = cams[c].n;
+        MORB_HIP(hipMemcpyAsync(F->b->d_desc.p + (size_t)F->desc_rows * 32, hcnt, (size_t)n_cams * sizeof(int), hipMemcpyHostToDevice, st));
         MORB_HIP(hipMemsetAsync(F->b->d_cursor.p, 0, (size_t)(ncell + 1) * 4, st));  // used as the per-cell counter first
         if (n) {
             hipLaunchKernelGGL(k_frame_fill, dim3((n + 255) / 256), dim3(256), 0, st, (const CamFeat*)F->b->d_cams.p, n_cams, n, mbf,
@@ -1800,6 +1852,38 @@ int orbm_cross_top2_blocks(orbm_matcher* m, const uint8_t* const* d_desc_blocks,
     return cross_launch(m, m->d_r.p, n, m->d_choice.p, n_blocks, q_off, nq, best_idx, best_dist, second_dist);
 }
 
+int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int world, size_t block_bytes, int cap_rows,
+                             int cams_per_rank, int rank, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                             int32_t* counts_out, int* nq_out) {
+    MORB_ARG(m && d_gathered && world >= 1 && cams_per_rank >= 1 && world * cams_per_rank <= 512 && rank >= 0 && rank < world &&
+             cap_rows >= 1 && block_bytes >= (size_t)cap_rows * 32 + (size_t)cams_per_rank * 4 && (block_bytes & 15) == 0 && nq_out);
+    MORB_ARG(((uintptr_t)d_gathered & 15) == 0);
+    MORB_HIP(hipSetDevice(m->device));
+    const int n_cams = world * cams_per_rank;
+    const int n_cap = world * cap_rows;  // capacity of the contiguous list
+    int rc;
+    if ((rc = m->d_r.reserve((size_t)n_cap * 32)) || (rc = m->d_choice.reserve(n_cams + 1 + 4)) || (rc = m->h_gcnt.reserve(n_cams + 1)))
+        return rc;
+    int* d_cam_start = m->d_choice.p;
+    int* d_range = m->d_choice.p + n_cams + 1;
+    hipStream_t st = m->stream;
+    hipLaunchKernelGGL(k_repack_gathered, dim3((2 * cap_rows + 255) / 256, world), dim3(256), 0, st, d_gathered, world, block_bytes, cap_rows,
+                       cams_per_rank, rank, (uint4*)m->d_r.p, d_cam_start, d_range, m->h_gcnt.dp);
+    MORB_HIP(hipGetLastError());
+    // the launch is sized for the capacity (cap_rows queries against world * cap_rows features); the counts come from HBM
+    if ((rc = cross_enqueue(m, st, m->d_r.p, n_cap, d_cam_start, n_cams, 0, cap_rows, d_range))) return rc;
+    MORB_HIP(hipStreamSynchronize(st));
+    const int nq = m->h_gcnt.p[n_cams];
+    *nq_out = nq;
+    if (counts_out) memcpy(counts_out, m->h_gcnt.p, (size_t)n_cams * 4);
+    if (nq) {
+        MORB_ARG(best_idx && best_dist && second_dist);
+        memcpy(best_idx, m->h_c0.p, (size_t)nq * 4); memcpy(best_dist, m->h_c1.p, (size_t)nq * 4);
+        memcpy(second_dist, m->h_c2.p, (size_t)nq * 4);
+    }
+    return ORB_OK;
+}
+
 
 // ================================================================================================ orbf (include/orbf.h)
 }  // extern "C"
@@ -1832,6 +1916,8 @@ struct orbf_frontend {
     bool have_next = false;
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path
     hipEvent_t ev_extracted = nullptr;  // extractor stream -> matcher stream on the synchronous path
+    // frame of the last completed step (orbf_export_block); a frame built on the synchronous path is kept until the next step
+    orbm_frame* last_frame = nullptr; bool last_frame_owned = false;
     // previous step (for orbf_step_motion)
     int prev_n = 0;
     std::vector<int32_t> prev_cam_of;
@@ -1870,6 +1956,7 @@ void orbf_destroy(orbf_frontend* f) {
     (void)hipSetDevice(f->device);
     if (f->ex) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->ex));
     if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
+    if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
     for (int k = 0; k < 2; ++k) if (f->pframe[k]) orbm_frame_destroy(f->pframe[k]);  // back to the matcher's pool first
     if (f->mt) orbm_destroy(f->mt);
     if (f->ex) orbx_destroy(f->ex);
@@ -1909,6 +1996,15 @@ int orbf_reset(orbf_frontend* f) {
     MORB_ARG(f != nullptr);
     f->prev_n = 0; f->have_next = false; f->overlap_ok = true;
     return orbf_drain(f);
+}
+
+int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_bytes, int* cap_rows) {
+    MORB_ARG(f && d_block && block_bytes && cap_rows);
+    if (!f->last_frame) { morb::set_error("no completed step to export"); return ORB_E_ARG; }
+    *d_block = f->last_frame->b->d_desc.p;
+    *cap_rows = f->last_frame->desc_rows;
+    *block_bytes = (size_t)f->last_frame->desc_rows * 32 + ORBM_BLOCK_TRAILER;
+    return ORB_OK;
 }
 
 int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images) {
@@ -2018,6 +2114,8 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     hipStream_t st_e = (hipStream_t)orbx_stream(f->ex);           // extraction
     int rc, W = 0, H = 0, went_async = 0;
     const bool small = small_rig(f);
+    if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
+    f->last_frame = nullptr; f->last_frame_owned = false;
 
     // ---- this step's extraction: already in flight (orbf_prefetch during the previous step) or enqueued now
     int set;
@@ -2077,7 +2175,9 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
             // the frame-build kernel mirrors the stereo arrays straight into this step's pinned result set (keypoints and
             // descriptors were mirrored by the extractor's describe kernel)
             m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp;
+            m->frame_min_rows = f->cap_total;  // every step's export block has the same size
             rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, nullptr, &fr);
+            m->frame_min_rows = 0;
             m->mirror_ur = nullptr; m->mirror_depth = nullptr;
             if (rc) return rc;
             fr_persistent = false;
@@ -2152,8 +2252,8 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     f->have_next = false;
     do_cross = do_cross && n > 0;
     rc = search_finish(m, J, f->h_match.p, &nmatches);
-    if (!fr_persistent) orbm_frame_destroy(fr);  // stream is idle: the buffers go straight back to the pool
-    if (rc) return rc;
+    if (rc) { if (!fr_persistent) orbm_frame_destroy(fr); return rc; }
+    f->last_frame = fr; f->last_frame_owned = !fr_persistent;  // (returned to the pool when the next step starts)
     f->cur = set;
     f->prev_n = n;
     f->prev_cam_of.resize(n);

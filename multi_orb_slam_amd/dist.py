@@ -3,45 +3,46 @@
 The reference has no distributed path (single process, two cameras extracted back to back, src/Frame.cc:182-185).
 Camera streams are independent until cross-camera matching, so the path shards by camera with no data-path
 collective except one all-gather of the fixed-capacity descriptor blocks (RCCL over xGMI when the backend is
-"nccl"; gloo on CPU for the world_size-2 tests).  The extractor writes its descriptors straight into the
-all-gather send buffer (orbx_bind_output), so there is no staging copy.
+"nccl"; gloo on CPU for the world_size-2 tests).  The send buffer IS the front end's frame (its describe kernel wrote
+the descriptors there), so there is no staging copy and the next timestep's extraction may already be running.
 """
 import numpy as np
 
 
+class _DeviceBlock:
+    """Zero-copy view of a native HBM block for torch (the __cuda_array_interface__ protocol)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
 class DescriptorExchange:
-    """All-gather of [n_cams, cap, 32] descriptor blocks + counts over torch.distributed."""
+    """ONE all-gather per timestep over torch.distributed: every rank ships its front end's export block (the merged
+    descriptors of its cameras + the per-camera counts in a trailer, orbf_export_block) and matches its own features against
+    the gathered blocks of the whole rig (orbm_cross_top2_gathered).  Nothing is staged and no count is exchanged separately."""
 
-    def __init__(self, n_cams, cap, device, dist):
+    def __init__(self, device, dist):
         import torch
-        self.torch, self.dist = torch, dist
-        self.n_cams, self.cap = n_cams, cap
+        self.torch, self.dist, self.device = torch, dist, device
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        self.send_desc = torch.zeros((n_cams, cap, 32), dtype=torch.uint8, device=device)
-        self.send_kps = torch.zeros((n_cams, cap, 28), dtype=torch.uint8, device=device)
-        self.recv_desc = torch.zeros((self.world * n_cams, cap, 32), dtype=torch.uint8, device=device)
-        self.send_cnt = torch.zeros(n_cams, dtype=torch.int32, device=device)
-        self.recv_cnt = torch.zeros(self.world * n_cams, dtype=torch.int32, device=device)
+        self.recv = None
+        self._send = {}
 
-    def bind(self, extractor):
-        for c in range(self.n_cams):
-            extractor.bind_output(c, self.send_kps[c].data_ptr(), self.send_desc[c].data_ptr(), self.cap)
-
-    def __call__(self, frontend, counts):
-        """-> (device pointers, counts) of every camera's descriptor block of the whole rig, global camera order."""
+    def __call__(self, frontend):
+        """frontend: pipeline.FrontEnd after a step -> (best_idx, best_dist, second_dist, counts of all cameras)."""
         torch, dist = self.torch, self.dist
-        self.send_cnt.copy_(torch.tensor(counts, dtype=torch.int32))
-        if self.send_desc.is_cuda:
-            # descriptors were produced on the extractor's stream: make sure they have landed before RCCL reads them
-            from . import rt
-            rt.stream_sync(frontend.stream)
-        dist.all_gather_into_tensor(self.recv_desc, self.send_desc)
-        dist.all_gather_into_tensor(self.recv_cnt, self.send_cnt)
-        if self.send_desc.is_cuda:
-            torch.cuda.current_stream().synchronize()
-        cnt = self.recv_cnt.cpu().numpy().tolist()
-        ptrs = [self.recv_desc[g].data_ptr() for g in range(self.world * self.n_cams)]
-        return ptrs, cnt
+        ptr, nbytes, rows = frontend.fe.export_block()
+        send = self._send.get(ptr)
+        if send is None:      # two blocks alternate (the front end's double-buffered frames): wrapped once each
+            send = self._send[ptr] = torch.as_tensor(_DeviceBlock(ptr, nbytes), device=self.device)
+        if self.recv is None or self.recv.numel() != self.world * nbytes:
+            self.recv = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.device)
+            self.recv_ptr = self.recv.data_ptr()
+        # the block was complete before the step returned (the matcher waited on the extractor's event), so RCCL may read
+        # it on torch's stream right away; the matcher's kernels then wait for the collective on the host
+        dist.all_gather_into_tensor(self.recv, send)
+        torch.cuda.current_stream().synchronize()
+        return frontend.mt.cross_top2_gathered(self.recv_ptr, self.world, nbytes, rows, frontend.n_cams, self.rank)
 
 
 def shard_cameras(n_cameras, world_size, rank):

@@ -78,6 +78,12 @@ class NativeFrontEnd:
                 dst[c] = FImage(im[0], im[1], im[2], im[3], 1 if (len(im) < 5 or im[4]) else 0)
         return keep
 
+    def export_block(self):
+        """(device pointer, bytes, rows) of the last step's descriptor block + count trailer (orbf_export_block)."""
+        p = C.c_void_p(); nb = C.c_size_t(); rows = C.c_int()
+        check(_lib.lib().orbf_export_block(self._h, C.byref(p), C.byref(nb), C.byref(rows)))
+        return p.value, nb.value, rows.value
+
     def prefetch(self, next_images):
         """Declare the images of the step after the next one (orbf_prefetch): their extraction overlaps the next step's
         matching.  The arrays / device buffers must stay alive and unchanged until the step that consumes them returns."""

@@ -172,6 +172,15 @@ class Matcher:
                                                 ptr(sd)))
         return bi[:nq], bd[:nq], sd[:nq]
 
+    def cross_top2_gathered(self, gathered_ptr, world, block_bytes, cap_rows, cams_per_rank, rank):
+        """Cross-camera top-2 of this rank's features against the whole rig from ONE all-gathered buffer
+        (orbm_cross_top2_gathered).  -> (best_idx, best_dist, second_dist, counts of every camera of the rig)."""
+        bi = np.zeros(cap_rows, np.int32); bd = np.zeros(cap_rows, np.int32); sd = np.zeros(cap_rows, np.int32)
+        cnt = np.zeros(world * cams_per_rank, np.int32); nq = C.c_int()
+        check(_lib.lib().orbm_cross_top2_gathered(self._h, C.c_void_p(gathered_ptr), world, block_bytes, cap_rows, cams_per_rank, rank,
+                                                  ptr(bi), ptr(bd), ptr(sd), ptr(cnt), C.byref(nq)))
+        return bi[:nq.value], bd[:nq.value], sd[:nq.value], cnt.tolist()
+
     def cross_top2(self, frame):
         n = max(frame.data.n_total, 1)
         bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32); sd = np.zeros(n, np.int32)

@@ -96,7 +96,7 @@ class FrontEnd:
             if next_images is not None:
                 next_images = [(im[0], self.width, self.height, im[1], 1) for im in next_images]
         distributed = self.world > 1 and self.gather is not None
-        if next_images is not None and not distributed:  # (the exchange buffers of a multi-GPU step are not double-buffered)
+        if next_images is not None:
             self.fe.prefetch(next_images)
         # queries = the previous step's features under the stream's known motion, built natively (orbf_step_motion;
         # same arithmetic as make_queries, which the oracle leg uses)
@@ -104,9 +104,9 @@ class FrontEnd:
                          motion=(MOTION[0], MOTION[1], TH_PROJ))
         counts = r["counts"]
         if distributed:
-            ptrs, cnts = self.gather(self, counts)
+            bi, bd, sd, cnts = self.gather(self)
             assert cnts[self.rank * self.n_cams:(self.rank + 1) * self.n_cams] == counts
-            r["cross"] = self.mt.cross_top2_blocks(ptrs, cnts, self.rank * self.n_cams, self.n_cams)
+            r["cross"] = (bi, bd, sd)
         bi, bd, sd = r["cross"]
         r["n_cross"] = int(accept_cross(bd, sd).sum())
         return r

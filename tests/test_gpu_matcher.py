@@ -244,3 +244,45 @@ def test_projection_search_large_frame_uses_big_lds_claim_table(matcher):
     on, omo = oracle.search_by_projection_frames(OF, q, 100, True)
     assert n == on and np.array_equal(mo, omo) and n > 5000
     F.close()
+
+
+@pytest.mark.parametrize("world,cams_per_rank", [(1, 2), (3, 2), (4, 1)])
+def test_cross_top2_from_a_gathered_buffer(world, cams_per_rank):
+    """orbm_cross_top2_gathered: what every rank does after the one all-gather of a timestep.  The gathered buffer is
+    built by hand here: per rank cap_rows descriptor rows (its cameras packed back to back, unused rows = garbage) and
+    the count trailer.  Every rank's answer must equal brute force against the other cameras in global order."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import rt
+    cap_rows = 700
+    block_bytes = cap_rows * 32 + 256
+    n_cams = world * cams_per_rank
+    counts = [(150 + 37 * g) % 301 + (0 if g != 1 else -((150 + 37) % 301)) for g in range(n_cams)]   # camera 1 is empty
+    base = synth.descriptors(400, 21)
+    descs = []
+    for g in range(n_cams):
+        d = synth.perturbed_queries(base, seed=50 + g, flip_p=0.05)[:counts[g]] if counts[g] else np.zeros((0, 32), np.uint8)
+        descs.append(np.ascontiguousarray(d))
+    buf = np.frombuffer(synth.descriptors((world * block_bytes + 31) // 32, 77).tobytes()[:world * block_bytes], np.uint8).copy()
+    for r in range(world):
+        blk = buf[r * block_bytes:(r + 1) * block_bytes]
+        packed = np.concatenate([descs[r * cams_per_rank + c] for c in range(cams_per_rank)])
+        assert len(packed) <= cap_rows
+        blk[:packed.size] = packed.reshape(-1)
+        blk[cap_rows * 32:cap_rows * 32 + 4 * cams_per_rank] = np.array(
+            [counts[r * cams_per_rank + c] for c in range(cams_per_rank)], np.int32).view(np.uint8)
+    dev = rt.DeviceBuffer(buf.nbytes); dev.upload(buf)
+    matcher = m.Matcher()
+    for rank in range(world):
+        bi, bd, sd, cnt = matcher.cross_top2_gathered(dev.ptr, world, block_bytes, cap_rows, cams_per_rank, rank)
+        assert cnt == counts
+        off = 0
+        for c in range(cams_per_rank):
+            g = rank * cams_per_rank + c
+            others = [descs[o] for o in range(n_cams) if o != g]
+            refs = np.concatenate(others) if others else np.zeros((0, 32), np.uint8)
+            ebi, ebd, esd = oracle.bf_top2(descs[g], refs)
+            nc = counts[g]
+            assert np.array_equal(bi[off:off + nc], ebi) and np.array_equal(bd[off:off + nc], ebd) and np.array_equal(sd[off:off + nc], esd)
+            off += nc
+        assert off == len(bi)
+    matcher.close()
