@@ -51,18 +51,41 @@ def shard_cameras(n_cameras, world_size, rank):
     return list(range(rank * per, min(n_cameras, (rank + 1) * per)))
 
 
-def gather_numpy(dist, per_cam, cap):
-    """CPU/gloo mirror of DescriptorExchange used by the world_size-2 tests: returns {global_cam: descriptors}."""
+BLOCK_TRAILER = 256  # bytes behind the descriptor rows of an export block: int32 per-camera counts (orbf_export_block)
+
+
+def pack_export_block(per_cam_desc, cap_rows):
+    """numpy restatement of the block orbf_export_block hands out: the rank's cameras packed back to back in cap_rows rows of
+    32 bytes (unused rows left as they are), then the count trailer."""
+    blk = np.full(cap_rows * 32 + BLOCK_TRAILER, 0xA5, np.uint8)  # unused rows / trailer bytes: arbitrary content
+    packed = np.concatenate([np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in per_cam_desc]) if per_cam_desc else np.zeros((0, 32), np.uint8)
+    assert len(packed) <= cap_rows
+    blk[:packed.size] = packed.reshape(-1)
+    blk[cap_rows * 32:cap_rows * 32 + 4 * len(per_cam_desc)] = np.array([len(d) for d in per_cam_desc], np.int32).view(np.uint8)
+    return blk
+
+
+def unpack_gathered(gathered, world, cap_rows, cams_per_rank):
+    """numpy restatement of what k_repack_gathered reads out of the all-gathered blocks: {global camera: descriptors}."""
+    block_bytes = cap_rows * 32 + BLOCK_TRAILER
+    out = {}
+    for r in range(world):
+        blk = gathered[r * block_bytes:(r + 1) * block_bytes]
+        counts = blk[cap_rows * 32:cap_rows * 32 + 4 * cams_per_rank].view(np.int32)
+        rows = blk[:cap_rows * 32].reshape(cap_rows, 32)
+        off = 0
+        for c in range(cams_per_rank):
+            out[r * cams_per_rank + c] = rows[off:off + int(counts[c])].copy()
+            off += int(counts[c])
+    return out
+
+
+def gather_numpy(dist, per_cam, cap_rows):
+    """CPU/gloo mirror of DescriptorExchange used by the world_size-2 tests: the same wire format (one export block per
+    rank, one all-gather), packed and unpacked by the numpy restatements above.  Returns {global_cam: descriptors}."""
     import torch
-    world, rank = dist.get_world_size(), dist.get_rank()
-    n_cams = len(per_cam)
-    send = torch.zeros((n_cams, cap, 32), dtype=torch.uint8)
-    cnt = torch.zeros(n_cams, dtype=torch.int32)
-    for c, (k, d) in enumerate(per_cam):
-        send[c, :len(d)] = torch.from_numpy(np.ascontiguousarray(d))
-        cnt[c] = len(d)
-    recv = torch.zeros((world * n_cams, cap, 32), dtype=torch.uint8)
-    rcnt = torch.zeros(world * n_cams, dtype=torch.int32)
+    world = dist.get_world_size()
+    send = torch.from_numpy(pack_export_block([d for (_k, d) in per_cam], cap_rows))
+    recv = torch.zeros(world * send.numel(), dtype=torch.uint8)
     dist.all_gather_into_tensor(recv, send)
-    dist.all_gather_into_tensor(rcnt, cnt)
-    return {g: recv[g, :int(rcnt[g])].numpy() for g in range(world * n_cams)}
+    return unpack_gathered(recv.numpy(), world, cap_rows, len(per_cam))

@@ -262,14 +262,11 @@ def test_cross_top2_from_a_gathered_buffer(world, cams_per_rank):
     for g in range(n_cams):
         d = synth.perturbed_queries(base, seed=50 + g, flip_p=0.05)[:counts[g]] if counts[g] else np.zeros((0, 32), np.uint8)
         descs.append(np.ascontiguousarray(d))
-    buf = np.frombuffer(synth.descriptors((world * block_bytes + 31) // 32, 77).tobytes()[:world * block_bytes], np.uint8).copy()
-    for r in range(world):
-        blk = buf[r * block_bytes:(r + 1) * block_bytes]
-        packed = np.concatenate([descs[r * cams_per_rank + c] for c in range(cams_per_rank)])
-        assert len(packed) <= cap_rows
-        blk[:packed.size] = packed.reshape(-1)
-        blk[cap_rows * 32:cap_rows * 32 + 4 * cams_per_rank] = np.array(
-            [counts[r * cams_per_rank + c] for c in range(cams_per_rank)], np.int32).view(np.uint8)
+    from multi_orb_slam_amd.dist import pack_export_block, unpack_gathered, BLOCK_TRAILER
+    assert block_bytes == cap_rows * 32 + BLOCK_TRAILER
+    buf = np.concatenate([pack_export_block([descs[r * cams_per_rank + c] for c in range(cams_per_rank)], cap_rows) for r in range(world)])
+    back = unpack_gathered(buf, world, cap_rows, cams_per_rank)          # the numpy restatement the gloo test relies on
+    assert all(np.array_equal(back[g], descs[g]) for g in range(n_cams))
     dev = rt.DeviceBuffer(buf.nbytes); dev.upload(buf)
     matcher = m.Matcher()
     for rank in range(world):

@@ -18,10 +18,10 @@ def _worker(rank, world, port, ret):
     import oracle
     from multi_orb_slam_amd import synth
     from multi_orb_slam_amd.dist import shard_cameras, gather_numpy
-    n_cameras, cap = 4, 700
+    n_cameras, cap = 4, 1500                 # rows per rank block (both cameras of a rank share it)
     mine = shard_cameras(n_cameras, world, rank)
     assert mine == [2 * rank, 2 * rank + 1]
-    # ragged per-camera descriptor sets (camera g has 300 + 100*g descriptors)
+    # ragged per-camera descriptor sets (camera g has 300 + 100*g descriptors; the ranks' blocks are unevenly filled)
     per_cam = [(np.zeros(300 + 100 * g, oracle.KP_DTYPE), synth.descriptors(300 + 100 * g, 1000 + g)) for g in mine]
     everyone = gather_numpy(dist, per_cam, cap)
     assert sorted(everyone) == [0, 1, 2, 3]
