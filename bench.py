@@ -128,10 +128,12 @@ def main():
     if world == 1:
         from oracle_pipeline import OracleFrontEnd, assert_same_step
         ofe = OracleFrontEnd(params, W, H, gcam)
-        for t in range(4):   # same call pattern as the timed loop: the next step's images are announced (orbf_prefetch)
-            got = fe.step(frame_args(t), resident=True, next_images=frame_args(t + 1) if overlap else None)
+        if overlap:
+            fe.announce(frame_args(1), resident=True)
+        for t in range(5):   # same call pattern as the timed loop: two future steps are announced (orbf_prefetch)
+            got = fe.step(frame_args(t), resident=True, next_images=frame_args(t + 2) if overlap else None)
             assert_same_step(got, ofe.step(host_frames[t % RING]))
-        parity = "bit-exact vs oracle on 4 steps (keypoints, descriptors, temporal + cross-camera matches)"
+        parity = "bit-exact vs oracle on 5 steps (keypoints, descriptors, temporal + cross-camera matches)"
         fe.reset()
 
     def sync_all():
@@ -141,11 +143,17 @@ def main():
             torch.cuda.synchronize()
             dist.barrier(device_ids=[local])
 
+    ahead = [0]   # index of the youngest timestep announced so far
+
     def run(nsteps, t0, overlap=overlap):
-        # every step completes one timestep (extract + match); with `overlap` it also announces the next one's images, so K
-        # steps enqueue K extractions and complete K matchings either way
+        # every step completes one timestep (extract + match); with `overlap` the images of the two steps after it are known
+        # to the front end (one new announcement per step), so K steps enqueue K extractions and complete K matchings
+        if overlap and ahead[0] < t0 + 1:
+            fe.announce(frame_args(t0 + 1), resident=True); ahead[0] = t0 + 1
         for i in range(nsteps):
-            fe.step(frame_args(t0 + i), resident=True, next_images=frame_args(t0 + i + 1) if overlap else None)
+            if overlap:
+                ahead[0] = t0 + i + 2
+            fe.step(frame_args(t0 + i), resident=True, next_images=frame_args(t0 + i + 2) if overlap else None)
 
     fe.copy_results = False          # timed loop: consume the results in place (views of the pinned buffers)
     # The interpreter's cyclic collector would otherwise run inside the loop (every torch.distributed call allocates
@@ -170,7 +178,7 @@ def main():
         fe.reset(); run(20, 0, False); sync_all()
         t1 = time.perf_counter(); run(200, 20, False); sync_all()
         serial_ms = 1e3 * (time.perf_counter() - t1) / 200
-        fe.reset()
+        fe.reset(); ahead[0] = 0
 
     gc.enable(); gc.unfreeze()
     # per-stage GPU time of the extractor (HIP events) on one extra profiled step
@@ -188,8 +196,8 @@ def main():
                    "cams_per_gpu": CAMS_PER_RANK, "width": W, "height": H, "nfeatures": NFEAT, "nlevels": 8,
                    "frame_unit": "one rig timestep (2 cameras)"},
         "parity": parity,
-        "overlap": ("extraction of timestep t+1 runs next to the matching of timestep t (orbf_prefetch); one isolated "
-                    "timestep takes %.4f ms" % serial_ms) if overlap else "off",
+        "overlap": ("the extractions of timesteps t+1 and t+2 run next to the matching of timestep t (orbf_prefetch, two "
+                    "extractor instances); one isolated timestep takes %.4f ms" % serial_ms) if overlap else "off",
         "extractor_stage_us": {k: round(v, 1) for k, v in stages.items()},
     }
     if rank == 0 and not a.no_roofline:

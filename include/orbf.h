@@ -52,13 +52,15 @@ void orbf_destroy(orbf_frontend* f);
 int orbf_set_depth(orbf_frontend* f, int cam, const float* d_depth, int stride_floats);
 /* mbf = Camera.bf; th_high / check_orientation as in ORBmatcher (defaults 40, 100, 1) */
 int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientation);
-/* Overlap of consecutive timesteps.  Declares the images of the step AFTER the next orbf_step / orbf_step_motion call:
- * that call enqueues their extraction on the extractor's stream right after it has enqueued its own matching, so the two
- * run next to each other on the GPU (matching occupies a handful of the 256 CUs), and the following step finds its
- * features ready or in flight.  The following step must then be called with exactly these images (same pointers, sizes,
- * strides), otherwise the prefetched work is dropped and the images are extracted again.  Host images are read while the
- * intervening step runs; device images must stay unchanged until the step that consumes them has returned.  Results are
- * bit-identical with and without prefetching; rigs of more than 4 cameras ignore the hint. */
+/* Overlap of consecutive timesteps.  Announces the images of a FUTURE step (a FIFO: the step after the next orbf_step /
+ * orbf_step_motion call, then the one after that; at most two steps ahead).  A step call enqueues the extraction of the
+ * announced images right after it has enqueued its own matching, so they run next to each other on the GPU (matching
+ * occupies a handful of the 256 CUs; with two steps announced two extraction chains run side by side on two extractor
+ * instances), and the following steps find their features ready or in flight.  Those steps must then be called with
+ * exactly the announced images, in order (same pointers, sizes, strides); otherwise everything in flight is dropped and
+ * the images are extracted again.  Host images are read while the intervening steps run; device images must stay
+ * unchanged until the step that consumes them has returned.  Results are bit-identical with and without announcements;
+ * rigs of more than 4 cameras ignore them. */
 int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images);
 /* Multi-GPU exchange: the HBM block holding the LAST step's merged descriptors -- cap_rows rows of 32 bytes in global
  * (camera-major, packed) order followed by a 256-byte trailer of int32 per-camera counts -- ready to be the send buffer

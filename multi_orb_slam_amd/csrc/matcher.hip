@@ -1101,10 +1101,14 @@ int orbm_create(int device, orbm_matcher** out) {
     if (rc != ORB_OK) return rc;
     orbm_matcher* m = new orbm_matcher();
     m->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
+    // Matching is the latency chain a caller waits for while extraction of later timesteps fills the rest of the chip:
+    // its streams get the highest priority the device offers.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    hipError_t e = hipStreamCreateWithPriority(&m->own_stream, hipStreamNonBlocking, prio_greatest);
     if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete m; return ORB_E_HIP; }
     m->stream = m->own_stream;
-    if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&m->side_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_q, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
@@ -1889,11 +1893,13 @@ int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int wor
 }  // extern "C"
 
 #include <chrono>
+#include <deque>
 #include "../../include/orbf.h"
 
 struct orbf_frontend {
     int device = 0, n_cams = 0, max_w = 0, max_h = 0;
-    orbx_extractor* ex = nullptr;
+    orbx_extractor* ex = nullptr;        // == exs[0]: the extractor isolated steps run on (orbf_extractor)
+    orbx_extractor* exs[2] = {nullptr, nullptr};  // small rigs: consecutive overlapped timesteps alternate between two
     orbm_matcher* mt = nullptr;
     std::vector<const float*> d_depth;
     std::vector<int> depth_stride;
@@ -1903,19 +1909,23 @@ struct orbf_frontend {
     int cap_total = 0;
     // pinned host result buffers.  The per-feature results exist twice: the extraction of the NEXT timestep (orbf_prefetch)
     // fills the other set while the caller still reads this step's.
-    struct ResultSet { PinnedBuf<orb_keypoint> kps; PinnedBuf<uint8_t> desc; PinnedBuf<float> ur, depth; } rs[2];
-    int cur = 0;  // set holding the results of the last completed step
+    static constexpr int NSETS = 4;  // this step's (held by the caller) + two timesteps in flight + the one being assigned
+    struct ResultSet { PinnedBuf<orb_keypoint> kps; PinnedBuf<uint8_t> desc; PinnedBuf<float> ur, depth; } rs[NSETS];
+    int cur = 0;       // set holding the results of the last completed step
+    int last_set = 0;  // set most recently handed to an extraction (sets are handed out round robin)
     PinnedBuf<uint8_t> h_queries;
     PinnedBuf<int32_t> h_match;
     // Small rigs (<= 4 cameras): one persistent frame per result set, filled by the extractor's describe kernel (FrameSink)
-    orbm_frame* pframe[2] = {nullptr, nullptr};
-    int pframe_W[2] = {0, 0}, pframe_H[2] = {0, 0};
-    // extraction in flight for the NEXT step (enqueued by the previous orbf_step after orbf_prefetch)
-    struct InFlight { bool active = false; std::vector<orbf_image> images; int set = 0, W = 0, H = 0; } inflight;
-    std::vector<orbf_image> next_images;  // declared by orbf_prefetch, consumed by the next step
-    bool have_next = false;
+    orbm_frame* pframe[NSETS] = {nullptr, nullptr, nullptr, nullptr};
+    int pframe_W[NSETS] = {0, 0, 0, 0}, pframe_H[NSETS] = {0, 0, 0, 0};
+    // extractions in flight for the NEXT steps (enqueued by earlier orbf_step calls after orbf_prefetch), oldest first
+    struct InFlight { std::vector<orbf_image> images; int set = 0, W = 0, H = 0, e = 0; };
+    std::deque<InFlight> inflight;
+    std::deque<std::vector<orbf_image>> announced;  // declared by orbf_prefetch, not enqueued yet (at most 2)
+    int last_e = 0;  // extractor most recently handed a timestep
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path
     hipEvent_t ev_extracted = nullptr;  // extractor stream -> matcher stream on the synchronous path
+    hipEvent_t ev_ready[NSETS] = {nullptr, nullptr, nullptr, nullptr};  // extraction + frame grid of the step using that set
     // frame of the last completed step (orbf_export_block); a frame built on the synchronous path is kept until the next step
     orbm_frame* last_frame = nullptr; bool last_frame_owned = false;
     // previous step (for orbf_step_motion)
@@ -1925,13 +1935,16 @@ struct orbf_frontend {
     std::chrono::steady_clock::time_point t_entry;
 };
 
+static bool small_rig(const orbf_frontend* f) { return f->n_cams <= 4 && f->cap_total <= 8192 && !f->mt->host_resolve; }
+
 extern "C" {
 
 int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbf_frontend** out) {
     MORB_ARG(params && out && n_cams >= 1 && n_cams <= 64);
     orbf_frontend* f = new orbf_frontend();
     f->device = device; f->n_cams = n_cams; f->max_w = max_width; f->max_h = max_height;
-    int rc = orbx_create(params, n_cams, max_width, max_height, device, &f->ex);
+    int rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[0]);
+    f->ex = f->exs[0];
     if (!rc) rc = orbm_create(device, &f->mt);
     // two streams: the matcher's own one follows the extractor's through events, so that the next step's extraction can
     // run next to this step's matching
@@ -1942,7 +1955,10 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     for (int c = 0; c < n_cams; ++c) { f->cam_cap.push_back(params[c].nfeatures + 4 * params[c].nlevels); f->cap_total += f->cam_cap.back(); }
     const size_t cap = (size_t)f->cap_total;
     if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
-    for (int k = 0; k < 2 && !rc; ++k)
+    for (int k = 0; k < orbf_frontend::NSETS; ++k)
+        if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
+    if (!rc && small_rig(f)) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[1]);  // overlap partner
+    for (int k = 0; k < orbf_frontend::NSETS && !rc; ++k)
         if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
             (rc = f->rs[k].depth.reserve(cap))) break;
     if (!rc) rc = f->h_match.reserve(cap);
@@ -1954,15 +1970,16 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
 void orbf_destroy(orbf_frontend* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    if (f->ex) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->ex));
+    for (int e = 0; e < 2; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
     if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
-    for (int k = 0; k < 2; ++k) if (f->pframe[k]) orbm_frame_destroy(f->pframe[k]);  // back to the matcher's pool first
+    for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->pframe[k]) orbm_frame_destroy(f->pframe[k]);  // back to the matcher's pool first
     if (f->mt) orbm_destroy(f->mt);
-    if (f->ex) orbx_destroy(f->ex);
-    for (int k = 0; k < 2; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); }
+    for (int e = 0; e < 2; ++e) if (f->exs[e]) orbx_destroy(f->exs[e]);
+    for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); }
     f->h_queries.release(); f->h_match.release();
     if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
+    for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->ev_ready[k]) (void)hipEventDestroy(f->ev_ready[k]);
     delete f;
 }
 
@@ -1994,7 +2011,7 @@ static int orbf_drain(orbf_frontend* f);
 
 int orbf_reset(orbf_frontend* f) {
     MORB_ARG(f != nullptr);
-    f->prev_n = 0; f->have_next = false; f->overlap_ok = true;
+    f->prev_n = 0; f->announced.clear(); f->overlap_ok = true;
     return orbf_drain(f);
 }
 
@@ -2009,8 +2026,9 @@ int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_b
 
 int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images) {
     MORB_ARG(f && next_images);
-    f->next_images.assign(next_images, next_images + f->n_cams);
-    f->have_next = true;
+    // (the step about to be called may itself still be in flight: two timesteps beyond it can be announced)
+    if (f->inflight.size() + f->announced.size() >= 3) { morb::set_error("too many future timesteps announced (at most two beyond the next step)"); return ORB_E_ARG; }
+    f->announced.emplace_back(next_images, next_images + f->n_cams);
     return ORB_OK;
 }
 
@@ -2039,36 +2057,36 @@ static bool same_images(const std::vector<orbf_image>& a, const orbf_image* b, i
     return true;
 }
 
-static bool small_rig(const orbf_frontend* f) { return f->n_cams <= 4 && f->cap_total <= 8192 && !f->mt->host_resolve; }
 
-static void fill_cam_capacities(orbf_frontend* f, orbm_cam_features* cams) {
+static void fill_cam_capacities(orbf_frontend* f, orbx_extractor* ex, orbm_cam_features* cams) {
     for (int c = 0; c < f->n_cams; ++c) {
-        cams[c].d_kps = orbx_device_keypoints(f->ex, c); cams[c].d_desc = orbx_device_descriptors(f->ex, c);
+        cams[c].d_kps = orbx_device_keypoints(ex, c); cams[c].d_desc = orbx_device_descriptors(ex, c);
         cams[c].n = f->cam_cap[c]; cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
     }
 }
 
-// Uploads + the whole extractor for one timestep into result set `set`, nothing synchronised.  Small rigs: the describe
-// kernel writes the merged frame pframe[set] through a FrameSink (*went_async = 1 unless the extractor took its
+// Uploads + the whole extractor `e` for one timestep into result set `set`, nothing synchronised.  Small rigs: the
+// describe kernel writes the merged frame pframe[set] through a FrameSink (*went_async = 1 unless the extractor took its
 // synchronous host-quadtree path; then the frame was not filled).
-static int enqueue_extract(orbf_frontend* f, const orbf_image* images, int set, int* W_out, int* H_out, int* went_async) {
+static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, int set, int* W_out, int* H_out, int* went_async) {
     orbm_matcher* m = f->mt;
+    orbx_extractor* ex = f->exs[e];
     int rc, W = 0, H = 0;
     for (int c = 0; c < f->n_cams; ++c) {
         const orbf_image& im = images[c];
-        rc = im.on_device ? orbx_upload_device(f->ex, c, im.data, im.width, im.height, im.stride)
-                          : orbx_upload(f->ex, c, im.data, im.width, im.height, im.stride);
+        rc = im.on_device ? orbx_upload_device(ex, c, im.data, im.width, im.height, im.stride)
+                          : orbx_upload(ex, c, im.data, im.width, im.height, im.stride);
         if (rc) return rc;
         W = std::max(W, im.width); H = std::max(H, im.height);
     }
     if (W == 0 || H == 0) { W = f->max_w; H = f->max_h; }
     *W_out = W; *H_out = H;
     orbf_frontend::ResultSet& R = f->rs[set];
-    if ((rc = orbx_set_host_mirror(f->ex, R.kps.dp, R.desc.dp, f->cap_total))) return rc;
+    if ((rc = orbx_set_host_mirror(ex, R.kps.dp, R.desc.dp, f->cap_total))) return rc;
     *went_async = 0;
-    if (!small_rig(f)) return orbx_run_async(f->ex);  // (> 4 cameras: the frame is assembled by the matcher's own kernels)
+    if (!small_rig(f)) return orbx_run_async(ex);  // (> 4 cameras: the frame is assembled by the matcher's own kernels)
     std::vector<orbm_cam_features> cams(f->n_cams);
-    fill_cam_capacities(f, cams.data());
+    fill_cam_capacities(f, ex, cams.data());
     if (f->pframe[set] && (f->pframe_W[set] != W || f->pframe_H[set] != H)) { orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr; }
     FrameSink sink;
     m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp;
@@ -2082,24 +2100,47 @@ static int enqueue_extract(orbf_frontend* f, const orbf_image* images, int set, 
     }
     m->mirror_ur = nullptr; m->mirror_depth = nullptr;
     if (rc) return rc;
-    if ((rc = orbx_set_frame_sink(f->ex, &sink))) return rc;
-    const int before = orbx_pending(f->ex);
-    rc = orbx_run_async(f->ex);
-    (void)orbx_set_frame_sink(f->ex, nullptr);
+    if ((rc = orbx_set_frame_sink(ex, &sink))) return rc;
+    const int before = orbx_pending(ex);
+    rc = orbx_run_async(ex);
+    (void)orbx_set_frame_sink(ex, nullptr);
     if (rc) return rc;
-    *went_async = orbx_pending(f->ex) > before ? 1 : 0;
+    *went_async = orbx_pending(ex) > before ? 1 : 0;
+    if (*went_async) {
+        // the frame's grid is part of the extraction chain: built on the extractor's stream right behind the describe
+        // kernel (counts read from HBM), so that a step's matching starts with the search itself
+        orbm_frame* frp = f->pframe[set];
+        hipStream_t keep = m->stream;
+        m->stream = (hipStream_t)orbx_stream(ex);
+        rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, orbx_device_counts(ex), &frp, true);
+        hipError_t he = rc ? hipSuccess : hipEventRecord(f->ev_ready[set], m->stream);
+        m->stream = keep;
+        if (rc) return rc;
+        if (he != hipSuccess) { morb::set_error("hipEventRecord: %s", hipGetErrorString(he)); return ORB_E_HIP; }
+    }
     return ORB_OK;
 }
 
-// Everything in flight is waited for and dropped (results of a prefetched extraction included).
+// Everything in flight is waited for and dropped (results of prefetched extractions included).
 static int orbf_drain(orbf_frontend* f) {
     MORB_HIP(hipSetDevice(f->device));
-    MORB_HIP(hipStreamSynchronize((hipStream_t)orbx_stream(f->ex)));
+    for (int e = 0; e < 2; ++e) if (f->exs[e]) MORB_HIP(hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e])));
     MORB_HIP(hipStreamSynchronize(f->mt->stream));
     MORB_HIP(hipStreamSynchronize(f->mt->side_stream));
-    while (orbx_pending(f->ex) > 0) { int rc = orbx_finish(f->ex); if (rc < 0) return rc; }
-    f->inflight.active = false;
+    for (int e = 0; e < 2; ++e)
+        while (f->exs[e] && orbx_pending(f->exs[e]) > 0) { int rc = orbx_finish(f->exs[e]); if (rc < 0) return rc; }
+    f->inflight.clear();
     return ORB_OK;
+}
+
+// The next free result set / extractor for a timestep that is about to be extracted.  Sets go round robin.  Isolated steps
+// (nothing in flight) always run on extractor 0; overlapped ones alternate, so that two extraction chains are on the GPU
+// at a time and each extractor keeps seeing the same two (count slot, result set) pairs -- its captured launch chains stay valid.
+static void next_slot(orbf_frontend* f, int* e, int* set) {
+    *set = (f->last_set + 1) % orbf_frontend::NSETS;
+    if (*set == f->cur) *set = (*set + 1) % orbf_frontend::NSETS;  // (the caller still reads the last step's results)
+    *e = (f->inflight.empty() || !f->exs[1]) ? 0 : (f->last_e ^ 1);
+    f->last_set = *set; f->last_e = *e;
 }
 
 static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
@@ -2111,22 +2152,28 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     MORB_HIP(hipSetDevice(f->device));
     orbm_matcher* m = f->mt;
     hipStream_t st = m->stream;                                   // matching
-    hipStream_t st_e = (hipStream_t)orbx_stream(f->ex);           // extraction
     int rc, W = 0, H = 0, went_async = 0;
     const bool small = small_rig(f);
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
     f->last_frame = nullptr; f->last_frame_owned = false;
 
-    // ---- this step's extraction: already in flight (orbf_prefetch during the previous step) or enqueued now
-    int set;
-    if (f->inflight.active && same_images(f->inflight.images, images, f->n_cams)) {
-        set = f->inflight.set; W = f->inflight.W; H = f->inflight.H; went_async = 1;
-        f->inflight.active = false;
+    // ---- this step's extraction: already in flight (orbf_prefetch during an earlier step) or enqueued now
+    int set, e;
+    if (!f->inflight.empty() && same_images(f->inflight.front().images, images, f->n_cams)) {
+        const orbf_frontend::InFlight& I = f->inflight.front();
+        set = I.set; e = I.e; W = I.W; H = I.H; went_async = 1;
+        f->inflight.pop_front();
     } else {
-        if (f->inflight.active && (rc = orbf_drain(f))) return rc;  // prefetched for other images: dropped
-        set = f->cur ^ 1;
-        if ((rc = enqueue_extract(f, images, set, &W, &H, &went_async))) return rc;
+        if (!f->inflight.empty()) {  // prefetched for other images: everything in flight is dropped
+            if ((rc = orbf_drain(f))) return rc;
+            f->announced.clear();
+        }
+        if (!f->announced.empty() && same_images(f->announced.front(), images, f->n_cams)) f->announced.pop_front();
+        next_slot(f, &e, &set);
+        if ((rc = enqueue_extract(f, e, images, set, &W, &H, &went_async))) return rc;
     }
+    orbx_extractor* ex = f->exs[e];
+    hipStream_t st_e = (hipStream_t)orbx_stream(ex);              // this step's extraction
     orbf_frontend::ResultSet& R = f->rs[set];
 
     // queries go through pinned staging; their H2D runs on the side stream next to the extractor's work
@@ -2146,20 +2193,15 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     SearchJob J{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
     if ((rc = f->h_match.reserve(std::max(f->cap_total, 1)))) return rc;
     bool async_path = small && went_async;
-    bool next_enqueued = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (async_path) {
-            // matching follows the extraction through its completion event; the counts are read from HBM
+            // matching follows the extraction chain (which ends with the frame grid) through its event; counts are in HBM
             fr = f->pframe[set]; fr_persistent = true;
-            fill_cam_capacities(f, cams.data());
-            MORB_HIP(hipStreamWaitEvent(st, (hipEvent_t)orbx_done_event(f->ex), 0));
+            MORB_HIP(hipStreamWaitEvent(st, f->ev_ready[set], 0));  // extraction + frame grid of this step
             if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
-            orbm_frame* frp = fr;
-            rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, orbx_device_counts(f->ex), &frp, true);
-            if (rc) return rc;
             n = fr->n_total;
         } else {
-            rc = orbx_finish(f->ex);  // synchronises; counts are on the host from here on
+            rc = orbx_finish(ex);  // synchronises; counts are on the host from here on
             if (rc < 0) return rc;
             // the host-quadtree path returns with its describe kernel still running on the extractor's stream
             MORB_HIP(hipEventRecord(f->ev_extracted, st_e));
@@ -2167,8 +2209,8 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
             if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
             n = 0;
             for (int c = 0; c < f->n_cams; ++c) {
-                cams[c].d_kps = orbx_device_keypoints(f->ex, c); cams[c].d_desc = orbx_device_descriptors(f->ex, c);
-                cams[c].n = orbx_count(f->ex, c);
+                cams[c].d_kps = orbx_device_keypoints(ex, c); cams[c].d_desc = orbx_device_descriptors(ex, c);
+                cams[c].n = orbx_count(ex, c);
                 cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
                 n += cams[c].n;
             }
@@ -2186,62 +2228,76 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         // fork: the camera-pair top-2 only needs the frame's descriptor block, so it runs on the side stream next to
         // project + resolve (both are a handful of workgroups on a 256-CU part); join before the one host sync
         const bool forked = do_cross && n > 0;
-        if (forked) {
-            hipError_t fe = hipEventRecord(m->ev_fork, st);
+        hipError_t fe = hipSuccess;
+        if (forked) {  // the fork point is the finished frame; the launches on the side stream come after the search's
+            fe = hipEventRecord(m->ev_fork, st);
             if (fe == hipSuccess) fe = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
             if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); if (!fr_persistent) orbm_frame_destroy(fr); return ORB_E_HIP; }
-            rc = cross_enqueue(m, m->side_stream, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n,
-                               async_path ? fr->b->d_ntotal.p : nullptr);
-            hipError_t je = hipEventRecord(m->ev_join, m->side_stream);
-            if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
         }
-        if (!rc) rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
-        if (forked) {  // join (also on the error path, so that the side stream never outlives the frame)
-            hipError_t je = hipStreamWaitEvent(st, m->ev_join, 0);
+        rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
+        if (forked) {
+            if (!rc) rc = cross_enqueue(m, m->side_stream, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n,
+                                        async_path ? fr->b->d_ntotal.p : nullptr);
+            // join (also on the error path, so that the side stream never outlives the frame)
+            hipError_t je = hipEventRecord(m->ev_join, m->side_stream);
+            if (je == hipSuccess) je = hipStreamWaitEvent(st, m->ev_join, 0);
             if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
         }
         if (rc) { (void)hipStreamSynchronize(st); if (!fr_persistent) orbm_frame_destroy(fr); return rc; }
-        // ---- the NEXT step's extraction goes onto the extractor's stream now: it runs while this step is being matched
-        if (async_path && attempt == 0 && f->have_next && f->overlap_ok && !next_enqueued) {
+        // ---- announced timesteps go onto the extractors now: they run while this step is being matched.  At most two
+        // are in flight; consecutive ones alternate between the two extractors (an extractor takes its next timestep as
+        // a second run behind the one whose results are being matched here).
+        while (async_path && attempt == 0 && f->overlap_ok && !f->announced.empty() && f->inflight.size() < 2) {
+            const int prev_e = f->inflight.empty() ? e : f->inflight.back().e;
+            const int e2 = f->exs[1] ? (prev_e ^ 1) : 0;
+            if (orbx_pending(f->exs[e2]) >= 2) break;
+            int set2 = (f->last_set + 1) % orbf_frontend::NSETS;
+            if (set2 == f->cur) set2 = (set2 + 1) % orbf_frontend::NSETS;
+            if (set2 == set) set2 = (set2 + 1) % orbf_frontend::NSETS;
             int w2 = 0, h2 = 0, async2 = 0;
-            rc = enqueue_extract(f, f->next_images.data(), set ^ 1, &w2, &h2, &async2);
+            rc = enqueue_extract(f, e2, f->announced.front().data(), set2, &w2, &h2, &async2);
             if (rc) { (void)hipStreamSynchronize(st); return rc; }
+            f->last_set = set2; f->last_e = e2;
             if (async2) {
-                f->inflight.active = true; f->inflight.images = f->next_images; f->inflight.set = set ^ 1; f->inflight.W = w2; f->inflight.H = h2;
+                orbf_frontend::InFlight I;
+                I.images = f->announced.front(); I.set = set2; I.W = w2; I.H = h2; I.e = e2;
+                f->inflight.push_back(std::move(I));
+                f->announced.pop_front();
             } else {
-                // the extractor ran synchronously (host quadtree): its outputs now belong to the next step, which cannot be
-                // kept apart from this one's -- give up overlapping; the next step extracts again
+                // the extractor ran synchronously (host quadtree): its outputs now belong to that future step, which cannot
+                // be kept apart from a later one's -- give up overlapping; the steps extract again when their turn comes
                 f->overlap_ok = false;
+                f->announced.clear();
             }
-            next_enqueued = true;
         }
         const auto t0 = std::chrono::steady_clock::now();
-        hipError_t e = hipStreamSynchronize(st);
+        hipError_t herr = hipStreamSynchronize(st);
         out->gpu_wait_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
         out->host_us[0] = us_between(f->t_entry, t_impl); out->host_us[1] = us_between(t_impl, t0); out->host_us[2] = out->gpu_wait_us;
         t_synced = std::chrono::steady_clock::now();
-        if (e != hipSuccess) {
-            morb::set_error("hipStreamSynchronize: %s", hipGetErrorString(e));
+        if (herr != hipSuccess) {
+            morb::set_error("hipStreamSynchronize: %s", hipGetErrorString(herr));
             if (!fr_persistent) orbm_frame_destroy(fr);
             return ORB_E_HIP;
         }
         if (async_path) {
-            rc = orbx_finish(f->ex);  // this step's run completed long ago: adopts its counts (or reports the fallback)
+            rc = orbx_finish(ex);  // this step's run (the oldest of its extractor) completed long ago: adopts its counts
             if (rc < 0) return rc;
             if (rc == 1 || rc == 2) {
                 // a pyramid level was outside the device quadtree's limits: this step is redone on the synchronous path
-                if (rc == 2) {  // ... from its images, because the next step's extraction has replaced them in HBM
+                if (rc == 2 || !f->inflight.empty()) {  // ... from its images: later timesteps are in flight, drop them first
                     if ((rc = orbf_drain(f))) return rc;
+                    f->announced.clear();
                     f->overlap_ok = false;
                     int w2, h2, a2;
-                    if ((rc = enqueue_extract(f, images, set, &w2, &h2, &a2))) return rc;
-                    if (a2) { rc = orbx_finish(f->ex); if (rc < 0) return rc; }
+                    if ((rc = enqueue_extract(f, e, images, set, &w2, &h2, &a2))) return rc;
+                    if (a2) { rc = orbx_finish(ex); if (rc < 0) return rc; }
                 }
                 fr = nullptr; fr_persistent = false;
                 async_path = false;
                 continue;
             }
-            for (int c = 0; c < f->n_cams; ++c) f->counts[c] = orbx_count(f->ex, c);
+            for (int c = 0; c < f->n_cams; ++c) f->counts[c] = orbx_count(ex, c);
             frame_set_counts(fr, f->counts.data());
             n = fr->n_total;
         } else {
@@ -2249,7 +2305,7 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         }
         break;
     }
-    f->have_next = false;
+    if (!async_path || !f->overlap_ok) f->announced.clear();  // (hints are only honoured on the asynchronous path)
     do_cross = do_cross && n > 0;
     rc = search_finish(m, J, f->h_match.p, &nmatches);
     if (rc) { if (!fr_persistent) orbm_frame_destroy(fr); return rc; }

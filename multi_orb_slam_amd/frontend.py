@@ -89,7 +89,9 @@ class NativeFrontEnd:
         matching.  The arrays / device buffers must stay alive and unchanged until the step that consumes them returns."""
         if not hasattr(self, "_next_imgs"):
             self._next_imgs = (FImage * self.n_cams)()
-        self._next_keep = self._fill(self._next_imgs, next_images)   # keeps host arrays alive across the two steps
+        if not hasattr(self, "_next_keep"):
+            self._next_keep = []
+        self._next_keep = (self._next_keep + [self._fill(self._next_imgs, next_images)])[-4:]   # host arrays stay alive across the steps in between
         check(_lib.lib().orbf_prefetch(self._h, self._next_imgs))
 
     def step(self, images, queries=None, flags=0, copy=True, motion=None):

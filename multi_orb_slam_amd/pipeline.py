@@ -87,17 +87,21 @@ class FrontEnd:
         self.fe.reset()
 
     # images: list of HxW uint8 arrays, or list of (device_ptr, stride) for HBM-resident frames
-    def step(self, images, resident=False, next_images=None):
-        """next_images: the images of the FOLLOWING step (same form as `images`): their extraction is overlapped with this
-        step's matching (orbf_prefetch); the following call must then pass exactly them."""
-        from .frontend import SKIP_CROSS
+    def announce(self, images, resident=False):
+        """Announce the images of a future step (orbf_prefetch; a FIFO, at most two steps ahead): their extraction runs next to
+        the matching of the steps before; those steps must then pass exactly these images, in order."""
         if resident:
             images = [(im[0], self.width, self.height, im[1], 1) for im in images]
-            if next_images is not None:
-                next_images = [(im[0], self.width, self.height, im[1], 1) for im in next_images]
-        distributed = self.world > 1 and self.gather is not None
+        self.fe.prefetch(images)
+
+    def step(self, images, resident=False, next_images=None):
+        """next_images: shorthand for announce(next_images) before the step."""
+        from .frontend import SKIP_CROSS
         if next_images is not None:
-            self.fe.prefetch(next_images)
+            self.announce(next_images, resident)
+        if resident:
+            images = [(im[0], self.width, self.height, im[1], 1) for im in images]
+        distributed = self.world > 1 and self.gather is not None
         # queries = the previous step's features under the stream's known motion, built natively (orbf_step_motion;
         # same arithmetic as make_queries, which the oracle leg uses)
         r = self.fe.step(images, None, SKIP_CROSS if distributed else 0, copy=self.copy_results,

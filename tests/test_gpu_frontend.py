@@ -31,16 +31,18 @@ def test_native_step_equals_oracle_pipeline(w, h, nfs):
     fe.close()
 
 
-@pytest.mark.parametrize("w,h,nfs,resident", [(320, 240, (300, 150), False), (640, 480, (1000, 1000), True)])
-def test_overlapped_steps_equal_oracle_pipeline(w, h, nfs, resident):
-    """orbf_prefetch: the next step's extraction runs next to this step's matching; results must not change."""
+@pytest.mark.parametrize("w,h,nfs,resident,depth", [(320, 240, (300, 150), False, 1), (640, 480, (1000, 1000), True, 1),
+                                                     (320, 240, (300, 150), True, 2), (640, 480, (1000, 1000), False, 2)])
+def test_overlapped_steps_equal_oracle_pipeline(w, h, nfs, resident, depth):
+    """orbf_prefetch: the extraction of the next step (depth 1) or the next two steps (depth 2, on two extractor instances)
+    runs next to this step's matching; results must not change."""
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import pipeline, rt
     from oracle_pipeline import OracleFrontEnd, assert_same_step
     params = [m.ExtractorParams(nfeatures=n) for n in nfs]
     fe = pipeline.FrontEnd(params, w, h)
     ofe = OracleFrontEnd(params, w, h)
-    T = 6
+    T = 8
     frames = [[synth.image(c, t, w, h) for c in range(len(nfs))] for t in range(T)]
     dev = []
     if resident:
@@ -50,9 +52,14 @@ def test_overlapped_steps_equal_oracle_pipeline(w, h, nfs, resident):
                 b = rt.DeviceBuffer(im.nbytes); b.upload(im); row.append(b)
             dev.append(row)
     arg = (lambda t: [(b.ptr, w) for b in dev[t]]) if resident else (lambda t: frames[t])
+    announced = 0                                     # index of the youngest step announced (or executed) so far
     for t in range(T):
-        nxt = arg(t + 1) if t + 1 < T and t != 3 else None     # step 4 is NOT prefetched: plain path in between
-        got = fe.step(arg(t), resident=resident, next_images=nxt)
+        # keep `depth` future steps announced -- except step 4, which nobody announces (plain path in between)
+        while announced < min(t + depth, T - 1) and announced + 1 != 4 and t != 4:
+            announced += 1
+            fe.announce(arg(announced), resident=resident)
+        announced = max(announced, t)
+        got = fe.step(arg(t), resident=resident)
         assert_same_step(got, ofe.step(frames[t]))
     assert got["n_temporal"] > 50
     fe.close()

@@ -25,8 +25,10 @@ for it in range(N + 20):
         tot = wait = 0.0; host[:] = 0
     t = it % 8
     t0 = time.perf_counter()
+    if OVERLAP and it == 0:
+        fe.announce([(dev[1][c].ptr, W) for c in range(2)], resident=True)
     r = fe.step([(dev[t][c].ptr, W) for c in range(2)], resident=True,
-                next_images=[(dev[(t + 1) % 8][c].ptr, W) for c in range(2)] if OVERLAP else None)
+                next_images=[(dev[(t + 2) % 8][c].ptr, W) for c in range(2)] if OVERLAP else None)
     tot += time.perf_counter() - t0; wait += r["gpu_wait_us"]; host += np.array(r["host_us"])
 fe.ex.set_profiling(True); fe.step([(dev[1][c].ptr, W) for c in range(2)], resident=True)
 print(json.dumps({"step_us": round(tot / N * 1e6, 1), "final_sync_wait_us": round(wait / N, 1), "host_us[query_prep,enqueue,wait,post]": [round(x / N, 1) for x in host], "extractor": fe.ex.stage_times_us()}))
