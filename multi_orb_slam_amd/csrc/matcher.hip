@@ -623,10 +623,10 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                                                   int check_ori, int max_it, int* __restrict__ choice,
                                                   const int* __restrict__ topk /* (2*RESOLVE_K+1)*nq ints */,
                                                   int* __restrict__ match_of_feature, int* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) int s_claim[];  // one entry per feature (capacity F.n_total)
+    extern __shared__ __attribute__((aligned(16))) int s_claim[];  // two claim tables, one entry per feature each (capacity F.n_total)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_keep[3];
-    __shared__ int s_red, s_nres;
+    __shared__ int s_red, s_nres2[2];  // (rescan counters alternate with the sweep parity: reset one sweep ahead)
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
     MORB_PHASE(g_ph_res, 0);
@@ -635,18 +635,19 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     // shortlist written by k_project: keys (dist << 16 | visiting position) and feature indices, sorted, occupied excluded
     const int* tk_key = topk;                             // [k*nq + i]
     const int* tk_g = topk + RESOLVE_K * nq;      // [k*nq + i]
-    // LDS after the claim table: rescan list u16[nq] (padded to 4 bytes); with LDSQ also
+    // LDS after the two claim tables: rescan list u16[nq] (padded to 4 bytes); with LDSQ also
     //   choice[nq] | shortlist g [K][nq] | query angle [nq] | feature angle [F.n_total] | shortlist d [K][nq] (u16) | flags [nq] (u8)
-    unsigned short* l_res = reinterpret_cast<unsigned short*>(s_claim + F.n_total);
-    int* l_choice = s_claim + F.n_total + (nq + 1) / 2;
+    int* s_claim2 = s_claim + F.n_total;
+    unsigned short* l_res = reinterpret_cast<unsigned short*>(s_claim + 2 * F.n_total);
+    int* l_choice = s_claim + 2 * F.n_total + (nq + 1) / 2;
     int* l_g = l_choice + nq;
     float* l_ang = reinterpret_cast<float*>(l_g + RESOLVE_K * nq);
     float* l_fang = l_ang + nq;
     unsigned short* l_d = reinterpret_cast<unsigned short*>(l_fang + F.n_total);
     unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_d + RESOLVE_K * nq);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
-    if (tid == 0) s_red = 0;
+    if (tid == 0) { s_red = 0; s_nres2[0] = 0; s_nres2[1] = 0; }
     for (int g = tid; g < F.n_total; g += T) {  // capacity-sized: rows past the real count are never referenced
-        s_claim[g] = 0x7fffffff;
+        s_claim[g] = 0x7fffffff; s_claim2[g] = 0x7fffffff;
         if (LDSQ && !POINTS && check_ori) l_fang[g] = f_angle[g];
     }
     int mx = 0;
@@ -678,14 +679,15 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     constexpr int NEED = POINTS ? 2 : 1;
     int it = 0, changed = 1;
     for (; it < max_it && changed; ++it) {
-        const int tag = (0x7ffe - it) << 16;  // newer sweep -> smaller tag -> wins atomicMin over stale entries
-        for (int i = tid; i < nq; i += T) {
-            const int c = LDSQ ? l_choice[i] : choice[i];
-            const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;  // loaded unconditionally: both loads in flight together
-            if (c >= 0 && bl) atomicMin(&s_claim[c], tag | i);
-        }
-        if (tid == 0) s_nres = 0;
-        __syncthreads();
+        // Two claim tables alternate: sweep `it` READS the claims the previous sweep's choices left in `rd` (entries tagged
+        // `tag`) and WRITES the claims of its own choices into `wr` (tagged `tag_next`), so a sweep is ONE pass over the
+        // queries and one barrier.  Tags decrease, so atomicMin prefers the newer sweep over stale entries of the same
+        // table (two sweeps old) and, within a sweep, the lowest query index.
+        const int tag = (0x7ffe - it) << 16, tag_next = (0x7ffd - it) << 16;
+        const int* rd = (it & 1) ? s_claim2 : s_claim;
+        int* wr = (it & 1) ? s_claim : s_claim2;
+        int& s_nres = s_nres2[it & 1];
+        if (tid == 0) s_nres2[(it + 1) & 1] = 0;  // nobody touches the other counter during this sweep
         int ch = 0;
         for (int i = tid; i < nq; i += T) {
             int sg[RESOLVE_K], sd[RESOLVE_K];
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 if (found >= NEED) break;
                 const int g = LDSQ ? l_g[k * nq + i] : sg[k];
                 if (g < 0) break;  // the shortlist is sorted: empty slots are at the end
-                const int cl = s_claim[g];
+                const int cl = rd[g];
                 if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) { ++taken; continue; }
                 const int d = LDSQ ? (int)l_d[k * nq + i] : sd[k];
                 if (found == 0) { best = d; bidx = g; if (POINTS) lvl = F.octave[g]; }
@@ -725,6 +727,8 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
             }
             if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
+            const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;
+            if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
         }
         __syncthreads();
         const int nres = s_nres;
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                     const int g = cand_idx[k * nq + i];
                     const int d = cand_dist[k * nq + i];
                     bool avail = !(occupied && occupied[g]);
-                    const int cl = s_claim[g];
+                    const int cl = rd[g];
                     if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) avail = false;
                     if (avail) key = (d << 16) | k;
                 }
@@ -772,6 +776,8 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 }
                 const int old = LDSQ ? l_choice[i] : choice[i];
                 if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
+                const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;
+                if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);
             }
         }
         changed = __syncthreads_or(ch);
@@ -1683,8 +1689,8 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     const int n = J.cur->n_total;
     J.device_path = false;
     if (J.nq == 0 || n == 0) return ORB_OK;
-    // claim table (one int per feature) + the rescan list (u16 per query, padded)
-    const size_t lds = (size_t)n * sizeof(int) + (size_t)((J.nq + 1) / 2) * sizeof(int);
+    // two claim tables (one int per feature each) + the rescan list (u16 per query, padded)
+    const size_t lds = (size_t)2 * n * sizeof(int) + (size_t)((J.nq + 1) / 2) * sizeof(int);
     if (m->host_resolve || J.nq > RESOLVE_MAX_Q || lds > 150 * 1024) return ORB_OK;  // finish() takes the host path
     if (lds > 48 * 1024) {  // large claim tables need the opt-in dynamic LDS limit (once per process)
         static bool raised = false;
