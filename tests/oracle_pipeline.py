@@ -6,8 +6,14 @@ from multi_orb_slam_amd import pipeline as P
 
 
 class OracleFrontEnd:
-    def __init__(self, params_per_cam, width, height, global_cams=None):
+    def __init__(self, params_per_cam, width, height, global_cams=None, cam_threads=False):
+        """cam_threads: extract the cameras (and match them across cameras) on one host thread each -- the variant ORB-SLAM2
+        upstream uses for stereo (reference src/Frame.cc:106-109, commented out there); results are identical."""
         self.params = list(params_per_cam); self.n_cams = len(self.params)
+        self.pool = None
+        if cam_threads and self.n_cams > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(self.n_cams)   # the oracle's C entry points release the GIL (ctypes)
         self.width, self.height = width, height
         p = self.params[0]
         self.scale = oracle.tables(p.nfeatures, p.scale_factor, p.nlevels, p.ini_th_fast, p.min_th_fast)["scale"]
@@ -18,8 +24,8 @@ class OracleFrontEnd:
     def step(self, images, other_descs=None):
         """other_descs(cam_index) -> list of descriptor arrays of every OTHER camera of the rig in global camera order
         (multi-GPU mirror); None = the rig is just this process' cameras."""
-        per_cam = [oracle.extract(im, p.nfeatures, p.scale_factor, p.nlevels, p.ini_th_fast, p.min_th_fast)
-                   for im, p in zip(images, self.params)]
+        ext = lambda a: oracle.extract(a[0], a[1].nfeatures, a[1].scale_factor, a[1].nlevels, a[1].ini_th_fast, a[1].min_th_fast)
+        per_cam = list(self.pool.map(ext, zip(images, self.params))) if self.pool else [ext(a) for a in zip(images, self.params)]
         counts = [len(k) for k, _ in per_cam]
         cat = np.concatenate
         kps = cat([k for k, _ in per_cam]); desc = cat([d for _, d in per_cam])
@@ -34,13 +40,12 @@ class OracleFrontEnd:
             q = P.make_queries(self.prev, self.scale)
             n_temporal, match_of = oracle.search_by_projection_frames(fr, q, 100, True)
         self.prev = (kps, desc, depth, cam_of)
-        bis, bds, sds = [], [], []
-        for c in range(self.n_cams):
+        def cross(c):
             others = other_descs(c) if other_descs is not None else [per_cam[o][1] for o in range(self.n_cams) if o != c]
             refs = cat(others) if others else np.zeros((0, 32), np.uint8)
-            bi, bd, sd = oracle.bf_top2(per_cam[c][1], refs)
-            bis.append(bi); bds.append(bd); sds.append(sd)
-        bi, bd, sd = cat(bis), cat(bds), cat(sds)
+            return oracle.bf_top2(per_cam[c][1], refs)
+        res = list(self.pool.map(cross, range(self.n_cams))) if self.pool else [cross(c) for c in range(self.n_cams)]
+        bi, bd, sd = cat([r[0] for r in res]), cat([r[1] for r in res]), cat([r[2] for r in res])
         return dict(kps=kps, desc=desc, uright=uright, depth=depth, counts=counts, n_temporal=n_temporal,
                     match_of_feature=match_of, cross=(bi, bd, sd), n_cross=int(P.accept_cross(bd, sd).sum()))
 

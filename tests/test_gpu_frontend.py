@@ -6,7 +6,8 @@ from multi_orb_slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("w,h,nfs", [(320, 240, (300, 150)), (640, 480, (1000, 500)), (640, 480, (1000, 1000, 700))])
+@pytest.mark.parametrize("w,h,nfs", [(320, 240, (300, 150)), (640, 480, (1000, 500)), (640, 480, (1000, 1000, 700)),
+                                     (1280, 720, (2000, 2000))])   # the last one = configs[2]
 def test_native_step_equals_oracle_pipeline(w, h, nfs):
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import pipeline, rt
