@@ -22,6 +22,14 @@ typedef struct orb_keypoint {
     int32_t class_id; /* always -1                                                              */
 } orb_keypoint;
 
+/* Pinhole + radial-tangential calibration as the reference holds it (CV_32F mK and mDistCoef, src/Tracking.cc;
+ * OtherFiles/multi.yaml:7-16).  k1 == 0 switches undistortion off altogether, as Frame::UndistortKeyPoints does
+ * (src/Frame.cc:676-680). */
+typedef struct orb_calibration {
+    float fx, fy, cx, cy;
+    float k1, k2, p1, p2, k3;
+} orb_calibration;
+
 /* status codes returned by every entry point (never throws across the ABI) */
 enum {
     ORB_OK = 0,

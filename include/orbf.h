@@ -42,6 +42,8 @@ typedef struct orbf_result { /* all pointers: pinned host memory owned by the ha
     float gpu_wait_us;                /* host time spent blocked in the final synchronisation                   */
     int32_t n_queries;                /* queries searched this step                                             */
     const orbm_query* queries;        /* [n_queries] (pinned copy)                                              */
+    const float* un_x;                /* [n_total] undistorted positions (mvKeysUn_total[i].pt): the keypoint positions     */
+    const float* un_y;                /*   themselves unless a calibration with k1 != 0 is set                            */
     float host_us[4];                 /* host timeline of the call: query preparation, enqueue of the whole step,
                                          blocked in the final synchronisation, bookkeeping after it            */
 } orbf_result;
@@ -50,6 +52,11 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
 void orbf_destroy(orbf_frontend* f);
 /* HBM-resident depth image (metres, float32) of one camera for ComputeStereoFromRGBD; NULL: uRight = -1 */
 int orbf_set_depth(orbf_frontend* f, int cam, const float* d_depth, int stride_floats);
+/* Camera calibration of the rig (the reference keeps ONE mK / mDistCoef for all cameras).  With k1 != 0 the frame is
+ * assembled as the reference does it: positions undistorted (Frame::UndistortKeyPoints), image bounds from the undistorted
+ * corners (ComputeImageBounds), uRight from the undistorted x, depth read at the distorted pixel.  NULL / k1 == 0: off
+ * (the default).  Drops whatever orbf_prefetch has in flight. */
+int orbf_set_calibration(orbf_frontend* f, const orb_calibration* calib);
 /* mbf = Camera.bf; th_high / check_orientation as in ORBmatcher (defaults 40, 100, 1) */
 int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientation);
 /* Overlap of consecutive timesteps.  Announces the images of a FUTURE step (a FIFO: the step after the next orbf_step /

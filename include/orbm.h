@@ -93,7 +93,18 @@ typedef struct orbm_query { /* one projected map point */
  * ur = u - mbf / depth (u where depth <= 0), levels octave-1 .. octave+1, blocks = 1, angle/desc copied.  A SLAM
  * caller computes the same fields from its 3-D map points instead (reference src/ORBmatcher.cc:3502-3552). */
 int orbm_queries_from_motion(const orb_keypoint* kps, const uint8_t* desc, const float* depth, const int32_t* cam_of, int n,
-                             float du, float dv, float th, const float* scale_factors, float mbf, orbm_query* out);
+                             float du, float dv, float th, const float* scale_factors, float mbf, orbm_query* out,
+                             const float* un_x, const float* un_y); /* undistorted positions, or NULL, NULL: kps[i].x/y */
+
+/* Frame::UndistortKeyPoints / ComputeImageBounds (reference src/Frame.cc:673-778) = cv::undistortPoints(pts, K, dist,
+ * noArray(), K) of OpenCV 2.4.x / 3.2, host side (the same operation sequence the kernels run).  calib == NULL or
+ * k1 == 0: plain copy / (0, 0, cols, rows), as in the reference.  out4 = {minX, minY, maxX, maxY}. */
+int orbm_undistort_points(const orb_calibration* calib, const float* x, const float* y, int n, float* ux, float* uy);
+int orbm_image_bounds(const orb_calibration* calib, int cols, int rows, float* out4);
+/* Calibration applied by the frames this handle assembles ON THE DEVICE from now on (orbm_frame_from_device): positions
+ * are undistorted before grid assignment and uRight, the depth image is still read at the distorted pixel
+ * (src/Frame.cc:968-981).  The caller passes matching bounds (orbm_image_bounds).  NULL switches it off. */
+int orbm_set_calibration(orbm_matcher* m, const orb_calibration* calib);
 
 /* Builds the 64x48 per-camera grid (round-to-cell insertion, ascending global indices) and uploads the frame. */
 int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** out);

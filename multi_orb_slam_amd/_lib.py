@@ -30,6 +30,10 @@ class Params(C.Structure):  # orbx_params
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+class Calibration(C.Structure):  # orb_calibration
+    _fields_ = [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+
+
 class CamFeatures(C.Structure):  # orbm_cam_features
     _fields_ = [("d_kps", C.c_void_p), ("d_desc", C.c_void_p), ("n", C.c_int32), ("d_depth", C.c_void_p),
                 ("depth_stride", C.c_int32)]
@@ -45,7 +49,7 @@ class FResult(C.Structure):  # orbf_result
                 ("desc", C.c_void_p), ("uright", C.c_void_p), ("depth", C.c_void_p), ("nmatches", C.c_int32),
                 ("match_of_feature", C.c_void_p), ("cross_best_idx", C.c_void_p), ("cross_best_dist", C.c_void_p),
                 ("cross_second_dist", C.c_void_p), ("gpu_wait_us", C.c_float), ("n_queries", C.c_int32),
-                ("queries", C.c_void_p), ("host_us", C.c_float * 4)]
+                ("queries", C.c_void_p), ("un_x", C.c_void_p), ("un_y", C.c_void_p), ("host_us", C.c_float * 4)]
 
 
 class FMotion(C.Structure):  # orbf_motion
@@ -126,7 +130,11 @@ def lib():
     L.orbf_extractor.argtypes = [vp]; L.orbf_extractor.restype = vp
     L.orbf_matcher.argtypes = [vp]; L.orbf_matcher.restype = vp
     L.orbm_debug_last_resolve.argtypes = [vp, vp]
-    L.orbm_queries_from_motion.argtypes = [vp, vp, vp, vp, i32, f32, f32, f32, vp, f32, vp]
+    L.orbm_queries_from_motion.argtypes = [vp, vp, vp, vp, i32, f32, f32, f32, vp, f32, vp, vp, vp]
+    L.orbm_set_calibration.argtypes = [vp, vp]
+    L.orbm_undistort_points.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.orbm_image_bounds.argtypes = [vp, i32, i32, vp]
+    L.orbf_set_calibration.argtypes = [vp, vp]
     L.orbm_cross_top2.argtypes = [vp, vp, vp, vp, vp]
     L.orbm_cross_top2_blocks.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.orbm_frame_grid.argtypes = [vp, vp, vp]

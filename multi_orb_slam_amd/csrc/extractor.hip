@@ -1052,16 +1052,19 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         if (mir.kps) mir.kps[g] = kp;
         if (to_sink) {
             // the per-feature half of the frame assembly: `_total` record, ComputeStereoFromRGBD, PosInGrid
-            sink.x[g] = kp.x; sink.y[g] = kp.y; sink.oct[g] = level; sink.ang[g] = angle; sink.kps[g] = kp;
+            float ux = kp.x, uy = kp.y;  // Frame::UndistortKeyPoints
+            if (sink.calib.k1 != 0.0f) morb_undistort_point(sink.calib, kp.x, kp.y, &ux, &uy);
+            sink.x[g] = ux; sink.y[g] = uy; sink.oct[g] = level; sink.ang[g] = angle; sink.kps[g] = kp;
+            if (sink.h_unx) { sink.h_unx[g] = ux; sink.h_uny[g] = uy; }
             float d = -1.f, u_r = -1.f;
             const float* depth = sink.cam_depth[cam & 3];
             if (depth) {
                 const float dv = depth[(size_t)(int)kp.y * sink.cam_depth_stride[cam & 3] + (int)kp.x];  // imDepth.at<float>(v,u)
-                if (dv > 0) { d = dv; u_r = kp.x - sink.mbf / dv; }
+                if (dv > 0) { d = dv; u_r = ux - sink.mbf / dv; }  // depth at the distorted pixel, uRight from the undistorted x
             }
             sink.ur[g] = u_r; sink.depth[g] = d;
             if (sink.h_ur) { sink.h_ur[g] = u_r; sink.h_depth[g] = d; }
-            const int px = (int)roundf((kp.x - sink.minX) * sink.invW), py = (int)roundf((kp.y - sink.minY) * sink.invH);
+            const int px = (int)roundf((ux - sink.minX) * sink.invW), py = (int)roundf((uy - sink.minY) * sink.invH);
             sink.cell_of[g] = (px >= 0 && px < 64 && py >= 0 && py < 48) ? (cam * 64 + px) * 48 + py : -1;
         }
     }

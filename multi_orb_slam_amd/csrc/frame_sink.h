@@ -16,6 +16,8 @@ struct FrameSink {
     uint32_t* desc;                    // [capacity][8] descriptors in global-index order
     int* cell_of;                      // [capacity] grid cell (camera-major), -1 outside the grid
     float *h_ur, *h_depth;             // mapped pinned mirrors of ur / depth (may be NULL)
+    float *h_unx, *h_uny;              // mapped pinned mirrors of the undistorted position (may be NULL)
+    orb_calibration calib;             // undistortion of the keypoint position (k1 == 0: off, src/Frame.cc:676)
     const float* cam_depth[4];         // HBM depth image per camera (NULL: no stereo coordinate)
     int cam_depth_stride[4];
     float mbf, minX, minY, invW, invH;

@@ -393,7 +393,7 @@ struct CamFeat {
 
 // Optional pinned-host (device-mapped) destinations: results the host needs are written there by the kernels
 // themselves, so no D2H copy kernels sit on the stream.
-struct HostMirror { orb_keypoint* kps; uint4* desc; float* ur; float* depth; };
+struct HostMirror { orb_keypoint* kps; uint4* desc; float* ur; float* depth; float* unx; float* uny; orb_calibration calib; };
 
 // One feature of the merged frame: the `_total` record, its stereo coordinate and its grid cell.
 __device__ __forceinline__ int frame_fill_one(const CamFeat* __restrict__ cams, int n_cams, int g, float mbf, float minX,
@@ -408,17 +408,20 @@ __device__ __forceinline__ int frame_fill_one(const CamFeat* __restrict__ cams, 
     const int l = g - C.base;
     const orb_keypoint k = C.kps[l];
     const uint4 d0 = C.desc[2 * l], d1 = C.desc[2 * l + 1];
-    x[g] = k.x; y[g] = k.y; oct[g] = k.octave; ang[g] = k.angle; kps_g[g] = k;
+    float ux = k.x, uy = k.y;  // Frame::UndistortKeyPoints (src/Frame.cc:673-705): a copy when k1 == 0
+    if (hm.calib.k1 != 0.0f) morb_undistort_point(hm.calib, k.x, k.y, &ux, &uy);
+    x[g] = ux; y[g] = uy; oct[g] = k.octave; ang[g] = k.angle; kps_g[g] = k;
     desc_g[2 * g] = d0; desc_g[2 * g + 1] = d1;
     float d = -1.f, u_r = -1.f;
     if (C.depth) {
         const float dv = C.depth[(size_t)(int)k.y * C.depth_stride + (int)k.x];  // imDepth.at<float>(v,u): float -> int truncation
-        if (dv > 0) { d = dv; u_r = k.x - mbf / dv; }
+        if (dv > 0) { d = dv; u_r = ux - mbf / dv; }  // kpU.pt.x - mbf/d (src/Frame.cc:981)
     }
     ur[g] = u_r; depth_out[g] = d;
     if (hm.kps) { hm.kps[g] = k; hm.desc[2 * g] = d0; hm.desc[2 * g + 1] = d1; }
     if (hm.ur) { hm.ur[g] = u_r; hm.depth[g] = d; }
-    const int px = (int)roundf((k.x - minX) * invW), py = (int)roundf((k.y - minY) * invH);
+    if (hm.unx) { hm.unx[g] = ux; hm.uny[g] = uy; }
+    const int px = (int)roundf((ux - minX) * invW), py = (int)roundf((uy - minY) * invH);
     if (px >= 0 && px < ORBM_GRID_COLS && py >= 0 && py < ORBM_GRID_ROWS) return (c * ORBM_GRID_COLS + px) * ORBM_GRID_ROWS + py;
     return -1;
 }
@@ -1035,6 +1038,8 @@ struct orbm_matcher {
     std::vector<FrameBufs*> pool;  // free list
     // device-visible pinned destinations the next orbm_frame_from_device mirrors its merged arrays into (orbf_step)
     orb_keypoint* mirror_kps = nullptr; uint8_t* mirror_desc = nullptr; float* mirror_ur = nullptr; float* mirror_depth = nullptr;
+    float* mirror_unx = nullptr; float* mirror_uny = nullptr;
+    orb_calibration calib = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // orbm_set_calibration: undistortion applied by device-built frames (k1 == 0: off)
     int frame_min_rows = 0;  // the next device-built frame gets at least this many descriptor rows (fixed export block size)
     int last_status[4] = {0, 0, 0, 0};  // {status, nmatches, sweeps, longest list} of the last device resolve
     bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
@@ -1172,14 +1177,41 @@ int orbm_descriptor_distance(const uint8_t* a, const uint8_t* b) {
     return dist;
 }
 
+int orbm_set_calibration(orbm_matcher* m, const orb_calibration* calib) {
+    MORB_ARG(m != nullptr);
+    if (calib) m->calib = *calib; else memset(&m->calib, 0, sizeof(m->calib));
+    return ORB_OK;
+}
+
+int orbm_undistort_points(const orb_calibration* calib, const float* x, const float* y, int n, float* ux, float* uy) {
+    MORB_ARG(n >= 0 && (n == 0 || (x && y && ux && uy)));
+    for (int i = 0; i < n; ++i) {
+        if (!calib || calib->k1 == 0.0f) { ux[i] = x[i]; uy[i] = y[i]; }
+        else morb_undistort_point(*calib, x[i], y[i], &ux[i], &uy[i]);
+    }
+    return ORB_OK;
+}
+
+int orbm_image_bounds(const orb_calibration* calib, int cols, int rows, float* out4) {
+    MORB_ARG(out4 != nullptr);
+    if (!calib || calib->k1 == 0.0f) { out4[0] = 0.f; out4[1] = 0.f; out4[2] = (float)cols; out4[3] = (float)rows; return ORB_OK; }
+    const float cx[4] = {0.f, (float)cols, 0.f, (float)cols}, cy[4] = {0.f, 0.f, (float)rows, (float)rows};
+    float ux[4], uy[4];
+    for (int i = 0; i < 4; ++i) morb_undistort_point(*calib, cx[i], cy[i], &ux[i], &uy[i]);
+    out4[0] = std::min(ux[0], ux[2]); out4[2] = std::max(ux[1], ux[3]);  // src/Frame.cc:768-771
+    out4[1] = std::min(uy[0], uy[1]); out4[3] = std::max(uy[2], uy[3]);
+    return ORB_OK;
+}
+
 int orbm_queries_from_motion(const orb_keypoint* kps, const uint8_t* desc, const float* depth, const int32_t* cam_of, int n,
-                             float du, float dv, float th, const float* scale_factors, float mbf, orbm_query* out) {
-    MORB_ARG(n >= 0 && (n == 0 || (kps && desc && depth && cam_of && scale_factors && out)));
+                             float du, float dv, float th, const float* scale_factors, float mbf, orbm_query* out,
+                             const float* un_x, const float* un_y) {
+    MORB_ARG(n >= 0 && (n == 0 || (kps && desc && depth && cam_of && scale_factors && out)) && ((un_x == nullptr) == (un_y == nullptr)));
     for (int i = 0; i < n; ++i) {
         orbm_query& Q = out[i];
         const orb_keypoint& k = kps[i];
-        const float u = k.x + du;
-        Q.u = u; Q.v = k.y + dv;
+        const float u = (un_x ? un_x[i] : k.x) + du;
+        Q.u = u; Q.v = (un_y ? un_y[i] : k.y) + dv;
         Q.radius = scale_factors[k.octave] * th;
         const float inv = depth[i] > 0 ? 1.0f / depth[i] : 0.0f;
         Q.ur = u - mbf * inv;
@@ -1384,7 +1416,8 @@ static int frame_prepare_sink(orbm_matcher* m, const orbm_cam_features* cams, in
     sink->x = F->b->d_x.p; sink->y = F->b->d_y.p; sink->ur = F->b->d_ur.p; sink->depth = F->b->d_depth.p; sink->ang = F->b->d_ang.p;
     sink->oct = F->b->d_oct.p; sink->kps = F->b->d_kps.p; sink->desc = reinterpret_cast<uint32_t*>(F->b->d_desc.p);
     sink->cell_of = F->b->d_cell_of.p;
-    sink->h_ur = m->mirror_ur; sink->h_depth = m->mirror_depth;
+    sink->h_ur = m->mirror_ur; sink->h_depth = m->mirror_depth; sink->h_unx = m->mirror_unx; sink->h_uny = m->mirror_uny;
+    sink->calib = m->calib;
     for (int c = 0; c < n_cams; ++c) { sink->cam_depth[c] = cams[c].d_depth; sink->cam_depth_stride[c] = cams[c].depth_stride; }
     sink->mbf = mbf; sink->minX = F->minX; sink->minY = F->minY; sink->invW = F->invW; sink->invH = F->invH;
     *out = F;
@@ -1398,7 +1431,8 @@ static int frame_sink_of(orbm_matcher* m, orbm_frame* F, const orbm_cam_features
     sink->x = F->b->d_x.p; sink->y = F->b->d_y.p; sink->ur = F->b->d_ur.p; sink->depth = F->b->d_depth.p; sink->ang = F->b->d_ang.p;
     sink->oct = F->b->d_oct.p; sink->kps = F->b->d_kps.p; sink->desc = reinterpret_cast<uint32_t*>(F->b->d_desc.p);
     sink->cell_of = F->b->d_cell_of.p;
-    sink->h_ur = m->mirror_ur; sink->h_depth = m->mirror_depth;
+    sink->h_ur = m->mirror_ur; sink->h_depth = m->mirror_depth; sink->h_unx = m->mirror_unx; sink->h_uny = m->mirror_uny;
+    sink->calib = m->calib;
     for (int c = 0; c < n_cams; ++c) { sink->cam_depth[c] = cams[c].d_depth; sink->cam_depth_stride[c] = cams[c].depth_stride; }
     sink->mbf = mbf; sink->minX = F->minX; sink->minY = F->minY; sink->invW = F->invW; sink->invH = F->invH;
     return ORB_OK;
@@ -1448,9 +1482,10 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
         MORB_HIP(hipMemcpyAsync(F->b->d_cams.p, hc, (size_t)n_cams * sizeof(CamFeat), hipMemcpyHostToDevice, st));
         MORB_HIP(hipMemcpyAsync(F->b->d_cam_start.p, hstart, (size_t)(n_cams + 1) * 4, hipMemcpyHostToDevice, st));
     }
-    HostMirror hm{nullptr, nullptr, nullptr, nullptr};
+    HostMirror hm{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, m->calib};
     if (m->mirror_kps) { hm.kps = m->mirror_kps; hm.desc = (uint4*)m->mirror_desc; }
     if (m->mirror_ur) { hm.ur = m->mirror_ur; hm.depth = m->mirror_depth; }
+    if (m->mirror_unx) { hm.unx = m->mirror_unx; hm.uny = m->mirror_uny; }
     if (small) {
         static bool raised = false;
         if (!raised) {
@@ -1912,11 +1947,12 @@ struct orbf_frontend {
     std::vector<int32_t> counts, cam_cap;
     float mbf = 40.f;
     int th_high = ORBM_TH_HIGH, check_ori = 1;
+    orb_calibration calib = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // k1 == 0: no undistortion (orbf_set_calibration)
     int cap_total = 0;
     // pinned host result buffers.  The per-feature results exist twice: the extraction of the NEXT timestep (orbf_prefetch)
     // fills the other set while the caller still reads this step's.
     static constexpr int NSETS = 4;  // this step's (held by the caller) + two timesteps in flight + the one being assigned
-    struct ResultSet { PinnedBuf<orb_keypoint> kps; PinnedBuf<uint8_t> desc; PinnedBuf<float> ur, depth; } rs[NSETS];
+    struct ResultSet { PinnedBuf<orb_keypoint> kps; PinnedBuf<uint8_t> desc; PinnedBuf<float> ur, depth, unx, uny; } rs[NSETS];
     int cur = 0;       // set holding the results of the last completed step
     int last_set = 0;  // set most recently handed to an extraction (sets are handed out round robin)
     PinnedBuf<uint8_t> h_queries;
@@ -1966,7 +2002,7 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     if (!rc && small_rig(f)) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[1]);  // overlap partner
     for (int k = 0; k < orbf_frontend::NSETS && !rc; ++k)
         if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
-            (rc = f->rs[k].depth.reserve(cap))) break;
+            (rc = f->rs[k].depth.reserve(cap)) || (rc = f->rs[k].unx.reserve(cap)) || (rc = f->rs[k].uny.reserve(cap))) break;
     if (!rc) rc = f->h_match.reserve(cap);
     if (rc) { orbf_destroy(f); return rc; }
     *out = f;
@@ -1982,7 +2018,7 @@ void orbf_destroy(orbf_frontend* f) {
     for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->pframe[k]) orbm_frame_destroy(f->pframe[k]);  // back to the matcher's pool first
     if (f->mt) orbm_destroy(f->mt);
     for (int e = 0; e < 2; ++e) if (f->exs[e]) orbx_destroy(f->exs[e]);
-    for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); }
+    for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); f->rs[k].unx.release(); f->rs[k].uny.release(); }
     f->h_queries.release(); f->h_match.release();
     if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->ev_ready[k]) (void)hipEventDestroy(f->ev_ready[k]);
@@ -1998,6 +2034,17 @@ int orbf_set_depth(orbf_frontend* f, int cam, const float* d_depth, int stride_f
     return ORB_OK;
 }
 
+static int orbf_drain(orbf_frontend* f);
+
+int orbf_set_calibration(orbf_frontend* f, const orb_calibration* calib) {
+    MORB_ARG(f != nullptr);
+    int rc = orbf_drain(f);  // (prefetched extractions carry the old calibration in their frame sinks)
+    if (rc) return rc;
+    f->announced.clear();
+    if (calib) f->calib = *calib; else memset(&f->calib, 0, sizeof(f->calib));
+    return orbm_set_calibration(f->mt, calib);
+}
+
 int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientation) {
     MORB_ARG(f && th_high >= 0 && th_high <= 256);
     f->mbf = mbf; f->th_high = th_high; f->check_ori = check_orientation ? 1 : 0;
@@ -2006,6 +2053,7 @@ int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientati
 
 static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
                           orbf_result* out, bool queries_in_pinned);
+static int orbf_drain(orbf_frontend* f);
 
 int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out) {
     MORB_ARG(f && images && out && nq >= 0 && (nq == 0 || queries));
@@ -2048,7 +2096,8 @@ int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_moti
         if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
         const orbf_frontend::ResultSet& R = f->rs[f->cur];
         rc = orbm_queries_from_motion(R.kps.p, R.desc.p, R.depth.p, f->prev_cam_of.data(), nq, motion->du, motion->dv,
-                                      motion->th, f->scale_factors.data(), f->mbf, reinterpret_cast<orbm_query*>(f->h_queries.p));
+                                      motion->th, f->scale_factors.data(), f->mbf, reinterpret_cast<orbm_query*>(f->h_queries.p),
+                                      R.unx.p, R.uny.p);  // (mvKeysUn: equal to the keypoint positions without a calibration)
         if (rc) return rc;
     }
     return orbf_step_impl(f, images, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, flags, out, true);
@@ -2095,16 +2144,22 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     fill_cam_capacities(f, ex, cams.data());
     if (f->pframe[set] && (f->pframe_W[set] != W || f->pframe_H[set] != H)) { orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr; }
     FrameSink sink;
-    m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp;
+    float bd[4];
+    if ((rc = orbm_image_bounds(&f->calib, W, H, bd))) return rc;  // Frame::ComputeImageBounds
+    m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp; m->mirror_unx = R.unx.dp; m->mirror_uny = R.uny.dp;
+    if (f->pframe[set] && (f->pframe[set]->minX != bd[0] || f->pframe[set]->minY != bd[1] || f->pframe[set]->maxX != bd[2] ||
+                           f->pframe[set]->maxY != bd[3])) {  // (calibration changed)
+        orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr;
+    }
     if (!f->pframe[set]) {
-        rc = frame_prepare_sink(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, &f->pframe[set], &sink);
+        rc = frame_prepare_sink(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], &f->pframe[set], &sink);
         f->pframe_W[set] = W; f->pframe_H[set] = H;
     } else {
         orbm_frame* F = f->pframe[set];
         F->n_total = f->cap_total; F->counts_on_device = true; F->host_valid = false;
         rc = frame_sink_of(m, F, cams.data(), f->n_cams, f->mbf, &sink);
     }
-    m->mirror_ur = nullptr; m->mirror_depth = nullptr;
+    m->mirror_ur = nullptr; m->mirror_depth = nullptr; m->mirror_unx = nullptr; m->mirror_uny = nullptr;
     if (rc) return rc;
     if ((rc = orbx_set_frame_sink(ex, &sink))) return rc;
     const int before = orbx_pending(ex);
@@ -2118,7 +2173,7 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
         orbm_frame* frp = f->pframe[set];
         hipStream_t keep = m->stream;
         m->stream = (hipStream_t)orbx_stream(ex);
-        rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, orbx_device_counts(ex), &frp, true);
+        rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], orbx_device_counts(ex), &frp, true);
         hipError_t he = rc ? hipSuccess : hipEventRecord(f->ev_ready[set], m->stream);
         m->stream = keep;
         if (rc) return rc;
@@ -2223,10 +2278,13 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
             // the frame-build kernel mirrors the stereo arrays straight into this step's pinned result set (keypoints and
             // descriptors were mirrored by the extractor's describe kernel)
             m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp;
+            m->mirror_unx = R.unx.dp; m->mirror_uny = R.uny.dp;
             m->frame_min_rows = f->cap_total;  // every step's export block has the same size
-            rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, 0.f, 0.f, (float)W, (float)H, nullptr, &fr);
+            float bd[4];
+            rc = orbm_image_bounds(&f->calib, W, H, bd);  // Frame::ComputeImageBounds
+            if (!rc) rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], nullptr, &fr);
             m->frame_min_rows = 0;
-            m->mirror_ur = nullptr; m->mirror_depth = nullptr;
+            m->mirror_ur = nullptr; m->mirror_depth = nullptr; m->mirror_unx = nullptr; m->mirror_uny = nullptr;
             if (rc) return rc;
             fr_persistent = false;
         }
@@ -2324,6 +2382,7 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     out->n_queries = nq; out->queries = reinterpret_cast<const orbm_query*>(f->h_queries.p);
     out->n_cams = f->n_cams; out->n_total = n; out->counts = f->counts.data();
     out->kps = R.kps.p; out->desc = R.desc.p; out->uright = R.ur.p; out->depth = R.depth.p;
+    out->un_x = R.unx.p; out->un_y = R.uny.p;
     out->nmatches = nmatches; out->match_of_feature = f->h_match.p;
     out->cross_best_idx = do_cross ? m->h_c0.p : nullptr;
     out->cross_best_dist = do_cross ? m->h_c1.p : nullptr;

@@ -50,6 +50,33 @@ __device__ __forceinline__ unsigned long long wave_incl_scan(unsigned long long 
 }
 #endif
 
+// cv::undistortPoints(pts, K, dist, noArray(), K) for one point -- the OpenCV 2.4.x / 3.2 generic path as
+// Frame::UndistortKeyPoints uses it (reference src/Frame.cc:692): float parameters promoted to double, five fixed-point
+// iterations of the radial-tangential model, re-projection with P = K (the zero entries of K take part in the sums as they
+// do in OpenCV), rounded to float.  One operation sequence for host and device (no contraction on either side).
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline void morb_undistort_point(const orb_calibration& c, float xs, float ys, float* xo, float* yo) {
+    const double fx = c.fx, fy = c.fy, cx = c.cx, cy = c.cy, k1 = c.k1, k2 = c.k2, p1 = c.p1, p2 = c.p2, k3 = c.k3;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = xs, y = ys;
+    const double x0 = x = (x - cx) * ifx;
+    const double y0 = y = (y - cy) * ify;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+        const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+        const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0. * y + cx;
+    const double yy = 0. * x + fy * y + cy;
+    const double ww = 1. / (0. * x + 0. * y + 1.);
+    *xo = (float)(xx * ww); *yo = (float)(yy * ww);
+}
+
 namespace morb {
 
 void set_error(const char* fmt, ...);

@@ -51,6 +51,15 @@ class NativeFrontEnd:
     def set_depth(self, cam, d_ptr, stride_floats):
         check(_lib.lib().orbf_set_depth(self._h, cam, C.c_void_p(d_ptr) if d_ptr else None, stride_floats))
 
+    def set_calibration(self, calib):
+        """calib = (fx, fy, cx, cy, k1, k2, p1, p2[, k3]) or None (orbf_set_calibration)."""
+        from ._lib import Calibration
+        if calib is None:
+            check(_lib.lib().orbf_set_calibration(self._h, None))
+        else:
+            c = Calibration(*(list(calib) + [0.0] * (9 - len(calib))))
+            check(_lib.lib().orbf_set_calibration(self._h, C.byref(c)))
+
     def configure(self, mbf=40.0, th_high=100, check_orientation=True):
         check(_lib.lib().orbf_configure(self._h, mbf, th_high, int(check_orientation)))
 
@@ -115,7 +124,8 @@ class NativeFrontEnd:
         V = self._cached
         out = dict(counts=V("counts", r.counts, np.int32, self.n_cams).tolist(), kps=cp(V("kps", r.kps, KP_DTYPE, cap)[:n]),
                    desc=cp(V("desc", r.desc, np.uint8, cap, 32)[:n]), uright=cp(V("ur", r.uright, np.float32, cap)[:n]),
-                   depth=cp(V("depth", r.depth, np.float32, cap)[:n]), n_temporal=r.nmatches,
+                   depth=cp(V("depth", r.depth, np.float32, cap)[:n]), un_x=cp(V("unx", r.un_x, np.float32, cap)[:n]),
+                   un_y=cp(V("uny", r.un_y, np.float32, cap)[:n]), n_temporal=r.nmatches,
                    match_of_feature=cp(V("match", r.match_of_feature, np.int32, cap)[:n]) if nq else np.zeros(0, np.int32),
                    gpu_wait_us=r.gpu_wait_us, host_us=tuple(r.host_us), n_queries=nq)
         if r.cross_best_idx:

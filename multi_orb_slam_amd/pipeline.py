@@ -37,12 +37,16 @@ def make_queries(prev, scale_factors):
     Host-only C helper (orbm_queries_from_motion), shared by the GPU leg and the CPU-oracle leg of the benchmark."""
     from . import _lib
     from ._lib import ptr
-    k, d, depth, cam_of = prev
+    k, d, depth, cam_of = prev[:4]
+    un = prev[4:6] if len(prev) >= 6 else (None, None)   # undistorted positions (mvKeysUn), when a calibration is in use
     n = len(k)
     q = np.empty(n, QUERY_DTYPE)
     sf = np.ascontiguousarray(scale_factors, np.float32)
+    unx = np.ascontiguousarray(un[0], np.float32) if un[0] is not None else None
+    uny = np.ascontiguousarray(un[1], np.float32) if un[1] is not None else None
     _lib.check(_lib.lib().orbm_queries_from_motion(ptr(k), ptr(d), ptr(depth), ptr(cam_of), n, MOTION[0], MOTION[1], TH_PROJ,
-                                                   ptr(sf), MBF, ptr(q)))
+                                                   ptr(sf), MBF, ptr(q), ptr(unx) if unx is not None else None,
+                                                   ptr(uny) if uny is not None else None))
     return q
 
 
@@ -54,7 +58,7 @@ def accept_cross(best_dist, second_dist):
 class FrontEnd:
     """The front end of the cameras owned by this process (one process per GPU), on the native orbf_step entry."""
 
-    def __init__(self, params_per_cam, width, height, device=0, rank=0, world_size=1, gather=None, global_cams=None):
+    def __init__(self, params_per_cam, width, height, device=0, rank=0, world_size=1, gather=None, global_cams=None, calib=None):
         from .frontend import NativeFrontEnd
         from .extractor import tables
         self.params = list(params_per_cam); self.n_cams = len(self.params)
@@ -65,6 +69,8 @@ class FrontEnd:
         rt.set_device(device)
         self.fe = NativeFrontEnd(self.params, width, height, device)
         self.fe.configure(MBF, 100, True)
+        if calib is not None:
+            self.fe.set_calibration(calib)   # (fx, fy, cx, cy, k1, k2, p1, p2[, k3]): undistortion as the reference's Frame does it
         self.caps = [p.nfeatures + 4 * p.nlevels for p in self.params]
         self.cap = max(self.caps)
         self.scale = tables(self.params[0])["scale"]

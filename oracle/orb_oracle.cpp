@@ -826,15 +826,60 @@ int orc_extract(const uint8_t* img, int W, int H, int stride, int nfeatures, flo
 
 int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
 
-// Frame::ComputeStereoFromRGBD (src/Frame.cc:959-986): depth lookup at (int)v,(int)u, virtual right coordinate.
-// Undistorted x == distorted x (k1 == 0, src/Frame.cc:676-680).
+// cv::undistortPoints(src, dst, K, distCoeffs, noArray(), K) as Frame::UndistortKeyPoints calls it (src/Frame.cc:692):
+// the OpenCV 2.4.x / 3.2 generic path (modules/imgproc/src/undistort.cpp, cvUndistortPoints) restated -- K and the
+// distortion vector are CV_32F in the reference (src/Tracking.cc) and are promoted to double, the point is promoted to
+// double, normalised, run through FIVE fixed-point iterations of the radial-tangential model (k4..k6 and the thin-prism
+// terms are zero for the reference's 4/5-element vector, so the numerator of icdist is exactly 1), re-projected with
+// P = K (R = I, so ww == 1) and rounded to float.  calib = {fx, fy, cx, cy, k1, k2, p1, p2, k3} as floats.
+static void undistort_point(const float* calib, float xs, float ys, float* xo, float* yo) {
+    const double fx = calib[0], fy = calib[1], cx = calib[2], cy = calib[3];
+    const double k1 = calib[4], k2 = calib[5], p1 = calib[6], p2 = calib[7], k3 = calib[8];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = xs, y = ys;
+    const double x0 = x = (x - cx) * ifx;
+    const double y0 = y = (y - cy) * ify;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+        const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+        const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0. * y + cx;   // RR = K * I: the zero entries take part in the sum as they do in OpenCV
+    const double yy = 0. * x + fy * y + cy;
+    const double ww = 1. / (0. * x + 0. * y + 1.);
+    *xo = (float)(xx * ww); *yo = (float)(yy * ww);
+}
+
+// Frame::UndistortKeyPoints (src/Frame.cc:673-705): a plain copy when k1 == 0.
+void orc_undistort_points(const float* calib, const float* x, const float* y, int n, float* ux, float* uy) {
+    for (int i = 0; i < n; i++) {
+        if (calib == nullptr || calib[4] == 0.0f) { ux[i] = x[i]; uy[i] = y[i]; }
+        else undistort_point(calib, x[i], y[i], &ux[i], &uy[i]);
+    }
+}
+
+// Frame::ComputeImageBounds (src/Frame.cc:743-778): out = {minX, minY, maxX, maxY}.
+void orc_image_bounds(const float* calib, int cols, int rows, float* out4) {
+    if (calib == nullptr || calib[4] == 0.0f) { out4[0] = 0.f; out4[1] = 0.f; out4[2] = (float)cols; out4[3] = (float)rows; return; }
+    const float cx[4] = {0.f, (float)cols, 0.f, (float)cols}, cy[4] = {0.f, 0.f, (float)rows, (float)rows};
+    float ux[4], uy[4];
+    for (int i = 0; i < 4; i++) undistort_point(calib, cx[i], cy[i], &ux[i], &uy[i]);
+    out4[0] = std::min(ux[0], ux[2]); out4[2] = std::max(ux[1], ux[3]);
+    out4[1] = std::min(uy[0], uy[1]); out4[3] = std::max(uy[2], uy[3]);
+}
+
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:959-986): depth lookup at (int)v,(int)u of the DISTORTED keypoint, virtual
+// right coordinate from the UNDISTORTED x (un_x == NULL: k1 == 0, undistorted == distorted, src/Frame.cc:676-680).
 void orc_stereo_from_depth(const KeyPoint* kps, int n, const float* depth, int stride, float mbf, float* uright,
-                           float* depth_out) {
+                           float* depth_out, const float* un_x) {
     for (int i = 0; i < n; i++) {
         uright[i] = -1; depth_out[i] = -1;
         const float v = kps[i].y, u = kps[i].x;
         const float d = depth[(size_t)(int)v * stride + (int)u];
-        if (d > 0) { depth_out[i] = d; uright[i] = kps[i].x - mbf / d; }
+        if (d > 0) { depth_out[i] = d; uright[i] = (un_x ? un_x[i] : kps[i].x) - mbf / d; }
     }
 }
 

@@ -206,13 +206,42 @@ def descriptor_distance(a, b):
     return lib().orc_descriptor_distance(_p(a), _p(b))
 
 
-def stereo_from_depth(kps, depth, mbf):
+def stereo_from_depth(kps, depth, mbf, un_x=None):
     kps = np.ascontiguousarray(kps, KP_DTYPE); depth = np.ascontiguousarray(depth, np.float32)
     ur = np.zeros(len(kps), np.float32); dd = np.zeros(len(kps), np.float32)
+    if un_x is not None:
+        un_x = np.ascontiguousarray(un_x, np.float32)
     L = lib()
-    L.orc_stereo_from_depth.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
-    L.orc_stereo_from_depth(_p(kps), len(kps), _p(depth), depth.shape[1], mbf, _p(ur), _p(dd))
+    L.orc_stereo_from_depth.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_stereo_from_depth(_p(kps), len(kps), _p(depth), depth.shape[1], mbf, _p(ur), _p(dd), _p(un_x) if un_x is not None else None)
     return ur, dd
+
+
+def calib_array(calib):
+    """(fx, fy, cx, cy, k1, k2, p1, p2[, k3]) -> float32[9] (the reference holds K and DistCoef as CV_32F)."""
+    c = list(calib) + [0.0] * (9 - len(calib))
+    return np.array(c, np.float32)
+
+
+def undistort_points(calib, x, y):
+    """Frame::UndistortKeyPoints: cv::undistortPoints(pts, K, dist, noArray(), K); a copy when k1 == 0 or calib is None."""
+    x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+    ux = np.zeros_like(x); uy = np.zeros_like(y)
+    c = calib_array(calib) if calib is not None else None
+    L = lib()
+    L.orc_undistort_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_undistort_points(_p(c) if c is not None else None, _p(x), _p(y), len(x), _p(ux), _p(uy))
+    return ux, uy
+
+
+def image_bounds(calib, cols, rows):
+    """Frame::ComputeImageBounds -> (minX, minY, maxX, maxY)."""
+    out = np.zeros(4, np.float32)
+    c = calib_array(calib) if calib is not None else None
+    L = lib()
+    L.orc_image_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.orc_image_bounds(_p(c) if c is not None else None, cols, rows, _p(out))
+    return tuple(float(v) for v in out)
 
 
 def bf_top2(q, r):

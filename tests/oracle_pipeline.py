@@ -6,10 +6,11 @@ from multi_orb_slam_amd import pipeline as P
 
 
 class OracleFrontEnd:
-    def __init__(self, params_per_cam, width, height, global_cams=None, cam_threads=False):
+    def __init__(self, params_per_cam, width, height, global_cams=None, cam_threads=False, calib=None):
         """cam_threads: extract the cameras (and match them across cameras) on one host thread each -- the variant ORB-SLAM2
         upstream uses for stereo (reference src/Frame.cc:106-109, commented out there); results are identical."""
         self.params = list(params_per_cam); self.n_cams = len(self.params)
+        self.calib = calib
         self.pool = None
         if cam_threads and self.n_cams > 1:
             from concurrent.futures import ThreadPoolExecutor
@@ -29,24 +30,26 @@ class OracleFrontEnd:
         counts = [len(k) for k, _ in per_cam]
         cat = np.concatenate
         kps = cat([k for k, _ in per_cam]); desc = cat([d for _, d in per_cam])
-        st = [oracle.stereo_from_depth(k, self.depth[c], P.MBF) for c, (k, _) in enumerate(per_cam)]
+        un_x, un_y = oracle.undistort_points(self.calib, kps["x"], kps["y"])           # Frame::UndistortKeyPoints
+        bounds = oracle.image_bounds(self.calib, self.width, self.height)               # Frame::ComputeImageBounds
+        off = np.concatenate([[0], np.cumsum(counts)])
+        st = [oracle.stereo_from_depth(k, self.depth[c], P.MBF, un_x[off[c]:off[c + 1]]) for c, (k, _) in enumerate(per_cam)]
         uright = cat([a for a, _ in st]); depth = cat([b for _, b in st])
         cam_of = np.repeat(np.arange(self.n_cams, dtype=np.int32), counts)
         n_temporal = 0; match_of = np.zeros(0, np.int32)
         if self.prev is not None and len(kps) > 0:
-            fr = oracle.FrameData(kps["x"], kps["y"], kps["octave"], kps["angle"], uright, cam_of,
-                                  cat([np.arange(n, dtype=np.int32) for n in counts]), [d for _, d in per_cam],
-                                  (0, 0, self.width, self.height))
+            fr = oracle.FrameData(un_x, un_y, kps["octave"], kps["angle"], uright, cam_of,
+                                  cat([np.arange(n, dtype=np.int32) for n in counts]), [d for _, d in per_cam], bounds)
             q = P.make_queries(self.prev, self.scale)
             n_temporal, match_of = oracle.search_by_projection_frames(fr, q, 100, True)
-        self.prev = (kps, desc, depth, cam_of)
+        self.prev = (kps, desc, depth, cam_of, un_x, un_y)
         def cross(c):
             others = other_descs(c) if other_descs is not None else [per_cam[o][1] for o in range(self.n_cams) if o != c]
             refs = cat(others) if others else np.zeros((0, 32), np.uint8)
             return oracle.bf_top2(per_cam[c][1], refs)
         res = list(self.pool.map(cross, range(self.n_cams))) if self.pool else [cross(c) for c in range(self.n_cams)]
         bi, bd, sd = cat([r[0] for r in res]), cat([r[1] for r in res]), cat([r[2] for r in res])
-        return dict(kps=kps, desc=desc, uright=uright, depth=depth, counts=counts, n_temporal=n_temporal,
+        return dict(kps=kps, desc=desc, uright=uright, depth=depth, un_x=un_x, un_y=un_y, counts=counts, n_temporal=n_temporal,
                     match_of_feature=match_of, cross=(bi, bd, sd), n_cross=int(P.accept_cross(bd, sd).sum()))
 
 
@@ -56,6 +59,7 @@ def assert_same_step(a, b):
     assert a["kps"].tobytes() == b["kps"].tobytes(), "keypoints differ"
     assert np.array_equal(a["desc"], b["desc"]), "descriptors differ"
     assert a["uright"].tobytes() == b["uright"].tobytes() and a["depth"].tobytes() == b["depth"].tobytes(), "stereo differs"
+    assert a["un_x"].tobytes() == b["un_x"].tobytes() and a["un_y"].tobytes() == b["un_y"].tobytes(), "undistorted positions differ"
     assert a["n_temporal"] == b["n_temporal"], (a["n_temporal"], b["n_temporal"])
     assert np.array_equal(a["match_of_feature"], b["match_of_feature"]), "temporal matches differ"
     for u, v in zip(a["cross"], b["cross"]):

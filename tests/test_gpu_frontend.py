@@ -66,6 +66,34 @@ def test_overlapped_steps_equal_oracle_pipeline(w, h, nfs, resident, depth):
     fe.close()
 
 
+@pytest.mark.parametrize("overlap,host_tree", [(False, False), (True, False), (False, True)])
+def test_reference_calibration_undistorts_as_the_reference_frame_does(overlap, host_tree, monkeypatch):
+    """OtherFiles/multi.yaml's calibration (k1 != 0): keypoints undistorted with cv::undistortPoints' iteration, image
+    bounds from the undistorted corners, uRight from the undistorted x, depth read at the distorted pixel -- on the
+    device, against the oracle's restatement of Frame::UndistortKeyPoints / ComputeImageBounds / ComputeStereoFromRGBD."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    from test_oracle_undistort import MULTI_YAML
+    if host_tree:   # the synchronous path assembles the frame in the matcher's own kernel (k_frame_build_small) instead
+        monkeypatch.setenv("MORB_HOST_OCTREE", "1")
+    params = [m.ExtractorParams(nfeatures=1000), m.ExtractorParams(nfeatures=500)]       # Tracking.cc:144-145
+    fe = pipeline.FrontEnd(params, 640, 480, calib=MULTI_YAML)
+    ofe = OracleFrontEnd(params, 640, 480, calib=MULTI_YAML)
+    frames = [[synth.image(c, t, 640, 480) for c in range(2)] for t in range(5)]
+    for t in range(5):
+        got = fe.step(frames[t], next_images=frames[t + 1] if overlap and t + 1 < 5 else None)
+        assert_same_step(got, ofe.step(frames[t]))
+    assert np.abs(got["un_x"] - got["kps"]["x"]).max() > 0.5 and got["n_temporal"] > 100
+    fe.fe.set_calibration(None); ofe.calib = None                                       # and off again
+    for t in range(2):
+        got = fe.step(frames[t]); exp = ofe.step(frames[t])
+        if t == 1:
+            assert_same_step(got, exp)
+    assert np.array_equal(got["un_x"], got["kps"]["x"])
+    fe.close()
+
+
 def test_overlap_survives_the_host_quadtree_fallback():
     """Noise frames put more than 4096 candidates on level 0: the device quadtree reports 'outside my limits' and the step
     is redone on the host path -- with the next step's extraction already in flight its images have to be uploaded again."""
