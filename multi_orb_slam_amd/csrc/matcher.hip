@@ -735,6 +735,9 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         }
         __syncthreads();
         const int nres = s_nres;
+#ifdef MORB_PHASE_CLOCKS
+        if (tid == 0 && it < 15) g_ph_res[40 + it] = (unsigned long long)nres;
+#endif
         for (int r = wave; r < nres; r += nwaves) {
             // full candidate list of query i, 64 candidates per round, keys (distance << 16 | visiting position): the
             // smallest available key is the sequential scan's first minimum, the next one its runner-up
