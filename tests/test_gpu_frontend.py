@@ -166,3 +166,61 @@ def test_native_step_with_an_empty_camera():
     bi, bd, sd = r["cross"]
     assert (bi == -1).all() and (bd == 256).all()        # nothing to match against
     fe.close()
+
+
+def test_full_size_rig_properties():
+    """configs[4]: 8 synthetic 1920x1080 streams, 4000 features per camera, through the native front end (the > 4-camera
+    path: host quadtree for the dense levels, multi-kernel frame assembly, 32k-feature searches).  The oracle needs
+    seconds per camera at this size, so it pins ONE camera; the rest is checked through size-independent properties."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd.frontend import NativeFrontEnd
+    from multi_orb_slam_amd import pipeline
+    import oracle
+    W, H, NF, NC = 1920, 1080, 4000, 8
+    params = [m.ExtractorParams(nfeatures=NF)] * NC
+    frames = [[synth.image(c, t, W, H) for c in range(NC)] for t in range(2)]
+
+    def run():
+        fe = NativeFrontEnd(params, W, H)
+        out = [fe.step(frames[t], motion=(pipeline.MOTION[0], pipeline.MOTION[1], pipeline.TH_PROJ)) for t in range(2)]
+        fe.close()
+        return out
+
+    a = run()
+    r0, r1 = a
+    counts = r1["counts"]
+    assert len(counts) == NC and all(NF * 0.95 < c <= NF + 32 for c in counts)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    # (1) one camera against the oracle at full size, (2) batch independence: a single-camera extractor gives the same
+    okps, odesc = oracle.extract(frames[1][3], nfeatures=NF)
+    assert r1["kps"][off[3]:off[4]].tobytes() == okps.tobytes() and np.array_equal(r1["desc"][off[3]:off[4]], odesc)
+    ex = m.Extractor([params[0]], W, H)
+    k6, d6 = ex.extract([frames[1][6]])[0]
+    ex.close()
+    assert r1["kps"][off[6]:off[7]].tobytes() == k6.tobytes() and np.array_equal(r1["desc"][off[6]:off[7]], d6)
+    # (3) cross-camera top-2 of a sample of features == popcount over every other camera's descriptors
+    desc = r1["desc"]; bi, bd, sd = r1["cross"]
+    rng = np.random.RandomState(3)
+    for g in rng.choice(len(desc), 60, replace=False):
+        c = int(np.searchsorted(off, g, side="right") - 1)
+        others = np.concatenate([desc[:off[c]], desc[off[c + 1]:]])
+        d = np.unpackbits(others ^ desc[g], axis=1).sum(1)
+        o = np.argsort(d, kind="stable")
+        assert bd[g] == d[o[0]] and sd[g] == d[o[1]] and bi[g] == o[0]
+    # (4) temporal matches: claimed pairs respect TH_HIGH, the level window and the search radius
+    q = pipeline.make_queries((r0["kps"], r0["desc"], r0["depth"], np.repeat(np.arange(NC, dtype=np.int32), r0["counts"])),
+                              oracle.tables(NF)["scale"])
+    mo = r1["match_of_feature"]
+    hit = np.nonzero(mo >= 0)[0]
+    assert len(hit) == r1["n_temporal"] and len(hit) > 0.5 * len(mo)
+    for g in hit[:: max(1, len(hit) // 300)]:
+        Q = q[mo[g]]; k = r1["kps"][g]
+        assert np.unpackbits(Q["desc"] ^ desc[g]).sum() <= 100
+        assert abs(k["x"] - Q["u"]) < Q["radius"] and abs(k["y"] - Q["v"]) < Q["radius"]
+        assert Q["min_level"] <= k["octave"] <= Q["max_level"]
+        assert Q["cam"] == int(np.searchsorted(off, g, side="right") - 1)
+    # (5) determinism: a second front end reproduces every byte
+    b = run()
+    for x, y in zip(a, b):
+        assert x["kps"].tobytes() == y["kps"].tobytes() and np.array_equal(x["desc"], y["desc"])
+        assert np.array_equal(x["match_of_feature"], y["match_of_feature"]) and all(np.array_equal(u, v) for u, v in zip(x["cross"], y["cross"]))
