@@ -102,6 +102,9 @@ int orbx_debug_candidates(orbx_extractor* ex, int cam, int level, orb_keypoint* 
  * candidates (x, y relative to (16,16), integral; response); runs without a GPU.  *n_out may exceed cap. */
 int orbx_debug_distribute_octree(const orb_keypoint* in, int n, int min_x, int max_x, int min_y, int max_y,
                                  int n_features, orb_keypoint* out, int cap, int* n_out);
+/* inspection: which keypoint-distribution path produced the last finished run -- 0 device quadtree, 1 device quadtree
+ * including the memory-backed pass for levels beyond 4096 candidates, 2 host quadtree (fallback / MORB_HOST_OCTREE=1) */
+int orbx_debug_last_path(const orbx_extractor* ex);
 int orbx_set_profiling(orbx_extractor* ex, int on);
 int orbx_stage_times_us(const orbx_extractor* ex, float* out6);
 

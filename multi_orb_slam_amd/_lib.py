@@ -117,6 +117,7 @@ def lib():
     L.orbm_frame_from_device.argtypes = [vp, vp, i32, f32, f32, f32, f32, f32, vp]
     L.orbm_frame_download.argtypes = [vp, vp, vp, vp, vp, vp]
     L.orbm_frame_count.argtypes = [vp]
+    L.orbx_debug_last_path.argtypes = [vp]
     L.orbf_create.argtypes = [vp, i32, i32, i32, i32, vp]
     L.orbf_destroy.argtypes = [vp]; L.orbf_destroy.restype = None
     L.orbf_set_depth.argtypes = [vp, i32, vp, i32]

@@ -395,26 +395,54 @@ __device__ __forceinline__ int oct_child(int x, int y, int ulx, int uly, int brx
     return (x < midx ? 0 : 1) + (y < midy ? 0 : 2);
 }
 
+// Key storage of the quadtree.  Up to OCT_NK candidates live in LDS (OctLds); levels beyond that (dense 1080p levels) run
+// the SAME code with the key arrays and the packed prefix in an HBM workspace (BIG: up to OCT_NKB candidates, L2-resident,
+// a few times slower per pass -- still two orders of magnitude ahead of the host round trip it replaces).
+constexpr int OCT_NKB = 16384;
+struct OctBig {            // workspace slice of one (camera, level) block
+    unsigned short *kx, *ky, *kn;   // [2][OCT_NKB] each
+    unsigned char* kr;              // [2][OCT_NKB]
+    unsigned long long* S;          // [OCT_NKB]
+};
+constexpr size_t OCT_BIG_BYTES = (size_t)OCT_NKB * (3 * 2 * 2 + 2 * 1 + 8);  // per block
+__device__ __forceinline__ OctBig oct_big_slice(unsigned char* ws, int blk) {
+    unsigned char* p = ws + (size_t)blk * OCT_BIG_BYTES;
+    OctBig B;
+    B.S = reinterpret_cast<unsigned long long*>(p); p += (size_t)OCT_NKB * 8;
+    B.kx = reinterpret_cast<unsigned short*>(p); p += (size_t)OCT_NKB * 4;
+    B.ky = reinterpret_cast<unsigned short*>(p); p += (size_t)OCT_NKB * 4;
+    B.kn = reinterpret_cast<unsigned short*>(p); p += (size_t)OCT_NKB * 4;
+    B.kr = p;
+    return B;
+}
+#define KX(a, p) (*(BIG ? &G.kx[(a) * OCT_NKB + (p)] : &L.kx[a][p]))
+#define KY(a, p) (*(BIG ? &G.ky[(a) * OCT_NKB + (p)] : &L.ky[a][p]))
+#define KN(a, p) (*(BIG ? &G.kn[(a) * OCT_NKB + (p)] : &L.kn[a][p]))
+#define KR(a, p) (*(BIG ? &G.kr[(a) * OCT_NKB + (p)] : &L.kr[a][p]))
+#define KS(p) (*(BIG ? &G.S[p] : &L.S[p]))
+
 // One split pass over the parents listed in L.P[0..np) (processing order), used by the careful phase.  The caller has
 // set L.procidx[node] = t for exactly those parents (0xffff for every other node).  `a` = current buffer, list size
 // `sz`.  Returns the new size; *n_expand = number of new children holding > 1 keypoint.
-__device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, int* n_expand) {
+template <bool BIG>
+__device__ int oct_split_pass(OctLds& L, const OctBig& G, int a, int n, int sz, int np, int tid, int* n_expand) {
     const int b = a ^ 1;
     const int lane = tid & 63, wave = tid >> 6;
     // classify + packed inclusive prefix over the key positions (4 keys per thread, blocked)
     {
-        unsigned long long loc[4];
+        constexpr int PER = BIG ? OCT_NKB / 1024 : OCT_NK / 1024;  // keys per thread, blocked
+        unsigned long long loc[PER];
         unsigned long long run = 0;
-        const int p0 = tid * 4;
+        const int p0 = tid * PER;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int pos = p0 + k;
             unsigned long long one = 0;
             if (pos < n) {
-                const int node = L.kn[a][pos];
+                const int node = KN(a, pos);
                 if (L.procidx[node] != 0xffff) {
                     int mx, my;
-                    const int c = oct_child(L.kx[a][pos], L.ky[a][pos], L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
+                    const int c = oct_child(KX(a, pos), KY(a, pos), L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
                     one = 1ull << (16 * c);
                 }
             }
@@ -429,7 +457,7 @@ __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, 
         for (int w = 0; w < wave; ++w) base += wsum64[w];
         base += incl - run;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (p0 + k < n) L.S[p0 + k] = base + loc[k];
+        for (int k = 0; k < PER; ++k) if (p0 + k < n) KS(p0 + k) = base + loc[k];
     }
     __syncthreads();
     // thread tid is parent t = tid (child counts) AND list node tid (survivor?): both ride in one packed scan
@@ -437,7 +465,7 @@ __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, 
     if (tid < np) {
         const int node = L.P[tid];
         const int kb = L.nb[a][node], ke = L.ne[a][node];
-        tot = L.S[ke - 1] - (kb ? L.S[kb - 1] : 0ull);
+        tot = KS(ke - 1) - (kb ? KS(kb - 1) : 0ull);
         int nch = 0, nex = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const int cnt = (int)((tot >> (16 * c)) & 0xffff); nch += cnt ? 1 : 0; nex += cnt > 1 ? 1 : 0; }
@@ -485,17 +513,17 @@ __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, 
     __syncthreads();
     // keys: stable 4-way partition inside every split node, others stay where they are
     for (int pos = tid; pos < n; pos += 1024) {
-        const int node = L.kn[a][pos];
+        const int node = KN(a, pos);
         const int t = L.procidx[node];
         int npos = pos, nnode;
-        const int x = L.kx[a][pos], y = L.ky[a][pos];
+        const int x = KX(a, pos), y = KY(a, pos);
         if (t != 0xffff) {
             int mx, my;
             const int c = oct_child(x, y, L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
             const unsigned long long cnts = L.pc[t];
             const int kb = L.nb[a][node];
-            const unsigned long long bef = kb ? L.S[kb - 1] : 0ull;
-            const int rank = (int)(((L.S[pos] - bef) >> (16 * c)) & 0xffff) - 1;
+            const unsigned long long bef = kb ? KS(kb - 1) : 0ull;
+            const int rank = (int)(((KS(pos) - bef) >> (16 * c)) & 0xffff) - 1;
             int off = 0, ne_before = 0;
             for (int c2 = 0; c2 < c; ++c2) { const int cc = (int)((cnts >> (16 * c2)) & 0xffff); off += cc; ne_before += cc ? 1 : 0; }
             npos = kb + off + rank;
@@ -503,8 +531,8 @@ __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, 
         } else {
             nnode = L.newpos[node];
         }
-        L.kx[b][npos] = (unsigned short)x; L.ky[b][npos] = (unsigned short)y; L.kr[b][npos] = L.kr[a][pos];
-        L.kn[b][npos] = (unsigned short)nnode;
+        KX(b, npos) = (unsigned short)x; KY(b, npos) = (unsigned short)y; KR(b, npos) = KR(a, pos);
+        KN(b, npos) = (unsigned short)nnode;
     }
     __syncthreads();
     *n_expand = nexp;
@@ -515,23 +543,25 @@ __device__ int oct_split_pass(OctLds& L, int a, int n, int sz, int np, int tid, 
 // for processing order == list order.  A parent is addressed by its own list index, so no parent list and no
 // node -> parent map are built, and the three block scans (children, survivors, expandable children) ride in one packed
 // 64-bit scan: 6 barriers instead of 17, which is what a pass costs (every phase is an LDS dependency chain).
-__device__ int oct_split_full(OctLds& L, int a, int n, int sz, int tid, int* n_expand) {
+template <bool BIG>
+__device__ int oct_split_full(OctLds& L, const OctBig& G, int a, int n, int sz, int tid, int* n_expand) {
     const int b = a ^ 1;
     const int lane = tid & 63, wave = tid >> 6;
     // classify + packed inclusive prefix over the key positions (4 keys per thread, blocked)
     {
-        unsigned long long loc[4];
+        constexpr int PER = BIG ? OCT_NKB / 1024 : OCT_NK / 1024;  // keys per thread, blocked
+        unsigned long long loc[PER];
         unsigned long long run = 0;
-        const int p0 = tid * 4;
+        const int p0 = tid * PER;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int pos = p0 + k;
             unsigned long long one = 0;
             if (pos < n) {
-                const int node = L.kn[a][pos];
+                const int node = KN(a, pos);
                 if (!(L.nfl[a][node] & 1)) {
                     int mx, my;
-                    const int c = oct_child(L.kx[a][pos], L.ky[a][pos], L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
+                    const int c = oct_child(KX(a, pos), KY(a, pos), L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
                     one = 1ull << (16 * c);
                 }
             }
@@ -545,7 +575,7 @@ __device__ int oct_split_full(OctLds& L, int a, int n, int sz, int tid, int* n_e
         for (int w = 0; w < wave; ++w) base += wsum64[w];
         base += incl - run;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (p0 + k < n) L.S[p0 + k] = base + loc[k];
+        for (int k = 0; k < PER; ++k) if (p0 + k < n) KS(p0 + k) = base + loc[k];
     }
     __syncthreads();
     // per node: child counts; {children, survivor, expandable children, parent} packed into one scan
@@ -555,7 +585,7 @@ __device__ int oct_split_full(OctLds& L, int a, int n, int sz, int tid, int* n_e
         if (!(L.nfl[a][tid] & 1)) {
             parent = true;
             const int kb = L.nb[a][tid], ke = L.ne[a][tid];
-            tot = L.S[ke - 1] - (kb ? L.S[kb - 1] : 0ull);
+            tot = KS(ke - 1) - (kb ? KS(kb - 1) : 0ull);
             int nch = 0, nex = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) { const int cnt = (int)((tot >> (16 * c)) & 0xffff); nch += cnt ? 1 : 0; nex += cnt > 1 ? 1 : 0; }
@@ -604,16 +634,16 @@ __device__ int oct_split_full(OctLds& L, int a, int n, int sz, int tid, int* n_e
     __syncthreads();
     // keys: stable 4-way partition inside every split node, others stay where they are
     for (int pos = tid; pos < n; pos += 1024) {
-        const int node = L.kn[a][pos];
+        const int node = KN(a, pos);
         int npos = pos, nnode;
-        const int x = L.kx[a][pos], y = L.ky[a][pos];
+        const int x = KX(a, pos), y = KY(a, pos);
         if (!(L.nfl[a][node] & 1)) {
             int mx, my;
             const int c = oct_child(x, y, L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
             const unsigned long long cnts = L.pc[node];
             const int kb = L.nb[a][node];
-            const unsigned long long bef = kb ? L.S[kb - 1] : 0ull;
-            const int rank = (int)(((L.S[pos] - bef) >> (16 * c)) & 0xffff) - 1;
+            const unsigned long long bef = kb ? KS(kb - 1) : 0ull;
+            const int rank = (int)(((KS(pos) - bef) >> (16 * c)) & 0xffff) - 1;
             int off = 0, ne_before = 0;
             for (int c2 = 0; c2 < c; ++c2) { const int cc = (int)((cnts >> (16 * c2)) & 0xffff); off += cc; ne_before += cc ? 1 : 0; }
             npos = kb + off + rank;
@@ -621,23 +651,31 @@ __device__ int oct_split_full(OctLds& L, int a, int n, int sz, int tid, int* n_e
         } else {
             nnode = L.newpos[node];
         }
-        L.kx[b][npos] = (unsigned short)x; L.ky[b][npos] = (unsigned short)y; L.kr[b][npos] = L.kr[a][pos];
-        L.kn[b][npos] = (unsigned short)nnode;
+        KX(b, npos) = (unsigned short)x; KY(b, npos) = (unsigned short)y; KR(b, npos) = KR(a, pos);
+        KN(b, npos) = (unsigned short)nnode;
     }
     __syncthreads();
     *n_expand = nexp;
     return M + (sz - np);
 }
 
-// status: 0 ok, 1 = outside the device limits (host falls back)
+// status: 0 ok, 1 = outside the device limits (host falls back), 2 = more candidates than the LDS layout holds but within
+// the reach of the BIG pass (k_octree<true>, launched behind this one when the stream has needed it before; it only
+// touches the blocks flagged 2).
 // The candidates are read straight from the per-cell slots k_fast_cells filled (cell-major, row-major inside a cell: the
 // order the reference hands them to DistributeOctTree), so no separate compaction kernel sits between them.
+template <bool BIG>
 __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ Lv_all, const int* __restrict__ cell_cnt,
                                                  const uint32_t* __restrict__ cell_items, SelKp* __restrict__ sel,
-                                                 int* __restrict__ sel_cnt, int* __restrict__ status, int max_levels) {
+                                                 int* __restrict__ sel_cnt, int* __restrict__ status, int max_levels,
+                                                 unsigned char* __restrict__ big_ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char oct_raw[];
     OctLds& L = *reinterpret_cast<OctLds*>(oct_raw);
     const int blk = blockIdx.x, tid = threadIdx.x;
+    if (BIG && status[blk] != 2) return;
+    OctBig G{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (BIG) G = oct_big_slice(big_ws, blk);
+    constexpr int NKEYS = BIG ? OCT_NKB : OCT_NK;
     MORB_PHASE(g_ph_oct, 0);
     const LevelInfo Lv = Lv_all[blk];
     const int N = Lv.quota;
@@ -659,8 +697,9 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
     if (n == 0) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 0; } return; }
     const int width = Lv.w - 2 * MIN_BORDER, height = Lv.h - 2 * MIN_BORDER;
     const int nIni = max(1, (int)roundf((float)width / (float)height));
-    if (n > OCT_NK || N + 4 > OCT_NL || nIni > 4 || width >= 32768 || height >= 32768) {
-        if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; }
+    if (n > NKEYS || N + 4 > OCT_NL || nIni > 4 || width >= 32768 || height >= 32768) {
+        const bool retry_big = !BIG && n <= OCT_NKB && N + 4 <= OCT_NL && nIni <= 4 && width < 32768 && height < 32768;
+        if (tid == 0) { sel_cnt[blk] = 0; status[blk] = retry_big ? 2 : 1; }
         return;
     }
     MORB_PHASE(g_ph_oct, 1);
@@ -677,24 +716,25 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                 if (cell_off[mid] <= p) lo = mid; else hi = mid;
             }
             const uint32_t v = cell_items[Lv.slot_base + (size_t)lo * Lv.slot_cap + (p - cell_off[lo])];
-            L.kx[1][p] = (unsigned short)(v & 0xfff); L.ky[1][p] = (unsigned short)((v >> 12) & 0xfff);
-            L.kr[1][p] = (unsigned char)(v >> 24);
+            KX(1, p) = (unsigned short)(v & 0xfff); KY(1, p) = (unsigned short)((v >> 12) & 0xfff);
+            KR(1, p) = (unsigned char)(v >> 24);
         }
         __syncthreads();
     }
     MORB_PHASE(g_ph_oct, 2);
     // ---- roots (:544-585): vertical strips, keypoints dealt by (int)(x / hX), empty roots dropped, order = strip order
     {
-        unsigned long long loc[4], run = 0;
-        int rx[4], ry[4], rr[4];
-        const int p0 = tid * 4;
+        constexpr int PER = NKEYS / 1024;  // keys per thread, blocked
+        unsigned long long loc[PER], run = 0;
+        int rx[PER], ry[PER], rr[PER];
+        const int p0 = tid * PER;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int pos = p0 + k;
             unsigned long long one = 0;
             rx[k] = ry[k] = rr[k] = 0;
             if (pos < n) {
-                rx[k] = L.kx[1][pos]; ry[k] = L.ky[1][pos];
+                rx[k] = KX(1, pos); ry[k] = KY(1, pos);
                 int r = (int)((float)rx[k] / hX);
                 r = min(max(r, 0), nIni - 1);
                 rr[k] = r; one = 1ull << (16 * r);
@@ -719,14 +759,14 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
             off += c;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int pos = p0 + k;
             if (pos < n) {
                 const int r = rr[k];
                 const int rank = (int)(((base + loc[k]) >> (16 * r)) & 0xffff) - 1;
                 const int np2 = roff[r] + rank;
-                L.kx[0][np2] = (unsigned short)rx[k]; L.ky[0][np2] = (unsigned short)ry[k];
-                L.kr[0][np2] = L.kr[1][pos]; L.kn[0][np2] = (unsigned short)rpos[r];
+                KX(0, np2) = (unsigned short)rx[k]; KY(0, np2) = (unsigned short)ry[k];
+                KR(0, np2) = KR(1, pos); KN(0, np2) = (unsigned short)rpos[r];
             }
         }
         if (tid < nIni) {
@@ -751,7 +791,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
         const int prev_size = sz;
         // parents = every node that still holds more than one keypoint, in list order
         int n_expand = 0;
-        sz = oct_split_full(L, a, n, sz, tid, &n_expand);
+        sz = oct_split_full<BIG>(L, G, a, n, sz, tid, &n_expand);
         a ^= 1;
         MORB_PHASE(g_ph_oct, ph_i); ph_i = min(ph_i + 1, 40);
         if (sz >= N || sz == prev_size) { finish = true; break; }
@@ -787,11 +827,11 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                 // growth of every candidate if it were split: #non-empty children - 1  (needs the child occupancy: classify
                 // the keys of ALL candidates, then keep only the prefix that is actually processed)
                 for (int pos = tid; pos < n; pos += 1024) {
-                    const int node = L.kn[a][pos];
+                    const int node = KN(a, pos);
                     const int t = L.procidx[node];
                     if (t != 0xffff) {
                         int mx, my;
-                        const int c = oct_child(L.kx[a][pos], L.ky[a][pos], L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
+                        const int c = oct_child(KX(a, pos), KY(a, pos), L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
                         atomicOr(&occ[t], 1u << c);
                     }
                 }
@@ -808,7 +848,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                 if (tid >= np2 && tid < nc) L.procidx[L.P[tid]] = 0xffff;  // candidates behind the stop are not split
                 __syncthreads();
                 int ne2 = 0;
-                sz = oct_split_pass(L, a, n, sz, np2, tid, &ne2);
+                sz = oct_split_pass<BIG>(L, G, a, n, sz, np2, tid, &ne2);
                 a ^= 1;
                 MORB_PHASE(g_ph_oct, ph_i); ph_i = min(ph_i + 1, 40);
                 if (sz >= N || sz == ps) finish = true;
@@ -818,13 +858,13 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
     // ---- best keypoint per node, first maximum wins (:742-763); output in list order
     if (tid < sz) {
         const int kb = L.nb[a][tid], ke = L.ne[a][tid];
-        int best = kb, bresp = L.kr[a][kb];
+        int best = kb, bresp = KR(a, kb);
         for (int k = kb + 1; k < ke; ++k) {
-            const int r = L.kr[a][k];
+            const int r = KR(a, k);
             if (r > bresp) { bresp = r; best = k; }
         }
         SelKp K;
-        K.x = (int)L.kx[a][best] + MIN_BORDER; K.y = (int)L.ky[a][best] + MIN_BORDER;
+        K.x = (int)KX(a, best) + MIN_BORDER; K.y = (int)KY(a, best) + MIN_BORDER;
         K.camlevel = ((blk / max_levels) << 8) | (blk % max_levels);
         K.resp_out = (int)(((unsigned)bresp << 24) | (unsigned)tid);
         sel[Lv.sel_base + tid] = K;
@@ -835,6 +875,12 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
     if (tid == 0 && blk == 0) g_ph_oct[61] = (unsigned long long)ph_i;
 #endif
 }
+
+#undef KX
+#undef KY
+#undef KN
+#undef KR
+#undef KS
 
 // ------------------------------------------------------------------------------------------------ K5-K7
 __device__ __forceinline__ int reflect101(int p, int n) {
@@ -1250,6 +1296,9 @@ struct orbx_extractor {
     DevBuf<SelKp> d_sel, d_sel_oct;
     DevBuf<uint32_t> d_cand_dev;
     DevBuf<int> d_level_cnt_dev, d_sel_cnt, d_oct_status, d_n_out;
+    DevBuf<unsigned char> d_oct_big;  // HBM key storage of the BIG quadtree pass (allocated when first needed)
+    bool need_big = false;            // a level exceeded the LDS layout once: the BIG pass is launched from then on
+    int last_path = 0;                // inspection: 0 device quadtree, 1 device quadtree incl. the BIG pass, 2 host quadtree
     DevBuf<unsigned short> d_slot_blk;
     int total_sel_slots = 0;
     int* h_oct = nullptr;            // pinned, mapped: [0..n_cams) n_out, [n_cams] status
@@ -1479,7 +1528,8 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     for (int i = 0; i < 2; ++i) ORBX_TRY_HIP(hipEventCreateWithFlags(&ex->ev_done[i], hipEventDisableTiming | hipEventReleaseToSystem));
     { const char* e = getenv("MORB_HOST_OCTREE"); ex->device_octree = !(e && atoi(e) != 0); }
     { const char* e = getenv("MORB_CHAIN_GRAPH"); ex->use_graph = !(e && atoi(e) == 0); }
-    ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
+    ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
+    ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
     {
@@ -1501,7 +1551,7 @@ void orbx_destroy(orbx_extractor* ex) {
     ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release();
     ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release(); ex->d_sel_oct.release();
     ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release();
-    ex->d_n_out.release(); ex->d_slot_blk.release();
+    ex->d_n_out.release(); ex->d_slot_blk.release(); ex->d_oct_big.release();
     for (auto& b : ex->d_kps) b.release();
     for (auto& b : ex->d_desc) b.release();
     ex->d_out_kps.release(); ex->d_out_desc.release();
@@ -1566,6 +1616,8 @@ int orbx_set_host_mirror(orbx_extractor* ex, orb_keypoint* kps_devptr, uint8_t* 
     if (!ex->mirror_cap) { ex->mirror_kps = nullptr; ex->mirror_desc = nullptr; }
     return ORB_OK;
 }
+
+int orbx_debug_last_path(const orbx_extractor* ex) { return ex ? ex->last_path : ORB_E_ARG; }
 
 int orbx_set_profiling(orbx_extractor* ex, int on) {
     MORB_ARG(ex != nullptr);
@@ -1648,9 +1700,14 @@ static int launch_tree_describe(orbx_extractor* ex, hipStream_t st, unsigned slo
     mir.kps = nullptr; mir.desc = nullptr;
     if (ex->mirror_kps) { mir.kps = ex->mirror_kps; mir.desc = ex->mirror_desc; }  // cap_total covers every camera's capacity
     for (int c = 0; c < 64; ++c) mir.base[c] = 0;
-    hipLaunchKernelGGL(k_octree, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
+    hipLaunchKernelGGL(k_octree<false>, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
                        (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
-                       ex->d_oct_status.p, ML);
+                       ex->d_oct_status.p, ML, (unsigned char*)nullptr);
+    if (ex->need_big) {  // this stream has produced levels beyond the LDS layout before: the BIG pass follows for those
+        hipLaunchKernelGGL(k_octree<true>, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
+                           (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
+                           ex->d_oct_status.p, ML, ex->d_oct_big.p);
+    }
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[4], st));
     hipLaunchKernelGGL(k_describe, dim3((ex->total_sel_slots + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
                        (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel_oct.p, ex->total_sel_slots,
@@ -1760,6 +1817,10 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         if (allow_async) return ORB_OK;
         MORB_HIP(hipStreamSynchronize(st));
         if (ex->h_oct[slot * (ex->n_cams + 1) + ex->n_cams] == 0) return finish_device_path(ex);
+        if ((ex->h_oct[slot * (ex->n_cams + 1) + ex->n_cams] & 2) && !ex->need_big &&
+            ex->d_oct_big.reserve((size_t)ex->levels.size() * OCT_BIG_BYTES) == ORB_OK) {
+            ex->need_big = true; ++ex->geom_epoch;
+        }
         ex->inflight = 0;
         std::fill(ex->n_out.begin(), ex->n_out.end(), 0);  // a level exceeded the device limits: redo the selection on the host
         hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ML), dim3(1024), 0, st, (const LevelInfo*)ex->d_levels.p,
@@ -1773,6 +1834,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
     }
     const auto t_host0 = std::chrono::steady_clock::now();
 
+    ex->last_path = 2;
     // K4 (host): quadtree per (camera, level) on the worker pool; output order = level-major, list order inside a level
     int n_tasks = 0;
     for (int c = 0; c < ex->n_cams; ++c) {
@@ -1868,6 +1930,7 @@ static int finish_device_path(orbx_extractor* ex) {
     const int* h_oct = ex->h_oct + oldest * (ex->n_cams + 1);
     --ex->inflight;
     if (h_oct[ex->n_cams] == 0) {
+        ex->last_path = ex->need_big ? 1 : 0;
         for (int c = 0; c < ex->n_cams; ++c) {
             ex->n_out[c] = h_oct[c];
             if (ex->n_out[c] > ex->out_cap_active[c]) { morb::set_error("a camera produced more keypoints than its output capacity"); return ORB_E_CAPACITY; }
@@ -1882,6 +1945,14 @@ static int finish_device_path(orbx_extractor* ex) {
             ex->stage_us[5] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - ex->t_begin_async).count();
         }
         return ORB_OK;
+    }
+    // A level held more candidates than the LDS layout but fits the BIG pass: from the next run on that pass is launched
+    // behind the normal one (this run still takes the host path).
+    if ((h_oct[ex->n_cams] & 2) && !ex->need_big) {
+        if (ex->d_oct_big.reserve((size_t)ex->levels.size() * OCT_BIG_BYTES) == ORB_OK) {
+            ex->need_big = true;
+            ++ex->geom_epoch;  // the captured launch chains get the extra kernel
+        }
     }
     // a level exceeded the device limits.  With a newer run in flight the resident images are already being replaced:
     // the caller has to upload this run's images again and run synchronously (2).  Otherwise the synchronous

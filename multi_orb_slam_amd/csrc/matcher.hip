@@ -618,14 +618,17 @@ MORB_PHASE_DECL(g_ph_res);
 // order given; FRAMES: first minimum.  POINTS: best + second (with multiplicity) and their levels.
 // LDSQ: the per-query sweep state (shortlist features + distances, blocks flag, current choice) also lives in LDS, so a
 // sweep touches no global memory at all; used whenever it fits next to the claim table.
-template <bool POINTS, bool LDSQ>
+// GCL: the two claim tables do not fit LDS (frames beyond ~18 000 features): they live in an HBM workspace (`g_claims`,
+// 2 x capacity ints, L2-resident) and only the rescan list stays in LDS.  Same sweeps, global atomics.
+template <bool POINTS, bool LDSQ, bool GCL = false>
 __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap,
                                                   const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
                                                   const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
                                                   const float* __restrict__ f_angle, int th_high, float nnratio,
                                                   int check_ori, int max_it, int* __restrict__ choice,
                                                   const int* __restrict__ topk /* (2*RESOLVE_K+1)*nq ints */,
-                                                  int* __restrict__ match_of_feature, int* __restrict__ status) {
+                                                  int* __restrict__ match_of_feature, int* __restrict__ status,
+                                                  int* __restrict__ g_claims = nullptr) {
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // two claim tables, one entry per feature each (capacity F.n_total)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_keep[3];
@@ -640,9 +643,12 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     const int* tk_g = topk + RESOLVE_K * nq;      // [k*nq + i]
     // LDS after the two claim tables: rescan list u16[nq] (padded to 4 bytes); with LDSQ also
     //   choice[nq] | shortlist g [K][nq] | query angle [nq] | feature angle [F.n_total] | shortlist d [K][nq] (u16) | flags [nq] (u8)
-    int* s_claim2 = s_claim + F.n_total;
-    unsigned short* l_res = reinterpret_cast<unsigned short*>(s_claim + 2 * F.n_total);
-    int* l_choice = s_claim + 2 * F.n_total + (nq + 1) / 2;
+    const int lds_tables = GCL ? 0 : 2 * F.n_total;  // ints of LDS taken by the claim tables
+    int* s_claim2 = s_claim + F.n_total;             // (LDS tables; unused with GCL)
+    int* g_claim = g_claims;                         // (HBM tables; unused without GCL)
+    int* g_claim2 = g_claims + F.n_total;
+    unsigned short* l_res = reinterpret_cast<unsigned short*>(s_claim + lds_tables);
+    int* l_choice = s_claim + lds_tables + (nq + 1) / 2;
     int* l_g = l_choice + nq;
     float* l_ang = reinterpret_cast<float*>(l_g + RESOLVE_K * nq);
     float* l_fang = l_ang + nq;
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_d + RESOLVE_K * nq);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
     if (tid == 0) { s_red = 0; s_nres2[0] = 0; s_nres2[1] = 0; }
     for (int g = tid; g < F.n_total; g += T) {  // capacity-sized: rows past the real count are never referenced
-        s_claim[g] = 0x7fffffff; s_claim2[g] = 0x7fffffff;
+        if (GCL) { g_claim[g] = 0x7fffffff; g_claim2[g] = 0x7fffffff; } else { s_claim[g] = 0x7fffffff; s_claim2[g] = 0x7fffffff; }
         if (LDSQ && !POINTS && check_ori) l_fang[g] = f_angle[g];
     }
     int mx = 0;
@@ -689,6 +695,8 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         const int tag = (0x7ffe - it) << 16, tag_next = (0x7ffd - it) << 16;
         const int* rd = (it & 1) ? s_claim2 : s_claim;
         int* wr = (it & 1) ? s_claim : s_claim2;
+        const int* grd = (it & 1) ? g_claim2 : g_claim;
+        int* gwr = (it & 1) ? g_claim : g_claim2;
         int& s_nres = s_nres2[it & 1];
         if (tid == 0) s_nres2[(it + 1) & 1] = 0;  // nobody touches the other counter during this sweep
         int ch = 0;
@@ -711,7 +719,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 if (found >= NEED) break;
                 const int g = LDSQ ? l_g[k * nq + i] : sg[k];
                 if (g < 0) break;  // the shortlist is sorted: empty slots are at the end
-                const int cl = rd[g];
+                const int cl = GCL ? grd[g] : rd[g];
                 if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) { ++taken; continue; }
                 const int d = LDSQ ? (int)l_d[k * nq + i] : sd[k];
                 if (found == 0) { best = d; bidx = g; if (POINTS) lvl = F.octave[g]; }
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             }
             if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
             const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;
-            if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
+            if (nc >= 0 && bl) atomicMin(GCL ? &gwr[nc] : &wr[nc], tag_next | i);  // what the next sweep sees
         }
         __syncthreads();
         const int nres = s_nres;
@@ -751,7 +759,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                     const int g = cand_idx[k * nq + i];
                     const int d = cand_dist[k * nq + i];
                     bool avail = !(occupied && occupied[g]);
-                    const int cl = rd[g];
+                    const int cl = GCL ? grd[g] : rd[g];
                     if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) avail = false;
                     if (avail) key = (d << 16) | k;
                 }
@@ -783,7 +791,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 const int old = LDSQ ? l_choice[i] : choice[i];
                 if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
                 const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;
-                if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);
+                if (nc >= 0 && bl) atomicMin(GCL ? &gwr[nc] : &wr[nc], tag_next | i);
             }
         }
         changed = __syncthreads_or(ch);
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         return;
     }
     // owners: the last claimant in query order (claims after a blocking one are impossible, so max index == final owner)
-    for (int g = tid; g < NT; g += T) s_claim[g] = -1;
+    for (int g = tid; g < NT; g += T) { if (GCL) g_claim[g] = -1; else s_claim[g] = -1; }
     if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
     if (tid == 0) s_red = 0;
     __syncthreads();
@@ -804,7 +812,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         const int c = LDSQ ? l_choice[i] : choice[i];
         if (c < 0) continue;
         ++acc;
-        atomicMax(&s_claim[c], i);
+        atomicMax(GCL ? &g_claim[c] : &s_claim[c], i);
         if (!POINTS && check_ori) {
             float rot = LDSQ ? l_ang[i] - l_fang[c] : q[i].angle - f_angle[c];
             if (rot < 0.0) rot += 360.0f;
@@ -854,7 +862,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 if (bin == ORBM_HISTO_LENGTH) bin = 0;
             }
             if (bin >= 0 && bin < ORBM_HISTO_LENGTH && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
-                s_claim[c] = -2;  // every writer stores -2; owners were settled before the barrier
+                if (GCL) g_claim[c] = -2; else s_claim[c] = -2;  // every writer stores -2; owners were settled before the barrier
                 ++rej;
             }
         }
@@ -864,7 +872,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         __syncthreads();
     }
     MORB_PHASE(g_ph_res, 60);
-    for (int g = tid; g < NT; g += T) match_of_feature[g] = s_claim[g];
+    for (int g = tid; g < NT; g += T) match_of_feature[g] = GCL ? g_claim[g] : s_claim[g];
     if (tid == 0) { status[0] = 0; status[1] = s_red; status[2] = it; status[3] = maxcount; }
     MORB_PHASE(g_ph_res, 61);
 #ifdef MORB_PHASE_CLOCKS
@@ -1028,6 +1036,7 @@ struct orbm_matcher {
     hipStream_t own_stream = nullptr, stream = nullptr;  // `stream` = the one in use (own or caller's)
     DevBuf<uint8_t> d_q, d_r, d_scratch, d_queries, d_occ;
     DevBuf<int32_t> d_i0, d_i1, d_i2, d_choice, d_claim, d_match, d_status, d_x0, d_x1, d_x2;
+    DevBuf<int32_t> d_gclaim;  // claim tables of the resolve when they do not fit LDS (2 x features)
     DevBuf<uint16_t> d_u16;
     PinnedBuf<int32_t> h_i0, h_i1, h_i2, h_match;
     PinnedBuf<int32_t> h_gcnt;            // per-camera counts of a gathered multi-GPU exchange (+ own query count)
@@ -1147,7 +1156,7 @@ void orbm_destroy(orbm_matcher* m) {
     m->h_c0.release(); m->h_c1.release(); m->h_c2.release(); m->d_cscratch.release(); m->h_gcnt.release();
     m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release(); m->d_occ.release();
     m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release();
-    m->d_match.release(); m->d_status.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
+    m->d_match.release(); m->d_status.release(); m->d_gclaim.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
     m->h_i0.release(); m->h_i1.release(); m->h_i2.release(); m->h_match.release(); m->h_u16.release(); m->h_ring.release();
     for (FrameBufs* b : m->pool) { b->release(); delete b; }
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
@@ -1727,14 +1736,20 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     const int n = J.cur->n_total;
     J.device_path = false;
     if (J.nq == 0 || n == 0) return ORB_OK;
-    // two claim tables (one int per feature each) + the rescan list (u16 per query, padded)
-    const size_t lds = (size_t)2 * n * sizeof(int) + (size_t)((J.nq + 1) / 2) * sizeof(int);
+    // two claim tables (one int per feature each) + the rescan list (u16 per query, padded); tables that do not fit LDS go
+    // to an HBM workspace (GCL variant of the kernel)
+    const size_t lds_res = (size_t)((J.nq + 1) / 2) * sizeof(int);
+    const bool gcl = (size_t)2 * n * sizeof(int) + lds_res > 150 * 1024;
+    const size_t lds = gcl ? lds_res : (size_t)2 * n * sizeof(int) + lds_res;
     if (m->host_resolve || J.nq > RESOLVE_MAX_Q || lds > 150 * 1024) return ORB_OK;  // finish() takes the host path
+    if (gcl) { int rcg = m->d_gclaim.reserve((size_t)2 * n); if (rcg) return rcg; }
     if (lds > 48 * 1024) {  // large claim tables need the opt-in dynamic LDS limit (once per process)
         static bool raised = false;
         if (!raised) {
             MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             raised = true;
         }
     }
@@ -1752,7 +1767,7 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
         return rc;
     // claim table + (when it fits) the per-query sweep state
     const size_t lds_q = lds + (size_t)nq * (sizeof(int) + sizeof(float) + RESOLVE_K * (sizeof(int) + sizeof(unsigned short)) + 1) + (size_t)n * sizeof(float) + 16;
-    const bool ldsq = lds_q <= 150 * 1024;
+    const bool ldsq = !gcl && lds_q <= 150 * 1024;
     const size_t lds_use = ldsq ? lds_q : lds;
     if (lds_use > 48 * 1024) {
         static bool raised2 = false;
@@ -1766,10 +1781,17 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     hipLaunchKernelGGL((k_resolve<PT, LQ>), dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, \
                        nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
                        (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
-                       (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp)
-    if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
+                       (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, gcl ? m->d_gclaim.p : (int*)nullptr)
+#define MORB_RESOLVE_LAUNCH_G(PT)                                                                                        \
+    hipLaunchKernelGGL((k_resolve<PT, false, true>), dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, \
+                       nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
+                       (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
+                       (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, m->d_gclaim.p)
+    if (gcl) { if (J.points) MORB_RESOLVE_LAUNCH_G(true); else MORB_RESOLVE_LAUNCH_G(false); }
+    else if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
     else { if (J.points) MORB_RESOLVE_LAUNCH(true, false); else MORB_RESOLVE_LAUNCH(false, false); }
 #undef MORB_RESOLVE_LAUNCH
+#undef MORB_RESOLVE_LAUNCH_G
     MORB_HIP(hipGetLastError());  // status + matches are written by the kernel into the mapped pinned buffer
     J.device_path = true;
     return ORB_OK;
@@ -1780,6 +1802,9 @@ static int search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_featur
     const int n = J.cur->n_total;
     *nmatches = 0;
     if (J.nq == 0 || n == 0) { for (int g = 0; g < n; g++) match_of_feature[g] = -1; return ORB_OK; }
+    if (!J.device_path) {
+        m->last_status[0] = -1; m->last_status[1] = 0; m->last_status[2] = 0; m->last_status[3] = 0;  // (host path)
+    }
     if (!J.device_path)
         return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, 64, match_of_feature, nmatches);
     for (;;) {
@@ -1968,7 +1993,8 @@ struct orbf_frontend {
     std::deque<InFlight> inflight;
     std::deque<std::vector<orbf_image>> announced;  // declared by orbf_prefetch, not enqueued yet (at most 2)
     int last_e = 0;  // extractor most recently handed a timestep
-    bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path
+    bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path ...
+    int clean_steps = 0;     // ... and set again after a few steps that stayed on the device path
     hipEvent_t ev_extracted = nullptr;  // extractor stream -> matcher stream on the synchronous path
     hipEvent_t ev_ready[NSETS] = {nullptr, nullptr, nullptr, nullptr};  // extraction + frame grid of the step using that set
     // frame of the last completed step (orbf_export_block); a frame built on the synchronous path is kept until the next step
@@ -2362,11 +2388,13 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
                 }
                 fr = nullptr; fr_persistent = false;
                 async_path = false;
+                f->clean_steps = 0;
                 continue;
             }
             for (int c = 0; c < f->n_cams; ++c) f->counts[c] = orbx_count(ex, c);
             frame_set_counts(fr, f->counts.data());
             n = fr->n_total;
+            if (!f->overlap_ok && ++f->clean_steps >= 3) f->overlap_ok = true;  // (e.g. the extractor has switched its BIG pass on)
         } else {
             for (int c = 0; c < f->n_cams; ++c) f->counts[c] = cams[c].n;
         }

@@ -145,6 +145,10 @@ class Extractor:
         check(_lib.lib().orbx_debug_level(self._h, cam, level, ptr(buf), buf.size, C.byref(w), C.byref(h)))
         return buf[:w.value * h.value].reshape(h.value, w.value).copy()
 
+    def last_path(self):
+        """0 device quadtree, 1 device quadtree incl. the memory-backed pass, 2 host quadtree (orbx_debug_last_path)."""
+        return _lib.lib().orbx_debug_last_path(self._h)
+
     def debug_candidates(self, cam, level):
         n = C.c_int()
         check(_lib.lib().orbx_debug_candidates(self._h, cam, level, None, 0, C.byref(n)))

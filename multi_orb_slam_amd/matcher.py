@@ -172,6 +172,12 @@ class Matcher:
                                                 ptr(sd)))
         return bi[:nq], bd[:nq], sd[:nq]
 
+    def last_resolve(self):
+        """(status, matches, sweeps, longest candidate list) of the last device resolve (orbm_debug_last_resolve)."""
+        out = (C.c_int * 4)()
+        check(_lib.lib().orbm_debug_last_resolve(self._h, out))
+        return tuple(out)
+
     def cross_top2_gathered(self, gathered_ptr, world, block_bytes, cap_rows, cams_per_rank, rank):
         """Cross-camera top-2 of this rank's features against the whole rig from ONE all-gathered buffer
         (orbm_cross_top2_gathered).  -> (best_idx, best_dist, second_dist, counts of every camera of the rig)."""

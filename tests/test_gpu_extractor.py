@@ -105,6 +105,29 @@ def test_larger_configs():
         ex.close()
 
 
+def test_dense_levels_move_to_the_memory_backed_quadtree_pass():
+    """1920x1080 @4000: levels 0..5 hold 4500-9400 candidates, more than the LDS layout of the device quadtree (4096).  The
+    first run notices and takes the host path; from the second run on the memory-backed pass (up to 16384 candidates) does
+    those levels on the device.  Both must equal the oracle; a noise image (> 16384 candidates) still goes to the host."""
+    import multi_orb_slam_amd as m
+    w, h, nf = 1920, 1080, 4000
+    ex = _mk([m.ExtractorParams(nfeatures=nf)], w, h)
+    for t in range(3):
+        img = synth.image(2, t, w, h)
+        kps, desc = ex(img)
+        okps, odesc = oracle.extract(img, nfeatures=nf)
+        _assert_same(kps, desc, okps, odesc)
+        assert ex.last_path() == (2 if t == 0 else 1), (t, ex.last_path())
+    assert max(len(ex.debug_candidates(0, l)) for l in range(8)) > 4096
+    rng = synth.hash32(np.arange(w * h, dtype=np.uint64) + np.uint64(5))
+    noise = (rng % 256).astype(np.uint8).reshape(h, w)
+    kps, desc = ex(noise)
+    okps, odesc = oracle.extract(noise, nfeatures=nf)
+    _assert_same(kps, desc, okps, odesc)
+    assert ex.last_path() == 2 and len(ex.debug_candidates(0, 0)) > 16384
+    ex.close()
+
+
 def test_resident_path_and_determinism():
     import multi_orb_slam_amd as m
     ex = _mk([m.ExtractorParams(nfeatures=1000)] * 2, 640, 480)

@@ -234,8 +234,9 @@ def test_device_resolve_long_dependency_chains_and_host_fallback_agree():
     assert on >= n                                           # every feature ends up claimed
 
 
-def test_projection_search_large_frame_uses_big_lds_claim_table(matcher):
-    """8 cameras x 4000 features (configs[4] scale): 32000-entry claim table (128 KB of LDS), wide windows."""
+def test_projection_search_large_frame_keeps_its_claim_tables_in_hbm(matcher):
+    """8 cameras x 4000 features (configs[4] scale): two 32000-entry claim tables do not fit LDS, the resolve kernel keeps
+    them in an HBM workspace (same sweeps, global atomics) instead of handing the search to the host."""
     import multi_orb_slam_amd as m
     fr = helpers.make_frame_arrays([4000] * 8, 1920, 1080, 17)
     q = helpers.make_queries(fr, 20000, 23, th=30.0)
@@ -243,6 +244,8 @@ def test_projection_search_large_frame_uses_big_lds_claim_table(matcher):
     n, mo = matcher.SearchByProjection(F, q)
     on, omo = oracle.search_by_projection_frames(OF, q, 100, True)
     assert n == on and np.array_equal(mo, omo) and n > 5000
+    status, nm, sweeps, longest = matcher.last_resolve()
+    assert status == 0 and nm == n and sweeps >= 2          # resolved on the device (the host path leaves no sweep count)
     F.close()
 
 
