@@ -941,14 +941,35 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __r
     const int chunk = (max(s1 - s0, 0) + TOP2_WAVES - 1) / TOP2_WAVES;
     const int j0 = s0 + wave * chunk, j1 = min(s1, j0 + chunk);
     int b = 256, s = 256, bi = -1;
-    for (int j = j0; j < j1; ++j) {
-        const uint4 a0 = desc[2 * j], a1 = desc[2 * j + 1];  // wave-uniform -> scalar loads
-        int d = (int)ham256_chain(a0, a1, q0, q1);
-        d = (j >= seg0 && j < seg1) ? 256 : d;               // own camera: distance 256 never registers
-        const int jj = j < seg0 ? j : j - seglen;            // index in the concatenation of the other cameras
-        s = min(s, max(b, d));
-        bi = d < b ? jj : bi;
-        b = min(b, d);
+    // 64 consecutive queries nearly always belong to one camera: then the own camera's rows are skipped as a range
+    // (for a 2-camera rig that is half of all pairs) and the per-pair segment test disappears
+    const int seg0u = __builtin_amdgcn_readfirstlane(seg0), seg1u = __builtin_amdgcn_readfirstlane(seg1);
+    if (__all(seg0 == seg0u)) {
+        for (int j = j0, je = min(j1, seg0u); j < je; ++j) {          // cameras in front of the own one: index unchanged
+            const uint4 a0 = desc[2 * j], a1 = desc[2 * j + 1];        // wave-uniform -> scalar loads
+            const int d = (int)ham256_chain(a0, a1, q0, q1);
+            s = min(s, max(b, d));
+            bi = d < b ? j : bi;
+            b = min(b, d);
+        }
+        const int shift = seg1u - seg0u;
+        for (int j = max(j0, seg1u); j < j1; ++j) {                    // cameras behind it: index minus the own count
+            const uint4 a0 = desc[2 * j], a1 = desc[2 * j + 1];
+            const int d = (int)ham256_chain(a0, a1, q0, q1);
+            s = min(s, max(b, d));
+            bi = d < b ? j - shift : bi;
+            b = min(b, d);
+        }
+    } else {
+        for (int j = j0; j < j1; ++j) {
+            const uint4 a0 = desc[2 * j], a1 = desc[2 * j + 1];
+            int d = (int)ham256_chain(a0, a1, q0, q1);
+            d = (j >= seg0 && j < seg1) ? 256 : d;               // own camera: distance 256 never registers
+            const int jj = j < seg0 ? j : j - seglen;            // index in the concatenation of the other cameras
+            s = min(s, max(b, d));
+            bi = d < b ? jj : bi;
+            b = min(b, d);
+        }
     }
     sb[wave][lane] = b; ss[wave][lane] = s; si[wave][lane] = bi;
     __syncthreads();
