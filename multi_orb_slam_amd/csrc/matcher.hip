@@ -618,17 +618,14 @@ MORB_PHASE_DECL(g_ph_res);
 // order given; FRAMES: first minimum.  POINTS: best + second (with multiplicity) and their levels.
 // LDSQ: the per-query sweep state (shortlist features + distances, blocks flag, current choice) also lives in LDS, so a
 // sweep touches no global memory at all; used whenever it fits next to the claim table.
-// GCL: the two claim tables do not fit LDS (frames beyond ~18 000 features): they live in an HBM workspace (`g_claims`,
-// 2 x capacity ints, L2-resident) and only the rescan list stays in LDS.  Same sweeps, global atomics.
-template <bool POINTS, bool LDSQ, bool GCL = false>
+template <bool POINTS, bool LDSQ>
 __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap,
                                                   const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
                                                   const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
                                                   const float* __restrict__ f_angle, int th_high, float nnratio,
                                                   int check_ori, int max_it, int* __restrict__ choice,
                                                   const int* __restrict__ topk /* (2*RESOLVE_K+1)*nq ints */,
-                                                  int* __restrict__ match_of_feature, int* __restrict__ status,
-                                                  int* __restrict__ g_claims = nullptr) {
+                                                  int* __restrict__ match_of_feature, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // two claim tables, one entry per feature each (capacity F.n_total)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_keep[3];
@@ -643,12 +640,9 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     const int* tk_g = topk + RESOLVE_K * nq;      // [k*nq + i]
     // LDS after the two claim tables: rescan list u16[nq] (padded to 4 bytes); with LDSQ also
     //   choice[nq] | shortlist g [K][nq] | query angle [nq] | feature angle [F.n_total] | shortlist d [K][nq] (u16) | flags [nq] (u8)
-    const int lds_tables = GCL ? 0 : 2 * F.n_total;  // ints of LDS taken by the claim tables
-    int* s_claim2 = s_claim + F.n_total;             // (LDS tables; unused with GCL)
-    int* g_claim = g_claims;                         // (HBM tables; unused without GCL)
-    int* g_claim2 = g_claims + F.n_total;
-    unsigned short* l_res = reinterpret_cast<unsigned short*>(s_claim + lds_tables);
-    int* l_choice = s_claim + lds_tables + (nq + 1) / 2;
+    int* s_claim2 = s_claim + F.n_total;
+    unsigned short* l_res = reinterpret_cast<unsigned short*>(s_claim + 2 * F.n_total);
+    int* l_choice = s_claim + 2 * F.n_total + (nq + 1) / 2;
     int* l_g = l_choice + nq;
     float* l_ang = reinterpret_cast<float*>(l_g + RESOLVE_K * nq);
     float* l_fang = l_ang + nq;
@@ -656,7 +650,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_d + RESOLVE_K * nq);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
     if (tid == 0) { s_red = 0; s_nres2[0] = 0; s_nres2[1] = 0; }
     for (int g = tid; g < F.n_total; g += T) {  // capacity-sized: rows past the real count are never referenced
-        if (GCL) { g_claim[g] = 0x7fffffff; g_claim2[g] = 0x7fffffff; } else { s_claim[g] = 0x7fffffff; s_claim2[g] = 0x7fffffff; }
+        s_claim[g] = 0x7fffffff; s_claim2[g] = 0x7fffffff;
         if (LDSQ && !POINTS && check_ori) l_fang[g] = f_angle[g];
     }
     int mx = 0;
@@ -695,8 +689,6 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         const int tag = (0x7ffe - it) << 16, tag_next = (0x7ffd - it) << 16;
         const int* rd = (it & 1) ? s_claim2 : s_claim;
         int* wr = (it & 1) ? s_claim : s_claim2;
-        const int* grd = (it & 1) ? g_claim2 : g_claim;
-        int* gwr = (it & 1) ? g_claim : g_claim2;
         int& s_nres = s_nres2[it & 1];
         if (tid == 0) s_nres2[(it + 1) & 1] = 0;  // nobody touches the other counter during this sweep
         int ch = 0;
@@ -719,7 +711,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 if (found >= NEED) break;
                 const int g = LDSQ ? l_g[k * nq + i] : sg[k];
                 if (g < 0) break;  // the shortlist is sorted: empty slots are at the end
-                const int cl = GCL ? grd[g] : rd[g];
+                const int cl = rd[g];
                 if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) { ++taken; continue; }
                 const int d = LDSQ ? (int)l_d[k * nq + i] : sd[k];
                 if (found == 0) { best = d; bidx = g; if (POINTS) lvl = F.octave[g]; }
@@ -739,7 +731,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             }
             if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
             const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;
-            if (nc >= 0 && bl) atomicMin(GCL ? &gwr[nc] : &wr[nc], tag_next | i);  // what the next sweep sees
+            if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
         }
         __syncthreads();
         const int nres = s_nres;
@@ -759,7 +751,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                     const int g = cand_idx[k * nq + i];
                     const int d = cand_dist[k * nq + i];
                     bool avail = !(occupied && occupied[g]);
-                    const int cl = GCL ? grd[g] : rd[g];
+                    const int cl = rd[g];
                     if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) avail = false;
                     if (avail) key = (d << 16) | k;
                 }
@@ -791,7 +783,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 const int old = LDSQ ? l_choice[i] : choice[i];
                 if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
                 const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;
-                if (nc >= 0 && bl) atomicMin(GCL ? &gwr[nc] : &wr[nc], tag_next | i);
+                if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);
             }
         }
         changed = __syncthreads_or(ch);
@@ -802,7 +794,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         return;
     }
     // owners: the last claimant in query order (claims after a blocking one are impossible, so max index == final owner)
-    for (int g = tid; g < NT; g += T) { if (GCL) g_claim[g] = -1; else s_claim[g] = -1; }
+    for (int g = tid; g < NT; g += T) s_claim[g] = -1;
     if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
     if (tid == 0) s_red = 0;
     __syncthreads();
@@ -812,7 +804,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         const int c = LDSQ ? l_choice[i] : choice[i];
         if (c < 0) continue;
         ++acc;
-        atomicMax(GCL ? &g_claim[c] : &s_claim[c], i);
+        atomicMax(&s_claim[c], i);
         if (!POINTS && check_ori) {
             float rot = LDSQ ? l_ang[i] - l_fang[c] : q[i].angle - f_angle[c];
             if (rot < 0.0) rot += 360.0f;
@@ -862,7 +854,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 if (bin == ORBM_HISTO_LENGTH) bin = 0;
             }
             if (bin >= 0 && bin < ORBM_HISTO_LENGTH && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
-                if (GCL) g_claim[c] = -2; else s_claim[c] = -2;  // every writer stores -2; owners were settled before the barrier
+                s_claim[c] = -2;  // every writer stores -2; owners were settled before the barrier
                 ++rej;
             }
         }
@@ -872,12 +864,191 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         __syncthreads();
     }
     MORB_PHASE(g_ph_res, 60);
-    for (int g = tid; g < NT; g += T) match_of_feature[g] = GCL ? g_claim[g] : s_claim[g];
+    for (int g = tid; g < NT; g += T) match_of_feature[g] = s_claim[g];
     if (tid == 0) { status[0] = 0; status[1] = s_red; status[2] = it; status[3] = maxcount; }
     MORB_PHASE(g_ph_res, 61);
 #ifdef MORB_PHASE_CLOCKS
     if (tid == 0) g_ph_res[62] = (unsigned long long)it;
 #endif
+}
+
+// ---- the same resolve for frames whose claim tables do not fit LDS (beyond ~18 000 features: 8 cameras x 4000), spread
+// over the whole chip.  The two claim tables, the choices and the owner table live in HBM (L2-resident); one launch per
+// sweep (a grid-wide barrier is exactly what a kernel boundary is), a fixed number of sweeps is enqueued and a sweep
+// that finds "nothing changed" in its predecessor's flag does nothing, so no host round trip sits between sweeps.
+// state: [0] longest candidate list, [1] matches, [2..4] kept rotation bins, [8..8+RS_MAX_SWEEPS) changed flags,
+//        [48..78) rotation histogram.
+constexpr int RS_MAX_SWEEPS = 24;
+constexpr int RS_STATE_INTS = 80;
+
+__global__ __launch_bounds__(256) void k_rs_init(int n_cap, int nq, int* __restrict__ tab0, int* __restrict__ tab1,
+                                                 int* __restrict__ owner, int* __restrict__ choice,
+                                                 const int* __restrict__ cand_count, int* __restrict__ state) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_cap) { tab0[i] = 0x7fffffff; tab1[i] = 0x7fffffff; owner[i] = -1; }
+    int mx = 0;
+    if (i < nq) { choice[i] = -1; mx = cand_count[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(&state[0], mx);
+}
+
+template <bool POINTS>
+__global__ __launch_bounds__(256) void k_rs_sweep(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap, int it,
+                                                  const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
+                                                  const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
+                                                  int th_high, float nnratio, int* __restrict__ choice,
+                                                  const int* __restrict__ topk, const int* __restrict__ rd,
+                                                  int* __restrict__ wr, int* __restrict__ state) {
+    if (state[0] > cap) return;                        // a candidate list overflowed: reported by k_rs_write
+    if (it > 0 && state[8 + it - 1] == 0) return;      // the previous sweep changed nothing: fixed point reached
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    constexpr int NEED = POINTS ? 2 : 1;
+    const int tag = (0x7ffe - it) << 16, tag_next = (0x7ffd - it) << 16;
+    int ch = 0;
+    if (i < nq) {
+        const int* tk_key = topk;
+        const int* tk_g = topk + RESOLVE_K * nq;
+        int sg[RESOLVE_K], sd[RESOLVE_K];
+#pragma unroll
+        for (int k = 0; k < RESOLVE_K; ++k) { sg[k] = tk_g[k * nq + i]; sd[k] = tk_key[k * nq + i] >> 16; }
+        const bool longer = topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K;
+        const int old = choice[i], bl = q[i].blocks;
+        int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
+        int found = 0, taken = 0;
+#pragma unroll
+        for (int k = 0; k < RESOLVE_K; ++k) {
+            if (found >= NEED) break;
+            const int g = sg[k];
+            if (g < 0) break;
+            const int cl = rd[g];
+            if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) { ++taken; continue; }
+            if (found == 0) { best = sd[k]; bidx = g; if (POINTS) lvl = F.octave[g]; }
+            else { best2 = sd[k]; lvl2 = F.octave[g]; }
+            ++found;
+        }
+        if (found < NEED && longer && taken > 0) {  // the shortlist ran dry: scan the whole list (rare), 8 loads in flight
+            best = 256; best2 = 256; lvl = -1; lvl2 = -1; bidx = -1;
+            const int full = cand_count[i];
+            for (int k0 = 0; k0 < full; k0 += 8) {
+                int cg[8], cdist[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = min(k0 + u, full - 1);
+                    cg[u] = cand_idx[k * nq + i];
+                    cdist[u] = cand_dist[k * nq + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + u >= full) continue;
+                    const int g = cg[u];
+                    if (occupied && occupied[g]) continue;
+                    const int cl = rd[g];
+                    if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) continue;
+                    const int d = cdist[u];
+                    if (POINTS) {
+                        if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = F.octave[g]; bidx = g; }
+                        else if (d < best2) { lvl2 = F.octave[g]; best2 = d; }
+                    } else if (d < best) { best = d; bidx = g; }
+                }
+            }
+        }
+        int nc = -1;
+        if (best <= th_high && bidx >= 0) {
+            nc = bidx;
+            if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
+        }
+        if (nc != old) { ch = 1; choice[i] = nc; }
+        if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);
+    }
+    if (__syncthreads_or(ch) && threadIdx.x == 0) atomicOr(&state[8 + it], 1);
+}
+
+// owners (last claimant in query order) + rotation histogram + match count
+__global__ __launch_bounds__(256) void k_rs_owner(const orbm_query* __restrict__ q, int nq, int cap, const int* __restrict__ choice,
+                                                  const float* __restrict__ f_angle, int check_ori, int* __restrict__ owner,
+                                                  int* __restrict__ state) {
+    if (state[0] > cap || state[8 + RS_MAX_SWEEPS - 1] != 0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = i < nq ? choice[i] : -1;
+    if (c >= 0) atomicMax(&owner[c], i);
+    const unsigned long long any = __ballot(c >= 0);
+    if (lane == 0 && any) atomicAdd(&state[1], __popcll(any));
+    if (check_ori) {
+        int bin = -1;
+        if (c >= 0) {
+            float rot = q[i].angle - f_angle[c];
+            if (rot < 0.0) rot += 360.0f;
+            bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            if (bin < 0 || bin >= ORBM_HISTO_LENGTH) bin = -1;
+        }
+        unsigned long long todo = __ballot(bin >= 0);
+        while (todo) {  // one atomic per distinct bin of the wave
+            const int b0 = __shfl(bin, __ffsll((long long)todo) - 1);
+            const unsigned long long same = __ballot(bin == b0);
+            if (bin == b0 && lane == __ffsll((long long)same) - 1) atomicAdd(&state[48 + b0], __popcll(same));
+            todo &= ~same;
+        }
+    }
+}
+
+// ComputeThreeMaxima (every block, redundantly) + rejection of the matches outside the three fullest rotation bins
+__global__ __launch_bounds__(256) void k_rs_reject(const orbm_query* __restrict__ q, int nq, int cap, const int* __restrict__ choice,
+                                                   const float* __restrict__ f_angle, int* __restrict__ owner,
+                                                   int* __restrict__ state) {
+    if (state[0] > cap || state[8 + RS_MAX_SWEEPS - 1] != 0) return;
+    __shared__ int s_keep[3];
+    if (threadIdx.x == 0) {  // reference src/ORBmatcher.cc:3948-3989
+        int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
+            const int sz = state[48 + b];
+            if (sz > m1) { m3 = m2; i3 = i2; m2 = m1; i2 = i1; m1 = sz; i1 = b; }
+            else if (sz > m2) { m3 = m2; i3 = i2; m2 = sz; i2 = b; }
+            else if (sz > m3) { m3 = sz; i3 = b; }
+        }
+        if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+        else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+        s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool rej = false;
+    if (i < nq) {
+        const int c = choice[i];
+        if (c >= 0) {
+            float rot = q[i].angle - f_angle[c];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < ORBM_HISTO_LENGTH && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
+                owner[c] = -2;  // every writer stores -2; the owners were settled by the previous kernel
+                rej = true;
+            }
+        }
+    }
+    const unsigned long long r = __ballot(rej);
+    if (lane == 0 && r) atomicSub(&state[1], __popcll(r));
+}
+
+__global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __restrict__ n_total_dev, int cap, const int* __restrict__ owner,
+                                                  const int* __restrict__ state, int* __restrict__ match_of_feature,
+                                                  int* __restrict__ status) {
+    const int NT = n_total_dev ? *n_total_dev : NT_host;
+    const bool overflow = state[0] > cap, stuck = state[8 + RS_MAX_SWEEPS - 1] != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int sweeps = 0;
+        for (int k = 0; k < RS_MAX_SWEEPS; ++k) sweeps += state[8 + k] ? 1 : 0;
+        status[0] = overflow ? 2 : (stuck ? 1 : 0);
+        status[1] = (overflow || stuck) ? 0 : state[1];
+        status[2] = sweeps + 1;
+        status[3] = state[0];
+    }
+    if (overflow || stuck) return;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < NT) match_of_feature[g] = owner[g];
 }
 
 // Multi-GPU exchange: `gathered` holds one block per rank (rank order), each = cap_rows descriptor rows (the rank's
@@ -1759,18 +1930,15 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     if (J.nq == 0 || n == 0) return ORB_OK;
     // two claim tables (one int per feature each) + the rescan list (u16 per query, padded); tables that do not fit LDS go
     // to an HBM workspace (GCL variant of the kernel)
-    const size_t lds_res = (size_t)((J.nq + 1) / 2) * sizeof(int);
-    const bool gcl = (size_t)2 * n * sizeof(int) + lds_res > 150 * 1024;
-    const size_t lds = gcl ? lds_res : (size_t)2 * n * sizeof(int) + lds_res;
-    if (m->host_resolve || J.nq > RESOLVE_MAX_Q || lds > 150 * 1024) return ORB_OK;  // finish() takes the host path
-    if (gcl) { int rcg = m->d_gclaim.reserve((size_t)2 * n); if (rcg) return rcg; }
-    if (lds > 48 * 1024) {  // large claim tables need the opt-in dynamic LDS limit (once per process)
+    const size_t lds = (size_t)2 * n * sizeof(int) + (size_t)((J.nq + 1) / 2) * sizeof(int);
+    const bool multi = lds > 150 * 1024;  // multi-workgroup resolve with the tables in HBM
+    if (m->host_resolve || J.nq > RESOLVE_MAX_Q) return ORB_OK;  // finish() takes the host path
+    if (multi) { int rcg = m->d_gclaim.reserve((size_t)2 * n + RS_STATE_INTS); if (rcg) return rcg; }
+    if (!multi && lds > 48 * 1024) {  // large claim tables need the opt-in dynamic LDS limit (once per process)
         static bool raised = false;
         if (!raised) {
             MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             raised = true;
         }
     }
@@ -1786,9 +1954,39 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device, false, /*transposed=*/1, d_occ, m->d_claim.p,
                           J.points ? 256 : th_high)))
         return rc;
+    if (multi) {
+        int* tab0 = m->d_gclaim.p; int* tab1 = tab0 + n; int* state = tab1 + n;
+        MORB_HIP(hipMemsetAsync(state, 0, RS_STATE_INTS * sizeof(int), m->stream));
+        const int nb_all = (std::max(n, nq) + 255) / 256, nb_q = (nq + 255) / 256, nb_f = (n + 255) / 256;
+        hipLaunchKernelGGL(k_rs_init, dim3(nb_all), dim3(256), 0, m->stream, n, nq, tab0, tab1, m->d_match.p, m->d_choice.p,
+                           (const int*)m->d_i1.p, state);
+        for (int it = 0; it < RS_MAX_SWEEPS; ++it) {
+            const int* rd = (it & 1) ? tab1 : tab0;
+            int* wr = (it & 1) ? tab0 : tab1;
+            if (J.points)
+                hipLaunchKernelGGL(k_rs_sweep<true>, dim3(nb_q), dim3(256), 0, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, nq,
+                                   cap, it, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ, th_high,
+                                   nnratio, m->d_choice.p, (const int*)m->d_claim.p, rd, wr, state);
+            else
+                hipLaunchKernelGGL(k_rs_sweep<false>, dim3(nb_q), dim3(256), 0, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, nq,
+                                   cap, it, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ, th_high,
+                                   nnratio, m->d_choice.p, (const int*)m->d_claim.p, rd, wr, state);
+        }
+        const int ori = J.points ? 0 : J.check_ori;
+        hipLaunchKernelGGL(k_rs_owner, dim3(nb_q), dim3(256), 0, m->stream, (const orbm_query*)m->d_queries.p, nq, cap,
+                           (const int*)m->d_choice.p, (const float*)cur->b->d_ang.p, ori, m->d_match.p, state);
+        if (ori)
+            hipLaunchKernelGGL(k_rs_reject, dim3(nb_q), dim3(256), 0, m->stream, (const orbm_query*)m->d_queries.p, nq, cap,
+                               (const int*)m->d_choice.p, (const float*)cur->b->d_ang.p, m->d_match.p, state);
+        hipLaunchKernelGGL(k_rs_write, dim3(nb_f), dim3(256), 0, m->stream, n, cur->dev().n_total_dev, cap, (const int*)m->d_match.p,
+                           (const int*)state, m->h_match.dp + 4, m->h_match.dp);
+        MORB_HIP(hipGetLastError());
+        J.device_path = true;
+        return ORB_OK;
+    }
     // claim table + (when it fits) the per-query sweep state
     const size_t lds_q = lds + (size_t)nq * (sizeof(int) + sizeof(float) + RESOLVE_K * (sizeof(int) + sizeof(unsigned short)) + 1) + (size_t)n * sizeof(float) + 16;
-    const bool ldsq = !gcl && lds_q <= 150 * 1024;
+    const bool ldsq = lds_q <= 150 * 1024;
     const size_t lds_use = ldsq ? lds_q : lds;
     if (lds_use > 48 * 1024) {
         static bool raised2 = false;
@@ -1802,17 +2000,10 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     hipLaunchKernelGGL((k_resolve<PT, LQ>), dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, \
                        nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
                        (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
-                       (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, gcl ? m->d_gclaim.p : (int*)nullptr)
-#define MORB_RESOLVE_LAUNCH_G(PT)                                                                                        \
-    hipLaunchKernelGGL((k_resolve<PT, false, true>), dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, \
-                       nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
-                       (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
-                       (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, m->d_gclaim.p)
-    if (gcl) { if (J.points) MORB_RESOLVE_LAUNCH_G(true); else MORB_RESOLVE_LAUNCH_G(false); }
-    else if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
+                       (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp)
+    if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
     else { if (J.points) MORB_RESOLVE_LAUNCH(true, false); else MORB_RESOLVE_LAUNCH(false, false); }
 #undef MORB_RESOLVE_LAUNCH
-#undef MORB_RESOLVE_LAUNCH_G
     MORB_HIP(hipGetLastError());  // status + matches are written by the kernel into the mapped pinned buffer
     J.device_path = true;
     return ORB_OK;
