@@ -433,8 +433,9 @@ __global__ __launch_bounds__(256) void k_frame_fill(const CamFeat* __restrict__ 
                                                     float* __restrict__ depth_out, int* __restrict__ oct,
                                                     float* __restrict__ ang, orb_keypoint* __restrict__ kps_g,
                                                     uint4* __restrict__ desc_g, int* __restrict__ cell_of,
-                                                    int* __restrict__ cell_cnt, HostMirror hm) {
+                                                    int* __restrict__ cell_cnt, HostMirror hm, const int* __restrict__ n_dev) {
     const int g = blockIdx.x * 256 + threadIdx.x;
+    if (n_dev) n_total = *n_dev;  // counts only known on the device: the launch was sized for the capacity
     if (g >= n_total) return;
     const int cell = frame_fill_one(cams, n_cams, g, mbf, minX, minY, invW, invH, x, y, ur, depth_out, oct, ang, kps_g, desc_g, hm);
     if (cell >= 0) atomicAdd(&cell_cnt[cell], 1);
@@ -550,6 +551,22 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
     MORB_PHASE(g_ph_fb, 5);
 }
 
+// Large frames with the per-camera counts still on the device: the camera table (count, base), the camera starts, the
+// {features, first query, queries} triple and the count trailer of the descriptor block, from the extractor's counts.
+__global__ void k_cams_from_counts(CamFeat* __restrict__ cams, int n_cams, const int* __restrict__ d_counts,
+                                   int* __restrict__ cam_start, int* __restrict__ range, int* __restrict__ trailer) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int base = 0;
+    for (int c = 0; c < n_cams; ++c) {
+        const int n = d_counts[c];
+        cams[c].n = n; cams[c].base = base;
+        cam_start[c] = base; trailer[c] = n;
+        base += n;
+    }
+    cam_start[n_cams] = base;
+    range[0] = base; range[1] = 0; range[2] = base;
+}
+
 // exclusive scan of cnt[0..n) into start[0..n], single 1024-thread block; cursor = copy of start
 __global__ __launch_bounds__(1024) void k_scan_cells(const int* cnt, int n, int* __restrict__ start, int* cursor) {
     // cnt and cursor may alias (the per-cell counters are turned into insert cursors in place)
@@ -578,8 +595,9 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const int* cnt, int n, int*
 }
 
 __global__ __launch_bounds__(256) void k_scatter_cells(const int* __restrict__ cell_of, int n_total, int* __restrict__ cursor,
-                                                       int* __restrict__ items) {
+                                                       int* __restrict__ items, const int* __restrict__ n_dev) {
     const int g = blockIdx.x * 256 + threadIdx.x;
+    if (n_dev) n_total = *n_dev;
     if (g >= n_total) return;
     const int cell = cell_of[g];
     if (cell >= 0) items[atomicAdd(&cursor[cell], 1)] = g;
@@ -1585,6 +1603,8 @@ extern "C" {
 
 int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
                            float max_x, float max_y, orbm_frame** out) {
+    MORB_ARG(out != nullptr);
+    *out = nullptr;
     return frame_from_device_impl(m, cams, n_cams, mbf, min_x, min_y, max_x, max_y, nullptr, out);
 }
 
@@ -1652,13 +1672,13 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
         MORB_ARG(((uintptr_t)cams[c].d_desc & 15) == 0 && ((uintptr_t)cams[c].d_kps & 3) == 0);
         n += cams[c].n;
     }
-    orbm_frame* F = nullptr;
+    orbm_frame* F = *out;  // non-NULL: a persistent frame of the same capacity is (re)filled
     int rc;
-    if (sink_filled) {
-        F = *out;
-        MORB_ARG(F && F->n_total == n && F->n_cams == n_cams && d_counts);
-    } else if ((rc = frame_shell(m, n, n_cams, min_x, min_y, max_x, max_y, d_counts != nullptr, &F))) {
-        return rc;
+    if (F) {
+        MORB_ARG(F->n_total == n && F->n_cams == n_cams && d_counts && F->desc_rows >= n);
+    } else {
+        MORB_ARG(!sink_filled);
+        if ((rc = frame_shell(m, n, n_cams, min_x, min_y, max_x, max_y, d_counts != nullptr, &F))) return rc;
     }
     rc = ORB_OK;
     const size_t slot = 64 * sizeof(CamFeat) + 65 * sizeof(int) + 64 * sizeof(int);
@@ -1680,7 +1700,6 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
     hipStream_t st = m->stream;
     const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int) + (size_t)8192 * sizeof(unsigned short);
     const bool small = n > 0 && n <= 8192 && n_cams <= 4 && lds_small <= 150 * 1024;
-    MORB_ARG(d_counts == nullptr || small);  // device-side counts are only wired into the single-workgroup build
     MORB_ARG(!sink_filled || small);
     if (!small) {
         MORB_HIP(hipMemcpyAsync(F->b->d_cams.p, hc, (size_t)n_cams * sizeof(CamFeat), hipMemcpyHostToDevice, st));
@@ -1705,23 +1724,31 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
                            F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_start.p,
                            F->b->d_items.p, hm, sink_filled ? (const int*)F->b->d_cell_of.p : nullptr, F->desc_rows);
     } else {
-        // count trailer of the descriptor block (the single-workgroup build writes it itself)
-        int* hcnt = reinterpret_cast<int*>(hs + 64 * sizeof(CamFeat) + 65 * sizeof(int));
-        for (int c = 0; c < n_cams; ++c) hcnt[c] = cams[c].n;
-        MORB_HIP(hipMemcpyAsync(F->b->d_desc.p + (size_t)F->desc_rows * 32, hcnt, (size_t)n_cams * sizeof(int), hipMemcpyHostToDevice, st));
+        const int* n_dev = nullptr;
+        if (d_counts) {
+            // counts still on the device (cams[c].n are capacities): the camera table is finished by a one-thread kernel
+            hipLaunchKernelGGL(k_cams_from_counts, dim3(1), dim3(64), 0, st, F->b->d_cams.p, n_cams, d_counts, F->b->d_cam_start.p,
+                               F->b->d_ntotal.p, reinterpret_cast<int*>(F->b->d_desc.p + (size_t)F->desc_rows * 32));
+            n_dev = F->b->d_ntotal.p;
+        } else {
+            // count trailer of the descriptor block (the single-workgroup build writes it itself)
+            int* hcnt = reinterpret_cast<int*>(hs + 64 * sizeof(CamFeat) + 65 * sizeof(int));
+            for (int c = 0; c < n_cams; ++c) hcnt[c] = cams[c].n;
+            MORB_HIP(hipMemcpyAsync(F->b->d_desc.p + (size_t)F->desc_rows * 32, hcnt, (size_t)n_cams * sizeof(int), hipMemcpyHostToDevice, st));
+        }
         MORB_HIP(hipMemsetAsync(F->b->d_cursor.p, 0, (size_t)(ncell + 1) * 4, st));  // used as the per-cell counter first
         if (n) {
             hipLaunchKernelGGL(k_frame_fill, dim3((n + 255) / 256), dim3(256), 0, st, (const CamFeat*)F->b->d_cams.p, n_cams, n, mbf,
                                F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
                                F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_of.p,
-                               F->b->d_cursor.p, hm);
+                               F->b->d_cursor.p, hm, n_dev);
         }
         // counts live in d_cursor; scan them into d_cell_start and leave d_cursor = running insert positions
         hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, (const int*)F->b->d_cursor.p, ncell, F->b->d_cell_start.p,
                            F->b->d_cursor.p);
         if (n) {
             hipLaunchKernelGGL(k_scatter_cells, dim3((n + 255) / 256), dim3(256), 0, st, (const int*)F->b->d_cell_of.p, n,
-                               F->b->d_cursor.p, F->b->d_items.p);
+                               F->b->d_cursor.p, F->b->d_items.p, n_dev);
             hipLaunchKernelGGL(k_sort_cells, dim3((ncell + 255) / 256), dim3(256), 0, st, (const int*)F->b->d_cell_start.p, ncell,
                                F->b->d_items.p);
         }
@@ -2240,7 +2267,7 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
     for (int k = 0; k < orbf_frontend::NSETS; ++k)
         if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
-    if (!rc && small_rig(f)) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[1]);  // overlap partner
+    if (!rc) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[1]);  // overlap partner
     for (int k = 0; k < orbf_frontend::NSETS && !rc; ++k)
         if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
             (rc = f->rs[k].depth.reserve(cap)) || (rc = f->rs[k].unx.reserve(cap)) || (rc = f->rs[k].uny.reserve(cap))) break;
@@ -2380,41 +2407,56 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     orbf_frontend::ResultSet& R = f->rs[set];
     if ((rc = orbx_set_host_mirror(ex, R.kps.dp, R.desc.dp, f->cap_total))) return rc;
     *went_async = 0;
-    if (!small_rig(f)) return orbx_run_async(ex);  // (> 4 cameras: the frame is assembled by the matcher's own kernels)
+    const bool small = small_rig(f);
     std::vector<orbm_cam_features> cams(f->n_cams);
     fill_cam_capacities(f, ex, cams.data());
-    if (f->pframe[set] && (f->pframe_W[set] != W || f->pframe_H[set] != H)) { orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr; }
-    FrameSink sink;
     float bd[4];
     if ((rc = orbm_image_bounds(&f->calib, W, H, bd))) return rc;  // Frame::ComputeImageBounds
+    if (f->pframe[set] && (f->pframe_W[set] != W || f->pframe_H[set] != H || f->pframe[set]->minX != bd[0] ||
+                           f->pframe[set]->minY != bd[1] || f->pframe[set]->maxX != bd[2] || f->pframe[set]->maxY != bd[3])) {
+        orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr;  // (image size or calibration changed)
+    }
     m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp; m->mirror_unx = R.unx.dp; m->mirror_uny = R.uny.dp;
-    if (f->pframe[set] && (f->pframe[set]->minX != bd[0] || f->pframe[set]->minY != bd[1] || f->pframe[set]->maxX != bd[2] ||
-                           f->pframe[set]->maxY != bd[3])) {  // (calibration changed)
-        orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr;
-    }
-    if (!f->pframe[set]) {
-        rc = frame_prepare_sink(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], &f->pframe[set], &sink);
-        f->pframe_W[set] = W; f->pframe_H[set] = H;
+    struct MirrorsOff { orbm_matcher* m; ~MirrorsOff() { m->mirror_ur = nullptr; m->mirror_depth = nullptr; m->mirror_unx = nullptr; m->mirror_uny = nullptr; } } mirrors_off{m};
+    if (small) {
+        // the describe kernel writes the per-feature half of the frame itself (FrameSink)
+        FrameSink sink;
+        if (!f->pframe[set]) {
+            rc = frame_prepare_sink(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], &f->pframe[set], &sink);
+            f->pframe_W[set] = W; f->pframe_H[set] = H;
+        } else {
+            orbm_frame* F = f->pframe[set];
+            F->n_total = f->cap_total; F->counts_on_device = true; F->host_valid = false;
+            rc = frame_sink_of(m, F, cams.data(), f->n_cams, f->mbf, &sink);
+        }
+        if (rc) return rc;
+        if ((rc = orbx_set_frame_sink(ex, &sink))) return rc;
     } else {
-        orbm_frame* F = f->pframe[set];
-        F->n_total = f->cap_total; F->counts_on_device = true; F->host_valid = false;
-        rc = frame_sink_of(m, F, cams.data(), f->n_cams, f->mbf, &sink);
+        // larger rigs: the matcher's own kernels assemble the frame from the extractor's per-camera outputs
+        if (!f->pframe[set]) {
+            m->frame_min_rows = f->cap_total;
+            rc = frame_shell(m, f->cap_total, f->n_cams, bd[0], bd[1], bd[2], bd[3], true, &f->pframe[set]);
+            m->frame_min_rows = 0;
+            if (rc) return rc;
+            f->pframe_W[set] = W; f->pframe_H[set] = H;
+        } else {
+            orbm_frame* F = f->pframe[set];
+            F->n_total = f->cap_total; F->counts_on_device = true; F->host_valid = false;
+        }
     }
-    m->mirror_ur = nullptr; m->mirror_depth = nullptr; m->mirror_unx = nullptr; m->mirror_uny = nullptr;
-    if (rc) return rc;
-    if ((rc = orbx_set_frame_sink(ex, &sink))) return rc;
     const int before = orbx_pending(ex);
     rc = orbx_run_async(ex);
-    (void)orbx_set_frame_sink(ex, nullptr);
+    if (small) (void)orbx_set_frame_sink(ex, nullptr);
     if (rc) return rc;
     *went_async = orbx_pending(ex) > before ? 1 : 0;
     if (*went_async) {
-        // the frame's grid is part of the extraction chain: built on the extractor's stream right behind the describe
-        // kernel (counts read from HBM), so that a step's matching starts with the search itself
+        // the frame's grid (larger rigs: the whole frame assembly) is part of the extraction chain: built on the
+        // extractor's stream right behind the describe kernel (counts read from HBM), so that a step's matching starts
+        // with the search itself
         orbm_frame* frp = f->pframe[set];
         hipStream_t keep = m->stream;
         m->stream = (hipStream_t)orbx_stream(ex);
-        rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], orbx_device_counts(ex), &frp, true);
+        rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], orbx_device_counts(ex), &frp, small);
         hipError_t he = rc ? hipSuccess : hipEventRecord(f->ev_ready[set], m->stream);
         m->stream = keep;
         if (rc) return rc;
@@ -2455,7 +2497,6 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     orbm_matcher* m = f->mt;
     hipStream_t st = m->stream;                                   // matching
     int rc, W = 0, H = 0, went_async = 0;
-    const bool small = small_rig(f);
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
     f->last_frame = nullptr; f->last_frame_owned = false;
 
@@ -2494,7 +2535,7 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     auto t_synced = t_impl;
     SearchJob J{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
     if ((rc = f->h_match.reserve(std::max(f->cap_total, 1)))) return rc;
-    bool async_path = small && went_async;
+    bool async_path = went_async != 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (async_path) {
             // matching follows the extraction chain (which ends with the frame grid) through its event; counts are in HBM

@@ -94,6 +94,29 @@ def test_reference_calibration_undistorts_as_the_reference_frame_does(overlap, h
     fe.close()
 
 
+@pytest.mark.parametrize("depth", [0, 2])
+def test_six_camera_rig_takes_the_multi_kernel_frame_path(depth):
+    """More than 4 cameras: the frame is assembled by the matcher's own kernels from the extractor's per-camera outputs
+    (camera table finished on the device from the counts in HBM), also with two timesteps announced ahead."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    nfs = (300, 150, 200, 300, 100, 250)
+    params = [m.ExtractorParams(nfeatures=n) for n in nfs]
+    fe = pipeline.FrontEnd(params, 320, 240)
+    ofe = OracleFrontEnd(params, 320, 240)
+    T = 6
+    frames = [[synth.image(c, t, 320, 240) for c in range(len(nfs))] for t in range(T)]
+    announced = 0
+    for t in range(T):
+        while announced < min(t + depth, T - 1):
+            announced += 1
+            fe.announce(frames[announced])
+        announced = max(announced, t)
+        assert_same_step(fe.step(frames[t]), ofe.step(frames[t]))
+    fe.close()
+
+
 def test_overlap_survives_the_host_quadtree_fallback():
     """Noise frames put more than 4096 candidates on level 0: the device quadtree reports 'outside my limits' and the step
     is redone on the host path -- with the next step's extraction already in flight its images have to be uploaded again."""

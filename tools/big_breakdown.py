@@ -17,14 +17,15 @@ for t in range(3):
     dev.append(row)
 rt.device_sync()
 arg = lambda t: [(dev[t % 3][c].ptr, W) for c in range(NC)]
+OV = os.environ.get('OVERLAP', '1') == '1'
 for i in range(5):
-    fe.step(arg(i), resident=True)
+    fe.step(arg(i), resident=True, next_images=arg(i + 1) if OV else None)
 hs = np.zeros(4); n = 20
 t0 = time.perf_counter()
 for i in range(5, 5 + n):
-    r = fe.step(arg(i), resident=True); hs += np.array(r["host_us"])
+    r = fe.step(arg(i), resident=True, next_images=arg(i + 1) if OV else None); hs += np.array(r["host_us"])
 dt = (time.perf_counter() - t0) / n
-fe.ex.set_profiling(True); fe.step(arg(0), resident=True)
+fe.reset(); fe.ex.set_profiling(True); fe.step(arg(0), resident=True)
 print(json.dumps({"ms_per_step": round(dt * 1e3, 3), "host_us[prep,enqueue,wait,post]": [round(x / n, 1) for x in hs],
                   "extractor_us": {k: round(v, 1) for k, v in fe.ex.stage_times_us().items()}, "path": fe.ex.last_path(),
                   "resolve": fe.mt.last_resolve()}))

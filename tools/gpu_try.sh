@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -X faulthandler -m pytest tests -m gpu -q -x 2>&1 | tail -4
-timeout 600 python tools/big_breakdown.py 2>&1 | tail -1 | cut -c1-330
-timeout 300 python bench.py --no-cpu --no-roofline 2>&1 | grep metric | cut -c1-200
+timeout 900 python -X faulthandler -m pytest tests/test_gpu_frontend.py -m gpu -q -x 2>&1 | tail -4
+timeout 600 python tools/bench_configs.py 2>&1 | tail -6 | cut -c1-130
