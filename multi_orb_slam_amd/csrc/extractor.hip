@@ -1316,7 +1316,10 @@ struct orbx_extractor {
             if (graph) (void)hipGraphDestroy(graph);
             exec = nullptr; graph = nullptr; epoch = -1;
         }
-    } chain[2];
+    };
+    static constexpr int CHAIN_WAYS = 4;
+    ChainGraph chain[2][CHAIN_WAYS];
+    int chain_next[2] = {0, 0};      // replacement cursor per slot
     bool use_graph = true;           // MORB_CHAIN_GRAPH=0 keeps plain launches
     int geom_epoch = 0;              // bumped by every rebuild_geometry
     int inflight = 0; unsigned run_seq = 0;
@@ -1547,7 +1550,7 @@ void orbx_destroy(orbx_extractor* ex) {
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    ex->chain[0].destroy(); ex->chain[1].destroy();
+    for (int sl = 0; sl < 2; ++sl) for (int w = 0; w < orbx_extractor::CHAIN_WAYS; ++w) ex->chain[sl][w].destroy();
     ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release();
     ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release(); ex->d_sel_oct.release();
     ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release();
@@ -1776,13 +1779,20 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         // The ten launches of the chain are captured once per slot into a kernel-only graph and replayed with one
         // hipGraphLaunch (the host cost of enqueueing them is what bounds overlapped timesteps).  Everything the launches
         // carry is in the key: geometry epoch, result mirrors, frame sink.
-        orbx_extractor::ChainGraph& G = ex->chain[slot];
         const FrameSink sink = allow_async ? ex->sink : FrameSink{};
         const bool graphable = ex->use_graph && allow_async && !ex->profiling;
         bool done = false;
         if (graphable) {
-            const bool hit = G.exec && G.epoch == ex->geom_epoch && G.mirror_kps == ex->mirror_kps && G.mirror_desc == ex->mirror_desc &&
-                             memcmp(&G.sink, &sink, sizeof(FrameSink)) == 0;
+            // a few graphs per slot: a caller rotates through more result sets / frames than there are slots
+            int way = -1;
+            for (int w = 0; w < orbx_extractor::CHAIN_WAYS; ++w) {
+                const orbx_extractor::ChainGraph& C = ex->chain[slot][w];
+                if (C.exec && C.epoch == ex->geom_epoch && C.mirror_kps == ex->mirror_kps && C.mirror_desc == ex->mirror_desc &&
+                    memcmp(&C.sink, &sink, sizeof(FrameSink)) == 0) { way = w; break; }
+            }
+            const bool hit = way >= 0;
+            if (!hit) { way = ex->chain_next[slot]; ex->chain_next[slot] = (way + 1) % orbx_extractor::CHAIN_WAYS; }
+            orbx_extractor::ChainGraph& G = ex->chain[slot][way];
             if (hit) {
                 MORB_HIP(hipGraphLaunch(G.exec, st));
                 done = true;
