@@ -82,6 +82,28 @@ __device__ __forceinline__ int ham256(const uint4& a0, const uint4& a1, const ui
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
+// Running top-2 of one query per lane against the rows [ja, jb) of `r` (wave-uniform addresses -> scalar loads, four rows =
+// 128 B per trip); the reported index is j - shift.  second = 2nd smallest with multiplicity, best index = first minimum
+// (strict '<' chain, ORBmatcher.cc:311-320).
+__device__ __forceinline__ void top2_scan(const uint4* __restrict__ r, int ja, int jb, int shift, const uint4& q0, const uint4& q1,
+                                          int& b, int& s, int& bi) {
+#define TOP2_UPDATE(d, j) do { s = min(s, max(b, (d))); bi = (d) < b ? (j) : bi; b = min(b, (d)); } while (0)
+    int j = ja;
+    for (; j + 4 <= jb; j += 4) {
+        const uint4 a0 = r[2 * j], a1 = r[2 * j + 1], b0 = r[2 * j + 2], b1 = r[2 * j + 3];
+        const uint4 c0 = r[2 * j + 4], c1 = r[2 * j + 5], e0 = r[2 * j + 6], e1 = r[2 * j + 7];
+        const int d0 = (int)ham256_chain(a0, a1, q0, q1), d1 = (int)ham256_chain(b0, b1, q0, q1);
+        const int d2 = (int)ham256_chain(c0, c1, q0, q1), d3 = (int)ham256_chain(e0, e1, q0, q1);
+        TOP2_UPDATE(d0, j - shift); TOP2_UPDATE(d1, j + 1 - shift); TOP2_UPDATE(d2, j + 2 - shift); TOP2_UPDATE(d3, j + 3 - shift);
+    }
+    for (; j < jb; ++j) {
+        const uint4 a0 = r[2 * j], a1 = r[2 * j + 1];
+        const int d = (int)ham256_chain(a0, a1, q0, q1);
+        TOP2_UPDATE(d, j - shift);
+    }
+#undef TOP2_UPDATE
+}
+
 // grid.x = ceil(nq/64), grid.y = S reference slices (S == 1: final results; S > 1: partials for k_top2_merge)
 __global__ __launch_bounds__(64 * TOP2_WAVES) void k_hamming_top2(const uint4* __restrict__ q, int nq,
                                                                  const uint4* __restrict__ r, int nr,
@@ -102,22 +124,7 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_hamming_top2(const uint4* _
     const int j0 = s0 + wave * chunk, j1 = min(s1, j0 + chunk);
 
     int b = 256, s = 256, bi = -1;
-    // second = 2nd smallest with multiplicity, best index = first minimum (strict '<' chain, ORBmatcher.cc:311-320)
-#define TOP2_UPDATE(d, j) do { s = min(s, max(b, (d))); bi = (d) < b ? (j) : bi; b = min(b, (d)); } while (0)
-    int j = j0;
-    for (; j + 4 <= j1; j += 4) {  // 4 references (128 B through the scalar cache) per trip
-        const uint4 a0 = r[2 * j], a1 = r[2 * j + 1], b0 = r[2 * j + 2], b1 = r[2 * j + 3];
-        const uint4 c0 = r[2 * j + 4], c1 = r[2 * j + 5], e0 = r[2 * j + 6], e1 = r[2 * j + 7];
-        const int d0 = (int)ham256_chain(a0, a1, q0, q1), d1 = (int)ham256_chain(b0, b1, q0, q1);
-        const int d2 = (int)ham256_chain(c0, c1, q0, q1), d3 = (int)ham256_chain(e0, e1, q0, q1);
-        TOP2_UPDATE(d0, j); TOP2_UPDATE(d1, j + 1); TOP2_UPDATE(d2, j + 2); TOP2_UPDATE(d3, j + 3);
-    }
-    for (; j < j1; ++j) {
-        const uint4 a0 = r[2 * j], a1 = r[2 * j + 1];  // wave-uniform address -> scalar loads
-        const int d = (int)ham256_chain(a0, a1, q0, q1);
-        TOP2_UPDATE(d, j);
-    }
-#undef TOP2_UPDATE
+    top2_scan(r, j0, j1, 0, q0, q1, b, s, bi);
     sb[wave][lane] = b; ss[wave][lane] = s; si[wave][lane] = bi;
     __syncthreads();
     if (wave == 0 && qi < nq) {
@@ -1134,21 +1141,8 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __r
     // (for a 2-camera rig that is half of all pairs) and the per-pair segment test disappears
     const int seg0u = __builtin_amdgcn_readfirstlane(seg0), seg1u = __builtin_amdgcn_readfirstlane(seg1);
     if (__all(seg0 == seg0u)) {
-        for (int j = j0, je = min(j1, seg0u); j < je; ++j) {          // cameras in front of the own one: index unchanged
-            const uint4 a0 = desc[2 * j], a1 = desc[2 * j + 1];        // wave-uniform -> scalar loads
-            const int d = (int)ham256_chain(a0, a1, q0, q1);
-            s = min(s, max(b, d));
-            bi = d < b ? j : bi;
-            b = min(b, d);
-        }
-        const int shift = seg1u - seg0u;
-        for (int j = max(j0, seg1u); j < j1; ++j) {                    // cameras behind it: index minus the own count
-            const uint4 a0 = desc[2 * j], a1 = desc[2 * j + 1];
-            const int d = (int)ham256_chain(a0, a1, q0, q1);
-            s = min(s, max(b, d));
-            bi = d < b ? j - shift : bi;
-            b = min(b, d);
-        }
+        top2_scan(desc, j0, min(j1, seg0u), 0, q0, q1, b, s, bi);                 // cameras in front of the own one
+        top2_scan(desc, max(j0, seg1u), j1, seg1u - seg0u, q0, q1, b, s, bi);     // cameras behind it: index minus the own count
     } else {
         for (int j = j0; j < j1; ++j) {
             const uint4 a0 = desc[2 * j], a1 = desc[2 * j + 1];
