@@ -19,15 +19,17 @@ for name, (W, H, NF, NC) in {"configs[2] 2x1280x720@2000": (1280, 720, 2000, 2),
         dev.append(row)
     rt.device_sync()
     arg = lambda t: [(dev[t % R][c].ptr, W) for c in range(NC)]
-    for ov in (False, True):
+    for ov in (0, 1, 2):        # timesteps announced ahead
         fe.reset()
         n = 40
+        if ov == 2:
+            fe.announce(arg(1), resident=True)
         for i in range(6):
-            fe.step(arg(i), resident=True, next_images=arg(i + 1) if ov else None)
+            fe.step(arg(i), resident=True, next_images=arg(i + ov) if ov else None)
         t0 = time.perf_counter()
         for i in range(6, 6 + n):
-            r = fe.step(arg(i), resident=True, next_images=arg(i + 1) if ov else None)
+            r = fe.step(arg(i), resident=True, next_images=arg(i + ov) if ov else None)
         dt = (time.perf_counter() - t0) / n
-        print(json.dumps({"config": name, "overlap": ov, "ms_per_step": round(dt * 1e3, 3), "steps_per_s": round(1 / dt, 1),
+        print(json.dumps({"config": name, "announced_ahead": ov, "ms_per_step": round(dt * 1e3, 3), "steps_per_s": round(1 / dt, 1),
                           "keypoints": r["counts"], "temporal_matches": r["n_temporal"]}))
     fe.close()
