@@ -39,6 +39,9 @@ void orbm_destroy(orbm_matcher* m);
 void* orbm_stream(const orbm_matcher* m);
 /* Make the matcher issue all its work on a caller-owned hipStream_t (e.g. orbx_stream(ex), so frame building and
  * matching are ordered after the extractor's kernels without events); NULL restores the matcher's own stream. */
+/* Orders this handle's stream behind everything enqueued so far on another HIP stream of the same device (e.g. the
+ * stream a collective library ran an all-gather on) without blocking the host. */
+int orbm_wait_for_stream(orbm_matcher* m, void* other_stream);
 int orbm_set_stream(orbm_matcher* m, void* stream);
 /* {status, nmatches, sweeps, longest candidate list} of the last device-side resolve (inspection only) */
 int orbm_debug_last_resolve(const orbm_matcher* m, int* out4);

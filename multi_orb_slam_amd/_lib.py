@@ -114,6 +114,7 @@ def lib():
     L.orbm_frame_create.argtypes = [vp, vp, vp]
     L.orbm_frame_destroy.argtypes = [vp]; L.orbm_frame_destroy.restype = None
     L.orbm_set_stream.argtypes = [vp, vp]
+    L.orbm_wait_for_stream.argtypes = [vp, vp]
     L.orbm_frame_from_device.argtypes = [vp, vp, i32, f32, f32, f32, f32, f32, vp]
     L.orbm_frame_download.argtypes = [vp, vp, vp, vp, vp, vp]
     L.orbm_frame_count.argtypes = [vp]

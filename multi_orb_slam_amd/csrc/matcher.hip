@@ -1375,6 +1375,15 @@ int orbm_debug_last_resolve(const orbm_matcher* m, int* out4) {
     return ORB_OK;
 }
 
+int orbm_wait_for_stream(orbm_matcher* m, void* other_stream) {
+    MORB_ARG(m != nullptr);
+    MORB_HIP(hipSetDevice(m->device));
+    // everything enqueued on `other_stream` so far happens before whatever this handle enqueues next (no host wait)
+    MORB_HIP(hipEventRecord(m->ev_fork, (hipStream_t)other_stream));
+    MORB_HIP(hipStreamWaitEvent(m->stream, m->ev_fork, 0));
+    return ORB_OK;
+}
+
 int orbm_set_stream(orbm_matcher* m, void* stream) {
     MORB_ARG(m != nullptr);
     MORB_HIP(hipSetDevice(m->device));

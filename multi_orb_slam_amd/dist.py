@@ -39,9 +39,10 @@ class DescriptorExchange:
             self.recv = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.device)
             self.recv_ptr = self.recv.data_ptr()
         # the block was complete before the step returned (the matcher waited on the extractor's event), so RCCL may read
-        # it on torch's stream right away; the matcher's kernels then wait for the collective on the host
+        # it on torch's stream right away; the matcher's stream is ordered behind the collective on the device
         dist.all_gather_into_tensor(self.recv, send)
-        torch.cuda.current_stream().synchronize()
+        if self.recv.is_cuda:
+            frontend.mt.wait_for_stream(torch.cuda.current_stream().cuda_stream)
         return frontend.mt.cross_top2_gathered(self.recv_ptr, self.world, nbytes, rows, frontend.n_cams, self.rank)
 
 

@@ -172,6 +172,10 @@ class Matcher:
                                                 ptr(sd)))
         return bi[:nq], bd[:nq], sd[:nq]
 
+    def wait_for_stream(self, stream_handle):
+        """Order this matcher's stream behind another HIP stream's work so far (orbm_wait_for_stream); no host wait."""
+        check(_lib.lib().orbm_wait_for_stream(self._h, C.c_void_p(stream_handle)))
+
     def last_resolve(self):
         """(status, matches, sweeps, longest candidate list) of the last device resolve (orbm_debug_last_resolve)."""
         out = (C.c_int * 4)()
@@ -181,11 +185,16 @@ class Matcher:
     def cross_top2_gathered(self, gathered_ptr, world, block_bytes, cap_rows, cams_per_rank, rank):
         """Cross-camera top-2 of this rank's features against the whole rig from ONE all-gathered buffer
         (orbm_cross_top2_gathered).  -> (best_idx, best_dist, second_dist, counts of every camera of the rig)."""
-        bi = np.zeros(cap_rows, np.int32); bd = np.zeros(cap_rows, np.int32); sd = np.zeros(cap_rows, np.int32)
-        cnt = np.zeros(world * cams_per_rank, np.int32); nq = C.c_int()
+        key = (cap_rows, world * cams_per_rank)
+        buf = getattr(self, "_gathered_buf", None)
+        if buf is None or buf[0] != key:      # result buffers are reused from call to call (copied out below)
+            buf = self._gathered_buf = (key, np.zeros(cap_rows, np.int32), np.zeros(cap_rows, np.int32), np.zeros(cap_rows, np.int32),
+                                        np.zeros(world * cams_per_rank, np.int32))
+        _, bi, bd, sd, cnt = buf
+        nq = C.c_int()
         check(_lib.lib().orbm_cross_top2_gathered(self._h, C.c_void_p(gathered_ptr), world, block_bytes, cap_rows, cams_per_rank, rank,
                                                   ptr(bi), ptr(bd), ptr(sd), ptr(cnt), C.byref(nq)))
-        return bi[:nq.value], bd[:nq.value], sd[:nq.value], cnt.tolist()
+        return bi[:nq.value].copy(), bd[:nq.value].copy(), sd[:nq.value].copy(), cnt.tolist()
 
     def cross_top2(self, frame):
         n = max(frame.data.n_total, 1)
