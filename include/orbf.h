@@ -81,7 +81,16 @@ int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* quer
  * first step or after orbf_reset).  out->n_queries / out->queries expose what was searched. */
 typedef struct orbf_motion { float du, dv, th; } orbf_motion;
 int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out);
-int orbf_reset(orbf_frontend* f); /* forget the previous step (next orbf_step_motion searches nothing) */
+int orbf_reset(orbf_frontend* f);
+
+/* A step in two halves.  _begin enqueues everything and returns at once; _end blocks (one synchronisation) and fills the
+ * result.  *block_ready (may be NULL) = 1 when this step's export block (orbf_export_block, valid right after _begin) is
+ * already final -- its extraction had completed cleanly before the call, the normal case with steps announced ahead --
+ * so that a multi-GPU caller may enqueue its all-gather and orbm_cross_top2_gathered_enqueue between the two halves and
+ * have them run next to the step's matching.  With 0 the block only becomes final in _end (exchange afterwards). */
+int orbf_step_begin(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, int* block_ready);
+int orbf_step_motion_begin(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, int* block_ready);
+int orbf_step_end(orbf_frontend* f, orbf_result* out); /* forget the previous step (next orbf_step_motion searches nothing) */
 
 /* the composed handles, e.g. for orbx_bind_output / orbx_stage_times_us / orbm_cross_top2_blocks */
 orbx_extractor* orbf_extractor(orbf_frontend* f);

@@ -127,6 +127,11 @@ def lib():
     L.orbf_step_motion.argtypes = [vp, vp, vp, i32, vp]
     L.orbf_reset.argtypes = [vp]
     L.orbf_prefetch.argtypes = [vp, vp]
+    L.orbf_step_begin.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.orbf_step_motion_begin.argtypes = [vp, vp, vp, i32, vp]
+    L.orbf_step_end.argtypes = [vp, vp]
+    L.orbm_cross_top2_gathered_enqueue.argtypes = [vp, vp, i32, C.c_size_t, i32, i32, i32, vp]
+    L.orbm_cross_top2_gathered_collect.argtypes = [vp, vp, vp, vp, vp, vp]
     L.orbf_export_block.argtypes = [vp, vp, vp, vp]
     L.orbm_cross_top2_gathered.argtypes = [vp, vp, i32, C.c_size_t, i32, i32, i32, vp, vp, vp, vp, vp]
     L.orbf_extractor.argtypes = [vp]; L.orbf_extractor.restype = vp

@@ -1668,6 +1668,13 @@ int orbx_set_frame_sink(orbx_extractor* ex, const FrameSink* sink) {
 // counts of the most recently enqueued run
 const int* orbx_device_counts(const orbx_extractor* ex) { return ex ? ex->d_n_out.p + ((ex->run_seq - 1u) & 1u) * ex->n_cams : nullptr; }
 int orbx_pending(const orbx_extractor* ex) { return ex ? ex->inflight : 0; }
+// Status word of the OLDEST run in flight (0: every level stayed inside the device quadtree's limits); only meaningful
+// once that run has completed on the device (the caller has seen its completion event).  -1: nothing in flight.
+int orbx_peek_status(const orbx_extractor* ex) {
+    if (!ex || ex->inflight == 0) return -1;
+    const unsigned oldest = (ex->run_seq - (unsigned)ex->inflight) & 1u;
+    return ex->h_oct[oldest * (ex->n_cams + 1) + ex->n_cams];
+}
 void* orbx_done_event(const orbx_extractor* ex) { return ex ? (void*)ex->ev_done[(ex->run_seq - 1u) & 1u] : nullptr; }
 
 // K1 + K2/K3 of a run: the pyramid chain and the per-cell FAST kernel

@@ -28,3 +28,4 @@ extern "C" int orbx_set_frame_sink(orbx_extractor* ex, const FrameSink* sink);
 
 // completion event of the most recently enqueued asynchronous run (valid while it is in flight)
 extern "C" void* orbx_done_event(const orbx_extractor* ex);
+extern "C" int orbx_peek_status(const orbx_extractor* ex);  // status of the oldest run in flight (valid once it completed)

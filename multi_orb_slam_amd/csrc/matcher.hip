@@ -1244,6 +1244,8 @@ struct orbm_matcher {
     DevBuf<uint16_t> d_u16;
     PinnedBuf<int32_t> h_i0, h_i1, h_i2, h_match;
     PinnedBuf<int32_t> h_gcnt;            // per-camera counts of a gathered multi-GPU exchange (+ own query count)
+    DevBuf<int32_t> d_gstart;             // camera starts + {features, first query, queries} of the gathered list
+    int gathered_cams = 0;                // cameras of the last orbm_cross_top2_gathered_enqueue
     PinnedBuf<int32_t> h_c0, h_c1, h_c2;  // cross top-2 results (own buffers: they coexist with a search's h_i0/h_i1)
     DevBuf<uint8_t> d_cscratch;           // cross top-2 slice partials
     hipStream_t side_stream = nullptr;    // orbf_step: cross top-2 runs here, next to project + resolve on `stream`
@@ -1357,7 +1359,7 @@ void orbm_destroy(orbm_matcher* m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->ev_q) (void)hipEventDestroy(m->ev_q);
-    m->h_c0.release(); m->h_c1.release(); m->h_c2.release(); m->d_cscratch.release(); m->h_gcnt.release();
+    m->h_c0.release(); m->h_c1.release(); m->h_c2.release(); m->d_cscratch.release(); m->h_gcnt.release(); m->d_gstart.release();
     m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release(); m->d_occ.release();
     m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release();
     m->d_match.release(); m->d_status.release(); m->d_gclaim.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
@@ -2167,27 +2169,42 @@ int orbm_cross_top2_blocks(orbm_matcher* m, const uint8_t* const* d_desc_blocks,
     return cross_launch(m, m->d_r.p, n, m->d_choice.p, n_blocks, q_off, nq, best_idx, best_dist, second_dist);
 }
 
-int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int world, size_t block_bytes, int cap_rows,
-                             int cams_per_rank, int rank, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
-                             int32_t* counts_out, int* nq_out) {
+// enqueue half: repack + top-2 on the handle's SIDE stream (next to whatever the main stream is doing), joined into the
+// main stream so that the next synchronisation of the main stream covers it
+int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered, int world, size_t block_bytes, int cap_rows,
+                                     int cams_per_rank, int rank, void* after_stream) {
     MORB_ARG(m && d_gathered && world >= 1 && cams_per_rank >= 1 && world * cams_per_rank <= 512 && rank >= 0 && rank < world &&
-             cap_rows >= 1 && block_bytes >= (size_t)cap_rows * 32 + (size_t)cams_per_rank * 4 && (block_bytes & 15) == 0 && nq_out);
+             cap_rows >= 1 && block_bytes >= (size_t)cap_rows * 32 + (size_t)cams_per_rank * 4 && (block_bytes & 15) == 0);
     MORB_ARG(((uintptr_t)d_gathered & 15) == 0);
     MORB_HIP(hipSetDevice(m->device));
     const int n_cams = world * cams_per_rank;
     const int n_cap = world * cap_rows;  // capacity of the contiguous list
     int rc;
-    if ((rc = m->d_r.reserve((size_t)n_cap * 32)) || (rc = m->d_choice.reserve(n_cams + 1 + 4)) || (rc = m->h_gcnt.reserve(n_cams + 1)))
+    if ((rc = m->d_r.reserve((size_t)n_cap * 32)) || (rc = m->d_gstart.reserve(n_cams + 1 + 4)) || (rc = m->h_gcnt.reserve(n_cams + 1)))
         return rc;
-    int* d_cam_start = m->d_choice.p;
-    int* d_range = m->d_choice.p + n_cams + 1;
-    hipStream_t st = m->stream;
-    hipLaunchKernelGGL(k_repack_gathered, dim3((2 * cap_rows + 255) / 256, world), dim3(256), 0, st, d_gathered, world, block_bytes, cap_rows,
+    hipStream_t sd = m->side_stream;
+    if (after_stream) {  // the gathered buffer is produced on another stream (the collective's): order the side stream behind it
+        MORB_HIP(hipEventRecord(m->ev_fork, (hipStream_t)after_stream));
+        MORB_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
+    }
+    int* d_cam_start = m->d_gstart.p;
+    int* d_range = m->d_gstart.p + n_cams + 1;
+    hipLaunchKernelGGL(k_repack_gathered, dim3((2 * cap_rows + 255) / 256, world), dim3(256), 0, sd, d_gathered, world, block_bytes, cap_rows,
                        cams_per_rank, rank, (uint4*)m->d_r.p, d_cam_start, d_range, m->h_gcnt.dp);
     MORB_HIP(hipGetLastError());
     // the launch is sized for the capacity (cap_rows queries against world * cap_rows features); the counts come from HBM
-    if ((rc = cross_enqueue(m, st, m->d_r.p, n_cap, d_cam_start, n_cams, 0, cap_rows, d_range))) return rc;
-    MORB_HIP(hipStreamSynchronize(st));
+    if ((rc = cross_enqueue(m, sd, m->d_r.p, n_cap, d_cam_start, n_cams, 0, cap_rows, d_range))) return rc;
+    MORB_HIP(hipEventRecord(m->ev_join, sd));
+    MORB_HIP(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+    m->gathered_cams = n_cams;
+    return ORB_OK;
+}
+
+// collect half, after the main stream has been synchronised (orbf_step_end does)
+int orbm_cross_top2_gathered_collect(orbm_matcher* m, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                                     int32_t* counts_out, int* nq_out) {
+    MORB_ARG(m && nq_out && m->gathered_cams > 0);
+    const int n_cams = m->gathered_cams;
     const int nq = m->h_gcnt.p[n_cams];
     *nq_out = nq;
     if (counts_out) memcpy(counts_out, m->h_gcnt.p, (size_t)n_cams * 4);
@@ -2197,6 +2214,19 @@ int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int wor
         memcpy(second_dist, m->h_c2.p, (size_t)nq * 4);
     }
     return ORB_OK;
+}
+
+int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int world, size_t block_bytes, int cap_rows,
+                             int cams_per_rank, int rank, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                             int32_t* counts_out, int* nq_out) {
+    MORB_ARG(nq_out != nullptr);
+    // (the main stream may have been ordered behind the collective by orbm_wait_for_stream: the side stream inherits that)
+    int rc;
+    MORB_HIP(hipSetDevice(m ? m->device : 0));
+    if (m) { MORB_HIP(hipEventRecord(m->ev_q, m->stream)); MORB_HIP(hipStreamWaitEvent(m->side_stream, m->ev_q, 0)); }
+    if ((rc = orbm_cross_top2_gathered_enqueue(m, d_gathered, world, block_bytes, cap_rows, cams_per_rank, rank, nullptr))) return rc;
+    MORB_HIP(hipStreamSynchronize(m->stream));
+    return orbm_cross_top2_gathered_collect(m, best_idx, best_dist, second_dist, counts_out, nq_out);
 }
 
 
@@ -2237,6 +2267,15 @@ struct orbf_frontend {
     int last_e = 0;  // extractor most recently handed a timestep
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path ...
     int clean_steps = 0;     // ... and set again after a few steps that stayed on the device path
+    struct Pending {  // a timestep between orbf_step_begin and orbf_step_end
+        bool active = false, async_path = false, fr_persistent = false, block_ready = false;
+        int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
+        orbm_frame* fr = nullptr;
+        SearchJob J{nullptr, nullptr, 0, nullptr, false, 0.f, 0, 0, 64, false};
+        std::vector<orbf_image> images;
+        std::vector<orbm_cam_features> cams;
+        std::chrono::steady_clock::time_point t_impl, t_enqueued;
+    } pending;
     hipEvent_t ev_extracted = nullptr;  // extractor stream -> matcher stream on the synchronous path
     hipEvent_t ev_ready[NSETS] = {nullptr, nullptr, nullptr, nullptr};  // extraction + frame grid of the step using that set
     // frame of the last completed step (orbf_export_block); a frame built on the synchronous path is kept until the next step
@@ -2269,7 +2308,7 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     const size_t cap = (size_t)f->cap_total;
     if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
     for (int k = 0; k < orbf_frontend::NSETS; ++k)
-        if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
+        if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
     if (!rc) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[1]);  // overlap partner
     for (int k = 0; k < orbf_frontend::NSETS && !rc; ++k)
         if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
@@ -2324,6 +2363,9 @@ int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientati
 
 static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
                           orbf_result* out, bool queries_in_pinned);
+static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
+                                bool queries_in_pinned, int* block_ready);
+static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out);
 static int orbf_drain(orbf_frontend* f);
 
 int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out) {
@@ -2342,10 +2384,12 @@ int orbf_reset(orbf_frontend* f) {
 
 int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_bytes, int* cap_rows) {
     MORB_ARG(f && d_block && block_bytes && cap_rows);
-    if (!f->last_frame) { morb::set_error("no completed step to export"); return ORB_E_ARG; }
-    *d_block = f->last_frame->b->d_desc.p;
-    *cap_rows = f->last_frame->desc_rows;
-    *block_bytes = (size_t)f->last_frame->desc_rows * 32 + ORBM_BLOCK_TRAILER;
+    // between orbf_step_begin and orbf_step_end: the frame of the step in flight; otherwise the last completed step's
+    const orbm_frame* F = (f->pending.active && f->pending.fr) ? f->pending.fr : f->last_frame;
+    if (!F) { morb::set_error("no step to export"); return ORB_E_ARG; }
+    *d_block = F->b->d_desc.p;
+    *cap_rows = F->desc_rows;
+    *block_bytes = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
     return ORB_OK;
 }
 
@@ -2357,20 +2401,49 @@ int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images) {
     return ORB_OK;
 }
 
+int orbf_step_begin(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, int* block_ready) {
+    MORB_ARG(f && images && nq >= 0 && (nq == 0 || queries));
+    f->t_entry = std::chrono::steady_clock::now();
+    int rc = orbf_step_begin_impl(f, images, queries, nq, flags, false, block_ready);
+    if (rc) f->pending.active = false;
+    return rc;
+}
+
+static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motion, int* nq_out);
+
+int orbf_step_motion_begin(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, int* block_ready) {
+    MORB_ARG(f && images && motion);
+    f->t_entry = std::chrono::steady_clock::now();
+    int nq = 0, rc;
+    if ((rc = queries_from_previous_step(f, motion, &nq))) return rc;
+    rc = orbf_step_begin_impl(f, images, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, flags, true, block_ready);
+    if (rc) f->pending.active = false;
+    return rc;
+}
+
+int orbf_step_end(orbf_frontend* f, orbf_result* out) {
+    MORB_ARG(f && out);
+    return orbf_step_end_impl(f, out);
+}
+
+// the previous step's features (still in their pinned result set) under the stream's motion -> this step's queries
+static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motion, int* nq_out) {
+    const int nq = f->prev_n;
+    *nq_out = nq;
+    if (!nq) return ORB_OK;
+    int rc;
+    if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
+    const orbf_frontend::ResultSet& R = f->rs[f->cur];
+    return orbm_queries_from_motion(R.kps.p, R.desc.p, R.depth.p, f->prev_cam_of.data(), nq, motion->du, motion->dv, motion->th,
+                                    f->scale_factors.data(), f->mbf, reinterpret_cast<orbm_query*>(f->h_queries.p),
+                                    R.unx.p, R.uny.p);  // (mvKeysUn: equal to the keypoint positions without a calibration)
+}
+
 int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out) {
     MORB_ARG(f && images && motion && out);
-    const int nq = f->prev_n;
-    int rc;
     f->t_entry = std::chrono::steady_clock::now();
-    if (nq) {
-        // the previous step's features are still in their pinned result set
-        if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
-        const orbf_frontend::ResultSet& R = f->rs[f->cur];
-        rc = orbm_queries_from_motion(R.kps.p, R.desc.p, R.depth.p, f->prev_cam_of.data(), nq, motion->du, motion->dv,
-                                      motion->th, f->scale_factors.data(), f->mbf, reinterpret_cast<orbm_query*>(f->h_queries.p),
-                                      R.unx.p, R.uny.p);  // (mvKeysUn: equal to the keypoint positions without a calibration)
-        if (rc) return rc;
-    }
+    int nq = 0, rc;
+    if ((rc = queries_from_previous_step(f, motion, &nq))) return rc;
     return orbf_step_impl(f, images, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, flags, out, true);
 }
 
@@ -2490,24 +2563,29 @@ static void next_slot(orbf_frontend* f, int* e, int* set) {
     f->last_set = *set; f->last_e = *e;
 }
 
-static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
-                          orbf_result* out, bool queries_in_pinned) {
-    const auto t_impl = std::chrono::steady_clock::now();
-    auto us_between = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<float, std::micro>(b - a).count();
-    };
+// A timestep in two halves.  orbf_step_begin enqueues everything (this step's matching, the extraction of the announced
+// steps) and returns; orbf_step_end blocks once and collects.  Between the two a caller may enqueue work of its own that
+// only needs the step's export block -- the multi-GPU exchange -- when begin reported the block ready.
+static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_attempt);
+
+static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
+                                bool queries_in_pinned, int* block_ready) {
+    orbf_frontend::Pending& P = f->pending;
+    MORB_ARG(!P.active);
+    P = orbf_frontend::Pending();
+    P.t_impl = std::chrono::steady_clock::now();
     MORB_HIP(hipSetDevice(f->device));
     orbm_matcher* m = f->mt;
-    hipStream_t st = m->stream;                                   // matching
-    int rc, W = 0, H = 0, went_async = 0;
+    int rc, went_async = 0;
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
     f->last_frame = nullptr; f->last_frame_owned = false;
+    P.images.assign(images, images + f->n_cams);
+    P.nq = nq; P.flags = flags;
 
     // ---- this step's extraction: already in flight (orbf_prefetch during an earlier step) or enqueued now
-    int set, e;
     if (!f->inflight.empty() && same_images(f->inflight.front().images, images, f->n_cams)) {
         const orbf_frontend::InFlight& I = f->inflight.front();
-        set = I.set; e = I.e; W = I.W; H = I.H; went_async = 1;
+        P.set = I.set; P.e = I.e; P.W = I.W; P.H = I.H; went_async = 1;
         f->inflight.pop_front();
     } else {
         if (!f->inflight.empty()) {  // prefetched for other images: everything in flight is dropped
@@ -2515,13 +2593,9 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
             f->announced.clear();
         }
         if (!f->announced.empty() && same_images(f->announced.front(), images, f->n_cams)) f->announced.pop_front();
-        next_slot(f, &e, &set);
-        if ((rc = enqueue_extract(f, e, images, set, &W, &H, &went_async))) return rc;
+        next_slot(f, &P.e, &P.set);
+        if ((rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async))) return rc;
     }
-    orbx_extractor* ex = f->exs[e];
-    hipStream_t st_e = (hipStream_t)orbx_stream(ex);              // this step's extraction
-    orbf_frontend::ResultSet& R = f->rs[set];
-
     // queries go through pinned staging; their H2D runs on the side stream next to the extractor's work
     if (nq) {
         if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))))
@@ -2530,106 +2604,144 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, f->h_queries.p, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->side_stream));
         MORB_HIP(hipEventRecord(m->ev_q, m->side_stream));
     }
-    std::vector<orbm_cam_features> cams(f->n_cams);
-    orbm_frame* fr = nullptr;
-    bool fr_persistent = false;
-    int n = 0, nmatches = 0;
-    bool do_cross = !(flags & ORBF_SKIP_CROSS);
-    auto t_synced = t_impl;
-    SearchJob J{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
+    P.J = SearchJob{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
     if ((rc = f->h_match.reserve(std::max(f->cap_total, 1)))) return rc;
-    bool async_path = went_async != 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (async_path) {
-            // matching follows the extraction chain (which ends with the frame grid) through its event; counts are in HBM
-            fr = f->pframe[set]; fr_persistent = true;
-            MORB_HIP(hipStreamWaitEvent(st, f->ev_ready[set], 0));  // extraction + frame grid of this step
-            if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
-            n = fr->n_total;
+    P.async_path = went_async != 0;
+    // The export block of this step is final already when its extraction chain has completed cleanly (the usual case with
+    // steps announced ahead): then nothing of this step can be redone and a caller may ship the block right away.
+    P.block_ready = false;
+    if (P.async_path && hipEventQuery(f->ev_ready[P.set]) == hipSuccess) P.block_ready = orbx_peek_status(f->exs[P.e]) == 0;
+    else (void)hipGetLastError();
+    if ((rc = step_enqueue(f, P, true))) return rc;
+    P.active = true;
+    if (block_ready) *block_ready = P.block_ready ? 1 : 0;
+    return ORB_OK;
+}
+
+// Enqueues the matching of the pending step (and, on the first attempt, the extraction of the announced steps).
+static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_attempt) {
+    orbm_matcher* m = f->mt;
+    hipStream_t st = m->stream;
+    orbx_extractor* ex = f->exs[P.e];
+    hipStream_t st_e = (hipStream_t)orbx_stream(ex);
+    orbf_frontend::ResultSet& R = f->rs[P.set];
+    const int nq = P.nq;
+    const bool do_cross = !(P.flags & ORBF_SKIP_CROSS);
+    int rc;
+    std::vector<orbm_cam_features>& cams = P.cams;
+    cams.resize(f->n_cams);
+    if (P.async_path) {
+        // matching follows the extraction chain (which ends with the frame grid) through its event; counts are in HBM
+        P.fr = f->pframe[P.set]; P.fr_persistent = true;
+        MORB_HIP(hipStreamWaitEvent(st, f->ev_ready[P.set], 0));  // extraction + frame grid of this step
+        if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
+        P.n = P.fr->n_total;
+    } else {
+        rc = orbx_finish(ex);  // synchronises; counts are on the host from here on
+        if (rc < 0) return rc;
+        // the host-quadtree path returns with its describe kernel still running on the extractor's stream
+        MORB_HIP(hipEventRecord(f->ev_extracted, st_e));
+        MORB_HIP(hipStreamWaitEvent(st, f->ev_extracted, 0));
+        if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
+        P.n = 0;
+        for (int c = 0; c < f->n_cams; ++c) {
+            cams[c].d_kps = orbx_device_keypoints(ex, c); cams[c].d_desc = orbx_device_descriptors(ex, c);
+            cams[c].n = orbx_count(ex, c);
+            cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
+            P.n += cams[c].n;
+        }
+        // the frame-build kernel mirrors the stereo arrays straight into this step's pinned result set (keypoints and
+        // descriptors were mirrored by the extractor's describe kernel)
+        m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp;
+        m->mirror_unx = R.unx.dp; m->mirror_uny = R.uny.dp;
+        m->frame_min_rows = f->cap_total;  // every step's export block has the same size
+        float bd[4];
+        rc = orbm_image_bounds(&f->calib, P.W, P.H, bd);  // Frame::ComputeImageBounds
+        P.fr = nullptr;
+        if (!rc) rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], nullptr, &P.fr);
+        m->frame_min_rows = 0;
+        m->mirror_ur = nullptr; m->mirror_depth = nullptr; m->mirror_unx = nullptr; m->mirror_uny = nullptr;
+        if (rc) return rc;
+        P.fr_persistent = false;
+    }
+    orbm_frame* fr = P.fr;
+    const int n = P.n;
+    P.J.cur = fr; P.J.cap = 64; P.J.device_path = false;
+    // fork: the camera-pair top-2 only needs the frame's descriptor block, so it runs on the side stream next to
+    // project + resolve (both are a handful of workgroups on a 256-CU part); join before the one host sync
+    const bool forked = do_cross && n > 0;
+    if (forked) {  // the fork point is the finished frame; the launches on the side stream come after the search's
+        hipError_t fe = hipEventRecord(m->ev_fork, st);
+        if (fe == hipSuccess) fe = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
+        if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return ORB_E_HIP; }
+    }
+    rc = search_enqueue(m, P.J, /*queries_already_on_device=*/true);
+    if (forked) {
+        if (!rc) rc = cross_enqueue(m, m->side_stream, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n,
+                                    P.async_path ? fr->b->d_ntotal.p : nullptr);
+        // join (also on the error path, so that the side stream never outlives the frame)
+        hipError_t je = hipEventRecord(m->ev_join, m->side_stream);
+        if (je == hipSuccess) je = hipStreamWaitEvent(st, m->ev_join, 0);
+        if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
+    }
+    if (rc) { (void)hipStreamSynchronize(st); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return rc; }
+    // ---- announced timesteps go onto the extractors now: they run while this step is being matched.  At most two
+    // are in flight; consecutive ones alternate between the two extractors (an extractor takes its next timestep as
+    // a second run behind the one whose results are being matched here).
+    while (P.async_path && first_attempt && f->overlap_ok && !f->announced.empty() && f->inflight.size() < 2) {
+        const int prev_e = f->inflight.empty() ? P.e : f->inflight.back().e;
+        const int e2 = f->exs[1] ? (prev_e ^ 1) : 0;
+        if (orbx_pending(f->exs[e2]) >= 2) break;
+        int set2 = (f->last_set + 1) % orbf_frontend::NSETS;
+        if (set2 == f->cur) set2 = (set2 + 1) % orbf_frontend::NSETS;
+        if (set2 == P.set) set2 = (set2 + 1) % orbf_frontend::NSETS;
+        int w2 = 0, h2 = 0, async2 = 0;
+        rc = enqueue_extract(f, e2, f->announced.front().data(), set2, &w2, &h2, &async2);
+        if (rc) { (void)hipStreamSynchronize(st); return rc; }
+        f->last_set = set2; f->last_e = e2;
+        if (async2) {
+            orbf_frontend::InFlight I;
+            I.images = f->announced.front(); I.set = set2; I.W = w2; I.H = h2; I.e = e2;
+            f->inflight.push_back(std::move(I));
+            f->announced.pop_front();
         } else {
-            rc = orbx_finish(ex);  // synchronises; counts are on the host from here on
-            if (rc < 0) return rc;
-            // the host-quadtree path returns with its describe kernel still running on the extractor's stream
-            MORB_HIP(hipEventRecord(f->ev_extracted, st_e));
-            MORB_HIP(hipStreamWaitEvent(st, f->ev_extracted, 0));
-            if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
-            n = 0;
-            for (int c = 0; c < f->n_cams; ++c) {
-                cams[c].d_kps = orbx_device_keypoints(ex, c); cams[c].d_desc = orbx_device_descriptors(ex, c);
-                cams[c].n = orbx_count(ex, c);
-                cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
-                n += cams[c].n;
-            }
-            // the frame-build kernel mirrors the stereo arrays straight into this step's pinned result set (keypoints and
-            // descriptors were mirrored by the extractor's describe kernel)
-            m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp;
-            m->mirror_unx = R.unx.dp; m->mirror_uny = R.uny.dp;
-            m->frame_min_rows = f->cap_total;  // every step's export block has the same size
-            float bd[4];
-            rc = orbm_image_bounds(&f->calib, W, H, bd);  // Frame::ComputeImageBounds
-            if (!rc) rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], nullptr, &fr);
-            m->frame_min_rows = 0;
-            m->mirror_ur = nullptr; m->mirror_depth = nullptr; m->mirror_unx = nullptr; m->mirror_uny = nullptr;
-            if (rc) return rc;
-            fr_persistent = false;
+            // the extractor ran synchronously (host quadtree): its outputs now belong to that future step, which cannot
+            // be kept apart from a later one's -- give up overlapping; the steps extract again when their turn comes
+            f->overlap_ok = false;
+            f->announced.clear();
         }
-        J.cur = fr; J.cap = 64; J.device_path = false;
-        // fork: the camera-pair top-2 only needs the frame's descriptor block, so it runs on the side stream next to
-        // project + resolve (both are a handful of workgroups on a 256-CU part); join before the one host sync
-        const bool forked = do_cross && n > 0;
-        hipError_t fe = hipSuccess;
-        if (forked) {  // the fork point is the finished frame; the launches on the side stream come after the search's
-            fe = hipEventRecord(m->ev_fork, st);
-            if (fe == hipSuccess) fe = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
-            if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); if (!fr_persistent) orbm_frame_destroy(fr); return ORB_E_HIP; }
-        }
-        rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
-        if (forked) {
-            if (!rc) rc = cross_enqueue(m, m->side_stream, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n,
-                                        async_path ? fr->b->d_ntotal.p : nullptr);
-            // join (also on the error path, so that the side stream never outlives the frame)
-            hipError_t je = hipEventRecord(m->ev_join, m->side_stream);
-            if (je == hipSuccess) je = hipStreamWaitEvent(st, m->ev_join, 0);
-            if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
-        }
-        if (rc) { (void)hipStreamSynchronize(st); if (!fr_persistent) orbm_frame_destroy(fr); return rc; }
-        // ---- announced timesteps go onto the extractors now: they run while this step is being matched.  At most two
-        // are in flight; consecutive ones alternate between the two extractors (an extractor takes its next timestep as
-        // a second run behind the one whose results are being matched here).
-        while (async_path && attempt == 0 && f->overlap_ok && !f->announced.empty() && f->inflight.size() < 2) {
-            const int prev_e = f->inflight.empty() ? e : f->inflight.back().e;
-            const int e2 = f->exs[1] ? (prev_e ^ 1) : 0;
-            if (orbx_pending(f->exs[e2]) >= 2) break;
-            int set2 = (f->last_set + 1) % orbf_frontend::NSETS;
-            if (set2 == f->cur) set2 = (set2 + 1) % orbf_frontend::NSETS;
-            if (set2 == set) set2 = (set2 + 1) % orbf_frontend::NSETS;
-            int w2 = 0, h2 = 0, async2 = 0;
-            rc = enqueue_extract(f, e2, f->announced.front().data(), set2, &w2, &h2, &async2);
-            if (rc) { (void)hipStreamSynchronize(st); return rc; }
-            f->last_set = set2; f->last_e = e2;
-            if (async2) {
-                orbf_frontend::InFlight I;
-                I.images = f->announced.front(); I.set = set2; I.W = w2; I.H = h2; I.e = e2;
-                f->inflight.push_back(std::move(I));
-                f->announced.pop_front();
-            } else {
-                // the extractor ran synchronously (host quadtree): its outputs now belong to that future step, which cannot
-                // be kept apart from a later one's -- give up overlapping; the steps extract again when their turn comes
-                f->overlap_ok = false;
-                f->announced.clear();
-            }
-        }
+    }
+    P.t_enqueued = std::chrono::steady_clock::now();
+    return ORB_OK;
+}
+
+static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
+    orbf_frontend::Pending& P = f->pending;
+    MORB_ARG(P.active && out);
+    P.active = false;
+    auto us_between = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<float, std::micro>(b - a).count();
+    };
+    MORB_HIP(hipSetDevice(f->device));
+    orbm_matcher* m = f->mt;
+    hipStream_t st = m->stream;
+    orbx_extractor* ex = f->exs[P.e];
+    orbf_frontend::ResultSet& R = f->rs[P.set];
+    int rc, nmatches = 0;
+    auto t_synced = P.t_impl;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (attempt == 1 && (rc = step_enqueue(f, P, false))) return rc;
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t herr = hipStreamSynchronize(st);
         out->gpu_wait_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        out->host_us[0] = us_between(f->t_entry, t_impl); out->host_us[1] = us_between(t_impl, t0); out->host_us[2] = out->gpu_wait_us;
+        out->host_us[0] = us_between(f->t_entry, P.t_impl); out->host_us[1] = us_between(P.t_impl, P.t_enqueued); out->host_us[2] = out->gpu_wait_us;
         t_synced = std::chrono::steady_clock::now();
         if (herr != hipSuccess) {
             morb::set_error("hipStreamSynchronize: %s", hipGetErrorString(herr));
-            if (!fr_persistent) orbm_frame_destroy(fr);
+            if (!P.fr_persistent && P.fr) orbm_frame_destroy(P.fr);
             return ORB_E_HIP;
         }
-        if (async_path) {
+        if (P.async_path) {
             rc = orbx_finish(ex);  // this step's run (the oldest of its extractor) completed long ago: adopts its counts
             if (rc < 0) return rc;
             if (rc == 1 || rc == 2) {
@@ -2639,29 +2751,30 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
                     f->announced.clear();
                     f->overlap_ok = false;
                     int w2, h2, a2;
-                    if ((rc = enqueue_extract(f, e, images, set, &w2, &h2, &a2))) return rc;
+                    if ((rc = enqueue_extract(f, P.e, P.images.data(), P.set, &w2, &h2, &a2))) return rc;
                     if (a2) { rc = orbx_finish(ex); if (rc < 0) return rc; }
                 }
-                fr = nullptr; fr_persistent = false;
-                async_path = false;
+                P.fr = nullptr; P.fr_persistent = false;
+                P.async_path = false;
                 f->clean_steps = 0;
                 continue;
             }
             for (int c = 0; c < f->n_cams; ++c) f->counts[c] = orbx_count(ex, c);
-            frame_set_counts(fr, f->counts.data());
-            n = fr->n_total;
+            frame_set_counts(P.fr, f->counts.data());
+            P.n = P.fr->n_total;
             if (!f->overlap_ok && ++f->clean_steps >= 3) f->overlap_ok = true;  // (e.g. the extractor has switched its BIG pass on)
         } else {
-            for (int c = 0; c < f->n_cams; ++c) f->counts[c] = cams[c].n;
+            for (int c = 0; c < f->n_cams; ++c) f->counts[c] = P.cams[c].n;
         }
         break;
     }
-    if (!async_path || !f->overlap_ok) f->announced.clear();  // (hints are only honoured on the asynchronous path)
-    do_cross = do_cross && n > 0;
-    rc = search_finish(m, J, f->h_match.p, &nmatches);
-    if (rc) { if (!fr_persistent) orbm_frame_destroy(fr); return rc; }
-    f->last_frame = fr; f->last_frame_owned = !fr_persistent;  // (returned to the pool when the next step starts)
-    f->cur = set;
+    if (!P.async_path || !f->overlap_ok) f->announced.clear();  // (hints are only honoured on the asynchronous path)
+    const int n = P.n, nq = P.nq;
+    const bool do_cross = !(P.flags & ORBF_SKIP_CROSS) && n > 0;
+    rc = search_finish(m, P.J, f->h_match.p, &nmatches);
+    if (rc) { if (!P.fr_persistent) orbm_frame_destroy(P.fr); return rc; }
+    f->last_frame = P.fr; f->last_frame_owned = !P.fr_persistent;  // (returned to the pool when the next step starts)
+    f->cur = P.set;
     f->prev_n = n;
     f->prev_cam_of.resize(n);
     for (int c = 0, g = 0; c < f->n_cams; ++c)
@@ -2676,6 +2789,13 @@ static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm
     out->cross_second_dist = do_cross ? m->h_c2.p : nullptr;
     out->host_us[3] = us_between(t_synced, std::chrono::steady_clock::now());
     return ORB_OK;
+}
+
+static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
+                          orbf_result* out, bool queries_in_pinned) {
+    int rc = orbf_step_begin_impl(f, images, queries, nq, flags, queries_in_pinned, nullptr);
+    if (rc) { f->pending.active = false; return rc; }
+    return orbf_step_end_impl(f, out);
 }
 
 }  // extern "C"

@@ -28,22 +28,36 @@ class DescriptorExchange:
         self.recv = None
         self._send = {}
 
-    def __call__(self, frontend):
-        """frontend: pipeline.FrontEnd after a step -> (best_idx, best_dist, second_dist, counts of all cameras)."""
+    def _gather(self, frontend):
         torch, dist = self.torch, self.dist
         ptr, nbytes, rows = frontend.fe.export_block()
         send = self._send.get(ptr)
-        if send is None:      # two blocks alternate (the front end's double-buffered frames): wrapped once each
+        if send is None:      # a few blocks alternate (the front end's rotating frames): wrapped once each
             send = self._send[ptr] = torch.as_tensor(_DeviceBlock(ptr, nbytes), device=self.device)
         if self.recv is None or self.recv.numel() != self.world * nbytes:
             self.recv = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.device)
             self.recv_ptr = self.recv.data_ptr()
+        dist.all_gather_into_tensor(self.recv, send)
+        return nbytes, rows
+
+    def __call__(self, frontend):
+        """After a completed step -> (best_idx, best_dist, second_dist, counts of all cameras)."""
         # the block was complete before the step returned (the matcher waited on the extractor's event), so RCCL may read
         # it on torch's stream right away; the matcher's stream is ordered behind the collective on the device
-        dist.all_gather_into_tensor(self.recv, send)
+        nbytes, rows = self._gather(frontend)
         if self.recv.is_cuda:
-            frontend.mt.wait_for_stream(torch.cuda.current_stream().cuda_stream)
+            frontend.mt.wait_for_stream(self.torch.cuda.current_stream().cuda_stream)
         return frontend.mt.cross_top2_gathered(self.recv_ptr, self.world, nbytes, rows, frontend.n_cams, self.rank)
+
+    def enqueue(self, frontend):
+        """Between FrontEnd begin and end, when begin reported the export block ready: the collective and the gathered
+        matching are enqueued next to the step's own matching; collect() after end() returns what __call__ would."""
+        nbytes, rows = self._gather(frontend)
+        frontend.mt.cross_top2_gathered_enqueue(self.recv_ptr, self.world, nbytes, rows, frontend.n_cams, self.rank,
+                                                self.torch.cuda.current_stream().cuda_stream if self.recv.is_cuda else 0)
+
+    def collect(self, frontend):
+        return frontend.mt.cross_top2_gathered_collect()
 
 
 def shard_cameras(n_cameras, world_size, rank):

@@ -107,17 +107,32 @@ class NativeFrontEnd:
         """images: [(ptr_or_array, width, height, stride, on_device)] or uint8 arrays.  `queries`: projected map points, or
         `motion` = (du, dv, th): queries built natively from the previous step's features (synthetic-stream driver).
         Returns a dict of numpy arrays (copies by default: the native buffers are reused by the next step)."""
-        keep = self._fill(self._imgs, images)
+        self.begin(images, queries, flags, motion)
+        return self.end(copy)
+
+    def begin(self, images, queries=None, flags=0, motion=None):
+        """First half of step() (orbf_step_begin): everything is enqueued, nothing waited for.  Returns True when the step's
+        export block is already final, i.e. a multi-GPU exchange may be enqueued before end()."""
+        self._keep = self._fill(self._imgs, images)
+        ready = C.c_int(0)
         if motion is not None:
             mo = FMotion(*motion)
-            check(_lib.lib().orbf_step_motion(self._h, self._imgs, C.byref(mo), flags, C.byref(self._res)))
-            nq = self._res.n_queries
+            check(_lib.lib().orbf_step_motion_begin(self._h, self._imgs, C.byref(mo), flags, C.byref(ready)))
+            self._nq = None
         else:
             nq = 0 if queries is None else len(queries)
             if nq:
                 queries = np.ascontiguousarray(queries, QUERY_DTYPE)
-            check(_lib.lib().orbf_step(self._h, self._imgs, ptr(queries) if nq else None, nq, flags, C.byref(self._res)))
+            self._keep.append(queries)
+            check(_lib.lib().orbf_step_begin(self._h, self._imgs, ptr(queries) if nq else None, nq, flags, C.byref(ready)))
+            self._nq = nq
+        return bool(ready.value)
+
+    def end(self, copy=True):
+        """Second half of step() (orbf_step_end): one synchronisation, then the results."""
+        check(_lib.lib().orbf_step_end(self._h, C.byref(self._res)))
         r = self._res
+        nq = r.n_queries if self._nq is None else self._nq
         n = r.n_total
         cap = self.cap_total
         cp = (lambda a: a.copy()) if copy else (lambda a: a)

@@ -196,6 +196,20 @@ class Matcher:
                                                   ptr(bi), ptr(bd), ptr(sd), ptr(cnt), C.byref(nq)))
         return bi[:nq.value].copy(), bd[:nq.value].copy(), sd[:nq.value].copy(), cnt.tolist()
 
+    def cross_top2_gathered_enqueue(self, gathered_ptr, world, block_bytes, cap_rows, cams_per_rank, rank, after_stream=0):
+        """Enqueue half of cross_top2_gathered (side stream, behind `after_stream`, joined into the main stream)."""
+        self._gathered_shape = (cap_rows, world * cams_per_rank)
+        check(_lib.lib().orbm_cross_top2_gathered_enqueue(self._h, C.c_void_p(gathered_ptr), world, block_bytes, cap_rows, cams_per_rank,
+                                                          rank, C.c_void_p(after_stream) if after_stream else None))
+
+    def cross_top2_gathered_collect(self):
+        """Collect half: after the handle's main stream has been synchronised (orbf_step_end)."""
+        cap_rows, n_cams = self._gathered_shape
+        bi = np.zeros(cap_rows, np.int32); bd = np.zeros(cap_rows, np.int32); sd = np.zeros(cap_rows, np.int32)
+        cnt = np.zeros(n_cams, np.int32); nq = C.c_int()
+        check(_lib.lib().orbm_cross_top2_gathered_collect(self._h, ptr(bi), ptr(bd), ptr(sd), ptr(cnt), C.byref(nq)))
+        return bi[:nq.value], bd[:nq.value], sd[:nq.value], cnt.tolist()
+
     def cross_top2(self, frame):
         n = max(frame.data.n_total, 1)
         bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32); sd = np.zeros(n, np.int32)

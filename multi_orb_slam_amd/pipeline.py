@@ -110,13 +110,21 @@ class FrontEnd:
         distributed = self.world > 1 and self.gather is not None
         # queries = the previous step's features under the stream's known motion, built natively (orbf_step_motion;
         # same arithmetic as make_queries, which the oracle leg uses)
-        r = self.fe.step(images, None, SKIP_CROSS if distributed else 0, copy=self.copy_results,
-                         motion=(MOTION[0], MOTION[1], TH_PROJ))
-        counts = r["counts"]
-        if distributed:
-            bi, bd, sd, cnts = self.gather(self)
-            assert cnts[self.rank * self.n_cams:(self.rank + 1) * self.n_cams] == counts
+        if not distributed:
+            r = self.fe.step(images, None, 0, copy=self.copy_results, motion=(MOTION[0], MOTION[1], TH_PROJ))
+        else:
+            # one all-gather per timestep.  When the step's descriptor block is final already at begin (its extraction ran
+            # ahead), the collective and the cross-camera matching are enqueued next to the step's own matching; otherwise
+            # they follow the step.  Every rank issues exactly one collective per step either way.
+            early = self.fe.begin(images, None, SKIP_CROSS, motion=(MOTION[0], MOTION[1], TH_PROJ))
+            self.early_exchanges = getattr(self, "early_exchanges", 0) + int(early)
+            if early:
+                self.gather.enqueue(self)
+            r = self.fe.end(copy=self.copy_results)
+            bi, bd, sd, cnts = self.gather.collect(self) if early else self.gather(self)
+            assert cnts[self.rank * self.n_cams:(self.rank + 1) * self.n_cams] == r["counts"]
             r["cross"] = (bi, bd, sd)
+        counts = r["counts"]
         bi, bd, sd = r["cross"]
         r["n_cross"] = int(accept_cross(bd, sd).sum())
         return r

@@ -247,3 +247,34 @@ def test_full_size_rig_properties():
     for x, y in zip(a, b):
         assert x["kps"].tobytes() == y["kps"].tobytes() and np.array_equal(x["desc"], y["desc"])
         assert np.array_equal(x["match_of_feature"], y["match_of_feature"]) and all(np.array_equal(u, v) for u, v in zip(x["cross"], y["cross"]))
+
+
+def test_single_rank_rccl_exchange_equals_oracle():
+    """The multi-GPU step on ONE rank (world-size-1 RCCL group): descriptors leave through orbf_export_block, come back
+    through one all-gather and are matched by orbm_cross_top2_gathered -- late (after the step) while nothing runs ahead,
+    early (enqueued between orbf_step_begin and orbf_step_end) once the extraction of announced steps does."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from multi_orb_slam_amd.dist import DescriptorExchange
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.cuda.set_device(0)
+        params = [m.ExtractorParams(nfeatures=300), m.ExtractorParams(nfeatures=150)]
+        fe = pipeline.FrontEnd(params, 320, 240)
+        fe.gather = DescriptorExchange(torch.device("cuda", 0), dist); fe.world = 2   # forced exchange on one rank
+        ofe = OracleFrontEnd(params, 320, 240)
+        T = 7
+        frames = [[synth.image(c, t, 320, 240) for c in range(2)] for t in range(T)]
+        fe.announce(frames[1])
+        for t in range(T):
+            got = fe.step(frames[t], next_images=frames[t + 2] if t + 2 < T else None)
+            assert_same_step(got, ofe.step(frames[t]))
+        assert 0 < fe.early_exchanges < T          # both orders of the exchange were exercised
+        fe.close()
+    finally:
+        dist.destroy_process_group()
