@@ -2379,6 +2379,10 @@ static int orbf_drain(orbf_frontend* f);
 int orbf_reset(orbf_frontend* f) {
     MORB_ARG(f != nullptr);
     f->prev_n = 0; f->announced.clear(); f->overlap_ok = true;
+    if (f->pending.active) {  // a begun step is abandoned with everything else in flight
+        if (f->pending.fr && !f->pending.fr_persistent) { (void)hipStreamSynchronize(f->mt->stream); orbm_frame_destroy(f->pending.fr); }
+        f->pending.active = false; f->pending.fr = nullptr;
+    }
     return orbf_drain(f);
 }
 
