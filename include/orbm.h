@@ -49,6 +49,9 @@ int orbm_debug_last_resolve(const orbm_matcher* m, int* out4);
 /* host helper, identical result to the reference's SWAR popcount; rows need 1-byte alignment only */
 int orbm_descriptor_distance(const uint8_t* a, const uint8_t* b);
 void orbm_three_maxima(const int* bin_sizes, int L, int* ind3);
+/* host: how many top-2 results pass SearchByBoW's acceptance (reference src/ORBmatcher.cc:324-327): best <= th_low and
+ * (float)best < ratio * (float)second.  Returns the count (>= 0) or ORB_E_ARG. */
+int orbm_count_ratio_accepted(const int32_t* best_dist, const int32_t* second_dist, int n, int th_low, float ratio);
 
 /* Exhaustive top-2 per query over all nr references, strict '<' updates in reference order:
  * best_idx = lowest index attaining the minimum, second_dist = 2nd smallest WITH multiplicity,

@@ -138,6 +138,7 @@ def lib():
     L.orbf_matcher.argtypes = [vp]; L.orbf_matcher.restype = vp
     L.orbm_debug_last_resolve.argtypes = [vp, vp]
     L.orbm_queries_from_motion.argtypes = [vp, vp, vp, vp, i32, f32, f32, f32, vp, f32, vp, vp, vp]
+    L.orbm_count_ratio_accepted.argtypes = [vp, vp, i32, i32, f32]
     L.orbm_set_calibration.argtypes = [vp, vp]
     L.orbm_undistort_points.argtypes = [vp, vp, vp, i32, vp, vp]
     L.orbm_image_bounds.argtypes = [vp, i32, i32, vp]

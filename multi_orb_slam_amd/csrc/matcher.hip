@@ -1449,6 +1449,15 @@ int orbm_queries_from_motion(const orb_keypoint* kps, const uint8_t* desc, const
     return ORB_OK;
 }
 
+int orbm_count_ratio_accepted(const int32_t* best_dist, const int32_t* second_dist, int n, int th_low, float ratio) {
+    // SearchByBoW's acceptance (reference src/ORBmatcher.cc:324-327): best <= TH_LOW and best < ratio * second (float compare)
+    if (n < 0 || (n > 0 && (!best_dist || !second_dist))) return ORB_E_ARG;
+    int acc = 0;
+    for (int i = 0; i < n; ++i)
+        acc += (best_dist[i] <= th_low && (float)best_dist[i] < ratio * (float)second_dist[i]) ? 1 : 0;
+    return acc;
+}
+
 void orbm_three_maxima(const int* histo, int L, int* ind) {
     // Keeps the three fullest bins; an earlier bin wins a tie (strict '>'), 2nd/3rd dropped below 10% of the 1st.
     int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;

@@ -12,6 +12,7 @@ step (the rest of a SLAM system needs them there); everything between extraction
 """
 import ctypes as C
 import numpy as np
+from . import _lib
 from ._lib import QUERY_DTYPE
 from .extractor import Extractor
 from .matcher import Matcher, TH_LOW
@@ -126,7 +127,9 @@ class FrontEnd:
             r["cross"] = (bi, bd, sd)
         counts = r["counts"]
         bi, bd, sd = r["cross"]
-        r["n_cross"] = int(accept_cross(bd, sd).sum())
+        # (native count of accept_cross: the arrays are views of pinned result buffers in the timed loop)
+        bd = np.ascontiguousarray(bd, np.int32); sd = np.ascontiguousarray(sd, np.int32)
+        r["n_cross"] = _lib.lib().orbm_count_ratio_accepted(_lib.ptr(bd), _lib.ptr(sd), len(bd), TH_LOW, BOW_RATIO)
         return r
 
 

@@ -1,6 +1,8 @@
 """orbf_step (include/orbf.h): the whole timestep as one native call must equal the oracle pipeline bit for bit."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libmorb: torch ships its own HIP runtime and has to be the one that initialises it,
+              #  see the exchange test at the end of this file)
 from multi_orb_slam_amd import synth
 
 pytestmark = pytest.mark.gpu
