@@ -2109,28 +2109,52 @@ int orbm_search_by_projection_points(orbm_matcher* m, const orbm_frame* cur, con
 
 // k_cross_top2 (+ merge) over `n` features in `d_desc` split into cameras by `d_cam_start`; queries [q_off, q_off+nq).
 // Results land in the pinned mirrors m->h_c0/h_c1/h_c2 once stream `st` has been synchronised.
+// Destination of a cross top-2: three mapped pinned result arrays + the HBM scratch of the slice partials.  The matcher
+// owns one (h_c0..2 / d_cscratch); the front end owns one per result set, because it runs the cross matching of steps
+// that were announced ahead at the end of their extraction chains.
+struct CrossOut {
+    PinnedBuf<int32_t> i, b, s;
+    DevBuf<uint8_t> scratch;
+    int reserve(int nq, int n) {
+        const int S = top2_slices(nq, n);
+        int rc;
+        if ((rc = scratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = i.reserve(nq)) || (rc = b.reserve(nq)) ||
+            (rc = s.reserve(nq)))
+            return rc;
+        return ORB_OK;
+    }
+    void release() { i.release(); b.release(); s.release(); scratch.release(); }
+};
+
+static int cross_enqueue_to(hipStream_t st, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off, int nq,
+                            const int* d_n, int* o_idx, int* o_best, int* o_second, void* scratch) {
+    if (nq == 0) return ORB_OK;
+    const int qblocks = (nq + 63) / 64;
+    const int S = top2_slices(nq, n);
+    if (S <= 1) {  // final results go straight to the mapped pinned mirrors
+        hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, 1), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
+                           n_cams, q_off, nq, o_idx, o_best, o_second, d_n);
+    } else {
+        int* p = (int*)scratch;
+        int *p_idx = p, *p_best = p + (size_t)S * nq, *p_second = p + 2 * (size_t)S * nq;
+        hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, S), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
+                           n_cams, q_off, nq, p_idx, p_best, p_second, d_n);
+        hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, o_idx, o_best,
+                           o_second, d_n);
+    }
+    MORB_HIP(hipGetLastError());
+    return ORB_OK;
+}
+
 static int cross_enqueue(orbm_matcher* m, hipStream_t st, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off,
                          int nq, const int* d_n = nullptr) {
     if (nq == 0) return ORB_OK;
-    const int qblocks = (nq + 63) / 64;
     const int S = top2_slices(nq, n);
     int rc;
     if ((rc = m->d_cscratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = m->h_c0.reserve(nq)) ||
         (rc = m->h_c1.reserve(nq)) || (rc = m->h_c2.reserve(nq)))
         return rc;
-    if (S <= 1) {  // final results go straight to the mapped pinned mirrors
-        hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, 1), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
-                           n_cams, q_off, nq, m->h_c0.dp, m->h_c1.dp, m->h_c2.dp, d_n);
-    } else {
-        int* p = (int*)m->d_cscratch.p;
-        int *p_idx = p, *p_best = p + (size_t)S * nq, *p_second = p + 2 * (size_t)S * nq;
-        hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, S), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
-                           n_cams, q_off, nq, p_idx, p_best, p_second, d_n);
-        hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, m->h_c0.dp,
-                           m->h_c1.dp, m->h_c2.dp, d_n);
-    }
-    MORB_HIP(hipGetLastError());
-    return ORB_OK;
+    return cross_enqueue_to(st, d_desc, n, d_cam_start, n_cams, q_off, nq, d_n, m->h_c0.dp, m->h_c1.dp, m->h_c2.dp, m->d_cscratch.p);
 }
 
 static int cross_launch(orbm_matcher* m, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off, int nq,
@@ -2261,7 +2285,12 @@ struct orbf_frontend {
     // pinned host result buffers.  The per-feature results exist twice: the extraction of the NEXT timestep (orbf_prefetch)
     // fills the other set while the caller still reads this step's.
     static constexpr int NSETS = 4;  // this step's (held by the caller) + two timesteps in flight + the one being assigned
-    struct ResultSet { PinnedBuf<orb_keypoint> kps; PinnedBuf<uint8_t> desc; PinnedBuf<float> ur, depth, unx, uny; } rs[NSETS];
+    struct ResultSet {
+        PinnedBuf<orb_keypoint> kps; PinnedBuf<uint8_t> desc; PinnedBuf<float> ur, depth, unx, uny;
+        CrossOut cross;            // cross-camera top-2 of the step, computed at the end of its extraction chain
+        bool cross_valid = false;  // ... when the chain was enqueued with cross matching on
+    } rs[NSETS];
+    int last_flags = 0;  // flags of the most recent step: what announced steps are assumed to want
     int cur = 0;       // set holding the results of the last completed step
     int last_set = 0;  // set most recently handed to an extraction (sets are handed out round robin)
     PinnedBuf<uint8_t> h_queries;
@@ -2277,7 +2306,7 @@ struct orbf_frontend {
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path ...
     int clean_steps = 0;     // ... and set again after a few steps that stayed on the device path
     struct Pending {  // a timestep between orbf_step_begin and orbf_step_end
-        bool active = false, async_path = false, fr_persistent = false, block_ready = false;
+        bool active = false, async_path = false, fr_persistent = false, block_ready = false, cross_from_set = false;
         int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
         orbm_frame* fr = nullptr;
         SearchJob J{nullptr, nullptr, 0, nullptr, false, 0.f, 0, 0, 64, false};
@@ -2337,7 +2366,7 @@ void orbf_destroy(orbf_frontend* f) {
     for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->pframe[k]) orbm_frame_destroy(f->pframe[k]);  // back to the matcher's pool first
     if (f->mt) orbm_destroy(f->mt);
     for (int e = 0; e < 2; ++e) if (f->exs[e]) orbx_destroy(f->exs[e]);
-    for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); f->rs[k].unx.release(); f->rs[k].uny.release(); }
+    for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); f->rs[k].unx.release(); f->rs[k].uny.release(); f->rs[k].cross.release(); }
     f->h_queries.release(); f->h_match.release();
     if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->ev_ready[k]) (void)hipEventDestroy(f->ev_ready[k]);
@@ -2480,7 +2509,8 @@ static void fill_cam_capacities(orbf_frontend* f, orbx_extractor* ex, orbm_cam_f
 // Uploads + the whole extractor `e` for one timestep into result set `set`, nothing synchronised.  Small rigs: the
 // describe kernel writes the merged frame pframe[set] through a FrameSink (*went_async = 1 unless the extractor took its
 // synchronous host-quadtree path; then the frame was not filled).
-static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, int set, int* W_out, int* H_out, int* went_async) {
+static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, int set, int* W_out, int* H_out, int* went_async,
+                           bool with_cross) {
     orbm_matcher* m = f->mt;
     orbx_extractor* ex = f->exs[e];
     int rc, W = 0, H = 0;
@@ -2494,6 +2524,7 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     if (W == 0 || H == 0) { W = f->max_w; H = f->max_h; }
     *W_out = W; *H_out = H;
     orbf_frontend::ResultSet& R = f->rs[set];
+    R.cross_valid = false;
     if ((rc = orbx_set_host_mirror(ex, R.kps.dp, R.desc.dp, f->cap_total))) return rc;
     *went_async = 0;
     const bool small = small_rig(f);
@@ -2546,6 +2577,15 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
         hipStream_t keep = m->stream;
         m->stream = (hipStream_t)orbx_stream(ex);
         rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], orbx_device_counts(ex), &frp, small);
+        // ... and so is the camera-pair top-2, which needs nothing but the frame's descriptor block
+        R.cross_valid = false;
+        if (!rc && with_cross && f->n_cams > 1) {
+            const int ncap = frp->n_total;
+            if (!(rc = R.cross.reserve(ncap, ncap)))
+                rc = cross_enqueue_to(m->stream, frp->b->d_desc.p, ncap, frp->b->d_cam_start.p, f->n_cams, 0, ncap, frp->b->d_ntotal.p,
+                                      R.cross.i.dp, R.cross.b.dp, R.cross.s.dp, R.cross.scratch.p);
+            R.cross_valid = !rc;
+        }
         hipError_t he = rc ? hipSuccess : hipEventRecord(f->ev_ready[set], m->stream);
         m->stream = keep;
         if (rc) return rc;
@@ -2607,7 +2647,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         }
         if (!f->announced.empty() && same_images(f->announced.front(), images, f->n_cams)) f->announced.pop_front();
         next_slot(f, &P.e, &P.set);
-        if ((rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async))) return rc;
+        if ((rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS)))) return rc;
     }
     // queries go through pinned staging; their H2D runs on the side stream next to the extractor's work
     if (nq) {
@@ -2682,7 +2722,9 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     P.J.cur = fr; P.J.cap = 64; P.J.device_path = false;
     // fork: the camera-pair top-2 only needs the frame's descriptor block, so it runs on the side stream next to
     // project + resolve (both are a handful of workgroups on a 256-CU part); join before the one host sync
-    const bool forked = do_cross && n > 0;
+    // (on the asynchronous path the cross top-2 normally rode at the end of the step's extraction chain already)
+    P.cross_from_set = do_cross && P.async_path && R.cross_valid;
+    const bool forked = do_cross && n > 0 && !P.cross_from_set;
     if (forked) {  // the fork point is the finished frame; the launches on the side stream come after the search's
         hipError_t fe = hipEventRecord(m->ev_fork, st);
         if (fe == hipSuccess) fe = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
@@ -2709,7 +2751,7 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         if (set2 == f->cur) set2 = (set2 + 1) % orbf_frontend::NSETS;
         if (set2 == P.set) set2 = (set2 + 1) % orbf_frontend::NSETS;
         int w2 = 0, h2 = 0, async2 = 0;
-        rc = enqueue_extract(f, e2, f->announced.front().data(), set2, &w2, &h2, &async2);
+        rc = enqueue_extract(f, e2, f->announced.front().data(), set2, &w2, &h2, &async2, !(P.flags & ORBF_SKIP_CROSS));
         if (rc) { (void)hipStreamSynchronize(st); return rc; }
         f->last_set = set2; f->last_e = e2;
         if (async2) {
@@ -2764,7 +2806,7 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
                     f->announced.clear();
                     f->overlap_ok = false;
                     int w2, h2, a2;
-                    if ((rc = enqueue_extract(f, P.e, P.images.data(), P.set, &w2, &h2, &a2))) return rc;
+                    if ((rc = enqueue_extract(f, P.e, P.images.data(), P.set, &w2, &h2, &a2, false))) return rc;
                     if (a2) { rc = orbx_finish(ex); if (rc < 0) return rc; }
                 }
                 P.fr = nullptr; P.fr_persistent = false;
@@ -2797,9 +2839,10 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     out->kps = R.kps.p; out->desc = R.desc.p; out->uright = R.ur.p; out->depth = R.depth.p;
     out->un_x = R.unx.p; out->un_y = R.uny.p;
     out->nmatches = nmatches; out->match_of_feature = f->h_match.p;
-    out->cross_best_idx = do_cross ? m->h_c0.p : nullptr;
-    out->cross_best_dist = do_cross ? m->h_c1.p : nullptr;
-    out->cross_second_dist = do_cross ? m->h_c2.p : nullptr;
+    const bool from_set = P.cross_from_set && P.async_path;  // (a step redone on the synchronous path matched in its own launch)
+    out->cross_best_idx = do_cross ? (from_set ? R.cross.i.p : m->h_c0.p) : nullptr;
+    out->cross_best_dist = do_cross ? (from_set ? R.cross.b.p : m->h_c1.p) : nullptr;
+    out->cross_second_dist = do_cross ? (from_set ? R.cross.s.p : m->h_c2.p) : nullptr;
     out->host_us[3] = us_between(t_synced, std::chrono::steady_clock::now());
     return ORB_OK;
 }
