@@ -1310,7 +1310,7 @@ struct orbx_extractor {
     // results are being matched): run r uses slot r & 1 of the count mirrors and of the completion events
     struct ChainGraph {  // captured kernel chain of one count slot (see orbx_run_impl)
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-        int epoch = -1; orb_keypoint* mirror_kps = nullptr; uint8_t* mirror_desc = nullptr; FrameSink sink;
+        int epoch = -1; orb_keypoint* mirror_kps = nullptr; uint8_t* mirror_desc = nullptr; FrameSink sink; int tail_tag = 0;
         void destroy() {
             if (exec) (void)hipGraphExecDestroy(exec);
             if (graph) (void)hipGraphDestroy(graph);
@@ -1321,6 +1321,7 @@ struct orbx_extractor {
     ChainGraph chain[2][CHAIN_WAYS];
     int chain_next[2] = {0, 0};      // replacement cursor per slot
     bool use_graph = true;           // MORB_CHAIN_GRAPH=0 keeps plain launches
+    orbx_tail_fn tail_fn = nullptr; void* tail_user = nullptr; int tail_tag = 0;  // orbx_set_chain_tail
     int geom_epoch = 0;              // bumped by every rebuild_geometry
     int inflight = 0; unsigned run_seq = 0;
     bool prof_valid[2] = {false, false};  // the stage events were recorded for the run in this slot
@@ -1659,6 +1660,12 @@ int orbx_finish(orbx_extractor* ex) {
     return finish_device_path(ex);
 }
 
+int orbx_set_chain_tail(orbx_extractor* ex, orbx_tail_fn fn, void* user, int tag) {
+    MORB_ARG(ex != nullptr);
+    ex->tail_fn = fn; ex->tail_user = user; ex->tail_tag = tag;
+    return ORB_OK;
+}
+
 int orbx_set_frame_sink(orbx_extractor* ex, const FrameSink* sink) {
     MORB_ARG(ex != nullptr && (sink == nullptr || ex->n_cams <= 4));
     if (sink) ex->sink = *sink; else memset(&ex->sink, 0, sizeof(ex->sink));
@@ -1795,7 +1802,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
             for (int w = 0; w < orbx_extractor::CHAIN_WAYS; ++w) {
                 const orbx_extractor::ChainGraph& C = ex->chain[slot][w];
                 if (C.exec && C.epoch == ex->geom_epoch && C.mirror_kps == ex->mirror_kps && C.mirror_desc == ex->mirror_desc &&
-                    memcmp(&C.sink, &sink, sizeof(FrameSink)) == 0) { way = w; break; }
+                    C.tail_tag == (ex->tail_fn ? ex->tail_tag : 0) && memcmp(&C.sink, &sink, sizeof(FrameSink)) == 0) { way = w; break; }
             }
             const bool hit = way >= 0;
             if (!hit) { way = ex->chain_next[slot]; ex->chain_next[slot] = (way + 1) % orbx_extractor::CHAIN_WAYS; }
@@ -1809,10 +1816,12 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
                 hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
                 if (e == hipSuccess) {
                     const int rc1 = launch_pyramid_fast(ex, st);
-                    const int rc2 = rc1 ? rc1 : launch_tree_describe(ex, st, slot, sink);
+                    int rc2 = rc1 ? rc1 : launch_tree_describe(ex, st, slot, sink);
+                    if (!rc2 && ex->tail_fn) { ++ex->run_seq; rc2 = ex->tail_fn(ex->tail_user, (void*)st); --ex->run_seq; }  // (the tail sees this run as the most recent one)
                     e = hipStreamEndCapture(st, &g);
                     if (!rc2 && e == hipSuccess && g && hipGraphInstantiate(&G.exec, g, nullptr, nullptr, 0) == hipSuccess) {
                         G.graph = g; G.epoch = ex->geom_epoch; G.mirror_kps = ex->mirror_kps; G.mirror_desc = ex->mirror_desc; G.sink = sink;
+                        G.tail_tag = ex->tail_fn ? ex->tail_tag : 0;
                         MORB_HIP(hipGraphLaunch(G.exec, st));
                         done = true;
                     } else {
@@ -1827,6 +1836,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
             if ((rc = launch_pyramid_fast(ex, st))) return rc;
             if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[3], st));
             if ((rc = launch_tree_describe(ex, st, slot, sink))) return rc;
+            if (ex->tail_fn) { ++ex->run_seq; rc = ex->tail_fn(ex->tail_user, (void*)st); --ex->run_seq; if (rc) return rc; }
         }
         MORB_HIP(hipEventRecord(ex->ev_done[slot], st));
         ex->prof_valid[slot] = ex->profiling && ex->inflight == 0;  // (one set of stage events: not for overlapped runs)

@@ -29,3 +29,9 @@ extern "C" int orbx_set_frame_sink(orbx_extractor* ex, const FrameSink* sink);
 // completion event of the most recently enqueued asynchronous run (valid while it is in flight)
 extern "C" void* orbx_done_event(const orbx_extractor* ex);
 extern "C" int orbx_peek_status(const orbx_extractor* ex);  // status of the oldest run in flight (valid once it completed)
+
+// Launches a caller wants at the very end of the extractor's launch chain, on its stream (orbf: the frame grid and the
+// camera-pair top-2).  They are issued from inside orbx_run_async, so they become part of the captured chain graph; `tag`
+// tells chains with different tails apart (the callback is NOT invoked when a captured chain is replayed).  fn == NULL: off.
+typedef int (*orbx_tail_fn)(void* user, void* stream);
+extern "C" int orbx_set_chain_tail(orbx_extractor* ex, orbx_tail_fn fn, void* user, int tag);

@@ -1624,6 +1624,16 @@ int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n
 
 }  // extern "C"
 
+// the single-workgroup frame kernel may use the opt-in dynamic LDS limit (set once per process)
+static int frame_build_lds_limit() {
+    static bool raised = false;
+    if (!raised) {
+        MORB_HIP(hipFuncSetAttribute((const void*)k_frame_build_small, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        raised = true;
+    }
+    return ORB_OK;
+}
+
 // Frame shell with storage for `n` features, no kernel launched yet.
 static int frame_shell(orbm_matcher* m, int n, int n_cams, float min_x, float min_y, float max_x, float max_y, bool counts_on_device,
                        orbm_frame** out) {
@@ -1724,11 +1734,7 @@ static int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams
     if (m->mirror_ur) { hm.ur = m->mirror_ur; hm.depth = m->mirror_depth; }
     if (m->mirror_unx) { hm.unx = m->mirror_unx; hm.uny = m->mirror_uny; }
     if (small) {
-        static bool raised = false;
-        if (!raised) {
-            MORB_HIP(hipFuncSetAttribute((const void*)k_frame_build_small, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            raised = true;
-        }
+        if ((rc = frame_build_lds_limit())) { if (!*out) orbm_frame_destroy(F); return rc; }
         CamFeat4 c4;
         memset(&c4, 0, sizeof(c4));
         for (int c = 0; c < n_cams; ++c) c4.c[c] = hc[c];
@@ -2564,31 +2570,44 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
             F->n_total = f->cap_total; F->counts_on_device = true; F->host_valid = false;
         }
     }
+    // The frame's grid (larger rigs: the whole frame assembly) and the camera-pair top-2 are the tail of the extraction
+    // chain: built on the extractor's stream right behind the describe kernel (counts read from HBM), so that a step's
+    // matching starts with the search itself.  For small rigs the tail is issued from inside orbx_run_async and is
+    // captured into the replayed launch chain (no host launches at all on replay); larger rigs launch it here (their
+    // assembly stages a parameter block with a copy, which a replayed chain should not carry).
+    struct Tail {
+        orbf_frontend* f; orbx_extractor* ex; orbm_cam_features* cams; const float* bd; int set; bool small, with_cross;
+        static int run(void* u, void* stream) {
+            Tail& T = *static_cast<Tail*>(u);
+            orbm_matcher* m = T.f->mt;
+            orbf_frontend::ResultSet& R = T.f->rs[T.set];
+            orbm_frame* frp = T.f->pframe[T.set];
+            hipStream_t keep = m->stream;
+            m->stream = (hipStream_t)stream;
+            int rc = frame_from_device_impl(m, T.cams, T.f->n_cams, T.f->mbf, T.bd[0], T.bd[1], T.bd[2], T.bd[3], orbx_device_counts(T.ex),
+                                            &frp, T.small);
+            if (!rc && T.with_cross && T.f->n_cams > 1) {
+                const int ncap = frp->n_total;
+                rc = cross_enqueue_to(m->stream, frp->b->d_desc.p, ncap, frp->b->d_cam_start.p, T.f->n_cams, 0, ncap, frp->b->d_ntotal.p,
+                                      R.cross.i.dp, R.cross.b.dp, R.cross.s.dp, R.cross.scratch.p);
+            }
+            m->stream = keep;
+            return rc;
+        }
+    } tail{f, ex, cams.data(), bd, set, small, with_cross};
+    const bool cross_here = with_cross && f->n_cams > 1;
+    if (cross_here && (rc = R.cross.reserve(f->cap_total, f->cap_total))) return rc;  // (storage first: nothing allocates inside a capture)
+    if (small) { if ((rc = m->h_ring.reserve((64 * sizeof(CamFeat) + 65 * sizeof(int) + 64 * sizeof(int)) * 4))) return rc; if ((rc = frame_build_lds_limit())) return rc; }
+    if (small && (rc = orbx_set_chain_tail(ex, &Tail::run, &tail, 1 + set * 2 + (cross_here ? 1 : 0)))) return rc;
     const int before = orbx_pending(ex);
     rc = orbx_run_async(ex);
-    if (small) (void)orbx_set_frame_sink(ex, nullptr);
+    if (small) { (void)orbx_set_frame_sink(ex, nullptr); (void)orbx_set_chain_tail(ex, nullptr, nullptr, 0); }
     if (rc) return rc;
     *went_async = orbx_pending(ex) > before ? 1 : 0;
     if (*went_async) {
-        // the frame's grid (larger rigs: the whole frame assembly) is part of the extraction chain: built on the
-        // extractor's stream right behind the describe kernel (counts read from HBM), so that a step's matching starts
-        // with the search itself
-        orbm_frame* frp = f->pframe[set];
-        hipStream_t keep = m->stream;
-        m->stream = (hipStream_t)orbx_stream(ex);
-        rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], orbx_device_counts(ex), &frp, small);
-        // ... and so is the camera-pair top-2, which needs nothing but the frame's descriptor block
-        R.cross_valid = false;
-        if (!rc && with_cross && f->n_cams > 1) {
-            const int ncap = frp->n_total;
-            if (!(rc = R.cross.reserve(ncap, ncap)))
-                rc = cross_enqueue_to(m->stream, frp->b->d_desc.p, ncap, frp->b->d_cam_start.p, f->n_cams, 0, ncap, frp->b->d_ntotal.p,
-                                      R.cross.i.dp, R.cross.b.dp, R.cross.s.dp, R.cross.scratch.p);
-            R.cross_valid = !rc;
-        }
-        hipError_t he = rc ? hipSuccess : hipEventRecord(f->ev_ready[set], m->stream);
-        m->stream = keep;
-        if (rc) return rc;
+        if (!small && (rc = Tail::run(&tail, orbx_stream(ex)))) return rc;
+        R.cross_valid = cross_here;
+        hipError_t he = hipEventRecord(f->ev_ready[set], (hipStream_t)orbx_stream(ex));
         if (he != hipSuccess) { morb::set_error("hipEventRecord: %s", hipGetErrorString(he)); return ORB_E_HIP; }
     }
     return ORB_OK;
