@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import multi_orb_slam_amd as m
 from multi_orb_slam_amd import synth, pipeline, rt
-for name, (W, H, NF, NC) in {"configs[2] 2x1280x720@2000": (1280, 720, 2000, 2), "configs[3] 4x640x480@1000": (640, 480, 1000, 4),
+for name, (W, H, NF, NC) in {"configs[1] 2x640x480@1000": (640, 480, 1000, 2), "configs[2] 2x1280x720@2000": (1280, 720, 2000, 2), "configs[3] 4x640x480@1000": (640, 480, 1000, 4),
                               "configs[4] 8x1920x1080@4000": (1920, 1080, 4000, 8)}.items():
     fe = pipeline.FrontEnd([m.ExtractorParams(nfeatures=NF)] * NC, W, H)
     fe.copy_results = False
@@ -21,7 +21,7 @@ for name, (W, H, NF, NC) in {"configs[2] 2x1280x720@2000": (1280, 720, 2000, 2),
     arg = lambda t: [(dev[t % R][c].ptr, W) for c in range(NC)]
     for ov in (0, 1, 2):        # timesteps announced ahead
         fe.reset()
-        n = 40
+        n = 400 if W <= 1280 else 40
         if ov == 2:
             fe.announce(arg(1), resident=True)
         for i in range(6):
