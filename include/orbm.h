@@ -157,10 +157,10 @@ int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int wor
                              int32_t* counts_out, int* nq_out);
 /* The same in two halves, for a caller that overlaps the exchange with an orbf_step in flight (orbf_step_begin reported
  * the export block ready): _enqueue puts repack + top-2 on this handle's side stream -- behind `after_stream`, the stream
- * the all-gather was enqueued on (may be NULL) -- and joins it into the handle's main stream; after that stream has been
- * synchronised (orbf_step_end does) _collect copies the results out. */
+ * the all-gather was enqueued on, when wait_after != 0 (NULL then means the default stream) -- and joins it into the
+ * handle's main stream; after that stream has been synchronised (orbf_step_end does) _collect copies the results out. */
 int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered, int world, size_t block_bytes, int cap_rows,
-                                     int cams_per_rank, int rank, void* after_stream);
+                                     int cams_per_rank, int rank, void* after_stream, int wait_after);
 int orbm_cross_top2_gathered_collect(orbm_matcher* m, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
                                      int32_t* counts_out, int* nq_out);
 void orbm_frame_destroy(orbm_frame* f);

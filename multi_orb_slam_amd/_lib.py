@@ -130,7 +130,7 @@ def lib():
     L.orbf_step_begin.argtypes = [vp, vp, vp, i32, i32, vp]
     L.orbf_step_motion_begin.argtypes = [vp, vp, vp, i32, vp]
     L.orbf_step_end.argtypes = [vp, vp]
-    L.orbm_cross_top2_gathered_enqueue.argtypes = [vp, vp, i32, C.c_size_t, i32, i32, i32, vp]
+    L.orbm_cross_top2_gathered_enqueue.argtypes = [vp, vp, i32, C.c_size_t, i32, i32, i32, vp, i32]
     L.orbm_cross_top2_gathered_collect.argtypes = [vp, vp, vp, vp, vp, vp]
     L.orbf_export_block.argtypes = [vp, vp, vp, vp]
     L.orbm_cross_top2_gathered.argtypes = [vp, vp, i32, C.c_size_t, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -2211,7 +2211,7 @@ int orbm_cross_top2_blocks(orbm_matcher* m, const uint8_t* const* d_desc_blocks,
 // enqueue half: repack + top-2 on the handle's SIDE stream (next to whatever the main stream is doing), joined into the
 // main stream so that the next synchronisation of the main stream covers it
 int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered, int world, size_t block_bytes, int cap_rows,
-                                     int cams_per_rank, int rank, void* after_stream) {
+                                     int cams_per_rank, int rank, void* after_stream, int wait_after) {
     MORB_ARG(m && d_gathered && world >= 1 && cams_per_rank >= 1 && world * cams_per_rank <= 512 && rank >= 0 && rank < world &&
              cap_rows >= 1 && block_bytes >= (size_t)cap_rows * 32 + (size_t)cams_per_rank * 4 && (block_bytes & 15) == 0);
     MORB_ARG(((uintptr_t)d_gathered & 15) == 0);
@@ -2222,7 +2222,7 @@ int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered,
     if ((rc = m->d_r.reserve((size_t)n_cap * 32)) || (rc = m->d_gstart.reserve(n_cams + 1 + 4)) || (rc = m->h_gcnt.reserve(n_cams + 1)))
         return rc;
     hipStream_t sd = m->side_stream;
-    if (after_stream) {  // the gathered buffer is produced on another stream (the collective's): order the side stream behind it
+    if (wait_after) {  // the gathered buffer is produced on another stream (the collective's; NULL = the default stream)
         MORB_HIP(hipEventRecord(m->ev_fork, (hipStream_t)after_stream));
         MORB_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
     }
@@ -2263,7 +2263,7 @@ int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int wor
     int rc;
     MORB_HIP(hipSetDevice(m ? m->device : 0));
     if (m) { MORB_HIP(hipEventRecord(m->ev_q, m->stream)); MORB_HIP(hipStreamWaitEvent(m->side_stream, m->ev_q, 0)); }
-    if ((rc = orbm_cross_top2_gathered_enqueue(m, d_gathered, world, block_bytes, cap_rows, cams_per_rank, rank, nullptr))) return rc;
+    if ((rc = orbm_cross_top2_gathered_enqueue(m, d_gathered, world, block_bytes, cap_rows, cams_per_rank, rank, nullptr, 0))) return rc;
     MORB_HIP(hipStreamSynchronize(m->stream));
     return orbm_cross_top2_gathered_collect(m, best_idx, best_dist, second_dist, counts_out, nq_out);
 }

@@ -54,7 +54,7 @@ class DescriptorExchange:
         matching are enqueued next to the step's own matching; collect() after end() returns what __call__ would."""
         nbytes, rows = self._gather(frontend)
         frontend.mt.cross_top2_gathered_enqueue(self.recv_ptr, self.world, nbytes, rows, frontend.n_cams, self.rank,
-                                                self.torch.cuda.current_stream().cuda_stream if self.recv.is_cuda else 0)
+                                                self.torch.cuda.current_stream().cuda_stream if self.recv.is_cuda else None)
 
     def collect(self, frontend):
         return frontend.mt.cross_top2_gathered_collect()

@@ -196,11 +196,12 @@ class Matcher:
                                                   ptr(bi), ptr(bd), ptr(sd), ptr(cnt), C.byref(nq)))
         return bi[:nq.value].copy(), bd[:nq.value].copy(), sd[:nq.value].copy(), cnt.tolist()
 
-    def cross_top2_gathered_enqueue(self, gathered_ptr, world, block_bytes, cap_rows, cams_per_rank, rank, after_stream=0):
-        """Enqueue half of cross_top2_gathered (side stream, behind `after_stream`, joined into the main stream)."""
+    def cross_top2_gathered_enqueue(self, gathered_ptr, world, block_bytes, cap_rows, cams_per_rank, rank, after_stream=None):
+        """Enqueue half of cross_top2_gathered (side stream, joined into the main stream).  after_stream: raw handle of the
+        stream the gathered buffer is produced on (0 = the default stream); None: no ordering needed."""
         self._gathered_shape = (cap_rows, world * cams_per_rank)
         check(_lib.lib().orbm_cross_top2_gathered_enqueue(self._h, C.c_void_p(gathered_ptr), world, block_bytes, cap_rows, cams_per_rank,
-                                                          rank, C.c_void_p(after_stream) if after_stream else None))
+                                                          rank, C.c_void_p(after_stream or 0), 0 if after_stream is None else 1))
 
     def cross_top2_gathered_collect(self):
         """Collect half: after the handle's main stream has been synchronised (orbf_step_end)."""

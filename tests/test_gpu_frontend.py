@@ -274,6 +274,8 @@ def test_single_rank_rccl_exchange_equals_oracle():
         frames = [[synth.image(c, t, 320, 240) for c in range(2)] for t in range(T)]
         fe.announce(frames[1])
         for t in range(T):
+            if t >= 3:      # a busy default stream delays the collective: the gathered matching must wait for it on the device
+                torch.cuda._sleep(4_000_000)
             got = fe.step(frames[t], next_images=frames[t + 2] if t + 2 < T else None)
             assert_same_step(got, ofe.step(frames[t]))
         assert 0 < fe.early_exchanges < T          # both orders of the exchange were exercised
