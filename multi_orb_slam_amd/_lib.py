@@ -63,6 +63,17 @@ class FrameDesc(C.Structure):  # orbm_frame_desc
                 ("max_x", C.c_float), ("max_y", C.c_float)]
 
 
+class BowSide(C.Structure):  # orbv_side
+    _fields_ = [("n", C.c_int32), ("desc", C.c_void_p), ("angle", C.c_void_p), ("flags", C.c_void_p), ("n_nodes", C.c_int32),
+                ("node_id", C.c_void_p), ("node_start", C.c_void_p), ("items", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
+                ("octave", C.c_void_p), ("cam_of", C.c_void_p)]
+
+
+class Triangulation(C.Structure):  # orbv_triangulation
+    _fields_ = [("n_cams", C.c_int32), ("n_levels", C.c_int32), ("F12", (C.c_float * 9) * 8), ("ex", C.c_float * 8),
+                ("ey", C.c_float * 8), ("scale_factors", C.c_void_p), ("level_sigma2", C.c_void_p)]
+
+
 def build(verbose=False):
     """Compile every HIP source for gfx950 into lib/libmorb.so (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", CSRC] + ([] if verbose else ["-s"])
@@ -150,6 +161,20 @@ def lib():
     L.orbm_project_candidates.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     L.orbm_search_by_projection.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp]
     L.orbm_search_by_projection_points.argtypes = [vp, vp, vp, i32, vp, f32, i32, vp, vp]
+    f64 = C.c_double
+    L.orbv_create.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp]
+    L.orbv_load_text.argtypes = [C.c_char_p, i32, vp]
+    L.orbv_destroy.argtypes = [vp]; L.orbv_destroy.restype = None
+    L.orbv_info.argtypes = [vp, vp, vp, vp, vp]
+    L.orbv_stream.argtypes = [vp]; L.orbv_stream.restype = vp
+    L.orbv_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.orbv_transform_device.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.orbv_bow_vectors.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.orbv_score_l1.argtypes = [vp, vp, i32, vp, vp, i32]; L.orbv_score_l1.restype = f64
+    L.orbv_workspace_create.argtypes = [i32, vp]
+    L.orbv_workspace_destroy.argtypes = [vp]; L.orbv_workspace_destroy.restype = None
+    L.orbv_search_by_bow.argtypes = [vp, vp, vp, i32, i32, f32, i32, vp, vp]
+    L.orbv_search_for_triangulation.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     _lib = L
     return L
 

@@ -1,0 +1,601 @@
+// bow.hip -- vocabulary-tree transform and BoW-gated searches on MI355X (gfx950).  C ABI: include/orbv.h.
+//
+//   k_bow_transform   one descent per feature, 16 lanes per feature (one child per lane, DBoW2's k <= 20 takes two
+//                     passes at most); the tree is renumbered breadth-first at load so that the children of a node are one
+//                     contiguous run of 32-byte descriptors (TemplatedVocabulary.h:1219-1260).
+//   k_bow_join<MODE>  one wavefront per vocabulary node common to both sides: queries strictly in the reference's order
+//                     (the "already matched" state makes them order-dependent inside a node, never across nodes), the
+//                     candidates of the node spread over the 64 lanes, top-2 by wave reductions
+//                     (src/ORBmatcher.cc:206-388, :996-1165, :1364-1786).
+//   k_bow_finish      rotation histogram -> three maxima -> removal -> count, results written to pinned host memory.
+//
+// Latency-bound integer work (a few 10^4 Hamming distances per call): no LDS tiling to speak of, no matrix cores.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <numeric>
+#include <sstream>
+#include <string>
+#include <vector>
+#include "../../include/orbv.h"
+#include "orb_common.h"
+
+using morb::DevBuf;
+using morb::PinnedBuf;
+
+namespace {
+
+constexpr int HISTO = 30;        // ORBmatcher::HISTO_LENGTH, src/ORBmatcher.cc:39
+constexpr int MAX_LEVELS = 32;   // pyramid levels a triangulation search may name
+constexpr int JOIN_MAX_NODE = 65536;  // candidates of one node (one LDS byte each)
+
+__device__ __forceinline__ int ham256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+           __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// wave64 minimum, every lane active; result in every lane
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ __launch_bounds__(256) void k_bow_transform(const uint4* __restrict__ vdesc, const int* __restrict__ first_child,
+                                                       const uint32_t* __restrict__ orig, const uint32_t* __restrict__ word,
+                                                       const uint4* __restrict__ feat, int n, int nid_level,
+                                                       uint32_t* __restrict__ word_out, uint32_t* __restrict__ node_out,
+                                                       uint32_t* __restrict__ leaf_out) {
+    const int sub = threadIdx.x & 15;
+    const int f = (int)((blockIdx.x * 256u + threadIdx.x) >> 4);
+    if (f >= n) return;
+    const uint4 a0 = feat[2 * (size_t)f], a1 = feat[2 * (size_t)f + 1];
+    int cur = 0, level = 0;
+    uint32_t nid = 0;
+    int fc = first_child[0], fe = first_child[1];
+    while (fe > fc) {
+        ++level;
+        unsigned best = 0xffffffffu;
+        for (int c = fc + sub; c < fe; c += 16) {
+            const int d = ham256(a0, a1, vdesc[2 * (size_t)c], vdesc[2 * (size_t)c + 1]);
+            best = min(best, ((unsigned)d << 22) | (unsigned)(c - fc));   // first child wins a tie (strict '<', :1241)
+        }
+        best = min(best, (unsigned)__shfl_xor((int)best, 1, 16));
+        best = min(best, (unsigned)__shfl_xor((int)best, 2, 16));
+        best = min(best, (unsigned)__shfl_xor((int)best, 4, 16));
+        best = min(best, (unsigned)__shfl_xor((int)best, 8, 16));
+        cur = fc + (int)(best & 0x3fffffu);
+        if (level == nid_level) nid = orig[cur];
+        fc = first_child[cur]; fe = first_child[cur + 1];
+    }
+    if (sub == 0) {
+        word_out[f] = word[cur]; node_out[f] = nid;
+        if (leaf_out) leaf_out[f] = orig[cur];
+    }
+}
+
+struct SideDev {
+    int n, n_nodes;
+    const uint4* desc; const float* angle; const uint8_t* flags; const uint32_t* node_id; const int32_t* node_start;
+    const uint32_t* items; const float* x; const float* y; const int32_t* octave; const int32_t* cam_of;
+};
+
+struct TriDev {
+    float F12[ORBV_MAX_CAMS][9];
+    float ex[ORBV_MAX_CAMS], ey[ORBV_MAX_CAMS];
+    float scale[MAX_LEVELS], sigma2[MAX_LEVELS];
+};
+
+struct JoinWork {
+    int32_t* match;    // n_out
+    uint8_t* bin_of;   // n_out: histogram bin of an accepted match
+    int* hist;         // HISTO bins, then [HISTO] = accepted matches
+};
+
+__global__ void k_bow_init(JoinWork W, int n_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_out) W.match[i] = -1;
+    if (i <= HISTO) W.hist[i] = 0;
+}
+
+__device__ __forceinline__ int rot_bin(float a1, float a2) {
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * (1.0f / HISTO));
+    if (bin == HISTO) bin = 0;
+    return bin;
+}
+
+// MODE 0: SearchByBoW(KF, F); 1: SearchByBoW(KF, KF); 2: SearchForTriangulation.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T, int th_low, float nnratio, int check_ori, JoinWork W) {
+    extern __shared__ uint8_t s_claimed[];
+    const int lane = threadIdx.x;
+    const int an = blockIdx.x;
+    const uint32_t id = A.node_id[an];
+    int lo = 0, hi = B.n_nodes;   // FeatureVector::lower_bound
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (B.node_id[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= B.n_nodes || B.node_id[lo] != id) return;
+    const int qa0 = A.node_start[an], qa1 = A.node_start[an + 1];
+    const int cb0 = B.node_start[lo], nc = B.node_start[lo + 1] - cb0;
+    if (nc <= 0 || qa1 <= qa0) return;
+    for (int j = lane; j < nc; j += 64) {
+        bool usable = true;
+        if (MODE != 0 && B.flags) usable = (B.flags[B.items[cb0 + j]] & 1) != 0;
+        s_claimed[j] = usable ? 0 : 1;
+    }
+    // the first 64 candidates stay in registers for every query of the node
+    const int my_idx2 = lane < nc ? (int)B.items[cb0 + lane] : 0;
+    uint4 m0 = make_uint4(0, 0, 0, 0), m1 = m0;
+    if (lane < nc) { m0 = B.desc[2 * (size_t)my_idx2]; m1 = B.desc[2 * (size_t)my_idx2 + 1]; }
+    __syncthreads();
+    for (int k1 = qa0; k1 < qa1; ++k1) {
+        const int idx1 = (int)A.items[k1];
+        const int fl1 = A.flags ? A.flags[idx1] : 1;
+        if (!(fl1 & 1)) continue;                      // wave-uniform
+        const uint4 q0 = A.desc[2 * (size_t)idx1], q1 = A.desc[2 * (size_t)idx1 + 1];
+        int cam1 = 0; float x1 = 0, y1 = 0, la = 0, lb = 0, lc = 0, den = 0;
+        if (MODE == 2) {
+            cam1 = A.cam_of[idx1]; x1 = A.x[idx1]; y1 = A.y[idx1];
+            const float* F = T.F12[cam1];              // CheckDistEpipolarLine, src/ORBmatcher.cc:170-178
+            la = x1 * F[0] + y1 * F[3] + F[6];
+            lb = x1 * F[1] + y1 * F[4] + F[7];
+            lc = x1 * F[2] + y1 * F[5] + F[8];
+            den = la * la + lb * lb;
+        }
+        int bd = 256, bj = -1, d2 = 256;               // per-lane top-2 (modes 0/1)
+        unsigned key2 = 0x7fffffffu;                   // per-lane best (mode 2): smallest distance, LAST candidate on ties
+        for (int j = lane, t = 0; j < nc; j += 64, ++t) {
+            if (s_claimed[j]) continue;
+            int idx2; uint4 c0, c1;
+            if (t == 0) { idx2 = my_idx2; c0 = m0; c1 = m1; }
+            else { idx2 = (int)B.items[cb0 + j]; c0 = B.desc[2 * (size_t)idx2]; c1 = B.desc[2 * (size_t)idx2 + 1]; }
+            const int d = ham256(q0, q1, c0, c1);
+            if (MODE != 2) {
+                if (d < bd) { d2 = bd; bd = d; bj = j; }
+                else if (d < d2) d2 = d;
+            } else {
+                if (d > th_low) continue;
+                if (B.cam_of[idx2] != cam1) continue;                          // :1562
+                const int fl2 = B.flags ? B.flags[idx2] : 1;
+                const float x2 = B.x[idx2], y2 = B.y[idx2];
+                const int oct2 = B.octave[idx2];
+                if (!(fl1 & 2) && !(fl2 & 2)) {                                // both monocular: too close to the epipole (:1582-1595)
+                    const float dex = T.ex[cam1] - x2, dey = T.ey[cam1] - y2;
+                    if (dex * dex + dey * dey < 100 * T.scale[oct2]) continue;
+                }
+                const float num = la * x2 + lb * y2 + lc;
+                if (den == 0) continue;
+                const float dsqr = num * num / den;
+                if (!((double)dsqr < 3.84 * (double)T.sigma2[oct2])) continue;
+                key2 = min(key2, ((unsigned)d << 20) | (unsigned)(0xfffff - j));
+            }
+        }
+        if (MODE != 2) {
+            const unsigned K = wave_min_u32(bj >= 0 ? (((unsigned)bd << 20) | (unsigned)bj) : 0x7fffffffu);
+            if (K == 0x7fffffffu) continue;            // wave-uniform: nothing closer than 256
+            const int best = (int)(K >> 20), J = (int)(K & 0xfffffu);
+            const int second = (int)wave_min_u32((unsigned)(((J & 63) == lane) ? d2 : bd));
+            const bool under = MODE == 0 ? best <= th_low : best < th_low;        // :324 / :1107
+            if (under && (float)best < nnratio * (float)second) {
+                if (lane == 0) {
+                    const int idx2 = (int)B.items[cb0 + J];
+                    const int oi = MODE == 0 ? idx2 : idx1;
+                    W.match[oi] = MODE == 0 ? idx1 : idx2;
+                    s_claimed[J] = 1;
+                    if (check_ori) {
+                        const int bin = rot_bin(A.angle[idx1], B.angle[idx2]);
+                        W.bin_of[oi] = (uint8_t)bin;
+                        atomicAdd(&W.hist[bin], 1);
+                    }
+                    atomicAdd(&W.hist[HISTO], 1);
+                }
+                __syncthreads();
+            }
+        } else {
+            const unsigned K = wave_min_u32(key2);
+            if (K == 0x7fffffffu) continue;
+            if (lane == 0) {
+                const int J = 0xfffff - (int)(K & 0xfffffu);
+                const int idx2 = (int)B.items[cb0 + J];
+                W.match[idx1] = idx2;
+                if (check_ori) {
+                    const int bin = rot_bin(A.angle[idx1], B.angle[idx2]);
+                    W.bin_of[idx1] = (uint8_t)bin;
+                    atomicAdd(&W.hist[bin], 1);
+                }
+                atomicAdd(&W.hist[HISTO], 1);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bow_finish(JoinWork W, int n_out, int check_ori, int32_t* __restrict__ h_match, int* __restrict__ h_result) {
+    __shared__ int s_keep[3];
+    __shared__ int s_removed;
+    if (threadIdx.x == 0) {
+        // ComputeThreeMaxima, src/ORBmatcher.cc:3948-3989
+        int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < HISTO; i++) {
+            const int s = W.hist[i];
+            if (s > m1) { m3 = m2; i3 = i2; m2 = m1; i2 = i1; m1 = s; i1 = i; }
+            else if (s > m2) { m3 = m2; i3 = i2; m2 = s; i2 = i; }
+            else if (s > m3) { m3 = s; i3 = i; }
+        }
+        if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+        else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+        s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3; s_removed = 0;
+    }
+    __syncthreads();
+    int removed = 0;
+    for (int i = threadIdx.x; i < n_out; i += 256) {
+        int mt = W.match[i];
+        if (check_ori && mt >= 0) {
+            const int b = W.bin_of[i];
+            if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) { mt = -1; ++removed; }
+        }
+        h_match[i] = mt;
+    }
+    if (removed) atomicAdd(&s_removed, removed);
+    __syncthreads();
+    if (threadIdx.x == 0) h_result[0] = W.hist[HISTO] - s_removed;
+}
+
+inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+}  // namespace
+
+struct orbv_vocabulary {
+    int device = 0, L = 0, k = 0, n_nodes = 0, n_words = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<uint4> d_desc;            // 2 per node, breadth-first order
+    DevBuf<int32_t> d_first_child;   // n_nodes + 1: children of node d are [first_child[d], first_child[d+1])
+    DevBuf<uint32_t> d_orig, d_word; // NodeId / WordId of a breadth-first index
+    std::vector<double> weight;      // by NodeId
+    DevBuf<uint8_t> d_feat;
+    DevBuf<uint32_t> d_out;
+    PinnedBuf<uint32_t> h_out;
+    PinnedBuf<uint8_t> h_feat;
+};
+
+struct orbv_workspace {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    PinnedBuf<uint8_t> h_stage;
+    DevBuf<uint8_t> d_stage, d_work;
+    PinnedBuf<int32_t> h_match;
+};
+
+extern "C" {
+
+int orbv_create(int n_nodes, int L, const int32_t* parent, const uint8_t* is_leaf, const uint8_t* desc, const double* weight,
+                int device, orbv_vocabulary** out) {
+    MORB_ARG(out != nullptr && n_nodes >= 2 && L >= 1 && parent && is_leaf && desc && weight);
+    for (int i = 1; i < n_nodes; ++i) MORB_ARG(parent[i] >= 0 && parent[i] < n_nodes && parent[i] != i);
+    int rc = morb::select_device(device);
+    if (rc != ORB_OK) return rc;
+    // children in ascending id (the loader pushes them back in file order, TemplatedVocabulary.h:1386-1393)
+    std::vector<int32_t> cstart(n_nodes + 1, 0), clist(n_nodes - 1);
+    for (int i = 1; i < n_nodes; ++i) cstart[parent[i] + 1]++;
+    for (int i = 0; i < n_nodes; ++i) cstart[i + 1] += cstart[i];
+    MORB_ARG(cstart[1] > 0);   // the root has children (the reference indexes children[0] unconditionally, :1236)
+    { std::vector<int32_t> fill(cstart.begin(), cstart.end() - 1);
+      for (int i = 1; i < n_nodes; ++i) clist[fill[parent[i]]++] = i; }
+    std::vector<uint32_t> word_of(n_nodes, 0);   // Node(): word_id(0); set for the flagged nodes in id order (:1409-1416)
+    uint32_t words = 0;
+    for (int i = 1; i < n_nodes; ++i) if (is_leaf[i]) word_of[i] = words++;
+    // breadth-first renumbering from the root: every node's children become one contiguous run
+    std::vector<int32_t> order; order.reserve(n_nodes); order.push_back(0);
+    std::vector<int32_t> first_child(n_nodes + 1, 0);
+    int kmax = 0;
+    for (size_t h = 0; h < order.size(); ++h) {
+        const int id = order[h];
+        first_child[h] = (int32_t)order.size();
+        for (int c = cstart[id]; c < cstart[id + 1]; ++c) order.push_back(clist[c]);
+        kmax = std::max(kmax, cstart[id + 1] - cstart[id]);
+    }
+    const int reach = (int)order.size();   // nodes not reachable from the root (cycles among themselves) can never be visited
+    first_child[reach] = reach;
+    orbv_vocabulary* v = new orbv_vocabulary();
+    v->device = device; v->L = L; v->k = kmax; v->n_nodes = n_nodes; v->n_words = (int)words;
+    v->weight.assign(weight, weight + n_nodes); v->weight[0] = 0.0;
+    std::vector<uint8_t> bdesc((size_t)reach * 32);
+    std::vector<uint32_t> borig(reach), bword(reach);
+    for (int h = 0; h < reach; ++h) {
+        const int id = order[h];
+        if (id) memcpy(&bdesc[(size_t)h * 32], desc + (size_t)id * 32, 32); else memset(&bdesc[0], 0, 32);
+        borig[h] = (uint32_t)id; bword[h] = word_of[id];
+    }
+    hipError_t e = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete v; return ORB_E_HIP; }
+    if ((rc = v->d_desc.reserve((size_t)reach * 2)) || (rc = v->d_first_child.reserve(reach + 1)) || (rc = v->d_orig.reserve(reach)) ||
+        (rc = v->d_word.reserve(reach))) { orbv_destroy(v); return rc; }
+    if (hipMemcpy(v->d_desc.p, bdesc.data(), bdesc.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(v->d_first_child.p, first_child.data(), (size_t)(reach + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(v->d_orig.p, borig.data(), (size_t)reach * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(v->d_word.p, bword.data(), (size_t)reach * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        morb::set_error("vocabulary upload failed"); orbv_destroy(v); return ORB_E_HIP;
+    }
+    *out = v;
+    return ORB_OK;
+}
+
+int orbv_load_text(const char* path, int device, orbv_vocabulary** out) {
+    MORB_ARG(path != nullptr && out != nullptr);
+    std::ifstream f(path);
+    if (!f.good()) { morb::set_error("cannot open vocabulary file %s", path); return ORB_E_ARG; }
+    std::string s;
+    std::getline(f, s);
+    int k = -1, L = -1, n1 = -1, n2 = -1;
+    { std::stringstream ss(s); ss >> k >> L >> n1 >> n2; }
+    if (k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) {   // the reference's sanity check (:1360)
+        morb::set_error("vocabulary loading failure: %s is not a correct text file", path); return ORB_E_ARG;
+    }
+    if (n1 != 0 || n2 != 0) { morb::set_error("only L1_NORM scoring with TF_IDF weighting (ORBvoc.txt) is supported, file declares %d %d", n1, n2); return ORB_E_ARG; }
+    std::vector<int32_t> parent(1, 0); std::vector<uint8_t> leaf(1, 0), desc(32, 0); std::vector<double> weight(1, 0.0);
+    while (std::getline(f, s)) {
+        const char* p = s.c_str(); char* q = nullptr;
+        while (*p == ' ' || *p == '\t' || *p == '\r') ++p;
+        if (!*p) continue;                                  // empty line (see orbv.h)
+        const long pid = strtol(p, &q, 10); p = q;
+        const long il = strtol(p, &q, 10); p = q;
+        uint8_t d[32];
+        for (int i = 0; i < 32; ++i) { d[i] = (uint8_t)strtol(p, &q, 10); p = q; }
+        const double w = strtod(p, &q);
+        if (q == p) { morb::set_error("vocabulary line %zu is malformed", parent.size()); return ORB_E_ARG; }
+        parent.push_back((int32_t)pid); leaf.push_back(il > 0); desc.insert(desc.end(), d, d + 32); weight.push_back(w);
+    }
+    return orbv_create((int)parent.size(), L, parent.data(), leaf.data(), desc.data(), weight.data(), device, out);
+}
+
+void orbv_destroy(orbv_vocabulary* v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    if (v->stream) { (void)hipStreamSynchronize(v->stream); (void)hipStreamDestroy(v->stream); }
+    v->d_desc.release(); v->d_first_child.release(); v->d_orig.release(); v->d_word.release(); v->d_feat.release(); v->d_out.release();
+    v->h_out.release(); v->h_feat.release();
+    delete v;
+}
+
+int orbv_info(const orbv_vocabulary* v, int* n_nodes, int* n_words, int* k, int* L) {
+    MORB_ARG(v != nullptr);
+    if (n_nodes) *n_nodes = v->n_nodes;
+    if (n_words) *n_words = v->n_words;
+    if (k) *k = v->k;
+    if (L) *L = v->L;
+    return ORB_OK;
+}
+
+void* orbv_stream(orbv_vocabulary* v) { return v ? (void*)v->stream : nullptr; }
+
+static int transform_enqueue(const orbv_vocabulary* v, const uint8_t* d_features, int n, int levelsup, uint32_t* d_word,
+                             uint32_t* d_node, uint32_t* d_leaf, hipStream_t st) {
+    if (n == 0) return ORB_OK;
+    k_bow_transform<<<(n + 15) / 16, 256, 0, st>>>(v->d_desc.p, v->d_first_child.p, v->d_orig.p, v->d_word.p, (const uint4*)d_features, n,
+                                                   v->L - levelsup, d_word, d_node, d_leaf);
+    MORB_HIP(hipGetLastError());
+    return ORB_OK;
+}
+
+int orbv_transform_device(const orbv_vocabulary* v, const uint8_t* d_features, int n, int levelsup, uint32_t* d_word_id,
+                          uint32_t* d_node_id, void* stream) {
+    MORB_ARG(v != nullptr && n >= 0 && (n == 0 || (d_features && d_word_id && d_node_id)) && ((uintptr_t)d_features & 15) == 0);
+    return transform_enqueue(v, d_features, n, levelsup, d_word_id, d_node_id, nullptr, (hipStream_t)stream);
+}
+
+// descents of n host features; results in v->h_out: [0,n) word, [n,2n) node, [2n,3n) leaf NodeId
+static int transform_host(orbv_vocabulary* v, const uint8_t* features, int n, int levelsup) {
+    MORB_HIP(hipSetDevice(v->device));
+    int rc;
+    if ((rc = v->h_feat.reserve((size_t)n * 32)) || (rc = v->d_feat.reserve((size_t)n * 32)) || (rc = v->d_out.reserve((size_t)n * 3)) ||
+        (rc = v->h_out.reserve((size_t)n * 3))) return rc;
+    memcpy(v->h_feat.p, features, (size_t)n * 32);
+    MORB_HIP(hipMemcpyAsync(v->d_feat.p, v->h_feat.p, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
+    if ((rc = transform_enqueue(v, v->d_feat.p, n, levelsup, v->d_out.p, v->d_out.p + n, v->d_out.p + 2 * (size_t)n, v->stream))) return rc;
+    MORB_HIP(hipMemcpyAsync(v->h_out.p, v->d_out.p, (size_t)n * 12, hipMemcpyDeviceToHost, v->stream));
+    MORB_HIP(hipStreamSynchronize(v->stream));
+    return ORB_OK;
+}
+
+int orbv_transform(orbv_vocabulary* v, const uint8_t* features, int n, int levelsup, uint32_t* word_id, uint32_t* node_id, double* weight) {
+    MORB_ARG(v != nullptr && n >= 0 && (n == 0 || (features && word_id && node_id)));
+    if (n == 0) return ORB_OK;
+    int rc = transform_host(v, features, n, levelsup);
+    if (rc) return rc;
+    memcpy(word_id, v->h_out.p, (size_t)n * 4);
+    memcpy(node_id, v->h_out.p + n, (size_t)n * 4);
+    if (weight) for (int i = 0; i < n; ++i) weight[i] = v->weight[v->h_out.p[2 * (size_t)n + i]];
+    return ORB_OK;
+}
+
+int orbv_bow_vectors(orbv_vocabulary* v, const uint8_t* features, int n, int levelsup, uint32_t* bow_id, double* bow_val,
+                     int* n_words, uint32_t* fv_node, int32_t* fv_start, uint32_t* fv_items, int* n_fv_nodes) {
+    MORB_ARG(v != nullptr && n >= 0 && n_words && n_fv_nodes && fv_start && (n == 0 || (features && bow_id && bow_val && fv_node && fv_items)));
+    *n_words = 0; *n_fv_nodes = 0; fv_start[0] = 0;
+    if (n == 0) return ORB_OK;
+    int rc = transform_host(v, features, n, levelsup);
+    if (rc) return rc;
+    const uint32_t* word = v->h_out.p; const uint32_t* node = v->h_out.p + n; const uint32_t* leaf = v->h_out.p + 2 * (size_t)n;
+    std::vector<int> keep; keep.reserve(n);
+    for (int i = 0; i < n; ++i) if (v->weight[leaf[i]] > 0) keep.push_back(i);   // "not stopped" (:1156)
+    // BowVector::addWeight per feature in feature order == per word, the weights of its features added one by one
+    std::vector<int> byw(keep);
+    std::stable_sort(byw.begin(), byw.end(), [&](int a, int b) { return word[a] < word[b]; });
+    int nw = 0;
+    for (size_t s = 0; s < byw.size();) {
+        size_t e = s;
+        double acc = v->weight[leaf[byw[s]]];           // insert(id, w)
+        for (e = s + 1; e < byw.size() && word[byw[e]] == word[byw[s]]; ++e) acc += v->weight[leaf[byw[e]]];   // vit->second += w
+        bow_id[nw] = word[byw[s]]; bow_val[nw] = acc; ++nw;
+        s = e;
+    }
+    double norm = 0.0;                                  // BowVector::normalize(L1), ascending word id
+    for (int i = 0; i < nw; ++i) norm += std::fabs(bow_val[i]);
+    if (norm > 0.0) for (int i = 0; i < nw; ++i) bow_val[i] /= norm;
+    *n_words = nw;
+    // FeatureVector::addFeature: nodes ascending, features of a node in feature order
+    std::vector<int> byn(keep);
+    std::stable_sort(byn.begin(), byn.end(), [&](int a, int b) { return node[a] < node[b]; });
+    int nn = 0, off = 0;
+    for (size_t s = 0; s < byn.size();) {
+        size_t e = s;
+        fv_node[nn] = node[byn[s]]; fv_start[nn] = off;
+        for (; e < byn.size() && node[byn[e]] == node[byn[s]]; ++e) fv_items[off++] = (uint32_t)byn[e];
+        ++nn; s = e;
+    }
+    fv_start[nn] = off;
+    *n_fv_nodes = nn;
+    return ORB_OK;
+}
+
+double orbv_score_l1(const uint32_t* id1, const double* v1, int n1, const uint32_t* id2, const double* v2, int n2) {
+    // L1Scoring::score over two id-sorted sparse vectors (ScoringObject.cpp:23-68)
+    double score = 0;
+    int i = 0, j = 0;
+    while (i < n1 && j < n2) {
+        if (id1[i] == id2[j]) { score += std::fabs(v1[i] - v2[j]) - std::fabs(v1[i]) - std::fabs(v2[j]); ++i; ++j; }
+        else if (id1[i] < id2[j]) i = (int)(std::lower_bound(id1 + i, id1 + n1, id2[j]) - id1);
+        else j = (int)(std::lower_bound(id2 + j, id2 + n2, id1[i]) - id2);
+    }
+    return -score / 2.0;
+}
+
+int orbv_workspace_create(int device, orbv_workspace** out) {
+    MORB_ARG(out != nullptr);
+    int rc = morb::select_device(device);
+    if (rc != ORB_OK) return rc;
+    orbv_workspace* w = new orbv_workspace();
+    w->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete w; return ORB_E_HIP; }
+    *out = w;
+    return ORB_OK;
+}
+
+void orbv_workspace_destroy(orbv_workspace* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->device);
+    if (w->stream) { (void)hipStreamSynchronize(w->stream); (void)hipStreamDestroy(w->stream); }
+    w->h_stage.release(); w->d_stage.release(); w->d_work.release(); w->h_match.release();
+    delete w;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Packer {   // lays the arrays of both sides out in one pinned block, mirrored by one device block
+    size_t off = 0;
+    uint8_t* h = nullptr; uint8_t* d = nullptr;
+    size_t reserve_bytes(size_t bytes) { const size_t o = off; off = up16(off + bytes); return o; }
+    template <typename T> const T* put(const T* src, size_t count) {
+        if (!src) return nullptr;
+        const size_t o = reserve_bytes(count * sizeof(T));
+        if (h) memcpy(h + o, src, count * sizeof(T));
+        return (const T*)(d + o);
+    }
+};
+
+int side_check(const orbv_side* s, bool tri) {
+    MORB_ARG(s != nullptr && s->n >= 0 && s->n_nodes >= 0);
+    if (s->n_nodes > 0) {
+        MORB_ARG(s->node_id && s->node_start && s->node_start[0] == 0);
+        for (int k = 0; k < s->n_nodes; ++k) {
+            MORB_ARG(s->node_start[k + 1] >= s->node_start[k]);
+            MORB_ARG(k == 0 || s->node_id[k] > s->node_id[k - 1]);
+        }
+        const int m = s->node_start[s->n_nodes];
+        MORB_ARG(m <= s->n && (m == 0 || s->items));
+        for (int i = 0; i < m; ++i) MORB_ARG(s->items[i] < (uint32_t)s->n);
+    }
+    if (s->n > 0) { MORB_ARG(s->desc && s->angle); if (tri) MORB_ARG(s->x && s->y && s->octave && s->cam_of); }
+    return ORB_OK;
+}
+
+SideDev pack_side(Packer& P, const orbv_side* s, bool tri) {
+    SideDev D;
+    D.n = s->n; D.n_nodes = s->n_nodes;
+    D.desc = (const uint4*)P.put(s->desc, (size_t)s->n * 32);
+    D.angle = P.put(s->angle, s->n);
+    D.flags = P.put(s->flags, s->n);
+    D.node_id = P.put(s->node_id, s->n_nodes);
+    D.node_start = P.put(s->node_start, (size_t)s->n_nodes + 1);
+    D.items = P.put(s->items, s->n_nodes ? (size_t)s->node_start[s->n_nodes] : 0);
+    D.x = tri ? P.put(s->x, s->n) : nullptr; D.y = tri ? P.put(s->y, s->n) : nullptr;
+    D.octave = tri ? P.put(s->octave, s->n) : nullptr; D.cam_of = tri ? P.put(s->cam_of, s->n) : nullptr;
+    return D;
+}
+
+int run_join(orbv_workspace* w, const orbv_side* a, const orbv_side* b, int mode, const orbv_triangulation* t, int th_low,
+             float nnratio, int check_ori, int32_t* match, int* nmatches) {
+    MORB_ARG(w != nullptr && nmatches != nullptr && mode >= 0 && mode <= 2);
+    const bool tri = mode == 2;
+    int rc;
+    if ((rc = side_check(a, tri)) || (rc = side_check(b, tri))) return rc;
+    const int n_out = mode == 0 ? b->n : a->n;
+    MORB_ARG(n_out == 0 || match != nullptr);
+    TriDev T; memset(&T, 0, sizeof(T));
+    if (tri) {
+        MORB_ARG(t != nullptr && t->n_cams >= 1 && t->n_cams <= ORBV_MAX_CAMS && t->n_levels >= 1 && t->n_levels <= MAX_LEVELS && t->scale_factors && t->level_sigma2);
+        memcpy(T.F12, t->F12, sizeof(T.F12)); memcpy(T.ex, t->ex, sizeof(T.ex)); memcpy(T.ey, t->ey, sizeof(T.ey));
+        memcpy(T.scale, t->scale_factors, t->n_levels * sizeof(float)); memcpy(T.sigma2, t->level_sigma2, t->n_levels * sizeof(float));
+        for (int i = 0; i < a->n; ++i) MORB_ARG(a->cam_of[i] >= 0 && a->cam_of[i] < t->n_cams);
+        for (int i = 0; i < b->n; ++i) MORB_ARG(b->octave[i] >= 0 && b->octave[i] < t->n_levels);
+    }
+    *nmatches = 0;
+    for (int i = 0; i < n_out; ++i) match[i] = -1;
+    if (a->n_nodes == 0 || b->n_nodes == 0 || a->n == 0 || b->n == 0) return ORB_OK;
+    int max_nc = 1;
+    for (int k = 0; k < b->n_nodes; ++k) max_nc = std::max(max_nc, b->node_start[k + 1] - b->node_start[k]);
+    if (max_nc > JOIN_MAX_NODE) { morb::set_error("a vocabulary node holds %d features (limit %d)", max_nc, JOIN_MAX_NODE); return ORB_E_CAPACITY; }
+    MORB_HIP(hipSetDevice(w->device));
+    Packer size_pass;                                   // first pass: sizes only
+    (void)pack_side(size_pass, a, tri); (void)pack_side(size_pass, b, tri);
+    if ((rc = w->h_stage.reserve(size_pass.off)) || (rc = w->d_stage.reserve(size_pass.off))) return rc;
+    Packer P; P.h = w->h_stage.p; P.d = w->d_stage.p;
+    const SideDev A = pack_side(P, a, tri), B = pack_side(P, b, tri);
+    const size_t work_bytes = up16((size_t)n_out * 4) + up16((HISTO + 1) * 4) + up16((size_t)n_out);
+    if ((rc = w->d_work.reserve(work_bytes)) || (rc = w->h_match.reserve((size_t)n_out + 4))) return rc;
+    JoinWork W;
+    W.match = (int32_t*)w->d_work.p;
+    W.hist = (int*)(w->d_work.p + up16((size_t)n_out * 4));
+    W.bin_of = w->d_work.p + up16((size_t)n_out * 4) + up16((HISTO + 1) * 4);
+    hipStream_t st = w->stream;
+    MORB_HIP(hipMemcpyAsync(w->d_stage.p, w->h_stage.p, P.off, hipMemcpyHostToDevice, st));
+    k_bow_init<<<(std::max(n_out, HISTO + 1) + 255) / 256, 256, 0, st>>>(W, n_out);
+    const size_t lds = (size_t)((max_nc + 63) & ~63);
+    if (mode == 0) k_bow_join<0><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W);
+    else if (mode == 1) k_bow_join<1><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W);
+    else k_bow_join<2><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W);
+    k_bow_finish<<<1, 256, 0, st>>>(W, n_out, check_ori, w->h_match.dp, w->h_match.dp + n_out);
+    MORB_HIP(hipGetLastError());
+    MORB_HIP(hipStreamSynchronize(st));
+    memcpy(match, w->h_match.p, (size_t)n_out * 4);
+    *nmatches = w->h_match.p[n_out];
+    return ORB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbv_search_by_bow(orbv_workspace* w, const orbv_side* a, const orbv_side* b, int mode, int th_low, float nnratio,
+                       int check_orientation, int32_t* match, int* nmatches) {
+    MORB_ARG(mode == 0 || mode == 1);
+    return run_join(w, a, b, mode, nullptr, th_low, nnratio, check_orientation, match, nmatches);
+}
+
+int orbv_search_for_triangulation(orbv_workspace* w, const orbv_side* a, const orbv_side* b, const orbv_triangulation* t,
+                                  int th_low, int check_orientation, int32_t* match, int* nmatches) {
+    return run_join(w, a, b, 2, t, th_low, 0.f, check_orientation, match, nmatches);
+}
+
+}  // extern "C"

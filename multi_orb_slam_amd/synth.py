@@ -62,3 +62,57 @@ def perturbed_queries(refs, seed=7, flip_p=0.08):
     half = (np.arange(n) % 2) == 1
     q[half] = fresh[half]
     return q
+
+
+def _flip_bits(rows, seed, p):
+    n = len(rows)
+    bits = hash32(np.arange(n * 256, dtype=np.uint64) + np.uint64((seed * 0x2545F491) & 0xFFFFFFFF)).astype(np.float64) / 2.0 ** 32 < p
+    return rows ^ np.packbits(bits.reshape(n, 256), axis=1, bitorder="little")
+
+
+def vocabulary(k=10, L=3, seed=11, ragged=False, stop_every=0):
+    """Synthetic vocabulary tree in the layout of DBoW2's text loader (no vocabulary file ships with the reference): node ids in
+    creation order, the children of a node = its descriptor with ~12 % of the bits flipped, idf-like positive weights.
+    ragged: every 7th inner node becomes a leaf early and child counts vary in [2, k]; stop_every: every n-th word gets weight 0.
+    -> dict(parent, is_leaf, desc, weight: arrays over node ids; k, L)."""
+    parent, leaf, desc, weight = [0], [0], [np.zeros(32, np.uint8)], [0.0]
+    root = descriptors(1, seed)[0]
+    frontier = [(0, root, 0)]
+    while frontier:
+        nxt = []
+        for (nid, d, lvl) in frontier:
+            h = int(hash32(np.array([nid * 31 + seed], np.uint64))[0])
+            kk = k if not ragged else 2 + h % (k - 1)
+            base = np.repeat(d[None, :], kk, 0) if nid else descriptors(kk, seed + 1)
+            kids = _flip_bits(base, seed + 13 * nid + 1, 0.12) if nid else base
+            for c in range(kk):
+                cid = len(parent)
+                is_leaf = (lvl + 1 == L) or (ragged and cid % 7 == 3)
+                parent.append(nid); leaf.append(int(is_leaf)); desc.append(kids[c])
+                wv = 0.5 + (int(hash32(np.array([cid + 977 * seed], np.uint64))[0]) % 100000) / 12345.0
+                weight.append(wv if is_leaf else 0.0)
+                if not is_leaf:
+                    nxt.append((cid, kids[c], lvl + 1))
+        frontier = nxt
+    weight = np.array(weight, np.float64); leaf = np.array(leaf, np.uint8)
+    if stop_every:
+        words = np.flatnonzero(leaf)
+        weight[words[::stop_every]] = 0.0
+    return dict(parent=np.array(parent, np.int32), is_leaf=leaf, desc=np.stack(desc).astype(np.uint8), weight=weight, k=k, L=L)
+
+
+def vocabulary_words(voc, n, seed=3, flip_p=0.05):
+    """n feature descriptors near random words of the vocabulary (so that descents reach varied leaves)."""
+    words = np.flatnonzero(voc["is_leaf"])
+    pick = words[hash32(np.arange(n, dtype=np.uint64) + np.uint64(seed * 1013)) % np.uint32(len(words))]
+    return _flip_bits(voc["desc"][pick].copy(), seed + 5, flip_p)
+
+
+def write_vocabulary_text(voc, path, trailing_blank=True):
+    """The text format TemplatedVocabulary::saveToTextFile writes / loadFromTextFile reads."""
+    with open(path, "w") as f:
+        f.write("%d %d  0 0\n" % (voc["k"], voc["L"]))
+        for i in range(1, len(voc["parent"])):
+            f.write("%d %d %s %r\n" % (voc["parent"][i], voc["is_leaf"][i], " ".join(str(int(b)) for b in voc["desc"][i]), float(voc["weight"][i])))
+        if trailing_blank:
+            f.write("\n")

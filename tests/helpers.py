@@ -60,3 +60,32 @@ def make_queries(fr, nq, seed=5, th=15.0, scale_factor=1.2, nlevels=8, dup_prob=
         q["desc"][i] = base_desc[i] if use_dup[i] else pert[i]
     q["angle"] = np.mod(q["angle"], 360).astype(np.float32)
     return q
+
+
+def make_bow_pair(voc, ovoc, n_a, n_b, seed=1, levelsup=2, n_cams=2, nlevels=8, flag_p=0.8, stereo_p=0.5):
+    """Two synthetic keyframes for the BoW searches: B holds perturbed copies of many of A's descriptors (so that node-local
+    nearest neighbours exist, some of them contested), angles of true pairs differ by a common rotation + jitter.
+    ovoc: an object with bow_vectors(features, levelsup) -> (_, (node_id, node_start, items)).  -> (side_a, side_b) dicts."""
+    from multi_orb_slam_amd import synth
+    da = synth.vocabulary_words(voc, n_a, seed)
+    src = rand_u32(n_b, seed + 1) % np.uint32(max(n_a, 1))
+    db = synth._flip_bits(da[src], seed + 2, 0.04) if n_a else synth.vocabulary_words(voc, n_b, seed + 9)
+    fresh = rand_unit(n_b, seed + 3) < 0.25
+    db[fresh] = synth.vocabulary_words(voc, int(fresh.sum()), seed + 4)
+    ang_a = (rand_unit(n_a, seed + 5) * 360.0).astype(np.float32)
+    jitter = (rand_unit(n_b, seed + 6) - 0.5) * 20.0
+    wild = rand_unit(n_b, seed + 7) < 0.15
+    ang_b = np.mod(ang_a[src].astype(np.float64) - 40.0 + jitter + wild * rand_unit(n_b, seed + 8) * 360.0, 360.0).astype(np.float32)
+
+    def side(desc, ang, n, s):
+        (_, (nid, nstart, items)) = ovoc.bow_vectors(desc, levelsup)
+        fl = (rand_unit(n, s) < flag_p).astype(np.uint8) | ((rand_unit(n, s + 1) < stereo_p).astype(np.uint8) << 1)
+        return dict(desc=desc, angle=ang, flags=fl, node_id=nid, node_start=nstart, items=items,
+                    x=(rand_unit(n, s + 2) * 640).astype(np.float32), y=(rand_unit(n, s + 3) * 480).astype(np.float32),
+                    octave=(rand_u32(n, s + 4) % np.uint32(nlevels)).astype(np.int32),
+                    cam_of=(rand_u32(n, s + 5) % np.uint32(n_cams)).astype(np.int32))
+    sa, sb = side(da, ang_a, n_a, seed + 20), side(db, ang_b, n_b, seed + 40)
+    if n_a:   # true pairs lie on (nearly) the same image row, 25 px apart: consistent with a sideways-translation F12
+        sb["x"] = (sa["x"][src] + 25.0).astype(np.float32)
+        sb["y"] = (sa["y"][src] + (rand_u32(n_b, seed + 60) % np.uint32(7)).astype(np.float32) - 3.0).astype(np.float32)
+    return sa, sb

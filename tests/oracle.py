@@ -64,6 +64,15 @@ def lib():
                                                          C.c_void_p]
         _lib.orc_search_by_projection_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
                                                          C.c_int, C.c_void_p]
+        _lib.orc_vocab_create.restype = C.c_void_p
+        _lib.orc_vocab_create.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4
+        _lib.orc_vocab_destroy.argtypes = [C.c_void_p]
+        _lib.orc_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_bow_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
+        _lib.orc_bow_score_l1.restype = C.c_double
+        _lib.orc_bow_score_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.orc_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        _lib.orc_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     return _lib
 
 
@@ -312,3 +321,79 @@ def search_by_projection_points(frame, queries, occupied=None, nnratio=0.8, th_h
     n = lib().orc_search_by_projection_points(frame.ptr(), _p(queries), len(queries),
                                               None if occ is None else _p(occ), nnratio, th_high, _p(m))
     return n, m[:frame.n_total]
+
+
+# ---------------------------------------------------------------------------------------------- vocabulary / BoW searches
+class Vocabulary:
+    def __init__(self, voc):
+        self._keep = [np.ascontiguousarray(voc["parent"], np.int32), np.ascontiguousarray(voc["is_leaf"], np.uint8),
+                      np.ascontiguousarray(voc["desc"], np.uint8), np.ascontiguousarray(voc["weight"], np.float64)]
+        self._h = lib().orc_vocab_create(len(self._keep[0]), int(voc["L"]), *[_p(a) for a in self._keep])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_vocab_destroy(self._h); self._h = None
+
+    def transform(self, features, levelsup=4):
+        f = _u8(features).reshape(-1, 32); n = len(f)
+        w, nd, wt = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.float64)
+        lib().orc_bow_transform(self._h, _p(f), n, levelsup, _p(w), _p(nd), _p(wt))
+        return w, nd, wt
+
+    def bow_vectors(self, features, levelsup=4):
+        """-> ((word ids, values), (node ids, node_start, items))"""
+        f = _u8(features).reshape(-1, 32); n = len(f)
+        bid, bval = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
+        fn, fs, fi = np.zeros(max(n, 1), np.uint32), np.zeros(n + 1, np.int32), np.zeros(max(n, 1), np.uint32)
+        nn = C.c_int()
+        nw = lib().orc_bow_vectors(self._h, _p(f), n, levelsup, _p(bid), _p(bval), _p(fn), _p(fs), _p(fi), C.byref(nn))
+        return (bid[:nw].copy(), bval[:nw].copy()), (fn[:nn.value].copy(), fs[:nn.value + 1].copy(), fi[:fs[nn.value]].copy())
+
+
+def bow_score_l1(a, b):
+    ia, va = np.ascontiguousarray(a[0], np.uint32), np.ascontiguousarray(a[1], np.float64)
+    ib, vb = np.ascontiguousarray(b[0], np.uint32), np.ascontiguousarray(b[1], np.float64)
+    return lib().orc_bow_score_l1(_p(ia), _p(va), len(ia), _p(ib), _p(vb), len(ib))
+
+
+class BowSideC(C.Structure):
+    _fields_ = [("n", C.c_int), ("desc", C.c_void_p), ("angle", C.c_void_p), ("flags", C.c_void_p), ("n_nodes", C.c_int),
+                ("node_id", C.c_void_p), ("node_start", C.c_void_p), ("items", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
+                ("octave", C.c_void_p), ("cam_of", C.c_void_p)]
+
+
+class TriangulationC(C.Structure):
+    _fields_ = [("n_cams", C.c_int), ("n_levels", C.c_int), ("F12", C.c_void_p), ("ex", C.c_void_p), ("ey", C.c_void_p),
+                ("scale_factors", C.c_void_p), ("level_sigma2", C.c_void_p)]
+
+
+def _bow_side(s):
+    """s: dict(desc, angle, flags, node_id, node_start, items[, x, y, octave, cam_of]) -> (struct, keepalive)"""
+    keep = dict(desc=_u8(s["desc"]).reshape(-1, 32), angle=np.ascontiguousarray(s["angle"], np.float32),
+                flags=np.ascontiguousarray(s["flags"], np.uint8), node_id=np.ascontiguousarray(s["node_id"], np.uint32),
+                node_start=np.ascontiguousarray(s["node_start"], np.int32), items=np.ascontiguousarray(s["items"], np.uint32))
+    for k, dt in (("x", np.float32), ("y", np.float32), ("octave", np.int32), ("cam_of", np.int32)):
+        keep[k] = np.ascontiguousarray(s[k], dt) if s.get(k) is not None else None
+    g = lambda k: keep[k].ctypes.data if keep[k] is not None else None
+    st = BowSideC(len(keep["desc"]), g("desc"), g("angle"), g("flags"), len(keep["node_id"]), g("node_id"), g("node_start"), g("items"),
+                  g("x"), g("y"), g("octave"), g("cam_of"))
+    return st, keep
+
+
+def search_by_bow(a, b, mode, th_low=50, nnratio=0.7, check_ori=True):
+    sa, ka = _bow_side(a); sb, kb = _bow_side(b)
+    n_out = sb.n if mode == 0 else sa.n
+    match = np.full(max(n_out, 1), -1, np.int32)
+    nm = lib().orc_search_by_bow(C.byref(sa), C.byref(sb), mode, th_low, nnratio, int(check_ori), _p(match))
+    return nm, match[:n_out]
+
+
+def search_for_triangulation(a, b, F12, ex, ey, scale_factors, level_sigma2, th_low=50, check_ori=True):
+    sa, ka = _bow_side(a); sb, kb = _bow_side(b)
+    F = np.ascontiguousarray(F12, np.float32).reshape(-1, 9)
+    exa, eya = np.ascontiguousarray(ex, np.float32), np.ascontiguousarray(ey, np.float32)
+    sf, s2 = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(level_sigma2, np.float32)
+    T = TriangulationC(len(F), len(sf), F.ctypes.data, exa.ctypes.data, eya.ctypes.data, sf.ctypes.data, s2.ctypes.data)
+    match = np.full(max(sa.n, 1), -1, np.int32)
+    nm = lib().orc_search_for_triangulation(C.byref(sa), C.byref(sb), C.byref(T), th_low, int(check_ori), _p(match))
+    return nm, match[:sa.n]

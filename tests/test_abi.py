@@ -12,14 +12,14 @@ def declared_functions():
     names = []
     for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
         src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
-        names += re.findall(r"\b(orb[xm]?_[a-z0-9_]+)\s*\(", src)
+        names += re.findall(r"\b(orb[xmfv]?_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))
 
 
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(m.LIB_PATH)
     fns = declared_functions()
-    assert len(fns) >= 30
+    assert len(fns) >= 80
     for f in fns:
         assert hasattr(lib, f), f
 
