@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "../../include/orbm.h"
+#include "../../include/orbv.h"
 
 namespace ORB_SLAM2 {
 
@@ -23,7 +24,24 @@ ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbChe
     mtcam21 = cv::Mat(3, 1, CV_32F);
 }
 
-ORBmatcher::~ORBmatcher() { orbm_destroy(handle_); }
+ORBmatcher::~ORBmatcher() { orbm_destroy(handle_); orbv_workspace_destroy(bow_); }
+
+orbv_workspace* ORBmatcher::Bow() {
+    if (!bow_) {
+        const char* dev = std::getenv("MORB_DEVICE");
+        int rc = orbv_workspace_create(dev ? std::atoi(dev) : 0, &bow_);
+        if (rc) die("orbv_workspace_create", rc);
+    }
+    return bow_;
+}
+
+cv::Mat ORBmatcher::SkewSymmetricMatrix(const cv::Mat& v) {  // reference :4012-4017
+    cv::Mat m = cv::Mat::zeros(3, 3, CV_32F);
+    m.at<float>(0, 1) = -v.at<float>(2); m.at<float>(0, 2) = v.at<float>(1);
+    m.at<float>(1, 0) = v.at<float>(2);  m.at<float>(1, 2) = -v.at<float>(0);
+    m.at<float>(2, 0) = -v.at<float>(1); m.at<float>(2, 1) = v.at<float>(0);
+    return m;
+}
 
 orbm_matcher* ORBmatcher::Handle() {
     if (!handle_) {
@@ -80,7 +98,120 @@ void flatten(const Frame& F, bool cam1_only, FlatFrame& ff) {
     ff.d.min_x = F.mnMinX; ff.d.min_y = F.mnMinY; ff.d.max_x = F.mnMaxX; ff.d.max_y = F.mnMaxY;
 }
 
+struct FlatSide {  // orbv_side backing store built from a Frame / KeyFrame
+    std::vector<uint8_t> desc, flags;
+    std::vector<float> ang, x, y;
+    std::vector<int32_t> oct, cam, nstart;
+    std::vector<uint32_t> nid, items;
+    orbv_side s;
+};
+
+template <class F>   // Frame or KeyFrame: same member names
+void flatten_side(const F& f, const std::vector<cv::KeyPoint>& keys, const DBoW2::FeatureVector& fv, int n, FlatSide& o) {
+    o.desc.resize((size_t)n * 32); o.flags.assign(n, 0); o.ang.resize(n); o.x.resize(n); o.y.resize(n); o.oct.resize(n); o.cam.resize(n);
+    for (int g = 0; g < n; ++g) {
+        const int cam = f.keypoint_to_cam.find(g)->second, loc = f.cont_idx_to_local_cam_idx.find(g)->second;
+        std::memcpy(&o.desc[(size_t)g * 32], f.mDescriptors_total[cam].ptr(loc), 32);
+        o.ang[g] = keys[g].angle; o.x[g] = keys[g].pt.x; o.y[g] = keys[g].pt.y; o.oct[g] = keys[g].octave; o.cam[g] = cam;
+    }
+    o.nid.clear(); o.nstart.assign(1, 0); o.items.clear();
+    for (const auto& e : fv) {
+        o.nid.push_back(e.first);
+        o.items.insert(o.items.end(), e.second.begin(), e.second.end());
+        o.nstart.push_back((int32_t)o.items.size());
+    }
+    o.s.n = n; o.s.desc = o.desc.data(); o.s.angle = o.ang.data(); o.s.flags = o.flags.data();
+    o.s.n_nodes = (int)o.nid.size(); o.s.node_id = o.nid.data(); o.s.node_start = o.nstart.data(); o.s.items = o.items.data();
+    o.s.x = o.x.data(); o.s.y = o.y.data(); o.s.octave = o.oct.data(); o.s.cam_of = o.cam.data();
+}
+
 }  // namespace
+
+// reference src/ORBmatcher.cc:206-388
+int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
+    const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPoint*>(F.N_total, static_cast<MapPoint*>(NULL));
+    FlatSide a, b;
+    flatten_side(*pKF, pKF->mvKeysUn_total, pKF->mFeatVec, (int)vpMapPointsKF.size(), a);
+    flatten_side(F, F.mvKeys_total, F.mFeatVec, F.N_total, b);
+    for (size_t i = 0; i < vpMapPointsKF.size(); ++i) a.flags[i] = (vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad()) ? 1 : 0;   // :259-264
+    b.s.flags = nullptr;
+    std::vector<int32_t> match(F.N_total > 0 ? F.N_total : 1);
+    int nmatches = 0;
+    const int rc = orbv_search_by_bow(Bow(), &a.s, &b.s, 0, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
+    if (rc) die("orbv_search_by_bow", rc);
+    for (int g = 0; g < F.N_total; ++g)
+        if (match[g] >= 0) vpMapPointMatches[g] = vpMapPointsKF[match[g]];
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:996-1165
+int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) {
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(NULL));
+    FlatSide a, b;
+    flatten_side(*pKF1, pKF1->mvKeysUn_total, pKF1->mFeatVec, (int)vpMapPoints1.size(), a);
+    flatten_side(*pKF2, pKF2->mvKeysUn_total, pKF2->mFeatVec, (int)vpMapPoints2.size(), b);
+    for (size_t i = 0; i < vpMapPoints1.size(); ++i) a.flags[i] = (vpMapPoints1[i] && !vpMapPoints1[i]->isBad()) ? 1 : 0;   // :1050-1055
+    for (size_t i = 0; i < vpMapPoints2.size(); ++i) b.flags[i] = (vpMapPoints2[i] && !vpMapPoints2[i]->isBad()) ? 1 : 0;   // :1077-1084
+    std::vector<int32_t> match(vpMapPoints1.empty() ? 1 : vpMapPoints1.size());
+    int nmatches = 0;
+    const int rc = orbv_search_by_bow(Bow(), &a.s, &b.s, 1, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
+    if (rc) die("orbv_search_by_bow", rc);
+    for (size_t i = 0; i < vpMapPoints1.size(); ++i)
+        if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]];
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:1364-1786.  As there, the F12 argument is not read: one fundamental matrix per camera of
+// the rig is recomputed from the keyframe poses (:1375-1423).
+int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                                       const bool bOnlyStereo, std::vector<bool> vbCam) {
+    cv::Mat R1w[2] = {pKF1->GetRotation(), pKF1->GetRotation_cam2()}, t1w[2] = {pKF1->GetTranslation(), pKF1->GetTranslation_cam2()};
+    cv::Mat R2w[2] = {pKF2->GetRotation(), pKF2->GetRotation_cam2()}, t2w[2] = {pKF2->GetTranslation(), pKF2->GetTranslation_cam2()};
+    cv::Mat Cw[2] = {pKF1->GetCameraCenter(), pKF1->GetCameraCenter_cam2()};
+    const cv::Mat& K1 = pKF1->mK;
+    const cv::Mat& K2 = pKF2->mK;
+    orbv_triangulation T;
+    std::memset(&T, 0, sizeof(T));
+    T.n_cams = 2; T.n_levels = (int)pKF2->mvScaleFactors.size();
+    T.scale_factors = pKF2->mvScaleFactors.data(); T.level_sigma2 = pKF2->mvLevelSigma2.data();
+    for (int i = 0; i < 2; ++i) {
+        const cv::Mat R12 = R1w[i] * R2w[i].t();
+        const cv::Mat t12 = -R1w[i] * R2w[i].t() * t2w[i] + t1w[i];
+        const cv::Mat t12x = SkewSymmetricMatrix(t12);
+        const cv::Mat F = K1.t().inv() * t12x * R12 * K2.inv();
+        for (int k = 0; k < 9; ++k) T.F12[i][k] = F.at<float>(k / 3, k % 3);
+        const cv::Mat C2 = R2w[i] * Cw[i] + t2w[i];                 // :1441-1452
+        const float invz = 1.0f / C2.at<float>(2);
+        T.ex[i] = pKF2->fx * C2.at<float>(0) * invz + pKF2->cx;
+        T.ey[i] = pKF2->fy * C2.at<float>(1) * invz + pKF2->cy;
+    }
+    const int n1 = (int)pKF1->mvKeysUn_total.size(), n2 = (int)pKF2->mvKeysUn_total.size();
+    FlatSide a, b;
+    flatten_side(*pKF1, pKF1->mvKeysUn_total, pKF1->mFeatVec, n1, a);
+    flatten_side(*pKF2, pKF2->mvKeysUn_total, pKF2->mFeatVec, n2, b);
+    for (int i = 0; i < n1; ++i) {
+        const bool stereo = pKF1->mvuRight_total[i] >= 0;
+        const bool usable = !pKF1->GetMapPoint(i) && vbCam[a.cam[i]] && (!bOnlyStereo || stereo);   // :1490-1505
+        a.flags[i] = (usable ? 1 : 0) | (stereo ? 2 : 0);
+    }
+    for (int i = 0; i < n2; ++i) {
+        const bool stereo = pKF2->mvuRight_total[i] >= 0;
+        const bool usable = !pKF2->GetMapPoint(i) && (!bOnlyStereo || stereo);                        // :1548-1575
+        b.flags[i] = (usable ? 1 : 0) | (stereo ? 2 : 0);
+    }
+    std::vector<int32_t> match(n1 > 0 ? n1 : 1);
+    int nmatches = 0;
+    const int rc = orbv_search_for_triangulation(Bow(), &a.s, &b.s, &T, TH_LOW, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
+    if (rc) die("orbv_search_for_triangulation", rc);
+    vMatchedPairs.clear();
+    vMatchedPairs.reserve(nmatches);
+    for (int i = 0; i < n1; ++i)
+        if (match[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match[i]));
+    return nmatches;
+}
 
 // reference src/ORBmatcher.cc:62-149
 int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th) {

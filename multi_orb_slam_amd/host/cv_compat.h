@@ -67,6 +67,29 @@ public:
         for (int r = 0; r < rows; ++r) std::memcpy(m.ptr(r), ptr(r), (size_t)cols * elemSize());
         return m;
     }
+    // 3x3 CV_32F inverse the way cv::invert(DECOMP_LU) special-cases it: determinant and cofactors in double, one rounding
+    // to float per element (modules/core/src/lapack.cpp); a singular matrix gives zeros.
+    Mat inv() const {
+        assert(type_ == CV_32F && rows == 3 && cols == 3);
+        const Mat& S = *this;
+        auto m = [&](int r, int c) { return (double)S.at<float>(r, c); };
+        double d = m(0, 0) * (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) - m(0, 1) * (m(1, 0) * m(2, 2) - m(1, 2) * m(2, 0)) +
+                   m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
+        Mat D = zeros(3, 3, CV_32F);
+        if (d != 0.) {
+            d = 1. / d;
+            D.at<float>(0, 0) = (float)((m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) * d);
+            D.at<float>(0, 1) = (float)((m(0, 2) * m(2, 1) - m(0, 1) * m(2, 2)) * d);
+            D.at<float>(0, 2) = (float)((m(0, 1) * m(1, 2) - m(0, 2) * m(1, 1)) * d);
+            D.at<float>(1, 0) = (float)((m(1, 2) * m(2, 0) - m(1, 0) * m(2, 2)) * d);
+            D.at<float>(1, 1) = (float)((m(0, 0) * m(2, 2) - m(0, 2) * m(2, 0)) * d);
+            D.at<float>(1, 2) = (float)((m(0, 2) * m(1, 0) - m(0, 0) * m(1, 2)) * d);
+            D.at<float>(2, 0) = (float)((m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0)) * d);
+            D.at<float>(2, 1) = (float)((m(0, 1) * m(2, 0) - m(0, 0) * m(2, 1)) * d);
+            D.at<float>(2, 2) = (float)((m(0, 0) * m(1, 1) - m(0, 1) * m(1, 0)) * d);
+        }
+        return D;
+    }
     Mat t() const {
         assert(type_ == CV_32F);
         Mat m(cols, rows, CV_32F);

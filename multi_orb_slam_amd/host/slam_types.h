@@ -8,6 +8,7 @@
 #include <map>
 #include <vector>
 #include "cv_compat.h"
+#include "ORBVocabulary.h"
 
 #define FRAME_GRID_ROWS 48
 #define FRAME_GRID_COLS 64
@@ -47,10 +48,40 @@ public:
     cv::Mat mTcw;  // 4x4 CV_32F
     float fx = 0, fy = 0, cx = 0, cy = 0, mb = 0, mbf = 0;
     float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;  // static members in the reference
+    DBoW2::BowVector mBowVec;       // all cameras (include/Frame.h:185-187)
+    DBoW2::FeatureVector mFeatVec;
+};
+
+// KeyFrame members the BoW-gated searches read (include/KeyFrame.h:53-59, :104-113, :218-219 and the Frame copies of
+// src/KeyFrame.cc:31-80).  Poses are world -> camera, one per camera of the rig.
+class KeyFrame {
+public:
+    std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+    MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+    cv::Mat GetDescriptor(const int& cam, const size_t& idx) const { return mDescriptors_total[cam].row((int)idx); }
+    cv::Mat GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }
+    cv::Mat GetTranslation() { return Tcw.rowRange(0, 3).col(3).clone(); }
+    cv::Mat GetRotation_cam2() { return Tcw_cam2.rowRange(0, 3).colRange(0, 3).clone(); }
+    cv::Mat GetTranslation_cam2() { return Tcw_cam2.rowRange(0, 3).col(3).clone(); }
+    cv::Mat GetCameraCenter() { return -(GetRotation().t() * GetTranslation()); }
+    cv::Mat GetCameraCenter_cam2() { return -(GetRotation_cam2().t() * GetTranslation_cam2()); }
+
+    std::vector<cv::KeyPoint> mvKeysUn_total;
+    std::vector<float> mvuRight_total;
+    std::vector<cv::Mat> mDescriptors_total;
+    std::map<size_t, int> keypoint_to_cam, cont_idx_to_local_cam_idx;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<float> mvScaleFactors, mvLevelSigma2;
+    DBoW2::BowVector mBowVec;
+    DBoW2::FeatureVector mFeatVec;
+    cv::Mat mK;                      // 3x3 CV_32F
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+    cv::Mat Tcw, Tcw_cam2;           // 4x4 CV_32F
 };
 
 }  // namespace ORB_SLAM2
 #else
 #include "Frame.h"
+#include "KeyFrame.h"
 #include "MapPoint.h"
 #endif

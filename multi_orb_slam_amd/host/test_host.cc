@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 #include "ORBextractor.h"
@@ -173,12 +174,122 @@ static int run_match(int argc, char** argv) {
     return 0;
 }
 
+// One keyframe / frame of a bow case: N, N_cam2, x y angle uright (f32 each), octave (i32), descriptors cam 0 then cam 1,
+// has-MapPoint and bad flags (u8 each), Tcw and Tcw_cam2 (16 f32 each).
+struct BowEntity {
+    int N = 0, N2 = 0, n = 0;
+    std::vector<cv::KeyPoint> keys;
+    std::vector<float> ur;
+    std::vector<cv::Mat> desc;
+    std::vector<unsigned char> has, bad;
+    cv::Mat Tcw, Tcw2;
+    std::vector<MapPoint> pool;
+    std::vector<MapPoint*> mps;
+    std::map<size_t, int> to_cam, to_local;
+};
+
+static void read_entity(Reader& R, BowEntity& E) {
+    E.N = R.get<int>(); E.N2 = R.get<int>(); E.n = E.N + E.N2;
+    const int n = E.n;
+    std::vector<float> x = R.arr<float>(n), y = R.arr<float>(n), ang = R.arr<float>(n);
+    E.ur = R.arr<float>(n);
+    std::vector<int> oct = R.arr<int>(n);
+    E.keys.resize(n);
+    for (int g = 0; g < n; ++g) {
+        E.keys[g].pt.x = x[g]; E.keys[g].pt.y = y[g]; E.keys[g].angle = ang[g]; E.keys[g].octave = oct[g];
+        E.to_cam[g] = g < E.N ? 0 : 1; E.to_local[g] = g < E.N ? g : g - E.N;
+    }
+    E.desc.resize(2);
+    for (int c = 0; c < 2; ++c) {
+        const int nc = c == 0 ? E.N : E.N2;
+        E.desc[c].create(nc > 0 ? nc : 1, 32, CV_8U);
+        std::vector<unsigned char> d = R.arr<unsigned char>((size_t)nc * 32);
+        if (nc) std::memcpy(E.desc[c].ptr(0), d.data(), d.size());
+    }
+    E.has = R.arr<unsigned char>(n); E.bad = R.arr<unsigned char>(n);
+    E.pool.resize(n); E.mps.assign(n, nullptr);
+    for (int g = 0; g < n; ++g) { E.pool[g].mbBad = E.bad[g] != 0; if (E.has[g]) E.mps[g] = &E.pool[g]; }
+    E.Tcw = cv::Mat(4, 4, CV_32F); E.Tcw2 = cv::Mat(4, 4, CV_32F);
+    std::vector<float> T = R.arr<float>(16), T2 = R.arr<float>(16);
+    for (int i = 0; i < 16; ++i) { E.Tcw.at<float>(i / 4, i % 4) = T[i]; E.Tcw2.at<float>(i / 4, i % 4) = T2[i]; }
+}
+
+static std::vector<cv::Mat> rows_of(const BowEntity& E) {  // Converter::toDescriptorVector(mDescriptors_total)
+    std::vector<cv::Mat> v;
+    for (int g = 0; g < E.n; ++g) v.push_back(E.desc[g < E.N ? 0 : 1].row(g < E.N ? g : g - E.N));
+    return v;
+}
+
+// bow <case.bin> <out.bin>: [vocabulary arrays][levelsup][KF1][KF2][F][fx fy cx cy][scale 8][sigma2 8][nnratio][check_ori]
+//                           [bOnlyStereo][vbCam0][vbCam1]
+static int run_bow(int argc, char** argv) {
+    std::vector<unsigned char> buf = slurp(argv[2]);
+    Reader R{buf.data()};
+    const int n_nodes = R.get<int>(), L = R.get<int>();
+    std::vector<int> parent = R.arr<int>(n_nodes);
+    std::vector<unsigned char> leaf = R.arr<unsigned char>(n_nodes), vdesc = R.arr<unsigned char>((size_t)n_nodes * 32);
+    std::vector<double> weight = R.arr<double>(n_nodes);
+    const int levelsup = R.get<int>();
+    ORBVocabulary voc;
+    if (!voc.empty()) return 3;
+    if (!voc.create(n_nodes, L, parent.data(), leaf.data(), vdesc.data(), weight.data())) return 4;
+    BowEntity E1, E2, EF;
+    read_entity(R, E1); read_entity(R, E2); read_entity(R, EF);
+    const float fx = R.get<float>(), fy = R.get<float>(), cx = R.get<float>(), cy = R.get<float>();
+    std::vector<float> scale = R.arr<float>(8), sigma2 = R.arr<float>(8);
+    const float nnratio = R.get<float>();
+    const int check_ori = R.get<int>(), only_stereo = R.get<int>(), cam0 = R.get<int>(), cam1 = R.get<int>();
+
+    KeyFrame K1, K2; Frame F;
+    BowEntity* Es[2] = {&E1, &E2}; KeyFrame* Ks[2] = {&K1, &K2};
+    for (int k = 0; k < 2; ++k) {
+        KeyFrame& K = *Ks[k]; BowEntity& E = *Es[k];
+        K.mvKeysUn_total = E.keys; K.mvuRight_total = E.ur; K.mDescriptors_total = E.desc; K.keypoint_to_cam = E.to_cam;
+        K.cont_idx_to_local_cam_idx = E.to_local; K.mvpMapPoints = E.mps; K.mvScaleFactors = scale; K.mvLevelSigma2 = sigma2;
+        K.mK = cv::Mat::eye(3, 3, CV_32F);
+        K.mK.at<float>(0, 0) = fx; K.mK.at<float>(1, 1) = fy; K.mK.at<float>(0, 2) = cx; K.mK.at<float>(1, 2) = cy;
+        K.fx = fx; K.fy = fy; K.cx = cx; K.cy = cy; K.Tcw = E.Tcw; K.Tcw_cam2 = E.Tcw2;
+        voc.transform(rows_of(E), K.mBowVec, K.mFeatVec, levelsup);     // KeyFrame::ComputeBoW
+    }
+    F.N = EF.N; F.N_cam2 = EF.N2; F.N_total = EF.n; F.mvKeys_total = EF.keys; F.mvKeysUn_total = EF.keys; F.mDescriptors_total = EF.desc;
+    F.keypoint_to_cam = EF.to_cam; F.cont_idx_to_local_cam_idx = EF.to_local;
+    voc.transform(rows_of(EF), F.mBowVec, F.mFeatVec, levelsup);         // Frame::ComputeBoW, src/Frame.cc:649-659
+
+    FILE* f = std::fopen(argv[3], "wb");
+    int nw = (int)K1.mBowVec.size(); put(f, &nw, 4);
+    for (const auto& e : K1.mBowVec) { put(f, &e.first, 4); put(f, &e.second, 8); }
+    int nn = (int)K1.mFeatVec.size(); put(f, &nn, 4);
+    for (const auto& e : K1.mFeatVec) { int c = (int)e.second.size(); put(f, &e.first, 4); put(f, &c, 4); put(f, e.second.data(), (size_t)c * 4); }
+    const double s12 = voc.score(K1.mBowVec, K2.mBowVec), s11 = voc.score(K1.mBowVec, K1.mBowVec);
+    put(f, &s12, 8); put(f, &s11, 8);
+    unsigned int words = voc.size(); put(f, &words, 4);
+
+    ORBmatcher m1(nnratio, check_ori != 0);
+    std::vector<MapPoint*> vF;
+    const int na = m1.SearchByBoW(&K1, F, vF);
+    put(f, &na, 4);
+    for (int g = 0; g < F.N_total; ++g) { int idx = vF[g] ? (int)(vF[g] - E1.pool.data()) : -1; put(f, &idx, 4); }
+    std::vector<MapPoint*> v12;
+    const int nb = m1.SearchByBoW(&K1, &K2, v12);
+    put(f, &nb, 4);
+    for (int g = 0; g < E1.n; ++g) { int idx = v12[g] ? (int)(v12[g] - E2.pool.data()) : -1; put(f, &idx, 4); }
+    std::vector<std::pair<size_t, size_t> > pairs;
+    std::vector<bool> vbCam = {cam0 != 0, cam1 != 0};
+    const int nc = m1.SearchForTriangulation(&K1, &K2, cv::Mat(), pairs, only_stereo != 0, vbCam);
+    int np = (int)pairs.size();
+    put(f, &nc, 4); put(f, &np, 4);
+    for (const auto& pr : pairs) { int a = (int)pr.first, b = (int)pr.second; put(f, &a, 4); put(f, &b, 4); }
+    std::fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: test_host extract|batch|match ...\n"); return 1; }
+    if (argc < 2) { std::fprintf(stderr, "usage: test_host extract|batch|match|bow ...\n"); return 1; }
     const std::string mode = argv[1];
     if (mode == "extract" && argc >= 7) return run_extract(argc, argv);
     if (mode == "batch" && argc >= 9) return run_batch(argc, argv);
     if (mode == "match" && argc >= 4) return run_match(argc, argv);
+    if (mode == "bow" && argc >= 4) return run_bow(argc, argv);
     std::fprintf(stderr, "bad arguments\n");
     return 1;
 }

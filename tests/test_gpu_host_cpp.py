@@ -25,6 +25,11 @@ def test_host_library_exports_reference_signatures():
                  "ORB_SLAM2::ORBmatcher::DescriptorDistance(cv::Mat const&, cv::Mat const&)",
                  "ORB_SLAM2::ORBmatcher::SearchByProjection(ORB_SLAM2::Frame&, std::vector<ORB_SLAM2::MapPoint*",
                  "ORB_SLAM2::ORBmatcher::SearchByProjection(ORB_SLAM2::Frame&, ORB_SLAM2::Frame const&, float, bool, cv::Mat)",
+                 "ORB_SLAM2::ORBmatcher::SearchByBoW(ORB_SLAM2::KeyFrame*, ORB_SLAM2::Frame&, std::vector<ORB_SLAM2::MapPoint*",
+                 "ORB_SLAM2::ORBmatcher::SearchByBoW(ORB_SLAM2::KeyFrame*, ORB_SLAM2::KeyFrame*, std::vector<ORB_SLAM2::MapPoint*",
+                 "ORB_SLAM2::ORBmatcher::SearchForTriangulation(ORB_SLAM2::KeyFrame*, ORB_SLAM2::KeyFrame*, cv::Mat, std::vector<std::pair<unsigned long, unsigned long>",
+                 "ORB_SLAM2::ORBVocabulary::loadFromTextFile(std::", "ORB_SLAM2::ORBVocabulary::transform(std::vector<cv::Mat",
+                 "ORB_SLAM2::ORBVocabulary::score(DBoW2::BowVector const&, DBoW2::BowVector const&)",
                  "ORB_SLAM2::ORBmatcher::TH_HIGH", "ORB_SLAM2::ORBmatcher::TH_LOW", "ORB_SLAM2::ORBmatcher::HISTO_LENGTH"):
         assert want in syms, want
 
@@ -189,3 +194,115 @@ def test_cpp_orbmatcher_search_by_projection_overloads(tmp_path, check_ori):
     assert got_n2 == en2 and np.array_equal(got_m2, exp2)
     assert got_n2 > 50
     assert got_dd == oracle.descriptor_distance(cur["descs"][0][0], cur["descs"][0][1])
+
+
+def _mm(a, b):
+    """cv::Mat product of the host compat layer: double accumulation in index order, one rounding to float per element."""
+    out = np.zeros((a.shape[0], b.shape[1]), np.float32)
+    for i in range(a.shape[0]):
+        for j in range(b.shape[1]):
+            s = 0.0
+            for k in range(a.shape[1]):
+                s += float(a[i, k]) * float(b[k, j])
+            out[i, j] = f32(s)
+    return out
+
+
+def _inv3(m):
+    """cv::invert of a 3x3 CV_32F matrix: cofactors and determinant in double."""
+    g = lambda r, c: float(m[r, c])
+    d = g(0, 0) * (g(1, 1) * g(2, 2) - g(1, 2) * g(2, 1)) - g(0, 1) * (g(1, 0) * g(2, 2) - g(1, 2) * g(2, 0)) + g(0, 2) * (g(1, 0) * g(2, 1) - g(1, 1) * g(2, 0))
+    d = 1.0 / d
+    e = [[(g(1, 1) * g(2, 2) - g(1, 2) * g(2, 1)) * d, (g(0, 2) * g(2, 1) - g(0, 1) * g(2, 2)) * d, (g(0, 1) * g(1, 2) - g(0, 2) * g(1, 1)) * d],
+         [(g(1, 2) * g(2, 0) - g(1, 0) * g(2, 2)) * d, (g(0, 0) * g(2, 2) - g(0, 2) * g(2, 0)) * d, (g(0, 2) * g(1, 0) - g(0, 0) * g(1, 2)) * d],
+         [(g(1, 0) * g(2, 1) - g(1, 1) * g(2, 0)) * d, (g(0, 1) * g(2, 0) - g(0, 0) * g(2, 1)) * d, (g(0, 0) * g(1, 1) - g(0, 1) * g(1, 0)) * d]]
+    return np.array(e, np.float64).astype(np.float32)
+
+
+def _entity_bytes(s, N, has, bad, Tcw, Tcw2):
+    n = len(s["desc"])
+    ur = np.where(s["flags"] & 2, f32(10.0), f32(-1.0)).astype(np.float32)
+    return (struct.pack("<ii", N, n - N) + s["x"].tobytes() + s["y"].tobytes() + s["angle"].tobytes() + ur.tobytes() +
+            s["octave"].astype(np.int32).tobytes() + s["desc"][:N].tobytes() + s["desc"][N:].tobytes() + has.tobytes() + bad.tobytes() +
+            Tcw.astype(np.float32).tobytes() + Tcw2.astype(np.float32).tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("check_ori,only_stereo,vbcam", [(1, 0, (1, 1)), (0, 1, (1, 0))])
+def test_cpp_vocabulary_and_bow_searches(tmp_path, check_ori, only_stereo, vbcam):
+    """ORBVocabulary::transform / score, both ORBmatcher::SearchByBoW overloads and SearchForTriangulation through the C++
+    classes with the reference's signatures (KeyFrame* / Frame& / std::map containers in, MapPoint* vectors out)."""
+    import oracle
+    voc = synth.vocabulary(10, 3, seed=31, stop_every=9)
+    O = oracle.Vocabulary(voc)
+    levelsup, n1, n2 = 2, 1400, 1500
+    a, b = helpers.make_bow_pair(voc, O, n1, n2, seed=12, levelsup=levelsup, stereo_p=0.4)
+    N1, N2 = 800, 900
+    a["cam_of"] = (np.arange(n1) >= N1).astype(np.int32); b["cam_of"] = (np.arange(n2) >= N2).astype(np.int32)
+    has1 = (helpers.rand_unit(n1, 301) < 0.6).astype(np.uint8); bad1 = (helpers.rand_unit(n1, 302) < 0.1).astype(np.uint8)
+    has2 = (helpers.rand_unit(n2, 303) < 0.6).astype(np.uint8); bad2 = (helpers.rand_unit(n2, 304) < 0.1).astype(np.uint8)
+    fx, fy, cx, cy = f32(520.0), f32(515.0), f32(320.5), f32(241.25)
+    scale = oracle.tables()["scale"]; sigma2 = (scale * scale).astype(np.float32)
+    T1 = np.eye(4, dtype=np.float32); T2 = np.eye(4, dtype=np.float32); T2[0, 3] = f32(-0.12); T2[1, 3] = f32(0.001); T2[2, 3] = f32(0.004)
+    c, s_ = f32(np.cos(0.01)), f32(np.sin(0.01))
+    Rz = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+    T1c = np.eye(4, dtype=np.float32); T1c[:3, :3] = Rz; T1c[:3, 3] = [0.05, 0, 0.01]
+    T2c = np.eye(4, dtype=np.float32); T2c[:3, :3] = Rz; T2c[:3, 3] = [-0.08, 0.002, 0.01]
+    blob = struct.pack("<ii", len(voc["parent"]), voc["L"]) + voc["parent"].tobytes() + voc["is_leaf"].tobytes() + voc["desc"].tobytes() + \
+        voc["weight"].tobytes() + struct.pack("<i", levelsup)
+    blob += _entity_bytes(a, N1, has1, bad1, T1, T1c) + _entity_bytes(b, N2, has2, bad2, T2, T2c) + _entity_bytes(b, N2, has2, bad2, T2, T2c)
+    nnratio = f32(0.75)
+    blob += struct.pack("<ffff", fx, fy, cx, cy) + scale.tobytes() + sigma2.tobytes() + struct.pack("<fiiii", nnratio, check_ori, only_stereo, *vbcam)
+    (tmp_path / "case.bin").write_bytes(blob)
+    subprocess.check_call([BIN, "bow", str(tmp_path / "case.bin"), str(tmp_path / "out.bin")])
+    buf = (tmp_path / "out.bin").read_bytes()
+    off = 0
+    nw = struct.unpack_from("<i", buf, off)[0]; off += 4
+    bow = np.frombuffer(buf, np.dtype([("id", "<u4"), ("v", "<f8")]), nw, off); off += 12 * nw
+    nn = struct.unpack_from("<i", buf, off)[0]; off += 4
+    fv = {}
+    for _ in range(nn):
+        nid, cnt = struct.unpack_from("<Ii", buf, off); off += 8
+        fv[nid] = np.frombuffer(buf, np.uint32, cnt, off).tolist(); off += 4 * cnt
+    s12, s11 = struct.unpack_from("<dd", buf, off); off += 16
+    words = struct.unpack_from("<I", buf, off)[0]; off += 4
+    na = struct.unpack_from("<i", buf, off)[0]; off += 4
+    mF = np.frombuffer(buf, np.int32, n2, off); off += 4 * n2
+    nb = struct.unpack_from("<i", buf, off)[0]; off += 4
+    m12 = np.frombuffer(buf, np.int32, n1, off); off += 4 * n1
+    nc, npairs = struct.unpack_from("<ii", buf, off); off += 8
+    pairs = np.frombuffer(buf, np.int32, 2 * npairs, off).reshape(-1, 2)
+
+    (oid, oval), (onid, onstart, oitems) = O.bow_vectors(a["desc"], levelsup)
+    assert words == int(voc["is_leaf"].sum())
+    assert np.array_equal(bow["id"], oid) and bow["v"].tobytes() == oval.tobytes()
+    assert fv == {int(k): oitems[onstart[i]:onstart[i + 1]].tolist() for i, k in enumerate(onid)}
+    ob = O.bow_vectors(b["desc"], levelsup)[0]
+    assert s12 == oracle.bow_score_l1((oid, oval), ob) and s11 == oracle.bow_score_l1((oid, oval), (oid, oval))
+
+    fa = dict(a, flags=(has1 & (1 - bad1)).astype(np.uint8)); fb = dict(b, flags=(has2 & (1 - bad2)).astype(np.uint8))
+    ena, emF = oracle.search_by_bow(fa, dict(b, flags=np.ones(n2, np.uint8)), 0, 50, float(nnratio), bool(check_ori))
+    assert na == ena and np.array_equal(mF, emF) and na > 50
+    enb, em12 = oracle.search_by_bow(fa, fb, 1, 50, float(nnratio), bool(check_ori))
+    assert nb == enb and np.array_equal(m12, em12) and nb > 20
+
+    # ---- SearchForTriangulation: the per-camera fundamental matrices of src/ORBmatcher.cc:1375-1423 in float32
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+    F12 = []; ex = []; ey = []
+    for (Ta, Tb) in ((T1, T2), (T1c, T2c)):
+        R1, t1, R2, t2 = Ta[:3, :3], Ta[:3, 3:4], Tb[:3, :3], Tb[:3, 3:4]
+        R12 = _mm(R1, R2.T.copy())
+        t12 = (_mm(_mm((-R1).astype(np.float32), R2.T.copy()), t2) + t1).astype(np.float32)
+        tx = np.array([[0, -t12[2, 0], t12[1, 0]], [t12[2, 0], 0, -t12[0, 0]], [-t12[1, 0], t12[0, 0], 0]], np.float32)
+        F12.append(_mm(_mm(_mm(_inv3(K.T.copy()), tx), R12), _inv3(K)).ravel())
+        Cw = (-_mm(R1.T.copy(), t1)).astype(np.float32)
+        C2 = (_mm(R2, Cw) + t2).astype(np.float32)
+        invz = f32(1.0) / C2[2, 0]
+        ex.append(f32(f32(f32(fx * C2[0, 0]) * invz) + cx)); ey.append(f32(f32(f32(fy * C2[1, 0]) * invz) + cy))
+    st1, st2 = (a["flags"] & 2) != 0, (b["flags"] & 2) != 0
+    cam_ok = np.array(vbcam, bool)[a["cam_of"]]
+    u1 = (has1 == 0) & cam_ok & (st1 | (only_stereo == 0)); u2 = (has2 == 0) & (st2 | (only_stereo == 0))
+    ta = dict(a, flags=(u1.astype(np.uint8) | (st1.astype(np.uint8) << 1))); tb = dict(b, flags=(u2.astype(np.uint8) | (st2.astype(np.uint8) << 1)))
+    enc, emt = oracle.search_for_triangulation(ta, tb, np.stack(F12), np.array(ex, np.float32), np.array(ey, np.float32), scale, sigma2, 50, bool(check_ori))
+    exp_pairs = np.stack([np.flatnonzero(emt >= 0), emt[emt >= 0]], 1)
+    assert nc == enc and np.array_equal(pairs, exp_pairs) and nc > 10
