@@ -28,7 +28,8 @@ namespace {
 
 constexpr int HISTO = 30;        // ORBmatcher::HISTO_LENGTH, src/ORBmatcher.cc:39
 constexpr int MAX_LEVELS = 32;   // pyramid levels a triangulation search may name
-constexpr int JOIN_MAX_NODE = 65536;  // candidates of one node (one LDS byte each)
+constexpr int JOIN_MAX_NODE = 32768;  // candidates of one node (one LDS byte each)
+constexpr int JOIN_LDS_BYTES = 65536; // dynamic LDS of one join workgroup: claimed bytes + staged descriptors
 
 __device__ __forceinline__ int ham256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
     return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
@@ -111,10 +112,24 @@ __device__ __forceinline__ int rot_bin(float a1, float a2) {
     return bin;
 }
 
+__device__ __forceinline__ int bcast_i(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+__device__ __forceinline__ float bcast_f(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
+__device__ __forceinline__ uint4 bcast_u4(const uint4& v, int l) {
+    return make_uint4((unsigned)bcast_i((int)v.x, l), (unsigned)bcast_i((int)v.y, l), (unsigned)bcast_i((int)v.z, l), (unsigned)bcast_i((int)v.w, l));
+}
+
 // MODE 0: SearchByBoW(KF, F); 1: SearchByBoW(KF, KF); 2: SearchForTriangulation.
+// One wavefront per node of A that B also has.  LDS: one "claimed" byte per candidate of the node, then the descriptors of
+// its first `lds_cand` candidates as two uint4 planes (conflict-free 16-byte lane stride); candidates beyond that are read
+// from HBM/L2 on every pass.  Queries are fetched 64 at a time (one per lane: index, flags, descriptor, angle, position) and
+// handed to the whole wave with readlane, so the serial query loop waits on no memory but LDS.
 template <int MODE>
-__global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T, int th_low, float nnratio, int check_ori, JoinWork W) {
-    extern __shared__ uint8_t s_claimed[];
+__global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T, int th_low, float nnratio, int check_ori, JoinWork W,
+                                                 int claimed_bytes, int lds_cand) {
+    extern __shared__ uint4 s_dyn[];
+    uint8_t* s_claimed = (uint8_t*)s_dyn;
+    uint4* s_lo = s_dyn + claimed_bytes / 16;
+    uint4* s_hi = s_lo + lds_cand;
     const int lane = threadIdx.x;
     const int an = blockIdx.x;
     const uint32_t id = A.node_id[an];
@@ -127,92 +142,109 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
     const int qa0 = A.node_start[an], qa1 = A.node_start[an + 1];
     const int cb0 = B.node_start[lo], nc = B.node_start[lo + 1] - cb0;
     if (nc <= 0 || qa1 <= qa0) return;
+    const int staged = min(nc, lds_cand);
     for (int j = lane; j < nc; j += 64) {
+        const int idx2 = (int)B.items[cb0 + j];
         bool usable = true;
-        if (MODE != 0 && B.flags) usable = (B.flags[B.items[cb0 + j]] & 1) != 0;
+        if (MODE != 0 && B.flags) usable = (B.flags[idx2] & 1) != 0;
         s_claimed[j] = usable ? 0 : 1;
+        if (j < staged) { s_lo[j] = B.desc[2 * (size_t)idx2]; s_hi[j] = B.desc[2 * (size_t)idx2 + 1]; }
     }
-    // the first 64 candidates stay in registers for every query of the node
-    const int my_idx2 = lane < nc ? (int)B.items[cb0 + lane] : 0;
-    uint4 m0 = make_uint4(0, 0, 0, 0), m1 = m0;
-    if (lane < nc) { m0 = B.desc[2 * (size_t)my_idx2]; m1 = B.desc[2 * (size_t)my_idx2 + 1]; }
     __syncthreads();
-    for (int k1 = qa0; k1 < qa1; ++k1) {
-        const int idx1 = (int)A.items[k1];
-        const int fl1 = A.flags ? A.flags[idx1] : 1;
-        if (!(fl1 & 1)) continue;                      // wave-uniform
-        const uint4 q0 = A.desc[2 * (size_t)idx1], q1 = A.desc[2 * (size_t)idx1 + 1];
-        int cam1 = 0; float x1 = 0, y1 = 0, la = 0, lb = 0, lc = 0, den = 0;
-        if (MODE == 2) {
-            cam1 = A.cam_of[idx1]; x1 = A.x[idx1]; y1 = A.y[idx1];
-            const float* F = T.F12[cam1];              // CheckDistEpipolarLine, src/ORBmatcher.cc:170-178
-            la = x1 * F[0] + y1 * F[3] + F[6];
-            lb = x1 * F[1] + y1 * F[4] + F[7];
-            lc = x1 * F[2] + y1 * F[5] + F[8];
-            den = la * la + lb * lb;
+    for (int kb = qa0; kb < qa1; kb += 64) {
+        // this lane's query of the block
+        const int kmine = kb + lane;
+        const bool have = kmine < qa1;
+        const int p_idx1 = have ? (int)A.items[kmine] : 0;
+        const int p_fl = have ? (A.flags ? (int)A.flags[p_idx1] : 1) : 0;
+        uint4 p_q0 = make_uint4(0, 0, 0, 0), p_q1 = p_q0;
+        float p_ang = 0.f, p_x = 0.f, p_y = 0.f; int p_cam = 0;
+        if (have && (p_fl & 1)) {
+            p_q0 = A.desc[2 * (size_t)p_idx1]; p_q1 = A.desc[2 * (size_t)p_idx1 + 1];
+            p_ang = A.angle[p_idx1];
+            if (MODE == 2) { p_x = A.x[p_idx1]; p_y = A.y[p_idx1]; p_cam = A.cam_of[p_idx1]; }
         }
-        int bd = 256, bj = -1, d2 = 256;               // per-lane top-2 (modes 0/1)
-        unsigned key2 = 0x7fffffffu;                   // per-lane best (mode 2): smallest distance, LAST candidate on ties
-        for (int j = lane, t = 0; j < nc; j += 64, ++t) {
-            if (s_claimed[j]) continue;
-            int idx2; uint4 c0, c1;
-            if (t == 0) { idx2 = my_idx2; c0 = m0; c1 = m1; }
-            else { idx2 = (int)B.items[cb0 + j]; c0 = B.desc[2 * (size_t)idx2]; c1 = B.desc[2 * (size_t)idx2 + 1]; }
-            const int d = ham256(q0, q1, c0, c1);
-            if (MODE != 2) {
-                if (d < bd) { d2 = bd; bd = d; bj = j; }
-                else if (d < d2) d2 = d;
-            } else {
-                if (d > th_low) continue;
-                if (B.cam_of[idx2] != cam1) continue;                          // :1562
-                const int fl2 = B.flags ? B.flags[idx2] : 1;
-                const float x2 = B.x[idx2], y2 = B.y[idx2];
-                const int oct2 = B.octave[idx2];
-                if (!(fl1 & 2) && !(fl2 & 2)) {                                // both monocular: too close to the epipole (:1582-1595)
-                    const float dex = T.ex[cam1] - x2, dey = T.ey[cam1] - y2;
-                    if (dex * dex + dey * dey < 100 * T.scale[oct2]) continue;
-                }
-                const float num = la * x2 + lb * y2 + lc;
-                if (den == 0) continue;
-                const float dsqr = num * num / den;
-                if (!((double)dsqr < 3.84 * (double)T.sigma2[oct2])) continue;
-                key2 = min(key2, ((unsigned)d << 20) | (unsigned)(0xfffff - j));
+        const int kend = min(64, qa1 - kb);
+        for (int kq = 0; kq < kend; ++kq) {
+            const int fl1 = bcast_i(p_fl, kq);
+            if (!(fl1 & 1)) continue;                      // wave-uniform
+            const int idx1 = bcast_i(p_idx1, kq);
+            const uint4 q0 = bcast_u4(p_q0, kq), q1 = bcast_u4(p_q1, kq);
+            const float ang1 = bcast_f(p_ang, kq);
+            int cam1 = 0; float la = 0, lb = 0, lc = 0, den = 0;
+            if (MODE == 2) {
+                cam1 = bcast_i(p_cam, kq);
+                const float x1 = bcast_f(p_x, kq), y1 = bcast_f(p_y, kq);
+                const float* F = T.F12[cam1];              // CheckDistEpipolarLine, src/ORBmatcher.cc:170-178
+                la = x1 * F[0] + y1 * F[3] + F[6];
+                lb = x1 * F[1] + y1 * F[4] + F[7];
+                lc = x1 * F[2] + y1 * F[5] + F[8];
+                den = la * la + lb * lb;
             }
-        }
-        if (MODE != 2) {
-            const unsigned K = wave_min_u32(bj >= 0 ? (((unsigned)bd << 20) | (unsigned)bj) : 0x7fffffffu);
-            if (K == 0x7fffffffu) continue;            // wave-uniform: nothing closer than 256
-            const int best = (int)(K >> 20), J = (int)(K & 0xfffffu);
-            const int second = (int)wave_min_u32((unsigned)(((J & 63) == lane) ? d2 : bd));
-            const bool under = MODE == 0 ? best <= th_low : best < th_low;        // :324 / :1107
-            if (under && (float)best < nnratio * (float)second) {
+            int bd = 256, bj = -1, d2 = 256;               // per-lane top-2 (modes 0/1)
+            unsigned key2 = 0x7fffffffu;                   // per-lane best (mode 2): smallest distance, LAST candidate on ties
+            for (int j = lane; j < nc; j += 64) {
+                if (s_claimed[j]) continue;
+                uint4 c0, c1; int idx2 = -1;
+                if (j < staged) { c0 = s_lo[j]; c1 = s_hi[j]; }
+                else { idx2 = (int)B.items[cb0 + j]; c0 = B.desc[2 * (size_t)idx2]; c1 = B.desc[2 * (size_t)idx2 + 1]; }
+                const int d = ham256(q0, q1, c0, c1);
+                if (MODE != 2) {
+                    if (d < bd) { d2 = bd; bd = d; bj = j; }
+                    else if (d < d2) d2 = d;
+                } else {
+                    if (d > th_low) continue;
+                    if (idx2 < 0) idx2 = (int)B.items[cb0 + j];
+                    if (B.cam_of[idx2] != cam1) continue;                          // :1562
+                    const int fl2 = B.flags ? B.flags[idx2] : 1;
+                    const float x2 = B.x[idx2], y2 = B.y[idx2];
+                    const int oct2 = B.octave[idx2];
+                    if (!(fl1 & 2) && !(fl2 & 2)) {                                // both monocular: too close to the epipole (:1582-1595)
+                        const float dex = T.ex[cam1] - x2, dey = T.ey[cam1] - y2;
+                        if (dex * dex + dey * dey < 100 * T.scale[oct2]) continue;
+                    }
+                    const float num = la * x2 + lb * y2 + lc;
+                    if (den == 0) continue;
+                    const float dsqr = num * num / den;
+                    if (!((double)dsqr < 3.84 * (double)T.sigma2[oct2])) continue;
+                    key2 = min(key2, ((unsigned)d << 20) | (unsigned)(0xfffff - j));
+                }
+            }
+            if (MODE != 2) {
+                const unsigned K = wave_min_u32(bj >= 0 ? (((unsigned)bd << 20) | (unsigned)bj) : 0x7fffffffu);
+                if (K == 0x7fffffffu) continue;            // wave-uniform: nothing closer than 256
+                const int best = (int)(K >> 20), J = (int)(K & 0xfffffu);
+                const int second = (int)wave_min_u32((unsigned)(((J & 63) == lane) ? d2 : bd));
+                const bool under = MODE == 0 ? best <= th_low : best < th_low;        // :324 / :1107
+                if (under && (float)best < nnratio * (float)second) {
+                    if (lane == 0) {
+                        const int idx2 = (int)B.items[cb0 + J];
+                        const int oi = MODE == 0 ? idx2 : idx1;
+                        W.match[oi] = MODE == 0 ? idx1 : idx2;
+                        s_claimed[J] = 1;
+                        if (check_ori) {
+                            const int bin = rot_bin(ang1, B.angle[idx2]);
+                            W.bin_of[oi] = (uint8_t)bin;
+                            atomicAdd(&W.hist[bin], 1);
+                        }
+                        atomicAdd(&W.hist[HISTO], 1);
+                    }
+                    __syncthreads();
+                }
+            } else {
+                const unsigned K = wave_min_u32(key2);
+                if (K == 0x7fffffffu) continue;
                 if (lane == 0) {
+                    const int J = 0xfffff - (int)(K & 0xfffffu);
                     const int idx2 = (int)B.items[cb0 + J];
-                    const int oi = MODE == 0 ? idx2 : idx1;
-                    W.match[oi] = MODE == 0 ? idx1 : idx2;
-                    s_claimed[J] = 1;
+                    W.match[idx1] = idx2;
                     if (check_ori) {
-                        const int bin = rot_bin(A.angle[idx1], B.angle[idx2]);
-                        W.bin_of[oi] = (uint8_t)bin;
+                        const int bin = rot_bin(ang1, B.angle[idx2]);
+                        W.bin_of[idx1] = (uint8_t)bin;
                         atomicAdd(&W.hist[bin], 1);
                     }
                     atomicAdd(&W.hist[HISTO], 1);
                 }
-                __syncthreads();
-            }
-        } else {
-            const unsigned K = wave_min_u32(key2);
-            if (K == 0x7fffffffu) continue;
-            if (lane == 0) {
-                const int J = 0xfffff - (int)(K & 0xfffffu);
-                const int idx2 = (int)B.items[cb0 + J];
-                W.match[idx1] = idx2;
-                if (check_ori) {
-                    const int bin = rot_bin(A.angle[idx1], B.angle[idx2]);
-                    W.bin_of[idx1] = (uint8_t)bin;
-                    atomicAdd(&W.hist[bin], 1);
-                }
-                atomicAdd(&W.hist[HISTO], 1);
             }
         }
     }
@@ -571,10 +603,12 @@ int run_join(orbv_workspace* w, const orbv_side* a, const orbv_side* b, int mode
     hipStream_t st = w->stream;
     MORB_HIP(hipMemcpyAsync(w->d_stage.p, w->h_stage.p, P.off, hipMemcpyHostToDevice, st));
     k_bow_init<<<(std::max(n_out, HISTO + 1) + 255) / 256, 256, 0, st>>>(W, n_out);
-    const size_t lds = (size_t)((max_nc + 63) & ~63);
-    if (mode == 0) k_bow_join<0><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W);
-    else if (mode == 1) k_bow_join<1><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W);
-    else k_bow_join<2><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W);
+    const int claimed_bytes = (max_nc + 63) & ~63;
+    const int lds_cand = std::min(max_nc, (JOIN_LDS_BYTES - claimed_bytes) / 32);   // descriptors staged in LDS (32 B each)
+    const size_t lds = (size_t)claimed_bytes + (size_t)std::max(lds_cand, 0) * 32;
+    if (mode == 0) k_bow_join<0><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, std::max(lds_cand, 0));
+    else if (mode == 1) k_bow_join<1><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, std::max(lds_cand, 0));
+    else k_bow_join<2><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, std::max(lds_cand, 0));
     k_bow_finish<<<1, 256, 0, st>>>(W, n_out, check_ori, w->h_match.dp, w->h_match.dp + n_out);
     MORB_HIP(hipGetLastError());
     MORB_HIP(hipStreamSynchronize(st));

@@ -70,30 +70,54 @@ def _flip_bits(rows, seed, p):
     return rows ^ np.packbits(bits.reshape(n, 256), axis=1, bitorder="little")
 
 
+def _flip_eighth(rows, seed):
+    """each bit flipped with probability 1/8 (three hashed words ANDed): cheap enough for a million rows"""
+    n = len(rows)
+    idx = np.arange(n * 8, dtype=np.uint64)
+    m = hash32(idx + np.uint64((seed * 0x2545F491) & 0xFFFFFFFF)) & hash32(idx + np.uint64((seed * 0x9E3779B1 + 1) & 0xFFFFFFFF)) & \
+        hash32(idx + np.uint64((seed * 0x85EBCA6B + 2) & 0xFFFFFFFF))
+    return rows ^ m.view(np.uint8).reshape(n, 32)
+
+
 def vocabulary(k=10, L=3, seed=11, ragged=False, stop_every=0):
     """Synthetic vocabulary tree in the layout of DBoW2's text loader (no vocabulary file ships with the reference): node ids in
     creation order, the children of a node = its descriptor with ~12 % of the bits flipped, idf-like positive weights.
     ragged: every 7th inner node becomes a leaf early and child counts vary in [2, k]; stop_every: every n-th word gets weight 0.
     -> dict(parent, is_leaf, desc, weight: arrays over node ids; k, L)."""
-    parent, leaf, desc, weight = [0], [0], [np.zeros(32, np.uint8)], [0.0]
-    root = descriptors(1, seed)[0]
-    frontier = [(0, root, 0)]
-    while frontier:
-        nxt = []
-        for (nid, d, lvl) in frontier:
-            h = int(hash32(np.array([nid * 31 + seed], np.uint64))[0])
-            kk = k if not ragged else 2 + h % (k - 1)
-            base = np.repeat(d[None, :], kk, 0) if nid else descriptors(kk, seed + 1)
-            kids = _flip_bits(base, seed + 13 * nid + 1, 0.12) if nid else base
-            for c in range(kk):
-                cid = len(parent)
-                is_leaf = (lvl + 1 == L) or (ragged and cid % 7 == 3)
-                parent.append(nid); leaf.append(int(is_leaf)); desc.append(kids[c])
-                wv = 0.5 + (int(hash32(np.array([cid + 977 * seed], np.uint64))[0]) % 100000) / 12345.0
-                weight.append(wv if is_leaf else 0.0)
-                if not is_leaf:
-                    nxt.append((cid, kids[c], lvl + 1))
-        frontier = nxt
+    if not ragged:   # full k-ary tree, level by level (vectorised: the stock k=10, L=6 shape has 1.1 M nodes)
+        parent, leaf, desc, weight = [np.zeros(1, np.int64)], [np.zeros(1, np.uint8)], [np.zeros((1, 32), np.uint8)], [np.zeros(1)]
+        ids = np.zeros(1, np.int64); dl = descriptors(1, seed); total = 1
+        for lvl in range(L):
+            cnt = len(ids) * k
+            base = np.repeat(dl, k, 0) if lvl else descriptors(k, seed + 1)
+            kids = _flip_eighth(base, seed + 13 * lvl + 1) if lvl else base
+            cid = total + np.arange(cnt, dtype=np.int64)
+            is_leaf = lvl + 1 == L
+            parent.append(np.repeat(ids, k)); leaf.append(np.full(cnt, int(is_leaf), np.uint8)); desc.append(kids)
+            wv = 0.5 + (hash32(cid.astype(np.uint64) + np.uint64(977 * seed)) % np.uint32(100000)).astype(np.float64) / 12345.0
+            weight.append(wv if is_leaf else np.zeros(cnt))
+            ids, dl, total = cid, kids, total + cnt
+        parent, leaf, desc, weight = np.concatenate(parent), np.concatenate(leaf), np.concatenate(desc), np.concatenate(weight)
+    else:
+        parent, leaf, desc, weight = [0], [0], [np.zeros(32, np.uint8)], [0.0]
+        root = descriptors(1, seed)[0]
+        frontier = [(0, root, 0)]
+        while frontier:
+            nxt = []
+            for (nid, d, lvl) in frontier:
+                h = int(hash32(np.array([nid * 31 + seed], np.uint64))[0])
+                kk = k if not ragged else 2 + h % (k - 1)
+                base = np.repeat(d[None, :], kk, 0) if nid else descriptors(kk, seed + 1)
+                kids = _flip_bits(base, seed + 13 * nid + 1, 0.12) if nid else base
+                for c in range(kk):
+                    cid = len(parent)
+                    is_leaf = (lvl + 1 == L) or (ragged and cid % 7 == 3)
+                    parent.append(nid); leaf.append(int(is_leaf)); desc.append(kids[c])
+                    wv = 0.5 + (int(hash32(np.array([cid + 977 * seed], np.uint64))[0]) % 100000) / 12345.0
+                    weight.append(wv if is_leaf else 0.0)
+                    if not is_leaf:
+                        nxt.append((cid, kids[c], lvl + 1))
+            frontier = nxt
     weight = np.array(weight, np.float64); leaf = np.array(leaf, np.uint8)
     if stop_every:
         words = np.flatnonzero(leaf)
