@@ -107,6 +107,21 @@ typedef struct orbv_triangulation {
 int orbv_search_for_triangulation(orbv_workspace* w, const orbv_side* a, const orbv_side* b, const orbv_triangulation* t,
                                   int th_low, int check_orientation, int32_t* match, int* nmatches);
 
+/* Resident form: a frame / keyframe is uploaded once (descriptors, angles, FeatureVector and -- when s->x is given -- the
+ * triangulation arrays; the caller's arrays are free again on return) and searched any number of times.  The MapPoint state
+ * changes between searches, so every search takes the two flag arrays of the moment (a->n / b->n bytes, meaning as above;
+ * NULL = the flags uploaded with the keyframe, which may themselves be NULL = all usable). */
+typedef struct orbv_keyframe orbv_keyframe;
+int orbv_keyframe_create(orbv_workspace* w, const orbv_side* s, orbv_keyframe** out);
+void orbv_keyframe_destroy(orbv_keyframe* k);
+int orbv_keyframe_count(const orbv_keyframe* k);
+int orbv_search_by_bow_resident(orbv_workspace* w, const orbv_keyframe* a, const uint8_t* flags_a, const orbv_keyframe* b,
+                                const uint8_t* flags_b, int mode, int th_low, float nnratio, int check_orientation, int32_t* match,
+                                int* nmatches);
+int orbv_search_for_triangulation_resident(orbv_workspace* w, const orbv_keyframe* a, const uint8_t* flags_a, const orbv_keyframe* b,
+                                           const uint8_t* flags_b, const orbv_triangulation* t, int th_low, int check_orientation,
+                                           int32_t* match, int* nmatches);
+
 #ifdef __cplusplus
 }
 #endif

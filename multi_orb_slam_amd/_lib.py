@@ -175,6 +175,11 @@ def lib():
     L.orbv_workspace_destroy.argtypes = [vp]; L.orbv_workspace_destroy.restype = None
     L.orbv_search_by_bow.argtypes = [vp, vp, vp, i32, i32, f32, i32, vp, vp]
     L.orbv_search_for_triangulation.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    L.orbv_keyframe_create.argtypes = [vp, vp, vp]
+    L.orbv_keyframe_destroy.argtypes = [vp]; L.orbv_keyframe_destroy.restype = None
+    L.orbv_keyframe_count.argtypes = [vp]
+    L.orbv_search_by_bow_resident.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, vp]
+    L.orbv_search_for_triangulation_resident.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     _lib = L
     return L
 

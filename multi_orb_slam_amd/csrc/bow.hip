@@ -120,7 +120,7 @@ __device__ __forceinline__ uint4 bcast_u4(const uint4& v, int l) {
 
 // MODE 0: SearchByBoW(KF, F); 1: SearchByBoW(KF, KF); 2: SearchForTriangulation.
 // One wavefront per node of A that B also has.  LDS: one "claimed" byte per candidate of the node, then the descriptors of
-// its first `lds_cand` candidates as two uint4 planes (conflict-free 16-byte lane stride); candidates beyond that are read
+// its first `lds_cand` candidates as two uint4 planes (conflict-free 16-byte lane stride) with their index and angle; the rest are read
 // from HBM/L2 on every pass.  Queries are fetched 64 at a time (one per lane: index, flags, descriptor, angle, position) and
 // handed to the whole wave with readlane, so the serial query loop waits on no memory but LDS.
 template <int MODE>
@@ -130,6 +130,8 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
     uint8_t* s_claimed = (uint8_t*)s_dyn;
     uint4* s_lo = s_dyn + claimed_bytes / 16;
     uint4* s_hi = s_lo + lds_cand;
+    int* s_idx = (int*)(s_hi + lds_cand);          // feature index and angle of the staged candidates: the accept path
+    float* s_ang = (float*)(s_idx + lds_cand);     // of a query touches no global memory but its (unwaited) stores
     const int lane = threadIdx.x;
     const int an = blockIdx.x;
     const uint32_t id = A.node_id[an];
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
         bool usable = true;
         if (MODE != 0 && B.flags) usable = (B.flags[idx2] & 1) != 0;
         s_claimed[j] = usable ? 0 : 1;
-        if (j < staged) { s_lo[j] = B.desc[2 * (size_t)idx2]; s_hi[j] = B.desc[2 * (size_t)idx2 + 1]; }
+        if (j < staged) { s_lo[j] = B.desc[2 * (size_t)idx2]; s_hi[j] = B.desc[2 * (size_t)idx2 + 1]; s_idx[j] = idx2; s_ang[j] = B.angle[idx2]; }
     }
     __syncthreads();
     for (int kb = qa0; kb < qa1; kb += 64) {
@@ -183,30 +185,45 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
             }
             int bd = 256, bj = -1, d2 = 256;               // per-lane top-2 (modes 0/1)
             unsigned key2 = 0x7fffffffu;                   // per-lane best (mode 2): smallest distance, LAST candidate on ties
-            for (int j = lane; j < nc; j += 64) {
-                if (s_claimed[j]) continue;
-                uint4 c0, c1; int idx2 = -1;
-                if (j < staged) { c0 = s_lo[j]; c1 = s_hi[j]; }
-                else { idx2 = (int)B.items[cb0 + j]; c0 = B.desc[2 * (size_t)idx2]; c1 = B.desc[2 * (size_t)idx2 + 1]; }
-                const int d = ham256(q0, q1, c0, c1);
+            // geometric gates of SearchForTriangulation for one candidate that is already close enough (:1562-1600)
+            auto tri_ok = [&](int idx2) -> bool {
+                if (B.cam_of[idx2] != cam1) return false;
+                const int fl2 = B.flags ? B.flags[idx2] : 1;
+                const float x2 = B.x[idx2], y2 = B.y[idx2];
+                const int oct2 = B.octave[idx2];
+                if (!(fl1 & 2) && !(fl2 & 2)) {                                    // both monocular: too close to the epipole
+                    const float dex = T.ex[cam1] - x2, dey = T.ey[cam1] - y2;
+                    if (dex * dex + dey * dey < 100 * T.scale[oct2]) return false;
+                }
+                const float num = la * x2 + lb * y2 + lc;
+                if (den == 0) return false;
+                const float dsqr = num * num / den;
+                return (double)dsqr < 3.84 * (double)T.sigma2[oct2];
+            };
+            // staged candidates: branch-free LDS reads (lanes past the end re-read the last one and are masked), so the passes
+            // of one query overlap instead of waiting on each other's LDS round trips
+#pragma unroll 2
+            for (int j0 = 0; j0 < staged; j0 += 64) {
+                const int j = j0 + lane;
+                const int jc = min(j, staged - 1);
+                const bool ok = j < staged && !s_claimed[jc];
+                const uint4 c0 = s_lo[jc], c1 = s_hi[jc];
+                const int d = ok ? ham256(q0, q1, c0, c1) : 257;
                 if (MODE != 2) {
                     if (d < bd) { d2 = bd; bd = d; bj = j; }
                     else if (d < d2) d2 = d;
-                } else {
-                    if (d > th_low) continue;
-                    if (idx2 < 0) idx2 = (int)B.items[cb0 + j];
-                    if (B.cam_of[idx2] != cam1) continue;                          // :1562
-                    const int fl2 = B.flags ? B.flags[idx2] : 1;
-                    const float x2 = B.x[idx2], y2 = B.y[idx2];
-                    const int oct2 = B.octave[idx2];
-                    if (!(fl1 & 2) && !(fl2 & 2)) {                                // both monocular: too close to the epipole (:1582-1595)
-                        const float dex = T.ex[cam1] - x2, dey = T.ey[cam1] - y2;
-                        if (dex * dex + dey * dey < 100 * T.scale[oct2]) continue;
-                    }
-                    const float num = la * x2 + lb * y2 + lc;
-                    if (den == 0) continue;
-                    const float dsqr = num * num / den;
-                    if (!((double)dsqr < 3.84 * (double)T.sigma2[oct2])) continue;
+                } else if (d <= th_low && tri_ok(s_idx[jc])) {
+                    key2 = min(key2, ((unsigned)d << 20) | (unsigned)(0xfffff - j));
+                }
+            }
+            for (int j = staged + lane; j < nc; j += 64) {   // nodes larger than the LDS stage: the rest from L2 / HBM
+                if (s_claimed[j]) continue;
+                const int idx2 = (int)B.items[cb0 + j];
+                const int d = ham256(q0, q1, B.desc[2 * (size_t)idx2], B.desc[2 * (size_t)idx2 + 1]);
+                if (MODE != 2) {
+                    if (d < bd) { d2 = bd; bd = d; bj = j; }
+                    else if (d < d2) d2 = d;
+                } else if (d <= th_low && tri_ok(idx2)) {
                     key2 = min(key2, ((unsigned)d << 20) | (unsigned)(0xfffff - j));
                 }
             }
@@ -218,12 +235,12 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
                 const bool under = MODE == 0 ? best <= th_low : best < th_low;        // :324 / :1107
                 if (under && (float)best < nnratio * (float)second) {
                     if (lane == 0) {
-                        const int idx2 = (int)B.items[cb0 + J];
+                        const int idx2 = J < staged ? s_idx[J] : (int)B.items[cb0 + J];
                         const int oi = MODE == 0 ? idx2 : idx1;
                         W.match[oi] = MODE == 0 ? idx1 : idx2;
                         s_claimed[J] = 1;
                         if (check_ori) {
-                            const int bin = rot_bin(ang1, B.angle[idx2]);
+                            const int bin = rot_bin(ang1, J < staged ? s_ang[J] : B.angle[idx2]);
                             W.bin_of[oi] = (uint8_t)bin;
                             atomicAdd(&W.hist[bin], 1);
                         }
@@ -236,10 +253,10 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
                 if (K == 0x7fffffffu) continue;
                 if (lane == 0) {
                     const int J = 0xfffff - (int)(K & 0xfffffu);
-                    const int idx2 = (int)B.items[cb0 + J];
+                    const int idx2 = J < staged ? s_idx[J] : (int)B.items[cb0 + J];
                     W.match[idx1] = idx2;
                     if (check_ori) {
-                        const int bin = rot_bin(ang1, B.angle[idx2]);
+                        const int bin = rot_bin(ang1, J < staged ? s_ang[J] : B.angle[idx2]);
                         W.bin_of[idx1] = (uint8_t)bin;
                         atomicAdd(&W.hist[bin], 1);
                     }
@@ -566,6 +583,48 @@ SideDev pack_side(Packer& P, const orbv_side* s, bool tri) {
     return D;
 }
 
+int tri_params(const orbv_triangulation* t, TriDev& T) {
+    MORB_ARG(t != nullptr && t->n_cams >= 1 && t->n_cams <= ORBV_MAX_CAMS && t->n_levels >= 1 && t->n_levels <= MAX_LEVELS && t->scale_factors && t->level_sigma2);
+    memcpy(T.F12, t->F12, sizeof(T.F12)); memcpy(T.ex, t->ex, sizeof(T.ex)); memcpy(T.ey, t->ey, sizeof(T.ey));
+    memcpy(T.scale, t->scale_factors, t->n_levels * sizeof(float)); memcpy(T.sigma2, t->level_sigma2, t->n_levels * sizeof(float));
+    return ORB_OK;
+}
+
+int max_node_of(const orbv_side* s) {
+    int m = 1;
+    for (int k = 0; k < s->n_nodes; ++k) m = std::max(m, s->node_start[k + 1] - s->node_start[k]);
+    return m;
+}
+
+// init + join + finish on the workspace's stream, one synchronisation, results out of pinned memory
+int launch_join(orbv_workspace* w, const SideDev& A, const SideDev& B, int max_nc, int mode, const TriDev& T, int th_low, float nnratio,
+                int check_ori, int32_t* match, int* nmatches) {
+    const int n_out = mode == 0 ? B.n : A.n;
+    if (max_nc > JOIN_MAX_NODE) { morb::set_error("a vocabulary node holds %d features (limit %d)", max_nc, JOIN_MAX_NODE); return ORB_E_CAPACITY; }
+    int rc;
+    const size_t work_bytes = up16((size_t)n_out * 4) + up16((HISTO + 1) * 4) + up16((size_t)n_out);
+    if ((rc = w->d_work.reserve(work_bytes)) || (rc = w->h_match.reserve((size_t)n_out + 4))) return rc;
+    JoinWork W;
+    W.match = (int32_t*)w->d_work.p;
+    W.hist = (int*)(w->d_work.p + up16((size_t)n_out * 4));
+    W.bin_of = w->d_work.p + up16((size_t)n_out * 4) + up16((HISTO + 1) * 4);
+    hipStream_t st = w->stream;
+    k_bow_init<<<(std::max(n_out, HISTO + 1) + 255) / 256, 256, 0, st>>>(W, n_out);
+    const int claimed_bytes = (max_nc + 63) & ~63;
+    int lds_cand = std::max(0, std::min(max_nc, (JOIN_LDS_BYTES - claimed_bytes) / 40));   // candidates staged in LDS (40 B each)
+    if (lds_cand < max_nc) lds_cand &= ~63;   // a partial stage ends on a lane-0 boundary: candidate j always belongs to lane j % 64
+    const size_t lds = (size_t)claimed_bytes + (size_t)lds_cand * 40;
+    if (mode == 0) k_bow_join<0><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
+    else if (mode == 1) k_bow_join<1><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
+    else k_bow_join<2><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
+    k_bow_finish<<<1, 256, 0, st>>>(W, n_out, check_ori, w->h_match.dp, w->h_match.dp + n_out);
+    MORB_HIP(hipGetLastError());
+    MORB_HIP(hipStreamSynchronize(st));
+    memcpy(match, w->h_match.p, (size_t)n_out * 4);
+    *nmatches = w->h_match.p[n_out];
+    return ORB_OK;
+}
+
 int run_join(orbv_workspace* w, const orbv_side* a, const orbv_side* b, int mode, const orbv_triangulation* t, int th_low,
              float nnratio, int check_ori, int32_t* match, int* nmatches) {
     MORB_ARG(w != nullptr && nmatches != nullptr && mode >= 0 && mode <= 2);
@@ -576,45 +635,63 @@ int run_join(orbv_workspace* w, const orbv_side* a, const orbv_side* b, int mode
     MORB_ARG(n_out == 0 || match != nullptr);
     TriDev T; memset(&T, 0, sizeof(T));
     if (tri) {
-        MORB_ARG(t != nullptr && t->n_cams >= 1 && t->n_cams <= ORBV_MAX_CAMS && t->n_levels >= 1 && t->n_levels <= MAX_LEVELS && t->scale_factors && t->level_sigma2);
-        memcpy(T.F12, t->F12, sizeof(T.F12)); memcpy(T.ex, t->ex, sizeof(T.ex)); memcpy(T.ey, t->ey, sizeof(T.ey));
-        memcpy(T.scale, t->scale_factors, t->n_levels * sizeof(float)); memcpy(T.sigma2, t->level_sigma2, t->n_levels * sizeof(float));
+        if ((rc = tri_params(t, T))) return rc;
         for (int i = 0; i < a->n; ++i) MORB_ARG(a->cam_of[i] >= 0 && a->cam_of[i] < t->n_cams);
         for (int i = 0; i < b->n; ++i) MORB_ARG(b->octave[i] >= 0 && b->octave[i] < t->n_levels);
     }
     *nmatches = 0;
     for (int i = 0; i < n_out; ++i) match[i] = -1;
     if (a->n_nodes == 0 || b->n_nodes == 0 || a->n == 0 || b->n == 0) return ORB_OK;
-    int max_nc = 1;
-    for (int k = 0; k < b->n_nodes; ++k) max_nc = std::max(max_nc, b->node_start[k + 1] - b->node_start[k]);
-    if (max_nc > JOIN_MAX_NODE) { morb::set_error("a vocabulary node holds %d features (limit %d)", max_nc, JOIN_MAX_NODE); return ORB_E_CAPACITY; }
     MORB_HIP(hipSetDevice(w->device));
     Packer size_pass;                                   // first pass: sizes only
     (void)pack_side(size_pass, a, tri); (void)pack_side(size_pass, b, tri);
     if ((rc = w->h_stage.reserve(size_pass.off)) || (rc = w->d_stage.reserve(size_pass.off))) return rc;
     Packer P; P.h = w->h_stage.p; P.d = w->d_stage.p;
     const SideDev A = pack_side(P, a, tri), B = pack_side(P, b, tri);
-    const size_t work_bytes = up16((size_t)n_out * 4) + up16((HISTO + 1) * 4) + up16((size_t)n_out);
-    if ((rc = w->d_work.reserve(work_bytes)) || (rc = w->h_match.reserve((size_t)n_out + 4))) return rc;
-    JoinWork W;
-    W.match = (int32_t*)w->d_work.p;
-    W.hist = (int*)(w->d_work.p + up16((size_t)n_out * 4));
-    W.bin_of = w->d_work.p + up16((size_t)n_out * 4) + up16((HISTO + 1) * 4);
-    hipStream_t st = w->stream;
-    MORB_HIP(hipMemcpyAsync(w->d_stage.p, w->h_stage.p, P.off, hipMemcpyHostToDevice, st));
-    k_bow_init<<<(std::max(n_out, HISTO + 1) + 255) / 256, 256, 0, st>>>(W, n_out);
-    const int claimed_bytes = (max_nc + 63) & ~63;
-    const int lds_cand = std::min(max_nc, (JOIN_LDS_BYTES - claimed_bytes) / 32);   // descriptors staged in LDS (32 B each)
-    const size_t lds = (size_t)claimed_bytes + (size_t)std::max(lds_cand, 0) * 32;
-    if (mode == 0) k_bow_join<0><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, std::max(lds_cand, 0));
-    else if (mode == 1) k_bow_join<1><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, std::max(lds_cand, 0));
-    else k_bow_join<2><<<a->n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, std::max(lds_cand, 0));
-    k_bow_finish<<<1, 256, 0, st>>>(W, n_out, check_ori, w->h_match.dp, w->h_match.dp + n_out);
-    MORB_HIP(hipGetLastError());
-    MORB_HIP(hipStreamSynchronize(st));
-    memcpy(match, w->h_match.p, (size_t)n_out * 4);
-    *nmatches = w->h_match.p[n_out];
-    return ORB_OK;
+    MORB_HIP(hipMemcpyAsync(w->d_stage.p, w->h_stage.p, P.off, hipMemcpyHostToDevice, w->stream));
+    return launch_join(w, A, B, max_node_of(b), mode, T, th_low, nnratio, check_ori, match, nmatches);
+}
+
+}  // namespace
+
+// One frame / keyframe resident in HBM for any number of searches (descriptors, angles, FeatureVector, and the triangulation
+// arrays when given): a keyframe is searched against ~20 covisible neighbours by LocalMapping alone (src/LocalMapping.cc).
+struct orbv_keyframe {
+    int device = 0;
+    DevBuf<uint8_t> block;
+    SideDev D;
+    int max_node = 1, max_cam = 0, max_octave = 0;
+    bool tri = false;
+};
+
+namespace {
+
+int run_join_resident(orbv_workspace* w, const orbv_keyframe* a, const uint8_t* flags_a, const orbv_keyframe* b, const uint8_t* flags_b,
+                      int mode, const orbv_triangulation* t, int th_low, float nnratio, int check_ori, int32_t* match, int* nmatches) {
+    MORB_ARG(w != nullptr && a != nullptr && b != nullptr && nmatches != nullptr && mode >= 0 && mode <= 2);
+    MORB_ARG(a->device == w->device && b->device == w->device);
+    const int n_out = mode == 0 ? b->D.n : a->D.n;
+    MORB_ARG(n_out == 0 || match != nullptr);
+    TriDev T; memset(&T, 0, sizeof(T));
+    int rc;
+    if (mode == 2) {
+        MORB_ARG(a->tri && b->tri);
+        if ((rc = tri_params(t, T))) return rc;
+        MORB_ARG(a->max_cam < t->n_cams && b->max_octave < t->n_levels);
+    }
+    *nmatches = 0;
+    for (int i = 0; i < n_out; ++i) match[i] = -1;
+    if (a->D.n_nodes == 0 || b->D.n_nodes == 0 || a->D.n == 0 || b->D.n == 0) return ORB_OK;
+    MORB_HIP(hipSetDevice(w->device));
+    SideDev A = a->D, B = b->D;
+    if (flags_a || flags_b) {       // per-call MapPoint state: two small arrays through the pinned stage
+        const size_t na = flags_a ? up16((size_t)A.n) : 0, nb = flags_b ? up16((size_t)B.n) : 0;
+        if ((rc = w->h_stage.reserve(na + nb)) || (rc = w->d_stage.reserve(na + nb))) return rc;
+        if (flags_a) { memcpy(w->h_stage.p, flags_a, (size_t)A.n); A.flags = w->d_stage.p; }
+        if (flags_b) { memcpy(w->h_stage.p + na, flags_b, (size_t)B.n); B.flags = w->d_stage.p + na; }
+        MORB_HIP(hipMemcpyAsync(w->d_stage.p, w->h_stage.p, na + nb, hipMemcpyHostToDevice, w->stream));
+    }
+    return launch_join(w, A, B, b->max_node, mode, T, th_low, nnratio, check_ori, match, nmatches);
 }
 
 }  // namespace
@@ -630,6 +707,52 @@ int orbv_search_by_bow(orbv_workspace* w, const orbv_side* a, const orbv_side* b
 int orbv_search_for_triangulation(orbv_workspace* w, const orbv_side* a, const orbv_side* b, const orbv_triangulation* t,
                                   int th_low, int check_orientation, int32_t* match, int* nmatches) {
     return run_join(w, a, b, 2, t, th_low, 0.f, check_orientation, match, nmatches);
+}
+
+int orbv_keyframe_create(orbv_workspace* w, const orbv_side* s, orbv_keyframe** out) {
+    MORB_ARG(w != nullptr && out != nullptr && s != nullptr);
+    const bool tri = s->x != nullptr;
+    int rc = side_check(s, tri);
+    if (rc) return rc;
+    MORB_HIP(hipSetDevice(w->device));
+    Packer size_pass;
+    (void)pack_side(size_pass, s, tri);
+    std::vector<uint8_t> host(std::max<size_t>(size_pass.off, 16));
+    orbv_keyframe* k = new orbv_keyframe();
+    k->device = w->device; k->tri = tri;
+    if ((rc = k->block.reserve(host.size()))) { delete k; return rc; }
+    Packer P; P.h = host.data(); P.d = k->block.p;
+    k->D = pack_side(P, s, tri);
+    k->max_node = max_node_of(s);
+    if (tri) for (int i = 0; i < s->n; ++i) {
+        if (s->cam_of[i] < 0 || s->octave[i] < 0) { morb::set_error("negative camera / octave"); orbv_keyframe_destroy(k); return ORB_E_ARG; }
+        k->max_cam = std::max(k->max_cam, (int)s->cam_of[i]); k->max_octave = std::max(k->max_octave, (int)s->octave[i]);
+    }
+    if (hipMemcpy(k->block.p, host.data(), P.off, hipMemcpyHostToDevice) != hipSuccess) { morb::set_error("keyframe upload failed"); orbv_keyframe_destroy(k); return ORB_E_HIP; }
+    *out = k;
+    return ORB_OK;
+}
+
+void orbv_keyframe_destroy(orbv_keyframe* k) {
+    if (!k) return;
+    (void)hipSetDevice(k->device);
+    k->block.release();
+    delete k;
+}
+
+int orbv_keyframe_count(const orbv_keyframe* k) { return k ? k->D.n : 0; }
+
+int orbv_search_by_bow_resident(orbv_workspace* w, const orbv_keyframe* a, const uint8_t* flags_a, const orbv_keyframe* b,
+                                const uint8_t* flags_b, int mode, int th_low, float nnratio, int check_orientation, int32_t* match,
+                                int* nmatches) {
+    MORB_ARG(mode == 0 || mode == 1);
+    return run_join_resident(w, a, flags_a, b, flags_b, mode, nullptr, th_low, nnratio, check_orientation, match, nmatches);
+}
+
+int orbv_search_for_triangulation_resident(orbv_workspace* w, const orbv_keyframe* a, const uint8_t* flags_a, const orbv_keyframe* b,
+                                           const uint8_t* flags_b, const orbv_triangulation* t, int th_low, int check_orientation,
+                                           int32_t* match, int* nmatches) {
+    return run_join_resident(w, a, flags_a, b, flags_b, 2, t, th_low, 0.f, check_orientation, match, nmatches);
 }
 
 }  // extern "C"

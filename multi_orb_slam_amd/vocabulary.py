@@ -115,6 +115,45 @@ class BowSearch:
         check(_lib.lib().orbv_search_by_bow(self._h, C.byref(ca), C.byref(cb), mode, th_low, nnratio, int(check_orientation), ptr(match), C.byref(nm)))
         return nm.value, match[:n_out]
 
+    def keyframe(self, side):
+        """Upload a Side once (orbv_keyframe_create); pass the result wherever a Side is accepted."""
+        return Keyframe(self, side)
+
+    @staticmethod
+    def _flags(f):
+        return None if f is None else np.ascontiguousarray(f, np.uint8)
+
+    def search_by_bow_resident(self, a, b, mode, flags_a=None, flags_b=None, th_low=50, nnratio=0.7, check_orientation=True):
+        n_out = b.n if mode == 0 else a.n
+        match = np.full(max(n_out, 1), -1, np.int32); nm = C.c_int()
+        fa, fb = self._flags(flags_a), self._flags(flags_b)
+        check(_lib.lib().orbv_search_by_bow_resident(self._h, a._h, None if fa is None else ptr(fa), b._h, None if fb is None else ptr(fb), mode,
+                                                     th_low, nnratio, int(check_orientation), ptr(match), C.byref(nm)))
+        return nm.value, match[:n_out]
+
+    def search_for_triangulation_resident(self, a, b, F12, ex, ey, scale_factors, level_sigma2, flags_a=None, flags_b=None, th_low=50,
+                                          check_orientation=True):
+        T, keep = self._tri(F12, ex, ey, scale_factors, level_sigma2)
+        match = np.full(max(a.n, 1), -1, np.int32); nm = C.c_int()
+        fa, fb = self._flags(flags_a), self._flags(flags_b)
+        check(_lib.lib().orbv_search_for_triangulation_resident(self._h, a._h, None if fa is None else ptr(fa), b._h, None if fb is None else ptr(fb),
+                                                                C.byref(T), th_low, int(check_orientation), ptr(match), C.byref(nm)))
+        return nm.value, match[:a.n]
+
+    @staticmethod
+    def _tri(F12, ex, ey, scale_factors, level_sigma2):
+        T = Triangulation()
+        F12 = np.ascontiguousarray(F12, np.float32).reshape(-1, 9)
+        T.n_cams = len(F12)
+        sf = np.ascontiguousarray(scale_factors, np.float32); s2 = np.ascontiguousarray(level_sigma2, np.float32)
+        T.n_levels = len(sf)
+        for c in range(len(F12)):
+            for k in range(9):
+                T.F12[c][k] = float(F12[c, k])
+            T.ex[c] = float(ex[c]); T.ey[c] = float(ey[c])
+        T.scale_factors = sf.ctypes.data; T.level_sigma2 = s2.ctypes.data
+        return T, (sf, s2)
+
     def search_for_triangulation(self, a, b, F12, ex, ey, scale_factors, level_sigma2, th_low=50, check_orientation=True):
         T = Triangulation()
         F12 = np.ascontiguousarray(F12, np.float32).reshape(-1, 9)
@@ -130,3 +169,19 @@ class BowSearch:
         ca, cb = a.c(), b.c()
         check(_lib.lib().orbv_search_for_triangulation(self._h, C.byref(ca), C.byref(cb), C.byref(T), th_low, int(check_orientation), ptr(match), C.byref(nm)))
         return nm.value, match[:a.n]
+
+
+class Keyframe:
+    """A Side resident in HBM (orbv_keyframe)."""
+
+    def __init__(self, search, side):
+        self._h = C.c_void_p(); self.n = side.n; self._search = search
+        cs = side.c()
+        check(_lib.lib().orbv_keyframe_create(search._h, C.byref(cs), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().orbv_keyframe_destroy(self._h)
+            self._h = None
+
+    __del__ = close

@@ -183,3 +183,37 @@ def test_search_for_triangulation_equals_oracle(k, na, nb, stereo_p):
         total += nm
     assert total > 50
     S.close()
+
+
+def test_resident_keyframes_equal_oracle_with_flags_of_the_moment():
+    """Keyframes uploaded once, searched repeatedly while the MapPoint flags change between calls."""
+    voc = synth.vocabulary(10, 3, seed=6)
+    O = oracle.Vocabulary(voc)
+    S = m.BowSearch()
+    a, b = make_bow_pair(voc, O, 1700, 1800, seed=13, levelsup=2, stereo_p=0.3)
+    KA, KB = S.keyframe(to_side(a, True)), S.keyframe(to_side(b, True))
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32); s2 = (sf * sf).astype(np.float32)
+    F12 = np.array([[0, 0, 0, 0, 0, -1, 0, 1, 0], [1e-5, 0, 0.004, 0, 2e-5, -1, -0.004, 1, 0.3]], np.float32)
+    ex, ey = np.array([300.0, -50.0], np.float32), np.array([200.0, 240.0], np.float32)
+    from helpers import rand_unit
+    for it in range(3):
+        if it == 0:
+            fa = fb = None; ea, eb = a, b                      # the flags uploaded with the keyframes
+        else:
+            fa = ((rand_unit(1700, 50 + it) < 0.7).astype(np.uint8) | (a["flags"] & 2)).astype(np.uint8)
+            fb = ((rand_unit(1800, 60 + it) < 0.7).astype(np.uint8) | (b["flags"] & 2)).astype(np.uint8)
+            ea, eb = dict(a, flags=fa), dict(b, flags=fb)
+        for mode in (0, 1):
+            nm, match = S.search_by_bow_resident(KA, KB, mode, fa, fb, 50, 0.75, True)
+            onm, omatch = oracle.search_by_bow(ea, eb, mode, 50, 0.75, True)
+            assert nm == onm and np.array_equal(match, omatch) and nm > 50
+        nm, match = S.search_for_triangulation_resident(KA, KB, F12, ex, ey, sf, s2, fa, fb)
+        onm, omatch = oracle.search_for_triangulation(ea, eb, F12, ex, ey, sf, s2)
+        assert nm == onm and np.array_equal(match, omatch) and nm > 20
+    # a keyframe without the triangulation arrays cannot be triangulated against: loud error
+    KC = S.keyframe(to_side(a))
+    with pytest.raises(m.OrbError):
+        S.search_for_triangulation_resident(KC, KB, F12, ex, ey, sf, s2)
+    for k in (KA, KB, KC):
+        k.close()
+    S.close()

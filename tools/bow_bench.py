@@ -56,21 +56,27 @@ def main():
         fv = lambda s: m.FeatureVector(s["node_id"], s["node_start"], s["items"])
         A = m.BowSide(a["desc"], a["angle"], fv(a), a["flags"], a["x"], a["y"], a["octave"], a["cam_of"])
         B = m.BowSide(bb["desc"], bb["angle"], fv(bb), bb["flags"], bb["x"], bb["y"], bb["octave"], bb["cam_of"])
+        KA, KB = S.keyframe(A), S.keyframe(B)
         for mode in (0, 1):
             nm, mt = S.search_by_bow(A, B, mode); onm, omt = oracle.search_by_bow(a, bb, mode)
             assert nm == onm and np.array_equal(mt, omt)
+            rn, rm = S.search_by_bow_resident(KA, KB, mode, a["flags"], bb["flags"])
+            assert rn == onm and np.array_equal(rm, omt)
+            r_ms = timeit(lambda: S.search_by_bow_resident(KA, KB, mode, a["flags"], bb["flags"]), 50)
             g_ms = timeit(lambda: S.search_by_bow(A, B, mode), 20)
             c_ms = timeit(lambda: oracle.search_by_bow(a, bb, mode), 3)
             print(json.dumps({"op": "search_by_bow", "mode": mode, "features": n, "nodes": len(a["node_id"]), "largest_node": int(np.diff(bb["node_start"]).max()),
-                              "matches": nm, "gpu_call_ms": round(g_ms, 3), "oracle_ms": round(c_ms, 2)}))
+                              "matches": nm, "gpu_call_ms": round(g_ms, 3), "gpu_resident_call_ms": round(r_ms, 3), "oracle_ms": round(c_ms, 2)}))
         sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32); s2 = (sf * sf).astype(np.float32)
         F12 = np.array([[0, 0, 0, 0, 0, -1, 0, 1, 0], [1e-5, 0, 0.004, 0, 2e-5, -1, -0.004, 1, 0.3]], np.float32)
         ex, ey = np.array([300.0, -50.0], np.float32), np.array([200.0, 240.0], np.float32)
         nm, mt = S.search_for_triangulation(A, B, F12, ex, ey, sf, s2); onm, omt = oracle.search_for_triangulation(a, bb, F12, ex, ey, sf, s2)
         assert nm == onm and np.array_equal(mt, omt)
+        r_ms = timeit(lambda: S.search_for_triangulation_resident(KA, KB, F12, ex, ey, sf, s2, a["flags"], bb["flags"]), 50)
         g_ms = timeit(lambda: S.search_for_triangulation(A, B, F12, ex, ey, sf, s2), 20)
         c_ms = timeit(lambda: oracle.search_for_triangulation(a, bb, F12, ex, ey, sf, s2), 3)
-        print(json.dumps({"op": "search_for_triangulation", "features": n, "matches": nm, "gpu_call_ms": round(g_ms, 3), "oracle_ms": round(c_ms, 2)}))
+        print(json.dumps({"op": "search_for_triangulation", "features": n, "matches": nm, "gpu_call_ms": round(g_ms, 3), "gpu_resident_call_ms": round(r_ms, 3), "oracle_ms": round(c_ms, 2)}))
+        KA.close(); KB.close()
 
 
 if __name__ == "__main__":
