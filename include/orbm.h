@@ -86,7 +86,8 @@ typedef struct orbm_frame_desc { /* flat view of the Frame members the matcher r
 typedef struct orbm_query { /* one projected map point */
     float u, v;             /* projection in the current frame                                               */
     float radius;           /* th * mvScaleFactors[octave]                      (src/ORBmatcher.cc:3543)     */
-    float ur;               /* u - mbf*invzc  |  mTrackProjXR                   (:3573 | :113)               */
+    float ur;               /* u - mbf*invzc  |  mTrackProjXR                   (:3573 | :113); NaN = no right-   */
+                            /* coordinate gate (relocalisation :3809-3946 and loop :753-867 overloads have none) */
     int32_t min_level, max_level; /* as handed to GetFeaturesInArea             (:3547-3552 | :89)           */
     int32_t cam;
     int32_t blocks;         /* 1 if the MapPoint has Observations()>0: its claim hides the feature (:3566)   */
@@ -185,6 +186,18 @@ int orbm_project_candidates(orbm_matcher* m, const orbm_frame* f, const orbm_que
 int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,
                               const uint8_t* occupied, int th_high, int check_orientation,
                               int32_t* match_of_feature, int* nmatches);
+
+/* The inner loop the remaining projection searches share: every projected point scans its window
+ * -- same cell walk and level gate as above -- and reports the FIRST candidate in visiting order with the smallest
+ * distance (`if(dist<bestDist)`), independently of every other point: no claims between queries.
+ *   SearchBySim3 (reference src/ORBmatcher.cc:2814-3135, each direction): gate NONE, caller accepts <= TH_HIGH
+ *   Fuse x2 (:1986-2509): gate CHI2 = the reprojection-error test of :2118-2143 (7.8 with a right coordinate, 5.99
+ *     without; q.ur = projected right coordinate), levels nPredictedLevel-1 .. nPredictedLevel, caller accepts <= TH_LOW
+ *     and then merges / replaces map points on the host as the reference does
+ * occupied[g] != 0 hides feature g (may be NULL).  best_idx[i] = -1 / best_dist[i] = 256 when the window holds nothing. */
+enum { ORBM_GATE_NONE = 0, ORBM_GATE_RIGHT = 1, ORBM_GATE_CHI2 = 2 };
+int orbm_project_best(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, const uint8_t* occupied, int gate,
+                      const float* inv_level_sigma2, int n_levels, int32_t* best_idx, int32_t* best_dist);
 
 /* SearchByProjection(F, vpMapPoints, th): camera-1 grid only, top-2 with level bookkeeping and nnratio.
  * occupied[g] != 0 where F.mvpMapPoints[g] already holds an observed point (may be NULL). */

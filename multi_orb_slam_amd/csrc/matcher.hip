@@ -276,7 +276,8 @@ constexpr int RESOLVE_K = 6;
 __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap,
                                                  int gate_right, int with_dist, int transposed, int* __restrict__ cand_idx,
                                                  uint16_t* __restrict__ cand_dist, int* __restrict__ cand_count,
-                                                 const uint8_t* __restrict__ occupied, int* __restrict__ topk, int short_th) {
+                                                 const uint8_t* __restrict__ occupied, int* __restrict__ topk, int short_th,
+                                                 const float* __restrict__ inv_sigma2 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (qi >= nq) return;
@@ -341,9 +342,21 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
                     const float distx = F.un_x[g] - x, disty = F.un_y[g] - y;
                     pass = fabsf(distx) < r && fabsf(disty) < r;
                 }
-                if (pass && gate_right) {
+                if (pass && gate_right == 1) {
                     const float urg = F.uright[g];
-                    if (urg > 0 && fabsf(ur - urg) > r) pass = false;
+                    if (urg > 0 && fabsf(ur - urg) > r) pass = false;   // a NaN `ur` never closes this gate
+                }
+                if (pass && gate_right == 2) {   // Fuse's reprojection-error gate (src/ORBmatcher.cc:2118-2143)
+                    const float kpr = F.uright[g];
+                    const float ex = x - F.un_x[g], ey = y - F.un_y[g];
+                    if (kpr >= 0) {
+                        const float er = ur - kpr;
+                        const float e2 = ex * ex + ey * ey + er * er;
+                        if ((double)(e2 * inv_sigma2[F.octave[g]]) > 7.8) pass = false;
+                    } else {
+                        const float e2 = ex * ex + ey * ey;
+                        if ((double)(e2 * inv_sigma2[F.octave[g]]) > 5.99) pass = false;
+                    }
                 }
                 const unsigned long long mask = __ballot(pass);
                 const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
@@ -1836,7 +1849,8 @@ int orbm_frame_grid(const orbm_frame* f, int32_t* cell_start, int32_t* items) {
 // k_project into m->d_i0 (idx) / d_u16 (dist) / d_i1 (count); optionally copied to the pinned host mirrors
 static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap, int gate_right,
                        int with_dist, bool upload_queries, bool to_host, int transposed = 0,
-                       const uint8_t* d_occupied = nullptr, int* d_topk = nullptr, int short_th = 256) {
+                       const uint8_t* d_occupied = nullptr, int* d_topk = nullptr, int short_th = 256,
+                       const float* d_inv_sigma2 = nullptr) {
     int rc;
     if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_i0.reserve((size_t)nq * cap)) ||
         (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)))
@@ -1845,7 +1859,7 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, q, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_project, dim3((nq + 3) / 4), dim3(256), 0, m->stream, f->dev(),
                        (const orbm_query*)m->d_queries.p, nq, cap, gate_right, with_dist, transposed, m->d_i0.p, m->d_u16.p,
-                       m->d_i1.p, d_occupied, d_topk, short_th);
+                       m->d_i1.p, d_occupied, d_topk, short_th, d_inv_sigma2);
     MORB_HIP(hipGetLastError());
     if (to_host) {
         if ((rc = m->h_i0.reserve((size_t)nq * cap)) || (rc = m->h_u16.reserve((size_t)nq * cap)) || (rc = m->h_i1.reserve(nq)))
@@ -1907,6 +1921,41 @@ int orbm_project_candidates(orbm_matcher* m, const orbm_frame* f, const orbm_que
     memcpy(cand_idx, m->h_i0.p, (size_t)nq * cap_per_query * 4);
     memcpy(cand_dist, m->h_u16.p, (size_t)nq * cap_per_query * 2);
     if (overflow) { morb::set_error("candidate list longer than cap_per_query=%d", cap_per_query); return ORB_E_CAPACITY; }
+    return ORB_OK;
+}
+
+int orbm_project_best(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, const uint8_t* occupied, int gate,
+                      const float* inv_level_sigma2, int n_levels, int32_t* best_idx, int32_t* best_dist) {
+    MORB_ARG(m && f && nq >= 0 && gate >= 0 && gate <= 2);
+    if (nq == 0) return ORB_OK;
+    MORB_ARG(q && best_idx && best_dist);
+    MORB_ARG(gate != ORBM_GATE_CHI2 || (inv_level_sigma2 && n_levels > 0 && n_levels <= 64));
+    MORB_HIP(hipSetDevice(m->device));
+    const int n = f->n_total;
+    if (n == 0) { for (int i = 0; i < nq; ++i) { best_idx[i] = -1; best_dist[i] = 256; } return ORB_OK; }
+    int rc;
+    if ((rc = m->d_claim.reserve((size_t)(2 * RESOLVE_K + 1) * nq)) || (rc = m->d_occ.reserve(std::max(n, 16) + 512)) ||
+        (rc = m->h_i2.reserve((size_t)2 * nq)))
+        return rc;
+    if (occupied) MORB_HIP(hipMemcpyAsync(m->d_occ.p, occupied, (size_t)n, hipMemcpyHostToDevice, m->stream));
+    float* d_sig = nullptr;
+    if (gate == ORBM_GATE_CHI2) {   // the level table rides behind the occupied bytes
+        if (ensure_host_copies(f)) return ORB_E_HIP;
+        for (int g = 0; g < n; ++g) MORB_ARG(f->octave[g] >= 0 && f->octave[g] < n_levels);
+        d_sig = (float*)(m->d_occ.p + ((std::max(n, 16) + 15) & ~15));
+        MORB_HIP(hipMemcpyAsync(d_sig, inv_level_sigma2, (size_t)n_levels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    }
+    // the sorted shortlist k_project keeps per query (distance << 16 | visiting position) starts with exactly the candidate
+    // the reference's `if (dist < bestDist)` loop ends on: smallest distance, first in visiting order
+    if ((rc = run_project(m, f, q, nq, /*cap=*/64, gate, 1, true, false, /*transposed=*/1, occupied ? m->d_occ.p : nullptr, m->d_claim.p, 256, d_sig)))
+        return rc;
+    MORB_HIP(hipMemcpyAsync(m->h_i2.p, m->d_claim.p, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+    MORB_HIP(hipMemcpyAsync(m->h_i2.p + nq, m->d_claim.p + (size_t)RESOLVE_K * nq, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+    MORB_HIP(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < nq; ++i) {
+        const int key = m->h_i2.p[i], g = m->h_i2.p[nq + i];
+        best_idx[i] = g; best_dist[i] = g >= 0 ? (key >> 16) : 256;
+    }
     return ORB_OK;
 }
 

@@ -224,6 +224,17 @@ class Matcher:
                                                C.byref(n)))
         return out[:n.value].copy()
 
+    def project_best(self, frame, queries, occupied=None, gate=0, inv_level_sigma2=None):
+        """Nearest candidate of every projected point on its own (orbm_project_best: the inner loop of SearchBySim3 / Fuse).
+        gate 0 none, 1 right-coordinate window, 2 Fuse's chi-square gate (needs inv_level_sigma2)."""
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE); nq = len(queries)
+        bi, bd = np.zeros(max(nq, 1), np.int32), np.zeros(max(nq, 1), np.int32)
+        occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        sg = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        check(_lib.lib().orbm_project_best(self._h, frame._h, ptr(queries), nq, None if occ is None else ptr(occ), gate,
+                                           None if sg is None else ptr(sg), 0 if sg is None else len(sg), ptr(bi), ptr(bd)))
+        return bi[:nq], bd[:nq]
+
     def project_candidates(self, frame, queries, cap):
         queries = np.ascontiguousarray(queries, QUERY_DTYPE); nq = len(queries)
         idx = np.zeros((max(nq, 1), cap), np.int32); dist = np.zeros((max(nq, 1), cap), np.uint16)

@@ -991,6 +991,44 @@ int orc_search_by_projection_frames(const orc_frame* cur, const orc_query* q, in
     return nmatches;
 }
 
+// f4  the inner loop shared by SearchBySim3 (ORBmatcher.cc:2814-3135) and Fuse (:1986-2509): nearest candidate of every
+// projected point on its own (no claims).  gate 0: none; 1: the tracking right-coordinate window (:3571-3577);
+// 2: Fuse's reprojection-error gate (:2118-2143) with q.ur = the projected right coordinate.
+void orc_project_best(const orc_frame* cur, const orc_query* q, int nq, const uint8_t* occupied, int gate, const float* inv_sigma2,
+                      int* best_idx, int* best_dist) {
+    FrameView F; make_view(cur, F);
+    std::vector<int> cand;
+    for (int i = 0; i < nq; i++) {
+        const orc_query& Q = q[i];
+        features_in_area(F, Q.cam, Q.u, Q.v, Q.radius, Q.min_level, Q.max_level, cand);
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : cand) {
+            if (occupied && occupied[idx]) continue;
+            if (gate == 1 && F.uright[idx] > 0) {
+                const float er = std::fabs(Q.ur - F.uright[idx]);
+                if (er > Q.radius) continue;
+            }
+            if (gate == 2) {
+                const float kpx = F.un_x[idx], kpy = F.un_y[idx], kpr = F.uright[idx];
+                const int kpLevel = F.octave[idx];
+                const float ex = Q.u - kpx, ey = Q.v - kpy;
+                if (kpr >= 0) {
+                    const float er = Q.ur - kpr;
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const uint8_t* d = F.desc[Q.cam] + (size_t)F.local_of[idx] * 32;
+            const int dist = descriptor_distance(Q.desc, d);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist;
+    }
+}
+
 // a11  ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)  (ORBmatcher.cc:62-149).
 // Query fields: u,v = mTrackProjX/Y; radius = r*mvScaleFactors[level] (:82-89); ur = mTrackProjXR;
 // min_level/max_level = level-1, level; cam = 0 (camera-1 grid only, Frame.cc:510-563); blocks as above.

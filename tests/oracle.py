@@ -64,6 +64,7 @@ def lib():
                                                          C.c_void_p]
         _lib.orc_search_by_projection_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
                                                          C.c_int, C.c_void_p]
+        _lib.orc_project_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_vocab_create.restype = C.c_void_p
         _lib.orc_vocab_create.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4
         _lib.orc_vocab_destroy.argtypes = [C.c_void_p]
@@ -303,6 +304,15 @@ def features_in_area(frame, cam, x, y, r, min_level=-1, max_level=-1):
     out = np.zeros(max(frame.n_total, 1), np.int32)
     n = lib().orc_features_in_area(frame.ptr(), cam, x, y, r, min_level, max_level, _p(out), len(out))
     return out[:n].copy()
+
+
+def project_best(frame, queries, occupied=None, gate=0, inv_sigma2=None):
+    queries = np.ascontiguousarray(queries, QUERY_DTYPE); nq = len(queries)
+    bi, bd = np.zeros(max(nq, 1), np.int32), np.zeros(max(nq, 1), np.int32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    sg = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+    lib().orc_project_best(frame.ptr(), _p(queries), nq, None if occ is None else _p(occ), gate, None if sg is None else _p(sg), _p(bi), _p(bd))
+    return bi[:nq], bd[:nq]
 
 
 def search_by_projection_frames(frame, queries, th_high=100, check_ori=True, occupied=None):

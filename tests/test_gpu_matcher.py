@@ -286,3 +286,52 @@ def test_cross_top2_from_a_gathered_buffer(world, cams_per_rank):
             off += nc
         assert off == len(bi)
     matcher.close()
+
+
+@pytest.mark.parametrize("n_per_cam,nq,th,seed", [([1000, 1000], 2000, 7.5, 1), ([2000], 3000, 4.0, 2), ([300, 200, 250], 900, 10.0, 3)])
+def test_project_best_equals_oracle(matcher, n_per_cam, nq, th, seed):
+    """orbm_project_best: the independent nearest-candidate loop of SearchBySim3 (gate none) and Fuse (chi-square gate)."""
+    import multi_orb_slam_amd as m
+    fr = helpers.make_frame_arrays(n_per_cam, 640, 480, seed)
+    q = helpers.make_queries(fr, nq, seed + 70, th=th)
+    lvl = np.maximum(q["max_level"], 0)
+    q["min_level"] = lvl - 1; q["max_level"] = lvl
+    n = len(fr["un_x"])
+    occ = (helpers.rand_unit(n, seed + 5) < 0.25).astype(np.uint8)
+    sg = (1.0 / (np.float32(1.2) ** np.arange(8)) ** 2).astype(np.float32)
+    F = matcher.frame(m.FrameData(**fr)); OF = oracle.FrameData(**fr)
+    found = 0
+    for gate in (0, 1, 2):
+        for o in (None, occ):
+            bi, bd = matcher.project_best(F, q, o, gate, sg)
+            obi, obd = oracle.project_best(OF, q, o, gate, sg)
+            assert np.array_equal(bi, obi) and np.array_equal(bd, obd), (gate, o is None)
+            found += int((bi >= 0).sum())
+    assert found > nq
+    bi, bd = matcher.project_best(F, q[:0], None, 0, None)
+    assert len(bi) == 0
+    with pytest.raises(m.OrbError):
+        matcher.project_best(F, q, None, 2, None)        # chi-square gate without its level table
+    F.close()
+
+
+@pytest.mark.parametrize("th_high,check_ori", [(100, True), (64, True), (50, False)])
+def test_relocalisation_and_loop_style_searches(matcher, th_high, check_ori):
+    """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (reference :3809-3946) and the loop overload
+    (:753-867) on the tracking primitive: no right-coordinate gate (ur = NaN), every claim blocks, pre-assigned features
+    hidden, ORBdist / TH_LOW as the acceptance threshold, histogram on or off."""
+    import multi_orb_slam_amd as m
+    fr = helpers.make_frame_arrays([1500], 640, 480, 11)
+    q = helpers.make_queries(fr, 1800, 31, th=10.0, blocks=1)
+    q["ur"] = np.nan; q["cam"] = 0
+    lvl = np.maximum(q["max_level"], 0)
+    q["min_level"] = lvl - 1; q["max_level"] = lvl + (1 if check_ori else 0)
+    occ = (helpers.rand_unit(1500, 17) < 0.3).astype(np.uint8)
+    F = matcher.frame(m.FrameData(**fr)); OF = oracle.FrameData(**fr)
+    matcher.check_orientation = check_ori
+    n, mo = matcher.SearchByProjection(F, q, th_high, occ)
+    on, omo = oracle.search_by_projection_frames(OF, q, th_high, check_ori, occ)
+    matcher.check_orientation = True
+    assert n == on and np.array_equal(mo, omo) and n > 100
+    assert not np.any((mo >= 0) & (occ != 0))
+    F.close()

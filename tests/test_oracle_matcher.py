@@ -137,3 +137,59 @@ def test_product_grid_host_code_matches_oracle_without_gpu():
     fd = m.FrameData.from_cameras([(k0, synth.descriptors(3, 1)), (k1, synth.descriptors(2, 2))], 640, 480)
     assert fd.n_total == 5 and fd.cam_of.tolist() == [0, 0, 0, 1, 1] and fd.local_of.tolist() == [0, 1, 2, 0, 1]
     assert fd.un_x.tolist() == [1, 2, 3, 7, 8]
+
+
+def _py_project_best(fr, q, occupied, gate, inv_sigma2):
+    """Second restatement of the nearest-candidate loop of SearchBySim3 / Fuse (ORBmatcher.cc:2105-2160) in Python floats."""
+    f32 = np.float32
+    OF = oracle.FrameData(**fr)
+    alld = np.concatenate(fr["descs"])
+    bi, bd = [], []
+    for i in range(len(q)):
+        cand = oracle.features_in_area(OF, int(q["cam"][i]), float(q["u"][i]), float(q["v"][i]), float(q["radius"][i]),
+                                       int(q["min_level"][i]), int(q["max_level"][i]))
+        best, bidx = 256, -1
+        for g in cand:
+            if occupied is not None and occupied[g]:
+                continue
+            kpr = f32(fr["uright"][g])
+            if gate == 1 and kpr > 0 and abs(f32(q["ur"][i]) - kpr) > q["radius"][i]:
+                continue
+            if gate == 2:
+                ex, ey = f32(q["u"][i] - fr["un_x"][g]), f32(q["v"][i] - fr["un_y"][g])
+                if kpr >= 0:
+                    er = f32(q["ur"][i] - kpr)
+                    e2 = f32(f32(f32(ex * ex) + f32(ey * ey)) + f32(er * er))
+                    if float(f32(e2 * inv_sigma2[fr["octave"][g]])) > 7.8:
+                        continue
+                else:
+                    e2 = f32(f32(ex * ex) + f32(ey * ey))
+                    if float(f32(e2 * inv_sigma2[fr["octave"][g]])) > 5.99:
+                        continue
+            d = oracle.descriptor_distance(q["desc"][i], alld[g])
+            if d < best:
+                best, bidx = d, int(g)
+        bi.append(bidx); bd.append(best)
+    return np.array(bi, np.int32), np.array(bd, np.int32)
+
+
+def test_project_best_matches_python_restatement():
+    import helpers
+    fr = helpers.make_frame_arrays([400, 300], 640, 480, 3)
+    q = helpers.make_queries(fr, 300, 9, th=6.0)
+    q["min_level"] = np.maximum(q["max_level"], 0) - 1; q["max_level"] = q["min_level"] + 1   # Fuse's nPredictedLevel-1 .. nPredictedLevel
+    occ = (helpers.rand_unit(700, 5) < 0.2).astype(np.uint8)
+    sg = (1.0 / (np.float32(1.2) ** np.arange(8)) ** 2).astype(np.float32)
+    OF = oracle.FrameData(**fr)
+    hits = 0
+    for gate in (0, 1, 2):
+        for o in (None, occ):
+            bi, bd = oracle.project_best(OF, q, o, gate, sg)
+            pi, pd = _py_project_best(fr, q, o, gate, sg)
+            assert np.array_equal(bi, pi) and np.array_equal(bd, pd), gate
+            hits += int((bi >= 0).sum())
+    assert hits > 200
+    # a NaN right coordinate never closes the tracking gate: gate 1 with NaN == gate 0
+    qn = q.copy(); qn["ur"] = np.nan
+    a = oracle.project_best(OF, qn, None, 1, None); b = oracle.project_best(OF, q, None, 0, None)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
