@@ -71,6 +71,18 @@ void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& i
 
 namespace {
 
+// MORB_DUMP_QUERIES=<file> (tests): appends {count, queries, index of each query's point in the caller's vector}
+void dump_queries(const std::vector<orbm_query>& q, const std::vector<int>& src) {
+    const char* path = std::getenv("MORB_DUMP_QUERIES");
+    if (!path) return;
+    FILE* f = std::fopen(path, "ab");
+    if (!f) return;
+    const int n = (int)q.size();
+    std::fwrite(&n, 4, 1, f);
+    if (n) { std::fwrite(q.data(), sizeof(orbm_query), n, f); std::fwrite(src.data(), 4, n, f); }
+    std::fclose(f);
+}
+
 struct FlatFrame {  // orbm_frame_desc backing store built from a Frame
     std::vector<float> x, y, ang, ur;
     std::vector<int32_t> oct, cam, loc;
@@ -78,7 +90,8 @@ struct FlatFrame {  // orbm_frame_desc backing store built from a Frame
     orbm_frame_desc d;
 };
 
-void flatten(const Frame& F, bool cam1_only, FlatFrame& ff) {
+template <class FrameOrKeyFrame>
+void flatten(const FrameOrKeyFrame& F, bool cam1_only, FlatFrame& ff) {
     const int n = cam1_only ? F.N : F.N_total;
     ff.x.resize(n); ff.y.resize(n); ff.ang.resize(n); ff.ur.resize(n); ff.oct.resize(n); ff.cam.resize(n); ff.loc.resize(n);
     const std::vector<cv::KeyPoint>& kun = cam1_only ? F.mvKeysUn : F.mvKeysUn_total;
@@ -126,6 +139,300 @@ void flatten_side(const F& f, const std::vector<cv::KeyPoint>& keys, const DBoW2
 }
 
 }  // namespace
+
+// reference src/ORBmatcher.cc:3809-3946 (relocalisation).  Candidates come from the camera-1 grid, no right-coordinate
+// gate, any MapPoint already in the frame hides its feature, every accepted match does too.
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th,
+                                   const int ORBdist) {
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat Ow = -Rcw.t() * tcw;
+    const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches_cam1();
+    std::vector<orbm_query> q;
+    std::vector<MapPoint*> qmp;
+    std::vector<int> qsrc;
+    for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
+        MapPoint* pMP = vpMPs[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+        cv::Mat x3Dw = pMP->GetWorldPos();
+        cv::Mat x3Dc = Rcw * x3Dw + tcw;
+        const float xc = x3Dc.at<float>(0);
+        const float yc = x3Dc.at<float>(1);
+        const float invzc = 1.0 / x3Dc.at<float>(2);
+        const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+        const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+        cv::Mat PO = x3Dw - Ow;
+        float dist3D = cv::norm(PO);
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+        const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
+        orbm_query Q;
+        Q.u = u; Q.v = v; Q.radius = radius; Q.ur = std::nanf("");
+        Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel + 1;
+        Q.cam = 0; Q.blocks = 1;
+        Q.angle = pKF->mvKeysUn[i].angle;
+        const cv::Mat dMP = pMP->GetDescriptor();
+        std::memcpy(Q.desc, dMP.ptr(0), 32);
+        q.push_back(Q); qmp.push_back(pMP); qsrc.push_back((int)i);
+    }
+    dump_queries(q, qsrc);
+    FlatFrame ff;
+    flatten(CurrentFrame, /*cam1_only=*/true, ff);
+    std::vector<uint8_t> occupied(CurrentFrame.N > 0 ? CurrentFrame.N : 1, 0);
+    for (int g = 0; g < CurrentFrame.N; ++g) occupied[g] = CurrentFrame.mvpMapPoints[g] ? 1 : 0;   // :3881
+    orbm_frame* fr = nullptr;
+    int rc = orbm_frame_create(Handle(), &ff.d, &fr);
+    if (rc) die("orbm_frame_create", rc);
+    std::vector<int32_t> match(occupied.size());
+    int nmatches = 0;
+    rc = orbm_search_by_projection(Handle(), fr, q.data(), (int)q.size(), occupied.data(), ORBdist, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
+    orbm_frame_destroy(fr);
+    if (rc) die("orbm_search_by_projection", rc);
+    for (int g = 0; g < CurrentFrame.N; ++g) {
+        if (match[g] >= 0) CurrentFrame.mvpMapPoints[g] = qmp[match[g]];
+        else if (match[g] == -2) CurrentFrame.mvpMapPoints[g] = NULL;   // :3936
+    }
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:753-867 (loop closing, camera 1)
+int ORBmatcher::SearchByProjection_cam1(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th) {
+    const float& fx = pKF->fx; const float& fy = pKF->fy; const float& cx = pKF->cx; const float& cy = pKF->cy;
+    // Decompose Scw
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+    std::vector<orbm_query> q;
+    std::vector<MapPoint*> qmp;
+    std::vector<int> qsrc;
+    for (int iMP = 0, iendMP = (int)vpPoints.size(); iMP < iendMP; iMP++) {
+        MapPoint* pMP = vpPoints[iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0) continue;
+        const float invz = 1 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz;
+        const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist = cv::norm(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist) continue;
+        int nPredictedLevel = pMP->PredictScale(dist, pKF);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        orbm_query Q;
+        Q.u = u; Q.v = v; Q.radius = radius; Q.ur = std::nanf("");
+        Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;   // :833-836
+        Q.cam = 0; Q.blocks = 1; Q.angle = 0;
+        const cv::Mat dMP = pMP->GetDescriptor();
+        std::memcpy(Q.desc, dMP.ptr(0), 32);
+        q.push_back(Q); qmp.push_back(pMP); qsrc.push_back(iMP);
+    }
+    dump_queries(q, qsrc);
+    FlatFrame ff;
+    flatten(*pKF, /*cam1_only=*/true, ff);
+    std::vector<uint8_t> occupied(pKF->N > 0 ? pKF->N : 1, 0);
+    for (int g = 0; g < pKF->N; ++g) occupied[g] = vpMatched[g] ? 1 : 0;    // :829
+    orbm_frame* fr = nullptr;
+    int rc = orbm_frame_create(Handle(), &ff.d, &fr);
+    if (rc) die("orbm_frame_create", rc);
+    std::vector<int32_t> match(occupied.size());
+    int nmatches = 0;
+    rc = orbm_search_by_projection(Handle(), fr, q.data(), (int)q.size(), occupied.data(), TH_LOW, 0, match.data(), &nmatches);
+    orbm_frame_destroy(fr);
+    if (rc) die("orbm_search_by_projection", rc);
+    for (int g = 0; g < pKF->N; ++g)
+        if (match[g] >= 0) vpMatched[g] = qmp[match[g]];
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:3137-3447: each keyframe's map points projected into the other one through the Sim3, nearest
+// descriptor per point on its own (orbm_project_best), then the mutual-agreement check
+int ORBmatcher::SearchBySim3_cam1(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
+                                  const cv::Mat& t12, const float th) {
+    const float& fx = pKF1->fx; const float& fy = pKF1->fy; const float& cx = pKF1->cx; const float& cy = pKF1->cy;
+    cv::Mat R1w = pKF1->GetRotation(), t1w = pKF1->GetTranslation(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+    cv::Mat sR12 = s12 * R12;
+    cv::Mat sR21 = (1.0 / s12) * R12.t();
+    cv::Mat t21 = -sR21 * t12;
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches_cam1();
+    const int N1 = (int)vpMapPoints1.size();
+    const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches_cam1();
+    const int N2 = (int)vpMapPoints2.size();
+    std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+    for (int i = 0; i < N1; i++) {
+        MapPoint* pMP = vpMatches12[i];
+        if (pMP) {
+            vbAlreadyMatched1[i] = true;
+            int idx2 = pMP->GetIndexInKeyFrame_cam1(pKF2);
+            if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+        }
+    }
+    std::vector<int> vnMatch1(N1, -1), vnMatch2(N2, -1);
+    // one direction: map points of `from` into `to`
+    auto direction = [&](KeyFrame* to, const std::vector<MapPoint*>& pts, const std::vector<bool>& already, const cv::Mat& Rw, const cv::Mat& tw,
+                         const cv::Mat& sR, const cv::Mat& t, std::vector<int>& out) {
+        std::vector<orbm_query> q; std::vector<int> src;
+        for (int i = 0; i < (int)pts.size(); i++) {
+            MapPoint* pMP = pts[i];
+            if (!pMP || already[i]) continue;
+            if (pMP->isBad()) continue;
+            cv::Mat p3Dw = pMP->GetWorldPos();
+            cv::Mat p3Da = Rw * p3Dw + tw;
+            cv::Mat p3Db = sR * p3Da + t;
+            if (p3Db.at<float>(2) < 0.0) continue;
+            const float invz = 1.0 / p3Db.at<float>(2);
+            const float x = p3Db.at<float>(0) * invz;
+            const float y = p3Db.at<float>(1) * invz;
+            const float u = fx * x + cx;
+            const float v = fy * y + cy;
+            if (!to->IsInImage(u, v)) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            const float dist3D = cv::norm(p3Db);
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            const int nPredictedLevel = pMP->PredictScale(dist3D, to);
+            const float radius = th * to->mvScaleFactors[nPredictedLevel];
+            orbm_query Q;
+            Q.u = u; Q.v = v; Q.radius = radius; Q.ur = std::nanf("");
+            Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;
+            Q.cam = 0; Q.blocks = 0; Q.angle = 0;
+            const cv::Mat dMP = pMP->GetDescriptor();
+            std::memcpy(Q.desc, dMP.ptr(0), 32);
+            q.push_back(Q); src.push_back(i);
+        }
+        dump_queries(q, src);
+        if (q.empty()) return;
+        FlatFrame ff;
+        flatten(*to, /*cam1_only=*/true, ff);
+        orbm_frame* fr = nullptr;
+        int rc = orbm_frame_create(Handle(), &ff.d, &fr);
+        if (rc) die("orbm_frame_create", rc);
+        std::vector<int32_t> bi(q.size()), bd(q.size());
+        rc = orbm_project_best(Handle(), fr, q.data(), (int)q.size(), nullptr, ORBM_GATE_NONE, nullptr, 0, bi.data(), bd.data());
+        orbm_frame_destroy(fr);
+        if (rc) die("orbm_project_best", rc);
+        for (size_t k = 0; k < q.size(); ++k)
+            if (bi[k] >= 0 && bd[k] <= TH_HIGH) out[src[k]] = bi[k];
+    };
+    direction(pKF2, vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, vnMatch1);   // :3208-3302
+    direction(pKF1, vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, vnMatch2);   // :3306-3403
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {
+        int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { vpMatches12[i1] = vpMapPoints2[idx2]; nFound++; }
+        }
+    }
+    return nFound;
+}
+
+// reference src/ORBmatcher.cc:1986-2210: every map point projected into both cameras of the keyframe, nearest descriptor
+// under the reprojection-error gate (orbm_project_best, ORBM_GATE_CHI2); the merge / replace bookkeeping stays host code
+int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const cv::Mat CalibMatrix, const float th) {
+    cv::Mat Rcw = pKF->GetRotation();
+    cv::Mat tcw = pKF->GetTranslation();
+    const float& fx = pKF->fx; const float& fy = pKF->fy; const float& cx = pKF->cx; const float& cy = pKF->cy; const float& bf = pKF->mbf;
+    const cv::Mat Rcam12 = CalibMatrix.rowRange(0, 3).colRange(0, 3);
+    cv::Mat tcam12(3, 1, CV_32F);
+    tcam12.at<float>(0, 0) = CalibMatrix.at<float>(3, 0);
+    tcam12.at<float>(1, 0) = CalibMatrix.at<float>(3, 1);
+    tcam12.at<float>(2, 0) = CalibMatrix.at<float>(3, 2);
+    const cv::Mat Rcam21 = Rcam12.inv();
+    const cv::Mat tcam21 = -Rcam21 * tcam12;
+    cv::Mat Ow[2] = {pKF->GetCameraCenter(), pKF->GetCameraCenter_cam2()};
+    const int nMPs = (int)vpMapPoints.size();
+    std::vector<orbm_query> q; std::vector<int> src;
+    // IsInKeyFrame(pKF) changes while the reference's loop runs (AddObservation below): it is re-checked in the merge pass
+    for (int i = 0; i < nMPs; i++) {
+        MapPoint* pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad()) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc;
+        for (int cam = 0; cam < 2; cam++) {
+            if (cam == 0) p3Dc = Rcw * p3Dw + tcw;
+            else p3Dc = Rcam21 * Rcw * p3Dw + Rcam21 * tcw + tcam21;
+            if (p3Dc.at<float>(2) < 0.0f) continue;
+            const float invz = 1 / p3Dc.at<float>(2);
+            const float x = p3Dc.at<float>(0) * invz;
+            const float y = p3Dc.at<float>(1) * invz;
+            const float u = fx * x + cx;
+            const float v = fy * y + cy;
+            if (!pKF->IsInImage(u, v)) continue;
+            const float ur = u - bf * invz;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            cv::Mat PO = p3Dw - Ow[cam];
+            const float dist3D = cv::norm(PO);
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            cv::Mat Pn = pMP->GetNormal();
+            if (PO.dot(Pn) < 0.5 * dist3D) continue;
+            int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+            const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+            orbm_query Q;
+            Q.u = u; Q.v = v; Q.radius = radius; Q.ur = ur;
+            Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;
+            Q.cam = cam; Q.blocks = 0; Q.angle = 0;
+            const cv::Mat dMP = pMP->GetDescriptor();
+            std::memcpy(Q.desc, dMP.ptr(0), 32);
+            q.push_back(Q); src.push_back(i);
+        }
+    }
+    dump_queries(q, src);
+    std::vector<int32_t> bi(q.size() ? q.size() : 1, -1), bd(q.size() ? q.size() : 1, 256);
+    if (!q.empty()) {
+        FlatFrame ff;
+        flatten(*pKF, /*cam1_only=*/false, ff);
+        orbm_frame* fr = nullptr;
+        int rc = orbm_frame_create(Handle(), &ff.d, &fr);
+        if (rc) die("orbm_frame_create", rc);
+        rc = orbm_project_best(Handle(), fr, q.data(), (int)q.size(), nullptr, ORBM_GATE_CHI2, pKF->mvInvLevelSigma2.data(),
+                               (int)pKF->mvInvLevelSigma2.size(), bi.data(), bd.data());
+        orbm_frame_destroy(fr);
+        if (rc) die("orbm_project_best", rc);
+    }
+    // merge pass in the reference's order: point by point, camera 1 then camera 2 (:2165-2195)
+    int nFused = 0;
+    size_t k = 0;
+    for (int i = 0; i < nMPs; i++) {
+        const size_t k0 = k;
+        while (k < q.size() && src[k] == i) ++k;
+        MapPoint* pMP = vpMapPoints[i];
+        if (k0 == k || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;   // :2020-2023 (Replace / AddObservation earlier in this call count)
+        for (size_t f = k0; f < k; ++f) {
+            if (bi[f] < 0 || bd[f] > TH_LOW) continue;
+            MapPoint* pMPinKF = pKF->GetMapPoint(bi[f]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bi[f]);
+                pKF->AddMapPoint(pMP, bi[f]);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
+}
 
 // reference src/ORBmatcher.cc:206-388
 int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {

@@ -1,13 +1,17 @@
 // ORBmatcher.h -- drop-in for the hot subset of the reference's include/ORBmatcher.h:37-137: constructor defaults,
 // static DescriptorDistance, the two tracking SearchByProjection overloads, the two SearchByBoW overloads,
-// SearchForTriangulation, the public constants and the public mRcam21 / mtcam21 scratch.  Candidate gathering and Hamming distances run in libmorb.so's HIP kernels
+// SearchForTriangulation, the relocalisation / loop-closing SearchByProjection overloads, SearchBySim3_cam1, Fuse(KF, points),
+// the public constants and the public mRcam21 / mtcam21 scratch.  Candidate gathering and Hamming distances run in libmorb.so's HIP kernels
 // (include/orbm.h); the 3-D projection of map points and the order-dependent accept/overwrite/histogram logic stay on
-// the host exactly where the reference has them; the BoW-gated searches run whole on the device (include/orbv.h).  The
-// remaining projection searches (Fuse, SearchBySim3, loop/relocalisation SearchByProjection: SURVEY section 8 f4) are not
-// part of this round.
+// the host exactly where the reference has them; the BoW-gated searches run whole on the device (include/orbv.h).  Of
+// the remaining overloads the Sim3 Fuse, the two-camera loop SearchByProjection, the two-camera
+// SearchBySim3 and SearchForInitialization are not part of this round (same device primitives, different host loops).
+// MORB_DUMP_QUERIES=<file>: every projection search appends the queries it built (int32 count + orbm_query records), so a
+// test can hold the device result against the oracle on exactly those queries.
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
+#include <set>
 #include <vector>
 #include "cv_compat.h"
 #include "slam_types.h"
@@ -35,6 +39,22 @@ public:
     // Used to track from previous frame (Tracking)
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono,
                            cv::Mat CalibMatrix);
+
+    // Project MapPoints seen in KeyFrame into the Frame and search matches.
+    // Used in relocalisation (Tracking)
+    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist);
+
+    // Project MapPoints using a Similarity Transformation and search matches.
+    // Used in loop detection (Loop Closing)
+    int SearchByProjection_cam1(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th);
+
+    // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12]
+    // In the stereo and RGB-D case, s12=1
+    int SearchBySim3_cam1(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
+                          const cv::Mat& t12, const float th);
+
+    // Project MapPoints into KeyFrame and search for duplicated MapPoints.
+    int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const cv::Mat CalibMatrix, const float th = 3.0);
 
     // Search matches between MapPoints in a KeyFrame and ORB in a Frame.
     // Brute force constrained to ORB that belong to the same vocabulary node (at a certain level)

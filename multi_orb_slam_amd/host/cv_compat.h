@@ -6,6 +6,7 @@
 #include <opencv2/core/core.hpp>
 #else
 #include <cassert>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -90,6 +91,13 @@ public:
         }
         return D;
     }
+    // a.dot(b): products summed in double (cv::Mat::dot for CV_32F)
+    double dot(const Mat& b) const {
+        assert(type_ == CV_32F && rows * cols == b.rows * b.cols);
+        double s = 0;
+        for (int k = 0; k < rows * cols; ++k) s += (double)at<float>(k / cols, k % cols) * (double)b.at<float>(k / b.cols, k % b.cols);
+        return s;
+    }
     Mat t() const {
         assert(type_ == CV_32F);
         Mat m(cols, rows, CV_32F);
@@ -127,6 +135,27 @@ inline Mat operator-(const Mat& a) {
     Mat m(a.rows, a.cols, CV_32F);
     for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) m.at<float>(i, j) = -a.at<float>(i, j);
     return m;
+}
+
+inline Mat operator-(const Mat& a, const Mat& b) {
+    Mat m(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) m.at<float>(i, j) = a.at<float>(i, j) - b.at<float>(i, j);
+    return m;
+}
+// scaling by a scalar: cv::MatExpr evaluates alpha*M (and M/s as (1/s)*M) through convertTo, whose float->float path works in
+// float with alpha rounded to float
+inline Mat operator*(double alpha, const Mat& a) {
+    Mat m(a.rows, a.cols, CV_32F);
+    const float al = (float)alpha;
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) m.at<float>(i, j) = a.at<float>(i, j) * al;
+    return m;
+}
+inline Mat operator/(const Mat& a, double s) { return (1.0 / s) * a; }
+// L2 norm: squares summed in double, square root in double (cv::norm, NORM_L2, CV_32F)
+inline double norm(const Mat& a) {
+    double s = 0;
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) s += (double)a.at<float>(i, j) * (double)a.at<float>(i, j);
+    return std::sqrt(s);
 }
 
 typedef const Mat& InputArray;

@@ -5,7 +5,9 @@
 // reference's include/ on the include path).
 #pragma once
 #ifndef MORB_USE_REFERENCE_TYPES
+#include <cmath>
 #include <map>
+#include <set>
 #include <vector>
 #include "cv_compat.h"
 #include "ORBVocabulary.h"
@@ -14,6 +16,9 @@
 #define FRAME_GRID_COLS 64
 
 namespace ORB_SLAM2 {
+
+class KeyFrame;
+class Frame;
 
 class MapPoint {
 public:
@@ -27,8 +32,28 @@ public:
     int mnTrackScaleLevel = 0;
     float mTrackViewCos = 1.f;
 
+    // members the remaining projection searches read (src/MapPoint.cc:559-617)
+    cv::Mat GetNormal() { return mNormalVector; }
+    float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+    float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+    template <class FrameOrKeyFrame> int PredictScale(const float& currentDist, FrameOrKeyFrame* pF) {
+        const float ratio = mfMaxDistance / currentDist;
+        int nScale = (int)std::ceil(std::log(ratio) / pF->mfLogScaleFactor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+        return nScale;
+    }
+    bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }
+    int GetIndexInKeyFrame_cam1(KeyFrame* pKF) { auto it = mObservations.find(pKF); return it != mObservations.end() ? (int)it->second : -1; }
+    void AddObservation(KeyFrame* pKF, size_t idx) { if (mObservations.count(pKF)) return; mObservations[pKF] = idx; nObs++; }
+    void Replace(MapPoint* pMP) { if (pMP == this) return; mpReplaced = pMP; mbBad = true; }
+
     cv::Mat mWorldPos;    // 3x1 CV_32F
     cv::Mat mDescriptor;  // 1x32 CV_8U
+    cv::Mat mNormalVector;  // 3x1 CV_32F
+    float mfMinDistance = 0, mfMaxDistance = 0;
+    std::map<KeyFrame*, size_t> mObservations;
+    MapPoint* mpReplaced = nullptr;
     int nObs = 1;
     bool mbBad = false;
 };
@@ -50,6 +75,7 @@ public:
     float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;  // static members in the reference
     DBoW2::BowVector mBowVec;       // all cameras (include/Frame.h:185-187)
     DBoW2::FeatureVector mFeatVec;
+    float mfLogScaleFactor = 0; int mnScaleLevels = 0;
 };
 
 // KeyFrame members the BoW-gated searches read (include/KeyFrame.h:53-59, :104-113, :218-219 and the Frame copies of
@@ -77,6 +103,18 @@ public:
     cv::Mat mK;                      // 3x3 CV_32F
     float fx = 0, fy = 0, cx = 0, cy = 0;
     cv::Mat Tcw, Tcw_cam2;           // 4x4 CV_32F
+
+    // members the remaining projection searches read
+    std::vector<MapPoint*> GetMapPointMatches_cam1() { return std::vector<MapPoint*>(mvpMapPoints.begin(), mvpMapPoints.begin() + N); }
+    void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+    bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
+    int N = 0, N_cam2 = 0, N_total = 0;
+    std::vector<cv::KeyPoint> mvKeysUn;   // camera 1
+    std::vector<float> mvuRight;
+    cv::Mat mDescriptors;                 // camera 1
+    std::vector<float> mvInvLevelSigma2;
+    float mbf = 0, mfLogScaleFactor = 0; int mnScaleLevels = 0;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
 };
 
 }  // namespace ORB_SLAM2

@@ -3,8 +3,10 @@
 // oracle.  Binary I/O only: little-endian int32 / float32 / uint8 arrays.
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 #include "ORBextractor.h"
@@ -283,6 +285,94 @@ static int run_bow(int argc, char** argv) {
     return 0;
 }
 
+static void to_keyframe(const Frame& F, KeyFrame& K) {
+    K.N = F.N; K.N_cam2 = F.N_cam2; K.N_total = F.N_total;
+    K.mvKeysUn_total = F.mvKeysUn_total; K.mvKeysUn = F.mvKeysUn; K.mvuRight_total = F.mvuRight_total; K.mvuRight = F.mvuRight;
+    K.mDescriptors_total = F.mDescriptors_total; K.mDescriptors = F.mDescriptors;
+    K.keypoint_to_cam = F.keypoint_to_cam; K.cont_idx_to_local_cam_idx = F.cont_idx_to_local_cam_idx;
+    K.mvScaleFactors = F.mvScaleFactors;
+    K.mvLevelSigma2.clear(); K.mvInvLevelSigma2.clear();
+    for (float s : F.mvScaleFactors) { K.mvLevelSigma2.push_back(s * s); K.mvInvLevelSigma2.push_back(1.0f / (s * s)); }
+    K.fx = F.fx; K.fy = F.fy; K.cx = F.cx; K.cy = F.cy; K.mbf = F.mbf;
+    K.mnMinX = F.mnMinX; K.mnMinY = F.mnMinY; K.mnMaxX = F.mnMaxX; K.mnMaxY = F.mnMaxY;
+    K.Tcw = F.mTcw.clone(); K.Tcw_cam2 = F.mTcw.clone();
+    K.mfLogScaleFactor = F.mfLogScaleFactor; K.mnScaleLevels = F.mnScaleLevels;
+    K.mvpMapPoints.assign(F.N_total, nullptr);
+}
+
+// f4 <case.bin> <out.bin>: the remaining projection searches through the reference signatures.
+// [Cur][KA][KB][Tcw_cam2 of KB 16f][M points: xyz 3f, desc 32, normal 3f, mind f, maxd f, bad i, nobs i]
+// [ids of Cur (N_total i), KA (N_total i), KB (N_total i)][nfound, ids][nloop, ids][vpMatched init KA.N i][Scw 16f][th_loop i]
+// [s12 f][R12 9f][t12 3f][vpMatches12 init KA.N i][th_sim3 f][nfuse, ids][Calib 12f][th_fuse f][th_reloc f][ORBdist i][check_ori i]
+static int run_f4(int argc, char** argv) {
+    std::vector<unsigned char> buf = slurp(argv[2]);
+    Reader R{buf.data()};
+    Frame Cur, FA, FB;
+    read_frame(R, Cur); read_frame(R, FA); read_frame(R, FB);
+    for (Frame* F : {&Cur, &FA, &FB}) { F->mfLogScaleFactor = std::log(1.2f); F->mnScaleLevels = 8; }
+    KeyFrame KA, KB;
+    to_keyframe(FA, KA); to_keyframe(FB, KB);
+    { std::vector<float> T = R.arr<float>(16); for (int i = 0; i < 16; ++i) KB.Tcw_cam2.at<float>(i / 4, i % 4) = T[i]; }
+    const int M = R.get<int>();
+    std::vector<MapPoint> pool(M);
+    for (int i = 0; i < M; ++i) {
+        MapPoint& mp = pool[i];
+        std::vector<float> xyz = R.arr<float>(3);
+        mp.mWorldPos = cv::Mat(3, 1, CV_32F); for (int k = 0; k < 3; ++k) mp.mWorldPos.at<float>(k) = xyz[k];
+        mp.mDescriptor = cv::Mat(1, 32, CV_8U);
+        std::vector<unsigned char> d = R.arr<unsigned char>(32); std::memcpy(mp.mDescriptor.ptr(0), d.data(), 32);
+        std::vector<float> nv = R.arr<float>(3);
+        mp.mNormalVector = cv::Mat(3, 1, CV_32F); for (int k = 0; k < 3; ++k) mp.mNormalVector.at<float>(k) = nv[k];
+        mp.mfMinDistance = R.get<float>(); mp.mfMaxDistance = R.get<float>();
+        mp.mbBad = R.get<int>() != 0; mp.nObs = R.get<int>();
+    }
+    auto ids_to = [&](std::vector<MapPoint*>& v, int n, KeyFrame* owner) {
+        std::vector<int> ids = R.arr<int>(n);
+        v.assign(n, nullptr);
+        for (int g = 0; g < n; ++g) if (ids[g] >= 0) { v[g] = &pool[ids[g]]; if (owner) pool[ids[g]].mObservations[owner] = g; }
+    };
+    auto id_of = [&](MapPoint* p) { return p ? (int)(p - pool.data()) : -1; };
+    ids_to(Cur.mvpMapPoints, Cur.N_total, nullptr); ids_to(KA.mvpMapPoints, KA.N_total, &KA); ids_to(KB.mvpMapPoints, KB.N_total, &KB);
+    std::set<MapPoint*> found;
+    { int n = R.get<int>(); std::vector<int> ids = R.arr<int>(n); for (int i : ids) found.insert(&pool[i]); }
+    std::vector<MapPoint*> loop_pts;
+    { int n = R.get<int>(); std::vector<int> ids = R.arr<int>(n); for (int i : ids) loop_pts.push_back(&pool[i]); }
+    std::vector<MapPoint*> vpMatched; ids_to(vpMatched, KA.N, nullptr);
+    cv::Mat Scw(4, 4, CV_32F);
+    { std::vector<float> T = R.arr<float>(16); for (int i = 0; i < 16; ++i) Scw.at<float>(i / 4, i % 4) = T[i]; }
+    const int th_loop = R.get<int>();
+    const float s12 = R.get<float>();
+    cv::Mat R12(3, 3, CV_32F), t12(3, 1, CV_32F);
+    { std::vector<float> v = R.arr<float>(9); for (int i = 0; i < 9; ++i) R12.at<float>(i / 3, i % 3) = v[i]; }
+    { std::vector<float> v = R.arr<float>(3); for (int i = 0; i < 3; ++i) t12.at<float>(i) = v[i]; }
+    std::vector<MapPoint*> vpMatches12; ids_to(vpMatches12, KA.N, nullptr);
+    const float th_sim3 = R.get<float>();
+    std::vector<MapPoint*> fuse_pts;
+    { int n = R.get<int>(); std::vector<int> ids = R.arr<int>(n); for (int i : ids) fuse_pts.push_back(i >= 0 ? &pool[i] : nullptr); }
+    cv::Mat calib(4, 3, CV_32F);
+    { std::vector<float> cm = R.arr<float>(12); for (int i = 0; i < 12; ++i) calib.at<float>(i / 3, i % 3) = cm[i]; }
+    const float th_fuse = R.get<float>(), th_reloc = R.get<float>();
+    const int ORBdist = R.get<int>(), check_ori = R.get<int>();
+
+    FILE* f = std::fopen(argv[3], "wb");
+    ORBmatcher m(0.9f, check_ori != 0);
+    const int n1 = m.SearchByProjection(Cur, &KA, found, th_reloc, ORBdist);
+    put(f, &n1, 4);
+    for (int g = 0; g < Cur.N_total; ++g) { int id = id_of(Cur.mvpMapPoints[g]); put(f, &id, 4); }
+    const int n2 = m.SearchByProjection_cam1(&KA, Scw, loop_pts, vpMatched, th_loop);
+    put(f, &n2, 4);
+    for (int g = 0; g < KA.N; ++g) { int id = id_of(vpMatched[g]); put(f, &id, 4); }
+    const int n3 = m.SearchBySim3_cam1(&KA, &KB, vpMatches12, s12, R12, t12, th_sim3);
+    put(f, &n3, 4);
+    for (int g = 0; g < KA.N; ++g) { int id = id_of(vpMatches12[g]); put(f, &id, 4); }
+    const int n4 = m.Fuse(&KB, fuse_pts, calib, th_fuse);
+    put(f, &n4, 4);
+    for (int g = 0; g < KB.N_total; ++g) { int id = id_of(KB.mvpMapPoints[g]); put(f, &id, 4); }
+    for (int i = 0; i < M; ++i) { int rep = id_of(pool[i].mpReplaced), bad = pool[i].mbBad ? 1 : 0; put(f, &rep, 4); put(f, &bad, 4); }
+    std::fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: test_host extract|batch|match|bow ...\n"); return 1; }
     const std::string mode = argv[1];
@@ -290,6 +380,7 @@ int main(int argc, char** argv) {
     if (mode == "batch" && argc >= 9) return run_batch(argc, argv);
     if (mode == "match" && argc >= 4) return run_match(argc, argv);
     if (mode == "bow" && argc >= 4) return run_bow(argc, argv);
+    if (mode == "f4" && argc >= 4) return run_f4(argc, argv);
     std::fprintf(stderr, "bad arguments\n");
     return 1;
 }

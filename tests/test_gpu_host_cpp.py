@@ -28,6 +28,10 @@ def test_host_library_exports_reference_signatures():
                  "ORB_SLAM2::ORBmatcher::SearchByBoW(ORB_SLAM2::KeyFrame*, ORB_SLAM2::Frame&, std::vector<ORB_SLAM2::MapPoint*",
                  "ORB_SLAM2::ORBmatcher::SearchByBoW(ORB_SLAM2::KeyFrame*, ORB_SLAM2::KeyFrame*, std::vector<ORB_SLAM2::MapPoint*",
                  "ORB_SLAM2::ORBmatcher::SearchForTriangulation(ORB_SLAM2::KeyFrame*, ORB_SLAM2::KeyFrame*, cv::Mat, std::vector<std::pair<unsigned long, unsigned long>",
+                 "ORB_SLAM2::ORBmatcher::SearchByProjection(ORB_SLAM2::Frame&, ORB_SLAM2::KeyFrame*, std::set<ORB_SLAM2::MapPoint*",
+                 "ORB_SLAM2::ORBmatcher::SearchByProjection_cam1(ORB_SLAM2::KeyFrame*, cv::Mat, std::vector<ORB_SLAM2::MapPoint*",
+                 "ORB_SLAM2::ORBmatcher::SearchBySim3_cam1(ORB_SLAM2::KeyFrame*, ORB_SLAM2::KeyFrame*, std::vector<ORB_SLAM2::MapPoint*",
+                 "ORB_SLAM2::ORBmatcher::Fuse(ORB_SLAM2::KeyFrame*, std::vector<ORB_SLAM2::MapPoint*",
                  "ORB_SLAM2::ORBVocabulary::loadFromTextFile(std::", "ORB_SLAM2::ORBVocabulary::transform(std::vector<cv::Mat",
                  "ORB_SLAM2::ORBVocabulary::score(DBoW2::BowVector const&, DBoW2::BowVector const&)",
                  "ORB_SLAM2::ORBmatcher::TH_HIGH", "ORB_SLAM2::ORBmatcher::TH_LOW", "ORB_SLAM2::ORBmatcher::HISTO_LENGTH"):
@@ -306,3 +310,218 @@ def test_cpp_vocabulary_and_bow_searches(tmp_path, check_ori, only_stereo, vbcam
     enc, emt = oracle.search_for_triangulation(ta, tb, np.stack(F12), np.array(ex, np.float32), np.array(ey, np.float32), scale, sigma2, 50, bool(check_ori))
     exp_pairs = np.stack([np.flatnonzero(emt >= 0), emt[emt >= 0]], 1)
     assert nc == enc and np.array_equal(pairs, exp_pairs) and nc > 10
+
+
+def _cam1_only(fr, n0):
+    return dict(un_x=fr["un_x"][:n0], un_y=fr["un_y"][:n0], octave=fr["octave"][:n0], angle=fr["angle"][:n0], uright=fr["uright"][:n0],
+                cam_of=fr["cam_of"][:n0], local_of=fr["local_of"][:n0], descs=[fr["descs"][0]], bounds=fr["bounds"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("check_ori", [1, 0])
+def test_cpp_remaining_projection_searches(tmp_path, check_ori):
+    """SURVEY section 8 f4 through the reference signatures: relocalisation SearchByProjection(Frame&, KeyFrame*, ...), the
+    loop-closing SearchByProjection_cam1, SearchBySim3_cam1 and Fuse(KeyFrame*, points, Calib, th).  The projection of the map
+    points is the reference's host cv::Mat algebra; the wrappers dump the queries they built (MORB_DUMP_QUERIES) and the
+    device results + write-back / mutual-check / merge logic are held against the oracle on exactly those queries; the dumped
+    projections themselves are checked against a float64 recomputation."""
+    import oracle
+    from multi_orb_slam_amd._lib import QUERY_DTYPE
+    W, H = 640, 480
+    fx, fy, cx, cy, mbf = 500.0, 505.0, 320.0, 240.0, 40.0
+    scale = oracle.tables()["scale"]
+    inv_sigma2 = (f32(1.0) / (scale * scale)).astype(np.float32)
+    nC, nA, nB = (900, 600), (800, 500), (850, 550)
+    cur = helpers.make_frame_arrays(list(nC), W, H, 41); ka = helpers.make_frame_arrays(list(nA), W, H, 42); kb = helpers.make_frame_arrays(list(nB), W, H, 43)
+    I4 = np.eye(4)
+    TB = np.eye(4); TB[:3, 3] = [0.05, -0.02, 0.01]
+    Rc = np.array([[np.cos(0.02), 0, np.sin(0.02)], [0, 1, 0], [-np.sin(0.02), 0, np.cos(0.02)]])
+    tc12 = np.array([0.1, 0.0, 0.02])
+    Rc21 = np.linalg.inv(Rc); tc21 = -Rc21 @ tc12
+    TB2 = np.eye(4); TB2[:3, :3] = Rc21 @ TB[:3, :3]; TB2[:3, 3] = Rc21 @ TB[:3, 3] + tc21
+    K = lambda u, v, z: np.array([(u - cx) / fx * z, (v - cy) / fy * z, z])
+
+    pool = []   # dicts: xyz, desc, normal, mind, maxd, bad, nobs
+
+    def add_point(xw, desc, level, cam_center, bad=0, nobs=1):
+        d = np.linalg.norm(xw - cam_center)
+        maxd = d * 1.2 ** (level - 0.5) if level > 0 else d * 1.05      # PredictScale -> `level`
+        pool.append(dict(xyz=xw, desc=desc, normal=(xw - cam_center) / d, mind=maxd / 1.2 ** 7.5, maxd=maxd, bad=bad, nobs=nobs))
+        return len(pool) - 1
+
+    def world_for(fr, g, T, z, jitter, cam2=False):
+        """world position whose projection by pose T (then the cam-2 extrinsics) lands `jitter` px from feature g"""
+        xc = K(float(fr["un_x"][g]) + jitter[0], float(fr["un_y"][g]) + jitter[1], z)
+        if cam2:
+            xc = np.linalg.inv(Rc21) @ (xc - tc21)
+        return np.linalg.inv(T[:3, :3]) @ (xc - T[:3, 3])
+
+    def near_desc(fr, g, seed):
+        alld = np.concatenate(fr["descs"])
+        return synth.perturbed_queries(alld[g:g + 1].repeat(2, 0), seed, 0.05)[0]
+
+    ru = helpers.rand_unit
+    # ---- relocalisation: KA's cam-1 points i < 500 look at cam-1 features of the current frame (pose I)
+    idsA = np.full(sum(nA), -1, np.int32)
+    for i in range(500):
+        g = int(helpers.rand_u32(1, 1000 + i)[0] % nC[0])
+        z = 2.0 + 4.0 * ru(1, 2000 + i)[0]
+        xw = world_for(cur, g, I4, z, (3 * (ru(1, 3000 + i)[0] - 0.5), 3 * (ru(1, 4000 + i)[0] - 0.5)))
+        pid = add_point(xw, near_desc(cur, g, 5000 + i), int(cur["octave"][g]), np.zeros(3), bad=int(ru(1, 6000 + i)[0] < 0.05))
+        if ru(1, 7000 + i)[0] < 0.9:
+            idsA[i] = pid
+        ka["angle"][i] = np.float32((float(cur["angle"][g]) + 12.0 + 6.0 * ru(1, 7500 + i)[0]) % 360.0)   # a consistent rotation: the histogram keeps most
+    found = [int(p) for p in idsA[:500][idsA[:500] >= 0][::11]]
+    idsC = np.full(sum(nC), -1, np.int32)
+    dummy = add_point(np.array([0.0, 0.0, 50.0]), synth.descriptors(1, 9)[0], 0, np.zeros(3))
+    idsC[np.flatnonzero(ru(sum(nC), 77) < 0.1)] = dummy
+    # ---- Sim3: KA's points 500..799 and KB's points form pairs that look at each other's features
+    s12 = 1.05; a12 = 0.03
+    R12 = np.array([[np.cos(a12), -np.sin(a12), 0], [np.sin(a12), np.cos(a12), 0], [0, 0, 1]]); t12 = np.array([0.03, 0.01, -0.02])
+    sR21 = (1.0 / s12) * R12.T; t21 = -sR21 @ t12
+    idsB = np.full(sum(nB), -1, np.int32)
+    for k_, i1 in enumerate(range(500, 800)):
+        i2 = int(helpers.rand_u32(1, 8000 + k_)[0] % nB[0])
+        z = 2.0 + 3.0 * ru(1, 8500 + k_)[0]
+        # KA's point: camera-1 frame of KA (pose I) -> Sim3 -> KB pixels of feature i2
+        x2 = K(float(kb["un_x"][i2]), float(kb["un_y"][i2]), z)
+        x1 = np.linalg.inv(sR21) @ (x2 - t21)
+        idsA[i1] = add_point(x1, near_desc(kb, i2, 9000 + k_), int(kb["octave"][i2]), x1 - x2 / np.linalg.norm(x2) * np.linalg.norm(x2))
+        pool[idsA[i1]]["maxd"] = np.linalg.norm(x2) * 1.2 ** (max(int(kb["octave"][i2]), 1) - 0.5); pool[idsA[i1]]["mind"] = pool[idsA[i1]]["maxd"] / 1.2 ** 7.5
+        if idsB[i2] < 0 and ru(1, 9500 + k_)[0] < 0.8:
+            # KB's point: KB camera frame (pose TB) -> Sim3 -> KA pixels of feature i1
+            y1 = K(float(ka["un_x"][i1]), float(ka["un_y"][i1]), z)
+            y2 = np.linalg.inv(s12 * R12) @ (y1 - t12)
+            yw = np.linalg.inv(TB[:3, :3]) @ (y2 - TB[:3, 3])
+            idsB[i2] = add_point(yw, near_desc(ka, i1, 9800 + k_), int(ka["octave"][i1]), np.zeros(3))
+            pool[idsB[i2]]["maxd"] = np.linalg.norm(y1) * 1.2 ** (max(int(ka["octave"][i1]), 1) - 0.5); pool[idsB[i2]]["mind"] = pool[idsB[i2]]["maxd"] / 1.2 ** 7.5
+    m12_init = np.full(nA[0], -1, np.int32)
+    pre = [i1 for i1 in range(500, 800, 17)]
+    for i1 in pre:   # a few pairs are matched already: skipped on both sides
+        m12_init[i1] = dummy
+    # ---- loop closing: points seen through the Sim3 pose Scw of KA
+    sc = 1.1; aS = -0.02
+    RS = np.array([[1, 0, 0], [0, np.cos(aS), -np.sin(aS)], [0, np.sin(aS), np.cos(aS)]]); tS = np.array([0.02, 0.03, -0.01])
+    Scw = np.eye(4); Scw[:3, :3] = sc * RS; Scw[:3, 3] = sc * tS
+    TS = np.eye(4); TS[:3, :3] = RS; TS[:3, 3] = tS
+    OwS = -RS.T @ tS
+    loop_ids = []
+    for k_ in range(700):
+        g = int(helpers.rand_u32(1, 11000 + k_)[0] % nA[0])
+        z = 2.0 + 4.0 * ru(1, 12000 + k_)[0]
+        xw = world_for(ka, g, TS, z, (2 * (ru(1, 13000 + k_)[0] - 0.5), 2 * (ru(1, 14000 + k_)[0] - 0.5)))
+        loop_ids.append(add_point(xw, near_desc(ka, g, 15000 + k_), int(ka["octave"][g]), OwS, bad=int(ru(1, 16000 + k_)[0] < 0.05)))
+    matched_init = np.full(nA[0], -1, np.int32)
+    matched_init[np.flatnonzero(ru(nA[0], 78) < 0.15)] = dummy
+    # ---- Fuse into KB (both cameras)
+    OwB = -TB[:3, :3].T @ TB[:3, 3]; OwB2 = -TB2[:3, :3].T @ TB2[:3, 3]
+    fuse_ids = []
+    for k_ in range(600):
+        cam2 = ru(1, 17000 + k_)[0] < 0.4
+        g = int(helpers.rand_u32(1, 18000 + k_)[0] % (nB[1] if cam2 else nB[0])) + (nB[0] if cam2 else 0)
+        z = 2.0 + 4.0 * ru(1, 19000 + k_)[0]
+        xw = world_for(kb, g, TB, z, (1.0 * (ru(1, 20000 + k_)[0] - 0.5), 1.0 * (ru(1, 21000 + k_)[0] - 0.5)), cam2)
+        fuse_ids.append(add_point(xw, near_desc(kb, g, 22000 + k_), int(kb["octave"][g]), OwB2 if cam2 else OwB,
+                                  bad=int(ru(1, 23000 + k_)[0] < 0.04), nobs=1 + int(helpers.rand_u32(1, 24000 + k_)[0] % 5)))
+    fuse_ids += [-1, fuse_ids[3], int(idsB[idsB >= 0][0])]     # a NULL entry, a duplicate, a point that is already in the keyframe
+    for j in np.flatnonzero(idsB >= 0):
+        pool[idsB[j]]["nobs"] = 1 + int(helpers.rand_u32(1, 25000 + int(j))[0] % 5)
+    calib = np.concatenate([Rc.ravel(), tc12]).astype(np.float32)
+    th_reloc, ORBdist, th_loop, th_sim3, th_fuse = 10.0, 100, 10, 7.5, 3.0
+
+    intr = (fx, fy, cx, cy, mbf); bnd = (0, 0, W, H)
+    blob = _frame_bytes(cur, nC[0], nC[1], scale, I4, intr, bnd) + _frame_bytes(ka, nA[0], nA[1], scale, I4, intr, bnd) + \
+        _frame_bytes(kb, nB[0], nB[1], scale, TB, intr, bnd) + TB2.astype(np.float32).tobytes()
+    blob += struct.pack("<i", len(pool))
+    for p in pool:
+        blob += np.asarray(p["xyz"], np.float32).tobytes() + np.asarray(p["desc"], np.uint8).tobytes() + np.asarray(p["normal"], np.float32).tobytes()
+        blob += struct.pack("<ffii", p["mind"], p["maxd"], p["bad"], p["nobs"])
+    blob += idsC.tobytes() + idsA.tobytes() + idsB.tobytes()
+    blob += struct.pack("<i", len(found)) + np.array(found, np.int32).tobytes()
+    blob += struct.pack("<i", len(loop_ids)) + np.array(loop_ids, np.int32).tobytes() + matched_init.tobytes()
+    blob += Scw.astype(np.float32).tobytes() + struct.pack("<i", th_loop)
+    blob += struct.pack("<f", s12) + R12.astype(np.float32).tobytes() + t12.astype(np.float32).tobytes() + m12_init.tobytes() + struct.pack("<f", th_sim3)
+    blob += struct.pack("<i", len(fuse_ids)) + np.array(fuse_ids, np.int32).tobytes() + calib.tobytes()
+    blob += struct.pack("<ffii", th_fuse, th_reloc, ORBdist, check_ori)
+    (tmp_path / "case.bin").write_bytes(blob)
+    env = dict(os.environ, MORB_DUMP_QUERIES=str(tmp_path / "queries.bin"))
+    subprocess.check_call([BIN, "f4", str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], env=env)
+
+    qb = (tmp_path / "queries.bin").read_bytes(); sets = []; off = 0
+    while off < len(qb):
+        n = struct.unpack_from("<i", qb, off)[0]; off += 4
+        q = np.frombuffer(qb, QUERY_DTYPE, n, off).copy(); off += 68 * n
+        src = np.frombuffer(qb, np.int32, n, off).copy(); off += 4 * n
+        sets.append((q, src))
+    assert len(sets) == 5
+    buf = (tmp_path / "out.bin").read_bytes(); off = 0
+
+    def take(n):
+        nonlocal off
+        a = np.frombuffer(buf, np.int32, n, off).copy(); off += 4 * n
+        return a
+    n1 = take(1)[0]; got_cur = take(sum(nC)); n2 = take(1)[0]; got_matched = take(nA[0]); n3 = take(1)[0]; got_m12 = take(nA[0])
+    n4 = take(1)[0]; got_kb = take(sum(nB)); rep_bad = take(2 * len(pool)).reshape(-1, 2)
+
+    # ---- relocalisation
+    q, src = sets[0]
+    assert len(q) > 300 and np.isnan(q["ur"]).all()
+    OF = oracle.FrameData(**_cam1_only(cur, nC[0]))
+    en, emo = oracle.search_by_projection_frames(OF, q, ORBdist, bool(check_ori), (idsC[:nC[0]] >= 0).astype(np.uint8))
+    exp = idsC.copy()
+    exp[:nC[0]] = np.where(emo >= 0, idsA[src[np.maximum(emo, 0)]], np.where(emo == -2, -1, idsC[:nC[0]]))
+    assert n1 == en and np.array_equal(got_cur, exp) and n1 > 100
+    # the dumped projections against float64 (pose I): u = fx X/Z + cx
+    xyz = np.array([pool[idsA[i]]["xyz"] for i in src])
+    assert np.abs(q["u"] - (fx * xyz[:, 0] / xyz[:, 2] + cx)).max() < 1e-2 and np.abs(q["v"] - (fy * xyz[:, 1] / xyz[:, 2] + cy)).max() < 1e-2
+    lv = (q["max_level"] - 1)
+    assert np.array_equal(q["min_level"], lv - 1) and np.allclose(q["radius"], th_reloc * scale[lv])
+    # ---- loop closing
+    q, src = sets[1]
+    assert len(q) > 400
+    OFa = oracle.FrameData(**_cam1_only(ka, nA[0]))
+    en, emo = oracle.search_by_projection_frames(OFa, q, 50, False, (matched_init >= 0).astype(np.uint8))
+    exp = np.where(emo >= 0, np.array(loop_ids, np.int32)[src[np.maximum(emo, 0)]], matched_init)
+    assert n2 == en and np.array_equal(got_matched, exp) and n2 > 200
+    xyz = np.array([pool[loop_ids[i]]["xyz"] for i in src]); xc = xyz @ RS.T + tS
+    assert np.abs(q["u"] - (fx * xc[:, 0] / xc[:, 2] + cx)).max() < 2e-2 and np.abs(q["v"] - (fy * xc[:, 1] / xc[:, 2] + cy)).max() < 2e-2
+    # ---- Sim3
+    (q12, s12src), (q21, s21src) = sets[2], sets[3]
+    OFb = oracle.FrameData(**_cam1_only(kb, nB[0]))
+    vn1 = np.full(nA[0], -1); vn2 = np.full(nB[0], -1)
+    bi, bd = oracle.project_best(OFb, q12, None, 0); vn1[s12src[(bi >= 0) & (bd <= 100)]] = bi[(bi >= 0) & (bd <= 100)]
+    bi, bd = oracle.project_best(OFa, q21, None, 0); vn2[s21src[(bi >= 0) & (bd <= 100)]] = bi[(bi >= 0) & (bd <= 100)]
+    exp = m12_init.copy(); nf = 0
+    for i1 in range(nA[0]):
+        if vn1[i1] >= 0 and vn2[vn1[i1]] == i1:
+            exp[i1] = idsB[vn1[i1]]; nf += 1
+    assert n3 == nf and np.array_equal(got_m12, exp) and n3 > 100
+    assert not set(s12src.tolist()) & set(pre)                   # already matched points are not projected again
+    # ---- Fuse
+    q, src = sets[4]
+    assert len(q) > 400 and (q["cam"] == 1).sum() > 100
+    OFk = oracle.FrameData(**kb)
+    bi, bd = oracle.project_best(OFk, q, None, 2, inv_sigma2)
+    kbm = idsB.copy(); bad = np.array([p["bad"] for p in pool]); nobs = np.array([p["nobs"] for p in pool]); rep = np.full(len(pool), -1)
+    in_kf = set(int(p) for p in idsB[idsB >= 0]); nfused = 0
+    for i, pid in enumerate(fuse_ids):
+        ks = np.flatnonzero(src == i)
+        if pid < 0 or len(ks) == 0 or bad[pid] or pid in in_kf:
+            continue
+        for k_ in ks:
+            if bi[k_] < 0 or bd[k_] > 50:
+                continue
+            other = kbm[bi[k_]]
+            if other >= 0:
+                if not bad[other]:
+                    if nobs[other] > nobs[pid]:
+                        if other != pid: rep[pid] = other; bad[pid] = 1
+                    else:
+                        if other != pid: rep[other] = pid; bad[other] = 1
+            else:
+                if pid not in in_kf:
+                    in_kf.add(pid); nobs[pid] += 1
+                kbm[bi[k_]] = pid
+            nfused += 1
+    assert n4 == nfused and np.array_equal(got_kb, kbm) and n4 > 150
+    assert np.array_equal(rep_bad[:, 0], rep) and np.array_equal(rep_bad[:, 1], bad)
