@@ -75,6 +75,21 @@ int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images);
  * one starts; orbm_cross_top2_gathered consumes the gathered blocks. */
 int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_bytes, int* cap_rows);
 /* queries: the projected last-frame map points (may be NULL / 0 on the first frame) */
+/* HBM-resident per-feature arrays of the last COMPLETED step's merged frame (global feature order, cameras back to back):
+ * what a keyframe built on the device starts from (orbv_keyframe_from_device).  Valid until the next step begins. */
+typedef struct orbf_device_features {
+    int32_t n_total, n_cams;
+    int32_t counts[8];          /* features per camera                                                  */
+    const uint8_t* d_desc;      /* n_total x 32                                                         */
+    const float* d_angle;       /* mvKeys_total[i].angle                                                */
+    const float* d_un_x;        /* mvKeysUn_total[i].pt                                                 */
+    const float* d_un_y;
+    const int32_t* d_octave;
+    const float* d_uright;      /* mvuRight_total                                                       */
+    void* stream;               /* the stream these arrays were last written on                         */
+} orbf_device_features;
+int orbf_export_features(orbf_frontend* f, orbf_device_features* out);
+
 int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out);
 /* Synthetic-stream driver: like orbf_step, with the queries built natively from the PREVIOUS step's features moved by a
  * constant image-plane motion (orbm_queries_from_motion on the handle's own pinned result buffers; no queries on the

@@ -115,6 +115,29 @@ typedef struct orbv_keyframe orbv_keyframe;
 int orbv_keyframe_create(orbv_workspace* w, const orbv_side* s, orbv_keyframe** out);
 void orbv_keyframe_destroy(orbv_keyframe* k);
 int orbv_keyframe_count(const orbv_keyframe* k);
+/* A keyframe that never leaves HBM: descriptors, angles (and positions / octaves / right coordinates for triangulation)
+ * are copied device-to-device -- e.g. from the frame orbf_export_features hands out --, the descents run on them and the
+ * FeatureVector is built on the device (the nodes `levelsup` above the leaves must number <= 4096: 100 for the stock
+ * k = 10, L = 6 vocabulary at levelsup = 4).  Flags start as bit0 = 1, bit1 = (uright >= 0).  after_stream: the stream the
+ * source arrays are produced on (NULL: they are complete).  One synchronisation (the node count comes back to the host). */
+typedef struct orbv_device_side {
+    int n;
+    const uint8_t* d_desc;     /* n x 32, 16-byte aligned                       */
+    const float* d_angle;      /* n                                             */
+    const float* d_x;          /* n, or NULL: no triangulation arrays           */
+    const float* d_y;
+    const int32_t* d_octave;
+    const float* d_uright;     /* n, or NULL (= no feature is stereo)           */
+    int n_cams;                /* cameras are contiguous index ranges:          */
+    int cam_start[9];          /* camera c = [cam_start[c], cam_start[c+1])     */
+} orbv_device_side;
+int orbv_keyframe_from_device(orbv_workspace* w, const orbv_vocabulary* v, const orbv_device_side* s, int levelsup, void* after_stream,
+                              orbv_keyframe** out);
+/* Per-feature word / node ids of a device-built keyframe (for the BowVector, which stays a host std::map) and its
+ * FeatureVector as CSR; any output pointer may be NULL.  fv_items needs fv_start. */
+int orbv_keyframe_download(orbv_workspace* w, const orbv_keyframe* k, uint32_t* word_id, uint32_t* node_of_feature, uint32_t* fv_node,
+                           int32_t* fv_start, uint32_t* fv_items, int* n_fv_nodes);
+
 int orbv_search_by_bow_resident(orbv_workspace* w, const orbv_keyframe* a, const uint8_t* flags_a, const orbv_keyframe* b,
                                 const uint8_t* flags_b, int mode, int th_low, float nnratio, int check_orientation, int32_t* match,
                                 int* nmatches);

@@ -63,6 +63,16 @@ class FrameDesc(C.Structure):  # orbm_frame_desc
                 ("max_x", C.c_float), ("max_y", C.c_float)]
 
 
+class DeviceFeatures(C.Structure):  # orbf_device_features
+    _fields_ = [("n_total", C.c_int32), ("n_cams", C.c_int32), ("counts", C.c_int32 * 8), ("d_desc", C.c_void_p), ("d_angle", C.c_void_p),
+                ("d_un_x", C.c_void_p), ("d_un_y", C.c_void_p), ("d_octave", C.c_void_p), ("d_uright", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class DeviceSide(C.Structure):  # orbv_device_side
+    _fields_ = [("n", C.c_int32), ("d_desc", C.c_void_p), ("d_angle", C.c_void_p), ("d_x", C.c_void_p), ("d_y", C.c_void_p),
+                ("d_octave", C.c_void_p), ("d_uright", C.c_void_p), ("n_cams", C.c_int32), ("cam_start", C.c_int32 * 9)]
+
+
 class BowSide(C.Structure):  # orbv_side
     _fields_ = [("n", C.c_int32), ("desc", C.c_void_p), ("angle", C.c_void_p), ("flags", C.c_void_p), ("n_nodes", C.c_int32),
                 ("node_id", C.c_void_p), ("node_start", C.c_void_p), ("items", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
@@ -179,6 +189,9 @@ def lib():
     L.orbv_keyframe_create.argtypes = [vp, vp, vp]
     L.orbv_keyframe_destroy.argtypes = [vp]; L.orbv_keyframe_destroy.restype = None
     L.orbv_keyframe_count.argtypes = [vp]
+    L.orbv_keyframe_from_device.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.orbv_keyframe_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orbf_export_features.argtypes = [vp, vp]
     L.orbv_search_by_bow_resident.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, vp]
     L.orbv_search_for_triangulation_resident.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     _lib = L

@@ -51,12 +51,13 @@ __global__ __launch_bounds__(256) void k_bow_transform(const uint4* __restrict__
                                                        const uint32_t* __restrict__ orig, const uint32_t* __restrict__ word,
                                                        const uint4* __restrict__ feat, int n, int nid_level,
                                                        uint32_t* __restrict__ word_out, uint32_t* __restrict__ node_out,
-                                                       uint32_t* __restrict__ leaf_out) {
+                                                       uint32_t* __restrict__ leaf_out, const int* __restrict__ rank = nullptr,
+                                                       const uint8_t* __restrict__ stop = nullptr, int* __restrict__ bin_out = nullptr) {
     const int sub = threadIdx.x & 15;
     const int f = (int)((blockIdx.x * 256u + threadIdx.x) >> 4);
     if (f >= n) return;
     const uint4 a0 = feat[2 * (size_t)f], a1 = feat[2 * (size_t)f + 1];
-    int cur = 0, level = 0;
+    int cur = 0, level = 0, bin = 0;   // bin: 0 = root (no node at nid_level on this path), else 1 + rank of that node by NodeId
     uint32_t nid = 0;
     int fc = first_child[0], fe = first_child[1];
     while (fe > fc) {
@@ -71,13 +72,82 @@ __global__ __launch_bounds__(256) void k_bow_transform(const uint4* __restrict__
         best = min(best, (unsigned)__shfl_xor((int)best, 4, 16));
         best = min(best, (unsigned)__shfl_xor((int)best, 8, 16));
         cur = fc + (int)(best & 0x3fffffu);
-        if (level == nid_level) nid = orig[cur];
+        if (level == nid_level) { nid = orig[cur]; if (bin_out) bin = 1 + rank[cur]; }
         fc = first_child[cur]; fe = first_child[cur + 1];
     }
     if (sub == 0) {
         word_out[f] = word[cur]; node_out[f] = nid;
         if (leaf_out) leaf_out[f] = orig[cur];
+        if (bin_out) bin_out[f] = stop[cur] ? -1 : bin;     // stopped words (weight 0) enter neither vector (:1156)
     }
+}
+
+// ---- FeatureVector on the device: histogram over the nodes of one tree level, compaction of the non-empty ones in
+// ascending NodeId, then one wave per node collects its features in ascending index (ballot compaction: stable, no sort)
+__global__ void k_fv_count(const int* __restrict__ bin, int n, int* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && bin[i] >= 0) atomicAdd(&counts[bin[i]], 1);
+}
+
+// one workgroup: counts[nbins] -> node_id / node_start of the non-empty bins, bin_to_node, meta = {n_nodes, largest node, items}
+__global__ __launch_bounds__(1024) void k_fv_offsets(const int* __restrict__ counts, int nbins, const uint32_t* __restrict__ orig_sorted,
+                                                      uint32_t* __restrict__ node_id, int* __restrict__ node_start, int* __restrict__ bin_to_node,
+                                                      int* __restrict__ meta) {
+    __shared__ int s_nodes[1024], s_items[1024], s_base[2], s_max;
+    const int t = threadIdx.x;
+    if (t == 0) { s_base[0] = 0; s_base[1] = 0; s_max = 0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < nbins; b0 += 1024) {
+        const int b = b0 + t;
+        const int c = b < nbins ? counts[b] : 0;
+        s_nodes[t] = c > 0; s_items[t] = c;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {     // inclusive scans of both columns
+            const int a = t >= o ? s_nodes[t - o] : 0, d = t >= o ? s_items[t - o] : 0;
+            __syncthreads();
+            s_nodes[t] += a; s_items[t] += d;
+            __syncthreads();
+        }
+        if (b < nbins) {
+            if (c > 0) {
+                const int nd = s_base[0] + s_nodes[t] - 1;
+                node_id[nd] = b == 0 ? 0u : orig_sorted[b - 1];
+                node_start[nd] = s_base[1] + s_items[t] - c;
+                bin_to_node[b] = nd;
+                atomicMax(&s_max, c);
+            } else bin_to_node[b] = -1;
+        }
+        __syncthreads();
+        if (t == 1023) { s_base[0] += s_nodes[1023]; s_base[1] += s_items[1023]; }
+        __syncthreads();
+    }
+    if (t == 0) { node_start[s_base[0]] = s_base[1]; meta[0] = s_base[0]; meta[1] = s_max; meta[2] = s_base[1]; }
+}
+
+__global__ __launch_bounds__(64) void k_fv_fill(const int* __restrict__ bin, int n, const int* __restrict__ bin_to_node,
+                                                const int* __restrict__ node_start, uint32_t* __restrict__ items) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int nd = bin_to_node[b];
+    if (nd < 0) return;
+    int pos = node_start[nd];
+    for (int f0 = 0; f0 < n; f0 += 64) {
+        const int f = f0 + lane;
+        const bool mine = f < n && bin[f] == b;
+        const unsigned long long m = __ballot(mine);
+        if (mine) items[pos + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)f;
+        pos += __popcll(m);
+    }
+}
+
+// camera of a feature from the per-camera starts, flags from the right coordinate (bit0 usable, bit1 stereo: mvuRight >= 0)
+struct CamStarts { int n_cams; int start[ORBV_MAX_CAMS + 1]; };
+__global__ void k_side_misc(int n, CamStarts C, const float* __restrict__ uright, int32_t* __restrict__ cam_of, uint8_t* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = 0;
+    while (c + 1 < C.n_cams && i >= C.start[c + 1]) ++c;
+    cam_of[i] = c;
+    flags[i] = (uint8_t)(1 | ((uright && uright[i] >= 0) ? 2 : 0));
 }
 
 struct SideDev {
@@ -309,6 +379,10 @@ struct orbv_vocabulary {
     DevBuf<int32_t> d_first_child;   // n_nodes + 1: children of node d are [first_child[d], first_child[d+1])
     DevBuf<uint32_t> d_orig, d_word; // NodeId / WordId of a breadth-first index
     std::vector<double> weight;      // by NodeId
+    std::vector<int> lvl_start;      // breadth-first index range of every depth (depth d: [lvl_start[d], lvl_start[d+1]))
+    DevBuf<int32_t> d_rank;          // rank of a node among the nodes of its depth, by NodeId
+    DevBuf<uint32_t> d_orig_sorted;  // NodeIds of every depth in ascending order (same index space as the breadth-first one)
+    DevBuf<uint8_t> d_stop;          // weight <= 0: a stopped word
     DevBuf<uint8_t> d_feat;
     DevBuf<uint32_t> d_out;
     PinnedBuf<uint32_t> h_out;
@@ -363,8 +437,28 @@ int orbv_create(int n_nodes, int L, const int32_t* parent, const uint8_t* is_lea
         if (id) memcpy(&bdesc[(size_t)h * 32], desc + (size_t)id * 32, 32); else memset(&bdesc[0], 0, 32);
         borig[h] = (uint32_t)id; bword[h] = word_of[id];
     }
+    // depth ranges + rank by NodeId inside each depth (the device-side FeatureVector bins)
+    std::vector<int> depth(reach, 0);
+    for (int h = 0; h < reach; ++h) for (int c = first_child[h]; c < first_child[h + 1]; ++c) depth[c] = depth[h] + 1;
+    v->lvl_start.assign(1, 0);
+    for (int h = 1; h < reach; ++h) if (depth[h] != depth[h - 1]) v->lvl_start.push_back(h);
+    v->lvl_start.push_back(reach);
+    std::vector<int32_t> brank(reach, 0); std::vector<uint32_t> bsorted(reach, 0); std::vector<uint8_t> bstop(reach, 0);
+    for (size_t d = 0; d + 1 < v->lvl_start.size(); ++d) {
+        std::vector<int> idx(v->lvl_start[d + 1] - v->lvl_start[d]);
+        std::iota(idx.begin(), idx.end(), v->lvl_start[d]);
+        std::sort(idx.begin(), idx.end(), [&](int a, int b) { return borig[a] < borig[b]; });
+        for (size_t r = 0; r < idx.size(); ++r) { brank[idx[r]] = (int32_t)r; bsorted[v->lvl_start[d] + r] = borig[idx[r]]; }
+    }
+    for (int h = 0; h < reach; ++h) bstop[h] = v->weight[borig[h]] > 0 ? 0 : 1;
     hipError_t e = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete v; return ORB_E_HIP; }
+    if ((rc = v->d_rank.reserve(reach)) || (rc = v->d_orig_sorted.reserve(reach)) || (rc = v->d_stop.reserve(reach))) { orbv_destroy(v); return rc; }
+    if (hipMemcpy(v->d_rank.p, brank.data(), (size_t)reach * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(v->d_orig_sorted.p, bsorted.data(), (size_t)reach * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(v->d_stop.p, bstop.data(), (size_t)reach, hipMemcpyHostToDevice) != hipSuccess) {
+        morb::set_error("vocabulary upload failed"); orbv_destroy(v); return ORB_E_HIP;
+    }
     if ((rc = v->d_desc.reserve((size_t)reach * 2)) || (rc = v->d_first_child.reserve(reach + 1)) || (rc = v->d_orig.reserve(reach)) ||
         (rc = v->d_word.reserve(reach))) { orbv_destroy(v); return rc; }
     if (hipMemcpy(v->d_desc.p, bdesc.data(), bdesc.size(), hipMemcpyHostToDevice) != hipSuccess ||
@@ -410,6 +504,7 @@ void orbv_destroy(orbv_vocabulary* v) {
     (void)hipSetDevice(v->device);
     if (v->stream) { (void)hipStreamSynchronize(v->stream); (void)hipStreamDestroy(v->stream); }
     v->d_desc.release(); v->d_first_child.release(); v->d_orig.release(); v->d_word.release(); v->d_feat.release(); v->d_out.release();
+    v->d_rank.release(); v->d_orig_sorted.release(); v->d_stop.release();
     v->h_out.release(); v->h_feat.release();
     delete v;
 }
@@ -662,6 +757,7 @@ struct orbv_keyframe {
     SideDev D;
     int max_node = 1, max_cam = 0, max_octave = 0;
     bool tri = false;
+    const uint32_t* d_word = nullptr; const uint32_t* d_node = nullptr;   // per-feature descent results (device-built keyframes)
 };
 
 namespace {
@@ -741,6 +837,94 @@ void orbv_keyframe_destroy(orbv_keyframe* k) {
 }
 
 int orbv_keyframe_count(const orbv_keyframe* k) { return k ? k->D.n : 0; }
+
+int orbv_keyframe_from_device(orbv_workspace* w, const orbv_vocabulary* v, const orbv_device_side* s, int levelsup, void* after_stream,
+                              orbv_keyframe** out) {
+    MORB_ARG(w != nullptr && v != nullptr && s != nullptr && out != nullptr && s->n >= 0 && w->device == v->device);
+    MORB_ARG(s->n == 0 || (s->d_desc && s->d_angle && ((uintptr_t)s->d_desc & 15) == 0));
+    const bool tri = s->d_x != nullptr;
+    if (tri) MORB_ARG(s->d_y && s->d_octave && s->n_cams >= 1 && s->n_cams <= ORBV_MAX_CAMS && s->cam_start[0] == 0 && s->cam_start[s->n_cams] == s->n);
+    const int nid_level = v->L - levelsup;
+    const int depths = (int)v->lvl_start.size() - 1;
+    const int lvl_nodes = (nid_level >= 1 && nid_level < depths) ? v->lvl_start[nid_level + 1] - v->lvl_start[nid_level] : 0;
+    const int nbins = 1 + lvl_nodes;
+    if (nbins > 4097) { morb::set_error("%d vocabulary nodes at level %d: build this FeatureVector with orbv_bow_vectors", lvl_nodes, nid_level); return ORB_E_CAPACITY; }
+    MORB_HIP(hipSetDevice(w->device));
+    const int n = s->n;
+    orbv_keyframe* k = new orbv_keyframe();
+    k->device = w->device; k->tri = tri;
+    // block: desc | angle | flags | node_id | node_start | items | word | node | bin | [x | y | octave | cam_of] | counts | bin_to_node | meta
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = up16(off + bytes); return o; };
+    const size_t nn = (size_t)std::max(n, 1);
+    const size_t o_desc = take(nn * 32), o_ang = take(nn * 4), o_fl = take(nn), o_nid = take((size_t)nbins * 4), o_ns = take((size_t)(nbins + 1) * 4),
+                 o_it = take(nn * 4), o_w = take(nn * 4), o_nd = take(nn * 4), o_bin = take(nn * 4);
+    const size_t o_x = tri ? take(nn * 4) : 0, o_y = tri ? take(nn * 4) : 0, o_oc = tri ? take(nn * 4) : 0;
+    const size_t o_cam = take(nn * 4), o_cnt = take((size_t)nbins * 4), o_b2n = take((size_t)nbins * 4), o_meta = take(16);
+    int rc = k->block.reserve(off);
+    if (rc) { delete k; return rc; }
+    uint8_t* B = k->block.p;
+    hipStream_t st = w->stream;
+    auto fail = [&](const char* what) { morb::set_error("%s failed: %s", what, hipGetErrorString(hipGetLastError())); orbv_keyframe_destroy(k); return ORB_E_HIP; };
+    if (after_stream) {   // the arrays are produced on another stream (the front end's): order ours behind it on the device
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate");
+        (void)hipEventRecord(ev, (hipStream_t)after_stream); (void)hipStreamWaitEvent(st, ev, 0); (void)hipEventDestroy(ev);
+    }
+    if (n > 0) {
+        if (hipMemcpyAsync(B + o_desc, s->d_desc, (size_t)n * 32, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(B + o_ang, s->d_angle, (size_t)n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("keyframe copy");
+        if (tri && (hipMemcpyAsync(B + o_x, s->d_x, (size_t)n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                    hipMemcpyAsync(B + o_y, s->d_y, (size_t)n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                    hipMemcpyAsync(B + o_oc, s->d_octave, (size_t)n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)) return fail("keyframe copy");
+    }
+    if (hipMemsetAsync(B + o_cnt, 0, (size_t)nbins * 4, st) != hipSuccess) return fail("hipMemsetAsync");
+    CamStarts C; memset(&C, 0, sizeof(C));
+    C.n_cams = tri ? s->n_cams : 1; if (tri) memcpy(C.start, s->cam_start, sizeof(int) * (s->n_cams + 1)); else C.start[1] = n;
+    if (n > 0) {
+        k_bow_transform<<<(n + 15) / 16, 256, 0, st>>>(v->d_desc.p, v->d_first_child.p, v->d_orig.p, v->d_word.p, (const uint4*)(B + o_desc), n, nid_level,
+                                                       (uint32_t*)(B + o_w), (uint32_t*)(B + o_nd), nullptr, v->d_rank.p,
+                                                       v->d_stop.p, (int*)(B + o_bin));
+        k_fv_count<<<(n + 255) / 256, 256, 0, st>>>((const int*)(B + o_bin), n, (int*)(B + o_cnt));
+        k_side_misc<<<(n + 255) / 256, 256, 0, st>>>(n, C, s->d_uright, (int32_t*)(B + o_cam), B + o_fl);
+    }
+    k_fv_offsets<<<1, 1024, 0, st>>>((const int*)(B + o_cnt), nbins, v->d_orig_sorted.p + (lvl_nodes ? v->lvl_start[nid_level] : 0), (uint32_t*)(B + o_nid),
+                                     (int*)(B + o_ns), (int*)(B + o_b2n), (int*)(B + o_meta));
+    if (n > 0) k_fv_fill<<<nbins, 64, 0, st>>>((const int*)(B + o_bin), n, (const int*)(B + o_b2n), (const int*)(B + o_ns), (uint32_t*)(B + o_it));
+    int meta[4] = {0, 0, 0, 0};
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(meta, B + o_meta, 12, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return fail("keyframe build");
+    SideDev& D = k->D;
+    D.n = n; D.n_nodes = meta[0];
+    D.desc = (const uint4*)(B + o_desc); D.angle = (const float*)(B + o_ang); D.flags = B + o_fl;
+    D.node_id = (const uint32_t*)(B + o_nid); D.node_start = (const int32_t*)(B + o_ns); D.items = (const uint32_t*)(B + o_it);
+    D.x = tri ? (const float*)(B + o_x) : nullptr; D.y = tri ? (const float*)(B + o_y) : nullptr;
+    D.octave = tri ? (const int32_t*)(B + o_oc) : nullptr; D.cam_of = tri ? (const int32_t*)(B + o_cam) : nullptr;
+    k->max_node = std::max(1, meta[1]);
+    k->max_cam = tri ? s->n_cams - 1 : 0; k->max_octave = 0;   // octaves stay on the device: the caller vouches for octave < n_levels
+    k->d_word = (const uint32_t*)(B + o_w); k->d_node = (const uint32_t*)(B + o_nd);
+    *out = k;
+    return ORB_OK;
+}
+
+int orbv_keyframe_download(orbv_workspace* w, const orbv_keyframe* k, uint32_t* word_id, uint32_t* node_of_feature, uint32_t* fv_node,
+                           int32_t* fv_start, uint32_t* fv_items, int* n_fv_nodes) {
+    MORB_ARG(w != nullptr && k != nullptr && w->device == k->device);
+    MORB_HIP(hipSetDevice(w->device));
+    const int n = k->D.n, nn = k->D.n_nodes;
+    if (word_id || node_of_feature) MORB_ARG(k->d_word != nullptr);   // host-uploaded keyframes carry no descent results
+    if (word_id && n) MORB_HIP(hipMemcpyAsync(word_id, k->d_word, (size_t)n * 4, hipMemcpyDeviceToHost, w->stream));
+    if (node_of_feature && n) MORB_HIP(hipMemcpyAsync(node_of_feature, k->d_node, (size_t)n * 4, hipMemcpyDeviceToHost, w->stream));
+    if (fv_node && nn) MORB_HIP(hipMemcpyAsync(fv_node, k->D.node_id, (size_t)nn * 4, hipMemcpyDeviceToHost, w->stream));
+    if (fv_start) MORB_HIP(hipMemcpyAsync(fv_start, k->D.node_start, (size_t)(nn + 1) * 4, hipMemcpyDeviceToHost, w->stream));
+    MORB_HIP(hipStreamSynchronize(w->stream));
+    if (fv_items && fv_start && fv_start[nn] > 0) {
+        MORB_HIP(hipMemcpyAsync(fv_items, k->D.items, (size_t)fv_start[nn] * 4, hipMemcpyDeviceToHost, w->stream));
+        MORB_HIP(hipStreamSynchronize(w->stream));
+    }
+    if (n_fv_nodes) *n_fv_nodes = nn;
+    return ORB_OK;
+}
 
 int orbv_search_by_bow_resident(orbv_workspace* w, const orbv_keyframe* a, const uint8_t* flags_a, const orbv_keyframe* b,
                                 const uint8_t* flags_b, int mode, int th_low, float nnratio, int check_orientation, int32_t* match,

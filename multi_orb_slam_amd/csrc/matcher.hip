@@ -2490,6 +2490,19 @@ int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_b
     return ORB_OK;
 }
 
+int orbf_export_features(orbf_frontend* f, orbf_device_features* out) {
+    MORB_ARG(f && out);
+    const orbm_frame* F = f->last_frame;
+    if (!F || (f->pending.active && f->pending.fr)) { morb::set_error("orbf_export_features: no completed step (call it after orbf_step / orbf_step_end)"); return ORB_E_ARG; }
+    memset(out, 0, sizeof(*out));
+    out->n_cams = f->n_cams; out->n_total = 0;
+    for (int c = 0; c < f->n_cams && c < 8; ++c) { out->counts[c] = f->counts[c]; out->n_total += f->counts[c]; }
+    out->d_desc = F->b->d_desc.p; out->d_angle = F->b->d_ang.p; out->d_un_x = F->b->d_x.p; out->d_un_y = F->b->d_y.p;
+    out->d_octave = F->b->d_oct.p; out->d_uright = F->b->d_ur.p;
+    out->stream = f->mt->stream;
+    return ORB_OK;
+}
+
 int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images) {
     MORB_ARG(f && next_images);
     // (the step about to be called may itself still be in flight: two timesteps beyond it can be announced)

@@ -93,6 +93,13 @@ class NativeFrontEnd:
         check(_lib.lib().orbf_export_block(self._h, C.byref(p), C.byref(nb), C.byref(rows)))
         return p.value, nb.value, rows.value
 
+    def export_features(self):
+        """HBM-resident arrays of the last completed step's frame (orbf_export_features) -> _lib.DeviceFeatures."""
+        from ._lib import DeviceFeatures
+        d = DeviceFeatures()
+        check(_lib.lib().orbf_export_features(self._h, C.byref(d)))
+        return d
+
     def prefetch(self, next_images):
         """Declare the images of the step after the next one (orbf_prefetch): their extraction overlaps the next step's
         matching.  The arrays / device buffers must stay alive and unchanged until the step that consumes them returns."""

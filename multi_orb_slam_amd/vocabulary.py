@@ -115,6 +115,32 @@ class BowSearch:
         check(_lib.lib().orbv_search_by_bow(self._h, C.byref(ca), C.byref(cb), mode, th_low, nnratio, int(check_orientation), ptr(match), C.byref(nm)))
         return nm.value, match[:n_out]
 
+    def keyframe_from_device(self, vocabulary, feats, levelsup=4, triangulation=True):
+        """Keyframe built entirely on the device from a front end's resident frame (feats = NativeFrontEnd.export_features())."""
+        from ._lib import DeviceSide
+        s = DeviceSide()
+        s.n = feats.n_total; s.d_desc = feats.d_desc; s.d_angle = feats.d_angle; s.d_uright = feats.d_uright
+        if triangulation:
+            s.d_x = feats.d_un_x; s.d_y = feats.d_un_y; s.d_octave = feats.d_octave
+        s.n_cams = feats.n_cams
+        acc = 0
+        for c in range(feats.n_cams):
+            s.cam_start[c] = acc; acc += feats.counts[c]
+        s.cam_start[feats.n_cams] = acc
+        k = Keyframe.__new__(Keyframe)
+        k._h = C.c_void_p(); k.n = feats.n_total; k._search = self
+        check(_lib.lib().orbv_keyframe_from_device(self._h, vocabulary._h, C.byref(s), levelsup, C.c_void_p(feats.stream) if feats.stream else None, C.byref(k._h)))
+        return k
+
+    def keyframe_download(self, k):
+        """-> (word_id, node_of_feature, FeatureVector) of a device-built keyframe."""
+        n = k.n
+        w, nd = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+        fn, fs, fi = np.zeros(4100, np.uint32), np.zeros(4101, np.int32), np.zeros(max(n, 1), np.uint32)
+        nn = C.c_int()
+        check(_lib.lib().orbv_keyframe_download(self._h, k._h, ptr(w), ptr(nd), ptr(fn), ptr(fs), ptr(fi), C.byref(nn)))
+        return w[:n], nd[:n], FeatureVector(fn[:nn.value], fs[:nn.value + 1], fi[:fs[nn.value]])
+
     def keyframe(self, side):
         """Upload a Side once (orbv_keyframe_create); pass the result wherever a Side is accepted."""
         return Keyframe(self, side)

@@ -217,3 +217,47 @@ def test_resident_keyframes_equal_oracle_with_flags_of_the_moment():
     for k in (KA, KB, KC):
         k.close()
     S.close()
+
+
+def test_keyframes_built_on_the_device_from_the_front_end():
+    """extract -> frame -> descents -> FeatureVector -> BoW searches without the features ever leaving HBM
+    (orbf_export_features + orbv_keyframe_from_device); every stage against the oracle on the downloaded copies."""
+    from multi_orb_slam_amd import pipeline
+    voc = synth.vocabulary(10, 3, seed=12, stop_every=6)
+    V, O = product_vocab(voc), oracle.Vocabulary(voc)
+    S = m.BowSearch()
+    params = [m.ExtractorParams(nfeatures=600), m.ExtractorParams(nfeatures=400)]
+    fe = pipeline.FrontEnd(params, 320, 240)
+    sides, kfs = [], []
+    for t in range(2):
+        got = fe.step([synth.image(c, 3 * t, 320, 240) for c in range(2)])
+        feats = fe.fe.export_features()
+        assert feats.n_total == sum(got["counts"]) == len(got["desc"]) and feats.n_total > 500
+        kf = S.keyframe_from_device(V, feats, levelsup=2)
+        w, nd, fv = S.keyframe_download(kf)
+        ow, ond, _ = O.transform(got["desc"], 2)
+        (_, (onid, onstart, oitems)) = O.bow_vectors(got["desc"], 2)
+        assert np.array_equal(w, ow) and np.array_equal(nd, ond)
+        assert np.array_equal(fv.node_id, onid) and np.array_equal(fv.node_start, onstart) and np.array_equal(fv.items, oitems)
+        assert len(oitems) < feats.n_total          # stopped words were dropped
+        n = feats.n_total
+        cam_of = np.repeat(np.arange(2), got["counts"]).astype(np.int32)
+        sides.append(dict(desc=got["desc"], angle=got["kps"]["angle"], flags=(1 | ((got["uright"] >= 0) << 1)).astype(np.uint8), node_id=onid,
+                          node_start=onstart, items=oitems, x=got["un_x"], y=got["un_y"], octave=got["kps"]["octave"], cam_of=cam_of))
+        kfs.append(kf)
+    a, b = sides
+    for mode in (0, 1):
+        nm, match = S.search_by_bow_resident(kfs[0], kfs[1], mode, None, None, 50, 0.8, True)
+        onm, omatch = oracle.search_by_bow(a, b, mode, 50, 0.8, True)
+        assert nm == onm and np.array_equal(match, omatch)
+    assert nm > 30
+    sf = oracle.tables()["scale"]; s2 = (sf * sf).astype(np.float32)
+    F12 = np.array([[0, 0, 0, 0, 0, -1, 0, 1, 0]] * 2, np.float32)       # rows of the two frames line up (the scene moves 9 px in x, 3 in y)
+    ex, ey = np.array([-500.0, -500.0], np.float32), np.array([120.0, 120.0], np.float32)
+    fl_a = (a["flags"] & 2) | 1; fl_b = (b["flags"] & 2) | 1
+    nm, match = S.search_for_triangulation_resident(kfs[0], kfs[1], F12, ex, ey, sf, s2, fl_a, fl_b)
+    onm, omatch = oracle.search_for_triangulation(dict(a, flags=fl_a), dict(b, flags=fl_b), F12, ex, ey, sf, s2)
+    assert nm == onm and np.array_equal(match, omatch)
+    for k in kfs:
+        k.close()
+    fe.close(); S.close(); V.close()
