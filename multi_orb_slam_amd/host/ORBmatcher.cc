@@ -434,6 +434,89 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
     return nFused;
 }
 
+// reference src/ORBmatcher.cc:2211-2517: as above through a Sim3 pose, no reprojection-error gate, duplicates reported in
+// vpReplacePoint instead of being replaced on the spot (vLoopMPCams is not read there either)
+int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<int>& vLoopMPCams, float th,
+                     std::vector<MapPoint*>& vpReplacePoint, const cv::Mat CalibMatrix) {
+    const float& fx = pKF->fx; const float& fy = pKF->fy; const float& cx = pKF->cx; const float& cy = pKF->cy;
+    const cv::Mat Rcam12 = CalibMatrix.rowRange(0, 3).colRange(0, 3);
+    cv::Mat tcam12(3, 1, CV_32F);
+    tcam12.at<float>(0, 0) = CalibMatrix.at<float>(3, 0);
+    tcam12.at<float>(1, 0) = CalibMatrix.at<float>(3, 1);
+    tcam12.at<float>(2, 0) = CalibMatrix.at<float>(3, 2);
+    const cv::Mat Rcam21 = Rcam12.inv();
+    const cv::Mat tcam21 = -Rcam21 * tcam12;
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+    const int nPoints = (int)vpPoints.size();
+    std::vector<orbm_query> q; std::vector<int> src;
+    for (int iMP = 0; iMP < nPoints; iMP++) {
+        MapPoint* pMP = vpPoints[iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        for (int camidx = 0; camidx < 2; ++camidx) {
+            cv::Mat p3Dc;
+            if (camidx == 1) p3Dc = Rcam21 * Rcw * p3Dw + Rcam21 * tcw + tcam21;
+            else p3Dc = Rcw * p3Dw + tcw;
+            if (p3Dc.at<float>(2) < 0.0f) continue;
+            const float invz = 1.0 / p3Dc.at<float>(2);
+            const float x = p3Dc.at<float>(0) * invz;
+            const float y = p3Dc.at<float>(1) * invz;
+            const float u = fx * x + cx;
+            const float v = fy * y + cy;
+            if (!pKF->IsInImage(u, v)) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            cv::Mat PO = p3Dw - Ow;
+            if (camidx == 1) PO = PO - Rcw.t() * tcam12;
+            const float dist3D = cv::norm(PO);
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            cv::Mat Pn = pMP->GetNormal();
+            if (PO.dot(Pn) < 0.5 * dist3D) continue;
+            const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+            const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+            orbm_query Q;
+            Q.u = u; Q.v = v; Q.radius = radius; Q.ur = std::nanf("");
+            Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;
+            Q.cam = camidx; Q.blocks = 0; Q.angle = 0;
+            const cv::Mat dMP = pMP->GetDescriptor();
+            std::memcpy(Q.desc, dMP.ptr(0), 32);
+            q.push_back(Q); src.push_back(iMP);
+        }
+    }
+    dump_queries(q, src);
+    std::vector<int32_t> bi(q.size() ? q.size() : 1, -1), bd(q.size() ? q.size() : 1, 256);
+    if (!q.empty()) {
+        FlatFrame ff;
+        flatten(*pKF, /*cam1_only=*/false, ff);
+        orbm_frame* fr = nullptr;
+        int rc = orbm_frame_create(Handle(), &ff.d, &fr);
+        if (rc) die("orbm_frame_create", rc);
+        rc = orbm_project_best(Handle(), fr, q.data(), (int)q.size(), nullptr, ORBM_GATE_NONE, nullptr, 0, bi.data(), bd.data());
+        orbm_frame_destroy(fr);
+        if (rc) die("orbm_project_best", rc);
+    }
+    int nFused = 0;
+    for (size_t f = 0; f < q.size(); ++f) {            // point by point, camera 1 then camera 2 (:2484-2506)
+        if (bi[f] < 0 || bd[f] > TH_LOW) continue;
+        const int iMP = src[f];
+        MapPoint* pMP = vpPoints[iMP];
+        MapPoint* pMPinKF = pKF->GetMapPoint(bi[f]);
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+        } else {
+            pMP->AddObservation(pKF, bi[f]);
+            pKF->AddMapPoint(pMP, bi[f]);
+        }
+        nFused++;
+    }
+    return nFused;
+}
+
 // reference src/ORBmatcher.cc:206-388
 int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
     const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();

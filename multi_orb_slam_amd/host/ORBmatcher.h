@@ -1,11 +1,11 @@
 // ORBmatcher.h -- drop-in for the hot subset of the reference's include/ORBmatcher.h:37-137: constructor defaults,
 // static DescriptorDistance, the two tracking SearchByProjection overloads, the two SearchByBoW overloads,
-// SearchForTriangulation, the relocalisation / loop-closing SearchByProjection overloads, SearchBySim3_cam1, Fuse(KF, points),
+// SearchForTriangulation, the relocalisation / loop-closing SearchByProjection overloads, SearchBySim3_cam1, both Fuse overloads,
 // the public constants and the public mRcam21 / mtcam21 scratch.  Candidate gathering and Hamming distances run in libmorb.so's HIP kernels
 // (include/orbm.h); the 3-D projection of map points and the order-dependent accept/overwrite/histogram logic stay on
 // the host exactly where the reference has them; the BoW-gated searches run whole on the device (include/orbv.h).  Of
-// the remaining overloads the Sim3 Fuse, the two-camera loop SearchByProjection, the two-camera
-// SearchBySim3 and SearchForInitialization are not part of this round (same device primitives, different host loops).
+// the remaining overloads the two-camera loop SearchByProjection, the two-camera SearchBySim3 (the
+// reference's threads call the _cam1 forms) and SearchForInitialization are not part of this round (same device primitives, different host loops).
 // MORB_DUMP_QUERIES=<file>: every projection search appends the queries it built (int32 count + orbm_query records), so a
 // test can hold the device result against the oracle on exactly those queries.
 #ifndef ORBMATCHER_H
@@ -55,6 +55,10 @@ public:
 
     // Project MapPoints into KeyFrame and search for duplicated MapPoints.
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const cv::Mat CalibMatrix, const float th = 3.0);
+
+    // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints.
+    int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<int>& vLoopMPCams, float th,
+             std::vector<MapPoint*>& vpReplacePoint, const cv::Mat CalibMatrix);
 
     // Search matches between MapPoints in a KeyFrame and ORB in a Frame.
     // Brute force constrained to ORB that belong to the same vocabulary node (at a certain level)

@@ -107,6 +107,7 @@ public:
     // members the remaining projection searches read
     std::vector<MapPoint*> GetMapPointMatches_cam1() { return std::vector<MapPoint*>(mvpMapPoints.begin(), mvpMapPoints.begin() + N); }
     void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+    std::set<MapPoint*> GetMapPoints() { std::set<MapPoint*> s; for (MapPoint* p : mvpMapPoints) if (p && !p->isBad()) s.insert(p); return s; }
     bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
     int N = 0, N_cam2 = 0, N_total = 0;
     std::vector<cv::KeyPoint> mvKeysUn;   // camera 1

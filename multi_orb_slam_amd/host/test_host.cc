@@ -369,6 +369,13 @@ static int run_f4(int argc, char** argv) {
     put(f, &n4, 4);
     for (int g = 0; g < KB.N_total; ++g) { int id = id_of(KB.mvpMapPoints[g]); put(f, &id, 4); }
     for (int i = 0; i < M; ++i) { int rep = id_of(pool[i].mpReplaced), bad = pool[i].mbBad ? 1 : 0; put(f, &rep, 4); put(f, &bad, 4); }
+    // Fuse through the Sim3 pose of the loop: the loop points into KA (both cameras)
+    std::vector<MapPoint*> vpReplace(loop_pts.size(), nullptr);
+    std::vector<int> cams(loop_pts.size(), 0);
+    const int n5 = m.Fuse(&KA, Scw, loop_pts, cams, th_fuse + 1.0f, vpReplace, calib);
+    put(f, &n5, 4);
+    for (int g = 0; g < KA.N_total; ++g) { int id = id_of(KA.mvpMapPoints[g]); put(f, &id, 4); }
+    for (size_t i = 0; i < vpReplace.size(); ++i) { int id = id_of(vpReplace[i]); put(f, &id, 4); }
     std::fclose(f);
     return 0;
 }

@@ -32,6 +32,7 @@ def test_host_library_exports_reference_signatures():
                  "ORB_SLAM2::ORBmatcher::SearchByProjection_cam1(ORB_SLAM2::KeyFrame*, cv::Mat, std::vector<ORB_SLAM2::MapPoint*",
                  "ORB_SLAM2::ORBmatcher::SearchBySim3_cam1(ORB_SLAM2::KeyFrame*, ORB_SLAM2::KeyFrame*, std::vector<ORB_SLAM2::MapPoint*",
                  "ORB_SLAM2::ORBmatcher::Fuse(ORB_SLAM2::KeyFrame*, std::vector<ORB_SLAM2::MapPoint*",
+                 "ORB_SLAM2::ORBmatcher::Fuse(ORB_SLAM2::KeyFrame*, cv::Mat, std::vector<ORB_SLAM2::MapPoint*",
                  "ORB_SLAM2::ORBVocabulary::loadFromTextFile(std::", "ORB_SLAM2::ORBVocabulary::transform(std::vector<cv::Mat",
                  "ORB_SLAM2::ORBVocabulary::score(DBoW2::BowVector const&, DBoW2::BowVector const&)",
                  "ORB_SLAM2::ORBmatcher::TH_HIGH", "ORB_SLAM2::ORBmatcher::TH_LOW", "ORB_SLAM2::ORBmatcher::HISTO_LENGTH"):
@@ -453,7 +454,7 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
         q = np.frombuffer(qb, QUERY_DTYPE, n, off).copy(); off += 68 * n
         src = np.frombuffer(qb, np.int32, n, off).copy(); off += 4 * n
         sets.append((q, src))
-    assert len(sets) == 5
+    assert len(sets) == 6
     buf = (tmp_path / "out.bin").read_bytes(); off = 0
 
     def take(n):
@@ -462,6 +463,7 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
         return a
     n1 = take(1)[0]; got_cur = take(sum(nC)); n2 = take(1)[0]; got_matched = take(nA[0]); n3 = take(1)[0]; got_m12 = take(nA[0])
     n4 = take(1)[0]; got_kb = take(sum(nB)); rep_bad = take(2 * len(pool)).reshape(-1, 2)
+    n5 = take(1)[0]; got_ka = take(sum(nA)); got_replace = take(len(loop_ids))
 
     # ---- relocalisation
     q, src = sets[0]
@@ -525,3 +527,19 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
             nfused += 1
     assert n4 == nfused and np.array_equal(got_kb, kbm) and n4 > 150
     assert np.array_equal(rep_bad[:, 0], rep) and np.array_equal(rep_bad[:, 1], bad)
+    # ---- Fuse through the loop's Sim3 (no reprojection-error gate; duplicates reported, not replaced)
+    q, src = sets[5]
+    assert len(q) > 400 and np.isnan(q["ur"]).all()
+    bi, bd = oracle.project_best(oracle.FrameData(**ka), q, None, 0)
+    kam = idsA.copy(); repl = np.full(len(loop_ids), -1); nf2 = 0
+    for k_ in range(len(q)):
+        if bi[k_] < 0 or bd[k_] > 50:
+            continue
+        other = kam[bi[k_]]
+        if other >= 0:
+            if not bad[other]:
+                repl[src[k_]] = other
+        else:
+            kam[bi[k_]] = loop_ids[src[k_]]
+        nf2 += 1
+    assert n5 == nf2 and np.array_equal(got_ka, kam) and np.array_equal(got_replace, repl) and n5 > 150
