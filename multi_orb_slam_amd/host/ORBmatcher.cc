@@ -138,7 +138,59 @@ void flatten_side(const F& f, const std::vector<cv::KeyPoint>& keys, const DBoW2
     o.s.x = o.x.data(); o.s.y = o.y.data(); o.s.octave = o.oct.data(); o.s.cam_of = o.cam.data();
 }
 
+// camera-1 view of a Frame / KeyFrame (mDescriptors, mvKeys / mvKeysUn, mFeatVec_cam1) for the _cam1 overloads
+void flatten_side_cam1(const cv::Mat& desc, const std::vector<cv::KeyPoint>& keys, const DBoW2::FeatureVector& fv, int n, FlatSide& o) {
+    o.desc.resize((size_t)n * 32); o.flags.assign(n, 0); o.ang.resize(n);
+    for (int g = 0; g < n; ++g) { std::memcpy(&o.desc[(size_t)g * 32], desc.ptr(g), 32); o.ang[g] = keys[g].angle; }
+    o.nid.clear(); o.nstart.assign(1, 0); o.items.clear();
+    for (const auto& e : fv) {
+        o.nid.push_back(e.first);
+        for (unsigned int idx : e.second) if ((int)idx < n) o.items.push_back(idx);   // `if (realIdx >= N) continue` (:431, :449)
+        o.nstart.push_back((int32_t)o.items.size());
+    }
+    std::memset(&o.s, 0, sizeof(o.s));
+    o.s.n = n; o.s.desc = o.desc.data(); o.s.angle = o.ang.data(); o.s.flags = o.flags.data();
+    o.s.n_nodes = (int)o.nid.size(); o.s.node_id = o.nid.data(); o.s.node_start = o.nstart.data(); o.s.items = o.items.data();
+}
+
 }  // namespace
+
+// reference src/ORBmatcher.cc:390-565: the camera-1 form Tracking::Relocalization calls (src/Tracking.cc:2011)
+int ORBmatcher::SearchByBoW_cam1(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
+    const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches_cam1();
+    vpMapPointMatches = std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL));
+    FlatSide a, b;
+    flatten_side_cam1(pKF->mDescriptors, pKF->mvKeysUn, pKF->mFeatVec_cam1, pKF->N, a);
+    flatten_side_cam1(F.mDescriptors, F.mvKeys, F.mFeatVec_cam1, F.N, b);
+    for (int i = 0; i < pKF->N; ++i) a.flags[i] = (vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad()) ? 1 : 0;
+    b.s.flags = nullptr;
+    std::vector<int32_t> match(F.N > 0 ? F.N : 1);
+    int nmatches = 0;
+    const int rc = orbv_search_by_bow(Bow(), &a.s, &b.s, 0, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
+    if (rc) die("orbv_search_by_bow", rc);
+    for (int g = 0; g < F.N; ++g)
+        if (match[g] >= 0) vpMapPointMatches[g] = vpMapPointsKF[match[g]];
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:1180-1363: the camera-1 form LoopClosing::ComputeSim3 calls (src/LoopClosing.cc:362)
+int ORBmatcher::SearchByBoW_cam1(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) {
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches_cam1();
+    const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches_cam1();
+    vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(NULL));
+    FlatSide a, b;
+    flatten_side_cam1(pKF1->mDescriptors, pKF1->mvKeysUn, pKF1->mFeatVec_cam1, pKF1->N, a);
+    flatten_side_cam1(pKF2->mDescriptors, pKF2->mvKeysUn, pKF2->mFeatVec_cam1, pKF2->N, b);
+    for (int i = 0; i < pKF1->N; ++i) a.flags[i] = (vpMapPoints1[i] && !vpMapPoints1[i]->isBad()) ? 1 : 0;
+    for (int i = 0; i < pKF2->N; ++i) b.flags[i] = (vpMapPoints2[i] && !vpMapPoints2[i]->isBad()) ? 1 : 0;
+    std::vector<int32_t> match(pKF1->N > 0 ? pKF1->N : 1);
+    int nmatches = 0;
+    const int rc = orbv_search_by_bow(Bow(), &a.s, &b.s, 1, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
+    if (rc) die("orbv_search_by_bow", rc);
+    for (int i = 0; i < pKF1->N; ++i)
+        if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]];
+    return nmatches;
+}
 
 // reference src/ORBmatcher.cc:3809-3946 (relocalisation).  Candidates come from the camera-1 grid, no right-coordinate
 // gate, any MapPoint already in the frame hides its feature, every accepted match does too.

@@ -75,6 +75,9 @@ public:
     float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;  // static members in the reference
     DBoW2::BowVector mBowVec;       // all cameras (include/Frame.h:185-187)
     DBoW2::FeatureVector mFeatVec;
+    DBoW2::BowVector mBowVec_cam1;  // camera 1 only (include/Frame.h:186,188)
+    DBoW2::FeatureVector mFeatVec_cam1;
+    std::vector<cv::KeyPoint> mvKeys;   // camera 1, distorted
     float mfLogScaleFactor = 0; int mnScaleLevels = 0;
 };
 
@@ -98,8 +101,8 @@ public:
     std::map<size_t, int> keypoint_to_cam, cont_idx_to_local_cam_idx;
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<float> mvScaleFactors, mvLevelSigma2;
-    DBoW2::BowVector mBowVec;
-    DBoW2::FeatureVector mFeatVec;
+    DBoW2::BowVector mBowVec, mBowVec_cam1;
+    DBoW2::FeatureVector mFeatVec, mFeatVec_cam1;
     cv::Mat mK;                      // 3x3 CV_32F
     float fx = 0, fy = 0, cx = 0, cy = 0;
     cv::Mat Tcw, Tcw_cam2;           // 4x4 CV_32F

@@ -281,6 +281,23 @@ static int run_bow(int argc, char** argv) {
     int np = (int)pairs.size();
     put(f, &nc, 4); put(f, &np, 4);
     for (const auto& pr : pairs) { int a = (int)pr.first, b = (int)pr.second; put(f, &a, 4); put(f, &b, 4); }
+    // the camera-1 forms the reference's threads call: camera-1 vocabulary vectors, camera-1 descriptors / keypoints
+    auto cam1_rows = [](const BowEntity& E) { std::vector<cv::Mat> v; for (int g = 0; g < E.N; ++g) v.push_back(E.desc[0].row(g)); return v; };
+    for (int k = 0; k < 2; ++k) {
+        KeyFrame& K = *Ks[k]; BowEntity& E = *Es[k];
+        K.N = E.N; K.N_cam2 = E.N2; K.N_total = E.n; K.mDescriptors = E.desc[0];
+        K.mvKeysUn.assign(E.keys.begin(), E.keys.begin() + E.N);
+        voc.transform(cam1_rows(E), K.mBowVec_cam1, K.mFeatVec_cam1, levelsup);
+    }
+    F.mDescriptors = EF.desc[0]; F.mvKeys.assign(EF.keys.begin(), EF.keys.begin() + EF.N);
+    voc.transform(cam1_rows(EF), F.mBowVec_cam1, F.mFeatVec_cam1, levelsup);
+    std::vector<MapPoint*> vF1, v121;
+    const int nd = m1.SearchByBoW_cam1(&K1, F, vF1);
+    put(f, &nd, 4);
+    for (int g = 0; g < F.N; ++g) { int idx = vF1[g] ? (int)(vF1[g] - E1.pool.data()) : -1; put(f, &idx, 4); }
+    const int ne = m1.SearchByBoW_cam1(&K1, &K2, v121);
+    put(f, &ne, 4);
+    for (int g = 0; g < E1.N; ++g) { int idx = v121[g] ? (int)(v121[g] - E2.pool.data()) : -1; put(f, &idx, 4); }
     std::fclose(f);
     return 0;
 }

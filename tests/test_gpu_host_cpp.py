@@ -27,6 +27,8 @@ def test_host_library_exports_reference_signatures():
                  "ORB_SLAM2::ORBmatcher::SearchByProjection(ORB_SLAM2::Frame&, ORB_SLAM2::Frame const&, float, bool, cv::Mat)",
                  "ORB_SLAM2::ORBmatcher::SearchByBoW(ORB_SLAM2::KeyFrame*, ORB_SLAM2::Frame&, std::vector<ORB_SLAM2::MapPoint*",
                  "ORB_SLAM2::ORBmatcher::SearchByBoW(ORB_SLAM2::KeyFrame*, ORB_SLAM2::KeyFrame*, std::vector<ORB_SLAM2::MapPoint*",
+                 "ORB_SLAM2::ORBmatcher::SearchByBoW_cam1(ORB_SLAM2::KeyFrame*, ORB_SLAM2::Frame&,",
+                 "ORB_SLAM2::ORBmatcher::SearchByBoW_cam1(ORB_SLAM2::KeyFrame*, ORB_SLAM2::KeyFrame*,",
                  "ORB_SLAM2::ORBmatcher::SearchForTriangulation(ORB_SLAM2::KeyFrame*, ORB_SLAM2::KeyFrame*, cv::Mat, std::vector<std::pair<unsigned long, unsigned long>",
                  "ORB_SLAM2::ORBmatcher::SearchByProjection(ORB_SLAM2::Frame&, ORB_SLAM2::KeyFrame*, std::set<ORB_SLAM2::MapPoint*",
                  "ORB_SLAM2::ORBmatcher::SearchByProjection_cam1(ORB_SLAM2::KeyFrame*, cv::Mat, std::vector<ORB_SLAM2::MapPoint*",
@@ -276,7 +278,11 @@ def test_cpp_vocabulary_and_bow_searches(tmp_path, check_ori, only_stereo, vbcam
     nb = struct.unpack_from("<i", buf, off)[0]; off += 4
     m12 = np.frombuffer(buf, np.int32, n1, off); off += 4 * n1
     nc, npairs = struct.unpack_from("<ii", buf, off); off += 8
-    pairs = np.frombuffer(buf, np.int32, 2 * npairs, off).reshape(-1, 2)
+    pairs = np.frombuffer(buf, np.int32, 2 * npairs, off).reshape(-1, 2); off += 8 * npairs
+    nd = struct.unpack_from("<i", buf, off)[0]; off += 4
+    mF1 = np.frombuffer(buf, np.int32, N2, off); off += 4 * N2
+    ne = struct.unpack_from("<i", buf, off)[0]; off += 4
+    m121 = np.frombuffer(buf, np.int32, N1, off); off += 4 * N1
 
     (oid, oval), (onid, onstart, oitems) = O.bow_vectors(a["desc"], levelsup)
     assert words == int(voc["is_leaf"].sum())
@@ -311,6 +317,16 @@ def test_cpp_vocabulary_and_bow_searches(tmp_path, check_ori, only_stereo, vbcam
     enc, emt = oracle.search_for_triangulation(ta, tb, np.stack(F12), np.array(ex, np.float32), np.array(ey, np.float32), scale, sigma2, 50, bool(check_ori))
     exp_pairs = np.stack([np.flatnonzero(emt >= 0), emt[emt >= 0]], 1)
     assert nc == enc and np.array_equal(pairs, exp_pairs) and nc > 10
+
+    # ---- the camera-1 forms (src/ORBmatcher.cc:390-565, :1180-1363)
+    def cam1(sd, N, flags):
+        (_, (nid, nstart, items)) = O.bow_vectors(sd["desc"][:N], levelsup)
+        return dict(desc=sd["desc"][:N], angle=sd["angle"][:N], flags=flags[:N], node_id=nid, node_start=nstart, items=items)
+    ca, cb = cam1(a, N1, fa["flags"]), cam1(b, N2, fb["flags"])
+    end_, emF1 = oracle.search_by_bow(ca, dict(cb, flags=np.ones(N2, np.uint8)), 0, 50, float(nnratio), bool(check_ori))
+    assert nd == end_ and np.array_equal(mF1, emF1) and nd > 30
+    ene, em121 = oracle.search_by_bow(ca, cb, 1, 50, float(nnratio), bool(check_ori))
+    assert ne == ene and np.array_equal(m121, em121) and ne > 10
 
 
 def _cam1_only(fr, n0):
