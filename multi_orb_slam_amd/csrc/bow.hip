@@ -197,7 +197,10 @@ template <int MODE>
 __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T, int th_low, float nnratio, int check_ori, JoinWork W,
                                                  int claimed_bytes, int lds_cand) {
     extern __shared__ uint4 s_dyn[];
-    uint8_t* s_claimed = (uint8_t*)s_dyn;
+    // one wave per workgroup: its LDS operations execute in program order, so a claim written by lane 0 is seen by every lane's
+    // next read without a barrier -- volatile keeps the compiler from caching or reordering them.  (A __syncthreads() here
+    // would also wait for the match / histogram stores of the accept path to reach L2: ~1 us per accepted match.)
+    volatile uint8_t* s_claimed = (volatile uint8_t*)s_dyn;
     uint4* s_lo = s_dyn + claimed_bytes / 16;
     uint4* s_hi = s_lo + lds_cand;
     int* s_idx = (int*)(s_hi + lds_cand);          // feature index and angle of the staged candidates: the accept path
@@ -316,7 +319,6 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
                         }
                         atomicAdd(&W.hist[HISTO], 1);
                     }
-                    __syncthreads();
                 }
             } else {
                 const unsigned K = wave_min_u32(key2);
@@ -340,11 +342,14 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
 __global__ __launch_bounds__(256) void k_bow_finish(JoinWork W, int n_out, int check_ori, int32_t* __restrict__ h_match, int* __restrict__ h_result) {
     __shared__ int s_keep[3];
     __shared__ int s_removed;
+    __shared__ int s_hist[HISTO + 1];
+    if (threadIdx.x <= HISTO) s_hist[threadIdx.x] = W.hist[threadIdx.x];   // one parallel fetch instead of 30 dependent ones
+    __syncthreads();
     if (threadIdx.x == 0) {
         // ComputeThreeMaxima, src/ORBmatcher.cc:3948-3989
         int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
         for (int i = 0; i < HISTO; i++) {
-            const int s = W.hist[i];
+            const int s = s_hist[i];
             if (s > m1) { m3 = m2; i3 = i2; m2 = m1; i2 = i1; m1 = s; i1 = i; }
             else if (s > m2) { m3 = m2; i3 = i2; m2 = s; i2 = i; }
             else if (s > m3) { m3 = s; i3 = i; }
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256) void k_bow_finish(JoinWork W, int n_out, int c
     }
     if (removed) atomicAdd(&s_removed, removed);
     __syncthreads();
-    if (threadIdx.x == 0) h_result[0] = W.hist[HISTO] - s_removed;
+    if (threadIdx.x == 0) h_result[0] = s_hist[HISTO] - s_removed;
 }
 
 inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }

@@ -3,7 +3,9 @@
 
 Launches, on one stream: a 1 GiB hipMemset (known write bytes: WRITE_SIZE calibration), a 1 GiB device-to-device
 copy (known read + write bytes: FETCH_SIZE calibration), then k_hamming_matrix at Q = R = 32000 and k_hamming_top2 at
-4000 x 4000 and 32000 x 32000, a few launches each."""
+4000 x 4000 and 32000 x 32000, a few launches each; then the radius-gated projection search of BASELINE.json configs[2]
+(2 cameras 1280x720, 2000 features each, 4000 projected points: k_project + k_resolve) and the BoW row (k_bow_transform on
+4000 descriptors of the stock-shape vocabulary, k_bow_join between two resident keyframes)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,4 +33,30 @@ for _ in range(5):
 for _ in range(5):
     m.Matcher.hamming_top2_device(dq.ptr, N, dr.ptr, N, res[0].ptr, res[1].ptr, res[2].ptr, scr.ptr, st)
 rt.stream_sync(st)
+
+# ---- configs[2]: SearchByProjection on a 2 x 2000-feature 1280x720 frame
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import helpers  # noqa: E402  (input builders only; the oracle is not loaded here)
+fr = helpers.make_frame_arrays([2000, 2000], 1280, 720, 7)
+qs = helpers.make_queries(fr, 4000, 47, th=15.0)
+F = mt.frame(m.FrameData(**fr))
+for _ in range(5):
+    n_match, _mo = mt.SearchByProjection(F, qs)
+print("configs[2] projection search: %d matches" % n_match)
+F.close()
+
+# ---- BoW row
+voc = synth.vocabulary(10, 6, seed=3)
+V = m.Vocabulary(voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"], voc["L"])
+S = m.BowSearch()
+sides = []
+for seed in (5, 6):
+    f = synth.vocabulary_words(voc, 4000, seed=seed)
+    for _ in range(5):
+        (bow, fv) = V.bow_vectors(f, 4)
+    ang = (helpers.rand_unit(4000, seed) * 360).astype(np.float32)
+    sides.append(S.keyframe(m.BowSide(f, ang, fv)))
+for _ in range(5):
+    nm, _ = S.search_by_bow_resident(sides[0], sides[1], 1)
+print("BoW search: %d matches" % nm)
 print("done")
