@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_bow.py tests/test_gpu_host_cpp.py -x -q -m gpu 2>&1 | tail -3
-timeout 900 python tools/bow_bench.py 2>&1 | grep -v transform | tail -13 | cut -c1-230
+for i in 1 2 3 4 5; do
+  (cd build/ab/old && python3 bench.py --steps 3000 --warmup 200 --no-cpu --no-roofline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('old', d['value'], d['ms_per_step'])")
+  python3 bench.py --steps 3000 --warmup 200 --no-cpu --no-roofline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('new', d['value'], d['ms_per_step'])"
+done
