@@ -676,16 +676,16 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     // shortlist written by k_project: keys (dist << 16 | visiting position) and feature indices, sorted, occupied excluded
     const int* tk_key = topk;                             // [k*nq + i]
     const int* tk_g = topk + RESOLVE_K * nq;      // [k*nq + i]
-    // LDS after the two claim tables: rescan list u16[nq] (padded to 4 bytes); with LDSQ also
-    //   choice[nq] | shortlist g [K][nq] | query angle [nq] | feature angle [F.n_total] | shortlist d [K][nq] (u16) | flags [nq] (u8)
+    // LDS after the two claim tables: rescan list u16[nq] + candidate counts u16[nq]; with LDSQ also
+    //   choice[nq] | shortlist (distance << 16 | feature, 0xffff = none) [K][nq] | query angle [nq] | feature angle [F.n_total] | flags [nq] (u8)
     int* s_claim2 = s_claim + F.n_total;
     unsigned short* l_res = reinterpret_cast<unsigned short*>(s_claim + 2 * F.n_total);
-    int* l_choice = s_claim + 2 * F.n_total + (nq + 1) / 2;
-    int* l_g = l_choice + nq;
-    float* l_ang = reinterpret_cast<float*>(l_g + RESOLVE_K * nq);
+    unsigned short* l_cnt = l_res + nq;   // candidate count of every query (rescans start without a trip to HBM)
+    int* l_choice = s_claim + 2 * F.n_total + nq;
+    int* l_gd = l_choice + nq;
+    float* l_ang = reinterpret_cast<float*>(l_gd + RESOLVE_K * nq);
     float* l_fang = l_ang + nq;
-    unsigned short* l_d = reinterpret_cast<unsigned short*>(l_fang + F.n_total);
-    unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_d + RESOLVE_K * nq);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
+    unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_fang + F.n_total);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
     if (tid == 0) { s_red = 0; s_nres2[0] = 0; s_nres2[1] = 0; }
     for (int g = tid; g < F.n_total; g += T) {  // capacity-sized: rows past the real count are never referenced
         s_claim[g] = 0x7fffffff; s_claim2[g] = 0x7fffffff;
@@ -693,15 +693,18 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     }
     int mx = 0;
     for (int i = tid; i < nq; i += T) {  // every load of this pass is independent: one trip to HBM for the whole set-up
-        mx = max(mx, cand_count[i]);
+        const int cnt_i = cand_count[i];
+        mx = max(mx, cnt_i);
+        l_cnt[i] = (unsigned short)min(cnt_i, 65535);
         if (LDSQ) {
             l_choice[i] = -1;
             l_fl[i] = (unsigned char)((q[i].blocks ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
             l_ang[i] = q[i].angle;
 #pragma unroll
             for (int k = 0; k < RESOLVE_K; ++k) {
-                l_g[k * nq + i] = tk_g[k * nq + i];
-                l_d[k * nq + i] = (unsigned short)(tk_key[k * nq + i] >> 16);
+                // distance in the high half, feature in the low one; an empty slot (feature -1) reads 0xffff there (the
+                // LDS-resident form is only chosen for frames below 65535 features)
+                l_gd[k * nq + i] = (tk_key[k * nq + i] & 0xffff0000) | (tk_g[k * nq + i] & 0xffff);
             }
         } else {
             choice[i] = -1;
@@ -730,35 +733,55 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         int& s_nres = s_nres2[it & 1];
         if (tid == 0) s_nres2[(it + 1) & 1] = 0;  // nobody touches the other counter during this sweep
         int ch = 0;
+        // The sweep is bound by the instruction count of its one workgroup (2000 queries on four SIMDs), so the walk is cut
+        // in two: entries 0-1 first -- almost every query is decided there -- and entries 2..K-1 only for waves in which
+        // some lane is still walking (wave-uniform branch).  A claim hides candidate g from query i when it carries this
+        // sweep's read tag and a lower query index, i.e. lies in [tag, tag + i): one subtract and one unsigned compare
+        // (older sweeps carry larger tags, 0x7fffffff is larger still).
+        constexpr int K0 = 2;
         for (int i = tid; i < nq; i += T) {
-            int sg[RESOLVE_K], sd[RESOLVE_K];
-            if (!LDSQ) {  // global shortlist: fetched up front (independent loads in flight), then walked
-#pragma unroll
-                for (int k = 0; k < RESOLVE_K; ++k) {
-                    sg[k] = tk_g[k * nq + i];
-                    sd[k] = tk_key[k * nq + i] >> 16;
-                }
-            }
-            // only "more eligible candidates than the shortlist holds" matters
-            const bool longer = LDSQ ? (l_fl[i] & 2) != 0 : topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K;
+            int gk[RESOLVE_K], dk[RESOLVE_K], ck[RESOLVE_K];
+            const int fl = LDSQ ? (int)l_fl[i] : ((q[i].blocks ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
             const int old = LDSQ ? l_choice[i] : choice[i];
-            int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
+            int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1, g2 = -1;
             int found = 0, taken = 0;
+            bool walking = true;
+            auto fetch = [&](int k) {
+                if (LDSQ) {
+                    const int v = l_gd[k * nq + i];
+                    gk[k] = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
+                    dk[k] = (int)((unsigned)v >> 16);
+                } else { gk[k] = tk_g[k * nq + i]; dk[k] = tk_key[k * nq + i] >> 16; }
+            };
+            auto walk = [&](int k) {
+                if (gk[k] < 0) walking = false;   // the shortlist is sorted: empty slots are at the end
+                if (walking) {
+                    if ((unsigned)(ck[k] - tag) < (unsigned)i) ++taken;
+                    else {
+                        if (found == 0) { best = dk[k]; bidx = gk[k]; }
+                        else { best2 = dk[k]; g2 = gk[k]; }
+                        if (++found >= NEED) walking = false;
+                    }
+                }
+            };
 #pragma unroll
-            for (int k = 0; k < RESOLVE_K; ++k) {
-                if (found >= NEED) break;
-                const int g = LDSQ ? l_g[k * nq + i] : sg[k];
-                if (g < 0) break;  // the shortlist is sorted: empty slots are at the end
-                const int cl = rd[g];
-                if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) { ++taken; continue; }
-                const int d = LDSQ ? (int)l_d[k * nq + i] : sd[k];
-                if (found == 0) { best = d; bidx = g; if (POINTS) lvl = F.octave[g]; }
-                else { best2 = d; lvl2 = F.octave[g]; }
-                ++found;
+            for (int k = 0; k < K0; ++k) fetch(k);
+#pragma unroll
+            for (int k = 0; k < K0; ++k) ck[k] = gk[k] >= 0 ? rd[gk[k]] : 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < K0; ++k) walk(k);
+            if (__ballot(walking)) {
+#pragma unroll
+                for (int k = K0; k < RESOLVE_K; ++k) fetch(k);
+#pragma unroll
+                for (int k = K0; k < RESOLVE_K; ++k) ck[k] = gk[k] >= 0 ? rd[gk[k]] : 0x7fffffff;
+#pragma unroll
+                for (int k = K0; k < RESOLVE_K; ++k) walk(k);
             }
+            if (POINTS) { if (bidx >= 0) lvl = F.octave[bidx]; if (g2 >= 0) lvl2 = F.octave[g2]; }
             // the shortlist is exact unless it ran dry while longer lists exist: those queries are rescanned below, one
             // wave each (rare)
-            if (found < NEED && longer && taken > 0) {
+            if (found < NEED && (fl & 2) && taken > 0) {
                 l_res[atomicAdd(&s_nres, 1)] = (unsigned short)i;
                 continue;
             }
@@ -768,10 +791,11 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
             }
             if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
-            const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;
-            if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
+            if (nc >= 0 && (fl & 1)) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
         }
+        if (it == 0) MORB_PHASE(g_ph_res, 20); else if (it == 5) MORB_PHASE(g_ph_res, 24);
         __syncthreads();
+        if (it == 0) MORB_PHASE(g_ph_res, 21); else if (it == 5) MORB_PHASE(g_ph_res, 25);
         const int nres = s_nres;
 #ifdef MORB_PHASE_CLOCKS
         if (tid == 0 && it < 15) g_ph_res[40 + it] = (unsigned long long)nres;
@@ -780,17 +804,16 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             // full candidate list of query i, 64 candidates per round, keys (distance << 16 | visiting position): the
             // smallest available key is the sequential scan's first minimum, the next one its runner-up
             const int i = l_res[r];
-            const int full = cand_count[i];
-            int k1 = 0x7fffffff, k2 = 0x7fffffff;
+            const int full = l_cnt[i];
+            int k1 = 0x7fffffff, k2 = 0x7fffffff, g1 = -1;
             for (int k0 = 0; k0 < full; k0 += 64) {
                 const int k = k0 + lane;
-                int key = 0x7fffffff;
+                int key = 0x7fffffff, g = -1;
                 if (k < full) {
-                    const int g = cand_idx[k * nq + i];
+                    g = cand_idx[k * nq + i];
                     const int d = cand_dist[k * nq + i];
                     bool avail = !(occupied && occupied[g]);
-                    const int cl = rd[g];
-                    if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) avail = false;
+                    if ((unsigned)(rd[g] - tag) < (unsigned)i) avail = false;
                     if (avail) key = (d << 16) | k;
                 }
                 int m1 = key;
@@ -802,14 +825,17 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) m2 = min(m2, __shfl_xor(m2, o));
                 }
-                // merge the round's (m1 <= m2) into the running (k1 <= k2)
-                if (m1 < k1) { k2 = min(k1, m2); k1 = m1; }
+                // merge the round's (m1 <= m2) into the running (k1 <= k2); the winner's feature index comes along by shuffle
+                if (m1 < k1) {
+                    k2 = min(k1, m2); k1 = m1;
+                    g1 = __shfl(g, __ffsll((long long)__ballot(key == m1)) - 1);   // visiting positions are unique
+                }
                 else k2 = min(k2, m1);
             }
             if (lane == 0) {
                 int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
                 if (k1 != 0x7fffffff) {
-                    best = k1 >> 16; bidx = cand_idx[(k1 & 0xffff) * nq + i];
+                    best = k1 >> 16; bidx = g1;
                     if (POINTS) lvl = F.octave[bidx];
                 }
                 if (POINTS && k2 != 0x7fffffff) { best2 = k2 >> 16; lvl2 = F.octave[cand_idx[(k2 & 0xffff) * nq + i]]; }
@@ -824,6 +850,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
                 if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);
             }
         }
+        if (it == 0) MORB_PHASE(g_ph_res, 22); else if (it == 5) MORB_PHASE(g_ph_res, 26);
         changed = __syncthreads_or(ch);
         MORB_PHASE(g_ph_res, min(3 + it, 50));
     }
@@ -2026,7 +2053,7 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     if (J.nq == 0 || n == 0) return ORB_OK;
     // two claim tables (one int per feature each) + the rescan list (u16 per query, padded); tables that do not fit LDS go
     // to an HBM workspace (GCL variant of the kernel)
-    const size_t lds = (size_t)2 * n * sizeof(int) + (size_t)((J.nq + 1) / 2) * sizeof(int);
+    const size_t lds = (size_t)2 * n * sizeof(int) + (size_t)J.nq * sizeof(int);
     const bool multi = lds > 150 * 1024;  // multi-workgroup resolve with the tables in HBM
     if (m->host_resolve || J.nq > RESOLVE_MAX_Q) return ORB_OK;  // finish() takes the host path
     if (multi) { int rcg = m->d_gclaim.reserve((size_t)2 * n + RS_STATE_INTS); if (rcg) return rcg; }
@@ -2081,8 +2108,8 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
         return ORB_OK;
     }
     // claim table + (when it fits) the per-query sweep state
-    const size_t lds_q = lds + (size_t)nq * (sizeof(int) + sizeof(float) + RESOLVE_K * (sizeof(int) + sizeof(unsigned short)) + 1) + (size_t)n * sizeof(float) + 16;
-    const bool ldsq = lds_q <= 150 * 1024;
+    const size_t lds_q = lds + (size_t)nq * (sizeof(int) + sizeof(float) + RESOLVE_K * sizeof(int) + 1) + (size_t)n * sizeof(float) + 16;
+    const bool ldsq = lds_q <= 150 * 1024 && n < 65535;
     const size_t lds_use = ldsq ? lds_q : lds;
     if (lds_use > 48 * 1024) {
         static bool raised2 = false;
