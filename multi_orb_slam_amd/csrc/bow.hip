@@ -36,17 +36,6 @@ __device__ __forceinline__ int ham256(const uint4& a0, const uint4& a1, const ui
            __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-// wave64 minimum, every lane active; result in every lane
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 __global__ __launch_bounds__(256) void k_bow_transform(const uint4* __restrict__ vdesc, const int* __restrict__ first_child,
                                                        const uint32_t* __restrict__ orig, const uint32_t* __restrict__ word,
                                                        const uint4* __restrict__ feat, int n, int nid_level,

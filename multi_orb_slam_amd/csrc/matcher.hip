@@ -667,21 +667,20 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // two claim tables, one entry per feature each (capacity F.n_total)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_keep[3];
-    __shared__ int s_red, s_nres2[2];  // (rescan counters alternate with the sweep parity: reset one sweep ahead)
+    __shared__ int s_red, s_nres2[2];  // (s_nres2: rescans per sweep, instrumented build only)
     const int tid = threadIdx.x, T = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    const int lane = tid & 63;
     MORB_PHASE(g_ph_res, 0);
     // the actual feature count is only needed by the last loops: nothing of the set-up waits for this load
     const int NT = F.n_total_dev ? *F.n_total_dev : F.n_total;
     // shortlist written by k_project: keys (dist << 16 | visiting position) and feature indices, sorted, occupied excluded
     const int* tk_key = topk;                             // [k*nq + i]
     const int* tk_g = topk + RESOLVE_K * nq;      // [k*nq + i]
-    // LDS after the two claim tables: rescan list u16[nq] + candidate counts u16[nq]; with LDSQ also
+    // LDS after the two claim tables: candidate counts u16[nq] (padded to 4 bytes); with LDSQ also
     //   choice[nq] | shortlist (distance << 16 | feature, 0xffff = none) [K][nq] | query angle [nq] | feature angle [F.n_total] | flags [nq] (u8)
     int* s_claim2 = s_claim + F.n_total;
-    unsigned short* l_res = reinterpret_cast<unsigned short*>(s_claim + 2 * F.n_total);
-    unsigned short* l_cnt = l_res + nq;   // candidate count of every query (rescans start without a trip to HBM)
-    int* l_choice = s_claim + 2 * F.n_total + nq;
+    unsigned short* l_cnt = reinterpret_cast<unsigned short*>(s_claim + 2 * F.n_total);   // candidate count of every query
+    int* l_choice = s_claim + 2 * F.n_total + (nq + 1) / 2;
     int* l_gd = l_choice + nq;
     float* l_ang = reinterpret_cast<float*>(l_gd + RESOLVE_K * nq);
     float* l_fang = l_ang + nq;
@@ -730,8 +729,10 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         const int tag = (0x7ffe - it) << 16, tag_next = (0x7ffd - it) << 16;
         const int* rd = (it & 1) ? s_claim2 : s_claim;
         int* wr = (it & 1) ? s_claim : s_claim2;
+#ifdef MORB_PHASE_CLOCKS
         int& s_nres = s_nres2[it & 1];
-        if (tid == 0) s_nres2[(it + 1) & 1] = 0;  // nobody touches the other counter during this sweep
+        if (tid == 0) s_nres2[(it + 1) & 1] = 0;
+#endif
         int ch = 0;
         // The sweep is bound by the instruction count of its one workgroup (2000 queries on four SIMDs), so the walk is cut
         // in two: entries 0-1 first -- almost every query is decided there -- and entries 2..K-1 only for waves in which
@@ -739,117 +740,115 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         // sweep's read tag and a lower query index, i.e. lies in [tag, tag + i): one subtract and one unsigned compare
         // (older sweeps carry larger tags, 0x7fffffff is larger still).
         constexpr int K0 = 2;
-        for (int i = tid; i < nq; i += T) {
+        for (int base = 0; base < nq; base += T) {   // uniform trip count: the cooperative rescans below need whole waves
+            const int i = base + tid;
+            const bool valid = i < nq;
             int gk[RESOLVE_K], dk[RESOLVE_K], ck[RESOLVE_K];
-            const int fl = LDSQ ? (int)l_fl[i] : ((q[i].blocks ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
-            const int old = LDSQ ? l_choice[i] : choice[i];
-            int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1, g2 = -1;
-            int found = 0, taken = 0;
-            bool walking = true;
-            auto fetch = [&](int k) {
-                if (LDSQ) {
-                    const int v = l_gd[k * nq + i];
-                    gk[k] = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
-                    dk[k] = (int)((unsigned)v >> 16);
-                } else { gk[k] = tk_g[k * nq + i]; dk[k] = tk_key[k * nq + i] >> 16; }
-            };
-            auto walk = [&](int k) {
-                if (gk[k] < 0) walking = false;   // the shortlist is sorted: empty slots are at the end
-                if (walking) {
-                    if ((unsigned)(ck[k] - tag) < (unsigned)i) ++taken;
-                    else {
-                        if (found == 0) { best = dk[k]; bidx = gk[k]; }
-                        else { best2 = dk[k]; g2 = gk[k]; }
-                        if (++found >= NEED) walking = false;
+            int fl = 0, old = -1, nc = -1;
+            bool need_rescan = false;
+            if (valid) {
+                fl = LDSQ ? (int)l_fl[i] : ((q[i].blocks ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
+                old = LDSQ ? l_choice[i] : choice[i];
+                int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1, g2 = -1;
+                int found = 0, taken = 0;
+                bool walking = true;
+                auto fetch = [&](int k) {
+                    if (LDSQ) {
+                        const int v = l_gd[k * nq + i];
+                        gk[k] = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
+                        dk[k] = (int)((unsigned)v >> 16);
+                    } else { gk[k] = tk_g[k * nq + i]; dk[k] = tk_key[k * nq + i] >> 16; }
+                };
+                auto walk = [&](int k) {
+                    if (gk[k] < 0) walking = false;   // the shortlist is sorted: empty slots are at the end
+                    if (walking) {
+                        if ((unsigned)(ck[k] - tag) < (unsigned)i) ++taken;
+                        else {
+                            if (found == 0) { best = dk[k]; bidx = gk[k]; }
+                            else { best2 = dk[k]; g2 = gk[k]; }
+                            if (++found >= NEED) walking = false;
+                        }
                     }
+                };
+#pragma unroll
+                for (int k = 0; k < K0; ++k) fetch(k);
+#pragma unroll
+                for (int k = 0; k < K0; ++k) ck[k] = gk[k] >= 0 ? rd[gk[k]] : 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < K0; ++k) walk(k);
+                if (__ballot(walking)) {
+#pragma unroll
+                    for (int k = K0; k < RESOLVE_K; ++k) fetch(k);
+#pragma unroll
+                    for (int k = K0; k < RESOLVE_K; ++k) ck[k] = gk[k] >= 0 ? rd[gk[k]] : 0x7fffffff;
+#pragma unroll
+                    for (int k = K0; k < RESOLVE_K; ++k) walk(k);
                 }
-            };
-#pragma unroll
-            for (int k = 0; k < K0; ++k) fetch(k);
-#pragma unroll
-            for (int k = 0; k < K0; ++k) ck[k] = gk[k] >= 0 ? rd[gk[k]] : 0x7fffffff;
-#pragma unroll
-            for (int k = 0; k < K0; ++k) walk(k);
-            if (__ballot(walking)) {
-#pragma unroll
-                for (int k = K0; k < RESOLVE_K; ++k) fetch(k);
-#pragma unroll
-                for (int k = K0; k < RESOLVE_K; ++k) ck[k] = gk[k] >= 0 ? rd[gk[k]] : 0x7fffffff;
-#pragma unroll
-                for (int k = K0; k < RESOLVE_K; ++k) walk(k);
+                if (POINTS) { if (bidx >= 0) lvl = F.octave[bidx]; if (g2 >= 0) lvl2 = F.octave[g2]; }
+                // the shortlist is exact unless it ran dry while longer lists exist (rare): rescanned right below
+                need_rescan = found < NEED && (fl & 2) && taken > 0;
+                if (!need_rescan && best <= th_high && bidx >= 0) {
+                    nc = bidx;
+                    if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
+                }
             }
-            if (POINTS) { if (bidx >= 0) lvl = F.octave[bidx]; if (g2 >= 0) lvl2 = F.octave[g2]; }
-            // the shortlist is exact unless it ran dry while longer lists exist: those queries are rescanned below, one
-            // wave each (rare)
-            if (found < NEED && (fl & 2) && taken > 0) {
-                l_res[atomicAdd(&s_nres, 1)] = (unsigned short)i;
-                continue;
-            }
-            int nc = -1;
-            if (best <= th_high && bidx >= 0) {
-                nc = bidx;
-                if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
-            }
-            if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
-            if (nc >= 0 && (fl & 1)) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
-        }
-        if (it == 0) MORB_PHASE(g_ph_res, 20); else if (it == 5) MORB_PHASE(g_ph_res, 24);
-        __syncthreads();
-        if (it == 0) MORB_PHASE(g_ph_res, 21); else if (it == 5) MORB_PHASE(g_ph_res, 25);
-        const int nres = s_nres;
+            // Rescans, one query at a time by the whole wave that owns it, in place: full candidate list of the query, 64
+            // candidates per round, keys (distance << 16 | visiting position) -- the smallest available key is the
+            // sequential scan's first minimum, the next one its runner-up.  (A separate rescan phase behind a barrier cost
+            // one more barrier and ~0.9 us per sweep that had any.)
+            unsigned long long todo = __ballot(need_rescan);
 #ifdef MORB_PHASE_CLOCKS
-        if (tid == 0 && it < 15) g_ph_res[40 + it] = (unsigned long long)nres;
+            if (todo && lane == 0 && it < 15) atomicAdd(&s_nres, __popcll(todo));
 #endif
-        for (int r = wave; r < nres; r += nwaves) {
-            // full candidate list of query i, 64 candidates per round, keys (distance << 16 | visiting position): the
-            // smallest available key is the sequential scan's first minimum, the next one its runner-up
-            const int i = l_res[r];
-            const int full = l_cnt[i];
-            int k1 = 0x7fffffff, k2 = 0x7fffffff, g1 = -1;
-            for (int k0 = 0; k0 < full; k0 += 64) {
-                const int k = k0 + lane;
-                int key = 0x7fffffff, g = -1;
-                if (k < full) {
-                    g = cand_idx[k * nq + i];
-                    const int d = cand_dist[k * nq + i];
-                    bool avail = !(occupied && occupied[g]);
-                    if ((unsigned)(rd[g] - tag) < (unsigned)i) avail = false;
-                    if (avail) key = (d << 16) | k;
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int qi = __builtin_amdgcn_readlane(i, src);
+                const int full = l_cnt[qi];
+                int k1 = 0x7fffffff, k2 = 0x7fffffff, g1 = -1;
+                for (int k0 = 0; k0 < full; k0 += 64) {
+                    const int k = k0 + lane;
+                    int key = 0x7fffffff, g = -1;
+                    if (k < full) {
+                        g = cand_idx[k * nq + qi];
+                        const int d = cand_dist[k * nq + qi];
+                        bool avail = !(occupied && occupied[g]);
+                        if ((unsigned)(rd[g] - tag) < (unsigned)qi) avail = false;
+                        if (avail) key = (d << 16) | k;
+                    }
+                    const int m1 = (int)wave_min_u32((unsigned)key);   // keys are non-negative: unsigned order == signed order
+                    int m2 = 0x7fffffff;
+                    if (POINTS) m2 = (int)wave_min_u32((unsigned)(key == m1 ? 0x7fffffff : key));
+                    // merge the round's (m1 <= m2) into the running (k1 <= k2); the winner's feature comes along by readlane
+                    if (m1 < k1) {
+                        k2 = min(k1, m2); k1 = m1;
+                        g1 = __builtin_amdgcn_readlane(g, __ffsll((long long)__ballot(key == m1)) - 1);   // positions are unique
+                    }
+                    else k2 = min(k2, m1);
                 }
-                int m1 = key;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m1 = min(m1, __shfl_xor(m1, o));
-                int m2 = 0x7fffffff;
-                if (POINTS) {
-                    m2 = key == m1 ? 0x7fffffff : key;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) m2 = min(m2, __shfl_xor(m2, o));
-                }
-                // merge the round's (m1 <= m2) into the running (k1 <= k2); the winner's feature index comes along by shuffle
-                if (m1 < k1) {
-                    k2 = min(k1, m2); k1 = m1;
-                    g1 = __shfl(g, __ffsll((long long)__ballot(key == m1)) - 1);   // visiting positions are unique
-                }
-                else k2 = min(k2, m1);
-            }
-            if (lane == 0) {
-                int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
+                int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;   // (wave-uniform from here on)
                 if (k1 != 0x7fffffff) {
                     best = k1 >> 16; bidx = g1;
                     if (POINTS) lvl = F.octave[bidx];
                 }
-                if (POINTS && k2 != 0x7fffffff) { best2 = k2 >> 16; lvl2 = F.octave[cand_idx[(k2 & 0xffff) * nq + i]]; }
-                int nc = -1;
+                if (POINTS && k2 != 0x7fffffff) { best2 = k2 >> 16; lvl2 = F.octave[cand_idx[(k2 & 0xffff) * nq + qi]]; }
+                int rnc = -1;
                 if (best <= th_high && bidx >= 0) {
-                    nc = bidx;
-                    if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
+                    rnc = bidx;
+                    if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) rnc = -1;
                 }
-                const int old = LDSQ ? l_choice[i] : choice[i];
+                if (lane == src) nc = rnc;
+            }
+            if (valid) {
                 if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
-                const int bl = LDSQ ? (l_fl[i] & 1) : q[i].blocks;
-                if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);
+                if (nc >= 0 && (fl & 1)) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
             }
         }
+#ifdef MORB_PHASE_CLOCKS
+        __syncthreads();
+        if (tid == 0 && it < 15) g_ph_res[40 + it] = (unsigned long long)s_nres;
+#endif
+        if (it == 0) MORB_PHASE(g_ph_res, 20); else if (it == 5) MORB_PHASE(g_ph_res, 24);
         if (it == 0) MORB_PHASE(g_ph_res, 22); else if (it == 5) MORB_PHASE(g_ph_res, 26);
         changed = __syncthreads_or(ch);
         MORB_PHASE(g_ph_res, min(3 + it, 50));
@@ -2051,9 +2050,9 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     const int n = J.cur->n_total;
     J.device_path = false;
     if (J.nq == 0 || n == 0) return ORB_OK;
-    // two claim tables (one int per feature each) + the rescan list (u16 per query, padded); tables that do not fit LDS go
+    // two claim tables (one int per feature each) + the candidate counts (u16 per query, padded); tables that do not fit LDS go
     // to an HBM workspace (GCL variant of the kernel)
-    const size_t lds = (size_t)2 * n * sizeof(int) + (size_t)J.nq * sizeof(int);
+    const size_t lds = (size_t)2 * n * sizeof(int) + (size_t)((J.nq + 1) / 2) * sizeof(int);
     const bool multi = lds > 150 * 1024;  // multi-workgroup resolve with the tables in HBM
     if (m->host_resolve || J.nq > RESOLVE_MAX_Q) return ORB_OK;  // finish() takes the host path
     if (multi) { int rcg = m->d_gclaim.reserve((size_t)2 * n + RS_STATE_INTS); if (rcg) return rcg; }

@@ -32,6 +32,18 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
+// wave64 minimum on the same DPP path (six VALU-rate steps; a __shfl_xor butterfly is six dependent LDS-crossbar round
+// trips).  Every lane of the wave must be active; the result is returned in every lane.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned long long morb_dpp0_u64(unsigned long long v) {
     const unsigned int lo = (unsigned int)morb_dpp0<CTRL, ROW_MASK>((int)(unsigned int)v);

@@ -29,8 +29,8 @@ it = int(v[62])
 idx = [0, 1, 2] + list(range(3, 3 + it)) + [60, 61]
 print("resolve: init, ldsq-load, sweeps x%d, tail, write:" % it, deltas(v, idx), "total", (v[61] - v[0]) / 100.0)
 print("  queries rescanned per sweep:", [int(x) for x in v[40:40 + it]])
-print("  sweep 0: thread-0 loop, first barrier, rescans, closing barrier:", deltas(v, [2, 20, 21, 22, 3]))
+print("  sweep 0: thread-0 loop (incl. its wave's rescans), closing barrier:", deltas(v, [2, 20, 3]))
 if it > 5:
-    print("  sweep 5: thread-0 loop, first barrier, rescans, closing barrier:", deltas(v, [7, 24, 25, 26, 8]))
+    print("  sweep 5: thread-0 loop (incl. its wave's rescans), closing barrier:", deltas(v, [7, 24, 8]))
 lib.morb_debug_phases_matcher(1, out); v = list(out)
 print("frame_build: counts, fill, scan, scatter, sort:", deltas(v, [0, 1, 2, 3, 4, 5]), "total", (v[5] - v[0]) / 100.0)
