@@ -862,6 +862,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
     if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
     if (tid == 0) s_red = 0;
     __syncthreads();
+    MORB_PHASE(g_ph_res, 52);
     const float factor = 1.0f / ORBM_HISTO_LENGTH;
     int acc = 0;
     for (int i = tid; i < nq; i += T) {
@@ -876,34 +877,46 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             if (bin == ORBM_HISTO_LENGTH) bin = 0;
             const bool inr = bin >= 0 && bin < ORBM_HISTO_LENGTH;
             if (LDSQ) l_fl[i] = (unsigned char)((l_fl[i] & 3) | ((inr ? bin + 1 : 0) << 2));
-            // most matches of a frame share a rotation bin: count per wave, one atomic per distinct bin
+            // most matches of a frame share a rotation bin: up to three bins of the wave (those of its first lanes) are
+            // counted with one atomic each, whatever is left (scattered bins: few lanes per address) goes in directly
             unsigned long long todo = __ballot(inr);
-            while (todo) {
-                const int b0 = __shfl(bin, __ffsll((long long)todo) - 1);
+            for (int rounds = 0; todo && rounds < 3; ++rounds) {
+                const int b0 = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);
                 const unsigned long long same = __ballot(inr && bin == b0);
                 if (inr && bin == b0 && lane == __ffsll((long long)same) - 1) atomicAdd(&s_hist[b0], __popcll(same));
                 todo &= ~same;
             }
+            if (inr && ((todo >> lane) & 1)) atomicAdd(&s_hist[bin], 1);
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) atomicAdd(&s_red, acc);
     __syncthreads();
+    MORB_PHASE(g_ph_res, 53);
     if (!POINTS && check_ori) {
-        if (tid == 0) {  // ComputeThreeMaxima (reference src/ORBmatcher.cc:3948-3989)
-            int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
-            for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
-                const int sz = s_hist[b];
-                if (sz > m1) { m3 = m2; i3 = i2; m2 = m1; i2 = i1; m1 = sz; i1 = b; }
-                else if (sz > m2) { m3 = m2; i3 = i2; m2 = sz; i2 = b; }
-                else if (sz > m3) { m3 = sz; i3 = b; }
+        if (tid < 64) {
+            // ComputeThreeMaxima (reference src/ORBmatcher.cc:3948-3989).  Its scan with strict '>' keeps the three fullest
+            // non-empty bins, the earlier bin first among equals: bin b's place is the number of bins that beat it
+            // (fuller, or as full and earlier) -- 30 readlanes on one wave instead of 30 dependent LDS reads on one thread.
+            const int sv = tid < ORBM_HISTO_LENGTH ? s_hist[tid] : 0;
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < ORBM_HISTO_LENGTH; ++j) {
+                const int sj = __builtin_amdgcn_readlane(sv, j);
+                rank += (sj > sv || (sj == sv && j < tid)) ? 1 : 0;
             }
+            const bool in = tid < ORBM_HISTO_LENGTH && sv > 0;
+            const unsigned long long r1 = __ballot(in && rank == 0), r2 = __ballot(in && rank == 1), r3 = __ballot(in && rank == 2);
+            int i1 = r1 ? __ffsll((long long)r1) - 1 : -1, i2 = r2 ? __ffsll((long long)r2) - 1 : -1, i3 = r3 ? __ffsll((long long)r3) - 1 : -1;
+            const int m1 = i1 >= 0 ? __builtin_amdgcn_readlane(sv, i1) : 0, m2 = i2 >= 0 ? __builtin_amdgcn_readlane(sv, i2) : 0,
+                      m3 = i3 >= 0 ? __builtin_amdgcn_readlane(sv, i3) : 0;
             if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
             else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
-            s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+            if (tid == 0) { s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3; }
         }
         __syncthreads();
+        MORB_PHASE(g_ph_res, 54);
         int rej = 0;
         for (int i = tid; i < nq; i += T) {
             const int c = LDSQ ? l_choice[i] : choice[i];

@@ -30,6 +30,7 @@ idx = [0, 1, 2] + list(range(3, 3 + it)) + [60, 61]
 print("resolve: init, ldsq-load, sweeps x%d, tail, write:" % it, deltas(v, idx), "total", (v[61] - v[0]) / 100.0)
 print("  queries rescanned per sweep:", [int(x) for x in v[40:40 + it]])
 print("  sweep 0: thread-0 loop (incl. its wave's rescans), closing barrier:", deltas(v, [2, 20, 3]))
+print("  tail: reset, owners + histogram, three maxima, reject:", deltas(v, [2 + it, 52, 53, 54, 60]))
 if it > 5:
     print("  sweep 5: thread-0 loop (incl. its wave's rescans), closing barrier:", deltas(v, [7, 24, 8]))
 lib.morb_debug_phases_matcher(1, out); v = list(out)
