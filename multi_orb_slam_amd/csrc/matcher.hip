@@ -311,13 +311,8 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
                 cs = F.cell_start[cell];
                 cn = F.cell_start[cell + 1] - cs;
             }
-            int incl = cn;  // inclusive prefix of the item counts over the lanes
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o);
-                if (lane >= o) incl += v;
-            }
-            const int items_in_chunk = __shfl(incl, 63);
+            const int incl = wave_incl_scan(cn);  // inclusive prefix of the item counts over the lanes (DPP)
+            const int items_in_chunk = __builtin_amdgcn_readlane(incl, 63);
             const int excl = incl - cn;
             for (int tbase = 0; tbase < items_in_chunk; tbase += 64) {
                 const int t = tbase + lane;  // t-th item of the chunk in (cell, ascending index) order
@@ -376,11 +371,9 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
                     int key = elig ? ((dist << 16) | pos) : 0x7fffffff;
 #pragma unroll
                     for (int e = 0; e < RESOLVE_K; ++e) {
-                        int mn = key;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+                        const int mn = (int)wave_min_u32((unsigned)key);   // keys are non-negative; DPP, no LDS crossbar
                         if (mn >= sk[RESOLVE_K - 1]) break;  // wave-uniform: nothing left that beats the shortlist tail
-                        const int mg = __shfl(g, __ffsll((long long)__ballot(key == mn)) - 1);
+                        const int mg = __builtin_amdgcn_readlane(g, __ffsll((long long)__ballot(key == mn)) - 1);
                         if (key == mn) key = 0x7fffffff;     // positions are unique, so exactly one lane matches
                         int ck = mn, cg = mg;
 #pragma unroll
