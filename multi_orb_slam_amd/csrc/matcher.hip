@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
                                                  int gate_right, int with_dist, int transposed, int* __restrict__ cand_idx,
                                                  uint16_t* __restrict__ cand_dist, int* __restrict__ cand_count,
                                                  const uint8_t* __restrict__ occupied, int* __restrict__ topk, int short_th,
-                                                 const float* __restrict__ inv_sigma2 = nullptr) {
+                                                 const float* __restrict__ inv_sigma2 = nullptr, int2* __restrict__ qmeta = nullptr) {
     const int lane = threadIdx.x & 63;
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (qi >= nq) return;
@@ -387,6 +387,9 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
     }
     if (lane == 0) {
         cand_count[qi] = total;
+        // what the resolve needs of a query besides its candidates: it never reads the query records themselves, which may
+        // therefore live in pinned host memory (read once, here)
+        if (qmeta) qmeta[qi] = make_int2(Q->blocks, __float_as_int(Q->angle));
         if (topk) {
 #pragma unroll
             for (int k = 0; k < RESOLVE_K; ++k) {
@@ -650,7 +653,7 @@ MORB_PHASE_DECL(g_ph_res);
 // LDSQ: the per-query sweep state (shortlist features + distances, blocks flag, current choice) also lives in LDS, so a
 // sweep touches no global memory at all; used whenever it fits next to the claim table.
 template <bool POINTS, bool LDSQ>
-__global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap,
+__global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __restrict__ qmeta /* {blocks, angle bits} */, int nq, int cap,
                                                   const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
                                                   const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
                                                   const float* __restrict__ f_angle, int th_high, float nnratio,
@@ -690,8 +693,9 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         l_cnt[i] = (unsigned short)min(cnt_i, 65535);
         if (LDSQ) {
             l_choice[i] = -1;
-            l_fl[i] = (unsigned char)((q[i].blocks ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
-            l_ang[i] = q[i].angle;
+            const int2 qm = qmeta[i];
+            l_fl[i] = (unsigned char)((qm.x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
+            l_ang[i] = __int_as_float(qm.y);
 #pragma unroll
             for (int k = 0; k < RESOLVE_K; ++k) {
                 // distance in the high half, feature in the low one; an empty slot (feature -1) reads 0xffff there (the
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             int fl = 0, old = -1, nc = -1;
             bool need_rescan = false;
             if (valid) {
-                fl = LDSQ ? (int)l_fl[i] : ((q[i].blocks ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
+                fl = LDSQ ? (int)l_fl[i] : ((qmeta[i].x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
                 old = LDSQ ? l_choice[i] : choice[i];
                 int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1, g2 = -1;
                 int found = 0, taken = 0;
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
         ++acc;
         atomicMax(&s_claim[c], i);
         if (!POINTS && check_ori) {
-            float rot = LDSQ ? l_ang[i] - l_fang[c] : q[i].angle - f_angle[c];
+            float rot = LDSQ ? l_ang[i] - l_fang[c] : __int_as_float(qmeta[i].y) - f_angle[c];
             if (rot < 0.0) rot += 360.0f;
             int bin = (int)roundf(rot * factor);
             if (bin == ORBM_HISTO_LENGTH) bin = 0;
@@ -918,7 +922,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const orbm_query* 
             if (LDSQ) {
                 bin = (int)(l_fl[i] >> 2) - 1;  // -1: outside the histogram, never rejected
             } else {
-                float rot = q[i].angle - f_angle[c];
+                float rot = __int_as_float(qmeta[i].y) - f_angle[c];
                 if (rot < 0.0) rot += 360.0f;
                 bin = (int)roundf(rot * factor);
                 if (bin == ORBM_HISTO_LENGTH) bin = 0;
@@ -1286,6 +1290,7 @@ struct orbm_matcher {
     DevBuf<uint8_t> d_q, d_r, d_scratch, d_queries, d_occ;
     DevBuf<int32_t> d_i0, d_i1, d_i2, d_choice, d_claim, d_match, d_status, d_x0, d_x1, d_x2;
     DevBuf<int32_t> d_gclaim;  // claim tables of the resolve when they do not fit LDS (2 x features)
+    DevBuf<int2> d_qmeta;      // {blocks, angle} of every query, written by k_project for the resolve
     DevBuf<uint16_t> d_u16;
     PinnedBuf<int32_t> h_i0, h_i1, h_i2, h_match;
     PinnedBuf<int32_t> h_gcnt;            // per-camera counts of a gathered multi-GPU exchange (+ own query count)
@@ -1406,7 +1411,7 @@ void orbm_destroy(orbm_matcher* m) {
     if (m->ev_q) (void)hipEventDestroy(m->ev_q);
     m->h_c0.release(); m->h_c1.release(); m->h_c2.release(); m->d_cscratch.release(); m->h_gcnt.release(); m->d_gstart.release();
     m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release(); m->d_occ.release();
-    m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release();
+    m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release(); m->d_qmeta.release();
     m->d_match.release(); m->d_status.release(); m->d_gclaim.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
     m->h_i0.release(); m->h_i1.release(); m->h_i2.release(); m->h_match.release(); m->h_u16.release(); m->h_ring.release();
     for (FrameBufs* b : m->pool) { b->release(); delete b; }
@@ -1882,7 +1887,7 @@ int orbm_frame_grid(const orbm_frame* f, int32_t* cell_start, int32_t* items) {
 static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap, int gate_right,
                        int with_dist, bool upload_queries, bool to_host, int transposed = 0,
                        const uint8_t* d_occupied = nullptr, int* d_topk = nullptr, int short_th = 256,
-                       const float* d_inv_sigma2 = nullptr) {
+                       const float* d_inv_sigma2 = nullptr, const orbm_query* q_device_visible = nullptr, int2* d_qmeta = nullptr) {
     int rc;
     if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_i0.reserve((size_t)nq * cap)) ||
         (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)))
@@ -1890,8 +1895,8 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
     if (upload_queries)
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, q, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_project, dim3((nq + 3) / 4), dim3(256), 0, m->stream, f->dev(),
-                       (const orbm_query*)m->d_queries.p, nq, cap, gate_right, with_dist, transposed, m->d_i0.p, m->d_u16.p,
-                       m->d_i1.p, d_occupied, d_topk, short_th, d_inv_sigma2);
+                       q_device_visible ? q_device_visible : (const orbm_query*)m->d_queries.p, nq, cap, gate_right, with_dist, transposed,
+                       m->d_i0.p, m->d_u16.p, m->d_i1.p, d_occupied, d_topk, short_th, d_inv_sigma2, d_qmeta);
     MORB_HIP(hipGetLastError());
     if (to_host) {
         if ((rc = m->h_i0.reserve((size_t)nq * cap)) || (rc = m->h_u16.reserve((size_t)nq * cap)) || (rc = m->h_i1.reserve(nq)))
@@ -2050,6 +2055,7 @@ struct SearchJob {
     const orbm_frame* cur; const orbm_query* q; int nq; const uint8_t* occupied;
     bool points; float nnratio; int th_high, check_ori;
     int cap; bool device_path;
+    const orbm_query* q_dev = nullptr;  // device-visible alias of `q` when it lives in mapped pinned memory: read in place, no H2D
 };
 
 static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_device = false) {
@@ -2079,8 +2085,16 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     const orbm_frame* cur = J.cur;
     const int nq = J.nq, cap = J.cap, th_high = J.th_high;
     const float nnratio = J.nnratio;
-    if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device, false, /*transposed=*/1, d_occ, m->d_claim.p,
-                          J.points ? 256 : th_high)))
+    if ((rc = m->d_qmeta.reserve(nq))) return rc;
+    // queries in mapped pinned memory are read in place by k_project (one 68-byte record per wave); only the multi-workgroup
+    // resolve, whose kernels read the records themselves, still wants them in HBM
+    const orbm_query* q_in_place = (J.q_dev && !multi) ? J.q_dev : nullptr;
+    if (J.q_dev && multi) {
+        if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
+        MORB_HIP(hipMemcpyAsync(m->d_queries.p, J.q, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
+    }
+    if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device && !J.q_dev, false, /*transposed=*/1, d_occ, m->d_claim.p,
+                          J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p)))
         return rc;
     if (multi) {
         int* tab0 = m->d_gclaim.p; int* tab1 = tab0 + n; int* state = tab1 + n;
@@ -2125,7 +2139,7 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
         }
     }
 #define MORB_RESOLVE_LAUNCH(PT, LQ)                                                                                      \
-    hipLaunchKernelGGL((k_resolve<PT, LQ>), dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, \
+    hipLaunchKernelGGL((k_resolve<PT, LQ>), dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const int2*)m->d_qmeta.p, \
                        nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
                        (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
                        (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp)
@@ -2762,15 +2776,14 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         next_slot(f, &P.e, &P.set);
         if ((rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS)))) return rc;
     }
-    // queries go through pinned staging; their H2D runs on the side stream next to the extractor's work
+    // queries go through pinned (device-mapped) staging and are read from there by the projection kernel
     if (nq) {
         if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))))
             return rc;
         if (!queries_in_pinned) memcpy(f->h_queries.p, queries, (size_t)nq * sizeof(orbm_query));
-        MORB_HIP(hipMemcpyAsync(m->d_queries.p, f->h_queries.p, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->side_stream));
-        MORB_HIP(hipEventRecord(m->ev_q, m->side_stream));
     }
     P.J = SearchJob{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
+    P.J.q_dev = nq ? reinterpret_cast<const orbm_query*>(f->h_queries.dp) : nullptr;   // no H2D on the step's critical chain
     if ((rc = f->h_match.reserve(std::max(f->cap_total, 1)))) return rc;
     P.async_path = went_async != 0;
     // The export block of this step is final already when its extraction chain has completed cleanly (the usual case with
@@ -2791,7 +2804,6 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     orbx_extractor* ex = f->exs[P.e];
     hipStream_t st_e = (hipStream_t)orbx_stream(ex);
     orbf_frontend::ResultSet& R = f->rs[P.set];
-    const int nq = P.nq;
     const bool do_cross = !(P.flags & ORBF_SKIP_CROSS);
     int rc;
     std::vector<orbm_cam_features>& cams = P.cams;
@@ -2800,7 +2812,6 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         // matching follows the extraction chain (which ends with the frame grid) through its event; counts are in HBM
         P.fr = f->pframe[P.set]; P.fr_persistent = true;
         MORB_HIP(hipStreamWaitEvent(st, f->ev_ready[P.set], 0));  // extraction + frame grid of this step
-        if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
         P.n = P.fr->n_total;
     } else {
         rc = orbx_finish(ex);  // synchronises; counts are on the host from here on
@@ -2808,7 +2819,6 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         // the host-quadtree path returns with its describe kernel still running on the extractor's stream
         MORB_HIP(hipEventRecord(f->ev_extracted, st_e));
         MORB_HIP(hipStreamWaitEvent(st, f->ev_extracted, 0));
-        if (nq) MORB_HIP(hipStreamWaitEvent(st, m->ev_q, 0));
         P.n = 0;
         for (int c = 0; c < f->n_cams; ++c) {
             cams[c].d_kps = orbx_device_keypoints(ex, c); cams[c].d_desc = orbx_device_descriptors(ex, c);
