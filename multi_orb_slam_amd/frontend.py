@@ -16,6 +16,33 @@ def _view(addr, dtype, count, shape=None):
     return a.reshape(shape) if shape is not None else a
 
 
+class _LazyStep(dict):
+    """Result of a step consumed in place (copy=False): the scalars are there, the per-feature arrays become numpy views of the
+    native pinned buffers when first asked for (building a dozen views costs more than the native call itself)."""
+
+    def __init__(self, scalars, makers):
+        super().__init__(scalars)
+        self._makers = makers
+
+    def __missing__(self, key):
+        mk = self._makers.get(key)
+        if mk is None:
+            raise KeyError(key)
+        v = self[key] = mk()
+        return v
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._makers
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def materialise(self):
+        for k in list(self._makers):
+            self[k]
+        return self
+
+
 class NativeFrontEnd:
     def _cached(self, name, addr, dtype, cap, row=None):
         """numpy view over a native pinned buffer, created once per (address) and sliced per step."""
@@ -142,8 +169,21 @@ class NativeFrontEnd:
         nq = r.n_queries if self._nq is None else self._nq
         n = r.n_total
         cap = self.cap_total
-        cp = (lambda a: a.copy()) if copy else (lambda a: a)
         V = self._cached
+        if not copy:
+            scalars = dict(counts=V("counts", r.counts, np.int32, self.n_cams).tolist(), n_temporal=r.nmatches, gpu_wait_us=r.gpu_wait_us,
+                           host_us=tuple(r.host_us), n_queries=nq, n_total=n,
+                           cross_dist_ptrs=(r.cross_best_dist, r.cross_second_dist) if r.cross_best_idx else None)
+            kps, desc, ur, dep, unx, uny, mof = r.kps, r.desc, r.uright, r.depth, r.un_x, r.un_y, r.match_of_feature
+            x0, x1, x2 = r.cross_best_idx, r.cross_best_dist, r.cross_second_dist
+            makers = dict(kps=lambda: V("kps", kps, KP_DTYPE, cap)[:n], desc=lambda: V("desc", desc, np.uint8, cap, 32)[:n],
+                          uright=lambda: V("ur", ur, np.float32, cap)[:n], depth=lambda: V("depth", dep, np.float32, cap)[:n],
+                          un_x=lambda: V("unx", unx, np.float32, cap)[:n], un_y=lambda: V("uny", uny, np.float32, cap)[:n],
+                          match_of_feature=(lambda: V("match", mof, np.int32, cap)[:n]) if nq else (lambda: np.zeros(0, np.int32)))
+            if x0:
+                makers["cross"] = lambda: (V("x0", x0, np.int32, cap)[:n], V("x1", x1, np.int32, cap)[:n], V("x2", x2, np.int32, cap)[:n])
+            return _LazyStep(scalars, makers)
+        cp = lambda a: a.copy()
         out = dict(counts=V("counts", r.counts, np.int32, self.n_cams).tolist(), kps=cp(V("kps", r.kps, KP_DTYPE, cap)[:n]),
                    desc=cp(V("desc", r.desc, np.uint8, cap, 32)[:n]), uright=cp(V("ur", r.uright, np.float32, cap)[:n]),
                    depth=cp(V("depth", r.depth, np.float32, cap)[:n]), un_x=cp(V("unx", r.un_x, np.float32, cap)[:n]),

@@ -125,11 +125,14 @@ class FrontEnd:
             bi, bd, sd, cnts = self.gather.collect(self) if early else self.gather(self)
             assert cnts[self.rank * self.n_cams:(self.rank + 1) * self.n_cams] == r["counts"]
             r["cross"] = (bi, bd, sd)
-        counts = r["counts"]
-        bi, bd, sd = r["cross"]
-        # (native count of accept_cross: the arrays are views of pinned result buffers in the timed loop)
-        bd = np.ascontiguousarray(bd, np.int32); sd = np.ascontiguousarray(sd, np.int32)
-        r["n_cross"] = _lib.lib().orbm_count_ratio_accepted(_lib.ptr(bd), _lib.ptr(sd), len(bd), TH_LOW, BOW_RATIO)
+        # native count of accept_cross; in the timed loop straight from the pinned result buffers
+        ptrs = r.get("cross_dist_ptrs") if not distributed else None
+        if ptrs:
+            r["n_cross"] = _lib.lib().orbm_count_ratio_accepted(ptrs[0], ptrs[1], r["n_total"], TH_LOW, BOW_RATIO)
+        else:
+            bi, bd, sd = r["cross"]
+            bd = np.ascontiguousarray(bd, np.int32); sd = np.ascontiguousarray(sd, np.int32)
+            r["n_cross"] = _lib.lib().orbm_count_ratio_accepted(_lib.ptr(bd), _lib.ptr(sd), len(bd), TH_LOW, BOW_RATIO)
         return r
 
 

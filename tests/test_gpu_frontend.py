@@ -282,3 +282,21 @@ def test_single_rank_rccl_exchange_equals_oracle():
         fe.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_results_consumed_in_place_are_the_same_arrays():
+    """copy_results = False (the timed loop of bench.py): the step hands out lazily built views of the native pinned buffers."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    params = [m.ExtractorParams(nfeatures=300), m.ExtractorParams(nfeatures=150)]
+    fe = pipeline.FrontEnd(params, 320, 240); ofe = OracleFrontEnd(params, 320, 240)
+    fe.copy_results = False
+    for t in range(3):
+        imgs = [synth.image(c, t, 320, 240) for c in range(2)]
+        got = fe.step(imgs)
+        assert "kps" in got and "cross" in got and got.get("nothing") is None and got["n_total"] == sum(got["counts"])
+        exp = ofe.step(imgs)
+        assert got["n_cross"] >= 0
+        assert_same_step(got.materialise(), exp)
+    fe.close()
