@@ -74,6 +74,11 @@ int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images);
  * of one all-gather (every rank has the same capacity, hence the same block size).  Valid until the step after the next
  * one starts; orbm_cross_top2_gathered consumes the gathered blocks. */
 int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_bytes, int* cap_rows);
+/* Before orbf_step_begin: is the export block of the step about to be begun with `images` final already (its extraction
+ * ran ahead and completed cleanly)?  Then *d_block is that block (the one orbf_export_block will name after the begin) and a
+ * multi-GPU caller may start its all-gather even before it begins the step; otherwise *d_block = NULL.  orbf_step_begin
+ * with the same images then reports block_ready = 1. */
+int orbf_peek_block(orbf_frontend* f, const orbf_image* images, const uint8_t** d_block, size_t* block_bytes, int* cap_rows);
 /* queries: the projected last-frame map points (may be NULL / 0 on the first frame) */
 /* HBM-resident per-feature arrays of the last COMPLETED step's merged frame (global feature order, cameras back to back):
  * what a keyframe built on the device starts from (orbv_keyframe_from_device).  Valid until the next step begins. */

@@ -162,6 +162,9 @@ int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int wor
  * handle's main stream; after that stream has been synchronised (orbf_step_end does) _collect copies the results out. */
 int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered, int world, size_t block_bytes, int cap_rows,
                                      int cams_per_rank, int rank, void* after_stream, int wait_after);
+/* (collect: the three result pointers may all be NULL when the caller reads the results in place through _views: pinned
+ * host arrays of *nq_out entries, valid until the next cross-camera search of this matcher) */
+int orbm_cross_top2_gathered_views(orbm_matcher* m, const int32_t** best_idx, const int32_t** best_dist, const int32_t** second_dist);
 int orbm_cross_top2_gathered_collect(orbm_matcher* m, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
                                      int32_t* counts_out, int* nq_out);
 void orbm_frame_destroy(orbm_frame* f);

@@ -154,6 +154,8 @@ def lib():
     L.orbm_cross_top2_gathered_enqueue.argtypes = [vp, vp, i32, C.c_size_t, i32, i32, i32, vp, i32]
     L.orbm_cross_top2_gathered_collect.argtypes = [vp, vp, vp, vp, vp, vp]
     L.orbf_export_block.argtypes = [vp, vp, vp, vp]
+    L.orbf_peek_block.argtypes = [vp, vp, vp, vp, vp]
+    L.orbm_cross_top2_gathered_views.argtypes = [vp, vp, vp, vp]
     L.orbm_cross_top2_gathered.argtypes = [vp, vp, i32, C.c_size_t, i32, i32, i32, vp, vp, vp, vp, vp]
     L.orbf_extractor.argtypes = [vp]; L.orbf_extractor.restype = vp
     L.orbf_matcher.argtypes = [vp]; L.orbf_matcher.restype = vp

@@ -2342,11 +2342,17 @@ int orbm_cross_top2_gathered_collect(orbm_matcher* m, int32_t* best_idx, int32_t
     const int nq = m->h_gcnt.p[n_cams];
     *nq_out = nq;
     if (counts_out) memcpy(counts_out, m->h_gcnt.p, (size_t)n_cams * 4);
-    if (nq) {
+    if (nq && (best_idx || best_dist || second_dist)) {
         MORB_ARG(best_idx && best_dist && second_dist);
         memcpy(best_idx, m->h_c0.p, (size_t)nq * 4); memcpy(best_dist, m->h_c1.p, (size_t)nq * 4);
         memcpy(second_dist, m->h_c2.p, (size_t)nq * 4);
     }
+    return ORB_OK;
+}
+
+int orbm_cross_top2_gathered_views(orbm_matcher* m, const int32_t** best_idx, const int32_t** best_dist, const int32_t** second_dist) {
+    MORB_ARG(m && best_idx && best_dist && second_dist);
+    *best_idx = m->h_c0.p; *best_dist = m->h_c1.p; *second_dist = m->h_c2.p;
     return ORB_OK;
 }
 
@@ -2533,6 +2539,22 @@ int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_b
     *d_block = F->b->d_desc.p;
     *cap_rows = F->desc_rows;
     *block_bytes = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
+    return ORB_OK;
+}
+
+static bool same_images(const std::vector<orbf_image>& a, const orbf_image* b, int n);
+
+int orbf_peek_block(orbf_frontend* f, const orbf_image* images, const uint8_t** d_block, size_t* block_bytes, int* cap_rows) {
+    MORB_ARG(f && images && d_block && block_bytes && cap_rows);
+    *d_block = nullptr; *block_bytes = 0; *cap_rows = 0;
+    if (f->pending.active || f->inflight.empty() || !same_images(f->inflight.front().images, images, f->n_cams)) return ORB_OK;
+    const orbf_frontend::InFlight& I = f->inflight.front();
+    MORB_HIP(hipSetDevice(f->device));
+    if (hipEventQuery(f->ev_ready[I.set]) != hipSuccess) { (void)hipGetLastError(); return ORB_OK; }
+    if (orbx_peek_status(f->exs[I.e]) != 0) return ORB_OK;
+    const orbm_frame* F = f->pframe[I.set];
+    if (!F) return ORB_OK;
+    *d_block = F->b->d_desc.p; *cap_rows = F->desc_rows; *block_bytes = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
     return ORB_OK;
 }
 

@@ -28,9 +28,9 @@ class DescriptorExchange:
         self.recv = None
         self._send = {}
 
-    def _gather(self, frontend):
+    def _gather(self, frontend, block=None):
         torch, dist = self.torch, self.dist
-        ptr, nbytes, rows = frontend.fe.export_block()
+        ptr, nbytes, rows = block if block is not None else frontend.fe.export_block()
         send = self._send.get(ptr)
         if send is None:      # a few blocks alternate (the front end's rotating frames): wrapped once each
             send = self._send[ptr] = torch.as_tensor(_DeviceBlock(ptr, nbytes), device=self.device)
@@ -49,15 +49,22 @@ class DescriptorExchange:
             frontend.mt.wait_for_stream(self.torch.cuda.current_stream().cuda_stream)
         return frontend.mt.cross_top2_gathered(self.recv_ptr, self.world, nbytes, rows, frontend.n_cams, self.rank)
 
+    def gather_ahead(self, frontend, block):
+        """Before the step is even begun (block = FrontEnd.peek_block(images), final already): start the collective now."""
+        self._ahead = self._gather(frontend, block)
+
     def enqueue(self, frontend):
-        """Between FrontEnd begin and end, when begin reported the export block ready: the collective and the gathered
-        matching are enqueued next to the step's own matching; collect() after end() returns what __call__ would."""
-        nbytes, rows = self._gather(frontend)
+        """Between FrontEnd begin and end, when begin reported the export block ready: the collective (unless gather_ahead
+        started it) and the gathered matching are enqueued next to the step's own matching; collect() after end() returns
+        what __call__ would."""
+        ahead = getattr(self, "_ahead", None)
+        self._ahead = None
+        nbytes, rows = ahead if ahead is not None else self._gather(frontend)
         frontend.mt.cross_top2_gathered_enqueue(self.recv_ptr, self.world, nbytes, rows, frontend.n_cams, self.rank,
                                                 self.torch.cuda.current_stream().cuda_stream if self.recv.is_cuda else None)
 
-    def collect(self, frontend):
-        return frontend.mt.cross_top2_gathered_collect()
+    def collect(self, frontend, views=False):
+        return frontend.mt.cross_top2_gathered_collect_views() if views else frontend.mt.cross_top2_gathered_collect()
 
 
 def shard_cameras(n_cameras, world_size, rank):

@@ -120,6 +120,14 @@ class NativeFrontEnd:
         check(_lib.lib().orbf_export_block(self._h, C.byref(p), C.byref(nb), C.byref(rows)))
         return p.value, nb.value, rows.value
 
+    def peek_block(self, images):
+        """Before begin(): (device pointer, bytes, rows) of the step's export block when it is final already, else None
+        (orbf_peek_block).  `images` as for begin()."""
+        self._keep_peek = self._fill(self._imgs, images)
+        p = C.c_void_p(); nb = C.c_size_t(); rows = C.c_int()
+        check(_lib.lib().orbf_peek_block(self._h, self._imgs, C.byref(p), C.byref(nb), C.byref(rows)))
+        return (p.value, nb.value, rows.value) if p.value else None
+
     def export_features(self):
         """HBM-resident arrays of the last completed step's frame (orbf_export_features) -> _lib.DeviceFeatures."""
         from ._lib import DeviceFeatures

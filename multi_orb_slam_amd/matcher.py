@@ -203,6 +203,17 @@ class Matcher:
         check(_lib.lib().orbm_cross_top2_gathered_enqueue(self._h, C.c_void_p(gathered_ptr), world, block_bytes, cap_rows, cams_per_rank,
                                                           rank, C.c_void_p(after_stream or 0), 0 if after_stream is None else 1))
 
+    def cross_top2_gathered_collect_views(self):
+        """Collect half without copies: (best_idx, best_dist, second_dist) as views of the native pinned arrays + counts."""
+        from .frontend import _view
+        cap_rows, n_cams = self._gathered_shape
+        cnt = np.zeros(n_cams, np.int32); nq = C.c_int()
+        check(_lib.lib().orbm_cross_top2_gathered_collect(self._h, None, None, None, ptr(cnt), C.byref(nq)))
+        p = [C.c_void_p() for _ in range(3)]
+        check(_lib.lib().orbm_cross_top2_gathered_views(self._h, *[C.byref(x) for x in p]))
+        n = nq.value
+        return tuple(_view(x.value, np.int32, n) for x in p) + (cnt.tolist(),)
+
     def cross_top2_gathered_collect(self):
         """Collect half: after the handle's main stream has been synchronised (orbf_step_end)."""
         cap_rows, n_cams = self._gathered_shape

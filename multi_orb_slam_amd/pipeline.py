@@ -117,12 +117,17 @@ class FrontEnd:
             # one all-gather per timestep.  When the step's descriptor block is final already at begin (its extraction ran
             # ahead), the collective and the cross-camera matching are enqueued next to the step's own matching; otherwise
             # they follow the step.  Every rank issues exactly one collective per step either way.
+            # (when the block is final before the step is even begun, the collective is started first of all)
+            ahead = self.fe.peek_block(images)
+            if ahead is not None:
+                self.gather.gather_ahead(self, ahead)
             early = self.fe.begin(images, None, SKIP_CROSS, motion=(MOTION[0], MOTION[1], TH_PROJ))
+            assert early or ahead is None
             self.early_exchanges = getattr(self, "early_exchanges", 0) + int(early)
             if early:
                 self.gather.enqueue(self)
             r = self.fe.end(copy=self.copy_results)
-            bi, bd, sd, cnts = self.gather.collect(self) if early else self.gather(self)
+            bi, bd, sd, cnts = self.gather.collect(self, views=not self.copy_results) if early else self.gather(self)
             assert cnts[self.rank * self.n_cams:(self.rank + 1) * self.n_cams] == r["counts"]
             r["cross"] = (bi, bd, sd)
         # native count of accept_cross; in the timed loop straight from the pinned result buffers

@@ -4,11 +4,10 @@ import os, sys, time, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
 import torch, torch.distributed as dist
-import numpy as np
 import multi_orb_slam_amd as m
 from multi_orb_slam_amd import synth, pipeline, rt
 from multi_orb_slam_amd.dist import DescriptorExchange
-dist.init_process_group("nccl", rank=0, world_size=1, **({"device_id": torch.device("cuda", 0)} if os.environ.get("DEVID") == "1" else {}))
+dist.init_process_group("nccl", rank=0, world_size=1)
 torch.cuda.set_device(0)
 W, H, RING = 640, 480, 8
 fe = pipeline.FrontEnd([m.ExtractorParams(nfeatures=1000)] * 2, W, H)
@@ -21,25 +20,53 @@ for t in range(RING):
         b = rt.DeviceBuffer(W * H); b.upload(host[t][c]); row.append(b)
     dev.append(row)
 rt.device_sync()
-RES = os.environ.get("RESIDENT", "1") == "1"
-arg = (lambda t: [(dev[t % RING][c].ptr, W) for c in range(2)]) if RES else (lambda t: host[t % RING])
+arg = lambda t: [(dev[t % RING][c].ptr, W) for c in range(2)]
 fe.copy_results = False
-T = {"step": 0.0, "gather": 0.0}
-orig_step, orig_gather = fe.fe.step, fe.gather.__call__
-def tstep(*a, **k):
-    t0 = time.perf_counter(); r = orig_step(*a, **k); T["step"] += time.perf_counter() - t0; return r
+T = {}
+
+
+def timed(obj, name, key):
+    f = getattr(obj, name)
+
+    def w(*a, **k):
+        t0 = time.perf_counter(); r = f(*a, **k); T[key] = T.get(key, 0.0) + time.perf_counter() - t0; return r
+    setattr(obj, name, w)
+
+
+MODE = os.environ.get("DB_MODE", "")
+if MODE == "nocross":      # the collective only: no gathered matching (results are then stale; timing experiment)
+    fe.gather.enqueue = lambda f: (setattr(fe.gather, "_ahead", None))
+    fe.gather.collect = lambda f, views=False: (None, None, None, [0] * 2)
+    import multi_orb_slam_amd.pipeline as _pl
+    def _step(images, resident=False, next_images=None):
+        if next_images is not None: fe.announce(next_images, resident)
+        images = [(im[0], fe.width, fe.height, im[1], 1) for im in images]
+        ahead = fe.fe.peek_block(images)
+        if ahead is not None: fe.gather.gather_ahead(fe, ahead)
+        fe.fe.begin(images, None, 1, motion=(_pl.MOTION[0], _pl.MOTION[1], _pl.TH_PROJ))
+        fe.gather._ahead = None
+        return fe.fe.end(copy=False)
+    fe.step = _step
+if MODE == "noorder":      # gathered matching not ordered behind the collective's stream (timing experiment only)
+    _orig = fe.mt.cross_top2_gathered_enqueue
+    fe.mt.cross_top2_gathered_enqueue = lambda *a: _orig(*a[:6], None)
+timed(fe.fe, "begin", "begin"); timed(fe.fe, "end", "end"); timed(fe.fe, "prefetch", "prefetch")
+timed(fe.gather, "enqueue", "exchange.enqueue"); timed(fe.gather, "collect", "exchange.collect"); timed(fe.gather, "_gather", "  of which all_gather call")
+g_call = fe.gather.__call__
 class G:
-    def __call__(self, f):
-        t0 = time.perf_counter(); r = orig_gather(f); T["gather"] += time.perf_counter() - t0; return r
-fe.fe.step = tstep; fe.gather = G()
+    def __getattr__(self, k): return getattr(fe_gather, k)
+fe_gather = fe.gather
 gc.collect(); gc.freeze(); gc.disable()
-for i in range(50):
-    fe.step(arg(i), resident=RES, next_images=arg(i + 1))
-T["step"] = T["gather"] = 0.0
-N = 500
+fe.announce(arg(1), resident=True)
+for i in range(100):
+    fe.step(arg(i), resident=True, next_images=arg(i + 2))
+T.clear(); fe.early_exchanges = 0
+N = 1000
 t0 = time.perf_counter()
-for i in range(50, 50 + N):
-    fe.step(arg(i), resident=RES, next_images=arg(i + 1))
+for i in range(100, 100 + N):
+    fe.step(arg(i), resident=True, next_images=arg(i + 2))
 tot = time.perf_counter() - t0
-print("us per step (resident %d): total %.1f | native step %.1f | gather+cross %.1f" % (RES, tot / N * 1e6, T["step"] / N * 1e6, T["gather"] / N * 1e6))
+print("us per step: total %.1f; early exchanges %d of %d" % (tot / N * 1e6, fe.early_exchanges, N))
+for k, v in T.items():
+    print("  %-28s %.1f" % (k, v / N * 1e6))
 dist.destroy_process_group()
