@@ -2091,7 +2091,7 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     const orbm_query* q_in_place = (J.q_dev && !multi) ? J.q_dev : nullptr;
     if (J.q_dev && multi) {
         if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
-        MORB_HIP(hipMemcpyAsync(m->d_queries.p, J.q, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
+        MORB_HIP(hipMemcpyAsync(m->d_queries.p, J.q_dev, (size_t)nq * sizeof(orbm_query), hipMemcpyDefault, m->stream));
     }
     if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device && !J.q_dev, false, /*transposed=*/1, d_occ, m->d_claim.p,
                           J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p)))
@@ -2400,7 +2400,7 @@ struct orbf_frontend {
     int last_flags = 0;  // flags of the most recent step: what announced steps are assumed to want
     int cur = 0;       // set holding the results of the last completed step
     int last_set = 0;  // set most recently handed to an extraction (sets are handed out round robin)
-    PinnedBuf<uint8_t> h_queries;
+    morb::StageBuf h_queries;   // this step's queries: written by the host, read once by k_project
     PinnedBuf<int32_t> h_match;
     // Small rigs (<= 4 cameras): one persistent frame per result set, filled by the extractor's describe kernel (FrameSink)
     orbm_frame* pframe[NSETS] = {nullptr, nullptr, nullptr, nullptr};
@@ -2803,6 +2803,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))))
             return rc;
         if (!queries_in_pinned) memcpy(f->h_queries.p, queries, (size_t)nq * sizeof(orbm_query));
+        f->h_queries.publish();
     }
     P.J = SearchJob{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
     P.J.q_dev = nq ? reinterpret_cast<const orbm_query*>(f->h_queries.dp) : nullptr;   // no H2D on the step's critical chain

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/orb_types.h"
 
@@ -143,6 +144,40 @@ struct PinnedBuf {  // grow-only pinned host buffer, mapped into the device addr
         return ORB_OK;
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }
+};
+
+// Host-written, device-read staging: fine-grained DEVICE memory written by the host through the large BAR when the part has
+// one (136 KB of queries land in HBM in ~4 us and the kernel reads them locally), otherwise mapped pinned host memory (the
+// kernel then fetches over PCIe).  p = host-usable address, dp = device address (the same pointer in the first case; host
+// READS of BAR memory work but are slow -- only rare fallback paths read this buffer back).
+struct StageBuf {
+    uint8_t* p = nullptr;
+    uint8_t* dp = nullptr;
+    size_t cap = 0;
+    bool in_hbm = false;
+    int reserve(size_t n) {
+        if (n <= cap) return ORB_OK;
+        release();
+        int dev = 0, large_bar = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { large_bar = 0; (void)hipGetLastError(); }
+        const char* off = getenv("MORB_NO_BAR_STAGING");
+        if (large_bar && !(off && atoi(off))) {
+            void* q = nullptr;
+            if (hipExtMallocWithFlags(&q, n, hipDeviceMallocFinegrained) == hipSuccess) { p = dp = (uint8_t*)q; cap = n; in_hbm = true; return ORB_OK; }
+            (void)hipGetLastError();
+        }
+        MORB_HIP(hipHostMalloc((void**)&p, n, hipHostMallocMapped));
+        MORB_HIP(hipHostGetDevicePointer((void**)&dp, p, 0));
+        cap = n; in_hbm = false;
+        return ORB_OK;
+    }
+    void release() {
+        if (p) { if (in_hbm) (void)hipFree(p); else (void)hipHostFree(p); }
+        p = nullptr; dp = nullptr; cap = 0; in_hbm = false;
+    }
+    // after the host has written: make the write-combined stores globally visible before a kernel is launched
+    void publish() const { if (in_hbm) __builtin_ia32_sfence(); }
 };
 
 }  // namespace morb
