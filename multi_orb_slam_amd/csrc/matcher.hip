@@ -644,6 +644,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(const int* __restrict__ star
 // status[0]: 0 ok, 1 not converged within max_it (host falls back), 2 a candidate list exceeded cap (host retries);
 // status[1] = nmatches, status[2] = sweeps, status[3] = longest candidate list.
 constexpr int RESOLVE_MAX_Q = 65535;
+constexpr int RESOLVE_PENDING = -0x5eed;   // status word while the resolve kernel has not finished
 MORB_PHASE_DECL(g_ph_res);
 
 // RESOLVE_K (above): sorted shortlist per query built by k_project; a full rescan happens only when all of it is taken
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
     __syncthreads();
     const int maxcount = s_red;
     if (maxcount > cap) {
-        if (tid == 0) { status[0] = 2; status[1] = 0; status[2] = 0; status[3] = maxcount; }
+        if (tid == 0) { status[1] = 0; status[2] = 0; status[3] = maxcount; __threadfence_system(); status[0] = 2; }
         return;
     }
     MORB_PHASE(g_ph_res, 2);
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
         MORB_PHASE(g_ph_res, min(3 + it, 50));
     }
     if (changed) {  // ran out of sweeps
-        if (tid == 0) { status[0] = 1; status[1] = 0; status[2] = it; status[3] = maxcount; }
+        if (tid == 0) { status[1] = 0; status[2] = it; status[3] = maxcount; __threadfence_system(); status[0] = 1; }
         return;
     }
     // owners: the last claimant in query order (claims after a blocking one are impossible, so max index == final owner)
@@ -939,7 +940,11 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
     }
     MORB_PHASE(g_ph_res, 60);
     for (int g = tid; g < NT; g += T) match_of_feature[g] = s_claim[g];
-    if (tid == 0) { status[0] = 0; status[1] = s_red; status[2] = it; status[3] = maxcount; }
+    // status[0] is written last, behind a system-scope fence: a host that finds it changed may read everything else (it polls
+    // this word in pinned memory instead of waiting for the end-of-kernel signal)
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) { status[1] = s_red; status[2] = it; status[3] = maxcount; __threadfence_system(); status[0] = 0; }
     MORB_PHASE(g_ph_res, 61);
 #ifdef MORB_PHASE_CLOCKS
     if (tid == 0) g_ph_res[62] = (unsigned long long)it;
@@ -1311,6 +1316,7 @@ struct orbm_matcher {
     int frame_min_rows = 0;  // the next device-built frame gets at least this many descriptor rows (fixed export block size)
     int last_status[4] = {0, 0, 0, 0};  // {status, nmatches, sweeps, longest list} of the last device resolve
     bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
+    bool foreign_work = false;     // something other than a step's own search was put on the stream (orbf_step_end then waits for all of it)
 };
 
 struct orbm_frame {
@@ -1433,6 +1439,7 @@ int orbm_wait_for_stream(orbm_matcher* m, void* other_stream) {
     // everything enqueued on `other_stream` so far happens before whatever this handle enqueues next (no host wait)
     MORB_HIP(hipEventRecord(m->ev_fork, (hipStream_t)other_stream));
     MORB_HIP(hipStreamWaitEvent(m->stream, m->ev_fork, 0));
+    m->foreign_work = true;
     return ORB_OK;
 }
 
@@ -2055,12 +2062,13 @@ struct SearchJob {
     const orbm_frame* cur; const orbm_query* q; int nq; const uint8_t* occupied;
     bool points; float nnratio; int th_high, check_ori;
     int cap; bool device_path;
+    bool pollable = false;              // single-workgroup resolve in flight: its status word flips last (see k_resolve)
     const orbm_query* q_dev = nullptr;  // device-visible alias of `q` when it lives in mapped pinned memory: read in place, no H2D
 };
 
 static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_device = false) {
     const int n = J.cur->n_total;
-    J.device_path = false;
+    J.device_path = false; J.pollable = false;
     if (J.nq == 0 || n == 0) return ORB_OK;
     // two claim tables (one int per feature each) + the candidate counts (u16 per query, padded); tables that do not fit LDS go
     // to an HBM workspace (GCL variant of the kernel)
@@ -2143,11 +2151,13 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
                        nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
                        (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
                        (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp)
+    m->h_match.p[0] = RESOLVE_PENDING;   // the kernel overwrites it last
     if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
     else { if (J.points) MORB_RESOLVE_LAUNCH(true, false); else MORB_RESOLVE_LAUNCH(false, false); }
 #undef MORB_RESOLVE_LAUNCH
     MORB_HIP(hipGetLastError());  // status + matches are written by the kernel into the mapped pinned buffer
     J.device_path = true;
+    J.pollable = true;
     return ORB_OK;
 }
 
@@ -2331,6 +2341,7 @@ int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered,
     MORB_HIP(hipEventRecord(m->ev_join, sd));
     MORB_HIP(hipStreamWaitEvent(m->stream, m->ev_join, 0));
     m->gathered_cams = n_cams;
+    m->foreign_work = true;
     return ORB_OK;
 }
 
@@ -2410,10 +2421,11 @@ struct orbf_frontend {
     std::deque<InFlight> inflight;
     std::deque<std::vector<orbf_image>> announced;  // declared by orbf_prefetch, not enqueued yet (at most 2)
     int last_e = 0;  // extractor most recently handed a timestep
+    bool poll_ok = true;     // MORB_POLL=0: orbf_step_end always waits with hipStreamSynchronize
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path ...
     int clean_steps = 0;     // ... and set again after a few steps that stayed on the device path
     struct Pending {  // a timestep between orbf_step_begin and orbf_step_end
-        bool active = false, async_path = false, fr_persistent = false, block_ready = false, cross_from_set = false;
+        bool active = false, async_path = false, fr_persistent = false, block_ready = false, cross_from_set = false, forked = false;
         int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
         orbm_frame* fr = nullptr;
         SearchJob J{nullptr, nullptr, 0, nullptr, false, 0.f, 0, 0, 64, false};
@@ -2447,6 +2459,7 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     // run next to this step's matching
     if (rc) { orbf_destroy(f); return rc; }
     f->d_depth.assign(n_cams, nullptr); f->depth_stride.assign(n_cams, 0); f->counts.assign(n_cams, 0);
+    { const char* pe = getenv("MORB_POLL"); f->poll_ok = !(pe && atoi(pe) == 0); }
     f->scale_factors.assign(params[0].nlevels, 1.f);
     if ((rc = orbx_tables(&params[0], f->scale_factors.data(), nullptr, nullptr, nullptr, nullptr, nullptr))) { orbf_destroy(f); return rc; }
     for (int c = 0; c < n_cams; ++c) { f->cam_cap.push_back(params[c].nfeatures + 4 * params[c].nlevels); f->cap_total += f->cam_cap.back(); }
@@ -2871,6 +2884,7 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     // (on the asynchronous path the cross top-2 normally rode at the end of the step's extraction chain already)
     P.cross_from_set = do_cross && P.async_path && R.cross_valid;
     const bool forked = do_cross && n > 0 && !P.cross_from_set;
+    P.forked = forked;
     if (forked) {  // the fork point is the finished frame; the launches on the side stream come after the search's
         hipError_t fe = hipEventRecord(m->ev_fork, st);
         if (fe == hipSuccess) fe = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
@@ -2933,7 +2947,19 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (attempt == 1 && (rc = step_enqueue(f, P, false))) return rc;
         const auto t0 = std::chrono::steady_clock::now();
-        hipError_t herr = hipStreamSynchronize(st);
+        hipError_t herr = hipSuccess;
+        bool polled = false;
+        if (f->poll_ok && P.async_path && P.J.pollable && !P.forked && !m->foreign_work) {
+            // the resolve is the last thing on the stream and flips its status word behind a system fence: watch that word
+            // (a few microseconds sooner than the end-of-kernel signal travels through the runtime)
+            volatile int32_t* flag = m->h_match.p;
+            for (int spin = 0; spin < 400000; ++spin) {
+                if (*flag != RESOLVE_PENDING) { polled = true; break; }
+                __builtin_ia32_pause();
+            }
+        }
+        if (!polled) herr = hipStreamSynchronize(st);
+        m->foreign_work = false;
         out->gpu_wait_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
         out->host_us[0] = us_between(f->t_entry, P.t_impl); out->host_us[1] = us_between(P.t_impl, P.t_enqueued); out->host_us[2] = out->gpu_wait_us;
         t_synced = std::chrono::steady_clock::now();
