@@ -62,8 +62,11 @@ class NativeFrontEnd:
         check(_lib.lib().orbf_create(arr, self.n_cams, max_width, max_height, device, C.byref(self._h)))
         self._res = FResult()
         self._views = {}
+        self._img_cache = {}
+        self._motion_cache = {}
         self.cap_total = sum(p.nfeatures + 4 * p.nlevels for p in self.params)
         self._imgs = (FImage * self.n_cams)()
+        self._ready = C.c_int(0)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -123,9 +126,9 @@ class NativeFrontEnd:
     def peek_block(self, images):
         """Before begin(): (device pointer, bytes, rows) of the step's export block when it is final already, else None
         (orbf_peek_block).  `images` as for begin()."""
-        self._keep_peek = self._fill(self._imgs, images)
+        arr, self._keep_peek = self._image_array(images, self._imgs)
         p = C.c_void_p(); nb = C.c_size_t(); rows = C.c_int()
-        check(_lib.lib().orbf_peek_block(self._h, self._imgs, C.byref(p), C.byref(nb), C.byref(rows)))
+        check(_lib.lib().orbf_peek_block(self._h, arr, C.byref(p), C.byref(nb), C.byref(rows)))
         return (p.value, nb.value, rows.value) if p.value else None
 
     def export_features(self):
@@ -135,6 +138,25 @@ class NativeFrontEnd:
         check(_lib.lib().orbf_export_features(self._h, C.byref(d)))
         return d
 
+    def _image_array(self, images, slot):
+        """ctypes orbf_image array for `images`; HBM-resident frames (tuples) are built once per distinct set and reused (a
+        stream cycles through a ring of buffers), host arrays are filled into the scratch array `slot`."""
+        try:
+            key = tuple(images)
+            arr = self._img_cache.get(key)
+        except TypeError:      # numpy arrays are not hashable: host images
+            key = arr = None
+        if arr is None:
+            if key is not None and all(isinstance(im, tuple) for im in images):
+                arr = (FImage * self.n_cams)()
+                self._fill(arr, images)
+                if len(self._img_cache) < 256:
+                    self._img_cache[key] = arr
+                return arr, []
+            arr = slot
+            return arr, self._fill(arr, images)
+        return arr, []
+
     def prefetch(self, next_images):
         """Declare the images of the step after the next one (orbf_prefetch): their extraction overlaps the next step's
         matching.  The arrays / device buffers must stay alive and unchanged until the step that consumes them returns."""
@@ -142,8 +164,10 @@ class NativeFrontEnd:
             self._next_imgs = (FImage * self.n_cams)()
         if not hasattr(self, "_next_keep"):
             self._next_keep = []
-        self._next_keep = (self._next_keep + [self._fill(self._next_imgs, next_images)])[-4:]   # host arrays stay alive across the steps in between
-        check(_lib.lib().orbf_prefetch(self._h, self._next_imgs))
+        arr, keep = self._image_array(next_images, self._next_imgs)
+        if keep:
+            self._next_keep = (self._next_keep + [keep])[-4:]   # host arrays stay alive across the steps in between
+        check(_lib.lib().orbf_prefetch(self._h, arr))
 
     def step(self, images, queries=None, flags=0, copy=True, motion=None):
         """images: [(ptr_or_array, width, height, stride, on_device)] or uint8 arrays.  `queries`: projected map points, or
@@ -155,18 +179,20 @@ class NativeFrontEnd:
     def begin(self, images, queries=None, flags=0, motion=None):
         """First half of step() (orbf_step_begin): everything is enqueued, nothing waited for.  Returns True when the step's
         export block is already final, i.e. a multi-GPU exchange may be enqueued before end()."""
-        self._keep = self._fill(self._imgs, images)
-        ready = C.c_int(0)
+        arr, self._keep = self._image_array(images, self._imgs)
+        ready = self._ready
         if motion is not None:
-            mo = FMotion(*motion)
-            check(_lib.lib().orbf_step_motion_begin(self._h, self._imgs, C.byref(mo), flags, C.byref(ready)))
+            mo = self._motion_cache.get(motion)
+            if mo is None:
+                mo = self._motion_cache[motion] = FMotion(*motion)
+            check(_lib.lib().orbf_step_motion_begin(self._h, arr, C.byref(mo), flags, C.byref(ready)))
             self._nq = None
         else:
             nq = 0 if queries is None else len(queries)
             if nq:
                 queries = np.ascontiguousarray(queries, QUERY_DTYPE)
             self._keep.append(queries)
-            check(_lib.lib().orbf_step_begin(self._h, self._imgs, ptr(queries) if nq else None, nq, flags, C.byref(ready)))
+            check(_lib.lib().orbf_step_begin(self._h, arr, ptr(queries) if nq else None, nq, flags, C.byref(ready)))
             self._nq = nq
         return bool(ready.value)
 
