@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-overlap", action="store_true", help="every step extracts its own images first (no orbf_prefetch)")
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--matrix-n", type=int, default=MATRIX_N)

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do MORB_LIB_PATH=multi_orb_slam_amd/lib/libmorb_phases.so timeout 300 python tools/phase_clocks.py 2>&1 | grep -A3 "^resolve"; done
+for M in "" ""; do DB_MODE=$M timeout 600 python tools/dist_breakdown.py 2>/dev/null | grep -E "us per step|^  " | tr '\n' ';'; echo; done
