@@ -105,6 +105,10 @@ def main():
         import torch
         fe.gather = DescriptorExchange(torch.device("cuda", local), dist)
         fe.world = max(world, 2) if world == 1 else world   # world 1 + forced exchange still takes the block path
+        # the all-gather from inside the native step (RCCL's C API; torch.distributed ships the communicator id once);
+        # MORB_NATIVE_EXCHANGE=0 keeps the torch.distributed collective of DescriptorExchange
+        if os.environ.get("MORB_NATIVE_EXCHANGE", "1") != "0":
+            fe.enable_native_exchange(dist, torch.device("cuda", local))
 
     # ---- synthetic stream of this rank's rig, resident in HBM before timing
     host_frames = [[synth.image(g, t, W, H) for g in gcam] for t in range(RING)]
@@ -199,6 +203,10 @@ def main():
         "overlap": ("the extractions of timesteps t+1 and t+2 run next to the matching of timestep t (orbf_prefetch, two "
                     "extractor instances); one isolated timestep takes %.4f ms" % serial_ms) if overlap else "off",
         "extractor_stage_us": {k: round(v, 1) for k, v in stages.items()},
+        "exchange": ("none (one rank)" if not use_dist else
+                     "one RCCL all-gather of the step's descriptor block per step, issued natively from inside the step (RCCL C API)"
+                     if getattr(fe, "native_exchange", False) else
+                     "one RCCL all-gather of the step's descriptor block per step through torch.distributed"),
     }
     if rank == 0 and not a.no_roofline:
         out["roofline"] = matcher_roofline(rt, m, fe.stream, a.matrix_n)

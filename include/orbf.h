@@ -46,6 +46,10 @@ typedef struct orbf_result { /* all pointers: pinned host memory owned by the ha
     const float* un_y;                /*   themselves unless a calibration with k1 != 0 is set                            */
     float host_us[4];                 /* host timeline of the call: query preparation, enqueue of the whole step,
                                          blocked in the final synchronisation, bookkeeping after it            */
+    int32_t rig_cams;                 /* native exchange active: cameras of the whole rig (world x n_cams), else 0      */
+    const int32_t* rig_counts;        /* [rig_cams] keypoints of every camera of the rig, rank-major; the cross_* arrays
+                                         then hold this rank's features matched against ALL cameras of the rig:
+                                         cross_best_idx indexes the rank-major concatenation of every rank's features */
 } orbf_result;
 
 int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbf_frontend** out);
@@ -94,6 +98,18 @@ typedef struct orbf_device_features {
     void* stream;               /* the stream these arrays were last written on                         */
 } orbf_device_features;
 int orbf_export_features(orbf_frontend* f, orbf_device_features* out);
+
+/* Native multi-GPU exchange (one process per GPU, the cameras of the rig sharded over the ranks).  Rank 0 draws an id
+ * (orbf_exchange_unique_id), the caller ships it to every rank by whatever means it has (torch.distributed broadcast,
+ * MPI, a file), and EVERY rank calls orbf_exchange_init with it (a collective: RCCL's ncclCommInitRank).  From then on
+ * every step ends with exactly one RCCL all-gather of the step's export block, issued from inside the step on the
+ * matcher's side stream -- right behind the step's own matching when the block was final at begin, after it otherwise --
+ * followed by the cross-camera top-2 of this rank's features against the whole rig (orbm_cross_top2_gathered); the
+ * rank-local cross matching is skipped.  All front ends of a communicator must have the same capacities (orbx_params). */
+int orbf_exchange_unique_id(uint8_t* out128);
+int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int rank);
+int orbf_exchange_active(const orbf_frontend* f);   /* world size, 0 = off */
+int orbf_exchange_shutdown(orbf_frontend* f);       /* back to rank-local steps (orbf_destroy does it too) */
 
 int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out);
 /* Synthetic-stream driver: like orbf_step, with the queries built natively from the PREVIOUS step's features moved by a

@@ -49,7 +49,8 @@ class FResult(C.Structure):  # orbf_result
                 ("desc", C.c_void_p), ("uright", C.c_void_p), ("depth", C.c_void_p), ("nmatches", C.c_int32),
                 ("match_of_feature", C.c_void_p), ("cross_best_idx", C.c_void_p), ("cross_best_dist", C.c_void_p),
                 ("cross_second_dist", C.c_void_p), ("gpu_wait_us", C.c_float), ("n_queries", C.c_int32),
-                ("queries", C.c_void_p), ("un_x", C.c_void_p), ("un_y", C.c_void_p), ("host_us", C.c_float * 4)]
+                ("queries", C.c_void_p), ("un_x", C.c_void_p), ("un_y", C.c_void_p), ("host_us", C.c_float * 4),
+                ("rig_cams", C.c_int32), ("rig_counts", C.c_void_p)]
 
 
 class FMotion(C.Structure):  # orbf_motion
@@ -154,6 +155,10 @@ def lib():
     L.orbm_cross_top2_gathered_enqueue.argtypes = [vp, vp, i32, C.c_size_t, i32, i32, i32, vp, i32]
     L.orbm_cross_top2_gathered_collect.argtypes = [vp, vp, vp, vp, vp, vp]
     L.orbf_export_block.argtypes = [vp, vp, vp, vp]
+    L.orbf_exchange_unique_id.argtypes = [vp]
+    L.orbf_exchange_init.argtypes = [vp, vp, i32, i32]
+    L.orbf_exchange_active.argtypes = [vp]
+    L.orbf_exchange_shutdown.argtypes = [vp]
     L.orbf_peek_block.argtypes = [vp, vp, vp, vp, vp]
     L.orbm_cross_top2_gathered_views.argtypes = [vp, vp, vp, vp]
     L.orbm_cross_top2_gathered.argtypes = [vp, vp, i32, C.c_size_t, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -2384,6 +2384,49 @@ int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int wor
 // ================================================================================================ orbf (include/orbf.h)
 }  // extern "C"
 
+// ---- native multi-GPU exchange: RCCL's C API resolved at run time (the copy torch.distributed already loaded, else the
+// ROCm one), one communicator per front end, the all-gather issued on the matcher's side stream from inside the step
+#include <dlfcn.h>
+namespace {
+struct XUniqueId { char internal[128]; };   // ncclUniqueId (rccl.h:43)
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(XUniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, XUniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather; }
+};
+RcclApi& rccl() {
+    static RcclApi api;
+    if (!api.lib) {
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (api.lib) break;
+        }
+        if (!api.lib) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (api.lib) {
+            api.GetUniqueId = (int (*)(XUniqueId*))dlsym(api.lib, "ncclGetUniqueId");
+            api.CommInitRank = (int (*)(void**, int, XUniqueId, int))dlsym(api.lib, "ncclCommInitRank");
+            api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+            api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
+            api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+        }
+    }
+    return api;
+}
+int rccl_fail(const char* what, int r) {
+    RcclApi& R = rccl();
+    morb::set_error("%s failed: %s", what, R.GetErrorString ? R.GetErrorString(r) : "RCCL error");
+    return ORB_E_HIP;
+}
+}  // namespace
+
+
 #include <chrono>
 #include <deque>
 #include "../../include/orbf.h"
@@ -2422,10 +2465,13 @@ struct orbf_frontend {
     std::deque<std::vector<orbf_image>> announced;  // declared by orbf_prefetch, not enqueued yet (at most 2)
     int last_e = 0;  // extractor most recently handed a timestep
     bool poll_ok = true;     // MORB_POLL=0: orbf_step_end always waits with hipStreamSynchronize
+    void* xcomm = nullptr; int xworld = 0, xrank = 0;   // native multi-GPU exchange (orbf_exchange_init)
+    DevBuf<uint8_t> d_xrecv;                            // the gathered export blocks of all ranks
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path ...
     int clean_steps = 0;     // ... and set again after a few steps that stayed on the device path
     struct Pending {  // a timestep between orbf_step_begin and orbf_step_end
         bool active = false, async_path = false, fr_persistent = false, block_ready = false, cross_from_set = false, forked = false;
+        bool x_enqueued = false;   // this step's exchange went out between begin and end
         int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
         orbm_frame* fr = nullptr;
         SearchJob J{nullptr, nullptr, 0, nullptr, false, 0.f, 0, 0, 64, false};
@@ -2480,6 +2526,8 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
 void orbf_destroy(orbf_frontend* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
+    if (f->xcomm) { if (f->mt) (void)hipStreamSynchronize(f->mt->side_stream); (void)rccl().CommDestroy(f->xcomm); f->xcomm = nullptr; }
+    f->d_xrecv.release();
     for (int e = 0; e < 2; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
     if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
@@ -2553,6 +2601,57 @@ int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_b
     *cap_rows = F->desc_rows;
     *block_bytes = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
     return ORB_OK;
+}
+
+int orbf_exchange_unique_id(uint8_t* out128) {
+    MORB_ARG(out128 != nullptr);
+    RcclApi& R = rccl();
+    if (!R.ok()) { morb::set_error("librccl is not available"); return ORB_E_HIP; }
+    XUniqueId id;
+    const int r = R.GetUniqueId(&id);
+    if (r) return rccl_fail("ncclGetUniqueId", r);
+    memcpy(out128, id.internal, 128);
+    return ORB_OK;
+}
+
+int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int rank) {
+    MORB_ARG(f && uid128 && world >= 1 && rank >= 0 && rank < world && world * f->n_cams <= 512 && !f->xcomm);
+    RcclApi& R = rccl();
+    if (!R.ok()) { morb::set_error("librccl is not available"); return ORB_E_HIP; }
+    MORB_HIP(hipSetDevice(f->device));
+    XUniqueId id; memcpy(id.internal, uid128, 128);
+    void* comm = nullptr;
+    const int r = R.CommInitRank(&comm, world, id, rank);
+    if (r) return rccl_fail("ncclCommInitRank", r);
+    const size_t block = (size_t)f->cap_total * 32 + ORBM_BLOCK_TRAILER;
+    int rc = f->d_xrecv.reserve((size_t)world * block);
+    if (rc) { (void)R.CommDestroy(comm); return rc; }
+    f->xcomm = comm; f->xworld = world; f->xrank = rank;
+    return ORB_OK;
+}
+
+int orbf_exchange_active(const orbf_frontend* f) { return f && f->xcomm ? f->xworld : 0; }
+
+int orbf_exchange_shutdown(orbf_frontend* f) {
+    MORB_ARG(f != nullptr);
+    if (!f->xcomm) return ORB_OK;
+    MORB_HIP(hipSetDevice(f->device));
+    if (f->mt) { (void)hipStreamSynchronize(f->mt->side_stream); (void)hipStreamSynchronize(f->mt->stream); }
+    (void)rccl().CommDestroy(f->xcomm);
+    f->xcomm = nullptr; f->xworld = 0; f->xrank = 0;
+    return ORB_OK;
+}
+
+// all-gather of the frame's export block + the gathered cross-camera top-2, all on the matcher's side stream (joined into its
+// main stream): the block must be final (its extraction chain has completed, or the main stream has been synchronised)
+static int exchange_enqueue(orbf_frontend* f, const orbm_frame* F) {
+    RcclApi& R = rccl();
+    orbm_matcher* m = f->mt;
+    const size_t block = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
+    MORB_ARG(F->desc_rows == f->cap_total);
+    const int r = R.AllGather(F->b->d_desc.p, f->d_xrecv.p, block, /*ncclUint8*/ 1, f->xcomm, m->side_stream);
+    if (r) return rccl_fail("ncclAllGather", r);
+    return orbm_cross_top2_gathered_enqueue(m, f->d_xrecv.p, f->xworld, block, F->desc_rows, f->n_cams, f->xrank, nullptr, 0);
 }
 
 static bool same_images(const std::vector<orbf_image>& a, const orbf_image* b, int n);
@@ -2794,6 +2893,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     int rc, went_async = 0;
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
     f->last_frame = nullptr; f->last_frame_owned = false;
+    if (f->xcomm) flags |= ORBF_SKIP_CROSS;   // the rig-wide matching of the exchange replaces the rank-local one
     P.images.assign(images, images + f->n_cams);
     P.nq = nq; P.flags = flags;
 
@@ -2900,6 +3000,11 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
     }
     if (rc) { (void)hipStreamSynchronize(st); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return rc; }
+    // ---- native exchange: a block that is final already goes out right behind the step's own matching
+    if (first_attempt && f->xcomm && P.async_path && P.block_ready && !P.x_enqueued) {
+        if ((rc = exchange_enqueue(f, fr))) return rc;
+        P.x_enqueued = true;
+    }
     // ---- announced timesteps go onto the extractors now: they run while this step is being matched.  At most two
     // are in flight; consecutive ones alternate between the two extractors (an extractor takes its next timestep as
     // a second run behind the one whose results are being matched here).
@@ -3015,6 +3120,18 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     out->cross_best_idx = do_cross ? (from_set ? R.cross.i.p : m->h_c0.p) : nullptr;
     out->cross_best_dist = do_cross ? (from_set ? R.cross.b.p : m->h_c1.p) : nullptr;
     out->cross_second_dist = do_cross ? (from_set ? R.cross.s.p : m->h_c2.p) : nullptr;
+    out->rig_cams = 0; out->rig_counts = nullptr;
+    if (f->xcomm) {
+        // every rank issues exactly one all-gather per step: between begin and end when the block was final at begin, here
+        // otherwise (the block is final now)
+        if (!P.x_enqueued) {
+            if ((rc = exchange_enqueue(f, f->last_frame))) return rc;
+            MORB_HIP(hipStreamSynchronize(st));
+            m->foreign_work = false;
+        }
+        out->cross_best_idx = m->h_c0.p; out->cross_best_dist = m->h_c1.p; out->cross_second_dist = m->h_c2.p;
+        out->rig_cams = m->gathered_cams; out->rig_counts = m->h_gcnt.p;
+    }
     out->host_us[3] = us_between(t_synced, std::chrono::steady_clock::now());
     return ORB_OK;
 }

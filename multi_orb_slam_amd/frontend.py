@@ -123,6 +123,23 @@ class NativeFrontEnd:
         check(_lib.lib().orbf_export_block(self._h, C.byref(p), C.byref(nb), C.byref(rows)))
         return p.value, nb.value, rows.value
 
+    def exchange_unique_id(self):
+        buf = (C.c_uint8 * 128)()
+        check(_lib.lib().orbf_exchange_unique_id(buf))
+        return bytes(buf)
+
+    def exchange_init(self, uid, world, rank):
+        """Collective over the ranks (orbf_exchange_init): from now on every step all-gathers natively over RCCL."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        check(_lib.lib().orbf_exchange_init(self._h, buf, world, rank))
+
+    def exchange_shutdown(self):
+        check(_lib.lib().orbf_exchange_shutdown(self._h))
+
+    @property
+    def exchange_world(self):
+        return _lib.lib().orbf_exchange_active(self._h)
+
     def peek_block(self, images):
         """Before begin(): (device pointer, bytes, rows) of the step's export block when it is final already, else None
         (orbf_peek_block).  `images` as for begin()."""
@@ -206,6 +223,7 @@ class NativeFrontEnd:
         V = self._cached
         if not copy:
             scalars = dict(counts=V("counts", r.counts, np.int32, self.n_cams).tolist(), n_temporal=r.nmatches, gpu_wait_us=r.gpu_wait_us,
+                           rig_counts=V("rigc", r.rig_counts, np.int32, r.rig_cams).tolist() if r.rig_cams else None,
                            host_us=tuple(r.host_us), n_queries=nq, n_total=n,
                            cross_dist_ptrs=(r.cross_best_dist, r.cross_second_dist) if r.cross_best_idx else None)
             kps, desc, ur, dep, unx, uny, mof = r.kps, r.desc, r.uright, r.depth, r.un_x, r.un_y, r.match_of_feature
@@ -224,6 +242,7 @@ class NativeFrontEnd:
                    un_y=cp(V("uny", r.un_y, np.float32, cap)[:n]), n_temporal=r.nmatches,
                    match_of_feature=cp(V("match", r.match_of_feature, np.int32, cap)[:n]) if nq else np.zeros(0, np.int32),
                    gpu_wait_us=r.gpu_wait_us, host_us=tuple(r.host_us), n_queries=nq)
+        out["rig_counts"] = V("rigc", r.rig_counts, np.int32, r.rig_cams).tolist() if r.rig_cams else None
         if r.cross_best_idx:
             out["cross"] = (cp(V("x0", r.cross_best_idx, np.int32, cap)[:n]), cp(V("x1", r.cross_best_dist, np.int32, cap)[:n]),
                             cp(V("x2", r.cross_second_dist, np.int32, cap)[:n]))

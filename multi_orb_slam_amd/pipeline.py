@@ -90,6 +90,37 @@ class FrontEnd:
     def close(self):
         self.fe.close()
 
+    def enable_native_exchange(self, dist, device):
+        """Collective: switch the multi-GPU exchange to the native form (RCCL's C API from inside the step, no Python or torch
+        call per step).  torch.distributed only carries the communicator id once.  Returns False -- on every rank -- if any
+        rank could not set it up (the torch.distributed exchange stays in charge then)."""
+        import torch
+        world, rank = dist.get_world_size(), dist.get_rank()
+        uid = torch.zeros(128, dtype=torch.uint8, device=device)
+        ok = 1
+        try:
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(self.fe.exchange_unique_id()), dtype=torch.uint8))
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.broadcast(flag, 0)
+        if int(flag.item()) == 0:
+            return False
+        dist.broadcast(uid, 0)
+        try:
+            self.fe.exchange_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+            ok = 1
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            self.fe.exchange_shutdown()
+            return False
+        self.native_exchange = True
+        return True
+
     def reset(self):
         self.fe.reset()
 
@@ -108,7 +139,8 @@ class FrontEnd:
             self.announce(next_images, resident)
         if resident:
             images = [(im[0], self.width, self.height, im[1], 1) for im in images]
-        distributed = self.world > 1 and self.gather is not None
+        native = getattr(self, "native_exchange", False)
+        distributed = self.world > 1 and self.gather is not None and not native
         # queries = the previous step's features under the stream's known motion, built natively (orbf_step_motion;
         # same arithmetic as make_queries, which the oracle leg uses)
         if not distributed:
@@ -130,6 +162,9 @@ class FrontEnd:
             bi, bd, sd, cnts = self.gather.collect(self, views=not self.copy_results) if early else self.gather(self)
             assert cnts[self.rank * self.n_cams:(self.rank + 1) * self.n_cams] == r["counts"]
             r["cross"] = (bi, bd, sd)
+        if native:
+            nc = self.n_cams
+            assert r["rig_counts"][self.rank * nc:(self.rank + 1) * nc] == r["counts"]
         # native count of accept_cross; in the timed loop straight from the pinned result buffers
         ptrs = r.get("cross_dist_ptrs") if not distributed else None
         if ptrs:

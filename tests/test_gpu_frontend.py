@@ -279,6 +279,16 @@ def test_single_rank_rccl_exchange_equals_oracle():
             got = fe.step(frames[t], next_images=frames[t + 2] if t + 2 < T else None)
             assert_same_step(got, ofe.step(frames[t]))
         assert 0 < fe.early_exchanges < T          # both orders of the exchange were exercised
+        # the same steps with the all-gather issued natively from inside the step (RCCL C API, communicator of its own)
+        assert fe.enable_native_exchange(dist, torch.device("cuda", 0)) and fe.fe.exchange_world == 1
+        fe.reset(); ofe = OracleFrontEnd(params, 320, 240)
+        fe.announce(frames[1])
+        for t in range(T):
+            got = fe.step(frames[t], next_images=frames[t + 2] if t + 2 < T else None)
+            assert got["rig_counts"] == got["counts"]
+            assert_same_step(got, ofe.step(frames[t]))
+        fe.fe.exchange_shutdown(); fe.native_exchange = False
+        assert fe.fe.exchange_world == 0
         fe.close()
     finally:
         dist.destroy_process_group()
