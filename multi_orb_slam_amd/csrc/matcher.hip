@@ -644,7 +644,6 @@ __global__ __launch_bounds__(256) void k_sort_cells(const int* __restrict__ star
 // status[0]: 0 ok, 1 not converged within max_it (host falls back), 2 a candidate list exceeded cap (host retries);
 // status[1] = nmatches, status[2] = sweeps, status[3] = longest candidate list.
 constexpr int RESOLVE_MAX_Q = 65535;
-constexpr int RESOLVE_PENDING = -0x5eed;   // status word while the resolve kernel has not finished
 MORB_PHASE_DECL(g_ph_res);
 
 // RESOLVE_K (above): sorted shortlist per query built by k_project; a full rescan happens only when all of it is taken
@@ -660,7 +659,10 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
                                                   const float* __restrict__ f_angle, int th_high, float nnratio,
                                                   int check_ori, int max_it, int* __restrict__ choice,
                                                   const int* __restrict__ topk /* (2*RESOLVE_K+1)*nq ints */,
-                                                  int* __restrict__ match_of_feature, int* __restrict__ status) {
+                                                  int* __restrict__ match_of_feature, int* __restrict__ status, int tagb) {
+    // tagb != 0: every result word carries this launch's sequence number in bits 20.. (values are small: a match word is
+    // stored as value + 2), so a host that watches the pinned result memory can tell, word by word, what has arrived --
+    // words written by different waves reach host memory in no particular order, a single "done" flag proves nothing.
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // two claim tables, one entry per feature each (capacity F.n_total)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_keep[3];
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
     __syncthreads();
     const int maxcount = s_red;
     if (maxcount > cap) {
-        if (tid == 0) { status[1] = 0; status[2] = 0; status[3] = maxcount; __threadfence_system(); status[0] = 2; }
+        if (tid == 0) { status[1] = tagb | 0; status[2] = tagb | 0; status[3] = tagb | maxcount; status[0] = tagb | 2; }
         return;
     }
     MORB_PHASE(g_ph_res, 2);
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
         MORB_PHASE(g_ph_res, min(3 + it, 50));
     }
     if (changed) {  // ran out of sweeps
-        if (tid == 0) { status[1] = 0; status[2] = it; status[3] = maxcount; __threadfence_system(); status[0] = 1; }
+        if (tid == 0) { status[1] = tagb | 0; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | 1; }
         return;
     }
     // owners: the last claimant in query order (claims after a blocking one are impossible, so max index == final owner)
@@ -939,12 +941,8 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
         __syncthreads();
     }
     MORB_PHASE(g_ph_res, 60);
-    for (int g = tid; g < NT; g += T) match_of_feature[g] = s_claim[g];
-    // status[0] is written last, behind a system-scope fence: a host that finds it changed may read everything else (it polls
-    // this word in pinned memory instead of waiting for the end-of-kernel signal)
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) { status[1] = s_red; status[2] = it; status[3] = maxcount; __threadfence_system(); status[0] = 0; }
+    for (int g = tid; g < NT; g += T) match_of_feature[g] = tagb ? (tagb | (s_claim[g] + 2)) : s_claim[g];
+    if (tid == 0) { status[1] = tagb | s_red; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | 0; }
     MORB_PHASE(g_ph_res, 61);
 #ifdef MORB_PHASE_CLOCKS
     if (tid == 0) g_ph_res[62] = (unsigned long long)it;
@@ -1316,6 +1314,7 @@ struct orbm_matcher {
     int frame_min_rows = 0;  // the next device-built frame gets at least this many descriptor rows (fixed export block size)
     int last_status[4] = {0, 0, 0, 0};  // {status, nmatches, sweeps, longest list} of the last device resolve
     bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
+    int resolve_seq = 0;           // sequence number of the last tagged resolve launch
     bool foreign_work = false;     // something other than a step's own search was put on the stream (orbf_step_end then waits for all of it)
 };
 
@@ -2062,7 +2061,8 @@ struct SearchJob {
     const orbm_frame* cur; const orbm_query* q; int nq; const uint8_t* occupied;
     bool points; float nnratio; int th_high, check_ori;
     int cap; bool device_path;
-    bool pollable = false;              // single-workgroup resolve in flight: its status word flips last (see k_resolve)
+    bool pollable = false;              // single-workgroup resolve in flight with tagged result words (see k_resolve)
+    bool want_tags = false; int seq = 0; // caller wants to watch the results arrive; sequence number of the launch in flight
     const orbm_query* q_dev = nullptr;  // device-visible alias of `q` when it lives in mapped pinned memory: read in place, no H2D
 };
 
@@ -2150,14 +2150,15 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     hipLaunchKernelGGL((k_resolve<PT, LQ>), dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const int2*)m->d_qmeta.p, \
                        nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
                        (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
-                       (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp)
-    m->h_match.p[0] = RESOLVE_PENDING;   // the kernel overwrites it last
+                       (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20)
+    J.seq = 0;
+    if (J.want_tags) { m->resolve_seq = m->resolve_seq % 2047 + 1; J.seq = m->resolve_seq; }   // 1..2047, never 0
     if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
     else { if (J.points) MORB_RESOLVE_LAUNCH(true, false); else MORB_RESOLVE_LAUNCH(false, false); }
 #undef MORB_RESOLVE_LAUNCH
     MORB_HIP(hipGetLastError());  // status + matches are written by the kernel into the mapped pinned buffer
     J.device_path = true;
-    J.pollable = true;
+    J.pollable = J.seq != 0;
     return ORB_OK;
 }
 
@@ -2171,22 +2172,46 @@ static int search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_featur
     }
     if (!J.device_path)
         return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, 64, match_of_feature, nmatches);
+    // Result words of a tagged launch are taken as they arrive (the caller may not have synchronised the stream): wait for
+    // the word to carry this launch's sequence number, then strip it.  After ~10 ms without progress the stream is
+    // synchronised for good (which also covers a launch that failed).
+    bool synced = false;
+    auto word = [&](int idx, int bias) -> int {
+        volatile int32_t* p = m->h_match.p + idx;
+        if (!J.seq) return *p;
+        for (int spin = 0;; ++spin) {
+            const int w = *p;
+            if ((w >> 20) == J.seq) return (w & 0xfffff) - bias;
+            if (spin > 100000 && !synced) { (void)hipStreamSynchronize(m->stream); synced = true; spin = 0; }
+            else if (spin > 100000) return -3;   // cannot happen after a synchronisation; reported below
+            __builtin_ia32_pause();
+        }
+    };
     for (;;) {
-        const int status = m->h_match.p[0];
-        for (int k = 0; k < 4; ++k) m->last_status[k] = m->h_match.p[k];
+        const int status = word(0, 0);
+        m->last_status[0] = status;
+        for (int k = 1; k < 4; ++k) m->last_status[k] = word(k, 0);
+        if (status == -3) { morb::set_error("resolve results never arrived"); return ORB_E_HIP; }
         if (status == 0) break;
         if (status == 2) {  // a candidate list overflowed: retry with room for the longest one
-            J.cap = (m->h_match.p[3] + 63) & ~63;
+            J.cap = (m->last_status[3] + 63) & ~63;
             int rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
             if (rc) return rc;
             MORB_HIP(hipStreamSynchronize(m->stream));
+            synced = true;
             continue;
         }
         // not converged within the sweep limit: exact host fallback
         return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, J.cap, match_of_feature, nmatches);
     }
-    if (match_of_feature != m->h_match.p + 4) memcpy(match_of_feature, m->h_match.p + 4, (size_t)n * 4);
-    *nmatches = m->h_match.p[1];
+    if (J.seq) {
+        for (int g = 0; g < n; ++g) {
+            const int v = word(4 + g, 2);
+            if (v == -3) { morb::set_error("resolve results never arrived"); return ORB_E_HIP; }
+            match_of_feature[g] = v;
+        }
+    } else if (match_of_feature != m->h_match.p + 4) memcpy(match_of_feature, m->h_match.p + 4, (size_t)n * 4);
+    *nmatches = m->last_status[1];
     return ORB_OK;
 }
 
@@ -2920,6 +2945,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     }
     P.J = SearchJob{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
     P.J.q_dev = nq ? reinterpret_cast<const orbm_query*>(f->h_queries.dp) : nullptr;   // no H2D on the step's critical chain
+    P.J.want_tags = f->poll_ok;
     if ((rc = f->h_match.reserve(std::max(f->cap_total, 1)))) return rc;
     P.async_path = went_async != 0;
     // The export block of this step is final already when its extraction chain has completed cleanly (the usual case with
@@ -3055,11 +3081,12 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
         hipError_t herr = hipSuccess;
         bool polled = false;
         if (f->poll_ok && P.async_path && P.J.pollable && !P.forked && !m->foreign_work) {
-            // the resolve is the last thing on the stream and flips its status word behind a system fence: watch that word
-            // (a few microseconds sooner than the end-of-kernel signal travels through the runtime)
+            // the resolve is the last thing on the stream and tags its result words with the launch's sequence number: watch
+            // the status word arrive (a few microseconds sooner than the end-of-kernel signal travels through the runtime);
+            // search_finish then takes every other word the same way
             volatile int32_t* flag = m->h_match.p;
             for (int spin = 0; spin < 400000; ++spin) {
-                if (*flag != RESOLVE_PENDING) { polled = true; break; }
+                if ((*flag >> 20) == P.J.seq) { polled = true; break; }
                 __builtin_ia32_pause();
             }
         }
