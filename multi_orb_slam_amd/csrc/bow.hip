@@ -328,11 +328,13 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
     }
 }
 
-__global__ __launch_bounds__(256) void k_bow_finish(JoinWork W, int n_out, int check_ori, int32_t* __restrict__ h_match, int* __restrict__ h_result) {
+// Every workgroup works the three maxima out for itself (30 bins from L2) and filters its own 256 results: no single
+// workgroup walking the whole array through sixteen dependent trips to memory.  The match count is taken by the host while it
+// copies the array out (it touches every word anyway).
+__global__ __launch_bounds__(256) void k_bow_finish(JoinWork W, int n_out, int check_ori, int32_t* __restrict__ h_match) {
     __shared__ int s_keep[3];
-    __shared__ int s_removed;
-    __shared__ int s_hist[HISTO + 1];
-    if (threadIdx.x <= HISTO) s_hist[threadIdx.x] = W.hist[threadIdx.x];   // one parallel fetch instead of 30 dependent ones
+    __shared__ int s_hist[HISTO];
+    if (threadIdx.x < HISTO) s_hist[threadIdx.x] = W.hist[threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) {
         // ComputeThreeMaxima, src/ORBmatcher.cc:3948-3989
@@ -345,21 +347,17 @@ __global__ __launch_bounds__(256) void k_bow_finish(JoinWork W, int n_out, int c
         }
         if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
         else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
-        s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3; s_removed = 0;
+        s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
     }
     __syncthreads();
-    int removed = 0;
-    for (int i = threadIdx.x; i < n_out; i += 256) {
-        int mt = W.match[i];
-        if (check_ori && mt >= 0) {
-            const int b = W.bin_of[i];
-            if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) { mt = -1; ++removed; }
-        }
-        h_match[i] = mt;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    int mt = W.match[i];
+    if (check_ori && mt >= 0) {
+        const int b = W.bin_of[i];
+        if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) mt = -1;
     }
-    if (removed) atomicAdd(&s_removed, removed);
-    __syncthreads();
-    if (threadIdx.x == 0) h_result[0] = s_hist[HISTO] - s_removed;
+    h_match[i] = mt;
 }
 
 inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -706,11 +704,12 @@ int launch_join(orbv_workspace* w, const SideDev& A, const SideDev& B, int max_n
     if (mode == 0) k_bow_join<0><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
     else if (mode == 1) k_bow_join<1><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
     else k_bow_join<2><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
-    k_bow_finish<<<1, 256, 0, st>>>(W, n_out, check_ori, w->h_match.dp, w->h_match.dp + n_out);
+    k_bow_finish<<<(n_out + 255) / 256, 256, 0, st>>>(W, n_out, check_ori, w->h_match.dp);
     MORB_HIP(hipGetLastError());
     MORB_HIP(hipStreamSynchronize(st));
-    memcpy(match, w->h_match.p, (size_t)n_out * 4);
-    *nmatches = w->h_match.p[n_out];
+    int nm = 0;
+    for (int i = 0; i < n_out; ++i) { const int v = w->h_match.p[i]; match[i] = v; nm += v >= 0; }
+    *nmatches = nm;   // == accepted - removed by the rotation filter: every accepted match owns one output word
     return ORB_OK;
 }
 
