@@ -251,6 +251,163 @@ __global__ __launch_bounds__(64 * MAT_WAVES, FULL ? 6 : 4) void k_hamming_matrix
     mat_rows<FULL>(q, qa, qb, ra, rb, out, nr, r0);
 }
 
+// ---- the same matrix on the matrix cores --------------------------------------------------------------------------
+// With every descriptor bit b mapped to the int8 value 1 - 2b, the dot product of two descriptors is
+// (#equal bits) - (#different bits) = 256 - 2 * Hamming: exact in the int32 accumulators of v_mfma_i32_32x32x32_i8, and
+// 8 MFMAs (K = 8 x 32) give a 32 x 32 block of distances for ~0.25 SIMD cycles per pair where the xor/popcount chain
+// above needs ~1.03.  What is left is the 2 bytes per pair that have to reach HBM.
+//
+// Workgroup = 4 waves = 256 queries; a wave keeps its 64 queries as B fragments in 64 VGPRs for the whole launch and
+// walks the references 64 at a time: the workgroup expands the 64 x 32 bytes of a tile into int8 in fragment order in
+// LDS (ds_read_b128 at lane * 16: no bank conflicts; tile t + 1 is fetched and expanded while tile t is multiplied),
+// each wave issues 32 MFMAs per tile and transposes its 64 x 64 result through a 4 KB LDS patch (XOR-swizzled 16-byte
+// chunks) so that every store instruction writes 8 rows x 128 contiguous bytes.  The order of K inside a fragment is
+// irrelevant to a dot product as long as both operands use the same one: fragment (ks, h) = descriptor bits
+// [32 ks + 16 h, +16) of row (lane & 31), for A (references) and B (queries) alike.
+using mm_i32x4 = __attribute__((ext_vector_type(4))) int;
+using mm_i32x16 = __attribute__((ext_vector_type(16))) int;
+constexpr int MM_WAVES = 4;
+constexpr int MM_Q_PER_BLOCK = 64 * MM_WAVES;
+constexpr int MM_R_TILE = 64;
+
+// 16 descriptor bits -> 16 int8: +1 where the bit is clear, -1 where it is set.  (x * 0x00204081) & 0x01010101 spreads
+// the four bits of a nibble over four bytes (the shifted copies x, x<<7, x<<14, x<<21 do not overlap for x < 16); the
+// bytes 0 / 1 then select 0x01 / 0xff out of a constant with v_perm_b32.
+__device__ __forceinline__ mm_i32x4 mm_expand16(uint32_t bits) {
+    mm_i32x4 v;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const uint32_t x = (bits >> (4 * n)) & 15u;
+        const uint32_t y = (x * 0x00204081u) & 0x01010101u;
+        v[n] = (int)__builtin_amdgcn_perm(0u, 0x0000ff01u, y);
+    }
+    return v;
+}
+
+typedef unsigned short mm_u16x2 __attribute__((ext_vector_type(2)));
+// two accumulators (256 - 2 * distance each) -> distance | distance << 16, on the packed 16-bit ALU
+__device__ __forceinline__ uint32_t mm_pack2(int d0, int d1) {
+    mm_u16x2 p;
+    p.x = (unsigned short)d0; p.y = (unsigned short)d1;
+    const mm_u16x2 k = {256, 256};
+    p = (k - p) >> 1;
+    return __builtin_bit_cast(uint32_t, p);
+}
+
+__global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_matrix_mfma(const uint32_t* __restrict__ q, int nq,
+                                                                      const uint32_t* __restrict__ r, int nr,
+                                                                      uint16_t* __restrict__ out, int tiles_per_block) {
+    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];   // [buffer][(reference group, ks, lane)]: 2 x 16 KB
+    __shared__ uint4 s_stage[MM_WAVES][32 * 8];  // per wave: 32 query rows x 8 chunks of 8 distances
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.y * MM_Q_PER_BLOCK + wave * 64;
+
+    // Rows past nq repeat query nq - 1 and are stored onto its row (identical values); the last reference tile is moved
+    // back to end at nr (it recomputes columns of its neighbour): no store below is conditional, so the loop body has
+    // no exec-mask branches and the wait for a prefetched tile does not have to drain the stores issued after it.
+    mm_i32x4 bq[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qi = min(q0 + g * 32 + c, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
+        const uint4 lo = p[0], hi = p[1];
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bq[g][ks] = mm_expand16(h ? (w[ks] >> 16) : (w[ks] & 0xffffu));
+    }
+
+    const int n_tiles = (nr + MM_R_TILE - 1) / MM_R_TILE;
+    const int t_begin = blockIdx.x * tiles_per_block, t_end = min(n_tiles, t_begin + tiles_per_block);
+    if (t_begin >= t_end) return;
+    // wave w expands descriptor words 2w, 2w + 1 (ks = 2w, 2w + 1; both halves) of the tile's 64 references, one per lane
+    // The prefetch is issued and awaited by hand: hipcc's own accounting drains every outstanding store (vmcnt(0)) when
+    // it waits for a load across the loop's back edge, and a wave would then stop once per tile until its previous
+    // 8 KB of distances has reached the L2.  gfx950 retires loads and stores in issue order on one counter, so with
+    // exactly eight stores issued after the request, vmcnt(8) means "the request has landed".
+    auto fetch = [&](int t) {
+        const int rr = min(min(t, t_end - 1) * MM_R_TILE, nr - MM_R_TILE) + lane;
+        const uint32_t* p = r + (size_t)rr * 8 + wave * 2;
+        unsigned long long v;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+        return v;
+    };
+    auto deposit = [&](int buf, unsigned long long w64) {
+        const uint2 w = make_uint2((uint32_t)w64, (uint32_t)(w64 >> 32));
+        mm_i32x4* base = &s_tile[buf][(h * 8 + wave * 2) * 64 + c];
+        base[0] = mm_expand16(w.x & 0xffffu);
+        base[32] = mm_expand16(w.x >> 16);
+        base[64] = mm_expand16(w.y & 0xffffu);
+        base[96] = mm_expand16(w.y >> 16);
+    };
+    // this lane's part of the four store instructions of a 32-query group: row (lane >> 3) + 8 i, chunk lane & 7
+    const int srow = lane >> 3, sch = lane & 7;
+    size_t row_off[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) row_off[g][i] = (size_t)min(q0 + g * 32 + i * 8 + srow, nq - 1) * nr + sch * 8;
+
+    unsigned long long nxt = fetch(t_begin);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt) : : "memory");
+    deposit(0, nxt);
+    nxt = fetch(t_begin + 1);
+    __syncthreads();
+    auto one_tile = [&](int t, auto first) {
+        const int buf = (t - t_begin) & 1;
+        mm_i32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][g][e] = 0;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const mm_i32x4 a0 = s_tile[buf][ks * 64 + lane], a1 = s_tile[buf][(8 + ks) * 64 + lane];
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[0][ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[1][ks], acc[1][1], 0, 0, 0);
+        }
+        // tile t + 1 into the other buffer (its last reader passed the barrier that ended iteration t - 1), tile t + 2
+        // requested BEFORE this iteration's stores are issued
+        if (decltype(first)::value) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt) : : "memory");
+        deposit(buf ^ 1, nxt);
+        nxt = fetch(t + 2);
+        // D[m][n]: lane holds column n = lane & 31 (a query), rows m = (e & 3) + 8 (e >> 2) + 4 h (references)
+        const int r0 = min(t * MM_R_TILE, nr - MM_R_TILE);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int chunk = (a * 4 + j) ^ (c & 7);
+                    reinterpret_cast<uint2*>(&s_stage[wave][c * 8 + chunk])[h] =
+                        make_uint2(mm_pack2(acc[a][g][4 * j + 0], acc[a][g][4 * j + 1]), mm_pack2(acc[a][g][4 * j + 2], acc[a][g][4 * j + 3]));
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 v = s_stage[wave][(i * 8 + srow) * 8 + (sch ^ srow)];
+                *reinterpret_cast<uint4*>(out + row_off[g][i] + r0) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __syncthreads();
+    };
+    // first tile outside the loop: no stores stand behind its prefetch yet
+    one_tile(t_begin, std::true_type{});
+    for (int t = t_begin + 1; t < t_end; ++t) one_tile(t, std::false_type{});
+}
+
 struct FrameDev {
     int n_total, n_cams;
     const int* n_total_dev;  // non-NULL: the feature count is only known on the device (n_total is then the capacity)
@@ -1259,6 +1416,21 @@ int launch_matrix(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16
     if (q_per_block_env > 0) q_per_block = q_per_block_env;
     dim3 grid((tiles + MAT_WAVES - 1) / MAT_WAVES, (nq + q_per_block - 1) / q_per_block);
     const bool aligned = (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && nr >= MAT_REFS_PER_WAVE;
+    // Matrix-core path: rows of 16-byte chunks, enough queries to fill 64-query waves.  MORB_MATRIX_MFMA=0 keeps the VALU kernel.
+    static const int mfma_env = [] { const char* e = getenv("MORB_MATRIX_MFMA"); return e ? atoi(e) : 1; }();
+    if (mfma_env && (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && nq >= 64 && nr >= MM_R_TILE && (((uintptr_t)d_r & 7) == 0)) {
+        const int n_tiles = (nr + MM_R_TILE - 1) / MM_R_TILE, qblocks = (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK;
+        // >= ~1500 workgroups when the problem has them; a workgroup re-expands its 256 queries once per launch, so
+        // at least 4 tiles each
+        int tpb = std::max(4, std::min(32, (int)(((long long)n_tiles * qblocks + 1535) / 1536)));
+        static const int tpb_env = [] { const char* e = getenv("MORB_MATRIX_TPB"); return e ? atoi(e) : 0; }();
+        if (tpb_env > 0) tpb = tpb_env;
+        dim3 g2((n_tiles + tpb - 1) / tpb, qblocks);
+        hipLaunchKernelGGL(k_hamming_matrix_mfma, g2, dim3(64 * MM_WAVES), 0, st, (const uint32_t*)d_q, nq, (const uint32_t*)d_r, nr,
+                           d_out, tpb);
+        MORB_HIP(hipGetLastError());
+        return ORB_OK;
+    }
     if (aligned)
         hipLaunchKernelGGL(k_hamming_matrix<true>, grid, dim3(64 * MAT_WAVES), 0, st, (const uint4*)d_q, nq, (const uint4*)d_r, nr,
                            d_out, q_per_block);

@@ -42,12 +42,23 @@ def test_top2_ties_and_duplicates(matcher):
     assert (bi == -1).all() and (bd == 256).all() and (sd == 256).all()
 
 
-@pytest.mark.parametrize("nq,nr", [(1, 1), (3, 8), (70, 513), (129, 1024), (200, 1000), (64, 4099)])
+# sizes with nq >= 64 and nr % 8 == 0 take the matrix-core kernel (ragged query blocks, ragged and partial reference tiles,
+# several tiles per workgroup), the others the xor/popcount kernel
+@pytest.mark.parametrize("nq,nr", [(1, 1), (3, 8), (70, 513), (129, 1024), (200, 1000), (64, 4099), (64, 64), (300, 72),
+                                   (257, 2056), (1000, 1000), (513, 8200)])
 def test_matrix_bit_exact(matcher, nq, nr):
     r = synth.descriptors(nr, 9); q = synth.descriptors(nq, 10)
     q[0] = r[0]
     out = matcher.hamming_matrix(q, r)
     assert np.array_equal(out, oracle.hamming_matrix(q, r))
+
+
+def test_matrix_extremes(matcher):
+    # all bits different = 256 (the int8 dot product is -256), identical = 0, on the matrix-core path
+    z = np.zeros((96, 32), np.uint8); o = np.full((128, 32), 255, np.uint8)
+    assert (matcher.hamming_matrix(z, o) == 256).all() and (matcher.hamming_matrix(o, o) == 0).all()
+    one = z.copy(); one[:, 31] = 0x80
+    assert (matcher.hamming_matrix(one, np.concatenate([z, o])) == np.r_[np.full(96, 1), np.full(128, 255)][None, :]).all()
 
 
 def test_matrix_properties_full_size(matcher):
