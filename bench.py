@@ -42,7 +42,7 @@ def parse():
 
 
 def matcher_roofline(rt, m, stream, n, iters=20):
-    """Hamming distance-matrix kernel (k_hamming_matrix), Q = R = n: algorithmic bytes 32(Q+R) + 2QR per launch,
+    """Hamming distance-matrix kernel (k_hamming_matrix_mfma at this size), Q = R = n: algorithmic bytes 32(Q+R) + 2QR per launch,
     average launch duration from HIP events on the stream the kernel runs on."""
     from multi_orb_slam_amd import synth
     d = synth.descriptors(n, 4242)
@@ -73,7 +73,7 @@ def matcher_roofline(rt, m, stream, n, iters=20):
             traffic = None
     for b in (dq, dr, dout):
         b.free()
-    return {"kernel": "k_hamming_matrix", "workload": "Q=R=%d uint16 distance matrix" % n, "bound": "hbm",
+    return {"kernel": "k_hamming_matrix_mfma", "workload": "Q=R=%d uint16 distance matrix" % n, "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(ms * 1e3, 2)}
 

@@ -385,8 +385,10 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_matrix_mfma(const uin
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    // 16-byte chunks XOR-swizzled by the row, and the two 8-byte halves of a chunk swapped on every second
+                    // group of eight rows: the 32 lanes of a half-wave (same h) then cover all 64 banks once
                     const int chunk = (a * 4 + j) ^ (c & 7);
-                    reinterpret_cast<uint2*>(&s_stage[wave][c * 8 + chunk])[h] =
+                    reinterpret_cast<uint2*>(&s_stage[wave][c * 8 + chunk])[h ^ ((c >> 3) & 1)] =
                         make_uint2(mm_pack2(acc[a][g][4 * j + 0], acc[a][g][4 * j + 1]), mm_pack2(acc[a][g][4 * j + 2], acc[a][g][4 * j + 3]));
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -394,7 +396,8 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_matrix_mfma(const uin
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint4 v = s_stage[wave][(i * 8 + srow) * 8 + (sch ^ srow)];
+                uint4 v = s_stage[wave][(i * 8 + srow) * 8 + (sch ^ srow)];
+                if (i & 1) v = make_uint4(v.z, v.w, v.x, v.y);  // rows 8..15, 24..31 hold their halves swapped
                 *reinterpret_cast<uint4*>(out + row_off[g][i] + r0) = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -1,13 +1,14 @@
 cd $GRAFT_REPO_ROOT
-for v in 1; do
-MORB_MATRIX_VARIANT=$v timeout 600 python - <<'PY'
+timeout 900 python -m pytest tests/test_gpu_matcher.py -x -q -m gpu -k "matrix" 2>&1 | grep -E "passed|failed|Error|assert" | head
+for tpb in 0 16; do
+MORB_MATRIX_TPB=$tpb timeout 600 python - <<'PY'
 import os, time, torch, numpy as np
 import multi_orb_slam_amd as m
 from multi_orb_slam_amd import synth
 mt = m.Matcher()
 n = 32000
 d = torch.from_numpy(synth.descriptors(n, 1)).cuda()
-out = torch.empty((n + 4096, n), dtype=torch.int16, device="cuda")
+out = torch.empty((n, n), dtype=torch.int16, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 def run(): mt.hamming_matrix_device(d.data_ptr(), n, d.data_ptr(), n, out.data_ptr(), s)
 for _ in range(3): run()
@@ -17,12 +18,6 @@ e0.record()
 for _ in range(20): run()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
-print("variant", os.environ.get("MORB_MATRIX_VARIANT"), "%.1f us  %.2f TB/s" % (us, (2.0 * n * n + 64 * n) / us / 1e6))
-out.zero_(); torch.cuda.synchronize()
-e0.record()
-for _ in range(10): out.zero_()
-e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / 10 * 1e3
-print("memset %.1f us %.2f TB/s" % (us, out.numel() * 2 / us / 1e6))
+print("tpb", os.environ.get("MORB_MATRIX_TPB"), "%.1f us  %.2f TB/s" % (us, (2.0 * n * n + 64 * n) / us / 1e6), "checksum", int(out.to(torch.int64).sum()))
 PY
 done
