@@ -411,6 +411,131 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_matrix_mfma(const uin
     for (int t = t_begin + 1; t < t_end; ++t) one_tile(t, std::false_type{});
 }
 
+// ---- exhaustive top-2 on the matrix cores ------------------------------------------------------------------------
+// Same tiling as k_hamming_matrix_mfma (a wave keeps 64 queries as B fragments, the workgroup expands 64 references per
+// step into LDS), but nothing is stored per pair and the MFMA delivers ready-made sort keys: references are expanded to
+// -32 / +32 (bit clear / set), queries to +1 / -1, so a dot product is 64 * distance - 8192, and the accumulators start at
+// 8192 + (row of the element within its 32 x 32 block) -- D[m][n] = distance << 6 | m, smaller = better, ties by reference
+// order.  Every lane keeps (best, second) of its query column and runs  second = med3(best, second, key); best =
+// min(best, key)  over the 16 keys a block gives it: three vector instructions per pair including the accumulator read,
+// no branches.  After each block the row bits of `best` are cleared (and the block + row remembered when `best` changed):
+// an equal distance in a later block then never replaces it -- the strict '<' chain of ORBmatcher.cc:311-320 (first
+// minimum wins, second = 2nd smallest with multiplicity).  grid.x = reference slices (partials for k_top2_merge when
+// > 1), grid.y = 256 queries.
+__device__ __forceinline__ mm_i32x4 mt_expand16(uint32_t bits) {  // 16 bits -> 16 int8: -32 where clear, +32 where set
+    mm_i32x4 v;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const uint32_t x = (bits >> (4 * n)) & 15u;
+        const uint32_t y = (x * 0x00204081u) & 0x01010101u;
+        v[n] = (int)__builtin_amdgcn_perm(0u, 0x000020e0u, y);
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t mt_umed3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
+
+__global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_top2_mfma(const uint32_t* __restrict__ q, int nq,
+                                                                    const uint32_t* __restrict__ r, int nr, int slice_len,
+                                                                    int* __restrict__ p_idx, int* __restrict__ p_best,
+                                                                    int* __restrict__ p_second) {
+    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.y * MM_Q_PER_BLOCK + wave * 64;
+
+    mm_i32x4 bq[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qi = min(q0 + g * 32 + c, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
+        const uint4 lo = p[0], hi = p[1];
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bq[g][ks] = mm_expand16(h ? (w[ks] >> 16) : (w[ks] & 0xffffu));
+    }
+    mm_i32x16 cinit;  // D[m][n]: lane holds column n = lane & 31 (a query), rows m = (e & 3) + 8 (e >> 2) + 4 h (references)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cinit[e] = 8192 + (e & 3) + 8 * (e >> 2) + 4 * h;
+
+    const int s0 = blockIdx.x * slice_len, s1 = min(nr, s0 + slice_len);  // slice_len is a multiple of 64
+    const int n_tiles = (s1 - s0 + MM_R_TILE - 1) / MM_R_TILE;
+    auto fetch = [&](int t) {
+        const int rr = min(s0 + min(t, n_tiles - 1) * MM_R_TILE + lane, nr - 1);  // rows past the end repeat the last one, masked below
+        return *reinterpret_cast<const uint2*>(r + (size_t)rr * 8 + wave * 2);
+    };
+    auto deposit = [&](int buf, uint2 w) {
+        mm_i32x4* base = &s_tile[buf][(h * 8 + wave * 2) * 64 + c];
+        base[0] = mt_expand16(w.x & 0xffffu);
+        base[32] = mt_expand16(w.x >> 16);
+        base[64] = mt_expand16(w.y & 0xffffu);
+        base[96] = mt_expand16(w.y >> 16);
+    };
+
+    constexpr uint32_t KEY_NONE = 256u << 6;
+    uint32_t kb[2] = {KEY_NONE, KEY_NONE}, ks2[2] = {KEY_NONE, KEY_NONE};
+    int where[2] = {-1, -1};  // (block << 5 | row) of the best key, block = 2 * tile + a
+    deposit(0, fetch(0));
+    uint2 nxt = fetch(1);
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        mm_i32x16 acc[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const mm_i32x4 a0 = s_tile[buf][ks * 64 + lane], a1 = s_tile[buf][(8 + ks) * 64 + lane];
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][ks], ks ? acc[0][0] : cinit, 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][ks], ks ? acc[0][1] : cinit, 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[0][ks], ks ? acc[1][0] : cinit, 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[1][ks], ks ? acc[1][1] : cinit, 0, 0, 0);
+        }
+        deposit(buf ^ 1, nxt);
+        nxt = fetch(t + 2);
+        const int valid = s1 - s0 - t * MM_R_TILE;  // references of this tile inside the slice (>= 64 except on the last tile)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const uint32_t before = kb[g];
+                if (valid >= MM_R_TILE) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t key = (uint32_t)acc[a][g][e];
+                        ks2[g] = mt_umed3(kb[g], ks2[g], key);
+                        kb[g] = min(kb[g], key);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int local = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const uint32_t key = local < valid ? (uint32_t)acc[a][g][e] : KEY_NONE;
+                        ks2[g] = mt_umed3(kb[g], ks2[g], key);
+                        kb[g] = min(kb[g], key);
+                    }
+                }
+                where[g] = kb[g] != before ? (((2 * t + a) << 5) | (int)(kb[g] & 31u)) : where[g];
+                kb[g] &= ~63u;
+            }
+        __syncthreads();
+    }
+    // the two half-waves hold disjoint references of the same query: full keys distance << 16 | index decide
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t mine_b = ((kb[g] >> 6) << 16) | (uint32_t)(where[g] & 0xffff), mine_s = (ks2[g] >> 6) << 16 | 0xffffu;
+        const uint32_t ob = (uint32_t)__shfl_xor((int)mine_b, 32), os = (uint32_t)__shfl_xor((int)mine_s, 32);
+        const uint32_t nb = min(mine_b, ob), ns = min(max(mine_b, ob), min(mine_s, os));
+        const int qrow = q0 + g * 32 + c;
+        if (h == 0 && qrow < nq) {
+            const size_t o = (size_t)blockIdx.x * nq + qrow;
+            const int best = (int)(nb >> 16);
+            p_best[o] = best;
+            p_idx[o] = best < 256 ? s0 + (int)(nb & 0xffffu) : -1;
+            p_second[o] = (int)min(ns >> 16, 256u);
+        }
+    }
+}
+
 struct FrameDev {
     int n_total, n_cams;
     const int* n_total_dev;  // non-NULL: the feature count is only known on the device (n_total is then the capacity)
@@ -1383,25 +1508,53 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __r
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-int launch_top2(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd,
-                void* d_scratch, int S, hipStream_t st) {
+// Plan of an exhaustive top-2: matrix-core kernel (256 queries x one reference slice per workgroup; slices are multiples
+// of 64 references and at most 65536 long: 16-bit indices in the keys) when both sides have at least a tile, else the
+// one-query-per-lane kernel.  S = number of reference slices (> 1 needs scratch for the partials).
+struct Top2Plan { bool mfma; int S; int slice_len; };
+
+Top2Plan top2_plan(int nq, int nr, bool have_scratch = true) {
+    static const int mfma_env = [] { const char* e = getenv("MORB_TOP2_MFMA"); return e ? atoi(e) : 1; }();
+    Top2Plan p{false, 1, nr};
+    if (mfma_env && nq >= 64 && nr >= MM_R_TILE) {
+        const int qblocks = (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK;
+        int S = (1024 + qblocks - 1) / qblocks;                 // ~2 workgroups per CU x 2 rounds
+        S = std::min(S, std::max(1, nr / (4 * MM_R_TILE)));     // at least four tiles per slice
+        S = std::max(S, (nr + 65535) / 65536);
+        S = std::min(S, 64);
+        if (!have_scratch) S = 1;
+        int len = ((nr + S - 1) / S + MM_R_TILE - 1) / MM_R_TILE * MM_R_TILE;
+        if (len <= 65536) {
+            p.mfma = true; p.slice_len = len; p.S = (nr + len - 1) / len;
+            return p;
+        }
+    }
     const int qblocks = (nq + 63) / 64;
-    if (S <= 1) {
-        hipLaunchKernelGGL(k_hamming_top2, dim3(qblocks, 1), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_q, nq,
-                           (const uint4*)d_r, nr, d_bi, d_bd, d_sd);
-    } else {
-        int* p = (int*)d_scratch;
-        int *p_idx = p, *p_best = p + (size_t)S * nq, *p_second = p + 2 * (size_t)S * nq;
-        hipLaunchKernelGGL(k_hamming_top2, dim3(qblocks, S), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_q, nq,
+    int S = (128 + qblocks - 1) / qblocks;               // target >= 128 blocks x 16 waves = 2048 waves
+    S = std::min(S, std::max(1, nr / (TOP2_WAVES * 16)));  // keep >= 16 references per wave
+    p.S = have_scratch ? std::max(1, std::min(S, 64)) : 1;
+    return p;
+}
+
+int launch_top2(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd,
+                void* d_scratch, const Top2Plan& plan, hipStream_t st) {
+    const int S = plan.S;
+    int* p = (int*)d_scratch;
+    int *p_idx = S > 1 ? p : d_bi, *p_best = S > 1 ? p + (size_t)S * nq : d_bd, *p_second = S > 1 ? p + 2 * (size_t)S * nq : d_sd;
+    if (plan.mfma)
+        hipLaunchKernelGGL(k_hamming_top2_mfma, dim3(S, (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK), dim3(64 * MM_WAVES), 0, st,
+                           (const uint32_t*)d_q, nq, (const uint32_t*)d_r, nr, plan.slice_len, p_idx, p_best, p_second);
+    else
+        hipLaunchKernelGGL(k_hamming_top2, dim3((nq + 63) / 64, S), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_q, nq,
                            (const uint4*)d_r, nr, p_idx, p_best, p_second);
+    if (S > 1)
         hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, d_bi,
                            d_bd, d_sd);
-    }
     MORB_HIP(hipGetLastError());
     return ORB_OK;
 }
 
-// number of reference slices: enough blocks to give every SIMD of the 256 CUs a wave
+// number of reference slices of the one-query-per-lane kernels (k_cross_top2): enough blocks to give every SIMD a wave
 int top2_slices(int nq, int nr) {
     const int qblocks = (nq + 63) / 64;
     int S = (128 + qblocks - 1) / qblocks;               // target >= 128 blocks x 16 waves = 2048 waves
@@ -1705,7 +1858,7 @@ void orbm_three_maxima(const int* histo, int L, int* ind) {
 
 size_t orbm_top2_scratch_bytes(int nq, int nr) {
     if (nq <= 0 || nr <= 0) return 0;
-    const int S = top2_slices(nq, nr);
+    const int S = top2_plan(nq, nr).S;
     return S <= 1 ? 0 : (size_t)3 * S * nq * sizeof(int);
 }
 
@@ -1715,9 +1868,8 @@ int orbm_hamming_top2_device(const uint8_t* d_q, int nq, const uint8_t* d_r, int
     if (nq == 0) return ORB_OK;
     MORB_ARG(d_q && d_best_idx && d_best_dist && d_second_dist && (nr == 0 || d_r));
     MORB_ARG((((uintptr_t)d_q | (uintptr_t)d_r) & 15) == 0);
-    int S = top2_slices(nq, std::max(nr, 1));
-    if (S > 1 && !d_scratch) S = 1;
-    return launch_top2(d_q, nq, d_r, nr, d_best_idx, d_best_dist, d_second_dist, d_scratch, S, (hipStream_t)stream);
+    const Top2Plan plan = top2_plan(nq, std::max(nr, 1), d_scratch != nullptr);
+    return launch_top2(d_q, nq, d_r, nr, d_best_idx, d_best_dist, d_second_dist, d_scratch, plan, (hipStream_t)stream);
 }
 
 int orbm_hamming_top2(orbm_matcher* m, const uint8_t* q, int nq, const uint8_t* r, int nr, int32_t* best_idx,

@@ -17,8 +17,10 @@ def matcher():
     mt.close()
 
 
+# nq >= 64 and nr >= 64 take the matrix-core kernel (ragged last tile, several slices, ragged query blocks), the rest
+# the one-query-per-lane kernel
 @pytest.mark.parametrize("nq,nr", [(1, 1), (1, 17), (63, 15), (64, 64), (65, 1000), (1000, 1000), (257, 4097),
-                                   (1500, 500), (5, 0), (0, 5)])
+                                   (1500, 500), (5, 0), (0, 5), (64, 65), (300, 127), (2000, 3001), (513, 20000)])
 def test_top2_bit_exact(matcher, nq, nr):
     r = synth.descriptors(max(nr, 1), 42)[:nr]
     q = synth.perturbed_queries(synth.descriptors(max(nq, 1), 42), 7)[:nq] if nq else np.zeros((0, 32), np.uint8)
@@ -40,6 +42,20 @@ def test_top2_ties_and_duplicates(matcher):
     z = np.zeros((4, 32), np.uint8); o = np.full((3, 32), 255, np.uint8)
     bi, bd, sd = matcher.hamming_top2(o, z)
     assert (bi == -1).all() and (bd == 256).all() and (sd == 256).all()
+    # the same on the matrix-core path, with duplicates falling into different tiles, half-waves and slices
+    r = synth.descriptors(5000, 8)
+    r[4999] = r[3]; r[70] = r[3]; r[36] = r[35]; r[2047] = r[2048]
+    q = np.concatenate([r[[3, 35, 2048, 4999]], synth.perturbed_queries(r[:96], 5)])
+    bi, bd, sd = matcher.hamming_top2(q, r)
+    obi, obd, osd = oracle.bf_top2(q, r)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
+    assert list(bi[:4]) == [3, 35, 2047, 3] and (sd[:4] == 0).all()
+    z = np.zeros((100, 32), np.uint8); o = np.full((130, 32), 255, np.uint8)
+    bi, bd, sd = matcher.hamming_top2(o, z)
+    assert (bi == -1).all() and (bd == 256).all() and (sd == 256).all()
+    z[77, 0] = 1; z[99, 0] = 3
+    bi, bd, sd = matcher.hamming_top2(o, z)
+    assert (bi == 99).all() and (bd == 254).all() and (sd == 255).all()
 
 
 # sizes with nq >= 64 and nr % 8 == 0 take the matrix-core kernel (ragged query blocks, ragged and partial reference tiles,
