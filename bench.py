@@ -42,6 +42,20 @@ def parse():
 
 
 def matcher_roofline(rt, m, stream, n, iters=20):
+    """`roofline` of the bench line: the distance matrix in its default (matrix-core) form, with the xor/popcount form of
+    the same kernel -- the formulation north_star names -- timed beside it under `popcount_form`."""
+    out = _matrix_launches(rt, m, stream, n, iters)
+    prev = m.Matcher.use_matrix_cores(0)
+    try:
+        alt = _matrix_launches(rt, m, stream, n, max(5, iters // 2))
+    finally:
+        m.Matcher.use_matrix_cores(prev)
+    out["popcount_form"] = {"kernel": "k_hamming_matrix", "achieved": alt["achieved"], "frac": alt["frac"],
+                            "avg_launch_us": alt["avg_launch_us"]}
+    return out
+
+
+def _matrix_launches(rt, m, stream, n, iters):
     """Hamming distance-matrix kernel (k_hamming_matrix_mfma at this size), Q = R = n: algorithmic bytes 32(Q+R) + 2QR per launch,
     average launch duration from HIP events on the stream the kernel runs on."""
     from multi_orb_slam_amd import synth
@@ -68,7 +82,8 @@ def matcher_roofline(rt, m, stream, n, iters=20):
     pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pj):
         try:
-            traffic = json.load(open(pj)).get("k_hamming_matrix", {}).get("hbm_bytes_per_launch")
+            pm = json.load(open(pj))
+            traffic = (pm.get("k_hamming_matrix_mfma") or pm.get("k_hamming_matrix") or {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     for b in (dq, dr, dout):

@@ -12,6 +12,7 @@
 // The order-dependent part of SearchByProjection (first-come claims, rotation histogram) is resolved on the host
 // from the ordered candidate lists.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -1512,11 +1513,13 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __r
 // of 64 references and at most 65536 long: 16-bit indices in the keys) when both sides have at least a tile, else the
 // one-query-per-lane kernel.  S = number of reference slices (> 1 needs scratch for the partials).
 struct Top2Plan { bool mfma; int S; int slice_len; };
+std::atomic<int> g_matrix_cores{-1};  // orbm_use_matrix_cores: -1 = environment default
 
 Top2Plan top2_plan(int nq, int nr, bool have_scratch = true) {
     static const int mfma_env = [] { const char* e = getenv("MORB_TOP2_MFMA"); return e ? atoi(e) : 1; }();
+    const int forced = g_matrix_cores.load(std::memory_order_relaxed);
     Top2Plan p{false, 1, nr};
-    if (mfma_env && nq >= 64 && nr >= MM_R_TILE) {
+    if ((forced < 0 ? mfma_env : forced) && nq >= 64 && nr >= MM_R_TILE) {
         const int qblocks = (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK;
         int S = (1024 + qblocks - 1) / qblocks;                 // ~2 workgroups per CU x 2 rounds
         S = std::min(S, std::max(1, nr / (4 * MM_R_TILE)));     // at least four tiles per slice
@@ -1574,7 +1577,8 @@ int launch_matrix(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16
     const bool aligned = (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && nr >= MAT_REFS_PER_WAVE;
     // Matrix-core path: rows of 16-byte chunks, enough queries to fill 64-query waves.  MORB_MATRIX_MFMA=0 keeps the VALU kernel.
     static const int mfma_env = [] { const char* e = getenv("MORB_MATRIX_MFMA"); return e ? atoi(e) : 1; }();
-    if (mfma_env && (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && nq >= 64 && nr >= MM_R_TILE && (((uintptr_t)d_r & 7) == 0)) {
+    const int forced = g_matrix_cores.load(std::memory_order_relaxed);
+    if ((forced < 0 ? mfma_env : forced) && (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && nq >= 64 && nr >= MM_R_TILE && (((uintptr_t)d_r & 7) == 0)) {
         const int n_tiles = (nr + MM_R_TILE - 1) / MM_R_TILE, qblocks = (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK;
         // >= ~1500 workgroups when the problem has them; a workgroup re-expands its 256 queries once per launch, so
         // at least 4 tiles each
@@ -1855,6 +1859,8 @@ void orbm_three_maxima(const int* histo, int L, int* ind) {
     else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
     ind[0] = i1; ind[1] = i2; ind[2] = i3;
 }
+
+int orbm_use_matrix_cores(int on) { return g_matrix_cores.exchange(on < 0 ? -1 : (on ? 1 : 0)); }
 
 size_t orbm_top2_scratch_bytes(int nq, int nr) {
     if (nq <= 0 || nr <= 0) return 0;

@@ -142,6 +142,12 @@ class Matcher:
                                                   C.c_void_p(stream)))
 
     @staticmethod
+    def use_matrix_cores(on):
+        """orbm_use_matrix_cores: 1 / 0 = matrix-core / popcount form of the all-pairs kernels, -1 = default; returns the
+        previous setting."""
+        return int(_lib.lib().orbm_use_matrix_cores(int(on)))
+
+    @staticmethod
     def hamming_matrix_device(d_q, nq, d_r, nr, d_out, stream):
         check(_lib.lib().orbm_hamming_matrix_device(C.c_void_p(d_q), nq, C.c_void_p(d_r), nr, C.c_void_p(d_out),
                                                     C.c_void_p(stream)))

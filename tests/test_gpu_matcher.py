@@ -77,6 +77,22 @@ def test_matrix_extremes(matcher):
     assert (matcher.hamming_matrix(one, np.concatenate([z, o])) == np.r_[np.full(96, 1), np.full(128, 255)][None, :]).all()
 
 
+def test_matrix_core_and_popcount_forms_agree(matcher):
+    # orbm_use_matrix_cores switches the two all-pairs kernels between their forms at run time: same bits either way
+    import multi_orb_slam_amd as m
+    r = synth.descriptors(3000, 21); q = synth.perturbed_queries(synth.descriptors(700, 21), 4)
+    out = {}
+    try:
+        for on in (1, 0):
+            m.Matcher.use_matrix_cores(on)
+            out[on] = (matcher.hamming_matrix(q, r[:2048]),) + tuple(matcher.hamming_top2(q, r))
+    finally:
+        assert m.Matcher.use_matrix_cores(-1) == 0
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[1][0], oracle.hamming_matrix(q, r[:2048]))
+
+
 def test_matrix_properties_full_size(matcher):
     # size-independent properties at an all-pairs size: symmetry, zero diagonal, row checksum vs popcount identity
     n = 4000

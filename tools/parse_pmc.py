@@ -9,9 +9,11 @@ def load(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
-        for key in ("k_hamming_matrix", "k_hamming_top2", "k_top2_merge", "k_project", "k_resolve", "k_bow_transform", "k_bow_join", "fillBuffer", "copyBuffer"):
+        for key in ("k_hamming_matrix_mfma", "k_hamming_top2_mfma", "k_hamming_matrix", "k_hamming_top2", "k_top2_merge", "k_project",
+                    "k_resolve", "k_bow_transform", "k_bow_join", "fillBuffer", "copyBuffer"):
             if key in name:
                 agg[(key, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+                break
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 def main(fetch_csv, write_csv, out_json):
@@ -24,7 +26,7 @@ def main(fetch_csv, write_csv, out_json):
     for k in sorted(set(f) | set(w)):
         fb = f.get(k, 0.0) * 1024 * 2.0
         wb = w.get(k, 0.0) * 1024
-        name = k[0] if k[0] != "k_hamming_top2" else "k_hamming_top2[grid=%d]" % k[1]
+        name = k[0] if not k[0].startswith("k_hamming_top2") else "%s[grid=%d]" % k
         out[name] = {"grid_size": k[1], "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                      "hbm_bytes_per_launch": round(fb + wb)}
     json.dump(out, open(out_json, "w"), indent=1)

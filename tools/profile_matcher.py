@@ -2,7 +2,7 @@
 """Workload for rocprofv3 passes over the matcher kernels (run under `rocprofv3 ... -- python3 tools/profile_matcher.py`).
 
 Launches, on one stream: a 1 GiB hipMemset (known write bytes: WRITE_SIZE calibration), a 1 GiB device-to-device
-copy (known read + write bytes: FETCH_SIZE calibration), then k_hamming_matrix at Q = R = 32000 and k_hamming_top2 at
+copy (known read + write bytes: FETCH_SIZE calibration), then -- in their matrix-core and their popcount forms -- k_hamming_matrix at Q = R = 32000 and k_hamming_top2 at
 4000 x 4000 and 32000 x 32000, a few launches each; then the radius-gated projection search of BASELINE.json configs[2]
 (2 cameras 1280x720, 2000 features each, 4000 projected points: k_project + k_resolve) and the BoW row (k_bow_transform on
 4000 descriptors of the stock-shape vocabulary, k_bow_join between two resident keyframes)."""
@@ -25,13 +25,20 @@ d = synth.descriptors(N, 4242)
 dq = rt.DeviceBuffer(N * 32); dr = rt.DeviceBuffer(N * 32); dout = rt.DeviceBuffer(N * N * 2)
 dq.upload(d); dr.upload(synth.perturbed_queries(d, 9))
 res = [rt.DeviceBuffer(N * 4) for _ in range(3)]
-scr = rt.DeviceBuffer(max(m.Matcher.top2_scratch_bytes(N, N), m.Matcher.top2_scratch_bytes(4000, 4000), 16))
-for _ in range(5):
-    m.Matcher.hamming_matrix_device(dq.ptr, N, dr.ptr, N, dout.ptr, st)
-for _ in range(5):
-    m.Matcher.hamming_top2_device(dq.ptr, 4000, dr.ptr, 4000, res[0].ptr, res[1].ptr, res[2].ptr, scr.ptr, st)
-for _ in range(5):
-    m.Matcher.hamming_top2_device(dq.ptr, N, dr.ptr, N, res[0].ptr, res[1].ptr, res[2].ptr, scr.ptr, st)
+sizes = []
+for on in (1, 0):
+    m.Matcher.use_matrix_cores(on)
+    sizes += [m.Matcher.top2_scratch_bytes(N, N), m.Matcher.top2_scratch_bytes(4000, 4000)]
+scr = rt.DeviceBuffer(max(sizes + [16]))
+for on in (1, 0):  # matrix-core form (the default), then the xor/popcount form of the same two all-pairs kernels
+    m.Matcher.use_matrix_cores(on)
+    for _ in range(5):
+        m.Matcher.hamming_matrix_device(dq.ptr, N, dr.ptr, N, dout.ptr, st)
+    for _ in range(5):
+        m.Matcher.hamming_top2_device(dq.ptr, 4000, dr.ptr, 4000, res[0].ptr, res[1].ptr, res[2].ptr, scr.ptr, st)
+    for _ in range(5):
+        m.Matcher.hamming_top2_device(dq.ptr, N, dr.ptr, N, res[0].ptr, res[1].ptr, res[2].ptr, scr.ptr, st)
+m.Matcher.use_matrix_cores(-1)
 rt.stream_sync(st)
 
 # ---- configs[2]: SearchByProjection on a 2 x 2000-feature 1280x720 frame
