@@ -2,8 +2,12 @@
 // BoW-gated searches of ORBmatcher.
 //
 // THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE (same rules as orb_oracle.cpp: only tests/, smoke() and the
-// cpu_baseline leg of bench.py may load it).  PARITY STATUS: **parity unpinned** -- the reference ships no vocabulary
-// file (Vocabulary/ORBvoc.txt.tar.gz is a missing blob), no tests and no fixtures; what is restated here is the
+// cpu_baseline leg of bench.py may load it).  PARITY STATUS: **parity unpinned** for the descent and the three searches --
+// the reference ships no vocabulary file (Vocabulary/ORBvoc.txt.tar.gz is a missing blob), no tests and no fixtures, and
+// those parts need OpenCV to build; **pinned against the reference's compiled code** for the BowVector / FeatureVector
+// half of orc_bow_vectors (weight accumulation order, L1 normalisation, grouping of feature indices):
+// oracle/_ref/libdbow2_ref.so = the reference's BowVector.cpp + FeatureVector.cpp built where they lie (make ref),
+// tests/test_oracle_ref_dbow2.py, fixtures tests/golden/dbow2_ref_vectors.npz.  What is restated here is the
 // reference's OWN code, literally, with std::map containers as the reference has them:
 //   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1180 (transform of a feature set, TF_IDF + L1 as ORBvoc declares),
 //   :1219-1260 (descent of one feature), :1339-1425 (text loader: node ids in file order, children in ascending id order),

@@ -261,3 +261,22 @@ def test_keyframes_built_on_the_device_from_the_front_end():
     for k in kfs:
         k.close()
     fe.close(); S.close(); V.close()
+
+
+def test_bow_vectors_match_reference_classes_golden():
+    # tests/golden/dbow2_ref_vectors.npz: outputs of the reference's own compiled BowVector / FeatureVector classes
+    import os, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_dbow2_golden as gold
+    G = np.load(os.path.join(here, "golden", "dbow2_ref_vectors.npz"))
+    import multi_orb_slam_amd as m
+    for i, c in enumerate(gold.CASES):
+        voc, feats = gold.case_inputs(c)
+        V = m.Vocabulary(voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"], voc["L"])
+        word, node, weight = V.transform(feats, c["levelsup"])
+        assert np.array_equal(word, G["c%d_word" % i]) and np.array_equal(node, G["c%d_node" % i]) and np.array_equal(weight, G["c%d_weight" % i])
+        (bid, bval), fv = V.bow_vectors(feats, c["levelsup"])
+        assert np.array_equal(bid, G["c%d_bow_id" % i]) and np.array_equal(bval, G["c%d_bow_val" % i])
+        assert np.array_equal(fv.node_id, G["c%d_fv_node" % i]) and np.array_equal(fv.node_start, G["c%d_fv_start" % i])
+        assert np.array_equal(fv.items, G["c%d_fv_items" % i])
