@@ -41,13 +41,15 @@ def parse():
     return ap.parse_args()
 
 
-def matcher_roofline(rt, m, stream, n, iters=20):
+def matcher_roofline(rt, m, stream, n, iters=80):
     """`roofline` of the bench line: the distance matrix in its default (matrix-core) form, with the xor/popcount form of
-    the same kernel -- the formulation north_star names -- timed beside it under `popcount_form`."""
+    the same kernel -- the formulation north_star names -- timed beside it under `popcount_form`.
+    80 launches (~35 ms): the chip boosts for the first ~6 launches (~410 us), dips for the next dozen (~510 us) and then
+    settles (profiles/r01/notes_experiments.md); the average over a run this long is the sustained figure."""
     out = _matrix_launches(rt, m, stream, n, iters)
     prev = m.Matcher.use_matrix_cores(0)
     try:
-        alt = _matrix_launches(rt, m, stream, n, max(5, iters // 2))
+        alt = _matrix_launches(rt, m, stream, n, max(5, iters // 4))
     finally:
         m.Matcher.use_matrix_cores(prev)
     out["popcount_form"] = {"kernel": "k_hamming_matrix", "achieved": alt["achieved"], "frac": alt["frac"],
