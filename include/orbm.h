@@ -71,7 +71,7 @@ int orbm_hamming_matrix_device(const uint8_t* d_q, int nq, const uint8_t* d_r, i
 
 /* The two all-pairs entry points above compute their distances either with xor + popcount on the vector ALU or, from one
  * tile of work on (>= 64 queries, >= 64 references), as an int8 dot product of the +-1-expanded descriptors on the matrix
- * cores (256 - 2 * distance, exact): same results bit for bit, the second form 1.4x / 2.4x faster at 32 000 x 32 000.
+ * cores (256 - 2 * distance, exact): same results bit for bit, the second form about 1.4x / 2x faster at 32 000 x 32 000.
  * on = 1 / 0 selects the matrix-core / popcount kernels for the whole process, -1 restores the default (matrix cores unless
  * MORB_MATRIX_MFMA=0 / MORB_TOP2_MFMA=0 are set).  Returns the previous setting.  orbm_top2_scratch_bytes follows it. */
 int orbm_use_matrix_cores(int on);
