@@ -1580,9 +1580,22 @@ int launch_matrix(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16
     const int forced = g_matrix_cores.load(std::memory_order_relaxed);
     if ((forced < 0 ? mfma_env : forced) && (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && nq >= 64 && nr >= MM_R_TILE && (((uintptr_t)d_r & 7) == 0)) {
         const int n_tiles = (nr + MM_R_TILE - 1) / MM_R_TILE, qblocks = (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK;
-        // >= ~1500 workgroups when the problem has them; a workgroup re-expands its 256 queries once per launch, so
-        // at least 4 tiles each
-        int tpb = std::max(4, std::min(32, (int)(((long long)n_tiles * qblocks + 1535) / 1536)));
+        // Tiles per workgroup: three workgroups are resident per CU (168 registers, 48 KB LDS), a launch runs in
+        // ceil(workgroups / slots) rounds of (tiles + ~1.5 for the query expansion) steps each; take the count that minimises
+        // that product (at 32 000 x 32 000: 21 tiles -> 3000 workgroups = 3.9 rounds, 411 us, where 32 tiles -> 2.6 rounds
+        // took 422 and 16 tiles -> 5.2 rounds 431).
+        static const int slots = [] {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return std::max(1, cus) * 3;
+        }();
+        int tpb = 4;
+        double best_cost = 1e300;
+        for (int c = 4; c <= 32; ++c) {
+            const long long wgs = (long long)((n_tiles + c - 1) / c) * qblocks;
+            const double cost = (double)((wgs + slots - 1) / slots) * (c + 1.5);
+            if (cost < best_cost) { best_cost = cost; tpb = c; }
+        }
         static const int tpb_env = [] { const char* e = getenv("MORB_MATRIX_TPB"); return e ? atoi(e) : 0; }();
         if (tpb_env > 0) tpb = tpb_env;
         dim3 g2((n_tiles + tpb - 1) / tpb, qblocks);
