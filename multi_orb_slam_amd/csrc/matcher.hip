@@ -1520,17 +1520,26 @@ Top2Plan top2_plan(int nq, int nr, bool have_scratch = true) {
     const int forced = g_matrix_cores.load(std::memory_order_relaxed);
     Top2Plan p{false, 1, nr};
     if ((forced < 0 ? mfma_env : forced) && nq >= 64 && nr >= MM_R_TILE) {
+        // Two workgroups are resident per CU (229 registers): a launch runs in ceil(workgroups / slots) rounds of
+        // (tiles per slice + ~2) steps; take the slice count that minimises the product (32 000 x 32 000: 8 slices = 1000
+        // workgroups = 1.95 rounds instead of 9 slices = 2.2 rounds, i.e. three).
+        static const int slots = [] {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return std::max(1, cus) * 2;
+        }();
         const int qblocks = (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK;
-        int S = (1024 + qblocks - 1) / qblocks;                 // ~2 workgroups per CU x 2 rounds
-        S = std::min(S, std::max(1, nr / (4 * MM_R_TILE)));     // at least four tiles per slice
-        S = std::max(S, (nr + 65535) / 65536);
-        S = std::min(S, 64);
-        if (!have_scratch) S = 1;
-        int len = ((nr + S - 1) / S + MM_R_TILE - 1) / MM_R_TILE * MM_R_TILE;
-        if (len <= 65536) {
-            p.mfma = true; p.slice_len = len; p.S = (nr + len - 1) / len;
-            return p;
+        const int s_max = have_scratch ? std::min(64, std::max(1, nr / (4 * MM_R_TILE))) : 1;  // at least four tiles per slice
+        double best_cost = 1e300;
+        for (int S = 1; S <= s_max; ++S) {
+            const int len = ((nr + S - 1) / S + MM_R_TILE - 1) / MM_R_TILE * MM_R_TILE;
+            if (len > 65536) continue;
+            const int s_eff = (nr + len - 1) / len;
+            const long long wgs = (long long)s_eff * qblocks;
+            const double cost = (double)((wgs + slots - 1) / slots) * (len / MM_R_TILE + 2.0) + 0.05 * s_eff;
+            if (cost < best_cost) { best_cost = cost; p.mfma = true; p.slice_len = len; p.S = s_eff; }
         }
+        if (p.mfma) return p;
     }
     const int qblocks = (nq + 63) / 64;
     int S = (128 + qblocks - 1) / qblocks;               // target >= 128 blocks x 16 waves = 2048 waves
