@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/s of the ORB front end (N-camera extract + match) on MI355X, with the matcher roofline and the
+"""bench.py -- frames/s of the ORB front end (N-camera extract + match) on MI355X, with the matcher rooflines and the
 CPU baseline in the same run.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4]
   (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
-One step = one timestep of one 2-camera 640x480 rig (BASELINE.json configs[1]): extract both cameras (8-level
-pyramid, 1000 features/camera), merge the frame, SearchByProjection of the previous frame's points, exhaustive
-cross-camera Hamming top-2.  Inputs are synthetic, generated once and resident in HBM before the timed region.
-Every rank owns one rig (weak scaling); with N > 1 the cross-camera matcher sees every rank's descriptors through
-one RCCL all-gather per step.  `value` = rig-frames/s summed over ranks.
+One step = one timestep of one camera rig: extract every camera (8-level pyramid), merge the frame, SearchByProjection of
+the previous frame's points, exhaustive cross-camera Hamming top-2.  Inputs are synthetic, generated once and resident in
+HBM before the timed region.  --config selects the BASELINE.json workload:
 
-Before anything is timed the GPU results of three steps are compared bit-for-bit with the CPU oracle.
+  1 (default)  configs[1]  2 x 640x480 @1000    every rank owns one whole rig                       weak scaling
+  2            configs[2]  2 x 1280x720 @2000   every rank owns one whole rig                       weak scaling
+  3            configs[3]  4 x 640x480 @1000    ONE rig, cameras sharded over the ranks (4/N each)  strong scaling
+  4            configs[4]  8 x 1920x1080 @4000  ONE rig, cameras sharded over the ranks (8/N each)  strong scaling
+
+With N > 1 the cross-camera matcher sees every rank's descriptors through ONE RCCL all-gather per step, issued natively
+from inside the step.  `value` = rig timesteps per second of the whole job (weak: summed over the ranks' rigs).
+
+Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + device synchronisation, repeated until
+at least --min-time seconds have been timed (so that a short K still gives a stable figure); `ms_per_step` is the median
+block, per-step median / p5 / p95 come from host timestamps of the individual step calls (each ends with the step's single
+synchronisation).  Before anything is timed the GPU results are compared bit for bit with the CPU oracle.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -23,29 +33,81 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-W, H, NFEAT, CAMS_PER_RANK, RING = 640, 480, 1000, 2, 8
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+INT_VALU_PEAK_TOPS = 39.3        # 256 CU x 4 SIMD x 16 int lanes/clk x 2.4 GHz (measured 36.9 for v_xor/v_bcnt/v_add)
+I8_MFMA_PEAK_TOPS = 5000.0       # dense int8 matrix peak = 2 x the 2.5 PF bf16 dense peak (microbench ceiling in the guide: 3944)
 MATRIX_N = 32000                 # all-pairs size of configs[4]: 8 cameras x 4000 descriptors
 
+CONFIGS = {
+    1: dict(name="configs[1]", width=640, height=480, nfeatures=1000, rig_cams=2, scaling="weak", ring=8,
+            text="one 2-cam 640x480 rig per GPU, 8-level pyramid, 1000 feat/cam"),
+    2: dict(name="configs[2]", width=1280, height=720, nfeatures=2000, rig_cams=2, scaling="weak", ring=8,
+            text="one 2-cam 1280x720 rig per GPU, 8-level pyramid, 2000 feat/cam, radius-gated SearchByProjection"),
+    3: dict(name="configs[3]", width=640, height=480, nfeatures=1000, rig_cams=4, scaling="strong", ring=8,
+            text="ONE 4-cam 640x480 rig, cameras sharded over the GPUs (one camera per GPU at N=4), 1000 feat/cam, "
+                 "RCCL all-gather of the 256-bit descriptors for cross-camera matching"),
+    4: dict(name="configs[4]", width=1920, height=1080, nfeatures=4000, rig_cams=8, scaling="strong", ring=4,
+            text="ONE rig of 8 synthetic 1920x1080 streams, cameras sharded over the GPUs, 4000 feat/cam, batched pyramid "
+                 "extract + all-pairs Hamming top-2 (32k x 28k at N=1)"),
+}
 
-def parse():
+
+def plan_for(config, world, rank):
+    """Which cameras rank `rank` of `world` owns under --config `config`, and how the job's value is counted.  Pure
+    arithmetic (no GPU, no torch): tests/test_bench_plan.py runs it for the torchrun shapes the driver uses."""
+    if config not in CONFIGS:
+        raise SystemExit("--config must be one of %s" % sorted(CONFIGS))
+    c = dict(CONFIGS[config])
+    if not (0 <= rank < world):
+        raise SystemExit("rank %d outside world %d" % (rank, world))
+    if c["scaling"] == "weak":
+        cams = c["rig_cams"]
+        gcam = [rank * cams + k for k in range(cams)]      # every rank: a rig of its own (distinct synthetic cameras)
+        rigs = world
+    else:
+        if world > c["rig_cams"] or c["rig_cams"] % world:
+            raise SystemExit("%s shards %d cameras: --gpus must divide %d (got %d)" % (c["name"], c["rig_cams"], c["rig_cams"], world))
+        from multi_orb_slam_amd.dist import shard_cameras
+        gcam = shard_cameras(c["rig_cams"], world, rank)
+        rigs = 1
+    c.update(cams_per_rank=len(gcam), global_cams=gcam, rigs=rigs, world=world, rank=rank,
+             exchange=world > 1)
+    return c
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="steps per timed block (default 2000; 100 for --config 4)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
+    ap.add_argument("--min-time", type=float, default=0.25, help="keep timing blocks of --steps steps until this many seconds are covered")
     ap.add_argument("--no-overlap", action="store_true", help="every step extracts its own images first (no orbf_prefetch)")
-    ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--matrix-n", type=int, default=MATRIX_N)
-    return ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.steps is None:
+        a.steps = 100 if a.config == 4 else 2000
+    if a.warmup is None:
+        a.warmup = 10 if a.config == 4 else 200
+    return a
 
 
+def pct(xs, p):
+    """p-th percentile (nearest rank) of a non-empty list"""
+    s = sorted(xs)
+    return s[min(len(s) - 1, max(0, int(math.ceil(p / 100.0 * len(s))) - 1))]
+
+
+# ------------------------------------------------------------------------------------------------ matcher rooflines
 def matcher_roofline(rt, m, stream, n, iters=80):
-    """`roofline` of the bench line: the distance matrix in its default (matrix-core) form, with the xor/popcount form of
-    the same kernel -- the formulation north_star names -- timed beside it under `popcount_form`.
-    80 launches (~35 ms): the chip boosts for the first ~6 launches (~410 us), dips for the next dozen (~510 us) and then
-    settles (profiles/r01/notes_experiments.md); the average over a run this long is the sustained figure."""
+    """`roofline` of the bench line (M2): the uint16 distance matrix in its default (matrix-core) form, with the xor/popcount
+    form of the same kernel -- the formulation north_star names -- timed beside it under `popcount_form`.
+    80 launches (~35 ms): the chip boosts for the first ~6 launches, dips for the next dozen and then settles
+    (profiles/r01/notes_experiments.md); the average over a run this long is the sustained figure."""
     out = _matrix_launches(rt, m, stream, n, iters)
     prev = m.Matcher.use_matrix_cores(0)
     try:
@@ -60,6 +122,7 @@ def matcher_roofline(rt, m, stream, n, iters=80):
 def _matrix_launches(rt, m, stream, n, iters):
     """Hamming distance-matrix kernel (k_hamming_matrix_mfma at this size), Q = R = n: algorithmic bytes 32(Q+R) + 2QR per launch,
     average launch duration from HIP events on the stream the kernel runs on."""
+    import numpy as np
     from multi_orb_slam_amd import synth
     d = synth.descriptors(n, 4242)
     dq = rt.DeviceBuffer(n * 32); dr = rt.DeviceBuffer(n * 32); dout = rt.DeviceBuffer(n * n * 2)
@@ -75,8 +138,7 @@ def _matrix_launches(rt, m, stream, n, iters):
     ms = e0.elapsed_ms(e1) / iters
     alg_bytes = 32.0 * (n + n) + 2.0 * n * n
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    # spot-check of the timed buffer against the host popcount (rows 0 and n-1)
-    import numpy as np
+    # spot-check of the timed buffer against the host popcount (row n-1)
     row = dout.download(np.uint16, n, stream, offset=(n - 1) * n * 2)
     ref = np.unpackbits(d[n - 1][None, :] ^ synth.perturbed_queries(d, 9), axis=1).sum(1).astype(np.uint16)
     assert np.array_equal(row, ref), "distance matrix spot check failed"
@@ -95,8 +157,92 @@ def _matrix_launches(rt, m, stream, n, iters):
             "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(ms * 1e3, 2)}
 
 
-def main():
-    a = parse()
+def top2_roofline(rt, m, stream, n, iters=20):
+    """`roofline_m1`: exhaustive top-2, Q = R = n.  18 int ops per 256-bit pair (8 xor + 8 popcount +
+    2 compare/select) against the integer vector peak for the xor/popcount form; the default matrix-core form of the same
+    entry point (int8 dot product of the +-1-expanded descriptors, 512 int8 ops per pair) against the dense int8 MFMA peak."""
+    import numpy as np
+    from multi_orb_slam_amd import synth
+    d = synth.descriptors(n, 777)
+    qh = synth.perturbed_queries(d, 11)
+    dq = rt.DeviceBuffer(n * 32); dr = rt.DeviceBuffer(n * 32)
+    dq.upload(qh); dr.upload(d)
+    o = [rt.DeviceBuffer(n * 4) for _ in range(3)]
+    out = {}
+    pairs = float(n) * n
+    for form, on in (("mfma_form", 1), ("popcount_form", 0)):
+        prev = m.Matcher.use_matrix_cores(on)
+        try:
+            sb = m.Matcher.top2_scratch_bytes(n, n)
+            scratch = rt.DeviceBuffer(max(sb, 16))
+            run = lambda: m.Matcher.hamming_top2_device(dq.ptr, n, dr.ptr, n, o[0].ptr, o[1].ptr, o[2].ptr, scratch.ptr if sb else None, stream)
+            for _ in range(2):
+                run()
+            rt.stream_sync(stream)
+            e0, e1 = rt.Event(), rt.Event()
+            e0.record(stream)
+            for _ in range(iters):
+                run()
+            e1.record(stream)
+            ms = e0.elapsed_ms(e1) / iters
+            bi = o[0].download(np.int32, 64, stream); bd = o[1].download(np.int32, 64, stream)
+            for i in range(0, 64, 9):   # spot check against the host popcount
+                dist = np.unpackbits(d ^ qh[i], axis=1).sum(1)
+                assert bd[i] == dist.min() and bi[i] == int(np.argmin(dist)), "top-2 spot check failed"
+            scratch.free()
+        finally:
+            m.Matcher.use_matrix_cores(prev)
+        if on:
+            ach = 512.0 * pairs / (ms * 1e-3) / 1e12
+            out[form] = {"kernel": "k_hamming_top2_mfma", "bound": "mfma", "achieved": round(ach, 1), "peak": I8_MFMA_PEAK_TOPS,
+                         "unit": "int8 TOP/s", "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
+                         "pairs_per_s": round(pairs / (ms * 1e-3), 0)}
+        else:
+            ach = 18.0 * pairs / (ms * 1e-3) / 1e12
+            out[form] = {"kernel": "k_hamming_top2", "bound": "valu", "achieved": round(ach, 2), "peak": INT_VALU_PEAK_TOPS,
+                         "unit": "int32 T lane-op/s", "frac": round(ach / INT_VALU_PEAK_TOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
+                         "pairs_per_s": round(pairs / (ms * 1e-3), 0)}
+    for b in [dq, dr] + o:
+        b.free()
+    out["workload"] = "Q=R=%d exhaustive top-2; algorithmic 18 int ops / pair (8 xor + 8 popcount + 2 select), bytes 32(Q+R)+12Q" % n
+    return out
+
+
+def project_roofline(m, n_feat=2000, width=1280, height=720, iters=50):
+    """`roofline_m3`: the projection-gated kernel alone on configs[2]'s matcher workload: a frame of
+    2 x n_feat extracted features, every feature of the previous timestep projected into it.  Algorithmic bytes per query:
+    68 (the query record) + 8 per grid cell of its window + per gated candidate 4 (index) + 16 (x, y, octave, uright) +
+    32 (descriptor) + 52 B of shortlist / count output; achieved = bytes / HIP-event launch time."""
+    import numpy as np
+    from multi_orb_slam_amd import synth, pipeline
+    import multi_orb_slam_amd as mm
+    params = [mm.ExtractorParams(nfeatures=n_feat)] * 2
+    ex = mm.Extractor(params, width, height)
+    fr = [ex.extract([synth.image(c, t, width, height) for c in range(2)]) for t in range(2)]
+    ex.close()
+    mt = mm.Matcher()
+    data = mm.FrameData.from_cameras(fr[1], width, height)
+    frame = mt.frame(data)
+    k0 = np.concatenate([k for k, _ in fr[0]]); d0 = np.concatenate([d for _, d in fr[0]])
+    cam_of = np.repeat(np.arange(2, dtype=np.int32), [len(k) for k, _ in fr[0]])
+    q = pipeline.make_queries((k0, d0, np.full(len(k0), -1.0, np.float32), cam_of), mm.tables(params[0])["scale"])
+    us, gated = mt.time_project(frame, q, 100, iters)
+    r = q["radius"].astype(np.float64)
+    cells = ((np.ceil((q["u"] + r) * 64.0 / width) - np.floor((q["u"] - r) * 64.0 / width) + 1).clip(1, 64) *
+             (np.ceil((q["v"] + r) * 48.0 / height) - np.floor((q["v"] - r) * 48.0 / height) + 1).clip(1, 48)).sum()
+    alg = 68.0 * len(q) + 8.0 * float(cells) + 52.0 * gated + 52.0 * len(q)
+    frame.close(); mt.close()
+    ach = alg / (us * 1e-6) / 1e9
+    return {"kernel": "k_project", "workload": "configs[2] matcher: %d queries into a 2 x %d-feature %dx%d frame, %d gated candidates"
+                      % (len(q), n_feat, width, height, gated),
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+            "alg_bytes_per_launch": alg, "avg_launch_us": round(us, 2),
+            "note": "latency-bound gather (one wave per query, dependent cell -> item -> descriptor loads), not a bandwidth kernel"}
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main(argv=None):
+    a = parse(argv)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -114,9 +260,10 @@ def main():
     from multi_orb_slam_amd import synth, pipeline, rt
     from multi_orb_slam_amd.dist import DescriptorExchange
 
+    P = plan_for(a.config, world, rank)
+    W, H, NFEAT, NC, RING, gcam = P["width"], P["height"], P["nfeatures"], P["cams_per_rank"], P["ring"], P["global_cams"]
     rt.set_device(local)
-    params = [m.ExtractorParams(nfeatures=NFEAT)] * CAMS_PER_RANK
-    gcam = [rank * CAMS_PER_RANK + c for c in range(CAMS_PER_RANK)]
+    params = [m.ExtractorParams(nfeatures=NFEAT)] * NC
     fe = pipeline.FrontEnd(params, W, H, device=local, rank=rank, world_size=world, global_cams=gcam)
     if use_dist:
         import torch
@@ -127,34 +274,51 @@ def main():
         if os.environ.get("MORB_NATIVE_EXCHANGE", "1") != "0":
             fe.enable_native_exchange(dist, torch.device("cuda", local))
 
-    # ---- synthetic stream of this rank's rig, resident in HBM before timing
+    # ---- synthetic stream of this rank's cameras: resident in HBM before timing, and once more in page-locked host memory
     host_frames = [[synth.image(g, t, W, H) for g in gcam] for t in range(RING)]
-    dev_frames = []
+    dev_frames, pin_frames = [], []
     for t in range(RING):
-        row = []
-        for c in range(CAMS_PER_RANK):
+        row, prow = [], []
+        for c in range(NC):
             b = rt.DeviceBuffer(W * H); b.upload(host_frames[t][c]); row.append(b)
-        dev_frames.append(row)
+            pb = rt.PinnedBuffer(W * H); pb.array[:] = host_frames[t][c].reshape(-1); prow.append(pb)
+        dev_frames.append(row); pin_frames.append(prow)
     rt.device_sync()
 
-    def frame_args(t):
-        return [(dev_frames[t % RING][c].ptr, W) for c in range(CAMS_PER_RANK)]
+    def frame_args(t, pinned=False):
+        src = pin_frames if pinned else dev_frames
+        return [(src[t % RING][c].ptr, W) for c in range(NC)]
 
     # Consecutive timesteps overlap: while step t is matched (and, with N > 1, exchanged), the extraction of step t+1 already
     # runs on the extractor's stream.
     overlap = not a.no_overlap
 
-    # ---- parity gate: four steps bit-exact vs the CPU oracle (single-rank view; N > 1 checks its own cameras)
-    parity = "skipped"
+    # ---- parity gate: bit-exact vs the CPU oracle (single-rank view) on the same call pattern as the timed loop
+    parity = "skipped (N > 1: every rank's cameras are covered by the N = 1 gate and tests/)"
     if world == 1:
         from oracle_pipeline import OracleFrontEnd, assert_same_step
-        ofe = OracleFrontEnd(params, W, H, gcam)
-        if overlap:
-            fe.announce(frame_args(1), resident=True)
-        for t in range(5):   # same call pattern as the timed loop: two future steps are announced (orbf_prefetch)
-            got = fe.step(frame_args(t), resident=True, next_images=frame_args(t + 2) if overlap else None)
-            assert_same_step(got, ofe.step(host_frames[t % RING]))
-        parity = "bit-exact vs oracle on 5 steps (keypoints, descriptors, temporal + cross-camera matches)"
+        import oracle
+        if a.config != 4:
+            ofe = OracleFrontEnd(params, W, H, gcam)
+            if overlap:
+                fe.announce(frame_args(1), resident=True)
+            for t in range(5):   # two future steps are announced (orbf_prefetch), as in the timed loop
+                got = fe.step(frame_args(t), resident=True, next_images=frame_args(t + 2) if overlap else None)
+                assert_same_step(got, ofe.step(host_frames[t % RING]))
+            parity = "bit-exact vs oracle on 5 steps (keypoints, descriptors, stereo, temporal + cross-camera matches)"
+        else:
+            # the oracle needs seconds per 1080p camera: one camera of the second step is pinned here, the whole rig by
+            # tests/test_gpu_frontend.py::test_full_size_rig_properties
+            for t in range(2):
+                got = fe.step(frame_args(t), resident=True)
+            off = np.concatenate([[0], np.cumsum(got["counts"])])
+            okps, odesc = oracle.extract(host_frames[1][3], nfeatures=NFEAT)
+            assert got["kps"][off[3]:off[4]].tobytes() == okps.tobytes() and np.array_equal(got["desc"][off[3]:off[4]], odesc)
+            g = 17; bi, bd, sd = got["cross"]
+            others = np.concatenate([got["desc"][:off[0]], got["desc"][off[1]:]])
+            dd = np.unpackbits(others ^ got["desc"][g], axis=1).sum(1); o = np.argsort(dd, kind="stable")
+            assert bd[g] == dd[o[0]] and sd[g] == dd[o[1]] and bi[g] == o[0]
+            parity = "camera 3 of step 1 bit-exact vs oracle at full size + cross top-2 spot check (whole rig: tests/)"
         fe.reset()
 
     def sync_all():
@@ -165,16 +329,46 @@ def main():
             dist.barrier(device_ids=[local])
 
     ahead = [0]   # index of the youngest timestep announced so far
+    stamps = []   # host timestamps after every step call of the current block
 
-    def run(nsteps, t0, overlap=overlap):
+    def run(nsteps, t0, overlap=overlap, pinned=False, record=False):
         # every step completes one timestep (extract + match); with `overlap` the images of the two steps after it are known
         # to the front end (one new announcement per step), so K steps enqueue K extractions and complete K matchings
+        res = "pinned" if pinned else True
         if overlap and ahead[0] < t0 + 1:
-            fe.announce(frame_args(t0 + 1), resident=True); ahead[0] = t0 + 1
+            fe.announce(frame_args(t0 + 1, pinned), resident=res); ahead[0] = t0 + 1
+        pc = time.perf_counter
         for i in range(nsteps):
             if overlap:
                 ahead[0] = t0 + i + 2
-            fe.step(frame_args(t0 + i), resident=True, next_images=frame_args(t0 + i + 2) if overlap else None)
+            fe.step(frame_args(t0 + i, pinned), resident=res, next_images=frame_args(t0 + i + 2, pinned) if overlap else None)
+            if record:
+                stamps.append(pc())
+
+    def timed_blocks(K, t0, min_time, overlap=overlap, pinned=False):
+        """blocks of exactly K steps, barrier + synchronise on both sides of each; -> (block seconds [max over ranks], per-step s)"""
+        blocks, per_step, covered, t = [], [], 0.0, t0
+        n_blocks = None
+        while True:
+            sync_all()
+            del stamps[:]
+            t_start = time.perf_counter()
+            run(K, t, overlap, pinned, record=True)
+            sync_all()
+            el = time.perf_counter() - t_start
+            if dist is not None:
+                import torch
+                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            blocks.append(el); covered += el; t += K
+            prev = t_start
+            for s in stamps:
+                per_step.append(s - prev); prev = s
+            if n_blocks is None:     # every rank derives the same count from the same (max-reduced) first block
+                n_blocks = max(1, min(200, int(math.ceil(min_time / max(el, 1e-9)))))
+            if len(blocks) >= n_blocks:
+                return blocks, per_step, t
 
     fe.copy_results = False          # timed loop: consume the results in place (views of the pinned buffers)
     # The interpreter's cyclic collector would otherwise run inside the loop (every torch.distributed call allocates
@@ -182,26 +376,28 @@ def main():
     import gc
     gc.collect(); gc.freeze(); gc.disable()
     run(a.warmup, 0)
-    sync_all()
-    t_start = time.perf_counter()
-    run(a.steps, a.warmup)
-    sync_all()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    value = world * a.steps / elapsed
-    # for reference: the same loop with every step extracting its own images first (latency of one isolated timestep)
-    serial_ms = None
-    if overlap:
-        fe.reset(); run(20, 0, False); sync_all()
-        t1 = time.perf_counter(); run(200, 20, False); sync_all()
-        serial_ms = 1e3 * (time.perf_counter() - t1) / 200
-        fe.reset(); ahead[0] = 0
+    blocks, per_step, t_next = timed_blocks(a.steps, a.warmup, a.min_time)
+    med_block = pct(blocks, 50)
+    rigs = P["rigs"]
+    value = rigs * a.steps / med_block
 
+    # ---- the same loop fed from page-locked HOST memory: the H2D copy of every image (PCIe) is inside the timed region
+    h2d = None
+    if world == 1:
+        fe.reset(); ahead[0] = 0
+        run(min(a.warmup, 50), 0, overlap, pinned=True)
+        b2, ps2, _ = timed_blocks(a.steps, min(a.warmup, 50), a.min_time, overlap, pinned=True)
+        h2d = {"value": round(rigs * a.steps / pct(b2, 50), 2), "ms_per_step": round(1e3 * pct(b2, 50) / a.steps, 4),
+               "bytes_per_step": NC * W * H, "source": "page-locked host memory, hipMemcpy2DAsync inside the step"}
+    # ---- one isolated timestep: no look-ahead, every step extracts its own images first (what a live rig sees as latency)
+    fe.reset(); ahead[0] = 0
+    n_iso = max(20, min(200, a.steps))
+    run(min(20, a.warmup), 0, False)
+    _b3, ps3, _ = timed_blocks(n_iso, 20, min(a.min_time, 0.1), overlap=False)
+    iso = {"median": round(1e3 * pct(ps3, 50), 4), "p5": round(1e3 * pct(ps3, 5), 4), "p95": round(1e3 * pct(ps3, 95), 4), "steps": len(ps3)}
+    fe.reset(); ahead[0] = 0
     gc.enable(); gc.unfreeze()
+
     # per-stage GPU time of the extractor (HIP events) on one extra profiled step
     fe.ex.set_profiling(True)
     fe.step(frame_args(0), resident=True); fe.step(frame_args(1), resident=True)
@@ -210,15 +406,22 @@ def main():
 
     out = {
         "metric": "frames/sec (N-cam extract+match)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "configs[1]: one 2-cam 640x480 rig per GPU, 8-level pyramid, 1000 feat/cam, HIP "
-                               "FAST+rBRIEF extract + SearchByProjection + cross-camera Hamming top-2",
-                   "cams_per_gpu": CAMS_PER_RANK, "width": W, "height": H, "nfeatures": NFEAT, "nlevels": 8,
-                   "frame_unit": "one rig timestep (2 cameras)"},
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * med_block / a.steps, 4),
+        "higher_is_better": True, "scaling": P["scaling"], "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%s: %s; HIP FAST+rBRIEF extract + SearchByProjection + cross-camera Hamming top-2" % (P["name"], P["text"]),
+                   "cams_per_gpu": NC, "rig_cams": P["rig_cams"], "rigs": rigs, "width": W, "height": H, "nfeatures": NFEAT, "nlevels": 8,
+                   "frame_unit": "one rig timestep (%d cameras)" % P["rig_cams"]},
+        "timing": {"blocks": len(blocks), "steps_per_block": a.steps, "timed_s": round(sum(blocks), 4),
+                   "block_ms_per_step": {"median": round(1e3 * med_block / a.steps, 4), "min": round(1e3 * min(blocks) / a.steps, 4),
+                                         "max": round(1e3 * max(blocks) / a.steps, 4)},
+                   "step_ms": {"median": round(1e3 * pct(per_step, 50), 4), "p5": round(1e3 * pct(per_step, 5), 4),
+                               "p95": round(1e3 * pct(per_step, 95), 4), "n": len(per_step)}},
+        "latency_ms_isolated": iso["median"], "latency_isolated": iso,
+        "value_isolated": round(rigs * 1e3 / iso["median"], 2),
+        "value_h2d_inclusive": h2d["value"] if h2d else None, "h2d_inclusive": h2d,
         "parity": parity,
-        "overlap": ("the extractions of timesteps t+1 and t+2 run next to the matching of timestep t (orbf_prefetch, two "
-                    "extractor instances); one isolated timestep takes %.4f ms" % serial_ms) if overlap else "off",
+        "overlap": ("the extractions of timesteps t+1 and t+2 run next to the matching of timestep t (orbf_prefetch); `value` needs "
+                    "the images two steps ahead, `latency_ms_isolated` / `value_isolated` do not") if overlap else "off",
         "extractor_stage_us": {k: round(v, 1) for k, v in stages.items()},
         "exchange": ("none (one rank)" if not use_dist else
                      "one RCCL all-gather of the step's descriptor block per step, issued natively from inside the step (RCCL C API)"
@@ -227,23 +430,31 @@ def main():
     }
     if rank == 0 and not a.no_roofline:
         out["roofline"] = matcher_roofline(rt, m, fe.stream, a.matrix_n)
+        out["roofline_m1"] = top2_roofline(rt, m, fe.stream, a.matrix_n)
+        out["roofline_m3"] = project_roofline(m)
+    if rank == 0 and world == 1 and not a.no_dropin and a.config == 1:
+        try:
+            from multi_orb_slam_amd import dropin
+            out["dropin"] = dropin.bench(W, H, NFEAT)
+        except ImportError:
+            pass
     if rank == 0 and world == 1 and not a.no_cpu:
         from oracle_pipeline import OracleFrontEnd
 
-        def cpu_rate(cam_threads):
+        def cpu_rate(cam_threads, budget):
             ofe = OracleFrontEnd(params, W, H, gcam, cam_threads=cam_threads)
             ofe.step(host_frames[0])                  # warm caches, establish `prev`
-            t0 = time.perf_counter()
-            for i in range(a.cpu_frames):
-                ofe.step(host_frames[(1 + i) % RING])
-            return a.cpu_frames / (time.perf_counter() - t0)
+            t0 = time.perf_counter(); n = 0
+            while n < 2 or (time.perf_counter() - t0 < budget and n < 400):
+                ofe.step(host_frames[(1 + n) % RING]); n += 1
+            return n / (time.perf_counter() - t0), n
 
-        v1 = cpu_rate(False)      # faithful to the reference: cameras back to back on the tracking thread (src/Frame.cc:182,185)
-        vn = cpu_rate(True)       # one thread per camera (the variant commented out at src/Frame.cc:106-109)
+        v1, n1 = cpu_rate(False, 0.6 * a.cpu_seconds)   # faithful to the reference: cameras back to back on the tracking thread (src/Frame.cc:182,185)
+        vn, _ = cpu_rate(True, 0.4 * a.cpu_seconds)     # one thread per camera (the variant commented out at src/Frame.cc:106-109)
         out["cpu_baseline"] = {"value": round(v1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": "%d steps of the same 2-cam 640x480 workload through oracle/liborb_oracle.so "
-                                         "(scalar C++ restatement, 1 thread; host has %d cores)" % (a.cpu_frames, os.cpu_count()),
-                               "value_one_thread_per_camera": round(vn, 3), "cores_one_thread_per_camera": CAMS_PER_RANK}
+                               "sample": "%d steps of the same %d-cam %dx%d workload through oracle/liborb_oracle.so "
+                                         "(scalar C++ restatement, 1 thread; host has %d cores)" % (n1, NC, W, H, os.cpu_count()),
+                               "value_one_thread_per_camera": round(vn, 3), "cores_one_thread_per_camera": NC}
     if rank == 0:
         print(json.dumps(out))
     fe.close()

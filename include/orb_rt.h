@@ -16,6 +16,8 @@ int orb_device_name(int device, char* out, int cap); /* gcnArchName, e.g. "gfx95
 int orb_set_device(int device);
 int orb_malloc(void** d_ptr, size_t bytes);       /* hipMalloc on the current device                           */
 int orb_free(void* d_ptr);
+int orb_malloc_host(void** h_ptr, size_t bytes);  /* page-locked host memory: H2D copies from it are true async DMA      */
+int orb_free_host(void* h_ptr);
 int orb_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream); /* async when stream != NULL   */
 int orb_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 int orb_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);

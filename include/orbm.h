@@ -187,6 +187,12 @@ int orbm_features_in_area(orbm_matcher* m, const orbm_frame* f, int cam, float x
 int orbm_project_candidates(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap_per_query,
                             int32_t* cand_idx, uint16_t* cand_dist, int32_t* cand_count);
 
+/* Inspection / bench (roofline M3): `iters` launches of the projection kernel alone, as the frame search
+ * launches it (window + level + right-coordinate gates, distances, shortlist), timed with HIP events on the handle's
+ * stream.  *avg_us = average launch duration, *n_gated = candidates that passed the gates, summed over the queries. */
+int orbm_debug_time_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int th_high, int iters,
+                            float* avg_us, long long* n_gated);
+
 /* SearchByProjection(CurrentFrame, LastFrame, th, bMono, Calib) from the projected queries on.
  * occupied[g] != 0 where CurrentFrame.mvpMapPoints[g] already holds an observed point before the call (may be NULL:
  * TrackWithMotionModel clears the vector first, reference src/Tracking.cc:1254).

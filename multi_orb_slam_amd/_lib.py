@@ -179,6 +179,7 @@ def lib():
     L.orbm_project_candidates.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     L.orbm_project_best.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, vp, vp]
     L.orbm_search_by_projection.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp]
+    L.orbm_debug_time_project.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     L.orbm_search_by_projection_points.argtypes = [vp, vp, vp, i32, vp, f32, i32, vp, vp]
     f64 = C.c_double
     L.orbv_create.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp]

@@ -1,18 +1,23 @@
-// matcher.hip -- gfx950 kernels + C ABI of the ORB matcher (include/orbm.h).
+// matcher.hip -- gfx950 kernels + C ABI of the ORB matcher (include/orbm.h) and of the one-call front end (include/orbf.h).
 //
-// Kernels (all integer / bit work, no MFMA by design -- BASELINE.json north_star):
-//   k_hamming_top2    K8/M1  exhaustive top-2 Hamming: one query per lane, references walked with wave-uniform
-//                            (scalar-cache) loads, 16 waves per block each scanning 1/16 of the references,
-//                            LDS merge.  VALU-bound (18 int ops / pair).  reference src/ORBmatcher.cc:287-321.
-//   k_hamming_matrix  M2     full uint16 distance matrix: 8 references per lane held in VGPRs, queries walked with
-//                            scalar loads, one 16-byte store per lane per query row.  HBM-write-bound.
-//   k_project         K9/M3  projection-gated search: one wave per query walks the 64x48 grid cells of the window in
-//                            the reference's visiting order, ballot-compacts the survivors in order and gathers their
-//                            descriptors.  reference src/ORBmatcher.cc:3547-3592 + src/Frame.cc:574-629.
-// The order-dependent part of SearchByProjection (first-come claims, rotation histogram) is resolved on the host
-// from the ordered candidate lists.
+// Kernels (integer / bit work on the vector ALU; the matrix cores are used in exactly two kernels, the all-pairs forms below):
+//   k_hamming_top2 / k_cross_top2   M1  exhaustive top-2 Hamming, xor + popcount form: one query per lane, references walked
+//                            with wave-uniform (scalar-cache) loads, 16 waves per block each scanning 1/16 of the references,
+//                            LDS merge.  VALU-bound.  reference src/ORBmatcher.cc:287-321.
+//   k_hamming_top2_mfma      M1  the same results from v_mfma_i32_32x32x32_i8 on the +-1-expanded descriptors
+//                            (dot = 256 - 2 * distance, exact); accumulators come out as ready-made sort keys.
+//   k_hamming_matrix[_mfma]  M2  full uint16 distance matrix, popcount / matrix-core form.  HBM-write-bound (mfma form).
+//   k_project                M3  projection-gated search: one wave per query walks the 64x48 grid cells of the window in
+//                            the reference's visiting order, ballot-compacts the survivors in order, gathers their
+//                            descriptors and keeps a sorted shortlist.  reference src/ORBmatcher.cc:3547-3592 + src/Frame.cc:574-629.
+//   k_resolve / k_rs_*       the order-dependent part of SearchByProjection (first-come claims, rotation histogram,
+//                            ComputeThreeMaxima) as a fixed-point iteration ON THE DEVICE; the host replay of the loop
+//                            (host_resolve) is the exact fallback (sweep limit, MORB_HOST_RESOLVE=1).
+//   k_frame_*                Frame merge, ComputeStereoFromRGBD, AssignFeaturesToGrid on the device (src/Frame.cc:191-395).
+//   k_repack_gathered        multi-GPU: the all-gathered export blocks -> one contiguous descriptor list.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -1418,16 +1423,27 @@ __global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __rest
 // cameras packed back to back) + the count trailer.  The rows in use are copied into one contiguous list in global camera
 // order; block (0, 0) also writes the camera starts, the {features, first query, queries} triple of rank `rank`, and a
 // copy of all counts into mapped pinned memory.  Every block recomputes the few prefix sums it needs from the trailers.
+// A remote trailer is data from another process: every count is clamped to what is left of its rank's cap_rows rows (a
+// mismatched or corrupt block can then neither run past its own block nor past the contiguous list), and the number of
+// counts that had to be clamped is reported in h_counts[n_cams + 1] (orbm_cross_top2_gathered_collect turns it into an error).
+__device__ __forceinline__ int repack_count(const int* __restrict__ tail, int c, int& room, int& bad) {
+    const int raw = tail[c];
+    const int n = min(max(raw, 0), room);
+    bad += (n != raw);
+    room -= n;
+    return n;
+}
+
 __global__ __launch_bounds__(256) void k_repack_gathered(const uint8_t* __restrict__ gathered, int world, size_t block_bytes,
                                                          int cap_rows, int cams_per_rank, int rank, uint4* __restrict__ dst,
                                                          int* __restrict__ cam_start, int* __restrict__ range,
                                                          int* __restrict__ h_counts) {
     const int r = blockIdx.y;
-    int goff = 0, n_r = 0, own_off = 0, own_n = 0, total = 0;
+    int goff = 0, n_r = 0, own_off = 0, own_n = 0, total = 0, bad = 0;
     for (int rr = 0; rr < world; ++rr) {
         const int* tail = reinterpret_cast<const int*>(gathered + (size_t)rr * block_bytes + (size_t)cap_rows * 32);
-        int nr = 0;
-        for (int c = 0; c < cams_per_rank; ++c) nr += tail[c];
+        int nr = 0, room = cap_rows;
+        for (int c = 0; c < cams_per_rank; ++c) nr += repack_count(tail, c, room, bad);
         if (rr == r) { goff = total; n_r = nr; }
         if (rr == rank) { own_off = total; own_n = nr; }
         total += nr;
@@ -1436,15 +1452,18 @@ __global__ __launch_bounds__(256) void k_repack_gathered(const uint8_t* __restri
         int run = 0;
         for (int rr = 0; rr < world; ++rr) {
             const int* tail = reinterpret_cast<const int*>(gathered + (size_t)rr * block_bytes + (size_t)cap_rows * 32);
+            int room = cap_rows, ignore = 0;
             for (int c = 0; c < cams_per_rank; ++c) {
+                const int n = repack_count(tail, c, room, ignore);
                 cam_start[rr * cams_per_rank + c] = run;
-                h_counts[rr * cams_per_rank + c] = tail[c];
-                run += tail[c];
+                h_counts[rr * cams_per_rank + c] = n;
+                run += n;
             }
         }
         cam_start[world * cams_per_rank] = run;
         range[0] = total; range[1] = own_off; range[2] = own_n;
         h_counts[world * cams_per_rank] = own_n;
+        h_counts[world * cams_per_rank + 1] = bad;
     }
     const uint4* src = reinterpret_cast<const uint4*>(gathered + (size_t)r * block_bytes);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * n_r; i += gridDim.x * 256) dst[2 * (size_t)goff + i] = src[i];
@@ -1733,10 +1752,31 @@ static int ensure_host_copies(const orbm_frame* f) {
 
 extern "C" {
 
+// The single-workgroup kernels (k_resolve, k_frame_build_small) use the opt-in dynamic LDS limit.  The attribute belongs to
+// the (kernel, device) pair, so it is raised once per DEVICE, on that device, when the first handle is created there
+// (std::call_once: handles are created from several threads).
+static int raise_lds_limits(int device) {
+    constexpr int MAX_DEV = 64;
+    static std::once_flag once[MAX_DEV];
+    static hipError_t result[MAX_DEV];
+    if (device < 0 || device >= MAX_DEV) { morb::set_error("device %d out of range", device); return ORB_E_ARG; }
+    std::call_once(once[device], [device] {
+        const void* fns[] = {(const void*)k_resolve<true, false>, (const void*)k_resolve<false, false>, (const void*)k_resolve<true, true>,
+                             (const void*)k_resolve<false, true>, (const void*)k_frame_build_small};
+        hipError_t e = hipSuccess;
+        for (const void* fn : fns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        result[device] = e;
+    });
+    if (result[device] != hipSuccess) { morb::set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(result[device])); return ORB_E_HIP; }
+    return ORB_OK;
+}
+
 int orbm_create(int device, orbm_matcher** out) {
     MORB_ARG(out != nullptr);
     int rc = morb::select_device(device);
     if (rc != ORB_OK) return rc;
+    if ((rc = raise_lds_limits(device))) return rc;
     orbm_matcher* m = new orbm_matcher();
     m->device = device;
     // Matching is the latency chain a caller waits for while extraction of later timesteps fills the rest of the chip:
@@ -2035,15 +2075,8 @@ int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n
 
 }  // extern "C"
 
-// the single-workgroup frame kernel may use the opt-in dynamic LDS limit (set once per process)
-static int frame_build_lds_limit() {
-    static bool raised = false;
-    if (!raised) {
-        MORB_HIP(hipFuncSetAttribute((const void*)k_frame_build_small, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        raised = true;
-    }
-    return ORB_OK;
-}
+// (the single-workgroup frame kernel's opt-in dynamic LDS limit is raised per device in orbm_create: raise_lds_limits)
+static int frame_build_lds_limit() { return ORB_OK; }
 
 // Frame shell with storage for `n` features, no kernel launched yet.
 static int frame_shell(orbm_matcher* m, int n, int n_cams, float min_x, float min_y, float max_x, float max_y, bool counts_on_device,
@@ -2357,6 +2390,35 @@ int orbm_project_best(orbm_matcher* m, const orbm_frame* f, const orbm_query* q,
     return ORB_OK;
 }
 
+// inspection / bench (roofline M3): the projection kernel alone, in the configuration the frame search launches it in
+// (gates on, distances, transposed lists, shortlist extraction), timed with HIP events on the handle's stream
+int orbm_debug_time_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int th_high, int iters, float* avg_us,
+                            long long* n_gated) {
+    MORB_ARG(m && f && q && nq > 0 && iters > 0 && avg_us && n_gated && f->n_total > 0);
+    MORB_HIP(hipSetDevice(m->device));
+    int rc;
+    if ((rc = m->d_claim.reserve((size_t)(2 * RESOLVE_K + 1) * nq)) || (rc = m->d_qmeta.reserve(nq)) || (rc = m->h_i1.reserve(nq)))
+        return rc;
+    if ((rc = run_project(m, f, q, nq, 64, 1, 1, true, false, 1, nullptr, m->d_claim.p, th_high, nullptr, nullptr, m->d_qmeta.p))) return rc;
+    hipEvent_t e0, e1;
+    MORB_HIP(hipEventCreate(&e0)); MORB_HIP(hipEventCreate(&e1));
+    MORB_HIP(hipEventRecord(e0, m->stream));
+    for (int it = 0; it < iters && !rc; ++it)
+        rc = run_project(m, f, q, nq, 64, 1, 1, false, false, 1, nullptr, m->d_claim.p, th_high, nullptr, nullptr, m->d_qmeta.p);
+    hipError_t he = hipEventRecord(e1, m->stream);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    MORB_HIP(he);
+    MORB_HIP(hipMemcpy(m->h_i1.p, m->d_i1.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    long long tot = 0;
+    for (int i = 0; i < nq; ++i) tot += m->h_i1.p[i];
+    *avg_us = ms * 1e3f / (float)iters; *n_gated = tot;
+    return ORB_OK;
+}
+
 // Sequential resolve on the host from the ordered candidate lists (fallback of the device resolve; same semantics).
 static int host_resolve(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, const uint8_t* occupied,
                         bool points, float nnratio, int th_high, int check_orientation, int cap0, int32_t* match_of_feature,
@@ -2431,14 +2493,7 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     const bool multi = lds > 150 * 1024;  // multi-workgroup resolve with the tables in HBM
     if (m->host_resolve || J.nq > RESOLVE_MAX_Q) return ORB_OK;  // finish() takes the host path
     if (multi) { int rcg = m->d_gclaim.reserve((size_t)2 * n + RS_STATE_INTS); if (rcg) return rcg; }
-    if (!multi && lds > 48 * 1024) {  // large claim tables need the opt-in dynamic LDS limit (once per process)
-        static bool raised = false;
-        if (!raised) {
-            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            raised = true;
-        }
-    }
+    // (tables beyond 48 KB use the opt-in dynamic LDS limit, raised per device in orbm_create)
     int rc;
     if ((rc = m->d_choice.reserve(J.nq)) || (rc = m->d_claim.reserve((size_t)(2 * RESOLVE_K + 1) * J.nq)) || (rc = m->d_match.reserve(n)) ||
         (rc = m->d_status.reserve(4)) || (rc = m->h_match.reserve((size_t)n + 4)) || (rc = m->d_occ.reserve(std::max(n, 16))))
@@ -2493,14 +2548,6 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     const size_t lds_q = lds + (size_t)nq * (sizeof(int) + sizeof(float) + RESOLVE_K * sizeof(int) + 1) + (size_t)n * sizeof(float) + 16;
     const bool ldsq = lds_q <= 150 * 1024 && n < 65535;
     const size_t lds_use = ldsq ? lds_q : lds;
-    if (lds_use > 48 * 1024) {
-        static bool raised2 = false;
-        if (!raised2) {
-            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            MORB_HIP(hipFuncSetAttribute((const void*)k_resolve<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            raised2 = true;
-        }
-    }
 #define MORB_RESOLVE_LAUNCH(PT, LQ)                                                                                      \
     hipLaunchKernelGGL((k_resolve<PT, LQ>), dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const int2*)m->d_qmeta.p, \
                        nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
@@ -2704,7 +2751,7 @@ int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered,
     const int n_cams = world * cams_per_rank;
     const int n_cap = world * cap_rows;  // capacity of the contiguous list
     int rc;
-    if ((rc = m->d_r.reserve((size_t)n_cap * 32)) || (rc = m->d_gstart.reserve(n_cams + 1 + 4)) || (rc = m->h_gcnt.reserve(n_cams + 1)))
+    if ((rc = m->d_r.reserve((size_t)n_cap * 32)) || (rc = m->d_gstart.reserve(n_cams + 1 + 4)) || (rc = m->h_gcnt.reserve(n_cams + 2)))
         return rc;
     hipStream_t sd = m->side_stream;
     if (wait_after) {  // the gathered buffer is produced on another stream (the collective's; NULL = the default stream)
@@ -2733,6 +2780,11 @@ int orbm_cross_top2_gathered_collect(orbm_matcher* m, int32_t* best_idx, int32_t
     const int nq = m->h_gcnt.p[n_cams];
     *nq_out = nq;
     if (counts_out) memcpy(counts_out, m->h_gcnt.p, (size_t)n_cams * 4);
+    if (m->h_gcnt.p[n_cams + 1] != 0) {
+        morb::set_error("gathered export blocks are inconsistent: %d per-camera counts in the trailers were negative or exceeded "
+                        "their block's capacity (mismatched cap_rows / cams_per_rank between ranks, or a corrupt block)", m->h_gcnt.p[n_cams + 1]);
+        return ORB_E_ARG;
+    }
     if (nq && (best_idx || best_dist || second_dist)) {
         MORB_ARG(best_idx && best_dist && second_dist);
         memcpy(best_idx, m->h_c0.p, (size_t)nq * 4); memcpy(best_dist, m->h_c1.p, (size_t)nq * 4);
@@ -3513,6 +3565,11 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
         }
         out->cross_best_idx = m->h_c0.p; out->cross_best_dist = m->h_c1.p; out->cross_second_dist = m->h_c2.p;
         out->rig_cams = m->gathered_cams; out->rig_counts = m->h_gcnt.p;
+        if (m->h_gcnt.p[m->gathered_cams + 1] != 0) {   // (k_repack_gathered clamped a remote count: nothing ran out of bounds)
+            morb::set_error("multi-GPU exchange: %d per-camera counts of the gathered blocks were out of range (ranks disagree on "
+                            "their capacities, or a block is corrupt)", m->h_gcnt.p[m->gathered_cams + 1]);
+            return ORB_E_ARG;
+        }
     }
     out->host_us[3] = us_between(t_synced, std::chrono::steady_clock::now());
     return ORB_OK;

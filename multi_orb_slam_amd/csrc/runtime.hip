@@ -21,6 +21,8 @@ int orb_device_name(int device, char* out, int cap) {
 int orb_set_device(int device) { MORB_HIP(hipSetDevice(device)); return ORB_OK; }
 int orb_malloc(void** d_ptr, size_t bytes) { MORB_ARG(d_ptr); MORB_HIP(hipMalloc(d_ptr, bytes)); return ORB_OK; }
 int orb_free(void* d_ptr) { MORB_HIP(hipFree(d_ptr)); return ORB_OK; }
+int orb_malloc_host(void** h_ptr, size_t bytes) { MORB_ARG(h_ptr); MORB_HIP(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault)); return ORB_OK; }
+int orb_free_host(void* h_ptr) { MORB_HIP(hipHostFree(h_ptr)); return ORB_OK; }
 
 static int copy(void* dst, const void* src, size_t bytes, void* stream, hipMemcpyKind kind) {
     if (bytes == 0) return ORB_OK;

@@ -67,9 +67,14 @@ class DescriptorExchange:
         return frontend.mt.cross_top2_gathered_collect_views() if views else frontend.mt.cross_top2_gathered_collect()
 
 
-def shard_cameras(n_cameras, world_size, rank):
-    """Camera c is owned by rank c // ceil(n/world): contiguous blocks keep the global camera order == rank order."""
+def shard_cameras(n_cameras, world_size, rank, allow_ragged=False):
+    """Camera c is owned by rank c // ceil(n/world): contiguous blocks keep the global camera order == rank order.
+    The exchange's wire format (export block + count trailer, k_repack_gathered) indexes cameras as rank * cams_per_rank + c,
+    i.e. it needs the SAME number of cameras on every rank: a rig that does not divide evenly is refused unless the caller
+    asks for the ragged split explicitly (bookkeeping only -- such a split cannot go through the exchange)."""
     per = (n_cameras + world_size - 1) // world_size
+    if n_cameras % world_size and not allow_ragged:
+        raise ValueError("%d cameras do not shard evenly over %d ranks (the descriptor exchange needs equal shards)" % (n_cameras, world_size))
     return list(range(rank * per, min(n_cameras, (rank + 1) * per)))
 
 
@@ -94,6 +99,8 @@ def unpack_gathered(gathered, world, cap_rows, cams_per_rank):
     for r in range(world):
         blk = gathered[r * block_bytes:(r + 1) * block_bytes]
         counts = blk[cap_rows * 32:cap_rows * 32 + 4 * cams_per_rank].view(np.int32)
+        if (counts < 0).any() or int(counts.sum()) > cap_rows:
+            raise ValueError("rank %d's trailer holds counts %s that do not fit its %d rows" % (r, counts.tolist(), cap_rows))
         rows = blk[:cap_rows * 32].reshape(cap_rows, 32)
         off = 0
         for c in range(cams_per_rank):

@@ -252,6 +252,14 @@ class Matcher:
                                            None if sg is None else ptr(sg), 0 if sg is None else len(sg), ptr(bi), ptr(bd)))
         return bi[:nq], bd[:nq]
 
+    def time_project(self, frame, queries, th_high=TH_HIGH, iters=50):
+        """(average launch duration of the projection kernel in microseconds, candidates that passed the gates):
+        orbm_debug_time_project -- the kernel alone, as the frame search launches it (roofline M3)."""
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+        us = C.c_float(); n = C.c_longlong()
+        check(_lib.lib().orbm_debug_time_project(self._h, frame._h, ptr(queries), len(queries), th_high, iters, C.byref(us), C.byref(n)))
+        return us.value, n.value
+
     def project_candidates(self, frame, queries, cap):
         queries = np.ascontiguousarray(queries, QUERY_DTYPE); nq = len(queries)
         idx = np.zeros((max(nq, 1), cap), np.int32); dist = np.zeros((max(nq, 1), cap), np.uint16)

@@ -11,6 +11,7 @@ def _L():
         vp, sz = C.c_void_p, C.c_size_t
         L.orb_device_name.argtypes = [C.c_int, vp, C.c_int]
         L.orb_malloc.argtypes = [vp, sz]; L.orb_free.argtypes = [vp]
+        L.orb_malloc_host.argtypes = [vp, sz]; L.orb_free_host.argtypes = [vp]
         for f in (L.orb_memcpy_h2d, L.orb_memcpy_d2h, L.orb_memcpy_d2d):
             f.argtypes = [vp, vp, sz, vp]
         L.orb_memset.argtypes = [vp, C.c_int, sz, vp]
@@ -65,6 +66,36 @@ class DeviceBuffer:
             self._p = C.c_void_p()
 
     __del__ = free
+
+
+class PinnedBuffer:
+    """Page-locked host memory (orb_malloc_host) with a numpy view: the source of asynchronous H2D image uploads."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self._p = C.c_void_p()
+        check(_L().orb_malloc_host(C.byref(self._p), max(self.nbytes, 16)))
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self._p.value), dtype=np.uint8)
+
+    @property
+    def ptr(self):
+        return self._p.value
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            try:
+                _L().orb_free_host(self._p)
+            except Exception:
+                pass
+            self._p = C.c_void_p()
+
+    __del__ = free
+
+
+def memcpy_d2d(dst_ptr, src_ptr, nbytes, stream=None):
+    """device-to-device copy between raw pointers (synchronous without a stream)"""
+    check(_L().orb_memcpy_d2d(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes, stream))
 
 
 def stream_sync(stream=None):

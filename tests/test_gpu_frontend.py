@@ -310,3 +310,63 @@ def test_results_consumed_in_place_are_the_same_arrays():
         assert got["n_cross"] >= 0
         assert_same_step(got.materialise(), exp)
     fe.close()
+
+
+@pytest.mark.parametrize("world,n_cams,w,h,nf,ahead", [(4, 4, 640, 480, 1000, 0), (4, 4, 640, 480, 1000, 2), (2, 4, 640, 480, 1000, 1),
+                                                       (4, 8, 320, 240, 300, 0)])
+def test_rig_sharded_over_ranks_through_the_gathered_blocks(world, n_cams, w, h, nf, ahead):
+    """configs[3]: a 4-camera 640x480 rig at 1000 features per camera, one camera per rank.  The ranks are `world` front ends
+    on this one device; what RCCL's all-gather would do is done by device-to-device copies of every front end's REAL export
+    block (descriptor rows of the step's frame with whatever earlier steps left behind the counted rows, count trailer) into
+    one receive buffer, and every "rank" then runs orbm_cross_top2_gathered on it.  Keypoints, descriptors, stereo, temporal
+    matches and the rig-wide cross-camera top-2 of every rank must equal the oracle's.  The reference analogue of the shard:
+    the per-camera extractor calls of src/Frame.cc:182-185."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline, rt
+    from multi_orb_slam_amd.dist import shard_cameras, BLOCK_TRAILER
+    from multi_orb_slam_amd.frontend import SKIP_CROSS
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    per = n_cams // world
+    fes, ofes = [], []
+    for r in range(world):
+        mine = shard_cameras(n_cams, world, r)
+        assert len(mine) == per
+        params = [m.ExtractorParams(nfeatures=nf)] * per
+        fes.append(pipeline.FrontEnd(params, w, h, rank=r, world_size=world, global_cams=mine))
+        ofes.append(OracleFrontEnd(params, w, h, mine))
+    T = 4
+    frames = [{g: synth.image(g, t, w, h) for g in range(n_cams)} for t in range(T)]
+    mo = (pipeline.MOTION[0], pipeline.MOTION[1], pipeline.TH_PROJ)
+    recv = None
+    for t in range(T):
+        got = []
+        for r, fe in enumerate(fes):
+            for a in range(t + 1, min(t + ahead, T - 1) + 1):       # keep `ahead` future steps announced (a FIFO)
+                if a > getattr(fe, "_announced", 0):
+                    fe.announce([frames[a][g] for g in fe.global_cams]); fe._announced = a
+            res = fe.fe.step([frames[t][g] for g in fe.global_cams], None, SKIP_CROSS, motion=mo)
+            p, nbytes, rows = fe.fe.export_block()
+            assert nbytes == rows * 32 + BLOCK_TRAILER and rows >= per * nf
+            if recv is None:
+                recv = rt.DeviceBuffer(world * nbytes)
+                recv.upload(np.full(world * nbytes, 0x5A, np.uint8))
+            rt.memcpy_d2d(recv.ptr + r * nbytes, p, nbytes)           # this rank's slice of the "all-gather"
+            got.append(res)
+        rt.device_sync()
+        desc_of = {}
+        for r, fe in enumerate(fes):
+            off = np.concatenate([[0], np.cumsum(got[r]["counts"])])
+            for c, g in enumerate(fe.global_cams):
+                desc_of[g] = got[r]["desc"][off[c]:off[c + 1]]
+        for r, fe in enumerate(fes):
+            bi, bd, sd, cnts = fe.mt.cross_top2_gathered(recv.ptr, world, nbytes, rows, per, r)
+            assert cnts == [len(desc_of[g]) for g in range(n_cams)]
+            got[r]["cross"] = (bi, bd, sd)
+            got[r]["n_cross"] = int(pipeline.accept_cross(bd, sd).sum())
+            exp = ofes[r].step([frames[t][g] for g in fe.global_cams],
+                               other_descs=lambda c, fe=fe: [desc_of[g] for g in range(n_cams) if g != fe.global_cams[c]])
+            assert_same_step(got[r], exp)
+            assert len(bi) == sum(got[r]["counts"]) and (bi >= 0).all()
+    assert all(g["n_temporal"] > 50 for g in got) and sum(g["n_cross"] for g in got) >= 0
+    for fe in fes:
+        fe.close()

@@ -331,6 +331,34 @@ def test_cross_top2_from_a_gathered_buffer(world, cams_per_rank):
     matcher.close()
 
 
+def test_gathered_buffer_with_a_corrupt_trailer_is_an_error_not_an_overrun():
+    """A remote rank's count trailer is data from another process: counts that are negative or exceed the block's rows are
+    clamped on the device (k_repack_gathered never leaves its block or the contiguous list) and the call reports ORB_E_ARG."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import rt
+    from multi_orb_slam_amd.dist import pack_export_block
+    cap_rows, world, cpr = 256, 3, 2
+    block_bytes = cap_rows * 32 + 256
+    descs = [synth.descriptors(40 + 10 * g, 300 + g) for g in range(world * cpr)]
+    good = np.concatenate([pack_export_block([descs[r * cpr + c] for c in range(cpr)], cap_rows) for r in range(world)])
+    matcher = m.Matcher()
+    dev = rt.DeviceBuffer(good.nbytes)
+    for bad_counts in ([250, 250], [-5, 40], [2 ** 30, 1]):
+        buf = good.copy()
+        t = 1 * block_bytes + cap_rows * 32                          # rank 1's trailer
+        buf[t:t + 8] = np.array(bad_counts, np.int32).view(np.uint8)
+        dev.upload(buf)
+        with pytest.raises(m.OrbError) as e:
+            matcher.cross_top2_gathered(dev.ptr, world, block_bytes, cap_rows, cpr, 0)
+        assert e.value.code == -1 and "counts" in str(e.value)
+    dev.upload(good)                                                 # the handle is still usable afterwards
+    bi, bd, sd, cnt = matcher.cross_top2_gathered(dev.ptr, world, block_bytes, cap_rows, cpr, 2)
+    assert cnt == [len(d) for d in descs] and len(bi) == len(descs[4]) + len(descs[5])
+    ebi, ebd, esd = oracle.bf_top2(descs[4], np.concatenate([descs[o] for o in range(6) if o != 4]))
+    assert np.array_equal(bi[:len(descs[4])], ebi) and np.array_equal(bd[:len(descs[4])], ebd)
+    matcher.close()
+
+
 @pytest.mark.parametrize("n_per_cam,nq,th,seed", [([1000, 1000], 2000, 7.5, 1), ([2000], 3000, 4.0, 2), ([300, 200, 250], 900, 10.0, 3)])
 def test_project_best_equals_oracle(matcher, n_per_cam, nq, th, seed):
     """orbm_project_best: the independent nearest-candidate loop of SearchBySim3 (gate none) and Fuse (chi-square gate)."""

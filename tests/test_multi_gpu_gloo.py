@@ -49,8 +49,31 @@ def test_world_size_2_descriptor_exchange_matches_single_process():
 
 
 def test_shard_cameras_covers_every_camera_once():
+    import pytest
     from multi_orb_slam_amd.dist import shard_cameras
     for n in (1, 2, 4, 7, 8):
         for w in (1, 2, 4, 8):
-            owned = [c for r in range(w) for c in shard_cameras(n, w, r)]
+            if n % w:      # the exchange needs equal shards: a ragged rig is refused unless asked for explicitly
+                with pytest.raises(ValueError):
+                    shard_cameras(n, w, 0)
+            owned = [c for r in range(w) for c in shard_cameras(n, w, r, allow_ragged=True)]
             assert owned == list(range(n))
+            if n % w == 0:
+                assert all(len(shard_cameras(n, w, r)) == n // w for r in range(w))
+
+
+def test_unpack_refuses_a_corrupt_trailer():
+    import pytest
+    from multi_orb_slam_amd import synth
+    from multi_orb_slam_amd.dist import pack_export_block, unpack_gathered
+    cap = 64
+    a = pack_export_block([synth.descriptors(10, 1), synth.descriptors(20, 2)], cap)
+    b = pack_export_block([synth.descriptors(5, 3), synth.descriptors(7, 4)], cap)
+    got = unpack_gathered(np.concatenate([a, b]), 2, cap, 2)
+    assert [len(got[g]) for g in range(4)] == [10, 20, 5, 7]
+    b[cap * 32:cap * 32 + 4] = np.array([60], np.int32).view(np.uint8)     # 60 + 7 rows do not fit 64
+    with pytest.raises(ValueError):
+        unpack_gathered(np.concatenate([a, b]), 2, cap, 2)
+    b[cap * 32:cap * 32 + 4] = np.array([-3], np.int32).view(np.uint8)
+    with pytest.raises(ValueError):
+        unpack_gathered(np.concatenate([a, b]), 2, cap, 2)
