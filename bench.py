@@ -433,11 +433,9 @@ def main(argv=None):
         out["roofline_m1"] = top2_roofline(rt, m, fe.stream, a.matrix_n)
         out["roofline_m3"] = project_roofline(m)
     if rank == 0 and world == 1 and not a.no_dropin and a.config == 1:
-        try:
-            from multi_orb_slam_amd import dropin
-            out["dropin"] = dropin.bench(W, H, NFEAT)
-        except ImportError:
-            pass
+        import dropin_leg       # tests/dropin_leg.py: the C++ classes with the reference's signatures, reference call pattern
+        out["dropin"] = dropin_leg.bench(W, H, NFEAT)
+        out["dropin_fps"] = out["dropin"]["dropin_fps"]
     if rank == 0 and world == 1 and not a.no_cpu:
         from oracle_pipeline import OracleFrontEnd
 

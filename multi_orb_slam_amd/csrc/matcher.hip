@@ -692,6 +692,22 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------ host-built frames
+// orbm_frame_create: the host packs a frame's arrays back to back (dword granularity) into ONE staging block; this kernel
+// scatters them into the frame's own buffers.
+struct UnpackPlan { const uint32_t* src; uint32_t* dst[9]; int end[9]; };   // end[k] = first dword behind section k
+
+__global__ __launch_bounds__(256) void k_frame_unpack(UnpackPlan P) {
+    const int total = P.end[8];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k += (i >= P.end[j]);
+        const int base = k ? P.end[k - 1] : 0;
+        P.dst[k][i - base] = P.src[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ device frame build
 struct CamFeat {
     const orb_keypoint* kps; const uint4* desc; const float* depth;
@@ -1678,6 +1694,12 @@ struct orbm_matcher {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_q = nullptr;
     PinnedBuf<uint16_t> h_u16;
     PinnedBuf<uint8_t> h_ring;  // 4 slots of {CamFeat[64], int cam_start[65]} for asynchronous H2D
+    // Host-written staging of the host-array entry points (orbm_frame_create; the queries / occupied flags of a search): the
+    // host writes the packed arrays once (HBM through the large BAR, or mapped pinned memory), ONE kernel scatters a frame's
+    // arrays into its buffers -- instead of a pageable hipMemcpyAsync per array.
+    morb::StageBuf stage_f, stage_q;
+    hipEvent_t ev_stage_f = nullptr;   // the unpack kernel of the last orbm_frame_create has read stage_f
+    bool stage_f_busy = false;
     unsigned ring_pos = 0;
     std::vector<FrameBufs*> pool;  // free list
     // device-visible pinned destinations the next orbm_frame_from_device mirrors its merged arrays into (orbf_step)
@@ -1789,6 +1811,7 @@ int orbm_create(int device, orbm_matcher** out) {
     if (hipStreamCreateWithPriority(&m->side_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_q, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_stage_f, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
         morb::set_error("side stream / events could not be created");
         orbm_destroy(m);
@@ -1813,6 +1836,8 @@ void orbm_destroy(orbm_matcher* m) {
     m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release(); m->d_qmeta.release();
     m->d_match.release(); m->d_status.release(); m->d_gclaim.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
     m->h_i0.release(); m->h_i1.release(); m->h_i2.release(); m->h_match.release(); m->h_u16.release(); m->h_ring.release();
+    m->stage_f.release(); m->stage_q.release();
+    if (m->ev_stage_f) (void)hipEventDestroy(m->ev_stage_f);
     for (FrameBufs* b : m->pool) { b->release(); delete b; }
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
@@ -2031,27 +2056,38 @@ int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** ou
             if (cell_of[g] >= 0) F->items[cursor[cell_of[g]]++] = g;
     }
     F->host_valid = true;
-    // descriptors re-laid in global-index order so the kernel gathers with one index
-    std::vector<uint8_t> desc((size_t)std::max(n, 1) * 32);
-    for (int g = 0; g < n; g++) memcpy(&desc[(size_t)g * 32], f->desc[f->cam_of[g]] + (size_t)f->local_of[g] * 32, 32);
 
     F->b = take_bufs(m);
     int rc = reserve_frame(F->b, n, f->n_cams);
     if (rc) { orbm_frame_destroy(F); return rc; }
     hipStream_t st = m->stream;
+    // everything goes through ONE staging block: x, y, uright, angle, octave, items (n dwords each), descriptors re-laid in
+    // global-index order so the kernels gather with one index (8n dwords), cell starts, camera starts
     const size_t nn = (size_t)n;
-    if (n) {
-        MORB_HIP(hipMemcpyAsync(F->b->d_x.p, f->un_x, nn * 4, hipMemcpyHostToDevice, st));
-        MORB_HIP(hipMemcpyAsync(F->b->d_y.p, f->un_y, nn * 4, hipMemcpyHostToDevice, st));
-        MORB_HIP(hipMemcpyAsync(F->b->d_ur.p, f->uright, nn * 4, hipMemcpyHostToDevice, st));
-        MORB_HIP(hipMemcpyAsync(F->b->d_ang.p, f->angle, nn * 4, hipMemcpyHostToDevice, st));
-        MORB_HIP(hipMemcpyAsync(F->b->d_oct.p, f->octave, nn * 4, hipMemcpyHostToDevice, st));
-        MORB_HIP(hipMemcpyAsync(F->b->d_desc.p, desc.data(), nn * 32, hipMemcpyHostToDevice, st));
-        MORB_HIP(hipMemcpyAsync(F->b->d_items.p, F->items.data(), nn * 4, hipMemcpyHostToDevice, st));
-    }
-    MORB_HIP(hipMemcpyAsync(F->b->d_cell_start.p, F->cell_start.data(), (size_t)(ncell + 1) * 4, hipMemcpyHostToDevice, st));
-    MORB_HIP(hipMemcpyAsync(F->b->d_cam_start.p, F->cam_start.data(), (size_t)(f->n_cams + 1) * 4, hipMemcpyHostToDevice, st));
-    MORB_HIP(hipStreamSynchronize(st));  // `desc` and the caller's arrays may go away after return
+    const size_t words = 6 * nn + 8 * nn + (size_t)(ncell + 1) + (size_t)(f->n_cams + 1);
+    if (m->stage_f_busy) { MORB_HIP(hipEventSynchronize(m->ev_stage_f)); m->stage_f_busy = false; }   // (the previous frame's unpack)
+    if ((rc = m->stage_f.reserve(words * 4))) { orbm_frame_destroy(F); return rc; }
+    uint32_t* w = reinterpret_cast<uint32_t*>(m->stage_f.p);
+    UnpackPlan P;
+    P.src = reinterpret_cast<const uint32_t*>(m->stage_f.dp);
+    size_t pos = 0;
+    int sec = 0;
+    auto section = [&](const void* src, size_t dwords, void* dst) {
+        if (dwords && src) memcpy(w + pos, src, dwords * 4);
+        pos += dwords;
+        P.dst[sec] = static_cast<uint32_t*>(dst); P.end[sec] = (int)pos; ++sec;
+    };
+    section(f->un_x, nn, F->b->d_x.p); section(f->un_y, nn, F->b->d_y.p); section(f->uright, nn, F->b->d_ur.p);
+    section(f->angle, nn, F->b->d_ang.p); section(f->octave, nn, F->b->d_oct.p); section(F->items.data(), nn, F->b->d_items.p);
+    for (int g = 0; g < n; g++) memcpy(w + pos + (size_t)g * 8, f->desc[f->cam_of[g]] + (size_t)f->local_of[g] * 32, 32);
+    section(nullptr, 8 * nn, F->b->d_desc.p);
+    section(F->cell_start.data(), (size_t)(ncell + 1), F->b->d_cell_start.p);
+    section(F->cam_start.data(), (size_t)(f->n_cams + 1), F->b->d_cam_start.p);
+    m->stage_f.publish();
+    hipLaunchKernelGGL(k_frame_unpack, dim3((unsigned)std::min<size_t>((words + 255) / 256, 512)), dim3(256), 0, st, P);
+    MORB_HIP(hipGetLastError());
+    MORB_HIP(hipEventRecord(m->ev_stage_f, st));
+    m->stage_f_busy = true;   // nothing is waited for here: whatever uses the frame is ordered behind the unpack on the stream
     *out = F;
     return ORB_OK;
 }
@@ -2481,6 +2517,7 @@ struct SearchJob {
     bool pollable = false;              // single-workgroup resolve in flight with tagged result words (see k_resolve)
     bool want_tags = false; int seq = 0; // caller wants to watch the results arrive; sequence number of the launch in flight
     const orbm_query* q_dev = nullptr;  // device-visible alias of `q` when it lives in mapped pinned memory: read in place, no H2D
+    const uint8_t* occ_dev = nullptr;   // device-visible copy of `occupied` (staged by the caller): no H2D either
 };
 
 static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_device = false) {
@@ -2498,8 +2535,8 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
     if ((rc = m->d_choice.reserve(J.nq)) || (rc = m->d_claim.reserve((size_t)(2 * RESOLVE_K + 1) * J.nq)) || (rc = m->d_match.reserve(n)) ||
         (rc = m->d_status.reserve(4)) || (rc = m->h_match.reserve((size_t)n + 4)) || (rc = m->d_occ.reserve(std::max(n, 16))))
         return rc;
-    if (J.occupied) MORB_HIP(hipMemcpyAsync(m->d_occ.p, J.occupied, (size_t)n, hipMemcpyHostToDevice, m->stream));
-    const uint8_t* d_occ = J.occupied ? m->d_occ.p : nullptr;
+    if (J.occupied && !J.occ_dev) MORB_HIP(hipMemcpyAsync(m->d_occ.p, J.occupied, (size_t)n, hipMemcpyHostToDevice, m->stream));
+    const uint8_t* d_occ = J.occ_dev ? J.occ_dev : (J.occupied ? m->d_occ.p : nullptr);
     const orbm_frame* cur = J.cur;
     const int nq = J.nq, cap = J.cap, th_high = J.th_high;
     const float nnratio = J.nnratio;
@@ -2621,7 +2658,20 @@ static int search_common(orbm_matcher* m, const orbm_frame* cur, const orbm_quer
                          bool points, float nnratio, int th_high, int check_orientation, int32_t* match_of_feature,
                          int* nmatches) {
     SearchJob J{cur, q, nq, occupied, points, nnratio, th_high, check_orientation, 64, false};
-    int rc = search_enqueue(m, J);
+    int rc;
+    // The queries and the occupied flags go through host-written staging (HBM behind the large BAR, or mapped pinned memory)
+    // and are read in place by the kernels: no pageable hipMemcpyAsync on the call's critical path.  The staging stays
+    // untouched until this call has synchronised.
+    if (nq > 0 && cur->n_total > 0 && !m->host_resolve && nq <= RESOLVE_MAX_Q) {
+        const size_t qbytes = ((size_t)nq * sizeof(orbm_query) + 255) & ~(size_t)255, obytes = occupied ? (size_t)cur->n_total : 0;
+        if ((rc = m->stage_q.reserve(qbytes + obytes + 16))) return rc;
+        memcpy(m->stage_q.p, q, (size_t)nq * sizeof(orbm_query));
+        if (occupied) memcpy(m->stage_q.p + qbytes, occupied, obytes);
+        m->stage_q.publish();
+        J.q_dev = reinterpret_cast<const orbm_query*>(m->stage_q.dp);
+        J.occ_dev = occupied ? m->stage_q.dp + qbytes : nullptr;
+    }
+    rc = search_enqueue(m, J);
     if (rc) return rc;
     if (J.device_path) MORB_HIP(hipStreamSynchronize(m->stream));
     return search_finish(m, J, match_of_feature, nmatches);

@@ -43,6 +43,12 @@ public:
     static void ExtractBatch(const std::vector<ORBextractor*>& extractors, const std::vector<cv::Mat>& images,
                              std::vector<std::vector<cv::KeyPoint> >& keypoints, std::vector<cv::Mat>& descriptors);
 
+    // MI355X addition: there is no CPU fallback and the reference's signatures have no error channel, so a failed device
+    // call leaves the outputs untouched (as an empty image does) and is reported here.  Thread-local text of the last
+    // failure on the calling thread ("" if none) and the process-wide number of failed calls.
+    static const char* LastError();
+    static unsigned long FailureCount();
+
 protected:
     int nfeatures;
     double scaleFactor;
@@ -57,7 +63,7 @@ protected:
     std::vector<float> mvInvLevelSigma2;
 
 private:
-    void EnsureHandle(int width, int height);
+    bool EnsureHandle(int width, int height);
     orbx_extractor* handle_ = nullptr;
     int cap_w_ = 0, cap_h_ = 0;
     bool materialise_ = false;

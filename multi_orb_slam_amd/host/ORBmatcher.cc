@@ -2,6 +2,8 @@
 // into the caller's Frame the way the reference does.
 #include "ORBmatcher.h"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,25 +16,71 @@ const int ORBmatcher::TH_HIGH = 100;     // reference src/ORBmatcher.cc:37
 const int ORBmatcher::TH_LOW = 50;       // :38
 const int ORBmatcher::HISTO_LENGTH = 30; // :39
 
-static void die(const char* what, int rc) {
-    std::fprintf(stderr, "ORBmatcher: %s failed (%d): %s\n", what, rc, orb_last_error());
-    std::abort();
+// ---- error convention.  The reference's searches have no error channel: they return a match count.  A failed device call
+// (there is no CPU fallback) returns 0 matches from the search, leaves the caller's match containers as the reference's own
+// prologue leaves them, reports once on stderr and keeps the text for ORBmatcher::LastError().  Nothing aborts: the
+// classes are called from the tracking, local-mapping and loop-closing threads of a long-running process.
+static std::atomic<unsigned long> g_failures{0};
+static int fail(const char* what, int rc) {
+    g_failures.fetch_add(1, std::memory_order_relaxed);
+    std::fprintf(stderr, "ORBmatcher: %s failed (%d): %s -- search reports 0 matches\n", what, rc, orb_last_error());
+    return 0;
 }
+const char* ORBmatcher::LastError() { return orb_last_error(); }
+unsigned long ORBmatcher::FailureCount() { return g_failures.load(std::memory_order_relaxed); }
+
+// ---- per-thread device state.  The reference constructs an ORBmatcher on the stack for every use (src/Tracking.cc:1237,
+// src/LocalMapping.cc, src/LoopClosing.cc), from three threads.  A matcher handle owns a HIP stream, events and scratch
+// buffers: creating one per stack object costs milliseconds.  So the handle (and the BoW workspace, and a small cache of
+// uploaded frames) belongs to the THREAD: every ORBmatcher object of a thread shares them, threads never share
+// (re-entrant, per-thread stream + scratch).
+namespace {
+struct CachedFrame { uint64_t hash = 0; int n = -1; bool cam1 = false; orbm_frame* fr = nullptr; unsigned long stamp = 0; };
+struct ThreadState {
+    orbm_matcher* m = nullptr;
+    orbv_workspace* w = nullptr;
+    static constexpr int CACHE = 8;
+    CachedFrame cache[CACHE];
+    unsigned long clock = 0, hits = 0, misses = 0;
+    float last_us[3] = {0, 0, 0};   // host query building / frame (hash + upload) / device search of the last projection search
+    ~ThreadState() {
+        for (CachedFrame& c : cache) if (c.fr) orbm_frame_destroy(c.fr);
+        orbm_destroy(m);
+        orbv_workspace_destroy(w);
+    }
+};
+thread_local ThreadState tls;
+
+inline uint64_t mix(uint64_t h, uint64_t v) { h = (h ^ v) * 0x9E3779B97F4A7C15ull; return h ^ (h >> 29); }
+uint64_t hash_bytes(uint64_t h, const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t v; std::memcpy(&v, b + i, 8); h = mix(h, v); }
+    uint64_t tail = 0;
+    if (i < n) { std::memcpy(&tail, b + i, n - i); h = mix(h, tail ^ ((uint64_t)(n - i) << 56)); }
+    return h;
+}
+using clk = std::chrono::steady_clock;
+inline float us_since(clk::time_point a) { return std::chrono::duration<float, std::micro>(clk::now() - a).count(); }
+}  // namespace
 
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
     mRcam21 = cv::Mat(3, 3, CV_32F);
     mtcam21 = cv::Mat(3, 1, CV_32F);
 }
 
-ORBmatcher::~ORBmatcher() { orbm_destroy(handle_); orbv_workspace_destroy(bow_); }
+ORBmatcher::~ORBmatcher() {}   // (the device state belongs to the thread, not to the object)
+
+void ORBmatcher::LastCallBreakdown(float* us3) { for (int k = 0; k < 3; ++k) us3[k] = tls.last_us[k]; }
+void ORBmatcher::FrameCacheStats(unsigned long* hits, unsigned long* misses) { *hits = tls.hits; *misses = tls.misses; }
 
 orbv_workspace* ORBmatcher::Bow() {
-    if (!bow_) {
+    if (!tls.w) {
         const char* dev = std::getenv("MORB_DEVICE");
-        int rc = orbv_workspace_create(dev ? std::atoi(dev) : 0, &bow_);
-        if (rc) die("orbv_workspace_create", rc);
+        int rc = orbv_workspace_create(dev ? std::atoi(dev) : 0, &tls.w);
+        if (rc) { tls.w = nullptr; fail("orbv_workspace_create", rc); }
     }
-    return bow_;
+    return tls.w;
 }
 
 cv::Mat ORBmatcher::SkewSymmetricMatrix(const cv::Mat& v) {  // reference :4012-4017
@@ -44,12 +92,12 @@ cv::Mat ORBmatcher::SkewSymmetricMatrix(const cv::Mat& v) {  // reference :4012-
 }
 
 orbm_matcher* ORBmatcher::Handle() {
-    if (!handle_) {
+    if (!tls.m) {
         const char* dev = std::getenv("MORB_DEVICE");
-        int rc = orbm_create(dev ? std::atoi(dev) : 0, &handle_);
-        if (rc) die("orbm_create", rc);
+        int rc = orbm_create(dev ? std::atoi(dev) : 0, &tls.m);
+        if (rc) { tls.m = nullptr; fail("orbm_create", rc); }
     }
-    return handle_;
+    return tls.m;
 }
 
 int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
@@ -90,17 +138,31 @@ struct FlatFrame {  // orbm_frame_desc backing store built from a Frame
     orbm_frame_desc d;
 };
 
+// The reference keeps global index -> camera / local index in std::map<size_t,int> (include/Frame.h): read with one ordered
+// walk (keys 0 .. n-1 in order is what Frame::Frame builds, src/Frame.cc:221-239), falling back to find() for anything else.
+struct MapWalk {
+    const std::map<size_t, int>& m; std::map<size_t, int>::const_iterator it;
+    explicit MapWalk(const std::map<size_t, int>& mm) : m(mm), it(mm.begin()) {}
+    int at(size_t g) {
+        if (it != m.end() && it->first == g) { const int v = it->second; ++it; return v; }
+        auto f = m.find(g);
+        if (f == m.end()) return -1;
+        it = f; const int v = it->second; ++it; return v;
+    }
+};
+
 template <class FrameOrKeyFrame>
 void flatten(const FrameOrKeyFrame& F, bool cam1_only, FlatFrame& ff) {
     const int n = cam1_only ? F.N : F.N_total;
     ff.x.resize(n); ff.y.resize(n); ff.ang.resize(n); ff.ur.resize(n); ff.oct.resize(n); ff.cam.resize(n); ff.loc.resize(n);
     const std::vector<cv::KeyPoint>& kun = cam1_only ? F.mvKeysUn : F.mvKeysUn_total;
     const std::vector<float>& ur = cam1_only ? F.mvuRight : F.mvuRight_total;
+    MapWalk cams(F.keypoint_to_cam), locs(F.cont_idx_to_local_cam_idx);
     for (int g = 0; g < n; ++g) {
         ff.x[g] = kun[g].pt.x; ff.y[g] = kun[g].pt.y; ff.ang[g] = kun[g].angle; ff.oct[g] = kun[g].octave;
         ff.ur[g] = ur[g];
-        ff.cam[g] = cam1_only ? 0 : F.keypoint_to_cam.find(g)->second;
-        ff.loc[g] = cam1_only ? g : F.cont_idx_to_local_cam_idx.find(g)->second;
+        ff.cam[g] = cam1_only ? 0 : cams.at(g);
+        ff.loc[g] = cam1_only ? g : locs.at(g);
     }
     ff.desc.clear();
     if (cam1_only) ff.desc.push_back(F.mDescriptors.ptr(0));
@@ -109,6 +171,48 @@ void flatten(const FrameOrKeyFrame& F, bool cam1_only, FlatFrame& ff) {
     ff.d.un_x = ff.x.data(); ff.d.un_y = ff.y.data(); ff.d.octave = ff.oct.data(); ff.d.angle = ff.ang.data();
     ff.d.uright = ff.ur.data(); ff.d.cam_of = ff.cam.data(); ff.d.local_of = ff.loc.data(); ff.d.desc = ff.desc.data();
     ff.d.min_x = F.mnMinX; ff.d.min_y = F.mnMinY; ff.d.max_x = F.mnMaxX; ff.d.max_y = F.mnMaxY;
+}
+
+// The matcher-side view of a Frame / KeyFrame (positions, octaves, angles, right coordinates, descriptors, 64x48 grid) in
+// HBM.  A Frame's features never change after construction, and the same frame is searched several times (TrackWithMotionModel
+// retries with 2*th, TrackLocalMap searches the same frame again, keyframes are fused into and searched for as long as they
+// live), so uploaded frames are cached per thread under a 64-bit hash of EVERYTHING the upload reads: a frame whose content
+// changed is simply a different key.  Least recently used of 8 entries is dropped.  Returns NULL after a reported failure.
+template <class FrameOrKeyFrame>
+orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_only) {
+    if (!m) return nullptr;
+    const int n = cam1_only ? F.N : F.N_total;
+    const std::vector<cv::KeyPoint>& kun = cam1_only ? F.mvKeysUn : F.mvKeysUn_total;
+    const std::vector<float>& ur = cam1_only ? F.mvuRight : F.mvuRight_total;
+    if ((int)kun.size() < n || (int)ur.size() < n) { fail("device_frame (Frame arrays shorter than N)", ORB_E_ARG); return nullptr; }
+    uint64_t h = mix(0x243F6A8885A308D3ull, (uint64_t)n * 2 + (cam1_only ? 1 : 0));
+    h = hash_bytes(h, kun.data(), (size_t)n * sizeof(cv::KeyPoint));
+    h = hash_bytes(h, ur.data(), (size_t)n * sizeof(float));
+    const float bounds[4] = {F.mnMinX, F.mnMinY, F.mnMaxX, F.mnMaxY};
+    h = hash_bytes(h, bounds, sizeof(bounds));
+    if (cam1_only) h = hash_bytes(h, F.mDescriptors.ptr(0), (size_t)n * 32);
+    else {
+        for (const cv::Mat& d : F.mDescriptors_total) { h = mix(h, (uint64_t)d.rows); if (!d.empty()) h = hash_bytes(h, d.ptr(0), (size_t)d.rows * 32); }
+        for (const auto& e : F.keypoint_to_cam) h = mix(h, (uint64_t)e.first * 8 + (uint64_t)(e.second & 7));
+        for (const auto& e : F.cont_idx_to_local_cam_idx) h = mix(h, ((uint64_t)e.first << 24) ^ (uint64_t)(uint32_t)e.second);
+    }
+    ThreadState& T = tls;
+    ++T.clock;
+    CachedFrame* victim = &T.cache[0];
+    for (CachedFrame& c : T.cache) {
+        if (c.fr && c.hash == h && c.n == n && c.cam1 == cam1_only) { c.stamp = T.clock; ++T.hits; return c.fr; }
+        if (!c.fr) { if (victim->fr) victim = &c; }
+        else if (victim->fr && c.stamp < victim->stamp) victim = &c;
+    }
+    ++T.misses;
+    FlatFrame ff;
+    flatten(F, cam1_only, ff);
+    orbm_frame* fr = nullptr;
+    const int rc = orbm_frame_create(m, &ff.d, &fr);
+    if (rc) { fail("orbm_frame_create", rc); return nullptr; }
+    if (victim->fr) orbm_frame_destroy(victim->fr);
+    victim->hash = h; victim->n = n; victim->cam1 = cam1_only; victim->fr = fr; victim->stamp = T.clock;
+    return fr;
 }
 
 struct FlatSide {  // orbv_side backing store built from a Frame / KeyFrame
@@ -167,7 +271,7 @@ int ORBmatcher::SearchByBoW_cam1(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>
     std::vector<int32_t> match(F.N > 0 ? F.N : 1);
     int nmatches = 0;
     const int rc = orbv_search_by_bow(Bow(), &a.s, &b.s, 0, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
-    if (rc) die("orbv_search_by_bow", rc);
+    if (rc) return fail("orbv_search_by_bow", rc);
     for (int g = 0; g < F.N; ++g)
         if (match[g] >= 0) vpMapPointMatches[g] = vpMapPointsKF[match[g]];
     return nmatches;
@@ -186,7 +290,7 @@ int ORBmatcher::SearchByBoW_cam1(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<Map
     std::vector<int32_t> match(pKF1->N > 0 ? pKF1->N : 1);
     int nmatches = 0;
     const int rc = orbv_search_by_bow(Bow(), &a.s, &b.s, 1, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
-    if (rc) die("orbv_search_by_bow", rc);
+    if (rc) return fail("orbv_search_by_bow", rc);
     for (int i = 0; i < pKF1->N; ++i)
         if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]];
     return nmatches;
@@ -233,18 +337,15 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std
         q.push_back(Q); qmp.push_back(pMP); qsrc.push_back((int)i);
     }
     dump_queries(q, qsrc);
-    FlatFrame ff;
-    flatten(CurrentFrame, /*cam1_only=*/true, ff);
+    orbm_frame* fr = device_frame(Handle(), CurrentFrame, true);
+    if (!fr) return 0;
     std::vector<uint8_t> occupied(CurrentFrame.N > 0 ? CurrentFrame.N : 1, 0);
     for (int g = 0; g < CurrentFrame.N; ++g) occupied[g] = CurrentFrame.mvpMapPoints[g] ? 1 : 0;   // :3881
-    orbm_frame* fr = nullptr;
-    int rc = orbm_frame_create(Handle(), &ff.d, &fr);
-    if (rc) die("orbm_frame_create", rc);
+    int rc;
     std::vector<int32_t> match(occupied.size());
     int nmatches = 0;
     rc = orbm_search_by_projection(Handle(), fr, q.data(), (int)q.size(), occupied.data(), ORBdist, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
-    orbm_frame_destroy(fr);
-    if (rc) die("orbm_search_by_projection", rc);
+    if (rc) return fail("orbm_search_by_projection", rc);
     for (int g = 0; g < CurrentFrame.N; ++g) {
         if (match[g] >= 0) CurrentFrame.mvpMapPoints[g] = qmp[match[g]];
         else if (match[g] == -2) CurrentFrame.mvpMapPoints[g] = NULL;   // :3936
@@ -296,57 +397,71 @@ int ORBmatcher::SearchByProjection_cam1(KeyFrame* pKF, cv::Mat Scw, const std::v
         q.push_back(Q); qmp.push_back(pMP); qsrc.push_back(iMP);
     }
     dump_queries(q, qsrc);
-    FlatFrame ff;
-    flatten(*pKF, /*cam1_only=*/true, ff);
+    orbm_frame* fr = device_frame(Handle(), *pKF, true);
+    if (!fr) return 0;
     std::vector<uint8_t> occupied(pKF->N > 0 ? pKF->N : 1, 0);
     for (int g = 0; g < pKF->N; ++g) occupied[g] = vpMatched[g] ? 1 : 0;    // :829
-    orbm_frame* fr = nullptr;
-    int rc = orbm_frame_create(Handle(), &ff.d, &fr);
-    if (rc) die("orbm_frame_create", rc);
+    int rc;
     std::vector<int32_t> match(occupied.size());
     int nmatches = 0;
     rc = orbm_search_by_projection(Handle(), fr, q.data(), (int)q.size(), occupied.data(), TH_LOW, 0, match.data(), &nmatches);
-    orbm_frame_destroy(fr);
-    if (rc) die("orbm_search_by_projection", rc);
+    if (rc) return fail("orbm_search_by_projection", rc);
     for (int g = 0; g < pKF->N; ++g)
         if (match[g] >= 0) vpMatched[g] = qmp[match[g]];
     return nmatches;
 }
 
-// reference src/ORBmatcher.cc:3137-3447: each keyframe's map points projected into the other one through the Sim3, nearest
-// descriptor per point on its own (orbm_project_best), then the mutual-agreement check
-int ORBmatcher::SearchBySim3_cam1(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
-                                  const cv::Mat& t12, const float th) {
+// reference src/ORBmatcher.cc:3137-3447 (camera 1 only; what LoopClosing::ComputeSim3 calls, src/LoopClosing.cc:444) and
+// :2814-3135 (both cameras: a point is searched in the grid of the camera it was observed in, after the cam2 <- cam1
+// extrinsics of the 4x3 calibration matrix).  Each keyframe's map points are projected into the other one through the Sim3,
+// every point takes the nearest descriptor of its window on its own (orbm_project_best), then the mutual-agreement check.
+static int sim3_search(ORBmatcher& self, orbm_matcher* handle, KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12,
+                       const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th, const cv::Mat* CalibMatrix) {
+    const bool two_cam = CalibMatrix != nullptr;
     const float& fx = pKF1->fx; const float& fy = pKF1->fy; const float& cx = pKF1->cx; const float& cy = pKF1->cy;
+    cv::Mat Rcam21, tcam21;
+    if (two_cam) {   // :2826-2836
+        const cv::Mat Rcam12 = CalibMatrix->rowRange(0, 3).colRange(0, 3);
+        cv::Mat tcam12(3, 1, CV_32F);
+        tcam12.at<float>(0, 0) = CalibMatrix->at<float>(3, 0);
+        tcam12.at<float>(1, 0) = CalibMatrix->at<float>(3, 1);
+        tcam12.at<float>(2, 0) = CalibMatrix->at<float>(3, 2);
+        Rcam21 = Rcam12.inv();
+        tcam21 = -Rcam21 * tcam12;
+    }
     cv::Mat R1w = pKF1->GetRotation(), t1w = pKF1->GetTranslation(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
     cv::Mat sR12 = s12 * R12;
     cv::Mat sR21 = (1.0 / s12) * R12.t();
     cv::Mat t21 = -sR21 * t12;
-    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches_cam1();
+    const std::vector<MapPoint*> vpMapPoints1 = two_cam ? pKF1->GetMapPointMatches() : pKF1->GetMapPointMatches_cam1();
     const int N1 = (int)vpMapPoints1.size();
-    const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches_cam1();
+    const std::vector<MapPoint*> vpMapPoints2 = two_cam ? pKF2->GetMapPointMatches() : pKF2->GetMapPointMatches_cam1();
     const int N2 = (int)vpMapPoints2.size();
     std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
     for (int i = 0; i < N1; i++) {
         MapPoint* pMP = vpMatches12[i];
         if (pMP) {
             vbAlreadyMatched1[i] = true;
-            int idx2 = pMP->GetIndexInKeyFrame_cam1(pKF2);
+            int idx2 = two_cam ? pMP->GetIndexInKeyFrame(pKF2) : pMP->GetIndexInKeyFrame_cam1(pKF2);
             if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
         }
     }
     std::vector<int> vnMatch1(N1, -1), vnMatch2(N2, -1);
+    bool failed = false;
     // one direction: map points of `from` into `to`
-    auto direction = [&](KeyFrame* to, const std::vector<MapPoint*>& pts, const std::vector<bool>& already, const cv::Mat& Rw, const cv::Mat& tw,
-                         const cv::Mat& sR, const cv::Mat& t, std::vector<int>& out) {
+    auto direction = [&](KeyFrame* from, KeyFrame* to, const std::vector<MapPoint*>& pts, const std::vector<bool>& already, const cv::Mat& Rw,
+                         const cv::Mat& tw, const cv::Mat& sR, const cv::Mat& t, std::vector<int>& out) {
         std::vector<orbm_query> q; std::vector<int> src;
+        MapWalk cams(from->keypoint_to_cam);
         for (int i = 0; i < (int)pts.size(); i++) {
             MapPoint* pMP = pts[i];
             if (!pMP || already[i]) continue;
             if (pMP->isBad()) continue;
+            const int camIdx = two_cam ? cams.at((size_t)i) : 0;   // the camera the point was observed in (:2893, :2995)
             cv::Mat p3Dw = pMP->GetWorldPos();
             cv::Mat p3Da = Rw * p3Dw + tw;
             cv::Mat p3Db = sR * p3Da + t;
+            if (camIdx == 1) p3Db = Rcam21 * p3Db + tcam21;
             if (p3Db.at<float>(2) < 0.0) continue;
             const float invz = 1.0 / p3Db.at<float>(2);
             const float x = p3Db.at<float>(0) * invz;
@@ -363,27 +478,24 @@ int ORBmatcher::SearchBySim3_cam1(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<Ma
             orbm_query Q;
             Q.u = u; Q.v = v; Q.radius = radius; Q.ur = std::nanf("");
             Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;
-            Q.cam = 0; Q.blocks = 0; Q.angle = 0;
+            Q.cam = camIdx; Q.blocks = 0; Q.angle = 0;
             const cv::Mat dMP = pMP->GetDescriptor();
             std::memcpy(Q.desc, dMP.ptr(0), 32);
             q.push_back(Q); src.push_back(i);
         }
         dump_queries(q, src);
-        if (q.empty()) return;
-        FlatFrame ff;
-        flatten(*to, /*cam1_only=*/true, ff);
-        orbm_frame* fr = nullptr;
-        int rc = orbm_frame_create(Handle(), &ff.d, &fr);
-        if (rc) die("orbm_frame_create", rc);
+        if (q.empty() || failed) return;
+        orbm_frame* fr = device_frame(handle, *to, /*cam1_only=*/!two_cam);
+        if (!fr) { failed = true; return; }
         std::vector<int32_t> bi(q.size()), bd(q.size());
-        rc = orbm_project_best(Handle(), fr, q.data(), (int)q.size(), nullptr, ORBM_GATE_NONE, nullptr, 0, bi.data(), bd.data());
-        orbm_frame_destroy(fr);
-        if (rc) die("orbm_project_best", rc);
+        const int rc = orbm_project_best(handle, fr, q.data(), (int)q.size(), nullptr, ORBM_GATE_NONE, nullptr, 0, bi.data(), bd.data());
+        if (rc) { fail("orbm_project_best", rc); failed = true; return; }
         for (size_t k = 0; k < q.size(); ++k)
-            if (bi[k] >= 0 && bd[k] <= TH_HIGH) out[src[k]] = bi[k];
+            if (bi[k] >= 0 && bd[k] <= ORBmatcher::TH_HIGH) out[src[k]] = bi[k];
     };
-    direction(pKF2, vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, vnMatch1);   // :3208-3302
-    direction(pKF1, vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, vnMatch2);   // :3306-3403
+    direction(pKF1, pKF2, vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, vnMatch1);   // :3208-3302 | :2877-2974
+    direction(pKF2, pKF1, vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, vnMatch2);   // :3306-3403 | :2978-3080
+    if (failed) return 0;
     int nFound = 0;
     for (int i1 = 0; i1 < N1; i1++) {
         int idx2 = vnMatch1[i1];
@@ -393,6 +505,16 @@ int ORBmatcher::SearchBySim3_cam1(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<Ma
         }
     }
     return nFound;
+}
+
+int ORBmatcher::SearchBySim3_cam1(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
+                                  const cv::Mat& t12, const float th) {
+    return sim3_search(*this, Handle(), pKF1, pKF2, vpMatches12, s12, R12, t12, th, nullptr);
+}
+
+int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
+                             const cv::Mat& t12, const float th, const cv::Mat CalibMatrix) {
+    return sim3_search(*this, Handle(), pKF1, pKF2, vpMatches12, s12, R12, t12, th, &CalibMatrix);
 }
 
 // reference src/ORBmatcher.cc:1986-2210: every map point projected into both cameras of the keyframe, nearest descriptor
@@ -450,15 +572,12 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
     dump_queries(q, src);
     std::vector<int32_t> bi(q.size() ? q.size() : 1, -1), bd(q.size() ? q.size() : 1, 256);
     if (!q.empty()) {
-        FlatFrame ff;
-        flatten(*pKF, /*cam1_only=*/false, ff);
-        orbm_frame* fr = nullptr;
-        int rc = orbm_frame_create(Handle(), &ff.d, &fr);
-        if (rc) die("orbm_frame_create", rc);
+        orbm_frame* fr = device_frame(Handle(), *pKF, false);
+        if (!fr) return 0;
+        int rc;
         rc = orbm_project_best(Handle(), fr, q.data(), (int)q.size(), nullptr, ORBM_GATE_CHI2, pKF->mvInvLevelSigma2.data(),
                                (int)pKF->mvInvLevelSigma2.size(), bi.data(), bd.data());
-        orbm_frame_destroy(fr);
-        if (rc) die("orbm_project_best", rc);
+        if (rc) return fail("orbm_project_best", rc);
     }
     // merge pass in the reference's order: point by point, camera 1 then camera 2 (:2165-2195)
     int nFused = 0;
@@ -543,14 +662,11 @@ int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& v
     dump_queries(q, src);
     std::vector<int32_t> bi(q.size() ? q.size() : 1, -1), bd(q.size() ? q.size() : 1, 256);
     if (!q.empty()) {
-        FlatFrame ff;
-        flatten(*pKF, /*cam1_only=*/false, ff);
-        orbm_frame* fr = nullptr;
-        int rc = orbm_frame_create(Handle(), &ff.d, &fr);
-        if (rc) die("orbm_frame_create", rc);
+        orbm_frame* fr = device_frame(Handle(), *pKF, false);
+        if (!fr) return 0;
+        int rc;
         rc = orbm_project_best(Handle(), fr, q.data(), (int)q.size(), nullptr, ORBM_GATE_NONE, nullptr, 0, bi.data(), bd.data());
-        orbm_frame_destroy(fr);
-        if (rc) die("orbm_project_best", rc);
+        if (rc) return fail("orbm_project_best", rc);
     }
     int nFused = 0;
     for (size_t f = 0; f < q.size(); ++f) {            // point by point, camera 1 then camera 2 (:2484-2506)
@@ -581,7 +697,7 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpM
     std::vector<int32_t> match(F.N_total > 0 ? F.N_total : 1);
     int nmatches = 0;
     const int rc = orbv_search_by_bow(Bow(), &a.s, &b.s, 0, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
-    if (rc) die("orbv_search_by_bow", rc);
+    if (rc) return fail("orbv_search_by_bow", rc);
     for (int g = 0; g < F.N_total; ++g)
         if (match[g] >= 0) vpMapPointMatches[g] = vpMapPointsKF[match[g]];
     return nmatches;
@@ -600,7 +716,7 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint
     std::vector<int32_t> match(vpMapPoints1.empty() ? 1 : vpMapPoints1.size());
     int nmatches = 0;
     const int rc = orbv_search_by_bow(Bow(), &a.s, &b.s, 1, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
-    if (rc) die("orbv_search_by_bow", rc);
+    if (rc) return fail("orbv_search_by_bow", rc);
     for (size_t i = 0; i < vpMapPoints1.size(); ++i)
         if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]];
     return nmatches;
@@ -647,7 +763,7 @@ int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F
     std::vector<int32_t> match(n1 > 0 ? n1 : 1);
     int nmatches = 0;
     const int rc = orbv_search_for_triangulation(Bow(), &a.s, &b.s, &T, TH_LOW, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
-    if (rc) die("orbv_search_for_triangulation", rc);
+    if (rc) return fail("orbv_search_for_triangulation", rc);
     vMatchedPairs.clear();
     vMatchedPairs.reserve(nmatches);
     for (int i = 0; i < n1; ++i)
@@ -680,20 +796,17 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
         std::memcpy(Q.desc, d.ptr(0), 32);
         q.push_back(Q); qmp.push_back(pMP);
     }
-    FlatFrame ff;
-    flatten(F, /*cam1_only=*/true, ff);
+    orbm_frame* fr = device_frame(Handle(), F, true);
+    if (!fr) return 0;
     std::vector<uint8_t> occupied(F.N, 0);
     for (int g = 0; g < F.N; ++g)
         occupied[g] = (F.mvpMapPoints[g] && F.mvpMapPoints[g]->Observations() > 0) ? 1 : 0;  // :107-109
-    orbm_frame* fr = nullptr;
-    int rc = orbm_frame_create(Handle(), &ff.d, &fr);
-    if (rc) die("orbm_frame_create", rc);
+    int rc;
     std::vector<int32_t> match(F.N > 0 ? F.N : 1);
     int nmatches = 0;
     rc = orbm_search_by_projection_points(Handle(), fr, q.data(), (int)q.size(), occupied.data(), mfNNratio, TH_HIGH,
                                           match.data(), &nmatches);
-    orbm_frame_destroy(fr);
-    if (rc) die("orbm_search_by_projection_points", rc);
+    if (rc) return fail("orbm_search_by_projection_points", rc);
     for (int g = 0; g < F.N; ++g)
         if (match[g] >= 0) F.mvpMapPoints[g] = qmp[match[g]];
     return nmatches;
@@ -702,6 +815,7 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
 // reference src/ORBmatcher.cc:3448-3641
 int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono,
                                    cv::Mat CalibMatrix) {
+    const clk::time_point t_entry = clk::now();
     // cam2 <- cam1 extrinsics from the 4x3 calibration matrix (:3463-3471)
     cv::Mat Rcam12 = CalibMatrix.rowRange(0, 3).colRange(0, 3);
     cv::Mat tcam12(3, 1, CV_32F);
@@ -759,20 +873,25 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
         q.push_back(Q); qmp.push_back(pMP);
     }
 
-    FlatFrame ff;
-    flatten(CurrentFrame, /*cam1_only=*/false, ff);
-    orbm_frame* fr = nullptr;
-    int rc = orbm_frame_create(Handle(), &ff.d, &fr);
-    if (rc) die("orbm_frame_create", rc);
+    tls.last_us[0] = us_since(t_entry);
+    const clk::time_point t_frame = clk::now();
+    orbm_frame* fr = device_frame(Handle(), CurrentFrame, false);
+    if (!fr) return 0;
+    tls.last_us[1] = us_since(t_frame);
+    const clk::time_point t_search = clk::now();
+    int rc;
     std::vector<int32_t> match(CurrentFrame.N_total > 0 ? CurrentFrame.N_total : 1);
     int nmatches = 0;
     std::vector<uint8_t> occupied(match.size(), 0);  // :3566-3568 also skips points that were there before the call
-    for (int g = 0; g < CurrentFrame.N_total; ++g)
+    bool any_occupied = false;                       // (none in TrackWithMotionModel: it clears the vector first, Tracking.cc:1254)
+    for (int g = 0; g < CurrentFrame.N_total; ++g) {
         occupied[g] = (CurrentFrame.mvpMapPoints[g] && CurrentFrame.mvpMapPoints[g]->Observations() > 0) ? 1 : 0;
-    rc = orbm_search_by_projection(Handle(), fr, q.data(), (int)q.size(), occupied.data(), TH_HIGH,
+        any_occupied |= occupied[g] != 0;
+    }
+    rc = orbm_search_by_projection(Handle(), fr, q.data(), (int)q.size(), any_occupied ? occupied.data() : nullptr, TH_HIGH,
                                    mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
-    orbm_frame_destroy(fr);
-    if (rc) die("orbm_search_by_projection", rc);
+    if (rc) return fail("orbm_search_by_projection", rc);
+    tls.last_us[2] = us_since(t_search);
     // The reference starts from whatever CurrentFrame.mvpMapPoints holds (all NULL in TrackWithMotionModel,
     // src/Tracking.cc:1254) and only ever writes accepted matches / NULLs for histogram rejects.
     for (int g = 0; g < CurrentFrame.N_total; ++g) {

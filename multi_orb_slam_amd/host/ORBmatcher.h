@@ -4,8 +4,8 @@
 // the public constants and the public mRcam21 / mtcam21 scratch.  Candidate gathering and Hamming distances run in libmorb.so's HIP kernels
 // (include/orbm.h); the 3-D projection of map points and the order-dependent accept/overwrite/histogram logic stay on
 // the host exactly where the reference has them; the BoW-gated searches run whole on the device (include/orbv.h).  Of
-// the remaining overloads the two-camera loop SearchByProjection, the two-camera SearchBySim3 (the
-// reference's threads call the _cam1 forms) and SearchForInitialization are not part of this round (same device primitives, different host loops).
+// the remaining overloads are here as well: the two-camera loop SearchByProjection, the two-camera SearchBySim3
+// and SearchForInitialization (the reference's threads call the _cam1 forms; same device primitives, different host loops).
 // MORB_DUMP_QUERIES=<file>: every projection search appends the queries it built (int32 count + orbm_query records), so a
 // test can hold the device result against the oracle on exactly those queries.
 #ifndef ORBMATCHER_H
@@ -52,6 +52,9 @@ public:
     // In the stereo and RGB-D case, s12=1
     int SearchBySim3_cam1(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
                           const cv::Mat& t12, const float th);
+    // Both cameras of the rig: every point is searched in the grid of the camera it was observed in (reference :2814-3135)
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
+                     const cv::Mat& t12, const float th, const cv::Mat CalibMatrix);
 
     // Project MapPoints into KeyFrame and search for duplicated MapPoints.
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const cv::Mat CalibMatrix, const float th = 3.0);
@@ -88,10 +91,23 @@ protected:
     float mfNNratio;
     bool mbCheckOrientation;
 
+public:
+    // MI355X additions.  There is no CPU fallback and the reference's signatures have no error channel: a failed device call
+    // makes the search return 0 matches (the caller's containers are left as the reference's own prologue leaves them), is
+    // reported once on stderr and kept here.  Thread-local text of the last failure on the calling thread / process-wide count.
+    static const char* LastError();
+    static unsigned long FailureCount();
+    // inspection: host microseconds of the calling thread's last SearchByProjection(Frame&, const Frame&, ...) call spent
+    // {projecting the points (the reference's cv::Mat algebra), hashing + uploading the frame, searching on the device},
+    // and the hit / miss counts of the calling thread's cache of uploaded frames
+    static void LastCallBreakdown(float* us3);
+    static void FrameCacheStats(unsigned long* hits, unsigned long* misses);
+
 private:
-    orbm_matcher* handle_ = nullptr;  // created on first GPU use; one per ORBmatcher (stack object, as in the reference)
+    // The device state (matcher handle with its stream and scratch, BoW workspace, cache of uploaded frames) belongs to the
+    // calling THREAD, created on its first GPU use and shared by every ORBmatcher object of that thread: the reference
+    // constructs an ORBmatcher on the stack for each use, from three threads.
     orbm_matcher* Handle();
-    orbv_workspace* bow_ = nullptr;   // stream + scratch of the BoW-gated searches, created on first use
     orbv_workspace* Bow();
 };
 

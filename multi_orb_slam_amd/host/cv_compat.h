@@ -1,6 +1,6 @@
 // cv_compat.h -- the handful of OpenCV types the ORB front end's public signatures mention, for builds without OpenCV
 // (this image has none).  Define HAVE_OPENCV to use the real headers instead; the wrappers only rely on members that
-// exist in both.  cv::KeyPoint is byte-compatible with orb_keypoint (28 bytes), which the wrappers static_assert.
+// exist in both (cv::InputArray / cv::OutputArray are proxy classes here as they are there: getMat(), create(), release()).  cv::KeyPoint is byte-compatible with orb_keypoint (28 bytes), which the wrappers static_assert.
 #pragma once
 #ifdef HAVE_OPENCV
 #include <opencv2/core/core.hpp>
@@ -158,8 +158,29 @@ inline double norm(const Mat& a) {
     return std::sqrt(s);
 }
 
-typedef const Mat& InputArray;
-typedef Mat& OutputArray;
+// Proxy argument types with the members of OpenCV's own cv::_InputArray / cv::_OutputArray that the wrappers use (getMat,
+// empty, create, release): the same wrapper source compiles against these stand-ins and against the real headers.
+class _InputArray {
+public:
+    _InputArray() {}
+    _InputArray(const Mat& m) : m_(&m) {}
+    Mat getMat() const { return m_ ? *m_ : Mat(); }   // a header sharing the caller's pixels, as in OpenCV
+    bool empty() const { return !m_ || m_->empty(); }
+private:
+    const Mat* m_ = nullptr;
+};
+class _OutputArray {
+public:
+    _OutputArray(Mat& m) : m_(&m) {}
+    void create(int rows, int cols, int type) const { m_->create(rows, cols, type); }
+    void release() const { m_->release(); }
+    Mat getMat() const { return *m_; }
+    bool empty() const { return m_->empty(); }
+private:
+    Mat* m_;
+};
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
 
 }  // namespace cv
 #endif

@@ -44,6 +44,7 @@ public:
         return nScale;
     }
     bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }
+    int GetIndexInKeyFrame(KeyFrame* pKF) { auto it = mObservations.find(pKF); return it != mObservations.end() ? (int)it->second : -1; }
     int GetIndexInKeyFrame_cam1(KeyFrame* pKF) { auto it = mObservations.find(pKF); return it != mObservations.end() ? (int)it->second : -1; }
     void AddObservation(KeyFrame* pKF, size_t idx) { if (mObservations.count(pKF)) return; mObservations[pKF] = idx; nObs++; }
     void Replace(MapPoint* pMP) { if (pMP == this) return; mpReplaced = pMP; mbBad = true; }

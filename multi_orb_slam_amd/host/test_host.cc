@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <vector>
@@ -397,6 +398,150 @@ static int run_f4(int argc, char** argv) {
     return 0;
 }
 
+// dropin <stream.bin> <out.bin> <batch 0|1>
+// The reference's per-frame call pattern on its tracking thread, timed: Frame::Frame runs the two extractors back to back
+// (reference src/Frame.cc:182,185), merges their outputs (:191-239) and fills mvuRight / mvDepth from the depth image
+// (:959-986); TrackWithMotionModel then constructs an ORBmatcher on the stack and searches the last frame's points in the
+// new frame (reference src/Tracking.cc:1254-1267).  batch = 1 replaces the two operator() calls by ONE ExtractBatch call (the
+// integration INTEGRATION.md recommends).  The Frame assembly in between is the reference's own host code and is timed
+// separately (it is not part of the accelerated path).
+// stream.bin: int32 {w, h, nf0, nf1, T, iters, warmup}; float32 {fx, fy, cx, cy, mbf, th, du, dv}; T x 2 images (w*h u8);
+//             2 depth images (w*h f32).
+// out.bin: float32 medians {extract0, extract1, frame_host, search, class_calls_total, loop_total, search: host projection,
+//          search: frame hash + upload, search: device} in us + {frame-cache hits, misses, failed calls}, then the per-step
+//          class-call times (iters f32), then for the last step: both cameras' keypoints + descriptors, nmatches, per current
+//          feature the index of the last-frame feature whose point it received (-1 none), then the last frame: N_total,
+//          world points (3 f32 each), has-point flags, octaves, angles, descriptors, cameras.
+#include <algorithm>
+#include <chrono>
+static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0 : v[v.size() / 2]; }
+
+static int run_dropin(int argc, char** argv) {
+    std::vector<unsigned char> buf = slurp(argv[2]);
+    Reader R{buf.data()};
+    const int w = R.get<int>(), h = R.get<int>(), nf0 = R.get<int>(), nf1 = R.get<int>(), T = R.get<int>(), iters = R.get<int>(),
+              warmup = R.get<int>();
+    const float fx = R.get<float>(), fy = R.get<float>(), cx = R.get<float>(), cy = R.get<float>(), mbf = R.get<float>(),
+                th = R.get<float>(), du = R.get<float>(), dv = R.get<float>();
+    const bool batch = std::atoi(argv[4]) != 0;
+    std::vector<std::vector<unsigned char> > img(2 * T);
+    for (int i = 0; i < 2 * T; ++i) img[i] = R.arr<unsigned char>((size_t)w * h);
+    std::vector<float> depth[2] = {R.arr<float>((size_t)w * h), R.arr<float>((size_t)w * h)};
+    ORBextractor ex0(nf0, 1.2f, 8, 20, 7), ex1(nf1, 1.2f, 8, 20, 7);   // Tracking.cc:144-145
+    const std::vector<float> sf = ex0.GetScaleFactors();
+    cv::Mat calib = cv::Mat::zeros(4, 3, CV_32F);
+    for (int i = 0; i < 3; ++i) calib.at<float>(i, i) = 1.f;   // cam 2 = cam 1 (identity extrinsics, zero baseline between the rigs' cameras)
+
+    struct Step { Frame F; std::vector<MapPoint> pool; std::vector<cv::KeyPoint> k[2]; cv::Mat d[2]; std::vector<float> world; };
+    std::unique_ptr<Step> last, cur;
+    std::vector<double> t_e0, t_e1, t_fr, t_s, t_calls, t_loop, t_brk[3];
+    std::vector<int> match_src;
+    int nmatches = 0;
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    for (int it = 0; it < warmup + iters; ++it) {
+        const int t = it % T;
+        cur.reset(new Step());
+        Step& S = *cur;
+        cv::Mat im0(h, w, CV_8UC1, img[2 * t].data()), im1(h, w, CV_8UC1, img[2 * t + 1].data());
+        const clk::time_point a0 = clk::now();
+        clk::time_point a1;
+        if (batch) {
+            std::vector<std::vector<cv::KeyPoint> > kk; std::vector<cv::Mat> dd;
+            ORBextractor::ExtractBatch({&ex0, &ex1}, {im0, im1}, kk, dd);
+            S.k[0].swap(kk[0]); S.k[1].swap(kk[1]); S.d[0] = dd[0]; S.d[1] = dd[1];
+            a1 = clk::now();
+        } else {
+            ex0(im0, cv::Mat(), S.k[0], S.d[0]);
+            a1 = clk::now();
+            ex1(im1, cv::Mat(), S.k[1], S.d[1]);
+        }
+        const clk::time_point a2 = clk::now();
+        // ---- the reference's host-side Frame assembly (merge, maps, ComputeStereoFromRGBD; k1 == 0: no undistortion)
+        Frame& F = S.F;
+        F.N = (int)S.k[0].size(); F.N_cam2 = (int)S.k[1].size(); F.N_total = F.N + F.N_cam2;
+        F.mvKeys_total.reserve(F.N_total);
+        for (int c = 0; c < 2; ++c) F.mvKeys_total.insert(F.mvKeys_total.end(), S.k[c].begin(), S.k[c].end());
+        F.mvKeysUn_total = F.mvKeys_total;
+        F.mvKeysUn.assign(F.mvKeys_total.begin(), F.mvKeys_total.begin() + F.N);
+        F.mvuRight_total.assign(F.N_total, -1.f); F.mvDepth_total.assign(F.N_total, -1.f);
+        for (int g = 0; g < F.N_total; ++g) {
+            const int c = g < F.N ? 0 : 1;
+            F.keypoint_to_cam[g] = c; F.cont_idx_to_local_cam_idx[g] = c == 0 ? g : g - F.N;
+            const cv::KeyPoint& kp = F.mvKeys_total[g];
+            const float d = depth[c][(size_t)(int)kp.pt.y * w + (int)kp.pt.x];
+            if (d > 0) { F.mvDepth_total[g] = d; F.mvuRight_total[g] = F.mvKeysUn_total[g].pt.x - mbf / d; }
+        }
+        F.mvuRight.assign(F.mvuRight_total.begin(), F.mvuRight_total.begin() + F.N);
+        F.mDescriptors_total = {S.d[0], S.d[1]}; F.mDescriptors = S.d[0];
+        F.mvpMapPoints.assign(F.N_total, nullptr); F.mvbOutlier.assign(F.N_total, false);
+        F.mvScaleFactors = sf;
+        F.mTcw = cv::Mat::eye(4, 4, CV_32F);
+        F.fx = fx; F.fy = fy; F.cx = cx; F.cy = cy; F.mbf = mbf; F.mb = mbf / fx;
+        F.mnMinX = 0; F.mnMinY = 0; F.mnMaxX = (float)w; F.mnMaxY = (float)h;
+        // every feature carries a map point (observed once) that the stream's motion moves by (du, dv) pixels
+        S.pool.resize(F.N_total); S.world.resize((size_t)3 * F.N_total);
+        for (int g = 0; g < F.N_total; ++g) {
+            const cv::KeyPoint& kp = F.mvKeysUn_total[g];
+            const float z = F.mvDepth_total[g] > 0 ? F.mvDepth_total[g] : 2.f;
+            MapPoint& mp = S.pool[g];
+            mp.mWorldPos = cv::Mat(3, 1, CV_32F);
+            mp.mWorldPos.at<float>(0) = (kp.pt.x + du - cx) / fx * z; mp.mWorldPos.at<float>(1) = (kp.pt.y + dv - cy) / fy * z;
+            mp.mWorldPos.at<float>(2) = z;
+            for (int k = 0; k < 3; ++k) S.world[(size_t)3 * g + k] = mp.mWorldPos.at<float>(k);
+            mp.mDescriptor = S.d[g < F.N ? 0 : 1].row(g < F.N ? g : g - F.N);
+            mp.nObs = 1;
+        }
+        const clk::time_point a3 = clk::now();
+        double search_us = 0;
+        if (last) {
+            Frame& L = last->F;
+            for (int g = 0; g < L.N_total; ++g) L.mvpMapPoints[g] = &last->pool[g];
+            std::fill(F.mvpMapPoints.begin(), F.mvpMapPoints.end(), static_cast<MapPoint*>(NULL));   // Tracking.cc:1254
+            const clk::time_point b0 = clk::now();
+            ORBmatcher matcher(0.9f, true);                                                           // Tracking.cc:1237
+            nmatches = matcher.SearchByProjection(F, L, th, false, calib);                            // Tracking.cc:1267
+            search_us = us(b0, clk::now());
+            float b3[3]; ORBmatcher::LastCallBreakdown(b3);
+            if (it >= warmup) for (int k = 0; k < 3; ++k) t_brk[k].push_back(b3[k]);
+            if (it == warmup + iters - 1) {
+                match_src.assign(F.N_total, -1);
+                for (int g = 0; g < F.N_total; ++g)
+                    if (F.mvpMapPoints[g]) match_src[g] = (int)(F.mvpMapPoints[g] - last->pool.data());
+            }
+        }
+        const clk::time_point a4 = clk::now();
+        if (it >= warmup) {
+            t_e0.push_back(us(a0, a1)); t_e1.push_back(us(a1, a2)); t_fr.push_back(us(a2, a3)); t_s.push_back(search_us);
+            t_calls.push_back(us(a0, a2) + search_us); t_loop.push_back(us(a0, a4));
+        }
+        if (it + 1 < warmup + iters) last = std::move(cur);
+    }
+    FILE* f = std::fopen(argv[3], "wb");
+    unsigned long hits = 0, misses = 0;
+    ORBmatcher::FrameCacheStats(&hits, &misses);
+    const float meds[12] = {(float)med(t_e0), (float)med(t_e1), (float)med(t_fr), (float)med(t_s), (float)med(t_calls), (float)med(t_loop),
+                            (float)med(t_brk[0]), (float)med(t_brk[1]), (float)med(t_brk[2]), (float)hits, (float)misses,
+                            (float)(ORBmatcher::FailureCount() + ORBextractor::FailureCount())};
+    put(f, meds, sizeof(meds));
+    for (double v : t_calls) { const float x = (float)v; put(f, &x, 4); }
+    for (int c = 0; c < 2; ++c) {
+        const int n = (int)cur->k[c].size();
+        put(f, &n, 4); put(f, cur->k[c].data(), (size_t)n * sizeof(cv::KeyPoint));
+        if (n) put(f, cur->d[c].ptr(0), (size_t)n * 32);
+    }
+    put(f, &nmatches, 4);
+    put(f, match_src.data(), match_src.size() * 4);
+    const Frame& L = last->F;
+    put(f, &L.N_total, 4); put(f, &L.N, 4);
+    put(f, last->world.data(), last->world.size() * 4);
+    for (int g = 0; g < L.N_total; ++g) { const int o = L.mvKeys_total[g].octave; put(f, &o, 4); }
+    for (int g = 0; g < L.N_total; ++g) { const float a = L.mvKeysUn_total[g].angle; put(f, &a, 4); }
+    for (int c = 0; c < 2; ++c) { const int n = c == 0 ? L.N : L.N_cam2; if (n) put(f, last->d[c].ptr(0), (size_t)n * 32); }
+    std::fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: test_host extract|batch|match|bow ...\n"); return 1; }
     const std::string mode = argv[1];
@@ -405,6 +550,7 @@ int main(int argc, char** argv) {
     if (mode == "match" && argc >= 4) return run_match(argc, argv);
     if (mode == "bow" && argc >= 4) return run_bow(argc, argv);
     if (mode == "f4" && argc >= 4) return run_f4(argc, argv);
+    if (mode == "dropin" && argc >= 5) return run_dropin(argc, argv);
     std::fprintf(stderr, "bad arguments\n");
     return 1;
 }

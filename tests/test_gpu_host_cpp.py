@@ -20,7 +20,8 @@ def test_host_library_exports_reference_signatures():
     assert os.path.exists(so) and os.path.exists(BIN), "run __graft_entry__.build()"
     syms = subprocess.check_output(["nm", "-DC", so]).decode()
     for want in ("ORB_SLAM2::ORBextractor::ORBextractor(int, float, int, int, int)",
-                 "ORB_SLAM2::ORBextractor::operator()(cv::Mat const&, cv::Mat const&, std::vector<cv::KeyPoint",
+                 "ORB_SLAM2::ORBextractor::operator()(cv::_InputArray const&, cv::_InputArray const&, std::vector<cv::KeyPoint",
+                 "ORB_SLAM2::ORBmatcher::SearchBySim3(ORB_SLAM2::KeyFrame*, ORB_SLAM2::KeyFrame*, std::vector<ORB_SLAM2::MapPoint*",
                  "ORB_SLAM2::ORBmatcher::ORBmatcher(float, bool)",
                  "ORB_SLAM2::ORBmatcher::DescriptorDistance(cv::Mat const&, cv::Mat const&)",
                  "ORB_SLAM2::ORBmatcher::SearchByProjection(ORB_SLAM2::Frame&, std::vector<ORB_SLAM2::MapPoint*",
@@ -559,3 +560,15 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
             kam[bi[k_]] = loop_ids[src[k_]]
         nf2 += 1
     assert n5 == nf2 and np.array_equal(got_ka, kam) and np.array_equal(got_replace, repl) and n5 > 150
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [False, True])
+def test_cpp_dropin_call_pattern_is_bit_exact(tmp_path, batch):
+    """The reference's per-frame call pattern through the C++ classes (two operator() calls or one ExtractBatch, then a
+    stack-constructed ORBmatcher's SearchByProjection, reference src/Frame.cc:182-185 + src/Tracking.cc:1237-1267) over a
+    short stream: the last step must equal the oracle (the matcher handle is pooled per thread and reused across the
+    stack objects, frames are re-uploaded per search)."""
+    import dropin_leg
+    r = dropin_leg.run(640, 480, (1000, 500), T=4, iters=6, warmup=1, batch=batch, workdir=str(tmp_path))
+    assert "bit-exact" in r["parity"] and r["dropin_fps"] > 0
