@@ -203,6 +203,21 @@ int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm
                               const uint8_t* occupied, int th_high, int check_orientation,
                               int32_t* match_of_feature, int* nmatches);
 
+/* The two-camera loop-closing search, SearchByProjection(KeyFrame*, Scw, vpPoints, vLoopMPCams, vpMatched, th, Calib)
+ * (reference src/ORBmatcher.cc:566-750): every point is projected into BOTH cameras of the keyframe; the candidates of the
+ * camera-2 window follow those of the camera-1 window (the reference's `for camidx` loop), ONE strict `<` chain runs over both,
+ * and an accepted match (<= th_high = TH_LOW there) hides its feature from the later points (vpMatched[idx]).  q[i] holds
+ * the first window (q[i].cam < 0: the point is not visible in that camera), second[i] the other one (cam < 0: none); the
+ * descriptor, `blocks` and `angle` come from q[i].  Everything else as orbm_search_by_projection. */
+typedef struct orbm_window {
+    float u, v, radius;
+    int32_t cam;                  /* < 0: no window */
+    int32_t min_level, max_level; /* level gate of this window, as in orbm_query */
+} orbm_window;
+int orbm_search_by_projection_windows(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, const orbm_window* second,
+                                      int nq, const uint8_t* occupied, int th_high, int check_orientation,
+                                      int32_t* match_of_feature, int* nmatches);
+
 /* The inner loop the remaining projection searches share: every projected point scans its window
  * -- same cell walk and level gate as above -- and reports the FIRST candidate in visiting order with the smallest
  * distance (`if(dist<bestDist)`), independently of every other point: no claims between queries.

@@ -14,7 +14,8 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("min_level", "<i4"),
                         ("max_level", "<i4"), ("cam", "<i4"), ("blocks", "<i4"), ("angle", "<f4"),
                         ("desc", "u1", (32,))])
-assert KP_DTYPE.itemsize == 28 and QUERY_DTYPE.itemsize == 68
+WINDOW_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("cam", "<i4"), ("min_level", "<i4"), ("max_level", "<i4")])
+assert KP_DTYPE.itemsize == 28 and QUERY_DTYPE.itemsize == 68 and WINDOW_DTYPE.itemsize == 24
 
 ORB_OK, ORB_E_ARG, ORB_E_HIP, ORB_E_CAPACITY, ORB_E_NO_DEVICE = 0, -1, -2, -3, -4
 
@@ -179,6 +180,7 @@ def lib():
     L.orbm_project_candidates.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     L.orbm_project_best.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, vp, vp]
     L.orbm_search_by_projection.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp]
+    L.orbm_search_by_projection_windows.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, vp, vp]
     L.orbm_debug_time_project.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     L.orbm_search_by_projection_points.argtypes = [vp, vp, vp, i32, vp, f32, i32, vp, vp]
     f64 = C.c_double

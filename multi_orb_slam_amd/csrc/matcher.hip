@@ -568,13 +568,15 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
                                                  int gate_right, int with_dist, int transposed, int* __restrict__ cand_idx,
                                                  uint16_t* __restrict__ cand_dist, int* __restrict__ cand_count,
                                                  const uint8_t* __restrict__ occupied, int* __restrict__ topk, int short_th,
-                                                 const float* __restrict__ inv_sigma2 = nullptr, int2* __restrict__ qmeta = nullptr) {
+                                                 const float* __restrict__ inv_sigma2 = nullptr, int2* __restrict__ qmeta = nullptr,
+                                                 const orbm_window* __restrict__ win2 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (qi >= nq) return;
     const orbm_query* Q = q + qi;
-    const float x = Q->u, y = Q->v, r = Q->radius, ur = Q->ur;
-    const int minLevel = Q->min_level, maxLevel = Q->max_level, cam = Q->cam;
+    float x = Q->u, y = Q->v, r = Q->radius;
+    const float ur = Q->ur;
+    int minLevel = Q->min_level, maxLevel = Q->max_level, cam = Q->cam;
     const uint32_t* qd = reinterpret_cast<const uint32_t*>(Q->desc);
     const uint4 q0 = make_uint4(qd[0], qd[1], qd[2], qd[3]), q1 = make_uint4(qd[4], qd[5], qd[6], qd[7]);
 
@@ -583,6 +585,15 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
     int sk[RESOLVE_K], sg[RESOLVE_K];  // wave-uniform sorted shortlist
 #pragma unroll
     for (int k = 0; k < RESOLVE_K; ++k) { sk[k] = 0x7fffffff; sg[k] = -1; }
+    // A query may carry a SECOND window (the two-camera loop search, reference src/ORBmatcher.cc:625-721: the point is projected
+    // into both cameras of the keyframe and the best candidate over both windows wins): its candidates simply follow the
+    // first window's in the list, i.e. in the reference's visiting order (camera 1's loop runs before camera 2's).
+    const int nwin = win2 ? 2 : 1;
+    for (int wi = 0; wi < nwin; ++wi) {
+    if (wi == 1) {
+        const orbm_window* W2 = win2 + qi;
+        x = W2->u; y = W2->v; r = W2->radius; cam = W2->cam; minLevel = W2->min_level; maxLevel = W2->max_level;
+    }
     const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.invW));
     const int nMaxCellX = min(ORBM_GRID_COLS - 1, (int)ceilf((x - F.minX + r) * F.invW));
     const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.invH));
@@ -676,6 +687,7 @@ __global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* _
             }
         }
     }
+    }  // windows
     if (lane == 0) {
         cand_count[qi] = total;
         // what the resolve needs of a query besides its candidates: it never reads the query records themselves, which may
@@ -1683,6 +1695,7 @@ struct orbm_matcher {
     DevBuf<int32_t> d_i0, d_i1, d_i2, d_choice, d_claim, d_match, d_status, d_x0, d_x1, d_x2;
     DevBuf<int32_t> d_gclaim;  // claim tables of the resolve when they do not fit LDS (2 x features)
     DevBuf<int2> d_qmeta;      // {blocks, angle} of every query, written by k_project for the resolve
+    DevBuf<orbm_window> d_win2; // second windows of a two-camera search
     DevBuf<uint16_t> d_u16;
     PinnedBuf<int32_t> h_i0, h_i1, h_i2, h_match;
     PinnedBuf<int32_t> h_gcnt;            // per-camera counts of a gathered multi-GPU exchange (+ own query count)
@@ -1833,7 +1846,7 @@ void orbm_destroy(orbm_matcher* m) {
     if (m->ev_q) (void)hipEventDestroy(m->ev_q);
     m->h_c0.release(); m->h_c1.release(); m->h_c2.release(); m->d_cscratch.release(); m->h_gcnt.release(); m->d_gstart.release();
     m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release(); m->d_occ.release();
-    m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release(); m->d_qmeta.release();
+    m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release(); m->d_qmeta.release(); m->d_win2.release();
     m->d_match.release(); m->d_status.release(); m->d_gclaim.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
     m->h_i0.release(); m->h_i1.release(); m->h_i2.release(); m->h_match.release(); m->h_u16.release(); m->h_ring.release();
     m->stage_f.release(); m->stage_q.release();
@@ -2317,7 +2330,8 @@ int orbm_frame_grid(const orbm_frame* f, int32_t* cell_start, int32_t* items) {
 static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap, int gate_right,
                        int with_dist, bool upload_queries, bool to_host, int transposed = 0,
                        const uint8_t* d_occupied = nullptr, int* d_topk = nullptr, int short_th = 256,
-                       const float* d_inv_sigma2 = nullptr, const orbm_query* q_device_visible = nullptr, int2* d_qmeta = nullptr) {
+                       const float* d_inv_sigma2 = nullptr, const orbm_query* q_device_visible = nullptr, int2* d_qmeta = nullptr,
+                       const orbm_window* d_win2 = nullptr) {
     int rc;
     if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_i0.reserve((size_t)nq * cap)) ||
         (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)))
@@ -2326,7 +2340,7 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, q, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_project, dim3((nq + 3) / 4), dim3(256), 0, m->stream, f->dev(),
                        q_device_visible ? q_device_visible : (const orbm_query*)m->d_queries.p, nq, cap, gate_right, with_dist, transposed,
-                       m->d_i0.p, m->d_u16.p, m->d_i1.p, d_occupied, d_topk, short_th, d_inv_sigma2, d_qmeta);
+                       m->d_i0.p, m->d_u16.p, m->d_i1.p, d_occupied, d_topk, short_th, d_inv_sigma2, d_qmeta, d_win2);
     MORB_HIP(hipGetLastError());
     if (to_host) {
         if ((rc = m->h_i0.reserve((size_t)nq * cap)) || (rc = m->h_u16.reserve((size_t)nq * cap)) || (rc = m->h_i1.reserve(nq)))
@@ -2341,11 +2355,11 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
 
 // Runs k_project with a growing per-query capacity until every list fits; results in m->h_i0 / h_u16 / h_i1.
 static int project_all(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int gate_right, int with_dist,
-                       int* cap_out, int cap0 = 64) {
+                       int* cap_out, int cap0 = 64, const orbm_window* d_win2 = nullptr) {
     int cap = cap0;
     bool first = true;
     for (;;) {
-        int rc = run_project(m, f, q, nq, cap, gate_right, with_dist, first, true);
+        int rc = run_project(m, f, q, nq, cap, gate_right, with_dist, first, true, 0, nullptr, nullptr, 256, nullptr, nullptr, nullptr, d_win2);
         if (rc) return rc;
         first = false;
         int mx = 0;
@@ -2458,11 +2472,11 @@ int orbm_debug_time_project(orbm_matcher* m, const orbm_frame* f, const orbm_que
 // Sequential resolve on the host from the ordered candidate lists (fallback of the device resolve; same semantics).
 static int host_resolve(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, const uint8_t* occupied,
                         bool points, float nnratio, int th_high, int check_orientation, int cap0, int32_t* match_of_feature,
-                        int* nmatches) {
+                        int* nmatches, const orbm_window* d_win2 = nullptr) {
     int rc = ensure_host_copies(cur);
     if (rc) return rc;
     int cap = 0;
-    if ((rc = project_all(m, cur, q, nq, 1, 1, &cap, cap0))) return rc;
+    if ((rc = project_all(m, cur, q, nq, 1, 1, &cap, cap0, d_win2))) return rc;
     for (int g = 0; g < cur->n_total; g++) match_of_feature[g] = -1;
     std::vector<int32_t> rot[ORBM_HISTO_LENGTH];
     const float factor = 1.0f / ORBM_HISTO_LENGTH;
@@ -2518,6 +2532,7 @@ struct SearchJob {
     bool want_tags = false; int seq = 0; // caller wants to watch the results arrive; sequence number of the launch in flight
     const orbm_query* q_dev = nullptr;  // device-visible alias of `q` when it lives in mapped pinned memory: read in place, no H2D
     const uint8_t* occ_dev = nullptr;   // device-visible copy of `occupied` (staged by the caller): no H2D either
+    const orbm_window* win2_dev = nullptr;  // second windows of the queries (device memory), or NULL
 };
 
 static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_device = false) {
@@ -2549,7 +2564,7 @@ static int search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, J.q_dev, (size_t)nq * sizeof(orbm_query), hipMemcpyDefault, m->stream));
     }
     if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device && !J.q_dev, false, /*transposed=*/1, d_occ, m->d_claim.p,
-                          J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p)))
+                          J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p, J.win2_dev)))
         return rc;
     if (multi) {
         int* tab0 = m->d_gclaim.p; int* tab1 = tab0 + n; int* state = tab1 + n;
@@ -2610,7 +2625,7 @@ static int search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_featur
         m->last_status[0] = -1; m->last_status[1] = 0; m->last_status[2] = 0; m->last_status[3] = 0;  // (host path)
     }
     if (!J.device_path)
-        return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, 64, match_of_feature, nmatches);
+        return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, 64, match_of_feature, nmatches, J.win2_dev);
     // Result words of a tagged launch are taken as they arrive (the caller may not have synchronised the stream): wait for
     // the word to carry this launch's sequence number, then strip it.  After ~10 ms without progress the stream is
     // synchronised for good (which also covers a launch that failed).
@@ -2641,7 +2656,7 @@ static int search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_featur
             continue;
         }
         // not converged within the sweep limit: exact host fallback
-        return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, J.cap, match_of_feature, nmatches);
+        return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, J.cap, match_of_feature, nmatches, J.win2_dev);
     }
     if (J.seq) {
         for (int g = 0; g < n; ++g) {
@@ -2656,9 +2671,15 @@ static int search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_featur
 
 static int search_common(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, const uint8_t* occupied,
                          bool points, float nnratio, int th_high, int check_orientation, int32_t* match_of_feature,
-                         int* nmatches) {
+                         int* nmatches, const orbm_window* second = nullptr) {
     SearchJob J{cur, q, nq, occupied, points, nnratio, th_high, check_orientation, 64, false};
     int rc;
+    if (second && nq > 0) {   // second windows (two-camera loop search): a device copy for the projection kernel
+        if ((rc = m->d_win2.reserve(nq))) return rc;
+        MORB_HIP(hipMemcpyAsync(m->d_win2.p, second, (size_t)nq * sizeof(orbm_window), hipMemcpyHostToDevice, m->stream));
+        MORB_HIP(hipStreamSynchronize(m->stream));   // (`second` is the caller's)
+        J.win2_dev = m->d_win2.p;
+    }
     // The queries and the occupied flags go through host-written staging (HBM behind the large BAR, or mapped pinned memory)
     // and are read in place by the kernels: no pageable hipMemcpyAsync on the call's critical path.  The staging stays
     // untouched until this call has synchronised.
@@ -2683,6 +2704,14 @@ int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm
     MORB_ARG(m && cur && nq >= 0 && nmatches && (cur->n_total == 0 || match_of_feature) && (nq == 0 || q));
     MORB_HIP(hipSetDevice(m->device));
     return search_common(m, cur, q, nq, occupied, false, 0.f, th_high, check_orientation, match_of_feature, nmatches);
+}
+
+int orbm_search_by_projection_windows(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, const orbm_window* second, int nq,
+                                      const uint8_t* occupied, int th_high, int check_orientation, int32_t* match_of_feature,
+                                      int* nmatches) {
+    MORB_ARG(m && cur && nq >= 0 && nmatches && (cur->n_total == 0 || match_of_feature) && (nq == 0 || (q && second)));
+    MORB_HIP(hipSetDevice(m->device));
+    return search_common(m, cur, q, nq, occupied, false, 0.f, th_high, check_orientation, match_of_feature, nmatches, second);
 }
 
 int orbm_search_by_projection_points(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,

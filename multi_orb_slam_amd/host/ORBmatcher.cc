@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -128,6 +129,18 @@ void dump_queries(const std::vector<orbm_query>& q, const std::vector<int>& src)
     const int n = (int)q.size();
     std::fwrite(&n, 4, 1, f);
     if (n) { std::fwrite(q.data(), sizeof(orbm_query), n, f); std::fwrite(src.data(), 4, n, f); }
+    std::fclose(f);
+}
+
+// second windows of the last dumped query set: {-count, windows}
+void dump_windows(const std::vector<orbm_window>& w) {
+    const char* path = std::getenv("MORB_DUMP_QUERIES");
+    if (!path) return;
+    FILE* f = std::fopen(path, "ab");
+    if (!f) return;
+    const int n = -(int)w.size();
+    std::fwrite(&n, 4, 1, f);
+    if (!w.empty()) std::fwrite(w.data(), sizeof(orbm_window), w.size(), f);
     std::fclose(f);
 }
 
@@ -408,6 +421,176 @@ int ORBmatcher::SearchByProjection_cam1(KeyFrame* pKF, cv::Mat Scw, const std::v
     if (rc) return fail("orbm_search_by_projection", rc);
     for (int g = 0; g < pKF->N; ++g)
         if (match[g] >= 0) vpMatched[g] = qmp[match[g]];
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:566-750 (loop closing, both cameras of the keyframe).  Every loop point is projected into camera 1
+// and, through the cam2 <- cam1 extrinsics, into camera 2; ONE `dist < bestDist` chain runs over the candidates of both
+// windows (camera 1's first), and an accepted match (<= TH_LOW) takes its feature out of the game for the points that follow
+// (vpMatched[idx]).  On the device: one query per point with a second window (orbm_search_by_projection_windows).
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<int>& /*vLoopMPCams*/,
+                                   std::vector<MapPoint*>& vpMatched, int th, const cv::Mat CalibMatrix) {
+    const float& fx = pKF->fx; const float& fy = pKF->fy; const float& cx = pKF->cx; const float& cy = pKF->cy;
+    const cv::Mat Rcam12 = CalibMatrix.rowRange(0, 3).colRange(0, 3);
+    cv::Mat tcam12(3, 1, CV_32F);
+    tcam12.at<float>(0, 0) = CalibMatrix.at<float>(3, 0);
+    tcam12.at<float>(1, 0) = CalibMatrix.at<float>(3, 1);
+    tcam12.at<float>(2, 0) = CalibMatrix.at<float>(3, 2);
+    const cv::Mat Rcam21 = Rcam12.inv();
+    const cv::Mat tcam21 = -Rcam21 * tcam12;
+    // Decompose Scw
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+    std::vector<orbm_query> q;
+    std::vector<orbm_window> w2;
+    std::vector<MapPoint*> qmp;
+    std::vector<int> qsrc;
+    for (int iMP = 0, iendMP = (int)vpPoints.size(); iMP < iendMP; iMP++) {
+        MapPoint* pMP = vpPoints[iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        orbm_query Q;
+        orbm_window W[2];
+        W[0].cam = W[1].cam = -1;
+        for (int camidx = 0; camidx < 2; ++camidx) {
+            cv::Mat p3Dc = Rcw * p3Dw + tcw;
+            if (camidx == 1) p3Dc = Rcam21 * p3Dc + tcam21;
+            if (p3Dc.at<float>(2) < 0.0) continue;
+            const float invz = 1 / p3Dc.at<float>(2);
+            const float x = p3Dc.at<float>(0) * invz;
+            const float y = p3Dc.at<float>(1) * invz;
+            const float u = fx * x + cx;
+            const float v = fy * y + cy;
+            if (!pKF->IsInImage(u, v)) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            cv::Mat PO = p3Dw - Ow;
+            const float dist = cv::norm(PO);
+            if (dist < minDistance || dist > maxDistance) continue;
+            cv::Mat Pn = pMP->GetNormal();
+            if (PO.dot(Pn) < 0.5 * dist) continue;
+            int nPredictedLevel = pMP->PredictScale(dist, pKF);
+            const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+            W[camidx].u = u; W[camidx].v = v; W[camidx].radius = radius; W[camidx].cam = camidx;
+            W[camidx].min_level = nPredictedLevel - 1; W[camidx].max_level = nPredictedLevel;   // :704-707
+        }
+        if (W[0].cam < 0 && W[1].cam < 0) continue;   // (nothing to search: bestDist stays 256)
+        Q.u = W[0].u; Q.v = W[0].v; Q.radius = W[0].radius; Q.ur = std::nanf("");
+        Q.min_level = W[0].min_level; Q.max_level = W[0].max_level; Q.cam = W[0].cam;
+        if (W[0].cam < 0) { Q.u = Q.v = Q.radius = 0.f; Q.min_level = Q.max_level = -1; }
+        Q.blocks = 1; Q.angle = 0;
+        const cv::Mat dMP = pMP->GetDescriptor();
+        std::memcpy(Q.desc, dMP.ptr(0), 32);
+        q.push_back(Q); w2.push_back(W[1]); qmp.push_back(pMP); qsrc.push_back(iMP);
+    }
+    dump_queries(q, qsrc);
+    dump_windows(w2);
+    orbm_frame* fr = device_frame(Handle(), *pKF, false);
+    if (!fr) return 0;
+    const int n = pKF->N_total;
+    std::vector<uint8_t> occupied(n > 0 ? n : 1, 0);
+    for (int g = 0; g < n; ++g) occupied[g] = vpMatched[g] ? 1 : 0;    // :696
+    std::vector<int32_t> match(occupied.size());
+    int nmatches = 0;
+    const int rc = orbm_search_by_projection_windows(Handle(), fr, q.data(), w2.data(), (int)q.size(), occupied.data(), TH_LOW, 0, match.data(),
+                                                     &nmatches);
+    if (rc) return fail("orbm_search_by_projection_windows", rc);
+    for (int g = 0; g < n; ++g)
+        if (match[g] >= 0) vpMatched[g] = qmp[match[g]];
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:868-994 (monocular initialisation; not reached by the RGB-D rig).  The windows around the
+// previously matched positions are gathered on the device in the reference's visiting order with their distances
+// (orbm_project_candidates: level-0 features of F2's camera-1 grid); the loop that follows mutates per-feature state between
+// queries (vMatchedDistance, vnMatches21 with un-matching) and is replayed on the host literally.
+int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                        int windowSize) {
+    int nmatches = 0;
+    vnMatches12 = std::vector<int>(F1.mvKeysUn.size(), -1);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(F2.mvKeysUn.size(), INT_MAX);
+    std::vector<int> vnMatches21(F2.mvKeysUn.size(), -1);
+    std::vector<orbm_query> q;
+    std::vector<int> qsrc;
+    for (size_t i1 = 0, iend1 = F1.mvKeysUn.size(); i1 < iend1; i1++) {
+        cv::KeyPoint kp1 = F1.mvKeysUn[i1];
+        int level1 = kp1.octave;
+        if (level1 > 0) continue;
+        orbm_query Q;
+        Q.u = vbPrevMatched[i1].x; Q.v = vbPrevMatched[i1].y; Q.radius = (float)windowSize; Q.ur = std::nanf("");
+        Q.min_level = level1; Q.max_level = level1; Q.cam = 0; Q.blocks = 0; Q.angle = kp1.angle;
+        std::memcpy(Q.desc, F1.mDescriptors.ptr((int)i1), 32);
+        q.push_back(Q); qsrc.push_back((int)i1);
+    }
+    dump_queries(q, qsrc);
+    const int nq = (int)q.size();
+    std::vector<int32_t> cidx, ccnt(nq > 0 ? nq : 1);
+    std::vector<uint16_t> cdist;
+    int cap = 64;
+    if (nq) {
+        orbm_frame* fr = device_frame(Handle(), F2, true);
+        if (!fr) return 0;
+        for (;;) {
+            cidx.resize((size_t)nq * cap); cdist.resize((size_t)nq * cap);
+            const int rc = orbm_project_candidates(Handle(), fr, q.data(), nq, cap, cidx.data(), cdist.data(), ccnt.data());
+            if (rc == ORB_OK) break;
+            if (rc != ORB_E_CAPACITY) return fail("orbm_project_candidates", rc);
+            int mx = cap;
+            for (int i = 0; i < nq; ++i) mx = std::max(mx, (int)ccnt[i]);
+            cap = (mx + 63) & ~63;
+        }
+    }
+    for (int k = 0; k < nq; ++k) {
+        const size_t i1 = (size_t)qsrc[k];
+        if (ccnt[k] == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = 0; c < ccnt[k]; ++c) {
+            const size_t i2 = (size_t)cidx[(size_t)k * cap + c];
+            const int dist = cdist[(size_t)k * cap + c];
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * mfNNratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = (int)i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (mbCheckOrientation) {
+                    float rot = F1.mvKeysUn[i1].angle - F2.mvKeysUn[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    assert(bin >= 0 && bin < HISTO_LENGTH);
+                    rotHist[bin].push_back((int)i1);
+                }
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                int idx1 = rotHist[i][j];
+                if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    // Update prev matched
+    for (size_t i1 = 0, iend1 = vnMatches12.size(); i1 < iend1; i1++)
+        if (vnMatches12[i1] >= 0) vbPrevMatched[i1] = F2.mvKeysUn[vnMatches12[i1]].pt;
     return nmatches;
 }
 

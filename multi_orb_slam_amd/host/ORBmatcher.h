@@ -48,6 +48,15 @@ public:
     // Used in loop detection (Loop Closing)
     int SearchByProjection_cam1(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th);
 
+    // The same over both cameras of the keyframe: each point is projected into camera 1 and camera 2, the best candidate over
+    // both windows wins (reference :566-750)
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<int>& vLoopMPCams,
+                           std::vector<MapPoint*>& vpMatched, int th, const cv::Mat CalibMatrix);
+
+    // Matching for the Map Initialization (only used in the monocular case)
+    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                int windowSize = 10);
+
     // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12]
     // In the stereo and RGB-D case, s12=1
     int SearchBySim3_cam1(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,

@@ -371,6 +371,11 @@ static int run_f4(int argc, char** argv) {
     { std::vector<float> cm = R.arr<float>(12); for (int i = 0; i < 12; ++i) calib.at<float>(i / 3, i % 3) = cm[i]; }
     const float th_fuse = R.get<float>(), th_reloc = R.get<float>();
     const int ORBdist = R.get<int>(), check_ori = R.get<int>();
+    // inputs of the two-camera overloads and of SearchForInitialization
+    std::vector<MapPoint*> vpMatchedFull; ids_to(vpMatchedFull, KA.N_total, nullptr);
+    std::vector<MapPoint*> vpMatches12Full; ids_to(vpMatches12Full, KA.N_total, nullptr);
+    std::vector<float> prev_x = R.arr<float>(FA.N), prev_y = R.arr<float>(FA.N);
+    const int window_size = R.get<int>();
 
     FILE* f = std::fopen(argv[3], "wb");
     ORBmatcher m(0.9f, check_ori != 0);
@@ -383,6 +388,21 @@ static int run_f4(int argc, char** argv) {
     const int n3 = m.SearchBySim3_cam1(&KA, &KB, vpMatches12, s12, R12, t12, th_sim3);
     put(f, &n3, 4);
     for (int g = 0; g < KA.N; ++g) { int id = id_of(vpMatches12[g]); put(f, &id, 4); }
+    // the overloads over both cameras of the rig (reference src/ORBmatcher.cc:566-750, :2814-3135) and SearchForInitialization
+    std::vector<int> loop_cams(loop_pts.size(), 0);
+    const int n6 = m.SearchByProjection(&KA, Scw, loop_pts, loop_cams, vpMatchedFull, th_loop, calib);
+    put(f, &n6, 4);
+    for (int g = 0; g < KA.N_total; ++g) { int id = id_of(vpMatchedFull[g]); put(f, &id, 4); }
+    const int n7 = m.SearchBySim3(&KA, &KB, vpMatches12Full, s12, R12, t12, th_sim3, calib);
+    put(f, &n7, 4);
+    for (int g = 0; g < KA.N_total; ++g) { int id = id_of(vpMatches12Full[g]); put(f, &id, 4); }
+    std::vector<cv::Point2f> vbPrev(FA.N);
+    for (int i = 0; i < FA.N; ++i) vbPrev[i] = cv::Point2f(prev_x[i], prev_y[i]);
+    std::vector<int> vnMatches12;
+    const int n8 = m.SearchForInitialization(FA, FB, vbPrev, vnMatches12, window_size);
+    put(f, &n8, 4);
+    put(f, vnMatches12.data(), vnMatches12.size() * 4);
+    for (int i = 0; i < FA.N; ++i) { put(f, &vbPrev[i].x, 4); put(f, &vbPrev[i].y, 4); }
     const int n4 = m.Fuse(&KB, fuse_pts, calib, th_fuse);
     put(f, &n4, 4);
     for (int g = 0; g < KB.N_total; ++g) { int id = id_of(KB.mvpMapPoints[g]); put(f, &id, 4); }

@@ -279,6 +279,18 @@ class Matcher:
                                                    int(self.check_orientation), ptr(m), C.byref(n)))
         return n.value, m[:frame.data.n_total]
 
+    def SearchByProjectionWindows(self, frame, queries, windows2, th_high=TH_LOW, occupied=None):
+        """Two-camera loop search (reference src/ORBmatcher.cc:566-750) from the projected windows on: queries[i] carries the
+        camera-1 window, windows2[i] the camera-2 window (cam < 0: none); orbm_search_by_projection_windows."""
+        from ._lib import WINDOW_DTYPE
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE); windows2 = np.ascontiguousarray(windows2, WINDOW_DTYPE)
+        assert len(queries) == len(windows2)
+        m = np.zeros(max(frame.data.n_total, 1), np.int32); n = C.c_int()
+        occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        check(_lib.lib().orbm_search_by_projection_windows(self._h, frame._h, ptr(queries), ptr(windows2), len(queries),
+                                                           None if occ is None else ptr(occ), th_high, 0, ptr(m), C.byref(n)))
+        return n.value, m[:frame.data.n_total]
+
     def SearchByProjectionPoints(self, frame, queries, occupied=None, th_high=TH_HIGH):
         """SearchByProjection(F, vpMapPoints, th) (reference src/ORBmatcher.cc:62-149)."""
         queries = np.ascontiguousarray(queries, QUERY_DTYPE)

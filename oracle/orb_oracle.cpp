@@ -991,6 +991,100 @@ int orc_search_by_projection_frames(const orc_frame* cur, const orc_query* q, in
     return nmatches;
 }
 
+// f4  SearchByProjection(KeyFrame*, Scw, vpPoints, vLoopMPCams, vpMatched, th, Calib), ORBmatcher.cc:566-750: the two-camera
+// loop search from the projected windows on.  Point i: first window = q[i] (cam < 0: the point failed the gates of :636-672
+// for camera 1), second window = w2[i]; GetFeaturesInArea is called WITHOUT level arguments (:680), the level gate
+// [nPredictedLevel-1, nPredictedLevel] (:704-707) is applied inside the candidate loop; bestDist / bestIdxs are shared by the
+// two cameras (:624-625 sit outside the `for camidx` loop); `vpMatched[idx]` (:696) hides both the features that were matched
+// before the call (occupied) and the ones matched by earlier points of this call.
+struct orc_window { float u, v, radius; int cam, min_level, max_level; };
+
+int orc_search_by_projection_loop2(const orc_frame* cur, const orc_query* q, const orc_window* w2, int nq, const uint8_t* occupied,
+                                   int th_low, int* match_of_feature) {
+    FrameView F; make_view(cur, F);
+    for (int g = 0; g < F.n_total; g++) match_of_feature[g] = -1;
+    int nmatches = 0;
+    std::vector<int> vIndices;
+    for (int iMP = 0; iMP < nq; iMP++) {
+        int bestDist = 256;
+        int bestIdxs = -1;
+        for (int camidx = 0; camidx < 2; ++camidx) {
+            float u, v, radius; int cam, lo, hi;
+            if (camidx == 0) { u = q[iMP].u; v = q[iMP].v; radius = q[iMP].radius; cam = q[iMP].cam; lo = q[iMP].min_level; hi = q[iMP].max_level; }
+            else { u = w2[iMP].u; v = w2[iMP].v; radius = w2[iMP].radius; cam = w2[iMP].cam; lo = w2[iMP].min_level; hi = w2[iMP].max_level; }
+            if (cam < 0) continue;                                            // one of the `continue`s of :636-672
+            features_in_area(F, cam, u, v, radius, -1, -1, vIndices);         // :680
+            if (vIndices.empty()) continue;
+            for (int idx : vIndices) {
+                if ((occupied && occupied[idx]) || match_of_feature[idx] >= 0) continue;   // if(vpMatched[idx]) :696
+                const int kpLevel = F.octave[idx];
+                if (kpLevel < lo || kpLevel > hi) continue;                                // :704-707
+                const uint8_t* dKF = F.desc[cam] + (size_t)F.local_of[idx] * 32;           // :710-711
+                const int dist = descriptor_distance(q[iMP].desc, dKF);
+                if (dist < bestDist) { bestDist = dist; bestIdxs = idx; }
+            }
+        }
+        if (bestDist <= th_low) { match_of_feature[bestIdxs] = iMP; nmatches++; }          // :732-736
+    }
+    return nmatches;
+}
+
+// f4  SearchForInitialization, ORBmatcher.cc:868-994, from the level-0 keypoints of F1 on (one query per kept keypoint, in
+// order: window centre = vbPrevMatched, radius = windowSize, levels level1..level1, descriptor and angle of the keypoint).
+// match12[k] = index in F2 matched to query k or -1 (vnMatches12 restricted to the kept keypoints); returns nmatches.
+int orc_search_for_initialization(const orc_frame* f2, const orc_query* q, int nq, float nnratio, int check_ori, int th_low,
+                                  int* match12) {
+    FrameView F; make_view(f2, F);
+    const int HISTO_LENGTH = 30;
+    int nmatches = 0;
+    for (int k = 0; k < nq; k++) match12[k] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(F.n_total, INT_MAX);
+    std::vector<int> vnMatches21(F.n_total, -1);
+    std::vector<int> vIndices2;
+    for (int i1 = 0; i1 < nq; i1++) {
+        const orc_query& Q = q[i1];
+        features_in_area(F, Q.cam, Q.u, Q.v, Q.radius, Q.min_level, Q.max_level, vIndices2);   // :887
+        if (vIndices2.empty()) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            const uint8_t* d2 = F.desc[Q.cam] + (size_t)F.local_of[i2] * 32;
+            const int dist = descriptor_distance(Q.desc, d2);
+            if (vMatchedDistance[i2] <= dist) continue;                                       // :906-907
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= th_low) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { match12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                match12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_ori) {
+                    float rot = Q.angle - F.angle[bestIdx2];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (check_ori) {
+        int sizes[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i])
+                if (match12[idx1] >= 0) { match12[idx1] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 // f4  the inner loop shared by SearchBySim3 (ORBmatcher.cc:2814-3135) and Fuse (:1986-2509): nearest candidate of every
 // projected point on its own (no claims).  gate 0: none; 1: the tracking right-coordinate window (:3571-3577);
 // 2: Fuse's reprojection-error gate (:2118-2143) with q.ur = the projected right coordinate.

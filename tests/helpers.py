@@ -89,3 +89,32 @@ def make_bow_pair(voc, ovoc, n_a, n_b, seed=1, levelsup=2, n_cams=2, nlevels=8, 
         sb["x"] = (sa["x"][src] + 25.0).astype(np.float32)
         sb["y"] = (sa["y"][src] + (rand_u32(n_b, seed + 60) % np.uint32(7)).astype(np.float32) - 3.0).astype(np.float32)
     return sa, sb
+
+
+def make_two_window_queries(fr, nq, seed=5, th=10.0, scale_factor=1.2, nlevels=8):
+    """Loop points of the two-camera loop search: every point looks at a feature of camera `c0` and (most of them) also at a
+    feature of the other camera -- either of the two windows may be missing -- with a descriptor close to one of the two
+    targets, so that the winner comes from either camera and contested features exist.  -> (queries, second windows)."""
+    from multi_orb_slam_amd._lib import WINDOW_DTYPE
+    n = len(fr["un_x"]); cam_of = np.asarray(fr["cam_of"])
+    idx_by_cam = [np.flatnonzero(cam_of == c) for c in (0, 1)]
+    q = np.zeros(nq, QUERY_DTYPE); w2 = np.zeros(nq, WINDOW_DTYPE)
+    scales = (np.float32(scale_factor) ** np.arange(nlevels)).astype(np.float32)
+    all_desc = np.concatenate(fr["descs"])
+    r0 = rand_u32(nq, seed); r1 = rand_u32(nq, seed + 1); mode = rand_u32(nq, seed + 2) % 10
+    jit = (rand_unit(4 * nq, seed + 3) - 0.5) * 8
+    tgt = np.zeros(nq, np.int64)
+    for i in range(nq):
+        g0 = int(idx_by_cam[0][r0[i] % len(idx_by_cam[0])]); g1 = int(idx_by_cam[1][r1[i] % len(idx_by_cam[1])])
+        lvl = int(fr["octave"][g0]) + int(mode[i] % 2)                  # predicted level: the feature's own or one above
+        lvl = min(max(lvl, 0), nlevels - 1)
+        rad = np.float32(th) * scales[lvl]
+        q["u"][i] = fr["un_x"][g0] + jit[4 * i]; q["v"][i] = fr["un_y"][g0] + jit[4 * i + 1]; q["radius"][i] = rad
+        q["min_level"][i] = lvl - 1; q["max_level"][i] = lvl; q["cam"][i] = 0 if mode[i] != 0 else -1     # 10 %: not visible in camera 1
+        w2["u"][i] = fr["un_x"][g1] + jit[4 * i + 2]; w2["v"][i] = fr["un_y"][g1] + jit[4 * i + 3]; w2["radius"][i] = rad
+        w2["min_level"][i] = lvl - 1; w2["max_level"][i] = lvl; w2["cam"][i] = 1 if mode[i] not in (1, 2) else -1   # 20 %: not in camera 2
+        tgt[i] = g0 if (mode[i] % 3 and q["cam"][i] >= 0) else g1
+    q["ur"] = np.nan; q["blocks"] = 1; q["angle"] = 0
+    q["desc"] = synth.perturbed_queries(all_desc[tgt], seed + 4, 0.04)
+    q["desc"][::3] = all_desc[tgt][::3]
+    return q, w2

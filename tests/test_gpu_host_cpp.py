@@ -351,6 +351,14 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
     inv_sigma2 = (f32(1.0) / (scale * scale)).astype(np.float32)
     nC, nA, nB = (900, 600), (800, 500), (850, 550)
     cur = helpers.make_frame_arrays(list(nC), W, H, 41); ka = helpers.make_frame_arrays(list(nA), W, H, 42); kb = helpers.make_frame_arrays(list(nB), W, H, 43)
+    # SearchForInitialization: 220 level-0 cam-1 keypoints of KA (indices 500..719) are near-copies of level-0 cam-1 features of KB
+    init_pairs = {}
+    for k_ in range(220):
+        i1 = 500 + k_; i2 = int(helpers.rand_u32(1, 30000 + k_)[0] % nB[0])
+        ka["octave"][i1] = 0; kb["octave"][i2] = 0
+        ka["descs"][0][i1] = synth.perturbed_queries(kb["descs"][0][i2:i2 + 1].repeat(2, 0), 31000 + k_, 0.03)[0]
+        ka["angle"][i1] = np.float32((float(kb["angle"][i2]) + 25.0 + (140.0 if k_ % 9 == 0 else 0.0)) % 360.0)
+        init_pairs[i1] = i2
     I4 = np.eye(4)
     TB = np.eye(4); TB[:3, 3] = [0.05, -0.02, 0.01]
     Rc = np.array([[np.cos(0.02), 0, np.sin(0.02)], [0, 1, 0], [-np.sin(0.02), 0, np.cos(0.02)]])
@@ -413,6 +421,23 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
             yw = np.linalg.inv(TB[:3, :3]) @ (y2 - TB[:3, 3])
             idsB[i2] = add_point(yw, near_desc(ka, i1, 9800 + k_), int(ka["octave"][i1]), np.zeros(3))
             pool[idsB[i2]]["maxd"] = np.linalg.norm(y1) * 1.2 ** (max(int(ka["octave"][i1]), 1) - 0.5); pool[idsB[i2]]["mind"] = pool[idsB[i2]]["maxd"] / 1.2 ** 7.5
+    # the same through camera 2 (two-camera SearchBySim3, reference :2814-3135): KA's cam-2 features nA[0]+j and KB's cam-2 features
+    inv = np.linalg.inv
+    for j in range(180):
+        i1 = nA[0] + j; i2 = nB[0] + int(helpers.rand_u32(1, 26000 + j)[0] % nB[1])
+        z = 2.0 + 3.0 * ru(1, 26500 + j)[0]
+        x2c2 = K(float(kb["un_x"][i2]), float(kb["un_y"][i2]), z)            # KB camera-2 frame
+        x2 = inv(Rc21) @ (x2c2 - tc21)                                       # KB camera-1 frame
+        x1 = inv(sR21) @ (x2 - t21)                                          # KA camera-1 frame = world (KA pose I)
+        idsA[i1] = add_point(x1, near_desc(kb, i2, 27000 + j), int(kb["octave"][i2]), np.zeros(3))
+        pool[idsA[i1]]["maxd"] = np.linalg.norm(x2c2) * 1.2 ** (max(int(kb["octave"][i2]), 1) - 0.5); pool[idsA[i1]]["mind"] = pool[idsA[i1]]["maxd"] / 1.2 ** 7.5
+        if idsB[i2] < 0 and ru(1, 27500 + j)[0] < 0.8:
+            y1c2 = K(float(ka["un_x"][i1]), float(ka["un_y"][i1]), z)        # KA camera-2 frame
+            y1 = inv(Rc21) @ (y1c2 - tc21)
+            y2 = inv(s12 * R12) @ (y1 - t12)
+            yw = inv(TB[:3, :3]) @ (y2 - TB[:3, 3])
+            idsB[i2] = add_point(yw, near_desc(ka, i1, 28000 + j), int(ka["octave"][i1]), np.zeros(3))
+            pool[idsB[i2]]["maxd"] = np.linalg.norm(y1c2) * 1.2 ** (max(int(ka["octave"][i1]), 1) - 0.5); pool[idsB[i2]]["mind"] = pool[idsB[i2]]["maxd"] / 1.2 ** 7.5
     m12_init = np.full(nA[0], -1, np.int32)
     pre = [i1 for i1 in range(500, 800, 17)]
     for i1 in pre:   # a few pairs are matched already: skipped on both sides
@@ -461,17 +486,32 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
     blob += struct.pack("<f", s12) + R12.astype(np.float32).tobytes() + t12.astype(np.float32).tobytes() + m12_init.tobytes() + struct.pack("<f", th_sim3)
     blob += struct.pack("<i", len(fuse_ids)) + np.array(fuse_ids, np.int32).tobytes() + calib.tobytes()
     blob += struct.pack("<ffii", th_fuse, th_reloc, ORBdist, check_ori)
+    matched_full_init = np.full(sum(nA), -1, np.int32)
+    matched_full_init[np.flatnonzero(ru(sum(nA), 79) < 0.12)] = dummy
+    m12_full_init = np.full(sum(nA), -1, np.int32)
+    pre_full = list(range(500, 800, 19)) + list(range(nA[0], nA[0] + 180, 23))
+    m12_full_init[pre_full] = dummy
+    prev_x = ka["un_x"][:nA[0]].copy(); prev_y = ka["un_y"][:nA[0]].copy(); window_size = 40
+    for i1, i2 in init_pairs.items():       # the "previously matched" position: a few pixels from the KB feature
+        prev_x[i1] = kb["un_x"][i2] + f32(6.0 * (ru(1, 32000 + i1)[0] - 0.5)); prev_y[i1] = kb["un_y"][i2] + f32(6.0 * (ru(1, 33000 + i1)[0] - 0.5))
+    blob += matched_full_init.tobytes() + m12_full_init.tobytes() + prev_x.astype(np.float32).tobytes() + prev_y.astype(np.float32).tobytes()
+    blob += struct.pack("<i", window_size)
     (tmp_path / "case.bin").write_bytes(blob)
     env = dict(os.environ, MORB_DUMP_QUERIES=str(tmp_path / "queries.bin"))
     subprocess.check_call([BIN, "f4", str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], env=env)
 
-    qb = (tmp_path / "queries.bin").read_bytes(); sets = []; off = 0
+    from multi_orb_slam_amd._lib import WINDOW_DTYPE
+    qb = (tmp_path / "queries.bin").read_bytes(); sets = []; windows = {}; off = 0
     while off < len(qb):
         n = struct.unpack_from("<i", qb, off)[0]; off += 4
+        if n < 0:      # the second windows of the set just read (two-camera loop search)
+            windows[len(sets) - 1] = np.frombuffer(qb, WINDOW_DTYPE, -n, off).copy(); off += 24 * -n
+            continue
         q = np.frombuffer(qb, QUERY_DTYPE, n, off).copy(); off += 68 * n
         src = np.frombuffer(qb, np.int32, n, off).copy(); off += 4 * n
         sets.append((q, src))
-    assert len(sets) == 6
+    assert len(sets) == 10 and list(windows) == [4]
+    new_sets = sets[4:8]; sets = sets[:4] + sets[8:]
     buf = (tmp_path / "out.bin").read_bytes(); off = 0
 
     def take(n):
@@ -479,6 +519,8 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
         a = np.frombuffer(buf, np.int32, n, off).copy(); off += 4 * n
         return a
     n1 = take(1)[0]; got_cur = take(sum(nC)); n2 = take(1)[0]; got_matched = take(nA[0]); n3 = take(1)[0]; got_m12 = take(nA[0])
+    n6 = take(1)[0]; got_matched_full = take(sum(nA)); n7 = take(1)[0]; got_m12_full = take(sum(nA))
+    n8 = take(1)[0]; got_vn12 = take(nA[0]); got_prev = take(2 * nA[0]).view(np.float32).reshape(-1, 2)
     n4 = take(1)[0]; got_kb = take(sum(nB)); rep_bad = take(2 * len(pool)).reshape(-1, 2)
     n5 = take(1)[0]; got_ka = take(sum(nA)); got_replace = take(len(loop_ids))
 
@@ -560,6 +602,43 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
             kam[bi[k_]] = loop_ids[src[k_]]
         nf2 += 1
     assert n5 == nf2 and np.array_equal(got_ka, kam) and np.array_equal(got_replace, repl) and n5 > 150
+
+    # ---- two-camera loop search (reference :566-750): windows in both cameras of KA, best over both
+    (q, src), w2 = new_sets[0], windows[4]
+    assert len(q) > 400 and (w2["cam"] == 1).sum() > 200 and (q["cam"] == 0).sum() > 400
+    OFka = oracle.FrameData(**ka)
+    en, emo = oracle.search_by_projection_loop2(OFka, q, w2, (matched_full_init >= 0).astype(np.uint8), 50)
+    exp = np.where(emo >= 0, np.array(loop_ids, np.int32)[src[np.maximum(emo, 0)]], matched_full_init)
+    assert n6 == en and np.array_equal(got_matched_full, exp) and n6 > 200
+    xyz = np.array([pool[loop_ids[i]]["xyz"] for i in src]); xc = xyz @ RS.T + tS; xc2 = xc @ Rc21.T + tc21
+    v1 = q["cam"] == 0; v2 = w2["cam"] == 1
+    assert np.abs(q["u"][v1] - (fx * xc[v1, 0] / xc[v1, 2] + cx)).max() < 2e-2 and np.abs(w2["u"][v2] - (fx * xc2[v2, 0] / xc2[v2, 2] + cx)).max() < 2e-2
+    assert np.abs(w2["v"][v2] - (fy * xc2[v2, 1] / xc2[v2, 2] + cy)).max() < 2e-2 and np.array_equal(w2["max_level"][v1 & v2], q["max_level"][v1 & v2])
+    # ---- two-camera SearchBySim3 (reference :2814-3135): every point in the grid of its own camera
+    (q12, s12src), (q21, s21src) = new_sets[1], new_sets[2]
+    assert (q12["cam"] == 1).sum() > 100 and (q21["cam"] == 1).sum() > 50 and (q12["cam"] == 0).sum() > 100
+    OFkb = oracle.FrameData(**kb)
+    vn1 = np.full(sum(nA), -1); vn2 = np.full(sum(nB), -1)
+    bi, bd = oracle.project_best(OFkb, q12, None, 0); ok = (bi >= 0) & (bd <= 100); vn1[s12src[ok]] = bi[ok]
+    bi, bd = oracle.project_best(OFka, q21, None, 0); ok = (bi >= 0) & (bd <= 100); vn2[s21src[ok]] = bi[ok]
+    exp = m12_full_init.copy(); nf = 0
+    for i1 in range(sum(nA)):
+        if vn1[i1] >= 0 and vn2[vn1[i1]] == i1:
+            exp[i1] = idsB[vn1[i1]]; nf += 1
+    assert n7 == nf and np.array_equal(got_m12_full, exp) and n7 > 150
+    assert (np.flatnonzero(exp != m12_full_init) >= nA[0]).sum() > 30         # matches found through camera 2 as well
+    assert not set(s12src.tolist()) & set(pre_full)
+    # ---- SearchForInitialization (reference :868-994)
+    q, src = new_sets[3]
+    lvl0 = np.flatnonzero(ka["octave"][:nA[0]] == 0)
+    assert np.array_equal(src, lvl0) and (q["radius"] == window_size).all() and (q["max_level"] == 0).all()
+    en, em = oracle.search_for_initialization(oracle.FrameData(**_cam1_only(kb, nB[0])), q, 0.9, bool(check_ori), 50)
+    exp = np.full(nA[0], -1, np.int32); exp[src] = em
+    assert n8 == en and np.array_equal(got_vn12, exp) and n8 > 100
+    exp_prev = np.stack([prev_x, prev_y], 1).astype(np.float32)
+    hit = np.flatnonzero(exp >= 0)
+    exp_prev[hit, 0] = kb["un_x"][exp[hit]]; exp_prev[hit, 1] = kb["un_y"][exp[hit]]
+    assert np.array_equal(got_prev, exp_prev)
 
 
 @pytest.mark.gpu

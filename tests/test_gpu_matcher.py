@@ -331,6 +331,34 @@ def test_cross_top2_from_a_gathered_buffer(world, cams_per_rank):
     matcher.close()
 
 
+@pytest.mark.parametrize("n_per_cam,nq,th,seed,occ_p", [([800, 600], 900, 10.0, 1, 0.1), ([1500, 1500], 3000, 20.0, 2, 0.0), ([300, 200], 1200, 10.0, 3, 0.3)])
+def test_two_window_loop_search_equals_oracle(matcher, n_per_cam, nq, th, seed, occ_p, monkeypatch):
+    """orbm_search_by_projection_windows = SearchByProjection(KeyFrame*, Scw, points, cams, vpMatched, th, Calib), reference
+    src/ORBmatcher.cc:566-750: best candidate over the windows of BOTH cameras, camera 1's candidates first, accepted matches
+    hide their feature from later points -- against the oracle's literal restatement, on the device resolve and on the
+    exact host fallback."""
+    import multi_orb_slam_amd as m
+    fr = helpers.make_frame_arrays(n_per_cam, 640, 480, seed + 60, with_right=False)
+    q, w2 = helpers.make_two_window_queries(fr, nq, seed + 70, th)
+    occ = (helpers.rand_unit(sum(n_per_cam), seed + 80) < occ_p).astype(np.uint8) if occ_p else None
+    F = matcher.frame(m.FrameData(**fr)); OF = oracle.FrameData(**fr)
+    en, emo = oracle.search_by_projection_loop2(OF, q, w2, occ, 50)
+    n, mo = matcher.SearchByProjectionWindows(F, q, w2, 50, occ)
+    assert n == en and np.array_equal(mo, emo) and n > nq // 10
+    cams_hit = np.asarray(fr["cam_of"])[np.flatnonzero(emo >= 0)]
+    assert (cams_hit == 0).sum() > 20 and (cams_hit == 1).sum() > 20          # winners come from both cameras
+    # a point whose camera-1 window is missing still matches through its second window, and the other way round
+    only2 = np.flatnonzero((q["cam"] < 0) & (w2["cam"] >= 0)); only1 = np.flatnonzero((q["cam"] >= 0) & (w2["cam"] < 0))
+    assert np.isin(emo[emo >= 0], only2).any() and np.isin(emo[emo >= 0], only1).any()
+    F.close()
+    monkeypatch.setenv("MORB_HOST_RESOLVE", "1")                                 # the host replay of the same loop
+    mt2 = m.Matcher(0.8, True)
+    F2 = mt2.frame(m.FrameData(**fr))
+    n2, mo2 = mt2.SearchByProjectionWindows(F2, q, w2, 50, occ)
+    assert n2 == en and np.array_equal(mo2, emo)
+    F2.close(); mt2.close()
+
+
 def test_gathered_buffer_with_a_corrupt_trailer_is_an_error_not_an_overrun():
     """A remote rank's count trailer is data from another process: counts that are negative or exceed the block's rows are
     clamped on the device (k_repack_gathered never leaves its block or the contiguous list) and the call reports ORB_E_ARG."""

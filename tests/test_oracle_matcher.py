@@ -193,3 +193,129 @@ def test_project_best_matches_python_restatement():
     qn = q.copy(); qn["ur"] = np.nan
     a = oracle.project_best(OF, qn, None, 1, None); b = oracle.project_best(OF, q, None, 0, None)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def _grid_candidates(fr, cam, x, y, r):
+    """GetFeaturesInArea(cam, x, y, r) without level arguments, restated over plain arrays (reference src/Frame.cc:574-629:
+    cells by round-to-cell insertion, visited ix outer / iy inner, ascending index inside a cell, |dx| < r and |dy| < r)."""
+    W = 64.0 / (fr["bounds"][2] - fr["bounds"][0]); Hh = 48.0 / (fr["bounds"][3] - fr["bounds"][1])
+    f32 = np.float32
+    x0 = max(0, int(np.floor(f32(f32(x - f32(fr["bounds"][0])) - r) * f32(W)))); x1 = min(63, int(np.ceil(f32(f32(x - f32(fr["bounds"][0])) + r) * f32(W))))
+    y0 = max(0, int(np.floor(f32(f32(y - f32(fr["bounds"][1])) - r) * f32(Hh)))); y1 = min(47, int(np.ceil(f32(f32(y - f32(fr["bounds"][1])) + r) * f32(Hh))))
+    if x0 >= 64 or x1 < 0 or y0 >= 48 or y1 < 0:
+        return []
+    out = []
+    cells = fr["_cells"]
+    for ix in range(x0, x1 + 1):
+        for iy in range(y0, y1 + 1):
+            for g in cells.get((cam, ix, iy), ()):
+                if abs(f32(fr["un_x"][g] - x)) < r and abs(f32(fr["un_y"][g] - y)) < r:
+                    out.append(g)
+    return out
+
+
+def _with_cells(fr):
+    f32 = np.float32
+    W = f32(64.0 / (fr["bounds"][2] - fr["bounds"][0])); Hh = f32(48.0 / (fr["bounds"][3] - fr["bounds"][1]))
+    cells = {}
+    for g in range(len(fr["un_x"])):
+        px = int(np.round(f32(f32(fr["un_x"][g]) - f32(fr["bounds"][0])) * W)); py = int(np.round(f32(f32(fr["un_y"][g]) - f32(fr["bounds"][1])) * Hh))
+        # C roundf rounds half away from zero; np.round half to even: equal here except at exact .5, which float32 products of
+        # these random coordinates do not hit (asserted through the comparison with the oracle's grid below)
+        if 0 <= px < 64 and 0 <= py < 48:
+            cells.setdefault((int(fr["cam_of"][g]), px, py), []).append(g)
+    fr = dict(fr); fr["_cells"] = cells
+    return fr
+
+
+def _ham(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_two_camera_loop_search_second_restatement(seed):
+    """The oracle's orc_search_by_projection_loop2 against an independent restatement of reference src/ORBmatcher.cc:566-750 in
+    plain Python loops (own grid walk, own bookkeeping)."""
+    fr = helpers.make_frame_arrays([260, 200], 640, 480, seed + 10, with_right=False)
+    q, w2 = helpers.make_two_window_queries(fr, 300, seed + 20, 12.0)
+    occ = (helpers.rand_unit(460, seed + 30) < 0.15).astype(np.uint8)
+    OF = oracle.FrameData(**fr)
+    en, emo = oracle.search_by_projection_loop2(OF, q, w2, occ, 50)
+    frc = _with_cells(fr)
+    alld = np.concatenate(fr["descs"])
+    matched = {g: -2 for g in np.flatnonzero(occ)}       # vpMatched: pre-existing points
+    n = 0
+    for i in range(len(q)):
+        best, best_idx = 256, -1
+        for (u, v, r, cam, lo, hi) in ((q["u"][i], q["v"][i], q["radius"][i], q["cam"][i], q["min_level"][i], q["max_level"][i]),
+                                       (w2["u"][i], w2["v"][i], w2["radius"][i], w2["cam"][i], w2["min_level"][i], w2["max_level"][i])):
+            if cam < 0:
+                continue
+            for g in _grid_candidates(frc, int(cam), np.float32(u), np.float32(v), np.float32(r)):
+                if g in matched:
+                    continue
+                if fr["octave"][g] < lo or fr["octave"][g] > hi:
+                    continue
+                d = _ham(q["desc"][i], alld[g])
+                if d < best:
+                    best, best_idx = d, g
+        if best <= 50:
+            matched[best_idx] = i; n += 1
+    exp = np.full(460, -1, np.int32)
+    for g, i in matched.items():
+        if i >= 0:
+            exp[g] = i
+    assert n == en and np.array_equal(exp, emo) and n > 60
+
+
+@pytest.mark.parametrize("seed,check_ori", [(1, True), (2, False), (3, True)])
+def test_search_for_initialization_second_restatement(seed, check_ori):
+    """orc_search_for_initialization against plain-Python loops over reference src/ORBmatcher.cc:868-994, including the
+    un-matching of a feature whose match is taken over by a closer keypoint and the rotation-histogram filter."""
+    f2 = helpers.make_frame_arrays([500], 640, 480, seed + 40, with_right=False)
+    f2["octave"] = (helpers.rand_u32(500, seed + 41) % 3 == 0).astype(np.int32) * (1 + helpers.rand_u32(500, seed + 42) % 3).astype(np.int32)  # 2/3 on level 0
+    d2 = f2["descs"][0]
+    nq = 400
+    pick = (helpers.rand_u32(nq, seed + 43) % 500).astype(np.int64)
+    q = np.zeros(nq, QUERY_DTYPE)
+    q["u"] = f2["un_x"][pick] + ((helpers.rand_unit(nq, seed + 44) - 0.5) * 12).astype(np.float32)
+    q["v"] = f2["un_y"][pick] + ((helpers.rand_unit(nq, seed + 45) - 0.5) * 12).astype(np.float32)
+    q["radius"] = 30.0; q["ur"] = np.nan; q["min_level"] = 0; q["max_level"] = 0; q["cam"] = 0
+    q["angle"] = np.mod(f2["angle"][pick] + 20.0 + (helpers.rand_unit(nq, seed + 46) < 0.2) * 150.0, 360.0).astype(np.float32)
+    q["desc"] = synth.perturbed_queries(d2[pick], seed + 47, 0.03); q["desc"][::2] = d2[pick][::2]
+    OF = oracle.FrameData(**f2)
+    en, em = oracle.search_for_initialization(OF, q, 0.9, check_ori, 50)
+    frc = _with_cells(f2)
+    INF = 2 ** 31 - 1
+    m12 = [-1] * nq; m21 = {}; mdist = {}; nm = 0; hist = [[] for _ in range(30)]
+    for i1 in range(nq):
+        best, best2, bi2 = INF, INF, -1
+        for g in _grid_candidates(frc, 0, q["u"][i1], q["v"][i1], np.float32(30.0)):
+            if f2["octave"][g] > 0:          # GetFeaturesInArea(x, y, r, 0, 0): level 0 only
+                continue
+            d = _ham(q["desc"][i1], d2[g])
+            if mdist.get(g, INF) <= d:
+                continue
+            if d < best:
+                best2, best, bi2 = best, d, g
+            elif d < best2:
+                best2 = d
+        if best <= 50 and np.float32(best) < np.float32(np.float32(best2) * np.float32(0.9)):
+            if bi2 in m21:
+                m12[m21[bi2]] = -1; nm -= 1
+            m12[i1] = bi2; m21[bi2] = i1; mdist[bi2] = best; nm += 1
+            if check_ori:
+                rot = np.float32(q["angle"][i1] - f2["angle"][bi2])
+                if rot < 0:
+                    rot = np.float32(rot + np.float32(360.0))
+                b = int(np.floor(np.float32(rot * np.float32(1.0 / 30)) + np.float32(0.5)))
+                hist[0 if b == 30 else b].append(i1)
+    if check_ori:
+        keep = oracle.three_maxima([len(h) for h in hist])
+        for b in range(30):
+            if b not in keep:
+                for i1 in hist[b]:
+                    if m12[i1] >= 0:
+                        m12[i1] = -1; nm -= 1
+    assert nm == en and np.array_equal(np.array(m12, np.int32), em) and en > 50
+    assert len(set(x for x in m12 if x >= 0)) == sum(1 for x in m12 if x >= 0)      # one keypoint per F2 feature
