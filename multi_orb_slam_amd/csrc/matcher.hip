@@ -1555,6 +1555,144 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __r
     }
 }
 
+// The same search on the matrix cores: k_hamming_top2_mfma's tiling (a wave keeps 64 queries as B fragments, the workgroup
+// expands 64 references per step into LDS, the accumulators come out as sort keys distance << 6 | row) with queries and
+// references taken from ONE descriptor list and the rows of a query's OWN camera left out:
+//   * a tile that lies inside the own camera of every query of the wave is skipped altogether (no MFMA, no key updates) -- 64
+//     consecutive queries nearly always belong to one camera, so 1/n_cams of all pairs costs nothing;
+//   * a tile that touches the own segment of some query of the wave takes the masked path (those rows enter as KEY_NONE,
+//     exactly like rows past the end of the slice); every other tile takes the unmasked path of the generic kernel;
+//   * the reported index is the position in the concatenation of the OTHER cameras (index minus the own count behind it).
+// Counts known only on the device come through d_range = {features, first query, queries}; the launch is then sized for the
+// capacity, slices beyond the features produce (256, 256, -1) partials and query blocks beyond the queries return at once.
+// grid.x = reference slices (partials for k_top2_merge when > 1), grid.y = 256 queries.
+__global__ __launch_bounds__(64 * MM_WAVES) void k_cross_top2_mfma(const uint32_t* __restrict__ desc, int n_total,
+                                                                  const int* __restrict__ cam_start, int n_cams, int q_off, int nq,
+                                                                  int slice_len, int* __restrict__ p_idx, int* __restrict__ p_best,
+                                                                  int* __restrict__ p_second, const int* __restrict__ d_range) {
+    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];
+    if (d_range) { n_total = d_range[0]; q_off = d_range[1]; nq = d_range[2]; }
+    if ((int)blockIdx.y * MM_Q_PER_BLOCK >= nq) return;   // (uniform over the workgroup; implies nq >= 1 and n_total >= 1 below)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.y * MM_Q_PER_BLOCK + wave * 64;
+    const uint32_t* __restrict__ q = desc + (size_t)q_off * 8;
+    const uint32_t* __restrict__ r = desc;
+    const int nr = n_total;
+
+    mm_i32x4 bq[2][8];
+    int seg0[2], seg1[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qi = min(q0 + g * 32 + c, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
+        const uint4 lo = p[0], hi = p[1];
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bq[g][ks] = mm_expand16(h ? (w[ks] >> 16) : (w[ks] & 0xffffu));
+        const int qc = q_off + qi;
+        int cam = 0;
+        while (cam + 1 < n_cams && qc >= cam_start[cam + 1]) ++cam;
+        seg0[g] = cam_start[cam]; seg1[g] = cam_start[cam + 1];
+    }
+    // the union of the wave's own segments: [seg_lo, seg_hi); `one_seg`: every query of the wave has the same own camera
+    const int first0 = __builtin_amdgcn_readfirstlane(seg0[0]), first1 = __builtin_amdgcn_readfirstlane(seg1[0]);
+    const bool one_seg = __all(seg0[0] == first0 && seg0[1] == first0 && seg1[0] == first1 && seg1[1] == first1);
+    const int seg_lo = (int)wave_min_u32((unsigned)min(seg0[0], seg0[1]));
+    const int seg_hi = (int)(0x7fffffffu - wave_min_u32(0x7fffffffu - (unsigned)max(seg1[0], seg1[1])));
+    mm_i32x16 cinit;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cinit[e] = 8192 + (e & 3) + 8 * (e >> 2) + 4 * h;
+
+    const int s0 = blockIdx.x * slice_len, s1 = min(nr, s0 + slice_len);  // slice_len is a multiple of 64
+    const int n_tiles = s1 > s0 ? (s1 - s0 + MM_R_TILE - 1) / MM_R_TILE : 0;
+    auto fetch = [&](int t) {
+        const int rr = max(0, min(s0 + min(t, n_tiles - 1) * MM_R_TILE + lane, nr - 1));
+        return *reinterpret_cast<const uint2*>(r + (size_t)rr * 8 + wave * 2);
+    };
+    auto deposit = [&](int buf, uint2 w) {
+        mm_i32x4* base = &s_tile[buf][(h * 8 + wave * 2) * 64 + c];
+        base[0] = mt_expand16(w.x & 0xffffu);
+        base[32] = mt_expand16(w.x >> 16);
+        base[64] = mt_expand16(w.y & 0xffffu);
+        base[96] = mt_expand16(w.y >> 16);
+    };
+
+    constexpr uint32_t KEY_NONE = 256u << 6;
+    uint32_t kb[2] = {KEY_NONE, KEY_NONE}, ks2[2] = {KEY_NONE, KEY_NONE};
+    int where[2] = {-1, -1};  // (block << 5 | row) of the best key, block = 2 * tile + a
+    if (n_tiles > 0) deposit(0, fetch(0));
+    uint2 nxt = fetch(1);
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        const int tj0 = s0 + t * MM_R_TILE;                          // first reference of the tile
+        const int valid = s1 - tj0;                                  // references of this tile inside the slice
+        const bool touches = tj0 < seg_hi && tj0 + MM_R_TILE > seg_lo;  // wave-uniform
+        const bool skip = one_seg && tj0 >= seg_lo && tj0 + min(valid, MM_R_TILE) <= seg_hi;   // the whole tile is the wave's own camera
+        if (!skip) {
+            mm_i32x16 acc[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const mm_i32x4 a0 = s_tile[buf][ks * 64 + lane], a1 = s_tile[buf][(8 + ks) * 64 + lane];
+                acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][ks], ks ? acc[0][0] : cinit, 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][ks], ks ? acc[0][1] : cinit, 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[0][ks], ks ? acc[1][0] : cinit, 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[1][ks], ks ? acc[1][1] : cinit, 0, 0, 0);
+            }
+            deposit(buf ^ 1, nxt);
+            nxt = fetch(t + 2);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const uint32_t before = kb[g];
+                    if (valid >= MM_R_TILE && !touches) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const uint32_t key = (uint32_t)acc[a][g][e];
+                            ks2[g] = mt_umed3(kb[g], ks2[g], key);
+                            kb[g] = min(kb[g], key);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int local = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            const int j = tj0 + local;
+                            const bool out = local >= valid || (j >= seg0[g] && j < seg1[g]);   // past the slice, or the query's own camera
+                            const uint32_t key = out ? KEY_NONE : (uint32_t)acc[a][g][e];
+                            ks2[g] = mt_umed3(kb[g], ks2[g], key);
+                            kb[g] = min(kb[g], key);
+                        }
+                    }
+                    where[g] = kb[g] != before ? (((2 * t + a) << 5) | (int)(kb[g] & 31u)) : where[g];
+                    kb[g] &= ~63u;
+                }
+        } else {
+            deposit(buf ^ 1, nxt);
+            nxt = fetch(t + 2);
+        }
+        __syncthreads();
+    }
+    // the two half-waves hold disjoint references of the same query: full keys distance << 16 | index decide
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t mine_b = ((kb[g] >> 6) << 16) | (uint32_t)(where[g] & 0xffff), mine_s = (ks2[g] >> 6) << 16 | 0xffffu;
+        const uint32_t ob = (uint32_t)__shfl_xor((int)mine_b, 32), os = (uint32_t)__shfl_xor((int)mine_s, 32);
+        const uint32_t nb = min(mine_b, ob), ns = min(max(mine_b, ob), min(mine_s, os));
+        const int qrow = q0 + g * 32 + c;
+        if (h == 0 && qrow < nq) {
+            const size_t o = (size_t)blockIdx.x * nq + qrow;
+            const int best = (int)(nb >> 16);
+            const int j = s0 + (int)(nb & 0xffffu);
+            p_best[o] = best;
+            p_idx[o] = best < 256 ? (j < seg0[g] ? j : j - (seg1[g] - seg0[g])) : -1;   // index among the other cameras
+            p_second[o] = (int)min(ns >> 16, 256u);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 // Plan of an exhaustive top-2: matrix-core kernel (256 queries x one reference slice per workgroup; slices are multiples
 // of 64 references and at most 65536 long: 16-bit indices in the keys) when both sides have at least a tile, else the
@@ -2733,7 +2871,7 @@ struct CrossOut {
     PinnedBuf<int32_t> i, b, s;
     DevBuf<uint8_t> scratch;
     int reserve(int nq, int n) {
-        const int S = top2_slices(nq, n);
+        const int S = std::max(top2_plan(nq, n).S, top2_slices(nq, n));   // (room for either form of the kernel)
         int rc;
         if ((rc = scratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = i.reserve(nq)) || (rc = b.reserve(nq)) ||
             (rc = s.reserve(nq)))
@@ -2747,7 +2885,19 @@ static int cross_enqueue_to(hipStream_t st, const uint8_t* d_desc, int n, const 
                             const int* d_n, int* o_idx, int* o_best, int* o_second, void* scratch) {
     if (nq == 0) return ORB_OK;
     const int qblocks = (nq + 63) / 64;
-    const int S = top2_slices(nq, n);
+    const Top2Plan plan = top2_plan(nq, n);   // (nq, n may be capacities: the kernels take the counts from d_n then)
+    const int S = plan.S;
+    if (plan.mfma) {   // matrix-core form (default from one tile of work on; orbm_use_matrix_cores(0) / MORB_TOP2_MFMA=0: popcount form)
+        int* p = (int*)scratch;
+        int *p_idx = S > 1 ? p : o_idx, *p_best = S > 1 ? p + (size_t)S * nq : o_best, *p_second = S > 1 ? p + 2 * (size_t)S * nq : o_second;
+        hipLaunchKernelGGL(k_cross_top2_mfma, dim3(S, (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK), dim3(64 * MM_WAVES), 0, st,
+                           (const uint32_t*)d_desc, n, d_cam_start, n_cams, q_off, nq, plan.slice_len, p_idx, p_best, p_second, d_n);
+        if (S > 1)
+            hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, o_idx, o_best,
+                               o_second, d_n);
+        MORB_HIP(hipGetLastError());
+        return ORB_OK;
+    }
     if (S <= 1) {  // final results go straight to the mapped pinned mirrors
         hipLaunchKernelGGL(k_cross_top2, dim3(qblocks, 1), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_desc, n, d_cam_start,
                            n_cams, q_off, nq, o_idx, o_best, o_second, d_n);
@@ -2766,7 +2916,7 @@ static int cross_enqueue_to(hipStream_t st, const uint8_t* d_desc, int n, const 
 static int cross_enqueue(orbm_matcher* m, hipStream_t st, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off,
                          int nq, const int* d_n = nullptr) {
     if (nq == 0) return ORB_OK;
-    const int S = top2_slices(nq, n);
+    const int S = std::max(top2_plan(nq, n).S, top2_slices(nq, n));   // (room for either form: the choice can change at run time)
     int rc;
     if ((rc = m->d_cscratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = m->h_c0.reserve(nq)) ||
         (rc = m->h_c1.reserve(nq)) || (rc = m->h_c2.reserve(nq)))

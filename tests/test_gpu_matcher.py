@@ -359,6 +359,48 @@ def test_two_window_loop_search_equals_oracle(matcher, n_per_cam, nq, th, seed, 
     F2.close(); mt2.close()
 
 
+@pytest.mark.parametrize("counts", [[1000, 1000], [1000, 500], [64, 64], [63, 200, 1], [300, 0, 257, 129, 64, 511, 2, 190],
+                                    [4000, 3900, 4031, 3968, 4000, 4027, 3999, 4001], [70], [5, 7]])
+def test_cross_top2_both_forms_equal_brute_force(counts):
+    """orbm_cross_top2 (reference analogue: the unrestricted inner loop of src/ORBmatcher.cc:287-321 between the cameras of a
+    rig) in its matrix-core form and in its xor/popcount form: camera boundaries inside a 64-row tile and inside a 64-query
+    wave, empty cameras, a single camera (nothing to match), duplicates across cameras (first index wins, the duplicate is the
+    second best), the configs[4] size (8 x ~4000: several reference slices, whole tiles skipped as the wave's own camera)."""
+    import multi_orb_slam_amd as m
+    n = sum(counts)
+    base = synth.descriptors(512, 77)
+    descs = []
+    for c, k in enumerate(counts):
+        d = synth.perturbed_queries(base, seed=900 + c, flip_p=0.06)
+        d = np.concatenate([d] * (k // len(d) + 1))[:k].copy() if k else np.zeros((0, 32), np.uint8)
+        if k > len(base):
+            d[len(base):] = synth.perturbed_queries(d[len(base):], seed=950 + c, flip_p=0.2)   # (no exact repeats inside a camera)
+        descs.append(np.ascontiguousarray(d))
+    if len(counts) >= 2 and counts[0] >= 40 and counts[1] >= 40:
+        descs[1][7] = descs[0][31]; descs[1][33] = descs[0][31]          # exact duplicates across cameras
+    fr = helpers.make_frame_arrays(counts, 640, 480, 5)
+    fr["descs"] = descs
+    exp = []
+    for c in range(len(counts)):
+        others = [descs[o] for o in range(len(counts)) if o != c]
+        refs = np.concatenate(others) if others else np.zeros((0, 32), np.uint8)
+        exp.append(oracle.bf_top2(descs[c], refs) if counts[c] else (np.zeros(0, np.int32),) * 3)
+    ebi, ebd, esd = (np.concatenate([e[k] for e in exp]) for k in range(3))
+    try:
+        for on in (1, 0):
+            m.Matcher.use_matrix_cores(on)
+            mt = m.Matcher()
+            F = mt.frame(m.FrameData(**fr))
+            bi, bd, sd = mt.cross_top2(F)
+            assert np.array_equal(bi, ebi) and np.array_equal(bd, ebd) and np.array_equal(sd, esd), "form %d" % on
+            F.close(); mt.close()
+    finally:
+        m.Matcher.use_matrix_cores(-1)
+    if len(counts) >= 2 and counts[0] >= 40 and counts[1] >= 40:
+        assert ebd[31] == 0 and esd[31] == 0 and ebi[31] == 7           # camera-0 feature 31: first duplicate wins, second = 0
+    assert n == len(ebi)
+
+
 def test_gathered_buffer_with_a_corrupt_trailer_is_an_error_not_an_overrun():
     """A remote rank's count trailer is data from another process: counts that are negative or exceed the block's rows are
     clamped on the device (k_repack_gathered never leaves its block or the contiguous list) and the call reports ORB_E_ARG."""
