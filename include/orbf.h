@@ -69,7 +69,9 @@ int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientati
  * occupies a handful of the 256 CUs; with two steps announced two extraction chains run side by side on two extractor
  * instances), and the following steps find their features ready or in flight.  Those steps must then be called with
  * exactly the announced images, in order (same pointers, sizes, strides); otherwise everything in flight is dropped and
- * the images are extracted again.  Host images are read while the intervening steps run; device images must stay
+ * the images are extracted again.  Host images are additionally fingerprinted (32 probes of 64 bytes each) when their
+ * upload is enqueued and when the step arrives: a buffer that was refilled in between is noticed and extracted again
+ * instead of handing out the stale extraction.  Host images are read while the intervening steps run; device images must stay
  * unchanged until the step that consumes them has returned.  Results are bit-identical with and without announcements;
  * rigs of more than 4 cameras ignore them. */
 int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images);

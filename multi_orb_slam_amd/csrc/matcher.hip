@@ -3121,7 +3121,8 @@ struct orbf_frontend {
     orbm_frame* pframe[NSETS] = {nullptr, nullptr, nullptr, nullptr};
     int pframe_W[NSETS] = {0, 0, 0, 0}, pframe_H[NSETS] = {0, 0, 0, 0};
     // extractions in flight for the NEXT steps (enqueued by earlier orbf_step calls after orbf_prefetch), oldest first
-    struct InFlight { std::vector<orbf_image> images; int set = 0, W = 0, H = 0, e = 0; };
+    // fp: content fingerprints of the HOST images taken when their upload was enqueued (see image_fingerprint)
+    struct InFlight { std::vector<orbf_image> images; std::vector<uint64_t> fp; int set = 0, W = 0, H = 0, e = 0; };
     std::deque<InFlight> inflight;
     std::deque<std::vector<orbf_image>> announced;  // declared by orbf_prefetch, not enqueued yet (at most 2)
     int last_e = 0;  // extractor most recently handed a timestep
@@ -3316,11 +3317,14 @@ static int exchange_enqueue(orbf_frontend* f, const orbm_frame* F) {
 }
 
 static bool same_images(const std::vector<orbf_image>& a, const orbf_image* b, int n);
+static bool same_content(const std::vector<uint64_t>& fp, const orbf_image* b, int n);
+static std::vector<uint64_t> image_fingerprints(const orbf_image* images, int n);
 
 int orbf_peek_block(orbf_frontend* f, const orbf_image* images, const uint8_t** d_block, size_t* block_bytes, int* cap_rows) {
     MORB_ARG(f && images && d_block && block_bytes && cap_rows);
     *d_block = nullptr; *block_bytes = 0; *cap_rows = 0;
-    if (f->pending.active || f->inflight.empty() || !same_images(f->inflight.front().images, images, f->n_cams)) return ORB_OK;
+    if (f->pending.active || f->inflight.empty() || !same_images(f->inflight.front().images, images, f->n_cams) ||
+        !same_content(f->inflight.front().fp, images, f->n_cams)) return ORB_OK;
     const orbf_frontend::InFlight& I = f->inflight.front();
     MORB_HIP(hipSetDevice(f->device));
     if (hipEventQuery(f->ev_ready[I.set]) != hipSuccess) { (void)hipGetLastError(); return ORB_OK; }
@@ -3396,6 +3400,36 @@ int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_moti
     int nq = 0, rc;
     if ((rc = queries_from_previous_step(f, motion, &nq))) return rc;
     return orbf_step_impl(f, images, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, flags, out, true);
+}
+
+// An extraction that ran ahead is only valid for the step that consumes it if the images are still the ones that were
+// uploaded.  Pointers, sizes and strides say nothing about a caller that refilled the same buffer in between, so host images
+// also carry a fingerprint of their content: 32 probes of 64 bytes spread over the rows (2 KB per image, well under a
+// microsecond), taken when the upload was enqueued and again when the step arrives.  A mismatch drops what is in flight and the
+// step extracts its images again.  Device images cannot be probed from the host: they must stay unchanged, as orbf.h says.
+static uint64_t image_fingerprint(const orbf_image& im) {
+    if (im.on_device || !im.data || im.width <= 0 || im.height <= 0) return 0;
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)im.width << 32) ^ (uint64_t)im.height;
+    const int span = std::min(64, im.width);
+    for (int k = 0; k < 32; ++k) {
+        const int row = (int)(((long long)k * im.height) / 32);
+        const int col = im.width > span ? (k * 149) % (im.width - span + 1) : 0;
+        const uint8_t* p = im.data + (size_t)row * im.stride + col;
+        for (int b = 0; b + 8 <= span; b += 8) { uint64_t v; memcpy(&v, p + b, 8); h = (h ^ v) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    }
+    return h | 1;
+}
+
+static std::vector<uint64_t> image_fingerprints(const orbf_image* images, int n) {
+    std::vector<uint64_t> fp(n);
+    for (int c = 0; c < n; ++c) fp[c] = image_fingerprint(images[c]);
+    return fp;
+}
+
+static bool same_content(const std::vector<uint64_t>& fp, const orbf_image* b, int n) {
+    if ((int)fp.size() != n) return false;
+    for (int c = 0; c < n; ++c) if (fp[c] != image_fingerprint(b[c])) return false;
+    return true;
 }
 
 static bool same_images(const std::vector<orbf_image>& a, const orbf_image* b, int n) {
@@ -3559,7 +3593,8 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     P.nq = nq; P.flags = flags;
 
     // ---- this step's extraction: already in flight (orbf_prefetch during an earlier step) or enqueued now
-    if (!f->inflight.empty() && same_images(f->inflight.front().images, images, f->n_cams)) {
+    if (!f->inflight.empty() && same_images(f->inflight.front().images, images, f->n_cams) &&
+        same_content(f->inflight.front().fp, images, f->n_cams)) {
         const orbf_frontend::InFlight& I = f->inflight.front();
         P.set = I.set; P.e = I.e; P.W = I.W; P.H = I.H; went_async = 1;
         f->inflight.pop_front();
@@ -3684,6 +3719,7 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         if (async2) {
             orbf_frontend::InFlight I;
             I.images = f->announced.front(); I.set = set2; I.W = w2; I.H = h2; I.e = e2;
+            I.fp = image_fingerprints(I.images.data(), f->n_cams);   // (the uploads were enqueued just above)
             f->inflight.push_back(std::move(I));
             f->announced.pop_front();
         } else {

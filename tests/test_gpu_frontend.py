@@ -370,3 +370,24 @@ def test_rig_sharded_over_ranks_through_the_gathered_blocks(world, n_cams, w, h,
     assert all(g["n_temporal"] > 50 for g in got) and sum(g["n_cross"] for g in got) >= 0
     for fe in fes:
         fe.close()
+
+
+def test_refilled_host_buffer_is_extracted_again_not_served_stale():
+    """orbf_prefetch identifies an announced frame by its pointers -- and, for host images, by a content fingerprint taken
+    when the upload was enqueued: a caller that announces a buffer and then REFILLS it before the step arrives gets the new
+    content extracted, not the extraction that ran ahead on the old bytes."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    params = [m.ExtractorParams(nfeatures=300), m.ExtractorParams(nfeatures=150)]
+    fe = pipeline.FrontEnd(params, 320, 240)
+    ofe = OracleFrontEnd(params, 320, 240)
+    frames = [[synth.image(c, t, 320, 240) for c in range(2)] for t in range(5)]
+    ring = [[frames[t][c].copy() for c in range(2)] for t in range(3)]      # three reusable host buffers per camera
+    assert_same_step(fe.step(ring[0], next_images=ring[1]), ofe.step(frames[0]))       # step 1's extraction now runs ahead ...
+    for c in range(2):
+        ring[1][c][:] = frames[3][c]                                                   # ... and the caller overwrites that buffer
+    assert_same_step(fe.step(ring[1]), ofe.step(frames[3]))                            # the step must see frame 3
+    assert_same_step(fe.step(ring[2], next_images=ring[0]), ofe.step(frames[2]))       # unchanged buffers still ride the prefetch
+    assert_same_step(fe.step(ring[0]), ofe.step(frames[0]))
+    fe.close()
