@@ -3134,6 +3134,7 @@ struct orbf_frontend {
     struct Pending {  // a timestep between orbf_step_begin and orbf_step_end
         bool active = false, async_path = false, fr_persistent = false, block_ready = false, cross_from_set = false, forked = false;
         bool x_enqueued = false;   // this step's exchange went out between begin and end
+        bool inline_match = false; // the step's own extraction was enqueued by this call: its matching follows on the SAME stream
         int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
         orbm_frame* fr = nullptr;
         SearchJob J{nullptr, nullptr, 0, nullptr, false, 0.f, 0, 0, 64, false};
@@ -3151,6 +3152,8 @@ struct orbf_frontend {
     std::vector<float> scale_factors;
     std::chrono::steady_clock::time_point t_entry;
 };
+
+static int getenv_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 static bool small_rig(const orbf_frontend* f) { return f->n_cams <= 4 && f->cap_total <= 8192 && !f->mt->host_resolve; }
 
@@ -3605,7 +3608,13 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         }
         if (!f->announced.empty() && same_images(f->announced.front(), images, f->n_cams)) f->announced.pop_front();
         next_slot(f, &P.e, &P.set);
-        if ((rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS)))) return rc;
+        // Nothing ran ahead for this step (a live rig: the images have only just arrived).  Its matching then goes onto the
+        // extractor's own stream, right behind the extraction chain -- a kernel boundary instead of a cross-stream event
+        // (measured: ~22 us between the chain's last kernel and the projection kernel on the matcher's stream) -- and the
+        // camera-pair top-2 leaves the chain: it forks onto the side stream next to project + resolve instead of standing in
+        // front of them.
+        P.inline_match = small_rig(f) && !f->xcomm && getenv_int("MORB_INLINE_MATCH", 1) != 0;
+        if ((rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match))) return rc;
     }
     // queries go through pinned (device-mapped) staging and are read from there by the projection kernel
     if (nq) {
@@ -3641,10 +3650,17 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     int rc;
     std::vector<orbm_cam_features>& cams = P.cams;
     cams.resize(f->n_cams);
+    const bool inline_match = P.async_path && P.inline_match;
+    struct StreamSwap {   // an inline step issues its matching on the extractor's stream
+        orbm_matcher* m; hipStream_t keep; bool on;
+        ~StreamSwap() { if (on) m->stream = keep; }
+    } swap{m, m->stream, inline_match};
+    if (inline_match) { m->stream = st_e; st = st_e; }
     if (P.async_path) {
-        // matching follows the extraction chain (which ends with the frame grid) through its event; counts are in HBM
+        // matching follows the extraction chain (which ends with the frame grid): through its event, or simply behind it on
+        // the same stream; counts are in HBM
         P.fr = f->pframe[P.set]; P.fr_persistent = true;
-        MORB_HIP(hipStreamWaitEvent(st, f->ev_ready[P.set], 0));  // extraction + frame grid of this step
+        if (!inline_match) MORB_HIP(hipStreamWaitEvent(st, f->ev_ready[P.set], 0));  // extraction + frame grid of this step
         P.n = P.fr->n_total;
     } else {
         rc = orbx_finish(ex);  // synchronises; counts are on the host from here on
@@ -3742,8 +3758,13 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     };
     MORB_HIP(hipSetDevice(f->device));
     orbm_matcher* m = f->mt;
-    hipStream_t st = m->stream;
     orbx_extractor* ex = f->exs[P.e];
+    struct StreamSwap {   // an inline step's matching lives on the extractor's stream (retries of the search go there too)
+        orbm_matcher* m; hipStream_t keep; bool on;
+        ~StreamSwap() { if (on) m->stream = keep; }
+    } swap{m, m->stream, P.async_path && P.inline_match};
+    if (swap.on) m->stream = (hipStream_t)orbx_stream(ex);
+    hipStream_t st = m->stream;
     orbf_frontend::ResultSet& R = f->rs[P.set];
     int rc, nmatches = 0;
     auto t_synced = P.t_impl;
