@@ -1321,6 +1321,7 @@ struct orbx_extractor {
     ChainGraph chain[2][CHAIN_WAYS];
     int chain_next[2] = {0, 0};      // replacement cursor per slot
     bool use_graph = true;           // MORB_CHAIN_GRAPH=0 keeps plain launches
+    bool graph_next_run = true;  // orbx_set_chain_graph: plain launches for the next run (its consumer follows on the same stream)
     orbx_tail_fn tail_fn = nullptr; void* tail_user = nullptr; int tail_tag = 0;  // orbx_set_chain_tail
     int geom_epoch = 0;              // bumped by every rebuild_geometry
     int inflight = 0; unsigned run_seq = 0;
@@ -1660,6 +1661,12 @@ int orbx_finish(orbx_extractor* ex) {
     return finish_device_path(ex);
 }
 
+int orbx_set_chain_graph(orbx_extractor* ex, int on) {
+    MORB_ARG(ex != nullptr);
+    ex->graph_next_run = on != 0;
+    return ORB_OK;
+}
+
 int orbx_set_chain_tail(orbx_extractor* ex, orbx_tail_fn fn, void* user, int tag) {
     MORB_ARG(ex != nullptr);
     ex->tail_fn = fn; ex->tail_user = user; ex->tail_tag = tag;
@@ -1794,7 +1801,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         // hipGraphLaunch (the host cost of enqueueing them is what bounds overlapped timesteps).  Everything the launches
         // carry is in the key: geometry epoch, result mirrors, frame sink.
         const FrameSink sink = allow_async ? ex->sink : FrameSink{};
-        const bool graphable = ex->use_graph && allow_async && !ex->profiling;
+        const bool graphable = ex->use_graph && ex->graph_next_run && allow_async && !ex->profiling;
         bool done = false;
         if (graphable) {
             // a few graphs per slot: a caller rotates through more result sets / frames than there are slots

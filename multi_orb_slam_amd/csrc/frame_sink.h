@@ -35,3 +35,8 @@ extern "C" int orbx_peek_status(const orbx_extractor* ex);  // status of the old
 // tells chains with different tails apart (the callback is NOT invoked when a captured chain is replayed).  fn == NULL: off.
 typedef int (*orbx_tail_fn)(void* user, void* stream);
 extern "C" int orbx_set_chain_tail(orbx_extractor* ex, orbx_tail_fn fn, void* user, int tag);
+// on = 0: the next asynchronous runs issue their launch chain as plain stream launches instead of replaying the captured
+// graph.  A graph replay costs the host one call instead of ten, but work that FOLLOWS it on the same stream starts ~25 us
+// after the graph's last kernel (measured); a step whose matching is waiting right behind its own extraction is better off
+// with plain launches (the host stays ahead of the 5-25 us kernels anyway).
+extern "C" int orbx_set_chain_graph(orbx_extractor* ex, int on);

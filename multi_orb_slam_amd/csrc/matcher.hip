@@ -3614,7 +3614,10 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         // camera-pair top-2 leaves the chain: it forks onto the side stream next to project + resolve instead of standing in
         // front of them.
         P.inline_match = small_rig(f) && !f->xcomm && getenv_int("MORB_INLINE_MATCH", 1) != 0;
-        if ((rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match))) return rc;
+        if (P.inline_match) (void)orbx_set_chain_graph(f->exs[P.e], getenv_int("MORB_INLINE_GRAPH", 0));
+        rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match);
+        if (P.inline_match) (void)orbx_set_chain_graph(f->exs[P.e], 1);
+        if (rc) return rc;
     }
     // queries go through pinned (device-mapped) staging and are read from there by the projection kernel
     if (nq) {
