@@ -1321,6 +1321,7 @@ struct orbx_extractor {
     ChainGraph chain[2][CHAIN_WAYS];
     int chain_next[2] = {0, 0};      // replacement cursor per slot
     bool use_graph = true;           // MORB_CHAIN_GRAPH=0 keeps plain launches
+    bool defer_done = false;      // orbx_set_defer_done: the caller records ev_done of the next asynchronous runs itself (orbx_record_done)
     bool graph_next_run = true;  // orbx_set_chain_graph: plain launches for the next run (its consumer follows on the same stream)
     orbx_tail_fn tail_fn = nullptr; void* tail_user = nullptr; int tail_tag = 0;  // orbx_set_chain_tail
     int geom_epoch = 0;              // bumped by every rebuild_geometry
@@ -1661,6 +1662,19 @@ int orbx_finish(orbx_extractor* ex) {
     return finish_device_path(ex);
 }
 
+int orbx_set_defer_done(orbx_extractor* ex, int on) {
+    MORB_ARG(ex != nullptr);
+    ex->defer_done = on != 0;
+    return ORB_OK;
+}
+
+int orbx_record_done(orbx_extractor* ex) {   // the completion event of the most recently enqueued run, recorded NOW on the stream
+    MORB_ARG(ex && ex->inflight > 0);
+    MORB_HIP(hipSetDevice(ex->device));
+    MORB_HIP(hipEventRecord(ex->ev_done[(ex->run_seq - 1u) & 1u], ex->stream));
+    return ORB_OK;
+}
+
 int orbx_set_chain_graph(orbx_extractor* ex, int on) {
     MORB_ARG(ex != nullptr);
     ex->graph_next_run = on != 0;
@@ -1845,7 +1859,9 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
             if ((rc = launch_tree_describe(ex, st, slot, sink))) return rc;
             if (ex->tail_fn) { ++ex->run_seq; rc = ex->tail_fn(ex->tail_user, (void*)st); --ex->run_seq; if (rc) return rc; }
         }
-        MORB_HIP(hipEventRecord(ex->ev_done[slot], st));
+        // (a caller that puts the run's consumer on the same stream records the completion event itself, behind that work:
+        // an event record with system-scope release standing between two dependent kernels costs ~10 us of queue time each)
+        if (!(allow_async && ex->defer_done)) MORB_HIP(hipEventRecord(ex->ev_done[slot], st));
         ex->prof_valid[slot] = ex->profiling && ex->inflight == 0;  // (one set of stage events: not for overlapped runs)
         ++ex->run_seq; ++ex->inflight; ex->t_begin_async = t_begin;
         if (allow_async) return ORB_OK;

@@ -40,3 +40,7 @@ extern "C" int orbx_set_chain_tail(orbx_extractor* ex, orbx_tail_fn fn, void* us
 // after the graph's last kernel (measured); a step whose matching is waiting right behind its own extraction is better off
 // with plain launches (the host stays ahead of the 5-25 us kernels anyway).
 extern "C" int orbx_set_chain_graph(orbx_extractor* ex, int on);
+// on = 1: asynchronous runs do not record their completion event; the caller does (orbx_record_done), after it has enqueued
+// the run's consumer on the same stream -- the event then no longer stands between the chain and that consumer.
+extern "C" int orbx_set_defer_done(orbx_extractor* ex, int on);
+extern "C" int orbx_record_done(orbx_extractor* ex);

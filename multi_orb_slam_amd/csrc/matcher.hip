@@ -3456,7 +3456,7 @@ static void fill_cam_capacities(orbf_frontend* f, orbx_extractor* ex, orbm_cam_f
 // describe kernel writes the merged frame pframe[set] through a FrameSink (*went_async = 1 unless the extractor took its
 // synchronous host-quadtree path; then the frame was not filled).
 static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, int set, int* W_out, int* H_out, int* went_async,
-                           bool with_cross) {
+                           bool with_cross, bool defer_events = false) {
     orbm_matcher* m = f->mt;
     orbx_extractor* ex = f->exs[e];
     int rc, W = 0, H = 0;
@@ -3547,8 +3547,10 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     if (*went_async) {
         if (!small && (rc = Tail::run(&tail, orbx_stream(ex)))) return rc;
         R.cross_valid = cross_here;
-        hipError_t he = hipEventRecord(f->ev_ready[set], (hipStream_t)orbx_stream(ex));
-        if (he != hipSuccess) { morb::set_error("hipEventRecord: %s", hipGetErrorString(he)); return ORB_E_HIP; }
+        if (!defer_events) {   // (an inline step records its events behind its matching: step_enqueue)
+            hipError_t he = hipEventRecord(f->ev_ready[set], (hipStream_t)orbx_stream(ex));
+            if (he != hipSuccess) { morb::set_error("hipEventRecord: %s", hipGetErrorString(he)); return ORB_E_HIP; }
+        }
     }
     return ORB_OK;
 }
@@ -3614,10 +3616,11 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         // camera-pair top-2 leaves the chain: it forks onto the side stream next to project + resolve instead of standing in
         // front of them.
         P.inline_match = small_rig(f) && !f->xcomm && getenv_int("MORB_INLINE_MATCH", 1) != 0;
-        if (P.inline_match) (void)orbx_set_chain_graph(f->exs[P.e], getenv_int("MORB_INLINE_GRAPH", 0));
-        rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match);
-        if (P.inline_match) (void)orbx_set_chain_graph(f->exs[P.e], 1);
+        if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], getenv_int("MORB_INLINE_GRAPH", 0)); (void)orbx_set_defer_done(f->exs[P.e], 1); }
+        rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match, P.inline_match);
+        if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], 1); (void)orbx_set_defer_done(f->exs[P.e], 0); }
         if (rc) return rc;
+        if (P.inline_match && !went_async) P.inline_match = false;   // (host-quadtree path: everything was synchronous)
     }
     // queries go through pinned (device-mapped) staging and are read from there by the projection kernel
     if (nq) {
@@ -3634,7 +3637,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     // The export block of this step is final already when its extraction chain has completed cleanly (the usual case with
     // steps announced ahead): then nothing of this step can be redone and a caller may ship the block right away.
     P.block_ready = false;
-    if (P.async_path && hipEventQuery(f->ev_ready[P.set]) == hipSuccess) P.block_ready = orbx_peek_status(f->exs[P.e]) == 0;
+    if (P.async_path && !P.inline_match && hipEventQuery(f->ev_ready[P.set]) == hipSuccess) P.block_ready = orbx_peek_status(f->exs[P.e]) == 0;
     else (void)hipGetLastError();
     if ((rc = step_enqueue(f, P, true))) return rc;
     P.active = true;
@@ -3714,6 +3717,12 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         hipError_t je = hipEventRecord(m->ev_join, m->side_stream);
         if (je == hipSuccess) je = hipStreamWaitEvent(st, m->ev_join, 0);
         if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
+    }
+    if (inline_match && first_attempt) {   // the events the extraction left for us: behind the matching, not in front of it
+        const int rd = orbx_record_done(ex);
+        hipError_t he = hipEventRecord(f->ev_ready[P.set], st);
+        if (!rc && rd) rc = rd;
+        if (!rc && he != hipSuccess) { morb::set_error("hipEventRecord: %s", hipGetErrorString(he)); rc = ORB_E_HIP; }
     }
     if (rc) { (void)hipStreamSynchronize(st); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return rc; }
     // ---- native exchange: a block that is final already goes out right behind the step's own matching
