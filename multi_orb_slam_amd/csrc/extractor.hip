@@ -142,6 +142,68 @@ __global__ __launch_bounds__(256) void k_resize(const LevelInfo* __restrict__ L,
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * D.stride + x4) = out;
 }
 
+// One pixel of a pyramid level from the level below it: cv::resize(INTER_LINEAR) in 11-bit fixed point, exactly the arithmetic
+// of k_resize (tables: xt = {sx0 | sx1 << 16, alpha0 | alpha1 << 16}, yt = {row0, row1, beta0, beta1}).
+__device__ __forceinline__ int resize_px(const uint8_t* __restrict__ src, int sstride, const int2 xt, const int4 yt) {
+    const uint8_t* s0 = src + (size_t)yt.x * sstride;
+    const uint8_t* s1 = src + (size_t)yt.y * sstride;
+    const int sx0 = xt.x & 0xffff, sx1 = (unsigned)xt.x >> 16;
+    const int a0 = (short)(xt.y & 0xffff), a1 = xt.y >> 16;
+    const int h0 = s0[sx0] * a0 + s0[sx1] * a1;
+    const int h1 = s1[sx0] * a0 + s1[sx1] * a1;
+    return ((((yt.z * (h0 >> 4)) >> 16) + ((yt.w * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+}
+
+// TWO pyramid levels per launch.  Level `level` is resized from level - 1 as in k_resize; level + 1 does not wait for it: each
+// of its pixels re-derives the 2 x 2 pixels of `level` it interpolates from straight out of level - 1 (integer arithmetic on
+// the same inputs: the same bytes the other half of the launch stores).  The resize chain of an 8-level pyramid is then 4
+// dependent launches instead of 7 -- these kernels take 3-5 us each, so it is the number of launches that costs.
+// grid.y: [0, yblocks_a) rows of `level`, [yblocks_a, ...) rows of level + 1.
+__global__ __launch_bounds__(256) void k_resize2(const LevelInfo* __restrict__ L, int max_levels, int level, int yblocks_a,
+                                                 uint8_t* __restrict__ pyr, size_t cam_pitch,
+                                                 const int2* __restrict__ xtab, const int4* __restrict__ ytab) {
+    const int cam = blockIdx.z;
+    const LevelInfo S = L[cam * max_levels + level - 1];
+    const LevelInfo A = L[cam * max_levels + level];
+    const uint8_t* src = pyr + cam * cam_pitch + S.pyr_off;
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if ((int)blockIdx.y < yblocks_a) {
+        const int y = blockIdx.y * 4 + threadIdx.y;
+        if (y >= A.h || x4 >= A.w) return;
+        const int4 yt = ytab[A.ytab_off + y];
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (x4 + k < A.w) out |= (uint32_t)resize_px(src, S.stride, xtab[A.xtab_off + x4 + k], yt) << (8 * k);
+        *reinterpret_cast<uint32_t*>(pyr + cam * cam_pitch + A.pyr_off + (size_t)y * A.stride + x4) = out;
+        return;
+    }
+    if (level + 1 >= max_levels) return;
+    const LevelInfo B = L[cam * max_levels + level + 1];
+    const int y = ((int)blockIdx.y - yblocks_a) * 4 + threadIdx.y;
+    if (y >= B.h || x4 >= B.w) return;
+    const int4 yb = ytab[B.ytab_off + y];                       // rows of level `level` this output row blends
+    const int4 ya0 = ytab[A.ytab_off + yb.x], ya1 = ytab[A.ytab_off + yb.y];
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x4 + k;
+        if (x < B.w) {
+            const int2 xb = xtab[B.xtab_off + x];
+            const int sx0 = xb.x & 0xffff, sx1 = (unsigned)xb.x >> 16;
+            const int a0 = (short)(xb.y & 0xffff), a1 = xb.y >> 16;
+            const int2 xa0 = xtab[A.xtab_off + sx0], xa1 = xtab[A.xtab_off + sx1];
+            const int p00 = resize_px(src, S.stride, xa0, ya0), p01 = resize_px(src, S.stride, xa1, ya0);
+            const int p10 = resize_px(src, S.stride, xa0, ya1), p11 = resize_px(src, S.stride, xa1, ya1);
+            const int h0 = p00 * a0 + p01 * a1;
+            const int h1 = p10 * a0 + p11 * a1;
+            const int v = ((((yb.z * (h0 >> 4)) >> 16) + ((yb.w * (h1 >> 4)) >> 16) + 2) >> 2);
+            out |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(pyr + cam * cam_pitch + B.pyr_off + (size_t)y * B.stride + x4) = out;
+}
+
 // ------------------------------------------------------------------------------------------------ K2 + K3
 // FAST-9/16 corner score of the pixel at t: max over the 16 arcs of 9 contiguous ring pixels of the minimum
 // |centre - ring| with a common sign, minus 1 (== cornerScore<16>, threshold-independent for corners; App. A-2).
@@ -1709,16 +1771,31 @@ void* orbx_done_event(const orbx_extractor* ex) { return ex ? (void*)ex->ev_done
 static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st) {
     const int ML = ex->max_levels;
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[0], st));
-    for (int l = 1; l < ML; ++l) {
-        int mw = 0, mh = 0;
+    // two levels per launch (k_resize2): (1,2) (3,4) (5,6) (7) for the usual 8 levels; MORB_PYRAMID_PAIRS=0: one launch per level
+    static const bool pairs = [] { const char* e = getenv("MORB_PYRAMID_PAIRS"); return !(e && atoi(e) == 0); }();
+    auto level_dims = [&](int l, int* mw, int* mh) {
+        *mw = 0; *mh = 0;
+        if (l >= ML) return;
         for (int c = 0; c < ex->n_cams; ++c) {
             const LevelInfo& Lv = ex->levels[(size_t)c * ML + l];
-            mw = std::max(mw, Lv.w); mh = std::max(mh, Lv.h);
+            *mw = std::max(*mw, Lv.w); *mh = std::max(*mh, Lv.h);
         }
+    };
+    for (int l = 1; l < ML; l += pairs ? 2 : 1) {
+        int mw = 0, mh = 0, mw2 = 0, mh2 = 0;
+        level_dims(l, &mw, &mh);
+        if (pairs) level_dims(l + 1, &mw2, &mh2);
         if (mw == 0) continue;
-        dim3 grid((mw + 255) / 256, (mh + 3) / 4, ex->n_cams), block(64, 4, 1);
-        hipLaunchKernelGGL(k_resize, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
-                           (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
+        if (!pairs) {
+            dim3 grid((mw + 255) / 256, (mh + 3) / 4, ex->n_cams), block(64, 4, 1);
+            hipLaunchKernelGGL(k_resize, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
+                               (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
+        } else {
+            const int yb_a = (mh + 3) / 4, yb_b = (mh2 + 3) / 4;
+            dim3 grid((mw + 255) / 256, yb_a + yb_b, ex->n_cams), block(64, 4, 1);
+            hipLaunchKernelGGL(k_resize2, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, yb_a, ex->d_pyr.p, ex->cam_pitch,
+                               (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
+        }
     }
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[1], st));
     // per-cell FAST / NMS / threshold / compaction
