@@ -179,29 +179,23 @@ __global__ __launch_bounds__(256) void k_resize2(const LevelInfo* __restrict__ L
         return;
     }
     if (level + 1 >= max_levels) return;
+    // (one pixel per thread here: four source pixels to re-derive for each, i.e. the same work per thread as the other half)
     const LevelInfo B = L[cam * max_levels + level + 1];
     const int y = ((int)blockIdx.y - yblocks_a) * 4 + threadIdx.y;
-    if (y >= B.h || x4 >= B.w) return;
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (y >= B.h || x >= B.w) return;
     const int4 yb = ytab[B.ytab_off + y];                       // rows of level `level` this output row blends
     const int4 ya0 = ytab[A.ytab_off + yb.x], ya1 = ytab[A.ytab_off + yb.y];
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = x4 + k;
-        if (x < B.w) {
-            const int2 xb = xtab[B.xtab_off + x];
-            const int sx0 = xb.x & 0xffff, sx1 = (unsigned)xb.x >> 16;
-            const int a0 = (short)(xb.y & 0xffff), a1 = xb.y >> 16;
-            const int2 xa0 = xtab[A.xtab_off + sx0], xa1 = xtab[A.xtab_off + sx1];
-            const int p00 = resize_px(src, S.stride, xa0, ya0), p01 = resize_px(src, S.stride, xa1, ya0);
-            const int p10 = resize_px(src, S.stride, xa0, ya1), p11 = resize_px(src, S.stride, xa1, ya1);
-            const int h0 = p00 * a0 + p01 * a1;
-            const int h1 = p10 * a0 + p11 * a1;
-            const int v = ((((yb.z * (h0 >> 4)) >> 16) + ((yb.w * (h1 >> 4)) >> 16) + 2) >> 2);
-            out |= (uint32_t)(v & 0xff) << (8 * k);
-        }
-    }
-    *reinterpret_cast<uint32_t*>(pyr + cam * cam_pitch + B.pyr_off + (size_t)y * B.stride + x4) = out;
+    const int2 xb = xtab[B.xtab_off + x];
+    const int sx0 = xb.x & 0xffff, sx1 = (unsigned)xb.x >> 16;
+    const int a0 = (short)(xb.y & 0xffff), a1 = xb.y >> 16;
+    const int2 xa0 = xtab[A.xtab_off + sx0], xa1 = xtab[A.xtab_off + sx1];
+    const int p00 = resize_px(src, S.stride, xa0, ya0), p01 = resize_px(src, S.stride, xa1, ya0);
+    const int p10 = resize_px(src, S.stride, xa0, ya1), p11 = resize_px(src, S.stride, xa1, ya1);
+    const int h0 = p00 * a0 + p01 * a1;
+    const int h1 = p10 * a0 + p11 * a1;
+    const int v = ((((yb.z * (h0 >> 4)) >> 16) + ((yb.w * (h1 >> 4)) >> 16) + 2) >> 2);
+    pyr[cam * cam_pitch + B.pyr_off + (size_t)y * B.stride + x] = (uint8_t)(v & 0xff);
 }
 
 // ------------------------------------------------------------------------------------------------ K2 + K3
@@ -1792,7 +1786,7 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st) {
                                (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
         } else {
             const int yb_a = (mh + 3) / 4, yb_b = (mh2 + 3) / 4;
-            dim3 grid((mw + 255) / 256, yb_a + yb_b, ex->n_cams), block(64, 4, 1);
+            dim3 grid(std::max((mw + 255) / 256, (mw2 + 63) / 64), yb_a + yb_b, ex->n_cams), block(64, 4, 1);
             hipLaunchKernelGGL(k_resize2, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, yb_a, ex->d_pyr.p, ex->cam_pitch,
                                (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
         }
