@@ -3233,9 +3233,9 @@ int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientati
 }
 
 static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
-                          orbf_result* out, bool queries_in_pinned);
+                          orbf_result* out, bool queries_in_pinned, const orbf_motion* motion = nullptr);
 static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
-                                bool queries_in_pinned, int* block_ready);
+                                bool queries_in_pinned, int* block_ready, const orbf_motion* motion = nullptr);
 static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out);
 static int orbf_drain(orbf_frontend* f);
 
@@ -3372,9 +3372,7 @@ static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motio
 int orbf_step_motion_begin(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, int* block_ready) {
     MORB_ARG(f && images && motion);
     f->t_entry = std::chrono::steady_clock::now();
-    int nq = 0, rc;
-    if ((rc = queries_from_previous_step(f, motion, &nq))) return rc;
-    rc = orbf_step_begin_impl(f, images, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, flags, true, block_ready);
+    int rc = orbf_step_begin_impl(f, images, nullptr, 0, flags, true, block_ready, motion);
     if (rc) f->pending.active = false;
     return rc;
 }
@@ -3400,9 +3398,7 @@ static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motio
 int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out) {
     MORB_ARG(f && images && motion && out);
     f->t_entry = std::chrono::steady_clock::now();
-    int nq = 0, rc;
-    if ((rc = queries_from_previous_step(f, motion, &nq))) return rc;
-    return orbf_step_impl(f, images, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, flags, out, true);
+    return orbf_step_impl(f, images, nullptr, 0, flags, out, true, motion);
 }
 
 // An extraction that ran ahead is only valid for the step that consumes it if the images are still the ones that were
@@ -3582,8 +3578,12 @@ static void next_slot(orbf_frontend* f, int* e, int* set) {
 // only needs the step's export block -- the multi-GPU exchange -- when begin reported the block ready.
 static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_attempt);
 
+static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motion, int* nq_out);
+
+// motion != NULL: the queries are built here from the previous step's features (orbf_step_motion) -- AFTER this step's
+// extraction has been enqueued, so that the GPU is already working while the host projects the points.
 static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
-                                bool queries_in_pinned, int* block_ready) {
+                                bool queries_in_pinned, int* block_ready, const orbf_motion* motion) {
     orbf_frontend::Pending& P = f->pending;
     MORB_ARG(!P.active);
     P = orbf_frontend::Pending();
@@ -3621,6 +3621,11 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], 1); (void)orbx_set_defer_done(f->exs[P.e], 0); }
         if (rc) return rc;
         if (P.inline_match && !went_async) P.inline_match = false;   // (host-quadtree path: everything was synchronous)
+    }
+    if (motion) {
+        if ((rc = queries_from_previous_step(f, motion, &nq))) return rc;
+        queries = reinterpret_cast<const orbm_query*>(f->h_queries.p); queries_in_pinned = true;
+        P.nq = nq;
     }
     // queries go through pinned (device-mapped) staging and are read from there by the projection kernel
     if (nq) {
@@ -3874,8 +3879,8 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
 }
 
 static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
-                          orbf_result* out, bool queries_in_pinned) {
-    int rc = orbf_step_begin_impl(f, images, queries, nq, flags, queries_in_pinned, nullptr);
+                          orbf_result* out, bool queries_in_pinned, const orbf_motion* motion) {
+    int rc = orbf_step_begin_impl(f, images, queries, nq, flags, queries_in_pinned, nullptr, motion);
     if (rc) { f->pending.active = false; return rc; }
     return orbf_step_end_impl(f, out);
 }
