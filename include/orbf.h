@@ -111,6 +111,12 @@ int orbf_export_features(orbf_frontend* f, orbf_device_features* out);
 int orbf_exchange_unique_id(uint8_t* out128);
 int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int rank);
 int orbf_exchange_active(const orbf_frontend* f);   /* world size, 0 = off */
+/* The same exchange between `world` front ends of ONE process on ONE device, each driven by its own host thread (RCCL does
+ * not admit two ranks on one GPU): every member calls this with the same `group` id and its own rank, then steps as a rank
+ * would -- a step's all-gather rendezvouses the members' threads and copies the blocks device-to-device behind the producers'
+ * events.  For machines with fewer GPUs than ranks (tests, the 1-GPU CI box); every kernel and every ordering decision of
+ * the multi-GPU step is the product code unchanged.  All members must keep stepping in lockstep (one collective per step). */
+int orbf_exchange_init_loopback(orbf_frontend* f, int group, int world, int rank);
 int orbf_exchange_shutdown(orbf_frontend* f);       /* back to rank-local steps (orbf_destroy does it too) */
 
 int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out);

@@ -160,6 +160,7 @@ def lib():
     L.orbf_exchange_unique_id.argtypes = [vp]
     L.orbf_exchange_init.argtypes = [vp, vp, i32, i32]
     L.orbf_exchange_active.argtypes = [vp]
+    L.orbf_exchange_init_loopback.argtypes = [vp, i32, i32, i32]
     L.orbf_exchange_shutdown.argtypes = [vp]
     L.orbf_peek_block.argtypes = [vp, vp, vp, vp, vp]
     L.orbm_cross_top2_gathered_views.argtypes = [vp, vp, vp, vp]

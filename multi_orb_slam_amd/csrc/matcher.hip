@@ -3048,6 +3048,8 @@ int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int wor
 // ---- native multi-GPU exchange: RCCL's C API resolved at run time (the copy torch.distributed already loaded, else the
 // ROCm one), one communicator per front end, the all-gather issued on the matcher's side stream from inside the step
 #include <dlfcn.h>
+#include <condition_variable>
+#include <map>
 namespace {
 struct XUniqueId { char internal[128]; };   // ncclUniqueId (rccl.h:43)
 struct RcclApi {
@@ -3084,6 +3086,58 @@ int rccl_fail(const char* what, int r) {
     RcclApi& R = rccl();
     morb::set_error("%s failed: %s", what, R.GetErrorString ? R.GetErrorString(r) : "RCCL error");
     return ORB_E_HIP;
+}
+
+// ---- loopback transport: the same exchange between front ends of ONE process on ONE device (one host thread per "rank").
+// RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so a 1-GPU machine could otherwise never run the world > 1
+// path of orbf_step.  The all-gather becomes: every rank announces its block and an event behind the work that produced it,
+// all ranks rendezvous on the host, then every rank copies every block into its own receive buffer on ITS stream, behind the
+// producers' events.  Same contract as the collective (every rank calls once per step, same block size); everything
+// downstream -- k_repack_gathered, the rig-wide top-2, the early / late placement of the exchange inside a step -- is the
+// product code unchanged.
+struct LoopGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    int world = 0, arrived = 0, members = 0;
+    unsigned long generation = 0;
+    bool broken = false;
+    std::vector<const void*> send;
+    std::vector<hipEvent_t> ev;
+};
+struct LoopComm { LoopGroup* g; int rank; };
+std::mutex g_loop_mu;
+std::map<int, LoopGroup*> g_loop_groups;
+
+int loop_allgather(LoopComm* C, const void* sendbuf, void* recvbuf, size_t bytes, hipStream_t st) {
+    LoopGroup& G = *C->g;
+    {
+        std::unique_lock<std::mutex> lk(G.mu);
+        if (G.broken) { morb::set_error("loopback exchange: a member has left the group"); return ORB_E_ARG; }
+        G.send[C->rank] = sendbuf;
+        if (hipEventRecord(G.ev[C->rank], st) != hipSuccess) { morb::set_error("loopback exchange: hipEventRecord failed"); return ORB_E_HIP; }
+        const unsigned long gen = G.generation;
+        if (++G.arrived == G.world) { G.arrived = 0; ++G.generation; G.cv.notify_all(); }
+        else if (!G.cv.wait_for(lk, std::chrono::seconds(20), [&] { return G.generation != gen || G.broken; }) || G.broken) {
+            G.broken = true; G.cv.notify_all();
+            morb::set_error("loopback exchange: rank %d waited 20 s for the other ranks of its group", C->rank);
+            return ORB_E_HIP;
+        }
+    }
+    for (int s = 0; s < G.world; ++s) {
+        MORB_HIP(hipStreamWaitEvent(st, G.ev[s], 0));
+        MORB_HIP(hipMemcpyAsync((uint8_t*)recvbuf + (size_t)s * bytes, G.send[s], bytes, hipMemcpyDeviceToDevice, st));
+    }
+    {   // nobody re-records its event / republishes its block before every rank has enqueued this round's copies
+        std::unique_lock<std::mutex> lk(G.mu);
+        const unsigned long gen = G.generation;
+        if (++G.arrived == G.world) { G.arrived = 0; ++G.generation; G.cv.notify_all(); }
+        else if (!G.cv.wait_for(lk, std::chrono::seconds(20), [&] { return G.generation != gen || G.broken; }) || G.broken) {
+            G.broken = true; G.cv.notify_all();
+            morb::set_error("loopback exchange: rank %d waited 20 s for the other ranks of its group", C->rank);
+            return ORB_E_HIP;
+        }
+    }
+    return ORB_OK;
 }
 }  // namespace
 
@@ -3128,6 +3182,7 @@ struct orbf_frontend {
     int last_e = 0;  // extractor most recently handed a timestep
     bool poll_ok = true;     // MORB_POLL=0: orbf_step_end always waits with hipStreamSynchronize
     void* xcomm = nullptr; int xworld = 0, xrank = 0;   // native multi-GPU exchange (orbf_exchange_init)
+    bool xloop = false;                                  // ... over the in-process loopback transport (orbf_exchange_init_loopback)
     DevBuf<uint8_t> d_xrecv;                            // the gathered export blocks of all ranks
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path ...
     int clean_steps = 0;     // ... and set again after a few steps that stayed on the device path
@@ -3191,7 +3246,7 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
 void orbf_destroy(orbf_frontend* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    if (f->xcomm) { if (f->mt) (void)hipStreamSynchronize(f->mt->side_stream); (void)rccl().CommDestroy(f->xcomm); f->xcomm = nullptr; }
+    if (f->xcomm) (void)orbf_exchange_shutdown(f);
     f->d_xrecv.release();
     for (int e = 0; e < 2; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
     if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
@@ -3297,13 +3352,63 @@ int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int r
 
 int orbf_exchange_active(const orbf_frontend* f) { return f && f->xcomm ? f->xworld : 0; }
 
+int orbf_exchange_init_loopback(orbf_frontend* f, int group, int world, int rank) {
+    MORB_ARG(f && world >= 1 && rank >= 0 && rank < world && world * f->n_cams <= 512 && !f->xcomm);
+    MORB_HIP(hipSetDevice(f->device));
+    const size_t block = (size_t)f->cap_total * 32 + ORBM_BLOCK_TRAILER;
+    int rc = f->d_xrecv.reserve((size_t)world * block);
+    if (rc) return rc;
+    LoopGroup* G = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_loop_mu);
+        auto it = g_loop_groups.find(group);
+        if (it == g_loop_groups.end()) {
+            G = new LoopGroup();
+            G->world = world; G->send.assign(world, nullptr); G->ev.assign(world, nullptr);
+            for (int r = 0; r < world; ++r)
+                if (hipEventCreateWithFlags(&G->ev[r], hipEventDisableTiming) != hipSuccess) {
+                    for (hipEvent_t e : G->ev) if (e) (void)hipEventDestroy(e);
+                    delete G;
+                    morb::set_error("loopback exchange: hipEventCreate failed");
+                    return ORB_E_HIP;
+                }
+            g_loop_groups[group] = G;
+        } else {
+            G = it->second;
+            if (G->world != world || G->members >= world) { morb::set_error("loopback group %d: world size mismatch or group full", group); return ORB_E_ARG; }
+        }
+        std::lock_guard<std::mutex> lk2(G->mu);
+        ++G->members;
+    }
+    f->xcomm = new LoopComm{G, rank}; f->xworld = world; f->xrank = rank; f->xloop = true;
+    return ORB_OK;
+}
+
 int orbf_exchange_shutdown(orbf_frontend* f) {
     MORB_ARG(f != nullptr);
     if (!f->xcomm) return ORB_OK;
     MORB_HIP(hipSetDevice(f->device));
     if (f->mt) { (void)hipStreamSynchronize(f->mt->side_stream); (void)hipStreamSynchronize(f->mt->stream); }
-    (void)rccl().CommDestroy(f->xcomm);
-    f->xcomm = nullptr; f->xworld = 0; f->xrank = 0;
+    if (f->xloop) {
+        LoopComm* C = static_cast<LoopComm*>(f->xcomm);
+        LoopGroup* G = C->g;
+        bool last = false;
+        {
+            std::lock_guard<std::mutex> lk(G->mu);
+            G->broken = true; G->cv.notify_all();          // (a group that lost a member cannot exchange any more)
+            last = --G->members == 0;
+        }
+        if (last) {
+            std::lock_guard<std::mutex> lk(g_loop_mu);
+            for (auto it = g_loop_groups.begin(); it != g_loop_groups.end(); ++it) if (it->second == G) { g_loop_groups.erase(it); break; }
+            for (hipEvent_t e : G->ev) if (e) (void)hipEventDestroy(e);
+            delete G;
+        }
+        delete C;
+    } else {
+        (void)rccl().CommDestroy(f->xcomm);
+    }
+    f->xcomm = nullptr; f->xworld = 0; f->xrank = 0; f->xloop = false;
     return ORB_OK;
 }
 
@@ -3314,8 +3419,13 @@ static int exchange_enqueue(orbf_frontend* f, const orbm_frame* F) {
     orbm_matcher* m = f->mt;
     const size_t block = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
     MORB_ARG(F->desc_rows == f->cap_total);
-    const int r = R.AllGather(F->b->d_desc.p, f->d_xrecv.p, block, /*ncclUint8*/ 1, f->xcomm, m->side_stream);
-    if (r) return rccl_fail("ncclAllGather", r);
+    if (f->xloop) {
+        const int rc = loop_allgather(static_cast<LoopComm*>(f->xcomm), F->b->d_desc.p, f->d_xrecv.p, block, m->side_stream);
+        if (rc) return rc;
+    } else {
+        const int r = R.AllGather(F->b->d_desc.p, f->d_xrecv.p, block, /*ncclUint8*/ 1, f->xcomm, m->side_stream);
+        if (r) return rccl_fail("ncclAllGather", r);
+    }
     return orbm_cross_top2_gathered_enqueue(m, f->d_xrecv.p, f->xworld, block, F->desc_rows, f->n_cams, f->xrank, nullptr, 0);
 }
 

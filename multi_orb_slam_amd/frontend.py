@@ -133,6 +133,10 @@ class NativeFrontEnd:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         check(_lib.lib().orbf_exchange_init(self._h, buf, world, rank))
 
+    def exchange_init_loopback(self, group, world, rank):
+        """Join an in-process exchange group (orbf_exchange_init_loopback): `world` front ends on one device, one thread each."""
+        check(_lib.lib().orbf_exchange_init_loopback(self._h, group, world, rank))
+
     def exchange_shutdown(self):
         check(_lib.lib().orbf_exchange_shutdown(self._h))
 

@@ -391,3 +391,65 @@ def test_refilled_host_buffer_is_extracted_again_not_served_stale():
     assert_same_step(fe.step(ring[2], next_images=ring[0]), ofe.step(frames[2]))       # unchanged buffers still ride the prefetch
     assert_same_step(fe.step(ring[0]), ofe.step(frames[0]))
     fe.close()
+
+
+@pytest.mark.parametrize("world,n_cams,w,h,nf,ahead", [(4, 4, 640, 480, 1000, 0), (4, 4, 640, 480, 1000, 2), (2, 4, 320, 240, 300, 2), (8, 8, 320, 240, 200, 1)])
+def test_world_size_n_native_steps_over_the_loopback_exchange(world, n_cams, w, h, nf, ahead):
+    """The multi-GPU step with world > 1, end to end through orbf_step: `world` front ends (one host thread each, the cameras
+    of ONE rig sharded over them -- configs[3]: one 640x480 camera @1000 per rank) exchange their export blocks from INSIDE the
+    native step, exactly as over RCCL, through the in-process loopback transport (RCCL refuses two ranks on one GPU).  Every
+    rank's keypoints, descriptors, stereo, temporal matches and rig-wide cross-camera top-2 must equal the oracle's; with
+    steps announced ahead some ranks ship their block early (between begin and end), others late -- any mix must work."""
+    import threading
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from multi_orb_slam_amd.dist import shard_cameras
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    per = n_cams // world
+    T = 6
+    frames = [{g: synth.image(g, t, w, h) for g in range(n_cams)} for t in range(T)]
+    results = [[None] * T for _ in range(world)]
+    errors = []
+    group = 1000 + world * 10 + ahead
+
+    def rank_main(r):
+        try:
+            mine = shard_cameras(n_cams, world, r)
+            fe = pipeline.FrontEnd([m.ExtractorParams(nfeatures=nf)] * per, w, h, rank=r, world_size=world, global_cams=mine)
+            fe.fe.exchange_init_loopback(group, world, r)
+            fe.native_exchange = True
+            assert fe.fe.exchange_world == world
+            announced = 0
+            for t in range(T):
+                while announced < min(t + ahead, T - 1):
+                    announced += 1
+                    fe.announce([frames[announced][g] for g in mine])
+                announced = max(announced, t)
+                results[r][t] = fe.step([frames[t][g] for g in mine])
+            fe.fe.exchange_shutdown()
+            fe.close()
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert not errors and not any(th.is_alive() for th in threads), errors
+    ofes = [OracleFrontEnd([m.ExtractorParams(nfeatures=nf)] * per, w, h, shard_cameras(n_cams, world, r)) for r in range(world)]
+    for t in range(T):
+        desc_of = {}
+        for r in range(world):
+            got = results[r][t]
+            off = np.concatenate([[0], np.cumsum(got["counts"])])
+            for c, g in enumerate(shard_cameras(n_cams, world, r)):
+                desc_of[g] = got["desc"][off[c]:off[c + 1]]
+        for r in range(world):
+            mine = shard_cameras(n_cams, world, r)
+            got = results[r][t]
+            assert got["rig_counts"] == [len(desc_of[g]) for g in range(n_cams)]
+            exp = ofes[r].step([frames[t][g] for g in mine],
+                               other_descs=lambda c, mine=mine: [desc_of[g] for g in range(n_cams) if g != mine[c]])
+            assert_same_step(got, exp)
+    assert all(results[r][T - 1]["n_temporal"] > 30 for r in range(world))
