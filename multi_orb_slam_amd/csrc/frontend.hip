@@ -1,0 +1,819 @@
+// frontend.hip -- orbf_* (include/orbf.h): one front-end timestep as ONE native call -- N-camera extraction, frame assembly
+// on the device, the tracking-path projection search and the cross-camera top-2 -- with consecutive timesteps overlapped
+// (orbf_prefetch), isolated timesteps kept on one stream, and the multi-GPU descriptor exchange issued from inside the step.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+#include "../../include/orbm.h"
+#include "orb_common.h"
+#include "frame_sink.h"
+#include "matcher_internal.h"
+#include <deque>
+#include "../../include/orbf.h"
+
+using namespace morb;
+
+
+struct orbf_frontend {
+    int device = 0, n_cams = 0, max_w = 0, max_h = 0;
+    orbx_extractor* ex = nullptr;        // == exs[0]: the extractor isolated steps run on (orbf_extractor)
+    orbx_extractor* exs[2] = {nullptr, nullptr};  // small rigs: consecutive overlapped timesteps alternate between two
+    orbm_matcher* mt = nullptr;
+    std::vector<const float*> d_depth;
+    std::vector<int> depth_stride;
+    std::vector<int32_t> counts, cam_cap;
+    float mbf = 40.f;
+    int th_high = ORBM_TH_HIGH, check_ori = 1;
+    orb_calibration calib = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // k1 == 0: no undistortion (orbf_set_calibration)
+    int cap_total = 0;
+    // pinned host result buffers.  The per-feature results exist twice: the extraction of the NEXT timestep (orbf_prefetch)
+    // fills the other set while the caller still reads this step's.
+    static constexpr int NSETS = 4;  // this step's (held by the caller) + two timesteps in flight + the one being assigned
+    struct ResultSet {
+        PinnedBuf<orb_keypoint> kps; PinnedBuf<uint8_t> desc; PinnedBuf<float> ur, depth, unx, uny;
+        CrossOut cross;            // cross-camera top-2 of the step, computed at the end of its extraction chain
+        bool cross_valid = false;  // ... when the chain was enqueued with cross matching on
+    } rs[NSETS];
+    int last_flags = 0;  // flags of the most recent step: what announced steps are assumed to want
+    int cur = 0;       // set holding the results of the last completed step
+    int last_set = 0;  // set most recently handed to an extraction (sets are handed out round robin)
+    morb::StageBuf h_queries;   // this step's queries: written by the host, read once by k_project
+    PinnedBuf<int32_t> h_match;
+    // Small rigs (<= 4 cameras): one persistent frame per result set, filled by the extractor's describe kernel (FrameSink)
+    orbm_frame* pframe[NSETS] = {nullptr, nullptr, nullptr, nullptr};
+    int pframe_W[NSETS] = {0, 0, 0, 0}, pframe_H[NSETS] = {0, 0, 0, 0};
+    // extractions in flight for the NEXT steps (enqueued by earlier orbf_step calls after orbf_prefetch), oldest first
+    // fp: content fingerprints of the HOST images taken when their upload was enqueued (see image_fingerprint)
+    struct InFlight { std::vector<orbf_image> images; std::vector<uint64_t> fp; int set = 0, W = 0, H = 0, e = 0; };
+    std::deque<InFlight> inflight;
+    std::deque<std::vector<orbf_image>> announced;  // declared by orbf_prefetch, not enqueued yet (at most 2)
+    int last_e = 0;  // extractor most recently handed a timestep
+    bool poll_ok = true;     // MORB_POLL=0: orbf_step_end always waits with hipStreamSynchronize
+    void* xcomm = nullptr; int xworld = 0, xrank = 0;   // native multi-GPU exchange (orbf_exchange_init)
+    bool xloop = false;                                  // ... over the in-process loopback transport (orbf_exchange_init_loopback)
+    DevBuf<uint8_t> d_xrecv;                            // the gathered export blocks of all ranks
+    bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path ...
+    int clean_steps = 0;     // ... and set again after a few steps that stayed on the device path
+    struct Pending {  // a timestep between orbf_step_begin and orbf_step_end
+        bool active = false, async_path = false, fr_persistent = false, block_ready = false, cross_from_set = false, forked = false;
+        bool x_enqueued = false;   // this step's exchange went out between begin and end
+        bool inline_match = false; // the step's own extraction was enqueued by this call: its matching follows on the SAME stream
+        int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
+        orbm_frame* fr = nullptr;
+        SearchJob J{nullptr, nullptr, 0, nullptr, false, 0.f, 0, 0, 64, false};
+        std::vector<orbf_image> images;
+        std::vector<orbm_cam_features> cams;
+        std::chrono::steady_clock::time_point t_impl, t_enqueued;
+    } pending;
+    hipEvent_t ev_extracted = nullptr;  // extractor stream -> matcher stream on the synchronous path
+    hipEvent_t ev_ready[NSETS] = {nullptr, nullptr, nullptr, nullptr};  // extraction + frame grid of the step using that set
+    // frame of the last completed step (orbf_export_block); a frame built on the synchronous path is kept until the next step
+    orbm_frame* last_frame = nullptr; bool last_frame_owned = false;
+    // previous step (for orbf_step_motion)
+    int prev_n = 0;
+    std::vector<int32_t> prev_cam_of;
+    std::vector<float> scale_factors;
+    std::chrono::steady_clock::time_point t_entry;
+};
+
+static int getenv_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+static bool small_rig(const orbf_frontend* f) { return f->n_cams <= 4 && f->cap_total <= 8192 && !f->mt->host_resolve; }
+
+
+int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbf_frontend** out) {
+    MORB_ARG(params && out && n_cams >= 1 && n_cams <= 64);
+    orbf_frontend* f = new orbf_frontend();
+    f->device = device; f->n_cams = n_cams; f->max_w = max_width; f->max_h = max_height;
+    int rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[0]);
+    f->ex = f->exs[0];
+    if (!rc) rc = orbm_create(device, &f->mt);
+    // two streams: the matcher's own one follows the extractor's through events, so that the next step's extraction can
+    // run next to this step's matching
+    if (rc) { orbf_destroy(f); return rc; }
+    f->d_depth.assign(n_cams, nullptr); f->depth_stride.assign(n_cams, 0); f->counts.assign(n_cams, 0);
+    { const char* pe = getenv("MORB_POLL"); f->poll_ok = !(pe && atoi(pe) == 0); }
+    f->scale_factors.assign(params[0].nlevels, 1.f);
+    if ((rc = orbx_tables(&params[0], f->scale_factors.data(), nullptr, nullptr, nullptr, nullptr, nullptr))) { orbf_destroy(f); return rc; }
+    for (int c = 0; c < n_cams; ++c) { f->cam_cap.push_back(params[c].nfeatures + 4 * params[c].nlevels); f->cap_total += f->cam_cap.back(); }
+    const size_t cap = (size_t)f->cap_total;
+    if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
+    for (int k = 0; k < orbf_frontend::NSETS; ++k)
+        if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
+    if (!rc) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[1]);  // overlap partner
+    for (int k = 0; k < orbf_frontend::NSETS && !rc; ++k)
+        if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
+            (rc = f->rs[k].depth.reserve(cap)) || (rc = f->rs[k].unx.reserve(cap)) || (rc = f->rs[k].uny.reserve(cap))) break;
+    if (!rc) rc = f->h_match.reserve(cap);
+    if (rc) { orbf_destroy(f); return rc; }
+    *out = f;
+    return ORB_OK;
+}
+
+void orbf_destroy(orbf_frontend* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->xcomm) (void)orbf_exchange_shutdown(f);
+    f->d_xrecv.release();
+    for (int e = 0; e < 2; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
+    if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
+    if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
+    for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->pframe[k]) orbm_frame_destroy(f->pframe[k]);  // back to the matcher's pool first
+    if (f->mt) orbm_destroy(f->mt);
+    for (int e = 0; e < 2; ++e) if (f->exs[e]) orbx_destroy(f->exs[e]);
+    for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); f->rs[k].unx.release(); f->rs[k].uny.release(); f->rs[k].cross.release(); }
+    f->h_queries.release(); f->h_match.release();
+    if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
+    for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->ev_ready[k]) (void)hipEventDestroy(f->ev_ready[k]);
+    delete f;
+}
+
+orbx_extractor* orbf_extractor(orbf_frontend* f) { return f ? f->ex : nullptr; }
+orbm_matcher* orbf_matcher(orbf_frontend* f) { return f ? f->mt : nullptr; }
+
+int orbf_set_depth(orbf_frontend* f, int cam, const float* d_depth, int stride_floats) {
+    MORB_ARG(f && cam >= 0 && cam < f->n_cams);
+    f->d_depth[cam] = d_depth; f->depth_stride[cam] = stride_floats;
+    return ORB_OK;
+}
+
+static int orbf_drain(orbf_frontend* f);
+
+int orbf_set_calibration(orbf_frontend* f, const orb_calibration* calib) {
+    MORB_ARG(f != nullptr);
+    int rc = orbf_drain(f);  // (prefetched extractions carry the old calibration in their frame sinks)
+    if (rc) return rc;
+    f->announced.clear();
+    if (calib) f->calib = *calib; else memset(&f->calib, 0, sizeof(f->calib));
+    return orbm_set_calibration(f->mt, calib);
+}
+
+int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientation) {
+    MORB_ARG(f && th_high >= 0 && th_high <= 256);
+    f->mbf = mbf; f->th_high = th_high; f->check_ori = check_orientation ? 1 : 0;
+    return ORB_OK;
+}
+
+static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
+                          orbf_result* out, bool queries_in_pinned, const orbf_motion* motion = nullptr);
+static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
+                                bool queries_in_pinned, int* block_ready, const orbf_motion* motion = nullptr);
+static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out);
+static int orbf_drain(orbf_frontend* f);
+
+int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out) {
+    MORB_ARG(f && images && out && nq >= 0 && (nq == 0 || queries));
+    f->t_entry = std::chrono::steady_clock::now();
+    return orbf_step_impl(f, images, queries, nq, flags, out, false);
+}
+
+static int orbf_drain(orbf_frontend* f);
+
+int orbf_reset(orbf_frontend* f) {
+    MORB_ARG(f != nullptr);
+    f->prev_n = 0; f->announced.clear(); f->overlap_ok = true;
+    if (f->pending.active) {  // a begun step is abandoned with everything else in flight
+        if (f->pending.fr && !f->pending.fr_persistent) { (void)hipStreamSynchronize(f->mt->stream); orbm_frame_destroy(f->pending.fr); }
+        f->pending.active = false; f->pending.fr = nullptr;
+    }
+    return orbf_drain(f);
+}
+
+int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_bytes, int* cap_rows) {
+    MORB_ARG(f && d_block && block_bytes && cap_rows);
+    // between orbf_step_begin and orbf_step_end: the frame of the step in flight; otherwise the last completed step's
+    const orbm_frame* F = (f->pending.active && f->pending.fr) ? f->pending.fr : f->last_frame;
+    if (!F) { morb::set_error("no step to export"); return ORB_E_ARG; }
+    *d_block = F->b->d_desc.p;
+    *cap_rows = F->desc_rows;
+    *block_bytes = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
+    return ORB_OK;
+}
+
+int orbf_exchange_unique_id(uint8_t* out128) {
+    MORB_ARG(out128 != nullptr);
+    return exchange_unique_id(out128);
+}
+
+int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int rank) {
+    MORB_ARG(f && uid128 && world >= 1 && rank >= 0 && rank < world && world * f->n_cams <= 512 && !f->xcomm);
+    MORB_HIP(hipSetDevice(f->device));
+    void* comm = nullptr;
+    int rc = exchange_comm_init(&comm, world, uid128, rank);
+    if (rc) return rc;
+    const size_t block = (size_t)f->cap_total * 32 + ORBM_BLOCK_TRAILER;
+    if ((rc = f->d_xrecv.reserve((size_t)world * block))) { exchange_comm_destroy(comm); return rc; }
+    f->xcomm = comm; f->xworld = world; f->xrank = rank;
+    return ORB_OK;
+}
+
+int orbf_exchange_active(const orbf_frontend* f) { return f && f->xcomm ? f->xworld : 0; }
+
+int orbf_exchange_init_loopback(orbf_frontend* f, int group, int world, int rank) {
+    MORB_ARG(f && world >= 1 && rank >= 0 && rank < world && world * f->n_cams <= 512 && !f->xcomm);
+    MORB_HIP(hipSetDevice(f->device));
+    const size_t block = (size_t)f->cap_total * 32 + ORBM_BLOCK_TRAILER;
+    int rc = f->d_xrecv.reserve((size_t)world * block);
+    if (rc) return rc;
+    LoopComm* C = nullptr;
+    if ((rc = loop_join(group, world, rank, &C))) return rc;
+    f->xcomm = C; f->xworld = world; f->xrank = rank; f->xloop = true;
+    return ORB_OK;
+}
+
+int orbf_exchange_shutdown(orbf_frontend* f) {
+    MORB_ARG(f != nullptr);
+    if (!f->xcomm) return ORB_OK;
+    MORB_HIP(hipSetDevice(f->device));
+    if (f->mt) { (void)hipStreamSynchronize(f->mt->side_stream); (void)hipStreamSynchronize(f->mt->stream); }
+    if (f->xloop) loop_leave(static_cast<LoopComm*>(f->xcomm));
+    else exchange_comm_destroy(f->xcomm);
+    f->xcomm = nullptr; f->xworld = 0; f->xrank = 0; f->xloop = false;
+    return ORB_OK;
+}
+
+// all-gather of the frame's export block + the gathered cross-camera top-2, all on the matcher's side stream (joined into its
+// main stream): the block must be final (its extraction chain has completed, or the main stream has been synchronised)
+static int exchange_enqueue(orbf_frontend* f, const orbm_frame* F) {
+    orbm_matcher* m = f->mt;
+    const size_t block = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
+    MORB_ARG(F->desc_rows == f->cap_total);
+    const int rc = f->xloop ? loop_allgather(static_cast<LoopComm*>(f->xcomm), F->b->d_desc.p, f->d_xrecv.p, block, m->side_stream)
+                            : exchange_allgather(f->xcomm, F->b->d_desc.p, f->d_xrecv.p, block, m->side_stream);
+    if (rc) return rc;
+    return orbm_cross_top2_gathered_enqueue(m, f->d_xrecv.p, f->xworld, block, F->desc_rows, f->n_cams, f->xrank, nullptr, 0);
+}
+
+static bool same_images(const std::vector<orbf_image>& a, const orbf_image* b, int n);
+static bool same_content(const std::vector<uint64_t>& fp, const orbf_image* b, int n);
+static std::vector<uint64_t> image_fingerprints(const orbf_image* images, int n);
+
+int orbf_peek_block(orbf_frontend* f, const orbf_image* images, const uint8_t** d_block, size_t* block_bytes, int* cap_rows) {
+    MORB_ARG(f && images && d_block && block_bytes && cap_rows);
+    *d_block = nullptr; *block_bytes = 0; *cap_rows = 0;
+    if (f->pending.active || f->inflight.empty() || !same_images(f->inflight.front().images, images, f->n_cams) ||
+        !same_content(f->inflight.front().fp, images, f->n_cams)) return ORB_OK;
+    const orbf_frontend::InFlight& I = f->inflight.front();
+    MORB_HIP(hipSetDevice(f->device));
+    if (hipEventQuery(f->ev_ready[I.set]) != hipSuccess) { (void)hipGetLastError(); return ORB_OK; }
+    if (orbx_peek_status(f->exs[I.e]) != 0) return ORB_OK;
+    const orbm_frame* F = f->pframe[I.set];
+    if (!F) return ORB_OK;
+    *d_block = F->b->d_desc.p; *cap_rows = F->desc_rows; *block_bytes = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
+    return ORB_OK;
+}
+
+int orbf_export_features(orbf_frontend* f, orbf_device_features* out) {
+    MORB_ARG(f && out);
+    const orbm_frame* F = f->last_frame;
+    if (!F || (f->pending.active && f->pending.fr)) { morb::set_error("orbf_export_features: no completed step (call it after orbf_step / orbf_step_end)"); return ORB_E_ARG; }
+    memset(out, 0, sizeof(*out));
+    out->n_cams = f->n_cams; out->n_total = 0;
+    for (int c = 0; c < f->n_cams && c < 8; ++c) { out->counts[c] = f->counts[c]; out->n_total += f->counts[c]; }
+    out->d_desc = F->b->d_desc.p; out->d_angle = F->b->d_ang.p; out->d_un_x = F->b->d_x.p; out->d_un_y = F->b->d_y.p;
+    out->d_octave = F->b->d_oct.p; out->d_uright = F->b->d_ur.p;
+    out->stream = f->mt->stream;
+    return ORB_OK;
+}
+
+int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images) {
+    MORB_ARG(f && next_images);
+    // (the step about to be called may itself still be in flight: two timesteps beyond it can be announced)
+    if (f->inflight.size() + f->announced.size() >= 3) { morb::set_error("too many future timesteps announced (at most two beyond the next step)"); return ORB_E_ARG; }
+    f->announced.emplace_back(next_images, next_images + f->n_cams);
+    return ORB_OK;
+}
+
+int orbf_step_begin(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, int* block_ready) {
+    MORB_ARG(f && images && nq >= 0 && (nq == 0 || queries));
+    f->t_entry = std::chrono::steady_clock::now();
+    int rc = orbf_step_begin_impl(f, images, queries, nq, flags, false, block_ready);
+    if (rc) f->pending.active = false;
+    return rc;
+}
+
+static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motion, int* nq_out);
+
+int orbf_step_motion_begin(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, int* block_ready) {
+    MORB_ARG(f && images && motion);
+    f->t_entry = std::chrono::steady_clock::now();
+    int rc = orbf_step_begin_impl(f, images, nullptr, 0, flags, true, block_ready, motion);
+    if (rc) f->pending.active = false;
+    return rc;
+}
+
+int orbf_step_end(orbf_frontend* f, orbf_result* out) {
+    MORB_ARG(f && out);
+    return orbf_step_end_impl(f, out);
+}
+
+// the previous step's features (still in their pinned result set) under the stream's motion -> this step's queries
+static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motion, int* nq_out) {
+    const int nq = f->prev_n;
+    *nq_out = nq;
+    if (!nq) return ORB_OK;
+    int rc;
+    if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
+    const orbf_frontend::ResultSet& R = f->rs[f->cur];
+    return orbm_queries_from_motion(R.kps.p, R.desc.p, R.depth.p, f->prev_cam_of.data(), nq, motion->du, motion->dv, motion->th,
+                                    f->scale_factors.data(), f->mbf, reinterpret_cast<orbm_query*>(f->h_queries.p),
+                                    R.unx.p, R.uny.p);  // (mvKeysUn: equal to the keypoint positions without a calibration)
+}
+
+int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out) {
+    MORB_ARG(f && images && motion && out);
+    f->t_entry = std::chrono::steady_clock::now();
+    return orbf_step_impl(f, images, nullptr, 0, flags, out, true, motion);
+}
+
+// An extraction that ran ahead is only valid for the step that consumes it if the images are still the ones that were
+// uploaded.  Pointers, sizes and strides say nothing about a caller that refilled the same buffer in between, so host images
+// also carry a fingerprint of their content: 32 probes of 64 bytes spread over the rows (2 KB per image, well under a
+// microsecond), taken when the upload was enqueued and again when the step arrives.  A mismatch drops what is in flight and the
+// step extracts its images again.  Device images cannot be probed from the host: they must stay unchanged, as orbf.h says.
+static uint64_t image_fingerprint(const orbf_image& im) {
+    if (im.on_device || !im.data || im.width <= 0 || im.height <= 0) return 0;
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)im.width << 32) ^ (uint64_t)im.height;
+    const int span = std::min(64, im.width);
+    for (int k = 0; k < 32; ++k) {
+        const int row = (int)(((long long)k * im.height) / 32);
+        const int col = im.width > span ? (k * 149) % (im.width - span + 1) : 0;
+        const uint8_t* p = im.data + (size_t)row * im.stride + col;
+        for (int b = 0; b + 8 <= span; b += 8) { uint64_t v; memcpy(&v, p + b, 8); h = (h ^ v) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    }
+    return h | 1;
+}
+
+static std::vector<uint64_t> image_fingerprints(const orbf_image* images, int n) {
+    std::vector<uint64_t> fp(n);
+    for (int c = 0; c < n; ++c) fp[c] = image_fingerprint(images[c]);
+    return fp;
+}
+
+static bool same_content(const std::vector<uint64_t>& fp, const orbf_image* b, int n) {
+    if ((int)fp.size() != n) return false;
+    for (int c = 0; c < n; ++c) if (fp[c] != image_fingerprint(b[c])) return false;
+    return true;
+}
+
+static bool same_images(const std::vector<orbf_image>& a, const orbf_image* b, int n) {
+    if ((int)a.size() != n) return false;
+    for (int c = 0; c < n; ++c)
+        if (a[c].data != b[c].data || a[c].width != b[c].width || a[c].height != b[c].height || a[c].stride != b[c].stride ||
+            (a[c].on_device != 0) != (b[c].on_device != 0))
+            return false;
+    return true;
+}
+
+
+static void fill_cam_capacities(orbf_frontend* f, orbx_extractor* ex, orbm_cam_features* cams) {
+    for (int c = 0; c < f->n_cams; ++c) {
+        cams[c].d_kps = orbx_device_keypoints(ex, c); cams[c].d_desc = orbx_device_descriptors(ex, c);
+        cams[c].n = f->cam_cap[c]; cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
+    }
+}
+
+// Uploads + the whole extractor `e` for one timestep into result set `set`, nothing synchronised.  Small rigs: the
+// describe kernel writes the merged frame pframe[set] through a FrameSink (*went_async = 1 unless the extractor took its
+// synchronous host-quadtree path; then the frame was not filled).
+static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, int set, int* W_out, int* H_out, int* went_async,
+                           bool with_cross, bool defer_events = false) {
+    orbm_matcher* m = f->mt;
+    orbx_extractor* ex = f->exs[e];
+    int rc, W = 0, H = 0;
+    for (int c = 0; c < f->n_cams; ++c) {
+        const orbf_image& im = images[c];
+        rc = im.on_device ? orbx_upload_device(ex, c, im.data, im.width, im.height, im.stride)
+                          : orbx_upload(ex, c, im.data, im.width, im.height, im.stride);
+        if (rc) return rc;
+        W = std::max(W, im.width); H = std::max(H, im.height);
+    }
+    if (W == 0 || H == 0) { W = f->max_w; H = f->max_h; }
+    *W_out = W; *H_out = H;
+    orbf_frontend::ResultSet& R = f->rs[set];
+    R.cross_valid = false;
+    if ((rc = orbx_set_host_mirror(ex, R.kps.dp, R.desc.dp, f->cap_total))) return rc;
+    *went_async = 0;
+    const bool small = small_rig(f);
+    std::vector<orbm_cam_features> cams(f->n_cams);
+    fill_cam_capacities(f, ex, cams.data());
+    float bd[4];
+    if ((rc = orbm_image_bounds(&f->calib, W, H, bd))) return rc;  // Frame::ComputeImageBounds
+    if (f->pframe[set] && (f->pframe_W[set] != W || f->pframe_H[set] != H || f->pframe[set]->minX != bd[0] ||
+                           f->pframe[set]->minY != bd[1] || f->pframe[set]->maxX != bd[2] || f->pframe[set]->maxY != bd[3])) {
+        orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr;  // (image size or calibration changed)
+    }
+    m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp; m->mirror_unx = R.unx.dp; m->mirror_uny = R.uny.dp;
+    struct MirrorsOff { orbm_matcher* m; ~MirrorsOff() { m->mirror_ur = nullptr; m->mirror_depth = nullptr; m->mirror_unx = nullptr; m->mirror_uny = nullptr; } } mirrors_off{m};
+    if (small) {
+        // the describe kernel writes the per-feature half of the frame itself (FrameSink)
+        FrameSink sink;
+        if (!f->pframe[set]) {
+            rc = frame_prepare_sink(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], &f->pframe[set], &sink);
+            f->pframe_W[set] = W; f->pframe_H[set] = H;
+        } else {
+            orbm_frame* F = f->pframe[set];
+            F->n_total = f->cap_total; F->counts_on_device = true; F->host_valid = false;
+            rc = frame_sink_of(m, F, cams.data(), f->n_cams, f->mbf, &sink);
+        }
+        if (rc) return rc;
+        if ((rc = orbx_set_frame_sink(ex, &sink))) return rc;
+    } else {
+        // larger rigs: the matcher's own kernels assemble the frame from the extractor's per-camera outputs
+        if (!f->pframe[set]) {
+            m->frame_min_rows = f->cap_total;
+            rc = frame_shell(m, f->cap_total, f->n_cams, bd[0], bd[1], bd[2], bd[3], true, &f->pframe[set]);
+            m->frame_min_rows = 0;
+            if (rc) return rc;
+            f->pframe_W[set] = W; f->pframe_H[set] = H;
+        } else {
+            orbm_frame* F = f->pframe[set];
+            F->n_total = f->cap_total; F->counts_on_device = true; F->host_valid = false;
+        }
+    }
+    // The frame's grid (larger rigs: the whole frame assembly) and the camera-pair top-2 are the tail of the extraction
+    // chain: built on the extractor's stream right behind the describe kernel (counts read from HBM), so that a step's
+    // matching starts with the search itself.  For small rigs the tail is issued from inside orbx_run_async and is
+    // captured into the replayed launch chain (no host launches at all on replay); larger rigs launch it here (their
+    // assembly stages a parameter block with a copy, which a replayed chain should not carry).
+    struct Tail {
+        orbf_frontend* f; orbx_extractor* ex; orbm_cam_features* cams; const float* bd; int set; bool small, with_cross;
+        static int run(void* u, void* stream) {
+            Tail& T = *static_cast<Tail*>(u);
+            orbm_matcher* m = T.f->mt;
+            orbf_frontend::ResultSet& R = T.f->rs[T.set];
+            orbm_frame* frp = T.f->pframe[T.set];
+            hipStream_t keep = m->stream;
+            m->stream = (hipStream_t)stream;
+            int rc = frame_from_device_impl(m, T.cams, T.f->n_cams, T.f->mbf, T.bd[0], T.bd[1], T.bd[2], T.bd[3], orbx_device_counts(T.ex),
+                                            &frp, T.small);
+            if (!rc && T.with_cross && T.f->n_cams > 1) {
+                const int ncap = frp->n_total;
+                rc = cross_enqueue_to(m->stream, frp->b->d_desc.p, ncap, frp->b->d_cam_start.p, T.f->n_cams, 0, ncap, frp->b->d_ntotal.p,
+                                      R.cross.i.dp, R.cross.b.dp, R.cross.s.dp, R.cross.scratch.p);
+            }
+            m->stream = keep;
+            return rc;
+        }
+    } tail{f, ex, cams.data(), bd, set, small, with_cross};
+    const bool cross_here = with_cross && f->n_cams > 1;
+    if (cross_here && (rc = R.cross.reserve(f->cap_total, f->cap_total))) return rc;  // (storage first: nothing allocates inside a capture)
+    if (small) { if ((rc = m->h_ring.reserve((64 * sizeof(CamFeat) + 65 * sizeof(int) + 64 * sizeof(int)) * 4))) return rc; }
+    if (small && (rc = orbx_set_chain_tail(ex, &Tail::run, &tail, 1 + set * 2 + (cross_here ? 1 : 0)))) return rc;
+    const int before = orbx_pending(ex);
+    rc = orbx_run_async(ex);
+    if (small) { (void)orbx_set_frame_sink(ex, nullptr); (void)orbx_set_chain_tail(ex, nullptr, nullptr, 0); }
+    if (rc) return rc;
+    *went_async = orbx_pending(ex) > before ? 1 : 0;
+    if (*went_async) {
+        if (!small && (rc = Tail::run(&tail, orbx_stream(ex)))) return rc;
+        R.cross_valid = cross_here;
+        if (!defer_events) {   // (an inline step records its events behind its matching: step_enqueue)
+            hipError_t he = hipEventRecord(f->ev_ready[set], (hipStream_t)orbx_stream(ex));
+            if (he != hipSuccess) { morb::set_error("hipEventRecord: %s", hipGetErrorString(he)); return ORB_E_HIP; }
+        }
+    }
+    return ORB_OK;
+}
+
+// Everything in flight is waited for and dropped (results of prefetched extractions included).
+static int orbf_drain(orbf_frontend* f) {
+    MORB_HIP(hipSetDevice(f->device));
+    for (int e = 0; e < 2; ++e) if (f->exs[e]) MORB_HIP(hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e])));
+    MORB_HIP(hipStreamSynchronize(f->mt->stream));
+    MORB_HIP(hipStreamSynchronize(f->mt->side_stream));
+    for (int e = 0; e < 2; ++e)
+        while (f->exs[e] && orbx_pending(f->exs[e]) > 0) { int rc = orbx_finish(f->exs[e]); if (rc < 0) return rc; }
+    f->inflight.clear();
+    return ORB_OK;
+}
+
+// The next free result set / extractor for a timestep that is about to be extracted.  Sets go round robin.  Isolated steps
+// (nothing in flight) always run on extractor 0; overlapped ones alternate, so that two extraction chains are on the GPU
+// at a time and each extractor keeps seeing the same two (count slot, result set) pairs -- its captured launch chains stay valid.
+static void next_slot(orbf_frontend* f, int* e, int* set) {
+    *set = (f->last_set + 1) % orbf_frontend::NSETS;
+    if (*set == f->cur) *set = (*set + 1) % orbf_frontend::NSETS;  // (the caller still reads the last step's results)
+    *e = (f->inflight.empty() || !f->exs[1]) ? 0 : (f->last_e ^ 1);
+    f->last_set = *set; f->last_e = *e;
+}
+
+// A timestep in two halves.  orbf_step_begin enqueues everything (this step's matching, the extraction of the announced
+// steps) and returns; orbf_step_end blocks once and collects.  Between the two a caller may enqueue work of its own that
+// only needs the step's export block -- the multi-GPU exchange -- when begin reported the block ready.
+static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_attempt);
+
+static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motion, int* nq_out);
+
+// motion != NULL: the queries are built here from the previous step's features (orbf_step_motion) -- AFTER this step's
+// extraction has been enqueued, so that the GPU is already working while the host projects the points.
+static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
+                                bool queries_in_pinned, int* block_ready, const orbf_motion* motion) {
+    orbf_frontend::Pending& P = f->pending;
+    MORB_ARG(!P.active);
+    P = orbf_frontend::Pending();
+    P.t_impl = std::chrono::steady_clock::now();
+    MORB_HIP(hipSetDevice(f->device));
+    orbm_matcher* m = f->mt;
+    int rc, went_async = 0;
+    if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
+    f->last_frame = nullptr; f->last_frame_owned = false;
+    if (f->xcomm) flags |= ORBF_SKIP_CROSS;   // the rig-wide matching of the exchange replaces the rank-local one
+    P.images.assign(images, images + f->n_cams);
+    P.nq = nq; P.flags = flags;
+
+    // ---- this step's extraction: already in flight (orbf_prefetch during an earlier step) or enqueued now
+    if (!f->inflight.empty() && same_images(f->inflight.front().images, images, f->n_cams) &&
+        same_content(f->inflight.front().fp, images, f->n_cams)) {
+        const orbf_frontend::InFlight& I = f->inflight.front();
+        P.set = I.set; P.e = I.e; P.W = I.W; P.H = I.H; went_async = 1;
+        f->inflight.pop_front();
+    } else {
+        if (!f->inflight.empty()) {  // prefetched for other images: everything in flight is dropped
+            if ((rc = orbf_drain(f))) return rc;
+            f->announced.clear();
+        }
+        if (!f->announced.empty() && same_images(f->announced.front(), images, f->n_cams)) f->announced.pop_front();
+        next_slot(f, &P.e, &P.set);
+        // Nothing ran ahead for this step (a live rig: the images have only just arrived).  Its matching then goes onto the
+        // extractor's own stream, right behind the extraction chain -- a kernel boundary instead of a cross-stream event
+        // (measured: ~22 us between the chain's last kernel and the projection kernel on the matcher's stream) -- and the
+        // camera-pair top-2 leaves the chain: it forks onto the side stream next to project + resolve instead of standing in
+        // front of them.
+        P.inline_match = small_rig(f) && !f->xcomm && getenv_int("MORB_INLINE_MATCH", 1) != 0;
+        if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], getenv_int("MORB_INLINE_GRAPH", 0)); (void)orbx_set_defer_done(f->exs[P.e], 1); }
+        rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match, P.inline_match);
+        if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], 1); (void)orbx_set_defer_done(f->exs[P.e], 0); }
+        if (rc) return rc;
+        if (P.inline_match && !went_async) P.inline_match = false;   // (host-quadtree path: everything was synchronous)
+    }
+    if (motion) {
+        if ((rc = queries_from_previous_step(f, motion, &nq))) return rc;
+        queries = reinterpret_cast<const orbm_query*>(f->h_queries.p); queries_in_pinned = true;
+        P.nq = nq;
+    }
+    // queries go through pinned (device-mapped) staging and are read from there by the projection kernel
+    if (nq) {
+        if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))))
+            return rc;
+        if (!queries_in_pinned) memcpy(f->h_queries.p, queries, (size_t)nq * sizeof(orbm_query));
+        f->h_queries.publish();
+    }
+    P.J = SearchJob{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
+    P.J.q_dev = nq ? reinterpret_cast<const orbm_query*>(f->h_queries.dp) : nullptr;   // no H2D on the step's critical chain
+    P.J.want_tags = f->poll_ok;
+    if ((rc = f->h_match.reserve(std::max(f->cap_total, 1)))) return rc;
+    P.async_path = went_async != 0;
+    // The export block of this step is final already when its extraction chain has completed cleanly (the usual case with
+    // steps announced ahead): then nothing of this step can be redone and a caller may ship the block right away.
+    P.block_ready = false;
+    if (P.async_path && !P.inline_match && hipEventQuery(f->ev_ready[P.set]) == hipSuccess) P.block_ready = orbx_peek_status(f->exs[P.e]) == 0;
+    else (void)hipGetLastError();
+    if ((rc = step_enqueue(f, P, true))) return rc;
+    P.active = true;
+    if (block_ready) *block_ready = P.block_ready ? 1 : 0;
+    return ORB_OK;
+}
+
+// Enqueues the matching of the pending step (and, on the first attempt, the extraction of the announced steps).
+static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_attempt) {
+    orbm_matcher* m = f->mt;
+    hipStream_t st = m->stream;
+    orbx_extractor* ex = f->exs[P.e];
+    hipStream_t st_e = (hipStream_t)orbx_stream(ex);
+    orbf_frontend::ResultSet& R = f->rs[P.set];
+    const bool do_cross = !(P.flags & ORBF_SKIP_CROSS);
+    int rc;
+    std::vector<orbm_cam_features>& cams = P.cams;
+    cams.resize(f->n_cams);
+    const bool inline_match = P.async_path && P.inline_match;
+    struct StreamSwap {   // an inline step issues its matching on the extractor's stream
+        orbm_matcher* m; hipStream_t keep; bool on;
+        ~StreamSwap() { if (on) m->stream = keep; }
+    } swap{m, m->stream, inline_match};
+    if (inline_match) { m->stream = st_e; st = st_e; }
+    if (P.async_path) {
+        // matching follows the extraction chain (which ends with the frame grid): through its event, or simply behind it on
+        // the same stream; counts are in HBM
+        P.fr = f->pframe[P.set]; P.fr_persistent = true;
+        if (!inline_match) MORB_HIP(hipStreamWaitEvent(st, f->ev_ready[P.set], 0));  // extraction + frame grid of this step
+        P.n = P.fr->n_total;
+    } else {
+        rc = orbx_finish(ex);  // synchronises; counts are on the host from here on
+        if (rc < 0) return rc;
+        // the host-quadtree path returns with its describe kernel still running on the extractor's stream
+        MORB_HIP(hipEventRecord(f->ev_extracted, st_e));
+        MORB_HIP(hipStreamWaitEvent(st, f->ev_extracted, 0));
+        P.n = 0;
+        for (int c = 0; c < f->n_cams; ++c) {
+            cams[c].d_kps = orbx_device_keypoints(ex, c); cams[c].d_desc = orbx_device_descriptors(ex, c);
+            cams[c].n = orbx_count(ex, c);
+            cams[c].d_depth = f->d_depth[c]; cams[c].depth_stride = f->depth_stride[c];
+            P.n += cams[c].n;
+        }
+        // the frame-build kernel mirrors the stereo arrays straight into this step's pinned result set (keypoints and
+        // descriptors were mirrored by the extractor's describe kernel)
+        m->mirror_kps = nullptr; m->mirror_desc = nullptr; m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp;
+        m->mirror_unx = R.unx.dp; m->mirror_uny = R.uny.dp;
+        m->frame_min_rows = f->cap_total;  // every step's export block has the same size
+        float bd[4];
+        rc = orbm_image_bounds(&f->calib, P.W, P.H, bd);  // Frame::ComputeImageBounds
+        P.fr = nullptr;
+        if (!rc) rc = frame_from_device_impl(m, cams.data(), f->n_cams, f->mbf, bd[0], bd[1], bd[2], bd[3], nullptr, &P.fr);
+        m->frame_min_rows = 0;
+        m->mirror_ur = nullptr; m->mirror_depth = nullptr; m->mirror_unx = nullptr; m->mirror_uny = nullptr;
+        if (rc) return rc;
+        P.fr_persistent = false;
+    }
+    orbm_frame* fr = P.fr;
+    const int n = P.n;
+    P.J.cur = fr; P.J.cap = 64; P.J.device_path = false;
+    // fork: the camera-pair top-2 only needs the frame's descriptor block, so it runs on the side stream next to
+    // project + resolve (both are a handful of workgroups on a 256-CU part); join before the one host sync
+    // (on the asynchronous path the cross top-2 normally rode at the end of the step's extraction chain already)
+    P.cross_from_set = do_cross && P.async_path && R.cross_valid;
+    const bool forked = do_cross && n > 0 && !P.cross_from_set;
+    P.forked = forked;
+    if (forked) {  // the fork point is the finished frame; the launches on the side stream come after the search's
+        hipError_t fe = hipEventRecord(m->ev_fork, st);
+        if (fe == hipSuccess) fe = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
+        if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return ORB_E_HIP; }
+    }
+    rc = search_enqueue(m, P.J, /*queries_already_on_device=*/true);
+    if (forked) {
+        if (!rc) rc = cross_enqueue(m, m->side_stream, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n,
+                                    P.async_path ? fr->b->d_ntotal.p : nullptr);
+        // join (also on the error path, so that the side stream never outlives the frame)
+        hipError_t je = hipEventRecord(m->ev_join, m->side_stream);
+        if (je == hipSuccess) je = hipStreamWaitEvent(st, m->ev_join, 0);
+        if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
+    }
+    if (inline_match && first_attempt) {   // the events the extraction left for us: behind the matching, not in front of it
+        const int rd = orbx_record_done(ex);
+        hipError_t he = hipEventRecord(f->ev_ready[P.set], st);
+        if (!rc && rd) rc = rd;
+        if (!rc && he != hipSuccess) { morb::set_error("hipEventRecord: %s", hipGetErrorString(he)); rc = ORB_E_HIP; }
+    }
+    if (rc) { (void)hipStreamSynchronize(st); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return rc; }
+    // ---- native exchange: a block that is final already goes out right behind the step's own matching
+    if (first_attempt && f->xcomm && P.async_path && P.block_ready && !P.x_enqueued) {
+        if ((rc = exchange_enqueue(f, fr))) return rc;
+        P.x_enqueued = true;
+    }
+    // ---- announced timesteps go onto the extractors now: they run while this step is being matched.  At most two
+    // are in flight; consecutive ones alternate between the two extractors (an extractor takes its next timestep as
+    // a second run behind the one whose results are being matched here).
+    while (P.async_path && first_attempt && f->overlap_ok && !f->announced.empty() && f->inflight.size() < 2) {
+        const int prev_e = f->inflight.empty() ? P.e : f->inflight.back().e;
+        const int e2 = f->exs[1] ? (prev_e ^ 1) : 0;
+        if (orbx_pending(f->exs[e2]) >= 2) break;
+        int set2 = (f->last_set + 1) % orbf_frontend::NSETS;
+        if (set2 == f->cur) set2 = (set2 + 1) % orbf_frontend::NSETS;
+        if (set2 == P.set) set2 = (set2 + 1) % orbf_frontend::NSETS;
+        int w2 = 0, h2 = 0, async2 = 0;
+        rc = enqueue_extract(f, e2, f->announced.front().data(), set2, &w2, &h2, &async2, !(P.flags & ORBF_SKIP_CROSS));
+        if (rc) { (void)hipStreamSynchronize(st); return rc; }
+        f->last_set = set2; f->last_e = e2;
+        if (async2) {
+            orbf_frontend::InFlight I;
+            I.images = f->announced.front(); I.set = set2; I.W = w2; I.H = h2; I.e = e2;
+            I.fp = image_fingerprints(I.images.data(), f->n_cams);   // (the uploads were enqueued just above)
+            f->inflight.push_back(std::move(I));
+            f->announced.pop_front();
+        } else {
+            // the extractor ran synchronously (host quadtree): its outputs now belong to that future step, which cannot
+            // be kept apart from a later one's -- give up overlapping; the steps extract again when their turn comes
+            f->overlap_ok = false;
+            f->announced.clear();
+        }
+    }
+    P.t_enqueued = std::chrono::steady_clock::now();
+    return ORB_OK;
+}
+
+static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
+    orbf_frontend::Pending& P = f->pending;
+    MORB_ARG(P.active && out);
+    P.active = false;
+    auto us_between = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<float, std::micro>(b - a).count();
+    };
+    MORB_HIP(hipSetDevice(f->device));
+    orbm_matcher* m = f->mt;
+    orbx_extractor* ex = f->exs[P.e];
+    struct StreamSwap {   // an inline step's matching lives on the extractor's stream (retries of the search go there too)
+        orbm_matcher* m; hipStream_t keep; bool on;
+        ~StreamSwap() { if (on) m->stream = keep; }
+    } swap{m, m->stream, P.async_path && P.inline_match};
+    if (swap.on) m->stream = (hipStream_t)orbx_stream(ex);
+    hipStream_t st = m->stream;
+    orbf_frontend::ResultSet& R = f->rs[P.set];
+    int rc, nmatches = 0;
+    auto t_synced = P.t_impl;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (attempt == 1 && (rc = step_enqueue(f, P, false))) return rc;
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t herr = hipSuccess;
+        bool polled = false;
+        if (f->poll_ok && P.async_path && P.J.pollable && !P.forked && !m->foreign_work) {
+            // the resolve is the last thing on the stream and tags its result words with the launch's sequence number: watch
+            // the status word arrive (a few microseconds sooner than the end-of-kernel signal travels through the runtime);
+            // search_finish then takes every other word the same way
+            volatile int32_t* flag = m->h_match.p;
+            for (int spin = 0; spin < 400000; ++spin) {
+                if ((*flag >> 20) == P.J.seq) { polled = true; break; }
+                __builtin_ia32_pause();
+            }
+        }
+        if (!polled) herr = hipStreamSynchronize(st);
+        m->foreign_work = false;
+        out->gpu_wait_us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        out->host_us[0] = us_between(f->t_entry, P.t_impl); out->host_us[1] = us_between(P.t_impl, P.t_enqueued); out->host_us[2] = out->gpu_wait_us;
+        t_synced = std::chrono::steady_clock::now();
+        if (herr != hipSuccess) {
+            morb::set_error("hipStreamSynchronize: %s", hipGetErrorString(herr));
+            if (!P.fr_persistent && P.fr) orbm_frame_destroy(P.fr);
+            return ORB_E_HIP;
+        }
+        if (P.async_path) {
+            rc = orbx_finish(ex);  // this step's run (the oldest of its extractor) completed long ago: adopts its counts
+            if (rc < 0) return rc;
+            if (rc == 1 || rc == 2) {
+                // a pyramid level was outside the device quadtree's limits: this step is redone on the synchronous path
+                if (rc == 2 || !f->inflight.empty()) {  // ... from its images: later timesteps are in flight, drop them first
+                    if ((rc = orbf_drain(f))) return rc;
+                    f->announced.clear();
+                    f->overlap_ok = false;
+                    int w2, h2, a2;
+                    if ((rc = enqueue_extract(f, P.e, P.images.data(), P.set, &w2, &h2, &a2, false))) return rc;
+                    if (a2) { rc = orbx_finish(ex); if (rc < 0) return rc; }
+                }
+                P.fr = nullptr; P.fr_persistent = false;
+                P.async_path = false;
+                f->clean_steps = 0;
+                continue;
+            }
+            for (int c = 0; c < f->n_cams; ++c) f->counts[c] = orbx_count(ex, c);
+            frame_set_counts(P.fr, f->counts.data());
+            P.n = P.fr->n_total;
+            if (!f->overlap_ok && ++f->clean_steps >= 3) f->overlap_ok = true;  // (e.g. the extractor has switched its BIG pass on)
+        } else {
+            for (int c = 0; c < f->n_cams; ++c) f->counts[c] = P.cams[c].n;
+        }
+        break;
+    }
+    if (!P.async_path || !f->overlap_ok) f->announced.clear();  // (hints are only honoured on the asynchronous path)
+    const int n = P.n, nq = P.nq;
+    const bool do_cross = !(P.flags & ORBF_SKIP_CROSS) && n > 0;
+    rc = search_finish(m, P.J, f->h_match.p, &nmatches);
+    if (rc) { if (!P.fr_persistent) orbm_frame_destroy(P.fr); return rc; }
+    f->last_frame = P.fr; f->last_frame_owned = !P.fr_persistent;  // (returned to the pool when the next step starts)
+    f->cur = P.set;
+    f->prev_n = n;
+    f->prev_cam_of.resize(n);
+    for (int c = 0, g = 0; c < f->n_cams; ++c)
+        for (int k = 0; k < f->counts[c]; ++k) f->prev_cam_of[g++] = c;
+    out->n_queries = nq; out->queries = reinterpret_cast<const orbm_query*>(f->h_queries.p);
+    out->n_cams = f->n_cams; out->n_total = n; out->counts = f->counts.data();
+    out->kps = R.kps.p; out->desc = R.desc.p; out->uright = R.ur.p; out->depth = R.depth.p;
+    out->un_x = R.unx.p; out->un_y = R.uny.p;
+    out->nmatches = nmatches; out->match_of_feature = f->h_match.p;
+    const bool from_set = P.cross_from_set && P.async_path;  // (a step redone on the synchronous path matched in its own launch)
+    out->cross_best_idx = do_cross ? (from_set ? R.cross.i.p : m->h_c0.p) : nullptr;
+    out->cross_best_dist = do_cross ? (from_set ? R.cross.b.p : m->h_c1.p) : nullptr;
+    out->cross_second_dist = do_cross ? (from_set ? R.cross.s.p : m->h_c2.p) : nullptr;
+    out->rig_cams = 0; out->rig_counts = nullptr;
+    if (f->xcomm) {
+        // every rank issues exactly one all-gather per step: between begin and end when the block was final at begin, here
+        // otherwise (the block is final now)
+        if (!P.x_enqueued) {
+            if ((rc = exchange_enqueue(f, f->last_frame))) return rc;
+            MORB_HIP(hipStreamSynchronize(st));
+            m->foreign_work = false;
+        }
+        out->cross_best_idx = m->h_c0.p; out->cross_best_dist = m->h_c1.p; out->cross_second_dist = m->h_c2.p;
+        out->rig_cams = m->gathered_cams; out->rig_counts = m->h_gcnt.p;
+        if (m->h_gcnt.p[m->gathered_cams + 1] != 0) {   // (k_repack_gathered clamped a remote count: nothing ran out of bounds)
+            morb::set_error("multi-GPU exchange: %d per-camera counts of the gathered blocks were out of range (ranks disagree on "
+                            "their capacities, or a block is corrupt)", m->h_gcnt.p[m->gathered_cams + 1]);
+            return ORB_E_ARG;
+        }
+    }
+    out->host_us[3] = us_between(t_synced, std::chrono::steady_clock::now());
+    return ORB_OK;
+}
+
+static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
+                          orbf_result* out, bool queries_in_pinned, const orbf_motion* motion) {
+    int rc = orbf_step_begin_impl(f, images, queries, nq, flags, queries_in_pinned, nullptr, motion);
+    if (rc) { f->pending.active = false; return rc; }
+    return orbf_step_end_impl(f, out);
+}
+
+

@@ -1,0 +1,1077 @@
+// search.hip -- the projection-gated searches of the ORB matcher (include/orbm.h).
+//   k_project        M3  one wave per query walks the 64x48 grid cells of its window(s) in the reference's visiting order,
+//                    ballot-compacts the survivors in order, gathers their descriptors and keeps a sorted shortlist.
+//                    reference src/ORBmatcher.cc:3547-3592 + src/Frame.cc:574-629.
+//   k_resolve / k_rs_*   the order-dependent part of SearchByProjection (first-come claims, rotation histogram,
+//                    ComputeThreeMaxima) as a fixed-point iteration ON THE DEVICE; host_resolve replays the loop on the host
+//                    as the exact fallback (sweep limit, MORB_HOST_RESOLVE=1).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+#include "../../include/orbm.h"
+#include "orb_common.h"
+#include "frame_sink.h"
+#include "matcher_internal.h"
+#include "hamming_dev.h"
+
+using namespace morb;
+
+namespace {
+// One wave per query.  The window's grid cells are enumerated ix (outer) / iy (inner) -- the reference's visiting
+// order, App. A-8 -- 64 cells at a time, one per lane: every lane fetches its cell's [start, end) in parallel, a wave
+// prefix sum turns the counts into ordered item positions, then the items are tested 64 at a time and the survivors
+// compacted with a ballot.  The output order is exactly the reference's candidate order (it decides distance ties);
+// the dependent-load chain is per 64 cells instead of per cell.
+// Output layout: element k of query i at [i*cap + k] (TRANSPOSED == 0) or [k*nq + i] (TRANSPOSED == 1, coalesced for
+// the thread-per-query resolve kernel).
+// With `topk` != NULL the wave also keeps the RESOLVE_K smallest (distance << 16 | position) keys of its non-occupied
+// survivors, sorted, and writes them (+ their feature indices) at topk[k*nq + i] / topk[(K + k)*nq + i]: the shortlist
+// the resolve kernel sweeps over.
+
+__global__ __launch_bounds__(256) void k_project(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap,
+                                                 int gate_right, int with_dist, int transposed, int* __restrict__ cand_idx,
+                                                 uint16_t* __restrict__ cand_dist, int* __restrict__ cand_count,
+                                                 const uint8_t* __restrict__ occupied, int* __restrict__ topk, int short_th,
+                                                 const float* __restrict__ inv_sigma2 = nullptr, int2* __restrict__ qmeta = nullptr,
+                                                 const orbm_window* __restrict__ win2 = nullptr) {
+    const int lane = threadIdx.x & 63;
+    const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (qi >= nq) return;
+    const orbm_query* Q = q + qi;
+    float x = Q->u, y = Q->v, r = Q->radius;
+    const float ur = Q->ur;
+    int minLevel = Q->min_level, maxLevel = Q->max_level, cam = Q->cam;
+    const uint32_t* qd = reinterpret_cast<const uint32_t*>(Q->desc);
+    const uint4 q0 = make_uint4(qd[0], qd[1], qd[2], qd[3]), q1 = make_uint4(qd[4], qd[5], qd[6], qd[7]);
+
+    int total = 0;
+    int n_elig = 0;                    // survivors that could ever be accepted: not occupied and distance <= short_th
+    int sk[RESOLVE_K], sg[RESOLVE_K];  // wave-uniform sorted shortlist
+#pragma unroll
+    for (int k = 0; k < RESOLVE_K; ++k) { sk[k] = 0x7fffffff; sg[k] = -1; }
+    // A query may carry a SECOND window (the two-camera loop search, reference src/ORBmatcher.cc:625-721: the point is projected
+    // into both cameras of the keyframe and the best candidate over both windows wins): its candidates simply follow the
+    // first window's in the list, i.e. in the reference's visiting order (camera 1's loop runs before camera 2's).
+    const int nwin = win2 ? 2 : 1;
+    for (int wi = 0; wi < nwin; ++wi) {
+    if (wi == 1) {
+        const orbm_window* W2 = win2 + qi;
+        x = W2->u; y = W2->v; r = W2->radius; cam = W2->cam; minLevel = W2->min_level; maxLevel = W2->max_level;
+    }
+    const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.invW));
+    const int nMaxCellX = min(ORBM_GRID_COLS - 1, (int)ceilf((x - F.minX + r) * F.invW));
+    const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.invH));
+    const int nMaxCellY = min(ORBM_GRID_ROWS - 1, (int)ceilf((y - F.minY + r) * F.invH));
+    const bool ok = nMinCellX < ORBM_GRID_COLS && nMaxCellX >= 0 && nMinCellY < ORBM_GRID_ROWS && nMaxCellY >= 0 &&
+                    nMinCellX <= nMaxCellX && nMinCellY <= nMaxCellY && cam >= 0 && cam < F.n_cams;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    if (ok) {
+        const int ny = nMaxCellY - nMinCellY + 1, ncells = (nMaxCellX - nMinCellX + 1) * ny;
+        for (int cbase = 0; cbase < ncells; cbase += 64) {
+            // this lane's cell of the chunk
+            const int ci = cbase + lane;
+            int cs = 0, cn = 0;
+            if (ci < ncells) {
+                const int ix = nMinCellX + ci / ny, iy = nMinCellY + ci % ny;
+                const int cell = (cam * ORBM_GRID_COLS + ix) * ORBM_GRID_ROWS + iy;
+                cs = F.cell_start[cell];
+                cn = F.cell_start[cell + 1] - cs;
+            }
+            const int incl = wave_incl_scan(cn);  // inclusive prefix of the item counts over the lanes (DPP)
+            const int items_in_chunk = __builtin_amdgcn_readlane(incl, 63);
+            const int excl = incl - cn;
+            for (int tbase = 0; tbase < items_in_chunk; tbase += 64) {
+                const int t = tbase + lane;  // t-th item of the chunk in (cell, ascending index) order
+                const bool valid = t < items_in_chunk;
+                // owner lane = first lane whose inclusive prefix exceeds t (binary search over the wave)
+                int lo = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int probe = lo + step - 1;
+                    const int pv = __shfl(incl, probe);
+                    if (pv <= t) lo += step;
+                }
+                const int oexcl = __shfl(excl, lo), ostart = __shfl(cs, lo);
+                const int g = valid ? F.items[ostart + (t - oexcl)] : 0;
+                bool pass = valid;
+                if (pass && bCheckLevels) {
+                    const int oct = F.octave[g];
+                    if (oct < minLevel) pass = false;
+                    if (maxLevel >= 0 && oct > maxLevel) pass = false;
+                }
+                if (pass) {
+                    const float distx = F.un_x[g] - x, disty = F.un_y[g] - y;
+                    pass = fabsf(distx) < r && fabsf(disty) < r;
+                }
+                if (pass && gate_right == 1) {
+                    const float urg = F.uright[g];
+                    if (urg > 0 && fabsf(ur - urg) > r) pass = false;   // a NaN `ur` never closes this gate
+                }
+                if (pass && gate_right == 2) {   // Fuse's reprojection-error gate (src/ORBmatcher.cc:2118-2143)
+                    const float kpr = F.uright[g];
+                    const float ex = x - F.un_x[g], ey = y - F.un_y[g];
+                    if (kpr >= 0) {
+                        const float er = ur - kpr;
+                        const float e2 = ex * ex + ey * ey + er * er;
+                        if ((double)(e2 * inv_sigma2[F.octave[g]]) > 7.8) pass = false;
+                    } else {
+                        const float e2 = ex * ex + ey * ey;
+                        if ((double)(e2 * inv_sigma2[F.octave[g]]) > 5.99) pass = false;
+                    }
+                }
+                const unsigned long long mask = __ballot(pass);
+                const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
+                int dist = 0;
+                if (pass && with_dist) dist = ham256(q0, q1, F.desc[2 * g], F.desc[2 * g + 1]);
+                if (pass && pos < cap) {
+                    const size_t o = transposed ? (size_t)pos * nq + qi : (size_t)qi * cap + pos;
+                    cand_idx[o] = g;
+                    if (with_dist) cand_dist[o] = (uint16_t)dist;
+                }
+                if (topk) {  // merge this batch's survivors into the sorted shortlist (at most RESOLVE_K extractions)
+                    // A frame search accepts only distance <= th_high, so farther candidates can neither win nor matter:
+                    // they stay out of the shortlist and out of the "list longer than the shortlist" count (short_th =
+                    // th_high there; 256 = keep everything for the top-2 / ratio-test search).
+                    const bool elig = pass && !(occupied && occupied[g]) && dist <= short_th;
+                    n_elig += __popcll(__ballot(elig));
+                    int key = elig ? ((dist << 16) | pos) : 0x7fffffff;
+#pragma unroll
+                    for (int e = 0; e < RESOLVE_K; ++e) {
+                        const int mn = (int)wave_min_u32((unsigned)key);   // keys are non-negative; DPP, no LDS crossbar
+                        if (mn >= sk[RESOLVE_K - 1]) break;  // wave-uniform: nothing left that beats the shortlist tail
+                        const int mg = __builtin_amdgcn_readlane(g, __ffsll((long long)__ballot(key == mn)) - 1);
+                        if (key == mn) key = 0x7fffffff;     // positions are unique, so exactly one lane matches
+                        int ck = mn, cg = mg;
+#pragma unroll
+                        for (int j = 0; j < RESOLVE_K; ++j)
+                            if (ck < sk[j]) { const int tk = sk[j], tg = sg[j]; sk[j] = ck; sg[j] = cg; ck = tk; cg = tg; }
+                    }
+                }
+                total += __popcll(mask);
+            }
+        }
+    }
+    }  // windows
+    if (lane == 0) {
+        cand_count[qi] = total;
+        // what the resolve needs of a query besides its candidates: it never reads the query records themselves, which may
+        // therefore live in pinned host memory (read once, here)
+        if (qmeta) qmeta[qi] = make_int2(Q->blocks, __float_as_int(Q->angle));
+        if (topk) {
+#pragma unroll
+            for (int k = 0; k < RESOLVE_K; ++k) {
+                topk[(size_t)k * nq + qi] = sk[k];
+                topk[(size_t)(RESOLVE_K + k) * nq + qi] = sg[k];
+            }
+            topk[(size_t)(2 * RESOLVE_K) * nq + qi] = n_elig;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ device resolve
+// The reference resolves claims sequentially in query order (src/ORBmatcher.cc:3502-3614): a feature claimed by a query
+// whose MapPoint is observed ("blocks") is invisible to every LATER query.  Query q therefore depends only on queries
+// < q, and the sequential answer is the unique fixed point of:  choice[q] = first arg-min over q's ordered candidates
+// that are not occupied and not claimed by a blocking query q' < q.  One workgroup iterates that map (Jacobi) until
+// nothing changes -- after k sweeps the first k queries are final, in practice a handful of sweeps suffice.
+// The claim table lives in LDS (one int per feature); entries carry the sweep number in the high 16 bits, decreasing,
+// so atomicMin both selects the newest sweep and the lowest query index and no reset pass is needed.
+// Candidates are read in the transposed layout [k*nq + i] (coalesced across the thread-per-query mapping).
+// status[0]: 0 ok, 1 not converged within max_it (host falls back), 2 a candidate list exceeded cap (host retries);
+// status[1] = nmatches, status[2] = sweeps, status[3] = longest candidate list.
+constexpr int RESOLVE_MAX_Q = 65535;
+MORB_PHASE_DECL(g_ph_res);
+
+// RESOLVE_K (above): sorted shortlist per query built by k_project; a full rescan happens only when all of it is taken
+
+// Evaluates query i against the current claim table.  `avail(g)` decides visibility.  Candidates are visited in the
+// order given; FRAMES: first minimum.  POINTS: best + second (with multiplicity) and their levels.
+// LDSQ: the per-query sweep state (shortlist features + distances, blocks flag, current choice) also lives in LDS, so a
+// sweep touches no global memory at all; used whenever it fits next to the claim table.
+template <bool POINTS, bool LDSQ>
+__global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __restrict__ qmeta /* {blocks, angle bits} */, int nq, int cap,
+                                                  const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
+                                                  const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
+                                                  const float* __restrict__ f_angle, int th_high, float nnratio,
+                                                  int check_ori, int max_it, int* __restrict__ choice,
+                                                  const int* __restrict__ topk /* (2*RESOLVE_K+1)*nq ints */,
+                                                  int* __restrict__ match_of_feature, int* __restrict__ status, int tagb) {
+    // tagb != 0: every result word carries this launch's sequence number in bits 20.. (values are small: a match word is
+    // stored as value + 2), so a host that watches the pinned result memory can tell, word by word, what has arrived --
+    // words written by different waves reach host memory in no particular order, a single "done" flag proves nothing.
+    extern __shared__ __attribute__((aligned(16))) int s_claim[];  // two claim tables, one entry per feature each (capacity F.n_total)
+    __shared__ int s_hist[ORBM_HISTO_LENGTH];
+    __shared__ int s_keep[3];
+    __shared__ int s_red, s_nres2[2];  // (s_nres2: rescans per sweep, instrumented build only)
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63;
+    MORB_PHASE(g_ph_res, 0);
+    // the actual feature count is only needed by the last loops: nothing of the set-up waits for this load
+    const int NT = F.n_total_dev ? *F.n_total_dev : F.n_total;
+    // shortlist written by k_project: keys (dist << 16 | visiting position) and feature indices, sorted, occupied excluded
+    const int* tk_key = topk;                             // [k*nq + i]
+    const int* tk_g = topk + RESOLVE_K * nq;      // [k*nq + i]
+    // LDS after the two claim tables: candidate counts u16[nq] (padded to 4 bytes); with LDSQ also
+    //   choice[nq] | shortlist (distance << 16 | feature, 0xffff = none) [K][nq] | query angle [nq] | feature angle [F.n_total] | flags [nq] (u8)
+    int* s_claim2 = s_claim + F.n_total;
+    unsigned short* l_cnt = reinterpret_cast<unsigned short*>(s_claim + 2 * F.n_total);   // candidate count of every query
+    int* l_choice = s_claim + 2 * F.n_total + (nq + 1) / 2;
+    int* l_gd = l_choice + nq;
+    float* l_ang = reinterpret_cast<float*>(l_gd + RESOLVE_K * nq);
+    float* l_fang = l_ang + nq;
+    unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_fang + F.n_total);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
+    if (tid == 0) { s_red = 0; s_nres2[0] = 0; s_nres2[1] = 0; }
+    for (int g = tid; g < F.n_total; g += T) {  // capacity-sized: rows past the real count are never referenced
+        s_claim[g] = 0x7fffffff; s_claim2[g] = 0x7fffffff;
+        if (LDSQ && !POINTS && check_ori) l_fang[g] = f_angle[g];
+    }
+    int mx = 0;
+    for (int i = tid; i < nq; i += T) {  // every load of this pass is independent: one trip to HBM for the whole set-up
+        const int cnt_i = cand_count[i];
+        mx = max(mx, cnt_i);
+        l_cnt[i] = (unsigned short)min(cnt_i, 65535);
+        if (LDSQ) {
+            l_choice[i] = -1;
+            const int2 qm = qmeta[i];
+            l_fl[i] = (unsigned char)((qm.x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
+            l_ang[i] = __int_as_float(qm.y);
+#pragma unroll
+            for (int k = 0; k < RESOLVE_K; ++k) {
+                // distance in the high half, feature in the low one; an empty slot (feature -1) reads 0xffff there (the
+                // LDS-resident form is only chosen for frames below 65535 features)
+                l_gd[k * nq + i] = (tk_key[k * nq + i] & 0xffff0000) | (tk_g[k * nq + i] & 0xffff);
+            }
+        } else {
+            choice[i] = -1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if (lane == 0) atomicMax(&s_red, mx);  // one LDS atomic per wave: same-address atomics of a whole block serialise
+    __syncthreads();
+    const int maxcount = s_red;
+    if (maxcount > cap) {
+        if (tid == 0) { status[1] = tagb | 0; status[2] = tagb | 0; status[3] = tagb | maxcount; status[0] = tagb | 2; }
+        return;
+    }
+    MORB_PHASE(g_ph_res, 2);
+    constexpr int NEED = POINTS ? 2 : 1;
+    int it = 0, changed = 1;
+    for (; it < max_it && changed; ++it) {
+        // Two claim tables alternate: sweep `it` READS the claims the previous sweep's choices left in `rd` (entries tagged
+        // `tag`) and WRITES the claims of its own choices into `wr` (tagged `tag_next`), so a sweep is ONE pass over the
+        // queries and one barrier.  Tags decrease, so atomicMin prefers the newer sweep over stale entries of the same
+        // table (two sweeps old) and, within a sweep, the lowest query index.
+        const int tag = (0x7ffe - it) << 16, tag_next = (0x7ffd - it) << 16;
+        const int* rd = (it & 1) ? s_claim2 : s_claim;
+        int* wr = (it & 1) ? s_claim : s_claim2;
+#ifdef MORB_PHASE_CLOCKS
+        int& s_nres = s_nres2[it & 1];
+        if (tid == 0) s_nres2[(it + 1) & 1] = 0;
+#endif
+        int ch = 0;
+        // The sweep is bound by the instruction count of its one workgroup (2000 queries on four SIMDs), so the walk is cut
+        // in two: entries 0-1 first -- almost every query is decided there -- and entries 2..K-1 only for waves in which
+        // some lane is still walking (wave-uniform branch).  A claim hides candidate g from query i when it carries this
+        // sweep's read tag and a lower query index, i.e. lies in [tag, tag + i): one subtract and one unsigned compare
+        // (older sweeps carry larger tags, 0x7fffffff is larger still).
+        constexpr int K0 = 2;
+        for (int base = 0; base < nq; base += T) {   // uniform trip count: the cooperative rescans below need whole waves
+            const int i = base + tid;
+            const bool valid = i < nq;
+            int gk[RESOLVE_K], dk[RESOLVE_K], ck[RESOLVE_K];
+            int fl = 0, old = -1, nc = -1;
+            bool need_rescan = false;
+            if (valid) {
+                fl = LDSQ ? (int)l_fl[i] : ((qmeta[i].x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
+                old = LDSQ ? l_choice[i] : choice[i];
+                int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1, g2 = -1;
+                int found = 0, taken = 0;
+                bool walking = true;
+                auto fetch = [&](int k) {
+                    if (LDSQ) {
+                        const int v = l_gd[k * nq + i];
+                        gk[k] = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
+                        dk[k] = (int)((unsigned)v >> 16);
+                    } else { gk[k] = tk_g[k * nq + i]; dk[k] = tk_key[k * nq + i] >> 16; }
+                };
+                auto walk = [&](int k) {
+                    if (gk[k] < 0) walking = false;   // the shortlist is sorted: empty slots are at the end
+                    if (walking) {
+                        if ((unsigned)(ck[k] - tag) < (unsigned)i) ++taken;
+                        else {
+                            if (found == 0) { best = dk[k]; bidx = gk[k]; }
+                            else { best2 = dk[k]; g2 = gk[k]; }
+                            if (++found >= NEED) walking = false;
+                        }
+                    }
+                };
+#pragma unroll
+                for (int k = 0; k < K0; ++k) fetch(k);
+#pragma unroll
+                for (int k = 0; k < K0; ++k) ck[k] = gk[k] >= 0 ? rd[gk[k]] : 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < K0; ++k) walk(k);
+                if (__ballot(walking)) {
+#pragma unroll
+                    for (int k = K0; k < RESOLVE_K; ++k) fetch(k);
+#pragma unroll
+                    for (int k = K0; k < RESOLVE_K; ++k) ck[k] = gk[k] >= 0 ? rd[gk[k]] : 0x7fffffff;
+#pragma unroll
+                    for (int k = K0; k < RESOLVE_K; ++k) walk(k);
+                }
+                if (POINTS) { if (bidx >= 0) lvl = F.octave[bidx]; if (g2 >= 0) lvl2 = F.octave[g2]; }
+                // the shortlist is exact unless it ran dry while longer lists exist (rare): rescanned right below
+                need_rescan = found < NEED && (fl & 2) && taken > 0;
+                if (!need_rescan && best <= th_high && bidx >= 0) {
+                    nc = bidx;
+                    if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
+                }
+            }
+            // Rescans, one query at a time by the whole wave that owns it, in place: full candidate list of the query, 64
+            // candidates per round, keys (distance << 16 | visiting position) -- the smallest available key is the
+            // sequential scan's first minimum, the next one its runner-up.  (A separate rescan phase behind a barrier cost
+            // one more barrier and ~0.9 us per sweep that had any.)
+            unsigned long long todo = __ballot(need_rescan);
+#ifdef MORB_PHASE_CLOCKS
+            if (todo && lane == 0 && it < 15) atomicAdd(&s_nres, __popcll(todo));
+#endif
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int qi = __builtin_amdgcn_readlane(i, src);
+                const int full = l_cnt[qi];
+                int k1 = 0x7fffffff, k2 = 0x7fffffff, g1 = -1;
+                for (int k0 = 0; k0 < full; k0 += 64) {
+                    const int k = k0 + lane;
+                    int key = 0x7fffffff, g = -1;
+                    if (k < full) {
+                        g = cand_idx[k * nq + qi];
+                        const int d = cand_dist[k * nq + qi];
+                        bool avail = !(occupied && occupied[g]);
+                        if ((unsigned)(rd[g] - tag) < (unsigned)qi) avail = false;
+                        if (avail) key = (d << 16) | k;
+                    }
+                    const int m1 = (int)wave_min_u32((unsigned)key);   // keys are non-negative: unsigned order == signed order
+                    int m2 = 0x7fffffff;
+                    if (POINTS) m2 = (int)wave_min_u32((unsigned)(key == m1 ? 0x7fffffff : key));
+                    // merge the round's (m1 <= m2) into the running (k1 <= k2); the winner's feature comes along by readlane
+                    if (m1 < k1) {
+                        k2 = min(k1, m2); k1 = m1;
+                        g1 = __builtin_amdgcn_readlane(g, __ffsll((long long)__ballot(key == m1)) - 1);   // positions are unique
+                    }
+                    else k2 = min(k2, m1);
+                }
+                int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;   // (wave-uniform from here on)
+                if (k1 != 0x7fffffff) {
+                    best = k1 >> 16; bidx = g1;
+                    if (POINTS) lvl = F.octave[bidx];
+                }
+                if (POINTS && k2 != 0x7fffffff) { best2 = k2 >> 16; lvl2 = F.octave[cand_idx[(k2 & 0xffff) * nq + qi]]; }
+                int rnc = -1;
+                if (best <= th_high && bidx >= 0) {
+                    rnc = bidx;
+                    if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) rnc = -1;
+                }
+                if (lane == src) nc = rnc;
+            }
+            if (valid) {
+                if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
+                if (nc >= 0 && (fl & 1)) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
+            }
+        }
+#ifdef MORB_PHASE_CLOCKS
+        __syncthreads();
+        if (tid == 0 && it < 15) g_ph_res[40 + it] = (unsigned long long)s_nres;
+#endif
+        if (it == 0) MORB_PHASE(g_ph_res, 20); else if (it == 5) MORB_PHASE(g_ph_res, 24);
+        if (it == 0) MORB_PHASE(g_ph_res, 22); else if (it == 5) MORB_PHASE(g_ph_res, 26);
+        changed = __syncthreads_or(ch);
+        MORB_PHASE(g_ph_res, min(3 + it, 50));
+    }
+    if (changed) {  // ran out of sweeps
+        if (tid == 0) { status[1] = tagb | 0; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | 1; }
+        return;
+    }
+    // owners: the last claimant in query order (claims after a blocking one are impossible, so max index == final owner)
+    for (int g = tid; g < NT; g += T) s_claim[g] = -1;
+    if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
+    if (tid == 0) s_red = 0;
+    __syncthreads();
+    MORB_PHASE(g_ph_res, 52);
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    int acc = 0;
+    for (int i = tid; i < nq; i += T) {
+        const int c = LDSQ ? l_choice[i] : choice[i];
+        if (c < 0) continue;
+        ++acc;
+        atomicMax(&s_claim[c], i);
+        if (!POINTS && check_ori) {
+            float rot = LDSQ ? l_ang[i] - l_fang[c] : __int_as_float(qmeta[i].y) - f_angle[c];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            const bool inr = bin >= 0 && bin < ORBM_HISTO_LENGTH;
+            if (LDSQ) l_fl[i] = (unsigned char)((l_fl[i] & 3) | ((inr ? bin + 1 : 0) << 2));
+            // most matches of a frame share a rotation bin: up to three bins of the wave (those of its first lanes) are
+            // counted with one atomic each, whatever is left (scattered bins: few lanes per address) goes in directly
+            unsigned long long todo = __ballot(inr);
+            for (int rounds = 0; todo && rounds < 3; ++rounds) {
+                const int b0 = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);
+                const unsigned long long same = __ballot(inr && bin == b0);
+                if (inr && bin == b0 && lane == __ffsll((long long)same) - 1) atomicAdd(&s_hist[b0], __popcll(same));
+                todo &= ~same;
+            }
+            if (inr && ((todo >> lane) & 1)) atomicAdd(&s_hist[bin], 1);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) atomicAdd(&s_red, acc);
+    __syncthreads();
+    MORB_PHASE(g_ph_res, 53);
+    if (!POINTS && check_ori) {
+        if (tid < 64) {
+            // ComputeThreeMaxima (reference src/ORBmatcher.cc:3948-3989).  Its scan with strict '>' keeps the three fullest
+            // non-empty bins, the earlier bin first among equals: bin b's place is the number of bins that beat it
+            // (fuller, or as full and earlier) -- 30 readlanes on one wave instead of 30 dependent LDS reads on one thread.
+            const int sv = tid < ORBM_HISTO_LENGTH ? s_hist[tid] : 0;
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < ORBM_HISTO_LENGTH; ++j) {
+                const int sj = __builtin_amdgcn_readlane(sv, j);
+                rank += (sj > sv || (sj == sv && j < tid)) ? 1 : 0;
+            }
+            const bool in = tid < ORBM_HISTO_LENGTH && sv > 0;
+            const unsigned long long r1 = __ballot(in && rank == 0), r2 = __ballot(in && rank == 1), r3 = __ballot(in && rank == 2);
+            int i1 = r1 ? __ffsll((long long)r1) - 1 : -1, i2 = r2 ? __ffsll((long long)r2) - 1 : -1, i3 = r3 ? __ffsll((long long)r3) - 1 : -1;
+            const int m1 = i1 >= 0 ? __builtin_amdgcn_readlane(sv, i1) : 0, m2 = i2 >= 0 ? __builtin_amdgcn_readlane(sv, i2) : 0,
+                      m3 = i3 >= 0 ? __builtin_amdgcn_readlane(sv, i3) : 0;
+            if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+            else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+            if (tid == 0) { s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3; }
+        }
+        __syncthreads();
+        MORB_PHASE(g_ph_res, 54);
+        int rej = 0;
+        for (int i = tid; i < nq; i += T) {
+            const int c = LDSQ ? l_choice[i] : choice[i];
+            if (c < 0) continue;
+            int bin;
+            if (LDSQ) {
+                bin = (int)(l_fl[i] >> 2) - 1;  // -1: outside the histogram, never rejected
+            } else {
+                float rot = __int_as_float(qmeta[i].y) - f_angle[c];
+                if (rot < 0.0) rot += 360.0f;
+                bin = (int)roundf(rot * factor);
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            }
+            if (bin >= 0 && bin < ORBM_HISTO_LENGTH && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
+                s_claim[c] = -2;  // every writer stores -2; owners were settled before the barrier
+                ++rej;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rej += __shfl_xor(rej, o);
+        if (lane == 0) atomicSub(&s_red, rej);
+        __syncthreads();
+    }
+    MORB_PHASE(g_ph_res, 60);
+    for (int g = tid; g < NT; g += T) match_of_feature[g] = tagb ? (tagb | (s_claim[g] + 2)) : s_claim[g];
+    if (tid == 0) { status[1] = tagb | s_red; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | 0; }
+    MORB_PHASE(g_ph_res, 61);
+#ifdef MORB_PHASE_CLOCKS
+    if (tid == 0) g_ph_res[62] = (unsigned long long)it;
+#endif
+}
+
+// ---- the same resolve for frames whose claim tables do not fit LDS (beyond ~18 000 features: 8 cameras x 4000), spread
+// over the whole chip.  The two claim tables, the choices and the owner table live in HBM (L2-resident); one launch per
+// sweep (a grid-wide barrier is exactly what a kernel boundary is), a fixed number of sweeps is enqueued and a sweep
+// that finds "nothing changed" in its predecessor's flag does nothing, so no host round trip sits between sweeps.
+// state: [0] longest candidate list, [1] matches, [2..4] kept rotation bins, [8..8+RS_MAX_SWEEPS) changed flags,
+//        [48..78) rotation histogram.
+constexpr int RS_MAX_SWEEPS = 24;
+constexpr int RS_STATE_INTS = 80;
+
+__global__ __launch_bounds__(256) void k_rs_init(int n_cap, int nq, int* __restrict__ tab0, int* __restrict__ tab1,
+                                                 int* __restrict__ owner, int* __restrict__ choice,
+                                                 const int* __restrict__ cand_count, int* __restrict__ state) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_cap) { tab0[i] = 0x7fffffff; tab1[i] = 0x7fffffff; owner[i] = -1; }
+    int mx = 0;
+    if (i < nq) { choice[i] = -1; mx = cand_count[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(&state[0], mx);
+}
+
+template <bool POINTS>
+__global__ __launch_bounds__(256) void k_rs_sweep(FrameDev F, const orbm_query* __restrict__ q, int nq, int cap, int it,
+                                                  const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
+                                                  const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
+                                                  int th_high, float nnratio, int* __restrict__ choice,
+                                                  const int* __restrict__ topk, const int* __restrict__ rd,
+                                                  int* __restrict__ wr, int* __restrict__ state) {
+    if (state[0] > cap) return;                        // a candidate list overflowed: reported by k_rs_write
+    if (it > 0 && state[8 + it - 1] == 0) return;      // the previous sweep changed nothing: fixed point reached
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    constexpr int NEED = POINTS ? 2 : 1;
+    const int tag = (0x7ffe - it) << 16, tag_next = (0x7ffd - it) << 16;
+    int ch = 0;
+    if (i < nq) {
+        const int* tk_key = topk;
+        const int* tk_g = topk + RESOLVE_K * nq;
+        int sg[RESOLVE_K], sd[RESOLVE_K];
+#pragma unroll
+        for (int k = 0; k < RESOLVE_K; ++k) { sg[k] = tk_g[k * nq + i]; sd[k] = tk_key[k * nq + i] >> 16; }
+        const bool longer = topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K;
+        const int old = choice[i], bl = q[i].blocks;
+        int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
+        int found = 0, taken = 0;
+#pragma unroll
+        for (int k = 0; k < RESOLVE_K; ++k) {
+            if (found >= NEED) break;
+            const int g = sg[k];
+            if (g < 0) break;
+            const int cl = rd[g];
+            if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) { ++taken; continue; }
+            if (found == 0) { best = sd[k]; bidx = g; if (POINTS) lvl = F.octave[g]; }
+            else { best2 = sd[k]; lvl2 = F.octave[g]; }
+            ++found;
+        }
+        if (found < NEED && longer && taken > 0) {  // the shortlist ran dry: scan the whole list (rare), 8 loads in flight
+            best = 256; best2 = 256; lvl = -1; lvl2 = -1; bidx = -1;
+            const int full = cand_count[i];
+            for (int k0 = 0; k0 < full; k0 += 8) {
+                int cg[8], cdist[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = min(k0 + u, full - 1);
+                    cg[u] = cand_idx[k * nq + i];
+                    cdist[u] = cand_dist[k * nq + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + u >= full) continue;
+                    const int g = cg[u];
+                    if (occupied && occupied[g]) continue;
+                    const int cl = rd[g];
+                    if ((cl >> 16) == (tag >> 16) && (cl & 0xffff) < i) continue;
+                    const int d = cdist[u];
+                    if (POINTS) {
+                        if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = F.octave[g]; bidx = g; }
+                        else if (d < best2) { lvl2 = F.octave[g]; best2 = d; }
+                    } else if (d < best) { best = d; bidx = g; }
+                }
+            }
+        }
+        int nc = -1;
+        if (best <= th_high && bidx >= 0) {
+            nc = bidx;
+            if (POINTS && lvl == lvl2 && (float)best > nnratio * (float)best2) nc = -1;
+        }
+        if (nc != old) { ch = 1; choice[i] = nc; }
+        if (nc >= 0 && bl) atomicMin(&wr[nc], tag_next | i);
+    }
+    if (__syncthreads_or(ch) && threadIdx.x == 0) atomicOr(&state[8 + it], 1);
+}
+
+// owners (last claimant in query order) + rotation histogram + match count
+__global__ __launch_bounds__(256) void k_rs_owner(const orbm_query* __restrict__ q, int nq, int cap, const int* __restrict__ choice,
+                                                  const float* __restrict__ f_angle, int check_ori, int* __restrict__ owner,
+                                                  int* __restrict__ state) {
+    if (state[0] > cap || state[8 + RS_MAX_SWEEPS - 1] != 0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = i < nq ? choice[i] : -1;
+    if (c >= 0) atomicMax(&owner[c], i);
+    const unsigned long long any = __ballot(c >= 0);
+    if (lane == 0 && any) atomicAdd(&state[1], __popcll(any));
+    if (check_ori) {
+        int bin = -1;
+        if (c >= 0) {
+            float rot = q[i].angle - f_angle[c];
+            if (rot < 0.0) rot += 360.0f;
+            bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            if (bin < 0 || bin >= ORBM_HISTO_LENGTH) bin = -1;
+        }
+        unsigned long long todo = __ballot(bin >= 0);
+        while (todo) {  // one atomic per distinct bin of the wave
+            const int b0 = __shfl(bin, __ffsll((long long)todo) - 1);
+            const unsigned long long same = __ballot(bin == b0);
+            if (bin == b0 && lane == __ffsll((long long)same) - 1) atomicAdd(&state[48 + b0], __popcll(same));
+            todo &= ~same;
+        }
+    }
+}
+
+// ComputeThreeMaxima (every block, redundantly) + rejection of the matches outside the three fullest rotation bins
+__global__ __launch_bounds__(256) void k_rs_reject(const orbm_query* __restrict__ q, int nq, int cap, const int* __restrict__ choice,
+                                                   const float* __restrict__ f_angle, int* __restrict__ owner,
+                                                   int* __restrict__ state) {
+    if (state[0] > cap || state[8 + RS_MAX_SWEEPS - 1] != 0) return;
+    __shared__ int s_keep[3];
+    if (threadIdx.x == 0) {  // reference src/ORBmatcher.cc:3948-3989
+        int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
+            const int sz = state[48 + b];
+            if (sz > m1) { m3 = m2; i3 = i2; m2 = m1; i2 = i1; m1 = sz; i1 = b; }
+            else if (sz > m2) { m3 = m2; i3 = i2; m2 = sz; i2 = b; }
+            else if (sz > m3) { m3 = sz; i3 = b; }
+        }
+        if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+        else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+        s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool rej = false;
+    if (i < nq) {
+        const int c = choice[i];
+        if (c >= 0) {
+            float rot = q[i].angle - f_angle[c];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < ORBM_HISTO_LENGTH && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
+                owner[c] = -2;  // every writer stores -2; the owners were settled by the previous kernel
+                rej = true;
+            }
+        }
+    }
+    const unsigned long long r = __ballot(rej);
+    if (lane == 0 && r) atomicSub(&state[1], __popcll(r));
+}
+
+__global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __restrict__ n_total_dev, int cap, const int* __restrict__ owner,
+                                                  const int* __restrict__ state, int* __restrict__ match_of_feature,
+                                                  int* __restrict__ status) {
+    const int NT = n_total_dev ? *n_total_dev : NT_host;
+    const bool overflow = state[0] > cap, stuck = state[8 + RS_MAX_SWEEPS - 1] != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int sweeps = 0;
+        for (int k = 0; k < RS_MAX_SWEEPS; ++k) sweeps += state[8 + k] ? 1 : 0;
+        status[0] = overflow ? 2 : (stuck ? 1 : 0);
+        status[1] = (overflow || stuck) ? 0 : state[1];
+        status[2] = sweeps + 1;
+        status[3] = state[0];
+    }
+    if (overflow || stuck) return;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < NT) match_of_feature[g] = owner[g];
+}
+
+// Multi-GPU exchange: `gathered` holds one block per rank (rank order), each = cap_rows descriptor rows (the rank's
+// cameras packed back to back) + the count trailer.  The rows in use are copied into one contiguous list in global camera
+// order; block (0, 0) also writes the camera starts, the {features, first query, queries} triple of rank `rank`, and a
+// copy of all counts into mapped pinned memory.  Every block recomputes the few prefix sums it needs from the trailers.
+}  // namespace
+
+int morb::search_raise_lds_limits() {
+    const void* fns[] = {(const void*)k_resolve<true, false>, (const void*)k_resolve<false, false>, (const void*)k_resolve<true, true>,
+                         (const void*)k_resolve<false, true>};
+    for (const void* fn : fns) MORB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    return ORB_OK;
+}
+
+int morb::phases_resolve(unsigned long long* out64) {
+#ifdef MORB_PHASE_CLOCKS
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_res), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+#else
+    (void)out64; return -1;
+#endif
+}
+
+// k_project into m->d_i0 (idx) / d_u16 (dist) / d_i1 (count); optionally copied to the pinned host mirrors
+static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap, int gate_right,
+                       int with_dist, bool upload_queries, bool to_host, int transposed = 0,
+                       const uint8_t* d_occupied = nullptr, int* d_topk = nullptr, int short_th = 256,
+                       const float* d_inv_sigma2 = nullptr, const orbm_query* q_device_visible = nullptr, int2* d_qmeta = nullptr,
+                       const orbm_window* d_win2 = nullptr) {
+    int rc;
+    if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_i0.reserve((size_t)nq * cap)) ||
+        (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)))
+        return rc;
+    if (upload_queries)
+        MORB_HIP(hipMemcpyAsync(m->d_queries.p, q, (size_t)nq * sizeof(orbm_query), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_project, dim3((nq + 3) / 4), dim3(256), 0, m->stream, f->dev(),
+                       q_device_visible ? q_device_visible : (const orbm_query*)m->d_queries.p, nq, cap, gate_right, with_dist, transposed,
+                       m->d_i0.p, m->d_u16.p, m->d_i1.p, d_occupied, d_topk, short_th, d_inv_sigma2, d_qmeta, d_win2);
+    MORB_HIP(hipGetLastError());
+    if (to_host) {
+        if ((rc = m->h_i0.reserve((size_t)nq * cap)) || (rc = m->h_u16.reserve((size_t)nq * cap)) || (rc = m->h_i1.reserve(nq)))
+            return rc;
+        MORB_HIP(hipMemcpyAsync(m->h_i1.p, m->d_i1.p, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+        MORB_HIP(hipMemcpyAsync(m->h_i0.p, m->d_i0.p, (size_t)nq * cap * 4, hipMemcpyDeviceToHost, m->stream));
+        if (with_dist) MORB_HIP(hipMemcpyAsync(m->h_u16.p, m->d_u16.p, (size_t)nq * cap * 2, hipMemcpyDeviceToHost, m->stream));
+        MORB_HIP(hipStreamSynchronize(m->stream));
+    }
+    return ORB_OK;
+}
+
+// Runs k_project with a growing per-query capacity until every list fits; results in m->h_i0 / h_u16 / h_i1.
+static int project_all(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int gate_right, int with_dist,
+                       int* cap_out, int cap0 = 64, const orbm_window* d_win2 = nullptr) {
+    int cap = cap0;
+    bool first = true;
+    for (;;) {
+        int rc = run_project(m, f, q, nq, cap, gate_right, with_dist, first, true, 0, nullptr, nullptr, 256, nullptr, nullptr, nullptr, d_win2);
+        if (rc) return rc;
+        first = false;
+        int mx = 0;
+        for (int i = 0; i < nq; i++) mx = std::max(mx, m->h_i1.p[i]);
+        if (mx <= cap) break;
+        cap = (mx + 63) & ~63;
+    }
+    *cap_out = cap;
+    return ORB_OK;
+}
+
+int orbm_features_in_area(orbm_matcher* m, const orbm_frame* f, int cam, float x, float y, float r, int min_level,
+                          int max_level, int32_t* out, int cap, int* n) {
+    MORB_ARG(m && f && n && (cap == 0 || out));
+    MORB_HIP(hipSetDevice(m->device));
+    orbm_query Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.u = x; Q.v = y; Q.radius = r; Q.min_level = min_level; Q.max_level = max_level; Q.cam = cam;
+    int pc = 0;
+    int rc = project_all(m, f, &Q, 1, /*gate_right=*/0, /*with_dist=*/0, &pc);
+    if (rc) return rc;
+    *n = m->h_i1.p[0];
+    for (int i = 0; i < *n && i < cap; i++) out[i] = m->h_i0.p[i];
+    return ORB_OK;
+}
+
+int orbm_project_candidates(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap_per_query,
+                            int32_t* cand_idx, uint16_t* cand_dist, int32_t* cand_count) {
+    MORB_ARG(m && f && nq >= 0 && cap_per_query > 0);
+    if (nq == 0) return ORB_OK;
+    MORB_ARG(q && cand_idx && cand_dist && cand_count);
+    MORB_HIP(hipSetDevice(m->device));
+    int rc = run_project(m, f, q, nq, cap_per_query, 1, 1, true, true);
+    if (rc) return rc;
+    bool overflow = false;
+    for (int i = 0; i < nq; i++) {
+        cand_count[i] = m->h_i1.p[i];
+        if (cand_count[i] > cap_per_query) overflow = true;
+    }
+    memcpy(cand_idx, m->h_i0.p, (size_t)nq * cap_per_query * 4);
+    memcpy(cand_dist, m->h_u16.p, (size_t)nq * cap_per_query * 2);
+    if (overflow) { morb::set_error("candidate list longer than cap_per_query=%d", cap_per_query); return ORB_E_CAPACITY; }
+    return ORB_OK;
+}
+
+int orbm_project_best(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, const uint8_t* occupied, int gate,
+                      const float* inv_level_sigma2, int n_levels, int32_t* best_idx, int32_t* best_dist) {
+    MORB_ARG(m && f && nq >= 0 && gate >= 0 && gate <= 2);
+    if (nq == 0) return ORB_OK;
+    MORB_ARG(q && best_idx && best_dist);
+    MORB_ARG(gate != ORBM_GATE_CHI2 || (inv_level_sigma2 && n_levels > 0 && n_levels <= 64));
+    MORB_HIP(hipSetDevice(m->device));
+    const int n = f->n_total;
+    if (n == 0) { for (int i = 0; i < nq; ++i) { best_idx[i] = -1; best_dist[i] = 256; } return ORB_OK; }
+    int rc;
+    if ((rc = m->d_claim.reserve((size_t)(2 * RESOLVE_K + 1) * nq)) || (rc = m->d_occ.reserve(std::max(n, 16) + 512)) ||
+        (rc = m->h_i2.reserve((size_t)2 * nq)))
+        return rc;
+    if (occupied) MORB_HIP(hipMemcpyAsync(m->d_occ.p, occupied, (size_t)n, hipMemcpyHostToDevice, m->stream));
+    float* d_sig = nullptr;
+    if (gate == ORBM_GATE_CHI2) {   // the level table rides behind the occupied bytes
+        if (ensure_host_copies(f)) return ORB_E_HIP;
+        for (int g = 0; g < n; ++g) MORB_ARG(f->octave[g] >= 0 && f->octave[g] < n_levels);
+        d_sig = (float*)(m->d_occ.p + ((std::max(n, 16) + 15) & ~15));
+        MORB_HIP(hipMemcpyAsync(d_sig, inv_level_sigma2, (size_t)n_levels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    }
+    // the sorted shortlist k_project keeps per query (distance << 16 | visiting position) starts with exactly the candidate
+    // the reference's `if (dist < bestDist)` loop ends on: smallest distance, first in visiting order
+    if ((rc = run_project(m, f, q, nq, /*cap=*/64, gate, 1, true, false, /*transposed=*/1, occupied ? m->d_occ.p : nullptr, m->d_claim.p, 256, d_sig)))
+        return rc;
+    MORB_HIP(hipMemcpyAsync(m->h_i2.p, m->d_claim.p, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+    MORB_HIP(hipMemcpyAsync(m->h_i2.p + nq, m->d_claim.p + (size_t)RESOLVE_K * nq, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+    MORB_HIP(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < nq; ++i) {
+        const int key = m->h_i2.p[i], g = m->h_i2.p[nq + i];
+        best_idx[i] = g; best_dist[i] = g >= 0 ? (key >> 16) : 256;
+    }
+    return ORB_OK;
+}
+
+// inspection / bench (roofline M3): the projection kernel alone, in the configuration the frame search launches it in
+// (gates on, distances, transposed lists, shortlist extraction), timed with HIP events on the handle's stream
+int orbm_debug_time_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int th_high, int iters, float* avg_us,
+                            long long* n_gated) {
+    MORB_ARG(m && f && q && nq > 0 && iters > 0 && avg_us && n_gated && f->n_total > 0);
+    MORB_HIP(hipSetDevice(m->device));
+    int rc;
+    if ((rc = m->d_claim.reserve((size_t)(2 * RESOLVE_K + 1) * nq)) || (rc = m->d_qmeta.reserve(nq)) || (rc = m->h_i1.reserve(nq)))
+        return rc;
+    if ((rc = run_project(m, f, q, nq, 64, 1, 1, true, false, 1, nullptr, m->d_claim.p, th_high, nullptr, nullptr, m->d_qmeta.p))) return rc;
+    hipEvent_t e0, e1;
+    MORB_HIP(hipEventCreate(&e0)); MORB_HIP(hipEventCreate(&e1));
+    MORB_HIP(hipEventRecord(e0, m->stream));
+    for (int it = 0; it < iters && !rc; ++it)
+        rc = run_project(m, f, q, nq, 64, 1, 1, false, false, 1, nullptr, m->d_claim.p, th_high, nullptr, nullptr, m->d_qmeta.p);
+    hipError_t he = hipEventRecord(e1, m->stream);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    MORB_HIP(he);
+    MORB_HIP(hipMemcpy(m->h_i1.p, m->d_i1.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    long long tot = 0;
+    for (int i = 0; i < nq; ++i) tot += m->h_i1.p[i];
+    *avg_us = ms * 1e3f / (float)iters; *n_gated = tot;
+    return ORB_OK;
+}
+
+// Sequential resolve on the host from the ordered candidate lists (fallback of the device resolve; same semantics).
+static int host_resolve(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, const uint8_t* occupied,
+                        bool points, float nnratio, int th_high, int check_orientation, int cap0, int32_t* match_of_feature,
+                        int* nmatches, const orbm_window* d_win2 = nullptr) {
+    int rc = ensure_host_copies(cur);
+    if (rc) return rc;
+    int cap = 0;
+    if ((rc = project_all(m, cur, q, nq, 1, 1, &cap, cap0, d_win2))) return rc;
+    for (int g = 0; g < cur->n_total; g++) match_of_feature[g] = -1;
+    std::vector<int32_t> rot[ORBM_HISTO_LENGTH];
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    int nm = 0;
+    for (int i = 0; i < nq; i++) {
+        const int cnt = m->h_i1.p[i];
+        const int32_t* ci = m->h_i0.p + (size_t)i * cap;
+        const uint16_t* cd = m->h_u16.p + (size_t)i * cap;
+        int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1;
+        for (int k = 0; k < cnt; k++) {
+            const int g = ci[k];
+            const int owner = match_of_feature[g];
+            if (owner >= 0 ? q[owner].blocks != 0 : (occupied && occupied[g])) continue;
+            const int d = cd[k];
+            if (points) {
+                if (d < best) { best2 = best; best = d; lvl2 = lvl; lvl = cur->octave[g]; bidx = g; }
+                else if (d < best2) { lvl2 = cur->octave[g]; best2 = d; }
+            } else if (d < best) { best = d; bidx = g; }
+        }
+        if (best <= th_high && bidx >= 0) {
+            if (points && lvl == lvl2 && (float)best > nnratio * (float)best2) continue;
+            match_of_feature[bidx] = i;
+            nm++;
+            if (!points && check_orientation) {
+                float rotv = q[i].angle - cur->angle[bidx];
+                if (rotv < 0.0) rotv += 360.0f;
+                int bin = (int)roundf(rotv * factor);
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < ORBM_HISTO_LENGTH) rot[bin].push_back(bidx);
+            }
+        }
+    }
+    if (!points && check_orientation) {
+        int sizes[ORBM_HISTO_LENGTH], ind[3];
+        for (int b = 0; b < ORBM_HISTO_LENGTH; b++) sizes[b] = (int)rot[b].size();
+        orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, ind);
+        for (int b = 0; b < ORBM_HISTO_LENGTH; b++)
+            if (b != ind[0] && b != ind[1] && b != ind[2])
+                for (int g : rot[b]) { match_of_feature[g] = -2; nm--; }
+    }
+    *nmatches = nm;
+    return ORB_OK;
+}
+
+int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_device) {
+    const int n = J.cur->n_total;
+    J.device_path = false; J.pollable = false;
+    if (J.nq == 0 || n == 0) return ORB_OK;
+    // two claim tables (one int per feature each) + the candidate counts (u16 per query, padded); tables that do not fit LDS go
+    // to an HBM workspace (GCL variant of the kernel)
+    const size_t lds = (size_t)2 * n * sizeof(int) + (size_t)((J.nq + 1) / 2) * sizeof(int);
+    const bool multi = lds > 150 * 1024;  // multi-workgroup resolve with the tables in HBM
+    if (m->host_resolve || J.nq > RESOLVE_MAX_Q) return ORB_OK;  // finish() takes the host path
+    if (multi) { int rcg = m->d_gclaim.reserve((size_t)2 * n + RS_STATE_INTS); if (rcg) return rcg; }
+    // (tables beyond 48 KB use the opt-in dynamic LDS limit, raised per device in orbm_create)
+    int rc;
+    if ((rc = m->d_choice.reserve(J.nq)) || (rc = m->d_claim.reserve((size_t)(2 * RESOLVE_K + 1) * J.nq)) || (rc = m->d_match.reserve(n)) ||
+        (rc = m->d_status.reserve(4)) || (rc = m->h_match.reserve((size_t)n + 4)) || (rc = m->d_occ.reserve(std::max(n, 16))))
+        return rc;
+    if (J.occupied && !J.occ_dev) MORB_HIP(hipMemcpyAsync(m->d_occ.p, J.occupied, (size_t)n, hipMemcpyHostToDevice, m->stream));
+    const uint8_t* d_occ = J.occ_dev ? J.occ_dev : (J.occupied ? m->d_occ.p : nullptr);
+    const orbm_frame* cur = J.cur;
+    const int nq = J.nq, cap = J.cap, th_high = J.th_high;
+    const float nnratio = J.nnratio;
+    if ((rc = m->d_qmeta.reserve(nq))) return rc;
+    // queries in mapped pinned memory are read in place by k_project (one 68-byte record per wave); only the multi-workgroup
+    // resolve, whose kernels read the records themselves, still wants them in HBM
+    const orbm_query* q_in_place = (J.q_dev && !multi) ? J.q_dev : nullptr;
+    if (J.q_dev && multi) {
+        if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
+        MORB_HIP(hipMemcpyAsync(m->d_queries.p, J.q_dev, (size_t)nq * sizeof(orbm_query), hipMemcpyDefault, m->stream));
+    }
+    if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device && !J.q_dev, false, /*transposed=*/1, d_occ, m->d_claim.p,
+                          J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p, J.win2_dev)))
+        return rc;
+    if (multi) {
+        int* tab0 = m->d_gclaim.p; int* tab1 = tab0 + n; int* state = tab1 + n;
+        MORB_HIP(hipMemsetAsync(state, 0, RS_STATE_INTS * sizeof(int), m->stream));
+        const int nb_all = (std::max(n, nq) + 255) / 256, nb_q = (nq + 255) / 256, nb_f = (n + 255) / 256;
+        hipLaunchKernelGGL(k_rs_init, dim3(nb_all), dim3(256), 0, m->stream, n, nq, tab0, tab1, m->d_match.p, m->d_choice.p,
+                           (const int*)m->d_i1.p, state);
+        for (int it = 0; it < RS_MAX_SWEEPS; ++it) {
+            const int* rd = (it & 1) ? tab1 : tab0;
+            int* wr = (it & 1) ? tab0 : tab1;
+            if (J.points)
+                hipLaunchKernelGGL(k_rs_sweep<true>, dim3(nb_q), dim3(256), 0, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, nq,
+                                   cap, it, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ, th_high,
+                                   nnratio, m->d_choice.p, (const int*)m->d_claim.p, rd, wr, state);
+            else
+                hipLaunchKernelGGL(k_rs_sweep<false>, dim3(nb_q), dim3(256), 0, m->stream, cur->dev(), (const orbm_query*)m->d_queries.p, nq,
+                                   cap, it, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ, th_high,
+                                   nnratio, m->d_choice.p, (const int*)m->d_claim.p, rd, wr, state);
+        }
+        const int ori = J.points ? 0 : J.check_ori;
+        hipLaunchKernelGGL(k_rs_owner, dim3(nb_q), dim3(256), 0, m->stream, (const orbm_query*)m->d_queries.p, nq, cap,
+                           (const int*)m->d_choice.p, (const float*)cur->b->d_ang.p, ori, m->d_match.p, state);
+        if (ori)
+            hipLaunchKernelGGL(k_rs_reject, dim3(nb_q), dim3(256), 0, m->stream, (const orbm_query*)m->d_queries.p, nq, cap,
+                               (const int*)m->d_choice.p, (const float*)cur->b->d_ang.p, m->d_match.p, state);
+        hipLaunchKernelGGL(k_rs_write, dim3(nb_f), dim3(256), 0, m->stream, n, cur->dev().n_total_dev, cap, (const int*)m->d_match.p,
+                           (const int*)state, m->h_match.dp + 4, m->h_match.dp);
+        MORB_HIP(hipGetLastError());
+        J.device_path = true;
+        return ORB_OK;
+    }
+    // claim table + (when it fits) the per-query sweep state
+    const size_t lds_q = lds + (size_t)nq * (sizeof(int) + sizeof(float) + RESOLVE_K * sizeof(int) + 1) + (size_t)n * sizeof(float) + 16;
+    const bool ldsq = lds_q <= 150 * 1024 && n < 65535;
+    const size_t lds_use = ldsq ? lds_q : lds;
+#define MORB_RESOLVE_LAUNCH(PT, LQ)                                                                                      \
+    hipLaunchKernelGGL((k_resolve<PT, LQ>), dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const int2*)m->d_qmeta.p, \
+                       nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
+                       (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
+                       (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20)
+    J.seq = 0;
+    if (J.want_tags) { m->resolve_seq = m->resolve_seq % 2047 + 1; J.seq = m->resolve_seq; }   // 1..2047, never 0
+    if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
+    else { if (J.points) MORB_RESOLVE_LAUNCH(true, false); else MORB_RESOLVE_LAUNCH(false, false); }
+#undef MORB_RESOLVE_LAUNCH
+    MORB_HIP(hipGetLastError());  // status + matches are written by the kernel into the mapped pinned buffer
+    J.device_path = true;
+    J.pollable = J.seq != 0;
+    return ORB_OK;
+}
+
+// After the stream has been synchronised.  match_of_feature may alias m->h_match.p + 4 (then nothing is copied).
+int morb::search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_feature, int* nmatches) {
+    const int n = J.cur->n_total;
+    *nmatches = 0;
+    if (J.nq == 0 || n == 0) { for (int g = 0; g < n; g++) match_of_feature[g] = -1; return ORB_OK; }
+    if (!J.device_path) {
+        m->last_status[0] = -1; m->last_status[1] = 0; m->last_status[2] = 0; m->last_status[3] = 0;  // (host path)
+    }
+    if (!J.device_path)
+        return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, 64, match_of_feature, nmatches, J.win2_dev);
+    // Result words of a tagged launch are taken as they arrive (the caller may not have synchronised the stream): wait for
+    // the word to carry this launch's sequence number, then strip it.  After ~10 ms without progress the stream is
+    // synchronised for good (which also covers a launch that failed).
+    bool synced = false;
+    auto word = [&](int idx, int bias) -> int {
+        volatile int32_t* p = m->h_match.p + idx;
+        if (!J.seq) return *p;
+        for (int spin = 0;; ++spin) {
+            const int w = *p;
+            if ((w >> 20) == J.seq) return (w & 0xfffff) - bias;
+            if (spin > 100000 && !synced) { (void)hipStreamSynchronize(m->stream); synced = true; spin = 0; }
+            else if (spin > 100000) return -3;   // cannot happen after a synchronisation; reported below
+            __builtin_ia32_pause();
+        }
+    };
+    for (;;) {
+        const int status = word(0, 0);
+        m->last_status[0] = status;
+        for (int k = 1; k < 4; ++k) m->last_status[k] = word(k, 0);
+        if (status == -3) { morb::set_error("resolve results never arrived"); return ORB_E_HIP; }
+        if (status == 0) break;
+        if (status == 2) {  // a candidate list overflowed: retry with room for the longest one
+            J.cap = (m->last_status[3] + 63) & ~63;
+            int rc = search_enqueue(m, J, /*queries_already_on_device=*/true);
+            if (rc) return rc;
+            MORB_HIP(hipStreamSynchronize(m->stream));
+            synced = true;
+            continue;
+        }
+        // not converged within the sweep limit: exact host fallback
+        return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, J.cap, match_of_feature, nmatches, J.win2_dev);
+    }
+    if (J.seq) {
+        for (int g = 0; g < n; ++g) {
+            const int v = word(4 + g, 2);
+            if (v == -3) { morb::set_error("resolve results never arrived"); return ORB_E_HIP; }
+            match_of_feature[g] = v;
+        }
+    } else if (match_of_feature != m->h_match.p + 4) memcpy(match_of_feature, m->h_match.p + 4, (size_t)n * 4);
+    *nmatches = m->last_status[1];
+    return ORB_OK;
+}
+
+static int search_common(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq, const uint8_t* occupied,
+                         bool points, float nnratio, int th_high, int check_orientation, int32_t* match_of_feature,
+                         int* nmatches, const orbm_window* second = nullptr) {
+    SearchJob J{cur, q, nq, occupied, points, nnratio, th_high, check_orientation, 64, false};
+    int rc;
+    if (second && nq > 0) {   // second windows (two-camera loop search): a device copy for the projection kernel
+        if ((rc = m->d_win2.reserve(nq))) return rc;
+        MORB_HIP(hipMemcpyAsync(m->d_win2.p, second, (size_t)nq * sizeof(orbm_window), hipMemcpyHostToDevice, m->stream));
+        MORB_HIP(hipStreamSynchronize(m->stream));   // (`second` is the caller's)
+        J.win2_dev = m->d_win2.p;
+    }
+    // The queries and the occupied flags go through host-written staging (HBM behind the large BAR, or mapped pinned memory)
+    // and are read in place by the kernels: no pageable hipMemcpyAsync on the call's critical path.  The staging stays
+    // untouched until this call has synchronised.
+    if (nq > 0 && cur->n_total > 0 && !m->host_resolve && nq <= RESOLVE_MAX_Q) {
+        const size_t qbytes = ((size_t)nq * sizeof(orbm_query) + 255) & ~(size_t)255, obytes = occupied ? (size_t)cur->n_total : 0;
+        if ((rc = m->stage_q.reserve(qbytes + obytes + 16))) return rc;
+        memcpy(m->stage_q.p, q, (size_t)nq * sizeof(orbm_query));
+        if (occupied) memcpy(m->stage_q.p + qbytes, occupied, obytes);
+        m->stage_q.publish();
+        J.q_dev = reinterpret_cast<const orbm_query*>(m->stage_q.dp);
+        J.occ_dev = occupied ? m->stage_q.dp + qbytes : nullptr;
+    }
+    rc = search_enqueue(m, J);
+    if (rc) return rc;
+    if (J.device_path) MORB_HIP(hipStreamSynchronize(m->stream));
+    return search_finish(m, J, match_of_feature, nmatches);
+}
+
+int orbm_search_by_projection(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,
+                              const uint8_t* occupied, int th_high, int check_orientation, int32_t* match_of_feature,
+                              int* nmatches) {
+    MORB_ARG(m && cur && nq >= 0 && nmatches && (cur->n_total == 0 || match_of_feature) && (nq == 0 || q));
+    MORB_HIP(hipSetDevice(m->device));
+    return search_common(m, cur, q, nq, occupied, false, 0.f, th_high, check_orientation, match_of_feature, nmatches);
+}
+
+int orbm_search_by_projection_windows(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, const orbm_window* second, int nq,
+                                      const uint8_t* occupied, int th_high, int check_orientation, int32_t* match_of_feature,
+                                      int* nmatches) {
+    MORB_ARG(m && cur && nq >= 0 && nmatches && (cur->n_total == 0 || match_of_feature) && (nq == 0 || (q && second)));
+    MORB_HIP(hipSetDevice(m->device));
+    return search_common(m, cur, q, nq, occupied, false, 0.f, th_high, check_orientation, match_of_feature, nmatches, second);
+}
+
+int orbm_search_by_projection_points(orbm_matcher* m, const orbm_frame* cur, const orbm_query* q, int nq,
+                                     const uint8_t* occupied, float nnratio, int th_high, int32_t* match_of_feature,
+                                     int* nmatches) {
+    MORB_ARG(m && cur && nq >= 0 && nmatches && (cur->n_total == 0 || match_of_feature) && (nq == 0 || q));
+    MORB_HIP(hipSetDevice(m->device));
+    std::vector<orbm_query> q0(q, q + nq);
+    for (auto& Q : q0) Q.cam = 0;  // camera-1 grid only (reference src/ORBmatcher.cc:88-89, src/Frame.cc:510-563)
+    return search_common(m, cur, q0.data(), nq, occupied, true, nnratio, th_high, 0, match_of_feature, nmatches);
+}
+
