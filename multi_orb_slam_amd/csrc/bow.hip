@@ -446,19 +446,20 @@ int orbv_create(int n_nodes, int L, const int32_t* parent, const uint8_t* is_lea
     hipError_t e = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete v; return ORB_E_HIP; }
     if ((rc = v->d_rank.reserve(reach)) || (rc = v->d_orig_sorted.reserve(reach)) || (rc = v->d_stop.reserve(reach))) { orbv_destroy(v); return rc; }
-    if (hipMemcpy(v->d_rank.p, brank.data(), (size_t)reach * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(v->d_orig_sorted.p, bsorted.data(), (size_t)reach * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(v->d_stop.p, bstop.data(), (size_t)reach, hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMemcpyAsync(v->d_rank.p, brank.data(), (size_t)reach * 4, hipMemcpyHostToDevice, v->stream) != hipSuccess ||
+        hipMemcpyAsync(v->d_orig_sorted.p, bsorted.data(), (size_t)reach * 4, hipMemcpyHostToDevice, v->stream) != hipSuccess ||
+        hipMemcpyAsync(v->d_stop.p, bstop.data(), (size_t)reach, hipMemcpyHostToDevice, v->stream) != hipSuccess) {
         morb::set_error("vocabulary upload failed"); orbv_destroy(v); return ORB_E_HIP;
     }
     if ((rc = v->d_desc.reserve((size_t)reach * 2)) || (rc = v->d_first_child.reserve(reach + 1)) || (rc = v->d_orig.reserve(reach)) ||
         (rc = v->d_word.reserve(reach))) { orbv_destroy(v); return rc; }
-    if (hipMemcpy(v->d_desc.p, bdesc.data(), bdesc.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(v->d_first_child.p, first_child.data(), (size_t)(reach + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(v->d_orig.p, borig.data(), (size_t)reach * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(v->d_word.p, bword.data(), (size_t)reach * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMemcpyAsync(v->d_desc.p, bdesc.data(), bdesc.size(), hipMemcpyHostToDevice, v->stream) != hipSuccess ||
+        hipMemcpyAsync(v->d_first_child.p, first_child.data(), (size_t)(reach + 1) * 4, hipMemcpyHostToDevice, v->stream) != hipSuccess ||
+        hipMemcpyAsync(v->d_orig.p, borig.data(), (size_t)reach * 4, hipMemcpyHostToDevice, v->stream) != hipSuccess ||
+        hipMemcpyAsync(v->d_word.p, bword.data(), (size_t)reach * 4, hipMemcpyHostToDevice, v->stream) != hipSuccess) {
         morb::set_error("vocabulary upload failed"); orbv_destroy(v); return ORB_E_HIP;
     }
+    if (hipStreamSynchronize(v->stream) != hipSuccess) { morb::set_error("vocabulary upload failed"); orbv_destroy(v); return ORB_E_HIP; }  // (the sources are locals)
     *out = v;
     return ORB_OK;
 }
@@ -817,7 +818,7 @@ int orbv_keyframe_create(orbv_workspace* w, const orbv_side* s, orbv_keyframe** 
         if (s->cam_of[i] < 0 || s->octave[i] < 0) { morb::set_error("negative camera / octave"); orbv_keyframe_destroy(k); return ORB_E_ARG; }
         k->max_cam = std::max(k->max_cam, (int)s->cam_of[i]); k->max_octave = std::max(k->max_octave, (int)s->octave[i]);
     }
-    if (hipMemcpy(k->block.p, host.data(), P.off, hipMemcpyHostToDevice) != hipSuccess) { morb::set_error("keyframe upload failed"); orbv_keyframe_destroy(k); return ORB_E_HIP; }
+    if (hipMemcpyAsync(k->block.p, host.data(), P.off, hipMemcpyHostToDevice, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess) { morb::set_error("keyframe upload failed"); orbv_keyframe_destroy(k); return ORB_E_HIP; }
     *out = k;
     return ORB_OK;
 }

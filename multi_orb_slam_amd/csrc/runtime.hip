@@ -24,11 +24,26 @@ int orb_free(void* d_ptr) { MORB_HIP(hipFree(d_ptr)); return ORB_OK; }
 int orb_malloc_host(void** h_ptr, size_t bytes) { MORB_ARG(h_ptr); MORB_HIP(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault)); return ORB_OK; }
 int orb_free_host(void* h_ptr) { MORB_HIP(hipHostFree(h_ptr)); return ORB_OK; }
 
+// "No stream" means synchronous, but NOT the legacy default stream: an operation on the legacy stream implicitly joins every
+// blocking stream of the process and is refused outright while another thread captures a launch chain ("operation would make
+// the legacy stream depend on a capturing stream").  Each thread keeps a private non-blocking stream per device for these calls.
+static hipStream_t private_stream() {
+    constexpr int MAX_DEV = 64;
+    static thread_local hipStream_t st[MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    if (!st[dev] && hipStreamCreateWithFlags(&st[dev], hipStreamNonBlocking) != hipSuccess) st[dev] = nullptr;
+    return st[dev];
+}
+
 static int copy(void* dst, const void* src, size_t bytes, void* stream, hipMemcpyKind kind) {
     if (bytes == 0) return ORB_OK;
     MORB_ARG(dst && src);
-    if (stream) MORB_HIP(hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t)stream));
-    else MORB_HIP(hipMemcpy(dst, src, bytes, kind));
+    if (stream) { MORB_HIP(hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t)stream)); return ORB_OK; }
+    hipStream_t ps = private_stream();
+    if (!ps) { morb::set_error("no private stream for a synchronous copy"); return ORB_E_HIP; }
+    MORB_HIP(hipMemcpyAsync(dst, src, bytes, kind, ps));
+    MORB_HIP(hipStreamSynchronize(ps));
     return ORB_OK;
 }
 int orb_memcpy_h2d(void* d, const void* h, size_t n, void* s) { return copy(d, h, n, s, hipMemcpyHostToDevice); }
@@ -37,8 +52,11 @@ int orb_memcpy_d2d(void* d, const void* s_, size_t n, void* s) { return copy(d, 
 int orb_memset(void* d, int v, size_t n, void* s) {
     if (n == 0) return ORB_OK;
     MORB_ARG(d != nullptr);
-    if (s) MORB_HIP(hipMemsetAsync(d, v, n, (hipStream_t)s));
-    else MORB_HIP(hipMemset(d, v, n));
+    if (s) { MORB_HIP(hipMemsetAsync(d, v, n, (hipStream_t)s)); return ORB_OK; }
+    hipStream_t ps = private_stream();
+    if (!ps) { morb::set_error("no private stream for a synchronous memset"); return ORB_E_HIP; }
+    MORB_HIP(hipMemsetAsync(d, v, n, ps));
+    MORB_HIP(hipStreamSynchronize(ps));
     return ORB_OK;
 }
 int orb_stream_sync(void* stream) { MORB_HIP(hipStreamSynchronize((hipStream_t)stream)); return ORB_OK; }

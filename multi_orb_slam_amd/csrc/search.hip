@@ -827,7 +827,8 @@ int orbm_debug_time_project(orbm_matcher* m, const orbm_frame* f, const orbm_que
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (rc) return rc;
     MORB_HIP(he);
-    MORB_HIP(hipMemcpy(m->h_i1.p, m->d_i1.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    MORB_HIP(hipMemcpyAsync(m->h_i1.p, m->d_i1.p, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+    MORB_HIP(hipStreamSynchronize(m->stream));
     long long tot = 0;
     for (int i = 0; i < nq; ++i) tot += m->h_i1.p[i];
     *avg_us = ms * 1e3f / (float)iters; *n_gated = tot;
