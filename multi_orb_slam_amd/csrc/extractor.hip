@@ -1766,7 +1766,12 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st) {
     const int ML = ex->max_levels;
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[0], st));
     // two levels per launch (k_resize2): (1,2) (3,4) (5,6) (7) for the usual 8 levels; MORB_PYRAMID_PAIRS=0: one launch per level
-    static const bool pairs = [] { const char* e = getenv("MORB_PYRAMID_PAIRS"); return !(e && atoi(e) == 0); }();
+    // ... while the levels are small: the re-deriving half does four times the arithmetic per pixel, which only pays as long as
+    // a level is a few microseconds of latency rather than work (up to ~1 M pixels on level 1 over all cameras).
+    static const bool pairs_env = [] { const char* e = getenv("MORB_PYRAMID_PAIRS"); return !(e && atoi(e) == 0); }();
+    long long level1_px = 0;
+    if (ML > 1) for (int c = 0; c < ex->n_cams; ++c) { const LevelInfo& Lv = ex->levels[(size_t)c * ML + 1]; level1_px += (long long)Lv.w * Lv.h; }
+    const bool pairs = pairs_env && level1_px <= (1ll << 20);
     auto level_dims = [&](int l, int* mw, int* mh) {
         *mw = 0; *mh = 0;
         if (l >= ML) return;
