@@ -1394,6 +1394,10 @@ struct orbx_extractor {
     DevBuf<uint8_t*> d_out_desc;
     bool out_ptrs_dirty = true;
     orb_keypoint* mirror_kps = nullptr; uint8_t* mirror_desc = nullptr; int mirror_cap = 0;
+    // orbx_extract (host buffers in, host buffers out): pageable images reach HBM through host-written staging (two slots:
+    // up to two runs may be in flight) + the ingest kernel, results come back through the handle's own pinned mirror
+    morb::StageBuf stage_img[2];
+    morb::PinnedBuf<orb_keypoint> own_mirror_kps; morb::PinnedBuf<uint8_t> own_mirror_desc;
 
     // pinned host (device-visible) buffers
     uint32_t* h_cand = nullptr; size_t h_cand_cap = 0;
@@ -1617,6 +1621,7 @@ void orbx_destroy(orbx_extractor* ex) {
     for (auto& b : ex->d_kps) b.release();
     for (auto& b : ex->d_desc) b.release();
     ex->d_out_kps.release(); ex->d_out_desc.release();
+    ex->stage_img[0].release(); ex->stage_img[1].release(); ex->own_mirror_kps.release(); ex->own_mirror_desc.release();
     if (ex->h_cand) (void)hipHostFree(ex->h_cand);
     if (ex->h_level_cnt) (void)hipHostFree(ex->h_level_cnt);
     if (ex->h_sel) (void)hipHostFree(ex->h_sel);
@@ -1646,6 +1651,25 @@ static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int wi
     if (kind == hipMemcpyDeviceToDevice) {  // copied by k_ingest at the start of the run, all cameras in one launch
         ex->ingest.src[cam] = src; ex->ingest.stride[cam] = stride; ex->ingest_pending = true;
         return ORB_OK;
+    }
+    // A host image in pageable memory (a cv::Mat): the runtime would stage it through an internal pinned buffer and a DMA of
+    // its own.  Instead the rows are written once into host-visible staging (HBM behind the large BAR where the part has one)
+    // and level 0 is filled by the ingest kernel of the run, together with every other camera.  Page-locked images keep the
+    // asynchronous DMA (the caller may refill a pageable buffer as soon as this call returns, a pinned one is read later).
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) {
+        (void)hipGetLastError();
+        morb::StageBuf& S = ex->stage_img[ex->run_seq & 1u];   // (the slot of the run that will consume it)
+        const size_t per_cam = (size_t)ex->max_w * ex->max_h;
+        if (S.reserve(per_cam * ex->n_cams) == ORB_OK) {
+            uint8_t* d = S.p + per_cam * cam;
+            if (stride == width) memcpy(d, src, (size_t)width * height);
+            else for (int y = 0; y < height; ++y) memcpy(d + (size_t)y * width, src + (size_t)y * stride, width);
+            S.publish();
+            ex->ingest.src[cam] = S.dp + per_cam * cam; ex->ingest.stride[cam] = width; ex->ingest_pending = true;
+            return ORB_OK;
+        }
     }
     ex->ingest.src[cam] = nullptr;
     MORB_HIP(hipMemcpy2DAsync(ex->d_pyr.p + (size_t)cam * ex->cam_pitch, align_up(width, 64), src, stride, width, height, kind, ex->stream));
@@ -2121,13 +2145,34 @@ int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, con
                  const int* stride, orb_keypoint* const* kps_out, uint8_t* const* desc_out, const int* cap, int* n_out) {
     MORB_ARG(ex && n_cams == ex->n_cams && gray && width && height && stride && kps_out && desc_out && cap && n_out);
     int rc;
+    MORB_HIP(hipSetDevice(ex->device));
     for (int c = 0; c < n_cams; ++c)
         if ((rc = orbx_upload(ex, c, gray[c], width[c], height[c], stride[c]))) return rc;
-    if ((rc = orbx_run(ex))) return rc;
+    // results through a pinned mirror the describe kernel writes itself (camera-major, packed): no D2H copies on the stream
+    const bool own = ex->mirror_kps == nullptr;
+    if (own) {
+        int cap_total = 0;
+        for (int c = 0; c < n_cams; ++c) cap_total += ex->out_cap[c];
+        if ((rc = ex->own_mirror_kps.reserve(cap_total)) || (rc = ex->own_mirror_desc.reserve((size_t)cap_total * 32))) return rc;
+        ex->mirror_kps = ex->own_mirror_kps.dp; ex->mirror_desc = ex->own_mirror_desc.dp; ex->mirror_cap = cap_total;
+    }
+    rc = orbx_run(ex);
+    const bool mirrored = own && ex->mirror_cap > 0;
+    if (own) { ex->mirror_kps = nullptr; ex->mirror_desc = nullptr; ex->mirror_cap = 0; }
+    if (rc) return rc;
+    int total = 0;
+    for (int c = 0; c < n_cams; ++c) total += ex->n_out[c];
+    int off = 0;
     for (int c = 0; c < n_cams; ++c) {
         n_out[c] = ex->n_out[c];
         if (n_out[c] == 0) continue;  // outputs untouched for an empty camera
-        if ((rc = orbx_download(ex, c, kps_out[c], desc_out[c], cap[c]))) return rc;
+        if (n_out[c] > cap[c]) { morb::set_error("camera %d has %d keypoints, capacity %d", c, n_out[c], cap[c]); return ORB_E_CAPACITY; }
+        if (mirrored && total <= (int)ex->own_mirror_kps.cap) {
+            MORB_ARG(kps_out[c] && desc_out[c]);
+            memcpy(kps_out[c], ex->own_mirror_kps.p + off, (size_t)n_out[c] * sizeof(orb_keypoint));
+            memcpy(desc_out[c], ex->own_mirror_desc.p + (size_t)off * 32, (size_t)n_out[c] * 32);
+        } else if ((rc = orbx_download(ex, c, kps_out[c], desc_out[c], cap[c]))) return rc;
+        off += n_out[c];
     }
     return ORB_OK;
 }

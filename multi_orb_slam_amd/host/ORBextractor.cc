@@ -54,23 +54,25 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1);
     if (!EnsureHandle(image.cols, image.rows)) return;
-    int rc = orbx_upload(handle_, 0, image.ptr(0), image.cols, image.rows, (int)image.step);
-    if (rc) { fail("orbx_upload", rc); return; }
-    if ((rc = orbx_run(handle_))) { fail("orbx_run", rc); return; }
-    const int n = orbx_count(handle_, 0);
+    // one call: the image goes up through host-written staging, the describe kernel mirrors its results into pinned memory,
+    // and they are copied from there into scratch of the right capacity (a failed call must not leave the caller with half)
+    const int cap = nfeatures + 4 * nlevels;
+    scratch_kps_.resize(cap); scratch_desc_.resize((size_t)cap * 32);
+    const uint8_t* img_ptr = image.ptr(0);
+    const int w = image.cols, h = image.rows, stride = (int)image.step;
+    orb_keypoint* kp_ptr = reinterpret_cast<orb_keypoint*>(scratch_kps_.data());
+    uint8_t* d_ptr = scratch_desc_.data();
+    int n = 0;
+    int rc = orbx_extract(handle_, 1, &img_ptr, &w, &h, &stride, &kp_ptr, &d_ptr, &cap, &n);
+    if (rc) { fail("orbx_extract", rc); return; }
     if (n == 0) {
         _keypoints.clear();
         _descriptors.release();
     } else {
-        // results land in fresh containers first: a failed download must not leave the caller with half of them
-        std::vector<cv::KeyPoint> kps(n);
-        cv::Mat desc(n, 32, CV_8U);
-        rc = orbx_download(handle_, 0, reinterpret_cast<orb_keypoint*>(kps.data()), desc.ptr(0), n);
-        if (rc) { fail("orbx_download", rc); return; }
-        _keypoints.swap(kps);
+        _keypoints.assign(scratch_kps_.begin(), scratch_kps_.begin() + n);
         _descriptors.create(n, 32, CV_8U);
         cv::Mat out = _descriptors.getMat();
-        std::memcpy(out.ptr(0), desc.ptr(0), (size_t)n * 32);
+        std::memcpy(out.ptr(0), scratch_desc_.data(), (size_t)n * 32);
     }
     if (materialise_) {
         for (int l = 0; l < nlevels; ++l) {
@@ -108,23 +110,29 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
         if (rc) { batch = nullptr; fail("orbx_create(batch)", rc); return; }
         batch_params = ps;
     }
-    int rc;
-    for (int i = 0; i < n; ++i)
-        if ((rc = orbx_upload(batch, i, images[i].empty() ? nullptr : images[i].ptr(0), images[i].cols, images[i].rows,
-                              (int)images[i].step))) {
-            fail("orbx_upload", rc); return;
-        }
-    if ((rc = orbx_run(batch))) { fail("orbx_run", rc); return; }
+    std::vector<const uint8_t*> img(n);
+    std::vector<int> w(n), h(n), st(n), cap(n), cnt(n, 0);
+    std::vector<std::vector<cv::KeyPoint> > kp(n);
+    std::vector<std::vector<uint8_t> > ds(n);
+    std::vector<orb_keypoint*> kp_ptr(n);
+    std::vector<uint8_t*> d_ptr(n);
+    for (int i = 0; i < n; ++i) {
+        img[i] = images[i].empty() ? nullptr : images[i].ptr(0);
+        w[i] = images[i].cols; h[i] = images[i].rows; st[i] = (int)images[i].step;
+        cap[i] = ex[i]->nfeatures + 4 * ex[i]->nlevels;
+        kp[i].resize(cap[i]); ds[i].resize((size_t)cap[i] * 32);
+        kp_ptr[i] = reinterpret_cast<orb_keypoint*>(kp[i].data()); d_ptr[i] = ds[i].data();
+    }
+    const int rc = orbx_extract(batch, n, img.data(), w.data(), h.data(), st.data(), kp_ptr.data(), d_ptr.data(), cap.data(), cnt.data());
+    if (rc) { fail("orbx_extract(batch)", rc); return; }
     for (int i = 0; i < n; ++i) {
         if (images[i].empty()) continue;  // untouched outputs, like operator()
-        const int k = orbx_count(batch, i);
-        keypoints[i].clear();
-        if (k == 0) { descriptors[i].release(); continue; }
-        keypoints[i].resize(k);
+        const int k = cnt[i];
+        if (k == 0) { keypoints[i].clear(); descriptors[i].release(); continue; }
+        kp[i].resize(k);
+        keypoints[i].swap(kp[i]);
         descriptors[i].create(k, 32, CV_8U);
-        if ((rc = orbx_download(batch, i, reinterpret_cast<orb_keypoint*>(keypoints[i].data()), descriptors[i].ptr(0), k))) {
-            fail("orbx_download", rc); keypoints[i].clear(); descriptors[i].release(); return;
-        }
+        std::memcpy(descriptors[i].ptr(0), ds[i].data(), (size_t)k * 32);
     }
 }
 

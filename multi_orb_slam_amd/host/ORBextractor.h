@@ -64,6 +64,8 @@ protected:
 
 private:
     bool EnsureHandle(int width, int height);
+    std::vector<cv::KeyPoint> scratch_kps_;      // results of a call land here first (capacity nfeatures + 4 * nlevels)
+    std::vector<unsigned char> scratch_desc_;
     orbx_extractor* handle_ = nullptr;
     int cap_w_ = 0, cap_h_ = 0;
     bool materialise_ = false;

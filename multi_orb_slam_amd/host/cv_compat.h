@@ -44,7 +44,15 @@ public:
     void create(int r, int c, int type) {
         if (r == rows && c == cols && type == type_ && data && owner_) return;
         rows = r; cols = c; type_ = type; step = (size_t)c * elemSize();
-        owner_.reset(new unsigned char[step * (size_t)(r > 0 ? r : 1)], std::default_delete<unsigned char[]>());
+        const size_t bytes = step * (size_t)(r > 0 ? r : 1);
+        if (bytes <= sizeof(SmallBlock)) {
+            // poses, points and descriptors (<= 64 bytes) are what the matcher's projection loops create by the thousand: one
+            // pooled block holds the reference count and the payload
+            std::shared_ptr<SmallBlock> b = std::allocate_shared<SmallBlock>(PoolAlloc<SmallBlock>());
+            owner_ = std::shared_ptr<unsigned char>(b, b->d);
+        } else {
+            owner_.reset(new unsigned char[bytes], std::default_delete<unsigned char[]>());
+        }
         data = owner_.get();
     }
     void release() { owner_.reset(); data = nullptr; rows = cols = 0; step = 0; }
@@ -105,6 +113,31 @@ public:
         return m;
     }
 private:
+    struct SmallBlock { alignas(16) unsigned char d[64]; };
+    // thread-local free list of fixed-size blocks (shared_ptr control block + SmallBlock); a block freed by another thread
+    // simply joins that thread's list
+    template <class T> struct PoolAlloc {
+        using value_type = T;
+        PoolAlloc() {}
+        template <class U> PoolAlloc(const PoolAlloc<U>&) {}
+        static constexpr size_t BLOCK = 160;
+        struct Node { Node* next; };
+        static Node*& head() { static thread_local Node* h = nullptr; return h; }
+        T* allocate(size_t n) {
+            if (n == 1 && sizeof(T) <= BLOCK) {
+                Node*& h = head();
+                if (h) { Node* p = h; h = p->next; return reinterpret_cast<T*>(p); }
+                return static_cast<T*>(::operator new(BLOCK));
+            }
+            return static_cast<T*>(::operator new(n * sizeof(T)));
+        }
+        void deallocate(T* p, size_t n) {
+            if (n == 1 && sizeof(T) <= BLOCK) { Node* q = reinterpret_cast<Node*>(p); q->next = head(); head() = q; return; }
+            ::operator delete(p);
+        }
+        template <class U> bool operator==(const PoolAlloc<U>&) const { return true; }
+        template <class U> bool operator!=(const PoolAlloc<U>&) const { return false; }
+    };
     Mat view(int r0, int r1, int c0, int c1) const {
         Mat m; m.rows = r1 - r0; m.cols = c1 - c0; m.type_ = type_; m.step = step; m.owner_ = owner_;
         m.data = data + step * r0 + (size_t)c0 * elemSize();
