@@ -2157,7 +2157,8 @@ int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, con
         ex->mirror_kps = ex->own_mirror_kps.dp; ex->mirror_desc = ex->own_mirror_desc.dp; ex->mirror_cap = cap_total;
     }
     rc = orbx_run(ex);
-    const bool mirrored = own && ex->mirror_cap > 0;
+    // (the host-quadtree fallback describes from a host-built list with its own mirror bookkeeping: plain downloads there)
+    const bool mirrored = own && ex->mirror_cap > 0 && ex->last_path != 2;
     if (own) { ex->mirror_kps = nullptr; ex->mirror_desc = nullptr; ex->mirror_cap = 0; }
     if (rc) return rc;
     int total = 0;

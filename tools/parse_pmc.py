@@ -9,7 +9,7 @@ def load(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
-        for key in ("k_hamming_matrix_mfma", "k_hamming_top2_mfma", "k_hamming_matrix", "k_hamming_top2", "k_top2_merge", "k_project",
+        for key in ("k_hamming_matrix_mfma", "k_hamming_top2_mfma", "k_cross_top2_mfma", "k_cross_top2", "k_hamming_matrix", "k_hamming_top2", "k_top2_merge", "k_project",
                     "k_resolve", "k_bow_transform", "k_bow_join", "fillBuffer", "copyBuffer"):
             if key in name:
                 agg[(key, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))

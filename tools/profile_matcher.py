@@ -41,6 +41,21 @@ for on in (1, 0):  # matrix-core form (the default), then the xor/popcount form 
 m.Matcher.use_matrix_cores(-1)
 rt.stream_sync(st)
 
+# ---- cross-camera top-2 of configs[4] (8 cameras x 4000 descriptors in one list, own camera excluded), both forms
+import multi_orb_slam_amd.matcher as mm
+cams = [synth.perturbed_queries(d[:4000], 100 + c, 0.06) for c in range(8)]
+frc = dict(un_x=np.zeros(32000, np.float32), un_y=np.zeros(32000, np.float32), octave=np.zeros(32000, np.int32), angle=np.zeros(32000, np.float32),
+           uright=np.full(32000, -1, np.float32), cam_of=np.repeat(np.arange(8, dtype=np.int32), 4000),
+           local_of=np.tile(np.arange(4000, dtype=np.int32), 8), descs=cams, bounds=(0.0, 0.0, 1920.0, 1080.0))
+Fc = mt.frame(m.FrameData(**frc))
+for on in (1, 0):
+    m.Matcher.use_matrix_cores(on)
+    for _ in range(5):
+        bi, bd, sd = mt.cross_top2(Fc)
+m.Matcher.use_matrix_cores(-1)
+print("cross top-2 8 x 4000: %d features matched" % int((bi >= 0).sum()))
+Fc.close()
+
 # ---- configs[2]: SearchByProjection on a 2 x 2000-feature 1280x720 frame
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import helpers  # noqa: E402  (input builders only; the oracle is not loaded here)
