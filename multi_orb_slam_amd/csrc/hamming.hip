@@ -677,15 +677,35 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_cross_top2_mfma(const uint32_
             }
             deposit(buf ^ 1, nxt);
             nxt = fetch(t + 2);
+            // 0: nothing of this tile is anybody's own camera (the usual case); 1: the tile lies inside the union of the wave's
+            // own segments but crosses none of their ends -- a query then takes the whole tile or none of it (one select per
+            // key; a wave straddling two cameras spends two whole slices here); 2: a segment ends inside the tile, or the slice
+            // does: every row is tested
+            int mode = 0;
+            if (valid < MM_R_TILE) mode = 2;
+            else if (touches) {
+                const int te = tj0 + MM_R_TILE;
+                const bool cut = (seg0[0] > tj0 && seg0[0] < te) || (seg1[0] > tj0 && seg1[0] < te) ||
+                                 (seg0[1] > tj0 && seg0[1] < te) || (seg1[1] > tj0 && seg1[1] < te);
+                mode = __any(cut) ? 2 : 1;
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const uint32_t before = kb[g];
-                    if (valid >= MM_R_TILE && !touches) {
+                    if (mode == 0) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             const uint32_t key = (uint32_t)acc[a][g][e];
+                            ks2[g] = mt_umed3(kb[g], ks2[g], key);
+                            kb[g] = min(kb[g], key);
+                        }
+                    } else if (mode == 1) {
+                        const bool own = tj0 >= seg0[g] && tj0 < seg1[g];   // (no end inside the tile: the whole tile is in or out)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const uint32_t key = own ? KEY_NONE : (uint32_t)acc[a][g][e];
                             ks2[g] = mt_umed3(kb[g], ks2[g], key);
                             kb[g] = min(kb[g], key);
                         }

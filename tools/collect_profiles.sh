@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the round's measurements on the GPU box: GPU tests, bench.py for every BASELINE.json configuration, and the
+# rocprofv3 summaries that go under profiles/ (kernel trace + stats of the same bench command; separate --pmc passes for
+# FETCH_SIZE and WRITE_SIZE as MI355X_MICROARCH.md prescribes).  Usage: gpurun -- 'bash tools/collect_profiles.sh'
+# rocprofv3 on this image dies with SIGSEGV inside its interception layer (below orbx_run_impl's HIP calls) when the extractor's
+# launch chain is captured / replayed as a graph in a long bench run; the profiled runs therefore issue the chain as plain
+# launches (MORB_CHAIN_GRAPH=0) and keep the host-written staging in mapped pinned memory (MORB_NO_BAR_STAGING=1).  The kernels
+# and their durations are the same; only the host's launch cost differs, and `value` is never taken from a profiled run.
+set -x
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02/final; mkdir -p $O
+cd $R
+if [ "$1" != "prof-only" ]; then
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed" > $O/pytest.txt
+python bench.py > $O/bench.json 2> $O/bench.err
+for c in 2 3 4; do python bench.py --config $c --no-roofline > $O/bench_c$c.json 2> $O/bench_c$c.err; done
+fi
+cd /tmp && export TMPDIR=/tmp
+export MORB_NO_BAR_STAGING=1
+export MORB_CHAIN_GRAPH=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python3 $R/bench.py --no-dropin > $O/bench_under_rocprof.json 2> $O/prof_bench.err
+if [ "$1" != "prof-only" ]; then
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4 -o c4 -- python3 $R/bench.py --config 4 --no-roofline --no-cpu > $O/bench_c4_under_rocprof.json 2> $O/prof_c4.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_matcher -o matcher -- python3 $R/tools/profile_matcher.py > $O/prof_matcher.out 2> $O/prof_matcher.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc_fetch -- python3 $R/tools/profile_matcher.py > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc_write -- python3 $R/tools/profile_matcher.py > /dev/null 2> $O/pmc_write.err
+fi
+find $O -name "*stats.csv"
