@@ -1020,9 +1020,9 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                                                   orb_keypoint* const* __restrict__ kps_out,
                                                   uint8_t* const* __restrict__ desc_out, MirrorArgs mir, SelListArgs sl,
                                                   FrameSink sink) {
-    __shared__ uint8_t s_raw[4][PW * RAW_PITCH];
-    __shared__ uint16_t s_row[4][PW * ROW_PITCH];
-    __shared__ uint8_t s_blur[4][BW * ROW_PITCH];
+    __shared__ alignas(16) uint8_t s_raw[4][PW * RAW_PITCH];
+    __shared__ alignas(16) uint16_t s_row[4][PW * ROW_PITCH];
+    __shared__ alignas(16) uint8_t s_blur[4][BW * ROW_PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ki = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
     const unsigned short* slot_blk = sl.slot_blk;
@@ -1067,11 +1067,23 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     uint16_t* rowp = s_row[wave];
     uint8_t* blur = s_blur[wave];
 
-    // 45x45 raw patch, reflect-101 at the level edge (== GaussianBlur's border on the cloned level, :1086-1087)
-    for (int i = lane; i < PW * PW; i += 64) {
-        const int ry = i / PW, rx = i - ry * PW;
-        const int gy = reflect101(K.y - PR + ry, Lv.h), gx = reflect101(K.x - PR + rx, Lv.w);
-        raw[ry * RAW_PITCH + rx] = img[(size_t)gy * Lv.stride + gx];
+    // 45x45 raw patch, reflect-101 at the level edge (== GaussianBlur's border on the cloned level, :1086-1087).  A patch whose
+    // 45 rows x 48 columns lie inside the level (all but a few-pixel band along the edges) is fetched as 12 dwords per row
+    // (unaligned dword loads; columns 45..47 are padding nothing reads); the others byte by byte with the reflection.
+    if (K.x - PR >= 0 && K.x - PR + RAW_PITCH <= Lv.w && K.y - PR >= 0 && K.y + PR < Lv.h) {
+        const uint8_t* p0 = img + (size_t)(K.y - PR) * Lv.stride + (K.x - PR);
+        for (int i = lane; i < PW * (RAW_PITCH / 4); i += 64) {
+            const int ry = i / (RAW_PITCH / 4), j = i - ry * (RAW_PITCH / 4);
+            uint32_t v;
+            __builtin_memcpy(&v, p0 + (size_t)ry * Lv.stride + 4 * j, 4);
+            reinterpret_cast<uint32_t*>(raw)[ry * (RAW_PITCH / 4) + j] = v;
+        }
+    } else {
+        for (int i = lane; i < PW * PW; i += 64) {
+            const int ry = i / PW, rx = i - ry * PW;
+            const int gy = reflect101(K.y - PR + ry, Lv.h), gx = reflect101(K.x - PR + rx, Lv.w);
+            raw[ry * RAW_PITCH + rx] = img[(size_t)gy * Lv.stride + gx];
+        }
     }
     wave_lds_sync();
 
@@ -1095,20 +1107,46 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // 7x7 sigma-2 Gaussian, OpenCV 8-bit fixed point: taps [18,34,49,55,49,34,18] on both axes (App. A-4)
-    for (int i = lane; i < PW * BW; i += 64) {
-        const int ry = i / BW, bx = i - ry * BW;
-        const uint8_t* s = &raw[ry * RAW_PITCH + bx];  // window bx .. bx+6 is centred on raw column bx+3
-        const int r = 18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 49 * (s[2] + s[4]) + 55 * s[3];
-        rowp[ry * ROW_PITCH + bx] = (uint16_t)r;  // <= 257*255 = 65535
+    // Horizontal pass, four outputs per item: the ten bytes they need are three dwords of the raw row; output j's window is
+    // brought into place with two funnel shifts and weighted with two v_dot4_u32_u8 (exact integer sums, <= 257 * 255).
+    {
+        const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(raw);
+        uint32_t* row32 = reinterpret_cast<uint32_t*>(rowp);
+        constexpr uint32_t W_LO = 18u | (34u << 8) | (49u << 16) | (55u << 24), W_HI = 49u | (34u << 8) | (18u << 16);
+        for (int i = lane; i < PW * (ROW_PITCH / 4); i += 64) {
+            const int ry = i / (ROW_PITCH / 4), q = i - ry * (ROW_PITCH / 4);   // columns 4q .. 4q+3 (column 39 is padding)
+            const uint32_t d0 = raw32[ry * (RAW_PITCH / 4) + q], d1 = raw32[ry * (RAW_PITCH / 4) + q + 1],
+                           d2 = raw32[ry * (RAW_PITCH / 4) + q + 2];
+            uint32_t r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = j ? __builtin_amdgcn_alignbyte(d1, d0, j) : d0, hi = j ? __builtin_amdgcn_alignbyte(d2, d1, j) : d1;
+                r[j] = __builtin_amdgcn_udot4(hi, W_HI, __builtin_amdgcn_udot4(lo, W_LO, 0u, false), false);
+            }
+            row32[ry * (ROW_PITCH / 2) + 2 * q] = r[0] | (r[1] << 16);
+            row32[ry * (ROW_PITCH / 2) + 2 * q + 1] = r[2] | (r[3] << 16);
+        }
     }
     wave_lds_sync();
-    for (int i = lane; i < BW * BW; i += 64) {
-        const int by = i / BW, bx = i - by * BW;
-        const uint16_t* s = &rowp[by * ROW_PITCH + bx];
-        const int c = 18 * (s[0] + s[6 * ROW_PITCH]) + 34 * (s[ROW_PITCH] + s[5 * ROW_PITCH]) +
-                      49 * (s[2 * ROW_PITCH] + s[4 * ROW_PITCH]) + 55 * s[3 * ROW_PITCH];
-        const int v = (c + 32768) >> 16;
-        blur[by * ROW_PITCH + bx] = (uint8_t)min(v, 255);
+    // Vertical pass with a sliding window in registers: a lane owns two adjacent columns (one dword of the row sums) and a
+    // third of the 39 output rows, reads its 19 rows once and emits 13 x 2 blurred bytes.
+    if (lane < 3 * (ROW_PITCH / 2)) {
+        const uint32_t* row32 = reinterpret_cast<const uint32_t*>(rowp);
+        const int seg = lane / (ROW_PITCH / 2), pcol = lane - seg * (ROW_PITCH / 2);
+        const int by0 = seg * 13;
+        uint32_t lo[19], hi[19];
+#pragma unroll
+        for (int t = 0; t < 19; ++t) {
+            const uint32_t d = row32[(by0 + t) * (ROW_PITCH / 2) + pcol];
+            lo[t] = d & 0xffffu; hi[t] = d >> 16;
+        }
+#pragma unroll
+        for (int o = 0; o < 13; ++o) {
+            const uint32_t cl = 18u * (lo[o] + lo[o + 6]) + 34u * (lo[o + 1] + lo[o + 5]) + 49u * (lo[o + 2] + lo[o + 4]) + 55u * lo[o + 3];
+            const uint32_t ch = 18u * (hi[o] + hi[o + 6]) + 34u * (hi[o + 1] + hi[o + 5]) + 49u * (hi[o + 2] + hi[o + 4]) + 55u * hi[o + 3];
+            const uint32_t vl = min((cl + 32768u) >> 16, 255u), vh = min((ch + 32768u) >> 16, 255u);
+            *reinterpret_cast<uint16_t*>(&blur[(by0 + o) * ROW_PITCH + 2 * pcol]) = (uint16_t)(vl | (vh << 8));
+        }
     }
     wave_lds_sync();
 
