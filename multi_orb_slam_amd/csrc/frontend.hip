@@ -73,10 +73,6 @@ struct orbf_frontend {
     } pending;
     hipEvent_t ev_extracted = nullptr;  // extractor stream -> matcher stream on the synchronous path
     hipEvent_t ev_ready[NSETS] = {nullptr, nullptr, nullptr, nullptr};  // extraction + frame grid of the step using that set
-    // larger rigs: the camera-pair top-2 of a step does not stand in its extractor's chain (hundreds of microseconds at
-    // 8 x 4000) but on a stream of its own, forked behind the frame assembly (ev_frame) and joined by the step's matching (ev_cross)
-    hipStream_t cross_stream = nullptr;
-    hipEvent_t ev_frame[NSETS] = {nullptr, nullptr, nullptr, nullptr}, ev_cross[NSETS] = {nullptr, nullptr, nullptr, nullptr};
     // frame of the last completed step (orbf_export_block); a frame built on the synchronous path is kept until the next step
     orbm_frame* last_frame = nullptr; bool last_frame_owned = false;
     // previous step (for orbf_step_motion)
@@ -109,10 +105,7 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     const size_t cap = (size_t)f->cap_total;
     if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
     for (int k = 0; k < orbf_frontend::NSETS; ++k)
-        if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess ||
-            hipEventCreateWithFlags(&f->ev_frame[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&f->ev_cross[k], hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
-    if (hipStreamCreateWithFlags(&f->cross_stream, hipStreamNonBlocking) != hipSuccess) { morb::set_error("hipStreamCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
+        if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
     if (!rc) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[1]);  // overlap partner
     for (int k = 0; k < orbf_frontend::NSETS && !rc; ++k)
         if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
@@ -130,7 +123,6 @@ void orbf_destroy(orbf_frontend* f) {
     f->d_xrecv.release();
     for (int e = 0; e < 2; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
     if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
-    if (f->cross_stream) (void)hipStreamSynchronize(f->cross_stream);
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->pframe[k]) orbm_frame_destroy(f->pframe[k]);  // back to the matcher's pool first
     if (f->mt) orbm_destroy(f->mt);
@@ -138,12 +130,7 @@ void orbf_destroy(orbf_frontend* f) {
     for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); f->rs[k].unx.release(); f->rs[k].uny.release(); f->rs[k].cross.release(); }
     f->h_queries.release(); f->h_match.release();
     if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
-    for (int k = 0; k < orbf_frontend::NSETS; ++k) {
-        if (f->ev_ready[k]) (void)hipEventDestroy(f->ev_ready[k]);
-        if (f->ev_frame[k]) (void)hipEventDestroy(f->ev_frame[k]);
-        if (f->ev_cross[k]) (void)hipEventDestroy(f->ev_cross[k]);
-    }
-    if (f->cross_stream) { (void)hipStreamSynchronize(f->cross_stream); (void)hipStreamDestroy(f->cross_stream); }
+    for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->ev_ready[k]) (void)hipEventDestroy(f->ev_ready[k]);
     delete f;
 }
 
@@ -474,7 +461,7 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
             m->stream = keep;
             return rc;
         }
-    } tail{f, ex, cams.data(), bd, set, small, with_cross && small};
+    } tail{f, ex, cams.data(), bd, set, small, with_cross};
     const bool cross_here = with_cross && f->n_cams > 1;
     if (cross_here && (rc = R.cross.reserve(f->cap_total, f->cap_total))) return rc;  // (storage first: nothing allocates inside a capture)
     if (small) { if ((rc = m->h_ring.reserve((64 * sizeof(CamFeat) + 65 * sizeof(int) + 64 * sizeof(int)) * 4))) return rc; }
@@ -485,18 +472,7 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     if (rc) return rc;
     *went_async = orbx_pending(ex) > before ? 1 : 0;
     if (*went_async) {
-        if (!small) {
-            if ((rc = Tail::run(&tail, orbx_stream(ex)))) return rc;       // frame assembly behind the describe kernel
-            if (cross_here) {                                               // fork: the top-2 only needs the frame's descriptors
-                orbm_frame* frp = f->pframe[set];
-                const int ncap = frp->n_total;
-                MORB_HIP(hipEventRecord(f->ev_frame[set], (hipStream_t)orbx_stream(ex)));
-                MORB_HIP(hipStreamWaitEvent(f->cross_stream, f->ev_frame[set], 0));
-                if ((rc = cross_enqueue_to(f->cross_stream, frp->b->d_desc.p, ncap, frp->b->d_cam_start.p, f->n_cams, 0, ncap, frp->b->d_ntotal.p,
-                                           R.cross.i.dp, R.cross.b.dp, R.cross.s.dp, R.cross.scratch.p))) return rc;
-                MORB_HIP(hipEventRecord(f->ev_cross[set], f->cross_stream));
-            }
-        }
+        if (!small && (rc = Tail::run(&tail, orbx_stream(ex)))) return rc;
         R.cross_valid = cross_here;
         if (!defer_events) {   // (an inline step records its events behind its matching: step_enqueue)
             hipError_t he = hipEventRecord(f->ev_ready[set], (hipStream_t)orbx_stream(ex));
@@ -512,7 +488,6 @@ static int orbf_drain(orbf_frontend* f) {
     for (int e = 0; e < 2; ++e) if (f->exs[e]) MORB_HIP(hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e])));
     MORB_HIP(hipStreamSynchronize(f->mt->stream));
     MORB_HIP(hipStreamSynchronize(f->mt->side_stream));
-    if (f->cross_stream) MORB_HIP(hipStreamSynchronize(f->cross_stream));
     for (int e = 0; e < 2; ++e)
         while (f->exs[e] && orbx_pending(f->exs[e]) > 0) { int rc = orbx_finish(f->exs[e]); if (rc < 0) return rc; }
     f->inflight.clear();
@@ -628,7 +603,6 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         // the same stream; counts are in HBM
         P.fr = f->pframe[P.set]; P.fr_persistent = true;
         if (!inline_match) MORB_HIP(hipStreamWaitEvent(st, f->ev_ready[P.set], 0));  // extraction + frame grid of this step
-        if (!small_rig(f) && R.cross_valid) MORB_HIP(hipStreamWaitEvent(st, f->ev_cross[P.set], 0));  // ... and its forked top-2
         P.n = P.fr->n_total;
     } else {
         rc = orbx_finish(ex);  // synchronises; counts are on the host from here on
