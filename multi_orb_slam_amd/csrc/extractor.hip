@@ -1698,6 +1698,8 @@ static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int wi
     const bool pinned = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;
     if (!pinned) {
         (void)hipGetLastError();
+        // the staging slot is written NOW, not in stream order: with two runs in flight both slots are still being read
+        if (ex->inflight >= 2) { morb::set_error("two runs are in flight: orbx_finish the older one before uploading the next images"); return ORB_E_ARG; }
         morb::StageBuf& S = ex->stage_img[ex->run_seq & 1u];   // (the slot of the run that will consume it)
         const size_t per_cam = (size_t)ex->max_w * ex->max_h;
         if (S.reserve(per_cam * ex->n_cams) == ORB_OK) {

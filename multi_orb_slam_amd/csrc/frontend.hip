@@ -546,8 +546,9 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         // (measured: ~22 us between the chain's last kernel and the projection kernel on the matcher's stream) -- and the
         // camera-pair top-2 leaves the chain: it forks onto the side stream next to project + resolve instead of standing in
         // front of them.
-        P.inline_match = small_rig(f) && !f->xcomm && getenv_int("MORB_INLINE_MATCH", 1) != 0;
-        if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], getenv_int("MORB_INLINE_GRAPH", 0)); (void)orbx_set_defer_done(f->exs[P.e], 1); }
+        static const bool inline_env = getenv_int("MORB_INLINE_MATCH", 1) != 0, inline_graph = getenv_int("MORB_INLINE_GRAPH", 0) != 0;
+        P.inline_match = small_rig(f) && !f->xcomm && inline_env;
+        if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], inline_graph ? 1 : 0); (void)orbx_set_defer_done(f->exs[P.e], 1); }
         rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match, P.inline_match);
         if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], 1); (void)orbx_set_defer_done(f->exs[P.e], 0); }
         if (rc) return rc;
