@@ -96,7 +96,7 @@ int orbx_set_host_mirror(orbx_extractor* ex, orb_keypoint* kps_devptr, uint8_t* 
 int orbx_debug_level(orbx_extractor* ex, int cam, int level, uint8_t* out, int cap_bytes, int* w, int* h);
 /* candidates handed to the quadtree (x, y relative to (16,16); response = score), cell-major order */
 int orbx_debug_candidates(orbx_extractor* ex, int cam, int level, orb_keypoint* out, int cap, int* n);
-/* per-stage GPU time of the last run in microseconds: {pyramid, fast_cells, compact, d2h+octree(host wall),
+/* per-stage GPU time of the last run in microseconds: {pyramid, fast_cells, compact, quadtree (device kernel, or D2H + host quadtree on the fallback path),
  * describe, total wall}; requires orbx_set_profiling(ex, 1) */
 /* host-only: the library's quadtree (DistributeOctTree, reference src/ORBextractor.cc:540-764) on caller-supplied
  * candidates (x, y relative to (16,16), integral; response); runs without a GPU.  *n_out may exceed cap. */

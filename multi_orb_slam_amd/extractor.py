@@ -136,7 +136,9 @@ class Extractor:
     def stage_times_us(self):
         out = np.zeros(6, np.float32)
         check(_lib.lib().orbx_stage_times_us(self._h, ptr(out)))
-        return dict(zip(["pyramid", "fast_cells", "compact", "host_octree", "describe", "total_wall"], out.tolist()))
+        # "quadtree": DistributeOctTree wherever the last run did it -- the device kernel (k_octree; GPU time between the FAST and
+        # describe stage events) or, on the host fallback, D2H + the host quadtree (wall time); "compact" is only non-trivial there
+        return dict(zip(["pyramid", "fast_cells", "compact", "quadtree", "describe", "total_wall"], out.tolist()))
 
     # -- stage inspection
     def debug_level(self, cam, level):
