@@ -3,7 +3,7 @@
 //   k_bow_transform   one descent per feature, 16 lanes per feature (one child per lane, DBoW2's k <= 20 takes two
 //                     passes at most); the tree is renumbered breadth-first at load so that the children of a node are one
 //                     contiguous run of 32-byte descriptors (TemplatedVocabulary.h:1219-1260).
-//   k_bow_join<MODE>  one wavefront per vocabulary node common to both sides: queries strictly in the reference's order
+//   k_bow_join<MODE, NW>  one (NW = 1) or four (NW = 4, nodes of >= 128 candidates) wavefronts per vocabulary node common to both sides: queries strictly in the reference's order
 //                     (the "already matched" state makes them order-dependent inside a node, never across nodes), the
 //                     candidates of the node spread over the 64 lanes, top-2 by wave reductions
 //                     (src/ORBmatcher.cc:206-388, :996-1165, :1364-1786).
@@ -182,10 +182,17 @@ __device__ __forceinline__ uint4 bcast_u4(const uint4& v, int l) {
 // its first `lds_cand` candidates as two uint4 planes (conflict-free 16-byte lane stride) with their index and angle; the rest are read
 // from HBM/L2 on every pass.  Queries are fetched 64 at a time (one per lane: index, flags, descriptor, angle, position) and
 // handed to the whole wave with readlane, so the serial query loop waits on no memory but LDS.
-template <int MODE>
-__global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T, int th_low, float nnratio, int check_ori, JoinWork W,
-                                                 int claimed_bytes, int lds_cand) {
+// NW = 1: one wavefront per node (small nodes).  NW = 4 (nodes of a few hundred features, the 8-camera sizes): four waves per
+// node.  SearchByBoW (MODE 0 / 1) keeps its queries strictly in order -- a claim hides a candidate from the queries behind it --
+// so the four waves split every query's CANDIDATES (stripes of 64), reduce their stripes on their own, meet at one workgroup
+// barrier per query to combine the four partial top-2s (every wave computes the same combination: all further decisions are
+// workgroup-uniform) and at a second one only when a match was accepted (the claim must be visible before the next scan).
+// SearchForTriangulation (MODE 2) has no claims: the waves simply take every fourth query each, no barriers at all.
+template <int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_bow_join(SideDev A, SideDev B, TriDev T, int th_low, float nnratio, int check_ori, JoinWork W,
+                                                      int claimed_bytes, int lds_cand) {
     extern __shared__ uint4 s_dyn[];
+    __shared__ unsigned s_part[2][4][2];   // NW > 1: {best key, second distance} of every wave's stripe, double-buffered by query
     // one wave per workgroup: its LDS operations execute in program order, so a claim written by lane 0 is seen by every lane's
     // next read without a barrier -- volatile keeps the compiler from caching or reordering them.  (A __syncthreads() here
     // would also wait for the match / histogram stores of the accept path to reach L2: ~1 us per accepted match.)
@@ -194,7 +201,8 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
     uint4* s_hi = s_lo + lds_cand;
     int* s_idx = (int*)(s_hi + lds_cand);          // feature index and angle of the staged candidates: the accept path
     float* s_ang = (float*)(s_idx + lds_cand);     // of a query touches no global memory but its (unwaited) stores
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int an = blockIdx.x;
     const uint32_t id = A.node_id[an];
     int lo = 0, hi = B.n_nodes;   // FeatureVector::lower_bound
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
     const int cb0 = B.node_start[lo], nc = B.node_start[lo + 1] - cb0;
     if (nc <= 0 || qa1 <= qa0) return;
     const int staged = min(nc, lds_cand);
-    for (int j = lane; j < nc; j += 64) {
+    for (int j = (int)threadIdx.x; j < nc; j += 64 * NW) {
         const int idx2 = (int)B.items[cb0 + j];
         bool usable = true;
         if (MODE != 0 && B.flags) usable = (B.flags[idx2] & 1) != 0;
@@ -215,6 +223,8 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
         if (j < staged) { s_lo[j] = B.desc[2 * (size_t)idx2]; s_hi[j] = B.desc[2 * (size_t)idx2 + 1]; s_idx[j] = idx2; s_ang[j] = B.angle[idx2]; }
     }
     __syncthreads();
+    unsigned parity = 0;   // NW > 1, MODE 0 / 1: which s_part buffer the next query that reaches the barrier uses (alternates
+                           // over the whole node: a buffer is rewritten only after a barrier every reader of it has passed)
     for (int kb = qa0; kb < qa1; kb += 64) {
         // this lane's query of the block
         const int kmine = kb + lane;
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
             if (MODE == 2) { p_x = A.x[p_idx1]; p_y = A.y[p_idx1]; p_cam = A.cam_of[p_idx1]; }
         }
         const int kend = min(64, qa1 - kb);
-        for (int kq = 0; kq < kend; ++kq) {
+        for (int kq = (MODE == 2 && NW > 1) ? wave : 0; kq < kend; kq += (MODE == 2 && NW > 1) ? NW : 1) {
             const int fl1 = bcast_i(p_fl, kq);
             if (!(fl1 & 1)) continue;                      // wave-uniform
             const int idx1 = bcast_i(p_idx1, kq);
@@ -264,8 +274,10 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
             };
             // staged candidates: branch-free LDS reads (lanes past the end re-read the last one and are masked), so the passes
             // of one query overlap instead of waiting on each other's LDS round trips
+            constexpr int STRIPE = (MODE != 2 && NW > 1) ? NW : 1;   // waves that share one query's candidates
+            const int w0 = STRIPE > 1 ? wave * 64 : 0;
 #pragma unroll 2
-            for (int j0 = 0; j0 < staged; j0 += 64) {
+            for (int j0 = w0; j0 < staged; j0 += 64 * STRIPE) {
                 const int j = j0 + lane;
                 const int jc = min(j, staged - 1);
                 const bool ok = j < staged && !s_claimed[jc];
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
                     key2 = min(key2, ((unsigned)d << 20) | (unsigned)(0xfffff - j));
                 }
             }
-            for (int j = staged + lane; j < nc; j += 64) {   // nodes larger than the LDS stage: the rest from L2 / HBM
+            for (int j = staged + w0 + lane; j < nc; j += 64 * STRIPE) {   // nodes larger than the LDS stage: the rest from L2 / HBM
                 if (s_claimed[j]) continue;
                 const int idx2 = (int)B.items[cb0 + j];
                 const int d = ham256(q0, q1, B.desc[2 * (size_t)idx2], B.desc[2 * (size_t)idx2 + 1]);
@@ -290,13 +302,31 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
                 }
             }
             if (MODE != 2) {
-                const unsigned K = wave_min_u32(bj >= 0 ? (((unsigned)bd << 20) | (unsigned)bj) : 0x7fffffffu);
-                if (K == 0x7fffffffu) continue;            // wave-uniform: nothing closer than 256
+                unsigned K = wave_min_u32(bj >= 0 ? (((unsigned)bd << 20) | (unsigned)bj) : 0x7fffffffu);
+                int second;
+                if (STRIPE == 1) {
+                    if (K == 0x7fffffffu) continue;            // wave-uniform: nothing closer than 256
+                    second = (int)wave_min_u32((unsigned)((((int)(K & 0xfffffu) & 63) == lane) ? d2 : bd));
+                } else {
+                    // this wave's stripe: its best key and the runner-up inside the stripe (candidate j sits in lane j % 64)
+                    const unsigned S = wave_min_u32((unsigned)((K != 0x7fffffffu && ((int)(K & 0xfffffu) & 63) == lane) ? d2 : bd));
+                    if (lane == 0) { s_part[parity][wave][0] = K; s_part[parity][wave][1] = S; }
+                    __syncthreads();
+                    unsigned kk[4], ss[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { kk[w] = w < NW ? s_part[parity][w][0] : 0x7fffffffu; ss[w] = w < NW ? s_part[parity][w][1] : 256u; }
+                    parity ^= 1u;
+                    K = min(min(kk[0], kk[1]), min(kk[2], kk[3]));
+                    if (K == 0x7fffffffu) continue;            // workgroup-uniform
+                    unsigned sec = 256u;                        // the winner's stripe gives its runner-up, every other stripe its best
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) sec = min(sec, kk[w] == K ? ss[w] : min(kk[w] >> 20, 256u));
+                    second = (int)sec;
+                }
                 const int best = (int)(K >> 20), J = (int)(K & 0xfffffu);
-                const int second = (int)wave_min_u32((unsigned)(((J & 63) == lane) ? d2 : bd));
                 const bool under = MODE == 0 ? best <= th_low : best < th_low;        // :324 / :1107
                 if (under && (float)best < nnratio * (float)second) {
-                    if (lane == 0) {
+                    if (lane == 0 && (STRIPE == 1 || wave == 0)) {
                         const int idx2 = J < staged ? s_idx[J] : (int)B.items[cb0 + J];
                         const int oi = MODE == 0 ? idx2 : idx1;
                         W.match[oi] = MODE == 0 ? idx1 : idx2;
@@ -308,6 +338,7 @@ __global__ __launch_bounds__(64) void k_bow_join(SideDev A, SideDev B, TriDev T,
                         }
                         atomicAdd(&W.hist[HISTO], 1);
                     }
+                    if (STRIPE > 1) __syncthreads();   // (workgroup-uniform branch) the claim before anybody's next scan
                 }
             } else {
                 const unsigned K = wave_min_u32(key2);
@@ -702,9 +733,18 @@ int launch_join(orbv_workspace* w, const SideDev& A, const SideDev& B, int max_n
     int lds_cand = std::max(0, std::min(max_nc, (JOIN_LDS_BYTES - claimed_bytes) / 40));   // candidates staged in LDS (40 B each)
     if (lds_cand < max_nc) lds_cand &= ~63;   // a partial stage ends on a lane-0 boundary: candidate j always belongs to lane j % 64
     const size_t lds = (size_t)claimed_bytes + (size_t)lds_cand * 40;
-    if (mode == 0) k_bow_join<0><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
-    else if (mode == 1) k_bow_join<1><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
-    else k_bow_join<2><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
+    // four waves per node from ~128 candidates per node on (the barriers cost more than they save below that)
+    static const int nw_env = [] { const char* e = getenv("MORB_BOW_WAVES"); return e ? atoi(e) : 0; }();
+    const bool wide = nw_env ? nw_env > 1 : max_nc >= 128;
+    if (wide) {
+        if (mode == 0) k_bow_join<0, 4><<<A.n_nodes, 256, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
+        else if (mode == 1) k_bow_join<1, 4><<<A.n_nodes, 256, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
+        else k_bow_join<2, 4><<<A.n_nodes, 256, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
+    } else {
+        if (mode == 0) k_bow_join<0, 1><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
+        else if (mode == 1) k_bow_join<1, 1><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
+        else k_bow_join<2, 1><<<A.n_nodes, 64, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
+    }
     k_bow_finish<<<(n_out + 255) / 256, 256, 0, st>>>(W, n_out, check_ori, w->h_match.dp);
     MORB_HIP(hipGetLastError());
     MORB_HIP(hipStreamSynchronize(st));
