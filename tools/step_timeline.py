@@ -20,5 +20,5 @@ st = steps[which]
 t0 = st[0][1]
 print("steps in trace: %d; step %d: %d kernels, span %.1f us" % (len(steps), which, len(st), (max(r[2] for r in st) - t0) / 1e3))
 for name, a, b, sid in st:
-    short = name.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[-40:]
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-40:]
     print("%8.1f %8.1f  dur %6.1f  stream %-4s %s" % ((a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3, sid, short))
