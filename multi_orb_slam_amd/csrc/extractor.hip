@@ -86,7 +86,9 @@ struct SelKp {  // one keypoint chosen by the quadtree, input of k_describe
 __device__ const signed char d_pattern[256][4] = {
 #include "../../include/orb_pattern_31.inc"
 };
-__device__ const int d_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // ctor :455-470
+// umax[v] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3} (ctor :455-470) as 16 nibbles of one constant (entry v
+// at bits 4v..4v+3): a register operand instead of a memory load per use
+constexpr unsigned long long UMAX_NIBBLES = 0x3689abcddeeeffffull;
 
 // ------------------------------------------------------------------------------------------------ K0
 // Level 0 of every camera whose image is already in HBM, in ONE launch (a 2-D copy per camera costs a launch each).
@@ -911,6 +913,9 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
             }
         }
     }
+    // (an unguarded first pass over four roots can leave up to 16 nodes: more than quota + 4 slots only for a quota below 12
+    // on a panorama-shaped level -- the host pass takes those)
+    if (sz > N + 4) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; } return; }
     // ---- best keypoint per node, first maximum wins (:742-763); output in list order
     if (tid < sz) {
         const int kb = L.nb[a][tid], ke = L.ne[a][tid];
@@ -1014,6 +1019,15 @@ constexpr int BR_ = 19;                // blurred half-size
 constexpr int BW = 2 * BR_ + 1;        // 39
 constexpr int ROW_PITCH = 40;
 
+MORB_PHASE_DECL(g_ph_desc);
+#ifdef MORB_PHASE_CLOCKS
+#define DPH(i) do { if (blockIdx.x == 40 && threadIdx.x == 0) g_ph_desc[i] = wall_clock64(); \
+                     if ((i) == 0 && (threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 4096) g_desc_wave[0][blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64(); \
+                     if ((i) == 7 && (threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 4096) g_desc_wave[1][blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_desc_wave[2][4096];
+#else
+#define DPH(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ L, int max_levels,
                                                   const uint8_t* __restrict__ pyr, size_t cam_pitch,
                                                   const SelKp* __restrict__ sel, int nsel,
@@ -1026,18 +1040,31 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ki = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
     const unsigned short* slot_blk = sl.slot_blk;
-    if (slot_blk && blockIdx.x == 0 && wave == 0) {
-        // bookkeeping of the device-quadtree mode, once per launch: per-camera totals and the fallback flag
+    if (slot_blk && ki == nsel - 1) {
+        // bookkeeping of the device-quadtree mode, once per launch: per-camera totals and the fallback flag.  Done by the wave
+        // of the launch's last slot (a level's fourth spare slot stays empty, so this wave has no keypoint of its own to
+        // delay), one (camera, level) count per lane where the rig fits a wave.
+        const int nb = sl.n_cams * max_levels;
         int bad = 0;
-        for (int c = lane; c < sl.n_cams; c += 64) {
-            int run = 0;
-            for (int l = 0; l < max_levels; ++l) { run += sl.sel_cnt[c * max_levels + l]; bad |= sl.status[c * max_levels + l]; }
-            sl.n_out[c] = run; sl.h_n_out[c] = run;
+        if (nb <= 64) {
+            int cnt = 0;
+            if (lane < nb) { cnt = sl.sel_cnt[lane]; bad = sl.status[lane]; }
+            const int incl = wave_incl_scan(cnt);
+            const int last = min(lane * max_levels + max_levels - 1, 63), first = lane * max_levels;   // lane c: camera c's range
+            const int hi = __shfl(incl, last), lo = __shfl(incl - cnt, min(first, 63));
+            if (lane < sl.n_cams) { sl.n_out[lane] = hi - lo; sl.h_n_out[lane] = hi - lo; }
+        } else {
+            for (int c = lane; c < sl.n_cams; c += 64) {
+                int run = 0;
+                for (int l = 0; l < max_levels; ++l) { run += sl.sel_cnt[c * max_levels + l]; bad |= sl.status[c * max_levels + l]; }
+                sl.n_out[c] = run; sl.h_n_out[c] = run;
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
         if (lane == 0) sl.h_n_out[sl.n_cams] = bad;
     }
+    DPH(0);
     if (ki >= nsel) return;
     SelKp K = sel[ki];
     int mirror_base = 0;
@@ -1067,44 +1094,87 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     uint16_t* rowp = s_row[wave];
     uint8_t* blur = s_blur[wave];
 
-    // 45x45 raw patch, reflect-101 at the level edge (== GaussianBlur's border on the cloned level, :1086-1087).  A patch whose
-    // 45 rows x 48 columns lie inside the level (all but a few-pixel band along the edges) is fetched as 12 dwords per row
-    // (unaligned dword loads; columns 45..47 are padding nothing reads); the others byte by byte with the reflection.
-    if (K.x - PR >= 0 && K.x - PR + RAW_PITCH <= Lv.w && K.y - PR >= 0 && K.y + PR < Lv.h) {
-        const uint8_t* p0 = img + (size_t)(K.y - PR) * Lv.stride + (K.x - PR);
-        for (int i = lane; i < PW * (RAW_PITCH / 4); i += 64) {
-            const int ry = i / (RAW_PITCH / 4), j = i - ry * (RAW_PITCH / 4);
-            uint32_t v;
-            __builtin_memcpy(&v, p0 + (size_t)ry * Lv.stride + 4 * j, 4);
-            reinterpret_cast<uint32_t*>(raw)[ry * (RAW_PITCH / 4) + j] = v;
+    DPH(1);
+    // The depth sample of the frame assembly (lane 0, end of the kernel) is a dependent global load: issued here, used there.
+    const bool to_sink = slot_blk && sink.x;
+    orb_keypoint* const kps_dst = kps_out[cam];   // (pointer loads: also ahead of their use at the end)
+    uint8_t* const desc_dst = desc_out[cam];
+    float depth_sample = 0.f;
+    bool have_depth = false;
+    if (lane == 0 && to_sink) {
+        const float* depth = sink.cam_depth[cam & 3];
+        if (depth) {
+            const float kx = level ? (float)K.x * Lv.scale : (float)K.x, ky = level ? (float)K.y * Lv.scale : (float)K.y;
+            depth_sample = depth[(size_t)(int)ky * sink.cam_depth_stride[cam & 3] + (int)kx];  // imDepth.at<float>(v,u)
+            have_depth = true;
         }
-    } else {
-        for (int i = lane; i < PW * PW; i += 64) {
-            const int ry = i / PW, rx = i - ry * PW;
-            const int gy = reflect101(K.y - PR + ry, Lv.h), gx = reflect101(K.x - PR + rx, Lv.w);
-            raw[ry * RAW_PITCH + rx] = img[(size_t)gy * Lv.stride + gx];
+    }
+    // 45x45 raw patch, reflect-101 at the level edge (== GaussianBlur's border on the cloned level, :1086-1087), fetched as 12
+    // unaligned dwords per row with every load of the wave in flight before the first LDS store (columns 45..47 are padding
+    // nothing reads).  Rows reflect per load.  A patch that crosses the left or right edge (keypoints sit >= 19 pixels inside,
+    // the patch reaches 22: at most three columns) fetches the 48 columns nearest to the edge into scratch and is then put in
+    // place, with the reflection, by an LDS-to-LDS byte copy.
+    {
+        const int xs_want = K.x - PR;
+        const int xs = min(max(xs_want, 0), Lv.w - RAW_PITCH);
+        const bool shifted = xs != xs_want;
+        uint32_t* dst32 = reinterpret_cast<uint32_t*>(shifted ? reinterpret_cast<uint8_t*>(rowp) : raw);
+        const uint8_t* p0 = img + xs;
+        constexpr int NDW = PW * (RAW_PITCH / 4);   // 540 dwords = 8 full rounds of the wave + 28
+        uint32_t v[(NDW + 63) / 64];
+#pragma unroll
+        for (int k = 0; k < (NDW + 63) / 64; ++k) {
+            const int i = lane + 64 * k;
+            v[k] = 0;
+            if (i < NDW) {
+                const int ry = i / (RAW_PITCH / 4), j = i - ry * (RAW_PITCH / 4);
+                __builtin_memcpy(&v[k], p0 + (size_t)reflect101(K.y - PR + ry, Lv.h) * Lv.stride + 4 * j, 4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < (NDW + 63) / 64; ++k) {
+            const int i = lane + 64 * k;
+            if (i < NDW) dst32[i] = v[k];   // (row pitch == 12 dwords: position i is (ry, j))
+        }
+        if (shifted) {
+            wave_lds_sync();
+            const uint8_t* tmp = reinterpret_cast<const uint8_t*>(rowp);
+            for (int i = lane; i < PW * PW; i += 64) {
+                const int ry = i / PW, rx = i - ry * PW;
+                raw[ry * RAW_PITCH + rx] = tmp[ry * RAW_PITCH + reflect101(xs_want + rx, Lv.w) - xs];
+            }
         }
     }
     wave_lds_sync();
+    DPH(2);
 
     // IC_Angle moments over the circular patch (reference :77-104), exact int32
+    // Row v of the disc is the columns |u| <= umax[|v|]; an item is one dword of a row (columns 4 + 4q .. 7 + 4q of the raw
+    // patch, u = 4q - 18 + byte): bytes outside the disc are masked off, then sum(I) and sum(byte * I) are one v_dot4 each.
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        const int vy = i / 31, ux = i - vy * 31;
-        const int v = vy - HALF_PATCH, u = ux - HALF_PATCH;
-        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        if (au <= d_umax[av]) {
-            const int I = raw[(PR + v) * RAW_PITCH + PR + u];
-            m10 += u * I;
-            m01 += v * I;
+    {
+        const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(raw);
+#pragma unroll
+        for (int k = 0; k < (31 * 9 + 63) / 64; ++k) {
+            const int i = lane + 64 * k;
+            if (i < 31 * 9) {
+                const int r = i / 9, q = i - r * 9;
+                const int v = r - HALF_PATCH, u0 = 4 * q - 18;
+                const int um = (int)((UMAX_NIBBLES >> (4 * (v < 0 ? -v : v))) & 15ull);
+                const int lo = min(max(-um - u0, 0), 4), hi = min(max(um - u0 + 1, 0), 4);   // valid bytes [lo, hi)
+                const unsigned long long ones = 0xffffffffull;
+                const uint32_t mask = hi > lo ? (uint32_t)((ones >> (8 * (4 - hi))) & (ones << (8 * lo))) : 0u;
+                const uint32_t d = raw32[(PR + v) * (RAW_PITCH / 4) + 1 + q] & mask;
+                const int s1 = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false), sw = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
+                m10 += u0 * s1 + sw;
+                m01 += v * s1;
+            }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
-    }
+    m10 = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);
+    m01 = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
+    DPH(3);
 
     // 7x7 sigma-2 Gaussian, OpenCV 8-bit fixed point: taps [18,34,49,55,49,34,18] on both axes (App. A-4)
     // Horizontal pass, four outputs per item: the ten bytes they need are three dwords of the raw row; output j's window is
@@ -1128,6 +1198,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         }
     }
     wave_lds_sync();
+    DPH(4);
     // Vertical pass with a sliding window in registers: a lane owns two adjacent columns (one dword of the row sums) and a
     // third of the 39 output rows, reads its 19 rows once and emits 13 x 2 blurred bytes.
     if (lane < 3 * (ROW_PITCH / 2)) {
@@ -1149,6 +1220,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         }
     }
     wave_lds_sync();
+    DPH(5);
 
     // steered rBRIEF (reference :108-147): 4 tests per lane, lanes 2j / 2j+1 make byte j
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
@@ -1166,15 +1238,15 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         nib |= (t0 < t1) << j;
     }
     const int other = __shfl_xor(nib, 1);
+    DPH(6);
     const int out_idx = K.resp_out & 0xffffff;
     // bytes sit in the even lanes (lane 2j = byte j): fold them into 8 dwords held by lanes 0, 8, .., 56
     unsigned int word = (unsigned int)(nib | (other << 4));
     word |= (unsigned int)__shfl_down((int)word, 2) << 8;
     word |= (unsigned int)__shfl_down((int)word, 4) << 16;
-    const bool to_sink = slot_blk && sink.x;
     const int g = mirror_base + out_idx;  // global index in camera-major order
     if ((lane & 7) == 0) {
-        reinterpret_cast<uint32_t*>(desc_out[cam])[(size_t)out_idx * 8 + (lane >> 3)] = word;
+        reinterpret_cast<uint32_t*>(desc_dst)[(size_t)out_idx * 8 + (lane >> 3)] = word;
         if (mir.desc) reinterpret_cast<uint32_t*>(mir.desc)[(size_t)g * 8 + (lane >> 3)] = word;
         if (to_sink) sink.desc[(size_t)g * 8 + (lane >> 3)] = word;
     }
@@ -1188,7 +1260,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         kp.response = (float)((unsigned)K.resp_out >> 24);
         kp.octave = level;
         kp.class_id = -1;
-        kps_out[cam][out_idx] = kp;
+        kps_dst[out_idx] = kp;
         if (mir.kps) mir.kps[g] = kp;
         if (to_sink) {
             // the per-feature half of the frame assembly: `_total` record, ComputeStereoFromRGBD, PosInGrid
@@ -1197,9 +1269,8 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
             sink.x[g] = ux; sink.y[g] = uy; sink.oct[g] = level; sink.ang[g] = angle; sink.kps[g] = kp;
             if (sink.h_unx) { sink.h_unx[g] = ux; sink.h_uny[g] = uy; }
             float d = -1.f, u_r = -1.f;
-            const float* depth = sink.cam_depth[cam & 3];
-            if (depth) {
-                const float dv = depth[(size_t)(int)kp.y * sink.cam_depth_stride[cam & 3] + (int)kp.x];  // imDepth.at<float>(v,u)
+            if (have_depth) {
+                const float dv = depth_sample;
                 if (dv > 0) { d = dv; u_r = ux - sink.mbf / dv; }  // depth at the distorted pixel, uRight from the undistorted x
             }
             sink.ur[g] = u_r; sink.depth[g] = d;
@@ -1208,6 +1279,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
             sink.cell_of[g] = (px >= 0 && px < 64 && py >= 0 && py < 48) ? (cam * 64 + px) * 48 + py : -1;
         }
     }
+    DPH(7);
 }
 
 // ------------------------------------------------------------------------------------------------ host tables
@@ -2275,7 +2347,8 @@ int orbx_debug_distribute_octree(const orb_keypoint* in, int n, int min_x, int m
 
 #ifdef MORB_PHASE_CLOCKS
 extern "C" int morb_debug_phases_extractor(int which, unsigned long long* out64) {
-    (void)which;
+    if (which == 2) return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_desc), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+    if (which == 3) return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_desc_wave), 2 * 4096 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
     return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_oct), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -64,6 +64,7 @@ struct orbf_frontend {
         bool active = false, async_path = false, fr_persistent = false, block_ready = false, cross_from_set = false, forked = false;
         bool x_enqueued = false;   // this step's exchange went out between begin and end
         bool inline_match = false; // the step's own extraction was enqueued by this call: its matching follows on the SAME stream
+        bool mirror_requested = false, mirror_pending = false;  // the pinned result mirrors are filled by a copy kernel of the step
         int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
         orbm_frame* fr = nullptr;
         SearchJob J{nullptr, nullptr, 0, nullptr, false, 0.f, 0, 0, 64, false};
@@ -383,7 +384,7 @@ static void fill_cam_capacities(orbf_frontend* f, orbx_extractor* ex, orbm_cam_f
 // describe kernel writes the merged frame pframe[set] through a FrameSink (*went_async = 1 unless the extractor took its
 // synchronous host-quadtree path; then the frame was not filled).
 static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, int set, int* W_out, int* H_out, int* went_async,
-                           bool with_cross, bool defer_events = false) {
+                           bool with_cross, bool defer_events = false, bool defer_mirror = false) {
     orbm_matcher* m = f->mt;
     orbx_extractor* ex = f->exs[e];
     int rc, W = 0, H = 0;
@@ -398,7 +399,9 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     *W_out = W; *H_out = H;
     orbf_frontend::ResultSet& R = f->rs[set];
     R.cross_valid = false;
-    if ((rc = orbx_set_host_mirror(ex, R.kps.dp, R.desc.dp, f->cap_total))) return rc;
+    // defer_mirror: the kernels of this extraction leave the pinned result mirrors alone; the step copies them on its side
+    // stream (frame_mirror_enqueue) instead of making every dependent kernel boundary wait for stores across PCIe
+    if ((rc = orbx_set_host_mirror(ex, defer_mirror ? nullptr : R.kps.dp, defer_mirror ? nullptr : R.desc.dp, f->cap_total))) return rc;
     *went_async = 0;
     const bool small = small_rig(f);
     std::vector<orbm_cam_features> cams(f->n_cams);
@@ -410,6 +413,7 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
         orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr;  // (image size or calibration changed)
     }
     m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp; m->mirror_unx = R.unx.dp; m->mirror_uny = R.uny.dp;
+    if (defer_mirror) { m->mirror_ur = nullptr; m->mirror_depth = nullptr; m->mirror_unx = nullptr; m->mirror_uny = nullptr; }
     struct MirrorsOff { orbm_matcher* m; ~MirrorsOff() { m->mirror_ur = nullptr; m->mirror_depth = nullptr; m->mirror_unx = nullptr; m->mirror_uny = nullptr; } } mirrors_off{m};
     if (small) {
         // the describe kernel writes the per-feature half of the frame itself (FrameSink)
@@ -549,7 +553,12 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         static const bool inline_env = getenv_int("MORB_INLINE_MATCH", 1) != 0, inline_graph = getenv_int("MORB_INLINE_GRAPH", 0) != 0;
         P.inline_match = small_rig(f) && !f->xcomm && inline_env;
         if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], inline_graph ? 1 : 0); (void)orbx_set_defer_done(f->exs[P.e], 1); }
-        rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match, P.inline_match);
+        // (the copy kernel wants the side stream the camera-pair top-2 forks onto anyway)
+        static const bool side_mirror_env = getenv_int("MORB_SIDE_MIRROR", 1) != 0;
+        P.mirror_requested = P.inline_match && side_mirror_env && !(flags & ORBF_SKIP_CROSS) && f->n_cams > 1;
+        rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match, P.inline_match,
+                             P.mirror_requested);
+        P.mirror_pending = P.mirror_requested;
         if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], 1); (void)orbx_set_defer_done(f->exs[P.e], 0); }
         if (rc) return rc;
         if (P.inline_match && !went_async) P.inline_match = false;   // (host-quadtree path: everything was synchronous)
@@ -647,9 +656,17 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return ORB_E_HIP; }
     }
     rc = search_enqueue(m, P.J, /*queries_already_on_device=*/true);
+    if (P.mirror_pending && !forked) {   // (no side stream in play: the copy follows the search on its stream)
+        if (!rc) rc = frame_mirror_enqueue(fr, st, R.kps.dp, R.desc.dp, R.unx.dp, R.uny.dp, R.ur.dp, R.depth.dp);
+        P.mirror_pending = false;
+    }
     if (forked) {
         if (!rc) rc = cross_enqueue(m, m->side_stream, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n,
                                     P.async_path ? fr->b->d_ntotal.p : nullptr);
+        if (P.mirror_pending) {   // the step's pinned result mirrors: next to project + resolve, behind the camera-pair top-2
+            if (!rc) rc = frame_mirror_enqueue(fr, m->side_stream, R.kps.dp, R.desc.dp, R.unx.dp, R.uny.dp, R.ur.dp, R.depth.dp);
+            P.mirror_pending = false;
+        }
         // join (also on the error path, so that the side stream never outlives the frame)
         hipError_t je = hipEventRecord(m->ev_join, m->side_stream);
         if (je == hipSuccess) je = hipStreamWaitEvent(st, m->ev_join, 0);
@@ -757,6 +774,7 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
                 }
                 P.fr = nullptr; P.fr_persistent = false;
                 P.async_path = false;
+                P.mirror_pending = P.mirror_requested;   // (the redone frame is mirrored again)
                 f->clean_steps = 0;
                 continue;
             }

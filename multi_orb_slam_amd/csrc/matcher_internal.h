@@ -144,6 +144,9 @@ int frame_shell(orbm_matcher* m, int n, int n_cams, float min_x, float min_y, fl
 int frame_prepare_sink(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
                        float max_x, float max_y, orbm_frame** out, FrameSink* sink);
 int frame_sink_of(orbm_matcher* m, orbm_frame* F, const orbm_cam_features* cams, int n_cams, float mbf, FrameSink* sink);
+// a finished frame's keypoints, descriptors, undistorted positions and stereo values into mapped pinned buffers, on `stream`
+int frame_mirror_enqueue(orbm_frame* F, void* stream, orb_keypoint* h_kps, uint8_t* h_desc, float* h_unx, float* h_uny, float* h_ur,
+                         float* h_depth);
 int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
                            float max_x, float max_y, const int* d_counts, orbm_frame** out, bool sink_filled = false);
 void frame_set_counts(orbm_frame* F, const int* counts);

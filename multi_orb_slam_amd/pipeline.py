@@ -80,7 +80,8 @@ class FrontEnd:
         for c, d in enumerate(self.depth_host):
             b = rt.DeviceBuffer(d.nbytes); b.upload(d); self.depth_dev.append(b)
             self.fe.set_depth(c, b.ptr, width)
-        rt.device_sync()
+        # (the uploads above are synchronous; no device-wide synchronisation here: another thread's front end may be
+        # capturing its launch chain at this moment, and hipDeviceSynchronize is refused while any capture is open)
         self.copy_results = True   # False: results are views of the native pinned buffers (valid until the next step)
         # thin views of the composed handles (stage timings, output binding, block-list cross matching)
         self.ex = _Handle(Extractor, self.fe.extractor_handle, self.params)
