@@ -251,10 +251,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
                                                     const uint8_t* __restrict__ pyr, size_t cam_pitch, int max_levels,
                                                     int* __restrict__ cell_cnt, uint32_t* __restrict__ cell_items) {
     __shared__ uint8_t tile[(CELL_MAX + 6) * TILE_PITCH];
-    __shared__ uint8_t score[(CELL_MAX + 2) * SCORE_PITCH];
-    __shared__ unsigned short s_surv[CELL_MAX * CELL_MAX];  // pixels that pass the quick test; reused as `keep` afterwards
+    __shared__ alignas(16) uint8_t score[(CELL_MAX + 2) * SCORE_PITCH];
+    __shared__ unsigned short s_surv[CELL_MAX * CELL_MAX];  // pixels that pass the quick test
+    __shared__ unsigned int s_max[CELL_MAX * CELL_MAX / 32];  // bit p: pixel p is a strict local maximum with a score >= minTh
     __shared__ int s_any, s_nsurv;
-    uint8_t* keep = reinterpret_cast<uint8_t*>(s_surv);
 
     const int cell = blockIdx.x;
     const int2 cm = cell_map[cell];  // {cam * max_levels + level, local cell index}
@@ -280,7 +280,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
         const int ty = (int)(((unsigned)i * inv_tw) >> 20), tx = i - ty * tw;
         tile[ty * TILE_PITCH + tx] = img[(size_t)(y0 - 3 + ty) * Lv.stride + (x0 - 3 + tx)];
     }
-    for (int i = tid; i < (ch + 2) * SCORE_PITCH; i += 256) score[i] = 0;
+    for (int i = tid; i < (ch + 2) * (SCORE_PITCH / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
+    if (tid < CELL_MAX * CELL_MAX / 32) s_max[tid] = 0;
     if (tid == 0) { s_any = 0; s_nsurv = 0; }
     __syncthreads();
 
@@ -311,37 +312,53 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
     }
     __syncthreads();
 
+    // Strict 8-neighbour maxima: only a pixel with a score can be one, so the pass runs over the survivor list (dense lanes,
+    // a tenth of the cell) and leaves one bit per maximum (bit p of the cell's row-major pixel index).
     int any_ini = 0;
-    for (int p = tid; p < npx; p += 256) {
+    for (int i = tid; i < nsurv; i += 256) {
+        const int p = s_surv[i];
         const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
         const uint8_t* c = &score[(py + 1) * SCORE_PITCH + px + 1];
         const int s = c[0];
-        const bool mx = s > 0 && s > c[-1] && s > c[1] && s > c[-SCORE_PITCH - 1] && s > c[-SCORE_PITCH] &&
-                        s > c[-SCORE_PITCH + 1] && s > c[SCORE_PITCH - 1] && s > c[SCORE_PITCH] && s > c[SCORE_PITCH + 1];
-        keep[p] = mx ? (uint8_t)s : 0;
-        any_ini |= (mx && s >= Lv.ini_th);
+        if (s > 0 && s > c[-1] && s > c[1] && s > c[-SCORE_PITCH - 1] && s > c[-SCORE_PITCH] && s > c[-SCORE_PITCH + 1] &&
+            s > c[SCORE_PITCH - 1] && s > c[SCORE_PITCH] && s > c[SCORE_PITCH + 1]) {
+            atomicOr(&s_max[p >> 5], 1u << (p & 31));
+            any_ini |= (s >= Lv.ini_th);
+        }
     }
     if (any_ini) s_any = 1;  // benign race: all writers store 1
     __syncthreads();
 
-    // Ordered compaction by wave 0: candidates in row-major order, exactly FAST_t's emission order.
+    // Ordered output by wave 0: candidates in row-major order, exactly FAST_t's emission order.  Lane j owns pixels
+    // 64j .. 64j+63 (one 64-bit word of the bitmap); a wave prefix sum of the per-lane counts gives every maximum its position.
     if (tid < 64) {
         const int T = s_any ? Lv.ini_th : Lv.min_th;  // reference :809-817: retry with minTh only if the cell is empty
         uint32_t* slot = cell_items + Lv.slot_base + (size_t)cm.y * Lv.slot_cap;
-        int total = 0;
-        for (int base = 0; base < npx; base += 64) {
-            const int p = base + tid;
-            const int s = p < npx ? keep[p] : 0;
-            const bool ok = s >= T && s > 0;
-            const unsigned long long m = __ballot(ok);
-            if (ok) {
-                const int pos = total + __popcll(m & ((1ull << tid) - 1ull));
+        unsigned long long w = (unsigned long long)s_max[2 * tid] | ((unsigned long long)s_max[2 * tid + 1] << 32);
+        if (s_any) {  // maxima below iniTh drop out (scores of maxima are >= minTh > 0 already)
+            unsigned long long rest = w;
+            while (rest) {
+                const int b = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                const int p = 64 * tid + b;
                 const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
-                const int xr = x0 + px - MIN_BORDER, yr = y0 + py - MIN_BORDER;  // relative to (16,16), :821-826
-                if (pos < Lv.slot_cap) slot[pos] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)s << 24);
+                if (score[(py + 1) * SCORE_PITCH + px + 1] < T) w &= ~(1ull << b);
             }
-            total += __popcll(m);
         }
+        const int cnt = __popcll(w);
+        const int incl = wave_incl_scan(cnt);
+        int pos = incl - cnt;
+        while (w) {
+            const int b = __ffsll((long long)w) - 1;
+            w &= w - 1;
+            const int p = 64 * tid + b;
+            const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
+            const int sc = score[(py + 1) * SCORE_PITCH + px + 1];
+            const int xr = x0 + px - MIN_BORDER, yr = y0 + py - MIN_BORDER;  // relative to (16,16), :821-826
+            if (pos < Lv.slot_cap) slot[pos] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)sc << 24);
+            ++pos;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
         if (tid == 0) cell_cnt[cell] = total;
     }
 }
