@@ -17,6 +17,7 @@
 #include "orb_common.h"
 #include "frame_sink.h"
 #include "matcher_internal.h"
+#include "mirror_dev.h"
 
 using namespace morb;
 
@@ -448,28 +449,25 @@ int morb::frame_prepare_sink(orbm_matcher* m, const orbm_cam_features* cams, int
 // before the stores have crossed PCIe (5.6 us for 2000 keypoints + descriptors, measured on k_describe); a step whose
 // matching waits behind the extraction on the same stream runs this copy on the side stream instead, next to project +
 // resolve.  Row count from the frame's device-side total when it has one.
-struct MirrorJob {
-    const uint32_t *kps, *desc, *x, *y, *ur, *depth;   // device (keypoints as 7 dwords, descriptors as 8)
-    uint32_t *h_kps, *h_desc, *h_x, *h_y, *h_ur, *h_depth;
-    const int* n_dev; int n_host;
-};
-__global__ __launch_bounds__(256) void k_mirror_frame(MirrorJob J) {
-    const int n = J.n_dev ? min(*J.n_dev, J.n_host) : J.n_host;
-    const int kp_dw = (int)(sizeof(orb_keypoint) / 4);
-    const int stride = gridDim.x * 256, t = blockIdx.x * 256 + threadIdx.x;
-    for (int i = t; i < n * 8; i += stride) J.h_desc[i] = J.desc[i];
-    for (int i = t; i < n * kp_dw; i += stride) J.h_kps[i] = J.kps[i];
-    for (int i = t; i < n; i += stride) {
-        J.h_x[i] = J.x[i]; J.h_y[i] = J.y[i]; J.h_ur[i] = J.ur[i]; J.h_depth[i] = J.depth[i];
-    }
-}
+__global__ __launch_bounds__(256) void k_mirror_frame(MirrorJob J) { mirror_rows(J, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256); }
 
 int morb::frame_mirror_enqueue(orbm_frame* F, void* stream, orb_keypoint* h_kps, uint8_t* h_desc, float* h_unx, float* h_uny,
                                float* h_ur, float* h_depth) {
-    MORB_ARG(F && F->b && h_kps && h_desc && h_unx && h_uny && h_ur && h_depth);
-    static_assert(sizeof(orb_keypoint) % 4 == 0, "keypoints are copied as dwords");
-    if (F->n_total <= 0) return ORB_OK;
+    if (F && F->n_total <= 0) return ORB_OK;
     MirrorJob J;
+    int rc = frame_mirror_job(F, h_kps, h_desc, h_unx, h_uny, h_ur, h_depth, &J);
+    if (rc) return rc;
+    const int blocks = std::min(64, (F->n_total * 8 + 255) / 256);
+    hipLaunchKernelGGL(k_mirror_frame, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
+    MORB_HIP(hipGetLastError());
+    return ORB_OK;
+}
+
+int morb::frame_mirror_job(orbm_frame* F, orb_keypoint* h_kps, uint8_t* h_desc, float* h_unx, float* h_uny, float* h_ur, float* h_depth,
+                           MirrorJob* out) {
+    MORB_ARG(F && F->b && h_kps && h_desc && h_unx && h_uny && h_ur && h_depth && out);
+    static_assert(sizeof(orb_keypoint) % 4 == 0, "keypoints are copied as dwords");
+    MirrorJob& J = *out;
     J.kps = reinterpret_cast<const uint32_t*>(F->b->d_kps.p); J.desc = reinterpret_cast<const uint32_t*>(F->b->d_desc.p);
     J.x = reinterpret_cast<const uint32_t*>(F->b->d_x.p); J.y = reinterpret_cast<const uint32_t*>(F->b->d_y.p);
     J.ur = reinterpret_cast<const uint32_t*>(F->b->d_ur.p); J.depth = reinterpret_cast<const uint32_t*>(F->b->d_depth.p);
@@ -477,9 +475,6 @@ int morb::frame_mirror_enqueue(orbm_frame* F, void* stream, orb_keypoint* h_kps,
     J.h_x = reinterpret_cast<uint32_t*>(h_unx); J.h_y = reinterpret_cast<uint32_t*>(h_uny);
     J.h_ur = reinterpret_cast<uint32_t*>(h_ur); J.h_depth = reinterpret_cast<uint32_t*>(h_depth);
     J.n_dev = F->counts_on_device ? F->b->d_ntotal.p : nullptr; J.n_host = F->n_total;
-    const int blocks = std::min(64, (F->n_total * 8 + 255) / 256);
-    hipLaunchKernelGGL(k_mirror_frame, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
-    MORB_HIP(hipGetLastError());
     return ORB_OK;
 }
 

@@ -648,7 +648,28 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     // project + resolve (both are a handful of workgroups on a 256-CU part); join before the one host sync
     // (on the asynchronous path the cross top-2 normally rode at the end of the step's extraction chain already)
     P.cross_from_set = do_cross && P.async_path && R.cross_valid;
-    const bool forked = do_cross && n > 0 && !P.cross_from_set;
+    bool forked = do_cross && n > 0 && !P.cross_from_set;
+    // An isolated step (its matching sits right behind its own extraction on one stream) takes no fork at all: the camera-pair
+    // top-2 and the copy into the pinned result mirrors ride in the projection kernel's launch (SideJob) -- a fork onto the
+    // side stream and the join behind it cost ~18 us of queue time per step (measured), a few more workgroups cost none.
+    static const bool side_env = getenv_int("MORB_SIDE_IN_LAUNCH", 1) != 0;
+    SideJob side;
+    const bool fused_side = forked && inline_match && side_env && first_attempt && P.nq > 0 && P.nq <= 65535 && !m->host_resolve &&
+                            morb::side_fusable(n, n);
+    if (fused_side) {
+        if ((rc = morb::side_reserve(m, n, n))) return rc;
+        memset(&side, 0, sizeof(side));
+        side.d_desc = fr->b->d_desc.p; side.n = n; side.d_cam_start = fr->b->d_cam_start.p; side.n_cams = f->n_cams;
+        side.d_range = fr->b->d_ntotal.p;
+        side.o_idx = m->h_c0.dp; side.o_best = m->h_c1.dp; side.o_second = m->h_c2.dp;
+        side.scratch = m->d_cscratch.p;
+        side.with_mirror = P.mirror_pending;
+        if (P.mirror_pending && (rc = morb::frame_mirror_job(fr, R.kps.dp, R.desc.dp, R.unx.dp, R.uny.dp, R.ur.dp, R.depth.dp, &side.mirror)))
+            return rc;
+        P.mirror_pending = false;
+        P.J.side = &side;
+        forked = false;
+    }
     P.forked = forked;
     if (forked) {  // the fork point is the finished frame; the launches on the side stream come after the search's
         hipError_t fe = hipEventRecord(m->ev_fork, st);

@@ -22,6 +22,8 @@
 #include "frame_sink.h"
 #include "matcher_internal.h"
 #include "hamming_dev.h"
+#include "project_dev.h"
+#include "mirror_dev.h"
 
 using namespace morb;
 
@@ -600,17 +602,17 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __r
 // Counts known only on the device come through d_range = {features, first query, queries}; the launch is then sized for the
 // capacity, slices beyond the features produce (256, 256, -1) partials and query blocks beyond the queries return at once.
 // grid.x = reference slices (partials for k_top2_merge when > 1), grid.y = 256 queries.
-__global__ __launch_bounds__(64 * MM_WAVES) void k_cross_top2_mfma(const uint32_t* __restrict__ desc, int n_total,
-                                                                  const int* __restrict__ cam_start, int n_cams, int q_off, int nq,
-                                                                  int slice_len, int* __restrict__ p_idx, int* __restrict__ p_best,
-                                                                  int* __restrict__ p_second, const int* __restrict__ d_range) {
-    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];
+// bx = reference slice, by = block of 256 queries
+__device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * 8 * 64], const uint32_t* __restrict__ desc, int n_total,
+                                                     const int* __restrict__ cam_start, int n_cams, int q_off, int nq, int slice_len,
+                                                     int* __restrict__ p_idx, int* __restrict__ p_best, int* __restrict__ p_second,
+                                                     const int* __restrict__ d_range, const int bx, const int by) {
     if (d_range) { n_total = d_range[0]; q_off = d_range[1]; nq = d_range[2]; }
-    if ((int)blockIdx.y * MM_Q_PER_BLOCK >= nq) return;   // (uniform over the workgroup; implies nq >= 1 and n_total >= 1 below)
+    if (by * MM_Q_PER_BLOCK >= nq) return;   // (uniform over the workgroup; implies nq >= 1 and n_total >= 1 below)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.y * MM_Q_PER_BLOCK + wave * 64;
+    const int q0 = by * MM_Q_PER_BLOCK + wave * 64;
     const uint32_t* __restrict__ q = desc + (size_t)q_off * 8;
     const uint32_t* __restrict__ r = desc;
     const int nr = n_total;
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_cross_top2_mfma(const uint32_
 #pragma unroll
     for (int e = 0; e < 16; ++e) cinit[e] = 8192 + (e & 3) + 8 * (e >> 2) + 4 * h;
 
-    const int s0 = blockIdx.x * slice_len, s1 = min(nr, s0 + slice_len);  // slice_len is a multiple of 64
+    const int s0 = bx * slice_len, s1 = min(nr, s0 + slice_len);  // slice_len is a multiple of 64
     const int n_tiles = s1 > s0 ? (s1 - s0 + MM_R_TILE - 1) / MM_R_TILE : 0;
     auto fetch = [&](int t) {
         const int rr = max(0, min(s0 + min(t, n_tiles - 1) * MM_R_TILE + lane, nr - 1));
@@ -737,13 +739,52 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_cross_top2_mfma(const uint32_
         const uint32_t nb = min(mine_b, ob), ns = min(max(mine_b, ob), min(mine_s, os));
         const int qrow = q0 + g * 32 + c;
         if (h == 0 && qrow < nq) {
-            const size_t o = (size_t)blockIdx.x * nq + qrow;
+            const size_t o = (size_t)bx * nq + qrow;
             const int best = (int)(nb >> 16);
             const int j = s0 + (int)(nb & 0xffffu);
             p_best[o] = best;
             p_idx[o] = best < 256 ? (j < seg0[g] ? j : j - (seg1[g] - seg0[g])) : -1;   // index among the other cameras
             p_second[o] = (int)min(ns >> 16, 256u);
         }
+    }
+}
+
+__global__ __launch_bounds__(64 * MM_WAVES) void k_cross_top2_mfma(const uint32_t* __restrict__ desc, int n_total,
+                                                                  const int* __restrict__ cam_start, int n_cams, int q_off, int nq,
+                                                                  int slice_len, int* __restrict__ p_idx, int* __restrict__ p_best,
+                                                                  int* __restrict__ p_second, const int* __restrict__ d_range) {
+    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];
+    cross_top2_mfma_body(s_tile, desc, n_total, cam_start, n_cams, q_off, nq, slice_len, p_idx, p_best, p_second, d_range,
+                         (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---- the projection kernel, the camera-pair top-2 and the result mirror of an isolated orbf_step in ONE launch ------------
+// Three kinds of workgroup, independent of each other: [0, n_cross) slices x query blocks of the top-2 (the longest: first),
+// [n_cross, n_cross + n_project) four queries each of k_project, the rest copies the frame into the pinned result mirrors.
+// The slices' partials are merged by k_top2_merge right behind this launch (an in-kernel merge by the last slice to arrive was
+// tried: the two device-scope fences it needs write the L2 back and cost ~7 us each).  Everything the top-2 and the mirror
+// produce is therefore complete before the resolve kernel starts: a host that watches the resolve's tagged result words
+// arrive may take those results as well.
+struct SideArgs {
+    const uint32_t* desc; int n_total; const int* cam_start; int n_cams; int slice_len; int S;
+    int *p_idx, *p_best, *p_second; const int* d_range;
+    int n_cross, n_project;
+    int with_mirror;
+    morb::MirrorJob mirror;
+};
+__global__ __launch_bounds__(64 * MM_WAVES) void k_project_side(morb::ProjectArgs P, SideArgs X) {
+    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];
+    const int b = blockIdx.x;
+    if (b < X.n_cross) {
+        const int by = b / X.S, bx = b - by * X.S;
+        cross_top2_mfma_body(s_tile, X.desc, X.n_total, X.cam_start, X.n_cams, 0, X.n_total, X.slice_len, X.p_idx, X.p_best,
+                             X.p_second, X.d_range, bx, by);
+    } else if (b < X.n_cross + X.n_project) {
+        const int qi = __builtin_amdgcn_readfirstlane((b - X.n_cross) * 4 + (int)(threadIdx.x >> 6));
+        if (qi < P.nq) morb::project_wave(P, qi, threadIdx.x & 63);
+    } else if (X.with_mirror) {
+        const int nb = (int)gridDim.x - X.n_cross - X.n_project;
+        morb::mirror_rows(X.mirror, (b - X.n_cross - X.n_project) * 256 + (int)threadIdx.x, nb * 256);
     }
 }
 
@@ -916,6 +957,46 @@ int morb::cross_enqueue(orbm_matcher* m, hipStream_t st, const uint8_t* d_desc, 
     return cross_enqueue_to(st, d_desc, n, d_cam_start, n_cams, q_off, nq, d_n, m->h_c0.dp, m->h_c1.dp, m->h_c2.dp, m->d_cscratch.p);
 }
 
+
+bool morb::side_fusable(int nq, int n) {
+    if (nq <= 0 || n <= 0) return false;
+    const Top2Plan plan = top2_plan(nq, n);
+    return plan.mfma && plan.S >= 1 && plan.S <= 64;
+}
+
+int morb::side_reserve(orbm_matcher* m, int nq, int n) {
+    const int S = std::max(top2_plan(nq, n).S, top2_slices(nq, n));
+    int rc;
+    if ((rc = m->d_cscratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = m->h_c0.reserve(nq)) ||
+        (rc = m->h_c1.reserve(nq)) || (rc = m->h_c2.reserve(nq)))
+        return rc;
+    return ORB_OK;
+}
+
+int morb::launch_project_side(hipStream_t st, const morb::ProjectArgs& P, const SideJob& J) {
+    const int nq = J.n;   // every feature of the frame is a query of the camera-pair top-2 (capacity; the count comes from d_range)
+    const Top2Plan plan = top2_plan(nq, J.n);
+    MORB_ARG(plan.mfma && J.d_range && J.scratch);
+    SideArgs X;
+    memset(&X, 0, sizeof(X));
+    X.desc = (const uint32_t*)J.d_desc; X.n_total = J.n; X.cam_start = J.d_cam_start; X.n_cams = J.n_cams;
+    X.slice_len = plan.slice_len; X.S = plan.S;
+    int* p = (int*)J.scratch;
+    const int S = plan.S;
+    X.p_idx = S > 1 ? p : J.o_idx; X.p_best = S > 1 ? p + (size_t)S * nq : J.o_best; X.p_second = S > 1 ? p + 2 * (size_t)S * nq : J.o_second;
+    X.d_range = J.d_range;
+    X.n_cross = plan.S * ((nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK);
+    X.n_project = (P.nq + 3) / 4;
+    X.with_mirror = J.with_mirror ? 1 : 0;
+    if (J.with_mirror) X.mirror = J.mirror;
+    const int n_mirror = J.with_mirror ? std::min(64, (J.mirror.n_host * 8 + 255) / 256) : 0;
+    hipLaunchKernelGGL(k_project_side, dim3(X.n_cross + X.n_project + n_mirror), dim3(64 * MM_WAVES), 0, st, P, X);
+    if (S > 1)
+        hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, X.p_idx, X.p_best, X.p_second, S, nq, J.o_idx, J.o_best,
+                           J.o_second, J.d_range);
+    MORB_HIP(hipGetLastError());
+    return ORB_OK;
+}
 
 int orbm_use_matrix_cores(int on) { return g_matrix_cores.exchange(on < 0 ? -1 : (on ? 1 : 0)); }
 

@@ -11,6 +11,7 @@
 #include "../../include/orbx.h"
 #include "orb_common.h"
 #include "frame_sink.h"
+#include "mirror_dev.h"
 
 using morb::DevBuf;
 using morb::PinnedBuf;
@@ -119,6 +120,18 @@ struct SearchJob {
     const orbm_query* q_dev = nullptr;  // device-visible alias of `q` when it lives in mapped pinned memory: read in place, no H2D
     const uint8_t* occ_dev = nullptr;   // device-visible copy of `occupied` (staged by the caller): no H2D either
     const orbm_window* win2_dev = nullptr;  // second windows of the queries (device memory), or NULL
+    const struct SideJob* side = nullptr;   // work that shares the projection kernel's launch (consumed by search_enqueue)
+};
+
+// Work of an isolated orbf_step that rides in the projection kernel's launch instead of on a stream of its own (a fork onto a
+// side stream and the join behind it cost ~18 us of queue time per step, measured): the camera-pair top-2 over the frame's
+// descriptors and the copy of the frame into the pinned result mirrors.  All of it (the slice merge included) is complete
+// before the resolve kernel behind it starts.
+struct SideJob {
+    const uint8_t* d_desc; int n; const int* d_cam_start; int n_cams; const int* d_range;   // d_range = {features, first query, queries} in HBM
+    int *o_idx, *o_best, *o_second;   // mapped pinned results
+    void* scratch;                    // slice partials (merged by k_top2_merge behind the launch)
+    bool with_mirror; morb::MirrorJob mirror;
 };
 
 // k_cross_top2 (+ merge) over `n` features in `d_desc` split into cameras by `d_cam_start`; queries [q_off, q_off+nq).
@@ -147,6 +160,13 @@ int frame_sink_of(orbm_matcher* m, orbm_frame* F, const orbm_cam_features* cams,
 // a finished frame's keypoints, descriptors, undistorted positions and stereo values into mapped pinned buffers, on `stream`
 int frame_mirror_enqueue(orbm_frame* F, void* stream, orb_keypoint* h_kps, uint8_t* h_desc, float* h_unx, float* h_uny, float* h_ur,
                          float* h_depth);
+int frame_mirror_job(orbm_frame* F, orb_keypoint* h_kps, uint8_t* h_desc, float* h_unx, float* h_uny, float* h_ur, float* h_depth,
+                     MirrorJob* out);
+// k_project next to a SideJob in one launch (hamming.hip); side_fusable: the sizes take the matrix-core top-2 this needs
+struct ProjectArgs;
+int launch_project_side(hipStream_t st, const ProjectArgs& P, const SideJob& S);
+bool side_fusable(int nq, int n);
+int side_reserve(orbm_matcher* m, int nq, int n);   // scratch and the pinned result arrays of the matcher's own CrossOut
 int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
                            float max_x, float max_y, const int* d_counts, orbm_frame** out, bool sink_filled = false);
 void frame_set_counts(orbm_frame* F, const int* counts);
