@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void k_project(ProjectArgs A) {
 // status[1] = nmatches, status[2] = sweeps, status[3] = longest candidate list.
 constexpr int RESOLVE_MAX_Q = 65535;
 MORB_PHASE_DECL(g_ph_res);
+MORB_PHASE_DECL(g_ph_chg);   // (instrumented build) queries whose choice changed, per sweep, accumulated over launches
 
 // RESOLVE_K (above): sorted shortlist per query built by k_project; a full rescan happens only when all of it is taken
 
@@ -238,6 +239,9 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
                 if (lane == src) nc = rnc;
             }
             if (valid) {
+#ifdef MORB_PHASE_CLOCKS
+                if (nc != old && it < 15) atomicAdd((unsigned long long*)&g_ph_chg[it], 1ull);
+#endif
                 if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
                 if (nc >= 0 && (fl & 1)) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
             }
@@ -541,6 +545,8 @@ int morb::search_raise_lds_limits() {
 
 int morb::phases_resolve(unsigned long long* out64) {
 #ifdef MORB_PHASE_CLOCKS
+    if (out64[0] == 0xC4A26Eull)   // (magic in out64[0]: the per-sweep change counters instead of the clocks)
+        return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_chg), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
     return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_res), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 #else
     (void)out64; return -1;

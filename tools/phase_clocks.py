@@ -36,5 +36,8 @@ print("  sweep 0: thread-0 loop (incl. its wave's rescans), closing barrier:", d
 print("  tail: reset, owners + histogram, three maxima, reject:", deltas(v, [2 + it, 52, 53, 54, 60]))
 if it > 5:
     print("  sweep 5: thread-0 loop (incl. its wave's rescans), closing barrier:", deltas(v, [7, 24, 8]))
+out[0] = 0xC4A26E
+lib.morb_debug_phases_matcher(0, out); c = list(out)
+print("  queries that changed their choice per sweep (sum over %d steps):" % 6, [int(x) for x in c[:12]])
 lib.morb_debug_phases_matcher(1, out); v = list(out)
 print("frame_build: counts, fill, scan, scatter, sort:", deltas(v, [0, 1, 2, 3, 4, 5]), "total", (v[5] - v[0]) / 100.0)
