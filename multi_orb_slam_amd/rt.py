@@ -44,7 +44,7 @@ class DeviceBuffer:
 
     @property
     def ptr(self):
-        return self._p.value
+        return self._p.value if self._p else None
 
     def upload(self, arr, stream=None, offset=0):
         arr = np.ascontiguousarray(arr)
@@ -63,7 +63,7 @@ class DeviceBuffer:
                 _L().orb_free(self._p)
             except Exception:
                 pass
-            self._p = C.c_void_p()
+            self._p = None   # (not a fresh c_void_p: at interpreter shutdown the ctypes module may be gone already)
 
     __del__ = free
 
@@ -79,7 +79,7 @@ class PinnedBuffer:
 
     @property
     def ptr(self):
-        return self._p.value
+        return self._p.value if self._p else None
 
     def free(self):
         if getattr(self, "_p", None):
@@ -88,7 +88,7 @@ class PinnedBuffer:
                 _L().orb_free_host(self._p)
             except Exception:
                 pass
-            self._p = C.c_void_p()
+            self._p = None
 
     __del__ = free
 

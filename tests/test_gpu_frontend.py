@@ -9,7 +9,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("w,h,nfs", [(320, 240, (300, 150)), (640, 480, (1000, 500)), (640, 480, (1000, 1000, 700)),
-                                     (1280, 720, (2000, 2000))])   # the last one = configs[2]
+                                     (1280, 720, (2000, 2000)),    # = configs[2]
+                                     (752, 480, (1200,)),          # one camera: no camera-pair matching at all
+                                     (800, 250, (600, 600)),       # panorama-shaped levels: three root strips in the quadtree
+                                     (640, 480, (2000, 50))])      # very unequal cameras
 def test_native_step_equals_oracle_pipeline(w, h, nfs):
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import pipeline, rt
