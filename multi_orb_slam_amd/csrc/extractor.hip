@@ -791,14 +791,22 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                 if (cell_off[mid] <= p) lo = mid; else hi = mid;
             }
             const uint32_t v = cell_items[Lv.slot_base + (size_t)lo * Lv.slot_cap + (p - cell_off[lo])];
-            KX(1, p) = (unsigned short)(v & 0xfff); KY(1, p) = (unsigned short)((v >> 12) & 0xfff);
-            KR(1, p) = (unsigned char)(v >> 24);
+            // (one root strip -- every level of a 4:3 image: the candidates ARE the root's keys, in this order)
+            const int buf = nIni == 1 ? 0 : 1;
+            KX(buf, p) = (unsigned short)(v & 0xfff); KY(buf, p) = (unsigned short)((v >> 12) & 0xfff);
+            KR(buf, p) = (unsigned char)(v >> 24);
+            if (nIni == 1) KN(0, p) = 0;
+        }
+        if (nIni == 1 && tid == 0) {
+            L.ulx[0][0] = 0; L.uly[0][0] = 0; L.brx[0][0] = (short)(int)(hX * 1.0f); L.bry[0][0] = (short)height;
+            L.nb[0][0] = 0; L.ne[0][0] = (unsigned short)n; L.ncrt[0][0] = 0xffff; L.nfl[0][0] = (unsigned char)(n == 1 ? 1 : 0);
+            L.v[0] = 1;
         }
         __syncthreads();
     }
     MORB_PHASE(g_ph_oct, 2);
     // ---- roots (:544-585): vertical strips, keypoints dealt by (int)(x / hX), empty roots dropped, order = strip order
-    {
+    if (nIni > 1) {
         constexpr int PER = NKEYS / 1024;  // keys per thread, blocked
         unsigned long long loc[PER], run = 0;
         int rx[PER], ry[PER], rr[PER];
