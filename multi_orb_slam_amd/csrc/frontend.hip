@@ -548,12 +548,12 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         // Nothing ran ahead for this step (a live rig: the images have only just arrived).  Its matching then goes onto the
         // extractor's own stream, right behind the extraction chain -- a kernel boundary instead of a cross-stream event
         // (measured: ~22 us between the chain's last kernel and the projection kernel on the matcher's stream) -- and the
-        // camera-pair top-2 leaves the chain: it forks onto the side stream next to project + resolve instead of standing in
-        // front of them.
+        // camera-pair top-2 leaves the chain: it rides in the projection kernel's launch (SideJob in step_enqueue; on the
+        // side stream when that does not apply) instead of standing in front of the search.
         static const bool inline_env = getenv_int("MORB_INLINE_MATCH", 1) != 0, inline_graph = getenv_int("MORB_INLINE_GRAPH", 0) != 0;
         P.inline_match = small_rig(f) && !f->xcomm && inline_env;
         if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], inline_graph ? 1 : 0); (void)orbx_set_defer_done(f->exs[P.e], 1); }
-        // (the copy kernel wants the side stream the camera-pair top-2 forks onto anyway)
+        // (the copy rides with the camera-pair top-2: in the projection kernel's launch, or on the side stream it forks onto)
         static const bool side_mirror_env = getenv_int("MORB_SIDE_MIRROR", 1) != 0;
         P.mirror_requested = P.inline_match && side_mirror_env && !(flags & ORBF_SKIP_CROSS) && f->n_cams > 1;
         rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match, P.inline_match,
