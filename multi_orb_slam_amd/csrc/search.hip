@@ -120,6 +120,22 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
     MORB_PHASE(g_ph_res, 2);
     constexpr int NEED = POINTS ? 2 : 1;
     int it = 0, changed = 1;
+    if (LDSQ && !POINTS) {
+        // Sweep 0 of the frame search needs no evaluation: without any claim a query takes the head of its shortlist (every
+        // entry there is acceptable: not occupied, distance <= th_high).  The choices and their claims -- what sweep 0 would
+        // have left for sweep 1 to read: table 2, tag 0x7ffd -- are written straight away.
+        const int tag_next = 0x7ffd << 16;
+        for (int i = tid; i < nq; i += T) {
+            const int v = l_gd[i];   // entry 0
+            const int g0 = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
+            const int nc = (g0 >= 0 && (int)((unsigned)v >> 16) <= th_high) ? g0 : -1;
+            l_choice[i] = nc;
+            if (nc >= 0 && (l_fl[i] & 1)) atomicMin(&s_claim2[nc], tag_next | i);
+        }
+        __syncthreads();
+        MORB_PHASE(g_ph_res, 20); MORB_PHASE(g_ph_res, 3);
+        it = 1;
+    }
     for (; it < max_it && changed; ++it) {
         // Two claim tables alternate: sweep `it` READS the claims the previous sweep's choices left in `rd` (entries tagged
         // `tag`) and WRITES the claims of its own choices into `wr` (tagged `tag_next`), so a sweep is ONE pass over the
