@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/orbm.h"
@@ -136,6 +137,23 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
         MORB_PHASE(g_ph_res, 20); MORB_PHASE(g_ph_res, 3);
         it = 1;
     }
+    // The shortlists never change: the entries of a thread's first two queries (all of them for up to 2048 queries) stay in
+    // registers over the sweeps instead of being read from LDS in every one.
+    constexpr int RQ = 2;
+    int gdr[RQ][RESOLVE_K];
+    if (LDSQ) {
+#pragma unroll
+        for (int b = 0; b < RQ; ++b)
+#pragma unroll
+            for (int k = 0; k < RESOLVE_K; ++k) gdr[b][k] = b * T + tid < nq ? l_gd[k * nq + b * T + tid] : 0xffff;
+    }
+    int flr[RQ], chr[RQ];   // ... and so do their flags and their current choices
+#pragma unroll
+    for (int b = 0; b < RQ; ++b) {
+        const bool in = LDSQ && b * T + tid < nq;
+        flr[b] = in ? (int)l_fl[b * T + tid] : 0;
+        chr[b] = in ? l_choice[b * T + tid] : -1;
+    }
     for (; it < max_it && changed; ++it) {
         // Two claim tables alternate: sweep `it` READS the claims the previous sweep's choices left in `rd` (entries tagged
         // `tag`) and WRITES the claims of its own choices into `wr` (tagged `tag_next`), so a sweep is ONE pass over the
@@ -155,21 +173,28 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
         // sweep's read tag and a lower query index, i.e. lies in [tag, tag + i): one subtract and one unsigned compare
         // (older sweeps carry larger tags, 0x7fffffff is larger still).
         constexpr int K0 = 2;
-        for (int base = 0; base < nq; base += T) {   // uniform trip count: the cooperative rescans below need whole waves
+        // one batch of 1024 queries; B < RQ: the batch whose shortlists sit in gdr[B] (uniform trip count over the batches:
+        // the cooperative rescans below need whole waves)
+        auto batch = [&](const int base, auto BC) {
+            constexpr int B = decltype(BC)::value;
             const int i = base + tid;
             const bool valid = i < nq;
             int gk[RESOLVE_K], dk[RESOLVE_K], ck[RESOLVE_K];
             int fl = 0, old = -1, nc = -1;
             bool need_rescan = false;
             if (valid) {
-                fl = LDSQ ? (int)l_fl[i] : ((qmeta[i].x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
-                old = LDSQ ? l_choice[i] : choice[i];
+                if constexpr (LDSQ && B < RQ) { fl = flr[B]; old = chr[B]; }
+                else {
+                    fl = LDSQ ? (int)l_fl[i] : ((qmeta[i].x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
+                    old = LDSQ ? l_choice[i] : choice[i];
+                }
                 int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1, g2 = -1;
                 int found = 0, taken = 0;
                 bool walking = true;
                 auto fetch = [&](int k) {
                     if (LDSQ) {
-                        const int v = l_gd[k * nq + i];
+                        int v;
+                        if constexpr (B < RQ) v = gdr[B][k]; else v = l_gd[k * nq + i];
                         gk[k] = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
                         dk[k] = (int)((unsigned)v >> 16);
                     } else { gk[k] = tk_g[k * nq + i]; dk[k] = tk_key[k * nq + i] >> 16; }
@@ -259,9 +284,13 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
                 if (nc != old && it < 15) atomicAdd((unsigned long long*)&g_ph_chg[it], 1ull);
 #endif
                 if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
+                if constexpr (LDSQ && B < RQ) chr[B] = nc;
                 if (nc >= 0 && (fl & 1)) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
             }
-        }
+        };
+        batch(0, std::integral_constant<int, 0>{});
+        if (T < nq) batch(T, std::integral_constant<int, 1>{});
+        for (int base = RQ * T; base < nq; base += T) batch(base, std::integral_constant<int, RQ>{});
 #ifdef MORB_PHASE_CLOCKS
         __syncthreads();
         if (tid == 0 && it < 15) g_ph_res[40 + it] = (unsigned long long)s_nres;
