@@ -182,6 +182,36 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
             int gk[RESOLVE_K], dk[RESOLVE_K], ck[RESOLVE_K];
             int fl = 0, old = -1, nc = -1;
             bool need_rescan = false;
+            if constexpr (!POINTS && LDSQ && B < RQ) {
+                // Frame search on register-resident shortlists, without a divergent branch: the first entry that is there and
+                // not hidden by a lower blocking query's claim wins.  Entries 0-1 first; 2..K-1 only for waves in which a lane
+                // is still looking.  (A lane past the last query holds empty entries and comes out with nc == old == -1.)
+                fl = flr[B]; old = chr[B];
+                int e[RESOLVE_K];
+                bool none[RESOLVE_K], hid[RESOLVE_K];
+                auto look = [&](int k) {
+                    e[k] = gdr[B][k];
+                    none[k] = (e[k] & 0xffff) == 0xffff;
+                    const int c = rd[none[k] ? 0 : (e[k] & 0xffff)];
+                    hid[k] = !none[k] && (unsigned)(c - tag) < (unsigned)i;   // claimed by a lower blocking query
+                };
+                look(0); look(1);
+                const bool av0 = !none[0] && !hid[0], av1 = !none[1] && !hid[1];
+                int pick = av0 ? e[0] : (av1 ? e[1] : -1);
+                bool anyh = hid[0] || hid[1];
+                const bool open = !av0 && !av1 && !none[1];   // (an empty slot ends the list; slot 0 empty implies slot 1 empty)
+                if (__ballot(open)) {
+#pragma unroll
+                    for (int k = K0; k < RESOLVE_K; ++k) look(k);
+                    int p2 = -1;
+#pragma unroll
+                    for (int k = RESOLVE_K - 1; k >= K0; --k) { p2 = (!none[k] && !hid[k]) ? e[k] : p2; anyh = anyh || (open && hid[k]); }
+                    pick = open ? p2 : pick;
+                }
+                // the shortlist is exact unless it ran dry while longer lists exist (rare): rescanned right below
+                need_rescan = pick < 0 && (fl & 2) && anyh;
+                if (pick >= 0 && (pick >> 16) <= th_high) nc = pick & 0xffff;
+            } else
             if (valid) {
                 if constexpr (LDSQ && B < RQ) { fl = flr[B]; old = chr[B]; }
                 else {
