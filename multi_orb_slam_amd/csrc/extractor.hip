@@ -1879,6 +1879,14 @@ int orbx_finish(orbx_extractor* ex) {
     return finish_device_path(ex);
 }
 
+// orbx_finish for a caller that has PROOF that the oldest run in flight completed (it has seen the results of work that was
+// ordered behind the run on the GPU): no wait on the completion event.
+int orbx_finish_completed(orbx_extractor* ex) {
+    MORB_ARG(ex != nullptr);
+    if (ex->inflight == 0) return ORB_OK;
+    return finish_device_path(ex);
+}
+
 int orbx_set_defer_done(orbx_extractor* ex, int on) {
     MORB_ARG(ex != nullptr);
     ex->defer_done = on != 0;

@@ -44,3 +44,6 @@ extern "C" int orbx_set_chain_graph(orbx_extractor* ex, int on);
 // the run's consumer on the same stream -- the event then no longer stands between the chain and that consumer.
 extern "C" int orbx_set_defer_done(orbx_extractor* ex, int on);
 extern "C" int orbx_record_done(orbx_extractor* ex);
+// orbx_finish without the wait on the completion event, for a caller that has already seen the results of GPU work ordered
+// behind the oldest run in flight (orbf_step_end after it watched the resolve's result words arrive)
+extern "C" int orbx_finish_completed(orbx_extractor* ex);

@@ -781,7 +781,9 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
             return ORB_E_HIP;
         }
         if (P.async_path) {
-            rc = orbx_finish(ex);  // this step's run (the oldest of its extractor) completed long ago: adopts its counts
+            // this step's run (the oldest of its extractor) completed long ago: adopts its counts.  A step whose result words
+            // were watched arriving has proof of that (the resolve was ordered behind the run) and skips the event wait.
+            rc = polled ? orbx_finish_completed(ex) : orbx_finish(ex);
             if (rc < 0) return rc;
             if (rc == 1 || rc == 2) {
                 // a pyramid level was outside the device quadtree's limits: this step is redone on the synchronous path
