@@ -81,6 +81,9 @@ struct orbf_frontend {
     std::vector<int32_t> prev_cam_of;
     std::vector<float> scale_factors;
     std::chrono::steady_clock::time_point t_entry;
+    // MORB_HOST_TIMELINE=1: where orbf_step_begin spends its host time (sums, printed by orbf_destroy)
+    bool timeline = false; double tl_us[6] = {0, 0, 0, 0, 0, 0}; long tl_n = 0;
+    std::chrono::steady_clock::time_point tl_t;
 };
 
 static int getenv_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -100,6 +103,7 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     if (rc) { orbf_destroy(f); return rc; }
     f->d_depth.assign(n_cams, nullptr); f->depth_stride.assign(n_cams, 0); f->counts.assign(n_cams, 0);
     { const char* pe = getenv("MORB_POLL"); f->poll_ok = !(pe && atoi(pe) == 0); }
+    { const char* te = getenv("MORB_HOST_TIMELINE"); f->timeline = te && atoi(te) != 0; }
     f->scale_factors.assign(params[0].nlevels, 1.f);
     if ((rc = orbx_tables(&params[0], f->scale_factors.data(), nullptr, nullptr, nullptr, nullptr, nullptr))) { orbf_destroy(f); return rc; }
     for (int c = 0; c < n_cams; ++c) { f->cam_cap.push_back(params[c].nfeatures + 4 * params[c].nlevels); f->cap_total += f->cam_cap.back(); }
@@ -118,6 +122,10 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
 }
 
 void orbf_destroy(orbf_frontend* f) {
+    if (f && f->timeline && f->tl_n > 0)
+        fprintf(stderr, "orbf host timeline over %ld steps, us per step: extraction / in-flight check %.2f, queries %.2f, frame + event %.2f, "
+                        "search launches %.2f, side work + events %.2f, prefetch enqueue %.2f\n", f->tl_n, f->tl_us[0] / f->tl_n,
+                f->tl_us[1] / f->tl_n, f->tl_us[2] / f->tl_n, f->tl_us[3] / f->tl_n, f->tl_us[4] / f->tl_n, f->tl_us[5] / f->tl_n);
     if (!f) return;
     (void)hipSetDevice(f->device);
     if (f->xcomm) (void)orbf_exchange_shutdown(f);
@@ -523,6 +531,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     MORB_ARG(!P.active);
     P = orbf_frontend::Pending();
     P.t_impl = std::chrono::steady_clock::now();
+    if (f->timeline) { f->tl_t = P.t_impl; ++f->tl_n; }
     MORB_HIP(hipSetDevice(f->device));
     orbm_matcher* m = f->mt;
     int rc, went_async = 0;
@@ -563,6 +572,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         if (rc) return rc;
         if (P.inline_match && !went_async) P.inline_match = false;   // (host-quadtree path: everything was synchronous)
     }
+    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[0] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     if (motion) {
         if ((rc = queries_from_previous_step(f, motion, &nq))) return rc;
         queries = reinterpret_cast<const orbm_query*>(f->h_queries.p); queries_in_pinned = true;
@@ -575,6 +585,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         if (!queries_in_pinned) memcpy(f->h_queries.p, queries, (size_t)nq * sizeof(orbm_query));
         f->h_queries.publish();
     }
+    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[1] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     P.J = SearchJob{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
     P.J.q_dev = nq ? reinterpret_cast<const orbm_query*>(f->h_queries.dp) : nullptr;   // no H2D on the step's critical chain
     P.J.want_tags = f->poll_ok;
@@ -676,7 +687,9 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         if (fe == hipSuccess) fe = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
         if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return ORB_E_HIP; }
     }
+    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[2] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     rc = search_enqueue(m, P.J, /*queries_already_on_device=*/true);
+    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[3] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     if (P.mirror_pending && !forked) {   // (no side stream in play: the copy follows the search on its stream)
         if (!rc) rc = frame_mirror_enqueue(fr, st, R.kps.dp, R.desc.dp, R.unx.dp, R.uny.dp, R.ur.dp, R.depth.dp);
         P.mirror_pending = false;
@@ -705,6 +718,7 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         if ((rc = exchange_enqueue(f, fr))) return rc;
         P.x_enqueued = true;
     }
+    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[4] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     // ---- announced timesteps go onto the extractors now: they run while this step is being matched.  At most two
     // are in flight; consecutive ones alternate between the two extractors (an extractor takes its next timestep as
     // a second run behind the one whose results are being matched here).
@@ -732,6 +746,7 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
             f->announced.clear();
         }
     }
+    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[5] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     P.t_enqueued = std::chrono::steady_clock::now();
     return ORB_OK;
 }
