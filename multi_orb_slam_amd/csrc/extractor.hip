@@ -465,8 +465,10 @@ __device__ __forceinline__ int oct_block_excl_scan(int val, int tid, int* wsum, 
 
 // child of a key inside node box (ulx,uly)-(brx,bry): DivideNode's halfX/halfY and its '<' tests (:482-523)
 __device__ __forceinline__ int oct_child(int x, int y, int ulx, int uly, int brx, int bry, int& midx, int& midy) {
-    midx = ulx + (int)ceilf((float)(brx - ulx) / 2);
-    midy = uly + (int)ceilf((float)(bry - uly) / 2);
+    // ceil((float)d / 2) for an integer d >= 0 (boxes never invert; d < 2^24 is exact in float) == (d + 1) >> 1: the float
+    // division of the reference costs ~15 instructions per coordinate here, twice per key and pass
+    midx = ulx + ((brx - ulx + 1) >> 1);
+    midy = uly + ((bry - uly + 1) >> 1);
     return (x < midx ? 0 : 1) + (y < midy ? 0 : 2);
 }
 
