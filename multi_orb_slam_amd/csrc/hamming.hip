@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __r
                                                                 const int* __restrict__ d_range) {
     // counts only known on the device ({features, first query, queries}): the launch was sized for the capacity
     if (d_range) { n_total = d_range[0]; q_off = d_range[1]; nq = d_range[2]; }
-    if (blockIdx.x * 64 >= nq) return;
+    if ((int)blockIdx.x * 64 >= nq) return;
     __shared__ int sb[TOP2_WAVES][64], ss[TOP2_WAVES][64], si[TOP2_WAVES][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
