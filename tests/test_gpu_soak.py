@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 N_STEPS = 5000
 
 
-def _run(monkeypatch, poll):
+def _run(monkeypatch, poll, isolated=False):
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import pipeline, rt
     monkeypatch.setenv("MORB_POLL", "1" if poll else "0")       # read when the front end is created
@@ -27,9 +27,10 @@ def _run(monkeypatch, poll):
     arg = lambda t: [(dev[t % RING][c].ptr, W) for c in range(2)]
     fe.copy_results = False                                       # results consumed in place, as the benchmark does
     digests = []
-    fe.announce(arg(1), resident=True)
+    if not isolated:
+        fe.announce(arg(1), resident=True)
     for t in range(N_STEPS):
-        r = fe.step(arg(t), resident=True, next_images=arg(t + 2))
+        r = fe.step(arg(t), resident=True, next_images=None if isolated else arg(t + 2))
         h = hashlib.blake2b(digest_size=8)
         for a in (r["match_of_feature"], r["kps"], r["desc"], r["uright"], r["cross"][0], r["cross"][1], r["cross"][2]):
             h.update(np.ascontiguousarray(a).tobytes())
@@ -47,3 +48,14 @@ def test_polled_and_synchronised_result_pickup_agree_over_5000_steps(monkeypatch
     # the stream repeats every 8 frames: from the second lap on the digests repeat too (nothing leaks from step to step)
     assert all(a[t] == a[t - 8] for t in range(24, N_STEPS))
     assert len(set(a[16:24])) == 8
+
+
+def test_isolated_steps_polled_and_synchronised_agree_over_5000_steps(monkeypatch):
+    """No look-ahead: every step extracts its own images, and the camera-pair top-2 and the copy into the pinned result
+    mirrors ride in the projection kernel's launch (k_project_side) -- their results are taken on the strength of the
+    resolve's result words alone, so they must be complete by then, every time."""
+    a = _run(monkeypatch, True, isolated=True)
+    b = _run(monkeypatch, False, isolated=True)
+    bad = [t for t in range(N_STEPS) if a[t] != b[t]]
+    assert not bad, "isolated steps whose polled results differ from the synchronised run: %s" % bad[:10]
+    assert all(a[t] == a[t - 8] for t in range(24, N_STEPS))
