@@ -157,21 +157,14 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
     const int c0 = min(ncell, tid * per), c1 = min(ncell, c0 + per);
     int mine = 0;
     for (int c = c0; c < c1; ++c) mine += s_cur[c];
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
+    const int incl = wave_incl_scan(mine);   // (DPP row shifts: no LDS crossbar round trips)
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int w = 0; w < 16; ++w) { const int v = wsum[w]; wsum[w] = acc; acc += v; }
-        s_start[ncell] = acc;
-    }
-    __syncthreads();
-    int run = wsum[wave] + incl - mine;
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int v = wsum[w]; if (w < wave) before += v; total += v; }   // (every thread sums the 16 wave totals itself: no serial pass, no second barrier)
+    if (tid == 0) s_start[ncell] = total;
+    int run = before + incl - mine;
     for (int c = c0; c < c1; ++c) { const int v = s_cur[c]; s_start[c] = run; s_cur[c] = run; run += v; }
     __syncthreads();
     MORB_PHASE(g_ph_fb, 3);
