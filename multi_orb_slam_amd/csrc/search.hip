@@ -109,8 +109,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
             choice[i] = -1;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    mx = (int)(0x7fffffffu - wave_min_u32(0x7fffffffu - (unsigned)mx));   // wave maximum on the DPP path (counts are >= 0)
     if (lane == 0) atomicMax(&s_red, mx);  // one LDS atomic per wave: same-address atomics of a whole block serialise
     __syncthreads();
     const int maxcount = s_red;
@@ -366,8 +365,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
             if (inr && ((todo >> lane) & 1)) atomicAdd(&s_hist[bin], 1);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    acc = __builtin_amdgcn_readlane(wave_incl_scan(acc), 63);   // wave sum on the DPP path
     if (lane == 0) atomicAdd(&s_red, acc);
     __syncthreads();
     MORB_PHASE(g_ph_res, 53);
@@ -412,8 +410,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
                 ++rej;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) rej += __shfl_xor(rej, o);
+        rej = __builtin_amdgcn_readlane(wave_incl_scan(rej), 63);
         if (lane == 0) atomicSub(&s_red, rej);
         __syncthreads();
     }
