@@ -120,38 +120,63 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
     MORB_PHASE(g_ph_res, 2);
     constexpr int NEED = POINTS ? 2 : 1;
     int it = 0, changed = 1;
-    if (LDSQ && !POINTS) {
-        // Sweep 0 of the frame search needs no evaluation: without any claim a query takes the head of its shortlist (every
-        // entry there is acceptable: not occupied, distance <= th_high).  The choices and their claims -- what sweep 0 would
-        // have left for sweep 1 to read: table 2, tag 0x7ffd -- are written straight away.
-        const int tag_next = 0x7ffd << 16;
-        for (int i = tid; i < nq; i += T) {
-            const int v = l_gd[i];   // entry 0
-            const int g0 = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
-            const int nc = (g0 >= 0 && (int)((unsigned)v >> 16) <= th_high) ? g0 : -1;
-            l_choice[i] = nc;
-            if (nc >= 0 && (l_fl[i] & 1)) atomicMin(&s_claim2[nc], tag_next | i);
+    // The shortlists never change: the entries of a thread's first two queries (four when the sweep state does not fit LDS and
+    // would be read from HBM in every sweep) stay in registers over the sweeps; so do their flags and their current choices.
+    // (Four for the LDS-resident form as well costs more than it saves: twice the code for batches that do not exist.)
+    constexpr int RQ = LDSQ ? 2 : 4;
+    int gdr[RQ][RESOLVE_K], flr[RQ], chr[RQ];
+    if constexpr (LDSQ) {
+        if (!POINTS) {
+            // Sweep 0 of the frame search needs no evaluation: without any claim a query takes the head of its shortlist (every
+            // entry there is acceptable: not occupied, distance <= th_high).  The choices and their claims -- what sweep 0
+            // would have left for sweep 1 to read: table 2, tag 0x7ffd -- are written straight away.
+            const int tag_next = 0x7ffd << 16;
+            for (int i = tid; i < nq; i += T) {
+                const int v = l_gd[i];   // entry 0
+                const int g0 = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
+                const int nc = (g0 >= 0 && (int)((unsigned)v >> 16) <= th_high) ? g0 : -1;
+                l_choice[i] = nc;
+                if (nc >= 0 && (l_fl[i] & 1)) atomicMin(&s_claim2[nc], tag_next | i);
+            }
+            __syncthreads();
+            MORB_PHASE(g_ph_res, 20); MORB_PHASE(g_ph_res, 3);
+            it = 1;
         }
-        __syncthreads();
-        MORB_PHASE(g_ph_res, 20); MORB_PHASE(g_ph_res, 3);
-        it = 1;
-    }
-    // The shortlists never change: the entries of a thread's first two queries (all of them for up to 2048 queries) stay in
-    // registers over the sweeps instead of being read from LDS in every one.
-    constexpr int RQ = 2;
-    int gdr[RQ][RESOLVE_K];
-    if (LDSQ) {
 #pragma unroll
-        for (int b = 0; b < RQ; ++b)
+        for (int b = 0; b < RQ; ++b) {
+            const bool in = b * T + tid < nq;
 #pragma unroll
-            for (int k = 0; k < RESOLVE_K; ++k) gdr[b][k] = b * T + tid < nq ? l_gd[k * nq + b * T + tid] : 0xffff;
-    }
-    int flr[RQ], chr[RQ];   // ... and so do their flags and their current choices
+            for (int k = 0; k < RESOLVE_K; ++k) gdr[b][k] = in ? l_gd[k * nq + b * T + tid] : 0xffff;
+            flr[b] = in ? (int)l_fl[b * T + tid] : 0;
+            chr[b] = in ? l_choice[b * T + tid] : -1;
+        }
+    } else {
 #pragma unroll
-    for (int b = 0; b < RQ; ++b) {
-        const bool in = LDSQ && b * T + tid < nq;
-        flr[b] = in ? (int)l_fl[b * T + tid] : 0;
-        chr[b] = in ? l_choice[b * T + tid] : -1;
+        for (int b = 0; b < RQ; ++b) {
+            const int i = b * T + tid;
+            const bool in = i < nq;
+#pragma unroll
+            for (int k = 0; k < RESOLVE_K; ++k) gdr[b][k] = in ? ((tk_key[k * nq + i] & 0xffff0000) | (tk_g[k * nq + i] & 0xffff)) : 0xffff;
+            flr[b] = in ? ((qmeta[i].x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0)) : 0;
+            chr[b] = -1;
+        }
+        if (!POINTS && nq <= RQ * T) {   // sweep 0 as above, from the registers
+            const int tag_next = 0x7ffd << 16;
+#pragma unroll
+            for (int b = 0; b < RQ; ++b) {
+                const int i = b * T + tid;
+                if (i < nq) {
+                    const int v = gdr[b][0];
+                    const int g0 = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
+                    const int nc = (g0 >= 0 && (int)((unsigned)v >> 16) <= th_high) ? g0 : -1;
+                    chr[b] = nc;
+                    choice[i] = nc;
+                    if (nc >= 0 && (flr[b] & 1)) atomicMin(&s_claim2[nc], tag_next | i);
+                }
+            }
+            __syncthreads();
+            it = 1;
+        }
     }
     for (; it < max_it && changed; ++it) {
         // Two claim tables alternate: sweep `it` READS the claims the previous sweep's choices left in `rd` (entries tagged
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
             int gk[RESOLVE_K], dk[RESOLVE_K], ck[RESOLVE_K];
             int fl = 0, old = -1, nc = -1;
             bool need_rescan = false;
-            if constexpr (!POINTS && LDSQ && B < RQ) {
+            if constexpr (!POINTS && B < RQ) {
                 // Frame search on register-resident shortlists, without a divergent branch: the first entry that is there and
                 // not hidden by a lower blocking query's claim wins.  Entries 0-1 first; 2..K-1 only for waves in which a lane
                 // is still looking.  (A lane past the last query holds empty entries and comes out with nc == old == -1.)
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
                 if (pick >= 0 && (pick >> 16) <= th_high) nc = pick & 0xffff;
             } else
             if (valid) {
-                if constexpr (LDSQ && B < RQ) { fl = flr[B]; old = chr[B]; }
+                if constexpr (B < RQ) { fl = flr[B]; old = chr[B]; }
                 else {
                     fl = LDSQ ? (int)l_fl[i] : ((qmeta[i].x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
                     old = LDSQ ? l_choice[i] : choice[i];
@@ -221,9 +246,12 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
                 int found = 0, taken = 0;
                 bool walking = true;
                 auto fetch = [&](int k) {
-                    if (LDSQ) {
-                        int v;
-                        if constexpr (B < RQ) v = gdr[B][k]; else v = l_gd[k * nq + i];
+                    if constexpr (B < RQ) {
+                        const int v = gdr[B][k];
+                        gk[k] = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
+                        dk[k] = (int)((unsigned)v >> 16);
+                    } else if (LDSQ) {
+                        const int v = l_gd[k * nq + i];
                         gk[k] = (v & 0xffff) == 0xffff ? -1 : (v & 0xffff);
                         dk[k] = (int)((unsigned)v >> 16);
                     } else { gk[k] = tk_g[k * nq + i]; dk[k] = tk_key[k * nq + i] >> 16; }
@@ -313,12 +341,16 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
                 if (nc != old && it < 15) atomicAdd((unsigned long long*)&g_ph_chg[it], 1ull);
 #endif
                 if (nc != old) { ch = 1; if (LDSQ) l_choice[i] = nc; else choice[i] = nc; }
-                if constexpr (LDSQ && B < RQ) chr[B] = nc;
+                if constexpr (B < RQ) chr[B] = nc;
                 if (nc >= 0 && (fl & 1)) atomicMin(&wr[nc], tag_next | i);  // what the next sweep sees
             }
         };
         batch(0, std::integral_constant<int, 0>{});
         if (T < nq) batch(T, std::integral_constant<int, 1>{});
+        if constexpr (RQ > 2) {
+            if (2 * T < nq) batch(2 * T, std::integral_constant<int, 2>{});
+            if (3 * T < nq) batch(3 * T, std::integral_constant<int, 3>{});
+        }
         for (int base = RQ * T; base < nq; base += T) batch(base, std::integral_constant<int, RQ>{});
 #ifdef MORB_PHASE_CLOCKS
         __syncthreads();
