@@ -391,6 +391,29 @@ def main(argv=None):
         b2, ps2, _ = timed_blocks(a.steps, min(a.warmup, 50), a.min_time, overlap, pinned=True)
         h2d = {"value": round(rigs * a.steps / pct(b2, 50), 2), "ms_per_step": round(1e3 * pct(b2, 50) / a.steps, 4),
                "bytes_per_step": NC * W * H, "source": "page-locked host memory, hipMemcpy2DAsync inside the step"}
+    # ---- the same overlapped loop inside the library (orbf_run_stream: prefetch + orbf_step_motion + the accepted-match count per
+    # step, one native call per block): the stream as a C or C++ host would drive it, without the Python binding around every step
+    c_abi_loop = None
+    if world == 1:
+        from multi_orb_slam_amd.matcher import TH_LOW
+        fe.reset(); ahead[0] = 0
+        ring = [[(dev_frames[t][c].ptr, W, H, W, 1) for c in range(NC)] for t in range(RING)]
+        motion = (pipeline.MOTION[0], pipeline.MOTION[1], pipeline.TH_PROJ)
+        la = 2 if overlap else 0
+        upto, t_loop = -1, 0
+        _st, upto = fe.fe.run_stream(ring, t_loop, min(a.warmup, 50), la, upto, motion, TH_LOW, pipeline.BOW_RATIO); t_loop += min(a.warmup, 50)
+        blk, covered = [], 0.0
+        while True:
+            sync_all()
+            t_start = time.perf_counter()
+            _st, upto = fe.fe.run_stream(ring, t_loop, a.steps, la, upto, motion, TH_LOW, pipeline.BOW_RATIO)
+            sync_all()
+            el = time.perf_counter() - t_start
+            blk.append(el); covered += el; t_loop += a.steps
+            if covered >= a.min_time or len(blk) >= 200:
+                break
+        c_abi_loop = {"value": round(rigs * a.steps / pct(blk, 50), 2), "ms_per_step": round(1e3 * pct(blk, 50) / a.steps, 4), "blocks": len(blk),
+                      "what": "orbf_run_stream: the same steps (two announced ahead, accepted-match count included) driven from inside the library"}
     # ---- one isolated timestep: no look-ahead, every step extracts its own images first (what a live rig sees as latency)
     fe.reset(); ahead[0] = 0
     n_iso = max(20, min(200, a.steps))
@@ -425,6 +448,7 @@ def main(argv=None):
                                          "max": round(1e3 * max(blocks) / a.steps, 4)},
                    "step_ms": {"median": round(1e3 * pct(per_step, 50), 4), "p5": round(1e3 * pct(per_step, 5), 4),
                                "p95": round(1e3 * pct(per_step, 95), 4), "n": len(per_step)}},
+        "value_c_abi_loop": c_abi_loop["value"] if c_abi_loop else None, "c_abi_loop": c_abi_loop,
         "latency_ms_isolated": iso["median"], "latency_isolated": iso,
         "value_isolated": round(rigs * 1e3 / iso["median"], 2),
         "value_h2d_inclusive": h2d["value"] if h2d else None, "h2d_inclusive": h2d,

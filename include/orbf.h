@@ -126,6 +126,20 @@ int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* quer
 typedef struct orbf_motion { float du, dv, th; } orbf_motion;
 int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out);
 int orbf_reset(orbf_frontend* f);
+/* The synthetic-stream loop in ONE call: for t = t0 .. t0 + steps - 1 announce timestep t + ahead (orbf_prefetch; ahead = 0:
+ * nothing is announced, every step is an isolated one; 1 or 2), run orbf_step_motion on ring[(t % ring_len) * n_cams ..] and
+ * count the cross-camera matches a SearchByBoW-style acceptance keeps (orbm_count_ratio_accepted(best, second, n, th_low,
+ * ratio)).  `ring` holds ring_len timesteps of n_cams images each.  *announced_upto (in/out): the youngest timestep announced so
+ * far, so that consecutive calls continue one stream (-1 / t0 - 1 at the start).  This is exactly what a host-language loop
+ * over orbf_prefetch + orbf_step_motion does -- a benchmark can time the library without its binding's per-call cost, a test
+ * can compare the totals with the step-by-step run. */
+typedef struct orbf_stream_stats {
+    int64_t features, temporal_matches, cross_accepted;   /* sums over the steps of this call */
+    uint64_t digest;                                       /* order-sensitive mix of the three per-step counts */
+    double seconds;                                        /* wall time of the loop (host clock, including the last step's wait) */
+} orbf_stream_stats;
+int orbf_run_stream(orbf_frontend* f, const orbf_image* ring, int ring_len, int t0, int steps, int ahead, int* announced_upto,
+                    const orbf_motion* motion, int th_low, float ratio, orbf_stream_stats* out);
 
 /* A step in two halves.  _begin enqueues everything and returns at once; _end blocks (one synchronisation) and fills the
  * result.  *block_ready (may be NULL) = 1 when this step's export block (orbf_export_block, valid right after _begin) is

@@ -58,6 +58,11 @@ class FMotion(C.Structure):  # orbf_motion
     _fields_ = [("du", C.c_float), ("dv", C.c_float), ("th", C.c_float)]
 
 
+class FStreamStats(C.Structure):  # orbf_stream_stats
+    _fields_ = [("features", C.c_int64), ("temporal_matches", C.c_int64), ("cross_accepted", C.c_int64), ("digest", C.c_uint64),
+                ("seconds", C.c_double)]
+
+
 class FrameDesc(C.Structure):  # orbm_frame_desc
     _fields_ = [("n_total", C.c_int32), ("n_cams", C.c_int32), ("un_x", C.c_void_p), ("un_y", C.c_void_p),
                 ("octave", C.c_void_p), ("angle", C.c_void_p), ("uright", C.c_void_p), ("cam_of", C.c_void_p),
@@ -150,6 +155,7 @@ def lib():
     L.orbf_step.argtypes = [vp, vp, vp, i32, i32, vp]
     L.orbf_step_motion.argtypes = [vp, vp, vp, i32, vp]
     L.orbf_reset.argtypes = [vp]
+    L.orbf_run_stream.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, C.c_float, vp]
     L.orbf_prefetch.argtypes = [vp, vp]
     L.orbf_step_begin.argtypes = [vp, vp, vp, i32, i32, vp]
     L.orbf_step_motion_begin.argtypes = [vp, vp, vp, i32, vp]

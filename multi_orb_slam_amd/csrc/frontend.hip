@@ -335,6 +335,34 @@ static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motio
                                     R.unx.p, R.uny.p);  // (mvKeysUn: equal to the keypoint positions without a calibration)
 }
 
+int orbf_run_stream(orbf_frontend* f, const orbf_image* ring, int ring_len, int t0, int steps, int ahead, int* announced_upto,
+                    const orbf_motion* motion, int th_low, float ratio, orbf_stream_stats* out) {
+    MORB_ARG(f && ring && ring_len >= 1 && t0 >= 0 && steps >= 0 && ahead >= 0 && ahead <= 2 && announced_upto && motion && out);
+    memset(out, 0, sizeof(*out));
+    const auto t_start = std::chrono::steady_clock::now();
+    auto images_of = [&](int t) { return ring + (size_t)(t % ring_len) * f->n_cams; };
+    orbf_result r;
+    for (int t = t0; t < t0 + steps; ++t) {
+        // every timestep up to t + ahead is announced exactly once, in order (the step's own images are never announced)
+        for (int a = std::max(*announced_upto + 1, t + 1); ahead > 0 && a <= t + ahead; ++a) {
+            int rc = orbf_prefetch(f, images_of(a));
+            if (rc) return rc;
+            *announced_upto = a;
+        }
+        int rc = orbf_step_motion(f, images_of(t), motion, 0, &r);
+        if (rc) return rc;
+        if (*announced_upto < t) *announced_upto = t;
+        const int nx = r.cross_best_dist ? orbm_count_ratio_accepted(r.cross_best_dist, r.cross_second_dist, r.n_total, th_low, ratio) : 0;
+        if (nx < 0) return nx;
+        out->features += r.n_total; out->temporal_matches += r.nmatches; out->cross_accepted += nx;
+        uint64_t h = out->digest ^ ((uint64_t)(uint32_t)r.n_total << 40) ^ ((uint64_t)(uint32_t)r.nmatches << 20) ^ (uint64_t)(uint32_t)nx;
+        h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29;
+        out->digest = h;
+    }
+    out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    return ORB_OK;
+}
+
 int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out) {
     MORB_ARG(f && images && motion && out);
     f->t_entry = std::chrono::steady_clock::now();

@@ -190,6 +190,25 @@ class NativeFrontEnd:
             self._next_keep = (self._next_keep + [keep])[-4:]   # host arrays stay alive across the steps in between
         check(_lib.lib().orbf_prefetch(self._h, arr))
 
+    def run_stream(self, ring, t0, steps, ahead, announced_upto, motion, th_low, ratio):
+        """orbf_run_stream: `steps` timesteps of the synthetic stream in one native call.  ring = list (one entry per ring
+        slot) of per-camera image tuples (ptr, width, height, stride, on_device).  -> (stats dict, new announced_upto)."""
+        from ._lib import FStreamStats
+        key = id(ring)
+        cached = getattr(self, "_ring_cache", None)
+        if cached is None or cached[0] != key:
+            arr = (FImage * (len(ring) * self.n_cams))()
+            for t, images in enumerate(ring):
+                sub = (FImage * self.n_cams).from_address(C.addressof(arr) + t * self.n_cams * C.sizeof(FImage))
+                self._fill(sub, images)
+            self._ring_cache = cached = (key, arr, ring)
+        st = FStreamStats(); upto = C.c_int(announced_upto)
+        mo = FMotion(*motion)
+        check(_lib.lib().orbf_run_stream(self._h, cached[1], len(ring), t0, steps, ahead, C.byref(upto), C.byref(mo), th_low,
+                                         C.c_float(ratio), C.byref(st)))
+        return (dict(features=st.features, temporal_matches=st.temporal_matches, cross_accepted=st.cross_accepted,
+                     digest=st.digest, seconds=st.seconds), upto.value)
+
     def step(self, images, queries=None, flags=0, copy=True, motion=None):
         """images: [(ptr_or_array, width, height, stride, on_device)] or uint8 arrays.  `queries`: projected map points, or
         `motion` = (du, dv, th): queries built natively from the previous step's features (synthetic-stream driver).

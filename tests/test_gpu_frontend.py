@@ -456,3 +456,57 @@ def test_world_size_n_native_steps_over_the_loopback_exchange(world, n_cams, w, 
                                other_descs=lambda c, mine=mine: [desc_of[g] for g in range(n_cams) if g != mine[c]])
             assert_same_step(got, exp)
     assert all(results[r][T - 1]["n_temporal"] > 30 for r in range(world))
+
+
+def test_native_stream_loop_equals_the_step_by_step_run():
+    """orbf_run_stream (the synthetic-stream loop in one native call, what bench.py times as `value_c_abi_loop`) must do exactly
+    what the binding's loop over announce + step does: same per-step feature, temporal-match and accepted cross-match counts,
+    with two steps announced ahead and with none -- and the overlapped run must equal the isolated one step for step."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline, rt
+    from multi_orb_slam_amd.matcher import TH_LOW
+    W, H, RING, N = 640, 480, 8, 40
+    params = [m.ExtractorParams(nfeatures=1000)] * 2
+    dev = []
+    for t in range(RING):
+        row = []
+        for c in range(2):
+            b = rt.DeviceBuffer(W * H); b.upload(synth.image(c, t, W, H)); row.append(b)
+        dev.append(row)
+    ring = [[(dev[t][c].ptr, W, H, W, 1) for c in range(2)] for t in range(RING)]
+    motion = (pipeline.MOTION[0], pipeline.MOTION[1], pipeline.TH_PROJ)
+
+    def mix(h, n, nt, nx):
+        h ^= ((n & 0xffffffff) << 40) ^ ((nt & 0xffffffff) << 20) ^ (nx & 0xffffffff)
+        h = (h * 0x9E3779B97F4A7C15) & 0xffffffffffffffff
+        return h ^ (h >> 29)
+
+    # step by step through the binding
+    fe = pipeline.FrontEnd(params, W, H)
+    fe.copy_results = False
+    arg = lambda t: [(dev[t % RING][c].ptr, W) for c in range(2)]
+    fe.announce(arg(1), resident=True)
+    tot = [0, 0, 0]; dig = 0
+    for t in range(N):
+        r = fe.step(arg(t), resident=True, next_images=arg(t + 2))
+        tot[0] += r["n_total"]; tot[1] += r["n_temporal"]; tot[2] += r["n_cross"]
+        dig = mix(dig, r["n_total"], r["n_temporal"], r["n_cross"])
+    fe.close()
+    for ahead in (2, 0):
+        fe = pipeline.FrontEnd(params, W, H)
+        upto = -1
+        acc = [0, 0, 0]; digests = []
+        for t0 in (0, 13, 27):     # three consecutive calls continue one stream
+            n = {0: 13, 13: 14, 27: N - 27}[t0]
+            st, upto = fe.fe.run_stream(ring, t0, n, ahead, upto, motion, TH_LOW, pipeline.BOW_RATIO)
+            acc[0] += st["features"]; acc[1] += st["temporal_matches"]; acc[2] += st["cross_accepted"]
+            digests.append(st["digest"])
+            assert st["seconds"] > 0
+        fe.close()
+        assert acc == tot, (ahead, acc, tot)
+    assert tot[1] > 30 * 1000 and tot[2] > 0
+    # one call over the whole stream reproduces the order-sensitive digest of the step-by-step run
+    fe = pipeline.FrontEnd(params, W, H)
+    st, _ = fe.fe.run_stream(ring, 0, N, 2, -1, motion, TH_LOW, pipeline.BOW_RATIO)
+    fe.close()
+    assert st["digest"] == dig
