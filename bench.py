@@ -3,7 +3,8 @@
 CPU baseline in the same run.
 
   python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4]
-  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+  (N > 1: one rank per GPU over RCCL -- launched by torch.distributed.run, or, when run as a plain process, by bench.py
+  itself: the parent starts N rank processes before it touches a GPU and relays rank 0's line)
 
 One step = one timestep of one camera rig: extract every camera (8-level pyramid), merge the frame, SearchByProjection of
 the previous frame's points, exhaustive cross-camera Hamming top-2.  Inputs are synthetic, generated once and resident in
@@ -77,7 +78,9 @@ def plan_for(config, world, rank):
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs = rank processes.  Under a launcher (WORLD_SIZE set) it must equal the "
+                    "world size; on its own `--gpus N` with N > 1 starts the N ranks itself.  Default: WORLD_SIZE, else 1")
+    ap.add_argument("--plan-only", action="store_true", help="no GPU: launch / rendezvous (gloo) / sharding plan only, one JSON line")
     ap.add_argument("--steps", type=int, default=None, help="steps per timed block (default 2000; 100 for --config 4)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
@@ -240,12 +243,100 @@ def project_roofline(m, n_feat=2000, width=1280, height=720, iters=50):
             "note": "latency-bound gather (one wave per query, dependent cell -> item -> descriptor loads), not a bandwidth kernel"}
 
 
+# ------------------------------------------------------------------------------------------------ self-launch
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start one rank process per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* as torch.distributed.run would set them), relay rank 0's JSON line, exit with the ranks' status.
+    This parent never touches the GPU (no HIP call, no torch import): the ranks are fresh child processes, nothing is
+    re-executed in a process that has initialised a device."""
+    import socket
+    import subprocess
+    import threading
+    n = a.gpus
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    base = dict(os.environ)
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this pool
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line.decode("utf-8", "replace")); sys.stdout.flush()
+    th = threading.Thread(target=relay, daemon=True); th.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, code))
+                for o in live:               # exactly the processes started above
+                    procs[o].terminate()
+        time.sleep(0.05)
+    th.join(5.0)
+    return rc if rc >= 0 else 128 - rc
+
+
+def plan_only(a, rank, world):
+    """--plan-only: no GPU.  Every rank computes its shard, the ranks rendezvous over gloo and rank 0 prints the line the
+    real run would head with (n_gpus, scaling, which rank owns which cameras) -- the launcher and the sharding arithmetic
+    checked on a CPU box (tests/test_bench_plan.py)."""
+    P = plan_for(a.config, world, rank)
+    owned = [P["global_cams"]]
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        owned = [None] * world
+        dist.all_gather_object(owned, P["global_cams"])
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec (N-cam extract+match)", "value": None, "unit": "frames/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "scaling": P["scaling"], "plan_only": True,
+                          "config": {"workload": "%s: %s" % (P["name"], P["text"]), "cams_per_gpu": P["cams_per_rank"],
+                                     "rig_cams": P["rig_cams"], "rigs": P["rigs"]},
+                          "cameras_of_rank": owned, "exchange": P["exchange"]}))
+    return 0
+
+
+def extract_alg_bytes(width, height, nfeatures, nlevels=8, scale=1.2):
+    """algorithmic bytes of one extraction = W*H (level 0 read) + 2 * sum over levels >= 1 of w*h (each
+    level is materialised: one quantised write, one read) + 60 B per feature (28-B keypoint + 32-B descriptor):
+    1.65 MB (640x480 @1000) / 4.90 MB (1280x720 @2000) / 11.01 MB (1920x1080 @4000)."""
+    import numpy as np
+    b = float(width * height)
+    s = np.float32(1.0)
+    for _l in range(1, nlevels):
+        s = np.float32(s * np.float32(scale))
+        inv = np.float32(1.0) / s
+        b += 2.0 * float(int(np.rint(np.float32(width) * inv))) * float(int(np.rint(np.float32(height) * inv)))
+    return b + 60.0 * nfeatures
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     a = parse(argv)
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (a.gpus or 1) > 1:
+        return launch_ranks(a, argv)           # before any GPU call; the ranks are children of this process
+    rank = int(os.environ.get("RANK", "0")); world = int(env_world or "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+    if a.gpus is not None and a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a line "
+                         "whose n_gpus is not the number of GPUs that worked" % (a.gpus, world))
+    if a.plan_only:
+        return plan_only(a, rank, world)
+    dist = None; ctl = None
     use_dist = world > 1 or os.environ.get("MORB_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
     if use_dist:
         import torch
@@ -255,6 +346,9 @@ def main(argv=None):
             os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29511")
         # (no device_id=: eager communicator init made every hipStreamSynchronize of this process ~100 us slower here)
         dist.init_process_group("nccl", rank=rank, world_size=world)
+        # control plane: the long waits (other ranks idle while rank 0 times the CPU baseline and the matcher rooflines) sit on a
+        # gloo barrier -- host sockets, no kernel spinning on the waiting GPUs
+        ctl = dist.new_group(backend="gloo")
     import numpy as np
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import synth, pipeline, rt
@@ -273,6 +367,9 @@ def main(argv=None):
         # MORB_NATIVE_EXCHANGE=0 keeps the torch.distributed collective of DescriptorExchange
         if os.environ.get("MORB_NATIVE_EXCHANGE", "1") != "0":
             fe.enable_native_exchange(dist, torch.device("cuda", local))
+        if getattr(fe, "native_exchange", False):
+            seen = fe.fe.exchange_world
+            assert seen == world, "RCCL communicator spans %d rank(s), the launcher started %d" % (seen, world)
 
     # ---- synthetic stream of this rank's cameras: resident in HBM before timing, and once more in page-locked host memory
     host_frames = [[synth.image(g, t, W, H) for g in gcam] for t in range(RING)]
@@ -293,40 +390,57 @@ def main(argv=None):
     # runs on the extractor's stream.
     overlap = not a.no_overlap
 
-    # ---- parity gate: bit-exact vs the CPU oracle (single-rank view) on the same call pattern as the timed loop
-    parity = "skipped (N > 1: every rank's cameras are covered by the N = 1 gate and tests/)"
-    if world == 1:
-        from oracle_pipeline import OracleFrontEnd, assert_same_step
-        import oracle
-        if a.config != 4:
-            ofe = OracleFrontEnd(params, W, H, gcam)
-            if overlap:
-                fe.announce(frame_args(1), resident=True)
-            for t in range(5):   # two future steps are announced (orbf_prefetch), as in the timed loop
-                got = fe.step(frame_args(t), resident=True, next_images=frame_args(t + 2) if overlap else None)
-                assert_same_step(got, ofe.step(host_frames[t % RING]))
-            parity = "bit-exact vs oracle on 5 steps (keypoints, descriptors, stereo, temporal + cross-camera matches)"
-        else:
-            # the oracle needs seconds per 1080p camera: one camera of the second step is pinned here, the whole rig by
-            # tests/test_gpu_frontend.py::test_full_size_rig_properties
-            for t in range(2):
-                got = fe.step(frame_args(t), resident=True)
-            off = np.concatenate([[0], np.cumsum(got["counts"])])
-            okps, odesc = oracle.extract(host_frames[1][3], nfeatures=NFEAT)
-            assert got["kps"][off[3]:off[4]].tobytes() == okps.tobytes() and np.array_equal(got["desc"][off[3]:off[4]], odesc)
-            g = 17; bi, bd, sd = got["cross"]
-            others = np.concatenate([got["desc"][:off[0]], got["desc"][off[1]:]])
-            dd = np.unpackbits(others ^ got["desc"][g], axis=1).sum(1); o = np.argsort(dd, kind="stable")
-            assert bd[g] == dd[o[0]] and sd[g] == dd[o[1]] and bi[g] == o[0]
-            parity = "camera 3 of step 1 bit-exact vs oracle at full size + cross top-2 spot check (whole rig: tests/)"
-        fe.reset()
-
-    def sync_all():
+    def sync_all(long_wait=False):
         rt.device_sync()
         if dist is not None:
             import torch
             torch.cuda.synchronize()
+            if long_wait:
+                dist.barrier(group=ctl)
             dist.barrier(device_ids=[local])
+
+    # ---- parity gate, on EVERY rank of any world size: this rank's cameras bit for bit against the CPU oracle on the call
+    # pattern of the timed loop (keypoint records, descriptors, stereo, undistorted positions, the temporal search with its
+    # rotation histogram), and the rig-wide cross-camera top-2 of this rank's features against the oracle's brute force over
+    # the descriptors of every OTHER camera of the job -- which the oracle extracts itself from the other ranks' synthetic
+    # images (nothing a GPU produced goes into the expectation).  One host thread per camera (the oracle's C entry points
+    # release the GIL).
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    import oracle
+    from concurrent.futures import ThreadPoolExecutor
+    job_cams = list(range(world * P["rig_cams"])) if P["scaling"] == "weak" else list(range(P["rig_cams"]))
+    if not use_dist or world == 1:
+        job_cams = list(gcam)
+    other_g = [g for g in job_cams if g not in gcam]
+    n_gate = 2 if a.config == 4 else 5
+    t_gate = time.perf_counter()
+    ofe = OracleFrontEnd(params, W, H, gcam, cam_threads=True)
+    pool = ThreadPoolExecutor(max(1, min(len(other_g), 16))) if other_g else None
+    if overlap:
+        fe.announce(frame_args(1), resident=True)
+    for t in range(n_gate):   # two future steps are announced (orbf_prefetch), as in the timed loop
+        got = fe.step(frame_args(t), resident=True, next_images=frame_args(t + 2) if overlap else None)
+        desc_of = {}
+        if other_g:
+            ext = lambda g: oracle.extract(synth.image(g, t % RING, W, H), nfeatures=NFEAT)[1]
+            desc_of = dict(zip(other_g, pool.map(ext, other_g)))
+        seen_own = {}
+
+        def others(c):
+            return [desc_of[g] if g in desc_of else seen_own[g] for g in job_cams if g != gcam[c]]
+        # the oracle front end extracts this rank's cameras first and then asks for the others per camera
+        own_hook = lambda per_cam: seen_own.update({g: per_cam[i][1] for i, g in enumerate(gcam)})
+        exp = ofe.step(host_frames[t % RING], other_descs=others if other_g else None, on_extracted=own_hook)
+        assert_same_step(got, exp)
+    if pool is not None:
+        pool.shutdown()
+    if hasattr(ofe, "pool") and ofe.pool is not None:
+        ofe.pool.shutdown()
+    parity = ("bit-exact vs oracle on %d steps, all %d camera(s) of this rank at full size (keypoints, descriptors, stereo, temporal "
+              "matches incl. rotation histogram) + the complete cross-camera top-2 against the oracle's brute force over %d camera(s) "
+              "of the job; every rank runs the gate (%.1f s on rank 0)" % (n_gate, NC, len(job_cams), time.perf_counter() - t_gate))
+    fe.reset()
+    sync_all(long_wait=True)      # a rank whose gate failed has raised by now: its exit stops the job
 
     ahead = [0]   # index of the youngest timestep announced so far
     stamps = []   # host timestamps after every step call of the current block
@@ -371,6 +485,16 @@ def main(argv=None):
                 n_blocks = max(1, min(200, int(math.ceil(min_time / max(el, 1e-9)))))
             if len(blocks) >= n_blocks:
                 return blocks, per_step, t
+
+    def latency(ps, c_abi_from=None):
+        o = {"median": round(1e3 * pct(ps, 50), 4), "p5": round(1e3 * pct(ps, 5), 4), "p95": round(1e3 * pct(ps, 95), 4), "steps": len(ps)}
+        # the same steps as the C ABI sees them: begin (everything enqueued) + end (wait + collect), without the Python binding
+        # around the two calls (argument marshalling, result views, the native count of accepted cross matches)
+        c_abi = sorted(1e-3 * (h[1] + h[2] + h[3]) for h in (c_abi_from or []))
+        if c_abi:
+            o["c_abi_ms"] = {"median": round(pct(c_abi, 50), 4), "p5": round(pct(c_abi, 5), 4), "p95": round(pct(c_abi, 95), 4),
+                             "what": "orbf_step_begin + orbf_step_end as timed inside the library (orbf_result::host_us[1..3])"}
+        return o
 
     fe.copy_results = False          # timed loop: consume the results in place (views of the pinned buffers)
     # The interpreter's cyclic collector would otherwise run inside the loop (every torch.distributed call allocates
@@ -420,21 +544,31 @@ def main(argv=None):
     run(min(20, a.warmup), 0, False)
     del native_us[:]
     _b3, ps3, _ = timed_blocks(n_iso, 20, min(a.min_time, 0.1), overlap=False)
-    iso = {"median": round(1e3 * pct(ps3, 50), 4), "p5": round(1e3 * pct(ps3, 5), 4), "p95": round(1e3 * pct(ps3, 95), 4), "steps": len(ps3)}
-    # the same steps as the C ABI sees them: begin (everything enqueued) + end (wait + collect), without the Python binding
-    # around the two calls (argument marshalling, result views, the native count of accepted cross matches)
-    c_abi = sorted(1e-3 * (h[1] + h[2] + h[3]) for h in native_us)
-    if c_abi:
-        iso["c_abi_ms"] = {"median": round(pct(c_abi, 50), 4), "p5": round(pct(c_abi, 5), 4), "p95": round(pct(c_abi, 95), 4),
-                           "what": "orbf_step_begin + orbf_step_end as timed inside the library (orbf_result::host_us[1..3])"}
+    iso = latency(ps3, native_us)
+    # ---- the live-rig number: the same isolated step with the images in page-locked HOST memory -- no look-ahead, the H2D
+    # copies of all cameras inside the step (what Frame::Frame, src/Frame.cc:148-288, would wait for on a rig that delivers
+    # host images)
+    fe.reset(); ahead[0] = 0
+    run(min(20, a.warmup), 0, False, pinned=True)
+    del native_us[:]
+    _b4, ps4, _ = timed_blocks(n_iso, 20, min(a.min_time, 0.1), overlap=False, pinned=True)
+    iso_h2d = latency(ps4, native_us)
+    iso_h2d["bytes_per_step"] = NC * W * H
     fe.reset(); ahead[0] = 0
     gc.enable(); gc.unfreeze()
 
-    # per-stage GPU time of the extractor (HIP events) on one extra profiled step
+    # per-stage GPU time of the extractor (HIP events): median over several profiled isolated steps (a single probe is noisy)
     fe.ex.set_profiling(True)
-    fe.step(frame_args(0), resident=True); fe.step(frame_args(1), resident=True)
-    stages = fe.ex.stage_times_us()
+    probes = []
+    for t in range(12):
+        fe.step(frame_args(t), resident=True)
+        if t >= 2:
+            probes.append(fe.ex.stage_times_us())
     fe.ex.set_profiling(False)
+    stages = {k: pct([p[k] for p in probes], 50) for k in probes[0]}
+    ex_us = sum(stages[k] for k in ("pyramid", "fast_cells", "compact", "quadtree", "describe"))
+    ex_bytes = NC * extract_alg_bytes(W, H, NFEAT)
+    ex_ach = ex_bytes / (ex_us * 1e-6) / 1e9 if ex_us > 0 else 0.0
 
     out = {
         "metric": "frames/sec (N-cam extract+match)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
@@ -450,12 +584,19 @@ def main(argv=None):
                                "p95": round(1e3 * pct(per_step, 95), 4), "n": len(per_step)}},
         "value_c_abi_loop": c_abi_loop["value"] if c_abi_loop else None, "c_abi_loop": c_abi_loop,
         "latency_ms_isolated": iso["median"], "latency_isolated": iso,
+        "latency_ms_isolated_h2d": iso_h2d["median"], "latency_isolated_h2d": iso_h2d,
         "value_isolated": round(rigs * 1e3 / iso["median"], 2),
         "value_h2d_inclusive": h2d["value"] if h2d else None, "h2d_inclusive": h2d,
         "parity": parity,
         "overlap": ("the extractions of timesteps t+1 and t+2 run next to the matching of timestep t (orbf_prefetch); `value` needs "
                     "the images two steps ahead, `latency_ms_isolated` / `value_isolated` do not") if overlap else "off",
         "extractor_stage_us": {k: round(v, 1) for k, v in stages.items()},
+        "roofline_extract": {"kernel": "extraction chain (k_ingest, k_resize2/k_resize, k_fast_cells, k_octree, k_describe)", "bound": "hbm",
+                             "achieved": round(ex_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ex_ach / HBM_PEAK_GBS, 5),
+                             "alg_bytes_per_image": extract_alg_bytes(W, H, NFEAT), "images": NC, "chain_us": round(ex_us, 1),
+                             "traffic": _pmc_bytes("extract_chain"),
+                             "note": "SURVEY 8(d): W*H + 2*sum(levels>=1) + 60*N per image over the GPU time of one isolated extraction "
+                                     "chain (HIP events, median of 10 steps); a latency chain of small launches, not a bandwidth kernel"},
         "exchange": ("none (one rank)" if not use_dist else
                      "one RCCL all-gather of the step's descriptor block per step, issued natively from inside the step (RCCL C API)"
                      if getattr(fe, "native_exchange", False) else
@@ -469,29 +610,45 @@ def main(argv=None):
         import dropin_leg       # tests/dropin_leg.py: the C++ classes with the reference's signatures, reference call pattern
         out["dropin"] = dropin_leg.bench(W, H, NFEAT)
         out["dropin_fps"] = out["dropin"]["dropin_fps"]
-    if rank == 0 and world == 1 and not a.no_cpu:
-        from oracle_pipeline import OracleFrontEnd
+    if rank == 0 and not a.no_cpu:
+        # the CPU baseline of the unit `value` counts: one rig timestep.  Weak configurations: this rank's own rig; strong
+        # ones: the WHOLE rig (all cameras, whichever rank owns them), so the figure is the same at every N.
+        cpu_cams = list(gcam) if P["scaling"] == "weak" else list(range(P["rig_cams"]))
+        cpu_params = [m.ExtractorParams(nfeatures=NFEAT)] * len(cpu_cams)
+        cpu_frames = host_frames if cpu_cams == list(gcam) else [[synth.image(g, t, W, H) for g in cpu_cams] for t in range(min(RING, 3))]
 
         def cpu_rate(cam_threads, budget):
-            ofe = OracleFrontEnd(params, W, H, gcam, cam_threads=cam_threads)
-            ofe.step(host_frames[0])                  # warm caches, establish `prev`
+            o = OracleFrontEnd(cpu_params, W, H, cpu_cams, cam_threads=cam_threads)
+            o.step(cpu_frames[0])                  # warm caches, establish `prev`
             t0 = time.perf_counter(); n = 0
             while n < 2 or (time.perf_counter() - t0 < budget and n < 400):
-                ofe.step(host_frames[(1 + n) % RING]); n += 1
+                o.step(cpu_frames[(1 + n) % len(cpu_frames)]); n += 1
             return n / (time.perf_counter() - t0), n
 
         v1, n1 = cpu_rate(False, 0.6 * a.cpu_seconds)   # faithful to the reference: cameras back to back on the tracking thread (src/Frame.cc:182,185)
         vn, _ = cpu_rate(True, 0.4 * a.cpu_seconds)     # one thread per camera (the variant commented out at src/Frame.cc:106-109)
         out["cpu_baseline"] = {"value": round(v1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": "%d steps of the same %d-cam %dx%d workload through oracle/liborb_oracle.so "
-                                         "(scalar C++ restatement, 1 thread; host has %d cores)" % (n1, NC, W, H, os.cpu_count()),
-                               "value_one_thread_per_camera": round(vn, 3), "cores_one_thread_per_camera": NC}
+                               "sample": "%d timesteps of one %d-cam %dx%d rig (the unit of `value`) through oracle/liborb_oracle.so "
+                                         "(scalar C++ restatement, 1 thread; host has %d cores), timed on rank 0 while the other ranks wait"
+                                         % (n1, len(cpu_cams), W, H, os.cpu_count()),
+                               "value_one_thread_per_camera": round(vn, 3), "cores_one_thread_per_camera": len(cpu_cams)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out)); sys.stdout.flush()
+    if dist is not None:
+        dist.barrier(group=ctl)       # the other ranks wait here (host sockets) while rank 0 runs the rooflines and the CPU baseline
     fe.close()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+def _pmc_bytes(key):
+    pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return (json.load(open(pj)).get(key) or {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -22,11 +22,14 @@ class OracleFrontEnd:
         self.depth = [P.synth_depth_image(g, width, height) for g in self.global_cams]
         self.prev = None
 
-    def step(self, images, other_descs=None):
+    def step(self, images, other_descs=None, on_extracted=None):
         """other_descs(cam_index) -> list of descriptor arrays of every OTHER camera of the rig in global camera order
-        (multi-GPU mirror); None = the rig is just this process' cameras."""
+        (multi-GPU mirror); None = the rig is just this process' cameras.  on_extracted(per_cam) is called with this front end's
+        own [(keypoints, descriptors)] before the cross-camera matching asks for the others."""
         ext = lambda a: oracle.extract(a[0], a[1].nfeatures, a[1].scale_factor, a[1].nlevels, a[1].ini_th_fast, a[1].min_th_fast)
         per_cam = list(self.pool.map(ext, zip(images, self.params))) if self.pool else [ext(a) for a in zip(images, self.params)]
+        if on_extracted is not None:
+            on_extracted(per_cam)
         counts = [len(k) for k, _ in per_cam]
         cat = np.concatenate
         kps = cat([k for k, _ in per_cam]); desc = cat([d for _, d in per_cam])

@@ -1,13 +1,28 @@
-"""bench.py's sharding plan for the torchrun shapes the driver uses (`--gpus N` with WORLD_SIZE = N): pure arithmetic,
+"""bench.py's launcher and sharding plan for the torchrun shapes the driver uses (`--gpus N` with WORLD_SIZE = N): pure arithmetic,
 no GPU.  configs[3] / configs[4] are ONE rig whose cameras are sharded over the ranks (strong scaling, the curve
 BASELINE.json's north_star asks for); configs[1] / configs[2] give every rank a rig of its own (weak scaling)."""
+import json
+import os
+import subprocess
+import sys
 import pytest
 import bench
+
+BENCH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def _json_lines(text):
+    return [json.loads(l) for l in text.splitlines() if l.startswith("{")]
 
 
 def test_default_run_is_configs1_on_one_gpu():
     a = bench.parse([])
-    assert a.config == 1 and a.gpus == 1 and a.steps > 0 and a.warmup > 0
+    assert a.config == 1 and a.gpus is None and a.steps > 0 and a.warmup > 0    # --gpus unset: WORLD_SIZE, else 1
     p = bench.plan_for(a.config, 1, 0)
     assert p["name"] == "configs[1]" and p["global_cams"] == [0, 1] and p["scaling"] == "weak" and p["rigs"] == 1
     assert (p["width"], p["height"], p["nfeatures"]) == (640, 480, 1000)
@@ -57,3 +72,44 @@ def test_torchrun_arguments_parse_as_the_driver_passes_them():
 def test_percentiles():
     xs = list(range(1, 101))
     assert bench.pct(xs, 50) == 50 and bench.pct(xs, 5) == 5 and bench.pct(xs, 95) == 95 and bench.pct([3.0], 95) == 3.0
+
+
+def test_gpus_n_as_a_plain_process_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher (how the driver ran round 2's N = 1 line): the parent starts two rank
+    processes, they rendezvous (gloo here, RCCL on the GPU box), ONE line comes back and it says n_gpus 2."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--config", "3", "--plan-only"], env=_clean_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1
+    assert lines[0]["n_gpus"] == 2 and lines[0]["scaling"] == "strong" and lines[0]["cameras_of_rank"] == [[0, 1], [2, 3]]
+    assert lines[0]["exchange"] is True and lines[0]["config"]["cams_per_gpu"] == 2
+
+
+def test_gpus_n_under_torch_distributed_run():
+    """the driver's N > 1 command line: torch.distributed.run sets WORLD_SIZE, bench.py must not launch a second layer"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", BENCH, "--gpus", "2", "--steps", "20", "--warmup", "5", "--plan-only"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["scaling"] == "weak"
+    assert lines[0]["cameras_of_rank"] == [[0, 1], [2, 3]] and lines[0]["steps"] == 20 and lines[0]["config"]["rigs"] == 2
+
+
+def test_one_gpu_plain_process_is_unchanged_and_a_mismatch_is_refused():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--plan-only"], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and _json_lines(r.stdout)[0]["n_gpus"] == 1
+    env = dict(_clean_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--plan-only"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in r.stderr and not _json_lines(r.stdout)
+    # a rank that dies takes the job down with its status (no line, no hang)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--config", "3", "--plan-only"], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and not _json_lines(r.stdout)
+
+
+def test_extractor_algorithmic_bytes_are_the_survey_figures():
+    # SURVEY section 8(d): 1.65 MB / 4.90 MB / 11.01 MB per image
+    assert round(bench.extract_alg_bytes(640, 480, 1000) / 1e6, 2) == 1.65
+    assert round(bench.extract_alg_bytes(1280, 720, 2000) / 1e6, 2) == 4.90
+    assert round(bench.extract_alg_bytes(1920, 1080, 4000) / 1e6, 2) == 11.01
