@@ -422,32 +422,43 @@ __global__ __launch_bounds__(1024) void k_compact(const LevelInfo* __restrict__ 
 //     keypoint are sorted by (size, creation order) and split from the back (largest, newest first) until the list
 //     reaches N nodes.  Every split grows the list by (#non-empty children - 1), so the stopping point is a prefix sum.
 //   * a node's keypoints keep their relative order when they are dealt to its children (stable 4-way partition), which
-//     the final "first maximum response wins" depends on.
-// Here the list is an array in list order (node id == list position, rebuilt every pass), a node's keypoints are a
-// contiguous slice of the key arrays, and every pass is: classify keys -> one packed prefix sum (4 x 16-bit child
-// counters) -> new node array -> scatter keys.  Creation order inside a pass replaces the reference's heap-address
-// tie-break exactly as the host code and the oracle do.
-constexpr int OCT_NK = 4096;   // candidates per (camera, level) handled on the device
+//     only the final "first maximum response wins" depends on: inside any node the keypoints stay in candidate order.
+// Here the list is an array in list order (node id == list position, rebuilt every pass).  Round 3: THE KEYS NEVER MOVE.
+// A key is the 32-bit candidate word k_fast_cells wrote (x | y << 12 | response << 24) at its candidate position p, plus
+// the 16-bit id of the node that owns it.  Nothing in the algorithm needs a node's keys to be contiguous: a split needs
+// the four child COUNTS of the node (an LDS histogram: one 64-bit atomic add of 1 << 16*child per key, one add per wave
+// while a wave's keys share a node), the new list needs only per-node records, and "first maximum in the node's key order"
+// is the maximum of (response, -p).  So a pass is: node phase (one thread per node: child counts -> one packed 64-bit
+// scan -> new node records) and key phase (every key: its new node from its parent's record, and -- same visit -- its
+// child inside that new node added to the node's histogram for the NEXT pass).  No per-key prefix sum, no scatter, no
+// double-buffered key arrays: 6 bytes of LDS per candidate, so 16 384 candidates (the dense levels of a 1080p image)
+// fit the same single-launch kernel that used to hold 4096 (the HBM-backed second launch of rounds 1-2 is gone).
+// Creation order inside a pass replaces the reference's heap-address tie-break exactly as the host code and the oracle do
+// (SURVEY App. C-1).
+constexpr int OCT_NK = 16384;  // candidates per (camera, level) handled on the device
 constexpr int OCT_NL = 1024;   // live nodes (>= quota + 4)
 
 MORB_PHASE_DECL(g_ph_oct);
 
 struct OctLds {
-    unsigned short kx[2][OCT_NK], ky[2][OCT_NK], kn[2][OCT_NK];
-    unsigned char kr[2][OCT_NK];           // FAST response of the key
-    unsigned long long S[OCT_NK];          // inclusive packed prefix of child one-hots; reused as scratch
-    short ulx[2][OCT_NL], uly[2][OCT_NL], brx[2][OCT_NL], bry[2][OCT_NL];
-    unsigned short nb[2][OCT_NL], ne[2][OCT_NL], ncrt[2][OCT_NL];
-    unsigned char nfl[2][OCT_NL];          // bit0 = holds exactly one keypoint (bNoMore), bit1 = created by the last pass
-    unsigned short P[OCT_NL];              // parents of this pass in processing order
-    unsigned short procidx[OCT_NL];        // node -> index in P (0xffff: not split)
-    unsigned short newpos[OCT_NL];         // surviving node -> new list position
-    unsigned short cbase[OCT_NL];          // parent t -> creation index of its first child
-    unsigned long long pc[OCT_NL];         // parent t -> packed child counts
+    uint32_t key[OCT_NK];                  // x | y << 12 | response << 24, candidate order (cell-major, row-major in a cell)
+    unsigned short kn[OCT_NK];             // list position of the node that owns the key (the cell offsets alias it while loading)
+    unsigned long long box[2][OCT_NL];     // ulx | uly << 16 | brx << 32 | bry << 48
+    unsigned long long pc[2][OCT_NL];      // child histogram (4 x 16 bit) of a node that holds more than one key
+    unsigned short cnt[2][OCT_NL];         // keys of the node (1 = bNoMore)
+    unsigned short ncrt[2][OCT_NL];        // creation index in the pass that made the node; 0xffff = older than the last pass
+    unsigned short newid[OCT_NL];          // survivor -> new list position; parent -> creation index of its first child
+    unsigned short procidx[OCT_NL];        // careful pass: node -> index in processing order (0xffff: not split)
+    unsigned short P[OCT_NL];              // careful pass: parents in processing order
+    unsigned short cnode[OCT_NL];          // careful pass: candidate -> node
     unsigned int sortkey[OCT_NL];
+    unsigned int best[OCT_NL];             // response << 14 | (16383 - p): maximum = first key of the largest response
+    unsigned long long wsum64[2][16];
     int wsum[16];
     int v[8];                              // block-uniform scalars
 };
+static_assert(sizeof(OctLds) <= 160 * 1024, "quadtree state must fit one CU's LDS");
+static_assert(OCT_NK <= 16384, "best[] packs the key position into 14 bits");
 
 __device__ __forceinline__ int oct_block_excl_scan(int val, int tid, int* wsum, int* total) {
     // exclusive scan of one int per thread over the 1024-thread block
@@ -463,303 +474,66 @@ __device__ __forceinline__ int oct_block_excl_scan(int val, int tid, int* wsum, 
     return base + incl - val;
 }
 
-// child of a key inside node box (ulx,uly)-(brx,bry): DivideNode's halfX/halfY and its '<' tests (:482-523)
-__device__ __forceinline__ int oct_child(int x, int y, int ulx, int uly, int brx, int bry, int& midx, int& midy) {
+__device__ __forceinline__ unsigned long long oct_pack_box(int ulx, int uly, int brx, int bry) {
+    return (unsigned long long)(unsigned)(ulx & 0xffff) | ((unsigned long long)(unsigned)(uly & 0xffff) << 16) |
+           ((unsigned long long)(unsigned)(brx & 0xffff) << 32) | ((unsigned long long)(unsigned)(bry & 0xffff) << 48);
+}
+
+// child of a key inside a node box: DivideNode's halfX/halfY and its '<' tests (:482-523)
+__device__ __forceinline__ int oct_child(int x, int y, unsigned long long bx, int& midx, int& midy) {
     // ceil((float)d / 2) for an integer d >= 0 (boxes never invert; d < 2^24 is exact in float) == (d + 1) >> 1: the float
     // division of the reference costs ~15 instructions per coordinate here, twice per key and pass
+    const int ulx = (int)(bx & 0xffff), uly = (int)((bx >> 16) & 0xffff), brx = (int)((bx >> 32) & 0xffff), bry = (int)(bx >> 48);
     midx = ulx + ((brx - ulx + 1) >> 1);
     midy = uly + ((bry - uly + 1) >> 1);
     return (x < midx ? 0 : 1) + (y < midy ? 0 : 2);
 }
 
-// Key storage of the quadtree.  Up to OCT_NK candidates live in LDS (OctLds); levels beyond that (dense 1080p levels) run
-// the SAME code with the key arrays and the packed prefix in an HBM workspace (BIG: up to OCT_NKB candidates, L2-resident,
-// a few times slower per pass -- still two orders of magnitude ahead of the host round trip it replaces).
-constexpr int OCT_NKB = 16384;
-struct OctBig {            // workspace slice of one (camera, level) block
-    unsigned short *kx, *ky, *kn;   // [2][OCT_NKB] each
-    unsigned char* kr;              // [2][OCT_NKB]
-    unsigned long long* S;          // [OCT_NKB]
-};
-constexpr size_t OCT_BIG_BYTES = (size_t)OCT_NKB * (3 * 2 * 2 + 2 * 1 + 8);  // per block
-__device__ __forceinline__ OctBig oct_big_slice(unsigned char* ws, int blk) {
-    unsigned char* p = ws + (size_t)blk * OCT_BIG_BYTES;
-    OctBig B;
-    B.S = reinterpret_cast<unsigned long long*>(p); p += (size_t)OCT_NKB * 8;
-    B.kx = reinterpret_cast<unsigned short*>(p); p += (size_t)OCT_NKB * 4;
-    B.ky = reinterpret_cast<unsigned short*>(p); p += (size_t)OCT_NKB * 4;
-    B.kn = reinterpret_cast<unsigned short*>(p); p += (size_t)OCT_NKB * 4;
-    B.kr = p;
-    return B;
-}
-#define KX(a, p) (*(BIG ? &G.kx[(a) * OCT_NKB + (p)] : &L.kx[a][p]))
-#define KY(a, p) (*(BIG ? &G.ky[(a) * OCT_NKB + (p)] : &L.ky[a][p]))
-#define KN(a, p) (*(BIG ? &G.kn[(a) * OCT_NKB + (p)] : &L.kn[a][p]))
-#define KR(a, p) (*(BIG ? &G.kr[(a) * OCT_NKB + (p)] : &L.kr[a][p]))
-#define KS(p) (*(BIG ? &G.S[p] : &L.S[p]))
-
-// One split pass over the parents listed in L.P[0..np) (processing order), used by the careful phase.  The caller has
-// set L.procidx[node] = t for exactly those parents (0xffff for every other node).  `a` = current buffer, list size
-// `sz`.  Returns the new size; *n_expand = number of new children holding > 1 keypoint.
-template <bool BIG>
-__device__ int oct_split_pass(OctLds& L, const OctBig& G, int a, int n, int sz, int np, int tid, int* n_expand) {
-    const int b = a ^ 1;
-    const int lane = tid & 63, wave = tid >> 6;
-    // classify + packed inclusive prefix over the key positions (4 keys per thread, blocked)
-    {
-        constexpr int PER = BIG ? OCT_NKB / 1024 : OCT_NK / 1024;  // keys per thread, blocked
-        unsigned long long loc[PER];
-        unsigned long long run = 0;
-        const int p0 = tid * PER;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int pos = p0 + k;
-            unsigned long long one = 0;
-            if (pos < n) {
-                const int node = KN(a, pos);
-                if (L.procidx[node] != 0xffff) {
-                    int mx, my;
-                    const int c = oct_child(KX(a, pos), KY(a, pos), L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
-                    one = 1ull << (16 * c);
-                }
-            }
-            run += one; loc[k] = run;
-        }
-        // exclusive scan of `run` across threads (fields cannot carry into each other: n <= 4096 < 2^16)
-        const unsigned long long incl = wave_incl_scan(run);
-        unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(L.sortkey);  // the rank sort is over by now
-        if (lane == 63) wsum64[wave] = incl;
-        __syncthreads();
-        unsigned long long base = 0;
-        for (int w = 0; w < wave; ++w) base += wsum64[w];
-        base += incl - run;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) if (p0 + k < n) KS(p0 + k) = base + loc[k];
-    }
-    __syncthreads();
-    // thread tid is parent t = tid (child counts) AND list node tid (survivor?): both ride in one packed scan
-    unsigned long long tot = 0, packed = 0;
-    if (tid < np) {
-        const int node = L.P[tid];
-        const int kb = L.nb[a][node], ke = L.ne[a][node];
-        tot = KS(ke - 1) - (kb ? KS(kb - 1) : 0ull);
-        int nch = 0, nex = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { const int cnt = (int)((tot >> (16 * c)) & 0xffff); nch += cnt ? 1 : 0; nex += cnt > 1 ? 1 : 0; }
-        packed = (unsigned long long)nch | ((unsigned long long)nex << 32);
-    }
-    const bool survivor = tid < sz && L.procidx[tid] == 0xffff;
-    if (survivor) packed |= 1ull << 16;
-    const unsigned long long incl = wave_incl_scan(packed);
-    unsigned long long* wsum64b = reinterpret_cast<unsigned long long*>(L.sortkey) + 16;
-    if (lane == 63) wsum64b[wave] = incl;
-    __syncthreads();
-    unsigned long long before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { const unsigned long long x = wsum64b[w]; if (w < wave) before += x; total += x; }
-    before += incl - packed;
-    const int M = (int)(total & 0xffff), nexp = (int)((total >> 32) & 0xffff);
-    const int cb = (int)(before & 0xffff), sr = (int)((before >> 16) & 0xffff);
-    if (survivor) {  // survivors keep their relative order behind the new children
-        const int np_ = M + sr;
-        L.newpos[tid] = (unsigned short)np_;
-        L.ulx[b][np_] = L.ulx[a][tid]; L.uly[b][np_] = L.uly[a][tid]; L.brx[b][np_] = L.brx[a][tid]; L.bry[b][np_] = L.bry[a][tid];
-        L.nb[b][np_] = L.nb[a][tid]; L.ne[b][np_] = L.ne[a][tid]; L.ncrt[b][np_] = 0xffff;
-        L.nfl[b][np_] = L.nfl[a][tid] & 1;  // no longer "fresh"
-    }
-    if (tid < np) {  // children: creation index ci -> list position M-1-ci
-        L.pc[tid] = tot; L.cbase[tid] = (unsigned short)cb;
-        const int node = L.P[tid];
-        int mx, my;
-        (void)oct_child(0, 0, L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
-        const int x0[4] = {L.ulx[a][node], mx, L.ulx[a][node], mx}, y0[4] = {L.uly[a][node], L.uly[a][node], my, my};
-        const int x1[4] = {mx, L.brx[a][node], mx, L.brx[a][node]}, y1[4] = {my, my, L.bry[a][node], L.bry[a][node]};
-        int ci = cb, off = L.nb[a][node];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int cnt = (int)((tot >> (16 * c)) & 0xffff);
-            if (cnt == 0) continue;
-            const int pos = M - 1 - ci;
-            L.ulx[b][pos] = (short)x0[c]; L.uly[b][pos] = (short)y0[c]; L.brx[b][pos] = (short)x1[c]; L.bry[b][pos] = (short)y1[c];
-            L.nb[b][pos] = (unsigned short)off; L.ne[b][pos] = (unsigned short)(off + cnt);
-            L.ncrt[b][pos] = (unsigned short)ci;
-            L.nfl[b][pos] = (unsigned char)((cnt == 1 ? 1 : 0) | 2);
-            off += cnt; ++ci;
-        }
-    }
-    __syncthreads();
-    // keys: stable 4-way partition inside every split node, others stay where they are
-    for (int pos = tid; pos < n; pos += 1024) {
-        const int node = KN(a, pos);
-        const int t = L.procidx[node];
-        int npos = pos, nnode;
-        const int x = KX(a, pos), y = KY(a, pos);
-        if (t != 0xffff) {
-            int mx, my;
-            const int c = oct_child(x, y, L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
-            const unsigned long long cnts = L.pc[t];
-            const int kb = L.nb[a][node];
-            const unsigned long long bef = kb ? KS(kb - 1) : 0ull;
-            const int rank = (int)(((KS(pos) - bef) >> (16 * c)) & 0xffff) - 1;
-            int off = 0, ne_before = 0;
-            for (int c2 = 0; c2 < c; ++c2) { const int cc = (int)((cnts >> (16 * c2)) & 0xffff); off += cc; ne_before += cc ? 1 : 0; }
-            npos = kb + off + rank;
-            nnode = M - 1 - (L.cbase[t] + ne_before);
-        } else {
-            nnode = L.newpos[node];
-        }
-        KX(b, npos) = (unsigned short)x; KY(b, npos) = (unsigned short)y; KR(b, npos) = KR(a, pos);
-        KN(b, npos) = (unsigned short)nnode;
-    }
-    __syncthreads();
-    *n_expand = nexp;
-    return M + (sz - np);
+// box of child c of box bx (n1..n4 of DivideNode)
+__device__ __forceinline__ unsigned long long oct_child_box(unsigned long long bx, int c, int midx, int midy) {
+    const int ulx = (int)(bx & 0xffff), uly = (int)((bx >> 16) & 0xffff), brx = (int)((bx >> 32) & 0xffff), bry = (int)(bx >> 48);
+    return oct_pack_box((c & 1) ? midx : ulx, (c & 2) ? midy : uly, (c & 1) ? brx : midx, (c & 2) ? bry : midy);
 }
 
-// A FULL pass (every node holding more than one keypoint is split, in list order): the specialisation of oct_split_pass
-// for processing order == list order.  A parent is addressed by its own list index, so no parent list and no
-// node -> parent map are built, and the three block scans (children, survivors, expandable children) ride in one packed
-// 64-bit scan: 6 barriers instead of 17, which is what a pass costs (every phase is an LDS dependency chain).
-template <bool BIG>
-__device__ int oct_split_full(OctLds& L, const OctBig& G, int a, int n, int sz, int tid, int* n_expand) {
-    const int b = a ^ 1;
-    const int lane = tid & 63, wave = tid >> 6;
-    // classify + packed inclusive prefix over the key positions (4 keys per thread, blocked)
-    {
-        constexpr int PER = BIG ? OCT_NKB / 1024 : OCT_NK / 1024;  // keys per thread, blocked
-        unsigned long long loc[PER];
-        unsigned long long run = 0;
-        const int p0 = tid * PER;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int pos = p0 + k;
-            unsigned long long one = 0;
-            if (pos < n) {
-                const int node = KN(a, pos);
-                if (!(L.nfl[a][node] & 1)) {
-                    int mx, my;
-                    const int c = oct_child(KX(a, pos), KY(a, pos), L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
-                    one = 1ull << (16 * c);
-                }
-            }
-            run += one; loc[k] = run;
-        }
-        const unsigned long long incl = wave_incl_scan(run);
-        unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(L.sortkey);  // free outside the careful pass
-        if (lane == 63) wsum64[wave] = incl;
-        __syncthreads();
-        unsigned long long base = 0;
-        for (int w = 0; w < wave; ++w) base += wsum64[w];
-        base += incl - run;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) if (p0 + k < n) KS(p0 + k) = base + loc[k];
-    }
-    __syncthreads();
-    // per node: child counts; {children, survivor, expandable children, parent} packed into one scan
-    unsigned long long tot = 0, packed = 0;
-    bool parent = false, survivor = false;
-    if (tid < sz) {
-        if (!(L.nfl[a][tid] & 1)) {
-            parent = true;
-            const int kb = L.nb[a][tid], ke = L.ne[a][tid];
-            tot = KS(ke - 1) - (kb ? KS(kb - 1) : 0ull);
-            int nch = 0, nex = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const int cnt = (int)((tot >> (16 * c)) & 0xffff); nch += cnt ? 1 : 0; nex += cnt > 1 ? 1 : 0; }
-            packed = (unsigned long long)nch | ((unsigned long long)nex << 32) | (1ull << 48);
-        } else {
-            survivor = true;
-            packed = 1ull << 16;
-        }
-    }
-    const unsigned long long incl = wave_incl_scan(packed);
-    unsigned long long* wsum64b = reinterpret_cast<unsigned long long*>(L.sortkey) + 16;
-    if (lane == 63) wsum64b[wave] = incl;
-    __syncthreads();
-    unsigned long long before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { const unsigned long long x = wsum64b[w]; if (w < wave) before += x; total += x; }
-    before += incl - packed;
-    const int M = (int)(total & 0xffff), nexp = (int)((total >> 32) & 0xffff), np = (int)(total >> 48);
-    const int cb = (int)(before & 0xffff), sr = (int)((before >> 16) & 0xffff);
-    if (survivor) {  // survivors keep their relative order behind the new children
-        const int np_ = M + sr;
-        L.newpos[tid] = (unsigned short)np_;
-        L.ulx[b][np_] = L.ulx[a][tid]; L.uly[b][np_] = L.uly[a][tid]; L.brx[b][np_] = L.brx[a][tid]; L.bry[b][np_] = L.bry[a][tid];
-        L.nb[b][np_] = L.nb[a][tid]; L.ne[b][np_] = L.ne[a][tid]; L.ncrt[b][np_] = 0xffff;
-        L.nfl[b][np_] = 1;  // one keypoint, no longer "fresh"
-    }
-    if (parent) {  // children: creation index ci -> list position M-1-ci
-        L.pc[tid] = tot; L.cbase[tid] = (unsigned short)cb;
-        int mx, my;
-        (void)oct_child(0, 0, L.ulx[a][tid], L.uly[a][tid], L.brx[a][tid], L.bry[a][tid], mx, my);
-        const int x0[4] = {L.ulx[a][tid], mx, L.ulx[a][tid], mx}, y0[4] = {L.uly[a][tid], L.uly[a][tid], my, my};
-        const int x1[4] = {mx, L.brx[a][tid], mx, L.brx[a][tid]}, y1[4] = {my, my, L.bry[a][tid], L.bry[a][tid]};
-        int ci = cb, off = L.nb[a][tid];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int cnt = (int)((tot >> (16 * c)) & 0xffff);
-            if (cnt == 0) continue;
-            const int pos = M - 1 - ci;
-            L.ulx[b][pos] = (short)x0[c]; L.uly[b][pos] = (short)y0[c]; L.brx[b][pos] = (short)x1[c]; L.bry[b][pos] = (short)y1[c];
-            L.nb[b][pos] = (unsigned short)off; L.ne[b][pos] = (unsigned short)(off + cnt);
-            L.ncrt[b][pos] = (unsigned short)ci;
-            L.nfl[b][pos] = (unsigned char)((cnt == 1 ? 1 : 0) | 2);
-            off += cnt; ++ci;
-        }
-    }
-    __syncthreads();
-    // keys: stable 4-way partition inside every split node, others stay where they are
-    for (int pos = tid; pos < n; pos += 1024) {
-        const int node = KN(a, pos);
-        int npos = pos, nnode;
-        const int x = KX(a, pos), y = KY(a, pos);
-        if (!(L.nfl[a][node] & 1)) {
-            int mx, my;
-            const int c = oct_child(x, y, L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
-            const unsigned long long cnts = L.pc[node];
-            const int kb = L.nb[a][node];
-            const unsigned long long bef = kb ? KS(kb - 1) : 0ull;
-            const int rank = (int)(((KS(pos) - bef) >> (16 * c)) & 0xffff) - 1;
-            int off = 0, ne_before = 0;
-            for (int c2 = 0; c2 < c; ++c2) { const int cc = (int)((cnts >> (16 * c2)) & 0xffff); off += cc; ne_before += cc ? 1 : 0; }
-            npos = kb + off + rank;
-            nnode = M - 1 - (L.cbase[node] + ne_before);
-        } else {
-            nnode = L.newpos[node];
-        }
-        KX(b, npos) = (unsigned short)x; KY(b, npos) = (unsigned short)y; KR(b, npos) = KR(a, pos);
-        KN(b, npos) = (unsigned short)nnode;
-    }
-    __syncthreads();
-    *n_expand = nexp;
-    return M + (sz - np);
+__device__ __forceinline__ int oct_nonzero_fields(unsigned long long t) {
+    return ((t & 0xffffull) ? 1 : 0) + ((t & 0xffff0000ull) ? 1 : 0) + ((t & 0xffff00000000ull) ? 1 : 0) + ((t >> 48) ? 1 : 0);
 }
 
-// status: 0 ok, 1 = outside the device limits (host falls back), 2 = more candidates than the LDS layout holds but within
-// the reach of the BIG pass (k_octree<true>, launched behind this one when the stream has needed it before; it only
-// touches the blocks flagged 2).
+// One key's contribution to the child histogram of node nn: pc[nn] += 1 << 16*c for the lanes with `act`.  While the
+// list is short, the 64 keys of a wave (neighbours in cell order) mostly share their node: then four ballots and ONE
+// atomic replace 64 same-address atomics, which LDS would serialise.
+__device__ __forceinline__ void oct_accum(unsigned long long* pc, int nn, int c, bool act) {
+    if (act) {
+        const int lead = __builtin_amdgcn_readfirstlane(nn);
+        if (__ballot(nn != lead) == 0ull) {
+            const unsigned long long e = __ballot(1);
+            const unsigned long long add = (unsigned long long)__popcll(__ballot(c == 0)) | ((unsigned long long)__popcll(__ballot(c == 1)) << 16) |
+                                           ((unsigned long long)__popcll(__ballot(c == 2)) << 32) | ((unsigned long long)__popcll(__ballot(c == 3)) << 48);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)e) - 1) atomicAdd(&pc[lead], add);
+        } else {
+            atomicAdd(&pc[nn], 1ull << (16 * c));
+        }
+    }
+}
+
+// status: 0 ok, 1 = outside the device limits (host falls back).
 // The candidates are read straight from the per-cell slots k_fast_cells filled (cell-major, row-major inside a cell: the
 // order the reference hands them to DistributeOctTree), so no separate compaction kernel sits between them.
-template <bool BIG>
 __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ Lv_all, const int* __restrict__ cell_cnt,
                                                  const uint32_t* __restrict__ cell_items, SelKp* __restrict__ sel,
                                                  int* __restrict__ sel_cnt, int* __restrict__ status, int max_levels,
-                                                 unsigned char* __restrict__ big_ws) {
+                                                 int max_keys) {
     extern __shared__ __attribute__((aligned(16))) unsigned char oct_raw[];
     OctLds& L = *reinterpret_cast<OctLds*>(oct_raw);
     const int blk = blockIdx.x, tid = threadIdx.x;
-    if (BIG && status[blk] != 2) return;
-    OctBig G{nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (BIG) G = oct_big_slice(big_ws, blk);
-    constexpr int NKEYS = BIG ? OCT_NKB : OCT_NK;
+    const int lane = tid & 63, wave = tid >> 6;
     MORB_PHASE(g_ph_oct, 0);
     const LevelInfo Lv = Lv_all[blk];
     const int N = Lv.quota;
     const int ncell = Lv.w ? Lv.n_cols * Lv.n_rows : 0;
-    if (ncell > 2 * OCT_NK) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; } return; }
+    int* cell_off = reinterpret_cast<int*>(L.kn);  // ncell + 1 ints of scratch (kn is first written behind the load's barrier)
+    if (ncell + 1 > OCT_NK / 2) /* ints that fit kn */ { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; } return; }
     // exclusive scan of the per-cell counts (cells in row-major order) -> dense position of every candidate
-    int* cell_off = reinterpret_cast<int*>(L.S);  // ncell + 1 ints of scratch
     int n = 0;
     {
         const int per = (ncell + 1023) / 1024;
@@ -769,192 +543,229 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
         const int ex = oct_block_excl_scan(mine, tid, L.wsum, &n);
         int run = ex;
         for (int c = c0; c < c1; ++c) { cell_off[c] = run; run += min(cell_cnt[Lv.cell_base + c], Lv.slot_cap); }
+        if (tid == 0) cell_off[ncell] = n;
         __syncthreads();
     }
     if (n == 0) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 0; } return; }
     const int width = Lv.w - 2 * MIN_BORDER, height = Lv.h - 2 * MIN_BORDER;
     const int nIni = max(1, (int)roundf((float)width / (float)height));
-    if (n > NKEYS || N + 4 > OCT_NL || nIni > 4 || width >= 32768 || height >= 32768) {
-        const bool retry_big = !BIG && n <= OCT_NKB && N + 4 <= OCT_NL && nIni <= 4 && width < 32768 && height < 32768;
-        if (tid == 0) { sel_cnt[blk] = 0; status[blk] = retry_big ? 2 : 1; }
+    if (n > max_keys || N + 4 > OCT_NL || nIni > 4 || width >= 32768 || height >= 32768) {
+        if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; }
         return;
     }
     MORB_PHASE(g_ph_oct, 1);
     const float hX = (float)width / (float)nIni;
-    // dense candidate list into buffer 1: thread per candidate, its cell found by bisection of the offsets (all the
-    // global loads of the block are independent and in flight together), then dealt to the roots into buffer 0
-    {
-        if (tid == 0) cell_off[ncell] = n;
-        __syncthreads();
-        for (int p = tid; p < n; p += 1024) {
-            int lo = 0, hi = ncell;  // last c with cell_off[c] <= p (empty cells share an offset: take the last one)
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (cell_off[mid] <= p) lo = mid; else hi = mid;
-            }
-            const uint32_t v = cell_items[Lv.slot_base + (size_t)lo * Lv.slot_cap + (p - cell_off[lo])];
-            // (one root strip -- every level of a 4:3 image: the candidates ARE the root's keys, in this order)
-            const int buf = nIni == 1 ? 0 : 1;
-            KX(buf, p) = (unsigned short)(v & 0xfff); KY(buf, p) = (unsigned short)((v >> 12) & 0xfff);
-            KR(buf, p) = (unsigned char)(v >> 24);
-            if (nIni == 1) KN(0, p) = 0;
+    // candidate p: its cell found by bisection of the offsets (all the global loads of the block are independent and in
+    // flight together); the candidate word IS the key
+    unsigned long long rootcnt = 0;  // per-thread packed count of the keys per root strip
+    for (int p = tid; p < n; p += 1024) {
+        int lo = 0, hi = ncell;  // last c with cell_off[c] <= p (empty cells share an offset: take the last one)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cell_off[mid] <= p) lo = mid; else hi = mid;
         }
-        if (nIni == 1 && tid == 0) {
-            L.ulx[0][0] = 0; L.uly[0][0] = 0; L.brx[0][0] = (short)(int)(hX * 1.0f); L.bry[0][0] = (short)height;
-            L.nb[0][0] = 0; L.ne[0][0] = (unsigned short)n; L.ncrt[0][0] = 0xffff; L.nfl[0][0] = (unsigned char)(n == 1 ? 1 : 0);
-            L.v[0] = 1;
+        const uint32_t v = cell_items[Lv.slot_base + (size_t)lo * Lv.slot_cap + (p - cell_off[lo])];
+        L.key[p] = v;
+        if (nIni > 1) {  // roots (:544-585): vertical strips, keypoints dealt by (int)(x / hX)
+            const int r = min(max((int)((float)(v & 0xfff) / hX), 0), nIni - 1);
+            rootcnt += 1ull << (16 * r);
         }
-        __syncthreads();
     }
+    {
+        const unsigned long long incl = wave_incl_scan(nIni > 1 ? rootcnt : 0ull);
+        if (lane == 63) L.wsum64[0][wave] = incl;
+    }
+    __syncthreads();   // every key is in LDS, nobody reads cell_off any more (kn may be written)
     MORB_PHASE(g_ph_oct, 2);
-    // ---- roots (:544-585): vertical strips, keypoints dealt by (int)(x / hX), empty roots dropped, order = strip order
-    if (nIni > 1) {
-        constexpr int PER = NKEYS / 1024;  // keys per thread, blocked
-        unsigned long long loc[PER], run = 0;
-        int rx[PER], ry[PER], rr[PER];
-        const int p0 = tid * PER;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int pos = p0 + k;
-            unsigned long long one = 0;
-            rx[k] = ry[k] = rr[k] = 0;
-            if (pos < n) {
-                rx[k] = KX(1, pos); ry[k] = KY(1, pos);
-                int r = (int)((float)rx[k] / hX);
-                r = min(max(r, 0), nIni - 1);
-                rr[k] = r; one = 1ull << (16 * r);
-            }
-            run += one; loc[k] = run;
-        }
-        const int lane = tid & 63, wave = tid >> 6;
-        const unsigned long long incl = wave_incl_scan(run);
-        unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(L.pc);
-        if (lane == 63) wsum64[wave] = incl;
-        __syncthreads();
-        unsigned long long base = 0, total = 0;
-        for (int w = 0; w < 16; ++w) { if (w < wave) base += wsum64[w]; total += wsum64[w]; }
-        base += incl - run;
-        // root r -> list position (non-empty roots only) and key offset
-        int rpos[4], roff[4], np_ = 0, off = 0;
+    // ---- roots: empty strips dropped, list order = strip order
+    int rpos[4] = {0, 0, 0, 0};
+    int sz = 0;
+    {
+        unsigned long long total = 0;
+        if (nIni > 1) { for (int w = 0; w < 16; ++w) total += L.wsum64[0][w]; }
+        else total = (unsigned long long)n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = (int)((total >> (16 * r)) & 0xffff);
-            rpos[r] = np_; roff[r] = off;
-            if (c) ++np_;
-            off += c;
-        }
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int pos = p0 + k;
-            if (pos < n) {
-                const int r = rr[k];
-                const int rank = (int)(((base + loc[k]) >> (16 * r)) & 0xffff) - 1;
-                const int np2 = roff[r] + rank;
-                KX(0, np2) = (unsigned short)rx[k]; KY(0, np2) = (unsigned short)ry[k];
-                KR(0, np2) = KR(1, pos); KN(0, np2) = (unsigned short)rpos[r];
+            rpos[r] = sz;
+            if (r < nIni && c) {
+                if (tid == r) {
+                    L.box[0][sz] = oct_pack_box((int)(hX * (float)r), 0, (int)(hX * (float)(r + 1)), height);
+                    L.cnt[0][sz] = (unsigned short)c; L.ncrt[0][sz] = 0xffff; L.pc[0][sz] = 0;
+                }
+                ++sz;
             }
         }
-        if (tid < nIni) {
-            const int c = (int)((total >> (16 * tid)) & 0xffff);
-            if (c) {
-                const int i = rpos[tid];
-                L.ulx[0][i] = (short)(int)(hX * (float)tid); L.uly[0][i] = 0;
-                L.brx[0][i] = (short)(int)(hX * (float)(tid + 1)); L.bry[0][i] = (short)height;
-                L.nb[0][i] = (unsigned short)roff[tid]; L.ne[0][i] = (unsigned short)(roff[tid] + c);
-                L.ncrt[0][i] = 0xffff; L.nfl[0][i] = (unsigned char)(c == 1 ? 1 : 0);
-            }
-        }
-        if (tid == 0) L.v[0] = np_;
-        __syncthreads();
     }
+    __syncthreads();
+    // every key: its root, and its child inside the root's box into the root's histogram
+    for (int p0 = 0; p0 < n; p0 += 1024) {
+        const int p = p0 + tid;
+        int nn = 0, c = 0;
+        bool act = false;
+        if (p < n) {
+            const uint32_t v = L.key[p];
+            const int x = (int)(v & 0xfff), y = (int)((v >> 12) & 0xfff);
+            int r = 0;
+            if (nIni > 1) r = min(max((int)((float)x / hX), 0), nIni - 1);
+            nn = rpos[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) if (r == q) nn = rpos[q];
+            L.kn[p] = (unsigned short)nn;
+            if (L.cnt[0][nn] > 1) { int mx, my; c = oct_child(x, y, L.box[0][nn], mx, my); act = true; }
+        }
+        oct_accum(L.pc[0], nn, c, act);
+    }
+    __syncthreads();
     MORB_PHASE(g_ph_oct, 3);
-    int a = 0, sz = L.v[0];
+    int a = 0;
     int ph_i = 4;
     // ---- main loop (:596-739)
-    bool finish = false;
+    bool careful = false, finish = false;
     while (!finish) {
+        const int b = a ^ 1;
         const int prev_size = sz;
-        // parents = every node that still holds more than one keypoint, in list order
-        int n_expand = 0;
-        sz = oct_split_full<BIG>(L, G, a, n, sz, tid, &n_expand);
-        a ^= 1;
-        MORB_PHASE(g_ph_oct, ph_i); ph_i = min(ph_i + 1, 40);
-        if (sz >= N || sz == prev_size) { finish = true; break; }
-        if (sz + n_expand * 3 > N) {
-            // careful passes: largest nodes first, stop the moment N is reached
-            while (!finish) {
-                const int ps = sz;
-                // candidates: children of the previous pass with > 1 keypoint
-                int isc = 0;
-                unsigned int key = 0;
-                if (tid < sz && (L.nfl[a][tid] & 2) && !(L.nfl[a][tid] & 1)) {
-                    isc = 1;
-                    key = ((unsigned)(L.ne[a][tid] - L.nb[a][tid]) << 16) | L.ncrt[a][tid];  // (size, creation order)
-                }
-                int nc = 0;
-                const int ci = oct_block_excl_scan(isc, tid, L.wsum, &nc);
-                if (isc) { L.sortkey[ci] = key; L.newpos[ci] = (unsigned short)tid; }  // newpos reused: candidate -> node
-                unsigned int* occ = reinterpret_cast<unsigned int*>(L.S);  // scratch: child occupancy per candidate
-                L.procidx[tid] = 0xffff; occ[tid] = 0;
-                if (tid == 0) L.v[1] = nc;  // default: every candidate is processed
-                __syncthreads();
-                if (nc == 0) { finish = true; break; }
-                // descending rank (all keys distinct: creation order is unique) = processing order
-                if (tid < nc) {
-                    const unsigned int mk = L.sortkey[tid];
-                    int myrank = 0;
-                    for (int j = 0; j < nc; ++j) myrank += L.sortkey[j] > mk ? 1 : 0;
-                    const unsigned short node = L.newpos[tid];
-                    L.P[myrank] = node;
-                    L.procidx[node] = (unsigned short)myrank;
-                }
-                __syncthreads();
-                // growth of every candidate if it were split: #non-empty children - 1  (needs the child occupancy: classify
-                // the keys of ALL candidates, then keep only the prefix that is actually processed)
-                for (int pos = tid; pos < n; pos += 1024) {
-                    const int node = KN(a, pos);
-                    const int t = L.procidx[node];
-                    if (t != 0xffff) {
-                        int mx, my;
-                        const int c = oct_child(KX(a, pos), KY(a, pos), L.ulx[a][node], L.uly[a][node], L.brx[a][node], L.bry[a][node], mx, my);
-                        atomicOr(&occ[t], 1u << c);
-                    }
-                }
-                __syncthreads();
-                int growth = 0;
-                if (tid < nc) growth = __popc(occ[tid]) - 1;
-                int gtot = 0;
-                const int gex = oct_block_excl_scan(growth, tid, L.wsum, &gtot);
-                // first t (processing order) after which the list has reached N: the condition holds for exactly one t
-                // when the running size crosses N (sizes never decrease), for none otherwise
-                if (tid < nc && ps + gex + growth >= N && ps + gex < N) L.v[1] = tid + 1;
-                __syncthreads();
-                const int np2 = L.v[1];
-                if (tid >= np2 && tid < nc) L.procidx[L.P[tid]] = 0xffff;  // candidates behind the stop are not split
-                __syncthreads();
-                int ne2 = 0;
-                sz = oct_split_pass<BIG>(L, G, a, n, sz, np2, tid, &ne2);
-                a ^= 1;
-                MORB_PHASE(g_ph_oct, ph_i); ph_i = min(ph_i + 1, 40);
-                if (sz >= N || sz == ps) finish = true;
+        int np = 0;  // parents of this pass
+        if (careful) {
+            // candidates: children of the previous pass with > 1 keypoint, sorted by (size, creation order), split from the
+            // back until the list has reached N
+            int isc = 0;
+            unsigned int key = 0;
+            if (tid < sz && L.ncrt[a][tid] != 0xffff && L.cnt[a][tid] > 1) {
+                isc = 1;
+                key = ((unsigned)L.cnt[a][tid] << 16) | L.ncrt[a][tid];  // (size, creation order)
+            }
+            int nc = 0;
+            const int ci = oct_block_excl_scan(isc, tid, L.wsum, &nc);
+            if (isc) { L.sortkey[ci] = key; L.cnode[ci] = (unsigned short)tid; }
+            L.procidx[tid] = 0xffff;
+            if (tid == 0) L.v[1] = nc;  // default: every candidate is processed
+            __syncthreads();
+            if (nc == 0) break;
+            // descending rank (all keys distinct: creation order is unique) = processing order
+            if (tid < nc) {
+                const unsigned int mk = L.sortkey[tid];
+                int myrank = 0;
+                for (int j = 0; j < nc; ++j) myrank += L.sortkey[j] > mk ? 1 : 0;
+                const unsigned short node = L.cnode[tid];
+                L.P[myrank] = node;
+                L.procidx[node] = (unsigned short)myrank;
+            }
+            __syncthreads();
+            // growth of every candidate if it were split: #non-empty children - 1 (its histogram is there already)
+            int growth = 0;
+            if (tid < nc) growth = oct_nonzero_fields(L.pc[a][L.P[tid]]) - 1;
+            int gtot = 0;
+            const int gex = oct_block_excl_scan(growth, tid, L.wsum, &gtot);
+            // first t (processing order) after which the list has reached N: the condition holds for exactly one t
+            // when the running size crosses N (sizes never decrease), for none otherwise
+            if (tid < nc && prev_size + gex + growth >= N && prev_size + gex < N) L.v[1] = tid + 1;
+            __syncthreads();
+            np = L.v[1];
+            if (tid >= np && tid < nc) L.procidx[L.P[tid]] = 0xffff;  // candidates behind the stop are not split
+            __syncthreads();
+        }
+        // ---- node phase: thread t is parent t (careful: in processing order; full pass: its own list index) AND list node
+        // tid (survivor?): children, survivors, expandable children and parents ride in one packed scan
+        unsigned long long tot = 0, packed = 0;
+        int pnode = -1;
+        if (careful) { if (tid < np) pnode = L.P[tid]; }
+        else if (tid < sz && L.cnt[a][tid] > 1) pnode = tid;
+        if (pnode >= 0) {
+            tot = L.pc[a][pnode];
+            int nch = 0, nex = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int cc = (int)((tot >> (16 * c)) & 0xffff); nch += cc ? 1 : 0; nex += cc > 1 ? 1 : 0; }
+            packed = (unsigned long long)nch | ((unsigned long long)nex << 32) | (1ull << 48);
+        }
+        const bool survivor = tid < sz && (careful ? L.procidx[tid] == 0xffff : L.cnt[a][tid] <= 1);
+        if (survivor) packed |= 1ull << 16;
+        const unsigned long long incl = wave_incl_scan(packed);
+        unsigned long long* ws = L.wsum64[1];
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        unsigned long long before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const unsigned long long x = ws[w]; if (w < wave) before += x; total += x; }
+        before += incl - packed;
+        const int M = (int)(total & 0xffff), nexp = (int)((total >> 32) & 0xffff);
+        np = (int)(total >> 48);
+        const int cb = (int)(before & 0xffff), sr = (int)((before >> 16) & 0xffff);
+        if (survivor) {  // survivors keep their relative order behind the new children
+            const int np_ = M + sr;
+            L.newid[tid] = (unsigned short)np_;
+            L.box[b][np_] = L.box[a][tid]; L.cnt[b][np_] = L.cnt[a][tid]; L.pc[b][np_] = L.pc[a][tid];
+            L.ncrt[b][np_] = 0xffff;  // no longer "fresh"
+        }
+        if (pnode >= 0) {  // children: creation index ci -> list position M-1-ci
+            L.newid[pnode] = (unsigned short)cb;
+            const unsigned long long bx = L.box[a][pnode];
+            int mx, my;
+            (void)oct_child(0, 0, bx, mx, my);
+            int ci = cb;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int cc = (int)((tot >> (16 * c)) & 0xffff);
+                if (cc == 0) continue;
+                const int pos = M - 1 - ci;
+                L.box[b][pos] = oct_child_box(bx, c, mx, my);
+                L.cnt[b][pos] = (unsigned short)cc; L.ncrt[b][pos] = (unsigned short)ci; L.pc[b][pos] = 0;
+                ++ci;
             }
         }
+        __syncthreads();
+        // ---- key phase: new node of every key; its child inside the new node goes into that node's histogram
+        for (int p0 = 0; p0 < n; p0 += 1024) {
+            const int p = p0 + tid;
+            int nn = 0, c2 = 0;
+            bool act = false;
+            if (p < n) {
+                const int node = L.kn[p];
+                const bool split = careful ? L.procidx[node] != 0xffff : L.cnt[a][node] > 1;
+                if (split) {
+                    const uint32_t v = L.key[p];
+                    const int x = (int)(v & 0xfff), y = (int)((v >> 12) & 0xfff);
+                    const unsigned long long bx = L.box[a][node];
+                    int mx, my;
+                    const int c = oct_child(x, y, bx, mx, my);
+                    const unsigned long long cnts = L.pc[a][node];
+                    const unsigned long long below = c ? (cnts & (~0ull >> (64 - 16 * c))) : 0ull;
+                    nn = M - 1 - ((int)L.newid[node] + oct_nonzero_fields(below));
+                    if (((cnts >> (16 * c)) & 0xffff) > 1) {
+                        int mx2, my2;
+                        c2 = oct_child(x, y, oct_child_box(bx, c, mx, my), mx2, my2);
+                        act = true;
+                    }
+                } else {
+                    nn = L.newid[node];
+                }
+                L.kn[p] = (unsigned short)nn;
+            }
+            oct_accum(L.pc[b], nn, c2, act);
+        }
+        __syncthreads();
+        sz = M + (sz - np);
+        a = b;
+        MORB_PHASE(g_ph_oct, ph_i); ph_i = min(ph_i + 1, 40);
+        if (sz >= N || sz == prev_size) finish = true;
+        else if (!careful && sz + nexp * 3 > N) careful = true;   // largest nodes first, stop the moment N is reached
     }
     // (an unguarded first pass over four roots can leave up to 16 nodes: more than quota + 4 slots only for a quota below 12
     // on a panorama-shaped level -- the host pass takes those)
     if (sz > N + 4) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; } return; }
     // ---- best keypoint per node, first maximum wins (:742-763); output in list order
+    if (tid < sz) L.best[tid] = 0;
+    __syncthreads();
+    for (int p = tid; p < n; p += 1024)
+        atomicMax(&L.best[L.kn[p]], ((L.key[p] >> 24) << 14) | (unsigned)(OCT_NK - 1 - p));
+    __syncthreads();
     if (tid < sz) {
-        const int kb = L.nb[a][tid], ke = L.ne[a][tid];
-        int best = kb, bresp = KR(a, kb);
-        for (int k = kb + 1; k < ke; ++k) {
-            const int r = KR(a, k);
-            if (r > bresp) { bresp = r; best = k; }
-        }
+        const unsigned int bb = L.best[tid];
+        const uint32_t v = L.key[OCT_NK - 1 - (int)(bb & (OCT_NK - 1))];
         SelKp K;
-        K.x = (int)KX(a, best) + MIN_BORDER; K.y = (int)KY(a, best) + MIN_BORDER;
+        K.x = (int)(v & 0xfff) + MIN_BORDER; K.y = (int)((v >> 12) & 0xfff) + MIN_BORDER;
         K.camlevel = ((blk / max_levels) << 8) | (blk % max_levels);
-        K.resp_out = (int)(((unsigned)bresp << 24) | (unsigned)tid);
+        K.resp_out = (int)((v & 0xff000000u) | (unsigned)tid);
         sel[Lv.sel_base + tid] = K;
     }
     if (tid == 0) { sel_cnt[blk] = sz; status[blk] = 0; }
@@ -963,12 +774,6 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
     if (tid == 0 && blk == 0) g_ph_oct[61] = (unsigned long long)ph_i;
 #endif
 }
-
-#undef KX
-#undef KY
-#undef KN
-#undef KR
-#undef KS
 
 // ------------------------------------------------------------------------------------------------ K5-K7
 __device__ __forceinline__ int reflect101(int p, int n) {
@@ -1489,9 +1294,8 @@ struct orbx_extractor {
     DevBuf<SelKp> d_sel, d_sel_oct;
     DevBuf<uint32_t> d_cand_dev;
     DevBuf<int> d_level_cnt_dev, d_sel_cnt, d_oct_status, d_n_out;
-    DevBuf<unsigned char> d_oct_big;  // HBM key storage of the BIG quadtree pass (allocated when first needed)
-    bool need_big = false;            // a level exceeded the LDS layout once: the BIG pass is launched from then on
-    int last_path = 0;                // inspection: 0 device quadtree, 1 device quadtree incl. the BIG pass, 2 host quadtree
+    int oct_max_keys = OCT_NK;        // candidates per (camera, level) the device quadtree takes (MORB_OCT_MAX_KEYS lowers it: tests of the fallback)
+    int last_path = 0;                // inspection: 0 device quadtree, 2 host quadtree
     DevBuf<unsigned short> d_slot_blk;
     int total_sel_slots = 0;
     int* h_oct = nullptr;            // pinned, mapped: [0..n_cams) n_out, [n_cams] status
@@ -1731,8 +1535,8 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     for (int i = 0; i < 2; ++i) ORBX_TRY_HIP(hipEventCreateWithFlags(&ex->ev_done[i], hipEventDisableTiming | hipEventReleaseToSystem));
     { const char* e = getenv("MORB_HOST_OCTREE"); ex->device_octree = !(e && atoi(e) != 0); }
     { const char* e = getenv("MORB_CHAIN_GRAPH"); ex->use_graph = !(e && atoi(e) == 0); }
-    ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
-    ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
+    ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
+    if (const char* e = getenv("MORB_OCT_MAX_KEYS")) ex->oct_max_keys = std::min(OCT_NK, std::max(1, atoi(e)));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
     {
@@ -1754,7 +1558,7 @@ void orbx_destroy(orbx_extractor* ex) {
     ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release();
     ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release(); ex->d_sel_oct.release();
     ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release();
-    ex->d_n_out.release(); ex->d_slot_blk.release(); ex->d_oct_big.release();
+    ex->d_n_out.release(); ex->d_slot_blk.release();
     for (auto& b : ex->d_kps) b.release();
     for (auto& b : ex->d_desc) b.release();
     ex->d_out_kps.release(); ex->d_out_desc.release();
@@ -1985,14 +1789,9 @@ static int launch_tree_describe(orbx_extractor* ex, hipStream_t st, unsigned slo
     mir.kps = nullptr; mir.desc = nullptr;
     if (ex->mirror_kps) { mir.kps = ex->mirror_kps; mir.desc = ex->mirror_desc; }  // cap_total covers every camera's capacity
     for (int c = 0; c < 64; ++c) mir.base[c] = 0;
-    hipLaunchKernelGGL(k_octree<false>, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
+    hipLaunchKernelGGL(k_octree, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
                        (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
-                       ex->d_oct_status.p, ML, (unsigned char*)nullptr);
-    if (ex->need_big) {  // this stream has produced levels beyond the LDS layout before: the BIG pass follows for those
-        hipLaunchKernelGGL(k_octree<true>, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
-                           (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
-                           ex->d_oct_status.p, ML, ex->d_oct_big.p);
-    }
+                       ex->d_oct_status.p, ML, ex->oct_max_keys);
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[4], st));
     hipLaunchKernelGGL(k_describe, dim3((ex->total_sel_slots + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
                        (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel_oct.p, ex->total_sel_slots,
@@ -2114,10 +1913,6 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         if (allow_async) return ORB_OK;
         MORB_HIP(hipStreamSynchronize(st));
         if (ex->h_oct[slot * (ex->n_cams + 1) + ex->n_cams] == 0) return finish_device_path(ex);
-        if ((ex->h_oct[slot * (ex->n_cams + 1) + ex->n_cams] & 2) && !ex->need_big &&
-            ex->d_oct_big.reserve((size_t)ex->levels.size() * OCT_BIG_BYTES) == ORB_OK) {
-            ex->need_big = true; ++ex->geom_epoch;
-        }
         ex->inflight = 0;
         std::fill(ex->n_out.begin(), ex->n_out.end(), 0);  // a level exceeded the device limits: redo the selection on the host
         hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ML), dim3(1024), 0, st, (const LevelInfo*)ex->d_levels.p,
@@ -2227,7 +2022,7 @@ static int finish_device_path(orbx_extractor* ex) {
     const int* h_oct = ex->h_oct + oldest * (ex->n_cams + 1);
     --ex->inflight;
     if (h_oct[ex->n_cams] == 0) {
-        ex->last_path = ex->need_big ? 1 : 0;
+        ex->last_path = 0;
         for (int c = 0; c < ex->n_cams; ++c) {
             ex->n_out[c] = h_oct[c];
             if (ex->n_out[c] > ex->out_cap_active[c]) { morb::set_error("a camera produced more keypoints than its output capacity"); return ORB_E_CAPACITY; }
@@ -2242,14 +2037,6 @@ static int finish_device_path(orbx_extractor* ex) {
             ex->stage_us[5] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - ex->t_begin_async).count();
         }
         return ORB_OK;
-    }
-    // A level held more candidates than the LDS layout but fits the BIG pass: from the next run on that pass is launched
-    // behind the normal one (this run still takes the host path).
-    if ((h_oct[ex->n_cams] & 2) && !ex->need_big) {
-        if (ex->d_oct_big.reserve((size_t)ex->levels.size() * OCT_BIG_BYTES) == ORB_OK) {
-            ex->need_big = true;
-            ++ex->geom_epoch;  // the captured launch chains get the extra kernel
-        }
     }
     // a level exceeded the device limits.  With a newer run in flight the resident images are already being replaced:
     // the caller has to upload this run's images again and run synchronously (2).  Otherwise the synchronous

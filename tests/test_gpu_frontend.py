@@ -123,8 +123,10 @@ def test_six_camera_rig_takes_the_multi_kernel_frame_path(depth):
 
 
 def test_overlap_survives_the_host_quadtree_fallback():
-    """Noise frames put more than 4096 candidates on level 0: the device quadtree reports 'outside my limits' and the step
-    is redone on the host path -- with the next step's extraction already in flight its images have to be uploaded again."""
+    """Noise frames put more candidates on level 0 than the device quadtree takes (its limit lowered to 4096 here; 16384 in
+    the product): the kernel reports 'outside my limits' and the step is redone on the host path -- with the next step's
+    extraction already in flight its images have to be uploaded again."""
+    import os
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import pipeline
     from oracle_pipeline import OracleFrontEnd, assert_same_step
@@ -136,7 +138,11 @@ def test_overlap_survives_the_host_quadtree_fallback():
         return (r % 256).astype(np.uint8).reshape(h, w)
 
     frames = [[noise(c, t) for c in range(2)] for t in range(2)] + [[synth.image(c, t, w, h) for c in range(2)] for t in range(2, 5)]
-    fe = pipeline.FrontEnd(params, w, h)
+    os.environ["MORB_OCT_MAX_KEYS"] = "4096"
+    try:
+        fe = pipeline.FrontEnd(params, w, h)
+    finally:
+        os.environ.pop("MORB_OCT_MAX_KEYS")
     ofe = OracleFrontEnd(params, w, h)
     for t in range(5):
         got = fe.step(frames[t], next_images=frames[t + 1] if t + 1 < 5 else None)
