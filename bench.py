@@ -338,7 +338,13 @@ def main(argv=None):
         return plan_only(a, rank, world)
     dist = None; ctl = None
     use_dist = world > 1 or os.environ.get("MORB_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
+    json_out = sys.stdout
     if use_dist:
+        # RCCL prints a version banner on the process' stdout when its first communicator comes up: keep fd 1 for the ONE
+        # JSON line, send everything else any library writes there to stderr
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -633,7 +639,7 @@ def main(argv=None):
                                          % (n1, len(cpu_cams), W, H, os.cpu_count()),
                                "value_one_thread_per_camera": round(vn, 3), "cores_one_thread_per_camera": len(cpu_cams)}
     if rank == 0:
-        print(json.dumps(out)); sys.stdout.flush()
+        json_out.write(json.dumps(out) + "\n"); json_out.flush()
     if dist is not None:
         dist.barrier(group=ctl)       # the other ranks wait here (host sockets) while rank 0 runs the rooflines and the CPU baseline
     fe.close()

@@ -23,6 +23,12 @@ typedef struct orbf_image {
     const uint8_t* data; /* 8-bit grey; host pointer, or device pointer when on_device != 0; NULL = empty image */
     int32_t width, height, stride;
     int32_t on_device;
+    /* Identity of the CONTENT, supplied by the caller: the frame's timestamp or sequence number (anything that differs between
+     * two frames that ever share a buffer); 0 = none.  orbf_prefetch serves an extraction that ran ahead only to a step whose
+     * images carry the same (pointer, size, stride, generation): with generations a recycled buffer -- host or device --
+     * can never be handed a stale extraction.  Without one (0) a host image falls back to a sampled content fingerprint (a
+     * heuristic, see orbf_prefetch) and a device image is identified by its pointer alone. */
+    uint64_t generation;
 } orbf_image;
 
 enum { ORBF_SKIP_CROSS = 1 }; /* flags of orbf_step */
@@ -69,11 +75,14 @@ int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientati
  * occupies a handful of the 256 CUs; with two steps announced two extraction chains run side by side on two extractor
  * instances), and the following steps find their features ready or in flight.  Those steps must then be called with
  * exactly the announced images, in order (same pointers, sizes, strides); otherwise everything in flight is dropped and
- * the images are extracted again.  Host images are additionally fingerprinted (32 probes of 64 bytes each) when their
- * upload is enqueued and when the step arrives: a buffer that was refilled in between is noticed and extracted again
- * instead of handing out the stale extraction.  Host images are read while the intervening steps run; device images must stay
- * unchanged until the step that consumes them has returned.  Results are bit-identical with and without announcements;
- * rigs of more than 4 cameras ignore them. */
+ * the images are extracted again.  The exact contract: a buffer must stay unchanged from its announcement until the step that
+ * consumes it has returned (host images are read by the copy engine while the intervening steps run).  A caller that recycles
+ * buffers says so with orbf_image::generation (frame timestamp / sequence number): it is part of an image's identity, so a
+ * refilled buffer is a different image and is extracted again.  For HOST images without a generation a sampled content
+ * fingerprint (32 probes of 64 bytes each, taken when the upload is enqueued and when the step arrives) catches most refills --
+ * a heuristic: a refill that leaves those 2 KB unchanged goes unnoticed, and so does any refill of a DEVICE image without a
+ * generation (it is identified by its pointer alone).  Results are bit-identical with and without announcements; rigs of
+ * more than 4 cameras ignore them. */
 int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images);
 /* Multi-GPU exchange: the HBM block holding the LAST step's merged descriptors -- cap_rows rows of 32 bytes in global
  * (camera-major, packed) order followed by a 256-byte trailer of int32 per-camera counts -- ready to be the send buffer

@@ -42,7 +42,7 @@ class CamFeatures(C.Structure):  # orbm_cam_features
 
 class FImage(C.Structure):  # orbf_image
     _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
-                ("on_device", C.c_int32)]
+                ("on_device", C.c_int32), ("generation", C.c_uint64)]
 
 
 class FResult(C.Structure):  # orbf_result

@@ -1294,6 +1294,7 @@ struct orbx_extractor {
     DevBuf<SelKp> d_sel, d_sel_oct;
     DevBuf<uint32_t> d_cand_dev;
     DevBuf<int> d_level_cnt_dev, d_sel_cnt, d_oct_status, d_n_out;
+    bool pinned_ingest = true;        // page-locked host images are read by k_ingest directly (MORB_PINNED_INGEST=0: hipMemcpy2DAsync)
     int oct_max_keys = OCT_NK;        // candidates per (camera, level) the device quadtree takes (MORB_OCT_MAX_KEYS lowers it: tests of the fallback)
     int last_path = 0;                // inspection: 0 device quadtree, 2 host quadtree
     DevBuf<unsigned short> d_slot_blk;
@@ -1536,6 +1537,7 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     { const char* e = getenv("MORB_HOST_OCTREE"); ex->device_octree = !(e && atoi(e) != 0); }
     { const char* e = getenv("MORB_CHAIN_GRAPH"); ex->use_graph = !(e && atoi(e) == 0); }
     ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
+    { const char* e = getenv("MORB_PINNED_INGEST"); ex->pinned_ingest = !(e && atoi(e) == 0); }
     if (const char* e = getenv("MORB_OCT_MAX_KEYS")) ex->oct_max_keys = std::min(OCT_NK, std::max(1, atoi(e)));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
@@ -1613,6 +1615,13 @@ static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int wi
             ex->ingest.src[cam] = S.dp + per_cam * cam; ex->ingest.stride[cam] = width; ex->ingest_pending = true;
             return ORB_OK;
         }
+    }
+    // A page-locked image is device-visible as it is: the ingest kernel of the run reads it across PCIe, all cameras in ONE
+    // launch (in stream order, like the DMA it replaces: a pitched hipMemcpy2DAsync per camera is a blit kernel of the runtime
+    // each plus ~10 us of host time).  MORB_PINNED_INGEST=0 keeps the copies.
+    if (pinned && ex->pinned_ingest && attr.devicePointer) {
+        ex->ingest.src[cam] = static_cast<const uint8_t*>(attr.devicePointer); ex->ingest.stride[cam] = stride; ex->ingest_pending = true;
+        return ORB_OK;
     }
     ex->ingest.src[cam] = nullptr;
     MORB_HIP(hipMemcpy2DAsync(ex->d_pyr.p + (size_t)cam * ex->cam_pitch, align_up(width, 64), src, stride, width, height, kind, ex->stream));

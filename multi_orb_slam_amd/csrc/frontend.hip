@@ -370,12 +370,14 @@ int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_moti
 }
 
 // An extraction that ran ahead is only valid for the step that consumes it if the images are still the ones that were
-// uploaded.  Pointers, sizes and strides say nothing about a caller that refilled the same buffer in between, so host images
-// also carry a fingerprint of their content: 32 probes of 64 bytes spread over the rows (2 KB per image, well under a
-// microsecond), taken when the upload was enqueued and again when the step arrives.  A mismatch drops what is in flight and the
-// step extracts its images again.  Device images cannot be probed from the host: they must stay unchanged, as orbf.h says.
+// uploaded.  Pointers, sizes and strides say nothing about a caller that refilled the same buffer in between.  The exact answer
+// is the caller's: orbf_image::generation (compared by same_images).  Host images WITHOUT a generation carry a sampled
+// fingerprint of their content instead: 32 probes of 64 bytes spread over the rows (2 KB per image, well under a microsecond),
+// taken when the upload was enqueued and again when the step arrives -- a heuristic that catches whole-frame refills, not an
+// identity.  A mismatch drops what is in flight and the step extracts its images again.  Device images cannot be probed from
+// the host: without a generation they are identified by their pointer alone, as orbf.h says.
 static uint64_t image_fingerprint(const orbf_image& im) {
-    if (im.on_device || !im.data || im.width <= 0 || im.height <= 0) return 0;
+    if (im.generation || im.on_device || !im.data || im.width <= 0 || im.height <= 0) return 0;
     uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)im.width << 32) ^ (uint64_t)im.height;
     const int span = std::min(64, im.width);
     for (int k = 0; k < 32; ++k) {
@@ -403,7 +405,7 @@ static bool same_images(const std::vector<orbf_image>& a, const orbf_image* b, i
     if ((int)a.size() != n) return false;
     for (int c = 0; c < n; ++c)
         if (a[c].data != b[c].data || a[c].width != b[c].width || a[c].height != b[c].height || a[c].stride != b[c].stride ||
-            (a[c].on_device != 0) != (b[c].on_device != 0))
+            (a[c].on_device != 0) != (b[c].on_device != 0) || a[c].generation != b[c].generation)
             return false;
     return true;
 }

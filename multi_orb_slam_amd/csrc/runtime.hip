@@ -27,13 +27,27 @@ int orb_free_host(void* h_ptr) { MORB_HIP(hipHostFree(h_ptr)); return ORB_OK; }
 // "No stream" means synchronous, but NOT the legacy default stream: an operation on the legacy stream implicitly joins every
 // blocking stream of the process and is refused outright while another thread captures a launch chain ("operation would make
 // the legacy stream depend on a capturing stream").  Each thread keeps a private non-blocking stream per device for these calls.
+// (The reference's call pattern uses short-lived threads: the streams go when their thread does.)
+namespace {
+struct PrivateStreams {
+    static constexpr int MAX_DEV = 64;
+    hipStream_t st[MAX_DEV] = {};
+    ~PrivateStreams() {
+        int cur = 0;
+        const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+        for (int d = 0; d < MAX_DEV; ++d)
+            if (st[d] && hipSetDevice(d) == hipSuccess) (void)hipStreamDestroy(st[d]);
+        if (have_cur) (void)hipSetDevice(cur);
+        (void)hipGetLastError();
+    }
+};
+}  // namespace
 static hipStream_t private_stream() {
-    constexpr int MAX_DEV = 64;
-    static thread_local hipStream_t st[MAX_DEV] = {};
+    static thread_local PrivateStreams P;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-    if (!st[dev] && hipStreamCreateWithFlags(&st[dev], hipStreamNonBlocking) != hipSuccess) st[dev] = nullptr;
-    return st[dev];
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PrivateStreams::MAX_DEV) return nullptr;
+    if (!P.st[dev] && hipStreamCreateWithFlags(&P.st[dev], hipStreamNonBlocking) != hipSuccess) P.st[dev] = nullptr;
+    return P.st[dev];
 }
 
 static int copy(void* dst, const void* src, size_t bytes, void* stream, hipMemcpyKind kind) {

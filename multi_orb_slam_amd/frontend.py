@@ -110,11 +110,12 @@ class NativeFrontEnd:
         for c, im in enumerate(images):
             if isinstance(im, np.ndarray):
                 im = np.ascontiguousarray(im, np.uint8); keep.append(im)
-                dst[c] = FImage(im.ctypes.data, im.shape[1], im.shape[0], im.strides[0], 0)
+                dst[c] = FImage(im.ctypes.data, im.shape[1], im.shape[0], im.strides[0], 0, 0)
             elif im is None:
-                dst[c] = FImage(None, 0, 0, 0, 0)
+                dst[c] = FImage(None, 0, 0, 0, 0, 0)
             else:
-                dst[c] = FImage(im[0], im[1], im[2], im[3], 1 if (len(im) < 5 or im[4]) else 0)
+                # (ptr, width, height, stride[, on_device[, generation]])
+                dst[c] = FImage(im[0], im[1], im[2], im[3], 1 if (len(im) < 5 or im[4]) else 0, im[5] if len(im) > 5 else 0)
         return keep
 
     def export_block(self):

@@ -53,7 +53,9 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (_image.empty()) return;
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1);
-    if (!EnsureHandle(image.cols, image.rows)) return;
+    // A failed device call (there is no CPU path) hands the caller an EMPTY frame -- the tracker's own too-few-features
+    // handling takes over -- never the previous frame's features under the new timestamp; LastError() / FailureCount() say why.
+    if (!EnsureHandle(image.cols, image.rows)) { _keypoints.clear(); _descriptors.release(); return; }
     // one call: the image goes up through host-written staging, the describe kernel mirrors its results into pinned memory,
     // and they are copied from there into scratch of the right capacity (a failed call must not leave the caller with half)
     const int cap = nfeatures + 4 * nlevels;
@@ -64,7 +66,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     uint8_t* d_ptr = scratch_desc_.data();
     int n = 0;
     int rc = orbx_extract(handle_, 1, &img_ptr, &w, &h, &stride, &kp_ptr, &d_ptr, &cap, &n);
-    if (rc) { fail("orbx_extract", rc); return; }
+    if (rc) { fail("orbx_extract", rc); _keypoints.clear(); _descriptors.release(); return; }
     if (n == 0) {
         _keypoints.clear();
         _descriptors.release();
@@ -90,10 +92,17 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
     const int n = (int)ex.size();
     assert((int)images.size() == n);
     keypoints.resize(n); descriptors.resize(n);
-    // one shared N-camera handle, cached on the first extractor of the batch
-    static thread_local orbx_extractor* batch = nullptr;
-    static thread_local std::vector<orbx_params> batch_params;
-    static thread_local int bw = 0, bh = 0;
+    // one shared N-camera handle per calling thread (destroyed when the thread exits)
+    struct BatchState {
+        orbx_extractor* h = nullptr; std::vector<orbx_params> params; int w = 0, h_px = 0;
+        ~BatchState() { orbx_destroy(h); }
+    };
+    static thread_local BatchState B;
+    orbx_extractor*& batch = B.h;
+    std::vector<orbx_params>& batch_params = B.params;
+    int &bw = B.w, &bh = B.h_px;
+    // (a failed call leaves EMPTY outputs for every non-empty input image, as operator() does)
+    auto empty_outputs = [&]() { for (int i = 0; i < n; ++i) if (!images[i].empty()) { keypoints[i].clear(); descriptors[i].release(); } };
     std::vector<orbx_params> ps(n);
     int mw = 64, mh = 64;
     for (int i = 0; i < n; ++i) {
@@ -107,7 +116,7 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
         bw = std::max(bw, mw); bh = std::max(bh, mh);
         const char* dev = std::getenv("MORB_DEVICE");
         int rc = orbx_create(ps.data(), n, bw, bh, dev ? std::atoi(dev) : 0, &batch);
-        if (rc) { batch = nullptr; fail("orbx_create(batch)", rc); return; }
+        if (rc) { batch = nullptr; fail("orbx_create(batch)", rc); empty_outputs(); return; }
         batch_params = ps;
     }
     std::vector<const uint8_t*> img(n);
@@ -124,7 +133,7 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
         kp_ptr[i] = reinterpret_cast<orb_keypoint*>(kp[i].data()); d_ptr[i] = ds[i].data();
     }
     const int rc = orbx_extract(batch, n, img.data(), w.data(), h.data(), st.data(), kp_ptr.data(), d_ptr.data(), cap.data(), cnt.data());
-    if (rc) { fail("orbx_extract(batch)", rc); return; }
+    if (rc) { fail("orbx_extract(batch)", rc); empty_outputs(); return; }
     for (int i = 0; i < n; ++i) {
         if (images[i].empty()) continue;  // untouched outputs, like operator()
         const int k = cnt[i];

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include "../../include/orbm.h"
 #include "../../include/orbv.h"
 
@@ -36,14 +37,20 @@ unsigned long ORBmatcher::FailureCount() { return g_failures.load(std::memory_or
 // uploaded frames) belongs to the THREAD: every ORBmatcher object of a thread shares them, threads never share
 // (re-entrant, per-thread stream + scratch).
 namespace {
-struct CachedFrame { uint64_t hash = 0; int n = -1; bool cam1 = false; orbm_frame* fr = nullptr; unsigned long stamp = 0; };
+// identity of an uploaded frame: kind (Frame / KeyFrame), the reference's own id (Frame::mnId / KeyFrame::mnId: assigned once
+// per constructed frame, copied with it, include/Frame.h, include/KeyFrame.h), the feature count and view, plus `guard`: the
+// address of the keypoint array and a hash of a few sampled records -- an object that was refilled under the same id (only
+// hand-built test fixtures do that) is a different key.
+struct CachedFrame { int kind = -1; unsigned long id = 0; uint64_t guard = 0; int n = -1; bool cam1 = false; orbm_frame* fr = nullptr; unsigned long stamp = 0; };
 struct ThreadState {
     orbm_matcher* m = nullptr;
     orbv_workspace* w = nullptr;
     static constexpr int CACHE = 8;
     CachedFrame cache[CACHE];
     unsigned long clock = 0, hits = 0, misses = 0;
-    float last_us[3] = {0, 0, 0};   // host query building / frame (hash + upload) / device search of the last projection search
+    float last_us[3] = {0, 0, 0};   // host query building / frame (lookup + upload) / device search of the last projection search
+    std::vector<orbm_query> q;      // query scratch of the per-frame tracking search
+    std::vector<MapPoint*> qmp;
     ~ThreadState() {
         for (CachedFrame& c : cache) if (c.fr) orbm_frame_destroy(c.fr);
         orbm_destroy(m);
@@ -63,7 +70,36 @@ uint64_t hash_bytes(uint64_t h, const void* p, size_t n) {
 }
 using clk = std::chrono::steady_clock;
 inline float us_since(clk::time_point a) { return std::chrono::duration<float, std::micro>(clk::now() - a).count(); }
+
+// The per-frame tracking search projects ~2000 points with `R * x + t` on 3x3 / 3x1 CV_32F cv::Mat objects: three
+// reference-counted temporaries per point.  apply_rt computes the same three floats without them, element by element as the
+// cv::Mat expression evaluates in cv_compat.h: per row the three products summed left to right in double from 0.0, rounded to
+// float (operator*), then the float addition of t (operator+).  host/test_host `rt` holds the two against each other bit for
+// bit on 10^6 random poses and points.  A build against the real OpenCV keeps the cv::Mat expressions (MORB_VERBATIM_MAT_ALGEBRA
+// is on by default there): cv::gemm has its own evaluation order for small matrices, and whoever switches the scalar path on
+// for such a build runs the same comparison against it first.
+#if defined(HAVE_OPENCV) && !defined(MORB_SCALAR_POSE_ALGEBRA) && !defined(MORB_VERBATIM_MAT_ALGEBRA)
+#define MORB_VERBATIM_MAT_ALGEBRA 1
+#endif
+struct Rt { float R[3][3], t[3]; };
+inline Rt load_rt(const cv::Mat& R, const cv::Mat& t) {
+    Rt P;
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) P.R[i][j] = R.at<float>(i, j); P.t[i] = t.at<float>(i); }
+    return P;
+}
+inline void apply_rt(const Rt& P, const float* x, float* o) {
+    for (int i = 0; i < 3; ++i) {
+        double s = 0;
+        s += (double)P.R[i][0] * (double)x[0];
+        s += (double)P.R[i][1] * (double)x[1];
+        s += (double)P.R[i][2] * (double)x[2];
+        o[i] = (float)s + P.t[i];
+    }
+}
 }  // namespace
+
+// test hook (host/test_host `rt`): R * x + t through apply_rt
+void ORBmatcher::DebugApplyRt(const cv::Mat& R, const cv::Mat& t, const float* x, float* out) { apply_rt(load_rt(R, t), x, out); }
 
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
     mRcam21 = cv::Mat(3, 3, CV_32F);
@@ -165,7 +201,7 @@ struct MapWalk {
 };
 
 template <class FrameOrKeyFrame>
-void flatten(const FrameOrKeyFrame& F, bool cam1_only, FlatFrame& ff) {
+bool flatten(const FrameOrKeyFrame& F, bool cam1_only, FlatFrame& ff) {
     const int n = cam1_only ? F.N : F.N_total;
     ff.x.resize(n); ff.y.resize(n); ff.ang.resize(n); ff.ur.resize(n); ff.oct.resize(n); ff.cam.resize(n); ff.loc.resize(n);
     const std::vector<cv::KeyPoint>& kun = cam1_only ? F.mvKeysUn : F.mvKeysUn_total;
@@ -176,6 +212,7 @@ void flatten(const FrameOrKeyFrame& F, bool cam1_only, FlatFrame& ff) {
         ff.ur[g] = ur[g];
         ff.cam[g] = cam1_only ? 0 : cams.at(g);
         ff.loc[g] = cam1_only ? g : locs.at(g);
+        if (ff.cam[g] < 0 || ff.loc[g] < 0) return false;   // a global index without an entry in the frame's maps
     }
     ff.desc.clear();
     if (cam1_only) ff.desc.push_back(F.mDescriptors.ptr(0));
@@ -184,13 +221,17 @@ void flatten(const FrameOrKeyFrame& F, bool cam1_only, FlatFrame& ff) {
     ff.d.un_x = ff.x.data(); ff.d.un_y = ff.y.data(); ff.d.octave = ff.oct.data(); ff.d.angle = ff.ang.data();
     ff.d.uright = ff.ur.data(); ff.d.cam_of = ff.cam.data(); ff.d.local_of = ff.loc.data(); ff.d.desc = ff.desc.data();
     ff.d.min_x = F.mnMinX; ff.d.min_y = F.mnMinY; ff.d.max_x = F.mnMaxX; ff.d.max_y = F.mnMaxY;
+    for (int g = 0; g < n; ++g)
+        if (ff.cam[g] >= ff.d.n_cams || !ff.desc[ff.cam[g]]) return false;
+    return true;
 }
 
 // The matcher-side view of a Frame / KeyFrame (positions, octaves, angles, right coordinates, descriptors, 64x48 grid) in
 // HBM.  A Frame's features never change after construction, and the same frame is searched several times (TrackWithMotionModel
 // retries with 2*th, TrackLocalMap searches the same frame again, keyframes are fused into and searched for as long as they
-// live), so uploaded frames are cached per thread under a 64-bit hash of EVERYTHING the upload reads: a frame whose content
-// changed is simply a different key.  Least recently used of 8 entries is dropped.  Returns NULL after a reported failure.
+// live), so uploaded frames are cached per thread under the frame's IDENTITY (see CachedFrame; rounds 1-2 hashed all ~150 KB
+// an upload reads -- 87 us per call -- and trusted a 64-bit hash alone).  Least recently used of 8 entries is dropped.
+// Returns NULL after a reported failure.
 template <class FrameOrKeyFrame>
 orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_only) {
     if (!m) return nullptr;
@@ -198,33 +239,34 @@ orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_on
     const std::vector<cv::KeyPoint>& kun = cam1_only ? F.mvKeysUn : F.mvKeysUn_total;
     const std::vector<float>& ur = cam1_only ? F.mvuRight : F.mvuRight_total;
     if ((int)kun.size() < n || (int)ur.size() < n) { fail("device_frame (Frame arrays shorter than N)", ORB_E_ARG); return nullptr; }
-    uint64_t h = mix(0x243F6A8885A308D3ull, (uint64_t)n * 2 + (cam1_only ? 1 : 0));
-    h = hash_bytes(h, kun.data(), (size_t)n * sizeof(cv::KeyPoint));
-    h = hash_bytes(h, ur.data(), (size_t)n * sizeof(float));
-    const float bounds[4] = {F.mnMinX, F.mnMinY, F.mnMaxX, F.mnMaxY};
-    h = hash_bytes(h, bounds, sizeof(bounds));
-    if (cam1_only) h = hash_bytes(h, F.mDescriptors.ptr(0), (size_t)n * 32);
-    else {
-        for (const cv::Mat& d : F.mDescriptors_total) { h = mix(h, (uint64_t)d.rows); if (!d.empty()) h = hash_bytes(h, d.ptr(0), (size_t)d.rows * 32); }
-        for (const auto& e : F.keypoint_to_cam) h = mix(h, (uint64_t)e.first * 8 + (uint64_t)(e.second & 7));
-        for (const auto& e : F.cont_idx_to_local_cam_idx) h = mix(h, ((uint64_t)e.first << 24) ^ (uint64_t)(uint32_t)e.second);
+    const int kind = std::is_same<FrameOrKeyFrame, KeyFrame>::value ? 1 : 0;
+    const unsigned long id = (unsigned long)F.mnId;
+    uint64_t guard = mix(0x243F6A8885A308D3ull, (uint64_t)(uintptr_t)kun.data());
+    if (n > 0) {
+        const int probe[3] = {0, n / 2, n - 1};
+        for (int k = 0; k < 3; ++k) { guard = hash_bytes(guard, &kun[probe[k]], sizeof(cv::KeyPoint)); guard = hash_bytes(guard, &ur[probe[k]], sizeof(float)); }
+        const cv::Mat& d0 = cam1_only ? F.mDescriptors : F.mDescriptors_total[0];
+        if (!d0.empty()) guard = hash_bytes(guard, d0.ptr(0), 32);
     }
     ThreadState& T = tls;
     ++T.clock;
     CachedFrame* victim = &T.cache[0];
     for (CachedFrame& c : T.cache) {
-        if (c.fr && c.hash == h && c.n == n && c.cam1 == cam1_only) { c.stamp = T.clock; ++T.hits; return c.fr; }
+        if (c.fr && c.kind == kind && c.id == id && c.guard == guard && c.n == n && c.cam1 == cam1_only) { c.stamp = T.clock; ++T.hits; return c.fr; }
         if (!c.fr) { if (victim->fr) victim = &c; }
         else if (victim->fr && c.stamp < victim->stamp) victim = &c;
     }
     ++T.misses;
     FlatFrame ff;
-    flatten(F, cam1_only, ff);
+    if (!flatten(F, cam1_only, ff)) {
+        fail("device_frame (a feature without an entry in keypoint_to_cam / cont_idx_to_local_cam_idx, or without a descriptor row)", ORB_E_ARG);
+        return nullptr;
+    }
     orbm_frame* fr = nullptr;
     const int rc = orbm_frame_create(m, &ff.d, &fr);
     if (rc) { fail("orbm_frame_create", rc); return nullptr; }
     if (victim->fr) orbm_frame_destroy(victim->fr);
-    victim->hash = h; victim->n = n; victim->cam1 = cam1_only; victim->fr = fr; victim->stamp = T.clock;
+    victim->kind = kind; victim->id = id; victim->guard = guard; victim->n = n; victim->cam1 = cam1_only; victim->fr = fr; victim->stamp = T.clock;
     return fr;
 }
 
@@ -868,6 +910,74 @@ int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& v
     return nFused;
 }
 
+// reference src/ORBmatcher.cc:2518-2813: the camera-1 form of the Sim3 fuse (defined in the reference; its only call, at
+// src/LoopClosing.cc:842, is commented out there).  The points are projected into camera 1 only and searched in the keyframe's
+// camera-1 grid (KeyFrame::GetFeaturesInArea(u, v, r), mvKeysUn, mDescriptors); no reprojection-error gate; the nearest
+// descriptor of the window wins on its own (orbm_project_best), duplicates are reported in vpReplacePoint.
+int ORBmatcher::Fuse_cam1(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) {
+    const float& fx = pKF->fx; const float& fy = pKF->fy; const float& cx = pKF->cx; const float& cy = pKF->cy;
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+    const int nPoints = (int)vpPoints.size();
+    std::vector<orbm_query> q; std::vector<int> src;
+    for (int iMP = 0; iMP < nPoints; iMP++) {
+        MapPoint* pMP = vpPoints[iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0f) continue;
+        const float invz = 1.0 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz;
+        const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist3D = cv::norm(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        orbm_query Q;
+        Q.u = u; Q.v = v; Q.radius = radius; Q.ur = std::nanf("");
+        Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;   // :2660-2663
+        Q.cam = 0; Q.blocks = 0; Q.angle = 0;
+        const cv::Mat dMP = pMP->GetDescriptor();
+        std::memcpy(Q.desc, dMP.ptr(0), 32);
+        q.push_back(Q); src.push_back(iMP);
+    }
+    dump_queries(q, src);
+    std::vector<int32_t> bi(q.size() ? q.size() : 1, -1), bd(q.size() ? q.size() : 1, 256);
+    if (!q.empty()) {
+        orbm_frame* fr = device_frame(Handle(), *pKF, true);
+        if (!fr) return 0;
+        const int rc = orbm_project_best(Handle(), fr, q.data(), (int)q.size(), nullptr, ORBM_GATE_NONE, nullptr, 0, bi.data(), bd.data());
+        if (rc) return fail("orbm_project_best", rc);
+    }
+    int nFused = 0;
+    for (size_t f = 0; f < q.size(); ++f) {            // in point order: an added point is what a later duplicate finds (:2700-2713)
+        if (bi[f] < 0 || bd[f] > TH_LOW) continue;
+        const int iMP = src[f];
+        MapPoint* pMP = vpPoints[iMP];
+        MapPoint* pMPinKF = pKF->GetMapPoint(bi[f]);
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+        } else {
+            pMP->AddObservation(pKF, bi[f]);
+            pKF->AddMapPoint(pMP, bi[f]);
+        }
+        nFused++;
+    }
+    return nFused;
+}
+
 // reference src/ORBmatcher.cc:206-388
 int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
     const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
@@ -1021,20 +1131,44 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     bBackward[0] = -tlc.at<float>(2) > CurrentFrame.mb && !bMono;
     bBackward[1] = -tlc.at<float>(0) > CurrentFrame.mb && !bMono;
 
-    std::vector<orbm_query> q;
-    std::vector<MapPoint*> qmp;
-    q.reserve(LastFrame.N_total);
+    // The current frame's matcher view is needed by the search only: its upload (one staging write + one unpack kernel,
+    // asynchronous) is started first, so that it is in flight while the host projects the points.
+    const clk::time_point t_frame = clk::now();
+    orbm_frame* fr = device_frame(Handle(), CurrentFrame, false);
+    if (!fr) return 0;
+    tls.last_us[1] = us_since(t_frame);
+    const clk::time_point t_query = clk::now();
+
+    std::vector<orbm_query>& q = tls.q;          // (per-thread scratch: 88 bytes per point, reused from call to call)
+    std::vector<MapPoint*>& qmp = tls.qmp;
+    q.clear(); qmp.clear();
+    q.reserve(LastFrame.N_total); qmp.reserve(LastFrame.N_total);
+#ifndef MORB_VERBATIM_MAT_ALGEBRA
+    const Rt Pcw = load_rt(Rcw, tcw), Pcam21 = load_rt(mRcam21, mtcam21);
+#endif
+    MapWalk cam_of(LastFrame.keypoint_to_cam);
     for (int i = 0; i < LastFrame.N_total; i++) {
         MapPoint* pMP = LastFrame.mvpMapPoints[i];
         if (!pMP) continue;
         if (LastFrame.mvbOutlier[i]) continue;
-        int cam = LastFrame.keypoint_to_cam.find(i)->second;
+        int cam = cam_of.at(i);                   // LastFrame.keypoint_to_cam.find(i)->second, by an ordered walk
+#ifdef MORB_VERBATIM_MAT_ALGEBRA
         cv::Mat x3Dw = pMP->GetWorldPos();
         cv::Mat x3Dc = Rcw * x3Dw + tcw;
         if (cam == 1) x3Dc = mRcam21 * x3Dc + mtcam21;
         const float xc = x3Dc.at<float>(0);
         const float yc = x3Dc.at<float>(1);
         const float invzc = 1.0 / x3Dc.at<float>(2);
+#else
+        // the same values as the cv::Mat expressions above, element by element (apply_rt), without the three temporaries
+        const cv::Mat x3Dw = pMP->GetWorldPos();
+        float xw[3] = {x3Dw.at<float>(0), x3Dw.at<float>(1), x3Dw.at<float>(2)}, x3Dc[3];
+        apply_rt(Pcw, xw, x3Dc);
+        if (cam == 1) { const float t3[3] = {x3Dc[0], x3Dc[1], x3Dc[2]}; apply_rt(Pcam21, t3, x3Dc); }
+        const float xc = x3Dc[0];
+        const float yc = x3Dc[1];
+        const float invzc = 1.0 / x3Dc[2];
+#endif
         if (invzc < 0) continue;
         float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
         float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
@@ -1042,7 +1176,8 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
         if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
         int nLastOctave = LastFrame.mvKeys_total[i].octave;
         float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];
-        orbm_query Q;
+        q.emplace_back();
+        orbm_query& Q = q.back();
         Q.u = u; Q.v = v; Q.radius = radius;
         Q.ur = u - CurrentFrame.mbf * invzc;
         if (bForward[cam]) { Q.min_level = nLastOctave; Q.max_level = -1; }            // GetFeaturesInArea(cam,u,v,r,nLastOctave)
@@ -1053,14 +1188,10 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
         Q.angle = LastFrame.mvKeysUn_total[i].angle;
         const cv::Mat dMP = pMP->GetDescriptor();
         std::memcpy(Q.desc, dMP.ptr(0), 32);
-        q.push_back(Q); qmp.push_back(pMP);
+        qmp.push_back(pMP);
     }
 
-    tls.last_us[0] = us_since(t_entry);
-    const clk::time_point t_frame = clk::now();
-    orbm_frame* fr = device_frame(Handle(), CurrentFrame, false);
-    if (!fr) return 0;
-    tls.last_us[1] = us_since(t_frame);
+    tls.last_us[0] = us_since(t_query) + std::chrono::duration<float, std::micro>(t_frame - t_entry).count();
     const clk::time_point t_search = clk::now();
     int rc;
     std::vector<int32_t> match(CurrentFrame.N_total > 0 ? CurrentFrame.N_total : 1);

@@ -71,6 +71,8 @@ public:
     // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints.
     int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<int>& vLoopMPCams, float th,
              std::vector<MapPoint*>& vpReplacePoint, const cv::Mat CalibMatrix);
+    // The camera-1 form (reference include/ORBmatcher.h:110, src/ORBmatcher.cc:2518-2813)
+    int Fuse_cam1(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint);
 
     // Search matches between MapPoints in a KeyFrame and ORB in a Frame.
     // Brute force constrained to ORB that belong to the same vocabulary node (at a certain level)
@@ -111,6 +113,9 @@ public:
     // and the hit / miss counts of the calling thread's cache of uploaded frames
     static void LastCallBreakdown(float* us3);
     static void FrameCacheStats(unsigned long* hits, unsigned long* misses);
+    // test hook: R * x + t (3x3, 3x1 CV_32F) through the scalar routine the per-frame tracking search uses instead of three
+    // cv::Mat temporaries per point; host/test_host `rt` compares it with the cv::Mat expression bit for bit
+    static void DebugApplyRt(const cv::Mat& R, const cv::Mat& t, const float* x, float* out);
 
 private:
     // The device state (matcher handle with its stream and scratch, BoW workspace, cache of uploaded frames) belongs to the

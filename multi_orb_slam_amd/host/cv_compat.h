@@ -122,7 +122,11 @@ private:
         template <class U> PoolAlloc(const PoolAlloc<U>&) {}
         static constexpr size_t BLOCK = 160;
         struct Node { Node* next; };
-        static Node*& head() { static thread_local Node* h = nullptr; return h; }
+        struct FreeList {   // the thread's pooled blocks go back to the heap when the thread exits
+            Node* h = nullptr;
+            ~FreeList() { while (h) { Node* p = h; h = p->next; ::operator delete(p); } }
+        };
+        static Node*& head() { static thread_local FreeList l; return l.h; }
         T* allocate(size_t n) {
             if (n == 1 && sizeof(T) <= BLOCK) {
                 Node*& h = head();

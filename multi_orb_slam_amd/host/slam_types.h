@@ -5,6 +5,7 @@
 // reference's include/ on the include path).
 #pragma once
 #ifndef MORB_USE_REFERENCE_TYPES
+#include <atomic>
 #include <cmath>
 #include <map>
 #include <set>
@@ -61,6 +62,11 @@ public:
 
 class Frame {
 public:
+    // identity (include/Frame.h: `static long unsigned int nNextId; long unsigned int mnId;`, assigned in the constructors,
+    // src/Frame.cc:257; copies keep it)
+    // (atomic here: the stand-in's test driver constructs frames on several threads; the reference's tracking thread is alone)
+    static std::atomic<long unsigned int>& NextId() { static std::atomic<long unsigned int> n{0}; return n; }
+    long unsigned int mnId = NextId()++;
     // multi-camera "_total" view (src/Frame.cc:191-239): global index g, cam-major
     int N = 0, N_cam2 = 0, N_total = 0;
     std::vector<cv::KeyPoint> mvKeys_total, mvKeysUn_total, mvKeysUn;
@@ -86,6 +92,9 @@ public:
 // src/KeyFrame.cc:31-80).  Poses are world -> camera, one per camera of the rig.
 class KeyFrame {
 public:
+    // identity (include/KeyFrame.h: `static long unsigned int nNextId; long unsigned int mnId;`)
+    static std::atomic<long unsigned int>& NextId() { static std::atomic<long unsigned int> n{0}; return n; }
+    long unsigned int mnId = NextId()++;
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
     MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
     cv::Mat GetDescriptor(const int& cam, const size_t& idx) const { return mDescriptors_total[cam].row((int)idx); }

@@ -114,8 +114,7 @@ static void read_frame(Reader& R, Frame& F) {
 
 // match <case.bin> <out.bin>: [current frame][last frame][nmp x {world xyz, desc32, obs, has, outlier}][calib 4x3]
 //                             [local points: count x {projX, projY, projXR, level, viewCos, desc32, inview, bad}]
-static int run_match(int argc, char** argv) {
-    std::vector<unsigned char> buf = slurp(argv[2]);
+static int do_match(const std::vector<unsigned char>& buf, FILE* f) {
     Reader R{buf.data()};
     Frame Cur, Last;
     read_frame(R, Cur); read_frame(R, Last);
@@ -141,7 +140,6 @@ static int run_match(int argc, char** argv) {
 
     ORBmatcher matcher(0.9f, check_ori != 0);
     const int n1 = matcher.SearchByProjection(Cur, Last, th, false, calib);
-    FILE* f = std::fopen(argv[3], "wb");
     put(f, &n1, 4);
     for (int g = 0; g < Cur.N_total; ++g) {
         int idx = Cur.mvpMapPoints[g] ? (int)(Cur.mvpMapPoints[g] - pool.data()) : -1;
@@ -173,8 +171,15 @@ static int run_match(int argc, char** argv) {
     // static DescriptorDistance
     const int dd = ORBmatcher::DescriptorDistance(Cur.mDescriptors.row(0), Cur.mDescriptors.row(1));
     put(f, &dd, 4);
-    std::fclose(f);
     return 0;
+}
+static int run_file(int (*fn)(const std::vector<unsigned char>&, FILE*), char** argv) {
+    std::vector<unsigned char> buf = slurp(argv[2]);
+    FILE* f = std::fopen(argv[3], "wb");
+    if (!f) { std::perror(argv[3]); return 2; }
+    const int rc = fn(buf, f);
+    std::fclose(f);
+    return rc;
 }
 
 // One keyframe / frame of a bow case: N, N_cam2, x y angle uright (f32 each), octave (i32), descriptors cam 0 then cam 1,
@@ -225,8 +230,7 @@ static std::vector<cv::Mat> rows_of(const BowEntity& E) {  // Converter::toDescr
 
 // bow <case.bin> <out.bin>: [vocabulary arrays][levelsup][KF1][KF2][F][fx fy cx cy][scale 8][sigma2 8][nnratio][check_ori]
 //                           [bOnlyStereo][vbCam0][vbCam1]
-static int run_bow(int argc, char** argv) {
-    std::vector<unsigned char> buf = slurp(argv[2]);
+static int do_bow(const std::vector<unsigned char>& buf, FILE* f) {
     Reader R{buf.data()};
     const int n_nodes = R.get<int>(), L = R.get<int>();
     std::vector<int> parent = R.arr<int>(n_nodes);
@@ -258,7 +262,6 @@ static int run_bow(int argc, char** argv) {
     F.keypoint_to_cam = EF.to_cam; F.cont_idx_to_local_cam_idx = EF.to_local;
     voc.transform(rows_of(EF), F.mBowVec, F.mFeatVec, levelsup);         // Frame::ComputeBoW, src/Frame.cc:649-659
 
-    FILE* f = std::fopen(argv[3], "wb");
     int nw = (int)K1.mBowVec.size(); put(f, &nw, 4);
     for (const auto& e : K1.mBowVec) { put(f, &e.first, 4); put(f, &e.second, 8); }
     int nn = (int)K1.mFeatVec.size(); put(f, &nn, 4);
@@ -299,7 +302,6 @@ static int run_bow(int argc, char** argv) {
     const int ne = m1.SearchByBoW_cam1(&K1, &K2, v121);
     put(f, &ne, 4);
     for (int g = 0; g < E1.N; ++g) { int idx = v121[g] ? (int)(v121[g] - E2.pool.data()) : -1; put(f, &idx, 4); }
-    std::fclose(f);
     return 0;
 }
 
@@ -322,8 +324,7 @@ static void to_keyframe(const Frame& F, KeyFrame& K) {
 // [Cur][KA][KB][Tcw_cam2 of KB 16f][M points: xyz 3f, desc 32, normal 3f, mind f, maxd f, bad i, nobs i]
 // [ids of Cur (N_total i), KA (N_total i), KB (N_total i)][nfound, ids][nloop, ids][vpMatched init KA.N i][Scw 16f][th_loop i]
 // [s12 f][R12 9f][t12 3f][vpMatches12 init KA.N i][th_sim3 f][nfuse, ids][Calib 12f][th_fuse f][th_reloc f][ORBdist i][check_ori i]
-static int run_f4(int argc, char** argv) {
-    std::vector<unsigned char> buf = slurp(argv[2]);
+static int do_f4(const std::vector<unsigned char>& buf, FILE* f) {
     Reader R{buf.data()};
     Frame Cur, FA, FB;
     read_frame(R, Cur); read_frame(R, FA); read_frame(R, FB);
@@ -351,6 +352,7 @@ static int run_f4(int argc, char** argv) {
     };
     auto id_of = [&](MapPoint* p) { return p ? (int)(p - pool.data()) : -1; };
     ids_to(Cur.mvpMapPoints, Cur.N_total, nullptr); ids_to(KA.mvpMapPoints, KA.N_total, &KA); ids_to(KB.mvpMapPoints, KB.N_total, &KB);
+    KeyFrame KA1 = KA;   // the keyframe as it is before any fuse touches it: Fuse_cam1 runs on this copy at the end
     std::set<MapPoint*> found;
     { int n = R.get<int>(); std::vector<int> ids = R.arr<int>(n); for (int i : ids) found.insert(&pool[i]); }
     std::vector<MapPoint*> loop_pts;
@@ -377,7 +379,6 @@ static int run_f4(int argc, char** argv) {
     std::vector<float> prev_x = R.arr<float>(FA.N), prev_y = R.arr<float>(FA.N);
     const int window_size = R.get<int>();
 
-    FILE* f = std::fopen(argv[3], "wb");
     ORBmatcher m(0.9f, check_ori != 0);
     const int n1 = m.SearchByProjection(Cur, &KA, found, th_reloc, ORBdist);
     put(f, &n1, 4);
@@ -414,7 +415,12 @@ static int run_f4(int argc, char** argv) {
     put(f, &n5, 4);
     for (int g = 0; g < KA.N_total; ++g) { int id = id_of(KA.mvpMapPoints[g]); put(f, &id, 4); }
     for (size_t i = 0; i < vpReplace.size(); ++i) { int id = id_of(vpReplace[i]); put(f, &id, 4); }
-    std::fclose(f);
+    // the camera-1 form of the same fuse (reference :2518-2813)
+    std::vector<MapPoint*> vpReplace1(loop_pts.size(), nullptr);
+    const int n9 = m.Fuse_cam1(&KA1, Scw, loop_pts, th_fuse + 1.0f, vpReplace1);
+    put(f, &n9, 4);
+    for (int g = 0; g < KA1.N_total; ++g) { int id = id_of(KA1.mvpMapPoints[g]); put(f, &id, 4); }
+    for (size_t i = 0; i < vpReplace1.size(); ++i) { int id = id_of(vpReplace1[i]); put(f, &id, 4); }
     return 0;
 }
 
@@ -562,14 +568,94 @@ static int run_dropin(int argc, char** argv) {
     return 0;
 }
 
+// threads <match_case.bin> <bow_case.bin> <f4_case.bin> <iters>
+// The reference calls ORBmatcher from three threads at once: Tracking (SearchByProjection, src/Tracking.cc:1267,1764),
+// LocalMapping (SearchForTriangulation + Fuse, src/LocalMapping.cc:361,741) and LoopClosing (SearchByBoW, SearchBySim3,
+// SearchByProjection, Fuse; src/LoopClosing.cc:362-536,841).  Here: the `match` case on one thread, the `bow` case (both
+// SearchByBoW forms, SearchForTriangulation) on a second, the `f4` case (relocalisation / loop searches, both SearchBySim3
+// forms, both Fuse overloads) on a third, each repeated `iters` times CONCURRENTLY on freshly parsed frames (so every
+// iteration uploads its frames again), every iteration's output compared byte for byte with the same case run alone.
+#include <atomic>
+#include <thread>
+static std::vector<unsigned char> run_mem(int (*fn)(const std::vector<unsigned char>&, FILE*), const std::vector<unsigned char>& buf, int* rc) {
+    char* p = nullptr; size_t n = 0;
+    FILE* f = open_memstream(&p, &n);
+    *rc = fn(buf, f);
+    std::fclose(f);
+    std::vector<unsigned char> out(p, p + n);
+    std::free(p);
+    return out;
+}
+
+static int run_threads(int argc, char** argv) {
+    typedef int (*Fn)(const std::vector<unsigned char>&, FILE*);
+    const Fn fns[3] = {do_match, do_bow, do_f4};
+    std::vector<unsigned char> cases[3] = {slurp(argv[2]), slurp(argv[3]), slurp(argv[4])};
+    const int iters = std::atoi(argv[5]);
+    std::vector<unsigned char> serial[3];
+    for (int k = 0; k < 3; ++k) {
+        int rc = 0;
+        serial[k] = run_mem(fns[k], cases[k], &rc);
+        if (rc || serial[k].empty()) { std::fprintf(stderr, "threads: serial run of case %d failed (%d)\n", k, rc); return 5; }
+    }
+    std::atomic<int> mismatches{0}, errors{0}, started{0};
+    std::vector<std::thread> th;
+    for (int k = 0; k < 3; ++k)
+        th.emplace_back([&, k]() {
+            ++started;
+            while (started.load() < 3) std::this_thread::yield();      // all three loops begin together
+            for (int it = 0; it < iters; ++it) {
+                int rc = 0;
+                std::vector<unsigned char> out = run_mem(fns[k], cases[k], &rc);
+                if (rc) ++errors;
+                if (out != serial[k]) ++mismatches;
+            }
+        });
+    for (std::thread& t : th) t.join();
+    const unsigned long fails = ORBmatcher::FailureCount() + ORBextractor::FailureCount();
+    std::printf("threads: 3 x %d concurrent iterations, %d mismatches, %d errors, %lu failed device calls\n", iters, mismatches.load(),
+                errors.load(), fails);
+    return (mismatches.load() || errors.load() || fails) ? 6 : 0;
+}
+
+// rt <n>: R * x + t on CV_32F cv::Mat objects (what the reference's projection loops write) against the scalar routine the
+// per-frame tracking search uses (ORBmatcher::DebugApplyRt), bit for bit, on n random poses x points: rotations with entries in
+// [-1, 1], translations and points over eight decades of magnitude, plus chained application (cam 2 behind cam 1).  No GPU.
+static int run_rt(int argc, char** argv) {
+    const long n = std::atol(argv[2]);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    auto unit = [&]() { return (float)((double)(rnd() >> 11) / 9007199254740992.0 * 2.0 - 1.0); };
+    long bad = 0;
+    cv::Mat Rm(3, 3, CV_32F), tm(3, 1, CV_32F), xm(3, 1, CV_32F), R2(3, 3, CV_32F), t2(3, 1, CV_32F);
+    for (long i = 0; i < n; ++i) {
+        const float mag_t = std::pow(10.f, (float)(rnd() % 8) - 3.f), mag_x = std::pow(10.f, (float)(rnd() % 8) - 3.f);
+        for (int k = 0; k < 9; ++k) { Rm.at<float>(k / 3, k % 3) = unit(); R2.at<float>(k / 3, k % 3) = unit(); }
+        for (int k = 0; k < 3; ++k) { tm.at<float>(k) = unit() * mag_t; t2.at<float>(k) = unit() * mag_t; xm.at<float>(k) = unit() * mag_x; }
+        cv::Mat y = Rm * xm + tm;
+        cv::Mat z = R2 * y + t2;
+        const float x[3] = {xm.at<float>(0), xm.at<float>(1), xm.at<float>(2)};
+        float ys[3], zs[3];
+        ORBmatcher::DebugApplyRt(Rm, tm, x, ys);
+        ORBmatcher::DebugApplyRt(R2, t2, ys, zs);
+        for (int k = 0; k < 3; ++k) {
+            if (std::memcmp(&ys[k], &y.at<float>(k), 4) != 0 || std::memcmp(&zs[k], &z.at<float>(k), 4) != 0) ++bad;
+        }
+    }
+    std::printf("rt: %ld poses x points, %ld differing floats\n", n, bad);
+    return bad ? 7 : 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: test_host extract|batch|match|bow ...\n"); return 1; }
     const std::string mode = argv[1];
     if (mode == "extract" && argc >= 7) return run_extract(argc, argv);
     if (mode == "batch" && argc >= 9) return run_batch(argc, argv);
-    if (mode == "match" && argc >= 4) return run_match(argc, argv);
-    if (mode == "bow" && argc >= 4) return run_bow(argc, argv);
-    if (mode == "f4" && argc >= 4) return run_f4(argc, argv);
+    if (mode == "match" && argc >= 4) return run_file(do_match, argv);
+    if (mode == "bow" && argc >= 4) return run_file(do_bow, argv);
+    if (mode == "f4" && argc >= 4) return run_file(do_f4, argv);
+    if (mode == "threads" && argc >= 6) return run_threads(argc, argv);
+    if (mode == "rt" && argc >= 3) return run_rt(argc, argv);
     if (mode == "dropin" && argc >= 5) return run_dropin(argc, argv);
     std::fprintf(stderr, "bad arguments\n");
     return 1;

@@ -129,8 +129,8 @@ class FrontEnd:
     def announce(self, images, resident=False):
         """Announce the images of a future step (orbf_prefetch; a FIFO, at most two steps ahead): their extraction runs next to
         the matching of the steps before; those steps must then pass exactly these images, in order."""
-        if resident:   # (ptr, stride): HBM-resident (True) or page-locked host memory ("pinned": copied H2D inside the step)
-            images = [(im[0], self.width, self.height, im[1], 0 if resident == "pinned" else 1) for im in images]
+        if resident:   # (ptr, stride[, generation]): HBM-resident (True) or page-locked host memory ("pinned": copied H2D inside the step)
+            images = [(im[0], self.width, self.height, im[1], 0 if resident == "pinned" else 1, im[2] if len(im) > 2 else 0) for im in images]
         self.fe.prefetch(images)
 
     def step(self, images, resident=False, next_images=None):
@@ -139,7 +139,7 @@ class FrontEnd:
         if next_images is not None:
             self.announce(next_images, resident)
         if resident:
-            images = [(im[0], self.width, self.height, im[1], 0 if resident == "pinned" else 1) for im in images]
+            images = [(im[0], self.width, self.height, im[1], 0 if resident == "pinned" else 1, im[2] if len(im) > 2 else 0) for im in images]
         native = getattr(self, "native_exchange", False)
         distributed = self.world > 1 and self.gather is not None and not native
         # queries = the previous step's features under the stream's known motion, built natively (orbf_step_motion;

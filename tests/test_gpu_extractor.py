@@ -150,14 +150,14 @@ def test_levels_beyond_the_device_limit_fall_back_to_the_host_quadtree():
     run is redone on the host path -- same results."""
     import os
     import multi_orb_slam_amd as m
-    os.environ["MORB_OCT_MAX_KEYS"] = "1000"
+    os.environ["MORB_OCT_MAX_KEYS"] = "500"
     try:
         ex = _mk([m.ExtractorParams(nfeatures=1000)] * 2, 640, 480)
     finally:
         os.environ.pop("MORB_OCT_MAX_KEYS")
     imgs = [synth.image(c, 3, 640, 480) for c in range(2)]
     out = ex.extract(imgs)
-    assert ex.last_path() == 2 and len(ex.debug_candidates(0, 0)) > 1000
+    assert ex.last_path() == 2 and len(ex.debug_candidates(0, 0)) > 500
     for c in range(2):
         okps, odesc = oracle.extract(imgs[c], nfeatures=1000)
         _assert_same(out[c][0], out[c][1], okps, odesc)

@@ -204,56 +204,39 @@ def test_native_step_with_an_empty_camera():
 
 def test_full_size_rig_properties():
     """configs[4]: 8 synthetic 1920x1080 streams, 4000 features per camera, through the native front end (the > 4-camera
-    path: host quadtree for the dense levels, multi-kernel frame assembly, 32k-feature searches).  The oracle needs
-    seconds per camera at this size, so it pins ONE camera; the rest is checked through size-independent properties."""
+    path: dense levels of up to 9400 candidates in the device quadtree, multi-kernel frame assembly, the 32 000-feature
+    first-come search with its claim tables in HBM, the 32k x 28k camera-pair top-2 on the matrix cores).  The WHOLE rig is
+    pinned against the oracle (one host thread per camera; a few seconds): keypoints, descriptors, stereo, the temporal
+    search and the complete cross-camera top-2 -- then batch independence and determinism."""
     import multi_orb_slam_amd as m
-    from multi_orb_slam_amd.frontend import NativeFrontEnd
     from multi_orb_slam_amd import pipeline
-    import oracle
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
     W, H, NF, NC = 1920, 1080, 4000, 8
     params = [m.ExtractorParams(nfeatures=NF)] * NC
     frames = [[synth.image(c, t, W, H) for c in range(NC)] for t in range(2)]
 
     def run():
-        fe = NativeFrontEnd(params, W, H)
-        out = [fe.step(frames[t], motion=(pipeline.MOTION[0], pipeline.MOTION[1], pipeline.TH_PROJ)) for t in range(2)]
+        fe = pipeline.FrontEnd(params, W, H)
+        out = [fe.step(frames[t]) for t in range(2)]
         fe.close()
         return out
 
     a = run()
-    r0, r1 = a
+    ofe = OracleFrontEnd(params, W, H, cam_threads=True)
+    for t in range(2):
+        assert_same_step(a[t], ofe.step(frames[t]))
+    ofe.pool.shutdown()
+    r1 = a[1]
     counts = r1["counts"]
     assert len(counts) == NC and all(NF * 0.95 < c <= NF + 32 for c in counts)
+    assert r1["n_temporal"] > 0.5 * sum(counts) and len(r1["cross"][0]) == sum(counts)
     off = np.concatenate([[0], np.cumsum(counts)])
-    # (1) one camera against the oracle at full size, (2) batch independence: a single-camera extractor gives the same
-    okps, odesc = oracle.extract(frames[1][3], nfeatures=NF)
-    assert r1["kps"][off[3]:off[4]].tobytes() == okps.tobytes() and np.array_equal(r1["desc"][off[3]:off[4]], odesc)
+    # batch independence: a single-camera extractor gives the same
     ex = m.Extractor([params[0]], W, H)
     k6, d6 = ex.extract([frames[1][6]])[0]
     ex.close()
     assert r1["kps"][off[6]:off[7]].tobytes() == k6.tobytes() and np.array_equal(r1["desc"][off[6]:off[7]], d6)
-    # (3) cross-camera top-2 of a sample of features == popcount over every other camera's descriptors
-    desc = r1["desc"]; bi, bd, sd = r1["cross"]
-    rng = np.random.RandomState(3)
-    for g in rng.choice(len(desc), 60, replace=False):
-        c = int(np.searchsorted(off, g, side="right") - 1)
-        others = np.concatenate([desc[:off[c]], desc[off[c + 1]:]])
-        d = np.unpackbits(others ^ desc[g], axis=1).sum(1)
-        o = np.argsort(d, kind="stable")
-        assert bd[g] == d[o[0]] and sd[g] == d[o[1]] and bi[g] == o[0]
-    # (4) temporal matches: claimed pairs respect TH_HIGH, the level window and the search radius
-    q = pipeline.make_queries((r0["kps"], r0["desc"], r0["depth"], np.repeat(np.arange(NC, dtype=np.int32), r0["counts"])),
-                              oracle.tables(NF)["scale"])
-    mo = r1["match_of_feature"]
-    hit = np.nonzero(mo >= 0)[0]
-    assert len(hit) == r1["n_temporal"] and len(hit) > 0.5 * len(mo)
-    for g in hit[:: max(1, len(hit) // 300)]:
-        Q = q[mo[g]]; k = r1["kps"][g]
-        assert np.unpackbits(Q["desc"] ^ desc[g]).sum() <= 100
-        assert abs(k["x"] - Q["u"]) < Q["radius"] and abs(k["y"] - Q["v"]) < Q["radius"]
-        assert Q["min_level"] <= k["octave"] <= Q["max_level"]
-        assert Q["cam"] == int(np.searchsorted(off, g, side="right") - 1)
-    # (5) determinism: a second front end reproduces every byte
+    # determinism: a second front end reproduces every byte
     b = run()
     for x, y in zip(a, b):
         assert x["kps"].tobytes() == y["kps"].tobytes() and np.array_equal(x["desc"], y["desc"])
@@ -318,6 +301,36 @@ def test_results_consumed_in_place_are_the_same_arrays():
         exp = ofe.step(imgs)
         assert got["n_cross"] >= 0
         assert_same_step(got.materialise(), exp)
+    fe.close()
+
+
+def test_recycled_device_buffer_with_a_generation_is_extracted_again():
+    """A device image cannot be fingerprinted from the host: a caller that recycles HBM buffers says so with
+    orbf_image::generation (the frame's sequence number).  The extraction that ran ahead on a buffer's OLD content is then
+    not served to the step that arrives with the buffer refilled under a new generation; the same (pointer, generation)
+    still rides the prefetch."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline, rt
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    W, H = 320, 240
+    params = [m.ExtractorParams(nfeatures=300), m.ExtractorParams(nfeatures=150)]
+    fe = pipeline.FrontEnd(params, W, H)
+    ofe = OracleFrontEnd(params, W, H)
+    frames = [[synth.image(c, t, W, H) for c in range(2)] for t in range(5)]
+    ring = [[rt.DeviceBuffer(W * H) for c in range(2)] for t in range(2)]      # two reusable HBM buffers per camera
+    def fill(slot, t):
+        for c in range(2):
+            ring[slot][c].upload(frames[t][c])
+    def args(slot, gen):
+        return [(ring[slot][c].ptr, W, gen) for c in range(2)]
+    fill(0, 0); fill(1, 1)
+    assert_same_step(fe.step(args(0, 1), resident=True, next_images=args(1, 2)), ofe.step(frames[0]))   # frame 1 runs ahead
+    assert_same_step(fe.step(args(1, 2), resident=True, next_images=args(0, 1)), ofe.step(frames[1]))   # served from the prefetch; slot 0 (frame 0) announced again
+    rt.device_sync()
+    fill(0, 3)                                                         # ... the caller refills slot 0 with frame 3, generation 4
+    assert_same_step(fe.step(args(0, 4), resident=True), ofe.step(frames[3]))                             # must see frame 3
+    fill(1, 4)
+    assert_same_step(fe.step(args(1, 5), resident=True), ofe.step(frames[4]))
     fe.close()
 
 
@@ -399,6 +412,36 @@ def test_refilled_host_buffer_is_extracted_again_not_served_stale():
     assert_same_step(fe.step(ring[1]), ofe.step(frames[3]))                            # the step must see frame 3
     assert_same_step(fe.step(ring[2], next_images=ring[0]), ofe.step(frames[2]))       # unchanged buffers still ride the prefetch
     assert_same_step(fe.step(ring[0]), ofe.step(frames[0]))
+    fe.close()
+
+
+def test_recycled_device_buffer_with_a_generation_is_extracted_again():
+    """A device image cannot be fingerprinted from the host: a caller that recycles HBM buffers says so with
+    orbf_image::generation (the frame's sequence number).  The extraction that ran ahead on a buffer's OLD content is then
+    not served to the step that arrives with the buffer refilled under a new generation; the same (pointer, generation)
+    still rides the prefetch."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline, rt
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    W, H = 320, 240
+    params = [m.ExtractorParams(nfeatures=300), m.ExtractorParams(nfeatures=150)]
+    fe = pipeline.FrontEnd(params, W, H)
+    ofe = OracleFrontEnd(params, W, H)
+    frames = [[synth.image(c, t, W, H) for c in range(2)] for t in range(5)]
+    ring = [[rt.DeviceBuffer(W * H) for c in range(2)] for t in range(2)]      # two reusable HBM buffers per camera
+    def fill(slot, t):
+        for c in range(2):
+            ring[slot][c].upload(frames[t][c])
+    def args(slot, gen):
+        return [(ring[slot][c].ptr, W, gen) for c in range(2)]
+    fill(0, 0); fill(1, 1)
+    assert_same_step(fe.step(args(0, 1), resident=True, next_images=args(1, 2)), ofe.step(frames[0]))   # frame 1 runs ahead
+    assert_same_step(fe.step(args(1, 2), resident=True, next_images=args(0, 1)), ofe.step(frames[1]))   # served from the prefetch; slot 0 (frame 0) announced again
+    rt.device_sync()
+    fill(0, 3)                                                         # ... the caller refills slot 0 with frame 3, generation 4
+    assert_same_step(fe.step(args(0, 4), resident=True), ofe.step(frames[3]))                             # must see frame 3
+    fill(1, 4)
+    assert_same_step(fe.step(args(1, 5), resident=True), ofe.step(frames[4]))
     fe.close()
 
 

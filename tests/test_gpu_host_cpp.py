@@ -510,7 +510,7 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
         q = np.frombuffer(qb, QUERY_DTYPE, n, off).copy(); off += 68 * n
         src = np.frombuffer(qb, np.int32, n, off).copy(); off += 4 * n
         sets.append((q, src))
-    assert len(sets) == 10 and list(windows) == [4]
+    assert len(sets) == 11 and list(windows) == [4]
     new_sets = sets[4:8]; sets = sets[:4] + sets[8:]
     buf = (tmp_path / "out.bin").read_bytes(); off = 0
 
@@ -523,6 +523,7 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
     n8 = take(1)[0]; got_vn12 = take(nA[0]); got_prev = take(2 * nA[0]).view(np.float32).reshape(-1, 2)
     n4 = take(1)[0]; got_kb = take(sum(nB)); rep_bad = take(2 * len(pool)).reshape(-1, 2)
     n5 = take(1)[0]; got_ka = take(sum(nA)); got_replace = take(len(loop_ids))
+    n9 = take(1)[0]; got_ka1 = take(sum(nA)); got_replace1 = take(len(loop_ids))
 
     # ---- relocalisation
     q, src = sets[0]
@@ -602,6 +603,25 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
             kam[bi[k_]] = loop_ids[src[k_]]
         nf2 += 1
     assert n5 == nf2 and np.array_equal(got_ka, kam) and np.array_equal(got_replace, repl) and n5 > 150
+    # ---- Fuse_cam1 (reference :2518-2813): the same fuse through camera 1 only, on the keyframe as it was before any fuse
+    q, src = sets[6]
+    assert len(q) > 200 and np.isnan(q["ur"]).all() and (q["cam"] == 0).all()
+    bi, bd = oracle.project_best(OFa, q, None, 0)
+    kam = idsA.copy(); repl = np.full(len(loop_ids), -1); nf3 = 0
+    for k_ in range(len(q)):
+        if bi[k_] < 0 or bd[k_] > 50:
+            continue
+        other = kam[bi[k_]]
+        if other >= 0:
+            if not bad[other]:
+                repl[src[k_]] = other
+        else:
+            kam[bi[k_]] = loop_ids[src[k_]]
+        nf3 += 1
+    assert n9 == nf3 and np.array_equal(got_ka1, kam) and np.array_equal(got_replace1, repl) and n9 > 100
+    assert (bi[(bi >= 0)] < nA[0]).all()                         # camera-1 features only
+    xyz = np.array([pool[loop_ids[i]]["xyz"] for i in src]); xc = xyz @ RS.T + tS
+    assert np.abs(q["u"] - (fx * xc[:, 0] / xc[:, 2] + cx)).max() < 2e-2 and np.abs(q["v"] - (fy * xc[:, 1] / xc[:, 2] + cy)).max() < 2e-2
 
     # ---- two-camera loop search (reference :566-750): windows in both cameras of KA, best over both
     (q, src), w2 = new_sets[0], windows[4]
@@ -651,3 +671,30 @@ def test_cpp_dropin_call_pattern_is_bit_exact(tmp_path, batch):
     import dropin_leg
     r = dropin_leg.run(640, 480, (1000, 500), T=4, iters=6, warmup=1, batch=batch, workdir=str(tmp_path))
     assert "bit-exact" in r["parity"] and r["dropin_fps"] > 0
+
+
+def test_scalar_pose_algebra_equals_the_cv_mat_expressions():
+    """The per-frame tracking search computes R * x + t with a scalar routine instead of three cv::Mat temporaries per point
+    (host/ORBmatcher.cc: apply_rt): bit-identical to the cv::Mat expressions on 10^6 random poses x points, chained
+    application (camera 2 behind camera 1) included.  No GPU."""
+    out = subprocess.check_output([BIN, "rt", "1000000"]).decode()
+    assert "1000000 poses x points, 0 differing floats" in out
+
+
+@pytest.mark.gpu
+def test_cpp_matcher_called_from_three_threads_at_once(tmp_path):
+    """The reference calls ORBmatcher concurrently from Tracking (src/Tracking.cc:1267), LocalMapping (src/LocalMapping.cc:361,741)
+    and LoopClosing (src/LoopClosing.cc:362,445,536).  The three class-level cases of this file (tracking searches | BoW searches +
+    SearchForTriangulation | relocalisation / loop searches, both SearchBySim3 forms, both Fuse overloads) -- each verified
+    against the oracle first by its own test body -- then run 200 times each on three threads at once: every iteration's
+    output must equal the case run alone, and no device call may fail."""
+    dirs = [tmp_path / k for k in ("match", "bow", "f4")]
+    for d in dirs:
+        d.mkdir()
+    test_cpp_orbmatcher_search_by_projection_overloads(dirs[0], 1)
+    test_cpp_vocabulary_and_bow_searches(dirs[1], 1, 0, (1, 1))
+    test_cpp_remaining_projection_searches(dirs[2], 1)
+    env = {k: v for k, v in os.environ.items() if k != "MORB_DUMP_QUERIES"}
+    out = subprocess.run([BIN, "threads"] + [str(d / "case.bin") for d in dirs] + ["200"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "3 x 200 concurrent iterations, 0 mismatches, 0 errors, 0 failed device calls" in out.stdout
