@@ -90,6 +90,13 @@ __device__ const signed char d_pattern[256][4] = {
 // at bits 4v..4v+3): a register operand instead of a memory load per use
 constexpr unsigned long long UMAX_NIBBLES = 0x3689abcddeeeffffull;
 
+// block b of a 1-D grid of n -> position in XCD-major order: XCD x = b % 8 owns the contiguous positions
+// [x * (n / 8) + min(x, n % 8), ...) and walks them in launch order (see k_fast_cells)
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+    const int x = b & 7, i = b >> 3, per = n >> 3, rem = n & 7;
+    return x * per + min(x, rem) + i;
+}
+
 // ------------------------------------------------------------------------------------------------ K0
 // Level 0 of every camera whose image is already in HBM, in ONE launch (a 2-D copy per camera costs a launch each).
 struct IngestArgs { const uint8_t* src[64]; int stride[64]; };
@@ -256,7 +263,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
     __shared__ unsigned int s_max[CELL_MAX * CELL_MAX / 32];  // bit p: pixel p is a strict local maximum with a score >= minTh
     __shared__ int s_any, s_nsurv;
 
-    const int cell = blockIdx.x;
+    // Workgroups go to the 8 XCDs round robin, each XCD has an L2 of its own, and neighbouring cells share the 128-byte lines
+    // of their halos: workgroup b takes cell (b % 8) * (cells / 8) + b / 8, so that an XCD works through ONE contiguous run of
+    // cells (a band of rows of a level) instead of every eighth cell of all of them (FETCH_SIZE of this kernel: 4.4 x the
+    // pyramid bytes before -- every line was pulled into several L2s).  Affinity only: any placement computes the same.
+    const int cell = xcd_contiguous(blockIdx.x, gridDim.x);
     const int2 cm = cell_map[cell];  // {cam * max_levels + level, local cell index}
     const LevelInfo Lv = L[cm.x];
     const int cam = cm.x / max_levels;
@@ -1294,7 +1305,8 @@ struct orbx_extractor {
     DevBuf<SelKp> d_sel, d_sel_oct;
     DevBuf<uint32_t> d_cand_dev;
     DevBuf<int> d_level_cnt_dev, d_sel_cnt, d_oct_status, d_n_out;
-    bool pinned_ingest = true;        // page-locked host images are read by k_ingest directly (MORB_PINNED_INGEST=0: hipMemcpy2DAsync)
+    bool pinned_ingest = false;       // page-locked host images are read by k_ingest directly (orbx_set_pinned_ingest) instead of hipMemcpy2DAsync
+    bool pinned_ingest_env = true;    // MORB_PINNED_INGEST=0: never
     int oct_max_keys = OCT_NK;        // candidates per (camera, level) the device quadtree takes (MORB_OCT_MAX_KEYS lowers it: tests of the fallback)
     int last_path = 0;                // inspection: 0 device quadtree, 2 host quadtree
     DevBuf<unsigned short> d_slot_blk;
@@ -1537,7 +1549,7 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     { const char* e = getenv("MORB_HOST_OCTREE"); ex->device_octree = !(e && atoi(e) != 0); }
     { const char* e = getenv("MORB_CHAIN_GRAPH"); ex->use_graph = !(e && atoi(e) == 0); }
     ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
-    { const char* e = getenv("MORB_PINNED_INGEST"); ex->pinned_ingest = !(e && atoi(e) == 0); }
+    { const char* e = getenv("MORB_PINNED_INGEST"); ex->pinned_ingest_env = !(e && atoi(e) == 0); }
     if (const char* e = getenv("MORB_OCT_MAX_KEYS")) ex->oct_max_keys = std::min(OCT_NK, std::max(1, atoi(e)));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
@@ -1616,10 +1628,10 @@ static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int wi
             return ORB_OK;
         }
     }
-    // A page-locked image is device-visible as it is: the ingest kernel of the run reads it across PCIe, all cameras in ONE
-    // launch (in stream order, like the DMA it replaces: a pitched hipMemcpy2DAsync per camera is a blit kernel of the runtime
-    // each plus ~10 us of host time).  MORB_PINNED_INGEST=0 keeps the copies.
-    if (pinned && ex->pinned_ingest && attr.devicePointer) {
+    // A page-locked image is device-visible as it is: when the caller asks for it (orbx_set_pinned_ingest: a run somebody
+    // is waiting for), the ingest kernel of the run reads it across PCIe, all cameras in ONE launch (in stream order, like the
+    // copy it replaces: a pitched hipMemcpy2DAsync per camera costs ~10 us of host time each).  MORB_PINNED_INGEST=0: never.
+    if (pinned && ex->pinned_ingest && ex->pinned_ingest_env && attr.devicePointer) {
         ex->ingest.src[cam] = static_cast<const uint8_t*>(attr.devicePointer); ex->ingest.stride[cam] = stride; ex->ingest_pending = true;
         return ORB_OK;
     }
@@ -1712,6 +1724,12 @@ int orbx_record_done(orbx_extractor* ex) {   // the completion event of the most
     MORB_ARG(ex && ex->inflight > 0);
     MORB_HIP(hipSetDevice(ex->device));
     MORB_HIP(hipEventRecord(ex->ev_done[(ex->run_seq - 1u) & 1u], ex->stream));
+    return ORB_OK;
+}
+
+int orbx_set_pinned_ingest(orbx_extractor* ex, int on) {
+    MORB_ARG(ex != nullptr);
+    ex->pinned_ingest = on != 0;
     return ORB_OK;
 }
 

@@ -43,6 +43,8 @@ extern "C" int orbx_set_chain_graph(orbx_extractor* ex, int on);
 // on = 1: asynchronous runs do not record their completion event; the caller does (orbx_record_done), after it has enqueued
 // the run's consumer on the same stream -- the event then no longer stands between the chain and that consumer.
 extern "C" int orbx_set_defer_done(orbx_extractor* ex, int on);
+// 1: page-locked host images handed to orbx_upload are read by the run's ingest kernel directly (no copy per camera)
+extern "C" int orbx_set_pinned_ingest(orbx_extractor* ex, int on);
 extern "C" int orbx_record_done(orbx_extractor* ex);
 // orbx_finish without the wait on the completion event, for a caller that has already seen the results of GPU work ordered
 // behind the oldest run in flight (orbf_step_end after it watched the resolve's result words arrive)

@@ -386,6 +386,42 @@ __device__ __forceinline__ mm_i32x4 mt_expand16(uint32_t bits) {  // 16 bits -> 
 
 __device__ __forceinline__ uint32_t mt_umed3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
 
+// Pieces shared by the two top-2 kernels.  Round 3: a tile's 64 references are two halves of 32 (a = 0, 1) with an accumulator
+// pair each; while the 16 MFMAs of one half run, the wave works through the 2 x 16 sort keys per lane of the half before --
+// in rounds 1-2 a wave issued all 32 MFMAs of a tile and only then started on its 128 keys, so the matrix pipe and the vector
+// ALU took turns (0.41 of the int8 peak at two waves per SIMD; the two accumulator sets of the pipelined form are live at
+// different times, the kernel needs 166 registers instead of 229 = three waves per SIMD, and 32 000 x 32 000 went 252 -> 199 us).
+struct Top2Run { uint32_t kb[2], ks2[2]; int where[2]; };   // per query group g: best key, second key, (block << 5 | row) of the best
+constexpr uint32_t MT_KEY_NONE = 256u << 6;
+
+__device__ __forceinline__ void mt_mfma_half(mm_i32x16 (&acc)[2], const mm_i32x4* __restrict__ tile, int a, int lane,
+                                             const mm_i32x4 (&bq)[2][8], const mm_i32x16& cinit) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const mm_i32x4 af = tile[(a * 8 + ks) * 64 + lane];
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bq[0][ks], ks ? acc[0] : cinit, 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bq[1][ks], ks ? acc[1] : cinit, 0, 0, 0);
+    }
+}
+
+// the 16 keys of one 32 x 32 block per query group; out(g, e) = "this row does not count for the queries of group g"
+template <class OutFn>
+__device__ __forceinline__ void mt_keys(Top2Run& R, const mm_i32x16 (&acc)[2], int blk, OutFn out) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t before = R.kb[g];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t key = out(g, e) ? MT_KEY_NONE : (uint32_t)acc[g][e];
+            R.ks2[g] = mt_umed3(R.kb[g], R.ks2[g], key);
+            R.kb[g] = min(R.kb[g], key);
+        }
+        R.where[g] = R.kb[g] != before ? ((blk << 5) | (int)(R.kb[g] & 31u)) : R.where[g];
+        R.kb[g] &= ~63u;
+    }
+}
+struct MtAll { __device__ __forceinline__ bool operator()(int, int) const { return false; } };
+
 __global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_top2_mfma(const uint32_t* __restrict__ q, int nq,
                                                                     const uint32_t* __restrict__ r, int nr, int slice_len,
                                                                     int* __restrict__ p_idx, int* __restrict__ p_best,
@@ -424,56 +460,33 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_top2_mfma(const uint3
         base[96] = mt_expand16(w.y >> 16);
     };
 
-    constexpr uint32_t KEY_NONE = 256u << 6;
-    uint32_t kb[2] = {KEY_NONE, KEY_NONE}, ks2[2] = {KEY_NONE, KEY_NONE};
-    int where[2] = {-1, -1};  // (block << 5 | row) of the best key, block = 2 * tile + a
+    Top2Run R{{MT_KEY_NONE, MT_KEY_NONE}, {MT_KEY_NONE, MT_KEY_NONE}, {-1, -1}};
     deposit(0, fetch(0));
     uint2 nxt = fetch(1);
     __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
+    mm_i32x16 acc0[2], acc1[2];
+    mt_mfma_half(acc0, s_tile[0], 0, lane, bq, cinit);
+    for (int t = 0; t + 1 < n_tiles; ++t) {   // every tile but the last one is full
         const int buf = t & 1;
-        mm_i32x16 acc[2][2];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const mm_i32x4 a0 = s_tile[buf][ks * 64 + lane], a1 = s_tile[buf][(8 + ks) * 64 + lane];
-            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][ks], ks ? acc[0][0] : cinit, 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][ks], ks ? acc[0][1] : cinit, 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[0][ks], ks ? acc[1][0] : cinit, 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[1][ks], ks ? acc[1][1] : cinit, 0, 0, 0);
-        }
+        mt_mfma_half(acc1, s_tile[buf], 1, lane, bq, cinit);       // second half of tile t on the matrix cores ...
+        mt_keys(R, acc0, 2 * t, MtAll());                          // ... the keys of its first half on the vector ALU
         deposit(buf ^ 1, nxt);
-        nxt = fetch(t + 2);
-        const int valid = s1 - s0 - t * MM_R_TILE;  // references of this tile inside the slice (>= 64 except on the last tile)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const uint32_t before = kb[g];
-                if (valid >= MM_R_TILE) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const uint32_t key = (uint32_t)acc[a][g][e];
-                        ks2[g] = mt_umed3(kb[g], ks2[g], key);
-                        kb[g] = min(kb[g], key);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int local = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const uint32_t key = local < valid ? (uint32_t)acc[a][g][e] : KEY_NONE;
-                        ks2[g] = mt_umed3(kb[g], ks2[g], key);
-                        kb[g] = min(kb[g], key);
-                    }
-                }
-                where[g] = kb[g] != before ? (((2 * t + a) << 5) | (int)(kb[g] & 31u)) : where[g];
-                kb[g] &= ~63u;
-            }
         __syncthreads();
+        nxt = fetch(t + 2);
+        mt_mfma_half(acc0, s_tile[buf ^ 1], 0, lane, bq, cinit);   // first half of tile t + 1 | keys of the second half of tile t
+        mt_keys(R, acc1, 2 * t + 1, MtAll());
+    }
+    {   // the last tile (its first half is in acc0): rows past the end of the slice do not count
+        const int t = n_tiles - 1;
+        const int valid = s1 - s0 - t * MM_R_TILE;
+        mt_mfma_half(acc1, s_tile[t & 1], 1, lane, bq, cinit);
+        mt_keys(R, acc0, 2 * t, [&](int, int e) { return (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
+        mt_keys(R, acc1, 2 * t + 1, [&](int, int e) { return 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
     }
     // the two half-waves hold disjoint references of the same query: full keys distance << 16 | index decide
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const uint32_t mine_b = ((kb[g] >> 6) << 16) | (uint32_t)(where[g] & 0xffff), mine_s = (ks2[g] >> 6) << 16 | 0xffffu;
+        const uint32_t mine_b = ((R.kb[g] >> 6) << 16) | (uint32_t)(R.where[g] & 0xffff), mine_s = (R.ks2[g] >> 6) << 16 | 0xffffu;
         const uint32_t ob = (uint32_t)__shfl_xor((int)mine_b, 32), os = (uint32_t)__shfl_xor((int)mine_s, 32);
         const uint32_t nb = min(mine_b, ob), ns = min(max(mine_b, ob), min(mine_s, os));
         const int qrow = q0 + g * 32 + c;
@@ -591,52 +604,50 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __r
     }
 }
 
-// The same search on the matrix cores: k_hamming_top2_mfma's tiling (a wave keeps 64 queries as B fragments, the workgroup
-// expands 64 references per step into LDS, the accumulators come out as sort keys distance << 6 | row) with queries and
-// references taken from ONE descriptor list and the rows of a query's OWN camera left out:
-//   * a tile that lies inside the own camera of every query of the wave is skipped altogether (no MFMA, no key updates) -- 64
-//     consecutive queries nearly always belong to one camera, so 1/n_cams of all pairs costs nothing;
-//   * a tile that touches the own segment of some query of the wave takes the masked path (those rows enter as KEY_NONE,
-//     exactly like rows past the end of the slice); every other tile takes the unmasked path of the generic kernel;
-//   * the reported index is the position in the concatenation of the OTHER cameras (index minus the own count behind it).
+// The same search on the matrix cores: k_hamming_top2_mfma's pipelined walk with queries and references taken from ONE
+// descriptor list and the rows of a query's OWN camera left out.  Round 3: nothing is masked any more --
+//   * a workgroup's 256 queries come from ONE camera (query blocks are dealt camera by camera: camera c holds
+//     ceil(its queries / 256) blocks, the last one partly filled), so the whole workgroup has the same own segment [seg0, seg1);
+//   * the references it walks are the concatenation of the OTHER cameras: position v of that list is row v of the descriptor
+//     list in front of the own segment and row v + (seg1 - seg0) behind it.  Only the loads know (every lane fetches its own
+//     row); slices, tiles and keys live in the list of the others, which is also what the reported index is defined in.
+// So the kernel body IS the generic one (166 registers, three waves per SIMD); rounds 1-2 skipped own-camera tiles and
+// masked the rows of boundary tiles per key, which cost a second code path and 230 registers.
 // Counts known only on the device come through d_range = {features, first query, queries}; the launch is then sized for the
-// capacity, slices beyond the features produce (256, 256, -1) partials and query blocks beyond the queries return at once.
-// grid.x = reference slices (partials for k_top2_merge when > 1), grid.y = 256 queries.
-// bx = reference slice, by = block of 256 queries
+// capacity (grid.y = cross_query_blocks(capacity, cameras)), slices beyond the references produce (256, 256, -1) partials and
+// query blocks beyond the queries return at once.  grid.x = reference slices (partials for k_top2_merge when > 1).
+// bx = reference slice, by = query block (camera-major)
 __device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * 8 * 64], const uint32_t* __restrict__ desc, int n_total,
                                                      const int* __restrict__ cam_start, int n_cams, int q_off, int nq, int slice_len,
                                                      int* __restrict__ p_idx, int* __restrict__ p_best, int* __restrict__ p_second,
                                                      const int* __restrict__ d_range, const int bx, const int by) {
     if (d_range) { n_total = d_range[0]; q_off = d_range[1]; nq = d_range[2]; }
-    if (by * MM_Q_PER_BLOCK >= nq) return;   // (uniform over the workgroup; implies nq >= 1 and n_total >= 1 below)
+    // block `by` -> (camera, first query of the block, end of the camera's queries); the queries are the features [q_off, q_off + nq)
+    int seg0 = 0, seg1 = 0, qb0 = 0, qb1 = -1;
+    for (int cam = 0, before = 0; cam < n_cams; ++cam) {
+        const int c0 = cam_start[cam], c1 = cam_start[cam + 1];
+        const int lo = max(c0, q_off), hi = min(c1, q_off + nq);
+        const int nb = hi > lo ? (hi - lo + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK : 0;
+        if (by < before + nb) { seg0 = c0; seg1 = c1; qb0 = lo + (by - before) * MM_Q_PER_BLOCK; qb1 = hi; break; }
+        before += nb;
+    }
+    if (qb1 < 0) return;   // (uniform over the workgroup: a block beyond the queries)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int q0 = by * MM_Q_PER_BLOCK + wave * 64;
-    const uint32_t* __restrict__ q = desc + (size_t)q_off * 8;
-    const uint32_t* __restrict__ r = desc;
-    const int nr = n_total;
+    const int q0 = qb0 + wave * 64;                 // first query of the wave (index in the descriptor list)
+    const int own = seg1 - seg0, nr = n_total - own;   // nr references: the other cameras
 
     mm_i32x4 bq[2][8];
-    int seg0[2], seg1[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const int qi = min(q0 + g * 32 + c, nq - 1);
-        const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
+        const int qi = min(q0 + g * 32 + c, qb1 - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(desc + (size_t)qi * 8);
         const uint4 lo = p[0], hi = p[1];
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) bq[g][ks] = mm_expand16(h ? (w[ks] >> 16) : (w[ks] & 0xffffu));
-        const int qc = q_off + qi;
-        int cam = 0;
-        while (cam + 1 < n_cams && qc >= cam_start[cam + 1]) ++cam;
-        seg0[g] = cam_start[cam]; seg1[g] = cam_start[cam + 1];
     }
-    // the union of the wave's own segments: [seg_lo, seg_hi); `one_seg`: every query of the wave has the same own camera
-    const int first0 = __builtin_amdgcn_readfirstlane(seg0[0]), first1 = __builtin_amdgcn_readfirstlane(seg1[0]);
-    const bool one_seg = __all(seg0[0] == first0 && seg0[1] == first0 && seg1[0] == first1 && seg1[1] == first1);
-    const int seg_lo = (int)wave_min_u32((unsigned)min(seg0[0], seg0[1]));
-    const int seg_hi = (int)(0x7fffffffu - wave_min_u32(0x7fffffffu - (unsigned)max(seg1[0], seg1[1])));
     mm_i32x16 cinit;
 #pragma unroll
     for (int e = 0; e < 16; ++e) cinit[e] = 8192 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -644,8 +655,9 @@ __device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * 8
     const int s0 = bx * slice_len, s1 = min(nr, s0 + slice_len);  // slice_len is a multiple of 64
     const int n_tiles = s1 > s0 ? (s1 - s0 + MM_R_TILE - 1) / MM_R_TILE : 0;
     auto fetch = [&](int t) {
-        const int rr = max(0, min(s0 + min(t, n_tiles - 1) * MM_R_TILE + lane, nr - 1));
-        return *reinterpret_cast<const uint2*>(r + (size_t)rr * 8 + wave * 2);
+        const int v = max(0, min(s0 + min(t, n_tiles - 1) * MM_R_TILE + lane, nr - 1));   // rows past the end repeat the last one, masked below
+        const int rr = v < seg0 ? v : v + own;
+        return *reinterpret_cast<const uint2*>(desc + (size_t)min(rr, n_total - 1) * 8 + wave * 2);
     };
     auto deposit = [&](int buf, uint2 w) {
         mm_i32x4* base = &s_tile[buf][(h * 8 + wave * 2) * 64 + c];
@@ -654,100 +666,50 @@ __device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * 8
         base[64] = mt_expand16(w.y & 0xffffu);
         base[96] = mt_expand16(w.y >> 16);
     };
-
-    constexpr uint32_t KEY_NONE = 256u << 6;
-    uint32_t kb[2] = {KEY_NONE, KEY_NONE}, ks2[2] = {KEY_NONE, KEY_NONE};
-    int where[2] = {-1, -1};  // (block << 5 | row) of the best key, block = 2 * tile + a
-    if (n_tiles > 0) deposit(0, fetch(0));
-    uint2 nxt = fetch(1);
-    __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
-        const int tj0 = s0 + t * MM_R_TILE;                          // first reference of the tile
-        const int valid = s1 - tj0;                                  // references of this tile inside the slice
-        const bool touches = tj0 < seg_hi && tj0 + MM_R_TILE > seg_lo;  // wave-uniform
-        const bool skip = one_seg && tj0 >= seg_lo && tj0 + min(valid, MM_R_TILE) <= seg_hi;   // the whole tile is the wave's own camera
-        if (!skip) {
-            mm_i32x16 acc[2][2];
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const mm_i32x4 a0 = s_tile[buf][ks * 64 + lane], a1 = s_tile[buf][(8 + ks) * 64 + lane];
-                acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][ks], ks ? acc[0][0] : cinit, 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][ks], ks ? acc[0][1] : cinit, 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[0][ks], ks ? acc[1][0] : cinit, 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[1][ks], ks ? acc[1][1] : cinit, 0, 0, 0);
-            }
-            deposit(buf ^ 1, nxt);
-            nxt = fetch(t + 2);
-            // 0: nothing of this tile is anybody's own camera (the usual case); 1: the tile lies inside the union of the wave's
-            // own segments but crosses none of their ends -- a query then takes the whole tile or none of it (one select per
-            // key; a wave straddling two cameras spends two whole slices here); 2: a segment ends inside the tile, or the slice
-            // does: every row is tested
-            int mode = 0;
-            if (valid < MM_R_TILE) mode = 2;
-            else if (touches) {
-                const int te = tj0 + MM_R_TILE;
-                const bool cut = (seg0[0] > tj0 && seg0[0] < te) || (seg1[0] > tj0 && seg1[0] < te) ||
-                                 (seg0[1] > tj0 && seg0[1] < te) || (seg1[1] > tj0 && seg1[1] < te);
-                mode = __any(cut) ? 2 : 1;
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const uint32_t before = kb[g];
-                    if (mode == 0) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const uint32_t key = (uint32_t)acc[a][g][e];
-                            ks2[g] = mt_umed3(kb[g], ks2[g], key);
-                            kb[g] = min(kb[g], key);
-                        }
-                    } else if (mode == 1) {
-                        const bool own = tj0 >= seg0[g] && tj0 < seg1[g];   // (no end inside the tile: the whole tile is in or out)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const uint32_t key = own ? KEY_NONE : (uint32_t)acc[a][g][e];
-                            ks2[g] = mt_umed3(kb[g], ks2[g], key);
-                            kb[g] = min(kb[g], key);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int local = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                            const int j = tj0 + local;
-                            const bool out = local >= valid || (j >= seg0[g] && j < seg1[g]);   // past the slice, or the query's own camera
-                            const uint32_t key = out ? KEY_NONE : (uint32_t)acc[a][g][e];
-                            ks2[g] = mt_umed3(kb[g], ks2[g], key);
-                            kb[g] = min(kb[g], key);
-                        }
-                    }
-                    where[g] = kb[g] != before ? (((2 * t + a) << 5) | (int)(kb[g] & 31u)) : where[g];
-                    kb[g] &= ~63u;
-                }
-        } else {
-            deposit(buf ^ 1, nxt);
-            nxt = fetch(t + 2);
-        }
+    Top2Run R{{MT_KEY_NONE, MT_KEY_NONE}, {MT_KEY_NONE, MT_KEY_NONE}, {-1, -1}};
+    if (n_tiles > 0) {
+        deposit(0, fetch(0));
+        uint2 nxt = fetch(1);
         __syncthreads();
+        mm_i32x16 acc0[2], acc1[2];
+        mt_mfma_half(acc0, s_tile[0], 0, lane, bq, cinit);
+        for (int t = 0; t + 1 < n_tiles; ++t) {   // every tile but the last one is full
+            const int buf = t & 1;
+            mt_mfma_half(acc1, s_tile[buf], 1, lane, bq, cinit);       // second half of tile t on the matrix cores ...
+            mt_keys(R, acc0, 2 * t, MtAll());                          // ... the keys of its first half on the vector ALU
+            deposit(buf ^ 1, nxt);
+            __syncthreads();
+            nxt = fetch(t + 2);
+            mt_mfma_half(acc0, s_tile[buf ^ 1], 0, lane, bq, cinit);   // first half of tile t + 1 | keys of the second half of tile t
+            mt_keys(R, acc1, 2 * t + 1, MtAll());
+        }
+        {   // the last tile (its first half is in acc0): rows past the end of the slice do not count
+            const int t = n_tiles - 1;
+            const int valid = s1 - s0 - t * MM_R_TILE;
+            mt_mfma_half(acc1, s_tile[t & 1], 1, lane, bq, cinit);
+            mt_keys(R, acc0, 2 * t, [&](int, int e) { return (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
+            mt_keys(R, acc1, 2 * t + 1, [&](int, int e) { return 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
+        }
     }
     // the two half-waves hold disjoint references of the same query: full keys distance << 16 | index decide
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const uint32_t mine_b = ((kb[g] >> 6) << 16) | (uint32_t)(where[g] & 0xffff), mine_s = (ks2[g] >> 6) << 16 | 0xffffu;
+        const uint32_t mine_b = ((R.kb[g] >> 6) << 16) | (uint32_t)(R.where[g] & 0xffff), mine_s = (R.ks2[g] >> 6) << 16 | 0xffffu;
         const uint32_t ob = (uint32_t)__shfl_xor((int)mine_b, 32), os = (uint32_t)__shfl_xor((int)mine_s, 32);
         const uint32_t nb = min(mine_b, ob), ns = min(max(mine_b, ob), min(mine_s, os));
-        const int qrow = q0 + g * 32 + c;
-        if (h == 0 && qrow < nq) {
-            const size_t o = (size_t)bx * nq + qrow;
+        const int qi = q0 + g * 32 + c;
+        if (h == 0 && qi < qb1) {
+            const size_t o = (size_t)bx * nq + (qi - q_off);
             const int best = (int)(nb >> 16);
-            const int j = s0 + (int)(nb & 0xffffu);
             p_best[o] = best;
-            p_idx[o] = best < 256 ? (j < seg0[g] ? j : j - (seg1[g] - seg0[g])) : -1;   // index among the other cameras
+            p_idx[o] = best < 256 ? s0 + (int)(nb & 0xffffu) : -1;   // position among the other cameras
             p_second[o] = (int)min(ns >> 16, 256u);
         }
     }
 }
+
+// query blocks a launch over nq queries from n_cams cameras may need: every camera can end with a partly filled block
+__host__ __device__ inline int cross_query_blocks(int nq, int n_cams) { return (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK + n_cams; }
 
 __global__ __launch_bounds__(64 * MM_WAVES) void k_cross_top2_mfma(const uint32_t* __restrict__ desc, int n_total,
                                                                   const int* __restrict__ cam_start, int n_cams, int q_off, int nq,
@@ -795,19 +757,20 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_project_side(morb::ProjectArg
 struct Top2Plan { bool mfma; int S; int slice_len; };
 std::atomic<int> g_matrix_cores{-1};  // orbm_use_matrix_cores: -1 = environment default
 
-Top2Plan top2_plan(int nq, int nr, bool have_scratch = true) {
+Top2Plan top2_plan(int nq, int nr, bool have_scratch = true, int wgs_per_cu = 3) {
     static const int mfma_env = [] { const char* e = getenv("MORB_TOP2_MFMA"); return e ? atoi(e) : 1; }();
     const int forced = g_matrix_cores.load(std::memory_order_relaxed);
     Top2Plan p{false, 1, nr};
     if ((forced < 0 ? mfma_env : forced) && nq >= 64 && nr >= MM_R_TILE) {
-        // Two workgroups are resident per CU (229 registers): a launch runs in ceil(workgroups / slots) rounds of
-        // (tiles per slice + ~2) steps; take the slice count that minimises the product (32 000 x 32 000: 8 slices = 1000
-        // workgroups = 1.95 rounds instead of 9 slices = 2.2 rounds, i.e. three).
-        static const int slots = [] {
+        // wgs_per_cu workgroups are resident per CU (166 registers: three; the 230-register build of the camera-pair kernel:
+        // two): a launch runs in ceil(workgroups / slots) rounds of (tiles per slice + ~2) steps; take the slice count that
+        // minimises the product.
+        static const int n_cus = [] {
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            return std::max(1, cus) * 2;
+            return std::max(1, cus);
         }();
+        const int slots = n_cus * wgs_per_cu;
         const int qblocks = (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK;
         const int s_max = have_scratch ? std::min(64, std::max(1, nr / (4 * MM_R_TILE))) : 1;  // at least four tiles per slice
         double best_cost = 1e300;
@@ -826,6 +789,12 @@ Top2Plan top2_plan(int nq, int nr, bool have_scratch = true) {
     S = std::min(S, std::max(1, nr / (TOP2_WAVES * 16)));  // keep >= 16 references per wave
     p.S = have_scratch ? std::max(1, std::min(S, 64)) : 1;
     return p;
+}
+
+int top2_slices(int nq, int nr);
+// slices any variant of the camera-pair kernels may ask for (scratch sizing: the choice can change at run time)
+static int cross_slices_max(int nq, int n) {
+    return std::max(std::max(top2_plan(nq, n, true, 2).S, top2_plan(nq, n, true, 3).S), top2_slices(nq, n));
 }
 
 int launch_top2(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd,
@@ -906,7 +875,7 @@ int launch_matrix(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16
 }  // namespace
 
 int CrossOut::reserve(int nq, int n) {
-        const int S = std::max(top2_plan(nq, n).S, top2_slices(nq, n));   // (room for either form of the kernel)
+        const int S = cross_slices_max(nq, n);   // (room for either form of the kernel)
         int rc;
         if ((rc = scratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = i.reserve(nq)) || (rc = b.reserve(nq)) ||
             (rc = s.reserve(nq)))
@@ -923,7 +892,7 @@ int morb::cross_enqueue_to(hipStream_t st, const uint8_t* d_desc, int n, const i
     if (plan.mfma) {   // matrix-core form (default from one tile of work on; orbm_use_matrix_cores(0) / MORB_TOP2_MFMA=0: popcount form)
         int* p = (int*)scratch;
         int *p_idx = S > 1 ? p : o_idx, *p_best = S > 1 ? p + (size_t)S * nq : o_best, *p_second = S > 1 ? p + 2 * (size_t)S * nq : o_second;
-        hipLaunchKernelGGL(k_cross_top2_mfma, dim3(S, (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK), dim3(64 * MM_WAVES), 0, st,
+        hipLaunchKernelGGL(k_cross_top2_mfma, dim3(S, cross_query_blocks(nq, n_cams)), dim3(64 * MM_WAVES), 0, st,
                            (const uint32_t*)d_desc, n, d_cam_start, n_cams, q_off, nq, plan.slice_len, p_idx, p_best, p_second, d_n);
         if (S > 1)
             hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, o_idx, o_best,
@@ -949,7 +918,7 @@ int morb::cross_enqueue_to(hipStream_t st, const uint8_t* d_desc, int n, const i
 int morb::cross_enqueue(orbm_matcher* m, hipStream_t st, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off,
                          int nq, const int* d_n) {
     if (nq == 0) return ORB_OK;
-    const int S = std::max(top2_plan(nq, n).S, top2_slices(nq, n));   // (room for either form: the choice can change at run time)
+    const int S = cross_slices_max(nq, n);   // (room for either form: the choice can change at run time)
     int rc;
     if ((rc = m->d_cscratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = m->h_c0.reserve(nq)) ||
         (rc = m->h_c1.reserve(nq)) || (rc = m->h_c2.reserve(nq)))
@@ -965,7 +934,7 @@ bool morb::side_fusable(int nq, int n) {
 }
 
 int morb::side_reserve(orbm_matcher* m, int nq, int n) {
-    const int S = std::max(top2_plan(nq, n).S, top2_slices(nq, n));
+    const int S = cross_slices_max(nq, n);
     int rc;
     if ((rc = m->d_cscratch.reserve(std::max<size_t>((size_t)3 * S * nq * 4, 16))) || (rc = m->h_c0.reserve(nq)) ||
         (rc = m->h_c1.reserve(nq)) || (rc = m->h_c2.reserve(nq)))
@@ -985,7 +954,7 @@ int morb::launch_project_side(hipStream_t st, const morb::ProjectArgs& P, const 
     const int S = plan.S;
     X.p_idx = S > 1 ? p : J.o_idx; X.p_best = S > 1 ? p + (size_t)S * nq : J.o_best; X.p_second = S > 1 ? p + 2 * (size_t)S * nq : J.o_second;
     X.d_range = J.d_range;
-    X.n_cross = plan.S * ((nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK);
+    X.n_cross = plan.S * cross_query_blocks(nq, J.n_cams);
     X.n_project = (P.nq + 3) / 4;
     X.with_mirror = J.with_mirror ? 1 : 0;
     if (J.with_mirror) X.mirror = J.mirror;
