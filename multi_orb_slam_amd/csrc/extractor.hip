@@ -43,7 +43,7 @@ constexpr int MIN_BORDER = 16;       // EDGE_THRESHOLD - 3, :772
 constexpr int PATCH_SIZE = 31;       // :72
 constexpr int HALF_PATCH = 15;       // :73
 constexpr int CELL_MAX = 64;         // largest wCell/hCell this build stages in LDS
-constexpr int TILE_PITCH = 72;       // LDS pitch of the image tile (CELL_MAX + 6 rounded up)
+constexpr int TILE_PITCH = 76;       // LDS pitch of the image tile (CELL_MAX + 6, plus up to 3 bytes of dword alignment, rounded up to 4)
 constexpr int SCORE_PITCH = 68;      // LDS pitch of the score map (CELL_MAX + 2 rounded up)
 constexpr int MAX_LEVELS = 16;
 constexpr int COEF_BITS = 11;        // OpenCV INTER_RESIZE_COEF_BITS
@@ -207,6 +207,205 @@ __global__ __launch_bounds__(256) void k_resize2(const LevelInfo* __restrict__ L
     pyr[cam * cam_pitch + B.pyr_off + (size_t)y * B.stride + x] = (uint8_t)(v & 0xff);
 }
 
+// ------------------------------------------------------------------------------------------------ K0 + K1 in one launch
+// The whole pyramid of every camera in ONE launch (round 3).  The resize chain is a chain of dependencies only between pixels
+// that lie over each other: a workgroup takes one T x T tile of level 0 and computes the part of EVERY level that hangs below
+// it, level after level in LDS, storing what it owns.  Ownership: destination column x of level l belongs to the tile that
+// owns the column of its left source tap sx0_l(x) on level l - 1 (rows alike with row0); sx0 and row0 are monotone, so on
+// every level the tiles own disjoint runs that cover it.  To compute its run a tile needs a little more of the level above
+// than it owns there -- the right / lower tap of its last pixel, and what THAT needs one level up: a halo that only grows to
+// the right and downwards (~13 pixels on level 0 for 8 levels) and is recomputed by the neighbour that owns it.  Every pixel
+// is the same integer function of the same source bytes as in k_resize (tables xt / yt), whoever computes it.
+// Spans per (camera, level, tile column / tile row) come from the host: {r0, r1, n1} = owned [r0, r1), needed [r0, n1).
+// Seven dependent launches of 3-25 us (5 with k_ingest folded in: A.src) become one; FAST, describe and the rest read the
+// levels from HBM as before.
+MORB_PHASE_DECL(g_ph_pyr);
+#ifdef MORB_PHASE_CLOCKS
+#define PPH(i) do { if (threadIdx.x == 0 && blockIdx.x == 3 && blockIdx.y == 3 && blockIdx.z == 0) g_ph_pyr[i] = wall_clock64(); } while (0)
+#else
+#define PPH(i) do {} while (0)
+#endif
+struct PyrArgs { const uint8_t* src[64]; int stride[64]; short tx[64], ty[64], w[64], h[64]; };   // src NULL: level 0 is already in place
+constexpr int PYR_L0_DW = 8;   // dwords of the level-0 block a thread holds: (64 + 16) / 4 x (64 + 16) / 256 rounded up
+constexpr int PYR_HALO = 16;   // what a tile needs of level 0 beyond its own T x T pixels (13 for 8 levels at 1.2; checked by the host)
+constexpr int PYR_MAX_LEVELS = 12;
+
+// LDS: [x table entries of all levels (int2)] [y table entries of all levels (int4)] [the regions, level after level]
+__global__ __launch_bounds__(256) void k_pyramid_tiled(PyrArgs A, const LevelInfo* __restrict__ L, int max_levels,
+                                                       uint8_t* __restrict__ pyr, size_t cam_pitch, const int2* __restrict__ xtab,
+                                                       const int4* __restrict__ ytab, const int4* __restrict__ spans_x,
+                                                       const int4* __restrict__ spans_y, int tx_max, int ty_max, int tab_cap, int T) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
+    __shared__ int4 s_sx[PYR_MAX_LEVELS], s_sy[PYR_MAX_LEVELS], s_lv[PYR_MAX_LEVELS];   // spans; {pyr_off, stride, xtab_off, ytab_off}
+    __shared__ int s_ox[PYR_MAX_LEVELS + 1], s_oy[PYR_MAX_LEVELS + 1];   // first table entry of a level in tabx / taby
+    __shared__ int s_nlev;
+    const int cam = blockIdx.z, kx = blockIdx.x, ky = blockIdx.y;
+    if (kx >= A.tx[cam] || ky >= A.ty[cam]) return;
+    PPH(0);
+    const int tid = threadIdx.x;
+    const LevelInfo* Lc = L + cam * max_levels;
+    uint8_t* base = pyr + cam * cam_pitch;
+    int4* taby = reinterpret_cast<int4*>(pyr_lds);                       // tab_cap entries
+    int2* tabx = reinterpret_cast<int2*>(pyr_lds + (size_t)tab_cap * 16);  // tab_cap entries
+    uint8_t* regions = pyr_lds + (size_t)tab_cap * 24;
+    // ---- round trip 1, issued first: what the levels look like for this tile (one thread per level, independent loads: a load
+    // per level inside the level loop would put a memory round trip on every level's critical path)
+    int4 rt_x = make_int4(0, 0, 0, 0), rt_y = rt_x, rt_v = make_int4(0, -1, 0, 0);
+    if (tid < PYR_MAX_LEVELS && tid < max_levels) {
+        rt_x = spans_x[(size_t)(cam * max_levels + tid) * tx_max + kx]; rt_y = spans_y[(size_t)(cam * max_levels + tid) * ty_max + ky];
+        const LevelInfo Lv = Lc[tid];
+        rt_v = make_int4(Lv.pyr_off, Lv.w > 0 ? Lv.stride : -1, Lv.xtab_off, Lv.ytab_off);   // stride -1: no such level
+    }
+    // ---- level 0 first: the T x T pixels of the tile plus a fixed halo to the right and below, clipped to the image (what the
+    // tile needs of level 0 is inside it; nothing here waits for the span tables), from the source image or from level 0 itself;
+    // the tile's own pixels go to level 0 when they came from elsewhere.  These loads fly while the two table round trips run.
+    const int W0 = A.w[cam], H0 = A.h[cam];
+    int px0 = kx * T, py0 = ky * T;
+    int pnh = min(T + PYR_HALO, H0 - py0), ppw = T + PYR_HALO;
+    uint8_t* cur = regions;
+    uint32_t l0v[PYR_L0_DW];
+    int l0_ndw = 0; unsigned l0_inv = 0;
+    {
+        const uint8_t* src = A.src[cam];
+        int sstride = A.stride[cam];
+        const bool inplace = src == nullptr;
+        const int l0_stride = (W0 + 63) & ~63;   // pitch of a pyramid level: align64(width); level 0 sits at offset 0 of the camera's block
+        if (inplace) { src = base; sstride = l0_stride; }
+        const int nw = min(T + PYR_HALO, W0 - px0), ow = min(T, W0 - px0), oh = min(T, H0 - py0);
+        // (the tile's first column is a multiple of T, hence of 4: whole dwords while source rows are 4-aligned; the last
+        // partial dword of a row byte by byte, so that nothing is read past the image)
+        const bool al = ((reinterpret_cast<uintptr_t>(src) | (unsigned)sstride) & 3u) == 0;
+        const int ndw = al ? nw >> 2 : 0, rem = nw - 4 * ndw;
+        // (the dwords wait in registers: their LDS stores come behind the first table round trip, so the two overlap)
+        l0_ndw = ndw; l0_inv = ndw > 0 ? ((1u << 20) + ndw - 1) / ndw : 0;   // i / ndw for i < 2^20 / ndw
+#pragma unroll
+        for (int u = 0; u < PYR_L0_DW; ++u) {
+            const int i = tid + 256 * u;
+            l0v[u] = 0;
+            if (i < ndw * pnh) {
+                const int y = (int)(((unsigned)i * l0_inv) >> 20), k = i - y * ndw;
+                l0v[u] = reinterpret_cast<const uint32_t*>(src + (size_t)(py0 + y) * sstride + px0)[k];
+            }
+        }
+        if (rem > 0) {
+            const unsigned inv = ((1u << 20) + rem - 1) / rem;
+            for (int i = tid; i < rem * pnh; i += 256) {
+                const int y = (int)(((unsigned)i * inv) >> 20), x = 4 * ndw + i - y * rem;
+                cur[y * ppw + x] = src[(size_t)(py0 + y) * sstride + px0 + x];
+            }
+        }
+        if (!inplace) {   // straight from the source to level 0 (the same bytes once more: L2 hits, independent of the LDS copy)
+            const uint8_t* s2 = src;
+            uint8_t* dst = base;
+            const int odw = al ? ow >> 2 : 0, orem = ow - 4 * odw;
+            if (odw > 0) {
+                const unsigned inv = ((1u << 20) + odw - 1) / odw;
+                for (int i = tid; i < odw * oh; i += 256) {
+                    const int y = (int)(((unsigned)i * inv) >> 20), k = i - y * odw;
+                    reinterpret_cast<uint32_t*>(dst + (size_t)(py0 + y) * l0_stride + px0)[k] = reinterpret_cast<const uint32_t*>(s2 + (size_t)(py0 + y) * sstride + px0)[k];
+                }
+            }
+            if (orem > 0) {
+                const unsigned inv = ((1u << 20) + orem - 1) / orem;
+                for (int i = tid; i < orem * oh; i += 256) {
+                    const int y = (int)(((unsigned)i * inv) >> 20), x = 4 * odw + i - y * orem;
+                    dst[(size_t)(py0 + y) * l0_stride + px0 + x] = s2[(size_t)(py0 + y) * sstride + px0 + x];
+                }
+            }
+        }
+    }
+    // (round trip 1 lands: the per-level records go to LDS)
+    if (tid < PYR_MAX_LEVELS) { s_sx[tid] = rt_x; s_sy[tid] = rt_y; s_lv[tid] = rt_v; }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 1, ox = 0, oy = 0;
+        s_ox[0] = s_ox[1] = 0; s_oy[0] = s_oy[1] = 0;
+        while (n < PYR_MAX_LEVELS && n < max_levels && s_lv[n].y >= 0) {
+            ox += max(s_sx[n].z - s_sx[n].x, 0); oy += max(s_sy[n].z - s_sy[n].x, 0);
+            ++n;
+            s_ox[n] = ox; s_oy[n] = oy;
+        }
+        s_nlev = n;
+    }
+    __syncthreads();
+    const int nlev = s_nlev;
+    PPH(1);
+    // ---- round trip 2: everything else that does not depend on pixels -- the table entries of every level's needed columns
+    // and rows (one entry per thread and step, the level found from the prefix counts: all requests in flight together) -- and
+    // the needed region of level 0 (from the source image or from level 0 itself)
+    {
+        const int nx = s_ox[nlev], ny = s_oy[nlev];
+        for (int e = tid; e < nx + ny; e += 256) {
+            const bool isx = e < nx;
+            const int k = isx ? e : e - nx;
+            int l = 1;
+            while (l + 1 < nlev && k >= (isx ? s_ox[l + 1] : s_oy[l + 1])) ++l;
+            if (isx) tabx[k] = xtab[s_lv[l].z + s_sx[l].x + (k - s_ox[l])];
+            else taby[k] = ytab[s_lv[l].w + s_sy[l].x + (k - s_oy[l])];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PYR_L0_DW; ++u) {
+        const int i = tid + 256 * u;
+        if (i < l0_ndw * pnh) { const int y = (int)(((unsigned)i * l0_inv) >> 20), k = i - y * l0_ndw; reinterpret_cast<uint32_t*>(cur + y * ppw)[k] = l0v[u]; }
+    }
+    PPH(2);
+    int4 sx, sy;
+    __syncthreads();
+    PPH(3);
+    // ---- levels 1 ..: the needed region of level l from the needed region of level l - 1, both in LDS, over the flattened
+    // region (every lane busy whatever the region's shape); two pixels per thread and step, their LDS reads issued together
+    // (the regions of consecutive levels are different LDS ranges, which the compiler cannot know: a store behind the first
+    // pixel would hold back the loads of the second)
+    for (int l = 1; l < nlev; ++l) {
+        const int4 lv = s_lv[l];
+        sx = s_sx[l]; sy = s_sy[l];
+        const int x0 = sx.x, y0 = sy.x, nw = max(sx.z - sx.x, 0), nh = max(sy.z - sy.x, 0), pw = (nw + 3) & ~3;
+        const int ow = sx.y - sx.x, oh = sy.y - sy.x;
+        uint8_t* nxt = cur + ppw * pnh;
+        uint8_t* dst = base + lv.x + (size_t)y0 * lv.y + x0;
+        const uint8_t* srcl = cur - py0 * ppw - px0;
+        const int4* ty_l = taby + s_oy[l];
+        const int2* tx_l = tabx + s_ox[l];
+        if (nw > 0) {
+            const unsigned inv = (unsigned)sx.w;   // 2^20 / nw, rounded up (host): i / nw for i < 2^20 / nw
+            const int npx = nw * nh;
+            for (int i0 = tid; i0 < npx; i0 += 512) {
+                int vv[2], yy[2], xx[2];
+                int p[2][4], a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = min(i0 + 256 * u, npx - 1);
+                    yy[u] = (int)(((unsigned)i * inv) >> 20); xx[u] = i - yy[u] * nw;
+                    const int4 yt = ty_l[yy[u]];   // {row0, row1, beta0, beta1}
+                    const int2 xt = tx_l[xx[u]];   // {sx0 | sx1 << 16, alpha0 | alpha1 << 16}
+                    const uint8_t* s0 = srcl + yt.x * ppw;
+                    const uint8_t* s1 = srcl + yt.y * ppw;
+                    const int c0 = xt.x & 0xffff, c1 = (unsigned)xt.x >> 16;
+                    p[u][0] = s0[c0]; p[u][1] = s0[c1]; p[u][2] = s1[c0]; p[u][3] = s1[c1];
+                    a0[u] = (short)(xt.y & 0xffff); a1[u] = xt.y >> 16; b0[u] = yt.z; b1[u] = yt.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int h0 = p[u][0] * a0[u] + p[u][1] * a1[u];
+                    const int h1 = p[u][2] * a0[u] + p[u][3] * a1[u];
+                    vv[u] = ((((b0[u] * (h0 >> 4)) >> 16) + ((b1[u] * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (i0 + 256 * u < npx) {
+                        nxt[yy[u] * pw + xx[u]] = (uint8_t)vv[u];
+                        if (yy[u] < oh && xx[u] < ow) dst[(size_t)yy[u] * lv.y + xx[u]] = (uint8_t)vv[u];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        PPH(3 + l);
+        cur = nxt; px0 = x0; py0 = y0; pnh = nh; ppw = pw;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K2 + K3
 // FAST-9/16 corner score of the pixel at t: max over the 16 arcs of 9 contiguous ring pixels of the minimum
 // |centre - ring| with a common sign, minus 1 (== cornerScore<16>, threshold-independent for corners; App. A-2).
@@ -257,7 +456,7 @@ __device__ __forceinline__ bool fast_may_be_corner(const uint8_t* t, int T) {
 __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict__ L, const int2* __restrict__ cell_map,
                                                     const uint8_t* __restrict__ pyr, size_t cam_pitch, int max_levels,
                                                     int* __restrict__ cell_cnt, uint32_t* __restrict__ cell_items) {
-    __shared__ uint8_t tile[(CELL_MAX + 6) * TILE_PITCH];
+    __shared__ alignas(16) uint8_t tile_raw[(CELL_MAX + 6) * TILE_PITCH];
     __shared__ alignas(16) uint8_t score[(CELL_MAX + 2) * SCORE_PITCH];
     __shared__ unsigned short s_surv[CELL_MAX * CELL_MAX];  // pixels that pass the quick test
     __shared__ unsigned int s_max[CELL_MAX * CELL_MAX / 32];  // bit p: pixel p is a strict local maximum with a score >= minTh
@@ -283,14 +482,23 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
     }
     const uint8_t* img = pyr + cam * cam_pitch + Lv.pyr_off;
     const int tw = cw + 6, th = ch + 6;
-    // i / tw and p / cw for i < 70 * 70 by multiplication: exact because i * divisor < 2^20 (divisors <= 70)
-    const unsigned inv_tw = ((1u << 20) + tw - 1) / tw, inv_cw = ((1u << 20) + cw - 1) / cw;
+    // p / cw (and i / ndw below) for p < 70 * 70 by multiplication: exact because p * divisor < 2^20 (divisors <= 70)
+    const unsigned inv_cw = ((1u << 20) + cw - 1) / cw;
 
-    // stage the tile (origin x0-3, y0-3; always inside the level)
-    for (int i = tid; i < tw * th; i += 256) {
-        const int ty = (int)(((unsigned)i * inv_tw) >> 20), tx = i - ty * tw;
-        tile[ty * TILE_PITCH + tx] = img[(size_t)(y0 - 3 + ty) * Lv.stride + (x0 - 3 + tx)];
+    // stage the tile (origin x0-3, y0-3; always inside the level) as aligned dwords: the rows of a level start on 64-byte
+    // boundaries, so the dwords that cover columns [x0-3, x0-3+tw) are fetched whole and the tile's origin sits `sh` bytes into
+    // its LDS rows (byte loads cost an address computation, a load and an LDS store per BYTE: a ninth of this kernel's
+    // instructions; reads stay inside the row: the last dword ends before column w - 13)
+    const int sh = (x0 - 3) & 3, ndw = (sh + tw + 3) >> 2;
+    const unsigned inv_ndw = ((1u << 20) + ndw - 1) / ndw;
+    {
+        const uint8_t* src = img + (size_t)(y0 - 3) * Lv.stride + (x0 - 3 - sh);
+        for (int i = tid; i < ndw * th; i += 256) {
+            const int ty = (int)(((unsigned)i * inv_ndw) >> 20), k = i - ty * ndw;
+            reinterpret_cast<uint32_t*>(tile_raw)[ty * (TILE_PITCH / 4) + k] = *reinterpret_cast<const uint32_t*>(src + (size_t)ty * Lv.stride + 4 * k);
+        }
     }
+    const uint8_t* tile = tile_raw + sh;
     for (int i = tid; i < (ch + 2) * (SCORE_PITCH / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
     if (tid < CELL_MAX * CELL_MAX / 32) s_max[tid] = 0;
     if (tid == 0) { s_any = 0; s_nsurv = 0; }
@@ -1299,6 +1507,13 @@ struct orbx_extractor {
     DevBuf<uint8_t> d_pyr;
     DevBuf<LevelInfo> d_levels;
     DevBuf<int2> d_cell_map, d_xtab;
+    // the tiled whole-pyramid launch (k_pyramid_tiled): spans per (camera, level, tile column / row), tiles per camera, LDS need
+    DevBuf<int4> d_pyr_sx, d_pyr_sy;
+    int pyr_tx_max = 0, pyr_ty_max = 0, pyr_lds = 0, pyr_tile = 0, pyr_tab_cap = 0;
+    short pyr_tx[64] = {}, pyr_ty[64] = {};
+    bool ingest_host = false;         // a pending ingest source lives in host memory (read across PCIe)
+    bool tiled_ok = false;            // ... and this geometry fits it (LDS, halo, level count)
+    bool tiled_pyramid = true;        // MORB_TILED_PYRAMID=0: the resize chain of rounds 1-2 (k_resize2 / k_resize launches)
     DevBuf<int4> d_ytab;
     DevBuf<int> d_cell_cnt, d_cell_off;
     DevBuf<uint32_t> d_cell_items;
@@ -1427,6 +1642,72 @@ static int rebuild_geometry(orbx_extractor* ex) {
         }
         if ((size_t)pyr_off > ex->cam_pitch) { morb::set_error("image larger than the size given at create"); return ORB_E_ARG; }
     }
+    // ---- spans of the tiled whole-pyramid launch (k_pyramid_tiled): tile k of a camera owns, on level l, the destination
+    // columns whose left source tap lies in what it owns on level l - 1 ([k T, (k + 1) T) on level 0), and needs them plus the
+    // taps of everything it needs one level down; rows alike.  Small rigs take 32-pixel tiles (more workgroups: the launch is
+    // one round of short workgroups), large ones 64 (less of the halo recomputed).
+    std::vector<int4> psx, psy;
+    {
+        long long px0 = 0;
+        for (int c = 0; c < ex->n_cams; ++c) px0 += (long long)ex->cur_w[c] * ex->cur_h[c];
+        const int T = px0 <= 1500000 ? 32 : 64;
+        ex->pyr_tile = T; ex->pyr_tx_max = 1; ex->pyr_ty_max = 1; ex->pyr_lds = 0; ex->pyr_tab_cap = 0;
+        bool halo_ok = true;
+        for (int c = 0; c < ex->n_cams; ++c) {
+            ex->pyr_tx[c] = (short)((ex->cur_w[c] + T - 1) / T); ex->pyr_ty[c] = (short)((ex->cur_h[c] + T - 1) / T);
+            ex->pyr_tx_max = std::max<int>(ex->pyr_tx_max, ex->pyr_tx[c]); ex->pyr_ty_max = std::max<int>(ex->pyr_ty_max, ex->pyr_ty[c]);
+        }
+        psx.assign((size_t)ex->n_cams * ML * ex->pyr_tx_max, make_int4(0, 0, 0, 0));
+        psy.assign((size_t)ex->n_cams * ML * ex->pyr_ty_max, make_int4(0, 0, 0, 0));
+        // one axis: dims[l], first / last source index of destination d on level l (l >= 1)
+        auto axis = [&](int c, int ntiles, int tmax, bool is_x, std::vector<int4>& out) {
+            const int NL = ex->cams[c].p.nlevels;
+            auto dim = [&](int l) { const LevelInfo& Lv = ex->levels[(size_t)c * ML + l]; return is_x ? Lv.w : Lv.h; };
+            auto s0 = [&](int l, int d) { const LevelInfo& Lv = ex->levels[(size_t)c * ML + l]; return is_x ? (xt[Lv.xtab_off + d].x & 0xffff) : yt[Lv.ytab_off + d].x; };
+            auto s1 = [&](int l, int d) { const LevelInfo& Lv = ex->levels[(size_t)c * ML + l]; return is_x ? (int)((unsigned)xt[Lv.xtab_off + d].x >> 16) : yt[Lv.ytab_off + d].y; };
+            std::vector<std::vector<int> > b(NL, std::vector<int>(ntiles + 1, 0));
+            for (int k = 0; k <= ntiles; ++k) b[0][k] = std::min(k * T, dim(0));
+            for (int l = 1; l < NL; ++l) {
+                int d = 0;
+                for (int k = 0; k <= ntiles; ++k) {   // first destination whose left tap is not in front of the boundary
+                    while (d < dim(l) && s0(l, d) < b[l - 1][k]) ++d;
+                    b[l][k] = k == ntiles ? dim(l) : d;
+                }
+            }
+            for (int k = 0; k < ntiles; ++k) {
+                int n1 = b[NL - 1][k + 1];
+                for (int l = NL - 1; l >= 0; --l) {
+                    const int nn = n1 - b[l][k];   // .w: 2^20 / needed extent, rounded up (index / extent by multiplication in the kernel)
+                    out[((size_t)c * ML + l) * tmax + k] = make_int4(b[l][k], b[l][k + 1], n1, nn > 0 ? (int)(((1u << 20) + nn - 1) / nn) : 0);
+                    if (l > 0) n1 = std::max(b[l - 1][k + 1], n1 > b[l][k] ? s1(l, n1 - 1) + 1 : b[l - 1][k]);
+                }
+            }
+        };
+        for (int c = 0; c < ex->n_cams; ++c) {
+            if (ex->cur_w[c] == 0 || ex->cur_h[c] == 0) { ex->pyr_tx[c] = ex->pyr_ty[c] = 0; continue; }
+            axis(c, ex->pyr_tx[c], ex->pyr_tx_max, true, psx);
+            axis(c, ex->pyr_ty[c], ex->pyr_ty_max, false, psy);
+            for (int ky = 0; ky < ex->pyr_ty[c]; ++ky)
+                for (int kx = 0; kx < ex->pyr_tx[c]; ++kx) {
+                    int bytes = 0, tx_n = 0, ty_n = 0;
+                    for (int l = 0; l < ex->cams[c].p.nlevels; ++l) {
+                        const int4 X = psx[((size_t)c * ML + l) * ex->pyr_tx_max + kx], Y = psy[((size_t)c * ML + l) * ex->pyr_ty_max + ky];
+                        if (l == 0) {   // the kernel stages a fixed (T + halo)^2 block of level 0: what the tile needs must lie inside it
+                            bytes += (T + PYR_HALO) * (T + PYR_HALO);
+                            if (X.z - X.x > T + PYR_HALO || Y.z - Y.x > T + PYR_HALO) halo_ok = false;
+                            continue;
+                        }
+                        bytes += ((std::max(X.z - X.x, 0) + 3) & ~3) * std::max(Y.z - Y.x, 0);
+                        tx_n += std::max(X.z - X.x, 0); ty_n += std::max(Y.z - Y.x, 0);
+                    }
+                    ex->pyr_lds = std::max(ex->pyr_lds, bytes);
+                    ex->pyr_tab_cap = std::max(ex->pyr_tab_cap, std::max(tx_n, ty_n));
+                }
+        }
+        ex->pyr_tab_cap = (ex->pyr_tab_cap + 3) & ~3;
+        ex->pyr_lds += ex->pyr_tab_cap * 24;   // the table entries of a tile's columns (int2) and rows (int4) in front of the regions
+        ex->tiled_ok = !(ex->pyr_lds > 60 * 1024 || ML > PYR_MAX_LEVELS || !halo_ok || ex->max_w > 32767 || ex->max_h > 32767);   // (cannot happen for tiles of 64 and scale factors >= 1.05)
+    }
     if (slot_base > (size_t)INT32_MAX) { morb::set_error("candidate slot space exceeds 2^31 entries"); return ORB_E_ARG; }
     ex->total_cells = cell_base;
     ex->total_slots = slot_base;
@@ -1442,6 +1723,7 @@ static int rebuild_geometry(orbx_extractor* ex) {
     int rc;
     if ((rc = ex->d_levels.reserve(ex->levels.size())) || (rc = ex->d_cell_map.reserve(std::max<size_t>(ex->cell_map.size(), 1))) ||
         (rc = ex->d_xtab.reserve(std::max<size_t>(xt.size(), 1))) || (rc = ex->d_ytab.reserve(std::max<size_t>(yt.size(), 1))) ||
+        (rc = ex->d_pyr_sx.reserve(std::max<size_t>(psx.size(), 1))) || (rc = ex->d_pyr_sy.reserve(std::max<size_t>(psy.size(), 1))) ||
         (rc = ex->d_cell_cnt.reserve(std::max(cell_base, 1))) || (rc = ex->d_cell_off.reserve(std::max(cell_base, 1))) ||
         (rc = ex->d_cell_items.reserve(std::max<size_t>(slot_base, 1))) || (rc = ex->d_cand_dev.reserve(std::max<size_t>(slot_base, 1))) ||
         (rc = ex->d_level_cnt_dev.reserve(ex->levels.size())) || (rc = ex->d_sel_cnt.reserve(ex->levels.size())) ||
@@ -1462,6 +1744,8 @@ static int rebuild_geometry(orbx_extractor* ex) {
         MORB_HIP(hipMemcpyAsync(ex->d_cell_map.p, ex->cell_map.data(), ex->cell_map.size() * sizeof(int2), hipMemcpyHostToDevice, ex->stream));
     if (!xt.empty()) MORB_HIP(hipMemcpyAsync(ex->d_xtab.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice, ex->stream));
     if (!yt.empty()) MORB_HIP(hipMemcpyAsync(ex->d_ytab.p, yt.data(), yt.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
+    if (!psx.empty()) MORB_HIP(hipMemcpyAsync(ex->d_pyr_sx.p, psx.data(), psx.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
+    if (!psy.empty()) MORB_HIP(hipMemcpyAsync(ex->d_pyr_sy.p, psy.data(), psy.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
     MORB_HIP(hipStreamSynchronize(ex->stream));  // xt / yt are locals
     ex->tables_dirty = false;
     return ORB_OK;
@@ -1550,6 +1834,7 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     { const char* e = getenv("MORB_CHAIN_GRAPH"); ex->use_graph = !(e && atoi(e) == 0); }
     ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
     { const char* e = getenv("MORB_PINNED_INGEST"); ex->pinned_ingest_env = !(e && atoi(e) == 0); }
+    { const char* e = getenv("MORB_TILED_PYRAMID"); ex->tiled_pyramid = !(e && atoi(e) == 0); }
     if (const char* e = getenv("MORB_OCT_MAX_KEYS")) ex->oct_max_keys = std::min(OCT_NK, std::max(1, atoi(e)));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
@@ -1569,7 +1854,7 @@ void orbx_destroy(orbx_extractor* ex) {
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     for (int sl = 0; sl < 2; ++sl) for (int w = 0; w < orbx_extractor::CHAIN_WAYS; ++w) ex->chain[sl][w].destroy();
-    ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release();
+    ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release(); ex->d_pyr_sx.release(); ex->d_pyr_sy.release();
     ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release(); ex->d_sel_oct.release();
     ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release();
     ex->d_n_out.release(); ex->d_slot_blk.release();
@@ -1625,6 +1910,7 @@ static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int wi
             else for (int y = 0; y < height; ++y) memcpy(d + (size_t)y * width, src + (size_t)y * stride, width);
             S.publish();
             ex->ingest.src[cam] = S.dp + per_cam * cam; ex->ingest.stride[cam] = width; ex->ingest_pending = true;
+            if (!S.in_hbm) ex->ingest_host = true;
             return ORB_OK;
         }
     }
@@ -1633,6 +1919,7 @@ static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int wi
     // copy it replaces: a pitched hipMemcpy2DAsync per camera costs ~10 us of host time each).  MORB_PINNED_INGEST=0: never.
     if (pinned && ex->pinned_ingest && ex->pinned_ingest_env && attr.devicePointer) {
         ex->ingest.src[cam] = static_cast<const uint8_t*>(attr.devicePointer); ex->ingest.stride[cam] = stride; ex->ingest_pending = true;
+        ex->ingest_host = true;
         return ORB_OK;
     }
     ex->ingest.src[cam] = nullptr;
@@ -1764,9 +2051,22 @@ int orbx_peek_status(const orbx_extractor* ex) {
 void* orbx_done_event(const orbx_extractor* ex) { return ex ? (void*)ex->ev_done[(ex->run_seq - 1u) & 1u] : nullptr; }
 
 // K1 + K2/K3 of a run: the pyramid chain and the per-cell FAST kernel
-static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st) {
+// fused: the level-0 sources of a pending ingest (k_pyramid_tiled then reads them itself: no k_ingest launch); NULL: level 0 is in place
+static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestArgs* fused = nullptr) {
     const int ML = ex->max_levels;
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[0], st));
+    if (ex->tiled_pyramid && ex->tiled_ok) {
+        PyrArgs A;
+        for (int c = 0; c < 64; ++c) {
+            A.src[c] = fused && c < ex->n_cams ? fused->src[c] : nullptr; A.stride[c] = fused ? fused->stride[c] : 0;
+            A.tx[c] = c < ex->n_cams ? ex->pyr_tx[c] : 0; A.ty[c] = c < ex->n_cams ? ex->pyr_ty[c] : 0;
+            A.w[c] = c < ex->n_cams ? (short)ex->cur_w[c] : 0; A.h[c] = c < ex->n_cams ? (short)ex->cur_h[c] : 0;
+        }
+        hipLaunchKernelGGL(k_pyramid_tiled, dim3(ex->pyr_tx_max, ex->pyr_ty_max, ex->n_cams), dim3(256), (size_t)ex->pyr_lds, st, A,
+                           (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch, (const int2*)ex->d_xtab.p,
+                           (const int4*)ex->d_ytab.p, (const int4*)ex->d_pyr_sx.p, (const int4*)ex->d_pyr_sy.p, ex->pyr_tx_max, ex->pyr_ty_max,
+                           ex->pyr_tab_cap, ex->pyr_tile);
+    } else {
     // two levels per launch (k_resize2): (1,2) (3,4) (5,6) (7) for the usual 8 levels; MORB_PYRAMID_PAIRS=0: one launch per level
     // ... while the levels are small: the re-deriving half does four times the arithmetic per pixel, which only pays as long as
     // a level is a few microseconds of latency rather than work (up to ~1 M pixels on level 1 over all cameras).
@@ -1797,6 +2097,7 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st) {
             hipLaunchKernelGGL(k_resize2, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, yb_a, ex->d_pyr.p, ex->cam_pitch,
                                (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
         }
+    }
     }
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[1], st));
     // per-cell FAST / NMS / threshold / compaction
@@ -1851,26 +2152,37 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
     }
     if (ex->inflight == 0) std::fill(ex->n_out.begin(), ex->n_out.end(), 0);
     if (ex->total_cells == 0) {  // every camera empty
-        memset(&ex->ingest, 0, sizeof(ex->ingest)); ex->ingest_pending = false;
+        memset(&ex->ingest, 0, sizeof(ex->ingest)); ex->ingest_pending = false; ex->ingest_host = false;
         return ORB_OK;
     }
     uint32_t* d_cand = nullptr; int* d_level_cnt = nullptr;
     MORB_HIP(hipHostGetDevicePointer((void**)&d_cand, ex->h_cand, 0));
     MORB_HIP(hipHostGetDevicePointer((void**)&d_level_cnt, ex->h_level_cnt, 0));
 
-    if (ex->ingest_pending) {
-        int mw = 0, mh = 0;
-        for (int c = 0; c < ex->n_cams; ++c)
-            if (ex->ingest.src[c]) { mw = std::max(mw, ex->cur_w[c]); mh = std::max(mh, ex->cur_h[c]); }
-        if (mw > 0)
-            hipLaunchKernelGGL(k_ingest, dim3((mw + 1023) / 1024, (mh + 3) / 4, ex->n_cams), dim3(64, 4, 1), 0, st, ex->ingest,
-                               (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch);
-        for (int c = 0; c < ex->n_cams; ++c) ex->ingest.src[c] = nullptr;
-        ex->ingest_pending = false;
-    }
+    // Level 0 of the images that are not in place yet (device images, staged pageable images, page-locked images read in place).
+    // A run whose launches are issued one by one hands the sources to the tiled pyramid launch, which reads them itself; a
+    // run that replays a captured chain (its launches carry no per-run pointers) copies them first with k_ingest.
     const bool dev_tree = ex->device_octree && ex->total_sel_slots > 0;
+    const bool will_replay = dev_tree && ex->use_graph && ex->graph_next_run && allow_async && !ex->profiling;
+    IngestArgs fused_src;
+    const IngestArgs* fused = nullptr;
+    if (ex->ingest_pending) {
+        // (sources in host memory are copied exactly once by k_ingest: the tiles' halos would cross PCIe twice)
+        if (ex->tiled_pyramid && ex->tiled_ok && !will_replay && !ex->ingest_host) {
+            fused_src = ex->ingest; fused = &fused_src;
+        } else {
+            int mw = 0, mh = 0;
+            for (int c = 0; c < ex->n_cams; ++c)
+                if (ex->ingest.src[c]) { mw = std::max(mw, ex->cur_w[c]); mh = std::max(mh, ex->cur_h[c]); }
+            if (mw > 0)
+                hipLaunchKernelGGL(k_ingest, dim3((mw + 1023) / 1024, (mh + 3) / 4, ex->n_cams), dim3(64, 4, 1), 0, st, ex->ingest,
+                                   (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch);
+        }
+        for (int c = 0; c < ex->n_cams; ++c) ex->ingest.src[c] = nullptr;
+        ex->ingest_pending = false; ex->ingest_host = false;
+    }
     if (!dev_tree) {
-        if ((rc = launch_pyramid_fast(ex, st))) return rc;
+        if ((rc = launch_pyramid_fast(ex, st, fused))) return rc;
         // K3b (only on the host-quadtree path and for the inspection hook): dense cell-major lists, also into pinned host memory
         hipLaunchKernelGGL(k_compact, dim3(ex->n_cams * ML), dim3(1024), 0, st, (const LevelInfo*)ex->d_levels.p,
                            (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_cell_off.p, d_cand, d_level_cnt,
@@ -1888,7 +2200,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         // hipGraphLaunch (the host cost of enqueueing them is what bounds overlapped timesteps).  Everything the launches
         // carry is in the key: geometry epoch, result mirrors, frame sink.
         const FrameSink sink = allow_async ? ex->sink : FrameSink{};
-        const bool graphable = ex->use_graph && ex->graph_next_run && allow_async && !ex->profiling;
+        const bool graphable = will_replay;
         bool done = false;
         if (graphable) {
             // a few graphs per slot: a caller rotates through more result sets / frames than there are slots
@@ -1927,7 +2239,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
             }
         }
         if (!done) {
-            if ((rc = launch_pyramid_fast(ex, st))) return rc;
+            if ((rc = launch_pyramid_fast(ex, st, fused))) return rc;
             if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[3], st));
             if ((rc = launch_tree_describe(ex, st, slot, sink))) return rc;
             if (ex->tail_fn) { ++ex->run_seq; rc = ex->tail_fn(ex->tail_user, (void*)st); --ex->run_seq; if (rc) return rc; }
@@ -2196,6 +2508,7 @@ int orbx_debug_distribute_octree(const orb_keypoint* in, int n, int min_x, int m
 
 #ifdef MORB_PHASE_CLOCKS
 extern "C" int morb_debug_phases_extractor(int which, unsigned long long* out64) {
+    if (which == 4) return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_pyr), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
     if (which == 2) return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_desc), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
     if (which == 3) return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_desc_wave), 2 * 4096 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
     return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_oct), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;

@@ -209,29 +209,27 @@ __global__ void k_cams_from_counts(CamFeat* __restrict__ cams, int n_cams, const
 
 // exclusive scan of cnt[0..n) into start[0..n], single 1024-thread block; cursor = copy of start
 __global__ __launch_bounds__(1024) void k_scan_cells(const int* cnt, int n, int* __restrict__ start, int* cursor) {
-    // cnt and cursor may alias (the per-cell counters are turned into insert cursors in place)
+    // cnt and cursor may alias (the per-cell counters are turned into insert cursors in place).
+    // Every wave owns one contiguous run of cells and walks it 64 cells at a time (coalesced; round 2 gave every THREAD a run
+    // of its own: 24 dependent, uncoalesced loads per thread for an 8-camera frame, twice -- 48 us).
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (n + 1023) / 1024;
-    const int c0 = min(n, tid * per), c1 = min(n, c0 + per);
+    const int per = ((n + 15) / 16 + 63) & ~63;              // cells per wave, a multiple of 64
+    const int c0 = min(n, wave * per), c1 = min(n, c0 + per);
     int mine = 0;
-    for (int c = c0; c < c1; ++c) mine += cnt[c];
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
+    for (int c = c0 + lane; c < c1; c += 64) mine += cnt[c];  // (independent loads: all in flight)
+    const int tot = __builtin_amdgcn_readlane(wave_incl_scan(mine), 63);
+    if (lane == 0) wsum[wave] = tot;
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int w = 0; w < 16; ++w) { const int v = wsum[w]; wsum[w] = acc; acc += v; }
-        start[n] = acc;
+    int run = 0;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    if (tid == 1023) start[n] = run + tot;
+    for (int c = c0; c < c1; c += 64) {
+        const int v = c + lane < c1 ? cnt[c + lane] : 0;
+        const int incl = wave_incl_scan(v);
+        if (c + lane < c1) { start[c + lane] = run + incl - v; cursor[c + lane] = run + incl - v; }
+        run += __builtin_amdgcn_readlane(incl, 63);
     }
-    __syncthreads();
-    int run = wsum[wave] + incl - mine;
-    for (int c = c0; c < c1; ++c) { const int v = cnt[c]; start[c] = run; cursor[c] = run; run += v; }
 }
 
 __global__ __launch_bounds__(256) void k_scatter_cells(const int* __restrict__ cell_of, int n_total, int* __restrict__ cursor,

@@ -81,6 +81,7 @@ struct orbm_matcher {
     orb_calibration calib = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // orbm_set_calibration: undistortion applied by device-built frames (k1 == 0: off)
     int frame_min_rows = 0;  // the next device-built frame gets at least this many descriptor rows (fixed export block size)
     int last_status[4] = {0, 0, 0, 0};  // {status, nmatches, sweeps, longest list} of the last device resolve
+    int rs_sweeps_hint = 24;           // sweeps the multi-workgroup resolve enqueues next time (what the last one needed + 4)
     bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
     int resolve_seq = 0;           // sequence number of the last tagged resolve launch
     bool foreign_work = false;     // something other than a step's own search was put on the stream (orbf_step_end then waits for all of it)
@@ -121,6 +122,7 @@ struct SearchJob {
     const uint8_t* occ_dev = nullptr;   // device-visible copy of `occupied` (staged by the caller): no H2D either
     const orbm_window* win2_dev = nullptr;  // second windows of the queries (device memory), or NULL
     const struct SideJob* side = nullptr;   // work that shares the projection kernel's launch (consumed by search_enqueue)
+    bool multi = false;                 // the resolve in flight is the multi-workgroup form (one launch per sweep)
 };
 
 // Work of an isolated orbf_step that rides in the projection kernel's launch instead of on a stream of its own (a fork onto a

@@ -448,6 +448,11 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
     }
     MORB_PHASE(g_ph_res, 60);
     for (int g = tid; g < NT; g += T) match_of_feature[g] = tagb ? (tagb | (s_claim[g] + 2)) : s_claim[g];
+    // A tagged launch rewrites EVERY word of the frame's capacity, the ones past this frame's count as "no match": a word can
+    // then only carry the current sequence number if this launch stored it (the numbers cycle after 2047 launches; a word
+    // left alone since its last use -- the count dropped, stayed low for a multiple of 2047 launches and rose again -- would
+    // otherwise show the right tag with an old value before this launch's store has crossed PCIe).
+    if (tagb) for (int g = NT + tid; g < F.n_total; g += T) match_of_feature[g] = tagb | 1;
     if (tid == 0) { status[1] = tagb | s_red; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | 0; }
     MORB_PHASE(g_ph_res, 61);
 #ifdef MORB_PHASE_CLOCKS
@@ -459,15 +464,16 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
 // over the whole chip.  The two claim tables, the choices and the owner table live in HBM (L2-resident); one launch per
 // sweep (a grid-wide barrier is exactly what a kernel boundary is), a fixed number of sweeps is enqueued and a sweep
 // that finds "nothing changed" in its predecessor's flag does nothing, so no host round trip sits between sweeps.
-// state: [0] longest candidate list, [1] matches, [2..4] kept rotation bins, [8..8+RS_MAX_SWEEPS) changed flags,
+// state: [0] longest candidate list, [1] matches, [2..4] kept rotation bins, [5] sweeps enqueued, [8..8+RS_MAX_SWEEPS) changed flags,
 //        [48..78) rotation histogram.
 constexpr int RS_MAX_SWEEPS = 24;
 constexpr int RS_STATE_INTS = 80;
 
 __global__ __launch_bounds__(256) void k_rs_init(int n_cap, int nq, int* __restrict__ tab0, int* __restrict__ tab1,
                                                  int* __restrict__ owner, int* __restrict__ choice,
-                                                 const int* __restrict__ cand_count, int* __restrict__ state) {
+                                                 const int* __restrict__ cand_count, int* __restrict__ state, int n_sweeps) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) state[5] = n_sweeps;
     if (i < n_cap) { tab0[i] = 0x7fffffff; tab1[i] = 0x7fffffff; owner[i] = -1; }
     int mx = 0;
     if (i < nq) { choice[i] = -1; mx = cand_count[i]; }
@@ -551,13 +557,18 @@ __global__ __launch_bounds__(256) void k_rs_sweep(FrameDev F, const orbm_query* 
 __global__ __launch_bounds__(256) void k_rs_owner(const orbm_query* __restrict__ q, int nq, int cap, const int* __restrict__ choice,
                                                   const float* __restrict__ f_angle, int check_ori, int* __restrict__ owner,
                                                   int* __restrict__ state) {
-    if (state[0] > cap || state[8 + RS_MAX_SWEEPS - 1] != 0) return;
+    if (state[0] > cap || state[8 + state[5] - 1] != 0) return;
+    // (the histogram and the match count are gathered per workgroup in LDS first: 32 000 queries put ~15 000 atomics on 31 words
+    // of HBM otherwise, which the L2 serialises -- 37 us of the 8 x 4000 search)
+    __shared__ int s_hist[ORBM_HISTO_LENGTH + 1];
+    if (threadIdx.x <= ORBM_HISTO_LENGTH) s_hist[threadIdx.x] = 0;
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int c = i < nq ? choice[i] : -1;
     if (c >= 0) atomicMax(&owner[c], i);
     const unsigned long long any = __ballot(c >= 0);
-    if (lane == 0 && any) atomicAdd(&state[1], __popcll(any));
+    if (lane == 0 && any) atomicAdd(&s_hist[ORBM_HISTO_LENGTH], __popcll(any));
     if (check_ori) {
         int bin = -1;
         if (c >= 0) {
@@ -567,21 +578,18 @@ __global__ __launch_bounds__(256) void k_rs_owner(const orbm_query* __restrict__
             if (bin == ORBM_HISTO_LENGTH) bin = 0;
             if (bin < 0 || bin >= ORBM_HISTO_LENGTH) bin = -1;
         }
-        unsigned long long todo = __ballot(bin >= 0);
-        while (todo) {  // one atomic per distinct bin of the wave
-            const int b0 = __shfl(bin, __ffsll((long long)todo) - 1);
-            const unsigned long long same = __ballot(bin == b0);
-            if (bin == b0 && lane == __ffsll((long long)same) - 1) atomicAdd(&state[48 + b0], __popcll(same));
-            todo &= ~same;
-        }
+        if (bin >= 0) atomicAdd(&s_hist[bin], 1);
     }
+    __syncthreads();
+    if (threadIdx.x < ORBM_HISTO_LENGTH) { const int v = s_hist[threadIdx.x]; if (v) atomicAdd(&state[48 + threadIdx.x], v); }
+    if (threadIdx.x == ORBM_HISTO_LENGTH) { const int v = s_hist[ORBM_HISTO_LENGTH]; if (v) atomicAdd(&state[1], v); }
 }
 
 // ComputeThreeMaxima (every block, redundantly) + rejection of the matches outside the three fullest rotation bins
 __global__ __launch_bounds__(256) void k_rs_reject(const orbm_query* __restrict__ q, int nq, int cap, const int* __restrict__ choice,
                                                    const float* __restrict__ f_angle, int* __restrict__ owner,
                                                    int* __restrict__ state) {
-    if (state[0] > cap || state[8 + RS_MAX_SWEEPS - 1] != 0) return;
+    if (state[0] > cap || state[8 + state[5] - 1] != 0) return;
     __shared__ int s_keep[3];
     if (threadIdx.x == 0) {  // reference src/ORBmatcher.cc:3948-3989
         int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
@@ -620,10 +628,10 @@ __global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __rest
                                                   const int* __restrict__ state, int* __restrict__ match_of_feature,
                                                   int* __restrict__ status) {
     const int NT = n_total_dev ? *n_total_dev : NT_host;
-    const bool overflow = state[0] > cap, stuck = state[8 + RS_MAX_SWEEPS - 1] != 0;
+    const bool overflow = state[0] > cap, stuck = state[8 + state[5] - 1] != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int sweeps = 0;
-        for (int k = 0; k < RS_MAX_SWEEPS; ++k) sweeps += state[8 + k] ? 1 : 0;
+        for (int k = 0; k < state[5]; ++k) sweeps += state[8 + k] ? 1 : 0;
         status[0] = overflow ? 2 : (stuck ? 1 : 0);
         status[1] = (overflow || stuck) ? 0 : state[1];
         status[2] = sweeps + 1;
@@ -862,7 +870,7 @@ static int host_resolve(orbm_matcher* m, const orbm_frame* cur, const orbm_query
 
 int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_device) {
     const int n = J.cur->n_total;
-    J.device_path = false; J.pollable = false;
+    J.device_path = false; J.pollable = false; J.multi = false;
     if (J.nq == 0 || n == 0) return ORB_OK;
     // two claim tables (one int per feature each) + the candidate counts (u16 per query, padded); tables that do not fit LDS go
     // to an HBM workspace (GCL variant of the kernel)
@@ -896,9 +904,15 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
         int* tab0 = m->d_gclaim.p; int* tab1 = tab0 + n; int* state = tab1 + n;
         MORB_HIP(hipMemsetAsync(state, 0, RS_STATE_INTS * sizeof(int), m->stream));
         const int nb_all = (std::max(n, nq) + 255) / 256, nb_q = (nq + 255) / 256, nb_f = (n + 255) / 256;
+        // One launch per sweep, enqueued blind: as many as the stream of searches has needed lately plus four (12 at least, 24 at
+        // most; 8 x 4000 features converge in 10-11), because a sweep that has nothing to do still costs its launch (~4.7 us each
+        // on the critical path of the step).  A search that does not converge in its allotment is finished by the exact host
+        // fallback and the next one gets the full 24 again.
+        const int n_sweeps = std::min(RS_MAX_SWEEPS, std::max(12, m->rs_sweeps_hint));
         hipLaunchKernelGGL(k_rs_init, dim3(nb_all), dim3(256), 0, m->stream, n, nq, tab0, tab1, m->d_match.p, m->d_choice.p,
-                           (const int*)m->d_i1.p, state);
-        for (int it = 0; it < RS_MAX_SWEEPS; ++it) {
+                           (const int*)m->d_i1.p, state, n_sweeps);
+        J.multi = true;
+        for (int it = 0; it < n_sweeps; ++it) {
             const int* rd = (it & 1) ? tab1 : tab0;
             int* wr = (it & 1) ? tab0 : tab1;
             if (J.points)
@@ -972,6 +986,7 @@ int morb::search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_feature
         m->last_status[0] = status;
         for (int k = 1; k < 4; ++k) m->last_status[k] = word(k, 0);
         if (status == -3) { morb::set_error("resolve results never arrived"); return ORB_E_HIP; }
+        if (J.multi) m->rs_sweeps_hint = status == 0 ? m->last_status[2] + 4 : RS_MAX_SWEEPS;   // (sweeps the next multi-workgroup resolve enqueues)
         if (status == 0) break;
         if (status == 2) {  // a candidate list overflowed: retry with room for the longest one
             J.cap = (m->last_status[3] + 63) & ~63;

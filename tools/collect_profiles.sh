@@ -7,7 +7,8 @@
 # launches (MORB_CHAIN_GRAPH=0) and keep the host-written staging in mapped pinned memory (MORB_NO_BAR_STAGING=1).  The kernels
 # and their durations are the same; only the host's launch cost differs, and `value` is never taken from a profiled run.
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02/final; mkdir -p $O
+ROUND=${ROUND:-r03}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$ROUND/final; mkdir -p $O
 cd $R
 if [ "$1" != "prof-only" ]; then
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed" > $O/pytest.txt
@@ -24,4 +25,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_matcher -o match
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc_fetch -- python3 $R/tools/profile_matcher.py > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc_write -- python3 $R/tools/profile_matcher.py > /dev/null 2> $O/pmc_write.err
 fi
+# matcher traffic (k_hamming_*, k_cross_top2*, k_project, k_resolve, BoW) -> pmc_traffic.json, then the extractor / step kernels
+# (FETCH_SIZE, WRITE_SIZE and one SQ pass per configuration) merged into the same file
+python3 $R/tools/parse_pmc.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/parse_pmc.out 2>&1
+STEPS=8
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+for c in 1 2 4; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cfg${c}_fetch -o p -- python3 $R/tools/profile_extractor.py $c $STEPS > $O/cfg${c}_fetch.out 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cfg${c}_write -o p -- python3 $R/tools/profile_extractor.py $c $STEPS > $O/cfg${c}_write.out 2>&1
+  rocprofv3 --pmc $SQ --output-format csv -d $O/cfg${c}_sq -o p -- python3 $R/tools/profile_extractor.py $c $STEPS > $O/cfg${c}_sq.out 2>&1
+done
+python3 $R/tools/parse_pmc_extractor.py $O $STEPS $O/pmc_traffic.json > $O/parse_pmc_extractor.out 2>&1
+find $O -name "*counter_collection.csv" -size +6M -delete
+find $O -name "*kernel_trace.csv" -size +6M -delete
 find $O -name "*stats.csv"

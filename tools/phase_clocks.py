@@ -24,6 +24,8 @@ lib.morb_debug_phases_extractor(0, out); v = list(out)
 npass = int(v[61])
 idx = list(range(0, npass)) + [62]
 print("octree (cam0 level0): load-scan, limits, dense-load, roots, passes..., select:", deltas(v, idx), "total", (v[62] - v[0]) / 100.0)
+lib.morb_debug_phases_extractor(4, out); v = list(out)
+print("pyramid tile (3, 3) of camera 0: spans, tables issued, level 0 in LDS, levels 1..7:", deltas(v, list(range(0, 11))), "total", (v[10] - v[0]) / 100.0)
 lib.morb_debug_phases_extractor(2, out); v = list(out)
 print("describe, one wave (block 40): slot bookkeeping, patch fetch, moments + angle, horizontal blur, vertical blur, rBRIEF, output:",
       deltas(v, [0, 1, 2, 3, 4, 5, 6, 7]), "total", (v[7] - v[0]) / 100.0)
