@@ -597,7 +597,7 @@ def main(argv=None):
         "overlap": ("the extractions of timesteps t+1 and t+2 run next to the matching of timestep t (orbf_prefetch); `value` needs "
                     "the images two steps ahead, `latency_ms_isolated` / `value_isolated` do not") if overlap else "off",
         "extractor_stage_us": {k: round(v, 1) for k, v in stages.items()},
-        "roofline_extract": {"kernel": "extraction chain (k_ingest, k_resize2/k_resize, k_fast_cells, k_octree, k_describe)", "bound": "hbm",
+        "roofline_extract": {"kernel": "extraction chain (k_pyramid_tiled [k_ingest], k_fast_cells, k_octree, k_describe)", "bound": "hbm",
                              "achieved": round(ex_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ex_ach / HBM_PEAK_GBS, 5),
                              "alg_bytes_per_image": extract_alg_bytes(W, H, NFEAT), "images": NC, "chain_us": round(ex_us, 1),
                              "traffic": _pmc_bytes("extract_chain"),

@@ -6,14 +6,14 @@ usage: parse_pmc_extractor.py <dir with cfg{1,2,4}_{fetch,write,sq}/..._counter_
 Per configuration and kernel: launches per timestep, HBM bytes fetched / written per timestep (FETCH_SIZE and WRITE_SIZE are
 in KiB; FETCH_SIZE counts 64 B per 128-B request on gfx950 -> x2, checked against the 1 GiB copy of the same run), and the SQ
 counters per timestep.  `extract_chain` = the extraction kernels (k_ingest, k_resize2 / k_resize, k_fast_cells, k_octree,
-k_describe) summed, per IMAGE, next to SURVEY section 8(d)'s algorithmic bytes per image."""
+k_describe; round 3: k_pyramid_tiled in place of the first three) summed, per IMAGE, next to SURVEY section 8(d)'s algorithmic bytes per image."""
 import collections, csv, glob, json, os, sys
 
-KERNELS = ["k_ingest", "k_resize2", "k_resize", "k_fast_cells", "k_octree", "k_describe", "k_frame_build_small", "k_frame_fill",
+KERNELS = ["k_pyramid_tiled", "k_ingest", "k_resize2", "k_resize", "k_fast_cells", "k_octree", "k_describe", "k_frame_build_small", "k_frame_fill",
            "k_scan_cells", "k_scatter_cells", "k_sort_cells", "k_cams_from_counts", "k_project_side", "k_project", "k_top2_merge",
            "k_cross_top2_mfma", "k_resolve", "k_rs_init", "k_rs_sweep", "k_rs_owner", "k_rs_reject", "k_rs_write", "k_mirror_frame",
            "fillBuffer", "copyBuffer"]
-EXTRACT = ["k_ingest", "k_resize2", "k_resize", "k_fast_cells", "k_octree", "k_describe"]
+EXTRACT = ["k_pyramid_tiled", "k_ingest", "k_resize2", "k_resize", "k_fast_cells", "k_octree", "k_describe"]
 SHAPES = {1: (640, 480, 1000, 2), 2: (1280, 720, 2000, 2), 4: (1920, 1080, 4000, 8)}
 
 
