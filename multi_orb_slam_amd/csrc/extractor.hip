@@ -231,7 +231,8 @@ constexpr int PYR_HALO = 16;   // what a tile needs of level 0 beyond its own T 
 constexpr int PYR_MAX_LEVELS = 12;
 
 // LDS: [x table entries of all levels (int2)] [y table entries of all levels (int4)] [the regions, level after level]
-__global__ __launch_bounds__(256) void k_pyramid_tiled(PyrArgs A, const LevelInfo* __restrict__ L, int max_levels,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pyramid_tiled(PyrArgs A, const LevelInfo* __restrict__ L, int max_levels,
                                                        uint8_t* __restrict__ pyr, size_t cam_pitch, const int2* __restrict__ xtab,
                                                        const int4* __restrict__ ytab, const int4* __restrict__ spans_x,
                                                        const int4* __restrict__ spans_y, int tx_max, int ty_max, int tab_cap, int T) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void k_pyramid_tiled(PyrArgs A, const LevelInf
         l0_ndw = ndw; l0_inv = ndw > 0 ? ((1u << 20) + ndw - 1) / ndw : 0;   // i / ndw for i < 2^20 / ndw
 #pragma unroll
         for (int u = 0; u < PYR_L0_DW; ++u) {
-            const int i = tid + 256 * u;
+            const int i = tid + NT * u;
             l0v[u] = 0;
             if (i < ndw * pnh) {
                 const int y = (int)(((unsigned)i * l0_inv) >> 20), k = i - y * ndw;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void k_pyramid_tiled(PyrArgs A, const LevelInf
         }
         if (rem > 0) {
             const unsigned inv = ((1u << 20) + rem - 1) / rem;
-            for (int i = tid; i < rem * pnh; i += 256) {
+            for (int i = tid; i < rem * pnh; i += NT) {
                 const int y = (int)(((unsigned)i * inv) >> 20), x = 4 * ndw + i - y * rem;
                 cur[y * ppw + x] = src[(size_t)(py0 + y) * sstride + px0 + x];
             }
@@ -300,14 +301,14 @@ __global__ __launch_bounds__(256) void k_pyramid_tiled(PyrArgs A, const LevelInf
             const int odw = al ? ow >> 2 : 0, orem = ow - 4 * odw;
             if (odw > 0) {
                 const unsigned inv = ((1u << 20) + odw - 1) / odw;
-                for (int i = tid; i < odw * oh; i += 256) {
+                for (int i = tid; i < odw * oh; i += NT) {
                     const int y = (int)(((unsigned)i * inv) >> 20), k = i - y * odw;
                     reinterpret_cast<uint32_t*>(dst + (size_t)(py0 + y) * l0_stride + px0)[k] = reinterpret_cast<const uint32_t*>(s2 + (size_t)(py0 + y) * sstride + px0)[k];
                 }
             }
             if (orem > 0) {
                 const unsigned inv = ((1u << 20) + orem - 1) / orem;
-                for (int i = tid; i < orem * oh; i += 256) {
+                for (int i = tid; i < orem * oh; i += NT) {
                     const int y = (int)(((unsigned)i * inv) >> 20), x = 4 * odw + i - y * orem;
                     dst[(size_t)(py0 + y) * l0_stride + px0 + x] = s2[(size_t)(py0 + y) * sstride + px0 + x];
                 }
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void k_pyramid_tiled(PyrArgs A, const LevelInf
     // the needed region of level 0 (from the source image or from level 0 itself)
     {
         const int nx = s_ox[nlev], ny = s_oy[nlev];
-        for (int e = tid; e < nx + ny; e += 256) {
+        for (int e = tid; e < nx + ny; e += NT) {
             const bool isx = e < nx;
             const int k = isx ? e : e - nx;
             int l = 1;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void k_pyramid_tiled(PyrArgs A, const LevelInf
     }
 #pragma unroll
     for (int u = 0; u < PYR_L0_DW; ++u) {
-        const int i = tid + 256 * u;
+        const int i = tid + NT * u;
         if (i < l0_ndw * pnh) { const int y = (int)(((unsigned)i * l0_inv) >> 20), k = i - y * l0_ndw; reinterpret_cast<uint32_t*>(cur + y * ppw)[k] = l0v[u]; }
     }
     PPH(2);
@@ -370,12 +371,12 @@ __global__ __launch_bounds__(256) void k_pyramid_tiled(PyrArgs A, const LevelInf
         if (nw > 0) {
             const unsigned inv = (unsigned)sx.w;   // 2^20 / nw, rounded up (host): i / nw for i < 2^20 / nw
             const int npx = nw * nh;
-            for (int i0 = tid; i0 < npx; i0 += 512) {
+            for (int i0 = tid; i0 < npx; i0 += 2 * NT) {
                 int vv[2], yy[2], xx[2];
                 int p[2][4], a0[2], a1[2], b0[2], b1[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int i = min(i0 + 256 * u, npx - 1);
+                    const int i = min(i0 + NT * u, npx - 1);
                     yy[u] = (int)(((unsigned)i * inv) >> 20); xx[u] = i - yy[u] * nw;
                     const int4 yt = ty_l[yy[u]];   // {row0, row1, beta0, beta1}
                     const int2 xt = tx_l[xx[u]];   // {sx0 | sx1 << 16, alpha0 | alpha1 << 16}
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void k_pyramid_tiled(PyrArgs A, const LevelInf
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    if (i0 + 256 * u < npx) {
+                    if (i0 + NT * u < npx) {
                         nxt[yy[u] * pw + xx[u]] = (uint8_t)vv[u];
                         if (yy[u] < oh && xx[u] < ow) dst[(size_t)yy[u] * lv.y + xx[u]] = (uint8_t)vv[u];
                     }
@@ -1509,7 +1510,7 @@ struct orbx_extractor {
     DevBuf<int2> d_cell_map, d_xtab;
     // the tiled whole-pyramid launch (k_pyramid_tiled): spans per (camera, level, tile column / row), tiles per camera, LDS need
     DevBuf<int4> d_pyr_sx, d_pyr_sy;
-    int pyr_tx_max = 0, pyr_ty_max = 0, pyr_lds = 0, pyr_tile = 0, pyr_tab_cap = 0;
+    int pyr_tx_max = 0, pyr_ty_max = 0, pyr_lds = 0, pyr_tile = 0, pyr_tab_cap = 0, pyr_threads = 256;
     short pyr_tx[64] = {}, pyr_ty[64] = {};
     bool ingest_host = false;         // a pending ingest source lives in host memory (read across PCIe)
     bool tiled_ok = false;            // ... and this geometry fits it (LDS, halo, level count)
@@ -1650,7 +1651,10 @@ static int rebuild_geometry(orbx_extractor* ex) {
     {
         long long px0 = 0;
         for (int c = 0; c < ex->n_cams; ++c) px0 += (long long)ex->cur_w[c] * ex->cur_h[c];
-        const int T = px0 <= 1500000 ? 32 : 64;
+        static const int tile_env = [] { const char* e = getenv("MORB_PYR_TILE"); return e ? atoi(e) : 0; }();
+        static const int thr_env = [] { const char* e = getenv("MORB_PYR_THREADS"); return e ? atoi(e) : 0; }();
+        const int T = tile_env == 32 || tile_env == 64 ? tile_env : (px0 <= 1500000 ? 32 : 64);
+        ex->pyr_threads = thr_env == 1024 ? 1024 : 256;
         ex->pyr_tile = T; ex->pyr_tx_max = 1; ex->pyr_ty_max = 1; ex->pyr_lds = 0; ex->pyr_tab_cap = 0;
         bool halo_ok = true;
         for (int c = 0; c < ex->n_cams; ++c) {
@@ -2062,10 +2066,17 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestA
             A.tx[c] = c < ex->n_cams ? ex->pyr_tx[c] : 0; A.ty[c] = c < ex->n_cams ? ex->pyr_ty[c] : 0;
             A.w[c] = c < ex->n_cams ? (short)ex->cur_w[c] : 0; A.h[c] = c < ex->n_cams ? (short)ex->cur_h[c] : 0;
         }
-        hipLaunchKernelGGL(k_pyramid_tiled, dim3(ex->pyr_tx_max, ex->pyr_ty_max, ex->n_cams), dim3(256), (size_t)ex->pyr_lds, st, A,
-                           (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch, (const int2*)ex->d_xtab.p,
-                           (const int4*)ex->d_ytab.p, (const int4*)ex->d_pyr_sx.p, (const int4*)ex->d_pyr_sy.p, ex->pyr_tx_max, ex->pyr_ty_max,
-                           ex->pyr_tab_cap, ex->pyr_tile);
+        // (small rigs: fewer than one 64-pixel tile per CU -- 1024 threads per tile then, the tile's levels are a latency chain)
+        if (ex->pyr_threads == 1024)
+            hipLaunchKernelGGL(k_pyramid_tiled<1024>, dim3(ex->pyr_tx_max, ex->pyr_ty_max, ex->n_cams), dim3(1024), (size_t)ex->pyr_lds, st, A,
+                               (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch, (const int2*)ex->d_xtab.p,
+                               (const int4*)ex->d_ytab.p, (const int4*)ex->d_pyr_sx.p, (const int4*)ex->d_pyr_sy.p, ex->pyr_tx_max, ex->pyr_ty_max,
+                               ex->pyr_tab_cap, ex->pyr_tile);
+        else
+            hipLaunchKernelGGL(k_pyramid_tiled<256>, dim3(ex->pyr_tx_max, ex->pyr_ty_max, ex->n_cams), dim3(256), (size_t)ex->pyr_lds, st, A,
+                               (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch, (const int2*)ex->d_xtab.p,
+                               (const int4*)ex->d_ytab.p, (const int4*)ex->d_pyr_sx.p, (const int4*)ex->d_pyr_sy.p, ex->pyr_tx_max, ex->pyr_ty_max,
+                               ex->pyr_tab_cap, ex->pyr_tile);
     } else {
     // two levels per launch (k_resize2): (1,2) (3,4) (5,6) (7) for the usual 8 levels; MORB_PYRAMID_PAIRS=0: one launch per level
     // ... while the levels are small: the re-deriving half does four times the arithmetic per pixel, which only pays as long as

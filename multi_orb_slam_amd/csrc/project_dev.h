@@ -151,7 +151,7 @@ __device__ __forceinline__ void project_wave(const ProjectArgs& A, const int qi,
         cand_count[qi] = total;
         // what the resolve needs of a query besides its candidates: it never reads the query records themselves, which may
         // therefore live in pinned host memory (read once, here)
-        if (qmeta) qmeta[qi] = make_int2(Q->blocks, __float_as_int(Q->angle));
+        if (qmeta) qmeta[qi] = make_int2((Q->blocks ? 1 : 0) | (Q->cam << 1), __float_as_int(Q->angle));   // {blocks | camera << 1, angle}
         if (topk) {
 #pragma unroll
             for (int k = 0; k < RESOLVE_K; ++k) {

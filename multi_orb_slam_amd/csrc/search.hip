@@ -53,7 +53,7 @@ MORB_PHASE_DECL(g_ph_chg);   // (instrumented build) queries whose choice change
 // LDSQ: the per-query sweep state (shortlist features + distances, blocks flag, current choice) also lives in LDS, so a
 // sweep touches no global memory at all; used whenever it fits next to the claim table.
 template <bool POINTS, bool LDSQ>
-__global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __restrict__ qmeta /* {blocks, angle bits} */, int nq, int cap,
+__global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __restrict__ qmeta /* {blocks | camera << 1, angle bits} */, int nq, int cap,
                                                   const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
                                                   const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
                                                   const float* __restrict__ f_angle, int th_high, float nnratio,
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
         if (LDSQ) {
             l_choice[i] = -1;
             const int2 qm = qmeta[i];
-            l_fl[i] = (unsigned char)((qm.x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
+            l_fl[i] = (unsigned char)((qm.x & 1) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
             l_ang[i] = __int_as_float(qm.y);
 #pragma unroll
             for (int k = 0; k < RESOLVE_K; ++k) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
             const bool in = i < nq;
 #pragma unroll
             for (int k = 0; k < RESOLVE_K; ++k) gdr[b][k] = in ? ((tk_key[k * nq + i] & 0xffff0000) | (tk_g[k * nq + i] & 0xffff)) : 0xffff;
-            flr[b] = in ? ((qmeta[i].x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0)) : 0;
+            flr[b] = in ? ((qmeta[i].x & 1) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0)) : 0;
             chr[b] = -1;
         }
         if (!POINTS && nq <= RQ * T) {   // sweep 0 as above, from the registers
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
             if (valid) {
                 if constexpr (B < RQ) { fl = flr[B]; old = chr[B]; }
                 else {
-                    fl = LDSQ ? (int)l_fl[i] : ((qmeta[i].x ? 1 : 0) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
+                    fl = LDSQ ? (int)l_fl[i] : ((qmeta[i].x & 1) | (topk[(2 * RESOLVE_K) * nq + i] > RESOLVE_K ? 2 : 0));
                     old = LDSQ ? l_choice[i] : choice[i];
                 }
                 int best = 256, best2 = 256, lvl = -1, lvl2 = -1, bidx = -1, g2 = -1;
@@ -460,6 +460,316 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
 #endif
 }
 
+// ---- the frame search's resolve as a MONOTONE iteration (round 3; the default for SearchByProjection(Frame, Frame) whenever the
+// sweep state fits LDS).  The Jacobi form above rebuilds every claim in every sweep (two tables, sweep tags) and re-evaluates
+// every query: 8-9 sweeps of ~3 us on the benchmark stream.  It does not have to.  Let every query keep a cursor into its ordered
+// candidate list and ONE claim table hold, per feature, the lowest index of a blocking query that ever claimed it (atomicMin, never
+// reset).  A query moves its cursor on exactly when the entry under it is claimed by a LOWER blocking query, and claims the
+// first entry that is not.  Then:
+//   * a claim only ever moves to lower indices, so what is hidden from a query stays hidden: cursors only move forward;
+//   * the lowest claimant of a feature never has a reason to let go of it (it moves on only if somebody LOWER claims the
+//     feature), so at rest every table entry names a query that really picks that feature -- no stale claim hides anything;
+//   * at rest every query sits on its first candidate that no lower blocking query picks, which is the fixed point of the
+//     reference's sequential loop (src/ORBmatcher.cc:3502-3614), and that fixed point is unique (induction over the query order).
+// So a round is: look at the claim on the current pick (one LDS read and a compare for the ~2/3 of the queries it does not
+// concern); only a displaced query walks on.  Rounds are counted as before (a claim still travels one link of a dependency
+// chain per round) but cost a tenth of a sweep.  Owners, rotation histogram and result words as in k_resolve.  POINTS (top-2 with
+// ratio test), two-window queries and states beyond LDS keep k_resolve.
+__global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* __restrict__ qmeta, int nq, int cap,
+                                                       const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
+                                                       const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
+                                                       const float* __restrict__ f_angle, int th_high, int check_ori, int max_it,
+                                                       const int* __restrict__ topk, int* __restrict__ match_of_feature,
+                                                       int* __restrict__ status, int tagb) {
+    extern __shared__ __attribute__((aligned(16))) int s_claim[];  // [0, n): lowest blocking claimant of a feature; [n, 2n): owner (last claimant)
+    __shared__ int s_hist[ORBM_HISTO_LENGTH];
+    __shared__ int s_keep[3];
+    __shared__ int s_red;
+    __shared__ int s_flag[3];   // "some wave changed something in round it": [it % 3]
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63;
+    MORB_PHASE(g_ph_res, 0);
+#ifdef MORB_PHASE_CLOCKS
+    if (tid == 0) { g_ph_res[1] = 0; g_ph_res[58] = clock64(); }   // (slot 1 zero = this kernel's layout; shader clock next to the 100 MHz one)
+#endif
+    if (tid < 3) s_flag[tid] = 0;
+    const int NT = F.n_total_dev ? *F.n_total_dev : F.n_total;
+    const int* tk_key = topk;
+    const int* tk_g = topk + RESOLVE_K * nq;
+    int* s_owner = s_claim + F.n_total;
+    unsigned short* l_cnt = reinterpret_cast<unsigned short*>(s_claim + 2 * F.n_total);
+    int* l_choice = s_claim + 2 * F.n_total + (nq + 1) / 2;
+    int* l_gd = l_choice + nq;
+    float* l_ang = reinterpret_cast<float*>(l_gd + RESOLVE_K * nq);
+    float* l_fang = l_ang + nq;
+    unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_fang + F.n_total);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
+    if (tid == 0) s_red = 0;
+    if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
+    for (int g = tid; g < F.n_total; g += T) {
+        s_claim[g] = 0x7fffffff; s_owner[g] = -1;
+        if (check_ori) l_fang[g] = f_angle[g];
+    }
+    __syncthreads();   // (the claims of round 0 go into the table right below)
+    // per query of this thread (two in registers; more only beyond 2048 queries, re-read from LDS every round): the shortlist
+    // (distance << 16 | feature, 0xffff = none), the cursor, the entry under it (a rescanned pick is not on the shortlist)
+    constexpr int RQ = 2, K = RESOLVE_K;
+    int sl[RQ][K], cur[RQ], pos[RQ], flr[RQ];
+    int mx = 0;
+    // set-up of one query: every load is independent of every other -- one trip to HBM for the whole pass.  Round 0 rides along:
+    // without any claim a query takes the head of its shortlist (every entry there is acceptable: not occupied, distance <=
+    // th_high checked here) and, if it blocks, claims it
+    auto setup = [&](const int i, int (&e)[K], int& c, int& fl) {
+        const int cnt_i = cand_count[i];
+        mx = max(mx, cnt_i);
+        l_cnt[i] = (unsigned short)min(cnt_i, 65535);
+        const int2 qm = qmeta[i];
+        fl = (qm.x & 1) | (topk[(2 * K) * nq + i] > K ? 2 : 0);
+        l_fl[i] = (unsigned char)fl;
+        l_ang[i] = __int_as_float(qm.y);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            e[k] = (tk_key[k * nq + i] & 0xffff0000) | (tk_g[k * nq + i] & 0xffff);
+            l_gd[k * nq + i] = e[k];
+        }
+        const bool has = (e[0] & 0xffff) != 0xffff && (int)((unsigned)e[0] >> 16) <= th_high;
+        c = has ? e[0] : -1;
+        l_choice[i] = has ? (e[0] & 0xffff) : -1;
+        if (has && (fl & 1)) atomicMin(&s_claim[e[0] & 0xffff], i);
+    };
+#pragma unroll
+    for (int b = 0; b < RQ; ++b) {
+        const int i = b * T + tid;
+        cur[b] = -1; pos[b] = 0; flr[b] = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) sl[b][k] = 0xffff;
+        if (i < nq) setup(i, sl[b], cur[b], flr[b]);
+    }
+    for (int i = RQ * T + tid; i < nq; i += T) { int e[K], c, fl; setup(i, e, c, fl); }
+    mx = (int)(0x7fffffffu - wave_min_u32(0x7fffffffu - (unsigned)mx));
+    if (lane == 0) atomicMax(&s_red, mx);
+    __syncthreads();
+    const int maxcount = s_red;
+    if (maxcount > cap) {
+        if (tid == 0) { status[1] = tagb | 0; status[2] = tagb | 0; status[3] = tagb | maxcount; status[0] = tagb | 2; }
+        return;
+    }
+    MORB_PHASE(g_ph_res, 2);
+    // one pass over a pair of queries: is the current pick still free of lower blocking claims (one LDS read each, issued
+    // together)?  For a displaced query the claims on ALL later shortlist entries are fetched in one batch, the first free one is
+    // taken and claimed; a dry shortlist that is not the whole list is rescanned by the whole wave (rare).  Returns "somebody in
+    // this wave was displaced".
+#ifdef MORB_PHASE_CLOCKS
+    int it_dbg = 0;
+#endif
+    auto pass = [&](const int (&qi)[RQ], const int (&e)[RQ][K], int (&c)[RQ], int (&p)[RQ], const int (&fl)[RQ]) -> bool {
+        bool disp[RQ], need_rescan[RQ];
+        int cl[RQ];
+#pragma unroll
+        for (int b = 0; b < RQ; ++b) cl[b] = s_claim[c[b] >= 0 ? (c[b] & 0xffff) : 0];   // (unconditional reads: issued together, no branch)
+#pragma unroll
+        for (int b = 0; b < RQ; ++b) { disp[b] = c[b] >= 0 && cl[b] < qi[b]; need_rescan[b] = false; }  // (only blocking queries write claims; an own claim equals the index)
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < RQ; ++b) any |= disp[b];
+        const unsigned long long wany = __ballot(any);
+        if (!wany) return false;
+        if (any) {
+            int ck[RQ][K];
+#pragma unroll
+            for (int b = 0; b < RQ; ++b)
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    const bool want = disp[b] && k > p[b] && (e[b][k] & 0xffff) != 0xffff;
+                    const int v = s_claim[want ? (e[b][k] & 0xffff) : 0];   // (as above: ten reads in flight at once.  Measured: asking
+                    ck[b][k] = want ? v : -1;                               // for the next entry alone first costs a third trip more often than it saves reads)
+                }
+#pragma unroll
+            for (int b = 0; b < RQ; ++b) {
+                if (!disp[b]) continue;
+                const int i = qi[b];
+#ifdef MORB_PHASE_CLOCKS
+                if (it_dbg < 15) atomicAdd((unsigned long long*)&g_ph_chg[it_dbg], 1ull);
+#endif
+                int nk = K;
+#pragma unroll
+                for (int k = K - 1; k >= 1; --k) if (ck[b][k] >= i) nk = k;
+                int ne = 0xffff;
+#pragma unroll
+                for (int k = 1; k < K; ++k) if (nk == k) ne = e[b][k];
+                if (nk < K && (int)((unsigned)ne >> 16) <= th_high) {
+                    c[b] = ne; p[b] = nk; l_choice[i] = ne & 0xffff;
+                    if (fl[b] & 1) atomicMin(&s_claim[ne & 0xffff], i);
+                } else {
+                    c[b] = -1; l_choice[i] = -1;
+                    // the shortlist is exact unless it ran dry while longer lists exist: rescanned right below.  (A first free
+                    // entry beyond th_high ends the query: whatever else is free is at least as far.)
+                    need_rescan[b] = nk == K && (fl[b] & 2);
+                    p[b] = K;
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < RQ; ++b) {
+            unsigned long long todo = __ballot(need_rescan[b]);
+#ifdef MORB_PHASE_CLOCKS
+            if (todo && lane == 0 && it_dbg < 15) atomicAdd((unsigned long long*)&g_ph_chg[16 + it_dbg], (unsigned long long)__popcll(todo));
+#endif
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int q = __builtin_amdgcn_readlane(qi[b], src);
+                const int full = l_cnt[q];
+                int k1 = 0x7fffffff, g1 = -1;
+                for (int k0 = 0; k0 < full; k0 += 64) {
+                    const int k = k0 + lane;
+                    int key = 0x7fffffff, gg = -1;
+                    if (k < full) {
+                        gg = cand_idx[k * nq + q];
+                        const int d = cand_dist[k * nq + q];
+                        bool avail = !(occupied && occupied[gg]);
+                        if (s_claim[gg] < q) avail = false;
+                        if (avail) key = (d << 16) | k;
+                    }
+                    const int m1 = (int)wave_min_u32((unsigned)key);
+                    if (m1 < k1) { k1 = m1; g1 = __builtin_amdgcn_readlane(gg, __ffsll((long long)__ballot(key == m1)) - 1); }
+                }
+                if (lane == src && k1 != 0x7fffffff && (k1 >> 16) <= th_high) {   // the rescanned pick is the entry under the cursor from now on
+                    c[b] = (k1 & 0xffff0000) | g1; l_choice[q] = g1;
+                    if (fl[b] & 1) atomicMin(&s_claim[g1], q);
+                }
+            }
+        }
+        return true;
+    };
+    // A ROUND = every wave repeats its pass until none of ITS queries is displaced (no barrier in between: what the other waves
+    // claim meanwhile is seen as it lands -- the iteration is monotone, so any interleaving ends in the same place), then one
+    // barrier; a round in which no wave saw anything displaced is the fixed point.  Dependency chains are followed at the pace
+    // of a pass (two LDS trips), not of a barrier: the benchmark stream needs 2-3 rounds where the Jacobi form needs 9 sweeps.
+    int it = 1, changed = 1;
+    const int qi01[RQ] = {tid, T + tid};
+    for (; it < max_it && changed; ++it) {
+#ifdef MORB_PHASE_CLOCKS
+        it_dbg = it;
+#endif
+        if (tid == 0) s_flag[(it + 1) % 3] = 0;   // (last read two rounds ago)
+        bool ch = false;
+        for (int guard = 0; guard < 4096; ++guard) {
+            bool w = pass(qi01, sl, cur, pos, flr);
+            // queries beyond the registers (more than 2048): shortlist and pick come back from LDS; the cursor restarts at the
+            // pick's place on the shortlist (a rescanned pick has none: cursor at the end)
+            for (int base = RQ * T; base < nq; base += RQ * T) {
+                int qx[RQ], e[RQ][K], c[RQ], p[RQ], fl[RQ];
+#pragma unroll
+                for (int b = 0; b < RQ; ++b) {
+                    const int i = base + b * T + tid;
+                    qx[b] = i; c[b] = -1; p[b] = K; fl[b] = 0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) e[b][k] = 0xffff;
+                    if (i < nq) {
+                        fl[b] = l_fl[i];
+                        const int g = l_choice[i];
+#pragma unroll
+                        for (int k = 0; k < K; ++k) e[b][k] = l_gd[k * nq + i];
+                        c[b] = g;   // (distance bits are only looked at when a pick is made)
+#pragma unroll
+                        for (int k = K - 1; k >= 0; --k) if (g >= 0 && (e[b][k] & 0xffff) == g) p[b] = k;
+                    }
+                }
+                w |= pass(qx, e, c, p, fl);
+            }
+            if (!w) {
+#ifdef MORB_PHASE_CLOCKS
+                if (lane == 0 && it_dbg < 15) atomicMax((unsigned long long*)&g_ph_chg[32 + it_dbg], (unsigned long long)guard);
+#endif
+                break;
+            }
+            ch = true;
+        }
+        if (ch && lane == 0) s_flag[it % 3] = 1;
+        __syncthreads();
+        changed = s_flag[it % 3];
+        MORB_PHASE(g_ph_res, min(2 + it, 50));
+    }
+    if (changed) {  // ran out of rounds
+        if (tid == 0) { status[1] = tagb | 0; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | 1; }
+        return;
+    }
+    if (tid == 0) s_red = 0;
+    __syncthreads();
+    MORB_PHASE(g_ph_res, 52);
+    // owners: the last claimant in query order (claims after a blocking one are impossible, so max index == final owner)
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    int acc = 0;
+    for (int i = tid; i < nq; i += T) {
+        const int c = l_choice[i];
+        if (c < 0) continue;
+        ++acc;
+        atomicMax(&s_owner[c], i);
+        if (check_ori) {
+            float rot = l_ang[i] - l_fang[c];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            const bool inr = bin >= 0 && bin < ORBM_HISTO_LENGTH;
+            l_fl[i] = (unsigned char)((l_fl[i] & 3) | ((inr ? bin + 1 : 0) << 2));
+            unsigned long long todo = __ballot(inr);
+            for (int r = 0; todo && r < 3; ++r) {
+                const int b0 = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);
+                const unsigned long long same = __ballot(inr && bin == b0);
+                if (inr && bin == b0 && lane == __ffsll((long long)same) - 1) atomicAdd(&s_hist[b0], __popcll(same));
+                todo &= ~same;
+            }
+            if (inr && ((todo >> lane) & 1)) atomicAdd(&s_hist[bin], 1);
+        }
+    }
+    acc = __builtin_amdgcn_readlane(wave_incl_scan(acc), 63);
+    if (lane == 0) atomicAdd(&s_red, acc);
+    __syncthreads();
+    MORB_PHASE(g_ph_res, 53);
+    if (check_ori) {
+        if (tid < 64) {   // ComputeThreeMaxima (reference src/ORBmatcher.cc:3948-3989), as in k_resolve
+            const int sv = tid < ORBM_HISTO_LENGTH ? s_hist[tid] : 0;
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < ORBM_HISTO_LENGTH; ++j) {
+                const int sj = __builtin_amdgcn_readlane(sv, j);
+                rank += (sj > sv || (sj == sv && j < tid)) ? 1 : 0;
+            }
+            const bool in = tid < ORBM_HISTO_LENGTH && sv > 0;
+            const unsigned long long r1 = __ballot(in && rank == 0), r2 = __ballot(in && rank == 1), r3 = __ballot(in && rank == 2);
+            int i1 = r1 ? __ffsll((long long)r1) - 1 : -1, i2 = r2 ? __ffsll((long long)r2) - 1 : -1, i3 = r3 ? __ffsll((long long)r3) - 1 : -1;
+            const int m1 = i1 >= 0 ? __builtin_amdgcn_readlane(sv, i1) : 0, m2 = i2 >= 0 ? __builtin_amdgcn_readlane(sv, i2) : 0,
+                      m3 = i3 >= 0 ? __builtin_amdgcn_readlane(sv, i3) : 0;
+            if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+            else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+            if (tid == 0) { s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3; }
+        }
+        __syncthreads();
+        MORB_PHASE(g_ph_res, 54);
+        int rej = 0;
+        for (int i = tid; i < nq; i += T) {
+            const int c = l_choice[i];
+            if (c < 0) continue;
+            const int bin = (int)(l_fl[i] >> 2) - 1;  // -1: outside the histogram, never rejected
+            if (bin >= 0 && bin < ORBM_HISTO_LENGTH && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
+                s_owner[c] = -2;  // every writer stores -2; owners were settled before the barrier
+                ++rej;
+            }
+        }
+        rej = __builtin_amdgcn_readlane(wave_incl_scan(rej), 63);
+        if (lane == 0) atomicSub(&s_red, rej);
+        __syncthreads();
+    }
+    MORB_PHASE(g_ph_res, 60);
+    for (int g = tid; g < NT; g += T) match_of_feature[g] = tagb ? (tagb | (s_owner[g] + 2)) : s_owner[g];
+    if (tagb) for (int g = NT + tid; g < F.n_total; g += T) match_of_feature[g] = tagb | 1;   // (see k_resolve: no stale tag can match)
+    if (tid == 0) { status[1] = tagb | s_red; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | 0; }
+    MORB_PHASE(g_ph_res, 61);
+#ifdef MORB_PHASE_CLOCKS
+    if (tid == 0) { g_ph_res[62] = (unsigned long long)it; g_ph_res[59] = clock64(); }
+#endif
+}
+
 // ---- the same resolve for frames whose claim tables do not fit LDS (beyond ~18 000 features: 8 cameras x 4000), spread
 // over the whole chip.  The two claim tables, the choices and the owner table live in HBM (L2-resident); one launch per
 // sweep (a grid-wide barrier is exactly what a kernel boundary is), a fixed number of sweeps is enqueued and a sweep
@@ -650,7 +960,7 @@ __global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __rest
 
 int morb::search_raise_lds_limits() {
     const void* fns[] = {(const void*)k_resolve<true, false>, (const void*)k_resolve<false, false>, (const void*)k_resolve<true, true>,
-                         (const void*)k_resolve<false, true>};
+                         (const void*)k_resolve<false, true>, (const void*)k_resolve_mono};
     for (const void* fn : fns) MORB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return ORB_OK;
 }
@@ -947,7 +1257,12 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
                        (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20)
     J.seq = 0;
     if (J.want_tags) { m->resolve_seq = m->resolve_seq % 2047 + 1; J.seq = m->resolve_seq; }   // 1..2047, never 0
-    if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
+    static const bool mono_env = [] { const char* e = getenv("MORB_RESOLVE_MONO"); return !(e && atoi(e) == 0); }();
+    if (ldsq && !J.points && mono_env)
+        hipLaunchKernelGGL(k_resolve_mono, dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const int2*)m->d_qmeta.p, nq, cap,
+                           (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ, (const float*)cur->b->d_ang.p,
+                           th_high, J.check_ori, 4096, (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20);
+    else if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
     else { if (J.points) MORB_RESOLVE_LAUNCH(true, false); else MORB_RESOLVE_LAUNCH(false, false); }
 #undef MORB_RESOLVE_LAUNCH
     MORB_HIP(hipGetLastError());  // status + matches are written by the kernel into the mapped pinned buffer

@@ -1,4 +1,5 @@
 """GPU parity: HIP matcher (through the C ABI) vs the CPU oracle.  Bit-exact for every output."""
+import os
 import numpy as np
 import pytest
 
@@ -275,6 +276,19 @@ def test_device_resolve_long_dependency_chains_and_host_fallback_agree():
         e_n, e_m = (on, omo) if k % 2 == 0 else (onp, omop)
         assert cnt == e_n and np.array_equal(mo, e_m), k
     assert on >= n                                           # every feature ends up claimed
+
+
+def test_frame_search_resolves_the_same_as_jacobi_sweeps_and_as_the_monotone_iteration():
+    """SearchByProjection(Frame, Frame) resolves with k_resolve_mono by default and with k_resolve's Jacobi sweeps under
+    MORB_RESOLVE_MONO=0 (read once per process: a child process runs the frame-search tests of this file, adversarial claim
+    chains included, on the other kernel).  Both must equal the oracle -- this process has just shown it for the default."""
+    import subprocess, sys
+    env = dict(os.environ, MORB_RESOLVE_MONO="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "search_by_projection_frames or long_dependency_chains"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    tail = r.stdout.decode()[-2000:]
+    assert r.returncode == 0 and " passed" in tail, tail
 
 
 def test_projection_search_large_frame_keeps_its_claim_tables_in_hbm(matcher):

@@ -31,15 +31,23 @@ print("describe, one wave (block 40): slot bookkeeping, patch fetch, moments + a
       deltas(v, [0, 1, 2, 3, 4, 5, 6, 7]), "total", (v[7] - v[0]) / 100.0)
 lib.morb_debug_phases_matcher(0, out); v = list(out)
 it = int(v[62])
-idx = [0, 1, 2] + list(range(3, 3 + it)) + [60, 61]
-print("resolve: init, ldsq-load, sweeps x%d, tail, write:" % it, deltas(v, idx), "total", (v[61] - v[0]) / 100.0)
-print("  queries rescanned per sweep:", [int(x) for x in v[40:40 + it]])
-print("  sweep 0: thread-0 loop (incl. its wave's rescans), closing barrier:", deltas(v, [2, 20, 3]))
-print("  tail: reset, owners + histogram, three maxima, reject:", deltas(v, [2 + it, 52, 53, 54, 60]))
-if it > 5:
-    print("  sweep 5: thread-0 loop (incl. its wave's rescans), closing barrier:", deltas(v, [7, 24, 8]))
+if v[1] == 0:   # k_resolve_mono (the default of the frame search): set-up incl. round 0, rounds 1.., tail
+    idx = [0, 2] + list(range(3, 2 + it)) + [60, 61]
+    print("resolve (monotone): set-up + round 0, rounds x%d, tail, write:" % (it - 1), deltas(v, idx), "total", (v[61] - v[0]) / 100.0)
+    print("  tail: owners + histogram, three maxima, reject:", deltas(v, [1 + it, 52, 53, 54, 60]))
+    print("  shader clock over the kernel: %.0f MHz" % ((v[59] - v[58]) / ((v[61] - v[0]) / 100.0)))
+else:           # k_resolve (Jacobi sweeps; MORB_RESOLVE_MONO=0, top-2 searches, states beyond LDS)
+    idx = [0, 1, 2] + list(range(3, 3 + it)) + [60, 61]
+    print("resolve: init, ldsq-load, sweeps x%d, tail, write:" % it, deltas(v, idx), "total", (v[61] - v[0]) / 100.0)
+    print("  queries rescanned per sweep:", [int(x) for x in v[40:40 + it]])
+    print("  sweep 0: thread-0 loop (incl. its wave's rescans), closing barrier:", deltas(v, [2, 20, 3]))
+    print("  tail: reset, owners + histogram, three maxima, reject:", deltas(v, [2 + it, 52, 53, 54, 60]))
+    if it > 5:
+        print("  sweep 5: thread-0 loop (incl. its wave's rescans), closing barrier:", deltas(v, [7, 24, 8]))
 out[0] = 0xC4A26E
 lib.morb_debug_phases_matcher(0, out); c = list(out)
-print("  queries that changed their choice per sweep (sum over %d steps):" % 6, [int(x) for x in c[:12]])
+print("  queries that changed their choice per sweep / were displaced per round (sum over %d steps):" % 6, [int(x) for x in c[:12]])
+print("  (monotone) queries rescanned per round (sum over %d steps):" % 6, [int(x) for x in c[16:28]])
+print("  (monotone) passes with displaced queries of the busiest wave per round (max over the steps):", [int(x) for x in c[32:44]])
 lib.morb_debug_phases_matcher(1, out); v = list(out)
 print("frame_build: counts, fill, scan, scatter, sort:", deltas(v, [0, 1, 2, 3, 4, 5]), "total", (v[5] - v[0]) / 100.0)
