@@ -106,11 +106,36 @@ def pct(xs, p):
 
 
 # ------------------------------------------------------------------------------------------------ matcher rooflines
-def matcher_roofline(rt, m, stream, n, iters=80):
+def _settled_launches(rt, run, stream, iters, group=10, tol=0.003, max_groups=40):
+    """Average duration (ms) of `iters` launches of `run` AFTER the launch duration has settled, + how many launches that took.
+    A kernel that keeps the whole chip busy runs its first ~100-150 launches (tens of ms after an idle period) up to 20 %
+    slower than the ones after -- the clocks take that long to settle (tools/experiments/top2_transient.py; the curve is in
+    profiles/r03/notes_experiments.md) -- so the sustained figure is timed only once the mean of three consecutive groups of
+    `group` launches is within `tol` of the mean of the three groups before (or after `max_groups` groups).  HIP events on the stream the kernels are launched on."""
+    ev = [rt.Event() for _ in range(max_groups + 1)]
+    ev[0].record(stream)
+    hist = []
+    used = 0
+    for g in range(max_groups):
+        for _ in range(group):
+            run()
+        ev[g + 1].record(stream)
+        hist.append(ev[g].elapsed_ms(ev[g + 1]) / group)   # (waits for the group: the transient is tens of groups long)
+        used += group
+        if len(hist) >= 6 and abs(sum(hist[-3:]) - sum(hist[-6:-3])) <= tol * sum(hist[-3:]):   # (no drift left between 3-group means)
+            break
+    e0, e1 = rt.Event(), rt.Event()
+    e0.record(stream)
+    for _ in range(iters):
+        run()
+    e1.record(stream)
+    return e0.elapsed_ms(e1) / iters, used, [round(h * 1e3, 1) for h in hist]
+
+
+def matcher_roofline(rt, m, stream, n, iters=200):
     """`roofline` of the bench line (M2): the uint16 distance matrix in its default (matrix-core) form, with the xor/popcount
     form of the same kernel -- the formulation north_star names -- timed beside it under `popcount_form`.
-    80 launches (~35 ms): the chip boosts for the first ~6 launches, dips for the next dozen and then settles
-    (profiles/r01/notes_experiments.md); the average over a run this long is the sustained figure."""
+    200 launches (~80 ms) timed after the launch duration has settled (_settled_launches): the sustained figure."""
     out = _matrix_launches(rt, m, stream, n, iters)
     prev = m.Matcher.use_matrix_cores(0)
     try:
@@ -130,15 +155,8 @@ def _matrix_launches(rt, m, stream, n, iters):
     d = synth.descriptors(n, 4242)
     dq = rt.DeviceBuffer(n * 32); dr = rt.DeviceBuffer(n * 32); dout = rt.DeviceBuffer(n * n * 2)
     dq.upload(d); dr.upload(synth.perturbed_queries(d, 9))
-    for _ in range(3):
-        m.Matcher.hamming_matrix_device(dq.ptr, n, dr.ptr, n, dout.ptr, stream)
-    rt.stream_sync(stream)
-    e0, e1 = rt.Event(), rt.Event()
-    e0.record(stream)
-    for _ in range(iters):
-        m.Matcher.hamming_matrix_device(dq.ptr, n, dr.ptr, n, dout.ptr, stream)
-    e1.record(stream)
-    ms = e0.elapsed_ms(e1) / iters
+    ms, settle_launches, settle_curve = _settled_launches(
+        rt, lambda: m.Matcher.hamming_matrix_device(dq.ptr, n, dr.ptr, n, dout.ptr, stream), stream, iters)
     alg_bytes = 32.0 * (n + n) + 2.0 * n * n
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     # spot-check of the timed buffer against the host popcount (row n-1)
@@ -157,10 +175,11 @@ def _matrix_launches(rt, m, stream, n, iters):
         b.free()
     return {"kernel": "k_hamming_matrix_mfma", "workload": "Q=R=%d uint16 distance matrix" % n, "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(ms * 1e3, 2)}
+            "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(ms * 1e3, 2), "timed_launches": iters,
+            "launches_before_timing": settle_launches, "settling_us_per_launch_groups_of_10": settle_curve}
 
 
-def top2_roofline(rt, m, stream, n, iters=20):
+def top2_roofline(rt, m, stream, n, iters=200):
     """`roofline_m1`: exhaustive top-2, Q = R = n.  18 int ops per 256-bit pair (8 xor + 8 popcount +
     2 compare/select) against the integer vector peak for the xor/popcount form; the default matrix-core form of the same
     entry point (int8 dot product of the +-1-expanded descriptors, 512 int8 ops per pair) against the dense int8 MFMA peak."""
@@ -179,15 +198,7 @@ def top2_roofline(rt, m, stream, n, iters=20):
             sb = m.Matcher.top2_scratch_bytes(n, n)
             scratch = rt.DeviceBuffer(max(sb, 16))
             run = lambda: m.Matcher.hamming_top2_device(dq.ptr, n, dr.ptr, n, o[0].ptr, o[1].ptr, o[2].ptr, scratch.ptr if sb else None, stream)
-            for _ in range(2):
-                run()
-            rt.stream_sync(stream)
-            e0, e1 = rt.Event(), rt.Event()
-            e0.record(stream)
-            for _ in range(iters):
-                run()
-            e1.record(stream)
-            ms = e0.elapsed_ms(e1) / iters
+            ms, settle_launches, settle_curve = _settled_launches(rt, run, stream, iters if on else max(5, iters // 4))
             bi = o[0].download(np.int32, 64, stream); bd = o[1].download(np.int32, 64, stream)
             for i in range(0, 64, 9):   # spot check against the host popcount
                 dist = np.unpackbits(d ^ qh[i], axis=1).sum(1)
@@ -199,7 +210,8 @@ def top2_roofline(rt, m, stream, n, iters=20):
             ach = 512.0 * pairs / (ms * 1e-3) / 1e12
             out[form] = {"kernel": "k_hamming_top2_mfma", "bound": "mfma", "achieved": round(ach, 1), "peak": I8_MFMA_PEAK_TOPS,
                          "unit": "int8 TOP/s", "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
-                         "pairs_per_s": round(pairs / (ms * 1e-3), 0)}
+                         "pairs_per_s": round(pairs / (ms * 1e-3), 0), "timed_launches": iters, "launches_before_timing": settle_launches,
+                         "settling_us_per_launch_groups_of_10": settle_curve}
         else:
             ach = 18.0 * pairs / (ms * 1e-3) / 1e12
             out[form] = {"kernel": "k_hamming_top2", "bound": "valu", "achieved": round(ach, 2), "peak": INT_VALU_PEAK_TOPS,

@@ -257,6 +257,10 @@ orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_on
         else if (victim->fr && c.stamp < victim->stamp) victim = &c;
     }
     ++T.misses;
+    // the evicted entry goes first: its buffers are recycled once the matcher's stream has drained, which it has now (the
+    // previous search ended with a synchronisation) and would not have right behind the new frame's upload (measured: 13 us
+    // of every SearchByProjection went into waiting for the unpack kernel just launched)
+    if (victim->fr) { orbm_frame_destroy(victim->fr); victim->fr = nullptr; }
     FlatFrame ff;
     if (!flatten(F, cam1_only, ff)) {
         fail("device_frame (a feature without an entry in keypoint_to_cam / cont_idx_to_local_cam_idx, or without a descriptor row)", ORB_E_ARG);
@@ -265,7 +269,6 @@ orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_on
     orbm_frame* fr = nullptr;
     const int rc = orbm_frame_create(m, &ff.d, &fr);
     if (rc) { fail("orbm_frame_create", rc); return nullptr; }
-    if (victim->fr) orbm_frame_destroy(victim->fr);
     victim->kind = kind; victim->id = id; victim->guard = guard; victim->n = n; victim->cam1 = cam1_only; victim->fr = fr; victim->stamp = T.clock;
     return fr;
 }

@@ -271,6 +271,150 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_pipe(const uint32_t* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------- balanced phases
+// k_pipe's two phases are unequal: 16 MFMAs next to 72 key instructions + the whole next tile's expansion (70), then 16 MFMAs
+// next to 72 key instructions.  Here the expansion of tile t + 2 is split: its first k-step pair in the second phase of
+// iteration t (into the LDS buffer tile t has just left), the other pair in the first phase of iteration t + 1; one barrier per
+// iteration as before, references fetched one tile further ahead.  ~107 vector instructions (428 cycles) next to 16 MFMAs
+// (512 cycles) in either phase.
+#ifndef VALU_B
+#define VALU_B 7
+#endif
+template <int MODE>
+__global__ __launch_bounds__(64 * MM_WAVES) void k_pipe2(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ r, int nr,
+                                                         int slice_len, int* __restrict__ p_idx, int* __restrict__ p_best,
+                                                         int* __restrict__ p_second) {
+    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.y * MM_Q_PER_BLOCK + wave * 64;
+    mm_i32x4 bq[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qi = min(q0 + g * 32 + c, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
+        const uint4 lo = p[0], hi = p[1];
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bq[g][ks] = mm_expand16(h ? (w[ks] >> 16) : (w[ks] & 0xffffu));
+    }
+    mm_i32x16 cinit;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cinit[e] = 8192 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    const int s0 = blockIdx.x * slice_len, s1 = min(nr, s0 + slice_len);
+    const int n_tiles = (s1 - s0 + MM_R_TILE - 1) / MM_R_TILE;
+    auto fetch = [&](int t) {
+        const int rr = min(s0 + min(t, n_tiles - 1) * MM_R_TILE + lane, nr - 1);
+        return *reinterpret_cast<const uint2*>(r + (size_t)rr * 8 + wave * 2);
+    };
+    auto deposit_x = [&](int buf, uint32_t w) {
+        mm_i32x4* base = &s_tile[buf][(h * 8 + wave * 2) * 64 + c];
+        base[0] = mt_expand16(w & 0xffffu);
+        base[32] = mt_expand16(w >> 16);
+    };
+    auto deposit_y = [&](int buf, uint32_t w) {
+        mm_i32x4* base = &s_tile[buf][(h * 8 + wave * 2) * 64 + c];
+        base[64] = mt_expand16(w & 0xffffu);
+        base[96] = mt_expand16(w >> 16);
+    };
+    constexpr uint32_t KEY_NONE = 256u << 6;
+    uint32_t kb[2] = {KEY_NONE, KEY_NONE}, ks2[2] = {KEY_NONE, KEY_NONE};
+    int where[2] = {-1, -1};
+    auto mfma_half = [&](mm_i32x16 (&acc)[2], int buf, int a) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const mm_i32x4 af = s_tile[buf][(a * 8 + ks) * 64 + lane];
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bq[0][ks], ks ? acc[0] : cinit, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bq[1][ks], ks ? acc[1] : cinit, 0, 0, 0);
+        }
+    };
+    auto keys_full = [&](const mm_i32x16 (&acc)[2], int blk) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint32_t before = kb[g];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t key = (uint32_t)acc[g][e];
+                ks2[g] = mt_umed3(kb[g], ks2[g], key);
+                kb[g] = min(kb[g], key);
+            }
+            where[g] = kb[g] != before ? ((blk << 5) | (int)(kb[g] & 31u)) : where[g];
+            kb[g] &= ~63u;
+        }
+    };
+    auto keys_masked = [&](const mm_i32x16 (&acc)[2], int blk, int a, int valid) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint32_t before = kb[g];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int local = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const uint32_t key = local < valid ? (uint32_t)acc[g][e] : KEY_NONE;
+                ks2[g] = mt_umed3(kb[g], ks2[g], key);
+                kb[g] = min(kb[g], key);
+            }
+            where[g] = kb[g] != before ? ((blk << 5) | (int)(kb[g] & 31u)) : where[g];
+            kb[g] &= ~63u;
+        }
+    };
+    auto hints = [&]() {
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VALU_B, 0);
+            }
+        }
+    };
+    {
+        const uint2 w0 = fetch(0);
+        deposit_x(0, w0.x); deposit_y(0, w0.y);
+    }
+    uint2 n1 = fetch(1), n2 = fetch(2);
+    deposit_x(1, n1.x);
+    __syncthreads();
+    mm_i32x16 acc0[2], acc1[2];
+    mfma_half(acc0, 0, 0);
+    for (int t = 0; t + 1 < n_tiles; ++t) {     // tiles 0 .. n_tiles-2 are full
+        const int buf = t & 1;
+        // P1: second half of tile t | keys of its first half | second k-step pair of tile t + 1 into the other buffer
+        mfma_half(acc1, buf, 1);
+        keys_full(acc0, 2 * t);
+        deposit_y(buf ^ 1, n1.y);
+        hints();
+        __syncthreads();
+        n1 = n2;
+        n2 = fetch(t + 3);
+        // P2: first half of tile t + 1 | keys of the second half of tile t | first k-step pair of tile t + 2 into tile t's buffer
+        mfma_half(acc0, buf ^ 1, 0);
+        keys_full(acc1, 2 * t + 1);
+        deposit_x(buf, n1.x);
+        hints();
+    }
+    {   // last tile (may be partial): its first half is in acc0 already
+        const int t = n_tiles - 1, buf = t & 1;
+        const int valid = s1 - s0 - t * MM_R_TILE;
+        mfma_half(acc1, buf, 1);
+        keys_masked(acc0, 2 * t, 0, valid);
+        keys_masked(acc1, 2 * t + 1, 1, valid);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t mine_b = ((kb[g] >> 6) << 16) | (uint32_t)(where[g] & 0xffff), mine_s = (ks2[g] >> 6) << 16 | 0xffffu;
+        const uint32_t ob = (uint32_t)__shfl_xor((int)mine_b, 32), os = (uint32_t)__shfl_xor((int)mine_s, 32);
+        const uint32_t nb = min(mine_b, ob), ns = min(max(mine_b, ob), min(mine_s, os));
+        const int qrow = q0 + g * 32 + c;
+        if (h == 0 && qrow < nq) {
+            const size_t o = (size_t)blockIdx.x * nq + qrow;
+            const int best = (int)(nb >> 16);
+            p_best[o] = best;
+            p_idx[o] = best < 256 ? s0 + (int)(nb & 0xffffu) : -1;
+            p_second[o] = (int)min(ns >> 16, 256u);
+        }
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 static uint32_t h32(uint64_t x) { x &= 0xffffffffu; x ^= x >> 16; x = (x * 0x85EBCA6Bu) & 0xffffffffu; x ^= x >> 13; x = (x * 0xC2B2AE35u) & 0xffffffffu; x ^= x >> 16; return (uint32_t)x; }
@@ -322,6 +466,13 @@ int main(int argc, char** argv) {
     CK(hipMemset(pi[1], 0, (size_t)s_eff * nq * 4));
     run(k_pipe<1>, "pipelined, sched groups", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
     grab(1, b); printf("   equal to baseline: %s\n", a == b ? "yes" : "NO");
+    CK(hipMemset(pi[1], 0, (size_t)s_eff * nq * 4));
+    run(k_pipe2<0>, "balanced phases, no hints", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
+    grab(1, b); printf("   equal to baseline: %s\n", a == b ? "yes" : "NO");
+    CK(hipMemset(pi[1], 0, (size_t)s_eff * nq * 4));
+    run(k_pipe2<1>, "balanced phases, sched groups", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
+    grab(1, b); printf("   equal to baseline: %s\n", a == b ? "yes" : "NO");
+    run(k_pipe<0>, "pipelined, no hints (again)", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
     run(k_base, "baseline again", s_eff, qb, dq, nq, dr, nr, len, pi[0], pb[0], ps[0], iters);
     return 0;
 }
