@@ -454,6 +454,51 @@ __device__ __forceinline__ bool fast_may_be_corner(const uint8_t* t, int T) {
     return bright || dark;
 }
 
+// The same test for FOUR horizontally adjacent pixels on packed 16-bit lanes (round 3).  `t32` points at the dword of the
+// centre row that holds tile columns [4 gx, 4 gx + 4); the four pixels sit at columns 4 gx + 3 .. 4 gx + 6 (the tile's origin is
+// three pixels left of the scored rectangle and dword-aligned in LDS), so every operand is a compile-time byte alignment of two
+// neighbouring dwords.  With d_k = centre - ring_k:  a bright arc needs  min over the four antipodal pairs of max(d_k, d_k+8) >= T,
+// a dark arc  max over the pairs of min(d_k, d_k+8) <= -T  -- 8 subtractions and 16 min/max per PAIR of pixels instead of 8
+// subtractions, 16 compares and the logic per pixel, and 13 dword reads per four pixels instead of up to 9 byte reads per pixel.
+// Returns bit j = pixel j may be a corner.
+using fq_s16x2 = short __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned fast_may_be_corner_x4(const uint32_t* t32, int T) {
+    constexpr int P = TILE_PITCH / 4;
+    auto ab = [](uint32_t hi, uint32_t lo, int sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); };
+    const uint32_t w0 = t32[0], w1 = t32[1], w2 = t32[2];
+    const uint32_t u0 = t32[3 * P], u1 = t32[3 * P + 1];            // ring 0: (+3, 0)
+    const uint32_t v0 = t32[-3 * P], v1 = t32[-3 * P + 1];          // ring 8: (-3, 0)
+    const uint32_t a0 = t32[2 * P], a1 = t32[2 * P + 1], a2 = t32[2 * P + 2];      // ring 2: (+2, +2), ring 14: (+2, -2)
+    const uint32_t b0 = t32[-2 * P], b1 = t32[-2 * P + 1], b2 = t32[-2 * P + 2];   // ring 6: (-2, +2), ring 10: (-2, -2)
+    const uint32_t ring[8] = {ab(u1, u0, 3), ab(v1, v0, 3),        // 0, 8
+                              ab(w2, w1, 2), w0,                   // 4 (0, +3), 12 (0, -3)
+                              ab(a2, a1, 1), ab(b1, b0, 1),        // 2, 10
+                              ab(b2, b1, 1), ab(a1, a0, 1)};       // 6, 14
+    const uint32_t c = ab(w1, w0, 3);
+    const short Ts = (short)T;
+    const fq_s16x2 T2 = {Ts, Ts}, zero = {0, 0};
+    unsigned pass = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t sel = h ? 0x0c030c02u : 0x0c010c00u;       // bytes 2h, 2h + 1 -> the low bytes of the two 16-bit lanes
+        const fq_s16x2 C = __builtin_bit_cast(fq_s16x2, __builtin_amdgcn_perm(0u, c, sel));
+        fq_s16x2 d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = C - __builtin_bit_cast(fq_s16x2, __builtin_amdgcn_perm(0u, ring[k], sel));
+        const fq_s16x2 bright = __builtin_elementwise_min(
+            __builtin_elementwise_min(__builtin_elementwise_max(d[0], d[1]), __builtin_elementwise_max(d[2], d[3])),
+            __builtin_elementwise_min(__builtin_elementwise_max(d[4], d[5]), __builtin_elementwise_max(d[6], d[7])));
+        const fq_s16x2 dark = __builtin_elementwise_max(
+            __builtin_elementwise_max(__builtin_elementwise_min(d[0], d[1]), __builtin_elementwise_min(d[2], d[3])),
+            __builtin_elementwise_max(__builtin_elementwise_min(d[4], d[5]), __builtin_elementwise_min(d[6], d[7])));
+        const fq_s16x2 m = __builtin_elementwise_max(bright, zero - dark) - T2;   // >= 0 where the pixel passes
+        const uint32_t mb = __builtin_bit_cast(uint32_t, m);
+        pass |= ((mb & 0x8000u) ? 0u : 1u) << (2 * h);
+        pass |= ((mb & 0x80000000u) ? 0u : 2u) << (2 * h);
+    }
+    return pass;
+}
+
 __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict__ L, const int2* __restrict__ cell_map,
                                                     const uint8_t* __restrict__ pyr, size_t cam_pitch, int max_levels,
                                                     int* __restrict__ cell_cnt, uint32_t* __restrict__ cell_items) {
@@ -486,40 +531,53 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
     // p / cw (and i / ndw below) for p < 70 * 70 by multiplication: exact because p * divisor < 2^20 (divisors <= 70)
     const unsigned inv_cw = ((1u << 20) + cw - 1) / cw;
 
-    // stage the tile (origin x0-3, y0-3; always inside the level) as aligned dwords: the rows of a level start on 64-byte
-    // boundaries, so the dwords that cover columns [x0-3, x0-3+tw) are fetched whole and the tile's origin sits `sh` bytes into
-    // its LDS rows (byte loads cost an address computation, a load and an LDS store per BYTE: a ninth of this kernel's
-    // instructions; reads stay inside the row: the last dword ends before column w - 13)
-    const int sh = (x0 - 3) & 3, ndw = (sh + tw + 3) >> 2;
+    // stage the tile (origin x0-3, y0-3; always inside the level) dword by dword: the rows of a level start on 64-byte
+    // boundaries, so the global dwords that cover columns [x0-3, x0-3+tw) are fetched whole (byte loads cost an address
+    // computation, a load and an LDS store per BYTE: a ninth of this kernel's instructions) and shifted by the origin's
+    // misalignment `sh` on the way in, so that the tile's origin is dword-aligned in LDS (the packed quick test relies on it).
+    // Reads stay inside the row: the last dword fetched ends before column w - 5.
+    const int sh = (x0 - 3) & 3, ndw = (tw + 3) >> 2;
     const unsigned inv_ndw = ((1u << 20) + ndw - 1) / ndw;
     {
         const uint8_t* src = img + (size_t)(y0 - 3) * Lv.stride + (x0 - 3 - sh);
         for (int i = tid; i < ndw * th; i += 256) {
             const int ty = (int)(((unsigned)i * inv_ndw) >> 20), k = i - ty * ndw;
-            reinterpret_cast<uint32_t*>(tile_raw)[ty * (TILE_PITCH / 4) + k] = *reinterpret_cast<const uint32_t*>(src + (size_t)ty * Lv.stride + 4 * k);
+            const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (size_t)ty * Lv.stride + 4 * k);
+            const uint32_t lo = g[0], hi = sh ? g[1] : 0u;
+            reinterpret_cast<uint32_t*>(tile_raw)[ty * (TILE_PITCH / 4) + k] = __builtin_amdgcn_alignbyte(hi, lo, sh);
         }
     }
-    const uint8_t* tile = tile_raw + sh;
+    const uint8_t* tile = tile_raw;
     for (int i = tid; i < (ch + 2) * (SCORE_PITCH / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
     if (tid < CELL_MAX * CELL_MAX / 32) s_max[tid] = 0;
     if (tid == 0) { s_any = 0; s_nsurv = 0; }
     __syncthreads();
 
-    // pass 1: quick test on every pixel, survivors compacted (any order) so that pass 2 runs the full score on dense lanes
-    const int npx = cw * ch;
+    // pass 1: quick test on every pixel, four adjacent pixels per lane (fast_may_be_corner_x4); survivors compacted (any order)
+    // so that pass 2 runs the full score on dense lanes
     const int lane = tid & 63;
-    for (int base = 0; base < npx; base += 256) {
-        const int p = base + tid;
-        bool ok = false;
-        if (p < npx) {
-            const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
-            ok = fast_may_be_corner(&tile[(py + 3) * TILE_PITCH + px + 3], Lv.min_th + 1);
+    const int gpr = (cw + 3) >> 2, ngroups = gpr * ch;               // groups of four per row
+    const unsigned inv_gpr = ((1u << 20) + gpr - 1) / gpr;           // (g / gpr exact: g * gpr < 2^20)
+    for (int base = 0; base < ngroups; base += 256) {
+        const int g = base + tid;
+        unsigned m4 = 0;
+        int p0 = 0;
+        if (g < ngroups) {
+            const int py = (int)(((unsigned)g * inv_gpr) >> 20), gx = g - py * gpr;
+            m4 = fast_may_be_corner_x4(reinterpret_cast<const uint32_t*>(tile_raw) + (py + 3) * (TILE_PITCH / 4) + gx, Lv.min_th + 1);
+            const int left = cw - 4 * gx;                            // pixels of this group inside the scored rectangle
+            if (left < 4) m4 &= (1u << left) - 1u;
+            p0 = py * cw + 4 * gx;
         }
-        const unsigned long long m = __ballot(ok);
+        const int cnt = __popc(m4);
+        const int incl = wave_incl_scan(cnt);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
         int wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(&s_nsurv, __popcll(m));
-        wbase = __shfl(wbase, 0);
-        if (ok) s_surv[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+        if (lane == 0 && total) wbase = atomicAdd(&s_nsurv, total);
+        int pos = __builtin_amdgcn_readfirstlane(wbase) + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((m4 >> j) & 1u) s_surv[pos++] = (unsigned short)(p0 + j);
     }
     __syncthreads();
     const int nsurv = s_nsurv;
