@@ -88,36 +88,44 @@ __device__ __forceinline__ void project_wave(const ProjectArgs& A, const int qi,
                 }
                 const int oexcl = __shfl(excl, lo), ostart = __shfl(cs, lo);
                 const int g = valid ? F.items[ostart + (t - oexcl)] : 0;
+                // Everything the gates and the distance need of item g is requested HERE, in one round trip: octave, position,
+                // right coordinate and the descriptor.  (Rounds 1-2 loaded each field inside the gate before it -- level,
+                // then window, then right coordinate, then the descriptor of the survivors: four dependent trips through a
+                // memory system that other streams' kernels keep busy, 20 us per launch next to two extraction chains against
+                // 9.5 us alone.  A window holds about twice as many items as pass its gates: the extra bytes are nothing
+                // next to the trips.)  Lanes beyond the chunk read item 0 (every frame array has at least one element).
+                const int oct = F.octave[g];
+                const float gx = F.un_x[g], gy = F.un_y[g], urg = F.uright[g];
+                uint4 gd0 = make_uint4(0, 0, 0, 0), gd1 = gd0;
+                if (with_dist) { gd0 = F.desc[2 * g]; gd1 = F.desc[2 * g + 1]; }
                 bool pass = valid;
-                if (pass && bCheckLevels) {
-                    const int oct = F.octave[g];
+                if (bCheckLevels) {
                     if (oct < minLevel) pass = false;
                     if (maxLevel >= 0 && oct > maxLevel) pass = false;
                 }
-                if (pass) {
-                    const float distx = F.un_x[g] - x, disty = F.un_y[g] - y;
-                    pass = fabsf(distx) < r && fabsf(disty) < r;
+                {
+                    const float distx = gx - x, disty = gy - y;
+                    pass = pass && fabsf(distx) < r && fabsf(disty) < r;
                 }
-                if (pass && gate_right == 1) {
-                    const float urg = F.uright[g];
+                if (gate_right == 1) {
                     if (urg > 0 && fabsf(ur - urg) > r) pass = false;   // a NaN `ur` never closes this gate
                 }
                 if (pass && gate_right == 2) {   // Fuse's reprojection-error gate (src/ORBmatcher.cc:2118-2143)
-                    const float kpr = F.uright[g];
-                    const float ex = x - F.un_x[g], ey = y - F.un_y[g];
+                    const float kpr = urg;
+                    const float ex = x - gx, ey = y - gy;
                     if (kpr >= 0) {
                         const float er = ur - kpr;
                         const float e2 = ex * ex + ey * ey + er * er;
-                        if ((double)(e2 * inv_sigma2[F.octave[g]]) > 7.8) pass = false;
+                        if ((double)(e2 * inv_sigma2[oct]) > 7.8) pass = false;
                     } else {
                         const float e2 = ex * ex + ey * ey;
-                        if ((double)(e2 * inv_sigma2[F.octave[g]]) > 5.99) pass = false;
+                        if ((double)(e2 * inv_sigma2[oct]) > 5.99) pass = false;
                     }
                 }
                 const unsigned long long mask = __ballot(pass);
                 const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
                 int dist = 0;
-                if (pass && with_dist) dist = ham256(q0, q1, F.desc[2 * g], F.desc[2 * g + 1]);
+                if (pass && with_dist) dist = ham256(q0, q1, gd0, gd1);
                 if (pass && pos < cap) {
                     const size_t o = transposed ? (size_t)pos * nq + qi : (size_t)qi * cap + pos;
                     cand_idx[o] = g;
