@@ -488,10 +488,15 @@ def main(argv=None):
             del stamps[:]
             t_start = time.perf_counter()
             run(K, t, overlap, pinned, record=True)
-            sync_all()
-            el = time.perf_counter() - t_start
+            # closing bracket: this rank's work has drained (synchronise), its clock is read, and the MAX over the ranks -- the
+            # moment the slowest rank was done -- is the block's time; the reduction itself is the closing barrier and stays
+            # outside the clock (a barrier's own latency is not the path's)
+            rt.device_sync()
             if dist is not None:
                 import torch
+                torch.cuda.synchronize()
+            el = time.perf_counter() - t_start
+            if dist is not None:
                 tt = torch.tensor([el], dtype=torch.float64, device="cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
