@@ -113,3 +113,36 @@ def test_extractor_algorithmic_bytes_are_the_survey_figures():
     assert round(bench.extract_alg_bytes(640, 480, 1000) / 1e6, 2) == 1.65
     assert round(bench.extract_alg_bytes(1280, 720, 2000) / 1e6, 2) == 4.90
     assert round(bench.extract_alg_bytes(1920, 1080, 4000) / 1e6, 2) == 11.01
+
+
+class _FakeClockRt:
+    """rt stand-in for _settled_launches: every launch advances a clock by the next duration of a scripted curve."""
+
+    def __init__(self, curve_ms):
+        self.curve = list(curve_ms); self.now = 0.0; self.launches = 0
+        rt = self
+
+        class Event:
+            def record(self, stream):
+                self.t = rt.now
+
+            def elapsed_ms(self, other):
+                return other.t - self.t
+        self.Event = Event
+
+    def launch(self):
+        self.now += self.curve[min(self.launches, len(self.curve) - 1)]
+        self.launches += 1
+
+
+def test_settled_launches_times_only_behind_the_transient():
+    """The roofline timing waits until three groups of ten launches agree with the three before within 0.3 %, then times `iters`
+    launches: a scripted curve that falls for 150 launches and then stands still must give the settled value."""
+    curve = [0.300 - 0.001 * i for i in range(100)] + [0.200 - 0.0002 * i for i in range(50)] + [0.190]
+    rt = _FakeClockRt(curve)
+    ms, used, hist = bench._settled_launches(rt, rt.launch, None, iters=50)
+    assert abs(ms - 0.190) < 1e-9 and used % 10 == 0 and 180 <= used <= 400 and len(hist) == used // 10
+    # a duration that never settles stops at the group limit and still reports what it timed
+    rt = _FakeClockRt([0.5 - 0.0005 * i for i in range(1000)])
+    ms, used, hist = bench._settled_launches(rt, rt.launch, None, iters=10, max_groups=12)
+    assert used == 120 and 0.0 < ms < 0.5
