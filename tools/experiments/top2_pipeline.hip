@@ -271,6 +271,149 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_pipe(const uint32_t* __restri
     }
 }
 
+// ---- k_pipe<0> with the references expanded through a 256-entry LDS table (byte -> 8 int8 of -32 / +32): 8 ds_read_b64 and
+// ~16 vector instructions per lane and tile instead of 64 vector instructions
+template <int MODE>
+__global__ __launch_bounds__(64 * MM_WAVES) void k_pipe3(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ r, int nr,
+                                                        int slice_len, int* __restrict__ p_idx, int* __restrict__ p_best,
+                                                        int* __restrict__ p_second) {
+    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];
+    __shared__ uint2 s_exp[256];
+    {   // entry b: bits 0..3 -> x (one int8 each, LSB first), bits 4..7 -> y
+        const uint32_t b = threadIdx.x;
+        const uint32_t lo = ((b & 15u) * 0x00204081u) & 0x01010101u, hi = (((b >> 4) & 15u) * 0x00204081u) & 0x01010101u;
+        s_exp[b] = make_uint2(__builtin_amdgcn_perm(0u, 0x000020e0u, lo), __builtin_amdgcn_perm(0u, 0x000020e0u, hi));
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.y * MM_Q_PER_BLOCK + wave * 64;
+    mm_i32x4 bq[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qi = min(q0 + g * 32 + c, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
+        const uint4 lo = p[0], hi = p[1];
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bq[g][ks] = mm_expand16(h ? (w[ks] >> 16) : (w[ks] & 0xffffu));
+    }
+    mm_i32x16 cinit;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cinit[e] = 8192 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    const int s0 = blockIdx.x * slice_len, s1 = min(nr, s0 + slice_len);
+    const int n_tiles = (s1 - s0 + MM_R_TILE - 1) / MM_R_TILE;
+    auto fetch = [&](int t) {
+        const int rr = min(s0 + min(t, n_tiles - 1) * MM_R_TILE + lane, nr - 1);
+        return *reinterpret_cast<const uint2*>(r + (size_t)rr * 8 + wave * 2);
+    };
+    auto ex16 = [&](uint32_t bits) {
+        const uint2 a = s_exp[bits & 0xffu], b = s_exp[(bits >> 8) & 0xffu];
+        mm_i32x4 v; v[0] = (int)a.x; v[1] = (int)a.y; v[2] = (int)b.x; v[3] = (int)b.y;
+        return v;
+    };
+    auto deposit = [&](int buf, uint2 w) {
+        mm_i32x4* base = &s_tile[buf][(h * 8 + wave * 2) * 64 + c];
+        base[0] = ex16(w.x & 0xffffu);
+        base[32] = ex16(w.x >> 16);
+        base[64] = ex16(w.y & 0xffffu);
+        base[96] = ex16(w.y >> 16);
+    };
+    constexpr uint32_t KEY_NONE = 256u << 6;
+    uint32_t kb[2] = {KEY_NONE, KEY_NONE}, ks2[2] = {KEY_NONE, KEY_NONE};
+    int where[2] = {-1, -1};
+    // half a = rows [32 a, 32 a + 32) of tile t from LDS buffer buf into acc[0..1]
+    auto mfma_half = [&](mm_i32x16 (&acc)[2], int buf, int a) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const mm_i32x4 af = s_tile[buf][(a * 8 + ks) * 64 + lane];
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bq[0][ks], ks ? acc[0] : cinit, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bq[1][ks], ks ? acc[1] : cinit, 0, 0, 0);
+        }
+    };
+    auto keys_full = [&](const mm_i32x16 (&acc)[2], int blk) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint32_t before = kb[g];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t key = (uint32_t)acc[g][e];
+                ks2[g] = mt_umed3(kb[g], ks2[g], key);
+                kb[g] = min(kb[g], key);
+            }
+            where[g] = kb[g] != before ? ((blk << 5) | (int)(kb[g] & 31u)) : where[g];
+            kb[g] &= ~63u;
+        }
+    };
+    auto keys_masked = [&](const mm_i32x16 (&acc)[2], int blk, int a, int valid) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint32_t before = kb[g];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int local = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const uint32_t key = local < valid ? (uint32_t)acc[g][e] : KEY_NONE;
+                ks2[g] = mt_umed3(kb[g], ks2[g], key);
+                kb[g] = min(kb[g], key);
+            }
+            where[g] = kb[g] != before ? ((blk << 5) | (int)(kb[g] & 31u)) : where[g];
+            kb[g] &= ~63u;
+        }
+    };
+    deposit(0, fetch(0));
+    uint2 nxt = fetch(1);
+    __syncthreads();
+    mm_i32x16 acc0[2], acc1[2];
+    mfma_half(acc0, 0, 0);
+    for (int t = 0; t + 1 < n_tiles; ++t) {     // tiles 0 .. n_tiles-2 are full
+        const int buf = t & 1;
+        // P1: second half of tile t on the matrix cores | keys of its first half, next tile into LDS
+        mfma_half(acc1, buf, 1);
+        keys_full(acc0, 2 * t);
+        deposit(buf ^ 1, nxt);
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GAP + 4, 0);
+            }
+        }
+        __syncthreads();
+        // P2: first half of tile t + 1 | keys of the second half of tile t
+        nxt = fetch(t + 2);
+        mfma_half(acc0, buf ^ 1, 0);
+        keys_full(acc1, 2 * t + 1);
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GAP, 0);
+            }
+        }
+    }
+    {   // last tile (may be partial): its first half is in acc0 already
+        const int t = n_tiles - 1, buf = t & 1;
+        const int valid = s1 - s0 - t * MM_R_TILE;
+        mfma_half(acc1, buf, 1);
+        keys_masked(acc0, 2 * t, 0, valid);
+        keys_masked(acc1, 2 * t + 1, 1, valid);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t mine_b = ((kb[g] >> 6) << 16) | (uint32_t)(where[g] & 0xffff), mine_s = (ks2[g] >> 6) << 16 | 0xffffu;
+        const uint32_t ob = (uint32_t)__shfl_xor((int)mine_b, 32), os = (uint32_t)__shfl_xor((int)mine_s, 32);
+        const uint32_t nb = min(mine_b, ob), ns = min(max(mine_b, ob), min(mine_s, os));
+        const int qrow = q0 + g * 32 + c;
+        if (h == 0 && qrow < nq) {
+            const size_t o = (size_t)blockIdx.x * nq + qrow;
+            const int best = (int)(nb >> 16);
+            p_best[o] = best;
+            p_idx[o] = best < 256 ? s0 + (int)(nb & 0xffffu) : -1;
+            p_second[o] = (int)min(ns >> 16, 256u);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- balanced phases
 // k_pipe's two phases are unequal: 16 MFMAs next to 72 key instructions + the whole next tile's expansion (70), then 16 MFMAs
 // next to 72 key instructions.  Here the expansion of tile t + 2 is split: its first k-step pair in the second phase of
@@ -472,7 +615,11 @@ int main(int argc, char** argv) {
     CK(hipMemset(pi[1], 0, (size_t)s_eff * nq * 4));
     run(k_pipe2<1>, "balanced phases, sched groups", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
     grab(1, b); printf("   equal to baseline: %s\n", a == b ? "yes" : "NO");
+    CK(hipMemset(pi[1], 0, (size_t)s_eff * nq * 4));
+    run(k_pipe3<0>, "pipelined, table expansion", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
+    grab(1, b); printf("   equal to baseline: %s\n", a == b ? "yes" : "NO");
     run(k_pipe<0>, "pipelined, no hints (again)", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
+    run(k_pipe3<0>, "pipelined, table expansion (again)", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
     run(k_base, "baseline again", s_eff, qb, dq, nq, dr, nr, len, pi[0], pb[0], ps[0], iters);
     return 0;
 }
