@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the MORB_EXTRACT_CU_RESERVE switch this script drives was removed from extractor.hip with the experiment: profiles/r03/notes_experiments.md)
 # overlapped throughput / isolated latency of configs[1] and configs[4] with n compute units kept free of extraction kernels
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03/$1; mkdir -p $O
 for n in 0 16 32 64 0; do for c in 1 4; do
