@@ -24,6 +24,7 @@
 //
 // Build: see oracle/Makefile (g++ -O3 -march=native -ffp-contract=off -shared -fPIC).
 
+#include <stdexcept>
 #include <algorithm>
 #include <cfloat>
 #include <climits>
@@ -314,6 +315,10 @@ std::vector<KeyPoint> distribute_octree(const std::vector<KeyPoint>& in, int min
     };
     long seq = 0;
     const int nIni = (int)std::round((float)(maxX - minX) / (maxY - minY));
+    // The reference divides by nIni and indexes vpIniNodes[kp.pt.x / hX] (:544-565): for a level that is more than twice as high as
+    // it is wide nIni is 0 and the reference's behaviour is undefined.  There is nothing to restate: the oracle refuses such a
+    // level (ORC_E_UNDEFINED from extract), it does not guess.
+    if (nIni < 1) throw std::domain_error("DistributeOctTree: round(width / height) == 0 is undefined in the reference");
     const float hX = (float)(maxX - minX) / nIni;
     std::list<Node> nodes;
     std::vector<Node*> ini(nIni);
@@ -583,13 +588,18 @@ void level_keypoints(const Params& P, const Image& im, int level, std::vector<Ke
 // ------------------------------------------------------------------------------------------------
 // a2  ORBextractor::operator() (:1044-1107)
 // ------------------------------------------------------------------------------------------------
+constexpr int ORC_E_UNDEFINED = INT32_MIN;   // the reference's own behaviour is undefined for this input (see distribute_octree)
 int extract(const Params& P, const uint8_t* img, int W, int H, int stride, KeyPoint* kps_out, uint8_t* desc_out,
             int cap) {
     if (!img || W <= 0 || H <= 0) return 0;
     std::vector<Image> pyr;
     compute_pyramid(P, img, W, H, stride, pyr);
     std::vector<std::vector<KeyPoint>> all(P.nlevels);
-    for (int l = 0; l < P.nlevels; l++) level_keypoints(P, pyr[l], l, all[l]);
+    try {
+        for (int l = 0; l < P.nlevels; l++) level_keypoints(P, pyr[l], l, all[l]);
+    } catch (const std::domain_error&) {
+        return ORC_E_UNDEFINED;
+    }
     int n = 0;
     for (int l = 0; l < P.nlevels; l++) n += (int)all[l].size();
     if (n > cap) return -n;
@@ -783,7 +793,8 @@ int orc_cell_candidates(const uint8_t* img, int w, int h, int iniTh, int minTh, 
 int orc_distribute_octree(const KeyPoint* in, int n_in, int minX, int maxX, int minY, int maxY, int N, KeyPoint* out,
                           int cap) {
     std::vector<KeyPoint> v(in, in + n_in);
-    std::vector<KeyPoint> r = distribute_octree(v, minX, maxX, minY, maxY, N);
+    std::vector<KeyPoint> r;
+    try { r = distribute_octree(v, minX, maxX, minY, maxY, N); } catch (const std::domain_error&) { return INT32_MIN; }   // (ORC_E_UNDEFINED)
     int n = (int)std::min<size_t>(r.size(), (size_t)cap);
     std::memcpy(out, r.data(), (size_t)n * sizeof(KeyPoint));
     return (int)r.size();

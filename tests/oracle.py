@@ -165,6 +165,8 @@ def distribute_octree(kps, minX, maxX, minY, maxY, N):
     kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
     out = np.zeros(max(len(kps), 1), KP_DTYPE)
     n = lib().orc_distribute_octree(_p(kps), len(kps), minX, maxX, minY, maxY, N, _p(out), len(out))
+    if n == -2 ** 31:
+        raise ValueError("the reference's DistributeOctTree is undefined for a %d x %d region (round(width / height) == 0)" % (maxX - minX, maxY - minY))
     return out[:n]
 
 
@@ -208,6 +210,8 @@ def extract(img, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=
     cap = nfeatures + 3 * nlevels + 64
     kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
     n = lib().orc_extract(_p(img), W, H, W, nfeatures, scale_factor, nlevels, ini_th, min_th, _p(kps), _p(desc), cap)
+    if n == -2 ** 31:
+        raise ValueError("the reference's DistributeOctTree is undefined for a %d x %d image (round(width / height) == 0 on some level)" % (W, H))
     assert n >= 0, "oracle capacity"
     return kps[:n].copy(), desc[:n].copy()
 

@@ -63,3 +63,16 @@ def test_octree_stops_when_a_pass_does_not_grow_the_list():
     out = oracle.distribute_octree(k, 16, 16 + 608, 16, 16 + 448, 2)
     assert len(out) == 1 and out["response"][0] == 60
     assert np.array_equal(out, distribute_octree(k, 16, 16 + 608, 16, 16 + 448, 2))
+
+
+def test_octree_refuses_regions_the_reference_leaves_undefined():
+    """nIni = round(width / height) root nodes (reference src/ORBextractor.cc:544): 0 for a region more than twice as high as it is
+    wide -- the reference then divides by zero and indexes an empty vector.  The oracle restates nothing there: it raises (the
+    product defines this case as ONE root, DESIGN.md section 5, without a reference to hold it against)."""
+    k = np.zeros(4, oracle.KP_DTYPE)
+    k["x"] = [10, 12, 50, 52]; k["y"] = [10, 12, 400, 402]; k["response"] = [50, 50, 30, 60]
+    with pytest.raises(ValueError):
+        oracle.distribute_octree(k, 16, 16 + 100, 16, 16 + 448, 2)
+    from multi_orb_slam_amd import synth
+    with pytest.raises(ValueError):
+        oracle.extract(synth.image(1, 0, 200, 600), nfeatures=100)
