@@ -210,3 +210,37 @@ def test_quota_sweep_device_quadtree(nf):
         okps, odesc = oracle.extract(img, nfeatures=nf)
         _assert_same(kps, desc, okps, odesc)
     ex.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,kw", [(640, 480, dict(nfeatures=1000, ini_th_fast=12, min_th_fast=3)),
+                                    (640, 480, dict(nfeatures=500, ini_th_fast=40, min_th_fast=20)),
+                                    (700, 333, dict(nfeatures=800, scale_factor=1.1, nlevels=10)),
+                                    (512, 512, dict(nfeatures=1500, scale_factor=1.5, nlevels=4)),
+                                    (777, 333, dict(nfeatures=600, scale_factor=1.3, nlevels=5, ini_th_fast=15, min_th_fast=7)),
+                                    (160, 120, dict(nfeatures=100, nlevels=3))])
+def test_odd_parameter_sets_equal_the_oracle(w, h, kw):
+    """Other FAST thresholds (the packed quick test's T), level counts, level steps (pyramid tables, quotas) and image shapes:
+    keypoint records and descriptors bit for bit."""
+    import multi_orb_slam_amd as m
+    p = m.ExtractorParams(**kw)
+    ex = _mk([p, p], w, h)
+    imgs = [synth.image(7 + c, 1, w, h) for c in range(2)]
+    out = ex.extract(imgs)
+    for c in range(2):
+        ok, od = oracle.extract(imgs[c], nfeatures=p.nfeatures, scale_factor=p.scale_factor, nlevels=p.nlevels,
+                                ini_th=p.ini_th_fast, min_th=p.min_th_fast)
+        assert out[c][0].tobytes() == ok.tobytes() and np.array_equal(out[c][1], od)
+    assert ex.last_path() == 0
+
+
+@pytest.mark.gpu
+def test_a_level_the_reference_leaves_undefined_still_runs():
+    """333 x 777: round(width / height) == 0 quadtree roots in the reference (undefined, the oracle refuses); the product takes one
+    root and returns features -- no parity is claimed, the call must simply succeed."""
+    import multi_orb_slam_amd as m
+    ex = _mk([m.ExtractorParams(nfeatures=600)], 333, 777)
+    out = ex.extract([synth.image(3, 0, 333, 777)])
+    assert 300 < len(out[0][0]) <= 600 + 3 * 8 and out[0][1].shape == (len(out[0][0]), 32)
+    with pytest.raises(ValueError):
+        oracle.extract(synth.image(3, 0, 333, 777), nfeatures=600)
