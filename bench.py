@@ -86,6 +86,8 @@ def parse(argv=None):
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--min-time", type=float, default=0.25, help="keep timing blocks of --steps steps until this many seconds are covered")
     ap.add_argument("--no-overlap", action="store_true", help="every step extracts its own images first (no orbf_prefetch)")
+    ap.add_argument("--ahead", type=int, default=3, choices=[1, 2, 3],
+                    help="timesteps whose images the front end knows ahead of the step it matches (orbf_prefetch); default 3")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -434,10 +436,12 @@ def main(argv=None):
     t_gate = time.perf_counter()
     ofe = OracleFrontEnd(params, W, H, gcam, cam_threads=True)
     pool = ThreadPoolExecutor(max(1, min(len(other_g), 16))) if other_g else None
+    AHEAD = a.ahead
     if overlap:
-        fe.announce(frame_args(1), resident=True)
-    for t in range(n_gate):   # two future steps are announced (orbf_prefetch), as in the timed loop
-        got = fe.step(frame_args(t), resident=True, next_images=frame_args(t + 2) if overlap else None)
+        for k in range(1, AHEAD):
+            fe.announce(frame_args(k), resident=True)
+    for t in range(n_gate):   # AHEAD future steps are announced (orbf_prefetch), as in the timed loop
+        got = fe.step(frame_args(t), resident=True, next_images=frame_args(t + AHEAD) if overlap else None)
         desc_of = {}
         if other_g:
             ext = lambda g: oracle.extract(synth.image(g, t % RING, W, H), nfeatures=NFEAT)[1]
@@ -468,13 +472,14 @@ def main(argv=None):
         # every step completes one timestep (extract + match); with `overlap` the images of the two steps after it are known
         # to the front end (one new announcement per step), so K steps enqueue K extractions and complete K matchings
         res = "pinned" if pinned else True
-        if overlap and ahead[0] < t0 + 1:
-            fe.announce(frame_args(t0 + 1, pinned), resident=res); ahead[0] = t0 + 1
+        if overlap:
+            for k in range(max(ahead[0] + 1, t0 + 1), t0 + AHEAD):
+                fe.announce(frame_args(k, pinned), resident=res); ahead[0] = k
         pc = time.perf_counter
         for i in range(nsteps):
             if overlap:
-                ahead[0] = t0 + i + 2
-            r = fe.step(frame_args(t0 + i, pinned), resident=res, next_images=frame_args(t0 + i + 2, pinned) if overlap else None)
+                ahead[0] = t0 + i + AHEAD
+            r = fe.step(frame_args(t0 + i, pinned), resident=res, next_images=frame_args(t0 + i + AHEAD, pinned) if overlap else None)
             if record:
                 stamps.append(pc())
                 native_us.append(r["host_us"])
@@ -546,7 +551,7 @@ def main(argv=None):
         fe.reset(); ahead[0] = 0
         ring = [[(dev_frames[t][c].ptr, W, H, W, 1) for c in range(NC)] for t in range(RING)]
         motion = (pipeline.MOTION[0], pipeline.MOTION[1], pipeline.TH_PROJ)
-        la = 2 if overlap else 0
+        la = AHEAD if overlap else 0
         upto, t_loop = -1, 0
         _st, upto = fe.fe.run_stream(ring, t_loop, min(a.warmup, 50), la, upto, motion, TH_LOW, pipeline.BOW_RATIO); t_loop += min(a.warmup, 50)
         blk, covered = [], 0.0
@@ -560,7 +565,7 @@ def main(argv=None):
             if covered >= a.min_time or len(blk) >= 200:
                 break
         c_abi_loop = {"value": round(rigs * a.steps / pct(blk, 50), 2), "ms_per_step": round(1e3 * pct(blk, 50) / a.steps, 4), "blocks": len(blk),
-                      "what": "orbf_run_stream: the same steps (two announced ahead, accepted-match count included) driven from inside the library"}
+                      "what": "orbf_run_stream: the same steps (%d announced ahead, accepted-match count included) driven from inside the library" % la}
     # ---- one isolated timestep: no look-ahead, every step extracts its own images first (what a live rig sees as latency)
     fe.reset(); ahead[0] = 0
     n_iso = max(20, min(200, a.steps))
@@ -611,8 +616,9 @@ def main(argv=None):
         "value_isolated": round(rigs * 1e3 / iso["median"], 2),
         "value_h2d_inclusive": h2d["value"] if h2d else None, "h2d_inclusive": h2d,
         "parity": parity,
-        "overlap": ("the extractions of timesteps t+1 and t+2 run next to the matching of timestep t (orbf_prefetch); `value` needs "
-                    "the images two steps ahead, `latency_ms_isolated` / `value_isolated` do not") if overlap else "off",
+        "ahead": AHEAD if overlap else 0,
+        "overlap": ("the extractions of timesteps t+1 .. t+%d run next to the matching of timestep t (orbf_prefetch); `value` needs "
+                    "the images %d steps ahead, `latency_ms_isolated` / `value_isolated` do not" % (AHEAD, AHEAD)) if overlap else "off",
         "extractor_stage_us": {k: round(v, 1) for k, v in stages.items()},
         "roofline_extract": {"kernel": "extraction chain (k_pyramid_tiled [k_ingest], k_fast_cells, k_octree, k_describe)", "bound": "hbm",
                              "achieved": round(ex_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ex_ach / HBM_PEAK_GBS, 5),

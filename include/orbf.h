@@ -70,10 +70,12 @@ int orbf_set_calibration(orbf_frontend* f, const orb_calibration* calib);
 /* mbf = Camera.bf; th_high / check_orientation as in ORBmatcher (defaults 40, 100, 1) */
 int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientation);
 /* Overlap of consecutive timesteps.  Announces the images of a FUTURE step (a FIFO: the step after the next orbf_step /
- * orbf_step_motion call, then the one after that; at most two steps ahead).  A step call enqueues the extraction of the
- * announced images right after it has enqueued its own matching, so they run next to each other on the GPU (matching
- * occupies a handful of the 256 CUs; with two steps announced two extraction chains run side by side on two extractor
- * instances), and the following steps find their features ready or in flight.  Those steps must then be called with
+ * orbf_step_motion call, then the ones after that; at most THREE steps ahead -- MORB_AHEAD_DEPTH=1..3 lowers the limit and
+ * the number of extractor instances the handle creates).  A step call enqueues the extraction of the announced images right
+ * after it has enqueued its own matching, so they run next to each other on the GPU (matching occupies a handful of the 256
+ * CUs; with three steps announced three extraction chains run side by side on three extractor instances -- together with
+ * the matcher's stream that is four hardware queues, as many as the part's command processor serves side by side), and the
+ * following steps find their features ready or in flight.  Those steps must then be called with
  * exactly the announced images, in order (same pointers, sizes, strides); otherwise everything in flight is dropped and
  * the images are extracted again.  The exact contract: a buffer must stay unchanged from its announcement until the step that
  * consumes it has returned (host images are read by the copy engine while the intervening steps run).  A caller that recycles

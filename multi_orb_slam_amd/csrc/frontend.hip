@@ -23,7 +23,9 @@ using namespace morb;
 struct orbf_frontend {
     int device = 0, n_cams = 0, max_w = 0, max_h = 0;
     orbx_extractor* ex = nullptr;        // == exs[0]: the extractor isolated steps run on (orbf_extractor)
-    orbx_extractor* exs[2] = {nullptr, nullptr};  // small rigs: consecutive overlapped timesteps alternate between two
+    static constexpr int NEX = 3;        // extractor handles = timesteps that can be extracted side by side
+    orbx_extractor* exs[NEX] = {nullptr, nullptr, nullptr};  // consecutive overlapped timesteps go round the handles in use
+    int n_ex = 2;                        // handles in use = look-ahead depth (MORB_AHEAD_DEPTH, 1..NEX; orbf_prefetch's limit)
     orbm_matcher* mt = nullptr;
     std::vector<const float*> d_depth;
     std::vector<int> depth_stride;
@@ -34,7 +36,7 @@ struct orbf_frontend {
     int cap_total = 0;
     // pinned host result buffers.  The per-feature results exist twice: the extraction of the NEXT timestep (orbf_prefetch)
     // fills the other set while the caller still reads this step's.
-    static constexpr int NSETS = 4;  // this step's (held by the caller) + two timesteps in flight + the one being assigned
+    static constexpr int NSETS = NEX + 3;  // this step's (held by the caller) + the timesteps in flight + the one being assigned
     struct ResultSet {
         PinnedBuf<orb_keypoint> kps; PinnedBuf<uint8_t> desc; PinnedBuf<float> ur, depth, unx, uny;
         CrossOut cross;            // cross-camera top-2 of the step, computed at the end of its extraction chain
@@ -46,8 +48,8 @@ struct orbf_frontend {
     morb::StageBuf h_queries;   // this step's queries: written by the host, read once by k_project
     PinnedBuf<int32_t> h_match;
     // Small rigs (<= 4 cameras): one persistent frame per result set, filled by the extractor's describe kernel (FrameSink)
-    orbm_frame* pframe[NSETS] = {nullptr, nullptr, nullptr, nullptr};
-    int pframe_W[NSETS] = {0, 0, 0, 0}, pframe_H[NSETS] = {0, 0, 0, 0};
+    orbm_frame* pframe[NSETS] = {};
+    int pframe_W[NSETS] = {}, pframe_H[NSETS] = {};
     // extractions in flight for the NEXT steps (enqueued by earlier orbf_step calls after orbf_prefetch), oldest first
     // fp: content fingerprints of the HOST images taken when their upload was enqueued (see image_fingerprint)
     struct InFlight { std::vector<orbf_image> images; std::vector<uint64_t> fp; int set = 0, W = 0, H = 0, e = 0; };
@@ -73,7 +75,7 @@ struct orbf_frontend {
         std::chrono::steady_clock::time_point t_impl, t_enqueued;
     } pending;
     hipEvent_t ev_extracted = nullptr;  // extractor stream -> matcher stream on the synchronous path
-    hipEvent_t ev_ready[NSETS] = {nullptr, nullptr, nullptr, nullptr};  // extraction + frame grid of the step using that set
+    hipEvent_t ev_ready[NSETS] = {};  // extraction + frame grid of the step using that set
     // frame of the last completed step (orbf_export_block); a frame built on the synchronous path is kept until the next step
     orbm_frame* last_frame = nullptr; bool last_frame_owned = false;
     // previous step (for orbf_step_motion)
@@ -111,7 +113,8 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
     for (int k = 0; k < orbf_frontend::NSETS; ++k)
         if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
-    if (!rc) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[1]);  // overlap partner
+    { const int d = getenv_int("MORB_AHEAD_DEPTH", 3); f->n_ex = d < 1 ? 1 : (d > orbf_frontend::NEX ? orbf_frontend::NEX : d); }
+    for (int e = 1; e < f->n_ex && !rc; ++e) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[e]);  // overlap partners
     for (int k = 0; k < orbf_frontend::NSETS && !rc; ++k)
         if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
             (rc = f->rs[k].depth.reserve(cap)) || (rc = f->rs[k].unx.reserve(cap)) || (rc = f->rs[k].uny.reserve(cap))) break;
@@ -130,12 +133,12 @@ void orbf_destroy(orbf_frontend* f) {
     (void)hipSetDevice(f->device);
     if (f->xcomm) (void)orbf_exchange_shutdown(f);
     f->d_xrecv.release();
-    for (int e = 0; e < 2; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
+    for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
     if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->pframe[k]) orbm_frame_destroy(f->pframe[k]);  // back to the matcher's pool first
     if (f->mt) orbm_destroy(f->mt);
-    for (int e = 0; e < 2; ++e) if (f->exs[e]) orbx_destroy(f->exs[e]);
+    for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) orbx_destroy(f->exs[e]);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); f->rs[k].unx.release(); f->rs[k].uny.release(); f->rs[k].cross.release(); }
     f->h_queries.release(); f->h_match.release();
     if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
@@ -240,7 +243,7 @@ int orbf_exchange_shutdown(orbf_frontend* f) {
     MORB_ARG(f != nullptr);
     if (!f->xcomm) return ORB_OK;
     MORB_HIP(hipSetDevice(f->device));
-    if (f->mt) { (void)hipStreamSynchronize(f->mt->side_stream); (void)hipStreamSynchronize(f->mt->stream); }
+    if (f->mt) { if (f->mt->side_stream) (void)hipStreamSynchronize(f->mt->side_stream); (void)hipStreamSynchronize(f->mt->stream); }
     if (f->xloop) loop_leave(static_cast<LoopComm*>(f->xcomm));
     else exchange_comm_destroy(f->xcomm);
     f->xcomm = nullptr; f->xworld = 0; f->xrank = 0; f->xloop = false;
@@ -253,8 +256,10 @@ static int exchange_enqueue(orbf_frontend* f, const orbm_frame* F) {
     orbm_matcher* m = f->mt;
     const size_t block = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
     MORB_ARG(F->desc_rows == f->cap_total);
-    const int rc = f->xloop ? loop_allgather(static_cast<LoopComm*>(f->xcomm), F->b->d_desc.p, f->d_xrecv.p, block, m->side_stream)
-                            : exchange_allgather(f->xcomm, F->b->d_desc.p, f->d_xrecv.p, block, m->side_stream);
+    hipStream_t sd = morb::side_stream(m);
+    if (!sd) return ORB_E_HIP;
+    const int rc = f->xloop ? loop_allgather(static_cast<LoopComm*>(f->xcomm), F->b->d_desc.p, f->d_xrecv.p, block, sd)
+                            : exchange_allgather(f->xcomm, F->b->d_desc.p, f->d_xrecv.p, block, sd);
     if (rc) return rc;
     return orbm_cross_top2_gathered_enqueue(m, f->d_xrecv.p, f->xworld, block, F->desc_rows, f->n_cams, f->xrank, nullptr, 0);
 }
@@ -294,7 +299,7 @@ int orbf_export_features(orbf_frontend* f, orbf_device_features* out) {
 int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images) {
     MORB_ARG(f && next_images);
     // (the step about to be called may itself still be in flight: two timesteps beyond it can be announced)
-    if (f->inflight.size() + f->announced.size() >= 3) { morb::set_error("too many future timesteps announced (at most two beyond the next step)"); return ORB_E_ARG; }
+    if ((int)(f->inflight.size() + f->announced.size()) >= f->n_ex + 1) { morb::set_error("too many future timesteps announced (at most %d beyond the next step)", f->n_ex); return ORB_E_ARG; }
     f->announced.emplace_back(next_images, next_images + f->n_cams);
     return ORB_OK;
 }
@@ -337,7 +342,7 @@ static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motio
 
 int orbf_run_stream(orbf_frontend* f, const orbf_image* ring, int ring_len, int t0, int steps, int ahead, int* announced_upto,
                     const orbf_motion* motion, int th_low, float ratio, orbf_stream_stats* out) {
-    MORB_ARG(f && ring && ring_len >= 1 && t0 >= 0 && steps >= 0 && ahead >= 0 && ahead <= 2 && announced_upto && motion && out);
+    MORB_ARG(f && ring && ring_len >= 1 && t0 >= 0 && steps >= 0 && ahead >= 0 && ahead <= orbf_frontend::NEX && announced_upto && motion && out);
     memset(out, 0, sizeof(*out));
     const auto t_start = std::chrono::steady_clock::now();
     auto images_of = [&](int t) { return ring + (size_t)(t % ring_len) * f->n_cams; };
@@ -527,10 +532,10 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
 // Everything in flight is waited for and dropped (results of prefetched extractions included).
 static int orbf_drain(orbf_frontend* f) {
     MORB_HIP(hipSetDevice(f->device));
-    for (int e = 0; e < 2; ++e) if (f->exs[e]) MORB_HIP(hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e])));
+    for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) MORB_HIP(hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e])));
     MORB_HIP(hipStreamSynchronize(f->mt->stream));
-    MORB_HIP(hipStreamSynchronize(f->mt->side_stream));
-    for (int e = 0; e < 2; ++e)
+    if (f->mt->side_stream) MORB_HIP(hipStreamSynchronize(f->mt->side_stream));
+    for (int e = 0; e < orbf_frontend::NEX; ++e)
         while (f->exs[e] && orbx_pending(f->exs[e]) > 0) { int rc = orbx_finish(f->exs[e]); if (rc < 0) return rc; }
     f->inflight.clear();
     return ORB_OK;
@@ -542,7 +547,7 @@ static int orbf_drain(orbf_frontend* f) {
 static void next_slot(orbf_frontend* f, int* e, int* set) {
     *set = (f->last_set + 1) % orbf_frontend::NSETS;
     if (*set == f->cur) *set = (*set + 1) % orbf_frontend::NSETS;  // (the caller still reads the last step's results)
-    *e = (f->inflight.empty() || !f->exs[1]) ? 0 : (f->last_e ^ 1);
+    *e = (f->inflight.empty() || f->n_ex < 2) ? 0 : (f->last_e + 1) % f->n_ex;
     f->last_set = *set; f->last_e = *e;
 }
 
@@ -718,9 +723,11 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         forked = false;
     }
     P.forked = forked;
+    hipStream_t sd = forked ? morb::side_stream(m) : nullptr;
+    if (forked && !sd) { if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return ORB_E_HIP; }
     if (forked) {  // the fork point is the finished frame; the launches on the side stream come after the search's
         hipError_t fe = hipEventRecord(m->ev_fork, st);
-        if (fe == hipSuccess) fe = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
+        if (fe == hipSuccess) fe = hipStreamWaitEvent(sd, m->ev_fork, 0);
         if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return ORB_E_HIP; }
     }
     if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[2] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
@@ -731,14 +738,14 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         P.mirror_pending = false;
     }
     if (forked) {
-        if (!rc) rc = cross_enqueue(m, m->side_stream, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n,
+        if (!rc) rc = cross_enqueue(m, sd, fr->b->d_desc.p, n, fr->b->d_cam_start.p, f->n_cams, 0, n,
                                     P.async_path ? fr->b->d_ntotal.p : nullptr);
         if (P.mirror_pending) {   // the step's pinned result mirrors: next to project + resolve, behind the camera-pair top-2
-            if (!rc) rc = frame_mirror_enqueue(fr, m->side_stream, R.kps.dp, R.desc.dp, R.unx.dp, R.uny.dp, R.ur.dp, R.depth.dp);
+            if (!rc) rc = frame_mirror_enqueue(fr, sd, R.kps.dp, R.desc.dp, R.unx.dp, R.uny.dp, R.ur.dp, R.depth.dp);
             P.mirror_pending = false;
         }
         // join (also on the error path, so that the side stream never outlives the frame)
-        hipError_t je = hipEventRecord(m->ev_join, m->side_stream);
+        hipError_t je = hipEventRecord(m->ev_join, sd);
         if (je == hipSuccess) je = hipStreamWaitEvent(st, m->ev_join, 0);
         if (!rc && je != hipSuccess) { morb::set_error("stream join: %s", hipGetErrorString(je)); rc = ORB_E_HIP; }
     }
@@ -758,9 +765,9 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     // ---- announced timesteps go onto the extractors now: they run while this step is being matched.  At most two
     // are in flight; consecutive ones alternate between the two extractors (an extractor takes its next timestep as
     // a second run behind the one whose results are being matched here).
-    while (P.async_path && first_attempt && f->overlap_ok && !f->announced.empty() && f->inflight.size() < 2) {
+    while (P.async_path && first_attempt && f->overlap_ok && !f->announced.empty() && (int)f->inflight.size() < std::max(f->n_ex, 2)) {
         const int prev_e = f->inflight.empty() ? P.e : f->inflight.back().e;
-        const int e2 = f->exs[1] ? (prev_e ^ 1) : 0;
+        const int e2 = f->n_ex > 1 ? (prev_e + 1) % f->n_ex : 0;
         if (orbx_pending(f->exs[e2]) >= 2) break;
         int set2 = (f->last_set + 1) % orbf_frontend::NSETS;
         if (set2 == f->cur) set2 = (set2 + 1) % orbf_frontend::NSETS;

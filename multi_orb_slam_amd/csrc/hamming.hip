@@ -1091,7 +1091,8 @@ int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered,
     int rc;
     if ((rc = m->d_r.reserve((size_t)n_cap * 32)) || (rc = m->d_gstart.reserve(n_cams + 1 + 4)) || (rc = m->h_gcnt.reserve(n_cams + 2)))
         return rc;
-    hipStream_t sd = m->side_stream;
+    hipStream_t sd = morb::side_stream(m);
+    if (!sd) return ORB_E_HIP;
     if (wait_after) {  // the gathered buffer is produced on another stream (the collective's; NULL = the default stream)
         MORB_HIP(hipEventRecord(m->ev_fork, (hipStream_t)after_stream));
         MORB_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
@@ -1144,7 +1145,7 @@ int orbm_cross_top2_gathered(orbm_matcher* m, const uint8_t* d_gathered, int wor
     // (the main stream may have been ordered behind the collective by orbm_wait_for_stream: the side stream inherits that)
     int rc;
     MORB_HIP(hipSetDevice(m ? m->device : 0));
-    if (m) { MORB_HIP(hipEventRecord(m->ev_q, m->stream)); MORB_HIP(hipStreamWaitEvent(m->side_stream, m->ev_q, 0)); }
+    if (m) { hipStream_t sd = morb::side_stream(m); if (!sd) return ORB_E_HIP; MORB_HIP(hipEventRecord(m->ev_q, m->stream)); MORB_HIP(hipStreamWaitEvent(sd, m->ev_q, 0)); }
     if ((rc = orbm_cross_top2_gathered_enqueue(m, d_gathered, world, block_bytes, cap_rows, cams_per_rank, rank, nullptr, 0))) return rc;
     MORB_HIP(hipStreamSynchronize(m->stream));
     return orbm_cross_top2_gathered_collect(m, best_idx, best_dist, second_dist, counts_out, nq_out);

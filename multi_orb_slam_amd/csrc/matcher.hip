@@ -66,6 +66,19 @@ static int raise_lds_limits(int device) {
     return result[device];
 }
 
+hipStream_t morb::side_stream(orbm_matcher* m) {
+    if (!m->side_stream) {
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (hipStreamCreateWithPriority(&m->side_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            m->side_stream = nullptr;
+            morb::set_error("side stream could not be created");
+        }
+    }
+    return m->side_stream;
+}
+
 int orbm_create(int device, orbm_matcher** out) {
     MORB_ARG(out != nullptr);
     int rc = morb::select_device(device);
@@ -80,12 +93,11 @@ int orbm_create(int device, orbm_matcher** out) {
     hipError_t e = hipStreamCreateWithPriority(&m->own_stream, hipStreamNonBlocking, prio_greatest);
     if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete m; return ORB_E_HIP; }
     m->stream = m->own_stream;
-    if (hipStreamCreateWithPriority(&m->side_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_q, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_stage_f, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
-        morb::set_error("side stream / events could not be created");
+        morb::set_error("events could not be created");
         orbm_destroy(m);
         return ORB_E_HIP;
     }

@@ -63,7 +63,11 @@ struct orbm_matcher {
     int gathered_cams = 0;                // cameras of the last orbm_cross_top2_gathered_enqueue
     PinnedBuf<int32_t> h_c0, h_c1, h_c2;  // cross top-2 results (own buffers: they coexist with a search's h_i0/h_i1)
     DevBuf<uint8_t> d_cscratch;           // cross top-2 slice partials
-    hipStream_t side_stream = nullptr;    // orbf_step: cross top-2 runs here, next to project + resolve on `stream`
+    // Created on first use (morb::side_stream): the cross top-2 next to project + resolve, the multi-GPU exchange.  Every stream is a
+    // hardware queue, and the part's command processor keeps four of them busy side by side: a fifth queue shares a pipe with
+    // another one, and a kernel then waits behind the DISPATCH of that queue's kernels (measured with three extraction streams +
+    // matcher + this one: single kernels of the chains stretched to 40-55 us, 83 us per step instead of 50).
+    hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_q = nullptr;
     PinnedBuf<uint16_t> h_u16;
     PinnedBuf<uint8_t> h_ring;  // 4 slots of {CamFeat[64], int cam_start[65]} for asynchronous H2D
@@ -86,6 +90,8 @@ struct orbm_matcher {
     int resolve_seq = 0;           // sequence number of the last tagged resolve launch
     bool foreign_work = false;     // something other than a step's own search was put on the stream (orbf_step_end then waits for all of it)
 };
+namespace morb { hipStream_t side_stream(orbm_matcher* m); }   // (lazily created; NULL after a reported failure)
+
 
 struct orbm_frame {
     orbm_matcher* owner = nullptr;

@@ -127,7 +127,7 @@ class FrontEnd:
 
     # images: list of HxW uint8 arrays, or list of (device_ptr, stride) for HBM-resident frames
     def announce(self, images, resident=False):
-        """Announce the images of a future step (orbf_prefetch; a FIFO, at most two steps ahead): their extraction runs next to
+        """Announce the images of a future step (orbf_prefetch; a FIFO, at most three steps ahead): their extraction runs next to
         the matching of the steps before; those steps must then pass exactly these images, in order."""
         if resident:   # (ptr, stride[, generation]): HBM-resident (True) or page-locked host memory ("pinned": copied H2D inside the step)
             images = [(im[0], self.width, self.height, im[1], 0 if resident == "pinned" else 1, im[2] if len(im) > 2 else 0) for im in images]

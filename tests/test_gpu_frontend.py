@@ -38,17 +38,18 @@ def test_native_step_equals_oracle_pipeline(w, h, nfs):
 
 
 @pytest.mark.parametrize("w,h,nfs,resident,depth", [(320, 240, (300, 150), False, 1), (640, 480, (1000, 1000), True, 1),
-                                                     (320, 240, (300, 150), True, 2), (640, 480, (1000, 1000), False, 2)])
+                                                     (320, 240, (300, 150), True, 2), (640, 480, (1000, 1000), False, 2),
+                                                     (640, 480, (1000, 1000), True, 3), (320, 240, (300, 150), False, 3)])
 def test_overlapped_steps_equal_oracle_pipeline(w, h, nfs, resident, depth):
-    """orbf_prefetch: the extraction of the next step (depth 1) or the next two steps (depth 2, on two extractor instances)
-    runs next to this step's matching; results must not change."""
+    """orbf_prefetch: the extraction of the next step (depth 1), the next two or the next three steps (on two / three extractor
+    instances going round) runs next to this step's matching; results must not change."""
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import pipeline, rt
     from oracle_pipeline import OracleFrontEnd, assert_same_step
     params = [m.ExtractorParams(nfeatures=n) for n in nfs]
     fe = pipeline.FrontEnd(params, w, h)
     ofe = OracleFrontEnd(params, w, h)
-    T = 8
+    T = 8 if depth < 3 else 13      # (depth 3: long enough for extractors and result sets to go round more than once)
     frames = [[synth.image(c, t, w, h) for c in range(len(nfs))] for t in range(T)]
     dev = []
     if resident:
