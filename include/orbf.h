@@ -59,6 +59,10 @@ typedef struct orbf_result { /* all pointers: pinned host memory owned by the ha
 } orbf_result;
 
 int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbf_frontend** out);
+/* The same with the look-ahead depth chosen by the caller (1..3; 0 = MORB_AHEAD_DEPTH, default 3): a handle creates one
+ * extractor instance, i.e. one stream, per timestep it can extract ahead.  Streams are hardware queues and the part serves four of
+ * them side by side: a front end that will run a multi-GPU exchange (orbf_exchange_init: one more stream) takes 2. */
+int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int max_height, int device, int ahead_depth, orbf_frontend** out);
 void orbf_destroy(orbf_frontend* f);
 /* HBM-resident depth image (metres, float32) of one camera for ComputeStereoFromRGBD; NULL: uRight = -1 */
 int orbf_set_depth(orbf_frontend* f, int cam, const float* d_depth, int stride_floats);
@@ -86,6 +90,9 @@ int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientati
  * generation (it is identified by its pointer alone).  Results are bit-identical with and without announcements; rigs of
  * more than 4 cameras ignore them. */
 int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images);
+/* How many timesteps orbf_prefetch accepts ahead of the step being matched on this handle: MORB_AHEAD_DEPTH (default 3), two
+ * once a multi-GPU exchange is set up (its collective occupies one of the four hardware queues). */
+int orbf_ahead_depth(const orbf_frontend* f);
 /* Multi-GPU exchange: the HBM block holding the LAST step's merged descriptors -- cap_rows rows of 32 bytes in global
  * (camera-major, packed) order followed by a 256-byte trailer of int32 per-camera counts -- ready to be the send buffer
  * of one all-gather (every rank has the same capacity, hence the same block size).  Valid until the step after the next

@@ -149,6 +149,7 @@ def lib():
     L.orbm_frame_count.argtypes = [vp]
     L.orbx_debug_last_path.argtypes = [vp]
     L.orbf_create.argtypes = [vp, i32, i32, i32, i32, vp]
+    L.orbf_create_depth.argtypes = [vp, i32, i32, i32, i32, i32, vp]
     L.orbf_destroy.argtypes = [vp]; L.orbf_destroy.restype = None
     L.orbf_set_depth.argtypes = [vp, i32, vp, i32]
     L.orbf_configure.argtypes = [vp, f32, i32, i32]
@@ -166,6 +167,7 @@ def lib():
     L.orbf_exchange_unique_id.argtypes = [vp]
     L.orbf_exchange_init.argtypes = [vp, vp, i32, i32]
     L.orbf_exchange_active.argtypes = [vp]
+    L.orbf_ahead_depth.argtypes = [vp]
     L.orbf_exchange_init_loopback.argtypes = [vp, i32, i32, i32]
     L.orbf_exchange_shutdown.argtypes = [vp]
     L.orbf_peek_block.argtypes = [vp, vp, vp, vp, vp]

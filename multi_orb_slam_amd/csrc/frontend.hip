@@ -26,6 +26,7 @@ struct orbf_frontend {
     static constexpr int NEX = 3;        // extractor handles = timesteps that can be extracted side by side
     orbx_extractor* exs[NEX] = {nullptr, nullptr, nullptr};  // consecutive overlapped timesteps go round the handles in use
     int n_ex = 2;                        // handles in use = look-ahead depth (MORB_AHEAD_DEPTH, 1..NEX; orbf_prefetch's limit)
+    std::vector<orbx_params> params;     // (instances beyond the first are created when a step first needs them: ensure_extractor)
     orbm_matcher* mt = nullptr;
     std::vector<const float*> d_depth;
     std::vector<int> depth_stride;
@@ -94,7 +95,11 @@ static bool small_rig(const orbf_frontend* f) { return f->n_cams <= 4 && f->cap_
 
 
 int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbf_frontend** out) {
-    MORB_ARG(params && out && n_cams >= 1 && n_cams <= 64);
+    return orbf_create_depth(params, n_cams, max_width, max_height, device, 0, out);
+}
+
+int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int max_height, int device, int ahead_depth, orbf_frontend** out) {
+    MORB_ARG(params && out && n_cams >= 1 && n_cams <= 64 && ahead_depth >= 0 && ahead_depth <= orbf_frontend::NEX);
     orbf_frontend* f = new orbf_frontend();
     f->device = device; f->n_cams = n_cams; f->max_w = max_width; f->max_h = max_height;
     int rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[0]);
@@ -113,7 +118,13 @@ int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_he
     if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
     for (int k = 0; k < orbf_frontend::NSETS; ++k)
         if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
-    { const int d = getenv_int("MORB_AHEAD_DEPTH", 3); f->n_ex = d < 1 ? 1 : (d > orbf_frontend::NEX ? orbf_frontend::NEX : d); }
+    // Every stream is a hardware queue and the command processor serves four side by side.  The streams
+    // that work next to each other are created HERE, together and first -- extractor 0, the matcher's, the overlap partners --
+    // because which queues end up sharing a pipe follows the order of creation (measured: the same four streams created
+    // lazily, behind a caller's own streams, ran the loop at 87-195 us per step instead of 50).  A handle that will run a
+    // multi-GPU exchange is created with a depth of two (orbf_create_depth): the exchange's side stream is its fourth queue.
+    { const int d = ahead_depth > 0 ? ahead_depth : getenv_int("MORB_AHEAD_DEPTH", 3); f->n_ex = d < 1 ? 1 : (d > orbf_frontend::NEX ? orbf_frontend::NEX : d); }
+    f->params.assign(params, params + n_cams);
     for (int e = 1; e < f->n_ex && !rc; ++e) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[e]);  // overlap partners
     for (int k = 0; k < orbf_frontend::NSETS && !rc; ++k)
         if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
@@ -213,6 +224,20 @@ int orbf_exchange_unique_id(uint8_t* out128) {
     return exchange_unique_id(out128);
 }
 
+static int orbf_drain(orbf_frontend* f);
+// The exchange runs on the matcher's side stream every step: that is one of the four hardware queues, so at most two extractor
+// instances go round from here on (an instance that exists already keeps its stream, but is no longer handed timesteps).
+static int exchange_queues(orbf_frontend* f) {
+    if (f->n_ex > 2) {   // (a handle created for a single GPU after all: the third instance and its stream go before the side stream comes)
+        int rc = orbf_drain(f);
+        if (rc) return rc;
+        f->announced.clear();
+        orbx_destroy(f->exs[2]); f->exs[2] = nullptr;
+        f->n_ex = 2;
+    }
+    return morb::side_stream(f->mt) ? ORB_OK : ORB_E_HIP;
+}
+
 int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int rank) {
     MORB_ARG(f && uid128 && world >= 1 && rank >= 0 && rank < world && world * f->n_cams <= 512 && !f->xcomm);
     MORB_HIP(hipSetDevice(f->device));
@@ -222,7 +247,7 @@ int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int r
     const size_t block = (size_t)f->cap_total * 32 + ORBM_BLOCK_TRAILER;
     if ((rc = f->d_xrecv.reserve((size_t)world * block))) { exchange_comm_destroy(comm); return rc; }
     f->xcomm = comm; f->xworld = world; f->xrank = rank;
-    return ORB_OK;
+    return exchange_queues(f);
 }
 
 int orbf_exchange_active(const orbf_frontend* f) { return f && f->xcomm ? f->xworld : 0; }
@@ -236,7 +261,7 @@ int orbf_exchange_init_loopback(orbf_frontend* f, int group, int world, int rank
     LoopComm* C = nullptr;
     if ((rc = loop_join(group, world, rank, &C))) return rc;
     f->xcomm = C; f->xworld = world; f->xrank = rank; f->xloop = true;
-    return ORB_OK;
+    return exchange_queues(f);
 }
 
 int orbf_exchange_shutdown(orbf_frontend* f) {
@@ -303,6 +328,8 @@ int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images) {
     f->announced.emplace_back(next_images, next_images + f->n_cams);
     return ORB_OK;
 }
+
+int orbf_ahead_depth(const orbf_frontend* f) { return f ? f->n_ex : ORB_E_ARG; }
 
 int orbf_step_begin(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, int* block_ready) {
     MORB_ARG(f && images && nq >= 0 && (nq == 0 || queries));
@@ -529,6 +556,11 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     return ORB_OK;
 }
 
+static int ensure_extractor(orbf_frontend* f, int e) {
+    if (f->exs[e]) return ORB_OK;
+    return orbx_create(f->params.data(), f->n_cams, f->max_w, f->max_h, f->device, &f->exs[e]);
+}
+
 // Everything in flight is waited for and dropped (results of prefetched extractions included).
 static int orbf_drain(orbf_frontend* f) {
     MORB_HIP(hipSetDevice(f->device));
@@ -589,6 +621,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         }
         if (!f->announced.empty() && same_images(f->announced.front(), images, f->n_cams)) f->announced.pop_front();
         next_slot(f, &P.e, &P.set);
+        if ((rc = ensure_extractor(f, P.e))) return rc;
         // Nothing ran ahead for this step (a live rig: the images have only just arrived).  Its matching then goes onto the
         // extractor's own stream, right behind the extraction chain -- a kernel boundary instead of a cross-stream event
         // (measured: ~22 us between the chain's last kernel and the projection kernel on the matcher's stream) -- and the
@@ -768,6 +801,7 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     while (P.async_path && first_attempt && f->overlap_ok && !f->announced.empty() && (int)f->inflight.size() < std::max(f->n_ex, 2)) {
         const int prev_e = f->inflight.empty() ? P.e : f->inflight.back().e;
         const int e2 = f->n_ex > 1 ? (prev_e + 1) % f->n_ex : 0;
+        if ((rc = ensure_extractor(f, e2))) { (void)hipStreamSynchronize(st); return rc; }
         if (orbx_pending(f->exs[e2]) >= 2) break;
         int set2 = (f->last_set + 1) % orbf_frontend::NSETS;
         if (set2 == f->cur) set2 = (set2 + 1) % orbf_frontend::NSETS;

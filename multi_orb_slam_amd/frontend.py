@@ -55,11 +55,13 @@ class NativeFrontEnd:
             self._views[(name, addr)] = ent
         return ent
 
-    def __init__(self, params, max_width, max_height, device=0):
+    def __init__(self, params, max_width, max_height, device=0, ahead_depth=0):
+        """ahead_depth: timesteps prefetch() accepts ahead (1..3; 0 = MORB_AHEAD_DEPTH, default 3).  A front end that will run a
+        multi-GPU exchange takes 2 (orbf_create_depth: its streams are hardware queues, the part serves four side by side)."""
         self.params = list(params); self.n_cams = len(self.params)
         arr = (Params * self.n_cams)(*[p.c() for p in self.params])
         self._h = C.c_void_p()
-        check(_lib.lib().orbf_create(arr, self.n_cams, max_width, max_height, device, C.byref(self._h)))
+        check(_lib.lib().orbf_create_depth(arr, self.n_cams, max_width, max_height, device, ahead_depth, C.byref(self._h)))
         self._res = FResult()
         self._views = {}
         self._img_cache = {}
@@ -140,6 +142,11 @@ class NativeFrontEnd:
 
     def exchange_shutdown(self):
         check(_lib.lib().orbf_exchange_shutdown(self._h))
+
+    @property
+    def ahead_depth(self):
+        """timesteps prefetch() accepts ahead of the step being matched (orbf_ahead_depth)"""
+        return _lib.lib().orbf_ahead_depth(self._h)
 
     @property
     def exchange_world(self):

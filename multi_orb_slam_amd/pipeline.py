@@ -68,7 +68,8 @@ class FrontEnd:
         self.gather = gather                      # DescriptorExchange (multi-GPU) or None
         self.global_cams = global_cams or list(range(rank * self.n_cams, (rank + 1) * self.n_cams))
         rt.set_device(device)
-        self.fe = NativeFrontEnd(self.params, width, height, device)
+        # (a rank of a multi-GPU job runs a collective next to its matching: one hardware queue less for extractor streams)
+        self.fe = NativeFrontEnd(self.params, width, height, device, ahead_depth=2 if world_size > 1 else 0)
         self.fe.configure(MBF, 100, True)
         if calib is not None:
             self.fe.set_calibration(calib)   # (fx, fy, cx, cy, k1, k2, p1, p2[, k3]): undistortion as the reference's Frame does it
