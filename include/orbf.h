@@ -143,6 +143,12 @@ int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* quer
  * first step or after orbf_reset).  out->n_queries / out->queries expose what was searched. */
 typedef struct orbf_motion { float du, dv, th; } orbf_motion;
 int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out);
+/* The three calls of a host that drives a stream, as one (a binding then crosses the ABI once per timestep instead of three
+ * times): orbf_prefetch(next_images) when next_images != NULL, orbf_step_motion(images, ...), and *n_cross =
+ * orbm_count_ratio_accepted over the step's cross-camera distances (th_low, ratio; -1 when the step has none).  Same results,
+ * same errors as the calls it stands for. */
+int orbf_step_motion_ahead(orbf_frontend* f, const orbf_image* images, const orbf_image* next_images, const orbf_motion* motion,
+                           int flags, int th_low, float ratio, orbf_result* out, int* n_cross);
 int orbf_reset(orbf_frontend* f);
 /* The synthetic-stream loop in ONE call: for t = t0 .. t0 + steps - 1 announce timestep t + ahead (orbf_prefetch; ahead = 0:
  * nothing is announced, every step is an isolated one; 1 or 2), run orbf_step_motion on ring[(t % ring_len) * n_cams ..] and

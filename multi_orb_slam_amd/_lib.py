@@ -167,6 +167,7 @@ def lib():
     L.orbf_exchange_unique_id.argtypes = [vp]
     L.orbf_exchange_init.argtypes = [vp, vp, i32, i32]
     L.orbf_exchange_active.argtypes = [vp]
+    L.orbf_step_motion_ahead.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp, vp]
     L.orbf_ahead_depth.argtypes = [vp]
     L.orbf_exchange_init_loopback.argtypes = [vp, i32, i32, i32]
     L.orbf_exchange_shutdown.argtypes = [vp]

@@ -401,6 +401,16 @@ int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_moti
     return orbf_step_impl(f, images, nullptr, 0, flags, out, true, motion);
 }
 
+int orbf_step_motion_ahead(orbf_frontend* f, const orbf_image* images, const orbf_image* next_images, const orbf_motion* motion,
+                           int flags, int th_low, float ratio, orbf_result* out, int* n_cross) {
+    MORB_ARG(f && images && motion && out && n_cross);
+    int rc;
+    if (next_images && (rc = orbf_prefetch(f, next_images))) return rc;
+    if ((rc = orbf_step_motion(f, images, motion, flags, out))) return rc;
+    *n_cross = out->cross_best_dist ? orbm_count_ratio_accepted(out->cross_best_dist, out->cross_second_dist, out->n_total, th_low, ratio) : -1;
+    return *n_cross < -1 ? *n_cross : ORB_OK;
+}
+
 // An extraction that ran ahead is only valid for the step that consumes it if the images are still the ones that were
 // uploaded.  Pointers, sizes and strides say nothing about a caller that refilled the same buffer in between.  The exact answer
 // is the caller's: orbf_image::generation (compared by same_images).  Host images WITHOUT a generation carry a sampled

@@ -63,6 +63,7 @@ class NativeFrontEnd:
         self._h = C.c_void_p()
         check(_lib.lib().orbf_create_depth(arr, self.n_cams, max_width, max_height, device, ahead_depth, C.byref(self._h)))
         self._res = FResult()
+        self._ncross = C.c_int(0)
         self._views = {}
         self._img_cache = {}
         self._motion_cache = {}
@@ -244,9 +245,35 @@ class NativeFrontEnd:
             self._nq = nq
         return bool(ready.value)
 
+    def step_ahead(self, images, next_images, motion, th_low, ratio, flags=0, copy=True):
+        """prefetch(next_images) + step(images, motion=...) + the count of cross-camera matches a (th_low, ratio) acceptance keeps,
+        in ONE native call (orbf_step_motion_ahead): what a stream-driving host does per timestep.  -> step() result with
+        ["n_cross"] (None when the step has no cross-camera distances)."""
+        arr, self._keep = self._image_array(images, self._imgs)
+        nxt = None
+        if next_images is not None:
+            if not hasattr(self, "_next_imgs"):
+                self._next_imgs = (FImage * self.n_cams)()
+                self._next_keep = []
+            nxt, keep = self._image_array(next_images, self._next_imgs)
+            if keep:
+                self._next_keep = (self._next_keep + [keep])[-4:]
+        mo = self._motion_cache.get(motion)
+        if mo is None:
+            mo = self._motion_cache[motion] = FMotion(*motion)
+        nc = self._ncross
+        check(_lib.lib().orbf_step_motion_ahead(self._h, arr, nxt, C.byref(mo), flags, th_low, ratio, C.byref(self._res), C.byref(nc)))
+        self._nq = None
+        r = self._collect(copy)
+        r["n_cross"] = nc.value if nc.value >= 0 else None
+        return r
+
     def end(self, copy=True):
         """Second half of step() (orbf_step_end): one synchronisation, then the results."""
         check(_lib.lib().orbf_step_end(self._h, C.byref(self._res)))
+        return self._collect(copy)
+
+    def _collect(self, copy):
         r = self._res
         nq = r.n_queries if self._nq is None else self._nq
         n = r.n_total

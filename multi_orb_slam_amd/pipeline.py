@@ -137,12 +137,25 @@ class FrontEnd:
     def step(self, images, resident=False, next_images=None):
         """next_images: shorthand for announce(next_images) before the step."""
         from .frontend import SKIP_CROSS
+        native = getattr(self, "native_exchange", False)
+        distributed = self.world > 1 and self.gather is not None and not native
+        if not distributed and not native:
+            # one native call per timestep: announce + step + the count of accepted cross-camera matches (orbf_step_motion_ahead)
+            if resident:
+                od = 0 if resident == "pinned" else 1
+                images = [(im[0], self.width, self.height, im[1], od, im[2] if len(im) > 2 else 0) for im in images]
+                if next_images is not None:
+                    next_images = [(im[0], self.width, self.height, im[1], od, im[2] if len(im) > 2 else 0) for im in next_images]
+            r = self.fe.step_ahead(images, next_images, (MOTION[0], MOTION[1], TH_PROJ), TH_LOW, BOW_RATIO, copy=self.copy_results)
+            if r["n_cross"] is None and "cross" in r:
+                bi, bd, sd = r["cross"]
+                bd = np.ascontiguousarray(bd, np.int32); sd = np.ascontiguousarray(sd, np.int32)
+                r["n_cross"] = _lib.lib().orbm_count_ratio_accepted(_lib.ptr(bd), _lib.ptr(sd), len(bd), TH_LOW, BOW_RATIO)
+            return r
         if next_images is not None:
             self.announce(next_images, resident)
         if resident:
             images = [(im[0], self.width, self.height, im[1], 0 if resident == "pinned" else 1, im[2] if len(im) > 2 else 0) for im in images]
-        native = getattr(self, "native_exchange", False)
-        distributed = self.world > 1 and self.gather is not None and not native
         # queries = the previous step's features under the stream's known motion, built natively (orbf_step_motion;
         # same arithmetic as make_queries, which the oracle leg uses)
         if not distributed:
