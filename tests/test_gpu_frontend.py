@@ -560,3 +560,35 @@ def test_native_stream_loop_equals_the_step_by_step_run():
     st, _ = fe.fe.run_stream(ring, 0, N, 2, -1, motion, TH_LOW, pipeline.BOW_RATIO)
     fe.close()
     assert st["digest"] == dig
+
+
+@pytest.mark.parametrize("handles", [1, 2])
+def test_fewer_extractor_instances_take_fewer_steps_ahead(handles, monkeypatch):
+    """MORB_AHEAD_DEPTH / orbf_create_depth: a front end with one or two extractor instances accepts that many timesteps ahead
+    (orbf_ahead_depth), refuses one more, and returns the oracle's results at its full depth."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from multi_orb_slam_amd._lib import OrbError
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    monkeypatch.setenv("MORB_AHEAD_DEPTH", str(handles))
+    w, h = 320, 240
+    params = [m.ExtractorParams(nfeatures=300), m.ExtractorParams(nfeatures=150)]
+    fe = pipeline.FrontEnd(params, w, h)
+    ofe = OracleFrontEnd(params, w, h)
+    assert fe.fe.ahead_depth == handles
+    T = 7
+    frames = [[synth.image(c, t, w, h) for c in range(2)] for t in range(T)]
+    announced = 0
+    for t in range(T):
+        while announced < min(t + handles, T - 1):
+            announced += 1
+            fe.announce(frames[announced])
+        got = fe.step(frames[t])
+        assert_same_step(got, ofe.step(frames[t]))
+    # one announcement too many is refused (the FIFO holds `handles` steps beyond the next one)
+    fe2 = pipeline.FrontEnd(params, w, h)
+    for k in range(handles + 1):
+        fe2.announce(frames[k + 1])
+    with pytest.raises(OrbError):
+        fe2.announce(frames[handles + 2])
+    fe.close(); fe2.close()
