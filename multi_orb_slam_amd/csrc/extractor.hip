@@ -151,6 +151,58 @@ __global__ __launch_bounds__(256) void k_resize(const LevelInfo* __restrict__ L,
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * D.stride + x4) = out;
 }
 
+// k_resize for LARGE rigs (round 3): four adjacent pixels per lane as in k_resize, but the eight taps of a source row are not
+// eight byte loads: with level steps of at most 1.6 they lie within 8 bytes of the first one, so a row is three aligned dwords
+// (one global_load_dwordx3), shifted to start at the first tap (v_alignbyte_b32), and one v_perm_b32 per row and side pulls the
+// four left (right) taps out -- 6 memory instructions per four pixels instead of 21.  The whole-pyramid tile kernel is a latency
+// design (one launch, everything in LDS: 8.7 us per tile); on 8 x 1080p it is 13 x its HBM time, and this chain -- one launch per
+// level, all cameras batched -- does the same arithmetic with a third of the instructions.  Same integers, same bytes.
+// (The reads past a row's last tap stay inside the camera's pyramid block: orbx_create leaves 16 spare bytes behind the last level.)
+__global__ __launch_bounds__(256) void k_resize_v4(const LevelInfo* __restrict__ L, int max_levels, int level,
+                                                   uint8_t* __restrict__ pyr, size_t cam_pitch,
+                                                   const int2* __restrict__ xtab, const int4* __restrict__ ytab) {
+    const int cam = blockIdx.z;
+    const LevelInfo D = L[cam * max_levels + level];
+    const LevelInfo S = L[cam * max_levels + level - 1];
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= D.h || x4 >= D.w) return;
+    const uint8_t* src = pyr + cam * cam_pitch + S.pyr_off;
+    uint8_t* dst = pyr + cam * cam_pitch + D.pyr_off;
+    const int4 yt = ytab[D.ytab_off + y];  // {row0, row1, beta0, beta1}, rows already clipped to [0, sh-1]
+    int2 xt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xt[j] = xtab[D.xtab_off + min(x4 + j, D.w - 1)];   // {sx0 | sx1 << 16, alpha0 | alpha1 << 16}
+    const int c = xt[0].x & 0xffff;
+    uint32_t sel_l = 0, sel_r = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sel_l |= (uint32_t)((xt[j].x & 0xffff) - c) << (8 * j);
+        sel_r |= (uint32_t)(((unsigned)xt[j].x >> 16) - c) << (8 * j);
+    }
+    uint32_t L4[2], R4[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint8_t* p = src + (size_t)(r ? yt.y : yt.x) * S.stride + c;
+        const int sh = (int)(reinterpret_cast<uintptr_t>(p) & 3);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(p - sh);
+        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        L4[r] = __builtin_amdgcn_perm(hi, lo, sel_l);
+        R4[r] = __builtin_amdgcn_perm(hi, lo, sel_r);
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int a0 = (short)(xt[j].y & 0xffff), a1 = xt[j].y >> 16;
+        const int h0 = (int)((L4[0] >> (8 * j)) & 0xff) * a0 + (int)((R4[0] >> (8 * j)) & 0xff) * a1;
+        const int h1 = (int)((L4[1] >> (8 * j)) & 0xff) * a0 + (int)((R4[1] >> (8 * j)) & 0xff) * a1;
+        const int v = ((((yt.z * (h0 >> 4)) >> 16) + ((yt.w * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+        out |= (uint32_t)v << (8 * j);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)y * D.stride + x4) = out;   // (columns past w: padding of the 64-byte row pitch, as k_resize)
+}
+
 // One pixel of a pyramid level from the level below it: cv::resize(INTER_LINEAR) in 11-bit fixed point, exactly the arithmetic
 // of k_resize (tables: xt = {sx0 | sx1 << 16, alpha0 | alpha1 << 16}, yt = {row0, row1, beta0, beta1}).
 __device__ __forceinline__ int resize_px(const uint8_t* __restrict__ src, int sstride, const int2 xt, const int4 yt) {
@@ -1571,7 +1623,8 @@ struct orbx_extractor {
     int pyr_tx_max = 0, pyr_ty_max = 0, pyr_lds = 0, pyr_tile = 0, pyr_tab_cap = 0, pyr_threads = 256;
     short pyr_tx[64] = {}, pyr_ty[64] = {};
     bool ingest_host = false;         // a pending ingest source lives in host memory (read across PCIe)
-    bool tiled_ok = false;            // ... and this geometry fits it (LDS, halo, level count)
+    bool tiled_ok = false;            // ... and this geometry fits it (LDS, halo, level count) and is small enough to prefer it
+    bool chain_v4 = false;            // the resize chain runs k_resize_v4 (level steps <= 1.6: the taps of four neighbours within 8 bytes)
     bool tiled_pyramid = true;        // MORB_TILED_PYRAMID=0: the resize chain of rounds 1-2 (k_resize2 / k_resize launches)
     DevBuf<int4> d_ytab;
     DevBuf<int> d_cell_cnt, d_cell_off;
@@ -1769,6 +1822,19 @@ static int rebuild_geometry(orbx_extractor* ex) {
         ex->pyr_tab_cap = (ex->pyr_tab_cap + 3) & ~3;
         ex->pyr_lds += ex->pyr_tab_cap * 24;   // the table entries of a tile's columns (int2) and rows (int4) in front of the regions
         ex->tiled_ok = !(ex->pyr_lds > 60 * 1024 || ML > PYR_MAX_LEVELS || !halo_ok || ex->max_w > 32767 || ex->max_h > 32767);   // (cannot happen for tiles of 64 and scale factors >= 1.05)
+        // Large rigs take the resize chain with four pixels per lane (k_resize_v4) instead: the one-launch tile kernel is a latency
+        // design and costs three times the instructions per pixel.  MORB_PYR_CHAIN = 1 / 0: always / never; default: above
+        // MORB_PYR_CHAIN_PX level-0 pixels over all cameras (4 M: 8 x 1080p yes, 2 x 1280x720 no).
+        ex->chain_v4 = true;
+        for (int c = 0; c < ex->n_cams && ex->chain_v4; ++c)
+            for (int l = 1; l < ex->cams[c].p.nlevels; ++l) {
+                const LevelInfo &Ls = ex->levels[(size_t)c * ML + l - 1], &Ld = ex->levels[(size_t)c * ML + l];
+                if (Ld.w > 0 && (long long)Ls.w * 10 > (long long)Ld.w * 16) ex->chain_v4 = false;
+            }
+        static const int chain_env = [] { const char* e = getenv("MORB_PYR_CHAIN"); return e ? atoi(e) : -1; }();
+        static const long long chain_px = [] { const char* e = getenv("MORB_PYR_CHAIN_PX"); return e ? atoll(e) : 4000000ll; }();
+        const bool prefer_chain = ex->chain_v4 && (chain_env == 1 || (chain_env < 0 && (long long)px0 > chain_px));
+        if (prefer_chain) ex->tiled_ok = false;
     }
     if (slot_base > (size_t)INT32_MAX) { morb::set_error("candidate slot space exceeds 2^31 entries"); return ORB_E_ARG; }
     ex->total_cells = cell_base;
@@ -2158,6 +2224,10 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestA
         if (mw == 0) continue;
         if (!pairs) {
             dim3 grid((mw + 255) / 256, (mh + 3) / 4, ex->n_cams), block(64, 4, 1);
+            if (ex->chain_v4)
+                hipLaunchKernelGGL(k_resize_v4, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
+                                   (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
+            else
             hipLaunchKernelGGL(k_resize, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
                                (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
         } else {
