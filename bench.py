@@ -402,9 +402,16 @@ def main(argv=None):
         dev_frames.append(row); pin_frames.append(prow)
     rt.device_sync()
 
+    _prepared = {}
+
     def frame_args(t, pinned=False):
-        src = pin_frames if pinned else dev_frames
-        return [(src[t % RING][c].ptr, W) for c in range(NC)]
+        # the ring's slots are marshalled once (pipeline.FrontEnd.prepare): the timed loop hands the binding finished orbf_image arrays
+        key = (t % RING, pinned)
+        arr = _prepared.get(key)
+        if arr is None:
+            src = pin_frames if pinned else dev_frames
+            arr = _prepared[key] = fe.prepare([(src[t % RING][c].ptr, W) for c in range(NC)], "pinned" if pinned else True)
+        return arr
 
     # Consecutive timesteps overlap: while step t is matched (and, with N > 1, exchanged), the extraction of step t+1 already
     # runs on the extractor's stream.

@@ -63,6 +63,7 @@ class NativeFrontEnd:
         self._h = C.c_void_p()
         check(_lib.lib().orbf_create_depth(arr, self.n_cams, max_width, max_height, device, ahead_depth, C.byref(self._h)))
         self._res = FResult()
+        self._arr_type = FImage * self.n_cams
         self._ncross = C.c_int(0)
         self._views = {}
         self._img_cache = {}
@@ -171,6 +172,8 @@ class NativeFrontEnd:
     def _image_array(self, images, slot):
         """ctypes orbf_image array for `images`; HBM-resident frames (tuples) are built once per distinct set and reused (a
         stream cycles through a ring of buffers), host arrays are filled into the scratch array `slot`."""
+        if type(images) is self._arr_type:      # prepared by prepare()
+            return images, []
         try:
             key = tuple(images)
             arr = self._img_cache.get(key)
@@ -245,13 +248,27 @@ class NativeFrontEnd:
             self._nq = nq
         return bool(ready.value)
 
+    def prepare(self, images):
+        """The orbf_image array of HBM-resident / page-locked frames (tuples (ptr, width, height, stride, on_device[, generation])),
+        built once: step_ahead() takes it as `images` / `next_images` without marshalling it again (a stream that cycles through a
+        ring of buffers prepares every slot once).  The buffers must stay alive, as for step()."""
+        arr = self._arr_type()
+        self._fill(arr, images)
+        return arr
+
     def step_ahead(self, images, next_images, motion, th_low, ratio, flags=0, copy=True):
         """prefetch(next_images) + step(images, motion=...) + the count of cross-camera matches a (th_low, ratio) acceptance keeps,
         in ONE native call (orbf_step_motion_ahead): what a stream-driving host does per timestep.  -> step() result with
         ["n_cross"] (None when the step has no cross-camera distances)."""
-        arr, self._keep = self._image_array(images, self._imgs)
+        AT = self._arr_type
+        if type(images) is AT:       # prepared by prepare(): HBM-resident frames of a ring, marshalled once
+            arr = images
+        else:
+            arr, self._keep = self._image_array(images, self._imgs)
         nxt = None
-        if next_images is not None:
+        if type(next_images) is AT:
+            nxt = next_images
+        elif next_images is not None:
             if not hasattr(self, "_next_imgs"):
                 self._next_imgs = (FImage * self.n_cams)()
                 self._next_keep = []

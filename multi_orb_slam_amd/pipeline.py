@@ -130,9 +130,17 @@ class FrontEnd:
     def announce(self, images, resident=False):
         """Announce the images of a future step (orbf_prefetch; a FIFO, at most three steps ahead): their extraction runs next to
         the matching of the steps before; those steps must then pass exactly these images, in order."""
-        if resident:   # (ptr, stride[, generation]): HBM-resident (True) or page-locked host memory ("pinned": copied H2D inside the step)
+        if type(images) is self.fe._arr_type:
+            pass           # (prepared by prepare())
+        elif resident:     # (ptr, stride[, generation]): HBM-resident (True) or page-locked host memory ("pinned": copied H2D inside the step)
             images = [(im[0], self.width, self.height, im[1], 0 if resident == "pinned" else 1, im[2] if len(im) > 2 else 0) for im in images]
         self.fe.prefetch(images)
+
+    def prepare(self, images, resident=True):
+        """Marshal the (ptr, stride[, generation]) tuples of HBM-resident (True) or page-locked ("pinned") frames once; step() and
+        its next_images take the result in place of the tuples (a ring of buffers is prepared slot by slot)."""
+        od = 0 if resident == "pinned" else 1
+        return self.fe.prepare([(im[0], self.width, self.height, im[1], od, im[2] if len(im) > 2 else 0) for im in images])
 
     def step(self, images, resident=False, next_images=None):
         """next_images: shorthand for announce(next_images) before the step."""
@@ -141,7 +149,10 @@ class FrontEnd:
         distributed = self.world > 1 and self.gather is not None and not native
         if not distributed and not native:
             # one native call per timestep: announce + step + the count of accepted cross-camera matches (orbf_step_motion_ahead)
-            if resident:
+            AT = self.fe._arr_type
+            if type(images) is AT:
+                pass                  # (prepared by prepare(): nothing to marshal)
+            elif resident:
                 od = 0 if resident == "pinned" else 1
                 images = [(im[0], self.width, self.height, im[1], od, im[2] if len(im) > 2 else 0) for im in images]
                 if next_images is not None:
@@ -154,7 +165,7 @@ class FrontEnd:
             return r
         if next_images is not None:
             self.announce(next_images, resident)
-        if resident:
+        if resident and type(images) is not self.fe._arr_type:
             images = [(im[0], self.width, self.height, im[1], 0 if resident == "pinned" else 1, im[2] if len(im) > 2 else 0) for im in images]
         # queries = the previous step's features under the stream's known motion, built natively (orbf_step_motion;
         # same arithmetic as make_queries, which the oracle leg uses)
