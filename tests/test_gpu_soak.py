@@ -1,4 +1,4 @@
-"""Soak of the overlapped front end: thousands of steps with two timesteps announced ahead.  orbf_step_end normally takes
+"""Soak of the overlapped front end: thousands of steps with three timesteps announced ahead (the bench's default depth).  orbf_step_end normally takes
 every result word from the pinned buffer as soon as it carries the launch's sequence number (no end-of-kernel wait,
 DESIGN section 7); MORB_POLL=0 makes it wait with hipStreamSynchronize instead.  Both must hand out exactly the same bytes
 for every step -- a result word read too early, a stale frame or a recycled result set would show up as a different digest."""
@@ -27,10 +27,12 @@ def _run(monkeypatch, poll, isolated=False):
     arg = lambda t: [(dev[t % RING][c].ptr, W) for c in range(2)]
     fe.copy_results = False                                       # results consumed in place, as the benchmark does
     digests = []
+    AHEAD = 3
     if not isolated:
-        fe.announce(arg(1), resident=True)
+        for k in range(1, AHEAD):
+            fe.announce(arg(k), resident=True)
     for t in range(N_STEPS):
-        r = fe.step(arg(t), resident=True, next_images=None if isolated else arg(t + 2))
+        r = fe.step(arg(t), resident=True, next_images=None if isolated else arg(t + AHEAD))
         h = hashlib.blake2b(digest_size=8)
         for a in (r["match_of_feature"], r["kps"], r["desc"], r["uright"], r["cross"][0], r["cross"][1], r["cross"][2]):
             h.update(np.ascontiguousarray(a).tobytes())
