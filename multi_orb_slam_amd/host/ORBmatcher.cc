@@ -141,6 +141,19 @@ int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
     return orbm_descriptor_distance(a.ptr(0), b.ptr(0));
 }
 
+// Squared distance of kp2 from the epipolar line of kp1 (l = x1^T F12, float32 as in the reference) against the 95 % chi-square
+// bound of one degree of freedom scaled by the octave's sigma^2 (the product is formed in double there, :183).
+bool ORBmatcher::CheckDistEpipolarLine(const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const cv::Mat& F12, const KeyFrame* pKF2) {
+    float l[3];
+    for (int j = 0; j < 3; ++j)
+        l[j] = kp1.pt.x * F12.at<float>(0, j) + kp1.pt.y * F12.at<float>(1, j) + F12.at<float>(2, j);
+    const float num = l[0] * kp2.pt.x + l[1] * kp2.pt.y + l[2];
+    const float den = l[0] * l[0] + l[1] * l[1];
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * pKF2->mvLevelSigma2[kp2.octave];
+}
+
 float ORBmatcher::RadiusByViewingCos(const float& viewCos) {  // reference :151-157
     if (viewCos > 0.998) return 2.5;
     else return 4.0;

@@ -95,6 +95,8 @@ public:
     cv::Mat mtcam21;
 
 protected:
+    // (reference include/ORBmatcher.h:116 / src/ORBmatcher.cc:167-184; the searches run the same test on the device)
+    bool CheckDistEpipolarLine(const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const cv::Mat& F12, const KeyFrame* pKF);
     float RadiusByViewingCos(const float& viewCos);
     cv::Mat SkewSymmetricMatrix(const cv::Mat& v);
     void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);

@@ -642,6 +642,18 @@ static int run_rt(int argc, char** argv) {
             if (std::memcmp(&ys[k], &y.at<float>(k), 4) != 0 || std::memcmp(&zs[k], &z.at<float>(k), 4) != 0) ++bad;
         }
     }
+    // CheckDistEpipolarLine (protected in the reference, src/ORBmatcher.cc:167-184): with F12 chosen so that the epipolar line of
+    // (u, v) is x = u, a point 2 px off the line passes at sigma^2 = 1.44 (4 < 3.84 * 1.44) and fails at sigma^2 = 1; a zero line fails
+    struct Probe : ORBmatcher { Probe() : ORBmatcher(0.6f, true) {} using ORBmatcher::CheckDistEpipolarLine; } probe;
+    cv::Mat F12 = cv::Mat::zeros(3, 3, CV_32F);
+    F12.at<float>(2, 0) = 1.f; F12.at<float>(0, 2) = -1.f;      // l = (1, 0, -u)
+    KeyFrame kf;
+    kf.mvLevelSigma2 = {1.0f, 1.44f};
+    cv::KeyPoint k1, k2;
+    k1.pt.x = 5.f; k1.pt.y = 9.f; k2.pt.x = 7.f; k2.pt.y = -3.f;
+    k2.octave = 1; if (!probe.CheckDistEpipolarLine(k1, k2, F12, &kf)) ++bad;
+    k2.octave = 0; if (probe.CheckDistEpipolarLine(k1, k2, F12, &kf)) ++bad;
+    if (probe.CheckDistEpipolarLine(k1, k2, cv::Mat::zeros(3, 3, CV_32F), &kf)) ++bad;
     std::printf("rt: %ld poses x points, %ld differing floats\n", n, bad);
     return bad ? 7 : 0;
 }
