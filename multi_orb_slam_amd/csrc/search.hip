@@ -475,6 +475,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
 // concern); only a displaced query walks on.  Rounds are counted as before (a claim still travels one link of a dependency
 // chain per round) but cost a tenth of a sweep.  Owners, rotation histogram and result words as in k_resolve.  POINTS (top-2 with
 // ratio test), two-window queries and states beyond LDS keep k_resolve.
+template <int RQ, bool ANG>
 __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* __restrict__ qmeta, int nq, int cap,
                                                        const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
                                                        const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
@@ -494,30 +495,34 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
 #endif
     if (tid < 3) s_flag[tid] = 0;
     const int NT = F.n_total_dev ? *F.n_total_dev : F.n_total;
-    const int* tk_key = topk;
     const int* tk_g = topk + RESOLVE_K * nq;
+    // LDS (mono_lds_bytes on the host): claims, owners (ints); per query: list length, pick, K shortlist features (u16: the frames
+    // this kernel takes have < 65535 features; 0xffff = none), flags (u8); with ANG the query / feature angles for the rotation
+    // histogram (else they are read from HBM in the tail: what lets 4 x 1000 or 2 x 2000 features in at all)
     int* s_owner = s_claim + F.n_total;
-    unsigned short* l_cnt = reinterpret_cast<unsigned short*>(s_claim + 2 * F.n_total);
-    int* l_choice = s_claim + 2 * F.n_total + (nq + 1) / 2;
-    int* l_gd = l_choice + nq;
-    float* l_ang = reinterpret_cast<float*>(l_gd + RESOLVE_K * nq);
+    const int nq2 = (nq + 1) & ~1;
+    unsigned short* l_cnt = reinterpret_cast<unsigned short*>(s_owner + F.n_total);
+    unsigned short* l_choice = l_cnt + nq2;
+    unsigned short* l_gd = l_choice + nq2;
+    unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_gd + RESOLVE_K * nq2);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
+    float* l_ang = reinterpret_cast<float*>(l_fl + ((nq + 3) & ~3));
     float* l_fang = l_ang + nq;
-    unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_fang + F.n_total);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
     if (tid == 0) s_red = 0;
     if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
     for (int g = tid; g < F.n_total; g += T) {
         s_claim[g] = 0x7fffffff; s_owner[g] = -1;
-        if (check_ori) l_fang[g] = f_angle[g];
+        if (ANG && check_ori) l_fang[g] = f_angle[g];
     }
     __syncthreads();   // (the claims of round 0 go into the table right below)
     // per query of this thread (two in registers; more only beyond 2048 queries, re-read from LDS every round): the shortlist
-    // (distance << 16 | feature, 0xffff = none), the cursor, the entry under it (a rescanned pick is not on the shortlist)
-    constexpr int RQ = 2, K = RESOLVE_K;
+    // (feature indices, 0xffff = none: every entry k_project put there is acceptable -- not occupied, distance <= th_high --, so the
+    // distances stay behind), the cursor, the pick under it (a rescanned pick is not on the shortlist)
+    constexpr int K = RESOLVE_K;
     int sl[RQ][K], cur[RQ], pos[RQ], flr[RQ];
     int mx = 0;
     // set-up of one query: every load is independent of every other -- one trip to HBM for the whole pass.  Round 0 rides along:
     // without any claim a query takes the head of its shortlist (every entry there is acceptable: not occupied, distance <=
-    // th_high checked here) and, if it blocks, claims it
+    // th_high) and, if it blocks, claims it
     auto setup = [&](const int i, int (&e)[K], int& c, int& fl) {
         const int cnt_i = cand_count[i];
         mx = max(mx, cnt_i);
@@ -525,16 +530,16 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
         const int2 qm = qmeta[i];
         fl = (qm.x & 1) | (topk[(2 * K) * nq + i] > K ? 2 : 0);
         l_fl[i] = (unsigned char)fl;
-        l_ang[i] = __int_as_float(qm.y);
+        if (ANG) l_ang[i] = __int_as_float(qm.y);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            e[k] = (tk_key[k * nq + i] & 0xffff0000) | (tk_g[k * nq + i] & 0xffff);
-            l_gd[k * nq + i] = e[k];
+            e[k] = tk_g[k * nq + i] & 0xffff;
+            l_gd[k * nq2 + i] = (unsigned short)e[k];
         }
-        const bool has = (e[0] & 0xffff) != 0xffff && (int)((unsigned)e[0] >> 16) <= th_high;
+        const bool has = e[0] != 0xffff;
         c = has ? e[0] : -1;
-        l_choice[i] = has ? (e[0] & 0xffff) : -1;
-        if (has && (fl & 1)) atomicMin(&s_claim[e[0] & 0xffff], i);
+        l_choice[i] = (unsigned short)(has ? e[0] : 0xffff);
+        if (has && (fl & 1)) atomicMin(&s_claim[e[0]], i);
     };
 #pragma unroll
     for (int b = 0; b < RQ; ++b) {
@@ -596,14 +601,13 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
                 int ne = 0xffff;
 #pragma unroll
                 for (int k = 1; k < K; ++k) if (nk == k) ne = e[b][k];
-                if (nk < K && (int)((unsigned)ne >> 16) <= th_high) {
-                    c[b] = ne; p[b] = nk; l_choice[i] = ne & 0xffff;
-                    if (fl[b] & 1) atomicMin(&s_claim[ne & 0xffff], i);
+                if (nk < K) {
+                    c[b] = ne; p[b] = nk; l_choice[i] = (unsigned short)ne;
+                    if (fl[b] & 1) atomicMin(&s_claim[ne], i);
                 } else {
-                    c[b] = -1; l_choice[i] = -1;
-                    // the shortlist is exact unless it ran dry while longer lists exist: rescanned right below.  (A first free
-                    // entry beyond th_high ends the query: whatever else is free is at least as far.)
-                    need_rescan[b] = nk == K && (fl[b] & 2);
+                    c[b] = -1; l_choice[i] = 0xffff;
+                    // the shortlist is exact unless it ran dry while longer lists exist: rescanned right below
+                    need_rescan[b] = (fl[b] & 2) != 0;
                     p[b] = K;
                 }
             }
@@ -634,7 +638,7 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
                     if (m1 < k1) { k1 = m1; g1 = __builtin_amdgcn_readlane(gg, __ffsll((long long)__ballot(key == m1)) - 1); }
                 }
                 if (lane == src && k1 != 0x7fffffff && (k1 >> 16) <= th_high) {   // the rescanned pick is the entry under the cursor from now on
-                    c[b] = (k1 & 0xffff0000) | g1; l_choice[q] = g1;
+                    c[b] = g1; l_choice[q] = (unsigned short)g1;
                     if (fl[b] & 1) atomicMin(&s_claim[g1], q);
                 }
             }
@@ -646,7 +650,9 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
     // barrier; a round in which no wave saw anything displaced is the fixed point.  Dependency chains are followed at the pace
     // of a pass (two LDS trips), not of a barrier: the benchmark stream needs 2-3 rounds where the Jacobi form needs 9 sweeps.
     int it = 1, changed = 1;
-    const int qi01[RQ] = {tid, T + tid};
+    int qi01[RQ];
+#pragma unroll
+    for (int b = 0; b < RQ; ++b) qi01[b] = b * T + tid;
     for (; it < max_it && changed; ++it) {
 #ifdef MORB_PHASE_CLOCKS
         it_dbg = it;
@@ -667,12 +673,12 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
                     for (int k = 0; k < K; ++k) e[b][k] = 0xffff;
                     if (i < nq) {
                         fl[b] = l_fl[i];
-                        const int g = l_choice[i];
+                        const int g = l_choice[i] == 0xffff ? -1 : (int)l_choice[i];
 #pragma unroll
-                        for (int k = 0; k < K; ++k) e[b][k] = l_gd[k * nq + i];
-                        c[b] = g;   // (distance bits are only looked at when a pick is made)
+                        for (int k = 0; k < K; ++k) e[b][k] = l_gd[k * nq2 + i];
+                        c[b] = g;
 #pragma unroll
-                        for (int k = K - 1; k >= 0; --k) if (g >= 0 && (e[b][k] & 0xffff) == g) p[b] = k;
+                        for (int k = K - 1; k >= 0; --k) if (g >= 0 && e[b][k] == g) p[b] = k;
                     }
                 }
                 w |= pass(qx, e, c, p, fl);
@@ -701,12 +707,12 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
     const float factor = 1.0f / ORBM_HISTO_LENGTH;
     int acc = 0;
     for (int i = tid; i < nq; i += T) {
-        const int c = l_choice[i];
+        const int c = l_choice[i] == 0xffff ? -1 : (int)l_choice[i];
         if (c < 0) continue;
         ++acc;
         atomicMax(&s_owner[c], i);
         if (check_ori) {
-            float rot = l_ang[i] - l_fang[c];
+            float rot = ANG ? l_ang[i] - l_fang[c] : __int_as_float(qmeta[i].y) - f_angle[c];
             if (rot < 0.0) rot += 360.0f;
             int bin = (int)roundf(rot * factor);
             if (bin == ORBM_HISTO_LENGTH) bin = 0;
@@ -748,7 +754,7 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
         MORB_PHASE(g_ph_res, 54);
         int rej = 0;
         for (int i = tid; i < nq; i += T) {
-            const int c = l_choice[i];
+            const int c = l_choice[i] == 0xffff ? -1 : (int)l_choice[i];
             if (c < 0) continue;
             const int bin = (int)(l_fl[i] >> 2) - 1;  // -1: outside the histogram, never rejected
             if (bin >= 0 && bin < ORBM_HISTO_LENGTH && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
@@ -960,7 +966,8 @@ __global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __rest
 
 int morb::search_raise_lds_limits() {
     const void* fns[] = {(const void*)k_resolve<true, false>, (const void*)k_resolve<false, false>, (const void*)k_resolve<true, true>,
-                         (const void*)k_resolve<false, true>, (const void*)k_resolve_mono};
+                         (const void*)k_resolve<false, true>, (const void*)k_resolve_mono<2, true>, (const void*)k_resolve_mono<2, false>,
+                         (const void*)k_resolve_mono<4, true>, (const void*)k_resolve_mono<4, false>};
     for (const void* fn : fns) MORB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return ORB_OK;
 }
@@ -1258,11 +1265,25 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
     J.seq = 0;
     if (J.want_tags) { m->resolve_seq = m->resolve_seq % 2047 + 1; J.seq = m->resolve_seq; }   // 1..2047, never 0
     static const bool mono_env = [] { const char* e = getenv("MORB_RESOLVE_MONO"); return !(e && atoi(e) == 0); }();
-    if (ldsq && !J.points && mono_env)
-        hipLaunchKernelGGL(k_resolve_mono, dim3(1), dim3(1024), lds_use, m->stream, cur->dev(), (const int2*)m->d_qmeta.p, nq, cap,
-                           (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ, (const float*)cur->b->d_ang.p,
-                           th_high, J.check_ori, 4096, (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20);
-    else if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
+    // The frame search's monotone resolve keeps less per query (16-bit features, no distances; mono_lds): it takes frames of up to
+    // ~6000 features / queries (4 x 1000, 2 x 2000: where k_resolve's Jacobi form keeps its query state in HBM and costs 53 us),
+    // four queries per thread in registers beyond 2048 queries, the rotation angles from HBM when they do not fit next to the rest.
+    auto mono_lds = [&](bool ang) {
+        const size_t nq2 = ((size_t)nq + 1) & ~(size_t)1;
+        return (size_t)n * 8 + nq2 * 4 + (size_t)RESOLVE_K * nq2 * 2 + (((size_t)nq + 3) & ~(size_t)3) + (ang ? ((size_t)nq + (size_t)n) * 4 : 0) + 16;
+    };
+    if (!J.points && mono_env && n < 65535 && mono_lds(false) <= 150 * 1024) {
+        const bool ang = mono_lds(true) <= 150 * 1024;
+        const size_t ml = mono_lds(ang);
+#define MORB_MONO_LAUNCH(RQ_, ANG_)                                                                                                       \
+        hipLaunchKernelGGL((k_resolve_mono<RQ_, ANG_>), dim3(1), dim3(1024), ml, m->stream, cur->dev(), (const int2*)m->d_qmeta.p, nq, cap, \
+                           (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,                                \
+                           (const float*)cur->b->d_ang.p, th_high, J.check_ori, 4096, (const int*)m->d_claim.p, m->h_match.dp + 4,          \
+                           m->h_match.dp, J.seq << 20)
+        if (nq <= 2048) { if (ang) MORB_MONO_LAUNCH(2, true); else MORB_MONO_LAUNCH(2, false); }
+        else { if (ang) MORB_MONO_LAUNCH(4, true); else MORB_MONO_LAUNCH(4, false); }
+#undef MORB_MONO_LAUNCH
+    } else if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
     else { if (J.points) MORB_RESOLVE_LAUNCH(true, false); else MORB_RESOLVE_LAUNCH(false, false); }
 #undef MORB_RESOLVE_LAUNCH
     MORB_HIP(hipGetLastError());  // status + matches are written by the kernel into the mapped pinned buffer
