@@ -47,6 +47,11 @@ struct orbf_frontend {
     int cur = 0;       // set holding the results of the last completed step
     int last_set = 0;  // set most recently handed to an extraction (sets are handed out round robin)
     morb::StageBuf h_queries;   // this step's queries: written by the host, read once by k_project
+    // The motion stream (orbf_step_motion) builds its queries inside the projection kernel from the previous frame's arrays in
+    // HBM (MotionSrc); the host keeps the same records for orbf_result::queries and the host fallbacks, written while it waits
+    DevBuf<float> d_scale;             // scale factor per level (device copy of scale_factors)
+    std::vector<orbm_query> q_host;
+    bool motion_on_device = true;      // MORB_MOTION_ON_DEVICE=0: the host writes the records into the staging buffer first (rounds 1-3)
     PinnedBuf<int32_t> h_match;
     // Small rigs (<= 4 cameras): one persistent frame per result set, filled by the extractor's describe kernel (FrameSink)
     orbm_frame* pframe[NSETS] = {};
@@ -69,6 +74,8 @@ struct orbf_frontend {
         bool inline_match = false; // the step's own extraction was enqueued by this call: its matching follows on the SAME stream
         bool mirror_requested = false, mirror_pending = false;  // the pinned result mirrors are filled by a copy kernel of the step
         int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
+        bool ext_done = false;     // the step's extraction + frame grid had completed when the step began (no event wait needed)
+        bool use_ms = false; MotionSrc ms; orbf_motion motion;   // queries built by the projection kernel (motion stream)
         orbm_frame* fr = nullptr;
         SearchJob J{nullptr, nullptr, 0, nullptr, false, 0.f, 0, 0, 64, false};
         std::vector<orbf_image> images;
@@ -111,8 +118,17 @@ int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int 
     f->d_depth.assign(n_cams, nullptr); f->depth_stride.assign(n_cams, 0); f->counts.assign(n_cams, 0);
     { const char* pe = getenv("MORB_POLL"); f->poll_ok = !(pe && atoi(pe) == 0); }
     { const char* te = getenv("MORB_HOST_TIMELINE"); f->timeline = te && atoi(te) != 0; }
+    f->motion_on_device = getenv_int("MORB_MOTION_ON_DEVICE", 1) != 0;
     f->scale_factors.assign(params[0].nlevels, 1.f);
     if ((rc = orbx_tables(&params[0], f->scale_factors.data(), nullptr, nullptr, nullptr, nullptr, nullptr))) { orbf_destroy(f); return rc; }
+    // (on the matcher's stream: a copy on the NULL stream would bring a fifth hardware queue into being -- measured: the overlapped loop
+    // at 9 300 steps/s instead of 19 000)
+    if ((rc = f->d_scale.reserve(f->scale_factors.size())) ||
+        hipMemcpyAsync(f->d_scale.p, f->scale_factors.data(), f->scale_factors.size() * sizeof(float), hipMemcpyHostToDevice, f->mt->stream) != hipSuccess ||
+        hipStreamSynchronize(f->mt->stream) != hipSuccess) {
+        if (!rc) { morb::set_error("scale table upload failed"); rc = ORB_E_HIP; }
+        orbf_destroy(f); return rc;
+    }
     for (int c = 0; c < n_cams; ++c) { f->cam_cap.push_back(params[c].nfeatures + 4 * params[c].nlevels); f->cap_total += f->cam_cap.back(); }
     const size_t cap = (size_t)f->cap_total;
     if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
@@ -151,7 +167,7 @@ void orbf_destroy(orbf_frontend* f) {
     if (f->mt) orbm_destroy(f->mt);
     for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) orbx_destroy(f->exs[e]);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); f->rs[k].unx.release(); f->rs[k].uny.release(); f->rs[k].cross.release(); }
-    f->h_queries.release(); f->h_match.release();
+    f->h_queries.release(); f->h_match.release(); f->d_scale.release();
     if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->ev_ready[k]) (void)hipEventDestroy(f->ev_ready[k]);
     delete f;
@@ -612,6 +628,8 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     MORB_HIP(hipSetDevice(f->device));
     orbm_matcher* m = f->mt;
     int rc, went_async = 0;
+    // (a persistent frame stays intact while its result set is f->cur: the motion stream's projection kernel reads it)
+    const orbm_frame* prev_frame = f->last_frame && !f->last_frame_owned ? f->last_frame : nullptr;
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
     f->last_frame = nullptr; f->last_frame_owned = false;
     if (f->xcomm) flags |= ORBF_SKIP_CROSS;   // the rig-wide matching of the exchange replaces the rank-local one
@@ -657,29 +675,43 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         if (P.inline_match && !went_async) P.inline_match = false;   // (host-quadtree path: everything was synchronous)
     }
     if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[0] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
-    if (motion) {
+    if (motion && f->motion_on_device && prev_frame && f->prev_n > 0 && prev_frame->n_total == f->prev_n &&
+        prev_frame->n_cams == f->n_cams) {
+        // query i = feature i of the previous frame (still in HBM) moved by the motion: built by the projection kernel itself
+        const FrameBufs* B = prev_frame->b;
+        nq = f->prev_n; P.nq = nq;
+        P.use_ms = true; P.motion = *motion;
+        P.ms = MotionSrc{B->d_x.p, B->d_y.p, B->d_depth.p, B->d_ang.p, B->d_oct.p, (const uint4*)B->d_desc.p, B->d_cam_start.p, f->n_cams,
+                         f->d_scale.p, motion->du, motion->dv, motion->th, f->mbf, nullptr};
+        f->q_host.resize((size_t)nq);   // (filled by orbf_step_end while it waits: orbf_result::queries, the host fallbacks)
+        queries = nullptr;
+    } else if (motion) {
         if ((rc = queries_from_previous_step(f, motion, &nq))) return rc;
         queries = reinterpret_cast<const orbm_query*>(f->h_queries.p); queries_in_pinned = true;
         P.nq = nq;
     }
     // queries go through pinned (device-mapped) staging and are read from there by the projection kernel
-    if (nq) {
+    if (nq && !P.use_ms) {
         if ((rc = f->h_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))))
             return rc;
         if (!queries_in_pinned) memcpy(f->h_queries.p, queries, (size_t)nq * sizeof(orbm_query));
         f->h_queries.publish();
     }
     if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[1] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
-    P.J = SearchJob{nullptr, reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f, f->th_high, f->check_ori, 64, false};
-    P.J.q_dev = nq ? reinterpret_cast<const orbm_query*>(f->h_queries.dp) : nullptr;   // no H2D on the step's critical chain
+    P.J = SearchJob{nullptr, P.use_ms ? f->q_host.data() : reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f,
+                    f->th_high, f->check_ori, 64, false};
+    P.J.q_dev = nq && !P.use_ms ? reinterpret_cast<const orbm_query*>(f->h_queries.dp) : nullptr;   // no H2D on the step's critical chain
+    P.J.msrc = P.use_ms ? &P.ms : nullptr;
     P.J.want_tags = f->poll_ok;
     if ((rc = f->h_match.reserve(std::max(f->cap_total, 1)))) return rc;
     P.async_path = went_async != 0;
     // The export block of this step is final already when its extraction chain has completed cleanly (the usual case with
     // steps announced ahead): then nothing of this step can be redone and a caller may ship the block right away.
     P.block_ready = false;
-    if (P.async_path && !P.inline_match && hipEventQuery(f->ev_ready[P.set]) == hipSuccess) P.block_ready = orbx_peek_status(f->exs[P.e]) == 0;
-    else (void)hipGetLastError();
+    if (P.async_path && !P.inline_match && hipEventQuery(f->ev_ready[P.set]) == hipSuccess) {
+        P.ext_done = true;   // (the matcher's stream then needs no event wait in front of the search: step_enqueue)
+        P.block_ready = orbx_peek_status(f->exs[P.e]) == 0;
+    } else (void)hipGetLastError();
     if ((rc = step_enqueue(f, P, true))) return rc;
     P.active = true;
     if (block_ready) *block_ready = P.block_ready ? 1 : 0;
@@ -707,7 +739,7 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         // matching follows the extraction chain (which ends with the frame grid): through its event, or simply behind it on
         // the same stream; counts are in HBM
         P.fr = f->pframe[P.set]; P.fr_persistent = true;
-        if (!inline_match) MORB_HIP(hipStreamWaitEvent(st, f->ev_ready[P.set], 0));  // extraction + frame grid of this step
+        if (!inline_match && !P.ext_done) MORB_HIP(hipStreamWaitEvent(st, f->ev_ready[P.set], 0));  // extraction + frame grid of this step
         P.n = P.fr->n_total;
     } else {
         rc = orbx_finish(ex);  // synchronises; counts are on the host from here on
@@ -857,6 +889,12 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     orbf_frontend::ResultSet& R = f->rs[P.set];
     int rc, nmatches = 0;
     auto t_synced = P.t_impl;
+    if (P.use_ms && P.nq > 0) {   // the records of the queries the projection kernel built for itself, while the GPU works
+        const orbf_frontend::ResultSet& Rp = f->rs[f->cur];
+        if ((rc = orbm_queries_from_motion(Rp.kps.p, Rp.desc.p, Rp.depth.p, f->prev_cam_of.data(), P.nq, P.motion.du, P.motion.dv, P.motion.th,
+                                           f->scale_factors.data(), f->mbf, f->q_host.data(), Rp.unx.p, Rp.uny.p)))
+            return rc;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (attempt == 1 && (rc = step_enqueue(f, P, false))) return rc;
         const auto t0 = std::chrono::steady_clock::now();
@@ -923,7 +961,7 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     f->prev_cam_of.resize(n);
     for (int c = 0, g = 0; c < f->n_cams; ++c)
         for (int k = 0; k < f->counts[c]; ++k) f->prev_cam_of[g++] = c;
-    out->n_queries = nq; out->queries = reinterpret_cast<const orbm_query*>(f->h_queries.p);
+    out->n_queries = nq; out->queries = P.use_ms ? f->q_host.data() : reinterpret_cast<const orbm_query*>(f->h_queries.p);
     out->n_cams = f->n_cams; out->n_total = n; out->counts = f->counts.data();
     out->kps = R.kps.p; out->desc = R.desc.p; out->uright = R.ur.p; out->depth = R.depth.p;
     out->un_x = R.unx.p; out->un_y = R.uny.p;

@@ -115,6 +115,17 @@ struct orbm_frame {
     }
 };
 
+// Queries of the motion stream built where they are used (orbf_step_motion): query i is feature i of the PREVIOUS step's frame,
+// still in HBM, moved by (du, dv) -- the arithmetic of orbm_queries_from_motion (matcher.hip), operation for operation, so the
+// host never writes a query record on the step's critical path (136 KB through the BAR per 2 x 1000-feature step before).
+struct MotionSrc {
+    const float* x; const float* y; const float* depth; const float* angle;   // the previous frame's arrays (global feature order)
+    const int* octave; const uint4* desc; const int* cam_start; int n_cams;
+    const float* scale;    // scale factor per pyramid level (device)
+    float du, dv, th, mbf;
+    orbm_query* rec_out;   // non-NULL: {blocks, angle} of every query into these records (the multi-workgroup resolve reads them)
+};
+
 // k_project + k_resolve on the device, one D2H of {status, matches}; falls back to host_resolve when the sweep limit is
 // hit, retries with a larger capacity when a candidate list overflowed.  Split in two so that a caller can enqueue
 // other work on the stream between the launch and the one synchronisation (orbf_step).
@@ -129,6 +140,7 @@ struct SearchJob {
     const orbm_window* win2_dev = nullptr;  // second windows of the queries (device memory), or NULL
     const struct SideJob* side = nullptr;   // work that shares the projection kernel's launch (consumed by search_enqueue)
     bool multi = false;                 // the resolve in flight is the multi-workgroup form (one launch per sweep)
+    const MotionSrc* msrc = nullptr;    // queries built by the projection kernel itself (then `q` is only read by the host fallbacks)
 };
 
 // Work of an isolated orbf_step that rides in the projection kernel's launch instead of on a stream of its own (a fork onto a

@@ -12,6 +12,7 @@ struct ProjectArgs {
     int* cand_idx; uint16_t* cand_dist; int* cand_count;
     const uint8_t* occupied; int* topk; int short_th;
     const float* inv_sigma2; int2* qmeta; const orbm_window* win2;
+    int from_motion = 0; MotionSrc ms;   // from_motion != 0: `q` is unused, the queries come from `ms`
 };
 
 // One wave per query.  The window's grid cells are enumerated ix (outer) / iy (inner) -- the reference's visiting
@@ -32,12 +33,32 @@ __device__ __forceinline__ void project_wave(const ProjectArgs& A, const int qi,
     const uint8_t* __restrict__ occupied = A.occupied; int* __restrict__ topk = A.topk; const int short_th = A.short_th;
     const float* __restrict__ inv_sigma2 = A.inv_sigma2; int2* __restrict__ qmeta = A.qmeta; const orbm_window* __restrict__ win2 = A.win2;
 
-    const orbm_query* Q = q + qi;
-    float x = Q->u, y = Q->v, r = Q->radius;
-    const float ur = Q->ur;
-    int minLevel = Q->min_level, maxLevel = Q->max_level, cam = Q->cam;
-    const uint32_t* qd = reinterpret_cast<const uint32_t*>(Q->desc);
-    const uint4 q0 = make_uint4(qd[0], qd[1], qd[2], qd[3]), q1 = make_uint4(qd[4], qd[5], qd[6], qd[7]);
+    float x, y, r, ur, q_angle;
+    int minLevel, maxLevel, cam, q_cam, q_blocks;
+    uint4 q0, q1;
+    if (A.from_motion) {
+        const MotionSrc& M = A.ms;
+        const int oct = M.octave[qi];
+        const float dep = M.depth[qi];
+        q0 = M.desc[2 * qi]; q1 = M.desc[2 * qi + 1];
+        q_angle = M.angle[qi];
+        x = M.x[qi] + M.du; y = M.y[qi] + M.dv;
+        r = M.scale[oct] * M.th;
+        const float inv = dep > 0 ? 1.0f / dep : 0.0f;
+        ur = x - M.mbf * inv;
+        minLevel = oct - 1; maxLevel = oct + 1;
+        cam = 0;
+        for (int c = 1; c < M.n_cams; ++c) cam += (M.cam_start[c] <= qi) ? 1 : 0;
+        q_blocks = 1;
+    } else {
+        const orbm_query* Q = q + qi;
+        x = Q->u; y = Q->v; r = Q->radius; ur = Q->ur;
+        minLevel = Q->min_level; maxLevel = Q->max_level; cam = Q->cam;
+        const uint32_t* qd = reinterpret_cast<const uint32_t*>(Q->desc);
+        q0 = make_uint4(qd[0], qd[1], qd[2], qd[3]); q1 = make_uint4(qd[4], qd[5], qd[6], qd[7]);
+        q_blocks = Q->blocks; q_angle = Q->angle;
+    }
+    q_cam = cam;
 
     int total = 0;
     int n_elig = 0;                    // survivors that could ever be accepted: not occupied and distance <= short_th
@@ -159,7 +180,8 @@ __device__ __forceinline__ void project_wave(const ProjectArgs& A, const int qi,
         cand_count[qi] = total;
         // what the resolve needs of a query besides its candidates: it never reads the query records themselves, which may
         // therefore live in pinned host memory (read once, here)
-        if (qmeta) qmeta[qi] = make_int2((Q->blocks ? 1 : 0) | (Q->cam << 1), __float_as_int(Q->angle));   // {blocks | camera << 1, angle}
+        if (qmeta) qmeta[qi] = make_int2((q_blocks ? 1 : 0) | (q_cam << 1), __float_as_int(q_angle));   // {blocks | camera << 1, angle}
+        if (A.from_motion && A.ms.rec_out) { A.ms.rec_out[qi].blocks = q_blocks; A.ms.rec_out[qi].angle = q_angle; }
         if (topk) {
 #pragma unroll
             for (int k = 0; k < RESOLVE_K; ++k) {

@@ -987,7 +987,8 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
                        int with_dist, bool upload_queries, bool to_host, int transposed = 0,
                        const uint8_t* d_occupied = nullptr, int* d_topk = nullptr, int short_th = 256,
                        const float* d_inv_sigma2 = nullptr, const orbm_query* q_device_visible = nullptr, int2* d_qmeta = nullptr,
-                       const orbm_window* d_win2 = nullptr, const SideJob* side = nullptr) {
+                       const orbm_window* d_win2 = nullptr, const SideJob* side = nullptr, const MotionSrc* msrc = nullptr,
+                       bool msrc_records = false) {
     int rc;
     if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_i0.reserve((size_t)nq * cap)) ||
         (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)))
@@ -999,6 +1000,10 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
     A.gate_right = gate_right; A.with_dist = with_dist; A.transposed = transposed;
     A.cand_idx = m->d_i0.p; A.cand_dist = m->d_u16.p; A.cand_count = m->d_i1.p;
     A.occupied = d_occupied; A.topk = d_topk; A.short_th = short_th; A.inv_sigma2 = d_inv_sigma2; A.qmeta = d_qmeta; A.win2 = d_win2;
+    if (msrc) {   // the kernel builds its queries from the previous frame's arrays (MotionSrc, matcher_internal.h)
+        A.from_motion = 1; A.ms = *msrc; A.q = nullptr;
+        A.ms.rec_out = msrc_records ? (orbm_query*)m->d_queries.p : nullptr;
+    }
     if (side) {   // the caller's side work (camera-pair top-2, result mirror) shares the launch: see k_project_side
         if ((rc = launch_project_side(m->stream, A, *side))) return rc;
     } else {
@@ -1209,12 +1214,12 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
     // queries in mapped pinned memory are read in place by k_project (one 68-byte record per wave); only the multi-workgroup
     // resolve, whose kernels read the records themselves, still wants them in HBM
     const orbm_query* q_in_place = (J.q_dev && !multi) ? J.q_dev : nullptr;
-    if (J.q_dev && multi) {
+    if (J.q_dev && multi && !J.msrc) {
         if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, J.q_dev, (size_t)nq * sizeof(orbm_query), hipMemcpyDefault, m->stream));
     }
-    if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device && !J.q_dev, false, /*transposed=*/1, d_occ, m->d_claim.p,
-                          J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p, J.win2_dev, J.side)))
+    if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device && !J.q_dev && !J.msrc, false, /*transposed=*/1, d_occ,
+                          m->d_claim.p, J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p, J.win2_dev, J.side, J.msrc, multi)))
         return rc;
     J.side = nullptr;   // (a retry of the search with more room per query does not repeat the side work)
     if (multi) {
