@@ -139,8 +139,10 @@ int orbf_exchange_shutdown(orbf_frontend* f);       /* back to rank-local steps 
 
 int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out);
 /* Synthetic-stream driver: like orbf_step, with the queries built natively from the PREVIOUS step's features moved by a
- * constant image-plane motion (orbm_queries_from_motion on the handle's own pinned result buffers; no queries on the
- * first step or after orbf_reset).  out->n_queries / out->queries expose what was searched. */
+ * constant image-plane motion (the arithmetic of orbm_queries_from_motion; no queries on the first step or after orbf_reset).
+ * The projection kernel builds them itself from the previous step's frame, which is still in HBM: nothing is written or copied
+ * for them on the step's critical path.  out->n_queries / out->queries expose what was searched (the same records, written by
+ * the host with orbm_queries_from_motion while it waits for the step's results). */
 typedef struct orbf_motion { float du, dv, th; } orbf_motion;
 int orbf_step_motion(orbf_frontend* f, const orbf_image* images, const orbf_motion* motion, int flags, orbf_result* out);
 /* The three calls of a host that drives a stream, as one (a binding then crosses the ABI once per timestep instead of three
