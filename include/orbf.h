@@ -31,7 +31,10 @@ typedef struct orbf_image {
     uint64_t generation;
 } orbf_image;
 
-enum { ORBF_SKIP_CROSS = 1 }; /* flags of orbf_step */
+enum { ORBF_SKIP_CROSS = 1,          /* flags of orbf_step: no cross-camera top-2 in this step */
+       ORBF_NO_QUERY_RECORDS = 2 };  /* orbf_step_motion*: orbf_result::queries stays NULL -- the queries of a motion step only exist
+                                      * inside the projection kernel; without this flag the host writes the same records for the
+                                      * caller (orbm_queries_from_motion, ~3 ns per byte: 6 us for 2000 queries) while it waits */
 
 typedef struct orbf_result { /* all pointers: pinned host memory owned by the handle, valid until the next step */
     int32_t n_cams, n_total;
@@ -47,7 +50,7 @@ typedef struct orbf_result { /* all pointers: pinned host memory owned by the ha
     const int32_t* cross_second_dist;
     float gpu_wait_us;                /* host time spent blocked in the final synchronisation                   */
     int32_t n_queries;                /* queries searched this step                                             */
-    const orbm_query* queries;        /* [n_queries] (pinned copy)                                              */
+    const orbm_query* queries;        /* [n_queries] host copy of what was searched (NULL with ORBF_NO_QUERY_RECORDS) */
     const float* un_x;                /* [n_total] undistorted positions (mvKeysUn_total[i].pt): the keypoint positions     */
     const float* un_y;                /*   themselves unless a calibration with k1 != 0 is set                            */
     float host_us[4];                 /* host timeline of the call: query preparation, enqueue of the whole step,

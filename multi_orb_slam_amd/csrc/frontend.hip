@@ -58,7 +58,8 @@ struct orbf_frontend {
     int pframe_W[NSETS] = {}, pframe_H[NSETS] = {};
     // extractions in flight for the NEXT steps (enqueued by earlier orbf_step calls after orbf_prefetch), oldest first
     // fp: content fingerprints of the HOST images taken when their upload was enqueued (see image_fingerprint)
-    struct InFlight { std::vector<orbf_image> images; std::vector<uint64_t> fp; int set = 0, W = 0, H = 0, e = 0; };
+    // done: the run's completion event was seen signalled (asked while an earlier step waited for its results: off the critical path)
+    struct InFlight { std::vector<orbf_image> images; std::vector<uint64_t> fp; int set = 0, W = 0, H = 0, e = 0; bool done = false; };
     std::deque<InFlight> inflight;
     std::deque<std::vector<orbf_image>> announced;  // declared by orbf_prefetch, not enqueued yet (at most 2)
     int last_e = 0;  // extractor most recently handed a timestep
@@ -397,7 +398,7 @@ int orbf_run_stream(orbf_frontend* f, const orbf_image* ring, int ring_len, int 
             if (rc) return rc;
             *announced_upto = a;
         }
-        int rc = orbf_step_motion(f, images_of(t), motion, 0, &r);
+        int rc = orbf_step_motion(f, images_of(t), motion, ORBF_NO_QUERY_RECORDS, &r);   // (the loop never reads orbf_result::queries)
         if (rc) return rc;
         if (*announced_upto < t) *announced_upto = t;
         const int nx = r.cross_best_dist ? orbm_count_ratio_accepted(r.cross_best_dist, r.cross_second_dist, r.n_total, th_low, ratio) : 0;
@@ -641,6 +642,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         same_content(f->inflight.front().fp, images, f->n_cams)) {
         const orbf_frontend::InFlight& I = f->inflight.front();
         P.set = I.set; P.e = I.e; P.W = I.W; P.H = I.H; went_async = 1;
+        P.ext_done = I.done;
         f->inflight.pop_front();
     } else {
         if (!f->inflight.empty()) {  // prefetched for other images: everything in flight is dropped
@@ -708,10 +710,10 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     // The export block of this step is final already when its extraction chain has completed cleanly (the usual case with
     // steps announced ahead): then nothing of this step can be redone and a caller may ship the block right away.
     P.block_ready = false;
-    if (P.async_path && !P.inline_match && hipEventQuery(f->ev_ready[P.set]) == hipSuccess) {
+    if (P.async_path && !P.inline_match && (P.ext_done || hipEventQuery(f->ev_ready[P.set]) == hipSuccess)) {
         P.ext_done = true;   // (the matcher's stream then needs no event wait in front of the search: step_enqueue)
         P.block_ready = orbx_peek_status(f->exs[P.e]) == 0;
-    } else (void)hipGetLastError();
+    } else { P.ext_done = false; (void)hipGetLastError(); }
     if ((rc = step_enqueue(f, P, true))) return rc;
     P.active = true;
     if (block_ready) *block_ready = P.block_ready ? 1 : 0;
@@ -889,11 +891,26 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     orbf_frontend::ResultSet& R = f->rs[P.set];
     int rc, nmatches = 0;
     auto t_synced = P.t_impl;
-    if (P.use_ms && P.nq > 0) {   // the records of the queries the projection kernel built for itself, while the GPU works
-        const orbf_frontend::ResultSet& Rp = f->rs[f->cur];
-        if ((rc = orbm_queries_from_motion(Rp.kps.p, Rp.desc.p, Rp.depth.p, f->prev_cam_of.data(), P.nq, P.motion.du, P.motion.dv, P.motion.th,
-                                           f->scale_factors.data(), f->mbf, f->q_host.data(), Rp.unx.p, Rp.uny.p)))
-            return rc;
+    // the records of the queries the projection kernel built for itself: written while the GPU works, or (ORBF_NO_QUERY_RECORDS) only if
+    // a host fallback of the search asks for them
+    struct FillQ {
+        static void run(void* ctx) {
+            orbf_frontend* f = static_cast<orbf_frontend*>(ctx);
+            const orbf_frontend::Pending& P = f->pending;
+            const orbf_frontend::ResultSet& Rp = f->rs[f->cur];   // (f->cur / prev_cam_of still describe the previous step here)
+            (void)orbm_queries_from_motion(Rp.kps.p, Rp.desc.p, Rp.depth.p, f->prev_cam_of.data(), P.nq, P.motion.du, P.motion.dv, P.motion.th,
+                                           f->scale_factors.data(), f->mbf, f->q_host.data(), Rp.unx.p, Rp.uny.p);
+        }
+    };
+    bool have_records = !P.use_ms;
+    if (P.use_ms && P.nq > 0) {
+        if (P.flags & ORBF_NO_QUERY_RECORDS) { P.J.q_fill = &FillQ::run; P.J.q_fill_ctx = f; }
+        else { FillQ::run(f); have_records = true; }
+    }
+    // has the NEXT step's extraction completed?  Asked now, while this step's matching runs, so that the next orbf_step_begin need not
+    if (!f->inflight.empty() && !f->inflight.front().done) {
+        if (hipEventQuery(f->ev_ready[f->inflight.front().set]) == hipSuccess) f->inflight.front().done = true;
+        else (void)hipGetLastError();
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (attempt == 1 && (rc = step_enqueue(f, P, false))) return rc;
@@ -961,7 +978,9 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     f->prev_cam_of.resize(n);
     for (int c = 0, g = 0; c < f->n_cams; ++c)
         for (int k = 0; k < f->counts[c]; ++k) f->prev_cam_of[g++] = c;
-    out->n_queries = nq; out->queries = P.use_ms ? f->q_host.data() : reinterpret_cast<const orbm_query*>(f->h_queries.p);
+    out->n_queries = nq;
+    if (P.use_ms && (P.flags & ORBF_NO_QUERY_RECORDS)) have_records = P.J.q_fill == nullptr;   // (a host fallback may have written them)
+    out->queries = !P.use_ms ? reinterpret_cast<const orbm_query*>(f->h_queries.p) : (have_records && nq > 0 ? f->q_host.data() : nullptr);
     out->n_cams = f->n_cams; out->n_total = n; out->counts = f->counts.data();
     out->kps = R.kps.p; out->desc = R.desc.p; out->uright = R.ur.p; out->depth = R.depth.p;
     out->un_x = R.unx.p; out->un_y = R.uny.p;

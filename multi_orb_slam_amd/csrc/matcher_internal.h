@@ -141,6 +141,7 @@ struct SearchJob {
     const struct SideJob* side = nullptr;   // work that shares the projection kernel's launch (consumed by search_enqueue)
     bool multi = false;                 // the resolve in flight is the multi-workgroup form (one launch per sweep)
     const MotionSrc* msrc = nullptr;    // queries built by the projection kernel itself (then `q` is only read by the host fallbacks)
+    void (*q_fill)(void*) = nullptr; void* q_fill_ctx = nullptr;   // ... which call this first when `q` has not been written yet
 };
 
 // Work of an isolated orbf_step that rides in the projection kernel's launch instead of on a stream of its own (a fork onto a

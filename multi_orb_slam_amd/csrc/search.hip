@@ -1305,8 +1305,11 @@ int morb::search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_feature
     if (!J.device_path) {
         m->last_status[0] = -1; m->last_status[1] = 0; m->last_status[2] = 0; m->last_status[3] = 0;  // (host path)
     }
-    if (!J.device_path)
+    auto need_q = [&] { if (J.q_fill) { J.q_fill(J.q_fill_ctx); J.q_fill = nullptr; } };   // (host records of a motion step, on demand)
+    if (!J.device_path) {
+        need_q();
         return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, 64, match_of_feature, nmatches, J.win2_dev);
+    }
     // Result words of a tagged launch are taken as they arrive (the caller may not have synchronised the stream): wait for
     // the word to carry this launch's sequence number, then strip it.  After ~10 ms without progress the stream is
     // synchronised for good (which also covers a launch that failed).
@@ -1338,6 +1341,7 @@ int morb::search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_feature
             continue;
         }
         // not converged within the sweep limit: exact host fallback
+        need_q();
         return host_resolve(m, J.cur, J.q, J.nq, J.occupied, J.points, J.nnratio, J.th_high, J.check_ori, J.cap, match_of_feature, nmatches, J.win2_dev);
     }
     if (J.seq) {

@@ -5,6 +5,7 @@ from . import _lib
 from ._lib import KP_DTYPE, QUERY_DTYPE, FImage, FMotion, FResult, Params, check, ptr
 
 SKIP_CROSS = 1
+NO_QUERY_RECORDS = 2      # orbf_step_motion*: do not materialise orbf_result::queries on the host (orbf.h)
 
 
 def _view(addr, dtype, count, shape=None):

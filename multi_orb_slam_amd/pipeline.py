@@ -144,7 +144,7 @@ class FrontEnd:
 
     def step(self, images, resident=False, next_images=None):
         """next_images: shorthand for announce(next_images) before the step."""
-        from .frontend import SKIP_CROSS
+        from .frontend import SKIP_CROSS, NO_QUERY_RECORDS
         native = getattr(self, "native_exchange", False)
         distributed = self.world > 1 and self.gather is not None and not native
         if not distributed and not native:
@@ -157,7 +157,9 @@ class FrontEnd:
                 images = [(im[0], self.width, self.height, im[1], od, im[2] if len(im) > 2 else 0) for im in images]
                 if next_images is not None:
                     next_images = [(im[0], self.width, self.height, im[1], od, im[2] if len(im) > 2 else 0) for im in next_images]
-            r = self.fe.step_ahead(images, next_images, (MOTION[0], MOTION[1], TH_PROJ), TH_LOW, BOW_RATIO, copy=self.copy_results)
+            # (the binding never hands out the query records: they stay on the device)
+            r = self.fe.step_ahead(images, next_images, (MOTION[0], MOTION[1], TH_PROJ), TH_LOW, BOW_RATIO, flags=NO_QUERY_RECORDS,
+                                   copy=self.copy_results)
             if r["n_cross"] is None and "cross" in r:
                 bi, bd, sd = r["cross"]
                 bd = np.ascontiguousarray(bd, np.int32); sd = np.ascontiguousarray(sd, np.int32)

@@ -592,3 +592,55 @@ def test_fewer_extractor_instances_take_fewer_steps_ahead(handles, monkeypatch):
     with pytest.raises(OrbError):
         fe2.announce(frames[handles + 2])
     fe.close(); fe2.close()
+
+
+@pytest.mark.parametrize("ahead", [0, 2])
+def test_motion_queries_built_on_the_device_are_the_hosts_records(ahead):
+    """orbf_step_motion lets the projection kernel build its queries from the previous frame in HBM.  The records the step hands back
+    (orbf_result::queries, written by the host while it waits) must be orbm_queries_from_motion of the previous step's results, and
+    with ORBF_NO_QUERY_RECORDS the pointer stays NULL while the matches stay the same.  (That the matches are the oracle's search over
+    exactly those records is what every oracle-pipeline test of this file checks: the oracle leg builds its queries with
+    make_queries.)"""
+    import ctypes as C
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from multi_orb_slam_amd.extractor import tables
+    from multi_orb_slam_amd.frontend import NativeFrontEnd, NO_QUERY_RECORDS
+    from multi_orb_slam_amd.matcher import QUERY_DTYPE
+    W, H, T = 640, 480, 6
+    params = [m.ExtractorParams(nfeatures=1000), m.ExtractorParams(nfeatures=600)]
+    frames = [[synth.image(c, t, W, H) for c in range(2)] for t in range(T)]
+    motion = (pipeline.MOTION[0], pipeline.MOTION[1], pipeline.TH_PROJ)
+    scale = np.asarray(tables(params[0])["scale"], np.float32)
+    runs = {}
+    for flags in (0, NO_QUERY_RECORDS):
+        fe = NativeFrontEnd(params, W, H)
+        fe.configure(pipeline.MBF, 100, True)
+        out = []
+        announced = 0
+        for t in range(T):
+            while announced < min(t + ahead, T - 1):
+                announced += 1
+                fe.prefetch(frames[announced])
+            r = fe.step(frames[t], flags=flags, motion=motion)
+            qp = fe._res.queries
+            recs = None
+            if qp:
+                nb = r["n_queries"] * QUERY_DTYPE.itemsize
+                recs = np.ctypeslib.as_array(C.cast(qp, C.POINTER(C.c_uint8)), shape=(nb,)).view(QUERY_DTYPE).copy()
+            out.append((r, recs))
+        runs[flags] = out
+        fe.close()
+    for t in range(T):
+        r0, q0 = runs[0][t]; r1, q1 = runs[NO_QUERY_RECORDS][t]
+        assert q1 is None
+        assert np.array_equal(r0["match_of_feature"], r1["match_of_feature"]) and r0["n_temporal"] == r1["n_temporal"]
+        if t == 0:
+            assert r0["n_queries"] == 0
+            continue
+        prev = runs[0][t - 1][0]
+        cam_of = np.repeat(np.arange(2, dtype=np.int32), prev["counts"])
+        expq = pipeline.make_queries((prev["kps"], prev["desc"], prev["depth"], cam_of, prev["un_x"], prev["un_y"]), scale)
+        assert q0 is not None and len(q0) == len(expq) == len(prev["kps"])
+        assert q0.tobytes() == expq.tobytes()
+    assert runs[0][T - 1][0]["n_temporal"] > 300
