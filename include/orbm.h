@@ -75,6 +75,12 @@ int orbm_hamming_matrix_device(const uint8_t* d_q, int nq, const uint8_t* d_r, i
  * on = 1 / 0 selects the matrix-core / popcount kernels for the whole process, -1 restores the default (matrix cores unless
  * MORB_MATRIX_MFMA=0 / MORB_TOP2_MFMA=0 are set).  Returns the previous setting.  orbm_top2_scratch_bytes follows it. */
 int orbm_use_matrix_cores(int on);
+/* The matrix-core form of the top-2 searches (orbm_hamming_top2*, the camera-pair searches of orbm_cross_top2* / orbf_step) has two
+ * arithmetic forms of its own: FP4 (the default: descriptor bits as +-4 in E2M1 on gfx950's v_mfma_f32_32x32x64_f8f6f4, twice the
+ * int8 rate, the f32 result is the exact integer sort key) and int8 (v_mfma_i32_32x32x32_i8).  Same results bit for bit.
+ * on = 1 / 0 selects FP4 / int8 for the whole process, -1 restores the default (FP4 unless MORB_TOP2_FP4=0).  Returns the
+ * previous setting. */
+int orbm_use_fp4_top2(int on);
 
 /* -- projection-gated search ---------------------------------------------------------------------------- */
 typedef struct orbm_frame_desc { /* flat view of the Frame members the matcher reads (src/Frame.cc:191-288) */

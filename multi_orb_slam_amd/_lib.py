@@ -136,6 +136,7 @@ def lib():
     L.orbm_three_maxima.argtypes = [vp, i32, vp]; L.orbm_three_maxima.restype = None
     L.orbm_hamming_top2.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
     L.orbm_use_matrix_cores.argtypes = [i32]
+    L.orbm_use_fp4_top2.argtypes = [i32]
     L.orbm_top2_scratch_bytes.argtypes = [i32, i32]; L.orbm_top2_scratch_bytes.restype = C.c_size_t
     L.orbm_hamming_top2_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]

@@ -387,64 +387,149 @@ __device__ __forceinline__ mm_i32x4 mt_expand16(uint32_t bits) {  // 16 bits -> 
 __device__ __forceinline__ uint32_t mt_umed3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
 
 // Pieces shared by the two top-2 kernels.  Round 3: a tile's 64 references are two halves of 32 (a = 0, 1) with an accumulator
-// pair each; while the 16 MFMAs of one half run, the wave works through the 2 x 16 sort keys per lane of the half before --
+// pair each; while the MFMAs of one half run, the wave works through the 2 x 16 sort keys per lane of the half before --
 // in rounds 1-2 a wave issued all 32 MFMAs of a tile and only then started on its 128 keys, so the matrix pipe and the vector
 // ALU took turns (0.41 of the int8 peak at two waves per SIMD; the two accumulator sets of the pipelined form are live at
 // different times, the kernel needs 166 registers instead of 229 = three waves per SIMD, and 32 000 x 32 000 went 252 -> 199 us).
+//
+// Two forms of the arithmetic (Mt<FP4>), same tiling, same keys, same results:
+//   Mt<false>  int8: v_mfma_i32_32x32x32_i8, 8 instructions per 32 x 32 block of 256-bit dot products (above).
+//   Mt<true>   FP4 (round 3, the default): gfx950's v_mfma_f32_32x32x64_f8f6f4 takes 64 E2M1 values per lane pair and instruction at
+//              twice the int8 rate -- 4 instructions per block -- and half the LDS bytes per reference.  A bit becomes +-4 (reference:
+//              set = +4 = 0x6, clear = -4 = 0xE; query: the other way round), a product is -16 where the bits agree and +16 where
+//              they differ, the 256-bit dot product is 32 * distance - 4096, and with the accumulators preset to 4096 + row the f32
+//              result IS the key 32 * distance + row: an integer below 2^24, so exact, and positive, so its BIT PATTERN orders like
+//              the number -- the integer min / med3 chain works on it unchanged.  Which of a lane's 32 K-slots a bit lands in does not
+//              matter: both operands are expanded by the same function.  32 000 x 32 000: 196-212 -> 141-145 us in the same run
+//              (tools/experiments/top2_fp4.hip), bit-identical at every size tried.
 struct Top2Run { uint32_t kb[2], ks2[2]; int where[2]; };   // per query group g: best key, second key, (block << 5 | row) of the best
-constexpr uint32_t MT_KEY_NONE = 256u << 6;
+using mm_i32x8 = __attribute__((ext_vector_type(8))) int;
+using mm_f32x16 = __attribute__((ext_vector_type(16))) float;
 
-__device__ __forceinline__ void mt_mfma_half(mm_i32x16 (&acc)[2], const mm_i32x4* __restrict__ tile, int a, int lane,
-                                             const mm_i32x4 (&bq)[2][8], const mm_i32x16& cinit) {
+template <bool QUERY>
+__device__ __forceinline__ mm_i32x4 f4_expand32(uint32_t bits) {   // 32 descriptor bits -> 32 FP4 values (+-4): two bits pick one byte
+    constexpr uint32_t POOL = QUERY ? 0xEEE66E66u : 0x666EE6EEu;   // byte f = nibble(bit 1) << 4 | nibble(bit 0), f = the two bits
+    mm_i32x4 v;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const mm_i32x4 af = tile[(a * 8 + ks) * 64 + lane];
-        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bq[0][ks], ks ? acc[0] : cinit, 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bq[1][ks], ks ? acc[1] : cinit, 0, 0, 0);
+    for (int n = 0; n < 4; ++n) {
+        const uint32_t x = (bits >> (8 * n)) & 255u;
+        const uint32_t t = (x | (x << 12)) & 0x000F000Fu;   // low nibble at bit 0, high nibble at bit 16: the products below cannot overlap
+        const uint32_t y = (t * 0x41u) & 0x03030303u;       // the byte's four 2-bit fields, one per selector byte
+        v[n] = (int)__builtin_amdgcn_perm(0u, POOL, y);
+    }
+    return v;
+}
+
+template <bool FP4> struct Mt;
+template <> struct Mt<false> {
+    using Acc = mm_i32x16;
+    static constexpr int KS = 8;                        // matrix instructions per 32 x 32 block
+    static constexpr uint32_t KEY_NONE = 256u << 6;     // key = distance << 6 | row
+    static __device__ __forceinline__ void queries(mm_i32x4 (&bq)[KS], const uint32_t (&w)[8], int h) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bq[ks] = mm_expand16(h ? (w[ks] >> 16) : (w[ks] & 0xffffu));
+    }
+    static __device__ __forceinline__ void preset(Acc& c, int h) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = 8192 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    }
+    // this thread's part of a tile: reference row `lane` (half h, row c), words 2 wave and 2 wave + 1
+    static __device__ __forceinline__ void deposit(mm_i32x4* tile, int h, int wave, int c, uint2 w) {
+        mm_i32x4* base = tile + (h * 8 + wave * 2) * 64 + c;
+        base[0] = mt_expand16(w.x & 0xffffu);
+        base[32] = mt_expand16(w.x >> 16);
+        base[64] = mt_expand16(w.y & 0xffffu);
+        base[96] = mt_expand16(w.y >> 16);
+    }
+    static __device__ __forceinline__ Acc mfma(mm_i32x4 a, mm_i32x4 b, Acc c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ uint32_t key(const Acc& a, int e) { return (uint32_t)a[e]; }
+    static __device__ __forceinline__ void close_block(uint32_t& kb, int& where, uint32_t before, int blk) {
+        where = kb != before ? ((blk << 5) | (int)(kb & 31u)) : where;
+        kb &= ~63u;
+    }
+    static __device__ __forceinline__ uint32_t distance(uint32_t k) { return k >> 6; }
+};
+template <> struct Mt<true> {
+    using Acc = mm_f32x16;
+    static constexpr int KS = 4;
+    static constexpr uint32_t KEY_NONE = 0x46000000u;   // 8192.0f = 32 * 256: key = (float)(32 * distance + row), compared as bits
+    static __device__ __forceinline__ void queries(mm_i32x4 (&bq)[KS], const uint32_t (&w)[8], int h) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bq[ks] = f4_expand32<true>(h ? w[2 * ks + 1] : w[2 * ks]);
+    }
+    static __device__ __forceinline__ void preset(Acc& c, int h) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = (float)(4096 + (e & 3) + 8 * (e >> 2) + 4 * h);
+    }
+    static __device__ __forceinline__ void deposit(mm_i32x4* tile, int h, int wave, int c, uint2 w) {
+        mm_i32x4* base = tile + (h * 4 + wave) * 64 + c;   // instruction ks = wave of half h; lanes c / 32 + c take word 2 ks / 2 ks + 1
+        base[0] = f4_expand32<false>(w.x);
+        base[32] = f4_expand32<false>(w.y);
+    }
+    static __device__ __forceinline__ Acc mfma(mm_i32x4 a, mm_i32x4 b, Acc c) {
+        const mm_i32x8 a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0, 0, 0);   // cbsz = blgp = 4: FP4; no block scales
+    }
+    static __device__ __forceinline__ uint32_t key(const Acc& a, int e) { return __float_as_uint(a[e]); }
+    static __device__ __forceinline__ void close_block(uint32_t& kb, int& where, uint32_t before, int blk) {
+        const int ki = (int)__uint_as_float(kb);   // 32 * distance + row
+        where = kb != before ? ((blk << 5) | (ki & 31)) : where;
+        kb = __float_as_uint((float)(ki & ~31));
+    }
+    static __device__ __forceinline__ uint32_t distance(uint32_t k) { return (uint32_t)(int)__uint_as_float(k) >> 5; }
+};
+
+template <bool FP4>
+__device__ __forceinline__ void mt_mfma_half(typename Mt<FP4>::Acc (&acc)[2], const mm_i32x4* __restrict__ tile, int a, int lane,
+                                             const mm_i32x4 (&bq)[2][Mt<FP4>::KS], const typename Mt<FP4>::Acc& cinit) {
+#pragma unroll
+    for (int ks = 0; ks < Mt<FP4>::KS; ++ks) {
+        const mm_i32x4 af = tile[(a * Mt<FP4>::KS + ks) * 64 + lane];
+        acc[0] = Mt<FP4>::mfma(af, bq[0][ks], ks ? acc[0] : cinit);
+        acc[1] = Mt<FP4>::mfma(af, bq[1][ks], ks ? acc[1] : cinit);
     }
 }
 
 // the 16 keys of one 32 x 32 block per query group; out(g, e) = "this row does not count for the queries of group g"
-template <class OutFn>
-__device__ __forceinline__ void mt_keys(Top2Run& R, const mm_i32x16 (&acc)[2], int blk, OutFn out) {
+template <bool FP4, class OutFn>
+__device__ __forceinline__ void mt_keys(Top2Run& R, const typename Mt<FP4>::Acc (&acc)[2], int blk, OutFn out) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const uint32_t before = R.kb[g];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const uint32_t key = out(g, e) ? MT_KEY_NONE : (uint32_t)acc[g][e];
+            const uint32_t key = out(g, e) ? Mt<FP4>::KEY_NONE : Mt<FP4>::key(acc[g], e);
             R.ks2[g] = mt_umed3(R.kb[g], R.ks2[g], key);
             R.kb[g] = min(R.kb[g], key);
         }
-        R.where[g] = R.kb[g] != before ? ((blk << 5) | (int)(R.kb[g] & 31u)) : R.where[g];
-        R.kb[g] &= ~63u;
+        Mt<FP4>::close_block(R.kb[g], R.where[g], before, blk);
     }
 }
 struct MtAll { __device__ __forceinline__ bool operator()(int, int) const { return false; } };
 
+template <bool FP4>
 __global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_top2_mfma(const uint32_t* __restrict__ q, int nq,
                                                                     const uint32_t* __restrict__ r, int nr, int slice_len,
                                                                     int* __restrict__ p_idx, int* __restrict__ p_best,
                                                                     int* __restrict__ p_second) {
-    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];
+    using M = Mt<FP4>;
+    __shared__ mm_i32x4 s_tile[2][2 * M::KS * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.y * MM_Q_PER_BLOCK + wave * 64;
 
-    mm_i32x4 bq[2][8];
+    mm_i32x4 bq[2][M::KS];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int qi = min(q0 + g * 32 + c, nq - 1);
         const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
         const uint4 lo = p[0], hi = p[1];
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) bq[g][ks] = mm_expand16(h ? (w[ks] >> 16) : (w[ks] & 0xffffu));
+        M::queries(bq[g], w, h);
     }
-    mm_i32x16 cinit;  // D[m][n]: lane holds column n = lane & 31 (a query), rows m = (e & 3) + 8 (e >> 2) + 4 h (references)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) cinit[e] = 8192 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    typename M::Acc cinit;  // D[m][n]: lane holds column n = lane & 31 (a query), rows m = (e & 3) + 8 (e >> 2) + 4 h (references)
+    M::preset(cinit, h);
 
     const int s0 = blockIdx.x * slice_len, s1 = min(nr, s0 + slice_len);  // slice_len is a multiple of 64
     const int n_tiles = (s1 - s0 + MM_R_TILE - 1) / MM_R_TILE;
@@ -452,41 +537,35 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_top2_mfma(const uint3
         const int rr = min(s0 + min(t, n_tiles - 1) * MM_R_TILE + lane, nr - 1);  // rows past the end repeat the last one, masked below
         return *reinterpret_cast<const uint2*>(r + (size_t)rr * 8 + wave * 2);
     };
-    auto deposit = [&](int buf, uint2 w) {
-        mm_i32x4* base = &s_tile[buf][(h * 8 + wave * 2) * 64 + c];
-        base[0] = mt_expand16(w.x & 0xffffu);
-        base[32] = mt_expand16(w.x >> 16);
-        base[64] = mt_expand16(w.y & 0xffffu);
-        base[96] = mt_expand16(w.y >> 16);
-    };
+    auto deposit = [&](int buf, uint2 w) { M::deposit(s_tile[buf], h, wave, c, w); };
 
-    Top2Run R{{MT_KEY_NONE, MT_KEY_NONE}, {MT_KEY_NONE, MT_KEY_NONE}, {-1, -1}};
+    Top2Run R{{M::KEY_NONE, M::KEY_NONE}, {M::KEY_NONE, M::KEY_NONE}, {-1, -1}};
     deposit(0, fetch(0));
     uint2 nxt = fetch(1);
     __syncthreads();
-    mm_i32x16 acc0[2], acc1[2];
-    mt_mfma_half(acc0, s_tile[0], 0, lane, bq, cinit);
+    typename M::Acc acc0[2], acc1[2];
+    mt_mfma_half<FP4>(acc0, s_tile[0], 0, lane, bq, cinit);
     for (int t = 0; t + 1 < n_tiles; ++t) {   // every tile but the last one is full
         const int buf = t & 1;
-        mt_mfma_half(acc1, s_tile[buf], 1, lane, bq, cinit);       // second half of tile t on the matrix cores ...
-        mt_keys(R, acc0, 2 * t, MtAll());                          // ... the keys of its first half on the vector ALU
+        mt_mfma_half<FP4>(acc1, s_tile[buf], 1, lane, bq, cinit);       // second half of tile t on the matrix cores ...
+        mt_keys<FP4>(R, acc0, 2 * t, MtAll());                          // ... the keys of its first half on the vector ALU
         deposit(buf ^ 1, nxt);
         __syncthreads();
         nxt = fetch(t + 2);
-        mt_mfma_half(acc0, s_tile[buf ^ 1], 0, lane, bq, cinit);   // first half of tile t + 1 | keys of the second half of tile t
-        mt_keys(R, acc1, 2 * t + 1, MtAll());
+        mt_mfma_half<FP4>(acc0, s_tile[buf ^ 1], 0, lane, bq, cinit);   // first half of tile t + 1 | keys of the second half of tile t
+        mt_keys<FP4>(R, acc1, 2 * t + 1, MtAll());
     }
     {   // the last tile (its first half is in acc0): rows past the end of the slice do not count
         const int t = n_tiles - 1;
         const int valid = s1 - s0 - t * MM_R_TILE;
-        mt_mfma_half(acc1, s_tile[t & 1], 1, lane, bq, cinit);
-        mt_keys(R, acc0, 2 * t, [&](int, int e) { return (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
-        mt_keys(R, acc1, 2 * t + 1, [&](int, int e) { return 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
+        mt_mfma_half<FP4>(acc1, s_tile[t & 1], 1, lane, bq, cinit);
+        mt_keys<FP4>(R, acc0, 2 * t, [&](int, int e) { return (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
+        mt_keys<FP4>(R, acc1, 2 * t + 1, [&](int, int e) { return 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
     }
     // the two half-waves hold disjoint references of the same query: full keys distance << 16 | index decide
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const uint32_t mine_b = ((R.kb[g] >> 6) << 16) | (uint32_t)(R.where[g] & 0xffff), mine_s = (R.ks2[g] >> 6) << 16 | 0xffffu;
+        const uint32_t mine_b = (M::distance(R.kb[g]) << 16) | (uint32_t)(R.where[g] & 0xffff), mine_s = M::distance(R.ks2[g]) << 16 | 0xffffu;
         const uint32_t ob = (uint32_t)__shfl_xor((int)mine_b, 32), os = (uint32_t)__shfl_xor((int)mine_s, 32);
         const uint32_t nb = min(mine_b, ob), ns = min(max(mine_b, ob), min(mine_s, os));
         const int qrow = q0 + g * 32 + c;
@@ -617,10 +696,12 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_cross_top2(const uint4* __r
 // capacity (grid.y = cross_query_blocks(capacity, cameras)), slices beyond the references produce (256, 256, -1) partials and
 // query blocks beyond the queries return at once.  grid.x = reference slices (partials for k_top2_merge when > 1).
 // bx = reference slice, by = query block (camera-major)
-__device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * 8 * 64], const uint32_t* __restrict__ desc, int n_total,
+template <bool FP4>
+__device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * Mt<FP4>::KS * 64], const uint32_t* __restrict__ desc, int n_total,
                                                      const int* __restrict__ cam_start, int n_cams, int q_off, int nq, int slice_len,
                                                      int* __restrict__ p_idx, int* __restrict__ p_best, int* __restrict__ p_second,
                                                      const int* __restrict__ d_range, const int bx, const int by) {
+    using M = Mt<FP4>;
     if (d_range) { n_total = d_range[0]; q_off = d_range[1]; nq = d_range[2]; }
     // block `by` -> (camera, first query of the block, end of the camera's queries); the queries are the features [q_off, q_off + nq)
     int seg0 = 0, seg1 = 0, qb0 = 0, qb1 = -1;
@@ -638,19 +719,17 @@ __device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * 8
     const int q0 = qb0 + wave * 64;                 // first query of the wave (index in the descriptor list)
     const int own = seg1 - seg0, nr = n_total - own;   // nr references: the other cameras
 
-    mm_i32x4 bq[2][8];
+    mm_i32x4 bq[2][M::KS];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int qi = min(q0 + g * 32 + c, qb1 - 1);
         const uint4* p = reinterpret_cast<const uint4*>(desc + (size_t)qi * 8);
         const uint4 lo = p[0], hi = p[1];
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) bq[g][ks] = mm_expand16(h ? (w[ks] >> 16) : (w[ks] & 0xffffu));
+        M::queries(bq[g], w, h);
     }
-    mm_i32x16 cinit;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) cinit[e] = 8192 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    typename M::Acc cinit;
+    M::preset(cinit, h);
 
     const int s0 = bx * slice_len, s1 = min(nr, s0 + slice_len);  // slice_len is a multiple of 64
     const int n_tiles = s1 > s0 ? (s1 - s0 + MM_R_TILE - 1) / MM_R_TILE : 0;
@@ -659,42 +738,36 @@ __device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * 8
         const int rr = v < seg0 ? v : v + own;
         return *reinterpret_cast<const uint2*>(desc + (size_t)min(rr, n_total - 1) * 8 + wave * 2);
     };
-    auto deposit = [&](int buf, uint2 w) {
-        mm_i32x4* base = &s_tile[buf][(h * 8 + wave * 2) * 64 + c];
-        base[0] = mt_expand16(w.x & 0xffffu);
-        base[32] = mt_expand16(w.x >> 16);
-        base[64] = mt_expand16(w.y & 0xffffu);
-        base[96] = mt_expand16(w.y >> 16);
-    };
-    Top2Run R{{MT_KEY_NONE, MT_KEY_NONE}, {MT_KEY_NONE, MT_KEY_NONE}, {-1, -1}};
+    auto deposit = [&](int buf, uint2 w) { M::deposit(s_tile[buf], h, wave, c, w); };
+    Top2Run R{{M::KEY_NONE, M::KEY_NONE}, {M::KEY_NONE, M::KEY_NONE}, {-1, -1}};
     if (n_tiles > 0) {
         deposit(0, fetch(0));
         uint2 nxt = fetch(1);
         __syncthreads();
-        mm_i32x16 acc0[2], acc1[2];
-        mt_mfma_half(acc0, s_tile[0], 0, lane, bq, cinit);
+        typename M::Acc acc0[2], acc1[2];
+        mt_mfma_half<FP4>(acc0, s_tile[0], 0, lane, bq, cinit);
         for (int t = 0; t + 1 < n_tiles; ++t) {   // every tile but the last one is full
             const int buf = t & 1;
-            mt_mfma_half(acc1, s_tile[buf], 1, lane, bq, cinit);       // second half of tile t on the matrix cores ...
-            mt_keys(R, acc0, 2 * t, MtAll());                          // ... the keys of its first half on the vector ALU
+            mt_mfma_half<FP4>(acc1, s_tile[buf], 1, lane, bq, cinit);       // second half of tile t on the matrix cores ...
+            mt_keys<FP4>(R, acc0, 2 * t, MtAll());                          // ... the keys of its first half on the vector ALU
             deposit(buf ^ 1, nxt);
             __syncthreads();
             nxt = fetch(t + 2);
-            mt_mfma_half(acc0, s_tile[buf ^ 1], 0, lane, bq, cinit);   // first half of tile t + 1 | keys of the second half of tile t
-            mt_keys(R, acc1, 2 * t + 1, MtAll());
+            mt_mfma_half<FP4>(acc0, s_tile[buf ^ 1], 0, lane, bq, cinit);   // first half of tile t + 1 | keys of the second half of tile t
+            mt_keys<FP4>(R, acc1, 2 * t + 1, MtAll());
         }
         {   // the last tile (its first half is in acc0): rows past the end of the slice do not count
             const int t = n_tiles - 1;
             const int valid = s1 - s0 - t * MM_R_TILE;
-            mt_mfma_half(acc1, s_tile[t & 1], 1, lane, bq, cinit);
-            mt_keys(R, acc0, 2 * t, [&](int, int e) { return (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
-            mt_keys(R, acc1, 2 * t + 1, [&](int, int e) { return 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
+            mt_mfma_half<FP4>(acc1, s_tile[t & 1], 1, lane, bq, cinit);
+            mt_keys<FP4>(R, acc0, 2 * t, [&](int, int e) { return (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
+            mt_keys<FP4>(R, acc1, 2 * t + 1, [&](int, int e) { return 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= valid; });
         }
     }
     // the two half-waves hold disjoint references of the same query: full keys distance << 16 | index decide
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const uint32_t mine_b = ((R.kb[g] >> 6) << 16) | (uint32_t)(R.where[g] & 0xffff), mine_s = (R.ks2[g] >> 6) << 16 | 0xffffu;
+        const uint32_t mine_b = (M::distance(R.kb[g]) << 16) | (uint32_t)(R.where[g] & 0xffff), mine_s = M::distance(R.ks2[g]) << 16 | 0xffffu;
         const uint32_t ob = (uint32_t)__shfl_xor((int)mine_b, 32), os = (uint32_t)__shfl_xor((int)mine_s, 32);
         const uint32_t nb = min(mine_b, ob), ns = min(max(mine_b, ob), min(mine_s, os));
         const int qi = q0 + g * 32 + c;
@@ -711,12 +784,13 @@ __device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * 8
 // query blocks a launch over nq queries from n_cams cameras may need: every camera can end with a partly filled block
 __host__ __device__ inline int cross_query_blocks(int nq, int n_cams) { return (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK + n_cams; }
 
+template <bool FP4>
 __global__ __launch_bounds__(64 * MM_WAVES) void k_cross_top2_mfma(const uint32_t* __restrict__ desc, int n_total,
                                                                   const int* __restrict__ cam_start, int n_cams, int q_off, int nq,
                                                                   int slice_len, int* __restrict__ p_idx, int* __restrict__ p_best,
                                                                   int* __restrict__ p_second, const int* __restrict__ d_range) {
-    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];
-    cross_top2_mfma_body(s_tile, desc, n_total, cam_start, n_cams, q_off, nq, slice_len, p_idx, p_best, p_second, d_range,
+    __shared__ mm_i32x4 s_tile[2][2 * Mt<FP4>::KS * 64];
+    cross_top2_mfma_body<FP4>(s_tile, desc, n_total, cam_start, n_cams, q_off, nq, slice_len, p_idx, p_best, p_second, d_range,
                          (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -734,12 +808,13 @@ struct SideArgs {
     int with_mirror;
     morb::MirrorJob mirror;
 };
+template <bool FP4>
 __global__ __launch_bounds__(64 * MM_WAVES) void k_project_side(morb::ProjectArgs P, SideArgs X) {
-    __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];
+    __shared__ mm_i32x4 s_tile[2][2 * Mt<FP4>::KS * 64];
     const int b = blockIdx.x;
     if (b < X.n_cross) {
         const int by = b / X.S, bx = b - by * X.S;
-        cross_top2_mfma_body(s_tile, X.desc, X.n_total, X.cam_start, X.n_cams, 0, X.n_total, X.slice_len, X.p_idx, X.p_best,
+        cross_top2_mfma_body<FP4>(s_tile, X.desc, X.n_total, X.cam_start, X.n_cams, 0, X.n_total, X.slice_len, X.p_idx, X.p_best,
                              X.p_second, X.d_range, bx, by);
     } else if (b < X.n_cross + X.n_project) {
         const int qi = __builtin_amdgcn_readfirstlane((b - X.n_cross) * 4 + (int)(threadIdx.x >> 6));
@@ -755,6 +830,13 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_project_side(morb::ProjectArg
 // of 64 references and at most 65536 long: 16-bit indices in the keys) when both sides have at least a tile, else the
 // one-query-per-lane kernel.  S = number of reference slices (> 1 needs scratch for the partials).
 struct Top2Plan { bool mfma; int S; int slice_len; };
+// orbm_use_fp4_top2(0) / MORB_TOP2_FP4=0: the matrix-core top-2 kernels run their int8 form (A/B; same results)
+std::atomic<int> g_top2_fp4{-1};      // -1 = environment default
+static bool top2_fp4() {
+    static const bool env_on = [] { const char* e = getenv("MORB_TOP2_FP4"); return !(e && atoi(e) == 0); }();
+    const int forced = g_top2_fp4.load(std::memory_order_relaxed);
+    return forced < 0 ? env_on : forced != 0;
+}
 std::atomic<int> g_matrix_cores{-1};  // orbm_use_matrix_cores: -1 = environment default
 
 Top2Plan top2_plan(int nq, int nr, bool have_scratch = true, int wgs_per_cu = 3) {
@@ -802,8 +884,11 @@ int launch_top2(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, int32_t*
     const int S = plan.S;
     int* p = (int*)d_scratch;
     int *p_idx = S > 1 ? p : d_bi, *p_best = S > 1 ? p + (size_t)S * nq : d_bd, *p_second = S > 1 ? p + 2 * (size_t)S * nq : d_sd;
-    if (plan.mfma)
-        hipLaunchKernelGGL(k_hamming_top2_mfma, dim3(S, (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK), dim3(64 * MM_WAVES), 0, st,
+    if (plan.mfma && top2_fp4())
+        hipLaunchKernelGGL(k_hamming_top2_mfma<true>, dim3(S, (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK), dim3(64 * MM_WAVES), 0, st,
+                           (const uint32_t*)d_q, nq, (const uint32_t*)d_r, nr, plan.slice_len, p_idx, p_best, p_second);
+    else if (plan.mfma)
+        hipLaunchKernelGGL(k_hamming_top2_mfma<false>, dim3(S, (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK), dim3(64 * MM_WAVES), 0, st,
                            (const uint32_t*)d_q, nq, (const uint32_t*)d_r, nr, plan.slice_len, p_idx, p_best, p_second);
     else
         hipLaunchKernelGGL(k_hamming_top2, dim3((nq + 63) / 64, S), dim3(64 * TOP2_WAVES), 0, st, (const uint4*)d_q, nq,
@@ -892,8 +977,12 @@ int morb::cross_enqueue_to(hipStream_t st, const uint8_t* d_desc, int n, const i
     if (plan.mfma) {   // matrix-core form (default from one tile of work on; orbm_use_matrix_cores(0) / MORB_TOP2_MFMA=0: popcount form)
         int* p = (int*)scratch;
         int *p_idx = S > 1 ? p : o_idx, *p_best = S > 1 ? p + (size_t)S * nq : o_best, *p_second = S > 1 ? p + 2 * (size_t)S * nq : o_second;
-        hipLaunchKernelGGL(k_cross_top2_mfma, dim3(S, cross_query_blocks(nq, n_cams)), dim3(64 * MM_WAVES), 0, st,
-                           (const uint32_t*)d_desc, n, d_cam_start, n_cams, q_off, nq, plan.slice_len, p_idx, p_best, p_second, d_n);
+        if (top2_fp4())
+            hipLaunchKernelGGL(k_cross_top2_mfma<true>, dim3(S, cross_query_blocks(nq, n_cams)), dim3(64 * MM_WAVES), 0, st,
+                               (const uint32_t*)d_desc, n, d_cam_start, n_cams, q_off, nq, plan.slice_len, p_idx, p_best, p_second, d_n);
+        else
+            hipLaunchKernelGGL(k_cross_top2_mfma<false>, dim3(S, cross_query_blocks(nq, n_cams)), dim3(64 * MM_WAVES), 0, st,
+                               (const uint32_t*)d_desc, n, d_cam_start, n_cams, q_off, nq, plan.slice_len, p_idx, p_best, p_second, d_n);
         if (S > 1)
             hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, p_idx, p_best, p_second, S, nq, o_idx, o_best,
                                o_second, d_n);
@@ -959,7 +1048,8 @@ int morb::launch_project_side(hipStream_t st, const morb::ProjectArgs& P, const 
     X.with_mirror = J.with_mirror ? 1 : 0;
     if (J.with_mirror) X.mirror = J.mirror;
     const int n_mirror = J.with_mirror ? std::min(64, (J.mirror.n_host * 8 + 255) / 256) : 0;
-    hipLaunchKernelGGL(k_project_side, dim3(X.n_cross + X.n_project + n_mirror), dim3(64 * MM_WAVES), 0, st, P, X);
+    if (top2_fp4()) hipLaunchKernelGGL(k_project_side<true>, dim3(X.n_cross + X.n_project + n_mirror), dim3(64 * MM_WAVES), 0, st, P, X);
+    else hipLaunchKernelGGL(k_project_side<false>, dim3(X.n_cross + X.n_project + n_mirror), dim3(64 * MM_WAVES), 0, st, P, X);
     if (S > 1)
         hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, X.p_idx, X.p_best, X.p_second, S, nq, J.o_idx, J.o_best,
                            J.o_second, J.d_range);
@@ -968,6 +1058,7 @@ int morb::launch_project_side(hipStream_t st, const morb::ProjectArgs& P, const 
 }
 
 int orbm_use_matrix_cores(int on) { return g_matrix_cores.exchange(on < 0 ? -1 : (on ? 1 : 0)); }
+int orbm_use_fp4_top2(int on) { return g_top2_fp4.exchange(on < 0 ? -1 : (on ? 1 : 0)); }
 
 size_t orbm_top2_scratch_bytes(int nq, int nr) {
     if (nq <= 0 || nr <= 0) return 0;

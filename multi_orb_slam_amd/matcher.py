@@ -148,6 +148,12 @@ class Matcher:
         return int(_lib.lib().orbm_use_matrix_cores(int(on)))
 
     @staticmethod
+    def use_fp4_top2(on):
+        """orbm_use_fp4_top2: 1 / 0 = FP4 / int8 arithmetic in the matrix-core top-2 kernels, -1 = default; returns the previous
+        setting."""
+        return int(_lib.lib().orbm_use_fp4_top2(int(on)))
+
+    @staticmethod
     def hamming_matrix_device(d_q, nq, d_r, nr, d_out, stream):
         check(_lib.lib().orbm_hamming_matrix_device(C.c_void_p(d_q), nq, C.c_void_p(d_r), nr, C.c_void_p(d_out),
                                                     C.c_void_p(stream)))

@@ -87,11 +87,18 @@ def test_matrix_core_and_popcount_forms_agree(matcher):
         for on in (1, 0):
             m.Matcher.use_matrix_cores(on)
             out[on] = (matcher.hamming_matrix(q, r[:2048]),) + tuple(matcher.hamming_top2(q, r))
+        # the matrix-core top-2 once more with int8 instead of FP4 arithmetic (orbm_use_fp4_top2)
+        m.Matcher.use_matrix_cores(1)
+        assert m.Matcher.use_fp4_top2(0) == -1
+        out[2] = (out[1][0],) + tuple(matcher.hamming_top2(q, r))
     finally:
-        assert m.Matcher.use_matrix_cores(-1) == 0
-    for a, b in zip(out[0], out[1]):
-        assert np.array_equal(a, b)
+        assert m.Matcher.use_matrix_cores(-1) == 1
+        assert m.Matcher.use_fp4_top2(-1) == 0
+    for a, b, c in zip(out[0], out[1], out[2]):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
     assert np.array_equal(out[1][0], oracle.hamming_matrix(q, r[:2048]))
+    ebi, ebd, esd = oracle.bf_top2(q, r)
+    assert np.array_equal(out[1][1], ebi) and np.array_equal(out[1][2], ebd) and np.array_equal(out[1][3], esd)
 
 
 def test_matrix_properties_full_size(matcher):
@@ -401,15 +408,15 @@ def test_cross_top2_both_forms_equal_brute_force(counts):
         exp.append(oracle.bf_top2(descs[c], refs) if counts[c] else (np.zeros(0, np.int32),) * 3)
     ebi, ebd, esd = (np.concatenate([e[k] for e in exp]) for k in range(3))
     try:
-        for on in (1, 0):
-            m.Matcher.use_matrix_cores(on)
+        for on, fp4 in ((1, 1), (1, 0), (0, -1)):     # matrix cores with FP4 / int8 arithmetic (orbm_use_fp4_top2), xor + popcount
+            m.Matcher.use_matrix_cores(on); m.Matcher.use_fp4_top2(fp4)
             mt = m.Matcher()
             F = mt.frame(m.FrameData(**fr))
             bi, bd, sd = mt.cross_top2(F)
-            assert np.array_equal(bi, ebi) and np.array_equal(bd, ebd) and np.array_equal(sd, esd), "form %d" % on
+            assert np.array_equal(bi, ebi) and np.array_equal(bd, ebd) and np.array_equal(sd, esd), "form %d / %d" % (on, fp4)
             F.close(); mt.close()
     finally:
-        m.Matcher.use_matrix_cores(-1)
+        m.Matcher.use_matrix_cores(-1); m.Matcher.use_fp4_top2(-1)
     if len(counts) >= 2 and counts[0] >= 40 and counts[1] >= 40:
         assert ebd[31] == 0 and esd[31] == 0 and ebi[31] == 7           # camera-0 feature 31: first duplicate wins, second = 0
     assert n == len(ebi)
@@ -490,3 +497,25 @@ def test_relocalisation_and_loop_style_searches(matcher, th_high, check_ori):
     assert n == on and np.array_equal(mo, omo) and n > 100
     assert not np.any((mo >= 0) & (occ != 0))
     F.close()
+
+
+@pytest.mark.parametrize("nq,nr", [(64, 64), (65, 127), (256, 4033), (700, 3000), (1000, 191)])
+def test_fp4_top2_edge_distances(matcher, nq, nr):
+    """The FP4 form of the matrix-core top-2 turns a descriptor bit into +-4 (E2M1) and reads the f32 accumulator as the integer key
+    32 * distance + row: the extremes of that arithmetic -- distance 0 (identical rows), 256 (complements), all-zero and all-one
+    descriptors, ties between rows of one 32-row block and between blocks (the first index wins, the second best equals the best) --
+    against the oracle's brute force, at sizes with ragged last tiles."""
+    import multi_orb_slam_amd as m
+    r = synth.descriptors(nr, 5)
+    r[0] = 0; r[1] = 255; r[min(40, nr - 1)] = r[min(3, nr - 1)]; r[nr - 1] = r[2]      # duplicates inside a block and across blocks
+    q = synth.perturbed_queries(np.concatenate([r] * (nq // nr + 1))[:nq], 9, flip_p=0.1)
+    q[0] = 0; q[1] = 255; q[2] = ~r[5 % nr]; q[3] = r[2]; q[4] = r[3 % nr]
+    ebi, ebd, esd = oracle.bf_top2(q, r)
+    try:
+        for fp4 in (1, 0):
+            m.Matcher.use_fp4_top2(fp4)
+            bi, bd, sd = matcher.hamming_top2(q, r)
+            assert np.array_equal(bi, ebi) and np.array_equal(bd, ebd) and np.array_equal(sd, esd), fp4
+    finally:
+        m.Matcher.use_fp4_top2(-1)
+    assert ebd[0] == 0 and ebd[1] == 0 and ebd[3] == 0 and ebi[3] == 2 and esd[3] == 0
