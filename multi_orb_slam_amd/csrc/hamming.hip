@@ -406,17 +406,16 @@ struct Top2Run { uint32_t kb[2], ks2[2]; int where[2]; };   // per query group g
 using mm_i32x8 = __attribute__((ext_vector_type(8))) int;
 using mm_f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// 32 descriptor bits -> 32 FP4 values (+-4): two bits select one byte (two nibbles) of a four-byte pool with v_perm_b32.  Output dword j
+// takes the 2-bit fields j of the word's four bytes -- which K slot of the instruction a bit lands in is free as long as both operands
+// agree, so no bit has to be moved next to its neighbours: one shift, one mask, one permute per dword (11 instructions per word; the
+// expansion that kept the bits in order cost 24).
 template <bool QUERY>
-__device__ __forceinline__ mm_i32x4 f4_expand32(uint32_t bits) {   // 32 descriptor bits -> 32 FP4 values (+-4): two bits pick one byte
+__device__ __forceinline__ mm_i32x4 f4_expand32(uint32_t bits) {
     constexpr uint32_t POOL = QUERY ? 0xEEE66E66u : 0x666EE6EEu;   // byte f = nibble(bit 1) << 4 | nibble(bit 0), f = the two bits
     mm_i32x4 v;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const uint32_t x = (bits >> (8 * n)) & 255u;
-        const uint32_t t = (x | (x << 12)) & 0x000F000Fu;   // low nibble at bit 0, high nibble at bit 16: the products below cannot overlap
-        const uint32_t y = (t * 0x41u) & 0x03030303u;       // the byte's four 2-bit fields, one per selector byte
-        v[n] = (int)__builtin_amdgcn_perm(0u, POOL, y);
-    }
+    for (int j = 0; j < 4; ++j) v[j] = (int)__builtin_amdgcn_perm(0u, POOL, (bits >> (2 * j)) & 0x03030303u);
     return v;
 }
 

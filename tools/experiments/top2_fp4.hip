@@ -178,16 +178,12 @@ using mm_f32x16 = __attribute__((ext_vector_type(16))) float;
 // 32 descriptor bits -> 32 FP4 values (4 dwords): two bits select one byte of the pool {lo nibble = bit 0, hi nibble = bit 1}
 template <bool QUERY>
 __device__ __forceinline__ mm_i32x4 f4_expand32(uint32_t bits) {
-    // reference: set = +4 (0x6), clear = -4 (0xE); query: the other way round
+    // reference: set = +4 (0x6), clear = -4 (0xE); query: the other way round.  Output dword j holds the 2-bit fields j of the word's four
+    // bytes (which K slot a bit lands in is free as long as both operands agree): one shift, one mask, one byte permute per dword
     constexpr uint32_t POOL = QUERY ? 0xEEE66E66u : 0x666EE6EEu;   // byte f = nib(bit1) << 4 | nib(bit0) for f = bit1 bit0
     mm_i32x4 v;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const uint32_t x = (bits >> (8 * n)) & 255u;
-        const uint32_t t = (x | (x << 12)) & 0x000F000Fu;     // low nibble at bit 0, high nibble at bit 16: the products below do not overlap
-        const uint32_t y = (t * 0x41u) & 0x03030303u;         // the four 2-bit fields of the byte, one per output byte
-        v[n] = (int)__builtin_amdgcn_perm(0u, POOL, y);
-    }
+    for (int j = 0; j < 4; ++j) v[j] = (int)__builtin_amdgcn_perm(0u, POOL, (bits >> (2 * j)) & 0x03030303u);
     return v;
 }
 
@@ -198,7 +194,7 @@ __device__ __forceinline__ mm_f32x16 f4_mfma(mm_i32x4 a, mm_i32x4 b, mm_f32x16 c
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 127, 0, 127);
 }
 
-template <int SCALE_MODE>
+template <int SCALE_MODE, bool SKIP = false>
 __global__ __launch_bounds__(64 * MM_WAVES) void k_fp4(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ r, int nr,
                                                        int slice_len, int* __restrict__ p_idx, int* __restrict__ p_best,
                                                        int* __restrict__ p_second) {
@@ -245,6 +241,16 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_fp4(const uint32_t* __restric
     auto keys = [&](const mm_f32x16 (&acc)[2], int blk, int a, int valid) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
+            if (SKIP && valid >= 64) {
+                // does any key of this block beat some lane's second best?  (min3 tree over the 16 keys, one ballot): if not, nothing changes
+                uint32_t m0 = min(min(__float_as_uint(acc[g][0]), __float_as_uint(acc[g][1])), __float_as_uint(acc[g][2]));
+                uint32_t m1 = min(min(__float_as_uint(acc[g][3]), __float_as_uint(acc[g][4])), __float_as_uint(acc[g][5]));
+                uint32_t m2 = min(min(__float_as_uint(acc[g][6]), __float_as_uint(acc[g][7])), __float_as_uint(acc[g][8]));
+                uint32_t m3 = min(min(__float_as_uint(acc[g][9]), __float_as_uint(acc[g][10])), __float_as_uint(acc[g][11]));
+                uint32_t m4 = min(min(__float_as_uint(acc[g][12]), __float_as_uint(acc[g][13])), __float_as_uint(acc[g][14]));
+                m0 = min(min(m0, m1), m2); m3 = min(min(m3, m4), __float_as_uint(acc[g][15]));
+                if (__ballot(min(m0, m3) < ks2[g]) == 0) continue;
+            }
             const uint32_t before = kb[g];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -359,7 +365,11 @@ int main(int argc, char** argv) {
     CK(hipMemset(pi[1], 0, (size_t)s_eff * nq * 4));
     run(k_fp4<1>, "fp4 form, scale operands 127", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
     grab(1, b); diff();
+    CK(hipMemset(pi[1], 0, (size_t)s_eff * nq * 4));
+    run(k_fp4<0, true>, "fp4 form, blocks skipped", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
+    grab(1, b); diff();
     run(k_pipe<0>, "int8 form (again)", s_eff, qb, dq, nq, dr, nr, len, pi[0], pb[0], ps[0], iters);
     run(k_fp4<0>, "fp4 form (again)", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
+    run(k_fp4<0, true>, "fp4 form, blocks skipped (again)", s_eff, qb, dq, nq, dr, nr, len, pi[1], pb[1], ps[1], iters);
     return 0;
 }
