@@ -104,6 +104,84 @@ template <int F> __global__ __launch_bounds__(256) void k_fill_f(uint4* out, siz
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) st16<F>(out + i, make_uint4(1, 2, 3, (unsigned)i));
 }
 
+
+// a chip-wide moving front: workgroup j owns the column strip [CW j, CW j + CW) of the matrix for ALL rows and walks down the row bands of RB rows,
+// so at any moment the workgroups together write RB complete rows = one contiguous block (the rows of a row-major matrix are adjacent)
+template <int CW, int RB> __global__ __launch_bounds__(256) void k_front(uint16_t* out, int n) {
+    constexpr int SEG = CW * 2;            // bytes per row segment
+    constexpr int LPR = SEG / 16;          // lanes per row segment (16 B each)
+    constexpr int RPI = 256 / LPR;         // rows per workgroup-wide store instruction
+    const int c0 = blockIdx.x * CW;
+    if (c0 >= n) return;
+    const int t = threadIdx.x, r_in = t / LPR, cb = (t % LPR) * 8;
+    const bool col_ok = c0 + cb + 8 <= n;
+    for (int r0 = 0; r0 < n; r0 += RB) {
+#pragma unroll
+        for (int i = 0; i < RB / RPI; ++i) {
+            const int r = r0 + i * RPI + r_in;
+            if (r < n && col_ok) *reinterpret_cast<uint4*>(out + (size_t)r * n + c0 + cb) = make_uint4(r, c0, i, t);
+        }
+    }
+}
+
+
+// the same front with LONG row segments: workgroup (x, y) owns the column strip [CW x, CW x + CW) and every gridDim.y-th band of RB rows;
+// a wave instruction writes 64 lanes x 16 B = 1 KB of ONE row when CW = 512 (the flat fill's shape per instruction)
+template <int CW, int RB> __global__ __launch_bounds__(256) void k_front2(uint16_t* out, int n) {
+    constexpr int SEG = CW * 2, LPR = SEG / 16, RPI = 256 / LPR;
+    const int c0 = blockIdx.x * CW;
+    const int t = threadIdx.x, r_in = t / LPR, cb = (t % LPR) * 8;
+    const bool col_ok = c0 + cb + 8 <= n;
+    for (int r0 = blockIdx.y * RB; r0 < n; r0 += RB * gridDim.y) {
+#pragma unroll
+        for (int i = 0; i < RB / RPI; ++i) {
+            const int r = r0 + i * RPI + r_in;
+            if (r < n && col_ok) *reinterpret_cast<uint4*>(out + (size_t)r * n + c0 + cb) = make_uint4(r, c0, i, t);
+        }
+    }
+}
+
+
+// k_front2 with an explicit row pitch (elements) and a byte offset of the whole matrix: is it the ALIGNMENT of the row segments?
+template <int CW, int RB> __global__ __launch_bounds__(256) void k_front3(uint16_t* out, int n, int pitch) {
+    constexpr int SEG = CW * 2, LPR = SEG / 16, RPI = 256 / LPR;
+    const int c0 = blockIdx.x * CW;
+    const int t = threadIdx.x, r_in = t / LPR, cb = (t % LPR) * 8;
+    const bool col_ok = c0 + cb + 8 <= n;
+    for (int r0 = blockIdx.y * RB; r0 < n; r0 += RB * gridDim.y) {
+#pragma unroll
+        for (int i = 0; i < RB / RPI; ++i) {
+            const int r = r0 + i * RPI + r_in;
+            if (r < n && col_ok) *reinterpret_cast<uint4*>(out + (size_t)r * pitch + c0 + cb) = make_uint4(r, c0, i, t);
+        }
+    }
+}
+// the flat fill with every 4 KB chunk of a workgroup moved by `shift` bytes (a multiple of 16)
+__global__ __launch_bounds__(256) void k_fill_shift(uint4* out, size_t n16, int shift16) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i + shift16 < n16; i += (size_t)gridDim.x * blockDim.x) out[i + shift16] = make_uint4(1, 2, 3, (unsigned)i);
+}
+
+
+// aligned 4 KB blocks of the LINEAR array, written one per workgroup instruction (256 threads x 16 B), in the order a tile of
+// 32 query rows 8 apart x one aligned block per row would produce them: workgroup j, tile t -> rows r0 + 8 i (i < 32), block k of
+// each row.  n = 32000: a row holds 15.625 blocks, rows r and r + 8 have the same block alignment.
+__global__ __launch_bounds__(256) void k_blocks(uint4* out, int n, int total_tiles) {
+    const size_t row_bytes = (size_t)n * 2;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        // tiles: (row group g of 256 rows, residue q of 8, block k of 15 whole blocks per row)
+        const int k = tile % 15, q = (tile / 15) % 8, g = tile / 120;
+        const int r0 = g * 256 + q;
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+            const size_t row_start = (size_t)(r0 + 8 * i) * row_bytes;
+            const size_t first = (row_start + 4095) / 4096;              // first aligned block inside the row
+            const size_t b = first + k;
+            out[b * 256 + threadIdx.x] = make_uint4(tile, i, k, threadIdx.x);
+        }
+    }
+}
+// the same blocks in linear order (control: the flat fill restricted to the blocks k_blocks writes)
+
 static void timeit(const char* name, std::function<void()> launch, double bytes) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 250; ++i) launch();          // settle
@@ -117,8 +195,34 @@ static void timeit(const char* name, std::function<void()> launch, double bytes)
 int main() {
     const int n = 32000;
     const double bytes = 2.0 * n * n;
-    uint16_t* d; CK(hipMalloc(&d, (size_t)32768 * 32768 * 2));
+    uint16_t* d; CK(hipMalloc(&d, (size_t)34816 * 32768 * 2));
     timeit("hipMemsetAsync", [&] { CK(hipMemsetAsync(d, 1, (size_t)bytes, 0)); }, bytes);
+    timeit("front: 250 wg x 128 columns, bands of 64 rows", [&] { hipLaunchKernelGGL((k_front<128, 64>), dim3(250), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front: 250 wg x 128 columns, bands of 16 rows", [&] { hipLaunchKernelGGL((k_front<128, 16>), dim3(250), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front: 500 wg x 64 columns, bands of 64 rows", [&] { hipLaunchKernelGGL((k_front<64, 64>), dim3(500), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front: 125 wg x 256 columns, bands of 64 rows", [&] { hipLaunchKernelGGL((k_front<256, 64>), dim3(125), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front: 250 wg x 128 columns, bands of 128 rows", [&] { hipLaunchKernelGGL((k_front<128, 128>), dim3(250), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front: 250 wg x 128 columns, bands of 32 rows", [&] { hipLaunchKernelGGL((k_front<128, 32>), dim3(250), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front2: 63 x 4 wg, 512 columns (1 KB / row / wave), bands of 32", [&] { hipLaunchKernelGGL((k_front2<512, 32>), dim3(63, 4), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front2: 63 x 4 wg, 512 columns, bands of 64", [&] { hipLaunchKernelGGL((k_front2<512, 64>), dim3(63, 4), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front2: 63 x 8 wg, 512 columns, bands of 32", [&] { hipLaunchKernelGGL((k_front2<512, 32>), dim3(63, 8), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front2: 32 x 8 wg, 1024 columns (2 KB / row), bands of 32", [&] { hipLaunchKernelGGL((k_front2<1024, 32>), dim3(32, 8), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front2: 16 x 16 wg, 2048 columns (4 KB / row), bands of 32", [&] { hipLaunchKernelGGL((k_front2<2048, 32>), dim3(16, 16), dim3(256), 0, 0, d, n); }, bytes);
+    timeit("front2: 125 x 2 wg, 256 columns, bands of 32", [&] { hipLaunchKernelGGL((k_front2<256, 32>), dim3(125, 2), dim3(256), 0, 0, d, n); }, bytes);
+    for (int pitch : {32000, 32768, 33792, 34816, 32256, 32512})
+        timeit(("front3: 63 x 4 wg, 512 columns, pitch " + std::to_string(pitch)).c_str(), [&] { hipLaunchKernelGGL((k_front3<512, 32>), dim3(63, 4), dim3(256), 0, 0, d, n, pitch); }, bytes);
+    for (int pitch : {33792, 34816})
+        timeit(("front3: 250 x 1 wg, 128 columns, pitch " + std::to_string(pitch)).c_str(), [&] { hipLaunchKernelGGL((k_front3<128, 64>), dim3(250, 1), dim3(256), 0, 0, d, n, pitch); }, bytes);
+    {
+        const int tiles = 125 * 8 * 15;   // 32000 rows / 256 * 8 residues * 15 blocks
+        const double b2 = (double)tiles * 32 * 4096;
+        for (int g : {256, 512, 768, 1024})
+            timeit(("aligned 4 KB blocks, 32 rows 8 apart per tile, grid " + std::to_string(g)).c_str(), [&] { hipLaunchKernelGGL(k_blocks, dim3(g), dim3(256), 0, 0, (uint4*)d, n, tiles); }, b2);
+    }
+    for (int sh : {0, 16, 64, 160})
+        timeit(("flat fill, grid 256, shifted by " + std::to_string(sh * 16) + " B").c_str(), [&] { hipLaunchKernelGGL(k_fill_shift, dim3(256), dim3(256), 0, 0, (uint4*)d, (size_t)(bytes / 16), sh); }, bytes);
+    timeit("flat dwordx4 fill, grid 256", [&] { hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, (uint4*)d, (size_t)(bytes / 16)); }, bytes);
+    if (getenv("FRONT_ONLY")) return 0;
     for (int g : {1024, 2048, 4096, 8192})
         timeit(("flat dwordx4 fill, grid " + std::to_string(g)).c_str(), [&] { hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, 0, (uint4*)d, (size_t)(bytes / 16)); }, bytes);
     for (int ctb : {500, 125, 25, 5}) {
