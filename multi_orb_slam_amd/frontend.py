@@ -18,30 +18,45 @@ def _view(addr, dtype, count, shape=None):
 
 
 class _LazyStep(dict):
-    """Result of a step consumed in place (copy=False): the scalars are there, the per-feature arrays become numpy views of the
-    native pinned buffers when first asked for (building a dozen views costs more than the native call itself)."""
+    """Result of a step consumed in place (copy=False): a few scalars are there, everything else -- the per-feature arrays as numpy
+    views of the native pinned buffers, the per-camera counts, the host timings -- is built from the native result record when first
+    asked for (building a dozen views costs more than the native call itself).  The record and the buffers belong to the front end and
+    are reused by its next step: asking for something new after that step is an error, not a stale answer."""
+    _LAZY = ("counts", "rig_counts", "host_us", "cross_dist_ptrs", "kps", "desc", "uright", "depth", "un_x", "un_y", "match_of_feature", "cross")
 
-    def __init__(self, scalars, makers):
+    def __init__(self, scalars, fe, nq):
         super().__init__(scalars)
-        self._makers = makers
+        self._fe = fe; self._seq = fe._step_seq; self._nq = nq
 
     def __missing__(self, key):
-        mk = self._makers.get(key)
-        if mk is None:
+        if key not in self._LAZY:
             raise KeyError(key)
-        v = self[key] = mk()
+        if self._fe._step_seq != self._seq:
+            raise RuntimeError("step result consumed in place: %r was first asked for after the front end's next step" % key)
+        v = self._fe._lazy(key, self._nq)
+        if v is _ABSENT:
+            raise KeyError(key)
+        self[key] = v
         return v
 
     def __contains__(self, key):
-        return dict.__contains__(self, key) or key in self._makers
+        if dict.__contains__(self, key):
+            return True
+        if key == "cross":
+            return self._fe._step_seq == self._seq and bool(self._fe._res.cross_best_idx)
+        return key in self._LAZY
 
     def get(self, key, default=None):
         return self[key] if key in self else default
 
     def materialise(self):
-        for k in list(self._makers):
-            self[k]
+        for k in self._LAZY:
+            if k in self:
+                self[k]
         return self
+
+
+_ABSENT = object()
 
 
 class NativeFrontEnd:
@@ -67,6 +82,7 @@ class NativeFrontEnd:
         self._arr_type = FImage * self.n_cams
         self._ncross = C.c_int(0)
         self._views = {}
+        self._step_seq = 0
         self._img_cache = {}
         self._motion_cache = {}
         self.cap_total = sum(p.nfeatures + 4 * p.nlevels for p in self.params)
@@ -286,6 +302,38 @@ class NativeFrontEnd:
         r["n_cross"] = nc.value if nc.value >= 0 else None
         return r
 
+    def _lazy(self, key, nq):
+        """one field of the last step's native result record (for _LazyStep)"""
+        r = self._res; V = self._cached; n = r.n_total; cap = self.cap_total
+        if key == "counts":
+            return V("counts", r.counts, np.int32, self.n_cams).tolist()
+        if key == "rig_counts":
+            return V("rigc", r.rig_counts, np.int32, r.rig_cams).tolist() if r.rig_cams else None
+        if key == "host_us":
+            return tuple(r.host_us)
+        if key == "cross_dist_ptrs":
+            return (r.cross_best_dist, r.cross_second_dist) if r.cross_best_idx else None
+        if key == "kps":
+            return V("kps", r.kps, KP_DTYPE, cap)[:n]
+        if key == "desc":
+            return V("desc", r.desc, np.uint8, cap, 32)[:n]
+        if key == "uright":
+            return V("ur", r.uright, np.float32, cap)[:n]
+        if key == "depth":
+            return V("depth", r.depth, np.float32, cap)[:n]
+        if key == "un_x":
+            return V("unx", r.un_x, np.float32, cap)[:n]
+        if key == "un_y":
+            return V("uny", r.un_y, np.float32, cap)[:n]
+        if key == "match_of_feature":
+            return V("match", r.match_of_feature, np.int32, cap)[:n] if nq else np.zeros(0, np.int32)
+        if key == "cross":
+            if not r.cross_best_idx:
+                return _ABSENT
+            return (V("x0", r.cross_best_idx, np.int32, cap)[:n], V("x1", r.cross_best_dist, np.int32, cap)[:n],
+                    V("x2", r.cross_second_dist, np.int32, cap)[:n])
+        return _ABSENT
+
     def end(self, copy=True):
         """Second half of step() (orbf_step_end): one synchronisation, then the results."""
         check(_lib.lib().orbf_step_end(self._h, C.byref(self._res)))
@@ -298,19 +346,8 @@ class NativeFrontEnd:
         cap = self.cap_total
         V = self._cached
         if not copy:
-            scalars = dict(counts=V("counts", r.counts, np.int32, self.n_cams).tolist(), n_temporal=r.nmatches, gpu_wait_us=r.gpu_wait_us,
-                           rig_counts=V("rigc", r.rig_counts, np.int32, r.rig_cams).tolist() if r.rig_cams else None,
-                           host_us=tuple(r.host_us), n_queries=nq, n_total=n,
-                           cross_dist_ptrs=(r.cross_best_dist, r.cross_second_dist) if r.cross_best_idx else None)
-            kps, desc, ur, dep, unx, uny, mof = r.kps, r.desc, r.uright, r.depth, r.un_x, r.un_y, r.match_of_feature
-            x0, x1, x2 = r.cross_best_idx, r.cross_best_dist, r.cross_second_dist
-            makers = dict(kps=lambda: V("kps", kps, KP_DTYPE, cap)[:n], desc=lambda: V("desc", desc, np.uint8, cap, 32)[:n],
-                          uright=lambda: V("ur", ur, np.float32, cap)[:n], depth=lambda: V("depth", dep, np.float32, cap)[:n],
-                          un_x=lambda: V("unx", unx, np.float32, cap)[:n], un_y=lambda: V("uny", uny, np.float32, cap)[:n],
-                          match_of_feature=(lambda: V("match", mof, np.int32, cap)[:n]) if nq else (lambda: np.zeros(0, np.int32)))
-            if x0:
-                makers["cross"] = lambda: (V("x0", x0, np.int32, cap)[:n], V("x1", x1, np.int32, cap)[:n], V("x2", x2, np.int32, cap)[:n])
-            return _LazyStep(scalars, makers)
+            self._step_seq += 1
+            return _LazyStep({"n_temporal": r.nmatches, "gpu_wait_us": r.gpu_wait_us, "n_queries": nq, "n_total": n}, self, nq)
         cp = lambda a: a.copy()
         out = dict(counts=V("counts", r.counts, np.int32, self.n_cams).tolist(), kps=cp(V("kps", r.kps, KP_DTYPE, cap)[:n]),
                    desc=cp(V("desc", r.desc, np.uint8, cap, 32)[:n]), uright=cp(V("ur", r.uright, np.float32, cap)[:n]),

@@ -17,6 +17,7 @@ from ._lib import QUERY_DTYPE
 from .extractor import Extractor
 from .matcher import Matcher, TH_LOW
 from . import rt
+from .frontend import SKIP_CROSS, NO_QUERY_RECORDS
 
 MOTION = (3.0, 1.0)      # synthetic stream: frame t+1 = frame t translated by (3, 1) px
 TH_PROJ = 15.0           # TrackWithMotionModel search radius parameter (src/Tracking.cc:1267)
@@ -144,7 +145,6 @@ class FrontEnd:
 
     def step(self, images, resident=False, next_images=None):
         """next_images: shorthand for announce(next_images) before the step."""
-        from .frontend import SKIP_CROSS, NO_QUERY_RECORDS
         native = getattr(self, "native_exchange", False)
         distributed = self.world > 1 and self.gather is not None and not native
         if not distributed and not native:

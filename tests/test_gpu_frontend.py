@@ -302,6 +302,14 @@ def test_results_consumed_in_place_are_the_same_arrays():
         exp = ofe.step(imgs)
         assert got["n_cross"] >= 0
         assert_same_step(got.materialise(), exp)
+    # a field nobody asked for before the front end's next step is refused afterwards (its record and buffers have been reused);
+    # what was asked for in time stays readable
+    first = fe.step([synth.image(c, 3, 320, 240) for c in range(2)])
+    n_first = first["n_total"]; counts_first = first["counts"]
+    fe.step([synth.image(c, 4, 320, 240) for c in range(2)])
+    assert first["n_total"] == n_first and first["counts"] == counts_first
+    with pytest.raises(RuntimeError):
+        first["kps"]
     fe.close()
 
 

@@ -11,11 +11,13 @@ for t in range(8):
     for c in range(2):
         dev[t][c].upload(synth.image(c, t, W, H))
 fe.copy_results = False
-args = [[(dev[t][c].ptr, W) for c in range(2)] for t in range(8)]
-fe.announce(args[1], resident=True)
+AHEAD = 3
+args = [fe.prepare([(dev[t][c].ptr, W) for c in range(2)], True) for t in range(8)]   # (as bench.py: marshalled once)
+for k in range(1, AHEAD):
+    fe.announce(args[k], resident=True)
 def loop(n):
     for it in range(n):
-        fe.step(args[it % 8], resident=True, next_images=args[(it + 2) % 8])
+        fe.step(args[it % 8], resident=True, next_images=args[(it + AHEAD) % 8])
 loop(200)
 pr = cProfile.Profile(); pr.enable(); loop(3000); pr.disable()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(18); print(s.getvalue()[:4000])
