@@ -77,6 +77,7 @@ struct orbf_frontend {
         int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
         bool ext_done = false;     // the step's extraction + frame grid had completed when the step began (no event wait needed)
         bool use_ms = false; MotionSrc ms; orbf_motion motion;   // queries built by the projection kernel (motion stream)
+        bool from_motion = false;  // orbf_step_motion* (either way of building the queries)
         orbm_frame* fr = nullptr;
         SearchJob J{nullptr, nullptr, 0, nullptr, false, 0.f, 0, 0, 64, false};
         std::vector<orbf_image> images;
@@ -635,7 +636,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     f->last_frame = nullptr; f->last_frame_owned = false;
     if (f->xcomm) flags |= ORBF_SKIP_CROSS;   // the rig-wide matching of the exchange replaces the rank-local one
     P.images.assign(images, images + f->n_cams);
-    P.nq = nq; P.flags = flags;
+    P.nq = nq; P.flags = flags; P.from_motion = motion != nullptr;
 
     // ---- this step's extraction: already in flight (orbf_prefetch during an earlier step) or enqueued now
     if (!f->inflight.empty() && same_images(f->inflight.front().images, images, f->n_cams) &&
@@ -981,6 +982,7 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     out->n_queries = nq;
     if (P.use_ms && (P.flags & ORBF_NO_QUERY_RECORDS)) have_records = P.J.q_fill == nullptr;   // (a host fallback may have written them)
     out->queries = !P.use_ms ? reinterpret_cast<const orbm_query*>(f->h_queries.p) : (have_records && nq > 0 ? f->q_host.data() : nullptr);
+    if (P.from_motion && (P.flags & ORBF_NO_QUERY_RECORDS) && !P.use_ms) out->queries = nullptr;   // (the flag means the same on the host-built path)
     out->n_cams = f->n_cams; out->n_total = n; out->counts = f->counts.data();
     out->kps = R.kps.p; out->desc = R.desc.p; out->uright = R.ur.p; out->depth = R.depth.p;
     out->un_x = R.unx.p; out->un_y = R.uny.p;

@@ -9,3 +9,14 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """No test may hang the suite: with pytest-timeout present (it is in this image) every test gets a limit -- generous next to the
+    slowest one (~10 s; minutes for the oracle-heavy CPU tests) -- unless it set its own."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    import pytest
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600 if item.get_closest_marker("gpu") is None else 240))

@@ -32,7 +32,7 @@ def run(width=640, height=480, nf=(1000, 500), T=12, iters=200, warmup=30, batch
     sp, op = os.path.join(tmp, "stream.bin"), os.path.join(tmp, "out.bin")
     with open(sp, "wb") as fh:
         fh.write(blob)
-    subprocess.check_call([BIN, "dropin", sp, op, "1" if batch else "0"])
+    subprocess.check_call([BIN, "dropin", sp, op, "1" if batch else "0"], timeout=180)
     buf = open(op, "rb").read()
     meds = np.frombuffer(buf, np.float32, 12, 0)
     per = np.frombuffer(buf, np.float32, iters, 48)[1:]        # (step 0 has no last frame to search)

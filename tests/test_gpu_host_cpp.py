@@ -55,7 +55,7 @@ def test_cpp_orbextractor_operator_call(tmp_path):
     import oracle
     img = synth.image(0, 3, 640, 480)
     (tmp_path / "img.bin").write_bytes(img.tobytes())
-    subprocess.check_call([BIN, "extract", str(tmp_path / "img.bin"), "640", "480", "1000", str(tmp_path / "out.bin")])
+    subprocess.check_call([BIN, "extract", str(tmp_path / "img.bin"), "640", "480", "1000", str(tmp_path / "out.bin")], timeout=180)
     buf = (tmp_path / "out.bin").read_bytes()
     k, d, off = _read_kps(buf, 0)
     ok, od = oracle.extract(img, nfeatures=1000)
@@ -71,7 +71,7 @@ def test_cpp_orbextractor_batch_two_cameras(tmp_path):
     for c in range(2):
         (tmp_path / ("img%d.bin" % c)).write_bytes(imgs[c].tobytes())
     subprocess.check_call([BIN, "batch", str(tmp_path / "out.bin"), "640", "480", str(tmp_path / "img0.bin"), "1000",
-                           str(tmp_path / "img1.bin"), "500"])   # cam 2 gets nFeatures/2 (reference Tracking.cc:145)
+                           str(tmp_path / "img1.bin"), "500"], timeout=180)   # cam 2 gets nFeatures/2 (reference Tracking.cc:145)
     buf = (tmp_path / "out.bin").read_bytes()
     off = 0
     for c, nf in enumerate((1000, 500)):
@@ -149,7 +149,7 @@ def test_cpp_orbmatcher_search_by_projection_overloads(tmp_path, check_ori):
     th2 = f32(3.0)
     blob += struct.pack("<f", float(th2))
     (tmp_path / "case.bin").write_bytes(blob)
-    subprocess.check_call([BIN, "match", str(tmp_path / "case.bin"), str(tmp_path / "out.bin")])
+    subprocess.check_call([BIN, "match", str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], timeout=180)
     buf = (tmp_path / "out.bin").read_bytes()
     n_total = n0 + n1
     got_n1 = struct.unpack_from("<i", buf, 0)[0]
@@ -262,7 +262,7 @@ def test_cpp_vocabulary_and_bow_searches(tmp_path, check_ori, only_stereo, vbcam
     nnratio = f32(0.75)
     blob += struct.pack("<ffff", fx, fy, cx, cy) + scale.tobytes() + sigma2.tobytes() + struct.pack("<fiiii", nnratio, check_ori, only_stereo, *vbcam)
     (tmp_path / "case.bin").write_bytes(blob)
-    subprocess.check_call([BIN, "bow", str(tmp_path / "case.bin"), str(tmp_path / "out.bin")])
+    subprocess.check_call([BIN, "bow", str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], timeout=180)
     buf = (tmp_path / "out.bin").read_bytes()
     off = 0
     nw = struct.unpack_from("<i", buf, off)[0]; off += 4
@@ -498,7 +498,7 @@ def test_cpp_remaining_projection_searches(tmp_path, check_ori):
     blob += struct.pack("<i", window_size)
     (tmp_path / "case.bin").write_bytes(blob)
     env = dict(os.environ, MORB_DUMP_QUERIES=str(tmp_path / "queries.bin"))
-    subprocess.check_call([BIN, "f4", str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], env=env)
+    subprocess.check_call([BIN, "f4", str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], env=env, timeout=180)
 
     from multi_orb_slam_amd._lib import WINDOW_DTYPE
     qb = (tmp_path / "queries.bin").read_bytes(); sets = []; windows = {}; off = 0
@@ -677,7 +677,7 @@ def test_scalar_pose_algebra_equals_the_cv_mat_expressions():
     """The per-frame tracking search computes R * x + t with a scalar routine instead of three cv::Mat temporaries per point
     (host/ORBmatcher.cc: apply_rt): bit-identical to the cv::Mat expressions on 10^6 random poses x points, chained
     application (camera 2 behind camera 1) included.  No GPU."""
-    out = subprocess.check_output([BIN, "rt", "1000000"]).decode()
+    out = subprocess.check_output([BIN, "rt", "1000000"], timeout=180).decode()
     assert "1000000 poses x points, 0 differing floats" in out
 
 
@@ -695,6 +695,6 @@ def test_cpp_matcher_called_from_three_threads_at_once(tmp_path):
     test_cpp_vocabulary_and_bow_searches(dirs[1], 1, 0, (1, 1))
     test_cpp_remaining_projection_searches(dirs[2], 1)
     env = {k: v for k, v in os.environ.items() if k != "MORB_DUMP_QUERIES"}
-    out = subprocess.run([BIN, "threads"] + [str(d / "case.bin") for d in dirs] + ["200"], env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([BIN, "threads"] + [str(d / "case.bin") for d in dirs] + ["200"], env=env, capture_output=True, text=True, timeout=200)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "3 x 200 concurrent iterations, 0 mismatches, 0 errors, 0 failed device calls" in out.stdout
