@@ -19,4 +19,7 @@ def pytest_collection_modifyitems(config, items):
     import pytest
     for item in items:
         if item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(600 if item.get_closest_marker("gpu") is None else 240))
+            if item.get_closest_marker("gpu") is None:
+                item.add_marker(pytest.mark.timeout(600))
+            else:   # (a thread stuck inside a HIP call never returns to the interpreter: only the watchdog-thread method can end it)
+                item.add_marker(pytest.mark.timeout(240, method="thread"))
