@@ -352,6 +352,11 @@ def main(argv=None):
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and (a.gpus or 1) > 1:
         return launch_ranks(a, argv)           # before any GPU call; the ranks are children of this process
+    # a run that makes no progress ends with a traceback instead of holding its GPU box (a default run takes well under a minute)
+    wd = int(os.environ.get("MORB_BENCH_WATCHDOG_S", "1500"))
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     rank = int(os.environ.get("RANK", "0")); world = int(env_world or "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus is not None and a.gpus != world:
