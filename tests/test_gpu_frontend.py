@@ -255,8 +255,11 @@ def test_single_rank_rccl_exchange_equals_oracle():
     from multi_orb_slam_amd import pipeline
     from multi_orb_slam_amd.dist import DescriptorExchange
     from oracle_pipeline import OracleFrontEnd, assert_same_step
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 300)
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    import datetime, socket
+    with socket.socket() as sk:      # a port nobody holds right now (the GPU boxes are shared machines)
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))
     try:
         torch.cuda.set_device(0)
         params = [m.ExtractorParams(nfeatures=300), m.ExtractorParams(nfeatures=150)]
