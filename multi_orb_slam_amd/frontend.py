@@ -81,10 +81,14 @@ class NativeFrontEnd:
         self._res = FResult()
         self._arr_type = FImage * self.n_cams
         self._ncross = C.c_int(0)
+        # (the per-step call of a stream: function object and argument references made once)
+        self._fn_step_ahead = _lib.lib().orbf_step_motion_ahead
+        self._res_ref = C.byref(self._res); self._ncross_ref = C.byref(self._ncross)
         self._views = {}
         self._step_seq = 0
         self._img_cache = {}
         self._motion_cache = {}
+        self._motion_refs = {}     # motion -> (byref, FMotion) for step_ahead
         self.cap_total = sum(p.nfeatures + 4 * p.nlevels for p in self.params)
         self._imgs = (FImage * self.n_cams)()
         self._ready = C.c_int(0)
@@ -292,11 +296,16 @@ class NativeFrontEnd:
             nxt, keep = self._image_array(next_images, self._next_imgs)
             if keep:
                 self._next_keep = (self._next_keep + [keep])[-4:]
-        mo = self._motion_cache.get(motion)
+        mo = self._motion_refs.get(motion)
         if mo is None:
-            mo = self._motion_cache[motion] = FMotion(*motion)
+            if len(self._motion_refs) >= 64:      # (a stream whose motion changes every step: keep the cache small)
+                self._motion_refs.clear()
+            m_ = FMotion(*motion)
+            mo = self._motion_refs[motion] = (C.byref(m_), m_)
         nc = self._ncross
-        check(_lib.lib().orbf_step_motion_ahead(self._h, arr, nxt, C.byref(mo), flags, th_low, ratio, C.byref(self._res), C.byref(nc)))
+        rc = self._fn_step_ahead(self._h, arr, nxt, mo[0], flags, th_low, ratio, self._res_ref, self._ncross_ref)
+        if rc:
+            check(rc)
         self._nq = None
         r = self._collect(copy)
         r["n_cross"] = nc.value if nc.value >= 0 else None
