@@ -49,7 +49,6 @@ struct orbf_frontend {
     morb::StageBuf h_queries;   // this step's queries: written by the host, read once by k_project
     // The motion stream (orbf_step_motion) builds its queries inside the projection kernel from the previous frame's arrays in
     // HBM (MotionSrc); the host keeps the same records for orbf_result::queries and the host fallbacks, written while it waits
-    DevBuf<float> d_scale;             // scale factor per level (device copy of scale_factors)
     std::vector<orbm_query> q_host;
     bool motion_on_device = true;      // MORB_MOTION_ON_DEVICE=0: the host writes the records into the staging buffer first (rounds 1-3)
     PinnedBuf<int32_t> h_match;
@@ -123,14 +122,6 @@ int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int 
     f->motion_on_device = getenv_int("MORB_MOTION_ON_DEVICE", 1) != 0;
     f->scale_factors.assign(params[0].nlevels, 1.f);
     if ((rc = orbx_tables(&params[0], f->scale_factors.data(), nullptr, nullptr, nullptr, nullptr, nullptr))) { orbf_destroy(f); return rc; }
-    // (on the matcher's stream: a copy on the NULL stream would bring a fifth hardware queue into being -- measured: the overlapped loop
-    // at 9 300 steps/s instead of 19 000)
-    if ((rc = f->d_scale.reserve(f->scale_factors.size())) ||
-        hipMemcpyAsync(f->d_scale.p, f->scale_factors.data(), f->scale_factors.size() * sizeof(float), hipMemcpyHostToDevice, f->mt->stream) != hipSuccess ||
-        hipStreamSynchronize(f->mt->stream) != hipSuccess) {
-        if (!rc) { morb::set_error("scale table upload failed"); rc = ORB_E_HIP; }
-        orbf_destroy(f); return rc;
-    }
     for (int c = 0; c < n_cams; ++c) { f->cam_cap.push_back(params[c].nfeatures + 4 * params[c].nlevels); f->cap_total += f->cam_cap.back(); }
     const size_t cap = (size_t)f->cap_total;
     if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
@@ -169,7 +160,7 @@ void orbf_destroy(orbf_frontend* f) {
     if (f->mt) orbm_destroy(f->mt);
     for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) orbx_destroy(f->exs[e]);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); f->rs[k].unx.release(); f->rs[k].uny.release(); f->rs[k].cross.release(); }
-    f->h_queries.release(); f->h_match.release(); f->d_scale.release();
+    f->h_queries.release(); f->h_match.release();
     if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->ev_ready[k]) (void)hipEventDestroy(f->ev_ready[k]);
     delete f;
@@ -679,13 +670,16 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     }
     if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[0] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     if (motion && f->motion_on_device && prev_frame && f->prev_n > 0 && prev_frame->n_total == f->prev_n &&
-        prev_frame->n_cams == f->n_cams) {
+        prev_frame->n_cams == f->n_cams && f->scale_factors.size() <= 16) {
         // query i = feature i of the previous frame (still in HBM) moved by the motion: built by the projection kernel itself
         const FrameBufs* B = prev_frame->b;
         nq = f->prev_n; P.nq = nq;
         P.use_ms = true; P.motion = *motion;
         P.ms = MotionSrc{B->d_x.p, B->d_y.p, B->d_depth.p, B->d_ang.p, B->d_oct.p, (const uint4*)B->d_desc.p, B->d_cam_start.p, f->n_cams,
-                         f->d_scale.p, motion->du, motion->dv, motion->th, f->mbf, nullptr};
+                         {}, motion->du, motion->dv, motion->th, f->mbf, nullptr};
+        // (the level scales travel in the kernel arguments: an upload in orbf_create would be one more HIP call next to other threads'
+        // graph captures, and a copy on the NULL stream a fifth hardware queue -- the first version measured 9 300 steps/s that way)
+        for (size_t l = 0; l < f->scale_factors.size(); ++l) P.ms.scale[l] = f->scale_factors[l];
         f->q_host.resize((size_t)nq);   // (filled by orbf_step_end while it waits: orbf_result::queries, the host fallbacks)
         queries = nullptr;
     } else if (motion) {

@@ -121,7 +121,7 @@ struct orbm_frame {
 struct MotionSrc {
     const float* x; const float* y; const float* depth; const float* angle;   // the previous frame's arrays (global feature order)
     const int* octave; const uint4* desc; const int* cam_start; int n_cams;
-    const float* scale;    // scale factor per pyramid level (device)
+    float scale[16];       // scale factor per pyramid level, by value (no table in memory: nothing to allocate or copy for it)
     float du, dv, th, mbf;
     orbm_query* rec_out;   // non-NULL: {blocks, angle} of every query into these records (the multi-workgroup resolve reads them)
 };
