@@ -457,7 +457,7 @@ def main(argv=None):
     t_gate = time.perf_counter()
     ofe = OracleFrontEnd(params, W, H, gcam, cam_threads=True)
     pool = ThreadPoolExecutor(max(1, min(len(other_g), 16))) if other_g else None
-    AHEAD = max(1, min(a.ahead, fe.fe.ahead_depth))   # (a front end with a multi-GPU exchange takes two: DESIGN.md section 4)
+    AHEAD = max(1, min(a.ahead, fe.fe.ahead_depth))   # (two with MORB_EXCHANGE_INLINE=0: DESIGN.md section 6)
     if overlap:
         for k in range(1, AHEAD):
             fe.announce(frame_args(k), resident=True)

@@ -64,7 +64,9 @@ typedef struct orbf_result { /* all pointers: pinned host memory owned by the ha
 int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbf_frontend** out);
 /* The same with the look-ahead depth chosen by the caller (1..3; 0 = MORB_AHEAD_DEPTH, default 3): a handle creates one
  * extractor instance, i.e. one stream, per timestep it can extract ahead.  Streams are hardware queues and the part serves four of
- * them side by side: a front end that will run a multi-GPU exchange (orbf_exchange_init: one more stream) takes 2. */
+ * them side by side.  A multi-GPU exchange (orbf_exchange_init) brings no stream of its own: the all-gather and the rig-wide top-2
+ * follow the step's search on the matcher's stream (MORB_EXCHANGE_INLINE=0: on a side stream, and the handle then keeps two
+ * extractor instances -- the arrangement of round 2, 50 % slower in the forced-exchange loop). */
 int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int max_height, int device, int ahead_depth, orbf_frontend** out);
 void orbf_destroy(orbf_frontend* f);
 /* HBM-resident depth image (metres, float32) of one camera for ComputeStereoFromRGBD; NULL: uRight = -1 */

@@ -130,8 +130,8 @@ int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int 
     // Every stream is a hardware queue and the command processor serves four side by side.  The streams
     // that work next to each other are created HERE, together and first -- extractor 0, the matcher's, the overlap partners --
     // because which queues end up sharing a pipe follows the order of creation (measured: the same four streams created
-    // lazily, behind a caller's own streams, ran the loop at 87-195 us per step instead of 50).  A handle that will run a
-    // multi-GPU exchange is created with a depth of two (orbf_create_depth): the exchange's side stream is its fourth queue.
+    // lazily, behind a caller's own streams, ran the loop at 87-195 us per step instead of 50).  A multi-GPU exchange runs on the
+    // matcher's stream (exchange_queues), so a handle keeps its depth of three with it.
     { const int d = ahead_depth > 0 ? ahead_depth : getenv_int("MORB_AHEAD_DEPTH", 3); f->n_ex = d < 1 ? 1 : (d > orbf_frontend::NEX ? orbf_frontend::NEX : d); }
     f->params.assign(params, params + n_cams);
     for (int e = 1; e < f->n_ex && !rc; ++e) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[e]);  // overlap partners
@@ -237,6 +237,10 @@ static int orbf_drain(orbf_frontend* f);
 // The exchange runs on the matcher's side stream every step: that is one of the four hardware queues, so at most two extractor
 // instances go round from here on (an instance that exists already keeps its stream, but is no longer handed timesteps).
 static int exchange_queues(orbf_frontend* f) {
+    // Default: the exchange runs on the matcher's own stream (orbm_matcher::side_inline) and every extractor instance stays.
+    // MORB_EXCHANGE_INLINE=0: the round-2 arrangement -- exchange on the side stream, at most two extractor instances (A/B only).
+    static const bool inl = getenv_int("MORB_EXCHANGE_INLINE", 1) != 0;
+    if (inl) { f->mt->side_inline = true; return ORB_OK; }
     if (f->n_ex > 2) {   // (a handle created for a single GPU after all: the third instance and its stream go before the side stream comes)
         int rc = orbf_drain(f);
         if (rc) return rc;
@@ -281,11 +285,13 @@ int orbf_exchange_shutdown(orbf_frontend* f) {
     if (f->xloop) loop_leave(static_cast<LoopComm*>(f->xcomm));
     else exchange_comm_destroy(f->xcomm);
     f->xcomm = nullptr; f->xworld = 0; f->xrank = 0; f->xloop = false;
+    if (f->mt) f->mt->side_inline = false;
     return ORB_OK;
 }
 
-// all-gather of the frame's export block + the gathered cross-camera top-2, all on the matcher's side stream (joined into its
-// main stream): the block must be final (its extraction chain has completed, or the main stream has been synchronised)
+// all-gather of the frame's export block + the gathered cross-camera top-2, behind the step's search on the matcher's stream (or, with
+// MORB_EXCHANGE_INLINE=0, on its side stream, joined into the main stream): the block must be final (its extraction chain has
+// completed, or the main stream has been synchronised)
 static int exchange_enqueue(orbf_frontend* f, const orbm_frame* F) {
     orbm_matcher* m = f->mt;
     const size_t block = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;

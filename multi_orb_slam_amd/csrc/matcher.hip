@@ -67,6 +67,7 @@ static int raise_lds_limits(int device) {
 }
 
 hipStream_t morb::side_stream(orbm_matcher* m) {
+    if (m->side_inline) return m->stream;   // (a front end with a multi-GPU exchange: see orbm_matcher::side_inline)
     if (!m->side_stream) {
         int prio_least = 0, prio_greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);

@@ -68,6 +68,11 @@ struct orbm_matcher {
     // another one, and a kernel then waits behind the DISPATCH of that queue's kernels (measured with three extraction streams +
     // matcher + this one: single kernels of the chains stretched to 40-55 us, 83 us per step instead of 50).
     hipStream_t side_stream = nullptr;
+    // A front end that runs a multi-GPU exchange keeps everything on the matcher's own stream: the all-gather, the repack and the
+    // rig-wide top-2 follow the step's search there.  Forked onto the side stream they were a fifth queue's worth of trouble next to
+    // three extraction chains, and with two chains the fork / join events and the waiting small kernels cost more than the overlap
+    // gave: 106-114 us per step against 72-74 us inline with three chains (forced exchange on one GPU, end of round 3).
+    bool side_inline = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_q = nullptr;
     PinnedBuf<uint16_t> h_u16;
     PinnedBuf<uint8_t> h_ring;  // 4 slots of {CamFeat[64], int cam_start[65]} for asynchronous H2D

@@ -72,8 +72,8 @@ class NativeFrontEnd:
         return ent
 
     def __init__(self, params, max_width, max_height, device=0, ahead_depth=0):
-        """ahead_depth: timesteps prefetch() accepts ahead (1..3; 0 = MORB_AHEAD_DEPTH, default 3).  A front end that will run a
-        multi-GPU exchange takes 2 (orbf_create_depth: its streams are hardware queues, the part serves four side by side)."""
+        """ahead_depth: timesteps prefetch() accepts ahead (1..3; 0 = MORB_AHEAD_DEPTH, default 3).  Streams are hardware queues and the
+        part serves four side by side; the multi-GPU exchange runs on the matcher's own stream and needs none."""
         self.params = list(params); self.n_cams = len(self.params)
         arr = (Params * self.n_cams)(*[p.c() for p in self.params])
         self._h = C.c_void_p()

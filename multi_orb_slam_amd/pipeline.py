@@ -69,8 +69,11 @@ class FrontEnd:
         self.gather = gather                      # DescriptorExchange (multi-GPU) or None
         self.global_cams = global_cams or list(range(rank * self.n_cams, (rank + 1) * self.n_cams))
         rt.set_device(device)
-        # (a rank of a multi-GPU job runs a collective next to its matching: one hardware queue less for extractor streams)
-        self.fe = NativeFrontEnd(self.params, width, height, device, ahead_depth=2 if world_size > 1 else 0)
+        # (the native exchange of a multi-GPU job runs on the matcher's own stream: the full look-ahead depth stays; the round-2
+        # arrangement -- exchange on a side stream, MORB_EXCHANGE_INLINE=0 -- gives that stream one of the four hardware queues)
+        import os
+        side = world_size > 1 and os.environ.get("MORB_EXCHANGE_INLINE", "1") == "0"
+        self.fe = NativeFrontEnd(self.params, width, height, device, ahead_depth=2 if side else 0)
         self.fe.configure(MBF, 100, True)
         if calib is not None:
             self.fe.set_calibration(calib)   # (fx, fy, cx, cy, k1, k2, p1, p2[, k3]): undistortion as the reference's Frame does it
