@@ -14,6 +14,9 @@ if [ "$1" != "prof-only" ]; then
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed" > $O/pytest.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 for c in 2 3 4; do python bench.py --config $c --no-roofline > $O/bench_c$c.json 2> $O/bench_c$c.err; done
+# the per-rank step of a multi-GPU job, forced on this one GPU (world-1 RCCL group: one all-gather + rig-wide top-2 per step), both arrangements
+MORB_FORCE_DIST=1 python bench.py --no-dropin --no-roofline --no-cpu > $O/bench_forced_exchange.json 2> $O/bench_forced_exchange.err
+MORB_FORCE_DIST=1 MORB_EXCHANGE_INLINE=0 python bench.py --no-dropin --no-roofline --no-cpu > $O/bench_forced_exchange_side_stream.json 2> $O/bench_forced_exchange_side_stream.err
 fi
 cd /tmp && export TMPDIR=/tmp
 export MORB_NO_BAR_STAGING=1

@@ -4,6 +4,7 @@
 R=${1:-r03}; F=gpurun_out/$R/final; P=profiles/$R; mkdir -p $P
 cp $F/bench.json $P/bench.json
 for c in 2 3 4; do cp $F/bench_c$c.json $P/bench_config$c.json; done
+cp $F/bench_forced_exchange.json $F/bench_forced_exchange_side_stream.json $P/ 2>/dev/null
 cp $F/bench_under_rocprof.json $P/bench_under_rocprof.json
 cp $F/bench_c4_under_rocprof.json $P/bench_config4_under_rocprof.json 2>/dev/null
 cp $F/prof_bench/bench_kernel_stats.csv $P/bench_kernel_stats.csv
