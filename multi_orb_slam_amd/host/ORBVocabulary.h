@@ -13,6 +13,16 @@
 
 struct orbv_vocabulary;
 
+#ifdef MORB_USE_REFERENCE_TYPES
+// inside the reference's tree the containers are DBoW2's own (Frame.h / KeyFrame.h include the same two headers)
+#include "Thirdparty/DBoW2/DBoW2/BowVector.h"
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+// The reference's own headers name std::vector / std::list unqualified (include/Frame.h:104,240, include/KeyFrame.h:214,
+// include/Map.h:62, include/KeyFrameDatabase.h:68) and get the using-directive from Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:36
+// through the include/ORBVocabulary.h this file takes the place of.  A replacement that did not pass it on would break them.
+#include <list>
+using namespace std;
+#else
 namespace DBoW2 {
 typedef unsigned int WordId;   // BowVector.h:22
 typedef double WordValue;      // BowVector.h:25
@@ -20,6 +30,7 @@ typedef unsigned int NodeId;   // BowVector.h:28
 class BowVector : public std::map<WordId, WordValue> {};                          // BowVector.h:56
 class FeatureVector : public std::map<NodeId, std::vector<unsigned int> > {};     // FeatureVector.h:20
 }  // namespace DBoW2
+#endif
 
 namespace ORB_SLAM2 {
 

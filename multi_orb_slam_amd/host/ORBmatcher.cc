@@ -72,12 +72,15 @@ using clk = std::chrono::steady_clock;
 inline float us_since(clk::time_point a) { return std::chrono::duration<float, std::micro>(clk::now() - a).count(); }
 
 // The per-frame tracking search projects ~2000 points with `R * x + t` on 3x3 / 3x1 CV_32F cv::Mat objects: three
-// reference-counted temporaries per point.  apply_rt computes the same three floats without them, element by element as the
-// cv::Mat expression evaluates in cv_compat.h: per row the three products summed left to right in double from 0.0, rounded to
-// float (operator*), then the float addition of t (operator+).  host/test_host `rt` holds the two against each other bit for
-// bit on 10^6 random poses and points.  A build against the real OpenCV keeps the cv::Mat expressions (MORB_VERBATIM_MAT_ALGEBRA
-// is on by default there): cv::gemm has its own evaluation order for small matrices, and whoever switches the scalar path on
-// for such a build runs the same comparison against it first.
+// reference-counted temporaries per point.  apply_rt computes the same three floats without them.  What `R * x + t` IS in
+// OpenCV: ONE cv::gemm call (MatOp_GEMM::add folds the addend in), which for a 3x3 * 3x1 product without transposition
+// flags takes gemm's small-matrix block (modules/core/src/matmul.cpp, `if( flags == 0 && 2 <= len && len <= 4 && ...`):
+// `float t = a[0]*b[0] + a[1]*b[b_step] + a[2]*b[2*b_step]` -- FLOAT products and sums, left to right -- then
+// `d = (float)(t*alpha + c*beta)` in double with alpha = beta = 1.  cv_compat.h restates that evaluation (gemm_small_f32 and the
+// expression rules around it) and host/test_host `rt` holds apply_rt against the cv::Mat expression bit for bit on 10^6 random
+// poses and points.  (Rounds 1-3 summed the three products in double -- the order of gemm's GENERAL path, which this shape
+// never reaches)  A build against the real OpenCV keeps the cv::Mat expressions (MORB_VERBATIM_MAT_ALGEBRA is on
+// by default there): whoever switches the scalar path on for such a build runs `test_host rt` against the real library first.
 #if defined(HAVE_OPENCV) && !defined(MORB_SCALAR_POSE_ALGEBRA) && !defined(MORB_VERBATIM_MAT_ALGEBRA)
 #define MORB_VERBATIM_MAT_ALGEBRA 1
 #endif
@@ -89,11 +92,8 @@ inline Rt load_rt(const cv::Mat& R, const cv::Mat& t) {
 }
 inline void apply_rt(const Rt& P, const float* x, float* o) {
     for (int i = 0; i < 3; ++i) {
-        double s = 0;
-        s += (double)P.R[i][0] * (double)x[0];
-        s += (double)P.R[i][1] * (double)x[1];
-        s += (double)P.R[i][2] * (double)x[2];
-        o[i] = (float)s + P.t[i];
+        const float t = P.R[i][0] * x[0] + P.R[i][1] * x[1] + P.R[i][2] * x[2];   // float, left to right (no contraction: -ffp-contract=off)
+        o[i] = (float)((double)t * 1.0 + (double)P.t[i] * 1.0);
     }
 }
 }  // namespace
@@ -200,17 +200,17 @@ struct FlatFrame {  // orbm_frame_desc backing store built from a Frame
     orbm_frame_desc d;
 };
 
-// The reference keeps global index -> camera / local index in std::map<size_t,int> (include/Frame.h): read with one ordered
-// walk (keys 0 .. n-1 in order is what Frame::Frame builds, src/Frame.cc:221-239), falling back to find() for anything else.
-struct MapWalk {
-    const std::map<size_t, int>& m; std::map<size_t, int>::const_iterator it;
-    explicit MapWalk(const std::map<size_t, int>& mm) : m(mm), it(mm.begin()) {}
-    int at(size_t g) {
-        if (it != m.end() && it->first == g) { const int v = it->second; ++it; return v; }
-        auto f = m.find(g);
-        if (f == m.end()) return -1;
-        it = f; const int v = it->second; ++it; return v;
+// The reference keeps global index -> camera / local index in std::unordered_map<size_t,int> (include/Frame.h:256,261,
+// include/KeyFrame.h:243,248) and reads them with one find() per access.  IndexTable reads such a map ONCE, by a single pass
+// over its entries in whatever order the container keeps them (so it takes std::map and std::unordered_map alike -- a build
+// against the reference's own headers and the stand-in of slam_types.h use the same code), into a flat array indexed by the
+// global feature index; a feature without an entry reads -1.
+struct IndexTable {
+    std::vector<int> v;
+    template <class Map> IndexTable(const Map& m, size_t n) : v(n, -1) {
+        for (const auto& e : m) if ((size_t)e.first < n) v[(size_t)e.first] = e.second;
     }
+    int at(size_t g) const { return g < v.size() ? v[g] : -1; }
 };
 
 template <class FrameOrKeyFrame>
@@ -219,7 +219,7 @@ bool flatten(const FrameOrKeyFrame& F, bool cam1_only, FlatFrame& ff) {
     ff.x.resize(n); ff.y.resize(n); ff.ang.resize(n); ff.ur.resize(n); ff.oct.resize(n); ff.cam.resize(n); ff.loc.resize(n);
     const std::vector<cv::KeyPoint>& kun = cam1_only ? F.mvKeysUn : F.mvKeysUn_total;
     const std::vector<float>& ur = cam1_only ? F.mvuRight : F.mvuRight_total;
-    MapWalk cams(F.keypoint_to_cam), locs(F.cont_idx_to_local_cam_idx);
+    const IndexTable cams(F.keypoint_to_cam, cam1_only ? 0 : n), locs(F.cont_idx_to_local_cam_idx, cam1_only ? 0 : n);
     for (int g = 0; g < n; ++g) {
         ff.x[g] = kun[g].pt.x; ff.y[g] = kun[g].pt.y; ff.ang[g] = kun[g].angle; ff.oct[g] = kun[g].octave;
         ff.ur[g] = ur[g];
@@ -693,7 +693,7 @@ static int sim3_search(ORBmatcher& self, orbm_matcher* handle, KeyFrame* pKF1, K
     auto direction = [&](KeyFrame* from, KeyFrame* to, const std::vector<MapPoint*>& pts, const std::vector<bool>& already, const cv::Mat& Rw,
                          const cv::Mat& tw, const cv::Mat& sR, const cv::Mat& t, std::vector<int>& out) {
         std::vector<orbm_query> q; std::vector<int> src;
-        MapWalk cams(from->keypoint_to_cam);
+        const IndexTable cams(from->keypoint_to_cam, two_cam ? pts.size() : 0);
         for (int i = 0; i < (int)pts.size(); i++) {
             MapPoint* pMP = pts[i];
             if (!pMP || already[i]) continue;
@@ -1162,12 +1162,13 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
 #ifndef MORB_VERBATIM_MAT_ALGEBRA
     const Rt Pcw = load_rt(Rcw, tcw), Pcam21 = load_rt(mRcam21, mtcam21);
 #endif
-    MapWalk cam_of(LastFrame.keypoint_to_cam);
+    const IndexTable cam_of(LastFrame.keypoint_to_cam, LastFrame.N_total > 0 ? LastFrame.N_total : 0);
     for (int i = 0; i < LastFrame.N_total; i++) {
         MapPoint* pMP = LastFrame.mvpMapPoints[i];
         if (!pMP) continue;
         if (LastFrame.mvbOutlier[i]) continue;
-        int cam = cam_of.at(i);                   // LastFrame.keypoint_to_cam.find(i)->second, by an ordered walk
+        int cam = cam_of.at(i);                   // LastFrame.keypoint_to_cam.find(i)->second (:3490)
+        if (cam < 0 || cam > 1) continue;         // no entry: the reference dereferences end() there -- undefined; skipped here
 #ifdef MORB_VERBATIM_MAT_ALGEBRA
         cv::Mat x3Dw = pMP->GetWorldPos();
         cv::Mat x3Dc = Rcw * x3Dw + tcw;

@@ -39,6 +39,11 @@ public:
     // Used to track from previous frame (Tracking)
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono,
                            cv::Mat CalibMatrix);
+    // Declared by the reference (include/ORBmatcher.h:53,55) and defined nowhere in it (single-camera forms the multi-camera
+    // fork left behind: a program that called them would not link there either).  Declared here for source compatibility,
+    // likewise undefined: there is no reference behaviour to reproduce.
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
+    int SearchByProjection_cam1(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
 
     // Project MapPoints seen in KeyFrame into the Frame and search matches.
     // Used in relocalisation (Tracking)
@@ -85,6 +90,14 @@ public:
     // Matching to triangulate new MapPoints. Check Epipolar Constraint.
     int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
                                const bool bOnlyStereo, std::vector<bool> vbCam);
+    // (include/ORBmatcher.h:90-91: the five-argument form is declared and never defined in the reference; same here)
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                               const bool bOnlyStereo);
+
+    // public in the reference (include/ORBmatcher.h:116-117); ComputeF12 is declared there and defined nowhere (LocalMapping has
+    // its own, src/LocalMapping.cc) -- declared, undefined
+    cv::Mat SkewSymmetricMatrix(const cv::Mat& v);
+    cv::Mat ComputeF12(KeyFrame*& pKF1, KeyFrame*& pKF2);
 
 public:
     static const int TH_LOW;
@@ -95,10 +108,9 @@ public:
     cv::Mat mtcam21;
 
 protected:
-    // (reference include/ORBmatcher.h:116 / src/ORBmatcher.cc:167-184; the searches run the same test on the device)
+    // (reference include/ORBmatcher.h:129 / src/ORBmatcher.cc:167-184; the searches run the same test on the device)
     bool CheckDistEpipolarLine(const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const cv::Mat& F12, const KeyFrame* pKF);
     float RadiusByViewingCos(const float& viewCos);
-    cv::Mat SkewSymmetricMatrix(const cv::Mat& v);
     void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
 
     float mfNNratio;

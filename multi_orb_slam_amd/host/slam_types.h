@@ -1,14 +1,19 @@
-// slam_types.h -- minimal stand-ins for the reference's Frame (include/Frame.h:155-261) and MapPoint
-// (include/MapPoint.h) carrying exactly the members ORBmatcher's two tracking searches read or write.  A real
-// integration compiles ORBmatcher.cc against the reference's own Frame.h / MapPoint.h instead: member names, types
-// and meanings are identical, so the wrapper source does not change (define MORB_USE_REFERENCE_TYPES and put the
-// reference's include/ on the include path).
+// slam_types.h -- minimal stand-ins for the reference's Frame (include/Frame.h:155-261), KeyFrame (include/KeyFrame.h:218-248)
+// and MapPoint (include/MapPoint.h) carrying the members ORBmatcher's searches read or write, under the reference's names
+// and with the reference's container types for everything the wrapper iterates or indexes (std::unordered_map<size_t,int>
+// for the two index maps, std::vector<cv::Mat> for the per-camera descriptors, DBoW2's map-derived vectors).  What is NOT the
+// reference's: the image bounds and the ids are per-object here and static members there (same spelling at the point of use),
+// nNextId is an atomic accessor, MapPoint keeps its observations in a std::map<KeyFrame*,size_t> without the mutexes.
+// A real integration compiles the wrapper against the reference's own headers instead: define MORB_USE_REFERENCE_TYPES and put
+// the reference's include/ (and its root, for Thirdparty/DBoW2) on the include path; tests/test_reference_headers.py holds
+// that build (-fsyntax-only, reference headers used in place) to zero errors on every CPU run.
 #pragma once
 #ifndef MORB_USE_REFERENCE_TYPES
 #include <atomic>
 #include <cmath>
 #include <map>
 #include <set>
+#include <unordered_map>
 #include <vector>
 #include "cv_compat.h"
 #include "ORBVocabulary.h"
@@ -73,7 +78,7 @@ public:
     std::vector<float> mvuRight_total, mvuRight, mvDepth_total;
     std::vector<cv::Mat> mDescriptors_total;  // per camera, N_c x 32
     cv::Mat mDescriptors;                     // camera 1
-    std::map<size_t, int> keypoint_to_cam, cont_idx_to_local_cam_idx;
+    std::unordered_map<size_t, int> keypoint_to_cam, cont_idx_to_local_cam_idx;   // include/Frame.h:256,261 / include/KeyFrame.h:243,248
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<bool> mvbOutlier;
     std::vector<float> mvScaleFactors;
@@ -108,7 +113,7 @@ public:
     std::vector<cv::KeyPoint> mvKeysUn_total;
     std::vector<float> mvuRight_total;
     std::vector<cv::Mat> mDescriptors_total;
-    std::map<size_t, int> keypoint_to_cam, cont_idx_to_local_cam_idx;
+    std::unordered_map<size_t, int> keypoint_to_cam, cont_idx_to_local_cam_idx;   // include/Frame.h:256,261 / include/KeyFrame.h:243,248
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<float> mvScaleFactors, mvLevelSigma2;
     DBoW2::BowVector mBowVec, mBowVec_cam1;

@@ -193,7 +193,7 @@ struct BowEntity {
     cv::Mat Tcw, Tcw2;
     std::vector<MapPoint> pool;
     std::vector<MapPoint*> mps;
-    std::map<size_t, int> to_cam, to_local;
+    std::unordered_map<size_t, int> to_cam, to_local;
 };
 
 static void read_entity(Reader& R, BowEntity& E) {
@@ -658,6 +658,91 @@ static int run_rt(int argc, char** argv) {
     return bad ? 7 : 0;
 }
 
+
+// gemm: known answers for the two evaluation orders of cv::gemm that cv_compat.h restates (small-matrix float block / general
+// double path), for the folding of `A*B + C` into one call, for alpha = -1, for cv::solve's LU and cv::invert's 3x3 closed form.
+// Every expected value is worked out by hand in the comments.  No GPU.
+static int run_gemm_kat() {
+    int bad = 0;
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto expect = [&](const char* what, float got, uint32_t want) {
+        if (bits(got) != want) { std::printf("gemm KAT %s: got %08x, expected %08x\n", what, bits(got), want); ++bad; }
+    };
+    const float e = std::ldexp(1.f, -24);   // half an ulp of 1.0f
+    // (1) row (1, e, e) . (1, 1, 1).  Float order: 1 + e = 1 (tie, even), + e = 1 -> 3f800000.
+    //     Double order: 1 + 2e = 1 + 2^-23 exactly -> 3f800001.
+    cv::Mat A = cv::Mat::zeros(3, 3, CV_32F), x(3, 1, CV_32F);
+    A.at<float>(0, 0) = 1; A.at<float>(0, 1) = e; A.at<float>(0, 2) = e;
+    for (int k = 0; k < 3; ++k) x.at<float>(k) = 1;
+    cv::Mat y = A * x;                                   // 3x3 * 3x1, no flags: small block
+    expect("small 3x3*3x1", y.at<float>(0), 0x3f800000u);
+    cv::Mat At = A.t();                                  // evaluated transpose; At.t() * x is GEMM_1_T: general path
+    cv::Mat yg = At.t() * x;
+    expect("general (A_T) 3x3*3x1", yg.at<float>(0), 0x3f800001u);
+    expect("gemm() small", cv::gemm(A, x, 1, cv::Mat(), 0, 0).at<float>(0), 0x3f800000u);
+    expect("gemm() general", cv::gemm(At, x, 1, cv::Mat(), 0, cv::GEMM_1_T).at<float>(0), 0x3f800001u);
+    // a 1x3 * 3x1 product has len 3 but neither side of D is 3: general path -> 3f800001
+    expect("1x3*3x1 is general", ((cv::Mat)(A.row(0) * x)).at<float>(0), 0x3f800001u);
+    // 3x3 * 3x3 (row form of the small block): column of ones -> 3f800000
+    cv::Mat ones3(3, 3, CV_32F); for (int k = 0; k < 9; ++k) ones3.at<float>(k / 3, k % 3) = 1;
+    expect("small 3x3*3x3", ((cv::Mat)(A * ones3)).at<float>(0, 2), 0x3f800000u);
+    // (2) len 4: row (1, e, e, e) . ones.  Float: 1.  Double: 1 + 3e = 1 + 1.5 ulp -> tie between 1+ulp and 1+2ulp -> even: 3f800002.
+    cv::Mat T = cv::Mat::zeros(4, 4, CV_32F), ones4(4, 4, CV_32F);
+    T.at<float>(0, 0) = 1; T.at<float>(0, 1) = e; T.at<float>(0, 2) = e; T.at<float>(0, 3) = e;
+    for (int k = 0; k < 16; ++k) ones4.at<float>(k / 4, k % 4) = 1;
+    expect("small 4x4*4x4", ((cv::Mat)(T * ones4)).at<float>(0, 1), 0x3f800000u);
+    expect("general 4x4*4x4t", ((cv::Mat)(T * ones4.t())).at<float>(0, 1), 0x3f800002u);
+    // (3) folding: row of zeros times (-1,-1,-1): t = -0.0f.  Alone: (float)(-0.0*1 + 0.0f*0) = +0.0 -> 00000000.
+    //     `Z*m + c` with c = -0.0f is ONE call: (float)(-0.0 + -0.0) = -0.0 -> 80000000 (product-then-sum would give +0.0 + -0.0 = +0.0).
+    cv::Mat Z = cv::Mat::zeros(3, 3, CV_32F), m(3, 1, CV_32F), c(3, 1, CV_32F);
+    for (int k = 0; k < 3; ++k) { m.at<float>(k) = -1; c.at<float>(k) = -0.0f; }
+    expect("product alone", ((cv::Mat)(Z * m)).at<float>(0), 0x00000000u);
+    expect("A*B + C folded", ((cv::Mat)(Z * m + c)).at<float>(0), 0x80000000u);
+    expect("C + A*B folded", ((cv::Mat)(c + Z * m)).at<float>(0), 0x80000000u);
+    // (4) -A*B is alpha = -1 on the same call: t = 1 -> -1 (bf800000); t = +0.0: (+0.0 * -1) + 0 = +0.0 (00000000, not 80000000)
+    cv::Mat I = cv::Mat::eye(3, 3, CV_32F);
+    expect("-I*x", ((cv::Mat)(-I * x)).at<float>(1), 0xbf800000u);
+    cv::Mat zero3 = cv::Mat::zeros(3, 1, CV_32F);
+    expect("-I*0", ((cv::Mat)(-I * zero3)).at<float>(1), 0x00000000u);
+    // C - A*B: alpha = -1, beta = 1: (2,2,2) - I*(1,1,1) = 1
+    cv::Mat two(3, 1, CV_32F); for (int k = 0; k < 3; ++k) two.at<float>(k) = 2;
+    expect("C - A*B", ((cv::Mat)(two - I * x)).at<float>(2), 0x3f800000u);
+    // -R.t() * t: the transpose is evaluated, alpha = -1, no flag -> small block (float order): row (1,e,e) again -> -1 exactly
+    expect("-A.t().t()*x small", ((cv::Mat)(-At.t() * x)).at<float>(0), 0xbf800000u);
+    // s*A.t() and A/s: float scale kernel x*(float)s + 0
+    expect("0.5*A.t()", ((cv::Mat)(0.5 * A.t())).at<float>(0, 0), 0x3f000000u);
+    expect("A/4", ((cv::Mat)(A / 4.0)).at<float>(0, 0), 0x3e800000u);
+    // (5) cv::solve LU with a row swap: A = [[0,1,0],[2,0,0],[0,0,4]], B = I -> X = [[0,.5,0],[1,0,0],[0,0,.25]] (all exact)
+    cv::Mat S = cv::Mat::zeros(3, 3, CV_32F);
+    S.at<float>(0, 1) = 1; S.at<float>(1, 0) = 2; S.at<float>(2, 2) = 4;
+    cv::Mat X = S.inv() * I;                             // inv() * Mat -> solve
+    expect("solve (0,1)", X.at<float>(0, 1), 0x3f000000u);
+    expect("solve (1,0)", X.at<float>(1, 0), 0x3f800000u);
+    expect("solve (2,2)", X.at<float>(2, 2), 0x3e800000u);
+    expect("solve (0,0)", X.at<float>(0, 0), 0x00000000u);
+    // singular -> zeros
+    expect("solve singular", ((cv::Mat)(Z.inv() * I)).at<float>(1, 1), 0x00000000u);
+    // (6) cv::invert 3x3 closed form: diag(2,4,8) -> diag(.5,.25,.125)
+    cv::Mat Dg = cv::Mat::zeros(3, 3, CV_32F);
+    Dg.at<float>(0, 0) = 2; Dg.at<float>(1, 1) = 4; Dg.at<float>(2, 2) = 8;
+    cv::Mat Di = Dg.inv();
+    expect("inv (0,0)", Di.at<float>(0, 0), 0x3f000000u);
+    expect("inv (1,1)", Di.at<float>(1, 1), 0x3e800000u);
+    expect("inv (2,2)", Di.at<float>(2, 2), 0x3e000000u);
+    // I * D.inv(): the inverse on the right is evaluated (no solve)
+    expect("I*inv", ((cv::Mat)(I * Dg.inv())).at<float>(2, 2), 0x3e000000u);
+    // (7) an aliased destination reads its operands first: x = P*x + t with a permutation P
+    cv::Mat P = cv::Mat::zeros(3, 3, CV_32F), v(3, 1, CV_32F);
+    P.at<float>(0, 1) = 1; P.at<float>(1, 2) = 1; P.at<float>(2, 0) = 1;
+    v.at<float>(0) = 1; v.at<float>(1) = 2; v.at<float>(2) = 3;
+    v = P * v + zero3;
+    expect("aliased (0)", v.at<float>(0), 0x40000000u);
+    expect("aliased (1)", v.at<float>(1), 0x40400000u);
+    expect("aliased (2)", v.at<float>(2), 0x3f800000u);
+    std::printf("gemm: %d known answers wrong\n", bad);
+    return bad ? 8 : 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: test_host extract|batch|match|bow ...\n"); return 1; }
     const std::string mode = argv[1];
@@ -668,6 +753,7 @@ int main(int argc, char** argv) {
     if (mode == "f4" && argc >= 4) return run_file(do_f4, argv);
     if (mode == "threads" && argc >= 6) return run_threads(argc, argv);
     if (mode == "rt" && argc >= 3) return run_rt(argc, argv);
+    if (mode == "gemm") return run_gemm_kat();
     if (mode == "dropin" && argc >= 5) return run_dropin(argc, argv);
     std::fprintf(stderr, "bad arguments\n");
     return 1;

@@ -675,10 +675,19 @@ def test_cpp_dropin_call_pattern_is_bit_exact(tmp_path, batch):
 
 def test_scalar_pose_algebra_equals_the_cv_mat_expressions():
     """The per-frame tracking search computes R * x + t with a scalar routine instead of three cv::Mat temporaries per point
-    (host/ORBmatcher.cc: apply_rt): bit-identical to the cv::Mat expressions on 10^6 random poses x points, chained
-    application (camera 2 behind camera 1) included.  No GPU."""
+    (host/ORBmatcher.cc: apply_rt): bit-identical to the cv::Mat expressions -- evaluated as cv::gemm's small-matrix float block
+    with the addend folded in, cv_compat.h -- on 10^6 random poses x points, chained application (camera 2 behind camera 1)
+    included.  No GPU."""
     out = subprocess.check_output([BIN, "rt", "1000000"], timeout=180).decode()
     assert "1000000 poses x points, 0 differing floats" in out
+
+
+def test_cv_gemm_restatement_known_answers():
+    """cv_compat.h restates cv::gemm's two evaluation orders (the float small-matrix block every R*x+t of the matcher takes, the
+    double general path behind transposition flags), the folding of `A*B + C` into one call, cv::solve's LU and cv::invert's 3x3
+    closed form: hand-computed known answers where the orders differ (host/test_host.cc: run_gemm_kat).  No GPU."""
+    out = subprocess.run([BIN, "gemm"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "gemm: 0 known answers wrong" in out.stdout, out.stdout
 
 
 @pytest.mark.gpu
