@@ -129,6 +129,15 @@ int orbm_set_calibration(orbm_matcher* m, const orb_calibration* calib);
 /* Builds the 64x48 per-camera grid (round-to-cell insertion, ascending global indices) and uploads the frame. */
 int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** out);
 
+/* orbm_frame_create for a frame whose descriptors are (partly) still in HBM: for every camera c with d_desc[c] != NULL the rows
+ * N_c x 32 are read from that DEVICE pointer (16-byte aligned; e.g. orbx_device_descriptors of the extraction that produced
+ * the frame -- the caller guarantees they hold what f->desc[c] holds and stay unchanged until the frame's first search has
+ * returned); the other cameras' rows are taken from f->desc[c] as usual.  The 64x48 grid is built on the device (same
+ * round-to-cell arithmetic), nothing but x, y, uright, angle, octave and one index word per feature crosses the bus.
+ * d_desc == NULL: every camera from the host.  f->desc must be valid for every camera in any case: frames beyond 8192
+ * features or 4 cameras, and MORB_RESIDENT_FRAMES=0, take orbm_frame_create. */
+int orbm_frame_create_resident(orbm_matcher* m, const orbm_frame_desc* f, const uint8_t* const* d_desc, orbm_frame** out);
+
 /* Frame assembly ON THE DEVICE from HBM-resident extractor outputs -- the merge of reference src/Frame.cc:191-239,
  * ComputeStereoFromRGBD (:959-986: depth lookup at (int)kp.pt.y,(int)kp.pt.x, uRight = x - mbf/d, -1 where d <= 0) and
  * AssignFeaturesToGrid (:348-395) -- with no host round trip.  Undistortion is the identity (k1 == 0, :676-680).

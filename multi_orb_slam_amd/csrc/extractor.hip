@@ -1643,6 +1643,9 @@ struct orbx_extractor {
     bool cand_valid = false;         // h_cand / h_level_cnt hold the last run's candidates (k_compact ran)
     // (in-flight bookkeeping: see `inflight` below), orbx_finish not yet called
     std::chrono::steady_clock::time_point t_begin_async;
+    // MORB_EXTRACT_TIMELINE=1: where the synchronous orbx_extract spends its host time (sums, printed by orbx_destroy)
+    bool timeline = false; double tl_us[5] = {0, 0, 0, 0, 0}; long tl_n = 0;
+    std::chrono::steady_clock::time_point tl_sync0, tl_sync1;
     // up to two asynchronous runs may be in flight (the second one is the next timestep's, enqueued while the first one's
     // results are being matched): run r uses slot r & 1 of the count mirrors and of the completion events
     struct ChainGraph {  // captured kernel chain of one count slot (see orbx_run_impl)
@@ -1959,6 +1962,7 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     ORBX_TRY_HIP(hipHostGetDevicePointer((void**)&ex->d_h_oct, ex->h_oct, 0));
     for (int i = 0; i < 2; ++i) ORBX_TRY_HIP(hipEventCreateWithFlags(&ex->ev_done[i], hipEventDisableTiming | hipEventReleaseToSystem));
     { const char* e = getenv("MORB_HOST_OCTREE"); ex->device_octree = !(e && atoi(e) != 0); }
+    { const char* e = getenv("MORB_EXTRACT_TIMELINE"); ex->timeline = e && atoi(e) != 0; }
     { const char* e = getenv("MORB_CHAIN_GRAPH"); ex->use_graph = !(e && atoi(e) == 0); }
     ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
     { const char* e = getenv("MORB_PINNED_INGEST"); ex->pinned_ingest_env = !(e && atoi(e) == 0); }
@@ -1979,6 +1983,9 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
 
 void orbx_destroy(orbx_extractor* ex) {
     if (!ex) return;
+    if (ex->timeline && ex->tl_n)
+        fprintf(stderr, "orbx_extract timeline over %ld calls (us): upload %.1f | enqueue %.1f | wait %.1f | after-wait %.1f | copy-out %.1f\n", ex->tl_n,
+                ex->tl_us[0] / ex->tl_n, ex->tl_us[1] / ex->tl_n, ex->tl_us[2] / ex->tl_n, ex->tl_us[3] / ex->tl_n, ex->tl_us[4] / ex->tl_n);
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     for (int sl = 0; sl < 2; ++sl) for (int w = 0; w < orbx_extractor::CHAIN_WAYS; ++w) ex->chain[sl][w].destroy();
@@ -2389,7 +2396,9 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         ex->prof_valid[slot] = ex->profiling && ex->inflight == 0;  // (one set of stage events: not for overlapped runs)
         ++ex->run_seq; ++ex->inflight; ex->t_begin_async = t_begin;
         if (allow_async) return ORB_OK;
+        if (ex->timeline) ex->tl_sync0 = std::chrono::steady_clock::now();
         MORB_HIP(hipStreamSynchronize(st));
+        if (ex->timeline) ex->tl_sync1 = std::chrono::steady_clock::now();
         if (ex->h_oct[slot * (ex->n_cams + 1) + ex->n_cams] == 0) return finish_device_path(ex);
         ex->inflight = 0;
         std::fill(ex->n_out.begin(), ex->n_out.end(), 0);  // a level exceeded the device limits: redo the selection on the host
@@ -2558,8 +2567,10 @@ int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, con
     MORB_ARG(ex && n_cams == ex->n_cams && gray && width && height && stride && kps_out && desc_out && cap && n_out);
     int rc;
     MORB_HIP(hipSetDevice(ex->device));
+    const auto tl0 = std::chrono::steady_clock::now();
     for (int c = 0; c < n_cams; ++c)
         if ((rc = orbx_upload(ex, c, gray[c], width[c], height[c], stride[c]))) return rc;
+    const auto tl1 = std::chrono::steady_clock::now();
     // results through a pinned mirror the describe kernel writes itself (camera-major, packed): no D2H copies on the stream
     const bool own = ex->mirror_kps == nullptr;
     if (own) {
@@ -2569,6 +2580,7 @@ int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, con
         ex->mirror_kps = ex->own_mirror_kps.dp; ex->mirror_desc = ex->own_mirror_desc.dp; ex->mirror_cap = cap_total;
     }
     rc = orbx_run(ex);
+    const auto tl2 = std::chrono::steady_clock::now();
     // (the host-quadtree fallback describes from a host-built list with its own mirror bookkeeping: plain downloads there)
     const bool mirrored = own && ex->mirror_cap > 0 && ex->last_path != 2;
     if (own) { ex->mirror_kps = nullptr; ex->mirror_desc = nullptr; ex->mirror_cap = 0; }
@@ -2586,6 +2598,11 @@ int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, con
             memcpy(desc_out[c], ex->own_mirror_desc.p + (size_t)off * 32, (size_t)n_out[c] * 32);
         } else if ((rc = orbx_download(ex, c, kps_out[c], desc_out[c], cap[c]))) return rc;
         off += n_out[c];
+    }
+    if (ex->timeline) {
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        ex->tl_us[0] += us(tl0, tl1); ex->tl_us[1] += us(tl1, ex->tl_sync0); ex->tl_us[2] += us(ex->tl_sync0, ex->tl_sync1);
+        ex->tl_us[3] += us(ex->tl_sync1, tl2); ex->tl_us[4] += us(tl2, std::chrono::steady_clock::now()); ++ex->tl_n;
     }
     return ORB_OK;
 }

@@ -94,6 +94,37 @@ __global__ __launch_bounds__(256) void k_frame_fill(const CamFeat* __restrict__ 
 struct CamFeat4 { CamFeat c[4]; };
 MORB_PHASE_DECL(g_ph_fb);
 
+// orbm_frame_create_resident: the per-feature fields of a host-built frame arrive in ONE staging block --
+// x | y | uright | angle | octave | src (n dwords each; src = cam << 24 | row inside that camera) | cam_start (n_cams + 1) |
+// pad to 16 bytes | the descriptor rows of the cameras that are not resident, camera after camera --
+// and the descriptors of the resident cameras are read where the extractor left them in HBM.  The grid is built here,
+// with the host's arithmetic (round-to-cell insertion of src/Frame.cc:632-642: float subtract, float multiply, roundf).
+struct StagedFill {
+    const uint32_t* stage;      // NULL: not this mode
+    const uint4* d_desc[4];     // resident cameras: device rows; NULL: rows in the staging block from host_row0[c] on
+    int host_row0[4];
+    int desc_off;               // dword offset of the staged descriptor rows
+};
+
+__device__ __forceinline__ int frame_fill_staged(const StagedFill& S, int n, int n_cams, int g, float minX, float minY, float invW,
+                                                 float invH, float* __restrict__ x, float* __restrict__ y, float* __restrict__ ur,
+                                                 int* __restrict__ oct, float* __restrict__ ang, uint4* __restrict__ desc_g) {
+    const uint32_t* w = S.stage;
+    const float fx = __uint_as_float(w[g]), fy = __uint_as_float(w[(size_t)n + g]);
+    const uint32_t src = w[(size_t)5 * n + g];
+    const int cam = (int)(src >> 24), row = (int)(src & 0xffffffu);
+    x[g] = fx; y[g] = fy; ur[g] = __uint_as_float(w[(size_t)2 * n + g]);
+    ang[g] = __uint_as_float(w[(size_t)3 * n + g]); oct[g] = (int)w[(size_t)4 * n + g];
+    if (cam < n_cams) {
+        const uint4* rows = S.d_desc[cam] ? S.d_desc[cam] + 2 * (size_t)row
+                                          : reinterpret_cast<const uint4*>(w + S.desc_off) + 2 * ((size_t)S.host_row0[cam] + row);
+        desc_g[2 * g] = rows[0]; desc_g[2 * g + 1] = rows[1];
+    }
+    const int px = (int)roundf((fx - minX) * invW), py = (int)roundf((fy - minY) * invH);
+    if (cam < n_cams && px >= 0 && px < ORBM_GRID_COLS && py >= 0 && py < ORBM_GRID_ROWS) return (cam * ORBM_GRID_COLS + px) * ORBM_GRID_ROWS + py;
+    return -1;
+}
+
 __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int* __restrict__ cam_start_out, const int* __restrict__ d_counts,
                                                             int* __restrict__ n_total_out, int n_cams, int n_total, float mbf,
                                                             float minX, float minY, float invW, float invH,
@@ -102,7 +133,7 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
                                                             int* __restrict__ oct, float* __restrict__ ang,
                                                             orb_keypoint* __restrict__ kps_g, uint4* __restrict__ desc_g,
                                                             int* __restrict__ cell_start, int* __restrict__ items, HostMirror hm,
-                                                            const int* __restrict__ cell_of_in, int desc_rows) {
+                                                            const int* __restrict__ cell_of_in, int desc_rows, StagedFill staged) {
     // cell_of_in != NULL: the per-feature arrays and the cells were already written by the extractor's describe kernel
     // (FrameSink); only the counts, the grid and its item lists are produced here.
     extern __shared__ __attribute__((aligned(16))) int s_cells[];  // [ncell + 1] start | [ncell + 1] cursor | u16 items[8192]
@@ -117,6 +148,7 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
         for (int c = 0; c < n_cams; ++c) {
             CamFeat cf = cams4.c[c];
             if (d_counts) { cf.n = d_counts[c]; cf.base = base; }
+            if (staged.stage) { cf.base = (int)staged.stage[(size_t)6 * n_total + c]; cf.n = (int)staged.stage[(size_t)6 * n_total + c + 1] - cf.base; }
             s_cams[c] = cf;
             cam_start_out[c] = cf.base;
             base = cf.base + cf.n;
@@ -146,6 +178,7 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
         mycell[k] = -1;
         if (g < n_total) {
             mycell[k] = cell_of_in ? cell_of_in[g]
+                        : staged.stage ? frame_fill_staged(staged, n_total, n_cams, g, minX, minY, invW, invH, x, y, ur, oct, ang, desc_g)
                                    : frame_fill_one(cams, n_cams, g, mbf, minX, minY, invW, invH, x, y, ur, depth_out, oct, ang, kps_g, desc_g, hm);
             if (mycell[k] >= 0) atomicAdd(&s_cur[mycell[k]], 1);
         }
@@ -388,6 +421,77 @@ int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** ou
 
 
 
+// orbm_frame_create with the grid built on the device and, for the cameras whose descriptors are still in HBM, without the
+// descriptors crossing the bus again.  Frames beyond the single-workgroup build (8192 features, 4 cameras) take
+// orbm_frame_create (f->desc must be valid for every camera either way).
+int orbm_frame_create_resident(orbm_matcher* m, const orbm_frame_desc* f, const uint8_t* const* d_desc, orbm_frame** out) {
+    MORB_ARG(m && f && out);
+    MORB_ARG(f->n_total >= 0 && f->n_cams >= 1);
+    MORB_ARG(f->max_x > f->min_x && f->max_y > f->min_y);
+    const int n = f->n_total, n_cams = f->n_cams;
+    const int ncell = n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
+    const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int) + (size_t)8192 * sizeof(unsigned short);
+    static const bool off = [] { const char* e = getenv("MORB_RESIDENT_FRAMES"); return e && atoi(e) == 0; }();
+    if (off || n == 0 || n > 8192 || n_cams > 4 || lds_small > 150 * 1024) return orbm_frame_create(m, f, out);
+    MORB_ARG(f->un_x && f->un_y && f->octave && f->angle && f->uright && f->cam_of && f->local_of && f->desc);
+    MORB_HIP(hipSetDevice(m->device));
+    // per-camera row counts (the highest row a feature names + 1) and the camera starts of the global order
+    int rows[4] = {0, 0, 0, 0}, count[4] = {0, 0, 0, 0};
+    for (int g = 0; g < n; ++g) {
+        const int c = f->cam_of[g], l = f->local_of[g];
+        if (c < 0 || c >= n_cams) continue;       // (a feature of no camera: no cell, no descriptor -- as orbm_frame_create treats it)
+        MORB_ARG(l >= 0 && l < (1 << 24));
+        ++count[c];
+        if (l + 1 > rows[c]) rows[c] = l + 1;
+    }
+    StagedFill S;
+    memset(&S, 0, sizeof(S));
+    int host_rows = 0;
+    for (int c = 0; c < n_cams; ++c) {
+        const bool resident = d_desc && d_desc[c] && ((uintptr_t)d_desc[c] & 15) == 0;
+        S.d_desc[c] = resident ? reinterpret_cast<const uint4*>(d_desc[c]) : nullptr;
+        S.host_row0[c] = host_rows;
+        if (!resident) { MORB_ARG(rows[c] == 0 || f->desc[c]); host_rows += rows[c]; }
+    }
+    int rc;
+    orbm_frame* F = nullptr;
+    if ((rc = frame_shell(m, n, n_cams, f->min_x, f->min_y, f->max_x, f->max_y, false, &F))) return rc;
+    F->device_built = false;   // (no keypoint records: orbm_frame_download refuses them, as for orbm_frame_create)
+    int base = 0;
+    for (int c = 0; c < n_cams; ++c) { F->cam_start[c] = base; base += count[c]; }
+    F->cam_start[n_cams] = base;
+    const size_t nn = (size_t)n;
+    const size_t head = (6 * nn + (size_t)n_cams + 1 + 3) & ~(size_t)3;          // descriptor rows start 16-byte aligned
+    const size_t words = head + 8 * (size_t)host_rows;
+    if (m->stage_f_busy) { MORB_HIP(hipEventSynchronize(m->ev_stage_f)); m->stage_f_busy = false; }
+    if ((rc = m->stage_f.reserve(words * 4))) { orbm_frame_destroy(F); return rc; }
+    uint32_t* w = reinterpret_cast<uint32_t*>(m->stage_f.p);
+    memcpy(w, f->un_x, nn * 4); memcpy(w + nn, f->un_y, nn * 4); memcpy(w + 2 * nn, f->uright, nn * 4);
+    memcpy(w + 3 * nn, f->angle, nn * 4); memcpy(w + 4 * nn, f->octave, nn * 4);
+    for (int g = 0; g < n; ++g) {
+        const int c = f->cam_of[g];
+        w[5 * nn + g] = (c < 0 || c >= n_cams) ? 0xff000000u : ((uint32_t)c << 24) | (uint32_t)f->local_of[g];
+    }
+    for (int c = 0; c <= n_cams; ++c) w[6 * nn + c] = (uint32_t)F->cam_start[c];
+    for (int c = 0; c < n_cams; ++c)
+        if (!S.d_desc[c] && rows[c]) memcpy(w + head + 8 * (size_t)S.host_row0[c], f->desc[c], (size_t)rows[c] * 32);
+    m->stage_f.publish();
+    S.stage = reinterpret_cast<const uint32_t*>(m->stage_f.dp);
+    S.desc_off = (int)head;
+    CamFeat4 c4;
+    memset(&c4, 0, sizeof(c4));
+    HostMirror hm{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, orb_calibration{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    hipLaunchKernelGGL(k_frame_build_small, dim3(1), dim3(1024), lds_small, m->stream, c4, F->b->d_cam_start.p, (const int*)nullptr,
+                       F->b->d_ntotal.p, n_cams, n, 0.f, F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p,
+                       F->b->d_depth.p, F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_start.p,
+                       F->b->d_items.p, hm, (const int*)nullptr, F->desc_rows, S);
+    if (hipGetLastError() != hipSuccess) { orbm_frame_destroy(F); morb::set_error("k_frame_build_small launch failed"); return ORB_E_HIP; }
+    MORB_HIP(hipEventRecord(m->ev_stage_f, m->stream));
+    m->stage_f_busy = true;
+    *out = F;
+    return ORB_OK;
+}
+
 int orbm_frame_from_device(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,
                            float max_x, float max_y, orbm_frame** out) {
     MORB_ARG(out != nullptr);
@@ -538,7 +642,7 @@ int morb::frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams,
                            n_cams, n, mbf,
                            F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
                            F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_start.p,
-                           F->b->d_items.p, hm, sink_filled ? (const int*)F->b->d_cell_of.p : nullptr, F->desc_rows);
+                           F->b->d_items.p, hm, sink_filled ? (const int*)F->b->d_cell_of.p : nullptr, F->desc_rows, StagedFill{});
     } else {
         const int* n_dev = nullptr;
         if (d_counts) {

@@ -4,8 +4,11 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 #include "../../include/orbx.h"
+#include "resident.h"
 
 namespace ORB_SLAM2 {
 
@@ -23,6 +26,40 @@ static bool fail(const char* what, int rc) {
 const char* ORBextractor::LastError() { return orb_last_error(); }
 unsigned long ORBextractor::FailureCount() { return g_failures.load(std::memory_order_relaxed); }
 
+// ---- resident.h
+namespace resident {
+namespace {
+struct Entry { const void* owner; std::thread::id thread; const uint8_t* host_rows; const uint8_t* d_rows; int n; };
+std::mutex g_mu;
+std::vector<Entry> g_entries;
+std::atomic<unsigned long> g_served{0}, g_missed{0};
+}  // namespace
+void publish(const void* owner, const uint8_t* host_rows, const uint8_t* d_rows, int n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (Entry& e : g_entries)
+        if (e.owner == owner) { e = Entry{owner, std::this_thread::get_id(), host_rows, d_rows, n}; return; }
+    g_entries.push_back(Entry{owner, std::this_thread::get_id(), host_rows, d_rows, n});
+}
+void retire(const void* owner) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_entries.size(); ++i)
+        if (g_entries[i].owner == owner) { g_entries[i] = g_entries.back(); g_entries.pop_back(); return; }
+}
+const uint8_t* find(const uint8_t* rows, int n) {
+    if (!rows || n <= 0) return nullptr;
+    const std::thread::id me = std::this_thread::get_id();
+    std::lock_guard<std::mutex> lk(g_mu);   // (entries of other threads are only skipped: whoever publishes or retires holds the same lock)
+    for (const Entry& e : g_entries)
+        if (e.n == n && e.thread == me && e.d_rows && std::memcmp(rows, e.host_rows, (size_t)n * 32) == 0) {
+            g_served.fetch_add(1, std::memory_order_relaxed);
+            return e.d_rows;
+        }
+    g_missed.fetch_add(1, std::memory_order_relaxed);
+    return nullptr;
+}
+void stats(unsigned long* served, unsigned long* missed) { *served = g_served.load(); *missed = g_missed.load(); }
+}  // namespace resident
+
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST) {
     orbx_params p = {nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST};
@@ -34,10 +71,11 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     mvImagePyramid.resize(nlevels);
 }
 
-ORBextractor::~ORBextractor() { orbx_destroy(handle_); }
+ORBextractor::~ORBextractor() { resident::retire(this); orbx_destroy(handle_); }
 
 bool ORBextractor::EnsureHandle(int width, int height) {
     if (handle_ && width <= cap_w_ && height <= cap_h_) return true;
+    resident::retire(this);
     orbx_destroy(handle_);
     handle_ = nullptr;
     cap_w_ = width > cap_w_ ? width : cap_w_; cap_h_ = height > cap_h_ ? height : cap_h_;
@@ -65,8 +103,12 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     orb_keypoint* kp_ptr = reinterpret_cast<orb_keypoint*>(scratch_kps_.data());
     uint8_t* d_ptr = scratch_desc_.data();
     int n = 0;
+    resident::retire(this);   // (the device rows of the previous call are about to be overwritten)
     int rc = orbx_extract(handle_, 1, &img_ptr, &w, &h, &stride, &kp_ptr, &d_ptr, &cap, &n);
     if (rc) { fail("orbx_extract", rc); _keypoints.clear(); _descriptors.release(); return; }
+    // the rows stay where the describe kernel wrote them until this extractor's next call: a search of the frame built from them
+    // reads them there (resident.h), held against scratch_desc_ byte for byte
+    if (n > 0) resident::publish(this, scratch_desc_.data(), orbx_device_descriptors(handle_, 0), n);
     if (n == 0) {
         _keypoints.clear();
         _descriptors.release();
@@ -95,7 +137,10 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
     // one shared N-camera handle per calling thread (destroyed when the thread exits)
     struct BatchState {
         orbx_extractor* h = nullptr; std::vector<orbx_params> params; int w = 0, h_px = 0;
-        ~BatchState() { orbx_destroy(h); }
+        std::vector<std::vector<uint8_t> > ds;   // the last call's descriptors per camera (resident.h holds frames against them)
+        char slot[64];                           // &slot[i] = identity of camera i's published rows
+        void retire_all() { for (int i = 0; i < 64; ++i) resident::retire(&slot[i]); }
+        ~BatchState() { retire_all(); orbx_destroy(h); }
     };
     static thread_local BatchState B;
     orbx_extractor*& batch = B.h;
@@ -111,6 +156,7 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
     }
     bool same = batch && (int)batch_params.size() == n && mw <= bw && mh <= bh;
     for (int i = 0; same && i < n; ++i) same = std::memcmp(&ps[i], &batch_params[i], sizeof(orbx_params)) == 0;
+    B.retire_all();   // (the device rows of the previous call are about to be overwritten)
     if (!same) {
         orbx_destroy(batch); batch = nullptr;
         bw = std::max(bw, mw); bh = std::max(bh, mh);
@@ -122,7 +168,8 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
     std::vector<const uint8_t*> img(n);
     std::vector<int> w(n), h(n), st(n), cap(n), cnt(n, 0);
     std::vector<std::vector<cv::KeyPoint> > kp(n);
-    std::vector<std::vector<uint8_t> > ds(n);
+    std::vector<std::vector<uint8_t> >& ds = B.ds;
+    ds.resize(n);
     std::vector<orb_keypoint*> kp_ptr(n);
     std::vector<uint8_t*> d_ptr(n);
     for (int i = 0; i < n; ++i) {
@@ -142,6 +189,7 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
         keypoints[i].swap(kp[i]);
         descriptors[i].create(k, 32, CV_8U);
         std::memcpy(descriptors[i].ptr(0), ds[i].data(), (size_t)k * 32);
+        if (i < 64) resident::publish(&B.slot[i], ds[i].data(), orbx_device_descriptors(batch, i), k);
     }
 }
 

@@ -11,6 +11,7 @@
 #include <type_traits>
 #include "../../include/orbm.h"
 #include "../../include/orbv.h"
+#include "resident.h"
 
 namespace ORB_SLAM2 {
 
@@ -110,6 +111,7 @@ ORBmatcher::~ORBmatcher() {}   // (the device state belongs to the thread, not t
 
 void ORBmatcher::LastCallBreakdown(float* us3) { for (int k = 0; k < 3; ++k) us3[k] = tls.last_us[k]; }
 void ORBmatcher::FrameCacheStats(unsigned long* hits, unsigned long* misses) { *hits = tls.hits; *misses = tls.misses; }
+void ORBmatcher::ResidentStats(unsigned long* served, unsigned long* missed) { resident::stats(served, missed); }
 
 orbv_workspace* ORBmatcher::Bow() {
     if (!tls.w) {
@@ -244,6 +246,9 @@ bool flatten(const FrameOrKeyFrame& F, bool cam1_only, FlatFrame& ff) {
 // retries with 2*th, TrackLocalMap searches the same frame again, keyframes are fused into and searched for as long as they
 // live), so uploaded frames are cached per thread under the frame's IDENTITY (see CachedFrame; rounds 1-2 hashed all ~150 KB
 // an upload reads -- 87 us per call -- and trusted a 64-bit hash alone).  Least recently used of 8 entries is dropped.
+// A frame that is not cached goes up through orbm_frame_create_resident: per-feature fields in one staging block, the grid
+// built on the device, and the descriptor rows of every camera the calling thread has just extracted (resident.h: byte-equal
+// to what the extractor handed out) read from where the describe kernel left them instead of being sent again.
 // Returns NULL after a reported failure.
 template <class FrameOrKeyFrame>
 orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_only) {
@@ -254,12 +259,33 @@ orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_on
     if ((int)kun.size() < n || (int)ur.size() < n) { fail("device_frame (Frame arrays shorter than N)", ORB_E_ARG); return nullptr; }
     const int kind = std::is_same<FrameOrKeyFrame, KeyFrame>::value ? 1 : 0;
     const unsigned long id = (unsigned long)F.mnId;
+    // guard: everything an upload reads is either sampled or sized here -- the keypoint array's address, three records with their
+    // right coordinates, the image bounds, the sizes of the two index maps, and per camera the descriptor matrix's address, row
+    // count, first and last row.  MORB_FRAME_CACHE_FULL_HASH=1 hashes every byte instead (test_host holds the two
+    // against each other: a hit under the sampled guard must be a hit under the full hash).
     uint64_t guard = mix(0x243F6A8885A308D3ull, (uint64_t)(uintptr_t)kun.data());
+    static const bool full_hash = [] { const char* e = std::getenv("MORB_FRAME_CACHE_FULL_HASH"); return e && std::atoi(e) != 0; }();
+    {
+        const float bounds[4] = {(float)F.mnMinX, (float)F.mnMinY, (float)F.mnMaxX, (float)F.mnMaxY};
+        guard = hash_bytes(guard, bounds, sizeof(bounds));
+        guard = mix(guard, (uint64_t)F.keypoint_to_cam.size()); guard = mix(guard, (uint64_t)F.cont_idx_to_local_cam_idx.size());
+    }
     if (n > 0) {
         const int probe[3] = {0, n / 2, n - 1};
         for (int k = 0; k < 3; ++k) { guard = hash_bytes(guard, &kun[probe[k]], sizeof(cv::KeyPoint)); guard = hash_bytes(guard, &ur[probe[k]], sizeof(float)); }
-        const cv::Mat& d0 = cam1_only ? F.mDescriptors : F.mDescriptors_total[0];
-        if (!d0.empty()) guard = hash_bytes(guard, d0.ptr(0), 32);
+        auto sample = [&](const cv::Mat& d) {
+            guard = mix(guard, (uint64_t)(uintptr_t)d.data); guard = mix(guard, (uint64_t)d.rows);
+            if (d.empty()) return;
+            if (full_hash) { for (int r = 0; r < d.rows; ++r) guard = hash_bytes(guard, d.ptr(r), 32); return; }
+            guard = hash_bytes(guard, d.ptr(0), 32); guard = hash_bytes(guard, d.ptr(d.rows - 1), 32);
+        };
+        if (cam1_only) sample(F.mDescriptors);
+        else for (const cv::Mat& d : F.mDescriptors_total) sample(d);
+        if (full_hash) {
+            guard = hash_bytes(guard, kun.data(), (size_t)n * sizeof(cv::KeyPoint)); guard = hash_bytes(guard, ur.data(), (size_t)n * sizeof(float));
+            for (const auto& e : F.keypoint_to_cam) guard += mix(e.first, (uint64_t)e.second);                        // (order-free)
+            for (const auto& e : F.cont_idx_to_local_cam_idx) guard += mix(e.first * 31 + 7, (uint64_t)e.second);
+        }
     }
     ThreadState& T = tls;
     ++T.clock;
@@ -270,18 +296,30 @@ orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_on
         else if (victim->fr && c.stamp < victim->stamp) victim = &c;
     }
     ++T.misses;
-    // the evicted entry goes first: its buffers are recycled once the matcher's stream has drained, which it has now (the
-    // previous search ended with a synchronisation) and would not have right behind the new frame's upload (measured: 13 us
-    // of every SearchByProjection went into waiting for the unpack kernel just launched)
-    if (victim->fr) { orbm_frame_destroy(victim->fr); victim->fr = nullptr; }
+    // everything that can fail on the caller's data happens before an entry is given up
     FlatFrame ff;
     if (!flatten(F, cam1_only, ff)) {
         fail("device_frame (a feature without an entry in keypoint_to_cam / cont_idx_to_local_cam_idx, or without a descriptor row)", ORB_E_ARG);
         return nullptr;
     }
+    const uint8_t* dres[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool any = false;
+    if (ff.d.n_cams <= 4) {
+        if (cam1_only) { dres[0] = resident::find(F.mDescriptors.ptr(0), F.mDescriptors.isContinuous() ? F.mDescriptors.rows : 0); any = dres[0] != nullptr; }
+        else for (int c = 0; c < ff.d.n_cams; ++c) {
+            const cv::Mat& d = F.mDescriptors_total[c];
+            if (d.empty() || !d.isContinuous()) continue;
+            dres[c] = resident::find(d.ptr(0), d.rows);
+            any |= dres[c] != nullptr;
+        }
+    }
+    // a full cache gives up its least recently used entry now: its buffers are recycled once the matcher's stream has drained,
+    // which it has at this point (the previous search ended with a synchronisation) and would not have right behind the new
+    // frame's upload (measured: 13 us of every SearchByProjection went into waiting for the kernel just launched)
+    if (victim->fr) { orbm_frame_destroy(victim->fr); victim->fr = nullptr; }
     orbm_frame* fr = nullptr;
-    const int rc = orbm_frame_create(m, &ff.d, &fr);
-    if (rc) { fail("orbm_frame_create", rc); return nullptr; }
+    const int rc = orbm_frame_create_resident(m, &ff.d, any ? dres : nullptr, &fr);
+    if (rc) { fail("orbm_frame_create_resident", rc); return nullptr; }
     victim->kind = kind; victim->id = id; victim->guard = guard; victim->n = n; victim->cam1 = cam1_only; victim->fr = fr; victim->stamp = T.clock;
     return fr;
 }

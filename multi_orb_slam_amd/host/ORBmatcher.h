@@ -127,6 +127,9 @@ public:
     // and the hit / miss counts of the calling thread's cache of uploaded frames
     static void LastCallBreakdown(float* us3);
     static void FrameCacheStats(unsigned long* hits, unsigned long* misses);
+    // process-wide: descriptor matrices of uploaded frames that were found still in HBM where ORBextractor left them (byte-equal,
+    // same thread: host/resident.h) / that were sent from the host
+    static void ResidentStats(unsigned long* served, unsigned long* missed);
     // test hook: R * x + t (3x3, 3x1 CV_32F) through the scalar routine the per-frame tracking search uses instead of three
     // cv::Mat temporaries per point; host/test_host `rt` compares it with the cv::Mat expression bit for bit
     static void DebugApplyRt(const cv::Mat& R, const cv::Mat& t, const float* x, float* out);

@@ -1,0 +1,25 @@
+// resident.h -- internal to libmorb_host.so: what ORBextractor::operator() / ExtractBatch left in HBM, for ORBmatcher's frame
+// upload.  The reference builds a Frame from the two extractor calls (src/Frame.cc:182-185) and searches it a moment later
+// (src/Tracking.cc:1267): the 32-byte descriptor rows the matcher needs on the device are the rows the extractor wrote
+// there, so they need not cross the bus again.  Nothing is taken on trust: an entry serves a descriptor matrix only if
+//   * the extraction ran on the CALLING thread (the next extraction of that extractor, which overwrites the device rows,
+//     is then sequenced behind the search that reads them), and
+//   * the matrix holds, byte for byte, the rows the extractor handed out (memcmp against the extractor's host copy) --
+//     pointer identity, frame ids or sequence numbers are not consulted.
+#pragma once
+#include <cstdint>
+
+namespace ORB_SLAM2 {
+namespace resident {
+
+// `owner` identifies the publishing extractor (or batch slot); a second publish by the same owner replaces the first.
+// host_rows / d_rows: n x 32 bytes on the host / on the device, both valid until the owner's next publish or retire.
+void publish(const void* owner, const uint8_t* host_rows, const uint8_t* d_rows, int n);
+void retire(const void* owner);
+// device rows equal to the n x 32 bytes at `rows`, published by the calling thread; NULL if there are none
+const uint8_t* find(const uint8_t* rows, int n);
+// inspection (tests / bench): lookups served from HBM / not served, on all threads
+void stats(unsigned long* served, unsigned long* missed);
+
+}  // namespace resident
+}  // namespace ORB_SLAM2

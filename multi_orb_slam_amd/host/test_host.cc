@@ -546,9 +546,11 @@ static int run_dropin(int argc, char** argv) {
     FILE* f = std::fopen(argv[3], "wb");
     unsigned long hits = 0, misses = 0;
     ORBmatcher::FrameCacheStats(&hits, &misses);
-    const float meds[12] = {(float)med(t_e0), (float)med(t_e1), (float)med(t_fr), (float)med(t_s), (float)med(t_calls), (float)med(t_loop),
+    unsigned long served = 0, unserved = 0;
+    ORBmatcher::ResidentStats(&served, &unserved);
+    const float meds[14] = {(float)med(t_e0), (float)med(t_e1), (float)med(t_fr), (float)med(t_s), (float)med(t_calls), (float)med(t_loop),
                             (float)med(t_brk[0]), (float)med(t_brk[1]), (float)med(t_brk[2]), (float)hits, (float)misses,
-                            (float)(ORBmatcher::FailureCount() + ORBextractor::FailureCount())};
+                            (float)(ORBmatcher::FailureCount() + ORBextractor::FailureCount()), (float)served, (float)unserved};
     put(f, meds, sizeof(meds));
     for (double v : t_calls) { const float x = (float)v; put(f, &x, 4); }
     for (int c = 0; c < 2; ++c) {

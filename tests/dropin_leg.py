@@ -34,9 +34,9 @@ def run(width=640, height=480, nf=(1000, 500), T=12, iters=200, warmup=30, batch
         fh.write(blob)
     subprocess.check_call([BIN, "dropin", sp, op, "1" if batch else "0"], timeout=180)
     buf = open(op, "rb").read()
-    meds = np.frombuffer(buf, np.float32, 12, 0)
-    per = np.frombuffer(buf, np.float32, iters, 48)[1:]        # (step 0 has no last frame to search)
-    off = 48 + 4 * iters
+    meds = np.frombuffer(buf, np.float32, 14, 0)
+    per = np.frombuffer(buf, np.float32, iters, 56)[1:]        # (step 0 has no last frame to search)
+    off = 56 + 4 * iters
     assert meds[11] == 0, "%d class calls failed" % int(meds[11])
     out = {"pattern": "ExtractBatch + SearchByProjection" if batch else "2 x operator() + SearchByProjection",
            "extract_cam0_us": round(float(meds[0]), 1), "extract_cam1_us": round(float(meds[1]), 1),
@@ -44,6 +44,7 @@ def run(width=640, height=480, nf=(1000, 500), T=12, iters=200, warmup=30, batch
            "search_breakdown_us": {"reference_host_projection": round(float(meds[6]), 1), "frame_hash_and_upload": round(float(meds[7]), 1),
                                    "device_search": round(float(meds[8]), 1)},
            "frame_cache": {"hits": int(meds[9]), "misses": int(meds[10])},
+           "descriptors_found_in_hbm": {"served": int(meds[12]), "sent_from_host": int(meds[13])},
            "class_calls_us": round(float(np.median(per)), 1), "class_calls_p5_us": round(float(np.percentile(per, 5)), 1),
            "class_calls_p95_us": round(float(np.percentile(per, 95)), 1), "loop_us": round(float(meds[5]), 1),
            "dropin_fps": round(1e6 / float(np.median(per)), 1), "steps": int(iters)}
