@@ -1644,7 +1644,7 @@ struct orbx_extractor {
     // (in-flight bookkeeping: see `inflight` below), orbx_finish not yet called
     std::chrono::steady_clock::time_point t_begin_async;
     // MORB_EXTRACT_TIMELINE=1: where the synchronous orbx_extract spends its host time (sums, printed by orbx_destroy)
-    bool timeline = false; double tl_us[5] = {0, 0, 0, 0, 0}; long tl_n = 0;
+    bool timeline = false; double tl_us[5] = {0, 0, 0, 0, 0}; long tl_n = 0, tl_calls = 0;
     std::chrono::steady_clock::time_point tl_sync0, tl_sync1;
     // up to two asynchronous runs may be in flight (the second one is the next timestep's, enqueued while the first one's
     // results are being matched): run r uses slot r & 1 of the count mirrors and of the completion events
@@ -2599,7 +2599,7 @@ int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, con
         } else if ((rc = orbx_download(ex, c, kps_out[c], desc_out[c], cap[c]))) return rc;
         off += n_out[c];
     }
-    if (ex->timeline) {
+    if (ex->timeline && ++ex->tl_calls > 10) {   // (the first calls load code objects and build tables)
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         ex->tl_us[0] += us(tl0, tl1); ex->tl_us[1] += us(tl1, ex->tl_sync0); ex->tl_us[2] += us(ex->tl_sync0, ex->tl_sync1);
         ex->tl_us[3] += us(ex->tl_sync1, tl2); ex->tl_us[4] += us(tl2, std::chrono::steady_clock::now()); ++ex->tl_n;

@@ -52,6 +52,7 @@ struct ThreadState {
     float last_us[3] = {0, 0, 0};   // host query building / frame (lookup + upload) / device search of the last projection search
     std::vector<orbm_query> q;      // query scratch of the per-frame tracking search
     std::vector<MapPoint*> qmp;
+    std::vector<int> idx_a, idx_b;  // index-table scratch of flatten() and of the tracking search (never live at the same time)
     ~ThreadState() {
         for (CachedFrame& c : cache) if (c.fr) orbm_frame_destroy(c.fr);
         orbm_destroy(m);
@@ -208,8 +209,12 @@ struct FlatFrame {  // orbm_frame_desc backing store built from a Frame
 // against the reference's own headers and the stand-in of slam_types.h use the same code), into a flat array indexed by the
 // global feature index; a feature without an entry reads -1.
 struct IndexTable {
-    std::vector<int> v;
-    template <class Map> IndexTable(const Map& m, size_t n) : v(n, -1) {
+    std::vector<int> own;
+    std::vector<int>& v;     // `own`, or scratch the caller keeps from call to call (no allocation per frame)
+    template <class Map> IndexTable(const Map& m, size_t n) : v(own) { fill(m, n); }
+    template <class Map> IndexTable(const Map& m, size_t n, std::vector<int>& scratch) : v(scratch) { fill(m, n); }
+    template <class Map> void fill(const Map& m, size_t n) {
+        v.assign(n, -1);
         for (const auto& e : m) if ((size_t)e.first < n) v[(size_t)e.first] = e.second;
     }
     int at(size_t g) const { return g < v.size() ? v[g] : -1; }
@@ -221,7 +226,7 @@ bool flatten(const FrameOrKeyFrame& F, bool cam1_only, FlatFrame& ff) {
     ff.x.resize(n); ff.y.resize(n); ff.ang.resize(n); ff.ur.resize(n); ff.oct.resize(n); ff.cam.resize(n); ff.loc.resize(n);
     const std::vector<cv::KeyPoint>& kun = cam1_only ? F.mvKeysUn : F.mvKeysUn_total;
     const std::vector<float>& ur = cam1_only ? F.mvuRight : F.mvuRight_total;
-    const IndexTable cams(F.keypoint_to_cam, cam1_only ? 0 : n), locs(F.cont_idx_to_local_cam_idx, cam1_only ? 0 : n);
+    const IndexTable cams(F.keypoint_to_cam, cam1_only ? 0 : n, tls.idx_a), locs(F.cont_idx_to_local_cam_idx, cam1_only ? 0 : n, tls.idx_b);
     for (int g = 0; g < n; ++g) {
         ff.x[g] = kun[g].pt.x; ff.y[g] = kun[g].pt.y; ff.ang[g] = kun[g].angle; ff.oct[g] = kun[g].octave;
         ff.ur[g] = ur[g];
@@ -297,7 +302,7 @@ orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_on
     }
     ++T.misses;
     // everything that can fail on the caller's data happens before an entry is given up
-    FlatFrame ff;
+    static thread_local FlatFrame ff;   // (seven arrays of n: their storage is kept from frame to frame)
     if (!flatten(F, cam1_only, ff)) {
         fail("device_frame (a feature without an entry in keypoint_to_cam / cont_idx_to_local_cam_idx, or without a descriptor row)", ORB_E_ARG);
         return nullptr;
@@ -1200,7 +1205,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
 #ifndef MORB_VERBATIM_MAT_ALGEBRA
     const Rt Pcw = load_rt(Rcw, tcw), Pcam21 = load_rt(mRcam21, mtcam21);
 #endif
-    const IndexTable cam_of(LastFrame.keypoint_to_cam, LastFrame.N_total > 0 ? LastFrame.N_total : 0);
+    const IndexTable cam_of(LastFrame.keypoint_to_cam, LastFrame.N_total > 0 ? LastFrame.N_total : 0, tls.idx_a);   // (device_frame above is done with it)
     for (int i = 0; i < LastFrame.N_total; i++) {
         MapPoint* pMP = LastFrame.mvpMapPoints[i];
         if (!pMP) continue;
