@@ -566,13 +566,72 @@ __device__ __forceinline__ unsigned fast_may_be_corner_x4(const uint32_t* t32, i
     return pass;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict__ L, const int2* __restrict__ cell_map,
+// fast_score_9_16 for TWO pixels at once on packed 16-bit lanes (round 4): the differences centre - ring fit 16 bits, so the
+// 16 subtractions and the 80 min / max of the log-step arc minima run as v_pk_sub_i16 / v_pk_min_i16 / v_pk_max_i16 on a pair
+// of survivors per lane: ~60 vector instructions per pixel instead of ~145.  Returns score(t0) | score(t1) << 16.
+__device__ __forceinline__ uint32_t fast_score_9_16_x2(const uint8_t* t0, const uint8_t* t1) {
+    auto ring2 = [&](int off) { return (uint32_t)t0[off] | ((uint32_t)t1[off] << 16); };
+    const fq_s16x2 v = __builtin_bit_cast(fq_s16x2, ring2(0));
+    fq_s16x2 d[16];
+    constexpr int R[16] = {3 * TILE_PITCH, 3 * TILE_PITCH + 1, 2 * TILE_PITCH + 2, 1 * TILE_PITCH + 3, 3, -1 * TILE_PITCH + 3,
+                           -2 * TILE_PITCH + 2, -3 * TILE_PITCH + 1, -3 * TILE_PITCH, -3 * TILE_PITCH - 1, -2 * TILE_PITCH - 2,
+                           -1 * TILE_PITCH - 3, -3, 1 * TILE_PITCH - 3, 2 * TILE_PITCH - 2, 3 * TILE_PITCH - 1};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - __builtin_bit_cast(fq_s16x2, ring2(R[k]));
+    fq_s16x2 lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { lo2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]); hi2[k] = __builtin_elementwise_max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { lo4[k] = __builtin_elementwise_min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = __builtin_elementwise_max(hi2[k], hi2[(k + 2) & 15]); }
+    fq_s16x2 sp = {-256, -256}, sm = {256, 256};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const fq_s16x2 lo9 = __builtin_elementwise_min(__builtin_elementwise_min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const fq_s16x2 hi9 = __builtin_elementwise_max(__builtin_elementwise_max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        sp = __builtin_elementwise_max(sp, lo9);
+        sm = __builtin_elementwise_min(sm, hi9);
+    }
+    const fq_s16x2 zero = {0, 0}, one = {1, 1};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(sp, zero - sm) - one);
+}
+
+// 2^20 / d rounded up, for d in 1 .. 127: i / d == (i * inv) >> 20 whenever i * d < 2^20 (the index splits of the cell kernel).
+// A table instead of a scalar integer division per workgroup (~40 scalar instructions each, four of them at the head of
+// every cell: 185 of the kernel's 400 scalar instructions).
+__device__ const unsigned d_inv20[128] = {
+#define I20(d) ((d) ? ((1u << 20) + (d) - 1) / ((d) ? (d) : 1) : 0u)
+#define I20_8(b) I20(b), I20(b + 1), I20(b + 2), I20(b + 3), I20(b + 4), I20(b + 5), I20(b + 6), I20(b + 7)
+    I20_8(0), I20_8(8), I20_8(16), I20_8(24), I20_8(32), I20_8(40), I20_8(48), I20_8(56),
+    I20_8(64), I20_8(72), I20_8(80), I20_8(88), I20_8(96), I20_8(104), I20_8(112), I20_8(120)
+#undef I20_8
+#undef I20
+};
+
+// k_fast_cells<NT, GW>: NT threads per cell, GW (4 or 8) adjacent pixels per lane in the quick test.  <128, 8> is the
+// throughput form (fewest instructions per cell: rigs whose cells fill the chip several times over); <256, 4> the latency
+// form (a cell's phases spread over four waves: 10.2 against 11.7 us for 2 x 640x480, where the launch is one round of cells).
+inline size_t fast_cells_lds(int cell_h_max, int cell_px_max) {   // the kernel's carve-up, in bytes
+    return (size_t)(cell_h_max + 6) * TILE_PITCH + (size_t)(cell_h_max + 2) * SCORE_PITCH + (size_t)((cell_px_max + 1) & ~1) * 2 +
+           (size_t)((cell_px_max + 63) / 64 * 2) * 2 * 4;
+}
+template <int FAST_NT, int GW>
+__global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restrict__ L, const int2* __restrict__ cell_map,
                                                     const uint8_t* __restrict__ pyr, size_t cam_pitch, int max_levels,
-                                                    int* __restrict__ cell_cnt, uint32_t* __restrict__ cell_items) {
-    __shared__ alignas(16) uint8_t tile_raw[(CELL_MAX + 6) * TILE_PITCH];
-    __shared__ alignas(16) uint8_t score[(CELL_MAX + 2) * SCORE_PITCH];
-    __shared__ unsigned short s_surv[CELL_MAX * CELL_MAX];  // pixels that pass the quick test
-    __shared__ unsigned int s_max[CELL_MAX * CELL_MAX / 32];  // bit p: pixel p is a strict local maximum with a score >= minTh
+                                                    int* __restrict__ cell_cnt, uint32_t* __restrict__ cell_items,
+                                                    int cell_h_max, int cell_px_max) {
+    // LDS sized at launch for the largest cell of the rig (fast_cells_lds: the reference's 30-pixel cells take 7 KB, so that
+    // sixteen two-wave cells fit a CU; the 64 x 64 worst case this build supports would take 19 KB):
+    // tile rows (pitch TILE_PITCH) | score rows (pitch SCORE_PITCH) | survivor list | the two bitmaps
+    extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
+    uint8_t* tile_raw = fast_lds;
+    uint8_t* score = tile_raw + (cell_h_max + 6) * TILE_PITCH;
+    unsigned short* s_surv = reinterpret_cast<unsigned short*>(score + (cell_h_max + 2) * SCORE_PITCH);  // pixels that pass the quick test
+    // bit p of s_max: pixel p (row-major inside the scored rectangle) is a strict local maximum with a score >= minTh;
+    // of s_ini: ... and its score reaches iniTh.  s_pref[j]: set bits of the chosen bitmap in front of its 64-bit word j.
+    const int bm_words = (cell_px_max + 63) / 64 * 2;
+    unsigned int* s_max = reinterpret_cast<unsigned int*>(s_surv + ((cell_px_max + 1) & ~1));
+    unsigned int* s_ini = s_max + bm_words;
+    __shared__ int s_pref[64];
     __shared__ int s_any, s_nsurv;
 
     // Workgroups go to the 8 XCDs round robin, each XCD has an L2 of its own, and neighbouring cells share the 128-byte lines
@@ -580,10 +639,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
     // cells (a band of rows of a level) instead of every eighth cell of all of them (FETCH_SIZE of this kernel: 4.4 x the
     // pyramid bytes before -- every line was pulled into several L2s).  Affinity only: any placement computes the same.
     const int cell = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int2 cm = cell_map[cell];  // {cam * max_levels + level, local cell index}
-    const LevelInfo Lv = L[cm.x];
-    const int cam = cm.x / max_levels;
-    const int ci = cm.y / Lv.n_cols, cj = cm.y - ci * Lv.n_cols;
+    const int2 cm = cell_map[cell];  // {cam * max_levels + level | cell column << 12 | cell row << 22, local cell index}
+    const int blk = cm.x & 0xfff, cj = (cm.x >> 12) & 0x3ff, ci = (int)((unsigned)cm.x >> 22);
+    const LevelInfo Lv = L[blk];
+    const int cam = blk / max_levels;
     // scored rectangle of this cell in level coordinates (App. A-3)
     const int x0 = EDGE_THRESHOLD + cj * Lv.w_cell, y0 = EDGE_THRESHOLD + ci * Lv.h_cell;
     const int cw = min(x0 + Lv.w_cell, Lv.w - EDGE_THRESHOLD) - x0;
@@ -596,7 +655,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
     const uint8_t* img = pyr + cam * cam_pitch + Lv.pyr_off;
     const int tw = cw + 6, th = ch + 6;
     // p / cw (and i / ndw below) for p < 70 * 70 by multiplication: exact because p * divisor < 2^20 (divisors <= 70)
-    const unsigned inv_cw = ((1u << 20) + cw - 1) / cw;
+    const unsigned inv_cw = d_inv20[cw];
 
     // stage the tile (origin x0-3, y0-3; always inside the level) dword by dword: the rows of a level start on 64-byte
     // boundaries, so the global dwords that cover columns [x0-3, x0-3+tw) are fetched whole (byte loads cost an address
@@ -604,10 +663,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
     // misalignment `sh` on the way in, so that the tile's origin is dword-aligned in LDS (the packed quick test relies on it).
     // Reads stay inside the row: the last dword fetched ends before column w - 5.
     const int sh = (x0 - 3) & 3, ndw = (tw + 3) >> 2;
-    const unsigned inv_ndw = ((1u << 20) + ndw - 1) / ndw;
+    const unsigned inv_ndw = d_inv20[ndw];
     {
         const uint8_t* src = img + (size_t)(y0 - 3) * Lv.stride + (x0 - 3 - sh);
-        for (int i = tid; i < ndw * th; i += 256) {
+        for (int i = tid; i < ndw * th; i += FAST_NT) {
             const int ty = (int)(((unsigned)i * inv_ndw) >> 20), k = i - ty * ndw;
             const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (size_t)ty * Lv.stride + 4 * k);
             const uint32_t lo = g[0], hi = sh ? g[1] : 0u;
@@ -615,96 +674,100 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo* __restrict_
         }
     }
     const uint8_t* tile = tile_raw;
-    for (int i = tid; i < (ch + 2) * (SCORE_PITCH / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
-    if (tid < CELL_MAX * CELL_MAX / 32) s_max[tid] = 0;
+    for (int i = tid; i < (ch + 2) * (SCORE_PITCH / 4); i += FAST_NT) reinterpret_cast<uint32_t*>(score)[i] = 0;
+    static_assert(CELL_MAX * CELL_MAX / 32 <= FAST_NT && (GW == 4 || GW == 8), "one bitmap word per thread; four or eight pixels per lane");
+    if (tid < bm_words) { s_max[tid] = 0; s_ini[tid] = 0; }
     if (tid == 0) { s_any = 0; s_nsurv = 0; }
     __syncthreads();
 
-    // pass 1: quick test on every pixel, four adjacent pixels per lane (fast_may_be_corner_x4); survivors compacted (any order)
-    // so that pass 2 runs the full score on dense lanes
+    // pass 1: quick test on every pixel, EIGHT adjacent pixels per lane (two fast_may_be_corner_x4 on neighbouring dwords, which
+    // share their loads); survivors compacted (any order) so that pass 2 runs the full score on dense lanes.  What a lane spends
+    // around the test -- index split, wave scan, the slot from the block counter -- is per lane, not per pixel: with eight pixels
+    // per lane and two waves per cell a 30 x 30 cell costs ~440 vector instructions here instead of ~610 (four pixels, four waves).
     const int lane = tid & 63;
-    const int gpr = (cw + 3) >> 2, ngroups = gpr * ch;               // groups of four per row
-    const unsigned inv_gpr = ((1u << 20) + gpr - 1) / gpr;           // (g / gpr exact: g * gpr < 2^20)
-    for (int base = 0; base < ngroups; base += 256) {
+    const int gpr = (cw + GW - 1) / GW, ngroups = gpr * ch;          // groups of GW per row
+    const unsigned inv_gpr = d_inv20[gpr];                           // (g / gpr exact: g * gpr < 2^20)
+    for (int base = 0; base < ngroups; base += FAST_NT) {
         const int g = base + tid;
-        unsigned m4 = 0;
+        unsigned m8 = 0;
         int p0 = 0;
         if (g < ngroups) {
             const int py = (int)(((unsigned)g * inv_gpr) >> 20), gx = g - py * gpr;
-            m4 = fast_may_be_corner_x4(reinterpret_cast<const uint32_t*>(tile_raw) + (py + 3) * (TILE_PITCH / 4) + gx, Lv.min_th + 1);
-            const int left = cw - 4 * gx;                            // pixels of this group inside the scored rectangle
-            if (left < 4) m4 &= (1u << left) - 1u;
-            p0 = py * cw + 4 * gx;
+            const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile_raw) + (py + 3) * (TILE_PITCH / 4) + (GW / 4) * gx;
+            m8 = fast_may_be_corner_x4(t32, Lv.min_th + 1);
+            const int left = cw - GW * gx;                           // pixels of this group inside the scored rectangle
+            if (GW == 8 && left > 4) m8 |= fast_may_be_corner_x4(t32 + 1, Lv.min_th + 1) << 4;   // (the second dword's reads stay inside the staged tile row then)
+            if (left < GW) m8 &= (1u << left) - 1u;
+            p0 = py * cw + GW * gx;
         }
-        const int cnt = __popc(m4);
+        const int cnt = __popc(m8);
         const int incl = wave_incl_scan(cnt);
         const int total = __builtin_amdgcn_readlane(incl, 63);
         int wbase = 0;
         if (lane == 0 && total) wbase = atomicAdd(&s_nsurv, total);
         int pos = __builtin_amdgcn_readfirstlane(wbase) + incl - cnt;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((m4 >> j) & 1u) s_surv[pos++] = (unsigned short)(p0 + j);
+        for (int j = 0; j < GW; ++j)
+            if ((m8 >> j) & 1u) s_surv[pos++] = (unsigned short)(p0 + j);
     }
     __syncthreads();
+    // pass 2: the full score, two survivors per lane on packed 16-bit lanes (an odd survivor count scores the last one twice)
     const int nsurv = s_nsurv;
-    for (int i = tid; i < nsurv; i += 256) {
-        const int p = s_surv[i];
-        const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
-        int s = fast_score_9_16(&tile[(py + 3) * TILE_PITCH + px + 3]);
-        s = s >= Lv.min_th ? s : 0;  // "not a corner at minTh" stores 0, like FAST_t's zeroed score rows
-        score[(py + 1) * SCORE_PITCH + px + 1] = (uint8_t)s;
+    for (int i = tid; 2 * i < nsurv; i += FAST_NT) {
+        const int pa = s_surv[2 * i], pb = s_surv[min(2 * i + 1, nsurv - 1)];
+        const int ya = (int)(((unsigned)pa * inv_cw) >> 20), xa = pa - ya * cw;
+        const int yb = (int)(((unsigned)pb * inv_cw) >> 20), xb = pb - yb * cw;
+        const uint32_t s2 = fast_score_9_16_x2(&tile[(ya + 3) * TILE_PITCH + xa + 3], &tile[(yb + 3) * TILE_PITCH + xb + 3]);
+        const int sa = (int)(short)(s2 & 0xffffu), sb = (int)(short)(s2 >> 16);
+        // "not a corner at minTh" stores 0, like FAST_t's zeroed score rows
+        score[(ya + 1) * SCORE_PITCH + xa + 1] = (uint8_t)(sa >= Lv.min_th ? sa : 0);
+        score[(yb + 1) * SCORE_PITCH + xb + 1] = (uint8_t)(sb >= Lv.min_th ? sb : 0);
     }
     __syncthreads();
 
     // Strict 8-neighbour maxima: only a pixel with a score can be one, so the pass runs over the survivor list (dense lanes,
-    // a tenth of the cell) and leaves one bit per maximum (bit p of the cell's row-major pixel index).
+    // a tenth of the cell) and leaves one bit per maximum in s_max, and in s_ini when the score reaches iniTh (the cell keeps
+    // those alone if there is any: reference :809-817 retries with minTh only when the cell is empty at iniTh).
     int any_ini = 0;
-    for (int i = tid; i < nsurv; i += 256) {
+    for (int i = tid; i < nsurv; i += FAST_NT) {
         const int p = s_surv[i];
         const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
         const uint8_t* c = &score[(py + 1) * SCORE_PITCH + px + 1];
         const int s = c[0];
-        if (s > 0 && s > c[-1] && s > c[1] && s > c[-SCORE_PITCH - 1] && s > c[-SCORE_PITCH] && s > c[-SCORE_PITCH + 1] &&
-            s > c[SCORE_PITCH - 1] && s > c[SCORE_PITCH] && s > c[SCORE_PITCH + 1]) {
+        const int m = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SCORE_PITCH - 1], (int)c[-SCORE_PITCH])),
+                          max(max((int)c[-SCORE_PITCH + 1], (int)c[SCORE_PITCH - 1]), max((int)c[SCORE_PITCH], (int)c[SCORE_PITCH + 1])));
+        if (s > m) {   // (s > m >= 0: it has a score)
             atomicOr(&s_max[p >> 5], 1u << (p & 31));
-            any_ini |= (s >= Lv.ini_th);
+            if (s >= Lv.ini_th) { atomicOr(&s_ini[p >> 5], 1u << (p & 31)); any_ini = 1; }
         }
     }
     if (any_ini) s_any = 1;  // benign race: all writers store 1
     __syncthreads();
 
-    // Ordered output by wave 0: candidates in row-major order, exactly FAST_t's emission order.  Lane j owns pixels
-    // 64j .. 64j+63 (one 64-bit word of the bitmap); a wave prefix sum of the per-lane counts gives every maximum its position.
+    // Ordered output: candidates in row-major order, exactly FAST_t's emission order.  Wave 0 counts the chosen bitmap's 64-bit
+    // words (lane j: pixels 64j .. 64j+63) and leaves their prefix sums; every maximum then finds its own position -- the
+    // word's prefix plus the set bits below its own -- and stores itself (round 3 walked the bits of every word one by one on
+    // wave 0: two dependent loops of up to 64 steps on one wave of the four).
+    const unsigned int* bm = s_any ? s_ini : s_max;
     if (tid < 64) {
-        const int T = s_any ? Lv.ini_th : Lv.min_th;  // reference :809-817: retry with minTh only if the cell is empty
-        uint32_t* slot = cell_items + Lv.slot_base + (size_t)cm.y * Lv.slot_cap;
-        unsigned long long w = (unsigned long long)s_max[2 * tid] | ((unsigned long long)s_max[2 * tid + 1] << 32);
-        if (s_any) {  // maxima below iniTh drop out (scores of maxima are >= minTh > 0 already)
-            unsigned long long rest = w;
-            while (rest) {
-                const int b = __ffsll((long long)rest) - 1;
-                rest &= rest - 1;
-                const int p = 64 * tid + b;
-                const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
-                if (score[(py + 1) * SCORE_PITCH + px + 1] < T) w &= ~(1ull << b);
-            }
-        }
+        const unsigned long long w = 2 * tid < bm_words ? (unsigned long long)bm[2 * tid] | ((unsigned long long)bm[2 * tid + 1] << 32) : 0ull;
         const int cnt = __popcll(w);
         const int incl = wave_incl_scan(cnt);
-        int pos = incl - cnt;
-        while (w) {
-            const int b = __ffsll((long long)w) - 1;
-            w &= w - 1;
-            const int p = 64 * tid + b;
-            const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
-            const int sc = score[(py + 1) * SCORE_PITCH + px + 1];
-            const int xr = x0 + px - MIN_BORDER, yr = y0 + py - MIN_BORDER;  // relative to (16,16), :821-826
-            if (pos < Lv.slot_cap) slot[pos] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)sc << 24);
-            ++pos;
-        }
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (tid == 0) cell_cnt[cell] = total;
+        s_pref[tid] = incl - cnt;
+        if (tid == 63) cell_cnt[cell] = incl;
+    }
+    __syncthreads();
+    uint32_t* slot = cell_items + Lv.slot_base + (size_t)cm.y * Lv.slot_cap;
+    for (int i = tid; i < nsurv; i += FAST_NT) {
+        const int p = s_surv[i];
+        const unsigned int wlo = bm[p >> 5];
+        if (!((wlo >> (p & 31)) & 1u)) continue;
+        const unsigned below = (p & 32) ? (unsigned)__popc(bm[(p >> 5) - 1]) : 0u;   // (low half of the same 64-bit word)
+        const int pos = s_pref[p >> 6] + (int)below + __popc(wlo & ((1u << (p & 31)) - 1u));
+        const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
+        const int sc = score[(py + 1) * SCORE_PITCH + px + 1];
+        const int xr = x0 + px - MIN_BORDER, yr = y0 + py - MIN_BORDER;  // relative to (16,16), :821-826
+        if (pos < Lv.slot_cap) slot[pos] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)sc << 24);
     }
 }
 
@@ -1629,6 +1692,7 @@ struct orbx_extractor {
     // geometry (host copies)
     std::vector<LevelInfo> levels;   // [cam * max_levels + level]
     std::vector<int2> cell_map;
+    int cell_h_max = 1, cell_px_max = 1;   // tallest cell / most pixels in a cell over all cameras and levels (k_fast_cells' LDS)
     int total_cells = 0;
     size_t total_slots = 0;
     size_t cam_pitch = 0;            // bytes of pyramid memory per camera
@@ -1724,6 +1788,7 @@ static int rebuild_geometry(orbx_extractor* ex) {
     ++ex->geom_epoch;  // captured launch chains carry the old geometry
     ex->levels.assign((size_t)ex->n_cams * ML, LevelInfo{});
     ex->cell_map.clear();
+    ex->cell_h_max = 1; ex->cell_px_max = 1;
     std::vector<int2> xt;
     std::vector<int4> yt;
     int cell_base = 0;
@@ -1759,13 +1824,15 @@ static int rebuild_geometry(orbx_extractor* ex) {
                                 Lv.w, Lv.h, Lv.w_cell, Lv.h_cell);
                 return ORB_E_ARG;
             }
+            ex->cell_h_max = std::max(ex->cell_h_max, Lv.h_cell); ex->cell_px_max = std::max(ex->cell_px_max, Lv.w_cell * Lv.h_cell);
             Lv.quota = T.quota[l];
             Lv.cell_base = cell_base;
             Lv.slot_cap = ((Lv.w_cell + 1) / 2) * ((Lv.h_cell + 1) / 2);  // strict 8-neighbour maxima cannot be denser
             Lv.slot_base = (int)slot_base;
             Lv.cand_base = (int)cand_base;
             const int ncell = nCols * nRows;
-            for (int k = 0; k < ncell; ++k) ex->cell_map.push_back(make_int2(c * ML + l, k));
+            for (int k = 0; k < ncell; ++k)   // {block | cell column << 12 | cell row << 22, local cell index}
+                ex->cell_map.push_back(make_int2((c * ML + l) | ((k % Lv.n_cols) << 12) | ((k / Lv.n_cols) << 22), k));
             cell_base += ncell;
             slot_base += (size_t)ncell * Lv.slot_cap;
             cand_base += (size_t)ncell * Lv.slot_cap;
@@ -2267,9 +2334,17 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestA
     }
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[1], st));
     // per-cell FAST / NMS / threshold / compaction
-    hipLaunchKernelGGL(k_fast_cells, dim3(ex->total_cells), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p,
-                       (const int2*)ex->d_cell_map.p, (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, ML, ex->d_cell_cnt.p,
-                       ex->d_cell_items.p);
+    // (throughput form from ~4 rounds of the chip's 2048 resident two-wave cells on; MORB_FAST_FORM=1 / 2 forces the latency / throughput form)
+    static const int form_env = [] { const char* e = getenv("MORB_FAST_FORM"); return e ? atoi(e) : 0; }();
+    const bool throughput = form_env ? form_env == 2 : ex->total_cells >= 8192;
+    if (throughput)
+        hipLaunchKernelGGL((k_fast_cells<128, 8>), dim3(ex->total_cells), dim3(128), fast_cells_lds(ex->cell_h_max, ex->cell_px_max), st,
+                           (const LevelInfo*)ex->d_levels.p, (const int2*)ex->d_cell_map.p, (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, ML,
+                           ex->d_cell_cnt.p, ex->d_cell_items.p, ex->cell_h_max, ex->cell_px_max);
+    else
+        hipLaunchKernelGGL((k_fast_cells<256, 4>), dim3(ex->total_cells), dim3(256), fast_cells_lds(ex->cell_h_max, ex->cell_px_max), st,
+                           (const LevelInfo*)ex->d_levels.p, (const int2*)ex->d_cell_map.p, (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, ML,
+                           ex->d_cell_cnt.p, ex->d_cell_items.p, ex->cell_h_max, ex->cell_px_max);
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[2], st));
     MORB_HIP(hipGetLastError());
     return ORB_OK;
