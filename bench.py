@@ -222,7 +222,8 @@ def top2_roofline(rt, m, stream, n, iters=200):
                          "launches_before_timing": settle_launches, "settling_us_per_launch_groups_of_10": settle_curve}
             if on == 1:
                 out[form]["note"] = ("the vector ALU (two instructions per key + the bit -> FP4 expansion) is this form's limit, not the matrix "
-                                     "pipe: 0.41 of the FP4 peak is 0.82 of what the int8 instruction could deliver at its peak")
+                                     "pipe: %.2f of the FP4 peak is %.2f of what the int8 instruction could deliver at its peak"
+                                     % (ach / peak, ach / I8_MFMA_PEAK_TOPS))
         else:
             ach = 18.0 * pairs / (ms * 1e-3) / 1e12
             out[form] = {"kernel": "k_hamming_top2", "bound": "valu", "achieved": round(ach, 2), "peak": INT_VALU_PEAK_TOPS,
@@ -292,6 +293,7 @@ def launch_ranks(a, argv):
     th = threading.Thread(target=relay, daemon=True); th.start()
     rc = 0
     live = set(range(n))
+    stop_at = None          # when the surviving ranks were asked to terminate
     while live:
         for r in sorted(live):
             code = procs[r].poll()
@@ -303,6 +305,13 @@ def launch_ranks(a, argv):
                 sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, code))
                 for o in live:               # exactly the processes started above
                     procs[o].terminate()
+                stop_at = time.time()
+        if stop_at is not None and live and time.time() - stop_at > 10.0:
+            # a rank that sits in a collective may ignore SIGTERM until its own watchdog fires: after a grace period the
+            # children started above (plain child processes of this one, by their exact handles) are killed
+            for o in live:
+                procs[o].kill()
+            stop_at = float("inf")
         time.sleep(0.05)
     th.join(5.0)
     return rc if rc >= 0 else 128 - rc
@@ -644,11 +653,14 @@ def main(argv=None):
         "roofline_extract": {"kernel": "extraction chain (k_pyramid_tiled [k_ingest], k_fast_cells, k_octree, k_describe)", "bound": "hbm",
                              "achieved": round(ex_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ex_ach / HBM_PEAK_GBS, 5),
                              "alg_bytes_per_image": extract_alg_bytes(W, H, NFEAT), "images": NC, "chain_us": round(ex_us, 1),
-                             "traffic": _pmc_bytes("extract_chain"),
+                             "traffic": _pmc_extract_bytes(a.config), "traffic_unit": "HBM bytes per image of THIS configuration (stored counter passes)",
                              "note": "SURVEY 8(d): W*H + 2*sum(levels>=1) + 60*N per image over the GPU time of one isolated extraction "
                                      "chain (HIP events, median of 10 steps); a latency chain of small launches, not a bandwidth kernel"},
         "exchange": ("none (one rank)" if not use_dist else
-                     "one RCCL all-gather of the step's descriptor block per step, issued natively from inside the step (RCCL C API)"
+                     "one RCCL all-gather of the step's descriptor block per step, issued natively from inside the step (RCCL C API), %s"
+                     % {1: "on the matcher's own stream behind the step's search (placement 1: inline)",
+                        2: "on the matcher's side stream next to the step's search, two extraction chains ahead (placement 2: side)"}.get(
+                            fe.fe.exchange_placement, "placement unknown")
                      if getattr(fe, "native_exchange", False) else
                      "one RCCL all-gather of the step's descriptor block per step through torch.distributed"),
     }
@@ -681,7 +693,11 @@ def main(argv=None):
                                "sample": "%d timesteps of one %d-cam %dx%d rig (the unit of `value`) through oracle/liborb_oracle.so "
                                          "(scalar C++ restatement, 1 thread; host has %d cores), timed on rank 0 while the other ranks wait"
                                          % (n1, len(cpu_cams), W, H, os.cpu_count()),
-                               "value_one_thread_per_camera": round(vn, 3), "cores_one_thread_per_camera": len(cpu_cams)}
+                               "value_one_thread_per_camera": round(vn, 3), "cores_one_thread_per_camera": len(cpu_cams),
+                               "build": "g++ -O3 -ffp-contract=off (portable: the file built in the build container)"}
+        # BASELINE.md quotes the CPU path at -O3 -march=native: the same sources built HERE for this host's CPU and timed in a
+        # child process (the checker library of this process stays the portable one), output equality asserted through a digest
+        out["cpu_baseline"]["march_native"] = cpu_native_leg(cpu_params, W, H, cpu_cams, cpu_frames, 0.5 * a.cpu_seconds)
     if rank == 0:
         json_out.write(json.dumps(out) + "\n"); json_out.flush()
     if dist is not None:
@@ -690,6 +706,74 @@ def main(argv=None):
     if dist is not None:
         dist.destroy_process_group()
     return 0
+
+
+def cpu_native_leg(cpu_params, W, H, cpu_cams, cpu_frames, budget):
+    """`cpu_baseline.march_native`: oracle/_native/liborb_oracle.so (`make -C oracle native`: the oracle's sources with
+    -march=native, built on this machine) timed on one thread over the same frames; the child loads ONLY that build
+    (MORB_ORACLE_SO) and reports a digest of its first step, which must equal the portable build's."""
+    import hashlib
+    import subprocess
+    import numpy as np
+    odir = os.path.join(ROOT, "oracle")
+    try:
+        subprocess.check_call(["make", "-s", "-C", odir, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    except Exception as e:      # noqa: BLE001 -- reported in the line
+        return {"value": None, "why": "could not build oracle/_native on this host: %r" % (e,)}
+    import tempfile
+    from oracle_pipeline import OracleFrontEnd
+
+    def digest(r):
+        h = hashlib.sha1()
+        for k in ("kps", "desc", "uright", "match_of_feature"):
+            h.update(np.ascontiguousarray(r[k]).tobytes())
+        return h.hexdigest()
+    o = OracleFrontEnd(cpu_params, W, H, cpu_cams)
+    o.step(cpu_frames[0])
+    want = digest(o.step(cpu_frames[1 % len(cpu_frames)]))
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), frames=np.stack([np.stack(f) for f in cpu_frames]), cams=np.array(cpu_cams),
+                 nf=np.array([p.nfeatures for p in cpu_params]), wh=np.array([W, H]), budget=np.array([budget]))
+        code = (
+            "import sys, os, json, time, hashlib\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "import multi_orb_slam_amd as m\n"
+            "from oracle_pipeline import OracleFrontEnd\n"
+            "z = np.load(sys.argv[1])\n"
+            "frames = [list(f) for f in z['frames']]; W, H = [int(v) for v in z['wh']]\n"
+            "params = [m.ExtractorParams(nfeatures=int(n)) for n in z['nf']]\n"
+            "o = OracleFrontEnd(params, W, H, [int(c) for c in z['cams']])\n"
+            "o.step(frames[0]); r = o.step(frames[1 %% len(frames)])\n"
+            "h = hashlib.sha1()\n"
+            "[h.update(np.ascontiguousarray(r[k]).tobytes()) for k in ('kps', 'desc', 'uright', 'match_of_feature')]\n"
+            "t0 = time.perf_counter(); n = 0\n"
+            "while n < 2 or (time.perf_counter() - t0 < float(z['budget'][0]) and n < 400):\n"
+            "    o.step(frames[(2 + n) %% len(frames)]); n += 1\n"
+            "print(json.dumps({'rate': n / (time.perf_counter() - t0), 'n': n, 'digest': h.hexdigest()}))\n"
+        ) % (ROOT, os.path.join(ROOT, "tests"))
+        env = dict(os.environ, MORB_ORACLE_SO=os.path.join(odir, "_native", "liborb_oracle.so"))
+        try:
+            p = subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.npz")], env=env, capture_output=True, text=True, timeout=300)
+            got = json.loads(p.stdout.strip().splitlines()[-1])
+        except Exception as e:      # noqa: BLE001
+            return {"value": None, "why": "child failed: %r" % (e,)}
+    if got["digest"] != want:
+        return {"value": None, "why": "the -march=native build's outputs differ from the portable build's (digest mismatch)"}
+    return {"value": round(got["rate"], 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "build": "g++ -O3 -march=native -ffp-contract=off, built on this host (oracle/Makefile: native)",
+            "sample": "%d timesteps, one thread, same frames; first step's outputs digest-equal to the portable build's" % got["n"]}
+
+
+def _pmc_extract_bytes(config):
+    """Counter-measured HBM bytes per image of the extraction chain for the configuration being run (profiles/pmc_traffic.json,
+    section `extractor`: one FETCH_SIZE + WRITE_SIZE collection per image size; configs[3] is four cameras of configs[1]'s size)."""
+    pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        sec = json.load(open(pj))["extractor"]["configs[%d]" % {1: 1, 2: 2, 3: 1, 4: 4}[config]]
+        return sec["extract_chain"]["hbm_bytes_per_image"]
+    except Exception:
+        return None
 
 
 def _pmc_bytes(key):

@@ -64,9 +64,10 @@ typedef struct orbf_result { /* all pointers: pinned host memory owned by the ha
 int orbf_create(const orbx_params* params, int n_cams, int max_width, int max_height, int device, orbf_frontend** out);
 /* The same with the look-ahead depth chosen by the caller (1..3; 0 = MORB_AHEAD_DEPTH, default 3): a handle creates one
  * extractor instance, i.e. one stream, per timestep it can extract ahead.  Streams are hardware queues and the part serves four of
- * them side by side.  A multi-GPU exchange (orbf_exchange_init) brings no stream of its own: the all-gather and the rig-wide top-2
- * follow the step's search on the matcher's stream (MORB_EXCHANGE_INLINE=0: on a side stream, and the handle then keeps two
- * extractor instances -- the arrangement of round 2, 50 % slower in the forced-exchange loop). */
+ * them side by side.  A multi-GPU exchange (orbf_exchange_init) brings no stream of its own by default: the all-gather and the
+ * rig-wide top-2 follow the step's search on the matcher's stream (orbf_exchange_placement() == 1).  The other arrangement
+ * (MORB_EXCHANGE_PLACEMENT=side, or =auto from three ranks on; == 2) runs them on a side stream, and the handle then keeps two
+ * extractor instances -- 50 % slower in the forced-exchange loop of round 3. */
 int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int max_height, int device, int ahead_depth, orbf_frontend** out);
 void orbf_destroy(orbf_frontend* f);
 /* HBM-resident depth image (metres, float32) of one camera for ComputeStereoFromRGBD; NULL: uRight = -1 */
@@ -95,8 +96,9 @@ int orbf_configure(orbf_frontend* f, float mbf, int th_high, int check_orientati
  * generation (it is identified by its pointer alone).  Results are bit-identical with and without announcements; rigs of
  * more than 4 cameras ignore them. */
 int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images);
-/* How many timesteps orbf_prefetch accepts ahead of the step being matched on this handle: MORB_AHEAD_DEPTH (default 3), two
- * once a multi-GPU exchange is set up (its collective occupies one of the four hardware queues). */
+/* How many timesteps orbf_prefetch accepts ahead of the step being matched on this handle: the depth it was created with
+ * (MORB_AHEAD_DEPTH, default 3), lowered to two only when a multi-GPU exchange was set up on the side stream
+ * (orbf_exchange_placement() == 2: its collective then occupies one of the four hardware queues). */
 int orbf_ahead_depth(const orbf_frontend* f);
 /* Multi-GPU exchange: the HBM block holding the LAST step's merged descriptors -- cap_rows rows of 32 bytes in global
  * (camera-major, packed) order followed by a 256-byte trailer of int32 per-camera counts -- ready to be the send buffer
@@ -134,6 +136,16 @@ int orbf_export_features(orbf_frontend* f, orbf_device_features* out);
 int orbf_exchange_unique_id(uint8_t* out128);
 int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int rank);
 int orbf_exchange_active(const orbf_frontend* f);   /* world size, 0 = off */
+/* Where this handle's exchange runs, decided per handle when the exchange is set up: 0 no exchange, 1 on the matcher's own stream
+ * behind the step's search (the default at every world size), 2 on the matcher's side stream next to the search
+ * (MORB_EXCHANGE_PLACEMENT = inline | side | auto, auto = 2 from three ranks on; the older MORB_EXCHANGE_INLINE = 0 means side).
+ * In both a step issues its search before its collective: a late peer delays the end of the step, never the local search. */
+int orbf_exchange_placement(const orbf_frontend* f);
+/* Probe for tests and the bench: with on != 0 every step of a handle with an exchange records, with HIP events on the matcher's
+ * stream, when its search and when its exchange (all-gather + repack + rig-wide top-2) had finished on the device;
+ * orbf_debug_exchange_us returns the last step's two figures in microseconds from the start of the step's matching. */
+int orbf_debug_exchange_timing(orbf_frontend* f, int on);
+int orbf_debug_exchange_us(const orbf_frontend* f, float* out2);
 /* The same exchange between `world` front ends of ONE process on ONE device, each driven by its own host thread (RCCL does
  * not admit two ranks on one GPU): every member calls this with the same `group` id and its own rank, then steps as a rank
  * would -- a step's all-gather rendezvouses the members' threads and copies the blocks device-to-device behind the producers'
@@ -158,7 +170,8 @@ int orbf_step_motion_ahead(orbf_frontend* f, const orbf_image* images, const orb
                            int flags, int th_low, float ratio, orbf_result* out, int* n_cross);
 int orbf_reset(orbf_frontend* f);
 /* The synthetic-stream loop in ONE call: for t = t0 .. t0 + steps - 1 announce timestep t + ahead (orbf_prefetch; ahead = 0:
- * nothing is announced, every step is an isolated one; 1 or 2), run orbf_step_motion on ring[(t % ring_len) * n_cams ..] and
+ * nothing is announced, every step is an isolated one; at most orbf_ahead_depth() + 1, refused with ORB_E_ARG before any step
+ * runs otherwise), run orbf_step_motion on ring[(t % ring_len) * n_cams ..] and
  * count the cross-camera matches a SearchByBoW-style acceptance keeps (orbm_count_ratio_accepted(best, second, n, th_low,
  * ratio)).  `ring` holds ring_len timesteps of n_cams images each.  *announced_upto (in/out): the youngest timestep announced so
  * far, so that consecutive calls continue one stream (-1 / t0 - 1 at the start).  This is exactly what a host-language loop

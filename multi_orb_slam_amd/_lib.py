@@ -170,6 +170,9 @@ def lib():
     L.orbf_exchange_active.argtypes = [vp]
     L.orbf_step_motion_ahead.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp, vp]
     L.orbf_ahead_depth.argtypes = [vp]
+    L.orbf_exchange_placement.argtypes = [vp]
+    L.orbf_debug_exchange_timing.argtypes = [vp, C.c_int]
+    L.orbf_debug_exchange_us.argtypes = [vp, C.POINTER(C.c_float)]
     L.orbf_exchange_init_loopback.argtypes = [vp, i32, i32, i32]
     L.orbf_exchange_shutdown.argtypes = [vp]
     L.orbf_peek_block.argtypes = [vp, vp, vp, vp, vp]

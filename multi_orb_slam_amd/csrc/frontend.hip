@@ -64,6 +64,8 @@ struct orbf_frontend {
     int last_e = 0;  // extractor most recently handed a timestep
     bool poll_ok = true;     // MORB_POLL=0: orbf_step_end always waits with hipStreamSynchronize
     void* xcomm = nullptr; int xworld = 0, xrank = 0;   // native multi-GPU exchange (orbf_exchange_init)
+    int x_placement = 0;                                // 0 no exchange, 1 on the matcher's own stream, 2 on its side stream (exchange_queues)
+    bool x_timing = false; hipEvent_t ev_x[3] = {nullptr, nullptr, nullptr}; float x_us[2] = {0.f, 0.f};   // orbf_debug_exchange_timing
     bool xloop = false;                                  // ... over the in-process loopback transport (orbf_exchange_init_loopback)
     DevBuf<uint8_t> d_xrecv;                            // the gathered export blocks of all ranks
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path ...
@@ -152,6 +154,7 @@ void orbf_destroy(orbf_frontend* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
     if (f->xcomm) (void)orbf_exchange_shutdown(f);
+    for (int i = 0; i < 3; ++i) if (f->ev_x[i]) (void)hipEventDestroy(f->ev_x[i]);
     f->d_xrecv.release();
     for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
     if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
@@ -234,13 +237,25 @@ int orbf_exchange_unique_id(uint8_t* out128) {
 }
 
 static int orbf_drain(orbf_frontend* f);
-// The exchange runs on the matcher's side stream every step: that is one of the four hardware queues, so at most two extractor
-// instances go round from here on (an instance that exists already keeps its stream, but is no longer handed timesteps).
+// Where a handle's exchange runs -- decided when the exchange is set up, per handle (not latched per process):
+//   1  on the matcher's OWN stream: the all-gather, the repack and the rig-wide top-2 follow the step's search there, nothing
+//      forks or joins and the handle keeps its extractor instances (three chains + the matcher = the four hardware queues);
+//   2  on the matcher's side stream (a queue of its own: at most two extractor instances go round from here on), next to the
+//      search when the block was final at begin, joined into the main stream.
+// MORB_EXCHANGE_PLACEMENT = inline | side | auto (auto: 1 up to two ranks, 2 from three on) or the older MORB_EXCHANGE_INLINE = 1 | 0
+// choose; the default is 1 at every world size.  Why not `auto`: in BOTH arrangements a step issues its search before its
+// collective, so a peer that arrives late never holds up the local search -- it holds up the END of the step, identically
+// (tests/test_gpu_frontend.py::test_slow_peer_...) -- while arrangement 2 pays a fork and a join per step
+// (~28 us of queue time, section 4) and gives up the third extraction chain.
 static int exchange_queues(orbf_frontend* f) {
-    // Default: the exchange runs on the matcher's own stream (orbm_matcher::side_inline) and every extractor instance stays.
-    // MORB_EXCHANGE_INLINE=0: the round-2 arrangement -- exchange on the side stream, at most two extractor instances (A/B only).
-    static const bool inl = getenv_int("MORB_EXCHANGE_INLINE", 1) != 0;
-    if (inl) { f->mt->side_inline = true; return ORB_OK; }
+    int placement = 1;
+    if (const char* e = getenv("MORB_EXCHANGE_PLACEMENT")) {
+        if (!strcmp(e, "side")) placement = 2;
+        else if (!strcmp(e, "auto")) placement = f->xworld >= 3 ? 2 : 1;
+    } else if (getenv_int("MORB_EXCHANGE_INLINE", 1) == 0) placement = 2;
+    f->x_placement = placement;
+    if (placement == 1) { f->mt->side_inline = true; return ORB_OK; }
+    f->mt->side_inline = false;
     if (f->n_ex > 2) {   // (a handle created for a single GPU after all: the third instance and its stream go before the side stream comes)
         int rc = orbf_drain(f);
         if (rc) return rc;
@@ -249,6 +264,23 @@ static int exchange_queues(orbf_frontend* f) {
         f->n_ex = 2;
     }
     return morb::side_stream(f->mt) ? ORB_OK : ORB_E_HIP;
+}
+
+int orbf_exchange_placement(const orbf_frontend* f) { return f ? (f->xcomm ? f->x_placement : 0) : ORB_E_ARG; }
+
+// Test / bench probe: with `on`, every step of a handle with an exchange records when its search and when its exchange had
+// finished on the device (HIP events on the matcher's stream; adds two event records to the step).
+int orbf_debug_exchange_timing(orbf_frontend* f, int on) {
+    MORB_ARG(f != nullptr);
+    MORB_HIP(hipSetDevice(f->device));
+    if (on) for (int i = 0; i < 3; ++i) if (!f->ev_x[i]) MORB_HIP(hipEventCreate(&f->ev_x[i]));
+    f->x_timing = on != 0;
+    return ORB_OK;
+}
+int orbf_debug_exchange_us(const orbf_frontend* f, float* out2) {
+    MORB_ARG(f && out2);
+    out2[0] = f->x_us[0]; out2[1] = f->x_us[1];
+    return ORB_OK;
 }
 
 int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int rank) {
@@ -284,7 +316,7 @@ int orbf_exchange_shutdown(orbf_frontend* f) {
     if (f->mt) { if (f->mt->side_stream) (void)hipStreamSynchronize(f->mt->side_stream); (void)hipStreamSynchronize(f->mt->stream); }
     if (f->xloop) loop_leave(static_cast<LoopComm*>(f->xcomm));
     else exchange_comm_destroy(f->xcomm);
-    f->xcomm = nullptr; f->xworld = 0; f->xrank = 0; f->xloop = false;
+    f->xcomm = nullptr; f->xworld = 0; f->xrank = 0; f->xloop = false; f->x_placement = 0;
     if (f->mt) f->mt->side_inline = false;
     return ORB_OK;
 }
@@ -385,6 +417,8 @@ static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motio
 int orbf_run_stream(orbf_frontend* f, const orbf_image* ring, int ring_len, int t0, int steps, int ahead, int* announced_upto,
                     const orbf_motion* motion, int th_low, float ratio, orbf_stream_stats* out) {
     MORB_ARG(f && ring && ring_len >= 1 && t0 >= 0 && steps >= 0 && ahead >= 0 && ahead <= orbf_frontend::NEX && announced_upto && motion && out);
+    // (refused before any step has run: orbf_prefetch would refuse the announcement in the middle of the stream otherwise)
+    if (ahead > f->n_ex + 1) { morb::set_error("orbf_run_stream: ahead = %d, this handle takes at most %d (orbf_ahead_depth() + 1)", ahead, f->n_ex + 1); return ORB_E_ARG; }
     memset(out, 0, sizeof(*out));
     const auto t_start = std::chrono::steady_clock::now();
     auto images_of = [&](int t) { return ring + (size_t)(t % ring_len) * f->n_cams; };
@@ -809,7 +843,10 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return ORB_E_HIP; }
     }
     if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[2] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
+    const bool x_probe = f->x_timing && f->xcomm && first_attempt;
+    if (x_probe) (void)hipEventRecord(f->ev_x[0], st);
     rc = search_enqueue(m, P.J, /*queries_already_on_device=*/true);
+    if (x_probe) (void)hipEventRecord(f->ev_x[1], st);   // (behind the resolve, in front of whatever the exchange puts or joins on this stream)
     if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[3] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     if (P.mirror_pending && !forked) {   // (no side stream in play: the copy follows the search on its stream)
         if (!rc) rc = frame_mirror_enqueue(fr, st, R.kps.dp, R.desc.dp, R.unx.dp, R.uny.dp, R.ur.dp, R.depth.dp);
@@ -838,6 +875,7 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     if (first_attempt && f->xcomm && P.async_path && P.block_ready && !P.x_enqueued) {
         if ((rc = exchange_enqueue(f, fr))) return rc;
         P.x_enqueued = true;
+        if (x_probe) (void)hipEventRecord(f->ev_x[2], st);
     }
     if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[4] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     // ---- announced timesteps go onto the extractors now: they run while this step is being matched.  At most two
@@ -997,8 +1035,15 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
         // otherwise (the block is final now)
         if (!P.x_enqueued) {
             if ((rc = exchange_enqueue(f, f->last_frame))) return rc;
+            if (f->x_timing) (void)hipEventRecord(f->ev_x[2], st);
             MORB_HIP(hipStreamSynchronize(st));
             m->foreign_work = false;
+        }
+        if (f->x_timing) {   // (everything has been synchronised: the three events are complete)
+            float a = 0.f, b = 0.f;
+            if (hipEventElapsedTime(&a, f->ev_x[0], f->ev_x[1]) == hipSuccess && hipEventElapsedTime(&b, f->ev_x[0], f->ev_x[2]) == hipSuccess) {
+                f->x_us[0] = a * 1000.f; f->x_us[1] = b * 1000.f;
+            } else (void)hipGetLastError();
         }
         out->cross_best_idx = m->h_c0.p; out->cross_best_dist = m->h_c1.p; out->cross_second_dist = m->h_c2.p;
         out->rig_cams = m->gathered_cams; out->rig_counts = m->h_gcnt.p;

@@ -42,9 +42,13 @@ class _LazyStep(dict):
     def __contains__(self, key):
         if dict.__contains__(self, key):
             return True
+        if key not in self._LAZY:
+            return False
+        if self._fe._step_seq != self._seq:   # (the record now belongs to a later step: no answer is better than a wrong one)
+            raise RuntimeError("step result consumed in place: %r was first asked about after the front end's next step" % key)
         if key == "cross":
-            return self._fe._step_seq == self._seq and bool(self._fe._res.cross_best_idx)
-        return key in self._LAZY
+            return bool(self._fe._res.cross_best_idx)
+        return True
 
     def get(self, key, default=None):
         return self[key] if key in self else default
@@ -175,6 +179,20 @@ class NativeFrontEnd:
     def exchange_world(self):
         return _lib.lib().orbf_exchange_active(self._h)
 
+    @property
+    def exchange_placement(self):
+        """0 no exchange, 1 on the matcher's own stream behind the search, 2 on its side stream (orbf_exchange_placement)"""
+        return _lib.lib().orbf_exchange_placement(self._h)
+
+    def debug_exchange_timing(self, on=True):
+        check(_lib.lib().orbf_debug_exchange_timing(self._h, 1 if on else 0))
+
+    def debug_exchange_us(self):
+        """(search finished, exchange finished) of the last step, microseconds of device time from the start of its matching"""
+        out = (C.c_float * 2)()
+        check(_lib.lib().orbf_debug_exchange_us(self._h, out))
+        return float(out[0]), float(out[1])
+
     def peek_block(self, images):
         """Before begin(): (device pointer, bytes, rows) of the step's export block when it is final already, else None
         (orbf_peek_block).  `images` as for begin()."""
@@ -237,6 +255,7 @@ class NativeFrontEnd:
             self._ring_cache = cached = (key, arr, ring)
         st = FStreamStats(); upto = C.c_int(announced_upto)
         mo = FMotion(*motion)
+        self._step_seq += 1        # (the native loop reuses the result record and the pinned buffers: earlier in-place results end here)
         check(_lib.lib().orbf_run_stream(self._h, cached[1], len(ring), t0, steps, ahead, C.byref(upto), C.byref(mo), th_low,
                                          C.c_float(ratio), C.byref(st)))
         return (dict(features=st.features, temporal_matches=st.temporal_matches, cross_accepted=st.cross_accepted,
@@ -254,6 +273,7 @@ class NativeFrontEnd:
         export block is already final, i.e. a multi-GPU exchange may be enqueued before end()."""
         arr, self._keep = self._image_array(images, self._imgs)
         ready = self._ready
+        self._step_seq += 1        # every native step reuses the result record: an in-place result of an earlier step is stale from here on
         if motion is not None:
             mo = self._motion_cache.get(motion)
             if mo is None:
@@ -303,6 +323,7 @@ class NativeFrontEnd:
             m_ = FMotion(*motion)
             mo = self._motion_refs[motion] = (C.byref(m_), m_)
         nc = self._ncross
+        self._step_seq += 1
         rc = self._fn_step_ahead(self._h, arr, nxt, mo[0], flags, th_low, ratio, self._res_ref, self._ncross_ref)
         if rc:
             check(rc)
@@ -355,7 +376,6 @@ class NativeFrontEnd:
         cap = self.cap_total
         V = self._cached
         if not copy:
-            self._step_seq += 1
             return _LazyStep({"n_temporal": r.nmatches, "gpu_wait_us": r.gpu_wait_us, "n_queries": nq, "n_total": n}, self, nq)
         cp = lambda a: a.copy()
         out = dict(counts=V("counts", r.counts, np.int32, self.n_cams).tolist(), kps=cp(V("kps", r.kps, KP_DTYPE, cap)[:n]),

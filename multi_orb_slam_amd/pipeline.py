@@ -69,11 +69,9 @@ class FrontEnd:
         self.gather = gather                      # DescriptorExchange (multi-GPU) or None
         self.global_cams = global_cams or list(range(rank * self.n_cams, (rank + 1) * self.n_cams))
         rt.set_device(device)
-        # (the native exchange of a multi-GPU job runs on the matcher's own stream: the full look-ahead depth stays; the round-2
-        # arrangement -- exchange on a side stream, MORB_EXCHANGE_INLINE=0 -- gives that stream one of the four hardware queues)
-        import os
-        side = world_size > 1 and os.environ.get("MORB_EXCHANGE_INLINE", "1") == "0"
-        self.fe = NativeFrontEnd(self.params, width, height, device, ahead_depth=2 if side else 0)
+        # (where a multi-GPU exchange runs is the native handle's decision, taken when the exchange is set up -- orbf_exchange_placement;
+        # a handle that moves it to the side stream gives up its third extractor instance itself: nothing to decide here)
+        self.fe = NativeFrontEnd(self.params, width, height, device, ahead_depth=0)
         self.fe.configure(MBF, 100, True)
         if calib is not None:
             self.fe.set_calibration(calib)   # (fx, fy, cx, cy, k1, k2, p1, p2[, k3]): undistortion as the reference's Frame does it
@@ -153,13 +151,13 @@ class FrontEnd:
         if not distributed and not native:
             # one native call per timestep: announce + step + the count of accepted cross-camera matches (orbf_step_motion_ahead)
             AT = self.fe._arr_type
-            if type(images) is AT:
-                pass                  # (prepared by prepare(): nothing to marshal)
-            elif resident:
-                od = 0 if resident == "pinned" else 1
+            od = 0 if resident == "pinned" else 1
+            # (prepared by prepare(): nothing to marshal; the two arguments are converted independently -- a prepared `images`
+            # next to `next_images` still given as (ptr, stride[, generation]) tuples is a legal mix)
+            if resident and type(images) is not AT:
                 images = [(im[0], self.width, self.height, im[1], od, im[2] if len(im) > 2 else 0) for im in images]
-                if next_images is not None:
-                    next_images = [(im[0], self.width, self.height, im[1], od, im[2] if len(im) > 2 else 0) for im in next_images]
+            if resident and next_images is not None and type(next_images) is not AT:
+                next_images = [(im[0], self.width, self.height, im[1], od, im[2] if len(im) > 2 else 0) for im in next_images]
             # (the binding never hands out the query records: they stay on the device)
             r = self.fe.step_ahead(images, next_images, (MOTION[0], MOTION[1], TH_PROJ), TH_LOW, BOW_RATIO, flags=NO_QUERY_RECORDS,
                                    copy=self.copy_results)

@@ -9,7 +9,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
-_SO = os.path.join(ORACLE_DIR, "liborb_oracle.so")
+# (MORB_ORACLE_SO: another build of the same sources, e.g. oracle/_native/liborb_oracle.so = `make -C oracle native`, -march=native,
+# which bench.py's cpu_baseline leg times in a child process next to the portable build)
+_SO = os.environ.get("MORB_ORACLE_SO") or os.path.join(ORACLE_DIR, "liborb_oracle.so")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
@@ -46,6 +48,8 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
+            if os.environ.get("MORB_ORACLE_SO"):
+                raise FileNotFoundError(_SO)
             build()
         _lib = C.CDLL(_SO)
         _lib.orc_fast_atan2.restype = C.c_float

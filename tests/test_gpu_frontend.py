@@ -316,36 +316,6 @@ def test_results_consumed_in_place_are_the_same_arrays():
     fe.close()
 
 
-def test_recycled_device_buffer_with_a_generation_is_extracted_again():
-    """A device image cannot be fingerprinted from the host: a caller that recycles HBM buffers says so with
-    orbf_image::generation (the frame's sequence number).  The extraction that ran ahead on a buffer's OLD content is then
-    not served to the step that arrives with the buffer refilled under a new generation; the same (pointer, generation)
-    still rides the prefetch."""
-    import multi_orb_slam_amd as m
-    from multi_orb_slam_amd import pipeline, rt
-    from oracle_pipeline import OracleFrontEnd, assert_same_step
-    W, H = 320, 240
-    params = [m.ExtractorParams(nfeatures=300), m.ExtractorParams(nfeatures=150)]
-    fe = pipeline.FrontEnd(params, W, H)
-    ofe = OracleFrontEnd(params, W, H)
-    frames = [[synth.image(c, t, W, H) for c in range(2)] for t in range(5)]
-    ring = [[rt.DeviceBuffer(W * H) for c in range(2)] for t in range(2)]      # two reusable HBM buffers per camera
-    def fill(slot, t):
-        for c in range(2):
-            ring[slot][c].upload(frames[t][c])
-    def args(slot, gen):
-        return [(ring[slot][c].ptr, W, gen) for c in range(2)]
-    fill(0, 0); fill(1, 1)
-    assert_same_step(fe.step(args(0, 1), resident=True, next_images=args(1, 2)), ofe.step(frames[0]))   # frame 1 runs ahead
-    assert_same_step(fe.step(args(1, 2), resident=True, next_images=args(0, 1)), ofe.step(frames[1]))   # served from the prefetch; slot 0 (frame 0) announced again
-    rt.device_sync()
-    fill(0, 3)                                                         # ... the caller refills slot 0 with frame 3, generation 4
-    assert_same_step(fe.step(args(0, 4), resident=True), ofe.step(frames[3]))                             # must see frame 3
-    fill(1, 4)
-    assert_same_step(fe.step(args(1, 5), resident=True), ofe.step(frames[4]))
-    fe.close()
-
-
 @pytest.mark.parametrize("world,n_cams,w,h,nf,ahead", [(4, 4, 640, 480, 1000, 0), (4, 4, 640, 480, 1000, 2), (2, 4, 640, 480, 1000, 1),
                                                        (4, 8, 320, 240, 300, 0)])
 def test_rig_sharded_over_ranks_through_the_gathered_blocks(world, n_cams, w, h, nf, ahead):
@@ -457,24 +427,25 @@ def test_recycled_device_buffer_with_a_generation_is_extracted_again():
     fe.close()
 
 
-@pytest.mark.parametrize("world,n_cams,w,h,nf,ahead", [(4, 4, 640, 480, 1000, 0), (4, 4, 640, 480, 1000, 2), (2, 4, 320, 240, 300, 2), (8, 8, 320, 240, 200, 1)])
-def test_world_size_n_native_steps_over_the_loopback_exchange(world, n_cams, w, h, nf, ahead):
-    """The multi-GPU step with world > 1, end to end through orbf_step: `world` front ends (one host thread each, the cameras
-    of ONE rig sharded over them -- configs[3]: one 640x480 camera @1000 per rank) exchange their export blocks from INSIDE the
-    native step, exactly as over RCCL, through the in-process loopback transport (RCCL refuses two ranks on one GPU).  Every
-    rank's keypoints, descriptors, stereo, temporal matches and rig-wide cross-camera top-2 must equal the oracle's; with
-    steps announced ahead some ranks ship their block early (between begin and end), others late -- any mix must work."""
+def _loopback_rig(world, n_cams, w, h, nf, ahead, T=6, group=None, delayed_rank=None, delay_s=0.0, probe=False):
+    """`world` front ends on this one device, one host thread each, the cameras of ONE rig sharded over them, exchanging their
+    export blocks from inside the native step through the in-process loopback transport.  Optionally one rank sleeps `delay_s`
+    before every step (a slow peer) and every rank records when its search / its exchange had finished on the device
+    (orbf_debug_exchange_timing).  Every rank's every step is then held against the oracle.
+    -> (results[r][t], timings[r][t] = (search_us, exchange_us) or None, placements[r])"""
     import threading
+    import time
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import pipeline
     from multi_orb_slam_amd.dist import shard_cameras
     from oracle_pipeline import OracleFrontEnd, assert_same_step
     per = n_cams // world
-    T = 6
     frames = [{g: synth.image(g, t, w, h) for g in range(n_cams)} for t in range(T)]
     results = [[None] * T for _ in range(world)]
+    timings = [[None] * T for _ in range(world)]
+    placements = [None] * world
     errors = []
-    group = 1000 + world * 10 + ahead
+    group = group if group is not None else 1000 + world * 10 + ahead
 
     def rank_main(r):
         try:
@@ -483,13 +454,20 @@ def test_world_size_n_native_steps_over_the_loopback_exchange(world, n_cams, w, 
             fe.fe.exchange_init_loopback(group, world, r)
             fe.native_exchange = True
             assert fe.fe.exchange_world == world
+            placements[r] = fe.fe.exchange_placement
+            if probe:
+                fe.fe.debug_exchange_timing(True)
             announced = 0
             for t in range(T):
+                if r == delayed_rank:
+                    time.sleep(delay_s)       # (releases the interpreter lock: the other ranks' threads keep stepping)
                 while announced < min(t + ahead, T - 1):
                     announced += 1
                     fe.announce([frames[announced][g] for g in mine])
                 announced = max(announced, t)
                 results[r][t] = fe.step([frames[t][g] for g in mine])
+                if probe:
+                    timings[r][t] = fe.fe.debug_exchange_us()
             fe.fe.exchange_shutdown()
             fe.close()
         except Exception as e:      # noqa: BLE001 -- reported by the main thread
@@ -517,6 +495,40 @@ def test_world_size_n_native_steps_over_the_loopback_exchange(world, n_cams, w, 
                                other_descs=lambda c, mine=mine: [desc_of[g] for g in range(n_cams) if g != mine[c]])
             assert_same_step(got, exp)
     assert all(results[r][T - 1]["n_temporal"] > 30 for r in range(world))
+    return results, timings, placements
+
+
+@pytest.mark.parametrize("world,n_cams,w,h,nf,ahead", [(4, 4, 640, 480, 1000, 0), (4, 4, 640, 480, 1000, 2), (2, 4, 320, 240, 300, 2), (8, 8, 320, 240, 200, 1)])
+def test_world_size_n_native_steps_over_the_loopback_exchange(world, n_cams, w, h, nf, ahead):
+    """The multi-GPU step with world > 1, end to end through orbf_step: `world` front ends (one host thread each, the cameras
+    of ONE rig sharded over them -- configs[3]: one 640x480 camera @1000 per rank) exchange their export blocks from INSIDE the
+    native step, exactly as over RCCL, through the in-process loopback transport (RCCL refuses two ranks on one GPU).  Every
+    rank's keypoints, descriptors, stereo, temporal matches and rig-wide cross-camera top-2 must equal the oracle's; with
+    steps announced ahead some ranks ship their block early (between begin and end), others late -- any mix must work."""
+    _results, _timings, placements = _loopback_rig(world, n_cams, w, h, nf, ahead)
+    assert placements == [1] * world          # the default at every world size: on the matcher's own stream
+
+
+@pytest.mark.parametrize("placement", ["inline", "side"])
+def test_slow_peer_delays_the_end_of_the_step_never_the_local_search(placement, monkeypatch):
+    """configs[3]'s rig over four ranks with one rank arriving 1 ms late at EVERY step, in both arrangements of the exchange
+    (on the matcher's own stream behind the search / on its side stream next to it, two chains ahead).  A step issues its
+    search before its collective in either, so on the three punctual ranks the search has long finished on the device when the
+    late block arrives: device time to `search done` stays a fraction of the delay, device time to `exchange done` carries it.
+    Results stay bit-identical with the oracle on every rank and step (VERDICT r03 #7)."""
+    monkeypatch.setenv("MORB_EXCHANGE_PLACEMENT", placement)
+    world, delay = 4, 1.0e-3
+    _results, timings, placements = _loopback_rig(world, 4, 640, 480, 1000, ahead=2, T=10, group=1900 + (placement == "side"),
+                                                  delayed_rank=1, delay_s=delay, probe=True)
+    assert placements == [1 if placement == "inline" else 2] * world
+    for r in (0, 2, 3):
+        search = np.median([timings[r][t][0] for t in range(3, 10)])
+        exch = np.median([timings[r][t][1] for t in range(3, 10)])
+        assert 0 < search < 0.5 * delay * 1e6, (r, search, exch)          # the local search never waited for the late peer
+        assert exch - search > 0.4 * delay * 1e6, (r, search, exch)       # ... the end of the step did
+    print("slow peer (%s): punctual ranks' median search done %.0f us, exchange done %.0f us after the start of the step's matching"
+          % (placement, np.median([timings[r][t][0] for r in (0, 2, 3) for t in range(3, 10)]),
+             np.median([timings[r][t][1] for r in (0, 2, 3) for t in range(3, 10)])))
 
 
 def test_native_stream_loop_equals_the_step_by_step_run():
