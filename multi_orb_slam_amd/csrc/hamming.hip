@@ -451,14 +451,18 @@ template <> struct Mt<false> {
 template <> struct Mt<true> {
     using Acc = mm_f32x16;
     static constexpr int KS = 4;
-    static constexpr uint32_t KEY_NONE = 0x46000000u;   // 8192.0f = 32 * 256: key = (float)(32 * distance + row), compared as bits
+    // Round 4: the accumulators are preset to 16384 + 4096 + row, so that every key 16384 + 32 * distance + row (distance 0 .. 256)
+    // lies in ONE binade, [16384, 32768): its bit pattern is 0x46800000 | (32 * distance + row) << 9 -- row in mantissa bits 9..13,
+    // distance in bits 14..22 -- and closing a block is integer work on the pattern (one v_and clears the row, a bit-field extract
+    // reads it) instead of a conversion to integer, the mask and a conversion back per query group and block.
+    static constexpr uint32_t KEY_NONE = 0x46C00000u;   // 16384 + 32 * 256 = 24576.0f: "distance 256"
     static __device__ __forceinline__ void queries(mm_i32x4 (&bq)[KS], const uint32_t (&w)[8], int h) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bq[ks] = f4_expand32<true>(h ? w[2 * ks + 1] : w[2 * ks]);
     }
     static __device__ __forceinline__ void preset(Acc& c, int h) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) c[e] = (float)(4096 + (e & 3) + 8 * (e >> 2) + 4 * h);
+        for (int e = 0; e < 16; ++e) c[e] = (float)(16384 + 4096 + (e & 3) + 8 * (e >> 2) + 4 * h);
     }
     static __device__ __forceinline__ void deposit(mm_i32x4* tile, int h, int wave, int c, uint2 w) {
         mm_i32x4* base = tile + (h * 4 + wave) * 64 + c;   // instruction ks = wave of half h; lanes c / 32 + c take word 2 ks / 2 ks + 1
@@ -471,11 +475,10 @@ template <> struct Mt<true> {
     }
     static __device__ __forceinline__ uint32_t key(const Acc& a, int e) { return __float_as_uint(a[e]); }
     static __device__ __forceinline__ void close_block(uint32_t& kb, int& where, uint32_t before, int blk) {
-        const int ki = (int)__uint_as_float(kb);   // 32 * distance + row
-        where = kb != before ? ((blk << 5) | (ki & 31)) : where;
-        kb = __float_as_uint((float)(ki & ~31));
+        where = kb != before ? ((blk << 5) | (int)((kb >> 9) & 31u)) : where;
+        kb &= ~(31u << 9);
     }
-    static __device__ __forceinline__ uint32_t distance(uint32_t k) { return (uint32_t)(int)__uint_as_float(k) >> 5; }
+    static __device__ __forceinline__ uint32_t distance(uint32_t k) { return (k >> 14) & 0x1ffu; }
 };
 
 template <bool FP4>
