@@ -142,6 +142,7 @@ def lib():
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
     L.orbm_hamming_matrix_device.argtypes = [vp, i32, vp, i32, vp, vp]
     L.orbm_frame_create.argtypes = [vp, vp, vp]
+    L.orbm_frame_create_resident.argtypes = [vp, vp, vp, vp]
     L.orbm_frame_destroy.argtypes = [vp]; L.orbm_frame_destroy.restype = None
     L.orbm_set_stream.argtypes = [vp, vp]
     L.orbm_wait_for_stream.argtypes = [vp, vp]

@@ -56,11 +56,19 @@ class _Count:
 
 
 class Frame:
-    def __init__(self, matcher, data=None, handle=None, n_total=0, n_cams=0):
+    def __init__(self, matcher, data=None, handle=None, n_total=0, n_cams=0, resident=None):
+        """resident: None -> orbm_frame_create (host-built grid, every array sent); a list with one entry per camera -- a DEVICE
+        pointer to that camera's descriptor rows, or 0 / None -- -> orbm_frame_create_resident (grid built on the device, the
+        named cameras' descriptors read where they are)."""
         self._m = matcher
         if handle is not None:           # device-built frame (orbm_frame_from_device)
             self._h = handle
             self.data = _Count(n_total, n_cams)
+        elif resident is not None:
+            self.data = data
+            self._h = C.c_void_p()
+            ptrs = (C.c_void_p * data.n_cams)(*[(p or None) for p in resident])
+            check(_lib.lib().orbm_frame_create_resident(matcher._h, C.byref(data.c), ptrs, C.byref(self._h)))
         else:
             self.data = data
             self._h = C.c_void_p()
@@ -158,8 +166,8 @@ class Matcher:
         check(_lib.lib().orbm_hamming_matrix_device(C.c_void_p(d_q), nq, C.c_void_p(d_r), nr, C.c_void_p(d_out),
                                                     C.c_void_p(stream)))
 
-    def frame(self, data):
-        return Frame(self, data)
+    def frame(self, data, resident=None):
+        return Frame(self, data, resident=resident)
 
     def set_stream(self, stream):
         check(_lib.lib().orbm_set_stream(self._h, C.c_void_p(stream) if stream else None))

@@ -132,6 +132,55 @@ def test_grid_and_area_queries(matcher, n_per_cam, seed):
     F.close()
 
 
+@pytest.mark.parametrize("n_per_cam,resident,seed", [([400, 300], (True, True), 1), ([1500, 700], (True, False), 2), ([50], (True,), 3),
+                                                     ([0, 20], (False, True), 4), ([1000, 1000, 600, 900], (False, True, True, False), 5),
+                                                     ([3000, 3000, 3000], (True, True, True), 6), ([300, 200], (False, False), 7)])
+def test_frame_created_with_resident_descriptors_equals_the_host_built_frame(matcher, n_per_cam, resident, seed):
+    """orbm_frame_create_resident (round 4: what the C++ ORBmatcher uploads frames through) -- per-feature fields in one staging
+    block, the 64x48 grid built by k_frame_build_small on the device, the descriptor rows of some cameras read from DEVICE memory
+    where an extractor left them -- must give the frame orbm_frame_create gives: the same grid (cell starts, item order), the
+    same candidates for every window, the same search results; with every mix of resident / host cameras, an empty camera, a
+    frame beyond 8192 features (which takes the host-built path) and a mapping that is NOT camera-major."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import rt
+    fr = helpers.make_frame_arrays(n_per_cam, 640, 480, seed)
+    if seed == 7:      # global order interleaves the cameras: cam_of / local_of say so, the descriptors stay per camera
+        n = len(fr["un_x"])
+        perm = np.random.RandomState(3).permutation(n)
+        for k in ("un_x", "un_y", "octave", "angle", "uright", "cam_of", "local_of"):
+            fr[k] = np.ascontiguousarray(fr[k][perm])
+    data = m.FrameData(**fr); OF = oracle.FrameData(**fr)
+    bufs = []
+    ptrs = []
+    for c, d in enumerate(data.descs):
+        if resident[c] and len(d):
+            b = rt.DeviceBuffer(max(d.nbytes, 32)); b.upload(d); bufs.append(b); ptrs.append(b.ptr)
+        else:
+            ptrs.append(0)
+    rt.device_sync()
+    F = matcher.frame(data, resident=ptrs)
+    G = matcher.frame(data)
+    cs, items = F.grid(); gcs, gitems = G.grid(); ocs, oitems = oracle.grid_csr(OF)
+    assert np.array_equal(cs, ocs) and np.array_equal(items, oitems)
+    assert np.array_equal(cs, gcs) and np.array_equal(items, gitems)
+    nq = min(1500, max(10, len(fr["un_x"])))
+    q = helpers.make_queries(fr, nq, seed + 70, th=20.0, blocks=1)
+    for check_ori in (True, False):
+        matcher.check_orientation = check_ori
+        n1, mo1 = matcher.SearchByProjection(F, q)
+        n2, mo2 = matcher.SearchByProjection(G, q)
+        on, omo = oracle.search_by_projection_frames(OF, q, 100, check_ori)
+        assert n1 == on and np.array_equal(mo1, omo)
+        assert n2 == on and np.array_equal(mo2, omo)
+    matcher.check_orientation = True
+    idx, dist, cnt = matcher.project_candidates(F, q[:64], 512)
+    idx2, dist2, cnt2 = matcher.project_candidates(G, q[:64], 512)
+    assert np.array_equal(cnt, cnt2) and np.array_equal(idx, idx2) and np.array_equal(dist, dist2)
+    F.close(); G.close()
+    for b in bufs:
+        b.free()
+
+
 @pytest.mark.parametrize("n_per_cam,nq,th,blocks,seed", [([1000, 500], 1200, 15.0, 1, 1), ([1000, 1000], 2500, 30.0, 1, 2),
                                                         ([300, 200], 900, 15.0, 2, 3), ([2000, 2000], 3000, 15.0, 0, 4),
                                                         ([64], 10, 7.0, 1, 5), ([1000, 1000], 2000, 30.0, 1, 6),
