@@ -1258,6 +1258,7 @@ constexpr int RAW_PITCH = 48;
 constexpr int BR_ = 19;                // blurred half-size
 constexpr int BW = 2 * BR_ + 1;        // 39
 constexpr int ROW_PITCH = 40;
+constexpr int VP_PAIRS = 24;           // row pairs of the horizontal pass: 23 hold the 45 rows, one more is read (never used) by the last segment
 
 MORB_PHASE_DECL(g_ph_desc);
 #ifdef MORB_PHASE_CLOCKS
@@ -1275,7 +1276,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                                                   uint8_t* const* __restrict__ desc_out, MirrorArgs mir, SelListArgs sl,
                                                   FrameSink sink) {
     __shared__ alignas(16) uint8_t s_raw[4][PW * RAW_PITCH];
-    __shared__ alignas(16) uint16_t s_row[4][PW * ROW_PITCH];
+    __shared__ alignas(16) uint32_t s_vp[4][VP_PAIRS * ROW_PITCH];   // horizontal sums as VERTICAL pairs: row 2m | row 2m+1 << 16 per column
     __shared__ alignas(16) uint8_t s_blur[4][BW * ROW_PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Workgroups go to the 8 XCDs round robin and every XCD has an L2 of its own.  The slots are ordered (camera, level, list
@@ -1336,7 +1337,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     const LevelInfo Lv = L[cam * max_levels + level];
     const uint8_t* img = pyr + cam * cam_pitch + Lv.pyr_off;
     uint8_t* raw = s_raw[wave];
-    uint16_t* rowp = s_row[wave];
+    uint32_t* vp = s_vp[wave];
     uint8_t* blur = s_blur[wave];
 
     DPH(1);
@@ -1356,34 +1357,30 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     }
     // 45x45 raw patch, reflect-101 at the level edge (== GaussianBlur's border on the cloned level, :1086-1087), fetched as 12
     // unaligned dwords per row with every load of the wave in flight before the first LDS store (columns 45..47 are padding
-    // nothing reads).  Rows reflect per load.  A patch that crosses the left or right edge (keypoints sit >= 19 pixels inside,
-    // the patch reaches 22: at most three columns) fetches the 48 columns nearest to the edge into scratch and is then put in
-    // place, with the reflection, by an LDS-to-LDS byte copy.
+    // nothing reads).  Round 4: lane = 12 g + j takes dword j of rows g, g + 5, .., g + 40 -- its nine LDS destinations are the
+    // constant offsets lane + 60 k, its nine row addresses one reflection + one multiply-add each (lanes 60..63 idle), where the
+    // flat index of rounds 2-3 paid a division by 12 and the address arithmetic per dword.  Rows reflect per load.  A patch that
+    // crosses the left or right edge (keypoints sit >= 19 pixels inside, the patch reaches 22: at most three columns) fetches
+    // the 48 columns nearest to the edge into scratch and is then put in place, with the reflection, by an LDS-to-LDS byte copy.
     {
         const int xs_want = K.x - PR;
         const int xs = min(max(xs_want, 0), Lv.w - RAW_PITCH);
         const bool shifted = xs != xs_want;
-        uint32_t* dst32 = reinterpret_cast<uint32_t*>(shifted ? reinterpret_cast<uint8_t*>(rowp) : raw);
-        const uint8_t* p0 = img + xs;
-        constexpr int NDW = PW * (RAW_PITCH / 4);   // 540 dwords = 8 full rounds of the wave + 28
-        uint32_t v[(NDW + 63) / 64];
+        uint32_t* dst32 = shifted ? vp : reinterpret_cast<uint32_t*>(raw);
+        const int g = (lane * 43) >> 9, j = lane - 12 * g;   // lane / 12, lane % 12 (exact for lane < 64)
+        const uint8_t* p0 = img + xs + 4 * j;
+        uint32_t v[9];
 #pragma unroll
-        for (int k = 0; k < (NDW + 63) / 64; ++k) {
-            const int i = lane + 64 * k;
+        for (int k = 0; k < 9; ++k) {
             v[k] = 0;
-            if (i < NDW) {
-                const int ry = i / (RAW_PITCH / 4), j = i - ry * (RAW_PITCH / 4);
-                __builtin_memcpy(&v[k], p0 + (size_t)reflect101(K.y - PR + ry, Lv.h) * Lv.stride + 4 * j, 4);
-            }
+            if (lane < 60) __builtin_memcpy(&v[k], p0 + (size_t)reflect101(K.y - PR + g + 5 * k, Lv.h) * Lv.stride, 4);
         }
 #pragma unroll
-        for (int k = 0; k < (NDW + 63) / 64; ++k) {
-            const int i = lane + 64 * k;
-            if (i < NDW) dst32[i] = v[k];   // (row pitch == 12 dwords: position i is (ry, j))
-        }
+        for (int k = 0; k < 9; ++k)
+            if (lane < 60) dst32[lane + 60 * k] = v[k];   // (row g + 5 k, dword j: position (12 g + j) + 60 k)
         if (shifted) {
             wave_lds_sync();
-            const uint8_t* tmp = reinterpret_cast<const uint8_t*>(rowp);
+            const uint8_t* tmp = reinterpret_cast<const uint8_t*>(vp);
             for (int i = lane; i < PW * PW; i += 64) {
                 const int ry = i / PW, rx = i - ry * PW;
                 raw[ry * RAW_PITCH + rx] = tmp[ry * RAW_PITCH + reflect101(xs_want + rx, Lv.w) - xs];
@@ -1422,46 +1419,72 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     DPH(3);
 
     // 7x7 sigma-2 Gaussian, OpenCV 8-bit fixed point: taps [18,34,49,55,49,34,18] on both axes (App. A-4)
-    // Horizontal pass, four outputs per item: the ten bytes they need are three dwords of the raw row; output j's window is
-    // brought into place with two funnel shifts and weighted with two v_dot4_u32_u8 (exact integer sums, <= 257 * 255).
+    // Horizontal pass (round 4): an item is FOUR output columns of TWO vertically adjacent rows (2m, 2m + 1).  The ten bytes a
+    // row's four outputs need are three dwords of the raw row; output j's window is brought into place with two funnel shifts
+    // and weighted with two v_dot4_u32_u8 (exact integer sums, <= 257 * 255 < 2^16).  The two rows' sums of a column go into ONE
+    // dword -- row 2m in the low half, row 2m + 1 in the high half -- so that the vertical pass can weight a pair with one
+    // v_dot2_u32_u16.  23 pairs x 10 column groups = 230 items: four rounds of the wave, one 16-byte LDS store per item.
     {
         const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(raw);
-        uint32_t* row32 = reinterpret_cast<uint32_t*>(rowp);
         constexpr uint32_t W_LO = 18u | (34u << 8) | (49u << 16) | (55u << 24), W_HI = 49u | (34u << 8) | (18u << 16);
-        for (int i = lane; i < PW * (ROW_PITCH / 4); i += 64) {
-            const int ry = i / (ROW_PITCH / 4), q = i - ry * (ROW_PITCH / 4);   // columns 4q .. 4q+3 (column 39 is padding)
-            const uint32_t d0 = raw32[ry * (RAW_PITCH / 4) + q], d1 = raw32[ry * (RAW_PITCH / 4) + q + 1],
-                           d2 = raw32[ry * (RAW_PITCH / 4) + q + 2];
-            uint32_t r[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t lo = j ? __builtin_amdgcn_alignbyte(d1, d0, j) : d0, hi = j ? __builtin_amdgcn_alignbyte(d2, d1, j) : d1;
-                r[j] = __builtin_amdgcn_udot4(hi, W_HI, __builtin_amdgcn_udot4(lo, W_LO, 0u, false), false);
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k;
+            if (i < 23 * (ROW_PITCH / 4)) {
+                const int m = (i * 6554) >> 16, q = i - m * (ROW_PITCH / 4);   // i / 10 (exact for i < 16384); columns 4q .. 4q+3 (column 39 is padding)
+                const int r0 = 2 * m, r1 = min(2 * m + 1, PW - 1);             // (pair 22's upper row does not exist: row 44 again, never used)
+                uint32_t out[4];
+                uint32_t hs[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t* row = raw32 + (u ? r1 : r0) * (RAW_PITCH / 4) + q;
+                    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t lo = j ? __builtin_amdgcn_alignbyte(d1, d0, j) : d0, hi = j ? __builtin_amdgcn_alignbyte(d2, d1, j) : d1;
+                        hs[u][j] = __builtin_amdgcn_udot4(hi, W_HI, __builtin_amdgcn_udot4(lo, W_LO, 0u, false), false);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[j] = hs[0][j] | (hs[1][j] << 16);
+                *reinterpret_cast<uint4*>(vp + m * ROW_PITCH + 4 * q) = make_uint4(out[0], out[1], out[2], out[3]);
             }
-            row32[ry * (ROW_PITCH / 2) + 2 * q] = r[0] | (r[1] << 16);
-            row32[ry * (ROW_PITCH / 2) + 2 * q + 1] = r[2] | (r[3] << 16);
         }
     }
     wave_lds_sync();
     DPH(4);
-    // Vertical pass with a sliding window in registers: a lane owns two adjacent columns (one dword of the row sums) and a
-    // third of the 39 output rows, reads its 19 rows once and emits 13 x 2 blurred bytes.
-    if (lane < 3 * (ROW_PITCH / 2)) {
-        const uint32_t* row32 = reinterpret_cast<const uint32_t*>(rowp);
-        const int seg = lane / (ROW_PITCH / 2), pcol = lane - seg * (ROW_PITCH / 2);
-        const int by0 = seg * 13;
-        uint32_t lo[19], hi[19];
+    // Vertical pass (round 4): an item is one column and one of three row segments (rows 0..13, 14..27, 28..41 -- every segment
+    // starts on an even row, rows 39..41 are computed and not stored): 117 items, two rounds of the wave.  A lane reads the ten
+    // row pairs its fourteen outputs need once; an output is four v_dot2_u32_u16 -- (18,34) (49,55) (49,34) (18,0) over the pairs
+    // from an even row, (0,18) (34,49) (55,49) (34,18) from an odd one, the rounding constant 32768 riding in the first
+    // accumulator -- a shift and the clamp: 6 vector instructions where rounds 2-3 spent 10 (and 38 to unpack the sums).
+    {
+        using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
+        auto dot2 = [](uint32_t pair, uint32_t w, uint32_t acc) {
+            return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, w), acc, false);
+        };
+        constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
+        constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
 #pragma unroll
-        for (int t = 0; t < 19; ++t) {
-            const uint32_t d = row32[(by0 + t) * (ROW_PITCH / 2) + pcol];
-            lo[t] = d & 0xffffu; hi[t] = d >> 16;
-        }
+        for (int k = 0; k < 2; ++k) {
+            const int id = lane + 64 * k;
+            if (id < 3 * BW) {
+                const int seg = (id * 1681) >> 16, col = id - seg * BW;   // id / 39 (exact for id < 117)
+                const uint32_t* src = vp + (7 * seg) * ROW_PITCH + col;   // first pair of the segment: rows 14 seg, 14 seg + 1
+                uint32_t P[10];
 #pragma unroll
-        for (int o = 0; o < 13; ++o) {
-            const uint32_t cl = 18u * (lo[o] + lo[o + 6]) + 34u * (lo[o + 1] + lo[o + 5]) + 49u * (lo[o + 2] + lo[o + 4]) + 55u * lo[o + 3];
-            const uint32_t ch = 18u * (hi[o] + hi[o + 6]) + 34u * (hi[o + 1] + hi[o + 5]) + 49u * (hi[o + 2] + hi[o + 4]) + 55u * hi[o + 3];
-            const uint32_t vl = min((cl + 32768u) >> 16, 255u), vh = min((ch + 32768u) >> 16, 255u);
-            *reinterpret_cast<uint16_t*>(&blur[(by0 + o) * ROW_PITCH + 2 * pcol]) = (uint16_t)(vl | (vh << 8));
+                for (int t = 0; t < 10; ++t) P[t] = src[t * ROW_PITCH];
+                uint8_t* dst = blur + (14 * seg) * ROW_PITCH + col;
+#pragma unroll
+                for (int o = 0; o < 14; ++o) {
+                    const int t0 = o >> 1;
+                    uint32_t acc;
+                    if (o & 1) acc = dot2(P[t0 + 3], O3, dot2(P[t0 + 2], O2, dot2(P[t0 + 1], O1, dot2(P[t0], O0, 32768u))));
+                    else acc = dot2(P[t0 + 3], E3, dot2(P[t0 + 2], E2, dot2(P[t0 + 1], E1, dot2(P[t0], E0, 32768u))));
+                    const uint32_t val = min(acc >> 16, 255u);
+                    if (o < 11 || seg < 2) dst[o * ROW_PITCH] = (uint8_t)val;   // (rows 39..41 of the last segment do not exist)
+                }
+            }
         }
     }
     wave_lds_sync();
