@@ -266,8 +266,8 @@ orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_on
     const unsigned long id = (unsigned long)F.mnId;
     // guard: everything an upload reads is either sampled or sized here -- the keypoint array's address, three records with their
     // right coordinates, the image bounds, the sizes of the two index maps, and per camera the descriptor matrix's address, row
-    // count, first and last row.  MORB_FRAME_CACHE_FULL_HASH=1 hashes every byte instead (test_host holds the two
-    // against each other: a hit under the sampled guard must be a hit under the full hash).
+    // count, first and last row.  MORB_FRAME_CACHE_FULL_HASH=1 hashes every byte instead (the three-thread class test
+    // runs its 600 cached searches under both and expects the same outputs).
     uint64_t guard = mix(0x243F6A8885A308D3ull, (uint64_t)(uintptr_t)kun.data());
     static const bool full_hash = [] { const char* e = std::getenv("MORB_FRAME_CACHE_FULL_HASH"); return e && std::atoi(e) != 0; }();
     {

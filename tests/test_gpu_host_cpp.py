@@ -691,12 +691,15 @@ def test_cv_gemm_restatement_known_answers():
 
 
 @pytest.mark.gpu
-def test_cpp_matcher_called_from_three_threads_at_once(tmp_path):
+@pytest.mark.parametrize("full_hash", [0, 1])
+def test_cpp_matcher_called_from_three_threads_at_once(tmp_path, full_hash):
     """The reference calls ORBmatcher concurrently from Tracking (src/Tracking.cc:1267), LocalMapping (src/LocalMapping.cc:361,741)
     and LoopClosing (src/LoopClosing.cc:362,445,536).  The three class-level cases of this file (tracking searches | BoW searches +
     SearchForTriangulation | relocalisation / loop searches, both SearchBySim3 forms, both Fuse overloads) -- each verified
     against the oracle first by its own test body -- then run 200 times each on three threads at once: every iteration's
-    output must equal the case run alone, and no device call may fail."""
+    output must equal the case run alone, and no device call may fail.  full_hash = 1: the per-thread cache of uploaded frames
+    keys its entries with a hash over EVERYTHING an upload reads (MORB_FRAME_CACHE_FULL_HASH) instead of the sampled guard --
+    600 cached searches must come out the same under either."""
     dirs = [tmp_path / k for k in ("match", "bow", "f4")]
     for d in dirs:
         d.mkdir()
@@ -704,6 +707,7 @@ def test_cpp_matcher_called_from_three_threads_at_once(tmp_path):
     test_cpp_vocabulary_and_bow_searches(dirs[1], 1, 0, (1, 1))
     test_cpp_remaining_projection_searches(dirs[2], 1)
     env = {k: v for k, v in os.environ.items() if k != "MORB_DUMP_QUERIES"}
+    env["MORB_FRAME_CACHE_FULL_HASH"] = str(full_hash)
     out = subprocess.run([BIN, "threads"] + [str(d / "case.bin") for d in dirs] + ["200"], env=env, capture_output=True, text=True, timeout=200)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "3 x 200 concurrent iterations, 0 mismatches, 0 errors, 0 failed device calls" in out.stdout
