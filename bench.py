@@ -93,6 +93,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the stored counter passes (profiles/pmc_traffic.json) instead of two rocprofv3 --pmc passes run now")
     ap.add_argument("--matrix-n", type=int, default=MATRIX_N)
     a = ap.parse_args(argv)
     if a.steps is None:
@@ -666,6 +668,13 @@ def main(argv=None):
     }
     if rank == 0 and not a.no_roofline:
         out["roofline"] = matcher_roofline(rt, m, fe.stream, a.matrix_n)
+        live = None if a.no_live_traffic else live_matrix_traffic(a.matrix_n)
+        if live and live.get("hbm_bytes_per_launch"):
+            out["roofline"]["traffic_stored"] = out["roofline"]["traffic"]
+            out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = live
+        else:
+            out["roofline"]["traffic_source"] = {"source": "stored counter passes (profiles/pmc_traffic.json)", "live": live}
         out["roofline_m1"] = top2_roofline(rt, m, fe.stream, a.matrix_n)
         out["roofline_m3"] = project_roofline(m)
     if rank == 0 and world == 1 and not a.no_dropin and a.config == 1:
@@ -706,6 +715,56 @@ def main(argv=None):
     if dist is not None:
         dist.destroy_process_group()
     return 0
+
+
+def live_matrix_traffic(n):
+    """`roofline.traffic` measured in THIS run: tools/matrix_once.py (1 GiB memset + 1 GiB copy as calibration, three launches of
+    the distance-matrix kernel at Q = R = n) in a child process under `rocprofv3 --pmc FETCH_SIZE` and, separately, `--pmc
+    WRITE_SIZE` (one counter per pass, nothing but the counters: MI355X_MICROARCH.md section HBM).  Both counters are in KiB;
+    FETCH_SIZE counts 64 B per 128-B request on gfx950 (x2: the copy's ratio is reported).  None / a reason when the profiler is
+    not there or a pass fails: the line then keeps the stored figure."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"why": "rocprofv3 not found"}
+    env = {k: v for k, v in os.environ.items() if not (k.startswith("ROCP") or k.startswith("ROCPROF") or k == "LD_PRELOAD")}
+    env.update(TMPDIR="/tmp", MORB_NO_BAR_STAGING="1")
+    GIB = float(1 << 30)
+    got = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            try:
+                p = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(td, counter), "-o", "p", "--",
+                                    sys.executable, os.path.join(ROOT, "tools", "matrix_once.py"), str(n)],
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                files = glob.glob(os.path.join(td, counter, "**", "*counter_collection.csv"), recursive=True)
+                if p.returncode != 0 or not files:
+                    return {"why": "%s pass failed (rc %s): %s" % (counter, p.returncode, (p.stderr or "")[-200:])}
+                acc = {}
+                for r in csv.DictReader(open(files[0])):
+                    if r["Counter_Name"] != counter:
+                        continue
+                    for key in ("k_hamming_matrix_mfma", "fillBuffer", "copyBuffer"):
+                        if key in r["Kernel_Name"]:
+                            acc.setdefault(key, []).append(float(r["Counter_Value"]) * 1024.0)
+                got[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+            except Exception as e:      # noqa: BLE001 -- reported in the line
+                return {"why": "%s pass: %r" % (counter, e)}
+    try:
+        fetch = got["FETCH_SIZE"]["k_hamming_matrix_mfma"] * 2.0
+        write = got["WRITE_SIZE"]["k_hamming_matrix_mfma"]
+        return {"source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over tools/matrix_once.py",
+                "hbm_bytes_per_launch": int(round(fetch + write)), "fetch_bytes_per_launch": int(round(fetch)),
+                "write_bytes_per_launch": int(round(write)),
+                "calibration": {"copy_1GiB_FETCH_SIZE_ratio": round(got["FETCH_SIZE"].get("copyBuffer", 0.0) / GIB, 4),
+                                "memset_1GiB_WRITE_SIZE_ratio": round(got["WRITE_SIZE"].get("fillBuffer", 0.0) / GIB, 4),
+                                "fetch_correction": 2.0}}
+    except Exception as e:      # noqa: BLE001
+        return {"why": "counters of the matrix kernel not found: %r" % (e,)}
 
 
 def cpu_native_leg(cpu_params, W, H, cpu_cams, cpu_frames, budget):

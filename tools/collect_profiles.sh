@@ -21,7 +21,7 @@ fi
 cd /tmp && export TMPDIR=/tmp
 export MORB_NO_BAR_STAGING=1
 export MORB_CHAIN_GRAPH=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python3 $R/bench.py --no-dropin > $O/bench_under_rocprof.json 2> $O/prof_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python3 $R/bench.py --no-dropin --no-live-traffic > $O/bench_under_rocprof.json 2> $O/prof_bench.err
 if [ "$1" != "prof-only" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4 -o c4 -- python3 $R/bench.py --config 4 --no-roofline --no-cpu > $O/bench_c4_under_rocprof.json 2> $O/prof_c4.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_matcher -o matcher -- python3 $R/tools/profile_matcher.py > $O/prof_matcher.out 2> $O/prof_matcher.err
