@@ -105,6 +105,9 @@ int orbx_debug_distribute_octree(const orb_keypoint* in, int n, int min_x, int m
 /* inspection: which keypoint-distribution path produced the last finished run -- 0 device quadtree, 1 device quadtree
  * including the memory-backed pass for levels beyond 4096 candidates, 2 host quadtree (fallback / MORB_HOST_OCTREE=1) */
 int orbx_debug_last_path(const orbx_extractor* ex);
+/* inspection: cameras whose pyramid level 0 the most recently enqueued run reads in the caller's device buffer instead of a copy
+ * (large rigs driven through orbf_*, which promises the buffers' lifetime; 0 everywhere else) */
+int orbx_debug_level0_in_place(const orbx_extractor* ex);
 int orbx_set_profiling(orbx_extractor* ex, int on);
 int orbx_stage_times_us(const orbx_extractor* ex, float* out6);
 

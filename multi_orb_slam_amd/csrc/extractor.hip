@@ -101,6 +101,22 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 // Level 0 of every camera whose image is already in HBM, in ONE launch (a 2-D copy per camera costs a launch each).
 struct IngestArgs { const uint8_t* src[64]; int stride[64]; };
 
+// Level 0 read IN PLACE (round 4, orbx_set_inplace_level0): on large rigs (the resize-chain pyramid) the copy of every camera's
+// image into the pyramid buffer was a kernel of its own -- 16.6 MB in and 16.6 MB out per 8 x 1080p step, 10 us alone and 40 us
+// next to the other chains -- although level 0 IS the image.  With the caller's promise that a device image stays valid and
+// unchanged until the camera's next upload, the three kernels that read level 0 (the first resize, FAST, describe) take it from
+// where it lies: a table of {pointer, pitch} per camera in device memory, written by a one-workgroup kernel per run (its
+// arguments change every step, so it stays outside a captured chain exactly as k_ingest did); an entry with a null pointer
+// means "level 0 is in the pyramid buffer".  Sources must be 4-byte aligned with a pitch that is a multiple of 4 (FAST stages
+// its tile as aligned dwords); anything else is copied as before.  A pageable host image the library has staged in HBM itself
+// (orbx_upload: the slot of the run that consumes it, rewritten two runs later at the earliest) is read in its staging slot alike.
+struct L0Src { const uint8_t* ptr; int stride; int pad; };
+
+__global__ void k_set_l0(IngestArgs A, L0Src* __restrict__ out, int n_cams) {
+    const int c = threadIdx.x;
+    if (c < n_cams) { L0Src s; s.ptr = A.src[c]; s.stride = A.stride[c]; s.pad = 0; out[c] = s; }
+}
+
 __global__ __launch_bounds__(256) void k_ingest(IngestArgs A, const LevelInfo* __restrict__ L, int max_levels,
                                                 uint8_t* __restrict__ pyr, size_t cam_pitch) {
     const int cam = blockIdx.z;
@@ -160,7 +176,8 @@ __global__ __launch_bounds__(256) void k_resize(const LevelInfo* __restrict__ L,
 // (The reads past a row's last tap stay inside the camera's pyramid block: orbx_create leaves 16 spare bytes behind the last level.)
 __global__ __launch_bounds__(256) void k_resize_v4(const LevelInfo* __restrict__ L, int max_levels, int level,
                                                    uint8_t* __restrict__ pyr, size_t cam_pitch,
-                                                   const int2* __restrict__ xtab, const int4* __restrict__ ytab) {
+                                                   const int2* __restrict__ xtab, const int4* __restrict__ ytab,
+                                                   const L0Src* __restrict__ l0) {
     // Workgroups reach the 8 XCDs round robin in dispatch order (x fastest, then y, then z), and a 256-pixel x 4-row block reads
     // source lines its neighbours on both axes read as well.  The launch's blocks are therefore dealt so that every XCD works
     // through ONE contiguous run of them in (camera, row band, column) order -- whole cameras of an 8-camera rig, bands of rows
@@ -177,6 +194,12 @@ __global__ __launch_bounds__(256) void k_resize_v4(const LevelInfo* __restrict__
     const int y = by * 4 + threadIdx.y;
     if (y >= D.h || x4 >= D.w) return;
     const uint8_t* src = pyr + cam * cam_pitch + S.pyr_off;
+    int sstride = S.stride;
+    bool external = false;   // level 0 read in the caller's buffer: nothing may be read past its last row
+    if (level == 1 && l0) {
+        const L0Src s0 = l0[cam];
+        if (s0.ptr) { src = s0.ptr; sstride = s0.stride; external = true; }
+    }
     uint8_t* dst = pyr + cam * cam_pitch + D.pyr_off;
     const int4 yt = ytab[D.ytab_off + y];  // {row0, row1, beta0, beta1}, rows already clipped to [0, sh-1]
     int2 xt[4];
@@ -192,8 +215,21 @@ __global__ __launch_bounds__(256) void k_resize_v4(const LevelInfo* __restrict__
     uint32_t L4[2], R4[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const uint8_t* p = src + (size_t)(r ? yt.y : yt.x) * S.stride + c;
+        const int row = r ? yt.y : yt.x;
+        const uint8_t* p = src + (size_t)row * sstride + c;
         const int sh = (int)(reinterpret_cast<uintptr_t>(p) & 3);
+        if (external && row == S.h - 1 && c - sh + 12 > S.w) {
+            // the three dwords would run past the end of the caller's buffer (last row, last columns): the eight taps byte by byte
+            const uint8_t* rowp = src + (size_t)row * sstride;
+            uint32_t l4 = 0, r4 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                l4 |= (uint32_t)rowp[xt[j].x & 0xffff] << (8 * j);
+                r4 |= (uint32_t)rowp[(unsigned)xt[j].x >> 16] << (8 * j);
+            }
+            L4[r] = l4; R4[r] = r4;
+            continue;
+        }
         const uint32_t* w = reinterpret_cast<const uint32_t*>(p - sh);
         const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
         const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
@@ -618,7 +654,7 @@ template <int FAST_NT, int GW>
 __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restrict__ L, const int2* __restrict__ cell_map,
                                                     const uint8_t* __restrict__ pyr, size_t cam_pitch, int max_levels,
                                                     int* __restrict__ cell_cnt, uint32_t* __restrict__ cell_items,
-                                                    int cell_h_max, int cell_px_max) {
+                                                    int cell_h_max, int cell_px_max, const L0Src* __restrict__ l0) {
     // LDS sized at launch for the largest cell of the rig (fast_cells_lds: the reference's 30-pixel cells take 7 KB, so that
     // sixteen two-wave cells fit a CU; the 64 x 64 worst case this build supports would take 19 KB):
     // tile rows (pitch TILE_PITCH) | score rows (pitch SCORE_PITCH) | survivor list | the two bitmaps
@@ -653,6 +689,11 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restr
         return;
     }
     const uint8_t* img = pyr + cam * cam_pitch + Lv.pyr_off;
+    int img_stride = Lv.stride;
+    if (l0 && blk == cam * max_levels) {   // level 0 may lie in the caller's buffer (k_set_l0)
+        const L0Src s0 = l0[cam];
+        if (s0.ptr) { img = s0.ptr; img_stride = s0.stride; }
+    }
     const int tw = cw + 6, th = ch + 6;
     // p / cw (and i / ndw below) for p < 70 * 70 by multiplication: exact because p * divisor < 2^20 (divisors <= 70)
     const unsigned inv_cw = d_inv20[cw];
@@ -665,10 +706,10 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restr
     const int sh = (x0 - 3) & 3, ndw = (tw + 3) >> 2;
     const unsigned inv_ndw = d_inv20[ndw];
     {
-        const uint8_t* src = img + (size_t)(y0 - 3) * Lv.stride + (x0 - 3 - sh);
+        const uint8_t* src = img + (size_t)(y0 - 3) * img_stride + (x0 - 3 - sh);
         for (int i = tid; i < ndw * th; i += FAST_NT) {
             const int ty = (int)(((unsigned)i * inv_ndw) >> 20), k = i - ty * ndw;
-            const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (size_t)ty * Lv.stride + 4 * k);
+            const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (size_t)ty * img_stride + 4 * k);
             const uint32_t lo = g[0], hi = sh ? g[1] : 0u;
             reinterpret_cast<uint32_t*>(tile_raw)[ty * (TILE_PITCH / 4) + k] = __builtin_amdgcn_alignbyte(hi, lo, sh);
         }
@@ -1274,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                                                   const SelKp* __restrict__ sel, int nsel,
                                                   orb_keypoint* const* __restrict__ kps_out,
                                                   uint8_t* const* __restrict__ desc_out, MirrorArgs mir, SelListArgs sl,
-                                                  FrameSink sink) {
+                                                  FrameSink sink, const L0Src* __restrict__ l0) {
     __shared__ alignas(16) uint8_t s_raw[4][PW * RAW_PITCH];
     __shared__ alignas(16) uint32_t s_vp[4][VP_PAIRS * ROW_PITCH];   // horizontal sums as VERTICAL pairs: row 2m | row 2m+1 << 16 per column
     __shared__ alignas(16) uint8_t s_blur[4][BW * ROW_PITCH];
@@ -1336,6 +1377,11 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     if (!slot_blk) mirror_base = mir.base[cam];
     const LevelInfo Lv = L[cam * max_levels + level];
     const uint8_t* img = pyr + cam * cam_pitch + Lv.pyr_off;
+    int img_stride = Lv.stride;
+    if (l0 && level == 0) {   // level 0 may lie in the caller's buffer (k_set_l0)
+        const L0Src s0 = l0[cam];
+        if (s0.ptr) { img = s0.ptr; img_stride = s0.stride; }
+    }
     uint8_t* raw = s_raw[wave];
     uint32_t* vp = s_vp[wave];
     uint8_t* blur = s_blur[wave];
@@ -1373,7 +1419,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             v[k] = 0;
-            if (lane < 60) __builtin_memcpy(&v[k], p0 + (size_t)reflect101(K.y - PR + g + 5 * k, Lv.h) * Lv.stride, 4);
+            if (lane < 60) __builtin_memcpy(&v[k], p0 + (size_t)reflect101(K.y - PR + g + 5 * k, Lv.h) * img_stride, 4);
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -1740,6 +1786,12 @@ struct orbx_extractor {
     DevBuf<uint32_t> d_cand_dev;
     DevBuf<int> d_level_cnt_dev, d_sel_cnt, d_oct_status, d_n_out;
     bool pinned_ingest = false;       // page-locked host images are read by k_ingest directly (orbx_set_pinned_ingest) instead of hipMemcpy2DAsync
+    // level 0 in place (orbx_set_inplace_level0): l0_on = the geometry takes it (resize-chain pyramid) and the caller opted in;
+    // l0_active = the device table holds pointers of the last run's images; l0_host = what it holds (inspection hook)
+    bool l0_optin = false, l0_on = false, l0_active = false;
+    DevBuf<L0Src> d_l0;
+    std::vector<L0Src> l0_host;
+    std::vector<uint8_t> uploaded;    // cameras handed an image (any kind, also an empty one) since the last run
     bool pinned_ingest_env = true;    // MORB_PINNED_INGEST=0: never
     int oct_max_keys = OCT_NK;        // candidates per (camera, level) the device quadtree takes (MORB_OCT_MAX_KEYS lowers it: tests of the fallback)
     int last_path = 0;                // inspection: 0 device quadtree, 2 host quadtree
@@ -1949,6 +2001,16 @@ static int rebuild_geometry(orbx_extractor* ex) {
         const bool prefer_chain = ex->chain_v4 && (chain_env == 1 || (chain_env < 0 && (long long)px0 > chain_px));
         if (prefer_chain) ex->tiled_ok = false;
     }
+    {
+        static const bool l0_env = [] { const char* e = getenv("MORB_L0_INPLACE"); return !(e && atoi(e) == 0); }();
+        // (only the one-level-per-launch chain of k_resize_v4 knows the table: the paired launches of small rigs -- k_resize2 -- and
+        // the tile kernel read level 0 in the pyramid buffer; same condition as launch_pyramid_fast's `pairs`)
+        static const bool pairs_env = [] { const char* e = getenv("MORB_PYRAMID_PAIRS"); return !(e && atoi(e) == 0); }();
+        long long level1_px = 0;
+        if (ML > 1) for (int c = 0; c < ex->n_cams; ++c) { const LevelInfo& Lv = ex->levels[(size_t)c * ML + 1]; level1_px += (long long)Lv.w * Lv.h; }
+        const bool pairs = pairs_env && level1_px <= (1ll << 20);
+        ex->l0_on = ex->l0_optin && l0_env && ex->chain_v4 && !(ex->tiled_pyramid && ex->tiled_ok) && !pairs;
+    }
     if (slot_base > (size_t)INT32_MAX) { morb::set_error("candidate slot space exceeds 2^31 entries"); return ORB_E_ARG; }
     ex->total_cells = cell_base;
     ex->total_slots = slot_base;
@@ -1974,6 +2036,11 @@ static int rebuild_geometry(orbx_extractor* ex) {
         return rc;
     if (!slot_blk.empty())
         MORB_HIP(hipMemcpyAsync(ex->d_slot_blk.p, slot_blk.data(), slot_blk.size() * sizeof(unsigned short), hipMemcpyHostToDevice, ex->stream));
+    // (the level-0 table starts empty with every geometry: level 0 is in the pyramid buffer until a run says otherwise)
+    if ((rc = ex->d_l0.reserve(64))) return rc;
+    MORB_HIP(hipMemsetAsync(ex->d_l0.p, 0, 64 * sizeof(L0Src), ex->stream));
+    ex->l0_host.assign(64, L0Src{nullptr, 0, 0});
+    ex->l0_active = false;
     if (slot_base > ex->h_cand_cap) {
         if (ex->h_cand) (void)hipHostFree(ex->h_cand);
         ex->h_cand = nullptr; ex->h_cand_cap = 0;
@@ -2080,6 +2147,8 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     if (const char* e = getenv("MORB_OCT_MAX_KEYS")) ex->oct_max_keys = std::min(OCT_NK, std::max(1, atoi(e)));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
+    ex->uploaded.assign(n_cams, 0);
+    ex->l0_host.assign(64, L0Src{nullptr, 0, 0});
     {
         const char* e = getenv("MORB_OCTREE_THREADS");
         int nt = e ? atoi(e) : 4;
@@ -2099,7 +2168,7 @@ void orbx_destroy(orbx_extractor* ex) {
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     for (int sl = 0; sl < 2; ++sl) for (int w = 0; w < orbx_extractor::CHAIN_WAYS; ++w) ex->chain[sl][w].destroy();
-    ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release(); ex->d_pyr_sx.release(); ex->d_pyr_sy.release();
+    ex->d_l0.release(); ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_ytab.release(); ex->d_pyr_sx.release(); ex->d_pyr_sy.release();
     ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release(); ex->d_sel_oct.release();
     ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release();
     ex->d_n_out.release(); ex->d_slot_blk.release();
@@ -2122,6 +2191,7 @@ void* orbx_stream(const orbx_extractor* ex) { return ex ? (void*)ex->stream : nu
 static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int width, int height, int stride, hipMemcpyKind kind) {
     MORB_ARG(ex && cam >= 0 && cam < ex->n_cams);
     MORB_HIP(hipSetDevice(ex->device));
+    ex->uploaded[cam] = 1;
     if (!src || width <= 0 || height <= 0) {  // empty image: camera produces nothing (reference :1047-1048)
         if (ex->cur_w[cam] != 0) { ex->cur_w[cam] = ex->cur_h[cam] = 0; ex->tables_dirty = true; }
         ex->ingest.src[cam] = nullptr;
@@ -2201,6 +2271,13 @@ int orbx_set_host_mirror(orbx_extractor* ex, orb_keypoint* kps_devptr, uint8_t* 
 
 int orbx_debug_last_path(const orbx_extractor* ex) { return ex ? ex->last_path : ORB_E_ARG; }
 
+int orbx_debug_level0_in_place(const orbx_extractor* ex) {
+    if (!ex) return ORB_E_ARG;
+    int n = 0;
+    if (ex->l0_active) for (int c = 0; c < ex->n_cams; ++c) n += ex->l0_host[c].ptr != nullptr;
+    return n;
+}
+
 int orbx_set_profiling(orbx_extractor* ex, int on) {
     MORB_ARG(ex != nullptr);
     ex->profiling = on != 0;
@@ -2259,6 +2336,15 @@ int orbx_record_done(orbx_extractor* ex) {   // the completion event of the most
     return ORB_OK;
 }
 
+// 1: device images handed to orbx_upload_device are read IN PLACE as pyramid level 0 by every run until the camera's next upload
+// (large rigs only: the resize-chain pyramid; see k_set_l0).  The caller promises that such an image stays valid and unchanged
+// until then -- orbf's own contract for the images of a step.  MORB_L0_INPLACE=0: never.
+int orbx_set_inplace_level0(orbx_extractor* ex, int on) {
+    MORB_ARG(ex != nullptr);
+    if (ex->l0_optin != (on != 0)) { ex->l0_optin = on != 0; ex->tables_dirty = true; }   // (captured chains carry the table pointer: new epoch)
+    return ORB_OK;
+}
+
 int orbx_set_pinned_ingest(orbx_extractor* ex, int on) {
     MORB_ARG(ex != nullptr);
     ex->pinned_ingest = on != 0;
@@ -2297,6 +2383,10 @@ void* orbx_done_event(const orbx_extractor* ex) { return ex ? (void*)ex->ev_done
 
 // K1 + K2/K3 of a run: the pyramid chain and the per-cell FAST kernel
 // fused: the level-0 sources of a pending ingest (k_pyramid_tiled then reads them itself: no k_ingest launch); NULL: level 0 is in place
+// the {pointer, pitch} table of level 0 the kernels are handed: the handle's table while the geometry reads level 0 in place
+// (part of what a captured chain carries: the flag only changes together with the geometry epoch), else none
+static inline const L0Src* l0_table(const orbx_extractor* ex) { return ex->l0_on ? (const L0Src*)ex->d_l0.p : nullptr; }
+
 static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestArgs* fused = nullptr) {
     const int ML = ex->max_levels;
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[0], st));
@@ -2343,7 +2433,7 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestA
             dim3 grid((mw + 255) / 256, (mh + 3) / 4, ex->n_cams), block(64, 4, 1);
             if (ex->chain_v4)
                 hipLaunchKernelGGL(k_resize_v4, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
-                                   (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
+                                   (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p, l0_table(ex));
             else
             hipLaunchKernelGGL(k_resize, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
                                (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
@@ -2363,11 +2453,11 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestA
     if (throughput)
         hipLaunchKernelGGL((k_fast_cells<128, 8>), dim3(ex->total_cells), dim3(128), fast_cells_lds(ex->cell_h_max, ex->cell_px_max), st,
                            (const LevelInfo*)ex->d_levels.p, (const int2*)ex->d_cell_map.p, (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, ML,
-                           ex->d_cell_cnt.p, ex->d_cell_items.p, ex->cell_h_max, ex->cell_px_max);
+                           ex->d_cell_cnt.p, ex->d_cell_items.p, ex->cell_h_max, ex->cell_px_max, l0_table(ex));
     else
         hipLaunchKernelGGL((k_fast_cells<256, 4>), dim3(ex->total_cells), dim3(256), fast_cells_lds(ex->cell_h_max, ex->cell_px_max), st,
                            (const LevelInfo*)ex->d_levels.p, (const int2*)ex->d_cell_map.p, (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, ML,
-                           ex->d_cell_cnt.p, ex->d_cell_items.p, ex->cell_h_max, ex->cell_px_max);
+                           ex->d_cell_cnt.p, ex->d_cell_items.p, ex->cell_h_max, ex->cell_px_max, l0_table(ex));
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[2], st));
     MORB_HIP(hipGetLastError());
     return ORB_OK;
@@ -2390,7 +2480,7 @@ static int launch_tree_describe(orbx_extractor* ex, hipStream_t st, unsigned slo
                        (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
                        SelListArgs{(const unsigned short*)ex->d_slot_blk.p, (const int*)ex->d_sel_cnt.p,
                                    (const int*)ex->d_oct_status.p, ex->d_n_out.p + slot * ex->n_cams, d_h_oct, ex->n_cams},
-                       sink);
+                       sink, l0_table(ex));
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[5], st));
     MORB_HIP(hipGetLastError());
     return ORB_OK;
@@ -2430,21 +2520,50 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
     const bool will_replay = dev_tree && ex->use_graph && ex->graph_next_run && allow_async && !ex->profiling;
     IngestArgs fused_src;
     const IngestArgs* fused = nullptr;
-    if (ex->ingest_pending) {
+    bool any_upload = false;
+    for (int c = 0; c < ex->n_cams; ++c) any_upload |= ex->uploaded[c] != 0;
+    if (ex->ingest_pending || (ex->l0_active && any_upload)) {
         // (sources in host memory are copied exactly once by k_ingest: the tiles' halos would cross PCIe twice)
-        if (ex->tiled_pyramid && ex->tiled_ok && !will_replay && !ex->ingest_host) {
+        if (ex->ingest_pending && ex->tiled_pyramid && ex->tiled_ok && !will_replay && !ex->ingest_host) {
             fused_src = ex->ingest; fused = &fused_src;
         } else {
-            int mw = 0, mh = 0;
-            for (int c = 0; c < ex->n_cams; ++c)
-                if (ex->ingest.src[c]) { mw = std::max(mw, ex->cur_w[c]); mh = std::max(mh, ex->cur_h[c]); }
-            if (mw > 0)
-                hipLaunchKernelGGL(k_ingest, dim3((mw + 1023) / 1024, (mh + 3) / 4, ex->n_cams), dim3(64, 4, 1), 0, st, ex->ingest,
-                                   (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch);
+            // Level 0 in place (k_set_l0 above): every camera that has an image must have been handed a device image for THIS run,
+            // 4-byte aligned with a pitch that is a multiple of 4.  Otherwise the images are copied -- and a camera that was read in
+            // place so far and got no new image in this run is copied too, from where it lies (valid until its next upload), before
+            // the table is emptied: no run ever finds a camera's level 0 in neither place.
+            bool inplace = ex->l0_on && ex->ingest_pending && !ex->ingest_host;
+            for (int c = 0; c < ex->n_cams && inplace; ++c) {
+                if (ex->cur_w[c] == 0) continue;
+                const uint8_t* p = ex->ingest.src[c];
+                if (!p || (reinterpret_cast<uintptr_t>(p) & 3) || (ex->ingest.stride[c] & 3)) inplace = false;
+            }
+            if (inplace) {
+                IngestArgs T = ex->ingest;
+                for (int c = 0; c < 64; ++c) if (c >= ex->n_cams || ex->cur_w[c] == 0) { T.src[c] = nullptr; T.stride[c] = 0; }
+                hipLaunchKernelGGL(k_set_l0, dim3(1), dim3(64), 0, st, T, ex->d_l0.p, ex->n_cams);
+                for (int c = 0; c < ex->n_cams; ++c) ex->l0_host[c] = L0Src{T.src[c], T.stride[c], 0};
+                ex->l0_active = true;
+            } else {
+                IngestArgs I = ex->ingest;
+                if (ex->l0_active) {
+                    for (int c = 0; c < ex->n_cams; ++c)
+                        if (!ex->uploaded[c] && ex->cur_w[c] > 0 && ex->l0_host[c].ptr) { I.src[c] = ex->l0_host[c].ptr; I.stride[c] = ex->l0_host[c].stride; }
+                    MORB_HIP(hipMemsetAsync(ex->d_l0.p, 0, 64 * sizeof(L0Src), st));
+                    ex->l0_host.assign(64, L0Src{nullptr, 0, 0});
+                    ex->l0_active = false;
+                }
+                int mw = 0, mh = 0;
+                for (int c = 0; c < ex->n_cams; ++c)
+                    if (I.src[c]) { mw = std::max(mw, ex->cur_w[c]); mh = std::max(mh, ex->cur_h[c]); }
+                if (mw > 0)
+                    hipLaunchKernelGGL(k_ingest, dim3((mw + 1023) / 1024, (mh + 3) / 4, ex->n_cams), dim3(64, 4, 1), 0, st, I,
+                                       (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch);
+            }
         }
         for (int c = 0; c < ex->n_cams; ++c) ex->ingest.src[c] = nullptr;
         ex->ingest_pending = false; ex->ingest_host = false;
     }
+    std::fill(ex->uploaded.begin(), ex->uploaded.end(), 0);
     if (!dev_tree) {
         if ((rc = launch_pyramid_fast(ex, st, fused))) return rc;
         // K3b (only on the host-quadtree path and for the inspection hook): dense cell-major lists, also into pinned host memory
@@ -2603,7 +2722,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         hipLaunchKernelGGL(k_describe, dim3((nsel + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
                            (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel.p, nsel,
                            (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
-                           SelListArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, FrameSink{});
+                           SelListArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, FrameSink{}, l0_table(ex));
         MORB_HIP(hipGetLastError());
     }
     if (ex->profiling) {
@@ -2733,7 +2852,10 @@ int orbx_debug_level(orbx_extractor* ex, int cam, int level, uint8_t* out, int c
     *w = Lv.w; *h = Lv.h;
     if (Lv.w == 0) return ORB_OK;
     if (Lv.w * Lv.h > cap_bytes) { morb::set_error("level needs %d bytes", Lv.w * Lv.h); return ORB_E_CAPACITY; }
-    MORB_HIP(hipMemcpy2DAsync(out, Lv.w, ex->d_pyr.p + (size_t)cam * ex->cam_pitch + Lv.pyr_off, Lv.stride, Lv.w, Lv.h,
+    const uint8_t* lsrc = ex->d_pyr.p + (size_t)cam * ex->cam_pitch + Lv.pyr_off;
+    size_t lpitch = (size_t)Lv.stride;
+    if (level == 0 && ex->l0_active && ex->l0_host[cam].ptr) { lsrc = ex->l0_host[cam].ptr; lpitch = (size_t)ex->l0_host[cam].stride; }   // (read in place)
+    MORB_HIP(hipMemcpy2DAsync(out, Lv.w, lsrc, lpitch, Lv.w, Lv.h,
                               hipMemcpyDeviceToHost, ex->stream));
     MORB_HIP(hipStreamSynchronize(ex->stream));
     return ORB_OK;

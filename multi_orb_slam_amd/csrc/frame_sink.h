@@ -45,6 +45,8 @@ extern "C" int orbx_set_chain_graph(orbx_extractor* ex, int on);
 extern "C" int orbx_set_defer_done(orbx_extractor* ex, int on);
 // 1: page-locked host images handed to orbx_upload are read by the run's ingest kernel directly (no copy per camera)
 extern "C" int orbx_set_pinned_ingest(orbx_extractor* ex, int on);
+// 1: device images are read in place as pyramid level 0 until the camera's next upload (large rigs; extractor.hip: k_set_l0)
+extern "C" int orbx_set_inplace_level0(orbx_extractor* ex, int on);
 extern "C" int orbx_record_done(orbx_extractor* ex);
 // orbx_finish without the wait on the completion event, for a caller that has already seen the results of GPU work ordered
 // behind the oldest run in flight (orbf_step_end after it watched the resolve's result words arrive)

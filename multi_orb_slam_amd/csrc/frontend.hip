@@ -114,6 +114,9 @@ int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int 
     f->device = device; f->n_cams = n_cams; f->max_w = max_width; f->max_h = max_height;
     int rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[0]);
     f->ex = f->exs[0];
+    // (device images of a step stay valid and unchanged until the step has returned -- this interface's own contract -- and every
+    // step hands every camera an image: large rigs read pyramid level 0 in the caller's buffers instead of copying it)
+    if (!rc) rc = orbx_set_inplace_level0(f->exs[0], 1);
     if (!rc) rc = orbm_create(device, &f->mt);
     // two streams: the matcher's own one follows the extractor's through events, so that the next step's extraction can
     // run next to this step's matching
@@ -136,7 +139,10 @@ int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int 
     // matcher's stream (exchange_queues), so a handle keeps its depth of three with it.
     { const int d = ahead_depth > 0 ? ahead_depth : getenv_int("MORB_AHEAD_DEPTH", 3); f->n_ex = d < 1 ? 1 : (d > orbf_frontend::NEX ? orbf_frontend::NEX : d); }
     f->params.assign(params, params + n_cams);
-    for (int e = 1; e < f->n_ex && !rc; ++e) rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[e]);  // overlap partners
+    for (int e = 1; e < f->n_ex && !rc; ++e) {   // overlap partners
+        rc = orbx_create(params, n_cams, max_width, max_height, device, &f->exs[e]);
+        if (!rc) rc = orbx_set_inplace_level0(f->exs[e], 1);
+    }
     for (int k = 0; k < orbf_frontend::NSETS && !rc; ++k)
         if ((rc = f->rs[k].kps.reserve(cap)) || (rc = f->rs[k].desc.reserve(cap * 32)) || (rc = f->rs[k].ur.reserve(cap)) ||
             (rc = f->rs[k].depth.reserve(cap)) || (rc = f->rs[k].unx.reserve(cap)) || (rc = f->rs[k].uny.reserve(cap))) break;
@@ -617,7 +623,9 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
 
 static int ensure_extractor(orbf_frontend* f, int e) {
     if (f->exs[e]) return ORB_OK;
-    return orbx_create(f->params.data(), f->n_cams, f->max_w, f->max_h, f->device, &f->exs[e]);
+    int rc = orbx_create(f->params.data(), f->n_cams, f->max_w, f->max_h, f->device, &f->exs[e]);
+    if (!rc) rc = orbx_set_inplace_level0(f->exs[e], 1);
+    return rc;
 }
 
 // Everything in flight is waited for and dropped (results of prefetched extractions included).

@@ -151,6 +151,10 @@ class Extractor:
         """0 device quadtree, 1 device quadtree incl. the memory-backed pass, 2 host quadtree (orbx_debug_last_path)."""
         return _lib.lib().orbx_debug_last_path(self._h)
 
+    def level0_in_place(self):
+        """cameras whose level 0 the last run read in the caller's device buffer (orbx_debug_level0_in_place)"""
+        return _lib.lib().orbx_debug_level0_in_place(self._h)
+
     def debug_candidates(self, cam, level):
         n = C.c_int()
         check(_lib.lib().orbx_debug_candidates(self._h, cam, level, None, 0, C.byref(n)))
