@@ -424,6 +424,7 @@ template <> struct Mt<false> {
     using Acc = mm_i32x16;
     static constexpr int KS = 8;                        // matrix instructions per 32 x 32 block
     static constexpr uint32_t KEY_NONE = 256u << 6;     // key = distance << 6 | row
+    static constexpr uint32_t ROW_MASK = 63u;
     static __device__ __forceinline__ void queries(mm_i32x4 (&bq)[KS], const uint32_t (&w)[8], int h) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bq[ks] = mm_expand16(h ? (w[ks] >> 16) : (w[ks] & 0xffffu));
@@ -456,6 +457,7 @@ template <> struct Mt<true> {
     // distance in bits 14..22 -- and closing a block is integer work on the pattern (one v_and clears the row, a bit-field extract
     // reads it) instead of a conversion to integer, the mask and a conversion back per query group and block.
     static constexpr uint32_t KEY_NONE = 0x46C00000u;   // 16384 + 32 * 256 = 24576.0f: "distance 256"
+    static constexpr uint32_t ROW_MASK = 31u << 9;
     static __device__ __forceinline__ void queries(mm_i32x4 (&bq)[KS], const uint32_t (&w)[8], int h) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bq[ks] = f4_expand32<true>(h ? w[2 * ks + 1] : w[2 * ks]);
@@ -509,6 +511,64 @@ __device__ __forceinline__ void mt_keys(Top2Run& R, const typename Mt<FP4>::Acc 
 }
 struct MtAll { __device__ __forceinline__ bool operator()(int, int) const { return false; } };
 
+// Round 4: one half-tile step with the key work GATED.  A key changes (best, second) of its lane only if it is below the lane's
+// `second` (best <= second always: second' = med3(best, second, key) >= best' = min(best, key), and closing a block only lowers
+// best) -- and once a query has seen a few hundred references almost no key is.  So the 16 keys of a block and query group are
+// taken four at a time (four consecutive reference rows): their minimum (v_min3 + v_min), one compare against `second`, and the
+// eight med3 / min instructions only when some lane of the wave passes it -- a wave-uniform branch, exact by the argument above.
+// Over a 4700-reference slice about a third of the quarters still take the long way (256 keys of the wave against thresholds
+// that start at "nothing seen"), the rest cost 3 instructions instead of 8.  The branches would keep the compiler from spreading
+// the next half's matrix instructions among this vector work (mt_mfma_half + mt_keys were one straight line), so the step is
+// written out: one (FP4) or two (int8) matrix instructions in front of every quarter.
+#ifndef MORB_TOP2_GATED
+#define MORB_TOP2_GATED 1
+#endif
+template <bool FP4>
+__device__ __forceinline__ void mt_step(typename Mt<FP4>::Acc (&nxt)[2], const mm_i32x4* __restrict__ tile, int a, int lane,
+                                        const mm_i32x4 (&bq)[2][Mt<FP4>::KS], const typename Mt<FP4>::Acc& cinit, Top2Run& R,
+                                        const typename Mt<FP4>::Acc (&acc)[2], int blk) {
+#if MORB_TOP2_GATED
+    using M = Mt<FP4>;
+    uint32_t before = 0;
+    // (all reference fragments of the half are requested up front: behind a branch the compiler no longer hoists a read above the
+    // vector work in front of it, and a read issued right before its matrix instruction stalls the wave for the LDS round trip)
+    mm_i32x4 af[M::KS];
+#pragma unroll
+    for (int ks = 0; ks < M::KS; ++ks) af[ks] = tile[(a * M::KS + ks) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int g = s >> 2, qd = s & 3;
+        // matrix instructions of this slot, in the order (ks, query group) of mt_mfma_half
+#pragma unroll
+        for (int u = 0; u < 2 * M::KS / 8; ++u) {
+            const int idx = s * (2 * M::KS / 8) + u, ks = idx >> 1, gg = idx & 1;
+            nxt[gg] = M::mfma(af[ks], bq[gg][ks], ks ? nxt[gg] : cinit);
+        }
+        if (qd == 0) before = R.kb[g];
+        uint32_t k[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = M::key(acc[g], 4 * qd + j);
+        const uint32_t m = min(min(min(k[0], k[1]), k[2]), k[3]);
+        if (__builtin_amdgcn_ballot_w64(m < R.ks2[g]) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                R.ks2[g] = mt_umed3(R.kb[g], R.ks2[g], k[j]);
+                R.kb[g] = min(R.kb[g], k[j]);
+            }
+        }
+        if (qd == 3) {
+            M::close_block(R.kb[g], R.where[g], before, blk);
+            // `second` is only ever reported as a distance: without its row bits the gate compares distances, and a key that merely
+            // TIES with `second` (it cannot beat `best` then: rows ascend within a block, earlier blocks' rows are cleared) stays out
+            R.ks2[g] &= ~M::ROW_MASK;
+        }
+    }
+#else
+    mt_mfma_half<FP4>(nxt, tile, a, lane, bq, cinit);
+    mt_keys<FP4>(R, acc, blk, MtAll());
+#endif
+}
+
 template <bool FP4>
 __global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_top2_mfma(const uint32_t* __restrict__ q, int nq,
                                                                     const uint32_t* __restrict__ r, int nr, int slice_len,
@@ -549,13 +609,11 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_top2_mfma(const uint3
     mt_mfma_half<FP4>(acc0, s_tile[0], 0, lane, bq, cinit);
     for (int t = 0; t + 1 < n_tiles; ++t) {   // every tile but the last one is full
         const int buf = t & 1;
-        mt_mfma_half<FP4>(acc1, s_tile[buf], 1, lane, bq, cinit);       // second half of tile t on the matrix cores ...
-        mt_keys<FP4>(R, acc0, 2 * t, MtAll());                          // ... the keys of its first half on the vector ALU
+        mt_step<FP4>(acc1, s_tile[buf], 1, lane, bq, cinit, R, acc0, 2 * t);   // second half of tile t on the matrix cores | the keys of its first half on the vector ALU
         deposit(buf ^ 1, nxt);
         __syncthreads();
         nxt = fetch(t + 2);
-        mt_mfma_half<FP4>(acc0, s_tile[buf ^ 1], 0, lane, bq, cinit);   // first half of tile t + 1 | keys of the second half of tile t
-        mt_keys<FP4>(R, acc1, 2 * t + 1, MtAll());
+        mt_step<FP4>(acc0, s_tile[buf ^ 1], 0, lane, bq, cinit, R, acc1, 2 * t + 1);   // first half of tile t + 1 | keys of the second half of tile t
     }
     {   // the last tile (its first half is in acc0): rows past the end of the slice do not count
         const int t = n_tiles - 1;
@@ -750,13 +808,11 @@ __device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * M
         mt_mfma_half<FP4>(acc0, s_tile[0], 0, lane, bq, cinit);
         for (int t = 0; t + 1 < n_tiles; ++t) {   // every tile but the last one is full
             const int buf = t & 1;
-            mt_mfma_half<FP4>(acc1, s_tile[buf], 1, lane, bq, cinit);       // second half of tile t on the matrix cores ...
-            mt_keys<FP4>(R, acc0, 2 * t, MtAll());                          // ... the keys of its first half on the vector ALU
+            mt_step<FP4>(acc1, s_tile[buf], 1, lane, bq, cinit, R, acc0, 2 * t);   // second half of tile t on the matrix cores | the keys of its first half on the vector ALU
             deposit(buf ^ 1, nxt);
             __syncthreads();
             nxt = fetch(t + 2);
-            mt_mfma_half<FP4>(acc0, s_tile[buf ^ 1], 0, lane, bq, cinit);   // first half of tile t + 1 | keys of the second half of tile t
-            mt_keys<FP4>(R, acc1, 2 * t + 1, MtAll());
+            mt_step<FP4>(acc0, s_tile[buf ^ 1], 0, lane, bq, cinit, R, acc1, 2 * t + 1);   // first half of tile t + 1 | keys of the second half of tile t
         }
         {   // the last tile (its first half is in acc0): rows past the end of the slice do not count
             const int t = n_tiles - 1;

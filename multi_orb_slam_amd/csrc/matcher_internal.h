@@ -90,6 +90,7 @@ struct orbm_matcher {
     orb_calibration calib = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // orbm_set_calibration: undistortion applied by device-built frames (k1 == 0: off)
     int frame_min_rows = 0;  // the next device-built frame gets at least this many descriptor rows (fixed export block size)
     int last_status[4] = {0, 0, 0, 0};  // {status, nmatches, sweeps, longest list} of the last device resolve
+    std::vector<int> rs_cam_count;     // scratch of search_enqueue: queries per camera (per-camera resolve)
     int rs_sweeps_hint = 24;           // sweeps the multi-workgroup resolve enqueues next time (what the last one needed + 4)
     bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
     int resolve_seq = 0;           // sequence number of the last tagged resolve launch
@@ -146,6 +147,7 @@ struct SearchJob {
     const struct SideJob* side = nullptr;   // work that shares the projection kernel's launch (consumed by search_enqueue)
     bool multi = false;                 // the resolve in flight is the multi-workgroup form (one launch per sweep)
     const MotionSrc* msrc = nullptr;    // queries built by the projection kernel itself (then `q` is only read by the host fallbacks)
+    int q_cam_max = 0;                  // upper bound of the queries any one camera has (0 = not known; counted from `q` when that is final)
     void (*q_fill)(void*) = nullptr; void* q_fill_ctx = nullptr;   // ... which call this first when `q` has not been written yet
 };
 

@@ -780,7 +780,7 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
 // over the whole chip.  The two claim tables, the choices and the owner table live in HBM (L2-resident); one launch per
 // sweep (a grid-wide barrier is exactly what a kernel boundary is), a fixed number of sweeps is enqueued and a sweep
 // that finds "nothing changed" in its predecessor's flag does nothing, so no host round trip sits between sweeps.
-// state: [0] longest candidate list, [1] matches, [2..4] kept rotation bins, [5] sweeps enqueued, [8..8+RS_MAX_SWEEPS) changed flags,
+// state: [0] longest candidate list, [1] matches, [2..4] kept rotation bins, [5] sweeps enqueued, [6] rounds (per-camera form), [8..8+RS_MAX_SWEEPS) changed flags,
 //        [48..78) rotation histogram.
 constexpr int RS_MAX_SWEEPS = 24;
 constexpr int RS_STATE_INTS = 80;
@@ -950,12 +950,221 @@ __global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __rest
         for (int k = 0; k < state[5]; ++k) sweeps += state[8 + k] ? 1 : 0;
         status[0] = overflow ? 2 : (stuck ? 1 : 0);
         status[1] = (overflow || stuck) ? 0 : state[1];
-        status[2] = sweeps + 1;
+        status[2] = state[6] ? state[6] : sweeps + 1;   // (rounds of the per-camera form, the slowest camera's)
         status[3] = state[0];
     }
     if (overflow || stuck) return;
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g < NT) match_of_feature[g] = owner[g];
+}
+
+// ---- the monotone resolve for frames beyond one workgroup's LDS, ONE WORKGROUP PER CAMERA (round 4).  A query of the frame
+// search looks at the grid of exactly one camera (project_dev.h: one window, `cam`), so its candidates are features of that camera
+// and a claim never crosses cameras: the reference's sequential loop (src/ORBmatcher.cc:3502-3614) falls apart into one independent
+// loop per camera, each over that camera's queries in their global order.  Workgroup c therefore gathers the queries of camera c
+// (ordered compaction over the {blocks | camera << 1} words k_project left), keeps that camera's claim and owner tables in LDS
+// (8 bytes per feature: 32 KB for 4000 features, against 256 KB for the whole 8-camera frame, which is what sent these frames to
+// one launch per sweep before) and runs the monotone iteration of k_resolve_mono on them with every query in registers (four per
+// thread: up to 4096 queries per camera).  What needs the WHOLE frame -- the rotation histogram's three maxima and the rejection
+// behind them -- stays with k_rs_reject / k_rs_write, fed through the same `state` words as the per-sweep form:
+// this kernel leaves choice[] (global feature index or -1 per query), owner[] per feature, state[0] (longest list), state[1]
+// (matches), state[5] = 1 and state[8] = "did not finish" (tables or queries beyond this launch's limits, or out of rounds:
+// the exact host fallback takes over, search_finish), state[48..78) the histogram.
+constexpr int RSC_RQ = 4;
+__global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __restrict__ f_cam_start, const int2* __restrict__ qmeta, int nq,
+                                                      int cap, int nf_cap, const int* __restrict__ cand_idx,
+                                                      const uint16_t* __restrict__ cand_dist, const int* __restrict__ cand_count,
+                                                      const uint8_t* __restrict__ occupied, const float* __restrict__ f_angle, int th_high,
+                                                      int check_ori, int max_it, const int* __restrict__ topk, int* __restrict__ choice,
+                                                      int* __restrict__ owner, int* __restrict__ state) {
+    extern __shared__ __attribute__((aligned(16))) int s_claim[];  // [0, nf_cap): lowest blocking claimant (global query index); [nf_cap, 2 nf_cap): owner
+    __shared__ int s_hist[ORBM_HISTO_LENGTH];
+    __shared__ int s_red, s_cnt;
+    __shared__ int s_flag[3];
+    __shared__ int s_wtot[16];
+    constexpr int K = RESOLVE_K, RQ = RSC_RQ, T = 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cam = blockIdx.x;
+    const int f0 = f_cam_start[cam], nf = f_cam_start[cam + 1] - f0;
+    int* s_owner = s_claim + nf_cap;
+    unsigned short* l_q = reinterpret_cast<unsigned short*>(s_owner + nf_cap);   // the camera's queries, ascending (global indices < 65536)
+    const int* tk_g = topk + K * nq;
+    if (tid < 3) s_flag[tid] = 0;
+    if (tid == 0) { s_red = 0; s_cnt = 0; if (cam == 0) state[5] = 1; }
+    if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
+    for (int g = tid; g < min(nf, nf_cap); g += T) { s_claim[g] = 0x7fffffff; s_owner[g] = -1; }
+    // the camera's queries: every thread looks at a contiguous run of the query list (64 at most: nq < 65536), a prefix sum over
+    // the workgroup gives each run its place.  Queries that name no camera of the frame have no candidates (project_dev.h): -1
+    // from workgroup 0.
+    const int chunk = (nq + T - 1) / T, i0 = min(nq, tid * chunk), i1 = min(nq, i0 + chunk);
+    unsigned long long mine = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int qc = qmeta[i].x >> 1;
+        if (qc == cam) mine |= 1ull << (i - i0);
+        else if (cam == 0 && (qc < 0 || qc >= F.n_cams)) choice[i] = -1;
+    }
+    const int cnt = __popcll(mine);
+    const int incl = wave_incl_scan(cnt);
+    if (lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    int off = incl - cnt;
+    for (int w = 0; w < wave; ++w) off += s_wtot[w];
+    if (tid == T - 1) s_cnt = off + cnt;
+    for (unsigned long long mm = mine; mm; mm &= mm - 1) {
+        if (off < RQ * T) l_q[off] = (unsigned short)(i0 + __ffsll((long long)mm) - 1);
+        ++off;
+    }
+    __syncthreads();
+    const int nqc = s_cnt;
+    if (nf > nf_cap || nqc > RQ * T) {   // beyond this launch's limits (the host sized them from capacities: cannot happen unless those lied)
+        if (tid == 0) atomicOr(&state[8], 1);
+        return;
+    }
+    int sl[RQ][K], cur[RQ], pos[RQ], flr[RQ], qi[RQ];
+    int mx = 0;
+#pragma unroll
+    for (int b = 0; b < RQ; ++b) {
+        const int j = b * T + tid;
+        cur[b] = -1; pos[b] = 0; flr[b] = 0; qi[b] = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < K; ++k) sl[b][k] = 0xffff;
+        if (j < nqc) {
+            // set-up of one query, round 0 riding along as in k_resolve_mono: the head of the shortlist is taken and claimed
+            const int i = l_q[j];
+            qi[b] = i;
+            const int cnt_i = cand_count[i];
+            mx = max(mx, cnt_i);
+            flr[b] = (qmeta[i].x & 1) | (topk[(2 * K) * nq + i] > K ? 2 : 0);
+#pragma unroll
+            for (int k = 0; k < K; ++k) { const int g = tk_g[k * nq + i]; sl[b][k] = g < 0 ? 0xffff : g - f0; }
+            const bool has = sl[b][0] != 0xffff;
+            cur[b] = has ? sl[b][0] : -1;
+            if (has && (flr[b] & 1)) atomicMin(&s_claim[sl[b][0]], i);
+        }
+    }
+    mx = (int)(0x7fffffffu - wave_min_u32(0x7fffffffu - (unsigned)mx));
+    if (lane == 0) atomicMax(&s_red, mx);
+    __syncthreads();
+    const int maxcount = s_red;
+    if (tid == 0 && maxcount > 0) atomicMax(&state[0], maxcount);
+    if (maxcount > cap) return;   // (state[0] > cap: k_rs_write reports the overflow, the search is repeated with more room)
+    // one pass over this thread's queries: k_resolve_mono's, with local feature indices into the tables and global query indices
+    // as the claims' values
+    auto pass = [&]() -> bool {
+        bool disp[RQ], need_rescan[RQ];
+        int cl[RQ];
+#pragma unroll
+        for (int b = 0; b < RQ; ++b) cl[b] = s_claim[cur[b] >= 0 ? cur[b] : 0];
+#pragma unroll
+        for (int b = 0; b < RQ; ++b) { disp[b] = cur[b] >= 0 && cl[b] < qi[b]; need_rescan[b] = false; }
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < RQ; ++b) any |= disp[b];
+        if (!__ballot(any)) return false;
+        if (any) {
+            int ck[RQ][K];
+#pragma unroll
+            for (int b = 0; b < RQ; ++b)
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    const bool want = disp[b] && k > pos[b] && sl[b][k] != 0xffff;
+                    const int v = s_claim[want ? sl[b][k] : 0];
+                    ck[b][k] = want ? v : -1;
+                }
+#pragma unroll
+            for (int b = 0; b < RQ; ++b) {
+                if (!disp[b]) continue;
+                const int i = qi[b];
+                int nk = K;
+#pragma unroll
+                for (int k = K - 1; k >= 1; --k) if (ck[b][k] >= i) nk = k;
+                int ne = 0xffff;
+#pragma unroll
+                for (int k = 1; k < K; ++k) if (nk == k) ne = sl[b][k];
+                if (nk < K) {
+                    cur[b] = ne; pos[b] = nk;
+                    if (flr[b] & 1) atomicMin(&s_claim[ne], i);
+                } else {
+                    cur[b] = -1; pos[b] = K;
+                    need_rescan[b] = (flr[b] & 2) != 0;   // the shortlist ran dry while the list is longer: rescanned by the wave
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < RQ; ++b) {
+            unsigned long long todo = __ballot(need_rescan[b]);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int q = __builtin_amdgcn_readlane(qi[b], src);
+                const int full = cand_count[q];
+                int k1 = 0x7fffffff, g1 = -1;
+                for (int k0 = 0; k0 < full; k0 += 64) {
+                    const int k = k0 + lane;
+                    int key = 0x7fffffff, gg = -1;
+                    if (k < full) {
+                        const int gglob = cand_idx[k * nq + q];
+                        const int d = cand_dist[k * nq + q];
+                        gg = gglob - f0;
+                        bool avail = !(occupied && occupied[gglob]);
+                        if (s_claim[gg] < q) avail = false;
+                        if (avail) key = (d << 16) | k;
+                    }
+                    const int m1 = (int)wave_min_u32((unsigned)key);
+                    if (m1 < k1) { k1 = m1; g1 = __builtin_amdgcn_readlane(gg, __ffsll((long long)__ballot(key == m1)) - 1); }
+                }
+                if (lane == src && k1 != 0x7fffffff && (k1 >> 16) <= th_high) {
+                    cur[b] = g1;
+                    if (flr[b] & 1) atomicMin(&s_claim[g1], q);
+                }
+            }
+        }
+        return true;
+    };
+    int it = 1, changed = 1;
+    for (; it < max_it && changed; ++it) {
+        if (tid == 0) s_flag[(it + 1) % 3] = 0;
+        bool ch = false;
+        for (int guard = 0; guard < 4096; ++guard) {
+            if (!pass()) break;
+            ch = true;
+        }
+        if (ch && lane == 0) s_flag[it % 3] = 1;
+        __syncthreads();
+        changed = s_flag[it % 3];
+    }
+    if (changed) {  // ran out of rounds
+        if (tid == 0) atomicOr(&state[8], 1);
+        return;
+    }
+    // owners (the last claimant in query order), this camera's share of the rotation histogram and of the match count
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    int acc = 0;
+#pragma unroll
+    for (int b = 0; b < RQ; ++b) {
+        const bool live = b * T + tid < nqc;
+        const int i = qi[b], c = cur[b];
+        if (live) choice[i] = c >= 0 ? c + f0 : -1;
+        if (c >= 0) { ++acc; atomicMax(&s_owner[c], i); }
+        if (check_ori) {
+            int bin = -1;
+            if (c >= 0) {
+                float rot = __int_as_float(qmeta[i].y) - f_angle[c + f0];
+                if (rot < 0.0) rot += 360.0f;
+                bin = (int)roundf(rot * factor);
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                if (bin < 0 || bin >= ORBM_HISTO_LENGTH) bin = -1;
+            }
+            if (bin >= 0) atomicAdd(&s_hist[bin], 1);
+        }
+    }
+    acc = __builtin_amdgcn_readlane(wave_incl_scan(acc), 63);
+    if (lane == 0 && acc) atomicAdd(&s_red, acc);   // (s_red still holds maxcount: taken off again below)
+    __syncthreads();
+    for (int g = tid; g < nf; g += T) owner[f0 + g] = s_owner[g];
+    if (tid < ORBM_HISTO_LENGTH) { const int v = s_hist[tid]; if (v) atomicAdd(&state[48 + tid], v); }
+    if (tid == 64) { const int v = s_red - maxcount; if (v) atomicAdd(&state[1], v); }
+    if (tid == 65) atomicMax(&state[6], it);
 }
 
 // Multi-GPU exchange: `gathered` holds one block per rank (rank order), each = cap_rows descriptor rows (the rank's
@@ -967,7 +1176,7 @@ __global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __rest
 int morb::search_raise_lds_limits() {
     const void* fns[] = {(const void*)k_resolve<true, false>, (const void*)k_resolve<false, false>, (const void*)k_resolve<true, true>,
                          (const void*)k_resolve<false, true>, (const void*)k_resolve_mono<2, true>, (const void*)k_resolve_mono<2, false>,
-                         (const void*)k_resolve_mono<4, true>, (const void*)k_resolve_mono<4, false>};
+                         (const void*)k_resolve_mono<4, true>, (const void*)k_resolve_mono<4, false>, (const void*)k_rs_mono_cam};
     for (const void* fn : fns) MORB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return ORB_OK;
 }
@@ -1230,6 +1439,34 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
         // most; 8 x 4000 features converge in 10-11), because a sweep that has nothing to do still costs its launch (~4.7 us each
         // on the critical path of the step).  A search that does not converge in its allotment is finished by the exact host
         // fallback and the next one gets the full 24 again.
+        // Frame searches (one window per query, no ratio test) resolve per camera in ONE launch when every camera's tables and
+        // queries fit a workgroup (k_rs_mono_cam); the per-sweep form below keeps the rest.  MORB_RS_PER_CAMERA=0: per-sweep form only.
+        static const bool cam_env = [] { const char* e = getenv("MORB_RS_PER_CAMERA"); return !(e && atoi(e) == 0); }();
+        int nf_cap = 0, q_cam_max = J.q_cam_max;
+        const bool starts_ok = (int)cur->cam_start.size() == cur->n_cams + 1 && cur->cam_start[cur->n_cams] == n;
+        if (starts_ok) for (int c = 0; c < cur->n_cams; ++c) nf_cap = std::max(nf_cap, cur->cam_start[c + 1] - cur->cam_start[c]);
+        if (cam_env && !J.points && !J.win2_dev && starts_ok && !q_cam_max && !J.msrc && J.q) {   // (host records: count them)
+            std::vector<int>& per = m->rs_cam_count;
+            per.assign((size_t)cur->n_cams, 0);
+            for (int i = 0; i < nq; ++i) { const int c = J.q[i].cam; if (c >= 0 && c < cur->n_cams) q_cam_max = std::max(q_cam_max, ++per[c]); }
+            if (!q_cam_max) q_cam_max = 1;
+        }
+        const size_t lds_cam = (size_t)8 * nf_cap + (size_t)2 * RSC_RQ * 1024;
+        if (cam_env && !J.points && !J.win2_dev && nf_cap > 0 && q_cam_max > 0 && q_cam_max <= RSC_RQ * 1024 && nq < 65536 &&
+            lds_cam <= 150 * 1024) {
+            hipLaunchKernelGGL(k_rs_mono_cam, dim3(cur->n_cams), dim3(1024), lds_cam, m->stream, cur->dev(), (const int*)cur->b->d_cam_start.p,
+                               (const int2*)m->d_qmeta.p, nq, cap, nf_cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p,
+                               (const int*)m->d_i1.p, d_occ, (const float*)cur->b->d_ang.p, th_high, J.check_ori, 4096,
+                               (const int*)m->d_claim.p, m->d_choice.p, m->d_match.p, state);
+            if (J.check_ori)
+                hipLaunchKernelGGL(k_rs_reject, dim3(nb_q), dim3(256), 0, m->stream, (const orbm_query*)m->d_queries.p, nq, cap,
+                                   (const int*)m->d_choice.p, (const float*)cur->b->d_ang.p, m->d_match.p, state);
+            hipLaunchKernelGGL(k_rs_write, dim3(nb_f), dim3(256), 0, m->stream, n, cur->dev().n_total_dev, cap, (const int*)m->d_match.p,
+                               (const int*)state, m->h_match.dp + 4, m->h_match.dp);
+            MORB_HIP(hipGetLastError());
+            J.multi = true; J.device_path = true;
+            return ORB_OK;
+        }
         const int n_sweeps = std::min(RS_MAX_SWEEPS, std::max(12, m->rs_sweeps_hint));
         hipLaunchKernelGGL(k_rs_init, dim3(nb_all), dim3(256), 0, m->stream, n, nq, tab0, tab1, m->d_match.p, m->d_choice.p,
                            (const int*)m->d_i1.p, state, n_sweeps);

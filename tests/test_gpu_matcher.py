@@ -347,19 +347,68 @@ def test_frame_search_resolves_the_same_as_jacobi_sweeps_and_as_the_monotone_ite
     assert r.returncode == 0 and " passed" in tail, tail
 
 
-def test_projection_search_large_frame_keeps_its_claim_tables_in_hbm(matcher):
-    """8 cameras x 4000 features (configs[4] scale): two 32000-entry claim tables do not fit LDS, the resolve kernel keeps
-    them in an HBM workspace (same sweeps, global atomics) instead of handing the search to the host."""
+def _large_frame_case(kind):
+    """(frame arrays, queries, occupied) of the large-frame searches below.  8 x 4000 features: "mixed" 20000 queries in random
+    camera order, "own" 32000 camera-major queries (the motion stream's shape: 4000 per camera), "occupied" with a third of the
+    features taken and non-blocking queries among the rest, "invalid" with queries that name no camera of the frame.  2 x 9000
+    features: "wide" 7000 queries (72 KB of tables per camera), "crowded" 24000 queries (more than 4096 per camera: beyond the
+    per-camera launch)."""
+    two = kind in ("wide", "crowded")
+    fr = helpers.make_frame_arrays([9000] * 2 if two else [4000] * 8, 1920, 1080, 17)
+    occ = None
+    if kind == "mixed":
+        q = helpers.make_queries(fr, 20000, 23, th=30.0)
+    elif kind == "own":
+        q = helpers.make_queries(fr, 32000, 29, th=25.0)
+        order = np.argsort(q["cam"], kind="stable")
+        q = np.ascontiguousarray(q[order])
+    elif kind == "wide":
+        q = helpers.make_queries(fr, 7000, 47, th=25.0)
+    elif kind == "crowded":
+        q = helpers.make_queries(fr, 24000, 31, th=20.0)
+    elif kind == "occupied":
+        q = helpers.make_queries(fr, 24000, 37, th=30.0, blocks=2)
+        occ = (helpers.rand_unit(32000, 41) < 0.33).astype(np.uint8)
+    else:
+        q = helpers.make_queries(fr, 16000, 43, th=30.0)
+        q["cam"][::7] = 9
+        q["cam"][3::11] = -1
+    return fr, q, occ
+
+
+@pytest.mark.parametrize("kind", ["mixed", "own", "wide", "crowded", "occupied", "invalid"])
+def test_projection_search_large_frame_resolves_per_camera(matcher, kind):
+    """8 cameras x 4000 features (configs[4] scale): the claim tables of the whole frame do not fit one workgroup's LDS.  A frame
+    search never crosses cameras, so every camera gets a workgroup of its own with that camera's tables in LDS (k_rs_mono_cam, one
+    launch); more than 4096 queries on one camera ("crowded") keep the tables in HBM and one launch per sweep.  Either way the
+    result is the oracle's sequential loop, bit for bit, and the search stays on the device."""
     import multi_orb_slam_amd as m
-    fr = helpers.make_frame_arrays([4000] * 8, 1920, 1080, 17)
-    q = helpers.make_queries(fr, 20000, 23, th=30.0)
+    fr, q, occ = _large_frame_case(kind)
     F = matcher.frame(m.FrameData(**fr)); OF = oracle.FrameData(**fr)
-    n, mo = matcher.SearchByProjection(F, q)
-    on, omo = oracle.search_by_projection_frames(OF, q, 100, True)
-    assert n == on and np.array_equal(mo, omo) and n > 5000
+    n, mo = matcher.SearchByProjection(F, q, occupied=occ)
+    qo = q
+    if kind == "invalid":   # (a camera the frame does not have is an out-of-bounds read in the reference and in the oracle: the
+        qo = q.copy()       # library treats such a point as one without candidates -- stated to the oracle as a window far outside)
+        bad = (q["cam"] < 0) | (q["cam"] >= 8)
+        assert bad.sum() > 3000
+        qo["cam"][bad] = 0; qo["u"][bad] = -1.0e6
+    on, omo = oracle.search_by_projection_frames(OF, qo, 100, True, occ)
+    assert n == on and np.array_equal(mo, omo) and n > 3000
     status, nm, sweeps, longest = matcher.last_resolve()
     assert status == 0 and nm == n and sweeps >= 2          # resolved on the device (the host path leaves no sweep count)
     F.close()
+
+
+def test_large_frame_per_sweep_form_is_still_exact():
+    """MORB_RS_PER_CAMERA=0 sends every large frame to the per-sweep form (tables in HBM): the cases above must equal the oracle on
+    it too (the switch is read once per process, hence the child)."""
+    import subprocess, sys
+    env = dict(os.environ, MORB_RS_PER_CAMERA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "large_frame_resolves_per_camera"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode()[-2000:]
+    assert r.returncode == 0 and " passed" in tail, tail
 
 
 @pytest.mark.parametrize("world,cams_per_rank", [(1, 2), (3, 2), (4, 1)])
