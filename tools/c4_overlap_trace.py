@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""configs[4] (8 x 1080p @4000) overlapped loop, a few dozen steps, for a kernel trace (rocprofv3 --kernel-trace) of the steady state."""
+"""Overlapped loop of one configuration (default configs[4]: 8 x 1080p @4000), a few dozen steps, for a kernel trace
+(rocprofv3 --kernel-trace) of the steady state; tools/experiments/trace_timeline.py prints one period of it per stream.
+usage: c4_overlap_trace.py [steps] [width height cameras features]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import multi_orb_slam_amd as m
 from multi_orb_slam_amd import pipeline, rt, synth
-W, H, NC, NF = 1920, 1080, 8, 4000
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+W, H, NC, NF = (int(v) for v in sys.argv[2:6]) if len(sys.argv) > 5 else (1920, 1080, 8, 4000)
 fe = pipeline.FrontEnd([m.ExtractorParams(nfeatures=NF)] * NC, W, H)
 RING = 6
 dev = [[rt.DeviceBuffer(W * H) for c in range(NC)] for t in range(RING)]

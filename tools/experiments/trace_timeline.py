@@ -9,7 +9,7 @@ for r in rows:
     r["n"] = n[:40]
 rows.sort(key=lambda r: r["s"])
 # steps are delimited by k_rs_write (one per search)
-marks = [r for r in rows if r["n"].startswith("k_rs_write")]
+marks = [r for r in rows if r["n"].startswith("k_rs_write") or r["n"].startswith("k_resolve")]
 print("searches:", len(marks))
 if len(marks) > 30:
     per = [(marks[i + 1]["e"] - marks[i]["e"]) / 1000 for i in range(20, len(marks) - 1)]
