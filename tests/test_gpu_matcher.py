@@ -399,13 +399,30 @@ def test_projection_search_large_frame_resolves_per_camera(matcher, kind):
     F.close()
 
 
+@pytest.mark.parametrize("n_per_cam,nq,seed", [([17000, 0, 3000], 4500, 3), ([6000, 1, 9000, 5000], 8000, 5), ([2500] * 8, 2500, 7),
+                                             ([19000, 500], 6000, 9)])
+def test_large_frame_unbalanced_rigs(matcher, n_per_cam, nq, seed):
+    """The per-camera resolve sizes its LDS for the LARGEST camera: 17 000 features on one camera (144 KB of tables) next to an empty
+    one, a one-feature camera, a rig whose cameras all fit easily; 19 000 on one camera is beyond a workgroup and keeps the per-sweep
+    form.  All equal the oracle."""
+    import multi_orb_slam_amd as m
+    fr = helpers.make_frame_arrays(n_per_cam, 1920, 1080, seed)
+    q = helpers.make_queries(fr, nq, seed + 1, th=25.0, blocks=2)
+    F = matcher.frame(m.FrameData(**fr)); OF = oracle.FrameData(**fr)
+    n, mo = matcher.SearchByProjection(F, q)
+    on, omo = oracle.search_by_projection_frames(OF, q, 100, True)
+    assert n == on and np.array_equal(mo, omo) and n > nq // 10
+    assert matcher.last_resolve()[0] == 0
+    F.close()
+
+
 def test_large_frame_per_sweep_form_is_still_exact():
     """MORB_RS_PER_CAMERA=0 sends every large frame to the per-sweep form (tables in HBM): the cases above must equal the oracle on
     it too (the switch is read once per process, hence the child)."""
     import subprocess, sys
     env = dict(os.environ, MORB_RS_PER_CAMERA="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "large_frame_resolves_per_camera"],
+                        "-k", "large_frame_resolves_per_camera or large_frame_unbalanced"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     tail = r.stdout.decode()[-2000:]
     assert r.returncode == 0 and " passed" in tail, tail
