@@ -989,32 +989,57 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
     int* s_owner = s_claim + nf_cap;
     unsigned short* l_q = reinterpret_cast<unsigned short*>(s_owner + nf_cap);   // the camera's queries, ascending (global indices < 65536)
     const int* tk_g = topk + K * nq;
+    MORB_PHASE(g_ph_res, 0);   // (stamps of camera 0's workgroup: start, counted, gathered, set up, rounds done, owners, end; slot 1 = 2: this layout)
     if (tid < 3) s_flag[tid] = 0;
     if (tid == 0) { s_red = 0; s_cnt = 0; if (cam == 0) state[5] = 1; }
     if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
     for (int g = tid; g < min(nf, nf_cap); g += T) { s_claim[g] = 0x7fffffff; s_owner[g] = -1; }
-    // the camera's queries: every thread looks at a contiguous run of the query list (64 at most: nq < 65536), a prefix sum over
-    // the workgroup gives each run its place.  Queries that name no camera of the frame have no candidates (project_dev.h): -1
-    // from workgroup 0.
-    const int chunk = (nq + T - 1) / T, i0 = min(nq, tid * chunk), i1 = min(nq, i0 + chunk);
-    unsigned long long mine = 0;
-    for (int i = i0; i < i1; ++i) {
-        const int qc = qmeta[i].x >> 1;
-        if (qc == cam) mine |= 1ull << (i - i0);
-        else if (cam == 0 && (qc < 0 || qc >= F.n_cams)) choice[i] = -1;
+    // the camera's queries: every WAVE takes a contiguous run of the query list (at most 4096 entries: nq < 65536) and reads it 64
+    // entries per load, coalesced, all 32 loads of a trip in flight (the words k_project wrote sit in another XCD's L2: every trip is a trip
+    // to memory, ~2 us; a run per THREAD -- the first form of this kernel -- also asked for 64 different lines with every load).  A
+    // lane keeps "my entry of group u is this camera's" as bit u of a 64-bit word, so the second pass -- the ordered store of the
+    // indices once the waves' totals are known -- needs no memory.
+    // Queries that name no camera of the frame have no candidates (project_dev.h): -1 from workgroup 0.
+    const int per_wave = (((nq + 15) / 16) + 63) & ~63, w0 = min(nq, wave * per_wave), w1 = min(nq, w0 + per_wave);
+    unsigned long long mybits = 0;
+    int mine = 0;
+    for (int b0 = 0; b0 < 64; b0 += 32) {   // (one trip for up to 32 768 queries, two beyond)
+        if (w0 + 64 * b0 >= w1) break;       // (wave-uniform)
+        int qc[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { const int i = w0 + 64 * (b0 + u) + lane; qc[u] = i < w1 ? qmeta[i].x >> 1 : -0x40000000; }
+        unsigned int bits = 0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const bool m = qc[u] == cam;
+            bits |= (unsigned int)m << u;
+            mine += __popcll(__ballot(m));
+        }
+        mybits |= (unsigned long long)bits << b0;
+        if (cam == 0) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int i = w0 + 64 * (b0 + u) + lane;
+                if (i < w1 && (qc[u] < 0 || qc[u] >= F.n_cams)) choice[i] = -1;
+            }
+        }
     }
-    const int cnt = __popcll(mine);
-    const int incl = wave_incl_scan(cnt);
-    if (lane == 63) s_wtot[wave] = incl;
+    if (lane == 0) s_wtot[wave] = mine;
     __syncthreads();
-    int off = incl - cnt;
+    MORB_PHASE(g_ph_res, 2);
+    int off = 0;
     for (int w = 0; w < wave; ++w) off += s_wtot[w];
-    if (tid == T - 1) s_cnt = off + cnt;
-    for (unsigned long long mm = mine; mm; mm &= mm - 1) {
-        if (off < RQ * T) l_q[off] = (unsigned short)(i0 + __ffsll((long long)mm) - 1);
-        ++off;
+    if (tid == T - 1) s_cnt = off + mine;
+    for (int u = 0; u < 64; ++u) {
+        if (w0 + 64 * u >= w1) break;    // (wave-uniform)
+        const bool m = (mybits >> u) & 1ull;
+        const unsigned long long mask = __ballot(m);
+        const int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+        if (m && pos < RQ * T) l_q[pos] = (unsigned short)(w0 + 64 * u + lane);
+        off += __popcll(mask);
     }
     __syncthreads();
+    MORB_PHASE(g_ph_res, 3);
     const int nqc = s_cnt;
     if (nf > nf_cap || nqc > RQ * T) {   // beyond this launch's limits (the host sized them from capacities: cannot happen unless those lied)
         if (tid == 0) atomicOr(&state[8], 1);
@@ -1046,6 +1071,7 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
     if (lane == 0) atomicMax(&s_red, mx);
     __syncthreads();
     const int maxcount = s_red;
+    MORB_PHASE(g_ph_res, 4);
     if (tid == 0 && maxcount > 0) atomicMax(&state[0], maxcount);
     if (maxcount > cap) return;   // (state[0] > cap: k_rs_write reports the overflow, the search is repeated with more room)
     // one pass over this thread's queries: k_resolve_mono's, with local feature indices into the tables and global query indices
@@ -1137,6 +1163,7 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
         if (tid == 0) atomicOr(&state[8], 1);
         return;
     }
+    MORB_PHASE(g_ph_res, 5);
     // owners (the last claimant in query order), this camera's share of the rotation histogram and of the match count
     const float factor = 1.0f / ORBM_HISTO_LENGTH;
     int acc = 0;
@@ -1161,10 +1188,15 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
     acc = __builtin_amdgcn_readlane(wave_incl_scan(acc), 63);
     if (lane == 0 && acc) atomicAdd(&s_red, acc);   // (s_red still holds maxcount: taken off again below)
     __syncthreads();
+    MORB_PHASE(g_ph_res, 6);
     for (int g = tid; g < nf; g += T) owner[f0 + g] = s_owner[g];
     if (tid < ORBM_HISTO_LENGTH) { const int v = s_hist[tid]; if (v) atomicAdd(&state[48 + tid], v); }
     if (tid == 64) { const int v = s_red - maxcount; if (v) atomicAdd(&state[1], v); }
     if (tid == 65) atomicMax(&state[6], it);
+    MORB_PHASE(g_ph_res, 7);
+#ifdef MORB_PHASE_CLOCKS
+    if (tid == 0 && cam == 0) { g_ph_res[1] = 2; g_ph_res[62] = (unsigned long long)it; }
+#endif
 }
 
 // Multi-GPU exchange: `gathered` holds one block per rank (rank order), each = cap_rows descriptor rows (the rank's
