@@ -1,4 +1,5 @@
 """GPU parity: HIP extractor (through the C ABI) vs the CPU oracle, stage by stage and end to end.  Bit-exact."""
+import os
 import numpy as np
 import pytest
 
@@ -244,3 +245,17 @@ def test_a_level_the_reference_leaves_undefined_still_runs():
     assert 300 < len(out[0][0]) <= 600 + 3 * 8 and out[0][1].shape == (len(out[0][0]), 32)
     with pytest.raises(ValueError):
         oracle.extract(synth.image(3, 0, 333, 777), nfeatures=600)
+
+
+def test_resize_chain_form_equals_the_oracle_at_every_size():
+    """Large rigs build their pyramid with one k_resize_v4 launch per level (four pixels per lane from a per-group table of byte
+    selectors and coefficient pairs) instead of the one-launch tile kernel; the arrangement is chosen once per process, so the stage
+    tests of this file -- every level byte for byte, odd sizes included -- run once more in a child with the chain forced at their sizes."""
+    import subprocess, sys
+    env = dict(os.environ, MORB_PYR_CHAIN="1", MORB_PYRAMID_PAIRS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "stages_and_end_to_end or mixed_sizes or larger_configs or odd_parameter"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode()[-2000:]
+    assert r.returncode == 0 and " passed" in tail, tail
+

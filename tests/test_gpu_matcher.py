@@ -30,6 +30,36 @@ def test_top2_bit_exact(matcher, nq, nr):
     assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
 
 
+@pytest.mark.parametrize("nq,nr,nbase,maxflip,seed", [(3000, 9000, 2, 1, 1), (257, 4097, 1, 0, 2), (1000, 1000, 5, 3, 3), (6000, 129, 40, 1, 4)])
+def test_top2_on_tie_heavy_rows_in_every_form(matcher, nq, nr, nbase, maxflip, seed):
+    """Rows drawn from a handful of base vectors with 0-3 flipped bits: equal distances everywhere, exact duplicates, best == second,
+    a few complemented rows (distance 256).  The matrix-core forms only do their key work for quarter-blocks in which some key is
+    below a lane's `second` (mt_step): on such data nearly every key TIES with it -- which must neither be skipped wrongly nor
+    change which duplicate is reported first.  FP4, int8 and popcount forms against the oracle's brute force."""
+    import multi_orb_slam_amd as m
+    rng = np.random.RandomState(seed)
+
+    def rows(n):
+        base = rng.randint(0, 256, (nbase, 32)).astype(np.uint8)
+        d = base[rng.randint(0, nbase, n)].copy()
+        for i in range(n):
+            for _ in range(rng.randint(0, maxflip + 1)):
+                b = rng.randint(0, 256); d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        far = rng.rand(n) < 0.02
+        d[far] = ~d[far]
+        return np.ascontiguousarray(d)
+    q = rows(nq); r = rows(nr)
+    r[:min(nq, nr) // 2] = q[:min(nq, nr) // 2]
+    e = oracle.bf_top2(q, r)
+    for mc, fp4 in ((1, -1), (1, 0), (0, -1)):
+        pm = m.Matcher.use_matrix_cores(mc); pf = m.Matcher.use_fp4_top2(fp4)
+        try:
+            g = matcher.hamming_top2(q, r)
+        finally:
+            m.Matcher.use_matrix_cores(pm); m.Matcher.use_fp4_top2(pf)
+        assert all(np.array_equal(a, b) for a, b in zip(g, e)), (mc, fp4)
+
+
 def test_top2_ties_and_duplicates(matcher):
     # exact duplicates: the first index wins, the duplicate becomes the second best (App. A-9)
     r = synth.descriptors(300, 3)
