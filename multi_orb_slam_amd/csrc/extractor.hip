@@ -84,12 +84,39 @@ struct SelKp {  // one keypoint chosen by the quadtree, input of k_describe
     int resp_out;    // response << 24 | output index within the camera
 };
 
-__device__ const signed char d_pattern[256][4] = {
+// the rBRIEF test locations (include/orb_pattern_31.inc) as floats, one 16-byte load per test (rounds 1-3 kept them as signed bytes and
+// k_describe converted four per test and lane: 8 instructions)
+struct PatternF {
+    float v[256][4];
+    constexpr PatternF() : v() {
+        constexpr signed char src[256][4] = {
 #include "../../include/orb_pattern_31.inc"
+        };
+        for (int i = 0; i < 256; ++i) for (int k = 0; k < 4; ++k) v[i][k] = (float)src[i][k];
+    }
 };
+__device__ constexpr PatternF d_pattern_f = PatternF();
 // umax[v] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3} (ctor :455-470) as 16 nibbles of one constant (entry v
 // at bits 4v..4v+3): a register operand instead of a memory load per use
 constexpr unsigned long long UMAX_NIBBLES = 0x3689abcddeeeffffull;
+// IC_Angle's disc as dword items (k_describe): item i = dword q = i % 9 of patch row r = i / 9 (columns u0 = 4 q - 18 .. u0 + 3 of row
+// v = r - 15): the byte mask of the columns inside the disc (|u| <= umax[|v|]) and (u0, v), evaluated at compile time -- the kernel spent
+// ~18 vector instructions per item on rebuilding them.
+struct IcAngleItems {
+    unsigned mask[31 * 9];
+    int uv[31 * 9];   // u0 & 0xffff | v << 16
+    constexpr IcAngleItems() : mask(), uv() {
+        for (int i = 0; i < 31 * 9; ++i) {
+            const int r = i / 9, q = i - r * 9, v = r - HALF_PATCH, u0 = 4 * q - 18;
+            const int um = (int)((UMAX_NIBBLES >> (4 * (v < 0 ? -v : v))) & 15ull);
+            unsigned m = 0;
+            for (int b = 0; b < 4; ++b) { const int u = u0 + b; if (u >= -um && u <= um) m |= 0xffu << (8 * b); }
+            mask[i] = m;
+            uv[i] = (u0 & 0xffff) | (v * 65536);
+        }
+    }
+};
+__device__ constexpr IcAngleItems d_ic_items = IcAngleItems();
 
 // block b of a 1-D grid of n -> position in XCD-major order: XCD x = b % 8 owns the contiguous positions
 // [x * (n / 8) + min(x, n % 8), ...) and walks them in launch order (see k_fast_cells)
@@ -1417,10 +1444,20 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         const int g = (lane * 43) >> 9, j = lane - 12 * g;   // lane / 12, lane % 12 (exact for lane < 64)
         const uint8_t* p0 = img + xs + 4 * j;
         uint32_t v[9];
+        if (K.y - PR >= 0 && K.y + PR < Lv.h) {   // (wave-uniform: no row of the patch leaves the level -- all but the keypoints of the outermost three rows)
+            const uint8_t* pr = p0 + (size_t)(K.y - PR + g) * img_stride;
+            const size_t step5 = (size_t)5 * img_stride;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                v[k] = 0;
+                if (lane < 60) __builtin_memcpy(&v[k], pr + k * step5, 4);
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             v[k] = 0;
             if (lane < 60) __builtin_memcpy(&v[k], p0 + (size_t)reflect101(K.y - PR + g + 5 * k, Lv.h) * img_stride, 4);
+        }
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -1447,13 +1484,11 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         for (int k = 0; k < (31 * 9 + 63) / 64; ++k) {
             const int i = lane + 64 * k;
             if (i < 31 * 9) {
-                const int r = i / 9, q = i - r * 9;
-                const int v = r - HALF_PATCH, u0 = 4 * q - 18;
-                const int um = (int)((UMAX_NIBBLES >> (4 * (v < 0 ? -v : v))) & 15ull);
-                const int lo = min(max(-um - u0, 0), 4), hi = min(max(um - u0 + 1, 0), 4);   // valid bytes [lo, hi)
-                const unsigned long long ones = 0xffffffffull;
-                const uint32_t mask = hi > lo ? (uint32_t)((ones >> (8 * (4 - hi))) & (ones << (8 * lo))) : 0u;
-                const uint32_t d = raw32[(PR + v) * (RAW_PITCH / 4) + 1 + q] & mask;
+                const int r = (i * 57) >> 9, q = i - r * 9;      // i / 9 (exact for i < 512)
+                const uint32_t mask = d_ic_items.mask[i];
+                const int uvp = d_ic_items.uv[i];
+                const int u0 = (int)(short)(uvp & 0xffff), v = uvp >> 16;
+                const uint32_t d = raw32[(PR - HALF_PATCH + r) * (RAW_PITCH / 4) + 1 + q] & mask;
                 const int s1 = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false), sw = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
                 m10 += u0 * s1 + sw;
                 m01 += v * s1;
@@ -1473,7 +1508,14 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     // v_dot2_u32_u16.  23 pairs x 10 column groups = 230 items: four rounds of the wave, one 16-byte LDS store per item.
     {
         const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(raw);
-        constexpr uint32_t W_LO = 18u | (34u << 8) | (49u << 16) | (55u << 24), W_HI = 49u | (34u << 8) | (18u << 16);
+        // (second half of round 4) output j's seven taps are bytes j .. j + 6 of the row's three dwords: instead of moving the window to
+        // the weights (two funnel shifts per output), the weights are moved to the window -- ten v_dot4 with constant weight words per
+        // four outputs where there were eight behind six shifts.  Same products, same sums.
+        constexpr uint32_t K0 = 18u, K1 = 34u, K2 = 49u, K3 = 55u;   // taps 0..3 (= 6..3 mirrored)
+        constexpr uint32_t A0 = K0 | (K1 << 8) | (K2 << 16) | (K3 << 24), B0 = K2 | (K1 << 8) | (K0 << 16);                  // j = 0: d0, d1
+        constexpr uint32_t A1 = (K0 << 8) | (K1 << 16) | (K2 << 24), B1 = K3 | (K2 << 8) | (K1 << 16) | (K0 << 24);          // j = 1: d0, d1
+        constexpr uint32_t A2 = (K0 << 16) | (K1 << 24), B2 = K2 | (K3 << 8) | (K2 << 16) | (K1 << 24), C2 = K0;             // j = 2: d0, d1, d2
+        constexpr uint32_t A3 = K0 << 24, B3 = K1 | (K2 << 8) | (K3 << 16) | (K2 << 24), C3 = K1 | (K0 << 8);                // j = 3: d0, d1, d2
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = lane + 64 * k;
@@ -1486,11 +1528,10 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                 for (int u = 0; u < 2; ++u) {
                     const uint32_t* row = raw32 + (u ? r1 : r0) * (RAW_PITCH / 4) + q;
                     const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t lo = j ? __builtin_amdgcn_alignbyte(d1, d0, j) : d0, hi = j ? __builtin_amdgcn_alignbyte(d2, d1, j) : d1;
-                        hs[u][j] = __builtin_amdgcn_udot4(hi, W_HI, __builtin_amdgcn_udot4(lo, W_LO, 0u, false), false);
-                    }
+                    hs[u][0] = __builtin_amdgcn_udot4(d1, B0, __builtin_amdgcn_udot4(d0, A0, 0u, false), false);
+                    hs[u][1] = __builtin_amdgcn_udot4(d1, B1, __builtin_amdgcn_udot4(d0, A1, 0u, false), false);
+                    hs[u][2] = __builtin_amdgcn_udot4(d2, C2, __builtin_amdgcn_udot4(d1, B2, __builtin_amdgcn_udot4(d0, A2, 0u, false), false), false);
+                    hs[u][3] = __builtin_amdgcn_udot4(d2, C3, __builtin_amdgcn_udot4(d1, B3, __builtin_amdgcn_udot4(d0, A3, 0u, false), false), false);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) out[j] = hs[0][j] | (hs[1][j] << 16);
@@ -1528,7 +1569,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                     uint32_t acc;
                     if (o & 1) acc = dot2(P[t0 + 3], O3, dot2(P[t0 + 2], O2, dot2(P[t0 + 1], O1, dot2(P[t0], O0, 32768u))));
                     else acc = dot2(P[t0 + 3], E3, dot2(P[t0 + 2], E2, dot2(P[t0 + 1], E1, dot2(P[t0], E0, 32768u))));
-                    const uint32_t val = min(acc >> 16, 255u);
+                    const uint32_t val = min(acc, 0xffffffu) >> 16;   // == min(acc >> 16, 255): the clamp first, so that the byte is bits 16..23 of a register (one d16_hi store, no shift)
                     if (o < 11 || seg < 2) dst[o * ROW_PITCH] = (uint8_t)val;   // (rows 39..41 of the last segment do not exist)
                 }
             }
@@ -1545,8 +1586,8 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     int nib = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const signed char* q = d_pattern[4 * lane + j];
-        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
+        const float4 q = *reinterpret_cast<const float4*>(d_pattern_f.v[4 * lane + j]);
+        const float x0 = q.x, y0 = q.y, x1 = q.z, y1 = q.w;
         const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
         const int t0 = centre[r0 * ROW_PITCH + c0], t1 = centre[r1 * ROW_PITCH + c1];
