@@ -95,7 +95,6 @@ struct PatternF {
         for (int i = 0; i < 256; ++i) for (int k = 0; k < 4; ++k) v[i][k] = (float)src[i][k];
     }
 };
-__device__ constexpr PatternF d_pattern_f = PatternF();
 // umax[v] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3} (ctor :455-470) as 16 nibbles of one constant (entry v
 // at bits 4v..4v+3): a register operand instead of a memory load per use
 constexpr unsigned long long UMAX_NIBBLES = 0x3689abcddeeeffffull;
@@ -116,7 +115,10 @@ struct IcAngleItems {
         }
     }
 };
-__device__ constexpr IcAngleItems d_ic_items = IcAngleItems();
+// Both tables are evaluated at compile time on the HOST and live in the extractor's own device memory (orbx_create uploads them,
+// k_describe takes the pointer).  (The library is compiled with -fno-slp-vectorize: see the Makefile for what packed f32 arithmetic on
+// freshly loaded table registers did in the loopback rig.)
+struct DescribeTables { IcAngleItems ic; alignas(16) PatternF pat; };
 
 // block b of a 1-D grid of n -> position in XCD-major order: XCD x = b % 8 owns the contiguous positions
 // [x * (n / 8) + min(x, n % 8), ...) and walks them in launch order (see k_fast_cells)
@@ -1343,7 +1345,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                                                   const SelKp* __restrict__ sel, int nsel,
                                                   orb_keypoint* const* __restrict__ kps_out,
                                                   uint8_t* const* __restrict__ desc_out, MirrorArgs mir, SelListArgs sl,
-                                                  FrameSink sink, const L0Src* __restrict__ l0) {
+                                                  FrameSink sink, const L0Src* __restrict__ l0, const DescribeTables* __restrict__ tabs) {
     __shared__ alignas(16) uint8_t s_raw[4][PW * RAW_PITCH];
     __shared__ alignas(16) uint32_t s_vp[4][VP_PAIRS * ROW_PITCH];   // horizontal sums as VERTICAL pairs: row 2m | row 2m+1 << 16 per column
     __shared__ alignas(16) uint8_t s_blur[4][BW * ROW_PITCH];
@@ -1485,8 +1487,8 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
             const int i = lane + 64 * k;
             if (i < 31 * 9) {
                 const int r = (i * 57) >> 9, q = i - r * 9;      // i / 9 (exact for i < 512)
-                const uint32_t mask = d_ic_items.mask[i];
-                const int uvp = d_ic_items.uv[i];
+                const uint32_t mask = tabs->ic.mask[i];
+                const int uvp = tabs->ic.uv[i];
                 const int u0 = (int)(short)(uvp & 0xffff), v = uvp >> 16;
                 const uint32_t d = raw32[(PR - HALF_PATCH + r) * (RAW_PITCH / 4) + 1 + q] & mask;
                 const int s1 = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false), sw = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
@@ -1586,7 +1588,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     int nib = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float4 q = *reinterpret_cast<const float4*>(d_pattern_f.v[4 * lane + j]);
+        const float4 q = *reinterpret_cast<const float4*>(tabs->pat.v[4 * lane + j]);
         const float x0 = q.x, y0 = q.y, x1 = q.z, y1 = q.w;
         const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
@@ -1834,6 +1836,7 @@ struct orbx_extractor {
     DevBuf<LevelInfo> d_levels;
     DevBuf<int2> d_cell_map, d_xtab;
     DevBuf<int4> d_xgrp;              // k_resize_v4's per-group view of the x table
+    DevBuf<uint8_t> d_desc_tabs;      // k_describe's DescribeTables (IC_Angle items + float test locations)
     // the tiled whole-pyramid launch (k_pyramid_tiled): spans per (camera, level, tile column / row), tiles per camera, LDS need
     DevBuf<int4> d_pyr_sx, d_pyr_sy;
     int pyr_tx_max = 0, pyr_ty_max = 0, pyr_lds = 0, pyr_tile = 0, pyr_tab_cap = 0, pyr_threads = 256;
@@ -2117,6 +2120,12 @@ static int rebuild_geometry(orbx_extractor* ex) {
         MORB_HIP(hipMemcpyAsync(ex->d_cell_map.p, ex->cell_map.data(), ex->cell_map.size() * sizeof(int2), hipMemcpyHostToDevice, ex->stream));
     if (!xt.empty()) MORB_HIP(hipMemcpyAsync(ex->d_xtab.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice, ex->stream));
     if (!xg.empty()) MORB_HIP(hipMemcpyAsync(ex->d_xgrp.p, xg.data(), xg.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
+    {
+        static constexpr DescribeTables k_tabs = DescribeTables();   // (compile-time; the copy below is synchronised with the others)
+        int rc_t = ex->d_desc_tabs.reserve(sizeof(DescribeTables));
+        if (rc_t) return rc_t;
+        MORB_HIP(hipMemcpyAsync(ex->d_desc_tabs.p, &k_tabs, sizeof(DescribeTables), hipMemcpyHostToDevice, ex->stream));
+    }
     if (!yt.empty()) MORB_HIP(hipMemcpyAsync(ex->d_ytab.p, yt.data(), yt.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
     if (!psx.empty()) MORB_HIP(hipMemcpyAsync(ex->d_pyr_sx.p, psx.data(), psx.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
     if (!psy.empty()) MORB_HIP(hipMemcpyAsync(ex->d_pyr_sy.p, psy.data(), psy.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
@@ -2234,7 +2243,7 @@ void orbx_destroy(orbx_extractor* ex) {
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     for (int sl = 0; sl < 2; ++sl) for (int w = 0; w < orbx_extractor::CHAIN_WAYS; ++w) ex->chain[sl][w].destroy();
-    ex->d_l0.release(); ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_xgrp.release(); ex->d_ytab.release(); ex->d_pyr_sx.release(); ex->d_pyr_sy.release();
+    ex->d_l0.release(); ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_xgrp.release(); ex->d_desc_tabs.release(); ex->d_ytab.release(); ex->d_pyr_sx.release(); ex->d_pyr_sy.release();
     ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release(); ex->d_sel_oct.release();
     ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release();
     ex->d_n_out.release(); ex->d_slot_blk.release();
@@ -2546,7 +2555,7 @@ static int launch_tree_describe(orbx_extractor* ex, hipStream_t st, unsigned slo
                        (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
                        SelListArgs{(const unsigned short*)ex->d_slot_blk.p, (const int*)ex->d_sel_cnt.p,
                                    (const int*)ex->d_oct_status.p, ex->d_n_out.p + slot * ex->n_cams, d_h_oct, ex->n_cams},
-                       sink, l0_table(ex));
+                       sink, l0_table(ex), (const DescribeTables*)ex->d_desc_tabs.p);
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[5], st));
     MORB_HIP(hipGetLastError());
     return ORB_OK;
@@ -2788,7 +2797,8 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         hipLaunchKernelGGL(k_describe, dim3((nsel + 3) / 4), dim3(256), 0, st, (const LevelInfo*)ex->d_levels.p, ML,
                            (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel.p, nsel,
                            (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
-                           SelListArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, FrameSink{}, l0_table(ex));
+                           SelListArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, FrameSink{}, l0_table(ex),
+                           (const DescribeTables*)ex->d_desc_tabs.p);
         MORB_HIP(hipGetLastError());
     }
     if (ex->profiling) {
