@@ -169,10 +169,18 @@ int morb::loop_allgather(LoopComm* C, const void* sendbuf, void* recvbuf, size_t
         if (hipEventRecord(G.ev[C->rank], st) != hipSuccess) { morb::set_error("loopback exchange: hipEventRecord failed"); return ORB_E_HIP; }
         const unsigned long gen = G.generation;
         if (++G.arrived == G.world) { G.arrived = 0; ++G.generation; G.cv.notify_all(); }
-        else if (!G.cv.wait_for(lk, std::chrono::seconds(20), [&] { return G.generation != gen || G.broken; }) || G.broken) {
-            G.broken = true; G.cv.notify_all();
-            morb::set_error("loopback exchange: rank %d waited 20 s for the other ranks of its group", C->rank);
-            return ORB_E_HIP;
+        else {
+            // (the round is complete when the generation has moved on -- a member that leaves right BEHIND a completed round sets
+            // `broken` before a slower waiter of that round has woken up, which must not fail the round it has just finished:
+            // one such false alarm per ~1000 rig runs before round 4's soak found it)
+            (void)G.cv.wait_for(lk, std::chrono::seconds(20), [&] { return G.generation != gen || G.broken; });
+            if (G.generation == gen) {
+                const bool left = G.broken;
+                G.broken = true; G.cv.notify_all();
+                if (left) morb::set_error("loopback exchange: a member left the group while rank %d waited for it", C->rank);
+                else morb::set_error("loopback exchange: rank %d waited 20 s for the other ranks of its group", C->rank);
+                return ORB_E_HIP;
+            }
         }
     }
     for (int s = 0; s < G.world; ++s) {
@@ -183,10 +191,15 @@ int morb::loop_allgather(LoopComm* C, const void* sendbuf, void* recvbuf, size_t
         std::unique_lock<std::mutex> lk(G.mu);
         const unsigned long gen = G.generation;
         if (++G.arrived == G.world) { G.arrived = 0; ++G.generation; G.cv.notify_all(); }
-        else if (!G.cv.wait_for(lk, std::chrono::seconds(20), [&] { return G.generation != gen || G.broken; }) || G.broken) {
-            G.broken = true; G.cv.notify_all();
-            morb::set_error("loopback exchange: rank %d waited 20 s for the other ranks of its group", C->rank);
-            return ORB_E_HIP;
+        else {
+            (void)G.cv.wait_for(lk, std::chrono::seconds(20), [&] { return G.generation != gen || G.broken; });
+            if (G.generation == gen) {
+                const bool left = G.broken;
+                G.broken = true; G.cv.notify_all();
+                if (left) morb::set_error("loopback exchange: a member left the group while rank %d waited for it", C->rank);
+                else morb::set_error("loopback exchange: rank %d waited 20 s for the other ranks of its group", C->rank);
+                return ORB_E_HIP;
+            }
         }
     }
     return ORB_OK;
