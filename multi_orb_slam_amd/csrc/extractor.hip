@@ -1340,6 +1340,9 @@ __device__ unsigned long long g_desc_wave[2][4096];
 #else
 #define DPH(i) do {} while (0)
 #endif
+#ifdef MORB_DESCRIBE_SELFCHECK
+__device__ unsigned long long g_describe_check[8 + 16 * 14];
+#endif
 __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ L, int max_levels,
                                                   const uint8_t* __restrict__ pyr, size_t cam_pitch,
                                                   const SelKp* __restrict__ sel, int nsel,
@@ -1586,15 +1589,87 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     det_sincos(angle * factorPI, a, b);
     const uint8_t* centre = &blur[BR_ * ROW_PITCH + BR_];
     int nib = 0;
+#ifdef MORB_DESCRIBE_SELFCHECK
+    float4 chk_q[4]; int chk_rc[4][4], chk_t[4][2];
+#endif
+#ifdef MORB_DESCRIBE_FENCE
+    float4 qf[4];   // experiment: all four table quads loaded, then a full wait plus idle cycles in front of the first use
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qf[j] = *reinterpret_cast<const float4*>(tabs->pat.v[4 * lane + j]);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" : "+v"(qf[0].x), "+v"(qf[0].y), "+v"(qf[0].z), "+v"(qf[0].w), "+v"(qf[1].x), "+v"(qf[1].y), "+v"(qf[1].z), "+v"(qf[1].w),
+                 "+v"(qf[2].x), "+v"(qf[2].y), "+v"(qf[2].z), "+v"(qf[2].w), "+v"(qf[3].x), "+v"(qf[3].y), "+v"(qf[3].z), "+v"(qf[3].w) :: "memory");
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#ifdef MORB_DESCRIBE_FENCE
+        const float4 q = qf[j];
+#else
         const float4 q = *reinterpret_cast<const float4*>(tabs->pat.v[4 * lane + j]);
+#endif
         const float x0 = q.x, y0 = q.y, x1 = q.z, y1 = q.w;
         const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
         const int t0 = centre[r0 * ROW_PITCH + c0], t1 = centre[r1 * ROW_PITCH + c1];
         nib |= (t0 < t1) << j;
+#ifdef MORB_DESCRIBE_SELFCHECK
+        chk_q[j] = q; chk_rc[j][0] = r0; chk_rc[j][1] = c0; chk_rc[j][2] = r1; chk_rc[j][3] = c1; chk_t[j][0] = t0; chk_t[j][1] = t1;
+#endif
     }
+#ifdef MORB_DESCRIBE_SELFCHECK
+    // Debug build only (csrc/Makefile SELFCHECK=1): every lane does its four tests a second time, step by step, and counts where the
+    // two evaluations part -- the table quad re-loaded past the CU's vector cache (class 0: the registers the tests used do not hold
+    // what memory holds), the rotation re-done one scalar-float instruction at a time on the registers the tests used (class 1: same
+    // operands, different result, or the packed instruction read its operands before the load had written them), the two bytes of the
+    // blurred patch re-read (class 2), the test re-decided (class 3).  g_describe_check[0..3] count lanes x tests, [4] the keypoints
+    // checked, [8..] hold the first few records.
+    {
+        auto f_mul = [](float x, float y) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+        auto f_add = [](float x, float y) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+        auto f_sub = [](float x, float y) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+        if (lane == 0) atomicAdd(&g_describe_check[4], 1ull);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* src = tabs->pat.v[4 * lane + j];
+            float m[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const float4 q = chk_q[j];
+            const bool bad_load = __float_as_uint(m[0]) != __float_as_uint(q.x) || __float_as_uint(m[1]) != __float_as_uint(q.y) ||
+                                  __float_as_uint(m[2]) != __float_as_uint(q.z) || __float_as_uint(m[3]) != __float_as_uint(q.w);
+            const int r0 = __float2int_rn(f_add(f_mul(q.x, b), f_mul(q.y, a))), c0 = __float2int_rn(f_sub(f_mul(q.x, a), f_mul(q.y, b)));
+            const int r1 = __float2int_rn(f_add(f_mul(q.z, b), f_mul(q.w, a))), c1 = __float2int_rn(f_sub(f_mul(q.z, a), f_mul(q.w, b)));
+            const bool bad_arith = r0 != chk_rc[j][0] || c0 != chk_rc[j][1] || r1 != chk_rc[j][2] || c1 != chk_rc[j][3];
+            const volatile uint8_t* vc = centre;
+            const int t0 = vc[chk_rc[j][0] * ROW_PITCH + chk_rc[j][1]], t1 = vc[chk_rc[j][2] * ROW_PITCH + chk_rc[j][3]];
+            const bool bad_lds = t0 != chk_t[j][0] || t1 != chk_t[j][1];
+            const bool bad_bit = ((nib >> j) & 1) != (int)(chk_t[j][0] < chk_t[j][1]);
+            if (bad_load) atomicAdd(&g_describe_check[0], 1ull);
+            if (bad_arith) atomicAdd(&g_describe_check[1], 1ull);
+            if (bad_lds) atomicAdd(&g_describe_check[2], 1ull);
+            if (bad_bit) atomicAdd(&g_describe_check[3], 1ull);
+            if (bad_load || bad_arith || bad_lds || bad_bit) {
+                const unsigned long long slot = atomicAdd(&g_describe_check[5], 1ull);
+                if (slot < 16) {
+                    unsigned long long* rec = g_describe_check + 8 + slot * 14;
+                    rec[0] = (unsigned long long)ki << 32 | (unsigned)(lane << 8 | j << 4 | bad_load | bad_arith << 1 | bad_lds << 2 | bad_bit << 3);
+                    rec[1] = (unsigned long long)__float_as_uint(q.x) << 32 | __float_as_uint(q.y);
+                    rec[2] = (unsigned long long)__float_as_uint(q.z) << 32 | __float_as_uint(q.w);
+                    rec[3] = (unsigned long long)__float_as_uint(m[0]) << 32 | __float_as_uint(m[1]);
+                    rec[4] = (unsigned long long)__float_as_uint(m[2]) << 32 | __float_as_uint(m[3]);
+                    rec[5] = (unsigned long long)__float_as_uint(a) << 32 | __float_as_uint(b);
+                    rec[6] = (unsigned long long)(unsigned)chk_rc[j][0] << 32 | (unsigned)chk_rc[j][1];
+                    rec[7] = (unsigned long long)(unsigned)chk_rc[j][2] << 32 | (unsigned)chk_rc[j][3];
+                    rec[8] = (unsigned long long)(unsigned)r0 << 32 | (unsigned)c0;
+                    rec[9] = (unsigned long long)(unsigned)r1 << 32 | (unsigned)c1;
+                    rec[10] = (unsigned long long)(unsigned)chk_t[j][0] << 32 | (unsigned)chk_t[j][1];
+                    rec[11] = (unsigned long long)(unsigned)t0 << 32 | (unsigned)t1;
+                    rec[12] = wall_clock64();
+                    rec[13] = (unsigned long long)blockIdx.x << 32 | (unsigned)K.camlevel;
+                }
+            }
+        }
+    }
+#endif
     const int other = __shfl_xor(nib, 1);
     DPH(6);
     const int out_idx = K.resp_out & 0xffffff;
@@ -2977,6 +3052,12 @@ int orbx_debug_distribute_octree(const orb_keypoint* in, int n, int min_x, int m
 }
 
 }  // extern "C"
+
+#ifdef MORB_DESCRIBE_SELFCHECK
+extern "C" int morb_debug_describe_check(unsigned long long* out, int n) {   // debug build only: k_describe's self-check words
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_describe_check), (size_t)std::min(n, 8 + 16 * 14) * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef MORB_PHASE_CLOCKS
 extern "C" int morb_debug_phases_extractor(int which, unsigned long long* out64) {
