@@ -662,7 +662,7 @@ def main(argv=None):
         "exchange": ("none (one rank)" if not use_dist else
                      "one RCCL all-gather of the step's descriptor block per step, issued natively from inside the step (RCCL C API), %s"
                      % {1: "on the matcher's own stream behind the step's search (placement 1: inline)",
-                        2: "on the matcher's side stream next to the step's search, two extraction chains ahead (placement 2: side)"}.get(
+                        3: "at the tail of the step's extraction chain on the extractor's stream, steps ahead of its matching (placement 3: chain)"}.get(
                             fe.fe.exchange_placement, "placement unknown")
                      if getattr(fe, "native_exchange", False) else
                      "one RCCL all-gather of the step's descriptor block per step through torch.distributed"),

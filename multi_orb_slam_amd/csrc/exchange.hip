@@ -1,6 +1,7 @@
 // exchange.hip -- the one collective of a multi-GPU timestep: an all-gather of every rank's descriptor export block.
 //   * RCCL's C API resolved at run time (the copy torch.distributed already loaded, else the ROCm one): no link-time
-//     dependency, one communicator per front end, the collective issued on the matcher's side stream from inside the step;
+//     dependency; a front end holds a few communicators over the same ranks (its steps' exchanges go round them by step
+//     number, each issued at the tail of the step's extraction chain on that chain's stream: frontend.hip);
 //   * an in-process loopback transport with the same contract for machines with fewer GPUs than ranks.
 #include <algorithm>
 #include <atomic>
@@ -16,8 +17,8 @@
 #include "frame_sink.h"
 #include "matcher_internal.h"
 #include <dlfcn.h>
-#include <condition_variable>
 #include <map>
+#include "loop_rendezvous.h"
 
 // ---- loopback transport: the same exchange between front ends of ONE process on ONE device (one host thread per "rank").
 // RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so a 1-GPU machine could otherwise never run the world > 1
@@ -28,11 +29,7 @@
 // product code unchanged.
 namespace morb {
 struct LoopGroup {
-    std::mutex mu;
-    std::condition_variable cv;
-    int world = 0, arrived = 0, members = 0;
-    unsigned long generation = 0;
-    bool broken = false;
+    Rendezvous rv;                   // (loop_rendezvous.h: the host-side meeting of the members, HIP-free and TSan-tested)
     std::vector<const void*> send;
     std::vector<hipEvent_t> ev;
 };
@@ -48,6 +45,7 @@ struct RcclApi {
     int (*GetUniqueId)(XUniqueId*) = nullptr;
     int (*CommInitRank)(void**, int, XUniqueId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommSplit)(void*, int, int, void**, void*) = nullptr;   // (optional: RCCL >= 2.18)
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather; }
@@ -67,6 +65,7 @@ RcclApi& rccl() {
             api.GetUniqueId = (int (*)(XUniqueId*))dlsym(api.lib, "ncclGetUniqueId");
             api.CommInitRank = (int (*)(void**, int, XUniqueId, int))dlsym(api.lib, "ncclCommInitRank");
             api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+            api.CommSplit = (int (*)(void*, int, int, void**, void*))dlsym(api.lib, "ncclCommSplit");
             api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
             api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
         }
@@ -105,6 +104,18 @@ int morb::exchange_comm_init(void** comm, int world, const uint8_t* uid128, int 
     return ORB_OK;
 }
 
+// A second communicator over the same ranks (collective: every rank calls, in the same order).  *out = comm itself where the library
+// has no ncclCommSplit or the split fails: the caller's collectives then share one communicator, which RCCL serialises in issue order.
+int morb::exchange_comm_clone(void* comm, int rank, void** out) {
+    RcclApi& R = rccl();
+    *out = comm;
+    if (!R.CommSplit || getenv("MORB_EXCHANGE_ONE_COMM")) return ORB_OK;
+    void* c2 = nullptr;
+    const int r = R.CommSplit(comm, /*color*/ 0, /*key*/ rank, &c2, nullptr);
+    if (r == 0 && c2) *out = c2;
+    return ORB_OK;
+}
+
 void morb::exchange_comm_destroy(void* comm) { if (comm) (void)rccl().CommDestroy(comm); }
 
 int morb::exchange_allgather(void* comm, const void* sendbuf, void* recvbuf, size_t bytes, hipStream_t st) {
@@ -120,7 +131,7 @@ int morb::loop_join(int group, int world, int rank, LoopComm** out) {
     auto it = g_loop_groups.find(group);
     if (it == g_loop_groups.end()) {
         G = new LoopGroup();
-        G->world = world; G->send.assign(world, nullptr); G->ev.assign(world, nullptr);
+        G->rv.world = world; G->send.assign(world, nullptr); G->ev.assign(world, nullptr);
         for (int r = 0; r < world; ++r)
             if (hipEventCreateWithFlags(&G->ev[r], hipEventDisableTiming) != hipSuccess) {
                 for (hipEvent_t e : G->ev) if (e) (void)hipEventDestroy(e);
@@ -131,12 +142,11 @@ int morb::loop_join(int group, int world, int rank, LoopComm** out) {
         g_loop_groups[group] = G;
     } else {
         G = it->second;
-        if (G->world != world || G->members >= world) { morb::set_error("loopback group %d: world size mismatch or group full", group); return ORB_E_ARG; }
+        bool full;
+        { std::lock_guard<std::mutex> lk2(G->rv.mu); full = G->rv.members >= world; }
+        if (G->rv.world != world || full) { morb::set_error("loopback group %d: world size mismatch or group full", group); return ORB_E_ARG; }
     }
-    {
-        std::lock_guard<std::mutex> lk2(G->mu);
-        ++G->members;
-    }
+    G->rv.join();
     *out = new LoopComm{G, rank};
     return ORB_OK;
 }
@@ -145,13 +155,7 @@ int morb::loop_join(int group, int world, int rank, LoopComm** out) {
 void morb::loop_leave(LoopComm* C) {
     if (!C) return;
     LoopGroup* G = C->g;
-    bool last = false;
-    {
-        std::lock_guard<std::mutex> lk(G->mu);
-        G->broken = true; G->cv.notify_all();
-        last = --G->members == 0;
-    }
-    if (last) {
+    if (G->rv.leave()) {
         std::lock_guard<std::mutex> lk(g_loop_mu);
         for (auto it = g_loop_groups.begin(); it != g_loop_groups.end(); ++it) if (it->second == G) { g_loop_groups.erase(it); break; }
         for (hipEvent_t e : G->ev) if (e) (void)hipEventDestroy(e);
@@ -160,47 +164,32 @@ void morb::loop_leave(LoopComm* C) {
     delete C;
 }
 
+static int loop_fail(morb::Rendezvous::Result r, int rank) {
+    using R = morb::Rendezvous;
+    if (r == R::BROKEN_BEFORE) morb::set_error("loopback exchange: a member has left the group");
+    else if (r == R::MEMBER_LEFT) morb::set_error("loopback exchange: a member left the group while rank %d waited for it", rank);
+    else morb::set_error("loopback exchange: rank %d waited 20 s for the other ranks of its group", rank);
+    return r == R::BROKEN_BEFORE ? ORB_E_ARG : ORB_E_HIP;
+}
+
+// Every member calls once per round, in the same order on every member (the host blocks until all have: a member that issues its
+// rounds in another order than its peers -- e.g. one that stopped extracting ahead after a quadtree fallback while a block has to be
+// shipped a second time -- can wait for peers that wait for it; RCCL calls return at once and have no such restriction).
 int morb::loop_allgather(LoopComm* C, const void* sendbuf, void* recvbuf, size_t bytes, hipStream_t st) {
     LoopGroup& G = *C->g;
-    {
-        std::unique_lock<std::mutex> lk(G.mu);
-        if (G.broken) { morb::set_error("loopback exchange: a member has left the group"); return ORB_E_ARG; }
+    bool rec_ok = true;
+    Rendezvous::Result r = G.rv.arrive([&] {
         G.send[C->rank] = sendbuf;
-        if (hipEventRecord(G.ev[C->rank], st) != hipSuccess) { morb::set_error("loopback exchange: hipEventRecord failed"); return ORB_E_HIP; }
-        const unsigned long gen = G.generation;
-        if (++G.arrived == G.world) { G.arrived = 0; ++G.generation; G.cv.notify_all(); }
-        else {
-            // (the round is complete when the generation has moved on -- a member that leaves right BEHIND a completed round sets
-            // `broken` before a slower waiter of that round has woken up, which must not fail the round it has just finished:
-            // one such false alarm per ~1000 rig runs before round 4's soak found it)
-            (void)G.cv.wait_for(lk, std::chrono::seconds(20), [&] { return G.generation != gen || G.broken; });
-            if (G.generation == gen) {
-                const bool left = G.broken;
-                G.broken = true; G.cv.notify_all();
-                if (left) morb::set_error("loopback exchange: a member left the group while rank %d waited for it", C->rank);
-                else morb::set_error("loopback exchange: rank %d waited 20 s for the other ranks of its group", C->rank);
-                return ORB_E_HIP;
-            }
-        }
-    }
-    for (int s = 0; s < G.world; ++s) {
+        rec_ok = hipEventRecord(G.ev[C->rank], st) == hipSuccess;
+    });
+    if (!rec_ok) { morb::set_error("loopback exchange: hipEventRecord failed"); return ORB_E_HIP; }
+    if (r != Rendezvous::OK) return loop_fail(r, C->rank);
+    for (int s = 0; s < G.rv.world; ++s) {
         MORB_HIP(hipStreamWaitEvent(st, G.ev[s], 0));
         MORB_HIP(hipMemcpyAsync((uint8_t*)recvbuf + (size_t)s * bytes, G.send[s], bytes, hipMemcpyDeviceToDevice, st));
     }
-    {   // nobody re-records its event / republishes its block before every rank has enqueued this round's copies
-        std::unique_lock<std::mutex> lk(G.mu);
-        const unsigned long gen = G.generation;
-        if (++G.arrived == G.world) { G.arrived = 0; ++G.generation; G.cv.notify_all(); }
-        else {
-            (void)G.cv.wait_for(lk, std::chrono::seconds(20), [&] { return G.generation != gen || G.broken; });
-            if (G.generation == gen) {
-                const bool left = G.broken;
-                G.broken = true; G.cv.notify_all();
-                if (left) morb::set_error("loopback exchange: a member left the group while rank %d waited for it", C->rank);
-                else morb::set_error("loopback exchange: rank %d waited 20 s for the other ranks of its group", C->rank);
-                return ORB_E_HIP;
-            }
-        }
-    }
+    // nobody re-records its event / republishes its block before every rank has enqueued this round's copies
+    r = G.rv.arrive();
+    if (r != Rendezvous::OK) return loop_fail(r, C->rank);
     return ORB_OK;
 }

@@ -73,7 +73,7 @@ struct SelListArgs {  // device-quadtree mode of k_describe: the slotted selecti
     const unsigned short* slot_blk;  // slot -> (camera, level) block; nullptr = host-list mode
     const int* sel_cnt;              // keypoints the quadtree kept per block
     const int* status;               // per-block quadtree status (non-zero: outside the device limits)
-    int* n_out;                      // per-camera totals in HBM (downstream kernels size themselves from these)
+    int* n_out;                      // per-camera totals in HBM (downstream kernels size themselves from these) + the OR of `status`
     int* h_n_out;                    // the same + the OR of `status` behind them, in mapped pinned memory
     int n_cams;
 };
@@ -1341,7 +1341,7 @@ __device__ unsigned long long g_desc_wave[2][4096];
 #define DPH(i) do {} while (0)
 #endif
 #ifdef MORB_DESCRIBE_SELFCHECK
-__device__ unsigned long long g_describe_check[8 + 16 * 14];
+__device__ unsigned long long g_describe_check[8 + 16 * 14 + 16 + 4];
 #endif
 __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ L, int max_levels,
                                                   const uint8_t* __restrict__ pyr, size_t cam_pitch,
@@ -1382,7 +1382,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
-        if (lane == 0) sl.h_n_out[sl.n_cams] = bad;
+        if (lane == 0) { sl.h_n_out[sl.n_cams] = bad; sl.n_out[sl.n_cams] = bad; }
     }
     DPH(0);
     if (ki >= nsel) return;
@@ -1644,7 +1644,12 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
             const bool bad_lds = t0 != chk_t[j][0] || t1 != chk_t[j][1];
             const bool bad_bit = ((nib >> j) & 1) != (int)(chk_t[j][0] < chk_t[j][1]);
             if (bad_load) atomicAdd(&g_describe_check[0], 1ull);
-            if (bad_arith) atomicAdd(&g_describe_check[1], 1ull);
+            if (bad_arith) {
+                atomicAdd(&g_describe_check[1], 1ull);
+                // which of the test's four coordinates (r0 = x0 b + y0 a, c0 = x0 a - y0 b, r1, c1), per table quad j; and the wave quarter
+                for (int c4 = 0; c4 < 4; ++c4) if ((c4 == 0 ? r0 : c4 == 1 ? c0 : c4 == 2 ? r1 : c1) != chk_rc[j][c4]) atomicAdd(&g_describe_check[8 + 16 * 14 + 4 * j + c4], 1ull);
+                atomicAdd(&g_describe_check[8 + 16 * 14 + 16 + (lane >> 4)], 1ull);
+            }
             if (bad_lds) atomicAdd(&g_describe_check[2], 1ull);
             if (bad_bit) atomicAdd(&g_describe_check[3], 1ull);
             if (bad_load || bad_arith || bad_lds || bad_bit) {
@@ -2174,7 +2179,7 @@ static int rebuild_geometry(orbx_extractor* ex) {
         (rc = ex->d_cell_items.reserve(std::max<size_t>(slot_base, 1))) || (rc = ex->d_cand_dev.reserve(std::max<size_t>(slot_base, 1))) ||
         (rc = ex->d_level_cnt_dev.reserve(ex->levels.size())) || (rc = ex->d_sel_cnt.reserve(ex->levels.size())) ||
         (rc = ex->d_oct_status.reserve(ex->levels.size())) ||
-        (rc = ex->d_n_out.reserve(2 * ex->n_cams)) ||
+        (rc = ex->d_n_out.reserve(2 * (ex->n_cams + 1))) ||
         (rc = ex->d_sel_oct.reserve(std::max<size_t>(slot_blk.size(), 1))) || (rc = ex->d_slot_blk.reserve(std::max<size_t>(slot_blk.size(), 1))))
         return rc;
     if (!slot_blk.empty())
@@ -2520,7 +2525,8 @@ int orbx_set_frame_sink(orbx_extractor* ex, const FrameSink* sink) {
 }
 
 // counts of the most recently enqueued run
-const int* orbx_device_counts(const orbx_extractor* ex) { return ex ? ex->d_n_out.p + ((ex->run_seq - 1u) & 1u) * ex->n_cams : nullptr; }
+// (n_cams totals + the OR of the quadtree's status words behind them: non-zero = this run's results will be redone on the host path)
+const int* orbx_device_counts(const orbx_extractor* ex) { return ex ? ex->d_n_out.p + ((ex->run_seq - 1u) & 1u) * (ex->n_cams + 1) : nullptr; }
 int orbx_pending(const orbx_extractor* ex) { return ex ? ex->inflight : 0; }
 // Status word of the OLDEST run in flight (0: every level stayed inside the device quadtree's limits); only meaningful
 // once that run has completed on the device (the caller has seen its completion event).  -1: nothing in flight.
@@ -2629,7 +2635,7 @@ static int launch_tree_describe(orbx_extractor* ex, hipStream_t st, unsigned slo
                        (const uint8_t*)ex->d_pyr.p, ex->cam_pitch, (const SelKp*)ex->d_sel_oct.p, ex->total_sel_slots,
                        (orb_keypoint* const*)ex->d_out_kps.p, (uint8_t* const*)ex->d_out_desc.p, mir,
                        SelListArgs{(const unsigned short*)ex->d_slot_blk.p, (const int*)ex->d_sel_cnt.p,
-                                   (const int*)ex->d_oct_status.p, ex->d_n_out.p + slot * ex->n_cams, d_h_oct, ex->n_cams},
+                                   (const int*)ex->d_oct_status.p, ex->d_n_out.p + slot * (ex->n_cams + 1), d_h_oct, ex->n_cams},
                        sink, l0_table(ex), (const DescribeTables*)ex->d_desc_tabs.p);
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[5], st));
     MORB_HIP(hipGetLastError());
@@ -3055,7 +3061,7 @@ int orbx_debug_distribute_octree(const orb_keypoint* in, int n, int min_x, int m
 
 #ifdef MORB_DESCRIBE_SELFCHECK
 extern "C" int morb_debug_describe_check(unsigned long long* out, int n) {   // debug build only: k_describe's self-check words
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_describe_check), (size_t)std::min(n, 8 + 16 * 14) * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_describe_check), (size_t)std::min(n, 8 + 16 * 14 + 16 + 4) * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -159,6 +159,8 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
         if (desc_g) {  // trailer of the descriptor block: the per-camera counts (what a multi-GPU exchange ships with it)
             int* tail = reinterpret_cast<int*>(desc_g + 2 * (size_t)desc_rows);
             for (int c = 0; c < n_cams; ++c) tail[c] = s_cams[c].n;
+            // (the extractor's status word rides behind its counts: a block of a run that will be redone says so -- ORBM_BLOCK_REDO)
+            if (d_counts && d_counts[n_cams] != 0) tail[0] |= ORBM_BLOCK_REDO;
         }
     }
     __syncthreads();
@@ -236,6 +238,7 @@ __global__ void k_cams_from_counts(CamFeat* __restrict__ cams, int n_cams, const
         cam_start[c] = base; trailer[c] = n;
         base += n;
     }
+    if (d_counts[n_cams] != 0) trailer[0] |= ORBM_BLOCK_REDO;
     cam_start[n_cams] = base;
     range[0] = base; range[1] = 0; range[2] = base;
 }

@@ -63,16 +63,35 @@ struct orbf_frontend {
     std::deque<std::vector<orbf_image>> announced;  // declared by orbf_prefetch, not enqueued yet (at most 2)
     int last_e = 0;  // extractor most recently handed a timestep
     bool poll_ok = true;     // MORB_POLL=0: orbf_step_end always waits with hipStreamSynchronize
-    void* xcomm = nullptr; int xworld = 0, xrank = 0;   // native multi-GPU exchange (orbf_exchange_init)
-    int x_placement = 0;                                // 0 no exchange, 1 on the matcher's own stream, 2 on its side stream (exchange_queues)
-    bool x_timing = false; hipEvent_t ev_x[3] = {nullptr, nullptr, nullptr}; float x_us[2] = {0.f, 0.f};   // orbf_debug_exchange_timing
+    // ---- native multi-GPU exchange (orbf_exchange_init): one all-gather of the step's export block + the rig-wide top-2 per step.
+    // A step's exchange needs nothing but the descriptors its extraction produced, so it is issued at the TAIL OF THE STEP'S
+    // EXTRACTION CHAIN, on that chain's stream, steps ahead of the step's matching (placement 3; placement 1 = behind the step's
+    // search on the matcher's stream, rounds 2-4).  Every step in flight has buffers of its own (XSlot, by step number); the
+    // collectives go round NXC communicators by step number -- the same sequence per communicator on every rank whatever stream a
+    // rank issues from -- and a block that has to be shipped a second time (its extraction fell back to the host path after it had
+    // gone out: ORBM_BLOCK_REDO) goes over a communicator of its own at the end of its step, on every rank.
+    static constexpr int NX = 8, NXC = 3;
+    struct XSlot {
+        DevBuf<uint8_t> recv, list;      // the gathered blocks of all ranks; their rows in use as one list
+        DevBuf<int32_t> gstart;          // camera starts + {features, first query, queries} of that list
+        PinnedBuf<int32_t> gcnt;         // per-camera counts, own queries, clamped counts, blocks marked "redo"
+        CrossOut out;                    // rig-wide top-2 of this rank's features
+        hipEvent_t done = nullptr, t_done = nullptr;   // behind the top-2 (t_done: with timing, orbf_debug_exchange_timing)
+        long seq = -1;                   // the step this slot's exchange belongs to
+        std::vector<orbf_image> images; std::vector<uint64_t> fp;   // what the shipped block was extracted from
+    } xs[NX];
+    void* xcomm = nullptr; int xworld = 0, xrank = 0;   // xcomm == xc[0]: non-null while an exchange is set up
+    void* xc[NXC + 1] = {};                              // communicators (RCCL) / loopback groups; the last one ships redone blocks
+    int x_placement = 0;                                // 0 no exchange, 1 behind the step's search, 3 at the tail of the step's extraction chain
+    long step_seq = 0, x_next = 0;                      // steps begun so far; first step whose exchange has not been issued
+    long set_xseq[NEX + 3] = {-1, -1, -1, -1, -1, -1};  // per result set: the step whose exchange reads that set's frame as its send buffer
+    bool x_timing = false; hipEvent_t ev_x[2] = {nullptr, nullptr}; float x_us[2] = {0.f, 0.f};   // orbf_debug_exchange_timing
     bool xloop = false;                                  // ... over the in-process loopback transport (orbf_exchange_init_loopback)
-    DevBuf<uint8_t> d_xrecv;                            // the gathered export blocks of all ranks
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path ...
     int clean_steps = 0;     // ... and set again after a few steps that stayed on the device path
     struct Pending {  // a timestep between orbf_step_begin and orbf_step_end
         bool active = false, async_path = false, fr_persistent = false, block_ready = false, cross_from_set = false, forked = false;
-        bool x_enqueued = false;   // this step's exchange went out between begin and end
+        long seq = 0;              // number of the step (orbf_frontend::step_seq when it began)
         bool inline_match = false; // the step's own extraction was enqueued by this call: its matching follows on the SAME stream
         bool mirror_requested = false, mirror_pending = false;  // the pinned result mirrors are filled by a copy kernel of the step
         int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
@@ -160,8 +179,12 @@ void orbf_destroy(orbf_frontend* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
     if (f->xcomm) (void)orbf_exchange_shutdown(f);
-    for (int i = 0; i < 3; ++i) if (f->ev_x[i]) (void)hipEventDestroy(f->ev_x[i]);
-    f->d_xrecv.release();
+    for (int i = 0; i < 2; ++i) if (f->ev_x[i]) (void)hipEventDestroy(f->ev_x[i]);
+    for (auto& X : f->xs) {
+        X.recv.release(); X.list.release(); X.gstart.release(); X.gcnt.release(); X.out.release();
+        if (X.done) (void)hipEventDestroy(X.done);
+        if (X.t_done) (void)hipEventDestroy(X.t_done);
+    }
     for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
     if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
@@ -223,7 +246,13 @@ int orbf_reset(orbf_frontend* f) {
         if (f->pending.fr && !f->pending.fr_persistent) { (void)hipStreamSynchronize(f->mt->stream); orbm_frame_destroy(f->pending.fr); }
         f->pending.active = false; f->pending.fr = nullptr;
     }
-    return orbf_drain(f);
+    const int rc = orbf_drain(f);
+    // With an exchange, blocks of steps that had been announced went out with their extraction chains: those step numbers are spent
+    // (the peers hold what the abandoned images gave).  The next step takes the first number nothing has been shipped for -- the
+    // same on every rank as long as the ranks reset at the same step with the same announcements, which a reset next to an exchange
+    // has to be anyway (every rank's collectives go round the communicators by step number).
+    if (f->xcomm && f->x_next > f->step_seq) f->step_seq = f->x_next;
+    return rc;
 }
 
 int orbf_export_block(orbf_frontend* f, const uint8_t** d_block, size_t* block_bytes, int* cap_rows) {
@@ -243,33 +272,23 @@ int orbf_exchange_unique_id(uint8_t* out128) {
 }
 
 static int orbf_drain(orbf_frontend* f);
-// Where a handle's exchange runs -- decided when the exchange is set up, per handle (not latched per process):
-//   1  on the matcher's OWN stream: the all-gather, the repack and the rig-wide top-2 follow the step's search there, nothing
-//      forks or joins and the handle keeps its extractor instances (three chains + the matcher = the four hardware queues);
-//   2  on the matcher's side stream (a queue of its own: at most two extractor instances go round from here on), next to the
-//      search when the block was final at begin, joined into the main stream.
-// MORB_EXCHANGE_PLACEMENT = inline | side | auto (auto: 1 up to two ranks, 2 from three on) or the older MORB_EXCHANGE_INLINE = 1 | 0
-// choose; the default is 1 at every world size.  Why not `auto`: in BOTH arrangements a step issues its search before its
-// collective, so a peer that arrives late never holds up the local search -- it holds up the END of the step, identically
-// (tests/test_gpu_frontend.py::test_slow_peer_...) -- while arrangement 2 pays a fork and a join per step
-// (~28 us of queue time, section 4) and gives up the third extraction chain.
+// Where a handle's exchange runs -- decided when the exchange is set up, per handle:
+//   3  (default) at the tail of the step's extraction chain, on the extractor's stream: the all-gather, the repack and the rig-wide
+//      top-2 of step t are on the device while steps t-1, t-2 are still being matched; the end of step t only waits for their event;
+//   1  behind the step's search on the matcher's own stream (rounds 2-4; what a step whose extraction ran synchronously gets anyway).
+// MORB_EXCHANGE_PLACEMENT = chain | inline chooses.  (Rounds 2-4 also had the collective on the matcher's side stream -- a fork and
+// a join per step, one extraction chain fewer; never ahead of `inline` in any measurement, removed in round 5.)
 static int exchange_queues(orbf_frontend* f) {
-    int placement = 1;
-    if (const char* e = getenv("MORB_EXCHANGE_PLACEMENT")) {
-        if (!strcmp(e, "side")) placement = 2;
-        else if (!strcmp(e, "auto")) placement = f->xworld >= 3 ? 2 : 1;
-    } else if (getenv_int("MORB_EXCHANGE_INLINE", 1) == 0) placement = 2;
+    int placement = 3;
+    if (const char* e = getenv("MORB_EXCHANGE_PLACEMENT")) { if (!strcmp(e, "inline")) placement = 1; }
     f->x_placement = placement;
-    if (placement == 1) { f->mt->side_inline = true; return ORB_OK; }
-    f->mt->side_inline = false;
-    if (f->n_ex > 2) {   // (a handle created for a single GPU after all: the third instance and its stream go before the side stream comes)
-        int rc = orbf_drain(f);
-        if (rc) return rc;
-        f->announced.clear();
-        orbx_destroy(f->exs[2]); f->exs[2] = nullptr;
-        f->n_ex = 2;
+    f->mt->side_inline = true;   // (no side stream next to an exchange: the handle keeps its extraction chains + the matcher = four queues)
+    f->x_next = f->step_seq;
+    for (auto& X : f->xs) {
+        X.seq = -1;
+        if (!X.done) MORB_HIP(hipEventCreateWithFlags(&X.done, hipEventDisableTiming));
     }
-    return morb::side_stream(f->mt) ? ORB_OK : ORB_E_HIP;
+    return ORB_OK;
 }
 
 int orbf_exchange_placement(const orbf_frontend* f) { return f ? (f->xcomm ? f->x_placement : 0) : ORB_E_ARG; }
@@ -279,7 +298,8 @@ int orbf_exchange_placement(const orbf_frontend* f) { return f ? (f->xcomm ? f->
 int orbf_debug_exchange_timing(orbf_frontend* f, int on) {
     MORB_ARG(f != nullptr);
     MORB_HIP(hipSetDevice(f->device));
-    if (on) for (int i = 0; i < 3; ++i) if (!f->ev_x[i]) MORB_HIP(hipEventCreate(&f->ev_x[i]));
+    if (on) for (int i = 0; i < 2; ++i) if (!f->ev_x[i]) MORB_HIP(hipEventCreate(&f->ev_x[i]));
+    if (on) for (auto& X : f->xs) if (!X.t_done) MORB_HIP(hipEventCreate(&X.t_done));
     f->x_timing = on != 0;
     return ORB_OK;
 }
@@ -295,8 +315,8 @@ int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int r
     void* comm = nullptr;
     int rc = exchange_comm_init(&comm, world, uid128, rank);
     if (rc) return rc;
-    const size_t block = (size_t)f->cap_total * 32 + ORBM_BLOCK_TRAILER;
-    if ((rc = f->d_xrecv.reserve((size_t)world * block))) { exchange_comm_destroy(comm); return rc; }
+    f->xc[0] = comm;
+    for (int k = 1; k <= orbf_frontend::NXC; ++k) (void)exchange_comm_clone(comm, rank, &f->xc[k]);   // (collective: same order on every rank)
     f->xcomm = comm; f->xworld = world; f->xrank = rank;
     return exchange_queues(f);
 }
@@ -306,12 +326,16 @@ int orbf_exchange_active(const orbf_frontend* f) { return f && f->xcomm ? f->xwo
 int orbf_exchange_init_loopback(orbf_frontend* f, int group, int world, int rank) {
     MORB_ARG(f && world >= 1 && rank >= 0 && rank < world && world * f->n_cams <= 512 && !f->xcomm);
     MORB_HIP(hipSetDevice(f->device));
-    const size_t block = (size_t)f->cap_total * 32 + ORBM_BLOCK_TRAILER;
-    int rc = f->d_xrecv.reserve((size_t)world * block);
-    if (rc) return rc;
-    LoopComm* C = nullptr;
-    if ((rc = loop_join(group, world, rank, &C))) return rc;
-    f->xcomm = C; f->xworld = world; f->xrank = rank; f->xloop = true;
+    int rc;
+    for (int k = 0; k <= orbf_frontend::NXC; ++k) {   // one rendezvous group per communicator slot
+        LoopComm* C = nullptr;
+        if ((rc = loop_join(group * (orbf_frontend::NXC + 1) + k, world, rank, &C))) {
+            for (int j = 0; j < k; ++j) { loop_leave(static_cast<LoopComm*>(f->xc[j])); f->xc[j] = nullptr; }
+            return rc;
+        }
+        f->xc[k] = C;
+    }
+    f->xcomm = f->xc[0]; f->xworld = world; f->xrank = rank; f->xloop = true;
     return exchange_queues(f);
 }
 
@@ -319,27 +343,47 @@ int orbf_exchange_shutdown(orbf_frontend* f) {
     MORB_ARG(f != nullptr);
     if (!f->xcomm) return ORB_OK;
     MORB_HIP(hipSetDevice(f->device));
+    for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));   // (exchanges run on the chains' streams)
     if (f->mt) { if (f->mt->side_stream) (void)hipStreamSynchronize(f->mt->side_stream); (void)hipStreamSynchronize(f->mt->stream); }
-    if (f->xloop) loop_leave(static_cast<LoopComm*>(f->xcomm));
-    else exchange_comm_destroy(f->xcomm);
+    for (int k = orbf_frontend::NXC; k >= 0; --k) {
+        if (!f->xc[k]) continue;
+        if (f->xloop) loop_leave(static_cast<LoopComm*>(f->xc[k]));
+        else if (k == 0 || f->xc[k] != f->xc[0]) exchange_comm_destroy(f->xc[k]);   // (a clone that is the first communicator itself goes with it)
+        f->xc[k] = nullptr;
+    }
     f->xcomm = nullptr; f->xworld = 0; f->xrank = 0; f->xloop = false; f->x_placement = 0;
     if (f->mt) f->mt->side_inline = false;
     return ORB_OK;
 }
 
-// all-gather of the frame's export block + the gathered cross-camera top-2, behind the step's search on the matcher's stream (or, with
-// MORB_EXCHANGE_INLINE=0, on its side stream, joined into the main stream): the block must be final (its extraction chain has
-// completed, or the main stream has been synchronised)
-static int exchange_enqueue(orbf_frontend* f, const orbm_frame* F) {
-    orbm_matcher* m = f->mt;
+static std::vector<uint64_t> image_fingerprints(const orbf_image* images, int n);
+
+// The exchange of step `seq`: all-gather of the frame's export block + repack + rig-wide top-2 into the step's slot, on `st` behind
+// whatever produced the block there.  redo: the block is shipped a second time (see XSlot), over the last communicator.
+static int exchange_issue(orbf_frontend* f, long seq, const orbm_frame* F, hipStream_t st, bool redo, const orbf_image* images, int set = -1) {
+    orbf_frontend::XSlot& X = f->xs[seq % orbf_frontend::NX];
     const size_t block = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
     MORB_ARG(F->desc_rows == f->cap_total);
-    hipStream_t sd = morb::side_stream(m);
-    if (!sd) return ORB_E_HIP;
-    const int rc = f->xloop ? loop_allgather(static_cast<LoopComm*>(f->xcomm), F->b->d_desc.p, f->d_xrecv.p, block, sd)
-                            : exchange_allgather(f->xcomm, F->b->d_desc.p, f->d_xrecv.p, block, sd);
+    const int n_cams = f->xworld * f->n_cams;
+    int rc;
+    if ((rc = X.recv.reserve((size_t)f->xworld * block)) || (rc = X.list.reserve((size_t)f->xworld * F->desc_rows * 32)) ||
+        (rc = X.gstart.reserve(n_cams + 1 + 4)) || (rc = X.gcnt.reserve(n_cams + 3)) || (rc = X.out.reserve(F->desc_rows, f->xworld * F->desc_rows)))
+        return rc;
+    void* comm = f->xc[redo ? orbf_frontend::NXC : (int)(seq % orbf_frontend::NXC)];
+    rc = f->xloop ? loop_allgather(static_cast<LoopComm*>(comm), F->b->d_desc.p, X.recv.p, block, st)
+                  : exchange_allgather(comm, F->b->d_desc.p, X.recv.p, block, st);
     if (rc) return rc;
-    return orbm_cross_top2_gathered_enqueue(m, f->d_xrecv.p, f->xworld, block, F->desc_rows, f->n_cams, f->xrank, nullptr, 0);
+    if ((rc = gathered_enqueue_to(st, X.recv.p, f->xworld, block, F->desc_rows, f->n_cams, f->xrank, X.list.p, X.gstart.p, X.gcnt.dp, X.out))) return rc;
+    if (f->x_timing && X.t_done) (void)hipEventRecord(X.t_done, st);
+    MORB_HIP(hipEventRecord(X.done, st));
+    if (!redo) {
+        X.seq = seq;
+        if (images) { X.images.assign(images, images + f->n_cams); X.fp = image_fingerprints(images, f->n_cams); }
+        else { X.images.clear(); X.fp.clear(); }
+        f->x_next = seq + 1;
+        if (set >= 0) f->set_xseq[set] = seq;
+    }
+    return ORB_OK;
 }
 
 static bool same_images(const std::vector<orbf_image>& a, const orbf_image* b, int n);
@@ -519,7 +563,7 @@ static void fill_cam_capacities(orbf_frontend* f, orbx_extractor* ex, orbm_cam_f
 // describe kernel writes the merged frame pframe[set] through a FrameSink (*went_async = 1 unless the extractor took its
 // synchronous host-quadtree path; then the frame was not filled).
 static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, int set, int* W_out, int* H_out, int* went_async,
-                           bool with_cross, bool defer_events = false, bool defer_mirror = false) {
+                           bool with_cross, bool defer_events = false, bool defer_mirror = false, long seq = -1) {
     orbm_matcher* m = f->mt;
     orbx_extractor* ex = f->exs[e];
     int rc, W = 0, H = 0;
@@ -534,6 +578,13 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     *W_out = W; *H_out = H;
     orbf_frontend::ResultSet& R = f->rs[set];
     R.cross_valid = false;
+    if (f->xcomm && f->set_xseq[set] >= 0) {
+        // an exchange reads this set's frame as its send buffer.  Its step has ended long ago (the end of a step waits for its
+        // exchange) -- unless the extraction was dropped and never stepped: then the collective may still be waiting for a peer
+        const orbf_frontend::XSlot& X = f->xs[f->set_xseq[set] % orbf_frontend::NX];
+        if (X.seq == f->set_xseq[set]) MORB_HIP(hipStreamWaitEvent((hipStream_t)orbx_stream(ex), X.done, 0));
+        f->set_xseq[set] = -1;
+    }
     // defer_mirror: the kernels of this extraction leave the pinned result mirrors alone; the step copies them on its side
     // stream (frame_mirror_enqueue) instead of making every dependent kernel boundary wait for stores across PCIe
     if ((rc = orbx_set_host_mirror(ex, defer_mirror ? nullptr : R.kps.dp, defer_mirror ? nullptr : R.desc.dp, f->cap_total))) return rc;
@@ -617,6 +668,10 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
             hipError_t he = hipEventRecord(f->ev_ready[set], (hipStream_t)orbx_stream(ex));
             if (he != hipSuccess) { morb::set_error("hipEventRecord: %s", hipGetErrorString(he)); return ORB_E_HIP; }
         }
+        // the step's exchange: behind everything its matching waits for, on this chain's stream (the block is this set's frame).  A
+        // block whose quadtree left the device limits says so in its trailer and is shipped again at the end of its step.
+        if (f->xcomm && f->x_placement == 3 && seq >= 0 && seq == f->x_next && (rc = exchange_issue(f, seq, f->pframe[set], (hipStream_t)orbx_stream(ex), false, images, set)))
+            return rc;
     }
     return ORB_OK;
 }
@@ -631,6 +686,11 @@ static int ensure_extractor(orbf_frontend* f, int e) {
 // Everything in flight is waited for and dropped (results of prefetched extractions included).
 static int orbf_drain(orbf_frontend* f) {
     MORB_HIP(hipSetDevice(f->device));
+    if (f->xcomm && f->x_placement == 3) {
+        // the chains' streams may end in collectives that wait for peers which have not announced that far (and may themselves be
+        // waiting for THIS rank, e.g. for a block shipped again): wait for the extractions, not for the exchanges behind them
+        for (const auto& I : f->inflight) MORB_HIP(hipEventSynchronize(f->ev_ready[I.set]));
+    } else
     for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) MORB_HIP(hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e])));
     MORB_HIP(hipStreamSynchronize(f->mt->stream));
     if (f->mt->side_stream) MORB_HIP(hipStreamSynchronize(f->mt->side_stream));
@@ -676,6 +736,17 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     if (f->xcomm) flags |= ORBF_SKIP_CROSS;   // the rig-wide matching of the exchange replaces the rank-local one
     P.images.assign(images, images + f->n_cams);
     P.nq = nq; P.flags = flags; P.from_motion = motion != nullptr;
+    P.seq = f->step_seq++;
+    if (f->xcomm && f->x_next > P.seq) {
+        // this step's block has been shipped already (its extraction was announced ahead): the other ranks hold what THOSE images
+        // gave, so with an exchange an announcement is binding
+        const orbf_frontend::XSlot& X = f->xs[P.seq % orbf_frontend::NX];
+        if (X.seq != P.seq || !same_images(X.images, images, f->n_cams) || !same_content(X.fp, images, f->n_cams)) {
+            morb::set_error("multi-GPU exchange: the images of this step differ from the ones announced for it (orbf_prefetch), whose "
+                            "descriptors have been shipped to the other ranks already -- with an exchange active announcements are binding");
+            return ORB_E_ARG;
+        }
+    }
 
     // ---- this step's extraction: already in flight (orbf_prefetch during an earlier step) or enqueued now
     if (!f->inflight.empty() && same_images(f->inflight.front().images, images, f->n_cams) &&
@@ -709,7 +780,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         // (measured: overlapped steps 7 % slower on configs[1], 25 % on configs[4] with direct reads).
         (void)orbx_set_pinned_ingest(f->exs[P.e], 1);
         rc = enqueue_extract(f, P.e, images, P.set, &P.W, &P.H, &went_async, !(flags & ORBF_SKIP_CROSS) && !P.inline_match, P.inline_match,
-                             P.mirror_requested);
+                             P.mirror_requested, P.seq);
         (void)orbx_set_pinned_ingest(f->exs[P.e], 0);
         P.mirror_pending = P.mirror_requested;
         if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], 1); (void)orbx_set_defer_done(f->exs[P.e], 0); }
@@ -856,7 +927,7 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     const bool x_probe = f->x_timing && f->xcomm && first_attempt;
     if (x_probe) (void)hipEventRecord(f->ev_x[0], st);
     rc = search_enqueue(m, P.J, /*queries_already_on_device=*/true);
-    if (x_probe) (void)hipEventRecord(f->ev_x[1], st);   // (behind the resolve, in front of whatever the exchange puts or joins on this stream)
+    if (x_probe) (void)hipEventRecord(f->ev_x[1], st);   // (behind the resolve, in front of whatever an exchange puts on this stream)
     if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[3] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     if (P.mirror_pending && !forked) {   // (no side stream in play: the copy follows the search on its stream)
         if (!rc) rc = frame_mirror_enqueue(fr, st, R.kps.dp, R.desc.dp, R.unx.dp, R.uny.dp, R.ur.dp, R.depth.dp);
@@ -882,10 +953,9 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     }
     if (rc) { (void)hipStreamSynchronize(st); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return rc; }
     // ---- native exchange: a block that is final already goes out right behind the step's own matching
-    if (first_attempt && f->xcomm && P.async_path && P.block_ready && !P.x_enqueued) {
-        if ((rc = exchange_enqueue(f, fr))) return rc;
-        P.x_enqueued = true;
-        if (x_probe) (void)hipEventRecord(f->ev_x[2], st);
+    if (first_attempt && f->xcomm && P.async_path && P.block_ready && f->x_next == P.seq) {   // (placement 1, or a step whose chain was enqueued before the exchange was set up)
+        if ((rc = exchange_issue(f, P.seq, fr, st, false, P.images.data()))) return rc;
+        m->foreign_work = true;   // (the end of the step cannot watch the resolve's tags: other work follows them on the stream)
     }
     if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[4] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     // ---- announced timesteps go onto the extractors now: they run while this step is being matched.  At most two
@@ -900,7 +970,8 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         if (set2 == f->cur) set2 = (set2 + 1) % orbf_frontend::NSETS;
         if (set2 == P.set) set2 = (set2 + 1) % orbf_frontend::NSETS;
         int w2 = 0, h2 = 0, async2 = 0;
-        rc = enqueue_extract(f, e2, f->announced.front().data(), set2, &w2, &h2, &async2, !(P.flags & ORBF_SKIP_CROSS));
+        rc = enqueue_extract(f, e2, f->announced.front().data(), set2, &w2, &h2, &async2, !(P.flags & ORBF_SKIP_CROSS), false, false,
+                             P.seq + 1 + (long)f->inflight.size());
         if (rc) { (void)hipStreamSynchronize(st); return rc; }
         f->last_set = set2; f->last_e = e2;
         if (async2) {
@@ -1041,25 +1112,32 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     out->cross_second_dist = do_cross ? (from_set ? R.cross.s.p : m->h_c2.p) : nullptr;
     out->rig_cams = 0; out->rig_counts = nullptr;
     if (f->xcomm) {
-        // every rank issues exactly one all-gather per step: between begin and end when the block was final at begin, here
-        // otherwise (the block is final now)
-        if (!P.x_enqueued) {
-            if ((rc = exchange_enqueue(f, f->last_frame))) return rc;
-            if (f->x_timing) (void)hipEventRecord(f->ev_x[2], st);
-            MORB_HIP(hipStreamSynchronize(st));
-            m->foreign_work = false;
+        // Every rank issues exactly one all-gather per step, in step order: with the step's extraction chain (placement 3), behind its
+        // search when the block was final at begin (placement 1), or here -- a step whose extraction ran synchronously.
+        orbf_frontend::XSlot& X = f->xs[P.seq % orbf_frontend::NX];
+        if (f->x_next == P.seq && (rc = exchange_issue(f, P.seq, f->last_frame, st, false, P.images.data()))) return rc;
+        MORB_ARG(X.seq == P.seq);
+        MORB_HIP(hipEventSynchronize(X.done));
+        const int gc = f->xworld * f->n_cams;
+        if (X.gcnt.p[gc + 2] != 0) {
+            // some rank's block came from an extraction that fell back to the host path afterwards (every rank reads the same marks in
+            // the same gathered blocks): all ranks ship the step's final blocks once more
+            if ((rc = exchange_issue(f, P.seq, f->last_frame, st, true, nullptr))) return rc;
+            MORB_HIP(hipEventSynchronize(X.done));
+            if (X.gcnt.p[gc + 2] != 0) { morb::set_error("multi-GPU exchange: a block shipped again is still marked unfinished"); return ORB_E_HIP; }
         }
-        if (f->x_timing) {   // (everything has been synchronised: the three events are complete)
+        m->foreign_work = false;
+        if (f->x_timing && f->ev_x[0] && X.t_done) {   // (everything has completed: search start -> search done, search start -> exchange done)
             float a = 0.f, b = 0.f;
-            if (hipEventElapsedTime(&a, f->ev_x[0], f->ev_x[1]) == hipSuccess && hipEventElapsedTime(&b, f->ev_x[0], f->ev_x[2]) == hipSuccess) {
-                f->x_us[0] = a * 1000.f; f->x_us[1] = b * 1000.f;
-            } else (void)hipGetLastError();
+            if (hipEventElapsedTime(&a, f->ev_x[0], f->ev_x[1]) == hipSuccess) f->x_us[0] = a * 1000.f; else (void)hipGetLastError();
+            if (hipEventElapsedTime(&b, f->ev_x[0], X.t_done) == hipSuccess) f->x_us[1] = b * 1000.f;   // (negative: the exchange was over before the search began)
+            else { (void)hipGetLastError(); f->x_us[1] = 0.f; }
         }
-        out->cross_best_idx = m->h_c0.p; out->cross_best_dist = m->h_c1.p; out->cross_second_dist = m->h_c2.p;
-        out->rig_cams = m->gathered_cams; out->rig_counts = m->h_gcnt.p;
-        if (m->h_gcnt.p[m->gathered_cams + 1] != 0) {   // (k_repack_gathered clamped a remote count: nothing ran out of bounds)
+        out->cross_best_idx = X.out.i.p; out->cross_best_dist = X.out.b.p; out->cross_second_dist = X.out.s.p;
+        out->rig_cams = gc; out->rig_counts = X.gcnt.p;
+        if (X.gcnt.p[gc + 1] != 0) {   // (k_repack_gathered clamped a remote count: nothing ran out of bounds)
             morb::set_error("multi-GPU exchange: %d per-camera counts of the gathered blocks were out of range (ranks disagree on "
-                            "their capacities, or a block is corrupt)", m->h_gcnt.p[m->gathered_cams + 1]);
+                            "their capacities, or a block is corrupt)", X.gcnt.p[gc + 1]);
             return ORB_E_ARG;
         }
     }

@@ -642,8 +642,11 @@ __global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_top2_mfma(const uint3
 // A remote trailer is data from another process: every count is clamped to what is left of its rank's cap_rows rows (a
 // mismatched or corrupt block can then neither run past its own block nor past the contiguous list), and the number of
 // counts that had to be clamped is reported in h_counts[n_cams + 1] (orbm_cross_top2_gathered_collect turns it into an error).
-__device__ __forceinline__ int repack_count(const int* __restrict__ tail, int c, int& room, int& bad) {
-    const int raw = tail[c];
+// redo_mark: the first count of a block may carry ORBM_BLOCK_REDO ("this block will be shipped again": matcher_internal.h) -- only the
+// front end's own exchange ships such blocks; for anybody else's buffer (orbm_cross_top2_gathered) the bit is a count out of range.
+__device__ __forceinline__ int repack_count(const int* __restrict__ tail, int c, int& room, int& bad, int redo_mark) {
+    int raw = tail[c];
+    if (redo_mark && c == 0 && raw >= 0) raw &= ~ORBM_BLOCK_REDO;
     const int n = min(max(raw, 0), room);
     bad += (n != raw);
     room -= n;
@@ -653,13 +656,13 @@ __device__ __forceinline__ int repack_count(const int* __restrict__ tail, int c,
 __global__ __launch_bounds__(256) void k_repack_gathered(const uint8_t* __restrict__ gathered, int world, size_t block_bytes,
                                                          int cap_rows, int cams_per_rank, int rank, uint4* __restrict__ dst,
                                                          int* __restrict__ cam_start, int* __restrict__ range,
-                                                         int* __restrict__ h_counts) {
+                                                         int* __restrict__ h_counts, int redo_mark) {
     const int r = blockIdx.y;
     int goff = 0, n_r = 0, own_off = 0, own_n = 0, total = 0, bad = 0;
     for (int rr = 0; rr < world; ++rr) {
         const int* tail = reinterpret_cast<const int*>(gathered + (size_t)rr * block_bytes + (size_t)cap_rows * 32);
         int nr = 0, room = cap_rows;
-        for (int c = 0; c < cams_per_rank; ++c) nr += repack_count(tail, c, room, bad);
+        for (int c = 0; c < cams_per_rank; ++c) nr += repack_count(tail, c, room, bad, redo_mark);
         if (rr == r) { goff = total; n_r = nr; }
         if (rr == rank) { own_off = total; own_n = nr; }
         total += nr;
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(256) void k_repack_gathered(const uint8_t* __restri
             const int* tail = reinterpret_cast<const int*>(gathered + (size_t)rr * block_bytes + (size_t)cap_rows * 32);
             int room = cap_rows, ignore = 0;
             for (int c = 0; c < cams_per_rank; ++c) {
-                const int n = repack_count(tail, c, room, ignore);
+                const int n = repack_count(tail, c, room, ignore, redo_mark);
                 cam_start[rr * cams_per_rank + c] = run;
                 h_counts[rr * cams_per_rank + c] = n;
                 run += n;
@@ -680,6 +683,12 @@ __global__ __launch_bounds__(256) void k_repack_gathered(const uint8_t* __restri
         range[0] = total; range[1] = own_off; range[2] = own_n;
         h_counts[world * cams_per_rank] = own_n;
         h_counts[world * cams_per_rank + 1] = bad;
+        int redo = 0;   // ranks whose block says it will be shipped again (every rank computes the same number from the same blocks)
+        for (int rr = 0; rr < world; ++rr) {
+            const int first = *reinterpret_cast<const int*>(gathered + (size_t)rr * block_bytes + (size_t)cap_rows * 32);
+            redo += redo_mark && first >= 0 && (first & ORBM_BLOCK_REDO) != 0;
+        }
+        h_counts[world * cams_per_rank + 2] = redo;
     }
     const uint4* src = reinterpret_cast<const uint4*>(gathered + (size_t)r * block_bytes);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * n_r; i += gridDim.x * 256) dst[2 * (size_t)goff + i] = src[i];
@@ -1238,7 +1247,7 @@ int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered,
     const int n_cams = world * cams_per_rank;
     const int n_cap = world * cap_rows;  // capacity of the contiguous list
     int rc;
-    if ((rc = m->d_r.reserve((size_t)n_cap * 32)) || (rc = m->d_gstart.reserve(n_cams + 1 + 4)) || (rc = m->h_gcnt.reserve(n_cams + 2)))
+    if ((rc = m->d_r.reserve((size_t)n_cap * 32)) || (rc = m->d_gstart.reserve(n_cams + 1 + 4)) || (rc = m->h_gcnt.reserve(n_cams + 3)))
         return rc;
     hipStream_t sd = morb::side_stream(m);
     if (!sd) return ORB_E_HIP;
@@ -1249,7 +1258,7 @@ int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered,
     int* d_cam_start = m->d_gstart.p;
     int* d_range = m->d_gstart.p + n_cams + 1;
     hipLaunchKernelGGL(k_repack_gathered, dim3((2 * cap_rows + 255) / 256, world), dim3(256), 0, sd, d_gathered, world, block_bytes, cap_rows,
-                       cams_per_rank, rank, (uint4*)m->d_r.p, d_cam_start, d_range, m->h_gcnt.dp);
+                       cams_per_rank, rank, (uint4*)m->d_r.p, d_cam_start, d_range, m->h_gcnt.dp, 0);
     MORB_HIP(hipGetLastError());
     // the launch is sized for the capacity (cap_rows queries against world * cap_rows features); the counts come from HBM
     if ((rc = cross_enqueue(m, sd, m->d_r.p, n_cap, d_cam_start, n_cams, 0, cap_rows, d_range))) return rc;
@@ -1258,6 +1267,19 @@ int orbm_cross_top2_gathered_enqueue(orbm_matcher* m, const uint8_t* d_gathered,
     m->gathered_cams = n_cams;
     m->foreign_work = true;
     return ORB_OK;
+}
+
+// The same two launches on a stream and buffers of the caller's choosing (frontend.hip: a step's exchange runs at the tail of its
+// extraction chain, every step in flight with buffers of its own): d_list >= world * cap_rows rows, d_gstart >= n_cams + 5 words,
+// h_gcnt_dp (device pointer of mapped pinned memory) n_cams + 3 words -- counts, own queries, clamped counts, blocks marked "redo".
+int morb::gathered_enqueue_to(hipStream_t st, const uint8_t* d_gathered, int world, size_t block_bytes, int cap_rows, int cams_per_rank,
+                              int rank, uint8_t* d_list, int* d_gstart, int* h_gcnt_dp, CrossOut& out) {
+    const int n_cams = world * cams_per_rank, n_cap = world * cap_rows;
+    int* d_range = d_gstart + n_cams + 1;
+    hipLaunchKernelGGL(k_repack_gathered, dim3((2 * cap_rows + 255) / 256, world), dim3(256), 0, st, d_gathered, world, block_bytes, cap_rows,
+                       cams_per_rank, rank, (uint4*)d_list, d_gstart, d_range, h_gcnt_dp, 1);
+    MORB_HIP(hipGetLastError());
+    return cross_enqueue_to(st, d_list, n_cap, d_gstart, n_cams, 0, cap_rows, d_range, out.i.dp, out.b.dp, out.s.dp, out.scratch.p);
 }
 
 // collect half, after the main stream has been synchronised (orbf_step_end does)

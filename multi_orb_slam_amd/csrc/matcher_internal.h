@@ -34,6 +34,9 @@ struct CamFeat {
 };
 
 constexpr size_t ORBM_BLOCK_TRAILER = 256;  // bytes behind the descriptor rows of a frame: int32 per-camera counts
+// bit 30 of the first count: the block comes from an extraction whose device quadtree left its limits -- the step is being redone
+// on the host path and the block will be shipped again (frontend.hip: the ranks of an exchange all see the bit and all take part)
+constexpr int ORBM_BLOCK_REDO = 1 << 30;
 
 struct FrameBufs {  // device storage of one frame; recycled through the matcher's pool (no hipMalloc per frame)
     DevBuf<float> d_x, d_y, d_ur, d_depth, d_ang;
@@ -209,11 +212,14 @@ int cross_enqueue_to(hipStream_t st, const uint8_t* d_desc, int n, const int* d_
                      const int* d_n, int* o_idx, int* o_best, int* o_second, void* scratch);
 int cross_enqueue(orbm_matcher* m, hipStream_t st, const uint8_t* d_desc, int n, const int* d_cam_start, int n_cams, int q_off,
                   int nq, const int* d_n = nullptr);
+int gathered_enqueue_to(hipStream_t st, const uint8_t* d_gathered, int world, size_t block_bytes, int cap_rows, int cams_per_rank, int rank,
+                        uint8_t* d_list, int* d_gstart, int* h_gcnt_dp, CrossOut& out);
 // ---- exchange.hip
 struct LoopComm;
 int exchange_rccl_available();
 int exchange_unique_id(uint8_t* out128);
 int exchange_comm_init(void** comm, int world, const uint8_t* uid128, int rank);
+int exchange_comm_clone(void* comm, int rank, void** out);
 void exchange_comm_destroy(void* comm);
 int exchange_allgather(void* comm, const void* sendbuf, void* recvbuf, size_t bytes, hipStream_t st);
 int loop_join(int group, int world, int rank, LoopComm** out);

@@ -181,14 +181,16 @@ class NativeFrontEnd:
 
     @property
     def exchange_placement(self):
-        """0 no exchange, 1 on the matcher's own stream behind the search, 2 on its side stream (orbf_exchange_placement)"""
+        """0 no exchange, 1 on the matcher's own stream behind the step's search, 3 at the tail of the step's extraction chain
+        (orbf_exchange_placement; MORB_EXCHANGE_PLACEMENT = chain | inline when the exchange is set up)"""
         return _lib.lib().orbf_exchange_placement(self._h)
 
     def debug_exchange_timing(self, on=True):
         check(_lib.lib().orbf_debug_exchange_timing(self._h, 1 if on else 0))
 
     def debug_exchange_us(self):
-        """(search finished, exchange finished) of the last step, microseconds of device time from the start of its matching"""
+        """(search finished, exchange finished) of the last step, microseconds of device time from the start of its matching (the second
+        one is negative when the exchange -- issued with the step's extraction chain -- was over before the matching began)"""
         out = (C.c_float * 2)()
         check(_lib.lib().orbf_debug_exchange_us(self._h, out))
         return float(out[0]), float(out[1])

@@ -69,8 +69,7 @@ class FrontEnd:
         self.gather = gather                      # DescriptorExchange (multi-GPU) or None
         self.global_cams = global_cams or list(range(rank * self.n_cams, (rank + 1) * self.n_cams))
         rt.set_device(device)
-        # (where a multi-GPU exchange runs is the native handle's decision, taken when the exchange is set up -- orbf_exchange_placement;
-        # a handle that moves it to the side stream gives up its third extractor instance itself: nothing to decide here)
+        # (where a multi-GPU exchange runs is the native handle's decision, taken when the exchange is set up -- orbf_exchange_placement)
         self.fe = NativeFrontEnd(self.params, width, height, device, ahead_depth=0)
         self.fe.configure(MBF, 100, True)
         if calib is not None:

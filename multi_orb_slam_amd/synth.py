@@ -48,6 +48,68 @@ def image(cam, t, width, height):
     return np.clip(img + noise, 0, 255).astype(np.uint8)
 
 
+# ---- further image families (round 5): what the rectangle scenes never put in front of the kernels -- smooth gradients, soft
+# edges, saturated regions and texture just under and just over the FAST thresholds, where the fixed-point roundings of the
+# resize (>>4 .. >>16 .. +2 >>2) and of the blur ((s + 32768) >> 16) decide bytes.  Integer arithmetic only, like image().
+FAMILIES = ("pink", "ramp", "soft", "saturated", "threshold")
+
+
+def _box_blur(a, r):
+    """(2r+1)^2 box mean of an int array, edge-replicated, rounded to nearest (integer arithmetic)."""
+    p = np.pad(a.astype(np.int64), r, mode="edge")
+    c = np.cumsum(np.cumsum(np.pad(p, ((1, 0), (1, 0))), axis=0), axis=1)
+    k = 2 * r + 1
+    s = c[k:, k:] - c[:-k, k:] - c[k:, :-k] + c[:-k, :-k]
+    return (s + k * k // 2) // (k * k)
+
+
+def _white(seed, h, w, mod):
+    return (hash32(np.arange(w * h, dtype=np.uint64) + np.uint64(seed & 0xFFFFFFFF)) % np.uint32(mod)).astype(np.int64).reshape(h, w)
+
+
+def family_image(kind, cam, t, width, height):
+    """uint8 HxW frame t of camera `cam` of one of FAMILIES:
+    pink       1/f-like noise: white noise octaves, each box-blurred at twice the radius and weighted by it
+    ramp       a smooth two-way gradient plus two broad quadratic bumps, dithered by +-1, the rectangle scene on top at a third of its contrast
+    soft       the rectangle scene of image() behind a 5x5 or 9x9 box blur (soft edges), little noise
+    saturated  the rectangle scene stretched so that a third of it clips at 0 and 255, with noise on top (clipped again)
+    threshold  weak rectangles (contrast 5..26 around mid-grey: both sides of iniThFAST = 20 / minThFAST = 7) on +-3 texture"""
+    seed = (cam * 100003 + t) * 2654435761 + 977 * FAMILIES.index(kind)
+    if kind == "pink":
+        acc = np.zeros((height, width), np.int64)
+        wsum = 0
+        for o, r in enumerate((0, 1, 2, 4, 8, 16)):
+            n = _white(seed + 7919 * o, height, width, 256) - 128
+            acc += (_box_blur(n, r) if r else n) * (2 * r + 1)
+            wsum += 1
+        img = 128 + acc // (2 * wsum)
+    elif kind == "ramp":
+        y, x = np.mgrid[0:height, 0:width].astype(np.int64)
+        cx, cy = width // 3 + 5 * t, height // 2 + 3 * t
+        bump = 90 - ((x - cx) ** 2 + (y - cy) ** 2) * 90 // (width * width // 9)
+        bump2 = 70 - ((x - 2 * cx) ** 2 + (y - cy // 2) ** 2) * 70 // (width * width // 16)
+        rects = (image(cam, t, width, height).astype(np.int64) - 128) // 3     # (something for FAST to find on the slopes)
+        img = 20 + (x * 150) // width + (y * 60) // height + np.maximum(bump, 0) + np.maximum(bump2, 0) + rects + _white(seed, height, width, 3) - 1
+    elif kind == "soft":
+        base = image(cam, t, width, height).astype(np.int64)
+        img = _box_blur(base, 2 if cam % 2 == 0 else 4) + _white(seed, height, width, 5) - 2
+    elif kind == "saturated":
+        base = image(cam, t, width, height).astype(np.int64)
+        img = (base - 128) * 3 + 128 + _white(seed, height, width, 41) - 20
+    elif kind == "threshold":
+        img = np.full((height, width), 128, np.int64)
+        dx, dy = 3 * t, t
+        for x0, y0, w, h, g in scene_rects(cam, width, height):
+            xa, ya = max(0, x0 + dx), max(0, y0 + dy)
+            xb, yb = min(width, x0 + dx + w), min(height, y0 + dy + h)
+            if xa < xb and ya < yb:
+                img[ya:yb, xa:xb] = 128 + (5 + g % 22) * (1 if g & 64 else -1)
+        img = img + _white(seed, height, width, 7) - 3
+    else:
+        raise ValueError(kind)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
 def descriptors(n, seed=42):
     return hash32(np.arange(n * 8, dtype=np.uint64) + np.uint64((seed * 0x9E3779B1) & 0xFFFFFFFF)).view(np.uint8).reshape(n, 32).copy()
 

@@ -776,7 +776,7 @@ int orc_is_corner(const uint8_t* img, int stride, int x, int y, int threshold) {
 int orc_fast(const uint8_t* view, int cols, int rows, int stride, int threshold, KeyPoint* out, int cap) {
     std::vector<KeyPoint> v; fast_9_16_nms(view, cols, rows, stride, threshold, v);
     int n = (int)std::min<size_t>(v.size(), (size_t)cap);
-    std::memcpy(out, v.data(), (size_t)n * sizeof(KeyPoint));
+    if (n > 0) std::memcpy(out, v.data(), (size_t)n * sizeof(KeyPoint));
     return (int)v.size();
 }
 
@@ -786,7 +786,7 @@ int orc_cell_candidates(const uint8_t* img, int w, int h, int iniTh, int minTh, 
     Image im; im.w = w; im.h = h; im.px.assign(img, img + (size_t)w * h);
     std::vector<KeyPoint> v; cell_candidates(P, im, v);
     int n = (int)std::min<size_t>(v.size(), (size_t)cap);
-    std::memcpy(out, v.data(), (size_t)n * sizeof(KeyPoint));
+    if (n > 0) std::memcpy(out, v.data(), (size_t)n * sizeof(KeyPoint));
     return (int)v.size();
 }
 
@@ -796,7 +796,7 @@ int orc_distribute_octree(const KeyPoint* in, int n_in, int minX, int maxX, int 
     std::vector<KeyPoint> r;
     try { r = distribute_octree(v, minX, maxX, minY, maxY, N); } catch (const std::domain_error&) { return INT32_MIN; }   // (ORC_E_UNDEFINED)
     int n = (int)std::min<size_t>(r.size(), (size_t)cap);
-    std::memcpy(out, r.data(), (size_t)n * sizeof(KeyPoint));
+    if (n > 0) std::memcpy(out, r.data(), (size_t)n * sizeof(KeyPoint));
     return (int)r.size();
 }
 

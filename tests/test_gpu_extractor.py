@@ -94,6 +94,32 @@ def test_noise_and_low_contrast_images():
     ex.close()
 
 
+@pytest.mark.parametrize("kind", list(synth.FAMILIES))
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (1920, 1080, 4000)])
+def test_image_families_stage_by_stage(kind, w, h, nf):
+    """What the rectangle scenes never show the kernels (round 5, synth.family_image): 1/f-like noise, dithered ramps, soft edges,
+    saturated regions, contrast on both sides of the FAST thresholds -- where the roundings of the fixed-point resize and blur decide
+    bytes.  Every pyramid level, every level's candidate list and the final keypoints + descriptors against the oracle, at 640x480 (the
+    tiled one-launch pyramid) and 1920x1080 (the resize chain), two cameras with different content in one launch."""
+    import multi_orb_slam_amd as m
+    ex = _mk([m.ExtractorParams(nfeatures=nf)] * 2, w, h)
+    imgs = [synth.family_image(kind, c, 1 + c, w, h) for c in range(2)]
+    out = ex.extract(imgs)
+    for c in range(2):
+        for l, ref in enumerate(oracle.pyramid(imgs[c])):
+            got = ex.debug_level(c, l)
+            assert got.shape == ref.shape and np.array_equal(got, ref), (kind, c, "level %d" % l)
+            cand = ex.debug_candidates(c, l)
+            ocand = oracle.cell_candidates(ref)
+            assert len(cand) == len(ocand), (kind, c, l)
+            for f in ("x", "y", "response"):
+                assert np.array_equal(cand[f], ocand[f]), (kind, c, l, f)
+        okps, odesc = oracle.extract(imgs[c], nfeatures=nf)
+        _assert_same(out[c][0], out[c][1], okps, odesc)
+        assert len(okps) > nf // 2
+    ex.close()
+
+
 def test_larger_configs():
     """configs[2] (1280x720 @2000) end to end; 1920x1080 @4000 on one camera."""
     import multi_orb_slam_amd as m

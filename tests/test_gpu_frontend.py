@@ -286,6 +286,41 @@ def test_single_rank_rccl_exchange_equals_oracle():
         fe.fe.exchange_shutdown(); fe.native_exchange = False
         assert fe.fe.exchange_world == 0
         fe.close()
+        # A block that went out with its extraction chain BEFORE the device quadtree's fallback was known carries the mark and is
+        # shipped again at the end of its step (frontend.hip: ORBM_BLOCK_REDO): noise in steps 1 and 2 (two redone steps in a row)
+        # with two steps announced ahead, in both placements of the exchange, over the real transport.
+        w, h = 640, 480
+        params2 = [m.ExtractorParams(nfeatures=500)] * 2
+
+        def noise(c, t):
+            r = synth.hash32(np.arange(w * h, dtype=np.uint64) + np.uint64(1000 * t + 17 * c))
+            return (r % 256).astype(np.uint8).reshape(h, w)
+
+        frames2 = [[noise(c, t) if t in (1, 2) else synth.image(c, t, w, h) for c in range(2)] for t in range(6)]
+        for placement in ("chain", "inline"):
+            os.environ["MORB_OCT_MAX_KEYS"] = "4096"; os.environ["MORB_EXCHANGE_PLACEMENT"] = placement
+            try:
+                fe2 = pipeline.FrontEnd(params2, w, h)
+                assert fe2.enable_native_exchange(dist, torch.device("cuda", 0))
+            finally:
+                os.environ.pop("MORB_OCT_MAX_KEYS"); os.environ.pop("MORB_EXCHANGE_PLACEMENT")
+            assert fe2.fe.exchange_placement == (3 if placement == "chain" else 1)
+            ofe2 = OracleFrontEnd(params2, w, h)
+            fe2.announce(frames2[1])
+            for t in range(6):
+                got = fe2.step(frames2[t], next_images=frames2[t + 2] if t + 2 < 6 else None)
+                assert got["rig_counts"] == got["counts"], (placement, t)
+                assert_same_step(got, ofe2.step(frames2[t]))
+                if t == 1:
+                    assert len(fe2.ex.debug_candidates(0, 0)) > 4096      # the case this part is about
+            # with an exchange an announcement is binding: the block of the announced images has been shipped
+            if placement == "chain":
+                fe2.announce(frames2[0])
+                fe2.step(frames2[3])              # (extracts the announced frame 0 as the NEXT step and ships its block)
+                with pytest.raises(m.OrbError, match="announcements are binding"):
+                    fe2.step(frames2[4])
+            fe2.fe.exchange_shutdown(); fe2.native_exchange = False
+            fe2.close()
     finally:
         dist.destroy_process_group()
 
@@ -427,7 +462,7 @@ def test_recycled_device_buffer_with_a_generation_is_extracted_again():
     fe.close()
 
 
-def _loopback_rig(world, n_cams, w, h, nf, ahead, T=6, group=None, delayed_rank=None, delay_s=0.0, probe=False):
+def _loopback_rig(world, n_cams, w, h, nf, ahead, T=6, group=None, delayed_rank=None, delay_s=0.0, probe=False, frame_fn=None):
     """`world` front ends on this one device, one host thread each, the cameras of ONE rig sharded over them, exchanging their
     export blocks from inside the native step through the in-process loopback transport.  Optionally one rank sleeps `delay_s`
     before every step (a slow peer) and every rank records when its search / its exchange had finished on the device
@@ -440,7 +475,7 @@ def _loopback_rig(world, n_cams, w, h, nf, ahead, T=6, group=None, delayed_rank=
     from multi_orb_slam_amd.dist import shard_cameras
     from oracle_pipeline import OracleFrontEnd, assert_same_step
     per = n_cams // world
-    frames = [{g: synth.image(g, t, w, h) for g in range(n_cams)} for t in range(T)]
+    frames = [{g: (frame_fn(g, t) if frame_fn else synth.image(g, t, w, h)) for g in range(n_cams)} for t in range(T)]
     results = [[None] * T for _ in range(world)]
     timings = [[None] * T for _ in range(world)]
     placements = [None] * world
@@ -506,26 +541,54 @@ def test_world_size_n_native_steps_over_the_loopback_exchange(world, n_cams, w, 
     rank's keypoints, descriptors, stereo, temporal matches and rig-wide cross-camera top-2 must equal the oracle's; with
     steps announced ahead some ranks ship their block early (between begin and end), others late -- any mix must work."""
     _results, _timings, placements = _loopback_rig(world, n_cams, w, h, nf, ahead)
-    assert placements == [1] * world          # the default at every world size: on the matcher's own stream
+    assert placements == [3] * world          # the default at every world size: at the tail of the step's extraction chain
 
 
-@pytest.mark.parametrize("placement", ["inline", "side"])
+@pytest.mark.parametrize("placement", ["chain", "inline"])
+def test_a_block_shipped_before_its_extraction_fell_back_is_shipped_again(placement, monkeypatch):
+    """A step's exchange goes out with its extraction chain, before anybody knows whether the device quadtree stayed inside its
+    limits.  Camera 2 (rank 2 of four) sees noise in step 1 -- more candidates on level 0 than the quadtree takes (limit lowered
+    to 4096 here) --, its step is redone on the host path, the block it had shipped carries the mark and EVERY rank ships its
+    final block a second time at the end of that step: all ranks' rig-wide top-2 must equal the oracle's on the final
+    descriptors, in the step with the redo and around it, with two steps announced ahead.  (Behind the search the same with two
+    redone steps in a row; with the chain the LOOPBACK transport cannot do that -- its rendezvous blocks the host, a rank that
+    stops extracting ahead after a fallback issues its later exchanges later than its peers, and a second redo would then wait
+    for ranks that wait for it.  RCCL calls return at once: test_single_rank_rccl_exchange_equals_oracle runs that case.)"""
+    monkeypatch.setenv("MORB_EXCHANGE_PLACEMENT", placement)
+    monkeypatch.setenv("MORB_OCT_MAX_KEYS", "4096")
+    w, h = 640, 480
+
+    def frame(g, t):
+        if g == 2 and t in ((1, 2) if placement == "inline" else (1,)):
+            r = synth.hash32(np.arange(w * h, dtype=np.uint64) + np.uint64(1000 * t + 17 * g))
+            return (r % 256).astype(np.uint8).reshape(h, w)
+        return synth.image(g, t, w, h)
+
+    results, _t, placements = _loopback_rig(4, 4, w, h, 500, ahead=2, T=6, group=2100 + (placement == "inline"), frame_fn=frame)
+    assert placements == [1 if placement == "inline" else 3] * 4
+    assert results[2][1]["counts"][0] > 400 and results[0][1]["rig_counts"][2] == results[2][1]["counts"][0]
+
+
+@pytest.mark.parametrize("placement", ["chain", "inline"])
 def test_slow_peer_delays_the_end_of_the_step_never_the_local_search(placement, monkeypatch):
-    """configs[3]'s rig over four ranks with one rank arriving 1 ms late at EVERY step, in both arrangements of the exchange
-    (on the matcher's own stream behind the search / on its side stream next to it, two chains ahead).  A step issues its
-    search before its collective in either, so on the three punctual ranks the search has long finished on the device when the
-    late block arrives: device time to `search done` stays a fraction of the delay, device time to `exchange done` carries it.
-    Results stay bit-identical with the oracle on every rank and step (VERDICT r03 #7)."""
+    """configs[3]'s rig over four ranks with one rank arriving 1 ms late at EVERY step, in both arrangements of the exchange: at the
+    tail of the step's extraction chain (the default: issued two steps ahead of the step's matching) and behind the step's search
+    on the matcher's stream (rounds 2-4).  In either the local search never waits for the late peer.  Behind the search the end of
+    the step carries the peer's delay; with the chain the step's exchange was over before its matching even began (negative time).
+    Results stay bit-identical with the oracle on every rank and step."""
     monkeypatch.setenv("MORB_EXCHANGE_PLACEMENT", placement)
     world, delay = 4, 1.0e-3
-    _results, timings, placements = _loopback_rig(world, 4, 640, 480, 1000, ahead=2, T=10, group=1900 + (placement == "side"),
+    _results, timings, placements = _loopback_rig(world, 4, 640, 480, 1000, ahead=2, T=10, group=1900 + (placement == "inline"),
                                                   delayed_rank=1, delay_s=delay, probe=True)
-    assert placements == [1 if placement == "inline" else 2] * world
+    assert placements == [1 if placement == "inline" else 3] * world
     for r in (0, 2, 3):
         search = np.median([timings[r][t][0] for t in range(3, 10)])
         exch = np.median([timings[r][t][1] for t in range(3, 10)])
         assert 0 < search < 0.5 * delay * 1e6, (r, search, exch)          # the local search never waited for the late peer
-        assert exch - search > 0.4 * delay * 1e6, (r, search, exch)       # ... the end of the step did
+        if placement == "inline":
+            assert exch - search > 0.4 * delay * 1e6, (r, search, exch)   # ... the end of the step did
+        else:
+            assert exch < search, (r, search, exch)                       # ... and with the chain the exchange is not on the step's path at all
     print("slow peer (%s): punctual ranks' median search done %.0f us, exchange done %.0f us after the start of the step's matching"
           % (placement, np.median([timings[r][t][0] for r in (0, 2, 3) for t in range(3, 10)]),
              np.median([timings[r][t][1] for r in (0, 2, 3) for t in range(3, 10)])))

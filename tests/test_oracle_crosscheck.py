@@ -1,0 +1,146 @@
+"""Independent cross-checks of the oracle's OpenCV restatements (written from memory of OpenCV 2.4 / 3.2, which is
+not in this image -- "parity unpinned").  What the image DOES have is used here as a second opinion:
+
+* torch's float64 bilinear interpolation (half-pixel centres, the convention cv::resize documents) against the oracle's 11-bit
+  fixed-point `resize`: error inside the (-3/4, +1/2] band the formula's two truncating shifts allow, equal on >= 85 % of the
+  pixels (the formula itself, not the restatement, moves every eighth pixel one level down);
+* scipy.ndimage's float64 correlation with the normalised sigma-2 Gaussian and mirror borders against the oracle's 8-bit
+  `GaussianBlur` (integer taps 18 34 49 55 49 34 18, sum 257): within 1 grey level everywhere, equal on >= 95 %;
+* FAST-9/16 by the published definition -- the segment test evaluated at every threshold, the score the largest threshold a pixel
+  survives -- over whole images against the oracle's corner score and corner test;
+* libm's atan2 / sincos against fastAtan2's polynomial and the deterministic sincos.
+
+All over the image families of multi_orb_slam_amd/synth.py (rectangles, 1/f-like noise, dithered ramps, soft edges, saturated
+regions, contrast at the FAST thresholds) at 640x480 and 1920x1080.  This does not pin the oracle to OpenCV -- only OpenCV could --
+but a restatement that misremembered a convention (pixel centres, border mode, kernel normalisation, rounding constant) fails here."""
+import numpy as np
+import pytest
+
+import oracle
+from multi_orb_slam_amd import synth
+
+SIZES = [(640, 480), (1920, 1080)]
+
+
+def images(w, h):
+    yield "rects", synth.image(1, 2, w, h)
+    for k in synth.FAMILIES:
+        yield k, synth.family_image(k, 1, 2, w, h)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_resize_against_float64_bilinear(w, h):
+    import torch
+    import torch.nn.functional as F
+    for name, img in images(w, h):
+        dw, dh = int(round(w / 1.2)), int(round(h / 1.2))
+        got = oracle.resize_linear(img, dw, dh).astype(np.int64)
+        ref = F.interpolate(torch.from_numpy(img.astype(np.float64))[None, None], size=(dh, dw), mode="bilinear", align_corners=False)[0, 0].numpy()
+        # The 8-bit path is ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2 with 11-bit coefficients: round-to-nearest of
+        # a sum of two terms that were each TRUNCATED to quarter grey levels.  Against the exact value that is an error in
+        # (-3/4 - coefficient quantisation, +1/2], biased downward by ~1/8 -- never a whole level, never upward beyond rounding; a
+        # wrong pixel-centre convention, clamp or coefficient would show as errors of whole levels along edges.
+        e = got - ref
+        q = 2 * 255 * 0.5 / 2048          # (what rounding the coefficients to 1/2048 can move a value of 255, both axes)
+        assert -0.75 - q <= e.min() and e.max() <= 0.5 + q, (name, e.min(), e.max())
+        assert -0.20 <= e.mean() <= -0.05, (name, e.mean())
+        same = np.mean(got == np.floor(ref + 0.5).astype(np.int64))
+        assert same >= 0.85, (name, same)                                          # (the truncations move ~12 % of the pixels one level down)
+        # chained like the pyramid (level l from the QUANTISED level l-1): the float chain stays within one level per step
+        lv = oracle.pyramid(img)
+        prev = lv[3].astype(np.float64)
+        ref4 = F.interpolate(torch.from_numpy(prev)[None, None], size=lv[4].shape, mode="bilinear", align_corners=False)[0, 0].numpy()
+        assert np.abs(lv[4].astype(np.int64) - ref4).max() <= 1.0, name
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_gaussian_against_float64_correlation(w, h):
+    from scipy import ndimage
+    x = np.arange(-3, 4, dtype=np.float64)
+    k = np.exp(-x * x / 8.0)
+    k /= k.sum()
+    assert np.array_equal(np.rint(k * 256).astype(int), oracle.gaussian_kernel())      # cvRound(k * 256): the integer taps
+    for name, img in images(w, h):
+        got = oracle.gaussian_blur7(img).astype(np.int64)
+        f = ndimage.correlate1d(img.astype(np.float64), k, axis=1, mode="mirror")     # (mirror == BORDER_REFLECT_101)
+        f = ndimage.correlate1d(f, k, axis=0, mode="mirror")
+        # the integer taps sum to 257 / 256 per axis: a constant c comes out as c * 257^2 / 65536 -- up to 2 above the float value at 255,
+        # saturated; so compare with the float result of the SAME (unnormalised) taps, and with the normalised one within 3
+        ki = oracle.gaussian_kernel().astype(np.float64) / 256.0
+        g = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), ki, axis=1, mode="mirror"), ki, axis=0, mode="mirror")
+        g = np.minimum(g, 255.0)
+        d = np.abs(got - g)
+        assert d.max() <= 1.0, (name, d.max())
+        assert np.mean(got == np.floor(g + 0.5).astype(np.int64)) >= 0.95, name
+        assert np.abs(got - f).max() <= 3.0, name
+
+
+def _fast_by_definition(img):
+    """score[y, x] = the largest t in [0, 255] for which (x, y) passes the segment test at threshold t (9 contiguous ring pixels all
+    brighter than p + t or all darker than p - t), or -1 if it passes at none; straight from the definition, vectorised per arc."""
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    a = img.astype(np.int16)
+    h, w = a.shape
+    c = a[3:h - 3, 3:w - 3]
+    d = np.stack([a[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] - c for dx, dy in ring])      # ring - centre
+    best = np.full(c.shape, -1, np.int16)
+    for s in range(16):
+        arc = d[[(s + i) % 16 for i in range(9)]]
+        bright = arc.min(axis=0)          # passes "all > p + t" for every t < bright
+        dark = (-arc).min(axis=0)
+        best = np.maximum(best, np.maximum(bright, dark) - 1)
+    return best                            # -1 where no arc has all nine strictly on one side
+
+
+@pytest.mark.parametrize("w,h", [(640, 480)])
+def test_fast_score_by_definition_on_whole_images(w, h):
+    for name, img in images(w, h):
+        best = _fast_by_definition(img)
+        ys, xs = np.nonzero(best >= 7)
+        assert len(ys) > 50, name
+        # every corner at threshold 7 (and a sample of the rest): the oracle's score is the definition's, its corner test agrees at both thresholds
+        pick = np.arange(len(ys))[:: max(1, len(ys) // 4000)]
+        for i in pick:
+            x, y = int(xs[i]) + 3, int(ys[i]) + 3
+            assert oracle.corner_score(img, x, y, 7) == best[ys[i], xs[i]], (name, x, y)
+            assert oracle.is_corner(img, x, y, 20) == (best[ys[i], xs[i]] >= 20), (name, x, y)
+        ny, nx = np.nonzero(best < 7)
+        for i in range(0, len(ny), max(1, len(ny) // 2000)):
+            assert not oracle.is_corner(img, int(nx[i]) + 3, int(ny[i]) + 3, 7), (name, nx[i], ny[i])
+        # and the whole-view detector (FAST with non-max suppression, what a cell runs): its keypoints are exactly the strict local
+        # maxima of the definition's score among the pixels that pass at the threshold
+        view = img[100:100 + 96, 200:200 + 96]
+        kp = oracle.fast(view, 20)
+        b = _fast_by_definition(view).astype(np.int32)
+        sc = np.where(b >= 20, b, 0)
+        pad = np.pad(sc, 1)
+        nb = np.max([pad[1 + dy:1 + dy + sc.shape[0], 1 + dx:1 + dx + sc.shape[1]] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dx, dy) != (0, 0)], axis=0)
+        my, mx = np.nonzero((sc > 0) & (sc > nb))
+        exp = sorted(zip((my + 3).tolist(), (mx + 3).tolist()))
+        got = sorted(zip(kp["y"].astype(int).tolist(), kp["x"].astype(int).tolist()))
+        assert got == exp, name
+        assert [int(sc[y - 3, x - 3]) for y, x in got] == [int(r) for _, r in sorted(zip(zip(kp["y"].astype(int).tolist(), kp["x"].astype(int).tolist()), kp["response"].tolist()))], name
+
+
+def test_angles_against_libm_on_the_families():
+    for name, img in images(640, 480):
+        kps, _ = oracle.extract(img, nfeatures=500)
+        assert len(kps) > 300, name
+        lv = oracle.pyramid(img)
+        for k in kps[::7]:
+            l = int(k["octave"])
+            s = oracle.tables()["scale"][l]
+            x, y = int(round(float(k["x"]) / s)) if l else int(k["x"]), int(round(float(k["y"]) / s)) if l else int(k["y"])
+            # IC_Angle by its definition in float64 (moments over the disc of radius 15), atan2 from libm: fastAtan2 stays within 0.3 degrees
+            patch = lv[l][y - 15:y + 16, x - 15:x + 16].astype(np.float64)
+            if patch.shape != (31, 31):
+                continue
+            vv, uu = np.mgrid[-15:16, -15:16]
+            umax = np.array([15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3])
+            inside = np.abs(uu) <= umax[np.abs(vv)]
+            m10, m01 = (uu * patch * inside).sum(), (vv * patch * inside).sum()
+            if abs(m10) + abs(m01) < 50:
+                continue
+            ref = np.degrees(np.arctan2(m01, m10)) % 360.0
+            d = abs(float(k["angle"]) - ref)
+            assert min(d, 360.0 - d) < 0.3, (name, float(k["angle"]), ref)

@@ -1,0 +1,169 @@
+// Stand-alone probe for the open k_describe defect (DESIGN.md "Known defect", profiles/r05/describe_defect.md).
+//
+// What the in-kernel self-check of round 5 showed (csrc/Makefile VARIANT=slp_check under tools/describe_defect/run_rig.py): the table
+// registers hold what memory holds, the LDS bytes are right, and the wrong result is the LOW half of a
+//     v_pk_mul_f32 vD, v[x:y], v[a:b] op_sel:[0,1] op_sel_hi:[1,0]          (D.lo = x * b, D.hi = y * a)
+// in lanes 48..63 of a wave -- the product comes out as if x * b were 0 -- and only in the lightly loaded phases of the rig (the last
+// steps of a run; 65 % of the runs with every stream on ONE hardware queue, 1 % with the default four, 0.1 % with eight).  This program
+// issues exactly that instruction sequence (hard-coded registers, the same neighbours: four 16-byte table loads, two v_cvt_f32_f64
+// producing (a, b), s_waitcnt vmcnt(3), the sixteen packed multiplies in the failing build's order) and compares every product with
+// what the operands give, under launch patterns from "back to back" to "one launch, then the part idles for milliseconds".
+//
+// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -ffp-contract=off -o pk_probe pk_probe.hip     run: ./pk_probe [seconds per cell]
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+__host__ __device__ inline float tab_value(int i, int k) { return (float)(((i * 7 + k * 3) % 27) - 13); }
+
+__global__ __launch_bounds__(256) void k_fill(float4* tab, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) tab[i] = make_float4(tab_value(i, 0), tab_value(i, 1), tab_value(i, 2), tab_value(i, 3));
+}
+
+// packed multiply D = (S.lo * b, S.hi * a) [O: op_sel form] or (S.lo * a, S.hi * b) [P: plain]; (a, b) = v[116:117]
+#define PKO(d0, d1, s0, s1) "v_pk_mul_f32 v[" #d0 ":" #d1 "], v[" #s0 ":" #s1 "], v[116:117] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+#define PKP(d0, d1, s0, s1) "v_pk_mul_f32 v[" #d0 ":" #d1 "], v[" #s0 ":" #s1 "], v[116:117]\n\t"
+// the same products from scalar-float multiplies (control)
+#define SCO(d0, d1, s0, s1) "v_mul_f32 v" #d0 ", v" #s0 ", v117\n\tv_mul_f32 v" #d1 ", v" #s1 ", v116\n\t"
+#define SCP(d0, d1, s0, s1) "v_mul_f32 v" #d0 ", v" #s0 ", v116\n\tv_mul_f32 v" #d1 ", v" #s1 ", v117\n\t"
+#define LOADS \
+    "global_load_dwordx4 v[100:103], %[voff], %[base] offset:0\n\t"  \
+    "global_load_dwordx4 v[104:107], %[voff], %[base] offset:16\n\t" \
+    "global_load_dwordx4 v[108:111], %[voff], %[base] offset:32\n\t" \
+    "global_load_dwordx4 v[112:115], %[voff], %[base] offset:48\n\t"
+// products: j-th load's registers 100 + 4 j .. ; results 118 + 8 j: xy O, xy P, zw O, zw P -- issued in the failing build's order
+#define MULS(O, P) \
+    "s_waitcnt vmcnt(3)\n\t" O(118, 119, 100, 101) P(120, 121, 100, 101) P(124, 125, 102, 103) \
+    "s_waitcnt vmcnt(2)\n\t" O(130, 131, 106, 107) \
+    "s_waitcnt vmcnt(0)\n\t" P(144, 145, 112, 113) "v_add_f32 v150, v118, v119\n\t" O(122, 123, 102, 103) O(126, 127, 104, 105) \
+    P(136, 137, 108, 109) O(142, 143, 112, 113) "v_sub_f32 v151, v120, v121\n\tv_sub_f32 v152, v124, v125\n\tv_rndne_f32 v150, v150\n\t" \
+    P(128, 129, 104, 105) P(132, 133, 106, 107) O(134, 135, 108, 109) O(138, 139, 110, 111) O(146, 147, 114, 115) \
+    "v_rndne_f32 v151, v151\n\t" P(140, 141, 110, 111) P(148, 149, 114, 115)
+#define STORES \
+    "global_store_dwordx4 %[ooff], v[118:121], %[obase] offset:0\n\t"   "global_store_dwordx4 %[ooff], v[122:125], %[obase] offset:16\n\t" \
+    "global_store_dwordx4 %[ooff], v[126:129], %[obase] offset:32\n\t"  "global_store_dwordx4 %[ooff], v[130:133], %[obase] offset:48\n\t" \
+    "global_store_dwordx4 %[ooff], v[134:137], %[obase] offset:64\n\t"  "global_store_dwordx4 %[ooff], v[138:141], %[obase] offset:80\n\t" \
+    "global_store_dwordx4 %[ooff], v[142:145], %[obase] offset:96\n\t"  "global_store_dwordx4 %[ooff], v[146:149], %[obase] offset:112\n\t" \
+    "s_waitcnt vmcnt(0)\n\t"
+#define CLOBBERS "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", \
+    "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", \
+    "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152"
+
+// errors[0..3]: wrong products by form -- op_sel low (x * b), op_sel high (y * a), plain low (x * a), plain high (y * b)
+// errors[4..7]: by lane / 16;  errors[8..11]: by table load j;  errors[12]: waves checked;  errors[13]: records;  rec[]: the first records
+// FORM 0: the failing kernel's order.  1: s_nop 7 twice between the conversions and the first packed multiply.
+//      2: (a, b) arrive by v_mov_b32 (no v_cvt_f32_f64 in front).  3: FORM 0 with every packed multiply as two v_mul_f32 (control).
+template <int FORM>
+__global__ __launch_bounds__(256) void k_probe(const float4* __restrict__ tab, const double* __restrict__ ang, float* __restrict__ out,
+                                               unsigned* __restrict__ errors, unsigned* __restrict__ rec) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = blockIdx.x * 4 + wave;
+    // (a, b) the way the kernel makes them: double arithmetic that ends in a conversion
+    double da = ang[2 * (w & 1023)], db = ang[2 * (w & 1023) + 1];
+    da = da * 0.99999994 + 1.0e-9 * (double)(w & 7); db = db * 1.00000012 - 1.0e-9 * (double)(w & 3);
+    const float fa = (float)da, fb = (float)db;
+    const unsigned voff = (unsigned)lane * 64u;
+    const unsigned ooff = (unsigned)(blockIdx.x * 256 + threadIdx.x) * 128u;
+    if (FORM == 0)
+        asm volatile(LOADS "v_cvt_f32_f64 v116, %[da]\n\tv_cvt_f32_f64 v117, %[db]\n\t" MULS(PKO, PKP) STORES
+                     : : [voff] "v"(voff), [base] "s"(tab), [da] "v"(da), [db] "v"(db), [fa] "v"(fa), [fb] "v"(fb), [ooff] "v"(ooff), [obase] "s"(out) : CLOBBERS);
+    else if (FORM == 1)
+        asm volatile(LOADS "v_cvt_f32_f64 v116, %[da]\n\tv_cvt_f32_f64 v117, %[db]\n\ts_nop 7\n\ts_nop 7\n\t" MULS(PKO, PKP) STORES
+                     : : [voff] "v"(voff), [base] "s"(tab), [da] "v"(da), [db] "v"(db), [fa] "v"(fa), [fb] "v"(fb), [ooff] "v"(ooff), [obase] "s"(out) : CLOBBERS);
+    else if (FORM == 2)
+        asm volatile(LOADS "v_mov_b32 v116, %[fa]\n\tv_mov_b32 v117, %[fb]\n\t" MULS(PKO, PKP) STORES
+                     : : [voff] "v"(voff), [base] "s"(tab), [da] "v"(da), [db] "v"(db), [fa] "v"(fa), [fb] "v"(fb), [ooff] "v"(ooff), [obase] "s"(out) : CLOBBERS);
+    else
+        asm volatile(LOADS "v_cvt_f32_f64 v116, %[da]\n\tv_cvt_f32_f64 v117, %[db]\n\t" MULS(SCO, SCP) STORES
+                     : : [voff] "v"(voff), [base] "s"(tab), [da] "v"(da), [db] "v"(db), [fa] "v"(fa), [fb] "v"(fb), [ooff] "v"(ooff), [obase] "s"(out) : CLOBBERS);
+    const float* mine = out + (size_t)(blockIdx.x * 256 + threadIdx.x) * 32;
+    if (lane == 0) atomicAdd(&errors[12], 1u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = 4 * lane + j;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // xy, zw
+            const float x = tab_value(i, 2 * h), y = tab_value(i, 2 * h + 1);
+            const float want[4] = {x * fb, y * fa, x * fa, y * fb};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float got = __hip_atomic_load(mine + 8 * j + 4 * h + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__float_as_uint(got) != __float_as_uint(want[k])) {
+                    atomicAdd(&errors[k], 1u); atomicAdd(&errors[4 + (lane >> 4)], 1u); atomicAdd(&errors[8 + j], 1u);
+                    const unsigned slot = atomicAdd(&errors[13], 1u);
+                    if (slot < 32) {
+                        unsigned* r = rec + slot * 8;
+                        r[0] = (unsigned)w; r[1] = (unsigned)(lane << 16 | j << 8 | h << 4 | k); r[2] = __float_as_uint(got); r[3] = __float_as_uint(want[k]);
+                        r[4] = __float_as_uint(x); r[5] = __float_as_uint(y); r[6] = __float_as_uint(fa); r[7] = __float_as_uint(fb);
+                    }
+                }
+            }
+        }
+    }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+template <int FORM>
+static void launch(int grid, hipStream_t st, const float4* tab, const double* ang, float* out, unsigned* errors, unsigned* rec) {
+    hipLaunchKernelGGL(k_probe<FORM>, dim3(grid), dim3(256), 0, st, tab, ang, out, errors, rec);
+}
+
+int main(int argc, char** argv) {
+    const double seconds = argc > 1 ? std::atof(argv[1]) : 4.0;
+    const int GRID = 270;   // k_describe's size at 1000 keypoints: about one workgroup (4 waves, one per SIMD) per CU
+    float4* tab; double* ang; float* out; unsigned* errors; unsigned* rec;
+    CK(hipMalloc(&tab, 256 * sizeof(float4))); CK(hipMalloc(&ang, 2048 * sizeof(double))); CK(hipMalloc(&errors, 64)); CK(hipMalloc(&rec, 32 * 8 * 4));
+    CK(hipMalloc(&out, (size_t)4 * GRID * 256 * 32 * sizeof(float)));
+    std::vector<double> hang(2048);
+    for (int i = 0; i < 2048; ++i) hang[i] = std::sin(0.37 * i + 0.1);
+    CK(hipMemcpy(ang, hang.data(), 2048 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, 0, tab, 256);
+    CK(hipDeviceSynchronize());
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const char* form_name[4] = {"as in the failing build", "s_nop 7 x2 behind the conversions", "(a, b) by v_mov_b32, no conversion", "control: v_mul_f32 pairs"};
+    // pattern: idle microseconds between launches (0 = back to back, 64 launches per synchronisation); grid multiple
+    const struct { int idle_us; int grid_mul; const char* name; } pat[] = {
+        {0, 1, "back to back"}, {0, 4, "back to back, 4 x the workgroups"}, {100, 1, "launch, sync, idle 100 us"}, {1000, 1, "launch, sync, idle 1 ms"},
+        {5000, 1, "launch, sync, idle 5 ms"}, {20000, 1, "launch, sync, idle 20 ms"}};
+    for (int form = 0; form < 4; ++form) {
+        for (const auto& P : pat) {
+            CK(hipMemset(errors, 0, 64)); CK(hipMemset(rec, 0, 32 * 8 * 4));
+            const auto t0 = std::chrono::steady_clock::now();
+            long n = 0;
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+                const int g = GRID * P.grid_mul;
+                switch (form) {
+                    case 0: launch<0>(g, st, tab, ang, out, errors, rec); break;
+                    case 1: launch<1>(g, st, tab, ang, out, errors, rec); break;
+                    case 2: launch<2>(g, st, tab, ang, out, errors, rec); break;
+                    default: launch<3>(g, st, tab, ang, out, errors, rec); break;
+                }
+                ++n;
+                if (P.idle_us > 0) { CK(hipStreamSynchronize(st)); std::this_thread::sleep_for(std::chrono::microseconds(P.idle_us)); }
+                else if ((n & 63) == 0) CK(hipStreamSynchronize(st));
+            }
+            CK(hipStreamSynchronize(st));
+            unsigned h[16], r[32 * 8];
+            CK(hipMemcpy(h, errors, 64, hipMemcpyDeviceToHost)); CK(hipMemcpy(r, rec, sizeof(r), hipMemcpyDeviceToHost));
+            std::printf("form %d (%s) | %s | launches %ld waves %u | wrong products: op_sel lo %u hi %u, plain lo %u hi %u | by lane/16: %u %u %u %u | by load: %u %u %u %u\n",
+                        form, form_name[form], P.name, n, h[12], h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+            for (unsigned s = 0; s < h[13] && s < 6; ++s) {
+                const unsigned* q = r + s * 8;
+                float got, want, x, y, a, b;
+                std::memcpy(&got, q + 2, 4); std::memcpy(&want, q + 3, 4); std::memcpy(&x, q + 4, 4); std::memcpy(&y, q + 5, 4); std::memcpy(&a, q + 6, 4); std::memcpy(&b, q + 7, 4);
+                std::printf("    wave %u lane %u load %u half %u product %u: got %.9g want %.9g (x %.0f y %.0f a %.9g b %.9g)\n", q[0], q[1] >> 16, (q[1] >> 8) & 0xff,
+                            (q[1] >> 4) & 0xf, q[1] & 0xf, got, want, x, y, a, b);
+            }
+            std::fflush(stdout);
+        }
+    }
+    return 0;
+}
