@@ -136,16 +136,16 @@ int orbf_export_features(orbf_frontend* f, orbf_device_features* out);
 int orbf_exchange_unique_id(uint8_t* out128);
 int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int rank);
 int orbf_exchange_active(const orbf_frontend* f);   /* world size, 0 = off */
-/* Where this handle's exchange runs, decided per handle when the exchange is set up: 0 no exchange, 1 on the matcher's own stream
- * behind the step's search (the default at every world size), 2 on the matcher's side stream next to the search
- * (MORB_EXCHANGE_PLACEMENT = inline | side | auto, auto = 2 from three ranks on; the older MORB_EXCHANGE_INLINE = 0 means side).
- * In both a step issues its search before its collective: a late peer delays the end of the step, never the local search. */
+/* Where this handle's exchange runs, decided per handle when the exchange is set up: 0 no exchange; 3 (default) at the tail of
+ * the step's extraction chain, on the extractor's stream -- the all-gather, the repack and the rig-wide top-2 of a step are on the
+ * device while the steps before it are still being matched, and the end of the step only waits for their event; 1 behind the
+ * step's search on the matcher's own stream (rounds 2-4; MORB_EXCHANGE_PLACEMENT = chain | inline).  With placement 3 an
+ * announcement (orbf_prefetch) is BINDING: the block of the announced images is shipped with their extraction, so the step
+ * must pass exactly those images (ORB_E_ARG otherwise), and orbf_reset is a decision of all ranks at the same step (it
+ * skips the step numbers whose blocks have been shipped).  A block whose extraction fell back to the host quadtree after it
+ * had been shipped carries a mark; every rank sees it and all ship that step's final blocks once more at the end of the step. */
 int orbf_exchange_placement(const orbf_frontend* f);
-/* Probe for tests and the bench: with on != 0 every step of a handle with an exchange records, with HIP events on the matcher's
- * stream, when its search and when its exchange (all-gather + repack + rig-wide top-2) had finished on the device;
- * orbf_debug_exchange_us returns the last step's two figures in microseconds from the start of the step's matching. */
-int orbf_debug_exchange_timing(orbf_frontend* f, int on);
-int orbf_debug_exchange_us(const orbf_frontend* f, float* out2);
+/* (probes of the exchange for tests and the bench -- orbf_debug_*: include/orb_debug.h) */
 /* The same exchange between `world` front ends of ONE process on ONE device, each driven by its own host thread (RCCL does
  * not admit two ranks on one GPU): every member calls this with the same `group` id and its own rank, then steps as a rank
  * would -- a step's all-gather rendezvouses the members' threads and copies the blocks device-to-device behind the producers'
@@ -170,8 +170,8 @@ int orbf_step_motion_ahead(orbf_frontend* f, const orbf_image* images, const orb
                            int flags, int th_low, float ratio, orbf_result* out, int* n_cross);
 int orbf_reset(orbf_frontend* f);
 /* The synthetic-stream loop in ONE call: for t = t0 .. t0 + steps - 1 announce timestep t + ahead (orbf_prefetch; ahead = 0:
- * nothing is announced, every step is an isolated one; at most orbf_ahead_depth() + 1, refused with ORB_E_ARG before any step
- * runs otherwise), run orbf_step_motion on ring[(t % ring_len) * n_cams ..] and
+ * nothing is announced, every step is an isolated one; at most min(orbf_ahead_depth() + 1, 3), refused with ORB_E_ARG and a
+ * message naming the limit before any step runs otherwise), run orbf_step_motion on ring[(t % ring_len) * n_cams ..] and
  * count the cross-camera matches a SearchByBoW-style acceptance keeps (orbm_count_ratio_accepted(best, second, n, th_low,
  * ratio)).  `ring` holds ring_len timesteps of n_cams images each.  *announced_upto (in/out): the youngest timestep announced so
  * far, so that consecutive calls continue one stream (-1 / t0 - 1 at the start).  This is exactly what a host-language loop

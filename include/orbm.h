@@ -43,8 +43,6 @@ void* orbm_stream(const orbm_matcher* m);
  * stream a collective library ran an all-gather on) without blocking the host. */
 int orbm_wait_for_stream(orbm_matcher* m, void* other_stream);
 int orbm_set_stream(orbm_matcher* m, void* stream);
-/* {status, nmatches, sweeps, longest candidate list} of the last device-side resolve (inspection only) */
-int orbm_debug_last_resolve(const orbm_matcher* m, int* out4);
 
 /* host helper, identical result to the reference's SWAR popcount; rows need 1-byte alignment only */
 int orbm_descriptor_distance(const uint8_t* a, const uint8_t* b);
@@ -202,11 +200,7 @@ int orbm_features_in_area(orbm_matcher* m, const orbm_frame* f, int cam, float x
 int orbm_project_candidates(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int cap_per_query,
                             int32_t* cand_idx, uint16_t* cand_dist, int32_t* cand_count);
 
-/* Inspection / bench (roofline M3): `iters` launches of the projection kernel alone, as the frame search
- * launches it (window + level + right-coordinate gates, distances, shortlist), timed with HIP events on the handle's
- * stream.  *avg_us = average launch duration, *n_gated = candidates that passed the gates, summed over the queries. */
-int orbm_debug_time_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q, int nq, int th_high, int iters,
-                            float* avg_us, long long* n_gated);
+/* (inspection and timing hooks -- orbm_debug_*: include/orb_debug.h) */
 
 /* SearchByProjection(CurrentFrame, LastFrame, th, bMono, Calib) from the projected queries on.
  * occupied[g] != 0 where CurrentFrame.mvpMapPoints[g] already holds an observed point before the call (may be NULL:

@@ -81,6 +81,10 @@ const orb_keypoint* orbx_device_keypoints(const orbx_extractor* ex, int cam);
 const uint8_t* orbx_device_descriptors(const orbx_extractor* ex, int cam);
 /* the handle's hipStream_t */
 void* orbx_stream(const orbx_extractor* ex);
+/* Everything enqueued on `other_stream` (a hipStream_t) so far happens before whatever this handle enqueues next; no host wait.
+ * For a caller with device work in flight on another stream that reads orbx_device_descriptors() / orbx_device_keypoints():
+ * called before the handle's next run, which overwrites them. */
+int orbx_wait_for_stream(orbx_extractor* ex, void* other_stream);
 /* redirect camera `cam`'s result buffers to caller-owned HBM (e.g. an RCCL all-gather send buffer);
  * d_kps holds cap keypoints, d_desc cap*32 bytes.  NULL restores the internal buffers. */
 int orbx_bind_output(orbx_extractor* ex, int cam, orb_keypoint* d_kps, uint8_t* d_desc, int cap);
@@ -91,23 +95,10 @@ int orbx_bind_output(orbx_extractor* ex, int cam, orb_keypoint* d_kps, uint8_t* 
  * handle's stream has been synchronised.  NULL disables. */
 int orbx_set_host_mirror(orbx_extractor* ex, orb_keypoint* kps_devptr, uint8_t* desc_devptr, int cap_total);
 
-/* -- stage inspection for level-by-level parity tests (not needed by a SLAM caller) -------------------- */
-/* pyramid level (dense w*h bytes) of the last run */
+/* pyramid level `level` of camera `cam` as the last run left it, dense w*h bytes (what the C++ class fills the reference's public
+ * ORBextractor::mvImagePyramid from when asked to; the parity tests compare every level through it) */
 int orbx_debug_level(orbx_extractor* ex, int cam, int level, uint8_t* out, int cap_bytes, int* w, int* h);
-/* candidates handed to the quadtree (x, y relative to (16,16); response = score), cell-major order */
-int orbx_debug_candidates(orbx_extractor* ex, int cam, int level, orb_keypoint* out, int cap, int* n);
-/* per-stage GPU time of the last run in microseconds: {pyramid, fast_cells, compact, quadtree (device kernel, or D2H + host quadtree on the fallback path),
- * describe, total wall}; requires orbx_set_profiling(ex, 1) */
-/* host-only: the library's quadtree (DistributeOctTree, reference src/ORBextractor.cc:540-764) on caller-supplied
- * candidates (x, y relative to (16,16), integral; response); runs without a GPU.  *n_out may exceed cap. */
-int orbx_debug_distribute_octree(const orb_keypoint* in, int n, int min_x, int max_x, int min_y, int max_y,
-                                 int n_features, orb_keypoint* out, int cap, int* n_out);
-/* inspection: which keypoint-distribution path produced the last finished run -- 0 device quadtree, 1 device quadtree
- * including the memory-backed pass for levels beyond 4096 candidates, 2 host quadtree (fallback / MORB_HOST_OCTREE=1) */
-int orbx_debug_last_path(const orbx_extractor* ex);
-/* inspection: cameras whose pyramid level 0 the most recently enqueued run reads in the caller's device buffer instead of a copy
- * (large rigs driven through orbf_*, which promises the buffers' lifetime; 0 everywhere else) */
-int orbx_debug_level0_in_place(const orbx_extractor* ex);
+/* (further stage inspection for the parity tests and the bench -- orbx_debug_*: include/orb_debug.h) */
 int orbx_set_profiling(orbx_extractor* ex, int on);
 int orbx_stage_times_us(const orbx_extractor* ex, float* out6);
 

@@ -123,6 +123,7 @@ def lib():
     L.orbx_device_keypoints.argtypes = [vp, i32]; L.orbx_device_keypoints.restype = vp
     L.orbx_device_descriptors.argtypes = [vp, i32]; L.orbx_device_descriptors.restype = vp
     L.orbx_stream.argtypes = [vp]; L.orbx_stream.restype = vp
+    L.orbx_wait_for_stream.argtypes = [vp, vp]
     L.orbx_bind_output.argtypes = [vp, i32, vp, vp, i32]
     L.orbx_debug_level.argtypes = [vp, i32, i32, vp, i32, vp, vp]
     L.orbx_debug_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
@@ -175,6 +176,7 @@ def lib():
     L.orbf_exchange_placement.argtypes = [vp]
     L.orbf_debug_exchange_timing.argtypes = [vp, C.c_int]
     L.orbf_debug_exchange_us.argtypes = [vp, C.POINTER(C.c_float)]
+    L.orbf_debug_exchange_redos.argtypes = [vp]; L.orbf_debug_exchange_redos.restype = C.c_long
     L.orbf_exchange_init_loopback.argtypes = [vp, i32, i32, i32]
     L.orbf_exchange_shutdown.argtypes = [vp]
     L.orbf_peek_block.argtypes = [vp, vp, vp, vp, vp]

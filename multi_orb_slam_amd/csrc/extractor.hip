@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/orbx.h"
+#include "../../include/orb_debug.h"
 #include "octree.h"
 #include "orb_common.h"
 #include "frame_sink.h"
@@ -1973,6 +1974,7 @@ struct orbx_extractor {
     int inflight = 0; unsigned run_seq = 0;
     bool prof_valid[2] = {false, false};  // the stage events were recorded for the run in this slot
     hipEvent_t ev_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_foreign = nullptr;   // orbx_wait_for_stream
     int* d_h_oct = nullptr;          // device alias of h_oct
     std::vector<DevBuf<orb_keypoint>> d_kps;
     std::vector<DevBuf<uint8_t>> d_desc;
@@ -2336,12 +2338,24 @@ void orbx_destroy(orbx_extractor* ex) {
     if (ex->h_sel) (void)hipHostFree(ex->h_sel);
     if (ex->h_oct) (void)hipHostFree(ex->h_oct);
     for (int i = 0; i < 2; ++i) if (ex->ev_done[i]) (void)hipEventDestroy(ex->ev_done[i]);
+    if (ex->ev_foreign) (void)hipEventDestroy(ex->ev_foreign);
     for (int i = 0; i < 6; ++i) if (ex->ev[i]) (void)hipEventDestroy(ex->ev[i]);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
 }
 
 void* orbx_stream(const orbx_extractor* ex) { return ex ? (void*)ex->stream : nullptr; }
+
+// Everything enqueued on `other_stream` so far happens before whatever this handle enqueues next (no host wait): a caller that has
+// device work reading this handle's output buffers in flight on another stream calls this before the next run overwrites them.
+int orbx_wait_for_stream(orbx_extractor* ex, void* other_stream) {
+    MORB_ARG(ex != nullptr);
+    MORB_HIP(hipSetDevice(ex->device));
+    if (!ex->ev_foreign) MORB_HIP(hipEventCreateWithFlags(&ex->ev_foreign, hipEventDisableTiming));
+    MORB_HIP(hipEventRecord(ex->ev_foreign, (hipStream_t)other_stream));
+    MORB_HIP(hipStreamWaitEvent(ex->stream, ex->ev_foreign, 0));
+    return ORB_OK;
+}
 
 static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int width, int height, int stride, hipMemcpyKind kind) {
     MORB_ARG(ex && cam >= 0 && cam < ex->n_cams);

@@ -364,11 +364,14 @@ int orbm_frame_create(orbm_matcher* m, const orbm_frame_desc* f, orbm_frame** ou
     std::vector<int32_t> cell_of(n);
     F->cell_start.assign(ncell + 1, 0);
     F->cam_start.assign(f->n_cams + 1, 0);
+    int last_cam = 0;
     for (int g = 0; g < n; g++) {
         const int px = (int)roundf((f->un_x[g] - F->minX) * F->invW);
         const int py = (int)roundf((f->un_y[g] - F->minY) * F->invH);
         const int cam = f->cam_of[g];
         if (cam >= 0 && cam < f->n_cams) F->cam_start[cam + 1]++;
+        if (cam < last_cam || cam >= f->n_cams) F->camera_major = false;   // (interleaved cameras, or a feature of no camera: cam_start[] is counts only)
+        else last_cam = cam;
         if (px < 0 || px >= ORBM_GRID_COLS || py < 0 || py >= ORBM_GRID_ROWS || cam < 0 || cam >= f->n_cams) {
             cell_of[g] = -1;
             continue;
@@ -439,10 +442,13 @@ int orbm_frame_create_resident(orbm_matcher* m, const orbm_frame_desc* f, const 
     MORB_ARG(f->un_x && f->un_y && f->octave && f->angle && f->uright && f->cam_of && f->local_of && f->desc);
     MORB_HIP(hipSetDevice(m->device));
     // per-camera row counts (the highest row a feature names + 1) and the camera starts of the global order
-    int rows[4] = {0, 0, 0, 0}, count[4] = {0, 0, 0, 0};
+    int rows[4] = {0, 0, 0, 0}, count[4] = {0, 0, 0, 0}, last_cam = 0;
     for (int g = 0; g < n; ++g) {
         const int c = f->cam_of[g], l = f->local_of[g];
-        if (c < 0 || c >= n_cams) continue;       // (a feature of no camera: no cell, no descriptor -- as orbm_frame_create treats it)
+        // a feature of no camera, or cameras interleaved in the global order: the device build derives every feature's place from the
+        // per-camera counts (it would drop the last features / misplace them) -- such a frame takes the host-built form
+        if (c < 0 || c >= n_cams || c < last_cam) return orbm_frame_create(m, f, out);
+        last_cam = c;
         MORB_ARG(l >= 0 && l < (1 << 24));
         ++count[c];
         if (l + 1 > rows[c]) rows[c] = l + 1;
@@ -458,6 +464,7 @@ int orbm_frame_create_resident(orbm_matcher* m, const orbm_frame_desc* f, const 
     }
     int rc;
     orbm_frame* F = nullptr;
+    if (m->stage_f_busy) { MORB_HIP(hipEventSynchronize(m->ev_stage_f)); m->stage_f_busy = false; }   // (before the frame exists: nothing to give back on failure)
     if ((rc = frame_shell(m, n, n_cams, f->min_x, f->min_y, f->max_x, f->max_y, false, &F))) return rc;
     F->device_built = false;   // (no keypoint records: orbm_frame_download refuses them, as for orbm_frame_create)
     int base = 0;
@@ -466,7 +473,6 @@ int orbm_frame_create_resident(orbm_matcher* m, const orbm_frame_desc* f, const 
     const size_t nn = (size_t)n;
     const size_t head = (6 * nn + (size_t)n_cams + 1 + 3) & ~(size_t)3;          // descriptor rows start 16-byte aligned
     const size_t words = head + 8 * (size_t)host_rows;
-    if (m->stage_f_busy) { MORB_HIP(hipEventSynchronize(m->ev_stage_f)); m->stage_f_busy = false; }
     if ((rc = m->stage_f.reserve(words * 4))) { orbm_frame_destroy(F); return rc; }
     uint32_t* w = reinterpret_cast<uint32_t*>(m->stage_f.p);
     memcpy(w, f->un_x, nn * 4); memcpy(w + nn, f->un_y, nn * 4); memcpy(w + 2 * nn, f->uright, nn * 4);
@@ -489,7 +495,10 @@ int orbm_frame_create_resident(orbm_matcher* m, const orbm_frame_desc* f, const 
                        F->b->d_depth.p, F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_start.p,
                        F->b->d_items.p, hm, (const int*)nullptr, F->desc_rows, S);
     if (hipGetLastError() != hipSuccess) { orbm_frame_destroy(F); morb::set_error("k_frame_build_small launch failed"); return ORB_E_HIP; }
-    MORB_HIP(hipEventRecord(m->ev_stage_f, m->stream));
+    if (hipEventRecord(m->ev_stage_f, m->stream) != hipSuccess) {   // (the staging block would be rewritten under the kernel: wait, give the frame back)
+        (void)hipStreamSynchronize(m->stream); orbm_frame_destroy(F);
+        morb::set_error("hipEventRecord failed behind the frame build"); return ORB_E_HIP;
+    }
     m->stage_f_busy = true;
     *out = F;
     return ORB_OK;

@@ -16,6 +16,7 @@
 #include "matcher_internal.h"
 #include <deque>
 #include "../../include/orbf.h"
+#include "../../include/orb_debug.h"
 
 using namespace morb;
 
@@ -84,6 +85,7 @@ struct orbf_frontend {
     void* xc[NXC + 1] = {};                              // communicators (RCCL) / loopback groups; the last one ships redone blocks
     int x_placement = 0;                                // 0 no exchange, 1 behind the step's search, 3 at the tail of the step's extraction chain
     long step_seq = 0, x_next = 0;                      // steps begun so far; first step whose exchange has not been issued
+    long x_redos = 0;                                   // steps whose blocks were shipped a second time (orbf_debug_exchange_redos)
     long set_xseq[NEX + 3] = {-1, -1, -1, -1, -1, -1};  // per result set: the step whose exchange reads that set's frame as its send buffer
     bool x_timing = false; hipEvent_t ev_x[2] = {nullptr, nullptr}; float x_us[2] = {0.f, 0.f};   // orbf_debug_exchange_timing
     bool xloop = false;                                  // ... over the in-process loopback transport (orbf_exchange_init_loopback)
@@ -303,6 +305,7 @@ int orbf_debug_exchange_timing(orbf_frontend* f, int on) {
     f->x_timing = on != 0;
     return ORB_OK;
 }
+long orbf_debug_exchange_redos(const orbf_frontend* f) { return f ? f->x_redos : -1; }
 int orbf_debug_exchange_us(const orbf_frontend* f, float* out2) {
     MORB_ARG(f && out2);
     out2[0] = f->x_us[0]; out2[1] = f->x_us[1];
@@ -466,9 +469,10 @@ static int queries_from_previous_step(orbf_frontend* f, const orbf_motion* motio
 
 int orbf_run_stream(orbf_frontend* f, const orbf_image* ring, int ring_len, int t0, int steps, int ahead, int* announced_upto,
                     const orbf_motion* motion, int th_low, float ratio, orbf_stream_stats* out) {
-    MORB_ARG(f && ring && ring_len >= 1 && t0 >= 0 && steps >= 0 && ahead >= 0 && ahead <= orbf_frontend::NEX && announced_upto && motion && out);
+    MORB_ARG(f && ring && ring_len >= 1 && t0 >= 0 && steps >= 0 && ahead >= 0 && announced_upto && motion && out);
     // (refused before any step has run: orbf_prefetch would refuse the announcement in the middle of the stream otherwise)
-    if (ahead > f->n_ex + 1) { morb::set_error("orbf_run_stream: ahead = %d, this handle takes at most %d (orbf_ahead_depth() + 1)", ahead, f->n_ex + 1); return ORB_E_ARG; }
+    const int ahead_max = std::min(f->n_ex + 1, (int)orbf_frontend::NEX);
+    if (ahead > ahead_max) { morb::set_error("orbf_run_stream: ahead = %d, this handle takes at most %d (min(orbf_ahead_depth() + 1, 3))", ahead, ahead_max); return ORB_E_ARG; }
     memset(out, 0, sizeof(*out));
     const auto t_start = std::chrono::steady_clock::now();
     auto images_of = [&](int t) { return ring + (size_t)(t % ring_len) * f->n_cams; };
@@ -1123,6 +1127,7 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
             // some rank's block came from an extraction that fell back to the host path afterwards (every rank reads the same marks in
             // the same gathered blocks): all ranks ship the step's final blocks once more
             if ((rc = exchange_issue(f, P.seq, f->last_frame, st, true, nullptr))) return rc;
+            ++f->x_redos;
             MORB_HIP(hipEventSynchronize(X.done));
             if (X.gcnt.p[gc + 2] != 0) { morb::set_error("multi-GPU exchange: a block shipped again is still marked unfinished"); return ORB_E_HIP; }
         }

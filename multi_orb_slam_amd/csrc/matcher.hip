@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/orbm.h"
+#include "../../include/orb_debug.h"
 #include "orb_common.h"
 #include "frame_sink.h"
 #include "matcher_internal.h"

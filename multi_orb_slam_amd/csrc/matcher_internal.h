@@ -115,6 +115,9 @@ struct orbm_frame {
     mutable std::vector<float> angle;
     mutable bool host_valid = false;
     std::vector<int32_t> cam_start;  // n_cams + 1
+    // global indices are camera-major (camera c's features are [cam_start[c], cam_start[c + 1])): what every frame built by this
+    // library is; a host-built frame with interleaved cam_of[] is not, and the per-camera resolve (k_rs_mono_cam) must not take it
+    bool camera_major = true;
     FrameDev dev() const {
         FrameDev F;
         F.n_total = n_total; F.n_cams = n_cams; F.n_total_dev = counts_on_device ? b->d_ntotal.p : nullptr; F.un_x = b->d_x.p; F.un_y = b->d_y.p; F.uright = b->d_ur.p;

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/orbm.h"
+#include "../../include/orb_debug.h"
 #include "orb_common.h"
 #include "frame_sink.h"
 #include "matcher_internal.h"
@@ -1475,7 +1476,7 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
         // queries fit a workgroup (k_rs_mono_cam); the per-sweep form below keeps the rest.  MORB_RS_PER_CAMERA=0: per-sweep form only.
         static const bool cam_env = [] { const char* e = getenv("MORB_RS_PER_CAMERA"); return !(e && atoi(e) == 0); }();
         int nf_cap = 0, q_cam_max = J.q_cam_max;
-        const bool starts_ok = (int)cur->cam_start.size() == cur->n_cams + 1 && cur->cam_start[cur->n_cams] == n;
+        const bool starts_ok = cur->camera_major && (int)cur->cam_start.size() == cur->n_cams + 1 && cur->cam_start[cur->n_cams] == n;
         if (starts_ok) for (int c = 0; c < cur->n_cams; ++c) nf_cap = std::max(nf_cap, cur->cam_start[c + 1] - cur->cam_start[c]);
         if (cam_env && !J.points && !J.win2_dev && starts_ok && !q_cam_max && !J.msrc && J.q) {   // (host records: count them)
             std::vector<int>& per = m->rs_cam_count;

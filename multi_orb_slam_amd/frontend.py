@@ -188,6 +188,10 @@ class NativeFrontEnd:
     def debug_exchange_timing(self, on=True):
         check(_lib.lib().orbf_debug_exchange_timing(self._h, 1 if on else 0))
 
+    def debug_exchange_redos(self):
+        """steps whose blocks were shipped a second time (orbf_debug_exchange_redos)"""
+        return int(_lib.lib().orbf_debug_exchange_redos(self._h))
+
     def debug_exchange_us(self):
         """(search finished, exchange finished) of the last step, microseconds of device time from the start of its matching (the second
         one is negative when the exchange -- issued with the step's extraction chain -- was over before the matching began)"""

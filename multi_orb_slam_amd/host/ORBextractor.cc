@@ -29,16 +29,21 @@ unsigned long ORBextractor::FailureCount() { return g_failures.load(std::memory_
 // ---- resident.h
 namespace resident {
 namespace {
-struct Entry { const void* owner; std::thread::id thread; const uint8_t* host_rows; const uint8_t* d_rows; int n; };
+struct Entry { const void* owner; unsigned long thread; const uint8_t* host_rows; const uint8_t* d_rows; int n; };
 std::mutex g_mu;
 std::vector<Entry> g_entries;
-std::atomic<unsigned long> g_served{0}, g_missed{0};
+std::atomic<unsigned long> g_served{0}, g_missed{0}, g_tokens{0};
+// a thread's token: handed out once, never again (std::thread::id values are reused when a thread has exited -- the reference's
+// stereo constructor extracts on short-lived threads)
+unsigned long my_token() { static thread_local const unsigned long t = g_tokens.fetch_add(1, std::memory_order_relaxed) + 1; return t; }
+thread_local void* t_reader = nullptr;
 }  // namespace
 void publish(const void* owner, const uint8_t* host_rows, const uint8_t* d_rows, int n) {
+    const unsigned long me = my_token();
     std::lock_guard<std::mutex> lk(g_mu);
     for (Entry& e : g_entries)
-        if (e.owner == owner) { e = Entry{owner, std::this_thread::get_id(), host_rows, d_rows, n}; return; }
-    g_entries.push_back(Entry{owner, std::this_thread::get_id(), host_rows, d_rows, n});
+        if (e.owner == owner) { e = Entry{owner, me, host_rows, d_rows, n}; return; }
+    g_entries.push_back(Entry{owner, me, host_rows, d_rows, n});
 }
 void retire(const void* owner) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -47,16 +52,23 @@ void retire(const void* owner) {
 }
 const uint8_t* find(const uint8_t* rows, int n) {
     if (!rows || n <= 0) return nullptr;
-    const std::thread::id me = std::this_thread::get_id();
-    std::lock_guard<std::mutex> lk(g_mu);   // (entries of other threads are only skipped: whoever publishes or retires holds the same lock)
-    for (const Entry& e : g_entries)
-        if (e.n == n && e.thread == me && e.d_rows && std::memcmp(rows, e.host_rows, (size_t)n * 32) == 0) {
-            g_served.fetch_add(1, std::memory_order_relaxed);
-            return e.d_rows;
-        }
+    const unsigned long me = my_token();
+    // this thread's entries of the right size are copied out under the lock and compared outside it: only their owner -- an extractor
+    // used on THIS thread -- republishes or retires them, so the rows they point at cannot change under the comparison
+    Entry mine[8];
+    int k = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (const Entry& e : g_entries) if (e.n == n && e.thread == me && e.d_rows && k < 8) mine[k++] = e;
+    }
+    for (int i = 0; i < k; ++i)
+        if (std::memcmp(rows, mine[i].host_rows, (size_t)n * 32) == 0) { g_served.fetch_add(1, std::memory_order_relaxed); return mine[i].d_rows; }
     g_missed.fetch_add(1, std::memory_order_relaxed);
     return nullptr;
 }
+void note_reader(void* stream) { t_reader = stream; }
+void* take_reader() { void* s = t_reader; t_reader = nullptr; return s; }
+void reader_done() { t_reader = nullptr; }
 void stats(unsigned long* served, unsigned long* missed) { *served = g_served.load(); *missed = g_missed.load(); }
 }  // namespace resident
 
@@ -103,7 +115,8 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     orb_keypoint* kp_ptr = reinterpret_cast<orb_keypoint*>(scratch_kps_.data());
     uint8_t* d_ptr = scratch_desc_.data();
     int n = 0;
-    resident::retire(this);   // (the device rows of the previous call are about to be overwritten)
+    resident::retire(this);   // (the device rows of the previous call are about to be overwritten ...
+    if (void* rs = resident::take_reader()) (void)orbx_wait_for_stream(handle_, rs);   // ... behind whatever still reads them on the matcher's stream)
     int rc = orbx_extract(handle_, 1, &img_ptr, &w, &h, &stride, &kp_ptr, &d_ptr, &cap, &n);
     if (rc) { fail("orbx_extract", rc); _keypoints.clear(); _descriptors.release(); return; }
     // the rows stay where the describe kernel wrote them until this extractor's next call: a search of the frame built from them
@@ -179,6 +192,7 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
         kp[i].resize(cap[i]); ds[i].resize((size_t)cap[i] * 32);
         kp_ptr[i] = reinterpret_cast<orb_keypoint*>(kp[i].data()); d_ptr[i] = ds[i].data();
     }
+    if (void* rs = resident::take_reader()) (void)orbx_wait_for_stream(batch, rs);   // (behind whatever still reads the previous call's rows on the matcher's stream)
     const int rc = orbx_extract(batch, n, img.data(), w.data(), h.data(), st.data(), kp_ptr.data(), d_ptr.data(), cap.data(), cnt.data());
     if (rc) { fail("orbx_extract(batch)", rc); empty_outputs(); return; }
     for (int i = 0; i < n; ++i) {

@@ -325,6 +325,7 @@ orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_on
     orbm_frame* fr = nullptr;
     const int rc = orbm_frame_create_resident(m, &ff.d, any ? dres : nullptr, &fr);
     if (rc) { fail("orbm_frame_create_resident", rc); return nullptr; }
+    if (any) resident::note_reader(orbm_stream(m));   // (the build kernel reads the extractor's rows: its next run orders itself behind this stream)
     victim->kind = kind; victim->id = id; victim->guard = guard; victim->n = n; victim->cam1 = cam1_only; victim->fr = fr; victim->stamp = T.clock;
     return fr;
 }

@@ -2,8 +2,9 @@
 // upload.  The reference builds a Frame from the two extractor calls (src/Frame.cc:182-185) and searches it a moment later
 // (src/Tracking.cc:1267): the 32-byte descriptor rows the matcher needs on the device are the rows the extractor wrote
 // there, so they need not cross the bus again.  Nothing is taken on trust: an entry serves a descriptor matrix only if
-//   * the extraction ran on the CALLING thread (the next extraction of that extractor, which overwrites the device rows,
-//     is then sequenced behind the search that reads them), and
+//   * the extraction ran on the CALLING thread (threads are told apart by a token that is never reused, not by std::thread::id;
+//     the next extraction of that extractor, which overwrites the device rows, orders itself behind the kernel that reads them:
+//     note_reader / take_reader below), and
 //   * the matrix holds, byte for byte, the rows the extractor handed out (memcmp against the extractor's host copy) --
 //     pointer identity, frame ids or sequence numbers are not consulted.
 #pragma once
@@ -18,6 +19,13 @@ void publish(const void* owner, const uint8_t* host_rows, const uint8_t* d_rows,
 void retire(const void* owner);
 // device rows equal to the n x 32 bytes at `rows`, published by the calling thread; NULL if there are none
 const uint8_t* find(const uint8_t* rows, int n);
+// The calling thread has enqueued device work on `stream` (a hipStream_t) that reads rows find() served.  The owner's next
+// extraction -- on the same thread: find() serves nobody else -- takes the stream with take_reader() and orders itself behind that
+// work on the device (orbx_wait_for_stream) before it overwrites the rows; a search that ended with its usual synchronisation has
+// nothing pending and says so with reader_done().
+void note_reader(void* stream);
+void* take_reader();
+void reader_done();
 // inspection (tests / bench): lookups served from HBM / not served, on all threads
 void stats(unsigned long* served, unsigned long* missed);
 

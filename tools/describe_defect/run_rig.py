@@ -46,7 +46,7 @@ t_start = time.time()
 inner = max(args.persistent, 1)
 
 
-def check(results, run):
+def check_run(results, run):
     bad = False
     for r in range(world):
         for t in range(T):
@@ -95,7 +95,7 @@ while time.time() - t_start < args.seconds and runs < args.max_runs:
     [x.start() for x in th]; [x.join(300) for x in th]
     assert not errors, errors
     for k in range(inner):
-        bad_runs += check(results[k], runs); runs += 1
+        bad_runs += check_run(results[k], runs); runs += 1
 el = time.time() - t_start
 out = {"tag": args.tag, "lib": os.path.basename(_lib.LIB_PATH), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "world": world,
        "options": {"persistent": args.persistent, "no_probe": args.no_probe, "no_delay": args.no_delay, "no_exchange": args.no_exchange, "placement": args.placement,
