@@ -137,11 +137,32 @@ def _settled_launches(rt, run, stream, iters, group=10, tol=0.003, max_groups=40
     return e0.elapsed_ms(e1) / iters, used, [round(h * 1e3, 1) for h in hist]
 
 
+def device_state():
+    """Clocks, power and temperature as rocm-smi reports them right now (the distance matrix runs in one of two bands
+    per process, 366-368 / 397-401 us, that nothing in the kernel explains -- whatever the part reports at roofline time goes into
+    the line so that the bands can be held against it).  None where the tool is missing or says nothing."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"],
+                             capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+    except Exception:
+        return None
+    keep = {}
+    for k, v in card.items():
+        lk = k.lower()
+        if any(w in lk for w in ("sclk", "mclk", "fclk", "socclk", "power", "temperature (sensor junction)", "temperature (sensor memory)", "performance level")):
+            keep[k] = v
+    return keep or None
+
+
 def matcher_roofline(rt, m, stream, n, iters=200):
     """`roofline` of the bench line (M2): the uint16 distance matrix in its default (matrix-core) form, with the xor/popcount
     form of the same kernel -- the formulation north_star names -- timed beside it under `popcount_form`.
     200 launches (~80 ms) timed after the launch duration has settled (_settled_launches): the sustained figure."""
+    before = device_state()
     out = _matrix_launches(rt, m, stream, n, iters)
+    out["device_state"] = {"before": before, "after": device_state()}
     prev = m.Matcher.use_matrix_cores(0)
     try:
         alt = _matrix_launches(rt, m, stream, n, max(5, iters // 4))
@@ -468,7 +489,7 @@ def main(argv=None):
     t_gate = time.perf_counter()
     ofe = OracleFrontEnd(params, W, H, gcam, cam_threads=True)
     pool = ThreadPoolExecutor(max(1, min(len(other_g), 16))) if other_g else None
-    AHEAD = max(1, min(a.ahead, fe.fe.ahead_depth))   # (two with MORB_EXCHANGE_INLINE=0: DESIGN.md section 6)
+    AHEAD = max(1, min(a.ahead, fe.fe.ahead_depth))
     if overlap:
         for k in range(1, AHEAD):
             fe.announce(frame_args(k), resident=True)

@@ -7,7 +7,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
+#include <condition_variable>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbm.h"
@@ -79,6 +82,7 @@ struct orbf_frontend {
         CrossOut out;                    // rig-wide top-2 of this rank's features
         hipEvent_t done = nullptr, t_done = nullptr;   // behind the top-2 (t_done: with timing, orbf_debug_exchange_timing)
         long seq = -1;                   // the step this slot's exchange belongs to
+        long job = 0;                    // the issuer's job that records `done` (0: the calls were made by the stepping thread)
         std::vector<orbf_image> images; std::vector<uint64_t> fp;   // what the shipped block was extracted from
     } xs[NX];
     void* xcomm = nullptr; int xworld = 0, xrank = 0;   // xcomm == xc[0]: non-null while an exchange is set up
@@ -86,6 +90,20 @@ struct orbf_frontend {
     int x_placement = 0;                                // 0 no exchange, 1 behind the step's search, 3 at the tail of the step's extraction chain
     long step_seq = 0, x_next = 0;                      // steps begun so far; first step whose exchange has not been issued
     long x_redos = 0;                                   // steps whose blocks were shipped a second time (orbf_debug_exchange_redos)
+    // The ISSUER (placement 3): a host thread of the handle's own that makes the exchange's calls -- the collective (RCCL's enqueue alone
+    // is ~20 us of host time), the repack and top-2 launches, the event records.  The stepping thread only queues a job: with the calls
+    // on its own path a step's host time exceeded its device time (forced exchange on one GPU, round 5: 56 us per step inside the
+    // library against 40 without an exchange).  Rules: every exchange call of the handle goes through the issuer (one thread per
+    // communicator at a time, every communicator's sequence in step order); the stepping thread enqueues nothing on a stream for
+    // which a job is still queued (x_wait_stream) and waits for a step's job before it waits for the step's event (x_wait_job).
+    struct XJob { long id, seq; const uint8_t* send; int rows; hipStream_t st; bool redo; };
+    std::thread x_thread;
+    std::mutex x_mu;
+    std::condition_variable x_cv;
+    std::deque<XJob> x_jobs;
+    long x_pushed = 0, x_issued = 0;   // jobs queued / jobs whose calls have been made
+    int x_rc = 0; std::string x_err;   // first failure of the issuer (sticky: reported by whoever waits next)
+    bool x_quit = false, x_async = false;
     long set_xseq[NEX + 3] = {-1, -1, -1, -1, -1, -1};  // per result set: the step whose exchange reads that set's frame as its send buffer
     bool x_timing = false; hipEvent_t ev_x[2] = {nullptr, nullptr}; float x_us[2] = {0.f, 0.f};   // orbf_debug_exchange_timing
     bool xloop = false;                                  // ... over the in-process loopback transport (orbf_exchange_init_loopback)
@@ -280,6 +298,8 @@ static int orbf_drain(orbf_frontend* f);
 //   1  behind the step's search on the matcher's own stream (rounds 2-4; what a step whose extraction ran synchronously gets anyway).
 // MORB_EXCHANGE_PLACEMENT = chain | inline chooses.  (Rounds 2-4 also had the collective on the matcher's side stream -- a fork and
 // a join per step, one extraction chain fewer; never ahead of `inline` in any measurement, removed in round 5.)
+static void x_issuer_main(orbf_frontend* f);
+static void x_stop(orbf_frontend* f);
 static int exchange_queues(orbf_frontend* f) {
     int placement = 3;
     if (const char* e = getenv("MORB_EXCHANGE_PLACEMENT")) { if (!strcmp(e, "inline")) placement = 1; }
@@ -287,9 +307,13 @@ static int exchange_queues(orbf_frontend* f) {
     f->mt->side_inline = true;   // (no side stream next to an exchange: the handle keeps its extraction chains + the matcher = four queues)
     f->x_next = f->step_seq;
     for (auto& X : f->xs) {
-        X.seq = -1;
+        X.seq = -1; X.job = 0;
         if (!X.done) MORB_HIP(hipEventCreateWithFlags(&X.done, hipEventDisableTiming));
     }
+    // the issuer thread (MORB_EXCHANGE_THREAD=0: the stepping thread makes the calls itself, as placement 1 always does)
+    f->x_rc = 0; f->x_err.clear(); f->x_pushed = f->x_issued = 0;
+    f->x_async = placement == 3 && getenv_int("MORB_EXCHANGE_THREAD", 1) != 0;
+    if (f->x_async) f->x_thread = std::thread(x_issuer_main, f);
     return ORB_OK;
 }
 
@@ -346,6 +370,7 @@ int orbf_exchange_shutdown(orbf_frontend* f) {
     MORB_ARG(f != nullptr);
     if (!f->xcomm) return ORB_OK;
     MORB_HIP(hipSetDevice(f->device));
+    x_stop(f);   // (everything queued is issued first)
     for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));   // (exchanges run on the chains' streams)
     if (f->mt) { if (f->mt->side_stream) (void)hipStreamSynchronize(f->mt->side_stream); (void)hipStreamSynchronize(f->mt->stream); }
     for (int k = orbf_frontend::NXC; k >= 0; --k) {
@@ -361,24 +386,84 @@ int orbf_exchange_shutdown(orbf_frontend* f) {
 
 static std::vector<uint64_t> image_fingerprints(const orbf_image* images, int n);
 
-// The exchange of step `seq`: all-gather of the frame's export block + repack + rig-wide top-2 into the step's slot, on `st` behind
-// whatever produced the block there.  redo: the block is shipped a second time (see XSlot), over the last communicator.
+// The calls of one exchange: all-gather of a frame's export block + repack + rig-wide top-2 into the step's slot, on `st` behind whatever
+// produced the block there.  Made by the issuer thread (placement 3) or by the stepping thread itself (placement 1).
+static int exchange_calls(orbf_frontend* f, const orbf_frontend::XJob& J) {
+    orbf_frontend::XSlot& X = f->xs[J.seq % orbf_frontend::NX];
+    const size_t block = (size_t)J.rows * 32 + ORBM_BLOCK_TRAILER;
+    void* comm = f->xc[J.redo ? orbf_frontend::NXC : (int)(J.seq % orbf_frontend::NXC)];
+    int rc = f->xloop ? loop_allgather(static_cast<LoopComm*>(comm), J.send, X.recv.p, block, J.st)
+                      : exchange_allgather(comm, J.send, X.recv.p, block, J.st);
+    if (rc) return rc;
+    if ((rc = gathered_enqueue_to(J.st, X.recv.p, f->xworld, block, J.rows, f->n_cams, f->xrank, X.list.p, X.gstart.p, X.gcnt.dp, X.out))) return rc;
+    if (f->x_timing && X.t_done) (void)hipEventRecord(X.t_done, J.st);
+    MORB_HIP(hipEventRecord(X.done, J.st));
+    return ORB_OK;
+}
+
+static void x_issuer_main(orbf_frontend* f) {
+    (void)hipSetDevice(f->device);
+    std::unique_lock<std::mutex> lk(f->x_mu);
+    for (;;) {
+        f->x_cv.wait(lk, [&] { return f->x_quit || !f->x_jobs.empty(); });
+        if (f->x_jobs.empty()) return;   // (quit with nothing left to do)
+        const orbf_frontend::XJob J = f->x_jobs.front();
+        lk.unlock();
+        const int rc = f->x_rc ? f->x_rc : exchange_calls(f, J);   // (after a failure the remaining jobs are dropped: their waiters get the first error)
+        lk.lock();
+        if (rc && !f->x_rc) { f->x_rc = rc; f->x_err = orb_last_error(); }
+        f->x_jobs.pop_front();
+        f->x_issued = J.id;
+        f->x_cv.notify_all();
+    }
+}
+
+static int x_failed(orbf_frontend* f) {   // (x_mu held) the issuer's first failure, in the calling thread's error text
+    if (f->x_rc) morb::set_error("%s", f->x_err.c_str());
+    return f->x_rc;
+}
+// the job `id` has been issued (its event recorded); 0: nothing to wait for
+static int x_wait_job(orbf_frontend* f, long id) {
+    if (!f->x_async || id <= 0) return ORB_OK;
+    std::unique_lock<std::mutex> lk(f->x_mu);
+    f->x_cv.wait(lk, [&] { return f->x_issued >= id; });
+    return x_failed(f);
+}
+// no job for stream `st` is queued any more: the stepping thread may enqueue on it (st == nullptr: no job at all)
+static int x_wait_stream(orbf_frontend* f, hipStream_t st) {
+    if (!f->x_async) return ORB_OK;
+    std::unique_lock<std::mutex> lk(f->x_mu);
+    f->x_cv.wait(lk, [&] { for (const auto& J : f->x_jobs) if (!st || J.st == st) return false; return true; });
+    return x_failed(f);
+}
+static void x_stop(orbf_frontend* f) {
+    if (!f->x_thread.joinable()) return;
+    { std::lock_guard<std::mutex> lk(f->x_mu); f->x_quit = true; f->x_cv.notify_all(); }   // (the issuer finishes what is queued first)
+    f->x_thread.join();
+    f->x_quit = false; f->x_async = false;
+}
+
+// The exchange of step `seq`: the slot's buffers, the bookkeeping, and the calls -- queued for the issuer or made here.  redo: the block
+// is shipped a second time (see XSlot), over the last communicator.
 static int exchange_issue(orbf_frontend* f, long seq, const orbm_frame* F, hipStream_t st, bool redo, const orbf_image* images, int set = -1) {
     orbf_frontend::XSlot& X = f->xs[seq % orbf_frontend::NX];
     const size_t block = (size_t)F->desc_rows * 32 + ORBM_BLOCK_TRAILER;
     MORB_ARG(F->desc_rows == f->cap_total);
     const int n_cams = f->xworld * f->n_cams;
     int rc;
+    if ((rc = x_wait_job(f, X.job))) return rc;   // (the slot's previous exchange -- eight steps ago -- has long been issued; its buffers may grow now)
     if ((rc = X.recv.reserve((size_t)f->xworld * block)) || (rc = X.list.reserve((size_t)f->xworld * F->desc_rows * 32)) ||
         (rc = X.gstart.reserve(n_cams + 1 + 4)) || (rc = X.gcnt.reserve(n_cams + 3)) || (rc = X.out.reserve(F->desc_rows, f->xworld * F->desc_rows)))
         return rc;
-    void* comm = f->xc[redo ? orbf_frontend::NXC : (int)(seq % orbf_frontend::NXC)];
-    rc = f->xloop ? loop_allgather(static_cast<LoopComm*>(comm), F->b->d_desc.p, X.recv.p, block, st)
-                  : exchange_allgather(comm, F->b->d_desc.p, X.recv.p, block, st);
-    if (rc) return rc;
-    if ((rc = gathered_enqueue_to(st, X.recv.p, f->xworld, block, F->desc_rows, f->n_cams, f->xrank, X.list.p, X.gstart.p, X.gcnt.dp, X.out))) return rc;
-    if (f->x_timing && X.t_done) (void)hipEventRecord(X.t_done, st);
-    MORB_HIP(hipEventRecord(X.done, st));
+    orbf_frontend::XJob J{0, seq, F->b->d_desc.p, F->desc_rows, st, redo};
+    if (f->x_async) {
+        std::lock_guard<std::mutex> lk(f->x_mu);
+        if ((rc = x_failed(f))) return rc;
+        J.id = ++f->x_pushed;
+        f->x_jobs.push_back(J);
+        f->x_cv.notify_all();
+    } else if ((rc = exchange_calls(f, J))) return rc;
+    X.job = J.id;
     if (!redo) {
         X.seq = seq;
         if (images) { X.images.assign(images, images + f->n_cams); X.fp = image_fingerprints(images, f->n_cams); }
@@ -582,6 +667,7 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     *W_out = W; *H_out = H;
     orbf_frontend::ResultSet& R = f->rs[set];
     R.cross_valid = false;
+    if (f->xcomm && (rc = x_wait_stream(f, (hipStream_t)orbx_stream(ex)))) return rc;   // (the issuer is done with this chain's stream: steps ago, normally)
     if (f->xcomm && f->set_xseq[set] >= 0) {
         // an exchange reads this set's frame as its send buffer.  Its step has ended long ago (the end of a step waits for its
         // exchange) -- unless the extraction was dropped and never stepped: then the collective may still be waiting for a peer
@@ -600,6 +686,10 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     if ((rc = orbm_image_bounds(&f->calib, W, H, bd))) return rc;  // Frame::ComputeImageBounds
     if (f->pframe[set] && (f->pframe_W[set] != W || f->pframe_H[set] != H || f->pframe[set]->minX != bd[0] ||
                            f->pframe[set]->minY != bd[1] || f->pframe[set]->maxX != bd[2] || f->pframe[set]->maxY != bd[3])) {
+        if (f->xcomm) {   // (an exchange may still read this frame's block: issued? then over?)
+            if ((rc = x_wait_stream(f, nullptr))) return rc;
+            for (auto& X : f->xs) if (X.done && X.seq >= 0) MORB_HIP(hipEventSynchronize(X.done));
+        }
         orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr;  // (image size or calibration changed)
     }
     m->mirror_ur = R.ur.dp; m->mirror_depth = R.depth.dp; m->mirror_unx = R.unx.dp; m->mirror_uny = R.uny.dp;
@@ -690,6 +780,7 @@ static int ensure_extractor(orbf_frontend* f, int e) {
 // Everything in flight is waited for and dropped (results of prefetched extractions included).
 static int orbf_drain(orbf_frontend* f) {
     MORB_HIP(hipSetDevice(f->device));
+    if (f->xcomm) { const int xr = x_wait_stream(f, nullptr); if (xr) return xr; }
     if (f->xcomm && f->x_placement == 3) {
         // the chains' streams may end in collectives that wait for peers which have not announced that far (and may themselves be
         // waiting for THIS rank, e.g. for a block shipped again): wait for the extractions, not for the exchanges behind them
@@ -1121,6 +1212,7 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
         orbf_frontend::XSlot& X = f->xs[P.seq % orbf_frontend::NX];
         if (f->x_next == P.seq && (rc = exchange_issue(f, P.seq, f->last_frame, st, false, P.images.data()))) return rc;
         MORB_ARG(X.seq == P.seq);
+        if ((rc = x_wait_job(f, X.job))) return rc;
         MORB_HIP(hipEventSynchronize(X.done));
         const int gc = f->xworld * f->n_cams;
         if (X.gcnt.p[gc + 2] != 0) {
@@ -1128,6 +1220,7 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
             // the same gathered blocks): all ranks ship the step's final blocks once more
             if ((rc = exchange_issue(f, P.seq, f->last_frame, st, true, nullptr))) return rc;
             ++f->x_redos;
+            if ((rc = x_wait_job(f, X.job))) return rc;
             MORB_HIP(hipEventSynchronize(X.done));
             if (X.gcnt.p[gc + 2] != 0) { morb::set_error("multi-GPU exchange: a block shipped again is still marked unfinished"); return ORB_E_HIP; }
         }

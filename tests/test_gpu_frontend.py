@@ -572,9 +572,8 @@ def test_a_block_shipped_before_its_extraction_fell_back_is_shipped_again(placem
 def test_slow_peer_delays_the_end_of_the_step_never_the_local_search(placement, monkeypatch):
     """configs[3]'s rig over four ranks with one rank arriving 1 ms late at EVERY step, in both arrangements of the exchange: at the
     tail of the step's extraction chain (the default: issued two steps ahead of the step's matching) and behind the step's search
-    on the matcher's stream (rounds 2-4).  In either the local search never waits for the late peer.  Behind the search the end of
-    the step carries the peer's delay; with the chain the step's exchange was over before its matching even began (negative time).
-    Results stay bit-identical with the oracle on every rank and step."""
+    on the matcher's stream (rounds 2-4).  In either the local search never waits for the late peer; behind the search the end of
+    the step carries the peer's delay.  Results stay bit-identical with the oracle on every rank and step."""
     monkeypatch.setenv("MORB_EXCHANGE_PLACEMENT", placement)
     world, delay = 4, 1.0e-3
     _results, timings, placements = _loopback_rig(world, 4, 640, 480, 1000, ahead=2, T=10, group=1900 + (placement == "inline"),
@@ -586,8 +585,9 @@ def test_slow_peer_delays_the_end_of_the_step_never_the_local_search(placement, 
         assert 0 < search < 0.5 * delay * 1e6, (r, search, exch)          # the local search never waited for the late peer
         if placement == "inline":
             assert exch - search > 0.4 * delay * 1e6, (r, search, exch)   # ... the end of the step did
-        else:
-            assert exch < search, (r, search, exch)                       # ... and with the chain the exchange is not on the step's path at all
+        # (with the chain a step's exchange is issued two steps earlier: what that absorbs is a peer's JITTER of up to the look-ahead;
+        # a peer that is late at every step sets the pace in any arrangement -- its block for step t cannot exist before it has
+        # extracted step t -- so nothing is asserted about `exch` here; the figures are printed)
     print("slow peer (%s): punctual ranks' median search done %.0f us, exchange done %.0f us after the start of the step's matching"
           % (placement, np.median([timings[r][t][0] for r in (0, 2, 3) for t in range(3, 10)]),
              np.median([timings[r][t][1] for r in (0, 2, 3) for t in range(3, 10)])))

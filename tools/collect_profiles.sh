@@ -7,16 +7,18 @@
 # launches (MORB_CHAIN_GRAPH=0) and keep the host-written staging in mapped pinned memory (MORB_NO_BAR_STAGING=1).  The kernels
 # and their durations are the same; only the host's launch cost differs, and `value` is never taken from a profiled run.
 set -x
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r05}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$ROUND/final; mkdir -p $O
 cd $R
 if [ "$1" != "prof-only" ]; then
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed" > $O/pytest.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 for c in 2 3 4; do python bench.py --config $c --no-roofline > $O/bench_c$c.json 2> $O/bench_c$c.err; done
-# the per-rank step of a multi-GPU job, forced on this one GPU (world-1 RCCL group: one all-gather + rig-wide top-2 per step), both arrangements
+# the per-rank step of a multi-GPU job, forced on this one GPU (world-1 RCCL group: one all-gather + rig-wide top-2 per step): at the
+# tail of the step's extraction chain (the default, with and without the issuer thread) and behind the step's search (rounds 2-4)
 MORB_FORCE_DIST=1 python bench.py --no-dropin --no-roofline --no-cpu > $O/bench_forced_exchange.json 2> $O/bench_forced_exchange.err
-MORB_FORCE_DIST=1 MORB_EXCHANGE_INLINE=0 python bench.py --no-dropin --no-roofline --no-cpu > $O/bench_forced_exchange_side_stream.json 2> $O/bench_forced_exchange_side_stream.err
+MORB_FORCE_DIST=1 MORB_EXCHANGE_THREAD=0 python bench.py --no-dropin --no-roofline --no-cpu > $O/bench_forced_exchange_no_issuer.json 2> $O/bench_forced_exchange_no_issuer.err
+MORB_FORCE_DIST=1 MORB_EXCHANGE_PLACEMENT=inline python bench.py --no-dropin --no-roofline --no-cpu > $O/bench_forced_exchange_inline.json 2> $O/bench_forced_exchange_inline.err
 fi
 cd /tmp && export TMPDIR=/tmp
 export MORB_NO_BAR_STAGING=1

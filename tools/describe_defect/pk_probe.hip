@@ -9,7 +9,7 @@
 // producing (a, b), s_waitcnt vmcnt(3), the sixteen packed multiplies in the failing build's order) and compares every product with
 // what the operands give, under launch patterns from "back to back" to "one launch, then the part idles for milliseconds".
 //
-// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -ffp-contract=off -o pk_probe pk_probe.hip     run: ./pk_probe [seconds per cell]
+// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -ffp-contract=off -o pk_probe pk_probe.hip     run: ./pk_probe [seconds per cell] [1 = next to a matrix-pipe neighbour kernel, 2 = matrix-pipe waves in the same workgroup]
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
@@ -108,6 +108,117 @@ __global__ __launch_bounds__(256) void k_probe(const float4* __restrict__ tab, c
     }
 }
 
+// A neighbour for the probe: waves that keep the matrix pipe of their SIMD busy (what the rig's exchange adds next to k_describe: the
+// rig-wide top-2 runs v_mfma_scale_f32_32x32x64_f8f6f4 -- or v_mfma_i32_32x32x32_i8 with MORB_TOP2_FP4=0 -- on the matcher's stream).
+// KIND 0: the FP4 form (cbsz = blgp = 4), 1: int8, 2: no matrix instructions (vector ALU only, the control).
+typedef int mm_i32x8 __attribute__((ext_vector_type(8)));
+typedef int mm_i32x4 __attribute__((ext_vector_type(4)));
+typedef int mm_i32x16 __attribute__((ext_vector_type(16)));
+typedef float mm_f32x16 __attribute__((ext_vector_type(16)));
+template <int KIND>
+__global__ __launch_bounds__(256) void k_neighbour(unsigned* sink, int rounds) {
+    const int t = threadIdx.x + blockIdx.x * 256;
+    if (KIND == 0) {
+        mm_i32x8 a, b; mm_f32x16 c;
+        for (int i = 0; i < 8; ++i) { a[i] = 0x22222222 ^ (t * (i + 1)); b[i] = 0x2a2a2a2a ^ (t + i); }
+        for (int i = 0; i < 16; ++i) c[i] = (float)i;
+        for (int r = 0; r < rounds; ++r) { c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0, 0, 0); a[r & 7] ^= r; }
+        float acc = 0; for (int i = 0; i < 16; ++i) acc += c[i];
+        if (acc == 12345.678f) sink[2] = 1;
+    } else if (KIND == 1) {
+        mm_i32x4 a, b; mm_i32x16 c;
+        for (int i = 0; i < 4; ++i) { a[i] = 0x01ff01ff ^ (t * (i + 1)); b[i] = 0xff01ff01 ^ (t + i); }
+        for (int i = 0; i < 16; ++i) c[i] = i;
+        for (int r = 0; r < rounds; ++r) { c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); a[r & 3] ^= r; }
+        int acc = 0; for (int i = 0; i < 16; ++i) acc += c[i];
+        if (acc == 0x12345678) sink[2] = 1;
+    } else {
+        unsigned v = t * 2654435761u;
+        for (int r = 0; r < rounds * 8; ++r) v = v * 1664525u + 1013904223u + (v >> 7);
+        if (v == 0xdeadbeefu) sink[2] = v;
+    }
+}
+
+// Third part (argv[2] = 2): both kinds of wave in ONE workgroup of 512 threads -- waves 0..3 repeat the packed-multiply sequence, waves
+// 4..7 (wave w + 4 shares its SIMD with wave w) issue matrix instructions the whole time, in VGPR form and interleaved with vector work as
+// the library's top-2 does.  MKIND 0: v_mfma_f32_32x32x64_f8f6f4 cbsz:4 blgp:4 (FP4), 1: v_mfma_i32_32x32x32_i8, 2: vector ALU only.
+typedef float pf_f32x16 __attribute__((ext_vector_type(16)));
+typedef int pf_i32x16 __attribute__((ext_vector_type(16)));
+typedef int pf_i32x4 __attribute__((ext_vector_type(4)));
+template <int FORM, int MKIND>
+__global__ __launch_bounds__(512) void k_mixed(const float4* __restrict__ tab, const double* __restrict__ ang, float* __restrict__ out,
+                                               unsigned* __restrict__ errors, unsigned* __restrict__ rec, int iters, unsigned* __restrict__ sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= 4) {
+        const int t = threadIdx.x + blockIdx.x * 512;
+        pf_i32x4 a = {0x22222222 ^ t, 0x2a2a2a2a ^ (t * 3), 0x12121212 ^ (t * 5), 0x1a1a1a1a ^ (t * 7)}, b = {t, t * 9, t * 11, t * 13};
+        unsigned v = (unsigned)t * 2654435761u;
+        if (MKIND == 0) {
+            pf_f32x16 c0, c1;
+            for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 1.f; }
+            for (int r = 0; r < iters * 40; ++r) {
+                asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %2, %3, %0 cbsz:4 blgp:4\n\tv_perm_b32 %4, 0, %4, %5\n\t"
+                             "v_mfma_f32_32x32x64_f8f6f4 %1, %3, %2, %1 cbsz:4 blgp:4\n\tv_and_b32 %5, 0x3030303, %4"
+                             : "+v"(c0), "+v"(c1) : "v"(a), "v"(b), "v"(v), "v"(t));
+            }
+            float acc = 0; for (int i = 0; i < 16; ++i) acc += c0[i] + c1[i];
+            if (acc == 12345.678f) sink[2] = v;
+        } else if (MKIND == 1) {
+            pf_i32x16 c0, c1;
+            for (int i = 0; i < 16; ++i) { c0[i] = 0; c1[i] = 1; }
+            for (int r = 0; r < iters * 40; ++r) {
+                asm volatile("v_mfma_i32_32x32x32_i8 %0, %2, %3, %0\n\tv_perm_b32 %4, 0, %4, %5\n\t"
+                             "v_mfma_i32_32x32x32_i8 %1, %3, %2, %1\n\tv_and_b32 %5, 0x3030303, %4"
+                             : "+v"(c0), "+v"(c1) : "v"(a), "v"(b), "v"(v), "v"(t));
+            }
+            int acc = 0; for (int i = 0; i < 16; ++i) acc += c0[i] + c1[i];
+            if (acc == 0x12345678) sink[2] = v;
+        } else {
+            for (int r = 0; r < iters * 600; ++r) v = v * 1664525u + 1013904223u + (v >> 7);
+            if (v == 0xdeadbeefu) sink[2] = v;
+        }
+        return;
+    }
+    const int w = blockIdx.x * 4 + wave;
+    double da = ang[2 * (w & 1023)], db = ang[2 * (w & 1023) + 1];
+    da = da * 0.99999994 + 1.0e-9 * (double)(w & 7); db = db * 1.00000012 - 1.0e-9 * (double)(w & 3);
+    const float fa = (float)da, fb = (float)db;
+    const unsigned voff = (unsigned)lane * 64u;
+    const unsigned ooff = (unsigned)(blockIdx.x * 256 + (threadIdx.x & 255)) * 128u;
+    const float* mine = out + (size_t)(blockIdx.x * 256 + (threadIdx.x & 255)) * 32;
+    for (int it = 0; it < iters; ++it) {
+        if (FORM == 0)
+            asm volatile(LOADS "v_cvt_f32_f64 v116, %[da]\n\tv_cvt_f32_f64 v117, %[db]\n\t" MULS(PKO, PKP) STORES
+                         : : [voff] "v"(voff), [base] "s"(tab), [da] "v"(da), [db] "v"(db), [fa] "v"(fa), [fb] "v"(fb), [ooff] "v"(ooff), [obase] "s"(out) : CLOBBERS);
+        else
+            asm volatile(LOADS "v_cvt_f32_f64 v116, %[da]\n\tv_cvt_f32_f64 v117, %[db]\n\t" MULS(SCO, SCP) STORES
+                         : : [voff] "v"(voff), [base] "s"(tab), [da] "v"(da), [db] "v"(db), [fa] "v"(fa), [fb] "v"(fb), [ooff] "v"(ooff), [obase] "s"(out) : CLOBBERS);
+        if (lane == 0) atomicAdd(&errors[12], 1u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * lane + j;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float x = tab_value(i, 2 * h), y = tab_value(i, 2 * h + 1);
+                const float want[4] = {x * fb, y * fa, x * fa, y * fb};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float got = __hip_atomic_load(mine + 8 * j + 4 * h + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__float_as_uint(got) != __float_as_uint(want[k])) {
+                        atomicAdd(&errors[k], 1u); atomicAdd(&errors[4 + (lane >> 4)], 1u); atomicAdd(&errors[8 + j], 1u);
+                        const unsigned slot = atomicAdd(&errors[13], 1u);
+                        if (slot < 32) {
+                            unsigned* r = rec + slot * 8;
+                            r[0] = (unsigned)w; r[1] = (unsigned)(lane << 16 | j << 8 | h << 4 | k); r[2] = __float_as_uint(got); r[3] = __float_as_uint(want[k]);
+                            r[4] = __float_as_uint(x); r[5] = __float_as_uint(y); r[6] = __float_as_uint(fa); r[7] = __float_as_uint(fb);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
 template <int FORM>
@@ -133,6 +244,75 @@ int main(int argc, char** argv) {
     const struct { int idle_us; int grid_mul; const char* name; } pat[] = {
         {0, 1, "back to back"}, {0, 4, "back to back, 4 x the workgroups"}, {100, 1, "launch, sync, idle 100 us"}, {1000, 1, "launch, sync, idle 1 ms"},
         {5000, 1, "launch, sync, idle 5 ms"}, {20000, 1, "launch, sync, idle 20 ms"}};
+    // Second part (argv[2] = 1): the probe next to a neighbour kernel on a second stream -- launches of both kept in flight together
+    // (the neighbour's workgroups share compute units with the probe's), for each kind of neighbour.
+    if (argc > 2 && std::atoi(argv[2]) == 1) {
+        hipStream_t st2;
+        CK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        const char* nb_name[3] = {"FP4 MFMA neighbour (v_mfma_scale_f32_32x32x64_f8f6f4)", "int8 MFMA neighbour (v_mfma_i32_32x32x32_i8)", "vector-ALU neighbour (control)"};
+        for (int form : {0, 3}) {
+            for (int nb = 0; nb < 3; ++nb) {
+                CK(hipMemset(errors, 0, 64)); CK(hipMemset(rec, 0, 32 * 8 * 4));
+                const auto t0 = std::chrono::steady_clock::now();
+                long n = 0;
+                while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+                    for (int k = 0; k < 8; ++k) {
+                        if (nb == 0) hipLaunchKernelGGL(k_neighbour<0>, dim3(512), dim3(256), 0, st2, errors, 400);
+                        else if (nb == 1) hipLaunchKernelGGL(k_neighbour<1>, dim3(512), dim3(256), 0, st2, errors, 400);
+                        else hipLaunchKernelGGL(k_neighbour<2>, dim3(512), dim3(256), 0, st2, errors, 400);
+                        for (int q = 0; q < 4; ++q) { if (form == 0) launch<0>(GRID, st, tab, ang, out, errors, rec); else launch<3>(GRID, st, tab, ang, out, errors, rec); ++n; }
+                    }
+                    CK(hipStreamSynchronize(st)); CK(hipStreamSynchronize(st2));
+                }
+                unsigned h[16], r[32 * 8];
+                CK(hipMemcpy(h, errors, 64, hipMemcpyDeviceToHost)); CK(hipMemcpy(r, rec, sizeof(r), hipMemcpyDeviceToHost));
+                std::printf("form %d (%s) | %s | launches %ld waves %u | wrong products: op_sel lo %u hi %u, plain lo %u hi %u | by lane/16: %u %u %u %u | by load: %u %u %u %u\n",
+                            form, form_name[form], nb_name[nb], n, h[12], h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+                for (unsigned s2 = 0; s2 < h[13] && s2 < 6; ++s2) {
+                    const unsigned* q = r + s2 * 8;
+                    float got, want, x, y, a, b;
+                    std::memcpy(&got, q + 2, 4); std::memcpy(&want, q + 3, 4); std::memcpy(&x, q + 4, 4); std::memcpy(&y, q + 5, 4); std::memcpy(&a, q + 6, 4); std::memcpy(&b, q + 7, 4);
+                    std::printf("    wave %u lane %u load %u half %u product %u: got %.9g want %.9g (x %.0f y %.0f a %.9g b %.9g)\n", q[0], q[1] >> 16, (q[1] >> 8) & 0xff,
+                                (q[1] >> 4) & 0xf, q[1] & 0xf, got, want, x, y, a, b);
+                }
+                std::fflush(stdout);
+            }
+        }
+        return 0;
+    }
+    if (argc > 2 && std::atoi(argv[2]) == 2) {
+        const char* mk_name[3] = {"FP4 MFMA waves on the same SIMDs (v_mfma_f32_32x32x64_f8f6f4 cbsz:4 blgp:4, VGPR form)", "int8 MFMA waves on the same SIMDs (v_mfma_i32_32x32x32_i8)",
+                                  "vector-ALU waves on the same SIMDs (control)"};
+        for (int form : {0, 3}) {
+            for (int mk = 0; mk < 3; ++mk) {
+                CK(hipMemset(errors, 0, 64)); CK(hipMemset(rec, 0, 32 * 8 * 4));
+                const auto t0 = std::chrono::steady_clock::now();
+                long n = 0;
+                while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+                    for (int k = 0; k < 16; ++k) {
+#define LM(F, M) hipLaunchKernelGGL((k_mixed<F, M>), dim3(GRID), dim3(512), 0, st, tab, ang, out, errors, rec, 24, errors)
+                        if (form == 0) { if (mk == 0) LM(0, 0); else if (mk == 1) LM(0, 1); else LM(0, 2); }
+                        else { if (mk == 0) LM(3, 0); else if (mk == 1) LM(3, 1); else LM(3, 2); }
+                        ++n;
+                    }
+                    CK(hipStreamSynchronize(st));
+                }
+                unsigned h[16], r[32 * 8];
+                CK(hipMemcpy(h, errors, 64, hipMemcpyDeviceToHost)); CK(hipMemcpy(r, rec, sizeof(r), hipMemcpyDeviceToHost));
+                std::printf("form %d (%s) | %s | launches %ld sequences %u | wrong products: op_sel lo %u hi %u, plain lo %u hi %u | by lane/16: %u %u %u %u | by load: %u %u %u %u\n",
+                            form, form_name[form], mk_name[mk], n, h[12], h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+                for (unsigned s2 = 0; s2 < h[13] && s2 < 6; ++s2) {
+                    const unsigned* q = r + s2 * 8;
+                    float got, want, x, y, a, b;
+                    std::memcpy(&got, q + 2, 4); std::memcpy(&want, q + 3, 4); std::memcpy(&x, q + 4, 4); std::memcpy(&y, q + 5, 4); std::memcpy(&a, q + 6, 4); std::memcpy(&b, q + 7, 4);
+                    std::printf("    wave %u lane %u load %u half %u product %u: got %.9g want %.9g (x %.0f y %.0f a %.9g b %.9g)\n", q[0], q[1] >> 16, (q[1] >> 8) & 0xff,
+                                (q[1] >> 4) & 0xf, q[1] & 0xf, got, want, x, y, a, b);
+                }
+                std::fflush(stdout);
+            }
+        }
+        return 0;
+    }
     for (int form = 0; form < 4; ++form) {
         for (const auto& P : pat) {
             CK(hipMemset(errors, 0, 64)); CK(hipMemset(rec, 0, 32 * 8 * 4));

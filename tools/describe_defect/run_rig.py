@@ -20,6 +20,7 @@ ap.add_argument("--persistent", type=int, default=0, help="N > 0: every rank kee
 ap.add_argument("--no-probe", action="store_true", help="no exchange timing probe")
 ap.add_argument("--no-delay", action="store_true", help="no late rank")
 ap.add_argument("--no-exchange", action="store_true", help="the ranks' front ends run side by side without any exchange")
+ap.add_argument("--all-delay", action="store_true", help="every rank sleeps 1 ms before every step (not only rank 1)")
 args = ap.parse_args()
 os.environ["MORB_EXCHANGE_PLACEMENT"] = args.placement
 import numpy as np
@@ -79,7 +80,7 @@ while time.time() - t_start < args.seconds and runs < args.max_runs:
                 if k: fe.reset()
                 announced = 0
                 for t in range(T):
-                    if r == 1 and not args.no_delay: time.sleep(1.0e-3)
+                    if (r == 1 or args.all_delay) and not args.no_delay: time.sleep(1.0e-3)
                     while announced < min(t + ahead, T - 1):
                         announced += 1
                         fe.announce([frames[announced][g] for g in mine])
@@ -98,8 +99,9 @@ while time.time() - t_start < args.seconds and runs < args.max_runs:
         bad_runs += check_run(results[k], runs); runs += 1
 el = time.time() - t_start
 out = {"tag": args.tag, "lib": os.path.basename(_lib.LIB_PATH), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "world": world,
-       "options": {"persistent": args.persistent, "no_probe": args.no_probe, "no_delay": args.no_delay, "no_exchange": args.no_exchange, "placement": args.placement,
-                   "MORB_CHAIN_GRAPH": os.environ.get("MORB_CHAIN_GRAPH")},
+       "options": {"persistent": args.persistent, "no_probe": args.no_probe, "no_delay": args.no_delay, "no_exchange": args.no_exchange, "all_delay": args.all_delay, "placement": args.placement,
+                   "MORB_CHAIN_GRAPH": os.environ.get("MORB_CHAIN_GRAPH"), "MORB_TOP2_MFMA": os.environ.get("MORB_TOP2_MFMA"),
+                   "MORB_TOP2_FP4": os.environ.get("MORB_TOP2_FP4")},
        "bad_steps_histogram": np.bincount(np.array(steps_bad, int), minlength=T).tolist(),
        "runs": runs, "bad_runs": bad_runs, "seconds": round(el, 1), "s_per_run": round(el / max(runs, 1), 3),
        "wrong_rows": len(bits_seen), "lanes": sorted({b // 4 for bs in bits_seen for b in bs}), "js": [sorted({b % 4 for b in bs}) for bs in bits_seen][:40],
