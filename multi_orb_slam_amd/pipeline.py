@@ -147,8 +147,9 @@ class FrontEnd:
         """next_images: shorthand for announce(next_images) before the step."""
         native = getattr(self, "native_exchange", False)
         distributed = self.world > 1 and self.gather is not None and not native
-        if not distributed and not native:
-            # one native call per timestep: announce + step + the count of accepted cross-camera matches (orbf_step_motion_ahead)
+        if not distributed:
+            # one native call per timestep: announce + step + the count of accepted cross-camera matches (orbf_step_motion_ahead) --
+            # also with the native multi-GPU exchange (the step then returns the rig-wide top-2 of this rank's features)
             AT = self.fe._arr_type
             od = 0 if resident == "pinned" else 1
             # (prepared by prepare(): nothing to marshal; the two arguments are converted independently -- a prepared `images`
@@ -164,6 +165,9 @@ class FrontEnd:
                 bi, bd, sd = r["cross"]
                 bd = np.ascontiguousarray(bd, np.int32); sd = np.ascontiguousarray(sd, np.int32)
                 r["n_cross"] = _lib.lib().orbm_count_ratio_accepted(_lib.ptr(bd), _lib.ptr(sd), len(bd), TH_LOW, BOW_RATIO)
+            if native and self.copy_results:   # (not in the timed loop: the gathered trailers name this rank's counts)
+                nc = self.n_cams
+                assert r["rig_counts"][self.rank * nc:(self.rank + 1) * nc] == r["counts"]
             return r
         if next_images is not None:
             self.announce(next_images, resident)
@@ -171,10 +175,8 @@ class FrontEnd:
             images = [(im[0], self.width, self.height, im[1], 0 if resident == "pinned" else 1, im[2] if len(im) > 2 else 0) for im in images]
         # queries = the previous step's features under the stream's known motion, built natively (orbf_step_motion;
         # same arithmetic as make_queries, which the oracle leg uses)
-        if not distributed:
-            r = self.fe.step(images, None, 0, copy=self.copy_results, motion=(MOTION[0], MOTION[1], TH_PROJ))
-        else:
-            # one all-gather per timestep.  When the step's descriptor block is final already at begin (its extraction ran
+        if True:
+            # the exchange through torch.distributed (MORB_NATIVE_EXCHANGE=0): one all-gather per timestep.  When the step's descriptor block is final already at begin (its extraction ran
             # ahead), the collective and the cross-camera matching are enqueued next to the step's own matching; otherwise
             # they follow the step.  Every rank issues exactly one collective per step either way.
             # (when the block is final before the step is even begun, the collective is started first of all)
@@ -190,17 +192,9 @@ class FrontEnd:
             bi, bd, sd, cnts = self.gather.collect(self, views=not self.copy_results) if early else self.gather(self)
             assert cnts[self.rank * self.n_cams:(self.rank + 1) * self.n_cams] == r["counts"]
             r["cross"] = (bi, bd, sd)
-        if native:
-            nc = self.n_cams
-            assert r["rig_counts"][self.rank * nc:(self.rank + 1) * nc] == r["counts"]
-        # native count of accept_cross; in the timed loop straight from the pinned result buffers
-        ptrs = r.get("cross_dist_ptrs") if not distributed else None
-        if ptrs:
-            r["n_cross"] = _lib.lib().orbm_count_ratio_accepted(ptrs[0], ptrs[1], r["n_total"], TH_LOW, BOW_RATIO)
-        else:
-            bi, bd, sd = r["cross"]
-            bd = np.ascontiguousarray(bd, np.int32); sd = np.ascontiguousarray(sd, np.int32)
-            r["n_cross"] = _lib.lib().orbm_count_ratio_accepted(_lib.ptr(bd), _lib.ptr(sd), len(bd), TH_LOW, BOW_RATIO)
+        bi, bd, sd = r["cross"]
+        bd = np.ascontiguousarray(bd, np.int32); sd = np.ascontiguousarray(sd, np.int32)
+        r["n_cross"] = _lib.lib().orbm_count_ratio_accepted(_lib.ptr(bd), _lib.ptr(sd), len(bd), TH_LOW, BOW_RATIO)
         return r
 
 
