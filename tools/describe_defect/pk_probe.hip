@@ -9,7 +9,7 @@
 // producing (a, b), s_waitcnt vmcnt(3), the sixteen packed multiplies in the failing build's order) and compares every product with
 // what the operands give, under launch patterns from "back to back" to "one launch, then the part idles for milliseconds".
 //
-// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -ffp-contract=off -o pk_probe pk_probe.hip     run: ./pk_probe [seconds per cell] [1 = next to a matrix-pipe neighbour kernel, 2 = matrix-pipe waves in the same workgroup]
+// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -ffp-contract=off -o pk_probe pk_probe.hip     run: ./pk_probe [seconds per cell] [1 = next to a matrix-pipe neighbour kernel, 2 = matrix-pipe waves in the same workgroup, 3 = which packed forms are affected]
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
@@ -32,6 +32,13 @@ __global__ __launch_bounds__(256) void k_fill(float4* tab, int n) {
 // the same products from scalar-float multiplies (control)
 #define SCO(d0, d1, s0, s1) "v_mul_f32 v" #d0 ", v" #s0 ", v117\n\tv_mul_f32 v" #d1 ", v" #s1 ", v116\n\t"
 #define SCP(d0, d1, s0, s1) "v_mul_f32 v" #d0 ", v" #s0 ", v116\n\tv_mul_f32 v" #d1 ", v" #s1 ", v117\n\t"
+// further forms for the scope of the fault (k_mixed, FORM 4..6): packed add, packed fma (addend -0.0 in v[154:155]: x * b + -0 == x * b
+// bit for bit), and the multiply with the redirect on the FIRST source (D.lo = S.hi * a, D.hi = S.lo * b)
+#define AKO(d0, d1, s0, s1) "v_pk_add_f32 v[" #d0 ":" #d1 "], v[" #s0 ":" #s1 "], v[116:117] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+#define AKP(d0, d1, s0, s1) "v_pk_add_f32 v[" #d0 ":" #d1 "], v[" #s0 ":" #s1 "], v[116:117]\n\t"
+#define FKO(d0, d1, s0, s1) "v_pk_fma_f32 v[" #d0 ":" #d1 "], v[" #s0 ":" #s1 "], v[116:117], v[154:155] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\t"
+#define FKP(d0, d1, s0, s1) "v_pk_fma_f32 v[" #d0 ":" #d1 "], v[" #s0 ":" #s1 "], v[116:117], v[154:155]\n\t"
+#define MKO(d0, d1, s0, s1) "v_pk_mul_f32 v[" #d0 ":" #d1 "], v[" #s0 ":" #s1 "], v[116:117] op_sel:[1,0] op_sel_hi:[0,1]\n\t"
 #define LOADS \
     "global_load_dwordx4 v[100:103], %[voff], %[base] offset:0\n\t"  \
     "global_load_dwordx4 v[104:107], %[voff], %[base] offset:16\n\t" \
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(256) void k_fill(float4* tab, int n) {
     "s_waitcnt vmcnt(0)\n\t"
 #define CLOBBERS "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", \
     "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", \
-    "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152"
+    "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v154", "v155"
 
 // errors[0..3]: wrong products by form -- op_sel low (x * b), op_sel high (y * a), plain low (x * a), plain high (y * b)
 // errors[4..7]: by lane / 16;  errors[8..11]: by table load j;  errors[12]: waves checked;  errors[13]: records;  rec[]: the first records
@@ -187,12 +194,14 @@ __global__ __launch_bounds__(512) void k_mixed(const float4* __restrict__ tab, c
     const unsigned ooff = (unsigned)(blockIdx.x * 256 + (threadIdx.x & 255)) * 128u;
     const float* mine = out + (size_t)(blockIdx.x * 256 + (threadIdx.x & 255)) * 32;
     for (int it = 0; it < iters; ++it) {
-        if (FORM == 0)
-            asm volatile(LOADS "v_cvt_f32_f64 v116, %[da]\n\tv_cvt_f32_f64 v117, %[db]\n\t" MULS(PKO, PKP) STORES
-                         : : [voff] "v"(voff), [base] "s"(tab), [da] "v"(da), [db] "v"(db), [fa] "v"(fa), [fb] "v"(fb), [ooff] "v"(ooff), [obase] "s"(out) : CLOBBERS);
-        else
-            asm volatile(LOADS "v_cvt_f32_f64 v116, %[da]\n\tv_cvt_f32_f64 v117, %[db]\n\t" MULS(SCO, SCP) STORES
-                         : : [voff] "v"(voff), [base] "s"(tab), [da] "v"(da), [db] "v"(db), [fa] "v"(fa), [fb] "v"(fb), [ooff] "v"(ooff), [obase] "s"(out) : CLOBBERS);
+#define SEQ(O, P) asm volatile(LOADS "v_cvt_f32_f64 v116, %[da]\n\tv_cvt_f32_f64 v117, %[db]\n\tv_mov_b32 v154, 0x80000000\n\tv_mov_b32 v155, 0x80000000\n\t" MULS(O, P) STORES \
+                         : : [voff] "v"(voff), [base] "s"(tab), [da] "v"(da), [db] "v"(db), [fa] "v"(fa), [fb] "v"(fb), [ooff] "v"(ooff), [obase] "s"(out) : CLOBBERS)
+        if (FORM == 0) SEQ(PKO, PKP);
+        else if (FORM == 4) SEQ(AKO, AKP);
+        else if (FORM == 5) SEQ(FKO, FKP);
+        else if (FORM == 6) SEQ(MKO, PKP);
+        else SEQ(SCO, SCP);
+#undef SEQ
         if (lane == 0) atomicAdd(&errors[12], 1u);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -200,7 +209,8 @@ __global__ __launch_bounds__(512) void k_mixed(const float4* __restrict__ tab, c
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float x = tab_value(i, 2 * h), y = tab_value(i, 2 * h + 1);
-                const float want[4] = {x * fb, y * fa, x * fa, y * fb};
+                const float want[4] = {FORM == 4 ? x + fb : FORM == 6 ? y * fa : x * fb, FORM == 4 ? y + fa : FORM == 6 ? x * fb : y * fa,
+                                       FORM == 4 ? x + fa : x * fa, FORM == 4 ? y + fb : y * fb};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float got = __hip_atomic_load(mine + 8 * j + 4 * h + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -277,6 +287,31 @@ int main(int argc, char** argv) {
                 }
                 std::fflush(stdout);
             }
+        }
+        return 0;
+    }
+    if (argc > 2 && std::atoi(argv[2]) == 3) {
+        // the scope of the fault: which packed-f32 forms go wrong next to int8 MFMA waves on the same SIMDs
+        const struct { int form; const char* name; } forms[] = {{0, "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (redirect on the second source)"},
+            {6, "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1] (redirect on the first source)"}, {4, "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]"},
+            {5, "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1]"}, {3, "v_mul_f32 pairs (control)"}};
+        for (const auto& F : forms) {
+            CK(hipMemset(errors, 0, 64)); CK(hipMemset(rec, 0, 32 * 8 * 4));
+            const auto t0 = std::chrono::steady_clock::now();
+            long n = 0;
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+                for (int k = 0; k < 16; ++k) {
+#define LS(Fm) hipLaunchKernelGGL((k_mixed<Fm, 1>), dim3(GRID), dim3(512), 0, st, tab, ang, out, errors, rec, 24, errors)
+                    switch (F.form) { case 0: LS(0); break; case 6: LS(6); break; case 4: LS(4); break; case 5: LS(5); break; default: LS(3); break; }
+                    ++n;
+                }
+                CK(hipStreamSynchronize(st));
+            }
+            unsigned h[16];
+            CK(hipMemcpy(h, errors, 64, hipMemcpyDeviceToHost));
+            std::printf("%s | int8 MFMA waves on the same SIMDs | sequences %u | wrong results: redirected-form low %u high %u, plain-form low %u high %u | by lane/16: %u %u %u %u\n",
+                        F.name, h[12], h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+            std::fflush(stdout);
         }
         return 0;
     }
