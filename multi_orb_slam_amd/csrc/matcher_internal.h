@@ -98,8 +98,6 @@ struct orbm_matcher {
     bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
     int resolve_seq = 0;           // sequence number of the last tagged resolve launch
     bool foreign_work = false;     // something other than a step's own search was put on the stream (orbf_step_end then waits for all of it)
-    DevBuf<int32_t> d_fuse;        // k_search_mono: the projection waves' running count (never reset: every launch waits for its own target)
-    bool fuse_ready = false; unsigned fuse_target = 0;
 };
 namespace morb { hipStream_t side_stream(orbm_matcher* m); }   // (lazily created; NULL after a reported failure)
 

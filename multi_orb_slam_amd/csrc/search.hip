@@ -476,18 +476,13 @@ __global__ __launch_bounds__(1024) void k_resolve(FrameDev F, const int2* __rest
 // concern); only a displaced query walks on.  Rounds are counted as before (a claim still travels one link of a dependency
 // chain per round) but cost a tenth of a sweep.  Owners, rotation histogram and result words as in k_resolve.  POINTS (top-2 with
 // ratio test), two-window queries and states beyond LDS keep k_resolve.
-// FUSED (k_search_mono, round 5): the same workgroup as the LAST one of a launch whose other workgroups are the projection's waves.  What
-// does not depend on the projection -- clearing the tables, fetching the frame's angles -- runs while they work; then thread 0 waits
-// for `done` to reach `target` (every projection wave adds one behind a device-scope release), everybody takes a device-scope acquire
-// and the set-up reads the shortlists.  A wait that does not end (it cannot, short of a lost launch) gives up after ~0.2 s with status 1:
-// the host's exact fallback takes over.
-template <int RQ, bool ANG, bool FUSED>
-__device__ __forceinline__ void resolve_mono_body(const FrameDev& F, const int2* __restrict__ qmeta, int nq, int cap,
-                                                  const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
-                                                  const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
-                                                  const float* __restrict__ f_angle, int th_high, int check_ori, int max_it,
-                                                  const int* __restrict__ topk, int* __restrict__ match_of_feature,
-                                                  int* __restrict__ status, int tagb, unsigned* __restrict__ done, unsigned target) {
+template <int RQ, bool ANG>
+__global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* __restrict__ qmeta, int nq, int cap,
+                                                       const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
+                                                       const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
+                                                       const float* __restrict__ f_angle, int th_high, int check_ori, int max_it,
+                                                       const int* __restrict__ topk, int* __restrict__ match_of_feature,
+                                                       int* __restrict__ status, int tagb) {
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // [0, n): lowest blocking claimant of a feature; [n, 2n): owner (last claimant)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_keep[3];
@@ -518,20 +513,6 @@ __device__ __forceinline__ void resolve_mono_body(const FrameDev& F, const int2*
     for (int g = tid; g < F.n_total; g += T) {
         s_claim[g] = 0x7fffffff; s_owner[g] = -1;
         if (ANG && check_ori) l_fang[g] = f_angle[g];
-    }
-    if (FUSED) {
-        __shared__ int s_lost;
-        if (tid == 0) {
-            int spins = 0;
-            while ((int)(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(8); ++spins; }
-            s_lost = spins >= (1 << 22);
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (every wave: what the projection's waves released is visible from here on)
-        if (s_lost) {
-            if (tid == 0) { status[1] = tagb | 0; status[2] = tagb | 0; status[3] = tagb | 0; status[0] = tagb | 1; }
-            return;
-        }
     }
     __syncthreads();   // (the claims of round 0 go into the table right below)
     // per query of this thread (two in registers; more only beyond 2048 queries, re-read from LDS every round): the shortlist
@@ -794,41 +775,6 @@ __device__ __forceinline__ void resolve_mono_body(const FrameDev& F, const int2*
 #ifdef MORB_PHASE_CLOCKS
     if (tid == 0) { g_ph_res[62] = (unsigned long long)it; g_ph_res[59] = clock64(); }
 #endif
-}
-
-template <int RQ, bool ANG>
-__global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* __restrict__ qmeta, int nq, int cap,
-                                                       const int* __restrict__ cand_idx, const uint16_t* __restrict__ cand_dist,
-                                                       const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
-                                                       const float* __restrict__ f_angle, int th_high, int check_ori, int max_it,
-                                                       const int* __restrict__ topk, int* __restrict__ match_of_feature,
-                                                       int* __restrict__ status, int tagb) {
-    resolve_mono_body<RQ, ANG, false>(F, qmeta, nq, cap, cand_idx, cand_dist, cand_count, occupied, f_angle, th_high, check_ori, max_it, topk,
-                                      match_of_feature, status, tagb, nullptr, 0u);
-}
-
-// k_search_mono (round 5): the frame search of a small rig as ONE launch.  Workgroups 0 .. ceil(nq / 16) - 1 are the projection (sixteen
-// waves = sixteen queries each: project_wave, as k_project's), the last one is the resolve (resolve_mono_body<.., FUSED>): the kernel
-// boundary between the two, the resolve's table set-up and its first trip to HBM no longer stand between the projection's last wave and
-// the first round.  Workgroups are dispatched in index order, so when the resolve's workgroup starts to wait every projection workgroup
-// has been handed to a compute unit already or will be as soon as one is free -- the waiting workgroup holds one slot of one unit.
-struct ResolveMonoArgs {
-    const int* cand_idx; const uint16_t* cand_dist; const int* cand_count; const uint8_t* occupied; const float* f_angle;
-    int th_high, check_ori, max_it; const int* topk; int* match_of_feature; int* status; int tagb; unsigned* done; unsigned target;
-};
-template <int RQ, bool ANG>
-__global__ __launch_bounds__(1024) void k_search_mono(ProjectArgs A, ResolveMonoArgs R) {
-    const int nproj = (A.nq + 15) >> 4;
-    if ((int)blockIdx.x < nproj) {
-        const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 16 + (threadIdx.x >> 6));
-        if (qi >= A.nq) return;
-        project_wave(A, qi, threadIdx.x & 63);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (this wave's lists and shortlist are visible device-wide before its count is)
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(R.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    resolve_mono_body<RQ, ANG, true>(A.F, A.qmeta, A.nq, A.cap, R.cand_idx, R.cand_dist, R.cand_count, R.occupied, R.f_angle, R.th_high, R.check_ori,
-                                     R.max_it, R.topk, R.match_of_feature, R.status, R.tagb, R.done, R.target);
 }
 
 // ---- the same resolve for frames whose claim tables do not fit LDS (beyond ~18 000 features: 8 cameras x 4000), spread
@@ -1263,9 +1209,7 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
 int morb::search_raise_lds_limits() {
     const void* fns[] = {(const void*)k_resolve<true, false>, (const void*)k_resolve<false, false>, (const void*)k_resolve<true, true>,
                          (const void*)k_resolve<false, true>, (const void*)k_resolve_mono<2, true>, (const void*)k_resolve_mono<2, false>,
-                         (const void*)k_resolve_mono<4, true>, (const void*)k_resolve_mono<4, false>, (const void*)k_rs_mono_cam,
-                         (const void*)k_search_mono<2, true>, (const void*)k_search_mono<2, false>, (const void*)k_search_mono<4, true>,
-                         (const void*)k_search_mono<4, false>};
+                         (const void*)k_resolve_mono<4, true>, (const void*)k_resolve_mono<4, false>, (const void*)k_rs_mono_cam};
     for (const void* fn : fns) MORB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return ORB_OK;
 }
@@ -1286,7 +1230,7 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
                        const uint8_t* d_occupied = nullptr, int* d_topk = nullptr, int short_th = 256,
                        const float* d_inv_sigma2 = nullptr, const orbm_query* q_device_visible = nullptr, int2* d_qmeta = nullptr,
                        const orbm_window* d_win2 = nullptr, const SideJob* side = nullptr, const MotionSrc* msrc = nullptr,
-                       bool msrc_records = false, ProjectArgs* defer = nullptr) {
+                       bool msrc_records = false) {
     int rc;
     if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_i0.reserve((size_t)nq * cap)) ||
         (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)))
@@ -1302,7 +1246,6 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
         A.from_motion = 1; A.ms = *msrc; A.q = nullptr;
         A.ms.rec_out = msrc_records ? (orbm_query*)m->d_queries.p : nullptr;
     }
-    if (defer) { *defer = A; return ORB_OK; }   // (the caller launches the projection itself: k_search_mono)
     if (side) {   // the caller's side work (camera-pair top-2, result mirror) shares the launch: see k_project_side
         if ((rc = launch_project_side(m->stream, A, *side))) return rc;
     } else {
@@ -1517,40 +1460,10 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
         if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, J.q_dev, (size_t)nq * sizeof(orbm_query), hipMemcpyDefault, m->stream));
     }
-    // The frame search of a small rig goes out as ONE launch (k_search_mono: projection + monotone resolve) when nothing else shares the
-    // projection's launch; MORB_FUSE_SEARCH=0: two launches as in rounds 3-4.
-    static const bool fuse_env = [] { const char* e = getenv("MORB_FUSE_SEARCH"); return !(e && atoi(e) == 0); }();
-    static const bool mono_env0 = [] { const char* e = getenv("MORB_RESOLVE_MONO"); return !(e && atoi(e) == 0); }();
-    auto mono_lds0 = [&](bool ang) {
-        const size_t nq2 = ((size_t)nq + 1) & ~(size_t)1;
-        return (size_t)n * 8 + nq2 * 4 + (size_t)RESOLVE_K * nq2 * 2 + (((size_t)nq + 3) & ~(size_t)3) + (ang ? ((size_t)nq + (size_t)n) * 4 : 0) + 16;
-    };
-    const bool fuse = fuse_env && mono_env0 && !multi && !J.side && !J.points && !J.win2_dev && n < 65535 && mono_lds0(false) <= 150 * 1024 &&
-                      !(J.occupied && !J.occ_dev) && (queries_already_on_device || J.q_dev || J.msrc);
-    ProjectArgs PA;
     if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device && !J.q_dev && !J.msrc, false, /*transposed=*/1, d_occ,
-                          m->d_claim.p, J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p, J.win2_dev, J.side, J.msrc, multi, fuse ? &PA : nullptr)))
+                          m->d_claim.p, J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p, J.win2_dev, J.side, J.msrc, multi)))
         return rc;
     J.side = nullptr;   // (a retry of the search with more room per query does not repeat the side work)
-    if (fuse) {
-        if ((rc = m->d_fuse.reserve(4))) return rc;
-        if (!m->fuse_ready) { MORB_HIP(hipMemsetAsync(m->d_fuse.p, 0, 16, m->stream)); m->fuse_ready = true; m->fuse_target = 0; }
-        m->fuse_target += (unsigned)nq;
-        J.seq = 0;
-        if (J.want_tags) { m->resolve_seq = m->resolve_seq % 2047 + 1; J.seq = m->resolve_seq; }
-        const bool ang = mono_lds0(true) <= 150 * 1024;
-        ResolveMonoArgs RA{(const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ, (const float*)cur->b->d_ang.p, th_high,
-                           J.check_ori, 4096, (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20,
-                           reinterpret_cast<unsigned*>(m->d_fuse.p), m->fuse_target};
-        const dim3 grid((nq + 15) / 16 + 1), block(1024);
-        const size_t ml = mono_lds0(ang);
-        if (nq <= 2048) { if (ang) hipLaunchKernelGGL((k_search_mono<2, true>), grid, block, ml, m->stream, PA, RA); else hipLaunchKernelGGL((k_search_mono<2, false>), grid, block, ml, m->stream, PA, RA); }
-        else { if (ang) hipLaunchKernelGGL((k_search_mono<4, true>), grid, block, ml, m->stream, PA, RA); else hipLaunchKernelGGL((k_search_mono<4, false>), grid, block, ml, m->stream, PA, RA); }
-        MORB_HIP(hipGetLastError());
-        J.device_path = true;
-        J.pollable = J.seq != 0;
-        return ORB_OK;
-    }
     if (multi) {
         int* tab0 = m->d_gclaim.p; int* tab1 = tab0 + n; int* state = tab1 + n;
         MORB_HIP(hipMemsetAsync(state, 0, RS_STATE_INTS * sizeof(int), m->stream));
