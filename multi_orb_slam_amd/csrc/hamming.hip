@@ -98,14 +98,7 @@ __global__ void k_top2_merge(const int* __restrict__ p_idx, const int* __restric
     if (d_range) nq = d_range[2];  // partial arrays are laid out with stride nq: the producer used the same device count
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
-    int B = 256, Sd = 256, I = -1;
-    for (int k = 0; k < S; ++k) {
-        const int b2 = p_best[(size_t)k * nq + qi], s2 = p_second[(size_t)k * nq + qi], i2 = p_idx[(size_t)k * nq + qi];
-        Sd = min(min(Sd, s2), max(B, b2));
-        I = b2 < B ? i2 : I;
-        B = min(B, b2);
-    }
-    best_idx[qi] = I; best_dist[qi] = B; second_dist[qi] = Sd;
+    top2_merge_query(p_idx, p_best, p_second, S, nq, qi, best_idx, best_dist, second_dist);
 }
 
 // One wave = 512 consecutive references (8 per lane, 64 VGPRs), one block = 4 such tiles; grid.y walks the queries in
@@ -1098,7 +1091,7 @@ int morb::side_reserve(orbm_matcher* m, int nq, int n) {
     return ORB_OK;
 }
 
-int morb::launch_project_side(hipStream_t st, const morb::ProjectArgs& P, const SideJob& J) {
+int morb::launch_project_side(hipStream_t st, const morb::ProjectArgs& P, const SideJob& J, MergeJob* defer_merge) {
     const int nq = J.n;   // every feature of the frame is a query of the camera-pair top-2 (capacity; the count comes from d_range)
     const Top2Plan plan = top2_plan(nq, J.n);
     MORB_ARG(plan.mfma && J.d_range && J.scratch);
@@ -1117,9 +1110,19 @@ int morb::launch_project_side(hipStream_t st, const morb::ProjectArgs& P, const 
     const int n_mirror = J.with_mirror ? std::min(64, (J.mirror.n_host * 8 + 255) / 256) : 0;
     if (top2_fp4()) hipLaunchKernelGGL(k_project_side<true>, dim3(X.n_cross + X.n_project + n_mirror), dim3(64 * MM_WAVES), 0, st, P, X);
     else hipLaunchKernelGGL(k_project_side<false>, dim3(X.n_cross + X.n_project + n_mirror), dim3(64 * MM_WAVES), 0, st, P, X);
-    if (S > 1)
+    // the merge of the slice partials: a launch of its own, or -- when the caller's next launch on this stream can carry it (the
+    // resolve of an isolated step: one kernel and one kernel boundary less on the step's chain) -- handed back as a job
+    if (S > 1 && defer_merge) *defer_merge = MergeJob{X.p_idx, X.p_best, X.p_second, S, nq, J.o_idx, J.o_best, J.o_second, J.d_range, nullptr, 0u};
+    else if (S > 1)
         hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, X.p_idx, X.p_best, X.p_second, S, nq, J.o_idx, J.o_best,
                            J.o_second, J.d_range);
+    MORB_HIP(hipGetLastError());
+    return ORB_OK;
+}
+
+// (a deferred merge whose carrier did not come after all)
+int morb::launch_merge(hipStream_t st, const MergeJob& M) {
+    hipLaunchKernelGGL(k_top2_merge, dim3((M.nq + 255) / 256), dim3(256), 0, st, M.p_idx, M.p_best, M.p_second, M.S, M.nq, M.o_idx, M.o_best, M.o_second, M.d_range);
     MORB_HIP(hipGetLastError());
     return ORB_OK;
 }

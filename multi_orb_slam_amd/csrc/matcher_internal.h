@@ -98,6 +98,8 @@ struct orbm_matcher {
     bool host_resolve = false;     // MORB_HOST_RESOLVE=1: always use the host resolve (testing / fallback path)
     int resolve_seq = 0;           // sequence number of the last tagged resolve launch
     bool foreign_work = false;     // something other than a step's own search was put on the stream (orbf_step_end then waits for all of it)
+    DevBuf<int32_t> d_mergecnt;    // running count of the merging workgroups that rode in resolve launches (MergeJob)
+    bool merge_ready = false; unsigned merge_target = 0;
 };
 namespace morb { hipStream_t side_stream(orbm_matcher* m); }   // (lazily created; NULL after a reported failure)
 
@@ -161,6 +163,7 @@ struct SearchJob {
 // side stream and the join behind it cost ~18 us of queue time per step, measured): the camera-pair top-2 over the frame's
 // descriptors and the copy of the frame into the pinned result mirrors.  All of it (the slice merge included) is complete
 // before the resolve kernel behind it starts.
+struct MergeJob;   // (hamming_dev.h)
 struct SideJob {
     const uint8_t* d_desc; int n; const int* d_cam_start; int n_cams; const int* d_range;   // d_range = {features, first query, queries} in HBM
     int *o_idx, *o_best, *o_second;   // mapped pinned results
@@ -198,7 +201,8 @@ int frame_mirror_job(orbm_frame* F, orb_keypoint* h_kps, uint8_t* h_desc, float*
                      MirrorJob* out);
 // k_project next to a SideJob in one launch (hamming.hip); side_fusable: the sizes take the matrix-core top-2 this needs
 struct ProjectArgs;
-int launch_project_side(hipStream_t st, const ProjectArgs& P, const SideJob& S);
+int launch_project_side(hipStream_t st, const ProjectArgs& P, const SideJob& S, struct ::MergeJob* defer_merge = nullptr);
+int launch_merge(hipStream_t st, const struct ::MergeJob& M);
 bool side_fusable(int nq, int n);
 int side_reserve(orbm_matcher* m, int nq, int n);   // scratch and the pinned result arrays of the matcher's own CrossOut
 int frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams, int n_cams, float mbf, float min_x, float min_y,

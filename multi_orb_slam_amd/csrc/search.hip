@@ -482,7 +482,18 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
                                                        const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
                                                        const float* __restrict__ f_angle, int th_high, int check_ori, int max_it,
                                                        const int* __restrict__ topk, int* __restrict__ match_of_feature,
-                                                       int* __restrict__ status, int tagb) {
+                                                       int* __restrict__ status, int tagb, MergeJob MJ) {
+    // Workgroups behind the first one (isolated steps only) merge the slice partials of the camera-pair top-2 that rode in the projection's
+    // launch: the resolve does not need them, the step does -- one kernel and one kernel boundary less between projection and resolve.
+    if (blockIdx.x > 0) {
+        const int mq = MJ.d_range ? MJ.d_range[2] : MJ.nq;
+        const int qi = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+        if (qi < mq) top2_merge_query(MJ.p_idx, MJ.p_best, MJ.p_second, MJ.S, mq, qi, MJ.o_idx, MJ.o_best, MJ.o_second);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // (system scope: the results live in mapped host memory)
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(MJ.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // [0, n): lowest blocking claimant of a feature; [n, 2n): owner (last claimant)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_keep[3];
@@ -768,6 +779,10 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
         __syncthreads();
     }
     MORB_PHASE(g_ph_res, 60);
+    if (MJ.S > 1 && MJ.done) {   // the merging workgroups of this launch finished long ago; the result words below must not say so before they have
+        if (tid == 0) { int spins = 0; while ((int)(__hip_atomic_load(MJ.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - MJ.target) < 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2); }
+        __syncthreads();
+    }
     for (int g = tid; g < NT; g += T) match_of_feature[g] = tagb ? (tagb | (s_owner[g] + 2)) : s_owner[g];
     if (tagb) for (int g = NT + tid; g < F.n_total; g += T) match_of_feature[g] = tagb | 1;   // (see k_resolve: no stale tag can match)
     if (tid == 0) { status[1] = tagb | s_red; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | 0; }
@@ -1230,7 +1245,7 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
                        const uint8_t* d_occupied = nullptr, int* d_topk = nullptr, int short_th = 256,
                        const float* d_inv_sigma2 = nullptr, const orbm_query* q_device_visible = nullptr, int2* d_qmeta = nullptr,
                        const orbm_window* d_win2 = nullptr, const SideJob* side = nullptr, const MotionSrc* msrc = nullptr,
-                       bool msrc_records = false) {
+                       bool msrc_records = false, MergeJob* defer_merge = nullptr) {
     int rc;
     if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query))) || (rc = m->d_i0.reserve((size_t)nq * cap)) ||
         (rc = m->d_u16.reserve((size_t)nq * cap)) || (rc = m->d_i1.reserve(nq)))
@@ -1247,7 +1262,7 @@ static int run_project(orbm_matcher* m, const orbm_frame* f, const orbm_query* q
         A.ms.rec_out = msrc_records ? (orbm_query*)m->d_queries.p : nullptr;
     }
     if (side) {   // the caller's side work (camera-pair top-2, result mirror) shares the launch: see k_project_side
-        if ((rc = launch_project_side(m->stream, A, *side))) return rc;
+        if ((rc = launch_project_side(m->stream, A, *side, defer_merge))) return rc;
     } else {
         hipLaunchKernelGGL(k_project, dim3((nq + 3) / 4), dim3(256), 0, m->stream, A);
     }
@@ -1460,8 +1475,11 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
         if ((rc = m->d_queries.reserve((size_t)nq * sizeof(orbm_query)))) return rc;
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, J.q_dev, (size_t)nq * sizeof(orbm_query), hipMemcpyDefault, m->stream));
     }
+    MergeJob MJ{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};   // (S > 1 after run_project: a merge waits for its carrier)
+    static const bool merge_rides = [] { const char* e = getenv("MORB_MERGE_IN_RESOLVE"); return !(e && atoi(e) == 0); }();
     if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device && !J.q_dev && !J.msrc, false, /*transposed=*/1, d_occ,
-                          m->d_claim.p, J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p, J.win2_dev, J.side, J.msrc, multi)))
+                          m->d_claim.p, J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p, J.win2_dev, J.side, J.msrc, multi,
+                          (J.side && merge_rides && !multi && !J.points) ? &MJ : nullptr)))
         return rc;
     J.side = nullptr;   // (a retry of the search with more room per query does not repeat the side work)
     if (multi) {
@@ -1547,16 +1565,26 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
         const size_t nq2 = ((size_t)nq + 1) & ~(size_t)1;
         return (size_t)n * 8 + nq2 * 4 + (size_t)RESOLVE_K * nq2 * 2 + (((size_t)nq + 3) & ~(size_t)3) + (ang ? ((size_t)nq + (size_t)n) * 4 : 0) + 16;
     };
-    if (!J.points && mono_env && n < 65535 && mono_lds(false) <= 150 * 1024) {
+    const bool will_mono = !J.points && mono_env && n < 65535 && mono_lds(false) <= 150 * 1024;
+    if (MJ.S > 1 && !will_mono) { if ((rc = launch_merge(m->stream, MJ))) return rc; MJ.S = 0; }   // (no carrier after all: a launch of its own)
+    if (will_mono) {
         const bool ang = mono_lds(true) <= 150 * 1024;
         const size_t ml = mono_lds(ang);
 #define MORB_MONO_LAUNCH(RQ_, ANG_)                                                                                                       \
-        hipLaunchKernelGGL((k_resolve_mono<RQ_, ANG_>), dim3(1), dim3(1024), ml, m->stream, cur->dev(), (const int2*)m->d_qmeta.p, nq, cap, \
+        hipLaunchKernelGGL((k_resolve_mono<RQ_, ANG_>), dim3(1 + merge_blocks), dim3(1024), ml, m->stream, cur->dev(), (const int2*)m->d_qmeta.p, nq, cap, \
                            (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,                                \
                            (const float*)cur->b->d_ang.p, th_high, J.check_ori, 4096, (const int*)m->d_claim.p, m->h_match.dp + 4,          \
-                           m->h_match.dp, J.seq << 20)
+                           m->h_match.dp, J.seq << 20, MJ)
+        const int merge_blocks = MJ.S > 1 ? (MJ.nq + 1023) / 1024 : 0;   // (behind workgroup 0, the resolve)
+        if (merge_blocks) {
+            if ((rc = m->d_mergecnt.reserve(4))) return rc;
+            if (!m->merge_ready) { MORB_HIP(hipMemsetAsync(m->d_mergecnt.p, 0, 16, m->stream)); m->merge_ready = true; m->merge_target = 0; }
+            m->merge_target += (unsigned)merge_blocks;
+            MJ.done = reinterpret_cast<unsigned*>(m->d_mergecnt.p); MJ.target = m->merge_target;
+        }
         if (nq <= 2048) { if (ang) MORB_MONO_LAUNCH(2, true); else MORB_MONO_LAUNCH(2, false); }
         else { if (ang) MORB_MONO_LAUNCH(4, true); else MORB_MONO_LAUNCH(4, false); }
+        MJ.S = 0;   // (carried)
 #undef MORB_MONO_LAUNCH
     } else if (ldsq) { if (J.points) MORB_RESOLVE_LAUNCH(true, true); else MORB_RESOLVE_LAUNCH(false, true); }
     else { if (J.points) MORB_RESOLVE_LAUNCH(true, false); else MORB_RESOLVE_LAUNCH(false, false); }
