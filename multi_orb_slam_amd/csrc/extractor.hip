@@ -610,22 +610,25 @@ __device__ __forceinline__ unsigned fast_may_be_corner_x4(const uint32_t* t32, i
                               ab(b2, b1, 1), ab(a1, a0, 1)};       // 6, 14
     const uint32_t c = ab(w1, w0, 3);
     const short Ts = (short)T;
-    const fq_s16x2 T2 = {Ts, Ts}, zero = {0, 0};
+    const fq_s16x2 T2 = {Ts, Ts};
     unsigned pass = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const uint32_t sel = h ? 0x0c030c02u : 0x0c010c00u;       // bytes 2h, 2h + 1 -> the low bytes of the two 16-bit lanes
         const fq_s16x2 C = __builtin_bit_cast(fq_s16x2, __builtin_amdgcn_perm(0u, c, sel));
-        fq_s16x2 d[8];
+        // (round 5) the differences need not be formed: max(d_k, d_k+8) = C - min(r_k, r_k+8), so the bright side is C - A with
+        // A = max over the pairs of min(r_k, r_k+8), the dark side B - C with B = min over the pairs of max(r_k, r_k+8) -- the same
+        // numbers, eight subtractions less per pair of pixels
+        fq_s16x2 r[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) d[k] = C - __builtin_bit_cast(fq_s16x2, __builtin_amdgcn_perm(0u, ring[k], sel));
-        const fq_s16x2 bright = __builtin_elementwise_min(
-            __builtin_elementwise_min(__builtin_elementwise_max(d[0], d[1]), __builtin_elementwise_max(d[2], d[3])),
-            __builtin_elementwise_min(__builtin_elementwise_max(d[4], d[5]), __builtin_elementwise_max(d[6], d[7])));
-        const fq_s16x2 dark = __builtin_elementwise_max(
-            __builtin_elementwise_max(__builtin_elementwise_min(d[0], d[1]), __builtin_elementwise_min(d[2], d[3])),
-            __builtin_elementwise_max(__builtin_elementwise_min(d[4], d[5]), __builtin_elementwise_min(d[6], d[7])));
-        const fq_s16x2 m = __builtin_elementwise_max(bright, zero - dark) - T2;   // >= 0 where the pixel passes
+        for (int k = 0; k < 8; ++k) r[k] = __builtin_bit_cast(fq_s16x2, __builtin_amdgcn_perm(0u, ring[k], sel));
+        const fq_s16x2 A = __builtin_elementwise_max(
+            __builtin_elementwise_max(__builtin_elementwise_min(r[0], r[1]), __builtin_elementwise_min(r[2], r[3])),
+            __builtin_elementwise_max(__builtin_elementwise_min(r[4], r[5]), __builtin_elementwise_min(r[6], r[7])));
+        const fq_s16x2 B = __builtin_elementwise_min(
+            __builtin_elementwise_min(__builtin_elementwise_max(r[0], r[1]), __builtin_elementwise_max(r[2], r[3])),
+            __builtin_elementwise_min(__builtin_elementwise_max(r[4], r[5]), __builtin_elementwise_max(r[6], r[7])));
+        const fq_s16x2 m = __builtin_elementwise_max(C - A, B - C) - T2;   // >= 0 where the pixel passes
         const uint32_t mb = __builtin_bit_cast(uint32_t, m);
         pass |= ((mb & 0x8000u) ? 0u : 1u) << (2 * h);
         pass |= ((mb & 0x80000000u) ? 0u : 2u) << (2 * h);
@@ -639,27 +642,30 @@ __device__ __forceinline__ unsigned fast_may_be_corner_x4(const uint32_t* t32, i
 __device__ __forceinline__ uint32_t fast_score_9_16_x2(const uint8_t* t0, const uint8_t* t1) {
     auto ring2 = [&](int off) { return (uint32_t)t0[off] | ((uint32_t)t1[off] << 16); };
     const fq_s16x2 v = __builtin_bit_cast(fq_s16x2, ring2(0));
-    fq_s16x2 d[16];
+    // (round 5) on the ring values themselves: the minimum of the differences v - r over an arc is v minus the arc's MAXIMUM, so
+    // S+ = v - P with P = min over the arcs of their maximum, S- = Q - v with Q = max over the arcs of their minimum; the sixteen
+    // subtractions of the difference form are gone, the log-step arc extrema are the same work
+    fq_s16x2 r[16];
     constexpr int R[16] = {3 * TILE_PITCH, 3 * TILE_PITCH + 1, 2 * TILE_PITCH + 2, 1 * TILE_PITCH + 3, 3, -1 * TILE_PITCH + 3,
                            -2 * TILE_PITCH + 2, -3 * TILE_PITCH + 1, -3 * TILE_PITCH, -3 * TILE_PITCH - 1, -2 * TILE_PITCH - 2,
                            -1 * TILE_PITCH - 3, -3, 1 * TILE_PITCH - 3, 2 * TILE_PITCH - 2, 3 * TILE_PITCH - 1};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = v - __builtin_bit_cast(fq_s16x2, ring2(R[k]));
+    for (int k = 0; k < 16; ++k) r[k] = __builtin_bit_cast(fq_s16x2, ring2(R[k]));
     fq_s16x2 lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { lo2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]); hi2[k] = __builtin_elementwise_max(d[k], d[(k + 1) & 15]); }
+    for (int k = 0; k < 16; ++k) { lo2[k] = __builtin_elementwise_min(r[k], r[(k + 1) & 15]); hi2[k] = __builtin_elementwise_max(r[k], r[(k + 1) & 15]); }
 #pragma unroll
     for (int k = 0; k < 16; ++k) { lo4[k] = __builtin_elementwise_min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = __builtin_elementwise_max(hi2[k], hi2[(k + 2) & 15]); }
-    fq_s16x2 sp = {-256, -256}, sm = {256, 256};
+    fq_s16x2 P = {256, 256}, Q = {-256, -256};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const fq_s16x2 lo9 = __builtin_elementwise_min(__builtin_elementwise_min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const fq_s16x2 hi9 = __builtin_elementwise_max(__builtin_elementwise_max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        sp = __builtin_elementwise_max(sp, lo9);
-        sm = __builtin_elementwise_min(sm, hi9);
+        const fq_s16x2 arc_min = __builtin_elementwise_min(__builtin_elementwise_min(lo4[k], lo4[(k + 4) & 15]), r[(k + 8) & 15]);  // min of r[k..k+8]
+        const fq_s16x2 arc_max = __builtin_elementwise_max(__builtin_elementwise_max(hi4[k], hi4[(k + 4) & 15]), r[(k + 8) & 15]);  // max of r[k..k+8]
+        P = __builtin_elementwise_min(P, arc_max);
+        Q = __builtin_elementwise_max(Q, arc_min);
     }
-    const fq_s16x2 zero = {0, 0}, one = {1, 1};
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(sp, zero - sm) - one);
+    const fq_s16x2 one = {1, 1};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v - P, Q - v) - one);
 }
 
 // 2^20 / d rounded up, for d in 1 .. 127: i / d == (i * inv) >> 20 whenever i * d < 2^20 (the index splits of the cell kernel).
