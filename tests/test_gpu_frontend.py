@@ -123,6 +123,31 @@ def test_six_camera_rig_takes_the_multi_kernel_frame_path(depth):
     fe.close()
 
 
+@pytest.mark.parametrize("kind", list(synth.FAMILIES))
+def test_whole_steps_on_the_image_families(kind):
+    """The image families of round 5 (synth.family_image: 1/f-like noise, dithered ramps, soft edges, saturated regions, contrast
+    at the FAST thresholds) through the WHOLE step -- extraction, frame assembly with stereo, the temporal search with its rotation
+    histogram, the camera-pair top-2 --, two cameras at 640x480, isolated steps and steps announced ahead, against the oracle."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    w, h, T = 640, 480, 5
+    params = [m.ExtractorParams(nfeatures=1000), m.ExtractorParams(nfeatures=500)]
+    frames = [[synth.family_image(kind, c, t, w, h) for c in range(2)] for t in range(T)]
+    for depth in (0, 2):
+        fe = pipeline.FrontEnd(params, w, h); ofe = OracleFrontEnd(params, w, h)
+        announced = 0
+        for t in range(T):
+            while announced < min(t + depth, T - 1):
+                announced += 1
+                fe.announce(frames[announced])
+            announced = max(announced, t)
+            got = fe.step(frames[t])
+            assert_same_step(got, ofe.step(frames[t]))
+        assert sum(got["counts"]) > 900, (kind, got["counts"])
+        fe.close()
+
+
 def test_overlap_survives_the_host_quadtree_fallback():
     """Noise frames put more candidates on level 0 than the device quadtree takes (its limit lowered to 4096 here; 16384 in
     the product): the kernel reports 'outside my limits' and the step is redone on the host path -- with the next step's
