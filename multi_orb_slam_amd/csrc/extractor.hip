@@ -591,12 +591,37 @@ __device__ __forceinline__ bool fast_may_be_corner(const uint8_t* t, int T) {
 // The same test for FOUR horizontally adjacent pixels on packed 16-bit lanes (round 3).  `t32` points at the dword of the
 // centre row that holds tile columns [4 gx, 4 gx + 4); the four pixels sit at columns 4 gx + 3 .. 4 gx + 6 (the tile's origin is
 // three pixels left of the scored rectangle and dword-aligned in LDS), so every operand is a compile-time byte alignment of two
-// neighbouring dwords.  With d_k = centre - ring_k:  a bright arc needs  min over the four antipodal pairs of max(d_k, d_k+8) >= T,
-// a dark arc  max over the pairs of min(d_k, d_k+8) <= -T  -- 8 subtractions and 16 min/max per PAIR of pixels instead of 8
-// subtractions, 16 compares and the logic per pixel, and 13 dword reads per four pixels instead of up to 9 byte reads per pixel.
-// Returns bit j = pixel j may be a corner.
+// neighbouring dwords.  With A = max over the four antipodal pairs of min(r_k, r_k+8) and B = min over the pairs of
+// max(r_k, r_k+8), a bright arc needs C - A >= T and a dark arc B - C >= T (T = min_th + 1).
+//
+// Round 5, second form: NO UNPACKING.  An unsigned 16-bit minimum / maximum orders by the HIGH byte first, so the high byte of any
+// min / max tree over 16-bit lanes is that tree over the high bytes, whatever the low bytes hold.  The four bytes starting at a ring
+// pixel of p0 therefore ARE the packed operand of the odd pixels p1 and p3 (bytes 1 and 3 = the high bytes of the two lanes, bytes
+// 0 and 2 = junk), and the four bytes starting one column earlier that of the even pixels p0 and p2 -- one v_alignbyte per operand
+// (none where the start is dword-aligned) where the round-3 form spent an alignbyte and two v_perm.  The junk is kept out of the
+// decision by the centre's low byte: with A' = A << 8 | a (a = junk, 0..255) and C0 = C << 8,  sat(C0 - A') = max(0, (C - A) * 256 - a)
+// is >= K = (T - 1) * 256 + 1 exactly when C - A >= T; with C1 = C << 8 | 255,  sat(B' - C1) = max(0, (B - C) * 256 + b - 255) is
+// >= K exactly when B - C >= T.  A saturating add of 0x8000 - K then puts "passes" into bit 15 of the lane (0 <= min_th <= 127: K
+// fits; other thresholds take the round-3 form below).  Returns the pass bits where they fall: p1 -> 15, p3 -> 31, p0 -> 14, p2 -> 30.
 using fq_s16x2 = short __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned fast_may_be_corner_x4(const uint32_t* t32, int T) {
+using fq_u16x2 = unsigned short __attribute__((ext_vector_type(2)));
+constexpr int FQ_BIT[8] = {14, 15, 30, 31, 12, 13, 28, 29};   // pixel j of a lane's eight -> its bit (the second four: two to the right)
+__device__ __forceinline__ uint32_t fq_scramble(unsigned lin) {   // bit j -> bit FQ_BIT[j]
+    return ((lin & 3u) << 14) | (((lin >> 2) & 3u) << 30) | (((lin >> 4) & 3u) << 12) | (((lin >> 6) & 3u) << 28);
+}
+__device__ __forceinline__ uint32_t fq_tree(const uint32_t (&ring)[8], uint32_t c, uint32_t kadd2) {
+    auto U = [](uint32_t w) { return __builtin_bit_cast(fq_u16x2, w); };
+    const fq_u16x2 A = __builtin_elementwise_max(
+        __builtin_elementwise_max(__builtin_elementwise_min(U(ring[0]), U(ring[1])), __builtin_elementwise_min(U(ring[2]), U(ring[3]))),
+        __builtin_elementwise_max(__builtin_elementwise_min(U(ring[4]), U(ring[5])), __builtin_elementwise_min(U(ring[6]), U(ring[7]))));
+    const fq_u16x2 B = __builtin_elementwise_min(
+        __builtin_elementwise_min(__builtin_elementwise_max(U(ring[0]), U(ring[1])), __builtin_elementwise_max(U(ring[2]), U(ring[3]))),
+        __builtin_elementwise_min(__builtin_elementwise_max(U(ring[4]), U(ring[5])), __builtin_elementwise_max(U(ring[6]), U(ring[7]))));
+    const fq_u16x2 v = __builtin_elementwise_max(__builtin_elementwise_sub_sat(U(c & 0xff00ff00u), A),
+                                                 __builtin_elementwise_sub_sat(B, U(c | 0x00ff00ffu)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(v, U(kadd2)));
+}
+__device__ __forceinline__ uint32_t fast_may_be_corner_x4(const uint32_t* t32, uint32_t kadd2) {
     constexpr int P = TILE_PITCH / 4;
     auto ab = [](uint32_t hi, uint32_t lo, int sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); };
     const uint32_t w0 = t32[0], w1 = t32[1], w2 = t32[2];
@@ -604,10 +629,27 @@ __device__ __forceinline__ unsigned fast_may_be_corner_x4(const uint32_t* t32, i
     const uint32_t v0 = t32[-3 * P], v1 = t32[-3 * P + 1];          // ring 8: (-3, 0)
     const uint32_t a0 = t32[2 * P], a1 = t32[2 * P + 1], a2 = t32[2 * P + 2];      // ring 2: (+2, +2), ring 14: (+2, -2)
     const uint32_t b0 = t32[-2 * P], b1 = t32[-2 * P + 1], b2 = t32[-2 * P + 2];   // ring 6: (-2, +2), ring 10: (-2, -2)
-    const uint32_t ring[8] = {ab(u1, u0, 3), ab(v1, v0, 3),        // 0, 8
-                              ab(w2, w1, 2), w0,                   // 4 (0, +3), 12 (0, -3)
-                              ab(a2, a1, 1), ab(b1, b0, 1),        // 2, 10
-                              ab(b2, b1, 1), ab(a1, a0, 1)};       // 6, 14
+    // odd pixels (p1, p3): the four bytes from p0's ring pixel on
+    const uint32_t odd[8] = {ab(u1, u0, 3), ab(v1, v0, 3),        // 0, 8
+                             ab(w2, w1, 2), w0,                   // 4 (0, +3), 12 (0, -3)
+                             ab(a2, a1, 1), ab(b1, b0, 1),        // 2, 10
+                             ab(b2, b1, 1), ab(a1, a0, 1)};       // 6, 14
+    // even pixels (p0, p2): the same, one column earlier (ring 12 would start in the dword before w0: a shift puts the same
+    // two bytes into the lanes' high halves)
+    const uint32_t even[8] = {ab(u1, u0, 2), ab(v1, v0, 2), ab(w2, w1, 1), w0 << 8, a1, b0, b1, a0};
+    const uint32_t e_odd = fq_tree(odd, ab(w1, w0, 3), kadd2), e_even = fq_tree(even, ab(w1, w0, 2), kadd2);
+    return (e_odd & 0x80008000u) | ((e_even >> 1) & 0x40004000u);
+}
+// The round-3 form of the same test (pixels unpacked to 16-bit lanes, signed arithmetic): any threshold.  Same bit positions.
+__device__ __forceinline__ uint32_t fast_may_be_corner_x4_wide(const uint32_t* t32, int T) {
+    constexpr int P = TILE_PITCH / 4;
+    auto ab = [](uint32_t hi, uint32_t lo, int sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); };
+    const uint32_t w0 = t32[0], w1 = t32[1], w2 = t32[2];
+    const uint32_t u0 = t32[3 * P], u1 = t32[3 * P + 1];
+    const uint32_t v0 = t32[-3 * P], v1 = t32[-3 * P + 1];
+    const uint32_t a0 = t32[2 * P], a1 = t32[2 * P + 1], a2 = t32[2 * P + 2];
+    const uint32_t b0 = t32[-2 * P], b1 = t32[-2 * P + 1], b2 = t32[-2 * P + 2];
+    const uint32_t ring[8] = {ab(u1, u0, 3), ab(v1, v0, 3), ab(w2, w1, 2), w0, ab(a2, a1, 1), ab(b1, b0, 1), ab(b2, b1, 1), ab(a1, a0, 1)};
     const uint32_t c = ab(w1, w0, 3);
     const short Ts = (short)T;
     const fq_s16x2 T2 = {Ts, Ts};
@@ -616,9 +658,6 @@ __device__ __forceinline__ unsigned fast_may_be_corner_x4(const uint32_t* t32, i
     for (int h = 0; h < 2; ++h) {
         const uint32_t sel = h ? 0x0c030c02u : 0x0c010c00u;       // bytes 2h, 2h + 1 -> the low bytes of the two 16-bit lanes
         const fq_s16x2 C = __builtin_bit_cast(fq_s16x2, __builtin_amdgcn_perm(0u, c, sel));
-        // (round 5) the differences need not be formed: max(d_k, d_k+8) = C - min(r_k, r_k+8), so the bright side is C - A with
-        // A = max over the pairs of min(r_k, r_k+8), the dark side B - C with B = min over the pairs of max(r_k, r_k+8) -- the same
-        // numbers, eight subtractions less per pair of pixels
         fq_s16x2 r[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) r[k] = __builtin_bit_cast(fq_s16x2, __builtin_amdgcn_perm(0u, ring[k], sel));
@@ -633,39 +672,43 @@ __device__ __forceinline__ unsigned fast_may_be_corner_x4(const uint32_t* t32, i
         pass |= ((mb & 0x8000u) ? 0u : 1u) << (2 * h);
         pass |= ((mb & 0x80000000u) ? 0u : 2u) << (2 * h);
     }
-    return pass;
+    return fq_scramble(pass);
 }
 
-// fast_score_9_16 for TWO pixels at once on packed 16-bit lanes (round 4): the differences centre - ring fit 16 bits, so the
-// 16 subtractions and the 80 min / max of the log-step arc minima run as v_pk_sub_i16 / v_pk_min_i16 / v_pk_max_i16 on a pair
-// of survivors per lane: ~60 vector instructions per pixel instead of ~145.  Returns score(t0) | score(t1) << 16.
+// fast_score_9_16 for TWO pixels at once on packed 16-bit lanes (round 4).  Round 5: on the ring values themselves -- the minimum
+// of the differences v - r over an arc is v minus the arc's MAXIMUM, so S+ = v - P with P = min over the arcs of their maximum,
+// S- = Q - v with Q = max over the arcs of their minimum -- and with THREE-input extrema: gfx950 has packed three-input minimum /
+// maximum only for f16 (v_pk_minimum3_f16 / v_pk_maximum3_f16), and a 16-bit lane holding 0..255 read as f16 is a non-negative
+// (denormal) number that orders exactly as the integer does (f16 denormals are preserved: .amdhsa_float_denorm_mode_16_64 3, which
+// tests/test_isa_guard.py holds), so the nine-element arc extrema are two levels of three (3 x 3) instead of log steps:
+// 2 x (16 + 16 + 8) packed instructions per pair of pixels where the two-input form took 2 x 80.  The selected values are the
+// operands' own bit patterns; the last subtractions are integer.  Returns score(t0) | score(t1) << 16.
+using fq_h16x2 = _Float16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fq_h16x2 fq_min3(fq_h16x2 a, fq_h16x2 b, fq_h16x2 c) { return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c); }
+__device__ __forceinline__ fq_h16x2 fq_max3(fq_h16x2 a, fq_h16x2 b, fq_h16x2 c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
 __device__ __forceinline__ uint32_t fast_score_9_16_x2(const uint8_t* t0, const uint8_t* t1) {
     auto ring2 = [&](int off) { return (uint32_t)t0[off] | ((uint32_t)t1[off] << 16); };
     const fq_s16x2 v = __builtin_bit_cast(fq_s16x2, ring2(0));
-    // (round 5) on the ring values themselves: the minimum of the differences v - r over an arc is v minus the arc's MAXIMUM, so
-    // S+ = v - P with P = min over the arcs of their maximum, S- = Q - v with Q = max over the arcs of their minimum; the sixteen
-    // subtractions of the difference form are gone, the log-step arc extrema are the same work
-    fq_s16x2 r[16];
+    fq_h16x2 r[16];
     constexpr int R[16] = {3 * TILE_PITCH, 3 * TILE_PITCH + 1, 2 * TILE_PITCH + 2, 1 * TILE_PITCH + 3, 3, -1 * TILE_PITCH + 3,
                            -2 * TILE_PITCH + 2, -3 * TILE_PITCH + 1, -3 * TILE_PITCH, -3 * TILE_PITCH - 1, -2 * TILE_PITCH - 2,
                            -1 * TILE_PITCH - 3, -3, 1 * TILE_PITCH - 3, 2 * TILE_PITCH - 2, 3 * TILE_PITCH - 1};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) r[k] = __builtin_bit_cast(fq_s16x2, ring2(R[k]));
-    fq_s16x2 lo2[16], hi2[16], lo4[16], hi4[16];
+    for (int k = 0; k < 16; ++k) r[k] = __builtin_bit_cast(fq_h16x2, ring2(R[k]));
+    fq_h16x2 lo3[16], hi3[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { lo2[k] = __builtin_elementwise_min(r[k], r[(k + 1) & 15]); hi2[k] = __builtin_elementwise_max(r[k], r[(k + 1) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { lo4[k] = __builtin_elementwise_min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = __builtin_elementwise_max(hi2[k], hi2[(k + 2) & 15]); }
-    fq_s16x2 P = {256, 256}, Q = {-256, -256};
+    for (int k = 0; k < 16; ++k) { lo3[k] = fq_min3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]); hi3[k] = fq_max3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]); }
+    fq_h16x2 amin[16], amax[16];   // extrema of r[k .. k+8]
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const fq_s16x2 arc_min = __builtin_elementwise_min(__builtin_elementwise_min(lo4[k], lo4[(k + 4) & 15]), r[(k + 8) & 15]);  // min of r[k..k+8]
-        const fq_s16x2 arc_max = __builtin_elementwise_max(__builtin_elementwise_max(hi4[k], hi4[(k + 4) & 15]), r[(k + 8) & 15]);  // max of r[k..k+8]
-        P = __builtin_elementwise_min(P, arc_max);
-        Q = __builtin_elementwise_max(Q, arc_min);
+        amin[k] = fq_min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+        amax[k] = fq_max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
     }
+    fq_h16x2 P = __builtin_elementwise_minimum(amax[0], amax[1]), Q = __builtin_elementwise_maximum(amin[0], amin[1]);
+#pragma unroll
+    for (int k = 2; k < 16; k += 2) { P = fq_min3(P, amax[k], amax[k + 1]); Q = fq_max3(Q, amin[k], amin[k + 1]); }
     const fq_s16x2 one = {1, 1};
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v - P, Q - v) - one);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v - __builtin_bit_cast(fq_s16x2, P), __builtin_bit_cast(fq_s16x2, Q) - v) - one);
 }
 
 // 2^20 / d rounded up, for d in 1 .. 127: i / d == (i * inv) >> 20 whenever i * d < 2^20 (the index splits of the cell kernel).
@@ -765,17 +808,27 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restr
     const int lane = tid & 63;
     const int gpr = (cw + GW - 1) / GW, ngroups = gpr * ch;          // groups of GW per row
     const unsigned inv_gpr = d_inv20[gpr];                           // (g / gpr exact: g * gpr < 2^20)
+    // (the quick test's constants: the byte form for 0 <= min_th <= 127, the unpacked form otherwise; the pass bits of a lane's
+    // pixels sit at FQ_BIT[j], and what the last group of a row has beyond the rectangle is masked there)
+    const bool narrow = Lv.min_th >= 0 && Lv.min_th <= 127;
+    const uint32_t kadd2 = (uint32_t)(0x8000 - (Lv.min_th * 256 + 1)) * 0x10001u;
+    const uint32_t tail_mask = fq_scramble((1u << (cw - GW * (gpr - 1))) - 1u);
     for (int base = 0; base < ngroups; base += FAST_NT) {
         const int g = base + tid;
-        unsigned m8 = 0;
+        uint32_t m8 = 0;
         int p0 = 0;
         if (g < ngroups) {
             const int py = (int)(((unsigned)g * inv_gpr) >> 20), gx = g - py * gpr;
             const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile_raw) + (py + 3) * (TILE_PITCH / 4) + (GW / 4) * gx;
-            m8 = fast_may_be_corner_x4(t32, Lv.min_th + 1);
             const int left = cw - GW * gx;                           // pixels of this group inside the scored rectangle
-            if (GW == 8 && left > 4) m8 |= fast_may_be_corner_x4(t32 + 1, Lv.min_th + 1) << 4;   // (the second dword's reads stay inside the staged tile row then)
-            if (left < GW) m8 &= (1u << left) - 1u;
+            if (narrow) {
+                m8 = fast_may_be_corner_x4(t32, kadd2);
+                if (GW == 8 && left > 4) m8 |= fast_may_be_corner_x4(t32 + 1, kadd2) >> 2;   // (the second dword's reads stay inside the staged tile row then)
+            } else {
+                m8 = fast_may_be_corner_x4_wide(t32, Lv.min_th + 1);
+                if (GW == 8 && left > 4) m8 |= fast_may_be_corner_x4_wide(t32 + 1, Lv.min_th + 1) >> 2;
+            }
+            if (gx == gpr - 1) m8 &= tail_mask;
             p0 = py * cw + GW * gx;
         }
         const int cnt = __popc(m8);
@@ -783,10 +836,10 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restr
         const int total = __builtin_amdgcn_readlane(incl, 63);
         int wbase = 0;
         if (lane == 0 && total) wbase = atomicAdd(&s_nsurv, total);
-        int pos = __builtin_amdgcn_readfirstlane(wbase) + incl - cnt;
+        unsigned short* q = s_surv + (__builtin_amdgcn_readfirstlane(wbase) + incl - cnt);
 #pragma unroll
         for (int j = 0; j < GW; ++j)
-            if ((m8 >> j) & 1u) s_surv[pos++] = (unsigned short)(p0 + j);
+            if (m8 & (1u << FQ_BIT[j])) *q++ = (unsigned short)(p0 + j);
     }
     __syncthreads();
     // pass 2: the full score, two survivors per lane on packed 16-bit lanes (an odd survivor count scores the last one twice)
