@@ -24,6 +24,10 @@ int orbx_debug_last_path(const orbx_extractor* ex);
 /* inspection: cameras whose pyramid level 0 the most recently enqueued run reads in the caller's device buffer instead of a copy
  * (large rigs driven through orbf_*, which promises the buffers' lifetime; 0 everywhere else) */
 int orbx_debug_level0_in_place(const orbx_extractor* ex);
+/* inspection: how the geometry of the most recent run builds its pyramid -- 0 one tile launch for all levels (k_pyramid_tiled: small
+ * rigs), 1 one k_resize_v4 launch per level, 2 the round-1 chain (k_resize2 / k_resize), 3 two tile launches with four pixels per lane
+ * (k_pyramid_tiled4: large rigs); -1 before the first run */
+int orbx_debug_pyramid_form(const orbx_extractor* ex);
 
 /* ---- matcher ------------------------------------------------------------------------------------------------------------- */
 /* {status, nmatches, sweeps, longest candidate list} of the last device-side resolve (inspection only) */

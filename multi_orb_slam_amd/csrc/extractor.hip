@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256) void k_resize_v4(const LevelInfo* __restrict__
     uint32_t out = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t v = (((((uint32_t)yt.z * (h[0][j] >> 4)) >> 16) + (((uint32_t)yt.w * (h[1][j] >> 4)) >> 16) + 2) >> 2) & 0xff;
+        // (24-bit multiplies: full rate where the 32-bit one takes four passes; beta <= 2048, the sums below 2^16)
+        const uint32_t v = ((((__umul24((uint32_t)yt.z, h[0][j] >> 4)) >> 16) + ((__umul24((uint32_t)yt.w, h[1][j] >> 4)) >> 16) + 2) >> 2) & 0xff;
         out |= v << (8 * j);
     }
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * D.stride + x4) = out;   // (columns past w: padding of the 64-byte row pitch, as k_resize)
@@ -418,15 +419,15 @@ __global__ __launch_bounds__(NT) void k_pyramid_tiled(PyrArgs A, const LevelInfo
             const int i = tid + NT * u;
             l0v[u] = 0;
             if (i < ndw * pnh) {
-                const int y = (int)(((unsigned)i * l0_inv) >> 20), k = i - y * ndw;
+                const int y = (int)(__umul24((unsigned)i, l0_inv) >> 20), k = i - (int)__umul24(y, ndw);
                 l0v[u] = reinterpret_cast<const uint32_t*>(src + (size_t)(py0 + y) * sstride + px0)[k];
             }
         }
         if (rem > 0) {
             const unsigned inv = ((1u << 20) + rem - 1) / rem;
             for (int i = tid; i < rem * pnh; i += NT) {
-                const int y = (int)(((unsigned)i * inv) >> 20), x = 4 * ndw + i - y * rem;
-                cur[y * ppw + x] = src[(size_t)(py0 + y) * sstride + px0 + x];
+                const int y = (int)(__umul24((unsigned)i, inv) >> 20), x = 4 * ndw + i - (int)__umul24(y, rem);
+                cur[__umul24(y, ppw) + x] = src[(size_t)(py0 + y) * sstride + px0 + x];
             }
         }
         if (!inplace) {   // straight from the source to level 0 (the same bytes once more: L2 hits, independent of the LDS copy)
@@ -436,14 +437,14 @@ __global__ __launch_bounds__(NT) void k_pyramid_tiled(PyrArgs A, const LevelInfo
             if (odw > 0) {
                 const unsigned inv = ((1u << 20) + odw - 1) / odw;
                 for (int i = tid; i < odw * oh; i += NT) {
-                    const int y = (int)(((unsigned)i * inv) >> 20), k = i - y * odw;
+                    const int y = (int)(__umul24((unsigned)i, inv) >> 20), k = i - (int)__umul24(y, odw);
                     reinterpret_cast<uint32_t*>(dst + (size_t)(py0 + y) * l0_stride + px0)[k] = reinterpret_cast<const uint32_t*>(s2 + (size_t)(py0 + y) * sstride + px0)[k];
                 }
             }
             if (orem > 0) {
                 const unsigned inv = ((1u << 20) + orem - 1) / orem;
                 for (int i = tid; i < orem * oh; i += NT) {
-                    const int y = (int)(((unsigned)i * inv) >> 20), x = 4 * odw + i - y * orem;
+                    const int y = (int)(__umul24((unsigned)i, inv) >> 20), x = 4 * odw + i - (int)__umul24(y, orem);
                     dst[(size_t)(py0 + y) * l0_stride + px0 + x] = s2[(size_t)(py0 + y) * sstride + px0 + x];
                 }
             }
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(NT) void k_pyramid_tiled(PyrArgs A, const LevelInfo
 #pragma unroll
     for (int u = 0; u < PYR_L0_DW; ++u) {
         const int i = tid + NT * u;
-        if (i < l0_ndw * pnh) { const int y = (int)(((unsigned)i * l0_inv) >> 20), k = i - y * l0_ndw; reinterpret_cast<uint32_t*>(cur + y * ppw)[k] = l0v[u]; }
+        if (i < l0_ndw * pnh) { const int y = (int)(__umul24((unsigned)i, l0_inv) >> 20), k = i - (int)__umul24(y, l0_ndw); reinterpret_cast<uint32_t*>(cur + __umul24(y, ppw))[k] = l0v[u]; }
     }
     PPH(2);
     int4 sx, sy;
@@ -511,32 +512,190 @@ __global__ __launch_bounds__(NT) void k_pyramid_tiled(PyrArgs A, const LevelInfo
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int i = min(i0 + NT * u, npx - 1);
-                    yy[u] = (int)(((unsigned)i * inv) >> 20); xx[u] = i - yy[u] * nw;
+                    yy[u] = (int)(__umul24((unsigned)i, inv) >> 20); xx[u] = i - (int)__umul24(yy[u], nw);   // (24-bit multiplies are full rate; 32-bit ones take four passes)
                     const int4 yt = ty_l[yy[u]];   // {row0, row1, beta0, beta1}
                     const int2 xt = tx_l[xx[u]];   // {sx0 | sx1 << 16, alpha0 | alpha1 << 16}
-                    const uint8_t* s0 = srcl + yt.x * ppw;
-                    const uint8_t* s1 = srcl + yt.y * ppw;
+                    const uint8_t* s0 = srcl + __mul24(yt.x, ppw);
+                    const uint8_t* s1 = srcl + __mul24(yt.y, ppw);
                     const int c0 = xt.x & 0xffff, c1 = (unsigned)xt.x >> 16;
                     p[u][0] = s0[c0]; p[u][1] = s0[c1]; p[u][2] = s1[c0]; p[u][3] = s1[c1];
                     a0[u] = (short)(xt.y & 0xffff); a1[u] = xt.y >> 16; b0[u] = yt.z; b1[u] = yt.w;
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int h0 = p[u][0] * a0[u] + p[u][1] * a1[u];
-                    const int h1 = p[u][2] * a0[u] + p[u][3] * a1[u];
-                    vv[u] = ((((b0[u] * (h0 >> 4)) >> 16) + ((b1[u] * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+                    const int h0 = __mul24(p[u][0], a0[u]) + __mul24(p[u][1], a1[u]);
+                    const int h1 = __mul24(p[u][2], a0[u]) + __mul24(p[u][3], a1[u]);
+                    vv[u] = ((((__mul24(b0[u], h0 >> 4)) >> 16) + ((__mul24(b1[u], h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if (i0 + NT * u < npx) {
-                        nxt[yy[u] * pw + xx[u]] = (uint8_t)vv[u];
-                        if (yy[u] < oh && xx[u] < ow) dst[(size_t)yy[u] * lv.y + xx[u]] = (uint8_t)vv[u];
+                        nxt[__mul24(yy[u], pw) + xx[u]] = (uint8_t)vv[u];
+                        if (yy[u] < oh && xx[u] < ow) dst[__umul24(yy[u], lv.y) + xx[u]] = (uint8_t)vv[u];
                     }
                 }
             }
         }
         __syncthreads();
         PPH(3 + l);
+        cur = nxt; px0 = x0; py0 = y0; pnh = nh; ppw = pw;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K1, tiled, four pixels per lane
+// Round 5: the tile scheme of k_pyramid_tiled (a workgroup takes a tile of ONE level -- the base -- and computes what hangs below it on
+// the next levels in LDS, recomputing the halo its neighbours own) with the arithmetic of k_resize_v4 (four adjacent pixels per lane:
+// a source row is three LDS dwords shifted to the first tap, one v_perm + v_dot2 per pixel and row, the x table ready-made per group
+// of four columns).  k_pyramid_tiled spends ~70 vector instructions per pixel (one pixel per lane and step, byte reads), this form
+// ~25 as the chain does -- so a LARGE rig's pyramid is two launches (levels 1..m below level 0, levels m+1.. below level m) instead of
+// one launch per level, at the chain's cost per pixel plus the halo.
+//   Ownership along x is by GROUPS of four destination columns: group g of level l belongs to the tile that owns, on level l - 1, the
+// column of the group's first tap (rows: the row of the left tap, as k_pyramid_tiled).  First taps are monotone in g, so on every level
+// the tiles own disjoint runs of whole groups that cover it; region starts are multiples of four on every level, so a dword of an LDS
+// region is a dword of the level.  What a tile needs beyond what it owns grows to the right and downwards only.  Every pixel is the
+// same integer function of the same source bytes as in k_resize_v4, whoever computes it.
+//   Spans per (camera, level, tile column / row) from the host (TilePlan): x {own0, own1, need1, 2^20 / needed groups} in pixels (all
+// multiples of four below the base), y {own0, own1, need1, 0}.
+struct Tile4Args {
+    const LevelInfo* L; uint8_t* pyr; size_t cam_pitch; const int4* xgrp; const int4* ytab; const int4* sx; const int4* sy; const L0Src* l0;
+    int max_levels, base, last, tw, th, halo_x, halo_y, tx_max, ty_max, gcap, rcap;
+    short tx[64], ty[64];
+};
+constexpr int T4_MAX_DW = 16;   // dwords of the base block a thread holds while the tables are on their way: (tw + halo) / 4 x (th + halo) <= 16 x threads (host)
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pyramid_tiled4(Tile4Args A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t t4_lds[];
+    __shared__ int4 s_sx[PYR_MAX_LEVELS], s_sy[PYR_MAX_LEVELS], s_lv[PYR_MAX_LEVELS];   // spans; {pyr_off, stride, xgrp_off, ytab_off} (index: level - base)
+    __shared__ int s_og[PYR_MAX_LEVELS + 1], s_or[PYR_MAX_LEVELS + 1];                   // first group / row entry of a level in the LDS tables
+    const int dealt = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int per_cam = gridDim.x * gridDim.y;
+    const int cam = dealt / per_cam, ky = (dealt - cam * per_cam) / (int)gridDim.x, kx = dealt - cam * per_cam - ky * (int)gridDim.x;
+    if (kx >= A.tx[cam] || ky >= A.ty[cam]) return;
+    const int tid = threadIdx.x;
+    const LevelInfo* Lc = A.L + cam * A.max_levels;
+    uint8_t* base_ptr = A.pyr + cam * A.cam_pitch;
+    const int nrec = A.last - A.base + 1;   // records of levels base .. last
+    int4* gtab = reinterpret_cast<int4*>(t4_lds);                       // 3 x gcap entries
+    int4* rtab = gtab + 3 * (size_t)A.gcap;                             // rcap entries
+    uint8_t* regions = reinterpret_cast<uint8_t*>(rtab + A.rcap);
+    // ---- round trip 1: the span records of this tile's levels (one thread per level)
+    int4 rt_x = make_int4(0, 0, 0, 0), rt_y = rt_x, rt_v = rt_x;
+    if (tid < nrec) {
+        const int l = A.base + tid;
+        rt_x = A.sx[(size_t)(cam * A.max_levels + l) * A.tx_max + kx]; rt_y = A.sy[(size_t)(cam * A.max_levels + l) * A.ty_max + ky];
+        const LevelInfo Lv = Lc[l];
+        rt_v = make_int4(Lv.pyr_off, Lv.stride, Lv.xgrp_off, Lv.ytab_off);
+    }
+    // ---- the base block: tw x th pixels of the tile plus the halo to the right and below, clipped to the level; whole dwords where the
+    // source allows it (always inside the pyramid buffer: rows start on 64-byte boundaries, tile columns are multiples of four)
+    const LevelInfo Lb = Lc[A.base];
+    const uint8_t* src = base_ptr + Lb.pyr_off;
+    int sstride = Lb.stride;
+    if (A.base == 0 && A.l0) { const L0Src s0 = A.l0[cam]; if (s0.ptr) { src = s0.ptr; sstride = s0.stride; } }
+    int px0 = kx * A.tw, py0 = ky * A.th;
+    int ppw = A.tw + A.halo_x, pnh = min(A.th + A.halo_y, Lb.h - py0);
+    uint8_t* cur = regions;
+    uint32_t held[T4_MAX_DW];
+    const int nw = min(A.tw + A.halo_x, Lb.w - px0);
+    const bool al = ((reinterpret_cast<uintptr_t>(src) | (unsigned)sstride) & 3u) == 0;
+    const int ndw = al ? nw >> 2 : 0, rem = nw - 4 * ndw;
+    const unsigned inv_ndw = ndw > 0 ? ((1u << 20) + ndw - 1) / ndw : 0;   // i / ndw for i < 2^20 / ndw
+#pragma unroll
+    for (int u = 0; u < T4_MAX_DW; ++u) {
+        const int i = tid + NT * u;
+        held[u] = 0;
+        if (i < ndw * pnh) {
+            const int y = (int)(__umul24((unsigned)i, inv_ndw) >> 20), k = i - (int)__umul24(y, ndw);
+            held[u] = reinterpret_cast<const uint32_t*>(src + (size_t)(py0 + y) * sstride + px0)[k];
+        }
+    }
+    if (rem > 0) {
+        const unsigned inv = ((1u << 20) + rem - 1) / rem;
+        for (int i = tid; i < rem * pnh; i += NT) {
+            const int y = (int)(__umul24((unsigned)i, inv) >> 20), x = 4 * ndw + i - (int)__umul24(y, rem);
+            cur[__umul24(y, ppw) + x] = src[(size_t)(py0 + y) * sstride + px0 + x];
+        }
+    }
+    if (tid < nrec) { s_sx[tid] = rt_x; s_sy[tid] = rt_y; s_lv[tid] = rt_v; }
+    __syncthreads();
+    if (tid == 0) {
+        int og = 0, orw = 0;
+        s_og[0] = 0; s_or[0] = 0;
+        for (int r = 1; r < nrec; ++r) {
+            s_og[r] = og; s_or[r] = orw;
+            og += max(s_sx[r].z - s_sx[r].x, 0) >> 2; orw += max(s_sy[r].z - s_sy[r].x, 0);
+        }
+        s_og[nrec] = og; s_or[nrec] = orw;
+    }
+    __syncthreads();
+    // ---- round trip 2: the table entries of every level's needed groups (3 x int4 each) and rows (int4), all requests in flight together
+    {
+        const int ng3 = 3 * s_og[nrec], nr = s_or[nrec];
+        for (int e = tid; e < ng3 + nr; e += NT) {
+            const bool isg = e < ng3;
+            const int k = isg ? e / 3 : e - ng3;
+            int r = 1;
+            while (r + 1 < nrec && k >= (isg ? s_og[r + 1] : s_or[r + 1])) ++r;
+            if (isg) gtab[e] = A.xgrp[3 * (size_t)(s_lv[r].z + (s_sx[r].x >> 2) + (k - s_og[r])) + (e - 3 * k)];
+            else rtab[k] = A.ytab[s_lv[r].w + s_sy[r].x + (k - s_or[r])];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < T4_MAX_DW; ++u) {
+        const int i = tid + NT * u;
+        if (i < ndw * pnh) { const int y = (int)(__umul24((unsigned)i, inv_ndw) >> 20), k = i - (int)__umul24(y, ndw); reinterpret_cast<uint32_t*>(cur + __umul24(y, ppw))[k] = held[u]; }
+    }
+    __syncthreads();
+    // ---- levels base + 1 .. last: the needed region of a level from the needed region of the level above it, both in LDS
+    using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
+    for (int r = 1; r < nrec; ++r) {
+        const int4 lv = s_lv[r], sx = s_sx[r], sy = s_sy[r];
+        const int x0 = sx.x, y0 = sy.x, ngn = max(sx.z - sx.x, 0) >> 2, nh = max(sy.z - sy.x, 0), pw = 4 * ngn;
+        const int ngo = (sx.y - sx.x) >> 2, oh = sy.y - sy.x;
+        if (ngn == 0 || nh == 0) break;   // (nothing of this level hangs below the tile: nothing of the next ones does either)
+        uint8_t* nxt = cur + ppw * pnh;
+        uint8_t* dst = base_ptr + lv.x + (size_t)y0 * lv.y + x0;
+        const int4* G_l = gtab + 3 * s_og[r];
+        const int4* R_l = rtab + s_or[r];
+        // A lane keeps ONE group of four columns and walks down its rows (NT / ngn rows per pass; the lanes beyond the last whole row
+        // idle): the group's table entry -- 36 bytes -- is read once per level instead of once per four pixels (it was two thirds of
+        // the loop's LDS traffic), and the index split per task is gone.
+        const unsigned inv = (unsigned)sx.w;   // 2^20 / ngn, rounded up: t / ngn for t * ngn < 2^20
+        const int ty = (int)(__umul24((unsigned)tid, inv) >> 20), g = tid - (int)__umul24(ty, ngn);
+        const int rpp = (int)(__umul24((unsigned)NT, inv) >> 20);   // rows per pass
+        if (ty < rpp) {
+            const int4 g0 = G_l[3 * g], g1 = G_l[3 * g + 1];
+            const int g2 = G_l[3 * g + 2].x;
+            const int c = g0.x - px0, sh = c & 3;
+            const uint32_t ps[4] = {(uint32_t)g0.y, (uint32_t)g0.z, (uint32_t)g0.w, (uint32_t)g1.x};
+            const uint32_t alp[4] = {(uint32_t)g1.y, (uint32_t)g1.z, (uint32_t)g1.w, (uint32_t)g2};
+            const uint32_t* colw = reinterpret_cast<const uint32_t*>(cur) + (c >> 2);
+            const bool own_g = g < ngo;
+            for (int y = ty; y < nh; y += rpp) {
+                const int4 yt = R_l[y];
+                uint32_t h[2][4];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int row = (q ? yt.y : yt.x) - py0;
+                    const uint32_t* w = colw + (__umul24(row, ppw) >> 2);   // (region pitches are multiples of four)
+                    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        h[q][j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, ps[j])), __builtin_bit_cast(u16x2, alp[j]), 0u, false);
+                }
+                uint32_t out = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t v = ((((__umul24((uint32_t)yt.z, h[0][j] >> 4)) >> 16) + ((__umul24((uint32_t)yt.w, h[1][j] >> 4)) >> 16) + 2) >> 2) & 0xff;
+                    out |= v << (8 * j);
+                }
+                reinterpret_cast<uint32_t*>(nxt + __umul24(y, pw))[g] = out;
+                if (own_g && y < oh) reinterpret_cast<uint32_t*>(dst + __umul24(y, lv.y))[g] = out;   // (columns past w: padding of the 64-byte row pitch, as k_resize_v4)
+            }
+        }
+        __syncthreads();
         cur = nxt; px0 = x0; py0 = y0; pnh = nh; ppw = pw;
     }
 }
@@ -788,7 +947,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restr
     {
         const uint8_t* src = img + (size_t)(y0 - 3) * img_stride + (x0 - 3 - sh);
         for (int i = tid; i < ndw * th; i += FAST_NT) {
-            const int ty = (int)(((unsigned)i * inv_ndw) >> 20), k = i - ty * ndw;
+            const int ty = (int)(__umul24((unsigned)i, inv_ndw) >> 20), k = i - (int)__umul24(ty, ndw);   // (24-bit multiplies: full rate, four times the 32-bit one's)
             const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (size_t)ty * img_stride + 4 * k);
             const uint32_t lo = g[0], hi = sh ? g[1] : 0u;
             reinterpret_cast<uint32_t*>(tile_raw)[ty * (TILE_PITCH / 4) + k] = __builtin_amdgcn_alignbyte(hi, lo, sh);
@@ -818,7 +977,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restr
         uint32_t m8 = 0;
         int p0 = 0;
         if (g < ngroups) {
-            const int py = (int)(((unsigned)g * inv_gpr) >> 20), gx = g - py * gpr;
+            const int py = (int)(__umul24((unsigned)g, inv_gpr) >> 20), gx = g - (int)__umul24(py, gpr);
             const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile_raw) + (py + 3) * (TILE_PITCH / 4) + (GW / 4) * gx;
             const int left = cw - GW * gx;                           // pixels of this group inside the scored rectangle
             if (narrow) {
@@ -829,7 +988,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restr
                 if (GW == 8 && left > 4) m8 |= fast_may_be_corner_x4_wide(t32 + 1, Lv.min_th + 1) >> 2;
             }
             if (gx == gpr - 1) m8 &= tail_mask;
-            p0 = py * cw + GW * gx;
+            p0 = (int)__umul24(py, cw) + GW * gx;
         }
         const int cnt = __popc(m8);
         const int incl = wave_incl_scan(cnt);
@@ -846,8 +1005,8 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restr
     const int nsurv = s_nsurv;
     for (int i = tid; 2 * i < nsurv; i += FAST_NT) {
         const int pa = s_surv[2 * i], pb = s_surv[min(2 * i + 1, nsurv - 1)];
-        const int ya = (int)(((unsigned)pa * inv_cw) >> 20), xa = pa - ya * cw;
-        const int yb = (int)(((unsigned)pb * inv_cw) >> 20), xb = pb - yb * cw;
+        const int ya = (int)(__umul24((unsigned)pa, inv_cw) >> 20), xa = pa - (int)__umul24(ya, cw);
+        const int yb = (int)(__umul24((unsigned)pb, inv_cw) >> 20), xb = pb - (int)__umul24(yb, cw);
         const uint32_t s2 = fast_score_9_16_x2(&tile[(ya + 3) * TILE_PITCH + xa + 3], &tile[(yb + 3) * TILE_PITCH + xb + 3]);
         const int sa = (int)(short)(s2 & 0xffffu), sb = (int)(short)(s2 >> 16);
         // "not a corner at minTh" stores 0, like FAST_t's zeroed score rows
@@ -862,7 +1021,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restr
     int any_ini = 0;
     for (int i = tid; i < nsurv; i += FAST_NT) {
         const int p = s_surv[i];
-        const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
+        const int py = (int)(__umul24((unsigned)p, inv_cw) >> 20), px = p - (int)__umul24(py, cw);
         const uint8_t* c = &score[(py + 1) * SCORE_PITCH + px + 1];
         const int s = c[0];
         const int m = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SCORE_PITCH - 1], (int)c[-SCORE_PITCH])),
@@ -895,7 +1054,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const LevelInfo* __restr
         if (!((wlo >> (p & 31)) & 1u)) continue;
         const unsigned below = (p & 32) ? (unsigned)__popc(bm[(p >> 5) - 1]) : 0u;   // (low half of the same 64-bit word)
         const int pos = s_pref[p >> 6] + (int)below + __popc(wlo & ((1u << (p & 31)) - 1u));
-        const int py = (int)(((unsigned)p * inv_cw) >> 20), px = p - py * cw;
+        const int py = (int)(__umul24((unsigned)p, inv_cw) >> 20), px = p - (int)__umul24(py, cw);
         const int sc = score[(py + 1) * SCORE_PITCH + px + 1];
         const int xr = x0 + px - MIN_BORDER, yr = y0 + py - MIN_BORDER;  // relative to (16,16), :821-826
         if (pos < Lv.slot_cap) slot[pos] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)sc << 24);
@@ -1513,9 +1672,10 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
             const uint8_t* pr = p0 + (size_t)(K.y - PR + g) * img_stride;
             const size_t step5 = (size_t)5 * img_stride;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
+            for (int k = 0; k < 9; ++k) {   // (the row addresses by addition: a 64-bit multiply-add per row is four passes of the vector ALU)
                 v[k] = 0;
-                if (lane < 60) __builtin_memcpy(&v[k], pr + k * step5, 4);
+                if (lane < 60) __builtin_memcpy(&v[k], pr, 4);
+                pr += step5;
             }
         } else {
 #pragma unroll
@@ -1669,7 +1829,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
         const float x0 = q.x, y0 = q.y, x1 = q.z, y1 = q.w;
         const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
-        const int t0 = centre[r0 * ROW_PITCH + c0], t1 = centre[r1 * ROW_PITCH + c1];
+        const int t0 = centre[__mul24(r0, ROW_PITCH) + c0], t1 = centre[__mul24(r1, ROW_PITCH) + c1];   // (24-bit multiply-add: one full-rate instruction)
         nib |= (t0 < t1) << j;
 #ifdef MORB_DESCRIBE_SELFCHECK
         chk_q[j] = q; chk_rc[j][0] = r0; chk_rc[j][1] = c0; chk_rc[j][2] = r1; chk_rc[j][3] = c1; chk_t[j][0] = t0; chk_t[j][1] = t1;
@@ -1985,6 +2145,16 @@ struct orbx_extractor {
     bool tiled_ok = false;            // ... and this geometry fits it (LDS, halo, level count) and is small enough to prefer it
     bool chain_v4 = false;            // the resize chain runs k_resize_v4 (level steps <= 1.6: the taps of four neighbours within 8 bytes)
     bool tiled_pyramid = true;        // MORB_TILED_PYRAMID=0: the resize chain of rounds 1-2 (k_resize2 / k_resize launches)
+    // large rigs (round 5): the pyramid as TWO tile launches with four pixels per lane (k_pyramid_tiled4): levels 1..m below level 0
+    // and levels m+1.. below level m, instead of one k_resize_v4 launch per level
+    struct TilePlan {
+        int base = 0, last = 0, tw = 0, th = 0, halo_x = 16, halo_y = 16, tx_max = 0, ty_max = 0, gcap = 0, rcap = 0, lds = 0, threads = 256;
+        short tx[64] = {}, ty[64] = {};
+        DevBuf<int4> d_sx, d_sy;
+        std::vector<int4> sx, sy;     // (host copies while the geometry is being built)
+        bool ok = false;
+    } tp[2];
+    bool tiled4 = false;              // this geometry takes the two tile launches
     DevBuf<int4> d_ytab;
     DevBuf<int> d_cell_cnt, d_cell_off;
     DevBuf<uint32_t> d_cell_items;
@@ -2209,6 +2379,126 @@ static int rebuild_geometry(orbx_extractor* ex) {
         const bool prefer_chain = ex->chain_v4 && (chain_env == 1 || (chain_env < 0 && (long long)px0 > chain_px));
         if (prefer_chain) ex->tiled_ok = false;
     }
+    // ---- large rigs: the two tile launches of k_pyramid_tiled4 (TilePlan).  Along x a tile owns whole groups of four destination
+    // columns (the group whose first tap lies in what the tile owns one level up), along y rows by their upper tap; what it needs
+    // beyond that is the taps of everything it needs one level down (rounded up to whole groups below the base).
+    ex->tiled4 = false;
+    {
+        static const int t4_env = [] { const char* e = getenv("MORB_PYR_TILED4"); return e ? atoi(e) : -1; }();
+        static const int split_env = [] { const char* e = getenv("MORB_PYR_SPLIT"); return e ? atoi(e) : 3; }();
+        static const int tw_env = [] { const char* e = getenv("MORB_PYR_T4_W"); return e ? atoi(e) : 128; }();
+        static const int th_env = [] { const char* e = getenv("MORB_PYR_T4_H"); return e ? atoi(e) : 64; }();
+        // (the second launch -- the upper levels -- may take a tile and a workgroup size of its own)
+        static const int tw1_env = [] { const char* e = getenv("MORB_PYR_T4_W1"); return e ? atoi(e) : 0; }();
+        static const int th1_env = [] { const char* e = getenv("MORB_PYR_T4_H1"); return e ? atoi(e) : 0; }();
+        static const int nt0_env = [] { const char* e = getenv("MORB_PYR_T4_NT0"); return e ? atoi(e) : 256; }();
+        static const int nt1_env = [] { const char* e = getenv("MORB_PYR_T4_NT1"); return e ? atoi(e) : 256; }();
+        int nl_max = 0;
+        for (int c = 0; c < ex->n_cams; ++c) nl_max = std::max(nl_max, ex->cams[c].p.nlevels);
+        const bool want = ex->chain_v4 && !(ex->tiled_pyramid && ex->tiled_ok) && t4_env != 0 && nl_max >= 2 && ML <= PYR_MAX_LEVELS &&
+                          tw_env >= 16 && tw_env % 4 == 0 && th_env >= 8 && ex->max_w <= 32767 && ex->max_h <= 32767;
+        const int split = std::min(std::max(split_env, 1), nl_max - 1);
+        bool all_ok = want;
+        for (int pi = 0; pi < 2 && all_ok; ++pi) {
+            orbx_extractor::TilePlan& P = ex->tp[pi];
+            P.ok = false;
+            P.base = pi == 0 ? 0 : split; P.last = pi == 0 ? split : nl_max - 1;
+            if (P.last <= P.base) { P.ok = true; P.tx_max = P.ty_max = 0; continue; }   // (nothing left for the second launch)
+            P.tw = pi == 1 && tw1_env >= 16 && tw1_env % 4 == 0 ? tw1_env : tw_env; P.th = pi == 1 && th1_env >= 8 ? th1_env : th_env; P.halo_x = 16; P.halo_y = 16;
+            P.threads = (pi == 0 ? nt0_env : nt1_env) == 512 ? 512 : 256;
+            P.tx_max = P.ty_max = 1; P.gcap = P.rcap = 0; P.lds = 0;
+            for (int c = 0; c < ex->n_cams; ++c) {
+                const LevelInfo& Lb = ex->levels[(size_t)c * ML + P.base];
+                P.tx[c] = (short)(Lb.w > 0 ? (Lb.w + P.tw - 1) / P.tw : 0); P.ty[c] = (short)(Lb.w > 0 ? (Lb.h + P.th - 1) / P.th : 0);
+                P.tx_max = std::max<int>(P.tx_max, P.tx[c]); P.ty_max = std::max<int>(P.ty_max, P.ty[c]);
+            }
+            P.sx.assign((size_t)ex->n_cams * ML * P.tx_max, make_int4(0, 0, 0, 0));
+            P.sy.assign((size_t)ex->n_cams * ML * P.ty_max, make_int4(0, 0, 0, 0));
+            bool ok = true;
+            int need_x = P.tw, need_y = P.th;   // what a tile needs of the base level, at most (the staged block: tile + halo)
+            for (int c = 0; c < ex->n_cams && ok; ++c) {
+                if (P.tx[c] == 0) continue;
+                const int NL = std::min(ex->cams[c].p.nlevels - 1, P.last);   // last level this camera has inside the plan
+                auto LV = [&](int l) -> const LevelInfo& { return ex->levels[(size_t)c * ML + l]; };
+                // x: boundaries in pixels, multiples of four below the base
+                {
+                    const int nt = P.tx[c];
+                    std::vector<std::vector<int> > b(ML, std::vector<int>(nt + 1, 0));
+                    for (int k = 0; k <= nt; ++k) b[P.base][k] = std::min(k * P.tw, LV(P.base).w);
+                    for (int l = P.base + 1; l <= NL; ++l) {
+                        const int G = (LV(l).w + 3) / 4;
+                        int g = 0;
+                        for (int k = 0; k <= nt; ++k) {
+                            while (g < G && (xt[LV(l).xtab_off + 4 * g].x & 0xffff) < b[l - 1][k]) ++g;
+                            b[l][k] = k == nt ? 4 * G : 4 * g;
+                        }
+                    }
+                    for (int k = 0; k < nt; ++k) {
+                        int n1 = b[NL][k + 1];
+                        for (int l = NL; l >= P.base; --l) {
+                            const int ngn = l > P.base ? std::max(n1 - b[l][k], 0) / 4 : 0;
+                            P.sx[((size_t)c * ML + l) * P.tx_max + k] = make_int4(b[l][k], b[l][k + 1], n1, ngn > 0 ? (int)(((1u << 20) + ngn - 1) / ngn) : 0);
+                            if (l == P.base) { need_x = std::max(need_x, n1 - b[l][k]); break; }
+                            // what level l - 1 must hold: its own run, and the right tap of the last column this level needs (padding
+                            // columns repeat the level's last one)
+                            int up = b[l - 1][k + 1];
+                            if (n1 > b[l][k]) up = std::max(up, (int)((unsigned)xt[LV(l).xtab_off + std::min(n1 - 1, LV(l).w - 1)].x >> 16) + 1);
+                            n1 = l - 1 > P.base ? std::min((up + 3) & ~3, 4 * ((LV(l - 1).w + 3) / 4)) : up;
+                        }
+                    }
+                }
+                // y: rows
+                {
+                    const int nt = P.ty[c];
+                    std::vector<std::vector<int> > b(ML, std::vector<int>(nt + 1, 0));
+                    for (int k = 0; k <= nt; ++k) b[P.base][k] = std::min(k * P.th, LV(P.base).h);
+                    for (int l = P.base + 1; l <= NL; ++l) {
+                        int d = 0;
+                        for (int k = 0; k <= nt; ++k) {
+                            while (d < LV(l).h && yt[LV(l).ytab_off + d].x < b[l - 1][k]) ++d;
+                            b[l][k] = k == nt ? LV(l).h : d;
+                        }
+                    }
+                    for (int k = 0; k < nt; ++k) {
+                        int n1 = b[NL][k + 1];
+                        for (int l = NL; l >= P.base; --l) {
+                            P.sy[((size_t)c * ML + l) * P.ty_max + k] = make_int4(b[l][k], b[l][k + 1], n1, 0);
+                            if (l == P.base) { need_y = std::max(need_y, n1 - b[l][k]); break; }
+                            int up = b[l - 1][k + 1];
+                            if (n1 > b[l][k]) up = std::max(up, yt[LV(l).ytab_off + n1 - 1].y + 1);
+                            n1 = up;
+                        }
+                    }
+                }
+            }
+            P.halo_x = ((need_x - P.tw + 3) & ~3); P.halo_y = need_y - P.th;
+            // what a workgroup holds in LDS: the staged base block, the regions of its levels, the table entries of their groups and rows
+            for (int c = 0; c < ex->n_cams && ok; ++c) {
+                if (P.tx[c] == 0) continue;
+                const int NL = std::min(ex->cams[c].p.nlevels - 1, P.last);
+                for (int ky = 0; ky < P.ty[c]; ++ky)
+                    for (int kx = 0; kx < P.tx[c]; ++kx) {
+                        int bytes = (P.tw + P.halo_x) * (P.th + P.halo_y), ng = 0, nr = 0;
+                        for (int l = P.base + 1; l <= NL; ++l) {
+                            const int4 X = P.sx[((size_t)c * ML + l) * P.tx_max + kx], Y = P.sy[((size_t)c * ML + l) * P.ty_max + ky];
+                            const int w = std::max(X.z - X.x, 0), h = std::max(Y.z - Y.x, 0);
+                            if ((long long)(w / 4) * h * (w / 4) >= (1 << 20)) ok = false;   // (index split by multiplication: tasks x groups < 2^20)
+                            bytes += w * h; ng += w / 4; nr += h;
+                        }
+                        P.lds = std::max(P.lds, bytes); P.gcap = std::max(P.gcap, ng); P.rcap = std::max(P.rcap, nr);
+                    }
+            }
+            P.gcap = std::max(P.gcap, 1); P.rcap = std::max(P.rcap, 1);
+            P.lds += P.gcap * 48 + P.rcap * 16 + 32;
+            if (P.lds > 64 * 1024 || (P.tw + P.halo_x) / 4 * (P.th + P.halo_y) > T4_MAX_DW * P.threads || (P.halo_x & 3)) ok = false;
+            P.ok = ok;
+            all_ok = all_ok && ok;
+            static const bool dbg = getenv("MORB_PYR_T4_DEBUG") != nullptr;
+            if (dbg) fprintf(stderr, "tile plan %d: levels %d..%d below %d, %d threads, tile %d x %d + halo %d x %d, %d x %d tiles, LDS %d B (%d groups, %d rows of tables): %s\n",
+                             pi, P.base + 1, P.last, P.base, P.threads, P.tw, P.th, P.halo_x, P.halo_y, P.tx_max, P.ty_max, P.lds, P.gcap, P.rcap, ok ? "ok" : "refused");
+        }
+        ex->tiled4 = all_ok;
+    }
     {
         static const bool l0_env = [] { const char* e = getenv("MORB_L0_INPLACE"); return !(e && atoi(e) == 0); }();
         // (only the one-level-per-launch chain of k_resize_v4 knows the table: the paired launches of small rigs -- k_resize2 -- and
@@ -2270,6 +2560,14 @@ static int rebuild_geometry(orbx_extractor* ex) {
     if (!yt.empty()) MORB_HIP(hipMemcpyAsync(ex->d_ytab.p, yt.data(), yt.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
     if (!psx.empty()) MORB_HIP(hipMemcpyAsync(ex->d_pyr_sx.p, psx.data(), psx.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
     if (!psy.empty()) MORB_HIP(hipMemcpyAsync(ex->d_pyr_sy.p, psy.data(), psy.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
+    for (int pi = 0; pi < 2 && ex->tiled4; ++pi) {
+        orbx_extractor::TilePlan& P = ex->tp[pi];
+        if (P.sx.empty() || P.sy.empty()) continue;
+        int rc_p;
+        if ((rc_p = P.d_sx.reserve(P.sx.size())) || (rc_p = P.d_sy.reserve(P.sy.size()))) return rc_p;
+        MORB_HIP(hipMemcpyAsync(P.d_sx.p, P.sx.data(), P.sx.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
+        MORB_HIP(hipMemcpyAsync(P.d_sy.p, P.sy.data(), P.sy.size() * sizeof(int4), hipMemcpyHostToDevice, ex->stream));
+    }
     MORB_HIP(hipStreamSynchronize(ex->stream));  // xt / yt are locals
     ex->tables_dirty = false;
     return ORB_OK;
@@ -2385,6 +2683,7 @@ void orbx_destroy(orbx_extractor* ex) {
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     for (int sl = 0; sl < 2; ++sl) for (int w = 0; w < orbx_extractor::CHAIN_WAYS; ++w) ex->chain[sl][w].destroy();
     ex->d_l0.release(); ex->d_pyr.release(); ex->d_levels.release(); ex->d_cell_map.release(); ex->d_xtab.release(); ex->d_xgrp.release(); ex->d_desc_tabs.release(); ex->d_ytab.release(); ex->d_pyr_sx.release(); ex->d_pyr_sy.release();
+    for (auto& P : ex->tp) { P.d_sx.release(); P.d_sy.release(); }
     ex->d_cell_cnt.release(); ex->d_cell_off.release(); ex->d_cell_items.release(); ex->d_sel.release(); ex->d_sel_oct.release();
     ex->d_cand_dev.release(); ex->d_level_cnt_dev.release(); ex->d_sel_cnt.release(); ex->d_oct_status.release();
     ex->d_n_out.release(); ex->d_slot_blk.release();
@@ -2504,6 +2803,21 @@ int orbx_debug_level0_in_place(const orbx_extractor* ex) {
     int n = 0;
     if (ex->l0_active) for (int c = 0; c < ex->n_cams; ++c) n += ex->l0_host[c].ptr != nullptr;
     return n;
+}
+
+// 0 one tile launch (k_pyramid_tiled), 1 one k_resize_v4 launch per level, 2 the round-1 chain (k_resize2 / k_resize), 3 two tile
+// launches with four pixels per lane (k_pyramid_tiled4); the geometry of the most recent run
+int orbx_debug_pyramid_form(const orbx_extractor* ex) {
+    if (!ex) return ORB_E_ARG;
+    if (ex->tables_dirty) return -1;
+    if (ex->tiled_pyramid && ex->tiled_ok) return 0;
+    static const bool pairs_env = [] { const char* e = getenv("MORB_PYRAMID_PAIRS"); return !(e && atoi(e) == 0); }();
+    long long level1_px = 0;
+    if (ex->max_levels > 1) for (int c = 0; c < ex->n_cams; ++c) { const LevelInfo& Lv = ex->levels[(size_t)c * ex->max_levels + 1]; level1_px += (long long)Lv.w * Lv.h; }
+    const bool pairs = pairs_env && level1_px <= (1ll << 20);
+    if (pairs) return 2;
+    if (ex->tiled4) return 3;
+    return ex->chain_v4 ? 1 : 2;
 }
 
 int orbx_set_profiling(orbx_extractor* ex, int on) {
@@ -2653,6 +2967,20 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestA
             *mw = std::max(*mw, Lv.w); *mh = std::max(*mh, Lv.h);
         }
     };
+    if (ex->tiled4 && !pairs) {
+        for (int pi = 0; pi < 2; ++pi) {
+            const orbx_extractor::TilePlan& P = ex->tp[pi];
+            if (P.last <= P.base || P.tx_max == 0) continue;
+            Tile4Args T;
+            T.L = (const LevelInfo*)ex->d_levels.p; T.pyr = ex->d_pyr.p; T.cam_pitch = ex->cam_pitch; T.xgrp = (const int4*)ex->d_xgrp.p;
+            T.ytab = (const int4*)ex->d_ytab.p; T.sx = (const int4*)P.d_sx.p; T.sy = (const int4*)P.d_sy.p; T.l0 = l0_table(ex);
+            T.max_levels = ML; T.base = P.base; T.last = P.last; T.tw = P.tw; T.th = P.th; T.halo_x = P.halo_x; T.halo_y = P.halo_y;
+            T.tx_max = P.tx_max; T.ty_max = P.ty_max; T.gcap = P.gcap; T.rcap = P.rcap;
+            for (int c = 0; c < 64; ++c) { T.tx[c] = c < ex->n_cams ? P.tx[c] : 0; T.ty[c] = c < ex->n_cams ? P.ty[c] : 0; }
+            if (P.threads == 512) hipLaunchKernelGGL(k_pyramid_tiled4<512>, dim3(P.tx_max, P.ty_max, ex->n_cams), dim3(512), (size_t)P.lds, st, T);
+            else hipLaunchKernelGGL(k_pyramid_tiled4<256>, dim3(P.tx_max, P.ty_max, ex->n_cams), dim3(256), (size_t)P.lds, st, T);
+        }
+    } else
     for (int l = 1; l < ML; l += pairs ? 2 : 1) {
         int mw = 0, mh = 0, mw2 = 0, mh2 = 0;
         level_dims(l, &mw, &mh);

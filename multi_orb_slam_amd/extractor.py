@@ -151,6 +151,10 @@ class Extractor:
         """0 device quadtree, 1 device quadtree incl. the memory-backed pass, 2 host quadtree (orbx_debug_last_path)."""
         return _lib.lib().orbx_debug_last_path(self._h)
 
+    def pyramid_form(self):
+        """0 k_pyramid_tiled, 1 k_resize_v4 per level, 2 k_resize2 / k_resize, 3 k_pyramid_tiled4 x 2 (orbx_debug_pyramid_form)"""
+        return _lib.lib().orbx_debug_pyramid_form(self._h)
+
     def level0_in_place(self):
         """cameras whose level 0 the last run read in the caller's device buffer (orbx_debug_level0_in_place)"""
         return _lib.lib().orbx_debug_level0_in_place(self._h)

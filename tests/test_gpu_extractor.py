@@ -30,6 +30,8 @@ def test_stages_and_end_to_end(w, h, nf):
     ex = _mk([p], w, h)
     img = synth.image(0, 0, w, h)
     kps, desc = ex(img)
+    if os.environ.get("MORB_EXPECT_PYRAMID_FORM"):   # (a child of test_resize_chain_form_...: the form it was asked to force did run)
+        assert ex.pyramid_form() == int(os.environ["MORB_EXPECT_PYRAMID_FORM"])
     # K1: every pyramid level
     for l, ref in enumerate(oracle.pyramid(img)):
         got = ex.debug_level(0, l)
@@ -273,14 +275,30 @@ def test_a_level_the_reference_leaves_undefined_still_runs():
         oracle.extract(synth.image(3, 0, 333, 777), nfeatures=600)
 
 
-def test_resize_chain_form_equals_the_oracle_at_every_size():
-    """Large rigs build their pyramid with one k_resize_v4 launch per level (four pixels per lane from a per-group table of byte
-    selectors and coefficient pairs) instead of the one-launch tile kernel; the arrangement is chosen once per process, so the stage
-    tests of this file -- every level byte for byte, odd sizes included -- run once more in a child with the chain forced at their sizes."""
+# The forms a large rig's pyramid can take, forced at the sizes of this file's stage tests (the arrangement is chosen once per process, so
+# each form runs them in a child): the round-3 chain (one k_resize_v4 launch per level), the round-5 tile launches (k_pyramid_tiled4: levels
+# 1..3 below level 0 and 4.. below level 3 in 128 x 64 tiles), the same with tiles so small that every image is dozens of them with
+# ragged last rows and columns, and with the split after level 1 / level 5 / beyond the last level (one launch does everything).
+PYRAMID_FORMS = {
+    "chain_v4": (1, {"MORB_PYR_TILED4": "0"}),
+    "tiled4": (3, {}),
+    "tiled4_small_tiles": (3, {"MORB_PYR_T4_W": "32", "MORB_PYR_T4_H": "16"}),
+    "tiled4_wide_tiles_split1": (3, {"MORB_PYR_T4_W": "256", "MORB_PYR_T4_H": "24", "MORB_PYR_SPLIT": "1"}),
+    "tiled4_split5": (3, {"MORB_PYR_SPLIT": "5", "MORB_PYR_T4_W": "64", "MORB_PYR_T4_H": "64"}),
+    "tiled4_one_launch": (3, {"MORB_PYR_SPLIT": "99", "MORB_PYR_T4_W": "64", "MORB_PYR_T4_H": "32"}),
+}
+
+
+@pytest.mark.parametrize("form", sorted(PYRAMID_FORMS))
+def test_resize_chain_form_equals_the_oracle_at_every_size(form):
+    """Large rigs build their pyramid with four pixels per lane from a per-group table of byte selectors and coefficient pairs instead of
+    the one-launch tile kernel of small rigs; the stage tests of this file -- every level byte for byte, odd sizes included -- run once
+    more in a child with each form of that forced at their sizes (MORB_EXPECT_PYRAMID_FORM makes the child check which one ran)."""
     import subprocess, sys
-    env = dict(os.environ, MORB_PYR_CHAIN="1", MORB_PYRAMID_PAIRS="0")
+    want, extra = PYRAMID_FORMS[form]
+    env = dict(os.environ, MORB_PYR_CHAIN="1", MORB_PYRAMID_PAIRS="0", MORB_EXPECT_PYRAMID_FORM=str(want), **extra)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "stages_and_end_to_end or mixed_sizes or larger_configs or odd_parameter"],
+                        "-k", "stages_and_end_to_end or mixed_sizes or larger_configs or odd_parameter or image_families"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     tail = r.stdout.decode()[-2000:]
     assert r.returncode == 0 and " passed" in tail, tail
