@@ -134,7 +134,7 @@ struct orbf_frontend {
     std::vector<float> scale_factors;
     std::chrono::steady_clock::time_point t_entry;
     // MORB_HOST_TIMELINE=1: where orbf_step_begin spends its host time (sums, printed by orbf_destroy)
-    bool timeline = false; double tl_us[6] = {0, 0, 0, 0, 0, 0}; long tl_n = 0;
+    bool timeline = false; double tl_us[6] = {0, 0, 0, 0, 0, 0}; long tl_n = 0, tl_not_done = 0, tl_queried = 0;
     std::chrono::steady_clock::time_point tl_t;
 };
 
@@ -194,8 +194,9 @@ int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int 
 void orbf_destroy(orbf_frontend* f) {
     if (f && f->timeline && f->tl_n > 0)
         fprintf(stderr, "orbf host timeline over %ld steps, us per step: extraction / in-flight check %.2f, queries %.2f, frame + event %.2f, "
-                        "search launches %.2f, side work + events %.2f, prefetch enqueue %.2f\n", f->tl_n, f->tl_us[0] / f->tl_n,
-                f->tl_us[1] / f->tl_n, f->tl_us[2] / f->tl_n, f->tl_us[3] / f->tl_n, f->tl_us[4] / f->tl_n, f->tl_us[5] / f->tl_n);
+                        "search launches %.2f, side work + events %.2f, prefetch enqueue %.2f; extraction not known complete at the step's begin %ld times "
+                        "(asked then: %ld), still running %ld times\n", f->tl_n, f->tl_us[0] / f->tl_n,
+                f->tl_us[1] / f->tl_n, f->tl_us[2] / f->tl_n, f->tl_us[3] / f->tl_n, f->tl_us[4] / f->tl_n, f->tl_us[5] / f->tl_n, f->tl_queried, f->tl_queried, f->tl_not_done);
     if (!f) return;
     (void)hipSetDevice(f->device);
     if (f->xcomm) (void)orbf_exchange_shutdown(f);
@@ -921,10 +922,11 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     // The export block of this step is final already when its extraction chain has completed cleanly (the usual case with
     // steps announced ahead): then nothing of this step can be redone and a caller may ship the block right away.
     P.block_ready = false;
+    if (f->timeline && P.async_path && !P.inline_match && !P.ext_done) ++f->tl_queried;
     if (P.async_path && !P.inline_match && (P.ext_done || hipEventQuery(f->ev_ready[P.set]) == hipSuccess)) {
         P.ext_done = true;   // (the matcher's stream then needs no event wait in front of the search: step_enqueue)
         P.block_ready = orbx_peek_status(f->exs[P.e]) == 0;
-    } else { P.ext_done = false; (void)hipGetLastError(); }
+    } else { P.ext_done = false; (void)hipGetLastError(); if (f->timeline) ++f->tl_not_done; }
     if ((rc = step_enqueue(f, P, true))) return rc;
     P.active = true;
     if (block_ready) *block_ready = P.block_ready ? 1 : 0;
