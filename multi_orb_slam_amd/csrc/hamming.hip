@@ -238,7 +238,15 @@ __device__ __forceinline__ uint32_t mm_pack2(int d0, int d1) {
     return __builtin_bit_cast(uint32_t, p);
 }
 
-__global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_matrix_mfma(const uint32_t* __restrict__ q, int nq,
+// The matrix instructions take their accumulators in ordinary vector registers.  With a launch bound of 256 threads alone the compiler
+// assumes one wave per SIMD may want more than 256 registers, puts the accumulators into the AccVGPR half of the file and moves every result
+// across with v_accvgpr_read before the vector ALU can touch it -- one extra instruction per key (128-160 per tile step in these kernels:
+// a third of k_cross_top2_mfma's vector instructions, round 5 counters).  Promising two waves per SIMD caps the budget at 256 registers,
+// the accumulators stay where the min / med3 chain reads them, and the kernels need fewer registers in total (180 -> 148, 240 -> 168:
+// three waves per SIMD instead of two).
+#define MORB_MFMA_IN_VGPRS __attribute__((amdgpu_waves_per_eu(2)))
+
+__global__ __launch_bounds__(64 * MM_WAVES) MORB_MFMA_IN_VGPRS void k_hamming_matrix_mfma(const uint32_t* __restrict__ q, int nq,
                                                                       const uint32_t* __restrict__ r, int nr,
                                                                       uint16_t* __restrict__ out, int tiles_per_block) {
     __shared__ mm_i32x4 s_tile[2][2 * 8 * 64];   // [buffer][(reference group, ks, lane)]: 2 x 16 KB
@@ -563,7 +571,7 @@ __device__ __forceinline__ void mt_step(typename Mt<FP4>::Acc (&nxt)[2], const m
 }
 
 template <bool FP4>
-__global__ __launch_bounds__(64 * MM_WAVES) void k_hamming_top2_mfma(const uint32_t* __restrict__ q, int nq,
+__global__ __launch_bounds__(64 * MM_WAVES) MORB_MFMA_IN_VGPRS void k_hamming_top2_mfma(const uint32_t* __restrict__ q, int nq,
                                                                     const uint32_t* __restrict__ r, int nr, int slice_len,
                                                                     int* __restrict__ p_idx, int* __restrict__ p_best,
                                                                     int* __restrict__ p_second) {
@@ -845,7 +853,7 @@ __device__ __forceinline__ void cross_top2_mfma_body(mm_i32x4 (&s_tile)[2][2 * M
 __host__ __device__ inline int cross_query_blocks(int nq, int n_cams) { return (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK + n_cams; }
 
 template <bool FP4>
-__global__ __launch_bounds__(64 * MM_WAVES) void k_cross_top2_mfma(const uint32_t* __restrict__ desc, int n_total,
+__global__ __launch_bounds__(64 * MM_WAVES) MORB_MFMA_IN_VGPRS void k_cross_top2_mfma(const uint32_t* __restrict__ desc, int n_total,
                                                                   const int* __restrict__ cam_start, int n_cams, int q_off, int nq,
                                                                   int slice_len, int* __restrict__ p_idx, int* __restrict__ p_best,
                                                                   int* __restrict__ p_second, const int* __restrict__ d_range) {
@@ -869,7 +877,7 @@ struct SideArgs {
     morb::MirrorJob mirror;
 };
 template <bool FP4>
-__global__ __launch_bounds__(64 * MM_WAVES) void k_project_side(morb::ProjectArgs P, SideArgs X) {
+__global__ __launch_bounds__(64 * MM_WAVES) MORB_MFMA_IN_VGPRS void k_project_side(morb::ProjectArgs P, SideArgs X) {
     __shared__ mm_i32x4 s_tile[2][2 * Mt<FP4>::KS * 64];
     const int b = blockIdx.x;
     if (b < X.n_cross) {
