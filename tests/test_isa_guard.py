@@ -79,6 +79,58 @@ def test_no_packed_f32_arithmetic_in_any_kernel(tmp_path):
     assert sum(i.startswith("global_load_dwordx4") for i in desc) >= 4
 
 
+def kernel_descriptors(co):
+    """{kernel symbol: its 64-byte kernel descriptor} out of one gfx950 code object (ELF64 little endian): the `<kernel>.kd` symbols."""
+    shoff, = struct.unpack_from("<Q", co, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", co, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", co, shoff + i * shentsize) for i in range(shnum)]   # name, type, flags, addr, offset, size, link, info, align, entsize
+    out = {}
+    for name, typ, flags, addr, off, size, link, info, align, entsize in secs:
+        if typ != 2 or not entsize:   # SHT_SYMTAB
+            continue
+        stroff = secs[link][4]
+        for k in range(size // entsize):
+            st_name, st_info, st_other, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", co, off + k * entsize)
+            end = co.index(b"\0", stroff + st_name)
+            sym = co[stroff + st_name:end].decode()
+            if not sym.endswith(".kd") or st_shndx == 0 or st_shndx >= shnum:
+                continue
+            sec = secs[st_shndx]
+            fo = sec[4] + (st_value - sec[3])
+            out[sym[:-3]] = co[fo:fo + 64]
+    return out
+
+
+def test_fast_kernels_keep_f16_denormals():
+    # k_fast_cells takes three-input extrema of 0..255 held in 16-bit lanes with v_pk_minimum3_f16 / v_pk_maximum3_f16: as f16 those are
+    # denormals, and the instructions return them unchanged only while the kernel runs with f16 denormals preserved
+    # (compute_pgm_rsrc1.FLOAT_DENORM_MODE_16_64 = 3: bits 19:18 of the dword at offset 48 of the kernel descriptor)
+    seen = 0
+    for co in code_objects(m.LIB_PATH):
+        for name, kd in kernel_descriptors(co).items():
+            if "k_fast_cells" not in name:
+                continue
+            rsrc1, = struct.unpack_from("<I", kd, 48)
+            assert (rsrc1 >> 18) & 3 == 3, (name, hex(rsrc1))
+            seen += 1
+    assert seen >= 2   # <128, 8> and <256, 4>
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="no llvm-objdump in this image")
+def test_fast_kernels_use_the_packed_three_input_extrema_and_matrix_kernels_no_accvgpr_moves(tmp_path):
+    kernels = disassemble(tmp_path)
+    fast = [v for k, v in kernels.items() if "k_fast_cells" in k]
+    assert len(fast) >= 2
+    for ins in fast:
+        assert sum(i.startswith("v_pk_minimum3_f16") for i in ins) >= 30 and sum(i.startswith("v_pk_maximum3_f16") for i in ins) >= 30
+        assert sum(i.startswith("v_mul_lo_u32") for i in ins) <= 6   # (index splits are 24-bit multiplies: csrc/extractor.hip)
+    # the matrix instructions' accumulators live in ordinary vector registers (MORB_MFMA_IN_VGPRS): no v_accvgpr_read per key
+    mfma = {k: v for k, v in kernels.items() if any(i.startswith("v_mfma") for i in v)}
+    assert len(mfma) >= 7
+    for k, ins in mfma.items():
+        assert not any(i.startswith("v_accvgpr") for i in ins), k
+
+
 def test_required_flags_survive_a_callers_hipflags():
     # `make -n HIPFLAGS=-O2` must still compile with the flags results depend on
     csrc = os.path.join(ROOT, "multi_orb_slam_amd", "csrc")
