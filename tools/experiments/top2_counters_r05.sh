@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters of the exhaustive top-2 kernel (M1, FP4 form, Q = R = 32 000): where do a wave's cycles go?
 # usage (on the GPU box): bash tools/top2_counters.sh      -> gpurun_out/top2_counters.txt
-R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/top2_counters; rm -rf $O; mkdir -p $O
+R=$(cd "$(dirname "$0")/../.." && pwd); O=$R/gpurun_out/top2_counters; rm -rf $O; mkdir -p $O
 cat > $O/run.py <<PY
 import os, sys
 sys.path.insert(0, "$R")
