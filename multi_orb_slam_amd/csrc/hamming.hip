@@ -240,10 +240,10 @@ __device__ __forceinline__ uint32_t mm_pack2(int d0, int d1) {
 
 // The matrix instructions take their accumulators in ordinary vector registers.  With a launch bound of 256 threads alone the compiler
 // assumes one wave per SIMD may want more than 256 registers, puts the accumulators into the AccVGPR half of the file and moves every result
-// across with v_accvgpr_read before the vector ALU can touch it -- one extra instruction per key (128-160 per tile step in these kernels:
-// a third of k_cross_top2_mfma's vector instructions, round 5 counters).  Promising two waves per SIMD caps the budget at 256 registers,
-// the accumulators stay where the min / med3 chain reads them, and the kernels need fewer registers in total (180 -> 148, 240 -> 168:
-// three waves per SIMD instead of two).
+// across with v_accvgpr_read before the vector ALU can touch it (128-160 moves per tile step in these kernels, 180 registers instead of 148
+// for the FP4 top-2, 240 instead of 168 for the distance matrix: two waves per SIMD instead of three).  Promising two waves per SIMD caps the
+// budget at 256 registers and the compiler selects the VGPR form.  (Rounds 2-4 got the same code through `-mllvm -amdgpu-mfma-vgpr-form` in
+// the Makefile; said here it holds however the file is built, and tests/test_isa_guard.py checks the result.)
 #define MORB_MFMA_IN_VGPRS __attribute__((amdgpu_waves_per_eu(2)))
 
 __global__ __launch_bounds__(64 * MM_WAVES) MORB_MFMA_IN_VGPRS void k_hamming_matrix_mfma(const uint32_t* __restrict__ q, int nq,
