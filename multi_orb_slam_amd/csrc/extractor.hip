@@ -1221,6 +1221,7 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                                                  const uint32_t* __restrict__ cell_items, SelKp* __restrict__ sel,
                                                  int* __restrict__ sel_cnt, int* __restrict__ status, int max_levels,
                                                  int max_keys) {
+    MORB_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) unsigned char oct_raw[];
     OctLds& L = *reinterpret_cast<OctLds*>(oct_raw);
     const int blk = blockIdx.x, tid = threadIdx.x;

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void k_frame_fill(const CamFeat* __restrict__ 
                                                     float* __restrict__ ang, orb_keypoint* __restrict__ kps_g,
                                                     uint4* __restrict__ desc_g, int* __restrict__ cell_of,
                                                     int* __restrict__ cell_cnt, HostMirror hm, const int* __restrict__ n_dev) {
+    MORB_LATENCY_KERNEL_WIDE();
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (n_dev) n_total = *n_dev;  // counts only known on the device: the launch was sized for the capacity
     if (g >= n_total) return;
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
                                                             orb_keypoint* __restrict__ kps_g, uint4* __restrict__ desc_g,
                                                             int* __restrict__ cell_start, int* __restrict__ items, HostMirror hm,
                                                             const int* __restrict__ cell_of_in, int desc_rows, StagedFill staged) {
+    MORB_LATENCY_KERNEL();
     // cell_of_in != NULL: the per-feature arrays and the cells were already written by the extractor's describe kernel
     // (FrameSink); only the counts, the grid and its item lists are produced here.
     extern __shared__ __attribute__((aligned(16))) int s_cells[];  // [ncell + 1] start | [ncell + 1] cursor | u16 items[8192]
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(1024) void k_frame_build_small(CamFeat4 cams4, int*
 // {features, first query, queries} triple and the count trailer of the descriptor block, from the extractor's counts.
 __global__ void k_cams_from_counts(CamFeat* __restrict__ cams, int n_cams, const int* __restrict__ d_counts,
                                    int* __restrict__ cam_start, int* __restrict__ range, int* __restrict__ trailer) {
+    MORB_LATENCY_KERNEL();
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int base = 0;
     for (int c = 0; c < n_cams; ++c) {
@@ -245,6 +248,7 @@ __global__ void k_cams_from_counts(CamFeat* __restrict__ cams, int n_cams, const
 
 // exclusive scan of cnt[0..n) into start[0..n], single 1024-thread block; cursor = copy of start
 __global__ __launch_bounds__(1024) void k_scan_cells(const int* cnt, int n, int* __restrict__ start, int* cursor) {
+    MORB_LATENCY_KERNEL();
     // cnt and cursor may alias (the per-cell counters are turned into insert cursors in place).
     // Every wave owns one contiguous run of cells and walks it 64 cells at a time (coalesced; round 2 gave every THREAD a run
     // of its own: 24 dependent, uncoalesced loads per thread for an 8-camera frame, twice -- 48 us).
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const int* cnt, int n, int*
 
 __global__ __launch_bounds__(256) void k_scatter_cells(const int* __restrict__ cell_of, int n_total, int* __restrict__ cursor,
                                                        int* __restrict__ items, const int* __restrict__ n_dev) {
+    MORB_LATENCY_KERNEL_WIDE();
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (n_dev) n_total = *n_dev;
     if (g >= n_total) return;
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(256) void k_scatter_cells(const int* __restrict__ c
 
 // ascending global index inside every cell (the atomics above scatter in arbitrary order; cells hold a handful of items)
 __global__ __launch_bounds__(256) void k_sort_cells(const int* __restrict__ start, int ncell, int* __restrict__ items) {
+    MORB_LATENCY_KERNEL_WIDE();
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= ncell) return;
     const int s = start[c], e = start[c + 1];

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(64 * TOP2_WAVES) void k_hamming_top2(const uint4* _
 __global__ void k_top2_merge(const int* __restrict__ p_idx, const int* __restrict__ p_best,
                              const int* __restrict__ p_second, int S, int nq, int* __restrict__ best_idx,
                              int* __restrict__ best_dist, int* __restrict__ second_dist, const int* __restrict__ d_range = nullptr) {
+    MORB_LATENCY_KERNEL_WIDE();
     if (d_range) nq = d_range[2];  // partial arrays are laid out with stride nq: the producer used the same device count
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;

@@ -18,6 +18,20 @@
 #endif
 
 #ifdef __HIPCC__
+// Kernels that are a handful of workgroups walking a chain of dependent steps (the quadtree, the resolves, the small-rig frame assembly, the
+// cell scan) run next to launches that fill every wave slot of the chip; their waves ask for the SIMD's issue slots first (s_setprio 3).
+// Measured on one box, three alternating runs each (tools/experiments/prio_ab.sh, profiles/r05/notes_experiments.md): configs[1] +2.1 % inside
+// the library (+3.3 % through the binding), configs[4] unchanged.  The same on the WIDE latency kernels (k_project, k_frame_fill, the cell
+// scatter / sort, k_rs_reject / k_rs_write, k_top2_merge: thousands of waves) costs configs[4] 1.9 % and gives configs[1] nothing: off.
+// Compile time: MORB_WAVE_PRIO=0 nobody, MORB_WAVE_PRIO_WIDE=3 the wide ones as well.
+#ifndef MORB_WAVE_PRIO
+#define MORB_WAVE_PRIO 3
+#endif
+#define MORB_LATENCY_KERNEL() do { if (MORB_WAVE_PRIO) __builtin_amdgcn_s_setprio(MORB_WAVE_PRIO); } while (0)
+#ifndef MORB_WAVE_PRIO_WIDE
+#define MORB_WAVE_PRIO_WIDE 0
+#endif
+#define MORB_LATENCY_KERNEL_WIDE() do { if (MORB_WAVE_PRIO_WIDE) __builtin_amdgcn_s_setprio(MORB_WAVE_PRIO_WIDE); } while (0)
 // Wave64 inclusive prefix sums on the DPP lanes-shift path (row_shr 1/2/4/8, then row_bcast 15 and 31): six VALU-rate
 // steps instead of six ds_bpermute round trips per __shfl_up scan.  Every lane of the wave must be active.
 template <int CTRL, int ROW_MASK>

@@ -27,6 +27,7 @@ using namespace morb;
 
 namespace {
 __global__ __launch_bounds__(256) void k_project(ProjectArgs A) {
+    MORB_LATENCY_KERNEL_WIDE();
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (qi >= A.nq) return;
     project_wave(A, qi, threadIdx.x & 63);
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
                                                        const float* __restrict__ f_angle, int th_high, int check_ori, int max_it,
                                                        const int* __restrict__ topk, int* __restrict__ match_of_feature,
                                                        int* __restrict__ status, int tagb, MergeJob MJ) {
+    MORB_LATENCY_KERNEL();
     // Workgroups behind the first one (isolated steps only) merge the slice partials of the camera-pair top-2 that rode in the projection's
     // launch: the resolve does not need them, the step does -- one kernel and one kernel boundary less between projection and resolve.
     if (blockIdx.x > 0) {
@@ -921,6 +923,7 @@ __global__ __launch_bounds__(256) void k_rs_owner(const orbm_query* __restrict__
 __global__ __launch_bounds__(256) void k_rs_reject(const orbm_query* __restrict__ q, int nq, int cap, const int* __restrict__ choice,
                                                    const float* __restrict__ f_angle, int* __restrict__ owner,
                                                    int* __restrict__ state) {
+    MORB_LATENCY_KERNEL_WIDE();
     if (state[0] > cap || state[8 + state[5] - 1] != 0) return;
     __shared__ int s_keep[3];
     if (threadIdx.x == 0) {  // reference src/ORBmatcher.cc:3948-3989
@@ -959,6 +962,7 @@ __global__ __launch_bounds__(256) void k_rs_reject(const orbm_query* __restrict_
 __global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __restrict__ n_total_dev, int cap, const int* __restrict__ owner,
                                                   const int* __restrict__ state, int* __restrict__ match_of_feature,
                                                   int* __restrict__ status) {
+    MORB_LATENCY_KERNEL_WIDE();
     const int NT = n_total_dev ? *n_total_dev : NT_host;
     const bool overflow = state[0] > cap, stuck = state[8 + state[5] - 1] != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -993,6 +997,7 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
                                                       const uint8_t* __restrict__ occupied, const float* __restrict__ f_angle, int th_high,
                                                       int check_ori, int max_it, const int* __restrict__ topk, int* __restrict__ choice,
                                                       int* __restrict__ owner, int* __restrict__ state) {
+    MORB_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // [0, nf_cap): lowest blocking claimant (global query index); [nf_cap, 2 nf_cap): owner
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
     __shared__ int s_red, s_cnt;
