@@ -246,6 +246,30 @@ __global__ void k_cams_from_counts(CamFeat* __restrict__ cams, int n_cams, const
     range[0] = base; range[1] = 0; range[2] = base;
 }
 
+// The same with everything the large-rig assembly used to put in front of k_frame_fill in one launch (round 5): the camera table comes in
+// the kernel arguments (it was a parameter block copied from pinned memory: two copies), workgroup 0's first thread finishes it from the
+// extractor's counts (k_cams_from_counts), and all workgroups clear the per-cell counters (a memset) -- four launches of a chain whose
+// small launches cost 5-8 us each inside the loop become one.  Up to 32 cameras (the argument block), else the separate launches.
+struct CamFeat32 { CamFeat c[32]; };
+__global__ __launch_bounds__(256) void k_frame_head(CamFeat32 H, CamFeat* __restrict__ cams, int n_cams, const int* __restrict__ d_counts,
+                                                    int* __restrict__ cam_start, int* __restrict__ range, int* __restrict__ trailer,
+                                                    int* __restrict__ cursor, int n_cursor) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_cursor; i += gridDim.x * 256) cursor[i] = 0;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int base = 0;
+    for (int c = 0; c < n_cams; ++c) {
+        const int n = d_counts[c];
+        CamFeat e = H.c[c];
+        e.n = n; e.base = base;
+        cams[c] = e;
+        cam_start[c] = base; trailer[c] = n;
+        base += n;
+    }
+    if (d_counts[n_cams] != 0) trailer[0] |= ORBM_BLOCK_REDO;
+    cam_start[n_cams] = base;
+    range[0] = base; range[1] = 0; range[2] = base;
+}
+
 // exclusive scan of cnt[0..n) into start[0..n], single 1024-thread block; cursor = copy of start
 __global__ __launch_bounds__(1024) void k_scan_cells(const int* cnt, int n, int* __restrict__ start, int* cursor) {
     MORB_LATENCY_KERNEL();
@@ -644,7 +668,9 @@ int morb::frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams,
     const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int) + (size_t)8192 * sizeof(unsigned short);
     const bool small = n > 0 && n <= 8192 && n_cams <= 4 && lds_small <= 150 * 1024;
     MORB_ARG(!sink_filled || small);
-    if (!small) {
+    static const bool head_env = [] { const char* e = getenv("MORB_FRAME_HEAD"); return !(e && atoi(e) == 0); }();
+    const bool one_head = !small && d_counts && n_cams <= 32 && head_env;   // (k_frame_head: table, counts and cleared counters in one launch)
+    if (!small && !one_head) {
         MORB_HIP(hipMemcpyAsync(F->b->d_cams.p, hc, (size_t)n_cams * sizeof(CamFeat), hipMemcpyHostToDevice, st));
         MORB_HIP(hipMemcpyAsync(F->b->d_cam_start.p, hstart, (size_t)(n_cams + 1) * 4, hipMemcpyHostToDevice, st));
     }
@@ -663,7 +689,15 @@ int morb::frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams,
                            F->b->d_items.p, hm, sink_filled ? (const int*)F->b->d_cell_of.p : nullptr, F->desc_rows, StagedFill{});
     } else {
         const int* n_dev = nullptr;
-        if (d_counts) {
+        if (one_head) {
+            CamFeat32 H;
+            memset(&H, 0, sizeof(H));
+            for (int c = 0; c < n_cams; ++c) H.c[c] = hc[c];
+            hipLaunchKernelGGL(k_frame_head, dim3(std::min(64, (ncell + 1 + 255) / 256)), dim3(256), 0, st, H, F->b->d_cams.p, n_cams, d_counts,
+                               F->b->d_cam_start.p, F->b->d_ntotal.p, reinterpret_cast<int*>(F->b->d_desc.p + (size_t)F->desc_rows * 32),
+                               F->b->d_cursor.p, ncell + 1);
+            n_dev = F->b->d_ntotal.p;
+        } else if (d_counts) {
             // counts still on the device (cams[c].n are capacities): the camera table is finished by a one-thread kernel
             hipLaunchKernelGGL(k_cams_from_counts, dim3(1), dim3(64), 0, st, F->b->d_cams.p, n_cams, d_counts, F->b->d_cam_start.p,
                                F->b->d_ntotal.p, reinterpret_cast<int*>(F->b->d_desc.p + (size_t)F->desc_rows * 32));
@@ -674,7 +708,7 @@ int morb::frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams,
             for (int c = 0; c < n_cams; ++c) hcnt[c] = cams[c].n;
             MORB_HIP(hipMemcpyAsync(F->b->d_desc.p + (size_t)F->desc_rows * 32, hcnt, (size_t)n_cams * sizeof(int), hipMemcpyHostToDevice, st));
         }
-        MORB_HIP(hipMemsetAsync(F->b->d_cursor.p, 0, (size_t)(ncell + 1) * 4, st));  // used as the per-cell counter first
+        if (!one_head) MORB_HIP(hipMemsetAsync(F->b->d_cursor.p, 0, (size_t)(ncell + 1) * 4, st));  // used as the per-cell counter first
         if (n) {
             hipLaunchKernelGGL(k_frame_fill, dim3((n + 255) / 256), dim3(256), 0, st, (const CamFeat*)F->b->d_cams.p, n_cams, n, mbf,
                                F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
