@@ -320,6 +320,77 @@ __global__ __launch_bounds__(256) void k_sort_cells(const int* __restrict__ star
     }
 }
 
+// The grid of a LARGE frame in one launch (round 5): one workgroup per camera turns the per-cell counts k_frame_fill left into the camera's
+// part of the CSR -- scan, scatter and the ascending order inside every cell all in LDS -- where k_scan_cells (one workgroup), k_scatter_cells
+// (global atomics) and k_sort_cells (insertion sort in HBM) were three dependent launches of 13 + 6-17 + 21-27 us inside the configs[4] loop.
+// Cameras are contiguous in both the cell numbering and the feature numbering, so a camera's part starts at the number of in-grid features of
+// the cameras in front of it: every workgroup adds those counts up for itself (no workgroup waits for another).  Same contents as the three
+// kernels produced: items of a cell in ascending global index.  Cameras of up to GRID_CAM_MAX features; larger ones keep the three launches.
+constexpr int GRID_CELLS = ORBM_GRID_COLS * ORBM_GRID_ROWS;   // 3072 cells per camera
+constexpr int GRID_CAM_MAX = 16384;
+__global__ __launch_bounds__(1024) void k_grid_cam(const int* __restrict__ cell_cnt, const int* __restrict__ cell_of,
+                                                   const int* __restrict__ cam_start, int n_cams, int* __restrict__ cell_start,
+                                                   int* __restrict__ items) {
+    MORB_LATENCY_KERNEL();
+    __shared__ int s_start[GRID_CELLS + 1];          // exclusive scan of the camera's counts (local positions)
+    __shared__ int s_fill[GRID_CELLS];               // insert cursors
+    __shared__ unsigned short s_items[GRID_CAM_MAX]; // feature index inside the camera, cell after cell
+    __shared__ int s_w[16], s_before;
+    const int cam = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f0 = cam_start[cam], nf = cam_start[cam + 1] - f0;
+    // in-grid features of the cameras in front of this one: the sum of their cells' counts (coalesced, all loads independent)
+    int before = 0;
+    for (int i = tid; i < cam * GRID_CELLS; i += 1024) before += cell_cnt[i];
+    // this camera's counts: three consecutive cells per thread
+    const int* cnt = cell_cnt + cam * GRID_CELLS;
+    const int c3 = 3 * tid;
+    const int k0 = cnt[c3], k1 = cnt[c3 + 1], k2 = cnt[c3 + 2];   // (3 x 1024 = GRID_CELLS)
+    static_assert(GRID_CELLS == 3 * 1024, "three cells per thread");
+    {
+        int b = before;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) b += __shfl_xor(b, off);
+        if (lane == 0) s_w[wave] = b;
+    }
+    __syncthreads();
+    if (tid == 0) { int b = 0; for (int w = 0; w < 16; ++w) b += s_w[w]; s_before = b; }
+    const int mine = k0 + k1 + k2;
+    const int incl = wave_incl_scan(mine);
+    __syncthreads();                                   // (s_w is read above, rewritten below)
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int run = 0;
+    for (int w = 0; w < wave; ++w) run += s_w[w];
+    const int e0 = run + incl - mine;
+    s_start[c3] = e0; s_start[c3 + 1] = e0 + k0; s_start[c3 + 2] = e0 + k0 + k1;
+    s_fill[c3] = e0; s_fill[c3 + 1] = e0 + k0; s_fill[c3 + 2] = e0 + k0 + k1;
+    if (tid == 1023) s_start[GRID_CELLS] = e0 + mine;
+    const int base = s_before;
+    int* gs = cell_start + cam * GRID_CELLS;
+    gs[c3] = base + e0; gs[c3 + 1] = base + e0 + k0; gs[c3 + 2] = base + e0 + k0 + k1;
+    __syncthreads();
+    const int n_in = s_start[GRID_CELLS];
+    if (cam == n_cams - 1 && tid == 0) cell_start[n_cams * GRID_CELLS] = base + n_in;
+    // scatter (LDS atomics: arbitrary order inside a cell), then every cell in ascending order
+    for (int i = tid; i < nf; i += 1024) {
+        const int cell = cell_of[f0 + i];
+        if (cell >= 0) s_items[atomicAdd(&s_fill[cell - cam * GRID_CELLS], 1)] = (unsigned short)i;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int s = s_start[c3 + k], e = s_start[c3 + k + 1];
+        for (int i = s + 1; i < e; ++i) {
+            const unsigned short v = s_items[i];
+            int j = i - 1;
+            while (j >= s && s_items[j] > v) { s_items[j + 1] = s_items[j]; --j; }
+            s_items[j + 1] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_in; i += 1024) items[base + i] = f0 + (int)s_items[i];
+}
+
 }  // namespace
 
 int morb::frame_raise_lds_limit() {
@@ -714,6 +785,16 @@ int morb::frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams,
                                F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
                                F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_of.p,
                                F->b->d_cursor.p, hm, n_dev);
+        }
+        static const bool grid_env = [] { const char* e = getenv("MORB_GRID_CAM"); return !(e && atoi(e) == 0); }();
+        bool grid_cam = grid_env;   // (every camera's features fit the kernel's LDS list: capacities are upper bounds of the counts)
+        for (int c = 0; c < n_cams; ++c) grid_cam = grid_cam && cams[c].n <= GRID_CAM_MAX;
+        if (grid_cam) {
+            hipLaunchKernelGGL(k_grid_cam, dim3(n_cams), dim3(1024), 0, st, (const int*)F->b->d_cursor.p, (const int*)F->b->d_cell_of.p,
+                               (const int*)F->b->d_cam_start.p, n_cams, F->b->d_cell_start.p, F->b->d_items.p);
+            MORB_HIP(hipGetLastError());
+            *out = F;
+            return ORB_OK;
         }
         // counts live in d_cursor; scan them into d_cell_start and leave d_cursor = running insert positions
         hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, (const int*)F->b->d_cursor.p, ncell, F->b->d_cell_start.p,
