@@ -276,9 +276,11 @@ def _depth_image(w, h, seed):
     return d.astype(np.float32)
 
 
-@pytest.mark.parametrize("sizes", [[(640, 480, 1000), (640, 480, 500)], [(320, 240, 300)]])
+@pytest.mark.parametrize("sizes", [[(640, 480, 1000), (640, 480, 500)], [(320, 240, 300)],
+                                   [(640, 480, 700), (640, 480, 300), (640, 480, 900), (640, 480, 40), (640, 480, 500)]])
 def test_frame_from_device_matches_host_assembly(matcher, sizes):
-    """Merge + ComputeStereoFromRGBD + AssignFeaturesToGrid on the device == oracle on the same keypoints."""
+    """Merge + ComputeStereoFromRGBD + AssignFeaturesToGrid on the device == oracle on the same keypoints.  (Five cameras: the large-rig
+    assembly -- k_frame_fill + one k_grid_cam workgroup per camera -- instead of the single-workgroup build of rigs up to four.)"""
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import rt
     W, H = sizes[0][0], sizes[0][1]
