@@ -303,3 +303,15 @@ def test_resize_chain_form_equals_the_oracle_at_every_size(form):
     tail = r.stdout.decode()[-2000:]
     assert r.returncode == 0 and " passed" in tail, tail
 
+
+
+@pytest.mark.parametrize("env", [{}, {"MORB_FAST_FORM": "2", "MORB_PYR_CHAIN": "1", "MORB_PYRAMID_PAIRS": "0"}], ids=["default_forms", "large_rig_forms"])
+def test_random_parameter_sets_equal_the_oracle(env):
+    """Twelve random parameter sets (image size, scale factor, level count, FAST thresholds on both sides of the packed quick test's 127,
+    feature count, image family) through the whole extraction, in the small-rig and in the large-rig forms of the kernels
+    (tools/experiments/fuzz_extractor_random.py; the same tool runs hundreds of cases by hand)."""
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "experiments", "fuzz_extractor_random.py")
+    r = subprocess.run([sys.executable, tool, "12", "5"], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()[-1500:]
+    assert r.returncode == 0 and "ok: " in out and "differs" not in out, out
