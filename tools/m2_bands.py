@@ -102,8 +102,52 @@ def stream_legs():
     out.free()
 
 
+def code_legs():
+    """(h) the same kernel from SECOND and THIRD copies of the library loaded into this process (other code objects at other addresses, the
+    same buffers and stream): is the band a property of where the kernel's code lies?"""
+    import ctypes as C, shutil, tempfile
+    out = rt.DeviceBuffer(SZ)
+    libs = [("first", None)]
+    d = tempfile.mkdtemp()
+    for k in range(3):
+        pth = os.path.join(d, "libmorb_copy%d.so" % k)
+        shutil.copy(m.LIB_PATH, pth)
+        libs.append(("copy%d" % k, C.CDLL(pth)))
+    for rnd in range(2):
+        for name, L in libs:
+            if L is None:
+                run = lambda: m.Matcher.hamming_matrix_device(dq.ptr, n, dr.ptr, n, out.ptr, st)
+            else:
+                fn = L.orbm_hamming_matrix_device
+                fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+                run = (lambda f: (lambda: f(dq.ptr, n, dr.ptr, n, out.ptr, st)))(fn)
+            ms, used, curve = bench._settled_launches(rt, run, st, 60)
+            print(json.dumps({"leg": "h_%s_round_%d" % (name, rnd), "us": round(ms * 1e3, 1), "settle_launches": used}), flush=True)
+    out.free()
+
+
+def input_legs():
+    """(i) fresh copies of the two 1 MB descriptor arrays (the kernel's inputs) at other addresses and offsets, the same result buffer"""
+    out = rt.DeviceBuffer(SZ)
+    keep = []
+    qd = synth.perturbed_queries(d, 9)
+    for k in range(8):
+        keep.append(rt.DeviceBuffer((3 + 17 * k) << 16))
+        q2 = rt.DeviceBuffer(n * 32 + 4096); r2 = rt.DeviceBuffer(n * 32 + 4096)
+        q2.upload(d); r2.upload(qd)
+        run = lambda: m.Matcher.hamming_matrix_device(q2.ptr, n, r2.ptr, n, out.ptr, st)
+        ms, used, curve = bench._settled_launches(rt, run, st, 60)
+        print(json.dumps({"leg": "i_inputs_%d" % k, "us": round(ms * 1e3, 1), "q_ptr": hex(q2.ptr), "r_ptr": hex(r2.ptr)}), flush=True)
+        keep += [q2, r2]
+    out.free()
+
+
 if "e" in LEGS or "f" in LEGS:
     clock_legs()
+if "i" in LEGS:
+    input_legs()
+if "h" in LEGS:
+    code_legs()
 if "g" in LEGS:
     stream_legs()
 if not any(c in LEGS for c in "abcd"):
