@@ -1571,7 +1571,9 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
                                                   FrameSink sink, const L0Src* __restrict__ l0, const DescribeTables* __restrict__ tabs) {
     __shared__ alignas(16) uint8_t s_raw[4][PW * RAW_PITCH];
     __shared__ alignas(16) uint32_t s_vp[4][VP_PAIRS * ROW_PITCH];   // horizontal sums as VERTICAL pairs: row 2m | row 2m+1 << 16 per column
+#ifdef MORB_DESCRIBE_OWN_BLUR
     __shared__ alignas(16) uint8_t s_blur[4][BW * ROW_PITCH];
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Workgroups go to the 8 XCDs round robin and every XCD has an L2 of its own.  The slots are ordered (camera, level, list
     // position), so workgroup b takes the b-th group of four of XCD (b % 8)'s CONTIGUOUS eighth of them: one L2 then serves
@@ -1637,7 +1639,15 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo* __restrict__ 
     }
     uint8_t* raw = s_raw[wave];
     uint32_t* vp = s_vp[wave];
+    // The blurred window lives where the raw patch was (round 5): the patch is dead once the horizontal pass has turned it into row
+    // pairs (the moments read it before that), the vertical pass writes 39 x 40 bytes from `vp` alone, and a wave's LDS accesses keep
+    // their order -- 24 KB per workgroup instead of 30: six workgroups per compute unit instead of five.
+    static_assert(BW * ROW_PITCH <= PW * RAW_PITCH, "the blurred window fits the raw patch's storage");
+#ifdef MORB_DESCRIBE_OWN_BLUR
     uint8_t* blur = s_blur[wave];
+#else
+    uint8_t* blur = raw;
+#endif
 
     DPH(1);
     // The depth sample of the frame assembly (lane 0, end of the kernel) is a dependent global load: issued here, used there.
