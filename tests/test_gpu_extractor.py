@@ -102,7 +102,7 @@ def test_image_families_stage_by_stage(kind, w, h, nf):
     """What the rectangle scenes never show the kernels (round 5, synth.family_image): 1/f-like noise, dithered ramps, soft edges,
     saturated regions, contrast on both sides of the FAST thresholds -- where the roundings of the fixed-point resize and blur decide
     bytes.  Every pyramid level, every level's candidate list and the final keypoints + descriptors against the oracle, at 640x480 (the
-    tiled one-launch pyramid) and 1920x1080 (the resize chain), two cameras with different content in one launch."""
+    tiled one-launch pyramid) and 1920x1080 (the large-rig form: two tile launches with four pixels per lane), two cameras with different content in one launch."""
     import multi_orb_slam_amd as m
     ex = _mk([m.ExtractorParams(nfeatures=nf)] * 2, w, h)
     imgs = [synth.family_image(kind, c, 1 + c, w, h) for c in range(2)]
