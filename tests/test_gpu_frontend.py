@@ -557,7 +557,8 @@ def _loopback_rig(world, n_cams, w, h, nf, ahead, T=6, group=None, delayed_rank=
     return results, timings, placements
 
 
-@pytest.mark.parametrize("world,n_cams,w,h,nf,ahead", [(4, 4, 640, 480, 1000, 0), (4, 4, 640, 480, 1000, 2), (2, 4, 320, 240, 300, 2), (8, 8, 320, 240, 200, 1)])
+@pytest.mark.parametrize("world,n_cams,w,h,nf,ahead", [(4, 4, 640, 480, 1000, 0), (4, 4, 640, 480, 1000, 2), (2, 4, 320, 240, 300, 2), (8, 8, 320, 240, 200, 1),
+                                                       (2, 10, 960, 540, 1800, 1)])   # (five cameras per rank: the large-rig frame assembly and pyramid behind an exchange)
 def test_world_size_n_native_steps_over_the_loopback_exchange(world, n_cams, w, h, nf, ahead):
     """The multi-GPU step with world > 1, end to end through orbf_step: `world` front ends (one host thread each, the cameras
     of ONE rig sharded over them -- configs[3]: one 640x480 camera @1000 per rank) exchange their export blocks from INSIDE the
