@@ -1133,30 +1133,7 @@ __global__ __launch_bounds__(1024) void k_compact(const LevelInfo* __restrict__ 
 // fit the same single-launch kernel that used to hold 4096 (the HBM-backed second launch of rounds 1-2 is gone).
 // Creation order inside a pass replaces the reference's heap-address tie-break exactly as the host code and the oracle do
 // (SURVEY App. C-1).
-constexpr int OCT_NK = 16384;  // candidates per (camera, level) handled on the device
 constexpr int OCT_NL = 1024;   // live nodes (>= quota + 4)
-
-MORB_PHASE_DECL(g_ph_oct);
-
-struct OctLds {
-    uint32_t key[OCT_NK];                  // x | y << 12 | response << 24, candidate order (cell-major, row-major in a cell)
-    unsigned short kn[OCT_NK];             // list position of the node that owns the key (the cell offsets alias it while loading)
-    unsigned long long box[2][OCT_NL];     // ulx | uly << 16 | brx << 32 | bry << 48
-    unsigned long long pc[2][OCT_NL];      // child histogram (4 x 16 bit) of a node that holds more than one key
-    unsigned short cnt[2][OCT_NL];         // keys of the node (1 = bNoMore)
-    unsigned short ncrt[2][OCT_NL];        // creation index in the pass that made the node; 0xffff = older than the last pass
-    unsigned short newid[OCT_NL];          // survivor -> new list position; parent -> creation index of its first child
-    unsigned short procidx[OCT_NL];        // careful pass: node -> index in processing order (0xffff: not split)
-    unsigned short P[OCT_NL];              // careful pass: parents in processing order
-    unsigned short cnode[OCT_NL];          // careful pass: candidate -> node
-    unsigned int sortkey[OCT_NL];
-    unsigned int best[OCT_NL];             // response << 14 | (16383 - p): maximum = first key of the largest response
-    unsigned long long wsum64[2][16];
-    int wsum[16];
-    int v[8];                              // block-uniform scalars
-};
-static_assert(sizeof(OctLds) <= 160 * 1024, "quadtree state must fit one CU's LDS");
-static_assert(OCT_NK <= 16384, "best[] packs the key position into 14 bits");
 
 __device__ __forceinline__ int oct_block_excl_scan(int val, int tid, int* wsum, int* total) {
     // exclusive scan of one int per thread over the 1024-thread block
@@ -1214,69 +1191,81 @@ __device__ __forceinline__ void oct_accum(unsigned long long* pc, int nn, int c,
     }
 }
 
-// status: 0 ok, 1 = outside the device limits (host falls back).
-// The candidates are read straight from the per-cell slots k_fast_cells filled (cell-major, row-major inside a cell: the
-// order the reference hands them to DistributeOctTree), so no separate compaction kernel sits between them.
-__global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ Lv_all, const int* __restrict__ cell_cnt,
-                                                 const uint32_t* __restrict__ cell_items, SelKp* __restrict__ sel,
-                                                 int* __restrict__ sel_cnt, int* __restrict__ status, int max_levels,
-                                                 int max_keys) {
-    MORB_LATENCY_KERNEL();
-    extern __shared__ __attribute__((aligned(16))) unsigned char oct_raw[];
-    OctLds& L = *reinterpret_cast<OctLds*>(oct_raw);
+// ---- the quadtree with the keys in REGISTERS (round 6).  A 1080p photograph holds 15 000 - 35 000 candidates on its first levels
+// (tests/natural.py: 32 834 on level 0 of `china`), beyond what 160 KB of LDS can keep at 6 bytes a key -- but a compute unit's
+// vector registers are 512 KB.  Key p = k * 1024 + tid lives in thread tid's register key[k], its node id in one half of kn2[k / 2];
+// every per-key loop is unrolled over k with the trip count cut by the block-uniform n, so a level with 3 000 candidates runs three
+// iterations and one with 65 535 runs 64.  LDS holds only the per-node records (56 KB; the cell offsets alias the node boxes while
+// the keys load).  Same algorithm, same passes, same barriers as k_octree above; the final "first maximum response" is found by
+// every key asking whether it is its node's maximum instead of reading the winner's key back by position.
+MORB_PHASE_DECL(g_ph_oct);
+
+constexpr int OCT_KPT = 64;                    // keys per thread
+constexpr int OCT_RK = OCT_KPT * 1024 - 1;     // candidates per (camera, level): counts and key positions are 16-bit fields
+constexpr int OCT_MAXCELLS = 8191;             // cells of a level (offsets alias box + pc)
+
+struct OctLdsR {
+    union {
+        struct { unsigned long long box[2][OCT_NL]; unsigned long long pc[2][OCT_NL]; } n;
+        int cell_off[OCT_MAXCELLS + 1];
+    } u;
+    unsigned short cnt[2][OCT_NL];
+    unsigned short ncrt[2][OCT_NL];
+    unsigned short newid[OCT_NL];
+    unsigned short procidx[OCT_NL];
+    unsigned short P[OCT_NL];
+    unsigned short cnode[OCT_NL];
+    unsigned int sortkey[OCT_NL];
+    unsigned int best[OCT_NL];             // response << 16 | (65535 - p)
+    unsigned long long wsum64[2][16];
+    int wsum[16];
+    int v[8];
+};
+static_assert(sizeof(OctLdsR) <= 64 * 1024, "node records of the register-resident quadtree");
+
+// (`base` = k * 1024 is kept opaque to the optimiser: anything it could derive per k -- key positions, remaining counts -- would be
+// hoisted out of the pass loop into 64 more live registers)
+#define OCT_FOR_KEYS _Pragma("unroll") for (int k = 0, base = 0; k < KPT; ++k, base += 1024) { asm volatile("" : "+s"(base));
+#define OCT_KN_GET(k) (((k) & 1) ? (int)(kn2[(k) >> 1] >> 16) : (int)(kn2[(k) >> 1] & 0xffffu))
+#define OCT_KN_SET(k, val) do { if ((k) & 1) kn2[(k) >> 1] = (kn2[(k) >> 1] & 0xffffu) | ((uint32_t)(val) << 16); \
+                                else kn2[(k) >> 1] = (kn2[(k) >> 1] & 0xffff0000u) | (uint32_t)(val); } while (0)
+
+template <int KPT>
+__device__ __forceinline__ void oct_run(OctLdsR& L, const LevelInfo& Lv, const uint32_t* __restrict__ cell_items, SelKp* __restrict__ sel,
+                                        int* __restrict__ sel_cnt, int* __restrict__ status, int max_levels, int n, int N, int ncell,
+                                        int nIni, float hX, int height) {
     const int blk = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    MORB_PHASE(g_ph_oct, 0);
-    const LevelInfo Lv = Lv_all[blk];
-    const int N = Lv.quota;
-    const int ncell = Lv.w ? Lv.n_cols * Lv.n_rows : 0;
-    int* cell_off = reinterpret_cast<int*>(L.kn);  // ncell + 1 ints of scratch (kn is first written behind the load's barrier)
-    if (ncell + 1 > OCT_NK / 2) /* ints that fit kn */ { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; } return; }
-    // exclusive scan of the per-cell counts (cells in row-major order) -> dense position of every candidate
-    int n = 0;
-    {
-        const int per = (ncell + 1023) / 1024;
-        const int c0 = min(ncell, tid * per), c1 = min(ncell, c0 + per);
-        int mine = 0;
-        for (int c = c0; c < c1; ++c) mine += min(cell_cnt[Lv.cell_base + c], Lv.slot_cap);
-        const int ex = oct_block_excl_scan(mine, tid, L.wsum, &n);
-        int run = ex;
-        for (int c = c0; c < c1; ++c) { cell_off[c] = run; run += min(cell_cnt[Lv.cell_base + c], Lv.slot_cap); }
-        if (tid == 0) cell_off[ncell] = n;
-        __syncthreads();
-    }
-    if (n == 0) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 0; } return; }
-    const int width = Lv.w - 2 * MIN_BORDER, height = Lv.h - 2 * MIN_BORDER;
-    const int nIni = max(1, (int)roundf((float)width / (float)height));
-    if (n > max_keys || N + 4 > OCT_NL || nIni > 4 || width >= 32768 || height >= 32768) {
-        if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; }
-        return;
-    }
-    MORB_PHASE(g_ph_oct, 1);
-    const float hX = (float)width / (float)nIni;
-    // candidate p: its cell found by bisection of the offsets (all the global loads of the block are independent and in
-    // flight together); the candidate word IS the key
-    unsigned long long rootcnt = 0;  // per-thread packed count of the keys per root strip
-    for (int p = tid; p < n; p += 1024) {
-        int lo = 0, hi = ncell;  // last c with cell_off[c] <= p (empty cells share an offset: take the last one)
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (cell_off[mid] <= p) lo = mid; else hi = mid;
-        }
-        const uint32_t v = cell_items[Lv.slot_base + (size_t)lo * Lv.slot_cap + (p - cell_off[lo])];
-        L.key[p] = v;
-        if (nIni > 1) {  // roots (:544-585): vertical strips, keypoints dealt by (int)(x / hX)
-            const int r = min(max((int)((float)(v & 0xfff) / hX), 0), nIni - 1);
-            rootcnt += 1ull << (16 * r);
+    const int* cell_off = L.u.cell_off;
+    uint32_t key[KPT];
+    uint32_t kn2[KPT / 2];
+    unsigned long long rootcnt = 0;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) { key[k] = 0; if ((k & 1) == 0) kn2[k >> 1] = 0; }
+    OCT_FOR_KEYS
+        if (base < n) {
+            const int p = base + tid;
+            if (p < n) {
+                int lo = 0, hi = ncell;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cell_off[mid] <= p) lo = mid; else hi = mid;
+                }
+                const uint32_t v = cell_items[Lv.slot_base + (size_t)lo * Lv.slot_cap + (p - cell_off[lo])];
+                key[k] = v;
+                if (nIni > 1) {
+                    const int r = min(max((int)((float)(v & 0xfff) / hX), 0), nIni - 1);
+                    rootcnt += 1ull << (16 * r);
+                }
+            }
         }
     }
     {
         const unsigned long long incl = wave_incl_scan(nIni > 1 ? rootcnt : 0ull);
         if (lane == 63) L.wsum64[0][wave] = incl;
     }
-    __syncthreads();   // every key is in LDS, nobody reads cell_off any more (kn may be written)
+    __syncthreads();   // every key is in its register; the cell offsets are dead (box / pc may be written)
     MORB_PHASE(g_ph_oct, 2);
-    // ---- roots: empty strips dropped, list order = strip order
     int rpos[4] = {0, 0, 0, 0};
     int sz = 0;
     {
@@ -1289,59 +1278,56 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
             rpos[r] = sz;
             if (r < nIni && c) {
                 if (tid == r) {
-                    L.box[0][sz] = oct_pack_box((int)(hX * (float)r), 0, (int)(hX * (float)(r + 1)), height);
-                    L.cnt[0][sz] = (unsigned short)c; L.ncrt[0][sz] = 0xffff; L.pc[0][sz] = 0;
+                    L.u.n.box[0][sz] = oct_pack_box((int)(hX * (float)r), 0, (int)(hX * (float)(r + 1)), height);
+                    L.cnt[0][sz] = (unsigned short)c; L.ncrt[0][sz] = 0xffff; L.u.n.pc[0][sz] = 0;
                 }
                 ++sz;
             }
         }
     }
     __syncthreads();
-    // every key: its root, and its child inside the root's box into the root's histogram
-    for (int p0 = 0; p0 < n; p0 += 1024) {
-        const int p = p0 + tid;
-        int nn = 0, c = 0;
-        bool act = false;
-        if (p < n) {
-            const uint32_t v = L.key[p];
-            const int x = (int)(v & 0xfff), y = (int)((v >> 12) & 0xfff);
-            int r = 0;
-            if (nIni > 1) r = min(max((int)((float)x / hX), 0), nIni - 1);
-            nn = rpos[0];
+    OCT_FOR_KEYS
+        if (base < n) {
+            const int p = base + tid;
+            int nn = 0, c = 0;
+            bool act = false;
+            if (p < n) {
+                const uint32_t v = key[k];
+                const int x = (int)(v & 0xfff), y = (int)((v >> 12) & 0xfff);
+                int r = 0;
+                if (nIni > 1) r = min(max((int)((float)x / hX), 0), nIni - 1);
+                nn = rpos[0];
 #pragma unroll
-            for (int q = 1; q < 4; ++q) if (r == q) nn = rpos[q];
-            L.kn[p] = (unsigned short)nn;
-            if (L.cnt[0][nn] > 1) { int mx, my; c = oct_child(x, y, L.box[0][nn], mx, my); act = true; }
+                for (int q = 1; q < 4; ++q) if (r == q) nn = rpos[q];
+                OCT_KN_SET(k, nn);
+                if (L.cnt[0][nn] > 1) { int mx, my; c = oct_child(x, y, L.u.n.box[0][nn], mx, my); act = true; }
+            }
+            oct_accum(L.u.n.pc[0], nn, c, act);
         }
-        oct_accum(L.pc[0], nn, c, act);
     }
     __syncthreads();
     MORB_PHASE(g_ph_oct, 3);
     int a = 0;
     int ph_i = 4;
-    // ---- main loop (:596-739)
     bool careful = false, finish = false;
     while (!finish) {
         const int b = a ^ 1;
         const int prev_size = sz;
-        int np = 0;  // parents of this pass
+        int np = 0;
         if (careful) {
-            // candidates: children of the previous pass with > 1 keypoint, sorted by (size, creation order), split from the
-            // back until the list has reached N
             int isc = 0;
-            unsigned int key = 0;
+            unsigned int skey = 0;
             if (tid < sz && L.ncrt[a][tid] != 0xffff && L.cnt[a][tid] > 1) {
                 isc = 1;
-                key = ((unsigned)L.cnt[a][tid] << 16) | L.ncrt[a][tid];  // (size, creation order)
+                skey = ((unsigned)L.cnt[a][tid] << 16) | L.ncrt[a][tid];
             }
             int nc = 0;
             const int ci = oct_block_excl_scan(isc, tid, L.wsum, &nc);
-            if (isc) { L.sortkey[ci] = key; L.cnode[ci] = (unsigned short)tid; }
+            if (isc) { L.sortkey[ci] = skey; L.cnode[ci] = (unsigned short)tid; }
             L.procidx[tid] = 0xffff;
-            if (tid == 0) L.v[1] = nc;  // default: every candidate is processed
+            if (tid == 0) L.v[1] = nc;
             __syncthreads();
             if (nc == 0) break;
-            // descending rank (all keys distinct: creation order is unique) = processing order
             if (tid < nc) {
                 const unsigned int mk = L.sortkey[tid];
                 int myrank = 0;
@@ -1351,27 +1337,22 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                 L.procidx[node] = (unsigned short)myrank;
             }
             __syncthreads();
-            // growth of every candidate if it were split: #non-empty children - 1 (its histogram is there already)
             int growth = 0;
-            if (tid < nc) growth = oct_nonzero_fields(L.pc[a][L.P[tid]]) - 1;
+            if (tid < nc) growth = oct_nonzero_fields(L.u.n.pc[a][L.P[tid]]) - 1;
             int gtot = 0;
             const int gex = oct_block_excl_scan(growth, tid, L.wsum, &gtot);
-            // first t (processing order) after which the list has reached N: the condition holds for exactly one t
-            // when the running size crosses N (sizes never decrease), for none otherwise
             if (tid < nc && prev_size + gex + growth >= N && prev_size + gex < N) L.v[1] = tid + 1;
             __syncthreads();
             np = L.v[1];
-            if (tid >= np && tid < nc) L.procidx[L.P[tid]] = 0xffff;  // candidates behind the stop are not split
+            if (tid >= np && tid < nc) L.procidx[L.P[tid]] = 0xffff;
             __syncthreads();
         }
-        // ---- node phase: thread t is parent t (careful: in processing order; full pass: its own list index) AND list node
-        // tid (survivor?): children, survivors, expandable children and parents ride in one packed scan
         unsigned long long tot = 0, packed = 0;
         int pnode = -1;
         if (careful) { if (tid < np) pnode = L.P[tid]; }
         else if (tid < sz && L.cnt[a][tid] > 1) pnode = tid;
         if (pnode >= 0) {
-            tot = L.pc[a][pnode];
+            tot = L.u.n.pc[a][pnode];
             int nch = 0, nex = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) { const int cc = (int)((tot >> (16 * c)) & 0xffff); nch += cc ? 1 : 0; nex += cc > 1 ? 1 : 0; }
@@ -1390,15 +1371,15 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
         const int M = (int)(total & 0xffff), nexp = (int)((total >> 32) & 0xffff);
         np = (int)(total >> 48);
         const int cb = (int)(before & 0xffff), sr = (int)((before >> 16) & 0xffff);
-        if (survivor) {  // survivors keep their relative order behind the new children
+        if (survivor) {
             const int np_ = M + sr;
             L.newid[tid] = (unsigned short)np_;
-            L.box[b][np_] = L.box[a][tid]; L.cnt[b][np_] = L.cnt[a][tid]; L.pc[b][np_] = L.pc[a][tid];
-            L.ncrt[b][np_] = 0xffff;  // no longer "fresh"
+            L.u.n.box[b][np_] = L.u.n.box[a][tid]; L.cnt[b][np_] = L.cnt[a][tid]; L.u.n.pc[b][np_] = L.u.n.pc[a][tid];
+            L.ncrt[b][np_] = 0xffff;
         }
-        if (pnode >= 0) {  // children: creation index ci -> list position M-1-ci
+        if (pnode >= 0) {
             L.newid[pnode] = (unsigned short)cb;
-            const unsigned long long bx = L.box[a][pnode];
+            const unsigned long long bx = L.u.n.box[a][pnode];
             int mx, my;
             (void)oct_child(0, 0, bx, mx, my);
             int ci = cb;
@@ -1407,65 +1388,75 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
                 const int cc = (int)((tot >> (16 * c)) & 0xffff);
                 if (cc == 0) continue;
                 const int pos = M - 1 - ci;
-                L.box[b][pos] = oct_child_box(bx, c, mx, my);
-                L.cnt[b][pos] = (unsigned short)cc; L.ncrt[b][pos] = (unsigned short)ci; L.pc[b][pos] = 0;
+                L.u.n.box[b][pos] = oct_child_box(bx, c, mx, my);
+                L.cnt[b][pos] = (unsigned short)cc; L.ncrt[b][pos] = (unsigned short)ci; L.u.n.pc[b][pos] = 0;
                 ++ci;
             }
         }
         __syncthreads();
-        // ---- key phase: new node of every key; its child inside the new node goes into that node's histogram
-        for (int p0 = 0; p0 < n; p0 += 1024) {
-            const int p = p0 + tid;
-            int nn = 0, c2 = 0;
-            bool act = false;
-            if (p < n) {
-                const int node = L.kn[p];
-                const bool split = careful ? L.procidx[node] != 0xffff : L.cnt[a][node] > 1;
-                if (split) {
-                    const uint32_t v = L.key[p];
-                    const int x = (int)(v & 0xfff), y = (int)((v >> 12) & 0xfff);
-                    const unsigned long long bx = L.box[a][node];
-                    int mx, my;
-                    const int c = oct_child(x, y, bx, mx, my);
-                    const unsigned long long cnts = L.pc[a][node];
-                    const unsigned long long below = c ? (cnts & (~0ull >> (64 - 16 * c))) : 0ull;
-                    nn = M - 1 - ((int)L.newid[node] + oct_nonzero_fields(below));
-                    if (((cnts >> (16 * c)) & 0xffff) > 1) {
-                        int mx2, my2;
-                        c2 = oct_child(x, y, oct_child_box(bx, c, mx, my), mx2, my2);
-                        act = true;
+        OCT_FOR_KEYS
+            if (base < n) {
+                const int p = base + tid;
+                int nn = 0, c2 = 0;
+                bool act = false;
+                if (p < n) {
+                    const int node = OCT_KN_GET(k);
+                    const bool split = careful ? L.procidx[node] != 0xffff : L.cnt[a][node] > 1;
+                    if (split) {
+                        uint32_t v = key[k];
+                        asm volatile("" : "+v"(v));   // (x and y of a key are the same in every pass: not hoisted out of the pass loop either)
+                        const int x = (int)(v & 0xfff), y = (int)((v >> 12) & 0xfff);
+                        const unsigned long long bx = L.u.n.box[a][node];
+                        int mx, my;
+                        const int c = oct_child(x, y, bx, mx, my);
+                        const unsigned long long cnts = L.u.n.pc[a][node];
+                        const unsigned long long below = c ? (cnts & (~0ull >> (64 - 16 * c))) : 0ull;
+                        nn = M - 1 - ((int)L.newid[node] + oct_nonzero_fields(below));
+                        if (((cnts >> (16 * c)) & 0xffff) > 1) {
+                            int mx2, my2;
+                            c2 = oct_child(x, y, oct_child_box(bx, c, mx, my), mx2, my2);
+                            act = true;
+                        }
+                    } else {
+                        nn = L.newid[node];
                     }
-                } else {
-                    nn = L.newid[node];
+                    OCT_KN_SET(k, nn);
                 }
-                L.kn[p] = (unsigned short)nn;
+                oct_accum(L.u.n.pc[b], nn, c2, act);
             }
-            oct_accum(L.pc[b], nn, c2, act);
         }
         __syncthreads();
         sz = M + (sz - np);
         a = b;
         MORB_PHASE(g_ph_oct, ph_i); ph_i = min(ph_i + 1, 40);
         if (sz >= N || sz == prev_size) finish = true;
-        else if (!careful && sz + nexp * 3 > N) careful = true;   // largest nodes first, stop the moment N is reached
+        else if (!careful && sz + nexp * 3 > N) careful = true;
     }
-    // (an unguarded first pass over four roots can leave up to 16 nodes: more than quota + 4 slots only for a quota below 12
-    // on a panorama-shaped level -- the host pass takes those)
     if (sz > N + 4) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; } return; }
-    // ---- best keypoint per node, first maximum wins (:742-763); output in list order
     if (tid < sz) L.best[tid] = 0;
     __syncthreads();
-    for (int p = tid; p < n; p += 1024)
-        atomicMax(&L.best[L.kn[p]], ((L.key[p] >> 24) << 14) | (unsigned)(OCT_NK - 1 - p));
+    OCT_FOR_KEYS
+        if (base < n) {
+            const int p = base + tid;
+            if (p < n) atomicMax(&L.best[OCT_KN_GET(k)], ((key[k] >> 24) << 16) | (unsigned)(65535 - p));
+        }
+    }
     __syncthreads();
-    if (tid < sz) {
-        const unsigned int bb = L.best[tid];
-        const uint32_t v = L.key[OCT_NK - 1 - (int)(bb & (OCT_NK - 1))];
-        SelKp K;
-        K.x = (int)(v & 0xfff) + MIN_BORDER; K.y = (int)((v >> 12) & 0xfff) + MIN_BORDER;
-        K.camlevel = ((blk / max_levels) << 8) | (blk % max_levels);
-        K.resp_out = (int)((v & 0xff000000u) | (unsigned)tid);
-        sel[Lv.sel_base + tid] = K;
+    OCT_FOR_KEYS
+        if (base < n) {
+            const int p = base + tid;
+            if (p < n) {
+                const int node = OCT_KN_GET(k);
+                const uint32_t v = key[k];
+                if (L.best[node] == (((v >> 24) << 16) | (unsigned)(65535 - p))) {   // (response, -p) is unique: one winner per node
+                    SelKp K;
+                    K.x = (int)(v & 0xfff) + MIN_BORDER; K.y = (int)((v >> 12) & 0xfff) + MIN_BORDER;
+                    K.camlevel = ((blk / max_levels) << 8) | (blk % max_levels);
+                    K.resp_out = (int)((v & 0xff000000u) | (unsigned)node);
+                    sel[Lv.sel_base + node] = K;
+                }
+            }
+        }
     }
     if (tid == 0) { sel_cnt[blk] = sz; status[blk] = 0; }
     MORB_PHASE(g_ph_oct, 62); MORB_PHASE(g_ph_oct, 63);
@@ -1473,6 +1464,50 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
     if (tid == 0 && blk == 0) g_ph_oct[61] = (unsigned long long)ph_i;
 #endif
 }
+
+__global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ Lv_all, const int* __restrict__ cell_cnt,
+                                                     const uint32_t* __restrict__ cell_items, SelKp* __restrict__ sel,
+                                                     int* __restrict__ sel_cnt, int* __restrict__ status, int max_levels,
+                                                     int max_keys) {
+    MORB_LATENCY_KERNEL();
+    extern __shared__ __attribute__((aligned(16))) unsigned char oct_raw[];
+    OctLdsR& L = *reinterpret_cast<OctLdsR*>(oct_raw);
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    MORB_PHASE(g_ph_oct, 0);
+    const LevelInfo Lv = Lv_all[blk];
+    const int N = Lv.quota;
+    const int ncell = Lv.w ? Lv.n_cols * Lv.n_rows : 0;
+    int* cell_off = L.u.cell_off;
+    if (ncell > OCT_MAXCELLS) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; } return; }
+    int n = 0;
+    {
+        const int per = (ncell + 1023) / 1024;
+        const int c0 = min(ncell, tid * per), c1 = min(ncell, c0 + per);
+        int mine = 0;
+        for (int c = c0; c < c1; ++c) mine += min(cell_cnt[Lv.cell_base + c], Lv.slot_cap);
+        const int ex = oct_block_excl_scan(mine, tid, L.wsum, &n);
+        int run = ex;
+        for (int c = c0; c < c1; ++c) { cell_off[c] = run; run += min(cell_cnt[Lv.cell_base + c], Lv.slot_cap); }
+        if (tid == 0) cell_off[ncell] = n;
+        __syncthreads();
+    }
+    if (n == 0) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 0; } return; }
+    const int width = Lv.w - 2 * MIN_BORDER, height = Lv.h - 2 * MIN_BORDER;
+    const int nIni = max(1, (int)roundf((float)width / (float)height));
+    if (n > max_keys || n > OCT_RK || N + 4 > OCT_NL || nIni > 4 || width >= 32768 || height >= 32768) {
+        if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; }
+        return;
+    }
+    const float hX = (float)width / (float)nIni;
+    MORB_PHASE(g_ph_oct, 1);
+    // one instantiation per size class: a level with 3 000 candidates runs loops of four keys per thread, not 64 guards per loop
+    if (n <= 4 * 1024) oct_run<4>(L, Lv, cell_items, sel, sel_cnt, status, max_levels, n, N, ncell, nIni, hX, height);
+    else if (n <= 16 * 1024) oct_run<16>(L, Lv, cell_items, sel, sel_cnt, status, max_levels, n, N, ncell, nIni, hX, height);
+    else oct_run<OCT_KPT>(L, Lv, cell_items, sel, sel_cnt, status, max_levels, n, N, ncell, nIni, hX, height);
+}
+#undef OCT_FOR_KEYS
+#undef OCT_KN_GET
+#undef OCT_KN_SET
 
 // ------------------------------------------------------------------------------------------------ K5-K7
 __device__ __forceinline__ int reflect101(int p, int n) {
@@ -2180,7 +2215,7 @@ struct orbx_extractor {
     std::vector<L0Src> l0_host;
     std::vector<uint8_t> uploaded;    // cameras handed an image (any kind, also an empty one) since the last run
     bool pinned_ingest_env = true;    // MORB_PINNED_INGEST=0: never
-    int oct_max_keys = OCT_NK;        // candidates per (camera, level) the device quadtree takes (MORB_OCT_MAX_KEYS lowers it: tests of the fallback)
+    int oct_max_keys = OCT_RK;        // candidates per (camera, level) the device quadtree takes (MORB_OCT_MAX_KEYS lowers it: tests of the fallback)
     int last_path = 0;                // inspection: 0 device quadtree, 2 host quadtree
     DevBuf<unsigned short> d_slot_blk;
     int total_sel_slots = 0;
@@ -2666,10 +2701,10 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     { const char* e = getenv("MORB_HOST_OCTREE"); ex->device_octree = !(e && atoi(e) != 0); }
     { const char* e = getenv("MORB_EXTRACT_TIMELINE"); ex->timeline = e && atoi(e) != 0; }
     { const char* e = getenv("MORB_CHAIN_GRAPH"); ex->use_graph = !(e && atoi(e) == 0); }
-    ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLds)));
     { const char* e = getenv("MORB_PINNED_INGEST"); ex->pinned_ingest_env = !(e && atoi(e) == 0); }
     { const char* e = getenv("MORB_TILED_PYRAMID"); ex->tiled_pyramid = !(e && atoi(e) == 0); }
-    if (const char* e = getenv("MORB_OCT_MAX_KEYS")) ex->oct_max_keys = std::min(OCT_NK, std::max(1, atoi(e)));
+    if (const char* e = getenv("MORB_OCT_MAX_KEYS")) ex->oct_max_keys = std::min(OCT_RK, std::max(1, atoi(e)));
+    ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLdsR)));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
     ex->uploaded.assign(n_cams, 0);
@@ -3039,7 +3074,7 @@ static int launch_tree_describe(orbx_extractor* ex, hipStream_t st, unsigned slo
     mir.kps = nullptr; mir.desc = nullptr;
     if (ex->mirror_kps) { mir.kps = ex->mirror_kps; mir.desc = ex->mirror_desc; }  // cap_total covers every camera's capacity
     for (int c = 0; c < 64; ++c) mir.base[c] = 0;
-    hipLaunchKernelGGL(k_octree, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLds), st, (const LevelInfo*)ex->d_levels.p,
+    hipLaunchKernelGGL(k_octree, dim3(ex->n_cams * ML), dim3(1024), sizeof(OctLdsR), st, (const LevelInfo*)ex->d_levels.p,
                        (const int*)ex->d_cell_cnt.p, (const uint32_t*)ex->d_cell_items.p, ex->d_sel_oct.p, ex->d_sel_cnt.p,
                        ex->d_oct_status.p, ML, ex->oct_max_keys);
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[4], st));

@@ -15,14 +15,17 @@ f32 = np.float32
 INTR = (f32(520.0), f32(520.0), f32(320.0), f32(240.0))   # fx, fy, cx, cy of the synthetic rig
 
 
-def run(width=640, height=480, nf=(1000, 500), T=12, iters=200, warmup=30, batch=False, check=True, workdir=None):
+def run(width=640, height=480, nf=(1000, 500), T=12, iters=200, warmup=30, batch=False, check=True, workdir=None, frames=None):
     """-> dict(us medians per call, class_calls_us, fps, per-step p5/p95, parity).
     T (frames of the synthetic ring) is larger than the per-thread cache of uploaded frames (8, least recently used), so
-    every timed SearchByProjection uploads its current frame as a live stream would: the timing never rides on a cache hit."""
+    every timed SearchByProjection uploads its current frame as a live stream would: the timing never rides on a cache hit.
+    frames: [T][2] uint8 images moving by pipeline.MOTION per step in place of the synthetic stream (tests/natural.py)."""
     from multi_orb_slam_amd import synth, pipeline
     import oracle
     tmp = workdir or tempfile.mkdtemp(prefix="morb_dropin_")
-    frames = [[synth.image(c, t, width, height) for c in range(2)] for t in range(T)]
+    if frames is None:
+        frames = [[synth.image(c, t, width, height) for c in range(2)] for t in range(T)]
+    assert len(frames) == T
     depth = [pipeline.synth_depth_image(c, width, height) for c in range(2)]
     fx, fy, cx, cy = INTR
     blob = struct.pack("<7i", width, height, nf[0], nf[1], T, iters, warmup)

@@ -149,7 +149,7 @@ def test_whole_steps_on_the_image_families(kind):
 
 
 def test_overlap_survives_the_host_quadtree_fallback():
-    """Noise frames put more candidates on level 0 than the device quadtree takes (its limit lowered to 4096 here; 16384 in
+    """Noise frames put more candidates on level 0 than the device quadtree takes (its limit lowered to 4096 here; 65535 in
     the product): the kernel reports 'outside my limits' and the step is redone on the host path -- with the next step's
     extraction already in flight its images have to be uploaded again."""
     import os

@@ -1,0 +1,190 @@
+"""Parity on real photographs and on cameras with overlapping views (round 6).
+
+The reference only ever runs on photographs (Examples/RGB-D/rgbd_tum.cc:108-132 -> src/Tracking.cc:236-287 -> src/Frame.cc:148-288)
+and its two cameras are rigidly mounted with overlapping views (OtherFiles/calibration.txt).  tests/natural.py cuts frame sequences
+and camera rigs from three photographs (committed grey planes, tests/golden/natural_photos.npz); tests/golden/natural_expected.npz
+holds the oracle's outputs on them (tests/golden/make_natural.py).  CPU: the oracle still reproduces the vectors.  GPU: the HIP path
+reproduces the vectors AND equals the live oracle stage by stage, through the whole step (isolated and three steps ahead), through
+the C++ drop-in classes, and accepts exactly the oracle's set of cross-camera matches -- a set that is not empty here."""
+import os
+import numpy as np
+import pytest
+import natural
+from natural import sha, step_digests, SEQ_STEPS
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = [(p, w, h, nf) for p in natural.PHOTOS for (w, h, nf) in natural.SIZES]
+IDS = ["%s-%dx%d" % (p, w, h) for p, w, h, _ in CASES]
+
+
+def _expected():
+    return np.load(os.path.join(G, "natural_expected.npz"))
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_frames_are_what_the_fixture_was_made_from():
+    """the stored grey planes and the integer frame arithmetic: sizes, the motion of the content, the overlap of the cameras"""
+    ph = natural.photos()
+    assert ph["china"].shape == (427, 640) and ph["flower"].shape == (427, 640) and ph["hopper"].shape == (600, 512)
+    assert [int(ph[k].astype(np.int64).sum()) for k in natural.PHOTOS] == [int(_expected()["photo_sums"][i]) for i in range(3)]
+    for photo in natural.PHOTOS:
+        a = natural.frame(photo, 0, 0, 640, 480, noise=0); b = natural.frame(photo, 0, 1, 640, 480, noise=0)
+        assert np.array_equal(a[:-1, :-3], b[1:, 3:])                         # content moves by (+3, +1) per timestep
+        c = natural.frame(photo, 1, 0, 640, 480, noise=0)
+        assert np.array_equal(a[:, natural.BASELINE:], c[:, :-natural.BASELINE])   # camera 1 sees camera 0's view moved by the baseline
+        n = natural.frame(photo, 0, 0, 640, 480)
+        d = n.astype(np.int32) - a
+        assert np.abs(d).max() <= 2 and (d != 0).mean() > 0.5
+    # the integer enlargement: a constant plane stays constant, a ramp stays monotone, centres aligned (the mean is kept)
+    g = np.arange(12, dtype=np.int64)[None, :] * 20 + np.zeros((5, 1), np.int64)
+    for k in (2, 3):
+        u = (natural._upsample_axis(natural._upsample_axis(g, k, 1), k, 0) + 2 * k * k) // (4 * k * k)
+        assert u.shape == (5 * k, 12 * k) and (np.diff(u, axis=1) >= 0).all() and (u[0] == u[-1]).all()
+        assert abs(float(u.mean()) - float(g.mean())) < 1.0
+
+
+@pytest.mark.parametrize("photo,w,h,nf", [c for c in CASES if c[1] <= 1280], ids=[i for i, c in zip(IDS, CASES) if c[1] <= 1280])
+def test_oracle_reproduces_the_natural_vectors(photo, w, h, nf):
+    """extraction of both cameras of frame 0 (full records at 640x480, digests above) and the first two steps of the sequence"""
+    import oracle
+    import multi_orb_slam_amd as m
+    from oracle_pipeline import OracleFrontEnd
+    g = _expected(); tag = "%s_%d" % (photo, w)
+    for c in range(2):
+        k, d = oracle.extract(natural.frame(photo, c, 0, w, h), nfeatures=nf)
+        assert len(k) == int(g["%s_n%d" % (tag, c)][0]) >= nf and np.array_equal(sha(k, d), g["%s_sha%d" % (tag, c)])
+        if w == 640:
+            assert k.tobytes() == g["%s_kps%d" % (tag, c)].tobytes() and np.array_equal(d, g["%s_desc%d" % (tag, c)])
+    ofe = OracleFrontEnd([m.ExtractorParams(nfeatures=nf)] * 2, w, h, cam_threads=True)
+    for t in range(2):
+        r = ofe.step(natural.rig(photo, t, w, h))
+        for key, v in step_digests(r).items():
+            assert np.array_equal(v, g["%s_step%d_%s" % (tag, t, key)]), (tag, t, key)
+    assert r["n_cross"] > nf // 2 and r["n_temporal"] > nf            # true positives across cameras and across time
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _assert_same(kps, desc, okps, odesc):
+    assert len(kps) == len(okps), (len(kps), len(okps))
+    assert kps.tobytes() == okps.tobytes(), "keypoints differ"
+    assert np.array_equal(desc, odesc), "descriptors differ"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("photo,w,h,nf", CASES, ids=IDS)
+def test_extractor_stage_by_stage_on_photographs(photo, w, h, nf):
+    """Every pyramid level, every level's candidate list (FAST + per-cell threshold fallback + NMS) and the final keypoints +
+    descriptors of both cameras against the live oracle AND the committed vectors.  640x480 and 1280x720 take the one-launch tile
+    pyramid, 2 x 1920x1080 the large-rig form (two tile launches, four pixels per lane); test_natural_pyramid_forms forces the others."""
+    import multi_orb_slam_amd as m
+    import oracle
+    g = _expected(); tag = "%s_%d" % (photo, w)
+    ex = m.Extractor([m.ExtractorParams(nfeatures=nf)] * 2, w, h)
+    imgs = [natural.frame(photo, c, 0, w, h) for c in range(2)]
+    out = ex.extract(imgs)
+    if os.environ.get("MORB_EXPECT_PYRAMID_FORM"):
+        assert ex.pyramid_form() == int(os.environ["MORB_EXPECT_PYRAMID_FORM"])
+    for c in range(2):
+        n_fallback = 0
+        for l, ref in enumerate(oracle.pyramid(imgs[c])):
+            got = ex.debug_level(c, l)
+            assert got.shape == ref.shape and np.array_equal(got, ref), (tag, c, "level %d" % l)
+            cand = ex.debug_candidates(c, l); ocand = oracle.cell_candidates(ref)
+            assert len(cand) == len(ocand), (tag, c, l)
+            for f in ("x", "y", "response"):
+                assert np.array_equal(cand[f], ocand[f]), (tag, c, l, f)
+            n_fallback += int((ocand["response"] < 20).sum())
+        assert n_fallback > 0, "no cell of this photograph fell back to minThFAST"
+        okps, odesc = oracle.extract(imgs[c], nfeatures=nf)
+        _assert_same(out[c][0], out[c][1], okps, odesc)
+        assert np.array_equal(sha(out[c][0], out[c][1]), g["%s_sha%d" % (tag, c)])          # the committed vector, without the oracle
+        if w == 640:
+            assert out[c][0].tobytes() == g["%s_kps%d" % (tag, c)].tobytes() and np.array_equal(out[c][1], g["%s_desc%d" % (tag, c)])
+    assert ex.last_path() == 0      # device quadtree, no host fallback
+    ex.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,want,extra", [("chain_v4", 1, {"MORB_PYR_TILED4": "0"}), ("tiled4", 3, {}),
+                                             ("tiled4_small_tiles", 3, {"MORB_PYR_T4_W": "32", "MORB_PYR_T4_H": "16"})])
+def test_natural_pyramid_forms(form, want, extra):
+    """the large-rig pyramid forms forced at 640x480 and 1280x720 on the photographs (the form is chosen once per process: a child)"""
+    import subprocess, sys
+    env = dict(os.environ, MORB_PYR_CHAIN="1", MORB_PYRAMID_PAIRS="0", MORB_EXPECT_PYRAMID_FORM=str(want), **extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "stage_by_stage and not 1920"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode()[-2000:]
+    assert r.returncode == 0 and " passed" in tail, tail
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [0, 3])
+@pytest.mark.parametrize("photo,w,h,nf", CASES, ids=IDS)
+def test_whole_steps_on_photograph_sequences(photo, w, h, nf, depth):
+    """orbf_step over an overlapping two-camera rig sliding over a photograph: extraction, frame assembly with stereo, the temporal
+    SearchByProjection with its rotation histogram, the cross-camera top-2 -- isolated steps (depth 0) and with three timesteps
+    announced ahead (depth 3: three extractor instances, replayed graphs) -- against the live oracle for T steps and against the
+    committed digests for the first SEQ_STEPS.  The accepted cross-camera set (SearchByBoW's rule, src/ORBmatcher.cc:324-327) must be
+    the oracle's and must not be empty: the cameras see the same scene."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    g = _expected(); tag = "%s_%d" % (photo, w)
+    T = 6 if w <= 1280 else 5
+    params = [m.ExtractorParams(nfeatures=nf)] * 2
+    fe = pipeline.FrontEnd(params, w, h); ofe = OracleFrontEnd(params, w, h, cam_threads=True)
+    frames = [natural.rig(photo, t, w, h) for t in range(T)]
+    announced = 0
+    for t in range(T):
+        while announced < min(t + depth, T - 1):
+            announced += 1
+            fe.announce(frames[announced])
+        announced = max(announced, t)
+        got = fe.step(frames[t]); exp = ofe.step(frames[t])
+        assert_same_step(got, exp)
+        acc_got = pipeline.accept_cross(got["cross"][1], got["cross"][2]); acc_exp = pipeline.accept_cross(exp["cross"][1], exp["cross"][2])
+        assert np.array_equal(acc_got, acc_exp) and np.array_equal(got["cross"][0][acc_got], exp["cross"][0][acc_exp])
+        assert got["n_cross"] == int(acc_exp.sum()) > nf // 4, (tag, t, got["n_cross"])
+        if t < SEQ_STEPS:
+            for key, v in step_digests(got).items():
+                assert np.array_equal(v, g["%s_step%d_%s" % (tag, t, key)]), (tag, t, key)
+    assert got["n_temporal"] > nf and sum(got["counts"]) >= 2 * nf
+    # the accepted pairs are geometrically the same scene point: camera 1 sees camera 0's content BASELINE px to the left
+    c0 = got["counts"][0]
+    bi = got["cross"][0][:c0][acc_got[:c0]]                  # camera 0's accepted features -> index into camera 1's features
+    k0 = got["kps"][:c0][acc_got[:c0]]; k1 = got["kps"][c0:][bi]
+    dx = k0["x"] - k1["x"]; dy = k0["y"] - k1["y"]
+    good = (np.abs(dx - natural.BASELINE) <= 2.5 * 1.2 ** k0["octave"]) & (np.abs(dy) <= 2.5 * 1.2 ** k0["octave"])
+    assert good.mean() > 0.8, (tag, float(good.mean()))      # (repetitive structure -- windows, roof tiles -- yields a few accepted look-alikes)
+    fe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("photo", natural.PHOTOS)
+@pytest.mark.parametrize("batch", [False, True])
+def test_cpp_dropin_call_pattern_on_photographs(tmp_path, photo, batch):
+    """The reference's per-frame call pattern through the C++ classes with the reference's signatures (2 x ORBextractor::operator()
+    or one ExtractBatch, host Frame assembly, stack-constructed ORBmatcher::SearchByProjection; src/Frame.cc:182-185,
+    src/Tracking.cc:1237-1267) over a photograph sequence, cameras configured as the reference does (nFeatures, nFeatures / 2)."""
+    import dropin_leg
+    T = 5
+    frames = [natural.rig(photo, t, 640, 480) for t in range(T)]
+    r = dropin_leg.run(640, 480, (1000, 500), T=T, iters=7, warmup=1, batch=batch, workdir=str(tmp_path), frames=frames)
+    assert "bit-exact" in r["parity"] and r["dropin_fps"] > 0
+
+
+@pytest.mark.gpu
+def test_four_camera_rig_on_a_photograph():
+    """configs[3]'s shape (4 x 640x480 @1000) on one GPU with neighbouring cameras overlapping: every camera's features against the
+    three others (the rig-wide top-2 an exchange would feed), whole steps against the oracle."""
+    import multi_orb_slam_amd as m
+    from multi_orb_slam_amd import pipeline
+    from oracle_pipeline import OracleFrontEnd, assert_same_step
+    params = [m.ExtractorParams(nfeatures=1000)] * 4
+    fe = pipeline.FrontEnd(params, 640, 480); ofe = OracleFrontEnd(params, 640, 480, cam_threads=True)
+    for t in range(4):
+        imgs = natural.rig("china", t, 640, 480, n_cams=4)
+        got = fe.step(imgs, next_images=natural.rig("china", t + 1, 640, 480, n_cams=4) if t < 3 else None)
+        assert_same_step(got, ofe.step(imgs))
+    assert got["n_cross"] > 2000 and got["n_temporal"] > 2000
+    fe.close()
