@@ -801,6 +801,7 @@ int orc_distribute_octree(const KeyPoint* in, int n_in, int minX, int maxX, int 
 }
 
 float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+int orc_cv_round(double v) { return cv_round(v); }
 
 float orc_ic_angle(const uint8_t* img, int w, int h, int x, int y, int* m01, int* m10) {
     Params P; init_params(P, 1000, 1.2f, 8, 20, 7);
