@@ -186,5 +186,7 @@ def test_four_camera_rig_on_a_photograph():
         imgs = natural.rig("china", t, 640, 480, n_cams=4)
         got = fe.step(imgs, next_images=natural.rig("china", t + 1, 640, 480, n_cams=4) if t < 3 else None)
         assert_same_step(got, ofe.step(imgs))
-    assert got["n_cross"] > 2000 and got["n_temporal"] > 2000
+    # (with three other cameras on the same scene the best and the second-best are often both true matches, in two cameras: the ratio
+    #  test of src/ORBmatcher.cc:324-327 rejects those, so fewer pairs are accepted per feature than in the two-camera rig)
+    assert got["n_cross"] > 1000 and got["n_temporal"] > 2000
     fe.close()
