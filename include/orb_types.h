@@ -36,7 +36,8 @@ enum {
     ORB_E_ARG = -1,      /* bad argument (null pointer, size out of range)          */
     ORB_E_HIP = -2,      /* a HIP runtime call failed; see orb_last_error()        */
     ORB_E_CAPACITY = -3, /* caller-provided output capacity too small              */
-    ORB_E_NO_DEVICE = -4 /* no usable gfx950 device: the product has no CPU path   */
+    ORB_E_NO_DEVICE = -4,/* no usable gfx950 device: the product has no CPU path   */
+    ORB_E_TIMEOUT = -5   /* a multi-GPU exchange waited for another rank longer than MORB_EXCHANGE_TIMEOUT_MS */
 };
 
 /* thread-local text of the last error on the calling thread ("" if none) */

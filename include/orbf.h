@@ -152,6 +152,23 @@ int orbf_exchange_placement(const orbf_frontend* f);
  * events.  For machines with fewer GPUs than ranks (tests, the 1-GPU CI box); every kernel and every ordering decision of
  * the multi-GPU step is the product code unchanged.  All members must keep stepping in lockstep (one collective per step). */
 int orbf_exchange_init_loopback(orbf_frontend* f, int group, int world, int rank);
+/* The same exchange between PROCESSES as direct one-hop writes (no RCCL): one process per GPU over xGMI peer access, or several
+ * processes per GPU on a machine with fewer GPUs than ranks, which RCCL refuses.  Two collective steps, the caller carries the
+ * handles between the processes by whatever means it has (torch.distributed over gloo, MPI, a file):
+ *   1. every rank: orbf_exchange_peer_export(f, world, rank, handle)   -- allocates this rank's receive arena (the blocks of all ranks
+ *      for the eight steps that can be in flight) and writes orbf_exchange_peer_handle_bytes() bytes (a hipIpcMemHandle_t);
+ *   2. every rank, once it holds all handles (rank r's at handles + r * handle_bytes): orbf_exchange_peer_open(f, handles).
+ * A step's exchange is then one kernel that copies the export block into every rank's arena and stores the step's number into this
+ * rank's arrival word there, and one single-wave kernel that waits for every rank's arrival word -- no collective call, no
+ * communicator, no ordering between the exchanges of different steps.  Everything downstream (repack, rig-wide top-2, placement,
+ * re-shipment of a block whose extraction fell back) is the code of the RCCL path. */
+size_t orbf_exchange_peer_handle_bytes(void);
+int orbf_exchange_peer_export(orbf_frontend* f, int world, int rank, uint8_t* handle_out);
+int orbf_exchange_peer_open(orbf_frontend* f, const uint8_t* handles);
+/* Whatever the transport, the end of a step waits for the other ranks at most MORB_EXCHANGE_TIMEOUT_MS (default 15 000): a rank that
+ * died or hangs makes orbf_step / orbf_step_end return ORB_E_TIMEOUT (the peer transport names the ranks that did not deliver; on
+ * the RCCL path ncclCommGetAsyncError is asked while waiting -> ORB_E_HIP).  The exchange is unusable afterwards:
+ * orbf_exchange_shutdown (RCCL communicators are aborted, not destroyed) or orbf_destroy. */
 int orbf_exchange_shutdown(orbf_frontend* f);       /* back to rank-local steps (orbf_destroy does it too) */
 
 int orbf_step(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, orbf_result* out);

@@ -17,7 +17,7 @@ QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", "<
 WINDOW_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("cam", "<i4"), ("min_level", "<i4"), ("max_level", "<i4")])
 assert KP_DTYPE.itemsize == 28 and QUERY_DTYPE.itemsize == 68 and WINDOW_DTYPE.itemsize == 24
 
-ORB_OK, ORB_E_ARG, ORB_E_HIP, ORB_E_CAPACITY, ORB_E_NO_DEVICE = 0, -1, -2, -3, -4
+ORB_OK, ORB_E_ARG, ORB_E_HIP, ORB_E_CAPACITY, ORB_E_NO_DEVICE, ORB_E_TIMEOUT = 0, -1, -2, -3, -4, -5
 
 
 class OrbError(RuntimeError):
@@ -180,6 +180,9 @@ def lib():
     L.orbf_debug_exchange_redos.argtypes = [vp]; L.orbf_debug_exchange_redos.restype = C.c_long
     L.orbf_exchange_init_loopback.argtypes = [vp, i32, i32, i32]
     L.orbf_exchange_shutdown.argtypes = [vp]
+    L.orbf_exchange_peer_handle_bytes.argtypes = []; L.orbf_exchange_peer_handle_bytes.restype = C.c_size_t
+    L.orbf_exchange_peer_export.argtypes = [vp, i32, i32, vp]
+    L.orbf_exchange_peer_open.argtypes = [vp, vp]
     L.orbf_peek_block.argtypes = [vp, vp, vp, vp, vp]
     L.orbm_cross_top2_gathered_views.argtypes = [vp, vp, vp, vp]
     L.orbm_cross_top2_gathered.argtypes = [vp, vp, i32, C.c_size_t, i32, i32, i32, vp, vp, vp, vp, vp]

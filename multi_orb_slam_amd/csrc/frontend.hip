@@ -107,11 +107,16 @@ struct orbf_frontend {
     long set_xseq[NEX + 3] = {-1, -1, -1, -1, -1, -1};  // per result set: the step whose exchange reads that set's frame as its send buffer
     bool x_timing = false; hipEvent_t ev_x[2] = {nullptr, nullptr}; float x_us[2] = {0.f, 0.f};   // orbf_debug_exchange_timing
     bool xloop = false;                                  // ... over the in-process loopback transport (orbf_exchange_init_loopback)
+    morb::PeerComm* xpeer = nullptr;                     // ... as direct writes into the peers' arenas (orbf_exchange_peer_*: processes, IPC)
+    bool x_one_comm = false;                             // RCCL: no second communicator could be made -- placement 1 only, which needs one
+    bool x_broken = false;                               // a peer did not deliver / RCCL reported an asynchronous error: the exchange is unusable
+    long x_timeout_ms = 15000;                           // how long the end of a step waits for the other ranks (MORB_EXCHANGE_TIMEOUT_MS)
     bool overlap_ok = true;  // cleared when an overlapped extraction had to be redone on the host path ...
     int clean_steps = 0;     // ... and set again after a few steps that stayed on the device path
     struct Pending {  // a timestep between orbf_step_begin and orbf_step_end
         bool active = false, async_path = false, fr_persistent = false, block_ready = false, cross_from_set = false, forked = false;
         long seq = 0;              // number of the step (orbf_frontend::step_seq when it began)
+        bool seq_taken = false;    // ... taken from step_seq: a begin that fails hands it back (the step can be retried)
         bool inline_match = false; // the step's own extraction was enqueued by this call: its matching follows on the SAME stream
         bool mirror_requested = false, mirror_pending = false;  // the pinned result mirrors are filled by a copy kernel of the step
         int set = 0, e = 0, W = 0, H = 0, nq = 0, flags = 0, n = 0;
@@ -191,15 +196,19 @@ int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int 
     return ORB_OK;
 }
 
+static void x_stop(orbf_frontend* f);
+
 void orbf_destroy(orbf_frontend* f) {
     if (f && f->timeline && f->tl_n > 0)
         fprintf(stderr, "orbf host timeline over %ld steps, us per step: extraction / in-flight check %.2f, queries %.2f, frame + event %.2f, "
-                        "search launches %.2f, side work + events %.2f, prefetch enqueue %.2f; extraction not known complete at the step's begin %ld times "
-                        "(asked then: %ld), still running %ld times\n", f->tl_n, f->tl_us[0] / f->tl_n,
-                f->tl_us[1] / f->tl_n, f->tl_us[2] / f->tl_n, f->tl_us[3] / f->tl_n, f->tl_us[4] / f->tl_n, f->tl_us[5] / f->tl_n, f->tl_queried, f->tl_queried, f->tl_not_done);
+                        "search launches %.2f, side work + events %.2f, prefetch enqueue %.2f; extraction not known complete at the step's begin (asked then) %ld times, "
+                        "still running %ld times\n", f->tl_n, f->tl_us[0] / f->tl_n,
+                f->tl_us[1] / f->tl_n, f->tl_us[2] / f->tl_n, f->tl_us[3] / f->tl_n, f->tl_us[4] / f->tl_n, f->tl_us[5] / f->tl_n, f->tl_queried, f->tl_not_done);
     if (!f) return;
     (void)hipSetDevice(f->device);
     if (f->xcomm) (void)orbf_exchange_shutdown(f);
+    x_stop(f);   // (whatever the shutdown returned: the issuer thread never outlives the handle)
+    if (f->xpeer) { morb::peer_close(f->xpeer); f->xpeer = nullptr; }
     for (int i = 0; i < 2; ++i) if (f->ev_x[i]) (void)hipEventDestroy(f->ev_x[i]);
     for (auto& X : f->xs) {
         X.recv.release(); X.list.release(); X.gstart.release(); X.gcnt.release(); X.out.release();
@@ -304,6 +313,9 @@ static void x_stop(orbf_frontend* f);
 static int exchange_queues(orbf_frontend* f) {
     int placement = 3;
     if (const char* e = getenv("MORB_EXCHANGE_PLACEMENT")) { if (!strcmp(e, "inline")) placement = 1; }
+    if (f->x_one_comm) placement = 1;   // (one communicator: a step's one collective at the end of the step, in step order, never a re-shipment)
+    f->x_timeout_ms = std::max(1L, (long)getenv_int("MORB_EXCHANGE_TIMEOUT_MS", 15000));
+    f->x_broken = false;
     f->x_placement = placement;
     f->mt->side_inline = true;   // (no side stream next to an exchange: the handle keeps its extraction chains + the matcher = four queues)
     f->x_next = f->step_seq;
@@ -344,8 +356,51 @@ int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int r
     int rc = exchange_comm_init(&comm, world, uid128, rank);
     if (rc) return rc;
     f->xc[0] = comm;
-    for (int k = 1; k <= orbf_frontend::NXC; ++k) (void)exchange_comm_clone(comm, rank, &f->xc[k]);   // (collective: same order on every rank)
+    // Placement 3 needs NXC + 1 INDEPENDENT communicators (steps in flight go round NXC of them, re-shipped blocks take the last).  Every
+    // rank tries to make them, in the same order; whether ALL ranks got ALL of them is settled with one all-gather of a flag over the
+    // first communicator.  If not, every rank drops its clones and the handle runs placement 1 over the one communicator -- one
+    // collective per step, at the end of the step, in step order: nothing there can pair up wrongly.
+    int mine = 1;
+    for (int k = 1; k <= orbf_frontend::NXC; ++k) {
+        (void)exchange_comm_clone(comm, world, rank, &f->xc[k]);   // (collective)
+        if (!f->xc[k]) { mine = 0; break; }                        // (the first failure is at the same k on every rank, or detected below)
+    }
+    int all = mine;
+    {
+        uint8_t* d = nullptr;
+        bool ok = hipMalloc((void**)&d, (size_t)world + 1) == hipSuccess;
+        const uint8_t v = (uint8_t)mine;
+        ok = ok && hipMemcpy(d, &v, 1, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && exchange_allgather(comm, d, d + 1, 1, nullptr) == ORB_OK && hipStreamSynchronize(nullptr) == hipSuccess;
+        std::vector<uint8_t> flags(world, 0);
+        ok = ok && hipMemcpy(flags.data(), d + 1, world, hipMemcpyDeviceToHost) == hipSuccess;
+        if (d) (void)hipFree(d);
+        if (!ok) { (void)hipGetLastError(); exchange_comm_destroy(comm); f->xc[0] = nullptr; morb::set_error("multi-GPU exchange: the ranks could not agree on their communicators"); return ORB_E_HIP; }
+        for (int r = 0; r < world; ++r) all = all && flags[r];
+    }
+    f->x_one_comm = !all;
+    if (!all) for (int k = 1; k <= orbf_frontend::NXC; ++k) { if (f->xc[k]) exchange_comm_destroy(f->xc[k]); f->xc[k] = nullptr; }
     f->xcomm = comm; f->xworld = world; f->xrank = rank;
+    return exchange_queues(f);
+}
+
+// ---- the peer transport (exchange.hip): processes that write their blocks straight into each other's arenas
+size_t orbf_exchange_peer_handle_bytes(void) { return morb::peer_handle_bytes(); }
+
+int orbf_exchange_peer_export(orbf_frontend* f, int world, int rank, uint8_t* handle_out) {
+    MORB_ARG(f && handle_out && world >= 1 && world <= 64 && rank >= 0 && rank < world && world * f->n_cams <= 512 && !f->xcomm && !f->xpeer);
+    MORB_HIP(hipSetDevice(f->device));
+    const size_t block = (size_t)f->cap_total * 32 + ORBM_BLOCK_TRAILER;
+    return morb::peer_export(&f->xpeer, world, rank, block, orbf_frontend::NX, handle_out);
+}
+
+int orbf_exchange_peer_open(orbf_frontend* f, const uint8_t* handles) {
+    MORB_ARG(f && handles && f->xpeer && !f->xcomm);
+    MORB_HIP(hipSetDevice(f->device));
+    int rc = morb::peer_open(f->xpeer, handles);
+    if (rc) { morb::peer_close(f->xpeer); f->xpeer = nullptr; return rc; }
+    f->xcomm = f->xpeer; f->xworld = morb::peer_world(f->xpeer); f->xrank = morb::peer_rank(f->xpeer);
+    f->x_one_comm = false;
     return exchange_queues(f);
 }
 
@@ -369,18 +424,24 @@ int orbf_exchange_init_loopback(orbf_frontend* f, int group, int world, int rank
 
 int orbf_exchange_shutdown(orbf_frontend* f) {
     MORB_ARG(f != nullptr);
-    if (!f->xcomm) return ORB_OK;
+    x_stop(f);   // (needs no device: everything queued is issued first, the thread is joined whatever follows)
+    if (!f->xcomm) {
+        if (f->xpeer) { (void)hipSetDevice(f->device); morb::peer_close(f->xpeer); f->xpeer = nullptr; }   // (exported, never opened)
+        return ORB_OK;
+    }
     MORB_HIP(hipSetDevice(f->device));
-    x_stop(f);   // (everything queued is issued first)
+    if (f->x_broken && !f->xloop && !f->xpeer)   // (a collective that will never complete sits on a stream: abort lets it end)
+        for (int k = orbf_frontend::NXC; k >= 0; --k) if (f->xc[k]) { exchange_comm_abort(f->xc[k]); f->xc[k] = nullptr; }
     for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));   // (exchanges run on the chains' streams)
     if (f->mt) { if (f->mt->side_stream) (void)hipStreamSynchronize(f->mt->side_stream); (void)hipStreamSynchronize(f->mt->stream); }
-    for (int k = orbf_frontend::NXC; k >= 0; --k) {
+    if (f->xpeer) { morb::peer_close(f->xpeer); f->xpeer = nullptr; }
+    else for (int k = orbf_frontend::NXC; k >= 0; --k) {
         if (!f->xc[k]) continue;
         if (f->xloop) loop_leave(static_cast<LoopComm*>(f->xc[k]));
-        else if (k == 0 || f->xc[k] != f->xc[0]) exchange_comm_destroy(f->xc[k]);   // (a clone that is the first communicator itself goes with it)
+        else exchange_comm_destroy(f->xc[k]);
         f->xc[k] = nullptr;
     }
-    f->xcomm = nullptr; f->xworld = 0; f->xrank = 0; f->xloop = false; f->x_placement = 0;
+    f->xcomm = nullptr; f->xworld = 0; f->xrank = 0; f->xloop = false; f->x_placement = 0; f->x_one_comm = false; f->x_broken = false;
     if (f->mt) f->mt->side_inline = false;
     return ORB_OK;
 }
@@ -392,11 +453,20 @@ static std::vector<uint64_t> image_fingerprints(const orbf_image* images, int n)
 static int exchange_calls(orbf_frontend* f, const orbf_frontend::XJob& J) {
     orbf_frontend::XSlot& X = f->xs[J.seq % orbf_frontend::NX];
     const size_t block = (size_t)J.rows * 32 + ORBM_BLOCK_TRAILER;
-    void* comm = f->xc[J.redo ? orbf_frontend::NXC : (int)(J.seq % orbf_frontend::NXC)];
-    int rc = f->xloop ? loop_allgather(static_cast<LoopComm*>(comm), J.send, X.recv.p, block, J.st)
+    int rc;
+    const uint8_t* recv = X.recv.p;
+    if (f->xpeer) {
+        const int slot = (int)(J.seq % orbf_frontend::NX);
+        rc = morb::peer_allgather(f->xpeer, slot, J.redo ? 1 : 0, (unsigned)(J.seq + 1), J.send, J.st);
+        recv = morb::peer_recv(f->xpeer, slot, J.redo ? 1 : 0);
+    } else {
+        // (one communicator -- placement 1 -- takes every collective, in step order; otherwise steps go round NXC, re-shipments take the last)
+        void* comm = f->x_one_comm ? f->xc[0] : f->xc[J.redo ? orbf_frontend::NXC : (int)(J.seq % orbf_frontend::NXC)];
+        rc = f->xloop ? loop_allgather(static_cast<LoopComm*>(comm), J.send, X.recv.p, block, J.st)
                       : exchange_allgather(comm, J.send, X.recv.p, block, J.st);
+    }
     if (rc) return rc;
-    if ((rc = gathered_enqueue_to(J.st, X.recv.p, f->xworld, block, J.rows, f->n_cams, f->xrank, X.list.p, X.gstart.p, X.gcnt.dp, X.out))) return rc;
+    if ((rc = gathered_enqueue_to(J.st, recv, f->xworld, block, J.rows, f->n_cams, f->xrank, X.list.p, X.gstart.p, X.gcnt.dp, X.out))) return rc;
     if (f->x_timing && X.t_done) (void)hipEventRecord(X.t_done, J.st);
     MORB_HIP(hipEventRecord(X.done, J.st));
     return ORB_OK;
@@ -444,6 +514,47 @@ static void x_stop(orbf_frontend* f) {
     f->x_quit = false; f->x_async = false;
 }
 
+// The end of a step waits for its exchange -- for OTHER RANKS -- and a rank that died or hangs must become an error of this call, not
+// a hang of every rank: the event is polled for at most the exchange's timeout (+ a margin: the peer transport's
+// own wait kernel gives up after exactly the timeout and then says which ranks were missing), RCCL's asynchronous error state is
+// asked while waiting.  After a failure the exchange stays unusable (x_broken): orbf_exchange_shutdown / orbf_destroy clean up.
+static int x_wait_done(orbf_frontend* f, orbf_frontend::XSlot& X, long seq, bool redo) {
+    if (f->x_broken) { morb::set_error("multi-GPU exchange: unusable after an earlier failure (shut it down and set it up again)"); return ORB_E_TIMEOUT; }
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit_ms = (double)f->x_timeout_ms + (f->xpeer ? 5000.0 : 0.0);
+    long polls = 0;
+    for (;;) {
+        const hipError_t q = hipEventQuery(X.done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { f->x_broken = true; morb::set_error("multi-GPU exchange: %s", hipGetErrorString(q)); return ORB_E_HIP; }
+        (void)hipGetLastError();
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (!f->xloop && !f->xpeer && (++polls & 1023) == 0) {
+            for (int k = 0; k <= orbf_frontend::NXC; ++k)
+                if (f->xc[k] && exchange_comm_async_error(f->xc[k]) != 0) { f->x_broken = true; return ORB_E_HIP; }
+        }
+        if (ms > limit_ms) {
+            f->x_broken = true;
+            morb::set_error("multi-GPU exchange: the exchange of step %ld had not completed after %.0f ms -- a rank is dead or far behind "
+                            "(MORB_EXCHANGE_TIMEOUT_MS)", seq, ms);
+            return ORB_E_TIMEOUT;
+        }
+        if (ms > 0.2) std::this_thread::sleep_for(std::chrono::microseconds(ms > 5.0 ? 200 : 20)); else __builtin_ia32_pause();
+    }
+    if (f->xpeer) {
+        const unsigned long long miss = morb::peer_missing(f->xpeer, (int)(seq % orbf_frontend::NX), redo ? 1 : 0);
+        if (miss) {
+            f->x_broken = true;
+            std::string who;
+            for (int r = 0; r < f->xworld; ++r) if ((miss >> r) & 1) who += (who.empty() ? "" : ", ") + std::to_string(r);
+            morb::set_error("multi-GPU exchange: rank(s) %s did not deliver the block of step %ld within %ld ms (MORB_EXCHANGE_TIMEOUT_MS): dead or far behind",
+                            who.c_str(), seq, f->x_timeout_ms);
+            return ORB_E_TIMEOUT;
+        }
+    }
+    return ORB_OK;
+}
+
 // The exchange of step `seq`: the slot's buffers, the bookkeeping, and the calls -- queued for the issuer or made here.  redo: the block
 // is shipped a second time (see XSlot), over the last communicator.
 static int exchange_issue(orbf_frontend* f, long seq, const orbm_frame* F, hipStream_t st, bool redo, const orbf_image* images, int set = -1) {
@@ -453,7 +564,7 @@ static int exchange_issue(orbf_frontend* f, long seq, const orbm_frame* F, hipSt
     const int n_cams = f->xworld * f->n_cams;
     int rc;
     if ((rc = x_wait_job(f, X.job))) return rc;   // (the slot's previous exchange -- eight steps ago -- has long been issued; its buffers may grow now)
-    if ((rc = X.recv.reserve((size_t)f->xworld * block)) || (rc = X.list.reserve((size_t)f->xworld * F->desc_rows * 32)) ||
+    if ((!f->xpeer && (rc = X.recv.reserve((size_t)f->xworld * block))) || (rc = X.list.reserve((size_t)f->xworld * F->desc_rows * 32)) ||
         (rc = X.gstart.reserve(n_cams + 1 + 4)) || (rc = X.gcnt.reserve(n_cams + 3)) || (rc = X.out.reserve(F->desc_rows, f->xworld * F->desc_rows)))
         return rc;
     orbf_frontend::XJob J{0, seq, F->b->d_desc.p, F->desc_rows, st, redo};
@@ -517,11 +628,19 @@ int orbf_prefetch(orbf_frontend* f, const orbf_image* next_images) {
 
 int orbf_ahead_depth(const orbf_frontend* f) { return f ? f->n_ex : ORB_E_ARG; }
 
+// A begin that failed (images that differ from the announced ones, a reserve or an enqueue that failed) leaves no step behind: its
+// number goes back, so that the retry -- with the right images -- is the same step on this rank as on the others (a spent
+// number made every later step miss its exchange).  What was shipped under the number stays shipped: the retry is checked against it.
+static void begin_failed(orbf_frontend* f) {
+    if (f->pending.seq_taken && f->step_seq == f->pending.seq + 1) f->step_seq = f->pending.seq;
+    f->pending.active = false; f->pending.seq_taken = false;
+}
+
 int orbf_step_begin(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags, int* block_ready) {
     MORB_ARG(f && images && nq >= 0 && (nq == 0 || queries));
     f->t_entry = std::chrono::steady_clock::now();
     int rc = orbf_step_begin_impl(f, images, queries, nq, flags, false, block_ready);
-    if (rc) f->pending.active = false;
+    if (rc) begin_failed(f);
     return rc;
 }
 
@@ -531,7 +650,7 @@ int orbf_step_motion_begin(orbf_frontend* f, const orbf_image* images, const orb
     MORB_ARG(f && images && motion);
     f->t_entry = std::chrono::steady_clock::now();
     int rc = orbf_step_begin_impl(f, images, nullptr, 0, flags, true, block_ready, motion);
-    if (rc) f->pending.active = false;
+    if (rc) begin_failed(f);
     return rc;
 }
 
@@ -689,7 +808,7 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
                            f->pframe[set]->minY != bd[1] || f->pframe[set]->maxX != bd[2] || f->pframe[set]->maxY != bd[3])) {
         if (f->xcomm) {   // (an exchange may still read this frame's block: issued? then over?)
             if ((rc = x_wait_stream(f, nullptr))) return rc;
-            for (auto& X : f->xs) if (X.done && X.seq >= 0) MORB_HIP(hipEventSynchronize(X.done));
+            for (auto& X : f->xs) if (X.done && X.seq >= 0 && !f->x_broken) (void)x_wait_done(f, X, X.seq, false);
         }
         orbm_frame_destroy(f->pframe[set]); f->pframe[set] = nullptr;  // (image size or calibration changed)
     }
@@ -832,7 +951,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     if (f->xcomm) flags |= ORBF_SKIP_CROSS;   // the rig-wide matching of the exchange replaces the rank-local one
     P.images.assign(images, images + f->n_cams);
     P.nq = nq; P.flags = flags; P.from_motion = motion != nullptr;
-    P.seq = f->step_seq++;
+    P.seq = f->step_seq++; P.seq_taken = true;
     if (f->xcomm && f->x_next > P.seq) {
         // this step's block has been shipped already (its extraction was announced ahead): the other ranks hold what THOSE images
         // gave, so with an exchange an announcement is binding
@@ -1215,7 +1334,7 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
         if (f->x_next == P.seq && (rc = exchange_issue(f, P.seq, f->last_frame, st, false, P.images.data()))) return rc;
         MORB_ARG(X.seq == P.seq);
         if ((rc = x_wait_job(f, X.job))) return rc;
-        MORB_HIP(hipEventSynchronize(X.done));
+        if ((rc = x_wait_done(f, X, P.seq, false))) return rc;
         const int gc = f->xworld * f->n_cams;
         if (X.gcnt.p[gc + 2] != 0) {
             // some rank's block came from an extraction that fell back to the host path afterwards (every rank reads the same marks in
@@ -1223,7 +1342,7 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
             if ((rc = exchange_issue(f, P.seq, f->last_frame, st, true, nullptr))) return rc;
             ++f->x_redos;
             if ((rc = x_wait_job(f, X.job))) return rc;
-            MORB_HIP(hipEventSynchronize(X.done));
+            if ((rc = x_wait_done(f, X, P.seq, true))) return rc;
             if (X.gcnt.p[gc + 2] != 0) { morb::set_error("multi-GPU exchange: a block shipped again is still marked unfinished"); return ORB_E_HIP; }
         }
         m->foreign_work = false;
@@ -1248,7 +1367,7 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
 static int orbf_step_impl(orbf_frontend* f, const orbf_image* images, const orbm_query* queries, int nq, int flags,
                           orbf_result* out, bool queries_in_pinned, const orbf_motion* motion) {
     int rc = orbf_step_begin_impl(f, images, queries, nq, flags, queries_in_pinned, nullptr, motion);
-    if (rc) { f->pending.active = false; return rc; }
+    if (rc) { begin_failed(f); return rc; }
     return orbf_step_end_impl(f, out);
 }
 

@@ -226,10 +226,22 @@ struct LoopComm;
 int exchange_rccl_available();
 int exchange_unique_id(uint8_t* out128);
 int exchange_comm_init(void** comm, int world, const uint8_t* uid128, int rank);
-int exchange_comm_clone(void* comm, int rank, void** out);
+int exchange_comm_clone(void* comm, int world, int rank, void** out);
+int exchange_comm_async_error(void* comm);
+void exchange_comm_abort(void* comm);
 void exchange_comm_destroy(void* comm);
 int exchange_allgather(void* comm, const void* sendbuf, void* recvbuf, size_t bytes, hipStream_t st);
 int loop_join(int group, int world, int rank, LoopComm** out);
 void loop_leave(LoopComm* c);
 int loop_allgather(LoopComm* C, const void* sendbuf, void* recvbuf, size_t bytes, hipStream_t st);
+struct PeerComm;
+size_t peer_handle_bytes();
+int peer_world(const PeerComm* C);
+int peer_rank(const PeerComm* C);
+int peer_export(PeerComm** out, int world, int rank, size_t block, int nslots, uint8_t* handle);
+int peer_open(PeerComm* C, const uint8_t* handles);
+void peer_close(PeerComm* C);
+const uint8_t* peer_recv(const PeerComm* C, int slot, int gen);
+int peer_allgather(PeerComm* C, int slot, int gen, unsigned version, const void* send, hipStream_t st);
+unsigned long long peer_missing(const PeerComm* C, int slot, int gen);
 }  // namespace morb

@@ -167,6 +167,20 @@ class NativeFrontEnd:
         """Join an in-process exchange group (orbf_exchange_init_loopback): `world` front ends on one device, one thread each."""
         check(_lib.lib().orbf_exchange_init_loopback(self._h, group, world, rank))
 
+    def exchange_peer_export(self, world, rank):
+        """Step 1 of the peer transport (orbf_exchange_peer_export): allocate this rank's receive arena; -> its IPC handle (bytes) for
+        the other ranks."""
+        n = int(_lib.lib().orbf_exchange_peer_handle_bytes())
+        buf = (C.c_uint8 * n)()
+        check(_lib.lib().orbf_exchange_peer_export(self._h, world, rank, buf))
+        return bytes(buf)
+
+    def exchange_peer_open(self, handles):
+        """Step 2 (orbf_exchange_peer_open): `handles` = every rank's handle in rank order (bytes objects)."""
+        blob = b"".join(handles)
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        check(_lib.lib().orbf_exchange_peer_open(self._h, buf))
+
     def exchange_shutdown(self):
         check(_lib.lib().orbf_exchange_shutdown(self._h))
 

@@ -124,6 +124,31 @@ class FrontEnd:
         self.native_exchange = True
         return True
 
+    def enable_peer_exchange(self, dist, group=None):
+        """Collective: the multi-GPU exchange as direct writes between the rank PROCESSES (orbf_exchange_peer_*: IPC-mapped arenas, no
+        RCCL) -- one process per GPU, or several per GPU where there are fewer GPUs than ranks.  torch.distributed (any backend: gloo
+        will do) only carries the 64-byte handles once.  Returns False -- on every rank -- if any rank could not set it up."""
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        try:
+            mine = self.fe.exchange_peer_export(world, rank)
+        except Exception as e:   # noqa: BLE001
+            mine = repr(e)
+        handles = [None] * world
+        dist.all_gather_object(handles, mine, group=group)
+        ok = all(isinstance(h, bytes) for h in handles)
+        if ok:
+            try:
+                self.fe.exchange_peer_open(handles)
+            except Exception:    # noqa: BLE001
+                ok = False
+        oks = [None] * world
+        dist.all_gather_object(oks, ok, group=group)
+        if not all(oks):
+            self.fe.exchange_shutdown()
+            return False
+        self.native_exchange = True
+        return True
+
     def reset(self):
         self.fe.reset()
 
