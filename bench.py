@@ -407,14 +407,29 @@ def main(argv=None):
         os.dup2(2, 1)
         import torch
         import torch.distributed as dist
+        # Transport of the per-step exchange: RCCL (one rank per GPU), or the peer transport -- direct writes into the other ranks'
+        # IPC-mapped arenas -- which also works with SEVERAL RANKS PER GPU: a box with fewer GPUs than ranks (the 1-GPU lease) can
+        # rehearse the whole N > 1 job that way (RCCL refuses two ranks on one device).  MORB_EXCHANGE_TRANSPORT = rccl | peer chooses;
+        # default: peer exactly when the ranks have to share devices.
+        ndev = max(1, torch.cuda.device_count())          # (counting devices does not initialise one)
+        shared_devices = world > ndev
+        transport = os.environ.get("MORB_EXCHANGE_TRANSPORT", "peer" if shared_devices else "rccl")
+        if shared_devices and transport != "peer":
+            raise SystemExit("bench.py: %d ranks on %d GPU(s) need MORB_EXCHANGE_TRANSPORT=peer (RCCL refuses two ranks on one device)" % (world, ndev))
+        local = local % ndev
         torch.cuda.set_device(local)
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29511")
-        # (no device_id=: eager communicator init made every hipStreamSynchronize of this process ~100 us slower here)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-        # control plane: the long waits (other ranks idle while rank 0 times the CPU baseline and the matcher rooflines) sit on a
-        # gloo barrier -- host sockets, no kernel spinning on the waiting GPUs
-        ctl = dist.new_group(backend="gloo")
+        if transport == "peer":
+            # no RCCL at all: gloo carries the handles, the barriers and the MAX-reduced block times (host tensors)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            ctl = dist.group.WORLD
+        else:
+            # (no device_id=: eager communicator init made every hipStreamSynchronize of this process ~100 us slower here)
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+            # control plane: the long waits (other ranks idle while rank 0 times the CPU baseline and the matcher rooflines) sit on a
+            # gloo barrier -- host sockets, no kernel spinning on the waiting GPUs
+            ctl = dist.new_group(backend="gloo")
     import numpy as np
     import multi_orb_slam_amd as m
     from multi_orb_slam_amd import synth, pipeline, rt
@@ -427,12 +442,16 @@ def main(argv=None):
     fe = pipeline.FrontEnd(params, W, H, device=local, rank=rank, world_size=world, global_cams=gcam)
     if use_dist:
         import torch
-        fe.gather = DescriptorExchange(torch.device("cuda", local), dist)
         fe.world = max(world, 2) if world == 1 else world   # world 1 + forced exchange still takes the block path
-        # the all-gather from inside the native step (RCCL's C API; torch.distributed ships the communicator id once);
-        # MORB_NATIVE_EXCHANGE=0 keeps the torch.distributed collective of DescriptorExchange
-        if os.environ.get("MORB_NATIVE_EXCHANGE", "1") != "0":
-            fe.enable_native_exchange(dist, torch.device("cuda", local))
+        if transport == "peer":
+            if not fe.enable_peer_exchange(dist):
+                raise SystemExit("bench.py: the peer transport could not be set up on every rank (hipIpc*; HSA_ENABLE_IPC_MODE_LEGACY=0?)")
+        else:
+            fe.gather = DescriptorExchange(torch.device("cuda", local), dist)
+            # the all-gather from inside the native step (RCCL's C API; torch.distributed ships the communicator id once);
+            # MORB_NATIVE_EXCHANGE=0 keeps the torch.distributed collective of DescriptorExchange
+            if os.environ.get("MORB_NATIVE_EXCHANGE", "1") != "0":
+                fe.enable_native_exchange(dist, torch.device("cuda", local))
         if getattr(fe, "native_exchange", False):
             seen = fe.fe.exchange_world
             assert seen == world, "RCCL communicator spans %d rank(s), the launcher started %d" % (seen, world)
@@ -468,9 +487,10 @@ def main(argv=None):
         if dist is not None:
             import torch
             torch.cuda.synchronize()
-            if long_wait:
+            if long_wait or transport == "peer":
                 dist.barrier(group=ctl)
-            dist.barrier(device_ids=[local])
+            if transport != "peer":
+                dist.barrier(device_ids=[local])
 
     # ---- parity gate, on EVERY rank of any world size: this rank's cameras bit for bit against the CPU oracle on the call
     # pattern of the timed loop (keypoint records, descriptors, stereo, undistorted positions, the temporal search with its
@@ -556,7 +576,7 @@ def main(argv=None):
                 torch.cuda.synchronize()
             el = time.perf_counter() - t_start
             if dist is not None:
-                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([el], dtype=torch.float64, device="cpu" if transport == "peer" else "cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             blocks.append(el); covered += el; t += K
@@ -652,8 +672,10 @@ def main(argv=None):
     ex_bytes = NC * extract_alg_bytes(W, H, NFEAT)
     ex_ach = ex_bytes / (ex_us * 1e-6) / 1e9 if ex_us > 0 else 0.0
 
+    # (ranks that share a device -- the peer transport's rehearsal on a box with fewer GPUs than ranks -- are not GPUs that worked)
+    n_gpus_used = world if not (use_dist and world > 1 and shared_devices) else ndev
     out = {
-        "metric": "frames/sec (N-cam extract+match)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+        "metric": "frames/sec (N-cam extract+match)", "value": round(value, 2), "unit": "frames/s", "n_gpus": n_gpus_used, "n_ranks": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * med_block / a.steps, 4),
         "higher_is_better": True, "scaling": P["scaling"], "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%s: %s; HIP FAST+rBRIEF extract + SearchByProjection + cross-camera Hamming top-2" % (P["name"], P["text"]),
@@ -681,6 +703,10 @@ def main(argv=None):
                              "note": "SURVEY 8(d): W*H + 2*sum(levels>=1) + 60*N per image over the GPU time of one isolated extraction "
                                      "chain (HIP events, median of 10 steps); a latency chain of small launches, not a bandwidth kernel"},
         "exchange": ("none (one rank)" if not use_dist else
+                     ("peer transport: every rank writes its descriptor block straight into every other rank's IPC-mapped arena (one put kernel + "
+                      "one wait kernel per step, no RCCL), issued at the tail of the step's extraction chain; %d rank process(es) on %d GPU(s)%s"
+                      % (world, ndev, " -- ranks SHARE a device: a rehearsal of the N > 1 job, not a scaling measurement" if shared_devices else ""))
+                     if transport == "peer" else
                      "one RCCL all-gather of the step's descriptor block per step, issued natively from inside the step (RCCL C API), %s"
                      % {1: "on the matcher's own stream behind the step's search (placement 1: inline)",
                         3: "at the tail of the step's extraction chain on the extractor's stream, steps ahead of its matching (placement 3: chain)"}.get(

@@ -51,3 +51,20 @@ def test_a_dead_rank_is_a_timeout_error_on_every_survivor():
     assert rcs[1] == 0 and rcs[0] == 3 and rcs[2] == 3, "\n".join(o[-1500:] for o in outs)
     assert "rank(s) 1 did not deliver" in outs[0] and "rank(s) 1 did not deliver" in outs[2]
     assert dt < 60.0
+
+
+@pytest.mark.timeout(300, method="thread")
+def test_bench_runs_two_rank_processes_on_this_one_gpu():
+    """`python bench.py --gpus 2 --config 3` on a box with ONE GPU: the launcher starts two rank processes (the parent never touches the
+    GPU), they share device 0, gloo is the control plane, the peer transport the exchange; each rank runs the parity gate against the
+    OTHER rank's cameras, blocks are timed with barriers on both sides and MAX-reduced, rank 0 relays the one JSON line -- which says
+    n_ranks 2 on n_gpus 1: a rehearsal, not a scaling measurement."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MORB_BENCH_WATCHDOG_S="240")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "3", "--steps", "60", "--warmup", "20", "--min-time", "0.05",
+                        "--no-roofline", "--no-cpu"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_ranks"] == 2 and line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "strong"
+    assert "bit-exact vs oracle" in line["parity"] and "peer transport" in line["exchange"]
