@@ -341,10 +341,34 @@ def test_single_rank_rccl_exchange_equals_oracle():
             if placement == "chain":
                 fe2.announce(frames2[0])
                 fe2.step(frames2[3])              # (extracts the announced frame 0 as the NEXT step and ships its block)
+                ofe2.step(frames2[3])
                 with pytest.raises(m.OrbError, match="announcements are binding"):
                     fe2.step(frames2[4])
+                # the refused call left no step behind (its number went back): the step the ranks agreed on can still be made
+                assert_same_step(fe2.step(frames2[0]), ofe2.step(frames2[0]))
             fe2.fe.exchange_shutdown(); fe2.native_exchange = False
             fe2.close()
+        # Communicators: the steps in flight and the re-shipped blocks need INDEPENDENT communicators.  Without ncclCommSplit
+        # (MORB_EXCHANGE_ONE_COMM=split-off) they are made with fresh ids gathered over the first one -- placement 3 as usual; when none can
+        # be made (=1) every rank falls back to placement 1 over the one communicator, where a block only ships when it is final: the
+        # same noise steps then need no re-shipment at all.
+        for one, want_placement, want_redos in (("split-off", 3, 2), ("1", 1, 0)):
+            os.environ["MORB_OCT_MAX_KEYS"] = "4096"; os.environ["MORB_EXCHANGE_ONE_COMM"] = one
+            try:
+                fe3 = pipeline.FrontEnd(params2, w, h)
+                assert fe3.enable_native_exchange(dist, torch.device("cuda", 0))
+            finally:
+                os.environ.pop("MORB_OCT_MAX_KEYS"); os.environ.pop("MORB_EXCHANGE_ONE_COMM")
+            assert fe3.fe.exchange_placement == want_placement, one
+            ofe3 = OracleFrontEnd(params2, w, h)
+            fe3.announce(frames2[1])
+            for t in range(6):
+                got = fe3.step(frames2[t], next_images=frames2[t + 2] if t + 2 < 6 else None)
+                assert got["rig_counts"] == got["counts"], (one, t)
+                assert_same_step(got, ofe3.step(frames2[t]))
+            assert fe3.fe.debug_exchange_redos() == want_redos, one
+            fe3.fe.exchange_shutdown(); fe3.native_exchange = False
+            fe3.close()
     finally:
         dist.destroy_process_group()
 
