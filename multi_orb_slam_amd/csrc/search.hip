@@ -498,6 +498,20 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
     }
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // [0, n): lowest blocking claimant of a feature; [n, 2n): owner (last claimant)
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
+    // Every exit of this workgroup publishes tagged result words the host takes as "the launch is over": none of them may be written
+    // before the merging workgroups of the same launch have released their results.  Called by all threads; false when
+    // the wait gave up -- the status word then says 3 and the host synchronises the stream before it reads anything.
+    __shared__ int s_merge_ok;
+    auto merge_wait = [&]() -> bool {
+        if (!(MJ.S > 1 && MJ.done)) return true;
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while ((int)(__hip_atomic_load(MJ.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - MJ.target) < 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+            s_merge_ok = spins < (1 << 22) ? 1 : 0;
+        }
+        __syncthreads();
+        return s_merge_ok != 0;
+    };
     __shared__ int s_keep[3];
     __shared__ int s_red;
     __shared__ int s_flag[3];   // "some wave changed something in round it": [it % 3]
@@ -569,6 +583,7 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
     __syncthreads();
     const int maxcount = s_red;
     if (maxcount > cap) {
+        (void)merge_wait();
         if (tid == 0) { status[1] = tagb | 0; status[2] = tagb | 0; status[3] = tagb | maxcount; status[0] = tagb | 2; }
         return;
     }
@@ -711,6 +726,7 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
         MORB_PHASE(g_ph_res, min(2 + it, 50));
     }
     if (changed) {  // ran out of rounds
+        (void)merge_wait();
         if (tid == 0) { status[1] = tagb | 0; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | 1; }
         return;
     }
@@ -781,13 +797,10 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
         __syncthreads();
     }
     MORB_PHASE(g_ph_res, 60);
-    if (MJ.S > 1 && MJ.done) {   // the merging workgroups of this launch finished long ago; the result words below must not say so before they have
-        if (tid == 0) { int spins = 0; while ((int)(__hip_atomic_load(MJ.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - MJ.target) < 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2); }
-        __syncthreads();
-    }
+    const bool merged = merge_wait();   // (the merging workgroups of this launch finished long ago; the result words below must not say so before they have)
     for (int g = tid; g < NT; g += T) match_of_feature[g] = tagb ? (tagb | (s_owner[g] + 2)) : s_owner[g];
     if (tagb) for (int g = NT + tid; g < F.n_total; g += T) match_of_feature[g] = tagb | 1;   // (see k_resolve: no stale tag can match)
-    if (tid == 0) { status[1] = tagb | s_red; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | 0; }
+    if (tid == 0) { status[1] = tagb | s_red; status[2] = tagb | it; status[3] = tagb | maxcount; status[0] = tagb | (merged ? 0 : 3); }
     MORB_PHASE(g_ph_res, 61);
 #ifdef MORB_PHASE_CLOCKS
     if (tid == 0) { g_ph_res[62] = (unsigned long long)it; g_ph_res[59] = clock64(); }
@@ -1634,7 +1647,10 @@ int morb::search_finish(orbm_matcher* m, SearchJob& J, int32_t* match_of_feature
         for (int k = 1; k < 4; ++k) m->last_status[k] = word(k, 0);
         if (status == -3) { morb::set_error("resolve results never arrived"); return ORB_E_HIP; }
         if (J.multi) m->rs_sweeps_hint = status == 0 ? m->last_status[2] + 4 : RS_MAX_SWEEPS;   // (sweeps the next multi-workgroup resolve enqueues)
-        if (status == 0) break;
+        // any other status than "done": nothing else of this launch is read before the stream has drained (the words of a tagged launch
+        // say the resolve's workgroup is over, not that the whole launch is -- status 3: its wait for the merging workgroups gave up)
+        if (status != 0 && !synced) { MORB_HIP(hipStreamSynchronize(m->stream)); synced = true; }
+        if (status == 0 || status == 3) { m->last_status[0] = 0; break; }
         if (status == 2) {  // a candidate list overflowed: retry with room for the longest one
             J.cap = (m->last_status[3] + 63) & ~63;
             int rc = search_enqueue(m, J, /*queries_already_on_device=*/true);

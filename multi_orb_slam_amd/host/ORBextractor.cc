@@ -29,28 +29,31 @@ unsigned long ORBextractor::FailureCount() { return g_failures.load(std::memory_
 // ---- resident.h
 namespace resident {
 namespace {
-struct Entry { const void* owner; unsigned long thread; const uint8_t* host_rows; const uint8_t* d_rows; int n; };
+struct Entry { const void* owner; unsigned long thread; const uint8_t* host_rows; const uint8_t* d_rows; int n; void* reader; };
 std::mutex g_mu;
 std::vector<Entry> g_entries;
 std::atomic<unsigned long> g_served{0}, g_missed{0}, g_tokens{0};
 // a thread's token: handed out once, never again (std::thread::id values are reused when a thread has exited -- the reference's
 // stereo constructor extracts on short-lived threads)
 unsigned long my_token() { static thread_local const unsigned long t = g_tokens.fetch_add(1, std::memory_order_relaxed) + 1; return t; }
-thread_local void* t_reader = nullptr;
 }  // namespace
 void publish(const void* owner, const uint8_t* host_rows, const uint8_t* d_rows, int n) {
     const unsigned long me = my_token();
     std::lock_guard<std::mutex> lk(g_mu);
     for (Entry& e : g_entries)
-        if (e.owner == owner) { e = Entry{owner, me, host_rows, d_rows, n}; return; }
-    g_entries.push_back(Entry{owner, me, host_rows, d_rows, n});
+        if (e.owner == owner) { e = Entry{owner, me, host_rows, d_rows, n, e.reader}; return; }
+    g_entries.push_back(Entry{owner, me, host_rows, d_rows, n, nullptr});
 }
-void retire(const void* owner) {
+void retire(const void* owner) {   // (the rows are about to be overwritten: nobody is served from them any more; a pending reader stays noted)
     std::lock_guard<std::mutex> lk(g_mu);
     for (size_t i = 0; i < g_entries.size(); ++i)
-        if (g_entries[i].owner == owner) { g_entries[i] = g_entries.back(); g_entries.pop_back(); return; }
+        if (g_entries[i].owner == owner) {
+            if (g_entries[i].reader) { g_entries[i].d_rows = nullptr; g_entries[i].host_rows = nullptr; g_entries[i].n = 0; }
+            else { g_entries[i] = g_entries.back(); g_entries.pop_back(); }
+            return;
+        }
 }
-const uint8_t* find(const uint8_t* rows, int n) {
+const uint8_t* find(const uint8_t* rows, int n, const void** owner_out) {
     if (!rows || n <= 0) return nullptr;
     const unsigned long me = my_token();
     // this thread's entries of the right size are copied out under the lock and compared outside it: only their owner -- an extractor
@@ -62,13 +65,29 @@ const uint8_t* find(const uint8_t* rows, int n) {
         for (const Entry& e : g_entries) if (e.n == n && e.thread == me && e.d_rows && k < 8) mine[k++] = e;
     }
     for (int i = 0; i < k; ++i)
-        if (std::memcmp(rows, mine[i].host_rows, (size_t)n * 32) == 0) { g_served.fetch_add(1, std::memory_order_relaxed); return mine[i].d_rows; }
+        if (std::memcmp(rows, mine[i].host_rows, (size_t)n * 32) == 0) {
+            g_served.fetch_add(1, std::memory_order_relaxed);
+            if (owner_out) *owner_out = mine[i].owner;
+            return mine[i].d_rows;
+        }
     g_missed.fetch_add(1, std::memory_order_relaxed);
     return nullptr;
 }
-void note_reader(void* stream) { t_reader = stream; }
-void* take_reader() { void* s = t_reader; t_reader = nullptr; return s; }
-void reader_done() { t_reader = nullptr; }
+void note_reader(const void* owner, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (Entry& e : g_entries) if (e.owner == owner) { e.reader = stream; return; }
+}
+void* take_reader(const void* owner) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_entries.size(); ++i)
+        if (g_entries[i].owner == owner) {
+            void* s = g_entries[i].reader;
+            g_entries[i].reader = nullptr;
+            if (!g_entries[i].d_rows) { g_entries[i] = g_entries.back(); g_entries.pop_back(); }   // (retired, kept for its reader only)
+            return s;
+        }
+    return nullptr;
+}
 void stats(unsigned long* served, unsigned long* missed) { *served = g_served.load(); *missed = g_missed.load(); }
 }  // namespace resident
 
@@ -83,7 +102,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     mvImagePyramid.resize(nlevels);
 }
 
-ORBextractor::~ORBextractor() { resident::retire(this); orbx_destroy(handle_); }
+ORBextractor::~ORBextractor() { resident::retire(this); (void)resident::take_reader(this); orbx_destroy(handle_); }   // (no entry outlives its owner)
 
 bool ORBextractor::EnsureHandle(int width, int height) {
     if (handle_ && width <= cap_w_ && height <= cap_h_) return true;
@@ -116,7 +135,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     uint8_t* d_ptr = scratch_desc_.data();
     int n = 0;
     resident::retire(this);   // (the device rows of the previous call are about to be overwritten ...
-    if (void* rs = resident::take_reader()) (void)orbx_wait_for_stream(handle_, rs);   // ... behind whatever still reads them on the matcher's stream)
+    if (void* rs = resident::take_reader(this)) (void)orbx_wait_for_stream(handle_, rs);   // ... behind whatever still reads THIS extractor's rows on a matcher's stream)
     int rc = orbx_extract(handle_, 1, &img_ptr, &w, &h, &stride, &kp_ptr, &d_ptr, &cap, &n);
     if (rc) { fail("orbx_extract", rc); _keypoints.clear(); _descriptors.release(); return; }
     // the rows stay where the describe kernel wrote them until this extractor's next call: a search of the frame built from them
@@ -152,7 +171,7 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
         orbx_extractor* h = nullptr; std::vector<orbx_params> params; int w = 0, h_px = 0;
         std::vector<std::vector<uint8_t> > ds;   // the last call's descriptors per camera (resident.h holds frames against them)
         char slot[64];                           // &slot[i] = identity of camera i's published rows
-        void retire_all() { for (int i = 0; i < 64; ++i) resident::retire(&slot[i]); }
+        void retire_all() { for (int i = 0; i < 64; ++i) { resident::retire(&slot[i]); (void)resident::take_reader(&slot[i]); } }
         ~BatchState() { retire_all(); orbx_destroy(h); }
     };
     static thread_local BatchState B;
@@ -192,7 +211,10 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
         kp[i].resize(cap[i]); ds[i].resize((size_t)cap[i] * 32);
         kp_ptr[i] = reinterpret_cast<orb_keypoint*>(kp[i].data()); d_ptr[i] = ds[i].data();
     }
-    if (void* rs = resident::take_reader()) (void)orbx_wait_for_stream(batch, rs);   // (behind whatever still reads the previous call's rows on the matcher's stream)
+    for (int i = 0; i < n && i < 64; ++i) {   // (behind whatever still reads the previous call's rows of any slot on a matcher's stream)
+        resident::retire(&B.slot[i]);
+        if (void* rs = resident::take_reader(&B.slot[i])) (void)orbx_wait_for_stream(batch, rs);
+    }
     const int rc = orbx_extract(batch, n, img.data(), w.data(), h.data(), st.data(), kp_ptr.data(), d_ptr.data(), cap.data(), cnt.data());
     if (rc) { fail("orbx_extract(batch)", rc); empty_outputs(); return; }
     for (int i = 0; i < n; ++i) {

@@ -308,13 +308,14 @@ orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_on
         return nullptr;
     }
     const uint8_t* dres[4] = {nullptr, nullptr, nullptr, nullptr};
+    const void* downer[4] = {nullptr, nullptr, nullptr, nullptr};   // the extractors whose device rows are served
     bool any = false;
     if (ff.d.n_cams <= 4) {
-        if (cam1_only) { dres[0] = resident::find(F.mDescriptors.ptr(0), F.mDescriptors.isContinuous() ? F.mDescriptors.rows : 0); any = dres[0] != nullptr; }
+        if (cam1_only) { dres[0] = resident::find(F.mDescriptors.ptr(0), F.mDescriptors.isContinuous() ? F.mDescriptors.rows : 0, &downer[0]); any = dres[0] != nullptr; }
         else for (int c = 0; c < ff.d.n_cams; ++c) {
             const cv::Mat& d = F.mDescriptors_total[c];
             if (d.empty() || !d.isContinuous()) continue;
-            dres[c] = resident::find(d.ptr(0), d.rows);
+            dres[c] = resident::find(d.ptr(0), d.rows, &downer[c]);
             any |= dres[c] != nullptr;
         }
     }
@@ -325,7 +326,8 @@ orbm_frame* device_frame(orbm_matcher* m, const FrameOrKeyFrame& F, bool cam1_on
     orbm_frame* fr = nullptr;
     const int rc = orbm_frame_create_resident(m, &ff.d, any ? dres : nullptr, &fr);
     if (rc) { fail("orbm_frame_create_resident", rc); return nullptr; }
-    if (any) resident::note_reader(orbm_stream(m));   // (the build kernel reads the extractor's rows: its next run orders itself behind this stream)
+    // (the build kernel reads those extractors' rows: the next run of each orders itself behind this stream)
+    for (int c = 0; c < 4; ++c) if (dres[c] && downer[c]) resident::note_reader(downer[c], orbm_stream(m));
     victim->kind = kind; victim->id = id; victim->guard = guard; victim->n = n; victim->cam1 = cam1_only; victim->fr = fr; victim->stamp = T.clock;
     return fr;
 }
