@@ -1174,34 +1174,17 @@ __device__ __forceinline__ int oct_nonzero_fields(unsigned long long t) {
     return ((t & 0xffffull) ? 1 : 0) + ((t & 0xffff0000ull) ? 1 : 0) + ((t & 0xffff00000000ull) ? 1 : 0) + ((t >> 48) ? 1 : 0);
 }
 
-// One key's contribution to the child histogram of node nn: pc[nn] += 1 << 16*c for the lanes with `act`.  While the
-// list is short, the 64 keys of a wave (neighbours in cell order) mostly share their node: then four ballots and ONE
-// atomic replace 64 same-address atomics, which LDS would serialise.
-__device__ __forceinline__ void oct_accum(unsigned long long* pc, int nn, int c, bool act) {
-    if (act) {
-        const int lead = __builtin_amdgcn_readfirstlane(nn);
-        if (__ballot(nn != lead) == 0ull) {
-            const unsigned long long e = __ballot(1);
-            const unsigned long long add = (unsigned long long)__popcll(__ballot(c == 0)) | ((unsigned long long)__popcll(__ballot(c == 1)) << 16) |
-                                           ((unsigned long long)__popcll(__ballot(c == 2)) << 32) | ((unsigned long long)__popcll(__ballot(c == 3)) << 48);
-            if ((int)(threadIdx.x & 63) == __ffsll((long long)e) - 1) atomicAdd(&pc[lead], add);
-        } else {
-            atomicAdd(&pc[nn], 1ull << (16 * c));
-        }
-    }
-}
-
-// ---- the quadtree with the keys in REGISTERS (round 6).  A 1080p photograph holds 15 000 - 35 000 candidates on its first levels
-// (tests/natural.py: 32 834 on level 0 of `china`), beyond what 160 KB of LDS can keep at 6 bytes a key -- but a compute unit's
-// vector registers are 512 KB.  Key p = k * 1024 + tid lives in thread tid's register key[k], its node id in one half of kn2[k / 2];
-// every per-key loop is unrolled over k with the trip count cut by the block-uniform n, so a level with 3 000 candidates runs three
-// iterations and one with 65 535 runs 64.  LDS holds only the per-node records (56 KB; the cell offsets alias the node boxes while
-// the keys load).  Same algorithm, same passes, same barriers as k_octree above; the final "first maximum response" is found by
-// every key asking whether it is its node's maximum instead of reading the winner's key back by position.
 MORB_PHASE_DECL(g_ph_oct);
+#ifdef MORB_PHASE_CLOCKS
+__device__ int g_oct_dbg = 0;   // experiments on the instrumented build: 1 = no histogram adds, 2 = no record read either, 4 = no node-id update
+#define OCT_DBG(bit) (g_oct_dbg & (bit))
+#else
+#define OCT_DBG(bit) 0
+#endif
 
-constexpr int OCT_KPT = 64;                    // keys per thread
+constexpr int OCT_KPT = 40;                    // keys per thread
 constexpr int OCT_RK = OCT_KPT * 1024 - 1;     // candidates per (camera, level): counts and key positions are 16-bit fields
+constexpr int OCT_P = 8;                       // copies of a node's child histogram
 constexpr int OCT_MAXCELLS = 8191;             // cells of a level (offsets alias box + pc)
 
 struct OctLdsR {
@@ -1209,9 +1192,10 @@ struct OctLdsR {
         struct { unsigned long long box[2][OCT_NL]; unsigned long long pc[2][OCT_NL]; } n;
         int cell_off[OCT_MAXCELLS + 1];
     } u;
+    uint4 rec[OCT_NL];                     // what a key needs to know about its node in this pass (oct_rec_*): ONE 16-byte read per key
+    unsigned long long pcp[OCT_NL][OCT_P]; // child histograms of the nodes made in this pass, OCT_P copies each (a lane adds to copy lane % OCT_P)
     unsigned short cnt[2][OCT_NL];
     unsigned short ncrt[2][OCT_NL];
-    unsigned short newid[OCT_NL];
     unsigned short procidx[OCT_NL];
     unsigned short P[OCT_NL];
     unsigned short cnode[OCT_NL];
@@ -1221,11 +1205,71 @@ struct OctLdsR {
     int wsum[16];
     int v[8];
 };
-static_assert(sizeof(OctLdsR) <= 64 * 1024, "node records of the register-resident quadtree");
+static_assert(sizeof(OctLdsR) <= 144 * 1024, "node records of the register-resident quadtree");
+
+// The record a pass's node phase leaves for the key phase (round 6: ~70 vector instructions per key and pass became ~30 -- one
+// compute unit walks all keys of a level, so instructions per key ARE the kernel's time on dense levels):
+//   node not split in this pass:  w = its new list position
+//   node split:  x = midx | midy << 16 (DivideNode's halves), y = the x-halves of its left | right children, z = the y-halves of its upper |
+//                lower children (the grandchild test), w = list position of its FIRST non-empty child | OCT_SPLIT | for child c the number of
+//                non-empty children before it (2 bits at 16 + 2c: position = first - that) | child c holds more than one key (bit 24 + c)
+constexpr unsigned OCT_SPLIT = 0x8000u;
+__device__ __forceinline__ uint4 oct_rec_split(unsigned long long bx, unsigned long long cnts, int first_pos) {
+    const int ulx = (int)(bx & 0xffff), uly = (int)((bx >> 16) & 0xffff), brx = (int)((bx >> 32) & 0xffff), bry = (int)(bx >> 48);
+    const int midx = ulx + ((brx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);
+    const int q1x = ulx + ((midx - ulx + 1) >> 1), q3x = midx + ((brx - midx + 1) >> 1);
+    const int q1y = uly + ((midy - uly + 1) >> 1), q3y = midy + ((bry - midy + 1) >> 1);
+    unsigned w = (unsigned)first_pos | OCT_SPLIT;
+    int before = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cc = (int)((cnts >> (16 * c)) & 0xffff);
+        w |= (unsigned)before << (16 + 2 * c);
+        if (cc > 1) w |= 1u << (24 + c);
+        before += cc ? 1 : 0;
+    }
+    return make_uint4((unsigned)midx | ((unsigned)midy << 16), (unsigned)q1x | ((unsigned)q3x << 16), (unsigned)q1y | ((unsigned)q3y << 16), w);
+}
+// a key's new node nn and, if that node holds more than one key, its child c2 in there (act)
+__device__ __forceinline__ void oct_rec_apply(const uint4 R, int x, int y, int& nn, int& c2, bool& act) {
+    nn = (int)(R.w & 0xfffu); c2 = 0; act = false;
+    if (R.w & OCT_SPLIT) {
+        const int c = (x >= (int)(R.x & 0xffff) ? 1 : 0) | (y >= (int)(R.x >> 16) ? 2 : 0);
+        const int qx = (int)((c & 1) ? R.y >> 16 : R.y & 0xffff), qy = (int)((c & 2) ? R.z >> 16 : R.z & 0xffff);
+        c2 = (x >= qx ? 1 : 0) | (y >= qy ? 2 : 0);
+        nn -= (int)((R.w >> (16 + 2 * c)) & 3u);
+        act = ((R.w >> (24 + c)) & 1u) != 0;
+    }
+}
+
+// One key's contribution to the child histogram of its node: child c of node nn.  The 64 keys of a wave are neighbours in cell order and
+// share a few nodes, and same-address LDS atomics take a clock per lane in the ONE LDS unit all sixteen waves share -- so every node has
+// OCT_P copies of its histogram and a lane adds to copy lane % OCT_P: at most 64 / OCT_P lanes per address.  (Rounds 3-5 counted a wave's
+// keys per node with ballots first: that chain of scalar instructions per key cost 4 us per pass on a level of 10 000 candidates,
+// profiles/r06/notes_experiments.md; the copies are summed once per node by the node's own thread.)
+__device__ __forceinline__ void oct_add(unsigned long long (*pcp)[OCT_P], int nn, int c, bool act) {
+    if (act) atomicAdd(&pcp[nn][threadIdx.x & (OCT_P - 1)], 1ull << (16 * c));
+}
+__device__ __forceinline__ unsigned long long oct_sum_copies(const unsigned long long (*pcp)[OCT_P], int node) {
+    const ulonglong2* q = reinterpret_cast<const ulonglong2*>(pcp[node]);
+    unsigned long long t = 0;
+#pragma unroll
+    for (int i = 0; i < OCT_P / 2; ++i) { const ulonglong2 v = q[i]; t += v.x + v.y; }   // (16-bit fields, totals below 65536: no carries)
+    return t;
+}
+__device__ __forceinline__ void oct_zero_copies(unsigned long long (*pcp)[OCT_P], int node) {
+    ulonglong2* q = reinterpret_cast<ulonglong2*>(pcp[node]);
+#pragma unroll
+    for (int i = 0; i < OCT_P / 2; ++i) q[i] = make_ulonglong2(0ull, 0ull);
+}
 
 // (`base` = k * 1024 is kept opaque to the optimiser: anything it could derive per k -- key positions, remaining counts -- would be
 // hoisted out of the pass loop into 64 more live registers)
-#define OCT_FOR_KEYS _Pragma("unroll") for (int k = 0, base = 0; k < KPT; ++k, base += 1024) { asm volatile("" : "+s"(base));
+// Keys are walked OCT_G at a time (four; two in the large size classes, whose registers are the keys): one block-uniform test per group, the
+// group's bodies in one basic block -- their LDS reads and their global loads are in flight together instead of one round trip per key.
+__device__ __forceinline__ int oct_opaque(int v) { asm volatile("" : "+s"(v)); return v; }
+#define OCT_FOR_KEYS _Pragma("unroll") for (int g_ = 0; g_ < KPT / OCT_G; ++g_) if (const int gbase_ = oct_opaque(g_ * OCT_G * 1024); gbase_ < n) \
+                     _Pragma("unroll") for (int j_ = 0; j_ < OCT_G; ++j_) { const int k = g_ * OCT_G + j_; const int base = gbase_ + j_ * 1024;
 #define OCT_KN_GET(k) (((k) & 1) ? (int)(kn2[(k) >> 1] >> 16) : (int)(kn2[(k) >> 1] & 0xffffu))
 #define OCT_KN_SET(k, val) do { if ((k) & 1) kn2[(k) >> 1] = (kn2[(k) >> 1] & 0xffffu) | ((uint32_t)(val) << 16); \
                                 else kn2[(k) >> 1] = (kn2[(k) >> 1] & 0xffff0000u) | (uint32_t)(val); } while (0)
@@ -1236,27 +1280,42 @@ __device__ __forceinline__ void oct_run(OctLdsR& L, const LevelInfo& Lv, const u
                                         int nIni, float hX, int height) {
     const int blk = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    constexpr int OCT_G = KPT <= 16 ? 4 : 2;
     const int* cell_off = L.u.cell_off;
+    const unsigned short* coarse = reinterpret_cast<const unsigned short*>(L.sortkey);   // (built by the kernel: cell of every 32nd candidate)
     uint32_t key[KPT];
     uint32_t kn2[KPT / 2];
     unsigned long long rootcnt = 0;
 #pragma unroll
     for (int k = 0; k < KPT; ++k) { key[k] = 0; if ((k & 1) == 0) kn2[k >> 1] = 0; }
     OCT_FOR_KEYS
-        if (base < n) {
+        {
             const int p = base + tid;
             if (p < n) {
-                int lo = 0, hi = ncell;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (cell_off[mid] <= p) lo = mid; else hi = mid;
+                // the cell of candidate p: the cell that holds position p & ~31 (table), then a few cells forward; bisection if that is
+                // not enough (runs of empty cells)
+                int lo = coarse[p >> 5];
+                if (!OCT_DBG(16)) {
+#pragma unroll
+                for (int sstep = 0; sstep < 4; ++sstep) if (cell_off[lo + 1] <= p) ++lo;
                 }
-                const uint32_t v = cell_items[Lv.slot_base + (size_t)lo * Lv.slot_cap + (p - cell_off[lo])];
-                key[k] = v;
-                if (nIni > 1) {
-                    const int r = min(max((int)((float)(v & 0xfff) / hX), 0), nIni - 1);
-                    rootcnt += 1ull << (16 * r);
+                if (!OCT_DBG(16) && cell_off[lo + 1] <= p) {
+                    int hi = ncell;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (cell_off[mid] <= p) lo = mid; else hi = mid;
+                    }
                 }
+                if (OCT_DBG(8)) key[k] = (uint32_t)(lo + p); else
+                key[k] = cell_items[Lv.slot_base + (size_t)lo * Lv.slot_cap + (p - cell_off[lo])];   // (nothing below waits for it: all of a thread's loads are in flight together)
+            }
+        }
+    }
+    if (nIni > 1) {   // keys per root strip (:544-585: dealt by (int)(x / hX)) -- in a loop of its own, behind ALL the loads
+        OCT_FOR_KEYS
+            if (base + tid < n) {
+                const int r = min(max((int)((float)(key[k] & 0xfff) / hX), 0), nIni - 1);
+                rootcnt += 1ull << (16 * r);
             }
         }
     }
@@ -1280,6 +1339,7 @@ __device__ __forceinline__ void oct_run(OctLdsR& L, const LevelInfo& Lv, const u
                 if (tid == r) {
                     L.u.n.box[0][sz] = oct_pack_box((int)(hX * (float)r), 0, (int)(hX * (float)(r + 1)), height);
                     L.cnt[0][sz] = (unsigned short)c; L.ncrt[0][sz] = 0xffff; L.u.n.pc[0][sz] = 0;
+                    oct_zero_copies(L.pcp, sz);
                 }
                 ++sz;
             }
@@ -1287,7 +1347,7 @@ __device__ __forceinline__ void oct_run(OctLdsR& L, const LevelInfo& Lv, const u
     }
     __syncthreads();
     OCT_FOR_KEYS
-        if (base < n) {
+        {
             const int p = base + tid;
             int nn = 0, c = 0;
             bool act = false;
@@ -1302,7 +1362,7 @@ __device__ __forceinline__ void oct_run(OctLdsR& L, const LevelInfo& Lv, const u
                 OCT_KN_SET(k, nn);
                 if (L.cnt[0][nn] > 1) { int mx, my; c = oct_child(x, y, L.u.n.box[0][nn], mx, my); act = true; }
             }
-            oct_accum(L.u.n.pc[0], nn, c, act);
+            oct_add(L.pcp, nn, c, act);
         }
     }
     __syncthreads();
@@ -1310,10 +1370,15 @@ __device__ __forceinline__ void oct_run(OctLdsR& L, const LevelInfo& Lv, const u
     int a = 0;
     int ph_i = 4;
     bool careful = false, finish = false;
+    bool first = true;
     while (!finish) {
         const int b = a ^ 1;
         const int prev_size = sz;
         int np = 0;
+        // the histograms the key phase just filled (nodes made in the last pass; the roots the first time): summed by the node's thread.
+        // Whoever else reads a node's sum does so behind a barrier (the careful pass's scans), the node phase reads its own.
+        if (tid < sz && (first || L.ncrt[a][tid] != 0xffff)) L.u.n.pc[a][tid] = oct_sum_copies(L.pcp, tid);
+        first = false;
         if (careful) {
             int isc = 0;
             unsigned int skey = 0;
@@ -1373,13 +1438,13 @@ __device__ __forceinline__ void oct_run(OctLdsR& L, const LevelInfo& Lv, const u
         const int cb = (int)(before & 0xffff), sr = (int)((before >> 16) & 0xffff);
         if (survivor) {
             const int np_ = M + sr;
-            L.newid[tid] = (unsigned short)np_;
+            L.rec[tid] = make_uint4(0u, 0u, 0u, (unsigned)np_);
             L.u.n.box[b][np_] = L.u.n.box[a][tid]; L.cnt[b][np_] = L.cnt[a][tid]; L.u.n.pc[b][np_] = L.u.n.pc[a][tid];
             L.ncrt[b][np_] = 0xffff;
         }
         if (pnode >= 0) {
-            L.newid[pnode] = (unsigned short)cb;
             const unsigned long long bx = L.u.n.box[a][pnode];
+            L.rec[pnode] = oct_rec_split(bx, tot, M - 1 - cb);
             int mx, my;
             (void)oct_child(0, 0, bx, mx, my);
             int ci = cb;
@@ -1390,39 +1455,24 @@ __device__ __forceinline__ void oct_run(OctLdsR& L, const LevelInfo& Lv, const u
                 const int pos = M - 1 - ci;
                 L.u.n.box[b][pos] = oct_child_box(bx, c, mx, my);
                 L.cnt[b][pos] = (unsigned short)cc; L.ncrt[b][pos] = (unsigned short)ci; L.u.n.pc[b][pos] = 0;
+                oct_zero_copies(L.pcp, pos);
                 ++ci;
             }
         }
         __syncthreads();
         OCT_FOR_KEYS
-            if (base < n) {
+            {
                 const int p = base + tid;
                 int nn = 0, c2 = 0;
                 bool act = false;
-                if (p < n) {
-                    const int node = OCT_KN_GET(k);
-                    const bool split = careful ? L.procidx[node] != 0xffff : L.cnt[a][node] > 1;
-                    if (split) {
-                        uint32_t v = key[k];
-                        asm volatile("" : "+v"(v));   // (x and y of a key are the same in every pass: not hoisted out of the pass loop either)
-                        const int x = (int)(v & 0xfff), y = (int)((v >> 12) & 0xfff);
-                        const unsigned long long bx = L.u.n.box[a][node];
-                        int mx, my;
-                        const int c = oct_child(x, y, bx, mx, my);
-                        const unsigned long long cnts = L.u.n.pc[a][node];
-                        const unsigned long long below = c ? (cnts & (~0ull >> (64 - 16 * c))) : 0ull;
-                        nn = M - 1 - ((int)L.newid[node] + oct_nonzero_fields(below));
-                        if (((cnts >> (16 * c)) & 0xffff) > 1) {
-                            int mx2, my2;
-                            c2 = oct_child(x, y, oct_child_box(bx, c, mx, my), mx2, my2);
-                            act = true;
-                        }
-                    } else {
-                        nn = L.newid[node];
-                    }
-                    OCT_KN_SET(k, nn);
+                if (p < n && !OCT_DBG(2)) {
+                    const uint4 R = L.rec[OCT_KN_GET(k)];
+                    uint32_t v = key[k];
+                    asm volatile("" : "+v"(v));   // (x and y of a key are the same in every pass: not hoisted out of the pass loop either)
+                    oct_rec_apply(R, (int)(v & 0xfff), (int)((v >> 12) & 0xfff), nn, c2, act);
+                    if (!OCT_DBG(4)) OCT_KN_SET(k, nn);
                 }
-                oct_accum(L.u.n.pc[b], nn, c2, act);
+                if (!OCT_DBG(1)) oct_add(L.pcp, nn, c2, act);
             }
         }
         __syncthreads();
@@ -1433,17 +1483,26 @@ __device__ __forceinline__ void oct_run(OctLdsR& L, const LevelInfo& Lv, const u
         else if (!careful && sz + nexp * 3 > N) careful = true;
     }
     if (sz > N + 4) { if (tid == 0) { sel_cnt[blk] = 0; status[blk] = 1; } return; }
-    if (tid < sz) L.best[tid] = 0;
+    // ---- best keypoint per node, first maximum wins (:742-763).  A node's keys sit next to each other in the waves: eight copies of
+    // every node's maximum (the boxes and histograms are dead: their LDS takes them), a lane adds to copy lane & 7, so that an atomic
+    // instruction meets at most eight lanes per address instead of sixty-four.
+    unsigned* best8 = reinterpret_cast<unsigned*>(&L.u);
+    for (int i = tid; i < sz * 8; i += 1024) best8[i] = 0;
     __syncthreads();
     OCT_FOR_KEYS
-        if (base < n) {
+        {
             const int p = base + tid;
-            if (p < n) atomicMax(&L.best[OCT_KN_GET(k)], ((key[k] >> 24) << 16) | (unsigned)(65535 - p));
+            if (p < n) atomicMax(&best8[OCT_KN_GET(k) * 8 + (lane & 7)], ((key[k] >> 24) << 16) | (unsigned)(65535 - p));
         }
     }
     __syncthreads();
+    if (tid < sz) {
+        const uint4 lo4 = *reinterpret_cast<const uint4*>(best8 + tid * 8), hi4 = *reinterpret_cast<const uint4*>(best8 + tid * 8 + 4);
+        L.best[tid] = max(max(max(lo4.x, lo4.y), max(lo4.z, lo4.w)), max(max(hi4.x, hi4.y), max(hi4.z, hi4.w)));
+    }
+    __syncthreads();
     OCT_FOR_KEYS
-        if (base < n) {
+        {
             const int p = base + tid;
             if (p < n) {
                 const int node = OCT_KN_GET(k);
@@ -1499,10 +1558,19 @@ __global__ __launch_bounds__(1024) void k_octree(const LevelInfo* __restrict__ L
         return;
     }
     const float hX = (float)width / (float)nIni;
+    {   // the cell of every 32nd candidate (u16, in the careful pass's sort keys: unused until then)
+        unsigned short* coarse = reinterpret_cast<unsigned short*>(L.sortkey);
+        for (int c = tid; c < ncell; c += 1024) {
+            const int a0 = cell_off[c], b0 = cell_off[c + 1];
+            for (int q = (a0 + 31) >> 5; (q << 5) < b0; ++q) coarse[q] = (unsigned short)c;
+        }
+        __syncthreads();
+    }
     MORB_PHASE(g_ph_oct, 1);
     // one instantiation per size class: a level with 3 000 candidates runs loops of four keys per thread, not 64 guards per loop
     if (n <= 4 * 1024) oct_run<4>(L, Lv, cell_items, sel, sel_cnt, status, max_levels, n, N, ncell, nIni, hX, height);
     else if (n <= 16 * 1024) oct_run<16>(L, Lv, cell_items, sel, sel_cnt, status, max_levels, n, N, ncell, nIni, hX, height);
+    else if (n <= 32 * 1024) oct_run<32>(L, Lv, cell_items, sel, sel_cnt, status, max_levels, n, N, ncell, nIni, hX, height);
     else oct_run<OCT_KPT>(L, Lv, cell_items, sel, sel_cnt, status, max_levels, n, N, ncell, nIni, hX, height);
 }
 #undef OCT_FOR_KEYS
@@ -3513,6 +3581,7 @@ extern "C" int morb_debug_describe_check(unsigned long long* out, int n) {   // 
 #endif
 
 #ifdef MORB_PHASE_CLOCKS
+extern "C" int morb_debug_oct_dbg(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_oct_dbg), &v, sizeof v) == hipSuccess ? 0 : -1; }
 extern "C" int morb_debug_phases_extractor(int which, unsigned long long* out64) {
     if (which == 4) return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_pyr), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
     if (which == 2) return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ph_desc), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;

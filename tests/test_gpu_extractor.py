@@ -137,8 +137,8 @@ def test_larger_configs():
 def test_dense_levels_stay_on_the_device_quadtree():
     """1920x1080 @4000: levels 0..5 hold 4500-9400 candidates.  Rounds 1-2 kept 4096 keys in LDS and ran denser levels through
     an HBM-backed second launch, rounds 3-5 held 16 384 keys in LDS; the round-6 quadtree keeps its keys in vector registers
-    (64 per thread), so up to 65 535 candidates per level run in the one launch, from the first frame on.  Must equal the oracle;
-    a 1080p noise image (> 65 535 candidates on level 0) still goes to the host."""
+    (up to 40 per thread), so up to 40 959 candidates per level run in the one launch, from the first frame on.  Must equal the oracle;
+    a 1080p noise image (> 40 959 candidates on level 0) still goes to the host."""
     import multi_orb_slam_amd as m
     w, h, nf = 1920, 1080, 4000
     ex = _mk([m.ExtractorParams(nfeatures=nf)], w, h)
@@ -154,14 +154,14 @@ def test_dense_levels_stay_on_the_device_quadtree():
     kps, desc = ex(noise)
     okps, odesc = oracle.extract(noise, nfeatures=nf)
     _assert_same(kps, desc, okps, odesc)
-    assert ex.last_path() == 2 and len(ex.debug_candidates(0, 0)) > 65535
+    assert ex.last_path() == 2 and len(ex.debug_candidates(0, 0)) > 40959
     ex.close()
 
 
-@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (800, 600, 1500), (800, 600, 300)])
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (760, 570, 1500), (760, 570, 300)])
 def test_register_resident_quadtree_size_classes(w, h, nf):
-    """Noise images put 27 703 (640x480) / 44 478 (800x600) candidates on level 0 and every count down to 161 on the levels above: the
-    quadtree's three instantiations (4, 16 and 64 keys per thread; k_octree picks one per (camera, level) from the candidate count)
+    """Noise images put 27 703 (640x480) / ~40 000 (760x570) candidates on level 0 and every count down to 161 on the levels above: the
+    quadtree's four instantiations (4, 16, 32 and 40 keys per thread; k_octree picks one per (camera, level) from the candidate count)
     all run in one launch, two cameras with different noise, nothing falls back to the host."""
     import multi_orb_slam_amd as m
     ex = _mk([m.ExtractorParams(nfeatures=nf)] * 2, w, h)
@@ -172,7 +172,7 @@ def test_register_resident_quadtree_size_classes(w, h, nf):
     out = ex.extract(imgs)
     assert ex.last_path() == 0
     n0 = [len(ex.debug_candidates(0, l)) for l in range(8)]
-    assert n0[0] > 16384 and 4096 < n0[3] <= 16384 and n0[7] <= 4096, n0
+    assert n0[0] > (32768 if w == 760 else 16384) and 16384 < n0[1] <= 32768 and 4096 < n0[3] <= 16384 and n0[7] <= 4096, n0
     for c in range(2):
         okps, odesc = oracle.extract(imgs[c], nfeatures=nf)
         _assert_same(out[c][0], out[c][1], okps, odesc)
