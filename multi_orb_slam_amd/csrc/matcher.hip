@@ -120,7 +120,7 @@ void orbm_destroy(orbm_matcher* m) {
     m->h_c0.release(); m->h_c1.release(); m->h_c2.release(); m->d_cscratch.release(); m->h_gcnt.release(); m->d_gstart.release();
     m->d_q.release(); m->d_r.release(); m->d_scratch.release(); m->d_queries.release(); m->d_occ.release();
     m->d_i0.release(); m->d_i1.release(); m->d_i2.release(); m->d_choice.release(); m->d_claim.release(); m->d_qmeta.release(); m->d_win2.release();
-    m->d_match.release(); m->d_status.release(); m->d_gclaim.release(); m->d_mergecnt.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
+    m->d_match.release(); m->d_status.release(); m->d_gclaim.release(); m->d_rsync.release(); m->d_mergecnt.release(); m->d_u16.release(); m->d_x0.release(); m->d_x1.release(); m->d_x2.release();
     m->h_i0.release(); m->h_i1.release(); m->h_i2.release(); m->h_match.release(); m->h_u16.release(); m->h_ring.release();
     m->stage_f.release(); m->stage_q.release();
     if (m->ev_stage_f) (void)hipEventDestroy(m->ev_stage_f);

@@ -57,6 +57,7 @@ struct orbm_matcher {
     DevBuf<uint8_t> d_q, d_r, d_scratch, d_queries, d_occ;
     DevBuf<int32_t> d_i0, d_i1, d_i2, d_choice, d_claim, d_match, d_status, d_x0, d_x1, d_x2;
     DevBuf<int32_t> d_gclaim;  // claim tables of the resolve when they do not fit LDS (2 x features)
+    DevBuf<int32_t> d_rsync;   // where the per-camera resolve's workgroups meet (k_resolve_cams): zero between launches
     DevBuf<int2> d_qmeta;      // {blocks, angle} of every query, written by k_project for the resolve
     DevBuf<orbm_window> d_win2; // second windows of a two-camera search
     DevBuf<uint16_t> d_u16;

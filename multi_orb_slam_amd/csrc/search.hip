@@ -607,18 +607,24 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
         for (int b = 0; b < RQ; ++b) any |= disp[b];
         const unsigned long long wany = __ballot(any);
         if (!wany) return false;
-        if (any) {
+        // (round 6: a register slot b none of whose 64 queries is displaced is skipped by the WAVE -- after the first pass or two a handful
+        //  of lanes are still moving, on one slot, and the wave whose queries depend on everybody else's walks eight passes while the other
+        //  fifteen wait at the round's barrier: its pass went from ~2 us to ~0.6, profiles/r06/notes_experiments.md)
+        {
             int ck[RQ][K];
 #pragma unroll
-            for (int b = 0; b < RQ; ++b)
+            for (int b = 0; b < RQ; ++b) {
+                if (!__ballot(disp[b])) continue;
 #pragma unroll
                 for (int k = 1; k < K; ++k) {
                     const bool want = disp[b] && k > p[b] && (e[b][k] & 0xffff) != 0xffff;
-                    const int v = s_claim[want ? (e[b][k] & 0xffff) : 0];   // (as above: ten reads in flight at once.  Measured: asking
+                    const int v = s_claim[want ? (e[b][k] & 0xffff) : 0];   // (the reads of a slot are in flight together.  Measured: asking
                     ck[b][k] = want ? v : -1;                               // for the next entry alone first costs a third trip more often than it saves reads)
                 }
+            }
 #pragma unroll
             for (int b = 0; b < RQ; ++b) {
+                if (!__ballot(disp[b])) continue;
                 if (!disp[b]) continue;
                 const int i = qi[b];
 #ifdef MORB_PHASE_CLOCKS
@@ -715,6 +721,7 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
             if (!w) {
 #ifdef MORB_PHASE_CLOCKS
                 if (lane == 0 && it_dbg < 15) atomicMax((unsigned long long*)&g_ph_chg[32 + it_dbg], (unsigned long long)guard);
+                if (lane == 0 && it_dbg == 1 && blockIdx.x == 0) g_ph_chg[48 + (tid >> 6)] = ((unsigned long long)guard << 32) | (unsigned long long)(wall_clock64() - g_ph_res[0]);   // when this wave left round 1, after how many passes
 #endif
                 break;
             }
@@ -1004,16 +1011,27 @@ __global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __rest
 // (matches), state[5] = 1 and state[8] = "did not finish" (tables or queries beyond this launch's limits, or out of rounds:
 // the exact host fallback takes over, search_finish), state[48..78) the histogram.
 constexpr int RSC_RQ = 4;
-__global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __restrict__ f_cam_start, const int2* __restrict__ qmeta, int nq,
-                                                      int cap, int nf_cap, const int* __restrict__ cand_idx,
-                                                      const uint16_t* __restrict__ cand_dist, const int* __restrict__ cand_count,
-                                                      const uint8_t* __restrict__ occupied, const float* __restrict__ f_angle, int th_high,
-                                                      int check_ori, int max_it, const int* __restrict__ topk, int* __restrict__ choice,
-                                                      int* __restrict__ owner, int* __restrict__ state) {
+__global__ __launch_bounds__(1024) void k_resolve_cams(FrameDev F, const int* __restrict__ f_cam_start, const int2* __restrict__ qmeta, int nq,
+                                                       int cap, int nf_cap, const int* __restrict__ cand_idx,
+                                                       const uint16_t* __restrict__ cand_dist, const int* __restrict__ cand_count,
+                                                       const uint8_t* __restrict__ occupied, const float* __restrict__ f_angle, int th_high,
+                                                       int check_ori, int max_it, const int* __restrict__ topk, int* __restrict__ state,
+                                                       int* __restrict__ match_of_feature, int* __restrict__ status, int tagb, int n_res,
+                                                       MergeJob MJ) {
     MORB_LATENCY_KERNEL();
+    if ((int)blockIdx.x >= n_res) {   // workgroups behind the cameras' (isolated steps): the slice merge of the camera-pair top-2, as in k_resolve_mono
+        const int mq = MJ.d_range ? MJ.d_range[2] : MJ.nq;
+        const int qi_ = ((int)blockIdx.x - n_res) * blockDim.x + threadIdx.x;
+        if (qi_ < mq) top2_merge_query(MJ.p_idx, MJ.p_best, MJ.p_second, MJ.S, mq, qi_, MJ.o_idx, MJ.o_best, MJ.o_second);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(MJ.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) int s_claim[];  // [0, nf_cap): lowest blocking claimant (global query index); [nf_cap, 2 nf_cap): owner
     __shared__ int s_hist[ORBM_HISTO_LENGTH];
-    __shared__ int s_red, s_cnt;
+    __shared__ int s_red, s_cnt, s_code, s_last;
+    __shared__ int s_keep[3];
     __shared__ int s_flag[3];
     __shared__ int s_wtot[16];
     constexpr int K = RESOLVE_K, RQ = RSC_RQ, T = 1024;
@@ -1025,7 +1043,7 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
     const int* tk_g = topk + K * nq;
     MORB_PHASE(g_ph_res, 0);   // (stamps of camera 0's workgroup: start, counted, gathered, set up, rounds done, owners, end; slot 1 = 2: this layout)
     if (tid < 3) s_flag[tid] = 0;
-    if (tid == 0) { s_red = 0; s_cnt = 0; if (cam == 0) state[5] = 1; }
+    if (tid == 0) { s_red = 0; s_cnt = 0; }
     if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
     for (int g = tid; g < min(nf, nf_cap); g += T) { s_claim[g] = 0x7fffffff; s_owner[g] = -1; }
     // the camera's queries: every WAVE takes a contiguous run of the query list (at most 4096 entries: nq < 65536) and reads it 64
@@ -1050,13 +1068,6 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
             mine += __popcll(__ballot(m));
         }
         mybits |= (unsigned long long)bits << b0;
-        if (cam == 0) {
-#pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int i = w0 + 64 * (b0 + u) + lane;
-                if (i < w1 && (qc[u] < 0 || qc[u] >= F.n_cams)) choice[i] = -1;
-            }
-        }
     }
     if (lane == 0) s_wtot[wave] = mine;
     __syncthreads();
@@ -1075,12 +1086,11 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
     __syncthreads();
     MORB_PHASE(g_ph_res, 3);
     const int nqc = s_cnt;
-    if (nf > nf_cap || nqc > RQ * T) {   // beyond this launch's limits (the host sized them from capacities: cannot happen unless those lied)
-        if (tid == 0) atomicOr(&state[8], 1);
-        return;
-    }
-    int sl[RQ][K], cur[RQ], pos[RQ], flr[RQ], qi[RQ];
-    int mx = 0;
+    int sl[RQ][K], cur[RQ], pos[RQ], flr[RQ], qi[RQ], bin_of[RQ];
+    int mx = 0, it = 1, maxcount = 0, acc = 0;
+    // 0 done, 1 = did not finish (limits, rounds), 2 = a candidate list overflowed -- the cameras' workgroups MEET below whatever happened
+    auto run = [&]() -> int {
+    if (nf > nf_cap || nqc > RQ * T) return 1;   // beyond this launch's limits (the host sized them from capacities: cannot happen unless those lied)
 #pragma unroll
     for (int b = 0; b < RQ; ++b) {
         const int j = b * T + tid;
@@ -1104,10 +1114,10 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
     mx = (int)(0x7fffffffu - wave_min_u32(0x7fffffffu - (unsigned)mx));
     if (lane == 0) atomicMax(&s_red, mx);
     __syncthreads();
-    const int maxcount = s_red;
+    maxcount = s_red;
     MORB_PHASE(g_ph_res, 4);
     if (tid == 0 && maxcount > 0) atomicMax(&state[0], maxcount);
-    if (maxcount > cap) return;   // (state[0] > cap: k_rs_write reports the overflow, the search is repeated with more room)
+    if (maxcount > cap) return 2;   // (reported through the status words, the search is repeated with more room)
     // one pass over this thread's queries: k_resolve_mono's, with local feature indices into the tables and global query indices
     // as the claims' values
     auto pass = [&]() -> bool {
@@ -1121,18 +1131,21 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
 #pragma unroll
         for (int b = 0; b < RQ; ++b) any |= disp[b];
         if (!__ballot(any)) return false;
-        if (any) {
+        {   // (slots none of whose queries is displaced are skipped by the wave: see k_resolve_mono)
             int ck[RQ][K];
 #pragma unroll
-            for (int b = 0; b < RQ; ++b)
+            for (int b = 0; b < RQ; ++b) {
+                if (!__ballot(disp[b])) continue;
 #pragma unroll
                 for (int k = 1; k < K; ++k) {
                     const bool want = disp[b] && k > pos[b] && sl[b][k] != 0xffff;
                     const int v = s_claim[want ? sl[b][k] : 0];
                     ck[b][k] = want ? v : -1;
                 }
+            }
 #pragma unroll
             for (int b = 0; b < RQ; ++b) {
+                if (!__ballot(disp[b])) continue;
                 if (!disp[b]) continue;
                 const int i = qi[b];
                 int nk = K;
@@ -1181,7 +1194,7 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
         }
         return true;
     };
-    int it = 1, changed = 1;
+    int changed = 1;
     for (; it < max_it && changed; ++it) {
         if (tid == 0) s_flag[(it + 1) % 3] = 0;
         bool ch = false;
@@ -1193,19 +1206,14 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
         __syncthreads();
         changed = s_flag[it % 3];
     }
-    if (changed) {  // ran out of rounds
-        if (tid == 0) atomicOr(&state[8], 1);
-        return;
-    }
+    if (changed) return 1;  // ran out of rounds
     MORB_PHASE(g_ph_res, 5);
     // owners (the last claimant in query order), this camera's share of the rotation histogram and of the match count
     const float factor = 1.0f / ORBM_HISTO_LENGTH;
-    int acc = 0;
 #pragma unroll
     for (int b = 0; b < RQ; ++b) {
-        const bool live = b * T + tid < nqc;
         const int i = qi[b], c = cur[b];
-        if (live) choice[i] = c >= 0 ? c + f0 : -1;
+        bin_of[b] = -1;
         if (c >= 0) { ++acc; atomicMax(&s_owner[c], i); }
         if (check_ori) {
             int bin = -1;
@@ -1216,20 +1224,94 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
                 if (bin == ORBM_HISTO_LENGTH) bin = 0;
                 if (bin < 0 || bin >= ORBM_HISTO_LENGTH) bin = -1;
             }
+            bin_of[b] = bin;
             if (bin >= 0) atomicAdd(&s_hist[bin], 1);
         }
     }
-    acc = __builtin_amdgcn_readlane(wave_incl_scan(acc), 63);
-    if (lane == 0 && acc) atomicAdd(&s_red, acc);   // (s_red still holds maxcount: taken off again below)
-    __syncthreads();
-    MORB_PHASE(g_ph_res, 6);
-    for (int g = tid; g < nf; g += T) owner[f0 + g] = s_owner[g];
-    if (tid < ORBM_HISTO_LENGTH) { const int v = s_hist[tid]; if (v) atomicAdd(&state[48 + tid], v); }
-    if (tid == 64) { const int v = s_red - maxcount; if (v) atomicAdd(&state[1], v); }
+    return 0;
+    };
+    const int code = run();
+    __syncthreads();   // (every wave's owners and histogram adds have landed)
+    // ---- the cameras meet: what needs the WHOLE frame -- the rotation histogram's three maxima -- is summed in `state` (device memory:
+    // [0] longest list, [1] matches, [6] rounds, [8] did-not-finish, [9] arrived, [10] finished, [48..78) histogram; all zero between launches:
+    // the last workgroup leaves it that way).  A workgroup that could not finish still arrives.
+    if (code == 0 && tid < ORBM_HISTO_LENGTH) { const int v = s_hist[tid]; if (v) atomicAdd(&state[48 + tid], v); }
+    if (tid == 64 && code == 1) atomicOr(&state[8], 1);
     if (tid == 65) atomicMax(&state[6], it);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(&state[9], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(&state[9], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_res && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+        if (spins >= (1 << 22)) atomicOr(&state[8], 1);   // (a camera's workgroup never came: the host's exact pass takes over)
+        const int gmax = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_code = gmax > cap ? 2 : (__hip_atomic_load(&state[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0);
+    }
+    __syncthreads();
+    const int all = s_code;
+    MORB_PHASE(g_ph_res, 6);
+    if (all == 0) {
+        int kept = 0;
+        if (check_ori) {
+            if (tid < 64) {   // ComputeThreeMaxima (reference src/ORBmatcher.cc:3948-3989) over the frame's histogram, by every camera alike
+                const int sv = tid < ORBM_HISTO_LENGTH ? __hip_atomic_load(&state[48 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                int rank = 0;
+#pragma unroll
+                for (int j = 0; j < ORBM_HISTO_LENGTH; ++j) {
+                    const int sj = __builtin_amdgcn_readlane(sv, j);
+                    rank += (sj > sv || (sj == sv && j < tid)) ? 1 : 0;
+                }
+                const bool in = tid < ORBM_HISTO_LENGTH && sv > 0;
+                const unsigned long long r1 = __ballot(in && rank == 0), r2 = __ballot(in && rank == 1), r3 = __ballot(in && rank == 2);
+                int i1 = r1 ? __ffsll((long long)r1) - 1 : -1, i2 = r2 ? __ffsll((long long)r2) - 1 : -1, i3 = r3 ? __ffsll((long long)r3) - 1 : -1;
+                const int m1 = i1 >= 0 ? __builtin_amdgcn_readlane(sv, i1) : 0, m2 = i2 >= 0 ? __builtin_amdgcn_readlane(sv, i2) : 0,
+                          m3 = i3 >= 0 ? __builtin_amdgcn_readlane(sv, i3) : 0;
+                if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+                else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+                if (tid == 0) { s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < RQ; ++b) {
+                const int c = cur[b], bin = bin_of[b];
+                if (c >= 0 && bin >= 0 && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) { s_owner[c] = -2; --acc; }   // (every writer stores -2; owners were settled before the meeting)
+            }
+        }
+        kept = __builtin_amdgcn_readlane(wave_incl_scan(acc), 63);
+        if (lane == 0 && kept) atomicAdd(&state[1], kept);
+        __syncthreads();
+        const int NT = F.n_total_dev ? *F.n_total_dev : F.n_total;
+        for (int g = tid; g < nf; g += T) match_of_feature[f0 + g] = tagb ? (tagb | (s_owner[g] + 2)) : s_owner[g];
+        if (tagb && cam == 0) for (int g = NT + tid; g < F.n_total; g += T) match_of_feature[g] = tagb | 1;   // (see k_resolve: no stale tag can match)
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&state[10], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == n_res - 1;
+    __syncthreads();
+    if (!s_last) return;
+    // the last camera out: the result words (behind the merging workgroups of the same launch, as in k_resolve_mono), then `state` back to zero
+    bool merged = true;
+    if (MJ.S > 1 && MJ.done) {
+        if (tid == 0) {
+            int spins = 0;
+            while ((int)(__hip_atomic_load(MJ.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - MJ.target) < 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+            s_code = spins < (1 << 22) ? 1 : 0;
+        }
+        __syncthreads();
+        merged = s_code != 0;
+    }
+    if (tid == 0) {
+        const int matches = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        status[1] = tagb | (all ? 0 : matches); status[2] = tagb | __hip_atomic_load(&state[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        status[3] = tagb | __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        status[0] = tagb | (all ? all : (merged ? 0 : 3));
+    }
+    __syncthreads();
+    if (tid < RS_STATE_INTS) state[tid] = 0;
     MORB_PHASE(g_ph_res, 7);
 #ifdef MORB_PHASE_CLOCKS
-    if (tid == 0 && cam == 0) { g_ph_res[1] = 2; g_ph_res[62] = (unsigned long long)it; }
+    if (tid == 0) { g_ph_res[1] = 2; g_ph_res[62] = (unsigned long long)it; }
 #endif
 }
 
@@ -1242,7 +1324,7 @@ __global__ __launch_bounds__(1024) void k_rs_mono_cam(FrameDev F, const int* __r
 int morb::search_raise_lds_limits() {
     const void* fns[] = {(const void*)k_resolve<true, false>, (const void*)k_resolve<false, false>, (const void*)k_resolve<true, true>,
                          (const void*)k_resolve<false, true>, (const void*)k_resolve_mono<2, true>, (const void*)k_resolve_mono<2, false>,
-                         (const void*)k_resolve_mono<4, true>, (const void*)k_resolve_mono<4, false>, (const void*)k_rs_mono_cam};
+                         (const void*)k_resolve_mono<4, true>, (const void*)k_resolve_mono<4, false>, (const void*)k_resolve_cams};
     for (const void* fn : fns) MORB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return ORB_OK;
 }
@@ -1500,42 +1582,59 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
                           (J.side && merge_rides && !multi && !J.points) ? &MJ : nullptr)))
         return rc;
     J.side = nullptr;   // (a retry of the search with more room per query does not repeat the side work)
-    if (multi) {
-        int* tab0 = m->d_gclaim.p; int* tab1 = tab0 + n; int* state = tab1 + n;
-        MORB_HIP(hipMemsetAsync(state, 0, RS_STATE_INTS * sizeof(int), m->stream));
-        const int nb_all = (std::max(n, nq) + 255) / 256, nb_q = (nq + 255) / 256, nb_f = (n + 255) / 256;
-        // One launch per sweep, enqueued blind: as many as the stream of searches has needed lately plus four (12 at least, 24 at
-        // most; 8 x 4000 features converge in 10-11), because a sweep that has nothing to do still costs its launch (~4.7 us each
-        // on the critical path of the step).  A search that does not converge in its allotment is finished by the exact host
-        // fallback and the next one gets the full 24 again.
-        // Frame searches (one window per query, no ratio test) resolve per camera in ONE launch when every camera's tables and
-        // queries fit a workgroup (k_rs_mono_cam); the per-sweep form below keeps the rest.  MORB_RS_PER_CAMERA=0: per-sweep form only.
-        static const bool cam_env = [] { const char* e = getenv("MORB_RS_PER_CAMERA"); return !(e && atoi(e) == 0); }();
-        int nf_cap = 0, q_cam_max = J.q_cam_max;
-        const bool starts_ok = cur->camera_major && (int)cur->cam_start.size() == cur->n_cams + 1 && cur->cam_start[cur->n_cams] == n;
-        if (starts_ok) for (int c = 0; c < cur->n_cams; ++c) nf_cap = std::max(nf_cap, cur->cam_start[c + 1] - cur->cam_start[c]);
-        if (cam_env && !J.points && !J.win2_dev && starts_ok && !q_cam_max && !J.msrc && J.q) {   // (host records: count them)
+    J.seq = 0;
+    if (J.want_tags) { m->resolve_seq = m->resolve_seq % 2047 + 1; J.seq = m->resolve_seq; }   // 1..2047, never 0
+    // Frame searches (one window per query, no ratio test) resolve PER CAMERA in one launch when every camera's tables fit a workgroup's
+    // LDS and its queries a workgroup's registers (k_resolve_cams: a query looks at one camera's grid, so claims never cross cameras;
+    // the cameras' workgroups meet once, in the kernel, for the rotation histogram).  Large rigs (tables of the whole frame beyond LDS)
+    // always take it.  Smaller rigs only when asked to (MORB_RS_CAMS_MIN_Q = queries from which on; default never): measured in round 6
+    // (VERDICT r05 #4 asked for it), 2 x 2000 queries take 38 us per camera against 31 in one workgroup and 4 x 1000 31 against 28 -- the
+    // rounds do get shorter (11 us against 17), but the scan for the camera's queries (4 us: one trip to memory), the meeting (6 us over
+    // L2 between XCDs) and the separate tail cost more than that (profiles/r06/notes_experiments.md).  MORB_RS_PER_CAMERA=0: never.
+    static const bool cam_env = [] { const char* e = getenv("MORB_RS_PER_CAMERA"); return !(e && atoi(e) == 0); }();
+    static const int cams_min_q = [] { const char* e = getenv("MORB_RS_CAMS_MIN_Q"); return e ? atoi(e) : 0x7fffffff; }();
+    int nf_cap = 0, q_cam_max = J.q_cam_max;
+    const bool starts_ok = cur->camera_major && (int)cur->cam_start.size() == cur->n_cams + 1 && cur->cam_start[cur->n_cams] == n;
+    const bool cams_want = cam_env && !J.points && !J.win2_dev && starts_ok && (multi || (cur->n_cams >= 2 && nq >= cams_min_q));
+    if (cams_want) {
+        for (int c = 0; c < cur->n_cams; ++c) nf_cap = std::max(nf_cap, cur->cam_start[c + 1] - cur->cam_start[c]);
+        if (!q_cam_max && !J.msrc && J.q) {   // (host records: count them)
             std::vector<int>& per = m->rs_cam_count;
             per.assign((size_t)cur->n_cams, 0);
             for (int i = 0; i < nq; ++i) { const int c = J.q[i].cam; if (c >= 0 && c < cur->n_cams) q_cam_max = std::max(q_cam_max, ++per[c]); }
             if (!q_cam_max) q_cam_max = 1;
         }
-        const size_t lds_cam = (size_t)8 * nf_cap + (size_t)2 * RSC_RQ * 1024;
-        if (cam_env && !J.points && !J.win2_dev && nf_cap > 0 && q_cam_max > 0 && q_cam_max <= RSC_RQ * 1024 && nq < 65536 &&
-            lds_cam <= 150 * 1024) {
-            hipLaunchKernelGGL(k_rs_mono_cam, dim3(cur->n_cams), dim3(1024), lds_cam, m->stream, cur->dev(), (const int*)cur->b->d_cam_start.p,
-                               (const int2*)m->d_qmeta.p, nq, cap, nf_cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p,
-                               (const int*)m->d_i1.p, d_occ, (const float*)cur->b->d_ang.p, th_high, J.check_ori, 4096,
-                               (const int*)m->d_claim.p, m->d_choice.p, m->d_match.p, state);
-            if (J.check_ori)
-                hipLaunchKernelGGL(k_rs_reject, dim3(nb_q), dim3(256), 0, m->stream, (const orbm_query*)m->d_queries.p, nq, cap,
-                                   (const int*)m->d_choice.p, (const float*)cur->b->d_ang.p, m->d_match.p, state);
-            hipLaunchKernelGGL(k_rs_write, dim3(nb_f), dim3(256), 0, m->stream, n, cur->dev().n_total_dev, cap, (const int*)m->d_match.p,
-                               (const int*)state, m->h_match.dp + 4, m->h_match.dp);
-            MORB_HIP(hipGetLastError());
-            J.multi = true; J.device_path = true;
+    }
+    const size_t lds_cam = (size_t)8 * nf_cap + (size_t)2 * RSC_RQ * 1024;
+    const bool cams_fit = cams_want && nf_cap > 0 && q_cam_max > 0 && q_cam_max <= RSC_RQ * 1024 && nq < 65536 && lds_cam <= 150 * 1024;
+    auto launch_cams = [&](MergeJob MJc, int merge_blocks) -> int {
+        int rcl;
+        if (!m->d_rsync.p) {   // the meeting's words: zero between launches (the last workgroup of a launch leaves them so)
+            if ((rcl = m->d_rsync.reserve(RS_STATE_INTS))) return rcl;
+            MORB_HIP(hipMemsetAsync(m->d_rsync.p, 0, RS_STATE_INTS * sizeof(int), m->stream));
+        }
+        hipLaunchKernelGGL(k_resolve_cams, dim3(cur->n_cams + merge_blocks), dim3(1024), lds_cam, m->stream, cur->dev(), (const int*)cur->b->d_cam_start.p,
+                           (const int2*)m->d_qmeta.p, nq, cap, nf_cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p,
+                           (const int*)m->d_i1.p, d_occ, (const float*)cur->b->d_ang.p, th_high, J.check_ori, 4096,
+                           (const int*)m->d_claim.p, m->d_rsync.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20, cur->n_cams, MJc);
+        MORB_HIP(hipGetLastError());
+        return ORB_OK;
+    };
+    if (multi) {
+        int* tab0 = m->d_gclaim.p; int* tab1 = tab0 + n; int* state = tab1 + n;
+        if (!cams_fit) MORB_HIP(hipMemsetAsync(state, 0, RS_STATE_INTS * sizeof(int), m->stream));
+        const int nb_all = (std::max(n, nq) + 255) / 256, nb_q = (nq + 255) / 256, nb_f = (n + 255) / 256;
+        // One launch per sweep, enqueued blind: as many as the stream of searches has needed lately plus four (12 at least, 24 at
+        // most; 8 x 4000 features converge in 10-11), because a sweep that has nothing to do still costs its launch (~4.7 us each
+        // on the critical path of the step).  A search that does not converge in its allotment is finished by the exact host
+        // fallback and the next one gets the full 24 again.
+        if (cams_fit) {   // one launch, one workgroup per camera (k_resolve_cams): meeting, rejection and the tagged result words inside
+            if ((rc = launch_cams(MergeJob{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr}, 0))) return rc;
+            J.device_path = true;
+            J.pollable = J.seq != 0;
             return ORB_OK;
         }
+        J.seq = 0;   // (the per-sweep form's result words carry no tags: the host synchronises the stream)
         const int n_sweeps = std::min(RS_MAX_SWEEPS, std::max(12, m->rs_sweeps_hint));
         hipLaunchKernelGGL(k_rs_init, dim3(nb_all), dim3(256), 0, m->stream, n, nq, tab0, tab1, m->d_match.p, m->d_choice.p,
                            (const int*)m->d_i1.p, state, n_sweeps);
@@ -1573,8 +1672,6 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
                        nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
                        (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
                        (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20)
-    J.seq = 0;
-    if (J.want_tags) { m->resolve_seq = m->resolve_seq % 2047 + 1; J.seq = m->resolve_seq; }   // 1..2047, never 0
     static const bool mono_env = [] { const char* e = getenv("MORB_RESOLVE_MONO"); return !(e && atoi(e) == 0); }();
     // The frame search's monotone resolve keeps less per query (16-bit features, no distances; mono_lds): it takes frames of up to
     // ~6000 features / queries (4 x 1000, 2 x 2000: where k_resolve's Jacobi form keeps its query state in HBM and costs 53 us),
@@ -1584,8 +1681,18 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
         return (size_t)n * 8 + nq2 * 4 + (size_t)RESOLVE_K * nq2 * 2 + (((size_t)nq + 3) & ~(size_t)3) + (ang ? ((size_t)nq + (size_t)n) * 4 : 0) + 16;
     };
     const bool will_mono = !J.points && mono_env && n < 65535 && mono_lds(false) <= 150 * 1024;
-    if (MJ.S > 1 && !will_mono) { if ((rc = launch_merge(m->stream, MJ))) return rc; MJ.S = 0; }   // (no carrier after all: a launch of its own)
-    if (will_mono) {
+    if (MJ.S > 1 && !will_mono && !cams_fit) { if ((rc = launch_merge(m->stream, MJ))) return rc; MJ.S = 0; }   // (no carrier after all: a launch of its own)
+    if (cams_fit) {
+        const int merge_blocks = MJ.S > 1 ? (MJ.nq + 1023) / 1024 : 0;   // (behind the cameras' workgroups)
+        if (merge_blocks) {
+            if ((rc = m->d_mergecnt.reserve(4))) return rc;
+            if (!m->merge_ready) { MORB_HIP(hipMemsetAsync(m->d_mergecnt.p, 0, 16, m->stream)); m->merge_ready = true; m->merge_target = 0; }
+            m->merge_target += (unsigned)merge_blocks;
+            MJ.done = reinterpret_cast<unsigned*>(m->d_mergecnt.p); MJ.target = m->merge_target;
+        }
+        if ((rc = launch_cams(MJ, merge_blocks))) return rc;
+        MJ.S = 0;   // (carried)
+    } else if (will_mono) {
         const bool ang = mono_lds(true) <= 150 * 1024;
         const size_t ml = mono_lds(ang);
 #define MORB_MONO_LAUNCH(RQ_, ANG_)                                                                                                       \
