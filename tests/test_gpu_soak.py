@@ -93,3 +93,22 @@ def test_digest_of_a_stream_with_changing_motion_does_not_depend_on_the_ab_switc
         out.append(r.stdout.strip().splitlines()[-1])
     assert out[0] == out[1] and "digest" in out[0], out
     assert int(out[0].split("temporal ")[1].split(",")[0]) > 600 * 300
+
+
+def test_extraction_next_to_the_matrix_core_top2_on_one_hardware_queue():
+    """The aggravated condition of profiles/r05/describe_defect.md as a regression test: ONE hardware queue
+    (GPU_MAX_HW_QUEUES=1, where the build WITH the SLP vectorizer produced wrong descriptor bits in 65 % of the runs), four front ends on
+    four host threads -- three extractor streams each, their describe / FAST / quadtree chains next to the rig-wide FP4 matrix-core top-2
+    of the exchange on the matcher streams -- kept alive over hundreds of 10-step runs for 12 s: every keypoint record (position,
+    response, angle: what k_fast_cells' candidates and the quadtree decide) and every descriptor of every step against the oracle.
+    The product build (-fno-slp-vectorize, held by tests/test_isa_guard.py) must not show a single wrong row."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "describe_defect", "run_rig.py"), "--seconds", "12", "--persistent", "25", "--placement", "chain",
+                        "--tag", "suite"], env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["GPU_MAX_HW_QUEUES"] == "1" and out["lib"] == "libmorb.so"
+    assert out["runs"] >= 50, out
+    assert out["bad_runs"] == 0 and out["wrong_rows"] == 0 and not out["detail"], out
