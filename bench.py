@@ -114,7 +114,7 @@ def pct(xs, p):
 def _settled_launches(rt, run, stream, iters, group=10, tol=0.003, max_groups=40):
     """Average duration (ms) of `iters` launches of `run` AFTER the launch duration has settled, + how many launches that took.
     A kernel that keeps the whole chip busy runs its first ~100-150 launches (tens of ms after an idle period) up to 20 %
-    slower than the ones after -- the clocks take that long to settle (tools/experiments/top2_transient.py; the curve is in
+    slower than the ones after -- the clocks take that long to settle (the curve is in
     profiles/r03/notes_experiments.md) -- so the sustained figure is timed only once the mean of three consecutive groups of
     `group` launches is within `tol` of the mean of the three groups before (or after `max_groups` groups).  HIP events on the stream the kernels are launched on."""
     ev = [rt.Event() for _ in range(max_groups + 1)]

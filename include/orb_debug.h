@@ -25,9 +25,12 @@ int orbx_debug_last_path(const orbx_extractor* ex);
  * (large rigs driven through orbf_*, which promises the buffers' lifetime; 0 everywhere else) */
 int orbx_debug_level0_in_place(const orbx_extractor* ex);
 /* inspection: how the geometry of the most recent run builds its pyramid -- 0 one tile launch for all levels (k_pyramid_tiled: small
- * rigs), 1 one k_resize_v4 launch per level, 2 the round-1 chain (k_resize2 / k_resize), 3 two tile launches with four pixels per lane
- * (k_pyramid_tiled4: large rigs); -1 before the first run */
+ * rigs), 2 the generic chain (one k_resize launch per level: parameter sets outside both tile forms, MORB_PYR_CHAIN=2), 3 two tile
+ * launches with four pixels per lane (k_pyramid_tiled4: large rigs, MORB_PYR_CHAIN=1); -1 before the first run */
 int orbx_debug_pyramid_form(const orbx_extractor* ex);
+/* tests of the large-rig plan's geometry: tile width / height and split level (defaults 128, 64, 3; 0 = unchanged) of every handle
+ * created afterwards.  Process-wide; the product never calls it. */
+int orbx_debug_pyramid_plan(int tile_w, int tile_h, int split);
 
 /* ---- matcher ------------------------------------------------------------------------------------------------------------- */
 /* {status, nmatches, sweeps, longest candidate list} of the last device-side resolve (inspection only) */

@@ -153,6 +153,7 @@ def lib():
     L.orbx_debug_last_path.argtypes = [vp]
     L.orbx_debug_level0_in_place.argtypes = [vp]
     L.orbx_debug_pyramid_form.argtypes = [vp]
+    L.orbx_debug_pyramid_plan.argtypes = [i32, i32, i32]
     L.orbf_create.argtypes = [vp, i32, i32, i32, i32, vp]
     L.orbf_create_depth.argtypes = [vp, i32, i32, i32, i32, i32, vp]
     L.orbf_destroy.argtypes = [vp]; L.orbf_destroy.restype = None

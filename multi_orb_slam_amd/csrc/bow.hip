@@ -734,8 +734,7 @@ int launch_join(orbv_workspace* w, const SideDev& A, const SideDev& B, int max_n
     if (lds_cand < max_nc) lds_cand &= ~63;   // a partial stage ends on a lane-0 boundary: candidate j always belongs to lane j % 64
     const size_t lds = (size_t)claimed_bytes + (size_t)lds_cand * 40;
     // four waves per node from ~128 candidates per node on (the barriers cost more than they save below that)
-    static const int nw_env = [] { const char* e = getenv("MORB_BOW_WAVES"); return e ? atoi(e) : 0; }();
-    const bool wide = nw_env ? nw_env > 1 : max_nc >= 128;
+    const bool wide = max_nc >= 128;
     if (wide) {
         if (mode == 0) k_bow_join<0, 4><<<A.n_nodes, 256, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);
         else if (mode == 1) k_bow_join<1, 4><<<A.n_nodes, 256, lds, st>>>(A, B, T, th_low, nnratio, check_ori, W, claimed_bytes, lds_cand);

@@ -314,7 +314,7 @@ int morb::peer_world(const PeerComm* C) { return C->world; }
 int morb::peer_rank(const PeerComm* C) { return C->rank; }
 
 // this rank's arena + its handle for the other ranks (block: bytes of one export block; nslots: exchanges in flight)
-int morb::peer_export(PeerComm** out, int world, int rank, size_t block, int nslots, uint8_t* handle) {
+int morb::peer_export(PeerComm** out, int world, int rank, size_t block, int nslots, long timeout_ms, uint8_t* handle) {
     MORB_ARG(out && handle && world >= 1 && world <= 64 && rank >= 0 && rank < world && block % 16 == 0 && nslots >= 1);
     std::unique_ptr<PeerComm> C(new PeerComm());
     C->world = world; C->rank = rank; C->nslots = nslots; C->block = block;
@@ -340,9 +340,7 @@ int morb::peer_export(PeerComm** out, int world, int rank, size_t block, int nsl
     if ((rc = C->d_peer.reserve(world)) || (rc = C->d_counter.reserve((size_t)nslots * 2)) || (rc = C->missing.reserve((size_t)nslots * 4))) { (void)hipFree(C->local); return rc; }
     MORB_HIP(hipMemset(C->d_counter.p, 0, (size_t)nslots * 2 * sizeof(unsigned)));
     memset(C->missing.p, 0, (size_t)nslots * 4 * sizeof(uint32_t));
-    const char* e = getenv("MORB_EXCHANGE_TIMEOUT_MS");
-    const long ms = e ? std::max(1L, atol(e)) : 15000L;
-    C->timeout_ticks = (unsigned long long)ms * 100000ull;
+    C->timeout_ticks = (unsigned long long)std::max(1L, timeout_ms) * 100000ull;   // (wall_clock64: 100 MHz)
     C->peer.assign(world, nullptr);
     C->peer[rank] = C->local;
     *out = C.release();

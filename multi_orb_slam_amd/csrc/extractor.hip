@@ -198,145 +198,6 @@ __global__ __launch_bounds__(256) void k_resize(const LevelInfo* __restrict__ L,
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * D.stride + x4) = out;
 }
 
-// k_resize for LARGE rigs (round 3): four adjacent pixels per lane as in k_resize, but the eight taps of a source row are not
-// eight byte loads: with level steps of at most 1.6 they lie within 8 bytes of the first one, so a row is three aligned dwords
-// (one global_load_dwordx3), shifted to start at the first tap (v_alignbyte_b32), and one v_perm_b32 per row and side pulls the
-// four left (right) taps out -- 6 memory instructions per four pixels instead of 21.  The whole-pyramid tile kernel is a latency
-// design (one launch, everything in LDS: 8.7 us per tile); on 8 x 1080p it is 13 x its HBM time, and this chain -- one launch per
-// level, all cameras batched -- does the same arithmetic with a third of the instructions.  Same integers, same bytes.
-// (The reads past a row's last tap stay inside the camera's pyramid block: orbx_create leaves 16 spare bytes behind the last level.)
-__global__ __launch_bounds__(256) void k_resize_v4(const LevelInfo* __restrict__ L, int max_levels, int level,
-                                                   uint8_t* __restrict__ pyr, size_t cam_pitch,
-                                                   const int4* __restrict__ xgrp, const int4* __restrict__ ytab,
-                                                   const L0Src* __restrict__ l0) {
-    // Workgroups reach the 8 XCDs round robin in dispatch order (x fastest, then y, then z), and a 256-pixel x 4-row block reads
-    // source lines its neighbours on both axes read as well.  The launch's blocks are therefore dealt so that every XCD works
-    // through ONE contiguous run of them in (camera, row band, column) order -- whole cameras of an 8-camera rig, bands of rows
-    // otherwise -- and a source line is pulled into one L2 (round 3 counters: 91.5 MB fetched per 8 x 1080p step for 50 MB of
-    // source levels).  Affinity only.
-    const int n_blocks = gridDim.x * gridDim.y * gridDim.z;
-    const int dealt = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), n_blocks);
-    const int per_cam = gridDim.x * gridDim.y;
-    const int cam = dealt / per_cam, in_cam = dealt - cam * per_cam;
-    const int by = in_cam / (int)gridDim.x, bx = in_cam - by * (int)gridDim.x;
-    const LevelInfo D = L[cam * max_levels + level];
-    const LevelInfo S = L[cam * max_levels + level - 1];
-    const int g4 = bx * 64 + threadIdx.x, x4 = g4 * 4;
-    const int y = by * 4 + threadIdx.y;
-    if (y >= D.h || x4 >= D.w) return;
-    const uint8_t* src = pyr + cam * cam_pitch + S.pyr_off;
-    int sstride = S.stride;
-    bool external = false;   // level 0 read in the caller's buffer: nothing may be read past its last row
-    if (level == 1 && l0) {
-        const L0Src s0 = l0[cam];
-        if (s0.ptr) { src = s0.ptr; sstride = s0.stride; external = true; }
-    }
-    uint8_t* dst = pyr + cam * cam_pitch + D.pyr_off;
-    const int4 yt = ytab[D.ytab_off + y];  // {row0, row1, beta0, beta1}, rows already clipped to [0, sh-1]
-    // Round 4 (second half): what the four columns need of the x table comes ready-made per group (build_resize_groups): the first
-    // tap's column c, per column ONE byte selector that puts its left tap into the low half and its right tap into the high half of
-    // a dword straight out of the row's eight bytes (v_perm_b32), and the coefficient pair alpha0 | alpha1 << 16 -- so a horizontal
-    // sum is one v_perm + one v_dot2_u32_u16 where it was two byte extracts, a multiply and a multiply-add behind two more permutes
-    // and twenty instructions of selector arithmetic per lane (155 -> ~95 vector instructions per four pixels; same integers).
-    const int4* G = xgrp + 3 * (size_t)(D.xgrp_off + g4);
-    const int4 g0 = G[0], g1 = G[1];
-    const int g2 = G[2].x;
-    const int c = g0.x;
-    const uint32_t ps[4] = {(uint32_t)g0.y, (uint32_t)g0.z, (uint32_t)g0.w, (uint32_t)g1.x};
-    const uint32_t al[4] = {(uint32_t)g1.y, (uint32_t)g1.z, (uint32_t)g1.w, (uint32_t)g2};
-    using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
-    uint32_t h[2][4];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int row = r ? yt.y : yt.x;
-        const uint8_t* p = src + (size_t)row * sstride + c;
-        const int sh = (int)(reinterpret_cast<uintptr_t>(p) & 3);
-        uint32_t lo, hi;
-        if (external && row == S.h - 1 && c - sh + 12 > S.w) {
-            // the three dwords would run past the end of the caller's buffer (last row, last columns): the eight bytes one by one
-            // (columns past the row's end are never selected: clamped to its last one)
-            lo = 0; hi = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                lo |= (uint32_t)p[min(k, S.w - 1 - c)] << (8 * k);
-                hi |= (uint32_t)p[min(4 + k, S.w - 1 - c)] << (8 * k);
-            }
-        } else {
-            const uint32_t* w = reinterpret_cast<const uint32_t*>(p - sh);
-            const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
-            lo = __builtin_amdgcn_alignbyte(d1, d0, sh); hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            h[r][j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, ps[j])), __builtin_bit_cast(u16x2, al[j]), 0u, false);
-    }
-    uint32_t out = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // (24-bit multiplies: full rate where the 32-bit one takes four passes; beta <= 2048, the sums below 2^16)
-        const uint32_t v = ((((__umul24((uint32_t)yt.z, h[0][j] >> 4)) >> 16) + ((__umul24((uint32_t)yt.w, h[1][j] >> 4)) >> 16) + 2) >> 2) & 0xff;
-        out |= v << (8 * j);
-    }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)y * D.stride + x4) = out;   // (columns past w: padding of the 64-byte row pitch, as k_resize)
-}
-
-// One pixel of a pyramid level from the level below it: cv::resize(INTER_LINEAR) in 11-bit fixed point, exactly the arithmetic
-// of k_resize (tables: xt = {sx0 | sx1 << 16, alpha0 | alpha1 << 16}, yt = {row0, row1, beta0, beta1}).
-__device__ __forceinline__ int resize_px(const uint8_t* __restrict__ src, int sstride, const int2 xt, const int4 yt) {
-    const uint8_t* s0 = src + (size_t)yt.x * sstride;
-    const uint8_t* s1 = src + (size_t)yt.y * sstride;
-    const int sx0 = xt.x & 0xffff, sx1 = (unsigned)xt.x >> 16;
-    const int a0 = (short)(xt.y & 0xffff), a1 = xt.y >> 16;
-    const int h0 = s0[sx0] * a0 + s0[sx1] * a1;
-    const int h1 = s1[sx0] * a0 + s1[sx1] * a1;
-    return ((((yt.z * (h0 >> 4)) >> 16) + ((yt.w * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
-}
-
-// TWO pyramid levels per launch.  Level `level` is resized from level - 1 as in k_resize; level + 1 does not wait for it: each
-// of its pixels re-derives the 2 x 2 pixels of `level` it interpolates from straight out of level - 1 (integer arithmetic on
-// the same inputs: the same bytes the other half of the launch stores).  The resize chain of an 8-level pyramid is then 4
-// dependent launches instead of 7 -- these kernels take 3-5 us each, so it is the number of launches that costs.
-// grid.y: [0, yblocks_a) rows of `level`, [yblocks_a, ...) rows of level + 1.
-__global__ __launch_bounds__(256) void k_resize2(const LevelInfo* __restrict__ L, int max_levels, int level, int yblocks_a,
-                                                 uint8_t* __restrict__ pyr, size_t cam_pitch,
-                                                 const int2* __restrict__ xtab, const int4* __restrict__ ytab) {
-    const int cam = blockIdx.z;
-    const LevelInfo S = L[cam * max_levels + level - 1];
-    const LevelInfo A = L[cam * max_levels + level];
-    const uint8_t* src = pyr + cam * cam_pitch + S.pyr_off;
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if ((int)blockIdx.y < yblocks_a) {
-        const int y = blockIdx.y * 4 + threadIdx.y;
-        if (y >= A.h || x4 >= A.w) return;
-        const int4 yt = ytab[A.ytab_off + y];
-        uint32_t out = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (x4 + k < A.w) out |= (uint32_t)resize_px(src, S.stride, xtab[A.xtab_off + x4 + k], yt) << (8 * k);
-        *reinterpret_cast<uint32_t*>(pyr + cam * cam_pitch + A.pyr_off + (size_t)y * A.stride + x4) = out;
-        return;
-    }
-    if (level + 1 >= max_levels) return;
-    // (one pixel per thread here: four source pixels to re-derive for each, i.e. the same work per thread as the other half)
-    const LevelInfo B = L[cam * max_levels + level + 1];
-    const int y = ((int)blockIdx.y - yblocks_a) * 4 + threadIdx.y;
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    if (y >= B.h || x >= B.w) return;
-    const int4 yb = ytab[B.ytab_off + y];                       // rows of level `level` this output row blends
-    const int4 ya0 = ytab[A.ytab_off + yb.x], ya1 = ytab[A.ytab_off + yb.y];
-    const int2 xb = xtab[B.xtab_off + x];
-    const int sx0 = xb.x & 0xffff, sx1 = (unsigned)xb.x >> 16;
-    const int a0 = (short)(xb.y & 0xffff), a1 = xb.y >> 16;
-    const int2 xa0 = xtab[A.xtab_off + sx0], xa1 = xtab[A.xtab_off + sx1];
-    const int p00 = resize_px(src, S.stride, xa0, ya0), p01 = resize_px(src, S.stride, xa1, ya0);
-    const int p10 = resize_px(src, S.stride, xa0, ya1), p11 = resize_px(src, S.stride, xa1, ya1);
-    const int h0 = p00 * a0 + p01 * a1;
-    const int h1 = p10 * a0 + p11 * a1;
-    const int v = ((((yb.z * (h0 >> 4)) >> 16) + ((yb.w * (h1 >> 4)) >> 16) + 2) >> 2);
-    pyr[cam * cam_pitch + B.pyr_off + (size_t)y * B.stride + x] = (uint8_t)(v & 0xff);
-}
-
-// ------------------------------------------------------------------------------------------------ K0 + K1 in one launch
 // The whole pyramid of every camera in ONE launch (round 3).  The resize chain is a chain of dependencies only between pixels
 // that lie over each other: a workgroup takes one T x T tile of level 0 and computes the part of EVERY level that hangs below
 // it, level after level in LDS, storing what it owns.  Ownership: destination column x of level l belongs to the tile that
@@ -2226,6 +2087,10 @@ struct OctreeTask {
 };
 
 // ================================================================================================ C ABI
+// tile width / height / split level of the large-rig pyramid plan (orbx_debug_pyramid_plan: the tests of the plan's geometry change it
+// before they create a handle; the product never does)
+static int g_t4_plan[3] = {128, 64, 3};
+
 struct orbx_extractor {
     int device = 0, n_cams = 0, max_w = 0, max_h = 0, max_levels = 0;
     hipStream_t stream = nullptr;
@@ -2253,12 +2118,12 @@ struct orbx_extractor {
     DevBuf<uint8_t> d_desc_tabs;      // k_describe's DescribeTables (IC_Angle items + float test locations)
     // the tiled whole-pyramid launch (k_pyramid_tiled): spans per (camera, level, tile column / row), tiles per camera, LDS need
     DevBuf<int4> d_pyr_sx, d_pyr_sy;
-    int pyr_tx_max = 0, pyr_ty_max = 0, pyr_lds = 0, pyr_tile = 0, pyr_tab_cap = 0, pyr_threads = 256;
+    int pyr_tx_max = 0, pyr_ty_max = 0, pyr_lds = 0, pyr_tile = 0, pyr_tab_cap = 0;
     short pyr_tx[64] = {}, pyr_ty[64] = {};
     bool ingest_host = false;         // a pending ingest source lives in host memory (read across PCIe)
     bool tiled_ok = false;            // ... and this geometry fits it (LDS, halo, level count) and is small enough to prefer it
-    bool chain_v4 = false;            // the resize chain runs k_resize_v4 (level steps <= 1.6: the taps of four neighbours within 8 bytes)
-    bool tiled_pyramid = true;        // MORB_TILED_PYRAMID=0: the resize chain of rounds 1-2 (k_resize2 / k_resize launches)
+    bool v4_ok = false;               // level steps <= 1.6: the four-pixels-per-lane arithmetic of k_pyramid_tiled4 applies (taps of four neighbours within 8 bytes)
+    bool generic_chain = false;       // MORB_PYR_CHAIN=2: neither tile form, one k_resize launch per level
     // large rigs (round 5): the pyramid as TWO tile launches with four pixels per lane (k_pyramid_tiled4): levels 1..m below level 0
     // and levels m+1.. below level m, instead of one k_resize_v4 launch per level
     struct TilePlan {
@@ -2276,13 +2141,12 @@ struct orbx_extractor {
     DevBuf<uint32_t> d_cand_dev;
     DevBuf<int> d_level_cnt_dev, d_sel_cnt, d_oct_status, d_n_out;
     bool pinned_ingest = false;       // page-locked host images are read by k_ingest directly (orbx_set_pinned_ingest) instead of hipMemcpy2DAsync
-    // level 0 in place (orbx_set_inplace_level0): l0_on = the geometry takes it (resize-chain pyramid) and the caller opted in;
+    // level 0 in place (orbx_set_inplace_level0): l0_on = the geometry takes it (the large-rig tile launches) and the caller opted in;
     // l0_active = the device table holds pointers of the last run's images; l0_host = what it holds (inspection hook)
     bool l0_optin = false, l0_on = false, l0_active = false;
     DevBuf<L0Src> d_l0;
     std::vector<L0Src> l0_host;
     std::vector<uint8_t> uploaded;    // cameras handed an image (any kind, also an empty one) since the last run
-    bool pinned_ingest_env = true;    // MORB_PINNED_INGEST=0: never
     int oct_max_keys = OCT_RK;        // candidates per (camera, level) the device quadtree takes (MORB_OCT_MAX_KEYS lowers it: tests of the fallback)
     int last_path = 0;                // inspection: 0 device quadtree, 2 host quadtree
     DevBuf<unsigned short> d_slot_blk;
@@ -2293,8 +2157,6 @@ struct orbx_extractor {
     // (in-flight bookkeeping: see `inflight` below), orbx_finish not yet called
     std::chrono::steady_clock::time_point t_begin_async;
     // MORB_EXTRACT_TIMELINE=1: where the synchronous orbx_extract spends its host time (sums, printed by orbx_destroy)
-    bool timeline = false; double tl_us[5] = {0, 0, 0, 0, 0}; long tl_n = 0, tl_calls = 0;
-    std::chrono::steady_clock::time_point tl_sync0, tl_sync1;
     // up to two asynchronous runs may be in flight (the second one is the next timestep's, enqueued while the first one's
     // results are being matched): run r uses slot r & 1 of the count mirrors and of the completion events
     struct ChainGraph {  // captured kernel chain of one count slot (see orbx_run_impl)
@@ -2419,10 +2281,7 @@ static int rebuild_geometry(orbx_extractor* ex) {
     {
         long long px0 = 0;
         for (int c = 0; c < ex->n_cams; ++c) px0 += (long long)ex->cur_w[c] * ex->cur_h[c];
-        static const int tile_env = [] { const char* e = getenv("MORB_PYR_TILE"); return e ? atoi(e) : 0; }();
-        static const int thr_env = [] { const char* e = getenv("MORB_PYR_THREADS"); return e ? atoi(e) : 0; }();
-        const int T = tile_env == 32 || tile_env == 64 ? tile_env : (px0 <= 1500000 ? 32 : 64);
-        ex->pyr_threads = thr_env == 1024 ? 1024 : 256;
+        const int T = px0 <= 1500000 ? 32 : 64;
         ex->pyr_tile = T; ex->pyr_tx_max = 1; ex->pyr_ty_max = 1; ex->pyr_lds = 0; ex->pyr_tab_cap = 0;
         bool halo_ok = true;
         for (int c = 0; c < ex->n_cams; ++c) {
@@ -2479,37 +2338,33 @@ static int rebuild_geometry(orbx_extractor* ex) {
         ex->pyr_tab_cap = (ex->pyr_tab_cap + 3) & ~3;
         ex->pyr_lds += ex->pyr_tab_cap * 24;   // the table entries of a tile's columns (int2) and rows (int4) in front of the regions
         ex->tiled_ok = !(ex->pyr_lds > 60 * 1024 || ML > PYR_MAX_LEVELS || !halo_ok || ex->max_w > 32767 || ex->max_h > 32767);   // (cannot happen for tiles of 64 and scale factors >= 1.05)
-        // Large rigs take the resize chain with four pixels per lane (k_resize_v4) instead: the one-launch tile kernel is a latency
-        // design and costs three times the instructions per pixel.  MORB_PYR_CHAIN = 1 / 0: always / never; default: above
-        // MORB_PYR_CHAIN_PX level-0 pixels over all cameras (4 M: 8 x 1080p yes, 2 x 1280x720 no).
-        ex->chain_v4 = true;
-        for (int c = 0; c < ex->n_cams && ex->chain_v4; ++c)
+        // Large rigs take two tile launches with four pixels per lane instead (k_pyramid_tiled4 below): the one-launch tile kernel is a
+        // latency design and costs three times the instructions per pixel.  Their arithmetic needs level steps of at most 1.6 (the taps of
+        // four neighbouring pixels within 8 bytes).  MORB_PYR_CHAIN: 1 = the large-rig form at every size, 2 = neither tile form (the
+        // generic one-launch-per-level chain, k_resize: what odd parameter sets fall back to), 0 = never the large-rig form; default: the
+        // large-rig form above 4 M level-0 pixels over all cameras (8 x 1080p yes, 2 x 1280x720 no).
+        ex->v4_ok = true;
+        for (int c = 0; c < ex->n_cams && ex->v4_ok; ++c)
             for (int l = 1; l < ex->cams[c].p.nlevels; ++l) {
                 const LevelInfo &Ls = ex->levels[(size_t)c * ML + l - 1], &Ld = ex->levels[(size_t)c * ML + l];
-                if (Ld.w > 0 && (long long)Ls.w * 10 > (long long)Ld.w * 16) ex->chain_v4 = false;
+                if (Ld.w > 0 && (long long)Ls.w * 10 > (long long)Ld.w * 16) ex->v4_ok = false;
             }
         static const int chain_env = [] { const char* e = getenv("MORB_PYR_CHAIN"); return e ? atoi(e) : -1; }();
-        static const long long chain_px = [] { const char* e = getenv("MORB_PYR_CHAIN_PX"); return e ? atoll(e) : 4000000ll; }();
-        const bool prefer_chain = ex->chain_v4 && (chain_env == 1 || (chain_env < 0 && (long long)px0 > chain_px));
-        if (prefer_chain) ex->tiled_ok = false;
+        ex->generic_chain = chain_env == 2;
+        const bool prefer_large = ex->v4_ok && (chain_env == 1 || (chain_env < 0 && (long long)px0 > 4000000ll));
+        if (prefer_large || ex->generic_chain) ex->tiled_ok = false;
     }
     // ---- large rigs: the two tile launches of k_pyramid_tiled4 (TilePlan).  Along x a tile owns whole groups of four destination
     // columns (the group whose first tap lies in what the tile owns one level up), along y rows by their upper tap; what it needs
     // beyond that is the taps of everything it needs one level down (rounded up to whole groups below the base).
     ex->tiled4 = false;
     {
-        static const int t4_env = [] { const char* e = getenv("MORB_PYR_TILED4"); return e ? atoi(e) : -1; }();
-        static const int split_env = [] { const char* e = getenv("MORB_PYR_SPLIT"); return e ? atoi(e) : 3; }();
-        static const int tw_env = [] { const char* e = getenv("MORB_PYR_T4_W"); return e ? atoi(e) : 128; }();
-        static const int th_env = [] { const char* e = getenv("MORB_PYR_T4_H"); return e ? atoi(e) : 64; }();
-        // (the second launch -- the upper levels -- may take a tile and a workgroup size of its own)
-        static const int tw1_env = [] { const char* e = getenv("MORB_PYR_T4_W1"); return e ? atoi(e) : 0; }();
-        static const int th1_env = [] { const char* e = getenv("MORB_PYR_T4_H1"); return e ? atoi(e) : 0; }();
-        static const int nt0_env = [] { const char* e = getenv("MORB_PYR_T4_NT0"); return e ? atoi(e) : 256; }();
-        static const int nt1_env = [] { const char* e = getenv("MORB_PYR_T4_NT1"); return e ? atoi(e) : 256; }();
+        // tile 128 x 64 below level 0 and below the split level 3, 256 threads (orbx_debug_pyramid_plan: other tiles / another split, for
+        // the tests of the plan's geometry)
+        const int split_env = g_t4_plan[2], tw_env = g_t4_plan[0], th_env = g_t4_plan[1], tw1_env = 0, th1_env = 0, nt0_env = 256, nt1_env = 256;
         int nl_max = 0;
         for (int c = 0; c < ex->n_cams; ++c) nl_max = std::max(nl_max, ex->cams[c].p.nlevels);
-        const bool want = ex->chain_v4 && !(ex->tiled_pyramid && ex->tiled_ok) && t4_env != 0 && nl_max >= 2 && ML <= PYR_MAX_LEVELS &&
+        const bool want = ex->v4_ok && !ex->tiled_ok && !ex->generic_chain && nl_max >= 2 && ML <= PYR_MAX_LEVELS &&
                           tw_env >= 16 && tw_env % 4 == 0 && th_env >= 8 && ex->max_w <= 32767 && ex->max_h <= 32767;
         const int split = std::min(std::max(split_env, 1), nl_max - 1);
         bool all_ok = want;
@@ -2607,21 +2462,13 @@ static int rebuild_geometry(orbx_extractor* ex) {
             if (P.lds > 64 * 1024 || (P.tw + P.halo_x) / 4 * (P.th + P.halo_y) > T4_MAX_DW * P.threads || (P.halo_x & 3)) ok = false;
             P.ok = ok;
             all_ok = all_ok && ok;
-            static const bool dbg = getenv("MORB_PYR_T4_DEBUG") != nullptr;
-            if (dbg) fprintf(stderr, "tile plan %d: levels %d..%d below %d, %d threads, tile %d x %d + halo %d x %d, %d x %d tiles, LDS %d B (%d groups, %d rows of tables): %s\n",
-                             pi, P.base + 1, P.last, P.base, P.threads, P.tw, P.th, P.halo_x, P.halo_y, P.tx_max, P.ty_max, P.lds, P.gcap, P.rcap, ok ? "ok" : "refused");
         }
         ex->tiled4 = all_ok;
     }
     {
-        static const bool l0_env = [] { const char* e = getenv("MORB_L0_INPLACE"); return !(e && atoi(e) == 0); }();
-        // (only the one-level-per-launch chain of k_resize_v4 knows the table: the paired launches of small rigs -- k_resize2 -- and
-        // the tile kernel read level 0 in the pyramid buffer; same condition as launch_pyramid_fast's `pairs`)
-        static const bool pairs_env = [] { const char* e = getenv("MORB_PYRAMID_PAIRS"); return !(e && atoi(e) == 0); }();
-        long long level1_px = 0;
-        if (ML > 1) for (int c = 0; c < ex->n_cams; ++c) { const LevelInfo& Lv = ex->levels[(size_t)c * ML + 1]; level1_px += (long long)Lv.w * Lv.h; }
-        const bool pairs = pairs_env && level1_px <= (1ll << 20);
-        ex->l0_on = ex->l0_optin && l0_env && ex->chain_v4 && !(ex->tiled_pyramid && ex->tiled_ok) && !pairs;
+        // level 0 is read where the caller's device image lies (orbx_set_inplace_level0) by the large-rig tile launches only: they take
+        // the {pointer, pitch} table; the one-launch tile kernel of small rigs and the generic chain read the pyramid buffer
+        ex->l0_on = ex->l0_optin && ex->tiled4;
     }
     if (slot_base > (size_t)INT32_MAX) { morb::set_error("candidate slot space exceeds 2^31 entries"); return ORB_E_ARG; }
     ex->total_cells = cell_base;
@@ -2767,22 +2614,16 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     ORBX_TRY_HIP(hipHostGetDevicePointer((void**)&ex->d_h_oct, ex->h_oct, 0));
     for (int i = 0; i < 2; ++i) ORBX_TRY_HIP(hipEventCreateWithFlags(&ex->ev_done[i], hipEventDisableTiming | hipEventReleaseToSystem));
     { const char* e = getenv("MORB_HOST_OCTREE"); ex->device_octree = !(e && atoi(e) != 0); }
-    { const char* e = getenv("MORB_EXTRACT_TIMELINE"); ex->timeline = e && atoi(e) != 0; }
     { const char* e = getenv("MORB_CHAIN_GRAPH"); ex->use_graph = !(e && atoi(e) == 0); }
-    { const char* e = getenv("MORB_PINNED_INGEST"); ex->pinned_ingest_env = !(e && atoi(e) == 0); }
-    { const char* e = getenv("MORB_TILED_PYRAMID"); ex->tiled_pyramid = !(e && atoi(e) == 0); }
     if (const char* e = getenv("MORB_OCT_MAX_KEYS")) ex->oct_max_keys = std::min(OCT_RK, std::max(1, atoi(e)));
     ORBX_TRY_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OctLdsR)));
     for (int i = 0; i < 6; ++i) ORBX_TRY_HIP(hipEventCreate(&ex->ev[i]));
     ex->level_cnt_last.assign((size_t)n_cams * ex->max_levels, 0);
     ex->uploaded.assign(n_cams, 0);
     ex->l0_host.assign(64, L0Src{nullptr, 0, 0});
-    {
-        const char* e = getenv("MORB_OCTREE_THREADS");
-        int nt = e ? atoi(e) : 4;
+    {   // host quadtree fallback: four threads (the calling one works too)
         const int hw = (int)std::thread::hardware_concurrency();
-        nt = std::max(1, std::min(nt, hw > 1 ? hw : 1));
-        ex->pool.reset(new TaskPool(nt - 1));  // the calling thread works too
+        ex->pool.reset(new TaskPool(std::max(1, std::min(4, hw > 1 ? hw : 1)) - 1));
     }
     *out = ex;
     return ORB_OK;
@@ -2790,9 +2631,6 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
 
 void orbx_destroy(orbx_extractor* ex) {
     if (!ex) return;
-    if (ex->timeline && ex->tl_n)
-        fprintf(stderr, "orbx_extract timeline over %ld calls (us): upload %.1f | enqueue %.1f | wait %.1f | after-wait %.1f | copy-out %.1f\n", ex->tl_n,
-                ex->tl_us[0] / ex->tl_n, ex->tl_us[1] / ex->tl_n, ex->tl_us[2] / ex->tl_n, ex->tl_us[3] / ex->tl_n, ex->tl_us[4] / ex->tl_n);
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     for (int sl = 0; sl < 2; ++sl) for (int w = 0; w < orbx_extractor::CHAIN_WAYS; ++w) ex->chain[sl][w].destroy();
@@ -2873,7 +2711,7 @@ static int upload_common(orbx_extractor* ex, int cam, const uint8_t* src, int wi
     // A page-locked image is device-visible as it is: when the caller asks for it (orbx_set_pinned_ingest: a run somebody
     // is waiting for), the ingest kernel of the run reads it across PCIe, all cameras in ONE launch (in stream order, like the
     // copy it replaces: a pitched hipMemcpy2DAsync per camera costs ~10 us of host time each).  MORB_PINNED_INGEST=0: never.
-    if (pinned && ex->pinned_ingest && ex->pinned_ingest_env && attr.devicePointer) {
+    if (pinned && ex->pinned_ingest && attr.devicePointer) {
         ex->ingest.src[cam] = static_cast<const uint8_t*>(attr.devicePointer); ex->ingest.stride[cam] = stride; ex->ingest_pending = true;
         ex->ingest_host = true;
         return ORB_OK;
@@ -2919,19 +2757,20 @@ int orbx_debug_level0_in_place(const orbx_extractor* ex) {
     return n;
 }
 
-// 0 one tile launch (k_pyramid_tiled), 1 one k_resize_v4 launch per level, 2 the round-1 chain (k_resize2 / k_resize), 3 two tile
-// launches with four pixels per lane (k_pyramid_tiled4); the geometry of the most recent run
+// 0 one tile launch (k_pyramid_tiled), 2 the generic chain (one k_resize launch per level), 3 two tile launches with four pixels per
+// lane (k_pyramid_tiled4); the geometry of the most recent run
 int orbx_debug_pyramid_form(const orbx_extractor* ex) {
     if (!ex) return ORB_E_ARG;
     if (ex->tables_dirty) return -1;
-    if (ex->tiled_pyramid && ex->tiled_ok) return 0;
-    static const bool pairs_env = [] { const char* e = getenv("MORB_PYRAMID_PAIRS"); return !(e && atoi(e) == 0); }();
-    long long level1_px = 0;
-    if (ex->max_levels > 1) for (int c = 0; c < ex->n_cams; ++c) { const LevelInfo& Lv = ex->levels[(size_t)c * ex->max_levels + 1]; level1_px += (long long)Lv.w * Lv.h; }
-    const bool pairs = pairs_env && level1_px <= (1ll << 20);
-    if (pairs) return 2;
-    if (ex->tiled4) return 3;
-    return ex->chain_v4 ? 1 : 2;
+    return ex->tiled_ok ? 0 : (ex->tiled4 ? 3 : 2);
+}
+
+// tests of the large-rig plan's geometry: other tiles, another split level (all handles created afterwards; 0 = keep)
+int orbx_debug_pyramid_plan(int tile_w, int tile_h, int split) {
+    if (tile_w > 0) g_t4_plan[0] = tile_w;
+    if (tile_h > 0) g_t4_plan[1] = tile_h;
+    if (split > 0) g_t4_plan[2] = split;
+    return ORB_OK;
 }
 
 int orbx_set_profiling(orbx_extractor* ex, int on) {
@@ -3047,32 +2886,18 @@ static inline const L0Src* l0_table(const orbx_extractor* ex) { return ex->l0_on
 static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestArgs* fused = nullptr) {
     const int ML = ex->max_levels;
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[0], st));
-    if (ex->tiled_pyramid && ex->tiled_ok) {
+    if (ex->tiled_ok) {
         PyrArgs A;
         for (int c = 0; c < 64; ++c) {
             A.src[c] = fused && c < ex->n_cams ? fused->src[c] : nullptr; A.stride[c] = fused ? fused->stride[c] : 0;
             A.tx[c] = c < ex->n_cams ? ex->pyr_tx[c] : 0; A.ty[c] = c < ex->n_cams ? ex->pyr_ty[c] : 0;
             A.w[c] = c < ex->n_cams ? (short)ex->cur_w[c] : 0; A.h[c] = c < ex->n_cams ? (short)ex->cur_h[c] : 0;
         }
-        // (small rigs: fewer than one 64-pixel tile per CU -- 1024 threads per tile then, the tile's levels are a latency chain)
-        if (ex->pyr_threads == 1024)
-            hipLaunchKernelGGL(k_pyramid_tiled<1024>, dim3(ex->pyr_tx_max, ex->pyr_ty_max, ex->n_cams), dim3(1024), (size_t)ex->pyr_lds, st, A,
-                               (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch, (const int2*)ex->d_xtab.p,
-                               (const int4*)ex->d_ytab.p, (const int4*)ex->d_pyr_sx.p, (const int4*)ex->d_pyr_sy.p, ex->pyr_tx_max, ex->pyr_ty_max,
-                               ex->pyr_tab_cap, ex->pyr_tile);
-        else
-            hipLaunchKernelGGL(k_pyramid_tiled<256>, dim3(ex->pyr_tx_max, ex->pyr_ty_max, ex->n_cams), dim3(256), (size_t)ex->pyr_lds, st, A,
-                               (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch, (const int2*)ex->d_xtab.p,
-                               (const int4*)ex->d_ytab.p, (const int4*)ex->d_pyr_sx.p, (const int4*)ex->d_pyr_sy.p, ex->pyr_tx_max, ex->pyr_ty_max,
-                               ex->pyr_tab_cap, ex->pyr_tile);
+        hipLaunchKernelGGL(k_pyramid_tiled<256>, dim3(ex->pyr_tx_max, ex->pyr_ty_max, ex->n_cams), dim3(256), (size_t)ex->pyr_lds, st, A,
+                           (const LevelInfo*)ex->d_levels.p, ML, ex->d_pyr.p, ex->cam_pitch, (const int2*)ex->d_xtab.p,
+                           (const int4*)ex->d_ytab.p, (const int4*)ex->d_pyr_sx.p, (const int4*)ex->d_pyr_sy.p, ex->pyr_tx_max, ex->pyr_ty_max,
+                           ex->pyr_tab_cap, ex->pyr_tile);
     } else {
-    // two levels per launch (k_resize2): (1,2) (3,4) (5,6) (7) for the usual 8 levels; MORB_PYRAMID_PAIRS=0: one launch per level
-    // ... while the levels are small: the re-deriving half does four times the arithmetic per pixel, which only pays as long as
-    // a level is a few microseconds of latency rather than work (up to ~1 M pixels on level 1 over all cameras).
-    static const bool pairs_env = [] { const char* e = getenv("MORB_PYRAMID_PAIRS"); return !(e && atoi(e) == 0); }();
-    long long level1_px = 0;
-    if (ML > 1) for (int c = 0; c < ex->n_cams; ++c) { const LevelInfo& Lv = ex->levels[(size_t)c * ML + 1]; level1_px += (long long)Lv.w * Lv.h; }
-    const bool pairs = pairs_env && level1_px <= (1ll << 20);
     auto level_dims = [&](int l, int* mw, int* mh) {
         *mw = 0; *mh = 0;
         if (l >= ML) return;
@@ -3081,7 +2906,7 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestA
             *mw = std::max(*mw, Lv.w); *mh = std::max(*mh, Lv.h);
         }
     };
-    if (ex->tiled4 && !pairs) {
+    if (ex->tiled4) {
         for (int pi = 0; pi < 2; ++pi) {
             const orbx_extractor::TilePlan& P = ex->tp[pi];
             if (P.last <= P.base || P.tx_max == 0) continue;
@@ -3095,25 +2920,13 @@ static int launch_pyramid_fast(orbx_extractor* ex, hipStream_t st, const IngestA
             else hipLaunchKernelGGL(k_pyramid_tiled4<256>, dim3(P.tx_max, P.ty_max, ex->n_cams), dim3(256), (size_t)P.lds, st, T);
         }
     } else
-    for (int l = 1; l < ML; l += pairs ? 2 : 1) {
-        int mw = 0, mh = 0, mw2 = 0, mh2 = 0;
+    for (int l = 1; l < ML; ++l) {   // the generic chain: one launch per level, any level step (what parameter sets outside both tile forms take)
+        int mw = 0, mh = 0;
         level_dims(l, &mw, &mh);
-        if (pairs) level_dims(l + 1, &mw2, &mh2);
         if (mw == 0) continue;
-        if (!pairs) {
-            dim3 grid((mw + 255) / 256, (mh + 3) / 4, ex->n_cams), block(64, 4, 1);
-            if (ex->chain_v4)
-                hipLaunchKernelGGL(k_resize_v4, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
-                                   (const int4*)ex->d_xgrp.p, (const int4*)ex->d_ytab.p, l0_table(ex));
-            else
-            hipLaunchKernelGGL(k_resize, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
-                               (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
-        } else {
-            const int yb_a = (mh + 3) / 4, yb_b = (mh2 + 3) / 4;
-            dim3 grid(std::max((mw + 255) / 256, (mw2 + 63) / 64), yb_a + yb_b, ex->n_cams), block(64, 4, 1);
-            hipLaunchKernelGGL(k_resize2, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, yb_a, ex->d_pyr.p, ex->cam_pitch,
-                               (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
-        }
+        dim3 grid((mw + 255) / 256, (mh + 3) / 4, ex->n_cams), block(64, 4, 1);
+        hipLaunchKernelGGL(k_resize, grid, block, 0, st, (const LevelInfo*)ex->d_levels.p, ML, l, ex->d_pyr.p, ex->cam_pitch,
+                           (const int2*)ex->d_xtab.p, (const int4*)ex->d_ytab.p);
     }
     }
     if (ex->profiling) MORB_HIP(hipEventRecord(ex->ev[1], st));
@@ -3195,7 +3008,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
     for (int c = 0; c < ex->n_cams; ++c) any_upload |= ex->uploaded[c] != 0;
     if (ex->ingest_pending || (ex->l0_active && any_upload)) {
         // (sources in host memory are copied exactly once by k_ingest: the tiles' halos would cross PCIe twice)
-        if (ex->ingest_pending && ex->tiled_pyramid && ex->tiled_ok && !will_replay && !ex->ingest_host) {
+        if (ex->ingest_pending && ex->tiled_ok && !will_replay && !ex->ingest_host) {
             fused_src = ex->ingest; fused = &fused_src;
         } else {
             // Level 0 in place (k_set_l0 above): every camera that has an image must have been handed a device image for THIS run,
@@ -3304,9 +3117,7 @@ static int orbx_run_impl(orbx_extractor* ex, bool allow_async) {
         ex->prof_valid[slot] = ex->profiling && ex->inflight == 0;  // (one set of stage events: not for overlapped runs)
         ++ex->run_seq; ++ex->inflight; ex->t_begin_async = t_begin;
         if (allow_async) return ORB_OK;
-        if (ex->timeline) ex->tl_sync0 = std::chrono::steady_clock::now();
         MORB_HIP(hipStreamSynchronize(st));
-        if (ex->timeline) ex->tl_sync1 = std::chrono::steady_clock::now();
         if (ex->h_oct[slot * (ex->n_cams + 1) + ex->n_cams] == 0) return finish_device_path(ex);
         ex->inflight = 0;
         std::fill(ex->n_out.begin(), ex->n_out.end(), 0);  // a level exceeded the device limits: redo the selection on the host
@@ -3476,10 +3287,8 @@ int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, con
     MORB_ARG(ex && n_cams == ex->n_cams && gray && width && height && stride && kps_out && desc_out && cap && n_out);
     int rc;
     MORB_HIP(hipSetDevice(ex->device));
-    const auto tl0 = std::chrono::steady_clock::now();
     for (int c = 0; c < n_cams; ++c)
         if ((rc = orbx_upload(ex, c, gray[c], width[c], height[c], stride[c]))) return rc;
-    const auto tl1 = std::chrono::steady_clock::now();
     // results through a pinned mirror the describe kernel writes itself (camera-major, packed): no D2H copies on the stream
     const bool own = ex->mirror_kps == nullptr;
     if (own) {
@@ -3489,7 +3298,6 @@ int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, con
         ex->mirror_kps = ex->own_mirror_kps.dp; ex->mirror_desc = ex->own_mirror_desc.dp; ex->mirror_cap = cap_total;
     }
     rc = orbx_run(ex);
-    const auto tl2 = std::chrono::steady_clock::now();
     // (the host-quadtree fallback describes from a host-built list with its own mirror bookkeeping: plain downloads there)
     const bool mirrored = own && ex->mirror_cap > 0 && ex->last_path != 2;
     if (own) { ex->mirror_kps = nullptr; ex->mirror_desc = nullptr; ex->mirror_cap = 0; }
@@ -3507,11 +3315,6 @@ int orbx_extract(orbx_extractor* ex, int n_cams, const uint8_t* const* gray, con
             memcpy(desc_out[c], ex->own_mirror_desc.p + (size_t)off * 32, (size_t)n_out[c] * 32);
         } else if ((rc = orbx_download(ex, c, kps_out[c], desc_out[c], cap[c]))) return rc;
         off += n_out[c];
-    }
-    if (ex->timeline && ++ex->tl_calls > 10) {   // (the first calls load code objects and build tables)
-        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        ex->tl_us[0] += us(tl0, tl1); ex->tl_us[1] += us(tl1, ex->tl_sync0); ex->tl_us[2] += us(ex->tl_sync0, ex->tl_sync1);
-        ex->tl_us[3] += us(ex->tl_sync1, tl2); ex->tl_us[4] += us(tl2, std::chrono::steady_clock::now()); ++ex->tl_n;
     }
     return ORB_OK;
 }

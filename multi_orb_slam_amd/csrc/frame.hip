@@ -538,8 +538,7 @@ int orbm_frame_create_resident(orbm_matcher* m, const orbm_frame_desc* f, const 
     const int n = f->n_total, n_cams = f->n_cams;
     const int ncell = n_cams * ORBM_GRID_COLS * ORBM_GRID_ROWS;
     const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int) + (size_t)8192 * sizeof(unsigned short);
-    static const bool off = [] { const char* e = getenv("MORB_RESIDENT_FRAMES"); return e && atoi(e) == 0; }();
-    if (off || n == 0 || n > 8192 || n_cams > 4 || lds_small > 150 * 1024) return orbm_frame_create(m, f, out);
+    if (n == 0 || n > 8192 || n_cams > 4 || lds_small > 150 * 1024) return orbm_frame_create(m, f, out);
     MORB_ARG(f->un_x && f->un_y && f->octave && f->angle && f->uright && f->cam_of && f->local_of && f->desc);
     MORB_HIP(hipSetDevice(m->device));
     // per-camera row counts (the highest row a feature names + 1) and the camera starts of the global order
@@ -739,8 +738,7 @@ int morb::frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams,
     const size_t lds_small = (size_t)2 * (ncell + 1) * sizeof(int) + (size_t)8192 * sizeof(unsigned short);
     const bool small = n > 0 && n <= 8192 && n_cams <= 4 && lds_small <= 150 * 1024;
     MORB_ARG(!sink_filled || small);
-    static const bool head_env = [] { const char* e = getenv("MORB_FRAME_HEAD"); return !(e && atoi(e) == 0); }();
-    const bool one_head = !small && d_counts && n_cams <= 32 && head_env;   // (k_frame_head: table, counts and cleared counters in one launch)
+    const bool one_head = !small && d_counts && n_cams <= 32;   // (k_frame_head: table, counts and cleared counters in one launch)
     if (!small && !one_head) {
         MORB_HIP(hipMemcpyAsync(F->b->d_cams.p, hc, (size_t)n_cams * sizeof(CamFeat), hipMemcpyHostToDevice, st));
         MORB_HIP(hipMemcpyAsync(F->b->d_cam_start.p, hstart, (size_t)(n_cams + 1) * 4, hipMemcpyHostToDevice, st));
@@ -786,8 +784,7 @@ int morb::frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams,
                                F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_of.p,
                                F->b->d_cursor.p, hm, n_dev);
         }
-        static const bool grid_env = [] { const char* e = getenv("MORB_GRID_CAM"); return !(e && atoi(e) == 0); }();
-        bool grid_cam = grid_env;   // (every camera's features fit the kernel's LDS list: capacities are upper bounds of the counts)
+        bool grid_cam = true;   // (every camera's features fit the kernel's LDS list: capacities are upper bounds of the counts)
         for (int c = 0; c < n_cams; ++c) grid_cam = grid_cam && cams[c].n <= GRID_CAM_MAX;
         if (grid_cam) {
             hipLaunchKernelGGL(k_grid_cam, dim3(n_cams), dim3(1024), 0, st, (const int*)F->b->d_cursor.p, (const int*)F->b->d_cell_of.p,

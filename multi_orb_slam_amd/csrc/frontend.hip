@@ -138,9 +138,6 @@ struct orbf_frontend {
     std::vector<int32_t> prev_cam_of;
     std::vector<float> scale_factors;
     std::chrono::steady_clock::time_point t_entry;
-    // MORB_HOST_TIMELINE=1: where orbf_step_begin spends its host time (sums, printed by orbf_destroy)
-    bool timeline = false; double tl_us[6] = {0, 0, 0, 0, 0, 0}; long tl_n = 0, tl_not_done = 0, tl_queried = 0;
-    std::chrono::steady_clock::time_point tl_t;
 };
 
 static int getenv_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -167,8 +164,8 @@ int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int 
     if (rc) { orbf_destroy(f); return rc; }
     f->d_depth.assign(n_cams, nullptr); f->depth_stride.assign(n_cams, 0); f->counts.assign(n_cams, 0);
     { const char* pe = getenv("MORB_POLL"); f->poll_ok = !(pe && atoi(pe) == 0); }
-    { const char* te = getenv("MORB_HOST_TIMELINE"); f->timeline = te && atoi(te) != 0; }
     f->motion_on_device = getenv_int("MORB_MOTION_ON_DEVICE", 1) != 0;
+    f->x_timeout_ms = std::max(1L, (long)getenv_int("MORB_EXCHANGE_TIMEOUT_MS", 15000));
     f->scale_factors.assign(params[0].nlevels, 1.f);
     if ((rc = orbx_tables(&params[0], f->scale_factors.data(), nullptr, nullptr, nullptr, nullptr, nullptr))) { orbf_destroy(f); return rc; }
     for (int c = 0; c < n_cams; ++c) { f->cam_cap.push_back(params[c].nfeatures + 4 * params[c].nlevels); f->cap_total += f->cam_cap.back(); }
@@ -199,11 +196,6 @@ int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int 
 static void x_stop(orbf_frontend* f);
 
 void orbf_destroy(orbf_frontend* f) {
-    if (f && f->timeline && f->tl_n > 0)
-        fprintf(stderr, "orbf host timeline over %ld steps, us per step: extraction / in-flight check %.2f, queries %.2f, frame + event %.2f, "
-                        "search launches %.2f, side work + events %.2f, prefetch enqueue %.2f; extraction not known complete at the step's begin (asked then) %ld times, "
-                        "still running %ld times\n", f->tl_n, f->tl_us[0] / f->tl_n,
-                f->tl_us[1] / f->tl_n, f->tl_us[2] / f->tl_n, f->tl_us[3] / f->tl_n, f->tl_us[4] / f->tl_n, f->tl_us[5] / f->tl_n, f->tl_queried, f->tl_not_done);
     if (!f) return;
     (void)hipSetDevice(f->device);
     if (f->xcomm) (void)orbf_exchange_shutdown(f);
@@ -314,7 +306,6 @@ static int exchange_queues(orbf_frontend* f) {
     int placement = 3;
     if (const char* e = getenv("MORB_EXCHANGE_PLACEMENT")) { if (!strcmp(e, "inline")) placement = 1; }
     if (f->x_one_comm) placement = 1;   // (one communicator: a step's one collective at the end of the step, in step order, never a re-shipment)
-    f->x_timeout_ms = std::max(1L, (long)getenv_int("MORB_EXCHANGE_TIMEOUT_MS", 15000));
     f->x_broken = false;
     f->x_placement = placement;
     f->mt->side_inline = true;   // (no side stream next to an exchange: the handle keeps its extraction chains + the matcher = four queues)
@@ -323,9 +314,9 @@ static int exchange_queues(orbf_frontend* f) {
         X.seq = -1; X.job = 0;
         if (!X.done) MORB_HIP(hipEventCreateWithFlags(&X.done, hipEventDisableTiming));
     }
-    // the issuer thread (MORB_EXCHANGE_THREAD=0: the stepping thread makes the calls itself, as placement 1 always does)
+    // the issuer thread (placement 1: the stepping thread makes the calls itself)
     f->x_rc = 0; f->x_err.clear(); f->x_pushed = f->x_issued = 0;
-    f->x_async = placement == 3 && getenv_int("MORB_EXCHANGE_THREAD", 1) != 0;
+    f->x_async = placement == 3;
     if (f->x_async) f->x_thread = std::thread(x_issuer_main, f);
     return ORB_OK;
 }
@@ -391,7 +382,7 @@ int orbf_exchange_peer_export(orbf_frontend* f, int world, int rank, uint8_t* ha
     MORB_ARG(f && handle_out && world >= 1 && world <= 64 && rank >= 0 && rank < world && world * f->n_cams <= 512 && !f->xcomm && !f->xpeer);
     MORB_HIP(hipSetDevice(f->device));
     const size_t block = (size_t)f->cap_total * 32 + ORBM_BLOCK_TRAILER;
-    return morb::peer_export(&f->xpeer, world, rank, block, orbf_frontend::NX, handle_out);
+    return morb::peer_export(&f->xpeer, world, rank, block, orbf_frontend::NX, f->x_timeout_ms, handle_out);
 }
 
 int orbf_exchange_peer_open(orbf_frontend* f, const uint8_t* handles) {
@@ -940,7 +931,6 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     MORB_ARG(!P.active);
     P = orbf_frontend::Pending();
     P.t_impl = std::chrono::steady_clock::now();
-    if (f->timeline) { f->tl_t = P.t_impl; ++f->tl_n; }
     MORB_HIP(hipSetDevice(f->device));
     orbm_matcher* m = f->mt;
     int rc, went_async = 0;
@@ -983,12 +973,10 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         // (measured: ~22 us between the chain's last kernel and the projection kernel on the matcher's stream) -- and the
         // camera-pair top-2 leaves the chain: it rides in the projection kernel's launch (SideJob in step_enqueue; on the
         // side stream when that does not apply) instead of standing in front of the search.
-        static const bool inline_env = getenv_int("MORB_INLINE_MATCH", 1) != 0, inline_graph = getenv_int("MORB_INLINE_GRAPH", 0) != 0;
-        P.inline_match = small_rig(f) && !f->xcomm && inline_env;
-        if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], inline_graph ? 1 : 0); (void)orbx_set_defer_done(f->exs[P.e], 1); }
+        P.inline_match = small_rig(f) && !f->xcomm;
+        if (P.inline_match) { (void)orbx_set_chain_graph(f->exs[P.e], 0); (void)orbx_set_defer_done(f->exs[P.e], 1); }
         // (the copy rides with the camera-pair top-2: in the projection kernel's launch, or on the side stream it forks onto)
-        static const bool side_mirror_env = getenv_int("MORB_SIDE_MIRROR", 1) != 0;
-        P.mirror_requested = P.inline_match && side_mirror_env && !(flags & ORBF_SKIP_CROSS) && f->n_cams > 1;
+        P.mirror_requested = P.inline_match && !(flags & ORBF_SKIP_CROSS) && f->n_cams > 1;
         // the step waits for THIS extraction: page-locked host images are read by the ingest kernel directly (one launch for
         // all cameras instead of a pitched copy per camera: -13 us on 2 x 640x480).  Extractions that run ahead keep the copies:
         // they overlap other streams' kernels, a kernel that reads across PCIe would hold CUs for the whole transfer
@@ -1002,7 +990,6 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         if (rc) return rc;
         if (P.inline_match && !went_async) P.inline_match = false;   // (host-quadtree path: everything was synchronous)
     }
-    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[0] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     if (motion && f->motion_on_device && prev_frame && f->prev_n > 0 && prev_frame->n_total == f->prev_n &&
         prev_frame->n_cams == f->n_cams && f->scale_factors.size() <= 16) {
         // query i = feature i of the previous frame (still in HBM) moved by the motion: built by the projection kernel itself
@@ -1028,7 +1015,6 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
         if (!queries_in_pinned) memcpy(f->h_queries.p, queries, (size_t)nq * sizeof(orbm_query));
         f->h_queries.publish();
     }
-    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[1] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     P.J = SearchJob{nullptr, P.use_ms ? f->q_host.data() : reinterpret_cast<const orbm_query*>(f->h_queries.p), nq, nullptr, false, 0.f,
                     f->th_high, f->check_ori, 64, false};
     P.J.q_dev = nq && !P.use_ms ? reinterpret_cast<const orbm_query*>(f->h_queries.dp) : nullptr;   // no H2D on the step's critical chain
@@ -1041,11 +1027,10 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     // The export block of this step is final already when its extraction chain has completed cleanly (the usual case with
     // steps announced ahead): then nothing of this step can be redone and a caller may ship the block right away.
     P.block_ready = false;
-    if (f->timeline && P.async_path && !P.inline_match && !P.ext_done) ++f->tl_queried;
     if (P.async_path && !P.inline_match && (P.ext_done || hipEventQuery(f->ev_ready[P.set]) == hipSuccess)) {
         P.ext_done = true;   // (the matcher's stream then needs no event wait in front of the search: step_enqueue)
         P.block_ready = orbx_peek_status(f->exs[P.e]) == 0;
-    } else { P.ext_done = false; (void)hipGetLastError(); if (f->timeline) ++f->tl_not_done; }
+    } else { P.ext_done = false; (void)hipGetLastError(); }
     if ((rc = step_enqueue(f, P, true))) return rc;
     P.active = true;
     if (block_ready) *block_ready = P.block_ready ? 1 : 0;
@@ -1113,9 +1098,8 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     // An isolated step (its matching sits right behind its own extraction on one stream) takes no fork at all: the camera-pair
     // top-2 and the copy into the pinned result mirrors ride in the projection kernel's launch (SideJob) -- a fork onto the
     // side stream and the join behind it cost ~18 us of queue time per step (measured), a few more workgroups cost none.
-    static const bool side_env = getenv_int("MORB_SIDE_IN_LAUNCH", 1) != 0;
     SideJob side;
-    const bool fused_side = forked && inline_match && side_env && first_attempt && P.nq > 0 && P.nq <= 65535 && !m->host_resolve &&
+    const bool fused_side = forked && inline_match && first_attempt && P.nq > 0 && P.nq <= 65535 && !m->host_resolve &&
                             morb::side_fusable(n, n);
     if (fused_side) {
         if ((rc = morb::side_reserve(m, n, n))) return rc;
@@ -1139,12 +1123,10 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         if (fe == hipSuccess) fe = hipStreamWaitEvent(sd, m->ev_fork, 0);
         if (fe != hipSuccess) { morb::set_error("stream fork: %s", hipGetErrorString(fe)); if (!P.fr_persistent) orbm_frame_destroy(fr); P.fr = nullptr; return ORB_E_HIP; }
     }
-    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[2] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     const bool x_probe = f->x_timing && f->xcomm && first_attempt;
     if (x_probe) (void)hipEventRecord(f->ev_x[0], st);
     rc = search_enqueue(m, P.J, /*queries_already_on_device=*/true);
     if (x_probe) (void)hipEventRecord(f->ev_x[1], st);   // (behind the resolve, in front of whatever an exchange puts on this stream)
-    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[3] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     if (P.mirror_pending && !forked) {   // (no side stream in play: the copy follows the search on its stream)
         if (!rc) rc = frame_mirror_enqueue(fr, st, R.kps.dp, R.desc.dp, R.unx.dp, R.uny.dp, R.ur.dp, R.depth.dp);
         P.mirror_pending = false;
@@ -1173,7 +1155,6 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
         if ((rc = exchange_issue(f, P.seq, fr, st, false, P.images.data()))) return rc;
         m->foreign_work = true;   // (the end of the step cannot watch the resolve's tags: other work follows them on the stream)
     }
-    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[4] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     // ---- announced timesteps go onto the extractors now: they run while this step is being matched.  At most two
     // are in flight; consecutive ones alternate between the two extractors (an extractor takes its next timestep as
     // a second run behind the one whose results are being matched here).
@@ -1203,7 +1184,6 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
             f->announced.clear();
         }
     }
-    if (f->timeline) { const auto now_ = std::chrono::steady_clock::now(); f->tl_us[5] += std::chrono::duration<double, std::micro>(now_ - f->tl_t).count(); f->tl_t = now_; }
     P.t_enqueued = std::chrono::steady_clock::now();
     return ORB_OK;
 }

@@ -909,10 +909,9 @@ static bool top2_fp4() {
 std::atomic<int> g_matrix_cores{-1};  // orbm_use_matrix_cores: -1 = environment default
 
 Top2Plan top2_plan(int nq, int nr, bool have_scratch = true, int wgs_per_cu = 3) {
-    static const int mfma_env = [] { const char* e = getenv("MORB_TOP2_MFMA"); return e ? atoi(e) : 1; }();
-    const int forced = g_matrix_cores.load(std::memory_order_relaxed);
+    const int forced = g_matrix_cores.load(std::memory_order_relaxed);   // (orbm_use_matrix_cores(0): the popcount kernels)
     Top2Plan p{false, 1, nr};
-    if ((forced < 0 ? mfma_env : forced) && nq >= 64 && nr >= MM_R_TILE) {
+    if (forced != 0 && nq >= 64 && nr >= MM_R_TILE) {
         // wgs_per_cu workgroups are resident per CU (166 registers: three; the 230-register build of the camera-pair kernel:
         // two): a launch runs in ceil(workgroups / slots) rounds of (tiles per slice + ~2) steps; take the slice count that
         // minimises the product.
@@ -981,16 +980,13 @@ int launch_matrix(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16
     const int tiles = (nr + MAT_REFS_PER_WAVE - 1) / MAT_REFS_PER_WAVE;
     // queries per block: 256 at all-pairs sizes (long streaming rows); fewer when the grid would otherwise be too
     // small to fill 256 CUs x 4 SIMDs (each wave walks its queries serially, ~0.35 us per query)
-    static const int q_per_block_env = [] { const char* e = getenv("MORB_MATRIX_QPB"); return e ? atoi(e) : 0; }();
     int q_per_block = (int)std::min<long long>(256, std::max<long long>(8, ((long long)nq * tiles + 4095) / 4096));
     q_per_block = (q_per_block + 1) & ~1;
-    if (q_per_block_env > 0) q_per_block = q_per_block_env;
     dim3 grid((tiles + MAT_WAVES - 1) / MAT_WAVES, (nq + q_per_block - 1) / q_per_block);
     const bool aligned = (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && nr >= MAT_REFS_PER_WAVE;
-    // Matrix-core path: rows of 16-byte chunks, enough queries to fill 64-query waves.  MORB_MATRIX_MFMA=0 keeps the VALU kernel.
-    static const int mfma_env = [] { const char* e = getenv("MORB_MATRIX_MFMA"); return e ? atoi(e) : 1; }();
+    // Matrix-core path: rows of 16-byte chunks, enough queries to fill 64-query waves.  orbm_use_matrix_cores(0) keeps the VALU kernel.
     const int forced = g_matrix_cores.load(std::memory_order_relaxed);
-    if ((forced < 0 ? mfma_env : forced) && (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && nq >= 64 && nr >= MM_R_TILE && (((uintptr_t)d_r & 7) == 0)) {
+    if (forced != 0 && (nr % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && nq >= 64 && nr >= MM_R_TILE && (((uintptr_t)d_r & 7) == 0)) {
         const int n_tiles = (nr + MM_R_TILE - 1) / MM_R_TILE, qblocks = (nq + MM_Q_PER_BLOCK - 1) / MM_Q_PER_BLOCK;
         // Tiles per workgroup: three workgroups are resident per CU (168 registers, 48 KB LDS), a launch runs in
         // ceil(workgroups / slots) rounds of (tiles + ~1.5 for the query expansion) steps each; take the count that minimises
@@ -1008,8 +1004,6 @@ int launch_matrix(const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, uint16
             const double cost = (double)((wgs + slots - 1) / slots) * (c + 1.5);
             if (cost < best_cost) { best_cost = cost; tpb = c; }
         }
-        static const int tpb_env = [] { const char* e = getenv("MORB_MATRIX_TPB"); return e ? atoi(e) : 0; }();
-        if (tpb_env > 0) tpb = tpb_env;
         dim3 g2((n_tiles + tpb - 1) / tpb, qblocks);
         hipLaunchKernelGGL(k_hamming_matrix_mfma, g2, dim3(64 * MM_WAVES), 0, st, (const uint32_t*)d_q, nq, (const uint32_t*)d_r, nr,
                            d_out, tpb);

@@ -239,7 +239,7 @@ struct PeerComm;
 size_t peer_handle_bytes();
 int peer_world(const PeerComm* C);
 int peer_rank(const PeerComm* C);
-int peer_export(PeerComm** out, int world, int rank, size_t block, int nslots, uint8_t* handle);
+int peer_export(PeerComm** out, int world, int rank, size_t block, int nslots, long timeout_ms, uint8_t* handle);
 int peer_open(PeerComm* C, const uint8_t* handles);
 void peer_close(PeerComm* C);
 const uint8_t* peer_recv(const PeerComm* C, int slot, int gen);

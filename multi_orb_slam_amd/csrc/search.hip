@@ -1576,10 +1576,9 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
         MORB_HIP(hipMemcpyAsync(m->d_queries.p, J.q_dev, (size_t)nq * sizeof(orbm_query), hipMemcpyDefault, m->stream));
     }
     MergeJob MJ{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};   // (S > 1 after run_project: a merge waits for its carrier)
-    static const bool merge_rides = [] { const char* e = getenv("MORB_MERGE_IN_RESOLVE"); return !(e && atoi(e) == 0); }();
     if ((rc = run_project(m, cur, J.q, nq, cap, 1, 1, !queries_already_on_device && !J.q_dev && !J.msrc, false, /*transposed=*/1, d_occ,
                           m->d_claim.p, J.points ? 256 : th_high, nullptr, q_in_place, m->d_qmeta.p, J.win2_dev, J.side, J.msrc, multi,
-                          (J.side && merge_rides && !multi && !J.points) ? &MJ : nullptr)))
+                          (J.side && !multi && !J.points) ? &MJ : nullptr)))
         return rc;
     J.side = nullptr;   // (a retry of the search with more room per query does not repeat the side work)
     J.seq = 0;
@@ -1587,12 +1586,13 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
     // Frame searches (one window per query, no ratio test) resolve PER CAMERA in one launch when every camera's tables fit a workgroup's
     // LDS and its queries a workgroup's registers (k_resolve_cams: a query looks at one camera's grid, so claims never cross cameras;
     // the cameras' workgroups meet once, in the kernel, for the rotation histogram).  Large rigs (tables of the whole frame beyond LDS)
-    // always take it.  Smaller rigs only when asked to (MORB_RS_CAMS_MIN_Q = queries from which on; default never): measured in round 6
+    // always take it.  Smaller rigs only when asked to (MORB_RS_PER_CAMERA = N > 1: from N queries on; default never): measured in round 6
     // (VERDICT r05 #4 asked for it), 2 x 2000 queries take 38 us per camera against 31 in one workgroup and 4 x 1000 31 against 28 -- the
     // rounds do get shorter (11 us against 17), but the scan for the camera's queries (4 us: one trip to memory), the meeting (6 us over
-    // L2 between XCDs) and the separate tail cost more than that (profiles/r06/notes_experiments.md).  MORB_RS_PER_CAMERA=0: never.
-    static const bool cam_env = [] { const char* e = getenv("MORB_RS_PER_CAMERA"); return !(e && atoi(e) == 0); }();
-    static const int cams_min_q = [] { const char* e = getenv("MORB_RS_CAMS_MIN_Q"); return e ? atoi(e) : 0x7fffffff; }();
+    // L2 between XCDs) and the separate tail cost more than that (profiles/r06/notes_experiments.md).
+    // MORB_RS_PER_CAMERA: 0 = never (large rigs take one launch per sweep), 1 = large rigs (default), N > 1 = also smaller rigs from N queries on
+    static const int cam_env = [] { const char* e = getenv("MORB_RS_PER_CAMERA"); return e ? atoi(e) : 1; }();
+    const int cams_min_q = cam_env > 1 ? cam_env : 0x7fffffff;
     int nf_cap = 0, q_cam_max = J.q_cam_max;
     const bool starts_ok = cur->camera_major && (int)cur->cam_start.size() == cur->n_cams + 1 && cur->cam_start[cur->n_cams] == n;
     const bool cams_want = cam_env && !J.points && !J.win2_dev && starts_ok && (multi || (cur->n_cams >= 2 && nq >= cams_min_q));

@@ -152,7 +152,7 @@ class Extractor:
         return _lib.lib().orbx_debug_last_path(self._h)
 
     def pyramid_form(self):
-        """0 k_pyramid_tiled, 1 k_resize_v4 per level, 2 k_resize2 / k_resize, 3 k_pyramid_tiled4 x 2 (orbx_debug_pyramid_form)"""
+        """0 k_pyramid_tiled, 2 k_resize per level (generic chain), 3 k_pyramid_tiled4 x 2 (orbx_debug_pyramid_form)"""
         return _lib.lib().orbx_debug_pyramid_form(self._h)
 
     def level0_in_place(self):

@@ -6,9 +6,11 @@
 #include <cstring>
 #include "../../include/orbv.h"
 
+#include "resident.h"
+
 namespace ORB_SLAM2 {
 
-static int device() { const char* d = std::getenv("MORB_DEVICE"); return d ? std::atoi(d) : 0; }
+static int device() { return host_device(); }
 
 ORBVocabulary::~ORBVocabulary() { orbv_destroy(handle_); }
 

@@ -111,8 +111,7 @@ bool ORBextractor::EnsureHandle(int width, int height) {
     handle_ = nullptr;
     cap_w_ = width > cap_w_ ? width : cap_w_; cap_h_ = height > cap_h_ ? height : cap_h_;
     orbx_params p = {nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST};
-    const char* dev = std::getenv("MORB_DEVICE");
-    int rc = orbx_create(&p, 1, cap_w_, cap_h_, dev ? std::atoi(dev) : 0, &handle_);
+    int rc = orbx_create(&p, 1, cap_w_, cap_h_, host_device(), &handle_);
     if (rc) { handle_ = nullptr; return fail("orbx_create", rc); }
     return true;
 }
@@ -192,8 +191,7 @@ void ORBextractor::ExtractBatch(const std::vector<ORBextractor*>& ex, const std:
     if (!same) {
         orbx_destroy(batch); batch = nullptr;
         bw = std::max(bw, mw); bh = std::max(bh, mh);
-        const char* dev = std::getenv("MORB_DEVICE");
-        int rc = orbx_create(ps.data(), n, bw, bh, dev ? std::atoi(dev) : 0, &batch);
+        int rc = orbx_create(ps.data(), n, bw, bh, host_device(), &batch);
         if (rc) { batch = nullptr; fail("orbx_create(batch)", rc); empty_outputs(); return; }
         batch_params = ps;
     }

@@ -116,8 +116,7 @@ void ORBmatcher::ResidentStats(unsigned long* served, unsigned long* missed) { r
 
 orbv_workspace* ORBmatcher::Bow() {
     if (!tls.w) {
-        const char* dev = std::getenv("MORB_DEVICE");
-        int rc = orbv_workspace_create(dev ? std::atoi(dev) : 0, &tls.w);
+        int rc = orbv_workspace_create(host_device(), &tls.w);
         if (rc) { tls.w = nullptr; fail("orbv_workspace_create", rc); }
     }
     return tls.w;
@@ -133,8 +132,7 @@ cv::Mat ORBmatcher::SkewSymmetricMatrix(const cv::Mat& v) {  // reference :4012-
 
 orbm_matcher* ORBmatcher::Handle() {
     if (!tls.m) {
-        const char* dev = std::getenv("MORB_DEVICE");
-        int rc = orbm_create(dev ? std::atoi(dev) : 0, &tls.m);
+        int rc = orbm_create(host_device(), &tls.m);
         if (rc) { tls.m = nullptr; fail("orbm_create", rc); }
     }
     return tls.m;
@@ -173,8 +171,9 @@ void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& i
 namespace {
 
 // MORB_DUMP_QUERIES=<file> (tests): appends {count, queries, index of each query's point in the caller's vector}
+const char* dump_path() { static const char* p = std::getenv("MORB_DUMP_QUERIES"); return p; }
 void dump_queries(const std::vector<orbm_query>& q, const std::vector<int>& src) {
-    const char* path = std::getenv("MORB_DUMP_QUERIES");
+    const char* path = dump_path();
     if (!path) return;
     FILE* f = std::fopen(path, "ab");
     if (!f) return;
@@ -186,7 +185,7 @@ void dump_queries(const std::vector<orbm_query>& q, const std::vector<int>& src)
 
 // second windows of the last dumped query set: {-count, windows}
 void dump_windows(const std::vector<orbm_window>& w) {
-    const char* path = std::getenv("MORB_DUMP_QUERIES");
+    const char* path = dump_path();
     if (!path) return;
     FILE* f = std::fopen(path, "ab");
     if (!f) return;
@@ -194,6 +193,41 @@ void dump_windows(const std::vector<orbm_window>& w) {
     std::fwrite(&n, 4, 1, f);
     if (!w.empty()) std::fwrite(w.data(), sizeof(orbm_window), w.size(), f);
     std::fclose(f);
+}
+
+// One map point seen from one camera of a keyframe: what the reference's projection searches do per point between "the point in
+// camera coordinates" and "GetFeaturesInArea" (src/ORBmatcher.cc:2023-2075, :2235-2285, :2650-2700, :2850-2900, :3160-3200 -- five
+// copies there).  p3Dc: the point in that camera's coordinates (the caller's pose chain, which differs per search); PO: the vector the
+// distance band and -- with view_angle -- the viewing-angle test are taken on (the point from the camera centre in world coordinates,
+// or p3Dc itself in the Sim3 searches).  The float expressions and their ORDER are the reference's: the query's bits depend on them.
+// Fills u, v, radius, the level window [level - 1, level], cam, blocks and the descriptor; ur stays NaN (*invz_out for callers with a
+// stereo gate).  false: the reference's loop `continue`s.
+template <class View>
+bool point_query(MapPoint* pMP, const cv::Mat& p3Dc, const cv::Mat& PO, View* view, float fx, float fy, float cx, float cy, float th,
+                 bool view_angle, int cam, int blocks, orbm_query& Q, float* invz_out = nullptr) {
+    if (p3Dc.at<float>(2) < 0.0f) return false;
+    const float invz = 1 / p3Dc.at<float>(2);   // (the reference writes 1 / z here and 1.0 / z there: the same float either way)
+    const float x = p3Dc.at<float>(0) * invz;
+    const float y = p3Dc.at<float>(1) * invz;
+    const float u = fx * x + cx;
+    const float v = fy * y + cy;
+    if (!view->IsInImage(u, v)) return false;
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    const float dist3D = cv::norm(PO);
+    if (dist3D < minDistance || dist3D > maxDistance) return false;
+    if (view_angle) {
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) return false;
+    }
+    const int nPredictedLevel = pMP->PredictScale(dist3D, view);
+    Q.u = u; Q.v = v; Q.radius = th * view->mvScaleFactors[nPredictedLevel]; Q.ur = std::nanf("");
+    Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;
+    Q.cam = cam; Q.blocks = blocks; Q.angle = 0;
+    const cv::Mat dMP = pMP->GetDescriptor();
+    std::memcpy(Q.desc, dMP.ptr(0), 32);
+    if (invz_out) *invz_out = invz;
+    return true;
 }
 
 struct FlatFrame {  // orbm_frame_desc backing store built from a Frame
@@ -489,28 +523,8 @@ int ORBmatcher::SearchByProjection_cam1(KeyFrame* pKF, cv::Mat Scw, const std::v
         if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
         cv::Mat p3Dw = pMP->GetWorldPos();
         cv::Mat p3Dc = Rcw * p3Dw + tcw;
-        if (p3Dc.at<float>(2) < 0.0) continue;
-        const float invz = 1 / p3Dc.at<float>(2);
-        const float x = p3Dc.at<float>(0) * invz;
-        const float y = p3Dc.at<float>(1) * invz;
-        const float u = fx * x + cx;
-        const float v = fy * y + cy;
-        if (!pKF->IsInImage(u, v)) continue;
-        const float maxDistance = pMP->GetMaxDistanceInvariance();
-        const float minDistance = pMP->GetMinDistanceInvariance();
-        cv::Mat PO = p3Dw - Ow;
-        const float dist = cv::norm(PO);
-        if (dist < minDistance || dist > maxDistance) continue;
-        cv::Mat Pn = pMP->GetNormal();
-        if (PO.dot(Pn) < 0.5 * dist) continue;
-        int nPredictedLevel = pMP->PredictScale(dist, pKF);
-        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
         orbm_query Q;
-        Q.u = u; Q.v = v; Q.radius = radius; Q.ur = std::nanf("");
-        Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;   // :833-836
-        Q.cam = 0; Q.blocks = 1; Q.angle = 0;
-        const cv::Mat dMP = pMP->GetDescriptor();
-        std::memcpy(Q.desc, dMP.ptr(0), 32);
+        if (!point_query(pMP, p3Dc, p3Dw - Ow, pKF, fx, fy, cx, cy, (float)th, /*view_angle=*/true, 0, 1, Q)) continue;   // (window [level - 1, level], :833-836)
         q.push_back(Q); qmp.push_back(pMP); qsrc.push_back(iMP);
     }
     dump_queries(q, qsrc);
@@ -749,25 +763,8 @@ static int sim3_search(ORBmatcher& self, orbm_matcher* handle, KeyFrame* pKF1, K
             cv::Mat p3Da = Rw * p3Dw + tw;
             cv::Mat p3Db = sR * p3Da + t;
             if (camIdx == 1) p3Db = Rcam21 * p3Db + tcam21;
-            if (p3Db.at<float>(2) < 0.0) continue;
-            const float invz = 1.0 / p3Db.at<float>(2);
-            const float x = p3Db.at<float>(0) * invz;
-            const float y = p3Db.at<float>(1) * invz;
-            const float u = fx * x + cx;
-            const float v = fy * y + cy;
-            if (!to->IsInImage(u, v)) continue;
-            const float maxDistance = pMP->GetMaxDistanceInvariance();
-            const float minDistance = pMP->GetMinDistanceInvariance();
-            const float dist3D = cv::norm(p3Db);
-            if (dist3D < minDistance || dist3D > maxDistance) continue;
-            const int nPredictedLevel = pMP->PredictScale(dist3D, to);
-            const float radius = th * to->mvScaleFactors[nPredictedLevel];
             orbm_query Q;
-            Q.u = u; Q.v = v; Q.radius = radius; Q.ur = std::nanf("");
-            Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;
-            Q.cam = camIdx; Q.blocks = 0; Q.angle = 0;
-            const cv::Mat dMP = pMP->GetDescriptor();
-            std::memcpy(Q.desc, dMP.ptr(0), 32);
+            if (!point_query(pMP, p3Db, p3Db, to, fx, fy, cx, cy, (float)th, /*view_angle=*/false, camIdx, 0, Q)) continue;
             q.push_back(Q); src.push_back(i);
         }
         dump_queries(q, src);
@@ -830,29 +827,9 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
         for (int cam = 0; cam < 2; cam++) {
             if (cam == 0) p3Dc = Rcw * p3Dw + tcw;
             else p3Dc = Rcam21 * Rcw * p3Dw + Rcam21 * tcw + tcam21;
-            if (p3Dc.at<float>(2) < 0.0f) continue;
-            const float invz = 1 / p3Dc.at<float>(2);
-            const float x = p3Dc.at<float>(0) * invz;
-            const float y = p3Dc.at<float>(1) * invz;
-            const float u = fx * x + cx;
-            const float v = fy * y + cy;
-            if (!pKF->IsInImage(u, v)) continue;
-            const float ur = u - bf * invz;
-            const float maxDistance = pMP->GetMaxDistanceInvariance();
-            const float minDistance = pMP->GetMinDistanceInvariance();
-            cv::Mat PO = p3Dw - Ow[cam];
-            const float dist3D = cv::norm(PO);
-            if (dist3D < minDistance || dist3D > maxDistance) continue;
-            cv::Mat Pn = pMP->GetNormal();
-            if (PO.dot(Pn) < 0.5 * dist3D) continue;
-            int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
-            const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
-            orbm_query Q;
-            Q.u = u; Q.v = v; Q.radius = radius; Q.ur = ur;
-            Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;
-            Q.cam = cam; Q.blocks = 0; Q.angle = 0;
-            const cv::Mat dMP = pMP->GetDescriptor();
-            std::memcpy(Q.desc, dMP.ptr(0), 32);
+            orbm_query Q; float invz = 0.f;
+            if (!point_query(pMP, p3Dc, p3Dw - Ow[cam], pKF, fx, fy, cx, cy, (float)th, /*view_angle=*/true, cam, 0, Q, &invz)) continue;
+            Q.ur = Q.u - bf * invz;
             q.push_back(Q); src.push_back(i);
         }
     }
@@ -920,29 +897,10 @@ int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& v
             cv::Mat p3Dc;
             if (camidx == 1) p3Dc = Rcam21 * Rcw * p3Dw + Rcam21 * tcw + tcam21;
             else p3Dc = Rcw * p3Dw + tcw;
-            if (p3Dc.at<float>(2) < 0.0f) continue;
-            const float invz = 1.0 / p3Dc.at<float>(2);
-            const float x = p3Dc.at<float>(0) * invz;
-            const float y = p3Dc.at<float>(1) * invz;
-            const float u = fx * x + cx;
-            const float v = fy * y + cy;
-            if (!pKF->IsInImage(u, v)) continue;
-            const float maxDistance = pMP->GetMaxDistanceInvariance();
-            const float minDistance = pMP->GetMinDistanceInvariance();
             cv::Mat PO = p3Dw - Ow;
             if (camidx == 1) PO = PO - Rcw.t() * tcam12;
-            const float dist3D = cv::norm(PO);
-            if (dist3D < minDistance || dist3D > maxDistance) continue;
-            cv::Mat Pn = pMP->GetNormal();
-            if (PO.dot(Pn) < 0.5 * dist3D) continue;
-            const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
-            const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
             orbm_query Q;
-            Q.u = u; Q.v = v; Q.radius = radius; Q.ur = std::nanf("");
-            Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;
-            Q.cam = camidx; Q.blocks = 0; Q.angle = 0;
-            const cv::Mat dMP = pMP->GetDescriptor();
-            std::memcpy(Q.desc, dMP.ptr(0), 32);
+            if (!point_query(pMP, p3Dc, PO, pKF, fx, fy, cx, cy, (float)th, /*view_angle=*/true, camidx, 0, Q)) continue;
             q.push_back(Q); src.push_back(iMP);
         }
     }
@@ -991,28 +949,8 @@ int ORBmatcher::Fuse_cam1(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint
         if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
         cv::Mat p3Dw = pMP->GetWorldPos();
         cv::Mat p3Dc = Rcw * p3Dw + tcw;
-        if (p3Dc.at<float>(2) < 0.0f) continue;
-        const float invz = 1.0 / p3Dc.at<float>(2);
-        const float x = p3Dc.at<float>(0) * invz;
-        const float y = p3Dc.at<float>(1) * invz;
-        const float u = fx * x + cx;
-        const float v = fy * y + cy;
-        if (!pKF->IsInImage(u, v)) continue;
-        const float maxDistance = pMP->GetMaxDistanceInvariance();
-        const float minDistance = pMP->GetMinDistanceInvariance();
-        cv::Mat PO = p3Dw - Ow;
-        const float dist3D = cv::norm(PO);
-        if (dist3D < minDistance || dist3D > maxDistance) continue;
-        cv::Mat Pn = pMP->GetNormal();
-        if (PO.dot(Pn) < 0.5 * dist3D) continue;
-        const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
-        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
         orbm_query Q;
-        Q.u = u; Q.v = v; Q.radius = radius; Q.ur = std::nanf("");
-        Q.min_level = nPredictedLevel - 1; Q.max_level = nPredictedLevel;   // :2660-2663
-        Q.cam = 0; Q.blocks = 0; Q.angle = 0;
-        const cv::Mat dMP = pMP->GetDescriptor();
-        std::memcpy(Q.desc, dMP.ptr(0), 32);
+        if (!point_query(pMP, p3Dc, p3Dw - Ow, pKF, fx, fy, cx, cy, (float)th, /*view_angle=*/true, 0, 0, Q)) continue;   // (:2660-2663)
         q.push_back(Q); src.push_back(iMP);
     }
     dump_queries(q, src);

@@ -9,8 +9,11 @@
 //     pointer identity, frame ids or sequence numbers are not consulted.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 
 namespace ORB_SLAM2 {
+// the device every handle of the host classes is created on (MORB_DEVICE, default 0: one process per GPU)
+inline int host_device() { static const int d = [] { const char* e = std::getenv("MORB_DEVICE"); return e ? std::atoi(e) : 0; }(); return d; }
 namespace resident {
 
 // `owner` identifies the publishing extractor (or batch slot); a second publish by the same owner replaces the first.

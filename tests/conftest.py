@@ -9,6 +9,13 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # children of the pyramid-form tests: another tile size / split level for the large-rig pyramid plan (a debug hook of the library,
+    # include/orb_debug.h: orbx_debug_pyramid_plan -- set before any handle exists)
+    plan = os.environ.get("MORB_TEST_PYRAMID_PLAN")
+    if plan:
+        from multi_orb_slam_amd import _lib
+        w, h, split = (int(x) for x in plan.split(","))
+        _lib.lib().orbx_debug_pyramid_plan(w, h, split)
 
 
 def pytest_collection_modifyitems(config, items):

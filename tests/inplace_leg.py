@@ -1,5 +1,5 @@
 """Run as a child process (the pyramid arrangement is chosen once per process from the environment): the front end on device images
-with the resize-chain pyramid forced (MORB_PYR_CHAIN=1 MORB_PYRAMID_PAIRS=0), so that pyramid level 0 is read IN PLACE in the caller's buffers
+with the large-rig pyramid form forced (MORB_PYR_CHAIN=1), so that pyramid level 0 is read IN PLACE in the caller's buffers
 (extractor.hip: k_set_l0), through every transition the table has to survive -- tight and padded pitches, a step from host
 images in between, a misaligned buffer (copied as before), a camera that keeps its buffer, steps announced ahead -- each
 step held against the oracle.  Prints one line `inplace_leg ok ...`; any mismatch raises."""
@@ -43,8 +43,7 @@ def step_dev(t, pitch=None, shift=(0, 0), gen=None, next_t=None):
 
 
 keep = []
-ON = os.environ.get("MORB_L0_INPLACE", "1") != "0"      # (MORB_L0_INPLACE=0: the same steps, everything copied)
-two = 2 if ON else 0
+two = 2
 step_dev(0)                                   # tight pitch, aligned: in place
 step_dev(1, pitch=W + 64)                     # padded pitch, aligned: in place
 assert used == [two, two], used

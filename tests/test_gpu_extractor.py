@@ -296,28 +296,31 @@ def test_a_level_the_reference_leaves_undefined_still_runs():
         oracle.extract(synth.image(3, 0, 333, 777), nfeatures=600)
 
 
-# The forms a large rig's pyramid can take, forced at the sizes of this file's stage tests (the arrangement is chosen once per process, so
-# each form runs them in a child): the round-3 chain (one k_resize_v4 launch per level), the round-5 tile launches (k_pyramid_tiled4: levels
-# 1..3 below level 0 and 4.. below level 3 in 128 x 64 tiles), the same with tiles so small that every image is dozens of them with
-# ragged last rows and columns, and with the split after level 1 / level 5 / beyond the last level (one launch does everything).
+# The forms a pyramid can take besides the one-launch tile kernel of small rigs, forced at the sizes of this file's stage tests (the
+# arrangement is chosen once per process, so each form runs them in a child): the generic chain (one k_resize launch per level: what odd
+# parameter sets fall back to), the large-rig tile launches (k_pyramid_tiled4: levels 1..3 below level 0 and 4.. below level 3 in
+# 128 x 64 tiles), the same with tiles so small that every image is dozens of them with ragged last rows and columns, and with the split
+# after level 1 / level 5 / beyond the last level (one launch does everything).  MORB_TEST_PYRAMID_PLAN = "tile_w,tile_h,split" is read
+# by the TESTS (tests/conftest.py) and handed to orbx_debug_pyramid_plan -- the library itself has no such switch.
 PYRAMID_FORMS = {
-    "chain_v4": (1, {"MORB_PYR_TILED4": "0"}),
+    "generic_chain": (2, {"MORB_PYR_CHAIN": "2"}),
     "tiled4": (3, {}),
-    "tiled4_small_tiles": (3, {"MORB_PYR_T4_W": "32", "MORB_PYR_T4_H": "16"}),
-    "tiled4_wide_tiles_split1": (3, {"MORB_PYR_T4_W": "256", "MORB_PYR_T4_H": "24", "MORB_PYR_SPLIT": "1"}),
-    "tiled4_split5": (3, {"MORB_PYR_SPLIT": "5", "MORB_PYR_T4_W": "64", "MORB_PYR_T4_H": "64"}),
-    "tiled4_one_launch": (3, {"MORB_PYR_SPLIT": "99", "MORB_PYR_T4_W": "64", "MORB_PYR_T4_H": "32"}),
+    "tiled4_small_tiles": (3, {"MORB_TEST_PYRAMID_PLAN": "32,16,0"}),
+    "tiled4_wide_tiles_split1": (3, {"MORB_TEST_PYRAMID_PLAN": "256,24,1"}),
+    "tiled4_split5": (3, {"MORB_TEST_PYRAMID_PLAN": "64,64,5"}),
+    "tiled4_one_launch": (3, {"MORB_TEST_PYRAMID_PLAN": "64,32,99"}),
 }
 
 
 @pytest.mark.parametrize("form", sorted(PYRAMID_FORMS))
 def test_resize_chain_form_equals_the_oracle_at_every_size(form):
     """Large rigs build their pyramid with four pixels per lane from a per-group table of byte selectors and coefficient pairs instead of
-    the one-launch tile kernel of small rigs; the stage tests of this file -- every level byte for byte, odd sizes included -- run once
-    more in a child with each form of that forced at their sizes (MORB_EXPECT_PYRAMID_FORM makes the child check which one ran)."""
+    the one-launch tile kernel of small rigs, parameter sets outside both take one plain launch per level; the stage tests of this file
+    -- every level byte for byte, odd sizes included -- run once more in a child with each form forced at their sizes
+    (MORB_EXPECT_PYRAMID_FORM makes the child check which one ran -- where the parameter set admits the form at all)."""
     import subprocess, sys
     want, extra = PYRAMID_FORMS[form]
-    env = dict(os.environ, MORB_PYR_CHAIN="1", MORB_PYRAMID_PAIRS="0", MORB_EXPECT_PYRAMID_FORM=str(want), **extra)
+    env = dict(os.environ, MORB_PYR_CHAIN="1", MORB_EXPECT_PYRAMID_FORM=str(want)); env.update(extra)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "stages_and_end_to_end or mixed_sizes or larger_configs or odd_parameter or image_families"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
@@ -326,13 +329,13 @@ def test_resize_chain_form_equals_the_oracle_at_every_size(form):
 
 
 
-@pytest.mark.parametrize("env", [{}, {"MORB_FAST_FORM": "2", "MORB_PYR_CHAIN": "1", "MORB_PYRAMID_PAIRS": "0"}], ids=["default_forms", "large_rig_forms"])
+@pytest.mark.parametrize("env", [{}, {"MORB_FAST_FORM": "2", "MORB_PYR_CHAIN": "1"}], ids=["default_forms", "large_rig_forms"])
 def test_random_parameter_sets_equal_the_oracle(env):
     """Twelve random parameter sets (image size, scale factor, level count, FAST thresholds on both sides of the packed quick test's 127,
     feature count, image family) through the whole extraction, in the small-rig and in the large-rig forms of the kernels
-    (tools/experiments/fuzz_extractor_random.py; the same tool runs hundreds of cases by hand)."""
+    (tools/fuzz_extractor_random.py; the same tool runs hundreds of cases by hand)."""
     import subprocess, sys
-    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "experiments", "fuzz_extractor_random.py")
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_extractor_random.py")
     r = subprocess.run([sys.executable, tool, "12", "5"], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()[-1500:]
     assert r.returncode == 0 and "ok: " in out and "differs" not in out, out

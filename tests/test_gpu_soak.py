@@ -80,11 +80,11 @@ def test_isolated_steps_polled_and_synchronised_agree_over_5000_steps(monkeypatc
 
 
 def test_digest_of_a_stream_with_changing_motion_does_not_depend_on_the_ab_switches():
-    """tools/experiments/soak_motion.py drives 600 overlapped steps whose motion (du, dv, th) changes every step and hashes every
+    """tools/soak_motion.py drives 600 overlapped steps whose motion (du, dv, th) changes every step and hashes every
     match list and cross-camera result.  The digest must be the same with the queries built on the device or by the host, the
     top-2 in FP4 or int8, the resolve monotone or Jacobi (the switches are read once per process: one process per setting)."""
     import os, subprocess, sys
-    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "experiments", "soak_motion.py")
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_motion.py")
     out = []
     for extra in ({}, {"MORB_MOTION_ON_DEVICE": "0", "MORB_TOP2_FP4": "0", "MORB_RESOLVE_MONO": "0"}):
         env = dict(os.environ); env.update(extra)

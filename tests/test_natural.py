@@ -105,12 +105,12 @@ def test_extractor_stage_by_stage_on_photographs(photo, w, h, nf):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form,want,extra", [("chain_v4", 1, {"MORB_PYR_TILED4": "0"}), ("tiled4", 3, {}),
-                                             ("tiled4_small_tiles", 3, {"MORB_PYR_T4_W": "32", "MORB_PYR_T4_H": "16"})])
+@pytest.mark.parametrize("form,want,extra", [("generic_chain", 2, {"MORB_PYR_CHAIN": "2"}), ("tiled4", 3, {}),
+                                             ("tiled4_small_tiles", 3, {"MORB_TEST_PYRAMID_PLAN": "32,16,0"})])
 def test_natural_pyramid_forms(form, want, extra):
-    """the large-rig pyramid forms forced at 640x480 and 1280x720 on the photographs (the form is chosen once per process: a child)"""
+    """the generic chain and the large-rig pyramid forms forced at 640x480 and 1280x720 on the photographs (the form is chosen once per process: a child)"""
     import subprocess, sys
-    env = dict(os.environ, MORB_PYR_CHAIN="1", MORB_PYRAMID_PAIRS="0", MORB_EXPECT_PYRAMID_FORM=str(want), **extra)
+    env = dict(os.environ, MORB_PYR_CHAIN="1", MORB_EXPECT_PYRAMID_FORM=str(want)); env.update(extra)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "stage_by_stage and not 1920"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     tail = r.stdout.decode()[-2000:]

@@ -4,7 +4,7 @@
 the byte form; 128 and above: the unpacked form) and ini_th at and above min_th, feature counts 50 .. 2500, the image families of
 synth.FAMILIES.  usage: fuzz_extractor_random.py [cases] [seed]"""
 import os, sys
-root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 import multi_orb_slam_amd as m
