@@ -88,6 +88,16 @@ void* take_reader(const void* owner) {
         }
     return nullptr;
 }
+void reader_done(void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_entries.size();) {
+        if (g_entries[i].reader == stream) {
+            g_entries[i].reader = nullptr;
+            if (!g_entries[i].d_rows) { g_entries[i] = g_entries.back(); g_entries.pop_back(); continue; }   // (retired, kept for its reader only)
+        }
+        ++i;
+    }
+}
 void stats(unsigned long* served, unsigned long* missed) { *served = g_served.load(); *missed = g_missed.load(); }
 }  // namespace resident
 

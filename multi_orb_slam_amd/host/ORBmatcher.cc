@@ -1206,6 +1206,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     rc = orbm_search_by_projection(Handle(), fr, q.data(), (int)q.size(), any_occupied ? occupied.data() : nullptr, TH_HIGH,
                                    mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
     if (rc) return fail("orbm_search_by_projection", rc);
+    resident::reader_done(orbm_stream(Handle()));   // (the results are here: the frame build that read the extractors' rows finished long before them)
     tls.last_us[2] = us_since(t_search);
     // The reference starts from whatever CurrentFrame.mvpMapPoints holds (all NULL in TrackWithMotionModel,
     // src/Tracking.cc:1254) and only ever writes accepted matches / NULLs for histogram rejects.

@@ -29,6 +29,9 @@ const uint8_t* find(const uint8_t* rows, int n, const void** owner_out = nullptr
 // rows); retire(owner) keeps it until it is taken.
 void note_reader(const void* owner, void* stream);
 void* take_reader(const void* owner);
+// Everything the calling thread had enqueued on `stream` is known to have completed (a search on it returned its results): nobody
+// reads served rows through it any more.
+void reader_done(void* stream);
 // inspection (tests / bench): lookups served from HBM / not served, on all threads
 void stats(unsigned long* served, unsigned long* missed);
 
