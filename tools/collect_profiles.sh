@@ -7,7 +7,7 @@
 # launches (MORB_CHAIN_GRAPH=0) and keep the host-written staging in mapped pinned memory (MORB_NO_BAR_STAGING=1).  The kernels
 # and their durations are the same; only the host's launch cost differs, and `value` is never taken from a profiled run.
 set -x
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$ROUND/final; mkdir -p $O
 cd $R
 if [ "$1" != "prof-only" ]; then
@@ -17,7 +17,10 @@ for c in 2 3 4; do python bench.py --config $c --no-roofline > $O/bench_c$c.json
 # the per-rank step of a multi-GPU job, forced on this one GPU (world-1 RCCL group: one all-gather + rig-wide top-2 per step): at the
 # tail of the step's extraction chain (the default, with and without the issuer thread) and behind the step's search (rounds 2-4)
 MORB_FORCE_DIST=1 python bench.py --no-dropin --no-roofline --no-cpu > $O/bench_forced_exchange.json 2> $O/bench_forced_exchange.err
-MORB_FORCE_DIST=1 MORB_EXCHANGE_THREAD=0 python bench.py --no-dropin --no-roofline --no-cpu > $O/bench_forced_exchange_no_issuer.json 2> $O/bench_forced_exchange_no_issuer.err
+# the N > 1 job rehearsed as rank PROCESSES on this one GPU (peer transport: direct writes into IPC-mapped arenas, gloo control plane)
+python bench.py --gpus 2 --no-dropin --no-roofline --no-cpu > $O/bench_2ranks_1gpu_config1_peer.json 2> $O/bench_2ranks_1gpu_config1_peer.err
+python bench.py --gpus 2 --config 3 --no-roofline --no-cpu > $O/bench_2ranks_1gpu_config3_peer.json 2> $O/bench_2ranks_1gpu_config3_peer.err
+python bench.py --gpus 4 --config 3 --no-roofline --no-cpu > $O/bench_4ranks_1gpu_config3_peer.json 2> $O/bench_4ranks_1gpu_config3_peer.err
 MORB_FORCE_DIST=1 MORB_EXCHANGE_PLACEMENT=inline python bench.py --no-dropin --no-roofline --no-cpu > $O/bench_forced_exchange_inline.json 2> $O/bench_forced_exchange_inline.err
 fi
 cd /tmp && export TMPDIR=/tmp
@@ -35,7 +38,7 @@ fi
 python3 $R/tools/parse_pmc.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/parse_pmc.out 2>&1
 STEPS=8
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
-for c in 1 2 4; do
+for c in 1 2 3 4; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cfg${c}_fetch -o p -- python3 $R/tools/profile_extractor.py $c $STEPS > $O/cfg${c}_fetch.out 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cfg${c}_write -o p -- python3 $R/tools/profile_extractor.py $c $STEPS > $O/cfg${c}_write.out 2>&1
   rocprofv3 --pmc $SQ --output-format csv -d $O/cfg${c}_sq -o p -- python3 $R/tools/profile_extractor.py $c $STEPS > $O/cfg${c}_sq.out 2>&1

@@ -11,10 +11,10 @@ import collections, csv, glob, json, os, sys
 
 KERNELS = ["k_pyramid_tiled4", "k_pyramid_tiled", "k_ingest", "k_set_l0", "k_resize_v4", "k_resize2", "k_resize", "k_fast_cells", "k_octree", "k_describe", "k_frame_build_small", "k_frame_fill",
            "k_scan_cells", "k_scatter_cells", "k_sort_cells", "k_cams_from_counts", "k_project_side", "k_project", "k_top2_merge",
-           "k_cross_top2_mfma", "k_resolve_mono", "k_resolve", "k_rs_mono_cam", "k_rs_init", "k_rs_sweep", "k_rs_owner", "k_rs_reject", "k_rs_write", "k_mirror_frame",
+           "k_cross_top2_mfma", "k_resolve_mono", "k_resolve_cams", "k_resolve", "k_peer_put", "k_peer_wait", "k_rs_init", "k_rs_sweep", "k_rs_owner", "k_rs_reject", "k_rs_write", "k_mirror_frame",
            "fillBuffer", "copyBuffer"]
 EXTRACT = ["k_pyramid_tiled4", "k_pyramid_tiled", "k_ingest", "k_set_l0", "k_resize_v4", "k_resize2", "k_resize", "k_fast_cells", "k_octree", "k_describe"]
-SHAPES = {1: (640, 480, 1000, 2), 2: (1280, 720, 2000, 2), 4: (1920, 1080, 4000, 8)}
+SHAPES = {1: (640, 480, 1000, 2), 2: (1280, 720, 2000, 2), 3: (640, 480, 1000, 4), 4: (1920, 1080, 4000, 8)}
 
 
 def short(name):
