@@ -1,16 +1,17 @@
 // extractor.hip -- gfx950 kernels + C ABI of the ORB extractor (include/orbx.h).
 //
 // Per call (all cameras batched in every launch; integer / byte work, no MFMA by design):
-//   k_resize        K1     pyramid level l from the QUANTISED level l-1 (serial chain, reference
-//                          src/ORBextractor.cc:1109-1134): OpenCV's 11-bit fixed-point bilinear, coefficient tables
-//                          precomputed on the host so the kernel is pure integer.
+//   k_pyramid_tiled K1     every level of every camera in ONE launch (small rigs): a workgroup per level-0 tile computes what hangs
+//   k_pyramid_tiled4       below it, level after level in LDS; large rigs: two such launches with four pixels per lane (levels 1-3 below
+//   k_resize               level 0, 4.. below level 3); parameter sets outside both: one plain launch per level.  OpenCV's 11-bit
+//                          fixed-point bilinear (reference src/ORBextractor.cc:1109-1134), coefficient tables from the host.
 //   k_fast_cells    K2+K3  one workgroup per 30-px detection cell (reference src/ORBextractor.cc:790-830): image tile +
 //                          3-px halo staged in LDS, threshold-free FAST-9/16 score per pixel (App. A-2), cell-local
 //                          3x3 non-max suppression, per-cell threshold choice (iniTh, else minTh) and ordered
-//                          (row-major) compaction -- all in LDS.
-//   k_compact       K3b    per (camera, level): scan of the cell counts -> dense cell-major candidate list written
-//                          straight into pinned host memory (one stream sync, no second D2H).
-//   (host)          K4     quadtree distribution (octree.cpp) on the candidates.
+//                          (row-major) output into per-cell slots -- all in LDS.
+//   k_octree        K4     DistributeOctTree on the device: one workgroup per (camera, level), keys in vector registers.
+//   k_compact + host K4'   the exact host quadtree (octree.cpp) for levels beyond the device limits: dense cell-major candidate
+//                          list written straight into pinned host memory.
 //   k_describe      K5-K7  one wave per keypoint: 45x45 patch (reflect-101 at the level edge) staged in LDS,
 //                          intensity-centroid moments + fastAtan2 on the raw patch, 7x7 sigma-2 fixed-point Gaussian
 //                          of the 39x39 neighbourhood actually sampled, 256 steered rBRIEF tests, keypoint record.
@@ -57,7 +58,7 @@ struct LevelInfo {
     int slot_base, slot_cap; // per-cell candidate slots: slot_base + local_cell*slot_cap (u32 units)
     int cand_base;           // dense candidate list of this level (u32 units, in the pinned host buffer)
     int xtab_off, ytab_off;  // resize coefficient tables (valid for level >= 1)
-    int xgrp_off;            // the x table once more per group of four destination columns (k_resize_v4), in groups
+    int xgrp_off;            // the x table once more per group of four destination columns (k_pyramid_tiled4), in groups
     int ini_th, min_th;
     float scale;             // mvScaleFactor[level]
     float patch_size;        // (float)(int)(31 * scale)
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(NT) void k_pyramid_tiled(PyrArgs A, const LevelInfo
 
 // ------------------------------------------------------------------------------------------------ K1, tiled, four pixels per lane
 // Round 5: the tile scheme of k_pyramid_tiled (a workgroup takes a tile of ONE level -- the base -- and computes what hangs below it on
-// the next levels in LDS, recomputing the halo its neighbours own) with the arithmetic of k_resize_v4 (four adjacent pixels per lane:
+// the next levels in LDS, recomputing the halo its neighbours own) with round 3's four-pixels-per-lane arithmetic (four adjacent pixels per lane:
 // a source row is three LDS dwords shifted to the first tap, one v_perm + v_dot2 per pixel and row, the x table ready-made per group
 // of four columns).  k_pyramid_tiled spends ~70 vector instructions per pixel (one pixel per lane and step, byte reads), this form
 // ~25 as the chain does -- so a LARGE rig's pyramid is two launches (levels 1..m below level 0, levels m+1.. below level m) instead of
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(NT) void k_pyramid_tiled(PyrArgs A, const LevelInfo
 // column of the group's first tap (rows: the row of the left tap, as k_pyramid_tiled).  First taps are monotone in g, so on every level
 // the tiles own disjoint runs of whole groups that cover it; region starts are multiples of four on every level, so a dword of an LDS
 // region is a dword of the level.  What a tile needs beyond what it owns grows to the right and downwards only.  Every pixel is the
-// same integer function of the same source bytes as in k_resize_v4, whoever computes it.
+// same integer function of the same source bytes as in k_resize, whoever computes it.
 //   Spans per (camera, level, tile column / row) from the host (TilePlan): x {own0, own1, need1, 2^20 / needed groups} in pixels (all
 // multiples of four below the base), y {own0, own1, need1, 0}.
 struct Tile4Args {
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(NT) void k_pyramid_tiled4(Tile4Args A) {
                     out |= v << (8 * j);
                 }
                 reinterpret_cast<uint32_t*>(nxt + __umul24(y, pw))[g] = out;
-                if (own_g && y < oh) reinterpret_cast<uint32_t*>(dst + __umul24(y, lv.y))[g] = out;   // (columns past w: padding of the 64-byte row pitch, as k_resize_v4)
+                if (own_g && y < oh) reinterpret_cast<uint32_t*>(dst + __umul24(y, lv.y))[g] = out;   // (columns past w: padding of the 64-byte row pitch, as k_resize)
             }
         }
         __syncthreads();
@@ -1992,7 +1993,7 @@ void build_resize_tables(int sw, int sh, int dw, int dh, std::vector<int2>& xt, 
     }
 }
 
-// k_resize_v4's view of the x table: per group of four destination columns {c, sel0, sel1, sel2} {sel3, alpha0..2} {alpha3}, c = the
+// k_pyramid_tiled4's view of the x table: per group of four destination columns {c, sel0, sel1, sel2} {sel3, alpha0..2} {alpha3}, c = the
 // first tap's source column, sel_j = (left tap - c) | 0x0c << 8 | (right tap - c) << 16 | 0x0c << 24 (v_perm_b32 selector over the
 // row's eight bytes from c on: tap | 0 | tap | 0), alpha_j = the column's coefficient pair.  Columns past the level's width repeat
 // its last one (they land in the row pitch's padding).
@@ -2114,7 +2115,7 @@ struct orbx_extractor {
     DevBuf<uint8_t> d_pyr;
     DevBuf<LevelInfo> d_levels;
     DevBuf<int2> d_cell_map, d_xtab;
-    DevBuf<int4> d_xgrp;              // k_resize_v4's per-group view of the x table
+    DevBuf<int4> d_xgrp;              // k_pyramid_tiled4's per-group view of the x table
     DevBuf<uint8_t> d_desc_tabs;      // k_describe's DescribeTables (IC_Angle items + float test locations)
     // the tiled whole-pyramid launch (k_pyramid_tiled): spans per (camera, level, tile column / row), tiles per camera, LDS need
     DevBuf<int4> d_pyr_sx, d_pyr_sy;
@@ -2125,7 +2126,7 @@ struct orbx_extractor {
     bool v4_ok = false;               // level steps <= 1.6: the four-pixels-per-lane arithmetic of k_pyramid_tiled4 applies (taps of four neighbours within 8 bytes)
     bool generic_chain = false;       // MORB_PYR_CHAIN=2: neither tile form, one k_resize launch per level
     // large rigs (round 5): the pyramid as TWO tile launches with four pixels per lane (k_pyramid_tiled4): levels 1..m below level 0
-    // and levels m+1.. below level m, instead of one k_resize_v4 launch per level
+    // and levels m+1.. below level m
     struct TilePlan {
         int base = 0, last = 0, tw = 0, th = 0, halo_x = 16, halo_y = 16, tx_max = 0, ty_max = 0, gcap = 0, rcap = 0, lds = 0, threads = 256;
         short tx[64] = {}, ty[64] = {};

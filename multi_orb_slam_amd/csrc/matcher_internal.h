@@ -119,7 +119,7 @@ struct orbm_frame {
     mutable bool host_valid = false;
     std::vector<int32_t> cam_start;  // n_cams + 1
     // global indices are camera-major (camera c's features are [cam_start[c], cam_start[c + 1])): what every frame built by this
-    // library is; a host-built frame with interleaved cam_of[] is not, and the per-camera resolve (k_rs_mono_cam) must not take it
+    // library is; a host-built frame with interleaved cam_of[] is not, and the per-camera resolve (k_resolve_cams) must not take it
     bool camera_major = true;
     FrameDev dev() const {
         FrameDev F;
