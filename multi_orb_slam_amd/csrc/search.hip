@@ -483,7 +483,7 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
                                                        const int* __restrict__ cand_count, const uint8_t* __restrict__ occupied,
                                                        const float* __restrict__ f_angle, int th_high, int check_ori, int max_it,
                                                        const int* __restrict__ topk, int* __restrict__ match_of_feature,
-                                                       int* __restrict__ status, int tagb, MergeJob MJ) {
+                                                       int* __restrict__ status, int tagb, MergeJob MJ, int worklist) {
     MORB_LATENCY_KERNEL();
     // Workgroups behind the first one (isolated steps only) merge the slice partials of the camera-pair top-2 that rode in the projection's
     // launch: the resolve does not need them, the step does -- one kernel and one kernel boundary less between projection and resolve.
@@ -535,6 +535,8 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
     unsigned char* l_fl = reinterpret_cast<unsigned char*>(l_gd + RESOLVE_K * nq2);  // bit0 blocks, bit1 list > K, bits 2.. rotation bin + 1
     float* l_ang = reinterpret_cast<float*>(l_fl + ((nq + 3) & ~3));
     float* l_fang = l_ang + nq;
+    unsigned short* l_wl = reinterpret_cast<unsigned short*>(ANG ? l_fang + F.n_total : l_ang);   // worklist of displaced queries (nq2 entries)
+    __shared__ int s_wl_n[2];
     if (tid == 0) s_red = 0;
     if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
     for (int g = tid; g < F.n_total; g += T) {
@@ -685,6 +687,104 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
     // barrier; a round in which no wave saw anything displaced is the fixed point.  Dependency chains are followed at the pace
     // of a pass (two LDS trips), not of a barrier: the benchmark stream needs 2-3 rounds where the Jacobi form needs 9 sweeps.
     int it = 1, changed = 1;
+    if (worklist) {
+        // ---- round 6: the rounds as a WORKLIST.  Above, a wave repeats its pass over its own queries until none of them is displaced,
+        // and the wave whose queries depend on everybody else's walks up to eight ~1.7 us passes while fifteen waves wait at the round's
+        // barrier.  Here a round is: (A) every thread looks at the claims on its queries' picks (two LDS reads each) and puts the
+        // displaced ones on a list; (B) the list is walked by ALL threads, one displaced query per thread: it moves to the first later
+        // entry of its shortlist that no lower blocking query claims and claims it.  Same monotone iteration, another schedule (any
+        // interleaving ends in the same fixed point); a round with an empty list is the fixed point.  The state of a query is what
+        // set-up left in LDS (shortlist, flags, pick); its cursor is the pick's place on the shortlist.
+        if (tid < 2) s_wl_n[tid] = 0;
+        __syncthreads();
+        for (; it < max_it; ++it) {
+            int* cnt = &s_wl_n[it & 1];
+            for (int i0 = 0; i0 < nq; i0 += RQ * T) {   // (RQ queries per thread and trip: their picks, then the claims on them, in flight together)
+                int cc[RQ], cl[RQ];
+#pragma unroll
+                for (int b = 0; b < RQ; ++b) { const int i = i0 + b * T + tid; cc[b] = i < nq ? (int)l_choice[i] : 0xffff; }
+#pragma unroll
+                for (int b = 0; b < RQ; ++b) cl[b] = s_claim[cc[b] != 0xffff ? cc[b] : 0];
+#pragma unroll
+                for (int b = 0; b < RQ; ++b) {
+                    const int i = i0 + b * T + tid;
+                    const bool disp = cc[b] != 0xffff && cl[b] < i;
+                    const unsigned long long m = __ballot(disp);
+                    if (m) {
+                        int base = 0;
+                        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(cnt, __popcll(m));
+                        base = __builtin_amdgcn_readlane(base, __ffsll((long long)m) - 1);
+                        if (disp) l_wl[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+                    }
+                }
+            }
+            if (tid == 0) s_wl_n[(it + 1) & 1] = 0;
+            __syncthreads();
+            const int nwl = *cnt;
+#ifdef MORB_PHASE_CLOCKS
+            if (tid == 0 && it < 15) atomicAdd((unsigned long long*)&g_ph_chg[it], (unsigned long long)nwl);
+#endif
+            if (nwl == 0) { changed = 0; break; }
+            for (int j0 = 0; j0 < nwl; j0 += T) {   // (whole waves: a rescan below is the wave's work)
+                const int j = j0 + tid;
+                const int i = j < nwl ? (int)l_wl[j] : -1;
+                bool need_rescan = false;
+                int fl = 0;
+                if (i >= 0) {
+                    fl = l_fl[i];
+                    const int c = l_choice[i];
+                    int e[K], p = K;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) e[k] = l_gd[k * nq2 + i];
+#pragma unroll
+                    for (int k = K - 1; k >= 0; --k) if (e[k] == c) p = k;   // (a rescanned pick is not on the shortlist: cursor at the end)
+                    int ck[K];
+#pragma unroll
+                    for (int k = 1; k < K; ++k) {
+                        const bool want = k > p && e[k] != 0xffff;
+                        const int v = s_claim[want ? e[k] : 0];
+                        ck[k] = want ? v : -1;
+                    }
+                    int nk = K;
+#pragma unroll
+                    for (int k = K - 1; k >= 1; --k) if (ck[k] >= i) nk = k;
+                    int ne = 0xffff;
+#pragma unroll
+                    for (int k = 1; k < K; ++k) if (nk == k) ne = e[k];
+                    l_choice[i] = (unsigned short)ne;
+                    if (nk < K) { if (fl & 1) atomicMin(&s_claim[ne], i); }
+                    else need_rescan = (fl & 2) != 0;   // the shortlist ran dry while the list is longer: rescanned by the wave
+                }
+                unsigned long long todo = __ballot(need_rescan);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int q = __builtin_amdgcn_readlane(i, src);
+                    const int full = l_cnt[q];
+                    int k1 = 0x7fffffff, g1 = -1;
+                    for (int k0 = 0; k0 < full; k0 += 64) {
+                        const int k = k0 + lane;
+                        int key = 0x7fffffff, gg = -1;
+                        if (k < full) {
+                            gg = cand_idx[k * nq + q];
+                            const int d = cand_dist[k * nq + q];
+                            bool avail = !(occupied && occupied[gg]);
+                            if (s_claim[gg] < q) avail = false;
+                            if (avail) key = (d << 16) | k;
+                        }
+                        const int m1 = (int)wave_min_u32((unsigned)key);
+                        if (m1 < k1) { k1 = m1; g1 = __builtin_amdgcn_readlane(gg, __ffsll((long long)__ballot(key == m1)) - 1); }
+                    }
+                    if (lane == src && k1 != 0x7fffffff && (k1 >> 16) <= th_high) {
+                        l_choice[q] = (unsigned short)g1;
+                        if (fl & 1) atomicMin(&s_claim[g1], q);
+                    }
+                }
+            }
+            __syncthreads();
+            MORB_PHASE(g_ph_res, min(2 + it, 50));
+        }
+    } else {
     int qi01[RQ];
 #pragma unroll
     for (int b = 0; b < RQ; ++b) qi01[b] = b * T + tid;
@@ -731,6 +831,7 @@ __global__ __launch_bounds__(1024) void k_resolve_mono(FrameDev F, const int2* _
         __syncthreads();
         changed = s_flag[it % 3];
         MORB_PHASE(g_ph_res, min(2 + it, 50));
+    }
     }
     if (changed) {  // ran out of rounds
         (void)merge_wait();
@@ -1672,13 +1773,17 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
                        nq, cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,            \
                        (const float*)cur->b->d_ang.p, th_high, nnratio, J.points ? 0 : J.check_ori, 256, m->d_choice.p,      \
                        (const int*)m->d_claim.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20)
-    static const bool mono_env = [] { const char* e = getenv("MORB_RESOLVE_MONO"); return !(e && atoi(e) == 0); }();
+    static const int mono_mode = [] { const char* e = getenv("MORB_RESOLVE_MONO"); return e ? atoi(e) : 2; }();   // 0 Jacobi sweeps, 1 monotone per-wave passes, 2 monotone worklist
+    const bool mono_env = mono_mode != 0;
+    // (the worklist rounds pay from four queries per thread on: 2 x 2000 queries 30.7 -> 24.7 us, 4 x 1000 29.3 -> 27.3; at 2 x 1000 a
+    //  round's two barriers cost more than the waves' own passes: 17.3 -> 20.5 us, so small rigs keep those -- profiles/r06/notes_experiments.md)
+    const int mono_worklist = mono_mode == 2 && nq > 2048 ? 1 : 0;
     // The frame search's monotone resolve keeps less per query (16-bit features, no distances; mono_lds): it takes frames of up to
     // ~6000 features / queries (4 x 1000, 2 x 2000: where k_resolve's Jacobi form keeps its query state in HBM and costs 53 us),
     // four queries per thread in registers beyond 2048 queries, the rotation angles from HBM when they do not fit next to the rest.
     auto mono_lds = [&](bool ang) {
         const size_t nq2 = ((size_t)nq + 1) & ~(size_t)1;
-        return (size_t)n * 8 + nq2 * 4 + (size_t)RESOLVE_K * nq2 * 2 + (((size_t)nq + 3) & ~(size_t)3) + (ang ? ((size_t)nq + (size_t)n) * 4 : 0) + 16;
+        return (size_t)n * 8 + nq2 * 4 + (size_t)RESOLVE_K * nq2 * 2 + (((size_t)nq + 3) & ~(size_t)3) + (ang ? ((size_t)nq + (size_t)n) * 4 : 0) + nq2 * 2 + 16;   // (+ the worklist)
     };
     const bool will_mono = !J.points && mono_env && n < 65535 && mono_lds(false) <= 150 * 1024;
     if (MJ.S > 1 && !will_mono && !cams_fit) { if ((rc = launch_merge(m->stream, MJ))) return rc; MJ.S = 0; }   // (no carrier after all: a launch of its own)
@@ -1699,7 +1804,7 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
         hipLaunchKernelGGL((k_resolve_mono<RQ_, ANG_>), dim3(1 + merge_blocks), dim3(1024), ml, m->stream, cur->dev(), (const int2*)m->d_qmeta.p, nq, cap, \
                            (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p, (const int*)m->d_i1.p, d_occ,                                \
                            (const float*)cur->b->d_ang.p, th_high, J.check_ori, 4096, (const int*)m->d_claim.p, m->h_match.dp + 4,          \
-                           m->h_match.dp, J.seq << 20, MJ)
+                           m->h_match.dp, J.seq << 20, MJ, mono_worklist)
         const int merge_blocks = MJ.S > 1 ? (MJ.nq + 1023) / 1024 : 0;   // (behind workgroup 0, the resolve)
         if (merge_blocks) {
             if ((rc = m->d_mergecnt.reserve(4))) return rc;
