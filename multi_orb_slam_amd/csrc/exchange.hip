@@ -133,7 +133,10 @@ int morb::exchange_comm_clone(void* comm, int world, int rank, void** out) {
     uint8_t* d = nullptr;
     if (hipMalloc((void**)&d, (size_t)(world + 1) * 128) != hipSuccess) { (void)hipGetLastError(); return ORB_OK; }
     bool ok = hipMemcpy(d, id.internal, 128, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && R.AllGather(d, d + 128, 128, /*ncclUint8*/ 1, comm, nullptr) == 0 && hipStreamSynchronize(nullptr) == hipSuccess;
+    hipStream_t ts = nullptr;   // (a stream of its own: the null stream would synchronise with every other stream of the process)
+    ok = ok && hipStreamCreateWithFlags(&ts, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && R.AllGather(d, d + 128, 128, /*ncclUint8*/ 1, comm, ts) == 0 && hipStreamSynchronize(ts) == hipSuccess;
+    if (ts) (void)hipStreamDestroy(ts);
     ok = ok && hipMemcpy(id.internal, d + 128, 128, hipMemcpyDeviceToHost) == hipSuccess;
     (void)hipFree(d);
     bool zero = true;
@@ -327,8 +330,13 @@ int morb::peer_export(PeerComm** out, int world, int rank, size_t block, int nsl
         (void)hipGetLastError();
         MORB_HIP(hipMalloc((void**)&C->local, C->bytes));
     }
-    MORB_HIP(hipMemset(C->local, 0, C->bytes));
-    MORB_HIP(hipDeviceSynchronize());
+    {   // zeroed on a stream of its own: no device-wide synchronisation (another thread's front end may be capturing its launch chain)
+        hipStream_t zs = nullptr;
+        MORB_HIP(hipStreamCreateWithFlags(&zs, hipStreamNonBlocking));
+        hipError_t e1 = hipMemsetAsync(C->local, 0, C->bytes, zs), e2 = hipStreamSynchronize(zs);
+        (void)hipStreamDestroy(zs);
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(C->local); morb::set_error("peer arena: hipMemsetAsync failed"); return ORB_E_HIP; }
+    }
     hipIpcMemHandle_t h;
     if (hipIpcGetMemHandle(&h, C->local) != hipSuccess) {
         morb::set_error("hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed where the driver only has dmabuf IPC)", hipGetErrorString(hipGetLastError()));
@@ -338,7 +346,7 @@ int morb::peer_export(PeerComm** out, int world, int rank, size_t block, int nsl
     memcpy(handle, &h, sizeof h);
     int rc;
     if ((rc = C->d_peer.reserve(world)) || (rc = C->d_counter.reserve((size_t)nslots * 2)) || (rc = C->missing.reserve((size_t)nslots * 4))) { (void)hipFree(C->local); return rc; }
-    MORB_HIP(hipMemset(C->d_counter.p, 0, (size_t)nslots * 2 * sizeof(unsigned)));
+    MORB_HIP(hipMemset(C->d_counter.p, 0, (size_t)nslots * 2 * sizeof(unsigned)));   // (synchronous for the host: a few bytes)
     memset(C->missing.p, 0, (size_t)nslots * 4 * sizeof(uint32_t));
     C->timeout_ticks = (unsigned long long)std::max(1L, timeout_ms) * 100000ull;   // (wall_clock64: 100 MHz)
     C->peer.assign(world, nullptr);

@@ -362,7 +362,10 @@ int orbf_exchange_init(orbf_frontend* f, const uint8_t* uid128, int world, int r
         bool ok = hipMalloc((void**)&d, (size_t)world + 1) == hipSuccess;
         const uint8_t v = (uint8_t)mine;
         ok = ok && hipMemcpy(d, &v, 1, hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && exchange_allgather(comm, d, d + 1, 1, nullptr) == ORB_OK && hipStreamSynchronize(nullptr) == hipSuccess;
+        hipStream_t ts = nullptr;   // (a stream of its own, not the null stream)
+        ok = ok && hipStreamCreateWithFlags(&ts, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && exchange_allgather(comm, d, d + 1, 1, ts) == ORB_OK && hipStreamSynchronize(ts) == hipSuccess;
+        if (ts) (void)hipStreamDestroy(ts);
         std::vector<uint8_t> flags(world, 0);
         ok = ok && hipMemcpy(flags.data(), d + 1, world, hipMemcpyDeviceToHost) == hipSuccess;
         if (d) (void)hipFree(d);
