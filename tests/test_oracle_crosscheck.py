@@ -11,7 +11,7 @@ not in this image -- "parity unpinned").  What the image DOES have is used here 
 * libm's atan2 / sincos against fastAtan2's polynomial and the deterministic sincos.
 
 All over the image families of multi_orb_slam_amd/synth.py (rectangles, 1/f-like noise, dithered ramps, soft edges, saturated
-regions, contrast at the FAST thresholds) at 640x480 and 1920x1080.  This does not pin the oracle to OpenCV -- only OpenCV could --
+regions, contrast at the FAST thresholds) and the three photographs of tests/natural.py at 640x480 and 1920x1080.  This does not pin the oracle to OpenCV -- only OpenCV could --
 but a restatement that misremembered a convention (pixel centres, border mode, kernel normalisation, rounding constant) fails here."""
 import numpy as np
 import pytest
@@ -26,6 +26,9 @@ def images(w, h):
     yield "rects", synth.image(1, 2, w, h)
     for k in synth.FAMILIES:
         yield k, synth.family_image(k, 1, 2, w, h)
+    import natural   # (round 6) the photographs: natural texture, where the roundings decide bytes in other places than on rectangles
+    for photo in natural.PHOTOS:
+        yield "photo:" + photo, natural.frame(photo, 1, 2, w, h)
 
 
 @pytest.mark.parametrize("w,h", SIZES)
