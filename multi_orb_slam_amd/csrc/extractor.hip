@@ -2095,6 +2095,7 @@ static int g_t4_plan[3] = {128, 64, 3};
 struct orbx_extractor {
     int device = 0, n_cams = 0, max_w = 0, max_h = 0, max_levels = 0;
     hipStream_t stream = nullptr;
+    bool stream_owned = true;            // false: borrowed (orbx_adopt_stream)
     std::vector<CamTables> cams;
     std::vector<int> cur_w, cur_h;   // size of the resident image per camera (0 = none)
     FrameSink sink;                  // orbf_step: merged-frame destination of the describe kernel (x == nullptr: off)
@@ -2651,7 +2652,7 @@ void orbx_destroy(orbx_extractor* ex) {
     for (int i = 0; i < 2; ++i) if (ex->ev_done[i]) (void)hipEventDestroy(ex->ev_done[i]);
     if (ex->ev_foreign) (void)hipEventDestroy(ex->ev_foreign);
     for (int i = 0; i < 6; ++i) if (ex->ev[i]) (void)hipEventDestroy(ex->ev[i]);
-    if (ex->stream) (void)hipStreamDestroy(ex->stream);
+    if (ex->stream && ex->stream_owned) (void)hipStreamDestroy(ex->stream);
     delete ex;
 }
 
@@ -2817,6 +2818,26 @@ int orbx_finish_completed(orbx_extractor* ex) {
     MORB_ARG(ex != nullptr);
     if (ex->inflight == 0) return ORB_OK;
     return finish_device_path(ex);
+}
+
+int orbx_adopt_stream(orbx_extractor* ex, void* stream) {
+    MORB_ARG(ex && stream && ex->inflight == 0);
+    MORB_HIP(hipSetDevice(ex->device));
+    if (ex->stream) {
+        MORB_HIP(hipStreamSynchronize(ex->stream));
+        if (ex->stream_owned) (void)hipStreamDestroy(ex->stream);
+    }
+    ex->stream = static_cast<hipStream_t>(stream); ex->stream_owned = false;
+    return ORB_OK;
+}
+
+int orbx_discard(orbx_extractor* ex) {
+    MORB_ARG(ex != nullptr);
+    if (ex->inflight == 0) return ORB_OK;
+    MORB_HIP(hipSetDevice(ex->device));
+    MORB_HIP(hipEventSynchronize(ex->ev_done[(ex->run_seq - (unsigned)ex->inflight) & 1]));
+    --ex->inflight;
+    return ORB_OK;
 }
 
 int orbx_set_defer_done(orbx_extractor* ex, int on) {

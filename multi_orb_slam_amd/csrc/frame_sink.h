@@ -51,3 +51,10 @@ extern "C" int orbx_record_done(orbx_extractor* ex);
 // orbx_finish without the wait on the completion event, for a caller that has already seen the results of GPU work ordered
 // behind the oldest run in flight (orbf_step_end after it watched the resolve's result words arrive)
 extern "C" int orbx_finish_completed(orbx_extractor* ex);
+// the oldest run in flight is waited for and FORGOTTEN: no counts adopted, and a run that left the device quadtree's limits is not
+// completed on the host path (orbx_finish would run that on the extractor's stream -- which, behind a dropped step of a front end
+// with an exchange, may hold a wait for other ranks; the caller extracts those images again when their step comes)
+extern "C" int orbx_discard(orbx_extractor* ex);
+// the handle gives up its own stream and enqueues on the caller's from now on (nothing in flight; the caller keeps the stream alive
+// for as long as the handle lives): the front end's spare extractor works on the matcher's stream -- no fifth hardware queue
+extern "C" int orbx_adopt_stream(orbx_extractor* ex, void* stream);

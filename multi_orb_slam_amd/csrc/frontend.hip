@@ -28,7 +28,8 @@ struct orbf_frontend {
     int device = 0, n_cams = 0, max_w = 0, max_h = 0;
     orbx_extractor* ex = nullptr;        // == exs[0]: the extractor isolated steps run on (orbf_extractor)
     static constexpr int NEX = 3;        // extractor handles = timesteps that can be extracted side by side
-    orbx_extractor* exs[NEX] = {nullptr, nullptr, nullptr};  // consecutive overlapped timesteps go round the handles in use
+    static constexpr int SPARE = NEX, NEX_ALL = NEX + 1;   // + the spare one (see x_spare_until), made when it is first needed
+    orbx_extractor* exs[NEX_ALL] = {nullptr, nullptr, nullptr, nullptr};  // consecutive overlapped timesteps go round the handles in use
     int n_ex = 2;                        // handles in use = look-ahead depth (MORB_AHEAD_DEPTH, 1..NEX; orbf_prefetch's limit)
     std::vector<orbx_params> params;     // (instances beyond the first are created when a step first needs them: ensure_extractor)
     orbm_matcher* mt = nullptr;
@@ -90,6 +91,18 @@ struct orbf_frontend {
     int x_placement = 0;                                // 0 no exchange, 1 behind the step's search, 3 at the tail of the step's extraction chain
     long step_seq = 0, x_next = 0;                      // steps begun so far; first step whose exchange has not been issued
     long x_redos = 0;                                   // steps whose blocks were shipped a second time (orbf_debug_exchange_redos)
+    // Placement 3 puts a step's exchange -- which ENDS IN A WAIT FOR THE OTHER RANKS -- on the stream of the step's extraction chain.
+    // Nothing this rank may still owe the others may queue behind a wait for a LATER step: when steps in flight are dropped after their
+    // exchanges were issued (the extraction of an earlier step fell back to the host path), their waits stay on the chains' streams
+    // until the other ranks get that far -- and those may be waiting for this rank's re-shipment of the earlier step, whose
+    // re-extraction would sit behind exactly these waits (found with rank processes of unequal look-ahead, round 6: every rank sat out
+    // the timeout).  So from the drop up to the last step whose exchange is out (x_spare_until) every extraction of this handle runs
+    // isolated on a SPARE extractor, whose stream never carries an exchange; by then every dropped wait has been answered.
+    // The spare extractor works on the MATCHER's stream (which only ever holds the current step's exchange): a fifth stream would
+    // share a hardware queue with one of the chains, possibly behind such a wait.  (Exchange streams of their own would be the general
+    // answer: measured, forced exchange on one GPU fell from 23.7 K to 9.7-15.3 K steps/s with one to three more streams next to the
+    // three chains and the matcher, an event or a word in HBM as the dependency.)
+    long x_spare_until = -1;
     // The ISSUER (placement 3): a host thread of the handle's own that makes the exchange's calls -- the collective (RCCL's enqueue alone
     // is ~20 us of host time), the repack and top-2 launches, the event records.  The stepping thread only queues a job: with the calls
     // on its own path a step's host time exceeded its device time (forced exchange on one GPU, round 5: 56 us per step inside the
@@ -207,12 +220,13 @@ void orbf_destroy(orbf_frontend* f) {
         if (X.done) (void)hipEventDestroy(X.done);
         if (X.t_done) (void)hipEventDestroy(X.t_done);
     }
-    for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
+    for (int e = 0; e < orbf_frontend::NEX_ALL; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));
     if (f->mt) (void)hipStreamSynchronize(f->mt->stream);
     if (f->last_frame && f->last_frame_owned) orbm_frame_destroy(f->last_frame);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->pframe[k]) orbm_frame_destroy(f->pframe[k]);  // back to the matcher's pool first
+    if (f->exs[orbf_frontend::SPARE]) { orbx_destroy(f->exs[orbf_frontend::SPARE]); f->exs[orbf_frontend::SPARE] = nullptr; }   // (it works on the matcher's stream)
     if (f->mt) orbm_destroy(f->mt);
-    for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) orbx_destroy(f->exs[e]);
+    for (int e = 0; e < orbf_frontend::NEX_ALL; ++e) if (f->exs[e]) orbx_destroy(f->exs[e]);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) { f->rs[k].kps.release(); f->rs[k].desc.release(); f->rs[k].ur.release(); f->rs[k].depth.release(); f->rs[k].unx.release(); f->rs[k].uny.release(); f->rs[k].cross.release(); }
     f->h_queries.release(); f->h_match.release();
     if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
@@ -426,7 +440,7 @@ int orbf_exchange_shutdown(orbf_frontend* f) {
     MORB_HIP(hipSetDevice(f->device));
     if (f->x_broken && !f->xloop && !f->xpeer)   // (a collective that will never complete sits on a stream: abort lets it end)
         for (int k = orbf_frontend::NXC; k >= 0; --k) if (f->xc[k]) { exchange_comm_abort(f->xc[k]); f->xc[k] = nullptr; }
-    for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));   // (exchanges run on the chains' streams)
+    for (int e = 0; e < orbf_frontend::NEX_ALL; ++e) if (f->exs[e]) (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e]));   // (exchanges run on the chains' streams)
     if (f->mt) { if (f->mt->side_stream) (void)hipStreamSynchronize(f->mt->side_stream); (void)hipStreamSynchronize(f->mt->stream); }
     if (f->xpeer) { morb::peer_close(f->xpeer); f->xpeer = nullptr; }
     else for (int k = orbf_frontend::NXC; k >= 0; --k) {
@@ -541,8 +555,8 @@ static int x_wait_done(orbf_frontend* f, orbf_frontend::XSlot& X, long seq, bool
             f->x_broken = true;
             std::string who;
             for (int r = 0; r < f->xworld; ++r) if ((miss >> r) & 1) who += (who.empty() ? "" : ", ") + std::to_string(r);
-            morb::set_error("multi-GPU exchange: rank(s) %s did not deliver the block of step %ld within %ld ms (MORB_EXCHANGE_TIMEOUT_MS): dead or far behind",
-                            who.c_str(), seq, f->x_timeout_ms);
+            morb::set_error("multi-GPU exchange: rank(s) %s did not deliver the %sblock of step %ld within %ld ms (MORB_EXCHANGE_TIMEOUT_MS): dead or far behind",
+                            who.c_str(), redo ? "re-shipped " : "", seq, f->x_timeout_ms);
             return ORB_E_TIMEOUT;
         }
     }
@@ -888,6 +902,9 @@ static int ensure_extractor(orbf_frontend* f, int e) {
     if (f->exs[e]) return ORB_OK;
     int rc = orbx_create(f->params.data(), f->n_cams, f->max_w, f->max_h, f->device, &f->exs[e]);
     if (!rc) rc = orbx_set_inplace_level0(f->exs[e], 1);
+    // the spare extractor works on the matcher's stream: the one stream of the handle that never holds a wait for a later step, and
+    // no fifth hardware queue (a stream beyond four shares a queue with one of the chains -- possibly behind such a wait)
+    if (!rc && e == orbf_frontend::SPARE) rc = orbx_adopt_stream(f->exs[e], f->mt->stream);
     return rc;
 }
 
@@ -895,16 +912,17 @@ static int ensure_extractor(orbf_frontend* f, int e) {
 static int orbf_drain(orbf_frontend* f) {
     MORB_HIP(hipSetDevice(f->device));
     if (f->xcomm) { const int xr = x_wait_stream(f, nullptr); if (xr) return xr; }
+    if (f->xcomm && f->x_placement == 3 && !f->inflight.empty()) f->x_spare_until = std::max(f->x_spare_until, f->x_next - 1);
     if (f->xcomm && f->x_placement == 3) {
         // the chains' streams may end in collectives that wait for peers which have not announced that far (and may themselves be
         // waiting for THIS rank, e.g. for a block shipped again): wait for the extractions, not for the exchanges behind them
         for (const auto& I : f->inflight) MORB_HIP(hipEventSynchronize(f->ev_ready[I.set]));
     } else
-    for (int e = 0; e < orbf_frontend::NEX; ++e) if (f->exs[e]) MORB_HIP(hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e])));
+    for (int e = 0; e < orbf_frontend::NEX_ALL; ++e) if (f->exs[e]) MORB_HIP(hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[e])));
     MORB_HIP(hipStreamSynchronize(f->mt->stream));
     if (f->mt->side_stream) MORB_HIP(hipStreamSynchronize(f->mt->side_stream));
-    for (int e = 0; e < orbf_frontend::NEX; ++e)
-        while (f->exs[e] && orbx_pending(f->exs[e]) > 0) { int rc = orbx_finish(f->exs[e]); if (rc < 0) return rc; }
+    for (int e = 0; e < orbf_frontend::NEX_ALL; ++e)
+        while (f->exs[e] && orbx_pending(f->exs[e]) > 0) { int rc = orbx_discard(f->exs[e]); if (rc < 0) return rc; }   // (dropped: nothing is completed)
     f->inflight.clear();
     return ORB_OK;
 }
@@ -912,10 +930,11 @@ static int orbf_drain(orbf_frontend* f) {
 // The next free result set / extractor for a timestep that is about to be extracted.  Sets go round robin.  Isolated steps
 // (nothing in flight) always run on extractor 0; overlapped ones alternate, so that two extraction chains are on the GPU
 // at a time and each extractor keeps seeing the same two (count slot, result set) pairs -- its captured launch chains stay valid.
-static void next_slot(orbf_frontend* f, int* e, int* set) {
+static void next_slot(orbf_frontend* f, int* e, int* set, long seq) {
     *set = (f->last_set + 1) % orbf_frontend::NSETS;
     if (*set == f->cur) *set = (*set + 1) % orbf_frontend::NSETS;  // (the caller still reads the last step's results)
     *e = (f->inflight.empty() || f->n_ex < 2) ? 0 : (f->last_e + 1) % f->n_ex;
+    if (f->xcomm && seq <= f->x_spare_until) *e = orbf_frontend::SPARE;   // (nothing is in flight then: see the look-ahead loop)
     f->last_set = *set; f->last_e = *e;
 }
 
@@ -969,7 +988,7 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
             f->announced.clear();
         }
         if (!f->announced.empty() && same_images(f->announced.front(), images, f->n_cams)) f->announced.pop_front();
-        next_slot(f, &P.e, &P.set);
+        next_slot(f, &P.e, &P.set, P.seq);
         if ((rc = ensure_extractor(f, P.e))) return rc;
         // Nothing ran ahead for this step (a live rig: the images have only just arrived).  Its matching then goes onto the
         // extractor's own stream, right behind the extraction chain -- a kernel boundary instead of a cross-stream event
@@ -1162,6 +1181,7 @@ static int step_enqueue(orbf_frontend* f, orbf_frontend::Pending& P, bool first_
     // are in flight; consecutive ones alternate between the two extractors (an extractor takes its next timestep as
     // a second run behind the one whose results are being matched here).
     while (P.async_path && first_attempt && f->overlap_ok && !f->announced.empty() && (int)f->inflight.size() < std::max(f->n_ex, 2)) {
+        if (f->xcomm && P.seq + 1 + (long)f->inflight.size() <= f->x_spare_until) break;   // (dropped exchanges are still out: isolated steps on the spare extractor)
         const int prev_e = f->inflight.empty() ? P.e : f->inflight.back().e;
         const int e2 = f->n_ex > 1 ? (prev_e + 1) % f->n_ex : 0;
         if ((rc = ensure_extractor(f, e2))) { (void)hipStreamSynchronize(st); return rc; }
@@ -1268,6 +1288,11 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
                     f->announced.clear();
                     f->overlap_ok = false;
                     int w2, h2, a2;
+                    if (f->xcomm && P.seq <= f->x_spare_until) {   // (the chains' streams may hold waits for the dropped steps)
+                        P.e = orbf_frontend::SPARE;
+                        if ((rc = ensure_extractor(f, P.e))) return rc;
+                        ex = f->exs[P.e];
+                    }
                     if ((rc = enqueue_extract(f, P.e, P.images.data(), P.set, &w2, &h2, &a2, false))) return rc;
                     if (a2) { rc = orbx_finish(ex); if (rc < 0) return rc; }
                 }
@@ -1342,6 +1367,12 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
                             "their capacities, or a block is corrupt)", X.gcnt.p[gc + 1]);
             return ORB_E_ARG;
         }
+    }
+    if (f->exs[orbf_frontend::SPARE] && P.e != orbf_frontend::SPARE && P.seq > f->x_spare_until && orbx_pending(f->exs[orbf_frontend::SPARE]) == 0) {
+        // the spare extractor has done its part: its buffers are given back
+        (void)hipStreamSynchronize((hipStream_t)orbx_stream(f->exs[orbf_frontend::SPARE]));
+        orbx_destroy(f->exs[orbf_frontend::SPARE]);
+        f->exs[orbf_frontend::SPARE] = nullptr;
     }
     out->host_us[3] = us_between(t_synced, std::chrono::steady_clock::now());
     return ORB_OK;

@@ -23,6 +23,9 @@ def main():
     opts = dict(a.split("=", 1) for a in sys.argv[11:])
     die_t, die_rank = (int(x) for x in opts["die_at"].split(":")) if "die_at" in opts else (-1, -1)
     photo = opts.get("photo", "china")
+    if "aheads" in opts:            # look-ahead per rank (ranks that run ahead by different amounts ship their blocks at different moments)
+        ahead = [int(x) for x in opts["aheads"].split(",")][rank]
+    noise_t, noise_cam = (int(x) for x in opts["noise_at"].split(":")) if "noise_at" in opts else (-1, -1)
     import datetime
     import numpy as np
     import torch.distributed as dist
@@ -41,6 +44,10 @@ def main():
     assert fe.fe.exchange_world == world and fe.fe.exchange_placement == 3
     ofe = OracleFrontEnd(params, W, H, mine)
     frames = [natural.rig(photo, t, W, H, n_cams=rig_cams) for t in range(steps)]
+    if noise_t >= 0:                # one camera sees noise in one step: more candidates than the device quadtree takes (MORB_OCT_MAX_KEYS lowered by
+        from multi_orb_slam_amd import synth   # the test) -> that rank's step is redone on the host path and EVERY rank ships its block a second time
+        r_ = synth.hash32(np.arange(W * H, dtype=np.uint64) + np.uint64(1000 * noise_t + 17 * noise_cam))
+        frames[noise_t][noise_cam] = (r_ % 256).astype(np.uint8).reshape(H, W)
     announced = 0
     t_step = []
     for t in range(steps):
@@ -60,6 +67,8 @@ def main():
                 os._exit(3)                  # the expected outcome of a die_at run (no collective shutdown with a dead peer)
             os._exit(4)
         t_step.append(time.time() - t0)
+        if "verbose" in opts:
+            print("rank %d step %d done in %.3f s, redos so far %d" % (rank, t, t_step[-1], fe.fe.debug_exchange_redos()), flush=True)
         # the checker: the other cameras' descriptors from the oracle's own extraction
         others = {g: oracle.extract(frames[t][g], nfeatures=nf)[1] for g in range(rig_cams) if g not in mine}
         exp = ofe.step([frames[t][g] for g in mine],
@@ -68,7 +77,7 @@ def main():
         assert_same_step(got, exp)
         assert got["rig_counts"] == [len(others[g]) if g in others else len(exp_own[g]) for g in range(rig_cams)]
     verdicts = [None] * world
-    dist.all_gather_object(verdicts, (rank, got["counts"], got["n_temporal"], got["n_cross"]))
+    dist.all_gather_object(verdicts, (rank, got["counts"], got["n_temporal"], got["n_cross"], fe.fe.debug_exchange_redos()))
     fe.fe.exchange_shutdown()
     fe.close()
     if rank == 0:

@@ -68,3 +68,26 @@ def test_bench_runs_two_rank_processes_on_this_one_gpu():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_ranks"] == 2 and line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "strong"
     assert "bit-exact vs oracle" in line["parity"] and "peer transport" in line["exchange"]
+
+
+@pytest.mark.timeout(300, method="thread")
+@pytest.mark.parametrize("max_keys, expected_redos", [(16384, 1), (4096, 7)], ids=["one_step_falls_back", "every_step_falls_back"])
+def test_reshipped_blocks_and_unequal_look_ahead_between_rank_processes(max_keys, expected_redos):
+    """ADVICE r05's scenario between PROCESSES: three ranks with DIFFERENT look-ahead (0, 1 and 3 steps); extractions fall back to the
+    host path AFTER their blocks went out (more level-0 candidates than the device quadtree takes: the limit is lowered here), the
+    blocks carry the mark, and every rank ships its final block a second time (the peer transport's second region).
+    one_step_falls_back: camera 1 sees noise in step 2 (27 703 candidates > 16 384).  every_step_falls_back: the photograph itself
+    (10 049 candidates at 640x480) is over a limit of 4096 on every rank in every step.
+    This is the test that found the round-6 ordering bug: a step's exchange ends in a wait for the other ranks and stands on the
+    stream of the step's extraction chain; the rank that ran ahead dropped its steps in flight and then had the waits for steps 1..3
+    IN FRONT of the re-extraction of step 0, whose re-shipment the rank without look-ahead was waiting for -- every rank sat out the
+    timeout.  Dropped runs are now forgotten instead of completed (orbx_discard) and, until the dropped exchanges have been answered,
+    the handle extracts on a spare extractor that works on the matcher's stream (frontend.hip: x_spare_until).
+    Every step of every rank is held against the oracle; every rank counts the same re-shipments."""
+    rcs, outs, _dt = _spawn(3, 3, 640, 480, 500, steps=7, ahead=0, extra=("aheads=0,1,3", "noise_at=2:1"),
+                            env_extra={"MORB_OCT_MAX_KEYS": str(max_keys), "MORB_EXCHANGE_TIMEOUT_MS": "10000"})
+    assert rcs == [0, 0, 0], "\n".join(o[-1500:] for o in outs)
+    assert "bit-exact vs the oracle" in outs[0]
+    import re
+    redos = [int(x) for x in re.findall(r"\(\d+, \[[^\]]*\], \d+, \d+, (\d+)\)", outs[0])]
+    assert redos == [expected_redos] * 3, outs[0][-800:]
