@@ -2,6 +2,7 @@
 """One RANK PROCESS of the multi-process rehearsal of the N > 1 job.  TEST INFRASTRUCTURE.
 
     python tests/mp_rank.py <world> <rank> <port> <rig_cams> <W> <H> <nf> <steps> <ahead> <device> [die_at=<t>:<rank>] [photo=<name>]
+                            [aheads=a0,a1,..] [noise_at=<t>:<cam>] [slow=<rank>:<ms>] [verbose=1]
 
 Every rank is a fresh process (started by tests/test_gpu_multiprocess.py or by hand) that owns rig_cams / world cameras of ONE rig of
 overlapping cameras sliding over a photograph (tests/natural.py), joins a gloo group on 127.0.0.1 -- the control plane: it carries the
@@ -26,6 +27,7 @@ def main():
     if "aheads" in opts:            # look-ahead per rank (ranks that run ahead by different amounts ship their blocks at different moments)
         ahead = [int(x) for x in opts["aheads"].split(",")][rank]
     noise_t, noise_cam = (int(x) for x in opts["noise_at"].split(":")) if "noise_at" in opts else (-1, -1)
+    slow_rank, slow_ms = (int(x) for x in opts["slow"].split(":")) if "slow" in opts else (-1, 0)   # that rank sleeps before every step
     import datetime
     import numpy as np
     import torch.distributed as dist
@@ -57,6 +59,8 @@ def main():
             announced += 1
             fe.announce([frames[announced][g] for g in mine])
         announced = max(announced, t)
+        if rank == slow_rank:
+            time.sleep(slow_ms / 1000.0)
         t0 = time.time()
         try:
             got = fe.step([frames[t][g] for g in mine])

@@ -91,3 +91,14 @@ def test_reshipped_blocks_and_unequal_look_ahead_between_rank_processes(max_keys
     import re
     redos = [int(x) for x in re.findall(r"\(\d+, \[[^\]]*\], \d+, \d+, (\d+)\)", outs[0])]
     assert redos == [expected_redos] * 3, outs[0][-800:]
+
+
+@pytest.mark.timeout(300, method="thread")
+def test_a_slow_rank_never_sees_a_block_overwritten():
+    """Three ranks three steps ahead, rank 1 sleeps 40 ms before every step: the fast ranks run into their look-ahead limit, ship the
+    blocks of up to three future steps into rank 1's arena while it is still busy with an old one, and wait; the eight slots per rank
+    must keep every block intact until its step (why eight suffice).  16 steps = two trips round the slots, every
+    step of every rank against the oracle."""
+    rcs, outs, _dt = _spawn(3, 3, 320, 240, 300, steps=16, ahead=3, extra=("slow=1:40",))
+    assert rcs == [0, 0, 0], "\n".join(o[-1500:] for o in outs)
+    assert "bit-exact vs the oracle" in outs[0]
