@@ -144,6 +144,12 @@ struct orbf_frontend {
     } pending;
     hipEvent_t ev_extracted = nullptr;  // extractor stream -> matcher stream on the synchronous path
     hipEvent_t ev_ready[NSETS] = {};  // extraction + frame grid of the step using that set
+    // Larger rigs: the camera-pair top-2 FOLLOWS that event on the extractor's stream (ev_cross behind it): an isolated step's search
+    // -- which needs the frame, not the top-2 -- then runs NEXT TO the top-2 instead of behind it (8 x 1080p: 129 us of top-2 in front
+    // of 60 + 100 us of projection + resolve; the resolve is eight workgroups).  The end of the step waits for ev_cross.  Small rigs keep
+    // the top-2 inside the captured chain (or in the projection's launch: SideJob).
+    hipEvent_t ev_cross[NSETS] = {};
+    bool cross_pending[NSETS] = {};
     // frame of the last completed step (orbf_export_block); a frame built on the synchronous path is kept until the next step
     orbm_frame* last_frame = nullptr; bool last_frame_owned = false;
     // previous step (for orbf_step_motion)
@@ -185,7 +191,8 @@ int orbf_create_depth(const orbx_params* params, int n_cams, int max_width, int 
     const size_t cap = (size_t)f->cap_total;
     if (hipEventCreateWithFlags(&f->ev_extracted, hipEventDisableTiming) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
     for (int k = 0; k < orbf_frontend::NSETS; ++k)
-        if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
+        if (hipEventCreateWithFlags(&f->ev_ready[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess ||
+            hipEventCreateWithFlags(&f->ev_cross[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { morb::set_error("hipEventCreate failed"); orbf_destroy(f); return ORB_E_HIP; }
     // Every stream is a hardware queue and the command processor serves four side by side.  The streams
     // that work next to each other are created HERE, together and first -- extractor 0, the matcher's, the overlap partners --
     // because which queues end up sharing a pipe follows the order of creation (measured: the same four streams created
@@ -231,6 +238,7 @@ void orbf_destroy(orbf_frontend* f) {
     f->h_queries.release(); f->h_match.release();
     if (f->ev_extracted) (void)hipEventDestroy(f->ev_extracted);
     for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->ev_ready[k]) (void)hipEventDestroy(f->ev_ready[k]);
+    for (int k = 0; k < orbf_frontend::NSETS; ++k) if (f->ev_cross[k]) (void)hipEventDestroy(f->ev_cross[k]);
     delete f;
 }
 
@@ -856,6 +864,7 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     // assembly stages a parameter block with a copy, which a replayed chain should not carry).
     struct Tail {
         orbf_frontend* f; orbx_extractor* ex; orbm_cam_features* cams; const float* bd; int set; bool small, with_cross;
+        int phases = 3;   // 1 the frame, 2 the camera-pair top-2 (larger rigs issue them apart, with the chain's event in between)
         static int run(void* u, void* stream) {
             Tail& T = *static_cast<Tail*>(u);
             orbm_matcher* m = T.f->mt;
@@ -863,9 +872,11 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
             orbm_frame* frp = T.f->pframe[T.set];
             hipStream_t keep = m->stream;
             m->stream = (hipStream_t)stream;
-            int rc = frame_from_device_impl(m, T.cams, T.f->n_cams, T.f->mbf, T.bd[0], T.bd[1], T.bd[2], T.bd[3], orbx_device_counts(T.ex),
+            int rc = ORB_OK;
+            if (T.phases & 1)
+                rc = frame_from_device_impl(m, T.cams, T.f->n_cams, T.f->mbf, T.bd[0], T.bd[1], T.bd[2], T.bd[3], orbx_device_counts(T.ex),
                                             &frp, T.small);
-            if (!rc && T.with_cross && T.f->n_cams > 1) {
+            if (!rc && (T.phases & 2) && T.with_cross && T.f->n_cams > 1) {
                 const int ncap = frp->n_total;
                 rc = cross_enqueue_to(m->stream, frp->b->d_desc.p, ncap, frp->b->d_cam_start.p, T.f->n_cams, 0, ncap, frp->b->d_ntotal.p,
                                       R.cross.i.dp, R.cross.b.dp, R.cross.s.dp, R.cross.scratch.p);
@@ -883,12 +894,20 @@ static int enqueue_extract(orbf_frontend* f, int e, const orbf_image* images, in
     if (small) { (void)orbx_set_frame_sink(ex, nullptr); (void)orbx_set_chain_tail(ex, nullptr, nullptr, 0); }
     if (rc) return rc;
     *went_async = orbx_pending(ex) > before ? 1 : 0;
+    f->cross_pending[set] = false;
     if (*went_async) {
-        if (!small && (rc = Tail::run(&tail, orbx_stream(ex)))) return rc;
+        const bool split = !small && cross_here && !defer_events;   // (the top-2 behind the chain's event: see ev_cross)
+        if (!small) { tail.phases = split ? 1 : 3; if ((rc = Tail::run(&tail, orbx_stream(ex)))) return rc; }
         R.cross_valid = cross_here;
         if (!defer_events) {   // (an inline step records its events behind its matching: step_enqueue)
             hipError_t he = hipEventRecord(f->ev_ready[set], (hipStream_t)orbx_stream(ex));
             if (he != hipSuccess) { morb::set_error("hipEventRecord: %s", hipGetErrorString(he)); return ORB_E_HIP; }
+        }
+        if (split) {
+            tail.phases = 2;
+            if ((rc = Tail::run(&tail, orbx_stream(ex)))) return rc;
+            MORB_HIP(hipEventRecord(f->ev_cross[set], (hipStream_t)orbx_stream(ex)));
+            f->cross_pending[set] = true;
         }
         // the step's exchange: behind everything its matching waits for, on this chain's stream (the block is this set's frame).  A
         // block whose quadtree left the device limits says so in its trailer and is shipped again at the end of its step.
@@ -1331,6 +1350,10 @@ static int orbf_step_end_impl(orbf_frontend* f, orbf_result* out) {
     out->un_x = R.unx.p; out->un_y = R.uny.p;
     out->nmatches = nmatches; out->match_of_feature = f->h_match.p;
     const bool from_set = P.cross_from_set && P.async_path;  // (a step redone on the synchronous path matched in its own launch)
+    if (f->cross_pending[P.set]) {   // (larger rigs: the camera-pair top-2 ran next to this step's search, behind an event of its own)
+        if (from_set && do_cross) MORB_HIP(hipEventSynchronize(f->ev_cross[P.set]));
+        f->cross_pending[P.set] = false;
+    }
     out->cross_best_idx = do_cross ? (from_set ? R.cross.i.p : m->h_c0.p) : nullptr;
     out->cross_best_dist = do_cross ? (from_set ? R.cross.b.p : m->h_c1.p) : nullptr;
     out->cross_second_dist = do_cross ? (from_set ? R.cross.s.p : m->h_c2.p) : nullptr;
