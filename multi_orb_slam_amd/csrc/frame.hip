@@ -270,6 +270,45 @@ __global__ __launch_bounds__(256) void k_frame_head(CamFeat32 H, CamFeat* __rest
     range[0] = base; range[1] = 0; range[2] = base;
 }
 
+// Round 6: k_frame_head's launch gone too.  Every workgroup of the fill derives the camera table (count, base) from the extractor's
+// counts for itself -- one count per lane of its first wave, a wave scan --, workgroup 0 also writes what later kernels and the host
+// read (table, camera starts, the {features, first query, queries} triple, the block's count trailer), and nobody counts cells in
+// HBM any more: k_grid_cam counts its camera's cells in LDS from the cell indices this kernel leaves (no counters to clear, no
+// global atomics).  One launch of the large-rig chain less (12 us of a 552 us isolated 8 x 1080p step, and of every overlapped step).
+__global__ __launch_bounds__(256) void k_frame_fill_head(CamFeat32 H, CamFeat* __restrict__ cams_out, int n_cams, const int* __restrict__ d_counts,
+                                                         int* __restrict__ cam_start, int* __restrict__ range, int* __restrict__ trailer,
+                                                         float mbf, float minX, float minY, float invW, float invH,
+                                                         float* __restrict__ x, float* __restrict__ y, float* __restrict__ ur,
+                                                         float* __restrict__ depth_out, int* __restrict__ oct,
+                                                         float* __restrict__ ang, orb_keypoint* __restrict__ kps_g,
+                                                         uint4* __restrict__ desc_g, int* __restrict__ cell_of, HostMirror hm) {
+    MORB_LATENCY_KERNEL_WIDE();
+    __shared__ CamFeat s_cams[32];
+    __shared__ int s_total;
+    if (threadIdx.x < 64) {   // (a whole wave: the scan needs every lane)
+        const int c = threadIdx.x;
+        const int n = c < n_cams ? d_counts[c] : 0;
+        const int incl = wave_incl_scan(n);
+        if (c < n_cams) {
+            CamFeat e = H.c[c];
+            e.n = n; e.base = incl - n;
+            s_cams[c] = e;
+            if (blockIdx.x == 0) {
+                cams_out[c] = e; cam_start[c] = incl - n;
+                trailer[c] = (c == 0 && d_counts[n_cams] != 0) ? (n | ORBM_BLOCK_REDO) : n;
+            }
+        }
+        if (c == 63) {
+            s_total = incl;
+            if (blockIdx.x == 0) { cam_start[n_cams] = incl; range[0] = incl; range[1] = 0; range[2] = incl; }
+        }
+    }
+    __syncthreads();
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= s_total) return;
+    cell_of[g] = frame_fill_one(s_cams, n_cams, g, mbf, minX, minY, invW, invH, x, y, ur, depth_out, oct, ang, kps_g, desc_g, hm);
+}
+
 // exclusive scan of cnt[0..n) into start[0..n], single 1024-thread block; cursor = copy of start
 __global__ __launch_bounds__(1024) void k_scan_cells(const int* cnt, int n, int* __restrict__ start, int* cursor) {
     MORB_LATENCY_KERNEL();
@@ -338,14 +377,28 @@ __global__ __launch_bounds__(1024) void k_grid_cam(const int* __restrict__ cell_
     __shared__ int s_w[16], s_before;
     const int cam = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = cam_start[cam], nf = cam_start[cam + 1] - f0;
-    // in-grid features of the cameras in front of this one: the sum of their cells' counts (coalesced, all loads independent)
-    int before = 0;
-    for (int i = tid; i < cam * GRID_CELLS; i += 1024) before += cell_cnt[i];
-    // this camera's counts: three consecutive cells per thread
-    const int* cnt = cell_cnt + cam * GRID_CELLS;
     const int c3 = 3 * tid;
-    const int k0 = cnt[c3], k1 = cnt[c3 + 1], k2 = cnt[c3 + 2];   // (3 x 1024 = GRID_CELLS)
     static_assert(GRID_CELLS == 3 * 1024, "three cells per thread");
+    int before = 0, k0, k1, k2;
+    if (cell_cnt) {
+        // in-grid features of the cameras in front of this one: the sum of their cells' counts (coalesced, all loads independent)
+        for (int i = tid; i < cam * GRID_CELLS; i += 1024) before += cell_cnt[i];
+        // this camera's counts: three consecutive cells per thread
+        const int* cnt = cell_cnt + cam * GRID_CELLS;
+        k0 = cnt[c3]; k1 = cnt[c3 + 1]; k2 = cnt[c3 + 2];   // (3 x 1024 = GRID_CELLS)
+    } else {
+        // no counts in HBM (k_frame_fill_head): the features in front of this camera that lie inside their grids are counted from
+        // their cell indices, this camera's cells in LDS
+        for (int i = tid; i < f0; i += 1024) before += cell_of[i] >= 0 ? 1 : 0;
+        s_fill[c3] = 0; s_fill[c3 + 1] = 0; s_fill[c3 + 2] = 0;
+        __syncthreads();
+        for (int i = tid; i < nf; i += 1024) {
+            const int cell = cell_of[f0 + i];
+            if (cell >= 0) atomicAdd(&s_fill[cell - cam * GRID_CELLS], 1);
+        }
+        __syncthreads();
+        k0 = s_fill[c3]; k1 = s_fill[c3 + 1]; k2 = s_fill[c3 + 2];
+    }
     {
         int b = before;
 #pragma unroll
@@ -758,6 +811,23 @@ int morb::frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams,
                            F->b->d_items.p, hm, sink_filled ? (const int*)F->b->d_cell_of.p : nullptr, F->desc_rows, StagedFill{});
     } else {
         const int* n_dev = nullptr;
+        bool grid_cam = true;   // (every camera's features fit k_grid_cam's LDS list: capacities are upper bounds of the counts)
+        for (int c = 0; c < n_cams; ++c) grid_cam = grid_cam && cams[c].n <= GRID_CAM_MAX;
+        if (one_head && grid_cam && n) {
+            // table + fill in one launch, cells counted by k_grid_cam itself (k_frame_fill_head)
+            CamFeat32 H;
+            memset(&H, 0, sizeof(H));
+            for (int c = 0; c < n_cams; ++c) H.c[c] = hc[c];
+            hipLaunchKernelGGL(k_frame_fill_head, dim3((n + 255) / 256), dim3(256), 0, st, H, F->b->d_cams.p, n_cams, d_counts,
+                               F->b->d_cam_start.p, F->b->d_ntotal.p, reinterpret_cast<int*>(F->b->d_desc.p + (size_t)F->desc_rows * 32),
+                               mbf, F->minX, F->minY, F->invW, F->invH, F->b->d_x.p, F->b->d_y.p, F->b->d_ur.p, F->b->d_depth.p,
+                               F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_of.p, hm);
+            hipLaunchKernelGGL(k_grid_cam, dim3(n_cams), dim3(1024), 0, st, (const int*)nullptr, (const int*)F->b->d_cell_of.p,
+                               (const int*)F->b->d_cam_start.p, n_cams, F->b->d_cell_start.p, F->b->d_items.p);
+            MORB_HIP(hipGetLastError());
+            *out = F;
+            return ORB_OK;
+        }
         if (one_head) {
             CamFeat32 H;
             memset(&H, 0, sizeof(H));
@@ -784,8 +854,6 @@ int morb::frame_from_device_impl(orbm_matcher* m, const orbm_cam_features* cams,
                                F->b->d_oct.p, F->b->d_ang.p, F->b->d_kps.p, (uint4*)F->b->d_desc.p, F->b->d_cell_of.p,
                                F->b->d_cursor.p, hm, n_dev);
         }
-        bool grid_cam = true;   // (every camera's features fit the kernel's LDS list: capacities are upper bounds of the counts)
-        for (int c = 0; c < n_cams; ++c) grid_cam = grid_cam && cams[c].n <= GRID_CAM_MAX;
         if (grid_cam) {
             hipLaunchKernelGGL(k_grid_cam, dim3(n_cams), dim3(1024), 0, st, (const int*)F->b->d_cursor.p, (const int*)F->b->d_cell_of.p,
                                (const int*)F->b->d_cam_start.p, n_cams, F->b->d_cell_start.p, F->b->d_items.p);
