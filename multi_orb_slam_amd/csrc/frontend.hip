@@ -1061,7 +1061,10 @@ static int orbf_step_begin_impl(orbf_frontend* f, const orbf_image* images, cons
     P.J.q_dev = nq && !P.use_ms ? reinterpret_cast<const orbm_query*>(f->h_queries.dp) : nullptr;   // no H2D on the step's critical chain
     P.J.msrc = P.use_ms ? &P.ms : nullptr;
     if (P.use_ms && (int)prev_frame->cam_start.size() == f->n_cams + 1)   // (query i = feature i of the previous frame: its camera capacities bound the counts)
+    {
         for (int c = 0; c < f->n_cams; ++c) P.J.q_cam_max = std::max(P.J.q_cam_max, prev_frame->cam_start[c + 1] - prev_frame->cam_start[c]);
+        P.J.q_cam_start = prev_frame->cam_start.data();   // (camera c's queries are its features of the previous frame: contiguous)
+    }
     P.J.want_tags = f->poll_ok;
     if ((rc = f->h_match.reserve(std::max(f->cap_total, 1)))) return rc;
     P.async_path = went_async != 0;

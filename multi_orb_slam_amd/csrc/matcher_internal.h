@@ -157,6 +157,7 @@ struct SearchJob {
     bool multi = false;                 // the resolve in flight is the multi-workgroup form (one launch per sweep)
     const MotionSrc* msrc = nullptr;    // queries built by the projection kernel itself (then `q` is only read by the host fallbacks)
     int q_cam_max = 0;                  // upper bound of the queries any one camera has (0 = not known; counted from `q` when that is final)
+    const int* q_cam_start = nullptr;   // host, n_cams + 1 entries: the queries are camera-contiguous, camera c's are [q_cam_start[c], q_cam_start[c + 1])
     void (*q_fill)(void*) = nullptr; void* q_fill_ctx = nullptr;   // ... which call this first when `q` has not been written yet
 };
 

@@ -1112,13 +1112,17 @@ __global__ __launch_bounds__(256) void k_rs_write(int NT_host, const int* __rest
 // (matches), state[5] = 1 and state[8] = "did not finish" (tables or queries beyond this launch's limits, or out of rounds:
 // the exact host fallback takes over, search_finish), state[48..78) the histogram.
 constexpr int RSC_RQ = 4;
+// n != 0: the queries are camera-contiguous (queries built from the previous frame's features; host lists in camera order) and camera
+// c's are [start[c], start[c + 1]) -- the workgroup then neither scans the query words for its camera nor gathers indices (8 x 4000
+// queries: 11 + 5 us of the kernel's 100)
+struct QRanges { int n; int start[65]; };
 __global__ __launch_bounds__(1024) void k_resolve_cams(FrameDev F, const int* __restrict__ f_cam_start, const int2* __restrict__ qmeta, int nq,
                                                        int cap, int nf_cap, const int* __restrict__ cand_idx,
                                                        const uint16_t* __restrict__ cand_dist, const int* __restrict__ cand_count,
                                                        const uint8_t* __restrict__ occupied, const float* __restrict__ f_angle, int th_high,
                                                        int check_ori, int max_it, const int* __restrict__ topk, int* __restrict__ state,
                                                        int* __restrict__ match_of_feature, int* __restrict__ status, int tagb, int n_res,
-                                                       MergeJob MJ) {
+                                                       MergeJob MJ, QRanges QR) {
     MORB_LATENCY_KERNEL();
     if ((int)blockIdx.x >= n_res) {   // workgroups behind the cameras' (isolated steps): the slice merge of the camera-pair top-2, as in k_resolve_mono
         const int mq = MJ.d_range ? MJ.d_range[2] : MJ.nq;
@@ -1153,6 +1157,11 @@ __global__ __launch_bounds__(1024) void k_resolve_cams(FrameDev F, const int* __
     // lane keeps "my entry of group u is this camera's" as bit u of a 64-bit word, so the second pass -- the ordered store of the
     // indices once the waves' totals are known -- needs no memory.
     // Queries that name no camera of the frame have no candidates (project_dev.h): -1 from workgroup 0.
+    const int q_first = QR.n ? QR.start[cam] : -1;
+    if (QR.n) {
+        if (tid == 0) s_cnt = QR.start[cam + 1] - q_first;
+        __syncthreads();
+    } else {
     const int per_wave = (((nq + 15) / 16) + 63) & ~63, w0 = min(nq, wave * per_wave), w1 = min(nq, w0 + per_wave);
     unsigned long long mybits = 0;
     int mine = 0;
@@ -1185,6 +1194,7 @@ __global__ __launch_bounds__(1024) void k_resolve_cams(FrameDev F, const int* __
         off += __popcll(mask);
     }
     __syncthreads();
+    }
     MORB_PHASE(g_ph_res, 3);
     const int nqc = s_cnt;
     int sl[RQ][K], cur[RQ], pos[RQ], flr[RQ], qi[RQ], bin_of[RQ];
@@ -1200,7 +1210,7 @@ __global__ __launch_bounds__(1024) void k_resolve_cams(FrameDev F, const int* __
         for (int k = 0; k < K; ++k) sl[b][k] = 0xffff;
         if (j < nqc) {
             // set-up of one query, round 0 riding along as in k_resolve_mono: the head of the shortlist is taken and claimed
-            const int i = l_q[j];
+            const int i = q_first >= 0 ? q_first + j : (int)l_q[j];
             qi[b] = i;
             const int cnt_i = cand_count[i];
             mx = max(mx, cnt_i);
@@ -1695,15 +1705,26 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
     static const int cam_env = [] { const char* e = getenv("MORB_RS_PER_CAMERA"); return e ? atoi(e) : 1; }();
     const int cams_min_q = cam_env > 1 ? cam_env : 0x7fffffff;
     int nf_cap = 0, q_cam_max = J.q_cam_max;
+    QRanges QR; QR.n = 0;
     const bool starts_ok = cur->camera_major && (int)cur->cam_start.size() == cur->n_cams + 1 && cur->cam_start[cur->n_cams] == n;
     const bool cams_want = cam_env && !J.points && !J.win2_dev && starts_ok && (multi || (cur->n_cams >= 2 && nq >= cams_min_q));
     if (cams_want) {
         for (int c = 0; c < cur->n_cams; ++c) nf_cap = std::max(nf_cap, cur->cam_start[c + 1] - cur->cam_start[c]);
-        if (!q_cam_max && !J.msrc && J.q) {   // (host records: count them)
+        if (!q_cam_max && !J.msrc && J.q) {   // (host records: count them -- and see whether they come camera after camera)
             std::vector<int>& per = m->rs_cam_count;
             per.assign((size_t)cur->n_cams, 0);
-            for (int i = 0; i < nq; ++i) { const int c = J.q[i].cam; if (c >= 0 && c < cur->n_cams) q_cam_max = std::max(q_cam_max, ++per[c]); }
+            bool sorted = cur->n_cams <= 64;
+            int last = 0;
+            for (int i = 0; i < nq; ++i) {
+                const int c = J.q[i].cam;
+                if (c >= 0 && c < cur->n_cams) q_cam_max = std::max(q_cam_max, ++per[c]);
+                if (c < last || c >= cur->n_cams) sorted = false; else last = c;
+            }
             if (!q_cam_max) q_cam_max = 1;
+            if (sorted) { QR.n = cur->n_cams; int b = 0; for (int c = 0; c < cur->n_cams; ++c) { QR.start[c] = b; b += per[c]; } QR.start[cur->n_cams] = b; }
+        } else if (J.q_cam_start && cur->n_cams <= 64 && J.q_cam_start[cur->n_cams] == nq) {
+            QR.n = cur->n_cams;
+            for (int c = 0; c <= cur->n_cams; ++c) QR.start[c] = J.q_cam_start[c];
         }
     }
     const size_t lds_cam = (size_t)8 * nf_cap + (size_t)2 * RSC_RQ * 1024;
@@ -1717,7 +1738,7 @@ int morb::search_enqueue(orbm_matcher* m, SearchJob& J, bool queries_already_on_
         hipLaunchKernelGGL(k_resolve_cams, dim3(cur->n_cams + merge_blocks), dim3(1024), lds_cam, m->stream, cur->dev(), (const int*)cur->b->d_cam_start.p,
                            (const int2*)m->d_qmeta.p, nq, cap, nf_cap, (const int*)m->d_i0.p, (const uint16_t*)m->d_u16.p,
                            (const int*)m->d_i1.p, d_occ, (const float*)cur->b->d_ang.p, th_high, J.check_ori, 4096,
-                           (const int*)m->d_claim.p, m->d_rsync.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20, cur->n_cams, MJc);
+                           (const int*)m->d_claim.p, m->d_rsync.p, m->h_match.dp + 4, m->h_match.dp, J.seq << 20, cur->n_cams, MJc, QR);
         MORB_HIP(hipGetLastError());
         return ORB_OK;
     };

@@ -8,7 +8,10 @@ import multi_orb_slam_amd as m
 from multi_orb_slam_amd import synth, pipeline, _lib
 lib = _lib.lib()
 out = (C.c_uint64 * 64)()
-for name, (W, H, NF, NC) in {"configs[2]": (1280, 720, 2000, 2), "configs[3]": (640, 480, 1000, 4), "configs[1]": (640, 480, 1000, 2)}.items():
+CFGS = {"configs[2]": (1280, 720, 2000, 2), "configs[3]": (640, 480, 1000, 4), "configs[1]": (640, 480, 1000, 2), "configs[4]": (1920, 1080, 4000, 8)}
+if len(sys.argv) > 1:
+    CFGS = {k: v for k, v in CFGS.items() if k in sys.argv[1:]}
+for name, (W, H, NF, NC) in CFGS.items():
     fe = pipeline.FrontEnd([m.ExtractorParams(nfeatures=NF)] * NC, W, H)
     for t in range(6):
         fe.step([synth.image(c, t, W, H) for c in range(NC)])
