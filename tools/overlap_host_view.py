@@ -11,9 +11,11 @@ import numpy as np
 import multi_orb_slam_amd as m
 from multi_orb_slam_amd import synth, pipeline, rt
 
-W, H, NC, RING = 640, 480, 2, 8
+W, H, NF, NC = (int(x) for x in sys.argv[1:5]) if len(sys.argv) > 4 else (640, 480, 1000, 2)   # e.g. 640 480 1000 4 = configs[3]
+RING = 8
 AHEAD = int(os.environ.get("AHEAD", "3"))
-fe = pipeline.FrontEnd([m.ExtractorParams(nfeatures=1000)] * NC, W, H)
+fe = pipeline.FrontEnd([m.ExtractorParams(nfeatures=NF)] * NC, W, H)
+fe.copy_results = False
 dev = []
 for t in range(RING):
     row = []
