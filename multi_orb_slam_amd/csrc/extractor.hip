@@ -2579,7 +2579,19 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     if (rc != ORB_OK) return rc;
     orbx_extractor* ex = new orbx_extractor();
     ex->device = device; ex->n_cams = n_cams; ex->max_w = max_width; ex->max_h = max_height;
-    hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
+    hipError_t e;
+    // MORB_RESERVE_CUS=k (default off): the extraction stream stays off k compute units of every XCD (a CU mask on its queue), which
+    // are then free for the matcher's stream -- whose resolve is ONE workgroup that otherwise shares its CU with extraction waves.
+    // Measured (round 6, profiles/r06/notes_experiments.md section 10): 4 x 640x480 overlapped 15 200 -> 17 900-18 600 steps/s with k = 4,
+    // 2 x 640x480 and 2 x 1280x720 unchanged or slightly worse, 8 x 1080p 9 % worse, every isolated step 3-6 % slower: a tunable.
+    if (const char* rs = getenv("MORB_RESERVE_CUS"); rs && atoi(rs) > 0) {
+        const int k = atoi(rs);
+        uint32_t mask[8];
+        for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
+        for (int b = 0; b < 8 * k && b < 256; ++b) mask[b >> 5] &= ~(1u << (b & 31));
+        e = hipExtStreamCreateWithCUMask(&ex->stream, 8, mask);
+    } else
+    e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { morb::set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete ex; return ORB_E_HIP; }
     ex->cams.resize(n_cams);
     ex->cur_w.assign(n_cams, 0); ex->cur_h.assign(n_cams, 0);
