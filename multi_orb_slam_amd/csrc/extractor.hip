@@ -2584,8 +2584,8 @@ int orbx_create(const orbx_params* params, int n_cams, int max_width, int max_he
     // are then free for the matcher's stream -- whose resolve is ONE workgroup that otherwise shares its CU with extraction waves.
     // Measured (round 6, profiles/r06/notes_experiments.md section 10): 4 x 640x480 overlapped 15 200 -> 17 900-18 600 steps/s with k = 4,
     // 2 x 640x480 and 2 x 1280x720 unchanged or slightly worse, 8 x 1080p 9 % worse, every isolated step 3-6 % slower: a tunable.
-    if (const char* rs = getenv("MORB_RESERVE_CUS"); rs && atoi(rs) > 0) {
-        const int k = atoi(rs);
+    if (const char* rs = getenv("MORB_RESERVE_CUS"); rs && atoi(rs) != 0) {
+        const int k = std::max(0, atoi(rs));   // (negative: a masked queue with every unit allowed -- what the mask itself costs or buys)
         uint32_t mask[8];
         for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
         for (int b = 0; b < 8 * k && b < 256; ++b) mask[b >> 5] &= ~(1u << (b & 31));
