@@ -847,3 +847,17 @@ def test_extraction_is_stable_on_a_rig_of_four_threads_and_twelve_streams():
                 ek, ed = expect[r][t]
                 assert kp.tobytes() == ek.tobytes(), ("keypoints", run, r, t)
                 assert np.array_equal(d, ed), ("descriptors", run, r, t, np.flatnonzero((d != ed).any(axis=1))[:8].tolist())
+
+
+@pytest.mark.timeout(600, method="thread")
+def test_reserved_compute_units_change_nothing_but_time():
+    """MORB_RESERVE_CUS=2: every extractor's queue is created with a CU mask (two units per XCD stay free for the matcher's stream:
+    csrc/extractor.hip, orbx_create).  Where a workgroup runs cannot change a result: the overlapped-step and six-camera tests of this
+    file once more in a child with the masks on, against the oracle."""
+    import os, subprocess, sys
+    env = dict(os.environ, MORB_RESERVE_CUS="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "test_overlapped_steps_equal_oracle_pipeline or test_six_camera_rig or test_native_stream_loop"],
+                       env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
